@@ -1,0 +1,215 @@
+/*
+ * rlsolver_hip.h -- C ABI of the MI355X (gfx950) combinatorial-optimisation
+ * environment engine.
+ *
+ * The reference (Open-Finance-Lab/RLSolver) has no FFI: its hot path is a set
+ * of duck-typed Python classes that launch chains of ATen ops.  Each entry
+ * point below replaces one such chain with ONE hand-written HIP kernel; the
+ * comment on each names the reference interface it stands in for (file:line
+ * relative to the reference root).  The Python classes in rlsolver_amd/ bind
+ * these symbols with ctypes (see INTEGRATION.md for the stub a reference
+ * maintainer would add).
+ *
+ * Conventions
+ *   - every function returns RLS_OK (0) or a negative RLS_E* code and records a
+ *     message retrievable with rls_last_error_string() (thread local);
+ *   - no function allocates, frees or synchronises; all work is enqueued on
+ *     `stream` (a hipStream_t passed as void*; NULL = the default stream);
+ *   - every pointer is a DEVICE pointer owned by the caller unless marked
+ *     [host]; sizes are int64_t; tensors are dense row-major;
+ *   - "spins" x are one byte per node (torch.bool / uint8, values 0|1),
+ *     env-major [B, N], unless the function takes `spin_bytes` (1 = uint8,
+ *     4 = float32 holding 0.0f|1.0f, the env_PPO surface);
+ *   - B = number of parallel environments ("sims"), N = nodes, E' = edges as
+ *     stored by the env (E, or 2E when if_bidirectional).
+ */
+#ifndef RLSOLVER_HIP_H
+#define RLSOLVER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RLS_ABI_VERSION 1
+
+enum {
+    RLS_OK = 0,
+    RLS_EINVAL = -1,      /* bad argument (null pointer, negative size, bad enum) */
+    RLS_EUNSUPPORTED = -2,/* valid request outside what the kernels cover (e.g. N too large for LDS) */
+    RLS_ELAUNCH = -3,     /* hipLaunchKernel / hipGetLastError reported a failure */
+    RLS_ENODEVICE = -4    /* no HIP device visible */
+};
+
+/* One shared graph, resident in HBM/L2.  Host struct of device pointers; built
+ * by the caller from rlsolver_amd.graph.GraphCSR.  Replaces the per-env index
+ * tensors n0_ids/n1_ids/sim_ids [B,E'] int64 of envs/env_L2A.py:46-59 (24*B*E'
+ * bytes there; (N+1+2E+2E')*4 bytes here, independent of B). */
+typedef struct rls_graph {
+    int64_t num_nodes;        /* N */
+    int64_t num_stored_edges; /* E' */
+    int64_t nnz;              /* 2E (symmetric CSR, self loops dropped) */
+    int32_t if_bidirectional; /* result of objective kernels is count / 2 when set */
+    int32_t max_degree;
+    const int32_t* eu;        /* [E'] edge endpoints as stored, sorted by (eu, ev) */
+    const int32_t* ev;        /* [E'] */
+    const int32_t* erowptr;   /* [N+1] offsets of each node's run in eu/ev (the env's adjacency_indies) */
+    const int32_t* rowptr;    /* [N+1] symmetric CSR */
+    const int32_t* col;       /* [nnz] */
+    const int32_t* wgt;       /* [nnz] integer edge weights or NULL (= all ones) */
+} rls_graph;
+
+int rls_version(void);
+const char* rls_last_error_string(void);
+/* Number of HIP devices visible (0 on a CPU-only host; never an error). */
+int rls_device_count(void);
+
+/* ------------------------------------------------------------------ MaxCut */
+
+/* K1  EnvMaxcut.calculate_obj_values(xs, if_sum=True)  envs/env_L2A.py:54-66
+ *     (= env_MCPG.py:54-66, env_PPO.py:108-121, env_k_spin.py:246-258).
+ * obj[b] = #{(u,v) in stored edges : x[b,u] != x[b,v]}  (// 2 if bidirectional). */
+int rls_maxcut_obj(const rls_graph* g, const void* x, int spin_bytes,
+                   int64_t B, int64_t* obj, void* stream);
+
+/* K1' calculate_obj_values(xs, if_sum=False): cutmask[b,e] = x[b,eu[e]] ^ x[b,ev[e]]
+ *     as bool bytes [B,E'].  envs/env_L2A.py:61 */
+int rls_maxcut_edge_cut_mask(const rls_graph* g, const uint8_t* x, int64_t B,
+                             uint8_t* cutmask, void* stream);
+
+/* K2  EnvMaxcut.calculate_obj_values_for_loop(xs, if_sum=False)  env_L2A.py:68-80
+ * cutdeg[b,i] = #{j in adj(i) : x[b,j] != x[b,i]} where adj = the env's stored
+ * adjacency (out-neighbours only when !if_bidirectional).  int64 [B,N]. */
+int rls_maxcut_node_cutdeg(const rls_graph* g, const uint8_t* x, int64_t B,
+                           int64_t* cutdeg, void* stream);
+
+/* K3  all-node single-flip gain: delta[b,i] = obj(flip_i(x_b)) - obj(x_b)
+ *     = sum_{j in N(i)} w_ij * (x_i == x_j ? +1 : -1), int32 [B,N].
+ * Replaces autograd of the energy (envs/env_ISCO.py:51-63), dense
+ * matmul(W,s)*s (ECO_S2V/src/envs/spinsystem_PECO.py:661) and the scatter_add
+ * form (S2V_PPO/env.py:84-100). */
+int rls_maxcut_delta_all(const rls_graph* g, const uint8_t* x, int64_t B,
+                         int32_t* delta, void* stream);
+
+/* K4  gym step: env_PPO.EnvMaxcut.step(action)  envs/env_PPO.py:92-106.
+ * For every env b: a = action[b]; x_out[b,:] = x_in[b,:] with node a flipped;
+ * d = cut gain of that flip; obj[b] += d (in/out, int32); reward[b] = (float)d;
+ * cur[b] = (float)obj[b] if cur != NULL; done[b] = done_value if done != NULL.
+ * x_out may equal x_in (in-place: only the flipped byte is written, O(deg)
+ * traffic); otherwise the whole next state is emitted (2N + 20 B / env-step,
+ * the headline byte accounting of SURVEY.md section 8d).  action values must
+ * be in [0, N). */
+int rls_maxcut_step(const rls_graph* g, const void* x_in, void* x_out, int spin_bytes,
+                    int64_t B, const int64_t* action, int32_t* obj,
+                    float* reward, float* cur, float* done, float done_value,
+                    void* stream);
+
+/* K5  greedy single-flip sweep ("addition" loop)  envs/env_L2A.py:109-116,
+ *     methods/LocalSearch.py:77-83:  for i in 0..N-1: flip i if the cut does
+ *     not decrease (ties accept, update_xs_by_vs uses ge, util_read_data.py:199).
+ * x [B,N] and obj [B] (int64) are updated in place.  One sequential O(E) pass
+ * per env instead of N full objective evaluations. */
+int rls_maxcut_greedy_sweep(const rls_graph* g, uint8_t* x, int64_t B,
+                            int64_t* obj, void* stream);
+
+/* K6  one multi-flip proposal round of local_search_inplace  envs/env_L2A.py:102-107
+ *     (= methods/LocalSearch.py:71-75):  xs = good_xs.clone(); xs[mask] = ~xs[mask];
+ *     vs = calculate_obj_values(xs); update_xs_by_vs(good_xs, good_vs, xs, vs).
+ * mask uint8 [B,N] is the caller's spin_rand.gt(thresh) (the noise and the
+ * kthvalue threshold stay torch ops so they consume torch's generator exactly as
+ * the reference does).  x/obj (int64) are updated in place: rows whose proposal
+ * has cut >= obj[b] take the proposal. */
+int rls_maxcut_propose_accept(const rls_graph* g, uint8_t* x, int64_t B, const uint8_t* mask,
+                              int64_t* obj, void* stream);
+
+/* K10 update_xs_by_vs(xs0, vs0, xs1, vs1, if_maximize)  methods/util_read_data.py:190-202:
+ *     rows of (xs1, vs1) that are >= (<= when !if_maximize) replace (xs0, vs0). */
+int rls_select_better_rows(uint8_t* xs0, int64_t* vs0, const uint8_t* xs1, const int64_t* vs1,
+                           int64_t B, int64_t N, int if_maximize, void* stream);
+
+/* K10 pick_xs_by_vs(xs, vs, num_repeats, if_maximize)  methods/util_read_data.py:204-216:
+ *     view xs as [R,S,N]; for each s take the r with the best vs (first on ties,
+ *     torch.argmax semantics). */
+int rls_pick_best_of_repeats(const uint8_t* xs, const int64_t* vs, int64_t R, int64_t S, int64_t N,
+                             int if_maximize, uint8_t* good_xs, int64_t* good_vs, void* stream);
+
+/* K14 generate_xs_randomly(num_sims)  envs/env_L2A.py:82-85: i.i.d. Bernoulli(1/2)
+ *     spins from a counter-based generator keyed by (seed, global env id), node 0
+ *     forced to 0.  env_offset lets a rank generate its shard of a global batch. */
+int rls_rand_spins(uint8_t* x, int64_t B, int64_t N, uint64_t seed, int64_t env_offset,
+                   void* stream);
+
+/* uniform actions in [0, N) from the same generator (bench / MCMC proposals). */
+int rls_rand_actions(int64_t* action, int64_t B, int64_t N, uint64_t seed, uint64_t step,
+                     int64_t env_offset, void* stream);
+
+/* -------------------------------------------------------------------- MCPG */
+
+/* K7  node-sequential stochastic local search of sampler_func  methods/MCPG.py:136-142.
+ * xs f32 [N, C] node-major (chains are the fast axis), values in {-0.5, 1.5}
+ * on entry to the first pass exactly as the reference (it maps 0/1 -> -0.5/1.5,
+ * MCPG.py:131-133) and 0/1 afterwards.  For each of num_ls passes, for node in
+ * `order` (degree-descending, int32 [N]):
+ *     x[node,c] = (sum_{j in nbr(node)} x[j,c] + u * 0.25) < (deg(node) + 0.25) / 2
+ * `uniforms` f32 [num_ls, N, C] are the torch.rand draws in visiting order
+ * (test mode); NULL = in-kernel counter-based generator keyed by `seed`. */
+int rls_mcpg_local_search(const rls_graph* g, float* xs, int64_t C, const int32_t* order,
+                          int64_t num_ls, const float* uniforms, uint64_t seed, void* stream);
+
+/* K8  expected cut + best-of-repeats of sampler_func  methods/MCPG.py:147-166.
+ * xs f32 [N, C], C = total_mcmc_num * repeat_times.  expected[c] =
+ * sum_e (2x_u - 1)(2x_v - 1) over the edge_index list (f32, exact small ints);
+ * best[m] = argmin over repeats r of expected[r*M + m] (first on ties). */
+int rls_mcpg_expected_cut(const rls_graph* g, const float* xs, int64_t C, float* expected,
+                          void* stream);
+
+/* K9  metro_sampling(probs, start_status, max_transfer_time)  methods/MCPG.py:88-117.
+ * One proposal round for every chain, T rounds fused: for t in 0..T-1:
+ *   i = index[t,c]; p = x[i,c] ? probs[i] : 1 - probs[i];
+ *   accept if u[t,c] < (1 - p) / p  -> flip x[i,c]; accepts[t] += 1.
+ * samples uint8 [N, C] in place; index int64 [T,C], u f32 [T,C] supplied (test
+ * mode) or NULL for the in-kernel generator.  accepts int64 [T] (per-round
+ * accept counts, so the caller can apply the reference's early-stop rule
+ * without a host sync per round). */
+int rls_mcpg_metro_rounds(uint8_t* samples, int64_t N, int64_t C, const float* probs,
+                          int64_t T, const int64_t* index, const float* u, uint64_t seed,
+                          int64_t* accepts, void* stream);
+
+/* --------------------------------------------------------------------- TSP */
+
+/* K12 ISCO_TSP.calculate_distance(sample)  envs/env_ISCO.py:346-350.
+ * len[b] = sum_k D[p[k], p[k+1]] + D[p[N-1], p[0]], f32, sequential k order. */
+int rls_tsp_tour_length(const float* dist, int64_t N, const int64_t* perm, int64_t B,
+                        float* length, void* stream);
+
+/* K13 the delta part of ISCO_TSP.opt_2  envs/env_ISCO.py:256-335, given the
+ * partner city already drawn for every position (selected int64 [B,N]):
+ * j = position of selected[b,i] in perm[b]; ban = partner adjacent to i+1's
+ * neighbours (:291-293); delta of swapping the cities at positions i+1 and j
+ * (:318-333).  Outputs logratio = -delta / temperature f32 [B,N], indices
+ * int64 [B,N], ban uint8 [B,N]. */
+int rls_tsp_swap_delta_all(const float* dist, int64_t N, const int64_t* perm, int64_t B,
+                           const int64_t* selected, float temperature,
+                           float* logratio, int64_t* indices, uint8_t* ban, void* stream);
+
+/* ISCO_TSP.switch  envs/env_ISCO.py:337-344 for one chosen position per env:
+ * if pos[b] >= 0 swap perm[b, (pos[b]+1) % N] and perm[b, indices[b, pos[b]]]. */
+int rls_tsp_apply_swap(int64_t* perm, int64_t B, int64_t N, const int64_t* pos,
+                       const int64_t* indices, void* stream);
+
+/* true 2-opt (segment reversal) delta for a closed tour, the move of
+ * methods_problem_specific/TSP/opt_2.py:27-57: reversing perm[i..j] changes
+ * the length by D[p[i-1],p[j]] + D[p[i],p[j+1]] - D[p[i-1],p[i]] - D[p[j],p[j+1]].
+ * i, j int64 [B] with 0 <= i <= j < N. */
+int rls_tsp_2opt_delta(const float* dist, int64_t N, const int64_t* perm, int64_t B,
+                       const int64_t* i, const int64_t* j, float* delta, void* stream);
+
+/* B random permutations (random_gen_init_sample, env_ISCO.py:352-354). */
+int rls_rand_perms(int64_t* perm, int64_t B, int64_t N, uint64_t seed, int64_t env_offset,
+                   void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RLSOLVER_HIP_H */

@@ -1,0 +1,492 @@
+"""CPU ORACLE (numpy) -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+A restatement of the reference's algorithms for the hot path, written the way the
+reference computes them (full objective re-evaluation per candidate, Python loops over
+nodes), so that it is an independent check of the restructured HIP kernels.  Only
+``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may
+import this module; nothing under ``rlsolver_amd/`` does.
+
+Parity status: PINNED.  Every function below is checked in tests/test_oracle_golden.py
+against golden vectors produced by importing the reference itself in the build
+container (tools/gen_golden.py -> tests/golden/*.npz).  The reference has no tests or
+golden vectors of its own.
+
+All paths in the citations are relative to the reference root (Open-Finance-Lab/RLSolver).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+# --------------------------------------------------------------------------- graph forms
+
+
+def stored_edges(graph: np.ndarray, if_bidirectional: bool):
+    """Edge endpoint lists exactly as EnvMaxcut.__init__ builds them
+    (rlsolver/envs/env_L2A.py:40-49 via util_read_data.py:144-187): per-n0 neighbour lists,
+    each sorted by n1, concatenated in n0 order; both directions when bidirectional."""
+    g = np.asarray(graph, dtype=np.int64).reshape(-1, 3)
+    u, v = g[:, 0], g[:, 1]
+    if if_bidirectional:
+        u, v = np.concatenate([u, v]), np.concatenate([v, u])
+    order = np.lexsort((v, u))
+    return u[order], v[order]
+
+
+def num_nodes_distinct(graph: np.ndarray) -> int:
+    """calc_num_nodes_in_mygraph, rlsolver/methods/util.py:35-40."""
+    g = np.asarray(graph, dtype=np.int64).reshape(-1, 3)
+    return int(np.unique(g[:, :2]).shape[0])
+
+
+def adjacency_lists(graph, num_nodes, if_bidirectional):
+    """adjacency_indies: List[sorted neighbour array], env_L2A.py:40-44."""
+    u, v = stored_edges(graph, if_bidirectional)
+    return [v[u == i] for i in range(num_nodes)]
+
+
+# --------------------------------------------------------------------------- MaxCut objective
+
+
+def maxcut_obj(xs, graph, if_bidirectional):
+    """calculate_obj_values(xs, if_sum=True), env_L2A.py:54-66:
+    values = xs[:, n0_ids] ^ xs[:, n1_ids]; sum(1); // 2 if bidirectional.  int64 [B]."""
+    xs = np.asarray(xs).astype(bool)
+    u, v = stored_edges(graph, if_bidirectional)
+    vals = (xs[:, u] ^ xs[:, v]).sum(axis=1).astype(np.int64)
+    return vals // 2 if if_bidirectional else vals
+
+
+def maxcut_edge_mask(xs, graph, if_bidirectional):
+    """calculate_obj_values(xs, if_sum=False), env_L2A.py:61: bool [B, E'].  (The reference
+    then applies ``// 2`` to the bool tensor when bidirectional, which zeroes it; callers only
+    use if_sum=False with the unidirectional env, and so do we.)"""
+    xs = np.asarray(xs).astype(bool)
+    u, v = stored_edges(graph, if_bidirectional)
+    return xs[:, u] ^ xs[:, v]
+
+
+def maxcut_node_cutdeg(xs, graph, num_nodes, if_bidirectional):
+    """calculate_obj_values_for_loop(xs, if_sum=False) before the bidirectional ``/ 2``,
+    env_L2A.py:68-76: values[:, node0] = (xs[:, node0, None] ^ xs[:, node1s]).sum(1).  int64 [B,N]."""
+    xs = np.asarray(xs).astype(bool)
+    adj = adjacency_lists(graph, num_nodes, if_bidirectional)
+    out = np.zeros((xs.shape[0], num_nodes), dtype=np.int64)
+    for n0 in range(num_nodes):
+        n1s = adj[n0]
+        if n1s.shape[0] > 0:
+            out[:, n0] = (xs[:, n0, None] ^ xs[:, n1s]).sum(axis=1)
+    return out
+
+
+def maxcut_obj_for_loop(xs, graph, num_nodes, if_bidirectional, if_sum=True):
+    """calculate_obj_values_for_loop, env_L2A.py:68-80 including its dtype quirk: int64 when
+    unidirectional, float32 (values / 2) when bidirectional."""
+    raw = maxcut_node_cutdeg(xs, graph, num_nodes, if_bidirectional)
+    vals = raw.sum(axis=1) if if_sum else raw
+    if if_bidirectional:
+        return vals.astype(np.float32) / np.float32(2)
+    return vals
+
+
+def maxcut_delta_all(xs, graph, num_nodes, weights=None):
+    """Definition used for K3: delta[b,i] = obj(flip_i(x_b)) - obj(x_b), computed literally
+    (flip, re-evaluate) with the (optionally weighted) cut; int64 [B,N]."""
+    xs = np.asarray(xs).astype(bool)
+    g = np.asarray(graph, dtype=np.int64).reshape(-1, 3)
+    u, v = g[:, 0], g[:, 1]
+    w = np.ones(len(u), np.int64) if weights is None else np.asarray(weights, np.int64)
+
+    def cut(x):
+        return ((x[:, u] ^ x[:, v]) * w).sum(axis=1)
+
+    base = cut(xs)
+    out = np.zeros((xs.shape[0], num_nodes), dtype=np.int64)
+    for i in range(num_nodes):
+        x1 = xs.copy()
+        x1[:, i] = ~x1[:, i]
+        out[:, i] = cut(x1) - base
+    return out
+
+
+# --------------------------------------------------------------------------- select ops
+
+
+def update_xs_by_vs(xs0, vs0, xs1, vs1, if_maximize=True):
+    """rlsolver/methods/util_read_data.py:190-202 (in place; returns B, sic)."""
+    good = vs1 >= vs0 if if_maximize else vs1 <= vs0
+    xs0[good] = xs1[good]
+    vs0[good] = vs1[good]
+    return good.shape[0]
+
+
+def pick_xs_by_vs(xs, vs, num_repeats, if_maximize=True):
+    """rlsolver/methods/util_read_data.py:204-216."""
+    n = xs.shape[1]
+    s = xs.shape[0] // num_repeats
+    xv = xs.reshape(num_repeats, s, n)
+    vv = vs.reshape(num_repeats, s)
+    ids = vv.argmax(axis=0) if if_maximize else vv.argmin(axis=0)
+    sid = np.arange(s)
+    return xv[ids, sid], vv[ids, sid]
+
+
+def evolutionary_replacement(xs, vs, low_k, perm, if_maximize=True):
+    """rlsolver/methods/util.py:87-94 with the randperm supplied (in place)."""
+    ids = np.argsort(vs, kind="stable")
+    top_ids, low_ids = (ids[:-low_k], ids[-low_k:]) if if_maximize else (ids[:low_k], ids[low_k:])
+    replace_ids = top_ids[perm[:low_k]]
+    xs[replace_ids] = xs[low_ids]
+    vs[replace_ids] = vs[low_ids]
+
+
+# --------------------------------------------------------------------------- local search
+
+
+def greedy_sweep(xs, vs, graph, if_bidirectional):
+    """The 'addition' loop of local_search_inplace, env_L2A.py:109-116, as written there:
+    for every node clone, flip the column, re-evaluate the full objective, keep rows that are
+    not worse.  O(N * E * B).  In place; returns (xs, vs)."""
+    n = xs.shape[1]
+    for i in range(n):
+        xs1 = xs.copy()
+        xs1[:, i] = ~xs1[:, i]
+        vs1 = maxcut_obj(xs1, graph, if_bidirectional)
+        update_xs_by_vs(xs, vs, xs1, vs1, True)
+    return xs, vs
+
+
+def local_search_inplace(xs, graph, num_nodes, if_bidirectional, noise, num_iters=8, num_spin=8,
+                         noise_std=0.3, good_vs=None):
+    """EnvMaxcut.local_search_inplace, env_L2A.py:87-116, with the randn_like draws supplied
+    as ``noise`` f32 [num_iters + 1, B, N] in call order (the first one only sets ``thresh``).
+    Arithmetic follows torch's type promotion: int64 ws + f32 tensor -> f32."""
+    xs = np.asarray(xs).astype(bool)
+    vs_raw = maxcut_node_cutdeg(xs, graph, num_nodes, if_bidirectional)
+    if if_bidirectional:  # calculate_obj_values_for_loop returns float / 2 (env_L2A.py:78-79)
+        vs_raw_f = vs_raw.astype(np.float32) / np.float32(2)
+    else:
+        vs_raw_f = vs_raw
+    good_vs = vs_raw_f.sum(axis=1).astype(np.int64) if good_vs is None else np.asarray(good_vs, np.int64)
+    u, v = stored_edges(graph, if_bidirectional)
+    n0_num_n1 = np.bincount(u, minlength=num_nodes).astype(np.int64)[None, :]
+    ws = n0_num_n1 - (2 if if_bidirectional else 1) * vs_raw_f        # int64, or f32 when bidirectional
+    ws_std = ws.max(axis=0, keepdims=True) - ws.min(axis=0, keepdims=True)
+    rd_std = ws_std.astype(np.float32) * np.float32(noise_std)
+    ws_f = ws.astype(np.float32)
+    spin_rand = ws_f + noise[0].astype(np.float32) * rd_std
+    k = num_nodes - num_spin
+    thresh = np.partition(spin_rand, k - 1, axis=1)[:, k - 1][:, None]  # kthvalue = k-th smallest
+    for it in range(num_iters):
+        spin_rand = ws_f + noise[1 + it].astype(np.float32) * rd_std
+        mask = spin_rand > thresh
+        x1 = xs.copy()
+        x1[mask] = ~x1[mask]
+        v1 = maxcut_obj(x1, graph, if_bidirectional)
+        update_xs_by_vs(xs, good_vs, x1, v1, True)
+    greedy_sweep(xs, good_vs, graph, if_bidirectional)
+    return xs, good_vs
+
+
+def local_search_class_random_search(good_xs, good_vs, graph, num_nodes, noise, num_iters, num_spin,
+                                     noise_std=0.3):
+    """LocalSearch.random_search, rlsolver/methods/LocalSearch.py:53-86 (unidirectional env only;
+    the reference raises for if_bidirectional=True).  noise f32 [num_iters, B, N]."""
+    if_bidirectional = False
+    kth = num_nodes - num_spin
+    prev_xs = good_xs.copy()
+    prev_vs_raw = maxcut_node_cutdeg(prev_xs, graph, num_nodes, if_bidirectional)
+    prev_vs = prev_vs_raw.sum(axis=1)
+    u, _ = stored_edges(graph, if_bidirectional)
+    n0_num_n1 = np.bincount(u, minlength=num_nodes).astype(np.int64)[None, :]
+    thresh = None
+    for it in range(num_iters):
+        ws = n0_num_n1 - 2 * prev_vs_raw
+        ws_std = ws.max(axis=0, keepdims=True) - ws.min(axis=0, keepdims=True)
+        spin_rand = ws.astype(np.float32) + noise[it].astype(np.float32) * (ws_std.astype(np.float32) * np.float32(noise_std))
+        if thresh is None:
+            thresh = np.partition(spin_rand, kth - 1, axis=1)[:, kth - 1][:, None]
+        mask = spin_rand > thresh
+        xs = prev_xs.copy()
+        xs[mask] = ~xs[mask]
+        vs = maxcut_obj(xs, graph, if_bidirectional)
+        update_xs_by_vs(prev_xs, prev_vs, xs, vs, True)
+    greedy_sweep(prev_xs, prev_vs, graph, if_bidirectional)
+    num_update = update_xs_by_vs(good_xs, good_vs, prev_xs, prev_vs, True)
+    return good_xs, good_vs, num_update
+
+
+# --------------------------------------------------------------------------- gym step
+
+
+class PPOEnvOracle:
+    """env_PPO.EnvMaxcut, rlsolver/envs/env_PPO.py:63-126: xs kept as float32 0/1, step() flips
+    one node per env, recomputes the whole cut, reward = cur - last, done every num_steps."""
+
+    def __init__(self, graph, num_nodes, num_steps, if_bidirectional):
+        self.graph, self.n, self.num_steps, self.bidir = graph, num_nodes, num_steps, if_bidirectional
+        self.action_count = 0
+        self.xs = None
+        self.last = None
+
+    def reset_to(self, xs_bool):
+        self.xs = np.asarray(xs_bool).astype(np.float32)
+        self.last = maxcut_obj(self.xs > 0, self.graph, self.bidir).astype(np.float32)
+        return self.xs
+
+    def step(self, action):
+        self.action_count += 1
+        b = np.arange(self.xs.shape[0])
+        self.xs[b, action] = np.logical_not(self.xs[b, action]).astype(np.float32)
+        cur = maxcut_obj(self.xs > 0, self.graph, self.bidir).astype(np.float32)
+        reward = cur - self.last
+        self.last = cur
+        if self.action_count == self.num_steps:
+            self.action_count = 0
+            done = np.ones(self.xs.shape[0], np.float32)
+        else:
+            done = np.zeros(self.xs.shape[0], np.float32)
+        return self.xs, reward, done, cur
+
+
+# --------------------------------------------------------------------------- counter-based RNG (build-defined)
+
+
+def philox4x32_10(key0, key1, c0, c1, c2, c3):
+    """Philox-4x32-10 (Salmon et al. 2011), the generator the HIP kernels use for K14.  Not a
+    reference algorithm (the reference calls torch.randint); restated so the kernels' output is
+    checkable bit for bit.  Vectorised over numpy uint64 arrays holding 32-bit values."""
+    M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+    W0, W1 = np.uint64(0x9E3779B9), np.uint64(0xBB67AE85)
+    mask = np.uint64(0xFFFFFFFF)
+    c0, c1, c2, c3 = (np.asarray(c, dtype=np.uint64) & mask for c in (c0, c1, c2, c3))
+    k0, k1 = np.uint64(key0) & mask, np.uint64(key1) & mask
+    for _ in range(10):
+        p0 = M0 * c0
+        p1 = M1 * c2
+        h0, l0 = p0 >> np.uint64(32), p0 & mask
+        h1, l1 = p1 >> np.uint64(32), p1 & mask
+        c0, c1, c2, c3 = (h1 ^ c1 ^ k0) & mask, l1, (h0 ^ c3 ^ k1) & mask, l0
+        k0 = (k0 + W0) & mask
+        k1 = (k1 + W1) & mask
+    return c0, c1, c2, c3
+
+
+def rand_spins(B, N, seed, env_offset=0):
+    """K14 definition: spin(b, n) = bit (n & 127) of Philox(seed; ctr = (gb_lo, gb_hi, n >> 7, 'SPIN')),
+    gb = env_offset + b; node 0 forced to 0 (generate_xs_randomly, env_L2A.py:82-85)."""
+    gb = (np.arange(B, dtype=np.uint64) + np.uint64(env_offset))[:, None]
+    blk = np.arange((N + 127) // 128, dtype=np.uint64)[None, :]
+    r = philox4x32_10(seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF, gb & np.uint64(0xFFFFFFFF), gb >> np.uint64(32),
+                      blk + np.zeros_like(gb), np.uint64(0x5350494E))
+    words = np.stack(r, axis=-1).astype(np.uint32)                      # [B, blocks, 4]
+    bits = ((words[..., None] >> np.arange(32, dtype=np.uint32)) & 1).astype(np.uint8)  # [B, blocks, 4, 32]
+    xs = bits.reshape(B, -1)[:, :N].copy()
+    xs[:, 0] = 0
+    return xs
+
+
+def rand_actions(B, N, seed, step, env_offset=0):
+    gb = np.arange(B, dtype=np.uint64) + np.uint64(env_offset)
+    r0 = philox4x32_10(seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF, gb & np.uint64(0xFFFFFFFF), gb >> np.uint64(32),
+                       np.uint64(step & 0xFFFFFFFF) + np.zeros_like(gb),
+                       np.uint64(((step >> 32) & 0xFFFFFFFF) ^ 0x41435431))[0]
+    return ((r0 * np.uint64(N)) >> np.uint64(32)).astype(np.int64)
+
+
+# --------------------------------------------------------------------------- MCPG
+
+
+def metro_sampling(probs, start_status, max_transfer_time, index, u):
+    """metro_sampling, rlsolver/methods/MCPG.py:88-117, with the randint/rand draws supplied
+    (index int64 [T', C], u f32 [T', C] in call order).  Returns float32 0/1 [N, C]."""
+    probs = np.asarray(probs, np.float32)
+    samples = np.asarray(start_status).astype(bool).copy()
+    num_chain = samples.shape[1]
+    col = np.arange(num_chain)
+    count = 0
+    t_used = 0
+    for t in range(max_transfer_time * 5):
+        if count >= num_chain * max_transfer_time:
+            break
+        row = index[t]
+        base = probs[row]
+        val = samples[row, col]
+        chosen = np.where(val, base, np.float32(1) - base).astype(np.float32)
+        accept_rate = (np.float32(1) - chosen) / chosen
+        is_accept = u[t].astype(np.float32) < accept_rate
+        samples[row, col] = np.where(is_accept, ~val, val)
+        count += int(is_accept.sum())
+        t_used += 1
+    return samples.astype(np.float32), t_used
+
+
+def mcpg_neighbors(edge_index, num_nodes):
+    """append_neighbors, MCPG.py:235-252: neighbour order = order of appearance in the edge list
+    (both endpoints appended per edge)."""
+    nb = [[] for _ in range(num_nodes)]
+    for a, b in zip(edge_index[0], edge_index[1]):
+        nb[int(a)].append(int(b))
+        nb[int(b)].append(int(a))
+    return [np.asarray(x, dtype=np.int64) for x in nb]
+
+
+def sampler_func(edge_index, num_nodes, sorted_degree_nodes, xs_sample, num_ls, total_mcmc_num,
+                 repeat_times, uniforms):
+    """sampler_func, rlsolver/methods/MCPG.py:120-166 with torch.rand draws supplied as
+    uniforms f32 [num_ls, N(visit order), C].  float32 arithmetic throughout."""
+    k = np.float32(1 / 4)
+    nb = mcpg_neighbors(edge_index, num_nodes)
+    wdeg = [np.float32(len(x)) for x in nb]
+    num_edges = edge_index.shape[1]
+    x = xs_sample.astype(np.float32).copy()
+    x *= np.float32(2)
+    x -= np.float32(0.5)
+    for cnt in range(num_ls):
+        for pos, node in enumerate(sorted_degree_nodes):
+            node = int(node)
+            s = x[nb[node]].sum(axis=0, dtype=np.float32) if len(nb[node]) else np.zeros(x.shape[1], np.float32)
+            rv = s + uniforms[cnt, pos].astype(np.float32) * k
+            x[node] = (rv < (wdeg[node] + k) / np.float32(2)).astype(np.float32)
+    C = total_mcmc_num * repeat_times
+    expected = np.empty(C, np.float32)
+    n0, n1 = edge_index[0], edge_index[1]
+    for j in range(repeat_times):
+        j0, j1 = total_mcmc_num * j, total_mcmc_num * (j + 1)
+        a = np.float32(2) * x[n0, j0:j1] - np.float32(1)
+        b = np.float32(2) * x[n1, j0:j1] - np.float32(1)
+        expected[j0:j1] = (a * b).sum(axis=0, dtype=np.float32)
+    er = expected.reshape(-1, total_mcmc_num)
+    index = er.argmin(axis=0)
+    index = np.arange(total_mcmc_num) + index * total_mcmc_num
+    max_cut = expected[index]
+    vs_good = (np.float32(num_edges) - max_cut) / np.float32(2)
+    xs_good = x[:, index]
+    value = expected.astype(np.float32).copy()
+    value -= value.mean(dtype=np.float32)
+    return vs_good, xs_good, value, x, expected
+
+
+# --------------------------------------------------------------------------- TSP
+
+
+def tsp_tour_length(distance, perms):
+    """ISCO_TSP.calculate_distance, rlsolver/envs/env_ISCO.py:346-350 (float32)."""
+    d = np.asarray(distance, np.float32)
+    p = np.asarray(perms, np.int64)
+    tot = d[p[:, :-1], p[:, 1:]].sum(axis=1, dtype=np.float32)
+    tot = tot + d[p[:, -1], p[:, 0]]
+    return tot.astype(np.float32)
+
+
+def tsp_tour_length_f64(distance, perms):
+    """distance_calc of methods_problem_specific/TSP/util.py:13-18 / opt_2.py:17-22 on the closed
+    tour (f64 accumulation, sequential)."""
+    d = np.asarray(distance, np.float64)
+    out = []
+    for p in np.asarray(perms, np.int64):
+        t = list(p) + [p[0]]
+        s = 0.0
+        for k in range(len(t) - 1):
+            s = s + d[t[k], t[k + 1]]
+        out.append(s)
+    return np.asarray(out)
+
+
+def tsp_selected_partner(perms, nearest_indices, random_indices, rand, randint_nearest, randint_random, K):
+    """First half of ISCO_TSP.opt_2, env_ISCO.py:246-266: the partner CITY drawn for each position."""
+    p = np.asarray(perms, np.int64)
+    cond = rand < np.float32(K / (K + 1))
+    near = np.take_along_axis(nearest_indices[p], randint_nearest[..., None], axis=2)[..., 0]
+    rnd = np.take_along_axis(random_indices[p], randint_random[..., None], axis=2)[..., 0]
+    return np.where(cond, near, rnd)
+
+
+def tsp_swap_delta_all(distance, perms, selected, temperature):
+    """Second half of ISCO_TSP.opt_2, env_ISCO.py:268-335: position of the partner, ban mask,
+    3-case delta; returns (-delta / T, indices, ban)."""
+    d = np.asarray(distance, np.float32)
+    p = np.asarray(perms, np.int64)
+    B, N = p.shape
+    inv = np.empty_like(p)
+    inv[np.arange(B)[:, None], p] = np.arange(N)[None, :]        # sort + searchsorted == inverse perm
+    indices = np.take_along_axis(inv, selected, axis=1)
+    mask = np.broadcast_to(np.arange(N)[None, :], (B, N))
+    mask0, mask1, mask2 = (mask - 1) % N, (mask + 1) % N, (mask + 2) % N
+    ind0, ind1 = (indices - 1) % N, (indices + 1) % N
+    g = lambda idx: np.take_along_axis(p, idx, axis=1)
+    s_m1, s_m0 = g(mask1), g(mask0)
+    c1, c2 = s_m1 == selected, s_m0 == selected
+    ban = c1 | c2
+    s_i0, s_i1, s_i = g(ind0), g(ind1), g(indices)
+    c3 = s_m1 == s_i0
+    nm, nm1, nm2 = g(mask), s_m1, g(mask2)
+    D = lambda a, b: d[a, b]
+    case3 = -(D(nm, nm1) + D(s_i, s_i1)) + (D(nm, s_i) + D(s_i0, s_i1))
+    case4 = -(D(nm, nm1) + D(nm1, nm2) + D(s_i0, s_i) + D(s_i, s_i1)) + \
+        (D(nm, s_i) + D(s_i, nm2) + D(s_i0, nm1) + D(nm1, s_i1))
+    delta = np.where(ban, np.float32(0), np.where(c3, case3, case4)).astype(np.float32)
+    return (-delta / np.float32(temperature)).astype(np.float32), indices, ban
+
+
+def tsp_switch(perms, pos, indices):
+    """ISCO_TSP.switch, env_ISCO.py:337-344 for one position per env (pos < 0 = no swap)."""
+    x = np.asarray(perms, np.int64).copy()
+    N = x.shape[1]
+    for b in range(x.shape[0]):
+        if pos[b] < 0:
+            continue
+        j = indices[b, pos[b]]
+        a = (pos[b] + 1) % N
+        x[b, a], x[b, j] = x[b, j], x[b, a]
+    return x
+
+
+def tsp_2opt_delta(distance, perms, env, i, j):
+    """True 2-opt move of methods_problem_specific/TSP/opt_2.py:40-45: reverse tour[i..j] of the
+    closed tour and re-evaluate with distance_calc; returns new - old (f64)."""
+    d = np.asarray(distance, np.float64)
+    out = []
+    for b, a, c in zip(env, i, j):
+        p = list(np.asarray(perms[b], np.int64))
+        t = p + [p[0]]
+        base = sum(d[t[k], t[k + 1]] for k in range(len(t) - 1))
+        t2 = list(t)
+        t2[a:c + 1] = list(reversed(t2[a:c + 1]))
+        t2[-1] = t2[0]
+        new = sum(d[t2[k], t2[k + 1]] for k in range(len(t2) - 1))
+        out.append(new - base)
+    return np.asarray(out)
+
+
+# --------------------------------------------------------------------------- base-64 solution strings
+
+BASE_DIGITS = "0123456789ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz_$"
+
+
+def b64_str_to_bool(x_str: str, encode_len: int) -> np.ndarray:
+    """EncoderBase64.str_to_bool, rlsolver/methods/util_evaluator.py:51-65."""
+    s = x_str.replace("\n", "").replace(" ", "")
+    x_int = 0
+    for ch in s:
+        x_int = x_int * 64 + BASE_DIGITS.index(ch)
+    x_bin = bin(x_int)[2:]
+    out = np.zeros(encode_len, dtype=bool)
+    out[-len(x_bin):] = [c == "1" for c in x_bin]
+    return out
+
+
+def b64_bool_to_str(x_bool, encode_len: int) -> str:
+    """EncoderBase64.bool_to_str, rlsolver/methods/util_evaluator.py:32-49."""
+    string_len = -int(-(encode_len / 6) // 1)
+    x_int = int("".join("1" if i else "0" for i in list(x_bool)), 2)
+    x_str = ""
+    while True:
+        x_str = BASE_DIGITS[x_int % 64] + x_str
+        x_int //= 64
+        if x_int == 0:
+            break
+    if len(x_str) > 120:
+        x_str = "\n".join(x_str[i:i + 120] for i in range(0, len(x_str), 120))
+    if len(x_str) > 64:
+        x_str = f"\n{x_str}"
+    return x_str.zfill(string_len)

@@ -1,0 +1,104 @@
+"""ctypes binding of the C ABI in include/rlsolver_hip.h.
+
+This is the only place the shared library is opened.  There is NO fallback: if
+``librlsolver_hip.so`` is missing or a call returns an error code, an exception
+is raised -- the product path never computes on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "librlsolver_hip.so")
+
+RLS_OK = 0
+ERROR_NAMES = {-1: "RLS_EINVAL", -2: "RLS_EUNSUPPORTED", -3: "RLS_ELAUNCH", -4: "RLS_ENODEVICE"}
+
+
+class RlsError(RuntimeError):
+    def __init__(self, fn: str, code: int, msg: str):
+        super().__init__(f"{fn} failed: {ERROR_NAMES.get(code, code)}: {msg}")
+        self.code = code
+
+
+class RlsGraph(C.Structure):
+    """struct rls_graph (host struct of device pointers)."""
+    _fields_ = [
+        ("num_nodes", C.c_int64),
+        ("num_stored_edges", C.c_int64),
+        ("nnz", C.c_int64),
+        ("if_bidirectional", C.c_int32),
+        ("max_degree", C.c_int32),
+        ("eu", C.c_void_p),
+        ("ev", C.c_void_p),
+        ("erowptr", C.c_void_p),
+        ("rowptr", C.c_void_p),
+        ("col", C.c_void_p),
+        ("wgt", C.c_void_p),
+    ]
+
+
+_P = C.c_void_p
+_I64 = C.c_int64
+_U64 = C.c_uint64
+_INT = C.c_int
+_F32 = C.c_float
+_G = C.POINTER(RlsGraph)
+
+# name -> argtypes; every function returns int.  Keep in sync with include/rlsolver_hip.h
+# (tests/test_abi.py parses the header and checks this table against it).
+SIGNATURES = {
+    "rls_maxcut_obj": [_G, _P, _INT, _I64, _P, _P],
+    "rls_maxcut_edge_cut_mask": [_G, _P, _I64, _P, _P],
+    "rls_maxcut_node_cutdeg": [_G, _P, _I64, _P, _P],
+    "rls_maxcut_delta_all": [_G, _P, _I64, _P, _P],
+    "rls_maxcut_step": [_G, _P, _P, _INT, _I64, _P, _P, _P, _P, _P, _F32, _P],
+    "rls_maxcut_greedy_sweep": [_G, _P, _I64, _P, _P],
+    "rls_maxcut_propose_accept": [_G, _P, _I64, _P, _P, _P],
+    "rls_select_better_rows": [_P, _P, _P, _P, _I64, _I64, _INT, _P],
+    "rls_pick_best_of_repeats": [_P, _P, _I64, _I64, _I64, _INT, _P, _P, _P],
+    "rls_rand_spins": [_P, _I64, _I64, _U64, _I64, _P],
+    "rls_rand_actions": [_P, _I64, _I64, _U64, _U64, _I64, _P],
+}
+PLAIN = {"rls_version": ([], _INT), "rls_device_count": ([], _INT), "rls_last_error_string": ([], C.c_char_p)}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib() -> C.CDLL:
+    """Open the library once.  Raises if it has not been built (python -m rlsolver_amd.build)."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise ImportError(
+                        f"{LIB_PATH} is missing: the HIP extension has not been built "
+                        "(run `python -m rlsolver_amd.build`); rlsolver_amd has no CPU fallback")
+                l = C.CDLL(LIB_PATH)
+                for name, (args, res) in PLAIN.items():
+                    f = getattr(l, name)
+                    f.argtypes, f.restype = args, res
+                for name, args in SIGNATURES.items():
+                    f = getattr(l, name)
+                    f.argtypes, f.restype = args, _INT
+                _lib = l
+    return _lib
+
+
+def call(name: str, *args) -> None:
+    rc = getattr(lib(), name)(*args)
+    if rc != RLS_OK:
+        msg = lib().rls_last_error_string()
+        raise RlsError(name, rc, msg.decode() if msg else "")
+
+
+def version() -> int:
+    return lib().rls_version()
+
+
+def device_count() -> int:
+    return lib().rls_device_count()

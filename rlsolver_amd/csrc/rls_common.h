@@ -1,0 +1,53 @@
+// Shared helpers for the gfx950 kernels.  Internal; the public ABI is include/rlsolver_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "rlsolver_hip.h"
+
+namespace rls {
+
+constexpr int kWave = 64;                 // CDNA wavefront
+constexpr int kLdsBytes = 160 * 1024;     // per-CU LDS on MI355X
+constexpr int kMaxDynLds = 64 * 1024 * 2; // what we are willing to ask for per workgroup
+
+int fail(int code, const char* fmt, ...);  // records the message, returns code
+int check_launch(const char* kernel_name); // hipGetLastError -> RLS_ELAUNCH
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- counter-based RNG (Philox-4x32-10), keyed by (seed, global env id) so results
+// do not depend on how envs are sharded over ranks/workgroups.
+struct Philox {
+    uint32_t key0, key1;
+    __host__ __device__ Philox(uint64_t seed) : key0((uint32_t)seed), key1((uint32_t)(seed >> 32)) {}
+    __host__ __device__ static inline void mulhilo(uint32_t a, uint32_t b, uint32_t& hi, uint32_t& lo) {
+        uint64_t p = (uint64_t)a * b;
+        hi = (uint32_t)(p >> 32);
+        lo = (uint32_t)p;
+    }
+    __host__ __device__ inline void operator()(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                               uint32_t out[4]) const {
+        uint32_t k0 = key0, k1 = key1;
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            uint32_t h0, l0, h1, l1;
+            mulhilo(0xD2511F53u, c0, h0, l0);
+            mulhilo(0xCD9E8D57u, c2, h1, l1);
+            uint32_t n0 = h1 ^ c1 ^ k0, n1 = l1, n2 = h0 ^ c3 ^ k1, n3 = l0;
+            c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+            k0 += 0x9E3779B9u;
+            k1 += 0xBB67AE85u;
+        }
+        out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+    }
+};
+
+// uniform float in [0,1) with 24 random bits (same granularity as torch.rand for f32)
+__host__ __device__ inline float u32_to_unit_float(uint32_t r) { return (float)(r >> 8) * (1.0f / 16777216.0f); }
+
+}  // namespace rls
+
+#define RLS_REQUIRE(cond, code, ...) \
+    do { if (!(cond)) return ::rls::fail((code), __VA_ARGS__); } while (0)

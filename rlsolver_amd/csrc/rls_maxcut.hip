@@ -1,0 +1,662 @@
+// MaxCut environment kernels for gfx950 (MI355X).  See include/rlsolver_hip.h for the
+// reference call site each entry point replaces, DESIGN.md for layouts and rooflines.
+#include "rls_tile.h"
+
+namespace rls {
+
+// =====================================================================================
+// K1 core: cut value of 64 envs held as a bit tile.
+// Each lane takes every 64th stored edge, XORs the two 64-env words (one XOR = one edge
+// in 64 envs) and feeds the result into a bit-sliced Harley-Seal counter (8 edges per
+// block: 7 carry-save adders + one ripple into the upper planes).  The 64 per-lane
+// bit-sliced counts are then summed with a butterfly of bit-sliced full adders, after
+// which every lane holds the total planes and extracts its own env's count.
+// P = number of planes (E' < 2^P).
+// =====================================================================================
+template <int P>
+__device__ __forceinline__ int64_t tile_cut_count(const uint64_t* __restrict__ words,
+                                                  const int32_t* __restrict__ eu,
+                                                  const int32_t* __restrict__ ev,
+                                                  int64_t E, int lane) {
+    uint64_t c[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) c[p] = 0;
+    uint64_t ones = 0, twos = 0, fours = 0;
+    constexpr int PL = (P - 5) < 4 ? 4 : (P - 5);  // per-lane count <= ceil(E/64) < 2^(P-5)
+
+    for (int64_t base = 0; base < E; base += 8 * kWave) {
+        uint64_t d[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int64_t e = base + k * kWave + lane;
+            if (e < E) {
+                const int u = eu[e], v = ev[e];
+                d[k] = words[u] ^ words[v];
+            } else {
+                d[k] = 0;
+            }
+        }
+        uint64_t twosA, twosB, foursA, foursB, eights;
+        csa(twosA, ones, ones, d[0], d[1]);
+        csa(twosB, ones, ones, d[2], d[3]);
+        csa(foursA, twos, twos, twosA, twosB);
+        csa(twosA, ones, ones, d[4], d[5]);
+        csa(twosB, ones, ones, d[6], d[7]);
+        csa(foursB, twos, twos, twosA, twosB);
+        csa(eights, fours, fours, foursA, foursB);
+        uint64_t carry = eights;
+#pragma unroll
+        for (int p = 3; p < PL; ++p) {
+            const uint64_t t = c[p] & carry;
+            c[p] ^= carry;
+            carry = t;
+        }
+    }
+    c[0] = ones; c[1] = twos; c[2] = fours;
+
+    // butterfly: after the step with mask m every lane holds the sum over its 2m-group
+#pragma unroll
+    for (int m = 1; m < kWave; m <<= 1) {
+        uint64_t carry = 0;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const uint64_t o = shfl_xor64(c[p], m);
+            const uint64_t u = c[p] ^ o;
+            const uint64_t s = u ^ carry;
+            carry = (c[p] & o) | (u & carry);
+            c[p] = s;
+        }
+    }
+    int64_t total = 0;
+#pragma unroll
+    for (int p = 0; p < P; ++p) total |= (int64_t)((c[p] >> lane) & 1ull) << p;
+    return total;
+}
+
+template <typename T, bool VEC, int P>
+__global__ __launch_bounds__(kWave) void k_maxcut_obj(const T* __restrict__ x, int64_t B, int64_t N,
+                                                      const int32_t* __restrict__ eu,
+                                                      const int32_t* __restrict__ ev, int64_t E,
+                                                      int halve, int64_t* __restrict__ obj) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* words = reinterpret_cast<uint64_t*>(smem);
+    const int lane = threadIdx.x;
+    const int64_t b0 = (int64_t)blockIdx.x * kWave;
+    tile_load_bits<T, VEC>(x, B, N, b0, words, lane);
+    __syncthreads();
+    int64_t total = tile_cut_count<P>(words, eu, ev, E, lane);
+    if (halve) total >>= 1;  // values // 2, env_L2A.py:65 (count is even and >= 0)
+    if (b0 + lane < B) obj[b0 + lane] = total;
+}
+
+// K6: proposal = x ^ mask for 64 envs; accept the row when its cut is >= the incumbent.
+template <bool VEC, int P>
+__global__ __launch_bounds__(kWave) void k_maxcut_propose_accept(uint8_t* __restrict__ x,
+                                                                 const uint8_t* __restrict__ mask,
+                                                                 int64_t B, int64_t N,
+                                                                 const int32_t* __restrict__ eu,
+                                                                 const int32_t* __restrict__ ev, int64_t E,
+                                                                 int halve, int64_t* __restrict__ obj) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* words = reinterpret_cast<uint64_t*>(smem);
+    uint64_t* mwords = words + N;
+    const int lane = threadIdx.x;
+    const int64_t b0 = (int64_t)blockIdx.x * kWave;
+    tile_load_bits<uint8_t, VEC>(x, B, N, b0, words, lane);
+    tile_load_bits<uint8_t, VEC>(mask, B, N, b0, mwords, lane);
+    __syncthreads();
+    for (int64_t n = lane; n < N; n += kWave) words[n] ^= mwords[n];
+    __syncthreads();
+    int64_t total = tile_cut_count<P>(words, eu, ev, E, lane);
+    if (halve) total >>= 1;
+    const int64_t b = b0 + lane;
+    const bool accept = (b < B) && (total >= obj[b]);  // vs1.ge(vs0), util_read_data.py:199
+    if (accept) obj[b] = total;
+    // accepted rows take the proposal; others are left untouched
+    if (accept) {
+        uint8_t* row = x + b * N;
+        const int half = lane >> 5, sh = lane & 31;
+        const uint32_t* w32 = reinterpret_cast<const uint32_t*>(words);
+        if constexpr (VEC) {
+            u32x4* rv = reinterpret_cast<u32x4*>(row);
+            for (int64_t i = 0; i < (N >> 4); ++i) {
+                uint32_t d[4] = {0, 0, 0, 0};
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    d[k >> 2] |= ((w32[(((i << 4) + k) << 1) + half] >> sh) & 1u) << ((k & 3) * 8);
+                rv[i] = u32x4{d[0], d[1], d[2], d[3]};
+            }
+        } else {
+            for (int64_t n = 0; n < N; ++n) row[n] = (uint8_t)((w32[(n << 1) + half] >> sh) & 1u);
+        }
+    }
+}
+
+// =====================================================================================
+// K5: greedy single-flip sweep.  One lane = one env, 64 envs per wave, state as a bit
+// tile in LDS.  For node i the wave walks i's CSR row (wave-uniform), each lane reads the
+// neighbour's word (broadcast LDS read) and extracts its env's bit.  Node i is flipped in
+// the envs whose gain deg - 2*cutdeg is >= 0 (ties accept).  The flip mask is one ballot.
+// =====================================================================================
+template <bool VEC, bool WEIGHTED>
+__global__ __launch_bounds__(kWave) void k_maxcut_greedy_sweep(uint8_t* __restrict__ x, int64_t B, int64_t N,
+                                                               const int32_t* __restrict__ rowptr,
+                                                               const int32_t* __restrict__ col,
+                                                               const int32_t* __restrict__ wgt,
+                                                               int64_t* __restrict__ obj) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* words = reinterpret_cast<uint64_t*>(smem);
+    const uint32_t* w32 = reinterpret_cast<const uint32_t*>(smem);
+    const int lane = threadIdx.x;
+    const int64_t b0 = (int64_t)blockIdx.x * kWave;
+    tile_load_bits<uint8_t, VEC>(x, B, N, b0, words, lane);
+    __syncthreads();
+    const int half = lane >> 5, sh = lane & 31;
+    int64_t gain = 0;
+    for (int64_t i = 0; i < N; ++i) {
+        const int r0 = rowptr[i], r1 = rowptr[i + 1];
+        const uint32_t xi = (w32[(i << 1) + half] >> sh) & 1u;
+        int same_minus_diff = 0;  // sum_j w_ij * (x_i == x_j ? +1 : -1)
+        for (int base = r0; base < r1; base += kWave) {
+            const int cnt = (r1 - base) < kWave ? (r1 - base) : kWave;
+            const int my_nb = (lane < cnt) ? col[base + lane] : 0;
+            int my_w = 1;
+            if constexpr (WEIGHTED) my_w = (lane < cnt) ? wgt[base + lane] : 0;
+            for (int j = 0; j < cnt; ++j) {
+                const int nb = __builtin_amdgcn_readlane(my_nb, j);
+                const uint32_t xn = (w32[((int64_t)nb << 1) + half] >> sh) & 1u;
+                if constexpr (WEIGHTED) {
+                    const int wj = __builtin_amdgcn_readlane(my_w, j);
+                    same_minus_diff += (xn == xi) ? wj : -wj;
+                } else {
+                    same_minus_diff += (xn == xi) ? 1 : -1;
+                }
+            }
+        }
+        const bool flip = same_minus_diff >= 0;
+        gain += flip ? same_minus_diff : 0;
+        const uint64_t fm = ballot64(flip);
+        if (lane == 0) words[i] ^= fm;  // LDS ops of one wave execute in order
+        __syncthreads();                // (single-wave block: compiler fence + waitcnt only)
+    }
+    tile_store_bytes<VEC>(x, B, N, b0, words, lane);
+    if (b0 + lane < B) obj[b0 + lane] += gain;
+}
+
+// =====================================================================================
+// K4: gym step.  One wave owns EPW consecutive envs.
+// Phase A (per env): the wave's lanes split the action node's CSR row, gather the
+//   neighbours' spins from the env's row and reduce: unweighted graphs need only a
+//   ballot + popcount (cutdeg c, gain = deg - 2c); weighted graphs a shuffle reduction.
+// Phase B (emit variant): the EPW rows are contiguous, so the wave streams them as one
+//   flat run of 16-byte vectors, patching the flipped spin in flight.
+// =====================================================================================
+template <typename T> __device__ __forceinline__ T spin_flip(T v);
+template <> __device__ __forceinline__ uint8_t spin_flip<uint8_t>(uint8_t v) { return v == 0 ? 1 : 0; }
+template <> __device__ __forceinline__ float spin_flip<float>(float v) { return v == 0.0f ? 1.0f : 0.0f; }  // logical_not
+
+template <typename T, int EPW, bool EMIT, bool VEC, bool WEIGHTED>
+__global__ __launch_bounds__(256) void k_maxcut_step(const T* __restrict__ xin, T* __restrict__ xout,
+                                                     int64_t B, int64_t N,
+                                                     const int32_t* __restrict__ rowptr,
+                                                     const int32_t* __restrict__ col,
+                                                     const int32_t* __restrict__ wgt,
+                                                     const int64_t* __restrict__ action,
+                                                     int32_t* __restrict__ obj, float* __restrict__ reward,
+                                                     float* __restrict__ cur, float* __restrict__ done,
+                                                     float done_value) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave));
+    const int64_t b0 = wave * EPW;
+    if (b0 >= B) return;
+    const int nenv = (int)((B - b0) < EPW ? (B - b0) : EPW);
+
+    int64_t act[EPW];
+    int my_delta = 0;  // lane k keeps env k's gain
+#pragma unroll
+    for (int k = 0; k < EPW; ++k) {
+        act[k] = -1;
+        if (k < nenv) {
+            const int64_t b = b0 + k;
+            const int64_t a = action[b];
+            act[k] = a;
+            const T* row = xin + b * N;
+            const int r0 = rowptr[a], r1 = rowptr[a + 1];
+            const bool xa = spin_is_set(row[a]);
+            int acc = 0;
+            for (int j = r0 + lane; j < r1; j += kWave) {
+                const bool xn = spin_is_set(row[col[j]]);
+                if constexpr (WEIGHTED) acc += (xn == xa) ? wgt[j] : -wgt[j];
+                else acc += (xn != xa) ? 1 : 0;
+            }
+            int delta;
+            if constexpr (WEIGHTED) {
+                delta = wave_sum_i32(acc);
+            } else {
+                int c;
+                if (r1 - r0 <= kWave) c = __popcll(ballot64(acc != 0));
+                else c = wave_sum_i32(acc);
+                delta = (r1 - r0) - 2 * c;
+            }
+            if (lane == k) my_delta = delta;
+        }
+    }
+    if (lane < nenv) {
+        const int64_t b = b0 + lane;
+        const int v = obj[b] + my_delta;
+        obj[b] = v;
+        reward[b] = (float)my_delta;
+        if (cur) cur[b] = (float)v;
+        if (done) done[b] = done_value;
+    }
+
+    if constexpr (!EMIT) {
+        // in place: only the flipped spins are written
+        if (lane < nenv) {
+            int64_t a = 0;
+#pragma unroll
+            for (int k = 0; k < EPW; ++k) if (lane == k) a = act[k];
+            T* p = xout + (b0 + lane) * N + a;
+            *p = spin_flip<T>(*p);
+        }
+    } else if constexpr (VEC) {
+        using V = typename SpinVec<T>::type;
+        constexpr int PER = SpinVec<T>::n;
+        const V* src = reinterpret_cast<const V*>(xin + b0 * N);
+        V* dst = reinterpret_cast<V*>(xout + b0 * N);
+        const int64_t nvec = (int64_t)nenv * N / PER;
+        int64_t fvec[EPW];
+        int fidx[EPW];
+#pragma unroll
+        for (int k = 0; k < EPW; ++k) {
+            const int64_t rel = (act[k] < 0) ? -1 : (int64_t)k * N + act[k];
+            fvec[k] = rel < 0 ? -1 : rel / PER;
+            fidx[k] = (int)(rel < 0 ? 0 : rel % PER);
+        }
+#pragma unroll 4
+        for (int64_t i = lane; i < nvec; i += kWave) {
+            V v = __builtin_nontemporal_load(src + i);
+#pragma unroll
+            for (int k = 0; k < EPW; ++k)
+                if (i == fvec[k]) v = SpinVec<T>::flip_at(v, fidx[k]);
+            __builtin_nontemporal_store(v, dst + i);
+        }
+    } else {
+        const T* src = xin + b0 * N;
+        T* dst = xout + b0 * N;
+        const int64_t nel = (int64_t)nenv * N;
+        for (int64_t i = lane; i < nel; i += kWave) {
+            T v = src[i];
+#pragma unroll
+            for (int k = 0; k < EPW; ++k)
+                if (act[k] >= 0 && i == (int64_t)k * N + act[k]) v = spin_flip<T>(v);
+            dst[i] = v;
+        }
+    }
+}
+
+// =====================================================================================
+// Straightforward element-parallel kernels (API completeness; not on the headline path)
+// =====================================================================================
+__global__ void k_edge_cut_mask(const uint8_t* __restrict__ x, int64_t B, int64_t N,
+                                const int32_t* __restrict__ eu, const int32_t* __restrict__ ev, int64_t E,
+                                uint8_t* __restrict__ out) {
+    const int64_t total = B * E;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = t / E, e = t - b * E;
+        const uint8_t* row = x + b * N;
+        out[t] = (uint8_t)((row[eu[e]] != 0) != (row[ev[e]] != 0));
+    }
+}
+
+// cutdeg over the env's *stored* adjacency (out-neighbours only unless bidirectional)
+__global__ void k_node_cutdeg(const uint8_t* __restrict__ x, int64_t B, int64_t N,
+                              const int32_t* __restrict__ erowptr, const int32_t* __restrict__ ev,
+                              int64_t* __restrict__ out) {
+    const int64_t total = B * N;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = t / N, i = t - b * N;
+        const uint8_t* row = x + b * N;
+        const bool xi = row[i] != 0;
+        int c = 0;
+        for (int j = erowptr[i]; j < erowptr[i + 1]; ++j) c += ((row[ev[j]] != 0) != xi);
+        out[t] = c;
+    }
+}
+
+template <bool WEIGHTED>
+__global__ void k_delta_all(const uint8_t* __restrict__ x, int64_t B, int64_t N,
+                            const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                            const int32_t* __restrict__ wgt, int32_t* __restrict__ out) {
+    const int64_t total = B * N;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = t / N, i = t - b * N;
+        const uint8_t* row = x + b * N;
+        const bool xi = row[i] != 0;
+        int d = 0;
+        for (int j = rowptr[i]; j < rowptr[i + 1]; ++j) {
+            const int w = WEIGHTED ? wgt[j] : 1;
+            d += ((row[col[j]] != 0) == xi) ? w : -w;
+        }
+        out[t] = d;
+    }
+}
+
+// one wave per row
+__global__ __launch_bounds__(256) void k_select_better_rows(uint8_t* __restrict__ xs0, int64_t* __restrict__ vs0,
+                                                            const uint8_t* __restrict__ xs1,
+                                                            const int64_t* __restrict__ vs1, int64_t B, int64_t N,
+                                                            int if_max) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+    if (b >= B) return;
+    const int64_t v0 = vs0[b], v1 = vs1[b];
+    const bool take = if_max ? (v1 >= v0) : (v1 <= v0);
+    if (!take) return;
+    const uint8_t* s = xs1 + b * N;
+    uint8_t* d = xs0 + b * N;
+    if ((N & 15) == 0 && ((((uintptr_t)xs0) | ((uintptr_t)xs1)) & 15) == 0) {
+        const uint4* sv = reinterpret_cast<const uint4*>(s);
+        uint4* dv = reinterpret_cast<uint4*>(d);
+        for (int64_t i = lane; i < (N >> 4); i += kWave) dv[i] = sv[i];
+    } else {
+        for (int64_t i = lane; i < N; i += kWave) d[i] = s[i];
+    }
+    if (lane == 0) vs0[b] = v1;
+}
+
+__global__ __launch_bounds__(256) void k_pick_best_of_repeats(const uint8_t* __restrict__ xs,
+                                                              const int64_t* __restrict__ vs, int64_t R, int64_t S,
+                                                              int64_t N, int if_max, uint8_t* __restrict__ gx,
+                                                              int64_t* __restrict__ gv) {
+    const int lane = threadIdx.x & 63;
+    const int64_t s = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+    if (s >= S) return;
+    int64_t best = vs[s];
+    int64_t br = 0;
+    for (int64_t r = 1; r < R; ++r) {  // first extremum wins (torch.argmax/argmin tie rule)
+        const int64_t v = vs[r * S + s];
+        if (if_max ? (v > best) : (v < best)) { best = v; br = r; }
+    }
+    const uint8_t* src = xs + (br * S + s) * N;
+    uint8_t* dst = gx + s * N;
+    for (int64_t i = lane; i < N; i += kWave) dst[i] = src[i];
+    if (lane == 0) gv[s] = best;
+}
+
+// K14: spin(b, n) = bit (n & 127) of Philox(seed; ctr = (b_lo, b_hi, n >> 7, 'SPIN')), node 0 := 0
+__global__ void k_rand_spins(uint8_t* __restrict__ x, int64_t B, int64_t N, uint64_t seed, int64_t env_offset) {
+    const int64_t chunks = (N + 15) >> 4;  // 16 spins per thread
+    const int64_t total = B * chunks;
+    const Philox ph(seed);
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+         t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = t / chunks, ch = t - b * chunks;
+        const uint64_t gb = (uint64_t)(b + env_offset);
+        uint32_t r[4];
+        ph((uint32_t)gb, (uint32_t)(gb >> 32), (uint32_t)(ch >> 3), 0x5350494Eu, r);
+        const uint32_t bits = (r[(ch & 7) >> 1] >> (((ch & 7) & 1) * 16)) & 0xffffu;
+        const int64_t n0 = ch << 4;
+        uint8_t* row = x + b * N;
+        for (int k = 0; k < 16 && n0 + k < N; ++k) row[n0 + k] = (uint8_t)((bits >> k) & 1u);
+        if (ch == 0) row[0] = 0;  // xs[:, 0] = 0, env_L2A.py:84
+    }
+}
+
+__global__ void k_rand_actions(int64_t* __restrict__ action, int64_t B, int64_t N, uint64_t seed, uint64_t step,
+                               int64_t env_offset) {
+    const Philox ph(seed);
+    for (int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; b < B; b += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t gb = (uint64_t)(b + env_offset);
+        uint32_t r[4];
+        ph((uint32_t)gb, (uint32_t)(gb >> 32), (uint32_t)step, (uint32_t)(step >> 32) ^ 0x41435431u, r);
+        action[b] = (int64_t)(((uint64_t)r[0] * (uint64_t)N) >> 32);
+    }
+}
+
+static inline int pick_planes(int64_t E) {
+    if (E < (1 << 12)) return 12;
+    if (E < (1 << 16)) return 16;
+    if (E < (1 << 20)) return 20;
+    if (E < (1 << 24)) return 24;
+    return 0;
+}
+
+static inline bool rows_vec_aligned(const void* p, int64_t N, int elt) {
+    return (((uintptr_t)p) & 15) == 0 && ((N * elt) & 15) == 0;
+}
+
+static inline int grid_for(int64_t total, int block) {
+    int64_t g = ceil_div(total, block);
+    const int64_t cap = 256 * 8 * 4;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+static int check_graph(const rls_graph* g) {
+    RLS_REQUIRE(g != nullptr, RLS_EINVAL, "graph is NULL");
+    RLS_REQUIRE(g->num_nodes > 0 && g->num_nodes < (1ll << 31), RLS_EINVAL, "bad num_nodes %lld",
+                (long long)g->num_nodes);
+    RLS_REQUIRE(g->num_stored_edges >= 0 && g->nnz >= 0, RLS_EINVAL, "negative edge count");
+    RLS_REQUIRE(g->num_stored_edges == 0 || (g->eu && g->ev), RLS_EINVAL, "edge list pointers are NULL");
+    RLS_REQUIRE(g->rowptr != nullptr && g->erowptr != nullptr, RLS_EINVAL, "rowptr/erowptr is NULL");
+    RLS_REQUIRE(g->nnz == 0 || g->col, RLS_EINVAL, "col is NULL");
+    return RLS_OK;
+}
+
+}  // namespace rls
+
+using namespace rls;
+
+extern "C" {
+
+int rls_maxcut_obj(const rls_graph* g, const void* x, int spin_bytes, int64_t B, int64_t* obj, void* stream) {
+    if (int rc = check_graph(g)) return rc;
+    RLS_REQUIRE(B >= 0, RLS_EINVAL, "B < 0");
+    if (B == 0) return RLS_OK;
+    RLS_REQUIRE(x && obj, RLS_EINVAL, "x/obj is NULL");
+    RLS_REQUIRE(spin_bytes == 1 || spin_bytes == 4, RLS_EINVAL, "spin_bytes must be 1 or 4");
+    const int64_t N = g->num_nodes, E = g->num_stored_edges;
+    const size_t lds = (size_t)N * 8;
+    RLS_REQUIRE(lds <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS per 64-env tile (max %d)",
+                (long long)N, lds, kLdsBytes);
+    const int P = pick_planes(E);
+    RLS_REQUIRE(P != 0, RLS_EUNSUPPORTED, "E'=%lld too large", (long long)E);
+    const bool vec = rows_vec_aligned(x, N, spin_bytes);
+    const dim3 grid((unsigned)ceil_div(B, kWave)), block(kWave);
+    hipStream_t s = as_stream(stream);
+    const int halve = g->if_bidirectional ? 1 : 0;
+#define LAUNCH_OBJ(T, VEC, PP)                                                                             \
+    do {                                                                                                   \
+        auto kern = k_maxcut_obj<T, VEC, PP>;                                                              \
+        if (lds > 64 * 1024)                                                                               \
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(kern, grid, block, lds, s, (const T*)x, B, N, g->eu, g->ev, E, halve, obj);     \
+    } while (0)
+#define DISPATCH_P(T, VEC)                       \
+    switch (P) {                                 \
+        case 12: LAUNCH_OBJ(T, VEC, 12); break;  \
+        case 16: LAUNCH_OBJ(T, VEC, 16); break;  \
+        case 20: LAUNCH_OBJ(T, VEC, 20); break;  \
+        default: LAUNCH_OBJ(T, VEC, 24); break;  \
+    }
+    if (spin_bytes == 1) {
+        if (vec) { DISPATCH_P(uint8_t, true) } else { DISPATCH_P(uint8_t, false) }
+    } else {
+        if (vec) { DISPATCH_P(float, true) } else { DISPATCH_P(float, false) }
+    }
+#undef DISPATCH_P
+#undef LAUNCH_OBJ
+    return check_launch("k_maxcut_obj");
+}
+
+int rls_maxcut_propose_accept(const rls_graph* g, uint8_t* x, int64_t B, const uint8_t* mask, int64_t* obj,
+                              void* stream) {
+    if (int rc = check_graph(g)) return rc;
+    RLS_REQUIRE(B >= 0, RLS_EINVAL, "B < 0");
+    if (B == 0) return RLS_OK;
+    RLS_REQUIRE(x && mask && obj, RLS_EINVAL, "x/mask/obj is NULL");
+    const int64_t N = g->num_nodes, E = g->num_stored_edges;
+    const size_t lds = (size_t)N * 16;
+    RLS_REQUIRE(lds <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS (max %d)", (long long)N, lds,
+                kLdsBytes);
+    const int P = pick_planes(E);
+    RLS_REQUIRE(P != 0, RLS_EUNSUPPORTED, "E'=%lld too large", (long long)E);
+    const bool vec = rows_vec_aligned(x, N, 1) && rows_vec_aligned(mask, N, 1);
+    const dim3 grid((unsigned)ceil_div(B, kWave)), block(kWave);
+    hipStream_t s = as_stream(stream);
+    const int halve = g->if_bidirectional ? 1 : 0;
+#define LAUNCH_PA(VEC, PP)                                                                                 \
+    do {                                                                                                   \
+        auto kern = k_maxcut_propose_accept<VEC, PP>;                                                      \
+        if (lds > 64 * 1024)                                                                               \
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(kern, grid, block, lds, s, x, mask, B, N, g->eu, g->ev, E, halve, obj);         \
+    } while (0)
+#define DISPATCH_P(VEC)                      \
+    switch (P) {                             \
+        case 12: LAUNCH_PA(VEC, 12); break;  \
+        case 16: LAUNCH_PA(VEC, 16); break;  \
+        case 20: LAUNCH_PA(VEC, 20); break;  \
+        default: LAUNCH_PA(VEC, 24); break;  \
+    }
+    if (vec) { DISPATCH_P(true) } else { DISPATCH_P(false) }
+#undef DISPATCH_P
+#undef LAUNCH_PA
+    return check_launch("k_maxcut_propose_accept");
+}
+
+int rls_maxcut_greedy_sweep(const rls_graph* g, uint8_t* x, int64_t B, int64_t* obj, void* stream) {
+    if (int rc = check_graph(g)) return rc;
+    RLS_REQUIRE(B >= 0, RLS_EINVAL, "B < 0");
+    if (B == 0) return RLS_OK;
+    RLS_REQUIRE(x && obj, RLS_EINVAL, "x/obj is NULL");
+    const int64_t N = g->num_nodes;
+    const size_t lds = (size_t)N * 8;
+    RLS_REQUIRE(lds <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS (max %d)", (long long)N, lds,
+                kLdsBytes);
+    const bool vec = rows_vec_aligned(x, N, 1);
+    const dim3 grid((unsigned)ceil_div(B, kWave)), block(kWave);
+    hipStream_t s = as_stream(stream);
+#define LAUNCH_SW(VEC, W)                                                                                  \
+    do {                                                                                                   \
+        auto kern = k_maxcut_greedy_sweep<VEC, W>;                                                         \
+        if (lds > 64 * 1024)                                                                               \
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(kern, grid, block, lds, s, x, B, N, g->rowptr, g->col, g->wgt, obj);            \
+    } while (0)
+    if (g->wgt) { if (vec) LAUNCH_SW(true, true); else LAUNCH_SW(false, true); }
+    else        { if (vec) LAUNCH_SW(true, false); else LAUNCH_SW(false, false); }
+#undef LAUNCH_SW
+    return check_launch("k_maxcut_greedy_sweep");
+}
+
+int rls_maxcut_step(const rls_graph* g, const void* x_in, void* x_out, int spin_bytes, int64_t B,
+                    const int64_t* action, int32_t* obj, float* reward, float* cur, float* done,
+                    float done_value, void* stream) {
+    if (int rc = check_graph(g)) return rc;
+    RLS_REQUIRE(B >= 0, RLS_EINVAL, "B < 0");
+    if (B == 0) return RLS_OK;
+    RLS_REQUIRE(x_in && x_out && action && obj && reward, RLS_EINVAL, "x_in/x_out/action/obj/reward is NULL");
+    RLS_REQUIRE(spin_bytes == 1 || spin_bytes == 4, RLS_EINVAL, "spin_bytes must be 1 or 4");
+    const int64_t N = g->num_nodes;
+    const bool emit = (x_in != x_out);
+    constexpr int EPW = 4;
+    // flat tiles of EPW rows start 16-byte aligned when one row is a multiple of 16 bytes
+    const bool vec = rows_vec_aligned(x_in, N, spin_bytes) && rows_vec_aligned(x_out, N, spin_bytes);
+    const int waves_per_block = 4;
+    const dim3 grid((unsigned)ceil_div(ceil_div(B, EPW), waves_per_block)), block(waves_per_block * kWave);
+    hipStream_t s = as_stream(stream);
+    const bool weighted = g->wgt != nullptr;
+#define LAUNCH_STEP(T, EMIT, VEC, W)                                                                       \
+    hipLaunchKernelGGL((k_maxcut_step<T, EPW, EMIT, VEC, W>), grid, block, 0, s, (const T*)x_in, (T*)x_out, \
+                       B, N, g->rowptr, g->col, g->wgt, action, obj, reward, cur, done, done_value)
+#define DISPATCH_W(T, EMIT, VEC) do { if (weighted) LAUNCH_STEP(T, EMIT, VEC, true); else LAUNCH_STEP(T, EMIT, VEC, false); } while (0)
+#define DISPATCH_V(T, EMIT) do { if (vec) DISPATCH_W(T, EMIT, true); else DISPATCH_W(T, EMIT, false); } while (0)
+    if (spin_bytes == 1) { if (emit) DISPATCH_V(uint8_t, true); else DISPATCH_W(uint8_t, false, false); }
+    else                 { if (emit) DISPATCH_V(float, true);   else DISPATCH_W(float, false, false); }
+#undef DISPATCH_V
+#undef DISPATCH_W
+#undef LAUNCH_STEP
+    return check_launch("k_maxcut_step");
+}
+
+int rls_maxcut_edge_cut_mask(const rls_graph* g, const uint8_t* x, int64_t B, uint8_t* cutmask, void* stream) {
+    if (int rc = check_graph(g)) return rc;
+    RLS_REQUIRE(B >= 0, RLS_EINVAL, "B < 0");
+    const int64_t E = g->num_stored_edges;
+    if (B == 0 || E == 0) return RLS_OK;
+    RLS_REQUIRE(x && cutmask, RLS_EINVAL, "x/cutmask is NULL");
+    hipLaunchKernelGGL(k_edge_cut_mask, dim3(grid_for(B * E, 256)), dim3(256), 0, as_stream(stream), x, B,
+                       g->num_nodes, g->eu, g->ev, E, cutmask);
+    return check_launch("k_edge_cut_mask");
+}
+
+int rls_maxcut_node_cutdeg(const rls_graph* g, const uint8_t* x, int64_t B, int64_t* cutdeg, void* stream) {
+    if (int rc = check_graph(g)) return rc;
+    RLS_REQUIRE(B >= 0, RLS_EINVAL, "B < 0");
+    if (B == 0) return RLS_OK;
+    RLS_REQUIRE(x && cutdeg, RLS_EINVAL, "x/cutdeg is NULL");
+    hipLaunchKernelGGL(k_node_cutdeg, dim3(grid_for(B * g->num_nodes, 256)), dim3(256), 0, as_stream(stream), x, B,
+                       g->num_nodes, g->erowptr, g->ev, cutdeg);
+    return check_launch("k_node_cutdeg");
+}
+
+int rls_maxcut_delta_all(const rls_graph* g, const uint8_t* x, int64_t B, int32_t* delta, void* stream) {
+    if (int rc = check_graph(g)) return rc;
+    RLS_REQUIRE(B >= 0, RLS_EINVAL, "B < 0");
+    if (B == 0) return RLS_OK;
+    RLS_REQUIRE(x && delta, RLS_EINVAL, "x/delta is NULL");
+    const dim3 grid(grid_for(B * g->num_nodes, 256)), block(256);
+    if (g->wgt)
+        hipLaunchKernelGGL(k_delta_all<true>, grid, block, 0, as_stream(stream), x, B, g->num_nodes, g->rowptr,
+                           g->col, g->wgt, delta);
+    else
+        hipLaunchKernelGGL(k_delta_all<false>, grid, block, 0, as_stream(stream), x, B, g->num_nodes, g->rowptr,
+                           g->col, g->wgt, delta);
+    return check_launch("k_delta_all");
+}
+
+int rls_select_better_rows(uint8_t* xs0, int64_t* vs0, const uint8_t* xs1, const int64_t* vs1, int64_t B,
+                           int64_t N, int if_maximize, void* stream) {
+    RLS_REQUIRE(B >= 0 && N >= 0, RLS_EINVAL, "negative size");
+    if (B == 0) return RLS_OK;
+    RLS_REQUIRE(xs0 && vs0 && xs1 && vs1, RLS_EINVAL, "NULL pointer");
+    hipLaunchKernelGGL(k_select_better_rows, dim3((unsigned)ceil_div(B, 4)), dim3(256), 0, as_stream(stream), xs0,
+                       vs0, xs1, vs1, B, N, if_maximize);
+    return check_launch("k_select_better_rows");
+}
+
+int rls_pick_best_of_repeats(const uint8_t* xs, const int64_t* vs, int64_t R, int64_t S, int64_t N,
+                             int if_maximize, uint8_t* good_xs, int64_t* good_vs, void* stream) {
+    RLS_REQUIRE(R > 0 && S >= 0 && N >= 0, RLS_EINVAL, "bad sizes R=%lld S=%lld N=%lld", (long long)R, (long long)S,
+                (long long)N);
+    if (S == 0) return RLS_OK;
+    RLS_REQUIRE(xs && vs && good_xs && good_vs, RLS_EINVAL, "NULL pointer");
+    hipLaunchKernelGGL(k_pick_best_of_repeats, dim3((unsigned)ceil_div(S, 4)), dim3(256), 0, as_stream(stream), xs,
+                       vs, R, S, N, if_maximize, good_xs, good_vs);
+    return check_launch("k_pick_best_of_repeats");
+}
+
+int rls_rand_spins(uint8_t* x, int64_t B, int64_t N, uint64_t seed, int64_t env_offset, void* stream) {
+    RLS_REQUIRE(B >= 0 && N > 0, RLS_EINVAL, "bad sizes");
+    if (B == 0) return RLS_OK;
+    RLS_REQUIRE(x, RLS_EINVAL, "x is NULL");
+    hipLaunchKernelGGL(k_rand_spins, dim3(grid_for(B * ((N + 15) >> 4), 256)), dim3(256), 0, as_stream(stream), x,
+                       B, N, seed, env_offset);
+    return check_launch("k_rand_spins");
+}
+
+int rls_rand_actions(int64_t* action, int64_t B, int64_t N, uint64_t seed, uint64_t step, int64_t env_offset,
+                     void* stream) {
+    RLS_REQUIRE(B >= 0 && N > 0, RLS_EINVAL, "bad sizes");
+    if (B == 0) return RLS_OK;
+    RLS_REQUIRE(action, RLS_EINVAL, "action is NULL");
+    hipLaunchKernelGGL(k_rand_actions, dim3(grid_for(B, 256)), dim3(256), 0, as_stream(stream), action, B, N, seed,
+                       step, env_offset);
+    return check_launch("k_rand_actions");
+}
+
+}  // extern "C"

@@ -1,0 +1,191 @@
+"""Tensor-level wrappers over the C ABI: check device/dtype/contiguity, pass raw
+device pointers and torch's current HIP stream.  PyTorch is plumbing here
+(memory + streams); all arithmetic happens in the HIP kernels.
+
+No CPU path: a CPU tensor is a TypeError, a missing library an ImportError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _abi
+from .graph import GraphCSR
+
+TEN = torch.Tensor
+
+
+def _stream(device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _check(t: TEN, name: str, dtypes, device=None, shape=None) -> TEN:
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if not t.is_cuda:
+        raise TypeError(f"{name} must live on a HIP device (got {t.device}); rlsolver_amd has no CPU path")
+    if device is not None and t.device != device:
+        raise ValueError(f"{name} is on {t.device}, expected {device}")
+    if t.dtype not in dtypes:
+        raise TypeError(f"{name} has dtype {t.dtype}, expected one of {dtypes}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name} has shape {tuple(t.shape)}, expected {tuple(shape)}")
+    return t
+
+
+def _ptr(t: Optional[TEN]) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+_SPIN_DTYPES = (torch.bool, torch.uint8)
+
+
+class DeviceGraph:
+    """One shared graph resident on a HIP device + the rls_graph descriptor."""
+
+    def __init__(self, csr: GraphCSR, device, use_weights: bool = False):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise TypeError(f"DeviceGraph needs a HIP device, got {self.device}")
+        self.csr = csr
+        i32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(self.device)
+        self.eu, self.ev = i32(csr.eu), i32(csr.ev)
+        counts = np.bincount(csr.eu, minlength=csr.num_nodes) if csr.eu.size else np.zeros(csr.num_nodes, np.int64)
+        erp = np.zeros(csr.num_nodes + 1, np.int64)
+        np.cumsum(counts, out=erp[1:])
+        self.erowptr = i32(erp)
+        self.rowptr, self.col = i32(csr.rowptr), i32(csr.col)
+        self.wgt = i32(csr.wgt) if use_weights else None
+        self.num_nodes, self.num_stored_edges, self.nnz = csr.num_nodes, csr.num_stored_edges, csr.nnz
+        self.if_bidirectional = csr.if_bidirectional
+        self.struct = _abi.RlsGraph(
+            num_nodes=csr.num_nodes, num_stored_edges=csr.num_stored_edges, nnz=csr.nnz,
+            if_bidirectional=int(csr.if_bidirectional), max_degree=csr.max_degree,
+            eu=self.eu.data_ptr(), ev=self.ev.data_ptr(), erowptr=self.erowptr.data_ptr(),
+            rowptr=self.rowptr.data_ptr(), col=self.col.data_ptr(),
+            wgt=0 if self.wgt is None else self.wgt.data_ptr())
+        self.ref = C.byref(self.struct)
+
+
+def _spins(x: TEN, name: str, g: DeviceGraph, allow_f32=False):
+    dt = _SPIN_DTYPES + ((torch.float32,) if allow_f32 else ())
+    _check(x, name, dt, g.device)
+    if x.dim() != 2 or x.shape[1] != g.num_nodes:
+        raise ValueError(f"{name} must be [B, {g.num_nodes}], got {tuple(x.shape)}")
+    return x.shape[0], (4 if x.dtype == torch.float32 else 1)
+
+
+# ------------------------------------------------------------------------ MaxCut
+def maxcut_obj(g: DeviceGraph, xs: TEN, out: Optional[TEN] = None) -> TEN:
+    B, sb = _spins(xs, "xs", g, allow_f32=True)
+    if out is None:
+        out = torch.empty(B, dtype=torch.int64, device=g.device)
+    _check(out, "out", (torch.int64,), g.device, (B,))
+    _abi.call("rls_maxcut_obj", g.ref, _ptr(xs), sb, B, _ptr(out), _stream(g.device))
+    return out
+
+
+def maxcut_edge_cut_mask(g: DeviceGraph, xs: TEN) -> TEN:
+    B, _ = _spins(xs, "xs", g)
+    out = torch.empty((B, g.num_stored_edges), dtype=torch.bool, device=g.device)
+    _abi.call("rls_maxcut_edge_cut_mask", g.ref, _ptr(xs), B, _ptr(out), _stream(g.device))
+    return out
+
+
+def maxcut_node_cutdeg(g: DeviceGraph, xs: TEN) -> TEN:
+    B, _ = _spins(xs, "xs", g)
+    out = torch.empty((B, g.num_nodes), dtype=torch.int64, device=g.device)
+    _abi.call("rls_maxcut_node_cutdeg", g.ref, _ptr(xs), B, _ptr(out), _stream(g.device))
+    return out
+
+
+def maxcut_delta_all(g: DeviceGraph, xs: TEN) -> TEN:
+    B, _ = _spins(xs, "xs", g)
+    out = torch.empty((B, g.num_nodes), dtype=torch.int32, device=g.device)
+    _abi.call("rls_maxcut_delta_all", g.ref, _ptr(xs), B, _ptr(out), _stream(g.device))
+    return out
+
+
+def maxcut_step(g: DeviceGraph, x_in: TEN, x_out: TEN, action: TEN, obj: TEN, reward: TEN,
+                cur: Optional[TEN] = None, done: Optional[TEN] = None, done_value: float = 0.0) -> None:
+    """K4.  x_out may be x_in (in-place flip) or a different buffer (emit next state)."""
+    B, sb = _spins(x_in, "x_in", g, allow_f32=True)
+    B2, sb2 = _spins(x_out, "x_out", g, allow_f32=True)
+    if (B2, sb2) != (B, sb):
+        raise ValueError("x_in and x_out must have the same shape and dtype")
+    _check(action, "action", (torch.int64,), g.device, (B,))
+    _check(obj, "obj", (torch.int32,), g.device, (B,))
+    _check(reward, "reward", (torch.float32,), g.device, (B,))
+    if cur is not None:
+        _check(cur, "cur", (torch.float32,), g.device, (B,))
+    if done is not None:
+        _check(done, "done", (torch.float32,), g.device, (B,))
+    _abi.call("rls_maxcut_step", g.ref, _ptr(x_in), _ptr(x_out), sb, B, _ptr(action), _ptr(obj),
+              _ptr(reward), _ptr(cur), _ptr(done), float(done_value), _stream(g.device))
+
+
+def maxcut_greedy_sweep(g: DeviceGraph, xs: TEN, obj: TEN) -> None:
+    B, _ = _spins(xs, "xs", g)
+    _check(obj, "obj", (torch.int64,), g.device, (B,))
+    _abi.call("rls_maxcut_greedy_sweep", g.ref, _ptr(xs), B, _ptr(obj), _stream(g.device))
+
+
+def maxcut_propose_accept(g: DeviceGraph, xs: TEN, mask: TEN, obj: TEN) -> None:
+    B, _ = _spins(xs, "xs", g)
+    _spins(mask, "mask", g)
+    if mask.shape[0] != B:
+        raise ValueError("mask must have the same shape as xs")
+    _check(obj, "obj", (torch.int64,), g.device, (B,))
+    _abi.call("rls_maxcut_propose_accept", g.ref, _ptr(xs), B, _ptr(mask), _ptr(obj), _stream(g.device))
+
+
+def select_better_rows(xs0: TEN, vs0: TEN, xs1: TEN, vs1: TEN, if_maximize: bool = True) -> None:
+    _check(xs0, "xs0", _SPIN_DTYPES)
+    dev = xs0.device
+    if xs0.dim() != 2:
+        raise ValueError("xs0 must be [B, N]")
+    B, N = xs0.shape
+    _check(xs1, "xs1", _SPIN_DTYPES, dev, (B, N))
+    _check(vs0, "vs0", (torch.int64,), dev, (B,))
+    _check(vs1, "vs1", (torch.int64,), dev, (B,))
+    _abi.call("rls_select_better_rows", _ptr(xs0), _ptr(vs0), _ptr(xs1), _ptr(vs1), B, N, int(bool(if_maximize)),
+              _stream(dev))
+
+
+def pick_best_of_repeats(xs: TEN, vs: TEN, num_repeats: int, if_maximize: bool = True):
+    _check(xs, "xs", _SPIN_DTYPES)
+    dev = xs.device
+    if xs.dim() != 2 or xs.shape[0] % num_repeats != 0:
+        raise ValueError("xs must be [R*S, N]")
+    S, N = xs.shape[0] // num_repeats, xs.shape[1]
+    _check(vs, "vs", (torch.int64,), dev, (xs.shape[0],))
+    gx = torch.empty((S, N), dtype=xs.dtype, device=dev)
+    gv = torch.empty(S, dtype=torch.int64, device=dev)
+    _abi.call("rls_pick_best_of_repeats", _ptr(xs), _ptr(vs), num_repeats, S, N, int(bool(if_maximize)),
+              _ptr(gx), _ptr(gv), _stream(dev))
+    return gx, gv
+
+
+def rand_spins(B: int, N: int, seed: int, device, env_offset: int = 0, out: Optional[TEN] = None) -> TEN:
+    device = torch.device(device)
+    if out is None:
+        out = torch.empty((B, N), dtype=torch.bool, device=device)
+    _check(out, "out", _SPIN_DTYPES, None, (B, N))
+    _abi.call("rls_rand_spins", _ptr(out), B, N, C.c_uint64(seed & (2 ** 64 - 1)), env_offset, _stream(out.device))
+    return out
+
+
+def rand_actions(B: int, N: int, seed: int, step: int, device, env_offset: int = 0,
+                 out: Optional[TEN] = None) -> TEN:
+    device = torch.device(device)
+    if out is None:
+        out = torch.empty(B, dtype=torch.int64, device=device)
+    _check(out, "out", (torch.int64,), None, (B,))
+    _abi.call("rls_rand_actions", _ptr(out), B, N, C.c_uint64(seed & (2 ** 64 - 1)), C.c_uint64(step), env_offset,
+              _stream(out.device))
+    return out

@@ -1,0 +1,468 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by IMPORTING the reference
+(Open-Finance-Lab/RLSolver, mounted read-only at /root/reference) and running its
+own functions on CPU.  Only data (inputs, recorded random draws, outputs) is written;
+no reference source travels.
+
+    PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py [--only maxcut,ppo,...]
+
+The fixtures are committed; this script only needs re-running when a fixture is added.
+Every array is small (a few KB); spins are stored as uint8.
+"""
+import argparse
+import importlib.util
+import os
+import sys
+import types
+
+REF = "/root/reference"
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+
+import numpy as np
+import torch as th
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+DATA = os.path.join(REF, "rlsolver", "data")
+
+GRAPHS = {
+    "BA_5_ID0": "syn_BA/BA_5_ID0.txt",
+    "BA_5_ID1": "syn_BA/BA_5_ID1.txt",
+    "PL_20_ID0": "syn_PL/PL_20_ID0.txt",
+    "BA_100_ID0": "syn_BA/BA_100_ID0.txt",
+    "ER_100_ID0": "syn_ER/ER_100_ID0.txt",
+    "PL_100_ID0": "syn_PL/PL_100_ID0.txt",
+    "gset_14_stub": "gset/gset_14.txt",
+}
+
+
+def u8(t):
+    return t.detach().cpu().numpy().copy().astype(np.uint8)
+
+
+def save(name, **arrays):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"wrote {path}  ({os.path.getsize(path)} bytes, {len(arrays)} arrays)")
+
+
+def graph_arrays(mygraph):
+    a = np.asarray(mygraph, dtype=np.int64).reshape(-1, 3)
+    return a
+
+
+class Recorder:
+    """Wrap a torch RNG function and keep every tensor it returns."""
+
+    def __init__(self, *names):
+        self.names = names
+        self.log = {n: [] for n in names}
+        self._orig = {}
+
+    def __enter__(self):
+        for n in self.names:
+            self._orig[n] = getattr(th, n)
+
+            def make(nm, fn):
+                def wrapped(*a, **k):
+                    out = fn(*a, **k)
+                    self.log[nm].append(out.detach().cpu().clone())
+                    return out
+                return wrapped
+
+            setattr(th, n, make(n, self._orig[n]))
+        return self
+
+    def __exit__(self, *exc):
+        for n in self.names:
+            setattr(th, n, self._orig[n])
+
+
+# ----------------------------------------------------------------------------- MaxCut (L2A flavour)
+def gen_maxcut():
+    from rlsolver.envs.env_L2A import EnvMaxcut
+    from rlsolver.methods.util_read_data import read_mygraph
+    out = {}
+    names = []
+    for gname, rel in GRAPHS.items():
+        mygraph = read_mygraph(os.path.join(DATA, rel))
+        out[f"{gname}/graph"] = graph_arrays(mygraph)
+        names.append(gname)
+        for bidir in (False, True):
+            env = EnvMaxcut(mygraph=mygraph, device=th.device("cpu"), if_bidirectional=bidir)
+            tag = f"{gname}/bidir{int(bidir)}"
+            out[f"{tag}/num_nodes"] = np.int64(env.num_nodes)
+            out[f"{tag}/n0_num_n1"] = env.n0_num_n1.numpy().copy()
+            for seed in (0, 1, 2):
+                th.manual_seed(seed)
+                xs = env.generate_xs_randomly(num_sims=32)
+                vs = env.calculate_obj_values(xs)
+                vs_loop = env.calculate_obj_values_for_loop(xs, if_sum=True)
+                raw = env.calculate_obj_values_for_loop(xs, if_sum=False)
+                t = f"{tag}/seed{seed}"
+                out[f"{t}/xs"] = u8(xs)
+                out[f"{t}/obj"] = vs.numpy().copy()
+                out[f"{t}/obj_dtype"] = np.array(str(vs.dtype))
+                out[f"{t}/obj_loop"] = vs_loop.numpy().copy()
+                out[f"{t}/obj_loop_dtype"] = np.array(str(vs_loop.dtype))
+                out[f"{t}/cutdeg"] = raw.numpy().copy()
+                out[f"{t}/cutdeg_dtype"] = np.array(str(raw.dtype))
+                if env.num_nodes <= 20:
+                    out[f"{t}/edge_mask"] = u8(env.calculate_obj_values(xs, if_sum=False))
+    out["names"] = np.array(names)
+    save("maxcut_obj", **out)
+
+
+def gen_sweep():
+    """K5: local_search_inplace(num_iters=0) = the greedy 'addition' sweep only; and K6+K5 with
+    the randn draws recorded."""
+    from rlsolver.envs.env_L2A import EnvMaxcut
+    from rlsolver.methods.util_read_data import read_mygraph
+    out = {}
+    for gname in ("PL_20_ID0", "BA_100_ID0", "ER_100_ID0", "gset_14_stub"):
+        mygraph = read_mygraph(os.path.join(DATA, GRAPHS[gname]))
+        out[f"{gname}/graph"] = graph_arrays(mygraph)
+        for bidir in (False, True):
+            env = EnvMaxcut(mygraph=mygraph, device=th.device("cpu"), if_bidirectional=bidir)
+            tag = f"{gname}/bidir{int(bidir)}"
+            th.manual_seed(7)
+            xs0 = env.generate_xs_randomly(num_sims=32)
+            # sweep only
+            xs = xs0.clone()
+            with Recorder("randn_like") as rec:
+                gx, gv = env.local_search_inplace(xs, th.empty(()), num_iters=0)
+            out[f"{tag}/sweep/xs_in"] = u8(xs0)
+            out[f"{tag}/sweep/xs_out"] = u8(gx)
+            out[f"{tag}/sweep/vs_out"] = gv.numpy().copy()
+            # full local search, noise recorded
+            xs = xs0.clone()
+            num_spin = 8 if env.num_nodes > 16 else 3
+            with Recorder("randn_like") as rec:
+                gx, gv = env.local_search_inplace(xs, th.empty(()), num_iters=8, num_spin=num_spin, noise_std=0.3)
+            out[f"{tag}/ls/xs_in"] = u8(xs0)
+            out[f"{tag}/ls/noise"] = th.stack(rec.log["randn_like"]).numpy().copy()  # [9, B, N]
+            out[f"{tag}/ls/num_spin"] = np.int64(num_spin)
+            out[f"{tag}/ls/xs_out"] = u8(gx)
+            out[f"{tag}/ls/vs_out"] = gv.numpy().copy()
+    save("maxcut_local_search", **out)
+
+
+def gen_local_search_class():
+    """methods/LocalSearch.py: reset + random_search with recorded noise."""
+    from rlsolver.envs.env_L2A import EnvMaxcut
+    from rlsolver.methods.LocalSearch import LocalSearch
+    from rlsolver.methods.util_read_data import read_mygraph
+    out = {}
+    for gname in ("BA_100_ID0", "PL_20_ID0"):
+        mygraph = read_mygraph(os.path.join(DATA, GRAPHS[gname]))
+        out[f"{gname}/graph"] = graph_arrays(mygraph)
+        # if_bidirectional=True makes the reference raise (float prev_vs vs int64 vs in
+        # update_xs_by_vs, LocalSearch.py:60-61,75), so only the working setting is recorded.
+        for bidir in (False,):
+            env = EnvMaxcut(mygraph=mygraph, device=th.device("cpu"), if_bidirectional=bidir)
+            tag = f"{gname}/bidir{int(bidir)}"
+            th.manual_seed(11)
+            xs0 = env.generate_xs_randomly(num_sims=16)
+            ls = LocalSearch(simulator=env, num_nodes=env.num_nodes)
+            vs0 = ls.reset(xs0.clone())
+            out[f"{tag}/xs_in"] = u8(xs0)
+            out[f"{tag}/vs_reset"] = vs0.numpy().copy()
+            rounds = []
+            for r in range(2):
+                with Recorder("randn_like") as rec:
+                    gx, gv, nupd = ls.random_search(num_iters=4, num_spin=4, noise_std=0.3)
+                out[f"{tag}/round{r}/noise"] = th.stack(rec.log["randn_like"]).numpy().copy()
+                out[f"{tag}/round{r}/xs"] = u8(gx)
+                out[f"{tag}/round{r}/vs"] = gv.numpy().copy()
+                out[f"{tag}/round{r}/num_update"] = np.int64(nupd)
+    save("local_search_class", **out)
+
+
+# ----------------------------------------------------------------------------- gym flavour
+def gen_ppo():
+    from rlsolver.envs.env_PPO import EnvMaxcut
+    from rlsolver.methods.util_read_data import read_mygraph
+    out = {}
+    for gname in ("BA_100_ID0", "gset_14_stub"):
+        mygraph = read_mygraph(os.path.join(DATA, GRAPHS[gname]))
+        out[f"{gname}/graph"] = graph_arrays(mygraph)
+        n = max(max(a, b) for a, b, _ in mygraph) + 1
+        for bidir in (False, True):
+            args = types.SimpleNamespace(num_nodes=n, num_envs=16, num_steps=20)
+            env = EnvMaxcut(args, mygraph=mygraph, device=th.device("cpu"), if_bidirectional=bidir)
+            tag = f"{gname}/bidir{int(bidir)}"
+            th.manual_seed(3)
+            xs = env.reset()
+            out[f"{tag}/xs0"] = u8(xs > 0)
+            out[f"{tag}/xs0_dtype"] = np.array(str(xs.dtype))
+            out[f"{tag}/cut0"] = env.last_reward.numpy().copy()
+            g = th.Generator().manual_seed(5)
+            acts, rews, dones, curs = [], [], [], []
+            for t in range(50):
+                a = th.randint(0, n, (16,), generator=g)
+                x, r, d, c = env.step(a)
+                acts.append(a.numpy().copy()); rews.append(r.numpy().copy()); dones.append(d.numpy().copy())
+                curs.append(c.numpy().copy())
+            out[f"{tag}/actions"] = np.stack(acts)
+            out[f"{tag}/rewards"] = np.stack(rews)
+            out[f"{tag}/dones"] = np.stack(dones)
+            out[f"{tag}/curs"] = np.stack(curs)
+            out[f"{tag}/xs_final"] = u8(env.xs > 0)
+            out[f"{tag}/ret_dtypes"] = np.array([str(x.dtype), str(r.dtype), str(d.dtype), str(c.dtype)])
+    save("env_ppo", **out)
+
+
+# ----------------------------------------------------------------------------- select ops
+def gen_select():
+    from rlsolver.methods.util_read_data import update_xs_by_vs, pick_xs_by_vs
+    from rlsolver.methods.util import evolutionary_replacement
+    out = {}
+    g = th.Generator().manual_seed(9)
+    B, N = 24, 37
+    xs0 = th.randint(0, 2, (B, N), generator=g, dtype=th.bool)
+    xs1 = th.randint(0, 2, (B, N), generator=g, dtype=th.bool)
+    vs0 = th.randint(0, 6, (B,), generator=g)
+    vs1 = th.randint(0, 6, (B,), generator=g)
+    for mx in (True, False):
+        a, b = xs0.clone(), vs0.clone()
+        ret = update_xs_by_vs(a, b, xs1, vs1, if_maximize=mx)
+        out[f"update/max{int(mx)}/xs"] = u8(a)
+        out[f"update/max{int(mx)}/vs"] = b.numpy().copy()
+        out[f"update/max{int(mx)}/ret"] = np.int64(ret)
+    out["update/xs0"], out["update/xs1"] = u8(xs0), u8(xs1)
+    out["update/vs0"], out["update/vs1"] = vs0.numpy().copy(), vs1.numpy().copy()
+    R, S = 6, 4
+    for mx in (True, False):
+        gx, gv = pick_xs_by_vs(xs0, vs0, num_repeats=R, if_maximize=mx)
+        out[f"pick/max{int(mx)}/xs"] = u8(gx)
+        out[f"pick/max{int(mx)}/vs"] = gv.numpy().copy()
+    out["pick/R"] = np.int64(R)
+    # evolutionary_replacement: record the randperm
+    vsd = th.randperm(B, generator=g)  # distinct values so argsort is unambiguous
+    # if_maximize=False indexes top_ids (size low_k) with randperm(B - low_k) and raises
+    # IndexError in the reference (util.py:91-92); only the working branch is recorded.
+    for mx in (True,):
+        a, b = xs0.clone(), vsd.clone()
+        with Recorder("randperm") as rec:
+            evolutionary_replacement(a, b, low_k=5, if_maximize=mx)
+        out[f"evo/max{int(mx)}/perm"] = rec.log["randperm"][0].numpy().copy()
+        out[f"evo/max{int(mx)}/xs"] = u8(a)
+        out[f"evo/max{int(mx)}/vs"] = b.numpy().copy()
+    out["evo/vs_in"] = vsd.numpy().copy()
+    save("select_ops", **out)
+
+
+# ----------------------------------------------------------------------------- MCPG
+def load_mcpg_module():
+    """rlsolver/methods/MCPG.py is shadowed by the MCPG/ package on import; load the file
+    directly, with a 6-line stand-in for torch_geometric.data.Data (an attribute bag)."""
+    tg = types.ModuleType("torch_geometric")
+    tgd = types.ModuleType("torch_geometric.data")
+
+    class Data:
+        def __init__(self, **kw):
+            self.__dict__.update(kw)
+
+        @property
+        def num_edges(self):
+            return self.edge_index.shape[1]
+
+    tgd.Data = Data
+    tg.data = tgd
+    sys.modules.setdefault("torch_geometric", tg)
+    sys.modules.setdefault("torch_geometric.data", tgd)
+    sys.path.insert(0, os.path.join(REF, "rlsolver", "methods"))
+    spec = importlib.util.spec_from_file_location("ref_mcpg_file", os.path.join(REF, "rlsolver", "methods", "MCPG.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def gen_mcpg():
+    m = load_mcpg_module()
+    from rlsolver.methods.util_read_data import read_mygraph
+    out = {}
+    dev = th.device("cpu")
+    for gname in ("BA_100_ID0", "PL_20_ID0"):
+        path = os.path.join(DATA, GRAPHS[gname])
+        out[f"{gname}/graph"] = graph_arrays(read_mygraph(path))
+        data, num_nodes = m.maxcut_dataloader(path, device=dev)
+        out[f"{gname}/sorted_degree_nodes"] = data.sorted_degree_nodes.numpy().copy()
+        out[f"{gname}/weighted_degree"] = np.asarray(data.weighted_degree, dtype=np.float64)
+        out[f"{gname}/edge_index"] = data.edge_index.numpy().copy()
+        total_mcmc_num, repeat_times, num_ls = 8, 4, 3
+        C = total_mcmc_num * repeat_times
+        g = th.Generator().manual_seed(21)
+        probs = th.rand(num_nodes, generator=g) * 0.6 + 0.2
+        start = th.randint(0, 2, (num_nodes, C), generator=g).float()
+        T = max(1, num_nodes // 10)
+        with Recorder("rand", "randint") as rec:
+            samples = m.metro_sampling(probs, start.clone(), T, device=dev)
+        out[f"{gname}/metro/probs"] = probs.numpy().copy()
+        out[f"{gname}/metro/start"] = u8(start)
+        out[f"{gname}/metro/T"] = np.int64(T)
+        out[f"{gname}/metro/index"] = th.stack(rec.log["randint"]).numpy().copy()
+        out[f"{gname}/metro/u"] = th.stack(rec.log["rand"]).numpy().copy()
+        out[f"{gname}/metro/out"] = u8(samples)
+        out[f"{gname}/metro/out_dtype"] = np.array(str(samples.dtype))
+        with Recorder("rand") as rec:
+            vs_good, xs_good, value = m.sampler_func(data, samples.clone(), num_ls, total_mcmc_num, repeat_times,
+                                                     device=dev)
+        out[f"{gname}/sampler/xs_in"] = u8(samples)
+        out[f"{gname}/sampler/uniforms"] = th.stack(rec.log["rand"]).numpy().copy().reshape(num_ls, num_nodes, C)
+        out[f"{gname}/sampler/num_ls"] = np.int64(num_ls)
+        out[f"{gname}/sampler/total_mcmc_num"] = np.int64(total_mcmc_num)
+        out[f"{gname}/sampler/repeat_times"] = np.int64(repeat_times)
+        out[f"{gname}/sampler/vs_good"] = vs_good.numpy().copy()
+        out[f"{gname}/sampler/xs_good"] = xs_good.numpy().copy()
+        out[f"{gname}/sampler/value"] = value.numpy().copy()
+    save("mcpg", **out)
+
+
+# ----------------------------------------------------------------------------- TSP
+def gen_tsp():
+    import rlsolver.envs.env_ISCO as env_isco
+    from rlsolver.methods.ISCO import util_TSP
+    sys.path.insert(0, os.path.join(REF, "rlsolver", "methods_problem_specific", "TSP"))
+    spec = importlib.util.spec_from_file_location(
+        "ref_opt2", os.path.join(REF, "rlsolver", "methods_problem_specific", "TSP", "opt_2.py"))
+    opt2 = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(opt2)
+    out = {}
+    for name in ("a5", "berlin52"):
+        path = os.path.join(DATA, "tsplib", name + ".tsp")
+        K = 20 if name == "berlin52" else 2
+        util_TSP.K = K
+        env_isco.K = K
+        params = util_TSP.load_data(path)
+        N = params["num_nodes"]
+        B = 17
+        env_isco.BATCH_SIZE = B
+        sampler = env_isco.ISCO_TSP(params)
+        out[f"{name}/coords"] = np.asarray(util_TSP.read_tsp_file(path), dtype=np.float64)
+        out[f"{name}/K"] = np.int64(K)
+        out[f"{name}/distance"] = params["distance"].numpy().copy()
+        out[f"{name}/nearest_indices"] = params["nearest_indices"].numpy().copy()
+        out[f"{name}/random_indices"] = params["random_indices"].numpy().copy()
+        th.manual_seed(13)
+        perms = sampler.random_gen_init_sample(params)
+        perms[0] = th.arange(N)
+        out[f"{name}/perms"] = perms.numpy().copy()
+        out[f"{name}/length_f32"] = sampler.calculate_distance(perms).numpy().copy()
+        d64 = params["distance"].double().numpy().copy()
+        out[f"{name}/length_f64_distance_calc"] = np.array([
+            opt2.distance_calc(d64, [[int(c) + 1 for c in p] + [int(p[0]) + 1], 0.0]) for p in perms.numpy().copy()])
+        # opt_2 with recorded draws
+        temperature = th.tensor(0.7)
+        with Recorder("rand", "randint") as rec:
+            logratio, indices, ban = sampler.opt_2(perms, temperature)
+        out[f"{name}/opt2/rand"] = rec.log["rand"][0].numpy().copy()
+        out[f"{name}/opt2/randint_nearest"] = rec.log["randint"][0].numpy().copy()
+        out[f"{name}/opt2/randint_random"] = rec.log["randint"][1].numpy().copy()
+        out[f"{name}/opt2/temperature"] = np.float32(0.7)
+        out[f"{name}/opt2/logratio"] = logratio.numpy().copy()
+        out[f"{name}/opt2/indices"] = indices.numpy().copy()
+        out[f"{name}/opt2/ban"] = u8(ban)
+        # switch on one (non-banned if possible) position per env
+        pos = []
+        for b in range(B):
+            ok = (~ban[b]).nonzero().flatten()
+            pos.append(int(ok[b % len(ok)]) if len(ok) else -1)
+        pos = th.tensor(pos)
+        envs = th.nonzero(pos >= 0).flatten()
+        sw = sampler.switch(perms, envs, pos[envs], indices)
+        out[f"{name}/switch/pos"] = pos.numpy().copy()
+        out[f"{name}/switch/out"] = sw.numpy().copy()
+        out[f"{name}/switch/length_f32"] = sampler.calculate_distance(sw).numpy().copy()
+        # true 2-opt (segment reversal) deltas via the reference's distance_calc, f64
+        rng = np.random.RandomState(17)
+        ii, jj, dd, pp = [], [], [], []
+        pn = perms.numpy().copy()
+        pairs = [(i, j) for i in range(N - 1) for j in range(i + 1, N)] if N <= 6 else None
+        for b in range(min(B, 4)):
+            cand = pairs if pairs is not None else [tuple(sorted(rng.choice(N, 2, replace=False))) for _ in range(50)]
+            tour = [int(c) + 1 for c in pn[b]] + [int(pn[b][0]) + 1]
+            base = opt2.distance_calc(d64, [tour, 0.0])
+            for i, j in cand:
+                t2 = list(tour)
+                t2[i:j + 1] = list(reversed(t2[i:j + 1]))
+                t2[-1] = t2[0]
+                ii.append(i); jj.append(j); pp.append(b)
+                dd.append(opt2.distance_calc(d64, [t2, 0.0]) - base)
+        out[f"{name}/twoopt/env"] = np.asarray(pp)
+        out[f"{name}/twoopt/i"] = np.asarray(ii)
+        out[f"{name}/twoopt/j"] = np.asarray(jj)
+        out[f"{name}/twoopt/delta_f64"] = np.asarray(dd)
+    save("tsp", **out)
+
+
+# ----------------------------------------------------------------------------- misc
+def gen_encoder():
+    from rlsolver.methods import util_evaluator as ue
+    out = {}
+    g = th.Generator().manual_seed(31)
+    for n in (5, 100, 800):
+        enc = ue.EncoderBase64(encode_len=n)
+        x = th.randint(0, 2, (n,), generator=g, dtype=th.bool)
+        s = enc.bool_to_str(x)
+        out[f"n{n}/x"] = u8(x)
+        out[f"n{n}/str"] = np.array(s)
+        assert bool((enc.str_to_bool(s) == x).all())
+    kat = {"G14": (800, 3064), "G15": (800, 3050), "G22": (2000, 13359), "G49": (3000, 6000),
+           "G50": (3000, 5880), "G55": (5000, 10298), "G70": (10000, 9583)}
+    for k, (n, val) in kat.items():
+        s = getattr(ue, "X_" + k)
+        out[f"kat/{k}/str"] = np.array(s)
+        out[f"kat/{k}/num_nodes"] = np.int64(n)
+        out[f"kat/{k}/claimed_cut"] = np.int64(val)
+        out[f"kat/{k}/x"] = u8(ue.EncoderBase64(encode_len=n).str_to_bool(s))
+    save("encoder_base64", **out)
+
+
+def gen_weighted_gain():
+    """Secondary oracle for the weighted delta: compute_gain / compute_cut_value of
+    methods_problem_specific/maxcut/util.py:125-142 on a +-1-weighted BA_100."""
+    spec = importlib.util.spec_from_file_location(
+        "ref_bls_util", os.path.join(REF, "rlsolver", "methods_problem_specific", "maxcut", "util.py"))
+    try:
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    except Exception as e:  # noqa
+        print("weighted_gain: cannot import reference util:", e)
+        return
+    import networkx as nx
+    from rlsolver.methods.util_read_data import read_mygraph
+    mygraph = read_mygraph(os.path.join(DATA, GRAPHS["BA_100_ID0"]))
+    rng = np.random.RandomState(5)
+    n = 100
+    G = nx.Graph()
+    G.add_nodes_from(range(n))
+    wl = []
+    for a, b, _ in mygraph:
+        w = int(rng.choice([-1, 1]))
+        G.add_edge(a, b, weight=w)
+        wl.append((a, b, w))
+    xs = rng.randint(0, 2, size=(8, n))
+    cuts, gains = [], []
+    for x in xs:
+        cut = {v: int(x[v]) for v in range(n)}
+        cuts.append(mod.compute_cut_value(G, cut))
+        gains.append([mod.compute_gain(G, cut, v) for v in range(n)])
+    save("weighted_gain", graph=np.asarray(wl, dtype=np.int64), xs=xs.astype(np.uint8),
+         cut=np.asarray(cuts, dtype=np.int64), gain=np.asarray(gains, dtype=np.int64))
+
+
+ALL = {"maxcut": gen_maxcut, "sweep": gen_sweep, "lsclass": gen_local_search_class, "ppo": gen_ppo,
+       "select": gen_select, "mcpg": gen_mcpg, "tsp": gen_tsp, "encoder": gen_encoder,
+       "wgain": gen_weighted_gain}
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    which = [w for w in a.only.split(",") if w] or list(ALL)
+    th.set_num_threads(4)
+    for w in which:
+        print("==", w)
+        ALL[w]()
