@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""Headline benchmark: env-steps/s of the MaxCut gym step (K4, rls_maxcut_step) on a
+Gset-G22-sized graph with 2^16 parallel envs per GPU, next-state emitted into a rollout ring
+(the PPO `obs[t+1] = next_obs` pattern), 1-byte spins in and out.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one K4 pass over the whole batch: for every env flip node a_b, compute the cut gain
+from the action node's CSR row, update obj, write reward, and emit the next state.  Algorithmic
+HBM bytes per env-step = 2N + 20.  Envs are sharded over ranks with no
+data-path collective (weak scaling: 2^16 envs per GPU); the episode-boundary best-objective
+exchange (8-byte RCCL all-reduce) runs once at the end of the timed region when N > 1.
+
+Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events on the launch stream;
+`cpu_baseline` is the C oracle (reference algorithm: flip + full objective re-evaluation, OpenMP)
+timed on the host cores on a bounded sample (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--envs-per-gpu", type=int, default=1 << 16)
+    ap.add_argument("--gset", type=int, default=22, help="Gset id whose (n, m) the graph has (22 = headline)")
+    ap.add_argument("--slots", type=int, default=8, help="rollout ring depth (slots of B*N bytes)")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(graph_arr, n, seconds):
+    """The reference's env step on the host cores: flip + full cut re-evaluation per env
+    (oracle/oracle.c: orc_step_u8, the algorithm of envs/env_PPO.py:92-121), OpenMP over envs."""
+    from oracle import oracle_c as oc
+    from oracle import oracle_np as onp
+    eu, ev = onp.stored_edges(graph_arr, False)
+    Bs = 4096
+    rng = np.random.RandomState(0)
+    xs = rng.randint(0, 2, size=(Bs, n)).astype(np.uint8)
+    last = oc.maxcut_obj(xs, eu, ev, 0)
+    acts = rng.randint(0, n, size=(64, Bs)).astype(np.int64)
+    oc.step_u8(xs, acts[0], eu, ev, 0, last)  # warm-up (thread pool, caches)
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        oc.step_u8(xs, acts[steps % 64], eu, ev, 0, last)
+        steps += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or steps >= 100000:
+            break
+    return {"value": Bs * steps / el, "unit": "env-steps/s", "cores": oc.num_threads(), "kind": "port",
+            "sample": f"{steps} steps x {Bs} envs of the same graph in {el:.1f} s; C/OpenMP restatement of "
+                      f"env_PPO.step (flip + full cut re-evaluation over E={len(eu)} edges)"}
+
+
+def main():
+    a = parse()
+    from rlsolver_amd import dist as rdist
+    from rlsolver_amd import ops
+    from rlsolver_amd.graph import build_csr, load_gset
+
+    rank, local_rank, world = rdist.init_from_env()
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
+                         f"--nproc-per-node {a.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    mygraph, n, is_real = load_gset(a.gset, os.path.join(ROOT, "data", "gset"))
+    graph_arr = np.asarray(mygraph, dtype=np.int64)
+    csr = build_csr(mygraph, num_nodes=n, if_bidirectional=False)
+    g = ops.DeviceGraph(csr, dev)
+    B, N, S = a.envs_per_gpu, n, a.slots
+    env_offset = rank * B
+
+    ring = torch.empty((S, B, N), dtype=torch.bool, device=dev)
+    ops.rand_spins(B, N, seed=0, device=dev, env_offset=env_offset, out=ring[0])
+    obj = ops.maxcut_obj(g, ring[0]).to(torch.int32)
+    reward = torch.empty(B, dtype=torch.float32, device=dev)
+    A = 64
+    actions = [ops.rand_actions(B, N, seed=1, step=s, device=dev, env_offset=env_offset) for s in range(A)]
+    slots = [ring[s] for s in range(S)]
+
+    def step(t):
+        ops.maxcut_step(g, slots[t % S], slots[(t + 1) % S], actions[t % A], obj, reward)
+
+    t = 0
+    for _ in range(a.warmup):
+        step(t)
+        t += 1
+
+    def barrier():
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(dev)
+    barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(a.steps):
+        step(t)
+        t += 1
+    e1.record()
+    if world > 1:  # episode boundary: best objective over all shards (C1, 8 bytes over RCCL)
+        best, owner, _ = rdist.global_best(obj)
+    torch.cuda.synchronize(dev)
+    barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    kernel_s = e0.elapsed_time(e1) * 1e-3 / max(a.steps, 1)
+
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if not a.no_verify:  # size-independent parity property at full size: incremental obj == recomputed
+        final = slots[t % S]
+        if not torch.equal(ops.maxcut_obj(g, final).to(torch.int32), obj):
+            raise SystemExit("PARITY FAILURE: incremental objective != recomputed objective")
+
+    if rank == 0:
+        bytes_per_launch = B * (2 * N + 20)
+        achieved = bytes_per_launch / kernel_s / 1e9
+        out = {
+            "metric": "env-steps/sec (all instances) on Gset G22 MaxCut; achieved HBM GB/s % peak",
+            "value": world * B * a.steps / elapsed,
+            "unit": "env-steps/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"Gset G{a.gset}{'' if is_real else '-sized G(n,m) stand-in'} MaxCut "
+                                   f"(N={N}, E={len(mygraph)}), {B} envs per GPU, K4 gym step emitting the next "
+                                   f"state into a {S}-slot rollout ring, uniform random actions",
+                       "num_nodes": N, "num_edges": len(mygraph), "envs_per_gpu": B, "global_envs": world * B,
+                       "parallelism": f"env-shard x{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_maxcut_step<u8, emit>", "us_per_launch": kernel_s * 1e6,
+                         "algorithmic_bytes_per_launch": bytes_per_launch},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(graph_arr, N, a.cpu_seconds)
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        dist.barrier(device_ids=[local_rank])
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

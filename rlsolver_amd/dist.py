@@ -1,0 +1,86 @@
+"""Multi-GPU sharding of the environment batch.
+
+Envs are independent: rank r owns global envs [r*B_local, (r+1)*B_local); graph tables are
+replicated; there is NO data-path collective during steps.  The only exchange is at episode
+boundaries:
+
+  C1  all_reduce(MAX) of ONE int64 key per rank, key = (best_obj << RANK_BITS) | (W-1-rank)
+      (MAXLOC emulation: the largest objective wins, ties go to the lowest rank);
+  C2  broadcast of the winner's solution (N bytes) when the caller wants it
+      (the single-device analogue is best_xs[best_vs.argmax()] / Evaluator.record2,
+      rlsolver/methods/L2A/demo_instance.py:165, rlsolver/methods/util_evaluator.py:90-107).
+
+Backend: "nccl" (= RCCL over xGMI on ROCm) on GPUs, "gloo" in the CPU tests.  Payloads are 8 B
+and <= N bytes, i.e. latency-bound.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+RANK_BITS = 20  # up to 2^20 ranks; objectives up to 2^43
+
+
+def env_shard(num_envs_global: int, rank: int, world_size: int) -> Tuple[int, int]:
+    """(offset, count) of the contiguous shard of rank `rank`; the first (B % W) ranks get one more."""
+    if not (0 <= rank < world_size):
+        raise ValueError(f"rank {rank} outside world of {world_size}")
+    base, rem = divmod(num_envs_global, world_size)
+    count = base + (1 if rank < rem else 0)
+    offset = rank * base + min(rank, rem)
+    return offset, count
+
+
+def pack_key(best_obj: torch.Tensor, rank: int, world_size: int) -> torch.Tensor:
+    if world_size > (1 << RANK_BITS):
+        raise ValueError("world too large for the packed key")
+    return (best_obj.to(torch.int64) << RANK_BITS) | (world_size - 1 - rank)
+
+
+def unpack_key(key: torch.Tensor, world_size: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    obj = key >> RANK_BITS                       # arithmetic shift: negative objectives survive
+    owner = (world_size - 1) - (key & ((1 << RANK_BITS) - 1))
+    return obj, owner
+
+
+def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    """(rank, local_rank, world_size) from torchrun's env; initialises the process group if W > 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kw = {}
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            kw["device_id"] = torch.device("cuda", local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+    return rank, local_rank, world
+
+
+def global_best(local_vs: torch.Tensor, local_xs: Optional[torch.Tensor] = None, want_solution: bool = False,
+                group=None):
+    """Episode-boundary exchange.  local_vs int [B_local], local_xs [B_local, N] (bool/uint8).
+
+    Returns (best_obj: int64 0-dim tensor, owner_rank: int64 0-dim tensor, best_x or None).
+    Single-process (no group initialised) degenerates to argmax over the local batch.
+    """
+    li = local_vs.argmax()
+    lbest = local_vs[li].to(torch.int64)
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return lbest, torch.zeros((), dtype=torch.int64, device=local_vs.device), \
+            (local_xs[li].clone() if (want_solution and local_xs is not None) else None)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    key = pack_key(lbest, rank, world).reshape(1)
+    dist.all_reduce(key, op=dist.ReduceOp.MAX, group=group)            # C1: 8 bytes
+    obj, owner = unpack_key(key[0], world)
+    best_x = None
+    if want_solution and local_xs is not None:
+        best_x = local_xs[li].clone() if rank == int(owner) else torch.empty_like(local_xs[0])
+        buf = best_x.view(torch.uint8) if best_x.dtype == torch.bool else best_x
+        dist.broadcast(buf, src=int(owner), group=group)                # C2: N bytes
+    return obj, owner, best_x

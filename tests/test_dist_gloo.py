@@ -1,0 +1,78 @@
+"""world_size-2 gloo test of the episode-boundary exchange (C1/C2) and the env sharding."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from rlsolver_amd import dist as rdist
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    r, lr, w = rdist.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    N, Bg = 33, 11
+    off, cnt = rdist.env_shard(Bg, rank, world)
+    g = torch.Generator().manual_seed(1234)
+    xs_all = torch.randint(0, 2, (Bg, N), generator=g, dtype=torch.bool)
+    vs_all = torch.tensor([5, 9, -3, 9, 2, 7, 1, 0, 9, 4, 8])
+    case = []
+    for shift in (0, 3, 7):  # move the maxima around, incl. a tie across ranks (lowest rank wins)
+        v = torch.roll(vs_all, shift)
+        obj, owner, bx = rdist.global_best(v[off:off + cnt], xs_all[off:off + cnt], want_solution=True)
+        case.append((int(obj), int(owner), bx.clone()))
+        gi = int(v.argmax())  # first maximum globally == lowest rank, first local index
+        assert int(obj) == int(v.max())
+        exp_owner = next(rk for rk in range(world) if rdist.env_shard(Bg, rk, world)[0] <= gi
+                         < sum(rdist.env_shard(Bg, rk, world)))
+        assert int(owner) == exp_owner
+        assert torch.equal(bx, xs_all[gi])
+    # negative objectives survive the packing
+    obj, owner, _ = rdist.global_best(torch.tensor([-7 - rank, -9]))
+    assert int(obj) == -7 and int(owner) == 0
+    dist.barrier()
+    dist.destroy_process_group()
+    ret[rank] = True
+
+
+def test_global_best_two_ranks():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert all(ret.get(r) for r in range(world))
+
+
+def test_env_shard_partition():
+    for B in (0, 1, 7, 64, 65537):
+        for W in (1, 2, 3, 8):
+            spans = [rdist.env_shard(B, r, W) for r in range(W)]
+            assert spans[0][0] == 0 and sum(c for _, c in spans) == B
+            for (o0, c0), (o1, _) in zip(spans, spans[1:]):
+                assert o0 + c0 == o1
+            assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+    with pytest.raises(ValueError):
+        rdist.env_shard(8, 2, 2)
+
+
+def test_pack_unpack_roundtrip():
+    for W in (1, 2, 8):
+        for r in range(W):
+            for v in (-5, 0, 13359, 2 ** 40):
+                k = rdist.pack_key(torch.tensor(v), r, W)
+                o, owner = rdist.unpack_key(k, W)
+                assert int(o) == v and int(owner) == r
+    # ordering: larger obj wins; equal obj -> lower rank wins
+    assert rdist.pack_key(torch.tensor(10), 1, 2) > rdist.pack_key(torch.tensor(9), 0, 2)
+    assert rdist.pack_key(torch.tensor(10), 0, 2) > rdist.pack_key(torch.tensor(10), 1, 2)

@@ -208,3 +208,56 @@ def test_philox_known_answer():
     assert xs.shape == (7, 300) and (xs[:, 0] == 0).all() and 0.4 < xs.mean() < 0.6
     # sharding invariance: rows depend on the global env id only
     assert np.array_equal(onp.rand_spins(3, 300, 12345, env_offset=5), xs[2:5])
+
+
+# ------------------------------------------------------------------ the C oracle (oracle/oracle.c)
+@pytest.mark.parametrize("gname", ["PL_20_ID0", "BA_100_ID0", "ER_100_ID0", "gset_14_stub"])
+@pytest.mark.parametrize("bidir", [0, 1])
+def test_c_oracle_maxcut(golden, gname, bidir):
+    from oracle import oracle_c as oc
+    z = golden("maxcut_obj")
+    graph = z[f"{gname}/graph"]
+    n = int(z[f"{gname}/bidir{bidir}/num_nodes"])
+    eu, ev = onp.stored_edges(graph, bool(bidir))
+    erp = np.concatenate([[0], np.cumsum(np.bincount(eu, minlength=n))])
+    for seed in (0, 1, 2):
+        t = f"{gname}/bidir{bidir}/seed{seed}"
+        assert np.array_equal(oc.maxcut_obj(z[f"{t}/xs"], eu, ev, bidir), z[f"{t}/obj"])
+        want = z[f"{t}/cutdeg"]
+        assert np.array_equal(oc.node_cutdeg(z[f"{t}/xs"], erp, ev), (want * 2 if bidir else want).astype(np.int64))
+    zs = golden("maxcut_local_search")
+    tag = f"{gname}/bidir{bidir}"
+    xs = zs[f"{tag}/sweep/xs_in"].copy()
+    vs = oc.maxcut_obj(xs, eu, ev, bidir)
+    oc.greedy_sweep(xs, vs, eu, ev, bidir)
+    assert np.array_equal(xs, zs[f"{tag}/sweep/xs_out"])
+    assert np.array_equal(vs, zs[f"{tag}/sweep/vs_out"])
+
+
+@pytest.mark.parametrize("gname", ["BA_100_ID0", "gset_14_stub"])
+@pytest.mark.parametrize("bidir", [0, 1])
+def test_c_oracle_ppo_step(golden, gname, bidir):
+    from oracle import oracle_c as oc
+    z = golden("env_ppo")
+    graph = z[f"{gname}/graph"]
+    tag = f"{gname}/bidir{bidir}"
+    eu, ev = onp.stored_edges(graph, bool(bidir))
+    xs = z[f"{tag}/xs0"].astype(np.float32)
+    last = z[f"{tag}/cut0"].copy()
+    xs8 = z[f"{tag}/xs0"].copy()
+    last8 = z[f"{tag}/cut0"].astype(np.int64)
+    for t in range(50):
+        r, c = oc.ppo_step(xs, z[f"{tag}/actions"][t], eu, ev, bidir, last)
+        assert np.array_equal(r, z[f"{tag}/rewards"][t]) and np.array_equal(c, z[f"{tag}/curs"][t])
+        r8 = oc.step_u8(xs8, z[f"{tag}/actions"][t], eu, ev, bidir, last8)
+        assert np.array_equal(r8.astype(np.float32), z[f"{tag}/rewards"][t])
+    assert np.array_equal((xs > 0).astype(np.uint8), z[f"{tag}/xs_final"])
+    assert np.array_equal(xs8, z[f"{tag}/xs_final"])
+
+
+def test_c_oracle_tsp(golden):
+    from oracle import oracle_c as oc
+    z = golden("tsp")
+    for name in ("a5", "berlin52"):
+        got = oc.tsp_tour_length(z[f"{name}/distance"], z[f"{name}/perms"])
+        np.testing.assert_allclose(got, z[f"{name}/length_f32"], rtol=1e-5)
