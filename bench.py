@@ -71,6 +71,23 @@ def cpu_baseline(graph_arr, n, seconds):
                       f"env_PPO.step (flip + full cut re-evaluation over E={len(eu)} edges)"}
 
 
+def pmc_traffic_per_launch():
+    """HBM bytes per k_maxcut_step launch from the committed rocprofv3 PMC summary (separate
+    FETCH_SIZE / WRITE_SIZE passes of this same command, gfx950-corrected; tools/summarize_prof.py).
+    PMC counters cannot be read from inside the process, so this is the profiled figure, not live."""
+    import glob
+    best = None
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
+        try:
+            d = json.load(open(p))
+            for k, v in d.get("kernels", {}).items():
+                if "k_maxcut_step<unsigned char" in k and "hbm_bytes_per_launch" in v and v.get("grid", 0) >= (1 << 20):
+                    best = (v["hbm_bytes_per_launch"], os.path.basename(p))
+        except Exception:
+            pass
+    return best
+
+
 def main():
     a = parse()
     from rlsolver_amd import dist as rdist
@@ -158,10 +175,13 @@ def main():
                        "num_nodes": N, "num_edges": len(mygraph), "envs_per_gpu": B, "global_envs": world * B,
                        "parallelism": f"env-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
                          "kernel": "k_maxcut_step<u8, emit>", "us_per_launch": kernel_s * 1e6,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
         }
+        tr = pmc_traffic_per_launch()
+        if tr is not None and B == (1 << 16) and N == 2000:
+            out["roofline"]["traffic"], out["roofline"]["traffic_source"] = tr[0], f"profiles/{tr[1]} (rocprofv3 --pmc)"
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(graph_arr, N, a.cpu_seconds)
         print(json.dumps(out), flush=True)

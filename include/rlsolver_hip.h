@@ -145,36 +145,43 @@ int rls_rand_actions(int64_t* action, int64_t B, int64_t N, uint64_t seed, uint6
                      int64_t env_offset, void* stream);
 
 /* -------------------------------------------------------------------- MCPG */
-
-/* K7  node-sequential stochastic local search of sampler_func  methods/MCPG.py:136-142.
- * xs f32 [N, C] node-major (chains are the fast axis), values in {-0.5, 1.5}
- * on entry to the first pass exactly as the reference (it maps 0/1 -> -0.5/1.5,
- * MCPG.py:131-133) and 0/1 afterwards.  For each of num_ls passes, for node in
- * `order` (degree-descending, int32 [N]):
- *     x[node,c] = (sum_{j in nbr(node)} x[j,c] + u * 0.25) < (deg(node) + 0.25) / 2
- * `uniforms` f32 [num_ls, N, C] are the torch.rand draws in visiting order
- * (test mode); NULL = in-kernel counter-based generator keyed by `seed`. */
-int rls_mcpg_local_search(const rls_graph* g, float* xs, int64_t C, const int32_t* order,
-                          int64_t num_ls, const float* uniforms, uint64_t seed, void* stream);
-
-/* K8  expected cut + best-of-repeats of sampler_func  methods/MCPG.py:147-166.
- * xs f32 [N, C], C = total_mcmc_num * repeat_times.  expected[c] =
- * sum_e (2x_u - 1)(2x_v - 1) over the edge_index list (f32, exact small ints);
- * best[m] = argmin over repeats r of expected[r*M + m] (first on ties). */
-int rls_mcpg_expected_cut(const rls_graph* g, const float* xs, int64_t C, float* expected,
-                          void* stream);
+/* Layout: node-major x[N, C] as in the reference (chains are the fast axis); spin_bytes = 4
+ * (float32 0.0|1.0, what metro_sampling returns) or 1 (uint8). */
 
 /* K9  metro_sampling(probs, start_status, max_transfer_time)  methods/MCPG.py:88-117.
- * One proposal round for every chain, T rounds fused: for t in 0..T-1:
+ * Runs rounds t = 0 .. min(T, *t_limit_dev) - 1 for every chain c:
  *   i = index[t,c]; p = x[i,c] ? probs[i] : 1 - probs[i];
- *   accept if u[t,c] < (1 - p) / p  -> flip x[i,c]; accepts[t] += 1.
- * samples uint8 [N, C] in place; index int64 [T,C], u f32 [T,C] supplied (test
- * mode) or NULL for the in-kernel generator.  accepts int64 [T] (per-round
- * accept counts, so the caller can apply the reference's early-stop rule
- * without a host sync per round). */
-int rls_mcpg_metro_rounds(uint8_t* samples, int64_t N, int64_t C, const float* probs,
+ *   accept iff u[t,c] < (1 - p) / p  -> flip x[i,c];  accepts[t] += #accepted chains.
+ * index int64 [T,C] and u f32 [T,C] are the reference's randint / rand draws in call order
+ * (test mode) or both NULL for the in-kernel Philox generator keyed by (seed, chain, t).
+ * The reference stops after the first round whose cumulative accept count reaches C*T_transfer
+ * (a host sync per round there).  Here: call once with write_back = 0 to get accepts[T]
+ * (int64, zeroed by the caller), derive the stop round on the device, then call again with
+ * t_limit_dev pointing at it (device int64) and write_back = 1.  t_limit_dev NULL = all T rounds.
+ * samples is updated in place only when write_back != 0. */
+int rls_mcpg_metro_rounds(void* samples, int spin_bytes, int64_t N, int64_t C, const float* probs,
                           int64_t T, const int64_t* index, const float* u, uint64_t seed,
-                          int64_t* accepts, void* stream);
+                          const int64_t* t_limit_dev, int write_back, int64_t* accepts, void* stream);
+
+/* K7 + K8 first half  sampler_func  methods/MCPG.py:128-152.
+ * xs_in [N,C] holds 0|1 (the sampler's input before the reference maps it to -0.5|1.5).
+ * For each of num_ls passes, for pos in 0..N-1, node = order[pos] (int32 [N], degree-descending):
+ *     s = sum_{j in nbr(node)} value(j)      value = -0.5|1.5 for nodes not yet visited in
+ *                                            pass 0, else 0|1 (MCPG.py:131-133,142)
+ *     x[node,c] = (s + u * 0.25f) < (deg(node) + 0.25f) / 2
+ * with u = uniforms[pass, pos, c] (f32 [num_ls,N,C], the torch.rand draws in visiting order; NULL =
+ * in-kernel Philox).  Then expected[c] = sum_e (2x_u - 1)(2x_v - 1) over the stored edge list
+ * (= E - 2*cut, exact in f32).  Outputs xs_out f32 [N,C] (0|1) and expected f32 [C]. */
+int rls_mcpg_local_search(const rls_graph* g, const void* xs_in, int spin_bytes, float* xs_out, int64_t C,
+                          const int32_t* order, int64_t num_ls, const float* uniforms, uint64_t seed,
+                          float* expected, void* stream);
+
+/* K8 second half  methods/MCPG.py:154-161: best_index[m] = m + M * argmin_r expected[r*M + m]
+ * (first minimum), vs_good[m] = (num_edges - expected[best]) / 2, xs_good[:, m] = xs[:, best].
+ * M = total_mcmc_num, R = repeat_times, xs f32 [N, M*R], xs_good f32 [N, M]. */
+int rls_mcpg_pick_best(const float* expected, const float* xs, int64_t N, int64_t total_mcmc_num,
+                       int64_t repeat_times, int64_t num_edges, int64_t* best_index, float* vs_good,
+                       float* xs_good, void* stream);
 
 /* --------------------------------------------------------------------- TSP */
 

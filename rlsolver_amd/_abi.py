@@ -61,6 +61,14 @@ SIGNATURES = {
     "rls_pick_best_of_repeats": [_P, _P, _I64, _I64, _I64, _INT, _P, _P, _P],
     "rls_rand_spins": [_P, _I64, _I64, _U64, _I64, _P],
     "rls_rand_actions": [_P, _I64, _I64, _U64, _U64, _I64, _P],
+    "rls_mcpg_metro_rounds": [_P, _INT, _I64, _I64, _P, _I64, _P, _P, _U64, _P, _INT, _P, _P],
+    "rls_mcpg_local_search": [_G, _P, _INT, _P, _I64, _P, _I64, _P, _U64, _P, _P],
+    "rls_mcpg_pick_best": [_P, _P, _I64, _I64, _I64, _I64, _P, _P, _P, _P],
+    "rls_tsp_tour_length": [_P, _I64, _P, _I64, _P, _P],
+    "rls_tsp_swap_delta_all": [_P, _I64, _P, _I64, _P, _F32, _P, _P, _P, _P],
+    "rls_tsp_apply_swap": [_P, _I64, _I64, _P, _P, _P],
+    "rls_tsp_2opt_delta": [_P, _I64, _P, _I64, _P, _P, _P, _P],
+    "rls_rand_perms": [_P, _I64, _I64, _U64, _I64, _P],
 }
 PLAIN = {"rls_version": ([], _INT), "rls_device_count": ([], _INT), "rls_last_error_string": ([], C.c_char_p)}
 

@@ -51,3 +51,28 @@ __host__ __device__ inline float u32_to_unit_float(uint32_t r) { return (float)(
 
 #define RLS_REQUIRE(cond, code, ...) \
     do { if (!(cond)) return ::rls::fail((code), __VA_ARGS__); } while (0)
+
+namespace rls {
+
+inline bool rows_vec_aligned(const void* p, int64_t N, int elt) {
+    return (((uintptr_t)p) & 15) == 0 && ((N * elt) & 15) == 0;
+}
+
+inline int grid_for(int64_t total, int block) {
+    int64_t g = ceil_div(total, block);
+    const int64_t cap = 256 * 8 * 4;
+    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+inline int check_graph(const rls_graph* g) {
+    RLS_REQUIRE(g != nullptr, RLS_EINVAL, "graph is NULL");
+    RLS_REQUIRE(g->num_nodes > 0 && g->num_nodes < (1ll << 31), RLS_EINVAL, "bad num_nodes %lld",
+                (long long)g->num_nodes);
+    RLS_REQUIRE(g->num_stored_edges >= 0 && g->nnz >= 0, RLS_EINVAL, "negative edge count");
+    RLS_REQUIRE(g->num_stored_edges == 0 || (g->eu && g->ev), RLS_EINVAL, "edge list pointers are NULL");
+    RLS_REQUIRE(g->rowptr != nullptr && g->erowptr != nullptr, RLS_EINVAL, "rowptr/erowptr is NULL");
+    RLS_REQUIRE(g->nnz == 0 || g->col, RLS_EINVAL, "col is NULL");
+    return RLS_OK;
+}
+
+}  // namespace rls

@@ -1,77 +1,8 @@
 // MaxCut environment kernels for gfx950 (MI355X).  See include/rlsolver_hip.h for the
 // reference call site each entry point replaces, DESIGN.md for layouts and rooflines.
-#include "rls_tile.h"
+#include "rls_cutcount.h"
 
 namespace rls {
-
-// =====================================================================================
-// K1 core: cut value of 64 envs held as a bit tile.
-// Each lane takes every 64th stored edge, XORs the two 64-env words (one XOR = one edge
-// in 64 envs) and feeds the result into a bit-sliced Harley-Seal counter (8 edges per
-// block: 7 carry-save adders + one ripple into the upper planes).  The 64 per-lane
-// bit-sliced counts are then summed with a butterfly of bit-sliced full adders, after
-// which every lane holds the total planes and extracts its own env's count.
-// P = number of planes (E' < 2^P).
-// =====================================================================================
-template <int P>
-__device__ __forceinline__ int64_t tile_cut_count(const uint64_t* __restrict__ words,
-                                                  const int32_t* __restrict__ eu,
-                                                  const int32_t* __restrict__ ev,
-                                                  int64_t E, int lane) {
-    uint64_t c[P];
-#pragma unroll
-    for (int p = 0; p < P; ++p) c[p] = 0;
-    uint64_t ones = 0, twos = 0, fours = 0;
-    constexpr int PL = (P - 5) < 4 ? 4 : (P - 5);  // per-lane count <= ceil(E/64) < 2^(P-5)
-
-    for (int64_t base = 0; base < E; base += 8 * kWave) {
-        uint64_t d[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int64_t e = base + k * kWave + lane;
-            if (e < E) {
-                const int u = eu[e], v = ev[e];
-                d[k] = words[u] ^ words[v];
-            } else {
-                d[k] = 0;
-            }
-        }
-        uint64_t twosA, twosB, foursA, foursB, eights;
-        csa(twosA, ones, ones, d[0], d[1]);
-        csa(twosB, ones, ones, d[2], d[3]);
-        csa(foursA, twos, twos, twosA, twosB);
-        csa(twosA, ones, ones, d[4], d[5]);
-        csa(twosB, ones, ones, d[6], d[7]);
-        csa(foursB, twos, twos, twosA, twosB);
-        csa(eights, fours, fours, foursA, foursB);
-        uint64_t carry = eights;
-#pragma unroll
-        for (int p = 3; p < PL; ++p) {
-            const uint64_t t = c[p] & carry;
-            c[p] ^= carry;
-            carry = t;
-        }
-    }
-    c[0] = ones; c[1] = twos; c[2] = fours;
-
-    // butterfly: after the step with mask m every lane holds the sum over its 2m-group
-#pragma unroll
-    for (int m = 1; m < kWave; m <<= 1) {
-        uint64_t carry = 0;
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-            const uint64_t o = shfl_xor64(c[p], m);
-            const uint64_t u = c[p] ^ o;
-            const uint64_t s = u ^ carry;
-            carry = (c[p] & o) | (u & carry);
-            c[p] = s;
-        }
-    }
-    int64_t total = 0;
-#pragma unroll
-    for (int p = 0; p < P; ++p) total |= (int64_t)((c[p] >> lane) & 1ull) << p;
-    return total;
-}
 
 template <typename T, bool VEC, int P>
 __global__ __launch_bounds__(kWave) void k_maxcut_obj(const T* __restrict__ x, int64_t B, int64_t N,
@@ -181,118 +112,6 @@ __global__ __launch_bounds__(kWave) void k_maxcut_greedy_sweep(uint8_t* __restri
     }
     tile_store_bytes<VEC>(x, B, N, b0, words, lane);
     if (b0 + lane < B) obj[b0 + lane] += gain;
-}
-
-// =====================================================================================
-// K4: gym step.  One wave owns EPW consecutive envs.
-// Phase A (per env): the wave's lanes split the action node's CSR row, gather the
-//   neighbours' spins from the env's row and reduce: unweighted graphs need only a
-//   ballot + popcount (cutdeg c, gain = deg - 2c); weighted graphs a shuffle reduction.
-// Phase B (emit variant): the EPW rows are contiguous, so the wave streams them as one
-//   flat run of 16-byte vectors, patching the flipped spin in flight.
-// =====================================================================================
-template <typename T> __device__ __forceinline__ T spin_flip(T v);
-template <> __device__ __forceinline__ uint8_t spin_flip<uint8_t>(uint8_t v) { return v == 0 ? 1 : 0; }
-template <> __device__ __forceinline__ float spin_flip<float>(float v) { return v == 0.0f ? 1.0f : 0.0f; }  // logical_not
-
-template <typename T, int EPW, bool EMIT, bool VEC, bool WEIGHTED>
-__global__ __launch_bounds__(256) void k_maxcut_step(const T* __restrict__ xin, T* __restrict__ xout,
-                                                     int64_t B, int64_t N,
-                                                     const int32_t* __restrict__ rowptr,
-                                                     const int32_t* __restrict__ col,
-                                                     const int32_t* __restrict__ wgt,
-                                                     const int64_t* __restrict__ action,
-                                                     int32_t* __restrict__ obj, float* __restrict__ reward,
-                                                     float* __restrict__ cur, float* __restrict__ done,
-                                                     float done_value) {
-    const int lane = threadIdx.x & (kWave - 1);
-    const int64_t wave = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave));
-    const int64_t b0 = wave * EPW;
-    if (b0 >= B) return;
-    const int nenv = (int)((B - b0) < EPW ? (B - b0) : EPW);
-
-    int64_t act[EPW];
-    int my_delta = 0;  // lane k keeps env k's gain
-#pragma unroll
-    for (int k = 0; k < EPW; ++k) {
-        act[k] = -1;
-        if (k < nenv) {
-            const int64_t b = b0 + k;
-            const int64_t a = action[b];
-            act[k] = a;
-            const T* row = xin + b * N;
-            const int r0 = rowptr[a], r1 = rowptr[a + 1];
-            const bool xa = spin_is_set(row[a]);
-            int acc = 0;
-            for (int j = r0 + lane; j < r1; j += kWave) {
-                const bool xn = spin_is_set(row[col[j]]);
-                if constexpr (WEIGHTED) acc += (xn == xa) ? wgt[j] : -wgt[j];
-                else acc += (xn != xa) ? 1 : 0;
-            }
-            int delta;
-            if constexpr (WEIGHTED) {
-                delta = wave_sum_i32(acc);
-            } else {
-                int c;
-                if (r1 - r0 <= kWave) c = __popcll(ballot64(acc != 0));
-                else c = wave_sum_i32(acc);
-                delta = (r1 - r0) - 2 * c;
-            }
-            if (lane == k) my_delta = delta;
-        }
-    }
-    if (lane < nenv) {
-        const int64_t b = b0 + lane;
-        const int v = obj[b] + my_delta;
-        obj[b] = v;
-        reward[b] = (float)my_delta;
-        if (cur) cur[b] = (float)v;
-        if (done) done[b] = done_value;
-    }
-
-    if constexpr (!EMIT) {
-        // in place: only the flipped spins are written
-        if (lane < nenv) {
-            int64_t a = 0;
-#pragma unroll
-            for (int k = 0; k < EPW; ++k) if (lane == k) a = act[k];
-            T* p = xout + (b0 + lane) * N + a;
-            *p = spin_flip<T>(*p);
-        }
-    } else if constexpr (VEC) {
-        using V = typename SpinVec<T>::type;
-        constexpr int PER = SpinVec<T>::n;
-        const V* src = reinterpret_cast<const V*>(xin + b0 * N);
-        V* dst = reinterpret_cast<V*>(xout + b0 * N);
-        const int64_t nvec = (int64_t)nenv * N / PER;
-        int64_t fvec[EPW];
-        int fidx[EPW];
-#pragma unroll
-        for (int k = 0; k < EPW; ++k) {
-            const int64_t rel = (act[k] < 0) ? -1 : (int64_t)k * N + act[k];
-            fvec[k] = rel < 0 ? -1 : rel / PER;
-            fidx[k] = (int)(rel < 0 ? 0 : rel % PER);
-        }
-#pragma unroll 4
-        for (int64_t i = lane; i < nvec; i += kWave) {
-            V v = __builtin_nontemporal_load(src + i);
-#pragma unroll
-            for (int k = 0; k < EPW; ++k)
-                if (i == fvec[k]) v = SpinVec<T>::flip_at(v, fidx[k]);
-            __builtin_nontemporal_store(v, dst + i);
-        }
-    } else {
-        const T* src = xin + b0 * N;
-        T* dst = xout + b0 * N;
-        const int64_t nel = (int64_t)nenv * N;
-        for (int64_t i = lane; i < nel; i += kWave) {
-            T v = src[i];
-#pragma unroll
-            for (int k = 0; k < EPW; ++k)
-                if (act[k] >= 0 && i == (int64_t)k * N + act[k]) v = spin_flip<T>(v);
-            dst[i] = v;
-        }
-    }
 }
 
 // =====================================================================================
@@ -417,34 +236,6 @@ __global__ void k_rand_actions(int64_t* __restrict__ action, int64_t B, int64_t 
     }
 }
 
-static inline int pick_planes(int64_t E) {
-    if (E < (1 << 12)) return 12;
-    if (E < (1 << 16)) return 16;
-    if (E < (1 << 20)) return 20;
-    if (E < (1 << 24)) return 24;
-    return 0;
-}
-
-static inline bool rows_vec_aligned(const void* p, int64_t N, int elt) {
-    return (((uintptr_t)p) & 15) == 0 && ((N * elt) & 15) == 0;
-}
-
-static inline int grid_for(int64_t total, int block) {
-    int64_t g = ceil_div(total, block);
-    const int64_t cap = 256 * 8 * 4;
-    return (int)(g < 1 ? 1 : (g > cap ? cap : g));
-}
-
-static int check_graph(const rls_graph* g) {
-    RLS_REQUIRE(g != nullptr, RLS_EINVAL, "graph is NULL");
-    RLS_REQUIRE(g->num_nodes > 0 && g->num_nodes < (1ll << 31), RLS_EINVAL, "bad num_nodes %lld",
-                (long long)g->num_nodes);
-    RLS_REQUIRE(g->num_stored_edges >= 0 && g->nnz >= 0, RLS_EINVAL, "negative edge count");
-    RLS_REQUIRE(g->num_stored_edges == 0 || (g->eu && g->ev), RLS_EINVAL, "edge list pointers are NULL");
-    RLS_REQUIRE(g->rowptr != nullptr && g->erowptr != nullptr, RLS_EINVAL, "rowptr/erowptr is NULL");
-    RLS_REQUIRE(g->nnz == 0 || g->col, RLS_EINVAL, "col is NULL");
-    return RLS_OK;
-}
 
 }  // namespace rls
 
@@ -551,36 +342,6 @@ int rls_maxcut_greedy_sweep(const rls_graph* g, uint8_t* x, int64_t B, int64_t* 
     else        { if (vec) LAUNCH_SW(true, false); else LAUNCH_SW(false, false); }
 #undef LAUNCH_SW
     return check_launch("k_maxcut_greedy_sweep");
-}
-
-int rls_maxcut_step(const rls_graph* g, const void* x_in, void* x_out, int spin_bytes, int64_t B,
-                    const int64_t* action, int32_t* obj, float* reward, float* cur, float* done,
-                    float done_value, void* stream) {
-    if (int rc = check_graph(g)) return rc;
-    RLS_REQUIRE(B >= 0, RLS_EINVAL, "B < 0");
-    if (B == 0) return RLS_OK;
-    RLS_REQUIRE(x_in && x_out && action && obj && reward, RLS_EINVAL, "x_in/x_out/action/obj/reward is NULL");
-    RLS_REQUIRE(spin_bytes == 1 || spin_bytes == 4, RLS_EINVAL, "spin_bytes must be 1 or 4");
-    const int64_t N = g->num_nodes;
-    const bool emit = (x_in != x_out);
-    constexpr int EPW = 4;
-    // flat tiles of EPW rows start 16-byte aligned when one row is a multiple of 16 bytes
-    const bool vec = rows_vec_aligned(x_in, N, spin_bytes) && rows_vec_aligned(x_out, N, spin_bytes);
-    const int waves_per_block = 4;
-    const dim3 grid((unsigned)ceil_div(ceil_div(B, EPW), waves_per_block)), block(waves_per_block * kWave);
-    hipStream_t s = as_stream(stream);
-    const bool weighted = g->wgt != nullptr;
-#define LAUNCH_STEP(T, EMIT, VEC, W)                                                                       \
-    hipLaunchKernelGGL((k_maxcut_step<T, EPW, EMIT, VEC, W>), grid, block, 0, s, (const T*)x_in, (T*)x_out, \
-                       B, N, g->rowptr, g->col, g->wgt, action, obj, reward, cur, done, done_value)
-#define DISPATCH_W(T, EMIT, VEC) do { if (weighted) LAUNCH_STEP(T, EMIT, VEC, true); else LAUNCH_STEP(T, EMIT, VEC, false); } while (0)
-#define DISPATCH_V(T, EMIT) do { if (vec) DISPATCH_W(T, EMIT, true); else DISPATCH_W(T, EMIT, false); } while (0)
-    if (spin_bytes == 1) { if (emit) DISPATCH_V(uint8_t, true); else DISPATCH_W(uint8_t, false, false); }
-    else                 { if (emit) DISPATCH_V(float, true);   else DISPATCH_W(float, false, false); }
-#undef DISPATCH_V
-#undef DISPATCH_W
-#undef LAUNCH_STEP
-    return check_launch("k_maxcut_step");
 }
 
 int rls_maxcut_edge_cut_mask(const rls_graph* g, const uint8_t* x, int64_t B, uint8_t* cutmask, void* stream) {

@@ -1,0 +1,270 @@
+// MCPG sampling kernels (K7, K8, K9) for gfx950.
+//
+// Layout at the boundary is the reference's: node-major x[N, C] (chains are the fast axis), f32
+// holding 0/1 (or uint8 0/1).  A wavefront owns 64 consecutive chains and keeps them as a bit tile
+// in LDS (words[n] bit c = x[n, c0+c]); node-major rows make the tile load perfectly coalesced
+// (64 lanes read 64 consecutive chains of one node) and one ballot per node builds the word.
+//
+//   K9 metro rounds    : lane = chain; per round one random node, MH accept, flip = atomic XOR of
+//                        the lane's bit in LDS.  Per-round accept counts let the host-side wrapper
+//                        apply the reference's global early-stop rule without a host sync.
+//   K7 local search    : sequential over nodes in the given order (as the reference's semantics
+//                        require), wave-uniform CSR row, broadcast LDS reads, lane = chain.
+//   K8 expected cut    : the K1 bit-sliced edge counter on the same tile; expected = E - 2*cut.
+//
+// f32 arithmetic of the reference is reproduced exactly: neighbour sums are multiples of 0.5
+// (exact in any order), `s + u * 0.25f` and the division `(1 - p) / p` are single IEEE f32 ops
+// (the library is built with -ffp-contract=off).
+#include "rls_cutcount.h"
+
+namespace rls {
+
+template <typename T>
+__device__ __forceinline__ void tile_load_bits_nodemajor(const T* __restrict__ x, int64_t N, int64_t C, int64_t c0,
+                                                         uint64_t* __restrict__ words, int lane) {
+    const int64_t c = c0 + lane;
+    const bool valid = c < C;
+    for (int64_t n0 = 0; n0 < N; n0 += kWave) {
+        const int lim = (int)((N - n0) < kWave ? (N - n0) : kWave);
+        uint64_t mine = 0;
+#pragma unroll 8
+        for (int k = 0; k < lim; ++k) {
+            const T v = valid ? x[(n0 + k) * C + c] : T(0);
+            const uint64_t w = ballot64(spin_is_set(v));
+            if (lane == k) mine = w;
+        }
+        if (lane < lim) words[n0 + lane] = mine;
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void tile_store_nodemajor(T* __restrict__ x, int64_t N, int64_t C, int64_t c0,
+                                                     const uint64_t* __restrict__ words, int lane) {
+    const int64_t c = c0 + lane;
+    if (c >= C) return;
+    const uint32_t* w32 = reinterpret_cast<const uint32_t*>(words);
+    const int half = lane >> 5, sh = lane & 31;
+    for (int64_t n = 0; n < N; ++n) x[n * C + c] = (T)((w32[(n << 1) + half] >> sh) & 1u);
+}
+
+// ------------------------------------------------------------------------------------- K9
+template <typename T>
+__global__ __launch_bounds__(kWave) void k_mcpg_metro(T* __restrict__ samples, int64_t N, int64_t C,
+                                                      const float* __restrict__ probs, int64_t T_rounds,
+                                                      const int64_t* __restrict__ index,
+                                                      const float* __restrict__ u, uint64_t seed,
+                                                      const int64_t* __restrict__ t_limit_dev, int write_back,
+                                                      unsigned long long* __restrict__ accepts) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* words = reinterpret_cast<uint64_t*>(smem);
+    const int lane = threadIdx.x;
+    const int64_t c0 = (int64_t)blockIdx.x * kWave;
+    const int64_t c = c0 + lane;
+    const bool valid = c < C;
+    tile_load_bits_nodemajor<T>(samples, N, C, c0, words, lane);
+    __syncthreads();
+    int64_t t_end = T_rounds;
+    if (t_limit_dev) {
+        const int64_t lim = *t_limit_dev;
+        t_end = lim < T_rounds ? lim : T_rounds;
+    }
+    const Philox ph(seed);
+    const uint64_t mybit = 1ull << lane;
+    for (int64_t t = 0; t < t_end; ++t) {
+        int64_t i = 0;
+        float uu = 2.0f;
+        if (valid) {
+            if (index) {
+                i = index[t * C + c];
+                uu = u[t * C + c];
+            } else {
+                uint32_t r[4];
+                ph((uint32_t)c, (uint32_t)((uint64_t)c >> 32), (uint32_t)t, 0x4D455452u, r);
+                i = (int64_t)(((uint64_t)r[0] * (uint64_t)N) >> 32);
+                uu = u32_to_unit_float(r[1]);
+            }
+        }
+        const bool val = (words[i] >> lane) & 1ull;
+        const float base = probs[i];
+        const float chosen = val ? base : 1.0f - base;            // torch.where(chosen_value, p, 1 - p)
+        const float accept_rate = (1.0f - chosen) / chosen;       // MCPG.py:107
+        const bool acc = valid && (uu < accept_rate);
+        if (acc) atomicXor(reinterpret_cast<unsigned long long*>(&words[i]), (unsigned long long)mybit);
+        if (accepts) {
+            const int cnt = __popcll(ballot64(acc));
+            if (lane == 0 && cnt) atomicAdd(&accepts[t], (unsigned long long)cnt);
+        }
+        __syncthreads();
+    }
+    if (write_back) tile_store_nodemajor<T>(samples, N, C, c0, words, lane);
+}
+
+// ------------------------------------------------------------------------------------- K7 + K8
+template <typename TI, int P>
+__global__ __launch_bounds__(kWave) void k_mcpg_local_search(const TI* __restrict__ xs_in, float* __restrict__ xs_out,
+                                                             int64_t N, int64_t C,
+                                                             const int32_t* __restrict__ rowptr,
+                                                             const int32_t* __restrict__ col,
+                                                             const int32_t* __restrict__ order, int64_t num_ls,
+                                                             const float* __restrict__ uniforms, uint64_t seed,
+                                                             const int32_t* __restrict__ eu,
+                                                             const int32_t* __restrict__ ev, int64_t E,
+                                                             float* __restrict__ expected) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* words = reinterpret_cast<uint64_t*>(smem);
+    uint32_t* updated = reinterpret_cast<uint32_t*>(words + N);  // 1 bit per node: visited in pass 0
+    const uint32_t* w32 = reinterpret_cast<const uint32_t*>(smem);
+    const int lane = threadIdx.x;
+    const int64_t c0 = (int64_t)blockIdx.x * kWave;
+    const int64_t c = c0 + lane;
+    const bool valid = c < C;
+    tile_load_bits_nodemajor<TI>(xs_in, N, C, c0, words, lane);
+    for (int64_t n = lane; n < (N + 31) / 32; n += kWave) updated[n] = 0;
+    __syncthreads();
+    const int half = lane >> 5, sh = lane & 31;
+    const Philox ph(seed);
+    for (int64_t cnt = 0; cnt < num_ls; ++cnt) {
+        for (int64_t pos = 0; pos < N; ++pos) {
+            const int node = order[pos];
+            const int r0 = rowptr[node], r1 = rowptr[node + 1];
+            // neighbour sum in units of 0.5: updated nbr contributes 2*b, fresh nbr (pass 0) 4*b - 1
+            int s2 = 0;
+            for (int base = r0; base < r1; base += kWave) {
+                const int n_here = (r1 - base) < kWave ? (r1 - base) : kWave;
+                const int my_nb = (lane < n_here) ? col[base + lane] : 0;
+                for (int j = 0; j < n_here; ++j) {
+                    const int nb = __builtin_amdgcn_readlane(my_nb, j);
+                    const int b = (int)((w32[((int64_t)nb << 1) + half] >> sh) & 1u);
+                    const bool upd = (cnt > 0) || ((updated[nb >> 5] >> (nb & 31)) & 1u);
+                    s2 += upd ? 2 * b : 4 * b - 1;
+                }
+            }
+            float uu;
+            if (uniforms) {
+                uu = valid ? uniforms[(cnt * N + pos) * C + c] : 0.0f;
+            } else {
+                uint32_t r[4];
+                ph((uint32_t)c, (uint32_t)((uint64_t)c >> 32), (uint32_t)(cnt * N + pos), 0x4C4F4353u, r);
+                uu = u32_to_unit_float(r[0]);
+            }
+            const float rv = (float)s2 * 0.5f + uu * 0.25f;                   // MCPG.py:139-141
+            const float thr = ((float)(r1 - r0) + 0.25f) / 2.0f;             // (weighted_degree + k) / 2
+            const uint64_t nw = ballot64(rv < thr);
+            if (lane == 0) {
+                words[node] = nw;
+                if (cnt == 0) updated[node >> 5] |= 1u << (node & 31);
+            }
+            __syncthreads();
+        }
+    }
+    // K8: expected[c] = sum_e (2x_u - 1)(2x_v - 1) = E - 2 * cut
+    const int64_t cut = tile_cut_count<P>(words, eu, ev, E, lane);
+    if (valid) {
+        expected[c] = (float)(E - 2 * cut);
+        for (int64_t n = 0; n < N; ++n) xs_out[n * C + c] = (float)((w32[(n << 1) + half] >> sh) & 1u);
+    }
+}
+
+// best-of-repeats: index = argmin_r expected[r*M + m] (first on ties); column gather
+__global__ void k_mcpg_pick_best(const float* __restrict__ expected, const float* __restrict__ xs, int64_t N,
+                                 int64_t M, int64_t R, float num_edges, int64_t* __restrict__ best_index,
+                                 float* __restrict__ vs_good, float* __restrict__ xs_good) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    float best = expected[m];
+    int64_t br = 0;
+    for (int64_t r = 1; r < R; ++r) {
+        const float v = expected[r * M + m];
+        if (v < best) { best = v; br = r; }
+    }
+    const int64_t idx = m + br * M;
+    best_index[m] = idx;
+    vs_good[m] = (num_edges - best) / 2.0f;                                   // MCPG.py:160
+    const int64_t Ctot = M * R;
+    for (int64_t n = 0; n < N; ++n) xs_good[n * M + m] = xs[n * Ctot + idx];  // lanes = consecutive m: coalesced writes
+}
+
+}  // namespace rls
+
+using namespace rls;
+
+extern "C" {
+
+int rls_mcpg_metro_rounds(void* samples, int spin_bytes, int64_t N, int64_t C, const float* probs, int64_t T,
+                          const int64_t* index, const float* u, uint64_t seed, const int64_t* t_limit_dev,
+                          int write_back, int64_t* accepts, void* stream) {
+    RLS_REQUIRE(N > 0 && C >= 0 && T >= 0, RLS_EINVAL, "bad sizes N=%lld C=%lld T=%lld", (long long)N, (long long)C,
+                (long long)T);
+    if (C == 0) return RLS_OK;
+    RLS_REQUIRE(samples && probs, RLS_EINVAL, "samples/probs is NULL");
+    RLS_REQUIRE((index == nullptr) == (u == nullptr), RLS_EINVAL, "index and u must both be given or both be NULL");
+    RLS_REQUIRE(spin_bytes == 1 || spin_bytes == 4, RLS_EINVAL, "spin_bytes must be 1 or 4");
+    const size_t lds = (size_t)N * 8;
+    RLS_REQUIRE(lds <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS (max %d)", (long long)N, lds,
+                kLdsBytes);
+    const dim3 grid((unsigned)ceil_div(C, kWave)), block(kWave);
+    hipStream_t s = as_stream(stream);
+    if (spin_bytes == 1) {
+        auto kern = k_mcpg_metro<uint8_t>;
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, grid, block, lds, s, (uint8_t*)samples, N, C, probs, T, index, u, seed, t_limit_dev,
+                           write_back, (unsigned long long*)accepts);
+    } else {
+        auto kern = k_mcpg_metro<float>;
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, grid, block, lds, s, (float*)samples, N, C, probs, T, index, u, seed, t_limit_dev,
+                           write_back, (unsigned long long*)accepts);
+    }
+    return check_launch("k_mcpg_metro");
+}
+
+int rls_mcpg_local_search(const rls_graph* g, const void* xs_in, int spin_bytes, float* xs_out, int64_t C,
+                          const int32_t* order, int64_t num_ls, const float* uniforms, uint64_t seed,
+                          float* expected, void* stream) {
+    if (int rc = check_graph(g)) return rc;
+    RLS_REQUIRE(C >= 0 && num_ls >= 0, RLS_EINVAL, "bad sizes");
+    if (C == 0) return RLS_OK;
+    RLS_REQUIRE(xs_in && xs_out && order && expected, RLS_EINVAL, "NULL pointer");
+    RLS_REQUIRE(spin_bytes == 1 || spin_bytes == 4, RLS_EINVAL, "spin_bytes must be 1 or 4");
+    const int64_t N = g->num_nodes, E = g->num_stored_edges;
+    const size_t lds = (size_t)N * 8 + (size_t)((N + 31) / 32) * 4 + 16;
+    RLS_REQUIRE(lds <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS (max %d)", (long long)N, lds,
+                kLdsBytes);
+    const int P = pick_planes(E);
+    RLS_REQUIRE(P != 0, RLS_EUNSUPPORTED, "E=%lld too large", (long long)E);
+    const dim3 grid((unsigned)ceil_div(C, kWave)), block(kWave);
+    hipStream_t s = as_stream(stream);
+#define LAUNCH_LS(TI, PP)                                                                                       \
+    do {                                                                                                        \
+        auto kern = k_mcpg_local_search<TI, PP>;                                                                \
+        if (lds > 64 * 1024)                                                                                    \
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(kern, grid, block, lds, s, (const TI*)xs_in, xs_out, N, C, g->rowptr, g->col, order, \
+                           num_ls, uniforms, seed, g->eu, g->ev, E, expected);                                  \
+    } while (0)
+#define DISPATCH_P(TI)                       \
+    switch (P) {                             \
+        case 12: LAUNCH_LS(TI, 12); break;   \
+        case 16: LAUNCH_LS(TI, 16); break;   \
+        case 20: LAUNCH_LS(TI, 20); break;   \
+        default: LAUNCH_LS(TI, 24); break;   \
+    }
+    if (spin_bytes == 1) { DISPATCH_P(uint8_t) } else { DISPATCH_P(float) }
+#undef DISPATCH_P
+#undef LAUNCH_LS
+    return check_launch("k_mcpg_local_search");
+}
+
+int rls_mcpg_pick_best(const float* expected, const float* xs, int64_t N, int64_t total_mcmc_num,
+                       int64_t repeat_times, int64_t num_edges, int64_t* best_index, float* vs_good,
+                       float* xs_good, void* stream) {
+    RLS_REQUIRE(N > 0 && total_mcmc_num >= 0 && repeat_times > 0, RLS_EINVAL, "bad sizes");
+    if (total_mcmc_num == 0) return RLS_OK;
+    RLS_REQUIRE(expected && xs && best_index && vs_good && xs_good, RLS_EINVAL, "NULL pointer");
+    hipLaunchKernelGGL(k_mcpg_pick_best, dim3((unsigned)ceil_div(total_mcmc_num, 64)), dim3(64), 0,
+                       as_stream(stream), expected, xs, N, total_mcmc_num, repeat_times, (float)num_edges,
+                       best_index, vs_good, xs_good);
+    return check_launch("k_mcpg_pick_best");
+}
+
+}  // extern "C"

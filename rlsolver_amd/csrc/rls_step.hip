@@ -1,0 +1,298 @@
+// K4: the gym step -- the headline kernel (HBM-bound: read state, write next state).
+//
+// One wave owns EPW consecutive envs, i.e. one contiguous run of EPW*N spins.
+//   gain : the wave's lanes split the action node's CSR row, fetch the neighbours' spins of
+//          that env and reduce.  Unweighted graphs need one ballot + popcount (cutdeg c,
+//          gain = deg - 2c); weighted graphs a wave shuffle reduction.
+//   emit : the run is streamed with 16-byte vectors, the flipped spin patched in flight.
+//
+// Three emit structures are kept (A/B-able in one process through RLS_STEP_MODE):
+//   MODE 0  gain first (gathers from global), then copy           -- first version
+//   MODE 1  issue the copy's loads first, compute the gain while they fly, patch, store
+//   MODE 2  stage the run in LDS with direct global->LDS loads (no VGPR round trip), gather
+//           the neighbours from LDS, patch the byte in LDS, stream LDS -> HBM
+#include "rls_tile.h"
+#include <cstdlib>
+
+namespace rls {
+
+template <typename T> __device__ __forceinline__ T spin_flip(T v);
+template <> __device__ __forceinline__ uint8_t spin_flip<uint8_t>(uint8_t v) { return v == 0 ? 1 : 0; }
+template <> __device__ __forceinline__ float spin_flip<float>(float v) { return v == 0.0f ? 1.0f : 0.0f; }  // logical_not
+
+// cut gain of flipping node a, neighbours' spins read through `row` (global or LDS)
+template <typename T, bool WEIGHTED>
+__device__ __forceinline__ int flip_gain(const T* row, int64_t a, const int32_t* __restrict__ rowptr,
+                                         const int32_t* __restrict__ col, const int32_t* __restrict__ wgt,
+                                         int lane) {
+    const int r0 = rowptr[a], r1 = rowptr[a + 1];
+    const bool xa = spin_is_set(row[a]);
+    int acc = 0;
+    for (int j = r0 + lane; j < r1; j += kWave) {
+        const bool xn = spin_is_set(row[col[j]]);
+        if constexpr (WEIGHTED) acc += (xn == xa) ? wgt[j] : -wgt[j];
+        else acc += (xn != xa) ? 1 : 0;
+    }
+    if constexpr (WEIGHTED) {
+        return wave_sum_i32(acc);
+    } else {
+        int c;
+        if (r1 - r0 <= kWave) c = __popcll(ballot64(acc != 0));
+        else c = wave_sum_i32(acc);
+        return (r1 - r0) - 2 * c;
+    }
+}
+
+template <bool NT, typename V> __device__ __forceinline__ V ld_vec(const V* p) {
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+template <bool NT, typename V> __device__ __forceinline__ void st_vec(V* p, V v) {
+    if constexpr (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <typename T, int EPW, int MODE, bool EMIT, bool VEC, bool WEIGHTED, bool NTL, bool NTS>
+__global__ __launch_bounds__(256) void k_maxcut_step(const T* __restrict__ xin, T* __restrict__ xout,
+                                                     int64_t B, int64_t N,
+                                                     const int32_t* __restrict__ rowptr,
+                                                     const int32_t* __restrict__ col,
+                                                     const int32_t* __restrict__ wgt,
+                                                     const int64_t* __restrict__ action,
+                                                     int32_t* __restrict__ obj, float* __restrict__ reward,
+                                                     float* __restrict__ cur, float* __restrict__ done,
+                                                     float done_value) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x / kWave) + wib;
+    const int64_t b0 = wave * EPW;
+    if (b0 >= B) return;
+    const int nenv = (int)((B - b0) < EPW ? (B - b0) : EPW);
+    using V = typename SpinVec<T>::type;
+    constexpr int PER = SpinVec<T>::n;
+
+    int64_t act[EPW];
+#pragma unroll
+    for (int k = 0; k < EPW; ++k) act[k] = (k < nenv) ? action[b0 + k] : -1;
+
+    int my_delta = 0;  // lane k keeps env k's gain
+    auto publish = [&]() {
+        if (lane < nenv) {
+            const int64_t b = b0 + lane;
+            const int v = obj[b] + my_delta;
+            obj[b] = v;
+            reward[b] = (float)my_delta;
+            if (cur) cur[b] = (float)v;
+            if (done) done[b] = done_value;
+        }
+    };
+
+    if constexpr (!EMIT) {
+#pragma unroll
+        for (int k = 0; k < EPW; ++k)
+            if (k < nenv) {
+                const int d = flip_gain<T, WEIGHTED>(xin + (b0 + k) * N, act[k], rowptr, col, wgt, lane);
+                if (lane == k) my_delta = d;
+            }
+        publish();
+        if (lane < nenv) {  // in place: only the flipped spins are written
+            int64_t a = 0;
+#pragma unroll
+            for (int k = 0; k < EPW; ++k) if (lane == k) a = act[k];
+            T* p = xout + (b0 + lane) * N + a;
+            *p = spin_flip<T>(*p);
+        }
+        return;
+    } else if constexpr (!VEC) {
+#pragma unroll
+        for (int k = 0; k < EPW; ++k)
+            if (k < nenv) {
+                const int d = flip_gain<T, WEIGHTED>(xin + (b0 + k) * N, act[k], rowptr, col, wgt, lane);
+                if (lane == k) my_delta = d;
+            }
+        publish();
+        const T* src = xin + b0 * N;
+        T* dst = xout + b0 * N;
+        const int64_t nel = (int64_t)nenv * N;
+        for (int64_t i = lane; i < nel; i += kWave) {
+            T v = src[i];
+#pragma unroll
+            for (int k = 0; k < EPW; ++k)
+                if (act[k] >= 0 && i == (int64_t)k * N + act[k]) v = spin_flip<T>(v);
+            dst[i] = v;
+        }
+        return;
+    } else {
+        const V* src = reinterpret_cast<const V*>(xin + b0 * N);
+        V* dst = reinterpret_cast<V*>(xout + b0 * N);
+        const int64_t nvec = (int64_t)nenv * N / PER;
+        int64_t fvec[EPW];
+        int fidx[EPW];
+#pragma unroll
+        for (int k = 0; k < EPW; ++k) {
+            const int64_t rel = (act[k] < 0) ? -1 : (int64_t)k * N + act[k];
+            fvec[k] = rel < 0 ? -1 : rel / PER;
+            fidx[k] = (int)(rel < 0 ? 0 : rel % PER);
+        }
+
+        if constexpr (MODE == 0) {
+#pragma unroll
+            for (int k = 0; k < EPW; ++k)
+                if (k < nenv) {
+                    const int d = flip_gain<T, WEIGHTED>(xin + (b0 + k) * N, act[k], rowptr, col, wgt, lane);
+                    if (lane == k) my_delta = d;
+                }
+            publish();
+#pragma unroll 4
+            for (int64_t i = lane; i < nvec; i += kWave) {
+                V v = ld_vec<NTL>(src + i);
+#pragma unroll
+                for (int k = 0; k < EPW; ++k)
+                    if (i == fvec[k]) v = SpinVec<T>::flip_at(v, fidx[k]);
+                st_vec<NTS>(dst + i, v);
+            }
+        } else if constexpr (MODE == 1) {
+            constexpr int BATCH = 8;  // 8 x 16 B per lane = 8 KB per wave in flight
+            V buf[BATCH];
+            bool first = true;
+            for (int64_t base = 0; base < nvec; base += BATCH * kWave) {
+#pragma unroll
+                for (int q = 0; q < BATCH; ++q) {
+                    const int64_t i = base + q * kWave + lane;
+                    if (i < nvec) buf[q] = ld_vec<NTL>(src + i);
+                }
+                if (first) {  // gains while the first batch is in flight
+                    first = false;
+#pragma unroll
+                    for (int k = 0; k < EPW; ++k)
+                        if (k < nenv) {
+                            const int d = flip_gain<T, WEIGHTED>(xin + (b0 + k) * N, act[k], rowptr, col, wgt, lane);
+                            if (lane == k) my_delta = d;
+                        }
+                    publish();
+                }
+#pragma unroll
+                for (int q = 0; q < BATCH; ++q) {
+                    const int64_t i = base + q * kWave + lane;
+                    if (i < nvec) {
+                        V v = buf[q];
+#pragma unroll
+                        for (int k = 0; k < EPW; ++k)
+                            if (i == fvec[k]) v = SpinVec<T>::flip_at(v, fidx[k]);
+                        st_vec<NTS>(dst + i, v);
+                    }
+                }
+            }
+        } else {
+            // MODE 2: LDS staged.  Per-wave region of EPW*N*sizeof(T) bytes (16-byte multiple).
+            T* stage = reinterpret_cast<T*>(smem) + (int64_t)wib * EPW * N;
+            V* stage_v = reinterpret_cast<V*>(stage);
+            for (int64_t base = 0; base < nvec; base += kWave) {
+                const int64_t i = base + lane;
+                if (i < nvec) glds16(src + i, stage_v + base);  // LDS dst = wave base + lane*16
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < EPW; ++k)
+                if (k < nenv) {
+                    const int d = flip_gain<T, WEIGHTED>(stage + (int64_t)k * N, act[k], rowptr, col, wgt, lane);
+                    if (lane == k) my_delta = d;
+                }
+            publish();
+            __builtin_amdgcn_wave_barrier();
+            if (lane < nenv) {
+                int64_t a = 0;
+#pragma unroll
+                for (int k = 0; k < EPW; ++k) if (lane == k) a = act[k];
+                T* p = stage + (int64_t)lane * N + a;
+                *p = spin_flip<T>(*p);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+            for (int64_t i = lane; i < nvec; i += kWave) st_vec<NTS>(dst + i, stage_v[i]);
+        }
+    }
+}
+
+static int step_mode_from_env() {
+    const char* e = getenv("RLS_STEP_MODE");  // development knob; default = MODE 2 (LDS staged), plain stores
+    return e ? atoi(e) : 2;
+}
+
+}  // namespace rls
+
+using namespace rls;
+
+extern "C" int rls_maxcut_step(const rls_graph* g, const void* x_in, void* x_out, int spin_bytes, int64_t B,
+                               const int64_t* action, int32_t* obj, float* reward, float* cur, float* done,
+                               float done_value, void* stream) {
+    if (int rc = check_graph(g)) return rc;
+    RLS_REQUIRE(B >= 0, RLS_EINVAL, "B < 0");
+    if (B == 0) return RLS_OK;
+    RLS_REQUIRE(x_in && x_out && action && obj && reward, RLS_EINVAL, "x_in/x_out/action/obj/reward is NULL");
+    RLS_REQUIRE(spin_bytes == 1 || spin_bytes == 4, RLS_EINVAL, "spin_bytes must be 1 or 4");
+    const int64_t N = g->num_nodes;
+    const bool emit = (x_in != x_out);
+    constexpr int EPW = 4;
+    // flat runs of EPW rows start 16-byte aligned when one row is a multiple of 16 bytes
+    const bool vec = rows_vec_aligned(x_in, N, spin_bytes) && rows_vec_aligned(x_out, N, spin_bytes);
+    const int waves_per_block = 4;
+    const dim3 grid((unsigned)ceil_div(ceil_div(B, EPW), waves_per_block)), block(waves_per_block * kWave);
+    hipStream_t s = as_stream(stream);
+    const bool weighted = g->wgt != nullptr;
+    // mode: units = structure (0/1/2), tens = nontemporal loads, hundreds = nontemporal stores
+    int mode = step_mode_from_env();
+    int structure = mode % 10;
+    const bool ntl = (mode / 10) % 10, nts = (mode / 100) % 10;
+    size_t lds = 0;
+    if (structure == 2) {
+        lds = (size_t)waves_per_block * EPW * N * spin_bytes;
+        if (lds > 64 * 1024) { structure = 1; lds = 0; }  // rows too long to stage: register path
+    }
+
+#define LAUNCH_STEP(T, MODE, EMIT, VEC, W, NTL, NTS)                                                          \
+    hipLaunchKernelGGL((k_maxcut_step<T, EPW, MODE, EMIT, VEC, W, NTL, NTS>), grid, block, lds, s, (const T*)x_in, \
+                       (T*)x_out, B, N, g->rowptr, g->col, g->wgt, action, obj, reward, cur, done, done_value)
+#define DISPATCH_NT(T, MODE, W)                                                    \
+    do {                                                                           \
+        if (ntl && nts) LAUNCH_STEP(T, MODE, true, true, W, true, true);           \
+        else if (ntl) LAUNCH_STEP(T, MODE, true, true, W, true, false);            \
+        else if (nts) LAUNCH_STEP(T, MODE, true, true, W, false, true);            \
+        else LAUNCH_STEP(T, MODE, true, true, W, false, false);                    \
+    } while (0)
+#define DISPATCH_MODE(T, W)                                  \
+    do {                                                     \
+        if (structure == 0) DISPATCH_NT(T, 0, W);            \
+        else if (structure == 2) DISPATCH_NT(T, 2, W);       \
+        else DISPATCH_NT(T, 1, W);                           \
+    } while (0)
+#define DISPATCH_T(T)                                                                       \
+    do {                                                                                    \
+        if (!emit) {                                                                        \
+            if (weighted) LAUNCH_STEP(T, 0, false, false, true, false, false);              \
+            else LAUNCH_STEP(T, 0, false, false, false, false, false);                      \
+        } else if (!vec) {                                                                  \
+            if (weighted) LAUNCH_STEP(T, 0, true, false, true, false, false);               \
+            else LAUNCH_STEP(T, 0, true, false, false, false, false);                       \
+        } else if (weighted) {                                                              \
+            DISPATCH_MODE(T, true);                                                         \
+        } else {                                                                            \
+            DISPATCH_MODE(T, false);                                                        \
+        }                                                                                   \
+    } while (0)
+    if (spin_bytes == 1) DISPATCH_T(uint8_t);
+    else DISPATCH_T(float);
+#undef DISPATCH_T
+#undef DISPATCH_MODE
+#undef DISPATCH_NT
+#undef LAUNCH_STEP
+    return check_launch("k_maxcut_step");
+}

@@ -1,0 +1,243 @@
+// TSP kernels (K12, K13, K14-perm) for gfx950.
+//
+// perm[B, N] int64 is the reference's `sample` (env-major); the distance matrix D[N, N] f32 is shared
+// by every env and staged in LDS once per workgroup when it fits (N <= 160: 100 KB; TSP-100 = 40 KB),
+// otherwise read through L2.  One wave owns one tour at a time: lanes run along the tour positions,
+// so perm reads and the [B, N] outputs are coalesced.
+#include "rls_tile.h"
+
+namespace rls {
+
+constexpr int kTspBlock = 256;
+
+__device__ __forceinline__ float wave_sum_f32(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+template <bool LDS_D>
+__device__ __forceinline__ const float* stage_dist(const float* __restrict__ dist, int64_t N, float* lds) {
+    if constexpr (LDS_D) {
+        const int64_t n2 = N * N;
+        for (int64_t i = threadIdx.x; i < n2; i += blockDim.x) lds[i] = dist[i];
+        __syncthreads();
+        return lds;
+    } else {
+        return dist;
+    }
+}
+
+// K12: length[b] = sum_k D[p[k], p[k+1]] + D[p[N-1], p[0]]
+template <bool LDS_D>
+__global__ __launch_bounds__(kTspBlock) void k_tsp_tour_length(const float* __restrict__ dist, int64_t N,
+                                                               const int64_t* __restrict__ perm, int64_t B,
+                                                               float* __restrict__ length) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const float* D = stage_dist<LDS_D>(dist, N, reinterpret_cast<float*>(smem));
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * (kTspBlock / kWave) + threadIdx.x / kWave;
+    const int64_t nwaves = (int64_t)gridDim.x * (kTspBlock / kWave);
+    for (int64_t b = wave; b < B; b += nwaves) {
+        const int64_t* p = perm + b * N;
+        float acc = 0.0f;
+        for (int64_t k = lane; k < N; k += kWave) {
+            const int64_t a = p[k];
+            const int64_t c = p[(k + 1 == N) ? 0 : k + 1];
+            acc += D[a * N + c];
+        }
+        acc = wave_sum_f32(acc);
+        if (lane == 0) length[b] = acc;
+    }
+}
+
+// K13: all-position swap delta of ISCO_TSP.opt_2 given the drawn partner city per position.
+template <bool LDS_D>
+__global__ __launch_bounds__(kTspBlock) void k_tsp_swap_delta_all(const float* __restrict__ dist, int64_t N,
+                                                                  const int64_t* __restrict__ perm, int64_t B,
+                                                                  const int64_t* __restrict__ selected, float temperature,
+                                                                  float* __restrict__ logratio,
+                                                                  int64_t* __restrict__ indices,
+                                                                  uint8_t* __restrict__ ban) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* dl = reinterpret_cast<float*>(smem);
+    const float* D = stage_dist<LDS_D>(dist, N, dl);
+    // per-wave scratch after the (optional) matrix: tour and its inverse, int32 each
+    int32_t* scratch = reinterpret_cast<int32_t*>(smem + (LDS_D ? (size_t)N * N * 4 : 0));
+    const int wib = threadIdx.x / kWave;
+    int32_t* P = scratch + (int64_t)wib * 2 * N;
+    int32_t* INV = P + N;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * (kTspBlock / kWave) + wib;
+    const int64_t nwaves = (int64_t)gridDim.x * (kTspBlock / kWave);
+    const int n = (int)N;
+    for (int64_t b = wave; b < B; b += nwaves) {
+        const int64_t* p = perm + b * N;
+        for (int k = lane; k < n; k += kWave) {
+            const int city = (int)p[k];
+            P[k] = city;
+            INV[city] = k;     // sort + searchsorted of the reference == inverse permutation
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int i = lane; i < n; i += kWave) {
+            const int sel = (int)selected[b * N + i];
+            const int j = INV[sel];
+            const int i0 = (i == 0) ? n - 1 : i - 1;
+            const int i1 = (i + 1 == n) ? 0 : i + 1;
+            const int i2 = (i1 + 1 == n) ? 0 : i1 + 1;
+            const int j0 = (j == 0) ? n - 1 : j - 1;
+            const int j1 = (j + 1 == n) ? 0 : j + 1;
+            const int s_m1 = P[i1], s_m0 = P[i0];
+            const bool banned = (s_m1 == sel) || (s_m0 == sel);           // env_ISCO.py:291-293
+            const int s_i0 = P[j0], s_i1 = P[j1], s_i = P[j];
+            const bool c3 = (s_m1 == s_i0);                                // partner sits at position i+2
+            const int nm = P[i], nm1 = s_m1, nm2 = P[i2];
+            auto DD = [&](int a, int c) { return D[(int64_t)a * n + c]; };
+            float delta;
+            if (banned) {
+                delta = 0.0f;
+            } else if (c3) {                                               // env_ISCO.py:320-324
+                delta = -(DD(nm, nm1) + DD(s_i, s_i1)) + (DD(nm, s_i) + DD(s_i0, s_i1));
+            } else {                                                       // env_ISCO.py:326-332
+                delta = -(((DD(nm, nm1) + DD(nm1, nm2)) + DD(s_i0, s_i)) + DD(s_i, s_i1)) +
+                        (((DD(nm, s_i) + DD(s_i, nm2)) + DD(s_i0, nm1)) + DD(nm1, s_i1));
+            }
+            logratio[b * N + i] = (-delta) / temperature;                  // -delta_yx / temperature
+            indices[b * N + i] = j;
+            ban[b * N + i] = banned ? 1 : 0;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+__global__ void k_tsp_apply_swap(int64_t* __restrict__ perm, int64_t B, int64_t N, const int64_t* __restrict__ pos,
+                                 const int64_t* __restrict__ indices) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int64_t q = pos[b];
+    if (q < 0) return;
+    const int64_t j = indices[b * N + q];
+    const int64_t a = (q + 1) % N;                                          // env_ISCO.py:340
+    int64_t* p = perm + b * N;
+    const int64_t t = p[a];
+    p[a] = p[j];
+    p[j] = t;
+}
+
+__global__ void k_tsp_2opt_delta(const float* __restrict__ dist, int64_t N, const int64_t* __restrict__ perm,
+                                 int64_t B, const int64_t* __restrict__ ii, const int64_t* __restrict__ jj,
+                                 float* __restrict__ delta) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int64_t i = ii[b], j = jj[b];
+    const int64_t* p = perm + b * N;
+    const int64_t im = (i == 0) ? N - 1 : i - 1, jp = (j + 1 == N) ? 0 : j + 1;
+    if (jp == i) { delta[b] = 0.0f; return; }                              // whole tour reversed
+    const int64_t a = p[im], c = p[i], d = p[j], e = p[jp];
+    delta[b] = (dist[a * N + d] + dist[c * N + e]) - (dist[a * N + c] + dist[d * N + e]);
+}
+
+// Fisher-Yates with Philox draws keyed by (seed, global env id, k): p = identity; for k = N-1..1:
+// j = (r * (k+1)) >> 32; swap(p[k], p[j]).
+__global__ void k_rand_perms(int64_t* __restrict__ perm, int64_t B, int64_t N, uint64_t seed, int64_t env_offset) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int64_t* p = perm + b * N;
+    for (int64_t k = 0; k < N; ++k) p[k] = k;
+    const Philox ph(seed);
+    const uint64_t gb = (uint64_t)(b + env_offset);
+    for (int64_t k = N - 1; k >= 1; --k) {
+        uint32_t r[4];
+        ph((uint32_t)gb, (uint32_t)(gb >> 32), (uint32_t)k, 0x5045524Du, r);
+        const int64_t j = (int64_t)(((uint64_t)r[0] * (uint64_t)(k + 1)) >> 32);
+        const int64_t t = p[k];
+        p[k] = p[j];
+        p[j] = t;
+    }
+}
+
+static inline bool dist_fits_lds(int64_t N, size_t extra) { return (size_t)N * N * 4 + extra <= (size_t)kLdsBytes - 1024; }
+
+static inline int tsp_grid(int64_t B) {
+    const int64_t waves = kTspBlock / kWave;
+    int64_t g = ceil_div(B, waves);
+    if (g > 1024) g = 1024;
+    return (int)(g < 1 ? 1 : g);
+}
+
+}  // namespace rls
+
+using namespace rls;
+
+extern "C" {
+
+int rls_tsp_tour_length(const float* dist, int64_t N, const int64_t* perm, int64_t B, float* length, void* stream) {
+    RLS_REQUIRE(N > 0 && N < (1 << 30) && B >= 0, RLS_EINVAL, "bad sizes N=%lld B=%lld", (long long)N, (long long)B);
+    if (B == 0) return RLS_OK;
+    RLS_REQUIRE(dist && perm && length, RLS_EINVAL, "NULL pointer");
+    const dim3 grid(tsp_grid(B)), block(kTspBlock);
+    if (dist_fits_lds(N, 0)) {
+        const size_t lds = (size_t)N * N * 4;
+        auto kern = k_tsp_tour_length<true>;
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, grid, block, lds, as_stream(stream), dist, N, perm, B, length);
+    } else {
+        hipLaunchKernelGGL(k_tsp_tour_length<false>, grid, block, 0, as_stream(stream), dist, N, perm, B, length);
+    }
+    return check_launch("k_tsp_tour_length");
+}
+
+int rls_tsp_swap_delta_all(const float* dist, int64_t N, const int64_t* perm, int64_t B, const int64_t* selected,
+                           float temperature, float* logratio, int64_t* indices, uint8_t* ban, void* stream) {
+    RLS_REQUIRE(N > 2 && N < (1 << 24) && B >= 0, RLS_EINVAL, "bad sizes N=%lld B=%lld", (long long)N, (long long)B);
+    if (B == 0) return RLS_OK;
+    RLS_REQUIRE(dist && perm && selected && logratio && indices && ban, RLS_EINVAL, "NULL pointer");
+    const size_t scratch = (size_t)(kTspBlock / kWave) * 2 * N * 4;
+    RLS_REQUIRE(scratch <= (size_t)kLdsBytes - 1024, RLS_EUNSUPPORTED, "N=%lld too large for the per-wave tour scratch",
+                (long long)N);
+    const dim3 grid(tsp_grid(B)), block(kTspBlock);
+    if (dist_fits_lds(N, scratch)) {
+        const size_t lds = (size_t)N * N * 4 + scratch;
+        auto kern = k_tsp_swap_delta_all<true>;
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, grid, block, lds, as_stream(stream), dist, N, perm, B, selected, temperature, logratio,
+                           indices, ban);
+    } else {
+        auto kern = k_tsp_swap_delta_all<false>;
+        if (scratch > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scratch);
+        hipLaunchKernelGGL(kern, grid, block, scratch, as_stream(stream), dist, N, perm, B, selected, temperature,
+                           logratio, indices, ban);
+    }
+    return check_launch("k_tsp_swap_delta_all");
+}
+
+int rls_tsp_apply_swap(int64_t* perm, int64_t B, int64_t N, const int64_t* pos, const int64_t* indices, void* stream) {
+    RLS_REQUIRE(N > 0 && B >= 0, RLS_EINVAL, "bad sizes");
+    if (B == 0) return RLS_OK;
+    RLS_REQUIRE(perm && pos && indices, RLS_EINVAL, "NULL pointer");
+    hipLaunchKernelGGL(k_tsp_apply_swap, dim3((unsigned)ceil_div(B, 256)), dim3(256), 0, as_stream(stream), perm, B, N,
+                       pos, indices);
+    return check_launch("k_tsp_apply_swap");
+}
+
+int rls_tsp_2opt_delta(const float* dist, int64_t N, const int64_t* perm, int64_t B, const int64_t* i,
+                       const int64_t* j, float* delta, void* stream) {
+    RLS_REQUIRE(N > 0 && B >= 0, RLS_EINVAL, "bad sizes");
+    if (B == 0) return RLS_OK;
+    RLS_REQUIRE(dist && perm && i && j && delta, RLS_EINVAL, "NULL pointer");
+    hipLaunchKernelGGL(k_tsp_2opt_delta, dim3((unsigned)ceil_div(B, 256)), dim3(256), 0, as_stream(stream), dist, N,
+                       perm, B, i, j, delta);
+    return check_launch("k_tsp_2opt_delta");
+}
+
+int rls_rand_perms(int64_t* perm, int64_t B, int64_t N, uint64_t seed, int64_t env_offset, void* stream) {
+    RLS_REQUIRE(N > 0 && B >= 0, RLS_EINVAL, "bad sizes");
+    if (B == 0) return RLS_OK;
+    RLS_REQUIRE(perm, RLS_EINVAL, "perm is NULL");
+    hipLaunchKernelGGL(k_rand_perms, dim3((unsigned)ceil_div(B, 256)), dim3(256), 0, as_stream(stream), perm, B, N,
+                       seed, env_offset);
+    return check_launch("k_rand_perms");
+}
+
+}  // extern "C"

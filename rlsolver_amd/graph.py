@@ -74,7 +74,9 @@ def read_mygraph(filename: str) -> MyGraph:
 def read_edge_arrays(filename: str) -> Tuple[int, np.ndarray, np.ndarray, np.ndarray]:
     """Streaming reader for big files: (num_nodes_from_header, eu, ev, w) as int32 arrays."""
     n, m = read_graph_header(filename)
-    data = np.loadtxt(filename, dtype=np.float64, comments="//", skiprows=1, ndmin=2)
+    it = _graph_lines(filename)
+    next(it)  # header
+    data = np.loadtxt(it, dtype=np.float64, ndmin=2)
     if data.size == 0:
         z = np.zeros(0, np.int32)
         return n, z, z.copy(), z.copy()

@@ -1,0 +1,89 @@
+"""MCPG sampling functions -- drop-in for rlsolver/methods/MCPG.py:88-166 (metro_sampling,
+sampler_func) and the graph part of maxcut_dataloader (:187-232), on HIP tensors.
+
+Shapes and dtypes follow the reference: probs f32 [N]; chains node-major f32 [N, C] holding 0/1;
+sampler_func returns (vs_good f32 [M], xs_good f32 [N, M], value f32 [C]).
+"""
+from __future__ import annotations
+
+import types
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .. import ops, ops_mcpg_tsp as mops
+from ..graph import build_csr, read_edge_arrays
+
+TEN = torch.Tensor
+
+
+def _seed_from_torch() -> int:
+    return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+
+
+def maxcut_dataloader(path, device):
+    """The parts of maxcut_dataloader (MCPG.py:187-232) that sampling needs: edge_index int64 [2, E],
+    per-node degree, sorted_degree_nodes = argsort(|weighted degree|, descending).  Built with numpy
+    in O(E) instead of the reference's Python O(E * deg) list surgery; the shared graph goes to the
+    device once as a CSR.  Returns (data, num_nodes) like the reference."""
+    num_nodes, eu, ev, w = read_edge_arrays(path)
+    return make_data(num_nodes, eu, ev, device), num_nodes
+
+
+def make_data(num_nodes: int, eu, ev, device, sorted_degree_nodes=None):
+    device = torch.device(device)
+    eu = np.asarray(eu, dtype=np.int64)
+    ev = np.asarray(ev, dtype=np.int64)
+    csr = build_csr((eu, ev, np.ones_like(eu)), num_nodes=num_nodes, if_bidirectional=False)
+    # the objective kernel walks the edge list in file order semantics (order is irrelevant to a sum)
+    data = types.SimpleNamespace()
+    data.num_nodes = num_nodes
+    data.edge_index = torch.from_numpy(np.stack([eu, ev])).to(device)
+    data.num_edges = int(eu.shape[0])
+    deg = np.bincount(np.concatenate([eu, ev]), minlength=num_nodes).astype(np.float64)
+    data.single_degree = deg.astype(np.int64).tolist()
+    data.weighted_degree = deg.tolist()
+    if sorted_degree_nodes is None:
+        # torch.argsort(descending=True) is not stable; any tie order is a valid reference outcome
+        sorted_degree_nodes = torch.argsort(torch.from_numpy(deg), descending=True, stable=True)
+    data.sorted_degree_nodes = torch.as_tensor(sorted_degree_nodes).to(torch.int64)
+    data.graph = ops.DeviceGraph(csr, device)
+    data._order_i32 = data.sorted_degree_nodes.to(device=device, dtype=torch.int32).contiguous()
+    return data
+
+
+def metro_sampling(probs: TEN, start_status: TEN, max_transfer_time: int, device=None,
+                   index: Optional[TEN] = None, u: Optional[TEN] = None) -> TEN:
+    """MCPG.py:88-117.  Up to 5*T proposal rounds per chain, stopping after the first round whose
+    cumulative accept count reaches C*T -- evaluated on the device (two kernel launches, no host
+    sync), where the reference syncs once per round.  ``index``/``u`` ([>=5T, C]) replace the
+    torch.randint / torch.rand draws (test hook)."""
+    device = start_status.device if device is None else torch.device(device)
+    samples = start_status.to(device=device, dtype=torch.float32).contiguous().clone()
+    probs = probs.detach().to(device=device, dtype=torch.float32).contiguous()
+    N, Cc = samples.shape
+    Tmax = max_transfer_time * 5
+    if index is not None:
+        Tmax = min(Tmax, index.shape[0])
+    seed = _seed_from_torch() if index is None else 0
+    accepts = torch.zeros(max(Tmax, 1), dtype=torch.int64, device=device)
+    mops.mcpg_metro_rounds(samples, probs, Tmax, index, u, seed, None, False, accepts)
+    # first t with cumsum(accepts)[t] >= C*T  ->  t+1 rounds; none -> all rounds
+    reached = accepts[:Tmax].cumsum(0) >= Cc * max_transfer_time
+    t_stop = torch.where(reached.any(), reached.to(torch.int64).argmax() + 1,
+                         torch.tensor(Tmax, dtype=torch.int64, device=device)).reshape(1).contiguous()
+    mops.mcpg_metro_rounds(samples, probs, Tmax, index, u, seed, t_stop, True, None)
+    return samples
+
+
+def sampler_func(data, xs_sample: TEN, num_ls: int, total_mcmc_num: int, repeat_times: int, device=None,
+                 uniforms: Optional[TEN] = None):
+    """MCPG.py:120-166: node-sequential stochastic local search (K7), expected cut (K8), best of
+    repeats.  ``uniforms`` f32 [num_ls, N, C] replaces torch.rand (test hook)."""
+    xs_sample = xs_sample.contiguous()
+    seed = _seed_from_torch() if uniforms is None else 0
+    xs_loc, expected = mops.mcpg_local_search(data.graph, xs_sample, data._order_i32, num_ls, uniforms, seed)
+    _, vs_good, xs_good = mops.mcpg_pick_best(expected, xs_loc, total_mcmc_num, repeat_times, data.num_edges)
+    value = expected - expected.mean()
+    return vs_good, xs_good, value

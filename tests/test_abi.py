@@ -1,0 +1,79 @@
+"""The C-ABI library loads on a CPU-only host and exports every symbol include/*.h declares,
+with the ctypes signature table in step with the header.  No compute calls (no GPU here)."""
+import ctypes
+import glob
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    names = {}
+    for h in glob.glob(os.path.join(ROOT, "include", "*.h")):
+        src = open(h).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        for m in re.finditer(r"\b(int|const char\*)\s+(rls_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+            args = [a.strip() for a in m.group(3).split(",")]
+            nargs = 0 if args == ["void"] else len(args)
+            names[m.group(2)] = nargs
+    return names
+
+
+def test_header_parses():
+    fns = declared_functions()
+    assert {"rls_version", "rls_maxcut_obj", "rls_maxcut_step", "rls_maxcut_greedy_sweep"} <= set(fns)
+    assert len(fns) >= 15
+
+
+def test_library_exports_every_declared_symbol():
+    from rlsolver_amd import _abi, build
+    build.build()
+    lib = ctypes.CDLL(_abi.LIB_PATH)
+    missing = [n for n in declared_functions() if not hasattr(lib, n)]
+    assert not missing, f"declared in include/ but not exported: {missing}"
+
+
+def test_ctypes_table_matches_header():
+    from rlsolver_amd import _abi
+    fns = declared_functions()
+    table = dict(_abi.SIGNATURES)
+    table.update({k: v[0] for k, v in _abi.PLAIN.items()})
+    assert set(table) == set(fns), (set(fns) ^ set(table))
+    for name, nargs in fns.items():
+        assert len(table[name]) == nargs, name
+
+
+def test_loads_without_gpu_and_reports_errors():
+    from rlsolver_amd import _abi
+    assert _abi.version() == 1
+    assert _abi.device_count() >= 0
+    # argument validation happens before any device work
+    with pytest.raises(_abi.RlsError) as e:
+        _abi.call("rls_maxcut_obj", None, None, 1, 4, None, None)
+    assert e.value.code == -1 and "graph" in str(e.value)
+    with pytest.raises(_abi.RlsError):
+        _abi.call("rls_rand_spins", None, 4, 0, 1, 0, None)
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing under rlsolver_amd/ may reference it."""
+    bad = []
+    for p in glob.glob(os.path.join(ROOT, "rlsolver_amd", "**", "*.py"), recursive=True):
+        txt = open(p).read()
+        if re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M) or "oracle_np" in txt or "oracle_c" in txt:
+            bad.append(p)
+    assert not bad, bad
+
+
+def test_cpu_tensor_is_rejected():
+    import torch
+    from rlsolver_amd import ops
+    with pytest.raises(TypeError):
+        ops.select_better_rows(torch.zeros((2, 4), dtype=torch.bool), torch.zeros(2, dtype=torch.int64),
+                               torch.zeros((2, 4), dtype=torch.bool), torch.zeros(2, dtype=torch.int64))
+    from rlsolver_amd.envs.env_L2A import EnvMaxcut
+    with pytest.raises(TypeError):
+        EnvMaxcut(mygraph=[(0, 1, 1)], device=torch.device("cpu"))

@@ -1,0 +1,137 @@
+"""The drop-in env classes against golden vectors captured from the reference classes."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle_np as onp
+from tests.gpu_util import DEV, to_dev_bool
+
+pytestmark = pytest.mark.gpu
+
+
+def mygraph_of(arr):
+    return [tuple(int(v) for v in r) for r in arr]
+
+
+@pytest.mark.parametrize("gname", ["PL_20_ID0", "BA_100_ID0", "ER_100_ID0", "gset_14_stub"])
+@pytest.mark.parametrize("bidir", [False, True])
+def test_env_l2a_local_search_inplace_golden(golden, gname, bidir):
+    from rlsolver_amd.envs.env_L2A import EnvMaxcut
+    z = golden("maxcut_local_search")
+    env = EnvMaxcut(mygraph=mygraph_of(z[f"{gname}/graph"]), device=DEV, if_bidirectional=bidir)
+    tag = f"{gname}/bidir{int(bidir)}"
+    assert env.num_nodes == onp.num_nodes_distinct(z[f"{gname}/graph"]) and env.if_maximize
+    xs = to_dev_bool(z[f"{tag}/ls/xs_in"]).clone()
+    noise = torch.from_numpy(z[f"{tag}/ls/noise"]).to(DEV)
+    gx, gv = env.local_search_inplace(xs, torch.empty(()), num_iters=8, num_spin=int(z[f"{tag}/ls/num_spin"]),
+                                      noise_std=0.3, noise=noise)
+    assert gx.data_ptr() == xs.data_ptr()                      # in place, like the reference
+    assert gv.dtype == torch.int64 and gx.dtype == torch.bool
+    assert np.array_equal(gx.cpu().numpy().astype(np.uint8), z[f"{tag}/ls/xs_out"])
+    assert np.array_equal(gv.cpu().numpy(), z[f"{tag}/ls/vs_out"])
+
+
+@pytest.mark.parametrize("gname", ["BA_5_ID0", "PL_20_ID0", "ER_100_ID0"])
+@pytest.mark.parametrize("bidir", [False, True])
+def test_env_l2a_objectives_golden(golden, gname, bidir):
+    from rlsolver_amd.envs.env_L2A import EnvMaxcut
+    z = golden("maxcut_obj")
+    env = EnvMaxcut(mygraph=mygraph_of(z[f"{gname}/graph"]), device=DEV, if_bidirectional=bidir)
+    tag = f"{gname}/bidir{int(bidir)}"
+    assert np.array_equal(env.n0_num_n1.cpu().numpy(), z[f"{tag}/n0_num_n1"])
+    assert env.n0_ids.shape == (1, len(z[f"{gname}/graph"]) * (2 if bidir else 1))
+    for seed in (0, 1, 2):
+        t = f"{tag}/seed{seed}"
+        xs = to_dev_bool(z[f"{t}/xs"])
+        v = env.calculate_obj_values(xs)
+        assert str(v.dtype) == str(z[f"{t}/obj_dtype"]) and np.array_equal(v.cpu().numpy(), z[f"{t}/obj"])
+        raw = env.calculate_obj_values_for_loop(xs, if_sum=False)
+        assert str(raw.dtype) == str(z[f"{t}/cutdeg_dtype"]) and np.array_equal(raw.cpu().numpy(), z[f"{t}/cutdeg"])
+        lp = env.calculate_obj_values_for_loop(xs, if_sum=True)
+        assert str(lp.dtype) == str(z[f"{t}/obj_loop_dtype"]) and np.array_equal(lp.cpu().numpy(), z[f"{t}/obj_loop"])
+        if f"{t}/edge_mask" in z.files and not bidir:
+            assert np.array_equal(env.calculate_obj_values(xs, if_sum=False).cpu().numpy().astype(np.uint8), z[f"{t}/edge_mask"])
+    torch.manual_seed(3)
+    a = env.generate_xs_randomly(50)
+    torch.manual_seed(3)
+    b = env.generate_xs_randomly(50)
+    assert a.dtype == torch.bool and a.shape == (50, env.num_nodes) and torch.equal(a, b) and not a[:, 0].any()
+    adj = env.adjacency_bool.cpu().numpy()
+    assert np.array_equal(adj, adj.T) and len(env.adjacency_indies) == env.num_nodes
+
+
+@pytest.mark.parametrize("gname", ["BA_100_ID0", "PL_20_ID0"])
+def test_local_search_class_golden(golden, gname):
+    from rlsolver_amd.envs.env_L2A import EnvMaxcut
+    from rlsolver_amd.methods.LocalSearch import LocalSearch
+    z = golden("local_search_class")
+    env = EnvMaxcut(mygraph=mygraph_of(z[f"{gname}/graph"]), device=DEV, if_bidirectional=False)
+    tag = f"{gname}/bidir0"
+    ls = LocalSearch(simulator=env, num_nodes=env.num_nodes)
+    vs = ls.reset(to_dev_bool(z[f"{tag}/xs_in"]).clone())
+    assert np.array_equal(vs.cpu().numpy(), z[f"{tag}/vs_reset"])
+    for r in range(2):
+        gx, gv, nupd = ls.random_search(num_iters=4, num_spin=4, noise_std=0.3,
+                                        noise=torch.from_numpy(z[f"{tag}/round{r}/noise"]).to(DEV))
+        assert np.array_equal(gx.cpu().numpy().astype(np.uint8), z[f"{tag}/round{r}/xs"])
+        assert np.array_equal(gv.cpu().numpy(), z[f"{tag}/round{r}/vs"])
+        assert nupd == int(z[f"{tag}/round{r}/num_update"])
+    env_b = EnvMaxcut(mygraph=mygraph_of(z[f"{gname}/graph"]), device=DEV, if_bidirectional=True)
+    lsb = LocalSearch(simulator=env_b, num_nodes=env_b.num_nodes)
+    lsb.reset(to_dev_bool(z[f"{tag}/xs_in"]).clone())
+    with pytest.raises(RuntimeError):          # the reference raises here as well
+        lsb.random_search(num_iters=1, num_spin=4)
+    xs = ls.reset_search(4)
+    assert xs.shape == (4, env.num_nodes) and xs.dtype == torch.bool
+
+
+@pytest.mark.parametrize("gname", ["BA_100_ID0", "gset_14_stub"])
+@pytest.mark.parametrize("bidir", [False, True])
+def test_env_ppo_class_golden(golden, gname, bidir):
+    from rlsolver_amd.envs.env_PPO import EnvMaxcut
+    z = golden("env_ppo")
+    graph = z[f"{gname}/graph"]
+    tag = f"{gname}/bidir{int(bidir)}"
+    n = int(graph[:, :2].max()) + 1
+    args = types.SimpleNamespace(num_nodes=n, num_envs=16, num_steps=20)
+    env = EnvMaxcut(args, mygraph=mygraph_of(graph), device=DEV, if_bidirectional=bidir)
+    obs = env.reset()
+    assert obs.dtype == torch.float32 and obs.shape == (16, n) and not obs[:, 0].any()
+    # load the golden initial state into the env (reset() draws from our own generator)
+    env.xs.copy_(torch.from_numpy(z[f"{tag}/xs0"]).to(DEV).float())
+    env._obj = env.calculate_obj_values().to(torch.int32)
+    env.last_reward = env._obj.float()
+    assert np.array_equal(env.last_reward.cpu().numpy(), z[f"{tag}/cut0"])
+    for t in range(50):
+        xs, r, d, c = env.step(torch.from_numpy(z[f"{tag}/actions"][t]).to(DEV))
+        assert xs.data_ptr() == env.xs.data_ptr()
+        assert [str(v.dtype) for v in (xs, r, d, c)] == list(z[f"{tag}/ret_dtypes"])
+        assert np.array_equal(r.cpu().numpy(), z[f"{tag}/rewards"][t])
+        assert np.array_equal(d.cpu().numpy(), z[f"{tag}/dones"][t])
+        assert np.array_equal(c.cpu().numpy(), z[f"{tag}/curs"][t])
+    assert np.array_equal((env.xs > 0).cpu().numpy().astype(np.uint8), z[f"{tag}/xs_final"])
+    # emitting variant: next state lands in a caller buffer (rollout slot)
+    slot = torch.empty_like(env.xs)
+    prev = env.xs.clone()
+    xs, r, d, c = env.step(torch.zeros(16, dtype=torch.int64, device=DEV), out=slot)
+    assert xs.data_ptr() == slot.data_ptr() and torch.equal(slot[:, 1:], prev[:, 1:]) and torch.equal(slot[:, 0], 1 - prev[:, 0])
+
+
+def test_select_wrappers_golden(golden):
+    from rlsolver_amd.methods.util_read_data import evolutionary_replacement, pick_xs_by_vs, update_xs_by_vs
+    z = golden("select_ops")
+    a = to_dev_bool(z["update/xs0"]).clone()
+    b = torch.from_numpy(z["update/vs0"]).to(DEV).clone()
+    ret = update_xs_by_vs(a, b, to_dev_bool(z["update/xs1"]), torch.from_numpy(z["update/vs1"]).to(DEV), True)
+    assert ret == int(z["update/max1/ret"])
+    assert np.array_equal(a.cpu().numpy().astype(np.uint8), z["update/max1/xs"])
+    gx, gv = pick_xs_by_vs(to_dev_bool(z["update/xs0"]), torch.from_numpy(z["update/vs0"]).to(DEV), int(z["pick/R"]), True)
+    assert np.array_equal(gx.cpu().numpy().astype(np.uint8), z["pick/max1/xs"])
+    xs = to_dev_bool(z["update/xs0"]).clone()
+    vs = torch.from_numpy(z["evo/vs_in"]).to(DEV).clone()
+    torch.manual_seed(0)
+    evolutionary_replacement(xs, vs, 5, True)
+    best5 = np.sort(z["evo/vs_in"])[-5:]
+    assert np.sum(np.isin(vs.cpu().numpy(), best5)) == 10       # the 5 best now appear twice

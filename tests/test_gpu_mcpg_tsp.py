@@ -1,0 +1,174 @@
+"""Parity of the MCPG and TSP kernels / Python surfaces against golden vectors and the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle_np as onp
+from rlsolver_amd import ops_mcpg_tsp as mops
+from rlsolver_amd.methods import MCPG as amcpg
+from tests.gpu_util import DEV, gnm_arr
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+    return t.to(dtype) if dtype is not None else t
+
+
+@pytest.mark.parametrize("gname", ["BA_100_ID0", "PL_20_ID0"])
+def test_mcpg_golden(golden, gname):
+    z = golden("mcpg")
+    graph = z[f"{gname}/graph"]
+    n = int(graph[:, :2].max()) + 1
+    ei = z[f"{gname}/edge_index"]
+    data = amcpg.make_data(n, ei[0], ei[1], DEV, sorted_degree_nodes=z[f"{gname}/sorted_degree_nodes"])
+    assert data.weighted_degree == z[f"{gname}/weighted_degree"].tolist()
+    T = int(z[f"{gname}/metro/T"])
+    out = amcpg.metro_sampling(dev(z[f"{gname}/metro/probs"]), dev(z[f"{gname}/metro/start"], torch.float32), T,
+                               device=DEV, index=dev(z[f"{gname}/metro/index"]), u=dev(z[f"{gname}/metro/u"]))
+    assert out.dtype == torch.float32
+    assert np.array_equal(out.cpu().numpy().astype(np.uint8), z[f"{gname}/metro/out"])
+    vs_good, xs_good, value = amcpg.sampler_func(
+        data, dev(z[f"{gname}/sampler/xs_in"], torch.float32), int(z[f"{gname}/sampler/num_ls"]),
+        int(z[f"{gname}/sampler/total_mcmc_num"]), int(z[f"{gname}/sampler/repeat_times"]), DEV,
+        uniforms=dev(z[f"{gname}/sampler/uniforms"]))
+    assert np.array_equal(vs_good.cpu().numpy(), z[f"{gname}/sampler/vs_good"])
+    assert np.array_equal(xs_good.cpu().numpy(), z[f"{gname}/sampler/xs_good"])
+    np.testing.assert_allclose(value.cpu().numpy(), z[f"{gname}/sampler/value"], rtol=0, atol=1e-4)
+
+
+@pytest.mark.parametrize("n,m,M,R,num_ls", [(300, 1500, 20, 5, 2), (2000, 19990, 64, 3, 1), (64, 200, 1, 1, 3)])
+def test_mcpg_random_vs_oracle(n, m, M, R, num_ls):
+    graph = gnm_arr(n, m, seed=5)
+    ei = graph[:, :2].T.copy()
+    rng = np.random.RandomState(3)
+    C = M * R
+    deg = np.bincount(ei.reshape(-1), minlength=n)
+    order = np.argsort(-deg, kind="stable")
+    data = amcpg.make_data(n, ei[0], ei[1], DEV, sorted_degree_nodes=order)
+    probs = (rng.rand(n) * 0.6 + 0.2).astype(np.float32)
+    start = rng.randint(0, 2, size=(n, C)).astype(np.float32)
+    T = max(1, n // 10)
+    index = rng.randint(0, n, size=(5 * T, C)).astype(np.int64)
+    u = rng.rand(5 * T, C).astype(np.float32)
+    want, t_used = onp.metro_sampling(probs, start, T, index, u)
+    got = amcpg.metro_sampling(dev(probs), dev(start), T, device=DEV, index=dev(index), u=dev(u))
+    assert np.array_equal(got.cpu().numpy(), want)
+    # forcing the stop rule to bite: tiny T budget relative to acceptance
+    uni = rng.rand(num_ls, n, C).astype(np.float32)
+    vs_w, xs_w, val_w, x_all, exp_w = onp.sampler_func(ei, n, order, want, num_ls, M, R, uni)
+    vs_g, xs_g, val_g = amcpg.sampler_func(data, got, num_ls, M, R, DEV, uniforms=dev(uni))
+    assert np.array_equal(vs_g.cpu().numpy(), vs_w)
+    assert np.array_equal(xs_g.cpu().numpy(), xs_w)
+    np.testing.assert_allclose(val_g.cpu().numpy(), val_w, atol=1e-3)
+
+
+def test_mcpg_production_rng_is_distributionally_sane():
+    n, m, C = 500, 3000, 4096
+    graph = gnm_arr(n, m, seed=9)
+    ei = graph[:, :2].T.copy()
+    data = amcpg.make_data(n, ei[0], ei[1], DEV)
+    torch.manual_seed(0)
+    probs = torch.full((n,), 0.5, device=DEV)
+    start = torch.zeros((n, C), device=DEV)
+    out = amcpg.metro_sampling(probs, start, n // 10, device=DEV)
+    # p = 0.5 -> accept rate 1 -> every proposal flips; C*T accepts reached after exactly T rounds
+    flips = out.sum(0)
+    assert float(flips.max()) <= n // 10 and float(flips.mean()) > 0.8 * (n // 10) * 0.9
+    vs_good, xs_good, value = amcpg.sampler_func(data, out, 4, 512, 8, DEV)
+    # local search must beat random assignment (m/2) clearly, and values are consistent with xs_good
+    assert float(vs_good.mean()) > 0.55 * m
+    cut = onp.maxcut_obj(xs_good.cpu().numpy().T > 0, graph, False)
+    assert np.array_equal(cut.astype(np.float32), vs_good.cpu().numpy())
+    assert abs(float(value.mean())) < 1e-2
+
+
+@pytest.mark.parametrize("name", ["a5", "berlin52"])
+def test_tsp_golden(golden, name):
+    z = golden("tsp")
+    d = dev(z[f"{name}/distance"])
+    perms = dev(z[f"{name}/perms"])
+    K = int(z[f"{name}/K"])
+    length = mops.tsp_tour_length(d, perms).cpu().numpy()
+    np.testing.assert_allclose(length, z[f"{name}/length_f32"], rtol=1e-5)            # north_star tolerance
+    np.testing.assert_allclose(length, z[f"{name}/length_f64_distance_calc"], rtol=1e-5)
+    sel = onp.tsp_selected_partner(z[f"{name}/perms"], z[f"{name}/nearest_indices"], z[f"{name}/random_indices"],
+                                   z[f"{name}/opt2/rand"], z[f"{name}/opt2/randint_nearest"],
+                                   z[f"{name}/opt2/randint_random"], K)
+    T = float(z[f"{name}/opt2/temperature"])
+    lr, idx, ban = mops.tsp_swap_delta_all(d, perms, dev(sel), T)
+    assert np.array_equal(idx.cpu().numpy(), z[f"{name}/opt2/indices"])
+    assert np.array_equal(ban.cpu().numpy().astype(np.uint8), z[f"{name}/opt2/ban"])
+    scale = np.abs(z[f"{name}/length_f32"]).max() / T
+    np.testing.assert_allclose(lr.cpu().numpy(), z[f"{name}/opt2/logratio"], rtol=1e-5, atol=1e-5 * scale)
+    x = perms.clone()
+    mops.tsp_apply_swap(x, dev(z[f"{name}/switch/pos"]), idx)
+    assert np.array_equal(x.cpu().numpy(), z[f"{name}/switch/out"])
+    np.testing.assert_allclose(mops.tsp_tour_length(d, x).cpu().numpy(), z[f"{name}/switch/length_f32"], rtol=1e-5)
+    env = z[f"{name}/twoopt/env"]
+    dl = mops.tsp_2opt_delta(d, perms[dev(env)].contiguous(), dev(z[f"{name}/twoopt/i"]), dev(z[f"{name}/twoopt/j"]))
+    np.testing.assert_allclose(dl.cpu().numpy(), z[f"{name}/twoopt/delta_f64"], rtol=1e-5,
+                               atol=1e-5 * float(z[f"{name}/length_f32"].max()))
+
+
+@pytest.mark.parametrize("N,B", [(100, 1000), (52, 65), (200, 130), (7, 64)])
+def test_tsp_random_properties(N, B):
+    from rlsolver_amd.graph import generate_tsp_coords, tsp_tables
+    dist, near, rnd = tsp_tables(generate_tsp_coords(N, seed=N), K=min(20, N - 2))
+    d = dev(dist)
+    perms = mops.rand_perms(B, N, seed=77, device=DEV, env_offset=5)
+    pn = perms.cpu().numpy()
+    assert np.array_equal(pn, onp.rand_perms(B, N, 77, 5))
+    assert np.array_equal(np.sort(pn, axis=1), np.tile(np.arange(N), (B, 1)))
+    length = mops.tsp_tour_length(d, perms).cpu().numpy()
+    np.testing.assert_allclose(length, onp.tsp_tour_length_f64(dist, pn), rtol=1e-5)
+    # invariant under rotation and reversal
+    np.testing.assert_allclose(mops.tsp_tour_length(d, torch.roll(perms, 3, 1).contiguous()).cpu().numpy(), length, rtol=1e-5)
+    np.testing.assert_allclose(mops.tsp_tour_length(d, torch.flip(perms, [1]).contiguous()).cpu().numpy(), length, rtol=1e-5)
+    rng = np.random.RandomState(1)
+    # partner city = the city some 1..N-1 positions ahead (the sampler never draws a position's own
+    # city: nearest/random tables exclude it, ISCO/util_TSP.py:9-16)
+    off = rng.randint(1, N, size=(B, N))
+    sel = np.take_along_axis(pn, (np.arange(N)[None, :] + off) % N, axis=1)
+    lr_w, idx_w, ban_w = onp.tsp_swap_delta_all(dist, pn, sel, 0.5)
+    lr, idx, ban = mops.tsp_swap_delta_all(d, perms, dev(sel), 0.5)
+    assert np.array_equal(idx.cpu().numpy(), idx_w) and np.array_equal(ban.cpu().numpy(), ban_w)
+    np.testing.assert_allclose(lr.cpu().numpy(), lr_w, rtol=1e-5, atol=1e-5 * length.max() / 0.5)
+    # swap delta == length(after) - length(before) for one random non-banned position per env
+    pos = np.array([rng.choice(np.flatnonzero(~ban_w[b])) if (~ban_w[b]).any() else -1 for b in range(B)])
+    x = perms.clone()
+    mops.tsp_apply_swap(x, dev(pos), idx)
+    after = mops.tsp_tour_length(d, x).cpu().numpy()
+    for b in range(B):
+        if pos[b] >= 0:
+            assert abs((after[b] - length[b]) - (-lr_w[b, pos[b]] * 0.5)) <= 2e-5 * length[b]
+    # true 2-opt delta == length difference of the reversed segment
+    i = rng.randint(0, N - 1, size=B)
+    j = np.array([rng.randint(a + 1, N) for a in i])
+    dl = mops.tsp_2opt_delta(d, perms, dev(i), dev(j)).cpu().numpy()
+    rev = pn.copy()
+    for b in range(B):
+        rev[b, i[b]:j[b] + 1] = rev[b, i[b]:j[b] + 1][::-1]
+    want = onp.tsp_tour_length_f64(dist, rev) - onp.tsp_tour_length_f64(dist, pn)
+    np.testing.assert_allclose(dl, want, atol=2e-5 * length.max())
+
+
+def test_isco_tsp_class_runs(golden):
+    from rlsolver_amd.envs.env_ISCO import ISCO_TSP
+    z = golden("tsp")
+    params = {"num_nodes": 52, "distance": dev(z["berlin52/distance"]),
+              "nearest_indices": dev(z["berlin52/nearest_indices"]), "random_indices": dev(z["berlin52/random_indices"])}
+    torch.manual_seed(0)
+    s = ISCO_TSP(params, batch_size=64, K=20, device=DEV)
+    x = s.random_gen_init_sample(params)
+    l0 = s.calculate_distance(x)
+    temp = s.init_temperature
+    for it in range(30):
+        x, acc = s.step(x, 3, temp)
+        assert 0.0 <= float(acc) <= 1.0
+    xs = x.cpu().numpy()
+    assert np.array_equal(np.sort(xs, axis=1), np.tile(np.arange(52), (64, 1)))
+    l1 = s.calculate_distance(x)
+    np.testing.assert_allclose(l1.cpu().numpy(), onp.tsp_tour_length_f64(z["berlin52/distance"], xs), rtol=1e-5)
+    assert float(l1.mean()) < float(l0.mean())     # annealing at T=1 on berlin52 improves random tours

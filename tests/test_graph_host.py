@@ -1,0 +1,84 @@
+"""Host-side graph layer: parsing, CSR construction, generators (CPU only)."""
+import numpy as np
+import pytest
+
+from rlsolver_amd import graph as G
+
+
+def test_read_write_roundtrip(tmp_path):
+    g = [(0, 1, 1), (0, 2, 1), (2, 3, 5)]
+    p = tmp_path / "g.txt"
+    G.write_mygraph(str(p), g, 4)
+    assert G.read_mygraph(str(p)) == g
+    assert G.read_graph_header(str(p)) == (4, 3)
+    # comments and blank lines are tolerated
+    p.write_text("// header follows\n4 3\n1 2 1\n\n1 3 1 // inline\n3 4 5\n")
+    assert G.read_mygraph(str(p)) == g
+    n, eu, ev, w = G.read_edge_arrays(str(p))
+    assert n == 4 and eu.tolist() == [0, 0, 2] and ev.tolist() == [1, 2, 3] and w.tolist() == [1, 1, 5]
+    assert G.load_mygraph2(graph_name=str(p)) == g
+    with pytest.raises(ValueError):
+        G.load_mygraph2(dataDir=str(tmp_path), graph_name="nope")
+
+
+def test_golden_graphs_csr(golden):
+    z = golden("maxcut_obj")
+    for name in z["names"]:
+        arr = z[f"{name}/graph"]
+        mg = [tuple(int(v) for v in r) for r in arr]
+        n = G.calc_num_nodes_in_mygraph(mg)
+        assert n == int(z[f"{name}/bidir0/num_nodes"])
+        for bidir in (False, True):
+            csr = G.build_csr(mg, num_nodes=n, if_bidirectional=bidir)
+            assert csr.num_stored_edges == len(mg) * (2 if bidir else 1)
+            assert np.array_equal(np.bincount(csr.eu, minlength=n)[None, :], z[f"{name}/bidir{int(bidir)}/n0_num_n1"])
+            assert (np.diff(csr.eu) >= 0).all()
+            # symmetric CSR: every edge appears in both rows, sorted
+            assert csr.nnz == 2 * len(mg)
+            for i in range(n):
+                row = csr.col[csr.rowptr[i]:csr.rowptr[i + 1]]
+                assert (np.diff(row) >= 0).all()
+            deg = np.zeros(n, int)
+            for a, b, _ in mg:
+                deg[a] += 1
+                deg[b] += 1
+            assert np.array_equal(csr.degree, deg)
+            n1s, _ = G.build_adjacency_indies(mg, bidir)
+            off = np.concatenate([[0], np.cumsum([len(x) for x in n1s])])
+            assert np.array_equal(np.concatenate(n1s), csr.ev)
+            assert off[-1] == csr.num_stored_edges
+        adj = G.build_adjacency_bool(mg, n, True)
+        assert adj.sum() == 2 * len({(min(a, b), max(a, b)) for a, b, _ in mg})
+
+
+def test_csr_edge_cases():
+    csr = G.build_csr([(0, 1, 1), (0, 1, 1), (2, 2, 1)], num_nodes=4)
+    assert csr.num_stored_edges == 3 and csr.nnz == 4      # self loop dropped from CSR, multi-edge kept
+    assert csr.degree.tolist() == [2, 2, 0, 0] and csr.max_degree == 2
+    with pytest.raises(ValueError):
+        G.build_csr([(0, 5, 1)], num_nodes=3)
+    e = G.build_csr([], num_nodes=3)
+    assert e.nnz == 0 and e.rowptr.tolist() == [0, 0, 0, 0]
+
+
+def test_generators_deterministic():
+    a = G.generate_gnm(200, 1000, seed=3)
+    assert a == G.generate_gnm(200, 1000, seed=3) and a != G.generate_gnm(200, 1000, seed=4)
+    assert len(a) == 1000 and len({(u, v) for u, v, _ in a}) == 1000 and all(u < v for u, v, _ in a)
+    b = G.generate_ba(300, 5, seed=5)
+    assert len(b) == 5 * (300 - 5) and len(set(b)) == len(b)
+    assert G.calc_num_nodes_in_mygraph(b) == 300
+    g, n, m = G.generate_mygraph("ER", 50, seed=1)
+    assert n == 50 and m == len(g)
+    mg, n22, real = G.load_gset(22, data_dir="/nonexistent")
+    assert (n22, len(mg), real) == (2000, 19990, False)
+    with pytest.raises(ValueError):
+        G.generate_gnm(4, 7, 0)
+
+
+def test_tsp_tables_small():
+    coords = np.array([[0, 0], [3, 4], [6, 8], [0, 1]], dtype=np.float64)
+    d, near, rnd = G.tsp_tables(coords, K=2)
+    assert d.dtype == np.float32 and d[0, 1] == 5 and d[0, 2] == 10 and d[1, 1] == 0
+    assert near.tolist()[0] == [3, 1] and rnd.tolist()[2] == [0, 1, 3]
+    assert G.generate_tsp_coords(100, 100).shape == (100, 2)

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 outputs (gpurun_out/prof_*) into small tracked files under profiles/.
+
+    python tools/summarize_prof.py <tag> [--kt DIR] [--fetch DIR] [--write DIR] [--prefix r01]
+
+Writes profiles/<tag>_kernel_stats.csv (the `rocprofv3 --kernel-trace --stats` summary, top rows)
+and profiles/<tag>_pmc.json (per-kernel mean FETCH_SIZE / WRITE_SIZE per launch from separate
+--pmc passes, with the gfx950 correction of MI355X_MICROARCH.md section HBM: FETCH_SIZE tallies
+64 B per 128-B request of a wide coalesced read, so read bytes = 2 x FETCH_SIZE; WRITE_SIZE is
+exact for 16-B-per-lane stores; both are reported by rocprofv3 in KB of 1024 B)."""
+import argparse
+import collections
+import csv
+import json
+import os
+
+ap = argparse.ArgumentParser()
+ap.add_argument("tag")
+ap.add_argument("--kt", default="gpurun_out/prof_kt")
+ap.add_argument("--fetch", default="gpurun_out/prof_fetch")
+ap.add_argument("--write", default="gpurun_out/prof_write")
+ap.add_argument("--prefix", default="r01")
+ap.add_argument("--cmd", default="")
+a = ap.parse_args()
+os.makedirs("profiles", exist_ok=True)
+
+
+def short(n):
+    return n.split("(")[0].replace("void ", "")[:110]
+
+
+ks = os.path.join(a.kt, f"{a.prefix}_kernel_stats.csv")
+if os.path.exists(ks):
+    rows = list(csv.DictReader(open(ks)))
+    with open(f"profiles/{a.tag}_kernel_stats.csv", "w", newline="") as f:
+        if a.cmd:
+            f.write(f"# rocprofv3 --kernel-trace --stats -- {a.cmd}\n")
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+        for r in rows[:12]:
+            w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
+                        r["MinNs"], r["MaxNs"], r["StdDev"]])
+    print("wrote", f"profiles/{a.tag}_kernel_stats.csv")
+
+pmc = collections.defaultdict(dict)
+for name, d in (("FETCH_SIZE", a.fetch), ("WRITE_SIZE", a.write)):
+    p = os.path.join(d, f"{a.prefix}_counter_collection.csv")
+    if not os.path.exists(p):
+        continue
+    agg = collections.defaultdict(list)
+    meta = {}
+    for r in csv.DictReader(open(p)):
+        if r["Counter_Name"] != name:
+            continue
+        k = short(r["Kernel_Name"])
+        agg[k].append(float(r["Counter_Value"]))
+        meta[k] = {"vgpr": int(r["VGPR_Count"]), "sgpr": int(r["SGPR_Count"]), "lds": int(r["LDS_Block_Size"]),
+                   "wg": int(r["Workgroup_Size"]), "grid": int(r["Grid_Size"])}
+    for k, v in agg.items():
+        pmc[k][name + "_KB_mean"] = sum(v) / len(v)
+        pmc[k][name + "_launches"] = len(v)
+        pmc[k].update(meta[k])
+for k, d in pmc.items():
+    if "FETCH_SIZE_KB_mean" in d:
+        d["read_bytes_per_launch_corrected"] = 2 * d["FETCH_SIZE_KB_mean"] * 1024
+    if "WRITE_SIZE_KB_mean" in d:
+        d["write_bytes_per_launch"] = d["WRITE_SIZE_KB_mean"] * 1024
+    if "read_bytes_per_launch_corrected" in d and "write_bytes_per_launch" in d:
+        d["hbm_bytes_per_launch"] = d["read_bytes_per_launch_corrected"] + d["write_bytes_per_launch"]
+if pmc:
+    out = {"note": "separate --pmc passes (FETCH_SIZE, WRITE_SIZE); gfx950 correction: read bytes = 2 x FETCH_SIZE "
+                   "for 16-B-per-lane coalesced streams (MI355X_MICROARCH.md, HBM section); counters in KB of 1024 B",
+           "command": a.cmd, "kernels": pmc}
+    json.dump(out, open(f"profiles/{a.tag}_pmc.json", "w"), indent=1, sort_keys=True)
+    print("wrote", f"profiles/{a.tag}_pmc.json")
