@@ -4,53 +4,65 @@
 
 namespace rls {
 
+constexpr int kTileWaves = 4;   // waves cooperating on one 64-env tile (one per SIMD)
+
+// K1.  One workgroup = one 64-env tile, kTileWaves waves: they share the byte->bit transpose
+// (every wave sees all 64 envs, each takes every 4th column batch) and the edge blocks.
 template <typename T, bool VEC, int P>
-__global__ __launch_bounds__(kWave) void k_maxcut_obj(const T* __restrict__ x, int64_t B, int64_t N,
-                                                      const int32_t* __restrict__ eu,
-                                                      const int32_t* __restrict__ ev, int64_t E,
-                                                      int halve, int64_t* __restrict__ obj) {
+__global__ __launch_bounds__(kTileWaves * kWave) void k_maxcut_obj(const T* __restrict__ x, int64_t B, int64_t N,
+                                                                   const int32_t* __restrict__ eu,
+                                                                   const int32_t* __restrict__ ev, int64_t E,
+                                                                   int halve, int64_t* __restrict__ obj) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* words = reinterpret_cast<uint64_t*>(smem);
-    const int lane = threadIdx.x;
+    int64_t* scratch = reinterpret_cast<int64_t*>(words + N);
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     const int64_t b0 = (int64_t)blockIdx.x * kWave;
-    tile_load_bits<T, VEC>(x, B, N, b0, words, lane);
+    tile_load_bits<T, VEC>(x, B, N, b0, words, lane, w, kTileWaves);
     __syncthreads();
-    int64_t total = tile_cut_count<P>(words, eu, ev, E, lane);
+    int64_t total = block_sum_partials<kTileWaves>(tile_cut_count<P>(words, eu, ev, E, lane, w, kTileWaves),
+                                                   scratch, lane, w);
     if (halve) total >>= 1;  // values // 2, env_L2A.py:65 (count is even and >= 0)
-    if (b0 + lane < B) obj[b0 + lane] = total;
+    if (w == 0 && b0 + lane < B) obj[b0 + lane] = total;
 }
 
 // K6: proposal = x ^ mask for 64 envs; accept the row when its cut is >= the incumbent.
 template <bool VEC, int P>
-__global__ __launch_bounds__(kWave) void k_maxcut_propose_accept(uint8_t* __restrict__ x,
-                                                                 const uint8_t* __restrict__ mask,
-                                                                 int64_t B, int64_t N,
-                                                                 const int32_t* __restrict__ eu,
-                                                                 const int32_t* __restrict__ ev, int64_t E,
-                                                                 int halve, int64_t* __restrict__ obj) {
+__global__ __launch_bounds__(kTileWaves * kWave) void k_maxcut_propose_accept(uint8_t* __restrict__ x,
+                                                                              const uint8_t* __restrict__ mask,
+                                                                              int64_t B, int64_t N,
+                                                                              const int32_t* __restrict__ eu,
+                                                                              const int32_t* __restrict__ ev,
+                                                                              int64_t E, int halve,
+                                                                              int64_t* __restrict__ obj) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* words = reinterpret_cast<uint64_t*>(smem);
     uint64_t* mwords = words + N;
-    const int lane = threadIdx.x;
+    int64_t* scratch = reinterpret_cast<int64_t*>(mwords + N);
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     const int64_t b0 = (int64_t)blockIdx.x * kWave;
-    tile_load_bits<uint8_t, VEC>(x, B, N, b0, words, lane);
-    tile_load_bits<uint8_t, VEC>(mask, B, N, b0, mwords, lane);
+    tile_load_bits<uint8_t, VEC>(x, B, N, b0, words, lane, w, kTileWaves);
+    tile_load_bits<uint8_t, VEC>(mask, B, N, b0, mwords, lane, w, kTileWaves);
     __syncthreads();
-    for (int64_t n = lane; n < N; n += kWave) words[n] ^= mwords[n];
+    for (int64_t n = threadIdx.x; n < N; n += kTileWaves * kWave) words[n] ^= mwords[n];
     __syncthreads();
-    int64_t total = tile_cut_count<P>(words, eu, ev, E, lane);
+    int64_t total = block_sum_partials<kTileWaves>(tile_cut_count<P>(words, eu, ev, E, lane, w, kTileWaves),
+                                                   scratch, lane, w);
     if (halve) total >>= 1;
     const int64_t b = b0 + lane;
     const bool accept = (b < B) && (total >= obj[b]);  // vs1.ge(vs0), util_read_data.py:199
-    if (accept) obj[b] = total;
-    // accepted rows take the proposal; others are left untouched
+    __syncthreads();                                   // every wave has read obj[b] before wave 0 updates it
+    if (accept && w == 0) obj[b] = total;
+    // accepted rows take the proposal (each wave writes a quarter of the columns); others are untouched
     if (accept) {
         uint8_t* row = x + b * N;
         const int half = lane >> 5, sh = lane & 31;
         const uint32_t* w32 = reinterpret_cast<const uint32_t*>(words);
         if constexpr (VEC) {
             u32x4* rv = reinterpret_cast<u32x4*>(row);
-            for (int64_t i = 0; i < (N >> 4); ++i) {
+            for (int64_t i = w; i < (N >> 4); i += kTileWaves) {
                 uint32_t d[4] = {0, 0, 0, 0};
 #pragma unroll
                 for (int k = 0; k < 16; ++k)
@@ -58,23 +70,120 @@ __global__ __launch_bounds__(kWave) void k_maxcut_propose_accept(uint8_t* __rest
                 rv[i] = u32x4{d[0], d[1], d[2], d[3]};
             }
         } else {
-            for (int64_t n = 0; n < N; ++n) row[n] = (uint8_t)((w32[(n << 1) + half] >> sh) & 1u);
+            for (int64_t n = w; n < N; n += kTileWaves) row[n] = (uint8_t)((w32[(n << 1) + half] >> sh) & 1u);
         }
     }
 }
 
 // =====================================================================================
-// K5: greedy single-flip sweep.  One lane = one env, 64 envs per wave, state as a bit
-// tile in LDS.  For node i the wave walks i's CSR row (wave-uniform), each lane reads the
-// neighbour's word (broadcast LDS read) and extracts its env's bit.  Node i is flipped in
-// the envs whose gain deg - 2*cutdeg is >= 0 (ties accept).  The flip mask is one ballot.
+// K5: greedy single-flip sweep.  One lane = one env, 64 envs per wave, state as a bit tile in LDS.
+// For node i (sequential, as the reference's semantics demand) every lane counts the set spins
+// among i's neighbours in ITS env: the neighbour id is a broadcast LDS read from a ring of CSR
+// `col` entries, the neighbour's word a second broadcast read, the lane's bit a v_bfe.  Node i is
+// flipped in the envs whose gain is >= 0 (ties accept); the flip mask is one ballot.
+//
+// Nothing on the per-node path touches global memory: rowptr is staged whole in LDS, `col` streams
+// through a 4096-entry LDS ring filled by direct global->LDS loads a quarter ring at a time, at
+// least half a ring ahead of the node being processed (first version: one L2 round trip per node
+// = 1.5 us/node, 3 ms per G22 sweep).
 // =====================================================================================
-template <bool VEC, bool WEIGHTED>
+constexpr int kRing = 4096;            // entries in the col ring (16 KB)
+constexpr int kRefill = kRing / 4;     // entries requested per refill
+constexpr int kSweepMaxDeg = kRing / 4;
+
+__device__ __forceinline__ void glds4(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+}
+
+// request entries [F, F + kRefill) of col into the ring (entries past nnz are skipped)
+__device__ __forceinline__ void ring_refill(const int32_t* __restrict__ col, int64_t nnz, int64_t F,
+                                            int32_t* ring, int lane) {
+#pragma unroll
+    for (int k = 0; k < kRefill / kWave; ++k) {
+        const int64_t e0 = F + (int64_t)k * kWave;
+        if (e0 + lane < nnz) glds4(col + e0 + lane, ring + (e0 & (kRing - 1)));
+    }
+}
+
+template <bool VEC>
 __global__ __launch_bounds__(kWave) void k_maxcut_greedy_sweep(uint8_t* __restrict__ x, int64_t B, int64_t N,
                                                                const int32_t* __restrict__ rowptr,
-                                                               const int32_t* __restrict__ col,
-                                                               const int32_t* __restrict__ wgt,
+                                                               const int32_t* __restrict__ col, int64_t nnz,
                                                                int64_t* __restrict__ obj) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* words = reinterpret_cast<uint64_t*>(smem);
+    int32_t* rp = reinterpret_cast<int32_t*>(smem + (size_t)(N + 2) * 8);
+    int32_t* ring = rp + ((N + 1 + 3) & ~3ll);
+    const int lane = threadIdx.x;
+    const int64_t b0 = (int64_t)blockIdx.x * kWave;
+    if (lane == 0) words[N] = 0;   // sentinel word
+    int64_t F = 0;
+    while (F < nnz && F < kRing / 2 + kRefill) { ring_refill(col, nnz, F, ring, lane); F += kRefill; }
+    for (int64_t i = lane; i <= N; i += kWave) rp[i] = rowptr[i];
+    tile_load_bits<uint8_t, VEC>(x, B, N, b0, words, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int sh = lane & 31;
+    const uint32_t half4 = (uint32_t)(lane >> 5) * 4u;   // byte offset of this lane's dword inside a word
+    const unsigned char* wbytes = smem;
+    int64_t gain = 0;
+    // software pipeline: node i+1's row bounds and this lane's ring entry are fetched while node i runs
+    int r0 = rp[0], r1 = rp[1];
+    const int sentinel = (int)N;   // words[N] == 0
+    int my_nb = (r0 + lane < r1) ? ring[(r0 + lane) & (kRing - 1)] : sentinel;
+    for (int64_t i = 0; i < N; ++i) {
+        if (F < nnz && F - r0 < kRing / 2) {           // wave-uniform; once per ~kRefill entries
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every earlier refill has landed
+            ring_refill(col, nnz, F, ring, lane);
+            F += kRefill;
+        }
+        const int r2 = (i + 2 <= N) ? rp[i + 2] : r1;
+        const int nxt_nb = (r1 + lane < r2) ? ring[(r1 + lane) & (kRing - 1)] : sentinel;
+        const uint32_t xi = (*reinterpret_cast<const uint32_t*>(wbytes + ((uint32_t)i * 8u + half4)) >> sh) & 1u;
+        int acc = 0;   // #neighbours with spin 1 in this lane's env
+        const int deg = r1 - r0;
+        const int first = deg < kWave ? deg : kWave;
+        // 8 neighbours per trip, written out by hand (readlane is convergent: hipcc will not unroll
+        // it, and a rolled loop pays one full LDS round trip per neighbour).  Lanes past the row end
+        // hold the sentinel id N whose word is always zero, so no tail predication is needed.
+        for (int j = 0; j < first; j += 8) {
+            uint32_t w[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t nb = (uint32_t)__builtin_amdgcn_readlane(my_nb, j + k);
+                w[k] = *reinterpret_cast<const uint32_t*>(wbytes + (nb * 8u + half4));
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc += (int)((w[k] >> sh) & 1u);
+        }
+        for (int j = r0 + kWave; j < r1; ++j) {        // hubs: the rest of the row straight from the ring
+            const uint32_t nb = (uint32_t)ring[j & (kRing - 1)];
+            acc += (int)((*reinterpret_cast<const uint32_t*>(wbytes + (nb * 8u + half4)) >> sh) & 1u);
+        }
+        const int same_minus_diff = xi ? (2 * acc - deg) : (deg - 2 * acc);   // sum_j (x_i == x_j ? +1 : -1)
+        const bool flip = same_minus_diff >= 0;
+        gain += flip ? same_minus_diff : 0;
+        const uint64_t fm = ballot64(flip);
+        if (lane == 0) words[i] ^= fm;
+        // one wave: DS ops execute in issue order, so a compiler barrier is all the next node needs
+        asm volatile("" ::: "memory");
+        r0 = r1;
+        r1 = r2;
+        my_nb = nxt_nb;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    tile_store_bytes<VEC>(x, B, N, b0, words, lane);
+    if (b0 + lane < B) obj[b0 + lane] += gain;
+}
+
+// generic fallback (weighted graphs, hubs with degree > kSweepMaxDeg): one global row fetch per node
+template <bool VEC, bool WEIGHTED>
+__global__ __launch_bounds__(kWave) void k_maxcut_greedy_sweep_generic(uint8_t* __restrict__ x, int64_t B, int64_t N,
+                                                                       const int32_t* __restrict__ rowptr,
+                                                                       const int32_t* __restrict__ col,
+                                                                       const int32_t* __restrict__ wgt,
+                                                                       int64_t* __restrict__ obj) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* words = reinterpret_cast<uint64_t*>(smem);
     const uint32_t* w32 = reinterpret_cast<const uint32_t*>(smem);
@@ -250,13 +359,13 @@ int rls_maxcut_obj(const rls_graph* g, const void* x, int spin_bytes, int64_t B,
     RLS_REQUIRE(x && obj, RLS_EINVAL, "x/obj is NULL");
     RLS_REQUIRE(spin_bytes == 1 || spin_bytes == 4, RLS_EINVAL, "spin_bytes must be 1 or 4");
     const int64_t N = g->num_nodes, E = g->num_stored_edges;
-    const size_t lds = (size_t)N * 8;
+    const size_t lds = (size_t)N * 8 + (size_t)kTileWaves * kWave * 8;
     RLS_REQUIRE(lds <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS per 64-env tile (max %d)",
                 (long long)N, lds, kLdsBytes);
     const int P = pick_planes(E);
     RLS_REQUIRE(P != 0, RLS_EUNSUPPORTED, "E'=%lld too large", (long long)E);
     const bool vec = rows_vec_aligned(x, N, spin_bytes);
-    const dim3 grid((unsigned)ceil_div(B, kWave)), block(kWave);
+    const dim3 grid((unsigned)ceil_div(B, kWave)), block(kTileWaves * kWave);
     hipStream_t s = as_stream(stream);
     const int halve = g->if_bidirectional ? 1 : 0;
 #define LAUNCH_OBJ(T, VEC, PP)                                                                             \
@@ -290,13 +399,13 @@ int rls_maxcut_propose_accept(const rls_graph* g, uint8_t* x, int64_t B, const u
     if (B == 0) return RLS_OK;
     RLS_REQUIRE(x && mask && obj, RLS_EINVAL, "x/mask/obj is NULL");
     const int64_t N = g->num_nodes, E = g->num_stored_edges;
-    const size_t lds = (size_t)N * 16;
+    const size_t lds = (size_t)N * 16 + (size_t)kTileWaves * kWave * 8;
     RLS_REQUIRE(lds <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS (max %d)", (long long)N, lds,
                 kLdsBytes);
     const int P = pick_planes(E);
     RLS_REQUIRE(P != 0, RLS_EUNSUPPORTED, "E'=%lld too large", (long long)E);
     const bool vec = rows_vec_aligned(x, N, 1) && rows_vec_aligned(mask, N, 1);
-    const dim3 grid((unsigned)ceil_div(B, kWave)), block(kWave);
+    const dim3 grid((unsigned)ceil_div(B, kWave)), block(kTileWaves * kWave);
     hipStream_t s = as_stream(stream);
     const int halve = g->if_bidirectional ? 1 : 0;
 #define LAUNCH_PA(VEC, PP)                                                                                 \
@@ -325,15 +434,30 @@ int rls_maxcut_greedy_sweep(const rls_graph* g, uint8_t* x, int64_t B, int64_t* 
     if (B == 0) return RLS_OK;
     RLS_REQUIRE(x && obj, RLS_EINVAL, "x/obj is NULL");
     const int64_t N = g->num_nodes;
-    const size_t lds = (size_t)N * 8;
-    RLS_REQUIRE(lds <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS (max %d)", (long long)N, lds,
-                kLdsBytes);
     const bool vec = rows_vec_aligned(x, N, 1);
     const dim3 grid((unsigned)ceil_div(B, kWave)), block(kWave);
     hipStream_t s = as_stream(stream);
+    const size_t lds_fast = (size_t)(N + 2) * 8 + (size_t)((N + 1 + 3) & ~3ll) * 4 + (size_t)kRing * 4;
+    const bool fast = !g->wgt && g->max_degree <= kSweepMaxDeg && lds_fast <= (size_t)kLdsBytes &&
+                      (((uintptr_t)g->col) & 3) == 0;
+    if (fast) {
+#define LAUNCH_SWF(VEC)                                                                                    \
+    do {                                                                                                   \
+        auto kern = k_maxcut_greedy_sweep<VEC>;                                                            \
+        if (lds_fast > 64 * 1024)                                                                          \
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fast); \
+        hipLaunchKernelGGL(kern, grid, block, lds_fast, s, x, B, N, g->rowptr, g->col, g->nnz, obj);       \
+    } while (0)
+        if (vec) LAUNCH_SWF(true); else LAUNCH_SWF(false);
+#undef LAUNCH_SWF
+        return check_launch("k_maxcut_greedy_sweep");
+    }
+    const size_t lds = (size_t)N * 8;
+    RLS_REQUIRE(lds <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS (max %d)", (long long)N, lds,
+                kLdsBytes);
 #define LAUNCH_SW(VEC, W)                                                                                  \
     do {                                                                                                   \
-        auto kern = k_maxcut_greedy_sweep<VEC, W>;                                                         \
+        auto kern = k_maxcut_greedy_sweep_generic<VEC, W>;                                                 \
         if (lds > 64 * 1024)                                                                               \
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(kern, grid, block, lds, s, x, B, N, g->rowptr, g->col, g->wgt, obj);            \
@@ -341,7 +465,7 @@ int rls_maxcut_greedy_sweep(const rls_graph* g, uint8_t* x, int64_t B, int64_t* 
     if (g->wgt) { if (vec) LAUNCH_SW(true, true); else LAUNCH_SW(false, true); }
     else        { if (vec) LAUNCH_SW(true, false); else LAUNCH_SW(false, false); }
 #undef LAUNCH_SW
-    return check_launch("k_maxcut_greedy_sweep");
+    return check_launch("k_maxcut_greedy_sweep_generic");
 }
 
 int rls_maxcut_edge_cut_mask(const rls_graph* g, const uint8_t* x, int64_t B, uint8_t* cutmask, void* stream) {

@@ -197,12 +197,36 @@ __global__ __launch_bounds__(256) void k_maxcut_step(const T* __restrict__ xin, 
                 const int64_t i = base + lane;
                 if (i < nvec) glds16(src + i, stage_v + base);  // LDS dst = wave base + lane*16
             }
+            // while the rows fly: CSR row bounds (scalar loads) and this lane's neighbour id / weight
+            int r0[EPW], deg[EPW], nb[EPW], wv[EPW];
+#pragma unroll
+            for (int k = 0; k < EPW; ++k) {
+                r0[k] = 0; deg[k] = 0; nb[k] = 0; wv[k] = 0;
+                if (k < nenv) {
+                    r0[k] = rowptr[act[k]];
+                    deg[k] = rowptr[act[k] + 1] - r0[k];
+                    if (lane < deg[k]) {
+                        nb[k] = col[r0[k] + lane];
+                        if constexpr (WEIGHTED) wv[k] = wgt[r0[k] + lane];
+                    }
+                }
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int k = 0; k < EPW; ++k)
                 if (k < nenv) {
-                    const int d = flip_gain<T, WEIGHTED>(stage + (int64_t)k * N, act[k], rowptr, col, wgt, lane);
+                    const T* row = stage + (int64_t)k * N;
+                    const bool xa = spin_is_set(row[act[k]]);
+                    int d;
+                    if (deg[k] <= kWave) {
+                        const bool on = lane < deg[k];
+                        const bool xn = on ? spin_is_set(row[nb[k]]) : xa;
+                        if constexpr (WEIGHTED) d = wave_sum_i32(on ? ((xn == xa) ? wv[k] : -wv[k]) : 0);
+                        else d = deg[k] - 2 * __popcll(ballot64(xn != xa));
+                    } else {
+                        d = flip_gain<T, WEIGHTED>(row, act[k], rowptr, col, wgt, lane);
+                    }
                     if (lane == k) my_delta = d;
                 }
             publish();
@@ -241,11 +265,16 @@ extern "C" int rls_maxcut_step(const rls_graph* g, const void* x_in, void* x_out
     RLS_REQUIRE(spin_bytes == 1 || spin_bytes == 4, RLS_EINVAL, "spin_bytes must be 1 or 4");
     const int64_t N = g->num_nodes;
     const bool emit = (x_in != x_out);
-    constexpr int EPW = 4;
+    RLS_REQUIRE(!emit || (const char*)x_in + (size_t)B * N * spin_bytes <= (const char*)x_out ||
+                    (const char*)x_out + (size_t)B * N * spin_bytes <= (const char*)x_in,
+                RLS_EINVAL, "x_in and x_out overlap partially");
     // flat runs of EPW rows start 16-byte aligned when one row is a multiple of 16 bytes
     const bool vec = rows_vec_aligned(x_in, N, spin_bytes) && rows_vec_aligned(x_out, N, spin_bytes);
-    const int waves_per_block = 4;
-    const dim3 grid((unsigned)ceil_div(ceil_div(B, EPW), waves_per_block)), block(waves_per_block * kWave);
+    const char* e_epw = getenv("RLS_STEP_EPW");
+    const char* e_wpb = getenv("RLS_STEP_WPB");
+    const int epw = e_epw ? atoi(e_epw) : 4;
+    const int waves_per_block = e_wpb ? atoi(e_wpb) : 4;
+    const dim3 grid((unsigned)ceil_div(ceil_div(B, epw), waves_per_block)), block(waves_per_block * kWave);
     hipStream_t s = as_stream(stream);
     const bool weighted = g->wgt != nullptr;
     // mode: units = structure (0/1/2), tens = nontemporal loads, hundreds = nontemporal stores
@@ -254,13 +283,20 @@ extern "C" int rls_maxcut_step(const rls_graph* g, const void* x_in, void* x_out
     const bool ntl = (mode / 10) % 10, nts = (mode / 100) % 10;
     size_t lds = 0;
     if (structure == 2) {
-        lds = (size_t)waves_per_block * EPW * N * spin_bytes;
+        lds = (size_t)waves_per_block * epw * N * spin_bytes;
         if (lds > 64 * 1024) { structure = 1; lds = 0; }  // rows too long to stage: register path
     }
 
-#define LAUNCH_STEP(T, MODE, EMIT, VEC, W, NTL, NTS)                                                          \
+#define LAUNCH_STEP_E(T, EPW, MODE, EMIT, VEC, W, NTL, NTS)                                                    \
     hipLaunchKernelGGL((k_maxcut_step<T, EPW, MODE, EMIT, VEC, W, NTL, NTS>), grid, block, lds, s, (const T*)x_in, \
                        (T*)x_out, B, N, g->rowptr, g->col, g->wgt, action, obj, reward, cur, done, done_value)
+#define LAUNCH_STEP(T, MODE, EMIT, VEC, W, NTL, NTS)                           \
+    do {                                                                       \
+        if (epw == 2) LAUNCH_STEP_E(T, 2, MODE, EMIT, VEC, W, NTL, NTS);       \
+        else if (epw == 8) LAUNCH_STEP_E(T, 8, MODE, EMIT, VEC, W, NTL, NTS);  \
+        else if (epw == 1) LAUNCH_STEP_E(T, 1, MODE, EMIT, VEC, W, NTL, NTS);  \
+        else LAUNCH_STEP_E(T, 4, MODE, EMIT, VEC, W, NTL, NTS);                \
+    } while (0)
 #define DISPATCH_NT(T, MODE, W)                                                    \
     do {                                                                           \
         if (ntl && nts) LAUNCH_STEP(T, MODE, true, true, W, true, true);           \
@@ -294,5 +330,6 @@ extern "C" int rls_maxcut_step(const rls_graph* g, const void* x_in, void* x_out
 #undef DISPATCH_MODE
 #undef DISPATCH_NT
 #undef LAUNCH_STEP
+#undef LAUNCH_STEP_E
     return check_launch("k_maxcut_step");
 }

@@ -49,32 +49,42 @@ __device__ __forceinline__ uint64_t ballot64(bool p) { return __ballot(p); }
 
 // Load the tile of envs [b0, b0+64) x nodes [0, N) into words[0..N).
 // VEC = true requires row starts to be 16-byte aligned (x aligned and N * sizeof(T) % 16 == 0).
+// W waves of one workgroup may share the job (wave w of W takes every W-th batch of columns); every
+// wave sees all 64 envs, so each ballot still yields a complete word.  Callers sync afterwards.
 template <typename T, bool VEC>
 __device__ __forceinline__ void tile_load_bits(const T* __restrict__ x, int64_t B, int64_t N, int64_t b0,
-                                               uint64_t* __restrict__ words, int lane) {
+                                               uint64_t* __restrict__ words, int lane, int w = 0, int W = 1) {
     const int64_t b = b0 + lane;
     const bool valid = b < B;
     const T* row = x + (valid ? b : 0) * N;
     if constexpr (VEC && sizeof(T) == 1) {
         const u32x4* rv = reinterpret_cast<const u32x4*>(row);
         const int64_t nv = N >> 4;
-#pragma unroll 2
-        for (int64_t i = 0; i < nv; ++i) {
-            u32x4 v = valid ? rv[i] : u32x4{0, 0, 0, 0};
-            const uint32_t d[4] = {v[0], v[1], v[2], v[3]};
-            uint64_t mine = 0;
+        constexpr int DEPTH = 8;  // row loads in flight per lane (the loop is latency-bound otherwise)
+        for (int64_t i0 = (int64_t)w * DEPTH; i0 < nv; i0 += (int64_t)W * DEPTH) {
+            u32x4 v[DEPTH];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                uint64_t w = ballot64(((d[k >> 2] >> ((k & 3) * 8)) & 0xffu) != 0);
-                if (lane == k) mine = w;
+            for (int q = 0; q < DEPTH; ++q)
+                v[q] = (valid && i0 + q < nv) ? rv[i0 + q] : u32x4{0, 0, 0, 0};
+#pragma unroll
+            for (int q = 0; q < DEPTH; ++q) {
+                if (i0 + q < nv) {
+                    const uint32_t d[4] = {v[q][0], v[q][1], v[q][2], v[q][3]};
+                    uint64_t mine = 0;
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) {
+                        uint64_t w = ballot64(((d[k >> 2] >> ((k & 3) * 8)) & 0xffu) != 0);
+                        if (lane == k) mine = w;
+                    }
+                    if (lane < 16) words[((i0 + q) << 4) + lane] = mine;
+                }
             }
-            if (lane < 16) words[(i << 4) + lane] = mine;
         }
     } else if constexpr (VEC && sizeof(T) == 4) {
         const f32x4* rv = reinterpret_cast<const f32x4*>(row);
         const int64_t nv = N >> 2;
 #pragma unroll 4
-        for (int64_t i = 0; i < nv; ++i) {
+        for (int64_t i = w; i < nv; i += W) {
             f32x4 v = valid ? rv[i] : f32x4{0.f, 0.f, 0.f, 0.f};
             const float d[4] = {v[0], v[1], v[2], v[3]};
             uint64_t mine = 0;
@@ -86,7 +96,7 @@ __device__ __forceinline__ void tile_load_bits(const T* __restrict__ x, int64_t 
             if (lane < 4) words[(i << 2) + lane] = mine;
         }
     } else {
-        for (int64_t n0 = 0; n0 < N; n0 += 64) {
+        for (int64_t n0 = (int64_t)w * 64; n0 < N; n0 += (int64_t)W * 64) {
             uint64_t mine = 0;
             const int lim = (int)((N - n0) < 64 ? (N - n0) : 64);
             for (int k = 0; k < lim; ++k) {
@@ -102,7 +112,7 @@ __device__ __forceinline__ void tile_load_bits(const T* __restrict__ x, int64_t 
 // Write the tile back as env-major bytes (uint8 0|1).
 template <bool VEC>
 __device__ __forceinline__ void tile_store_bytes(uint8_t* __restrict__ x, int64_t B, int64_t N, int64_t b0,
-                                                 const uint64_t* __restrict__ words, int lane) {
+                                                 const uint64_t* __restrict__ words, int lane, int w = 0, int W = 1) {
     const int64_t b = b0 + lane;
     if (b >= B) return;
     uint8_t* row = x + b * N;
@@ -111,7 +121,7 @@ __device__ __forceinline__ void tile_store_bytes(uint8_t* __restrict__ x, int64_
     if constexpr (VEC) {
         u32x4* rv = reinterpret_cast<u32x4*>(row);
         const int64_t nv = N >> 4;
-        for (int64_t i = 0; i < nv; ++i) {
+        for (int64_t i = w; i < nv; i += W) {
             uint32_t d[4] = {0, 0, 0, 0};
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
@@ -121,7 +131,7 @@ __device__ __forceinline__ void tile_store_bytes(uint8_t* __restrict__ x, int64_
             rv[i] = u32x4{d[0], d[1], d[2], d[3]};
         }
     } else {
-        for (int64_t n = 0; n < N; ++n) row[n] = (uint8_t)((w32[(n << 1) + half] >> sh) & 1u);
+        for (int64_t n = w; n < N; n += W) row[n] = (uint8_t)((w32[(n << 1) + half] >> sh) & 1u);
     }
 }
 

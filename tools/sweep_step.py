@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""A/B the step kernel's development knobs in one process (interleaved rounds; guide rule 24)."""
+import itertools, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from rlsolver_amd import ops
+from rlsolver_amd.graph import build_csr, generate_gnm
+
+n, m, B, S = 2000, 19990, 65536, 8
+dev = torch.device("cuda:0")
+g = ops.DeviceGraph(build_csr(generate_gnm(n, m, 22), num_nodes=n), dev)
+x = ops.rand_spins(B, n, 1, dev)
+slots = [torch.empty_like(x) for _ in range(S)]
+slots[0].copy_(x)
+obj = ops.maxcut_obj(g, x).to(torch.int32)
+reward = torch.empty(B, dtype=torch.float32, device=dev)
+acts = [ops.rand_actions(B, n, 7, s, dev) for s in range(16)]
+
+
+def timeit(iters=200):
+    for i in range(5):
+        ops.maxcut_step(g, slots[i % S], slots[(i + 1) % S], acts[i % 16], obj, reward)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(iters):
+        ops.maxcut_step(g, slots[i % S], slots[(i + 1) % S], acts[i % 16], obj, reward)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+configs = [dict(RLS_STEP_MODE=str(md), RLS_STEP_EPW=str(e), RLS_STEP_WPB=str(w))
+           for md, e, w in itertools.product(os.environ.get("SW_MODES", "2").split(","),
+                                             os.environ.get("SW_EPW", "1,2,4,8").split(","),
+                                             os.environ.get("SW_WPB", "1,2,4").split(","))]
+res = {i: [] for i in range(len(configs))}
+for rep in range(3):
+    for i, c in enumerate(configs):
+        os.environ.update(c)
+        try:
+            res[i].append(timeit())
+        except Exception as ex:
+            res[i].append(float("nan"))
+by = B * (2 * n + 20)
+for i, c in enumerate(configs):
+    t = min(res[i])
+    print(f"{c}: best {t*1e6:7.1f} us  med {sorted(res[i])[1]*1e6:7.1f} us  {by/t/8e12*100:5.1f}% of 8 TB/s")
