@@ -183,6 +183,15 @@ int rls_mcpg_pick_best(const float* expected, const float* xs, int64_t N, int64_
                        int64_t repeat_times, int64_t num_edges, int64_t* best_index, float* vs_good,
                        float* xs_good, void* stream);
 
+/* K11 mcpg_sampling_qubo / mcpg_sampling_qubo_bin  methods/MCPG/sampling.py:323-370 (after the
+ * metro step): num_ls Gauss-Seidel sweeps  x_i <- [Q[i,:] . x (x_i := 0) > thr_i]  over variables in
+ * index order, then value[c] = x^T Q x.  binary = 0: spins +-1, thr = 0 (:332-340); binary = 1:
+ * spins 0|1, thr = -Q_ii / 2 (:357-365).  Q f32 [n,n] dense; xs_in/xs_out f32 [n,C] node-major holding
+ * 0|1 (the +-1 variant maps 0 -> -1 internally and returns (s+1)/2 as the reference does).
+ * Exact for integer-valued Q (f32 sums order-independent below 2^24). */
+int rls_qubo_local_search_value(const float* Q, int64_t n, const float* xs_in, float* xs_out, int64_t C,
+                                int64_t num_ls, int binary, float* value, void* stream);
+
 /* --------------------------------------------------------------------- TSP */
 
 /* K12 ISCO_TSP.calculate_distance(sample)  envs/env_ISCO.py:346-350.

@@ -1,0 +1,69 @@
+"""QUBO samplers of the upstream MCPG package -- drop-in for
+rlsolver/methods/MCPG/sampling.py:323-370 (mcpg_sampling_qubo, mcpg_sampling_qubo_bin) and the
+loader rlsolver/methods/MCPG/dataloader.py:278-294, on HIP tensors."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .. import _abi
+from ..ops import _check, _ptr, _stream
+from .MCPG import metro_sampling
+
+TEN = torch.Tensor
+
+
+def qubo_dataloader(filename, device):
+    """Comma-separated dense matrix rows -> {'Q': f32 [n, n], 'nvar': n} (dataloader.py:278-294)."""
+    rows = []
+    with open(filename, "r", encoding="utf-8") as f:
+        for line in f:
+            vals = [v for v in line.replace(" ", "").strip().split(",") if v]
+            if not vals:
+                break
+            rows.append([float(v) for v in vals])
+    Q = torch.tensor(np.asarray(rows, dtype=np.float64)).float().to(device)
+    return {"Q": Q, "nvar": Q.shape[0]}, Q.shape[0]
+
+
+def qubo_local_search_value(Q: TEN, xs: TEN, num_ls: int, binary: bool):
+    _check(Q, "Q", (torch.float32,))
+    dev = Q.device
+    n = Q.shape[0]
+    if Q.shape != (n, n):
+        raise ValueError("Q must be square")
+    _check(xs, "xs", (torch.float32,), dev)
+    if xs.dim() != 2 or xs.shape[0] != n:
+        raise ValueError(f"xs must be [{n}, C]")
+    Cc = xs.shape[1]
+    out = torch.empty_like(xs)
+    value = torch.empty(Cc, dtype=torch.float32, device=dev)
+    _abi.call("rls_qubo_local_search_value", _ptr(Q), n, _ptr(xs), _ptr(out), Cc, num_ls, int(bool(binary)),
+              _ptr(value), _stream(dev))
+    return out, value
+
+
+def _sample(data, start_result, probs, num_ls, change_times, total_mcmc_num, device, binary, index, u):
+    Q = data['Q'].to(device=device, dtype=torch.float32).contiguous()
+    raw_samples = metro_sampling(probs, start_result.clone(), change_times, device, index=index, u=u)
+    samples, res_sample = qubo_local_search_value(Q, raw_samples.contiguous(), num_ls, binary)
+    res_reshape = res_sample.reshape(-1, total_mcmc_num)
+    idx = torch.argmax(res_reshape, dim=0)
+    idx = torch.arange(total_mcmc_num, device=res_sample.device) + idx * total_mcmc_num
+    max_res = res_sample[idx]
+    return max_res, samples[:, idx], raw_samples, -(res_sample - torch.mean(res_sample.float()))
+
+
+def mcpg_sampling_qubo(data, start_result, probs, num_ls, change_times, total_mcmc_num, device=None,
+                       index: Optional[TEN] = None, u: Optional[TEN] = None):
+    device = start_result.device if device is None else torch.device(device)
+    return _sample(data, start_result, probs, num_ls, change_times, total_mcmc_num, device, False, index, u)
+
+
+def mcpg_sampling_qubo_bin(data, start_result, probs, num_ls, change_times, total_mcmc_num, device=None,
+                           index: Optional[TEN] = None, u: Optional[TEN] = None):
+    device = start_result.device if device is None else torch.device(device)
+    return _sample(data, start_result, probs, num_ls, change_times, total_mcmc_num, device, True, index, u)

@@ -453,7 +453,91 @@ def gen_weighted_gain():
          cut=np.asarray(cuts, dtype=np.int64), gain=np.asarray(gains, dtype=np.int64))
 
 
-ALL = {"maxcut": gen_maxcut, "sweep": gen_sweep, "lsclass": gen_local_search_class, "ppo": gen_ppo,
+def gen_isco_maxcut():
+    """ISCO_maxcut.model / get_local_dist (envs/env_ISCO.py:51-63,79-86): energy = #cut / T and the
+    log-softmax of the all-node flip score (autograd of the energy in the reference)."""
+    import rlsolver.envs.env_ISCO as env_isco
+    from rlsolver.methods.util_read_data import read_mygraph
+    out = {}
+    for gname in ("BA_100_ID0", "PL_20_ID0"):
+        mygraph = read_mygraph(os.path.join(DATA, GRAPHS[gname]))
+        g = graph_arrays(mygraph)
+        n = int(g[:, :2].max()) + 1
+        out[f"{gname}/graph"] = g
+        B = 12
+        env_isco.BATCH_SIZE = B
+        params = {"num_nodes": n, "num_edges": len(g), "edge_from": th.from_numpy(g[:, 0].copy()),
+                  "edge_to": th.from_numpy(g[:, 1].copy())}
+        s = env_isco.ISCO_maxcut(params)
+        th.manual_seed(5)
+        x = s.random_gen_init_sample(params)
+        for T in (1.0, 0.37):
+            energy, logp = s.get_local_dist(x, th.tensor(T))
+            out[f"{gname}/T{T}/energy"] = energy.numpy().copy()
+            out[f"{gname}/T{T}/log_prob"] = logp.numpy().copy()
+        out[f"{gname}/x"] = u8(x)
+        out[f"{gname}/x_dtype"] = np.array(str(x.dtype))
+    save("isco_maxcut", **out)
+
+
+def gen_qubo():
+    """mcpg_sampling_qubo / _qubo_bin of rlsolver/methods/MCPG/sampling.py:323-370 on nbiq_5 and on a
+    seeded integer Q (n = 24, nbiq-style: symmetric, 80 % dense, entries +-[10, 100]); rand/randint
+    draws of the embedded metro_sampling recorded."""
+    ts = types.ModuleType("torch_scatter")
+    ts.scatter = lambda *a, **k: (_ for _ in ()).throw(NotImplementedError("MaxSAT only"))
+    sys.modules.setdefault("torch_scatter", ts)
+    pkg = os.path.join(REF, "rlsolver", "methods", "MCPG")
+    saved_cfg = sys.modules.pop("config", None)
+    sys.path.insert(0, pkg)
+    try:
+        spec = importlib.util.spec_from_file_location("ref_mcpg_sampling", os.path.join(pkg, "sampling.py"))
+        smp = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(smp)
+    finally:
+        sys.path.remove(pkg)
+        sys.modules.pop("config", None)
+        if saved_cfg is not None:
+            sys.modules["config"] = saved_cfg
+    out = {}
+    rows = [[float(v) for v in line.replace(" ", "").strip().strip(",").split(",")]
+            for line in open(os.path.join(DATA, "qubo", "nbiq_5.txt")) if line.strip()]
+    rng = np.random.RandomState(24)
+    n = 24
+    Q = np.zeros((n, n))
+    for i in range(n):
+        for j in range(i, n):
+            if rng.rand() < 0.8:
+                v = rng.randint(10, 101) * (1 if rng.rand() < 0.5 else -1)
+                Q[i, j] = Q[j, i] = v
+    cases = {"nbiq_5": np.asarray(rows, dtype=np.float64), "rand_24": Q}
+    for name, Qn in cases.items():
+        nvar = Qn.shape[0]
+        data = {"Q": th.tensor(Qn).float(), "nvar": nvar}
+        M, R, num_ls = 6, 4, 2
+        C = M * R
+        g = th.Generator().manual_seed(77)
+        probs = th.rand(nvar, generator=g) * 0.6 + 0.2
+        start = th.randint(0, 2, (nvar, C), generator=g).float()
+        change_times = max(1, nvar // 10)
+        out[f"{name}/Q"] = data["Q"].numpy().copy()
+        out[f"{name}/probs"] = probs.numpy().copy()
+        out[f"{name}/start"] = u8(start)
+        out[f"{name}/change_times"] = np.int64(change_times)
+        out[f"{name}/M"], out[f"{name}/R"], out[f"{name}/num_ls"] = np.int64(M), np.int64(R), np.int64(num_ls)
+        for mode, fn in (("pm1", smp.mcpg_sampling_qubo), ("bin", smp.mcpg_sampling_qubo_bin)):
+            with Recorder("rand", "randint") as rec:
+                max_res, best, raw, value = fn(data, start.clone(), probs, num_ls, change_times, M, device=th.device("cpu"))
+            out[f"{name}/{mode}/index"] = th.stack(rec.log["randint"]).numpy().copy()
+            out[f"{name}/{mode}/u"] = th.stack(rec.log["rand"]).numpy().copy()
+            out[f"{name}/{mode}/max_res"] = max_res.numpy().copy()
+            out[f"{name}/{mode}/best"] = best.numpy().copy()
+            out[f"{name}/{mode}/raw"] = u8(raw)
+            out[f"{name}/{mode}/value"] = value.numpy().copy()
+    save("qubo", **out)
+
+
+ALL = {"qubo": gen_qubo, "isco_maxcut": gen_isco_maxcut, "maxcut": gen_maxcut, "sweep": gen_sweep, "lsclass": gen_local_search_class, "ppo": gen_ppo,
        "select": gen_select, "mcpg": gen_mcpg, "tsp": gen_tsp, "encoder": gen_encoder,
        "wgain": gen_weighted_gain}
 
