@@ -144,6 +144,28 @@ int rls_rand_spins(uint8_t* x, int64_t B, int64_t N, uint64_t seed, int64_t env_
 int rls_rand_actions(int64_t* action, int64_t B, int64_t N, uint64_t seed, uint64_t step,
                      int64_t env_offset, void* stream);
 
+/* ----------------------------------------------------- S2V / ECO / PECO spin system */
+
+/* Gains of all single flips from signed f32 spins: delta[b,i] = s_i * sum_j W_ij s_j, s = state[b,0,:]
+ * in {+1,-1}  (_get_immeditate_cuts_avaialable, ECO_S2V/src/envs/spinsystem_PECO.py:660-661, a dense
+ * matmul there).  state f32 [B, num_rows, N]; delta int32 [B, N]. */
+int rls_spin_delta_init(const rls_graph* g, const float* state, int64_t B, int32_t num_rows, int32_t* delta,
+                        void* stream);
+
+/* One env step of SpinSystemUnbiased  ECO_S2V/src/envs/spinsystem_PECO.py:306-486 on a shared graph:
+ * flip action[b]; gain = delta[b,a]; incremental update of delta (O(deg), cf. S2V_PPO/env.py:197-206);
+ * score += gain; reward (mode 0 DENSE = gain, 1 BLS = max(score - best_before, 0), 2 CUSTOM_BLS =
+ * impr / (impr + 0.1)), divided by reward_div (n_spins under norm_rewards, else 1); best_score /
+ * best_spins tracking; observable rows of state written in place.  row_index [host] int32[7] gives the
+ * row of IMMEDIATE_REWARD_AVAILABLE, TIME_SINCE_FLIP, EPISODE_TIME, TERMINATION_IMMANENCY,
+ * NUMBER_OF_GREEDY_ACTIONS_AVAILABLE, DISTANCE_FROM_BEST_SCORE, DISTANCE_FROM_BEST_STATE in state
+ * (-1 = not observed; row 0 is always the signed spins).  num_nonpos[b] = #{i : delta[b,i] <= 0}
+ * (the basin test of :392-397).  g->wgt = integer weights or NULL. */
+int rls_spin_step(const rls_graph* g, float* state, int64_t B, int32_t num_rows, const int32_t* row_index,
+                  int32_t* delta, const int64_t* action, float* score, float* best_score, float* best_spins,
+                  float* reward, int32_t* num_nonpos, float max_local, float time_inc, float termination_value,
+                  int32_t reward_mode, float reward_div, void* stream);
+
 /* -------------------------------------------------------------------- MCPG */
 /* Layout: node-major x[N, C] as in the reference (chains are the fast axis); spin_bytes = 4
  * (float32 0.0|1.0, what metro_sampling returns) or 1 (uint8). */

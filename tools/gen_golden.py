@@ -537,7 +537,73 @@ def gen_qubo():
     save("qubo", **out)
 
 
-ALL = {"qubo": gen_qubo, "isco_maxcut": gen_isco_maxcut, "maxcut": gen_maxcut, "sweep": gen_sweep, "lsclass": gen_local_search_class, "ppo": gen_ppo,
+def gen_spinsystem():
+    """The batched PECO SpinSystem (ECO_S2V/src/envs/spinsystem_PECO.py) driven with ONE shared
+    +-1-weighted graph for every env (a generator stub returning W.expand(B, N, N)), two configs:
+    ECO (BLS reward, normalised, basin reward) and dense reward.  Actions drawn from a seeded
+    generator; the 7 observable rows, reward, done, score and best score recorded per step."""
+    from rlsolver.methods.ECO_S2V.src.envs import spinsystem_PECO as sp
+    from rlsolver.methods.ECO_S2V.src.envs.util_envs import (ECO_PECO_OBSERVABLES, ExtraAction, OptimisationTarget,
+                                                             RewardSignal, SpinBasis)
+    from rlsolver.methods.util_read_data import read_mygraph
+    out = {}
+    for gname in ("PL_20_ID0", "BA_100_ID0"):
+        mygraph = read_mygraph(os.path.join(DATA, GRAPHS[gname]))
+        n = max(max(a, b) for a, b, _ in mygraph) + 1
+        rng = np.random.RandomState(41)
+        wl = [(a, b, int(rng.choice([-1, 1]))) for a, b, _ in mygraph]
+        W = np.zeros((n, n), dtype=np.float32)
+        for a, b, w in wl:
+            W[a, b] = W[b, a] = w
+        out[f"{gname}/graph"] = np.asarray(wl, dtype=np.int64)
+        B = 6
+
+        class SharedGraph:
+            n_spins = n
+            biased = False
+
+            def get(self, with_padding=False):
+                return th.from_numpy(W)[None].expand(B, n, n).clone()
+
+        cfgs = {"eco": dict(reward_signal=RewardSignal.BLS, norm_rewards=True, basin_reward=1.0 / n),
+                "dense": dict(reward_signal=RewardSignal.DENSE, norm_rewards=False, basin_reward=None)}
+        for cname, cfg in cfgs.items():
+            th.manual_seed(3)
+            max_steps = 2 * n if n <= 20 else 40
+            env = sp.SpinSystemFactory.get(SharedGraph(), max_steps, observables=ECO_PECO_OBSERVABLES,
+                                           extra_action=ExtraAction.NONE, optimisation_target=OptimisationTarget.CUT,
+                                           spin_basis=SpinBasis.BINARY, memory_length=None, horizon_length=None,
+                                           stag_punishment=None, reversible_spins=True, device=th.device("cpu"),
+                                           num_envs=B, **cfg)
+            tag = f"{gname}/{cname}"
+            out[f"{tag}/max_steps"] = np.int64(max_steps)
+            out[f"{tag}/spins0"] = env.state[:, 0, :].numpy().copy()
+            out[f"{tag}/obs0"] = env.get_observation()[:, :7, :].numpy().copy()
+            out[f"{tag}/score0"] = env.score.numpy().copy()
+            out[f"{tag}/max_local"] = env.max_local_reward_available_.numpy().copy()
+            g = th.Generator().manual_seed(9)
+            acts, obs, rews, dones, scores, bests = [], [], [], [], [], []
+            for t in range(max_steps):
+                a = th.randint(0, n, (B,), generator=g)
+                if t % 7 == 3:
+                    a[:] = a[0]
+                o, r, d = env.step(a)
+                acts.append(a.numpy().copy()); obs.append(o[:, :7, :].numpy().copy()); rews.append(r.numpy().copy())
+                dones.append(d.numpy().copy()); scores.append(env.score.numpy().copy())
+                bests.append(env.best_score.numpy().copy())
+            assert o.shape == (B, 7 + n, n)
+            out[f"{tag}/adj_rows"] = o[0, 7:, :].numpy().copy()
+            out[f"{tag}/actions"] = np.stack(acts)
+            out[f"{tag}/obs"] = np.stack(obs)
+            out[f"{tag}/rew"] = np.stack(rews)
+            out[f"{tag}/done"] = np.stack(dones)
+            out[f"{tag}/score"] = np.stack(scores)
+            out[f"{tag}/best_score"] = np.stack(bests)
+            out[f"{tag}/best_spins"] = env.best_spins.numpy().copy()
+    save("spinsystem", **out)
+
+
+ALL = {"spinsystem": gen_spinsystem, "qubo": gen_qubo, "isco_maxcut": gen_isco_maxcut, "maxcut": gen_maxcut, "sweep": gen_sweep, "lsclass": gen_local_search_class, "ppo": gen_ppo,
        "select": gen_select, "mcpg": gen_mcpg, "tsp": gen_tsp, "encoder": gen_encoder,
        "wgain": gen_weighted_gain}
 
