@@ -193,10 +193,15 @@ int rls_mcpg_metro_rounds(void* samples, int spin_bytes, int64_t N, int64_t C, c
  *     x[node,c] = (s + u * 0.25f) < (deg(node) + 0.25f) / 2
  * with u = uniforms[pass, pos, c] (f32 [num_ls,N,C], the torch.rand draws in visiting order; NULL =
  * in-kernel Philox).  Then expected[c] = sum_e (2x_u - 1)(2x_v - 1) over the stored edge list
- * (= E - 2*cut, exact in f32).  Outputs xs_out f32 [N,C] (0|1) and expected f32 [C]. */
+ * (= E - 2*cut, exact in f32).  Outputs xs_out f32 [N,C] (0|1) and expected f32 [C].
+ * visit_stream (optional, int32 [nnz + 3N]) is the visiting order flattened by the caller:
+ *     for pos in 0..N-1: node, deg, nfresh, then deg entries  nb | (fresh << 31)
+ * where fresh marks a neighbour visited LATER than node (it still holds -0.5|1.5 in pass 0) and
+ * nfresh counts them.  With it the kernel streams the graph through an LDS ring and never waits on
+ * global memory per node; NULL selects the generic kernel (one CSR row fetch per node). */
 int rls_mcpg_local_search(const rls_graph* g, const void* xs_in, int spin_bytes, float* xs_out, int64_t C,
-                          const int32_t* order, int64_t num_ls, const float* uniforms, uint64_t seed,
-                          float* expected, void* stream);
+                          const int32_t* order, const int32_t* visit_stream, int64_t visit_len, int64_t num_ls,
+                          const float* uniforms, uint64_t seed, float* expected, void* stream);
 
 /* K8 second half  methods/MCPG.py:154-161: best_index[m] = m + M * argmin_r expected[r*M + m]
  * (first minimum), vs_good[m] = (num_edges - expected[best]) / 2, xs_good[:, m] = xs[:, best].

@@ -1,6 +1,7 @@
 // MaxCut environment kernels for gfx950 (MI355X).  See include/rlsolver_hip.h for the
 // reference call site each entry point replaces, DESIGN.md for layouts and rooflines.
 #include "rls_cutcount.h"
+#include "rls_ring.h"
 
 namespace rls {
 
@@ -87,24 +88,7 @@ __global__ __launch_bounds__(kTileWaves * kWave) void k_maxcut_propose_accept(ui
 // least half a ring ahead of the node being processed (first version: one L2 round trip per node
 // = 1.5 us/node, 3 ms per G22 sweep).
 // =====================================================================================
-constexpr int kRing = 4096;            // entries in the col ring (16 KB)
-constexpr int kRefill = kRing / 4;     // entries requested per refill
-constexpr int kSweepMaxDeg = kRing / 4;
-
-__device__ __forceinline__ void glds4(const void* gsrc, void* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
-}
-
-// request entries [F, F + kRefill) of col into the ring (entries past nnz are skipped)
-__device__ __forceinline__ void ring_refill(const int32_t* __restrict__ col, int64_t nnz, int64_t F,
-                                            int32_t* ring, int lane) {
-#pragma unroll
-    for (int k = 0; k < kRefill / kWave; ++k) {
-        const int64_t e0 = F + (int64_t)k * kWave;
-        if (e0 + lane < nnz) glds4(col + e0 + lane, ring + (e0 & (kRing - 1)));
-    }
-}
+constexpr int kSweepMaxDeg = kRingMaxRun;
 
 template <bool VEC>
 __global__ __launch_bounds__(kWave) void k_maxcut_greedy_sweep(uint8_t* __restrict__ x, int64_t B, int64_t N,
@@ -118,8 +102,8 @@ __global__ __launch_bounds__(kWave) void k_maxcut_greedy_sweep(uint8_t* __restri
     const int lane = threadIdx.x;
     const int64_t b0 = (int64_t)blockIdx.x * kWave;
     if (lane == 0) words[N] = 0;   // sentinel word
-    int64_t F = 0;
-    while (F < nnz && F < kRing / 2 + kRefill) { ring_refill(col, nnz, F, ring, lane); F += kRefill; }
+    int64_t F;
+    ring_prime(col, nnz, F, ring, lane);
     for (int64_t i = lane; i <= N; i += kWave) rp[i] = rowptr[i];
     tile_load_bits<uint8_t, VEC>(x, B, N, b0, words, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -133,11 +117,7 @@ __global__ __launch_bounds__(kWave) void k_maxcut_greedy_sweep(uint8_t* __restri
     const int sentinel = (int)N;   // words[N] == 0
     int my_nb = (r0 + lane < r1) ? ring[(r0 + lane) & (kRing - 1)] : sentinel;
     for (int64_t i = 0; i < N; ++i) {
-        if (F < nnz && F - r0 < kRing / 2) {           // wave-uniform; once per ~kRefill entries
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every earlier refill has landed
-            ring_refill(col, nnz, F, ring, lane);
-            F += kRefill;
-        }
+        ring_advance(col, nnz, F, r0, ring, lane);     // wave-uniform; refills once per ~kRefill entries
         const int r2 = (i + 2 <= N) ? rp[i + 2] : r1;
         const int nxt_nb = (r1 + lane < r2) ? ring[(r1 + lane) & (kRing - 1)] : sentinel;
         const uint32_t xi = (*reinterpret_cast<const uint32_t*>(wbytes + ((uint32_t)i * 8u + half4)) >> sh) & 1u;

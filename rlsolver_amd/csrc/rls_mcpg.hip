@@ -16,6 +16,7 @@
 // (exact in any order), `s + u * 0.25f` and the division `(1 - p) / p` are single IEEE f32 ops
 // (the library is built with -ffp-contract=off).
 #include "rls_cutcount.h"
+#include "rls_ring.h"
 
 namespace rls {
 
@@ -48,7 +49,7 @@ __device__ __forceinline__ void tile_store_nodemajor(T* __restrict__ x, int64_t 
 }
 
 // ------------------------------------------------------------------------------------- K9
-template <typename T>
+template <typename T, bool PROBS_LDS>
 __global__ __launch_bounds__(kWave) void k_mcpg_metro(T* __restrict__ samples, int64_t N, int64_t C,
                                                       const float* __restrict__ probs, int64_t T_rounds,
                                                       const int64_t* __restrict__ index,
@@ -57,10 +58,16 @@ __global__ __launch_bounds__(kWave) void k_mcpg_metro(T* __restrict__ samples, i
                                                       unsigned long long* __restrict__ accepts) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* words = reinterpret_cast<uint64_t*>(smem);
+    // probs staged in LDS when it fits: a per-round random gather from global memory would put an
+    // L2 round trip (~2 us under load) on every round of every chain
+    float* probs_l = reinterpret_cast<float*>(words + N);
+    uint32_t* acc_cnt = reinterpret_cast<uint32_t*>(probs_l + (PROBS_LDS ? N : 0));   // per-round accept counts
     const int lane = threadIdx.x;
     const int64_t c0 = (int64_t)blockIdx.x * kWave;
     const int64_t c = c0 + lane;
     const bool valid = c < C;
+    if constexpr (PROBS_LDS)
+        for (int64_t n = lane; n < N; n += kWave) probs_l[n] = probs[n];
     tile_load_bits_nodemajor<T>(samples, N, C, c0, words, lane);
     __syncthreads();
     int64_t t_end = T_rounds;
@@ -85,16 +92,23 @@ __global__ __launch_bounds__(kWave) void k_mcpg_metro(T* __restrict__ samples, i
             }
         }
         const bool val = (words[i] >> lane) & 1ull;
-        const float base = probs[i];
+        const float base = PROBS_LDS ? probs_l[i] : probs[i];
         const float chosen = val ? base : 1.0f - base;            // torch.where(chosen_value, p, 1 - p)
         const float accept_rate = (1.0f - chosen) / chosen;       // MCPG.py:107
         const bool acc = valid && (uu < accept_rate);
+        // all lanes have read their word before any flip of this round lands (one wave, DS in order)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (acc) atomicXor(reinterpret_cast<unsigned long long*>(&words[i]), (unsigned long long)mybit);
         if (accepts) {
             const int cnt = __popcll(ballot64(acc));
-            if (lane == 0 && cnt) atomicAdd(&accepts[t], (unsigned long long)cnt);
+            if (lane == 0) acc_cnt[t] = (uint32_t)cnt;
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    if (accepts) {   // one coalesced burst of atomics per wave instead of one contended atomic per round
         __syncthreads();
+        for (int64_t t = lane; t < t_end; t += kWave)
+            if (acc_cnt[t]) atomicAdd(&accepts[t], (unsigned long long)acc_cnt[t]);
     }
     if (write_back) tile_store_nodemajor<T>(samples, N, C, c0, words, lane);
 }
@@ -165,6 +179,108 @@ __global__ __launch_bounds__(kWave) void k_mcpg_local_search(const TI* __restric
     }
 }
 
+// K7 fast path.  The host flattens the visiting order into ONE int32 "visit stream":
+//     for pos in 0..N-1:  node, deg, nfresh, then deg entries  nb | (fresh << 31)
+// (fresh = nb is visited later than node in pass 0, i.e. still holds -0.5|1.5 there; nfresh = their
+// count).  The stream is consumed strictly in order through an LDS ring (rls_ring.h), so the
+// per-node path is: 3 broadcast LDS reads for the header, one lane-parallel ring read for the row,
+// v_readlane + broadcast word read + v_bfe + v_mad per neighbour, one ballot.  No global memory
+// latency per node (the generic kernel pays 2-3 dependent L2 round trips per node).
+template <typename TI, int P>
+__global__ __launch_bounds__(kWave) void k_mcpg_local_search_stream(const TI* __restrict__ xs_in,
+                                                                    float* __restrict__ xs_out, int64_t N, int64_t C,
+                                                                    const int32_t* __restrict__ vstream,
+                                                                    int64_t vlen, int64_t num_ls,
+                                                                    const float* __restrict__ uniforms, uint64_t seed,
+                                                                    const int32_t* __restrict__ eu,
+                                                                    const int32_t* __restrict__ ev, int64_t E,
+                                                                    float* __restrict__ expected) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* words = reinterpret_cast<uint64_t*>(smem);
+    int32_t* ring = reinterpret_cast<int32_t*>(smem + (size_t)(N + 2) * 8);
+    const uint32_t* w32 = reinterpret_cast<const uint32_t*>(smem);
+    const unsigned char* wbytes = smem;
+    const int lane = threadIdx.x;
+    const int64_t c0 = (int64_t)blockIdx.x * kWave;
+    const int64_t c = c0 + lane;
+    const bool valid = c < C;
+    if (lane == 0) words[N] = 0;   // sentinel word for lanes past a row's end
+    tile_load_bits_nodemajor<TI>(xs_in, N, C, c0, words, lane);
+    const int sh = lane & 31;
+    const uint32_t half4 = (uint32_t)(lane >> 5) * 4u;
+    const uint32_t sentinel = (uint32_t)N;
+    const Philox ph(seed);
+    for (int64_t cnt = 0; cnt < num_ls; ++cnt) {
+        int64_t F;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        ring_prime(vstream, vlen, F, ring, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int64_t cur = 0;
+        uint32_t rnd[4] = {0, 0, 0, 0};
+        // one lane-parallel ring read fetches a node's header (lanes 0-2) and its first 61 entries;
+        // it is issued one node ahead so its latency hides behind the current node's work
+        uint32_t blk = (uint32_t)ring[(cur + lane) & (kRing - 1)];
+        for (int64_t pos = 0; pos < N; ++pos) {
+            const int node = __builtin_amdgcn_readlane((int)blk, 0);
+            const int deg = __builtin_amdgcn_readlane((int)blk, 1);
+            const int nfresh = (cnt == 0) ? __builtin_amdgcn_readlane((int)blk, 2) : 0;
+            const int64_t row = cur + 3;
+            const int64_t nxt = row + deg;
+            ring_advance(vstream, vlen, F, nxt, ring, lane);
+            const uint32_t nblk = (pos + 1 < N) ? (uint32_t)ring[(nxt + lane) & (kRing - 1)] : 0u;
+            float uu;
+            if (uniforms) {
+                uu = valid ? uniforms[(cnt * N + pos) * C + c] : 0.0f;
+            } else {   // one Philox-4x32 call feeds four consecutive positions
+                if ((pos & 3) == 0)
+                    ph((uint32_t)c, (uint32_t)((uint64_t)c >> 32), (uint32_t)((cnt * N + pos) >> 2), 0x4C4F4353u, rnd);
+                const int q = (int)(pos & 3);   // select chain: a runtime-indexed register array would go to scratch
+                uu = u32_to_unit_float(q == 0 ? rnd[0] : q == 1 ? rnd[1] : q == 2 ? rnd[2] : rnd[3]);
+            }
+            int acc = 0;  // sum over neighbours of mult * bit, mult = 4 for fresh (pass 0), else 2
+            // entries 0..60 of the row sit in lanes 3..63 of blk; lanes past the row end read the sentinel
+            const uint32_t mine = (lane >= 3 && lane - 3 < deg) ? blk : sentinel;
+            const int first = deg < (kWave - 3) ? deg : (kWave - 3);
+            for (int j = 0; j < first; j += 8) {
+                uint32_t w[8], mult[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int src = (j + k + 3) < kWave ? (j + k + 3) : (kWave - 1);
+                    uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)mine, src);
+                    if (j + k >= first) e = sentinel;
+                    mult[k] = (cnt == 0 && (e >> 31)) ? 4u : 2u;
+                    w[k] = *reinterpret_cast<const uint32_t*>(wbytes + ((e & 0x7fffffffu) * 8u + half4));
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc += (int)(((w[k] >> sh) & 1u) * mult[k]);
+            }
+            for (int j = kWave - 3; j < deg; ++j) {      // hubs: the rest of the row straight from the ring
+                const uint32_t e = (uint32_t)ring[(row + j) & (kRing - 1)];
+                const uint32_t mult = (cnt == 0 && (e >> 31)) ? 4u : 2u;
+                acc += (int)(((*reinterpret_cast<const uint32_t*>(wbytes + ((e & 0x7fffffffu) * 8u + half4)) >> sh) & 1u) * mult);
+            }
+            const int s2 = acc - nfresh;                                      // units of 0.5
+            const float rv = (float)s2 * 0.5f + uu * 0.25f;                   // MCPG.py:139-141
+            const float thr = ((float)deg + 0.25f) / 2.0f;                    // (weighted_degree + k) / 2
+            const uint64_t nw = ballot64(rv < thr);
+            if (lane == 0) words[node] = nw;
+            asm volatile("" ::: "memory");
+            cur = nxt;
+            blk = nblk;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int64_t cut = tile_cut_count<P>(words, eu, ev, E, lane);
+    if (valid) {
+        expected[c] = (float)(E - 2 * cut);
+        const int half = lane >> 5;
+        for (int64_t n = 0; n < N; ++n) xs_out[n * C + c] = (float)((w32[(n << 1) + half] >> sh) & 1u);
+    }
+}
+
 // best-of-repeats: index = argmin_r expected[r*M + m] (first on ties); column gather
 __global__ void k_mcpg_pick_best(const float* __restrict__ expected, const float* __restrict__ xs, int64_t N,
                                  int64_t M, int64_t R, float num_edges, int64_t* __restrict__ best_index,
@@ -199,41 +315,69 @@ int rls_mcpg_metro_rounds(void* samples, int spin_bytes, int64_t N, int64_t C, c
     RLS_REQUIRE(samples && probs, RLS_EINVAL, "samples/probs is NULL");
     RLS_REQUIRE((index == nullptr) == (u == nullptr), RLS_EINVAL, "index and u must both be given or both be NULL");
     RLS_REQUIRE(spin_bytes == 1 || spin_bytes == 4, RLS_EINVAL, "spin_bytes must be 1 or 4");
-    const size_t lds = (size_t)N * 8;
-    RLS_REQUIRE(lds <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS (max %d)", (long long)N, lds,
-                kLdsBytes);
+    const size_t lds_base = (size_t)N * 8 + (accepts ? (size_t)T * 4 : 0) + 16;
+    const bool probs_lds = lds_base + (size_t)N * 4 <= (size_t)kLdsBytes;
+    const size_t lds = lds_base + (probs_lds ? (size_t)N * 4 : 0);
+    RLS_REQUIRE(lds <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld, T=%lld need %zu B of LDS (max %d)", (long long)N,
+                (long long)T, lds, kLdsBytes);
     const dim3 grid((unsigned)ceil_div(C, kWave)), block(kWave);
     hipStream_t s = as_stream(stream);
-    if (spin_bytes == 1) {
-        auto kern = k_mcpg_metro<uint8_t>;
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, grid, block, lds, s, (uint8_t*)samples, N, C, probs, T, index, u, seed, t_limit_dev,
-                           write_back, (unsigned long long*)accepts);
-    } else {
-        auto kern = k_mcpg_metro<float>;
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, grid, block, lds, s, (float*)samples, N, C, probs, T, index, u, seed, t_limit_dev,
-                           write_back, (unsigned long long*)accepts);
-    }
+#define LAUNCH_METRO(TT, PL)                                                                                        \
+    do {                                                                                                            \
+        auto kern = k_mcpg_metro<TT, PL>;                                                                           \
+        if (lds > 64 * 1024)                                                                                        \
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
+        hipLaunchKernelGGL(kern, grid, block, lds, s, (TT*)samples, N, C, probs, T, index, u, seed, t_limit_dev,     \
+                           write_back, (unsigned long long*)accepts);                                               \
+    } while (0)
+    if (spin_bytes == 1) { if (probs_lds) LAUNCH_METRO(uint8_t, true); else LAUNCH_METRO(uint8_t, false); }
+    else                 { if (probs_lds) LAUNCH_METRO(float, true);   else LAUNCH_METRO(float, false); }
+#undef LAUNCH_METRO
     return check_launch("k_mcpg_metro");
 }
 
 int rls_mcpg_local_search(const rls_graph* g, const void* xs_in, int spin_bytes, float* xs_out, int64_t C,
-                          const int32_t* order, int64_t num_ls, const float* uniforms, uint64_t seed,
-                          float* expected, void* stream) {
+                          const int32_t* order, const int32_t* visit_stream, int64_t visit_len, int64_t num_ls,
+                          const float* uniforms, uint64_t seed, float* expected, void* stream) {
     if (int rc = check_graph(g)) return rc;
     RLS_REQUIRE(C >= 0 && num_ls >= 0, RLS_EINVAL, "bad sizes");
     if (C == 0) return RLS_OK;
     RLS_REQUIRE(xs_in && xs_out && order && expected, RLS_EINVAL, "NULL pointer");
     RLS_REQUIRE(spin_bytes == 1 || spin_bytes == 4, RLS_EINVAL, "spin_bytes must be 1 or 4");
     const int64_t N = g->num_nodes, E = g->num_stored_edges;
-    const size_t lds = (size_t)N * 8 + (size_t)((N + 31) / 32) * 4 + 16;
-    RLS_REQUIRE(lds <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS (max %d)", (long long)N, lds,
-                kLdsBytes);
     const int P = pick_planes(E);
     RLS_REQUIRE(P != 0, RLS_EUNSUPPORTED, "E=%lld too large", (long long)E);
     const dim3 grid((unsigned)ceil_div(C, kWave)), block(kWave);
     hipStream_t s = as_stream(stream);
+    const size_t lds_fast = (size_t)(N + 2) * 8 + (size_t)kRing * 4;
+    const bool fast = visit_stream != nullptr && g->max_degree + 3 <= kRingMaxRun && lds_fast <= (size_t)kLdsBytes &&
+                      (((uintptr_t)visit_stream) & 3) == 0;
+    if (fast) {
+        RLS_REQUIRE(visit_len == g->nnz + 3 * N, RLS_EINVAL, "visit_len %lld != nnz + 3N = %lld", (long long)visit_len,
+                    (long long)(g->nnz + 3 * N));
+#define LAUNCH_LSS(TI, PP)                                                                                           \
+    do {                                                                                                             \
+        auto kern = k_mcpg_local_search_stream<TI, PP>;                                                              \
+        if (lds_fast > 64 * 1024)                                                                                    \
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fast); \
+        hipLaunchKernelGGL(kern, grid, block, lds_fast, s, (const TI*)xs_in, xs_out, N, C, visit_stream, visit_len,   \
+                           num_ls, uniforms, seed, g->eu, g->ev, E, expected);                                       \
+    } while (0)
+#define DISPATCH_PS(TI)                       \
+    switch (P) {                              \
+        case 12: LAUNCH_LSS(TI, 12); break;   \
+        case 16: LAUNCH_LSS(TI, 16); break;   \
+        case 20: LAUNCH_LSS(TI, 20); break;   \
+        default: LAUNCH_LSS(TI, 24); break;   \
+    }
+        if (spin_bytes == 1) { DISPATCH_PS(uint8_t) } else { DISPATCH_PS(float) }
+#undef DISPATCH_PS
+#undef LAUNCH_LSS
+        return check_launch("k_mcpg_local_search_stream");
+    }
+    const size_t lds = (size_t)N * 8 + (size_t)((N + 31) / 32) * 4 + 16;
+    RLS_REQUIRE(lds <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS (max %d)", (long long)N, lds,
+                kLdsBytes);
 #define LAUNCH_LS(TI, PP)                                                                                       \
     do {                                                                                                        \
         auto kern = k_mcpg_local_search<TI, PP>;                                                                \

@@ -272,7 +272,10 @@ extern "C" int rls_maxcut_step(const rls_graph* g, const void* x_in, void* x_out
     const bool vec = rows_vec_aligned(x_in, N, spin_bytes) && rows_vec_aligned(x_out, N, spin_bytes);
     const char* e_epw = getenv("RLS_STEP_EPW");
     const char* e_wpb = getenv("RLS_STEP_WPB");
-    const int epw = e_epw ? atoi(e_epw) : 4;
+    // envs per wave: the largest of {8,4,2,1} whose staged run fits ~8 KB of LDS per wave (G22: 4)
+    int epw_auto = 8;
+    while (epw_auto > 1 && (int64_t)epw_auto * N * spin_bytes > 8192) epw_auto >>= 1;
+    const int epw = e_epw ? atoi(e_epw) : (emit ? epw_auto : 4);   // in place: nothing is staged
     const int waves_per_block = e_wpb ? atoi(e_wpb) : 4;
     const dim3 grid((unsigned)ceil_div(ceil_div(B, epw), waves_per_block)), block(waves_per_block * kWave);
     hipStream_t s = as_stream(stream);

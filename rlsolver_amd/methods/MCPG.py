@@ -50,7 +50,33 @@ def make_data(num_nodes: int, eu, ev, device, sorted_degree_nodes=None):
     data.sorted_degree_nodes = torch.as_tensor(sorted_degree_nodes).to(torch.int64)
     data.graph = ops.DeviceGraph(csr, device)
     data._order_i32 = data.sorted_degree_nodes.to(device=device, dtype=torch.int32).contiguous()
+    data._visit_stream = torch.from_numpy(build_visit_stream(csr, data.sorted_degree_nodes.cpu().numpy())).to(device)
     return data
+
+
+def build_visit_stream(csr, order: np.ndarray) -> np.ndarray:
+    """Flatten the visiting order for the streaming K7 kernel (include/rlsolver_hip.h):
+    per position [node, deg, nfresh, nb | fresh << 31 ...], int32 [nnz + 3N]."""
+    n = csr.num_nodes
+    order = np.asarray(order, dtype=np.int64)
+    pos_of = np.empty(n, dtype=np.int64)
+    pos_of[order] = np.arange(n)
+    deg = np.diff(csr.rowptr).astype(np.int64)
+    deg_o = deg[order]
+    out_ptr = np.concatenate([[0], np.cumsum(deg_o + 3)])
+    stream = np.empty(int(out_ptr[-1]), dtype=np.int64)
+    # gather every row in visiting order
+    starts = csr.rowptr[order].astype(np.int64)
+    idx = np.repeat(starts - np.concatenate([[0], np.cumsum(deg_o)[:-1]]), deg_o) + np.arange(int(deg_o.sum()))
+    nbr = csr.col[idx].astype(np.int64)
+    row_pos = np.repeat(np.arange(n), deg_o)
+    fresh = pos_of[nbr] > row_pos
+    nfresh = np.bincount(row_pos, weights=fresh, minlength=n).astype(np.int64)
+    hdr = out_ptr[:-1]
+    stream[hdr], stream[hdr + 1], stream[hdr + 2] = order, deg_o, nfresh
+    dst = np.repeat(hdr + 3 - np.concatenate([[0], np.cumsum(deg_o)[:-1]]), deg_o) + np.arange(int(deg_o.sum()))
+    stream[dst] = nbr | (fresh.astype(np.int64) << 31)
+    return (stream & 0xFFFFFFFF).astype(np.uint32).view(np.int32)
 
 
 def metro_sampling(probs: TEN, start_status: TEN, max_transfer_time: int, device=None,
@@ -83,7 +109,8 @@ def sampler_func(data, xs_sample: TEN, num_ls: int, total_mcmc_num: int, repeat_
     repeats.  ``uniforms`` f32 [num_ls, N, C] replaces torch.rand (test hook)."""
     xs_sample = xs_sample.contiguous()
     seed = _seed_from_torch() if uniforms is None else 0
-    xs_loc, expected = mops.mcpg_local_search(data.graph, xs_sample, data._order_i32, num_ls, uniforms, seed)
+    xs_loc, expected = mops.mcpg_local_search(data.graph, xs_sample, data._order_i32, num_ls, uniforms, seed,
+                                              visit_stream=getattr(data, '_visit_stream', None))
     _, vs_good, xs_good = mops.mcpg_pick_best(expected, xs_loc, total_mcmc_num, repeat_times, data.num_edges)
     value = expected - expected.mean()
     return vs_good, xs_good, value

@@ -46,7 +46,7 @@ def mcpg_metro_rounds(samples: TEN, probs: TEN, T: int, index: Optional[TEN] = N
 
 
 def mcpg_local_search(g: DeviceGraph, xs_in: TEN, order: TEN, num_ls: int, uniforms: Optional[TEN] = None,
-                      seed: int = 0):
+                      seed: int = 0, visit_stream: Optional[TEN] = None):
     """K7 + expected cut.  Returns (xs_out f32 [N, C], expected f32 [C])."""
     _check(xs_in, "xs_in", _NM_DTYPES, g.device)
     if xs_in.dim() != 2 or xs_in.shape[0] != g.num_nodes:
@@ -57,8 +57,11 @@ def mcpg_local_search(g: DeviceGraph, xs_in: TEN, order: TEN, num_ls: int, unifo
         _check(uniforms, "uniforms", (torch.float32,), g.device, (num_ls, g.num_nodes, Cc))
     xs_out = torch.empty((g.num_nodes, Cc), dtype=torch.float32, device=g.device)
     expected = torch.empty(Cc, dtype=torch.float32, device=g.device)
+    if visit_stream is not None:
+        _check(visit_stream, "visit_stream", (torch.int32,), g.device)
     _abi.call("rls_mcpg_local_search", g.ref, _ptr(xs_in), 4 if xs_in.dtype == torch.float32 else 1, _ptr(xs_out), Cc,
-              _ptr(order), num_ls, _ptr(uniforms), _u64(seed), _ptr(expected), _stream(g.device))
+              _ptr(order), _ptr(visit_stream), 0 if visit_stream is None else visit_stream.numel(), num_ls,
+              _ptr(uniforms), _u64(seed), _ptr(expected), _stream(g.device))
     return xs_out, expected
 
 

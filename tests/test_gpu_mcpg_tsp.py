@@ -62,6 +62,11 @@ def test_mcpg_random_vs_oracle(n, m, M, R, num_ls):
     assert np.array_equal(vs_g.cpu().numpy(), vs_w)
     assert np.array_equal(xs_g.cpu().numpy(), xs_w)
     np.testing.assert_allclose(val_g.cpu().numpy(), val_w, atol=1e-3)
+    # the streaming kernel (visit stream through an LDS ring) and the generic one agree exactly
+    xa, ea = mops.mcpg_local_search(data.graph, got, data._order_i32, num_ls, dev(uni), 0, visit_stream=data._visit_stream)
+    xb, eb = mops.mcpg_local_search(data.graph, got, data._order_i32, num_ls, dev(uni), 0, visit_stream=None)
+    assert torch.equal(xa, xb) and torch.equal(ea, eb)
+    assert np.array_equal(xa.cpu().numpy(), x_all) and np.array_equal(ea.cpu().numpy(), exp_w)
 
 
 def test_mcpg_production_rng_is_distributionally_sane():

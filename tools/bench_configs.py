@@ -1,0 +1,118 @@
+#!/usr/bin/env python3
+"""Per-kernel throughput on the BASELINE.json configs (1 GPU): one JSON line per measurement.
+Development / documentation aid; bench.py is the judged harness (headline K4 only).
+
+    python tools/bench_configs.py [--quick] > gpurun_out/configs.jsonl
+"""
+import argparse, json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from rlsolver_amd import ops, ops_mcpg_tsp as mops
+from rlsolver_amd.graph import build_csr, generate_ba, generate_gnm, generate_tsp_coords, tsp_tables
+from rlsolver_amd.methods import MCPG as amcpg
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--quick", action="store_true")
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+HBM = 8e12
+
+
+def timeit(fn, iters, warm=2):
+    for i in range(warm):
+        fn(i)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(iters):
+        fn(i)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def emit(config, kernel, unit, units_per_launch, t, alg_bytes_per_unit=None, note=""):
+    rec = {"config": config, "kernel": kernel, "us_per_launch": round(t * 1e6, 2), "unit": unit,
+           "units_per_s": units_per_launch / t}
+    if alg_bytes_per_unit is not None:
+        rec["algorithmic_GBps"] = units_per_launch * alg_bytes_per_unit / t / 1e9
+        rec["frac_of_8TBps"] = units_per_launch * alg_bytes_per_unit / t / HBM
+    if note:
+        rec["note"] = note
+    print(json.dumps(rec), flush=True)
+
+
+def maxcut_suite(tag, n, m, B, seed, iters):
+    g = ops.DeviceGraph(build_csr(generate_gnm(n, m, seed), num_nodes=n), dev)
+    S = 4
+    slots = [ops.rand_spins(B, n, s, dev) for s in range(S)]
+    obj = ops.maxcut_obj(g, slots[0]).to(torch.int32)
+    rew = torch.empty(B, dtype=torch.float32, device=dev)
+    acts = [ops.rand_actions(B, n, 7, s, dev) for s in range(8)]
+    t = timeit(lambda i: ops.maxcut_step(g, slots[i % S], slots[(i + 1) % S], acts[i % 8], obj, rew), iters)
+    emit(tag, "K4 maxcut_step (emit)", "env-steps", B, t, 2 * n + 20)
+    x = slots[0].clone()
+    t = timeit(lambda i: ops.maxcut_step(g, x, x, acts[i % 8], obj, rew), iters)
+    emit(tag, "K4 maxcut_step (in place)", "env-steps", B, t, None, "O(deg) bytes per step")
+    out = torch.empty(B, dtype=torch.int64, device=dev)
+    t = timeit(lambda i: ops.maxcut_obj(g, slots[0], out), iters)
+    emit(tag, "K1 maxcut_obj", "evals", B, t, n + 8)
+    mask = torch.rand((B, n), device=dev) < 8.0 / n
+    vs = ops.maxcut_obj(g, x)
+    t = timeit(lambda i: ops.maxcut_propose_accept(g, x, mask, vs), max(3, iters // 4))
+    emit(tag, "K6 propose_accept", "proposals", B, t, 2 * n + 16)
+    t = timeit(lambda i: ops.maxcut_greedy_sweep(g, x, vs), max(2, iters // 10))
+    emit(tag, "K5 greedy_sweep", "candidate flips", B * n, t, (2 * n + 16) / n, "on-chip bound by design")
+    d = None
+    t = timeit(lambda i: ops.maxcut_delta_all(g, x), max(3, iters // 4))
+    emit(tag, "K3 delta_all", "envs", B, t, 5 * n)
+    return g
+
+
+def local_search_suite(tag, n, m, seed, B, iters):
+    from rlsolver_amd.envs.env_L2A import EnvMaxcut
+    env = EnvMaxcut(mygraph=generate_gnm(n, m, seed), device=dev, num_nodes=n)
+    torch.manual_seed(0)
+    xs = env.generate_xs_randomly(B)
+    vs = env.calculate_obj_values(xs)
+    t = timeit(lambda i: env.local_search_inplace(xs, vs, num_iters=8, num_spin=8, noise_std=0.3), iters, warm=1)
+    emit(tag, "local_search_inplace (K2 + 8 x K6 + K5 + torch weights/noise/kthvalue)", "candidate evaluations",
+         B * (n + 8), t, None, f"B={B}; the reference performs N+8 full objective evaluations per env per call")
+
+
+def mcpg_suite(tag, n, m_ba, C, num_ls, iters):
+    mg = generate_ba(n, m_ba, seed=5)
+    arr = np.asarray(mg, dtype=np.int64)
+    data = amcpg.make_data(n, arr[:, 0], arr[:, 1], dev)
+    torch.manual_seed(0)
+    xs = (torch.rand((n, C), device=dev) < 0.5).float()
+    probs = torch.full((n,), 0.5, device=dev)
+    t = timeit(lambda i: amcpg.sampler_func(data, xs, num_ls, C // 128, 128, dev), iters, warm=1)
+    emit(tag, f"K7+K8 sampler_func (num_ls={num_ls})", "node updates", C * n * num_ls, t, None,
+         f"C={C} chains, E={len(mg)}; f32 [N,C] in/out = {2 * 4 * n} B per chain")
+    emit(tag, f"K7+K8 sampler_func (num_ls={num_ls})", "chain-sweeps", C * num_ls, t, 2 * 4 * n / num_ls)
+    T = n // 10
+    t = timeit(lambda i: amcpg.metro_sampling(probs, xs, T, dev), iters, warm=1)
+    emit(tag, "K9 metro_sampling (two-pass, sync-free stop rule)", "proposals", C * T, t, None, f"T={T}")
+
+
+def tsp_suite(tag, N, B, iters):
+    dist, near, rnd = tsp_tables(generate_tsp_coords(N, 100), K=20)
+    d = torch.from_numpy(dist).to(dev)
+    perms = mops.rand_perms(B, N, 3, dev)
+    t = timeit(lambda i: mops.tsp_tour_length(d, perms), iters)
+    emit(tag, "K12 tsp_tour_length", "tours", B, t, 8 * N + 4)
+    sel = torch.roll(perms, 7, 1).contiguous()
+    t = timeit(lambda i: mops.tsp_swap_delta_all(d, perms, sel, 0.5), iters)
+    emit(tag, "K13 tsp_swap_delta_all", "envs (N candidate moves each)", B, t, 8 * N + 8 * N + 13 * N)
+
+
+it = 5 if a.quick else 30
+maxcut_suite("G22-sized G(2000,19990), B=2^16", 2000, 19990, 1 << 16, 22, it)
+local_search_suite("G22-sized, dREINFORCE batch", 2000, 19990, 22, 4096, max(2, it // 5))
+local_search_suite("G22-sized, dREINFORCE batch x16", 2000, 19990, 22, 65536, max(2, it // 5))
+maxcut_suite("G70-sized G(10000,9999), B=2^17 (one GPU's shard of 2^20)", 10000, 9999, 1 << 17, 70, max(3, it // 3))
+maxcut_suite("G14-sized G(800,4694), B=256", 800, 4694, 256, 14, it)
+tsp_suite("TSP-100 uniform, B=2^16", 100, 1 << 16, it)
+mcpg_suite("BA n=10^4 m=5, 2^18 chains", 10000, 5, 1 << 18 if not a.quick else 1 << 14, 8, 2)
