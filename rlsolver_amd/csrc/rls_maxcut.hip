@@ -253,6 +253,87 @@ __global__ void k_delta_all(const uint8_t* __restrict__ x, int64_t B, int64_t N,
     }
 }
 
+// =====================================================================================
+// K2 / K3 on a bit tile: per-node cut degree (int64, the env's stored adjacency) or flip gain
+// (int32, symmetric CSR, optional weights) for all nodes of 64 envs.  Nodes are independent, so the
+// kTileWaves waves of the workgroup take alternating blocks of 128/sizeof(OutT) consecutive nodes;
+// each lane (= env) collects its block in an LDS staging row and writes it back as full 128-byte
+// lines (a lane-per-env layout writing one 4-byte result per node would touch 64 lines per store).
+// Per (node, neighbour): v_readlane + v_lshl_add + broadcast ds_read + v_bfe + add, 8 per trip.
+// =====================================================================================
+template <typename OutT, bool DELTA, bool WEIGHTED, bool VEC>
+__global__ __launch_bounds__(kTileWaves * kWave) void k_node_stats_tile(const uint8_t* __restrict__ x, int64_t B,
+                                                                         int64_t N,
+                                                                         const int32_t* __restrict__ rowptr,
+                                                                         const int32_t* __restrict__ col,
+                                                                         const int32_t* __restrict__ wgt,
+                                                                         OutT* __restrict__ out) {
+    constexpr int NB = 128 / (int)sizeof(OutT);       // nodes per block: one 128-B line per env
+    constexpr int STRIDE = 144;                       // staging row stride in bytes (16-B aligned, off the 128-B period)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* words = reinterpret_cast<uint64_t*>(smem);
+    const unsigned char* wbytes = smem;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    unsigned char* stage = smem + (size_t)(N + 2) * 8 + (size_t)w * kWave * STRIDE;
+    const int64_t b0 = (int64_t)blockIdx.x * kWave;
+    if (threadIdx.x == 0) words[N] = 0;               // sentinel word: lanes past a row's end read zero
+    tile_load_bits<uint8_t, VEC>(x, B, N, b0, words, lane, w, kTileWaves);
+    __syncthreads();
+    const int sh = lane & 31;
+    const uint32_t half4 = (uint32_t)(lane >> 5) * 4u;
+    const int64_t b = b0 + lane;
+    for (int64_t i0 = (int64_t)w * NB; i0 < N; i0 += (int64_t)kTileWaves * NB) {
+        const int nb_here = (int)((N - i0) < NB ? (N - i0) : NB);
+        for (int k = 0; k < nb_here; ++k) {
+            const int64_t i = i0 + k;
+            const int r0 = rowptr[i], r1 = rowptr[i + 1];
+            const uint32_t xi = (*reinterpret_cast<const uint32_t*>(wbytes + ((uint32_t)i * 8u + half4)) >> sh) & 1u;
+            int acc = 0, wsum = 0;
+            for (int base = r0; base < r1; base += kWave) {
+                const int cnt = (r1 - base) < kWave ? (r1 - base) : kWave;
+                const uint32_t my_nb = (lane < cnt) ? (uint32_t)col[base + lane] : (uint32_t)N;
+                int my_w = 0;
+                if constexpr (WEIGHTED) my_w = (lane < cnt) ? wgt[base + lane] : 0;
+                for (int j = 0; j < cnt; j += 8) {
+                    uint32_t wv[8];
+                    int ww[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const uint32_t nb = (uint32_t)__builtin_amdgcn_readlane((int)my_nb, j + q);
+                        wv[q] = *reinterpret_cast<const uint32_t*>(wbytes + (nb * 8u + half4));
+                        if constexpr (WEIGHTED) ww[q] = __builtin_amdgcn_readlane(my_w, j + q);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int bit = (int)((wv[q] >> sh) & 1u);
+                        if constexpr (WEIGHTED) { acc += bit ? ww[q] : 0; wsum += ww[q]; }
+                        else acc += bit;
+                    }
+                }
+            }
+            if constexpr (!WEIGHTED) wsum = r1 - r0;
+            OutT res;
+            if constexpr (DELTA) res = (OutT)(xi ? (2 * acc - wsum) : (wsum - 2 * acc));   // sum w (same ? +1 : -1)
+            else res = (OutT)(xi ? (wsum - acc) : acc);                                  // #neighbours that differ
+            *reinterpret_cast<OutT*>(stage + lane * STRIDE + k * (int)sizeof(OutT)) = res;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (b < B) {
+            OutT* dst = out + b * N + i0;
+            const unsigned char* src = stage + lane * STRIDE;
+            if (nb_here == NB && ((((uintptr_t)dst) & 15) == 0)) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    reinterpret_cast<u32x4*>(dst)[q] = *reinterpret_cast<const u32x4*>(src + q * 16);
+            } else {
+                for (int k = 0; k < nb_here; ++k) dst[k] = *reinterpret_cast<const OutT*>(src + k * (int)sizeof(OutT));
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
 // one wave per row
 __global__ __launch_bounds__(256) void k_select_better_rows(uint8_t* __restrict__ xs0, int64_t* __restrict__ vs0,
                                                             const uint8_t* __restrict__ xs1,
@@ -459,13 +540,33 @@ int rls_maxcut_edge_cut_mask(const rls_graph* g, const uint8_t* x, int64_t B, ui
     return check_launch("k_edge_cut_mask");
 }
 
+static inline size_t node_stats_lds(int64_t N) { return (size_t)(N + 2) * 8 + (size_t)kTileWaves * kWave * 144; }
+// the tile kernels are latency-bound per node; with few tiles the element-parallel kernels win
+static inline bool node_stats_use_tile(int64_t B, int64_t N) { return B >= 2048 && node_stats_lds(N) <= (size_t)kLdsBytes; }
+
 int rls_maxcut_node_cutdeg(const rls_graph* g, const uint8_t* x, int64_t B, int64_t* cutdeg, void* stream) {
     if (int rc = check_graph(g)) return rc;
     RLS_REQUIRE(B >= 0, RLS_EINVAL, "B < 0");
     if (B == 0) return RLS_OK;
     RLS_REQUIRE(x && cutdeg, RLS_EINVAL, "x/cutdeg is NULL");
-    hipLaunchKernelGGL(k_node_cutdeg, dim3(grid_for(B * g->num_nodes, 256)), dim3(256), 0, as_stream(stream), x, B,
-                       g->num_nodes, g->erowptr, g->ev, cutdeg);
+    const int64_t N = g->num_nodes;
+    const size_t lds = node_stats_lds(N);
+    if (node_stats_use_tile(B, N)) {
+        const dim3 grid((unsigned)ceil_div(B, kWave)), block(kTileWaves * kWave);
+        hipStream_t s = as_stream(stream);
+#define LAUNCH_NS(VEC)                                                                                           \
+    do {                                                                                                         \
+        auto kern = k_node_stats_tile<int64_t, false, false, VEC>;                                               \
+        if (lds > 64 * 1024)                                                                                     \
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+        hipLaunchKernelGGL(kern, grid, block, lds, s, x, B, N, g->erowptr, g->ev, (const int32_t*)nullptr, cutdeg); \
+    } while (0)
+        if (rows_vec_aligned(x, N, 1)) LAUNCH_NS(true); else LAUNCH_NS(false);
+#undef LAUNCH_NS
+        return check_launch("k_node_stats_tile<cutdeg>");
+    }
+    hipLaunchKernelGGL(k_node_cutdeg, dim3(grid_for(B * N, 256)), dim3(256), 0, as_stream(stream), x, B, N, g->erowptr,
+                       g->ev, cutdeg);
     return check_launch("k_node_cutdeg");
 }
 
@@ -474,13 +575,31 @@ int rls_maxcut_delta_all(const rls_graph* g, const uint8_t* x, int64_t B, int32_
     RLS_REQUIRE(B >= 0, RLS_EINVAL, "B < 0");
     if (B == 0) return RLS_OK;
     RLS_REQUIRE(x && delta, RLS_EINVAL, "x/delta is NULL");
-    const dim3 grid(grid_for(B * g->num_nodes, 256)), block(256);
+    const int64_t N = g->num_nodes;
+    const size_t lds = node_stats_lds(N);
+    if (node_stats_use_tile(B, N)) {
+        const dim3 grid((unsigned)ceil_div(B, kWave)), block(kTileWaves * kWave);
+        hipStream_t s = as_stream(stream);
+#define LAUNCH_ND(W, VEC)                                                                                        \
+    do {                                                                                                         \
+        auto kern = k_node_stats_tile<int32_t, true, W, VEC>;                                                    \
+        if (lds > 64 * 1024)                                                                                     \
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+        hipLaunchKernelGGL(kern, grid, block, lds, s, x, B, N, g->rowptr, g->col, g->wgt, delta);               \
+    } while (0)
+        const bool vec = rows_vec_aligned(x, N, 1);
+        if (g->wgt) { if (vec) LAUNCH_ND(true, true); else LAUNCH_ND(true, false); }
+        else        { if (vec) LAUNCH_ND(false, true); else LAUNCH_ND(false, false); }
+#undef LAUNCH_ND
+        return check_launch("k_node_stats_tile<delta>");
+    }
+    const dim3 grid(grid_for(B * N, 256)), block(256);
     if (g->wgt)
-        hipLaunchKernelGGL(k_delta_all<true>, grid, block, 0, as_stream(stream), x, B, g->num_nodes, g->rowptr,
-                           g->col, g->wgt, delta);
+        hipLaunchKernelGGL(k_delta_all<true>, grid, block, 0, as_stream(stream), x, B, N, g->rowptr, g->col, g->wgt,
+                           delta);
     else
-        hipLaunchKernelGGL(k_delta_all<false>, grid, block, 0, as_stream(stream), x, B, g->num_nodes, g->rowptr,
-                           g->col, g->wgt, delta);
+        hipLaunchKernelGGL(k_delta_all<false>, grid, block, 0, as_stream(stream), x, B, N, g->rowptr, g->col, g->wgt,
+                           delta);
     return check_launch("k_delta_all");
 }
 

@@ -1,0 +1,32 @@
+"""K2/K3 have two implementations (bit-tile kernel for B >= 2048, element-parallel below):
+they must agree with each other and with the oracle, incl. ragged N, weights, bidirectional."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle_np as onp
+from rlsolver_amd import ops
+from tests.gpu_util import DEV, device_graph, gnm_arr, to_dev_bool
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n,m,B", [(333, 2000, 2100), (2000, 19990, 2048), (64, 300, 4096), (1000, 3000, 2049)])
+@pytest.mark.parametrize("weighted", [False, True])
+@pytest.mark.parametrize("bidir", [0, 1])
+def test_tile_and_element_kernels_agree(n, m, B, weighted, bidir):
+    graph = gnm_arr(n, m, seed=n)
+    rng = np.random.RandomState(B)
+    if weighted:
+        graph[:, 2] = rng.choice([-3, -1, 1, 2], size=len(graph))
+    g = device_graph(graph, n, bidir, use_weights=weighted)
+    xs = rng.randint(0, 2, size=(B, n)).astype(np.uint8)
+    x = to_dev_bool(xs)
+    d_tile = ops.maxcut_delta_all(g, x)                       # B >= 2048 -> tile kernel
+    c_tile = ops.maxcut_node_cutdeg(g, x)
+    d_el = torch.cat([ops.maxcut_delta_all(g, x[i:i + 1000].contiguous()) for i in range(0, B, 1000)])
+    c_el = torch.cat([ops.maxcut_node_cutdeg(g, x[i:i + 1000].contiguous()) for i in range(0, B, 1000)])
+    assert torch.equal(d_tile, d_el) and torch.equal(c_tile, c_el)
+    sub = rng.choice(B, 6, replace=False)
+    assert np.array_equal(d_tile[sub].cpu().numpy(), onp.maxcut_delta_all(xs[sub], graph, n, graph[:, 2] if weighted else None))
+    assert np.array_equal(c_tile[sub].cpu().numpy(), onp.maxcut_node_cutdeg(xs[sub], graph, n, bool(bidir)))
