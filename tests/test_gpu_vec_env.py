@@ -1,0 +1,77 @@
+"""elegantrl vec-env contract + torch.ops registration + a dREINFORCE-shaped outer loop."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle_np as onp
+from tests.gpu_util import DEV, gnm_arr
+
+pytestmark = pytest.mark.gpu
+
+
+def test_vec_env_contract():
+    from rlsolver_amd.envs.vec_env import MaxcutVecEnv
+    n, m, B = 300, 1500, 70
+    garr = gnm_arr(n, m, 3)
+    env = MaxcutVecEnv([tuple(int(v) for v in r) for r in garr], n, B, max_step=5, gpu_id=0)
+    assert (env.num_envs, env.state_dim, env.action_dim, env.if_discrete, env.max_step) == (B, n, n, True, 5)
+    torch.manual_seed(0)
+    state, info = env.reset()
+    assert state.shape == (B, n) and state.dtype == torch.float32 and isinstance(info, dict)
+    ref = onp.PPOEnvOracle(garr, n, 5, False)
+    ref.reset_to(state.cpu().numpy() > 0)
+    rng = np.random.RandomState(1)
+    for t in range(5):
+        a = torch.from_numpy(rng.randint(0, n, size=B).astype(np.int32)).to(DEV)     # int32 like AgentBase.py:149
+        state, reward, terminal, truncate, info = env.step(a)
+        _, rr, dd, cc = ref.step(a.cpu().numpy().astype(np.int64))
+        assert reward.dtype == torch.float32 and terminal.dtype == torch.bool and truncate.dtype == torch.bool
+        assert np.array_equal(reward.cpu().numpy(), rr) and np.array_equal(info["obj"].cpu().numpy(), cc)
+        assert not terminal.any() and bool(truncate.all()) == (t == 4)
+    assert np.array_equal(state.cpu().numpy(), ref.xs)
+
+
+def test_torch_ops_registered_and_equal():
+    from rlsolver_amd import ops, torch_ops
+    from rlsolver_amd.graph import build_csr, generate_gnm
+    n, B = 256, 130
+    g = ops.DeviceGraph(build_csr(generate_gnm(n, 1200, 5), num_nodes=n), DEV)
+    h = torch_ops.register_graph(g)
+    xs = ops.rand_spins(B, n, 3, DEV)
+    assert torch.equal(torch.ops.rlsolver_hip.maxcut_obj(h, xs), ops.maxcut_obj(g, xs))
+    assert torch.equal(torch.ops.rlsolver_hip.maxcut_delta_all(h, xs), ops.maxcut_delta_all(g, xs))
+    x2, v2 = xs.clone(), ops.maxcut_obj(g, xs)
+    x3, v3 = xs.clone(), v2.clone()
+    torch.ops.rlsolver_hip.maxcut_greedy_sweep(h, x2, v2)
+    ops.maxcut_greedy_sweep(g, x3, v3)
+    assert torch.equal(x2, x3) and torch.equal(v2, v3)
+    with pytest.raises(NotImplementedError):
+        torch.ops.rlsolver_hip.maxcut_obj(h, xs.cpu())          # no CPU kernel registered
+    torch_ops.release_graph(h)
+    with pytest.raises(RuntimeError):
+        torch.ops.rlsolver_hip.maxcut_obj(h, xs)
+
+
+def test_dreinforce_shaped_outer_loop_improves():
+    """The call pattern of L2A/demo_instance.py:141-165 (sub-set sampling replaced by random
+    restarts): local_search_inplace x searchers -> pick_xs_by_vs -> update_xs_by_vs -> best tracking."""
+    from rlsolver_amd.envs.env_L2A import EnvMaxcut
+    from rlsolver_amd.methods.util_read_data import pick_xs_by_vs, update_xs_by_vs
+    n, m = 800, 4694
+    garr = gnm_arr(n, m, 14)
+    env = EnvMaxcut(mygraph=[tuple(int(v) for v in r) for r in garr], device=DEV, if_bidirectional=True, num_nodes=n)
+    torch.manual_seed(0)
+    num_sims, num_repeats = 16, 8
+    best_xs = env.generate_xs_randomly(num_sims)
+    best_vs = env.calculate_obj_values(best_xs)
+    v_start = best_vs.clone()
+    for it in range(3):
+        full_xs = best_xs.repeat(num_repeats, 1)
+        full_xs ^= torch.rand(full_xs.shape, device=DEV) < 0.02
+        full_vs = env.calculate_obj_values(full_xs)
+        for _ in range(2):
+            env.local_search_inplace(full_xs, full_vs, num_iters=4, num_spin=8)
+        good_xs, good_vs = pick_xs_by_vs(full_xs, full_vs, num_repeats, True)
+        update_xs_by_vs(best_xs, best_vs, good_xs, good_vs, True)
+    assert (best_vs >= v_start).all() and float(best_vs.float().mean()) > 0.6 * m
+    assert np.array_equal(best_vs.cpu().numpy(), onp.maxcut_obj(best_xs.cpu().numpy(), garr, True))
