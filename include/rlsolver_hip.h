@@ -123,6 +123,32 @@ int rls_maxcut_greedy_sweep(const rls_graph* g, uint8_t* x, int64_t B,
 int rls_maxcut_propose_accept(const rls_graph* g, uint8_t* x, int64_t B, const uint8_t* mask,
                               int64_t* obj, void* stream);
 
+/* Pre-pass of the fused local search  envs/env_L2A.py:90-92 (methods/LocalSearch.py:64):
+ *   ws[b,i] = n0_num_n1[i] - mult * cutdeg[b,i]   (stored adjacency; int32 [B,N], exact)
+ * mult = 1 for local_search_inplace in both env flavours (bidirectional: 2 * (cutdeg / 2)),
+ * 2 for LocalSearch.random_search on a unidirectional env.  (ws_std = max_b ws - min_b ws is a
+ * whole-batch statistic: one aminmax pass over ws by the caller.) */
+int rls_maxcut_ls_weights(const rls_graph* g, const uint8_t* x, int64_t B, int32_t mult, int32_t* ws, void* stream);
+
+/* K2+K6+K5 fused: EnvMaxcut.local_search_inplace  envs/env_L2A.py:87-116 (first_draw_proposes = 0)
+ * and the body of LocalSearch.random_search  methods/LocalSearch.py:53-83 (first_draw_proposes = 1)
+ * in one kernel, the 64-env tile resident in LDS throughout:
+ *   thresh[b] = kthvalue(ws[b,:] + noise[0,b,:] * rd_std, k = N - num_spin)
+ *   for t in rounds: mask = (ws + noise[t] * rd_std) > thresh; proposal = x ^ mask;
+ *                    rows whose proposal has cut >= obj take it                     (:98-107)
+ *   greedy single-flip sweep (:109-116)
+ * ws int32 [B,N] = the reference's  n0_num_n1 - k * cutdeg  (exact integer), rd_std f32 [N] =
+ * (max_b ws - min_b ws) * noise_std  -- a whole-batch statistic, hence computed by the caller.
+ * noise f32 [num_iters + 1 - first_draw_proposes, B, N] = the randn_like draws in call order (test
+ * mode: bit-exact against the reference) or NULL = in-kernel Philox + Box-Muller keyed by
+ * (seed, env_offset + b, node, round).  obj int64 [B]: in/out, or out only when compute_obj != 0
+ * (the reference's good_vs.shape == () case).  Unweighted graphs, max degree <= 512,
+ * num_spin <= 15; RLS_EUNSUPPORTED otherwise (callers fall back to K2 / K6 / K5). */
+int rls_maxcut_local_search(const rls_graph* g, uint8_t* x, int64_t B, const int32_t* ws, const float* rd_std,
+                            const float* noise, uint64_t seed, int64_t env_offset, int32_t num_iters,
+                            int32_t num_spin, int32_t first_draw_proposes, int64_t* obj, int32_t compute_obj,
+                            void* stream);
+
 /* K10 update_xs_by_vs(xs0, vs0, xs1, vs1, if_maximize)  methods/util_read_data.py:190-202:
  *     rows of (xs1, vs1) that are >= (<= when !if_maximize) replace (xs0, vs0). */
 int rls_select_better_rows(uint8_t* xs0, int64_t* vs0, const uint8_t* xs1, const int64_t* vs1,

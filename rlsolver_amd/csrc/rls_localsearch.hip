@@ -1,0 +1,255 @@
+// Fused local search: EnvMaxcut.local_search_inplace (envs/env_L2A.py:87-116) and
+// LocalSearch.random_search (methods/LocalSearch.py:53-86) as ONE kernel per call.
+//
+// The decomposed path (K2 -> torch weights/noise/kthvalue -> 8 x K6 -> K5) re-transposes the 64-env
+// tile ten times and spends 85 % of its time in torch ops on [B, N] int64/f32 tensors (17.7 ms at
+// B = 2^16 on G22).  Here the tile is transposed once and stays in LDS:
+//
+//   phase 0  4 waves load the bit tile, the CSR rowptr, (optionally) count the initial cut
+//   phase 1  thresh[b] = kthvalue(ws + noise_0 * rd_std, k = N - num_spin): every lane keeps the
+//            num_spin+1 largest values of its env in registers (max/min insertion network), the four
+//            waves' lists are merged through LDS
+//   phase 2  num_iters proposal rounds: mask bit = (ws + noise_t * rd_std) > thresh, one ballot per
+//            node gives the mask word directly (no byte->bit transpose), proposal = words ^ mask,
+//            cut by the bit-sliced counter (4 waves), accepted envs merged with one AND/XOR per word
+//   phase 3  wave 0 runs the greedy sweep (rls_sweep.h) on the resident tile
+//   phase 4  4 waves write the tile back
+//
+// ws = int32 [B, N] (the reference's  n0_num_n1 - k * cutdeg, an exact integer in both flavours) and
+// rd_std f32 [N] come from a pre-pass because rd_std is a statistic over the WHOLE batch
+// (max - min over dim 0, env_L2A.py:93-94).  noise = the randn_like draws (test mode, bit-exact
+// against the reference) or NULL for an in-kernel counter-based hash + Box-Muller keyed by (seed, global env,
+// node, round).  f32 arithmetic follows torch: (float)ws + (noise * rd_std), two roundings.
+#include "rls_cutcount.h"
+#include "rls_sweep.h"
+
+namespace rls {
+
+constexpr int kLsWaves = 4;
+constexpr int kTopCap = 16;  // num_spin + 1 <= kTopCap
+
+__device__ __forceinline__ void top_insert(float (&t)[kTopCap], float v) {
+#pragma unroll
+    for (int j = 0; j < kTopCap; ++j) {
+        const float hi = fmaxf(t[j], v);
+        v = fminf(t[j], v);
+        t[j] = hi;
+    }
+}
+
+// Counter-based noise for the production path: murmur3's 32-bit finaliser over (seed, global env,
+// node quad, round) -- order-independent like Philox (so results do not depend on how envs are
+// sharded or how waves split the nodes) at a quarter of its cost; the statistical bar here is
+// "exploration noise", the parity bar is met by the test mode with supplied draws.
+__device__ __forceinline__ uint32_t fmix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+
+// four standard normals (Box-Muller) for nodes 4q..4q+3 in round `it`; env_key = per-env mixed seed
+__device__ __forceinline__ void normal4(uint32_t env_key, uint32_t q, uint32_t it, float (&z)[4]) {
+    const uint32_t k = env_key ^ (q * 0x9E3779B1u) ^ (it * 0x7FEB352Du + 0x165667B1u);
+    const uint32_t r0 = fmix32(k), r1 = fmix32(k + 0x27D4EB2Fu), r2 = fmix32(k + 0x4FA9D65Eu), r3 = fmix32(k + 0x777EC18Du);
+    const float u1 = ((float)(r0 >> 8) + 1.0f) * (1.0f / 16777216.0f);  // (0, 1]
+    const float u2 = (float)(r1 >> 8) * (1.0f / 16777216.0f);
+    const float u3 = ((float)(r2 >> 8) + 1.0f) * (1.0f / 16777216.0f);
+    const float u4 = (float)(r3 >> 8) * (1.0f / 16777216.0f);
+    const float ra = sqrtf(-2.0f * __logf(u1)), rb = sqrtf(-2.0f * __logf(u3));
+    const float ta = 6.28318530718f * u2, tb = 6.28318530718f * u4;
+    z[0] = ra * __cosf(ta); z[1] = ra * __sinf(ta);
+    z[2] = rb * __cosf(tb); z[3] = rb * __sinf(tb);
+}
+
+template <bool VEC, bool V4, int P>
+__global__ __launch_bounds__(kLsWaves * kWave) void k_maxcut_local_search(
+    uint8_t* __restrict__ x, int64_t B, int64_t N, const int32_t* __restrict__ eu, const int32_t* __restrict__ ev,
+    int64_t E, int halve, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t nnz,
+    const int32_t* __restrict__ ws, const float* __restrict__ rd_std, const float* __restrict__ noise, uint64_t seed,
+    int64_t env_offset, int num_iters, int num_spin, int first_draw_proposes, int64_t* __restrict__ obj,
+    int compute_obj) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* words = reinterpret_cast<uint64_t*>(smem);
+    uint64_t* prop = words + (N + 2);
+    int32_t* rp = reinterpret_cast<int32_t*>(prop + N);
+    int32_t* ring = rp + ((N + 1 + 3) & ~3ll);
+    int64_t* scratch = reinterpret_cast<int64_t*>(ring + kRing);
+    float* tops = reinterpret_cast<float*>(scratch + kLsWaves * kWave);   // [waves][kTopCap][64]
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    const int64_t b0 = (int64_t)blockIdx.x * kWave;
+    const int64_t b = b0 + lane;
+    const bool valid = b < B;
+    const uint64_t gb = (uint64_t)(b + env_offset);
+    const uint32_t env_key = fmix32((uint32_t)seed ^ fmix32((uint32_t)(seed >> 32) ^ fmix32((uint32_t)gb) ^
+                                                            ((uint32_t)(gb >> 32) * 0x9E3779B1u)));
+
+    // ---- phase 0
+    if (threadIdx.x == 0) words[N] = 0;
+    for (int64_t i = threadIdx.x; i <= N; i += kLsWaves * kWave) rp[i] = rowptr[i];
+    tile_load_bits<uint8_t, VEC>(x, B, N, b0, words, lane, w, kLsWaves);
+    __syncthreads();
+    int64_t my_obj;
+    if (compute_obj) {
+        my_obj = block_sum_partials<kLsWaves>(tile_cut_count<P>(words, eu, ev, E, lane, w, kLsWaves), scratch, lane, w);
+        if (halve) my_obj >>= 1;
+        __syncthreads();
+    } else {
+        my_obj = valid ? obj[b] : 0;
+    }
+
+    const int32_t* ws_row = ws + (valid ? b : 0) * N;
+    const int64_t nquads = (N + 3) >> 2;
+    constexpr int G = 4;   // quads per trip: all of a trip's (lane-strided) row loads are issued before use
+    typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+    // spin_rand for the G quads q0, q0 + kLsWaves, ...: v[g][k] = (float)ws + noise * rd_std
+    auto spin_rand_trip = [&](int64_t q0, int it, float (&v)[G][4]) {
+        i32x4 wq[G];
+        f32x4 zq[G];
+#pragma unroll
+        for (int gI = 0; gI < G; ++gI) {
+            const int64_t q = q0 + (int64_t)gI * kLsWaves;
+            wq[gI] = i32x4{0, 0, 0, 0};
+            zq[gI] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (q < nquads && valid) {
+                if constexpr (V4) {
+                    wq[gI] = *reinterpret_cast<const i32x4*>(ws_row + q * 4);
+                    if (noise) zq[gI] = *reinterpret_cast<const f32x4*>(noise + ((int64_t)it * B + b) * N + q * 4);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (q * 4 + k < N) {
+                            wq[gI][k] = ws_row[q * 4 + k];
+                            if (noise) zq[gI][k] = noise[((int64_t)it * B + b) * N + q * 4 + k];
+                        }
+                }
+            }
+        }
+#pragma unroll
+        for (int gI = 0; gI < G; ++gI) {
+            const int64_t q = q0 + (int64_t)gI * kLsWaves;
+            float z[4] = {zq[gI][0], zq[gI][1], zq[gI][2], zq[gI][3]};
+            if (!noise) normal4(env_key, (uint32_t)q, (uint32_t)it, z);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int64_t n = q * 4 + k;
+                const float sd = (n < N) ? rd_std[n] : 0.0f;
+                v[gI][k] = (float)wq[gI][k] + z[k] * sd;   // two roundings (fp-contract off): torch's ws + randn * rd_std
+            }
+        }
+    };
+
+    // ---- phase 1: threshold = (num_spin + 1)-th largest of the first draw
+    float t[kTopCap];
+#pragma unroll
+    for (int j = 0; j < kTopCap; ++j) t[j] = -INFINITY;
+    for (int64_t q0 = w; q0 < nquads; q0 += (int64_t)G * kLsWaves) {
+        float v[G][4];
+        spin_rand_trip(q0, 0, v);
+#pragma unroll
+        for (int gI = 0; gI < G; ++gI)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if ((q0 + (int64_t)gI * kLsWaves) * 4 + k < N) top_insert(t, v[gI][k]);
+    }
+#pragma unroll
+    for (int j = 0; j < kTopCap; ++j) tops[(w * kTopCap + j) * kWave + lane] = t[j];
+    __syncthreads();
+    for (int ow = 0; ow < kLsWaves; ++ow) {
+        if (ow == w) continue;
+#pragma unroll
+        for (int j = 0; j < kTopCap; ++j) top_insert(t, tops[(ow * kTopCap + j) * kWave + lane]);
+    }
+    float thresh = t[0];
+#pragma unroll
+    for (int j = 1; j < kTopCap; ++j) thresh = (j == num_spin) ? t[j] : thresh;   // kthvalue(k = N - num_spin)
+    __syncthreads();
+
+    // ---- phase 2: proposal rounds
+    for (int itp = 0; itp < num_iters; ++itp) {
+        const int it = first_draw_proposes ? itp : itp + 1;
+        for (int64_t q0 = w; q0 < nquads; q0 += (int64_t)G * kLsWaves) {
+            float v[G][4];
+            spin_rand_trip(q0, it, v);
+#pragma unroll
+            for (int gI = 0; gI < G; ++gI) {
+                const int64_t q = q0 + (int64_t)gI * kLsWaves;
+                if (q >= nquads) break;
+                uint64_t mine = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint64_t mm = ballot64(valid && (q * 4 + k < N) && (v[gI][k] > thresh));   // spin_rand.gt(thresh)
+                    if (lane == k) mine = mm;
+                }
+                if (lane < 4 && q * 4 + lane < N) prop[q * 4 + lane] = words[q * 4 + lane] ^ mine;
+            }
+        }
+        __syncthreads();
+        int64_t total = block_sum_partials<kLsWaves>(tile_cut_count<P>(prop, eu, ev, E, lane, w, kLsWaves), scratch, lane, w);
+        if (halve) total >>= 1;
+        const bool accept = valid && (total >= my_obj);          // update_xs_by_vs: vs1.ge(vs0)
+        if (accept) my_obj = total;
+        const uint64_t am = ballot64(accept);
+        __syncthreads();
+        for (int64_t n = threadIdx.x; n < N; n += kLsWaves * kWave) words[n] ^= (words[n] ^ prop[n]) & am;
+        __syncthreads();
+    }
+
+    // ---- phase 3: greedy sweep on the resident tile (one wave; the step is sequential per node)
+    if (w == 0) {
+        my_obj += sweep_tile(words, rp, ring, col, nnz, N, lane);
+        if (valid) obj[b] = my_obj;
+    }
+    __syncthreads();
+    // ---- phase 4
+    tile_store_bytes<VEC>(x, B, N, b0, words, lane, w, kLsWaves);
+}
+
+}  // namespace rls
+
+using namespace rls;
+
+extern "C" int rls_maxcut_local_search(const rls_graph* g, uint8_t* x, int64_t B, const int32_t* ws,
+                                       const float* rd_std, const float* noise, uint64_t seed, int64_t env_offset,
+                                       int32_t num_iters, int32_t num_spin, int32_t first_draw_proposes, int64_t* obj,
+                                       int32_t compute_obj, void* stream) {
+    if (int rc = check_graph(g)) return rc;
+    RLS_REQUIRE(B >= 0 && num_iters >= 0, RLS_EINVAL, "bad sizes");
+    if (B == 0) return RLS_OK;
+    RLS_REQUIRE(x && ws && rd_std && obj, RLS_EINVAL, "NULL pointer");
+    const int64_t N = g->num_nodes, E = g->num_stored_edges;
+    RLS_REQUIRE(num_spin >= 0 && num_spin + 1 <= kTopCap && num_spin < N, RLS_EUNSUPPORTED,
+                "num_spin=%d outside [0, %d] (and < N)", num_spin, kTopCap - 1);
+    RLS_REQUIRE(!g->wgt && g->max_degree <= kRingMaxRun, RLS_EUNSUPPORTED,
+                "fused local search needs an unweighted graph with max degree <= %d", kRingMaxRun);
+    const size_t lds = (size_t)(N + 2) * 8 + (size_t)N * 8 + (size_t)((N + 1 + 3) & ~3ll) * 4 + (size_t)kRing * 4 +
+                       (size_t)kLsWaves * kWave * 8 + (size_t)kLsWaves * kTopCap * kWave * 4;
+    RLS_REQUIRE(lds <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS (max %d)", (long long)N, lds,
+                kLdsBytes);
+    const int P = pick_planes(E);
+    RLS_REQUIRE(P != 0, RLS_EUNSUPPORTED, "E'=%lld too large", (long long)E);
+    const bool vec = rows_vec_aligned(x, N, 1);
+    const bool v4 = (N % 4 == 0) && ((((uintptr_t)ws) | ((uintptr_t)noise)) & 15) == 0;   // 16-byte row slices of ws / noise
+    const dim3 grid((unsigned)ceil_div(B, kWave)), block(kLsWaves * kWave);
+    hipStream_t s = as_stream(stream);
+    const int halve = g->if_bidirectional ? 1 : 0;
+#define LAUNCH_LSF(VEC, PP)                                                                                          \
+    do {                                                                                                             \
+        auto kern = v4 ? k_maxcut_local_search<VEC, true, PP> : k_maxcut_local_search<VEC, false, PP>; \
+        if (lds > 64 * 1024)                                                                                         \
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
+        hipLaunchKernelGGL(kern, grid, block, lds, s, x, B, N, g->eu, g->ev, E, halve, g->rowptr, g->col, g->nnz, ws, \
+                           rd_std, noise, seed, env_offset, (int)num_iters, (int)num_spin, (int)first_draw_proposes,  \
+                           obj, (int)compute_obj);                                                                   \
+    } while (0)
+#define DISPATCH_P(VEC)                       \
+    switch (P) {                              \
+        case 12: LAUNCH_LSF(VEC, 12); break;  \
+        case 16: LAUNCH_LSF(VEC, 16); break;  \
+        case 20: LAUNCH_LSF(VEC, 20); break;  \
+        default: LAUNCH_LSF(VEC, 24); break;  \
+    }
+    if (vec) { DISPATCH_P(true) } else { DISPATCH_P(false) }
+#undef DISPATCH_P
+#undef LAUNCH_LSF
+    return check_launch("k_maxcut_local_search");
+}

@@ -1,7 +1,7 @@
 // MaxCut environment kernels for gfx950 (MI355X).  See include/rlsolver_hip.h for the
 // reference call site each entry point replaces, DESIGN.md for layouts and rooflines.
 #include "rls_cutcount.h"
-#include "rls_ring.h"
+#include "rls_sweep.h"
 
 namespace rls {
 
@@ -102,57 +102,11 @@ __global__ __launch_bounds__(kWave) void k_maxcut_greedy_sweep(uint8_t* __restri
     const int lane = threadIdx.x;
     const int64_t b0 = (int64_t)blockIdx.x * kWave;
     if (lane == 0) words[N] = 0;   // sentinel word
-    int64_t F;
-    ring_prime(col, nnz, F, ring, lane);
     for (int64_t i = lane; i <= N; i += kWave) rp[i] = rowptr[i];
     tile_load_bits<uint8_t, VEC>(x, B, N, b0, words, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const int sh = lane & 31;
-    const uint32_t half4 = (uint32_t)(lane >> 5) * 4u;   // byte offset of this lane's dword inside a word
-    const unsigned char* wbytes = smem;
-    int64_t gain = 0;
-    // software pipeline: node i+1's row bounds and this lane's ring entry are fetched while node i runs
-    int r0 = rp[0], r1 = rp[1];
-    const int sentinel = (int)N;   // words[N] == 0
-    int my_nb = (r0 + lane < r1) ? ring[(r0 + lane) & (kRing - 1)] : sentinel;
-    for (int64_t i = 0; i < N; ++i) {
-        ring_advance(col, nnz, F, r0, ring, lane);     // wave-uniform; refills once per ~kRefill entries
-        const int r2 = (i + 2 <= N) ? rp[i + 2] : r1;
-        const int nxt_nb = (r1 + lane < r2) ? ring[(r1 + lane) & (kRing - 1)] : sentinel;
-        const uint32_t xi = (*reinterpret_cast<const uint32_t*>(wbytes + ((uint32_t)i * 8u + half4)) >> sh) & 1u;
-        int acc = 0;   // #neighbours with spin 1 in this lane's env
-        const int deg = r1 - r0;
-        const int first = deg < kWave ? deg : kWave;
-        // 8 neighbours per trip, written out by hand (readlane is convergent: hipcc will not unroll
-        // it, and a rolled loop pays one full LDS round trip per neighbour).  Lanes past the row end
-        // hold the sentinel id N whose word is always zero, so no tail predication is needed.
-        for (int j = 0; j < first; j += 8) {
-            uint32_t w[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const uint32_t nb = (uint32_t)__builtin_amdgcn_readlane(my_nb, j + k);
-                w[k] = *reinterpret_cast<const uint32_t*>(wbytes + (nb * 8u + half4));
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) acc += (int)((w[k] >> sh) & 1u);
-        }
-        for (int j = r0 + kWave; j < r1; ++j) {        // hubs: the rest of the row straight from the ring
-            const uint32_t nb = (uint32_t)ring[j & (kRing - 1)];
-            acc += (int)((*reinterpret_cast<const uint32_t*>(wbytes + (nb * 8u + half4)) >> sh) & 1u);
-        }
-        const int same_minus_diff = xi ? (2 * acc - deg) : (deg - 2 * acc);   // sum_j (x_i == x_j ? +1 : -1)
-        const bool flip = same_minus_diff >= 0;
-        gain += flip ? same_minus_diff : 0;
-        const uint64_t fm = ballot64(flip);
-        if (lane == 0) words[i] ^= fm;
-        // one wave: DS ops execute in issue order, so a compiler barrier is all the next node needs
-        asm volatile("" ::: "memory");
-        r0 = r1;
-        r1 = r2;
-        my_nb = nxt_nb;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const int64_t gain = sweep_tile(words, rp, ring, col, nnz, N, lane);
     tile_store_bytes<VEC>(x, B, N, b0, words, lane);
     if (b0 + lane < B) obj[b0 + lane] += gain;
 }
@@ -328,6 +282,70 @@ __global__ __launch_bounds__(kTileWaves * kWave) void k_node_stats_tile(const ui
                     reinterpret_cast<u32x4*>(dst)[q] = *reinterpret_cast<const u32x4*>(src + q * 16);
             } else {
                 for (int k = 0; k < nb_here; ++k) dst[k] = *reinterpret_cast<const OutT*>(src + k * (int)sizeof(OutT));
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
+// Local-search weights: ws[b,i] = stored_deg(i) - mult * cutdeg(b,i) as int32 -- the pre-pass of
+// rls_maxcut_local_search (the whole-batch max/min per node is one aminmax pass over this tensor; doing
+// it here with 2 atomics per (tile, node) cost 3x the kernel itself).  Same structure as k_node_stats_tile.
+template <bool VEC>
+__global__ __launch_bounds__(kTileWaves * kWave) void k_ls_weights(const uint8_t* __restrict__ x, int64_t B, int64_t N,
+                                                                   const int32_t* __restrict__ rowptr,
+                                                                   const int32_t* __restrict__ col, int mult,
+                                                                   int32_t* __restrict__ ws) {
+    constexpr int NB = 32, STRIDE = 144;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* words = reinterpret_cast<uint64_t*>(smem);
+    const unsigned char* wbytes = smem;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    unsigned char* stage = smem + (size_t)(N + 2) * 8 + (size_t)w * kWave * STRIDE;
+    const int64_t b0 = (int64_t)blockIdx.x * kWave;
+    if (threadIdx.x == 0) words[N] = 0;
+    tile_load_bits<uint8_t, VEC>(x, B, N, b0, words, lane, w, kTileWaves);
+    __syncthreads();
+    const int sh = lane & 31;
+    const uint32_t half4 = (uint32_t)(lane >> 5) * 4u;
+    const int64_t b = b0 + lane;
+    const bool valid = b < B;
+    for (int64_t i0 = (int64_t)w * NB; i0 < N; i0 += (int64_t)kTileWaves * NB) {
+        const int nb_here = (int)((N - i0) < NB ? (N - i0) : NB);
+        for (int k = 0; k < nb_here; ++k) {
+            const int64_t i = i0 + k;
+            const int r0 = rowptr[i], r1 = rowptr[i + 1];
+            const uint32_t xi = (*reinterpret_cast<const uint32_t*>(wbytes + ((uint32_t)i * 8u + half4)) >> sh) & 1u;
+            int acc = 0;
+            for (int base = r0; base < r1; base += kWave) {
+                const int cnt = (r1 - base) < kWave ? (r1 - base) : kWave;
+                const uint32_t my_nb = (lane < cnt) ? (uint32_t)col[base + lane] : (uint32_t)N;
+                for (int j = 0; j < cnt; j += 8) {
+                    uint32_t wv[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const uint32_t nb = (uint32_t)__builtin_amdgcn_readlane((int)my_nb, j + q);
+                        wv[q] = *reinterpret_cast<const uint32_t*>(wbytes + (nb * 8u + half4));
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) acc += (int)((wv[q] >> sh) & 1u);
+                }
+            }
+            const int deg = r1 - r0;
+            const int val = deg - mult * (xi ? (deg - acc) : acc);
+            *reinterpret_cast<int32_t*>(stage + lane * STRIDE + k * 4) = val;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (valid) {
+            int32_t* dst = ws + b * N + i0;
+            const unsigned char* src = stage + lane * STRIDE;
+            if (nb_here == NB && ((((uintptr_t)dst) & 15) == 0)) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    reinterpret_cast<u32x4*>(dst)[q] = *reinterpret_cast<const u32x4*>(src + q * 16);
+            } else {
+                for (int k = 0; k < nb_here; ++k) dst[k] = *reinterpret_cast<const int32_t*>(src + k * 4);
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -601,6 +619,29 @@ int rls_maxcut_delta_all(const rls_graph* g, const uint8_t* x, int64_t B, int32_
         hipLaunchKernelGGL(k_delta_all<false>, grid, block, 0, as_stream(stream), x, B, N, g->rowptr, g->col, g->wgt,
                            delta);
     return check_launch("k_delta_all");
+}
+
+int rls_maxcut_ls_weights(const rls_graph* g, const uint8_t* x, int64_t B, int32_t mult, int32_t* ws, void* stream) {
+    if (int rc = check_graph(g)) return rc;
+    RLS_REQUIRE(B >= 0 && mult >= 0, RLS_EINVAL, "bad arguments");
+    if (B == 0) return RLS_OK;
+    RLS_REQUIRE(x && ws, RLS_EINVAL, "NULL pointer");
+    const int64_t N = g->num_nodes;
+    const size_t lds = node_stats_lds(N);
+    RLS_REQUIRE(lds <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS (max %d)", (long long)N, lds,
+                kLdsBytes);
+    const dim3 grid((unsigned)ceil_div(B, kWave)), block(kTileWaves * kWave);
+    hipStream_t s = as_stream(stream);
+#define LAUNCH_LW(VEC)                                                                                           \
+    do {                                                                                                         \
+        auto kern = k_ls_weights<VEC>;                                                                           \
+        if (lds > 64 * 1024)                                                                                     \
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+        hipLaunchKernelGGL(kern, grid, block, lds, s, x, B, N, g->erowptr, g->ev, (int)mult, ws);                 \
+    } while (0)
+    if (rows_vec_aligned(x, N, 1)) LAUNCH_LW(true); else LAUNCH_LW(false);
+#undef LAUNCH_LW
+    return check_launch("k_ls_weights");
 }
 
 int rls_select_better_rows(uint8_t* xs0, int64_t* vs0, const uint8_t* xs1, const int64_t* vs1, int64_t B,

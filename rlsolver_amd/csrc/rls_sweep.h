@@ -1,0 +1,66 @@
+// The greedy single-flip sweep over a 64-env bit tile, as a device function shared by the stand-alone
+// K5 kernel and the fused local-search kernel.  One wave; see rls_maxcut.hip for the design notes.
+#pragma once
+#include "rls_ring.h"
+#include "rls_tile.h"
+
+namespace rls {
+
+// words[0..N) = tile (words[N] must be 0: the sentinel), rp[0..N] = CSR rowptr in LDS, ring = kRing
+// int32 entries of LDS.  `wbytes` is the byte address of words[0].  Returns this lane's total gain.
+// The caller must have made words / rp visible (barrier) and must not have ring loads in flight.
+__device__ __forceinline__ int64_t sweep_tile(uint64_t* words, const int32_t* rp, int32_t* ring,
+                                              const int32_t* __restrict__ col, int64_t nnz, int64_t N, int lane) {
+    const unsigned char* wbytes = reinterpret_cast<const unsigned char*>(words);
+    int64_t F;
+    ring_prime(col, nnz, F, ring, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    const int sh = lane & 31;
+    const uint32_t half4 = (uint32_t)(lane >> 5) * 4u;   // byte offset of this lane's dword inside a word
+    int64_t gain = 0;
+    // software pipeline: node i+1's row bounds and this lane's ring entry are fetched while node i runs
+    int r0 = rp[0], r1 = rp[1];
+    const int sentinel = (int)N;   // words[N] == 0
+    int my_nb = (r0 + lane < r1) ? ring[(r0 + lane) & (kRing - 1)] : sentinel;
+    for (int64_t i = 0; i < N; ++i) {
+        ring_advance(col, nnz, F, r0, ring, lane);     // wave-uniform; refills once per ~kRefill entries
+        const int r2 = (i + 2 <= N) ? rp[i + 2] : r1;
+        const int nxt_nb = (r1 + lane < r2) ? ring[(r1 + lane) & (kRing - 1)] : sentinel;
+        const uint32_t xi = (*reinterpret_cast<const uint32_t*>(wbytes + ((uint32_t)i * 8u + half4)) >> sh) & 1u;
+        int acc = 0;   // #neighbours with spin 1 in this lane's env
+        const int deg = r1 - r0;
+        const int first = deg < kWave ? deg : kWave;
+        // 8 neighbours per trip, written out by hand (readlane is convergent: hipcc will not unroll
+        // it, and a rolled loop pays one full LDS round trip per neighbour).  Lanes past the row end
+        // hold the sentinel id N whose word is always zero, so no tail predication is needed.
+        for (int j = 0; j < first; j += 8) {
+            uint32_t w[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint32_t nb = (uint32_t)__builtin_amdgcn_readlane(my_nb, j + k);
+                w[k] = *reinterpret_cast<const uint32_t*>(wbytes + (nb * 8u + half4));
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) acc += (int)((w[k] >> sh) & 1u);
+        }
+        for (int j = r0 + kWave; j < r1; ++j) {        // hubs: the rest of the row straight from the ring
+            const uint32_t nb = (uint32_t)ring[j & (kRing - 1)];
+            acc += (int)((*reinterpret_cast<const uint32_t*>(wbytes + (nb * 8u + half4)) >> sh) & 1u);
+        }
+        const int same_minus_diff = xi ? (2 * acc - deg) : (deg - 2 * acc);   // sum_j (x_i == x_j ? +1 : -1)
+        const bool flip = same_minus_diff >= 0;
+        gain += flip ? same_minus_diff : 0;
+        const uint64_t fm = ballot64(flip);
+        if (lane == 0) words[i] ^= fm;
+        // one wave: DS ops execute in issue order, so a compiler barrier is all the next node needs
+        asm volatile("" ::: "memory");
+        r0 = r1;
+        r1 = r2;
+        my_nb = nxt_nb;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    return gain;
+}
+
+}  // namespace rls

@@ -53,6 +53,7 @@ class EnvMaxcut:
         self.n0_num_n1 = th.from_numpy(counts.astype(np.int64)).to(self.device)[None, :]
         self._adjacency_indies = None
         self._adjacency_bool = None
+        self.fused_local_search = True   # False: K2 + torch weights/noise/kthvalue + K6 + K5 as separate launches
 
     # ---- lazily built forms of the reference attributes
     @property
@@ -106,11 +107,25 @@ class EnvMaxcut:
         'addition' loop is ONE sequential O(E) sweep kernel instead of N objective evaluations.
 
         ``noise`` (f32 [num_iters + 1, B, N]) replaces the randn_like draws -- test hook."""
+        compute_vs = good_vs.shape == ()
+        if self.fused_local_search and ops.local_search_fusable(self.graph, num_spin):
+            # pre-pass kernel (weights + whole-batch max/min), then ONE kernel: threshold selection,
+            # num_iters proposal rounds, greedy sweep, with the 64-env tile resident in LDS
+            ws32, ws_std = ops.maxcut_ls_weights(self.graph, good_xs, 1)   # n0_num_n1 - k * vs_raw, exact in both flavours
+            rd_std = ws_std.float() * noise_std
+            good_vs = th.empty(good_xs.shape[0], dtype=th.long, device=self.device) if compute_vs else good_vs.long()
+            if noise is not None:
+                noise = noise.to(device=self.device, dtype=th.float32).contiguous()
+            ops.maxcut_local_search(self.graph, good_xs, ws32, rd_std.contiguous(), good_vs, num_iters, num_spin,
+                                    noise=noise, seed=0 if noise is not None else _seed_from_torch(),
+                                    first_draw_proposes=False, compute_obj=compute_vs)
+            return good_xs, good_vs
+
         vs_raw = self.calculate_obj_values_for_loop(good_xs, if_sum=False)
-        good_vs = vs_raw.sum(dim=1).long() if good_vs.shape == () else good_vs.long()
         ws = self.n0_num_n1 - (2 if self.if_bidirectional else 1) * vs_raw
         ws_std = ws.max(dim=0, keepdim=True)[0] - ws.min(dim=0, keepdim=True)[0]
         rd_std = ws_std.float() * noise_std
+        good_vs = vs_raw.sum(dim=1).long() if compute_vs else good_vs.long()
         draw = (lambda i: noise[i]) if noise is not None else (lambda i: th.randn_like(ws, dtype=th.float32))
         spin_rand = ws + draw(0) * rd_std
         thresh = th.kthvalue(spin_rand, k=self.num_nodes - num_spin, dim=1)[0][:, None]

@@ -50,16 +50,27 @@ class LocalSearch:
             raise RuntimeError("Index put requires the source and destination dtypes match, "
                                "got Float for the destination and Long for the source.")
 
-        thresh = None
-        for it in range(num_iters):
+        if getattr(sim, "fused_local_search", False) and ops.local_search_fusable(sim.graph, num_spin) and num_iters > 0:
+            # pre-pass + one kernel; here the first draw both fixes the threshold and is the first proposal (:66-69)
+            ws32, ws_std = ops.maxcut_ls_weights(sim.graph, prev_xs, 2)     # n0_num_n1 - 2 * prev_vs_raw (:64)
+            rd_std = ws_std.float() * noise_std
+            if noise is not None:
+                noise = noise.to(device=sim.device, dtype=th.float32).contiguous()
+            seed = 0 if noise is not None else int(th.randint(0, 2 ** 62, (1,), dtype=th.int64).item())
+            ops.maxcut_local_search(sim.graph, prev_xs, ws32, rd_std.contiguous(), prev_vs, num_iters, num_spin,
+                                    noise=noise, seed=seed, first_draw_proposes=True)
+        else:
             ws = sim.n0_num_n1 - (4 if sim.if_bidirectional else 2) * prev_vs_raw
             ws_std = ws.max(dim=0, keepdim=True)[0] - ws.min(dim=0, keepdim=True)[0]
-            rnd = noise[it] if noise is not None else th.randn_like(ws, dtype=th.float32)
-            spin_rand = ws + rnd * (ws_std.float() * noise_std)
-            thresh = th.kthvalue(spin_rand, k=kth, dim=1)[0][:, None] if thresh is None else thresh
-            spin_mask = spin_rand.gt(thresh)
-            ops.maxcut_propose_accept(sim.graph, prev_xs, spin_mask, prev_vs)
+            rd_std = ws_std.float() * noise_std
+            thresh = None
+            for it in range(num_iters):
+                rnd = noise[it] if noise is not None else th.randn_like(ws, dtype=th.float32)
+                spin_rand = ws + rnd * rd_std
+                thresh = th.kthvalue(spin_rand, k=kth, dim=1)[0][:, None] if thresh is None else thresh
+                spin_mask = spin_rand.gt(thresh)
+                ops.maxcut_propose_accept(sim.graph, prev_xs, spin_mask, prev_vs)
+            ops.maxcut_greedy_sweep(sim.graph, prev_xs, prev_vs)
 
-        ops.maxcut_greedy_sweep(sim.graph, prev_xs, prev_vs)
         num_update = update_xs_by_vs(self.good_xs, self.good_vs, prev_xs, prev_vs)
         return self.good_xs, self.good_vs, num_update

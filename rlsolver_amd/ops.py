@@ -173,6 +173,44 @@ def maxcut_propose_accept(g: DeviceGraph, xs: TEN, mask: TEN, obj: TEN) -> None:
     _abi.call("rls_maxcut_propose_accept", g.ref, _ptr(xs), B, _ptr(mask), _ptr(obj), _stream(g.device))
 
 
+LOCAL_SEARCH_MAX_SPIN = 15
+
+
+def local_search_fusable(g: DeviceGraph, num_spin: int) -> bool:
+    """Whether rls_maxcut_local_search covers this graph / setting (else: K2 + K6 + K5 path)."""
+    n = g.num_nodes
+    lds = (n + 2) * 8 + n * 8 + ((n + 4) // 4) * 16 + 4096 * 4 + 4 * 64 * 8 + 4 * 16 * 64 * 4
+    return (g.wgt is None and g.csr.max_degree <= 512 and 0 <= num_spin <= LOCAL_SEARCH_MAX_SPIN and num_spin < n
+            and lds <= 160 * 1024 and g.num_stored_edges < (1 << 24))
+
+
+def maxcut_ls_weights(g: DeviceGraph, xs: TEN, mult: int):
+    """Pre-pass of the fused local search: (ws int32 [B,N], ws_std int32 [N] = max_b ws - min_b ws)."""
+    B, _ = _spins(xs, "xs", g)
+    ws = torch.empty((B, g.num_nodes), dtype=torch.int32, device=g.device)
+    _abi.call("rls_maxcut_ls_weights", g.ref, _ptr(xs), B, int(mult), _ptr(ws), _stream(g.device))
+    mn, mx = torch.aminmax(ws, dim=0)
+    return ws, mx - mn
+
+
+def maxcut_local_search(g: DeviceGraph, xs: TEN, ws: TEN, rd_std: TEN, obj: TEN, num_iters: int, num_spin: int,
+                        noise: Optional[TEN] = None, seed: int = 0, env_offset: int = 0,
+                        first_draw_proposes: bool = False, compute_obj: bool = False) -> None:
+    """Fused local search (include/rlsolver_hip.h: rls_maxcut_local_search).  xs / obj in place."""
+    B, _ = _spins(xs, "xs", g)
+    _check(ws, "ws", (torch.int32,), g.device, (B, g.num_nodes))
+    _check(rd_std, "rd_std", (torch.float32,), g.device, (g.num_nodes,))
+    _check(obj, "obj", (torch.int64,), g.device, (B,))
+    if noise is not None:
+        need = num_iters + (0 if first_draw_proposes else 1)
+        _check(noise, "noise", (torch.float32,), g.device)
+        if noise.dim() != 3 or noise.shape[0] < need or tuple(noise.shape[1:]) != (B, g.num_nodes):
+            raise ValueError(f"noise must be [>= {need}, {B}, {g.num_nodes}]")
+    _abi.call("rls_maxcut_local_search", g.ref, _ptr(xs), B, _ptr(ws), _ptr(rd_std), _ptr(noise),
+              C.c_uint64(seed & (2 ** 64 - 1)), env_offset, num_iters, num_spin, int(bool(first_draw_proposes)),
+              _ptr(obj), int(bool(compute_obj)), _stream(g.device))
+
+
 def select_better_rows(xs0: TEN, vs0: TEN, xs1: TEN, vs1: TEN, if_maximize: bool = True) -> None:
     _check(xs0, "xs0", _SPIN_DTYPES)
     dev = xs0.device

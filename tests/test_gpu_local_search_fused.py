@@ -1,0 +1,104 @@
+"""The fused local-search kernel (rls_maxcut_local_search): bit-exact against the reference's
+golden traces in test mode (noise supplied), equal to the decomposed K2/K6/K5 path, and sane in
+production mode (in-kernel Philox + Box-Muller noise)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle_np as onp
+from tests.gpu_util import DEV, gnm_arr, to_dev_bool
+
+pytestmark = pytest.mark.gpu
+
+
+def mygraph_of(arr):
+    return [tuple(int(v) for v in r) for r in arr]
+
+
+@pytest.mark.parametrize("gname", ["PL_20_ID0", "BA_100_ID0", "ER_100_ID0", "gset_14_stub"])
+@pytest.mark.parametrize("bidir", [False, True])
+@pytest.mark.parametrize("fused", [True, False])
+def test_local_search_inplace_golden_both_paths(golden, gname, bidir, fused):
+    from rlsolver_amd import ops
+    from rlsolver_amd.envs.env_L2A import EnvMaxcut
+    z = golden("maxcut_local_search")
+    env = EnvMaxcut(mygraph=mygraph_of(z[f"{gname}/graph"]), device=DEV, if_bidirectional=bidir)
+    env.fused_local_search = fused
+    tag = f"{gname}/bidir{int(bidir)}"
+    num_spin = int(z[f"{tag}/ls/num_spin"])
+    assert ops.local_search_fusable(env.graph, num_spin)
+    xs = to_dev_bool(z[f"{tag}/ls/xs_in"]).clone()
+    noise = torch.from_numpy(z[f"{tag}/ls/noise"]).to(DEV)
+    gx, gv = env.local_search_inplace(xs, torch.empty(()), num_iters=8, num_spin=num_spin, noise_std=0.3, noise=noise)
+    assert np.array_equal(gx.cpu().numpy().astype(np.uint8), z[f"{tag}/ls/xs_out"])
+    assert np.array_equal(gv.cpu().numpy(), z[f"{tag}/ls/vs_out"])
+    # second call on the result with an explicit good_vs (the in/out objective path)
+    xs2 = to_dev_bool(z[f"{tag}/ls/xs_in"]).clone()
+    vs2 = env.calculate_obj_values(xs2)
+    gx2, gv2 = env.local_search_inplace(xs2, vs2, num_iters=8, num_spin=num_spin, noise_std=0.3, noise=noise)
+    assert gv2.data_ptr() == vs2.data_ptr() and torch.equal(gx2, gx) and torch.equal(gv2, gv)
+
+
+@pytest.mark.parametrize("n,m,B,bidir", [(2000, 19990, 130, False), (333, 2000, 70, True), (64, 400, 64, False)])
+def test_fused_equals_decomposed_random(n, m, B, bidir):
+    from rlsolver_amd.envs.env_L2A import EnvMaxcut
+    garr = gnm_arr(n, m, seed=n)
+    env = EnvMaxcut(mygraph=mygraph_of(garr), device=DEV, if_bidirectional=bidir, num_nodes=n)
+    g = torch.Generator(device="cpu").manual_seed(1)
+    xs0 = torch.randint(0, 2, (B, n), generator=g, dtype=torch.bool).to(DEV)
+    noise = torch.randn((6, B, n), generator=g).to(DEV)
+    outs = []
+    for fused in (True, False):
+        env.fused_local_search = fused
+        xs = xs0.clone()
+        gx, gv = env.local_search_inplace(xs, torch.empty(()), num_iters=5, num_spin=6, noise_std=0.3, noise=noise)
+        outs.append((gx.clone(), gv.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert np.array_equal(outs[0][1].cpu().numpy(), onp.maxcut_obj(outs[0][0].cpu().numpy(), garr, bidir))
+    if n <= 64:   # and against the reference-shaped oracle
+        wx, wv = onp.local_search_inplace(xs0.cpu().numpy(), garr, n, bidir, noise.cpu().numpy(), num_iters=5, num_spin=6)
+        assert np.array_equal(outs[0][0].cpu().numpy(), wx) and np.array_equal(outs[0][1].cpu().numpy(), wv)
+
+
+def test_fused_production_noise_is_sane():
+    from rlsolver_amd.envs.env_L2A import EnvMaxcut
+    n, m, B = 800, 4694, 512
+    garr = gnm_arr(n, m, seed=14)
+    env = EnvMaxcut(mygraph=mygraph_of(garr), device=DEV, num_nodes=n)
+    torch.manual_seed(0)
+    xs = env.generate_xs_randomly(B)
+    v0 = env.calculate_obj_values(xs)
+    vs = v0.clone()
+    for _ in range(3):
+        prev = vs.clone()
+        env.local_search_inplace(xs, vs, num_iters=8, num_spin=8, noise_std=0.3)
+        assert (vs >= prev).all()
+    assert torch.equal(env.calculate_obj_values(xs), vs)
+    assert float(vs.float().mean()) > 0.62 * m > float(v0.float().mean())
+    # reproducible under torch.manual_seed, different otherwise
+    res = []
+    for seed in (5, 5, 6):
+        torch.manual_seed(seed)
+        x = env.generate_xs_randomly(64)
+        v = env.calculate_obj_values(x)
+        env.local_search_inplace(x, v, num_iters=8, num_spin=8)
+        res.append(x.clone())
+    assert torch.equal(res[0], res[1]) and not torch.equal(res[0], res[2])
+
+
+@pytest.mark.parametrize("gname", ["BA_100_ID0", "PL_20_ID0"])
+@pytest.mark.parametrize("fused", [True, False])
+def test_local_search_class_golden_both_paths(golden, gname, fused):
+    from rlsolver_amd.envs.env_L2A import EnvMaxcut
+    from rlsolver_amd.methods.LocalSearch import LocalSearch
+    z = golden("local_search_class")
+    env = EnvMaxcut(mygraph=mygraph_of(z[f"{gname}/graph"]), device=DEV, if_bidirectional=False)
+    env.fused_local_search = fused
+    tag = f"{gname}/bidir0"
+    ls = LocalSearch(simulator=env, num_nodes=env.num_nodes)
+    ls.reset(to_dev_bool(z[f"{tag}/xs_in"]).clone())
+    for r in range(2):
+        gx, gv, nupd = ls.random_search(num_iters=4, num_spin=4, noise_std=0.3,
+                                        noise=torch.from_numpy(z[f"{tag}/round{r}/noise"]).to(DEV))
+        assert np.array_equal(gx.cpu().numpy().astype(np.uint8), z[f"{tag}/round{r}/xs"])
+        assert np.array_equal(gv.cpu().numpy(), z[f"{tag}/round{r}/vs"])
