@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RLS_ABI_VERSION 1
+#define RLS_ABI_VERSION 2
 
 enum {
     RLS_OK = 0,
@@ -58,12 +58,22 @@ typedef struct rls_graph {
     const int32_t* rowptr;    /* [N+1] symmetric CSR */
     const int32_t* col;       /* [nnz] */
     const int32_t* wgt;       /* [nnz] integer edge weights or NULL (= all ones) */
+    const int32_t* sweep_rowptr; /* [N+1] rowptr with bit 31 marking the first node of each independent batch
+                                  * (rls_graph_sweep_batches), or NULL: enables the 4-wave batched sweep */
 } rls_graph;
 
 int rls_version(void);
 const char* rls_last_error_string(void);
 /* Number of HIP devices visible (0 on a CPU-only host; never an error). */
 int rls_device_count(void);
+
+/* [host] Cut the node order 0..N-1 into maximal runs of pairwise NON-adjacent consecutive nodes
+ * (<= max_nodes nodes and <= max_entries CSR entries each).  The greedy sweep may decide the nodes of
+ * a run in parallel with results identical to the sequential pass of envs/env_L2A.py:109-116.
+ * rowptr/col: HOST symmetric CSR; rowptr_flagged [host, N+1] = rowptr with bit 31 set on the first
+ * node of each run.  Upload it and store the device pointer in rls_graph.sweep_rowptr. */
+int rls_graph_sweep_batches(const int32_t* rowptr, const int32_t* col, int64_t N, int32_t max_nodes,
+                            int32_t max_entries, int32_t* rowptr_flagged, int64_t* num_batches);
 
 /* ------------------------------------------------------------------ MaxCut */
 

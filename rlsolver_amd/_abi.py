@@ -37,6 +37,7 @@ class RlsGraph(C.Structure):
         ("rowptr", C.c_void_p),
         ("col", C.c_void_p),
         ("wgt", C.c_void_p),
+        ("sweep_rowptr", C.c_void_p),
     ]
 
 
@@ -50,6 +51,7 @@ _G = C.POINTER(RlsGraph)
 # name -> argtypes; every function returns int.  Keep in sync with include/rlsolver_hip.h
 # (tests/test_abi.py parses the header and checks this table against it).
 SIGNATURES = {
+    "rls_graph_sweep_batches": [_P, _P, _I64, C.c_int32, C.c_int32, _P, _P],
     "rls_maxcut_obj": [_G, _P, _INT, _I64, _P, _P],
     "rls_maxcut_edge_cut_mask": [_G, _P, _I64, _P, _P],
     "rls_maxcut_node_cutdeg": [_G, _P, _I64, _P, _P],

@@ -2,6 +2,7 @@
 #include "rls_common.h"
 #include <cstdarg>
 #include <cstdio>
+#include <vector>
 
 namespace rls {
 
@@ -28,6 +29,29 @@ extern "C" {
 int rls_version(void) { return RLS_ABI_VERSION; }
 
 const char* rls_last_error_string(void) { return rls::g_err; }
+
+int rls_graph_sweep_batches(const int32_t* rowptr, const int32_t* col, int64_t N, int32_t max_nodes,
+                            int32_t max_entries, int32_t* rowptr_flagged, int64_t* num_batches) {
+    if (!rowptr || !rowptr_flagged || N < 0 || max_nodes < 1 || max_nodes > 64 || max_entries < 1 ||
+        (N > 0 && rowptr[N] > 0 && !col))
+        return rls::fail(RLS_EINVAL, "rls_graph_sweep_batches: bad arguments");
+    std::vector<int32_t> stamp((size_t)(N > 0 ? N : 1), -1);
+    int64_t nb = 0;
+    int32_t cur = -1, nodes = 0, entries = 0;
+    for (int64_t i = 0; i < N; ++i) {
+        const int32_t r0 = rowptr[i], r1 = rowptr[i + 1];
+        bool start = (i == 0) || nodes >= max_nodes || entries + (r1 - r0) > max_entries;
+        for (int32_t j = r0; j < r1 && !start; ++j) start = stamp[(size_t)col[j]] == cur;   // adjacent to a member
+        if (start) { ++cur; ++nb; nodes = 0; entries = 0; }
+        stamp[(size_t)i] = cur;
+        ++nodes;
+        entries += r1 - r0;
+        rowptr_flagged[i] = (int32_t)((uint32_t)r0 | (start ? 0x80000000u : 0u));
+    }
+    rowptr_flagged[N] = rowptr[N];
+    if (num_batches) *num_batches = nb;
+    return RLS_OK;
+}
 
 int rls_device_count(void) {
     int n = 0;

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(kLsWaves * kWave) void k_maxcut_local_search(
     int64_t E, int halve, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t nnz,
     const int32_t* __restrict__ ws, const float* __restrict__ rd_std, const float* __restrict__ noise, uint64_t seed,
     int64_t env_offset, int num_iters, int num_spin, int first_draw_proposes, int64_t* __restrict__ obj,
-    int compute_obj) {
+    int compute_obj, int batched) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* words = reinterpret_cast<uint64_t*>(smem);
     uint64_t* prop = words + (N + 2);
@@ -194,8 +194,12 @@ __global__ __launch_bounds__(kLsWaves * kWave) void k_maxcut_local_search(
         __syncthreads();
     }
 
-    // ---- phase 3: greedy sweep on the resident tile (one wave; the step is sequential per node)
-    if (w == 0) {
+    // ---- phase 3: greedy sweep on the resident tile
+    if (batched) {   // 4 waves over the host-built independent-node batches (rp carries the batch flags)
+        const int64_t part = sweep_tile_batched<kLsWaves>(words, rp, ring, col, nnz, N, lane, w);
+        my_obj += block_sum_partials<kLsWaves>(part, scratch, lane, w);
+        if (w == 0 && valid) obj[b] = my_obj;
+    } else if (w == 0) {   // one wave, strictly sequential
         my_obj += sweep_tile(words, rp, ring, col, nnz, N, lane);
         if (valid) obj[b] = my_obj;
     }
@@ -232,14 +236,16 @@ extern "C" int rls_maxcut_local_search(const rls_graph* g, uint8_t* x, int64_t B
     const dim3 grid((unsigned)ceil_div(B, kWave)), block(kLsWaves * kWave);
     hipStream_t s = as_stream(stream);
     const int halve = g->if_bidirectional ? 1 : 0;
+    const int batched = g->sweep_rowptr != nullptr;
+    const int32_t* rp_src = batched ? g->sweep_rowptr : g->rowptr;
 #define LAUNCH_LSF(VEC, PP)                                                                                          \
     do {                                                                                                             \
         auto kern = v4 ? k_maxcut_local_search<VEC, true, PP> : k_maxcut_local_search<VEC, false, PP>; \
         if (lds > 64 * 1024)                                                                                         \
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
-        hipLaunchKernelGGL(kern, grid, block, lds, s, x, B, N, g->eu, g->ev, E, halve, g->rowptr, g->col, g->nnz, ws, \
+        hipLaunchKernelGGL(kern, grid, block, lds, s, x, B, N, g->eu, g->ev, E, halve, rp_src, g->col, g->nnz, ws,    \
                            rd_std, noise, seed, env_offset, (int)num_iters, (int)num_spin, (int)first_draw_proposes,  \
-                           obj, (int)compute_obj);                                                                   \
+                           obj, (int)compute_obj, batched);                                                          \
     } while (0)
 #define DISPATCH_P(VEC)                       \
     switch (P) {                              \

@@ -2,6 +2,7 @@
 // reference call site each entry point replaces, DESIGN.md for layouts and rooflines.
 #include "rls_cutcount.h"
 #include "rls_sweep.h"
+#include <cstdlib>
 
 namespace rls {
 
@@ -109,6 +110,31 @@ __global__ __launch_bounds__(kWave) void k_maxcut_greedy_sweep(uint8_t* __restri
     const int64_t gain = sweep_tile(words, rp, ring, col, nnz, N, lane);
     tile_store_bytes<VEC>(x, B, N, b0, words, lane);
     if (b0 + lane < B) obj[b0 + lane] += gain;
+}
+
+// 4-wave variant over the host-built independent-node batches (rls_sweep.h: sweep_tile_batched)
+template <bool VEC>
+__global__ __launch_bounds__(kTileWaves * kWave) void k_maxcut_greedy_sweep_batched(
+    uint8_t* __restrict__ x, int64_t B, int64_t N, const int32_t* __restrict__ rowptr_flagged,
+    const int32_t* __restrict__ col, int64_t nnz, int64_t* __restrict__ obj) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* words = reinterpret_cast<uint64_t*>(smem);
+    int32_t* rp = reinterpret_cast<int32_t*>(smem + (size_t)(N + 2) * 8);
+    int32_t* ring = rp + ((N + 1 + 3) & ~3ll);
+    int64_t* scratch = reinterpret_cast<int64_t*>(ring + kRing);
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    const int64_t b0 = (int64_t)blockIdx.x * kWave;
+    if (threadIdx.x == 0) words[N] = 0;
+    for (int64_t i = threadIdx.x; i <= N; i += kTileWaves * kWave) rp[i] = rowptr_flagged[i];
+    tile_load_bits<uint8_t, VEC>(x, B, N, b0, words, lane, w, kTileWaves);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int64_t part = sweep_tile_batched<kTileWaves>(words, rp, ring, col, nnz, N, lane, w);
+    const int64_t gain = block_sum_partials<kTileWaves>(part, scratch, lane, w);
+    __syncthreads();
+    tile_store_bytes<VEC>(x, B, N, b0, words, lane, w, kTileWaves);
+    if (w == 0 && b0 + lane < B) obj[b0 + lane] += gain;
 }
 
 // generic fallback (weighted graphs, hubs with degree > kSweepMaxDeg): one global row fetch per node
@@ -519,6 +545,22 @@ int rls_maxcut_greedy_sweep(const rls_graph* g, uint8_t* x, int64_t B, int64_t* 
     const size_t lds_fast = (size_t)(N + 2) * 8 + (size_t)((N + 1 + 3) & ~3ll) * 4 + (size_t)kRing * 4;
     const bool fast = !g->wgt && g->max_degree <= kSweepMaxDeg && lds_fast <= (size_t)kLdsBytes &&
                       (((uintptr_t)g->col) & 3) == 0;
+    if (fast && g->sweep_rowptr && getenv("RLS_SWEEP_UNBATCHED") == nullptr) {
+        const size_t lds_b = lds_fast + (size_t)kTileWaves * kWave * 8;
+        const dim3 block4(kTileWaves * kWave);
+#define LAUNCH_SWB(VEC)                                                                                    \
+    do {                                                                                                   \
+        auto kern = k_maxcut_greedy_sweep_batched<VEC>;                                                    \
+        if (lds_b > 64 * 1024)                                                                             \
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b); \
+        hipLaunchKernelGGL(kern, grid, block4, lds_b, s, x, B, N, g->sweep_rowptr, g->col, g->nnz, obj);   \
+    } while (0)
+        if (lds_b <= (size_t)kLdsBytes) {
+            if (vec) LAUNCH_SWB(true); else LAUNCH_SWB(false);
+            return check_launch("k_maxcut_greedy_sweep_batched");
+        }
+#undef LAUNCH_SWB
+    }
     if (fast) {
 #define LAUNCH_SWF(VEC)                                                                                    \
     do {                                                                                                   \

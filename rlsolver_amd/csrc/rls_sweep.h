@@ -63,4 +63,68 @@ __device__ __forceinline__ int64_t sweep_tile(uint64_t* words, const int32_t* rp
     return gain;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Batched sweep: consecutive nodes that are pairwise NON-adjacent can be decided in any order (none of
+// them sees another's flip), so the host cuts 0..N-1 into maximal runs of mutually independent nodes
+// ("batches": bit 31 of rpf[i] marks the first node of a batch) and the W waves of the workgroup take
+// the nodes of a batch round-robin, with one workgroup barrier per batch.  Results are bit-identical
+// to the sequential sweep.  Every wave runs the same ring protocol on the SAME LDS ring (the loads are
+// idempotent; a wave only ever relies on loads it issued itself), so the ring needs no extra sync; the
+// host bounds a batch to <= 16 nodes / <= 768 entries, which keeps all waves inside the ring window.
+// Returns this wave's partial gain for the lane's env (sum the W partials).
+template <int W>
+__device__ __forceinline__ int64_t sweep_tile_batched(uint64_t* words, const int32_t* rpf, int32_t* ring,
+                                                      const int32_t* __restrict__ col, int64_t nnz, int64_t N,
+                                                      int lane, int w) {
+    const unsigned char* wbytes = reinterpret_cast<const unsigned char*>(words);
+    constexpr uint32_t M = 0x7fffffffu;
+    int64_t F;
+    ring_prime(col, nnz, F, ring, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int sh = lane & 31;
+    const uint32_t half4 = (uint32_t)(lane >> 5) * 4u;
+    const int sentinel = (int)N;
+    int64_t gain = 0;
+    int64_t bstart = 0;
+    while (bstart < N) {
+        // batch end = first flagged node after bstart (or N): 64 candidates checked at once
+        const int64_t cand = bstart + 1 + lane;
+        const bool is_end = (cand >= N) || (((uint32_t)rpf[cand]) >> 31);
+        const int64_t bend = bstart + 1 + __builtin_ctzll(ballot64(is_end));
+        for (int64_t i = bstart + w; i < bend; i += W) {
+            const int r0 = (int)((uint32_t)rpf[i] & M), r1 = (int)((uint32_t)rpf[i + 1] & M);
+            ring_advance(col, nnz, F, r0, ring, lane);
+            const int my_nb = (r0 + lane < r1) ? ring[(r0 + lane) & (kRing - 1)] : sentinel;
+            const uint32_t xi = (*reinterpret_cast<const uint32_t*>(wbytes + ((uint32_t)i * 8u + half4)) >> sh) & 1u;
+            int acc = 0;
+            const int deg = r1 - r0;
+            const int first = deg < kWave ? deg : kWave;
+            for (int j = 0; j < first; j += 8) {
+                uint32_t wv[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const uint32_t nb = (uint32_t)__builtin_amdgcn_readlane(my_nb, j + k);
+                    wv[k] = *reinterpret_cast<const uint32_t*>(wbytes + (nb * 8u + half4));
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc += (int)((wv[k] >> sh) & 1u);
+            }
+            for (int j = r0 + kWave; j < r1; ++j) {
+                const uint32_t nb = (uint32_t)ring[j & (kRing - 1)];
+                acc += (int)((*reinterpret_cast<const uint32_t*>(wbytes + (nb * 8u + half4)) >> sh) & 1u);
+            }
+            const int same_minus_diff = xi ? (2 * acc - deg) : (deg - 2 * acc);
+            const bool flip = same_minus_diff >= 0;
+            gain += flip ? same_minus_diff : 0;
+            const uint64_t fm = ballot64(flip);
+            if (lane == 0) words[i] ^= fm;
+        }
+        __syncthreads();   // the batch's flips are visible to every wave before the next batch reads them
+        bstart = bend;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    return gain;
+}
+
 }  // namespace rls

@@ -61,6 +61,15 @@ class DeviceGraph:
         self.erowptr = i32(erp)
         self.rowptr, self.col = i32(csr.rowptr), i32(csr.col)
         self.wgt = i32(csr.wgt) if use_weights else None
+        # independent-node batches for the 4-wave greedy sweep (host pass over the CSR in the C library)
+        rp_h = np.ascontiguousarray(csr.rowptr, dtype=np.int32)
+        col_h = np.ascontiguousarray(csr.col, dtype=np.int32)
+        flagged = np.empty(csr.num_nodes + 1, dtype=np.int32)
+        nb = C.c_int64(0)
+        _abi.call("rls_graph_sweep_batches", rp_h.ctypes.data_as(C.c_void_p), col_h.ctypes.data_as(C.c_void_p),
+                  csr.num_nodes, 16, 768, flagged.ctypes.data_as(C.c_void_p), C.byref(nb))
+        self.num_sweep_batches = int(nb.value)
+        self.sweep_rowptr = torch.from_numpy(flagged).to(self.device)
         self.num_nodes, self.num_stored_edges, self.nnz = csr.num_nodes, csr.num_stored_edges, csr.nnz
         self.if_bidirectional = csr.if_bidirectional
         self.struct = _abi.RlsGraph(
@@ -68,7 +77,7 @@ class DeviceGraph:
             if_bidirectional=int(csr.if_bidirectional), max_degree=csr.max_degree,
             eu=self.eu.data_ptr(), ev=self.ev.data_ptr(), erowptr=self.erowptr.data_ptr(),
             rowptr=self.rowptr.data_ptr(), col=self.col.data_ptr(),
-            wgt=0 if self.wgt is None else self.wgt.data_ptr())
+            wgt=0 if self.wgt is None else self.wgt.data_ptr(), sweep_rowptr=self.sweep_rowptr.data_ptr())
         self.ref = C.byref(self.struct)
 
 
