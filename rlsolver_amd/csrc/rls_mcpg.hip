@@ -179,105 +179,127 @@ __global__ __launch_bounds__(kWave) void k_mcpg_local_search(const TI* __restric
     }
 }
 
-// K7 fast path.  The host flattens the visiting order into ONE int32 "visit stream":
-//     for pos in 0..N-1:  node, deg, nfresh, then deg entries  nb | (fresh << 31)
+// K7 fast path.  The host flattens the visiting order into ONE int32 "visit stream", cut into batches
+// of consecutive, pairwise NON-adjacent nodes (<= 16 nodes, <= 400 entries; nodes of a batch cannot see
+// each other's updates, so they may be decided in any order with identical results):
+//     per batch:  m, next_batch_offset, first_visit_position, off_0 .. off_{m-1}
+//     per node (at stream offset off_k):  node, deg, nfresh, then deg entries  nb | (fresh << 31)
 // (fresh = nb is visited later than node in pass 0, i.e. still holds -0.5|1.5 there; nfresh = their
-// count).  The stream is consumed strictly in order through an LDS ring (rls_ring.h), so the
-// per-node path is: 3 broadcast LDS reads for the header, one lane-parallel ring read for the row,
-// v_readlane + broadcast word read + v_bfe + v_mad per neighbour, one ballot.  No global memory
-// latency per node (the generic kernel pays 2-3 dependent L2 round trips per node).
+// count).  The stream is consumed in order through an LDS ring (rls_ring.h).  The 4 waves of the
+// workgroup take the nodes of a batch round-robin, one barrier per batch; per node: ONE lane-parallel
+// ring read (header in lanes 0-2, first 61 entries behind it), v_readlane + broadcast word read +
+// v_bfe + v_mad per neighbour, one ballot.  No global-memory latency per node (the generic kernel pays
+// 2-3 dependent L2 round trips per node).  Production noise: one counter-based hash per (chain, pass,
+// position); test mode reads the reference's torch.rand draws.
+constexpr int kK7Waves = 4;
+
+__device__ __forceinline__ uint32_t k7_fmix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+
 template <typename TI, int P>
-__global__ __launch_bounds__(kWave) void k_mcpg_local_search_stream(const TI* __restrict__ xs_in,
-                                                                    float* __restrict__ xs_out, int64_t N, int64_t C,
-                                                                    const int32_t* __restrict__ vstream,
-                                                                    int64_t vlen, int64_t num_ls,
-                                                                    const float* __restrict__ uniforms, uint64_t seed,
-                                                                    const int32_t* __restrict__ eu,
-                                                                    const int32_t* __restrict__ ev, int64_t E,
-                                                                    float* __restrict__ expected) {
+__global__ __launch_bounds__(kK7Waves * kWave) void k_mcpg_local_search_stream(
+    const TI* __restrict__ xs_in, float* __restrict__ xs_out, int64_t N, int64_t C,
+    const int32_t* __restrict__ vstream, int64_t vlen, int64_t num_ls, const float* __restrict__ uniforms,
+    uint64_t seed, const int32_t* __restrict__ eu, const int32_t* __restrict__ ev, int64_t E,
+    float* __restrict__ expected) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* words = reinterpret_cast<uint64_t*>(smem);
     int32_t* ring = reinterpret_cast<int32_t*>(smem + (size_t)(N + 2) * 8);
+    int64_t* scratch = reinterpret_cast<int64_t*>(ring + kRing);
     const uint32_t* w32 = reinterpret_cast<const uint32_t*>(smem);
     const unsigned char* wbytes = smem;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     const int64_t c0 = (int64_t)blockIdx.x * kWave;
     const int64_t c = c0 + lane;
     const bool valid = c < C;
-    if (lane == 0) words[N] = 0;   // sentinel word for lanes past a row's end
-    tile_load_bits_nodemajor<TI>(xs_in, N, C, c0, words, lane);
+    if (threadIdx.x == 0) words[N] = 0;   // sentinel word for lanes past a row's end
+    // node-major rows: wave w transposes every 4th group of 64 nodes
+    for (int64_t n0 = (int64_t)w * kWave; n0 < N; n0 += (int64_t)kK7Waves * kWave) {
+        const int lim = (int)((N - n0) < kWave ? (N - n0) : kWave);
+        uint64_t mine = 0;
+#pragma unroll 8
+        for (int k = 0; k < lim; ++k) {
+            const TI v = valid ? xs_in[(n0 + k) * C + c] : TI(0);
+            const uint64_t wd = ballot64(spin_is_set(v));
+            if (lane == k) mine = wd;
+        }
+        if (lane < lim) words[n0 + lane] = mine;
+    }
     const int sh = lane & 31;
     const uint32_t half4 = (uint32_t)(lane >> 5) * 4u;
     const uint32_t sentinel = (uint32_t)N;
-    const Philox ph(seed);
+    const uint32_t chain_key = k7_fmix32((uint32_t)seed ^ k7_fmix32((uint32_t)(seed >> 32) ^ k7_fmix32((uint32_t)c) ^
+                                                                    ((uint32_t)((uint64_t)c >> 32) * 0x9E3779B1u)));
     for (int64_t cnt = 0; cnt < num_ls; ++cnt) {
         int64_t F;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();
         ring_prime(vstream, vlen, F, ring, lane);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         int64_t cur = 0;
-        uint32_t rnd[4] = {0, 0, 0, 0};
-        // one lane-parallel ring read fetches a node's header (lanes 0-2) and its first 61 entries;
-        // it is issued one node ahead so its latency hides behind the current node's work
-        uint32_t blk = (uint32_t)ring[(cur + lane) & (kRing - 1)];
-        for (int64_t pos = 0; pos < N; ++pos) {
-            const int node = __builtin_amdgcn_readlane((int)blk, 0);
-            const int deg = __builtin_amdgcn_readlane((int)blk, 1);
-            const int nfresh = (cnt == 0) ? __builtin_amdgcn_readlane((int)blk, 2) : 0;
-            const int64_t row = cur + 3;
-            const int64_t nxt = row + deg;
-            ring_advance(vstream, vlen, F, nxt, ring, lane);
-            const uint32_t nblk = (pos + 1 < N) ? (uint32_t)ring[(nxt + lane) & (kRing - 1)] : 0u;
-            float uu;
-            if (uniforms) {
-                uu = valid ? uniforms[(cnt * N + pos) * C + c] : 0.0f;
-            } else {   // one Philox-4x32 call feeds four consecutive positions
-                if ((pos & 3) == 0)
-                    ph((uint32_t)c, (uint32_t)((uint64_t)c >> 32), (uint32_t)((cnt * N + pos) >> 2), 0x4C4F4353u, rnd);
-                const int q = (int)(pos & 3);   // select chain: a runtime-indexed register array would go to scratch
-                uu = u32_to_unit_float(q == 0 ? rnd[0] : q == 1 ? rnd[1] : q == 2 ? rnd[2] : rnd[3]);
-            }
-            int acc = 0;  // sum over neighbours of mult * bit, mult = 4 for fresh (pass 0), else 2
-            // entries 0..60 of the row sit in lanes 3..63 of blk; lanes past the row end read the sentinel
-            const uint32_t mine = (lane >= 3 && lane - 3 < deg) ? blk : sentinel;
-            const int first = deg < (kWave - 3) ? deg : (kWave - 3);
-            for (int j = 0; j < first; j += 8) {
-                uint32_t w[8], mult[8];
+        while (cur < vlen) {
+            ring_advance(vstream, vlen, F, cur, ring, lane);
+            const uint32_t hb = (uint32_t)ring[(cur + lane) & (kRing - 1)];
+            const int m = __builtin_amdgcn_readlane((int)hb, 0);
+            const int64_t nxt = (uint32_t)__builtin_amdgcn_readlane((int)hb, 1);
+            const int64_t pos0 = (uint32_t)__builtin_amdgcn_readlane((int)hb, 2);
+            for (int k = w; k < m; k += kK7Waves) {
+                const int64_t off = (uint32_t)__builtin_amdgcn_readlane((int)hb, 3 + k);
+                const uint32_t blk = (uint32_t)ring[(off + lane) & (kRing - 1)];
+                const int node = __builtin_amdgcn_readlane((int)blk, 0);
+                const int deg = __builtin_amdgcn_readlane((int)blk, 1);
+                const int nfresh = (cnt == 0) ? __builtin_amdgcn_readlane((int)blk, 2) : 0;
+                const int64_t row = off + 3;
+                const int64_t pos = pos0 + k;
+                float uu;
+                if (uniforms) uu = valid ? uniforms[(cnt * N + pos) * C + c] : 0.0f;
+                else uu = u32_to_unit_float(k7_fmix32(chain_key ^ ((uint32_t)pos * 0x9E3779B1u) ^
+                                                      ((uint32_t)cnt * 0x7FEB352Du + 0x165667B1u)));
+                int acc = 0;  // sum over neighbours of mult * bit, mult = 4 for fresh (pass 0), else 2
+                // entries 0..60 of the row sit in lanes 3..63 of blk; lanes past the row end read the sentinel
+                const uint32_t mine = (lane >= 3 && lane - 3 < deg) ? blk : sentinel;
+                const int first = deg < (kWave - 3) ? deg : (kWave - 3);
+                for (int j = 0; j < first; j += 8) {
+                    uint32_t wv[8], mult[8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int src = (j + k + 3) < kWave ? (j + k + 3) : (kWave - 1);
-                    uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)mine, src);
-                    if (j + k >= first) e = sentinel;
-                    mult[k] = (cnt == 0 && (e >> 31)) ? 4u : 2u;
-                    w[k] = *reinterpret_cast<const uint32_t*>(wbytes + ((e & 0x7fffffffu) * 8u + half4));
+                    for (int q = 0; q < 8; ++q) {
+                        const int src = (j + q + 3) < kWave ? (j + q + 3) : (kWave - 1);
+                        uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)mine, src);
+                        if (j + q >= first) e = sentinel;
+                        mult[q] = (cnt == 0 && (e >> 31)) ? 4u : 2u;
+                        wv[q] = *reinterpret_cast<const uint32_t*>(wbytes + ((e & 0x7fffffffu) * 8u + half4));
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) acc += (int)(((wv[q] >> sh) & 1u) * mult[q]);
                 }
-#pragma unroll
-                for (int k = 0; k < 8; ++k) acc += (int)(((w[k] >> sh) & 1u) * mult[k]);
+                for (int j = kWave - 3; j < deg; ++j) {      // hubs: the rest of the row straight from the ring
+                    const uint32_t e = (uint32_t)ring[(row + j) & (kRing - 1)];
+                    const uint32_t mult = (cnt == 0 && (e >> 31)) ? 4u : 2u;
+                    acc += (int)(((*reinterpret_cast<const uint32_t*>(wbytes + ((e & 0x7fffffffu) * 8u + half4)) >> sh) & 1u) * mult);
+                }
+                const int s2 = acc - nfresh;                                      // units of 0.5
+                const float rv = (float)s2 * 0.5f + uu * 0.25f;                   // MCPG.py:139-141
+                const float thr = ((float)deg + 0.25f) / 2.0f;                    // (weighted_degree + k) / 2
+                const uint64_t nw = ballot64(rv < thr);
+                if (lane == 0) words[node] = nw;
             }
-            for (int j = kWave - 3; j < deg; ++j) {      // hubs: the rest of the row straight from the ring
-                const uint32_t e = (uint32_t)ring[(row + j) & (kRing - 1)];
-                const uint32_t mult = (cnt == 0 && (e >> 31)) ? 4u : 2u;
-                acc += (int)(((*reinterpret_cast<const uint32_t*>(wbytes + ((e & 0x7fffffffu) * 8u + half4)) >> sh) & 1u) * mult);
-            }
-            const int s2 = acc - nfresh;                                      // units of 0.5
-            const float rv = (float)s2 * 0.5f + uu * 0.25f;                   // MCPG.py:139-141
-            const float thr = ((float)deg + 0.25f) / 2.0f;                    // (weighted_degree + k) / 2
-            const uint64_t nw = ballot64(rv < thr);
-            if (lane == 0) words[node] = nw;
-            asm volatile("" ::: "memory");
+            __syncthreads();   // the batch's updates are visible before any wave reads the next batch's neighbours
             cur = nxt;
-            blk = nblk;
         }
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
-    const int64_t cut = tile_cut_count<P>(words, eu, ev, E, lane);
+    // K8: expected[c] = sum_e (2x_u - 1)(2x_v - 1) = E - 2 * cut
+    const int64_t cut = block_sum_partials<kK7Waves>(tile_cut_count<P>(words, eu, ev, E, lane, w, kK7Waves), scratch,
+                                                     lane, w);
     if (valid) {
-        expected[c] = (float)(E - 2 * cut);
+        if (w == 0) expected[c] = (float)(E - 2 * cut);
         const int half = lane >> 5;
-        for (int64_t n = 0; n < N; ++n) xs_out[n * C + c] = (float)((w32[(n << 1) + half] >> sh) & 1u);
+        for (int64_t n = w; n < N; n += kK7Waves) xs_out[n * C + c] = (float)((w32[(n << 1) + half] >> sh) & 1u);
     }
 }
 
@@ -349,12 +371,14 @@ int rls_mcpg_local_search(const rls_graph* g, const void* xs_in, int spin_bytes,
     RLS_REQUIRE(P != 0, RLS_EUNSUPPORTED, "E=%lld too large", (long long)E);
     const dim3 grid((unsigned)ceil_div(C, kWave)), block(kWave);
     hipStream_t s = as_stream(stream);
-    const size_t lds_fast = (size_t)(N + 2) * 8 + (size_t)kRing * 4;
+    const size_t lds_fast = (size_t)(N + 2) * 8 + (size_t)kRing * 4 + (size_t)kK7Waves * kWave * 8;
     const bool fast = visit_stream != nullptr && g->max_degree + 3 <= kRingMaxRun && lds_fast <= (size_t)kLdsBytes &&
                       (((uintptr_t)visit_stream) & 3) == 0;
     if (fast) {
-        RLS_REQUIRE(visit_len == g->nnz + 3 * N, RLS_EINVAL, "visit_len %lld != nnz + 3N = %lld", (long long)visit_len,
-                    (long long)(g->nnz + 3 * N));
+        RLS_REQUIRE(visit_len > g->nnz + 4 * N && visit_len <= g->nnz + 7 * N, RLS_EINVAL,
+                    "visit_len %lld is not a batched visit stream of this graph (nnz + 4N + 3*batches)",
+                    (long long)visit_len);
+        const dim3 block(kK7Waves * kWave);
 #define LAUNCH_LSS(TI, PP)                                                                                           \
     do {                                                                                                             \
         auto kern = k_mcpg_local_search_stream<TI, PP>;                                                              \

@@ -54,27 +54,55 @@ def make_data(num_nodes: int, eu, ev, device, sorted_degree_nodes=None):
     return data
 
 
-def build_visit_stream(csr, order: np.ndarray) -> np.ndarray:
-    """Flatten the visiting order for the streaming K7 kernel (include/rlsolver_hip.h):
-    per position [node, deg, nfresh, nb | fresh << 31 ...], int32 [nnz + 3N]."""
+def build_visit_stream(csr, order: np.ndarray, max_nodes: int = 16, max_entries: int = 400) -> np.ndarray:
+    """Flatten the visiting order for the streaming K7 kernel (format: include/rlsolver_hip.h).
+
+    Batches = maximal runs of consecutive (in visiting order), pairwise non-adjacent nodes, found by the
+    library's host pass (rls_graph_sweep_batches) on the graph relabelled by visiting position."""
+    import ctypes as C
+    from .. import _abi
     n = csr.num_nodes
     order = np.asarray(order, dtype=np.int64)
     pos_of = np.empty(n, dtype=np.int64)
     pos_of[order] = np.arange(n)
     deg = np.diff(csr.rowptr).astype(np.int64)
     deg_o = deg[order]
-    out_ptr = np.concatenate([[0], np.cumsum(deg_o + 3)])
-    stream = np.empty(int(out_ptr[-1]), dtype=np.int64)
-    # gather every row in visiting order
+    nnz = int(deg_o.sum())
+    cum = np.concatenate([[0], np.cumsum(deg_o)])
+    # rows gathered in visiting order
     starts = csr.rowptr[order].astype(np.int64)
-    idx = np.repeat(starts - np.concatenate([[0], np.cumsum(deg_o)[:-1]]), deg_o) + np.arange(int(deg_o.sum()))
+    idx = np.repeat(starts - cum[:-1], deg_o) + np.arange(nnz)
     nbr = csr.col[idx].astype(np.int64)
     row_pos = np.repeat(np.arange(n), deg_o)
     fresh = pos_of[nbr] > row_pos
     nfresh = np.bincount(row_pos, weights=fresh, minlength=n).astype(np.int64)
-    hdr = out_ptr[:-1]
-    stream[hdr], stream[hdr + 1], stream[hdr + 2] = order, deg_o, nfresh
-    dst = np.repeat(hdr + 3 - np.concatenate([[0], np.cumsum(deg_o)[:-1]]), deg_o) + np.arange(int(deg_o.sum()))
+    # batches over visiting positions (graph relabelled by position)
+    rp_p = np.ascontiguousarray(cum, dtype=np.int32)
+    col_p = np.ascontiguousarray(pos_of[nbr], dtype=np.int32)
+    flagged = np.empty(n + 1, dtype=np.int32)
+    nb = C.c_int64(0)
+    _abi.call("rls_graph_sweep_batches", rp_p.ctypes.data_as(C.c_void_p), col_p.ctypes.data_as(C.c_void_p), n,
+              max_nodes, max_entries, flagged.ctypes.data_as(C.c_void_p), C.byref(nb))
+    is_start = (flagged[:n].view(np.uint32) >> 31).astype(bool)
+    bid = np.cumsum(is_start) - 1                                   # batch of each position
+    first_pos = np.flatnonzero(is_start)
+    m = np.diff(np.concatenate([first_pos, [n]]))                    # nodes per batch
+    rec_len = deg_o + 3
+    rec_total = np.add.reduceat(rec_len, first_pos)
+    batch_size = 3 + m + rec_total
+    H = np.concatenate([[0], np.cumsum(batch_size)])                 # header offset of each batch
+    # record offset of each position = H[b] + 3 + m[b] + (sum of rec_len of earlier positions in the batch)
+    rec_cum = np.cumsum(rec_len) - rec_len
+    within = rec_cum - rec_cum[first_pos][bid]
+    rec_off = H[bid] + 3 + m[bid] + within
+    stream = np.zeros(int(H[-1]), dtype=np.int64)
+    stream[H[:-1]] = m
+    stream[H[:-1] + 1] = H[1:]
+    stream[H[:-1] + 2] = first_pos
+    k_in_batch = np.arange(n) - first_pos[bid]
+    stream[H[bid] + 3 + k_in_batch] = rec_off
+    stream[rec_off], stream[rec_off + 1], stream[rec_off + 2] = order, deg_o, nfresh
+    dst = np.repeat(rec_off + 3 - cum[:-1], deg_o) + np.arange(nnz)
     stream[dst] = nbr | (fresh.astype(np.int64) << 31)
     return (stream & 0xFFFFFFFF).astype(np.uint32).view(np.int32)
 
