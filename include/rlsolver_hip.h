@@ -207,18 +207,21 @@ int rls_spin_step(const rls_graph* g, float* state, int64_t B, int32_t num_rows,
  * (float32 0.0|1.0, what metro_sampling returns) or 1 (uint8). */
 
 /* K9  metro_sampling(probs, start_status, max_transfer_time)  methods/MCPG.py:88-117.
- * Runs rounds t = 0 .. min(T, *t_limit_dev) - 1 for every chain c:
+ * Runs rounds t = t_offset .. t_offset + min(T, *t_limit_dev) - 1 for every chain c:
  *   i = index[t,c]; p = x[i,c] ? probs[i] : 1 - probs[i];
- *   accept iff u[t,c] < (1 - p) / p  -> flip x[i,c];  accepts[t] += #accepted chains.
- * index int64 [T,C] and u f32 [T,C] are the reference's randint / rand draws in call order
- * (test mode) or both NULL for the in-kernel Philox generator keyed by (seed, chain, t).
+ *   accept iff u[t,c] < (1 - p) / p  -> flip x[i,c];  accepts[t - t_offset] += #accepted chains.
+ * index int64 [*,C] and u f32 [*,C] are the reference's randint / rand draws in call order (rows
+ * indexed by the absolute round t; test mode) or both NULL for the in-kernel Philox generator keyed
+ * by (seed, chain, t).
  * The reference stops after the first round whose cumulative accept count reaches C*T_transfer
- * (a host sync per round there).  Here: call once with write_back = 0 to get accepts[T]
- * (int64, zeroed by the caller), derive the stop round on the device, then call again with
- * t_limit_dev pointing at it (device int64) and write_back = 1.  t_limit_dev NULL = all T rounds.
- * samples is updated in place only when write_back != 0. */
+ * (one host sync per round there).  Here the caller walks the 5*T_transfer rounds in chunks: a dry
+ * call (write_back = 0) fills accepts[T] (int64, zeroed by the caller), the stop round is derived
+ * on the device, a second call with t_limit_dev pointing at it (device int64) and write_back = 1
+ * applies the chunk; *t_limit_dev <= 0 makes a call return immediately, so chunks after the stop
+ * round cost one empty launch.  t_limit_dev NULL = all T rounds.  samples is updated in place only
+ * when write_back != 0. */
 int rls_mcpg_metro_rounds(void* samples, int spin_bytes, int64_t N, int64_t C, const float* probs,
-                          int64_t T, const int64_t* index, const float* u, uint64_t seed,
+                          int64_t T, int64_t t_offset, const int64_t* index, const float* u, uint64_t seed,
                           const int64_t* t_limit_dev, int write_back, int64_t* accepts, void* stream);
 
 /* K7 + K8 first half  sampler_func  methods/MCPG.py:128-152.

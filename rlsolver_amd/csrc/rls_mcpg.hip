@@ -20,19 +20,25 @@
 
 namespace rls {
 
+// wave w of W transposes every W-th group of 64 nodes; 16 row loads are in flight per wave (the loop
+// is latency-bound: each load is one coalesced 64-chain row segment)
 template <typename T>
 __device__ __forceinline__ void tile_load_bits_nodemajor(const T* __restrict__ x, int64_t N, int64_t C, int64_t c0,
-                                                         uint64_t* __restrict__ words, int lane) {
+                                                         uint64_t* __restrict__ words, int lane, int w = 0, int W = 1) {
     const int64_t c = c0 + lane;
     const bool valid = c < C;
-    for (int64_t n0 = 0; n0 < N; n0 += kWave) {
+    for (int64_t n0 = (int64_t)w * kWave; n0 < N; n0 += (int64_t)W * kWave) {
         const int lim = (int)((N - n0) < kWave ? (N - n0) : kWave);
         uint64_t mine = 0;
-#pragma unroll 8
-        for (int k = 0; k < lim; ++k) {
-            const T v = valid ? x[(n0 + k) * C + c] : T(0);
-            const uint64_t w = ballot64(spin_is_set(v));
-            if (lane == k) mine = w;
+        for (int k0 = 0; k0 < lim; k0 += 16) {
+            T v[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) v[q] = (valid && k0 + q < lim) ? x[(n0 + k0 + q) * C + c] : T(0);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const uint64_t wd = ballot64(spin_is_set(v[q]));
+                if (lane == k0 + q) mine = wd;
+            }
         }
         if (lane < lim) words[n0 + lane] = mine;
     }
@@ -40,35 +46,40 @@ __device__ __forceinline__ void tile_load_bits_nodemajor(const T* __restrict__ x
 
 template <typename T>
 __device__ __forceinline__ void tile_store_nodemajor(T* __restrict__ x, int64_t N, int64_t C, int64_t c0,
-                                                     const uint64_t* __restrict__ words, int lane) {
+                                                     const uint64_t* __restrict__ words, int lane, int w = 0, int W = 1) {
     const int64_t c = c0 + lane;
     if (c >= C) return;
     const uint32_t* w32 = reinterpret_cast<const uint32_t*>(words);
     const int half = lane >> 5, sh = lane & 31;
-    for (int64_t n = 0; n < N; ++n) x[n * C + c] = (T)((w32[(n << 1) + half] >> sh) & 1u);
+#pragma unroll 8
+    for (int64_t n = w; n < N; n += W) x[n * C + c] = (T)((w32[(n << 1) + half] >> sh) & 1u);
 }
 
 // ------------------------------------------------------------------------------------- K9
+constexpr int kMetroWaves = 4;
+
 template <typename T, bool PROBS_LDS>
-__global__ __launch_bounds__(kWave) void k_mcpg_metro(T* __restrict__ samples, int64_t N, int64_t C,
+__global__ __launch_bounds__(kMetroWaves * kWave) void k_mcpg_metro(T* __restrict__ samples, int64_t N, int64_t C,
                                                       const float* __restrict__ probs, int64_t T_rounds,
                                                       const int64_t* __restrict__ index,
                                                       const float* __restrict__ u, uint64_t seed,
                                                       const int64_t* __restrict__ t_limit_dev, int write_back,
-                                                      unsigned long long* __restrict__ accepts) {
+                                                      unsigned long long* __restrict__ accepts, int64_t t_offset) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* words = reinterpret_cast<uint64_t*>(smem);
     // probs staged in LDS when it fits: a per-round random gather from global memory would put an
     // L2 round trip (~2 us under load) on every round of every chain
     float* probs_l = reinterpret_cast<float*>(words + N);
     uint32_t* acc_cnt = reinterpret_cast<uint32_t*>(probs_l + (PROBS_LDS ? N : 0));   // per-round accept counts
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     const int64_t c0 = (int64_t)blockIdx.x * kWave;
     const int64_t c = c0 + lane;
     const bool valid = c < C;
+    if (t_limit_dev && *t_limit_dev <= 0) return;   // nothing to do for this chunk (stop rule already met)
     if constexpr (PROBS_LDS)
-        for (int64_t n = lane; n < N; n += kWave) probs_l[n] = probs[n];
-    tile_load_bits_nodemajor<T>(samples, N, C, c0, words, lane);
+        for (int64_t n = threadIdx.x; n < N; n += kMetroWaves * kWave) probs_l[n] = probs[n];
+    tile_load_bits_nodemajor<T>(samples, N, C, c0, words, lane, w, kMetroWaves);
     __syncthreads();
     int64_t t_end = T_rounds;
     if (t_limit_dev) {
@@ -77,16 +88,16 @@ __global__ __launch_bounds__(kWave) void k_mcpg_metro(T* __restrict__ samples, i
     }
     const Philox ph(seed);
     const uint64_t mybit = 1ull << lane;
-    for (int64_t t = 0; t < t_end; ++t) {
+    for (int64_t t = 0; w == 0 && t < t_end; ++t) {   // the chain walk itself is one wave (64 chains = 64 lanes)
         int64_t i = 0;
         float uu = 2.0f;
         if (valid) {
             if (index) {
-                i = index[t * C + c];
-                uu = u[t * C + c];
+                i = index[(t_offset + t) * C + c];
+                uu = u[(t_offset + t) * C + c];
             } else {
                 uint32_t r[4];
-                ph((uint32_t)c, (uint32_t)((uint64_t)c >> 32), (uint32_t)t, 0x4D455452u, r);
+                ph((uint32_t)c, (uint32_t)((uint64_t)c >> 32), (uint32_t)(t_offset + t), 0x4D455452u, r);
                 i = (int64_t)(((uint64_t)r[0] * (uint64_t)N) >> 32);
                 uu = u32_to_unit_float(r[1]);
             }
@@ -105,12 +116,12 @@ __global__ __launch_bounds__(kWave) void k_mcpg_metro(T* __restrict__ samples, i
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-    if (accepts) {   // one coalesced burst of atomics per wave instead of one contended atomic per round
-        __syncthreads();
-        for (int64_t t = lane; t < t_end; t += kWave)
+    __syncthreads();
+    if (accepts) {   // one coalesced burst of atomics per workgroup instead of one contended atomic per round
+        for (int64_t t = threadIdx.x; t < t_end; t += kMetroWaves * kWave)
             if (acc_cnt[t]) atomicAdd(&accepts[t], (unsigned long long)acc_cnt[t]);
     }
-    if (write_back) tile_store_nodemajor<T>(samples, N, C, c0, words, lane);
+    if (write_back) tile_store_nodemajor<T>(samples, N, C, c0, words, lane, w, kMetroWaves);
 }
 
 // ------------------------------------------------------------------------------------- K7 + K8
@@ -216,18 +227,7 @@ __global__ __launch_bounds__(kK7Waves * kWave) void k_mcpg_local_search_stream(
     const int64_t c = c0 + lane;
     const bool valid = c < C;
     if (threadIdx.x == 0) words[N] = 0;   // sentinel word for lanes past a row's end
-    // node-major rows: wave w transposes every 4th group of 64 nodes
-    for (int64_t n0 = (int64_t)w * kWave; n0 < N; n0 += (int64_t)kK7Waves * kWave) {
-        const int lim = (int)((N - n0) < kWave ? (N - n0) : kWave);
-        uint64_t mine = 0;
-#pragma unroll 8
-        for (int k = 0; k < lim; ++k) {
-            const TI v = valid ? xs_in[(n0 + k) * C + c] : TI(0);
-            const uint64_t wd = ballot64(spin_is_set(v));
-            if (lane == k) mine = wd;
-        }
-        if (lane < lim) words[n0 + lane] = mine;
-    }
+    tile_load_bits_nodemajor<TI>(xs_in, N, C, c0, words, lane, w, kK7Waves);
     const int sh = lane & 31;
     const uint32_t half4 = (uint32_t)(lane >> 5) * 4u;
     const uint32_t sentinel = (uint32_t)N;
@@ -329,9 +329,9 @@ using namespace rls;
 extern "C" {
 
 int rls_mcpg_metro_rounds(void* samples, int spin_bytes, int64_t N, int64_t C, const float* probs, int64_t T,
-                          const int64_t* index, const float* u, uint64_t seed, const int64_t* t_limit_dev,
-                          int write_back, int64_t* accepts, void* stream) {
-    RLS_REQUIRE(N > 0 && C >= 0 && T >= 0, RLS_EINVAL, "bad sizes N=%lld C=%lld T=%lld", (long long)N, (long long)C,
+                          int64_t t_offset, const int64_t* index, const float* u, uint64_t seed,
+                          const int64_t* t_limit_dev, int write_back, int64_t* accepts, void* stream) {
+    RLS_REQUIRE(N > 0 && C >= 0 && T >= 0 && t_offset >= 0, RLS_EINVAL, "bad sizes N=%lld C=%lld T=%lld", (long long)N, (long long)C,
                 (long long)T);
     if (C == 0) return RLS_OK;
     RLS_REQUIRE(samples && probs, RLS_EINVAL, "samples/probs is NULL");
@@ -342,7 +342,7 @@ int rls_mcpg_metro_rounds(void* samples, int spin_bytes, int64_t N, int64_t C, c
     const size_t lds = lds_base + (probs_lds ? (size_t)N * 4 : 0);
     RLS_REQUIRE(lds <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld, T=%lld need %zu B of LDS (max %d)", (long long)N,
                 (long long)T, lds, kLdsBytes);
-    const dim3 grid((unsigned)ceil_div(C, kWave)), block(kWave);
+    const dim3 grid((unsigned)ceil_div(C, kWave)), block(kMetroWaves * kWave);
     hipStream_t s = as_stream(stream);
 #define LAUNCH_METRO(TT, PL)                                                                                        \
     do {                                                                                                            \
@@ -350,7 +350,7 @@ int rls_mcpg_metro_rounds(void* samples, int spin_bytes, int64_t N, int64_t C, c
         if (lds > 64 * 1024)                                                                                        \
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
         hipLaunchKernelGGL(kern, grid, block, lds, s, (TT*)samples, N, C, probs, T, index, u, seed, t_limit_dev,     \
-                           write_back, (unsigned long long*)accepts);                                               \
+                           write_back, (unsigned long long*)accepts, t_offset);                                     \
     } while (0)
     if (spin_bytes == 1) { if (probs_lds) LAUNCH_METRO(uint8_t, true); else LAUNCH_METRO(uint8_t, false); }
     else                 { if (probs_lds) LAUNCH_METRO(float, true);   else LAUNCH_METRO(float, false); }

@@ -20,7 +20,7 @@ def _u64(v: int) -> C.c_uint64:
 # ------------------------------------------------------------------------------ MCPG
 def mcpg_metro_rounds(samples: TEN, probs: TEN, T: int, index: Optional[TEN] = None, u: Optional[TEN] = None,
                       seed: int = 0, t_limit: Optional[TEN] = None, write_back: bool = True,
-                      accepts: Optional[TEN] = None) -> None:
+                      accepts: Optional[TEN] = None, t_offset: int = 0) -> None:
     """K9 (see include/rlsolver_hip.h).  samples [N, C] f32/uint8 in place."""
     _check(samples, "samples", _NM_DTYPES)
     dev = samples.device
@@ -33,8 +33,8 @@ def mcpg_metro_rounds(samples: TEN, probs: TEN, T: int, index: Optional[TEN] = N
     if index is not None:
         _check(index, "index", (torch.int64,), dev)
         _check(u, "u", (torch.float32,), dev)
-        if index.shape[0] < T or u.shape[0] < T or index.shape[1:] != (Cc,) or u.shape[1:] != (Cc,):
-            raise ValueError("index/u must be [>=T, C]")
+        if index.shape[0] < t_offset + T or u.shape[0] < t_offset + T or index.shape[1:] != (Cc,) or u.shape[1:] != (Cc,):
+            raise ValueError("index/u must be [>= t_offset + T, C]")
     if t_limit is not None:
         _check(t_limit, "t_limit", (torch.int64,), dev)
     if accepts is not None:
@@ -42,7 +42,8 @@ def mcpg_metro_rounds(samples: TEN, probs: TEN, T: int, index: Optional[TEN] = N
         if accepts.numel() < T:
             raise ValueError("accepts must hold T entries")
     _abi.call("rls_mcpg_metro_rounds", _ptr(samples), 4 if samples.dtype == torch.float32 else 1, N, Cc, _ptr(probs),
-              T, _ptr(index), _ptr(u), _u64(seed), _ptr(t_limit), int(bool(write_back)), _ptr(accepts), _stream(dev))
+              T, t_offset, _ptr(index), _ptr(u), _u64(seed), _ptr(t_limit), int(bool(write_back)), _ptr(accepts),
+              _stream(dev))
 
 
 def mcpg_local_search(g: DeviceGraph, xs_in: TEN, order: TEN, num_ls: int, uniforms: Optional[TEN] = None,
