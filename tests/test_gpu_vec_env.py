@@ -75,3 +75,18 @@ def test_dreinforce_shaped_outer_loop_improves():
         update_xs_by_vs(best_xs, best_vs, good_xs, good_vs, True)
     assert (best_vs >= v_start).all() and float(best_vs.float().mean()) > 0.6 * m
     assert np.array_equal(best_vs.cpu().numpy(), onp.maxcut_obj(best_xs.cpu().numpy(), garr, True))
+
+
+def test_k_spin_simulator_aliases(golden):
+    from rlsolver_amd.envs.env_k_spin import MaxcutSimulatorReinforce, SimulatorGraphMaxCut
+    z = golden("maxcut_obj")
+    graph = [tuple(int(v) for v in r) for r in z["BA_100_ID0/graph"]]
+    for cls, kw in ((SimulatorGraphMaxCut, dict(graph=graph)), (MaxcutSimulatorReinforce, dict(graph=graph))):
+        for bidir in (False, True):
+            sim = cls(device=DEV, if_bidirectional=bidir, **kw)
+            t = f"BA_100_ID0/bidir{int(bidir)}/seed0"
+            xs = torch.from_numpy(z[f"{t}/xs"]).to(DEV).bool()
+            assert np.array_equal(sim.calculate_obj_values(xs).cpu().numpy(), z[f"{t}/obj"])
+            assert np.array_equal(sim.calculate_obj_values_for_loop(xs, if_sum=False).cpu().numpy(), z[f"{t}/cutdeg"])
+            sol = sim.generate_solutions_randomly(8)
+            assert sol.shape == (8, sim.num_nodes) and not sol[:, 0].any()
