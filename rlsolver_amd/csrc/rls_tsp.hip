@@ -5,10 +5,12 @@
 // otherwise read through L2.  One wave owns one tour at a time: lanes run along the tour positions,
 // so perm reads and the [B, N] outputs are coalesced.
 #include "rls_tile.h"
+#include "rls_ring.h"
 
 namespace rls {
 
-constexpr int kTspBlock = 256;
+constexpr int kTspBlock = 1024;     // launch bound; small tours use it whole (32 waves/CU hide the HBM round trip)
+constexpr int kTspBlockSmall = 256;  // large N: the per-wave LDS tour scratch limits waves per workgroup
 
 __device__ __forceinline__ float wave_sum_f32(float v) {
 #pragma unroll
@@ -19,8 +21,13 @@ __device__ __forceinline__ float wave_sum_f32(float v) {
 template <bool LDS_D>
 __device__ __forceinline__ const float* stage_dist(const float* __restrict__ dist, int64_t N, float* lds) {
     if constexpr (LDS_D) {
+        // LDS-DMA, 256 B per wave instruction, every chunk in flight at once (a load->ds_write loop
+        // serialises on the L2 round trip and dominated the kernel)
         const int64_t n2 = N * N;
-        for (int64_t i = threadIdx.x; i < n2; i += blockDim.x) lds[i] = dist[i];
+        const int lane = threadIdx.x & 63;
+        for (int64_t c = (threadIdx.x >> 6) * (int64_t)kWave; c < n2; c += blockDim.x)
+            if (c + lane < n2) glds4(dist + c + lane, lds + c);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         return lds;
     } else {
@@ -36,18 +43,31 @@ __global__ __launch_bounds__(kTspBlock) void k_tsp_tour_length(const float* __re
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const float* D = stage_dist<LDS_D>(dist, N, reinterpret_cast<float*>(smem));
     const int lane = threadIdx.x & 63;
-    const int64_t wave = (int64_t)blockIdx.x * (kTspBlock / kWave) + threadIdx.x / kWave;
-    const int64_t nwaves = (int64_t)gridDim.x * (kTspBlock / kWave);
-    for (int64_t b = wave; b < B; b += nwaves) {
-        const int64_t* p = perm + b * N;
-        float acc = 0.0f;
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x / kWave);
+    constexpr int TPT = 4;   // tours per trip: their (independent) perm loads are all in flight together --
+                             // one tour at a time leaves each wave waiting a full HBM round trip per tour
+    for (int64_t b = wave * TPT; b < B; b += nwaves * TPT) {
+        float acc[TPT];
+#pragma unroll
+        for (int t = 0; t < TPT; ++t) acc[t] = 0.0f;
         for (int64_t k = lane; k < N; k += kWave) {
-            const int64_t a = p[k];
-            const int64_t c = p[(k + 1 == N) ? 0 : k + 1];
-            acc += D[a * N + c];
+            const int64_t k1 = (k + 1 == N) ? 0 : k + 1;
+            int64_t a[TPT], c[TPT];
+#pragma unroll
+            for (int t = 0; t < TPT; ++t) {
+                const int64_t bb = (b + t < B) ? b + t : b;
+                a[t] = perm[bb * N + k];
+                c[t] = perm[bb * N + k1];
+            }
+#pragma unroll
+            for (int t = 0; t < TPT; ++t) acc[t] += D[a[t] * N + c[t]];
         }
-        acc = wave_sum_f32(acc);
-        if (lane == 0) length[b] = acc;
+#pragma unroll
+        for (int t = 0; t < TPT; ++t) {
+            const float tot = wave_sum_f32(acc[t]);
+            if (lane == t && b + t < B) length[b + t] = tot;
+        }
     }
 }
 
@@ -68,8 +88,8 @@ __global__ __launch_bounds__(kTspBlock) void k_tsp_swap_delta_all(const float* _
     int32_t* P = scratch + (int64_t)wib * 2 * N;
     int32_t* INV = P + N;
     const int lane = threadIdx.x & 63;
-    const int64_t wave = (int64_t)blockIdx.x * (kTspBlock / kWave) + wib;
-    const int64_t nwaves = (int64_t)gridDim.x * (kTspBlock / kWave);
+    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x / kWave) + wib;
+    const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x / kWave);
     const int n = (int)N;
     for (int64_t b = wave; b < B; b += nwaves) {
         const int64_t* p = perm + b * N;
@@ -159,10 +179,13 @@ __global__ void k_rand_perms(int64_t* __restrict__ perm, int64_t B, int64_t N, u
 
 static inline bool dist_fits_lds(int64_t N, size_t extra) { return (size_t)N * N * 4 + extra <= (size_t)kLdsBytes - 1024; }
 
-static inline int tsp_grid(int64_t B) {
-    const int64_t waves = kTspBlock / kWave;
+static inline int tsp_block(int64_t N) { return N <= 256 ? kTspBlock : kTspBlockSmall; }
+
+static inline int tsp_grid(int64_t B, int block) {
+    const int64_t waves = block / kWave;
+    const int64_t cap = (int64_t)2 * 256 * kTspBlock / block;   // 32 waves per CU
     int64_t g = ceil_div(B, waves);
-    if (g > 1024) g = 1024;
+    if (g > cap) g = cap;
     return (int)(g < 1 ? 1 : g);
 }
 
@@ -176,7 +199,7 @@ int rls_tsp_tour_length(const float* dist, int64_t N, const int64_t* perm, int64
     RLS_REQUIRE(N > 0 && N < (1 << 30) && B >= 0, RLS_EINVAL, "bad sizes N=%lld B=%lld", (long long)N, (long long)B);
     if (B == 0) return RLS_OK;
     RLS_REQUIRE(dist && perm && length, RLS_EINVAL, "NULL pointer");
-    const dim3 grid(tsp_grid(B)), block(kTspBlock);
+    const dim3 grid(tsp_grid(B, tsp_block(N))), block(tsp_block(N));
     if (dist_fits_lds(N, 0)) {
         const size_t lds = (size_t)N * N * 4;
         auto kern = k_tsp_tour_length<true>;
@@ -193,10 +216,10 @@ int rls_tsp_swap_delta_all(const float* dist, int64_t N, const int64_t* perm, in
     RLS_REQUIRE(N > 2 && N < (1 << 24) && B >= 0, RLS_EINVAL, "bad sizes N=%lld B=%lld", (long long)N, (long long)B);
     if (B == 0) return RLS_OK;
     RLS_REQUIRE(dist && perm && selected && logratio && indices && ban, RLS_EINVAL, "NULL pointer");
-    const size_t scratch = (size_t)(kTspBlock / kWave) * 2 * N * 4;
+    const size_t scratch = (size_t)(tsp_block(N) / kWave) * 2 * N * 4;
     RLS_REQUIRE(scratch <= (size_t)kLdsBytes - 1024, RLS_EUNSUPPORTED, "N=%lld too large for the per-wave tour scratch",
                 (long long)N);
-    const dim3 grid(tsp_grid(B)), block(kTspBlock);
+    const dim3 grid(tsp_grid(B, tsp_block(N))), block(tsp_block(N));
     if (dist_fits_lds(N, scratch)) {
         const size_t lds = (size_t)N * N * 4 + scratch;
         auto kern = k_tsp_swap_delta_all<true>;

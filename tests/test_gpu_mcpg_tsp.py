@@ -117,7 +117,7 @@ def test_tsp_golden(golden, name):
                                atol=1e-5 * float(z[f"{name}/length_f32"].max()))
 
 
-@pytest.mark.parametrize("N,B", [(100, 1000), (52, 65), (200, 130), (7, 64)])
+@pytest.mark.parametrize("N,B", [(100, 1000), (52, 65), (200, 130), (7, 64), (256, 70), (300, 50)])
 def test_tsp_random_properties(N, B):
     from rlsolver_amd.graph import generate_tsp_coords, tsp_tables
     dist, near, rnd = tsp_tables(generate_tsp_coords(N, seed=N), K=min(20, N - 2))
