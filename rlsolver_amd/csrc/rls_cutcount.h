@@ -7,36 +7,53 @@ namespace rls {
 // =====================================================================================
 // K1 core: cut value of 64 envs held as a bit tile.
 // Each lane takes every 64th stored edge, XORs the two 64-env words (one XOR = one edge
-// in 64 envs) and feeds the result into a bit-sliced Harley-Seal counter (8 edges per
-// block: 7 carry-save adders + one ripple into the upper planes).  The 64 per-lane
-// bit-sliced counts are then summed with a butterfly of bit-sliced full adders, after
-// which every lane holds the total planes and extracts its own env's count.
-// P = number of planes (E' < 2^P).  Wave w of W takes every W-th block of 512 edges and the
+// in 64 envs) and feeds the result into a bit-sliced Harley-Seal counter (16 edges per
+// block: 15 carry-save adders + one ripple into the upper planes).  The 64 lanes' bit-sliced
+// counts are then summed by TRANSPOSING each plane across the wave (bit_transpose64): lane e ends up
+// with "bit p of every lane's count for env e", whose popcount weighs 2^p.  (The butterfly of
+// bit-sliced full adders this replaces was 1400 of the kernel's 3000 VALU instructions per wave.)
+// P = number of planes (E' < 2^P).  Wave w of W takes every W-th block of 1024 edges and the
 // result is that wave's partial count (sum the W partials, see block_sum_partials).
 //
-// Full blocks run without bounds checks and with all 16 endpoint loads issued before the
-// 16 LDS reads (a per-edge `if (e < E)` made hipcc serialise load -> wait -> read per edge:
+// Full blocks run without bounds checks and with all endpoint loads issued before the
+// LDS reads (a per-edge `if (e < E)` made hipcc serialise load -> wait -> read per edge:
 // 8 L2 round trips per block, the whole kernel at 10 % of its HBM bound).
 // =====================================================================================
+template <int P> struct HsState {
+    static constexpr int PL = (P - 5) < 5 ? 5 : (P - 5);   // per-lane count <= ceil(E/64) < 2^(P-5)
+    uint64_t ones = 0, twos = 0, fours = 0, eights = 0;
+    uint64_t c[PL];                                        // planes 4.. live in c[4..]; c[0..3] unused until finish()
+};
+
 template <int P>
-__device__ __forceinline__ void hs_block(const uint64_t (&d)[8], uint64_t& ones, uint64_t& twos, uint64_t& fours,
-                                         uint64_t (&c)[P]) {
-    constexpr int PL = (P - 5) < 4 ? 4 : (P - 5);  // per-lane count <= ceil(E/64) < 2^(P-5)
+__device__ __forceinline__ uint64_t hs_eight(const uint64_t (&d)[8], HsState<P>& st) {
     uint64_t twosA, twosB, foursA, foursB, eights;
-    csa(twosA, ones, ones, d[0], d[1]);
-    csa(twosB, ones, ones, d[2], d[3]);
-    csa(foursA, twos, twos, twosA, twosB);
-    csa(twosA, ones, ones, d[4], d[5]);
-    csa(twosB, ones, ones, d[6], d[7]);
-    csa(foursB, twos, twos, twosA, twosB);
-    csa(eights, fours, fours, foursA, foursB);
-    uint64_t carry = eights;
+    csa(twosA, st.ones, st.ones, d[0], d[1]);
+    csa(twosB, st.ones, st.ones, d[2], d[3]);
+    csa(foursA, st.twos, st.twos, twosA, twosB);
+    csa(twosA, st.ones, st.ones, d[4], d[5]);
+    csa(twosB, st.ones, st.ones, d[6], d[7]);
+    csa(foursB, st.twos, st.twos, twosA, twosB);
+    csa(eights, st.fours, st.fours, foursA, foursB);
+    return eights;
+}
+
+template <int P>
+__device__ __forceinline__ void hs_ripple16(uint64_t carry, HsState<P>& st) {
 #pragma unroll
-    for (int p = 3; p < PL; ++p) {
-        const uint64_t t = c[p] & carry;
-        c[p] ^= carry;
+    for (int p = 4; p < HsState<P>::PL; ++p) {
+        const uint64_t t = st.c[p] & carry;
+        st.c[p] ^= carry;
         carry = t;
     }
+}
+
+template <int P>
+__device__ __forceinline__ void hs_block16(const uint64_t (&dA)[8], const uint64_t (&dB)[8], HsState<P>& st) {
+    const uint64_t eA = hs_eight<P>(dA, st), eB = hs_eight<P>(dB, st);
+    uint64_t sixteens;
+    csa(sixteens, st.eights, st.eights, eA, eB);
+    hs_ripple16<P>(sixteens, st);
 }
 
 template <int P>
@@ -44,55 +61,48 @@ __device__ __forceinline__ int64_t tile_cut_count(const uint64_t* __restrict__ w
                                                   const int32_t* __restrict__ eu,
                                                   const int32_t* __restrict__ ev,
                                                   int64_t E, int lane, int w = 0, int W = 1) {
-    uint64_t c[P];
+    HsState<P> st;
 #pragma unroll
-    for (int p = 0; p < P; ++p) c[p] = 0;
-    uint64_t ones = 0, twos = 0, fours = 0;
-    constexpr int64_t BLK = 8 * kWave;
+    for (int p = 0; p < HsState<P>::PL; ++p) st.c[p] = 0;
+    constexpr int64_t BLK = 16 * kWave;
     const int64_t nfull = E / BLK;
 
     for (int64_t blk = w; blk < nfull; blk += W) {
         const int32_t* pu = eu + blk * BLK + lane;
         const int32_t* pv = ev + blk * BLK + lane;
-        int u[8], v[8];
+        int u[16], v[16];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { u[k] = pu[k * kWave]; v[k] = pv[k * kWave]; }
-        uint64_t a[8], b[8], d[8];
+        for (int k = 0; k < 16; ++k) { u[k] = pu[k * kWave]; v[k] = pv[k * kWave]; }
+        uint64_t dA[8], dB[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) { a[k] = words[u[k]]; b[k] = words[v[k]]; }
+        for (int k = 0; k < 8; ++k) dA[k] = words[u[k]] ^ words[v[k]];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) d[k] = a[k] ^ b[k];
-        hs_block<P>(d, ones, twos, fours, c);
+        for (int k = 0; k < 8; ++k) dB[k] = words[u[8 + k]] ^ words[v[8 + k]];
+        hs_block16<P>(dA, dB, st);
     }
     if (nfull * BLK < E && (nfull % W) == w) {  // the ragged last block
-        uint64_t d[8];
+        uint64_t dA[8], dB[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < 16; ++k) {
             const int64_t e = nfull * BLK + k * kWave + lane;
             const bool in = e < E;
             const int u = in ? eu[e] : 0, v = in ? ev[e] : 0;
-            d[k] = in ? (words[u] ^ words[v]) : 0ull;
+            const uint64_t d = in ? (words[u] ^ words[v]) : 0ull;
+            if (k < 8) dA[k] = d; else dB[k - 8] = d;
         }
-        hs_block<P>(d, ones, twos, fours, c);
+        hs_block16<P>(dA, dB, st);
     }
-    c[0] = ones; c[1] = twos; c[2] = fours;
+    st.c[0] = st.ones; st.c[1] = st.twos; st.c[2] = st.fours; st.c[3] = st.eights;
 
-    // butterfly: after the step with mask m every lane holds the sum over its 2m-group
-#pragma unroll
-    for (int m = 1; m < kWave; m <<= 1) {
-        uint64_t carry = 0;
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-            const uint64_t o = shfl_xor64(c[p], m);
-            const uint64_t u = c[p] ^ o;
-            const uint64_t s = u ^ carry;
-            carry = (c[p] & o) | (u & carry);
-            c[p] = s;
-        }
-    }
+    // sum over the 64 lanes: transpose each plane, popcount, weigh
+    const BitXpose xc = bit_xpose_consts(lane);
     int64_t total = 0;
 #pragma unroll
-    for (int p = 0; p < P; ++p) total |= (int64_t)((c[p] >> lane) & 1ull) << p;
+    for (int p = 0; p < HsState<P>::PL; ++p) {
+        uint32_t r0 = (uint32_t)st.c[p], r1 = (uint32_t)(st.c[p] >> 32);
+        bit_transpose64(r0, r1, xc);
+        total += (int64_t)(__builtin_popcount(r0) + __builtin_popcount(r1)) << p;
+    }
     return total;
 }
 

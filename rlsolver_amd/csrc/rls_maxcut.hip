@@ -14,14 +14,16 @@ template <typename T, bool VEC, int P>
 __global__ __launch_bounds__(kTileWaves * kWave) void k_maxcut_obj(const T* __restrict__ x, int64_t B, int64_t N,
                                                                    const int32_t* __restrict__ eu,
                                                                    const int32_t* __restrict__ ev, int64_t E,
-                                                                   int halve, int64_t* __restrict__ obj) {
+                                                                   int halve, int64_t* __restrict__ obj,
+                                                                   int stage_off) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* words = reinterpret_cast<uint64_t*>(smem);
     int64_t* scratch = reinterpret_cast<int64_t*>(words + N);
     const int lane = threadIdx.x & (kWave - 1);
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     const int64_t b0 = (int64_t)blockIdx.x * kWave;
-    tile_load_bits<T, VEC>(x, B, N, b0, words, lane, w, kTileWaves);
+    unsigned char* stage = stage_off >= 0 ? smem + stage_off + w * kStageBytes : nullptr;
+    tile_load_bits<T, VEC>(x, B, N, b0, words, lane, w, kTileWaves, stage);
     __syncthreads();
     int64_t total = block_sum_partials<kTileWaves>(tile_cut_count<P>(words, eu, ev, E, lane, w, kTileWaves),
                                                    scratch, lane, w);
@@ -58,23 +60,7 @@ __global__ __launch_bounds__(kTileWaves * kWave) void k_maxcut_propose_accept(ui
     __syncthreads();                                   // every wave has read obj[b] before wave 0 updates it
     if (accept && w == 0) obj[b] = total;
     // accepted rows take the proposal (each wave writes a quarter of the columns); others are untouched
-    if (accept) {
-        uint8_t* row = x + b * N;
-        const int half = lane >> 5, sh = lane & 31;
-        const uint32_t* w32 = reinterpret_cast<const uint32_t*>(words);
-        if constexpr (VEC) {
-            u32x4* rv = reinterpret_cast<u32x4*>(row);
-            for (int64_t i = w; i < (N >> 4); i += kTileWaves) {
-                uint32_t d[4] = {0, 0, 0, 0};
-#pragma unroll
-                for (int k = 0; k < 16; ++k)
-                    d[k >> 2] |= ((w32[(((i << 4) + k) << 1) + half] >> sh) & 1u) << ((k & 3) * 8);
-                rv[i] = u32x4{d[0], d[1], d[2], d[3]};
-            }
-        } else {
-            for (int64_t n = w; n < N; n += kTileWaves) row[n] = (uint8_t)((w32[(n << 1) + half] >> sh) & 1u);
-        }
-    }
+    tile_store_bytes<VEC>(x, B, N, b0, words, lane, w, kTileWaves, accept);
 }
 
 // =====================================================================================
@@ -464,21 +450,24 @@ int rls_maxcut_obj(const rls_graph* g, const void* x, int spin_bytes, int64_t B,
     RLS_REQUIRE(x && obj, RLS_EINVAL, "x/obj is NULL");
     RLS_REQUIRE(spin_bytes == 1 || spin_bytes == 4, RLS_EINVAL, "spin_bytes must be 1 or 4");
     const int64_t N = g->num_nodes, E = g->num_stored_edges;
-    const size_t lds = (size_t)N * 8 + (size_t)kTileWaves * kWave * 8;
+    size_t lds = (size_t)N * 8 + (size_t)kTileWaves * kWave * 8;
     RLS_REQUIRE(lds <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS per 64-env tile (max %d)",
                 (long long)N, lds, kLdsBytes);
     const int P = pick_planes(E);
     RLS_REQUIRE(P != 0, RLS_EUNSUPPORTED, "E'=%lld too large", (long long)E);
     const bool vec = rows_vec_aligned(x, N, spin_bytes);
+    const int stage_off = tile_stage_offset(&lds, kTileWaves, vec && spin_bytes == 1);
     const dim3 grid((unsigned)ceil_div(B, kWave)), block(kTileWaves * kWave);
     hipStream_t s = as_stream(stream);
     const int halve = g->if_bidirectional ? 1 : 0;
+    static const long long dbgE = getenv("RLS_K1_E") ? atoll(getenv("RLS_K1_E")) : -1;   // DEV ONLY
+    const int64_t Ek = dbgE >= 0 ? dbgE : E;
 #define LAUNCH_OBJ(T, VEC, PP)                                                                             \
     do {                                                                                                   \
         auto kern = k_maxcut_obj<T, VEC, PP>;                                                              \
         if (lds > 64 * 1024)                                                                               \
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL(kern, grid, block, lds, s, (const T*)x, B, N, g->eu, g->ev, E, halve, obj);     \
+        hipLaunchKernelGGL(kern, grid, block, lds, s, (const T*)x, B, N, g->eu, g->ev, Ek, halve, obj, stage_off); \
     } while (0)
 #define DISPATCH_P(T, VEC)                       \
     switch (P) {                                 \

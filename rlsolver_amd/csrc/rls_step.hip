@@ -52,11 +52,6 @@ template <bool NT, typename V> __device__ __forceinline__ void st_vec(V* p, V v)
     else *p = v;
 }
 
-__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-
 template <typename T, int EPW, int MODE, bool EMIT, bool VEC, bool WEIGHTED, bool NTL, bool NTS>
 __global__ __launch_bounds__(256) void k_maxcut_step(const T* __restrict__ xin, T* __restrict__ xout,
                                                      int64_t B, int64_t N,

@@ -8,6 +8,7 @@
 // spin.  N * 8 bytes of LDS per wave (16 KB for G22, 80 KB for N = 10^4).
 #pragma once
 #include "rls_common.h"
+#include <cstdlib>
 
 namespace rls {
 
@@ -47,37 +48,169 @@ template <> struct SpinVec<float> {
 // 64-bit ballot as two dwords
 __device__ __forceinline__ uint64_t ballot64(bool p) { return __ballot(p); }
 
+// ---- 64x64 bit-matrix transpose across a wavefront.
+// Lane l holds row l as (r1:r0); afterwards lane p holds column p (bit l = old bit p of lane l).
+// Six index-bit exchanges: lanes l and l^s trade the bits whose position differs in bit s.
+//   s = 32 : one v_permlane32_swap (gfx950)
+//   s = 16, 8 : partner's dword through ds_swizzle (LDS crossbar, no memory) + one v_perm_b32
+//   s = 4, 2, 1 : ds_swizzle + v_alignbit (rotate) + one v_bitop3 (bit select)
+// 17 VALU + 10 swizzles per 4096 bits; the ballot-per-node form it replaces cost ~5 VALU per 64 bits.
+struct BitXpose {
+    uint32_t sel16, sel8, m4, m2, m1;
+    int r4, r2, r1;
+    int node;   // node offset (within a 64-node block) of the column this lane ends up with, see pack_bits
+};
+
+__device__ __forceinline__ BitXpose bit_xpose_consts(int lane) {
+    BitXpose c;
+    c.sel16 = (lane & 16) ? 0x03020706u : 0x05040100u;
+    c.sel8 = (lane & 8) ? 0x03070105u : 0x06020400u;
+    c.m4 = (lane & 4) ? 0xF0F0F0F0u : 0x0F0F0F0Fu;
+    c.m2 = (lane & 2) ? 0xCCCCCCCCu : 0x33333333u;
+    c.m1 = (lane & 1) ? 0xAAAAAAAAu : 0x55555555u;
+    c.r4 = (lane & 4) ? 4 : 28;
+    c.r2 = (lane & 2) ? 2 : 30;
+    c.r1 = (lane & 1) ? 1 : 31;
+    c.node = (lane & 32) | ((lane & 7) << 2) | ((lane >> 3) & 3);
+    return c;
+}
+
+template <int XOR> __device__ __forceinline__ uint32_t lane_xor(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x1F | (XOR << 10));
+}
+
+__device__ __forceinline__ uint32_t xpose_sub(uint32_t x, uint32_t other, uint32_t keep, int rot) {
+    const uint32_t t = __builtin_amdgcn_alignbit(other, other, rot);
+    return (keep & x) | (~keep & t);
+}
+
+__device__ __forceinline__ void bit_transpose64(uint32_t& r0, uint32_t& r1, const BitXpose& c) {
+    auto sw = __builtin_amdgcn_permlane32_swap(r0, r1, false, false);
+    r0 = sw[0];
+    r1 = sw[1];
+    uint32_t o0 = lane_xor<16>(r0), o1 = lane_xor<16>(r1);
+    r0 = __builtin_amdgcn_perm(o0, r0, c.sel16);
+    r1 = __builtin_amdgcn_perm(o1, r1, c.sel16);
+    o0 = lane_xor<8>(r0); o1 = lane_xor<8>(r1);
+    r0 = __builtin_amdgcn_perm(o0, r0, c.sel8);
+    r1 = __builtin_amdgcn_perm(o1, r1, c.sel8);
+    o0 = lane_xor<4>(r0); o1 = lane_xor<4>(r1);
+    r0 = xpose_sub(r0, o0, c.m4, c.r4);
+    r1 = xpose_sub(r1, o1, c.m4, c.r4);
+    o0 = lane_xor<2>(r0); o1 = lane_xor<2>(r1);
+    r0 = xpose_sub(r0, o0, c.m2, c.r2);
+    r1 = xpose_sub(r1, o1, c.m2, c.r2);
+    o0 = lane_xor<1>(r0); o1 = lane_xor<1>(r1);
+    r0 = xpose_sub(r0, o0, c.m1, c.r1);
+    r1 = xpose_sub(r1, o1, c.m1, c.r1);
+}
+
+// 32 spin bytes (0|1) of one env -> 32 bits: bit 8*b + q = byte b of dword q, i.e. node 4*q + b.
+__device__ __forceinline__ uint32_t pack_bits(const u32x4& lo, const u32x4& hi) {
+    uint32_t r = lo[0];
+    r |= lo[1] << 1; r |= lo[2] << 2; r |= lo[3] << 3;
+    r |= hi[0] << 4; r |= hi[1] << 5; r |= hi[2] << 6; r |= hi[3] << 7;
+    return r;
+}
+__device__ __forceinline__ void unpack_bits(uint32_t r, u32x4& lo, u32x4& hi) {
+    lo = u32x4{r & 0x01010101u, (r >> 1) & 0x01010101u, (r >> 2) & 0x01010101u, (r >> 3) & 0x01010101u};
+    hi = u32x4{(r >> 4) & 0x01010101u, (r >> 5) & 0x01010101u, (r >> 6) & 0x01010101u, (r >> 7) & 0x01010101u};
+}
+
+// direct global -> LDS load, 16 B per lane: lane l's bytes land at lds_wave_base + 16 * l
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// ---- row-piece staging (the env-major <-> lane-per-env corner turn).
+// A lane-per-env global access touches 64 different cache lines per instruction and the texture path
+// spends ~3 clocks per line: the tile load ran at 2.5 TB/s however many waves were resident.  With a
+// per-wave 8 KB LDS stage the global side moves 128-byte row pieces instead (8 lanes x 16 B per row,
+// 8 rows per instruction, LDS-DMA on the way in) and each lane then picks its env's 8 pieces out of LDS.
+// Slot of (row 8*i + r, piece j) inside the 1 KB region of instruction i: 8 * (j ^ (i & 1)) + r, so that
+// the 16 lanes of one ds_read_b128 pass hit 16 different bank quads.
+constexpr int kStageBytes = 8192;   // per wave
+
+// Host side: append W stages to a kernel's dynamic LDS when they fit; returns their byte offset or -1.
+inline int tile_stage_offset(size_t* lds_bytes, int W, bool wanted) {
+    static const bool off = getenv("RLS_TILE_NOSTAGE") != nullptr;   // dev knob: lane-per-env global access
+    const size_t base = (*lds_bytes + 15) & ~(size_t)15;
+    if (!wanted || off || base + (size_t)W * kStageBytes > (size_t)kLdsBytes) return -1;
+    *lds_bytes = base + (size_t)W * kStageBytes;
+    return (int)base;
+}
+
+__device__ __forceinline__ int stage_slot_off(int env, int piece) {   // byte offset of (env's row, piece j)
+    const int i = env >> 3, r = env & 7;
+    return (i << 10) + ((((piece ^ (i & 1)) << 3) + r) << 4);
+}
+
 // Load the tile of envs [b0, b0+64) x nodes [0, N) into words[0..N).
 // VEC = true requires row starts to be 16-byte aligned (x aligned and N * sizeof(T) % 16 == 0).
 // W waves of one workgroup may share the job (wave w of W takes every W-th batch of columns); every
 // wave sees all 64 envs, so each ballot still yields a complete word.  Callers sync afterwards.
 template <typename T, bool VEC>
 __device__ __forceinline__ void tile_load_bits(const T* __restrict__ x, int64_t B, int64_t N, int64_t b0,
-                                               uint64_t* __restrict__ words, int lane, int w = 0, int W = 1) {
+                                               uint64_t* __restrict__ words, int lane, int w = 0, int W = 1,
+                                               unsigned char* stage = nullptr) {
     const int64_t b = b0 + lane;
     const bool valid = b < B;
     const T* row = x + (valid ? b : 0) * N;
     if constexpr (VEC && sizeof(T) == 1) {
+        if (stage != nullptr) {   // `stage`: this wave's kStageBytes of LDS, 16-byte aligned
+            const int64_t nv = N >> 4;
+            const int64_t nchunk = (N + 127) >> 7;
+            const BitXpose xc = bit_xpose_consts(lane);
+            const int r = lane & 7, jj = lane >> 3;
+            const uint8_t* xb = reinterpret_cast<const uint8_t*>(x);
+            for (int64_t ch = w; ch < nchunk; ch += W) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // last trip's LDS reads are done
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int64_t rw = b0 + 8 * i + r;
+                    const int64_t vi = (ch << 3) + (jj ^ (i & 1));
+                    if (rw < B && vi < nv) glds16(xb + rw * N + (vi << 4), stage + (i << 10));
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                u32x4 v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    v[j] = *reinterpret_cast<const u32x4*>(stage + stage_slot_off(lane, j));
+                    if (!(valid && (ch << 3) + j < nv)) v[j] = u32x4{0, 0, 0, 0};
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    uint32_t r0 = pack_bits(v[4 * h], v[4 * h + 1]), r1 = pack_bits(v[4 * h + 2], v[4 * h + 3]);
+                    bit_transpose64(r0, r1, xc);
+                    const int64_t n = (ch << 7) + (h << 6) + xc.node;
+                    if (n < N) words[n] = ((uint64_t)r1 << 32) | r0;
+                }
+            }
+            return;
+        }
+        // 64 nodes per block: every lane packs 64 bytes of its env's row into 64 bits, the wave transposes
+        // the 64x64 bit matrix, lane p then holds the word of node n0 + node(p).  Bytes must be 0|1.
         const u32x4* rv = reinterpret_cast<const u32x4*>(row);
         const int64_t nv = N >> 4;
-        constexpr int DEPTH = 8;  // row loads in flight per lane (the loop is latency-bound otherwise)
-        for (int64_t i0 = (int64_t)w * DEPTH; i0 < nv; i0 += (int64_t)W * DEPTH) {
-            u32x4 v[DEPTH];
+        const int64_t nblk = (N + 63) >> 6;
+        const BitXpose xc = bit_xpose_consts(lane);
+        constexpr int DEPTH = 2;  // blocks (8 row loads) in flight per lane
+        for (int64_t blk0 = (int64_t)w * DEPTH; blk0 < nblk; blk0 += (int64_t)W * DEPTH) {
+            u32x4 v[DEPTH][4];
 #pragma unroll
             for (int q = 0; q < DEPTH; ++q)
-                v[q] = (valid && i0 + q < nv) ? rv[i0 + q] : u32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int64_t idx = ((blk0 + q) << 2) + j;
+                    v[q][j] = (valid && idx < nv) ? rv[idx] : u32x4{0, 0, 0, 0};
+                }
 #pragma unroll
             for (int q = 0; q < DEPTH; ++q) {
-                if (i0 + q < nv) {
-                    const uint32_t d[4] = {v[q][0], v[q][1], v[q][2], v[q][3]};
-                    uint64_t mine = 0;
-#pragma unroll
-                    for (int k = 0; k < 16; ++k) {
-                        uint64_t w = ballot64(((d[k >> 2] >> ((k & 3) * 8)) & 0xffu) != 0);
-                        if (lane == k) mine = w;
-                    }
-                    if (lane < 16) words[((i0 + q) << 4) + lane] = mine;
-                }
+                uint32_t r0 = pack_bits(v[q][0], v[q][1]), r1 = pack_bits(v[q][2], v[q][3]);
+                bit_transpose64(r0, r1, xc);
+                const int64_t n = ((blk0 + q) << 6) + xc.node;
+                if (n < N) words[n] = ((uint64_t)r1 << 32) | r0;
             }
         }
     } else if constexpr (VEC && sizeof(T) == 4) {
@@ -109,37 +242,83 @@ __device__ __forceinline__ void tile_load_bits(const T* __restrict__ x, int64_t 
     }
 }
 
-// Write the tile back as env-major bytes (uint8 0|1).
+// Write the tile back as env-major bytes (uint8 0|1); lanes with store_row == false leave their row untouched.
 template <bool VEC>
 __device__ __forceinline__ void tile_store_bytes(uint8_t* __restrict__ x, int64_t B, int64_t N, int64_t b0,
-                                                 const uint64_t* __restrict__ words, int lane, int w = 0, int W = 1) {
+                                                 const uint64_t* __restrict__ words, int lane, int w = 0, int W = 1,
+                                                 bool store_row = true, unsigned char* stage = nullptr) {
     const int64_t b = b0 + lane;
-    if (b >= B) return;
-    uint8_t* row = x + b * N;
+    const bool valid = b < B && store_row;   // all 64 lanes take part in the transpose whatever they store
+    uint8_t* row = x + (valid ? b : 0) * N;
     const int half = lane >> 5, sh = lane & 31;
     const uint32_t* w32 = reinterpret_cast<const uint32_t*>(words);
     if constexpr (VEC) {
+        if (stage != nullptr) {   // through the row-piece stage: 128-byte runs on the global side
+            const int64_t nv = N >> 4;
+            const int64_t nchunk = (N + 127) >> 7;
+            const BitXpose xc = bit_xpose_consts(lane);
+            const int r = lane & 7, jj = lane >> 3;
+            const uint64_t rows_ok = ballot64(valid);
+            for (int64_t ch = w; ch < nchunk; ch += W) {
+                u32x4 v[8];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int64_t n = (ch << 7) + (h << 6) + xc.node;
+                    const uint64_t wd = (n < N) ? words[n] : 0ull;
+                    uint32_t r0 = (uint32_t)wd, r1 = (uint32_t)(wd >> 32);
+                    bit_transpose64(r0, r1, xc);
+                    unpack_bits(r0, v[4 * h], v[4 * h + 1]);
+                    unpack_bits(r1, v[4 * h + 2], v[4 * h + 3]);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) *reinterpret_cast<u32x4*>(stage + stage_slot_off(lane, j)) = v[j];
+                asm volatile("" ::: "memory");   // LDS ops of one wave execute in order
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int64_t rw = b0 + 8 * i + r;
+                    const int64_t vi = (ch << 3) + (jj ^ (i & 1));
+                    const u32x4 o = *reinterpret_cast<const u32x4*>(stage + (i << 10) + (lane << 4));
+                    if (((rows_ok >> (8 * i + r)) & 1ull) && vi < nv)
+                        *reinterpret_cast<u32x4*>(x + rw * N + (vi << 4)) = o;
+                }
+                asm volatile("" ::: "memory");
+            }
+            return;
+        }
+        // inverse of the load: lane p fetches the word of node n0 + node(p), transpose, unpack to bytes
         u32x4* rv = reinterpret_cast<u32x4*>(row);
         const int64_t nv = N >> 4;
-        for (int64_t i = w; i < nv; i += W) {
-            uint32_t d[4] = {0, 0, 0, 0};
+        const int64_t nblk = (N + 63) >> 6;
+        const BitXpose xc = bit_xpose_consts(lane);
+        for (int64_t blk = w; blk < nblk; blk += W) {
+            const int64_t n = (blk << 6) + xc.node;
+            const uint64_t wd = (n < N) ? words[n] : 0ull;
+            uint32_t r0 = (uint32_t)wd, r1 = (uint32_t)(wd >> 32);
+            bit_transpose64(r0, r1, xc);
+            u32x4 v[4];
+            unpack_bits(r0, v[0], v[1]);
+            unpack_bits(r1, v[2], v[3]);
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                uint32_t bit = (w32[(((i << 4) + k) << 1) + half] >> sh) & 1u;
-                d[k >> 2] |= bit << ((k & 3) * 8);
+            for (int j = 0; j < 4; ++j) {
+                const int64_t idx = (blk << 2) + j;
+                if (valid && idx < nv) rv[idx] = v[j];
             }
-            rv[i] = u32x4{d[0], d[1], d[2], d[3]};
         }
     } else {
+        if (!valid) return;
         for (int64_t n = w; n < N; n += W) row[n] = (uint8_t)((w32[(n << 1) + half] >> sh) & 1u);
     }
 }
 
 // ---- bit-sliced (vertical) counters: plane p holds bit p of 64 independent counts.
+// carry-save adder on 64 counters at once; gfx950's v_bitop3 does a 3-input majority / parity in one op
 __device__ __forceinline__ void csa(uint64_t& hi, uint64_t& lo, uint64_t a, uint64_t b, uint64_t c) {
-    const uint64_t u = a ^ b;
-    hi = (a & b) | (u & c);
-    lo = u ^ c;
+    const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32),
+                   c0 = (uint32_t)c, c1 = (uint32_t)(c >> 32);
+    const uint32_t h0 = __builtin_amdgcn_bitop3_b32(a0, b0, c0, 0xE8), h1 = __builtin_amdgcn_bitop3_b32(a1, b1, c1, 0xE8);
+    const uint32_t l0 = __builtin_amdgcn_bitop3_b32(a0, b0, c0, 0x96), l1 = __builtin_amdgcn_bitop3_b32(a1, b1, c1, 0x96);
+    hi = ((uint64_t)h1 << 32) | h0;
+    lo = ((uint64_t)l1 << 32) | l0;
 }
 
 __device__ __forceinline__ uint64_t shfl_xor64(uint64_t v, int mask) {
