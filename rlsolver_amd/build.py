@@ -56,6 +56,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(obj_dir, exist_ok=True)
     common = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
               f"-I{INCLUDE}", f"-I{CSRC}", "-Wall", "-Wno-unused-function", "-Wno-pass-failed"]
+    common += os.environ.get("RLS_EXTRA_CFLAGS", "").split()   # dev builds, e.g. -DRLS_PROF
     procs = []
     for src in _sources():
         obj = os.path.join(obj_dir, os.path.basename(src).replace(".hip", ".o"))

@@ -58,6 +58,18 @@ inline bool rows_vec_aligned(const void* p, int64_t N, int elt) {
     return (((uintptr_t)p) & 15) == 0 && ((N * elt) & 15) == 0;
 }
 
+// compute units of the current device (256 on MI355X); cached per process
+inline int num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
 inline int grid_for(int64_t total, int block) {
     int64_t g = ceil_div(total, block);
     const int64_t cap = 256 * 8 * 4;

@@ -125,12 +125,18 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
 
 // ---- row-piece staging (the env-major <-> lane-per-env corner turn).
 // A lane-per-env global access touches 64 different cache lines per instruction and the texture path
-// spends ~3 clocks per line: the tile load ran at 2.5 TB/s however many waves were resident.  With a
-// per-wave 8 KB LDS stage the global side moves 128-byte row pieces instead (8 lanes x 16 B per row,
-// 8 rows per instruction, LDS-DMA on the way in) and each lane then picks its env's 8 pieces out of LDS.
-// Slot of (row 8*i + r, piece j) inside the 1 KB region of instruction i: 8 * (j ^ (i & 1)) + r, so that
-// the 16 lanes of one ds_read_b128 pass hit 16 different bank quads.
-constexpr int kStageBytes = 8192;   // per wave
+// spends ~3 clocks per line: the tile load ran at 2.5 TB/s however many waves were resident.  So the
+// global side moves contiguous 64-byte row pieces instead (instruction i: rows 16i..16i+15, lane l ->
+// row 16i + (l & 15), 16-byte piece l >> 4), and the wave turns the corner through a 4 KB LDS stage:
+// each lane writes what it fetched (slot = its lane id in the instruction's 1 KB region) and reads back
+// the 4 pieces of ITS env's row.  Both sides are conflict-free: the 16 lanes of a ds_*_b128 pass touch 16
+// different bank quads.  Loads land in registers, kStageDepth chunks (4 KB each) per wave in flight --
+// an LDS-DMA version needed one stage per chunk in flight and LDS capped the bytes in flight per CU.
+constexpr int kStagePieces = 4;                      // 16-byte pieces per row per chunk
+constexpr int kStageRows = 64 / kStagePieces;        // rows per load instruction
+constexpr int kStageBytes = 1024 * kStagePieces;     // per wave
+constexpr int kStageNodes = 16 * kStagePieces;       // nodes per chunk (= one 64x64 transpose block)
+constexpr int kStageDepth = 3;                       // chunks in flight per wave
 
 // Host side: append W stages to a kernel's dynamic LDS when they fit; returns their byte offset or -1.
 inline int tile_stage_offset(size_t* lds_bytes, int W, bool wanted) {
@@ -141,16 +147,17 @@ inline int tile_stage_offset(size_t* lds_bytes, int W, bool wanted) {
     return (int)base;
 }
 
+// what lane l of load/store instruction i moves: row 16i + r, piece j
+__device__ __forceinline__ void stage_io_lane(int l, int& r, int& j) { r = l & 15; j = l >> 4; }
 __device__ __forceinline__ int stage_slot_off(int env, int piece) {   // byte offset of (env's row, piece j)
-    const int i = env >> 3, r = env & 7;
-    return (i << 10) + ((((piece ^ (i & 1)) << 3) + r) << 4);
+    return ((env >> 4) << 10) + (((piece << 4) + (env & 15)) << 4);
 }
 
 // Load the tile of envs [b0, b0+64) x nodes [0, N) into words[0..N).
 // VEC = true requires row starts to be 16-byte aligned (x aligned and N * sizeof(T) % 16 == 0).
 // W waves of one workgroup may share the job (wave w of W takes every W-th batch of columns); every
 // wave sees all 64 envs, so each ballot still yields a complete word.  Callers sync afterwards.
-template <typename T, bool VEC>
+template <typename T, bool VEC, int DEPTH = kStageDepth>
 __device__ __forceinline__ void tile_load_bits(const T* __restrict__ x, int64_t B, int64_t N, int64_t b0,
                                                uint64_t* __restrict__ words, int lane, int w = 0, int W = 1,
                                                unsigned char* stage = nullptr) {
@@ -160,31 +167,45 @@ __device__ __forceinline__ void tile_load_bits(const T* __restrict__ x, int64_t 
     if constexpr (VEC && sizeof(T) == 1) {
         if (stage != nullptr) {   // `stage`: this wave's kStageBytes of LDS, 16-byte aligned
             const int64_t nv = N >> 4;
-            const int64_t nchunk = (N + 127) >> 7;
+            const int64_t nchunk = (N + kStageNodes - 1) / kStageNodes;
             const BitXpose xc = bit_xpose_consts(lane);
-            const int r = lane & 7, jj = lane >> 3;
-            const uint8_t* xb = reinterpret_cast<const uint8_t*>(x);
-            for (int64_t ch = w; ch < nchunk; ch += W) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // last trip's LDS reads are done
+            int r, j;
+            stage_io_lane(lane, r, j);
+            const u32x4* src[kStagePieces];     // row starts of the 4 rows this lane fetches from
+            bool row_ok[kStagePieces];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int64_t rw = b0 + 8 * i + r;
-                    const int64_t vi = (ch << 3) + (jj ^ (i & 1));
-                    if (rw < B && vi < nv) glds16(xb + rw * N + (vi << 4), stage + (i << 10));
+            for (int i = 0; i < kStagePieces; ++i) {
+                const int64_t rw = b0 + kStageRows * i + r;
+                row_ok[i] = rw < B;
+                src[i] = reinterpret_cast<const u32x4*>(x + (row_ok[i] ? rw : 0) * N);
+            }
+            for (int64_t ch0 = w; ch0 < nchunk; ch0 += (int64_t)W * DEPTH) {
+                u32x4 g[DEPTH][kStagePieces];
+#pragma unroll
+                for (int d = 0; d < DEPTH; ++d) {
+                    const int64_t vi = (ch0 + (int64_t)d * W) * kStagePieces + j;
+#pragma unroll
+                    for (int i = 0; i < kStagePieces; ++i)
+                        g[d][i] = (row_ok[i] && vi < nv) ? src[i][vi] : u32x4{0, 0, 0, 0};
                 }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                u32x4 v[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    v[j] = *reinterpret_cast<const u32x4*>(stage + stage_slot_off(lane, j));
-                    if (!(valid && (ch << 3) + j < nv)) v[j] = u32x4{0, 0, 0, 0};
-                }
+                for (int d = 0; d < DEPTH; ++d) {
+                    const int64_t ch = ch0 + (int64_t)d * W;
+                    if (ch < nchunk) {
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    uint32_t r0 = pack_bits(v[4 * h], v[4 * h + 1]), r1 = pack_bits(v[4 * h + 2], v[4 * h + 3]);
-                    bit_transpose64(r0, r1, xc);
-                    const int64_t n = (ch << 7) + (h << 6) + xc.node;
-                    if (n < N) words[n] = ((uint64_t)r1 << 32) | r0;
+                        for (int i = 0; i < kStagePieces; ++i)
+                            *reinterpret_cast<u32x4*>(stage + (i << 10) + (lane << 4)) = g[d][i];
+                        asm volatile("" ::: "memory");   // LDS ops of one wave execute in order
+                        u32x4 v[kStagePieces];
+#pragma unroll
+                        for (int q = 0; q < kStagePieces; ++q)
+                            v[q] = *reinterpret_cast<const u32x4*>(stage + stage_slot_off(lane, q));
+                        asm volatile("" ::: "memory");
+                        uint32_t r0 = pack_bits(v[0], v[1]), r1 = pack_bits(v[2], v[3]);
+                        bit_transpose64(r0, r1, xc);
+                        const int64_t n = ch * kStageNodes + xc.node;
+                        if (n < N) words[n] = ((uint64_t)r1 << 32) | r0;
+                    }
                 }
             }
             return;
@@ -195,18 +216,18 @@ __device__ __forceinline__ void tile_load_bits(const T* __restrict__ x, int64_t 
         const int64_t nv = N >> 4;
         const int64_t nblk = (N + 63) >> 6;
         const BitXpose xc = bit_xpose_consts(lane);
-        constexpr int DEPTH = 2;  // blocks (8 row loads) in flight per lane
-        for (int64_t blk0 = (int64_t)w * DEPTH; blk0 < nblk; blk0 += (int64_t)W * DEPTH) {
-            u32x4 v[DEPTH][4];
+        constexpr int BLKS = 2;  // blocks (8 row loads) in flight per lane
+        for (int64_t blk0 = (int64_t)w * BLKS; blk0 < nblk; blk0 += (int64_t)W * BLKS) {
+            u32x4 v[BLKS][4];
 #pragma unroll
-            for (int q = 0; q < DEPTH; ++q)
+            for (int q = 0; q < BLKS; ++q)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int64_t idx = ((blk0 + q) << 2) + j;
                     v[q][j] = (valid && idx < nv) ? rv[idx] : u32x4{0, 0, 0, 0};
                 }
 #pragma unroll
-            for (int q = 0; q < DEPTH; ++q) {
+            for (int q = 0; q < BLKS; ++q) {
                 uint32_t r0 = pack_bits(v[q][0], v[q][1]), r1 = pack_bits(v[q][2], v[q][3]);
                 bit_transpose64(r0, r1, xc);
                 const int64_t n = ((blk0 + q) << 6) + xc.node;
@@ -255,31 +276,36 @@ __device__ __forceinline__ void tile_store_bytes(uint8_t* __restrict__ x, int64_
     if constexpr (VEC) {
         if (stage != nullptr) {   // through the row-piece stage: 128-byte runs on the global side
             const int64_t nv = N >> 4;
-            const int64_t nchunk = (N + 127) >> 7;
+            const int64_t nchunk = (N + kStageNodes - 1) / kStageNodes;
             const BitXpose xc = bit_xpose_consts(lane);
-            const int r = lane & 7, jj = lane >> 3;
             const uint64_t rows_ok = ballot64(valid);
+            int r, j;
+            stage_io_lane(lane, r, j);
+            u32x4* dst[kStagePieces];
+            bool row_ok[kStagePieces];
+#pragma unroll
+            for (int i = 0; i < kStagePieces; ++i) {
+                const int rr = kStageRows * i + r;
+                row_ok[i] = (rows_ok >> rr) & 1ull;
+                dst[i] = reinterpret_cast<u32x4*>(x + (row_ok[i] ? b0 + rr : 0) * N);
+            }
             for (int64_t ch = w; ch < nchunk; ch += W) {
-                u32x4 v[8];
+                const int64_t n = ch * kStageNodes + xc.node;
+                const uint64_t wd = (n < N) ? words[n] : 0ull;
+                uint32_t r0 = (uint32_t)wd, r1 = (uint32_t)(wd >> 32);
+                bit_transpose64(r0, r1, xc);
+                u32x4 v[kStagePieces];
+                unpack_bits(r0, v[0], v[1]);
+                unpack_bits(r1, v[2], v[3]);
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int64_t n = (ch << 7) + (h << 6) + xc.node;
-                    const uint64_t wd = (n < N) ? words[n] : 0ull;
-                    uint32_t r0 = (uint32_t)wd, r1 = (uint32_t)(wd >> 32);
-                    bit_transpose64(r0, r1, xc);
-                    unpack_bits(r0, v[4 * h], v[4 * h + 1]);
-                    unpack_bits(r1, v[4 * h + 2], v[4 * h + 3]);
-                }
-#pragma unroll
-                for (int j = 0; j < 8; ++j) *reinterpret_cast<u32x4*>(stage + stage_slot_off(lane, j)) = v[j];
+                for (int q = 0; q < kStagePieces; ++q)
+                    *reinterpret_cast<u32x4*>(stage + stage_slot_off(lane, q)) = v[q];
                 asm volatile("" ::: "memory");   // LDS ops of one wave execute in order
+                const int64_t vi = ch * kStagePieces + j;
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int64_t rw = b0 + 8 * i + r;
-                    const int64_t vi = (ch << 3) + (jj ^ (i & 1));
+                for (int i = 0; i < kStagePieces; ++i) {
                     const u32x4 o = *reinterpret_cast<const u32x4*>(stage + (i << 10) + (lane << 4));
-                    if (((rows_ok >> (8 * i + r)) & 1ull) && vi < nv)
-                        *reinterpret_cast<u32x4*>(x + rw * N + (vi << 4)) = o;
+                    if (row_ok[i] && vi < nv) dst[i][vi] = o;
                 }
                 asm volatile("" ::: "memory");
             }

@@ -49,6 +49,29 @@ def test_obj_random_vs_oracle(n, m, B, bidir):
     assert np.array_equal(ops.maxcut_obj(g, to_dev_bool(1 - xs)).cpu().numpy(), got)
 
 
+@pytest.mark.parametrize("n,m,B,bidir", [(64, 300, 98304 + 37, 0), (2000, 19990, 98304 + 1, 0), (800, 4694, 131072, 1),
+                                         (5008, 12000, 98304 + 64, 0)])
+def test_obj_large_batch_persistent_kernel(n, m, B, bidir):
+    """B >= 6 tiles per CU takes the wave-specialised persistent kernel (edges resident in LDS, producer /
+    consumer waves); n = 5008 does not fit two bit tiles + edges and stays on the plain one."""
+    graph = gnm_arr(n, m, seed=n + m)
+    g = device_graph(graph, n, bidir)
+    xs = ops.rand_spins(B, n, 12345, DEV)
+    got = ops.maxcut_obj(g, xs)
+    # every row against an independent torch formulation on the device ...
+    eu, ev = g.eu.long(), g.ev.long()
+    for lo in range(0, B, 8192):
+        blk = xs[lo:lo + 8192]
+        want = (blk[:, eu] ^ blk[:, ev]).sum(dim=1)
+        if bidir:
+            want = want // 2
+        assert torch.equal(got[lo:lo + 8192], want)
+    # ... and a sample of rows (first / last tile, a stride in between) against the oracle
+    rows = np.unique(np.concatenate([np.arange(130), np.arange(B - 130, B), np.arange(0, B, 997)]))
+    xs_h = xs[torch.from_numpy(rows).to(DEV)].cpu().numpy().astype(np.uint8)
+    assert np.array_equal(got.cpu().numpy()[rows], onp.maxcut_obj(xs_h, graph, bool(bidir)))
+
+
 def test_obj_edge_cases():
     graph = gnm_arr(50, 100, 1)
     g = device_graph(graph, 50, 0)
