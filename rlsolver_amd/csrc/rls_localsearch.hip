@@ -86,7 +86,10 @@ __global__ __launch_bounds__(kLsWaves * kWave) void k_maxcut_local_search(
     // ---- phase 0
     if (threadIdx.x == 0) words[N] = 0;
     for (int64_t i = threadIdx.x; i <= N; i += kLsWaves * kWave) rp[i] = rowptr[i];
-    tile_load_bits<uint8_t, VEC>(x, B, N, b0, words, lane, w, kLsWaves);
+    // the ring is idle outside the sweep: it doubles as the row-piece stage of the tile load / store
+    static_assert(kRing * 4 >= kLsWaves * kStageBytes, "the ring doubles as the tile stage");
+    unsigned char* stage = VEC ? reinterpret_cast<unsigned char*>(ring) + w * kStageBytes : nullptr;
+    tile_load_bits<uint8_t, VEC>(x, B, N, b0, words, lane, w, kLsWaves, stage);
     __syncthreads();
     int64_t my_obj;
     if (compute_obj) {
@@ -203,9 +206,10 @@ __global__ __launch_bounds__(kLsWaves * kWave) void k_maxcut_local_search(
         my_obj += sweep_tile(words, rp, ring, col, nnz, N, lane);
         if (valid) obj[b] = my_obj;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     // ---- phase 4
-    tile_store_bytes<VEC>(x, B, N, b0, words, lane, w, kLsWaves);
+    tile_store_bytes<VEC>(x, B, N, b0, words, lane, w, kLsWaves, true, stage);
 }
 
 }  // namespace rls

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(kTileWaves * kWave) void k_maxcut_propose_accept(ui
                                                                               const int32_t* __restrict__ eu,
                                                                               const int32_t* __restrict__ ev,
                                                                               int64_t E, int halve,
-                                                                              int64_t* __restrict__ obj) {
+                                                                              int64_t* __restrict__ obj, int stage_off) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* words = reinterpret_cast<uint64_t*>(smem);
     uint64_t* mwords = words + N;
@@ -105,8 +105,9 @@ __global__ __launch_bounds__(kTileWaves * kWave) void k_maxcut_propose_accept(ui
     const int lane = threadIdx.x & (kWave - 1);
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     const int64_t b0 = (int64_t)blockIdx.x * kWave;
-    tile_load_bits<uint8_t, VEC>(x, B, N, b0, words, lane, w, kTileWaves);
-    tile_load_bits<uint8_t, VEC>(mask, B, N, b0, mwords, lane, w, kTileWaves);
+    unsigned char* stage = stage_off >= 0 ? smem + stage_off + w * kStageBytes : nullptr;
+    tile_load_bits<uint8_t, VEC>(x, B, N, b0, words, lane, w, kTileWaves, stage);
+    tile_load_bits<uint8_t, VEC>(mask, B, N, b0, mwords, lane, w, kTileWaves, stage);
     __syncthreads();
     for (int64_t n = threadIdx.x; n < N; n += kTileWaves * kWave) words[n] ^= mwords[n];
     __syncthreads();
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(kTileWaves * kWave) void k_maxcut_propose_accept(ui
     __syncthreads();                                   // every wave has read obj[b] before wave 0 updates it
     if (accept && w == 0) obj[b] = total;
     // accepted rows take the proposal (each wave writes a quarter of the columns); others are untouched
-    tile_store_bytes<VEC>(x, B, N, b0, words, lane, w, kTileWaves, accept);
+    tile_store_bytes<VEC>(x, B, N, b0, words, lane, w, kTileWaves, accept, stage);
 }
 
 // =====================================================================================
@@ -148,11 +149,15 @@ __global__ __launch_bounds__(kWave) void k_maxcut_greedy_sweep(uint8_t* __restri
     const int64_t b0 = (int64_t)blockIdx.x * kWave;
     if (lane == 0) words[N] = 0;   // sentinel word
     for (int64_t i = lane; i <= N; i += kWave) rp[i] = rowptr[i];
-    tile_load_bits<uint8_t, VEC>(x, B, N, b0, words, lane);
+    // the ring is idle before and after the sweep: it doubles as the row-piece stage of the tile load / store
+    unsigned char* stage = VEC ? reinterpret_cast<unsigned char*>(ring) : nullptr;
+    tile_load_bits<uint8_t, VEC>(x, B, N, b0, words, lane, 0, 1, stage);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int64_t gain = sweep_tile(words, rp, ring, col, nnz, N, lane);
-    tile_store_bytes<VEC>(x, B, N, b0, words, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    tile_store_bytes<VEC>(x, B, N, b0, words, lane, 0, 1, true, stage);
     if (b0 + lane < B) obj[b0 + lane] += gain;
 }
 
@@ -171,13 +176,16 @@ __global__ __launch_bounds__(kTileWaves * kWave) void k_maxcut_greedy_sweep_batc
     const int64_t b0 = (int64_t)blockIdx.x * kWave;
     if (threadIdx.x == 0) words[N] = 0;
     for (int64_t i = threadIdx.x; i <= N; i += kTileWaves * kWave) rp[i] = rowptr_flagged[i];
-    tile_load_bits<uint8_t, VEC>(x, B, N, b0, words, lane, w, kTileWaves);
+    static_assert(kRing * 4 >= kTileWaves * kStageBytes, "the ring doubles as the tile stage");
+    unsigned char* stage = VEC ? reinterpret_cast<unsigned char*>(ring) + w * kStageBytes : nullptr;
+    tile_load_bits<uint8_t, VEC>(x, B, N, b0, words, lane, w, kTileWaves, stage);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int64_t part = sweep_tile_batched<kTileWaves>(words, rp, ring, col, nnz, N, lane, w);
     const int64_t gain = block_sum_partials<kTileWaves>(part, scratch, lane, w);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    tile_store_bytes<VEC>(x, B, N, b0, words, lane, w, kTileWaves);
+    tile_store_bytes<VEC>(x, B, N, b0, words, lane, w, kTileWaves, true, stage);
     if (w == 0 && b0 + lane < B) obj[b0 + lane] += gain;
 }
 
@@ -302,7 +310,8 @@ __global__ __launch_bounds__(kTileWaves * kWave) void k_node_stats_tile(const ui
     unsigned char* stage = smem + (size_t)(N + 2) * 8 + (size_t)w * kWave * STRIDE;
     const int64_t b0 = (int64_t)blockIdx.x * kWave;
     if (threadIdx.x == 0) words[N] = 0;               // sentinel word: lanes past a row's end read zero
-    tile_load_bits<uint8_t, VEC>(x, B, N, b0, words, lane, w, kTileWaves);
+    static_assert(kWave * STRIDE >= kStageBytes, "the output staging rows double as the tile-load stage");
+    tile_load_bits<uint8_t, VEC>(x, B, N, b0, words, lane, w, kTileWaves, VEC ? stage : nullptr);
     __syncthreads();
     const int sh = lane & 31;
     const uint32_t half4 = (uint32_t)(lane >> 5) * 4u;
@@ -375,7 +384,8 @@ __global__ __launch_bounds__(kTileWaves * kWave) void k_ls_weights(const uint8_t
     unsigned char* stage = smem + (size_t)(N + 2) * 8 + (size_t)w * kWave * STRIDE;
     const int64_t b0 = (int64_t)blockIdx.x * kWave;
     if (threadIdx.x == 0) words[N] = 0;
-    tile_load_bits<uint8_t, VEC>(x, B, N, b0, words, lane, w, kTileWaves);
+    static_assert(kWave * STRIDE >= kStageBytes, "the output staging rows double as the tile-load stage");
+    tile_load_bits<uint8_t, VEC>(x, B, N, b0, words, lane, w, kTileWaves, VEC ? stage : nullptr);
     __syncthreads();
     const int sh = lane & 31;
     const uint32_t half4 = (uint32_t)(lane >> 5) * 4u;
@@ -578,12 +588,13 @@ int rls_maxcut_propose_accept(const rls_graph* g, uint8_t* x, int64_t B, const u
     if (B == 0) return RLS_OK;
     RLS_REQUIRE(x && mask && obj, RLS_EINVAL, "x/mask/obj is NULL");
     const int64_t N = g->num_nodes, E = g->num_stored_edges;
-    const size_t lds = (size_t)N * 16 + (size_t)kTileWaves * kWave * 8;
+    size_t lds = (size_t)N * 16 + (size_t)kTileWaves * kWave * 8;
     RLS_REQUIRE(lds <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS (max %d)", (long long)N, lds,
                 kLdsBytes);
     const int P = pick_planes(E);
     RLS_REQUIRE(P != 0, RLS_EUNSUPPORTED, "E'=%lld too large", (long long)E);
     const bool vec = rows_vec_aligned(x, N, 1) && rows_vec_aligned(mask, N, 1);
+    const int stage_off = tile_stage_offset(&lds, kTileWaves, vec);
     const dim3 grid((unsigned)ceil_div(B, kWave)), block(kTileWaves * kWave);
     hipStream_t s = as_stream(stream);
     const int halve = g->if_bidirectional ? 1 : 0;
@@ -592,7 +603,7 @@ int rls_maxcut_propose_accept(const rls_graph* g, uint8_t* x, int64_t B, const u
         auto kern = k_maxcut_propose_accept<VEC, PP>;                                                      \
         if (lds > 64 * 1024)                                                                               \
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL(kern, grid, block, lds, s, x, mask, B, N, g->eu, g->ev, E, halve, obj);         \
+        hipLaunchKernelGGL(kern, grid, block, lds, s, x, mask, B, N, g->eu, g->ev, E, halve, obj, stage_off); \
     } while (0)
 #define DISPATCH_P(VEC)                      \
     switch (P) {                             \
