@@ -3,6 +3,9 @@
 #include "rls_tile.h"
 
 namespace rls {
+#ifdef RLS_PROF
+static __device__ unsigned long long g_prof[8];   // per translation unit (dev profiling only)
+#endif
 
 // =====================================================================================
 // K1 core: cut value of 64 envs held as a bit tile.

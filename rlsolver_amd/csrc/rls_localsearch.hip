@@ -25,7 +25,7 @@
 
 namespace rls {
 
-constexpr int kLsWaves = 4;
+constexpr int kLsMergeWaves = 4;   // waves that own the top-k merge and the batched sweep; a tile runs on 4 or 8 waves
 constexpr int kTopCap = 16;  // num_spin + 1 <= kTopCap
 
 __device__ __forceinline__ void top_insert(float (&t)[kTopCap], float v) {
@@ -46,22 +46,26 @@ __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
     return h;
 }
 
-// four standard normals (Box-Muller) for nodes 4q..4q+3 in round `it`; env_key = per-env mixed seed
+// four standard normals (Box-Muller) for nodes 4q..4q+3 in round `it`; env_key = per-env mixed seed.
+// Two hashes per quad: each 32-bit hash gives a 16-bit radius uniform and a 16-bit angle (the radius
+// tail ends at sqrt(2 ln 2^16) = 4.7 sigma); hardware log2 / sqrt / sin / cos (v_sin/v_cos take
+// revolutions).  This is the VALU floor of the proposal rounds: 2000 x 64 normals per round and tile.
 __device__ __forceinline__ void normal4(uint32_t env_key, uint32_t q, uint32_t it, float (&z)[4]) {
     const uint32_t k = env_key ^ (q * 0x9E3779B1u) ^ (it * 0x7FEB352Du + 0x165667B1u);
-    const uint32_t r0 = fmix32(k), r1 = fmix32(k + 0x27D4EB2Fu), r2 = fmix32(k + 0x4FA9D65Eu), r3 = fmix32(k + 0x777EC18Du);
-    const float u1 = ((float)(r0 >> 8) + 1.0f) * (1.0f / 16777216.0f);  // (0, 1]
-    const float u2 = (float)(r1 >> 8) * (1.0f / 16777216.0f);
-    const float u3 = ((float)(r2 >> 8) + 1.0f) * (1.0f / 16777216.0f);
-    const float u4 = (float)(r3 >> 8) * (1.0f / 16777216.0f);
-    const float ra = sqrtf(-2.0f * __logf(u1)), rb = sqrtf(-2.0f * __logf(u3));
-    const float ta = 6.28318530718f * u2, tb = 6.28318530718f * u4;
-    z[0] = ra * __cosf(ta); z[1] = ra * __sinf(ta);
-    z[2] = rb * __cosf(tb); z[3] = rb * __sinf(tb);
+    const uint32_t r0 = fmix32(k), r1 = fmix32(k + 0x27D4EB2Fu);
+    const float u1 = ((float)(r0 >> 16) + 1.0f) * (1.0f / 65536.0f);   // (0, 1]
+    const float u3 = ((float)(r1 >> 16) + 1.0f) * (1.0f / 65536.0f);
+    const float t2 = (float)(r0 & 0xFFFFu) * (1.0f / 65536.0f);        // [0, 1) revolutions
+    const float t4 = (float)(r1 & 0xFFFFu) * (1.0f / 65536.0f);
+    // -2 ln u = -2 ln2 * log2 u
+    const float ra = __builtin_amdgcn_sqrtf(-1.3862943611f * __builtin_amdgcn_logf(u1));
+    const float rb = __builtin_amdgcn_sqrtf(-1.3862943611f * __builtin_amdgcn_logf(u3));
+    z[0] = ra * __builtin_amdgcn_cosf(t2); z[1] = ra * __builtin_amdgcn_sinf(t2);
+    z[2] = rb * __builtin_amdgcn_cosf(t4); z[3] = rb * __builtin_amdgcn_sinf(t4);
 }
 
-template <bool VEC, bool V4, int P>
-__global__ __launch_bounds__(kLsWaves * kWave) void k_maxcut_local_search(
+template <bool VEC, bool V4, int P, int W>
+__global__ __launch_bounds__(W * kWave) void k_maxcut_local_search(
     uint8_t* __restrict__ x, int64_t B, int64_t N, const int32_t* __restrict__ eu, const int32_t* __restrict__ ev,
     int64_t E, int halve, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t nnz,
     const int32_t* __restrict__ ws, const float* __restrict__ rd_std, const float* __restrict__ noise, uint64_t seed,
@@ -73,7 +77,7 @@ __global__ __launch_bounds__(kLsWaves * kWave) void k_maxcut_local_search(
     int32_t* rp = reinterpret_cast<int32_t*>(prop + N);
     int32_t* ring = rp + ((N + 1 + 3) & ~3ll);
     int64_t* scratch = reinterpret_cast<int64_t*>(ring + kRing);
-    float* tops = reinterpret_cast<float*>(scratch + kLsWaves * kWave);   // [waves][kTopCap][64]
+    float* tops = reinterpret_cast<float*>(scratch + W * kWave);   // [kLsMergeWaves][kTopCap][64]
     const int lane = threadIdx.x & (kWave - 1);
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     const int64_t b0 = (int64_t)blockIdx.x * kWave;
@@ -85,15 +89,19 @@ __global__ __launch_bounds__(kLsWaves * kWave) void k_maxcut_local_search(
 
     // ---- phase 0
     if (threadIdx.x == 0) words[N] = 0;
-    for (int64_t i = threadIdx.x; i <= N; i += kLsWaves * kWave) rp[i] = rowptr[i];
+    for (int64_t i = threadIdx.x; i <= N; i += W * kWave) rp[i] = rowptr[i];
     // the ring is idle outside the sweep: it doubles as the row-piece stage of the tile load / store
-    static_assert(kRing * 4 >= kLsWaves * kStageBytes, "the ring doubles as the tile stage");
-    unsigned char* stage = VEC ? reinterpret_cast<unsigned char*>(ring) + w * kStageBytes : nullptr;
-    tile_load_bits<uint8_t, VEC>(x, B, N, b0, words, lane, w, kLsWaves, stage);
+    // waves 0..3 stage in the ring, waves 4..7 in the top-k merge buffer (free until the merge, see the barrier there)
+    static_assert(kRing * 4 >= kLsMergeWaves * kStageBytes && kLsMergeWaves * kTopCap * kWave * 4 >= (W - kLsMergeWaves) * kStageBytes,
+                  "ring + merge buffer double as the row-piece stages");
+    unsigned char* wstage = (w < kLsMergeWaves ? reinterpret_cast<unsigned char*>(ring) + w * kStageBytes
+                                               : reinterpret_cast<unsigned char*>(tops) + (w - kLsMergeWaves) * kStageBytes);
+    unsigned char* stage = VEC ? wstage : nullptr;
+    tile_load_bits<uint8_t, VEC>(x, B, N, b0, words, lane, w, W, stage);
     __syncthreads();
     int64_t my_obj;
     if (compute_obj) {
-        my_obj = block_sum_partials<kLsWaves>(tile_cut_count<P>(words, eu, ev, E, lane, w, kLsWaves), scratch, lane, w);
+        my_obj = block_sum_partials<W>(tile_cut_count<P>(words, eu, ev, E, lane, w, W), scratch, lane, w);
         if (halve) my_obj >>= 1;
         __syncthreads();
     } else {
@@ -102,105 +110,184 @@ __global__ __launch_bounds__(kLsWaves * kWave) void k_maxcut_local_search(
 
     const int32_t* ws_row = ws + (valid ? b : 0) * N;
     const int64_t nquads = (N + 3) >> 2;
-    constexpr int G = 4;   // quads per trip: all of a trip's (lane-strided) row loads are issued before use
+    const int64_t nchunks = (nquads + 3) >> 2;   // chunk = 4 consecutive quads = 64 bytes of a ws row
     typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
-    // spin_rand for the G quads q0, q0 + kLsWaves, ...: v[g][k] = (float)ws + noise * rd_std
-    auto spin_rand_trip = [&](int64_t q0, int it, float (&v)[G][4]) {
-        i32x4 wq[G];
-        f32x4 zq[G];
+    constexpr int D = 2;                          // chunks per trip; the next trip's loads fly during this trip's math
+    // ws rows come in through the row-piece stage (rls_tile.h) like the spins: lane l of load i fetches piece
+    // l >> 4 of row 16 i + (l & 15), 64-byte runs on the global side (a lane-per-env read of 16 B touched 64
+    // cache lines per instruction and every trip waited a full memory round trip: 120 us per round).
+    int io_r, io_j;
+    stage_io_lane(lane, io_r, io_j);
+    auto issue = [&](int64_t c0, i32x4 (&g)[D][4], f32x4 (&sd)[D][4]) {
 #pragma unroll
-        for (int gI = 0; gI < G; ++gI) {
-            const int64_t q = q0 + (int64_t)gI * kLsWaves;
-            wq[gI] = i32x4{0, 0, 0, 0};
-            zq[gI] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (q < nquads && valid) {
+        for (int d = 0; d < D; ++d) {
+            const int64_t c = c0 + (int64_t)d * W;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                g[d][i] = i32x4{0, 0, 0, 0};
+                sd[d][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                {   // rd_std of quad 4c + i: wave-uniform address (scalar loads), fetched a trip ahead like ws
+                    const int64_t q = c * 4 + i;
+                    if constexpr (V4) {
+                        if (q < nquads) sd[d][i] = *reinterpret_cast<const f32x4*>(rd_std + q * 4);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            if (q * 4 + k < N) sd[d][i][k] = rd_std[q * 4 + k];
+                    }
+                }
                 if constexpr (V4) {
-                    wq[gI] = *reinterpret_cast<const i32x4*>(ws_row + q * 4);
-                    if (noise) zq[gI] = *reinterpret_cast<const f32x4*>(noise + ((int64_t)it * B + b) * N + q * 4);
-                } else {
+                    const int64_t rw = b0 + kStageRows * i + io_r;
+                    const int64_t q = c * 4 + io_j;
+                    if (c < nchunks && rw < B && q < nquads) g[d][i] = *reinterpret_cast<const i32x4*>(ws + rw * N + q * 4);
+                } else {   // unaligned rows: each lane reads its own env's quad i of the chunk, element-wise
+                    const int64_t q = c * 4 + i;
+                    if (c < nchunks && valid)
 #pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (q * 4 + k < N) {
-                            wq[gI][k] = ws_row[q * 4 + k];
-                            if (noise) zq[gI][k] = noise[((int64_t)it * B + b) * N + q * 4 + k];
-                        }
+                        for (int k = 0; k < 4; ++k)
+                            if (q * 4 + k < N) g[d][i][k] = ws_row[q * 4 + k];
                 }
             }
         }
+    };
+    // corner turn: afterwards wq[i] = this lane's env, quad 4c + i
+    auto turn = [&](const i32x4 (&gd)[4], i32x4 (&wq)[4]) {
+        if constexpr (V4) {
 #pragma unroll
-        for (int gI = 0; gI < G; ++gI) {
-            const int64_t q = q0 + (int64_t)gI * kLsWaves;
-            float z[4] = {zq[gI][0], zq[gI][1], zq[gI][2], zq[gI][3]};
-            if (!noise) normal4(env_key, (uint32_t)q, (uint32_t)it, z);
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<i32x4*>(wstage + (i << 10) + (lane << 4)) = gd[i];
+            asm volatile("" ::: "memory");   // LDS ops of one wave execute in order
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int64_t n = q * 4 + k;
-                const float sd = (n < N) ? rd_std[n] : 0.0f;
-                v[gI][k] = (float)wq[gI][k] + z[k] * sd;   // two roundings (fp-contract off): torch's ws + randn * rd_std
-            }
+            for (int i = 0; i < 4; ++i) wq[i] = *reinterpret_cast<const i32x4*>(wstage + stage_slot_off(lane, i));
+            asm volatile("" ::: "memory");
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wq[i] = gd[i];
         }
     };
-
+    // spin_rand of quad q: v[k] = (float)ws + noise * rd_std
+    auto spin_rand_quad = [&](int64_t q, int it, const i32x4& wq, const f32x4& sdq, float (&v)[4]) {
+        float z[4] = {0.f, 0.f, 0.f, 0.f};
+        if (noise) {
+            if (valid && q < nquads) {
+                if constexpr (V4) {
+                    const f32x4 zz = *reinterpret_cast<const f32x4*>(noise + ((int64_t)it * B + b) * N + q * 4);
+                    z[0] = zz[0]; z[1] = zz[1]; z[2] = zz[2]; z[3] = zz[3];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (q * 4 + k < N) z[k] = noise[((int64_t)it * B + b) * N + q * 4 + k];
+                }
+            }
+        } else {
+            normal4(env_key, (uint32_t)q, (uint32_t)it, z);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            v[k] = (float)wq[k] + z[k] * sdq[k];   // two roundings (fp-contract off): torch's ws + randn * rd_std
+    };
+    // one pass over the tile's ws: f(q, v) for every quad q of this wave's chunks
+    auto for_each_quad = [&](int it, auto&& f) {
+        i32x4 ga[D][4], gb[D][4];
+        f32x4 sa[D][4], sb[D][4];
+        issue(w, ga, sa);
+        for (int64_t c0 = w; c0 < nchunks; c0 += (int64_t)D * W) {
+            issue(c0 + (int64_t)D * W, gb, sb);
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const int64_t c = c0 + (int64_t)d * W;
+                if (c < nchunks) {
+                    i32x4 wq[4];
+                    turn(ga[d], wq);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int64_t q = c * 4 + i;
+                        if (q < nquads) {
+                            float v[4];
+                            spin_rand_quad(q, it, wq[i], sa[d][i], v);
+                            f(q, v);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < D; ++d)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { ga[d][i] = gb[d][i]; sa[d][i] = sb[d][i]; }
+        }
+    };
     // ---- phase 1: threshold = (num_spin + 1)-th largest of the first draw
     float t[kTopCap];
 #pragma unroll
     for (int j = 0; j < kTopCap; ++j) t[j] = -INFINITY;
-    for (int64_t q0 = w; q0 < nquads; q0 += (int64_t)G * kLsWaves) {
-        float v[G][4];
-        spin_rand_trip(q0, 0, v);
+    for_each_quad(0, [&](int64_t q, const float (&v)[4]) {
 #pragma unroll
-        for (int gI = 0; gI < G; ++gI)
+        for (int k = 0; k < 4; ++k)
+            if (q * 4 + k < N) top_insert(t, v[k]);
+    });
+    __syncthreads();   // every wave is done with its stage (waves >= 4 stage inside `tops`)
+    // waves 4.. hand their lists to waves 0..3, four at a time, through the merge buffer
+    for (int base = kLsMergeWaves; base < W; base += kLsMergeWaves) {
+        if (w >= base && w < base + kLsMergeWaves) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                if ((q0 + (int64_t)gI * kLsWaves) * 4 + k < N) top_insert(t, v[gI][k]);
+            for (int j = 0; j < kTopCap; ++j) tops[((w - base) * kTopCap + j) * kWave + lane] = t[j];
+        }
+        __syncthreads();
+        if (w < kLsMergeWaves && base + w < W) {
+#pragma unroll
+            for (int j = 0; j < kTopCap; ++j) top_insert(t, tops[(w * kTopCap + j) * kWave + lane]);
+        }
+        __syncthreads();
     }
+    if (w < kLsMergeWaves) {
 #pragma unroll
-    for (int j = 0; j < kTopCap; ++j) tops[(w * kTopCap + j) * kWave + lane] = t[j];
-    __syncthreads();
-    for (int ow = 0; ow < kLsWaves; ++ow) {
-        if (ow == w) continue;
-#pragma unroll
-        for (int j = 0; j < kTopCap; ++j) top_insert(t, tops[(ow * kTopCap + j) * kWave + lane]);
+        for (int j = 0; j < kTopCap; ++j) tops[(w * kTopCap + j) * kWave + lane] = t[j];
     }
-    float thresh = t[0];
-#pragma unroll
-    for (int j = 1; j < kTopCap; ++j) thresh = (j == num_spin) ? t[j] : thresh;   // kthvalue(k = N - num_spin)
     __syncthreads();
+    float thresh = 0.0f;
+    if (w < kLsMergeWaves) {
+        for (int ow = 0; ow < kLsMergeWaves; ++ow) {
+            if (ow == w) continue;
+#pragma unroll
+            for (int j = 0; j < kTopCap; ++j) top_insert(t, tops[(ow * kTopCap + j) * kWave + lane]);
+        }
+        thresh = t[0];
+#pragma unroll
+        for (int j = 1; j < kTopCap; ++j) thresh = (j == num_spin) ? t[j] : thresh;   // kthvalue(k = N - num_spin)
+    }
+    __syncthreads();
+    if constexpr (W > kLsMergeWaves) {   // the other waves read the threshold of their lane's env
+        if (w == 0) tops[lane] = thresh;
+        __syncthreads();
+        thresh = tops[lane];
+        __syncthreads();
+    }
 
     // ---- phase 2: proposal rounds
     for (int itp = 0; itp < num_iters; ++itp) {
         const int it = first_draw_proposes ? itp : itp + 1;
-        for (int64_t q0 = w; q0 < nquads; q0 += (int64_t)G * kLsWaves) {
-            float v[G][4];
-            spin_rand_trip(q0, it, v);
+        for_each_quad(it, [&](int64_t q, const float (&v)[4]) {
+            uint64_t mine = 0;
 #pragma unroll
-            for (int gI = 0; gI < G; ++gI) {
-                const int64_t q = q0 + (int64_t)gI * kLsWaves;
-                if (q >= nquads) break;
-                uint64_t mine = 0;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const uint64_t mm = ballot64(valid && (q * 4 + k < N) && (v[gI][k] > thresh));   // spin_rand.gt(thresh)
-                    if (lane == k) mine = mm;
-                }
-                if (lane < 4 && q * 4 + lane < N) prop[q * 4 + lane] = words[q * 4 + lane] ^ mine;
+            for (int k = 0; k < 4; ++k) {
+                const uint64_t mm = ballot64(valid && (q * 4 + k < N) && (v[k] > thresh));   // spin_rand.gt(thresh)
+                if (lane == k) mine = mm;
             }
-        }
+            if (lane < 4 && q * 4 + lane < N) prop[q * 4 + lane] = words[q * 4 + lane] ^ mine;
+        });
         __syncthreads();
-        int64_t total = block_sum_partials<kLsWaves>(tile_cut_count<P>(prop, eu, ev, E, lane, w, kLsWaves), scratch, lane, w);
+        int64_t total = block_sum_partials<W>(tile_cut_count<P>(prop, eu, ev, E, lane, w, W), scratch, lane, w);
         if (halve) total >>= 1;
         const bool accept = valid && (total >= my_obj);          // update_xs_by_vs: vs1.ge(vs0)
         if (accept) my_obj = total;
         const uint64_t am = ballot64(accept);
         __syncthreads();
-        for (int64_t n = threadIdx.x; n < N; n += kLsWaves * kWave) words[n] ^= (words[n] ^ prop[n]) & am;
+        for (int64_t n = threadIdx.x; n < N; n += W * kWave) words[n] ^= (words[n] ^ prop[n]) & am;
         __syncthreads();
     }
-
     // ---- phase 3: greedy sweep on the resident tile
-    if (batched) {   // 4 waves over the host-built independent-node batches (rp carries the batch flags)
-        const int64_t part = sweep_tile_batched<kLsWaves>(words, rp, ring, col, nnz, N, lane, w);
-        my_obj += block_sum_partials<kLsWaves>(part, scratch, lane, w);
+    if (batched) {   // 4 waves (the others only keep the barriers) over the host-built independent-node batches (rp carries the batch flags)
+        const int64_t part = sweep_tile_batched<W, kLsMergeWaves>(words, rp, ring, col, nnz, N, lane, w);
+        my_obj += block_sum_partials<W>(part, scratch, lane, w);
         if (w == 0 && valid) obj[b] = my_obj;
     } else if (w == 0) {   // one wave, strictly sequential
         my_obj += sweep_tile(words, rp, ring, col, nnz, N, lane);
@@ -209,12 +296,13 @@ __global__ __launch_bounds__(kLsWaves * kWave) void k_maxcut_local_search(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     // ---- phase 4
-    tile_store_bytes<VEC>(x, B, N, b0, words, lane, w, kLsWaves, true, stage);
+    tile_store_bytes<VEC>(x, B, N, b0, words, lane, w, W, true, stage);
 }
 
 }  // namespace rls
 
 using namespace rls;
+
 
 extern "C" int rls_maxcut_local_search(const rls_graph* g, uint8_t* x, int64_t B, const int32_t* ws,
                                        const float* rd_std, const float* noise, uint64_t seed, int64_t env_offset,
@@ -229,22 +317,27 @@ extern "C" int rls_maxcut_local_search(const rls_graph* g, uint8_t* x, int64_t B
                 "num_spin=%d outside [0, %d] (and < N)", num_spin, kTopCap - 1);
     RLS_REQUIRE(!g->wgt && g->max_degree <= kRingMaxRun, RLS_EUNSUPPORTED,
                 "fused local search needs an unweighted graph with max degree <= %d", kRingMaxRun);
+    // few tiles (<= 2 per CU): 8 waves per tile halve the noise / top-k / mask phases, which are VALU-latency bound
+    // with one wave per SIMD; many tiles: 4 waves per tile and two tiles per CU
+    static const int force_w = getenv("RLS_LS_WAVES") ? atoi(getenv("RLS_LS_WAVES")) : 0;   // dev knob
+    const int W = force_w == 4 || force_w == 8 ? force_w : (ceil_div(B, kWave) <= 2 * (int64_t)num_cus() ? 8 : 4);
     const size_t lds = (size_t)(N + 2) * 8 + (size_t)N * 8 + (size_t)((N + 1 + 3) & ~3ll) * 4 + (size_t)kRing * 4 +
-                       (size_t)kLsWaves * kWave * 8 + (size_t)kLsWaves * kTopCap * kWave * 4;
+                       (size_t)W * kWave * 8 + (size_t)kLsMergeWaves * kTopCap * kWave * 4;
     RLS_REQUIRE(lds <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS (max %d)", (long long)N, lds,
                 kLdsBytes);
     const int P = pick_planes(E);
     RLS_REQUIRE(P != 0, RLS_EUNSUPPORTED, "E'=%lld too large", (long long)E);
     const bool vec = rows_vec_aligned(x, N, 1);
     const bool v4 = (N % 4 == 0) && ((((uintptr_t)ws) | ((uintptr_t)noise)) & 15) == 0;   // 16-byte row slices of ws / noise
-    const dim3 grid((unsigned)ceil_div(B, kWave)), block(kLsWaves * kWave);
+    const dim3 grid((unsigned)ceil_div(B, kWave)), block(W * kWave);
     hipStream_t s = as_stream(stream);
     const int halve = g->if_bidirectional ? 1 : 0;
     const int batched = g->sweep_rowptr != nullptr;
     const int32_t* rp_src = batched ? g->sweep_rowptr : g->rowptr;
 #define LAUNCH_LSF(VEC, PP)                                                                                          \
     do {                                                                                                             \
-        auto kern = v4 ? k_maxcut_local_search<VEC, true, PP> : k_maxcut_local_search<VEC, false, PP>; \
+        auto kern = W == 8 ? (v4 ? k_maxcut_local_search<VEC, true, PP, 8> : k_maxcut_local_search<VEC, false, PP, 8>) \
+                           : (v4 ? k_maxcut_local_search<VEC, true, PP, 4> : k_maxcut_local_search<VEC, false, PP, 4>); \
         if (lds > 64 * 1024)                                                                                         \
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
         hipLaunchKernelGGL(kern, grid, block, lds, s, x, B, N, g->eu, g->ev, E, halve, rp_src, g->col, g->nnz, ws,    \

@@ -72,14 +72,14 @@ __device__ __forceinline__ int64_t sweep_tile(uint64_t* words, const int32_t* rp
 // idempotent; a wave only ever relies on loads it issued itself), so the ring needs no extra sync; the
 // host bounds a batch to <= 16 nodes / <= 768 entries, which keeps all waves inside the ring window.
 // Returns this wave's partial gain for the lane's env (sum the W partials).
-template <int W>
+template <int W, int WA = W>   // WA = waves that take nodes; waves WA..W-1 only keep the barrier schedule
 __device__ __forceinline__ int64_t sweep_tile_batched(uint64_t* words, const int32_t* rpf, int32_t* ring,
                                                       const int32_t* __restrict__ col, int64_t nnz, int64_t N,
                                                       int lane, int w) {
     const unsigned char* wbytes = reinterpret_cast<const unsigned char*>(words);
     constexpr uint32_t M = 0x7fffffffu;
-    int64_t F;
-    ring_prime(col, nnz, F, ring, lane);
+    int64_t F = 0;
+    if (w < WA) ring_prime(col, nnz, F, ring, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int sh = lane & 31;
@@ -92,7 +92,7 @@ __device__ __forceinline__ int64_t sweep_tile_batched(uint64_t* words, const int
         const int64_t cand = bstart + 1 + lane;
         const bool is_end = (cand >= N) || (((uint32_t)rpf[cand]) >> 31);
         const int64_t bend = bstart + 1 + __builtin_ctzll(ballot64(is_end));
-        for (int64_t i = bstart + w; i < bend; i += W) {
+        for (int64_t i = (w < WA ? bstart + w : bend); i < bend; i += WA) {
             const int r0 = (int)((uint32_t)rpf[i] & M), r1 = (int)((uint32_t)rpf[i + 1] & M);
             ring_advance(col, nnz, F, r0, ring, lane);
             const int my_nb = (r0 + lane < r1) ? ring[(r0 + lane) & (kRing - 1)] : sentinel;
