@@ -118,9 +118,10 @@ __device__ __forceinline__ void unpack_bits(uint32_t r, u32x4& lo, u32x4& hi) {
 }
 
 // direct global -> LDS load, 16 B per lane: lane l's bytes land at lds_wave_base + 16 * l
+template <bool NT = false>   // NT: nontemporal (aux = 2) for bytes that are read exactly once
 __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, NT ? 2 : 0);
 }
 
 // ---- row-piece staging (the env-major <-> lane-per-env corner turn).
