@@ -77,7 +77,7 @@ def local_search_suite(tag, n, m, seed, B, iters):
     xs = env.generate_xs_randomly(B)
     vs = env.calculate_obj_values(xs)
     t = timeit(lambda i: env.local_search_inplace(xs, vs, num_iters=8, num_spin=8, noise_std=0.3), iters, warm=1)
-    emit(tag, "local_search_inplace (K2 + 8 x K6 + K5 + torch weights/noise/kthvalue)", "candidate evaluations",
+    emit(tag, "local_search_inplace (ls_weights pre-pass + fused kernel: threshold, 8 proposal rounds, greedy sweep)", "candidate evaluations",
          B * (n + 8), t, None, f"B={B}; the reference performs N+8 full objective evaluations per env per call")
 
 
