@@ -124,9 +124,22 @@ __global__ __launch_bounds__(256) void k_maxcut_step(const T* __restrict__ xin, 
         }
         return;
     } else {
+        // VEC: a full run of EPW rows is a whole number of 16-byte vectors and starts 16-byte aligned (the rows
+        // themselves need not be: N = 1000 bytes works with EPW = 4).  Only the last run of a batch can be
+        // short; its nel % PER trailing elements go element-wise (tail_copy).
         const V* src = reinterpret_cast<const V*>(xin + b0 * N);
         V* dst = reinterpret_cast<V*>(xout + b0 * N);
-        const int64_t nvec = (int64_t)nenv * N / PER;
+        const int64_t nel = (int64_t)nenv * N;
+        const int64_t nvec = nel / PER;
+        auto tail_copy = [&]() {   // register modes: copy + flip the elements past the last full vector
+            for (int64_t i = nvec * PER + lane; i < nel; i += kWave) {
+                T v = xin[b0 * N + i];
+#pragma unroll
+                for (int k = 0; k < EPW; ++k)
+                    if (act[k] >= 0 && i == (int64_t)k * N + act[k]) v = spin_flip<T>(v);
+                xout[b0 * N + i] = v;
+            }
+        };
         int64_t fvec[EPW];
         int fidx[EPW];
 #pragma unroll
@@ -152,6 +165,7 @@ __global__ __launch_bounds__(256) void k_maxcut_step(const T* __restrict__ xin, 
                     if (i == fvec[k]) v = SpinVec<T>::flip_at(v, fidx[k]);
                 st_vec<NTS>(dst + i, v);
             }
+            tail_copy();
         } else if constexpr (MODE == 1) {
             constexpr int BATCH = 8;  // 8 x 16 B per lane = 8 KB per wave in flight
             V buf[BATCH];
@@ -184,6 +198,7 @@ __global__ __launch_bounds__(256) void k_maxcut_step(const T* __restrict__ xin, 
                     }
                 }
             }
+            tail_copy();
         } else {
             // MODE 2: LDS staged.  Per-wave region of EPW*N*sizeof(T) bytes (16-byte multiple).
             T* stage = reinterpret_cast<T*>(smem) + (int64_t)wib * EPW * N;
@@ -192,6 +207,7 @@ __global__ __launch_bounds__(256) void k_maxcut_step(const T* __restrict__ xin, 
                 const int64_t i = base + lane;
                 if (i < nvec) glds16<NTL>(src + i, stage_v + base);  // LDS dst = wave base + lane*16
             }
+            for (int64_t i = nvec * PER + lane; i < nel; i += kWave) stage[i] = xin[b0 * N + i];   // short last run only
             // while the rows fly: CSR row bounds (scalar loads) and this lane's neighbour id / weight
             int r0[EPW], deg[EPW], nb[EPW], wv[EPW];
 #pragma unroll
@@ -206,7 +222,7 @@ __global__ __launch_bounds__(256) void k_maxcut_step(const T* __restrict__ xin, 
                     }
                 }
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int k = 0; k < EPW; ++k)
@@ -237,6 +253,7 @@ __global__ __launch_bounds__(256) void k_maxcut_step(const T* __restrict__ xin, 
             __builtin_amdgcn_wave_barrier();
 #pragma unroll 4
             for (int64_t i = lane; i < nvec; i += kWave) st_vec<NTS>(dst + i, stage_v[i]);
+            for (int64_t i = nvec * PER + lane; i < nel; i += kWave) xout[b0 * N + i] = stage[i];
         }
     }
 }
@@ -265,14 +282,17 @@ extern "C" int rls_maxcut_step(const rls_graph* g, const void* x_in, void* x_out
     RLS_REQUIRE(!emit || (const char*)x_in + (size_t)B * N * spin_bytes <= (const char*)x_out ||
                     (const char*)x_out + (size_t)B * N * spin_bytes <= (const char*)x_in,
                 RLS_EINVAL, "x_in and x_out overlap partially");
-    // flat runs of EPW rows start 16-byte aligned when one row is a multiple of 16 bytes
-    const bool vec = rows_vec_aligned(x_in, N, spin_bytes) && rows_vec_aligned(x_out, N, spin_bytes);
     const char* e_epw = getenv("RLS_STEP_EPW");
     const char* e_wpb = getenv("RLS_STEP_WPB");
-    // envs per wave: the largest of {8,4,2,1} whose staged run fits ~8 KB of LDS per wave (G22: 4)
+    // envs per wave: the largest of {8,4,2,1} whose staged run fits ~8 KB of LDS per wave (G22: 4) ...
     int epw_auto = 8;
     while (epw_auto > 1 && (int64_t)epw_auto * N * spin_bytes > 8192) epw_auto >>= 1;
+    // ... but at least enough rows for a run to be a whole number of 16-byte vectors (N = 1000 bytes: >= 2 rows,
+    // N = 7003 bytes: none of {1..8} works and the element-wise kernel runs)
+    while (epw_auto < 8 && ((int64_t)epw_auto * N * spin_bytes) % 16 != 0) epw_auto <<= 1;
     const int epw = e_epw ? atoi(e_epw) : (emit ? epw_auto : 4);   // in place: nothing is staged
+    // flat runs of EPW rows start 16-byte aligned when one RUN is a multiple of 16 bytes
+    const bool vec = ((((uintptr_t)x_in) | ((uintptr_t)x_out)) & 15) == 0 && ((int64_t)epw * N * spin_bytes) % 16 == 0;
     const int waves_per_block = e_wpb ? atoi(e_wpb) : 4;
     const dim3 grid((unsigned)ceil_div(ceil_div(B, epw), waves_per_block)), block(waves_per_block * kWave);
     hipStream_t s = as_stream(stream);

@@ -152,7 +152,11 @@ def test_step_golden(golden, gname, bidir, mode):
     assert np.array_equal((x > 0).cpu().numpy().astype(np.uint8), z[f"{tag}/xs_final"])
 
 
-@pytest.mark.parametrize("n,m,B", [(2000, 19990, 203), (96, 400, 5), (10000, 49975, 66)])
+@pytest.mark.parametrize("n,m,B", [(2000, 19990, 203), (96, 400, 5), (10000, 49975, 66),
+                                   # rows that are not a multiple of 16 bytes: runs of 8 / 2 / 4 rows are (vector path with
+                                   # an element-wise tail on the short last run); 333 and 7003 are not (element-wise kernel)
+                                   (1000, 5000, 203), (7000, 20000, 67), (100, 384, 13), (3004, 9000, 41), (333, 2000, 70),
+                                   (7003, 9000, 9)])
 def test_step_random_vs_oracle(n, m, B):
     graph = gnm_arr(n, m, seed=3)
     g = device_graph(graph, n, 0)
