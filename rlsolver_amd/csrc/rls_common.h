@@ -58,6 +58,11 @@ inline bool rows_vec_aligned(const void* p, int64_t N, int elt) {
     return (((uintptr_t)p) & 15) == 0 && ((N * elt) & 15) == 0;
 }
 
+// bit-tile kernels (rls_tile.h): base 16-byte aligned, every row 4-byte aligned
+inline bool tile_rows_aligned(const void* p, int64_t N, int elt) {
+    return (((uintptr_t)p) & 15) == 0 && ((N * elt) & 3) == 0 && (elt == 1 || ((N * elt) & 15) == 0);
+}
+
 // compute units of the current device (256 on MI355X); cached per process
 inline int num_cus() {
     static int n = 0;

@@ -327,7 +327,7 @@ extern "C" int rls_maxcut_local_search(const rls_graph* g, uint8_t* x, int64_t B
                 kLdsBytes);
     const int P = pick_planes(E);
     RLS_REQUIRE(P != 0, RLS_EUNSUPPORTED, "E'=%lld too large", (long long)E);
-    const bool vec = rows_vec_aligned(x, N, 1);
+    const bool vec = tile_rows_aligned(x, N, 1);
     const bool v4 = (N % 4 == 0) && ((((uintptr_t)ws) | ((uintptr_t)noise)) & 15) == 0;   // 16-byte row slices of ws / noise
     const dim3 grid((unsigned)ceil_div(B, kWave)), block(W * kWave);
     hipStream_t s = as_stream(stream);

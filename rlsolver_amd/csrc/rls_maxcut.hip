@@ -42,6 +42,7 @@ __global__ __launch_bounds__(kTileWaves * kWave) void k_maxcut_obj(const T* __re
 constexpr int kPipeProd = 8, kPipeCons = 8;
 constexpr int kPipeDepth = 4;                          // producer chunks in flight per wave
 constexpr int kPipeEdgePad = 8 * kWave * kPipeCons;    // edge padding granule
+constexpr int kPipeMinNodes = 1536;                    // shorter rows: the per-tile barrier + reduction outweigh the overlap (N = 1000: 74 vs 34 us)
 constexpr int kPipeMinTilesPerCu = 6;                  // below this the pipeline fill/drain (2 of n+1 steps) costs more than it saves
 
 template <int P>
@@ -524,7 +525,7 @@ int rls_maxcut_obj(const rls_graph* g, const void* x, int spin_bytes, int64_t B,
                 (long long)N, lds, kLdsBytes);
     const int P = pick_planes(E);
     RLS_REQUIRE(P != 0, RLS_EUNSUPPORTED, "E'=%lld too large", (long long)E);
-    const bool vec = rows_vec_aligned(x, N, spin_bytes);
+    const bool vec = tile_rows_aligned(x, N, spin_bytes);
     const int stage_off = tile_stage_offset(&lds, kTileWaves, vec && spin_bytes == 1);
     const dim3 grid((unsigned)ceil_div(B, kWave)), block(kTileWaves * kWave);
     hipStream_t s = as_stream(stream);
@@ -534,7 +535,7 @@ int rls_maxcut_obj(const rls_graph* g, const void* x, int spin_bytes, int64_t B,
         const int64_t Epad = ceil_div(E, (int64_t)kPipeEdgePad) * kPipeEdgePad;
         const size_t lds_p = (size_t)N * 16 + (size_t)2 * kPipeCons * kWave * 8 + (size_t)kPipeProd * kStageBytes +
                              (size_t)Epad * 4;
-        if (!no_pipe && spin_bytes == 1 && vec && N * 8 < 65536 && lds_p <= (size_t)kLdsBytes &&
+        if (!no_pipe && spin_bytes == 1 && vec && N >= kPipeMinNodes && N * 8 < 65536 && lds_p <= (size_t)kLdsBytes &&
             ceil_div(B, kWave) >= (int64_t)kPipeMinTilesPerCu * num_cus()) {
             int64_t gp = num_cus();
             const int64_t ntiles = ceil_div(B, kWave);
@@ -593,7 +594,7 @@ int rls_maxcut_propose_accept(const rls_graph* g, uint8_t* x, int64_t B, const u
                 kLdsBytes);
     const int P = pick_planes(E);
     RLS_REQUIRE(P != 0, RLS_EUNSUPPORTED, "E'=%lld too large", (long long)E);
-    const bool vec = rows_vec_aligned(x, N, 1) && rows_vec_aligned(mask, N, 1);
+    const bool vec = tile_rows_aligned(x, N, 1) && tile_rows_aligned(mask, N, 1);
     const int stage_off = tile_stage_offset(&lds, kTileWaves, vec);
     const dim3 grid((unsigned)ceil_div(B, kWave)), block(kTileWaves * kWave);
     hipStream_t s = as_stream(stream);
@@ -624,7 +625,7 @@ int rls_maxcut_greedy_sweep(const rls_graph* g, uint8_t* x, int64_t B, int64_t* 
     if (B == 0) return RLS_OK;
     RLS_REQUIRE(x && obj, RLS_EINVAL, "x/obj is NULL");
     const int64_t N = g->num_nodes;
-    const bool vec = rows_vec_aligned(x, N, 1);
+    const bool vec = tile_rows_aligned(x, N, 1);
     const dim3 grid((unsigned)ceil_div(B, kWave)), block(kWave);
     hipStream_t s = as_stream(stream);
     const size_t lds_fast = (size_t)(N + 2) * 8 + (size_t)((N + 1 + 3) & ~3ll) * 4 + (size_t)kRing * 4;
@@ -706,7 +707,7 @@ int rls_maxcut_node_cutdeg(const rls_graph* g, const uint8_t* x, int64_t B, int6
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
         hipLaunchKernelGGL(kern, grid, block, lds, s, x, B, N, g->erowptr, g->ev, (const int32_t*)nullptr, cutdeg); \
     } while (0)
-        if (rows_vec_aligned(x, N, 1)) LAUNCH_NS(true); else LAUNCH_NS(false);
+        if (tile_rows_aligned(x, N, 1)) LAUNCH_NS(true); else LAUNCH_NS(false);
 #undef LAUNCH_NS
         return check_launch("k_node_stats_tile<cutdeg>");
     }
@@ -732,7 +733,7 @@ int rls_maxcut_delta_all(const rls_graph* g, const uint8_t* x, int64_t B, int32_
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
         hipLaunchKernelGGL(kern, grid, block, lds, s, x, B, N, g->rowptr, g->col, g->wgt, delta);               \
     } while (0)
-        const bool vec = rows_vec_aligned(x, N, 1);
+        const bool vec = tile_rows_aligned(x, N, 1);
         if (g->wgt) { if (vec) LAUNCH_ND(true, true); else LAUNCH_ND(true, false); }
         else        { if (vec) LAUNCH_ND(false, true); else LAUNCH_ND(false, false); }
 #undef LAUNCH_ND
@@ -766,7 +767,7 @@ int rls_maxcut_ls_weights(const rls_graph* g, const uint8_t* x, int64_t B, int32
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
         hipLaunchKernelGGL(kern, grid, block, lds, s, x, B, N, g->erowptr, g->ev, (int)mult, ws);                 \
     } while (0)
-    if (rows_vec_aligned(x, N, 1)) LAUNCH_LW(true); else LAUNCH_LW(false);
+    if (tile_rows_aligned(x, N, 1)) LAUNCH_LW(true); else LAUNCH_LW(false);
 #undef LAUNCH_LW
     return check_launch("k_ls_weights");
 }

@@ -154,8 +154,114 @@ __device__ __forceinline__ int stage_slot_off(int env, int piece) {   // byte of
     return ((env >> 4) << 10) + (((piece << 4) + (env & 15)) << 4);
 }
 
+// ---- staged tile I/O, generic over the piece size PB = 16, 8 or 4 bytes (rows need only be PB-aligned:
+// N % 16 == 0 -> 16, N % 8 == 0 -> 8 (Gset's 1000 / 3000 / 5000 / 7000-node graphs), N % 4 == 0 -> 4).
+// A chunk = 64 nodes = 64 bytes of every row = PP = 64 / PB pieces per row; instruction i of PP moves the
+// rows RPI*i .. RPI*i + RPI-1 (RPI = 64 / PP): lane l -> row RPI*i + (l % RPI), piece l / RPI, i.e. 64-byte runs
+// on the global side whatever PB.  Stage layout: slot (piece j, row) at byte (64 j + row) * PB, so the read
+// back by lane = row is contiguous across lanes (conflict-free); the writes of PB < 16 see 4- / 16-way
+// bank conflicts, which is noise next to the memory time.
+template <int PB> struct PieceVec;
+template <> struct PieceVec<16> { using type = u32x4; };
+template <> struct PieceVec<8> { typedef uint32_t type __attribute__((ext_vector_type(2))); };
+template <> struct PieceVec<4> { using type = uint32_t; };
+
+template <int PB>
+__device__ __forceinline__ void piece_to_dwords(const typename PieceVec<PB>::type& v, uint32_t* d) {
+    if constexpr (PB == 16) { d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3]; }
+    else if constexpr (PB == 8) { d[0] = v[0]; d[1] = v[1]; }
+    else d[0] = v;
+}
+template <int PB>
+__device__ __forceinline__ typename PieceVec<PB>::type dwords_to_piece(const uint32_t* d) {
+    if constexpr (PB == 16) return u32x4{d[0], d[1], d[2], d[3]};
+    else if constexpr (PB == 8) return typename PieceVec<8>::type{d[0], d[1]};
+    else return d[0];
+}
+
+template <int PB, int DEPTH>
+__device__ __forceinline__ void tile_load_bits_staged(const uint8_t* __restrict__ x, int64_t B, int64_t N, int64_t b0,
+                                                      uint64_t* __restrict__ words, int lane, int w, int W,
+                                                      unsigned char* stage) {
+    using PV = typename PieceVec<PB>::type;
+    constexpr int PP = 64 / PB, RPI = 64 / PP, DW = PB / 4;
+    const int64_t nchunk = (N + 63) >> 6;
+    const BitXpose xc = bit_xpose_consts(lane);
+    const int r = lane % RPI, j = lane / RPI;
+    for (int64_t ch0 = w; ch0 < nchunk; ch0 += (int64_t)W * DEPTH) {
+        PV g[DEPTH][PP];
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const int64_t off = ((ch0 + (int64_t)d * W) << 6) + j * PB;   // byte (= node) offset of this lane's piece
+#pragma unroll
+            for (int i = 0; i < PP; ++i) {
+                const int64_t rw = b0 + RPI * i + r;
+                PV z{};
+                g[d][i] = (rw < B && off < N) ? *reinterpret_cast<const PV*>(x + rw * N + off) : z;
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const int64_t ch = ch0 + (int64_t)d * W;
+            if (ch < nchunk) {
+#pragma unroll
+                for (int i = 0; i < PP; ++i)
+                    *reinterpret_cast<PV*>(stage + (j * 64 + RPI * i + r) * PB) = g[d][i];
+                asm volatile("" ::: "memory");   // LDS ops of one wave execute in order
+                uint32_t dw[16];
+#pragma unroll
+                for (int q = 0; q < PP; ++q) {
+                    const PV v = *reinterpret_cast<const PV*>(stage + (q * 64 + lane) * PB);
+                    piece_to_dwords<PB>(v, dw + q * DW);
+                }
+                asm volatile("" ::: "memory");
+                uint32_t r0 = pack_bits(u32x4{dw[0], dw[1], dw[2], dw[3]}, u32x4{dw[4], dw[5], dw[6], dw[7]});
+                uint32_t r1 = pack_bits(u32x4{dw[8], dw[9], dw[10], dw[11]}, u32x4{dw[12], dw[13], dw[14], dw[15]});
+                bit_transpose64(r0, r1, xc);
+                const int64_t n = (ch << 6) + xc.node;
+                if (n < N) words[n] = ((uint64_t)r1 << 32) | r0;
+            }
+        }
+    }
+}
+
+template <int PB>
+__device__ __forceinline__ void tile_store_bytes_staged(uint8_t* __restrict__ x, int64_t N, int64_t b0,
+                                                        const uint64_t* __restrict__ words, int lane, int w, int W,
+                                                        uint64_t rows_ok, unsigned char* stage) {
+    using PV = typename PieceVec<PB>::type;
+    constexpr int PP = 64 / PB, RPI = 64 / PP, DW = PB / 4;
+    const int64_t nchunk = (N + 63) >> 6;
+    const BitXpose xc = bit_xpose_consts(lane);
+    const int r = lane % RPI, j = lane / RPI;
+    for (int64_t ch = w; ch < nchunk; ch += W) {
+        const int64_t n = (ch << 6) + xc.node;
+        const uint64_t wd = (n < N) ? words[n] : 0ull;
+        uint32_t r0 = (uint32_t)wd, r1 = (uint32_t)(wd >> 32);
+        bit_transpose64(r0, r1, xc);
+        u32x4 v[4];
+        unpack_bits(r0, v[0], v[1]);
+        unpack_bits(r1, v[2], v[3]);
+        const uint32_t dw[16] = {v[0][0], v[0][1], v[0][2], v[0][3], v[1][0], v[1][1], v[1][2], v[1][3],
+                                 v[2][0], v[2][1], v[2][2], v[2][3], v[3][0], v[3][1], v[3][2], v[3][3]};
+#pragma unroll
+        for (int q = 0; q < PP; ++q)
+            *reinterpret_cast<PV*>(stage + (q * 64 + lane) * PB) = dwords_to_piece<PB>(dw + q * DW);
+        asm volatile("" ::: "memory");   // LDS ops of one wave execute in order
+        const int64_t off = (ch << 6) + j * PB;
+#pragma unroll
+        for (int i = 0; i < PP; ++i) {
+            const int rr = RPI * i + r;
+            const PV o = *reinterpret_cast<const PV*>(stage + (j * 64 + rr) * PB);
+            if (((rows_ok >> rr) & 1ull) && off < N) *reinterpret_cast<PV*>(x + (b0 + rr) * N + off) = o;
+        }
+        asm volatile("" ::: "memory");
+    }
+}
+
 // Load the tile of envs [b0, b0+64) x nodes [0, N) into words[0..N).
-// VEC = true requires row starts to be 16-byte aligned (x aligned and N * sizeof(T) % 16 == 0).
+// VEC = true requires x 16-byte aligned and rows 4-byte aligned (tile_rows_aligned); without a stage, byte spins
+// with N % 16 != 0 fall back to the element-wise path.
 // W waves of one workgroup may share the job (wave w of W takes every W-th batch of columns); every
 // wave sees all 64 envs, so each ballot still yields a complete word.  Callers sync afterwards.
 template <typename T, bool VEC, int DEPTH = kStageDepth>
@@ -166,51 +272,14 @@ __device__ __forceinline__ void tile_load_bits(const T* __restrict__ x, int64_t 
     const bool valid = b < B;
     const T* row = x + (valid ? b : 0) * N;
     if constexpr (VEC && sizeof(T) == 1) {
-        if (stage != nullptr) {   // `stage`: this wave's kStageBytes of LDS, 16-byte aligned
-            const int64_t nv = N >> 4;
-            const int64_t nchunk = (N + kStageNodes - 1) / kStageNodes;
-            const BitXpose xc = bit_xpose_consts(lane);
-            int r, j;
-            stage_io_lane(lane, r, j);
-            const u32x4* src[kStagePieces];     // row starts of the 4 rows this lane fetches from
-            bool row_ok[kStagePieces];
-#pragma unroll
-            for (int i = 0; i < kStagePieces; ++i) {
-                const int64_t rw = b0 + kStageRows * i + r;
-                row_ok[i] = rw < B;
-                src[i] = reinterpret_cast<const u32x4*>(x + (row_ok[i] ? rw : 0) * N);
-            }
-            for (int64_t ch0 = w; ch0 < nchunk; ch0 += (int64_t)W * DEPTH) {
-                u32x4 g[DEPTH][kStagePieces];
-#pragma unroll
-                for (int d = 0; d < DEPTH; ++d) {
-                    const int64_t vi = (ch0 + (int64_t)d * W) * kStagePieces + j;
-#pragma unroll
-                    for (int i = 0; i < kStagePieces; ++i)
-                        g[d][i] = (row_ok[i] && vi < nv) ? src[i][vi] : u32x4{0, 0, 0, 0};
-                }
-#pragma unroll
-                for (int d = 0; d < DEPTH; ++d) {
-                    const int64_t ch = ch0 + (int64_t)d * W;
-                    if (ch < nchunk) {
-#pragma unroll
-                        for (int i = 0; i < kStagePieces; ++i)
-                            *reinterpret_cast<u32x4*>(stage + (i << 10) + (lane << 4)) = g[d][i];
-                        asm volatile("" ::: "memory");   // LDS ops of one wave execute in order
-                        u32x4 v[kStagePieces];
-#pragma unroll
-                        for (int q = 0; q < kStagePieces; ++q)
-                            v[q] = *reinterpret_cast<const u32x4*>(stage + stage_slot_off(lane, q));
-                        asm volatile("" ::: "memory");
-                        uint32_t r0 = pack_bits(v[0], v[1]), r1 = pack_bits(v[2], v[3]);
-                        bit_transpose64(r0, r1, xc);
-                        const int64_t n = ch * kStageNodes + xc.node;
-                        if (n < N) words[n] = ((uint64_t)r1 << 32) | r0;
-                    }
-                }
-            }
+        if (stage != nullptr) {   // `stage`: this wave's kStageBytes of LDS, 16-byte aligned; rows 4-byte aligned
+            const uint8_t* xb = reinterpret_cast<const uint8_t*>(x);
+            if ((N & 15) == 0) tile_load_bits_staged<16, DEPTH>(xb, B, N, b0, words, lane, w, W, stage);
+            else if ((N & 7) == 0) tile_load_bits_staged<8, DEPTH>(xb, B, N, b0, words, lane, w, W, stage);
+            else tile_load_bits_staged<4, DEPTH>(xb, B, N, b0, words, lane, w, W, stage);
             return;
         }
+        if ((N & 15) == 0) {
         // 64 nodes per block: every lane packs 64 bytes of its env's row into 64 bits, the wave transposes
         // the 64x64 bit matrix, lane p then holds the word of node n0 + node(p).  Bytes must be 0|1.
         const u32x4* rv = reinterpret_cast<const u32x4*>(row);
@@ -235,7 +304,11 @@ __device__ __forceinline__ void tile_load_bits(const T* __restrict__ x, int64_t 
                 if (n < N) words[n] = ((uint64_t)r1 << 32) | r0;
             }
         }
-    } else if constexpr (VEC && sizeof(T) == 4) {
+            return;
+        }
+        // no stage and rows not 16-byte aligned: the element-wise path below
+    }
+    if constexpr (VEC && sizeof(T) == 4) {
         const f32x4* rv = reinterpret_cast<const f32x4*>(row);
         const int64_t nv = N >> 2;
 #pragma unroll 4
@@ -250,17 +323,17 @@ __device__ __forceinline__ void tile_load_bits(const T* __restrict__ x, int64_t 
             }
             if (lane < 4) words[(i << 2) + lane] = mine;
         }
-    } else {
-        for (int64_t n0 = (int64_t)w * 64; n0 < N; n0 += (int64_t)W * 64) {
-            uint64_t mine = 0;
-            const int lim = (int)((N - n0) < 64 ? (N - n0) : 64);
-            for (int k = 0; k < lim; ++k) {
-                T v = valid ? row[n0 + k] : T(0);
-                uint64_t w = ballot64(spin_is_set(v));
-                if (lane == k) mine = w;
-            }
-            if (lane < lim) words[n0 + lane] = mine;
+        return;
+    }
+    for (int64_t n0 = (int64_t)w * 64; n0 < N; n0 += (int64_t)W * 64) {
+        uint64_t mine = 0;
+        const int lim = (int)((N - n0) < 64 ? (N - n0) : 64);
+        for (int k = 0; k < lim; ++k) {
+            T v = valid ? row[n0 + k] : T(0);
+            uint64_t w = ballot64(spin_is_set(v));
+            if (lane == k) mine = w;
         }
+        if (lane < lim) words[n0 + lane] = mine;
     }
 }
 
@@ -275,43 +348,14 @@ __device__ __forceinline__ void tile_store_bytes(uint8_t* __restrict__ x, int64_
     const int half = lane >> 5, sh = lane & 31;
     const uint32_t* w32 = reinterpret_cast<const uint32_t*>(words);
     if constexpr (VEC) {
-        if (stage != nullptr) {   // through the row-piece stage: 128-byte runs on the global side
-            const int64_t nv = N >> 4;
-            const int64_t nchunk = (N + kStageNodes - 1) / kStageNodes;
-            const BitXpose xc = bit_xpose_consts(lane);
+        if (stage != nullptr) {   // through the row-piece stage: 64-byte runs on the global side
             const uint64_t rows_ok = ballot64(valid);
-            int r, j;
-            stage_io_lane(lane, r, j);
-            u32x4* dst[kStagePieces];
-            bool row_ok[kStagePieces];
-#pragma unroll
-            for (int i = 0; i < kStagePieces; ++i) {
-                const int rr = kStageRows * i + r;
-                row_ok[i] = (rows_ok >> rr) & 1ull;
-                dst[i] = reinterpret_cast<u32x4*>(x + (row_ok[i] ? b0 + rr : 0) * N);
-            }
-            for (int64_t ch = w; ch < nchunk; ch += W) {
-                const int64_t n = ch * kStageNodes + xc.node;
-                const uint64_t wd = (n < N) ? words[n] : 0ull;
-                uint32_t r0 = (uint32_t)wd, r1 = (uint32_t)(wd >> 32);
-                bit_transpose64(r0, r1, xc);
-                u32x4 v[kStagePieces];
-                unpack_bits(r0, v[0], v[1]);
-                unpack_bits(r1, v[2], v[3]);
-#pragma unroll
-                for (int q = 0; q < kStagePieces; ++q)
-                    *reinterpret_cast<u32x4*>(stage + stage_slot_off(lane, q)) = v[q];
-                asm volatile("" ::: "memory");   // LDS ops of one wave execute in order
-                const int64_t vi = ch * kStagePieces + j;
-#pragma unroll
-                for (int i = 0; i < kStagePieces; ++i) {
-                    const u32x4 o = *reinterpret_cast<const u32x4*>(stage + (i << 10) + (lane << 4));
-                    if (row_ok[i] && vi < nv) dst[i][vi] = o;
-                }
-                asm volatile("" ::: "memory");
-            }
+            if ((N & 15) == 0) tile_store_bytes_staged<16>(x, N, b0, words, lane, w, W, rows_ok, stage);
+            else if ((N & 7) == 0) tile_store_bytes_staged<8>(x, N, b0, words, lane, w, W, rows_ok, stage);
+            else tile_store_bytes_staged<4>(x, N, b0, words, lane, w, W, rows_ok, stage);
             return;
         }
+        if ((N & 15) == 0) {
         // inverse of the load: lane p fetches the word of node n0 + node(p), transpose, unpack to bytes
         u32x4* rv = reinterpret_cast<u32x4*>(row);
         const int64_t nv = N >> 4;
@@ -331,10 +375,11 @@ __device__ __forceinline__ void tile_store_bytes(uint8_t* __restrict__ x, int64_
                 if (valid && idx < nv) rv[idx] = v[j];
             }
         }
-    } else {
-        if (!valid) return;
-        for (int64_t n = w; n < N; n += W) row[n] = (uint8_t)((w32[(n << 1) + half] >> sh) & 1u);
+            return;
+        }
     }
+    if (!valid) return;
+    for (int64_t n = w; n < N; n += W) row[n] = (uint8_t)((w32[(n << 1) + half] >> sh) & 1u);
 }
 
 // ---- bit-sliced (vertical) counters: plane p holds bit p of 64 independent counts.

@@ -39,7 +39,8 @@ def test_local_search_inplace_golden_both_paths(golden, gname, bidir, fused):
     assert gv2.data_ptr() == vs2.data_ptr() and torch.equal(gx2, gx) and torch.equal(gv2, gv)
 
 
-@pytest.mark.parametrize("n,m,B,bidir", [(2000, 19990, 130, False), (333, 2000, 70, True), (64, 400, 64, False)])
+@pytest.mark.parametrize("n,m,B,bidir", [(2000, 19990, 130, False), (333, 2000, 70, True), (64, 400, 64, False), (1000, 5000, 65, False),
+                                         (3004, 9000, 64, True)])
 def test_fused_equals_decomposed_random(n, m, B, bidir):
     from rlsolver_amd.envs.env_L2A import EnvMaxcut
     garr = gnm_arr(n, m, seed=n)

@@ -35,7 +35,7 @@ def test_obj_cutdeg_golden(golden, gname, bidir):
             assert np.array_equal(ops.maxcut_edge_cut_mask(g, xs).cpu().numpy().astype(np.uint8), z[f"{t}/edge_mask"])
 
 
-@pytest.mark.parametrize("n,m,B", [(2000, 19990, 200), (800, 4694, 256), (64, 300, 1), (1000, 5000, 65),
+@pytest.mark.parametrize("n,m,B", [(2000, 19990, 200), (800, 4694, 256), (64, 300, 1), (1000, 5000, 65), (3004, 9000, 129),
                                    (333, 2000, 130), (10000, 9999, 70)])
 @pytest.mark.parametrize("bidir", [0, 1])
 def test_obj_random_vs_oracle(n, m, B, bidir):
@@ -200,7 +200,8 @@ def test_greedy_sweep_golden(golden, gname, bidir):
     assert np.array_equal(vs.cpu().numpy(), z[f"{tag}/sweep/vs_out"])
 
 
-@pytest.mark.parametrize("n,m,B", [(800, 4694, 70), (2000, 19990, 64), (128, 1000, 129)])
+@pytest.mark.parametrize("n,m,B", [(800, 4694, 70), (2000, 19990, 64), (128, 1000, 129), (1000, 5000, 70), (3004, 9000, 65),
+                                   (100, 384, 200)])
 def test_greedy_sweep_properties(n, m, B):
     graph = gnm_arr(n, m, seed=11)
     g = device_graph(graph, n, 0)
@@ -224,7 +225,8 @@ def test_greedy_sweep_properties(n, m, B):
     assert torch.equal(ops.maxcut_obj(g, xs), vs)
 
 
-@pytest.mark.parametrize("n,m,B,bidir", [(100, 384, 40, 0), (2000, 19990, 65, 1), (50, 200, 64, 0)])
+@pytest.mark.parametrize("n,m,B,bidir", [(100, 384, 40, 0), (2000, 19990, 65, 1), (50, 200, 64, 0), (1000, 5000, 130, 0),
+                                         (3004, 9000, 67, 1)])
 def test_propose_accept(n, m, B, bidir):
     graph = gnm_arr(n, m, seed=13)
     g = device_graph(graph, n, bidir)

@@ -11,7 +11,7 @@ from tests.gpu_util import DEV, device_graph, gnm_arr, to_dev_bool
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("n,m,B", [(333, 2000, 2100), (2000, 19990, 2048), (64, 300, 4096), (1000, 3000, 2049)])
+@pytest.mark.parametrize("n,m,B", [(333, 2000, 2100), (2000, 19990, 2048), (64, 300, 4096), (1000, 3000, 2049), (100, 384, 2050)])
 @pytest.mark.parametrize("weighted", [False, True])
 @pytest.mark.parametrize("bidir", [0, 1])
 def test_tile_and_element_kernels_agree(n, m, B, weighted, bidir):
