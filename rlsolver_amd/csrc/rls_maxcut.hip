@@ -101,16 +101,15 @@ __global__ __launch_bounds__(kTileWaves * kWave) void k_maxcut_propose_accept(ui
                                                                               int64_t* __restrict__ obj, int stage_off) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* words = reinterpret_cast<uint64_t*>(smem);
-    uint64_t* mwords = words + N;
-    int64_t* scratch = reinterpret_cast<int64_t*>(mwords + N);
+    int64_t* scratch = reinterpret_cast<int64_t*>(words + N);
     const int lane = threadIdx.x & (kWave - 1);
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     const int64_t b0 = (int64_t)blockIdx.x * kWave;
     unsigned char* stage = stage_off >= 0 ? smem + stage_off + w * kStageBytes : nullptr;
+    // proposal = x ^ mask, built in ONE bit tile: the mask pass XORs into the words the x pass wrote (same lane of
+    // the same wave owns a word in both passes); a second tile halved the workgroups per CU for N >= 5000
     tile_load_bits<uint8_t, VEC>(x, B, N, b0, words, lane, w, kTileWaves, stage);
-    tile_load_bits<uint8_t, VEC>(mask, B, N, b0, mwords, lane, w, kTileWaves, stage);
-    __syncthreads();
-    for (int64_t n = threadIdx.x; n < N; n += kTileWaves * kWave) words[n] ^= mwords[n];
+    tile_load_bits<uint8_t, VEC, kStageDepth, true>(mask, B, N, b0, words, lane, w, kTileWaves, stage);
     __syncthreads();
     int64_t total = block_sum_partials<kTileWaves>(tile_cut_count<P>(words, eu, ev, E, lane, w, kTileWaves),
                                                    scratch, lane, w);
@@ -589,7 +588,7 @@ int rls_maxcut_propose_accept(const rls_graph* g, uint8_t* x, int64_t B, const u
     if (B == 0) return RLS_OK;
     RLS_REQUIRE(x && mask && obj, RLS_EINVAL, "x/mask/obj is NULL");
     const int64_t N = g->num_nodes, E = g->num_stored_edges;
-    size_t lds = (size_t)N * 16 + (size_t)kTileWaves * kWave * 8;
+    size_t lds = (size_t)N * 8 + (size_t)kTileWaves * kWave * 8;
     RLS_REQUIRE(lds <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS (max %d)", (long long)N, lds,
                 kLdsBytes);
     const int P = pick_planes(E);

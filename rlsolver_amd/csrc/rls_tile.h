@@ -179,7 +179,14 @@ __device__ __forceinline__ typename PieceVec<PB>::type dwords_to_piece(const uin
     else return d[0];
 }
 
-template <int PB, int DEPTH>
+// XORW: XOR the loaded bits into words[] instead of overwriting (x ^ mask without a second tile; every word is
+// produced by the same lane of the same wave in both passes, so no barrier is needed in between)
+template <bool XORW> __device__ __forceinline__ void put_word(uint64_t* words, int64_t n, uint64_t v) {
+    if constexpr (XORW) words[n] ^= v;
+    else words[n] = v;
+}
+
+template <int PB, int DEPTH, bool XORW>
 __device__ __forceinline__ void tile_load_bits_staged(const uint8_t* __restrict__ x, int64_t B, int64_t N, int64_t b0,
                                                       uint64_t* __restrict__ words, int lane, int w, int W,
                                                       unsigned char* stage) {
@@ -219,7 +226,7 @@ __device__ __forceinline__ void tile_load_bits_staged(const uint8_t* __restrict_
                 uint32_t r1 = pack_bits(u32x4{dw[8], dw[9], dw[10], dw[11]}, u32x4{dw[12], dw[13], dw[14], dw[15]});
                 bit_transpose64(r0, r1, xc);
                 const int64_t n = (ch << 6) + xc.node;
-                if (n < N) words[n] = ((uint64_t)r1 << 32) | r0;
+                if (n < N) put_word<XORW>(words, n, ((uint64_t)r1 << 32) | r0);
             }
         }
     }
@@ -264,7 +271,7 @@ __device__ __forceinline__ void tile_store_bytes_staged(uint8_t* __restrict__ x,
 // with N % 16 != 0 fall back to the element-wise path.
 // W waves of one workgroup may share the job (wave w of W takes every W-th batch of columns); every
 // wave sees all 64 envs, so each ballot still yields a complete word.  Callers sync afterwards.
-template <typename T, bool VEC, int DEPTH = kStageDepth>
+template <typename T, bool VEC, int DEPTH = kStageDepth, bool XORW = false>
 __device__ __forceinline__ void tile_load_bits(const T* __restrict__ x, int64_t B, int64_t N, int64_t b0,
                                                uint64_t* __restrict__ words, int lane, int w = 0, int W = 1,
                                                unsigned char* stage = nullptr) {
@@ -274,9 +281,9 @@ __device__ __forceinline__ void tile_load_bits(const T* __restrict__ x, int64_t 
     if constexpr (VEC && sizeof(T) == 1) {
         if (stage != nullptr) {   // `stage`: this wave's kStageBytes of LDS, 16-byte aligned; rows 4-byte aligned
             const uint8_t* xb = reinterpret_cast<const uint8_t*>(x);
-            if ((N & 15) == 0) tile_load_bits_staged<16, DEPTH>(xb, B, N, b0, words, lane, w, W, stage);
-            else if ((N & 7) == 0) tile_load_bits_staged<8, DEPTH>(xb, B, N, b0, words, lane, w, W, stage);
-            else tile_load_bits_staged<4, DEPTH>(xb, B, N, b0, words, lane, w, W, stage);
+            if ((N & 15) == 0) tile_load_bits_staged<16, DEPTH, XORW>(xb, B, N, b0, words, lane, w, W, stage);
+            else if ((N & 7) == 0) tile_load_bits_staged<8, DEPTH, XORW>(xb, B, N, b0, words, lane, w, W, stage);
+            else tile_load_bits_staged<4, DEPTH, XORW>(xb, B, N, b0, words, lane, w, W, stage);
             return;
         }
         if ((N & 15) == 0) {
@@ -301,7 +308,7 @@ __device__ __forceinline__ void tile_load_bits(const T* __restrict__ x, int64_t 
                 uint32_t r0 = pack_bits(v[q][0], v[q][1]), r1 = pack_bits(v[q][2], v[q][3]);
                 bit_transpose64(r0, r1, xc);
                 const int64_t n = ((blk0 + q) << 6) + xc.node;
-                if (n < N) words[n] = ((uint64_t)r1 << 32) | r0;
+                if (n < N) put_word<XORW>(words, n, ((uint64_t)r1 << 32) | r0);
             }
         }
             return;
@@ -321,7 +328,7 @@ __device__ __forceinline__ void tile_load_bits(const T* __restrict__ x, int64_t 
                 uint64_t w = ballot64(spin_is_set(d[k]));
                 if (lane == k) mine = w;
             }
-            if (lane < 4) words[(i << 2) + lane] = mine;
+            if (lane < 4) put_word<XORW>(words, (i << 2) + lane, mine);
         }
         return;
     }
@@ -333,7 +340,7 @@ __device__ __forceinline__ void tile_load_bits(const T* __restrict__ x, int64_t 
             uint64_t w = ballot64(spin_is_set(v));
             if (lane == k) mine = w;
         }
-        if (lane < lim) words[n0 + lane] = mine;
+        if (lane < lim) put_word<XORW>(words, n0 + lane, mine);
     }
 }
 
