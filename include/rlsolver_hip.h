@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RLS_ABI_VERSION 2
+#define RLS_ABI_VERSION 3
 
 enum {
     RLS_OK = 0,
@@ -58,8 +58,9 @@ typedef struct rls_graph {
     const int32_t* rowptr;    /* [N+1] symmetric CSR */
     const int32_t* col;       /* [nnz] */
     const int32_t* wgt;       /* [nnz] integer edge weights or NULL (= all ones) */
-    const int32_t* sweep_rowptr; /* [N+1] rowptr with bit 31 marking the first node of each independent batch
-                                  * (rls_graph_sweep_batches), or NULL: enables the 4-wave batched sweep */
+    const int32_t* sweep_rowptr; /* [N+1] offsets into sweep_stream per schedule position, bit 31 = first position
+                                  * of a batch (rls_graph_sweep_schedule), or NULL: single-wave sweep */
+    const int32_t* sweep_stream; /* [nnz+N] per schedule position: node id, then its neighbours; or NULL */
 } rls_graph;
 
 int rls_version(void);
@@ -67,13 +68,28 @@ const char* rls_last_error_string(void);
 /* Number of HIP devices visible (0 on a CPU-only host; never an error). */
 int rls_device_count(void);
 
+/* [host] Level schedule of the sequential greedy sweep (envs/env_L2A.py:109-116 visits i = 0..N-1 and every
+ * decision sees the flips of the earlier nodes).  level(i) = 1 + max level of i's lower-numbered neighbours:
+ * nodes of one level are pairwise non-adjacent, all earlier neighbours of a node sit in lower levels and all
+ * later ones in higher levels, so deciding level after level (any order inside a level) gives exactly the
+ * sequential result.  Positions are nodes sorted by (level, id); a level is cut into batches of <= max_nodes
+ * nodes and <= max_entries stream entries (what the kernels' LDS ring can hold).
+ * rowptr/col: HOST symmetric CSR.  Outputs (host): rowptr_flagged [N+1] = offset of each position's run in
+ * `stream`, bit 31 set on the first position of a batch; stream [nnz+N] = node id followed by its neighbours,
+ * position after position.  Upload both and store the device pointers in rls_graph.sweep_rowptr /
+ * sweep_stream. */
+int rls_graph_sweep_schedule(const int32_t* rowptr, const int32_t* col, int64_t N, int32_t max_nodes,
+                             int32_t max_entries, int32_t* rowptr_flagged, int32_t* stream, int64_t* num_batches,
+                             int64_t* num_levels);
+
 /* [host] Cut the node order 0..N-1 into maximal runs of pairwise NON-adjacent consecutive nodes
  * (<= max_nodes nodes and <= max_entries CSR entries each).  The greedy sweep may decide the nodes of
  * a run in parallel with results identical to the sequential pass of envs/env_L2A.py:109-116.
  * rowptr/col: HOST symmetric CSR; rowptr_flagged [host, N+1] = rowptr with bit 31 set on the first
- * node of each run.  Upload it and store the device pointer in rls_graph.sweep_rowptr. */
+ * node of each run.  (Used for visiting orders other than 0..N-1: the MCPG visit stream, methods/MCPG.py.) */
 int rls_graph_sweep_batches(const int32_t* rowptr, const int32_t* col, int64_t N, int32_t max_nodes,
                             int32_t max_entries, int32_t* rowptr_flagged, int64_t* num_batches);
+
 
 /* ------------------------------------------------------------------ MaxCut */
 

@@ -30,6 +30,51 @@ int rls_version(void) { return RLS_ABI_VERSION; }
 
 const char* rls_last_error_string(void) { return rls::g_err; }
 
+int rls_graph_sweep_schedule(const int32_t* rowptr, const int32_t* col, int64_t N, int32_t max_nodes,
+                             int32_t max_entries, int32_t* rowptr_flagged, int32_t* stream, int64_t* num_batches,
+                             int64_t* num_levels) {
+    if (!rowptr || !rowptr_flagged || !stream || N < 0 || max_nodes < 1 || max_nodes > 64 || max_entries < 1 ||
+        (N > 0 && rowptr[N] > 0 && !col))
+        return rls::fail(RLS_EINVAL, "rls_graph_sweep_schedule: bad arguments");
+    if ((int64_t)rowptr[N > 0 ? N : 0] + N >= (int64_t)0x7fffffff)
+        return rls::fail(RLS_EUNSUPPORTED, "rls_graph_sweep_schedule: stream offsets need 31 bits");
+    std::vector<int32_t> level((size_t)(N > 0 ? N : 1), 0);
+    int32_t nlev = 0;
+    for (int64_t i = 0; i < N; ++i) {
+        int32_t l = 0;
+        for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j)
+            if (col[j] < i && level[(size_t)col[j]] + 1 > l) l = level[(size_t)col[j]] + 1;
+        level[(size_t)i] = l;
+        if (l + 1 > nlev) nlev = l + 1;
+    }
+    // counting sort by level (stable: ids ascending inside a level)
+    std::vector<int64_t> start((size_t)nlev + 1, 0);
+    for (int64_t i = 0; i < N; ++i) ++start[(size_t)level[(size_t)i] + 1];
+    for (int32_t l = 0; l < nlev; ++l) start[(size_t)l + 1] += start[(size_t)l];
+    std::vector<int32_t> order((size_t)(N > 0 ? N : 1));
+    {
+        std::vector<int64_t> fill(start.begin(), start.end() - 1);
+        for (int64_t i = 0; i < N; ++i) order[(size_t)fill[(size_t)level[(size_t)i]]++] = (int32_t)i;
+    }
+    int64_t nb = 0, off = 0;
+    int32_t nodes = 0, entries = 0, cur_level = -1;
+    for (int64_t k = 0; k < N; ++k) {
+        const int32_t i = order[(size_t)k];
+        const int32_t len = 1 + rowptr[i + 1] - rowptr[i];
+        const bool first = level[(size_t)i] != cur_level || nodes >= max_nodes || entries + len > max_entries;
+        if (first) { ++nb; nodes = 0; entries = 0; cur_level = level[(size_t)i]; }
+        ++nodes;
+        entries += len;
+        rowptr_flagged[k] = (int32_t)((uint32_t)off | (first ? 0x80000000u : 0u));
+        stream[off++] = i;
+        for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) stream[off++] = col[j];
+    }
+    rowptr_flagged[N] = (int32_t)off;
+    if (num_batches) *num_batches = nb;
+    if (num_levels) *num_levels = nlev;
+    return RLS_OK;
+}
+
 int rls_graph_sweep_batches(const int32_t* rowptr, const int32_t* col, int64_t N, int32_t max_nodes,
                             int32_t max_entries, int32_t* rowptr_flagged, int64_t* num_batches) {
     if (!rowptr || !rowptr_flagged || N < 0 || max_nodes < 1 || max_nodes > 64 || max_entries < 1 ||

@@ -67,7 +67,7 @@ __device__ __forceinline__ void normal4(uint32_t env_key, uint32_t q, uint32_t i
 template <bool VEC, bool V4, int P, int W>
 __global__ __launch_bounds__(W * kWave) void k_maxcut_local_search(
     uint8_t* __restrict__ x, int64_t B, int64_t N, const int32_t* __restrict__ eu, const int32_t* __restrict__ ev,
-    int64_t E, int halve, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t nnz,
+    int64_t E, int halve, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ sweep_src, int64_t sweep_len,
     const int32_t* __restrict__ ws, const float* __restrict__ rd_std, const float* __restrict__ noise, uint64_t seed,
     int64_t env_offset, int num_iters, int num_spin, int first_draw_proposes, int64_t* __restrict__ obj,
     int compute_obj, int batched) {
@@ -285,12 +285,12 @@ __global__ __launch_bounds__(W * kWave) void k_maxcut_local_search(
         __syncthreads();
     }
     // ---- phase 3: greedy sweep on the resident tile
-    if (batched) {   // 4 waves (the others only keep the barriers) over the host-built independent-node batches (rp carries the batch flags)
-        const int64_t part = sweep_tile_batched<W, kLsMergeWaves>(words, rp, ring, col, nnz, N, lane, w);
+    if (batched) {   // all W waves over the host-built independent-node batches (rp carries the batch flags)
+        const int64_t part = sweep_tile_batched<W>(words, rp, ring, sweep_src, sweep_len, N, lane, w);
         my_obj += block_sum_partials<W>(part, scratch, lane, w);
         if (w == 0 && valid) obj[b] = my_obj;
     } else if (w == 0) {   // one wave, strictly sequential
-        my_obj += sweep_tile(words, rp, ring, col, nnz, N, lane);
+        my_obj += sweep_tile(words, rp, ring, sweep_src, sweep_len, N, lane);
         if (valid) obj[b] = my_obj;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -315,8 +315,8 @@ extern "C" int rls_maxcut_local_search(const rls_graph* g, uint8_t* x, int64_t B
     const int64_t N = g->num_nodes, E = g->num_stored_edges;
     RLS_REQUIRE(num_spin >= 0 && num_spin + 1 <= kTopCap && num_spin < N, RLS_EUNSUPPORTED,
                 "num_spin=%d outside [0, %d] (and < N)", num_spin, kTopCap - 1);
-    RLS_REQUIRE(!g->wgt && g->max_degree <= kRingMaxRun, RLS_EUNSUPPORTED,
-                "fused local search needs an unweighted graph with max degree <= %d", kRingMaxRun);
+    RLS_REQUIRE(!g->wgt && g->max_degree < kRingMaxRun, RLS_EUNSUPPORTED,
+                "fused local search needs an unweighted graph with max degree < %d", kRingMaxRun);
     // few tiles (<= 2 per CU): 8 waves per tile halve the noise / top-k / mask phases, which are VALU-latency bound
     // with one wave per SIMD; many tiles: 4 waves per tile and two tiles per CU
     static const int force_w = getenv("RLS_LS_WAVES") ? atoi(getenv("RLS_LS_WAVES")) : 0;   // dev knob
@@ -332,15 +332,17 @@ extern "C" int rls_maxcut_local_search(const rls_graph* g, uint8_t* x, int64_t B
     const dim3 grid((unsigned)ceil_div(B, kWave)), block(W * kWave);
     hipStream_t s = as_stream(stream);
     const int halve = g->if_bidirectional ? 1 : 0;
-    const int batched = g->sweep_rowptr != nullptr;
-    const int32_t* rp_src = batched ? g->sweep_rowptr : g->rowptr;
+    const int batched = g->sweep_rowptr != nullptr && g->sweep_stream != nullptr;
+    const int32_t* rp_src = batched ? g->sweep_rowptr : g->rowptr;            // level schedule, or the CSR as it is
+    const int32_t* sw_src = batched ? g->sweep_stream : g->col;
+    const int64_t sw_len = batched ? g->nnz + N : g->nnz;
 #define LAUNCH_LSF(VEC, PP)                                                                                          \
     do {                                                                                                             \
         auto kern = W == 8 ? (v4 ? k_maxcut_local_search<VEC, true, PP, 8> : k_maxcut_local_search<VEC, false, PP, 8>) \
                            : (v4 ? k_maxcut_local_search<VEC, true, PP, 4> : k_maxcut_local_search<VEC, false, PP, 4>); \
         if (lds > 64 * 1024)                                                                                         \
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
-        hipLaunchKernelGGL(kern, grid, block, lds, s, x, B, N, g->eu, g->ev, E, halve, rp_src, g->col, g->nnz, ws,    \
+        hipLaunchKernelGGL(kern, grid, block, lds, s, x, B, N, g->eu, g->ev, E, halve, rp_src, sw_src, sw_len, ws,    \
                            rd_std, noise, seed, env_offset, (int)num_iters, (int)num_spin, (int)first_draw_proposes,  \
                            obj, (int)compute_obj, batched);                                                          \
     } while (0)

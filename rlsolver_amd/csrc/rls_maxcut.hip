@@ -161,11 +161,16 @@ __global__ __launch_bounds__(kWave) void k_maxcut_greedy_sweep(uint8_t* __restri
     if (b0 + lane < B) obj[b0 + lane] += gain;
 }
 
-// 4-wave variant over the host-built independent-node batches (rls_sweep.h: sweep_tile_batched)
-template <bool VEC>
-__global__ __launch_bounds__(kTileWaves * kWave) void k_maxcut_greedy_sweep_batched(
+// SW-wave variant over the host-built level schedule (rls_sweep.h: sweep_tile_batched).  A node costs one
+// wave ~0.9 us of dependent LDS round trips whatever the schedule, so the tile's time is (N / SW) x that:
+// 16 waves when there is at most one tile per CU, otherwise 8 (G22, B = 2^16: 4 waves 1.40, 8 waves 1.68,
+// 16 waves 1.31 x 10^11 candidate flips/s).
+constexpr int kSweepLoadWaves = 4;   // waves that move the tile (the ring holds 4 row-piece stages)
+
+template <bool VEC, int SW>
+__global__ __launch_bounds__(SW * kWave) void k_maxcut_greedy_sweep_batched(
     uint8_t* __restrict__ x, int64_t B, int64_t N, const int32_t* __restrict__ rowptr_flagged,
-    const int32_t* __restrict__ col, int64_t nnz, int64_t* __restrict__ obj) {
+    const int32_t* __restrict__ stream, int64_t stream_len, int64_t* __restrict__ obj) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* words = reinterpret_cast<uint64_t*>(smem);
     int32_t* rp = reinterpret_cast<int32_t*>(smem + (size_t)(N + 2) * 8);
@@ -175,17 +180,17 @@ __global__ __launch_bounds__(kTileWaves * kWave) void k_maxcut_greedy_sweep_batc
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     const int64_t b0 = (int64_t)blockIdx.x * kWave;
     if (threadIdx.x == 0) words[N] = 0;
-    for (int64_t i = threadIdx.x; i <= N; i += kTileWaves * kWave) rp[i] = rowptr_flagged[i];
-    static_assert(kRing * 4 >= kTileWaves * kStageBytes, "the ring doubles as the tile stage");
-    unsigned char* stage = VEC ? reinterpret_cast<unsigned char*>(ring) + w * kStageBytes : nullptr;
-    tile_load_bits<uint8_t, VEC>(x, B, N, b0, words, lane, w, kTileWaves, stage);
+    for (int64_t i = threadIdx.x; i <= N; i += SW * kWave) rp[i] = rowptr_flagged[i];
+    static_assert(kRing * 4 >= kSweepLoadWaves * kStageBytes, "the ring doubles as the tile stage");
+    unsigned char* stage = VEC ? reinterpret_cast<unsigned char*>(ring) + (w % kSweepLoadWaves) * kStageBytes : nullptr;
+    if (w < kSweepLoadWaves) tile_load_bits<uint8_t, VEC>(x, B, N, b0, words, lane, w, kSweepLoadWaves, stage);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const int64_t part = sweep_tile_batched<kTileWaves>(words, rp, ring, col, nnz, N, lane, w);
-    const int64_t gain = block_sum_partials<kTileWaves>(part, scratch, lane, w);
+    const int64_t part = sweep_tile_batched<SW>(words, rp, ring, stream, stream_len, N, lane, w);
+    const int64_t gain = block_sum_partials<SW>(part, scratch, lane, w);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    tile_store_bytes<VEC>(x, B, N, b0, words, lane, w, kTileWaves, true, stage);
+    if (w < kSweepLoadWaves) tile_store_bytes<VEC>(x, B, N, b0, words, lane, w, kSweepLoadWaves, true, stage);
     if (w == 0 && b0 + lane < B) obj[b0 + lane] += gain;
 }
 
@@ -628,17 +633,21 @@ int rls_maxcut_greedy_sweep(const rls_graph* g, uint8_t* x, int64_t B, int64_t* 
     const dim3 grid((unsigned)ceil_div(B, kWave)), block(kWave);
     hipStream_t s = as_stream(stream);
     const size_t lds_fast = (size_t)(N + 2) * 8 + (size_t)((N + 1 + 3) & ~3ll) * 4 + (size_t)kRing * 4;
-    const bool fast = !g->wgt && g->max_degree <= kSweepMaxDeg && lds_fast <= (size_t)kLdsBytes &&
+    const bool fast = !g->wgt && g->max_degree < kSweepMaxDeg && lds_fast <= (size_t)kLdsBytes &&
                       (((uintptr_t)g->col) & 3) == 0;
-    if (fast && g->sweep_rowptr && getenv("RLS_SWEEP_UNBATCHED") == nullptr) {
-        const size_t lds_b = lds_fast + (size_t)kTileWaves * kWave * 8;
-        const dim3 block4(kTileWaves * kWave);
+    if (fast && g->sweep_rowptr && g->sweep_stream && getenv("RLS_SWEEP_UNBATCHED") == nullptr) {
+        static const int force_sw = getenv("RLS_SWEEP_WAVES") ? atoi(getenv("RLS_SWEEP_WAVES")) : 0;   // dev knob
+        const int sw = force_sw == 4 || force_sw == 8 || force_sw == 16 ? force_sw
+                                                                         : (ceil_div(B, kWave) <= (int64_t)num_cus() ? 16 : 8);
+        const size_t lds_b = lds_fast + (size_t)sw * kWave * 8;
+        const dim3 blockw(sw * kWave);
 #define LAUNCH_SWB(VEC)                                                                                    \
     do {                                                                                                   \
-        auto kern = k_maxcut_greedy_sweep_batched<VEC>;                                                    \
+        auto kern = sw == 16 ? k_maxcut_greedy_sweep_batched<VEC, 16>                                      \
+                             : (sw == 8 ? k_maxcut_greedy_sweep_batched<VEC, 8> : k_maxcut_greedy_sweep_batched<VEC, 4>); \
         if (lds_b > 64 * 1024)                                                                             \
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b); \
-        hipLaunchKernelGGL(kern, grid, block4, lds_b, s, x, B, N, g->sweep_rowptr, g->col, g->nnz, obj);   \
+        hipLaunchKernelGGL(kern, grid, blockw, lds_b, s, x, B, N, g->sweep_rowptr, g->sweep_stream, g->nnz + N, obj); \
     } while (0)
         if (lds_b <= (size_t)kLdsBytes) {
             if (vec) LAUNCH_SWB(true); else LAUNCH_SWB(false);

@@ -43,6 +43,7 @@ def _ptr(t: Optional[TEN]) -> C.c_void_p:
 
 
 _SPIN_DTYPES = (torch.bool, torch.uint8)
+SWEEP_BATCH_NODES, SWEEP_BATCH_ENTRIES = 64, 768   # what one batch may hold (rls_sweep.h: LDS ring window)
 
 
 class DeviceGraph:
@@ -61,15 +62,19 @@ class DeviceGraph:
         self.erowptr = i32(erp)
         self.rowptr, self.col = i32(csr.rowptr), i32(csr.col)
         self.wgt = i32(csr.wgt) if use_weights else None
-        # independent-node batches for the 4-wave greedy sweep (host pass over the CSR in the C library)
+        # level schedule of the greedy sweep (host pass over the CSR in the C library): nodes sorted by dependency
+        # level, each followed by its neighbours, as one int32 stream for the kernels' LDS ring
         rp_h = np.ascontiguousarray(csr.rowptr, dtype=np.int32)
         col_h = np.ascontiguousarray(csr.col, dtype=np.int32)
         flagged = np.empty(csr.num_nodes + 1, dtype=np.int32)
-        nb = C.c_int64(0)
-        _abi.call("rls_graph_sweep_batches", rp_h.ctypes.data_as(C.c_void_p), col_h.ctypes.data_as(C.c_void_p),
-                  csr.num_nodes, 16, 768, flagged.ctypes.data_as(C.c_void_p), C.byref(nb))
-        self.num_sweep_batches = int(nb.value)
+        stream = np.empty(csr.nnz + csr.num_nodes, dtype=np.int32)
+        nb, nl = C.c_int64(0), C.c_int64(0)
+        _abi.call("rls_graph_sweep_schedule", rp_h.ctypes.data_as(C.c_void_p), col_h.ctypes.data_as(C.c_void_p),
+                  csr.num_nodes, SWEEP_BATCH_NODES, SWEEP_BATCH_ENTRIES, flagged.ctypes.data_as(C.c_void_p),
+                  stream.ctypes.data_as(C.c_void_p), C.byref(nb), C.byref(nl))
+        self.num_sweep_batches, self.num_sweep_levels = int(nb.value), int(nl.value)
         self.sweep_rowptr = torch.from_numpy(flagged).to(self.device)
+        self.sweep_stream = torch.from_numpy(stream).to(self.device)
         self.num_nodes, self.num_stored_edges, self.nnz = csr.num_nodes, csr.num_stored_edges, csr.nnz
         self.if_bidirectional = csr.if_bidirectional
         self.struct = _abi.RlsGraph(
@@ -77,7 +82,8 @@ class DeviceGraph:
             if_bidirectional=int(csr.if_bidirectional), max_degree=csr.max_degree,
             eu=self.eu.data_ptr(), ev=self.ev.data_ptr(), erowptr=self.erowptr.data_ptr(),
             rowptr=self.rowptr.data_ptr(), col=self.col.data_ptr(),
-            wgt=0 if self.wgt is None else self.wgt.data_ptr(), sweep_rowptr=self.sweep_rowptr.data_ptr())
+            wgt=0 if self.wgt is None else self.wgt.data_ptr(), sweep_rowptr=self.sweep_rowptr.data_ptr(),
+            sweep_stream=self.sweep_stream.data_ptr())
         self.ref = C.byref(self.struct)
 
 

@@ -82,3 +82,38 @@ def test_tsp_tables_small():
     assert d.dtype == np.float32 and d[0, 1] == 5 and d[0, 2] == 10 and d[1, 1] == 0
     assert near.tolist()[0] == [3, 1] and rnd.tolist()[2] == [0, 1, 3]
     assert G.generate_tsp_coords(100, 100).shape == (100, 2)
+
+
+def test_sweep_level_schedule_is_a_valid_reordering_of_the_sequential_pass():
+    """rls_graph_sweep_schedule (host, in the C library): positions are a permutation; nodes of one batch are
+    pairwise non-adjacent; for every edge the lower-numbered endpoint sits in an earlier batch -- together
+    these make the batched sweep equal to the sequential one (envs/env_L2A.py:109-116)."""
+    import ctypes as C
+    from rlsolver_amd import _abi
+    from rlsolver_amd.graph import build_csr, generate_gnm, generate_ba
+    for g, n in ((generate_gnm(300, 1500, seed=3), 300), (generate_ba(200, 4, seed=1), 200), ([(0, 1, 1)], 5),
+                 (generate_gnm(2000, 19990, seed=22), 2000)):
+        csr = build_csr(g, num_nodes=n, if_bidirectional=False)
+        rp = np.ascontiguousarray(csr.rowptr, dtype=np.int32)
+        col = np.ascontiguousarray(csr.col, dtype=np.int32)
+        flagged = np.empty(n + 1, dtype=np.int32)
+        stream = np.empty(csr.nnz + n, dtype=np.int32)
+        nb, nl = C.c_int64(0), C.c_int64(0)
+        _abi.call("rls_graph_sweep_schedule", rp.ctypes.data_as(C.c_void_p), col.ctypes.data_as(C.c_void_p), n, 64, 768,
+                  flagged.ctypes.data_as(C.c_void_p), stream.ctypes.data_as(C.c_void_p), C.byref(nb), C.byref(nl))
+        off = flagged.view(np.uint32) & 0x7FFFFFFF
+        first = (flagged.view(np.uint32)[:n] >> 31).astype(bool)
+        assert first[0] and off[n] == csr.nnz + n and first.sum() == nb.value and 1 <= nl.value <= nb.value
+        nodes = stream[off[:n]]
+        assert sorted(nodes.tolist()) == list(range(n))
+        batch_of = np.empty(n, np.int64)
+        batch_of[nodes] = np.cumsum(first) - 1
+        for k in range(n):   # the stream carries each node's CSR row
+            i = nodes[k]
+            assert off[k + 1] - off[k] == 1 + rp[i + 1] - rp[i]
+            assert np.array_equal(stream[off[k] + 1: off[k + 1]], col[rp[i]: rp[i + 1]])
+            nbrs = col[rp[i]: rp[i + 1]]
+            assert (batch_of[nbrs[nbrs < i]] < batch_of[i]).all() and (batch_of[nbrs[nbrs > i]] > batch_of[i]).all()
+        sizes = np.bincount(batch_of)
+        ents = np.add.reduceat(np.diff(off.astype(np.int64)), np.flatnonzero(first))
+        assert sizes.max() <= 64 and ents.max() <= 768
