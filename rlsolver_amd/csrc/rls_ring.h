@@ -29,12 +29,19 @@ __device__ __forceinline__ void ring_refill(const int32_t* __restrict__ stream, 
 // Keep the ring at least half full ahead of `cursor` (wave-uniform call).  Entries the consumer is
 // about to read (cursor .. cursor + kRingMaxRun) always belong to a refill older than the newest one,
 // and every older refill has been waited for before the newest is issued.
+// A wave that sat out earlier batches (fewer nodes than waves) may find the cursor far ahead of its own F:
+// it skips what nobody will read and refills until the window is restored (the wait in front of every
+// refill but the first covers the run at `cursor`, which lies in the first one or two of them).
 __device__ __forceinline__ void ring_advance(const int32_t* __restrict__ stream, int64_t len, int64_t& F,
                                              int64_t cursor, int32_t* ring, int lane) {
     if (F < len && F - cursor < kRing / 2) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        ring_refill(stream, len, F, ring, lane);
-        F += kRefill;
+        if (F < cursor) F = cursor & ~(int64_t)(kRefill - 1);
+        do {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ring_refill(stream, len, F, ring, lane);
+            F += kRefill;
+        } while (F < len && F - cursor < kRing / 2);
+        if (F - kRefill <= cursor + kRingMaxRun) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // end of stream
     }
 }
 

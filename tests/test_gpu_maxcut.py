@@ -225,6 +225,44 @@ def test_greedy_sweep_properties(n, m, B):
     assert torch.equal(ops.maxcut_obj(g, xs), vs)
 
 
+def _chain_fan_graph(chain=500, fan=1000, seed=0):
+    """A path 0..chain-1 (one node per dependency level) whose last 8 nodes fan out to `fan` later nodes, plus
+    random edges among those: hundreds of one-node batches followed by batches of 64 -- waves that sat idle
+    through the chain must re-synchronise their view of the LDS ring (rls_ring.h: ring_advance)."""
+    rng = np.random.RandomState(seed)
+    e = [(i, i + 1) for i in range(chain - 1)]
+    e += [(chain - 1 - (k % 8), chain + k) for k in range(fan)]
+    extra = rng.randint(chain, chain + fan, size=(3 * fan, 2))
+    e += [(min(a, b), max(a, b)) for a, b in extra.tolist() if a != b]
+    e = sorted(set(e))
+    return np.array([(a, b, 1) for a, b in e], dtype=np.int64), chain + fan
+
+
+@pytest.mark.parametrize("case", ["chain_fan", "g22", "fan_first"])
+def test_greedy_sweep_level_schedule_vs_sequential_oracle(case):
+    """The level-scheduled multi-wave sweep against the C oracle's strictly sequential flip / re-evaluate /
+    keep-if-not-worse loop (env_L2A.py:109-116) at sizes the numpy oracle cannot reach."""
+    from oracle import oracle_c as oc
+    if case == "chain_fan":
+        graph, n = _chain_fan_graph()
+    elif case == "fan_first":       # the same shape relabelled so that the wide levels come first
+        graph, n = _chain_fan_graph(chain=300, fan=1200, seed=1)
+        relabel = np.concatenate([np.arange(n - 300, n), np.arange(0, n - 300)])   # old id -> new id
+        graph = np.stack([relabel[graph[:, 0]], relabel[graph[:, 1]], graph[:, 2]], axis=1)
+    else:
+        n = 2000
+        graph = gnm_arr(2000, 19990, seed=22)
+    B = 70
+    g = device_graph(graph, n, 0)
+    xs0 = np.random.RandomState(9).randint(0, 2, size=(B, n)).astype(np.uint8)
+    xs = to_dev_bool(xs0).clone()
+    vs = ops.maxcut_obj(g, xs)
+    want_x, want_v = oc.greedy_sweep(xs0.copy(), vs.cpu().numpy().copy(), graph[:, 0], graph[:, 1], False)
+    ops.maxcut_greedy_sweep(g, xs, vs)
+    assert np.array_equal(vs.cpu().numpy(), want_v)
+    assert np.array_equal(xs.cpu().numpy().astype(np.uint8), want_x)
+
+
 @pytest.mark.parametrize("n,m,B,bidir", [(100, 384, 40, 0), (2000, 19990, 65, 1), (50, 200, 64, 0), (1000, 5000, 130, 0),
                                          (3004, 9000, 67, 1)])
 def test_propose_accept(n, m, B, bidir):
