@@ -249,14 +249,16 @@ int rls_mcpg_metro_rounds(void* samples, int spin_bytes, int64_t N, int64_t C, c
  * with u = uniforms[pass, pos, c] (f32 [num_ls,N,C], the torch.rand draws in visiting order; NULL =
  * in-kernel Philox).  Then expected[c] = sum_e (2x_u - 1)(2x_v - 1) over the stored edge list
  * (= E - 2*cut, exact in f32).  Outputs xs_out f32 [N,C] (0|1) and expected f32 [C].
- * visit_stream (optional, int32) is the visiting order flattened by the caller and cut into batches of
- * consecutive, pairwise non-adjacent nodes (<= 16 nodes and <= 400 entries per batch):
- *     per batch: m, next_batch_offset, first_visit_position, off_0 .. off_{m-1}
- *     per node (at stream offset off_k): node, deg, nfresh, then deg entries  nb | (fresh << 31)
+ * visit_stream (optional, int32) is the visiting order flattened by the caller: visiting positions level-
+ * scheduled (a position's level = 1 + max level of its earlier-visited neighbours; sorted by (level, position))
+ * and cut into batches of pairwise non-adjacent nodes (<= 32 nodes and <= 400 entries per batch) whose
+ * earlier-visited neighbours all sit in earlier batches:
+ *     per batch: m, next_batch_offset, 0, off_0 .. off_{m-1}
+ *     per node (at stream offset off_k): node, deg, nfresh, visiting position, then deg entries  nb | (fresh << 31)
  * where fresh marks a neighbour visited LATER than node (it still holds -0.5|1.5 in pass 0) and
  * nfresh counts them (rlsolver_amd.methods.MCPG.build_visit_stream builds it).  With it the kernel
- * streams the graph through an LDS ring, 4 waves share each batch, and nothing waits on global memory
- * per node; NULL selects the generic kernel (one CSR row fetch per node). */
+ * streams the graph through an LDS ring, the waves of a workgroup share each batch, and nothing waits on
+ * global memory per node; NULL selects the generic kernel (one CSR row fetch per node). */
 int rls_mcpg_local_search(const rls_graph* g, const void* xs_in, int spin_bytes, float* xs_out, int64_t C,
                           const int32_t* order, const int32_t* visit_stream, int64_t visit_len, int64_t num_ls,
                           const float* uniforms, uint64_t seed, float* expected, void* stream);

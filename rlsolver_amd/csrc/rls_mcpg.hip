@@ -190,19 +190,20 @@ __global__ __launch_bounds__(kWave) void k_mcpg_local_search(const TI* __restric
     }
 }
 
-// K7 fast path.  The host flattens the visiting order into ONE int32 "visit stream", cut into batches
-// of consecutive, pairwise NON-adjacent nodes (<= 16 nodes, <= 400 entries; nodes of a batch cannot see
-// each other's updates, so they may be decided in any order with identical results):
-//     per batch:  m, next_batch_offset, first_visit_position, off_0 .. off_{m-1}
-//     per node (at stream offset off_k):  node, deg, nfresh, then deg entries  nb | (fresh << 31)
+// K7 fast path.  The host flattens the visiting order into ONE int32 "visit stream": visiting positions
+// level-scheduled (methods/MCPG.py: build_visit_stream; same argument as rls_sweep.h) and cut into batches of
+// pairwise NON-adjacent nodes (<= 32 nodes, <= 400 entries) whose earlier-visited neighbours all sit in earlier
+// batches, so a batch may be decided in any order with results identical to the sequential pass:
+//     per batch:  m, next_batch_offset, 0, off_0 .. off_{m-1}
+//     per node (at stream offset off_k):  node, deg, nfresh, visiting position, then deg entries  nb | (fresh << 31)
 // (fresh = nb is visited later than node in pass 0, i.e. still holds -0.5|1.5 there; nfresh = their
-// count).  The stream is consumed in order through an LDS ring (rls_ring.h).  The 4 waves of the
+// count).  The stream is consumed in order through an LDS ring (rls_ring.h).  The waves of the
 // workgroup take the nodes of a batch round-robin, one barrier per batch; per node: ONE lane-parallel
-// ring read (header in lanes 0-2, first 61 entries behind it), v_readlane + broadcast word read +
+// ring read (header in lanes 0-3, first 60 entries behind it), v_readlane + broadcast word read +
 // v_bfe + v_mad per neighbour, one ballot.  No global-memory latency per node (the generic kernel pays
 // 2-3 dependent L2 round trips per node).  Production noise: one counter-based hash per (chain, pass,
-// position); test mode reads the reference's torch.rand draws.
-constexpr int kK7Waves = 4;
+// visiting position); test mode reads the reference's torch.rand draws.
+constexpr int kK7Waves = 16;   // one workgroup per CU (80 KB bit tile at N = 10^4): 4 waves 27.5, 8 waves 20.1, 16 waves 18.1 ms
 
 __device__ __forceinline__ uint32_t k7_fmix32(uint32_t h) {
     h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
@@ -237,37 +238,36 @@ __global__ __launch_bounds__(kK7Waves * kWave) void k_mcpg_local_search_stream(
         int64_t F;
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();
-        ring_prime(vstream, vlen, F, ring, lane);
+        F = 0;
+        if (w == 0) ring_prime(vstream, vlen, F, ring, lane);   // wave 0 alone feeds the ring (rls_sweep.h)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         int64_t cur = 0;
         while (cur < vlen) {
-            ring_advance(vstream, vlen, F, cur, ring, lane);
             const uint32_t hb = (uint32_t)ring[(cur + lane) & (kRing - 1)];
             const int m = __builtin_amdgcn_readlane((int)hb, 0);
             const int64_t nxt = (uint32_t)__builtin_amdgcn_readlane((int)hb, 1);
-            const int64_t pos0 = (uint32_t)__builtin_amdgcn_readlane((int)hb, 2);
             for (int k = w; k < m; k += kK7Waves) {
                 const int64_t off = (uint32_t)__builtin_amdgcn_readlane((int)hb, 3 + k);
                 const uint32_t blk = (uint32_t)ring[(off + lane) & (kRing - 1)];
                 const int node = __builtin_amdgcn_readlane((int)blk, 0);
                 const int deg = __builtin_amdgcn_readlane((int)blk, 1);
                 const int nfresh = (cnt == 0) ? __builtin_amdgcn_readlane((int)blk, 2) : 0;
-                const int64_t row = off + 3;
-                const int64_t pos = pos0 + k;
+                const int64_t pos = (uint32_t)__builtin_amdgcn_readlane((int)blk, 3);   // visiting position: RNG key / draw index
+                const int64_t row = off + 4;
                 float uu;
                 if (uniforms) uu = valid ? uniforms[(cnt * N + pos) * C + c] : 0.0f;
                 else uu = u32_to_unit_float(k7_fmix32(chain_key ^ ((uint32_t)pos * 0x9E3779B1u) ^
                                                       ((uint32_t)cnt * 0x7FEB352Du + 0x165667B1u)));
                 int acc = 0;  // sum over neighbours of mult * bit, mult = 4 for fresh (pass 0), else 2
-                // entries 0..60 of the row sit in lanes 3..63 of blk; lanes past the row end read the sentinel
-                const uint32_t mine = (lane >= 3 && lane - 3 < deg) ? blk : sentinel;
-                const int first = deg < (kWave - 3) ? deg : (kWave - 3);
+                // entries 0..59 of the row sit in lanes 4..63 of blk; lanes past the row end read the sentinel
+                const uint32_t mine = (lane >= 4 && lane - 4 < deg) ? blk : sentinel;
+                const int first = deg < (kWave - 4) ? deg : (kWave - 4);
                 for (int j = 0; j < first; j += 8) {
                     uint32_t wv[8], mult[8];
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
-                        const int src = (j + q + 3) < kWave ? (j + q + 3) : (kWave - 1);
+                        const int src = (j + q + 4) < kWave ? (j + q + 4) : (kWave - 1);
                         uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)mine, src);
                         if (j + q >= first) e = sentinel;
                         mult[q] = (cnt == 0 && (e >> 31)) ? 4u : 2u;
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(kK7Waves * kWave) void k_mcpg_local_search_stream(
 #pragma unroll
                     for (int q = 0; q < 8; ++q) acc += (int)(((wv[q] >> sh) & 1u) * mult[q]);
                 }
-                for (int j = kWave - 3; j < deg; ++j) {      // hubs: the rest of the row straight from the ring
+                for (int j = kWave - 4; j < deg; ++j) {      // hubs: the rest of the row straight from the ring
                     const uint32_t e = (uint32_t)ring[(row + j) & (kRing - 1)];
                     const uint32_t mult = (cnt == 0 && (e >> 31)) ? 4u : 2u;
                     acc += (int)(((*reinterpret_cast<const uint32_t*>(wbytes + ((e & 0x7fffffffu) * 8u + half4)) >> sh) & 1u) * mult);
@@ -287,6 +287,7 @@ __global__ __launch_bounds__(kK7Waves * kWave) void k_mcpg_local_search_stream(
                 const uint64_t nw = ballot64(rv < thr);
                 if (lane == 0) words[node] = nw;
             }
+            if (w == 0) ring_advance(vstream, vlen, F, nxt, ring, lane);
             __syncthreads();   // the batch's updates are visible before any wave reads the next batch's neighbours
             cur = nxt;
         }
@@ -372,7 +373,7 @@ int rls_mcpg_local_search(const rls_graph* g, const void* xs_in, int spin_bytes,
     const dim3 grid((unsigned)ceil_div(C, kWave)), block(kWave);
     hipStream_t s = as_stream(stream);
     const size_t lds_fast = (size_t)(N + 2) * 8 + (size_t)kRing * 4 + (size_t)kK7Waves * kWave * 8;
-    const bool fast = visit_stream != nullptr && g->max_degree + 3 <= kRingMaxRun && lds_fast <= (size_t)kLdsBytes &&
+    const bool fast = visit_stream != nullptr && g->max_degree + 4 <= kRingMaxRun && lds_fast <= (size_t)kLdsBytes &&
                       (((uintptr_t)visit_stream) & 3) == 0;
     if (fast) {
         RLS_REQUIRE(visit_len > g->nnz + 4 * N && visit_len <= g->nnz + 7 * N, RLS_EINVAL,

@@ -72,9 +72,7 @@ __device__ __forceinline__ int64_t sweep_tile(uint64_t* words, const int32_t* rp
 // cuts levels into batches the LDS ring can hold and writes one int32 stream: for every schedule position
 // the node id followed by its neighbours.  rpf[k] = offset of position k in the stream, bit 31 = first
 // position of a batch.  The WA working waves of the workgroup take the positions of a batch round-robin, one
-// workgroup barrier per batch.  Every wave runs the same ring protocol on the SAME LDS ring (the loads are
-// idempotent; a wave only ever relies on loads it issued itself), so the ring needs no extra sync; a batch of
-// <= 768 entries keeps all waves inside the ring window.
+// workgroup barrier per batch; a batch of <= 768 entries stays inside the ring window wave 0 maintains.
 // Returns this wave's partial gain for the lane's env (sum the W partials).
 template <int W, int WA = W>   // WA = waves that take nodes; waves WA..W-1 only keep the barrier schedule
 __device__ __forceinline__ int64_t sweep_tile_batched(uint64_t* words, const int32_t* rpf, int32_t* ring,
@@ -82,8 +80,11 @@ __device__ __forceinline__ int64_t sweep_tile_batched(uint64_t* words, const int
                                                       int lane, int w) {
     const unsigned char* wbytes = reinterpret_cast<const unsigned char*>(words);
     constexpr uint32_t M = 0x7fffffffu;
+    // wave 0 alone feeds the ring: it requests ahead of the NEXT batch before the barrier that ends the current
+    // one, so what a batch reads (<= 768 entries from its first) was complete before that barrier
+    // (ring_advance waits for every refill but the newest, and the newest starts >= 1024 entries ahead).
     int64_t F = 0;
-    if (w < WA) ring_prime(stream, len, F, ring, lane);
+    if (w == 0) ring_prime(stream, len, F, ring, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const int sh = lane & 31;
@@ -98,7 +99,6 @@ __device__ __forceinline__ int64_t sweep_tile_batched(uint64_t* words, const int
         const int64_t bend = bstart + 1 + __builtin_ctzll(ballot64(is_end));
         for (int64_t p = (w < WA ? bstart + w : bend); p < bend; p += WA) {
             const int r0 = (int)((uint32_t)rpf[p] & M), r1 = (int)((uint32_t)rpf[p + 1] & M);
-            ring_advance(stream, len, F, r0, ring, lane);
             const uint32_t i = (uint32_t)ring[r0 & (kRing - 1)];              // node at this position (broadcast read)
             const int deg = r1 - r0 - 1;
             const int my_nb = (lane < deg) ? ring[(r0 + 1 + lane) & (kRing - 1)] : sentinel;
@@ -125,7 +125,8 @@ __device__ __forceinline__ int64_t sweep_tile_batched(uint64_t* words, const int
             const uint64_t fm = ballot64(flip);
             if (lane == 0) words[i] ^= fm;
         }
-        __syncthreads();   // the batch's flips are visible to every wave before the next batch reads them
+        if (w == 0) ring_advance(stream, len, F, (int64_t)((uint32_t)rpf[bend] & M), ring, lane);
+        __syncthreads();   // the batch's flips (and the next batch's ring entries) are visible to every wave
         bstart = bend;
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");

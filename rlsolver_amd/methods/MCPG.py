@@ -54,11 +54,14 @@ def make_data(num_nodes: int, eu, ev, device, sorted_degree_nodes=None):
     return data
 
 
-def build_visit_stream(csr, order: np.ndarray, max_nodes: int = 16, max_entries: int = 400) -> np.ndarray:
-    """Flatten the visiting order for the streaming K7 kernel (format: include/rlsolver_hip.h).
+def build_visit_stream(csr, order: np.ndarray, max_nodes: int = 32, max_entries: int = 400) -> np.ndarray:
+    """Flatten the visiting order for the streaming K7 kernel (format: rls_mcpg.hip / include/rlsolver_hip.h).
 
-    Batches = maximal runs of consecutive (in visiting order), pairwise non-adjacent nodes, found by the
-    library's host pass (rls_graph_sweep_batches) on the graph relabelled by visiting position."""
+    The sequential pass (MCPG.py:136-142) only orders ADJACENT nodes, so the visiting positions are
+    level-scheduled by the library's host pass (rls_graph_sweep_schedule, on the graph relabelled by visiting
+    position): positions sorted by (dependency level, position), levels cut into batches of <= max_nodes
+    nodes / <= max_entries stream entries.  Nodes of a batch are pairwise non-adjacent and every neighbour
+    visited earlier sits in an earlier batch: deciding batch after batch reproduces the sequential result."""
     import ctypes as C
     from .. import _abi
     n = csr.num_nodes
@@ -76,34 +79,40 @@ def build_visit_stream(csr, order: np.ndarray, max_nodes: int = 16, max_entries:
     row_pos = np.repeat(np.arange(n), deg_o)
     fresh = pos_of[nbr] > row_pos
     nfresh = np.bincount(row_pos, weights=fresh, minlength=n).astype(np.int64)
-    # batches over visiting positions (graph relabelled by position)
+    # level schedule over visiting positions (graph relabelled by position); a record is 3 entries longer than
+    # the scheduler's (1 + deg) count
     rp_p = np.ascontiguousarray(cum, dtype=np.int32)
     col_p = np.ascontiguousarray(pos_of[nbr], dtype=np.int32)
     flagged = np.empty(n + 1, dtype=np.int32)
-    nb = C.c_int64(0)
-    _abi.call("rls_graph_sweep_batches", rp_p.ctypes.data_as(C.c_void_p), col_p.ctypes.data_as(C.c_void_p), n,
-              max_nodes, max_entries, flagged.ctypes.data_as(C.c_void_p), C.byref(nb))
+    tmp = np.empty(nnz + n, dtype=np.int32)
+    nb, nl = C.c_int64(0), C.c_int64(0)
+    _abi.call("rls_graph_sweep_schedule", rp_p.ctypes.data_as(C.c_void_p), col_p.ctypes.data_as(C.c_void_p), n,
+              max_nodes, max(max_entries - 3 * max_nodes, 1), flagged.ctypes.data_as(C.c_void_p),
+              tmp.ctypes.data_as(C.c_void_p), C.byref(nb), C.byref(nl))
+    off = (flagged.view(np.uint32) & 0x7FFFFFFF).astype(np.int64)
+    sp = tmp[off[:n]].astype(np.int64)                               # visiting position at schedule slot k
     is_start = (flagged[:n].view(np.uint32) >> 31).astype(bool)
-    bid = np.cumsum(is_start) - 1                                   # batch of each position
-    first_pos = np.flatnonzero(is_start)
-    m = np.diff(np.concatenate([first_pos, [n]]))                    # nodes per batch
-    rec_len = deg_o + 3
-    rec_total = np.add.reduceat(rec_len, first_pos)
+    bid = np.cumsum(is_start) - 1                                   # batch of each slot
+    first_slot = np.flatnonzero(is_start)
+    m = np.diff(np.concatenate([first_slot, [n]]))                   # nodes per batch
+    deg_s = deg_o[sp]
+    rec_len = deg_s + 4
+    rec_total = np.add.reduceat(rec_len, first_slot)
     batch_size = 3 + m + rec_total
     H = np.concatenate([[0], np.cumsum(batch_size)])                 # header offset of each batch
-    # record offset of each position = H[b] + 3 + m[b] + (sum of rec_len of earlier positions in the batch)
     rec_cum = np.cumsum(rec_len) - rec_len
-    within = rec_cum - rec_cum[first_pos][bid]
+    within = rec_cum - rec_cum[first_slot][bid]
     rec_off = H[bid] + 3 + m[bid] + within
     stream = np.zeros(int(H[-1]), dtype=np.int64)
     stream[H[:-1]] = m
     stream[H[:-1] + 1] = H[1:]
-    stream[H[:-1] + 2] = first_pos
-    k_in_batch = np.arange(n) - first_pos[bid]
+    k_in_batch = np.arange(n) - first_slot[bid]
     stream[H[bid] + 3 + k_in_batch] = rec_off
-    stream[rec_off], stream[rec_off + 1], stream[rec_off + 2] = order, deg_o, nfresh
-    dst = np.repeat(rec_off + 3 - cum[:-1], deg_o) + np.arange(nnz)
-    stream[dst] = nbr | (fresh.astype(np.int64) << 31)
+    stream[rec_off], stream[rec_off + 1], stream[rec_off + 2], stream[rec_off + 3] = order[sp], deg_s, nfresh[sp], sp
+    # rows: entries of visiting position sp[k] copied to rec_off[k] + 4 ...
+    src = np.repeat(cum[:-1][sp], deg_s) + (np.arange(int(deg_s.sum())) - np.repeat(np.cumsum(deg_s) - deg_s, deg_s))
+    dst = np.repeat(rec_off + 4, deg_s) + (np.arange(int(deg_s.sum())) - np.repeat(np.cumsum(deg_s) - deg_s, deg_s))
+    stream[dst] = nbr[src] | (fresh[src].astype(np.int64) << 31)
     return (stream & 0xFFFFFFFF).astype(np.uint32).view(np.int32)
 
 
