@@ -259,27 +259,44 @@ __global__ __launch_bounds__(kK7Waves * kWave) void k_mcpg_local_search_stream(
                 if (uniforms) uu = valid ? uniforms[(cnt * N + pos) * C + c] : 0.0f;
                 else uu = u32_to_unit_float(k7_fmix32(chain_key ^ ((uint32_t)pos * 0x9E3779B1u) ^
                                                       ((uint32_t)cnt * 0x7FEB352Du + 0x165667B1u)));
-                int acc = 0;  // sum over neighbours of mult * bit, mult = 4 for fresh (pass 0), else 2
-                // entries 0..59 of the row sit in lanes 4..63 of blk; lanes past the row end read the sentinel
+                // s2 = sum over neighbours of value in units of 0.5: 2 * bit, or in pass 0 for a neighbour not visited
+                // yet 4 * bit - 1 (the -1s are nfresh).  Entries 0..55 of the row sit in lanes 4..59 of blk (lanes
+                // past the row end read the sentinel, whose word is 0); longer rows continue from the ring.
                 const uint32_t mine = (lane >= 4 && lane - 4 < deg) ? blk : sentinel;
-                const int first = deg < (kWave - 4) ? deg : (kWave - 4);
-                for (int j = 0; j < first; j += 8) {
-                    uint32_t wv[8], mult[8];
+                const int first = deg < 56 ? deg : 56;
+                int acc = 0;
+                if (cnt == 0) {
+                    for (int j = 0; j < first; j += 8) {
+                        uint32_t wv[8], ee[8];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const int src = (j + q + 4) < kWave ? (j + q + 4) : (kWave - 1);
-                        uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)mine, src);
-                        if (j + q >= first) e = sentinel;
-                        mult[q] = (cnt == 0 && (e >> 31)) ? 4u : 2u;
-                        wv[q] = *reinterpret_cast<const uint32_t*>(wbytes + ((e & 0x7fffffffu) * 8u + half4));
+                        for (int q = 0; q < 8; ++q) {
+                            ee[q] = (uint32_t)__builtin_amdgcn_readlane((int)mine, j + q + 4);
+                            wv[q] = *reinterpret_cast<const uint32_t*>(wbytes + ((ee[q] & 0x7fffffffu) * 8u + half4));
+                        }
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) acc += (int)(((wv[q] >> sh) & 1u) << (1u + (ee[q] >> 31)));
                     }
+                    for (int j = 56; j < deg; ++j) {
+                        const uint32_t e = (uint32_t)ring[(row + j) & (kRing - 1)];
+                        const uint32_t bit = (*reinterpret_cast<const uint32_t*>(wbytes + ((e & 0x7fffffffu) * 8u + half4)) >> sh) & 1u;
+                        acc += (int)(bit << (1u + (e >> 31)));
+                    }
+                } else {
+                    for (int j = 0; j < first; j += 8) {
+                        uint32_t wv[8];
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) acc += (int)(((wv[q] >> sh) & 1u) * mult[q]);
-                }
-                for (int j = kWave - 4; j < deg; ++j) {      // hubs: the rest of the row straight from the ring
-                    const uint32_t e = (uint32_t)ring[(row + j) & (kRing - 1)];
-                    const uint32_t mult = (cnt == 0 && (e >> 31)) ? 4u : 2u;
-                    acc += (int)(((*reinterpret_cast<const uint32_t*>(wbytes + ((e & 0x7fffffffu) * 8u + half4)) >> sh) & 1u) * mult);
+                        for (int q = 0; q < 8; ++q) {
+                            const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)mine, j + q + 4);
+                            wv[q] = *reinterpret_cast<const uint32_t*>(wbytes + ((e & 0x7fffffffu) * 8u + half4));
+                        }
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) acc += (int)((wv[q] >> sh) & 1u);
+                    }
+                    for (int j = 56; j < deg; ++j) {
+                        const uint32_t e = (uint32_t)ring[(row + j) & (kRing - 1)];
+                        acc += (int)((*reinterpret_cast<const uint32_t*>(wbytes + ((e & 0x7fffffffu) * 8u + half4)) >> sh) & 1u);
+                    }
+                    acc <<= 1;
                 }
                 const int s2 = acc - nfresh;                                      // units of 0.5
                 const float rv = (float)s2 * 0.5f + uu * 0.25f;                   // MCPG.py:139-141
