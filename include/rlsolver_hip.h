@@ -227,8 +227,8 @@ int rls_spin_step(const rls_graph* g, float* state, int64_t B, int32_t num_rows,
  *   i = index[t,c]; p = x[i,c] ? probs[i] : 1 - probs[i];
  *   accept iff u[t,c] < (1 - p) / p  -> flip x[i,c];  accepts[t - t_offset] += #accepted chains.
  * index int64 [*,C] and u f32 [*,C] are the reference's randint / rand draws in call order (rows
- * indexed by the absolute round t; test mode) or both NULL for the in-kernel Philox generator keyed
- * by (seed, chain, t).
+ * indexed by the absolute round t; test mode) or both NULL for the in-kernel counter-based generator
+ * (murmur3 finaliser) keyed by (seed, chain, t).
  * The reference stops after the first round whose cumulative accept count reaches C*T_transfer
  * (one host sync per round there).  Here the caller walks the 5*T_transfer rounds in chunks: a dry
  * call (write_back = 0) fills accepts[T] (int64, zeroed by the caller), the stop round is derived

@@ -58,6 +58,13 @@ __device__ __forceinline__ void tile_store_nodemajor(T* __restrict__ x, int64_t 
 // ------------------------------------------------------------------------------------- K9
 constexpr int kMetroWaves = 4;
 
+// murmur3's 32-bit finaliser: the counter-based generator of the production paths of K7 and K9 (two hashes
+// per draw pair instead of a 10-round Philox, which was 70 % of a K9 round on its single walking wave)
+__device__ __forceinline__ uint32_t k7_fmix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+
 template <typename T, bool PROBS_LDS>
 __global__ __launch_bounds__(kMetroWaves * kWave) void k_mcpg_metro(T* __restrict__ samples, int64_t N, int64_t C,
                                                       const float* __restrict__ probs, int64_t T_rounds,
@@ -86,7 +93,8 @@ __global__ __launch_bounds__(kMetroWaves * kWave) void k_mcpg_metro(T* __restric
         const int64_t lim = *t_limit_dev;
         t_end = lim < T_rounds ? lim : T_rounds;
     }
-    const Philox ph(seed);
+    const uint32_t chain_key = k7_fmix32((uint32_t)seed ^ k7_fmix32((uint32_t)(seed >> 32) ^ k7_fmix32((uint32_t)c) ^
+                                                                    ((uint32_t)((uint64_t)c >> 32) * 0x9E3779B1u)));
     const uint64_t mybit = 1ull << lane;
     for (int64_t t = 0; w == 0 && t < t_end; ++t) {   // the chain walk itself is one wave (64 chains = 64 lanes)
         int64_t i = 0;
@@ -96,10 +104,10 @@ __global__ __launch_bounds__(kMetroWaves * kWave) void k_mcpg_metro(T* __restric
                 i = index[(t_offset + t) * C + c];
                 uu = u[(t_offset + t) * C + c];
             } else {
-                uint32_t r[4];
-                ph((uint32_t)c, (uint32_t)((uint64_t)c >> 32), (uint32_t)(t_offset + t), 0x4D455452u, r);
-                i = (int64_t)(((uint64_t)r[0] * (uint64_t)N) >> 32);
-                uu = u32_to_unit_float(r[1]);
+                const uint32_t k = chain_key ^ ((uint32_t)(t_offset + t) * 0x9E3779B1u);
+                const uint32_t r0 = k7_fmix32(k ^ 0x4D455452u), r1 = k7_fmix32(k + 0x7FEB352Du);
+                i = (int64_t)(((uint64_t)r0 * (uint64_t)N) >> 32);
+                uu = u32_to_unit_float(r1);
             }
         }
         const bool val = (words[i] >> lane) & 1ull;
@@ -107,14 +115,14 @@ __global__ __launch_bounds__(kMetroWaves * kWave) void k_mcpg_metro(T* __restric
         const float chosen = val ? base : 1.0f - base;            // torch.where(chosen_value, p, 1 - p)
         const float accept_rate = (1.0f - chosen) / chosen;       // MCPG.py:107
         const bool acc = valid && (uu < accept_rate);
-        // all lanes have read their word before any flip of this round lands (one wave, DS in order)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // One wave, and the LDS executes a wave's operations in issue order: every lane's read of this round
+        // precedes the flips, and the flips precede the next round's reads -- no waits needed, so the next
+        // round's hash and address math overlap this round's LDS round trips.
         if (acc) atomicXor(reinterpret_cast<unsigned long long*>(&words[i]), (unsigned long long)mybit);
         if (accepts) {
             const int cnt = __popcll(ballot64(acc));
             if (lane == 0) acc_cnt[t] = (uint32_t)cnt;
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     __syncthreads();
     if (accepts) {   // one coalesced burst of atomics per workgroup instead of one contended atomic per round
@@ -204,11 +212,6 @@ __global__ __launch_bounds__(kWave) void k_mcpg_local_search(const TI* __restric
 // 2-3 dependent L2 round trips per node).  Production noise: one counter-based hash per (chain, pass,
 // visiting position); test mode reads the reference's torch.rand draws.
 constexpr int kK7Waves = 16;   // one workgroup per CU (80 KB bit tile at N = 10^4): 4 waves 27.5, 8 waves 20.1, 16 waves 18.1 ms
-
-__device__ __forceinline__ uint32_t k7_fmix32(uint32_t h) {
-    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
-    return h;
-}
 
 template <typename TI, int P>
 __global__ __launch_bounds__(kK7Waves * kWave) void k_mcpg_local_search_stream(
