@@ -61,6 +61,12 @@ typedef struct rls_graph {
     const int32_t* sweep_rowptr; /* [N+1] offsets into sweep_stream per schedule position, bit 31 = first position
                                   * of a batch (rls_graph_sweep_schedule), or NULL: single-wave sweep */
     const int32_t* sweep_stream; /* [nnz+N] per schedule position: node id, then its neighbours; or NULL */
+    /* Lane-per-node slabs of the two adjacencies (rls_graph_ell), or NULL: for the 64-node group g, entries
+     * ell_ptr[g] + 64 k + l = k-th neighbour of node 64 g + l, or that node itself past the end of its row. */
+    const int32_t* ell_sym_ptr;  /* [ceil(N/64)+1]   symmetric CSR (rowptr/col): K3 */
+    const int32_t* ell_sym;
+    const int32_t* ell_st_ptr;   /* [ceil(N/64)+1]   adjacency as stored (erowptr/ev): K2, local-search weights */
+    const int32_t* ell_st;
 } rls_graph;
 
 int rls_version(void);
@@ -81,6 +87,13 @@ int rls_device_count(void);
 int rls_graph_sweep_schedule(const int32_t* rowptr, const int32_t* col, int64_t N, int32_t max_nodes,
                              int32_t max_entries, int32_t* rowptr_flagged, int32_t* stream, int64_t* num_batches,
                              int64_t* num_levels);
+
+/* [host] Lane-per-node ("ELL") slabs of a CSR adjacency for the bit-sliced per-node kernels: nodes in groups of
+ * 64; group g holds max-degree-in-group rounds of 64 entries, round k = the k-th neighbour of each of the 64
+ * nodes (the node itself where its row is shorter: x_i ^ x_i contributes nothing).  ell_ptr [host, G+1] with
+ * G = ceil(N/64); ell [host, capacity] or NULL to only compute *total (= ell_ptr[G]) for sizing. */
+int rls_graph_ell(const int32_t* rowptr, const int32_t* col, int64_t N, int32_t* ell_ptr, int32_t* ell,
+                  int64_t capacity, int64_t* total);
 
 /* [host] Cut the node order 0..N-1 into maximal runs of pairwise NON-adjacent consecutive nodes
  * (<= max_nodes nodes and <= max_entries CSR entries each).  The greedy sweep may decide the nodes of

@@ -39,6 +39,10 @@ class RlsGraph(C.Structure):
         ("wgt", C.c_void_p),
         ("sweep_rowptr", C.c_void_p),
         ("sweep_stream", C.c_void_p),
+        ("ell_sym_ptr", C.c_void_p),
+        ("ell_sym", C.c_void_p),
+        ("ell_st_ptr", C.c_void_p),
+        ("ell_st", C.c_void_p),
     ]
 
 
@@ -53,6 +57,7 @@ _G = C.POINTER(RlsGraph)
 # (tests/test_abi.py parses the header and checks this table against it).
 SIGNATURES = {
     "rls_graph_sweep_batches": [_P, _P, _I64, C.c_int32, C.c_int32, _P, _P],
+    "rls_graph_ell": [_P, _P, _I64, _P, _P, _I64, _P],
     "rls_graph_sweep_schedule": [_P, _P, _I64, C.c_int32, C.c_int32, _P, _P, _P, _P],
     "rls_maxcut_obj": [_G, _P, _INT, _I64, _P, _P],
     "rls_maxcut_edge_cut_mask": [_G, _P, _I64, _P, _P],

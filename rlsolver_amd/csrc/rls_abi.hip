@@ -98,6 +98,36 @@ int rls_graph_sweep_batches(const int32_t* rowptr, const int32_t* col, int64_t N
     return RLS_OK;
 }
 
+int rls_graph_ell(const int32_t* rowptr, const int32_t* col, int64_t N, int32_t* ell_ptr, int32_t* ell,
+                  int64_t capacity, int64_t* total) {
+    if (!rowptr || !ell_ptr || N < 0 || (N > 0 && rowptr[N] > 0 && !col))
+        return rls::fail(RLS_EINVAL, "rls_graph_ell: bad arguments");
+    const int64_t G = (N + 63) / 64;
+    int64_t off = 0;
+    for (int64_t g = 0; g < G; ++g) {
+        const int64_t i0 = g * 64, i1 = (i0 + 64 < N) ? i0 + 64 : N;
+        int32_t md = 0;
+        for (int64_t i = i0; i < i1; ++i)
+            if (rowptr[i + 1] - rowptr[i] > md) md = rowptr[i + 1] - rowptr[i];
+        if (off + (int64_t)md * 64 >= (int64_t)0x7fffffff) return rls::fail(RLS_EUNSUPPORTED, "rls_graph_ell: too large");
+        ell_ptr[g] = (int32_t)off;
+        if (ell) {
+            if (off + (int64_t)md * 64 > capacity) return rls::fail(RLS_EINVAL, "rls_graph_ell: capacity too small");
+            for (int32_t k = 0; k < md; ++k)
+                for (int64_t l = 0; l < 64; ++l) {
+                    const int64_t i = i0 + l;
+                    int32_t v = (int32_t)(i < N ? i : 0);
+                    if (i < N && rowptr[i] + k < rowptr[i + 1]) v = col[rowptr[i] + k];
+                    ell[off + (int64_t)k * 64 + l] = v;
+                }
+        }
+        off += (int64_t)md * 64;
+    }
+    ell_ptr[G] = (int32_t)off;
+    if (total) *total = off;
+    return RLS_OK;
+}
+
 int rls_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) {

@@ -372,6 +372,121 @@ __global__ __launch_bounds__(kTileWaves * kWave) void k_node_stats_tile(const ui
     }
 }
 
+// =====================================================================================
+// K2 / K3 / local-search weights, bit-sliced with LANE = NODE (unweighted graphs, max degree < 256).
+// In the lane = env form above every (env, node, neighbour) costs ~4.5 instructions of one lane; here a lane owns
+// a node and works on 64-env WORDS: per neighbour one random ds_read_b64, one XOR with the node's own word and
+// a carry-save add into vertical counters -- c(e, i) = #{j in adj(i) : x_j != x_i} for all 64 envs in ~10
+// instructions per (node, neighbour) instead of ~290.  Neighbours come from the lane-per-node slabs of
+// rls_graph_ell (coalesced; rows shorter than the group's longest are padded with the node itself).  The
+// counters are then read out four envs at a time ((plane >> r) & 0x01010101 lines up envs r, r+8, r+16, r+24 in
+// the four bytes of a dword) and every env's 64 consecutive results leave as ONE 256-byte store (the lane = env
+// form wrote 16 bytes per lane into 64 different rows).  out = cutdeg (int64) | deg - 2c (int32) | deg - mult c.
+// =====================================================================================
+constexpr int kNsWaves = 4;
+
+template <int NP>
+__device__ __forceinline__ uint32_t ns_extract4(const uint64_t (&pl)[8], int half, int r) {
+    uint32_t acc = 0;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const uint32_t h = half ? (uint32_t)(pl[p] >> 32) : (uint32_t)pl[p];
+        acc += ((h >> r) & 0x01010101u) << p;
+    }
+    return acc;
+}
+
+template <int MODE, bool VEC>   // MODE 0: cutdeg int64, 1: flip gain int32, 2: local-search weight int32
+__global__ __launch_bounds__(kNsWaves * kWave) void k_node_stats_bits(const uint8_t* __restrict__ x, int64_t B, int64_t N,
+                                                                     const int32_t* __restrict__ rowptr,
+                                                                     const int32_t* __restrict__ ell_ptr,
+                                                                     const int32_t* __restrict__ ell, int mult,
+                                                                     void* __restrict__ out_v) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* words = reinterpret_cast<uint64_t*>(smem);
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    unsigned char* stage = smem + (((size_t)N * 8 + 15) & ~(size_t)15) + (size_t)w * kStageBytes;
+    const int64_t b0 = (int64_t)blockIdx.x * kWave;
+    tile_load_bits<uint8_t, VEC>(x, B, N, b0, words, lane, w, kNsWaves, VEC ? stage : nullptr);
+    __syncthreads();
+    const int64_t G = (N + 63) >> 6;
+    const int nenv = (int)((B - b0) < kWave ? (B - b0) : kWave);
+    for (int64_t g = w; g < G; g += kNsWaves) {
+        const int64_t i = (g << 6) + lane;
+        const bool in = i < N;
+        const uint32_t iself = in ? (uint32_t)i : 0u;
+        const uint64_t own = words[iself];
+        const int e0 = ell_ptr[g], e1 = ell_ptr[g + 1];
+        const int deg = in ? rowptr[i + 1] - rowptr[i] : 0;
+        uint64_t ones = 0, twos = 0, fours = 0, c[5] = {0, 0, 0, 0, 0};
+        for (int k = e0; k < e1; k += 8 * kWave) {
+            uint32_t nb[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) nb[q] = (k + q * kWave < e1) ? (uint32_t)ell[k + q * kWave + lane] : iself;
+            uint64_t d[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) d[q] = words[nb[q]] ^ own;
+            uint64_t twosA, twosB, foursA, foursB, carry;
+            csa(twosA, ones, ones, d[0], d[1]);
+            csa(twosB, ones, ones, d[2], d[3]);
+            csa(foursA, twos, twos, twosA, twosB);
+            csa(twosA, ones, ones, d[4], d[5]);
+            csa(twosB, ones, ones, d[6], d[7]);
+            csa(foursB, twos, twos, twosA, twosB);
+            csa(carry, fours, fours, foursA, foursB);
+#pragma unroll
+            for (int p = 0; p < 5; ++p) {
+                const uint64_t t = c[p] & carry;
+                c[p] ^= carry;
+                carry = t;
+            }
+        }
+        const uint64_t pl[8] = {ones, twos, fours, c[0], c[1], c[2], c[3], c[4]};
+        const int md = (e1 - e0) >> 6;                        // longest row of the group (wave-uniform)
+        for (int half = 0; half < 2; ++half) {
+            for (int r = 0; r < 8; ++r) {
+                if (half * 32 + r >= nenv) break;             // envs are consecutive: nothing further in this half
+                const uint32_t acc = md < 16 ? ns_extract4<4>(pl, half, r)
+                                             : (md < 64 ? ns_extract4<6>(pl, half, r) : ns_extract4<8>(pl, half, r));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int e = half * 32 + r + 8 * j;
+                    const int cnt = (int)((acc >> (8 * j)) & 0xFFu);
+                    if (e < nenv && in) {
+                        if constexpr (MODE == 0) reinterpret_cast<int64_t*>(out_v)[(b0 + e) * N + i] = cnt;
+                        else if constexpr (MODE == 1) reinterpret_cast<int32_t*>(out_v)[(b0 + e) * N + i] = deg - 2 * cnt;
+                        else reinterpret_cast<int32_t*>(out_v)[(b0 + e) * N + i] = deg - mult * cnt;
+                    }
+                }
+            }
+        }
+    }
+}
+
+static inline size_t node_stats_bits_lds(int64_t N) {
+    return (((size_t)N * 8 + 15) & ~(size_t)15) + (size_t)kNsWaves * kStageBytes;
+}
+// the bit-sliced kernel needs the slabs, an unweighted graph, byte-sized counters and a tile that fits
+static inline bool node_stats_use_bits(const rls_graph* g, const int32_t* ell_ptr, const int32_t* ell, int64_t B) {
+    static const bool off = getenv("RLS_NODE_STATS_LANE_ENV") != nullptr;   // dev knob: the lane = env kernels
+    return !off && ell_ptr && ell && !g->wgt && g->max_degree < 256 && B >= 2048 &&
+           node_stats_bits_lds(g->num_nodes) <= (size_t)kLdsBytes;
+}
+template <int MODE>
+static int launch_node_stats_bits(const rls_graph* g, const uint8_t* x, int64_t B, const int32_t* rowptr,
+                                  const int32_t* ell_ptr, const int32_t* ell, int mult, void* out, void* stream) {
+    const int64_t N = g->num_nodes;
+    const size_t lds = node_stats_bits_lds(N);
+    const dim3 grid((unsigned)ceil_div(B, kWave)), block(kNsWaves * kWave);
+    const bool vec = tile_rows_aligned(x, N, 1);
+    auto kern = vec ? k_node_stats_bits<MODE, true> : k_node_stats_bits<MODE, false>;
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, grid, block, lds, as_stream(stream), x, B, N, rowptr, ell_ptr, ell, mult, out);
+    return check_launch("k_node_stats_bits");
+}
+
 // Local-search weights: ws[b,i] = stored_deg(i) - mult * cutdeg(b,i) as int32 -- the pre-pass of
 // rls_maxcut_local_search (the whole-batch max/min per node is one aminmax pass over this tensor; doing
 // it here with 2 atomics per (tile, node) cost 3x the kernel itself).  Same structure as k_node_stats_tile.
@@ -703,6 +818,8 @@ int rls_maxcut_node_cutdeg(const rls_graph* g, const uint8_t* x, int64_t B, int6
     RLS_REQUIRE(B >= 0, RLS_EINVAL, "B < 0");
     if (B == 0) return RLS_OK;
     RLS_REQUIRE(x && cutdeg, RLS_EINVAL, "x/cutdeg is NULL");
+    if (node_stats_use_bits(g, g->ell_st_ptr, g->ell_st, B))
+        return launch_node_stats_bits<0>(g, x, B, g->erowptr, g->ell_st_ptr, g->ell_st, 0, cutdeg, stream);
     const int64_t N = g->num_nodes;
     const size_t lds = node_stats_lds(N);
     if (node_stats_use_tile(B, N)) {
@@ -729,6 +846,8 @@ int rls_maxcut_delta_all(const rls_graph* g, const uint8_t* x, int64_t B, int32_
     RLS_REQUIRE(B >= 0, RLS_EINVAL, "B < 0");
     if (B == 0) return RLS_OK;
     RLS_REQUIRE(x && delta, RLS_EINVAL, "x/delta is NULL");
+    if (node_stats_use_bits(g, g->ell_sym_ptr, g->ell_sym, B))
+        return launch_node_stats_bits<1>(g, x, B, g->rowptr, g->ell_sym_ptr, g->ell_sym, 0, delta, stream);
     const int64_t N = g->num_nodes;
     const size_t lds = node_stats_lds(N);
     if (node_stats_use_tile(B, N)) {
@@ -762,6 +881,8 @@ int rls_maxcut_ls_weights(const rls_graph* g, const uint8_t* x, int64_t B, int32
     RLS_REQUIRE(B >= 0 && mult >= 0, RLS_EINVAL, "bad arguments");
     if (B == 0) return RLS_OK;
     RLS_REQUIRE(x && ws, RLS_EINVAL, "NULL pointer");
+    if (node_stats_use_bits(g, g->ell_st_ptr, g->ell_st, B))
+        return launch_node_stats_bits<2>(g, x, B, g->erowptr, g->ell_st_ptr, g->ell_st, (int)mult, ws, stream);
     const int64_t N = g->num_nodes;
     const size_t lds = node_stats_lds(N);
     RLS_REQUIRE(lds <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS (max %d)", (long long)N, lds,

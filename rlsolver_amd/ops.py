@@ -75,6 +75,11 @@ class DeviceGraph:
         self.num_sweep_batches, self.num_sweep_levels = int(nb.value), int(nl.value)
         self.sweep_rowptr = torch.from_numpy(flagged).to(self.device)
         self.sweep_stream = torch.from_numpy(stream).to(self.device)
+        # lane-per-node slabs of both adjacencies for the bit-sliced per-node kernels (K2 / K3 / local-search weights)
+        erp_h = np.ascontiguousarray(erp, dtype=np.int32)
+        ev_h = np.ascontiguousarray(csr.ev, dtype=np.int32)
+        self.ell_sym_ptr, self.ell_sym = self._ell(rp_h, col_h, csr.num_nodes)
+        self.ell_st_ptr, self.ell_st = self._ell(erp_h, ev_h, csr.num_nodes)
         self.num_nodes, self.num_stored_edges, self.nnz = csr.num_nodes, csr.num_stored_edges, csr.nnz
         self.if_bidirectional = csr.if_bidirectional
         self.struct = _abi.RlsGraph(
@@ -83,8 +88,24 @@ class DeviceGraph:
             eu=self.eu.data_ptr(), ev=self.ev.data_ptr(), erowptr=self.erowptr.data_ptr(),
             rowptr=self.rowptr.data_ptr(), col=self.col.data_ptr(),
             wgt=0 if self.wgt is None else self.wgt.data_ptr(), sweep_rowptr=self.sweep_rowptr.data_ptr(),
-            sweep_stream=self.sweep_stream.data_ptr())
+            sweep_stream=self.sweep_stream.data_ptr(),
+            ell_sym_ptr=self.ell_sym_ptr.data_ptr(), ell_sym=self.ell_sym.data_ptr(),
+            ell_st_ptr=self.ell_st_ptr.data_ptr(), ell_st=self.ell_st.data_ptr())
         self.ref = C.byref(self.struct)
+
+
+def _ell_build(self, rowptr_h, col_h, n):
+    groups = (n + 63) // 64
+    ptr = np.empty(groups + 1, dtype=np.int32)
+    total = C.c_int64(0)
+    args = (rowptr_h.ctypes.data_as(C.c_void_p), col_h.ctypes.data_as(C.c_void_p), n, ptr.ctypes.data_as(C.c_void_p))
+    _abi.call("rls_graph_ell", *args, None, 0, C.byref(total))
+    ell = np.empty(max(int(total.value), 1), dtype=np.int32)
+    _abi.call("rls_graph_ell", *args, ell.ctypes.data_as(C.c_void_p), int(total.value), C.byref(total))
+    return torch.from_numpy(ptr).to(self.device), torch.from_numpy(ell).to(self.device)
+
+
+DeviceGraph._ell = _ell_build
 
 
 def _spins(x: TEN, name: str, g: DeviceGraph, allow_f32=False):
@@ -195,7 +216,7 @@ def local_search_fusable(g: DeviceGraph, num_spin: int) -> bool:
     """Whether rls_maxcut_local_search covers this graph / setting (else: K2 + K6 + K5 path)."""
     n = g.num_nodes
     lds = (n + 2) * 8 + n * 8 + ((n + 4) // 4) * 16 + 4096 * 4 + 4 * 64 * 8 + 4 * 16 * 64 * 4
-    return (g.wgt is None and g.csr.max_degree <= 512 and 0 <= num_spin <= LOCAL_SEARCH_MAX_SPIN and num_spin < n
+    return (g.wgt is None and g.csr.max_degree < 512 and 0 <= num_spin <= LOCAL_SEARCH_MAX_SPIN and num_spin < n
             and lds <= 160 * 1024 and g.num_stored_edges < (1 << 24))
 
 
