@@ -67,6 +67,10 @@ typedef struct rls_graph {
     const int32_t* ell_sym;
     const int32_t* ell_st_ptr;   /* [ceil(N/64)+1]   adjacency as stored (erowptr/ev): K2, local-search weights */
     const int32_t* ell_st;
+    /* Level-parallel form of the sweep schedule (rls_graph_sweep_levels), or NULL / 0 */
+    const int32_t* sweep_lv_ptr; /* [num_sweep_groups+1] offset of each 64-node group in sweep_lv_data, bit 31 = first group of a level */
+    const int32_t* sweep_lv_data;
+    int64_t num_sweep_groups;
 } rls_graph;
 
 int rls_version(void);
@@ -87,6 +91,17 @@ int rls_device_count(void);
 int rls_graph_sweep_schedule(const int32_t* rowptr, const int32_t* col, int64_t N, int32_t max_nodes,
                              int32_t max_entries, int32_t* rowptr_flagged, int32_t* stream, int64_t* num_batches,
                              int64_t* num_levels);
+
+/* [host] The level schedule of rls_graph_sweep_schedule in lane-per-node form: the nodes of a level in groups of
+ * 64 lanes.  Group record in lv_data: 64 words  node | (deg / 2) << 20  (node = N on idle lanes), then
+ * longest-row-of-the-group rounds of 64 neighbour ids (round k = the k-th neighbour of each lane's node; the
+ * node itself where its row is shorter, N on idle lanes).  A wave decides a whole group at once on 64-env
+ * words: bit-sliced count of differing neighbours, bit-sliced compare with deg/2, XOR of the flip mask into
+ * the node's word -- bit-identical to the sequential pass (see rls_graph_sweep_schedule).
+ * lv_ptr [host, groups+1] (bit 31 = first group of a level); lv_data [host, capacity] or NULL to size
+ * (*num_groups, *total).  Needs N < 2^20 and max degree < 256. */
+int rls_graph_sweep_levels(const int32_t* rowptr, const int32_t* col, int64_t N, int32_t* lv_ptr, int64_t ptr_capacity,
+                           int32_t* lv_data, int64_t data_capacity, int64_t* num_groups, int64_t* total);
 
 /* [host] Lane-per-node ("ELL") slabs of a CSR adjacency for the bit-sliced per-node kernels: nodes in groups of
  * 64; group g holds max-degree-in-group rounds of 64 entries, round k = the k-th neighbour of each of the 64

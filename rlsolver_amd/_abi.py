@@ -43,6 +43,9 @@ class RlsGraph(C.Structure):
         ("ell_sym", C.c_void_p),
         ("ell_st_ptr", C.c_void_p),
         ("ell_st", C.c_void_p),
+        ("sweep_lv_ptr", C.c_void_p),
+        ("sweep_lv_data", C.c_void_p),
+        ("num_sweep_groups", C.c_int64),
     ]
 
 
@@ -57,6 +60,7 @@ _G = C.POINTER(RlsGraph)
 # (tests/test_abi.py parses the header and checks this table against it).
 SIGNATURES = {
     "rls_graph_sweep_batches": [_P, _P, _I64, C.c_int32, C.c_int32, _P, _P],
+    "rls_graph_sweep_levels": [_P, _P, _I64, _P, _I64, _P, _I64, _P, _P],
     "rls_graph_ell": [_P, _P, _I64, _P, _P, _I64, _P],
     "rls_graph_sweep_schedule": [_P, _P, _I64, C.c_int32, C.c_int32, _P, _P, _P, _P],
     "rls_maxcut_obj": [_G, _P, _INT, _I64, _P, _P],

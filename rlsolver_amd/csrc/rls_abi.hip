@@ -98,6 +98,68 @@ int rls_graph_sweep_batches(const int32_t* rowptr, const int32_t* col, int64_t N
     return RLS_OK;
 }
 
+int rls_graph_sweep_levels(const int32_t* rowptr, const int32_t* col, int64_t N, int32_t* lv_ptr, int64_t ptr_capacity,
+                           int32_t* lv_data, int64_t data_capacity, int64_t* num_groups, int64_t* total) {
+    if (!rowptr || N < 0 || (N > 0 && rowptr[N] > 0 && !col) || !num_groups || !total)
+        return rls::fail(RLS_EINVAL, "rls_graph_sweep_levels: bad arguments");
+    if (N >= (1 << 20)) return rls::fail(RLS_EUNSUPPORTED, "rls_graph_sweep_levels: N >= 2^20");
+    std::vector<int32_t> level((size_t)(N > 0 ? N : 1), 0);
+    int32_t nlev = 0;
+    for (int64_t i = 0; i < N; ++i) {
+        if (rowptr[i + 1] - rowptr[i] >= 256) return rls::fail(RLS_EUNSUPPORTED, "rls_graph_sweep_levels: degree >= 256");
+        int32_t l = 0;
+        for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j)
+            if (col[j] < i && level[(size_t)col[j]] + 1 > l) l = level[(size_t)col[j]] + 1;
+        level[(size_t)i] = l;
+        if (l + 1 > nlev) nlev = l + 1;
+    }
+    std::vector<int64_t> start((size_t)nlev + 1, 0);
+    for (int64_t i = 0; i < N; ++i) ++start[(size_t)level[(size_t)i] + 1];
+    for (int32_t l = 0; l < nlev; ++l) start[(size_t)l + 1] += start[(size_t)l];
+    std::vector<int32_t> order((size_t)(N > 0 ? N : 1));
+    {
+        std::vector<int64_t> fill(start.begin(), start.end() - 1);
+        for (int64_t i = 0; i < N; ++i) order[(size_t)fill[(size_t)level[(size_t)i]]++] = (int32_t)i;
+    }
+    int64_t ng = 0, off = 0;
+    for (int32_t l = 0; l < nlev; ++l) {
+        for (int64_t k0 = start[(size_t)l]; k0 < start[(size_t)l + 1]; k0 += 64) {
+            const int64_t k1 = (k0 + 64 < start[(size_t)l + 1]) ? k0 + 64 : start[(size_t)l + 1];
+            int32_t md = 0;
+            for (int64_t k = k0; k < k1; ++k) {
+                const int32_t i = order[(size_t)k];
+                if (rowptr[i + 1] - rowptr[i] > md) md = rowptr[i + 1] - rowptr[i];
+            }
+            const int64_t len = (int64_t)(1 + md) * 64;
+            if (off + len >= (int64_t)0x7fffffff) return rls::fail(RLS_EUNSUPPORTED, "rls_graph_sweep_levels: too large");
+            if (lv_ptr) {
+                if (ng + 1 >= ptr_capacity) return rls::fail(RLS_EINVAL, "rls_graph_sweep_levels: ptr capacity too small");
+                lv_ptr[ng] = (int32_t)((uint32_t)off | (k0 == start[(size_t)l] ? 0x80000000u : 0u));
+            }
+            if (lv_data) {
+                if (off + len > data_capacity) return rls::fail(RLS_EINVAL, "rls_graph_sweep_levels: data capacity too small");
+                for (int64_t ln = 0; ln < 64; ++ln) {
+                    const int64_t k = k0 + ln;
+                    const int32_t i = k < k1 ? order[(size_t)k] : (int32_t)N;
+                    const int32_t deg = k < k1 ? rowptr[i + 1] - rowptr[i] : 0;
+                    lv_data[off + ln] = (int32_t)((uint32_t)i | ((uint32_t)(deg >> 1) << 20));
+                    for (int32_t r = 0; r < md; ++r)
+                        lv_data[off + (int64_t)(1 + r) * 64 + ln] = (r < deg) ? col[rowptr[i] + r] : i;
+                }
+            }
+            off += len;
+            ++ng;
+        }
+    }
+    if (lv_ptr) {
+        if (ng >= ptr_capacity) return rls::fail(RLS_EINVAL, "rls_graph_sweep_levels: ptr capacity too small");
+        lv_ptr[ng] = (int32_t)off;
+    }
+    *num_groups = ng;
+    *total = off;
+    return RLS_OK;
+}
+
 int rls_graph_ell(const int32_t* rowptr, const int32_t* col, int64_t N, int32_t* ell_ptr, int32_t* ell,
                   int64_t capacity, int64_t* total) {
     if (!rowptr || !ell_ptr || N < 0 || (N > 0 && rowptr[N] > 0 && !col))

@@ -89,7 +89,8 @@ __global__ __launch_bounds__(W * kWave) void k_maxcut_local_search(
 
     // ---- phase 0
     if (threadIdx.x == 0) words[N] = 0;
-    for (int64_t i = threadIdx.x; i <= N; i += W * kWave) rp[i] = rowptr[i];
+    // rp: CSR rowptr / schedule offsets (N + 1 entries), or the level-group offsets (sweep_len + 1 <= N + 1 entries)
+    for (int64_t i = threadIdx.x; i <= (batched == 2 ? sweep_len : N); i += W * kWave) rp[i] = rowptr[i];
     // the ring is idle outside the sweep: it doubles as the row-piece stage of the tile load / store
     // waves 0..3 stage in the ring, waves 4..7 in the top-k merge buffer (free until the merge, see the barrier there)
     static_assert(kRing * 4 >= kLsMergeWaves * kStageBytes && kLsMergeWaves * kTopCap * kWave * 4 >= (W - kLsMergeWaves) * kStageBytes,
@@ -285,7 +286,14 @@ __global__ __launch_bounds__(W * kWave) void k_maxcut_local_search(
         __syncthreads();
     }
     // ---- phase 3: greedy sweep on the resident tile
-    if (batched) {   // all W waves over the host-built independent-node batches (rp carries the batch flags)
+    if (batched == 2) {   // level-parallel (lane = node): sweep_src = group records, sweep_len = number of groups
+        const int64_t before = block_sum_partials<W>(tile_cut_count<P>(words, eu, ev, E, lane, w, W), scratch, lane, w);
+        __syncthreads();
+        sweep_tile_levels<W>(words, rp, sweep_src, sweep_len, N, lane, w);
+        const int64_t after = block_sum_partials<W>(tile_cut_count<P>(words, eu, ev, E, lane, w, W), scratch, lane, w);
+        my_obj += halve ? ((after - before) >> 1) : (after - before);
+        if (w == 0 && valid) obj[b] = my_obj;
+    } else if (batched) {   // all W waves over the host-built level schedule, one node per wave step (rp carries the batch flags)
         const int64_t part = sweep_tile_batched<W>(words, rp, ring, sweep_src, sweep_len, N, lane, w);
         my_obj += block_sum_partials<W>(part, scratch, lane, w);
         if (w == 0 && valid) obj[b] = my_obj;
@@ -332,10 +340,14 @@ extern "C" int rls_maxcut_local_search(const rls_graph* g, uint8_t* x, int64_t B
     const dim3 grid((unsigned)ceil_div(B, kWave)), block(W * kWave);
     hipStream_t s = as_stream(stream);
     const int halve = g->if_bidirectional ? 1 : 0;
-    const int batched = g->sweep_rowptr != nullptr && g->sweep_stream != nullptr;
-    const int32_t* rp_src = batched ? g->sweep_rowptr : g->rowptr;            // level schedule, or the CSR as it is
-    const int32_t* sw_src = batched ? g->sweep_stream : g->col;
-    const int64_t sw_len = batched ? g->nnz + N : g->nnz;
+    static const bool no_levels = getenv("RLS_SWEEP_NO_LEVELS") != nullptr;   // dev knob
+    const bool levels = !no_levels && g->sweep_lv_ptr && g->sweep_lv_data && g->num_sweep_groups > 0 &&
+                        g->num_sweep_groups <= N;
+    const int batched = levels ? 2 : (g->sweep_rowptr != nullptr && g->sweep_stream != nullptr ? 1 : 0);
+    // sweep schedule: level groups (lane = node) | level schedule stream (lane = env) | the CSR as it is
+    const int32_t* rp_src = batched == 2 ? g->sweep_lv_ptr : (batched ? g->sweep_rowptr : g->rowptr);
+    const int32_t* sw_src = batched == 2 ? g->sweep_lv_data : (batched ? g->sweep_stream : g->col);
+    const int64_t sw_len = batched == 2 ? g->num_sweep_groups : (batched ? g->nnz + N : g->nnz);
 #define LAUNCH_LSF(VEC, PP)                                                                                          \
     do {                                                                                                             \
         auto kern = W == 8 ? (v4 ? k_maxcut_local_search<VEC, true, PP, 8> : k_maxcut_local_search<VEC, false, PP, 8>) \

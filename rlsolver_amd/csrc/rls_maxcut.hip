@@ -194,6 +194,35 @@ __global__ __launch_bounds__(SW * kWave) void k_maxcut_greedy_sweep_batched(
     if (w == 0 && b0 + lane < B) obj[b0 + lane] += gain;
 }
 
+// Level-parallel variant (rls_sweep.h: sweep_tile_levels): lane = node, one pass per dependency level.
+// obj += cut(after) - cut(before), both from the bit-sliced counter on the resident tile.
+template <bool VEC, int SW, int P>
+__global__ __launch_bounds__(SW * kWave) void k_maxcut_greedy_sweep_levels(
+    uint8_t* __restrict__ x, int64_t B, int64_t N, const int32_t* __restrict__ lv_ptr,
+    const int32_t* __restrict__ lv_data, int64_t G, const int32_t* __restrict__ eu, const int32_t* __restrict__ ev,
+    int64_t E, int halve, int64_t* __restrict__ obj) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* words = reinterpret_cast<uint64_t*>(smem);
+    int32_t* lvp = reinterpret_cast<int32_t*>(smem + (size_t)(N + 2) * 8);
+    int64_t* scratch = reinterpret_cast<int64_t*>(smem + (size_t)(N + 2) * 8 + (((size_t)(G + 1) * 4 + 15) & ~(size_t)15));
+    unsigned char* stages = reinterpret_cast<unsigned char*>(scratch + SW * kWave);
+    constexpr int LW = SW < kSweepLoadWaves ? SW : kSweepLoadWaves;   // waves that move the tile
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    const int64_t b0 = (int64_t)blockIdx.x * kWave;
+    if (threadIdx.x == 0) words[N] = 0;
+    for (int64_t i = threadIdx.x; i <= G; i += SW * kWave) lvp[i] = lv_ptr[i];
+    unsigned char* stage = VEC ? stages + (w % LW) * kStageBytes : nullptr;
+    if (w < LW) tile_load_bits<uint8_t, VEC>(x, B, N, b0, words, lane, w, LW, stage);
+    __syncthreads();
+    const int64_t before = block_sum_partials<SW>(tile_cut_count<P>(words, eu, ev, E, lane, w, SW), scratch, lane, w);
+    __syncthreads();
+    sweep_tile_levels<SW>(words, lvp, lv_data, G, N, lane, w);
+    const int64_t after = block_sum_partials<SW>(tile_cut_count<P>(words, eu, ev, E, lane, w, SW), scratch, lane, w);
+    if (w < LW) tile_store_bytes<VEC>(x, B, N, b0, words, lane, w, LW, true, stage);
+    if (w == 0 && b0 + lane < B) obj[b0 + lane] += halve ? ((after - before) >> 1) : (after - before);
+}
+
 // generic fallback (weighted graphs, hubs with degree > kSweepMaxDeg): one global row fetch per node
 template <bool VEC, bool WEIGHTED>
 __global__ __launch_bounds__(kWave) void k_maxcut_greedy_sweep_generic(uint8_t* __restrict__ x, int64_t B, int64_t N,
@@ -750,6 +779,48 @@ int rls_maxcut_greedy_sweep(const rls_graph* g, uint8_t* x, int64_t B, int64_t* 
     const size_t lds_fast = (size_t)(N + 2) * 8 + (size_t)((N + 1 + 3) & ~3ll) * 4 + (size_t)kRing * 4;
     const bool fast = !g->wgt && g->max_degree < kSweepMaxDeg && lds_fast <= (size_t)kLdsBytes &&
                       (((uintptr_t)g->col) & 3) == 0;
+    {   // level-parallel sweep: needs the lane-per-node schedule (N < 2^20, degrees < 256) and the tile in LDS
+        static const bool no_levels = getenv("RLS_SWEEP_NO_LEVELS") != nullptr;   // dev knob
+        const int64_t G = g->num_sweep_groups, E = g->num_stored_edges;
+        const int P = pick_planes(E);
+        static const int force_lw = getenv("RLS_SWEEP_WAVES") ? atoi(getenv("RLS_SWEEP_WAVES")) : 0;
+        // one group per level (G22: 44 nodes per group): a level is ONE wave's pass and the others only prefetch -- few
+        // waves, more tiles per CU; well-filled groups (G70: 9 levels of ~17 groups): 8 waves share a level
+        const int sw = force_lw == 2 || force_lw == 4 || force_lw == 8 || force_lw == 16 ? force_lw : (N >= 56 * G ? 8 : 4);
+        const size_t lds_l = (size_t)(N + 2) * 8 + (((size_t)(G + 1) * 4 + 15) & ~(size_t)15) + (size_t)sw * kWave * 8 +
+                             (size_t)kSweepLoadWaves * kStageBytes;
+        if (!no_levels && !g->wgt && g->sweep_lv_ptr && g->sweep_lv_data && G > 0 && P != 0 && lds_l <= (size_t)kLdsBytes) {
+            const dim3 blockl(sw * kWave);
+            const int halve = g->if_bidirectional ? 1 : 0;
+#define LAUNCH_SWL(VEC, SWV, PP)                                                                             \
+    do {                                                                                                     \
+        auto kern = k_maxcut_greedy_sweep_levels<VEC, SWV, PP>;                                              \
+        if (lds_l > 64 * 1024)                                                                               \
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l); \
+        hipLaunchKernelGGL(kern, grid, blockl, lds_l, s, x, B, N, g->sweep_lv_ptr, g->sweep_lv_data, G, g->eu, g->ev, \
+                           E, halve, obj);                                                                    \
+    } while (0)
+#define DISPATCH_SWL_P(VEC, SWV)                       \
+    switch (P) {                                       \
+        case 12: LAUNCH_SWL(VEC, SWV, 12); break;      \
+        case 16: LAUNCH_SWL(VEC, SWV, 16); break;      \
+        case 20: LAUNCH_SWL(VEC, SWV, 20); break;      \
+        default: LAUNCH_SWL(VEC, SWV, 24); break;      \
+    }
+#define DISPATCH_SWL(VEC)                                       \
+    do {                                                        \
+        if (sw == 16) { DISPATCH_SWL_P(VEC, 16) }               \
+        else if (sw == 4) { DISPATCH_SWL_P(VEC, 4) }            \
+        else if (sw == 2) { DISPATCH_SWL_P(VEC, 2) }            \
+        else { DISPATCH_SWL_P(VEC, 8) }                         \
+    } while (0)
+            if (vec) DISPATCH_SWL(true); else DISPATCH_SWL(false);
+#undef DISPATCH_SWL
+#undef DISPATCH_SWL_P
+#undef LAUNCH_SWL
+            return check_launch("k_maxcut_greedy_sweep_levels");
+        }
+    }
     if (fast && g->sweep_rowptr && g->sweep_stream && getenv("RLS_SWEEP_UNBATCHED") == nullptr) {
         static const int force_sw = getenv("RLS_SWEEP_WAVES") ? atoi(getenv("RLS_SWEEP_WAVES")) : 0;   // dev knob
         const int sw = force_sw == 4 || force_sw == 8 || force_sw == 16 ? force_sw

@@ -80,6 +80,20 @@ class DeviceGraph:
         ev_h = np.ascontiguousarray(csr.ev, dtype=np.int32)
         self.ell_sym_ptr, self.ell_sym = self._ell(rp_h, col_h, csr.num_nodes)
         self.ell_st_ptr, self.ell_st = self._ell(erp_h, ev_h, csr.num_nodes)
+        # the same level schedule in lane-per-node groups for the level-parallel sweep (N < 2^20, degrees < 256)
+        self.sweep_lv_ptr = self.sweep_lv_data = None
+        self.num_sweep_groups = 0
+        if csr.num_nodes < (1 << 20) and csr.max_degree < 256:
+            ng, tot = C.c_int64(0), C.c_int64(0)
+            a = (rp_h.ctypes.data_as(C.c_void_p), col_h.ctypes.data_as(C.c_void_p), csr.num_nodes)
+            _abi.call("rls_graph_sweep_levels", *a, None, 0, None, 0, C.byref(ng), C.byref(tot))
+            lvp = np.empty(int(ng.value) + 1, dtype=np.int32)
+            lvd = np.empty(max(int(tot.value), 1), dtype=np.int32)
+            _abi.call("rls_graph_sweep_levels", *a, lvp.ctypes.data_as(C.c_void_p), lvp.size,
+                      lvd.ctypes.data_as(C.c_void_p), lvd.size, C.byref(ng), C.byref(tot))
+            self.num_sweep_groups = int(ng.value)
+            self.sweep_lv_ptr = torch.from_numpy(lvp).to(self.device)
+            self.sweep_lv_data = torch.from_numpy(lvd).to(self.device)
         self.num_nodes, self.num_stored_edges, self.nnz = csr.num_nodes, csr.num_stored_edges, csr.nnz
         self.if_bidirectional = csr.if_bidirectional
         self.struct = _abi.RlsGraph(
@@ -90,7 +104,10 @@ class DeviceGraph:
             wgt=0 if self.wgt is None else self.wgt.data_ptr(), sweep_rowptr=self.sweep_rowptr.data_ptr(),
             sweep_stream=self.sweep_stream.data_ptr(),
             ell_sym_ptr=self.ell_sym_ptr.data_ptr(), ell_sym=self.ell_sym.data_ptr(),
-            ell_st_ptr=self.ell_st_ptr.data_ptr(), ell_st=self.ell_st.data_ptr())
+            ell_st_ptr=self.ell_st_ptr.data_ptr(), ell_st=self.ell_st.data_ptr(),
+            sweep_lv_ptr=0 if self.sweep_lv_ptr is None else self.sweep_lv_ptr.data_ptr(),
+            sweep_lv_data=0 if self.sweep_lv_data is None else self.sweep_lv_data.data_ptr(),
+            num_sweep_groups=self.num_sweep_groups)
         self.ref = C.byref(self.struct)
 
 

@@ -117,3 +117,46 @@ def test_sweep_level_schedule_is_a_valid_reordering_of_the_sequential_pass():
         sizes = np.bincount(batch_of)
         ents = np.add.reduceat(np.diff(off.astype(np.int64)), np.flatnonzero(first))
         assert sizes.max() <= 64 and ents.max() <= 768
+
+
+def test_sweep_level_groups_encode_the_same_schedule():
+    """rls_graph_sweep_levels: every node appears once, lanes of a group are pairwise non-adjacent, lower-numbered
+    neighbours sit in earlier LEVELS, rounds list each node's CSR row padded with the node itself."""
+    import ctypes as C
+    from rlsolver_amd import _abi
+    from rlsolver_amd.graph import build_csr, generate_gnm, generate_ba
+    for g, n in ((generate_gnm(300, 1500, seed=3), 300), (generate_ba(200, 4, seed=1), 200), ([(0, 1, 1)], 70),
+                 (generate_gnm(2000, 19990, seed=22), 2000)):
+        csr = build_csr(g, num_nodes=n, if_bidirectional=False)
+        rp = np.ascontiguousarray(csr.rowptr, dtype=np.int32)
+        col = np.ascontiguousarray(csr.col, dtype=np.int32)
+        a = (rp.ctypes.data_as(C.c_void_p), col.ctypes.data_as(C.c_void_p), n)
+        ng, tot = C.c_int64(0), C.c_int64(0)
+        _abi.call("rls_graph_sweep_levels", *a, None, 0, None, 0, C.byref(ng), C.byref(tot))
+        lvp = np.empty(ng.value + 1, dtype=np.int32)
+        lvd = np.empty(tot.value, dtype=np.int32)
+        _abi.call("rls_graph_sweep_levels", *a, lvp.ctypes.data_as(C.c_void_p), lvp.size, lvd.ctypes.data_as(C.c_void_p),
+                  lvd.size, C.byref(ng), C.byref(tot))
+        off = (lvp.view(np.uint32) & 0x7FFFFFFF).astype(np.int64)
+        first = (lvp.view(np.uint32)[:-1] >> 31).astype(bool)
+        assert first[0] and off[-1] == tot.value
+        level_of_group = np.cumsum(first) - 1
+        level_of = np.full(n, -1)
+        seen = []
+        for k in range(ng.value):
+            rec = lvd[off[k]: off[k + 1]].reshape(-1, 64)
+            hdr = rec[0].view(np.uint32)
+            nodes, half = (hdr & 0xFFFFF).astype(np.int64), hdr >> 20
+            live = nodes < n
+            seen += nodes[live].tolist()
+            level_of[nodes[live]] = level_of_group[k]
+            for ln in np.flatnonzero(live):
+                i = nodes[ln]
+                deg = rp[i + 1] - rp[i]
+                assert half[ln] == deg // 2
+                assert np.array_equal(rec[1:1 + deg, ln], col[rp[i]: rp[i + 1]]) and (rec[1 + deg:, ln] == i).all()
+            assert (rec[1:, ~live] == n).all()
+        assert sorted(seen) == list(range(n))
+        for i in range(n):
+            nbrs = col[rp[i]: rp[i + 1]]
+            assert (level_of[nbrs[nbrs < i]] < level_of[i]).all() and (level_of[nbrs[nbrs > i]] > level_of[i]).all()
