@@ -291,6 +291,31 @@ int rls_mcpg_local_search(const rls_graph* g, const void* xs_in, int spin_bytes,
                           const int32_t* order, const int32_t* visit_stream, int64_t visit_len, int64_t num_ls,
                           const float* uniforms, uint64_t seed, float* expected, void* stream);
 
+/* [host] Level-parallel form of the K7 visiting order (lane = node; same dependency-level argument as
+ * rls_graph_sweep_levels, levels taken over visiting POSITIONS: order[pos] = node).  Nodes of a level with degree
+ * <= 64 are packed 64 to a group (sorted by degree so that rows of a group have similar length); a node of
+ * higher degree forms a group of its own and is decided with lane = neighbour.  Group record in lv_data:
+ *     64 words  node | K << 20 | tie << 31        K = ceil(deg / 2), tie = deg even            (passes >= 1)
+ *     64 words  pos  | K0 << 20 | tie0 << 31      K0 = ceil((deg + nfresh) / 2), tie0 = (deg + nfresh) even  (pass 0)
+ *     rounds of 64 words  nb | fresh << 31        padding / idle lanes: N
+ * (a normal group has longest-row rounds, round k = k-th neighbour of each lane's node; a hub group uses lane 0 of
+ * the two header rows plus word 2 of the first = deg, and ceil(deg / 64) rounds listing its neighbours).
+ * The accept rule of MCPG.py:139-141, (s + u/4) < (deg + 1/4)/2 with s in half-integers, is  2s < deg, or
+ * 2s == deg and u < 1/2:  new bit = [count < K] | ([count == K] & tie & coin), count = #ones among the neighbours
+ * (pass 0: #ones among visited + 2 #ones among not-yet-visited ones, against K0).
+ * lv_ptr [host, groups+1]: offset | bit 31 = first group of a level | bit 30 = hub group.  NULL outputs: sizing.
+ * Needs N < 2^20 and max degree < 1024. */
+int rls_mcpg_visit_levels(const int32_t* rowptr, const int32_t* col, int64_t N, const int32_t* order, int32_t* lv_ptr,
+                          int64_t ptr_capacity, int32_t* lv_data, int64_t data_capacity, int64_t* num_groups,
+                          int64_t* total);
+
+/* K7 + K8 first half on that schedule (production path: tie coins from a counter hash keyed by (seed, 64-chain
+ * block, pass, position); coins uint64 [num_ls * N, ceil(C / 64)] -- bit c % 64 of word [pass * N + pos, c / 64] =
+ * "u < 1/2" for chain c -- replaces them for tests).  Same outputs as rls_mcpg_local_search. */
+int rls_mcpg_local_search_levels(const rls_graph* g, const void* xs_in, int spin_bytes, float* xs_out, int64_t C,
+                                 const int32_t* lv_ptr, const int32_t* lv_data, int64_t num_groups, int64_t num_ls,
+                                 const uint64_t* coins, uint64_t seed, float* expected, void* stream);
+
 /* K8 second half  methods/MCPG.py:154-161: best_index[m] = m + M * argmin_r expected[r*M + m]
  * (first minimum), vs_good[m] = (num_edges - expected[best]) / 2, xs_good[:, m] = xs[:, best].
  * M = total_mcmc_num, R = repeat_times, xs f32 [N, M*R], xs_good f32 [N, M]. */

@@ -61,6 +61,8 @@ _G = C.POINTER(RlsGraph)
 SIGNATURES = {
     "rls_graph_sweep_batches": [_P, _P, _I64, C.c_int32, C.c_int32, _P, _P],
     "rls_graph_sweep_levels": [_P, _P, _I64, _P, _I64, _P, _I64, _P, _P],
+    "rls_mcpg_visit_levels": [_P, _P, _I64, _P, _P, _I64, _P, _I64, _P, _P],
+    "rls_mcpg_local_search_levels": [_G, _P, _INT, _P, _I64, _P, _P, _I64, _I64, _P, _U64, _P, _P],
     "rls_graph_ell": [_P, _P, _I64, _P, _P, _I64, _P],
     "rls_graph_sweep_schedule": [_P, _P, _I64, C.c_int32, C.c_int32, _P, _P, _P, _P],
     "rls_maxcut_obj": [_G, _P, _INT, _I64, _P, _P],

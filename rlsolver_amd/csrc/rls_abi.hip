@@ -2,6 +2,7 @@
 #include "rls_common.h"
 #include <cstdarg>
 #include <cstdio>
+#include <algorithm>
 #include <vector>
 
 namespace rls {
@@ -153,6 +154,100 @@ int rls_graph_sweep_levels(const int32_t* rowptr, const int32_t* col, int64_t N,
     }
     if (lv_ptr) {
         if (ng >= ptr_capacity) return rls::fail(RLS_EINVAL, "rls_graph_sweep_levels: ptr capacity too small");
+        lv_ptr[ng] = (int32_t)off;
+    }
+    *num_groups = ng;
+    *total = off;
+    return RLS_OK;
+}
+
+int rls_mcpg_visit_levels(const int32_t* rowptr, const int32_t* col, int64_t N, const int32_t* order, int32_t* lv_ptr,
+                          int64_t ptr_capacity, int32_t* lv_data, int64_t data_capacity, int64_t* num_groups,
+                          int64_t* total) {
+    if (!rowptr || !order || N < 0 || (N > 0 && rowptr[N] > 0 && !col) || !num_groups || !total)
+        return rls::fail(RLS_EINVAL, "rls_mcpg_visit_levels: bad arguments");
+    if (N >= (1 << 20)) return rls::fail(RLS_EUNSUPPORTED, "rls_mcpg_visit_levels: N >= 2^20");
+    constexpr int32_t kHubDeg = 64;
+    std::vector<int32_t> pos_of((size_t)(N > 0 ? N : 1), -1);
+    for (int64_t p = 0; p < N; ++p) {
+        if (order[p] < 0 || order[p] >= N || pos_of[(size_t)order[p]] != -1)
+            return rls::fail(RLS_EINVAL, "rls_mcpg_visit_levels: order is not a permutation");
+        pos_of[(size_t)order[p]] = (int32_t)p;
+    }
+    std::vector<int32_t> level((size_t)(N > 0 ? N : 1), 0), nfresh((size_t)(N > 0 ? N : 1), 0);   // per position
+    int32_t nlev = 0;
+    for (int64_t p = 0; p < N; ++p) {
+        const int32_t i = order[p];
+        if (rowptr[i + 1] - rowptr[i] >= 1024) return rls::fail(RLS_EUNSUPPORTED, "rls_mcpg_visit_levels: degree >= 1024");
+        int32_t l = 0, nf = 0;
+        for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
+            const int32_t q = pos_of[(size_t)col[j]];
+            if (q < p) { if (level[(size_t)q] + 1 > l) l = level[(size_t)q] + 1; }
+            else if (q > p) ++nf;
+        }
+        level[(size_t)p] = l;
+        nfresh[(size_t)p] = nf;
+        if (l + 1 > nlev) nlev = l + 1;
+    }
+    // positions by (level, hub last, degree descending, position)
+    std::vector<int32_t> sp((size_t)(N > 0 ? N : 1));
+    for (int64_t p = 0; p < N; ++p) sp[(size_t)p] = (int32_t)p;
+    auto degp = [&](int32_t p) { return rowptr[order[p] + 1] - rowptr[order[p]]; };
+    std::stable_sort(sp.begin(), sp.begin() + N, [&](int32_t a, int32_t b) {
+        if (level[(size_t)a] != level[(size_t)b]) return level[(size_t)a] < level[(size_t)b];
+        const bool ha = degp(a) > kHubDeg, hb = degp(b) > kHubDeg;
+        if (ha != hb) return hb;
+        return degp(a) > degp(b);
+    });
+    int64_t ng = 0, off = 0;
+    auto header = [&](int32_t p, int32_t& h0, int32_t& h1) {
+        const int32_t i = order[p], deg = degp(p), t0 = deg + nfresh[(size_t)p];
+        h0 = (int32_t)((uint32_t)i | ((uint32_t)((deg + 1) >> 1) << 20) | ((deg & 1) ? 0u : 0x80000000u));
+        h1 = (int32_t)((uint32_t)p | ((uint32_t)((t0 + 1) >> 1) << 20) | ((t0 & 1) ? 0u : 0x80000000u));
+    };
+    auto entry = [&](int32_t p, int32_t r) {   // r-th neighbour word of position p
+        const int32_t i = order[p], nb = col[rowptr[i] + r];
+        return (int32_t)((uint32_t)nb | (pos_of[(size_t)nb] > p ? 0x80000000u : 0u));
+    };
+    int64_t k0 = 0;
+    while (k0 < N) {
+        const int32_t lev = level[(size_t)sp[(size_t)k0]];
+        const bool level_start = (k0 == 0) || level[(size_t)sp[(size_t)(k0 - 1)]] != lev;
+        const bool hub = degp(sp[(size_t)k0]) > kHubDeg;
+        int64_t k1 = k0 + 1;
+        if (!hub)
+            while (k1 < N && k1 - k0 < 64 && level[(size_t)sp[(size_t)k1]] == lev && degp(sp[(size_t)k1]) <= kHubDeg) ++k1;
+        const int32_t md = degp(sp[(size_t)k0]);                       // degree-descending: the first is the longest
+        const int64_t rounds = hub ? (md + 63) / 64 : md;
+        const int64_t len = (2 + rounds) * 64;
+        if (off + len >= (int64_t)0x3fffffff) return rls::fail(RLS_EUNSUPPORTED, "rls_mcpg_visit_levels: too large");
+        if (lv_ptr) {
+            if (ng + 1 >= ptr_capacity) return rls::fail(RLS_EINVAL, "rls_mcpg_visit_levels: ptr capacity too small");
+            lv_ptr[ng] = (int32_t)((uint32_t)off | (level_start ? 0x80000000u : 0u) | (hub ? 0x40000000u : 0u));
+        }
+        if (lv_data) {
+            if (off + len > data_capacity) return rls::fail(RLS_EINVAL, "rls_mcpg_visit_levels: data capacity too small");
+            int32_t* rec = lv_data + off;
+            for (int64_t e = 0; e < len; ++e) rec[e] = (int32_t)N;
+            if (hub) {
+                const int32_t p = sp[(size_t)k0];
+                header(p, rec[0], rec[64]);
+                rec[2] = md;
+                for (int32_t r = 0; r < md; ++r) rec[128 + r] = entry(p, r);
+            } else {
+                for (int64_t k = k0; k < k1; ++k) {
+                    const int32_t p = sp[(size_t)k], ln = (int32_t)(k - k0), deg = degp(p);
+                    header(p, rec[ln], rec[64 + ln]);
+                    for (int32_t r = 0; r < deg; ++r) rec[(int64_t)(2 + r) * 64 + ln] = entry(p, r);
+                }
+            }
+        }
+        off += len;
+        ++ng;
+        k0 = k1;
+    }
+    if (lv_ptr) {
+        if (ng >= ptr_capacity) return rls::fail(RLS_EINVAL, "rls_mcpg_visit_levels: ptr capacity too small");
         lv_ptr[ng] = (int32_t)off;
     }
     *num_groups = ng;

@@ -324,6 +324,203 @@ __global__ __launch_bounds__(kK7Waves * kWave) void k_mcpg_local_search_stream(
     }
 }
 
+// K7 level-parallel (lane = node): include/rlsolver_hip.h, rls_mcpg_visit_levels / rls_mcpg_local_search_levels.
+// A wave decides the 64 nodes of a group at once on 64-chain words: vertical counters of the neighbours' ones
+// (pass 0: visited and not-yet-visited neighbours counted apart, C = cV + 2 cF), a bit-sliced compare with the
+// per-node constant K and  new word = [C < K] | ([C == K] & tie & coin).  Nodes of degree > 64 get a group of
+// their own and the lanes share the NEIGHBOURS instead (per-lane counters, then transpose + popcount per plane).
+constexpr int kLvWaves = 8;
+
+template <int NP>
+__device__ __forceinline__ void lv_cmp(const uint64_t (&pl)[9], uint32_t K, uint64_t& lt, uint64_t& eq) {
+    uint32_t lt0 = 0, lt1 = 0, eq0 = 0xFFFFFFFFu, eq1 = 0xFFFFFFFFu;
+#pragma unroll
+    for (int p = NP - 1; p >= 0; --p) {
+        const uint32_t kb = 0u - ((K >> p) & 1u);
+        const uint32_t c0 = (uint32_t)pl[p], c1 = (uint32_t)(pl[p] >> 32);
+        lt0 |= eq0 & ~c0 & kb;  lt1 |= eq1 & ~c1 & kb;
+        eq0 &= ~(c0 ^ kb);      eq1 &= ~(c1 ^ kb);
+    }
+    lt = ((uint64_t)lt1 << 32) | lt0;
+    eq = ((uint64_t)eq1 << 32) | eq0;
+}
+
+// 8 words into a (ones, twos, fours, c[0..4] = planes 3..7) vertical counter
+__device__ __forceinline__ void lv_add8(const uint64_t (&d)[8], uint64_t& ones, uint64_t& twos, uint64_t& fours,
+                                        uint64_t (&c)[5]) {
+    uint64_t twosA, twosB, foursA, foursB, carry;
+    csa(twosA, ones, ones, d[0], d[1]);
+    csa(twosB, ones, ones, d[2], d[3]);
+    csa(foursA, twos, twos, twosA, twosB);
+    csa(twosA, ones, ones, d[4], d[5]);
+    csa(twosB, ones, ones, d[6], d[7]);
+    csa(foursB, twos, twos, twosA, twosB);
+    csa(carry, fours, fours, foursA, foursB);
+#pragma unroll
+    for (int p = 0; p < 5; ++p) {
+        const uint64_t t = c[p] & carry;
+        c[p] ^= carry;
+        carry = t;
+    }
+}
+
+template <typename TI, int P>
+__global__ __launch_bounds__(kLvWaves * kWave) void k_mcpg_local_search_levels(
+    const TI* __restrict__ xs_in, float* __restrict__ xs_out, int64_t N, int64_t C,
+    const int32_t* __restrict__ lv_ptr, const int32_t* __restrict__ data, int64_t G, int64_t num_ls,
+    const uint64_t* __restrict__ coins, uint64_t seed, const int32_t* __restrict__ eu, const int32_t* __restrict__ ev,
+    int64_t E, float* __restrict__ expected) {
+    constexpr int W = kLvWaves;
+    constexpr uint32_t M30 = 0x3fffffffu, M31 = 0x7fffffffu;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* words = reinterpret_cast<uint64_t*>(smem);
+    int32_t* lvp = reinterpret_cast<int32_t*>(smem + (size_t)(N + 2) * 8);
+    int64_t* scratch = reinterpret_cast<int64_t*>(smem + (size_t)(N + 2) * 8 + (((size_t)(G + 1) * 4 + 15) & ~(size_t)15));
+    const uint32_t* w32 = reinterpret_cast<const uint32_t*>(smem);
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    const int64_t c0 = (int64_t)blockIdx.x * kWave;
+    const int64_t c = c0 + lane;
+    const bool valid = c < C;
+    const int64_t CB = (C + kWave - 1) / kWave;               // 64-chain blocks = words per coins row
+    if (threadIdx.x == 0) words[N] = 0;                       // padding / idle lanes point here
+    for (int64_t i = threadIdx.x; i <= G; i += W * kWave) lvp[i] = lv_ptr[i];
+    tile_load_bits_nodemajor<TI>(xs_in, N, C, c0, words, lane, w, W);
+    const uint32_t blk_key = k7_fmix32((uint32_t)seed ^ k7_fmix32((uint32_t)(seed >> 32) ^
+                                                                  k7_fmix32((uint32_t)blockIdx.x * 0x9E3779B1u + 0x632BE5ABu)));
+    const BitXpose xc = bit_xpose_consts(lane);
+    auto coin_word = [&](int64_t cnt, uint32_t pos) -> uint64_t {   // bit e: "u < 1/2" for chain c0 + e at (pass, pos)
+        if (coins) return coins[((int64_t)cnt * N + pos) * CB + blockIdx.x];
+        const uint32_t k = blk_key ^ (pos * 0x9E3779B1u) ^ ((uint32_t)cnt * 0x7FEB352Du + 0x165667B1u);
+        return ((uint64_t)k7_fmix32(k ^ 0x4C4F4353u) << 32) | k7_fmix32(k + 0x27D4EB2Fu);
+    };
+    for (int64_t cnt = 0; cnt < num_ls; ++cnt) {
+        const bool pass0 = cnt == 0;
+        int64_t mine = w;
+        uint32_t h0 = (uint32_t)N, h1 = (uint32_t)N, e0[8];
+        auto prefetch = [&](int64_t k) {
+            if (k < G) {
+                const int64_t p0 = (uint32_t)lvp[k] & M30, p1 = (uint32_t)lvp[k + 1] & M30;
+                h0 = (uint32_t)data[p0 + lane];
+                h1 = (uint32_t)data[p0 + kWave + lane];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int64_t at = p0 + (int64_t)(2 + q) * kWave;
+                    e0[q] = at < p1 ? (uint32_t)data[at + lane] : (uint32_t)N;
+                }
+            }
+        };
+        prefetch(mine);
+        for (int64_t k = 0; k < G; ++k) {
+            const uint32_t flags = (uint32_t)lvp[k];
+            if (flags >> 31) __syncthreads();                 // new level (k = 0: new pass): earlier updates are visible
+            if (k != mine) continue;
+            const int64_t p0 = flags & M30, p1 = (uint32_t)lvp[k + 1] & M30;
+            const int rounds = (int)((p1 - p0) >> 6) - 2;
+            if (!((flags >> 30) & 1u)) {
+                // ---- 64 nodes, lane = node
+                const uint32_t node = h0 & 0xFFFFFu, pos = h1 & 0xFFFFFu;
+                const uint32_t K = pass0 ? ((h1 >> 20) & 0x7FFu) : ((h0 >> 20) & 0x7FFu);
+                const uint64_t tie = 0ull - (uint64_t)((pass0 ? h1 : h0) >> 31);
+                uint64_t vo = 0, vt = 0, vf = 0, vc[5] = {0, 0, 0, 0, 0};      // ones among visited (all, after pass 0)
+                uint64_t fo = 0, ft = 0, ff = 0, fc[5] = {0, 0, 0, 0, 0};      // ones among not-yet-visited (pass 0)
+                uint32_t e[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) e[q] = e0[q];
+                for (int r0 = 0; r0 < rounds; r0 += 8) {
+                    uint32_t nxt[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        const int64_t at = p0 + (int64_t)(2 + r0 + 8 + q) * kWave;
+                        nxt[q] = at < p1 ? (uint32_t)data[at + lane] : (uint32_t)N;
+                    }
+                    uint64_t d[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) d[q] = words[e[q] & M31];
+                    if (pass0) {
+                        uint64_t dv[8], df[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const uint64_t fm = 0ull - (uint64_t)(e[q] >> 31);
+                            df[q] = d[q] & fm;
+                            dv[q] = d[q] & ~fm;
+                        }
+                        lv_add8(dv, vo, vt, vf, vc);
+                        lv_add8(df, fo, ft, ff, fc);
+                    } else {
+                        lv_add8(d, vo, vt, vf, vc);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) e[q] = nxt[q];
+                }
+                uint64_t pl[9] = {vo, vt, vf, vc[0], vc[1], vc[2], vc[3], vc[4], 0};
+                if (pass0) {   // C = cV + 2 cF, plane by plane
+                    const uint64_t fp[8] = {fo, ft, ff, fc[0], fc[1], fc[2], fc[3], fc[4]};
+                    uint64_t carry = 0;
+#pragma unroll
+                    for (int p = 1; p < 9; ++p) csa(carry, pl[p], pl[p], fp[p - 1], carry);
+                }
+                uint64_t lt, eq;
+                if (rounds < 8) lv_cmp<5>(pl, K, lt, eq);          // degrees <= 7: C <= 14
+                else lv_cmp<9>(pl, K, lt, eq);                     // degrees <= 64: C <= 128
+                const uint64_t nw = lt | (eq & tie & coin_word(cnt, pos));
+                if (node < (uint32_t)N) words[node] = nw;
+            } else {
+                // ---- one node of high degree, lane = neighbour
+                const uint32_t g0 = (uint32_t)__builtin_amdgcn_readlane((int)h0, 0);
+                const uint32_t g1 = (uint32_t)__builtin_amdgcn_readlane((int)h1, 0);
+                const uint32_t node = g0 & 0xFFFFFu, pos = g1 & 0xFFFFFu;
+                const uint32_t K = pass0 ? ((g1 >> 20) & 0x7FFu) : ((g0 >> 20) & 0x7FFu);
+                const bool tie = (pass0 ? g1 : g0) >> 31;
+                uint64_t cv[5] = {0, 0, 0, 0, 0}, cf[5] = {0, 0, 0, 0, 0};     // per-lane counts over <= 16 rounds
+                auto hub_add = [&](uint32_t en) {
+                    const uint64_t d = words[en & M31];
+                    const uint64_t fm = pass0 ? 0ull - (uint64_t)(en >> 31) : 0ull;
+                    uint64_t carry = d & ~fm;
+#pragma unroll
+                    for (int p = 0; p < 5; ++p) { const uint64_t t = cv[p] & carry; cv[p] ^= carry; carry = t; }
+                    carry = d & fm;
+#pragma unroll
+                    for (int p = 0; p < 5; ++p) { const uint64_t t = cf[p] & carry; cf[p] ^= carry; carry = t; }
+                };
+#pragma unroll
+                for (int q = 0; q < 8; ++q) hub_add(e0[q]);            // rounds past the end were prefetched as N (word 0)
+                for (int r = 8; r < rounds; ++r) hub_add((uint32_t)data[p0 + (int64_t)(2 + r) * kWave + lane]);
+                int cV = 0, cF = 0;                                           // now lane = chain
+#pragma unroll
+                for (int p = 0; p < 5; ++p) {
+                    uint32_t r0 = (uint32_t)cv[p], r1 = (uint32_t)(cv[p] >> 32);
+                    bit_transpose64(r0, r1, xc);
+                    cV += (__builtin_popcount(r0) + __builtin_popcount(r1)) << p;
+                }
+                if (pass0) {
+#pragma unroll
+                    for (int p = 0; p < 5; ++p) {
+                        uint32_t r0 = (uint32_t)cf[p], r1 = (uint32_t)(cf[p] >> 32);
+                        bit_transpose64(r0, r1, xc);
+                        cF += (__builtin_popcount(r0) + __builtin_popcount(r1)) << p;
+                    }
+                }
+                const uint32_t Cc = (uint32_t)(cV + 2 * cF);
+                const uint64_t coin = coin_word(cnt, pos);
+                const bool bit = (Cc < K) || (Cc == K && tie && ((coin >> lane) & 1ull));
+                const uint64_t nw = ballot64(bit);
+                if (lane == 0) words[node] = nw;
+            }
+            mine += W;
+            prefetch(mine);
+        }
+    }
+    __syncthreads();
+    // K8: expected[c] = sum_e (2x_u - 1)(2x_v - 1) = E - 2 * cut
+    const int64_t cut = block_sum_partials<W>(tile_cut_count<P>(words, eu, ev, E, lane, w, W), scratch, lane, w);
+    if (valid) {
+        if (w == 0) expected[c] = (float)(E - 2 * cut);
+        const int half = lane >> 5, sh = lane & 31;
+        for (int64_t n = w; n < N; n += W) xs_out[n * C + c] = (float)((w32[(n << 1) + half] >> sh) & 1u);
+    }
+}
+
 // best-of-repeats: index = argmin_r expected[r*M + m] (first on ties); column gather
 __global__ void k_mcpg_pick_best(const float* __restrict__ expected, const float* __restrict__ xs, int64_t N,
                                  int64_t M, int64_t R, float num_edges, int64_t* __restrict__ best_index,
@@ -377,6 +574,45 @@ int rls_mcpg_metro_rounds(void* samples, int spin_bytes, int64_t N, int64_t C, c
     else                 { if (probs_lds) LAUNCH_METRO(float, true);   else LAUNCH_METRO(float, false); }
 #undef LAUNCH_METRO
     return check_launch("k_mcpg_metro");
+}
+
+int rls_mcpg_local_search_levels(const rls_graph* g, const void* xs_in, int spin_bytes, float* xs_out, int64_t C,
+                                 const int32_t* lv_ptr, const int32_t* lv_data, int64_t num_groups, int64_t num_ls,
+                                 const uint64_t* coins, uint64_t seed, float* expected, void* stream) {
+    if (int rc = check_graph(g)) return rc;
+    RLS_REQUIRE(C >= 0 && num_ls >= 0 && num_groups > 0, RLS_EINVAL, "bad sizes");
+    if (C == 0) return RLS_OK;
+    RLS_REQUIRE(xs_in && xs_out && lv_ptr && lv_data && expected, RLS_EINVAL, "NULL pointer");
+    RLS_REQUIRE(spin_bytes == 1 || spin_bytes == 4, RLS_EINVAL, "spin_bytes must be 1 or 4");
+    const int64_t N = g->num_nodes, E = g->num_stored_edges;
+    RLS_REQUIRE(N < (1 << 20) && g->max_degree < 1024 && !g->wgt, RLS_EUNSUPPORTED,
+                "level-parallel K7 needs an unweighted graph, N < 2^20, degrees < 1024");
+    const int P = pick_planes(E);
+    RLS_REQUIRE(P != 0, RLS_EUNSUPPORTED, "E=%lld too large", (long long)E);
+    const size_t lds = (size_t)(N + 2) * 8 + (((size_t)(num_groups + 1) * 4 + 15) & ~(size_t)15) + (size_t)kLvWaves * kWave * 8;
+    RLS_REQUIRE(lds <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS (max %d)", (long long)N, lds,
+                kLdsBytes);
+    const dim3 grid((unsigned)ceil_div(C, kWave)), block(kLvWaves * kWave);
+    hipStream_t s = as_stream(stream);
+#define LAUNCH_LVL(TI, PP)                                                                                      \
+    do {                                                                                                        \
+        auto kern = k_mcpg_local_search_levels<TI, PP>;                                                         \
+        if (lds > 64 * 1024)                                                                                    \
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(kern, grid, block, lds, s, (const TI*)xs_in, xs_out, N, C, lv_ptr, lv_data, num_groups, \
+                           num_ls, coins, seed, g->eu, g->ev, E, expected);                                      \
+    } while (0)
+#define DISPATCH_LVL(TI)                      \
+    switch (P) {                              \
+        case 12: LAUNCH_LVL(TI, 12); break;   \
+        case 16: LAUNCH_LVL(TI, 16); break;   \
+        case 20: LAUNCH_LVL(TI, 20); break;   \
+        default: LAUNCH_LVL(TI, 24); break;   \
+    }
+    if (spin_bytes == 1) { DISPATCH_LVL(uint8_t) } else { DISPATCH_LVL(float) }
+#undef DISPATCH_LVL
+#undef LAUNCH_LVL
+    return check_launch("k_mcpg_local_search_levels");
 }
 
 int rls_mcpg_local_search(const rls_graph* g, const void* xs_in, int spin_bytes, float* xs_out, int64_t C,

@@ -51,7 +51,31 @@ def make_data(num_nodes: int, eu, ev, device, sorted_degree_nodes=None):
     data.graph = ops.DeviceGraph(csr, device)
     data._order_i32 = data.sorted_degree_nodes.to(device=device, dtype=torch.int32).contiguous()
     data._visit_stream = torch.from_numpy(build_visit_stream(csr, data.sorted_degree_nodes.cpu().numpy())).to(device)
+    lv = build_visit_levels(csr, data.sorted_degree_nodes.cpu().numpy())
+    data._lv_ptr, data._lv_data = (None, None) if lv is None else (torch.from_numpy(lv[0]).to(device),
+                                                                  torch.from_numpy(lv[1]).to(device))
     return data
+
+
+def build_visit_levels(csr, order: np.ndarray):
+    """Level-parallel (lane = node) form of the visiting order for the production K7 kernel
+    (include/rlsolver_hip.h: rls_mcpg_visit_levels).  None when the graph is outside its limits."""
+    import ctypes as C
+    from .. import _abi
+    n = csr.num_nodes
+    if n >= (1 << 20) or csr.max_degree >= 1024:
+        return None
+    rp = np.ascontiguousarray(csr.rowptr, dtype=np.int32)
+    col = np.ascontiguousarray(csr.col, dtype=np.int32)
+    od = np.ascontiguousarray(order, dtype=np.int32)
+    a = (rp.ctypes.data_as(C.c_void_p), col.ctypes.data_as(C.c_void_p), n, od.ctypes.data_as(C.c_void_p))
+    ng, tot = C.c_int64(0), C.c_int64(0)
+    _abi.call("rls_mcpg_visit_levels", *a, None, 0, None, 0, C.byref(ng), C.byref(tot))
+    lvp = np.empty(int(ng.value) + 1, dtype=np.int32)
+    lvd = np.empty(max(int(tot.value), 1), dtype=np.int32)
+    _abi.call("rls_mcpg_visit_levels", *a, lvp.ctypes.data_as(C.c_void_p), lvp.size, lvd.ctypes.data_as(C.c_void_p),
+              lvd.size, C.byref(ng), C.byref(tot))
+    return lvp, lvd
 
 
 def build_visit_stream(csr, order: np.ndarray, max_nodes: int = 32, max_entries: int = 400) -> np.ndarray:
@@ -161,8 +185,12 @@ def sampler_func(data, xs_sample: TEN, num_ls: int, total_mcmc_num: int, repeat_
     repeats.  ``uniforms`` f32 [num_ls, N, C] replaces torch.rand (test hook)."""
     xs_sample = xs_sample.contiguous()
     seed = _seed_from_torch() if uniforms is None else 0
-    xs_loc, expected = mops.mcpg_local_search(data.graph, xs_sample, data._order_i32, num_ls, uniforms, seed,
-                                              visit_stream=getattr(data, '_visit_stream', None))
+    if uniforms is None and getattr(data, '_lv_ptr', None) is not None and xs_sample.shape[0] * 8 + 8192 < 150 * 1024:
+        # production path: level-parallel kernel (the draws only ever decide ties, so it carries coins, not uniforms)
+        xs_loc, expected = mops.mcpg_local_search_levels(data.graph, xs_sample, data._lv_ptr, data._lv_data, num_ls, seed)
+    else:
+        xs_loc, expected = mops.mcpg_local_search(data.graph, xs_sample, data._order_i32, num_ls, uniforms, seed,
+                                                  visit_stream=getattr(data, '_visit_stream', None))
     _, vs_good, xs_good = mops.mcpg_pick_best(expected, xs_loc, total_mcmc_num, repeat_times, data.num_edges)
     value = expected - expected.mean()
     return vs_good, xs_good, value

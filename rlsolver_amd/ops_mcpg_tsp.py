@@ -66,6 +66,27 @@ def mcpg_local_search(g: DeviceGraph, xs_in: TEN, order: TEN, num_ls: int, unifo
     return xs_out, expected
 
 
+def mcpg_local_search_levels(g: DeviceGraph, xs_in: TEN, lv_ptr: TEN, lv_data: TEN, num_ls: int, seed: int = 0,
+                             coins: Optional[TEN] = None):
+    """K7 + expected cut on the level-parallel schedule (rls_mcpg_visit_levels).  ``coins`` int64 (bit pattern of
+    uint64) [num_ls * N, ceil(C / 64)]: the tie coins "u < 1/2" -- test hook; None = counter hash keyed by seed.
+    Returns (xs_out f32 [N, C], expected f32 [C])."""
+    _check(xs_in, "xs_in", _NM_DTYPES, g.device)
+    if xs_in.dim() != 2 or xs_in.shape[0] != g.num_nodes:
+        raise ValueError(f"xs_in must be [{g.num_nodes}, C]")
+    Cc = xs_in.shape[1]
+    _check(lv_ptr, "lv_ptr", (torch.int32,), g.device)
+    _check(lv_data, "lv_data", (torch.int32,), g.device)
+    if coins is not None:
+        _check(coins, "coins", (torch.int64,), g.device, (num_ls * g.num_nodes, (Cc + 63) // 64))
+    xs_out = torch.empty((g.num_nodes, Cc), dtype=torch.float32, device=g.device)
+    expected = torch.empty(Cc, dtype=torch.float32, device=g.device)
+    _abi.call("rls_mcpg_local_search_levels", g.ref, _ptr(xs_in), 4 if xs_in.dtype == torch.float32 else 1, _ptr(xs_out),
+              Cc, _ptr(lv_ptr), _ptr(lv_data), lv_ptr.numel() - 1, num_ls, _ptr(coins), _u64(seed), _ptr(expected),
+              _stream(g.device))
+    return xs_out, expected
+
+
 def mcpg_pick_best(expected: TEN, xs: TEN, total_mcmc_num: int, repeat_times: int, num_edges: int):
     """K8 second half.  Returns (best_index int64 [M], vs_good f32 [M], xs_good f32 [N, M])."""
     _check(xs, "xs", (torch.float32,))

@@ -69,6 +69,39 @@ def test_mcpg_random_vs_oracle(n, m, M, R, num_ls):
     assert np.array_equal(xa.cpu().numpy(), x_all) and np.array_equal(ea.cpu().numpy(), exp_w)
 
 
+@pytest.mark.parametrize("kind,n,m,C,num_ls", [("gnm", 300, 1500, 100, 2), ("gnm", 2000, 19990, 130, 1), ("ba", 600, 5, 64, 3),
+                                                ("star", 400, 0, 70, 2), ("gnm", 64, 200, 1, 3)])
+def test_mcpg_level_parallel_kernel_vs_oracle(kind, n, m, C, num_ls):
+    """The production K7 kernel (lane = node on the level schedule, tie coins instead of uniforms) against the
+    oracle's sequential pass fed with uniforms of 0.25 / 0.75: away from 1/2 the reference's float rule
+    (s + u/4) < (deg + 1/4)/2 is exactly "2s < deg, or 2s == deg and u < 1/2"."""
+    from rlsolver_amd import graph as G
+    if kind == "gnm":
+        graph = gnm_arr(n, m, seed=7)
+    elif kind == "ba":
+        graph = np.asarray(G.generate_ba(n, m, seed=3), dtype=np.int64)        # hubs above 64: lane = neighbour groups
+    else:
+        graph = np.array([(0, j, 1) for j in range(1, 301)] + [(j, j + 1, 1) for j in range(1, n - 1)], dtype=np.int64)
+    ei = graph[:, :2].T.copy()
+    rng = np.random.RandomState(11)
+    deg = np.bincount(ei.reshape(-1), minlength=n)
+    order = np.argsort(-deg, kind="stable")
+    data = amcpg.make_data(n, ei[0], ei[1], DEV, sorted_degree_nodes=order)
+    assert data._lv_ptr is not None
+    xs0 = rng.randint(0, 2, size=(n, C)).astype(np.float32)
+    coin = rng.randint(0, 2, size=(num_ls, n, C)).astype(bool)                 # indexed [pass, visiting position, chain]
+    uni = np.where(coin, 0.25, 0.75).astype(np.float32)
+    _, _, _, x_all, exp_w = onp.sampler_func(ei, n, order, xs0, num_ls, C, 1, uni)
+    CB = (C + 63) // 64
+    bits = np.zeros((num_ls * n, CB * 64), dtype=np.uint64)
+    bits[:, :C] = coin.reshape(num_ls * n, C)
+    words = (bits.reshape(num_ls * n, CB, 64) << np.arange(64, dtype=np.uint64)).sum(axis=2, dtype=np.uint64)
+    xs_g, exp_g = mops.mcpg_local_search_levels(data.graph, dev(xs0), data._lv_ptr, data._lv_data, num_ls, 0,
+                                                coins=torch.from_numpy(words.view(np.int64)).to(DEV))
+    assert np.array_equal(xs_g.cpu().numpy(), x_all)
+    assert np.array_equal(exp_g.cpu().numpy(), exp_w)
+
+
 def test_mcpg_production_rng_is_distributionally_sane():
     n, m, C = 500, 3000, 4096
     graph = gnm_arr(n, m, seed=9)
