@@ -521,10 +521,10 @@ __global__ __launch_bounds__(kLvWaves * kWave) void k_mcpg_local_search_levels(
     }
 }
 
-// best-of-repeats: index = argmin_r expected[r*M + m] (first on ties); column gather
-__global__ void k_mcpg_pick_best(const float* __restrict__ expected, const float* __restrict__ xs, int64_t N,
-                                 int64_t M, int64_t R, float num_edges, int64_t* __restrict__ best_index,
-                                 float* __restrict__ vs_good, float* __restrict__ xs_good) {
+// best-of-repeats: index = argmin_r expected[r*M + m] (first on ties), then the column gather as its own
+// grid over (node, m) -- one thread per m walking all N rows took 5 ms at N = 10^4, three times the K7 kernel
+__global__ void k_mcpg_pick_argmin(const float* __restrict__ expected, int64_t M, int64_t R, float num_edges,
+                                   int64_t* __restrict__ best_index, float* __restrict__ vs_good) {
     const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;
     float best = expected[m];
@@ -533,11 +533,16 @@ __global__ void k_mcpg_pick_best(const float* __restrict__ expected, const float
         const float v = expected[r * M + m];
         if (v < best) { best = v; br = r; }
     }
-    const int64_t idx = m + br * M;
-    best_index[m] = idx;
+    best_index[m] = m + br * M;
     vs_good[m] = (num_edges - best) / 2.0f;                                   // MCPG.py:160
-    const int64_t Ctot = M * R;
-    for (int64_t n = 0; n < N; ++n) xs_good[n * M + m] = xs[n * Ctot + idx];  // lanes = consecutive m: coalesced writes
+}
+
+__global__ void k_mcpg_pick_gather(const float* __restrict__ xs, int64_t N, int64_t M, int64_t Ctot,
+                                   const int64_t* __restrict__ best_index, float* __restrict__ xs_good) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // t = n * M + m: coalesced writes
+    if (t >= N * M) return;
+    const int64_t n = t / M, m = t - n * M;
+    xs_good[t] = xs[n * Ctot + best_index[m]];
 }
 
 }  // namespace rls
@@ -686,9 +691,10 @@ int rls_mcpg_pick_best(const float* expected, const float* xs, int64_t N, int64_
     RLS_REQUIRE(N > 0 && total_mcmc_num >= 0 && repeat_times > 0, RLS_EINVAL, "bad sizes");
     if (total_mcmc_num == 0) return RLS_OK;
     RLS_REQUIRE(expected && xs && best_index && vs_good && xs_good, RLS_EINVAL, "NULL pointer");
-    hipLaunchKernelGGL(k_mcpg_pick_best, dim3((unsigned)ceil_div(total_mcmc_num, 64)), dim3(64), 0,
-                       as_stream(stream), expected, xs, N, total_mcmc_num, repeat_times, (float)num_edges,
-                       best_index, vs_good, xs_good);
+    hipLaunchKernelGGL(k_mcpg_pick_argmin, dim3((unsigned)ceil_div(total_mcmc_num, 64)), dim3(64), 0,
+                       as_stream(stream), expected, total_mcmc_num, repeat_times, (float)num_edges, best_index, vs_good);
+    hipLaunchKernelGGL(k_mcpg_pick_gather, dim3(grid_for(N * total_mcmc_num, 256)), dim3(256), 0, as_stream(stream), xs,
+                       N, total_mcmc_num, total_mcmc_num * repeat_times, best_index, xs_good);
     return check_launch("k_mcpg_pick_best");
 }
 
