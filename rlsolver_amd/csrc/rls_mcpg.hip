@@ -56,7 +56,7 @@ __device__ __forceinline__ void tile_store_nodemajor(T* __restrict__ x, int64_t 
 }
 
 // ------------------------------------------------------------------------------------- K9
-constexpr int kMetroWaves = 4;
+constexpr int kMetroWaves = 16;   // the walk is one wave; the other 15 only move the tile (4 waves: 1.1 ms per 2.5 MB tile load)
 
 // murmur3's 32-bit finaliser: the counter-based generator of the production paths of K7 and K9 (two hashes
 // per draw pair instead of a 10-round Philox, which was 70 % of a K9 round on its single walking wave)
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(kK7Waves * kWave) void k_mcpg_local_search_stream(
 // (pass 0: visited and not-yet-visited neighbours counted apart, C = cV + 2 cF), a bit-sliced compare with the
 // per-node constant K and  new word = [C < K] | ([C == K] & tie & coin).  Nodes of degree > 64 get a group of
 // their own and the lanes share the NEIGHBOURS instead (per-lane counters, then transpose + popcount per plane).
-constexpr int kLvWaves = 8;
+constexpr int kLvWaves = 16;
 
 template <int NP>
 __device__ __forceinline__ void lv_cmp(const uint64_t (&pl)[9], uint32_t K, uint64_t& lt, uint64_t& eq) {
@@ -389,6 +389,7 @@ __global__ __launch_bounds__(kLvWaves * kWave) void k_mcpg_local_search_levels(
     const uint32_t blk_key = k7_fmix32((uint32_t)seed ^ k7_fmix32((uint32_t)(seed >> 32) ^
                                                                   k7_fmix32((uint32_t)blockIdx.x * 0x9E3779B1u + 0x632BE5ABu)));
     const BitXpose xc = bit_xpose_consts(lane);
+    __syncthreads();   // lvp and the tile are complete before any wave prefetches its first group
     auto coin_word = [&](int64_t cnt, uint32_t pos) -> uint64_t {   // bit e: "u < 1/2" for chain c0 + e at (pass, pos)
         if (coins) return coins[((int64_t)cnt * N + pos) * CB + blockIdx.x];
         const uint32_t k = blk_key ^ (pos * 0x9E3779B1u) ^ ((uint32_t)cnt * 0x7FEB352Du + 0x165667B1u);
