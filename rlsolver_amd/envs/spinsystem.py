@@ -131,7 +131,8 @@ class SpinSystem:
         self.graph = ops.DeviceGraph(csr, self.device, use_weights=True)
         wdeg = np.zeros(num_nodes, np.int64)
         np.add.at(wdeg, np.repeat(np.arange(num_nodes), np.diff(csr.rowptr)), csr.wgt)
-        self.max_local_reward_available_ = torch.full((num_envs,), float(wdeg.max()), device=self.device)
+        self._max_local = float(wdeg.max())              # host copy: reading it back from the device synced every step
+        self.max_local_reward_available_ = torch.full((num_envs,), self._max_local, device=self.device)
         if float(wdeg.max()) == 0.0 or np.abs(wdeg).sum() == 0:
             raise ValueError("empty graph / zero max local reward (the reference re-draws the graph here)")
         self.max_local_reward_available = self.max_local_reward_available_.unsqueeze(1).expand(-1, num_nodes)
@@ -210,11 +211,11 @@ class SpinSystem:
         B = self.num_envs
         action = action.to(device=self.device, dtype=torch.int64).contiguous()
         rew = torch.empty(B, dtype=torch.float32, device=self.device)
-        term = float(torch.max(torch.tensor(0.), torch.tensor((self.current_step - self.max_steps) /
-                                                              self.horizon_length) + 1))
+        # max(0, (current_step - max_steps) / horizon_length + 1), evaluated in f32 like the reference's torch ops
+        term = float(max(np.float32(0.0), np.float32((self.current_step - self.max_steps) / self.horizon_length) + np.float32(1)))
         _abi.call("rls_spin_step", self.graph.ref, _ptr(self.state), B, self.state.shape[1], self._rows,
                   _ptr(self._delta), _ptr(action), _ptr(self.score), _ptr(self.best_score), _ptr(self.best_spins),
-                  _ptr(rew), _ptr(self._num_nonpos), float(self.max_local_reward_available_[0]),
+                  _ptr(rew), _ptr(self._num_nonpos), self._max_local,
                   float(np.float32(1.0 / self.max_steps)), term, _REWARD_MODE[self.reward_signal],
                   float(self.n_spins) if self.norm_rewards else 1.0, _stream(self.device))
         if self.history_buffer is not None:
