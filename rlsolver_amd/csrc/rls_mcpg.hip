@@ -540,10 +540,10 @@ __global__ void k_mcpg_pick_argmin(const float* __restrict__ expected, int64_t M
 
 __global__ void k_mcpg_pick_gather(const float* __restrict__ xs, int64_t N, int64_t M, int64_t Ctot,
                                    const int64_t* __restrict__ best_index, float* __restrict__ xs_good) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;     // t = n * M + m: coalesced writes
-    if (t >= N * M) return;
-    const int64_t n = t / M, m = t - n * M;
-    xs_good[t] = xs[n * Ctot + best_index[m]];
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < N * M; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = t / M, m = t - n * M;                           // t = n * M + m: coalesced writes
+        xs_good[t] = xs[n * Ctot + best_index[m]];
+    }
 }
 
 }  // namespace rls

@@ -1,0 +1,148 @@
+"""Size-independent properties at BASELINE.json's full sizes (the oracle cannot reach them in seconds):
+G22-sized graph with 2^16 envs, G70-sized with one GPU's shard of 2^17, TSP-100 with 2^16 tours, BA n = 10^4
+with 2^16 chains.  Exact for integers; TSP within 1e-5 relative."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle_np as onp
+from rlsolver_amd import ops
+from rlsolver_amd import ops_mcpg_tsp as mops
+from rlsolver_amd.methods import MCPG as amcpg
+from tests.gpu_util import DEV, device_graph, gnm_arr
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch_cut(g, xs, rows):
+    sub = xs[rows]
+    return (sub[:, g.eu.long()] ^ sub[:, g.ev.long()]).sum(dim=1)
+
+
+@pytest.mark.parametrize("n,m,B", [(2000, 19990, 1 << 16), (10000, 9999, 1 << 17)])
+def test_gym_step_chain_keeps_objective_consistent(n, m, B):
+    graph = gnm_arr(n, m, seed=22 if n == 2000 else 70)
+    g = device_graph(graph, n, 0)
+    x = ops.rand_spins(B, n, 1, DEV)
+    y = torch.empty_like(x)
+    x0 = x.clone()
+    obj = ops.maxcut_obj(g, x).to(torch.int32)
+    obj0 = obj.clone()
+    reward = torch.empty(B, dtype=torch.float32, device=DEV)
+    total = torch.zeros(B, dtype=torch.float64, device=DEV)
+    acts = [ops.rand_actions(B, n, 9, t, DEV) for t in range(6)]
+    for a in acts:                                   # emit path: next state into the other buffer
+        ops.maxcut_step(g, x, y, a, obj, reward)
+        x, y = y, x
+        total += reward.double()
+    assert torch.equal(ops.maxcut_obj(g, x), obj.long())             # incremental == recomputed, every env
+    assert torch.equal(total.long(), (obj - obj0).long())            # rewards telescope
+    rows = torch.arange(0, B, 4099, device=DEV)
+    assert torch.equal(_torch_cut(g, x, rows), obj[rows].long())     # independent formulation on a sample
+    for a in reversed(acts):                         # in-place path undoes the same flips
+        ops.maxcut_step(g, x, x, a, obj, reward)
+    assert torch.equal(x, x0) and torch.equal(obj, obj0)
+    # the in-place and the emitting kernels agree
+    ops.maxcut_step(g, x, y, acts[0], obj, reward)
+    x2, obj2, r2 = x0.clone(), obj0.clone(), torch.empty_like(reward)
+    ops.maxcut_step(g, x2, x2, acts[0], obj2, r2)
+    assert torch.equal(y, x2) and torch.equal(obj, obj2) and torch.equal(reward, r2)
+
+
+def test_objective_sweep_and_proposals_at_full_size():
+    n, m, B = 2000, 19990, 1 << 16
+    graph = gnm_arr(n, m, seed=22)
+    g = device_graph(graph, n, 0)
+    x = ops.rand_spins(B, n, 3, DEV)
+    v = ops.maxcut_obj(g, x)
+    assert torch.equal(ops.maxcut_obj(g, ~x), v)                     # global spin flip
+    rows = torch.arange(0, B, 3001, device=DEV)
+    assert torch.equal(_torch_cut(g, x, rows), v[rows])
+    d = ops.maxcut_delta_all(g, x)                                   # flip gain of node 7 == objective difference
+    x7 = x.clone()
+    x7[:, 7] = ~x7[:, 7]
+    assert torch.equal(ops.maxcut_obj(g, x7) - v, d[:, 7].long())
+    assert torch.equal(ops.maxcut_node_cutdeg(g, x).sum(dim=1), v)   # stored edges counted once, at their first endpoint
+    # proposals: accepted rows take x ^ mask, the others stay; the value never drops
+    mask = torch.rand((B, n), device=DEV) < 0.004
+    xp, vp = x.clone(), v.clone()
+    ops.maxcut_propose_accept(g, xp, mask, vp)
+    took = (xp != x).any(dim=1)
+    assert (vp >= v).all() and torch.equal(ops.maxcut_obj(g, xp), vp)
+    assert torch.equal(xp[took], (x ^ mask)[took]) and torch.equal(vp[~took], v[~took])
+    # greedy sweep: value never drops, stays consistent, and a sweep of a sweep still never drops
+    xs, vs = x.clone(), v.clone()
+    ops.maxcut_greedy_sweep(g, xs, vs)
+    assert (vs >= v).all() and torch.equal(ops.maxcut_obj(g, xs), vs)
+    v1 = vs.clone()
+    ops.maxcut_greedy_sweep(g, xs, vs)
+    assert (vs >= v1).all() and torch.equal(ops.maxcut_obj(g, xs), vs)
+    # a small prefix of the batch gives the same rows as the full launch (different tile counts / kernels)
+    xq, vq = x[:200].clone(), v[:200].clone()
+    ops.maxcut_greedy_sweep(g, xq, vq)
+    xr, vr = x.clone(), v.clone()
+    ops.maxcut_greedy_sweep(g, xr, vr)
+    assert torch.equal(xq, xr[:200]) and torch.equal(vq, vr[:200])
+
+
+def test_local_search_inplace_at_dreinforce_batch():
+    from rlsolver_amd.envs.env_L2A import EnvMaxcut
+    n, m, B = 2000, 19990, 64 * 1024
+    graph = gnm_arr(n, m, seed=22)
+    env = EnvMaxcut(mygraph=[tuple(int(t) for t in r) for r in graph], device=DEV, num_nodes=n)
+    torch.manual_seed(0)
+    xs = env.generate_xs_randomly(B)
+    vs = env.calculate_obj_values(xs)
+    v0 = vs.clone()
+    env.local_search_inplace(xs, vs)
+    assert (vs >= v0).all() and torch.equal(env.calculate_obj_values(xs), vs)
+    assert float((vs - v0).float().mean()) > 0.05 * m               # it does search: > 5 % of m gained from random
+
+
+def test_tsp_lengths_and_swap_deltas_at_full_size():
+    from rlsolver_amd.graph import generate_tsp_coords, tsp_tables
+    N, B = 100, 1 << 16
+    dist, near, rnd = tsp_tables(generate_tsp_coords(N, seed=100), K=20)
+    d = torch.from_numpy(dist).to(DEV)
+    perms = mops.rand_perms(B, N, seed=5, device=DEV)
+    length = mops.tsp_tour_length(d, perms)
+    for other in (torch.roll(perms, 17, 1).contiguous(), torch.flip(perms, [1]).contiguous()):
+        torch.testing.assert_close(mops.tsp_tour_length(d, other), length, rtol=1e-5, atol=0)
+    rows = np.arange(0, B, 2111)
+    np.testing.assert_allclose(length[torch.from_numpy(rows).to(DEV)].cpu().numpy(),
+                               onp.tsp_tour_length_f64(dist, perms.cpu().numpy()[rows]), rtol=1e-5)
+    # partner city = the city 1..N-1 positions ahead; swap delta == length(after) - length(before)
+    off = torch.randint(1, N, (B, N), device=DEV)
+    sel = torch.gather(perms, 1, (torch.arange(N, device=DEV)[None, :] + off) % N)
+    temp = 0.5
+    lr, idx, ban = mops.tsp_swap_delta_all(d, perms, sel, temp)
+    pos = torch.argmin(ban.to(torch.uint8), dim=1)                  # first non-banned position of every tour
+    ok = ~ban[torch.arange(B, device=DEV), pos]
+    pos = torch.where(ok, pos, torch.full_like(pos, -1))
+    x = perms.clone()
+    mops.tsp_apply_swap(x, pos, idx)
+    after = mops.tsp_tour_length(d, x)
+    want = -lr[torch.arange(B, device=DEV), pos.clamp(min=0)] * temp
+    err = ((after - length) - want).abs()
+    assert bool((err[ok] <= 2e-5 * length[ok]).all()) and bool((x[~ok] == perms[~ok]).all())
+
+
+def test_mcpg_sampler_at_full_size():
+    from rlsolver_amd import graph as G
+    n, C, R = 10000, 1 << 16, 128
+    gb = np.asarray(G.generate_ba(n, 5, seed=5), dtype=np.int64)
+    ei = gb[:, :2].T.copy()
+    data = amcpg.make_data(n, ei[0], ei[1], DEV)
+    torch.manual_seed(3)
+    xs = (torch.rand((n, C), device=DEV) < 0.5).float()
+    vs_good, xs_good, value = amcpg.sampler_func(data, xs, 4, C // R, R, DEV)
+    # the reported value of every kept chain is the cut of the kept chain, and the local search beat random clearly
+    cut = ops.maxcut_obj(data.graph, (xs_good.t() > 0).contiguous())
+    assert torch.equal(cut.float(), vs_good)
+    assert float(vs_good.mean()) > 0.6 * data.num_edges
+    assert abs(float(value.mean())) < 1e-2
+    # metro sampling keeps a 0/1 state and respects the proposal budget per chain
+    probs = torch.full((n,), 0.5, device=DEV)
+    out = amcpg.metro_sampling(probs, torch.zeros((n, 4096), device=DEV), n // 10, device=DEV)
+    flips = out.sum(0)
+    assert bool(((out == 0) | (out == 1)).all()) and float(flips.max()) <= n // 10
