@@ -20,23 +20,30 @@
 
 namespace rls {
 
-// wave w of W transposes every W-th group of 64 nodes; 16 row loads are in flight per wave (the loop
+// wave w of W transposes every W-th group of 64 nodes; 32 row loads are in flight per wave (the loop
 // is latency-bound: each load is one coalesced 64-chain row segment)
 template <typename T>
 __device__ __forceinline__ void tile_load_bits_nodemajor(const T* __restrict__ x, int64_t N, int64_t C, int64_t c0,
                                                          uint64_t* __restrict__ words, int lane, int w = 0, int W = 1) {
     const int64_t c = c0 + lane;
     const bool valid = c < C;
+    const int64_t cc = valid ? c : C - 1;
+    constexpr int DEPTH = 32;   // row loads in flight per wave (256 B each): the loop is pure HBM latency
     for (int64_t n0 = (int64_t)w * kWave; n0 < N; n0 += (int64_t)W * kWave) {
         const int lim = (int)((N - n0) < kWave ? (N - n0) : kWave);
         uint64_t mine = 0;
-        for (int k0 = 0; k0 < lim; k0 += 16) {
-            T v[16];
+        for (int k0 = 0; k0 < lim; k0 += DEPTH) {
+            // clamped, unconditional loads (a guarded load per row makes hipcc wait for each one in turn); rows and
+            // chains past the end are masked after the fact
+            T v[DEPTH];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) v[q] = (valid && k0 + q < lim) ? x[(n0 + k0 + q) * C + c] : T(0);
+            for (int q = 0; q < DEPTH; ++q) {
+                const int64_t nn = (k0 + q < lim) ? n0 + k0 + q : N - 1;
+                v[q] = x[nn * C + cc];
+            }
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const uint64_t wd = ballot64(spin_is_set(v[q]));
+            for (int q = 0; q < DEPTH; ++q) {
+                const uint64_t wd = ballot64(valid && spin_is_set(v[q]));
                 if (lane == k0 + q) mine = wd;
             }
         }
