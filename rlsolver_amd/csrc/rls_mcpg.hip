@@ -645,8 +645,9 @@ int rls_mcpg_local_search(const rls_graph* g, const void* xs_in, int spin_bytes,
     const bool fast = visit_stream != nullptr && g->max_degree + 4 <= kRingMaxRun && lds_fast <= (size_t)kLdsBytes &&
                       (((uintptr_t)visit_stream) & 3) == 0;
     if (fast) {
-        RLS_REQUIRE(visit_len > g->nnz + 4 * N && visit_len <= g->nnz + 7 * N, RLS_EINVAL,
-                    "visit_len %lld is not a batched visit stream of this graph (nnz + 4N + 3*batches)",
+        // records nnz + 4N, one offset per node, 3 header words per batch (1 <= batches <= N)
+        RLS_REQUIRE(visit_len >= g->nnz + 5 * N + 3 && visit_len <= g->nnz + 8 * N, RLS_EINVAL,
+                    "visit_len %lld is not a batched visit stream of this graph (nnz + 5N + 3*batches)",
                     (long long)visit_len);
         const dim3 block(kK7Waves * kWave);
 #define LAUNCH_LSS(TI, PP)                                                                                           \

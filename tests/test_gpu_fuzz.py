@@ -118,3 +118,41 @@ def test_random_shapes_large_batch_paths(seed):
         sub = np.arange(0, B, 97)
         x_ref, v_ref = onp.greedy_sweep(xs[sub].astype(bool), want[sub].copy(), graph, bool(bidir))
         assert np.array_equal(xs_s.cpu().numpy()[sub], x_ref) and np.array_equal(vs_s.cpu().numpy()[sub], v_ref)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_mcpg_level_kernel_random_shapes(seed):
+    """Level-parallel K7 (lane = node groups, hub groups, tie coins) and the lane = chain stream kernel against the
+    oracle's sequential pass, on random graphs / chain counts / pass counts."""
+    from rlsolver_amd import ops_mcpg_tsp as mops
+    from rlsolver_amd.methods import MCPG as amcpg
+    rng = np.random.RandomState(9000 + seed)
+    n = int(rng.choice([2, 3, 17, 64, 65, 100, 129, 300]))
+    graph = _random_graph(rng, n)
+    if rng.randint(3) == 0 and n >= 100:                             # add a hub of degree > 64
+        hub = rng.randint(n)
+        extra = np.array([(min(hub, j), max(hub, j), 1) for j in rng.choice(n, size=min(n - 1, 90), replace=False) if j != hub])
+        graph = np.concatenate([graph, extra])
+    if len(graph) == 0:
+        pytest.skip("edgeless graph")
+    ei = graph[:, :2].T.copy()
+    C = int(rng.choice([1, 63, 64, 65, 130]))
+    num_ls = int(rng.randint(1, 4))
+    deg = np.bincount(ei.reshape(-1), minlength=n)
+    order = np.argsort(-deg, kind="stable")
+    data = amcpg.make_data(n, ei[0], ei[1], DEV, sorted_degree_nodes=order)
+    xs0 = rng.randint(0, 2, size=(n, C)).astype(np.float32)
+    coin = rng.randint(0, 2, size=(num_ls, n, C)).astype(bool)
+    uni = np.where(coin, 0.25, 0.75).astype(np.float32)
+    _, _, _, x_all, exp_w = onp.sampler_func(ei, n, order, xs0, num_ls, C, 1, uni)
+    CB = (C + 63) // 64
+    bits = np.zeros((num_ls * n, CB * 64), dtype=np.uint64)
+    bits[:, :C] = coin.reshape(num_ls * n, C)
+    words = (bits.reshape(num_ls * n, CB, 64) << np.arange(64, dtype=np.uint64)).sum(axis=2, dtype=np.uint64)
+    x0 = torch.from_numpy(xs0).to(DEV)
+    xs_g, exp_g = mops.mcpg_local_search_levels(data.graph, x0, data._lv_ptr, data._lv_data, num_ls, 0,
+                                                coins=torch.from_numpy(words.view(np.int64)).to(DEV))
+    assert np.array_equal(xs_g.cpu().numpy(), x_all) and np.array_equal(exp_g.cpu().numpy(), exp_w)
+    xs_s, exp_s = mops.mcpg_local_search(data.graph, x0, data._order_i32, num_ls, torch.from_numpy(uni).to(DEV), 0,
+                                         visit_stream=data._visit_stream)
+    assert np.array_equal(xs_s.cpu().numpy(), x_all) and np.array_equal(exp_s.cpu().numpy(), exp_w)
