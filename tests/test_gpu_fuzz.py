@@ -156,3 +156,28 @@ def test_mcpg_level_kernel_random_shapes(seed):
     xs_s, exp_s = mops.mcpg_local_search(data.graph, x0, data._order_i32, num_ls, torch.from_numpy(uni).to(DEV), 0,
                                          visit_stream=data._visit_stream)
     assert np.array_equal(xs_s.cpu().numpy(), x_all) and np.array_equal(exp_s.cpu().numpy(), exp_w)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_fused_local_search_random_shapes(seed):
+    """EnvMaxcut.local_search_inplace, fused kernel with supplied noise, against the oracle on random shapes."""
+    from rlsolver_amd.envs.env_L2A import EnvMaxcut
+    rng = np.random.RandomState(7000 + seed)
+    n = int(rng.choice([20, 33, 64, 100, 128, 130, 257]))
+    graph = _random_graph(rng, n)
+    graph = graph[np.unique(graph[:, :2], axis=0, return_index=True)[1]]      # simple graph: the env takes mygraph tuples
+    if len(graph) < 2:
+        pytest.skip("too few edges")
+    bidir = bool(rng.randint(2))
+    B = int(rng.choice([1, 7, 64, 65, 130]))
+    num_iters, num_spin = int(rng.randint(0, 5)), int(rng.randint(1, min(9, n - 1)))
+    env = EnvMaxcut(mygraph=[tuple(int(t) for t in r) for r in graph], device=DEV, if_bidirectional=bidir, num_nodes=n)
+    xs = rng.randint(0, 2, size=(B, n)).astype(bool)
+    noise = rng.randn(num_iters + 1, B, n).astype(np.float32)
+    x = torch.from_numpy(xs).to(DEV)
+    v = env.calculate_obj_values(x)
+    gx, gv = env.local_search_inplace(x, v.clone(), num_iters=num_iters, num_spin=num_spin, noise_std=0.3,
+                                      noise=torch.from_numpy(noise).to(DEV))
+    wx, wv = onp.local_search_inplace(xs.copy(), graph, n, bidir, noise, num_iters=num_iters, num_spin=num_spin,
+                                      noise_std=0.3)
+    assert np.array_equal(gv.cpu().numpy(), wv) and np.array_equal(gx.cpu().numpy(), wx)
