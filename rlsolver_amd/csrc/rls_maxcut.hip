@@ -412,7 +412,7 @@ __global__ __launch_bounds__(kTileWaves * kWave) void k_node_stats_tile(const ui
 // the four bytes of a dword) and every env's 64 consecutive results leave as ONE 256-byte store (the lane = env
 // form wrote 16 bytes per lane into 64 different rows).  out = cutdeg (int64) | deg - 2c (int32) | deg - mult c.
 // =====================================================================================
-constexpr int kNsWaves = 4;
+constexpr int kNsWaves = 8;
 
 template <int NP>
 __device__ __forceinline__ uint32_t ns_extract4(const uint64_t (&pl)[8], int half, int r) {
