@@ -7,11 +7,14 @@
 namespace rls {
 
 constexpr int kTileWaves = 4;   // waves cooperating on one 64-env tile (one per SIMD)
+constexpr int kTileWavesMax = 8;   // K1 / K6 take 8 when the tile is so large that only one workgroup fits a CU
+// waves per tile for a bit tile of N nodes: with one workgroup per CU, 4 waves cannot keep enough loads in flight
+static inline int tile_waves_for(int64_t N) { return (size_t)N * 8 + 4 * 4096 + 4096 > 80 * 1024 ? kTileWavesMax : kTileWaves; }
 
 // K1.  One workgroup = one 64-env tile, kTileWaves waves: they share the byte->bit transpose
 // (every wave sees all 64 envs, each takes every 4th column batch) and the edge blocks.
-template <typename T, bool VEC, int P>
-__global__ __launch_bounds__(kTileWaves * kWave) void k_maxcut_obj(const T* __restrict__ x, int64_t B, int64_t N,
+template <typename T, bool VEC, int P, int W>
+__global__ __launch_bounds__(W * kWave) void k_maxcut_obj(const T* __restrict__ x, int64_t B, int64_t N,
                                                                    const int32_t* __restrict__ eu,
                                                                    const int32_t* __restrict__ ev, int64_t E,
                                                                    int halve, int64_t* __restrict__ obj,
@@ -23,10 +26,10 @@ __global__ __launch_bounds__(kTileWaves * kWave) void k_maxcut_obj(const T* __re
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     const int64_t b0 = (int64_t)blockIdx.x * kWave;
     unsigned char* stage = stage_off >= 0 ? smem + stage_off + w * kStageBytes : nullptr;
-    tile_load_bits<T, VEC>(x, B, N, b0, words, lane, w, kTileWaves, stage);
+    tile_load_bits<T, VEC>(x, B, N, b0, words, lane, w, W, stage);
     __syncthreads();
-    const int64_t part = tile_cut_count<P>(words, eu, ev, E, lane, w, kTileWaves);
-    int64_t total = block_sum_partials<kTileWaves>(part, scratch, lane, w);
+    const int64_t part = tile_cut_count<P>(words, eu, ev, E, lane, w, W);
+    int64_t total = block_sum_partials<W>(part, scratch, lane, w);
     if (halve) total >>= 1;  // values // 2, env_L2A.py:65 (count is even and >= 0)
     if (w == 0 && b0 + lane < B) obj[b0 + lane] = total;
 }
@@ -91,8 +94,8 @@ __global__ __launch_bounds__((kPipeProd + kPipeCons) * kWave) void k_maxcut_obj_
 }
 
 // K6: proposal = x ^ mask for 64 envs; accept the row when its cut is >= the incumbent.
-template <bool VEC, int P>
-__global__ __launch_bounds__(kTileWaves * kWave) void k_maxcut_propose_accept(uint8_t* __restrict__ x,
+template <bool VEC, int P, int W>
+__global__ __launch_bounds__(W * kWave) void k_maxcut_propose_accept(uint8_t* __restrict__ x,
                                                                               const uint8_t* __restrict__ mask,
                                                                               int64_t B, int64_t N,
                                                                               const int32_t* __restrict__ eu,
@@ -108,18 +111,17 @@ __global__ __launch_bounds__(kTileWaves * kWave) void k_maxcut_propose_accept(ui
     unsigned char* stage = stage_off >= 0 ? smem + stage_off + w * kStageBytes : nullptr;
     // proposal = x ^ mask, built in ONE bit tile: the mask pass XORs into the words the x pass wrote (same lane of
     // the same wave owns a word in both passes); a second tile halved the workgroups per CU for N >= 5000
-    tile_load_bits<uint8_t, VEC>(x, B, N, b0, words, lane, w, kTileWaves, stage);
-    tile_load_bits<uint8_t, VEC, kStageDepth, true>(mask, B, N, b0, words, lane, w, kTileWaves, stage);
+    tile_load_bits<uint8_t, VEC>(x, B, N, b0, words, lane, w, W, stage);
+    tile_load_bits<uint8_t, VEC, kStageDepth, true>(mask, B, N, b0, words, lane, w, W, stage);
     __syncthreads();
-    int64_t total = block_sum_partials<kTileWaves>(tile_cut_count<P>(words, eu, ev, E, lane, w, kTileWaves),
-                                                   scratch, lane, w);
+    int64_t total = block_sum_partials<W>(tile_cut_count<P>(words, eu, ev, E, lane, w, W), scratch, lane, w);
     if (halve) total >>= 1;
     const int64_t b = b0 + lane;
     const bool accept = (b < B) && (total >= obj[b]);  // vs1.ge(vs0), util_read_data.py:199
     __syncthreads();                                   // every wave has read obj[b] before wave 0 updates it
     if (accept && w == 0) obj[b] = total;
     // accepted rows take the proposal (each wave writes a quarter of the columns); others are untouched
-    tile_store_bytes<VEC>(x, B, N, b0, words, lane, w, kTileWaves, accept, stage);
+    tile_store_bytes<VEC>(x, B, N, b0, words, lane, w, W, accept, stage);
 }
 
 // =====================================================================================
@@ -668,14 +670,15 @@ int rls_maxcut_obj(const rls_graph* g, const void* x, int spin_bytes, int64_t B,
     RLS_REQUIRE(x && obj, RLS_EINVAL, "x/obj is NULL");
     RLS_REQUIRE(spin_bytes == 1 || spin_bytes == 4, RLS_EINVAL, "spin_bytes must be 1 or 4");
     const int64_t N = g->num_nodes, E = g->num_stored_edges;
-    size_t lds = (size_t)N * 8 + (size_t)kTileWaves * kWave * 8;
+    const int tw = tile_waves_for(N);
+    size_t lds = (size_t)N * 8 + (size_t)tw * kWave * 8;
     RLS_REQUIRE(lds <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS per 64-env tile (max %d)",
                 (long long)N, lds, kLdsBytes);
     const int P = pick_planes(E);
     RLS_REQUIRE(P != 0, RLS_EUNSUPPORTED, "E'=%lld too large", (long long)E);
     const bool vec = tile_rows_aligned(x, N, spin_bytes);
-    const int stage_off = tile_stage_offset(&lds, kTileWaves, vec && spin_bytes == 1);
-    const dim3 grid((unsigned)ceil_div(B, kWave)), block(kTileWaves * kWave);
+    const int stage_off = tile_stage_offset(&lds, tw, vec && spin_bytes == 1);
+    const dim3 grid((unsigned)ceil_div(B, kWave)), block(tw * kWave);
     hipStream_t s = as_stream(stream);
     const int halve = g->if_bidirectional ? 1 : 0;
     {   // wave-specialised persistent variant: byte spins, aligned rows, two tiles + edges + stages fit in LDS
@@ -708,7 +711,7 @@ int rls_maxcut_obj(const rls_graph* g, const void* x, int spin_bytes, int64_t B,
     }
 #define LAUNCH_OBJ(T, VEC, PP)                                                                             \
     do {                                                                                                   \
-        auto kern = k_maxcut_obj<T, VEC, PP>;                                                              \
+        auto kern = tw == kTileWavesMax ? k_maxcut_obj<T, VEC, PP, kTileWavesMax> : k_maxcut_obj<T, VEC, PP, kTileWaves>; \
         if (lds > 64 * 1024)                                                                               \
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(kern, grid, block, lds, s, (const T*)x, B, N, g->eu, g->ev, E, halve, obj, stage_off); \
@@ -737,19 +740,21 @@ int rls_maxcut_propose_accept(const rls_graph* g, uint8_t* x, int64_t B, const u
     if (B == 0) return RLS_OK;
     RLS_REQUIRE(x && mask && obj, RLS_EINVAL, "x/mask/obj is NULL");
     const int64_t N = g->num_nodes, E = g->num_stored_edges;
-    size_t lds = (size_t)N * 8 + (size_t)kTileWaves * kWave * 8;
+    const int tw = tile_waves_for(N);
+    size_t lds = (size_t)N * 8 + (size_t)tw * kWave * 8;
     RLS_REQUIRE(lds <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS (max %d)", (long long)N, lds,
                 kLdsBytes);
     const int P = pick_planes(E);
     RLS_REQUIRE(P != 0, RLS_EUNSUPPORTED, "E'=%lld too large", (long long)E);
     const bool vec = tile_rows_aligned(x, N, 1) && tile_rows_aligned(mask, N, 1);
-    const int stage_off = tile_stage_offset(&lds, kTileWaves, vec);
-    const dim3 grid((unsigned)ceil_div(B, kWave)), block(kTileWaves * kWave);
+    const int stage_off = tile_stage_offset(&lds, tw, vec);
+    const dim3 grid((unsigned)ceil_div(B, kWave)), block(tw * kWave);
     hipStream_t s = as_stream(stream);
     const int halve = g->if_bidirectional ? 1 : 0;
 #define LAUNCH_PA(VEC, PP)                                                                                 \
     do {                                                                                                   \
-        auto kern = k_maxcut_propose_accept<VEC, PP>;                                                      \
+        auto kern = tw == kTileWavesMax ? k_maxcut_propose_accept<VEC, PP, kTileWavesMax>                 \
+                                        : k_maxcut_propose_accept<VEC, PP, kTileWaves>;                   \
         if (lds > 64 * 1024)                                                                               \
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(kern, grid, block, lds, s, x, mask, B, N, g->eu, g->ev, E, halve, obj, stage_off); \
