@@ -90,3 +90,33 @@ def test_k_spin_simulator_aliases(golden):
             assert np.array_equal(sim.calculate_obj_values_for_loop(xs, if_sum=False).cpu().numpy(), z[f"{t}/cutdeg"])
             sol = sim.generate_solutions_randomly(8)
             assert sol.shape == (8, sim.num_nodes) and not sol[:, 0].any()
+
+
+def test_rollout_captured_in_a_hipgraph_equals_eager():
+    """64 gym steps over two ping-pong state buffers as ONE graph launch (rlsolver_amd.hipgraph)."""
+    import numpy as np
+    from rlsolver_amd import ops
+    from rlsolver_amd.hipgraph import CapturedLaunches
+    from tests.gpu_util import device_graph, gnm_arr
+    n, m, B, T = 800, 4694, 256, 64
+    g = device_graph(gnm_arr(n, m, seed=14), n, 0)
+    x0 = ops.rand_spins(B, n, 3, DEV)
+    acts = torch.stack([ops.rand_actions(B, n, 5, t, DEV) for t in range(T)])
+    bufs = [x0.clone(), torch.empty_like(x0)]
+    obj0 = ops.maxcut_obj(g, x0).to(torch.int32)
+    obj, rew, tot = obj0.clone(), torch.empty(B, dtype=torch.float32, device=DEV), torch.zeros(B, device=DEV)
+
+    def rollout():
+        for t in range(T):
+            ops.maxcut_step(g, bufs[t & 1], bufs[(t + 1) & 1], acts[t], obj, rew)
+            tot.add_(rew)
+
+    rollout()                                            # eager reference
+    want_x, want_obj, want_tot = bufs[T & 1].clone(), obj.clone(), tot.clone()
+    cap = CapturedLaunches(rollout, DEV)                 # warm-up + capture ran the rollout twice more; reset, replay
+    for _ in range(2):
+        bufs[0].copy_(x0); obj.copy_(obj0); tot.zero_()
+        cap.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(bufs[T & 1], want_x) and torch.equal(obj, want_obj) and torch.equal(tot, want_tot)
+    assert torch.equal(ops.maxcut_obj(g, bufs[T & 1]), obj.long())

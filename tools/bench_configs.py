@@ -52,6 +52,17 @@ def maxcut_suite(tag, n, m, B, seed, iters):
     acts = [ops.rand_actions(B, n, 7, s, dev) for s in range(8)]
     t = timeit(lambda i: ops.maxcut_step(g, slots[i % S], slots[(i + 1) % S], acts[i % 8], obj, rew), iters)
     emit(tag, "K4 maxcut_step (emit)", "env-steps", B, t, 2 * n + 20)
+    if B <= 4096:   # launch-bound regime: the same steps captured as one hipGraph (rlsolver_amd.hipgraph)
+        from rlsolver_amd.hipgraph import CapturedLaunches
+        T = 64
+
+        def rollout():
+            for k in range(T):
+                ops.maxcut_step(g, slots[k % S], slots[(k + 1) % S], acts[k % 8], obj, rew)
+        cap = CapturedLaunches(rollout, dev)
+        tg = timeit(lambda i: cap.replay(), max(3, iters // 16)) / T
+        emit(tag, "K4 maxcut_step (emit), 64 steps per hipGraph replay", "env-steps", B, tg, 2 * n + 20,
+             "per-step time inside the graph")
     x = slots[0].clone()
     t = timeit(lambda i: ops.maxcut_step(g, x, x, acts[i % 8], obj, rew), iters)
     emit(tag, "K4 maxcut_step (in place)", "env-steps", B, t, None, "O(deg) bytes per step")
