@@ -11,8 +11,9 @@ constexpr int kTileWavesMax = 8;   // K1 / K6 take 8 when the tile is so large t
 // waves per tile for a bit tile of N nodes: with one workgroup per CU, 4 waves cannot keep enough loads in flight
 static inline int tile_waves_for(int64_t N) { return (size_t)N * 8 + 4 * 4096 + 4096 > 80 * 1024 ? kTileWavesMax : kTileWaves; }
 
-// K1.  One workgroup = one 64-env tile, kTileWaves waves: they share the byte->bit transpose
-// (every wave sees all 64 envs, each takes every 4th column batch) and the edge blocks.
+// K1.  One workgroup = one 64-env tile, W waves (4, or 8 for tiles that leave one workgroup per CU): they share
+// the tile load (rls_tile.h: row pieces -> corner turn -> pack -> 64x64 bit transpose; wave w takes every W-th
+// 64-node chunk) and the edge blocks of the bit-sliced count (rls_cutcount.h).
 template <typename T, bool VEC, int P, int W>
 __global__ __launch_bounds__(W * kWave) void k_maxcut_obj(const T* __restrict__ x, int64_t B, int64_t N,
                                                                    const int32_t* __restrict__ eu,
@@ -125,7 +126,11 @@ __global__ __launch_bounds__(W * kWave) void k_maxcut_propose_accept(uint8_t* __
 }
 
 // =====================================================================================
-// K5: greedy single-flip sweep.  One lane = one env, 64 envs per wave, state as a bit tile in LDS.
+// K5: greedy single-flip sweep.  Three forms, fastest first (the launcher picks; all bit-identical):
+//   k_maxcut_greedy_sweep_levels   lane = node, one pass per dependency level (rls_sweep.h: sweep_tile_levels)
+//   k_maxcut_greedy_sweep_batched  lane = env on the level schedule, one node per wave step (degrees >= 256)
+//   k_maxcut_greedy_sweep          lane = env, one wave, strictly sequential (no schedule), described here:
+// One lane = one env, 64 envs per wave, state as a bit tile in LDS.
 // For node i (sequential, as the reference's semantics demand) every lane counts the set spins
 // among i's neighbours in ITS env: the neighbour id is a broadcast LDS read from a ring of CSR
 // `col` entries, the neighbour's word a second broadcast read, the lane's bit a v_bfe.  Node i is
@@ -322,7 +327,8 @@ __global__ void k_delta_all(const uint8_t* __restrict__ x, int64_t B, int64_t N,
 }
 
 // =====================================================================================
-// K2 / K3 on a bit tile: per-node cut degree (int64, the env's stored adjacency) or flip gain
+// K2 / K3 on a bit tile, lane = env form (weighted graphs, degrees >= 256; k_node_stats_bits below is the
+// fast path): per-node cut degree (int64, the env's stored adjacency) or flip gain
 // (int32, symmetric CSR, optional weights) for all nodes of 64 envs.  Nodes are independent, so the
 // kTileWaves waves of the workgroup take alternating blocks of 128/sizeof(OutT) consecutive nodes;
 // each lane (= env) collects its block in an LDS staging row and writes it back as full 128-byte
