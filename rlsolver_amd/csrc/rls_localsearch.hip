@@ -72,12 +72,19 @@ __global__ __launch_bounds__(W * kWave) void k_maxcut_local_search(
     int64_t env_offset, int num_iters, int num_spin, int first_draw_proposes, int64_t* __restrict__ obj,
     int compute_obj, int batched) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // LDS: words | prop | [rp] | ring | scratch | [tops].  With 4 waves per tile (many tiles: occupancy matters) the
+    // sweep schedule offsets `rp` live in `prop` (proposals are over when the sweep starts) and the top-k merge
+    // buffer in the ring (idle between the threshold pass and the first proposal round): 50 KB for G22, three
+    // workgroups per CU instead of two.  With 8 waves per tile (few tiles) waves 4..7 stage in `tops`.
+    constexpr bool COMPACT = (W == kLsMergeWaves);
     uint64_t* words = reinterpret_cast<uint64_t*>(smem);
     uint64_t* prop = words + (N + 2);
-    int32_t* rp = reinterpret_cast<int32_t*>(prop + N);
-    int32_t* ring = rp + ((N + 1 + 3) & ~3ll);
+    int32_t* rp = COMPACT ? reinterpret_cast<int32_t*>(prop) : reinterpret_cast<int32_t*>(prop + N);
+    int32_t* ring = COMPACT ? reinterpret_cast<int32_t*>(prop + N) : rp + ((N + 1 + 3) & ~3ll);
     int64_t* scratch = reinterpret_cast<int64_t*>(ring + kRing);
-    float* tops = reinterpret_cast<float*>(scratch + W * kWave);   // [kLsMergeWaves][kTopCap][64]
+    float* tops = COMPACT ? reinterpret_cast<float*>(ring)
+                          : reinterpret_cast<float*>(scratch + W * kWave);   // [kLsMergeWaves][kTopCap][64]
+    static_assert(kRing * 4 >= kLsMergeWaves * kTopCap * kWave * 4, "the ring holds the merge buffer");
     const int lane = threadIdx.x & (kWave - 1);
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     const int64_t b0 = (int64_t)blockIdx.x * kWave;
@@ -90,11 +97,12 @@ __global__ __launch_bounds__(W * kWave) void k_maxcut_local_search(
     // ---- phase 0
     if (threadIdx.x == 0) words[N] = 0;
     // rp: CSR rowptr / schedule offsets (N + 1 entries), or the level-group offsets (sweep_len + 1 <= N + 1 entries)
-    for (int64_t i = threadIdx.x; i <= (batched == 2 ? sweep_len : N); i += W * kWave) rp[i] = rowptr[i];
+    if constexpr (!COMPACT)
+        for (int64_t i = threadIdx.x; i <= (batched == 2 ? sweep_len : N); i += W * kWave) rp[i] = rowptr[i];
     // the ring is idle outside the sweep: it doubles as the row-piece stage of the tile load / store
     // waves 0..3 stage in the ring, waves 4..7 in the top-k merge buffer (free until the merge, see the barrier there)
     static_assert(kRing * 4 >= kLsMergeWaves * kStageBytes && kLsMergeWaves * kTopCap * kWave * 4 >= (W - kLsMergeWaves) * kStageBytes,
-                  "ring + merge buffer double as the row-piece stages");
+                  "ring (+ merge buffer for waves 4..7) double as the row-piece stages");
     unsigned char* wstage = (w < kLsMergeWaves ? reinterpret_cast<unsigned char*>(ring) + w * kStageBytes
                                                : reinterpret_cast<unsigned char*>(tops) + (w - kLsMergeWaves) * kStageBytes);
     unsigned char* stage = VEC ? wstage : nullptr;
@@ -286,6 +294,10 @@ __global__ __launch_bounds__(W * kWave) void k_maxcut_local_search(
         __syncthreads();
     }
     // ---- phase 3: greedy sweep on the resident tile
+    if constexpr (COMPACT) {   // the schedule offsets move into `prop` now that the proposals are over
+        for (int64_t i = threadIdx.x; i <= (batched == 2 ? sweep_len : N); i += W * kWave) rp[i] = rowptr[i];
+        __syncthreads();
+    }
     if (batched == 2) {   // level-parallel (lane = node): sweep_src = group records, sweep_len = number of groups
         const int64_t before = block_sum_partials<W>(tile_cut_count<P>(words, eu, ev, E, lane, w, W), scratch, lane, w);
         __syncthreads();
@@ -329,8 +341,10 @@ extern "C" int rls_maxcut_local_search(const rls_graph* g, uint8_t* x, int64_t B
     // with one wave per SIMD; many tiles: 4 waves per tile and two tiles per CU
     static const int force_w = getenv("RLS_LS_WAVES") ? atoi(getenv("RLS_LS_WAVES")) : 0;   // dev knob
     const int W = force_w == 4 || force_w == 8 ? force_w : (ceil_div(B, kWave) <= 2 * (int64_t)num_cus() ? 8 : 4);
-    const size_t lds = (size_t)(N + 2) * 8 + (size_t)N * 8 + (size_t)((N + 1 + 3) & ~3ll) * 4 + (size_t)kRing * 4 +
-                       (size_t)W * kWave * 8 + (size_t)kLsMergeWaves * kTopCap * kWave * 4;
+    const size_t lds = W == kLsMergeWaves
+                           ? (size_t)(N + 2) * 8 + (size_t)N * 8 + (size_t)kRing * 4 + (size_t)W * kWave * 8
+                           : (size_t)(N + 2) * 8 + (size_t)N * 8 + (size_t)((N + 1 + 3) & ~3ll) * 4 + (size_t)kRing * 4 +
+                                 (size_t)W * kWave * 8 + (size_t)kLsMergeWaves * kTopCap * kWave * 4;
     RLS_REQUIRE(lds <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS (max %d)", (long long)N, lds,
                 kLdsBytes);
     const int P = pick_planes(E);
