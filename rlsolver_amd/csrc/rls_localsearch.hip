@@ -84,6 +84,9 @@ __global__ __launch_bounds__(W * kWave) void k_maxcut_local_search(
     int64_t* scratch = reinterpret_cast<int64_t*>(ring + kRing);
     float* tops = COMPACT ? reinterpret_cast<float*>(ring)
                           : reinterpret_cast<float*>(scratch + W * kWave);   // [kLsMergeWaves][kTopCap][64]
+    // rd_std [N] in LDS: read per quad as one broadcast ds_read_b128 (kept in SGPRs a trip ahead it cost 64 scalar
+    // registers and pushed the kernel to ~200 SGPR spills)
+    float* sdl = COMPACT ? reinterpret_cast<float*>(scratch + W * kWave) : tops + kLsMergeWaves * kTopCap * kWave;
     static_assert(kRing * 4 >= kLsMergeWaves * kTopCap * kWave * 4, "the ring holds the merge buffer");
     const int lane = threadIdx.x & (kWave - 1);
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
@@ -106,6 +109,7 @@ __global__ __launch_bounds__(W * kWave) void k_maxcut_local_search(
     unsigned char* wstage = (w < kLsMergeWaves ? reinterpret_cast<unsigned char*>(ring) + w * kStageBytes
                                                : reinterpret_cast<unsigned char*>(tops) + (w - kLsMergeWaves) * kStageBytes);
     unsigned char* stage = VEC ? wstage : nullptr;
+    for (int64_t i = threadIdx.x; i < ((N + 3) & ~3ll); i += W * kWave) sdl[i] = i < N ? rd_std[i] : 0.0f;
     tile_load_bits<uint8_t, VEC>(x, B, N, b0, words, lane, w, W, stage);
     __syncthreads();
     int64_t my_obj;
@@ -127,24 +131,13 @@ __global__ __launch_bounds__(W * kWave) void k_maxcut_local_search(
     // cache lines per instruction and every trip waited a full memory round trip: 120 us per round).
     int io_r, io_j;
     stage_io_lane(lane, io_r, io_j);
-    auto issue = [&](int64_t c0, i32x4 (&g)[D][4], f32x4 (&sd)[D][4]) {
+    auto issue = [&](int64_t c0, i32x4 (&g)[D][4]) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             const int64_t c = c0 + (int64_t)d * W;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 g[d][i] = i32x4{0, 0, 0, 0};
-                sd[d][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-                {   // rd_std of quad 4c + i: wave-uniform address (scalar loads), fetched a trip ahead like ws
-                    const int64_t q = c * 4 + i;
-                    if constexpr (V4) {
-                        if (q < nquads) sd[d][i] = *reinterpret_cast<const f32x4*>(rd_std + q * 4);
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            if (q * 4 + k < N) sd[d][i][k] = rd_std[q * 4 + k];
-                    }
-                }
                 if constexpr (V4) {
                     const int64_t rw = b0 + kStageRows * i + io_r;
                     const int64_t q = c * 4 + io_j;
@@ -174,7 +167,8 @@ __global__ __launch_bounds__(W * kWave) void k_maxcut_local_search(
         }
     };
     // spin_rand of quad q: v[k] = (float)ws + noise * rd_std
-    auto spin_rand_quad = [&](int64_t q, int it, const i32x4& wq, const f32x4& sdq, float (&v)[4]) {
+    auto spin_rand_quad = [&](int64_t q, int it, const i32x4& wq, float (&v)[4]) {
+        const f32x4 sdq = *reinterpret_cast<const f32x4*>(sdl + q * 4);   // wave-uniform address: broadcast read
         float z[4] = {0.f, 0.f, 0.f, 0.f};
         if (noise) {
             if (valid && q < nquads) {
@@ -197,10 +191,9 @@ __global__ __launch_bounds__(W * kWave) void k_maxcut_local_search(
     // one pass over the tile's ws: f(q, v) for every quad q of this wave's chunks
     auto for_each_quad = [&](int it, auto&& f) {
         i32x4 ga[D][4], gb[D][4];
-        f32x4 sa[D][4], sb[D][4];
-        issue(w, ga, sa);
+        issue(w, ga);
         for (int64_t c0 = w; c0 < nchunks; c0 += (int64_t)D * W) {
-            issue(c0 + (int64_t)D * W, gb, sb);
+            issue(c0 + (int64_t)D * W, gb);
 #pragma unroll
             for (int d = 0; d < D; ++d) {
                 const int64_t c = c0 + (int64_t)d * W;
@@ -212,7 +205,7 @@ __global__ __launch_bounds__(W * kWave) void k_maxcut_local_search(
                         const int64_t q = c * 4 + i;
                         if (q < nquads) {
                             float v[4];
-                            spin_rand_quad(q, it, wq[i], sa[d][i], v);
+                            spin_rand_quad(q, it, wq[i], v);
                             f(q, v);
                         }
                     }
@@ -221,7 +214,7 @@ __global__ __launch_bounds__(W * kWave) void k_maxcut_local_search(
 #pragma unroll
             for (int d = 0; d < D; ++d)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { ga[d][i] = gb[d][i]; sa[d][i] = sb[d][i]; }
+                for (int i = 0; i < 4; ++i) ga[d][i] = gb[d][i];
         }
     };
     // ---- phase 1: threshold = (num_spin + 1)-th largest of the first draw
@@ -341,10 +334,11 @@ extern "C" int rls_maxcut_local_search(const rls_graph* g, uint8_t* x, int64_t B
     // with one wave per SIMD; many tiles: 4 waves per tile and two tiles per CU
     static const int force_w = getenv("RLS_LS_WAVES") ? atoi(getenv("RLS_LS_WAVES")) : 0;   // dev knob
     const int W = force_w == 4 || force_w == 8 ? force_w : (ceil_div(B, kWave) <= 2 * (int64_t)num_cus() ? 8 : 4);
-    const size_t lds = W == kLsMergeWaves
+    const size_t sd_bytes = (size_t)((N + 3) & ~3ll) * 4;   // rd_std in LDS
+    const size_t lds = sd_bytes + (W == kLsMergeWaves
                            ? (size_t)(N + 2) * 8 + (size_t)N * 8 + (size_t)kRing * 4 + (size_t)W * kWave * 8
                            : (size_t)(N + 2) * 8 + (size_t)N * 8 + (size_t)((N + 1 + 3) & ~3ll) * 4 + (size_t)kRing * 4 +
-                                 (size_t)W * kWave * 8 + (size_t)kLsMergeWaves * kTopCap * kWave * 4;
+                                 (size_t)W * kWave * 8 + (size_t)kLsMergeWaves * kTopCap * kWave * 4);
     RLS_REQUIRE(lds <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS (max %d)", (long long)N, lds,
                 kLdsBytes);
     const int P = pick_planes(E);
