@@ -52,6 +52,11 @@ def maxcut_suite(tag, n, m, B, seed, iters):
     acts = [ops.rand_actions(B, n, 7, s, dev) for s in range(8)]
     t = timeit(lambda i: ops.maxcut_step(g, slots[i % S], slots[(i + 1) % S], acts[i % 8], obj, rew), iters)
     emit(tag, "K4 maxcut_step (emit)", "env-steps", B, t, 2 * n + 20)
+    if B * n * 4 * 6 < 40e9:   # gym surface (env_PPO keeps f32 spins): its own label, 2*4N + 20 bytes per env-step
+        fs = [sl.float() for sl in slots] + [slots[0].float(), slots[1].float()]
+        tf = timeit(lambda i: ops.maxcut_step(g, fs[i % 6], fs[(i + 1) % 6], acts[i % 8], obj, rew), max(5, iters // 2))
+        emit(tag, "K4 maxcut_step (emit, f32 gym surface)", "env-steps", B, tf, 8 * n + 20)
+        del fs
     if B <= 4096:   # launch-bound regime: the same steps captured as one hipGraph (rlsolver_amd.hipgraph)
         from rlsolver_amd.hipgraph import CapturedLaunches
         T = 64
