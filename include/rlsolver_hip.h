@@ -258,15 +258,17 @@ int rls_spin_step(const rls_graph* g, float* state, int64_t B, int32_t num_rows,
  * indexed by the absolute round t; test mode) or both NULL for the in-kernel counter-based generator
  * (murmur3 finaliser) keyed by (seed, chain, t).
  * The reference stops after the first round whose cumulative accept count reaches C*T_transfer
+ * samples_in (same dtype, may be NULL = samples) is where the chains are READ; they are written to samples:
+ * the first chunk of a call turns the caller's start state into the result buffer without a copy.
  * (one host sync per round there).  Here the caller walks the 5*T_transfer rounds in chunks: a dry
  * call (write_back = 0) fills accepts[T] (int64, zeroed by the caller), the stop round is derived
  * on the device, a second call with t_limit_dev pointing at it (device int64) and write_back = 1
  * applies the chunk; *t_limit_dev <= 0 makes a call return immediately, so chunks after the stop
  * round cost one empty launch.  t_limit_dev NULL = all T rounds.  samples is updated in place only
  * when write_back != 0. */
-int rls_mcpg_metro_rounds(void* samples, int spin_bytes, int64_t N, int64_t C, const float* probs,
-                          int64_t T, int64_t t_offset, const int64_t* index, const float* u, uint64_t seed,
-                          const int64_t* t_limit_dev, int write_back, int64_t* accepts, void* stream);
+int rls_mcpg_metro_rounds(void* samples, const void* samples_in, int spin_bytes, int64_t N, int64_t C,
+                          const float* probs, int64_t T, int64_t t_offset, const int64_t* index, const float* u,
+                          uint64_t seed, const int64_t* t_limit_dev, int write_back, int64_t* accepts, void* stream);
 
 /* K7 + K8 first half  sampler_func  methods/MCPG.py:128-152.
  * xs_in [N,C] holds 0|1 (the sampler's input before the reference maps it to -0.5|1.5).

@@ -80,7 +80,7 @@ SIGNATURES = {
     "rls_rand_actions": [_P, _I64, _I64, _U64, _U64, _I64, _P],
     "rls_spin_delta_init": [_G, _P, _I64, C.c_int32, _P, _P],
     "rls_spin_step": [_G, _P, _I64, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _F32, _F32, _F32, C.c_int32, _F32, _P],
-    "rls_mcpg_metro_rounds": [_P, _INT, _I64, _I64, _P, _I64, _I64, _P, _P, _U64, _P, _INT, _P, _P],
+    "rls_mcpg_metro_rounds": [_P, _P, _INT, _I64, _I64, _P, _I64, _I64, _P, _P, _U64, _P, _INT, _P, _P],
     "rls_mcpg_local_search": [_G, _P, _INT, _P, _I64, _P, _P, _I64, _I64, _P, _U64, _P, _P],
     "rls_mcpg_pick_best": [_P, _P, _I64, _I64, _I64, _I64, _P, _P, _P, _P],
     "rls_qubo_local_search_value": [_P, _I64, _P, _P, _I64, _I64, _INT, _P, _P],

@@ -73,7 +73,7 @@ __device__ __forceinline__ uint32_t k7_fmix32(uint32_t h) {
 }
 
 template <typename T, bool PROBS_LDS>
-__global__ __launch_bounds__(kMetroWaves * kWave) void k_mcpg_metro(T* __restrict__ samples, int64_t N, int64_t C,
+__global__ __launch_bounds__(kMetroWaves * kWave) void k_mcpg_metro(T* samples, const T* samples_in, int64_t N, int64_t C,
                                                       const float* __restrict__ probs, int64_t T_rounds,
                                                       const int64_t* __restrict__ index,
                                                       const float* __restrict__ u, uint64_t seed,
@@ -90,15 +90,16 @@ __global__ __launch_bounds__(kMetroWaves * kWave) void k_mcpg_metro(T* __restric
     const int64_t c0 = (int64_t)blockIdx.x * kWave;
     const int64_t c = c0 + lane;
     const bool valid = c < C;
-    if (t_limit_dev && *t_limit_dev <= 0) return;   // nothing to do for this chunk (stop rule already met)
+    // nothing to do for this chunk (stop rule already met) -- unless the chains still have to be moved to `samples`
+    if (t_limit_dev && *t_limit_dev <= 0 && samples_in == samples) return;
     if constexpr (PROBS_LDS)
         for (int64_t n = threadIdx.x; n < N; n += kMetroWaves * kWave) probs_l[n] = probs[n];
-    tile_load_bits_nodemajor<T>(samples, N, C, c0, words, lane, w, kMetroWaves);
+    tile_load_bits_nodemajor<T>(samples_in, N, C, c0, words, lane, w, kMetroWaves);
     __syncthreads();
     int64_t t_end = T_rounds;
     if (t_limit_dev) {
         const int64_t lim = *t_limit_dev;
-        t_end = lim < T_rounds ? lim : T_rounds;
+        t_end = lim < T_rounds ? (lim > 0 ? lim : 0) : T_rounds;
     }
     const uint32_t chain_key = k7_fmix32((uint32_t)seed ^ k7_fmix32((uint32_t)(seed >> 32) ^ k7_fmix32((uint32_t)c) ^
                                                                     ((uint32_t)((uint64_t)c >> 32) * 0x9E3779B1u)));
@@ -559,15 +560,17 @@ using namespace rls;
 
 extern "C" {
 
-int rls_mcpg_metro_rounds(void* samples, int spin_bytes, int64_t N, int64_t C, const float* probs, int64_t T,
-                          int64_t t_offset, const int64_t* index, const float* u, uint64_t seed,
-                          const int64_t* t_limit_dev, int write_back, int64_t* accepts, void* stream) {
+int rls_mcpg_metro_rounds(void* samples, const void* samples_in, int spin_bytes, int64_t N, int64_t C,
+                          const float* probs, int64_t T, int64_t t_offset, const int64_t* index, const float* u,
+                          uint64_t seed, const int64_t* t_limit_dev, int write_back, int64_t* accepts, void* stream) {
     RLS_REQUIRE(N > 0 && C >= 0 && T >= 0 && t_offset >= 0, RLS_EINVAL, "bad sizes N=%lld C=%lld T=%lld", (long long)N, (long long)C,
                 (long long)T);
     if (C == 0) return RLS_OK;
     RLS_REQUIRE(samples && probs, RLS_EINVAL, "samples/probs is NULL");
     RLS_REQUIRE((index == nullptr) == (u == nullptr), RLS_EINVAL, "index and u must both be given or both be NULL");
     RLS_REQUIRE(spin_bytes == 1 || spin_bytes == 4, RLS_EINVAL, "spin_bytes must be 1 or 4");
+    if (!samples_in) samples_in = samples;
+    RLS_REQUIRE(samples_in == samples || write_back, RLS_EINVAL, "samples_in != samples needs write_back");
     const size_t lds_base = (size_t)N * 8 + (accepts ? (size_t)T * 4 : 0) + 16;
     const bool probs_lds = lds_base + (size_t)N * 4 <= (size_t)kLdsBytes;
     const size_t lds = lds_base + (probs_lds ? (size_t)N * 4 : 0);
@@ -580,7 +583,7 @@ int rls_mcpg_metro_rounds(void* samples, int spin_bytes, int64_t N, int64_t C, c
         auto kern = k_mcpg_metro<TT, PL>;                                                                           \
         if (lds > 64 * 1024)                                                                                        \
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
-        hipLaunchKernelGGL(kern, grid, block, lds, s, (TT*)samples, N, C, probs, T, index, u, seed, t_limit_dev,     \
+        hipLaunchKernelGGL(kern, grid, block, lds, s, (TT*)samples, (const TT*)samples_in, N, C, probs, T, index, u, seed, t_limit_dev, \
                            write_back, (unsigned long long*)accepts, t_offset);                                     \
     } while (0)
     if (spin_bytes == 1) { if (probs_lds) LAUNCH_METRO(uint8_t, true); else LAUNCH_METRO(uint8_t, false); }

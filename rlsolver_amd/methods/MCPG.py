@@ -147,16 +147,19 @@ def metro_sampling(probs: TEN, start_status: TEN, max_transfer_time: int, device
     sync), where the reference syncs once per round.  ``index``/``u`` ([>=5T, C]) replace the
     torch.randint / torch.rand draws (test hook)."""
     device = start_status.device if device is None else torch.device(device)
-    samples = start_status.to(device=device, dtype=torch.float32).contiguous().clone()
+    start = start_status.to(device=device, dtype=torch.float32).contiguous()
+    # the first chunk reads the caller's start state and writes the result buffer: no copy of the [N, C] state
+    samples = torch.empty_like(start) if start.data_ptr() == start_status.data_ptr() else start
     probs = probs.detach().to(device=device, dtype=torch.float32).contiguous()
     N, Cc = samples.shape
     Tmax = max_transfer_time * 5
     if index is not None:
         Tmax = min(Tmax, index.shape[0])
     seed = _seed_from_torch() if index is None else 0
-    # walk the rounds in chunks of T: dry pass -> accept counts -> stop round (on the device) -> apply.
-    # Chunks after the stop round see a zero limit and return at once, so the work is ~2x the rounds
-    # the reference actually runs instead of always simulating all 5T.
+    # Walk the rounds in chunks of T.  A round accepts at most C proposals, so the cumulative count cannot reach
+    # C*T before the LAST round of the first chunk: that chunk is applied directly (one pass, counting as it
+    # goes).  Later chunks: dry pass -> accept counts -> stop round (on the device) -> apply.  Chunks after the
+    # stop round see a zero limit and return at once.
     chunk = max(1, max_transfer_time)
     target = Cc * max_transfer_time
     cum_prev = torch.zeros((), dtype=torch.int64, device=device)
@@ -165,15 +168,21 @@ def metro_sampling(probs: TEN, start_status: TEN, max_transfer_time: int, device
     for t0 in range(0, Tmax, chunk):
         tk = min(chunk, Tmax - t0)
         tk_dev = torch.full((), tk, dtype=torch.int64, device=device)
-        limit = torch.where(live, tk_dev, zero).reshape(1).contiguous()
         accepts = torch.zeros(tk, dtype=torch.int64, device=device)
-        mops.mcpg_metro_rounds(samples, probs, tk, index, u, seed, limit, False, accepts, t_offset=t0)
-        cum = cum_prev + accepts.cumsum(0)
-        reached = cum >= target
-        hit = reached.any()
-        t_stop = torch.where(hit, reached.to(torch.int64).argmax() + 1, tk_dev)
-        apply_limit = torch.minimum(limit[0], t_stop).reshape(1).contiguous()
-        mops.mcpg_metro_rounds(samples, probs, tk, index, u, seed, apply_limit, True, None, t_offset=t0)
+        if t0 == 0:
+            mops.mcpg_metro_rounds(samples, probs, tk, index, u, seed, None, True, accepts, t_offset=0,
+                                   samples_in=None if samples is start else start)
+            cum = accepts.cumsum(0)
+            hit = cum[-1] >= target
+        else:
+            limit = torch.where(live, tk_dev, zero).reshape(1).contiguous()
+            mops.mcpg_metro_rounds(samples, probs, tk, index, u, seed, limit, False, accepts, t_offset=t0)
+            cum = cum_prev + accepts.cumsum(0)
+            reached = cum >= target
+            hit = reached.any()
+            t_stop = torch.where(hit, reached.to(torch.int64).argmax() + 1, tk_dev)
+            apply_limit = torch.minimum(limit[0], t_stop).reshape(1).contiguous()
+            mops.mcpg_metro_rounds(samples, probs, tk, index, u, seed, apply_limit, True, None, t_offset=t0)
         cum_prev = cum[-1]
         live = live & ~hit
     return samples

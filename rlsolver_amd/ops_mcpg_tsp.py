@@ -20,8 +20,9 @@ def _u64(v: int) -> C.c_uint64:
 # ------------------------------------------------------------------------------ MCPG
 def mcpg_metro_rounds(samples: TEN, probs: TEN, T: int, index: Optional[TEN] = None, u: Optional[TEN] = None,
                       seed: int = 0, t_limit: Optional[TEN] = None, write_back: bool = True,
-                      accepts: Optional[TEN] = None, t_offset: int = 0) -> None:
-    """K9 (see include/rlsolver_hip.h).  samples [N, C] f32/uint8 in place."""
+                      accepts: Optional[TEN] = None, t_offset: int = 0, samples_in: Optional[TEN] = None) -> None:
+    """K9 (see include/rlsolver_hip.h).  samples [N, C] f32/uint8 in place, or read from ``samples_in`` (same
+    shape / dtype) and written to ``samples``."""
     _check(samples, "samples", _NM_DTYPES)
     dev = samples.device
     if samples.dim() != 2:
@@ -41,7 +42,11 @@ def mcpg_metro_rounds(samples: TEN, probs: TEN, T: int, index: Optional[TEN] = N
         _check(accepts, "accepts", (torch.int64,), dev)
         if accepts.numel() < T:
             raise ValueError("accepts must hold T entries")
-    _abi.call("rls_mcpg_metro_rounds", _ptr(samples), 4 if samples.dtype == torch.float32 else 1, N, Cc, _ptr(probs),
+    if samples_in is not None:
+        _check(samples_in, "samples_in", (samples.dtype,), dev, (N, Cc))
+        if not write_back:
+            raise ValueError("samples_in needs write_back")
+    _abi.call("rls_mcpg_metro_rounds", _ptr(samples), _ptr(samples_in), 4 if samples.dtype == torch.float32 else 1, N, Cc, _ptr(probs),
               T, t_offset, _ptr(index), _ptr(u), _u64(seed), _ptr(t_limit), int(bool(write_back)), _ptr(accepts),
               _stream(dev))
 
