@@ -110,7 +110,7 @@ def mcpg_suite(tag, n, m_ba, C, num_ls, iters):
     emit(tag, f"K7+K8 sampler_func (num_ls={num_ls})", "chain-sweeps", C * num_ls, t, 2 * 4 * n / num_ls)
     T = n // 10
     t = timeit(lambda i: amcpg.metro_sampling(probs, xs, T, dev), iters, warm=1)
-    emit(tag, "K9 metro_sampling (two-pass, sync-free stop rule)", "proposals", C * T, t, None, f"T={T}")
+    emit(tag, "K9 metro_sampling (sync-free stop rule)", "proposals", C * T, t, None, f"T={T}")
 
 
 def tsp_suite(tag, N, B, iters):
