@@ -48,7 +48,7 @@ def qubo_local_search_value(Q: TEN, xs: TEN, num_ls: int, binary: bool):
 
 def _sample(data, start_result, probs, num_ls, change_times, total_mcmc_num, device, binary, index, u):
     Q = data['Q'].to(device=device, dtype=torch.float32).contiguous()
-    raw_samples = metro_sampling(probs, start_result.clone(), change_times, device, index=index, u=u)
+    raw_samples = metro_sampling(probs, start_result, change_times, device, index=index, u=u)   # never modifies its input
     samples, res_sample = qubo_local_search_value(Q, raw_samples.contiguous(), num_ls, binary)
     res_reshape = res_sample.reshape(-1, total_mcmc_num)
     idx = torch.argmax(res_reshape, dim=0)
