@@ -372,6 +372,52 @@ __device__ __forceinline__ void lv_add8(const uint64_t (&d)[8], uint64_t& ones, 
     }
 }
 
+// One node of high degree, lanes share its neighbours: per-lane vertical counters over the node's <= 2^NP - 1 rounds
+// (ones among visited / not-yet-visited neighbours), then every plane is transposed across the wave and
+// popcounted -- afterwards lane = chain holds that chain's counts.  NP follows the number of rounds, so a node of
+// degree <= 64 (one round) costs one transpose per counter.
+template <int NP>
+__device__ __forceinline__ void lv_hub_counts(const uint64_t* words, const int32_t* __restrict__ data, int64_t p0,
+                                              int rounds, const uint32_t (&e0)[8], bool pass0, int lane,
+                                              const BitXpose& xc, int& cV, int& cF) {
+    constexpr uint32_t M31 = 0x7fffffffu;
+    uint64_t cv[NP], cf[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) { cv[p] = 0; cf[p] = 0; }
+    auto add = [&](uint32_t en) {
+        const uint64_t d = words[en & M31];
+        const uint64_t fm = pass0 ? 0ull - (uint64_t)(en >> 31) : 0ull;
+        uint64_t carry = d & ~fm;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) { const uint64_t t = cv[p] & carry; cv[p] ^= carry; carry = t; }
+        if (pass0) {
+            carry = d & fm;
+#pragma unroll
+            for (int p = 0; p < NP; ++p) { const uint64_t t = cf[p] & carry; cf[p] ^= carry; carry = t; }
+        }
+    };
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+        if (q < rounds) add(e0[q]);
+    for (int r = 8; r < rounds; ++r) add((uint32_t)data[p0 + (int64_t)(2 + r) * kWave + lane]);
+    cV = 0;
+    cF = 0;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        uint32_t r0 = (uint32_t)cv[p], r1 = (uint32_t)(cv[p] >> 32);
+        bit_transpose64(r0, r1, xc);
+        cV += (__builtin_popcount(r0) + __builtin_popcount(r1)) << p;
+    }
+    if (pass0) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            uint32_t r0 = (uint32_t)cf[p], r1 = (uint32_t)(cf[p] >> 32);
+            bit_transpose64(r0, r1, xc);
+            cF += (__builtin_popcount(r0) + __builtin_popcount(r1)) << p;
+        }
+    }
+}
+
 template <typename TI, int P>
 __global__ __launch_bounds__(kLvWaves * kWave) void k_mcpg_local_search_levels(
     const TI* __restrict__ xs_in, float* __restrict__ xs_out, int64_t N, int64_t C,
@@ -481,35 +527,11 @@ __global__ __launch_bounds__(kLvWaves * kWave) void k_mcpg_local_search_levels(
                 const uint32_t node = g0 & 0xFFFFFu, pos = g1 & 0xFFFFFu;
                 const uint32_t K = pass0 ? ((g1 >> 20) & 0x7FFu) : ((g0 >> 20) & 0x7FFu);
                 const bool tie = (pass0 ? g1 : g0) >> 31;
-                uint64_t cv[5] = {0, 0, 0, 0, 0}, cf[5] = {0, 0, 0, 0, 0};     // per-lane counts over <= 16 rounds
-                auto hub_add = [&](uint32_t en) {
-                    const uint64_t d = words[en & M31];
-                    const uint64_t fm = pass0 ? 0ull - (uint64_t)(en >> 31) : 0ull;
-                    uint64_t carry = d & ~fm;
-#pragma unroll
-                    for (int p = 0; p < 5; ++p) { const uint64_t t = cv[p] & carry; cv[p] ^= carry; carry = t; }
-                    carry = d & fm;
-#pragma unroll
-                    for (int p = 0; p < 5; ++p) { const uint64_t t = cf[p] & carry; cf[p] ^= carry; carry = t; }
-                };
-#pragma unroll
-                for (int q = 0; q < 8; ++q) hub_add(e0[q]);            // rounds past the end were prefetched as N (word 0)
-                for (int r = 8; r < rounds; ++r) hub_add((uint32_t)data[p0 + (int64_t)(2 + r) * kWave + lane]);
-                int cV = 0, cF = 0;                                           // now lane = chain
-#pragma unroll
-                for (int p = 0; p < 5; ++p) {
-                    uint32_t r0 = (uint32_t)cv[p], r1 = (uint32_t)(cv[p] >> 32);
-                    bit_transpose64(r0, r1, xc);
-                    cV += (__builtin_popcount(r0) + __builtin_popcount(r1)) << p;
-                }
-                if (pass0) {
-#pragma unroll
-                    for (int p = 0; p < 5; ++p) {
-                        uint32_t r0 = (uint32_t)cf[p], r1 = (uint32_t)(cf[p] >> 32);
-                        bit_transpose64(r0, r1, xc);
-                        cF += (__builtin_popcount(r0) + __builtin_popcount(r1)) << p;
-                    }
-                }
+                int cV, cF;                                                   // lane = chain after the call
+                if (rounds <= 1) lv_hub_counts<1>(words, data, p0, rounds, e0, pass0, lane, xc, cV, cF);
+                else if (rounds <= 3) lv_hub_counts<2>(words, data, p0, rounds, e0, pass0, lane, xc, cV, cF);
+                else if (rounds <= 7) lv_hub_counts<3>(words, data, p0, rounds, e0, pass0, lane, xc, cV, cF);
+                else lv_hub_counts<5>(words, data, p0, rounds, e0, pass0, lane, xc, cV, cF);
                 const uint32_t Cc = (uint32_t)(cV + 2 * cF);
                 const uint64_t coin = coin_word(cnt, pos);
                 const bool bit = (Cc < K) || (Cc == K && tie && ((coin >> lane) & 1ull));
