@@ -152,8 +152,8 @@ int rls_maxcut_delta_all(const rls_graph* g, const uint8_t* x, int64_t B,
  * cur[b] = (float)obj[b] if cur != NULL; done[b] = done_value if done != NULL.
  * x_out may equal x_in (in-place: only the flipped byte is written, O(deg)
  * traffic); otherwise the whole next state is emitted (2N + 20 B / env-step,
- * the headline byte accounting of SURVEY.md section 8d).  action values must
- * be in [0, N). */
+ * the headline byte accounting of SURVEY.md section 8d).  An action outside
+ * [0, N) leaves its env untouched and yields reward = NaN (the reference raises). */
 int rls_maxcut_step(const rls_graph* g, const void* x_in, void* x_out, int spin_bytes,
                     int64_t B, const int64_t* action, int32_t* obj,
                     float* reward, float* cur, float* done, float done_value,
@@ -203,6 +203,10 @@ int rls_maxcut_local_search(const rls_graph* g, uint8_t* x, int64_t B, const int
                             int32_t num_spin, int32_t first_draw_proposes, int64_t* obj, int32_t compute_obj,
                             void* stream);
 
+/* 1 when rls_maxcut_local_search covers this graph / batch / num_spin (the same test its launcher applies: the
+ * 8- or 4-wave LDS layout must fit 160 KB), else 0 -- callers then take the K2 + K6 + K5 path. */
+int rls_maxcut_local_search_supported(const rls_graph* g, int64_t B, int32_t num_spin);
+
 /* K10 update_xs_by_vs(xs0, vs0, xs1, vs1, if_maximize)  methods/util_read_data.py:190-202:
  *     rows of (xs1, vs1) that are >= (<= when !if_maximize) replace (xs0, vs0). */
 int rls_select_better_rows(uint8_t* xs0, int64_t* vs0, const uint8_t* xs1, const int64_t* vs1,
@@ -226,25 +230,53 @@ int rls_rand_actions(int64_t* action, int64_t B, int64_t N, uint64_t seed, uint6
 
 /* ----------------------------------------------------- S2V / ECO / PECO spin system */
 
-/* Gains of all single flips from signed f32 spins: delta[b,i] = s_i * sum_j W_ij s_j, s = state[b,0,:]
- * in {+1,-1}  (_get_immeditate_cuts_avaialable, ECO_S2V/src/envs/spinsystem_PECO.py:660-661, a dense
- * matmul there).  state f32 [B, num_rows, N]; delta int32 [B, N]. */
-int rls_spin_delta_init(const rls_graph* g, const float* state, int64_t B, int32_t num_rows, int32_t* delta,
-                        void* stream);
+/* Resident per-env state of the spin-system env (all device pointers, owned by the caller).  T = float
+ * (state_bytes = 4: the batched PECO env, spinsystem_PECO.py) or double (state_bytes = 8: the numpy env,
+ * ECO_S2V/src/envs/spinsystem.py). */
+typedef struct rls_spin_env {
+    void* state;           /* T [B, R, N]: observable rows, row 0 = signed spins {+1,-1} */
+    int32_t* delta;        /* [B, N] gain cache: delta[b,i] = s_i * sum_j W_ij s_j ("immediate cuts available",
+                            * _get_immeditate_cuts_avaialable, spinsystem_PECO.py:660-661: a dense matmul there) */
+    void* score;           /* T [B] */
+    void* best_score;      /* T [B] */
+    void* best_spins;      /* T [B, N] */
+    int32_t* num_nonpos;   /* [B] #{i : delta[b,i] <= 0}, kept incrementally (greedy-actions row, basin test :392-397) */
+    int32_t* dist_best;    /* [B] Hamming distance between the spins and best_spins, kept incrementally */
+    /* visited-state memory behind stag_punishment / basin_reward (HistoryBuffer, util_envs_PECO.py:228-288,
+     * util_envs.py:355-381), or all NULL / 0: W = ceil(N / 64) words per state */
+    uint64_t* packed;      /* [B, W] current spins, bit n % 64 of word n / 64 = (s_n > 0) */
+    uint64_t* hash;        /* [B] Zobrist hash of packed (pre-filter of the exact compare) */
+    uint64_t* hist;        /* [B, hist_cap, W] the state after each earlier step of the episode */
+    uint64_t* hist_hash;   /* [B, hist_cap] */
+    int64_t hist_cap;
+} rls_spin_env;
 
-/* One env step of SpinSystemUnbiased  ECO_S2V/src/envs/spinsystem_PECO.py:306-486 on a shared graph:
- * flip action[b]; gain = delta[b,a]; incremental update of delta (O(deg), cf. S2V_PPO/env.py:197-206);
- * score += gain; reward (mode 0 DENSE = gain, 1 BLS = max(score - best_before, 0), 2 CUSTOM_BLS =
- * impr / (impr + 0.1)), divided by reward_div (n_spins under norm_rewards, else 1); best_score /
- * best_spins tracking; observable rows of state written in place.  row_index [host] int32[7] gives the
- * row of IMMEDIATE_REWARD_AVAILABLE, TIME_SINCE_FLIP, EPISODE_TIME, TERMINATION_IMMANENCY,
- * NUMBER_OF_GREEDY_ACTIONS_AVAILABLE, DISTANCE_FROM_BEST_SCORE, DISTANCE_FROM_BEST_STATE in state
- * (-1 = not observed; row 0 is always the signed spins).  num_nonpos[b] = #{i : delta[b,i] <= 0}
- * (the basin test of :392-397).  g->wgt = integer weights or NULL. */
-int rls_spin_step(const rls_graph* g, float* state, int64_t B, int32_t num_rows, const int32_t* row_index,
-                  int32_t* delta, const int64_t* action, float* score, float* best_score, float* best_spins,
-                  float* reward, int32_t* num_nonpos, float max_local, float time_inc, float termination_value,
-                  int32_t reward_mode, float reward_div, void* stream);
+/* reset()  spinsystem_PECO.py:150-195 / spinsystem.py:176-252, after the caller has written the signed spins into
+ * row 0 of state and their gains into delta (rls_maxcut_delta_all on the spins as bits: the two definitions
+ * coincide).  Fills the IMMEDIATE_REWARD_AVAILABLE and NUMBER_OF_GREEDY_ACTIONS_AVAILABLE rows, zeroes the other
+ * rows, score = best_score = cut = (weight_sum - sum_i delta_i) / 4 with weight_sum = sum of W over ORDERED pairs,
+ * best_spins = spins, num_nonpos, dist_best = 0, packed / hash (the history starts empty: hist_len = 0).
+ * row_index [host] int32[7]: as rls_spin_step. */
+int rls_spin_reset(const rls_graph* g, const rls_spin_env* env, int state_bytes, int64_t B, int32_t num_rows,
+                   const int32_t* row_index, double max_local, int64_t weight_sum, void* stream);
+
+/* One env step of SpinSystemUnbiased  ECO_S2V/src/envs/spinsystem_PECO.py:306-486 (f32, batched) and
+ * ECO_S2V/src/envs/spinsystem.py:333-482 (f64, B = 1) on a shared graph: flip action[b]; gain = delta[b,a];
+ * incremental update of delta (O(deg), cf. S2V_PPO/env.py:197-206); score += gain; reward (mode 0 DENSE = gain,
+ * 1 BLS = max(score - best_before, 0), 2 CUSTOM_BLS = impr / (impr + 0.1)), divided by reward_div (n_spins under
+ * norm_rewards, else 1); visited-state test against the hist_len earlier states of the episode and append
+ * (when env->packed): reward -= stag_punishment on a revisit (use_stag), reward += basin_reward on a first
+ * visit of a state with no improving flip (use_basin); best_score / best_spins tracking; observable rows of
+ * state written in place.  row_index [host] int32[7] gives the row of IMMEDIATE_REWARD_AVAILABLE,
+ * TIME_SINCE_FLIP, EPISODE_TIME, TERMINATION_IMMANENCY, NUMBER_OF_GREEDY_ACTIONS_AVAILABLE,
+ * DISTANCE_FROM_BEST_SCORE, DISTANCE_FROM_BEST_STATE in state (-1 = not observed; row 0 is always the signed
+ * spins).  reward T [B]; visited_new uint8 [B] or NULL (1 = state not seen before).  The scalar parameters are
+ * rounded to T inside (pass the f32-rounded values for the f32 env).  An action outside [0, N) leaves its env
+ * untouched and yields reward = NaN.  g->wgt = integer weights or NULL. */
+int rls_spin_step(const rls_graph* g, const rls_spin_env* env, int state_bytes, int64_t B, int32_t num_rows,
+                  const int32_t* row_index, const int64_t* action, void* reward, uint8_t* visited_new, double max_local,
+                  double time_inc, double termination_value, int32_t reward_mode, double reward_div, int64_t hist_len,
+                  int32_t use_stag, double stag_punishment, int32_t use_basin, double basin_reward, void* stream);
 
 /* -------------------------------------------------------------------- MCPG */
 /* Layout: node-major x[N, C] as in the reference (chains are the fast axis); spin_bytes = 4
@@ -317,6 +349,10 @@ int rls_mcpg_visit_levels(const int32_t* rowptr, const int32_t* col, int64_t N, 
 int rls_mcpg_local_search_levels(const rls_graph* g, const void* xs_in, int spin_bytes, float* xs_out, int64_t C,
                                  const int32_t* lv_ptr, const int32_t* lv_data, int64_t num_groups, int64_t num_ls,
                                  const uint64_t* coins, uint64_t seed, float* expected, void* stream);
+
+/* 1 when rls_mcpg_local_search_levels covers this graph with a schedule of num_groups groups (bit tile + group
+ * offsets + scratch within 160 KB of LDS, unweighted, N < 2^20, degrees < 1024), else 0. */
+int rls_mcpg_local_search_levels_supported(const rls_graph* g, int64_t num_groups);
 
 /* K8 second half  methods/MCPG.py:154-161: best_index[m] = m + M * argmin_r expected[r*M + m]
  * (first minimum), vs_good[m] = (num_edges - expected[best]) / 2, xs_good[:, m] = xs[:, best].

@@ -16,11 +16,13 @@ class SpinSystemOracle:
     # observable row order = ECO_PECO_OBSERVABLES (ECO_S2V/src/envs/util_envs.py:53-59)
     SPIN, IMMEDIATE, TIME_SINCE_FLIP, DIST_SCORE, DIST_STATE, GREEDY, TERMINATION = range(7)
 
-    def __init__(self, W, num_envs, max_steps, reward="DENSE", norm_rewards=False, basin_reward=None):
+    def __init__(self, W, num_envs, max_steps, reward="DENSE", norm_rewards=False, basin_reward=None,
+                 stag_punishment=None):
         self.W = np.asarray(W, F)
         self.n = self.W.shape[0]
         self.B, self.max_steps = num_envs, max_steps
         self.reward, self.norm_rewards, self.basin_reward = reward, norm_rewards, basin_reward
+        self.stag_punishment = stag_punishment
         ones = np.ones((num_envs, self.n), F)
         self.max_local = self._imm(ones).max(axis=-1)                       # spinsystem_PECO.py:160-170
 
@@ -42,7 +44,8 @@ class SpinSystemOracle:
         self.score = self.calculate_cut(self.state[:, 0])
         self.best_score = self.score.copy()
         self.best_spins = self.state[:, 0].copy()
-        self.visited = [set() for _ in range(self.B)] if self.basin_reward is not None else None
+        self.visited = [set() for _ in range(self.B)] if (self.basin_reward is not None or
+                                                              self.stag_punishment is not None) else None
         return self.observation()
 
     def observation(self):
@@ -62,6 +65,8 @@ class SpinSystemOracle:
         improvement = self.score - self.best_score
         if self.reward == "BLS":
             rew = np.where(improvement > 0, improvement, F(0)).astype(F)
+        elif self.reward == "CUSTOM_BLS":                                      # :372-374
+            rew = np.where(improvement > 0, improvement / (improvement + F(0.1)), F(0)).astype(F)
         else:
             rew = delta.astype(F)
         if self.norm_rewards:
@@ -73,7 +78,10 @@ class SpinSystemOracle:
                 fresh[b] = key not in self.visited[b]
                 self.visited[b].add(key)
             rew = rew.copy()
-            rew[np.all(imm <= 0, axis=-1) & fresh] += F(self.basin_reward)
+            if self.stag_punishment is not None:
+                rew[~fresh] -= F(self.stag_punishment)
+            if self.basin_reward is not None:
+                rew[np.all(imm <= 0, axis=-1) & fresh] += F(self.basin_reward)
         upd = self.score > self.best_score
         self.best_score = np.where(upd, self.score, self.best_score)
         self.best_spins = np.where(upd[:, None], self.state[:, 0], self.best_spins)
@@ -87,3 +95,86 @@ class SpinSystemOracle:
         st[:, self.DIST_STATE] = np.count_nonzero(self.best_spins - st[:, 0], axis=-1)[:, None]
         done = np.full(self.B, self.t == self.max_steps)
         return self.observation(), rew, done
+
+
+class SpinSystemOracleF64:
+    """The numpy single-instance env, rlsolver/methods/ECO_S2V/src/envs/spinsystem.py (SpinSystemUnbiased :588-661,
+    step :333-482, reset :176-252, observation :484-495), restated in float64 with a DENSE matvec for the gains and
+    the action-parity-set visited memory of util_envs.py:355-381.  ECO_PECO_OBSERVABLES row order, ExtraAction.NONE,
+    OptimisationTarget.CUT, infinite memory.  Pinned against tests/golden/spinsystem_cpu.npz."""
+    SPIN, IMMEDIATE, TIME_SINCE_FLIP, DIST_SCORE, DIST_STATE, GREEDY, TERMINATION = range(7)
+
+    def __init__(self, W, max_steps, reward="DENSE", norm_rewards=False, basin_reward=None, stag_punishment=None):
+        self.W = np.asarray(W, np.float64)
+        self.n = self.W.shape[0]
+        self.max_steps = max_steps
+        self.reward, self.norm_rewards = reward, norm_rewards
+        self.basin_reward, self.stag_punishment = basin_reward, stag_punishment
+        imm1 = self._imm(np.ones(self.n))
+        self.max_local = np.max(imm1[np.nonzero(imm1)])                        # :190-196
+
+    def _imm(self, s):
+        return s * (self.W @ s)                                                # :659-661
+
+    def reset(self, spins_signed):
+        self.t = 0
+        st = np.zeros((7, self.n))
+        st[0] = spins_signed
+        imm = self._imm(st[0])
+        st[self.IMMEDIATE] = imm / self.max_local
+        st[self.GREEDY] = 1 - np.sum(imm <= 0) / self.n
+        self.state = st
+        self.score = 0.25 * np.sum(self.W * (1 - np.outer(st[0], st[0])))      # :601-607
+        self.best_score = self.score
+        self.best_spins = st[0].copy()
+        self.flipped = frozenset()                                             # HistoryBuffer.current_action_hist
+        self.seen = set()
+        return self.observation()
+
+    def observation(self):
+        s = self.state.copy()
+        s[0] = (1 - s[0]) / 2                                                  # SpinBasis.BINARY
+        return np.vstack((s, self.W))
+
+    def gains(self):
+        return self._imm(self.state[0])
+
+    def step(self, a):
+        self.t += 1
+        new = self.state.copy()
+        new[0, a] = -self.state[0, a]
+        delta = -1 * new[0, a] * (new[0] @ self.W[:, a])                       # _calculate_cut_change :631
+        self.score += delta
+        self.state = new
+        imm = self._imm(new[0])
+        rew = 0
+        if self.score > self.best_score:
+            if self.reward == "BLS":
+                rew = self.score - self.best_score
+            elif self.reward == "CUSTOM_BLS":
+                rew = self.score - self.best_score
+                rew = rew / (rew + 0.1)
+        if self.reward == "DENSE":
+            rew = delta
+        if self.norm_rewards:
+            rew /= self.n
+        if self.stag_punishment is not None or self.basin_reward is not None:
+            self.flipped = self.flipped ^ frozenset([a])
+            fresh = self.flipped not in self.seen
+            self.seen.add(self.flipped)
+            if self.stag_punishment is not None and not fresh:
+                rew -= self.stag_punishment
+            if self.basin_reward is not None and np.all(imm <= 0) and fresh:
+                rew += self.basin_reward
+        if self.score > self.best_score:
+            self.best_score = self.score
+            self.best_spins = new[0].copy()
+        st = self.state
+        st[self.IMMEDIATE] = imm / self.max_local
+        st[self.TIME_SINCE_FLIP] += 1. / self.max_steps
+        st[self.TIME_SINCE_FLIP, a] = 0
+        st[self.TERMINATION] = max(0, ((self.t - self.max_steps) / self.max_steps) + 1)
+        st[self.GREEDY] = 1 - np.sum(imm <= 0) / self.n
+        st[self.DIST_SCORE] = np.abs(self.score - self.best_score) / self.max_local
+        st[self.DIST_STATE] = np.count_nonzero(self.best_spins - st[0])
+        return self.observation(), rew, self.t == self.max_steps

@@ -54,7 +54,17 @@ _I64 = C.c_int64
 _U64 = C.c_uint64
 _INT = C.c_int
 _F32 = C.c_float
+_F64 = C.c_double
 _G = C.POINTER(RlsGraph)
+
+
+class RlsSpinEnv(C.Structure):
+    """struct rls_spin_env (host struct of device pointers)."""
+    _fields_ = [(n, C.c_void_p) for n in ("state", "delta", "score", "best_score", "best_spins", "num_nonpos", "dist_best",
+                                          "packed", "hash", "hist", "hist_hash")] + [("hist_cap", C.c_int64)]
+
+
+_SE = C.POINTER(RlsSpinEnv)
 
 # name -> argtypes; every function returns int.  Keep in sync with include/rlsolver_hip.h
 # (tests/test_abi.py parses the header and checks this table against it).
@@ -78,8 +88,9 @@ SIGNATURES = {
     "rls_pick_best_of_repeats": [_P, _P, _I64, _I64, _I64, _INT, _P, _P, _P],
     "rls_rand_spins": [_P, _I64, _I64, _U64, _I64, _P],
     "rls_rand_actions": [_P, _I64, _I64, _U64, _U64, _I64, _P],
-    "rls_spin_delta_init": [_G, _P, _I64, C.c_int32, _P, _P],
-    "rls_spin_step": [_G, _P, _I64, C.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _F32, _F32, _F32, C.c_int32, _F32, _P],
+    "rls_spin_reset": [_SE, _INT, _I64, C.c_int32, _P, _F64, _I64, _P],
+    "rls_spin_step": [_SE, _INT, _I64, C.c_int32, _P, _P, _P, _P, _F64, _F64, _F64, C.c_int32, _F64, _I64, C.c_int32, _F64,
+                      C.c_int32, _F64, _P],
     "rls_mcpg_metro_rounds": [_P, _P, _INT, _I64, _I64, _P, _I64, _I64, _P, _P, _U64, _P, _INT, _P, _P],
     "rls_mcpg_local_search": [_G, _P, _INT, _P, _I64, _P, _P, _I64, _I64, _P, _U64, _P, _P],
     "rls_mcpg_pick_best": [_P, _P, _I64, _I64, _I64, _I64, _P, _P, _P, _P],
@@ -90,7 +101,10 @@ SIGNATURES = {
     "rls_tsp_2opt_delta": [_P, _I64, _P, _I64, _P, _P, _P, _P],
     "rls_rand_perms": [_P, _I64, _I64, _U64, _I64, _P],
 }
-PLAIN = {"rls_version": ([], _INT), "rls_device_count": ([], _INT), "rls_last_error_string": ([], C.c_char_p)}
+# functions that return a value, not an error code
+PLAIN = {"rls_version": ([], _INT), "rls_device_count": ([], _INT), "rls_last_error_string": ([], C.c_char_p),
+         "rls_maxcut_local_search_supported": ([_G, _I64, C.c_int32], _INT),
+         "rls_mcpg_local_search_levels_supported": ([_G, _I64], _INT)}
 
 _lib = None
 _lock = threading.Lock()

@@ -317,6 +317,33 @@ __global__ __launch_bounds__(W * kWave) void k_maxcut_local_search(
 using namespace rls;
 
 
+// LDS bytes of the W-wave layout (W = 4: compact, the sweep offsets reuse the proposal tile; W = 8: separate tables)
+static size_t ls_lds_bytes(int64_t N, int W) {
+    const size_t sd_bytes = (size_t)((N + 3) & ~3ll) * 4;   // rd_std in LDS
+    return sd_bytes + (W == kLsMergeWaves
+                           ? (size_t)(N + 2) * 8 + (size_t)N * 8 + (size_t)kRing * 4 + (size_t)W * kWave * 8
+                           : (size_t)(N + 2) * 8 + (size_t)N * 8 + (size_t)((N + 1 + 3) & ~3ll) * 4 + (size_t)kRing * 4 +
+                                 (size_t)W * kWave * 8 + (size_t)kLsMergeWaves * kTopCap * kWave * 4);
+}
+
+// 8 waves per tile when there are few tiles (<= 2 per CU: the noise / top-k / mask phases are VALU-latency bound with
+// one wave per SIMD) and that layout fits LDS; else 4 waves per tile (two tiles per CU); 0 = neither layout fits
+static int ls_pick_waves(int64_t N, int64_t B) {
+    static const int force_w = getenv("RLS_LS_WAVES") ? atoi(getenv("RLS_LS_WAVES")) : 0;   // dev knob
+    int W = force_w == 4 || force_w == 8 ? force_w : (ceil_div(B, kWave) <= 2 * (int64_t)num_cus() ? 8 : 4);
+    if (W == 8 && ls_lds_bytes(N, 8) > (size_t)kLdsBytes) W = 4;
+    return ls_lds_bytes(N, W) <= (size_t)kLdsBytes ? W : 0;
+}
+
+extern "C" int rls_maxcut_local_search_supported(const rls_graph* g, int64_t B, int32_t num_spin) {
+    if (!g || g->num_nodes <= 0) return 0;
+    const int64_t N = g->num_nodes;
+    if (num_spin < 0 || num_spin + 1 > kTopCap || num_spin >= N) return 0;
+    if (g->wgt || g->max_degree >= kRingMaxRun) return 0;
+    if (pick_planes(g->num_stored_edges) == 0) return 0;
+    return ls_pick_waves(N, B > 0 ? B : 1) != 0;
+}
+
 extern "C" int rls_maxcut_local_search(const rls_graph* g, uint8_t* x, int64_t B, const int32_t* ws,
                                        const float* rd_std, const float* noise, uint64_t seed, int64_t env_offset,
                                        int32_t num_iters, int32_t num_spin, int32_t first_draw_proposes, int64_t* obj,
@@ -330,17 +357,9 @@ extern "C" int rls_maxcut_local_search(const rls_graph* g, uint8_t* x, int64_t B
                 "num_spin=%d outside [0, %d] (and < N)", num_spin, kTopCap - 1);
     RLS_REQUIRE(!g->wgt && g->max_degree < kRingMaxRun, RLS_EUNSUPPORTED,
                 "fused local search needs an unweighted graph with max degree < %d", kRingMaxRun);
-    // few tiles (<= 2 per CU): 8 waves per tile halve the noise / top-k / mask phases, which are VALU-latency bound
-    // with one wave per SIMD; many tiles: 4 waves per tile and two tiles per CU
-    static const int force_w = getenv("RLS_LS_WAVES") ? atoi(getenv("RLS_LS_WAVES")) : 0;   // dev knob
-    const int W = force_w == 4 || force_w == 8 ? force_w : (ceil_div(B, kWave) <= 2 * (int64_t)num_cus() ? 8 : 4);
-    const size_t sd_bytes = (size_t)((N + 3) & ~3ll) * 4;   // rd_std in LDS
-    const size_t lds = sd_bytes + (W == kLsMergeWaves
-                           ? (size_t)(N + 2) * 8 + (size_t)N * 8 + (size_t)kRing * 4 + (size_t)W * kWave * 8
-                           : (size_t)(N + 2) * 8 + (size_t)N * 8 + (size_t)((N + 1 + 3) & ~3ll) * 4 + (size_t)kRing * 4 +
-                                 (size_t)W * kWave * 8 + (size_t)kLsMergeWaves * kTopCap * kWave * 4);
-    RLS_REQUIRE(lds <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS (max %d)", (long long)N, lds,
-                kLdsBytes);
+    const int W = ls_pick_waves(N, B);
+    RLS_REQUIRE(W != 0, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS (max %d)", (long long)N, ls_lds_bytes(N, 4), kLdsBytes);
+    const size_t lds = ls_lds_bytes(N, W);
     const int P = pick_planes(E);
     RLS_REQUIRE(P != 0, RLS_EUNSUPPORTED, "E'=%lld too large", (long long)E);
     const bool vec = tile_rows_aligned(x, N, 1);

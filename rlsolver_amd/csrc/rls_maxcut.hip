@@ -832,7 +832,8 @@ int rls_maxcut_greedy_sweep(const rls_graph* g, uint8_t* x, int64_t B, int64_t* 
             return check_launch("k_maxcut_greedy_sweep_levels");
         }
     }
-    if (fast && g->sweep_rowptr && g->sweep_stream && getenv("RLS_SWEEP_UNBATCHED") == nullptr) {
+    static const bool unbatched = getenv("RLS_SWEEP_UNBATCHED") != nullptr;   // dev knob
+    if (fast && g->sweep_rowptr && g->sweep_stream && !unbatched) {
         static const int force_sw = getenv("RLS_SWEEP_WAVES") ? atoi(getenv("RLS_SWEEP_WAVES")) : 0;   // dev knob
         const int sw = force_sw == 4 || force_sw == 8 || force_sw == 16 ? force_sw
                                                                          : (ceil_div(B, kWave) <= (int64_t)num_cus() ? 16 : 8);

@@ -614,6 +614,17 @@ int rls_mcpg_metro_rounds(void* samples, const void* samples_in, int spin_bytes,
     return check_launch("k_mcpg_metro");
 }
 
+static size_t lv_lds_bytes(int64_t N, int64_t num_groups) {
+    return (size_t)(N + 2) * 8 + (((size_t)(num_groups + 1) * 4 + 15) & ~(size_t)15) + (size_t)kLvWaves * kWave * 8;
+}
+
+int rls_mcpg_local_search_levels_supported(const rls_graph* g, int64_t num_groups) {
+    if (!g || g->num_nodes <= 0 || num_groups <= 0) return 0;
+    if (g->num_nodes >= (1 << 20) || g->max_degree >= 1024 || g->wgt) return 0;
+    if (pick_planes(g->num_stored_edges) == 0) return 0;
+    return lv_lds_bytes(g->num_nodes, num_groups) <= (size_t)kLdsBytes;
+}
+
 int rls_mcpg_local_search_levels(const rls_graph* g, const void* xs_in, int spin_bytes, float* xs_out, int64_t C,
                                  const int32_t* lv_ptr, const int32_t* lv_data, int64_t num_groups, int64_t num_ls,
                                  const uint64_t* coins, uint64_t seed, float* expected, void* stream) {
@@ -627,7 +638,7 @@ int rls_mcpg_local_search_levels(const rls_graph* g, const void* xs_in, int spin
                 "level-parallel K7 needs an unweighted graph, N < 2^20, degrees < 1024");
     const int P = pick_planes(E);
     RLS_REQUIRE(P != 0, RLS_EUNSUPPORTED, "E=%lld too large", (long long)E);
-    const size_t lds = (size_t)(N + 2) * 8 + (((size_t)(num_groups + 1) * 4 + 15) & ~(size_t)15) + (size_t)kLvWaves * kWave * 8;
+    const size_t lds = lv_lds_bytes(N, num_groups);
     RLS_REQUIRE(lds <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS (max %d)", (long long)N, lds,
                 kLdsBytes);
     const dim3 grid((unsigned)ceil_div(C, kWave)), block(kLvWaves * kWave);

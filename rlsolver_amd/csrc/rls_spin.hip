@@ -1,17 +1,25 @@
-// S2V / ECO / PECO spin-system step: the batched env of
-// rlsolver/methods/ECO_S2V/src/envs/spinsystem_PECO.py:306-486 (and its shared-graph inference twin
-// inference_network_env.py:295-444) on ONE shared signed-weight graph.
+// S2V / ECO / PECO spin-system env on ONE shared signed-weight graph:
+//   batched f32   rlsolver/methods/ECO_S2V/src/envs/spinsystem_PECO.py:306-486 (and its shared-graph
+//                 inference twin inference_network_env.py:295-444), visited-state memory util_envs_PECO.py:228-288
+//   single f64    rlsolver/methods/ECO_S2V/src/envs/spinsystem.py:333-482 (numpy), HistoryBuffer util_envs.py:355-381
+// Both are the same kernel, templated on the float type of the observable rows.
 //
-// The reference recomputes all single-flip gains with a dense [B,N,N] matmul every step.  Here the
-// gains ("immediate cuts available", delta[b,i] = s_i * sum_j W_ij s_j) are a resident int32 [B,N]
-// cache updated incrementally: flipping node a negates delta[a] and changes delta[j] of each
-// neighbour j by 2 * W_ja * s_j * s_a'  -- O(deg) instead of O(N^2) -- the idea of
-// rlsolver/methods/S2V_PPO/env.py:197-206.  The observable rows (state f32 [B,R,N]) are then written
-// in the same kernel; they are O(N) per env by their definition (time-since-flip touches every
-// node every step), which makes this kernel HBM-bound on (R + 2) * 4 * N bytes per env-step.
+// The reference recomputes all single-flip gains with a dense [B,N,N] matmul every step and re-derives
+// every per-env statistic from scratch.  Here everything that a flip changes in O(deg) is kept as resident
+// per-env state and updated in O(deg):
+//   delta[b,i] = s_i * sum_j W_ij s_j   ("immediate cuts available", int32) -- flipping a negates delta[a] and
+//                                        moves delta[j] of each neighbour by 2 W_ja s_j s_a' (S2V_PPO/env.py:197-206)
+//   num_nonpos[b] = #{i : delta_i <= 0}  (greedy-actions observable, basin test)
+//   dist_best[b]  = Hamming distance to best_spins
+//   packed[b,:], hash[b]                 bit-packed spins + their Zobrist hash (visited-state memory)
+// and only the entries of the IMMEDIATE_REWARD_AVAILABLE row that changed are rewritten.  What is left per
+// step is what the observation contract itself makes O(N): time-since-flip (+= 1/max_steps everywhere) and the
+// four broadcast rows (termination, greedy count, distance from best score / state): 6 * sizeof(T) * N bytes
+// per env-step with the ECO observables, streamed with 16-byte lanes.
 //
-// One wave per env; lanes stride over nodes / over the action node's CSR row.
+// One wave per env.
 #include "rls_tile.h"
+#include <cmath>
 
 namespace rls {
 
@@ -19,111 +27,276 @@ struct SpinRows {  // row index of each observable inside state[b], or -1 when a
     int immediate, time_since_flip, episode_time, termination, greedy, dist_score, dist_state;
 };
 
-__device__ __forceinline__ float wave_sum_f(float v) {
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+template <typename T> struct RowVec;
+template <> struct RowVec<float> { using type = f32x4; static constexpr int n = 4; };
+template <> struct RowVec<double> { using type = f64x2; static constexpr int n = 2; };
+
+// splitmix64 finaliser: the Zobrist key of a node
+__device__ __forceinline__ uint64_t spin_zobrist(uint32_t node) {
+    uint64_t z = ((uint64_t)node + 1ull) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__device__ __forceinline__ uint64_t wave_xor_u64(uint64_t v) {
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    for (int m = 32; m >= 1; m >>= 1) v ^= __shfl_xor(v, m, 64);
     return v;
 }
 
-__global__ __launch_bounds__(256) void k_spin_step(float* __restrict__ state, int64_t B, int64_t N, int R,
-                                                   int32_t* __restrict__ delta,
+// row[n] = f(n, row[n]) for all n; 16-byte lanes when VEC
+template <typename T, bool VEC, typename F>
+__device__ __forceinline__ void row_update(T* __restrict__ row, int64_t N, int lane, F f) {
+    if constexpr (VEC) {
+        using V = typename RowVec<T>::type;
+        constexpr int PER = RowVec<T>::n;
+        V* rv = reinterpret_cast<V*>(row);
+        const int64_t nv = N / PER;
+#pragma unroll 2
+        for (int64_t i = lane; i < nv; i += kWave) {
+            V v = rv[i];
+#pragma unroll
+            for (int q = 0; q < PER; ++q) v[q] = f(i * PER + q, v[q]);
+            rv[i] = v;
+        }
+    } else {
+        for (int64_t n = lane; n < N; n += kWave) row[n] = f(n, row[n]);
+    }
+}
+
+template <typename T, bool VEC>
+__device__ __forceinline__ void row_fill(T* __restrict__ row, int64_t N, int lane, T value) {
+    if constexpr (VEC) {
+        using V = typename RowVec<T>::type;
+        constexpr int PER = RowVec<T>::n;
+        V* rv = reinterpret_cast<V*>(row);
+        V v;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) v[q] = value;
+        const int64_t nv = N / PER;
+#pragma unroll 4
+        for (int64_t i = lane; i < nv; i += kWave) rv[i] = v;
+    } else {
+        for (int64_t n = lane; n < N; n += kWave) row[n] = value;
+    }
+}
+
+struct SpinStepArgs {
+    double max_local, time_inc, termination_value, reward_div, stag_punishment, basin_reward;
+    int reward_mode, use_stag, use_basin;
+    int64_t hist_len;
+};
+
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void k_spin_step(rls_spin_env env, int64_t B, int64_t N, int R,
                                                    const int32_t* __restrict__ rowptr,
                                                    const int32_t* __restrict__ col,
                                                    const int32_t* __restrict__ wgt,
-                                                   const int64_t* __restrict__ action,
-                                                   float* __restrict__ score, float* __restrict__ best_score,
-                                                   float* __restrict__ best_spins, float* __restrict__ reward,
-                                                   int32_t* __restrict__ num_nonpos, SpinRows rows,
-                                                   float max_local, float time_inc, float termination_value,
-                                                   int reward_mode, float reward_div) {
+                                                   const int64_t* __restrict__ action, T* __restrict__ reward,
+                                                   uint8_t* __restrict__ visited_new, SpinRows rows, SpinStepArgs p) {
     const int lane = threadIdx.x & (kWave - 1);
     const int64_t b = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
     if (b >= B) return;
-    float* st = state + b * R * N;
-    float* spins = st;  // row 0 = SPIN_STATE, signed {+1, -1}
-    int32_t* dl = delta + b * N;
+    T* st = reinterpret_cast<T*>(env.state) + b * R * N;
+    T* spins = st;  // row 0 = SPIN_STATE, signed {+1, -1}
+    int32_t* dl = env.delta + b * N;
+    T* score = reinterpret_cast<T*>(env.score);
+    T* best_score = reinterpret_cast<T*>(env.best_score);
+    T* bs = reinterpret_cast<T*>(env.best_spins) + b * N;
     const int64_t a = action[b];
+    if ((uint64_t)a >= (uint64_t)N) {   // the reference raises an IndexError; leave the env untouched, report NaN
+        if (lane == 0) {
+            reward[b] = (T)NAN;
+            if (visited_new) visited_new[b] = 0;
+        }
+        return;
+    }
+    const T max_local = (T)p.max_local, time_inc = (T)p.time_inc;
 
-    // 1. flip + score change (spinsystem_PECO.py:336-348): gain = delta[a] before the flip
-    const float s_old = spins[a];
-    const float s_new = -s_old;
+    // 1. flip + score change (spinsystem_PECO.py:336-348): gain = delta[a] before the flip.  Neighbour updates
+    //    are returning L2 atomics (multi-edges may hit one node twice in a wave-instruction): every lane sees
+    //    the value its own add replaced, so the <= 0 census telescopes correctly.
+    const T s_old = spins[a];
+    const T s_new = -s_old;
+    const int sn = s_new > (T)0 ? 1 : -1;
     const int gain = dl[a];
     const int r0 = rowptr[a], r1 = rowptr[a + 1];
-    // Neighbour updates are L2 atomics (multi-edges may hit one node twice in a wave-instruction);
-    // everything that re-reads delta / spins below uses agent-scope (sc1) loads, which bypass this
-    // CU's L1 and therefore see the atomics' results once vmcnt has drained.
+    int adj = 0;
     for (int j = r0 + lane; j < r1; j += kWave) {
         const int nb = col[j];
         const int w = wgt ? wgt[j] : 1;
-        const int sj = spins[nb] > 0.0f ? 1 : -1;
-        atomicAdd(&dl[nb], 2 * w * sj * (s_new > 0.0f ? 1 : -1));
+        const int sj = spins[nb] > (T)0 ? 1 : -1;
+        const int c = 2 * w * sj * sn;
+        const int old = atomicAdd(&dl[nb], c);
+        adj += (int)((old + c) <= 0) - (int)(old <= 0);
     }
     if (lane == 0) {
+        adj += (int)(-gain <= 0) - (int)(gain <= 0);
         __hip_atomic_store(&dl[a], -gain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&spins[a], s_new, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        spins[a] = s_new;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
+    if (rows.immediate >= 0) {   // only the entries whose gain changed (agent-scope loads see the atomics' results)
+        T* imm = st + (int64_t)rows.immediate * N;
+        for (int j = r0 + lane; j < r1; j += kWave) {
+            const int nb = col[j];
+            const int d = __hip_atomic_load(&dl[nb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            imm[nb] = (T)d / max_local;
+        }
+        if (lane == 0) imm[a] = (T)(-gain) / max_local;
+    }
+    const int nonpos = env.num_nonpos[b] + wave_sum_i32(adj);
 
     // 2. reward w.r.t. the best observed score, best tracking (:366-401)
-    const float sc = score[b] + (float)gain;
-    const float best_before = best_score[b];
-    const float improvement = sc - best_before;
-    float rew;
-    if (reward_mode == 1) rew = improvement > 0.0f ? improvement : 0.0f;                       // BLS
-    else if (reward_mode == 2) rew = improvement > 0.0f ? improvement / (improvement + 0.1f) : 0.0f;  // CUSTOM_BLS
-    else rew = (float)gain;                                                                     // DENSE
-    rew = rew / reward_div;                                                                     // norm_rewards: rew /= n_spins
+    const T sc = score[b] + (T)gain;
+    const T best_before = best_score[b];
+    const T improvement = sc - best_before;
+    T rew;
+    if (p.reward_mode == 1) rew = improvement > (T)0 ? improvement : (T)0;                              // BLS
+    else if (p.reward_mode == 2) rew = improvement > (T)0 ? improvement / (improvement + (T)0.1) : (T)0; // CUSTOM_BLS
+    else rew = (T)gain;                                                                                  // DENSE
+    rew = rew / (T)p.reward_div;                                                                        // norm_rewards
     const bool new_best = sc > best_before;
-    const float best_now = new_best ? sc : best_before;
+    const T best_now = new_best ? sc : best_before;
 
-    // 3. observables (:412-451) + the O(N) pass: greedy count, distance to best state, best copy
-    int nonpos = 0, hamming = 0;
-    float* bs = best_spins + b * N;
-    for (int64_t n = lane; n < N; n += kWave) {
-        const int d = __hip_atomic_load(&dl[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        nonpos += (d <= 0);
-        const float s = __hip_atomic_load(&spins[n], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (new_best) bs[n] = s;
-        else hamming += (bs[n] != s);
-        if (rows.immediate >= 0) st[(int64_t)rows.immediate * N + n] = (float)d / max_local;
-        if (rows.time_since_flip >= 0) {
-            float* p = st + (int64_t)rows.time_since_flip * N + n;
-            *p = (n == a) ? 0.0f : (*p + time_inc);
+    // 3. visited-state memory (util_envs_PECO.py:228-288 / util_envs.py:355-381): exact compare of the bit-packed
+    //    spins against every earlier state of this env, Zobrist hash as the pre-filter
+    bool fresh = true;
+    if (env.packed) {
+        const int64_t W = (N + 63) >> 6;
+        uint64_t* pk = env.packed + b * W;
+        const int64_t wa = a >> 6;
+        const uint64_t bit = 1ull << (a & 63);
+        const uint64_t h = env.hash[b] ^ spin_zobrist((uint32_t)a);
+        const uint64_t* hh = env.hist_hash + b * env.hist_cap;
+        const uint64_t* hs = env.hist + b * env.hist_cap * W;
+        bool found = false;
+        for (int64_t t0 = 0; t0 < p.hist_len; t0 += kWave) {
+            const int64_t t = t0 + lane;
+            bool cand = t < p.hist_len && hh[t] == h;
+            if (cand) {
+                const uint64_t* e = hs + t * W;
+                for (int64_t k = 0; k < W && cand; ++k) cand = e[k] == (pk[k] ^ (k == wa ? bit : 0ull));
+            }
+            found = found || cand;
         }
-        if (rows.episode_time >= 0) st[(int64_t)rows.episode_time * N + n] += time_inc;
-        if (rows.termination >= 0) st[(int64_t)rows.termination * N + n] = termination_value;
+        fresh = ballot64(found) == 0;
+        __builtin_amdgcn_wave_barrier();
+        uint64_t* dst = env.hist + (b * env.hist_cap + p.hist_len) * W;
+        for (int64_t k = lane; k < W; k += kWave) {
+            const uint64_t cur = pk[k] ^ (k == wa ? bit : 0ull);
+            dst[k] = cur;
+            if (k == wa) pk[k] = cur;
+        }
+        if (lane == 0) {
+            env.hist_hash[b * env.hist_cap + p.hist_len] = h;
+            env.hash[b] = h;
+        }
+        if (p.use_stag && !fresh) rew = rew - (T)p.stag_punishment;
+        if (p.use_basin && fresh && nonpos == (int)N) rew = rew + (T)p.basin_reward;
     }
-    nonpos = wave_sum_i32(nonpos);
-    hamming = wave_sum_i32(hamming);
-    const float greedy = 1.0f - (float)nonpos / (float)N;
-    const float dscore = fabsf(sc - best_now) / max_local;
-    for (int64_t n = lane; n < N; n += kWave) {
-        if (rows.greedy >= 0) st[(int64_t)rows.greedy * N + n] = greedy;
-        if (rows.dist_score >= 0) st[(int64_t)rows.dist_score * N + n] = dscore;
-        if (rows.dist_state >= 0) st[(int64_t)rows.dist_state * N + n] = (float)hamming;
+
+    // 4. best spins / Hamming distance to them, kept incrementally
+    int ham;
+    if (new_best) {
+        ham = 0;
+        if constexpr (VEC) {
+            using V = typename RowVec<T>::type;
+            constexpr int PER = RowVec<T>::n;
+            const V* src = reinterpret_cast<const V*>(spins);
+            V* dst = reinterpret_cast<V*>(bs);
+            for (int64_t i = lane; i < N / PER; i += kWave) {
+                V v = src[i];
+#pragma unroll
+                for (int q = 0; q < PER; ++q) if (i * PER + q == a) v[q] = s_new;
+                dst[i] = v;
+            }
+        } else {
+            for (int64_t n = lane; n < N; n += kWave) bs[n] = (n == a) ? s_new : spins[n];
+        }
+    } else {
+        ham = env.dist_best[b] + ((bs[a] != s_new) ? 1 : -1);
     }
+
+    // 5. the rows that change everywhere every step (:412-451)
+    if (rows.time_since_flip >= 0)
+        row_update<T, VEC>(st + (int64_t)rows.time_since_flip * N, N, lane,
+                           [&](int64_t n, T v) { return n == a ? (T)0 : v + time_inc; });
+    if (rows.episode_time >= 0)
+        row_update<T, VEC>(st + (int64_t)rows.episode_time * N, N, lane, [&](int64_t, T v) { return v + time_inc; });
+    if (rows.termination >= 0) row_fill<T, VEC>(st + (int64_t)rows.termination * N, N, lane, (T)p.termination_value);
+    if (rows.greedy >= 0) row_fill<T, VEC>(st + (int64_t)rows.greedy * N, N, lane, (T)1 - (T)nonpos / (T)N);
+    if (rows.dist_score >= 0)
+        row_fill<T, VEC>(st + (int64_t)rows.dist_score * N, N, lane, (T)fabs((double)(sc - best_now)) / max_local);
+    if (rows.dist_state >= 0) row_fill<T, VEC>(st + (int64_t)rows.dist_state * N, N, lane, (T)ham);
     if (lane == 0) {
         score[b] = sc;
         best_score[b] = best_now;
         reward[b] = rew;
-        num_nonpos[b] = nonpos;
+        env.num_nonpos[b] = nonpos;
+        env.dist_best[b] = ham;
+        if (visited_new) visited_new[b] = fresh ? 1 : 0;
     }
 }
 
-// reset helper: delta[b,i] = s_i * sum_j W_ij s_j from signed f32 spins (row 0 of state)
-__global__ void k_spin_delta_init(const float* __restrict__ state, int64_t B, int64_t N, int R,
-                                  const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-                                  const int32_t* __restrict__ wgt, int32_t* __restrict__ delta) {
-    const int64_t total = B * N;
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
-         t += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t b = t / N, i = t - b * N;
-        const float* s = state + b * R * N;
-        const int si = s[i] > 0.0f ? 1 : -1;
-        int acc = 0;
-        for (int j = rowptr[i]; j < rowptr[i + 1]; ++j) acc += (wgt ? wgt[j] : 1) * (s[col[j]] > 0.0f ? 1 : -1);
-        delta[t] = si * acc;
+// reset: rows and per-env statistics from the signed spins in row 0 and the gain cache (spinsystem_PECO.py:150-195,
+// spinsystem.py:176-252): immediate row, greedy row, every other row zero, score = cut, best := current, census,
+// packed spins + hash, empty history.
+template <typename T>
+__global__ __launch_bounds__(256) void k_spin_reset(rls_spin_env env, int64_t B, int64_t N, int R, SpinRows rows,
+                                                    double max_local_d, int64_t weight_sum) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int64_t b = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+    if (b >= B) return;
+    T* st = reinterpret_cast<T*>(env.state) + b * R * N;
+    const int32_t* dl = env.delta + b * N;
+    T* bs = reinterpret_cast<T*>(env.best_spins) + b * N;
+    const T max_local = (T)max_local_d;
+    int nonpos = 0;
+    int64_t dsum = 0;
+    uint64_t h = 0;
+    const int64_t W = (N + 63) >> 6;
+    for (int64_t n0 = 0; n0 < N; n0 += kWave) {
+        const int64_t n = n0 + lane;
+        const bool in = n < N;
+        const T s = in ? st[n] : (T)-1;
+        const int d = in ? dl[n] : 1;
+        nonpos += (in && d <= 0);
+        dsum += in ? d : 0;
+        if (in) bs[n] = s;
+        const uint64_t word = ballot64(in && s > (T)0);
+        if (env.packed) {
+            if (in && s > (T)0) h ^= spin_zobrist((uint32_t)n);
+            if (lane == 0) env.packed[b * W + (n0 >> 6)] = word;
+        }
+    }
+    nonpos = wave_sum_i32(nonpos);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) dsum += __shfl_xor(dsum, m, 64);
+    const T greedy = (T)1 - (T)nonpos / (T)N;
+    for (int r = 1; r < R; ++r) {
+        T* row = st + (int64_t)r * N;
+        for (int64_t n = lane; n < N; n += kWave) {
+            T v = (T)0;
+            if (r == rows.immediate) v = (T)dl[n] / max_local;
+            else if (r == rows.greedy) v = greedy;
+            row[n] = v;
+        }
+    }
+    if (lane == 0) {
+        // cut = 1/4 sum_ij W_ij (1 - s_i s_j) = (sum_ij W_ij - sum_i delta_i) / 4: an integer, exact in T
+        const T sc = (T)(weight_sum - dsum) / (T)4;
+        reinterpret_cast<T*>(env.score)[b] = sc;
+        reinterpret_cast<T*>(env.best_score)[b] = sc;
+        env.num_nonpos[b] = nonpos;
+        env.dist_best[b] = 0;
+    }
+    if (env.packed) {
+        h = wave_xor_u64(h);
+        if (lane == 0) env.hash[b] = h;
     }
 }
 
@@ -131,36 +304,68 @@ __global__ void k_spin_delta_init(const float* __restrict__ state, int64_t B, in
 
 using namespace rls;
 
-extern "C" {
-
-int rls_spin_delta_init(const rls_graph* g, const float* state, int64_t B, int32_t num_rows, int32_t* delta,
-                        void* stream) {
-    if (int rc = check_graph(g)) return rc;
-    RLS_REQUIRE(B >= 0 && num_rows >= 1, RLS_EINVAL, "bad sizes");
-    if (B == 0) return RLS_OK;
-    RLS_REQUIRE(state && delta, RLS_EINVAL, "NULL pointer");
-    hipLaunchKernelGGL(k_spin_delta_init, dim3(grid_for(B * g->num_nodes, 256)), dim3(256), 0, as_stream(stream), state,
-                       B, g->num_nodes, num_rows, g->rowptr, g->col, g->wgt, delta);
-    return check_launch("k_spin_delta_init");
+static int check_spin_env(const rls_spin_env* env, int state_bytes, int32_t num_rows, const int32_t* row_index,
+                          SpinRows* rows) {
+    RLS_REQUIRE(env && row_index, RLS_EINVAL, "env / row_index is NULL");
+    RLS_REQUIRE(state_bytes == 4 || state_bytes == 8, RLS_EINVAL, "state_bytes must be 4 (f32) or 8 (f64)");
+    RLS_REQUIRE(num_rows >= 1, RLS_EINVAL, "num_rows < 1");
+    RLS_REQUIRE(env->state && env->delta && env->score && env->best_score && env->best_spins && env->num_nonpos &&
+                    env->dist_best, RLS_EINVAL, "NULL pointer in rls_spin_env");
+    RLS_REQUIRE(!env->packed || (env->hash && env->hist && env->hist_hash && env->hist_cap > 0), RLS_EINVAL,
+                "visited-state memory needs packed, hash, hist, hist_hash and hist_cap > 0");
+    *rows = SpinRows{row_index[0], row_index[1], row_index[2], row_index[3], row_index[4], row_index[5], row_index[6]};
+    const int* ri = &rows->immediate;
+    for (int k = 0; k < 7; ++k) RLS_REQUIRE(ri[k] < num_rows && ri[k] != 0, RLS_EINVAL, "row_index[%d]=%d out of range", k, ri[k]);
+    return RLS_OK;
 }
 
-int rls_spin_step(const rls_graph* g, float* state, int64_t B, int32_t num_rows, const int32_t* row_index,
-                  int32_t* delta, const int64_t* action, float* score, float* best_score, float* best_spins,
-                  float* reward, int32_t* num_nonpos, float max_local, float time_inc, float termination_value,
-                  int32_t reward_mode, float reward_div, void* stream) {
+extern "C" {
+
+int rls_spin_reset(const rls_graph* g, const rls_spin_env* env, int state_bytes, int64_t B, int32_t num_rows,
+                   const int32_t* row_index, double max_local, int64_t weight_sum, void* stream) {
     if (int rc = check_graph(g)) return rc;
-    RLS_REQUIRE(B >= 0 && num_rows >= 1, RLS_EINVAL, "bad sizes");
+    RLS_REQUIRE(B >= 0, RLS_EINVAL, "B < 0");
+    SpinRows rows;
+    if (int rc = check_spin_env(env, state_bytes, num_rows, row_index, &rows)) return rc;
     if (B == 0) return RLS_OK;
-    RLS_REQUIRE(state && row_index && delta && action && score && best_score && best_spins && reward && num_nonpos,
-                RLS_EINVAL, "NULL pointer");
+    RLS_REQUIRE(max_local != 0.0, RLS_EINVAL, "max_local_reward_available is 0");
+    const dim3 grid((unsigned)ceil_div(B, 4)), block(256);
+    if (state_bytes == 4)
+        hipLaunchKernelGGL(k_spin_reset<float>, grid, block, 0, as_stream(stream), *env, B, g->num_nodes, num_rows, rows,
+                           max_local, weight_sum);
+    else
+        hipLaunchKernelGGL(k_spin_reset<double>, grid, block, 0, as_stream(stream), *env, B, g->num_nodes, num_rows, rows,
+                           max_local, weight_sum);
+    return check_launch("k_spin_reset");
+}
+
+int rls_spin_step(const rls_graph* g, const rls_spin_env* env, int state_bytes, int64_t B, int32_t num_rows,
+                  const int32_t* row_index, const int64_t* action, void* reward, uint8_t* visited_new, double max_local,
+                  double time_inc, double termination_value, int32_t reward_mode, double reward_div, int64_t hist_len,
+                  int32_t use_stag, double stag_punishment, int32_t use_basin, double basin_reward, void* stream) {
+    if (int rc = check_graph(g)) return rc;
+    RLS_REQUIRE(B >= 0, RLS_EINVAL, "B < 0");
+    SpinRows rows;
+    if (int rc = check_spin_env(env, state_bytes, num_rows, row_index, &rows)) return rc;
+    if (B == 0) return RLS_OK;
+    RLS_REQUIRE(action && reward, RLS_EINVAL, "action / reward is NULL");
     RLS_REQUIRE(reward_mode >= 0 && reward_mode <= 2, RLS_EINVAL, "reward_mode must be 0 (DENSE), 1 (BLS), 2 (CUSTOM_BLS)");
-    RLS_REQUIRE(max_local != 0.0f && reward_div != 0.0f, RLS_EINVAL, "max_local_reward_available / reward_div is 0");
-    SpinRows rows{row_index[0], row_index[1], row_index[2], row_index[3], row_index[4], row_index[5], row_index[6]};
-    const int* ri = &rows.immediate;
-    for (int k = 0; k < 7; ++k) RLS_REQUIRE(ri[k] < num_rows && ri[k] != 0, RLS_EINVAL, "row_index[%d]=%d out of range", k, ri[k]);
-    hipLaunchKernelGGL(k_spin_step, dim3((unsigned)ceil_div(B, 4)), dim3(256), 0, as_stream(stream), state, B,
-                       g->num_nodes, num_rows, delta, g->rowptr, g->col, g->wgt, action, score, best_score, best_spins,
-                       reward, num_nonpos, rows, max_local, time_inc, termination_value, reward_mode, reward_div);
+    RLS_REQUIRE(max_local != 0.0 && reward_div != 0.0, RLS_EINVAL, "max_local_reward_available / reward_div is 0");
+    RLS_REQUIRE(!(use_stag || use_basin) || env->packed, RLS_EINVAL, "stag_punishment / basin_reward need the visited-state memory");
+    RLS_REQUIRE(!env->packed || (hist_len >= 0 && hist_len < env->hist_cap), RLS_EINVAL,
+                "hist_len %lld outside [0, hist_cap = %lld)", (long long)hist_len, (long long)env->hist_cap);
+    const int64_t N = g->num_nodes;
+    const bool vec = ((((uintptr_t)env->state) | ((uintptr_t)env->best_spins)) & 15) == 0 && (N * state_bytes) % 16 == 0;
+    SpinStepArgs p{max_local, time_inc, termination_value, reward_div, stag_punishment, basin_reward,
+                   reward_mode, use_stag, use_basin, hist_len};
+    const dim3 grid((unsigned)ceil_div(B, 4)), block(256);
+    hipStream_t s = as_stream(stream);
+#define LAUNCH_SPIN(T, VEC)                                                                                            \
+    hipLaunchKernelGGL((k_spin_step<T, VEC>), grid, block, 0, s, *env, B, N, num_rows, g->rowptr, g->col, g->wgt, action, \
+                       (T*)reward, visited_new, rows, p)
+    if (state_bytes == 4) { if (vec) LAUNCH_SPIN(float, true); else LAUNCH_SPIN(float, false); }
+    else                  { if (vec) LAUNCH_SPIN(double, true); else LAUNCH_SPIN(double, false); }
+#undef LAUNCH_SPIN
     return check_launch("k_spin_step");
 }
 

@@ -74,15 +74,23 @@ __global__ __launch_bounds__(256) void k_maxcut_step(const T* __restrict__ xin, 
 
     int64_t act[EPW];
 #pragma unroll
-    for (int k = 0; k < EPW; ++k) act[k] = (k < nenv) ? action[b0 + k] : -1;
+    for (int k = 0; k < EPW; ++k) {
+        // an action outside [0, N) leaves its env untouched and reports reward = NaN (the reference raises an
+        // IndexError there; a kernel cannot, but it must not read or write another env's bytes)
+        const int64_t a = (k < nenv) ? action[b0 + k] : -1;
+        act[k] = ((uint64_t)a < (uint64_t)N) ? a : -1;
+    }
 
     int my_delta = 0;  // lane k keeps env k's gain
     auto publish = [&]() {
         if (lane < nenv) {
             const int64_t b = b0 + lane;
+            bool ok = false;
+#pragma unroll
+            for (int k = 0; k < EPW; ++k) if (lane == k) ok = act[k] >= 0;
             const int v = obj[b] + my_delta;
             obj[b] = v;
-            reward[b] = (float)my_delta;
+            reward[b] = ok ? (float)my_delta : __builtin_nanf("");
             if (cur) cur[b] = (float)v;
             if (done) done[b] = done_value;
         }
@@ -91,23 +99,25 @@ __global__ __launch_bounds__(256) void k_maxcut_step(const T* __restrict__ xin, 
     if constexpr (!EMIT) {
 #pragma unroll
         for (int k = 0; k < EPW; ++k)
-            if (k < nenv) {
+            if (act[k] >= 0) {
                 const int d = flip_gain<T, WEIGHTED>(xin + (b0 + k) * N, act[k], rowptr, col, wgt, lane);
                 if (lane == k) my_delta = d;
             }
         publish();
         if (lane < nenv) {  // in place: only the flipped spins are written
-            int64_t a = 0;
+            int64_t a = -1;
 #pragma unroll
             for (int k = 0; k < EPW; ++k) if (lane == k) a = act[k];
-            T* p = xout + (b0 + lane) * N + a;
-            *p = spin_flip<T>(*p);
+            if (a >= 0) {
+                T* p = xout + (b0 + lane) * N + a;
+                *p = spin_flip<T>(*p);
+            }
         }
         return;
     } else if constexpr (!VEC) {
 #pragma unroll
         for (int k = 0; k < EPW; ++k)
-            if (k < nenv) {
+            if (act[k] >= 0) {
                 const int d = flip_gain<T, WEIGHTED>(xin + (b0 + k) * N, act[k], rowptr, col, wgt, lane);
                 if (lane == k) my_delta = d;
             }
@@ -152,7 +162,7 @@ __global__ __launch_bounds__(256) void k_maxcut_step(const T* __restrict__ xin, 
         if constexpr (MODE == 0) {
 #pragma unroll
             for (int k = 0; k < EPW; ++k)
-                if (k < nenv) {
+                if (act[k] >= 0) {
                     const int d = flip_gain<T, WEIGHTED>(xin + (b0 + k) * N, act[k], rowptr, col, wgt, lane);
                     if (lane == k) my_delta = d;
                 }
@@ -180,7 +190,7 @@ __global__ __launch_bounds__(256) void k_maxcut_step(const T* __restrict__ xin, 
                     first = false;
 #pragma unroll
                     for (int k = 0; k < EPW; ++k)
-                        if (k < nenv) {
+                        if (act[k] >= 0) {
                             const int d = flip_gain<T, WEIGHTED>(xin + (b0 + k) * N, act[k], rowptr, col, wgt, lane);
                             if (lane == k) my_delta = d;
                         }
@@ -213,7 +223,7 @@ __global__ __launch_bounds__(256) void k_maxcut_step(const T* __restrict__ xin, 
 #pragma unroll
             for (int k = 0; k < EPW; ++k) {
                 r0[k] = 0; deg[k] = 0; nb[k] = 0; wv[k] = 0;
-                if (k < nenv) {
+                if (act[k] >= 0) {
                     r0[k] = rowptr[act[k]];
                     deg[k] = rowptr[act[k] + 1] - r0[k];
                     if (lane < deg[k]) {
@@ -226,7 +236,7 @@ __global__ __launch_bounds__(256) void k_maxcut_step(const T* __restrict__ xin, 
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int k = 0; k < EPW; ++k)
-                if (k < nenv) {
+                if (act[k] >= 0) {
                     const T* row = stage + (int64_t)k * N;
                     const bool xa = spin_is_set(row[act[k]]);
                     int d;
@@ -243,11 +253,13 @@ __global__ __launch_bounds__(256) void k_maxcut_step(const T* __restrict__ xin, 
             publish();
             __builtin_amdgcn_wave_barrier();
             if (lane < nenv) {
-                int64_t a = 0;
+                int64_t a = -1;
 #pragma unroll
                 for (int k = 0; k < EPW; ++k) if (lane == k) a = act[k];
-                T* p = stage + (int64_t)lane * N + a;
-                *p = spin_flip<T>(*p);
+                if (a >= 0) {
+                    T* p = stage + (int64_t)lane * N + a;
+                    *p = spin_flip<T>(*p);
+                }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
@@ -258,11 +270,20 @@ __global__ __launch_bounds__(256) void k_maxcut_step(const T* __restrict__ xin, 
     }
 }
 
-static int step_mode_from_env() {
-    // development knob; default 12 = MODE 2 (LDS staged) with nontemporal LDS-DMA loads (every input byte is
-    // read exactly once: 45.1 us vs 51.0 us per G22 launch), plain stores (nontemporal stores lose 2 us)
-    const char* e = getenv("RLS_STEP_MODE");
-    return e ? atoi(e) : 12;
+// development knobs, read once per process (no getenv on the launch path).  mode default 12 = MODE 2 (LDS staged) with nontemporal LDS-DMA loads
+// (every input byte is read exactly once: 45.1 us vs 51.0 us per G22 launch), plain stores (nontemporal stores
+// lose 2 us); epw / wpb = 0: automatic
+struct StepKnobs { int mode, epw, wpb; };
+static StepKnobs read_step_knobs() {
+    const char* m = getenv("RLS_STEP_MODE");
+    const char* e = getenv("RLS_STEP_EPW");
+    const char* w = getenv("RLS_STEP_WPB");
+    return StepKnobs{m ? atoi(m) : 12, e ? atoi(e) : 0, w ? atoi(w) : 0};
+}
+static StepKnobs step_knobs() {
+    static const bool reread = getenv("RLS_DEV_REREAD_ENV") != nullptr;   // tools/microbench.py, tools/sweep_step.py: A/B in one process
+    static const StepKnobs k = read_step_knobs();
+    return reread ? read_step_knobs() : k;
 }
 
 }  // namespace rls
@@ -282,23 +303,22 @@ extern "C" int rls_maxcut_step(const rls_graph* g, const void* x_in, void* x_out
     RLS_REQUIRE(!emit || (const char*)x_in + (size_t)B * N * spin_bytes <= (const char*)x_out ||
                     (const char*)x_out + (size_t)B * N * spin_bytes <= (const char*)x_in,
                 RLS_EINVAL, "x_in and x_out overlap partially");
-    const char* e_epw = getenv("RLS_STEP_EPW");
-    const char* e_wpb = getenv("RLS_STEP_WPB");
+    const StepKnobs knobs = step_knobs();
     // envs per wave: the largest of {8,4,2,1} whose staged run fits ~8 KB of LDS per wave (G22: 4) ...
     int epw_auto = 8;
     while (epw_auto > 1 && (int64_t)epw_auto * N * spin_bytes > 8192) epw_auto >>= 1;
     // ... but at least enough rows for a run to be a whole number of 16-byte vectors (N = 1000 bytes: >= 2 rows,
     // N = 7003 bytes: none of {1..8} works and the element-wise kernel runs)
     while (epw_auto < 8 && ((int64_t)epw_auto * N * spin_bytes) % 16 != 0) epw_auto <<= 1;
-    const int epw = e_epw ? atoi(e_epw) : (emit ? epw_auto : 4);   // in place: nothing is staged
+    const int epw = knobs.epw ? knobs.epw : (emit ? epw_auto : 4);   // in place: nothing is staged
     // flat runs of EPW rows start 16-byte aligned when one RUN is a multiple of 16 bytes
     const bool vec = ((((uintptr_t)x_in) | ((uintptr_t)x_out)) & 15) == 0 && ((int64_t)epw * N * spin_bytes) % 16 == 0;
-    const int waves_per_block = e_wpb ? atoi(e_wpb) : 4;
+    const int waves_per_block = knobs.wpb ? knobs.wpb : 4;
     const dim3 grid((unsigned)ceil_div(ceil_div(B, epw), waves_per_block)), block(waves_per_block * kWave);
     hipStream_t s = as_stream(stream);
     const bool weighted = g->wgt != nullptr;
     // mode: units = structure (0/1/2), tens = nontemporal loads, hundreds = nontemporal stores
-    int mode = step_mode_from_env();
+    const int mode = knobs.mode;
     int structure = mode % 10;
     const bool ntl = (mode / 10) % 10, nts = (mode / 100) % 10;
     size_t lds = 0;

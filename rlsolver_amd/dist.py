@@ -65,25 +65,66 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     return rank, local_rank, world
 
 
+OBJ_LIMIT = 1 << 42   # |objective| (doubled for float inputs) must stay below this for the packed key
+_EMPTY_KEY = -(1 << 63)  # what a rank with no envs contributes: loses against every real key
+
+
+def pack_bits(x: torch.Tensor) -> torch.Tensor:
+    """bool/uint8 [N] (0|1) -> uint8 [ceil(N/8)], bit k of byte j = x[8j + k] (control-plane sized: <= 10 KB)."""
+    n = x.numel()
+    pad = (-n) % 8
+    b = x.reshape(-1).to(torch.uint8)
+    if pad:
+        b = torch.cat([b, torch.zeros(pad, dtype=torch.uint8, device=b.device)])
+    w = torch.tensor([1, 2, 4, 8, 16, 32, 64, 128], dtype=torch.uint8, device=b.device)
+    return (b.view(-1, 8) * w).sum(dim=1, dtype=torch.uint8)
+
+
+def unpack_bits(p: torch.Tensor, n: int, dtype=torch.bool) -> torch.Tensor:
+    sh = torch.arange(8, dtype=torch.uint8, device=p.device)
+    return ((p[:, None] >> sh) & 1).reshape(-1)[:n].to(dtype)
+
+
 def global_best(local_vs: torch.Tensor, local_xs: Optional[torch.Tensor] = None, want_solution: bool = False,
                 group=None):
-    """Episode-boundary exchange.  local_vs int [B_local], local_xs [B_local, N] (bool/uint8).
+    """Episode-boundary exchange.  local_vs [B_local] integer, or float holding integers / half-integers (the
+    bidirectional envs return ``count / 2`` as float); local_xs [B_local, N] (bool/uint8).  B_local may be 0
+    (env_shard gives some ranks nothing when B < world): such a rank still joins every collective.
 
-    Returns (best_obj: int64 0-dim tensor, owner_rank: int64 0-dim tensor, best_x or None).
-    Single-process (no group initialised) degenerates to argmax over the local batch.
+    Returns (best_obj 0-dim tensor -- int64, or float64 for float input --, owner_rank int64 0-dim, best_x or
+    None).  The solution travels bit-packed (ceil(N/8) bytes).  Single-process (no group initialised)
+    degenerates to argmax over the local batch.
     """
-    li = local_vs.argmax()
-    lbest = local_vs[li].to(torch.int64)
+    is_float = local_vs.is_floating_point()
+    scale = 2 if is_float else 1
+    n_local = local_vs.numel()
+    dev = local_vs.device
+    if n_local:
+        li = local_vs.argmax()
+        raw = local_vs[li]
+        lbest = torch.round(raw.to(torch.float64) * 2).to(torch.int64) if is_float else raw.to(torch.int64)
+        ok = lbest.abs() < OBJ_LIMIT
+        if is_float:
+            ok = ok & (lbest.to(torch.float64) == raw.to(torch.float64) * 2)
+        torch._assert_async(ok, "global_best: objective outside the packed-key range (|obj| < 2^42) or not a half-integer")
+    else:
+        li, lbest = None, None
+    finish = (lambda o: o.to(torch.float64) / 2) if is_float else (lambda o: o)
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return lbest, torch.zeros((), dtype=torch.int64, device=local_vs.device), \
+        if not n_local:
+            raise ValueError("global_best: no envs at all")
+        return finish(lbest), torch.zeros((), dtype=torch.int64, device=dev), \
             (local_xs[li].clone() if (want_solution and local_xs is not None) else None)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    key = pack_key(lbest, rank, world).reshape(1)
+    key = (pack_key(lbest, rank, world) if n_local else torch.full((), _EMPTY_KEY, dtype=torch.int64, device=dev)).reshape(1)
     dist.all_reduce(key, op=dist.ReduceOp.MAX, group=group)            # C1: 8 bytes
     obj, owner = unpack_key(key[0], world)
     best_x = None
     if want_solution and local_xs is not None:
-        best_x = local_xs[li].clone() if rank == int(owner) else torch.empty_like(local_xs[0])
-        buf = best_x.view(torch.uint8) if best_x.dtype == torch.bool else best_x
-        dist.broadcast(buf, src=int(owner), group=group)                # C2: N bytes
-    return obj, owner, best_x
+        n = local_xs.shape[1]
+        src = int(owner)                                                # one host read per episode boundary
+        buf = pack_bits(local_xs[li]) if (rank == src and n_local) else \
+            torch.empty((n + 7) // 8, dtype=torch.uint8, device=local_xs.device)
+        dist.broadcast(buf, src=src, group=group)                      # C2: ceil(N/8) bytes
+        best_x = unpack_bits(buf, n, local_xs.dtype)
+    return finish(obj), owner, best_x

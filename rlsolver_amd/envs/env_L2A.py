@@ -108,7 +108,7 @@ class EnvMaxcut:
 
         ``noise`` (f32 [num_iters + 1, B, N]) replaces the randn_like draws -- test hook."""
         compute_vs = good_vs.shape == ()
-        if self.fused_local_search and ops.local_search_fusable(self.graph, num_spin):
+        if self.fused_local_search and ops.local_search_fusable(self.graph, num_spin, good_xs.shape[0]):
             # pre-pass kernel (weights + whole-batch max/min), then ONE kernel: threshold selection,
             # num_iters proposal rounds, greedy sweep, with the 64-env tile resident in LDS
             ws32, ws_std = ops.maxcut_ls_weights(self.graph, good_xs, 1)   # n0_num_n1 - k * vs_raw, exact in both flavours

@@ -13,9 +13,14 @@ SpinSystemUnbiased) and its instance-wise inference twin inference_network_env.p
 
 What runs where: the flip, the score change, the all-node gain cache ("immediate cuts available",
 kept as int32 [B, N] and updated in O(deg) instead of the reference's dense [B,N,N] matmul), reward,
-best tracking and every observable row are ONE HIP kernel per step (rls_spin_step).  The visited
-state memory behind stag_punishment / basin_reward is the reference's own packed-bit XOR compare
-(util_envs_PECO.py:228-288) in torch.  Edge weights must be integers (EdgeType.DISCRETE / unweighted).
+best tracking, every observable row AND the visited-state memory behind stag_punishment /
+basin_reward (HistoryBuffer, util_envs_PECO.py:228-288: bit-packed states of the episode in a
+pre-allocated [B, max_steps, N/64] ring, exact compare behind a Zobrist-hash pre-filter) are ONE HIP
+kernel per step (rls_spin_step); reset is the K3 gain kernel + rls_spin_reset.  Edge weights must
+be integers (EdgeType.DISCRETE / unweighted).
+
+``dtype=torch.float64`` gives the arithmetic of the reference's numpy env
+(ECO_S2V/src/envs/spinsystem.py); ``SpinSystemUnbiased`` below is that env's single-instance surface.
 """
 from __future__ import annotations
 
@@ -67,28 +72,6 @@ _ROW_ORDER = [Observable.IMMEDIATE_REWARD_AVAILABLE, Observable.TIME_SINCE_FLIP,
 _REWARD_MODE = {RewardSignal.DENSE: 0, RewardSignal.BLS: 1, RewardSignal.CUSTOM_BLS: 2}
 
 
-class _HistoryBuffer:
-    """Visited-state memory, util_envs_PECO.py:228-288: spins packed 8 per byte, exact compare
-    against every earlier state of the same env."""
-
-    def __init__(self, num_envs, device):
-        self.num_envs, self.device, self.buffer = num_envs, device, None
-        self._w = 2 ** torch.arange(7, -1, -1, device=device)
-
-    def update(self, spins_signed):
-        b01 = ((spins_signed + 1) / 2).to(torch.int64)
-        pad = (-b01.shape[1]) % 8
-        if pad:
-            b01 = torch.cat([b01, torch.zeros(b01.shape[0], pad, dtype=b01.dtype, device=b01.device)], dim=1)
-        packed = (b01.view(b01.shape[0], -1, 8) * self._w).sum(dim=2).to(torch.uint8)
-        if self.buffer is None:
-            self.buffer = packed.unsqueeze(0)
-            return torch.ones(self.num_envs, dtype=torch.bool, device=self.device)
-        visited = ((self.buffer ^ packed.unsqueeze(0)).sum(dim=2) == 0).any(dim=0)
-        self.buffer = torch.cat([self.buffer, packed.unsqueeze(0)], dim=0)
-        return ~visited
-
-
 class SpinSystem:
     class _ActionSpace:
         def __init__(self, n, device):
@@ -107,10 +90,13 @@ class SpinSystem:
                  reward_signal: RewardSignal = RewardSignal.DENSE, spin_basis: SpinBasis = SpinBasis.SIGNED,
                  norm_rewards: bool = False, horizon_length: Optional[int] = None,
                  stag_punishment: Optional[float] = None, basin_reward: Optional[float] = None,
-                 device=None, include_adjacency: bool = True):
+                 device=None, include_adjacency: bool = True, dtype=torch.float32):
         self.device = torch.device(device if device is not None else "cuda:0")
         if self.device.type != "cuda":
             raise TypeError(f"rlsolver_amd.SpinSystem needs a HIP device (got {self.device}); there is no CPU path")
+        if dtype not in (torch.float32, torch.float64):
+            raise TypeError("dtype must be torch.float32 or torch.float64")
+        self.dtype = dtype
         if observables[0] != Observable.SPIN_STATE:
             raise AssertionError("First observable must be Observation.SPIN_STATE.")
         if reward_signal not in _REWARD_MODE:
@@ -132,19 +118,38 @@ class SpinSystem:
         wdeg = np.zeros(num_nodes, np.int64)
         np.add.at(wdeg, np.repeat(np.arange(num_nodes), np.diff(csr.rowptr)), csr.wgt)
         self._max_local = float(wdeg.max())              # host copy: reading it back from the device synced every step
-        self.max_local_reward_available_ = torch.full((num_envs,), self._max_local, device=self.device)
+        self.max_local_reward_available_ = torch.full((num_envs,), self._max_local, device=self.device, dtype=dtype)
         if float(wdeg.max()) == 0.0 or np.abs(wdeg).sum() == 0:
             raise ValueError("empty graph / zero max local reward (the reference re-draws the graph here)")
         self.max_local_reward_available = self.max_local_reward_available_.unsqueeze(1).expand(-1, num_nodes)
         self._rows = (C.c_int32 * 7)(*[next((i for i, o in self.observables if o == want), -1) for want in _ROW_ORDER])
         self._matrix = None
-        R, B = len(observables), num_envs
-        self.state = torch.zeros((B, R, num_nodes), dtype=torch.float32, device=self.device)
-        self._delta = torch.zeros((B, num_nodes), dtype=torch.int32, device=self.device)
+        self._weight_sum = int(csr.wgt.sum())             # sum of W over ordered pairs
+        R, B, N = len(observables), num_envs, num_nodes
+        dt = self.dtype
+        self.state = torch.zeros((B, R, N), dtype=dt, device=self.device)
+        self._delta = torch.zeros((B, N), dtype=torch.int32, device=self.device)
         self._num_nonpos = torch.zeros(B, dtype=torch.int32, device=self.device)
-        self.score = torch.zeros(B, dtype=torch.float32, device=self.device)
-        self.best_score = self.score.clone()
-        self.best_spins = torch.zeros((B, num_nodes), dtype=torch.float32, device=self.device)
+        self._dist_best = torch.zeros(B, dtype=torch.int32, device=self.device)
+        self.score = torch.zeros(B, dtype=dt, device=self.device)
+        self.best_score = torch.zeros(B, dtype=dt, device=self.device)
+        self.best_spins = torch.zeros((B, N), dtype=dt, device=self.device)
+        self._use_hist = stag_punishment is not None or basin_reward is not None
+        W = (N + 63) // 64
+        if self._use_hist:   # one slot per step of an episode; torch.int64 carries the uint64 bit patterns
+            self._packed = torch.zeros((B, W), dtype=torch.int64, device=self.device)
+            self._hash = torch.zeros(B, dtype=torch.int64, device=self.device)
+            self._hist = torch.zeros((B, max_steps, W), dtype=torch.int64, device=self.device)
+            self._hist_hash = torch.zeros((B, max_steps), dtype=torch.int64, device=self.device)
+        self._visited_new = torch.ones(B, dtype=torch.uint8, device=self.device)
+        self._env = _abi.RlsSpinEnv(
+            state=self.state.data_ptr(), delta=self._delta.data_ptr(), score=self.score.data_ptr(),
+            best_score=self.best_score.data_ptr(), best_spins=self.best_spins.data_ptr(),
+            num_nonpos=self._num_nonpos.data_ptr(), dist_best=self._dist_best.data_ptr(),
+            packed=self._packed.data_ptr() if self._use_hist else 0, hash=self._hash.data_ptr() if self._use_hist else 0,
+            hist=self._hist.data_ptr() if self._use_hist else 0,
+            hist_hash=self._hist_hash.data_ptr() if self._use_hist else 0, hist_cap=max_steps if self._use_hist else 0)
+        self._sb = 8 if dt == torch.float64 else 4
         self.current_step = 0
         self.reset()
 
@@ -153,77 +158,69 @@ class SpinSystem:
     def matrix(self):
         if self._matrix is None:
             csr = self.graph.csr
-            m = np.zeros((self.n_spins, self.n_spins), dtype=np.float32)
-            np.add.at(m, (np.repeat(np.arange(self.n_spins), np.diff(csr.rowptr)), csr.col), csr.wgt.astype(np.float32))
-            self._matrix = torch.from_numpy(m).to(self.device)
+            m = np.zeros((self.n_spins, self.n_spins), dtype=np.float64)
+            np.add.at(m, (np.repeat(np.arange(self.n_spins), np.diff(csr.rowptr)), csr.col), csr.wgt.astype(np.float64))
+            self._matrix = torch.from_numpy(m).to(device=self.device, dtype=self.dtype)
         return self._matrix
 
     matrix_obs = matrix
+
+    def _round(self, v: float) -> float:
+        """A host scalar as the env's float type sees it (the f32 env rounds python floats to f32 first)."""
+        return float(np.float32(v)) if self.dtype == torch.float32 else float(v)
 
     def reset(self, spins=None):
         """spinsystem_PECO.py:150-195.  spins: optional [B, N] in the env's spin basis."""
         self.current_step = 0
         B, N = self.num_envs, self.n_spins
-        self.state.zero_()
         if spins is None:
             bits = ops.rand_spins(B, N, _seed_from_torch(), self.device)
             bits[:, 0] = torch.randint(0, 2, (B,), device=self.device, dtype=torch.bool)  # no gauge fixing here
-            self.state[:, 0, :] = 2 * bits.float() - 1
         else:
-            spins = torch.as_tensor(spins, device=self.device, dtype=torch.float32)
-            self.state[:, 0, :] = (2 * spins - 1) if self.spin_basis == SpinBasis.BINARY and spins.min() >= 0 else spins
-        _abi.call("rls_spin_delta_init", self.graph.ref, _ptr(self.state), B, self.state.shape[1], _ptr(self._delta),
-                  _stream(self.device))
-        # f32 quotients formed in f64 and rounded once: identical to a correctly rounded f32 division
-        # (torch's GPU tensor/scalar division multiplies by the reciprocal, 1 ulp off the CPU result)
-        imm = self._delta.double()
-        for idx, obs in self.observables:
-            if obs == Observable.IMMEDIATE_REWARD_AVAILABLE:
-                self.state[:, idx, :] = (imm / self.max_local_reward_available.double()).float()
-            elif obs == Observable.NUMBER_OF_GREEDY_ACTIONS_AVAILABLE:
-                self.state[:, idx, :] = (1 - (torch.sum(imm <= 0, dim=-1).double() / N).float()).unsqueeze(-1)
-        self.score = self.calculate_cut()
-        self.best_score = self.score.clone()
+            spins = torch.as_tensor(spins, device=self.device, dtype=self.dtype).reshape(B, N)
+            # _format_spins_to_signed (spinsystem_PECO.py:548-557): 0/1 input under the BINARY basis -> 2 s - 1 (sic:
+            # not the inverse of get_observation's (1 - s) / 2); already-signed input passes through
+            signed = (2 * spins - 1) if (self.spin_basis == SpinBasis.BINARY and spins.min() >= 0) else spins
+            bits = (signed > 0).contiguous()
+        self.state[:, 0, :] = 2 * bits.to(self.dtype) - 1
+        # gains of all single flips: delta_i = s_i sum_j W_ij s_j = sum_j W_ij (x_i == x_j ? 1 : -1): the K3 kernel
+        ops.maxcut_delta_all(self.graph, bits, out=self._delta)
+        _abi.call("rls_spin_reset", self.graph.ref, C.byref(self._env), self._sb, B, self.state.shape[1], self._rows,
+                  self._max_local, self._weight_sum, _stream(self.device))
         self.best_obs_score = self.best_score
-        self.best_spins = self.state[:, 0, :].clone()
         self.best_obs_spins = self.best_spins
-        self.history_buffer = _HistoryBuffer(B, self.device) if (self.stag_punishment is not None or
-                                                                  self.basin_reward is not None) else None
         return self.get_observation()
 
     def calculate_cut(self, spins=None):
-        """cut = 1/4 * sum_ij W_ij (1 - s_i s_j)  (spinsystem_PECO.py:564-566) = (sum(W)/2 - sum_i delta_i / 2) / 2,
+        """cut = 1/4 * sum_ij W_ij (1 - s_i s_j)  (spinsystem_PECO.py:564-566) = (sum(W) - sum_i delta_i) / 4,
         exact in integers."""
         if spins is not None:
             raise NotImplementedError("calculate_cut(spins) for foreign spins: use rlsolver_amd.ops.maxcut_obj")
-        wsum = int(self.graph.csr.wgt.sum())             # = sum_ij W_ij over ordered pairs
-        return (wsum - self._delta.sum(dim=1)).float() / 4
+        return (self._weight_sum - self._delta.sum(dim=1)).to(self.dtype) / 4
 
     def calculate_score(self, spins=None):
         return self.calculate_cut(spins)
 
     def step(self, action):
-        """spinsystem_PECO.py:306-486 -> (obs, reward f32 [B], done bool [B])"""
+        """spinsystem_PECO.py:306-486 -> (obs, reward [B], done bool [B])"""
         self.current_step += 1
         if self.current_step > self.max_steps:
             print("The environment has already returned done. Stop it!")
             raise NotImplementedError
         B = self.num_envs
-        action = action.to(device=self.device, dtype=torch.int64).contiguous()
-        rew = torch.empty(B, dtype=torch.float32, device=self.device)
-        # max(0, (current_step - max_steps) / horizon_length + 1), evaluated in f32 like the reference's torch ops
-        term = float(max(np.float32(0.0), np.float32((self.current_step - self.max_steps) / self.horizon_length) + np.float32(1)))
-        _abi.call("rls_spin_step", self.graph.ref, _ptr(self.state), B, self.state.shape[1], self._rows,
-                  _ptr(self._delta), _ptr(action), _ptr(self.score), _ptr(self.best_score), _ptr(self.best_spins),
-                  _ptr(rew), _ptr(self._num_nonpos), self._max_local,
-                  float(np.float32(1.0 / self.max_steps)), term, _REWARD_MODE[self.reward_signal],
-                  float(self.n_spins) if self.norm_rewards else 1.0, _stream(self.device))
-        if self.history_buffer is not None:
-            visiting_new_state = self.history_buffer.update(self.state[:, 0, :])
-            if self.stag_punishment is not None:
-                rew[~visiting_new_state] -= self.stag_punishment
-            if self.basin_reward is not None:
-                rew[(self._num_nonpos == self.n_spins) & visiting_new_state] += self.basin_reward
+        action = torch.as_tensor(action, device=self.device).to(torch.int64).reshape(B).contiguous()
+        rew = torch.empty(B, dtype=self.dtype, device=self.device)
+        # max(0, (current_step - max_steps) / horizon_length + 1), evaluated in the env's float type like the reference
+        if self.dtype == torch.float32:
+            term = float(max(np.float32(0.0), np.float32((self.current_step - self.max_steps) / self.horizon_length) + np.float32(1)))
+        else:
+            term = max(0.0, ((self.current_step - self.max_steps) / self.horizon_length) + 1)
+        _abi.call("rls_spin_step", self.graph.ref, C.byref(self._env), self._sb, B, self.state.shape[1], self._rows,
+                  _ptr(action), _ptr(rew), _ptr(self._visited_new), self._max_local, self._round(1.0 / self.max_steps), term,
+                  _REWARD_MODE[self.reward_signal], float(self.n_spins) if self.norm_rewards else 1.0,
+                  self.current_step - 1, int(self.stag_punishment is not None),
+                  self._round(self.stag_punishment or 0.0), int(self.basin_reward is not None),
+                  self._round(self.basin_reward or 0.0), _stream(self.device))
         done = torch.full((B,), self.current_step == self.max_steps, dtype=torch.bool, device=self.device)
         return self.get_observation(), rew, done
 
@@ -236,10 +233,85 @@ class SpinSystem:
         return torch.cat((state, self.matrix.unsqueeze(0).expand(state.shape[0], -1, -1)), dim=-2)
 
     def get_immeditate_rewards_avaialable(self, spins=None):
-        return self._delta.float()
+        return self._delta.to(self.dtype)
 
     def get_allowed_action_states(self):
         return (0, 1) if self.spin_basis == SpinBasis.BINARY else (1, -1)
 
     def get_best_cut(self):
         return self.best_score
+
+    # ---- checkpoint of the env state: everything a later step depends on
+    _STATE_KEYS = ("state", "_delta", "score", "best_score", "best_spins", "_num_nonpos", "_dist_best")
+    _HIST_KEYS = ("_packed", "_hash", "_hist", "_hist_hash")
+
+    def state_dict(self):
+        keys = self._STATE_KEYS + (self._HIST_KEYS if self._use_hist else ())
+        d = {k.lstrip("_"): getattr(self, k).clone() for k in keys}
+        d["current_step"] = self.current_step
+        return d
+
+    def load_state_dict(self, d):
+        keys = self._STATE_KEYS + (self._HIST_KEYS if self._use_hist else ())
+        for k in keys:
+            getattr(self, k).copy_(d[k.lstrip("_")])     # in place: the kernel's pointer table stays valid
+        self.current_step = int(d["current_step"])
+
+
+class SpinSystemUnbiased:
+    """The single-instance numpy surface of rlsolver/methods/ECO_S2V/src/envs/spinsystem.py:588-661
+    (``SpinSystemUnbiased``; base class :62-520) on the HIP env above with one env in float64:
+
+        reset(spins=None) -> obs  np.float64 [R + N, N]   (np.vstack((state, matrix)), :484-495)
+        step(action: int) -> (obs, reward: float, done: bool, None)                      (:333-482)
+
+    attrs: n_spins, max_steps, current_step, score, best_score, best_spins, state (np [R, N]), matrix.
+    ExtraAction.NONE, OptimisationTarget.CUT, infinite memory, reversible spins (what ECO / S2V use)."""
+
+    def __init__(self, mygraph, num_nodes: int, max_steps: int = 20,
+                 observables: Sequence[Observable] = ECO_PECO_OBSERVABLES,
+                 reward_signal: RewardSignal = RewardSignal.DENSE, spin_basis: SpinBasis = SpinBasis.SIGNED,
+                 norm_rewards: bool = False, horizon_length: Optional[int] = None,
+                 stag_punishment: Optional[float] = None, basin_reward: Optional[float] = None, device=None,
+                 init_spins=None):
+        self._env = SpinSystem(mygraph, num_nodes, 1, max_steps, observables, reward_signal, spin_basis, norm_rewards,
+                               horizon_length, stag_punishment, basin_reward, device, include_adjacency=True,
+                               dtype=torch.float64)
+        self.n_spins, self.max_steps, self.n_actions = num_nodes, max_steps, num_nodes
+        self.observables = self._env.observables
+        self.action_space, self.observation_space = self._env.action_space, self._env.observation_space
+        self.max_local_reward_available = self._env._max_local
+        if init_spins is not None:
+            self.reset(init_spins)
+
+    def _obs(self, obs):
+        return obs[0].cpu().numpy()
+
+    def reset(self, spins=None):
+        return self._obs(self._env.reset(None if spins is None else np.asarray(spins, dtype=np.float64)[None, :]))
+
+    def step(self, action):
+        obs, rew, done = self._env.step(torch.tensor([int(action)], dtype=torch.int64))
+        return self._obs(obs), float(rew[0]), bool(done[0]), None
+
+    def get_observation(self):
+        return self._obs(self._env.get_observation())
+
+    current_step = property(lambda self: self._env.current_step)
+    score = property(lambda self: float(self._env.score[0]))
+    best_score = property(lambda self: float(self._env.best_score[0]))
+    best_spins = property(lambda self: self._env.best_spins[0].cpu().numpy())
+    state = property(lambda self: self._env.state[0].cpu().numpy())
+    matrix = property(lambda self: self._env.matrix.cpu().numpy())
+
+    def get_immeditate_rewards_avaialable(self, spins=None):
+        return self._env._delta[0].cpu().numpy().astype(np.float64)
+
+    def calculate_score(self, spins=None):
+        return float(self._env.calculate_cut()[0])
+
+    def get_best_cut(self):
+        return self.best_score
+
+    def get_allowed_action_states(self):
+        return self._env.get_allowed_action_states()

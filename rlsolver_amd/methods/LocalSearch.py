@@ -50,7 +50,7 @@ class LocalSearch:
             raise RuntimeError("Index put requires the source and destination dtypes match, "
                                "got Float for the destination and Long for the source.")
 
-        if getattr(sim, "fused_local_search", False) and ops.local_search_fusable(sim.graph, num_spin) and num_iters > 0:
+        if getattr(sim, "fused_local_search", False) and ops.local_search_fusable(sim.graph, num_spin, prev_xs.shape[0]) and num_iters > 0:
             # pre-pass + one kernel; here the first draw both fixes the threshold and is the first proposal (:66-69)
             ws32, ws_std = ops.maxcut_ls_weights(sim.graph, prev_xs, 2)     # n0_num_n1 - 2 * prev_vs_raw (:64)
             rd_std = ws_std.float() * noise_std

@@ -12,7 +12,7 @@ from typing import Optional
 import numpy as np
 import torch
 
-from .. import ops, ops_mcpg_tsp as mops
+from .. import _abi, ops, ops_mcpg_tsp as mops
 from ..graph import build_csr, read_edge_arrays
 
 TEN = torch.Tensor
@@ -155,6 +155,8 @@ def metro_sampling(probs: TEN, start_status: TEN, max_transfer_time: int, device
     Tmax = max_transfer_time * 5
     if index is not None:
         Tmax = min(Tmax, index.shape[0])
+    if Tmax <= 0:   # no rounds (N < 10 gives T = int(N / 10) = 0): the reference returns start_status.bool().float()
+        return start.clone() if samples is not start else start
     seed = _seed_from_torch() if index is None else 0
     # Walk the rounds in chunks of T.  A round accepts at most C proposals, so the cumulative count cannot reach
     # C*T before the LAST round of the first chunk: that chunk is applied directly (one pass, counting as it
@@ -194,7 +196,8 @@ def sampler_func(data, xs_sample: TEN, num_ls: int, total_mcmc_num: int, repeat_
     repeats.  ``uniforms`` f32 [num_ls, N, C] replaces torch.rand (test hook)."""
     xs_sample = xs_sample.contiguous()
     seed = _seed_from_torch() if uniforms is None else 0
-    if uniforms is None and getattr(data, '_lv_ptr', None) is not None and xs_sample.shape[0] * 8 + 8192 < 150 * 1024:
+    if uniforms is None and getattr(data, '_lv_ptr', None) is not None and _abi.lib().rls_mcpg_local_search_levels_supported(
+            data.graph.ref, data._lv_ptr.numel() - 1):
         # production path: level-parallel kernel (the draws only ever decide ties, so it carries coins, not uniforms)
         xs_loc, expected = mops.mcpg_local_search_levels(data.graph, xs_sample, data._lv_ptr, data._lv_data, num_ls, seed)
     else:

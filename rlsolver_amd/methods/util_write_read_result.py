@@ -14,11 +14,32 @@ from typing import Optional, Sequence, Union
 import numpy as np
 
 
+def result_file_name(filename: str, running_duration: Optional[int]) -> str:
+    """Where the reference would put the result of ``filename`` (util_write_read_result.py:55-67 with
+    methods/util.py:200-211): a path under .../data/... goes to the same place under .../result/... (directory
+    created), the running duration is appended as ``_<seconds>`` (``_`` alone when it is None); and an existing
+    file is NEVER overwritten -- lowercase letters are appended until the name is free."""
+    tail = "_" if running_duration is None else ("_" + str(int(running_duration)) if "data" in filename else None)
+    new = filename.replace("data", "result") if "data" in filename else filename
+    d = os.path.dirname(new)
+    if d and not os.path.exists(d):
+        os.makedirs(d, exist_ok=True)
+    if tail is not None:
+        new = new.replace(".txt", "") + tail + ".txt"
+    rng = np.random.default_rng()
+    while os.path.exists(new):
+        stem, ext = os.path.splitext(new)
+        new = stem + "abcdefghijklmnopqrstuvwxyz"[int(rng.integers(26))] + ext
+    return new
+
+
 def write_graph_result(obj: Union[float, int], running_duration: Optional[int], num_nodes: Optional[int],
                        alg_name: str, solution: Sequence, filename: str, plus1: bool = True,
                        info_dict: Optional[dict] = None) -> str:
+    """Writes the result and returns the path actually used (see result_file_name: never an existing file)."""
     sol = np.asarray(solution.detach().cpu().numpy() if hasattr(solution, "detach") else solution).astype(np.int64)
-    with open(filename, "w", encoding="UTF-8") as f:
+    filename = result_file_name(filename, running_duration)
+    with open(filename, "x", encoding="UTF-8") as f:
         f.write(f"// obj: {obj}\n")
         f.write(f"// running_duration: {running_duration}\n")
         if num_nodes is not None:

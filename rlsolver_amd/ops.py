@@ -18,8 +18,13 @@ from .graph import GraphCSR
 TEN = torch.Tensor
 
 
+_raw_stream = torch._C._cuda_getCurrentRawStream   # (device index) -> hipStream_t as int; ~0.1 us
+
+
 def _stream(device) -> C.c_void_p:
-    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    """torch's CURRENT HIP stream of ``device``, resolved at call time (so a capture stream is honoured)."""
+    idx = device.index
+    return C.c_void_p(_raw_stream(torch.cuda.current_device() if idx is None else idx))
 
 
 def _check(t: TEN, name: str, dtypes, device=None, shape=None) -> TEN:
@@ -157,9 +162,11 @@ def maxcut_node_cutdeg(g: DeviceGraph, xs: TEN) -> TEN:
     return out
 
 
-def maxcut_delta_all(g: DeviceGraph, xs: TEN) -> TEN:
+def maxcut_delta_all(g: DeviceGraph, xs: TEN, out: Optional[TEN] = None) -> TEN:
     B, _ = _spins(xs, "xs", g)
-    out = torch.empty((B, g.num_nodes), dtype=torch.int32, device=g.device)
+    if out is None:
+        out = torch.empty((B, g.num_nodes), dtype=torch.int32, device=g.device)
+    _check(out, "out", (torch.int32,), g.device, (B, g.num_nodes))
     _abi.call("rls_maxcut_delta_all", g.ref, _ptr(xs), B, _ptr(out), _stream(g.device))
     return out
 
@@ -184,10 +191,10 @@ def maxcut_step(g: DeviceGraph, x_in: TEN, x_out: TEN, action: TEN, obj: TEN, re
 
 def maxcut_step_launcher(g: DeviceGraph, x_in: TEN, x_out: TEN, action: TEN, obj: TEN, reward: TEN,
                          cur: Optional[TEN] = None, done: Optional[TEN] = None, done_value: float = 0.0):
-    """Validate once, launch many times: returns a zero-argument callable that enqueues K4 on the
-    stream that was current at creation time with the given (fixed) buffers -- for rollout loops that
-    cycle through a ring of pre-allocated slots, where per-call argument checking would otherwise
-    dominate the host cost of a 50 us kernel."""
+    """Validate once, launch many times: returns a zero-argument callable that enqueues K4 on torch's
+    current stream (resolved at every call, so the launcher also works under hipGraph capture) with the
+    given (fixed) buffers -- for rollout loops that cycle through a ring of pre-allocated slots, where
+    per-call argument checking would otherwise dominate the host cost of a 50 us kernel."""
     B, sb = _spins(x_in, "x_in", g, allow_f32=True)
     B2, sb2 = _spins(x_out, "x_out", g, allow_f32=True)
     if (B2, sb2) != (B, sb):
@@ -201,11 +208,12 @@ def maxcut_step_launcher(g: DeviceGraph, x_in: TEN, x_out: TEN, action: TEN, obj
         _check(done, "done", (torch.float32,), g.device, (B,))
     fn = _abi.lib().rls_maxcut_step
     args = (g.ref, _ptr(x_in), _ptr(x_out), sb, B, _ptr(action), _ptr(obj), _ptr(reward), _ptr(cur), _ptr(done),
-            C.c_float(done_value), _stream(g.device))
+            C.c_float(done_value))
     keep = (g, x_in, x_out, action, obj, reward, cur, done)   # keep the buffers alive with the closure
+    dev_index = g.device.index if g.device.index is not None else torch.cuda.current_device()
 
     def launch(_keep=keep):
-        rc = fn(*args)
+        rc = fn(*args, _raw_stream(dev_index))
         if rc != 0:
             raise _abi.RlsError("rls_maxcut_step", rc, _abi.lib().rls_last_error_string().decode())
     return launch
@@ -229,12 +237,10 @@ def maxcut_propose_accept(g: DeviceGraph, xs: TEN, mask: TEN, obj: TEN) -> None:
 LOCAL_SEARCH_MAX_SPIN = 15
 
 
-def local_search_fusable(g: DeviceGraph, num_spin: int) -> bool:
-    """Whether rls_maxcut_local_search covers this graph / setting (else: K2 + K6 + K5 path)."""
-    n = g.num_nodes
-    lds = (n + 2) * 8 + n * 8 + ((n + 4) // 4) * 16 + 4096 * 4 + 4 * 64 * 8 + 4 * 16 * 64 * 4
-    return (g.wgt is None and g.csr.max_degree < 512 and 0 <= num_spin <= LOCAL_SEARCH_MAX_SPIN and num_spin < n
-            and lds <= 160 * 1024 and g.num_stored_edges < (1 << 24))
+def local_search_fusable(g: DeviceGraph, num_spin: int, B: int = 1) -> bool:
+    """Whether rls_maxcut_local_search covers this graph / batch / setting (else: K2 + K6 + K5 path).  The library
+    answers with the test its launcher applies, so the gate and the launcher cannot disagree."""
+    return bool(_abi.lib().rls_maxcut_local_search_supported(g.ref, int(B), int(num_spin)))
 
 
 def maxcut_ls_weights(g: DeviceGraph, xs: TEN, mult: int):

@@ -1,4 +1,4 @@
-"""world_size-2 gloo test of the episode-boundary exchange (C1/C2) and the env sharding."""
+"""world_size-2 and -4 gloo tests of the episode-boundary exchange (C1/C2) and the env sharding."""
 import os
 import socket
 
@@ -52,6 +52,56 @@ def test_global_best_two_ranks():
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
     assert all(ret.get(r) for r in range(world))
+
+
+def _worker4(rank, world, port, ret):
+    """4 ranks, uneven shards (B = 6 -> 2, 2, 1, 1), an EMPTY shard (B = 3), float (bidirectional) objectives,
+    bit-packed solution broadcast for an N that is not a multiple of 8."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    rdist.init_from_env(backend="gloo")
+    N = 77
+    g = torch.Generator().manual_seed(99)
+    for Bg in (6, 3, 13):
+        xs_all = torch.randint(0, 2, (Bg, N), generator=g, dtype=torch.bool)
+        vs_all = torch.randint(-50, 50, (Bg,), generator=g)
+        off, cnt = rdist.env_shard(Bg, rank, world)
+        if Bg == 3:
+            assert cnt == (1 if rank < 3 else 0)          # rank 3 owns nothing and must not hang the others
+        obj, owner, bx = rdist.global_best(vs_all[off:off + cnt], xs_all[off:off + cnt], want_solution=True)
+        gi = int(vs_all.argmax())
+        assert int(obj) == int(vs_all.max()) and torch.equal(bx, xs_all[gi]) and bx.dtype == torch.bool
+        spans = [rdist.env_shard(Bg, rk, world) for rk in range(world)]
+        assert int(owner) == next(rk for rk, (o, c) in enumerate(spans) if o <= gi < o + c)
+        # float objectives of a bidirectional env (count / 2: integers or half-integers) keep their value
+        vf = vs_all.to(torch.float32) / 2
+        objf, ownerf, _ = rdist.global_best(vf[off:off + cnt])
+        assert objf.dtype == torch.float64 and float(objf) == float(vf.max()) and int(ownerf) == int(owner)
+    dist.barrier()
+    dist.destroy_process_group()
+    ret[rank] = True
+
+
+def test_global_best_four_ranks_uneven_and_empty_shards():
+    world = 4
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker4, args=(world, port, ret), nprocs=world, join=True)
+    assert all(ret.get(r) for r in range(world))
+
+
+def test_pack_bits_roundtrip():
+    g = torch.Generator().manual_seed(5)
+    for n in (1, 7, 8, 9, 77, 2000):
+        x = torch.randint(0, 2, (n,), generator=g, dtype=torch.bool)
+        p = rdist.pack_bits(x)
+        assert p.numel() == (n + 7) // 8 and torch.equal(rdist.unpack_bits(p, n), x)
+    with pytest.raises(Exception):
+        rdist.global_best(torch.tensor([1 << 50]))
+    with pytest.raises(Exception):
+        rdist.global_best(torch.tensor([0.25]))
+    assert float(rdist.global_best(torch.tensor([1.5, -2.0]))[0]) == 1.5
 
 
 def test_env_shard_partition():

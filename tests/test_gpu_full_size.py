@@ -128,21 +128,102 @@ def test_tsp_lengths_and_swap_deltas_at_full_size():
 
 
 def test_mcpg_sampler_at_full_size():
+    """BASELINE.json config #3 at its full size: BA n = 10^4, m = 5, 2^18 chains (2048 kept x 128 repeats)."""
     from rlsolver_amd import graph as G
-    n, C, R = 10000, 1 << 16, 128
+    n, C, R = 10000, 1 << 18, 128
     gb = np.asarray(G.generate_ba(n, 5, seed=5), dtype=np.int64)
     ei = gb[:, :2].T.copy()
     data = amcpg.make_data(n, ei[0], ei[1], DEV)
     torch.manual_seed(3)
-    xs = (torch.rand((n, C), device=DEV) < 0.5).float()
+    xs = torch.empty((n, C), device=DEV)
+    for c0 in range(0, C, 1 << 15):       # chunked: no second 10 GB temporary
+        xs[:, c0:c0 + (1 << 15)] = (torch.rand((n, 1 << 15), device=DEV) < 0.5).float()
     vs_good, xs_good, value = amcpg.sampler_func(data, xs, 4, C // R, R, DEV)
+    assert vs_good.shape == (C // R,) and xs_good.shape == (n, C // R) and value.shape == (C,)
     # the reported value of every kept chain is the cut of the kept chain, and the local search beat random clearly
+    assert bool(((xs_good == 0) | (xs_good == 1)).all())
     cut = ops.maxcut_obj(data.graph, (xs_good.t() > 0).contiguous())
     assert torch.equal(cut.float(), vs_good)
     assert float(vs_good.mean()) > 0.6 * data.num_edges
     assert abs(float(value.mean())) < 1e-2
-    # metro sampling keeps a 0/1 state and respects the proposal budget per chain
+    # value[c] = expected[c] - mean = (E - 2 cut_c) - mean: the best repeat of every kept chain has the lowest value
+    best = value.view(R, C // R).min(dim=0).values
+    torch.testing.assert_close(best - best[0], -2 * (vs_good - vs_good[0]), rtol=0, atol=1e-2)
+    del xs, xs_good
+    # metro sampling at the same size keeps a 0/1 state and respects the proposal budget per chain
     probs = torch.full((n,), 0.5, device=DEV)
-    out = amcpg.metro_sampling(probs, torch.zeros((n, 4096), device=DEV), n // 10, device=DEV)
+    start = torch.zeros((n, C), device=DEV)
+    out = amcpg.metro_sampling(probs, start, n // 10, device=DEV)
     flips = out.sum(0)
-    assert bool(((out == 0) | (out == 1)).all()) and float(flips.max()) <= n // 10
+    assert out.shape == (n, C) and bool(((out == 0) | (out == 1)).all()) and float(flips.max()) <= n // 10
+    assert float(flips.min()) > 0 and float(start.abs().sum()) == 0       # the caller's state is not modified
+    # p = 1/2 everywhere: every proposal is accepted ((1 - p) / p = 1 > u), so the stop rule fires after exactly
+    # T = n / 10 rounds: a chain has flipped between 1 and T distinct-parity nodes
+    assert float(flips.mean()) > 0.8 * (n // 10)
+
+
+def test_mcpg_metro_zero_rounds_returns_start():
+    """max_transfer_time = 0 (every graph with N < 10: change_times = int(N / 10)) must return the start
+    state like the reference (start_status.bool().float()), not uninitialised memory."""
+    start = (torch.rand((7, 96), device=DEV) < 0.5).float()
+    probs = torch.full((7,), 0.3, device=DEV)
+    out = amcpg.metro_sampling(probs, start, 0, device=DEV)
+    assert torch.equal(out, start) and out.data_ptr() != start.data_ptr()
+    out = amcpg.metro_sampling(probs, start.bool(), 0, device=DEV)
+    assert torch.equal(out, start) and out.dtype == torch.float32
+
+
+def test_local_search_falls_back_to_four_waves_when_eight_do_not_fit():
+    """N in ~5290..6449 with few tiles: the 8-wave LDS layout exceeds 160 KB, the 4-wave one fits; the
+    launcher must take it (it returned RLS_EUNSUPPORTED) and the Python gate must agree with the launcher."""
+    from rlsolver_amd.envs.env_L2A import EnvMaxcut
+    from rlsolver_amd.graph import generate_gnm
+    n, m, B = 6000, 18000, 256
+    mg = generate_gnm(n, m, 6)
+    env = EnvMaxcut(mygraph=mg, device=DEV, num_nodes=n)
+    assert ops.local_search_fusable(env.graph, 8, B)
+    torch.manual_seed(0)
+    xs = env.generate_xs_randomly(B)
+    x0 = xs.clone()
+    vs = env.calculate_obj_values(xs)
+    v0 = vs.clone()
+    env.local_search_inplace(xs, vs, num_iters=0)      # no proposal rounds: == the greedy sweep
+    ops.maxcut_greedy_sweep(env.graph, x0, v0)
+    assert torch.equal(xs, x0) and torch.equal(vs, v0) and torch.equal(env.calculate_obj_values(xs), vs)
+    xs2 = env.generate_xs_randomly(B)
+    vs2 = env.calculate_obj_values(xs2)
+    before = vs2.clone()
+    env.local_search_inplace(xs2, vs2, num_iters=4, num_spin=8)
+    assert bool((vs2 >= before).all()) and torch.equal(env.calculate_obj_values(xs2), vs2)
+    # beyond both layouts the gate says no and the decomposed path runs
+    big = EnvMaxcut(mygraph=generate_gnm(9000, 20000, 7), device=DEV, num_nodes=9000)
+    assert not ops.local_search_fusable(big.graph, 8, 64)
+    xb = big.generate_xs_randomly(64)
+    vb = big.calculate_obj_values(xb)
+    big.local_search_inplace(xb, vb, num_iters=2)
+    assert torch.equal(big.calculate_obj_values(xb), vb)
+
+
+def test_step_rejects_out_of_range_action():
+    """an action outside [0, N) must not touch another env's bytes: env untouched, reward NaN."""
+    from rlsolver_amd.graph import build_csr, generate_gnm
+    n, B = 200, 37
+    g = ops.DeviceGraph(build_csr(generate_gnm(n, 900, 1), num_nodes=n), DEV)
+    for dtype in (torch.bool, torch.float32):
+        x = ops.rand_spins(B, n, 3, DEV).to(dtype)
+        act = torch.randint(0, n, (B,), device=DEV)
+        act[5], act[6], act[36] = n, -1, 1 << 40
+        bad = torch.zeros(B, dtype=torch.bool, device=DEV)
+        bad[[5, 6, 36]] = True
+        obj = ops.maxcut_obj(g, x).to(torch.int32)
+        obj0 = obj.clone()
+        for emit in (True, False):
+            src = x.clone()
+            dst = torch.zeros_like(src) if emit else src
+            o = obj0.clone()
+            rew = torch.zeros(B, device=DEV)
+            ops.maxcut_step(g, src, dst, act, o, rew)
+            assert bool(torch.isnan(rew[bad]).all()) and not bool(torch.isnan(rew[~bad]).any())
+            assert torch.equal(dst[bad], x[bad]) and torch.equal(o[bad], obj0[bad])
+            assert torch.equal(ops.maxcut_obj(g, dst).to(torch.int32), o)
+            assert int((dst[~bad] != x[~bad]).sum()) == int((~bad).sum())

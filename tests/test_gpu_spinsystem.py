@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("gname", ["PL_20_ID0", "BA_100_ID0"])
-@pytest.mark.parametrize("cname", ["eco", "dense"])
+@pytest.mark.parametrize("cname", ["eco", "dense", "stag"])
 def test_spinsystem_golden(golden, gname, cname):
     from rlsolver_amd.envs.spinsystem import ECO_PECO_OBSERVABLES, RewardSignal, SpinBasis, SpinSystem
     z = golden("spinsystem")
@@ -18,8 +18,10 @@ def test_spinsystem_golden(golden, gname, cname):
     n = int(g[:, :2].max()) + 1
     tag = f"{gname}/{cname}"
     max_steps = int(z[f"{tag}/max_steps"])
-    cfg = dict(reward_signal=RewardSignal.BLS, norm_rewards=True, basin_reward=1.0 / n) if cname == "eco" else \
-        dict(reward_signal=RewardSignal.DENSE, norm_rewards=False, basin_reward=None)
+    cfg = {"eco": dict(reward_signal=RewardSignal.BLS, norm_rewards=True, basin_reward=1.0 / n),
+           "dense": dict(reward_signal=RewardSignal.DENSE, norm_rewards=False, basin_reward=None),
+           "stag": dict(reward_signal=RewardSignal.CUSTOM_BLS, norm_rewards=False, basin_reward=0.25,
+                        stag_punishment=0.125)}[cname]
     env = SpinSystem([tuple(int(v) for v in r) for r in g], n, 6, max_steps=max_steps,
                      observables=ECO_PECO_OBSERVABLES, spin_basis=SpinBasis.BINARY, device=DEV, **cfg)
     assert env.action_space.n == n and env.observation_space.shape == [n, 7]
@@ -61,3 +63,87 @@ def test_spinsystem_large_consistency():
     assert torch.equal(ops.maxcut_obj(env.graph, x).float(), env.score)
     assert torch.equal(ops.maxcut_delta_all(env.graph, x), env._delta)
     assert bool(d.all()) and torch.equal(env.best_score, torch.maximum(env.best_score, env.score))
+
+
+@pytest.mark.parametrize("gname", ["PL_20_ID0", "BA_100_ID0"])
+@pytest.mark.parametrize("cname", ["eco", "dense", "stag"])
+def test_spinsystem_single_env_f64_golden(golden, gname, cname):
+    """the numpy env of ECO_S2V/src/envs/spinsystem.py:333-482 (float64,
+    obs [7 + N, N]) -- the same HIP kernel instantiated for double, bit for bit against the reference's trace."""
+    from rlsolver_amd.envs.spinsystem import ECO_PECO_OBSERVABLES, RewardSignal, SpinBasis, SpinSystemUnbiased
+    z = golden("spinsystem_cpu")
+    g = z[f"{gname}/graph"]
+    n = int(g[:, :2].max()) + 1
+    tag = f"{gname}/{cname}"
+    T = int(z[f"{tag}/max_steps"])
+    cfg = {"eco": dict(reward_signal=RewardSignal.BLS, norm_rewards=True, basin_reward=1.0 / n),
+           "dense": dict(reward_signal=RewardSignal.DENSE, norm_rewards=False),
+           "stag": dict(reward_signal=RewardSignal.CUSTOM_BLS, norm_rewards=False, basin_reward=0.25,
+                        stag_punishment=0.125)}[cname]
+    env = SpinSystemUnbiased([tuple(int(v) for v in r) for r in g], n, max_steps=T, observables=ECO_PECO_OBSERVABLES,
+                             spin_basis=SpinBasis.BINARY, device=DEV, **cfg)
+    assert env.max_local_reward_available == float(z[f"{tag}/max_local"])
+    obs = env.reset(z[f"{tag}/spins0"])
+    assert obs.dtype == np.float64 and obs.shape == (7 + n, n)
+    assert np.array_equal(obs, z[f"{tag}/obs0"])
+    assert env.score == float(z[f"{tag}/score0"])
+    for t in range(T):
+        o, r, d, info = env.step(int(z[f"{tag}/actions"][t]))
+        assert info is None and isinstance(r, float) and isinstance(d, bool)
+        assert np.array_equal(o[:7], z[f"{tag}/obs"][t]), t
+        assert np.array_equal(env.get_immeditate_rewards_avaialable(), z[f"{tag}/gains"][t]), t
+        assert r == z[f"{tag}/rew"][t], t
+        assert d == bool(z[f"{tag}/done"][t])
+        assert env.score == z[f"{tag}/score"][t] and env.best_score == z[f"{tag}/best_score"][t]
+    assert np.array_equal(env.best_spins, z[f"{tag}/best_spins"])
+    assert np.array_equal(o[7:], z[f"{tag}/adj_rows"])
+
+
+def test_spinsystem_history_against_oracle_and_state_dict():
+    """Visited-state memory at a size where revisits, hash pre-filter and the multi-word compare all occur
+    (N = 130: 3 words per state; odd N: the scalar row path), against the dense oracle; then checkpoint /
+    restore in the middle of an episode."""
+    from oracle.oracle_spin import SpinSystemOracle
+    from rlsolver_amd.envs.spinsystem import ECO_PECO_OBSERVABLES, RewardSignal, SpinBasis, SpinSystem
+    from rlsolver_amd.graph import generate_gnm
+    for n, m in ((130, 400), (67, 150)):
+        rng = np.random.RandomState(n)
+        mg = [(a, b, int(rng.choice([-1, 1]))) for a, b, _ in generate_gnm(n, m, 3)]
+        W = np.zeros((n, n), np.float32)
+        for a, b, w in mg:
+            W[a, b] = W[b, a] = w
+        B, T = 9, 60
+        kw = dict(reward_signal=RewardSignal.BLS, norm_rewards=True, basin_reward=0.5, stag_punishment=0.25)
+        env = SpinSystem(mg, n, B, max_steps=T, observables=ECO_PECO_OBSERVABLES, spin_basis=SpinBasis.BINARY,
+                         device=DEV, **kw)
+        ora = SpinSystemOracle(W, B, T, reward="BLS", norm_rewards=True, basin_reward=0.5, stag_punishment=0.25)
+        s0 = (2 * rng.randint(0, 2, size=(B, n)) - 1).astype(np.float32)
+        assert np.array_equal(env.reset(torch.from_numpy(s0))[:, :7].cpu().numpy(), ora.reset(s0))
+        acts = rng.randint(0, n, size=(T, B))
+        for t in range(2, T, 4):        # undo moves and 3-cycles of returns: plenty of revisits
+            acts[t] = acts[t - 1]
+        snap = None
+        for t in range(T):
+            if t == 20:
+                snap = env.state_dict()
+            o, r, d = env.step(torch.from_numpy(acts[t]).to(DEV))
+            oo, rr, dd = ora.step(acts[t])
+            assert np.array_equal(o[:, :7].cpu().numpy(), oo), (n, t)
+            assert np.array_equal(r.cpu().numpy(), rr), (n, t)
+        end = env.state_dict()
+        env.load_state_dict(snap)
+        for t in range(20, T):
+            env.step(torch.from_numpy(acts[t]).to(DEV))
+        again = env.state_dict()
+        assert all(torch.equal(end[k], again[k]) if torch.is_tensor(end[k]) else end[k] == again[k] for k in end)
+
+
+def test_spin_step_rejects_out_of_range_action():
+    from rlsolver_amd.envs.spinsystem import S2V_OBSERVABLES, SpinSystem
+    from rlsolver_amd.graph import generate_gnm
+    env = SpinSystem(generate_gnm(40, 90, 1), 40, 4, max_steps=5, observables=S2V_OBSERVABLES, device=DEV,
+                     include_adjacency=False)
+    before = env.state.clone()
+    _, r, _ = env.step(torch.tensor([3, 40, -1, 7], device=DEV))
+    assert torch.isnan(r[1]) and torch.isnan(r[2]) and not torch.isnan(r[0]) and not torch.isnan(r[3])
+    assert torch.equal(env.state[1:3], before[1:3]) and not torch.equal(env.state[0], before[0])

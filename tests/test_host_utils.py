@@ -1,3 +1,4 @@
+import os
 """Host-side helpers (CPU): base-64 solution strings, result files."""
 import numpy as np
 import torch
@@ -42,10 +43,24 @@ def test_evaluator_tracks_best(tmp_path):
 
 def test_result_file_roundtrip(tmp_path):
     p = str(tmp_path / "res.txt")
-    write_graph_result(13359, 12, 5, "dREINFORCE", torch.tensor([0, 1, 1, 0, 1]), p, plus1=True, info_dict={"seed": 3})
+    p = write_graph_result(13359, 12, 5, "dREINFORCE", torch.tensor([0, 1, 1, 0, 1]), p, plus1=True, info_dict={"seed": 3})
     txt = open(p).read().splitlines()
     assert txt[:5] == ["// obj: 13359", "// running_duration: 12", "// num_nodes: 5", "// alg_name: dREINFORCE",
                        "// seed: 3"]
     assert txt[5:] == ["1 1", "2 2", "3 2", "4 1", "5 2"]
     hdr, lab = read_graph_result(p)
     assert hdr["obj"] == "13359" and lab.tolist() == [1, 2, 2, 1, 2]
+
+
+def test_result_file_is_never_overwritten(tmp_path):
+    """util_write_read_result.py:55-67: data/ -> result/, `_<duration>` tail, a letter appended while the name exists."""
+    os.makedirs(tmp_path / "data" / "syn")
+    src = str(tmp_path / "data" / "syn" / "BA_100_ID0.txt")
+    sol = torch.tensor([1, 0, 1])
+    a = write_graph_result(7, 12, 3, "greedy", sol, src)
+    b = write_graph_result(9, 12, 3, "greedy", sol, src)
+    assert a == str(tmp_path / "result" / "syn" / "BA_100_ID0_12.txt") and os.path.exists(a)
+    assert b != a and os.path.exists(b) and b.startswith(a[:-4]) and len(b) == len(a) + 1
+    assert read_graph_result(a)[0]["obj"] == "7" and read_graph_result(b)[0]["obj"] == "9"
+    c = write_graph_result(1, None, 3, "greedy", sol, str(tmp_path / "plain.txt"))
+    assert c.endswith("plain_.txt")

@@ -261,3 +261,22 @@ def test_c_oracle_tsp(golden):
     for name in ("a5", "berlin52"):
         got = oc.tsp_tour_length(z[f"{name}/distance"], z[f"{name}/perms"])
         np.testing.assert_allclose(got, z[f"{name}/length_f32"], rtol=1e-5)
+
+
+def test_fixtures_carry_provenance():
+    """Every committed fixture names the command that regenerates it (tools/gen_golden.py --only <key>) and its
+    seeding rule; the generator seeds the global RNGs per key, so any subset regenerates byte-identically."""
+    import glob
+    import os
+    import re
+    from tests.conftest import GOLDEN
+    files = sorted(glob.glob(os.path.join(GOLDEN, "*.npz")))
+    assert len(files) >= 14
+    gen_src = open(os.path.join(os.path.dirname(GOLDEN), "..", "tools", "gen_golden.py")).read()
+    keys = set(re.findall(r'"(\w+)": gen_\w+', gen_src))
+    for f in files:
+        z = np.load(f, allow_pickle=False)
+        assert "__generator__" in z.files and "__seeding__" in z.files, f
+        m = re.search(r"tools/gen_golden.py --only (\w+)$", str(z["__generator__"]))
+        assert m and m.group(1) in keys, (f, str(z["__generator__"]))
+        assert "seed" in str(z["__seeding__"])

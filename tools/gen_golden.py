@@ -40,9 +40,19 @@ def u8(t):
     return t.detach().cpu().numpy().copy().astype(np.uint8)
 
 
+_CURRENT = {"key": None}
+
+
 def save(name, **arrays):
+    """Every fixture carries its own provenance: the command that regenerates it and the seeding rule
+    (tests/test_oracle_golden.py::test_fixtures_carry_provenance fails on a fixture without them)."""
     os.makedirs(OUT, exist_ok=True)
     path = os.path.join(OUT, name + ".npz")
+    arrays["__generator__"] = np.array(f"PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py --only {_CURRENT['key']}")
+    arrays["__seeding__"] = np.array("explicit torch.manual_seed / torch.Generator / numpy RandomState seeds before every "
+                                     "reference call (see the generator function); reference = /root/reference "
+                                     "(Open-Finance-Lab/RLSolver, 2026-03-13 snapshot) imported on CPU, torch "
+                                     + th.__version__.split("+")[0])
     np.savez_compressed(path, **arrays)
     print(f"wrote {path}  ({os.path.getsize(path)} bytes, {len(arrays)} arrays)")
 
@@ -526,6 +536,7 @@ def gen_qubo():
         out[f"{name}/change_times"] = np.int64(change_times)
         out[f"{name}/M"], out[f"{name}/R"], out[f"{name}/num_ls"] = np.int64(M), np.int64(R), np.int64(num_ls)
         for mode, fn in (("pm1", smp.mcpg_sampling_qubo), ("bin", smp.mcpg_sampling_qubo_bin)):
+            th.manual_seed(177 if mode == "pm1" else 178)   # the samplers draw from the global generator
             with Recorder("rand", "randint") as rec:
                 max_res, best, raw, value = fn(data, start.clone(), probs, num_ls, change_times, M, device=th.device("cpu"))
             out[f"{name}/{mode}/index"] = th.stack(rec.log["randint"]).numpy().copy()
@@ -566,15 +577,17 @@ def gen_spinsystem():
                 return th.from_numpy(W)[None].expand(B, n, n).clone()
 
         cfgs = {"eco": dict(reward_signal=RewardSignal.BLS, norm_rewards=True, basin_reward=1.0 / n),
-                "dense": dict(reward_signal=RewardSignal.DENSE, norm_rewards=False, basin_reward=None)}
+                "dense": dict(reward_signal=RewardSignal.DENSE, norm_rewards=False, basin_reward=None),
+                "stag": dict(reward_signal=RewardSignal.CUSTOM_BLS, norm_rewards=False, basin_reward=0.25,
+                             stag_punishment=0.125)}
         for cname, cfg in cfgs.items():
             th.manual_seed(3)
             max_steps = 2 * n if n <= 20 else 40
             env = sp.SpinSystemFactory.get(SharedGraph(), max_steps, observables=ECO_PECO_OBSERVABLES,
                                            extra_action=ExtraAction.NONE, optimisation_target=OptimisationTarget.CUT,
                                            spin_basis=SpinBasis.BINARY, memory_length=None, horizon_length=None,
-                                           stag_punishment=None, reversible_spins=True, device=th.device("cpu"),
-                                           num_envs=B, **cfg)
+                                           reversible_spins=True, device=th.device("cpu"),
+                                           num_envs=B, **{"stag_punishment": None, **cfg})
             tag = f"{gname}/{cname}"
             out[f"{tag}/max_steps"] = np.int64(max_steps)
             out[f"{tag}/spins0"] = env.state[:, 0, :].numpy().copy()
@@ -587,6 +600,9 @@ def gen_spinsystem():
                 a = th.randint(0, n, (B,), generator=g)
                 if t % 7 == 3:
                     a[:] = a[0]
+                if cname == "stag" and t % 3 == 2:
+                    a = acts_prev.clone()        # undo the previous flip: a revisited state (stag_punishment)
+                acts_prev = a
                 o, r, d = env.step(a)
                 acts.append(a.numpy().copy()); obs.append(o[:, :7, :].numpy().copy()); rews.append(r.numpy().copy())
                 dones.append(d.numpy().copy()); scores.append(env.score.numpy().copy())
@@ -603,7 +619,185 @@ def gen_spinsystem():
     save("spinsystem", **out)
 
 
-ALL = {"spinsystem": gen_spinsystem, "qubo": gen_qubo, "isco_maxcut": gen_isco_maxcut, "maxcut": gen_maxcut, "sweep": gen_sweep, "lsclass": gen_local_search_class, "ppo": gen_ppo,
+def gen_spinsystem_cpu():
+    """the numpy single-instance env (ECO_S2V/src/envs/spinsystem.py:333-482,
+    SpinSystemUnbiased :588-661) in float64 on a fixed +-1-weighted graph: per step the full 7-row state, the all-node
+    gain vector, reward, done, score, best score; three configs (dense / ECO with basin reward / stag punishment)."""
+    from rlsolver.methods.ECO_S2V.src.envs import spinsystem as spc
+    from rlsolver.methods.ECO_S2V.src.envs.util_envs import (ECO_PECO_OBSERVABLES, EdgeType, ExtraAction, GraphGenerator,
+                                                             OptimisationTarget, RewardSignal, SpinBasis)
+    from rlsolver.methods.util_read_data import read_mygraph
+    out = {}
+    for gname in ("PL_20_ID0", "BA_100_ID0"):
+        mygraph = read_mygraph(os.path.join(DATA, GRAPHS[gname]))
+        n = max(max(a, b) for a, b, _ in mygraph) + 1
+        rng = np.random.RandomState(43)
+        wl = [(a, b, int(rng.choice([-1, 1]))) for a, b, _ in mygraph]
+        W = np.zeros((n, n), dtype=np.float64)
+        for a, b, w in wl:
+            W[a, b] = W[b, a] = w
+        out[f"{gname}/graph"] = np.asarray(wl, dtype=np.int64)
+
+        class Fixed(GraphGenerator):
+            def __init__(self):
+                super().__init__(n, EdgeType.DISCRETE, False)
+
+            def get(self, with_padding=False):
+                return W.copy()
+
+        cfgs = {"dense": dict(reward_signal=RewardSignal.DENSE, norm_rewards=False, basin_reward=None, stag_punishment=None),
+                "eco": dict(reward_signal=RewardSignal.BLS, norm_rewards=True, basin_reward=1.0 / n, stag_punishment=None),
+                "stag": dict(reward_signal=RewardSignal.CUSTOM_BLS, norm_rewards=False, basin_reward=0.25,
+                             stag_punishment=0.125)}
+        for cname, cfg in cfgs.items():
+            max_steps = 2 * n if n <= 20 else 50
+            env = spc.SpinSystemFactory.get(Fixed(), max_steps, observables=ECO_PECO_OBSERVABLES,
+                                            extra_action=ExtraAction.NONE, optimisation_target=OptimisationTarget.CUT,
+                                            spin_basis=SpinBasis.BINARY, memory_length=None, horizon_length=None,
+                                            reversible_spins=True, seed=17, **cfg)
+            tag = f"{gname}/{cname}"
+            out[f"{tag}/max_steps"] = np.int64(max_steps)
+            out[f"{tag}/spins0"] = env.state[0, :].copy()
+            out[f"{tag}/obs0"] = env.get_observation().copy()
+            out[f"{tag}/score0"] = np.float64(env.score)
+            out[f"{tag}/max_local"] = np.float64(env.max_local_reward_available)
+            r2 = np.random.RandomState(19)
+            acts, states, gains, rews, dones, scores, bests = [], [], [], [], [], [], []
+            prev = 0
+            for t in range(max_steps):
+                a = int(r2.randint(0, n))
+                if t % 3 == 2:
+                    a = prev                       # undo the previous flip: a revisited state
+                prev = a
+                o, r, d, _ = env.step(a)
+                assert o.shape == (7 + n, n) and o.dtype == np.float64
+                acts.append(a); states.append(o[:7].copy()); rews.append(float(r)); dones.append(bool(d))
+                gains.append(env.get_immeditate_rewards_avaialable().copy())
+                scores.append(float(env.score)); bests.append(float(env.best_score))
+            out[f"{tag}/adj_rows"] = o[7:].copy()
+            out[f"{tag}/actions"] = np.asarray(acts, dtype=np.int64)
+            out[f"{tag}/obs"] = np.stack(states)
+            out[f"{tag}/gains"] = np.stack(gains)
+            out[f"{tag}/rew"] = np.asarray(rews, dtype=np.float64)
+            out[f"{tag}/done"] = np.asarray(dones)
+            out[f"{tag}/score"] = np.asarray(scores, dtype=np.float64)
+            out[f"{tag}/best_score"] = np.asarray(bests, dtype=np.float64)
+            out[f"{tag}/best_spins"] = np.asarray(env.best_spins, dtype=np.float64)
+    save("spinsystem_cpu", **out)
+
+
+def gen_isco_steps():
+    """Full sampler steps of the two ISCO envs with every torch draw recorded:
+    ISCO_maxcut.step (envs/env_ISCO.py:26-49; methods/util.py:498-570 multinomial / mh_step) and
+    ISCO_TSP.step (:188-236).  Intermediate quantities are captured by wrapping the instance's own methods."""
+    import rlsolver.envs.env_ISCO as env_isco
+    from rlsolver.methods.ISCO import util_TSP
+    from rlsolver.methods.util_read_data import read_mygraph
+    out = {}
+    # ---- MaxCut
+    for gname in ("BA_100_ID0", "PL_20_ID0"):
+        mygraph = read_mygraph(os.path.join(DATA, GRAPHS[gname]))
+        g = graph_arrays(mygraph)
+        n = int(g[:, :2].max()) + 1
+        B = 12
+        env_isco.BATCH_SIZE = B
+        params = {"num_nodes": n, "num_edges": len(g), "edge_from": th.from_numpy(g[:, 0].copy()),
+                  "edge_to": th.from_numpy(g[:, 1].copy())}
+        smp = env_isco.ISCO_maxcut(params)
+        cap = {}
+        o_prop, o_y2x, o_sel = smp.proposal, smp.ll_y2x, smp.select_sample
+
+        def w_prop(x, pl, T):
+            r = o_prop(x, pl, T)
+            cap["ll_x"], cap["y_prop"] = r[0].clone(), r[1].clone()
+            cap["ll_x2y"], cap["mask"] = r[2]["ll_x2y"].clone(), r[2]["selected_idx"]["selected_mask"].clone()
+            return r
+
+        def w_y2x(tr, y, T):
+            r = o_y2x(tr, y, T)
+            cap["ll_y"], cap["ll_y2x"] = r[0].clone(), r[1].clone()
+            return r
+
+        def w_sel(la, x, y):
+            cap["log_acc"] = la.clone()
+            return o_sel(la, x, y)
+
+        smp.proposal, smp.ll_y2x, smp.select_sample = w_prop, w_y2x, w_sel
+        th.manual_seed(5)
+        x = smp.random_gen_init_sample(params)
+        gen = th.Generator().manual_seed(15)
+        tag0 = f"maxcut/{gname}"
+        out[f"{tag0}/graph"] = g
+        for k, T in enumerate((1.0, 0.5, 0.2)):
+            pl = th.randint(1, min(n, 14), (B,), generator=gen)
+            pl[0], pl[1] = 1, n                      # the two ends of the clamp in main_ISCO_maxcut.py:26
+            th.manual_seed(100 + k)
+            with Recorder("rand") as rec:
+                y, energy, acc = smp.step(x, pl, th.tensor(T))
+            assert len(rec.log["rand"]) == 2
+            tag = f"{tag0}/step{k}"
+            out[f"{tag}/x"] = u8(x)
+            out[f"{tag}/path_length"] = pl.numpy().copy()
+            out[f"{tag}/temperature"] = np.float32(T)
+            out[f"{tag}/rand_gumbel"] = rec.log["rand"][0].numpy().copy()
+            out[f"{tag}/rand_accept"] = rec.log["rand"][1].numpy().copy()
+            for kk in ("ll_x", "ll_x2y", "ll_y", "ll_y2x", "log_acc"):
+                out[f"{tag}/{kk}"] = cap[kk].numpy().copy()
+            out[f"{tag}/mask"] = u8(cap["mask"])
+            out[f"{tag}/y_prop"] = u8(cap["y_prop"])
+            out[f"{tag}/y"] = u8(y)
+            out[f"{tag}/energy"] = energy.numpy().copy()
+            out[f"{tag}/acc"] = acc.numpy().copy()
+            x = y
+    # ---- TSP
+    for name, plen in (("a5", 3), ("berlin52", 5)):
+        path = os.path.join(DATA, "tsplib", name + ".tsp")
+        K = 20 if name == "berlin52" else 2
+        util_TSP.K = K
+        env_isco.K = K
+        params = util_TSP.load_data(path)
+        N = params["num_nodes"]
+        B = 9
+        env_isco.BATCH_SIZE = B
+        smp = env_isco.ISCO_TSP(params)
+        cap = {}
+        o_sel = smp.select_sample
+
+        def w_sel2(la, x, y):
+            cap["log_acc"], cap["cur_x"] = la.clone(), y.clone()
+            return o_sel(la, x, y)
+
+        smp.select_sample = w_sel2
+        th.manual_seed(23)
+        x = smp.random_gen_init_sample(params)
+        tag0 = f"tsp/{name}"
+        out[f"{tag0}/K"] = np.int64(K)
+        out[f"{tag0}/distance"] = params["distance"].numpy().copy()
+        out[f"{tag0}/nearest_indices"] = params["nearest_indices"].numpy().copy()
+        out[f"{tag0}/random_indices"] = params["random_indices"].numpy().copy()
+        for k, T in enumerate((0.7, 0.3)):
+            th.manual_seed(200 + k)
+            with Recorder("rand", "randint") as rec:
+                y, mean_acc = smp.step(x, plen, th.tensor(T))
+            assert len(rec.log["rand"]) == 2 * plen + 1 and len(rec.log["randint"]) == 2 * plen
+            tag = f"{tag0}/step{k}"
+            out[f"{tag}/x"] = x.numpy().copy()
+            out[f"{tag}/path_length"] = np.int64(plen)
+            out[f"{tag}/temperature"] = np.float32(T)
+            out[f"{tag}/rand_partner"] = th.stack(rec.log["rand"][0:2 * plen:2]).numpy().copy()     # opt_2: near/far coin
+            out[f"{tag}/rand_gumbel"] = th.stack(rec.log["rand"][1:2 * plen:2]).numpy().copy()      # multinomial
+            out[f"{tag}/rand_accept"] = rec.log["rand"][2 * plen].numpy().copy()
+            out[f"{tag}/randint_nearest"] = th.stack(rec.log["randint"][0::2]).numpy().copy()
+            out[f"{tag}/randint_random"] = th.stack(rec.log["randint"][1::2]).numpy().copy()
+            out[f"{tag}/log_acc"] = cap["log_acc"].numpy().copy()
+            out[f"{tag}/cur_x"] = cap["cur_x"].numpy().copy()
+            out[f"{tag}/y"] = y.numpy().copy()
+            out[f"{tag}/mean_acc"] = np.float32(mean_acc)
+            x = y
+    save("isco_steps", **out)
+
+
+ALL = {"isco_steps": gen_isco_steps, "spinsystem_cpu": gen_spinsystem_cpu, "spinsystem": gen_spinsystem, "qubo": gen_qubo, "isco_maxcut": gen_isco_maxcut, "maxcut": gen_maxcut, "sweep": gen_sweep, "lsclass": gen_local_search_class, "ppo": gen_ppo,
        "select": gen_select, "mcpg": gen_mcpg, "tsp": gen_tsp, "encoder": gen_encoder,
        "wgain": gen_weighted_gain}
 
@@ -615,4 +809,9 @@ if __name__ == "__main__":
     th.set_num_threads(4)
     for w in which:
         print("==", w)
+        _CURRENT["key"] = w
+        # every generator starts from its own fixed global-RNG state, so any --only subset regenerates byte-identically
+        k = sorted(ALL).index(w)
+        th.manual_seed(90000 + k)
+        np.random.seed(90000 + k)
         ALL[w]()

@@ -4,6 +4,7 @@ import argparse
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+os.environ["RLS_DEV_REREAD_ENV"] = "1"   # the library reads its knobs once per process otherwise
 import torch
 from rlsolver_amd import ops
 from rlsolver_amd.graph import build_csr, generate_gnm

@@ -2,6 +2,7 @@
 """A/B the step kernel's development knobs in one process (interleaved rounds; guide rule 24)."""
 import itertools, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["RLS_DEV_REREAD_ENV"] = "1"   # the library reads its knobs once per process otherwise
 import torch
 from rlsolver_amd import ops
 from rlsolver_amd.graph import build_csr, generate_gnm
