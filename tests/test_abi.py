@@ -22,6 +22,18 @@ def declared_functions():
     return names
 
 
+def declared_signatures():
+    """name -> list of C parameter types (normalised) from the header."""
+    sigs = {}
+    for h in glob.glob(os.path.join(ROOT, "include", "*.h")):
+        src = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
+        for m in re.finditer(r"\b(int|const char\*)\s+(rls_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+            args = [" ".join(a.split()) for a in m.group(3).split(",")]
+            sigs[m.group(2)] = [] if args == ["void"] else [re.sub(r"\s*\w+$", "", a) if not a.endswith("*") else a
+                                                            for a in args]
+    return sigs
+
+
 def test_header_parses():
     fns = declared_functions()
     assert {"rls_version", "rls_maxcut_obj", "rls_maxcut_step", "rls_maxcut_greedy_sweep"} <= set(fns)
@@ -44,6 +56,30 @@ def test_ctypes_table_matches_header():
     assert set(table) == set(fns), (set(fns) ^ set(table))
     for name, nargs in fns.items():
         assert len(table[name]) == nargs, name
+
+
+def test_ctypes_argument_types_match_header():
+    """Not only the arity: every parameter's C type maps to the ctypes type in the table."""
+    from rlsolver_amd import _abi
+    table = dict(_abi.SIGNATURES)
+    table.update({k: v[0] for k, v in _abi.PLAIN.items()})
+
+    def want(ctype):
+        t = ctype.replace("const ", "").strip()
+        if t == "rls_graph*":
+            return _abi._G
+        if t == "rls_spin_env*":
+            return _abi._SE
+        if t.endswith("*"):
+            return ctypes.c_void_p
+        return {"int64_t": ctypes.c_int64, "uint64_t": ctypes.c_uint64, "int32_t": ctypes.c_int32, "int": ctypes.c_int,
+                "float": ctypes.c_float, "double": ctypes.c_double}[t]
+
+    for name, params in declared_signatures().items():
+        got = table[name]
+        assert len(got) == len(params), name
+        for i, (g, p) in enumerate(zip(got, params)):
+            assert g is want(p), f"{name} arg {i}: header says '{p}', table has {g}"
 
 
 def test_loads_without_gpu_and_reports_errors():

@@ -124,6 +124,46 @@ def tsp_suite(tag, N, B, iters):
     emit(tag, "K13 tsp_swap_delta_all", "envs (N candidate moves each)", B, t, 8 * N + 8 * N + 13 * N)
 
 
+def spin_suite(tag, n, m, B, T, iters):
+    """S1: the S2V / ECO / PECO env step on a shared graph (resident O(deg) state; 6 rows x 4N bytes change per step
+    under the ECO observables: time-since-flip read + write, four broadcast rows written)."""
+    from rlsolver_amd.envs.spinsystem import ECO_PECO_OBSERVABLES, RewardSignal, SpinBasis, SpinSystem
+    rng = np.random.RandomState(1)
+    mg = [(u, v, int(rng.choice([-1, 1]))) for u, v, _ in generate_gnm(n, m, 22)]
+    for label, kw in (("ECO observables, BLS reward", dict()),
+                      ("ECO observables, BLS + basin reward (visited-state memory)", dict(basin_reward=1.0 / n))):
+        env = SpinSystem(mg, n, B, max_steps=T, observables=ECO_PECO_OBSERVABLES, reward_signal=RewardSignal.BLS,
+                         norm_rewards=True, spin_basis=SpinBasis.BINARY, device=dev, include_adjacency=False, **kw)
+        acts = [ops.rand_actions(B, n, 11, s, dev) for s in range(8)]
+        rew = torch.empty(B, device=dev)
+        from rlsolver_amd import _abi
+        import ctypes as C
+
+        def one(i):   # the bare kernel, as EnvMaxcutGym's launcher: no observation copy
+            if env.current_step >= T:
+                env.current_step = 0
+            env.current_step += 1
+            _abi.call("rls_spin_step", env.graph.ref, C.byref(env._env), 4, B, 7, env._rows, ops._ptr(acts[i % 8]),
+                      ops._ptr(rew), None, env._max_local, float(np.float32(1.0 / T)), 1.0, 1, float(n),
+                      env.current_step - 1, 0, 0.0, int("basin" in label), float(np.float32(1.0 / n)), ops._stream(dev))
+        t = timeit(one, iters)
+        emit(tag, f"S1 spin_step ({label})", "env-steps", B, t, 6 * 4 * n,
+             "algorithmic bytes = the rows the observation contract changes everywhere each step")
+
+
+def qubo_suite(tag, n, C, num_ls, iters):
+    from rlsolver_amd.methods import MCPG_qubo as mq
+    rng = np.random.RandomState(3)
+    Q = np.triu(rng.randint(10, 101, size=(n, n)) * rng.choice([-1, 1], size=(n, n)) * (rng.rand(n, n) < 0.8), 0)
+    Q = (Q + np.triu(Q, 1).T).astype(np.float32)
+    Qd = torch.from_numpy(Q).to(dev)
+    xs = (torch.rand((n, C), device=dev) < 0.5).float()
+    for binary in (False, True):
+        t = timeit(lambda i: mq.qubo_local_search_value(Qd, xs, num_ls, binary), iters, warm=1)
+        emit(tag, f"K11 qubo_local_search_value ({'0/1' if binary else '+-1'}, num_ls={num_ls})", "variable updates",
+             C * n * (num_ls + 1), t, None, f"n={n} dense, C={C}; {2 * n * n * (num_ls + 1) * C / t / 1e12:.2f} Tflop/s of f32 FMA work")
+
+
 it = 5 if a.quick else 30
 maxcut_suite("G22-sized G(2000,19990), B=2^16", 2000, 19990, 1 << 16, 22, it)
 local_search_suite("G22-sized, dREINFORCE batch", 2000, 19990, 22, 4096, max(2, it // 5))
@@ -131,4 +171,7 @@ local_search_suite("G22-sized, dREINFORCE batch x16", 2000, 19990, 22, 65536, ma
 maxcut_suite("G70-sized G(10000,9999), B=2^17 (one GPU's shard of 2^20)", 10000, 9999, 1 << 17, 70, max(3, it // 3))
 maxcut_suite("G14-sized G(800,4694), B=256", 800, 4694, 256, 14, it)
 tsp_suite("TSP-100 uniform, B=2^16", 100, 1 << 16, it)
+spin_suite("G22-sized +-1 weighted, B=2^14", 2000, 19990, 1 << 14, 64, it)
+spin_suite("BA-200-sized (ECO), B=4096", 200, 784, 4096, 400, it)
+qubo_suite("nbiq-style dense QUBO n=1000, 2^13 chains", 1000, 1 << 13, 2, 2)
 mcpg_suite("BA n=10^4 m=5, 2^18 chains", 10000, 5, 1 << 18 if not a.quick else 1 << 14, 8, 2)
