@@ -218,6 +218,15 @@ int rls_select_better_rows(uint8_t* xs0, int64_t* vs0, const uint8_t* xs1, const
 int rls_pick_best_of_repeats(const uint8_t* xs, const int64_t* vs, int64_t R, int64_t S, int64_t N,
                              int if_maximize, uint8_t* good_xs, int64_t* good_vs, void* stream);
 
+/* Evaluator.record2(i, vs, xs)  methods/util_evaluator.py:90-107 without the host read: good = first argmax
+ * (argmin when !if_maximize) of vs [B] (vs_kind 0 = int64, 1 = float32, 2 = float64); if good is STRICTLY better
+ * than best_v[0] (or force != 0: the constructor's first record), best_v[0] = good and best_x[:] = xs[good, :];
+ * improved[0] = 1 | 0; log_v[log_index] = good when log_v != NULL.  best_v double[1], best_x uint8[N], improved
+ * uint8[1], log_v double[*]: device memory the host reads only when it prints.  One workgroup. */
+int rls_best_update(const uint8_t* xs, const void* vs, int vs_kind, int64_t B, int64_t N, int if_maximize,
+                    uint8_t* best_x, double* best_v, uint8_t* improved, double* log_v, int64_t log_index, int force,
+                    void* stream);
+
 /* K14 generate_xs_randomly(num_sims)  envs/env_L2A.py:82-85: i.i.d. Bernoulli(1/2)
  *     spins from a counter-based generator keyed by (seed, global env id), node 0
  *     forced to 0.  env_offset lets a rank generate its shard of a global batch. */
@@ -398,6 +407,46 @@ int rls_tsp_apply_swap(int64_t* perm, int64_t B, int64_t N, const int64_t* pos,
  * i, j int64 [B] with 0 <= i <= j < N. */
 int rls_tsp_2opt_delta(const float* dist, int64_t N, const int64_t* perm, int64_t B,
                        const int64_t* i, const int64_t* j, float* delta, void* stream);
+
+/* ------------------------------------------------------------------- ISCO sampler steps */
+
+/* ISCO_maxcut.step(x, path_length, temperature)  envs/env_ISCO.py:26-49 in ONE kernel (one wave per env):
+ *   ll_x = cut(x) / T;  log_prob = log_softmax(gain / 2T)   (get_local_dist :51-63: the closed form of the autograd)
+ *   Gumbel top-k without replacement of path_length[b] nodes  (multinomial, methods/util.py:514-555) -> mask, ll_x2y
+ *   y = x with the masked nodes flipped; ll_y, log_prob(y); ll_y2x = probability of undoing the selection in
+ *   reverse order (ll_y2x :65-77);  log_acc = min(ll_y + ll_y2x - ll_x - ll_x2y, 0);
+ *   y_out[b] = accepted ? y : x  with  log(u_accept + 1e-24) < log_acc   (mh_step, methods/util.py:556-570)
+ * x, y_out f32 [B, N] holding 0|1 (y_out may alias x); path_length int64 [B], clamped to [1, N] as the caller's
+ * torch.clamp does (methods/ISCO/main_ISCO_maxcut.py:26).  u_gumbel f32 [B, N] and u_accept f32 [B]: the
+ * reference's two torch.rand draws in call order (tests), or both NULL: counter-based generator keyed by
+ * (seed, env_offset + b, node).  Outputs (each may be NULL): energy_out f32 [B] = ll_y * T (of the PROPOSAL, as
+ * the reference returns it), acc_out f32 [B] = exp(log_acc), terms_out f32 [B, 5] = ll_x, ll_x2y, ll_y, ll_y2x,
+ * log_acc, mask_out uint8 [B, N] = the selected nodes.  Unweighted (the reference's energy ignores weights). */
+int rls_isco_maxcut_step(const rls_graph* g, const float* x, float* y_out, int64_t B, const int64_t* path_length,
+                         float temperature, const float* u_gumbel, const float* u_accept, uint64_t seed,
+                         int64_t env_offset, float* energy_out, float* acc_out, float* terms_out, uint8_t* mask_out,
+                         void* stream);
+
+/* ISCO_TSP.step(x, path_length, temperature)  envs/env_ISCO.py:188-236 in ONE kernel (one wave per env, the tour,
+ * its inverse and -- when it fits -- the distance matrix in LDS): path_length times { opt_2 (:238-335: partner
+ * city per position from the nearest / random tables, swap delta, ban mask) -> logits = -delta / 2T (banned:
+ * -5e5) -> log_softmax -> one Gumbel draw -> selected position q; ll_x2y = log_prob[q]; ll_y2x = log_softmax of
+ * the logits with entry q negated, at q (y2x :214-226); swap positions q + 1 and j(q) unless banned (switch
+ * :337-344) }, then log_acc = min(sum of the delta_yx, -ll_x2y, ll_y2x terms, 0) and the Metropolis accept
+ * between perm_in and the walked tour.  nearest int32 [N, K], random int32 [N, N-K-1] (ISCO/util_TSP.py:9-16),
+ * near_threshold = (float)(K / (K + 1)) as the reference's comparison sees it.  Test draws, all or none:
+ * u_partner f32, r_near int64, r_rand int64, u_gumbel f32, each [path_length, B, N] in call order, u_accept f32
+ * [B].  perm_out int64 [B, N] (must not alias perm_in); log_acc_out / acc_out f32 [B] and cur_out int64 [B, N]
+ * (the walked tour before the accept) may be NULL. */
+int rls_isco_tsp_step(const float* dist, int64_t N, const int32_t* nearest, int32_t K, float near_threshold,
+                      const int32_t* random, const int64_t* perm_in, int64_t* perm_out, int64_t B, int32_t path_length,
+                      float temperature, const float* u_partner, const int64_t* r_near, const int64_t* r_rand,
+                      const float* u_gumbel, const float* u_accept, uint64_t seed, int64_t env_offset,
+                      float* log_acc_out, float* acc_out, int64_t* cur_out, void* stream);
+
+/* The row moves of evolutionary_replacement  methods/util.py:87-94:  xs[dst[k]] = xs[src[k]], vs[dst[k]] =
+ * vs[src[k]] for k < K (dst and src disjoint: top_ids vs low_ids there).  xs uint8 [*, N], vs int64 or NULL. */
+int rls_copy_rows(uint8_t* xs, int64_t* vs, int64_t N, const int64_t* dst, const int64_t* src, int64_t K, void* stream);
 
 /* B random permutations (random_gen_init_sample, env_ISCO.py:352-354). */
 int rls_rand_perms(int64_t* perm, int64_t B, int64_t N, uint64_t seed, int64_t env_offset,

@@ -19,7 +19,7 @@ LIB_NAME = "librlsolver_hip.so"
 LIB_PATH = os.path.join(PKG_DIR, LIB_NAME)
 ARCH = "gfx950"
 
-SOURCES = ["rls_abi.hip", "rls_maxcut.hip", "rls_step.hip", "rls_mcpg.hip", "rls_tsp.hip", "rls_qubo.hip", "rls_spin.hip", "rls_localsearch.hip"]
+SOURCES = ["rls_abi.hip", "rls_maxcut.hip", "rls_step.hip", "rls_mcpg.hip", "rls_tsp.hip", "rls_qubo.hip", "rls_spin.hip", "rls_localsearch.hip", "rls_isco.hip", "rls_track.hip"]
 
 
 def _hipcc() -> str:

@@ -1,0 +1,77 @@
+// Best-solution tracking on the device: the argmax / compare / copy of
+// Evaluator.record2 (rlsolver/methods/util_evaluator.py:90-107) as one launch that never synchronises -- the
+// reference's  float(good_v)  forces a host read per call.  State lives in device memory: best_v (double[1]),
+// best_x (uint8[N]), improved (uint8[1]) and a value log; the host reads them only when it prints.
+#include "rls_common.h"
+
+namespace rls {
+
+constexpr int kTrackThreads = 1024;
+
+template <typename V>
+__global__ __launch_bounds__(kTrackThreads) void k_best_update(const uint8_t* __restrict__ xs, const V* __restrict__ vs,
+                                                               int64_t B, int64_t N, int if_maximize,
+                                                               uint8_t* __restrict__ best_x, double* __restrict__ best_v,
+                                                               uint8_t* __restrict__ improved, double* __restrict__ log_v,
+                                                               int64_t log_index, int force) {
+    __shared__ double s_val[kTrackThreads / 64];
+    __shared__ int64_t s_idx[kTrackThreads / 64];
+    __shared__ int64_t s_win;
+    __shared__ int s_take;
+    const double sign = if_maximize ? 1.0 : -1.0;
+    double bv = -INFINITY;
+    int64_t bi = INT64_MAX;
+    for (int64_t b = threadIdx.x; b < B; b += kTrackThreads) {           // first extremum, like torch.argmax / argmin
+        const double v = sign * (double)vs[b];
+        if (v > bv) { bv = v; bi = b; }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const double ov = __shfl_xor(bv, m, 64);
+        const int64_t oi = __shfl_xor(bi, m, 64);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { s_val[threadIdx.x >> 6] = bv; s_idx[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kTrackThreads / 64; ++w)
+            if (s_val[w] > bv || (s_val[w] == bv && s_idx[w] < bi)) { bv = s_val[w]; bi = s_idx[w]; }
+        const double good = sign * bv;
+        const bool take = force || (if_maximize ? good > best_v[0] : good < best_v[0]);   // strict, util_evaluator.py:103
+        if (take) best_v[0] = good;
+        improved[0] = take ? 1 : 0;
+        if (log_v) log_v[log_index] = good;
+        s_win = bi;
+        s_take = take;
+    }
+    __syncthreads();
+    if (s_take) {
+        const uint8_t* row = xs + s_win * N;
+        for (int64_t n = threadIdx.x; n < N; n += kTrackThreads) best_x[n] = row[n];
+    }
+}
+
+}  // namespace rls
+
+using namespace rls;
+
+extern "C" int rls_best_update(const uint8_t* xs, const void* vs, int vs_kind, int64_t B, int64_t N, int if_maximize,
+                               uint8_t* best_x, double* best_v, uint8_t* improved, double* log_v, int64_t log_index,
+                               int force, void* stream) {
+    RLS_REQUIRE(B >= 1 && N >= 1, RLS_EINVAL, "bad sizes B=%lld N=%lld", (long long)B, (long long)N);
+    RLS_REQUIRE(xs && vs && best_x && best_v && improved, RLS_EINVAL, "NULL pointer");
+    RLS_REQUIRE(vs_kind >= 0 && vs_kind <= 2, RLS_EINVAL, "vs_kind must be 0 (int64), 1 (float32) or 2 (float64)");
+    RLS_REQUIRE(!log_v || log_index >= 0, RLS_EINVAL, "negative log_index");
+    hipStream_t s = as_stream(stream);
+    const dim3 grid(1), block(kTrackThreads);
+    if (vs_kind == 0)
+        hipLaunchKernelGGL(k_best_update<int64_t>, grid, block, 0, s, xs, (const int64_t*)vs, B, N, if_maximize, best_x, best_v,
+                           improved, log_v, log_index, force);
+    else if (vs_kind == 1)
+        hipLaunchKernelGGL(k_best_update<float>, grid, block, 0, s, xs, (const float*)vs, B, N, if_maximize, best_x, best_v,
+                           improved, log_v, log_index, force);
+    else
+        hipLaunchKernelGGL(k_best_update<double>, grid, block, 0, s, xs, (const double*)vs, B, N, if_maximize, best_x, best_v,
+                           improved, log_v, log_index, force);
+    return check_launch("k_best_update");
+}

@@ -1,19 +1,29 @@
 """ISCO_TSP -- drop-in for rlsolver/envs/env_ISCO.py:176-363 (TSP sampler) on a HIP device.
 
-The objective pieces run in HIP kernels: ``calculate_distance`` (K12), the delta part of ``opt_2``
-(K13: inverse permutation, ban mask, 3-case swap delta -- replacing sort + searchsorted + a
-[B, N, N-1] 3-D gather) and ``switch``.  The sampler's softmax / Gumbel-top-k / MH bookkeeping
-(``proposal``, ``y2x``, ``step``) is the reference's own [B, N] torch arithmetic.
+``step`` is ONE kernel (rls_isco_tsp_step): the ``path_length`` rounds of opt_2 -> log_softmax -> Gumbel
+draw -> reverse-move log-probability -> swap, and the final Metropolis accept, with the tour, its inverse and
+the distance matrix resident in LDS.  The reference walks the same rounds as ~40 torch ops each (sort +
+searchsorted to invert the tour, a [B, N, N-1] 3-D gather of the random-neighbour table, two softmaxes, two sorts).
+``calculate_distance`` (K12), ``opt_2`` (K13) and ``switch`` remain available as the reference's methods.
 
 Unlike the reference, which reads BATCH_SIZE / K / DEVICE from star-imported config modules at call
 time, they are explicit constructor arguments here.
 """
 from __future__ import annotations
 
+import ctypes as C
+from typing import Optional
+
+import numpy as np
 import torch
 
+from .. import _abi
 from .. import ops_mcpg_tsp as mops
-from ..methods.util import mh_step, multinomial, noreplacement_sampling_renormalize
+from ..ops import _check, _ptr, _stream
+
+
+def _seed_from_torch() -> int:
+    return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
 
 
 class ISCO_TSP:
@@ -32,63 +42,49 @@ class ISCO_TSP:
         self.distance = self.distance.to(self.device, torch.float32).contiguous()
         self.nearest_indices = params_dict['nearest_indices'].to(self.device)
         self.random_indices = params_dict['random_indices'].to(self.device)
+        self._near32 = self.nearest_indices.to(torch.int32).contiguous()
+        self._rand32 = self.random_indices.to(torch.int32).contiguous()
+        # rand < K / (K + 1): the python double is rounded to f32 by the comparison with an f32 tensor
+        self._near_thr = float(np.float32(K / (K + 1)))
 
-    # ---- sampler loop (reference arithmetic, env_ISCO.py:188-236)
-    def step(self, x, path_length, temperature):
-        cur_x = x.clone()
-        traj = torch.zeros((self.batch_size, 3, path_length), dtype=torch.float, device=self.device)
-        for i in range(path_length):
-            cur_x, logits, trajectory, delta_yx = self.proposal(cur_x, temperature)
-            ll_x2y = trajectory['ll_x2y']
-            ll_y2x = self.y2x(logits, trajectory)
-            traj[:, 0, i], traj[:, 1, i], traj[:, 2, i] = delta_yx, -ll_x2y, ll_y2x
-        log_acc = torch.clamp(torch.sum(traj, dim=(1, 2)), max=0.0)
-        y, accepted = self.select_sample(log_acc, x, cur_x)
-        return y, torch.mean(log_acc.exp())
+    def step(self, x, path_length, temperature, draws: Optional[dict] = None, want_terms: bool = False):
+        """env_ISCO.py:188-201 -> (y int64 [B, N], mean acceptance probability 0-dim f32).
 
-    def proposal(self, sample, temperature):
-        x = sample.clone()
-        logits, log_prob, indices, ban_mask, delta_yx = self.get_local_dist(x, temperature)
-        selected_idx, ll_selected = multinomial(log_prob, torch.ones(self.batch_size, dtype=torch.int64,
-                                                                     device=self.device))
-        logits = logits * (1 - 2 * selected_idx['selected_mask'])
-        swap_env_mask, swap_sample_mask = torch.where(((selected_idx['selected_mask'] == 1) & (~ban_mask)) == 1)
-        x = self.switch(sample, swap_env_mask, swap_sample_mask, indices)
-        trajectory = {'ll_x2y': torch.sum(ll_selected, dim=-1), 'selected_idx': selected_idx}
-        return x, logits, trajectory, torch.sum(delta_yx * selected_idx['selected_mask'], dim=-1)
+        ``draws`` (test hook) = the reference's torch draws in call order: u_partner / u_gumbel f32 and r_near /
+        r_rand int64, each [path_length, B, N], u_accept f32 [B].  ``want_terms`` additionally returns
+        (log_acc [B], walked tour before the accept [B, N])."""
+        x = _check(x.contiguous(), "x", (torch.int64,), self.device)
+        B, N = x.shape
+        L = int(path_length)
+        y = torch.empty_like(x)
+        acc = torch.empty(B, dtype=torch.float32, device=self.device)
+        log_acc = torch.empty(B, dtype=torch.float32, device=self.device) if want_terms else None
+        cur = torch.empty_like(x) if want_terms else None
+        d = {}
+        if draws is not None:
+            for k, dt in (("u_partner", torch.float32), ("r_near", torch.int64), ("r_rand", torch.int64),
+                          ("u_gumbel", torch.float32)):
+                d[k] = _check(draws[k].to(self.device).contiguous(), k, (dt,), self.device, (L, B, N))
+            d["u_accept"] = _check(draws["u_accept"].to(self.device).contiguous(), "u_accept", (torch.float32,), self.device, (B,))
+        _abi.call("rls_isco_tsp_step", _ptr(self.distance), N, _ptr(self._near32), self.K, self._near_thr, _ptr(self._rand32),
+                  _ptr(x), _ptr(y), B, L, float(temperature), _ptr(d.get("u_partner")), _ptr(d.get("r_near")),
+                  _ptr(d.get("r_rand")), _ptr(d.get("u_gumbel")), _ptr(d.get("u_accept")),
+                  C.c_uint64(0 if draws is not None else _seed_from_torch()), 0, _ptr(log_acc), _ptr(acc), _ptr(cur),
+                  _stream(self.device))
+        if want_terms:
+            return y, acc.mean(), log_acc, cur
+        return y, acc.mean()
 
-    def get_local_dist(self, sample, temperature):
-        x = sample.detach()
-        logratio, indices, ban_mask = self.opt_2(x, temperature)
-        logratio[ban_mask] = -1e6
-        logits = self.apply_weight_function_logscale(logratio)
-        log_prob = torch.nn.functional.log_softmax(logits, dim=-1)
-        return logits, log_prob, indices, ban_mask, logratio
-
-    def y2x(self, logits, forward_trajectory):
-        log_prob = torch.nn.functional.log_softmax(logits, dim=-1)
-        selected_mask = forward_trajectory['selected_idx']['selected_mask']
-        order_info = forward_trajectory['selected_idx']['perturbed_ll']
-        backwd_idx = torch.argsort(order_info, dim=-1)
-        log_prob = torch.where(selected_mask.bool(), log_prob, torch.tensor(-1e18, device=self.device))
-        backwd_ll = torch.gather(log_prob, dim=-1, index=backwd_idx)
-        backwd_mask = torch.gather(selected_mask, dim=-1, index=backwd_idx)
-        ll_backwd = noreplacement_sampling_renormalize(backwd_ll)
-        return torch.sum(torch.where(backwd_mask.bool(), ll_backwd, torch.tensor(0.0, device=self.device)), dim=-1)
-
-    # ---- hot path
+    # ---- the pieces of a step as the reference exposes them
     def draw_partners(self, sample):
         """First half of opt_2 (env_ISCO.py:246-266): the partner CITY for every position, drawn with
         torch's generator exactly like the reference (rand, randint K, randint N-K-1) but with 2-D
         gathers instead of materialising nearest_indices[sample] / random_indices[sample]."""
         B, N, K = sample.shape[0], self.num_nodes, self.K
-        rand_numbers = torch.rand(B, N, device=self.device)
-        condition = rand_numbers < (K / (K + 1))
-        nearest_rand = torch.randint(0, K, (B, N), device=self.device)
-        random_rand = torch.randint(0, N - K - 1, (B, N), device=self.device)
-        near = self.nearest_indices[sample, nearest_rand]
-        rnd = self.random_indices[sample, random_rand]
-        return torch.where(condition, near, rnd)
+        coin = torch.rand(B, N, device=self.device) < (K / (K + 1))
+        pick_near = torch.randint(0, K, (B, N), device=self.device)
+        pick_far = torch.randint(0, N - K - 1, (B, N), device=self.device)
+        return torch.where(coin, self.nearest_indices[sample, pick_near], self.random_indices[sample, pick_far])
 
     def opt_2(self, sample, temperature, selected=None):
         """env_ISCO.py:238-335 -> (-delta/T f32 [B,N], indices int64 [B,N], ban bool [B,N])."""
@@ -111,12 +107,4 @@ class ISCO_TSP:
 
     def random_gen_init_sample(self, params_dict=None):
         """env_ISCO.py:352-354: batch_size random permutations (Philox Fisher-Yates kernel seeded from torch)."""
-        seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
-        return mops.rand_perms(self.batch_size, self.num_nodes, seed, self.device)
-
-    def select_sample(self, log_acc, x, y):
-        y, accepted = mh_step(log_acc, x, y)
-        return y, accepted
-
-    def apply_weight_function_logscale(self, logratio):
-        return logratio / 2
+        return mops.rand_perms(self.batch_size, self.num_nodes, _seed_from_torch(), self.device)

@@ -1,20 +1,24 @@
 """ISCO_maxcut -- drop-in for rlsolver/envs/env_ISCO.py:10-92 (the MaxCut ISCO sampler).
 
-The two quantities the reference gets from ``vmap(model)`` + ``autograd.grad`` (env_ISCO.py:51-63,
-79-86) are closed-form on a graph and come from HIP kernels here:
-    energy_x[b]          = cut(x_b) / T                          (K1, rls_maxcut_obj)
-    score_change_x[b, i] = (1 - 2x_i) * dE/dx_i / 2 = delta_i / (2T)   (K3, rls_maxcut_delta_all)
-where delta_i is the cut gain of flipping node i.  Samples keep the reference's dtype/shape
-(float32 0/1, [B, N]); the path-length / Gumbel bookkeeping is the reference's [B, N] torch math.
+``step`` is ONE kernel (rls_isco_maxcut_step): energies and single-flip scores of x and of the proposal in
+closed form (the reference gets them from ``vmap(model)`` + ``autograd.grad``, env_ISCO.py:51-63), the Gumbel
+top-k selection of ``path_length`` nodes, the forward / reverse path log-probabilities and the Metropolis accept.
+    energy_x[b]          = cut(x_b) / T
+    score_change_x[b, i] = (1 - 2 x_i) * dE/dx_i / 2 = gain_i / (2T),  gain_i = cut gain of flipping node i
+Samples keep the reference's dtype / shape (float32 0/1, [B, N]).
 """
 from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
 
 import numpy as np
 import torch
 
-from .. import ops
+from .. import _abi, ops
 from ..graph import build_csr
-from ..methods.util import mh_step, multinomial, noreplacement_sampling_renormalize
+from ..ops import _check, _ptr, _stream
+from .env_ISCO import _seed_from_torch
 
 
 class ISCO_maxcut:
@@ -37,50 +41,49 @@ class ISCO_maxcut:
         self.graph = ops.DeviceGraph(csr, self.device)
 
     def random_gen_init_sample(self, params_dict=None):
-        return torch.bernoulli(torch.full((self.batch_size, self.max_num_nodes), 0.5, device=self.device))
+        """env_ISCO.py:22-25: Bernoulli(1/2) samples as float32 (Philox kernel seeded from torch)."""
+        bits = ops.rand_spins(self.batch_size, self.max_num_nodes, _seed_from_torch(), self.device)
+        bits[:, 0] = torch.randint(0, 2, (self.batch_size,), device=self.device, dtype=torch.bool)   # no gauge fixing here
+        return bits.to(torch.float32)
 
-    def step(self, x, path_length, temperature):
-        ll_x, y, trajectory = self.proposal(x, path_length, temperature)
-        ll_x2y = trajectory['ll_x2y']
-        ll_y, ll_y2x = self.ll_y2x(trajectory, y, temperature)
-        log_acc = torch.clamp(ll_y + ll_y2x - ll_x - ll_x2y, max=0.0)
-        y = self.select_sample(log_acc, x, y)
-        return y, ll_y * temperature, log_acc.exp()
+    def step(self, x, path_length, temperature, draws: Optional[dict] = None, want_terms: bool = False):
+        """env_ISCO.py:26-35 -> (y f32 [B, N], ll_y * temperature f32 [B], acceptance probability f32 [B]).
 
-    def proposal(self, x, path_length, temperature):
-        ll_x, log_prob = self.get_local_dist(x, temperature)
-        selected_idx, ll_selected = multinomial(log_prob, path_length)
-        mask = selected_idx['selected_mask']
-        y = x * (1 - mask) + mask * (1 - x)
-        return ll_x, y, {'ll_x2y': torch.sum(ll_selected, dim=-1), 'selected_idx': selected_idx}
+        ``draws`` (test hook) = {"u_gumbel": f32 [B, N], "u_accept": f32 [B]}, the reference's two torch.rand
+        draws.  ``want_terms`` additionally returns (terms f32 [B, 5] = ll_x, ll_x2y, ll_y, ll_y2x, log_acc;
+        mask bool [B, N])."""
+        x = _check(x.contiguous(), "x", (torch.float32,), self.device)
+        B, N = x.shape
+        if N != self.max_num_nodes:
+            raise ValueError(f"x must be [B, {self.max_num_nodes}]")
+        pl = torch.as_tensor(path_length, device=self.device).to(torch.int64).expand(B).contiguous()
+        y = torch.empty_like(x)
+        energy = torch.empty(B, dtype=torch.float32, device=self.device)
+        acc = torch.empty(B, dtype=torch.float32, device=self.device)
+        terms = torch.empty((B, 5), dtype=torch.float32, device=self.device) if want_terms else None
+        mask = torch.empty((B, N), dtype=torch.bool, device=self.device) if want_terms else None
+        ug = ua = None
+        if draws is not None:
+            ug = _check(draws["u_gumbel"].to(self.device).contiguous(), "u_gumbel", (torch.float32,), self.device, (B, N))
+            ua = _check(draws["u_accept"].to(self.device).contiguous(), "u_accept", (torch.float32,), self.device, (B,))
+        _abi.call("rls_isco_maxcut_step", self.graph.ref, _ptr(x), _ptr(y), B, _ptr(pl), float(temperature), _ptr(ug),
+                  _ptr(ua), C.c_uint64(0 if draws is not None else _seed_from_torch()), 0, _ptr(energy), _ptr(acc),
+                  _ptr(terms), _ptr(mask), _stream(self.device))
+        if want_terms:
+            return y, energy, acc, terms, mask
+        return y, energy, acc
 
     def get_local_dist(self, sample, temperature):
-        """-> (energy f32 [B], log_prob f32 [B, N])"""
+        """env_ISCO.py:51-63 -> (energy f32 [B], log_prob f32 [B, N])  (K1 + K3)."""
         xb = (sample > 0).contiguous()
         t = float(temperature)
         energy_x = ops.maxcut_obj(self.graph, xb).to(torch.float32) / t
         score_change_x = ops.maxcut_delta_all(self.graph, xb).to(torch.float32) / (2.0 * t)
         return energy_x, torch.log_softmax(score_change_x, dim=-1)
 
-    def ll_y2x(self, forward_trajectory, y, temperature):
-        ll_y, log_prob = self.get_local_dist(y, temperature)
-        selected_mask = forward_trajectory['selected_idx']['selected_mask']
-        order_info = forward_trajectory['selected_idx']['perturbed_ll']
-        backwd_idx = torch.argsort(order_info, dim=-1)
-        log_prob = torch.where(selected_mask.bool(), log_prob, torch.tensor(-1e18, device=self.device))
-        backwd_ll = torch.gather(log_prob, dim=-1, index=backwd_idx)
-        backwd_mask = torch.gather(selected_mask, dim=-1, index=backwd_idx)
-        ll_backwd = noreplacement_sampling_renormalize(backwd_ll)
-        ll_y2x = torch.sum(torch.where(backwd_mask.bool(), ll_backwd, torch.tensor(0.0, device=self.device)), dim=-1)
-        return ll_y, ll_y2x
-
     def model(self, sample, temperature):
-        """energy of a batch (the reference vmaps a per-sample version): #cut / T."""
+        """energy of a batch (the reference vmaps a per-sample version, env_ISCO.py:79-86): #cut / T."""
         xb = (sample > 0).contiguous()
         if xb.dim() == 1:
             xb = xb[None, :]
         return ops.maxcut_obj(self.graph, xb).to(torch.float32) / float(temperature)
-
-    def select_sample(self, log_acc, x, y):
-        y, acc = mh_step(log_acc, x, y)
-        return y

@@ -101,39 +101,46 @@ class EnvMaxcut:
     def local_search_inplace(self, good_xs: TEN, good_vs: TEN,
                              num_iters: int = 8, num_spin: int = 8, noise_std: float = 0.3,
                              noise: Optional[TEN] = None):
-        """env_L2A.py:87-116.  The weights / noise / kthvalue threshold are the reference's own
-        [B, N] torch ops (they consume torch's generator the same way); each proposal round
-        (clone + masked flip + objective + keep-if-not-worse) is ONE kernel, and the N-iteration
-        'addition' loop is ONE sequential O(E) sweep kernel instead of N objective evaluations.
-
-        ``noise`` (f32 [num_iters + 1, B, N]) replaces the randn_like draws -- test hook."""
+        """env_L2A.py:87-116: ``num_iters`` noisy top-``num_spin`` multi-flip proposals (threshold from a first,
+        separate draw), then the N-step greedy 'addition' loop; both accept ties.  ``good_vs`` may be a 0-dim tensor
+        meaning "compute it" (:91).  ``noise`` (f32 [num_iters + 1, B, N]) replaces the randn_like draws -- test hook."""
         compute_vs = good_vs.shape == ()
-        if self.fused_local_search and ops.local_search_fusable(self.graph, num_spin, good_xs.shape[0]):
-            # pre-pass kernel (weights + whole-batch max/min), then ONE kernel: threshold selection,
-            # num_iters proposal rounds, greedy sweep, with the 64-env tile resident in LDS
-            ws32, ws_std = ops.maxcut_ls_weights(self.graph, good_xs, 1)   # n0_num_n1 - k * vs_raw, exact in both flavours
-            rd_std = ws_std.float() * noise_std
-            good_vs = th.empty(good_xs.shape[0], dtype=th.long, device=self.device) if compute_vs else good_vs.long()
-            if noise is not None:
-                noise = noise.to(device=self.device, dtype=th.float32).contiguous()
-            ops.maxcut_local_search(self.graph, good_xs, ws32, rd_std.contiguous(), good_vs, num_iters, num_spin,
-                                    noise=noise, seed=0 if noise is not None else _seed_from_torch(),
-                                    first_draw_proposes=False, compute_obj=compute_vs)
-            return good_xs, good_vs
+        vs = th.empty(good_xs.shape[0], dtype=th.long, device=self.device) if compute_vs else good_vs.long()
+        self.local_search_pipeline(good_xs, vs, weight_mult=1, num_iters=num_iters, num_spin=num_spin, noise_std=noise_std,
+                                   noise=noise, first_draw_proposes=False, compute_vs=compute_vs)
+        return good_xs, vs
 
-        vs_raw = self.calculate_obj_values_for_loop(good_xs, if_sum=False)
-        ws = self.n0_num_n1 - (2 if self.if_bidirectional else 1) * vs_raw
-        ws_std = ws.max(dim=0, keepdim=True)[0] - ws.min(dim=0, keepdim=True)[0]
-        rd_std = ws_std.float() * noise_std
-        good_vs = vs_raw.sum(dim=1).long() if compute_vs else good_vs.long()
-        draw = (lambda i: noise[i]) if noise is not None else (lambda i: th.randn_like(ws, dtype=th.float32))
-        spin_rand = ws + draw(0) * rd_std
-        thresh = th.kthvalue(spin_rand, k=self.num_nodes - num_spin, dim=1)[0][:, None]
-
-        for it in range(num_iters):
-            spin_rand = ws + draw(1 + it) * rd_std
-            spin_mask = spin_rand.gt(thresh)
-            ops.maxcut_propose_accept(self.graph, good_xs, spin_mask, good_vs)
-
-        ops.maxcut_greedy_sweep(self.graph, good_xs, good_vs)
-        return good_xs, good_vs
+    def local_search_pipeline(self, xs: TEN, vs: TEN, weight_mult: int, num_iters: int, num_spin: int, noise_std: float,
+                              noise: Optional[TEN], first_draw_proposes: bool, compute_vs: bool = False) -> None:
+        """The common body of local_search_inplace (env_L2A.py:87-116) and LocalSearch.random_search
+        (methods/LocalSearch.py:53-83), in place on xs [B, N] bool / vs [B] int64:
+            ws = n0_num_n1 - weight_mult * cut-degree;  rd_std = (max_b ws - min_b ws) * noise_std
+            thresh = kthvalue(ws + draw_0 * rd_std, N - num_spin)
+            proposals mask = (ws + draw_t * rd_std) > thresh for t = 1..num_iters (t = 0.. when first_draw_proposes),
+            each kept where the cut does not decrease; then the greedy single-flip sweep.
+        One pre-pass + ONE fused kernel when the library covers the shape (rls_maxcut_local_search_supported), else
+        K2-weights + torch noise / kthvalue + K6 per round + K5."""
+        B = xs.shape[0]
+        ws32, ws_span = ops.maxcut_ls_weights(self.graph, xs, weight_mult)     # exact integers in both env flavours
+        rd_std = (ws_span.float() * noise_std).contiguous()
+        if noise is not None:
+            noise = noise.to(device=self.device, dtype=th.float32).contiguous()
+        fused_ok = self.fused_local_search and ops.local_search_fusable(self.graph, num_spin, B)
+        if fused_ok and (num_iters > 0 or not first_draw_proposes):
+            ops.maxcut_local_search(self.graph, xs, ws32, rd_std, vs, num_iters, num_spin, noise=noise,
+                                    seed=0 if noise is not None else _seed_from_torch(),
+                                    first_draw_proposes=first_draw_proposes, compute_obj=compute_vs)
+            return
+        if compute_vs:
+            ops.maxcut_obj(self.graph, xs, out=vs)
+        draws = (lambda t: noise[t]) if noise is not None else (lambda t: th.randn((B, self.num_nodes), device=self.device))
+        thresh, t = None, 0
+        for it in range(num_iters + (0 if first_draw_proposes else 1)):
+            noisy = ws32 + draws(t) * rd_std
+            t += 1
+            if thresh is None:
+                thresh = th.kthvalue(noisy, k=self.num_nodes - num_spin, dim=1)[0][:, None]
+                if not first_draw_proposes:
+                    continue
+            ops.maxcut_propose_accept(self.graph, xs, noisy.gt(thresh), vs)
+        ops.maxcut_greedy_sweep(self.graph, xs, vs)

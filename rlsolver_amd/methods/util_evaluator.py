@@ -4,7 +4,8 @@ rlsolver/methods/util_evaluator.py:22-150 (EncoderBase64, Evaluator).
 EncoderBase64 keeps the reference's text format bit for bit (digits ``0-9A-Za-z_$``, most
 significant spin first, zero-filled to ceil(N/6) characters, 120-column wrapping) but converts
 through ``int.from_bytes`` / ``np.packbits`` instead of building decimal strings, so a 10^6-spin
-solution encodes in milliseconds.
+solution encodes in milliseconds.  Evaluator tracks the best solution in device memory (one kernel per
+record2, no host read), see the class.
 """
 from __future__ import annotations
 
@@ -14,6 +15,8 @@ from typing import Union
 
 import numpy as np
 import torch as th
+
+from .. import _abi, ops
 
 TEN = th.Tensor
 _DIGITS = "0123456789ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz_$"
@@ -59,61 +62,109 @@ class EncoderBase64:
         return th.from_numpy(bits[-self.encode_len:].astype(bool))
 
 
-class Evaluator:
-    """Best-solution tracker with the reference's interface (util_evaluator.py:68-150).  record2
-    picks the batch best on the device; like the reference it returns a Python bool (one scalar
-    host read per call -- call it at episode boundaries, not per step)."""
+class _DeviceFlag:
+    """What record2 returns: "did this call improve the best?" -- on the device.  Truth-testing it (``if flag:``,
+    ``logging_print(if_show_x=flag)``) is the host read; a training loop that only passes it on never syncs."""
 
-    def __init__(self, save_dir: str, num_bits: int, x: TEN, v: float, if_maximize: bool):
+    def __init__(self, tensor: TEN):
+        self.tensor = tensor.clone()
+
+    def __bool__(self):
+        return bool(self.tensor.item())
+
+
+class Evaluator:
+    """Best-solution tracker with the interface of rlsolver/methods/util_evaluator.py:68-150 (constructor, record1,
+    record2, save_record_draw_plot, logging_print, first_v, best_x_str, attributes best_x / best_v / recorder1 /
+    recorder2) -- but the state lives on the device.  ``record2`` is one kernel (rls_best_update: first argmax of
+    the batch, strict compare with the best so far, copy of the winning row, append to a value log) and NEVER reads
+    back; the reference's ``float(good_v)`` synchronises on every call.  Host reads happen where the reference
+    prints or saves: ``best_v``, ``best_x``, ``recorder2``, ``logging_print``, ``first_v``."""
+
+    LOG_CHUNK = 4096
+
+    def __init__(self, save_dir: str, num_bits: int, x: TEN, v, if_maximize: bool):
+        if not (isinstance(x, th.Tensor) and x.is_cuda):
+            raise TypeError("rlsolver_amd.Evaluator tracks solutions on a HIP device; x must be a device tensor")
         self.start_timer = time.time()
         self.recorder1 = []
-        self.recorder2 = []
         enc = EncoderBase64(encode_len=num_bits)
         self.bool_to_str = enc.bool_to_str
         self.str_to_bool = enc.str_to_bool
-        self.best_x = x
-        self.best_v = v
         self.if_maximize = if_maximize
         self.save_dir = save_dir
         os.makedirs(self.save_dir, exist_ok=True)
-        self.record1(i=0, v=self.best_v)
-        self.record2(i=0, vs=self.best_v, xs=self.best_x)
+        self.device = x.device
+        self._best_x = th.zeros(x.shape[-1], dtype=th.bool, device=self.device)
+        self._best_v = th.zeros(1, dtype=th.float64, device=self.device)
+        self._improved = th.zeros(1, dtype=th.uint8, device=self.device)
+        self._log = th.zeros(self.LOG_CHUNK, dtype=th.float64, device=self.device)
+        self._log_meta = []                       # (i, host time) per record2 call; values stay in self._log
+        self.record1(i=0, v=v)
+        self._record(0, v, x, force=True)         # the reference's constructor: best := (x, v)
 
-    def record1(self, i: float, v: float):
+    # ---- device side
+    def _record(self, i, vs, xs, force=False):
+        xs2 = xs if xs.dim() == 2 else xs[None, :]
+        if not th.is_tensor(vs):
+            vs = th.tensor([float(vs)], dtype=th.float64, device=self.device)
+        vs1 = vs.reshape(-1)
+        if vs1.dtype not in (th.int64, th.float32, th.float64):
+            vs1 = vs1.to(th.float64)
+        xs2, vs1 = xs2.contiguous(), vs1.contiguous()
+        ops._check(xs2, "xs", (th.bool, th.uint8), self.device, (vs1.numel(), self._best_x.numel()))
+        n = len(self._log_meta)
+        if n == self._log.numel():                # grow the value log (amortised, stream-ordered copy)
+            self._log = th.cat([self._log, th.zeros_like(self._log)])
+        _abi.call("rls_best_update", ops._ptr(xs2), ops._ptr(vs1), {th.int64: 0, th.float32: 1, th.float64: 2}[vs1.dtype],
+                  vs1.numel(), self._best_x.numel(), int(bool(self.if_maximize)), ops._ptr(self._best_x),
+                  ops._ptr(self._best_v), ops._ptr(self._improved), ops._ptr(self._log), n, int(bool(force)),
+                  ops._stream(self.device))
+        self._log_meta.append((i, time.time() - self.start_timer))
+        return _DeviceFlag(self._improved)
+
+    def record1(self, i: float, v):
         self.recorder1.append((i, v))
 
     def record2(self, i: float, vs: Union[TEN, float], xs: TEN):
-        if len(xs.shape) == 2:
-            good_i = vs.argmax() if self.if_maximize else vs.argmin()
-            good_x, good_v = xs[good_i], vs[good_i]
-        else:
-            good_x, good_v = xs, vs
-        good_v = float(good_v)
-        self.recorder2.append((i, good_v, time.time() - self.start_timer))
-        if_update = (good_v > self.best_v) if self.if_maximize else (good_v < self.best_v)
-        if if_update:
-            self.best_x = good_x
-            self.best_v = good_v
-        return if_update
+        """util_evaluator.py:90-107.  Returns a flag object whose truth value is the reference's ``if_update``."""
+        return self._record(i, vs, xs)
+
+    # ---- host views (each is a device read)
+    @property
+    def best_v(self) -> float:
+        v = float(self._best_v.item())
+        return int(v) if v.is_integer() else v
+
+    @property
+    def best_x(self) -> TEN:
+        return self._best_x
+
+    @property
+    def recorder2(self):
+        vals = self._log[:len(self._log_meta)].cpu().tolist()
+        return [(i, v, t) for (i, t), v in zip(self._log_meta, vals)]
 
     def save_record_draw_plot(self, fig_dpi: int = 300):
-        if not self.recorder1 or not self.recorder2:
+        rec2 = self.recorder2
+        if not self.recorder1 or not rec2:
             return
-        np.save(f"{self.save_dir}/recorder1.npy", np.array(self.recorder1))
-        np.save(f"{self.save_dir}/recorder2.npy", np.array(self.recorder2))
+        rec1 = [(i, float(v.item()) if th.is_tensor(v) else v) for i, v in self.recorder1]
+        np.save(f"{self.save_dir}/recorder1.npy", np.array(rec1))
+        np.save(f"{self.save_dir}/recorder2.npy", np.array(rec2))
 
     def logging_print(self, show_str: str = '', if_show_x: bool = False):
         used_time = int(time.time() - self.start_timer)
         x_str = self.best_x_str if if_show_x else ''
-        i = self.recorder2[-1][0]
+        i = self._log_meta[-1][0]
         log_str = f"|{i:6} {used_time:4} sec  best {self.best_v:12.4f} {show_str}  x_str: {x_str}"
         print(log_str, flush=True)
         return log_str
 
     @property
     def first_v(self) -> float:
-        return self.recorder2[0][1]
+        return float(self._log[0].item())
 
     @property
     def best_x_str(self):
-        return self.bool_to_str(self.best_x).replace('\n', '')
+        return self.bool_to_str(self._best_x).replace('\n', '')

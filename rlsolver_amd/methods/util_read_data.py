@@ -4,7 +4,7 @@ from __future__ import annotations
 
 import torch as th
 
-from .. import ops
+from .. import _abi, ops
 from ..graph import (MyGraph, build_adjacency_bool, build_adjacency_indies,  # noqa: F401
                      calc_num_nodes_in_mygraph, load_mygraph2, read_mygraph, read_tsp_file)
 
@@ -32,12 +32,28 @@ def pick_xs_by_vs(xs: TEN, vs: TEN, num_repeats: int, if_maximize: bool = True):
 
 
 def evolutionary_replacement(xs: TEN, vs: TEN, low_k: int, if_maximize: bool = True):
-    """rlsolver/methods/util.py:87-94 (the reference's index arithmetic, including its naming:
-    the ``low_k`` BEST rows overwrite ``low_k`` random others when maximising).  Row moves are
-    [low_k, N] gathers -- control-plane sized, left to torch indexing."""
-    num_sims = xs.shape[0]
-    ids = vs.argsort()
-    top_ids, low_ids = (ids[:-low_k], ids[-low_k:]) if if_maximize else (ids[:low_k], ids[low_k:])
-    replace_ids = top_ids[th.randperm(num_sims - low_k, device=xs.device)[:low_k]]
-    xs[replace_ids] = xs[low_ids]
-    vs[replace_ids] = vs[low_ids]
+    """rlsolver/methods/util.py:87-94, in place: the ``low_k`` rows with the best values (sic -- the reference calls
+    them ``low_ids``) overwrite ``low_k`` rows drawn without replacement from the others.  The ranking and the draw
+    are [B]-sized torch ops (they define how torch's generator is consumed: one randperm(B - low_k)); the row
+    moves are one kernel (rls_copy_rows).  With if_maximize=False the reference indexes a low_k-long tensor with
+    randperm(B - low_k) and raises IndexError unless the draw happens to stay in range: reproduced."""
+    B = xs.shape[0]
+    rank = vs.argsort()
+    if if_maximize:
+        others, donors = rank[:B - low_k], rank[B - low_k:]
+    else:
+        others, donors = rank[:low_k], rank[low_k:]
+    draw = th.randperm(B - low_k, device=xs.device)[:low_k]
+    if (not if_maximize) and (draw.numel() and int(draw.max()) >= others.numel() or donors.numel() != draw.numel()):
+        raise IndexError(f"index out of range: evolutionary_replacement(if_maximize=False) with B={B}, low_k={low_k} "
+                         "(rlsolver/methods/util.py:91-92 fails the same way)")
+    targets = others[draw].contiguous()
+    donors = donors.contiguous()
+    if xs.dtype in (th.bool, th.uint8) and xs.is_cuda and xs.is_contiguous():
+        v64 = vs if (vs.dtype == th.int64 and vs.is_contiguous()) else None
+        _abi.call("rls_copy_rows", ops._ptr(xs), ops._ptr(v64), xs.shape[1], ops._ptr(targets), ops._ptr(donors),
+                  targets.numel(), ops._stream(xs.device))
+        if v64 is None:
+            vs[targets] = vs[donors]
+    else:
+        raise TypeError("evolutionary_replacement needs contiguous bool / uint8 xs on a HIP device; there is no CPU path")

@@ -135,3 +135,66 @@ def test_select_wrappers_golden(golden):
     evolutionary_replacement(xs, vs, 5, True)
     best5 = np.sort(z["evo/vs_in"])[-5:]
     assert np.sum(np.isin(vs.cpu().numpy(), best5)) == 10       # the 5 best now appear twice
+
+
+def test_evolutionary_replacement_golden(golden, monkeypatch):
+    """methods/util.py:87-94 with the reference's recorded randperm: rows and values bit for bit."""
+    from rlsolver_amd.methods import util_read_data as urd
+    z = golden("select_ops")
+    perm = torch.from_numpy(z["evo/max1/perm"]).to(DEV)
+    monkeypatch.setattr(urd.th, "randperm", lambda n, device=None: perm[:n] if perm.numel() == n else (_ for _ in ()).throw(AssertionError(n)))
+    xs = to_dev_bool(z["update/xs0"]).clone()
+    vs = torch.from_numpy(z["evo/vs_in"]).to(DEV).clone()
+    urd.evolutionary_replacement(xs, vs, 5, True)
+    assert np.array_equal(xs.cpu().numpy().astype(np.uint8), z["evo/max1/xs"])
+    assert np.array_equal(vs.cpu().numpy(), z["evo/max1/vs"])
+    monkeypatch.undo()
+    with pytest.raises(IndexError):                             # the reference's minimise branch fails the same way
+        urd.evolutionary_replacement(xs, vs, 5, False)
+    # rows that are a multiple of 16 bytes (vector path) and float values (torch moves them)
+    x2 = (torch.rand((64, 160), device=DEV) < 0.5)
+    v2 = torch.randperm(64, device=DEV).float()
+    keep = x2.clone()
+    urd.evolutionary_replacement(x2, v2, 8, True)
+    vals, counts = torch.unique(v2, return_counts=True)
+    assert int((counts == 2).sum()) == 8 and bool((vals[counts == 2] >= 56).all())
+    for val in vals[counts == 2]:
+        rows = torch.nonzero(v2 == val).flatten()
+        assert torch.equal(x2[rows[0]], x2[rows[1]])
+    assert int((x2 != keep).any(dim=1).sum()) <= 8
+
+
+def test_evaluator_tracks_best_on_device(tmp_path):
+    """Evaluator.record2 (util_evaluator.py:90-107) as a device-side tracker: same decisions as the reference's
+    host logic on a random stream of batches (first argmax, strict improvement), int64 and float values, both
+    directions, single-solution form; the value log and best_x_str read back what the reference would hold."""
+    from rlsolver_amd.methods.util_evaluator import EncoderBase64, Evaluator
+    rng = np.random.RandomState(8)
+    N = 77
+    for maximize in (True, False):
+        for dtype in (torch.int64, torch.float32):
+            x0 = torch.from_numpy(rng.randint(0, 2, N).astype(bool)).to(DEV)
+            ev = Evaluator(str(tmp_path / f"{maximize}{dtype}"), N, x0, 50, maximize)
+            best_v, best_x, log = 50.0, x0.cpu().numpy(), [50.0]
+            for it in range(1, 40):
+                B = int(rng.randint(1, 3000))
+                xs = torch.from_numpy(rng.randint(0, 2, (B, N)).astype(bool)).to(DEV)
+                vs_np = rng.randint(0, 100, B)
+                flag = ev.record2(it, torch.from_numpy(vs_np).to(DEV).to(dtype), xs)
+                gi = int(vs_np.argmax() if maximize else vs_np.argmin())
+                gv = float(vs_np[gi])
+                upd = gv > best_v if maximize else gv < best_v
+                if upd:
+                    best_v, best_x = gv, xs[gi].cpu().numpy()
+                log.append(gv)
+                assert bool(flag) is bool(upd), (maximize, dtype, it)
+            assert ev.best_v == best_v and np.array_equal(ev.best_x.cpu().numpy(), best_x)
+            assert [r[1] for r in ev.recorder2] == log and [r[0] for r in ev.recorder2] == list(range(40))
+            assert ev.first_v == 50.0 and ev.best_x_str == EncoderBase64(N).bool_to_str(best_x).replace("\n", "")
+            # single solution + python float value (TNCO-style callers pass good_v.item())
+            one = torch.from_numpy(rng.randint(0, 2, N).astype(bool)).to(DEV)
+            better = best_v + 1 if maximize else best_v - 1
+            assert bool(ev.record2(99, better, one)) and ev.best_v == better and torch.equal(ev.best_x, one)
+            assert "best" in ev.logging_print(show_str="x", if_show_x=flag)
+            ev.save_record_draw_plot()
+            assert (tmp_path / f"{maximize}{dtype}" / "recorder2.npy").exists()

@@ -1,0 +1,158 @@
+"""The fused ISCO sampler steps (rls_isco_maxcut_step, rls_isco_tsp_step) against traces of the reference's own
+ISCO_maxcut.step / ISCO_TSP.step with every torch draw recorded (tests/golden/isco_steps.npz), and against the
+numpy oracle at sizes and path lengths the traces do not cover.  Discrete results exact; path log-probabilities
+with the conditioning-aware tolerance of tests/isco_tol.py."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle_isco as oi
+from tests.gpu_util import DEV
+from tests.isco_tol import RTOL, assert_ll_close, ll_atol
+
+pytestmark = pytest.mark.gpu
+
+
+def _maxcut_sampler(g, n, B):
+    from rlsolver_amd.envs.env_ISCO_maxcut import ISCO_maxcut
+    params = {"num_nodes": n, "num_edges": len(g), "edge_from": torch.from_numpy(g[:, 0].copy()).to(DEV),
+              "edge_to": torch.from_numpy(g[:, 1].copy()).to(DEV)}
+    return ISCO_maxcut(params, batch_size=B, device=DEV)
+
+
+def _check_maxcut(s, x, pl, T, ug, ua, want, mass, margin, what):
+    y, energy, acc, terms, mask = s.step(torch.from_numpy(x).to(DEV).float(), torch.from_numpy(pl).to(DEV), T,
+                                         draws={"u_gumbel": torch.from_numpy(ug), "u_accept": torch.from_numpy(ua)},
+                                         want_terms=True)
+    terms = terms.cpu().numpy()
+    assert np.array_equal(mask.cpu().numpy().astype(np.uint8), want["mask"].astype(np.uint8)), what
+    np.testing.assert_allclose(terms[:, 0], want["ll_x"], rtol=RTOL, atol=1e-5)
+    np.testing.assert_allclose(terms[:, 2], want["ll_y"], rtol=RTOL, atol=1e-5)
+    np.testing.assert_allclose(energy.cpu().numpy(), want["energy"], rtol=RTOL, atol=1e-5)
+    n_ok = [assert_ll_close(terms[:, c], want[k], mass, f"{what}/{k}") for c, k in ((1, "ll_x2y"), (3, "ll_y2x"), (4, "log_acc"))]
+    ok = mass >= 1e-6
+    np.testing.assert_allclose(acc.cpu().numpy()[ok], want["acc"][ok], rtol=0, atol=2 * ll_atol(mass[ok]).max())
+    sure = margin > 2 * ll_atol(mass)
+    yk = y.cpu().numpy()
+    assert np.array_equal(yk[sure], want["y"][sure].astype(np.float32)), what
+    assert set(np.unique(yk)) <= {0.0, 1.0}
+    return min(n_ok), int(sure.sum())
+
+
+@pytest.mark.parametrize("gname", ["BA_100_ID0", "PL_20_ID0"])
+def test_isco_maxcut_step_golden(golden, gname):
+    z = golden("isco_steps")
+    g = z[f"maxcut/{gname}/graph"]
+    n = int(g[:, :2].max()) + 1
+    s = _maxcut_sampler(g, n, 12)
+    for k in range(3):
+        t = f"maxcut/{gname}/step{k}"
+        T = float(z[f"{t}/temperature"])
+        # conditioning / accept margin of every env: from the oracle (float64), test infrastructure only
+        r = oi.maxcut_step(z[f"{t}/x"], g[:, 0], g[:, 1], z[f"{t}/path_length"], T, z[f"{t}/rand_gumbel"], z[f"{t}/rand_accept"])
+        want = {kk: z[f"{t}/{kk}"] for kk in ("mask", "ll_x", "ll_x2y", "ll_y", "ll_y2x", "log_acc", "energy", "acc", "y")}
+        n_ok, n_sure = _check_maxcut(s, z[f"{t}/x"], z[f"{t}/path_length"], T, z[f"{t}/rand_gumbel"], z[f"{t}/rand_accept"],
+                                     want, r["remaining_mass"], r["accept_margin"], t)
+        assert n_ok >= 10 and n_sure >= 9
+
+
+@pytest.mark.parametrize("n,m,B", [(2000, 19990, 40), (333, 1500, 70), (64, 200, 5)])
+def test_isco_maxcut_step_vs_oracle(n, m, B):
+    """G22-sized graph, rows that are no multiple of the wave, path lengths from 1 to N / 2."""
+    from rlsolver_amd.graph import generate_gnm
+    g = np.asarray(generate_gnm(n, m, 9), dtype=np.int64)
+    s = _maxcut_sampler(g, n, B)
+    rng = np.random.RandomState(n)
+    x = rng.randint(0, 2, size=(B, n)).astype(np.float32)
+    for T in (1.0, 0.4):
+        pl = rng.randint(1, max(2, n // 2), size=B).astype(np.int64)
+        pl[0], pl[-1] = 1, 70 if n > 70 else n // 2
+        ug = rng.rand(B, n).astype(np.float32).clip(1e-7, 1 - 1e-7)
+        ua = rng.rand(B).astype(np.float32)
+        r = oi.maxcut_step(x, g[:, 0], g[:, 1], pl, T, ug, ua)
+        n_ok, n_sure = _check_maxcut(s, x, pl, T, ug, ua, r, r["remaining_mass"], r["accept_margin"], f"n={n} T={T}")
+        assert n_ok >= B // 2
+        x = r["y"]
+    # production draws: same distributional behaviour (annealing increases the cut), 0/1 samples, seeded by torch
+    torch.manual_seed(3)
+    xs = s.random_gen_init_sample()
+    e0 = float(s.model(xs, 1.0).mean())
+    for it in range(30):
+        xs, en, acc = s.step(xs, torch.full((B,), 4, dtype=torch.int64, device=DEV), 0.5)
+        assert bool(((acc >= 0) & (acc <= 1)).all())
+    assert set(np.unique(xs.cpu().numpy())) <= {0.0, 1.0} and float(s.model(xs, 1.0).mean()) > e0
+    torch.manual_seed(3)
+    xs2 = s.random_gen_init_sample()
+    for it in range(30):
+        xs2, _, _ = s.step(xs2, torch.full((B,), 4, dtype=torch.int64, device=DEV), 0.5)
+    assert torch.equal(xs, xs2)
+
+
+def _tsp_sampler(z, p, B):
+    from rlsolver_amd.envs.env_ISCO import ISCO_TSP
+    N = z[f"{p}/distance"].shape[0]
+    params = {"num_nodes": N, "distance": torch.from_numpy(z[f"{p}/distance"]).to(DEV),
+              "nearest_indices": torch.from_numpy(z[f"{p}/nearest_indices"]).to(DEV),
+              "random_indices": torch.from_numpy(z[f"{p}/random_indices"]).to(DEV)}
+    return ISCO_TSP(params, batch_size=B, K=int(z[f"{p}/K"]), device=DEV)
+
+
+@pytest.mark.parametrize("name", ["a5", "berlin52"])
+def test_isco_tsp_step_golden(golden, name):
+    z = golden("isco_steps")
+    p = f"tsp/{name}"
+    s = _tsp_sampler(z, p, 9)
+    for k in range(2):
+        t = f"{p}/step{k}"
+        draws = {"u_partner": torch.from_numpy(z[f"{t}/rand_partner"]), "r_near": torch.from_numpy(z[f"{t}/randint_nearest"]),
+                 "r_rand": torch.from_numpy(z[f"{t}/randint_random"]), "u_gumbel": torch.from_numpy(z[f"{t}/rand_gumbel"]),
+                 "u_accept": torch.from_numpy(z[f"{t}/rand_accept"])}
+        y, mean_acc, log_acc, cur = s.step(torch.from_numpy(z[f"{t}/x"]).to(DEV), int(z[f"{t}/path_length"]),
+                                           float(z[f"{t}/temperature"]), draws=draws, want_terms=True)
+        assert np.array_equal(cur.cpu().numpy(), z[f"{t}/cur_x"]), t                 # the walked tour: exact
+        np.testing.assert_allclose(log_acc.cpu().numpy(), z[f"{t}/log_acc"], rtol=RTOL, atol=2e-5)
+        margin = np.abs(np.log(z[f"{t}/rand_accept"].astype(np.float64) + 1e-24) - z[f"{t}/log_acc"])
+        sure = margin > 1e-4 * np.maximum(1.0, np.abs(z[f"{t}/log_acc"]))
+        assert sure.sum() >= 8 and np.array_equal(y.cpu().numpy()[sure], z[f"{t}/y"][sure])
+        np.testing.assert_allclose(float(mean_acc), float(z[f"{t}/mean_acc"]), rtol=1e-5, atol=1e-7)
+
+
+def test_isco_tsp_step_vs_oracle_and_production():
+    """TSP-100 (the BASELINE config's instance size), 200 envs, 6 rounds per step, against the numpy oracle; then
+    production draws: tours stay permutations, annealing shortens them, torch.manual_seed reproduces the run."""
+    from rlsolver_amd.envs.env_ISCO import ISCO_TSP
+    from rlsolver_amd.graph import generate_tsp_coords, tsp_tables
+    N, K, B, L = 100, 20, 200, 6
+    dist, near, rnd = tsp_tables(generate_tsp_coords(N, seed=100), K=K)
+    params = {"num_nodes": N, "distance": torch.from_numpy(dist).to(DEV), "nearest_indices": torch.from_numpy(near).to(DEV),
+              "random_indices": torch.from_numpy(rnd).to(DEV)}
+    s = ISCO_TSP(params, batch_size=B, K=K, device=DEV)
+    rng = np.random.RandomState(4)
+    x = np.stack([rng.permutation(N) for _ in range(B)]).astype(np.int64)
+    for T in (0.7, 0.2):
+        d = dict(u_partner=rng.rand(L, B, N).astype(np.float32), r_near=rng.randint(0, K, size=(L, B, N)).astype(np.int64),
+                 r_rand=rng.randint(0, N - K - 1, size=(L, B, N)).astype(np.int64),
+                 u_gumbel=rng.rand(L, B, N).astype(np.float32).clip(1e-7, 1 - 1e-7), u_accept=rng.rand(B).astype(np.float32))
+        r = oi.tsp_step(x, dist, near, rnd, K, L, T, d["u_partner"], d["r_near"], d["r_rand"], d["u_gumbel"], d["u_accept"])
+        y, mean_acc, log_acc, cur = s.step(torch.from_numpy(x).to(DEV), L, T, draws={k: torch.from_numpy(v) for k, v in d.items()},
+                                           want_terms=True)
+        assert np.array_equal(cur.cpu().numpy(), r["cur_x"])
+        np.testing.assert_allclose(log_acc.cpu().numpy(), r["log_acc"], rtol=2e-5, atol=1e-4)
+        margin = np.abs(np.log(d["u_accept"].astype(np.float64) + 1e-24) - r["log_acc"])
+        sure = margin > 1e-3 * np.maximum(1.0, np.abs(r["log_acc"]))
+        assert sure.sum() > 0.9 * B and np.array_equal(y.cpu().numpy()[sure], r["y"][sure])
+        x = r["y"]
+    torch.manual_seed(11)
+    t0 = s.random_gen_init_sample()
+    l0 = float(s.calculate_distance(t0).mean())
+    tours = t0
+    for it in range(150):
+        tours, acc = s.step(tours, 4, 0.05)
+    srt = torch.sort(tours, dim=1).values
+    assert torch.equal(srt, torch.arange(N, device=DEV)[None, :].expand(B, N))
+    assert float(s.calculate_distance(tours).mean()) < 0.8 * l0
+    torch.manual_seed(11)
+    t1 = s.random_gen_init_sample()
+    for it in range(150):
+        t1, _ = s.step(t1, 4, 0.05)
+    assert torch.equal(t1, tours)

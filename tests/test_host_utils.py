@@ -1,6 +1,7 @@
 import os
 """Host-side helpers (CPU): base-64 solution strings, result files."""
 import numpy as np
+import pytest
 import torch
 
 from rlsolver_amd.methods.util_evaluator import EncoderBase64, Evaluator
@@ -31,14 +32,10 @@ def test_encoder_edge_cases():
             assert np.array_equal(enc.str_to_bool(s).numpy(), x)
 
 
-def test_evaluator_tracks_best(tmp_path):
+def test_evaluator_has_no_cpu_path(tmp_path):
     xs = torch.tensor([[0, 1, 1], [1, 0, 0]], dtype=torch.bool)
-    ev = Evaluator(str(tmp_path), 3, xs[0], 1.0, True)
-    assert ev.record2(1, torch.tensor([1, 5]), xs) is True and ev.best_v == 5.0 and torch.equal(ev.best_x, xs[1])
-    assert ev.record2(2, torch.tensor([4, 5]), xs) is False
-    assert ev.first_v == 1.0 and ev.best_x_str == EncoderBase64(3).bool_to_str(xs[1])
-    ev.save_record_draw_plot()
-    assert (tmp_path / "recorder2.npy").exists()
+    with pytest.raises(TypeError):
+        Evaluator(str(tmp_path), 3, xs[0], 1.0, True)
 
 
 def test_result_file_roundtrip(tmp_path):

@@ -14,6 +14,7 @@ from rlsolver_amd.methods import MCPG as amcpg
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--quick", action="store_true")
+ap.add_argument("--profile", action="store_true", help="few launches per kernel: for rocprofv3 passes (PMC serialises kernels)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 HBM = 8e12
@@ -164,7 +165,7 @@ def qubo_suite(tag, n, C, num_ls, iters):
              C * n * (num_ls + 1), t, None, f"n={n} dense, C={C}; {2 * n * n * (num_ls + 1) * C / t / 1e12:.2f} Tflop/s of f32 FMA work")
 
 
-it = 5 if a.quick else 30
+it = 5 if (a.quick or a.profile) else 30
 maxcut_suite("G22-sized G(2000,19990), B=2^16", 2000, 19990, 1 << 16, 22, it)
 local_search_suite("G22-sized, dREINFORCE batch", 2000, 19990, 22, 4096, max(2, it // 5))
 local_search_suite("G22-sized, dREINFORCE batch x16", 2000, 19990, 22, 65536, max(2, it // 5))

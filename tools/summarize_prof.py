@@ -21,6 +21,7 @@ ap.add_argument("--fetch", default="gpurun_out/prof_fetch")
 ap.add_argument("--write", default="gpurun_out/prof_write")
 ap.add_argument("--prefix", default="r01")
 ap.add_argument("--cmd", default="")
+ap.add_argument("--rows", type=int, default=12)
 a = ap.parse_args()
 os.makedirs("profiles", exist_ok=True)
 
@@ -37,7 +38,7 @@ if os.path.exists(ks):
             f.write(f"# rocprofv3 --kernel-trace --stats -- {a.cmd}\n")
         w = csv.writer(f)
         w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
-        for r in rows[:12]:
+        for r in rows[:a.rows]:
             w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
                         r["MinNs"], r["MaxNs"], r["StdDev"]])
     print("wrote", f"profiles/{a.tag}_kernel_stats.csv")
