@@ -15,7 +15,9 @@ exchange (8-byte RCCL all-reduce) runs once at the end of the timed region when 
 
 Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events on the launch stream;
 `cpu_baseline` is the C oracle (reference algorithm: flip + full objective re-evaluation, OpenMP)
-timed on the host cores on a bounded sample (rank 0, N = 1 only).
+timed on the host cores on a bounded sample (rank 0, N = 1 only); `cpu_baseline_ref_shaped` is the reference's
+own op chain in torch-CPU ops (oracle/oracle_torch.py).  BASELINE config #5's per-GPU shard:
+`--gset 70 --envs-per-gpu 131072`.
 """
 import argparse
 import json
@@ -43,6 +45,9 @@ def parse():
     ap.add_argument("--slots", type=int, default=8, help="rollout ring depth (slots of B*N bytes)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--via-env", action="store_true",
+                    help="time the drop-in class surface, EnvMaxcutGym.step(action, out=slot) with 1-byte spins, instead of "
+                         "the pre-validated C-ABI launcher (same kernel, plus the Python / ctypes path of the class)")
     ap.add_argument("--no-verify", action="store_true")
     return ap.parse_args()
 
@@ -69,6 +74,33 @@ def cpu_baseline(graph_arr, n, seconds):
     return {"value": Bs * steps / el, "unit": "env-steps/s", "cores": oc.num_threads(), "kind": "port",
             "sample": f"{steps} steps x {Bs} envs of the same graph in {el:.1f} s; C/OpenMP restatement of "
                       f"env_PPO.step (flip + full cut re-evaluation over E={len(eu)} edges)"}
+
+
+def cpu_baseline_ref_shaped(graph_arr, n, seconds):
+    """SURVEY.md section 8d form (i): the reference's env_PPO.step op chain itself (Python loop over envs + three int64
+    [B, E'] index tensors + two advanced-index gathers, envs/env_PPO.py:92-121) in torch-CPU ops on all host cores
+    (oracle/oracle_torch.py, pinned on the reference's trace).  B is reduced so that the 24*B*E' bytes of index
+    tensors fit comfortably in host memory."""
+    import torch as th
+    from oracle.oracle_torch import PPOEnvRefShaped
+    cores = os.cpu_count() or 1
+    th.set_num_threads(cores)
+    Bs = 1024
+    rng = np.random.RandomState(0)
+    env = PPOEnvRefShaped(graph_arr, n, Bs, 10 ** 9, False)
+    env.reset_to(rng.randint(0, 2, size=(Bs, n)).astype(bool))
+    acts = th.from_numpy(rng.randint(0, n, size=(16, Bs)).astype(np.int64))
+    env.step(acts[0])
+    steps, t0 = 0, time.perf_counter()
+    while True:
+        env.step(acts[steps % 16])
+        steps += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or steps >= 10000:
+            break
+    return {"value": Bs * steps / el, "unit": "env-steps/s", "cores": cores, "kind": "ref-shaped",
+            "sample": f"{steps} steps x {Bs} envs of the same graph in {el:.1f} s; torch-CPU restatement of env_PPO.step in "
+                      f"the reference's shape (per-env Python loop, int64 [B,E'] index gathers, {th.get_num_threads()} threads)"}
 
 
 def pmc_traffic_per_launch():
@@ -122,11 +154,22 @@ def main():
     # bare C-ABI call per step (the ring and the action pool are fixed buffers)
     import math
     period = S * A // math.gcd(S, A)
-    launchers = [ops.maxcut_step_launcher(g, slots[t % S], slots[(t + 1) % S], actions[t % A], obj, reward)
-                 for t in range(period)]
+    if a.via_env:
+        import types
+        from rlsolver_amd.envs.env_PPO import EnvMaxcut as EnvMaxcutGym
+        env = EnvMaxcutGym(types.SimpleNamespace(num_nodes=N, num_envs=B, num_steps=10 ** 9), mygraph=mygraph, device=dev,
+                           spin_dtype=torch.bool, reuse_buffers=True)
+        env.xs, env._obj = slots[0], obj        # same initial state as the launcher mode
+        env.graph = g
 
-    def step(t):
-        launchers[t % period]()
+        def step(t):
+            env.step(actions[t % A], out=slots[(t + 1) % S])
+    else:
+        launchers = [ops.maxcut_step_launcher(g, slots[t % S], slots[(t + 1) % S], actions[t % A], obj, reward)
+                     for t in range(period)]
+
+        def step(t):
+            launchers[t % period]()
 
     t = 0
     for _ in range(a.warmup):
@@ -181,7 +224,11 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"Gset G{a.gset}{'' if is_real else '-sized G(n,m) stand-in'} MaxCut "
                                    f"(N={N}, E={len(mygraph)}), {B} envs per GPU, K4 gym step emitting the next "
-                                   f"state into a {S}-slot rollout ring, uniform random actions",
+                                   f"state into a {S}-slot rollout ring, uniform random actions"
+                                   + ("; through EnvMaxcutGym.step(action, out=slot)" if a.via_env else "")
+                                   + ("; BASELINE config #5 shard (2^20 envs over 8 GPUs = 131072 per GPU)"
+                                      if (a.gset == 70 and B == 131072) else ""),
+                       "entry": "EnvMaxcutGym.step" if a.via_env else "rls_maxcut_step launcher",
                        "num_nodes": N, "num_edges": len(mygraph), "envs_per_gpu": B, "global_envs": world * B,
                        "parallelism": f"env-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -194,6 +241,7 @@ def main():
             out["roofline"]["traffic"], out["roofline"]["traffic_source"] = tr[0], f"profiles/{tr[1]} (rocprofv3 --pmc)"
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(graph_arr, N, a.cpu_seconds)
+            out["cpu_baseline_ref_shaped"] = cpu_baseline_ref_shaped(graph_arr, N, max(3.0, a.cpu_seconds / 2))
 
     if use_pg:
         dist.barrier(device_ids=[local_rank])

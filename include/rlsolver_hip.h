@@ -433,13 +433,14 @@ int rls_isco_maxcut_step(const rls_graph* g, const float* x, float* y_out, int64
  * -5e5) -> log_softmax -> one Gumbel draw -> selected position q; ll_x2y = log_prob[q]; ll_y2x = log_softmax of
  * the logits with entry q negated, at q (y2x :214-226); swap positions q + 1 and j(q) unless banned (switch
  * :337-344) }, then log_acc = min(sum of the delta_yx, -ll_x2y, ll_y2x terms, 0) and the Metropolis accept
- * between perm_in and the walked tour.  nearest int32 [N, K], random int32 [N, N-K-1] (ISCO/util_TSP.py:9-16),
+ * between perm_in and the walked tour.  nearest int32 [N, K], random int32 [N, random_stride] of which columns 0 .. N-K-2 are drawn from (the
+ * reference's table has N - 1 columns, ISCO/util_TSP.py:9-16),
  * near_threshold = (float)(K / (K + 1)) as the reference's comparison sees it.  Test draws, all or none:
  * u_partner f32, r_near int64, r_rand int64, u_gumbel f32, each [path_length, B, N] in call order, u_accept f32
  * [B].  perm_out int64 [B, N] (must not alias perm_in); log_acc_out / acc_out f32 [B] and cur_out int64 [B, N]
  * (the walked tour before the accept) may be NULL. */
 int rls_isco_tsp_step(const float* dist, int64_t N, const int32_t* nearest, int32_t K, float near_threshold,
-                      const int32_t* random, const int64_t* perm_in, int64_t* perm_out, int64_t B, int32_t path_length,
+                      const int32_t* random, int32_t random_stride, const int64_t* perm_in, int64_t* perm_out, int64_t B, int32_t path_length,
                       float temperature, const float* u_partner, const int64_t* r_near, const int64_t* r_rand,
                       const float* u_gumbel, const float* u_accept, uint64_t seed, int64_t env_offset,
                       float* log_acc_out, float* acc_out, int64_t* cur_out, void* stream);

@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void k_isco_maxcut_step(IscoMcArgs a) {
 
 // ----------------------------------------------------------------------------------------------- TSP
 struct IscoTspArgs {
-    const float* dist; int64_t N; int32_t K; float near_threshold;
+    const float* dist; int64_t N; int32_t K; int32_t random_stride; float near_threshold;
     const int32_t* nearest; const int32_t* random;       // [N, K], [N, N-K-1]
     const int64_t* perm_in; int64_t* perm_out; int64_t B; int32_t path_length; float temperature;
     const float* u_partner; const int64_t* r_near; const int64_t* r_rand; const float* u_gumbel;   // [L, B, N] or NULL
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256) void k_isco_tsp_step(IscoTspArgs a) {
                 rr = NR > 0 ? (int)(((uint64_t)isco_draw(a.seed, genv, (uint32_t)i, (uint32_t)it, 5) * (uint64_t)NR) >> 32) : 0;
             }
             const bool near = up < a.near_threshold;                              // rand < K / (K + 1)
-            const int sel = near ? a.nearest[(int64_t)city * K + rn] : a.random[(int64_t)city * NR + rr];
+            const int sel = near ? a.nearest[(int64_t)city * K + rn] : a.random[(int64_t)city * a.random_stride + rr];
             const int j = INV[sel];
             const int i0 = (i == 0) ? n - 1 : i - 1;
             const int i1 = (i + 1 == n) ? 0 : i + 1;
@@ -441,12 +441,14 @@ int rls_isco_maxcut_step(const rls_graph* g, const float* x, float* y_out, int64
 }
 
 int rls_isco_tsp_step(const float* dist, int64_t N, const int32_t* nearest, int32_t K, float near_threshold, const int32_t* random,
+                      int32_t random_stride,
                       const int64_t* perm_in, int64_t* perm_out, int64_t B, int32_t path_length, float temperature,
                       const float* u_partner, const int64_t* r_near, const int64_t* r_rand, const float* u_gumbel,
                       const float* u_accept, uint64_t seed, int64_t env_offset, float* log_acc_out, float* acc_out,
                       int64_t* cur_out, void* stream) {
     RLS_REQUIRE(N > 2 && N < (1 << 24) && B >= 0 && path_length >= 0, RLS_EINVAL, "bad sizes N=%lld B=%lld", (long long)N, (long long)B);
     RLS_REQUIRE(K >= 1 && K < N - 1, RLS_EINVAL, "K=%d outside [1, N-2]", K);
+    RLS_REQUIRE(random_stride >= N - K - 1, RLS_EINVAL, "random_stride=%d < N - K - 1", random_stride);
     if (B == 0) return RLS_OK;
     RLS_REQUIRE(dist && nearest && random && perm_in && perm_out, RLS_EINVAL, "NULL pointer");
     RLS_REQUIRE(perm_in != perm_out, RLS_EINVAL, "perm_out must not alias perm_in (a rejected move restores it)");
@@ -463,7 +465,7 @@ int rls_isco_tsp_step(const float* dist, int64_t N, const int32_t* nearest, int3
         while (waves > 1 && per_wave * waves > (size_t)kLdsBytes) waves >>= 1;
     }
     const size_t lds = (lds_d ? dbytes : 0) + per_wave * waves;
-    IscoTspArgs a{dist, N, K, near_threshold, nearest, random, perm_in, perm_out, B, path_length, temperature, u_partner, r_near, r_rand,
+    IscoTspArgs a{dist, N, K, random_stride, near_threshold, nearest, random, perm_in, perm_out, B, path_length, temperature, u_partner, r_near, r_rand,
                   u_gumbel, u_accept, seed, env_offset, log_acc_out, acc_out, cur_out};
     const dim3 grid((unsigned)ceil_div(B, waves)), block(waves * kWave);
     if (lds_d) {

@@ -66,7 +66,7 @@ class ISCO_TSP:
                           ("u_gumbel", torch.float32)):
                 d[k] = _check(draws[k].to(self.device).contiguous(), k, (dt,), self.device, (L, B, N))
             d["u_accept"] = _check(draws["u_accept"].to(self.device).contiguous(), "u_accept", (torch.float32,), self.device, (B,))
-        _abi.call("rls_isco_tsp_step", _ptr(self.distance), N, _ptr(self._near32), self.K, self._near_thr, _ptr(self._rand32),
+        _abi.call("rls_isco_tsp_step", _ptr(self.distance), N, _ptr(self._near32), self.K, self._near_thr, _ptr(self._rand32), self._rand32.shape[1],
                   _ptr(x), _ptr(y), B, L, float(temperature), _ptr(d.get("u_partner")), _ptr(d.get("r_near")),
                   _ptr(d.get("r_rand")), _ptr(d.get("u_gumbel")), _ptr(d.get("u_accept")),
                   C.c_uint64(0 if draws is not None else _seed_from_torch()), 0, _ptr(log_acc), _ptr(acc), _ptr(cur),

@@ -19,7 +19,12 @@ TEN = th.Tensor
 
 
 class EnvMaxcut:
-    def __init__(self, args, mygraph: MyGraph = (), device=th.device('cpu'), if_bidirectional: bool = False):
+    def __init__(self, args, mygraph: MyGraph = (), device=th.device('cpu'), if_bidirectional: bool = False,
+                 spin_dtype=th.float32, reuse_buffers: bool = False):
+        """``spin_dtype``: torch.float32 is the reference's surface (xs cast to float, env_PPO.py:87); torch.bool keeps
+        the state at 1 byte per spin (4x less HBM traffic per step) for callers that cast where they consume it.
+        ``reuse_buffers``: reward / done / cur are written into two alternating pre-allocated sets instead of fresh
+        tensors (no allocator call on the step path); a returned tensor then stays valid for ONE further step."""
         self.device = th.device(device)
         if self.device.type != 'cuda':
             raise TypeError(f"rlsolver_amd.EnvMaxcut needs a HIP device (got {self.device}); there is no CPU path")
@@ -37,14 +42,18 @@ class EnvMaxcut:
         self.n0_ids = self.graph.eu.to(th.long)[None, :]
         self.n1_ids = self.graph.ev.to(th.long)[None, :]
         B = self.num_envs
+        if spin_dtype not in (th.float32, th.bool):
+            raise TypeError("spin_dtype must be torch.float32 (reference surface) or torch.bool")
+        self.spin_dtype = spin_dtype
         self._obj = th.zeros(B, dtype=th.int32, device=self.device)
-        self._reward = th.zeros(B, dtype=th.float32, device=self.device)
-        self._done = th.zeros(B, dtype=th.float32, device=self.device)
+        self._sets = [tuple(th.zeros(B, dtype=th.float32, device=self.device) for _ in range(3)) for _ in range(2)] \
+            if reuse_buffers else None
+        self._flip = 0
 
     def reset(self):
         xs = self.generate_xs_randomly(num_sims=self.num_envs)
-        self.xs = xs.to(th.float)
-        self._obj = ops.maxcut_obj(self.graph, self.xs).to(th.int32)
+        self.xs = xs.to(self.spin_dtype)
+        self._obj.copy_(ops.maxcut_obj(self.graph, self.xs))
         self.last_reward = self._obj.to(th.float)
         return self.xs
 
@@ -52,15 +61,18 @@ class EnvMaxcut:
         """env_PPO.py:92-106.  ``out`` (f32 [B, N]) makes the step emit the next state there (the
         rollout-buffer form); by default xs is updated in place like the reference."""
         self.action_count += 1
-        action = action.to(device=self.device, dtype=th.int64).contiguous()
-        cur = th.empty(self.num_envs, dtype=th.float32, device=self.device)
-        reward = th.empty(self.num_envs, dtype=th.float32, device=self.device)
+        if action.dtype != th.int64 or action.device != self.device or not action.is_contiguous():
+            action = action.to(device=self.device, dtype=th.int64).contiguous()
+        if self._sets is not None:
+            reward, next_done, cur = self._sets[self._flip]
+            self._flip ^= 1
+        else:
+            reward, next_done, cur = (th.empty(self.num_envs, dtype=th.float32, device=self.device) for _ in range(3))
         if self.action_count == self.num_steps:
             self.action_count = 0
             done_value = 1.0
         else:
             done_value = 0.0
-        next_done = th.empty(self.num_envs, dtype=th.float32, device=self.device)
         dst = self.xs if out is None else out
         ops.maxcut_step(self.graph, self.xs, dst, action, self._obj, reward, cur, next_done, done_value)
         self.xs = dst
@@ -71,10 +83,21 @@ class EnvMaxcut:
         """env_PPO.py:108-121 (objective of the env's own state)."""
         if if_sum:
             return ops.maxcut_obj(self.graph, self.xs)
-        values = ops.maxcut_edge_cut_mask(self.graph, self.xs > 0)
+        values = ops.maxcut_edge_cut_mask(self.graph, self.xs if self.xs.dtype == th.bool else self.xs > 0)
         if self.if_bidirectional:
             values = values // 2
         return values
 
     def generate_xs_randomly(self, num_sims):
         return ops.rand_spins(num_sims, self.num_nodes, _seed_from_torch(), self.device)
+
+    # ---- checkpoint of the env state (SURVEY.md section 5)
+    def state_dict(self):
+        return {"xs": self.xs.clone(), "obj": self._obj.clone(), "action_count": self.action_count,
+                "last_reward": None if self.last_reward is None else self.last_reward.clone()}
+
+    def load_state_dict(self, d):
+        self.xs = d["xs"].to(device=self.device, dtype=self.spin_dtype).clone()
+        self._obj.copy_(d["obj"])
+        self.action_count = int(d["action_count"])
+        self.last_reward = None if d["last_reward"] is None else d["last_reward"].clone()

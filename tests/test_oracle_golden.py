@@ -100,6 +100,26 @@ def test_env_ppo(golden, gname, bidir):
     assert list(z[f"{tag}/ret_dtypes"]) == ["torch.float32"] * 4
 
 
+@pytest.mark.parametrize("gname", ["BA_100_ID0", "gset_14_stub"])
+@pytest.mark.parametrize("bidir", [0, 1])
+def test_env_ppo_ref_shaped_torch_baseline(golden, gname, bidir):
+    """The torch-CPU op chain bench.py times as cpu_baseline_ref_shaped is the reference's env_PPO.step, bit for bit."""
+    import torch
+    from oracle.oracle_torch import PPOEnvRefShaped
+    z = golden("env_ppo")
+    graph = z[f"{gname}/graph"]
+    tag = f"{gname}/bidir{bidir}"
+    n = int(graph[:, :2].max()) + 1
+    env = PPOEnvRefShaped(graph, n, z[f"{tag}/xs0"].shape[0], 20, bool(bidir))
+    env.reset_to(z[f"{tag}/xs0"])
+    assert np.array_equal(env.last_reward.numpy(), z[f"{tag}/cut0"])
+    for t in range(50):
+        xs, r, d, c = env.step(torch.from_numpy(z[f"{tag}/actions"][t]))
+        assert np.array_equal(r.numpy(), z[f"{tag}/rewards"][t]) and np.array_equal(d.numpy(), z[f"{tag}/dones"][t])
+        assert np.array_equal(c.numpy(), z[f"{tag}/curs"][t])
+    assert np.array_equal((env.xs > 0).numpy().astype(np.uint8), z[f"{tag}/xs_final"])
+
+
 def test_select_ops(golden):
     z = golden("select_ops")
     for mx in (1, 0):

@@ -26,7 +26,7 @@ def test_isco_maxcut_step_oracle_golden(golden, gname):
         assert np.array_equal(r["y_prop"], z[f"{t}/y_prop"])
         for key in ("ll_x", "ll_y", "energy"):           # no renormalisation involved: tight
             np.testing.assert_allclose(r[key], z[f"{t}/{key}"], rtol=RTOL, atol=1e-5, err_msg=f"{t}/{key}")
-        checked = [assert_ll_close(r[key], z[f"{t}/{key}"], r["remaining_mass"], f"{t}/{key}")
+        checked = [assert_ll_close(r[key], z[f"{t}/{key}"], r["remaining_mass"], f"{t}/{key}", z[f"{t}/path_length"])
                    for key in ("ll_x2y", "ll_y2x", "log_acc")]
         assert min(checked) >= 10                        # all but the path_length = N env carry information
         sure = r["accept_margin"] > 2 * (2e-5 + 2e-6 / np.maximum(r["remaining_mass"], 1e-6))

@@ -1,0 +1,139 @@
+#!/usr/bin/env python3
+"""Per-kernel roofline table of a round from the three rocprofv3 passes of tools/profile_round.sh over
+tools/bench_configs.py (kernel trace; --pmc FETCH_SIZE; --pmc WRITE_SIZE):
+
+    python tools/kernel_table.py r02 [--src gpurun_out/r02a]   ->  profiles/r02_kernels.json, profiles/r02_kernels.md
+
+Dispatches are grouped by (kernel, grid size, workgroup size, LDS): the same kernel runs at several BASELINE configs
+in one bench_configs pass.  Per group: launches, mean duration (kernel trace), HBM bytes per launch from the PMC
+passes with the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE tallies 64 B per 128-B request of a wide
+coalesced read -> read bytes = 2 x FETCH_SIZE; WRITE_SIZE exact for 16-B-per-lane stores; both in KB of 1024 B),
+and -- where the group is one of the rows below -- the ALGORITHMIC bytes per launch (SURVEY.md section 8d x the units
+one launch processes) and achieved / 8 TB/s.
+"""
+import argparse
+import collections
+import csv
+import json
+import os
+import re
+
+HBM = 8e12
+
+# (kernel regex, grid threads, units B per launch, algorithmic bytes per unit, label).  The grid pins the config: tile
+# kernels launch B / 64 workgroups, the step kernel B / EPW waves, wave-per-env kernels B waves.
+N22, N70, N14, NT, NBA = 2000, 10000, 800, 100, 10000
+T22, T70 = 65536 // 64, 131072 // 64          # 64-env tiles
+ROWS = [
+    (r"k_maxcut_step<unsigned char, 4, 2, true", 65536 // 4 * 64, 65536, 2 * N22 + 20, "K4 maxcut_step emit u8 | G22 2^16 (headline)"),
+    (r"k_maxcut_step<float, 1, 2, true", 65536 * 64, 65536, 8 * N22 + 20, "K4 maxcut_step emit f32 gym surface | G22 2^16"),
+    (r"k_maxcut_step<unsigned char, 1, 2, true", 131072 * 64, 131072, 2 * N70 + 20, "K4 maxcut_step emit u8 | G70 2^17"),
+    (r"k_maxcut_step<float, 1, 1, true", 131072 * 64, 131072, 8 * N70 + 20, "K4 maxcut_step emit f32 gym surface | G70 2^17"),
+    (r"k_maxcut_step<unsigned char, 8, 2, true", 256 // 8 * 64, 256, 2 * N14 + 20, "K4 maxcut_step emit u8 | G14 256 (launch-bound)"),
+    (r"k_maxcut_obj<", T22 * 256, 65536, N22 + 8, "K1 maxcut_obj | G22 2^16"),
+    (r"k_maxcut_obj<", T70 * 512, 131072, N70 + 8, "K1 maxcut_obj | G70 2^17"),
+    (r"k_maxcut_obj_pipe", None, 65536, N22 + 8, "K1 maxcut_obj (persistent) | G22 2^16"),
+    (r"k_maxcut_propose_accept<", T22 * 256, 65536, 2 * N22 + 16, "K6 propose_accept | G22 2^16"),
+    (r"k_maxcut_propose_accept<", T70 * 512, 131072, 2 * N70 + 16, "K6 propose_accept | G70 2^17"),
+    (r"k_maxcut_greedy_sweep_levels<", T22 * 256, 65536, 2 * N22 + 16, "K5 greedy_sweep | G22 2^16 (on-chip bound)"),
+    (r"k_maxcut_greedy_sweep_levels<", T70 * 512, 131072, 2 * N70 + 16, "K5 greedy_sweep | G70 2^17 (on-chip bound)"),
+    (r"k_node_stats_bits<1", T22 * 512, 65536, 5 * N22, "K3 delta_all | G22 2^16"),
+    (r"k_node_stats_bits<1", T70 * 512, 131072, 5 * N70, "K3 delta_all | G70 2^17"),
+    (r"k_node_stats_bits<2", T22 * 512, 65536, 5 * N22, "ls_weights pre-pass | G22 2^16"),
+    (r"k_tsp_tour_length", None, 65536, 8 * NT + 4, "K12 tsp_tour_length | TSP-100 2^16"),
+    (r"k_tsp_swap_delta_all", None, 65536, 29 * NT, "K13 tsp_swap_delta_all | TSP-100 2^16"),
+    (r"k_spin_step<float, true>", 16384 * 64, 16384, 24 * N22, "S1 spin_step | G22-sized 2^14 (6 rows x 4N change per step)"),
+    (r"k_spin_step<float, true>", 4096 * 64, 4096, 24 * 200, "S1 spin_step | BA-200 4096"),
+    (r"k_mcpg_local_search_levels", None, 262144, 8 * NBA, "K7+K8 local_search_levels | BA-1e4 2^18 (f32 [N,C] in + out)"),
+    (r"k_mcpg_pick_gather", None, 2048, 4 * NBA, "K8b pick gather | 2048 kept chains"),
+]
+
+
+def short(n):
+    n = n.replace("void rls::", "").replace("rls::", "")
+    return re.sub(r"\(.*$", "", n)[:120]
+
+
+def load_trace(path):
+    g = collections.defaultdict(list)
+    meta = {}
+    for r in csv.DictReader(open(path)):
+        k = (short(r["Kernel_Name"]), int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]),
+             int(r["Workgroup_Size_X"]), int(r["LDS_Block_Size"]))
+        g[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        meta[k] = {"vgpr": int(r["VGPR_Count"]), "sgpr": int(r["SGPR_Count"]), "scratch": int(r["Scratch_Size"])}
+    return g, meta
+
+
+def load_pmc(path, name):
+    g = collections.defaultdict(list)
+    if not os.path.exists(path):
+        return g
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != name:
+            continue
+        k = (short(r["Kernel_Name"]), int(r["Grid_Size"]), int(r["Workgroup_Size"]), int(r["LDS_Block_Size"]))
+        g[k].append(float(r["Counter_Value"]))
+    return g
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("tag")
+    ap.add_argument("--src", default=None, help="prefix of the gpurun_out directories (default gpurun_out/<tag>)")
+    ap.add_argument("--what", default="cfg")
+    a = ap.parse_args()
+    src = a.src or f"gpurun_out/{a.tag}"
+    pfx = os.path.basename(src)
+    trace, meta = load_trace(f"{src}_{a.what}_kt/{pfx}_kernel_trace.csv")
+    fetch = load_pmc(f"{src}_{a.what}_fetch/{pfx}_counter_collection.csv", "FETCH_SIZE")
+    write = load_pmc(f"{src}_{a.what}_write/{pfx}_counter_collection.csv", "WRITE_SIZE")
+    out = []
+    for k, durs in sorted(trace.items(), key=lambda kv: -sum(kv[1])):
+        name, grid, wg, lds = k
+        if name.startswith("__amd") or "at::native" in name or "elementwise" in name or "hipcub" in name or "rocprim" in name \
+                or name.strip() in ("void", ""):
+            continue
+        d = sorted(durs)
+        # steady state: drop the first (cold) launch of a group when there are several
+        use = durs[1:] if len(durs) > 2 else durs
+        rec = {"kernel": name, "grid": grid, "workgroup": wg, "lds_bytes": lds, "launches": len(durs),
+               "mean_us": sum(use) / len(use) / 1e3, "min_us": d[0] / 1e3, **meta[k]}
+        f, w = fetch.get(k), write.get(k)
+        if f:
+            rec["read_bytes"] = 2 * 1024 * sum(f) / len(f)
+        if w:
+            rec["write_bytes"] = 1024 * sum(w) / len(w)
+        if f and w:
+            rec["hbm_bytes"] = rec["read_bytes"] + rec["write_bytes"]
+        for pat, want_grid, B, per_unit, label in ROWS:
+            if re.search(pat, name) is None or (want_grid is not None and want_grid != grid):
+                continue
+            rec.update({"row": label, "units_per_launch": B, "algorithmic_bytes": B * per_unit,
+                        "achieved_GBps": B * per_unit / (rec["mean_us"] * 1e-6) / 1e9,
+                        "frac_of_8TBps": B * per_unit / (rec["mean_us"] * 1e-6) / HBM})
+            if "hbm_bytes" in rec:
+                rec["traffic_over_algorithmic"] = rec["hbm_bytes"] / (B * per_unit)
+            break
+        out.append(rec)
+    os.makedirs("profiles", exist_ok=True)
+    json.dump({"note": __doc__.strip().split("\n\n")[1], "source": f"{src}_{a.what}_*", "groups": out},
+              open(f"profiles/{a.tag}_kernels.json", "w"), indent=1)
+    with open(f"profiles/{a.tag}_kernels.md", "w") as f:
+        f.write(f"# {a.tag}: per-kernel rocprofv3 summary (tools/profile_round.sh -> tools/kernel_table.py)\n\n")
+        f.write("mean us = kernel-trace duration (first launch of a group dropped); read = 2 x FETCH_SIZE, write = WRITE_SIZE "
+                "(separate --pmc passes, KB of 1024 B); frac = algorithmic bytes / mean / 8 TB/s\n\n")
+        f.write("| kernel | grid x wg | LDS | VGPR | launches | mean us | read MB | write MB | row | alg MB | frac | traffic/alg |\n")
+        f.write("|---|---|---|---|---|---|---|---|---|---|---|---|\n")
+        for r in out:
+            f.write("| `{}` | {} x {} | {} | {} | {} | {:.1f} | {} | {} | {} | {} | {} | {} |\n".format(
+                r["kernel"][:90], r["grid"], r["workgroup"], r["lds_bytes"], r["vgpr"], r["launches"], r["mean_us"],
+                f"{r['read_bytes'] / 1e6:.1f}" if "read_bytes" in r else "", f"{r['write_bytes'] / 1e6:.1f}" if "write_bytes" in r else "",
+                r.get("row", ""), f"{r['algorithmic_bytes'] / 1e6:.1f}" if "row" in r else "",
+                f"{r['frac_of_8TBps']:.3f}" if "row" in r else "",
+                f"{r['traffic_over_algorithmic']:.2f}" if "traffic_over_algorithmic" in r else ""))
+    print(open(f"profiles/{a.tag}_kernels.md").read())
+
+
+if __name__ == "__main__":
+    main()

@@ -12,13 +12,13 @@ export TMPDIR=/tmp
 cd /tmp
 BENCH="python3 $R/bench.py --steps 500 --warmup 20 --no-cpu-baseline"
 CFG="python3 $R/tools/bench_configs.py --profile"
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${P}_bench_kt -o $P -- $BENCH > $R/gpurun_out/${P}_bench_kt.log 2>&1
-rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/${P}_bench_fetch -o $P -- $BENCH > $R/gpurun_out/${P}_bench_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/${P}_bench_write -o $P -- $BENCH > $R/gpurun_out/${P}_bench_write.log 2>&1
-rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${P}_cfg_kt -o $P -- $CFG > $R/gpurun_out/${P}_cfg_kt.jsonl 2> $R/gpurun_out/${P}_cfg_kt.err
-rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/${P}_cfg_fetch -o $P -- $CFG > $R/gpurun_out/${P}_cfg_fetch.jsonl 2> $R/gpurun_out/${P}_cfg_fetch.err
-rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/${P}_cfg_write -o $P -- $CFG > $R/gpurun_out/${P}_cfg_write.jsonl 2> $R/gpurun_out/${P}_cfg_write.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${P}_bench_kt -o $P -- $BENCH > $R/gpurun_out/${P}_bench_kt.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${P}_bench_fetch -o $P -- $BENCH > $R/gpurun_out/${P}_bench_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${P}_bench_write -o $P -- $BENCH > $R/gpurun_out/${P}_bench_write.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${P}_cfg_kt -o $P -- $CFG > $R/gpurun_out/${P}_cfg_kt.jsonl 2> $R/gpurun_out/${P}_cfg_kt.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${P}_cfg_fetch -o $P -- $CFG > $R/gpurun_out/${P}_cfg_fetch.jsonl 2> $R/gpurun_out/${P}_cfg_fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${P}_cfg_write -o $P -- $CFG > $R/gpurun_out/${P}_cfg_write.jsonl 2> $R/gpurun_out/${P}_cfg_write.err
 cd $R
 # the raw per-dispatch traces are large; keep the stats and the counter tables
-find gpurun_out/${P}_*_kt -name "*_kernel_trace.csv" -size +20M -delete
+find gpurun_out/${P}_* -name "*_kernel_trace.csv" -size +8M -delete; find gpurun_out/${P}_* -name "*.db" -delete
 ls -la gpurun_out/${P}_*
