@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RLS_ABI_VERSION 3
+#define RLS_ABI_VERSION 4
 
 enum {
     RLS_OK = 0,
@@ -288,8 +288,13 @@ int rls_spin_step(const rls_graph* g, const rls_spin_env* env, int state_bytes, 
                   int32_t use_stag, double stag_punishment, int32_t use_basin, double basin_reward, void* stream);
 
 /* -------------------------------------------------------------------- MCPG */
-/* Layout: node-major x[N, C] as in the reference (chains are the fast axis); spin_bytes = 4
- * (float32 0.0|1.0, what metro_sampling returns) or 1 (uint8). */
+/* Layouts of a batch of C chains:
+ *   spin_bytes = 4 | 1   node-major x[N, C] as in the reference (chains are the fast axis): float32 0.0|1.0 (what
+ *                        metro_sampling returns) or uint8;
+ *   spin_bytes = 0       bit-packed, tile-major uint64 [ceil(C / 64), N]: word (t, n) holds node n of the chains
+ *                        64 t .. 64 t + 63 (bit e = chain 64 t + e; bits of chains >= C are 0).  1/32 of the f32
+ *                        surface's bytes, a 64-chain tile is N consecutive words; the form in which a sampling round
+ *                        stays on the device (rls_mcpg_pack_chains / rls_mcpg_unpack_chains convert). */
 
 /* K9  metro_sampling(probs, start_status, max_transfer_time)  methods/MCPG.py:88-117.
  * Runs rounds t = t_offset .. t_offset + min(T, *t_limit_dev) - 1 for every chain c:
@@ -306,8 +311,11 @@ int rls_spin_step(const rls_graph* g, const rls_spin_env* env, int state_bytes, 
  * on the device, a second call with t_limit_dev pointing at it (device int64) and write_back = 1
  * applies the chunk; *t_limit_dev <= 0 makes a call return immediately, so chunks after the stop
  * round cost one empty launch.  t_limit_dev NULL = all T rounds.  samples is updated in place only
- * when write_back != 0. */
-int rls_mcpg_metro_rounds(void* samples, const void* samples_in, int spin_bytes, int64_t N, int64_t C,
+ * when write_back != 0.
+ * C_in (bit-packed layout only; 0 or C otherwise): samples_in holds C_in < C chains, C_in a multiple of 64, and chain c
+ * starts from chain c % C_in -- the reference's  xs_bool = temp_max_info.repeat(1, repeat_times)  (MCPG.py:393-394)
+ * without materialising the repeat. */
+int rls_mcpg_metro_rounds(void* samples, const void* samples_in, int64_t C_in, int spin_bytes, int64_t N, int64_t C,
                           const float* probs, int64_t T, int64_t t_offset, const int64_t* index, const float* u,
                           uint64_t seed, const int64_t* t_limit_dev, int write_back, int64_t* accepts, void* stream);
 
@@ -354,10 +362,13 @@ int rls_mcpg_visit_levels(const int32_t* rowptr, const int32_t* col, int64_t N, 
 
 /* K7 + K8 first half on that schedule (production path: tie coins from a counter hash keyed by (seed, 64-chain
  * block, pass, position); coins uint64 [num_ls * N, ceil(C / 64)] -- bit c % 64 of word [pass * N + pos, c / 64] =
- * "u < 1/2" for chain c -- replaces them for tests).  Same outputs as rls_mcpg_local_search. */
-int rls_mcpg_local_search_levels(const rls_graph* g, const void* xs_in, int spin_bytes, float* xs_out, int64_t C,
-                                 const int32_t* lv_ptr, const int32_t* lv_data, int64_t num_groups, int64_t num_ls,
-                                 const uint64_t* coins, uint64_t seed, float* expected, void* stream);
+ * "u < 1/2" for chain c -- replaces them for tests).  Same outputs as rls_mcpg_local_search; xs_out is float32
+ * node-major (out_spin_bytes = 4) or bit-packed (0; then xs_out may alias a bit-packed xs_in).  C_in: as in
+ * rls_mcpg_metro_rounds. */
+int rls_mcpg_local_search_levels(const rls_graph* g, const void* xs_in, int spin_bytes, int64_t C_in, void* xs_out,
+                                 int out_spin_bytes, int64_t C, const int32_t* lv_ptr, const int32_t* lv_data,
+                                 int64_t num_groups, int64_t num_ls, const uint64_t* coins, uint64_t seed, float* expected,
+                                 void* stream);
 
 /* 1 when rls_mcpg_local_search_levels covers this graph with a schedule of num_groups groups (bit tile + group
  * offsets + scratch within 160 KB of LDS, unweighted, N < 2^20, degrees < 1024), else 0. */
@@ -366,9 +377,29 @@ int rls_mcpg_local_search_levels_supported(const rls_graph* g, int64_t num_group
 /* K8 second half  methods/MCPG.py:154-161: best_index[m] = m + M * argmin_r expected[r*M + m]
  * (first minimum), vs_good[m] = (num_edges - expected[best]) / 2, xs_good[:, m] = xs[:, best].
  * M = total_mcmc_num, R = repeat_times, xs f32 [N, M*R], xs_good f32 [N, M]. */
-int rls_mcpg_pick_best(const float* expected, const float* xs, int64_t N, int64_t total_mcmc_num,
+int rls_mcpg_pick_best(const float* expected, const void* xs, int spin_bytes, int64_t N, int64_t total_mcmc_num,
                        int64_t repeat_times, int64_t num_edges, int64_t* best_index, float* vs_good,
-                       float* xs_good, void* stream);
+                       void* xs_good, void* stream);
+
+/* The best-merge of the MCPG outer loop  methods/MCPG.py:376-391 on bit-packed kept chains (M = total_mcmc_num,
+ * temp_info / now_info uint64 [ceil(M/64), N]), all on the device:
+ *   for m: if temp_max[m] > now_max_res[m]: now_max_res[m] = temp_max[m]; now_info[:, m] = temp_info[:, m]   (:377-380)
+ *   hi = first argmax, lo = first argmin of now_max_res; now_max_res[lo] = now_max_res[hi];
+ *   now_info[:, lo] = now_info[:, hi]; temp_info[:, lo] = now_info[:, hi]                                     (:383-391)
+ * temp_info afterwards is the start state of the next round (rls_mcpg_metro_rounds with C_in = M).  mask_scratch
+ * uint64 [ceil(M/64)]; best_value f32 [1] / best_index int64 [1] (may be NULL) receive max(now_max_res) and its chain. */
+int rls_mcpg_merge_best(const float* temp_max, uint64_t* temp_info, float* now_max_res, uint64_t* now_info, int64_t N,
+                        int64_t total_mcmc_num, uint64_t* mask_scratch, float* best_value, int64_t* best_index, void* stream);
+
+/* What get_return  methods/MCPG.py:292-302 needs from the samples: A[n] += sum_c value[c] * s[n, c] over the C
+ * bit-packed chains (A f32 [N], zeroed by the caller).  With s in {0,1},  log(s p + (1-s)(1-p)) summed over nodes is
+ * sum_n log(1-p_n) + sum_n s_n (log p_n - log(1-p_n)), so the objective mean_c(log_prob_sum_c * value_c) and its
+ * gradient with respect to p follow from A and sum(value) -- the [C, N] float products are never formed. */
+int rls_mcpg_value_bit_sums(const uint64_t* samples, int64_t N, int64_t C, const float* value, float* A, void* stream);
+
+/* node-major uint8 / float32 [N, C] -> bit-packed tiles, and back to float32 (the shims of the reference-shaped API) */
+int rls_mcpg_pack_chains(const void* xs, int spin_bytes, int64_t N, int64_t C, uint64_t* packed, void* stream);
+int rls_mcpg_unpack_chains(const uint64_t* packed, int64_t N, int64_t C, float* xs, void* stream);
 
 /* K11 mcpg_sampling_qubo / mcpg_sampling_qubo_bin  methods/MCPG/sampling.py:323-370 (after the
  * metro step): num_ls Gauss-Seidel sweeps  x_i <- [Q[i,:] . x (x_i := 0) > thr_i]  over variables in

@@ -507,3 +507,39 @@ def rand_perms(B, N, seed, env_offset=0):
         p[rows, k] = p[rows, j]
         p[rows, j] = tk
     return p
+
+
+# --------------------------------------------------------------------------- MCPG outer loop (methods/MCPG.py:292-302, 376-394)
+
+
+def mcpg_merge_best(temp_max, temp_max_info, now_max_res, now_max_info):
+    """The per-chain best-merge loop and the min/max replacement of mcpg(), rlsolver/methods/MCPG.py:376-391, on
+    copies.  temp_max / now_max_res f32 [M]; *_info [N, M].  Returns (now_max_res, now_max_info, temp_max_info,
+    now_max, now_max_index)."""
+    now_max_res, now_max_info, temp_max_info = now_max_res.copy(), now_max_info.copy(), temp_max_info.copy()
+    for i0 in range(temp_max.shape[0]):
+        if temp_max[i0] > now_max_res[i0]:
+            now_max_res[i0] = temp_max[i0]
+            now_max_info[:, i0] = temp_max_info[:, i0]
+    now_max = now_max_res.max()
+    now_max_index = int(np.argmax(now_max_res))
+    now_min_index = int(np.argmin(now_max_res))
+    now_max_res[now_min_index] = now_max
+    now_max_info[:, now_min_index] = now_max_info[:, now_max_index]
+    temp_max_info[:, now_min_index] = now_max_info[:, now_max_index]
+    return now_max_res, now_max_info, temp_max_info, now_max, now_max_index
+
+
+def mcpg_get_return(probs, samples, value, total_mcmc_num, repeat_times):
+    """get_return, rlsolver/methods/MCPG.py:292-302 (samples [C, N] 0/1, probs [N], value [C]) in float64, and its
+    gradient with respect to probs (what autograd returns): objective = mean_c(log_prob_sum_c * value_c)."""
+    s = samples.astype(np.float64)
+    p = probs.astype(np.float64)
+    v = value.astype(np.float64)
+    log_prob_sum = np.empty(s.shape[0])
+    for j in range(repeat_times):
+        j0, j1 = total_mcmc_num * j, total_mcmc_num * (j + 1)
+        log_prob_sum[j0:j1] = np.log(s[j0:j1] * p + (1 - s[j0:j1]) * (1 - p)).sum(axis=1)
+    objective = (log_prob_sum * v).mean()
+    grad = ((s / p - (1 - s) / (1 - p)) * v[:, None]).mean(axis=0)
+    return objective, grad

@@ -17,6 +17,7 @@
 // (the library is built with -ffp-contract=off).
 #include "rls_cutcount.h"
 #include "rls_ring.h"
+#include <type_traits>
 
 namespace rls {
 
@@ -60,6 +61,45 @@ __device__ __forceinline__ void tile_store_nodemajor(T* __restrict__ x, int64_t 
     const int half = lane >> 5, sh = lane & 31;
 #pragma unroll 8
     for (int64_t n = w; n < N; n += W) x[n * C + c] = (T)((w32[(n << 1) + half] >> sh) & 1u);
+}
+
+// ---- bit-packed chains ("spin_bytes = 0"): tile-major uint64 [ceil(C / 64), N]; word (t, n) holds node n of the chains
+// 64 t .. 64 t + 63 (bit e = chain 64 t + e).  A 64-chain tile is N CONSECUTIVE words: the LDS tile is a straight
+// copy (16-byte lanes), 1/32 of the f32 node-major surface's bytes.  tiles_in < tiles broadcasts: tile t reads
+// tile t % tiles_in (the reference's  xs_bool = temp_max_info.repeat(1, repeat_times)  without materialising it).
+struct Packed64 {};
+template <typename T> struct ChainStore { using type = T; };
+template <> struct ChainStore<Packed64> { using type = uint64_t; };
+
+__device__ __forceinline__ void tile_load_packed(const uint64_t* __restrict__ x, int64_t N, int64_t C, int64_t tile,
+                                                 int64_t tiles_in, uint64_t* __restrict__ words, int tid, int nthreads) {
+    const uint64_t* src = x + (tile % tiles_in) * N;
+    const int64_t left = C - tile * kWave;
+    const uint64_t live = left >= kWave ? ~0ull : ((1ull << left) - 1ull);   // chains past C read as 0
+    if ((N & 1) == 0 && (((uintptr_t)src) & 15) == 0) {
+        typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+        const u64x2* s2 = reinterpret_cast<const u64x2*>(src);
+        u64x2* d2 = reinterpret_cast<u64x2*>(words);
+        const u64x2 m{live, live};
+#pragma unroll 4
+        for (int64_t i = tid; i < N / 2; i += nthreads) d2[i] = s2[i] & m;
+    } else {
+        for (int64_t i = tid; i < N; i += nthreads) words[i] = src[i] & live;
+    }
+}
+
+__device__ __forceinline__ void tile_store_packed(uint64_t* __restrict__ x, int64_t N, int64_t tile,
+                                                  const uint64_t* __restrict__ words, int tid, int nthreads) {
+    uint64_t* dst = x + tile * N;
+    if ((N & 1) == 0 && (((uintptr_t)dst) & 15) == 0) {
+        typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+        const u64x2* s2 = reinterpret_cast<const u64x2*>(words);
+        u64x2* d2 = reinterpret_cast<u64x2*>(dst);
+#pragma unroll 4
+        for (int64_t i = tid; i < N / 2; i += nthreads) d2[i] = s2[i];
+    } else {
+        for (int64_t i = tid; i < N; i += nthreads) dst[i] = words[i];
+    }
 }
 
 // ------------------------------------------------------------------------------------- K9
@@ -138,6 +178,92 @@ __global__ __launch_bounds__(kMetroWaves * kWave) void k_mcpg_metro(T* samples, 
             if (acc_cnt[t]) atomicAdd(&accepts[t], (unsigned long long)acc_cnt[t]);
     }
     if (write_back) tile_store_nodemajor<T>(samples, N, C, c0, words, lane, w, kMetroWaves);
+}
+
+// K9 on bit-packed chains.  One wave per 64-chain tile and the tile (N * 8 bytes) is the ONLY LDS, so two tiles are
+// resident per CU at N = 10^4 where the f32 kernel above fits one; there is no tile transposition and the tile moves
+// as a straight 16-byte-lane copy.  probs are gathered from global memory a batch of rounds AHEAD (the drawn node does
+// not depend on the chain state, so the loads of batch k + 1 fly while batch k walks); per-round accept counts ride
+// in registers (lane t % 64 keeps round t's count) and leave as one coalesced atomic per 64 rounds.  Same draws as the
+// f32 kernel for the same seed.
+constexpr int kMetroBatch = 8;
+
+__global__ __launch_bounds__(kWave) void k_mcpg_metro_packed(uint64_t* __restrict__ samples,
+                                                             const uint64_t* __restrict__ samples_in, int64_t tiles_in,
+                                                             int64_t N, int64_t C, const float* __restrict__ probs,
+                                                             int64_t T_rounds, const int64_t* __restrict__ index,
+                                                             const float* __restrict__ u, uint64_t seed,
+                                                             const int64_t* __restrict__ t_limit_dev, int write_back,
+                                                             unsigned long long* __restrict__ accepts, int64_t t_offset) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* words = reinterpret_cast<uint64_t*>(smem);
+    const int lane = threadIdx.x;
+    const int64_t tile = blockIdx.x;
+    const int64_t c = tile * kWave + lane;
+    const bool valid = c < C;
+    const bool in_place = (samples_in == samples) && tiles_in == (int64_t)gridDim.x;
+    int64_t t_end = T_rounds;
+    if (t_limit_dev) {
+        const int64_t lim = *t_limit_dev;
+        t_end = lim < T_rounds ? (lim > 0 ? lim : 0) : T_rounds;
+    }
+    if (t_end == 0 && in_place) return;           // stop rule already met and nothing to move
+    tile_load_packed(samples_in, N, C, tile, tiles_in, words, lane, kWave);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t chain_key = k7_fmix32((uint32_t)seed ^ k7_fmix32((uint32_t)(seed >> 32) ^ k7_fmix32((uint32_t)c) ^
+                                                                    ((uint32_t)((uint64_t)c >> 32) * 0x9E3779B1u)));
+    const uint64_t mybit = 1ull << lane;
+    auto fetch = [&](int64_t t, int64_t& i, float& uu, float& p) {
+        i = 0;
+        uu = 2.0f;
+        if (valid && t < t_end) {
+            if (index) {
+                i = index[(t_offset + t) * C + c];
+                uu = u[(t_offset + t) * C + c];
+            } else {
+                const uint32_t k = chain_key ^ ((uint32_t)(t_offset + t) * 0x9E3779B1u);
+                const uint32_t r0 = k7_fmix32(k ^ 0x4D455452u), r1 = k7_fmix32(k + 0x7FEB352Du);
+                i = (int64_t)(((uint64_t)r0 * (uint64_t)N) >> 32);
+                uu = u32_to_unit_float(r1);
+            }
+        }
+        p = probs[i];
+    };
+    int64_t ci[kMetroBatch], ni[kMetroBatch];
+    float cu[kMetroBatch], cp[kMetroBatch], nu[kMetroBatch], np_[kMetroBatch];
+#pragma unroll
+    for (int q = 0; q < kMetroBatch; ++q) fetch(q, ci[q], cu[q], cp[q]);
+    uint32_t mycnt = 0;
+    for (int64_t t0 = 0; t0 < t_end; t0 += kMetroBatch) {
+#pragma unroll
+        for (int q = 0; q < kMetroBatch; ++q) fetch(t0 + kMetroBatch + q, ni[q], nu[q], np_[q]);   // next batch in flight
+#pragma unroll
+        for (int q = 0; q < kMetroBatch; ++q) {
+            const int64_t t = t0 + q;
+            const bool val = (words[ci[q]] >> lane) & 1ull;
+            const float chosen = val ? cp[q] : 1.0f - cp[q];               // torch.where(chosen_value, p, 1 - p)
+            const float accept_rate = (1.0f - chosen) / chosen;            // MCPG.py:107
+            const bool acc = cu[q] < accept_rate;                          // idle lanes / rounds carry u = 2
+            // one wave, and the LDS executes a wave's operations in issue order: this round's reads precede its
+            // flips, and the flips precede the next round's reads
+            if (acc) atomicXor(reinterpret_cast<unsigned long long*>(&words[ci[q]]), (unsigned long long)mybit);
+            if (accepts) {
+                const uint32_t cnt = (uint32_t)__popcll(ballot64(acc));
+                if (lane == (int)(t & 63)) mycnt = cnt;
+                if ((t & 63) == 63 || t + 1 >= t_end) {                    // uniform: flush the window's counts
+                    const int64_t tw = t & ~(int64_t)63;
+                    if (tw + lane <= t && mycnt) atomicAdd(&accepts[tw + lane], (unsigned long long)mycnt);
+                    mycnt = 0;
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < kMetroBatch; ++q) { ci[q] = ni[q]; cu[q] = nu[q]; cp[q] = np_[q]; }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if (write_back) tile_store_packed(samples, N, tile, words, lane, kWave);
 }
 
 // ------------------------------------------------------------------------------------- K7 + K8
@@ -337,7 +463,8 @@ __global__ __launch_bounds__(kK7Waves * kWave) void k_mcpg_local_search_stream(
 // (pass 0: visited and not-yet-visited neighbours counted apart, C = cV + 2 cF), a bit-sliced compare with the
 // per-node constant K and  new word = [C < K] | ([C == K] & tie & coin).  Nodes of degree > 64 get a group of
 // their own and the lanes share the NEIGHBOURS instead (per-lane counters, then transpose + popcount per plane).
-constexpr int kLvWaves = 16;
+constexpr int kLvWaves = 16;      // f32 / uint8 node-major surface: 16 waves mostly to move the tile
+constexpr int kLvWavesPacked = 8; // bit-packed chains: the tile is a straight copy; 8 waves, two workgroups per CU at N = 10^4
 
 template <int NP>
 __device__ __forceinline__ void lv_cmp(const uint64_t (&pl)[9], uint32_t K, uint64_t& lt, uint64_t& eq) {
@@ -418,18 +545,18 @@ __device__ __forceinline__ void lv_hub_counts(const uint64_t* words, const int32
     }
 }
 
-template <typename TI, int P>
-__global__ __launch_bounds__(kLvWaves * kWave) void k_mcpg_local_search_levels(
-    const TI* __restrict__ xs_in, float* __restrict__ xs_out, int64_t N, int64_t C,
-    const int32_t* __restrict__ lv_ptr, const int32_t* __restrict__ data, int64_t G, int64_t num_ls,
-    const uint64_t* __restrict__ coins, uint64_t seed, const int32_t* __restrict__ eu, const int32_t* __restrict__ ev,
-    int64_t E, float* __restrict__ expected) {
-    constexpr int W = kLvWaves;
+// LDS: the bit tile (N + 2 words) and 64 int32 slots for the cut reduction -- nothing else, so that two workgroups fit a
+// CU at N = 10^4 (2 x 80 272 B); the group offsets lv_ptr[] are wave-uniform and come through the scalar cache.
+template <typename TI, typename TO, int P, int W>
+__global__ __launch_bounds__(W * kWave) void k_mcpg_local_search_levels(
+    const typename ChainStore<TI>::type* __restrict__ xs_in, typename ChainStore<TO>::type* __restrict__ xs_out, int64_t N,
+    int64_t C, int64_t tiles_in, const int32_t* __restrict__ lv_ptr, const int32_t* __restrict__ data, int64_t G,
+    int64_t num_ls, const uint64_t* __restrict__ coins, uint64_t seed, const int32_t* __restrict__ eu,
+    const int32_t* __restrict__ ev, int64_t E, float* __restrict__ expected) {
     constexpr uint32_t M30 = 0x3fffffffu, M31 = 0x7fffffffu;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* words = reinterpret_cast<uint64_t*>(smem);
-    int32_t* lvp = reinterpret_cast<int32_t*>(smem + (size_t)(N + 2) * 8);
-    int64_t* scratch = reinterpret_cast<int64_t*>(smem + (size_t)(N + 2) * 8 + (((size_t)(G + 1) * 4 + 15) & ~(size_t)15));
+    int* cut_slots = reinterpret_cast<int*>(smem + (size_t)(N + 2) * 8);          // [64]
     const uint32_t* w32 = reinterpret_cast<const uint32_t*>(smem);
     const int lane = threadIdx.x & (kWave - 1);
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
@@ -438,12 +565,15 @@ __global__ __launch_bounds__(kLvWaves * kWave) void k_mcpg_local_search_levels(
     const bool valid = c < C;
     const int64_t CB = (C + kWave - 1) / kWave;               // 64-chain blocks = words per coins row
     if (threadIdx.x == 0) words[N] = 0;                       // padding / idle lanes point here
-    for (int64_t i = threadIdx.x; i <= G; i += W * kWave) lvp[i] = lv_ptr[i];
-    tile_load_bits_nodemajor<TI>(xs_in, N, C, c0, words, lane, w, W);
+    if (threadIdx.x < kWave) cut_slots[threadIdx.x] = 0;
+    if constexpr (std::is_same<TI, Packed64>::value) tile_load_packed(xs_in, N, C, blockIdx.x, tiles_in, words, threadIdx.x, W * kWave);
+    else tile_load_bits_nodemajor<TI>(xs_in, N, C, c0, words, lane, w, W);
     const uint32_t blk_key = k7_fmix32((uint32_t)seed ^ k7_fmix32((uint32_t)(seed >> 32) ^
                                                                   k7_fmix32((uint32_t)blockIdx.x * 0x9E3779B1u + 0x632BE5ABu)));
     const BitXpose xc = bit_xpose_consts(lane);
-    __syncthreads();   // lvp and the tile are complete before any wave prefetches its first group
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // the tile is complete before any wave reads a neighbour word
+    auto lvp = [&](int64_t k) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane(lv_ptr[k]); };
     auto coin_word = [&](int64_t cnt, uint32_t pos) -> uint64_t {   // bit e: "u < 1/2" for chain c0 + e at (pass, pos)
         if (coins) return coins[((int64_t)cnt * N + pos) * CB + blockIdx.x];
         const uint32_t k = blk_key ^ (pos * 0x9E3779B1u) ^ ((uint32_t)cnt * 0x7FEB352Du + 0x165667B1u);
@@ -455,7 +585,7 @@ __global__ __launch_bounds__(kLvWaves * kWave) void k_mcpg_local_search_levels(
         uint32_t h0 = (uint32_t)N, h1 = (uint32_t)N, e0[8];
         auto prefetch = [&](int64_t k) {
             if (k < G) {
-                const int64_t p0 = (uint32_t)lvp[k] & M30, p1 = (uint32_t)lvp[k + 1] & M30;
+                const int64_t p0 = lvp(k) & M30, p1 = lvp(k + 1) & M30;
                 h0 = (uint32_t)data[p0 + lane];
                 h1 = (uint32_t)data[p0 + kWave + lane];
 #pragma unroll
@@ -467,10 +597,10 @@ __global__ __launch_bounds__(kLvWaves * kWave) void k_mcpg_local_search_levels(
         };
         prefetch(mine);
         for (int64_t k = 0; k < G; ++k) {
-            const uint32_t flags = (uint32_t)lvp[k];
+            const uint32_t flags = lvp(k);
             if (flags >> 31) __syncthreads();                 // new level (k = 0: new pass): earlier updates are visible
             if (k != mine) continue;
-            const int64_t p0 = flags & M30, p1 = (uint32_t)lvp[k + 1] & M30;
+            const int64_t p0 = flags & M30, p1 = lvp(k + 1) & M30;
             const int rounds = (int)((p1 - p0) >> 6) - 2;
             if (!((flags >> 30) & 1u)) {
                 // ---- 64 nodes, lane = node
@@ -543,12 +673,18 @@ __global__ __launch_bounds__(kLvWaves * kWave) void k_mcpg_local_search_levels(
         }
     }
     __syncthreads();
-    // K8: expected[c] = sum_e (2x_u - 1)(2x_v - 1) = E - 2 * cut
-    const int64_t cut = block_sum_partials<W>(tile_cut_count<P>(words, eu, ev, E, lane, w, W), scratch, lane, w);
-    if (valid) {
-        if (w == 0) expected[c] = (float)(E - 2 * cut);
-        const int half = lane >> 5, sh = lane & 31;
-        for (int64_t n = w; n < N; n += W) xs_out[n * C + c] = (float)((w32[(n << 1) + half] >> sh) & 1u);
+    // K8: expected[c] = sum_e (2x_u - 1)(2x_v - 1) = E - 2 * cut; the W partial counts meet in 64 LDS slots
+    const int part = (int)tile_cut_count<P>(words, eu, ev, E, lane, w, W);
+    atomicAdd(&cut_slots[lane], part);
+    __syncthreads();
+    if (valid && w == 0) expected[c] = (float)(E - 2 * (int64_t)cut_slots[lane]);
+    if constexpr (std::is_same<TO, Packed64>::value) {
+        tile_store_packed(xs_out, N, blockIdx.x, words, threadIdx.x, W * kWave);
+    } else {
+        if (valid) {
+            const int half = lane >> 5, sh = lane & 31;
+            for (int64_t n = w; n < N; n += W) xs_out[n * C + c] = (float)((w32[(n << 1) + half] >> sh) & 1u);
+        }
     }
 }
 
@@ -576,13 +712,153 @@ __global__ void k_mcpg_pick_gather(const float* __restrict__ xs, int64_t N, int6
     }
 }
 
+// best-of-repeats gather on bit-packed chains: kept tile j, node n: bit e = node n of chain best_index[64 j + e].
+// lane = node; for each of the 64 kept chains one coalesced read of 64 consecutive words of the winner's tile.
+__global__ __launch_bounds__(256) void k_mcpg_pick_gather_packed(const uint64_t* __restrict__ xs, int64_t N, int64_t M,
+                                                                 const int64_t* __restrict__ best_index,
+                                                                 uint64_t* __restrict__ xs_good) {
+    const int64_t j = blockIdx.y;
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ int64_t src[kWave];
+    if (threadIdx.x < kWave) {
+        const int64_t m = j * kWave + threadIdx.x;
+        src[threadIdx.x] = m < M ? best_index[m] : -1;
+    }
+    __syncthreads();
+    if (n >= N) return;
+    uint64_t out = 0;
+#pragma unroll 8
+    for (int e = 0; e < kWave; ++e) {
+        const int64_t bi = src[e];
+        if (bi < 0) break;
+        out |= ((xs[(bi >> 6) * N + n] >> (bi & 63)) & 1ull) << e;
+    }
+    xs_good[j * N + n] = out;
+}
+
+// Best-merge of the MCPG outer loop, methods/MCPG.py:376-391, on bit-packed kept chains (M = total_mcmc_num):
+//   (a) per chain m: if temp_max[m] > now_max_res[m] the incumbent takes the value and the chain     (:377-380)
+//   (b) the globally best incumbent (first argmax) overwrites the worst (first argmin): value, incumbent
+//       column and the column of temp_max_info that seeds the next round                              (:383-391)
+// k_mcpg_merge_mask does (a) on the values and leaves one mask word per 64 chains; k_mcpg_merge_apply moves the bits;
+// k_mcpg_merge_minmax does (b) in one workgroup.
+__global__ void k_mcpg_merge_mask(const float* __restrict__ temp_max, float* __restrict__ now_max_res, int64_t M,
+                                  uint64_t* __restrict__ mask) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in = m < M;
+    const float t = in ? temp_max[m] : 0.0f, r = in ? now_max_res[m] : 0.0f;
+    const bool take = in && t > r;
+    if (take) now_max_res[m] = t;
+    const uint64_t w = ballot64(take);
+    if ((threadIdx.x & 63) == 0 && m < M + 63) mask[m >> 6] = w;
+}
+
+__global__ void k_mcpg_merge_apply(const uint64_t* __restrict__ temp_info, uint64_t* __restrict__ now_info, int64_t N,
+                                   int64_t tiles, const uint64_t* __restrict__ mask) {
+    const int64_t total = tiles * N;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t mk = mask[t / N];
+        if (mk) now_info[t] = (now_info[t] & ~mk) | (temp_info[t] & mk);
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_mcpg_merge_minmax(float* __restrict__ now_max_res, int64_t M, int64_t N,
+                                                            uint64_t* __restrict__ now_info, uint64_t* __restrict__ temp_info,
+                                                            float* __restrict__ best_value, int64_t* __restrict__ best_index) {
+    __shared__ float s_hi[16], s_lo[16];
+    __shared__ int64_t s_hii[16], s_loi[16];
+    float hi = -INFINITY, lo = INFINITY;
+    int64_t hii = INT64_MAX, loi = INT64_MAX;
+    for (int64_t m = threadIdx.x; m < M; m += blockDim.x) {
+        const float v = now_max_res[m];
+        if (v > hi) { hi = v; hii = m; }
+        if (v < lo) { lo = v; loi = m; }
+    }
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        const float oh = __shfl_xor(hi, s, 64), ol = __shfl_xor(lo, s, 64);
+        const int64_t ohi = __shfl_xor(hii, s, 64), oli = __shfl_xor(loi, s, 64);
+        if (oh > hi || (oh == hi && ohi < hii)) { hi = oh; hii = ohi; }
+        if (ol < lo || (ol == lo && oli < loi)) { lo = ol; loi = oli; }
+    }
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_hi[wv] = hi; s_hii[wv] = hii; s_lo[wv] = lo; s_loi[wv] = loi; }
+    __syncthreads();
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) {
+        if (s_hi[k] > hi || (s_hi[k] == hi && s_hii[k] < hii)) { hi = s_hi[k]; hii = s_hii[k]; }
+        if (s_lo[k] < lo || (s_lo[k] == lo && s_loi[k] < loi)) { lo = s_lo[k]; loi = s_loi[k]; }
+    }
+    if (threadIdx.x == 0) {
+        now_max_res[loi] = hi;                                                  // :388
+        if (best_value) best_value[0] = hi;
+        if (best_index) best_index[0] = hii;
+    }
+    const uint64_t* srcw = now_info + (hii >> 6) * N;
+    uint64_t* d0 = now_info + (loi >> 6) * N;
+    uint64_t* d1 = temp_info + (loi >> 6) * N;
+    const int sb = (int)(hii & 63), db = (int)(loi & 63);
+    if (hii == loi) return;
+    for (int64_t n = threadIdx.x; n < N; n += blockDim.x) {
+        const uint64_t bit = (srcw[n] >> sb) & 1ull;                            // read before either write: d0 may alias srcw's tile
+        const uint64_t a = d0[n], b = d1[n];
+        d0[n] = (a & ~(1ull << db)) | (bit << db);                              // :389
+        d1[n] = (b & ~(1ull << db)) | (bit << db);                              // :390
+    }
+}
+
+// get_return, methods/MCPG.py:292-302, reduced to what it needs: with s in {0,1},
+//   sum_n log(s p + (1 - s)(1 - p)) = sum_n log(1 - p_n) + sum_n s_n (log p_n - log(1 - p_n)),
+// so the objective mean_b(log_prob_sum_b * value_b) and its gradient need only  A_n = sum_b value_b s_bn  and
+// V = sum_b value_b.  One workgroup per (64-chain tile, 256-node slab): lane = node, the tile's 64 values broadcast
+// from LDS, float atomics into A[N] (zeroed by the caller).
+__global__ __launch_bounds__(256) void k_mcpg_value_bit_sums(const uint64_t* __restrict__ samples, int64_t N, int64_t C,
+                                                             const float* __restrict__ value, float* __restrict__ A) {
+    __shared__ float v[kWave];
+    const int64_t tile = blockIdx.y;
+    if (threadIdx.x < kWave) {
+        const int64_t c = tile * kWave + threadIdx.x;
+        v[threadIdx.x] = c < C ? value[c] : 0.0f;
+    }
+    __syncthreads();
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const uint64_t wd = samples[tile * N + n];
+    float acc = 0.0f;
+#pragma unroll 16
+    for (int e = 0; e < kWave; ++e) acc += ((wd >> e) & 1ull) ? v[e] : 0.0f;
+    if (acc != 0.0f) atomicAdd(&A[n], acc);
+}
+
+// bit-packed tiles <-> the reference's node-major f32 [N, C] surface (shims for callers that want it)
+__global__ __launch_bounds__(256) void k_mcpg_unpack(const uint64_t* __restrict__ packed, int64_t N, int64_t C, float* __restrict__ xs) {
+    const int64_t total = N * C;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t n = t / C, c = t - n * C;
+        xs[t] = (float)((packed[(c >> 6) * N + n] >> (c & 63)) & 1ull);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kWave) void k_mcpg_pack(const T* __restrict__ xs, int64_t N, int64_t C, uint64_t* __restrict__ packed) {
+    const int lane = threadIdx.x;
+    const int64_t tile = blockIdx.y;
+    const int64_t c = tile * kWave + lane;
+    const int64_t n0 = (int64_t)blockIdx.x * kWave;
+    uint64_t mine = 0;
+    for (int k = 0; k < kWave && n0 + k < N; ++k) {
+        const uint64_t w = ballot64(c < C && spin_is_set(xs[(n0 + k) * C + c]));
+        if (lane == k) mine = w;
+    }
+    if (n0 + lane < N) packed[tile * N + n0 + lane] = mine;
+}
+
 }  // namespace rls
 
 using namespace rls;
 
 extern "C" {
 
-int rls_mcpg_metro_rounds(void* samples, const void* samples_in, int spin_bytes, int64_t N, int64_t C,
+int rls_mcpg_metro_rounds(void* samples, const void* samples_in, int64_t C_in, int spin_bytes, int64_t N, int64_t C,
                           const float* probs, int64_t T, int64_t t_offset, const int64_t* index, const float* u,
                           uint64_t seed, const int64_t* t_limit_dev, int write_back, int64_t* accepts, void* stream) {
     RLS_REQUIRE(N > 0 && C >= 0 && T >= 0 && t_offset >= 0, RLS_EINVAL, "bad sizes N=%lld C=%lld T=%lld", (long long)N, (long long)C,
@@ -590,9 +866,24 @@ int rls_mcpg_metro_rounds(void* samples, const void* samples_in, int spin_bytes,
     if (C == 0) return RLS_OK;
     RLS_REQUIRE(samples && probs, RLS_EINVAL, "samples/probs is NULL");
     RLS_REQUIRE((index == nullptr) == (u == nullptr), RLS_EINVAL, "index and u must both be given or both be NULL");
-    RLS_REQUIRE(spin_bytes == 1 || spin_bytes == 4, RLS_EINVAL, "spin_bytes must be 1 or 4");
-    if (!samples_in) samples_in = samples;
+    RLS_REQUIRE(spin_bytes == 0 || spin_bytes == 1 || spin_bytes == 4, RLS_EINVAL, "spin_bytes must be 0 (bit-packed), 1 or 4");
+    if (!samples_in) { samples_in = samples; C_in = C; }
+    if (C_in <= 0) C_in = C;
     RLS_REQUIRE(samples_in == samples || write_back, RLS_EINVAL, "samples_in != samples needs write_back");
+    if (spin_bytes == 0) {
+        RLS_REQUIRE(C_in == C || (C_in % kWave == 0 && C_in < C && write_back), RLS_EINVAL,
+                    "broadcast start state: C_in=%lld must be a multiple of 64 below C (and write_back set)", (long long)C_in);
+        RLS_REQUIRE(samples_in != samples || C_in == C, RLS_EINVAL, "a broadcast start state cannot be updated in place");
+        const size_t lds = (size_t)N * 8;
+        RLS_REQUIRE(lds <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS (max %d)", (long long)N, lds, kLdsBytes);
+        if (lds > 64 * 1024)
+            (void)hipFuncSetAttribute((const void*)k_mcpg_metro_packed, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(k_mcpg_metro_packed, dim3((unsigned)ceil_div(C, kWave)), dim3(kWave), lds, as_stream(stream),
+                           (uint64_t*)samples, (const uint64_t*)samples_in, ceil_div(C_in, kWave), N, C, probs, T, index, u, seed,
+                           t_limit_dev, write_back, (unsigned long long*)accepts, t_offset);
+        return check_launch("k_mcpg_metro_packed");
+    }
+    RLS_REQUIRE(C_in == C, RLS_EINVAL, "a broadcast start state (C_in != C) needs the bit-packed layout");
     const size_t lds_base = (size_t)N * 8 + (accepts ? (size_t)T * 4 : 0) + 16;
     const bool probs_lds = lds_base + (size_t)N * 4 <= (size_t)kLdsBytes;
     const size_t lds = lds_base + (probs_lds ? (size_t)N * 4 : 0);
@@ -614,51 +905,68 @@ int rls_mcpg_metro_rounds(void* samples, const void* samples_in, int spin_bytes,
     return check_launch("k_mcpg_metro");
 }
 
-static size_t lv_lds_bytes(int64_t N, int64_t num_groups) {
-    return (size_t)(N + 2) * 8 + (((size_t)(num_groups + 1) * 4 + 15) & ~(size_t)15) + (size_t)kLvWaves * kWave * 8;
-}
+static size_t lv_lds_bytes(int64_t N) { return (size_t)(N + 2) * 8 + (size_t)kWave * 4; }
 
 int rls_mcpg_local_search_levels_supported(const rls_graph* g, int64_t num_groups) {
     if (!g || g->num_nodes <= 0 || num_groups <= 0) return 0;
     if (g->num_nodes >= (1 << 20) || g->max_degree >= 1024 || g->wgt) return 0;
     if (pick_planes(g->num_stored_edges) == 0) return 0;
-    return lv_lds_bytes(g->num_nodes, num_groups) <= (size_t)kLdsBytes;
+    return lv_lds_bytes(g->num_nodes) <= (size_t)kLdsBytes;
 }
 
-int rls_mcpg_local_search_levels(const rls_graph* g, const void* xs_in, int spin_bytes, float* xs_out, int64_t C,
-                                 const int32_t* lv_ptr, const int32_t* lv_data, int64_t num_groups, int64_t num_ls,
-                                 const uint64_t* coins, uint64_t seed, float* expected, void* stream) {
+int rls_mcpg_local_search_levels(const rls_graph* g, const void* xs_in, int spin_bytes, int64_t C_in, void* xs_out,
+                                 int out_spin_bytes, int64_t C, const int32_t* lv_ptr, const int32_t* lv_data,
+                                 int64_t num_groups, int64_t num_ls, const uint64_t* coins, uint64_t seed, float* expected,
+                                 void* stream) {
     if (int rc = check_graph(g)) return rc;
     RLS_REQUIRE(C >= 0 && num_ls >= 0 && num_groups > 0, RLS_EINVAL, "bad sizes");
     if (C == 0) return RLS_OK;
     RLS_REQUIRE(xs_in && xs_out && lv_ptr && lv_data && expected, RLS_EINVAL, "NULL pointer");
-    RLS_REQUIRE(spin_bytes == 1 || spin_bytes == 4, RLS_EINVAL, "spin_bytes must be 1 or 4");
+    RLS_REQUIRE(spin_bytes == 0 || spin_bytes == 1 || spin_bytes == 4, RLS_EINVAL, "spin_bytes must be 0 (bit-packed), 1 or 4");
+    RLS_REQUIRE(out_spin_bytes == 0 || out_spin_bytes == 4, RLS_EINVAL, "out_spin_bytes must be 0 (bit-packed) or 4 (float32)");
+    if (C_in <= 0) C_in = C;
+    RLS_REQUIRE(C_in == C || (spin_bytes == 0 && C_in % kWave == 0 && C_in < C), RLS_EINVAL,
+                "broadcast input (C_in != C) needs the bit-packed layout and C_in a multiple of 64");
+    RLS_REQUIRE(xs_in != xs_out || (spin_bytes == 0 && out_spin_bytes == 0 && C_in == C), RLS_EINVAL,
+                "in-place local search needs the bit-packed layout on both sides");
     const int64_t N = g->num_nodes, E = g->num_stored_edges;
     RLS_REQUIRE(N < (1 << 20) && g->max_degree < 1024 && !g->wgt, RLS_EUNSUPPORTED,
                 "level-parallel K7 needs an unweighted graph, N < 2^20, degrees < 1024");
     const int P = pick_planes(E);
     RLS_REQUIRE(P != 0, RLS_EUNSUPPORTED, "E=%lld too large", (long long)E);
-    const size_t lds = lv_lds_bytes(N, num_groups);
+    const size_t lds = lv_lds_bytes(N);
     RLS_REQUIRE(lds <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS (max %d)", (long long)N, lds,
                 kLdsBytes);
-    const dim3 grid((unsigned)ceil_div(C, kWave)), block(kLvWaves * kWave);
+    const int64_t tiles_in = ceil_div(C_in, kWave);
+    const dim3 grid((unsigned)ceil_div(C, kWave));
     hipStream_t s = as_stream(stream);
-#define LAUNCH_LVL(TI, PP)                                                                                      \
+    static const int force_w = getenv("RLS_K7_WAVES") ? atoi(getenv("RLS_K7_WAVES")) : 0;   // dev knob
+#define LAUNCH_LVL(TI, TO, PP, WW)                                                                              \
     do {                                                                                                        \
-        auto kern = k_mcpg_local_search_levels<TI, PP>;                                                         \
+        auto kern = k_mcpg_local_search_levels<TI, TO, PP, WW>;                                                 \
         if (lds > 64 * 1024)                                                                                    \
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL(kern, grid, block, lds, s, (const TI*)xs_in, xs_out, N, C, lv_ptr, lv_data, num_groups, \
+        hipLaunchKernelGGL(kern, grid, dim3(WW * kWave), lds, s, (const typename ChainStore<TI>::type*)xs_in,   \
+                           (typename ChainStore<TO>::type*)xs_out, N, C, tiles_in, lv_ptr, lv_data, num_groups,  \
                            num_ls, coins, seed, g->eu, g->ev, E, expected);                                      \
     } while (0)
-#define DISPATCH_LVL(TI)                      \
-    switch (P) {                              \
-        case 12: LAUNCH_LVL(TI, 12); break;   \
-        case 16: LAUNCH_LVL(TI, 16); break;   \
-        case 20: LAUNCH_LVL(TI, 20); break;   \
-        default: LAUNCH_LVL(TI, 24); break;   \
+#define DISPATCH_LVL(TI, TO, WW)                      \
+    switch (P) {                                      \
+        case 12: LAUNCH_LVL(TI, TO, 12, WW); break;   \
+        case 16: LAUNCH_LVL(TI, TO, 16, WW); break;   \
+        case 20: LAUNCH_LVL(TI, TO, 20, WW); break;   \
+        default: LAUNCH_LVL(TI, TO, 24, WW); break;   \
     }
-    if (spin_bytes == 1) { DISPATCH_LVL(uint8_t) } else { DISPATCH_LVL(float) }
+    if (spin_bytes == 0 && out_spin_bytes == 0) {
+        const int ww = force_w ? force_w : kLvWavesPacked;
+        if (ww == 4) { DISPATCH_LVL(Packed64, Packed64, 4) }
+        else if (ww == 16) { DISPATCH_LVL(Packed64, Packed64, 16) }
+        else { DISPATCH_LVL(Packed64, Packed64, kLvWavesPacked) }
+    } else if (spin_bytes == 0) { DISPATCH_LVL(Packed64, float, kLvWaves) }
+    else if (spin_bytes == 1 && out_spin_bytes == 4) { DISPATCH_LVL(uint8_t, float, kLvWaves) }
+    else if (spin_bytes == 4 && out_spin_bytes == 4) { DISPATCH_LVL(float, float, kLvWaves) }
+    else if (spin_bytes == 1) { DISPATCH_LVL(uint8_t, Packed64, kLvWaves) }
+    else { DISPATCH_LVL(float, Packed64, kLvWaves) }
 #undef DISPATCH_LVL
 #undef LAUNCH_LVL
     return check_launch("k_mcpg_local_search_levels");
@@ -730,17 +1038,65 @@ int rls_mcpg_local_search(const rls_graph* g, const void* xs_in, int spin_bytes,
     return check_launch("k_mcpg_local_search");
 }
 
-int rls_mcpg_pick_best(const float* expected, const float* xs, int64_t N, int64_t total_mcmc_num,
+int rls_mcpg_pick_best(const float* expected, const void* xs, int spin_bytes, int64_t N, int64_t total_mcmc_num,
                        int64_t repeat_times, int64_t num_edges, int64_t* best_index, float* vs_good,
-                       float* xs_good, void* stream) {
+                       void* xs_good, void* stream) {
     RLS_REQUIRE(N > 0 && total_mcmc_num >= 0 && repeat_times > 0, RLS_EINVAL, "bad sizes");
     if (total_mcmc_num == 0) return RLS_OK;
     RLS_REQUIRE(expected && xs && best_index && vs_good && xs_good, RLS_EINVAL, "NULL pointer");
+    RLS_REQUIRE(spin_bytes == 0 || spin_bytes == 4, RLS_EINVAL, "spin_bytes must be 0 (bit-packed) or 4 (float32)");
     hipLaunchKernelGGL(k_mcpg_pick_argmin, dim3((unsigned)ceil_div(total_mcmc_num, 64)), dim3(64), 0,
                        as_stream(stream), expected, total_mcmc_num, repeat_times, (float)num_edges, best_index, vs_good);
-    hipLaunchKernelGGL(k_mcpg_pick_gather, dim3(grid_for(N * total_mcmc_num, 256)), dim3(256), 0, as_stream(stream), xs,
-                       N, total_mcmc_num, total_mcmc_num * repeat_times, best_index, xs_good);
+    if (spin_bytes == 0)
+        hipLaunchKernelGGL(k_mcpg_pick_gather_packed, dim3((unsigned)ceil_div(N, 256), (unsigned)ceil_div(total_mcmc_num, kWave)),
+                           dim3(256), 0, as_stream(stream), (const uint64_t*)xs, N, total_mcmc_num, best_index, (uint64_t*)xs_good);
+    else
+        hipLaunchKernelGGL(k_mcpg_pick_gather, dim3(grid_for(N * total_mcmc_num, 256)), dim3(256), 0, as_stream(stream),
+                           (const float*)xs, N, total_mcmc_num, total_mcmc_num * repeat_times, best_index, (float*)xs_good);
     return check_launch("k_mcpg_pick_best");
+}
+
+int rls_mcpg_merge_best(const float* temp_max, uint64_t* temp_info, float* now_max_res, uint64_t* now_info, int64_t N,
+                        int64_t total_mcmc_num, uint64_t* mask_scratch, float* best_value, int64_t* best_index, void* stream) {
+    RLS_REQUIRE(N > 0 && total_mcmc_num > 0, RLS_EINVAL, "bad sizes");
+    RLS_REQUIRE(temp_max && temp_info && now_max_res && now_info && mask_scratch, RLS_EINVAL, "NULL pointer");
+    const int64_t M = total_mcmc_num, tiles = ceil_div(M, kWave);
+    hipStream_t s = as_stream(stream);
+    hipLaunchKernelGGL(k_mcpg_merge_mask, dim3((unsigned)ceil_div(tiles * kWave, 256)), dim3(256), 0, s, temp_max, now_max_res, M,
+                       mask_scratch);
+    hipLaunchKernelGGL(k_mcpg_merge_apply, dim3(grid_for(tiles * N, 256)), dim3(256), 0, s, temp_info, now_info, N, tiles,
+                       mask_scratch);
+    hipLaunchKernelGGL(k_mcpg_merge_minmax, dim3(1), dim3(1024), 0, s, now_max_res, M, N, now_info, temp_info, best_value,
+                       best_index);
+    return check_launch("k_mcpg_merge_best");
+}
+
+int rls_mcpg_value_bit_sums(const uint64_t* samples, int64_t N, int64_t C, const float* value, float* A, void* stream) {
+    RLS_REQUIRE(N > 0 && C >= 0, RLS_EINVAL, "bad sizes");
+    if (C == 0) return RLS_OK;
+    RLS_REQUIRE(samples && value && A, RLS_EINVAL, "NULL pointer");
+    hipLaunchKernelGGL(k_mcpg_value_bit_sums, dim3((unsigned)ceil_div(N, 256), (unsigned)ceil_div(C, kWave)), dim3(256), 0,
+                       as_stream(stream), samples, N, C, value, A);
+    return check_launch("k_mcpg_value_bit_sums");
+}
+
+int rls_mcpg_pack_chains(const void* xs, int spin_bytes, int64_t N, int64_t C, uint64_t* packed, void* stream) {
+    RLS_REQUIRE(N > 0 && C >= 0, RLS_EINVAL, "bad sizes");
+    if (C == 0) return RLS_OK;
+    RLS_REQUIRE(xs && packed, RLS_EINVAL, "NULL pointer");
+    RLS_REQUIRE(spin_bytes == 1 || spin_bytes == 4, RLS_EINVAL, "spin_bytes must be 1 or 4");
+    const dim3 grid((unsigned)ceil_div(N, kWave), (unsigned)ceil_div(C, kWave));
+    if (spin_bytes == 1) hipLaunchKernelGGL(k_mcpg_pack<uint8_t>, grid, dim3(kWave), 0, as_stream(stream), (const uint8_t*)xs, N, C, packed);
+    else hipLaunchKernelGGL(k_mcpg_pack<float>, grid, dim3(kWave), 0, as_stream(stream), (const float*)xs, N, C, packed);
+    return check_launch("k_mcpg_pack");
+}
+
+int rls_mcpg_unpack_chains(const uint64_t* packed, int64_t N, int64_t C, float* xs, void* stream) {
+    RLS_REQUIRE(N > 0 && C >= 0, RLS_EINVAL, "bad sizes");
+    if (C == 0) return RLS_OK;
+    RLS_REQUIRE(xs && packed, RLS_EINVAL, "NULL pointer");
+    hipLaunchKernelGGL(k_mcpg_unpack, dim3(grid_for(N * C, 256)), dim3(256), 0, as_stream(stream), packed, N, C, xs);
+    return check_launch("k_mcpg_unpack");
 }
 
 }  // extern "C"

@@ -13,6 +13,7 @@ import numpy as np
 import torch
 
 from .. import _abi, ops, ops_mcpg_tsp as mops
+from ..ops_mcpg_tsp import PackedChains
 from ..graph import build_csr, read_edge_arrays
 
 TEN = torch.Tensor
@@ -140,28 +141,28 @@ def build_visit_stream(csr, order: np.ndarray, max_nodes: int = 32, max_entries:
     return (stream & 0xFFFFFFFF).astype(np.uint32).view(np.int32)
 
 
-def metro_sampling(probs: TEN, start_status: TEN, max_transfer_time: int, device=None,
-                   index: Optional[TEN] = None, u: Optional[TEN] = None) -> TEN:
-    """MCPG.py:88-117.  Up to 5*T proposal rounds per chain, stopping after the first round whose
-    cumulative accept count reaches C*T -- evaluated on the device (two kernel launches, no host
-    sync), where the reference syncs once per round.  ``index``/``u`` ([>=5T, C]) replace the
-    torch.randint / torch.rand draws (test hook)."""
-    device = start_status.device if device is None else torch.device(device)
-    start = start_status.to(device=device, dtype=torch.float32).contiguous()
-    # the first chunk reads the caller's start state and writes the result buffer: no copy of the [N, C] state
-    samples = torch.empty_like(start) if start.data_ptr() == start_status.data_ptr() else start
+def metro_sampling_packed(probs: TEN, start: PackedChains, max_transfer_time: int, num_chains: Optional[int] = None,
+                          index: Optional[TEN] = None, u: Optional[TEN] = None, out: Optional[PackedChains] = None) -> PackedChains:
+    """metro_sampling (MCPG.py:88-117) on bit-packed chains.  ``start`` may hold fewer chains than ``num_chains`` (a
+    multiple of 64): chain c starts from chain c % start.num_chains, the reference's ``xs_bool.repeat(1, repeat_times)``.
+    Up to 5*T proposal rounds per chain, stopping after the first round whose cumulative accept count reaches C*T --
+    evaluated on the device (no host sync), where the reference syncs once per round."""
+    device = start.device
+    Cc = start.num_chains if num_chains is None else num_chains
+    N = start.num_nodes
     probs = probs.detach().to(device=device, dtype=torch.float32).contiguous()
-    N, Cc = samples.shape
+    samples = out if out is not None else PackedChains.empty(N, Cc, device)
     Tmax = max_transfer_time * 5
     if index is not None:
         Tmax = min(Tmax, index.shape[0])
-    if Tmax <= 0:   # no rounds (N < 10 gives T = int(N / 10) = 0): the reference returns start_status.bool().float()
-        return start.clone() if samples is not start else start
     seed = _seed_from_torch() if index is None else 0
+    if Tmax <= 0:   # no rounds (N < 10 gives T = int(N / 10) = 0): the start state, broadcast
+        mops.mcpg_metro_rounds(samples, probs, 0, None, None, 0, None, True, None, samples_in=start)
+        return samples
     # Walk the rounds in chunks of T.  A round accepts at most C proposals, so the cumulative count cannot reach
     # C*T before the LAST round of the first chunk: that chunk is applied directly (one pass, counting as it
-    # goes).  Later chunks: dry pass -> accept counts -> stop round (on the device) -> apply.  Chunks after the
-    # stop round see a zero limit and return at once.
+    # goes, reading the caller's start state and writing the result buffer).  Later chunks: dry pass -> accept counts
+    # -> stop round (on the device) -> apply.  Chunks after the stop round see a zero limit and return at once.
     chunk = max(1, max_transfer_time)
     target = Cc * max_transfer_time
     cum_prev = torch.zeros((), dtype=torch.int64, device=device)
@@ -190,19 +191,171 @@ def metro_sampling(probs: TEN, start_status: TEN, max_transfer_time: int, device
     return samples
 
 
+def metro_sampling(probs: TEN, start_status: TEN, max_transfer_time: int, device=None,
+                   index: Optional[TEN] = None, u: Optional[TEN] = None) -> TEN:
+    """MCPG.py:88-117 with the reference's surface: start_status [N, C] (anything bool-able) -> float32 [N, C] of
+    0.0 | 1.0, the caller's tensor untouched.  The walk itself runs on bit-packed chains (one pack and one unpack
+    kernel around metro_sampling_packed).  ``index``/``u`` ([>=5T, C]) replace the torch.randint / torch.rand draws
+    (test hook)."""
+    device = start_status.device if device is None else torch.device(device)
+    start = start_status.to(device=device)
+    if start.dtype not in (torch.float32, torch.uint8, torch.bool):
+        start = start.to(torch.float32)
+    packed = PackedChains.pack(start.contiguous())
+    return metro_sampling_packed(probs, packed, max_transfer_time, index=index, u=u, out=packed).unpack()
+
+
+def _levels_ok(data) -> bool:
+    return getattr(data, '_lv_ptr', None) is not None and bool(
+        _abi.lib().rls_mcpg_local_search_levels_supported(data.graph.ref, data._lv_ptr.numel() - 1))
+
+
+def sampler_func_packed(data, xs: PackedChains, num_ls: int, total_mcmc_num: int, repeat_times: int,
+                        num_chains: Optional[int] = None, in_place: bool = True):
+    """sampler_func (MCPG.py:120-166) on bit-packed chains, production draws: level-parallel K7 (in place on ``xs``
+    unless told otherwise), expected cut, best of repeats.  Returns (vs_good f32 [M], xs_good PackedChains of M
+    chains, value f32 [C], xs after the local search)."""
+    if not _levels_ok(data):
+        raise _abi.RlsError("sampler_func_packed", -2, "the level-parallel K7 kernel does not cover this graph")
+    Cc = xs.num_chains if num_chains is None else num_chains
+    out = xs if (in_place and xs.num_chains == Cc) else PackedChains.empty(xs.num_nodes, Cc, xs.device)
+    xs_loc, expected = mops.mcpg_local_search_levels(data.graph, xs, data._lv_ptr, data._lv_data, num_ls, _seed_from_torch(),
+                                                     out=out, num_chains=Cc)
+    _, vs_good, xs_good = mops.mcpg_pick_best(expected, xs_loc, total_mcmc_num, repeat_times, data.num_edges)
+    return vs_good, xs_good, expected - expected.mean(), xs_loc
+
+
 def sampler_func(data, xs_sample: TEN, num_ls: int, total_mcmc_num: int, repeat_times: int, device=None,
                  uniforms: Optional[TEN] = None):
     """MCPG.py:120-166: node-sequential stochastic local search (K7), expected cut (K8), best of
     repeats.  ``uniforms`` f32 [num_ls, N, C] replaces torch.rand (test hook)."""
     xs_sample = xs_sample.contiguous()
-    seed = _seed_from_torch() if uniforms is None else 0
-    if uniforms is None and getattr(data, '_lv_ptr', None) is not None and _abi.lib().rls_mcpg_local_search_levels_supported(
-            data.graph.ref, data._lv_ptr.numel() - 1):
-        # production path: level-parallel kernel (the draws only ever decide ties, so it carries coins, not uniforms)
-        xs_loc, expected = mops.mcpg_local_search_levels(data.graph, xs_sample, data._lv_ptr, data._lv_data, num_ls, seed)
-    else:
-        xs_loc, expected = mops.mcpg_local_search(data.graph, xs_sample, data._order_i32, num_ls, uniforms, seed,
-                                                  visit_stream=getattr(data, '_visit_stream', None))
+    if uniforms is None and _levels_ok(data):
+        # production path: level-parallel kernel (the draws only ever decide ties, so it carries coins, not uniforms);
+        # the f32 [N, C] input is read once, everything after it is bit-packed, xs_good leaves as f32 [N, M]
+        out = PackedChains.empty(xs_sample.shape[0], xs_sample.shape[1], xs_sample.device)
+        xs_loc, expected = mops.mcpg_local_search_levels(data.graph, xs_sample, data._lv_ptr, data._lv_data, num_ls,
+                                                         _seed_from_torch(), out=out)
+        _, vs_good, xs_good = mops.mcpg_pick_best(expected, xs_loc, total_mcmc_num, repeat_times, data.num_edges)
+        return vs_good, xs_good.unpack(), expected - expected.mean()
+    xs_loc, expected = mops.mcpg_local_search(data.graph, xs_sample, data._order_i32, num_ls, uniforms,
+                                              0 if uniforms is not None else _seed_from_torch(),
+                                              visit_stream=getattr(data, '_visit_stream', None))
     _, vs_good, xs_good = mops.mcpg_pick_best(expected, xs_loc, total_mcmc_num, repeat_times, data.num_edges)
     value = expected - expected.mean()
     return vs_good, xs_good, value
+
+
+class _ReturnFn(torch.autograd.Function):
+    """get_return (MCPG.py:292-302) with the samples bit-packed: objective = mean_c(log_prob_sum_c * value_c) where
+    log_prob_sum_c = sum_n log(s p + (1 - s)(1 - p)).  Forward and backward need only A_n = sum_c value_c s_nc
+    (one kernel over the packed chains) and V = sum_c value_c."""
+
+    @staticmethod
+    def forward(ctx, probs, samples, value):
+        A = mops.mcpg_value_bit_sums(samples, value)
+        V = value.sum()
+        C = samples.num_chains
+        lp, l1p = probs.log(), (1 - probs).log()
+        ctx.save_for_backward(probs, A, V)
+        ctx.C = C
+        return (l1p.sum() * V + ((lp - l1p) * A).sum()) / C
+
+    @staticmethod
+    def backward(ctx, g):
+        probs, A, V = ctx.saved_tensors
+        return g * (A / probs - (V - A) / (1 - probs)) / ctx.C, None, None
+
+
+def get_return(probs: TEN, samples, value: TEN, total_mcmc_num: int = 0, repeat_times: int = 0):
+    """MCPG.py:292-302.  ``samples``: PackedChains (the metro output of the round), or the reference's float
+    [C, N] tensor (packed on the way in)."""
+    if not isinstance(samples, PackedChains):
+        samples = PackedChains.pack(samples.t().contiguous())
+    return _ReturnFn.apply(probs, samples, value.detach().to(torch.float32).contiguous())
+
+
+class MCPGRound:
+    """One sampling round of the MCPG outer loop (methods/MCPG.py:366-413) kept on the device, sync-free:
+
+        xs_sample = metro_sampling(xs_prob, xs_bool, change_times)                    K9, bit-packed
+        temp_max, temp_max_info, value = sampler_func(...)                            K7 + K8, bit-packed
+        best-merge into now_max_res / now_max_info, min/max replacement (:376-391)    rls_mcpg_merge_best
+        xs_bool = temp_max_info.repeat(1, repeat_times)                               never materialised (C_in broadcast)
+        get_return(xs_prob, xs_sample.t(), value, ...) for the policy update          rls_mcpg_value_bit_sums
+
+    State: now_max_res f32 [M], now_max_info / start PackedChains of M chains, samples PackedChains of C = M * R."""
+
+    def __init__(self, data, now_max_info, now_max_res: TEN, total_mcmc_num: int, repeat_times: int, num_ls: int,
+                 change_times: Optional[int] = None):
+        self.data, self.M, self.R, self.num_ls = data, total_mcmc_num, repeat_times, num_ls
+        if total_mcmc_num % 64 != 0:
+            raise ValueError("total_mcmc_num must be a multiple of 64 (one bit tile holds 64 chains)")
+        self.N = data.num_nodes
+        self.change_times = int(self.N / 10) if change_times is None else change_times     # MCPG.py:331
+        info = now_max_info if isinstance(now_max_info, PackedChains) else PackedChains.pack(now_max_info.contiguous())
+        self.now_max_info = info
+        self.now_max_res = now_max_res.to(torch.float32).clone()
+        self.start = info.clone()                                                            # xs_bool, before the repeat
+        self.samples = PackedChains.empty(self.N, self.M * self.R, info.device)              # the round's metro output
+        self.work = PackedChains.empty(self.N, self.M * self.R, info.device)                 # after the local search
+        self.value = None
+        self.best_value = self.best_index = None
+
+    def step(self, xs_prob: TEN):
+        """One round; returns (value f32 [C], best value so far f32 [1]) -- device tensors, nothing is read back."""
+        C = self.M * self.R
+        metro_sampling_packed(xs_prob, self.start, self.change_times, num_chains=C, out=self.samples)
+        xs_loc, expected = mops.mcpg_local_search_levels(self.data.graph, self.samples, self.data._lv_ptr, self.data._lv_data,
+                                                         self.num_ls, _seed_from_torch(), out=self.work)
+        _, temp_max, temp_info = mops.mcpg_pick_best(expected, xs_loc, self.M, self.R, self.data.num_edges)
+        self.best_value, self.best_index = mops.mcpg_merge_best(temp_max, temp_info, self.now_max_res, self.now_max_info)
+        self.start = temp_info
+        self.value = expected - expected.mean()
+        return self.value, self.best_value
+
+    def get_return(self, xs_prob: TEN):
+        return get_return(xs_prob, self.samples, self.value)
+
+    def best_solution(self):
+        """(value: float, x: bool [N]) of the best incumbent -- a host read, for the end of a run."""
+        i = int(self.best_index.item())
+        word = self.now_max_info.words[i // 64]
+        return float(self.best_value.item()), ((word >> (i % 64)) & 1).bool()
+
+
+def run_mcpg(data, xs_init: TEN, vs_init: TEN, total_mcmc_num: int, repeat_times: int, num_ls: int, num_rounds: int,
+             sample_epoch_num: int = 8, lr: float = 8e-2, log=print):
+    """The sampling loop of mcpg() (methods/MCPG.py:353-413) on MCPGRound, with the reference's per-round prints
+    ("value ... entropy ..." and "num_samples_per_second: ..." as defined at :405-411: kept chains per round divided
+    by the wall time of metro + sampler + merge).  ``xs_init`` [N, M] / ``vs_init`` [M]: the incumbents the reference
+    gets from LocalSearch (:337-346).  The policy is the reference's parameter vector through a sigmoid (Simpler,
+    :62-73) trained with Adam: dense torch, out of the hot path.  Returns (best value, best x bool [N], samples/s list)."""
+    import time
+    device = data.graph.device
+    rnd = MCPGRound(data, xs_init, vs_init, total_mcmc_num, repeat_times, num_ls)
+    lin = torch.nn.Parameter(torch.zeros(data.num_nodes, device=device))
+    opt = torch.optim.Adam([lin], lr=lr)
+    xs_prob = torch.full((data.num_nodes,), 0.5, device=device)
+    rates = []
+    for r in range(num_rounds):
+        torch.cuda.synchronize(device)
+        t0 = time.time()
+        _, best = rnd.step(xs_prob)
+        p = xs_prob[None, :]
+        entropy = -(p * p.log2() + (1 - p) * (1 - p).log2()).mean(dim=1).mean()
+        now_max = float(best.item())                                   # the reference reads it for the print, too
+        running = time.time() - t0
+        log(f"value {now_max: 9.2f}  entropy {float(entropy): 9.3f}")
+        rates.append(total_mcmc_num / running)
+        log("num_samples_per_second: ", rates[-1])
+        for _ in range(sample_epoch_num):
+            xs_prob = torch.sigmoid(lin)
+            loss = rnd.get_return(xs_prob)
+            opt.zero_grad()
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_([lin], 1)
+            opt.step()
+        xs_prob = torch.sigmoid(lin).detach()
+    v, x = rnd.best_solution()
+    return v, x, rates

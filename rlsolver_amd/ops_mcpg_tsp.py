@@ -18,16 +18,67 @@ def _u64(v: int) -> C.c_uint64:
 
 
 # ------------------------------------------------------------------------------ MCPG
-def mcpg_metro_rounds(samples: TEN, probs: TEN, T: int, index: Optional[TEN] = None, u: Optional[TEN] = None,
+class PackedChains:
+    """C chains over N nodes, bit-packed tile-major: ``words`` int64 [ceil(C / 64), N] (the uint64 bit patterns; word
+    (t, n) bit e = node n of chain 64 t + e).  include/rlsolver_hip.h, "Layouts of a batch of C chains"."""
+
+    __slots__ = ("words", "num_chains")
+
+    def __init__(self, words: TEN, num_chains: int):
+        _check(words, "words", (torch.int64,))
+        if words.dim() != 2 or words.shape[0] != (num_chains + 63) // 64:
+            raise ValueError(f"words must be [ceil({num_chains} / 64), N]")
+        self.words, self.num_chains = words, num_chains
+
+    @property
+    def num_nodes(self) -> int:
+        return self.words.shape[1]
+
+    @property
+    def device(self):
+        return self.words.device
+
+    @classmethod
+    def empty(cls, num_nodes: int, num_chains: int, device):
+        return cls(torch.empty(((num_chains + 63) // 64, num_nodes), dtype=torch.int64, device=device), num_chains)
+
+    @classmethod
+    def pack(cls, xs: TEN):
+        """node-major [N, C] float32 / uint8 / bool -> PackedChains (one kernel)."""
+        _check(xs, "xs", _NM_DTYPES)
+        N, Cc = xs.shape
+        out = cls.empty(N, Cc, xs.device)
+        _abi.call("rls_mcpg_pack_chains", _ptr(xs), 4 if xs.dtype == torch.float32 else 1, N, Cc, _ptr(out.words), _stream(xs.device))
+        return out
+
+    def unpack(self) -> TEN:
+        """-> node-major float32 [N, C] holding 0.0 | 1.0 (the reference's surface)."""
+        xs = torch.empty((self.num_nodes, self.num_chains), dtype=torch.float32, device=self.device)
+        _abi.call("rls_mcpg_unpack_chains", _ptr(self.words), self.num_nodes, self.num_chains, _ptr(xs), _stream(self.device))
+        return xs
+
+    def clone(self):
+        return PackedChains(self.words.clone(), self.num_chains)
+
+
+def _chains(x, name):
+    """(pointer tensor, spin_bytes, N, C) of a node-major tensor or a PackedChains."""
+    if isinstance(x, PackedChains):
+        return x.words, 0, x.num_nodes, x.num_chains
+    _check(x, name, _NM_DTYPES)
+    if x.dim() != 2:
+        raise ValueError(f"{name} must be [N, C]")
+    return x, (4 if x.dtype == torch.float32 else 1), x.shape[0], x.shape[1]
+
+
+def mcpg_metro_rounds(samples, probs: TEN, T: int, index: Optional[TEN] = None, u: Optional[TEN] = None,
                       seed: int = 0, t_limit: Optional[TEN] = None, write_back: bool = True,
-                      accepts: Optional[TEN] = None, t_offset: int = 0, samples_in: Optional[TEN] = None) -> None:
-    """K9 (see include/rlsolver_hip.h).  samples [N, C] f32/uint8 in place, or read from ``samples_in`` (same
-    shape / dtype) and written to ``samples``."""
-    _check(samples, "samples", _NM_DTYPES)
-    dev = samples.device
-    if samples.dim() != 2:
-        raise ValueError("samples must be [N, C]")
-    N, Cc = samples.shape
+                      accepts: Optional[TEN] = None, t_offset: int = 0, samples_in=None) -> None:
+    """K9 (see include/rlsolver_hip.h).  samples [N, C] f32/uint8 or PackedChains, in place, or read from
+    ``samples_in`` (same layout; a PackedChains with fewer chains -- a multiple of 64 -- is broadcast) and written to
+    ``samples``."""
+    st, sb, N, Cc = _chains(samples, "samples")
+    dev = st.device
     _check(probs, "probs", (torch.float32,), dev, (N,))
     if (index is None) != (u is None):
         raise ValueError("index and u must be given together")
@@ -42,11 +93,14 @@ def mcpg_metro_rounds(samples: TEN, probs: TEN, T: int, index: Optional[TEN] = N
         _check(accepts, "accepts", (torch.int64,), dev)
         if accepts.numel() < T:
             raise ValueError("accepts must hold T entries")
+    sin, c_in = None, Cc
     if samples_in is not None:
-        _check(samples_in, "samples_in", (samples.dtype,), dev, (N, Cc))
+        sin, sb_in, n_in, c_in = _chains(samples_in, "samples_in")
+        if sb_in != sb or n_in != N or (sb != 0 and (c_in != Cc or sin.dtype != st.dtype)) or sin.device != dev:
+            raise ValueError("samples_in must have the layout and node count of samples")
         if not write_back:
             raise ValueError("samples_in needs write_back")
-    _abi.call("rls_mcpg_metro_rounds", _ptr(samples), _ptr(samples_in), 4 if samples.dtype == torch.float32 else 1, N, Cc, _ptr(probs),
+    _abi.call("rls_mcpg_metro_rounds", _ptr(st), _ptr(sin), c_in, sb, N, Cc, _ptr(probs),
               T, t_offset, _ptr(index), _ptr(u), _u64(seed), _ptr(t_limit), int(bool(write_back)), _ptr(accepts),
               _stream(dev))
 
@@ -71,41 +125,77 @@ def mcpg_local_search(g: DeviceGraph, xs_in: TEN, order: TEN, num_ls: int, unifo
     return xs_out, expected
 
 
-def mcpg_local_search_levels(g: DeviceGraph, xs_in: TEN, lv_ptr: TEN, lv_data: TEN, num_ls: int, seed: int = 0,
-                             coins: Optional[TEN] = None):
-    """K7 + expected cut on the level-parallel schedule (rls_mcpg_visit_levels).  ``coins`` int64 (bit pattern of
-    uint64) [num_ls * N, ceil(C / 64)]: the tie coins "u < 1/2" -- test hook; None = counter hash keyed by seed.
-    Returns (xs_out f32 [N, C], expected f32 [C])."""
-    _check(xs_in, "xs_in", _NM_DTYPES, g.device)
-    if xs_in.dim() != 2 or xs_in.shape[0] != g.num_nodes:
-        raise ValueError(f"xs_in must be [{g.num_nodes}, C]")
-    Cc = xs_in.shape[1]
+def mcpg_local_search_levels(g: DeviceGraph, xs_in, lv_ptr: TEN, lv_data: TEN, num_ls: int, seed: int = 0,
+                             coins: Optional[TEN] = None, out=None, num_chains: Optional[int] = None):
+    """K7 + expected cut on the level-parallel schedule (rls_mcpg_visit_levels).  ``xs_in``: node-major [N, C] or
+    PackedChains (which may hold fewer chains than ``num_chains``, a multiple of 64: broadcast).  ``coins`` int64 (bit
+    pattern of uint64) [num_ls * N, ceil(C / 64)]: the tie coins "u < 1/2" -- test hook; None = counter hash keyed by
+    seed.  ``out``: a PackedChains to write (may be xs_in itself) or None = node-major f32.
+    Returns (xs_out, expected f32 [C])."""
+    st, sb, N, c_in = _chains(xs_in, "xs_in")
+    if st.device != g.device or N != g.num_nodes:
+        raise ValueError(f"xs_in must hold {g.num_nodes} nodes on {g.device}")
+    Cc = c_in if num_chains is None else num_chains
     _check(lv_ptr, "lv_ptr", (torch.int32,), g.device)
     _check(lv_data, "lv_data", (torch.int32,), g.device)
     if coins is not None:
         _check(coins, "coins", (torch.int64,), g.device, (num_ls * g.num_nodes, (Cc + 63) // 64))
-    xs_out = torch.empty((g.num_nodes, Cc), dtype=torch.float32, device=g.device)
+    if out is None:
+        xs_out = torch.empty((g.num_nodes, Cc), dtype=torch.float32, device=g.device)
+        ot, osb = xs_out, 4
+    else:
+        if not isinstance(out, PackedChains) or out.num_chains != Cc or out.num_nodes != N or out.device != g.device:
+            raise ValueError("out must be a PackedChains of num_chains chains")
+        xs_out, ot, osb = out, out.words, 0
     expected = torch.empty(Cc, dtype=torch.float32, device=g.device)
-    _abi.call("rls_mcpg_local_search_levels", g.ref, _ptr(xs_in), 4 if xs_in.dtype == torch.float32 else 1, _ptr(xs_out),
-              Cc, _ptr(lv_ptr), _ptr(lv_data), lv_ptr.numel() - 1, num_ls, _ptr(coins), _u64(seed), _ptr(expected),
-              _stream(g.device))
+    _abi.call("rls_mcpg_local_search_levels", g.ref, _ptr(st), sb, c_in, _ptr(ot), osb, Cc, _ptr(lv_ptr), _ptr(lv_data),
+              lv_ptr.numel() - 1, num_ls, _ptr(coins), _u64(seed), _ptr(expected), _stream(g.device))
     return xs_out, expected
 
 
-def mcpg_pick_best(expected: TEN, xs: TEN, total_mcmc_num: int, repeat_times: int, num_edges: int):
-    """K8 second half.  Returns (best_index int64 [M], vs_good f32 [M], xs_good f32 [N, M])."""
-    _check(xs, "xs", (torch.float32,))
-    dev = xs.device
-    N, Cc = xs.shape
+def mcpg_pick_best(expected: TEN, xs, total_mcmc_num: int, repeat_times: int, num_edges: int):
+    """K8 second half.  Returns (best_index int64 [M], vs_good f32 [M], xs_good: f32 [N, M] or PackedChains of M chains)."""
+    st, sb, N, Cc = _chains(xs, "xs")
+    if sb == 1:
+        raise TypeError("xs must be float32 node-major or PackedChains")
+    dev = st.device
     if Cc != total_mcmc_num * repeat_times:
-        raise ValueError("xs must be [N, total_mcmc_num * repeat_times]")
+        raise ValueError("xs must hold total_mcmc_num * repeat_times chains")
     _check(expected, "expected", (torch.float32,), dev, (Cc,))
     idx = torch.empty(total_mcmc_num, dtype=torch.int64, device=dev)
     vs = torch.empty(total_mcmc_num, dtype=torch.float32, device=dev)
-    xg = torch.empty((N, total_mcmc_num), dtype=torch.float32, device=dev)
-    _abi.call("rls_mcpg_pick_best", _ptr(expected), _ptr(xs), N, total_mcmc_num, repeat_times, num_edges, _ptr(idx),
-              _ptr(vs), _ptr(xg), _stream(dev))
+    if sb == 0:
+        xg = PackedChains.empty(N, total_mcmc_num, dev)
+        xgt = xg.words
+    else:
+        xg = xgt = torch.empty((N, total_mcmc_num), dtype=torch.float32, device=dev)
+    _abi.call("rls_mcpg_pick_best", _ptr(expected), _ptr(st), sb, N, total_mcmc_num, repeat_times, num_edges, _ptr(idx),
+              _ptr(vs), _ptr(xgt), _stream(dev))
     return idx, vs, xg
+
+
+def mcpg_merge_best(temp_max: TEN, temp_info: PackedChains, now_max_res: TEN, now_info: PackedChains):
+    """The best-merge of methods/MCPG.py:376-391 in place on the device.  Returns (best value f32 [1], its chain int64 [1])."""
+    M, N, dev = temp_info.num_chains, temp_info.num_nodes, temp_info.device
+    _check(temp_max, "temp_max", (torch.float32,), dev, (M,))
+    _check(now_max_res, "now_max_res", (torch.float32,), dev, (M,))
+    if now_info.num_chains != M or now_info.num_nodes != N:
+        raise ValueError("now_info must match temp_info")
+    mask = torch.empty((M + 63) // 64, dtype=torch.int64, device=dev)
+    bv = torch.empty(1, dtype=torch.float32, device=dev)
+    bi = torch.empty(1, dtype=torch.int64, device=dev)
+    _abi.call("rls_mcpg_merge_best", _ptr(temp_max), _ptr(temp_info.words), _ptr(now_max_res), _ptr(now_info.words), N, M,
+              _ptr(mask), _ptr(bv), _ptr(bi), _stream(dev))
+    return bv, bi
+
+
+def mcpg_value_bit_sums(samples: PackedChains, value: TEN) -> TEN:
+    """A[n] = sum_c value[c] * s[n, c]  (f32 [N]); see rls_mcpg_value_bit_sums."""
+    _check(value, "value", (torch.float32,), samples.device, (samples.num_chains,))
+    A = torch.zeros(samples.num_nodes, dtype=torch.float32, device=samples.device)
+    _abi.call("rls_mcpg_value_bit_sums", _ptr(samples.words), samples.num_nodes, samples.num_chains, _ptr(value), _ptr(A),
+              _stream(samples.device))
+    return A
 
 
 # ------------------------------------------------------------------------------ TSP

@@ -84,7 +84,7 @@ def test_ctypes_argument_types_match_header():
 
 def test_loads_without_gpu_and_reports_errors():
     from rlsolver_amd import _abi
-    assert _abi.version() == 3
+    assert _abi.version() == 4
     assert _abi.device_count() >= 0
     # argument validation happens before any device work
     with pytest.raises(_abi.RlsError) as e:

@@ -210,3 +210,139 @@ def test_isco_tsp_class_runs(golden):
     l1 = s.calculate_distance(x)
     np.testing.assert_allclose(l1.cpu().numpy(), onp.tsp_tour_length_f64(z["berlin52/distance"], xs), rtol=1e-5)
     assert float(l1.mean()) < float(l0.mean())     # annealing at T=1 on berlin52 improves random tours
+
+
+# ------------------------------------------------------------------ bit-packed chains and the on-device round
+def _ba_data(n, m, seed):
+    from rlsolver_amd.graph import generate_ba
+    g = np.asarray(generate_ba(n, m, seed=seed), dtype=np.int64)
+    return amcpg.make_data(n, g[:, 0].copy(), g[:, 1].copy(), DEV), g
+
+
+@pytest.mark.parametrize("n,C", [(300, 192), (1001, 64 * 5 + 17), (64, 70)])
+def test_packed_chains_roundtrip_and_layouts_agree(n, C):
+    """pack / unpack are inverse; the packed metro and K7 kernels give bit for bit what the f32 node-major kernels give
+    for the same seed (production draws are keyed by chain id, not by layout), for C not a multiple of 64 too."""
+    from rlsolver_amd.ops_mcpg_tsp import PackedChains
+    data, g = _ba_data(n, 4, 3)
+    rng = np.random.RandomState(n)
+    xs = dev((rng.rand(n, C) < 0.5).astype(np.float32))
+    pk = PackedChains.pack(xs)
+    assert pk.words.shape == ((C + 63) // 64, n) and torch.equal(pk.unpack(), xs)
+    assert torch.equal(PackedChains.pack(xs.bool()).words, pk.words)
+    probs = dev((rng.rand(n) * 0.6 + 0.2).astype(np.float32))
+    T = max(1, n // 10)
+    # metro, production draws: f32 kernel vs packed kernel, one chunk with per-round accept counts
+    a32 = torch.zeros(T, dtype=torch.int64, device=DEV)
+    apk = torch.zeros(T, dtype=torch.int64, device=DEV)
+    o32 = xs.clone()
+    mops.mcpg_metro_rounds(o32, probs, T, seed=77, accepts=a32)
+    opk = pk.clone()
+    mops.mcpg_metro_rounds(opk, probs, T, seed=77, accepts=apk)
+    assert torch.equal(opk.unpack(), o32) and torch.equal(a32, apk) and int(a32.sum()) > 0
+    # the reference-shaped function (pack -> packed walk -> unpack) with recorded draws == the oracle
+    index = rng.randint(0, n, size=(5 * T, C)).astype(np.int64)
+    u = rng.rand(5 * T, C).astype(np.float32)
+    want, _ = onp.metro_sampling(probs.cpu().numpy(), xs.cpu().numpy(), T, index, u)
+    got = amcpg.metro_sampling(probs, xs, T, device=DEV, index=dev(index), u=dev(u))
+    assert np.array_equal(got.cpu().numpy(), want)
+    # K7 levels: f32 in / f32 out vs packed in / packed out (in place), same seed
+    x32, e32 = mops.mcpg_local_search_levels(data.graph, o32, data._lv_ptr, data._lv_data, 3, seed=5)
+    xpk, epk = mops.mcpg_local_search_levels(data.graph, opk, data._lv_ptr, data._lv_data, 3, seed=5, out=opk)
+    assert xpk is opk and torch.equal(xpk.unpack(), x32) and torch.equal(e32, epk)
+    cut = ops_obj(data, x32)
+    assert torch.equal((data.num_edges - 2 * cut).float(), e32)
+
+
+def ops_obj(data, xs_nm):
+    from rlsolver_amd import ops
+    return ops.maxcut_obj(data.graph, (xs_nm.t() > 0).contiguous())
+
+
+def test_packed_broadcast_start_pick_and_merge_vs_oracle():
+    """C_in broadcast (xs_bool.repeat(1, R) never materialised), best-of-repeats on packed chains, and the best-merge
+    of MCPG.py:376-391 against its numpy restatement."""
+    from rlsolver_amd.ops_mcpg_tsp import PackedChains
+    n, M, R = 500, 128, 6
+    data, g = _ba_data(n, 5, 9)
+    rng = np.random.RandomState(1)
+    kept = dev((rng.rand(n, M) < 0.5).astype(np.float32))
+    probs = dev((rng.rand(n) * 0.6 + 0.2).astype(np.float32))
+    T = n // 10
+    start = PackedChains.pack(kept)
+    torch.manual_seed(4)
+    got = amcpg.metro_sampling_packed(probs, start, T, num_chains=M * R)
+    torch.manual_seed(4)
+    want = amcpg.metro_sampling_packed(probs, PackedChains.pack(kept.repeat(1, R)), T)
+    assert got.num_chains == M * R and torch.equal(got.words, want.words)
+    assert not torch.equal(got.unpack()[:, :M], got.unpack()[:, M:2 * M])         # repeats walk with their own draws
+    # sampler on packed chains == the f32 path for the same seed
+    torch.manual_seed(6)
+    vs_p, xg_p, val_p, xloc = amcpg.sampler_func_packed(data, got.clone(), 2, M, R)
+    torch.manual_seed(6)
+    vs_f, xg_f, val_f = amcpg.sampler_func(data, got.unpack(), 2, M, R, DEV)
+    assert torch.equal(vs_p, vs_f) and torch.equal(xg_p.unpack(), xg_f) and torch.equal(val_p, val_f)
+    assert torch.equal(ops_obj(data, xg_f).float(), vs_f)
+    # merge: incumbents that are partly better, partly worse, with ties on both ends
+    now_res = vs_f.cpu().numpy() + rng.randint(-3, 4, size=M).astype(np.float32)
+    now_res[7] = now_res.max() + 2
+    now_res[9] = now_res[7]                      # tie at the top: the first wins
+    now_res[30] = now_res.min() - 1
+    now_res[40] = now_res[30]                    # tie at the bottom
+    now_info = (rng.rand(n, M) < 0.5).astype(np.float32)
+    w_res, w_info, w_temp, w_max, w_idx = onp.mcpg_merge_best(vs_f.cpu().numpy(), xg_f.cpu().numpy(), now_res, now_info)
+    d_res = dev(now_res)
+    d_info = PackedChains.pack(dev(now_info))
+    bv, bi = mops.mcpg_merge_best(vs_p, xg_p, d_res, d_info)
+    assert np.array_equal(d_res.cpu().numpy(), w_res) and np.array_equal(d_info.unpack().cpu().numpy(), w_info)
+    assert np.array_equal(xg_p.unpack().cpu().numpy(), w_temp)
+    assert float(bv) == float(w_max) and int(bi) == w_idx == 7
+
+
+def test_get_return_packed_vs_oracle_and_autograd():
+    """get_return (MCPG.py:292-302) from the bit sums: objective and gradient against the float64 restatement, and
+    against torch autograd on the reference's own [C, N] float expression."""
+    from rlsolver_amd.ops_mcpg_tsp import PackedChains
+    n, M, R = 333, 64, 3
+    C = M * R
+    rng = np.random.RandomState(2)
+    s = (rng.rand(C, n) < 0.4).astype(np.float32)
+    value = (rng.randn(C) * 20).astype(np.float32)
+    lin = torch.tensor(rng.randn(n).astype(np.float32), device=DEV, requires_grad=True)
+    probs = torch.sigmoid(lin)
+    samples = PackedChains.pack(dev(s.T.copy()))
+    obj = amcpg.get_return(probs, samples, dev(value), M, R)
+    obj.backward()
+    w_obj, w_grad_p = onp.mcpg_get_return(probs.detach().cpu().numpy(), s, value, M, R)
+    p = probs.detach().cpu().numpy().astype(np.float64)
+    np.testing.assert_allclose(float(obj), w_obj, rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(lin.grad.cpu().numpy(), w_grad_p * p * (1 - p), rtol=2e-4, atol=2e-4)
+    # the reference's expression through autograd (f32): same objective / gradient within f32 summation noise
+    lin2 = torch.tensor(lin.detach().cpu().numpy(), device=DEV, requires_grad=True)
+    p2 = torch.sigmoid(lin2)
+    sd = dev(s)
+    ref = ((sd * p2 + (1 - sd) * (1 - p2)).log().sum(dim=1) * dev(value)).mean()
+    ref.backward()
+    np.testing.assert_allclose(float(obj), float(ref), rtol=1e-4, atol=1e-2)
+    np.testing.assert_allclose(lin.grad.cpu().numpy(), lin2.grad.cpu().numpy(), rtol=1e-3, atol=1e-3)
+    # the reference-shaped call (float [C, N] samples) goes through the same kernel
+    assert float(amcpg.get_return(torch.sigmoid(lin.detach()), sd, dev(value), M, R)) == pytest.approx(float(obj), rel=1e-6)
+
+
+def test_mcpg_round_on_device_improves_and_prints_like_the_reference():
+    """run_mcpg: the sampling loop of mcpg() (MCPG.py:353-413) on MCPGRound; incumbents never get worse, every kept
+    value is the cut of its kept chain, the prints are the reference's."""
+    from rlsolver_amd import ops
+    n, M, R = 800, 64, 8
+    data, g = _ba_data(n, 4, 11)
+    torch.manual_seed(0)
+    xs0 = ops.rand_spins(M, n, 3, DEV)
+    vs0 = ops.maxcut_obj(data.graph, xs0).float()
+    lines = []
+    v, x, rates = amcpg.run_mcpg(data, xs0.t().contiguous().float(), vs0, M, R, num_ls=2, num_rounds=6, sample_epoch_num=2,
+                                 log=lambda *a: lines.append(" ".join(str(t) for t in a)))
+    assert len(rates) == 6 and all(r > 0 for r in rates)
+    assert sum(l.startswith("value ") and "entropy" in l for l in lines) == 6
+    assert sum(l.startswith("num_samples_per_second:") for l in lines) == 6
+    assert v >= float(vs0.max()) and v > 0.6 * data.num_edges
+    assert int(ops.maxcut_obj(data.graph, x[None, :].contiguous())) == int(v)
