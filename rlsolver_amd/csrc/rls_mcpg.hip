@@ -180,15 +180,22 @@ __global__ __launch_bounds__(kMetroWaves * kWave) void k_mcpg_metro(T* samples, 
     if (write_back) tile_store_nodemajor<T>(samples, N, C, c0, words, lane, w, kMetroWaves);
 }
 
-// K9 on bit-packed chains.  One wave per 64-chain tile and the tile (N * 8 bytes) is the ONLY LDS, so two tiles are
-// resident per CU at N = 10^4 where the f32 kernel above fits one; there is no tile transposition and the tile moves
-// as a straight 16-byte-lane copy.  probs are gathered from global memory a batch of rounds AHEAD (the drawn node does
-// not depend on the chain state, so the loads of batch k + 1 fly while batch k walks); per-round accept counts ride
-// in registers (lane t % 64 keeps round t's count) and leave as one coalesced atomic per 64 rounds.  Same draws as the
-// f32 kernel for the same seed.
-constexpr int kMetroBatch = 8;
+// K9 on bit-packed chains.  The tile moves as a straight 16-byte-lane copy (no transposition) and the workgroup is split
+// into ONE walking wave and kMetroPW - 1 draw producers, because a lone wave is instruction-issue bound (~5 cycles per
+// VALU instruction): of the ~100 instructions of a round, ~85 do not depend on the chain state -- the counter hash, the
+// node id, the probs gather and BOTH possible Metropolis tests "u < (1 - q) / q" (q = p if the bit is set, 1 - p if not;
+// the same two IEEE operations as MCPG.py:105-107).  Producers fill a window of 64 rounds in LDS, one dword per (round,
+// chain): node | accept-if-0 << 30 | accept-if-1 << 31, while the walker consumes the previous window: read the word
+// of the drawn node, pick the pre-computed verdict by the chain's bit, flip with an LDS XOR.  The walker issues the
+// read of round r + 1 BEFORE the flip of round r (the LDS executes a wave's operations in issue order, so flips of
+// rounds <= r - 1 are visible) and patches the one hazard in registers: its own flip of round r on the same node.
+// Per-round accept counts ride in registers (lane r keeps round r of the window) and leave as one coalesced atomic
+// per window.  Same draws as the f32 kernel for the same seed.
+constexpr int kMetroPW = 8;       // waves per workgroup
+constexpr int kMetroWin = 64;     // rounds per window
 
-__global__ __launch_bounds__(kWave) void k_mcpg_metro_packed(uint64_t* __restrict__ samples,
+template <bool GIVEN>   // GIVEN: the reference's recorded draws (tests); else the counter hash
+__global__ __launch_bounds__(kMetroPW * kWave) void k_mcpg_metro_packed(uint64_t* __restrict__ samples,
                                                              const uint64_t* __restrict__ samples_in, int64_t tiles_in,
                                                              int64_t N, int64_t C, const float* __restrict__ probs,
                                                              int64_t T_rounds, const int64_t* __restrict__ index,
@@ -197,7 +204,9 @@ __global__ __launch_bounds__(kWave) void k_mcpg_metro_packed(uint64_t* __restric
                                                              unsigned long long* __restrict__ accepts, int64_t t_offset) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* words = reinterpret_cast<uint64_t*>(smem);
-    const int lane = threadIdx.x;
+    uint32_t* queue = reinterpret_cast<uint32_t*>(smem + (size_t)((N + 1) & ~(int64_t)1) * 8);   // [2][kMetroWin][64]
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     const int64_t tile = blockIdx.x;
     const int64_t c = tile * kWave + lane;
     const bool valid = c < C;
@@ -208,62 +217,85 @@ __global__ __launch_bounds__(kWave) void k_mcpg_metro_packed(uint64_t* __restric
         t_end = lim < T_rounds ? (lim > 0 ? lim : 0) : T_rounds;
     }
     if (t_end == 0 && in_place) return;           // stop rule already met and nothing to move
-    tile_load_packed(samples_in, N, C, tile, tiles_in, words, lane, kWave);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
+    tile_load_packed(samples_in, N, C, tile, tiles_in, words, threadIdx.x, kMetroPW * kWave);
     const uint32_t chain_key = k7_fmix32((uint32_t)seed ^ k7_fmix32((uint32_t)(seed >> 32) ^ k7_fmix32((uint32_t)c) ^
                                                                     ((uint32_t)((uint64_t)c >> 32) * 0x9E3779B1u)));
-    const uint64_t mybit = 1ull << lane;
-    auto fetch = [&](int64_t t, int64_t& i, float& uu, float& p) {
-        i = 0;
-        uu = 2.0f;
-        if (valid && t < t_end) {
-            if (index) {
-                i = index[(t_offset + t) * C + c];
-                uu = u[(t_offset + t) * C + c];
+    const int64_t nwin = (t_end + kMetroWin - 1) / kMetroWin;
+    auto produce = [&](int64_t win) {             // waves 1 .. PW-1 share the window's rounds
+        uint32_t* q = queue + (win & 1) * (kMetroWin * kWave);
+        for (int r = w - 1; r < kMetroWin; r += kMetroPW - 1) {
+            const int64_t t = win * kMetroWin + r;
+            const bool live = valid && t < t_end;
+            int64_t i;
+            float uu;
+            if constexpr (GIVEN) {
+                const int64_t at = live ? (t_offset + t) * C + c : 0;
+                i = index[at];
+                uu = u[at];
             } else {
                 const uint32_t k = chain_key ^ ((uint32_t)(t_offset + t) * 0x9E3779B1u);
                 const uint32_t r0 = k7_fmix32(k ^ 0x4D455452u), r1 = k7_fmix32(k + 0x7FEB352Du);
                 i = (int64_t)(((uint64_t)r0 * (uint64_t)N) >> 32);
                 uu = u32_to_unit_float(r1);
             }
+            i = live ? i : 0;
+            const float p = probs[i];
+            const float q1 = p, q0 = 1.0f - p;                    // torch.where(chosen_value, p, 1 - p)
+            const bool a1 = uu < (1.0f - q1) / q1;                // MCPG.py:107 for a set bit
+            const bool a0 = uu < (1.0f - q0) / q0;                //             for a clear bit
+            q[r * kWave + lane] = live ? ((uint32_t)i | ((uint32_t)a0 << 30) | ((uint32_t)a1 << 31)) : 0u;
         }
-        p = probs[i];
     };
-    int64_t ci[kMetroBatch], ni[kMetroBatch];
-    float cu[kMetroBatch], cp[kMetroBatch], nu[kMetroBatch], np_[kMetroBatch];
+    if (w > 0 && nwin > 0) produce(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const uint64_t mybit = 1ull << lane;
+    for (int64_t win = 0; win < nwin; ++win) {
+        if (w == 0) {
+            const uint32_t* q = queue + (win & 1) * (kMetroWin * kWave);
+            const int rounds = (int)((t_end - win * kMetroWin) < kMetroWin ? (t_end - win * kMetroWin) : kMetroWin);
+            uint32_t mycnt = 0;
+            __builtin_amdgcn_s_setprio(3);                        // the walker is the critical path of the workgroup
+            // entries come 8 rounds at a time (they do not depend on the chain state); the word of round r + 1 is
+            // requested before the flip of round r is issued
+            uint32_t eb[8];
 #pragma unroll
-    for (int q = 0; q < kMetroBatch; ++q) fetch(q, ci[q], cu[q], cp[q]);
-    uint32_t mycnt = 0;
-    for (int64_t t0 = 0; t0 < t_end; t0 += kMetroBatch) {
+            for (int k = 0; k < 8; ++k) eb[k] = q[k * kWave + lane];
+            uint64_t wv = words[eb[0] & 0x3fffffffu];
+            for (int r0 = 0; r0 < rounds; r0 += 8) {
+                uint32_t en8[8];
 #pragma unroll
-        for (int q = 0; q < kMetroBatch; ++q) fetch(t0 + kMetroBatch + q, ni[q], nu[q], np_[q]);   // next batch in flight
+                for (int k = 0; k < 8; ++k) en8[k] = (r0 + 8 + k < kMetroWin) ? q[(r0 + 8 + k) * kWave + lane] : 0u;
 #pragma unroll
-        for (int q = 0; q < kMetroBatch; ++q) {
-            const int64_t t = t0 + q;
-            const bool val = (words[ci[q]] >> lane) & 1ull;
-            const float chosen = val ? cp[q] : 1.0f - cp[q];               // torch.where(chosen_value, p, 1 - p)
-            const float accept_rate = (1.0f - chosen) / chosen;            // MCPG.py:107
-            const bool acc = cu[q] < accept_rate;                          // idle lanes / rounds carry u = 2
-            // one wave, and the LDS executes a wave's operations in issue order: this round's reads precede its
-            // flips, and the flips precede the next round's reads
-            if (acc) atomicXor(reinterpret_cast<unsigned long long*>(&words[ci[q]]), (unsigned long long)mybit);
-            if (accepts) {
-                const uint32_t cnt = (uint32_t)__popcll(ballot64(acc));
-                if (lane == (int)(t & 63)) mycnt = cnt;
-                if ((t & 63) == 63 || t + 1 >= t_end) {                    // uniform: flush the window's counts
-                    const int64_t tw = t & ~(int64_t)63;
-                    if (tw + lane <= t && mycnt) atomicAdd(&accepts[tw + lane], (unsigned long long)mycnt);
-                    mycnt = 0;
+                for (int k = 0; k < 8; ++k) {
+                    const int r = r0 + k;
+                    const uint32_t e = eb[k];
+                    const uint32_t i = e & 0x3fffffffu;
+                    const uint32_t bit = (uint32_t)(wv >> lane) & 1u;
+                    const bool acc = (r < rounds) && ((e >> (30 + bit)) & 1u);
+                    const uint32_t en = (k + 1 < 8) ? eb[(k + 1) & 7] : en8[0];
+                    const uint32_t inx = en & 0x3fffffffu;
+                    uint64_t wn = words[inx];
+                    if (acc) atomicXor(reinterpret_cast<unsigned long long*>(&words[i]), (unsigned long long)mybit);
+                    if (acc && inx == i) wn ^= mybit;             // the one flip the early read cannot have seen
+                    if (accepts) {
+                        const uint32_t cnt = (uint32_t)__popcll(ballot64(acc));
+                        if (lane == r) mycnt = cnt;
+                    }
+                    wv = wn;
                 }
-            }
-        }
 #pragma unroll
-        for (int q = 0; q < kMetroBatch; ++q) { ci[q] = ni[q]; cu[q] = nu[q]; cp[q] = np_[q]; }
+                for (int k = 0; k < 8; ++k) eb[k] = en8[k];
+            }
+            __builtin_amdgcn_s_setprio(0);
+            if (accepts && lane < rounds && mycnt) atomicAdd(&accepts[win * kMetroWin + lane], (unsigned long long)mycnt);
+        } else if (win + 1 < nwin) {
+            produce(win + 1);
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    if (write_back) tile_store_packed(samples, N, tile, words, lane, kWave);
+    if (write_back) tile_store_packed(samples, N, tile, words, threadIdx.x, kMetroPW * kWave);
 }
 
 // ------------------------------------------------------------------------------------- K7 + K8
@@ -545,8 +577,9 @@ __device__ __forceinline__ void lv_hub_counts(const uint64_t* words, const int32
     }
 }
 
-// LDS: the bit tile (N + 2 words) and 64 int32 slots for the cut reduction -- nothing else, so that two workgroups fit a
-// CU at N = 10^4 (2 x 80 272 B); the group offsets lv_ptr[] are wave-uniform and come through the scalar cache.
+// LDS: the bit tile (N + 2 words), 64 int32 slots for the cut reduction and the group offsets lv_ptr[] (G + 2 dwords; a
+// wave reads them 64 at a time into a register and walks them with v_readlane) -- small enough that two workgroups fit
+// a CU at N = 10^4 (2 x ~81.3 KB).
 template <typename TI, typename TO, int P, int W>
 __global__ __launch_bounds__(W * kWave) void k_mcpg_local_search_levels(
     const typename ChainStore<TI>::type* __restrict__ xs_in, typename ChainStore<TO>::type* __restrict__ xs_out, int64_t N,
@@ -557,6 +590,7 @@ __global__ __launch_bounds__(W * kWave) void k_mcpg_local_search_levels(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* words = reinterpret_cast<uint64_t*>(smem);
     int* cut_slots = reinterpret_cast<int*>(smem + (size_t)(N + 2) * 8);          // [64]
+    int32_t* lvl = cut_slots + kWave;                                             // [G + 2]
     const uint32_t* w32 = reinterpret_cast<const uint32_t*>(smem);
     const int lane = threadIdx.x & (kWave - 1);
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
@@ -566,6 +600,7 @@ __global__ __launch_bounds__(W * kWave) void k_mcpg_local_search_levels(
     const int64_t CB = (C + kWave - 1) / kWave;               // 64-chain blocks = words per coins row
     if (threadIdx.x == 0) words[N] = 0;                       // padding / idle lanes point here
     if (threadIdx.x < kWave) cut_slots[threadIdx.x] = 0;
+    for (int64_t i = threadIdx.x; i <= G + 1; i += W * kWave) lvl[i] = i <= G ? lv_ptr[i] : lv_ptr[G];
     if constexpr (std::is_same<TI, Packed64>::value) tile_load_packed(xs_in, N, C, blockIdx.x, tiles_in, words, threadIdx.x, W * kWave);
     else tile_load_bits_nodemajor<TI>(xs_in, N, C, c0, words, lane, w, W);
     const uint32_t blk_key = k7_fmix32((uint32_t)seed ^ k7_fmix32((uint32_t)(seed >> 32) ^
@@ -573,7 +608,7 @@ __global__ __launch_bounds__(W * kWave) void k_mcpg_local_search_levels(
     const BitXpose xc = bit_xpose_consts(lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();   // the tile is complete before any wave reads a neighbour word
-    auto lvp = [&](int64_t k) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane(lv_ptr[k]); };
+    auto lvp = [&](int64_t k) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane(lvl[k]); };
     auto coin_word = [&](int64_t cnt, uint32_t pos) -> uint64_t {   // bit e: "u < 1/2" for chain c0 + e at (pass, pos)
         if (coins) return coins[((int64_t)cnt * N + pos) * CB + blockIdx.x];
         const uint32_t k = blk_key ^ (pos * 0x9E3779B1u) ^ ((uint32_t)cnt * 0x7FEB352Du + 0x165667B1u);
@@ -596,11 +631,17 @@ __global__ __launch_bounds__(W * kWave) void k_mcpg_local_search_levels(
             }
         };
         prefetch(mine);
+        int chunk = 0, chunk_next = 0;                        // lvl[k0 + lane] and lvl[k0 + 1 + lane] of the current 64 groups
         for (int64_t k = 0; k < G; ++k) {
-            const uint32_t flags = lvp(k);
+            if ((k & 63) == 0) {
+                const int64_t a0 = k + lane <= G ? k + lane : G, a1 = k + 1 + lane <= G ? k + 1 + lane : G;
+                chunk = lvl[a0];
+                chunk_next = lvl[a1];
+            }
+            const uint32_t flags = (uint32_t)__builtin_amdgcn_readlane(chunk, (int)(k & 63));
             if (flags >> 31) __syncthreads();                 // new level (k = 0: new pass): earlier updates are visible
             if (k != mine) continue;
-            const int64_t p0 = flags & M30, p1 = lvp(k + 1) & M30;
+            const int64_t p0 = flags & M30, p1 = (uint32_t)__builtin_amdgcn_readlane(chunk_next, (int)(k & 63)) & M30;
             const int rounds = (int)((p1 - p0) >> 6) - 2;
             if (!((flags >> 30) & 1u)) {
                 // ---- 64 nodes, lane = node
@@ -874,11 +915,12 @@ int rls_mcpg_metro_rounds(void* samples, const void* samples_in, int64_t C_in, i
         RLS_REQUIRE(C_in == C || (C_in % kWave == 0 && C_in < C && write_back), RLS_EINVAL,
                     "broadcast start state: C_in=%lld must be a multiple of 64 below C (and write_back set)", (long long)C_in);
         RLS_REQUIRE(samples_in != samples || C_in == C, RLS_EINVAL, "a broadcast start state cannot be updated in place");
-        const size_t lds = (size_t)N * 8;
+        RLS_REQUIRE(N < (1 << 30), RLS_EUNSUPPORTED, "N=%lld: the packed walk keeps node ids in 30 bits", (long long)N);
+        const size_t lds = (size_t)((N + 1) & ~(int64_t)1) * 8 + (size_t)2 * kMetroWin * kWave * 4;
         RLS_REQUIRE(lds <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS (max %d)", (long long)N, lds, kLdsBytes);
-        if (lds > 64 * 1024)
-            (void)hipFuncSetAttribute((const void*)k_mcpg_metro_packed, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(k_mcpg_metro_packed, dim3((unsigned)ceil_div(C, kWave)), dim3(kWave), lds, as_stream(stream),
+        auto kern = index ? k_mcpg_metro_packed<true> : k_mcpg_metro_packed<false>;
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(C, kWave)), dim3(kMetroPW * kWave), lds, as_stream(stream),
                            (uint64_t*)samples, (const uint64_t*)samples_in, ceil_div(C_in, kWave), N, C, probs, T, index, u, seed,
                            t_limit_dev, write_back, (unsigned long long*)accepts, t_offset);
         return check_launch("k_mcpg_metro_packed");
@@ -905,13 +947,15 @@ int rls_mcpg_metro_rounds(void* samples, const void* samples_in, int64_t C_in, i
     return check_launch("k_mcpg_metro");
 }
 
-static size_t lv_lds_bytes(int64_t N) { return (size_t)(N + 2) * 8 + (size_t)kWave * 4; }
+static size_t lv_lds_bytes(int64_t N, int64_t num_groups) {
+    return (size_t)(N + 2) * 8 + (size_t)kWave * 4 + (((size_t)(num_groups + 2) * 4 + 15) & ~(size_t)15);
+}
 
 int rls_mcpg_local_search_levels_supported(const rls_graph* g, int64_t num_groups) {
     if (!g || g->num_nodes <= 0 || num_groups <= 0) return 0;
     if (g->num_nodes >= (1 << 20) || g->max_degree >= 1024 || g->wgt) return 0;
     if (pick_planes(g->num_stored_edges) == 0) return 0;
-    return lv_lds_bytes(g->num_nodes) <= (size_t)kLdsBytes;
+    return lv_lds_bytes(g->num_nodes, num_groups) <= (size_t)kLdsBytes;
 }
 
 int rls_mcpg_local_search_levels(const rls_graph* g, const void* xs_in, int spin_bytes, int64_t C_in, void* xs_out,
@@ -934,7 +978,7 @@ int rls_mcpg_local_search_levels(const rls_graph* g, const void* xs_in, int spin
                 "level-parallel K7 needs an unweighted graph, N < 2^20, degrees < 1024");
     const int P = pick_planes(E);
     RLS_REQUIRE(P != 0, RLS_EUNSUPPORTED, "E=%lld too large", (long long)E);
-    const size_t lds = lv_lds_bytes(N);
+    const size_t lds = lv_lds_bytes(N, num_groups);
     RLS_REQUIRE(lds <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS (max %d)", (long long)N, lds,
                 kLdsBytes);
     const int64_t tiles_in = ceil_div(C_in, kWave);

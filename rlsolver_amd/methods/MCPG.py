@@ -193,16 +193,54 @@ def metro_sampling_packed(probs: TEN, start: PackedChains, max_transfer_time: in
 
 def metro_sampling(probs: TEN, start_status: TEN, max_transfer_time: int, device=None,
                    index: Optional[TEN] = None, u: Optional[TEN] = None) -> TEN:
-    """MCPG.py:88-117 with the reference's surface: start_status [N, C] (anything bool-able) -> float32 [N, C] of
-    0.0 | 1.0, the caller's tensor untouched.  The walk itself runs on bit-packed chains (one pack and one unpack
-    kernel around metro_sampling_packed).  ``index``/``u`` ([>=5T, C]) replace the torch.randint / torch.rand draws
-    (test hook)."""
+    """MCPG.py:88-117 with the reference's surface (float32 [N, C] in and out, the caller's tensor untouched): the
+    node-major f32 kernel, whose 16 loader waves overlap the 2 x 4N bytes per chain of this surface with the walk
+    (routing it through pack -> packed walk -> unpack measured slower: 10.8 vs 6.9 ms at BA-10^4 / 2^18 chains).
+    The sync-free form of a sampling round is metro_sampling_packed.  Up to 5*T proposal rounds per chain, stopping
+    after the first round whose cumulative accept count reaches C*T -- evaluated on the device, where the reference
+    syncs once per round.  ``index``/``u`` ([>=5T, C]) replace the torch.randint / torch.rand draws (test hook)."""
     device = start_status.device if device is None else torch.device(device)
-    start = start_status.to(device=device)
-    if start.dtype not in (torch.float32, torch.uint8, torch.bool):
-        start = start.to(torch.float32)
-    packed = PackedChains.pack(start.contiguous())
-    return metro_sampling_packed(probs, packed, max_transfer_time, index=index, u=u, out=packed).unpack()
+    start = start_status.to(device=device, dtype=torch.float32).contiguous()
+    # the first chunk reads the caller's start state and writes the result buffer: no copy of the [N, C] state
+    samples = torch.empty_like(start) if start.data_ptr() == start_status.data_ptr() else start
+    probs = probs.detach().to(device=device, dtype=torch.float32).contiguous()
+    N, Cc = samples.shape
+    Tmax = max_transfer_time * 5
+    if index is not None:
+        Tmax = min(Tmax, index.shape[0])
+    if Tmax <= 0:   # no rounds (N < 10 gives T = int(N / 10) = 0): the reference returns start_status.bool().float()
+        return start.clone() if samples is not start else start
+    seed = _seed_from_torch() if index is None else 0
+    # Walk the rounds in chunks of T.  A round accepts at most C proposals, so the cumulative count cannot reach
+    # C*T before the LAST round of the first chunk: that chunk is applied directly (one pass, counting as it
+    # goes).  Later chunks: dry pass -> accept counts -> stop round (on the device) -> apply.  Chunks after the
+    # stop round see a zero limit and return at once.
+    chunk = max(1, max_transfer_time)
+    target = Cc * max_transfer_time
+    cum_prev = torch.zeros((), dtype=torch.int64, device=device)
+    live = torch.ones((), dtype=torch.bool, device=device)
+    zero = torch.zeros((), dtype=torch.int64, device=device)
+    for t0 in range(0, Tmax, chunk):
+        tk = min(chunk, Tmax - t0)
+        tk_dev = torch.full((), tk, dtype=torch.int64, device=device)
+        accepts = torch.zeros(tk, dtype=torch.int64, device=device)
+        if t0 == 0:
+            mops.mcpg_metro_rounds(samples, probs, tk, index, u, seed, None, True, accepts, t_offset=0,
+                                   samples_in=None if samples is start else start)
+            cum = accepts.cumsum(0)
+            hit = cum[-1] >= target
+        else:
+            limit = torch.where(live, tk_dev, zero).reshape(1).contiguous()
+            mops.mcpg_metro_rounds(samples, probs, tk, index, u, seed, limit, False, accepts, t_offset=t0)
+            cum = cum_prev + accepts.cumsum(0)
+            reached = cum >= target
+            hit = reached.any()
+            t_stop = torch.where(hit, reached.to(torch.int64).argmax() + 1, tk_dev)
+            apply_limit = torch.minimum(limit[0], t_stop).reshape(1).contiguous()
+            mops.mcpg_metro_rounds(samples, probs, tk, index, u, seed, apply_limit, True, None, t_offset=t0)
+        cum_prev = cum[-1]
+        live = live & ~hit
+    return samples
 
 
 def _levels_ok(data) -> bool:

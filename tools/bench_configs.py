@@ -15,6 +15,7 @@ from rlsolver_amd.methods import MCPG as amcpg
 ap = argparse.ArgumentParser()
 ap.add_argument("--quick", action="store_true")
 ap.add_argument("--profile", action="store_true", help="few launches per kernel: for rocprofv3 passes (PMC serialises kernels)")
+ap.add_argument("--only", default="", help="comma list of suites: maxcut,ls,g70,g14,tsp,spin,qubo,mcpg")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 HBM = 8e12
@@ -111,7 +112,32 @@ def mcpg_suite(tag, n, m_ba, C, num_ls, iters):
     emit(tag, f"K7+K8 sampler_func (num_ls={num_ls})", "chain-sweeps", C * num_ls, t, 2 * 4 * n / num_ls)
     T = n // 10
     t = timeit(lambda i: amcpg.metro_sampling(probs, xs, T, dev), iters, warm=1)
-    emit(tag, "K9 metro_sampling (sync-free stop rule)", "proposals", C * T, t, None, f"T={T}")
+    emit(tag, "K9 metro_sampling (f32 [N,C] surface)", "proposals", C * T, t, None, f"T={T}")
+    # the on-device round: bit-packed chains end to end
+    from rlsolver_amd.ops_mcpg_tsp import PackedChains
+    M, R = C // 128, 128
+    kept = PackedChains.pack((torch.rand((n, M), device=dev) < 0.5).float())
+    out = PackedChains.empty(n, C, dev)
+    t = timeit(lambda i: amcpg.metro_sampling_packed(probs, kept, T, num_chains=C, out=out), iters, warm=1)
+    emit(tag, "K9 metro_sampling_packed (broadcast start, T rounds)", "proposals", C * T, t, (n // 8 + n // 8) / T,
+         f"T={T}; bytes = packed tile out + broadcast tile in")
+    t = timeit(lambda i: amcpg.sampler_func_packed(data, out, num_ls, M, R), iters, warm=1)
+    emit(tag, f"K7+K8 sampler_func_packed (num_ls={num_ls})", "chain-sweeps", C * num_ls, t, 2 * (n // 8) / num_ls,
+         "bytes = packed tile in + out")
+    emit(tag, f"K7+K8 sampler_func_packed (num_ls={num_ls})", "node updates", C * n * num_ls, t, None, f"C={C} chains")
+    vs0 = torch.zeros(M, device=dev)
+    rnd = amcpg.MCPGRound(data, kept.clone(), vs0, M, R, num_ls)
+    t = timeit(lambda i: rnd.step(probs), iters, warm=1)
+    emit(tag, "MCPG round on device (metro + sampler + best-merge)", "kept chains (reference's num_samples)", M, t, None,
+         f"M={M}, R={R}: the reference's num_samples_per_second = M / round time")
+    val = torch.randn(C, device=dev)
+    pr = torch.full((n,), 0.4, device=dev, requires_grad=True)
+
+    def ret(i):
+        o = amcpg.get_return(pr, out, val)
+        o.backward()
+    t = timeit(ret, iters, warm=1)
+    emit(tag, "get_return forward + backward from bit sums", "chains", C, t, n // 8, "bytes = the packed samples")
 
 
 def tsp_suite(tag, N, B, iters):
@@ -166,13 +192,23 @@ def qubo_suite(tag, n, C, num_ls, iters):
 
 
 it = 5 if (a.quick or a.profile) else 30
-maxcut_suite("G22-sized G(2000,19990), B=2^16", 2000, 19990, 1 << 16, 22, it)
-local_search_suite("G22-sized, dREINFORCE batch", 2000, 19990, 22, 4096, max(2, it // 5))
-local_search_suite("G22-sized, dREINFORCE batch x16", 2000, 19990, 22, 65536, max(2, it // 5))
-maxcut_suite("G70-sized G(10000,9999), B=2^17 (one GPU's shard of 2^20)", 10000, 9999, 1 << 17, 70, max(3, it // 3))
-maxcut_suite("G14-sized G(800,4694), B=256", 800, 4694, 256, 14, it)
-tsp_suite("TSP-100 uniform, B=2^16", 100, 1 << 16, it)
-spin_suite("G22-sized +-1 weighted, B=2^14", 2000, 19990, 1 << 14, 64, it)
-spin_suite("BA-200-sized (ECO), B=4096", 200, 784, 4096, 400, it)
-qubo_suite("nbiq-style dense QUBO n=1000, 2^13 chains", 1000, 1 << 13, 2, 2)
-mcpg_suite("BA n=10^4 m=5, 2^18 chains", 10000, 5, 1 << 18 if not a.quick else 1 << 14, 8, 2)
+only = set(w for w in a.only.split(",") if w)
+want = lambda k: not only or k in only
+if want("maxcut"):
+    maxcut_suite("G22-sized G(2000,19990), B=2^16", 2000, 19990, 1 << 16, 22, it)
+if want("ls"):
+    local_search_suite("G22-sized, dREINFORCE batch", 2000, 19990, 22, 4096, max(2, it // 5))
+    local_search_suite("G22-sized, dREINFORCE batch x16", 2000, 19990, 22, 65536, max(2, it // 5))
+if want("g70"):
+    maxcut_suite("G70-sized G(10000,9999), B=2^17 (one GPU's shard of 2^20)", 10000, 9999, 1 << 17, 70, max(3, it // 3))
+if want("g14"):
+    maxcut_suite("G14-sized G(800,4694), B=256", 800, 4694, 256, 14, it)
+if want("tsp"):
+    tsp_suite("TSP-100 uniform, B=2^16", 100, 1 << 16, it)
+if want("spin"):
+    spin_suite("G22-sized +-1 weighted, B=2^14", 2000, 19990, 1 << 14, 64, it)
+    spin_suite("BA-200-sized (ECO), B=4096", 200, 784, 4096, 400, it)
+if want("qubo"):
+    qubo_suite("nbiq-style dense QUBO n=1000, 2^13 chains", 1000, 1 << 13, 2, 2)
+if want("mcpg"):
+    mcpg_suite("BA n=10^4 m=5, 2^18 chains", 10000, 5, 1 << 18 if not a.quick else 1 << 14, 8, 2)
