@@ -160,7 +160,6 @@ def main():
         env = EnvMaxcutGym(types.SimpleNamespace(num_nodes=N, num_envs=B, num_steps=10 ** 9), mygraph=mygraph, device=dev,
                            spin_dtype=torch.bool, reuse_buffers=True)
         env.xs, env._obj = slots[0], obj        # same initial state as the launcher mode
-        env.graph = g
 
         def step(t):
             env.step(actions[t % A], out=slots[(t + 1) % S])

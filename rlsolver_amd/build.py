@@ -17,6 +17,9 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 INCLUDE = os.path.join(ROOT, "include")
 LIB_NAME = "librlsolver_hip.so"
 LIB_PATH = os.path.join(PKG_DIR, LIB_NAME)
+OPS_NAME = "librlsolver_torch_ops.so"       # torch.ops.rlsolver_hip.*: host-only C++ over the C ABI (csrc/torch_ops.cpp)
+OPS_PATH = os.path.join(PKG_DIR, OPS_NAME)
+OPS_SRC = os.path.join(CSRC, "torch_ops.cpp")
 ARCH = "gfx950"
 
 SOURCES = ["rls_abi.hip", "rls_maxcut.hip", "rls_step.hip", "rls_mcpg.hip", "rls_tsp.hip", "rls_qubo.hip", "rls_spin.hip", "rls_localsearch.hip", "rls_isco.hip", "rls_track.hip"]
@@ -45,6 +48,36 @@ def is_stale() -> bool:
         return True
     t = os.path.getmtime(LIB_PATH)
     return any(os.path.getmtime(d) > t for d in _deps())
+
+
+def ops_is_stale() -> bool:
+    if not os.path.exists(OPS_PATH):
+        return True
+    t = os.path.getmtime(OPS_PATH)
+    deps = [OPS_SRC, LIB_PATH] + [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE) if f.endswith(".h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_torch_ops(force: bool = False, verbose: bool = False) -> str:
+    """Compile csrc/torch_ops.cpp (no device code) against libtorch and link it to librlsolver_hip.so, in-tree."""
+    if not force and not ops_is_stale():
+        return OPS_PATH
+    import torch
+    from torch.utils import cpp_extension as ce
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cxx = shutil.which("g++") or "g++"
+    cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", "-Wno-deprecated-declarations"]
+    cmd += [f"-I{p}" for p in ce.include_paths()] + [f"-I{rocm}/include", f"-I{INCLUDE}"]
+    cmd += [OPS_SRC, "-o", OPS_PATH, f"-L{tlib}", "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch", f"-L{PKG_DIR}",
+            "-lrlsolver_hip", "-Wl,-rpath,$ORIGIN", f"-Wl,-rpath,{tlib}"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"building {OPS_NAME} failed:\n{r.stdout}")
+    return OPS_PATH
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -84,3 +117,4 @@ def build(force: bool = False, verbose: bool = False) -> str:
 if __name__ == "__main__":
     path = build(force="--force" in sys.argv, verbose=True)
     print("built", path)
+    print("built", build_torch_ops(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,457 @@
+// torch.ops.rlsolver_hip.* -- every DEVICE entry point of include/rlsolver_hip.h as a native PyTorch custom op
+// (north_star: "hand-written HIP kernels through PyTorch-ROCm custom ops over a thin C-ABI").
+//
+// Thin by construction: an op checks device / dtype / contiguity, takes torch's CURRENT HIP stream and calls the
+// C-ABI function of the same name in librlsolver_hip.so.  Outputs are caller-allocated and mutated in place, exactly
+// like the C ABI (allocation conveniences live in rlsolver_amd/ops.py).  Only the HIP dispatch key gets an
+// implementation ("CUDA" is what PyTorch-ROCm calls it): CPU tensors end in the dispatcher's NotImplementedError.
+// The shared graph and the spin-system env travel as integer handles = addresses of the host structs rls_graph /
+// rls_spin_env (op schemas cannot carry a struct of device pointers).
+//
+// No kernels here: compiled with the host compiler against libtorch, linked against librlsolver_hip.so.
+#include <ATen/ATen.h>
+#include <c10/hip/HIPStream.h>
+#include <torch/library.h>
+
+#include <optional>
+
+#include "rlsolver_hip.h"
+
+namespace {
+
+using at::Tensor;
+using OptTensor = std::optional<Tensor>;
+
+inline void* cur_stream(const Tensor& t) { return (void*)c10::hip::getCurrentHIPStream(t.get_device()).stream(); }
+
+inline void ok(int rc, const char* fn) {
+    TORCH_CHECK(rc == RLS_OK, fn, " failed (", rc, "): ", rls_last_error_string());
+}
+
+inline const rls_graph* G(int64_t handle) {
+    TORCH_CHECK(handle != 0, "rlsolver_hip: null graph handle");
+    return reinterpret_cast<const rls_graph*>(handle);
+}
+
+inline void dev(const Tensor& t, const char* name) {
+    TORCH_CHECK(t.is_cuda(), name, " must live on a HIP device; rlsolver_hip has no CPU path");
+    TORCH_CHECK(t.is_contiguous(), name, " must be contiguous");
+}
+inline void dev(const Tensor& t, const char* name, at::ScalarType dt) {
+    dev(t, name);
+    TORCH_CHECK(t.scalar_type() == dt, name, " has dtype ", t.scalar_type(), ", expected ", dt);
+}
+inline void* p(const Tensor& t) { return t.data_ptr(); }
+inline void* p(const OptTensor& t) { return t.has_value() ? t->data_ptr() : nullptr; }
+inline void optdev(const OptTensor& t, const char* name, at::ScalarType dt) {
+    if (t.has_value()) dev(*t, name, dt);
+}
+// spins: bool / uint8 (1 byte) or float32 (4 bytes); -> spin_bytes
+inline int spin_bytes(const Tensor& t, const char* name, bool allow_f32) {
+    dev(t, name);
+    if (t.scalar_type() == at::kBool || t.scalar_type() == at::kByte) return 1;
+    TORCH_CHECK(allow_f32 && t.scalar_type() == at::kFloat, name, " must be bool / uint8", allow_f32 ? " / float32" : "");
+    return 4;
+}
+// chain batches: float32 / uint8 / bool node-major, or int64 = bit-packed tiles (spin_bytes 0)
+inline int chain_bytes(const Tensor& t, const char* name) {
+    dev(t, name);
+    if (t.scalar_type() == at::kLong) return 0;
+    if (t.scalar_type() == at::kFloat) return 4;
+    TORCH_CHECK(t.scalar_type() == at::kBool || t.scalar_type() == at::kByte, name, " must be float32 / uint8 / bool / int64 (bit-packed)");
+    return 1;
+}
+
+constexpr auto I64 = at::kLong;
+constexpr auto I32 = at::kInt;
+constexpr auto F32 = at::kFloat;
+constexpr auto F64 = at::kDouble;
+constexpr auto U8 = at::kByte;
+
+// ------------------------------------------------------------------------------------------------ MaxCut
+void maxcut_obj(int64_t g, const Tensor& xs, Tensor obj) {
+    const int sb = spin_bytes(xs, "xs", true);
+    dev(obj, "obj", I64);
+    ok(rls_maxcut_obj(G(g), p(xs), sb, xs.size(0), (int64_t*)p(obj), cur_stream(xs)), "rls_maxcut_obj");
+}
+void maxcut_edge_cut_mask(int64_t g, const Tensor& xs, Tensor mask) {
+    spin_bytes(xs, "xs", false);
+    dev(mask, "mask");
+    ok(rls_maxcut_edge_cut_mask(G(g), (const uint8_t*)p(xs), xs.size(0), (uint8_t*)p(mask), cur_stream(xs)), "rls_maxcut_edge_cut_mask");
+}
+void maxcut_node_cutdeg(int64_t g, const Tensor& xs, Tensor out) {
+    spin_bytes(xs, "xs", false);
+    dev(out, "out", I64);
+    ok(rls_maxcut_node_cutdeg(G(g), (const uint8_t*)p(xs), xs.size(0), (int64_t*)p(out), cur_stream(xs)), "rls_maxcut_node_cutdeg");
+}
+void maxcut_delta_all(int64_t g, const Tensor& xs, Tensor out) {
+    spin_bytes(xs, "xs", false);
+    dev(out, "out", I32);
+    ok(rls_maxcut_delta_all(G(g), (const uint8_t*)p(xs), xs.size(0), (int32_t*)p(out), cur_stream(xs)), "rls_maxcut_delta_all");
+}
+void maxcut_step(int64_t g, const Tensor& x_in, Tensor x_out, const Tensor& action, Tensor obj, Tensor reward,
+                 const OptTensor& cur, const OptTensor& done, double done_value) {
+    const int sb = spin_bytes(x_in, "x_in", true);
+    TORCH_CHECK(spin_bytes(x_out, "x_out", true) == sb && x_out.sizes() == x_in.sizes(), "x_in and x_out must have the same shape and dtype");
+    dev(action, "action", I64);
+    dev(obj, "obj", I32);
+    dev(reward, "reward", F32);
+    optdev(cur, "cur", F32);
+    optdev(done, "done", F32);
+    ok(rls_maxcut_step(G(g), p(x_in), p(x_out), sb, x_in.size(0), (const int64_t*)p(action), (int32_t*)p(obj), (float*)p(reward),
+                       (float*)p(cur), (float*)p(done), (float)done_value, cur_stream(x_in)), "rls_maxcut_step");
+}
+void maxcut_greedy_sweep(int64_t g, Tensor xs, Tensor obj) {
+    spin_bytes(xs, "xs", false);
+    dev(obj, "obj", I64);
+    ok(rls_maxcut_greedy_sweep(G(g), (uint8_t*)p(xs), xs.size(0), (int64_t*)p(obj), cur_stream(xs)), "rls_maxcut_greedy_sweep");
+}
+void maxcut_propose_accept(int64_t g, Tensor xs, const Tensor& mask, Tensor obj) {
+    spin_bytes(xs, "xs", false);
+    spin_bytes(mask, "mask", false);
+    dev(obj, "obj", I64);
+    ok(rls_maxcut_propose_accept(G(g), (uint8_t*)p(xs), xs.size(0), (const uint8_t*)p(mask), (int64_t*)p(obj), cur_stream(xs)),
+       "rls_maxcut_propose_accept");
+}
+void maxcut_ls_weights(int64_t g, const Tensor& xs, int64_t mult, Tensor ws) {
+    spin_bytes(xs, "xs", false);
+    dev(ws, "ws", I32);
+    ok(rls_maxcut_ls_weights(G(g), (const uint8_t*)p(xs), xs.size(0), (int32_t)mult, (int32_t*)p(ws), cur_stream(xs)), "rls_maxcut_ls_weights");
+}
+void maxcut_local_search(int64_t g, Tensor xs, const Tensor& ws, const Tensor& rd_std, const OptTensor& noise, int64_t seed,
+                         int64_t env_offset, int64_t num_iters, int64_t num_spin, bool first_draw_proposes, Tensor obj, bool compute_obj) {
+    spin_bytes(xs, "xs", false);
+    dev(ws, "ws", I32);
+    dev(rd_std, "rd_std", F32);
+    optdev(noise, "noise", F32);
+    dev(obj, "obj", I64);
+    ok(rls_maxcut_local_search(G(g), (uint8_t*)p(xs), xs.size(0), (const int32_t*)p(ws), (const float*)p(rd_std), (const float*)p(noise),
+                               (uint64_t)seed, env_offset, (int32_t)num_iters, (int32_t)num_spin, first_draw_proposes, (int64_t*)p(obj),
+                               compute_obj, cur_stream(xs)), "rls_maxcut_local_search");
+}
+void select_better_rows(Tensor xs0, Tensor vs0, const Tensor& xs1, const Tensor& vs1, bool if_maximize) {
+    spin_bytes(xs0, "xs0", false);
+    spin_bytes(xs1, "xs1", false);
+    dev(vs0, "vs0", I64);
+    dev(vs1, "vs1", I64);
+    ok(rls_select_better_rows((uint8_t*)p(xs0), (int64_t*)p(vs0), (const uint8_t*)p(xs1), (const int64_t*)p(vs1), xs0.size(0), xs0.size(1),
+                              if_maximize, cur_stream(xs0)), "rls_select_better_rows");
+}
+void pick_best_of_repeats(const Tensor& xs, const Tensor& vs, int64_t R, bool if_maximize, Tensor good_xs, Tensor good_vs) {
+    spin_bytes(xs, "xs", false);
+    spin_bytes(good_xs, "good_xs", false);
+    dev(vs, "vs", I64);
+    dev(good_vs, "good_vs", I64);
+    TORCH_CHECK(R > 0 && xs.size(0) % R == 0, "xs must be [R*S, N]");
+    ok(rls_pick_best_of_repeats((const uint8_t*)p(xs), (const int64_t*)p(vs), R, xs.size(0) / R, xs.size(1), if_maximize, (uint8_t*)p(good_xs),
+                                (int64_t*)p(good_vs), cur_stream(xs)), "rls_pick_best_of_repeats");
+}
+void copy_rows(Tensor xs, const OptTensor& vs, const Tensor& dst, const Tensor& src) {
+    spin_bytes(xs, "xs", false);
+    optdev(vs, "vs", I64);
+    dev(dst, "dst", I64);
+    dev(src, "src", I64);
+    ok(rls_copy_rows((uint8_t*)p(xs), (int64_t*)p(vs), xs.size(1), (const int64_t*)p(dst), (const int64_t*)p(src), dst.numel(), cur_stream(xs)),
+       "rls_copy_rows");
+}
+void best_update(const Tensor& xs, const Tensor& vs, bool if_maximize, Tensor best_x, Tensor best_v, Tensor improved, const OptTensor& log_v,
+                 int64_t log_index, bool force) {
+    spin_bytes(xs, "xs", false);
+    dev(vs, "vs");
+    const int kind = vs.scalar_type() == I64 ? 0 : (vs.scalar_type() == F32 ? 1 : 2);
+    TORCH_CHECK(kind != 2 || vs.scalar_type() == F64, "vs must be int64 / float32 / float64");
+    spin_bytes(best_x, "best_x", false);
+    dev(best_v, "best_v", F64);
+    dev(improved, "improved", U8);
+    optdev(log_v, "log_v", F64);
+    ok(rls_best_update((const uint8_t*)p(xs), p(vs), kind, vs.numel(), best_x.numel(), if_maximize, (uint8_t*)p(best_x), (double*)p(best_v),
+                       (uint8_t*)p(improved), (double*)p(log_v), log_index, force, cur_stream(xs)), "rls_best_update");
+}
+void rand_spins(Tensor x, int64_t seed, int64_t env_offset) {
+    spin_bytes(x, "x", false);
+    ok(rls_rand_spins((uint8_t*)p(x), x.size(0), x.size(1), (uint64_t)seed, env_offset, cur_stream(x)), "rls_rand_spins");
+}
+void rand_actions(Tensor action, int64_t N, int64_t seed, int64_t step, int64_t env_offset) {
+    dev(action, "action", I64);
+    ok(rls_rand_actions((int64_t*)p(action), action.numel(), N, (uint64_t)seed, (uint64_t)step, env_offset, cur_stream(action)), "rls_rand_actions");
+}
+void rand_perms(Tensor perm, int64_t seed, int64_t env_offset) {
+    dev(perm, "perm", I64);
+    ok(rls_rand_perms((int64_t*)p(perm), perm.size(0), perm.size(1), (uint64_t)seed, env_offset, cur_stream(perm)), "rls_rand_perms");
+}
+
+// ------------------------------------------------------------------------------------------------ spin system
+void spin_reset(int64_t g, int64_t env, const Tensor& state, const Tensor& row_index, double max_local, int64_t weight_sum) {
+    dev(state, "state");
+    TORCH_CHECK(!row_index.is_cuda() && row_index.scalar_type() == I32 && row_index.numel() == 7, "row_index must be a host int32[7]");
+    const int sb = state.scalar_type() == F64 ? 8 : 4;
+    ok(rls_spin_reset(G(g), reinterpret_cast<const rls_spin_env*>(env), sb, state.size(0), (int32_t)state.size(1), (const int32_t*)p(row_index),
+                      max_local, weight_sum, cur_stream(state)), "rls_spin_reset");
+}
+void spin_step(int64_t g, int64_t env, const Tensor& state, const Tensor& row_index, const Tensor& action, Tensor reward,
+               const OptTensor& visited_new, double max_local, double time_inc, double termination_value, int64_t reward_mode,
+               double reward_div, int64_t hist_len, bool use_stag, double stag_punishment, bool use_basin, double basin_reward) {
+    dev(state, "state");
+    dev(action, "action", I64);
+    dev(reward, "reward", state.scalar_type());
+    optdev(visited_new, "visited_new", U8);
+    TORCH_CHECK(!row_index.is_cuda() && row_index.scalar_type() == I32 && row_index.numel() == 7, "row_index must be a host int32[7]");
+    const int sb = state.scalar_type() == F64 ? 8 : 4;
+    ok(rls_spin_step(G(g), reinterpret_cast<const rls_spin_env*>(env), sb, state.size(0), (int32_t)state.size(1), (const int32_t*)p(row_index),
+                     (const int64_t*)p(action), p(reward), (uint8_t*)p(visited_new), max_local, time_inc, termination_value, (int32_t)reward_mode,
+                     reward_div, hist_len, use_stag, stag_punishment, use_basin, basin_reward, cur_stream(state)), "rls_spin_step");
+}
+
+// ------------------------------------------------------------------------------------------------ MCPG
+void mcpg_metro_rounds(Tensor samples, const OptTensor& samples_in, int64_t C_in, int64_t C, const Tensor& probs, int64_t T,
+                       int64_t t_offset, const OptTensor& index, const OptTensor& u, int64_t seed, const OptTensor& t_limit, bool write_back,
+                       const OptTensor& accepts) {
+    const int sb = chain_bytes(samples, "samples");
+    if (samples_in.has_value()) TORCH_CHECK(chain_bytes(*samples_in, "samples_in") == sb, "samples_in must have the layout of samples");
+    dev(probs, "probs", F32);
+    optdev(index, "index", I64);
+    optdev(u, "u", F32);
+    optdev(t_limit, "t_limit", I64);
+    optdev(accepts, "accepts", I64);
+    const int64_t N = sb == 0 ? samples.size(1) : samples.size(0);
+    ok(rls_mcpg_metro_rounds(p(samples), p(samples_in), C_in, sb, N, C, (const float*)p(probs), T, t_offset, (const int64_t*)p(index),
+                             (const float*)p(u), (uint64_t)seed, (const int64_t*)p(t_limit), write_back, (int64_t*)p(accepts), cur_stream(samples)),
+       "rls_mcpg_metro_rounds");
+}
+void mcpg_local_search(int64_t g, const Tensor& xs_in, Tensor xs_out, const Tensor& order, const OptTensor& visit_stream, int64_t num_ls,
+                       const OptTensor& uniforms, int64_t seed, Tensor expected) {
+    const int sb = chain_bytes(xs_in, "xs_in");
+    TORCH_CHECK(sb != 0, "rls_mcpg_local_search takes node-major chains");
+    dev(xs_out, "xs_out", F32);
+    dev(order, "order", I32);
+    optdev(visit_stream, "visit_stream", I32);
+    optdev(uniforms, "uniforms", F32);
+    dev(expected, "expected", F32);
+    ok(rls_mcpg_local_search(G(g), p(xs_in), sb, (float*)p(xs_out), xs_in.size(1), (const int32_t*)p(order), (const int32_t*)p(visit_stream),
+                             visit_stream.has_value() ? visit_stream->numel() : 0, num_ls, (const float*)p(uniforms), (uint64_t)seed,
+                             (float*)p(expected), cur_stream(xs_in)), "rls_mcpg_local_search");
+}
+void mcpg_local_search_levels(int64_t g, const Tensor& xs_in, int64_t C_in, Tensor xs_out, int64_t C, const Tensor& lv_ptr,
+                              const Tensor& lv_data, int64_t num_ls, const OptTensor& coins, int64_t seed, Tensor expected) {
+    const int sb = chain_bytes(xs_in, "xs_in"), osb = chain_bytes(xs_out, "xs_out");
+    dev(lv_ptr, "lv_ptr", I32);
+    dev(lv_data, "lv_data", I32);
+    optdev(coins, "coins", I64);
+    dev(expected, "expected", F32);
+    ok(rls_mcpg_local_search_levels(G(g), p(xs_in), sb, C_in, p(xs_out), osb, C, (const int32_t*)p(lv_ptr), (const int32_t*)p(lv_data),
+                                    lv_ptr.numel() - 1, num_ls, (const uint64_t*)p(coins), (uint64_t)seed, (float*)p(expected), cur_stream(xs_in)),
+       "rls_mcpg_local_search_levels");
+}
+void mcpg_pick_best(const Tensor& expected, const Tensor& xs, int64_t N, int64_t total_mcmc_num, int64_t repeat_times, int64_t num_edges,
+                    Tensor best_index, Tensor vs_good, Tensor xs_good) {
+    dev(expected, "expected", F32);
+    const int sb = chain_bytes(xs, "xs");
+    TORCH_CHECK(chain_bytes(xs_good, "xs_good") == sb, "xs_good must have the layout of xs");
+    dev(best_index, "best_index", I64);
+    dev(vs_good, "vs_good", F32);
+    ok(rls_mcpg_pick_best((const float*)p(expected), p(xs), sb, N, total_mcmc_num, repeat_times, num_edges, (int64_t*)p(best_index),
+                          (float*)p(vs_good), p(xs_good), cur_stream(xs)), "rls_mcpg_pick_best");
+}
+void mcpg_merge_best(const Tensor& temp_max, Tensor temp_info, Tensor now_max_res, Tensor now_info, int64_t total_mcmc_num, Tensor mask_scratch,
+                     const OptTensor& best_value, const OptTensor& best_index) {
+    dev(temp_max, "temp_max", F32);
+    dev(temp_info, "temp_info", I64);
+    dev(now_max_res, "now_max_res", F32);
+    dev(now_info, "now_info", I64);
+    dev(mask_scratch, "mask_scratch", I64);
+    optdev(best_value, "best_value", F32);
+    optdev(best_index, "best_index", I64);
+    ok(rls_mcpg_merge_best((const float*)p(temp_max), (uint64_t*)p(temp_info), (float*)p(now_max_res), (uint64_t*)p(now_info), temp_info.size(1),
+                           total_mcmc_num, (uint64_t*)p(mask_scratch), (float*)p(best_value), (int64_t*)p(best_index), cur_stream(temp_info)),
+       "rls_mcpg_merge_best");
+}
+void mcpg_value_bit_sums(const Tensor& samples, int64_t C, const Tensor& value, Tensor A) {
+    dev(samples, "samples", I64);
+    dev(value, "value", F32);
+    dev(A, "A", F32);
+    ok(rls_mcpg_value_bit_sums((const uint64_t*)p(samples), samples.size(1), C, (const float*)p(value), (float*)p(A), cur_stream(samples)),
+       "rls_mcpg_value_bit_sums");
+}
+void mcpg_pack_chains(const Tensor& xs, Tensor packed) {
+    const int sb = chain_bytes(xs, "xs");
+    TORCH_CHECK(sb != 0, "xs must be node-major");
+    dev(packed, "packed", I64);
+    ok(rls_mcpg_pack_chains(p(xs), sb, xs.size(0), xs.size(1), (uint64_t*)p(packed), cur_stream(xs)), "rls_mcpg_pack_chains");
+}
+void mcpg_unpack_chains(const Tensor& packed, int64_t C, Tensor xs) {
+    dev(packed, "packed", I64);
+    dev(xs, "xs", F32);
+    ok(rls_mcpg_unpack_chains((const uint64_t*)p(packed), packed.size(1), C, (float*)p(xs), cur_stream(packed)), "rls_mcpg_unpack_chains");
+}
+void qubo_local_search_value(const Tensor& Q, const Tensor& xs_in, Tensor xs_out, int64_t num_ls, bool binary, Tensor value) {
+    dev(Q, "Q", F32);
+    dev(xs_in, "xs_in", F32);
+    dev(xs_out, "xs_out", F32);
+    dev(value, "value", F32);
+    ok(rls_qubo_local_search_value((const float*)p(Q), Q.size(0), (const float*)p(xs_in), (float*)p(xs_out), xs_in.size(1), num_ls, binary,
+                                   (float*)p(value), cur_stream(Q)), "rls_qubo_local_search_value");
+}
+
+// ------------------------------------------------------------------------------------------------ TSP / ISCO
+void tsp_tour_length(const Tensor& dist, const Tensor& perm, Tensor length) {
+    dev(dist, "dist", F32);
+    dev(perm, "perm", I64);
+    dev(length, "length", F32);
+    ok(rls_tsp_tour_length((const float*)p(dist), perm.size(1), (const int64_t*)p(perm), perm.size(0), (float*)p(length), cur_stream(perm)),
+       "rls_tsp_tour_length");
+}
+void tsp_swap_delta_all(const Tensor& dist, const Tensor& perm, const Tensor& selected, double temperature, Tensor logratio, Tensor indices,
+                        Tensor ban) {
+    dev(dist, "dist", F32);
+    dev(perm, "perm", I64);
+    dev(selected, "selected", I64);
+    dev(logratio, "logratio", F32);
+    dev(indices, "indices", I64);
+    spin_bytes(ban, "ban", false);
+    ok(rls_tsp_swap_delta_all((const float*)p(dist), perm.size(1), (const int64_t*)p(perm), perm.size(0), (const int64_t*)p(selected),
+                              (float)temperature, (float*)p(logratio), (int64_t*)p(indices), (uint8_t*)p(ban), cur_stream(perm)),
+       "rls_tsp_swap_delta_all");
+}
+void tsp_apply_swap(Tensor perm, const Tensor& pos, const Tensor& indices) {
+    dev(perm, "perm", I64);
+    dev(pos, "pos", I64);
+    dev(indices, "indices", I64);
+    ok(rls_tsp_apply_swap((int64_t*)p(perm), perm.size(0), perm.size(1), (const int64_t*)p(pos), (const int64_t*)p(indices), cur_stream(perm)),
+       "rls_tsp_apply_swap");
+}
+void tsp_2opt_delta(const Tensor& dist, const Tensor& perm, const Tensor& i, const Tensor& j, Tensor delta) {
+    dev(dist, "dist", F32);
+    dev(perm, "perm", I64);
+    dev(i, "i", I64);
+    dev(j, "j", I64);
+    dev(delta, "delta", F32);
+    ok(rls_tsp_2opt_delta((const float*)p(dist), perm.size(1), (const int64_t*)p(perm), perm.size(0), (const int64_t*)p(i), (const int64_t*)p(j),
+                          (float*)p(delta), cur_stream(perm)), "rls_tsp_2opt_delta");
+}
+void isco_maxcut_step(int64_t g, const Tensor& x, Tensor y_out, const Tensor& path_length, double temperature, const OptTensor& u_gumbel,
+                      const OptTensor& u_accept, int64_t seed, int64_t env_offset, const OptTensor& energy_out, const OptTensor& acc_out,
+                      const OptTensor& terms_out, const OptTensor& mask_out) {
+    dev(x, "x", F32);
+    dev(y_out, "y_out", F32);
+    dev(path_length, "path_length", I64);
+    optdev(u_gumbel, "u_gumbel", F32);
+    optdev(u_accept, "u_accept", F32);
+    optdev(energy_out, "energy_out", F32);
+    optdev(acc_out, "acc_out", F32);
+    optdev(terms_out, "terms_out", F32);
+    ok(rls_isco_maxcut_step(G(g), (const float*)p(x), (float*)p(y_out), x.size(0), (const int64_t*)p(path_length), (float)temperature,
+                            (const float*)p(u_gumbel), (const float*)p(u_accept), (uint64_t)seed, env_offset, (float*)p(energy_out),
+                            (float*)p(acc_out), (float*)p(terms_out), (uint8_t*)p(mask_out), cur_stream(x)), "rls_isco_maxcut_step");
+}
+void isco_tsp_step(const Tensor& dist, const Tensor& nearest, double near_threshold, const Tensor& random, const Tensor& perm_in, Tensor perm_out,
+                   int64_t path_length, double temperature, const OptTensor& u_partner, const OptTensor& r_near, const OptTensor& r_rand,
+                   const OptTensor& u_gumbel, const OptTensor& u_accept, int64_t seed, int64_t env_offset, const OptTensor& log_acc_out,
+                   const OptTensor& acc_out, const OptTensor& cur_out) {
+    dev(dist, "dist", F32);
+    dev(nearest, "nearest", I32);
+    dev(random, "random", I32);
+    dev(perm_in, "perm_in", I64);
+    dev(perm_out, "perm_out", I64);
+    optdev(u_partner, "u_partner", F32);
+    optdev(r_near, "r_near", I64);
+    optdev(r_rand, "r_rand", I64);
+    optdev(u_gumbel, "u_gumbel", F32);
+    optdev(u_accept, "u_accept", F32);
+    optdev(log_acc_out, "log_acc_out", F32);
+    optdev(acc_out, "acc_out", F32);
+    optdev(cur_out, "cur_out", I64);
+    ok(rls_isco_tsp_step((const float*)p(dist), perm_in.size(1), (const int32_t*)p(nearest), (int32_t)nearest.size(1), (float)near_threshold,
+                         (const int32_t*)p(random), (int32_t)random.size(1), (const int64_t*)p(perm_in), (int64_t*)p(perm_out), perm_in.size(0),
+                         (int32_t)path_length, (float)temperature, (const float*)p(u_partner), (const int64_t*)p(r_near), (const int64_t*)p(r_rand),
+                         (const float*)p(u_gumbel), (const float*)p(u_accept), (uint64_t)seed, env_offset, (float*)p(log_acc_out),
+                         (float*)p(acc_out), (int64_t*)p(cur_out), cur_stream(perm_in)), "rls_isco_tsp_step");
+}
+
+}  // namespace
+
+// name -> C-ABI function: the table tests/test_abi.py compares with the header's device entry points
+TORCH_LIBRARY(rlsolver_hip, m) {
+    m.def("maxcut_obj(int graph, Tensor xs, Tensor(a!) obj) -> ()");
+    m.def("maxcut_edge_cut_mask(int graph, Tensor xs, Tensor(a!) mask) -> ()");
+    m.def("maxcut_node_cutdeg(int graph, Tensor xs, Tensor(a!) out) -> ()");
+    m.def("maxcut_delta_all(int graph, Tensor xs, Tensor(a!) out) -> ()");
+    m.def("maxcut_step(int graph, Tensor x_in, Tensor(a!) x_out, Tensor action, Tensor(b!) obj, Tensor(c!) reward, Tensor(d!)? cur, "
+          "Tensor(e!)? done, float done_value) -> ()");
+    m.def("maxcut_greedy_sweep(int graph, Tensor(a!) xs, Tensor(b!) obj) -> ()");
+    m.def("maxcut_propose_accept(int graph, Tensor(a!) xs, Tensor mask, Tensor(b!) obj) -> ()");
+    m.def("maxcut_ls_weights(int graph, Tensor xs, int mult, Tensor(a!) ws) -> ()");
+    m.def("maxcut_local_search(int graph, Tensor(a!) xs, Tensor ws, Tensor rd_std, Tensor? noise, int seed, int env_offset, int num_iters, "
+          "int num_spin, bool first_draw_proposes, Tensor(b!) obj, bool compute_obj) -> ()");
+    m.def("select_better_rows(Tensor(a!) xs0, Tensor(b!) vs0, Tensor xs1, Tensor vs1, bool if_maximize) -> ()");
+    m.def("pick_best_of_repeats(Tensor xs, Tensor vs, int R, bool if_maximize, Tensor(a!) good_xs, Tensor(b!) good_vs) -> ()");
+    m.def("copy_rows(Tensor(a!) xs, Tensor(b!)? vs, Tensor dst, Tensor src) -> ()");
+    m.def("best_update(Tensor xs, Tensor vs, bool if_maximize, Tensor(a!) best_x, Tensor(b!) best_v, Tensor(c!) improved, Tensor(d!)? log_v, "
+          "int log_index, bool force) -> ()");
+    m.def("rand_spins(Tensor(a!) x, int seed, int env_offset) -> ()");
+    m.def("rand_actions(Tensor(a!) action, int N, int seed, int step, int env_offset) -> ()");
+    m.def("rand_perms(Tensor(a!) perm, int seed, int env_offset) -> ()");
+    m.def("spin_reset(int graph, int env, Tensor(a!) state, Tensor row_index, float max_local, int weight_sum) -> ()");
+    m.def("spin_step(int graph, int env, Tensor(a!) state, Tensor row_index, Tensor action, Tensor(b!) reward, Tensor(c!)? visited_new, "
+          "float max_local, float time_inc, float termination_value, int reward_mode, float reward_div, int hist_len, bool use_stag, "
+          "float stag_punishment, bool use_basin, float basin_reward) -> ()");
+    m.def("mcpg_metro_rounds(Tensor(a!) samples, Tensor? samples_in, int C_in, int C, Tensor probs, int T, int t_offset, Tensor? index, "
+          "Tensor? u, int seed, Tensor? t_limit, bool write_back, Tensor(b!)? accepts) -> ()");
+    m.def("mcpg_local_search(int graph, Tensor xs_in, Tensor(a!) xs_out, Tensor order, Tensor? visit_stream, int num_ls, Tensor? uniforms, "
+          "int seed, Tensor(b!) expected) -> ()");
+    m.def("mcpg_local_search_levels(int graph, Tensor xs_in, int C_in, Tensor(a!) xs_out, int C, Tensor lv_ptr, Tensor lv_data, int num_ls, "
+          "Tensor? coins, int seed, Tensor(b!) expected) -> ()");
+    m.def("mcpg_pick_best(Tensor expected, Tensor xs, int N, int total_mcmc_num, int repeat_times, int num_edges, Tensor(a!) best_index, "
+          "Tensor(b!) vs_good, Tensor(c!) xs_good) -> ()");
+    m.def("mcpg_merge_best(Tensor temp_max, Tensor(a!) temp_info, Tensor(b!) now_max_res, Tensor(c!) now_info, int total_mcmc_num, "
+          "Tensor(d!) mask_scratch, Tensor(e!)? best_value, Tensor(f!)? best_index) -> ()");
+    m.def("mcpg_value_bit_sums(Tensor samples, int C, Tensor value, Tensor(a!) A) -> ()");
+    m.def("mcpg_pack_chains(Tensor xs, Tensor(a!) packed) -> ()");
+    m.def("mcpg_unpack_chains(Tensor packed, int C, Tensor(a!) xs) -> ()");
+    m.def("qubo_local_search_value(Tensor Q, Tensor xs_in, Tensor(a!) xs_out, int num_ls, bool binary, Tensor(b!) value) -> ()");
+    m.def("tsp_tour_length(Tensor dist, Tensor perm, Tensor(a!) length) -> ()");
+    m.def("tsp_swap_delta_all(Tensor dist, Tensor perm, Tensor selected, float temperature, Tensor(a!) logratio, Tensor(b!) indices, "
+          "Tensor(c!) ban) -> ()");
+    m.def("tsp_apply_swap(Tensor(a!) perm, Tensor pos, Tensor indices) -> ()");
+    m.def("tsp_2opt_delta(Tensor dist, Tensor perm, Tensor i, Tensor j, Tensor(a!) delta) -> ()");
+    m.def("isco_maxcut_step(int graph, Tensor x, Tensor(a!) y_out, Tensor path_length, float temperature, Tensor? u_gumbel, Tensor? u_accept, "
+          "int seed, int env_offset, Tensor(b!)? energy_out, Tensor(c!)? acc_out, Tensor(d!)? terms_out, Tensor(e!)? mask_out) -> ()");
+    m.def("isco_tsp_step(Tensor dist, Tensor nearest, float near_threshold, Tensor random, Tensor perm_in, Tensor(a!) perm_out, int path_length, "
+          "float temperature, Tensor? u_partner, Tensor? r_near, Tensor? r_rand, Tensor? u_gumbel, Tensor? u_accept, int seed, int env_offset, "
+          "Tensor(b!)? log_acc_out, Tensor(c!)? acc_out, Tensor(d!)? cur_out) -> ()");
+}
+
+TORCH_LIBRARY_IMPL(rlsolver_hip, CUDA, m) {   // "CUDA" is the HIP dispatch key on PyTorch-ROCm
+    m.impl("maxcut_obj", &maxcut_obj);
+    m.impl("maxcut_edge_cut_mask", &maxcut_edge_cut_mask);
+    m.impl("maxcut_node_cutdeg", &maxcut_node_cutdeg);
+    m.impl("maxcut_delta_all", &maxcut_delta_all);
+    m.impl("maxcut_step", &maxcut_step);
+    m.impl("maxcut_greedy_sweep", &maxcut_greedy_sweep);
+    m.impl("maxcut_propose_accept", &maxcut_propose_accept);
+    m.impl("maxcut_ls_weights", &maxcut_ls_weights);
+    m.impl("maxcut_local_search", &maxcut_local_search);
+    m.impl("select_better_rows", &select_better_rows);
+    m.impl("pick_best_of_repeats", &pick_best_of_repeats);
+    m.impl("copy_rows", &copy_rows);
+    m.impl("best_update", &best_update);
+    m.impl("rand_spins", &rand_spins);
+    m.impl("rand_actions", &rand_actions);
+    m.impl("rand_perms", &rand_perms);
+    m.impl("spin_reset", &spin_reset);
+    m.impl("spin_step", &spin_step);
+    m.impl("mcpg_metro_rounds", &mcpg_metro_rounds);
+    m.impl("mcpg_local_search", &mcpg_local_search);
+    m.impl("mcpg_local_search_levels", &mcpg_local_search_levels);
+    m.impl("mcpg_pick_best", &mcpg_pick_best);
+    m.impl("mcpg_merge_best", &mcpg_merge_best);
+    m.impl("mcpg_value_bit_sums", &mcpg_value_bit_sums);
+    m.impl("mcpg_pack_chains", &mcpg_pack_chains);
+    m.impl("mcpg_unpack_chains", &mcpg_unpack_chains);
+    m.impl("qubo_local_search_value", &qubo_local_search_value);
+    m.impl("tsp_tour_length", &tsp_tour_length);
+    m.impl("tsp_swap_delta_all", &tsp_swap_delta_all);
+    m.impl("tsp_apply_swap", &tsp_apply_swap);
+    m.impl("tsp_2opt_delta", &tsp_2opt_delta);
+    m.impl("isco_maxcut_step", &isco_maxcut_step);
+    m.impl("isco_tsp_step", &isco_tsp_step);
+}

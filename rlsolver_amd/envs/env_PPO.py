@@ -11,7 +11,7 @@ from typing import Optional
 
 import torch as th
 
-from .. import ops
+from .. import ops, torch_ops
 from ..graph import MyGraph, build_csr
 from .env_L2A import _seed_from_torch
 
@@ -39,6 +39,8 @@ class EnvMaxcut:
         self.num_edges = len(mygraph)
         csr = build_csr(mygraph, num_nodes=self.num_nodes, if_bidirectional=if_bidirectional)
         self.graph = ops.DeviceGraph(csr, self.device)
+        self._gh = torch_ops.graph_handle(self.graph)
+        self._step_op = torch_ops.ops.maxcut_step       # native custom op: the launch-bound path of this class
         self.n0_ids = self.graph.eu.to(th.long)[None, :]
         self.n1_ids = self.graph.ev.to(th.long)[None, :]
         B = self.num_envs
@@ -74,7 +76,7 @@ class EnvMaxcut:
         else:
             done_value = 0.0
         dst = self.xs if out is None else out
-        ops.maxcut_step(self.graph, self.xs, dst, action, self._obj, reward, cur, next_done, done_value)
+        self._step_op(self._gh, self.xs, dst, action, self._obj, reward, cur, next_done, done_value)
         self.xs = dst
         self.last_reward = cur
         return self.xs, reward, next_done, cur

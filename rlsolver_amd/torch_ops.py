@@ -1,70 +1,57 @@
-"""The kernels as PyTorch custom ops: ``torch.ops.rlsolver_hip.*``.
+"""The kernels as native PyTorch custom ops: ``torch.ops.rlsolver_hip.*``.
 
-north_star asks for "hand-written HIP kernels through PyTorch-ROCm custom ops over a thin C-ABI":
-this module registers the hot-path entry points with ``torch.library`` (dispatch key CUDA = HIP on
-ROCm) so they appear in the dispatcher, profiler traces and ``torch.ops``.  Only the CUDA/HIP key
-gets an implementation -- calling an op with CPU tensors raises NotImplementedError from the
-dispatcher (no CPU fallback).  The shared graph is passed as an integer handle from
-``register_graph`` because op schemas cannot carry a struct of device pointers.
+north_star asks for "hand-written HIP kernels through PyTorch-ROCm custom ops over a thin C-ABI".  The ops are C++
+(``csrc/torch_ops.cpp`` -> ``librlsolver_torch_ops.so``, built in-tree by ``rlsolver_amd.build``): one op per DEVICE
+entry point of ``include/rlsolver_hip.h``, same name without the ``rls_`` prefix, same argument order minus what a
+tensor already carries (sizes, spin_bytes, the stream = torch's current HIP stream).  Outputs are caller-allocated
+(``Tensor(a!)``), like the C ABI.  Only the HIP dispatch key is implemented: CPU tensors raise NotImplementedError
+from the dispatcher.
 
-The env classes call ``rlsolver_amd.ops`` directly (same C ABI, one dispatcher hop less).
+The shared graph (and the spin-system env) travel as integer handles -- ``graph_handle(g)`` is the address of the
+host-side ``struct rls_graph`` that the DeviceGraph keeps alive.
+
+``ops.py`` / ``ops_mcpg_tsp.py`` bind the same C ABI through ctypes; the launch-bound paths (the gym step) call these
+ops instead: a dispatcher call costs about a third of a ctypes call with twelve converted arguments.
 """
 from __future__ import annotations
 
-import itertools
-from typing import Dict
+import ctypes as C
+import os
 
 import torch
 
-from . import ops
+from . import _abi
 
-_graphs: Dict[int, ops.DeviceGraph] = {}
-_next = itertools.count(1)
+_PKG = os.path.dirname(os.path.abspath(__file__))
+OPS_PATH = os.path.join(_PKG, "librlsolver_torch_ops.so")
 
+if not os.path.exists(OPS_PATH):
+    raise ImportError(f"{OPS_PATH} is missing: the torch.ops extension has not been built "
+                      "(run `python -m rlsolver_amd.build`); rlsolver_amd has no fallback for it")
+_abi.lib()                                   # librlsolver_hip.so first (the ops library links against it by rpath)
+torch.ops.load_library(OPS_PATH)
+ops = torch.ops.rlsolver_hip
 
-def register_graph(g: ops.DeviceGraph) -> int:
-    h = next(_next)
-    _graphs[h] = g
-    return h
-
-
-def release_graph(handle: int) -> None:
-    _graphs.pop(handle, None)
-
-
-def _g(handle: int) -> ops.DeviceGraph:
-    try:
-        return _graphs[handle]
-    except KeyError:
-        raise RuntimeError(f"unknown rlsolver_hip graph handle {handle}") from None
-
-
-_lib = torch.library.Library("rlsolver_hip", "DEF")
-_lib.define("maxcut_obj(int graph, Tensor xs) -> Tensor")
-_lib.define("maxcut_delta_all(int graph, Tensor xs) -> Tensor")
-_lib.define("maxcut_node_cutdeg(int graph, Tensor xs) -> Tensor")
-_lib.define("maxcut_step(int graph, Tensor x_in, Tensor(a!) x_out, Tensor action, Tensor(b!) obj, "
-            "Tensor(c!) reward) -> ()")
-_lib.define("maxcut_greedy_sweep(int graph, Tensor(a!) xs, Tensor(b!) obj) -> ()")
-_lib.define("maxcut_propose_accept(int graph, Tensor(a!) xs, Tensor mask, Tensor(b!) obj) -> ()")
-_lib.define("select_better_rows(Tensor(a!) xs0, Tensor(b!) vs0, Tensor xs1, Tensor vs1, bool if_maximize) -> ()")
-_lib.define("tsp_tour_length(Tensor dist, Tensor perm) -> Tensor")
-
-_impl = torch.library.Library("rlsolver_hip", "IMPL", "CUDA")
-_impl.impl("maxcut_obj", lambda graph, xs: ops.maxcut_obj(_g(graph), xs))
-_impl.impl("maxcut_delta_all", lambda graph, xs: ops.maxcut_delta_all(_g(graph), xs))
-_impl.impl("maxcut_node_cutdeg", lambda graph, xs: ops.maxcut_node_cutdeg(_g(graph), xs))
-_impl.impl("maxcut_step", lambda graph, x_in, x_out, action, obj, reward:
-           ops.maxcut_step(_g(graph), x_in, x_out, action, obj, reward))
-_impl.impl("maxcut_greedy_sweep", lambda graph, xs, obj: ops.maxcut_greedy_sweep(_g(graph), xs, obj))
-_impl.impl("maxcut_propose_accept", lambda graph, xs, mask, obj: ops.maxcut_propose_accept(_g(graph), xs, mask, obj))
-_impl.impl("select_better_rows", lambda xs0, vs0, xs1, vs1, if_maximize:
-           ops.select_better_rows(xs0, vs0, xs1, vs1, if_maximize))
+# C-ABI device entry point -> op name (tests/test_abi.py checks this list against the header)
+DEVICE_ENTRY_POINTS = [
+    "maxcut_obj", "maxcut_edge_cut_mask", "maxcut_node_cutdeg", "maxcut_delta_all", "maxcut_step", "maxcut_greedy_sweep",
+    "maxcut_propose_accept", "maxcut_ls_weights", "maxcut_local_search", "select_better_rows", "pick_best_of_repeats", "copy_rows",
+    "best_update", "rand_spins", "rand_actions", "rand_perms", "spin_reset", "spin_step", "mcpg_metro_rounds", "mcpg_local_search",
+    "mcpg_local_search_levels", "mcpg_pick_best", "mcpg_merge_best", "mcpg_value_bit_sums", "mcpg_pack_chains", "mcpg_unpack_chains",
+    "qubo_local_search_value", "tsp_tour_length", "tsp_swap_delta_all", "tsp_apply_swap", "tsp_2opt_delta", "isco_maxcut_step",
+    "isco_tsp_step",
+]
+# declared in the header but not device work: host-side schedule builders and queries (plain C calls, no op)
+HOST_ENTRY_POINTS = [
+    "version", "last_error_string", "device_count", "graph_sweep_schedule", "graph_sweep_levels", "graph_ell", "graph_sweep_batches",
+    "mcpg_visit_levels", "maxcut_local_search_supported", "mcpg_local_search_levels_supported",
+]
 
 
-def _tsp_len(dist, perm):
-    from . import ops_mcpg_tsp as mops
-    return mops.tsp_tour_length(dist, perm)
+def graph_handle(g) -> int:
+    """Integer handle of a DeviceGraph for the ``graph`` argument of the ops (address of its host struct)."""
+    return C.addressof(g.struct)
 
 
-_impl.impl("tsp_tour_length", _tsp_len)
+def struct_handle(s: C.Structure) -> int:
+    return C.addressof(s)

@@ -82,6 +82,27 @@ def test_ctypes_argument_types_match_header():
             assert g is want(p), f"{name} arg {i}: header says '{p}', table has {g}"
 
 
+def test_every_device_entry_point_is_a_torch_op():
+    """north_star: the kernels are reached "through PyTorch-ROCm custom ops over a thin C-ABI" -- every function the
+    header declares is either a registered torch.ops.rlsolver_hip.* op (device work) or listed as a host-side
+    builder / query; the ops are native (C++ library), have a CUDA (= HIP) kernel only, and reject CPU tensors."""
+    import torch
+    from rlsolver_amd import torch_ops
+    declared = {n[len("rls_"):] for n in declared_functions()}
+    assert set(torch_ops.DEVICE_ENTRY_POINTS) | set(torch_ops.HOST_ENTRY_POINTS) == declared
+    assert not set(torch_ops.DEVICE_ENTRY_POINTS) & set(torch_ops.HOST_ENTRY_POINTS)
+    assert len(torch_ops.DEVICE_ENTRY_POINTS) >= 33
+    for name in torch_ops.DEVICE_ENTRY_POINTS:
+        op = getattr(torch.ops.rlsolver_hip, name)
+        assert torch._C._dispatch_has_kernel_for_dispatch_key(f"rlsolver_hip::{name}", "CUDA"), name
+        assert not torch._C._dispatch_has_kernel_for_dispatch_key(f"rlsolver_hip::{name}", "CPU"), name
+        assert op.default._schema.name == f"rlsolver_hip::{name}"
+    with pytest.raises(NotImplementedError):
+        torch.ops.rlsolver_hip.tsp_tour_length(torch.zeros((3, 3)), torch.zeros((1, 3), dtype=torch.int64), torch.zeros(1))
+    # the library is native code in-tree
+    assert os.path.basename(torch_ops.OPS_PATH) == "librlsolver_torch_ops.so" and os.path.exists(torch_ops.OPS_PATH)
+
+
 def test_loads_without_gpu_and_reports_errors():
     from rlsolver_amd import _abi
     assert _abi.version() == 4

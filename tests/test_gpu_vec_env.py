@@ -31,25 +31,58 @@ def test_vec_env_contract():
     assert np.array_equal(state.cpu().numpy(), ref.xs)
 
 
-def test_torch_ops_registered_and_equal():
-    from rlsolver_amd import ops, torch_ops
-    from rlsolver_amd.graph import build_csr, generate_gnm
+def test_torch_ops_native_and_equal_to_ctypes_path():
+    """torch.ops.rlsolver_hip.* (C++ ops over the C ABI) give what the ctypes wrappers give, honour torch's current
+    stream, and the gym env's step goes through the native op."""
+    from rlsolver_amd import ops, ops_mcpg_tsp as mops, torch_ops
+    from rlsolver_amd.graph import build_csr, generate_gnm, generate_tsp_coords, tsp_tables
+    R = torch.ops.rlsolver_hip
     n, B = 256, 130
     g = ops.DeviceGraph(build_csr(generate_gnm(n, 1200, 5), num_nodes=n), DEV)
-    h = torch_ops.register_graph(g)
+    h = torch_ops.graph_handle(g)
     xs = ops.rand_spins(B, n, 3, DEV)
-    assert torch.equal(torch.ops.rlsolver_hip.maxcut_obj(h, xs), ops.maxcut_obj(g, xs))
-    assert torch.equal(torch.ops.rlsolver_hip.maxcut_delta_all(h, xs), ops.maxcut_delta_all(g, xs))
+    obj = torch.empty(B, dtype=torch.int64, device=DEV)
+    R.maxcut_obj(h, xs, obj)
+    assert torch.equal(obj, ops.maxcut_obj(g, xs))
+    d = torch.empty((B, n), dtype=torch.int32, device=DEV)
+    R.maxcut_delta_all(h, xs, d)
+    assert torch.equal(d, ops.maxcut_delta_all(g, xs))
     x2, v2 = xs.clone(), ops.maxcut_obj(g, xs)
     x3, v3 = xs.clone(), v2.clone()
-    torch.ops.rlsolver_hip.maxcut_greedy_sweep(h, x2, v2)
+    R.maxcut_greedy_sweep(h, x2, v2)
     ops.maxcut_greedy_sweep(g, x3, v3)
     assert torch.equal(x2, x3) and torch.equal(v2, v3)
+    # K4 through the op == through ctypes, on a side stream
+    act = ops.rand_actions(B, n, 1, 0, DEV)
+    o1, o2 = obj.to(torch.int32), obj.to(torch.int32)
+    r1, r2 = torch.empty(B, device=DEV), torch.empty(B, device=DEV)
+    y1, y2 = torch.empty_like(xs), torch.empty_like(xs)
+    side = torch.cuda.Stream(device=DEV)
+    side.wait_stream(torch.cuda.current_stream(DEV))
+    with torch.cuda.stream(side):
+        R.maxcut_step(h, xs, y1, act, o1, r1, None, None, 0.0)
+    side.synchronize()
+    ops.maxcut_step(g, xs, y2, act, o2, r2)
+    assert torch.equal(y1, y2) and torch.equal(o1, o2) and torch.equal(r1, r2)
+    # a TSP op and a random op
+    dist, near, rnd = tsp_tables(generate_tsp_coords(40, 1), K=5)
+    perms = mops.rand_perms(64, 40, 9, DEV)
+    p2 = torch.empty_like(perms)
+    R.rand_perms(p2, 9, 0)
+    assert torch.equal(perms, p2)
+    length = torch.empty(64, device=DEV)
+    R.tsp_tour_length(torch.from_numpy(dist).to(DEV), perms, length)
+    assert torch.equal(length, mops.tsp_tour_length(torch.from_numpy(dist).to(DEV), perms))
     with pytest.raises(NotImplementedError):
-        torch.ops.rlsolver_hip.maxcut_obj(h, xs.cpu())          # no CPU kernel registered
-    torch_ops.release_graph(h)
+        R.maxcut_obj(h, xs.cpu(), obj.cpu())                       # no CPU kernel registered
     with pytest.raises(RuntimeError):
-        torch.ops.rlsolver_hip.maxcut_obj(h, xs)
+        R.maxcut_obj(h, xs.float().double(), obj)                  # dtype checked in the op
+    with pytest.raises(RuntimeError):
+        R.maxcut_obj(0, xs, obj)                                   # null graph handle
+    import types
+    from rlsolver_amd.envs.env_PPO import EnvMaxcut as Gym
+    env = Gym(types.SimpleNamespace(num_nodes=n, num_envs=B, num_steps=3), mygraph=generate_gnm(n, 1200, 5), device=DEV)
+    assert env._step_op is torch.ops.rlsolver_hip.maxcut_step
 
 
 def test_dreinforce_shaped_outer_loop_improves():
