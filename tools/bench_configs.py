@@ -59,6 +59,21 @@ def maxcut_suite(tag, n, m, B, seed, iters):
         tf = timeit(lambda i: ops.maxcut_step(g, fs[i % 6], fs[(i + 1) % 6], acts[i % 8], obj, rew), max(5, iters // 2))
         emit(tag, "K4 maxcut_step (emit, f32 gym surface)", "env-steps", B, tf, 8 * n + 20)
         del fs
+    if B <= 4096:   # launch-bound regime: the class surface through the native torch op, eager
+        import types
+        from rlsolver_amd.envs.env_PPO import EnvMaxcut as Gym
+        for dt, lab in ((torch.float32, "f32 reference surface"), (torch.bool, "1-byte spins")):
+            env = Gym(types.SimpleNamespace(num_nodes=n, num_envs=B, num_steps=10 ** 9), mygraph=generate_gnm(n, m, seed), device=dev,
+                      spin_dtype=dt, reuse_buffers=True)
+            env.reset()
+            te = timeit(lambda i: env.step(acts[i % 8]), max(200, iters * 20))
+            emit(tag, f"EnvMaxcutGym.step in place, eager, torch.ops path ({lab})", "env-steps", B, te, None,
+                 "host-bound: one dispatcher call + one HIP launch per step")
+            bufs = [torch.empty((B, n), dtype=dt, device=dev) for _ in range(4)]
+            te = timeit(lambda i: env.step(acts[i % 8], out=bufs[i % 4]), max(200, iters * 20))
+            emit(tag, f"EnvMaxcutGym.step(out=slot), eager, torch.ops path ({lab})", "env-steps", B, te, (8 if dt == torch.float32 else 2) * n + 20)
+        tc = timeit(lambda i: ops.maxcut_step(g, slots[i % S], slots[(i + 1) % S], acts[i % 8], obj, rew), max(200, iters * 20))
+        emit(tag, "K4 maxcut_step (emit), eager, ctypes path with per-call validation", "env-steps", B, tc, 2 * n + 20)
     if B <= 4096:   # launch-bound regime: the same steps captured as one hipGraph (rlsolver_amd.hipgraph)
         from rlsolver_amd.hipgraph import CapturedLaunches
         T = 64
