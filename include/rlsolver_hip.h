@@ -337,10 +337,18 @@ int rls_mcpg_metro_rounds(void* samples, const void* samples_in, int64_t C_in, i
  * where fresh marks a neighbour visited LATER than node (it still holds -0.5|1.5 in pass 0) and
  * nfresh counts them (rlsolver_amd.methods.MCPG.build_visit_stream builds it).  With it the kernel
  * streams the graph through an LDS ring, the waves of a workgroup share each batch, and nothing waits on
- * global memory per node; NULL selects the generic kernel (one CSR row fetch per node). */
+ * global memory per node; NULL selects the generic kernel (one CSR row fetch per node).
+ * Weighted graphs (upstream MCPG's weighted MaxCut sampler, methods/MCPG/sampling.py:89-127): edge_weights int32 [E'] in
+ * the order of g->eu / g->ev, and a visit stream whose node records are
+ *     node, deg, Wfresh, visiting position, Wdeg, then deg PAIRS (nb | fresh << 31, weight)
+ * (Wfresh = sum of the weights of the not-yet-visited neighbours, Wdeg = the weighted degree).  The test becomes
+ * sum_j w_j v_j + u / 4 < Wdeg / 2 + 0.125 (:114-116) and expected = sum_e w_e (2x_u - 1)(2x_v - 1).  gauge_node >= 0
+ * applies that sampler's gauge fix first: every chain is XORed with its own value at gauge_node (:101-104); -1: none.
+ * Both need the visit stream (RLS_EUNSUPPORTED without it). */
 int rls_mcpg_local_search(const rls_graph* g, const void* xs_in, int spin_bytes, float* xs_out, int64_t C,
                           const int32_t* order, const int32_t* visit_stream, int64_t visit_len, int64_t num_ls,
-                          const float* uniforms, uint64_t seed, float* expected, void* stream);
+                          const float* uniforms, uint64_t seed, const int32_t* edge_weights, int64_t gauge_node,
+                          float* expected, void* stream);
 
 /* [host] Level-parallel form of the K7 visiting order (lane = node; same dependency-level argument as
  * rls_graph_sweep_levels, levels taken over visiting POSITIONS: order[pos] = node).  Nodes of a level with degree

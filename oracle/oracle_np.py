@@ -543,3 +543,47 @@ def mcpg_get_return(probs, samples, value, total_mcmc_num, repeat_times):
     objective = (log_prob_sum * v).mean()
     grad = ((s / p - (1 - s) / (1 - p)) * v[:, None]).mean(axis=0)
     return objective, grad
+
+
+# --------------------------------------------------------------------------- upstream MCPG weighted MaxCut sampler
+
+
+def mcpg_metro_sampling_upstream(probs, start_status, max_transfer_time, index, u):
+    """metro_sampling of the MCPG package, rlsolver/methods/MCPG/sampling.py:67-86 (the same walk as MCPG.py:88-117;
+    restated separately because it is a separate function there).  -> (float32 0/1 [N, C], rounds used)"""
+    return metro_sampling(probs, start_status, max_transfer_time, index, u)
+
+
+def mcpg_sampling_maxcut(graph_w, num_nodes, sorted_degree_nodes, start_status, probs, num_ls, change_times, total_mcmc_num,
+                         metro_index, metro_u, uniforms):
+    """mcpg_sampling_maxcut, rlsolver/methods/MCPG/sampling.py:89-127, float32, with every torch draw supplied.
+    graph_w int [E, 3] (n0, n1, weight, 0-based, file order).  Neighbour lists follow append_neighbors
+    (dataloader.py:106-125: both endpoints appended per edge, in file order).
+    -> (vs, xs_good, start, value, expected)"""
+    n0, n1, w = graph_w[:, 0], graph_w[:, 1], graph_w[:, 2].astype(np.float32)
+    nbr = [[] for _ in range(num_nodes)]
+    nbw = [[] for _ in range(num_nodes)]
+    for a, b, ww in zip(n0, n1, w):
+        nbr[int(a)].append(int(b)); nbw[int(a)].append(ww)
+        nbr[int(b)].append(int(a)); nbw[int(b)].append(ww)
+    wdeg = [np.float32(np.sum(x, dtype=np.float32)) for x in nbw]                       # dataloader.py:82
+    edge_weight_sum = np.float32(w.sum(dtype=np.float32))
+    start, _ = mcpg_metro_sampling_upstream(probs, start_status, change_times, metro_index, metro_u)
+    x = start.copy()
+    hub = int(sorted_degree_nodes[0])
+    x = (x + x[hub]) % np.float32(2)                                                   # :101-103
+    x = (x - np.float32(0.5)) * np.float32(2) + np.float32(0.5)                         # :104  -> -0.5 | 1.5
+    for cnt in range(num_ls):
+        for pos in range(num_nodes):
+            node = int(sorted_degree_nodes[pos])
+            if nbr[node]:
+                tv = (np.asarray(nbw[node], np.float32)[None, :] @ x[nbr[node]]).astype(np.float32)[0]
+            else:
+                tv = np.zeros(x.shape[1], np.float32)
+            tv = tv + uniforms[cnt, pos].astype(np.float32) / np.float32(4)
+            x[node] = (tv < wdeg[node] / np.float32(2) + np.float32(0.125)).astype(np.float32)
+    expected = ((np.float32(2) * x[n0] - 1) * (np.float32(2) * x[n1] - 1) * w[:, None]).sum(axis=0, dtype=np.float32)
+    index = expected.reshape(-1, total_mcmc_num).argmin(axis=0)
+    index = np.arange(total_mcmc_num) + index * total_mcmc_num
+    vs = (edge_weight_sum - expected[index]) / np.float32(2)
+    return vs, x[:, index], start, expected - expected.mean(dtype=np.float32), expected

@@ -379,12 +379,19 @@ __global__ __launch_bounds__(kWave) void k_mcpg_local_search(const TI* __restric
 // visiting position); test mode reads the reference's torch.rand draws.
 constexpr int kK7Waves = 16;   // one workgroup per CU (80 KB bit tile at N = 10^4): 4 waves 27.5, 8 waves 20.1, 16 waves 18.1 ms
 
-template <typename TI, int P>
+// WEIGHTED (upstream MCPG's weighted MaxCut sampler, rlsolver/methods/MCPG/sampling.py:89-127): records carry
+//     node, deg, Wfresh, visiting position, Wdeg, then deg PAIRS (nb | fresh << 31, weight)
+// (Wfresh = sum of the weights of not-yet-visited neighbours, Wdeg = weighted degree = sum of all weights, integers);
+// the test becomes  sum_j w_j v_j + u / 4 < Wdeg / 2 + 0.125  and the expected value sum_e w_e (2x_u - 1)(2x_v - 1).
+// `gauge_node` >= 0 applies the sampler's gauge fix first: every chain is XORed with its value at that node (:101-104).
+template <typename TI, int P, bool WEIGHTED>
 __global__ __launch_bounds__(kK7Waves * kWave) void k_mcpg_local_search_stream(
     const TI* __restrict__ xs_in, float* __restrict__ xs_out, int64_t N, int64_t C,
     const int32_t* __restrict__ vstream, int64_t vlen, int64_t num_ls, const float* __restrict__ uniforms,
-    uint64_t seed, const int32_t* __restrict__ eu, const int32_t* __restrict__ ev, int64_t E,
-    float* __restrict__ expected) {
+    uint64_t seed, const int32_t* __restrict__ eu, const int32_t* __restrict__ ev, const int32_t* __restrict__ ew, int64_t E,
+    int gauge_node, float* __restrict__ expected) {
+    constexpr int HDR = WEIGHTED ? 5 : 4;                 // header words of a node record
+    constexpr int FIRST = WEIGHTED ? 28 : 56;             // neighbours whose entries sit in the record's first 64 words
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* words = reinterpret_cast<uint64_t*>(smem);
     int32_t* ring = reinterpret_cast<int32_t*>(smem + (size_t)(N + 2) * 8);
@@ -398,11 +405,20 @@ __global__ __launch_bounds__(kK7Waves * kWave) void k_mcpg_local_search_stream(
     const bool valid = c < C;
     if (threadIdx.x == 0) words[N] = 0;   // sentinel word for lanes past a row's end
     tile_load_bits_nodemajor<TI>(xs_in, N, C, c0, words, lane, w, kK7Waves);
+    if (gauge_node >= 0) {                // graph_probs = (graph_probs + graph_probs[hub]) % 2
+        __syncthreads();
+        const uint64_t hub = words[gauge_node];
+        __syncthreads();
+        for (int64_t n = threadIdx.x; n < N; n += kK7Waves * kWave) words[n] ^= hub;
+    }
     const int sh = lane & 31;
     const uint32_t half4 = (uint32_t)(lane >> 5) * 4u;
     const uint32_t sentinel = (uint32_t)N;
     const uint32_t chain_key = k7_fmix32((uint32_t)seed ^ k7_fmix32((uint32_t)(seed >> 32) ^ k7_fmix32((uint32_t)c) ^
                                                                     ((uint32_t)((uint64_t)c >> 32) * 0x9E3779B1u)));
+    auto bit_of = [&](uint32_t e) -> uint32_t {
+        return (*reinterpret_cast<const uint32_t*>(wbytes + ((e & 0x7fffffffu) * 8u + half4)) >> sh) & 1u;
+    };
     for (int64_t cnt = 0; cnt < num_ls; ++cnt) {
         int64_t F;
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -421,55 +437,66 @@ __global__ __launch_bounds__(kK7Waves * kWave) void k_mcpg_local_search_stream(
                 const uint32_t blk = (uint32_t)ring[(off + lane) & (kRing - 1)];
                 const int node = __builtin_amdgcn_readlane((int)blk, 0);
                 const int deg = __builtin_amdgcn_readlane((int)blk, 1);
-                const int nfresh = (cnt == 0) ? __builtin_amdgcn_readlane((int)blk, 2) : 0;
+                const int nfresh = (cnt == 0) ? __builtin_amdgcn_readlane((int)blk, 2) : 0;   // WEIGHTED: sum of fresh weights
                 const int64_t pos = (uint32_t)__builtin_amdgcn_readlane((int)blk, 3);   // visiting position: RNG key / draw index
-                const int64_t row = off + 4;
+                const int wdeg = WEIGHTED ? __builtin_amdgcn_readlane((int)blk, 4) : deg;
+                const int64_t row = off + HDR;
                 float uu;
                 if (uniforms) uu = valid ? uniforms[(cnt * N + pos) * C + c] : 0.0f;
                 else uu = u32_to_unit_float(k7_fmix32(chain_key ^ ((uint32_t)pos * 0x9E3779B1u) ^
                                                       ((uint32_t)cnt * 0x7FEB352Du + 0x165667B1u)));
-                // s2 = sum over neighbours of value in units of 0.5: 2 * bit, or in pass 0 for a neighbour not visited
-                // yet 4 * bit - 1 (the -1s are nfresh).  Entries 0..55 of the row sit in lanes 4..59 of blk (lanes
-                // past the row end read the sentinel, whose word is 0); longer rows continue from the ring.
-                const uint32_t mine = (lane >= 4 && lane - 4 < deg) ? blk : sentinel;
-                const int first = deg < 56 ? deg : 56;
+                // s2 = sum over neighbours of weight * value in units of 0.5: 2 * bit, or in pass 0 for a neighbour not
+                // visited yet 4 * bit - 1 (the -1s are nfresh).  The first entries of the row sit behind the header in blk
+                // (lanes past the row end read the sentinel, whose word is 0); longer rows continue from the ring.
                 int acc = 0;
-                if (cnt == 0) {
-                    for (int j = 0; j < first; j += 8) {
-                        uint32_t wv[8], ee[8];
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) {
-                            ee[q] = (uint32_t)__builtin_amdgcn_readlane((int)mine, j + q + 4);
-                            wv[q] = *reinterpret_cast<const uint32_t*>(wbytes + ((ee[q] & 0x7fffffffu) * 8u + half4));
-                        }
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) acc += (int)(((wv[q] >> sh) & 1u) << (1u + (ee[q] >> 31)));
+                if constexpr (WEIGHTED) {
+                    const int first = deg < FIRST ? deg : FIRST;
+                    for (int j = 0; j < first; ++j) {
+                        const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)blk, HDR + 2 * j);
+                        const int wj = __builtin_amdgcn_readlane((int)blk, HDR + 2 * j + 1);
+                        acc += wj * (int)(bit_of(e) << (1u + ((cnt == 0) ? (e >> 31) : 0u)));
                     }
-                    for (int j = 56; j < deg; ++j) {
-                        const uint32_t e = (uint32_t)ring[(row + j) & (kRing - 1)];
-                        const uint32_t bit = (*reinterpret_cast<const uint32_t*>(wbytes + ((e & 0x7fffffffu) * 8u + half4)) >> sh) & 1u;
-                        acc += (int)(bit << (1u + (e >> 31)));
+                    for (int j = FIRST; j < deg; ++j) {
+                        const uint32_t e = (uint32_t)ring[(row + 2 * j) & (kRing - 1)];
+                        const int wj = ring[(row + 2 * j + 1) & (kRing - 1)];
+                        acc += wj * (int)(bit_of(e) << (1u + ((cnt == 0) ? (e >> 31) : 0u)));
                     }
                 } else {
-                    for (int j = 0; j < first; j += 8) {
-                        uint32_t wv[8];
+                    const uint32_t mine = (lane >= 4 && lane - 4 < deg) ? blk : sentinel;
+                    const int first = deg < FIRST ? deg : FIRST;
+                    if (cnt == 0) {
+                        for (int j = 0; j < first; j += 8) {
+                            uint32_t wv[8], ee[8];
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) {
-                            const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)mine, j + q + 4);
-                            wv[q] = *reinterpret_cast<const uint32_t*>(wbytes + ((e & 0x7fffffffu) * 8u + half4));
+                            for (int q = 0; q < 8; ++q) {
+                                ee[q] = (uint32_t)__builtin_amdgcn_readlane((int)mine, j + q + 4);
+                                wv[q] = *reinterpret_cast<const uint32_t*>(wbytes + ((ee[q] & 0x7fffffffu) * 8u + half4));
+                            }
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) acc += (int)(((wv[q] >> sh) & 1u) << (1u + (ee[q] >> 31)));
                         }
+                        for (int j = FIRST; j < deg; ++j) {
+                            const uint32_t e = (uint32_t)ring[(row + j) & (kRing - 1)];
+                            acc += (int)(bit_of(e) << (1u + (e >> 31)));
+                        }
+                    } else {
+                        for (int j = 0; j < first; j += 8) {
+                            uint32_t wv[8];
 #pragma unroll
-                        for (int q = 0; q < 8; ++q) acc += (int)((wv[q] >> sh) & 1u);
+                            for (int q = 0; q < 8; ++q) {
+                                const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)mine, j + q + 4);
+                                wv[q] = *reinterpret_cast<const uint32_t*>(wbytes + ((e & 0x7fffffffu) * 8u + half4));
+                            }
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) acc += (int)((wv[q] >> sh) & 1u);
+                        }
+                        for (int j = FIRST; j < deg; ++j) acc += (int)bit_of((uint32_t)ring[(row + j) & (kRing - 1)]);
+                        acc <<= 1;
                     }
-                    for (int j = 56; j < deg; ++j) {
-                        const uint32_t e = (uint32_t)ring[(row + j) & (kRing - 1)];
-                        acc += (int)((*reinterpret_cast<const uint32_t*>(wbytes + ((e & 0x7fffffffu) * 8u + half4)) >> sh) & 1u);
-                    }
-                    acc <<= 1;
                 }
                 const int s2 = acc - nfresh;                                      // units of 0.5
-                const float rv = (float)s2 * 0.5f + uu * 0.25f;                   // MCPG.py:139-141
-                const float thr = ((float)deg + 0.25f) / 2.0f;                    // (weighted_degree + k) / 2
+                const float rv = (float)s2 * 0.5f + uu * 0.25f;                   // MCPG.py:139-141 / sampling.py:114-116
+                const float thr = ((float)wdeg + 0.25f) / 2.0f;                   // (weighted_degree + k) / 2
                 const uint64_t nw = ballot64(rv < thr);
                 if (lane == 0) words[node] = nw;
             }
@@ -480,11 +507,21 @@ __global__ __launch_bounds__(kK7Waves * kWave) void k_mcpg_local_search_stream(
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
-    // K8: expected[c] = sum_e (2x_u - 1)(2x_v - 1) = E - 2 * cut
-    const int64_t cut = block_sum_partials<kK7Waves>(tile_cut_count<P>(words, eu, ev, E, lane, w, kK7Waves), scratch,
-                                                     lane, w);
+    // K8: expected[c] = sum_e w_e (2x_u - 1)(2x_v - 1) = W - 2 * (weight of the cut)
+    int64_t total;
+    if constexpr (WEIGHTED) {
+        int64_t part = 0;                                                         // lane = chain, the waves split the edges
+        for (int64_t e = w; e < E; e += kK7Waves) {
+            const uint32_t d = bit_of((uint32_t)eu[e]) ^ bit_of((uint32_t)ev[e]);
+            part += d ? -(int64_t)ew[e] : (int64_t)ew[e];
+        }
+        total = block_sum_partials<kK7Waves>(part, scratch, lane, w);             // = sum_e w_e (+1 | -1)
+    } else {
+        const int64_t cut = block_sum_partials<kK7Waves>(tile_cut_count<P>(words, eu, ev, E, lane, w, kK7Waves), scratch, lane, w);
+        total = E - 2 * cut;
+    }
     if (valid) {
-        if (w == 0) expected[c] = (float)(E - 2 * cut);
+        if (w == 0) expected[c] = (float)total;
         const int half = lane >> 5;
         for (int64_t n = w; n < N; n += kK7Waves) xs_out[n * C + c] = (float)((w32[(n << 1) + half] >> sh) & 1u);
     }
@@ -1018,40 +1055,48 @@ int rls_mcpg_local_search_levels(const rls_graph* g, const void* xs_in, int spin
 
 int rls_mcpg_local_search(const rls_graph* g, const void* xs_in, int spin_bytes, float* xs_out, int64_t C,
                           const int32_t* order, const int32_t* visit_stream, int64_t visit_len, int64_t num_ls,
-                          const float* uniforms, uint64_t seed, float* expected, void* stream) {
+                          const float* uniforms, uint64_t seed, const int32_t* edge_weights, int64_t gauge_node,
+                          float* expected, void* stream) {
     if (int rc = check_graph(g)) return rc;
     RLS_REQUIRE(C >= 0 && num_ls >= 0, RLS_EINVAL, "bad sizes");
     if (C == 0) return RLS_OK;
     RLS_REQUIRE(xs_in && xs_out && order && expected, RLS_EINVAL, "NULL pointer");
     RLS_REQUIRE(spin_bytes == 1 || spin_bytes == 4, RLS_EINVAL, "spin_bytes must be 1 or 4");
     const int64_t N = g->num_nodes, E = g->num_stored_edges;
+    RLS_REQUIRE(gauge_node >= -1 && gauge_node < N, RLS_EINVAL, "gauge_node %lld outside [-1, N)", (long long)gauge_node);
     const int P = pick_planes(E);
     RLS_REQUIRE(P != 0, RLS_EUNSUPPORTED, "E=%lld too large", (long long)E);
     const dim3 grid((unsigned)ceil_div(C, kWave)), block(kWave);
     hipStream_t s = as_stream(stream);
+    const bool weighted = edge_weights != nullptr;
     const size_t lds_fast = (size_t)(N + 2) * 8 + (size_t)kRing * 4 + (size_t)kK7Waves * kWave * 8;
-    const bool fast = visit_stream != nullptr && g->max_degree + 4 <= kRingMaxRun && lds_fast <= (size_t)kLdsBytes &&
+    const int64_t hdr = weighted ? 5 : 4, ent = weighted ? 2 : 1;
+    const bool fast = visit_stream != nullptr && ent * g->max_degree + hdr <= kRingMaxRun && lds_fast <= (size_t)kLdsBytes &&
                       (((uintptr_t)visit_stream) & 3) == 0;
+    RLS_REQUIRE(fast || (!weighted && gauge_node < 0), RLS_EUNSUPPORTED,
+                "weighted / gauge-fixed K7 needs the batched visit stream (max degree <= %d, N * 8 + 24 KB of LDS)",
+                (int)((kRingMaxRun - 5) / 2));
     if (fast) {
-        // records nnz + 4N, one offset per node, 3 header words per batch (1 <= batches <= N)
-        RLS_REQUIRE(visit_len >= g->nnz + 5 * N + 3 && visit_len <= g->nnz + 8 * N, RLS_EINVAL,
-                    "visit_len %lld is not a batched visit stream of this graph (nnz + 5N + 3*batches)",
-                    (long long)visit_len);
+        // records ent * nnz + hdr * N, one offset per node, 3 header words per batch (1 <= batches <= N)
+        RLS_REQUIRE(visit_len >= ent * g->nnz + (hdr + 1) * N + 3 && visit_len <= ent * g->nnz + (hdr + 4) * N, RLS_EINVAL,
+                    "visit_len %lld is not a batched visit stream of this graph", (long long)visit_len);
         const dim3 block(kK7Waves * kWave);
-#define LAUNCH_LSS(TI, PP)                                                                                           \
+        const int gn = (int)gauge_node;
+#define LAUNCH_LSS(TI, PP, WGT)                                                                                      \
     do {                                                                                                             \
-        auto kern = k_mcpg_local_search_stream<TI, PP>;                                                              \
+        auto kern = k_mcpg_local_search_stream<TI, PP, WGT>;                                                         \
         if (lds_fast > 64 * 1024)                                                                                    \
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fast); \
         hipLaunchKernelGGL(kern, grid, block, lds_fast, s, (const TI*)xs_in, xs_out, N, C, visit_stream, visit_len,   \
-                           num_ls, uniforms, seed, g->eu, g->ev, E, expected);                                       \
+                           num_ls, uniforms, seed, g->eu, g->ev, edge_weights, E, gn, expected);                      \
     } while (0)
-#define DISPATCH_PS(TI)                       \
-    switch (P) {                              \
-        case 12: LAUNCH_LSS(TI, 12); break;   \
-        case 16: LAUNCH_LSS(TI, 16); break;   \
-        case 20: LAUNCH_LSS(TI, 20); break;   \
-        default: LAUNCH_LSS(TI, 24); break;   \
+#define DISPATCH_PS(TI)                              \
+    if (weighted) { LAUNCH_LSS(TI, 12, true); }      \
+    else switch (P) {                                \
+        case 12: LAUNCH_LSS(TI, 12, false); break;   \
+        case 16: LAUNCH_LSS(TI, 16, false); break;   \
+        case 20: LAUNCH_LSS(TI, 20, false); break;   \
+        default: LAUNCH_LSS(TI, 24, false); break;   \
     }
         if (spin_bytes == 1) { DISPATCH_PS(uint8_t) } else { DISPATCH_PS(float) }
 #undef DISPATCH_PS

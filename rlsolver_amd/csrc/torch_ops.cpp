@@ -219,17 +219,18 @@ void mcpg_metro_rounds(Tensor samples, const OptTensor& samples_in, int64_t C_in
        "rls_mcpg_metro_rounds");
 }
 void mcpg_local_search(int64_t g, const Tensor& xs_in, Tensor xs_out, const Tensor& order, const OptTensor& visit_stream, int64_t num_ls,
-                       const OptTensor& uniforms, int64_t seed, Tensor expected) {
+                       const OptTensor& uniforms, int64_t seed, const OptTensor& edge_weights, int64_t gauge_node, Tensor expected) {
     const int sb = chain_bytes(xs_in, "xs_in");
     TORCH_CHECK(sb != 0, "rls_mcpg_local_search takes node-major chains");
     dev(xs_out, "xs_out", F32);
     dev(order, "order", I32);
     optdev(visit_stream, "visit_stream", I32);
     optdev(uniforms, "uniforms", F32);
+    optdev(edge_weights, "edge_weights", I32);
     dev(expected, "expected", F32);
     ok(rls_mcpg_local_search(G(g), p(xs_in), sb, (float*)p(xs_out), xs_in.size(1), (const int32_t*)p(order), (const int32_t*)p(visit_stream),
                              visit_stream.has_value() ? visit_stream->numel() : 0, num_ls, (const float*)p(uniforms), (uint64_t)seed,
-                             (float*)p(expected), cur_stream(xs_in)), "rls_mcpg_local_search");
+                             (const int32_t*)p(edge_weights), gauge_node, (float*)p(expected), cur_stream(xs_in)), "rls_mcpg_local_search");
 }
 void mcpg_local_search_levels(int64_t g, const Tensor& xs_in, int64_t C_in, Tensor xs_out, int64_t C, const Tensor& lv_ptr,
                               const Tensor& lv_data, int64_t num_ls, const OptTensor& coins, int64_t seed, Tensor expected) {
@@ -397,7 +398,7 @@ TORCH_LIBRARY(rlsolver_hip, m) {
     m.def("mcpg_metro_rounds(Tensor(a!) samples, Tensor? samples_in, int C_in, int C, Tensor probs, int T, int t_offset, Tensor? index, "
           "Tensor? u, int seed, Tensor? t_limit, bool write_back, Tensor(b!)? accepts) -> ()");
     m.def("mcpg_local_search(int graph, Tensor xs_in, Tensor(a!) xs_out, Tensor order, Tensor? visit_stream, int num_ls, Tensor? uniforms, "
-          "int seed, Tensor(b!) expected) -> ()");
+          "int seed, Tensor? edge_weights, int gauge_node, Tensor(b!) expected) -> ()");
     m.def("mcpg_local_search_levels(int graph, Tensor xs_in, int C_in, Tensor(a!) xs_out, int C, Tensor lv_ptr, Tensor lv_data, int num_ls, "
           "Tensor? coins, int seed, Tensor(b!) expected) -> ()");
     m.def("mcpg_pick_best(Tensor expected, Tensor xs, int N, int total_mcmc_num, int repeat_times, int num_edges, Tensor(a!) best_index, "

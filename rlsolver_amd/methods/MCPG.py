@@ -79,17 +79,21 @@ def build_visit_levels(csr, order: np.ndarray):
     return lvp, lvd
 
 
-def build_visit_stream(csr, order: np.ndarray, max_nodes: int = 32, max_entries: int = 400) -> np.ndarray:
+def build_visit_stream(csr, order: np.ndarray, max_nodes: int = 32, max_entries: int = 400, weighted: bool = False) -> np.ndarray:
     """Flatten the visiting order for the streaming K7 kernel (format: rls_mcpg.hip / include/rlsolver_hip.h).
 
     The sequential pass (MCPG.py:136-142) only orders ADJACENT nodes, so the visiting positions are
     level-scheduled by the library's host pass (rls_graph_sweep_schedule, on the graph relabelled by visiting
     position): positions sorted by (dependency level, position), levels cut into batches of <= max_nodes
     nodes / <= max_entries stream entries.  Nodes of a batch are pairwise non-adjacent and every neighbour
-    visited earlier sits in an earlier batch: deciding batch after batch reproduces the sequential result."""
+    visited earlier sits in an earlier batch: deciding batch after batch reproduces the sequential result.
+
+    ``weighted``: records carry the CSR weights (node, deg, Wfresh, position, Wdeg, then (neighbour, weight) pairs) for
+    the weighted sampler of rlsolver/methods/MCPG/sampling.py:89-127."""
     import ctypes as C
     from .. import _abi
     n = csr.num_nodes
+    hdr, ent = (5, 2) if weighted else (4, 1)
     order = np.asarray(order, dtype=np.int64)
     pos_of = np.empty(n, dtype=np.int64)
     pos_of[order] = np.arange(n)
@@ -101,18 +105,21 @@ def build_visit_stream(csr, order: np.ndarray, max_nodes: int = 32, max_entries:
     starts = csr.rowptr[order].astype(np.int64)
     idx = np.repeat(starts - cum[:-1], deg_o) + np.arange(nnz)
     nbr = csr.col[idx].astype(np.int64)
+    wgt = csr.wgt[idx].astype(np.int64)
     row_pos = np.repeat(np.arange(n), deg_o)
     fresh = pos_of[nbr] > row_pos
-    nfresh = np.bincount(row_pos, weights=fresh, minlength=n).astype(np.int64)
-    # level schedule over visiting positions (graph relabelled by position); a record is 3 entries longer than
-    # the scheduler's (1 + deg) count
+    nfresh = np.bincount(row_pos, weights=fresh * (wgt if weighted else 1), minlength=n).astype(np.int64)
+    wdeg = np.bincount(row_pos, weights=wgt, minlength=n).astype(np.int64)
+    # level schedule over visiting positions (graph relabelled by position); a record is hdr - 1 entries longer than
+    # the scheduler's (1 + deg) count per neighbour entry
     rp_p = np.ascontiguousarray(cum, dtype=np.int32)
     col_p = np.ascontiguousarray(pos_of[nbr], dtype=np.int32)
     flagged = np.empty(n + 1, dtype=np.int32)
     tmp = np.empty(nnz + n, dtype=np.int32)
     nb, nl = C.c_int64(0), C.c_int64(0)
+    budget = max((max_entries - 3 * max_nodes - (hdr - 4) * max_nodes) // ent, 1)
     _abi.call("rls_graph_sweep_schedule", rp_p.ctypes.data_as(C.c_void_p), col_p.ctypes.data_as(C.c_void_p), n,
-              max_nodes, max(max_entries - 3 * max_nodes, 1), flagged.ctypes.data_as(C.c_void_p),
+              max_nodes, budget, flagged.ctypes.data_as(C.c_void_p),
               tmp.ctypes.data_as(C.c_void_p), C.byref(nb), C.byref(nl))
     off = (flagged.view(np.uint32) & 0x7FFFFFFF).astype(np.int64)
     sp = tmp[off[:n]].astype(np.int64)                               # visiting position at schedule slot k
@@ -121,7 +128,7 @@ def build_visit_stream(csr, order: np.ndarray, max_nodes: int = 32, max_entries:
     first_slot = np.flatnonzero(is_start)
     m = np.diff(np.concatenate([first_slot, [n]]))                   # nodes per batch
     deg_s = deg_o[sp]
-    rec_len = deg_s + 4
+    rec_len = ent * deg_s + hdr
     rec_total = np.add.reduceat(rec_len, first_slot)
     batch_size = 3 + m + rec_total
     H = np.concatenate([[0], np.cumsum(batch_size)])                 # header offset of each batch
@@ -134,10 +141,15 @@ def build_visit_stream(csr, order: np.ndarray, max_nodes: int = 32, max_entries:
     k_in_batch = np.arange(n) - first_slot[bid]
     stream[H[bid] + 3 + k_in_batch] = rec_off
     stream[rec_off], stream[rec_off + 1], stream[rec_off + 2], stream[rec_off + 3] = order[sp], deg_s, nfresh[sp], sp
-    # rows: entries of visiting position sp[k] copied to rec_off[k] + 4 ...
-    src = np.repeat(cum[:-1][sp], deg_s) + (np.arange(int(deg_s.sum())) - np.repeat(np.cumsum(deg_s) - deg_s, deg_s))
-    dst = np.repeat(rec_off + 4, deg_s) + (np.arange(int(deg_s.sum())) - np.repeat(np.cumsum(deg_s) - deg_s, deg_s))
+    if weighted:
+        stream[rec_off + 4] = wdeg[sp]
+    # rows: entries of visiting position sp[k] copied behind the header of its record
+    j_in_row = np.arange(int(deg_s.sum())) - np.repeat(np.cumsum(deg_s) - deg_s, deg_s)
+    src = np.repeat(cum[:-1][sp], deg_s) + j_in_row
+    dst = np.repeat(rec_off + hdr, deg_s) + ent * j_in_row
     stream[dst] = nbr[src] | (fresh[src].astype(np.int64) << 31)
+    if weighted:
+        stream[dst + 1] = wgt[src]
     return (stream & 0xFFFFFFFF).astype(np.uint32).view(np.int32)
 
 

@@ -106,8 +106,11 @@ def mcpg_metro_rounds(samples, probs: TEN, T: int, index: Optional[TEN] = None, 
 
 
 def mcpg_local_search(g: DeviceGraph, xs_in: TEN, order: TEN, num_ls: int, uniforms: Optional[TEN] = None,
-                      seed: int = 0, visit_stream: Optional[TEN] = None):
-    """K7 + expected cut.  Returns (xs_out f32 [N, C], expected f32 [C])."""
+                      seed: int = 0, visit_stream: Optional[TEN] = None, edge_weights: Optional[TEN] = None,
+                      gauge_node: int = -1):
+    """K7 + expected cut.  Returns (xs_out f32 [N, C], expected f32 [C]).  ``edge_weights`` int32 [E'] (in the order of
+    the graph's stored edges) + a weighted visit stream select the weighted sampler; ``gauge_node`` >= 0 XORs every
+    chain with its value at that node first (rlsolver/methods/MCPG/sampling.py:101-104)."""
     _check(xs_in, "xs_in", _NM_DTYPES, g.device)
     if xs_in.dim() != 2 or xs_in.shape[0] != g.num_nodes:
         raise ValueError(f"xs_in must be [{g.num_nodes}, C]")
@@ -119,9 +122,11 @@ def mcpg_local_search(g: DeviceGraph, xs_in: TEN, order: TEN, num_ls: int, unifo
     expected = torch.empty(Cc, dtype=torch.float32, device=g.device)
     if visit_stream is not None:
         _check(visit_stream, "visit_stream", (torch.int32,), g.device)
+    if edge_weights is not None:
+        _check(edge_weights, "edge_weights", (torch.int32,), g.device, (g.num_stored_edges,))
     _abi.call("rls_mcpg_local_search", g.ref, _ptr(xs_in), 4 if xs_in.dtype == torch.float32 else 1, _ptr(xs_out), Cc,
               _ptr(order), _ptr(visit_stream), 0 if visit_stream is None else visit_stream.numel(), num_ls,
-              _ptr(uniforms), _u64(seed), _ptr(expected), _stream(g.device))
+              _ptr(uniforms), _u64(seed), _ptr(edge_weights), int(gauge_node), _ptr(expected), _stream(g.device))
     return xs_out, expected
 
 

@@ -346,3 +346,61 @@ def test_mcpg_round_on_device_improves_and_prints_like_the_reference():
     assert sum(l.startswith("num_samples_per_second:") for l in lines) == 6
     assert v >= float(vs0.max()) and v > 0.6 * data.num_edges
     assert int(ops.maxcut_obj(data.graph, x[None, :].contiguous())) == int(v)
+
+
+# ------------------------------------------------------------------ weighted sampler of the upstream MCPG package
+@pytest.mark.parametrize("gname", ["BA_100_ID0", "PL_20_ID0"])
+def test_mcpg_weighted_sampler_golden(golden, gname):
+    """mcpg_sampling_maxcut (methods/MCPG/sampling.py:89-127: gauge fix, weighted node-sequential search, weighted
+    expected value) against the reference's trace with every torch draw recorded: bit for bit."""
+    from rlsolver_amd.methods import MCPG_maxcut as wm
+    z = golden("mcpg_weighted")
+    g = z[f"{gname}/graph"]
+    n = int(g[:, :2].max()) + 1
+    data = wm.make_data(n, g[:, 0], g[:, 1], g[:, 2], DEV, sorted_degree_nodes=z[f"{gname}/sorted_degree_nodes"])
+    assert data.weighted_degree == z[f"{gname}/weighted_degree"].tolist()
+    assert data.edge_weight_sum == float(z[f"{gname}/edge_weight_sum"])
+    vs, xs_good, start, value = wm.mcpg_sampling_maxcut(
+        data, dev(z[f"{gname}/start"], torch.float32), dev(z[f"{gname}/probs"]), int(z[f"{gname}/num_ls"]),
+        int(z[f"{gname}/change_times"]), int(z[f"{gname}/M"]), DEV, index=dev(z[f"{gname}/metro_index"]),
+        u=dev(z[f"{gname}/metro_u"]), uniforms=dev(z[f"{gname}/uniforms"]))
+    assert np.array_equal(start.cpu().numpy().astype(np.uint8), z[f"{gname}/metro_out"])
+    assert np.array_equal(vs.cpu().numpy(), z[f"{gname}/vs"])
+    assert np.array_equal(xs_good.cpu().numpy(), z[f"{gname}/xs_good"])
+    np.testing.assert_allclose(value.cpu().numpy(), z[f"{gname}/value"], rtol=0, atol=1e-4)
+
+
+@pytest.mark.parametrize("n,m,M,R,num_ls,wset", [(300, 1500, 16, 4, 2, (-1, 1)), (2000, 19990, 64, 2, 1, (-3, -1, 1, 2)),
+                                                 (130, 600, 1, 3, 3, (1,))])
+def test_mcpg_weighted_sampler_vs_oracle(n, m, M, R, num_ls, wset):
+    """Larger / denser weighted graphs (rows longer than the record's first 28 neighbours, multi-batch levels) against
+    the numpy restatement; production draws: the gauge node ends at 0 in every chain and the kept value is the weight
+    of the kept chain's cut."""
+    from rlsolver_amd.methods import MCPG_maxcut as wm
+    g = gnm_arr(n, m, seed=8)
+    rng = np.random.RandomState(n)
+    g[:, 2] = rng.choice(wset, size=len(g))
+    C = M * R
+    adeg = np.zeros(n)
+    np.add.at(adeg, g[:, 0], np.abs(g[:, 2]))
+    np.add.at(adeg, g[:, 1], np.abs(g[:, 2]))
+    order = np.argsort(-adeg, kind="stable")
+    data = wm.make_data(n, g[:, 0], g[:, 1], g[:, 2], DEV, sorted_degree_nodes=order)
+    probs = (rng.rand(n) * 0.6 + 0.2).astype(np.float32)
+    start = rng.randint(0, 2, size=(n, C)).astype(np.float32)
+    T = max(1, n // 10)
+    index = rng.randint(0, n, size=(5 * T, C)).astype(np.int64)
+    u = rng.rand(5 * T, C).astype(np.float32)
+    uni = rng.rand(num_ls, n, C).astype(np.float32)
+    w_vs, w_xs, w_start, w_val, w_exp = onp.mcpg_sampling_maxcut(g, n, order, start, probs, num_ls, T, M, index, u, uni)
+    vs, xs_good, st, value = wm.mcpg_sampling_maxcut(data, dev(start), dev(probs), num_ls, T, M, DEV, index=dev(index), u=dev(u),
+                                                     uniforms=dev(uni))
+    assert np.array_equal(st.cpu().numpy(), w_start) and np.array_equal(vs.cpu().numpy(), w_vs)
+    assert np.array_equal(xs_good.cpu().numpy(), w_xs)
+    np.testing.assert_allclose(value.cpu().numpy(), w_val, rtol=0, atol=2e-3)
+    torch.manual_seed(0)
+    vs, xs_good, st, value = wm.mcpg_sampling_maxcut(data, dev(start), dev(probs), num_ls, T, M, DEV)
+    xg = xs_good.cpu().numpy()
+    cutw = ((xg[g[:, 0]] != xg[g[:, 1]]) * g[:, 2][:, None]).sum(axis=0)
+    assert np.array_equal(vs.cpu().numpy(), cutw.astype(np.float32))
+    assert set(np.unique(xg)) <= {0.0, 1.0}

@@ -160,3 +160,34 @@ def test_sweep_level_groups_encode_the_same_schedule():
         for i in range(n):
             nbrs = col[rp[i]: rp[i + 1]]
             assert (level_of[nbrs[nbrs < i]] < level_of[i]).all() and (level_of[nbrs[nbrs > i]] > level_of[i]).all()
+
+
+def test_streaming_reader_matches_line_reader_and_scales(tmp_path):
+    """the chunked reader gives what the per-line reader gives (comments, blank lines, float
+    weights, rows without a weight, blocks cut anywhere) and parses a 2*10^6-edge file in a few seconds."""
+    import time
+    from rlsolver_amd.graph import read_edge_arrays, read_mygraph
+    p = tmp_path / "g.txt"
+    p.write_text("// a comment\n5 6\n1 2 1\n2 3 -1\n\n3 4 1.0  // trailing\n4 5 2\n5 1 -3\n1 3 1\n")
+    n, eu, ev, w = read_edge_arrays(str(p), chunk_bytes=7)           # blocks far smaller than a line
+    mg = read_mygraph(str(p))
+    assert n == 5 and list(zip(eu.tolist(), ev.tolist(), w.tolist())) == mg
+    q = tmp_path / "nw.txt"
+    q.write_text("4 3\n1 2\n2 3\n3 4\n")
+    n, eu, ev, w = read_edge_arrays(str(q))
+    assert n == 4 and w.tolist() == [1, 1, 1] and eu.tolist() == [0, 1, 2]
+    (tmp_path / "e.txt").write_text("7 0\n")
+    assert read_edge_arrays(str(tmp_path / "e.txt"))[1].size == 0
+    # 10^6 nodes, 2*10^6 edges
+    rng = np.random.RandomState(0)
+    N, E = 1_000_000, 2_000_000
+    a = rng.randint(1, N + 1, size=(E, 2))
+    big = tmp_path / "big.txt"
+    with open(big, "w") as f:
+        f.write(f"{N} {E}\n")
+        np.savetxt(f, np.column_stack([a, rng.choice([-1, 1], size=E)]), fmt="%d")
+    t0 = time.time()
+    n, eu, ev, w = read_edge_arrays(str(big), chunk_bytes=8 << 20)
+    dt = time.time() - t0
+    assert n == N and eu.shape == (E,) and np.array_equal(eu, a[:, 0] - 1) and np.array_equal(ev, a[:, 1] - 1)
+    assert set(np.unique(w)) == {-1, 1} and dt < 30

@@ -300,3 +300,18 @@ def test_fixtures_carry_provenance():
         m = re.search(r"tools/gen_golden.py --only (\w+)$", str(z["__generator__"]))
         assert m and m.group(1) in keys, (f, str(z["__generator__"]))
         assert "seed" in str(z["__seeding__"])
+
+
+@pytest.mark.parametrize("gname", ["BA_100_ID0", "PL_20_ID0"])
+def test_mcpg_weighted_sampler_oracle(golden, gname):
+    """The weighted MaxCut sampler of the upstream MCPG package (methods/MCPG/sampling.py:89-127), bit for bit."""
+    z = golden("mcpg_weighted")
+    g = z[f"{gname}/graph"]
+    n = int(g[:, :2].max()) + 1
+    vs, xs_good, start, value, expected = onp.mcpg_sampling_maxcut(
+        g, n, z[f"{gname}/sorted_degree_nodes"], z[f"{gname}/start"], z[f"{gname}/probs"], int(z[f"{gname}/num_ls"]),
+        int(z[f"{gname}/change_times"]), int(z[f"{gname}/M"]), z[f"{gname}/metro_index"], z[f"{gname}/metro_u"], z[f"{gname}/uniforms"])
+    assert np.array_equal(start.astype(np.uint8), z[f"{gname}/metro_out"])
+    assert np.array_equal(vs, z[f"{gname}/vs"]) and np.array_equal(xs_good, z[f"{gname}/xs_good"])
+    np.testing.assert_allclose(value, z[f"{gname}/value"], rtol=0, atol=1e-4)
+    assert float(z[f"{gname}/edge_weight_sum"]) == float(g[:, 2].sum())

@@ -548,6 +548,96 @@ def gen_qubo():
     save("qubo", **out)
 
 
+def _load_upstream_mcpg(modname):
+    """rlsolver/methods/MCPG/{sampling,dataloader}.py: both do `from config import DEVICE, Problem` (the package's own
+    config.py) and need stand-ins for torch_scatter (MaxSAT only) / torch_geometric.data.Data (an attribute bag)."""
+    ts = types.ModuleType("torch_scatter")
+    ts.scatter = lambda *a, **k: (_ for _ in ()).throw(NotImplementedError("MaxSAT only"))
+    sys.modules.setdefault("torch_scatter", ts)
+    load_mcpg_module  # noqa: B018  (defines the torch_geometric stand-in on first use)
+    tg = types.ModuleType("torch_geometric")
+    tgd = types.ModuleType("torch_geometric.data")
+
+    class Data:
+        def __init__(self, **kw):
+            self.__dict__.update(kw)
+
+        def to(self, device):
+            return self
+
+        @property
+        def num_edges(self):
+            return self.edge_index.shape[1]
+
+    tgd.Data = Data
+    tg.data = tgd
+    sys.modules["torch_geometric"] = tg
+    sys.modules["torch_geometric.data"] = tgd
+    pkg = os.path.join(REF, "rlsolver", "methods", "MCPG")
+    saved_cfg = sys.modules.pop("config", None)
+    sys.path.insert(0, pkg)
+    try:
+        spec = importlib.util.spec_from_file_location("ref_mcpg_" + modname, os.path.join(pkg, modname + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    finally:
+        sys.path.remove(pkg)
+        sys.modules.pop("config", None)
+        if saved_cfg is not None:
+            sys.modules["config"] = saved_cfg
+    return mod
+
+
+def gen_mcpg_weighted():
+    """mcpg_sampling_maxcut of rlsolver/methods/MCPG/sampling.py:89-127 (weighted MaxCut: gauge fix, weighted
+    node-sequential search, weighted expected value) on +-1 / small-integer weighted copies of two graphs loaded by
+    the package's own maxcut_dataloader (dataloader.py:53-103); every torch draw recorded."""
+    import tempfile
+    smp = _load_upstream_mcpg("sampling")
+    dl = _load_upstream_mcpg("dataloader")
+    from rlsolver.methods.util_read_data import read_mygraph
+    out = {}
+    for gname, wset in (("BA_100_ID0", (-1, 1)), ("PL_20_ID0", (-2, -1, 1, 3))):
+        mygraph = read_mygraph(os.path.join(DATA, GRAPHS[gname]))
+        n = max(max(a, b) for a, b, _ in mygraph) + 1
+        rng = np.random.RandomState(47)
+        wl = [(a, b, int(rng.choice(wset))) for a, b, _ in mygraph]
+        with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False) as f:
+            f.write(f"{n} {len(wl)}\n")
+            for a, b, w in wl:
+                f.write(f"{a + 1} {b + 1} {w}\n")
+            path = f.name
+        data, num_nodes = dl.maxcut_dataloader(path, device=th.device("cpu"))
+        os.unlink(path)
+        out[f"{gname}/graph"] = np.asarray(wl, dtype=np.int64)
+        out[f"{gname}/sorted_degree_nodes"] = data.sorted_degree_nodes.numpy().copy()
+        out[f"{gname}/weighted_degree"] = np.asarray(data.weighted_degree, dtype=np.float64)
+        out[f"{gname}/edge_weight_sum"] = np.float64(data.edge_weight_sum)
+        M, R, num_ls = 8, 4, 3
+        C = M * R
+        g = th.Generator().manual_seed(23)
+        probs = th.rand(num_nodes, generator=g) * 0.6 + 0.2
+        start = th.randint(0, 2, (num_nodes, C), generator=g).float()
+        change_times = max(1, num_nodes // 10)
+        th.manual_seed(301)
+        with Recorder("rand", "randint") as rec:
+            vs, xs_good, start_out, value = smp.mcpg_sampling_maxcut(data, start.clone(), probs, num_ls, change_times, M,
+                                                                     device=th.device("cpu"))
+        nm = len(rec.log["randint"])                     # metro rounds actually run (one randint + one rand each)
+        out[f"{gname}/probs"] = probs.numpy().copy()
+        out[f"{gname}/start"] = u8(start)
+        out[f"{gname}/change_times"] = np.int64(change_times)
+        out[f"{gname}/M"], out[f"{gname}/R"], out[f"{gname}/num_ls"] = np.int64(M), np.int64(R), np.int64(num_ls)
+        out[f"{gname}/metro_index"] = th.stack(rec.log["randint"]).numpy().copy()
+        out[f"{gname}/metro_u"] = th.stack(rec.log["rand"][:nm]).numpy().copy()
+        out[f"{gname}/uniforms"] = th.stack(rec.log["rand"][nm:]).numpy().copy().reshape(num_ls, num_nodes, C)
+        out[f"{gname}/vs"] = vs.numpy().copy()
+        out[f"{gname}/xs_good"] = xs_good.numpy().copy()
+        out[f"{gname}/metro_out"] = u8(start_out)
+        out[f"{gname}/value"] = value.numpy().copy()
+    save("mcpg_weighted", **out)
+
+
 def gen_spinsystem():
     """The batched PECO SpinSystem (ECO_S2V/src/envs/spinsystem_PECO.py) driven with ONE shared
     +-1-weighted graph for every env (a generator stub returning W.expand(B, N, N)), two configs:
@@ -797,7 +887,7 @@ def gen_isco_steps():
     save("isco_steps", **out)
 
 
-ALL = {"isco_steps": gen_isco_steps, "spinsystem_cpu": gen_spinsystem_cpu, "spinsystem": gen_spinsystem, "qubo": gen_qubo, "isco_maxcut": gen_isco_maxcut, "maxcut": gen_maxcut, "sweep": gen_sweep, "lsclass": gen_local_search_class, "ppo": gen_ppo,
+ALL = {"mcpg_weighted": gen_mcpg_weighted, "isco_steps": gen_isco_steps, "spinsystem_cpu": gen_spinsystem_cpu, "spinsystem": gen_spinsystem, "qubo": gen_qubo, "isco_maxcut": gen_isco_maxcut, "maxcut": gen_maxcut, "sweep": gen_sweep, "lsclass": gen_local_search_class, "ppo": gen_ppo,
        "select": gen_select, "mcpg": gen_mcpg, "tsp": gen_tsp, "encoder": gen_encoder,
        "wgain": gen_weighted_gain}
 
@@ -811,7 +901,8 @@ if __name__ == "__main__":
         print("==", w)
         _CURRENT["key"] = w
         # every generator starts from its own fixed global-RNG state, so any --only subset regenerates byte-identically
-        k = sorted(ALL).index(w)
+        import zlib
+        k = zlib.crc32(w.encode()) % 1_000_000         # a function of the key alone: adding a fixture moves no other seed
         th.manual_seed(90000 + k)
         np.random.seed(90000 + k)
         ALL[w]()
