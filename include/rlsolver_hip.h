@@ -418,6 +418,13 @@ int rls_mcpg_unpack_chains(const uint64_t* packed, int64_t N, int64_t C, float* 
 int rls_qubo_local_search_value(const float* Q, int64_t n, const float* xs_in, float* xs_out, int64_t C,
                                 int64_t num_ls, int binary, float* value, void* stream);
 
+/* K11, sparse form: the same coordinate search and value with Q in CSR form -- rowptr int32
+ * [n+1], col int32 [nnz], val f32 [nnz], the diagonal stored as ordinary entries; step i costs O(nnz_i), not O(n).
+ * Same arguments and outputs otherwise; same exactness condition (integer-valued Q). */
+int rls_qubo_sparse_local_search_value(const int32_t* rowptr, const int32_t* col, const float* val, int64_t n,
+                                       const float* xs_in, float* xs_out, int64_t C, int64_t num_ls, int binary,
+                                       float* value, void* stream);
+
 /* --------------------------------------------------------------------- TSP */
 
 /* K12 ISCO_TSP.calculate_distance(sample)  envs/env_ISCO.py:346-350.

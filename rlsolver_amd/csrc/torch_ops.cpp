@@ -293,6 +293,19 @@ void qubo_local_search_value(const Tensor& Q, const Tensor& xs_in, Tensor xs_out
                                    (float*)p(value), cur_stream(Q)), "rls_qubo_local_search_value");
 }
 
+void qubo_sparse_local_search_value(const Tensor& rowptr, const Tensor& col, const Tensor& val, const Tensor& xs_in, Tensor xs_out,
+                                    int64_t num_ls, bool binary, Tensor value) {
+    dev(rowptr, "rowptr", I32);
+    dev(col, "col", I32);
+    dev(val, "val", F32);
+    dev(xs_in, "xs_in", F32);
+    dev(xs_out, "xs_out", F32);
+    dev(value, "value", F32);
+    ok(rls_qubo_sparse_local_search_value((const int32_t*)p(rowptr), (const int32_t*)p(col), (const float*)p(val), rowptr.numel() - 1,
+                                          (const float*)p(xs_in), (float*)p(xs_out), xs_in.size(1), num_ls, binary, (float*)p(value),
+                                          cur_stream(xs_in)), "rls_qubo_sparse_local_search_value");
+}
+
 // ------------------------------------------------------------------------------------------------ TSP / ISCO
 void tsp_tour_length(const Tensor& dist, const Tensor& perm, Tensor length) {
     dev(dist, "dist", F32);
@@ -409,6 +422,8 @@ TORCH_LIBRARY(rlsolver_hip, m) {
     m.def("mcpg_pack_chains(Tensor xs, Tensor(a!) packed) -> ()");
     m.def("mcpg_unpack_chains(Tensor packed, int C, Tensor(a!) xs) -> ()");
     m.def("qubo_local_search_value(Tensor Q, Tensor xs_in, Tensor(a!) xs_out, int num_ls, bool binary, Tensor(b!) value) -> ()");
+    m.def("qubo_sparse_local_search_value(Tensor rowptr, Tensor col, Tensor val, Tensor xs_in, Tensor(a!) xs_out, int num_ls, bool binary, "
+          "Tensor(b!) value) -> ()");
     m.def("tsp_tour_length(Tensor dist, Tensor perm, Tensor(a!) length) -> ()");
     m.def("tsp_swap_delta_all(Tensor dist, Tensor perm, Tensor selected, float temperature, Tensor(a!) logratio, Tensor(b!) indices, "
           "Tensor(c!) ban) -> ()");
@@ -449,6 +464,7 @@ TORCH_LIBRARY_IMPL(rlsolver_hip, CUDA, m) {   // "CUDA" is the HIP dispatch key 
     m.impl("mcpg_pack_chains", &mcpg_pack_chains);
     m.impl("mcpg_unpack_chains", &mcpg_unpack_chains);
     m.impl("qubo_local_search_value", &qubo_local_search_value);
+    m.impl("qubo_sparse_local_search_value", &qubo_sparse_local_search_value);
     m.impl("tsp_tour_length", &tsp_tour_length);
     m.impl("tsp_swap_delta_all", &tsp_swap_delta_all);
     m.impl("tsp_apply_swap", &tsp_apply_swap);

@@ -46,10 +46,48 @@ def qubo_local_search_value(Q: TEN, xs: TEN, num_ls: int, binary: bool):
     return out, value
 
 
+def qubo_to_csr(Q: TEN):
+    """Dense Q [n, n] -> (rowptr int32 [n+1], col int32 [nnz], val f32 [nnz]) on Q's device, diagonal included."""
+    Qc = Q.detach().to(torch.float32)
+    nz = Qc != 0
+    counts = nz.sum(dim=1)
+    rowptr = torch.zeros(Qc.shape[0] + 1, dtype=torch.int32, device=Q.device)
+    rowptr[1:] = counts.cumsum(0).to(torch.int32)
+    idx = nz.nonzero()
+    return rowptr.contiguous(), idx[:, 1].to(torch.int32).contiguous(), Qc[nz].contiguous()
+
+
+def qubo_sparse_local_search_value(csr, xs: TEN, num_ls: int, binary: bool):
+    """The same coordinate search + value on a CSR matrix (rowptr, col, val) -- O(nnz) per sweep."""
+    rowptr, col, val = csr
+    dev = xs.device
+    _check(rowptr, "rowptr", (torch.int32,), dev)
+    _check(col, "col", (torch.int32,), dev)
+    _check(val, "val", (torch.float32,), dev)
+    n = rowptr.numel() - 1
+    _check(xs, "xs", (torch.float32,), dev)
+    if xs.dim() != 2 or xs.shape[0] != n:
+        raise ValueError(f"xs must be [{n}, C]")
+    out = torch.empty_like(xs)
+    value = torch.empty(xs.shape[1], dtype=torch.float32, device=dev)
+    _abi.call("rls_qubo_sparse_local_search_value", _ptr(rowptr), _ptr(col), _ptr(val), n, _ptr(xs), _ptr(out), xs.shape[1], num_ls,
+              int(bool(binary)), _ptr(value), _stream(dev))
+    return out, value
+
+
+SPARSE_DENSITY = 0.25     # below this fill the CSR kernel does less work than the dense one
+
+
 def _sample(data, start_result, probs, num_ls, change_times, total_mcmc_num, device, binary, index, u):
     Q = data['Q'].to(device=device, dtype=torch.float32).contiguous()
     raw_samples = metro_sampling(probs, start_result, change_times, device, index=index, u=u)   # never modifies its input
-    samples, res_sample = qubo_local_search_value(Q, raw_samples.contiguous(), num_ls, binary)
+    if 'csr' not in data and float((Q != 0).float().mean()) < SPARSE_DENSITY:
+        data['csr'] = qubo_to_csr(Q)
+    if data.get('csr') is not None:
+        samples, res_sample = qubo_sparse_local_search_value(data['csr'], raw_samples.contiguous(), num_ls, binary)
+    else:
+        data.setdefault('csr', None)
+        samples, res_sample = qubo_local_search_value(Q, raw_samples.contiguous(), num_ls, binary)
     res_reshape = res_sample.reshape(-1, total_mcmc_num)
     idx = torch.argmax(res_reshape, dim=0)
     idx = torch.arange(total_mcmc_num, device=res_sample.device) + idx * total_mcmc_num

@@ -91,7 +91,7 @@ def test_every_device_entry_point_is_a_torch_op():
     declared = {n[len("rls_"):] for n in declared_functions()}
     assert set(torch_ops.DEVICE_ENTRY_POINTS) | set(torch_ops.HOST_ENTRY_POINTS) == declared
     assert not set(torch_ops.DEVICE_ENTRY_POINTS) & set(torch_ops.HOST_ENTRY_POINTS)
-    assert len(torch_ops.DEVICE_ENTRY_POINTS) >= 33
+    assert len(torch_ops.DEVICE_ENTRY_POINTS) >= 34
     for name in torch_ops.DEVICE_ENTRY_POINTS:
         op = getattr(torch.ops.rlsolver_hip, name)
         assert torch._C._dispatch_has_kernel_for_dispatch_key(f"rlsolver_hip::{name}", "CUDA"), name

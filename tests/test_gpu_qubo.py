@@ -45,3 +45,48 @@ def test_qubo_value_is_quadratic_form_and_sweep_is_monotone():
         s2 = x2.cpu().numpy() if binary else 2 * x2.cpu().numpy() - 1
         assert np.array_equal(v2.cpu().numpy(), np.einsum("ic,ij,jc->c", s2, Qn, s2).astype(np.float32))
         assert (v2 >= v1).all()                                          # symmetric Q: coordinate ascent never loses
+
+
+@pytest.mark.parametrize("n,C,density", [(150, 130, 0.05), (1000, 70, 0.01), (64, 64, 0.5), (333, 200, 0.2)])
+def test_qubo_sparse_equals_dense_and_block_sweep_equals_sequential(n, C, density):
+    """(1) The block Gauss-Seidel kernel (8 variables per block, in-block corrections) gives exactly the variable-by-
+    variable sweep of MCPG/sampling.py:332-337 / :357-362 -- checked against a numpy restatement of that loop;
+    (2) the CSR kernel gives exactly what the dense kernel gives (integer Q: every sum is order independent)."""
+    rng = np.random.RandomState(n)
+    Qn = (rng.randint(-30, 31, size=(n, n)) * (rng.rand(n, n) < density)).astype(np.float32)
+    Qn = np.triu(Qn) + np.triu(Qn, 1).T
+    x0 = rng.randint(0, 2, size=(n, C)).astype(np.float32)
+    Q = dev(Qn)
+    csr = q.qubo_to_csr(Q)
+    assert int(csr[0][-1]) == int((Qn != 0).sum())
+    for binary in (False, True):
+        s = x0.copy() if binary else 2 * x0 - 1
+        for cnt in range(2):                                                   # the reference's loop, sampling.py:332-337
+            for i in range(n):
+                s[i] = 0
+                res = Qn[i] @ s
+                s[i] = ((res > -Qn[i, i] / 2).astype(np.float32)) if binary else (2 * (res > 0) - 1).astype(np.float32)
+        want_x = s if binary else (s + 1) / 2
+        want_v = np.einsum("ic,ij,jc->c", s, Qn, s).astype(np.float32)
+        xd, vd = q.qubo_local_search_value(Q, dev(x0), 2, binary)
+        xs_, vs_ = q.qubo_sparse_local_search_value(csr, dev(x0), 2, binary)
+        assert np.array_equal(xd.cpu().numpy(), want_x) and np.array_equal(vd.cpu().numpy(), want_v)
+        assert torch.equal(xd, xs_) and torch.equal(vd, vs_)
+
+
+def test_qubo_sampler_takes_the_sparse_path_below_a_quarter_fill():
+    rng = np.random.RandomState(5)
+    n, M, R = 200, 16, 4
+    Qn = (rng.randint(-9, 10, size=(n, n)) * (rng.rand(n, n) < 0.03)).astype(np.float32)
+    Qn = np.triu(Qn) + np.triu(Qn, 1).T
+    start = dev(rng.randint(0, 2, size=(n, M * R)).astype(np.float32))
+    probs = dev((rng.rand(n) * 0.6 + 0.2).astype(np.float32))
+    T = n // 10
+    index = dev(rng.randint(0, n, size=(5 * T, M * R)).astype(np.int64))
+    u = dev(rng.rand(5 * T, M * R).astype(np.float32))
+    sparse = {"Q": dev(Qn), "nvar": n}
+    dense = {"Q": dev(Qn), "nvar": n, "csr": None}
+    a = q.mcpg_sampling_qubo(sparse, start, probs, 2, T, M, DEV, index=index, u=u)
+    b = q.mcpg_sampling_qubo(dense, start, probs, 2, T, M, DEV, index=index, u=u)
+    assert sparse["csr"] is not None and dense["csr"] is None
+    assert all(torch.equal(x, y) for x, y in zip(a, b))

@@ -202,8 +202,18 @@ def qubo_suite(tag, n, C, num_ls, iters):
     xs = (torch.rand((n, C), device=dev) < 0.5).float()
     for binary in (False, True):
         t = timeit(lambda i: mq.qubo_local_search_value(Qd, xs, num_ls, binary), iters, warm=1)
-        emit(tag, f"K11 qubo_local_search_value ({'0/1' if binary else '+-1'}, num_ls={num_ls})", "variable updates",
-             C * n * (num_ls + 1), t, None, f"n={n} dense, C={C}; {2 * n * n * (num_ls + 1) * C / t / 1e12:.2f} Tflop/s of f32 FMA work")
+        rec_flops = 2 * n * n * (num_ls + 1) * C / t
+        print(json.dumps({"config": tag, "kernel": f"K11 qubo_local_search_value ({'0/1' if binary else '+-1'}, num_ls={num_ls})",
+                          "us_per_launch": round(t * 1e6, 2), "unit": "variable updates", "units_per_s": C * n * (num_ls + 1) / t,
+                          "achieved_TFLOPs_f32": rec_flops / 1e12, "frac_of_157TFLOPs_vector_peak": rec_flops / 157.3e12,
+                          "note": f"n={n} dense, C={C}; compute-bound contraction: roofline = f32 vector peak (3 VALU per multiply-add "
+                                  "bound it at ~1/3)"}), flush=True)
+    Qs = Q * (rng.rand(n, n) < 0.02)
+    Qs = (np.triu(Qs) + np.triu(Qs, 1).T).astype(np.float32)
+    csr = mq.qubo_to_csr(torch.from_numpy(Qs).to(dev))
+    t = timeit(lambda i: mq.qubo_sparse_local_search_value(csr, xs, num_ls, False), iters, warm=1)
+    emit(tag, f"K11s qubo_sparse_local_search_value (+-1, 2 % fill, num_ls={num_ls})", "variable updates", C * n * (num_ls + 1), t, None,
+         f"nnz={int(csr[0][-1])}")
 
 
 it = 5 if (a.quick or a.profile) else 30
