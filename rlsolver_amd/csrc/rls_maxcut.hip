@@ -307,6 +307,21 @@ __global__ void k_node_cutdeg(const uint8_t* __restrict__ x, int64_t B, int64_t 
     }
 }
 
+// element-parallel local-search weights (no LDS tile: any N): ws[b,i] = #stored out-neighbours - mult * cutdeg[b,i]
+__global__ void k_ls_weights_elem(const uint8_t* __restrict__ x, int64_t B, int64_t N, const int32_t* __restrict__ erowptr,
+                                  const int32_t* __restrict__ ev, int mult, int32_t* __restrict__ ws) {
+    const int64_t total = B * N;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = t / N, i = t - b * N;
+        const uint8_t* row = x + b * N;
+        const bool xi = row[i] != 0;
+        const int r0 = erowptr[i], r1 = erowptr[i + 1];
+        int c = 0;
+        for (int j = r0; j < r1; ++j) c += ((row[ev[j]] != 0) != xi);
+        ws[t] = (r1 - r0) - mult * c;
+    }
+}
+
 template <bool WEIGHTED>
 __global__ void k_delta_all(const uint8_t* __restrict__ x, int64_t B, int64_t N,
                             const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
@@ -662,6 +677,105 @@ __global__ void k_rand_actions(int64_t* __restrict__ action, int64_t B, int64_t 
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------
+// Row kernels: graphs whose 64-env bit tile (8 N bytes) does not fit LDS (N > ~19 000: G81-class Gset graphs).
+// One wave owns ONE env and keeps its row in LDS as plain BYTES (N bytes: up to N = 160 000 with one wave per
+// workgroup), so K1 / K6 / K5 stay exact and on chip; throughput is per-env (no 64-env bit parallelism) -- a
+// functional path for sizes the tile kernels cannot take, not a roofline one.
+template <typename T>
+__device__ __forceinline__ void row_load_bytes(const T* __restrict__ xr, int64_t N, uint8_t* row, int lane) {
+    for (int64_t i = lane; i < N; i += kWave) row[i] = spin_is_set(xr[i]) ? 1 : 0;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ int64_t row_cut_count(const uint8_t* row, const int32_t* __restrict__ eu, const int32_t* __restrict__ ev,
+                                                 int64_t E, int lane) {
+    int cnt = 0;
+    for (int64_t e = lane; e < E; e += kWave) cnt += row[eu[e]] != row[ev[e]];
+    return (int64_t)wave_sum_i32(cnt);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_maxcut_obj_rows(const T* __restrict__ x, int64_t B, int64_t N, const int32_t* __restrict__ eu,
+                                                         const int32_t* __restrict__ ev, int64_t E, int halve, int64_t* __restrict__ obj) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wib = threadIdx.x / kWave;
+    const int64_t b = (int64_t)blockIdx.x * (blockDim.x / kWave) + wib;
+    if (b >= B) return;
+    uint8_t* row = smem + (size_t)wib * (((size_t)N + 15) & ~(size_t)15);
+    row_load_bytes<T>(x + b * N, N, row, lane);
+    int64_t total = row_cut_count(row, eu, ev, E, lane);
+    if (halve) total >>= 1;
+    if (lane == 0) obj[b] = total;
+}
+
+__global__ __launch_bounds__(256) void k_maxcut_propose_accept_rows(uint8_t* __restrict__ x, const uint8_t* __restrict__ mask, int64_t B,
+                                                                    int64_t N, const int32_t* __restrict__ eu,
+                                                                    const int32_t* __restrict__ ev, int64_t E, int halve,
+                                                                    int64_t* __restrict__ obj) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wib = threadIdx.x / kWave;
+    const int64_t b = (int64_t)blockIdx.x * (blockDim.x / kWave) + wib;
+    if (b >= B) return;
+    uint8_t* row = smem + (size_t)wib * (((size_t)N + 15) & ~(size_t)15);
+    const uint8_t* xr = x + b * N;
+    const uint8_t* mr = mask + b * N;
+    for (int64_t i = lane; i < N; i += kWave) row[i] = (uint8_t)((xr[i] != 0) ^ (mr[i] != 0));
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    int64_t total = row_cut_count(row, eu, ev, E, lane);
+    if (halve) total >>= 1;
+    if (total >= obj[b]) {                                               // vs1.ge(vs0), util_read_data.py:199
+        for (int64_t i = lane; i < N; i += kWave) x[b * N + i] = row[i];
+        if (lane == 0) obj[b] = total;
+    }
+}
+
+// K5 on a byte row: strictly sequential over i = 0 .. N-1; the lanes split node i's CSR row.
+template <bool WEIGHTED>
+__global__ __launch_bounds__(256) void k_maxcut_greedy_sweep_rows(uint8_t* __restrict__ x, int64_t B, int64_t N,
+                                                                  const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                                  const int32_t* __restrict__ wgt, int halve_unused,
+                                                                  int64_t* __restrict__ obj) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wib = threadIdx.x / kWave;
+    const int64_t b = (int64_t)blockIdx.x * (blockDim.x / kWave) + wib;
+    if (b >= B) return;
+    uint8_t* row = smem + (size_t)wib * (((size_t)N + 15) & ~(size_t)15);
+    row_load_bytes<uint8_t>(x + b * N, N, row, lane);
+    int64_t gain_total = 0;
+    for (int64_t i = 0; i < N; ++i) {
+        const int r0 = rowptr[i], r1 = rowptr[i + 1];
+        const uint8_t xi = row[i];
+        int acc = 0;
+        for (int j = r0 + lane; j < r1; j += kWave) {
+            const bool same = row[col[j]] == xi;
+            if constexpr (WEIGHTED) acc += same ? wgt[j] : -wgt[j];
+            else acc += same ? 1 : -1;
+        }
+        const int gain = wave_sum_i32(acc);                               // cut(after the flip) - cut(before)
+        if (gain >= 0) {                                                  // ties accept (update_xs_by_vs uses ge)
+            if (lane == 0) row[i] = xi ^ 1;
+            gain_total += gain;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
+    for (int64_t i = lane; i < N; i += kWave) x[b * N + i] = row[i];
+    if (lane == 0) obj[b] += gain_total;
+}
+
+static inline int rows_waves(int64_t N) {   // waves (= envs) per workgroup of a row kernel, 0 when even one row does not fit
+    const size_t per = ((size_t)N + 15) & ~(size_t)15;
+    if (per > (size_t)kLdsBytes) return 0;
+    int w = (int)((size_t)kLdsBytes / per);
+    return w > 4 ? 4 : w;
+}
+
 }  // namespace rls
 
 using namespace rls;
@@ -678,8 +792,21 @@ int rls_maxcut_obj(const rls_graph* g, const void* x, int spin_bytes, int64_t B,
     const int64_t N = g->num_nodes, E = g->num_stored_edges;
     const int tw = tile_waves_for(N);
     size_t lds = (size_t)N * 8 + (size_t)tw * kWave * 8;
-    RLS_REQUIRE(lds <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS per 64-env tile (max %d)",
-                (long long)N, lds, kLdsBytes);
+    if (lds > (size_t)kLdsBytes) {   // the 64-env bit tile does not fit: one env per wave on a byte row
+        const int rw = rows_waves(N);
+        RLS_REQUIRE(rw > 0, RLS_EUNSUPPORTED, "N=%lld: a row of %lld bytes does not fit LDS (max %d)", (long long)N, (long long)N, kLdsBytes);
+        const size_t lr = (size_t)rw * (((size_t)N + 15) & ~(size_t)15);
+        const dim3 gr((unsigned)ceil_div(B, rw)), br(rw * kWave);
+        const int hv = g->if_bidirectional ? 1 : 0;
+        if (spin_bytes == 1) {
+            if (lr > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_maxcut_obj_rows<uint8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lr);
+            hipLaunchKernelGGL(k_maxcut_obj_rows<uint8_t>, gr, br, lr, as_stream(stream), (const uint8_t*)x, B, N, g->eu, g->ev, E, hv, obj);
+        } else {
+            if (lr > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_maxcut_obj_rows<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lr);
+            hipLaunchKernelGGL(k_maxcut_obj_rows<float>, gr, br, lr, as_stream(stream), (const float*)x, B, N, g->eu, g->ev, E, hv, obj);
+        }
+        return check_launch("k_maxcut_obj_rows");
+    }
     const int P = pick_planes(E);
     RLS_REQUIRE(P != 0, RLS_EUNSUPPORTED, "E'=%lld too large", (long long)E);
     const bool vec = tile_rows_aligned(x, N, spin_bytes);
@@ -748,8 +875,15 @@ int rls_maxcut_propose_accept(const rls_graph* g, uint8_t* x, int64_t B, const u
     const int64_t N = g->num_nodes, E = g->num_stored_edges;
     const int tw = tile_waves_for(N);
     size_t lds = (size_t)N * 8 + (size_t)tw * kWave * 8;
-    RLS_REQUIRE(lds <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS (max %d)", (long long)N, lds,
-                kLdsBytes);
+    if (lds > (size_t)kLdsBytes) {   // the 64-env bit tile does not fit: one env per wave on a byte row
+        const int rw = rows_waves(N);
+        RLS_REQUIRE(rw > 0, RLS_EUNSUPPORTED, "N=%lld: a row does not fit LDS (max %d)", (long long)N, kLdsBytes);
+        const size_t lr = (size_t)rw * (((size_t)N + 15) & ~(size_t)15);
+        if (lr > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_maxcut_propose_accept_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lr);
+        hipLaunchKernelGGL(k_maxcut_propose_accept_rows, dim3((unsigned)ceil_div(B, rw)), dim3(rw * kWave), lr, as_stream(stream), x, mask, B, N,
+                           g->eu, g->ev, E, g->if_bidirectional ? 1 : 0, obj);
+        return check_launch("k_maxcut_propose_accept_rows");
+    }
     const int P = pick_planes(E);
     RLS_REQUIRE(P != 0, RLS_EUNSUPPORTED, "E'=%lld too large", (long long)E);
     const bool vec = tile_rows_aligned(x, N, 1) && tile_rows_aligned(mask, N, 1);
@@ -866,8 +1000,21 @@ int rls_maxcut_greedy_sweep(const rls_graph* g, uint8_t* x, int64_t B, int64_t* 
         return check_launch("k_maxcut_greedy_sweep");
     }
     const size_t lds = (size_t)N * 8;
-    RLS_REQUIRE(lds <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS (max %d)", (long long)N, lds,
-                kLdsBytes);
+    if (lds > (size_t)kLdsBytes) {   // the 64-env bit tile does not fit: one env per wave on a byte row
+        const int rw = rows_waves(N);
+        RLS_REQUIRE(rw > 0, RLS_EUNSUPPORTED, "N=%lld: a row does not fit LDS (max %d)", (long long)N, kLdsBytes);
+        const size_t lr = (size_t)rw * (((size_t)N + 15) & ~(size_t)15);
+        const dim3 gr((unsigned)ceil_div(B, rw)), br(rw * kWave);
+        // the symmetric CSR counts every undirected edge once per endpoint: the gain of a flip needs no halving
+        if (g->wgt) {
+            if (lr > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_maxcut_greedy_sweep_rows<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lr);
+            hipLaunchKernelGGL(k_maxcut_greedy_sweep_rows<true>, gr, br, lr, s, x, B, N, g->rowptr, g->col, g->wgt, 0, obj);
+        } else {
+            if (lr > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_maxcut_greedy_sweep_rows<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lr);
+            hipLaunchKernelGGL(k_maxcut_greedy_sweep_rows<false>, gr, br, lr, s, x, B, N, g->rowptr, g->col, g->wgt, 0, obj);
+        }
+        return check_launch("k_maxcut_greedy_sweep_rows");
+    }
 #define LAUNCH_SW(VEC, W)                                                                                  \
     do {                                                                                                   \
         auto kern = k_maxcut_greedy_sweep_generic<VEC, W>;                                                 \
@@ -968,8 +1115,11 @@ int rls_maxcut_ls_weights(const rls_graph* g, const uint8_t* x, int64_t B, int32
         return launch_node_stats_bits<2>(g, x, B, g->erowptr, g->ell_st_ptr, g->ell_st, (int)mult, ws, stream);
     const int64_t N = g->num_nodes;
     const size_t lds = node_stats_lds(N);
-    RLS_REQUIRE(lds <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS (max %d)", (long long)N, lds,
-                kLdsBytes);
+    if (lds > (size_t)kLdsBytes) {   // no tile for this N: element-parallel
+        hipLaunchKernelGGL(k_ls_weights_elem, dim3(grid_for(B * N, 256)), dim3(256), 0, as_stream(stream), x, B, N, g->erowptr, g->ev,
+                           (int)mult, ws);
+        return check_launch("k_ls_weights_elem");
+    }
     const dim3 grid((unsigned)ceil_div(B, kWave)), block(kTileWaves * kWave);
     hipStream_t s = as_stream(stream);
 #define LAUNCH_LW(VEC)                                                                                           \
