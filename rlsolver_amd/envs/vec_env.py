@@ -47,3 +47,9 @@ class MaxcutVecEnv:
     @property
     def best_obj(self):
         return self._env.last_reward.max()
+
+    def state_dict(self):
+        return self._env.state_dict()
+
+    def load_state_dict(self, d):
+        self._env.load_state_dict(d)

@@ -37,6 +37,13 @@ class LocalSearch:
         best, _ = ops.pick_best_of_repeats(cand, sim.calculate_obj_values(cand), num_sims, if_maximize=True)
         return best
 
+    # ---- checkpoint: the incumbents
+    def state_dict(self):
+        return {"good_xs": self.good_xs.clone(), "good_vs": self.good_vs.clone(), "num_sims": self.num_sims}
+
+    def load_state_dict(self, d):
+        self.good_xs, self.good_vs, self.num_sims = d["good_xs"].clone(), d["good_vs"].clone(), int(d["num_sims"])
+
     def random_search(self, num_iters: int = 8, num_spin: int = 8, noise_std: float = 0.3,
                       noise: Optional[TEN] = None):
         """LocalSearch.py:53-86: a copy of the incumbents goes through ``num_iters`` noisy top-``num_spin`` multi-flip

@@ -315,7 +315,7 @@ def test_get_return_packed_vs_oracle_and_autograd():
     obj.backward()
     w_obj, w_grad_p = onp.mcpg_get_return(probs.detach().cpu().numpy(), s, value, M, R)
     p = probs.detach().cpu().numpy().astype(np.float64)
-    np.testing.assert_allclose(float(obj), w_obj, rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(float(obj.detach()), w_obj, rtol=1e-5, atol=1e-4)
     np.testing.assert_allclose(lin.grad.cpu().numpy(), w_grad_p * p * (1 - p), rtol=2e-4, atol=2e-4)
     # the reference's expression through autograd (f32): same objective / gradient within f32 summation noise
     lin2 = torch.tensor(lin.detach().cpu().numpy(), device=DEV, requires_grad=True)
@@ -323,10 +323,10 @@ def test_get_return_packed_vs_oracle_and_autograd():
     sd = dev(s)
     ref = ((sd * p2 + (1 - sd) * (1 - p2)).log().sum(dim=1) * dev(value)).mean()
     ref.backward()
-    np.testing.assert_allclose(float(obj), float(ref), rtol=1e-4, atol=1e-2)
+    np.testing.assert_allclose(float(obj.detach()), float(ref.detach()), rtol=1e-4, atol=1e-2)
     np.testing.assert_allclose(lin.grad.cpu().numpy(), lin2.grad.cpu().numpy(), rtol=1e-3, atol=1e-3)
     # the reference-shaped call (float [C, N] samples) goes through the same kernel
-    assert float(amcpg.get_return(torch.sigmoid(lin.detach()), sd, dev(value), M, R)) == pytest.approx(float(obj), rel=1e-6)
+    assert float(amcpg.get_return(torch.sigmoid(lin.detach()), sd, dev(value), M, R)) == pytest.approx(float(obj.detach()), rel=1e-6)
 
 
 def test_mcpg_round_on_device_improves_and_prints_like_the_reference():

@@ -153,3 +153,40 @@ def test_rollout_captured_in_a_hipgraph_equals_eager():
         torch.cuda.synchronize()
         assert torch.equal(bufs[T & 1], want_x) and torch.equal(obj, want_obj) and torch.equal(tot, want_tot)
     assert torch.equal(ops.maxcut_obj(g, bufs[T & 1]), obj.long())
+
+
+def test_env_state_dict_roundtrip_gym_and_local_search():
+    """env-state checkpoint -- a gym env restored from state_dict() continues bit for bit; the
+    LocalSearch incumbents likewise."""
+    import types
+    from rlsolver_amd.envs.env_L2A import EnvMaxcut
+    from rlsolver_amd.envs.vec_env import MaxcutVecEnv
+    from rlsolver_amd.graph import generate_gnm
+    from rlsolver_amd.methods.LocalSearch import LocalSearch
+    n, B = 300, 70
+    mg = generate_gnm(n, 1500, 2)
+    env = MaxcutVecEnv(mg, n, B, max_step=7)
+    torch.manual_seed(0)
+    env.reset()
+    acts = [torch.randint(0, n, (B,), device=DEV) for _ in range(10)]
+    for a in acts[:4]:
+        env.step(a)
+    snap = env.state_dict()
+    outs = [tuple(t.clone() if torch.is_tensor(t) else t for t in env.step(a)[:4]) for a in acts[4:]]
+    env2 = MaxcutVecEnv(mg, n, B, max_step=7)
+    env2.load_state_dict(snap)
+    outs2 = [tuple(t.clone() if torch.is_tensor(t) else t for t in env2.step(a)[:4]) for a in acts[4:]]
+    assert all(torch.equal(x, y) for o, p in zip(outs, outs2) for x, y in zip(o, p))
+    sim = EnvMaxcut(mygraph=mg, device=DEV, num_nodes=n)
+    ls = LocalSearch(sim, n)
+    ls.reset(sim.generate_xs_randomly(B))
+    torch.manual_seed(5)
+    ls.random_search(num_iters=2, num_spin=4)
+    sd = ls.state_dict()
+    torch.manual_seed(6)
+    a = ls.random_search(num_iters=2, num_spin=4)
+    ls2 = LocalSearch(sim, n)
+    ls2.load_state_dict(sd)
+    torch.manual_seed(6)
+    b = ls2.random_search(num_iters=2, num_spin=4)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
