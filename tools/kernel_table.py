@@ -44,8 +44,13 @@ ROWS = [
     (r"k_tsp_swap_delta_all", None, 65536, 29 * NT, "K13 tsp_swap_delta_all | TSP-100 2^16"),
     (r"k_spin_step<float, true>", 16384 * 64, 16384, 24 * N22, "S1 spin_step | G22-sized 2^14 (6 rows x 4N change per step)"),
     (r"k_spin_step<float, true>", 4096 * 64, 4096, 24 * 200, "S1 spin_step | BA-200 4096"),
-    (r"k_mcpg_local_search_levels", None, 262144, 8 * NBA, "K7+K8 local_search_levels | BA-1e4 2^18 (f32 [N,C] in + out)"),
-    (r"k_mcpg_pick_gather", None, 2048, 4 * NBA, "K8b pick gather | 2048 kept chains"),
+    (r"k_qubo_ls_value", None, None, None, None),
+    (r"k_mcpg_local_search_levels<float, rls::Packed64", None, 262144, 4 * NBA + NBA // 8, "K7+K8 local_search_levels, f32 [N,C] in -> packed out | BA-1e4 2^18"),
+    (r"k_mcpg_local_search_levels<rls::Packed64, rls::Packed64", None, 262144, 2 * (NBA // 8), "K7+K8 local_search_levels, bit-packed in place | BA-1e4 2^18 (VALU-bound)"),
+    (r"k_mcpg_metro_packed", None, 262144, 2 * (NBA // 8), "K9 metro rounds, bit-packed (1000 rounds per launch) | BA-1e4 2^18 (latency-bound walk)"),
+    (r"k_mcpg_pick_gather_packed", None, 2048, 64 * (NBA // 8), "K8b best-of-repeats gather, bit-packed | 2048 kept chains (reads 64 tiles per kept tile)"),
+    (r"k_mcpg_value_bit_sums", None, 262144, NBA // 8, "get_return bit sums | BA-1e4 2^18"),
+    (r"k_isco", None, None, None, None),
 ]
 
 
@@ -107,7 +112,7 @@ def main():
         if f and w:
             rec["hbm_bytes"] = rec["read_bytes"] + rec["write_bytes"]
         for pat, want_grid, B, per_unit, label in ROWS:
-            if re.search(pat, name) is None or (want_grid is not None and want_grid != grid):
+            if label is None or re.search(pat, name) is None or (want_grid is not None and want_grid != grid):
                 continue
             rec.update({"row": label, "units_per_launch": B, "algorithmic_bytes": B * per_unit,
                         "achieved_GBps": B * per_unit / (rec["mean_us"] * 1e-6) / 1e9,
