@@ -5,6 +5,7 @@
 namespace rls {
 #ifdef RLS_PROF
 static __device__ unsigned long long g_prof[8];   // per translation unit (dev profiling only)
+static __device__ unsigned long long g_prof_w[5 * 65536];   // five stamps per wave, plain stores (atomics distort)
 #endif
 
 // =====================================================================================

@@ -27,12 +27,34 @@ __global__ __launch_bounds__(W * kWave) void k_maxcut_obj(const T* __restrict__ 
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     const int64_t b0 = (int64_t)blockIdx.x * kWave;
     unsigned char* stage = stage_off >= 0 ? smem + stage_off + w * kStageBytes : nullptr;
+#ifdef RLS_PROF
+    const unsigned long long t0 = wall_clock64();
+#endif
     tile_load_bits<T, VEC>(x, B, N, b0, words, lane, w, W, stage);
+#ifdef RLS_PROF
+    const unsigned long long t1 = wall_clock64();
+#endif
     __syncthreads();
+#ifdef RLS_PROF
+    const unsigned long long t2 = wall_clock64();
+#endif
     const int64_t part = tile_cut_count<P>(words, eu, ev, E, lane, w, W);
+#ifdef RLS_PROF
+    const unsigned long long t3 = wall_clock64();
+#endif
     int64_t total = block_sum_partials<W>(part, scratch, lane, w);
     if (halve) total >>= 1;  // values // 2, env_L2A.py:65 (count is even and >= 0)
     if (w == 0 && b0 + lane < B) obj[b0 + lane] = total;
+#ifdef RLS_PROF
+    if (lane == 0) {   // dev build only: phase durations summed over waves, first start / last end of the launch
+        const unsigned long long t4 = wall_clock64();
+        const int64_t wid = (int64_t)blockIdx.x * W + w;
+        if (wid < 65536) {
+            unsigned long long* q = g_prof_w + wid * 5;
+            q[0] = t0; q[1] = t1; q[2] = t2; q[3] = t3; q[4] = t4;
+        }
+    }
+#endif
 }
 
 // K1, wave-specialised and persistent: one workgroup per CU, edge list resident in LDS.
@@ -782,6 +804,19 @@ using namespace rls;
 
 extern "C" {
 
+#ifdef RLS_PROF
+// dev builds only (RLS_EXTRA_CFLAGS=-DRLS_PROF): read (reset != 0: clear) the phase counters of this translation unit
+int rls_dev_prof(unsigned long long* out, int reset) {
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, ~0ull, 0, 0};
+        return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z));
+    }
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof), sizeof(unsigned long long) * 8);
+}
+int rls_dev_prof_waves(unsigned long long* out, int64_t nwaves) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_prof_w), sizeof(unsigned long long) * 5 * (size_t)nwaves);
+}
+#endif
 
 int rls_maxcut_obj(const rls_graph* g, const void* x, int spin_bytes, int64_t B, int64_t* obj, void* stream) {
     if (int rc = check_graph(g)) return rc;

@@ -124,6 +124,10 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, NT ? 2 : 0);
 }
 
+// long rows take 128-byte row pieces in the staged tile loader (measured: G70-sized rows, N = 10^4: K1 314 -> 285 us;
+// G22-sized rows, N = 2000: no difference, and the shorter chunk list balances better over the waves)
+__device__ __forceinline__ bool tile_row128(int64_t N) { return N >= 4096; }
+
 // ---- row-piece staging (the env-major <-> lane-per-env corner turn).
 // A lane-per-env global access touches 64 different cache lines per instruction and the texture path
 // spends ~3 clocks per line: the tile load ran at 2.5 TB/s however many waves were resident.  So the
@@ -232,6 +236,61 @@ __device__ __forceinline__ void tile_load_bits_staged(const uint8_t* __restrict_
     }
 }
 
+// The same corner turn with 128-BYTE row pieces per load instruction (lane l -> row 8 i + (l & 7), 16-byte piece l >> 3):
+// an instruction touches 8 WHOLE 128-byte cache lines instead of 16 half lines, so the texture path handles half as
+// many lines for the same bytes.  A chunk is 64 rows x 128 nodes = two 64 x 64 transpose blocks, turned through the
+// same 4 KB stage one block at a time.
+template <int DEPTH, bool XORW>
+__device__ __forceinline__ void tile_load_bits_staged128(const uint8_t* __restrict__ x, int64_t B, int64_t N, int64_t b0,
+                                                         uint64_t* __restrict__ words, int lane, int w, int W,
+                                                         unsigned char* stage) {
+    using PV = u32x4;
+    const int64_t nchunk = (N + 127) >> 7;                         // 128-node chunks
+    const BitXpose xc = bit_xpose_consts(lane);
+    const int r = lane & 7, j = lane >> 3;                         // row within the instruction's 8, piece 0..7 of the row's 128 B
+    for (int64_t ch0 = w; ch0 < nchunk; ch0 += (int64_t)W * DEPTH) {
+        PV g[DEPTH][8];
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const int64_t off = ((ch0 + (int64_t)d * W) << 7) + j * 16;   // byte (= node) offset of this lane's piece
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int64_t rw = b0 + 8 * i + r;
+                PV z{};
+                g[d][i] = (rw < B && off < N) ? *reinterpret_cast<const PV*>(x + rw * N + off) : z;
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const int64_t ch = ch0 + (int64_t)d * W;
+            if (ch < nchunk) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {                     // block h = nodes 128 ch + 64 h .. + 63 = pieces 4h .. 4h + 3
+                    // lanes whose piece belongs to this block park it: slot (piece-in-block, row)
+                    if ((j >> 2) == h) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i)
+                            *reinterpret_cast<PV*>(stage + ((j & 3) * 64 + 8 * i + r) * 16) = g[d][i];
+                    }
+                    asm volatile("" ::: "memory");               // LDS ops of one wave execute in order
+                    uint32_t dw[16];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const PV v = *reinterpret_cast<const PV*>(stage + (q * 64 + lane) * 16);
+                        dw[q * 4 + 0] = v[0]; dw[q * 4 + 1] = v[1]; dw[q * 4 + 2] = v[2]; dw[q * 4 + 3] = v[3];
+                    }
+                    asm volatile("" ::: "memory");
+                    uint32_t r0 = pack_bits(u32x4{dw[0], dw[1], dw[2], dw[3]}, u32x4{dw[4], dw[5], dw[6], dw[7]});
+                    uint32_t r1 = pack_bits(u32x4{dw[8], dw[9], dw[10], dw[11]}, u32x4{dw[12], dw[13], dw[14], dw[15]});
+                    bit_transpose64(r0, r1, xc);
+                    const int64_t n = (ch << 7) + 64 * h + xc.node;
+                    if (n < N) put_word<XORW>(words, n, ((uint64_t)r1 << 32) | r0);
+                }
+            }
+        }
+    }
+}
+
 template <int PB>
 __device__ __forceinline__ void tile_store_bytes_staged(uint8_t* __restrict__ x, int64_t N, int64_t b0,
                                                         const uint64_t* __restrict__ words, int lane, int w, int W,
@@ -281,7 +340,10 @@ __device__ __forceinline__ void tile_load_bits(const T* __restrict__ x, int64_t 
     if constexpr (VEC && sizeof(T) == 1) {
         if (stage != nullptr) {   // `stage`: this wave's kStageBytes of LDS, 16-byte aligned; rows 4-byte aligned
             const uint8_t* xb = reinterpret_cast<const uint8_t*>(x);
-            if ((N & 15) == 0) tile_load_bits_staged<16, DEPTH, XORW>(xb, B, N, b0, words, lane, w, W, stage);
+            if ((N & 15) == 0) {
+                if (tile_row128(N)) tile_load_bits_staged128<(DEPTH > 2 ? 2 : DEPTH), XORW>(xb, B, N, b0, words, lane, w, W, stage);
+                else tile_load_bits_staged<16, DEPTH, XORW>(xb, B, N, b0, words, lane, w, W, stage);
+            }
             else if ((N & 7) == 0) tile_load_bits_staged<8, DEPTH, XORW>(xb, B, N, b0, words, lane, w, W, stage);
             else tile_load_bits_staged<4, DEPTH, XORW>(xb, B, N, b0, words, lane, w, W, stage);
             return;
