@@ -669,7 +669,10 @@ __global__ __launch_bounds__(256) void k_pick_best_of_repeats(const uint8_t* __r
 }
 
 // K14: spin(b, n) = bit (n & 127) of Philox(seed; ctr = (b_lo, b_hi, n >> 7, 'SPIN')), node 0 := 0
-__global__ void k_rand_spins(uint8_t* __restrict__ x, int64_t B, int64_t N, uint64_t seed, int64_t env_offset) {
+// A thread owns 16 spins = one 16-byte store (VEC16: rows start 16-byte aligned), consecutive lanes consecutive
+// pieces, so a wave's store covers 1 KB of a row.  (One byte store per spin ran at 0.8 TB/s.)
+template <bool VEC16>
+__global__ __launch_bounds__(256) void k_rand_spins(uint8_t* __restrict__ x, int64_t B, int64_t N, uint64_t seed, int64_t env_offset) {
     const int64_t chunks = (N + 15) >> 4;  // 16 spins per thread
     const int64_t total = B * chunks;
     const Philox ph(seed);
@@ -679,11 +682,21 @@ __global__ void k_rand_spins(uint8_t* __restrict__ x, int64_t B, int64_t N, uint
         const uint64_t gb = (uint64_t)(b + env_offset);
         uint32_t r[4];
         ph((uint32_t)gb, (uint32_t)(gb >> 32), (uint32_t)(ch >> 3), 0x5350494Eu, r);
-        const uint32_t bits = (r[(ch & 7) >> 1] >> (((ch & 7) & 1) * 16)) & 0xffffu;
+        uint32_t bits = (r[(ch & 7) >> 1] >> (((ch & 7) & 1) * 16)) & 0xffffu;
+        if (ch == 0) bits &= ~1u;  // xs[:, 0] = 0, env_L2A.py:84
         const int64_t n0 = ch << 4;
         uint8_t* row = x + b * N;
-        for (int k = 0; k < 16 && n0 + k < N; ++k) row[n0 + k] = (uint8_t)((bits >> k) & 1u);
-        if (ch == 0) row[0] = 0;  // xs[:, 0] = 0, env_L2A.py:84
+        if constexpr (VEC16) {
+            // nibble -> 4 bytes of 0/1: the multiply puts bit j at bit 8j (+ copies the mask drops)
+            uint4 v;
+            v.x = ((bits & 0xFu) * 0x00204081u) & 0x01010101u;
+            v.y = (((bits >> 4) & 0xFu) * 0x00204081u) & 0x01010101u;
+            v.z = (((bits >> 8) & 0xFu) * 0x00204081u) & 0x01010101u;
+            v.w = (((bits >> 12) & 0xFu) * 0x00204081u) & 0x01010101u;
+            *reinterpret_cast<uint4*>(row + n0) = v;
+        } else {
+            for (int k = 0; k < 16 && n0 + k < N; ++k) row[n0 + k] = (uint8_t)((bits >> k) & 1u);
+        }
     }
 }
 
@@ -1194,8 +1207,9 @@ int rls_rand_spins(uint8_t* x, int64_t B, int64_t N, uint64_t seed, int64_t env_
     RLS_REQUIRE(B >= 0 && N > 0, RLS_EINVAL, "bad sizes");
     if (B == 0) return RLS_OK;
     RLS_REQUIRE(x, RLS_EINVAL, "x is NULL");
-    hipLaunchKernelGGL(k_rand_spins, dim3(grid_for(B * ((N + 15) >> 4), 256)), dim3(256), 0, as_stream(stream), x,
-                       B, N, seed, env_offset);
+    const bool vec16 = (N % 16 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0);
+    hipLaunchKernelGGL(vec16 ? k_rand_spins<true> : k_rand_spins<false>, dim3(grid_for(B * ((N + 15) >> 4), 256)),
+                       dim3(256), 0, as_stream(stream), x, B, N, seed, env_offset);
     return check_launch("k_rand_spins");
 }
 

@@ -774,6 +774,7 @@ __global__ void k_mcpg_pick_argmin(const float* __restrict__ expected, int64_t M
     if (m >= M) return;
     float best = expected[m];
     int64_t br = 0;
+#pragma unroll 8
     for (int64_t r = 1; r < R; ++r) {
         const float v = expected[r * M + m];
         if (v < best) { best = v; br = r; }
@@ -905,6 +906,60 @@ __global__ __launch_bounds__(256) void k_mcpg_value_bit_sums(const uint64_t* __r
 #pragma unroll 16
     for (int e = 0; e < kWave; ++e) acc += ((wd >> e) & 1ull) ? v[e] : 0.0f;
     if (acc != 0.0f) atomicAdd(&A[n], acc);
+}
+
+// The same sums for N that fits LDS (4 N + 8 KB): a workgroup walks tiles blockIdx.x, + gridDim.x, ... and keeps its
+// partial A[] in LDS, so the atomics fall from one per (tile, node) -- 41 M onto 10^4 addresses at BA-10^4 / 2^18, the
+// whole cost of the kernel above -- to one per (workgroup, node).  Per tile the 64 values become 8 tables of 256 partial
+// sums (table q, entry i = sum of the values of chains 8q + j over the set bits j of i): a word costs 8 lookups + 8 adds
+// instead of 64 selects + 64 adds.
+constexpr int kBitSumThreads = 256;
+__global__ __launch_bounds__(kBitSumThreads) void k_mcpg_value_bit_sums_lut(const uint64_t* __restrict__ samples, int64_t N,
+                                                                            int64_t C, int64_t tiles,
+                                                                            const float* __restrict__ value,
+                                                                            float* __restrict__ A) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* lut = reinterpret_cast<float*>(smem);          // [8][256]
+    float* v = lut + 8 * 256;                             // [64]
+    float* acc = v + kWave;                               // [N]
+    const int t = threadIdx.x;
+    for (int64_t n = t; n < N; n += kBitSumThreads) acc[n] = 0.0f;
+    for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        __syncthreads();                                  // the previous tile's lookups are done
+        if (t < kWave) {
+            const int64_t c = tile * kWave + t;
+            v[t] = c < C ? value[c] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            float sum = 0.0f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sum += ((t >> j) & 1) ? v[8 * q + j] : 0.0f;
+            lut[q * 256 + t] = sum;
+        }
+        __syncthreads();
+        const uint64_t* row = samples + tile * N;
+        for (int64_t n0 = t; n0 < N; n0 += 4 * kBitSumThreads) {
+            uint64_t wd[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t n = n0 + (int64_t)u * kBitSumThreads;
+                wd[u] = n < N ? row[n] : 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t n = n0 + (int64_t)u * kBitSumThreads;
+                if (n >= N) break;
+                float sum = 0.0f;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) sum += lut[q * 256 + (int)((wd[u] >> (8 * q)) & 255u)];
+                acc[n] += sum;                            // n = t mod 256: this thread's own slot
+            }
+        }
+    }
+    for (int64_t n = t; n < N; n += kBitSumThreads)
+        if (acc[n] != 0.0f) atomicAdd(&A[n], acc[n]);
 }
 
 // bit-packed tiles <-> the reference's node-major f32 [N, C] surface (shims for callers that want it)
@@ -1164,6 +1219,18 @@ int rls_mcpg_value_bit_sums(const uint64_t* samples, int64_t N, int64_t C, const
     RLS_REQUIRE(N > 0 && C >= 0, RLS_EINVAL, "bad sizes");
     if (C == 0) return RLS_OK;
     RLS_REQUIRE(samples && value && A, RLS_EINVAL, "NULL pointer");
+    const int64_t tiles = ceil_div(C, kWave);
+    const size_t lds = (size_t)(8 * 256 + kWave) * 4 + (size_t)N * 4;
+    if (lds <= (size_t)kLdsBytes / 2) {
+        auto kern = k_mcpg_value_bit_sums_lut;
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        const int64_t per_cu = (int64_t)kLdsBytes / (int64_t)lds;           // resident workgroups per CU by LDS
+        int64_t grid = 256 * (per_cu < 8 ? per_cu : 8);
+        if (grid > tiles) grid = tiles;
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kBitSumThreads), lds, as_stream(stream), samples, N, C, tiles,
+                           value, A);
+        return check_launch("k_mcpg_value_bit_sums_lut");
+    }
     hipLaunchKernelGGL(k_mcpg_value_bit_sums, dim3((unsigned)ceil_div(N, 256), (unsigned)ceil_div(C, kWave)), dim3(256), 0,
                        as_stream(stream), samples, N, C, value, A);
     return check_launch("k_mcpg_value_bit_sums");

@@ -177,6 +177,36 @@ __global__ void k_rand_perms(int64_t* __restrict__ perm, int64_t B, int64_t N, u
     }
 }
 
+// Same shuffle with the 64 tours of a wave held in LDS as uint16 (lane = env; position k of the 64 envs sits in 66
+// halfwords = 33 dwords, so both the per-lane random accesses of the shuffle and the row-wise write-out, where lanes walk
+// k, spread over the banks).  The int64 rows then leave as contiguous 512-byte stores -- the in-place global shuffle
+// above moved 13x the bytes of its result (every swap a read-modify-write of an 800-byte-strided line).
+constexpr int kPermStride = 66;
+__global__ __launch_bounds__(kWave) void k_rand_perms_lds(int64_t* __restrict__ perm, int64_t B, int64_t N, uint64_t seed,
+                                                           int64_t env_offset) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint16_t* p = reinterpret_cast<uint16_t*>(smem);
+    const int lane = threadIdx.x;
+    const int64_t b0 = (int64_t)blockIdx.x * kWave, b = b0 + lane;
+    for (int64_t k = 0; k < N; ++k) p[k * kPermStride + lane] = (uint16_t)k;
+    const Philox ph(seed);
+    const uint64_t gb = (uint64_t)(b + env_offset);
+    for (int64_t k = N - 1; k >= 1; --k) {
+        uint32_t r[4];
+        ph((uint32_t)gb, (uint32_t)(gb >> 32), (uint32_t)k, 0x5045524Du, r);
+        const int64_t j = (int64_t)(((uint64_t)r[0] * (uint64_t)(k + 1)) >> 32);
+        const uint16_t t = p[k * kPermStride + lane];
+        p[k * kPermStride + lane] = p[j * kPermStride + lane];
+        p[j * kPermStride + lane] = t;
+    }
+    __syncthreads();
+    const int64_t nb = (B - b0 < kWave) ? B - b0 : kWave;
+    for (int64_t e = 0; e < nb; ++e) {
+        int64_t* row = perm + (b0 + e) * N;
+        for (int64_t k = lane; k < N; k += kWave) row[k] = (int64_t)p[k * kPermStride + e];
+    }
+}
+
 static inline bool dist_fits_lds(int64_t N, size_t extra) { return (size_t)N * N * 4 + extra <= (size_t)kLdsBytes - 1024; }
 
 static inline int tsp_block(int64_t N) { return N <= 256 ? kTspBlock : kTspBlockSmall; }
@@ -258,6 +288,14 @@ int rls_rand_perms(int64_t* perm, int64_t B, int64_t N, uint64_t seed, int64_t e
     RLS_REQUIRE(N > 0 && B >= 0, RLS_EINVAL, "bad sizes");
     if (B == 0) return RLS_OK;
     RLS_REQUIRE(perm, RLS_EINVAL, "perm is NULL");
+    const size_t lds = (size_t)N * kPermStride * sizeof(uint16_t);
+    if (N <= 65535 && lds <= (size_t)kLdsBytes / 2) {
+        auto kern = k_rand_perms_lds;
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(B, kWave)), dim3(kWave), lds, as_stream(stream), perm, B, N, seed,
+                           env_offset);
+        return check_launch("k_rand_perms_lds");
+    }
     hipLaunchKernelGGL(k_rand_perms, dim3((unsigned)ceil_div(B, 256)), dim3(256), 0, as_stream(stream), perm, B, N,
                        seed, env_offset);
     return check_launch("k_rand_perms");

@@ -49,6 +49,11 @@ def maxcut_suite(tag, n, m, B, seed, iters):
     g = ops.DeviceGraph(build_csr(generate_gnm(n, m, seed), num_nodes=n), dev)
     S = 4
     slots = [ops.rand_spins(B, n, s, dev) for s in range(S)]
+    if B >= 4096:
+        t = timeit(lambda i: ops.rand_spins(B, n, i, dev, out=slots[i % S]), max(3, iters // 4))
+        emit(tag, "K14 rand_spins (a4)", "envs", B, t, n, "bytes = the uint8 [B, N] result")
+        for sidx in range(S):
+            ops.rand_spins(B, n, sidx, dev, out=slots[sidx])
     obj = ops.maxcut_obj(g, slots[0]).to(torch.int32)
     rew = torch.empty(B, dtype=torch.float32, device=dev)
     acts = [ops.rand_actions(B, n, 7, s, dev) for s in range(8)]
@@ -159,6 +164,8 @@ def tsp_suite(tag, N, B, iters):
     dist, near, rnd = tsp_tables(generate_tsp_coords(N, 100), K=20)
     d = torch.from_numpy(dist).to(dev)
     perms = mops.rand_perms(B, N, 3, dev)
+    t = timeit(lambda i: mops.rand_perms(B, N, 3 + i, dev), max(3, iters // 4))
+    emit(tag, "K14 rand_perms", "tours", B, t, 8 * N, "bytes = the int64 [B, N] result")
     t = timeit(lambda i: mops.tsp_tour_length(d, perms), iters)
     emit(tag, "K12 tsp_tour_length", "tours", B, t, 8 * N + 4)
     sel = torch.roll(perms, 7, 1).contiguous()
