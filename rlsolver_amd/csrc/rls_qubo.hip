@@ -2,152 +2,240 @@
 //
 // The reference sweeps the variables one at a time, each step a dense row dot product  Q[i, :] . s  (s_i := 0) over
 // the CURRENT spins: n^2 multiply-adds per chain per sweep with a sequential dependency over i.  Only one term of
-// step i + 1 depends on step i, though -- so the sweep is done in BLOCKS of W variables (block Gauss-Seidel, the
-// same results): the W waves of a workgroup each take one row of the block and compute its dot product against the
-// spins as they stand at the block's start (the n-long part, all waves in parallel, Q rows read once each,
-// coalesced), then one wave resolves the block in order with the W x W in-block corrections
-//     res_k += sum_{j < k in block} Q[i0+k, i0+j] * (s_j_new - s_j_old)
-// -- two barriers per W variables instead of two per variable, and W times the arithmetic in flight.
+// step i + 1 depends on step i, though -- so the sweep is done in BLOCKS of 32 variables (block Gauss-Seidel, the
+// same results): the n-long part of a block's products against the spins as they stand at the block's start IS a GEMM,
+//     D[32 variables, chains] = Q[i0 .. i0+31, :] (32 x n)  x  S (n x chains, entries +-1 or 0/1),
+// and the block is then resolved in order with the in-block corrections
+//     res_k += sum_{j < k in block} Q[i0+k, i0+j] * (s_j_new - s_j_old).
 //
-// 64 chains per workgroup as a bit tile in LDS (words[j] bit c = variable j of chain c0 + c).  A wave turns each
-// 64-variable chunk of the tile into "lane = chain" form with one 64 x 64 bit transpose (rls_tile.h) and then spends
-// 3 VALU instructions per (variable, chain-lane): bit extract, convert, multiply-add with the row entry broadcast by
-// v_readlane.  Sums run in a different order than torch.mv's: exact w.r.t. the reference whenever Q is integer-valued
-// with |partial sums| < 2^24 (nbiq instances: entries +-[10, 100]), as before.
+// Both parts run on the matrix cores as v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate: the arithmetic of the
+// reference's f32 matmul; sums run in a different order than torch.mv's, exact w.r.t. the reference whenever Q is
+// integer-valued with |partial sums| < 2^24 -- nbiq instances: entries +-[10, 100]).
+//   * A workgroup owns NT tiles of 32 chains; its W waves split the n columns, each streaming its slice of the block's
+//     32 rows from L2 (64 contiguous bytes per lane and batch: a full 128-byte line per row), expanding the spins from a
+//     bit tile in LDS (one 32 NT-bit word per variable; 2 VALU per operand) and accumulating independent 32 x 32 tiles
+//     (NT = 1: even / odd column pairs), so consecutive MFMAs never wait for each other.  The diagonal term is zeroed in
+//     the A operand (s_i := 0 of sampling.py:333), not subtracted afterwards.
+//   * The partial tiles meet in LDS and wave 0 resolves the block: the residual tile R stays in accumulator layout,
+//     step k reads row k, decides, and applies the rank-1 update  R[m, c] += Q[i0+m, i0+k] * delta_k[c]  as ONE more
+//     MFMA (A = column k of the block's 32 x 32 corner of Q, held one row per lane; B = delta in one k-slot, zero in the
+//     other) -- 32 dependent MFMAs and ~10 VALU per step, where broadcast multiply-adds cost k per step plus a scalar
+//     load, LDS read or SGPR each.
+// MFMA operand layout (32x32x2): lane = (r = lane % 32, h = lane / 32); A[r][h], B[h][r]; D register v of lane (c, h) is
+// row 8 (v / 4) + 4 h + v % 4, column c.  A batch is 32 columns: half h takes the 16 contiguous columns kb + 16 h + e and
+// MFMA e pairs column kb + e (h = 0) with kb + 16 + e (h = 1) -- any pairing works as long as A and B agree.
 //
-// Roofline: this IS a dense contraction ([n, n] x [n, C] per sweep); on the f32 VALU it is bounded by
-// 3 instructions per multiply-add, i.e. ~1/3 of the 157 TFLOP/s vector peak.  An MFMA formulation would need the
-// spins expanded to f32 fragments per step and is outside the stated (sparse, HBM-bound) roofline -- SURVEY.md 8d.
+// Roofline: a dense contraction, 2 n^2 flops per chain per sweep (+ one more for the value) against the f32 matrix
+// peak (157 TFLOP/s); Q is re-read from L2 by every workgroup, 4 n^2 bytes per (workgroup, sweep), which is what NT = 2
+// halves once there are enough chains to fill the chip with 64-chain workgroups.
 #include "rls_tile.h"
 
 namespace rls {
 
-constexpr int kQuboWaves = 8;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 
-// sum over j of Q[i, j] * b_j for the lane's chain (b = the tile's bits), j != skip; also the plain row sum.
-// `qrow` points at Q[i, 0]; the row is read in 64-entry chunks, one coalesced load per chunk, next chunk in flight.
-__device__ __forceinline__ void qubo_row_dot(const float* __restrict__ qrow, int64_t n, int64_t skip,
-                                             const uint64_t* __restrict__ words, int lane, const BitXpose& xc,
-                                             float& ones_dot, float& row_sum) {
-    float acc = 0.0f, rs = 0.0f;
-    const int64_t nchunk = (n + 63) >> 6;
-    int64_t j = lane;
-    float qn = (j < n && j != skip) ? qrow[j] : 0.0f;
-    for (int64_t c = 0; c < nchunk; ++c) {
-        const float qv = qn;
-        const int64_t jn = ((c + 1) << 6) + lane;
-        qn = (c + 1 < nchunk && jn < n && jn != skip) ? qrow[jn] : 0.0f;
-        const int64_t jw = (c << 6) + lane;                      // lane l holds the word of variable 64c + l (bits = chains) ...
-        const uint64_t wd = jw < n ? words[jw] : 0ull;
-        uint32_t r0 = (uint32_t)wd, r1 = (uint32_t)(wd >> 32);
-        bit_transpose64(r0, r1, xc);                             // ... now lane p holds chain p: bit jj = variable 64c + jj
-        rs += qv;
-#pragma unroll
-        for (int jj = 0; jj < 32; ++jj) {
-            const float q = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qv), jj));
-            acc += q * (float)((r0 >> jj) & 1u);
-        }
-#pragma unroll
-        for (int jj = 0; jj < 32; ++jj) {
-            const float q = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qv), 32 + jj));
-            acc += q * (float)((r1 >> jj) & 1u);
-        }
-    }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) rs += __shfl_xor(rs, m, 64);
-    ones_dot = acc;
-    row_sum = rs;
-}
+template <int NT> struct QmWord;
+template <> struct QmWord<1> { using type = uint32_t; };
+template <> struct QmWord<2> { using type = uint64_t; };
+template <int NT> constexpr int qm_part_stride() { return 32 * NT + 8; }   // the lane halves (rows r, r + 4) hit disjoint banks
 
 template <bool BIN>
-__global__ __launch_bounds__(kQuboWaves * kWave) void k_qubo_ls_value(const float* __restrict__ Q, int64_t n,
-                                                                      const float* __restrict__ xs_in, float* __restrict__ xs_out,
-                                                                      int64_t C, int64_t num_ls, float* __restrict__ value) {
-    constexpr int W = kQuboWaves;
+__device__ __forceinline__ float qm_spin(uint32_t word, int c) {
+    const uint32_t t = word << (31 - c);                        // bit c -> sign position
+    if (BIN) return __builtin_bit_cast(float, (uint32_t)((int32_t)t >> 31) & 0x3f800000u);      // 1.0 or 0.0
+    return __builtin_bit_cast(float, (~t & 0x80000000u) | 0x3f800000u);                          // +1.0 or -1.0
+}
+
+// acc[.] += Q[i0 + r, k] * s[k, chains] over the batches [kb0, kb1) (multiples of 32) of this wave.
+// NT = 1: acc[0] / acc[1] take the even / odd MFMAs of the one chain tile; NT = 2: acc[t] is chain tile t.
+template <bool BIN, int NT, bool MASK_DIAG>
+__device__ __forceinline__ void qm_block_dot(const float* __restrict__ Q, int64_t n, int64_t i0, int64_t kb0, int64_t kb1,
+                                             const typename QmWord<NT>::type* __restrict__ words, int r, int h,
+                                             f32x16 (&acc)[2]) {
+    const int64_t row = i0 + r;
+    const bool row_ok = row < n;
+    const float* qrow = Q + (row_ok ? row : 0) * n;
+    auto load_a = [&](int64_t kb, float (&a)[16]) {
+        const int64_t kk = kb + 16 * h;
+        if (row_ok && kk + 16 <= n) {
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const f32x4u v = *reinterpret_cast<const f32x4u*>(qrow + kk + 4 * q4);
+                a[4 * q4] = v.x; a[4 * q4 + 1] = v.y; a[4 * q4 + 2] = v.z; a[4 * q4 + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) a[e] = (row_ok && kk + e < n) ? qrow[kk + e] : 0.0f;
+        }
+    };
+    float a[16], an[16];
+    if (kb0 < kb1) load_a(kb0, a);
+    for (int64_t kb = kb0; kb < kb1; kb += 32) {
+        if (kb + 32 < kb1) load_a(kb + 32, an);
+        const int64_t kk = kb + 16 * h;
+        typename QmWord<NT>::type wd[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) wd[e] = words[kk + e];     // 16-byte LDS reads, one address per lane half
+        if (MASK_DIAG && kb < i0 + 32 && kb + 32 > i0) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                if (kk + e == row) a[e] = 0.0f;
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            if constexpr (NT == 1) {
+                acc[e & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], qm_spin<BIN>(wd[e], r), acc[e & 1], 0, 0, 0);
+            } else {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], qm_spin<BIN>((uint32_t)wd[e], r), acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e], qm_spin<BIN>((uint32_t)(wd[e] >> 32), r), acc[1], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) a[e] = an[e];
+    }
+}
+
+template <bool BIN, int NT, int W>
+__global__ __launch_bounds__(W * kWave) void k_qubo_ls_value_mfma(const float* __restrict__ Q, int64_t n, int64_t n_pad,
+                                                                  const float* __restrict__ xs_in, float* __restrict__ xs_out,
+                                                                  int64_t C, int64_t num_ls, float* __restrict__ value) {
+    using Word = typename QmWord<NT>::type;
+    constexpr int PS = qm_part_stride<NT>();
+    constexpr int CH = 32 * NT;                                  // chains per workgroup
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint64_t* words = reinterpret_cast<uint64_t*>(smem);
-    float* part = reinterpret_cast<float*>(words + n);           // [W][64] partial results of a block
-    uint64_t* neww = reinterpret_cast<uint64_t*>(part + W * kWave);   // [W] the block's new words
-    const uint32_t* w32 = reinterpret_cast<const uint32_t*>(smem);
+    Word* words = reinterpret_cast<Word*>(smem);                                 // [n_pad] bit c = chain c0 + c
+    float* part = reinterpret_cast<float*>(words + n_pad);                       // [W][32][PS]
     const int lane = threadIdx.x & (kWave - 1);
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
-    const int64_t c0 = (int64_t)blockIdx.x * kWave;
-    const int64_t c = c0 + lane;
-    const bool valid = c < C;
-    const int half = lane >> 5, sh = lane & 31;
-    const BitXpose xc = bit_xpose_consts(lane);
-    // tile load: node-major f32 rows, one ballot per variable
-    for (int64_t n0 = (int64_t)w * kWave; n0 < n; n0 += (int64_t)W * kWave) {
-        const int lim = (int)((n - n0) < kWave ? (n - n0) : kWave);
-        uint64_t mine = 0;
-        for (int k = 0; k < lim; ++k) {
-            const float v = valid ? xs_in[(n0 + k) * C + c] : 0.0f;
-            const uint64_t wd = ballot64(v > 0.0f);
-            if (lane == k) mine = wd;
+    const int r = lane & 31, h = lane >> 5;                      // r doubles as the chain column of B / D
+    const int64_t c0 = (int64_t)blockIdx.x * CH;
+    // tile load from the node-major f32 surface: NT = 2: one variable (64 chains) per ballot; NT = 1: two variables
+    if constexpr (NT == 2) {
+        const bool valid = c0 + lane < C;
+        for (int64_t j = w; j < n_pad; j += W) {
+            const float v = (valid && j < n) ? xs_in[j * C + c0 + lane] : 0.0f;
+            const uint64_t b = ballot64(v > 0.0f);
+            if (lane == 0) words[j] = b;
         }
-        if (lane < lim) words[n0 + lane] = mine;
+    } else {
+        const bool valid = c0 + r < C;
+        for (int64_t j0 = (int64_t)w * 2; j0 < n_pad; j0 += (int64_t)W * 2) {
+            const int64_t j = j0 + h;
+            const float v = (valid && j < n) ? xs_in[j * C + c0 + r] : 0.0f;
+            const uint64_t b = ballot64(v > 0.0f);
+            if (lane == 0) { words[j0] = (uint32_t)b; words[j0 + 1] = (uint32_t)(b >> 32); }
+        }
     }
     __syncthreads();
-    // dot of row i with the current spins, s_i := 0:  +-1 spins: 2 * sum_{b_j = 1} Q_ij - sum_j Q_ij;  0/1: sum_{b_j = 1} Q_ij
-    auto row_result = [&](int64_t i, bool skip_diag) -> float {
-        float od, rs;
-        qubo_row_dot(Q + i * n, n, skip_diag ? i : -1, words, lane, xc, od, rs);
-        return BIN ? od : (2.0f * od - rs);
-    };
+    const int64_t kper = n_pad / W;                              // a multiple of 32
+    const int64_t kb0 = (int64_t)w * kper, kb1 = kb0 + kper;
+    float* mypart = part + (size_t)w * 32 * PS;
+    auto tile_word = [&](Word wd, int t) -> uint32_t { return NT == 1 ? (uint32_t)wd : (uint32_t)((uint64_t)wd >> (32 * t)); };
     for (int64_t cnt = 0; cnt < num_ls; ++cnt) {
-        for (int64_t i0 = 0; i0 < n; i0 += W) {
-            const int64_t i = i0 + w;
-            if (i < n) part[w * kWave + lane] = row_result(i, true);
-            __syncthreads();
-            if (w == 0) {   // resolve the block in order: variable i0 + k sees the new values of i0 .. i0 + k - 1
-                const int kb = (int)((n - i0) < W ? (n - i0) : W);
-                // the block's W x W corner of Q and its diagonal, one entry per lane
-                const int rk = lane / W, cj = lane % W;
-                const float qc = (rk < kb && cj < kb) ? Q[(i0 + rk) * n + i0 + cj] : 0.0f;
-                float delta[W];                                   // s_new - s_old of the block's earlier variables (this chain)
+        for (int64_t i0 = 0; i0 < n; i0 += 32) {
+            // wave 0 fetches its rows of the block's 32 x 32 corner of Q first (lane (r, .) holds Q[i0 + r, i0 .. i0 + 31]):
+            // the loads are long done when the resolution below uses column k as the A operand of step k
+            float qc[32];
+            if (w == 0) {
+                const int64_t row = i0 + r;
+                if (row < n && i0 + 32 <= n) {
 #pragma unroll
-                for (int k = 0; k < W; ++k) {
-                    if (k < kb) {
-                        float res = part[k * kWave + lane];
-#pragma unroll
-                        for (int j = 0; j < W; ++j)
-                            if (j < k) res += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qc), k * W + j)) * delta[j];
-                        const float qii = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, qc), k * W + k));
-                        const float thr = BIN ? (-qii / 2.0f) : 0.0f;          // res > -Q_ii / 2   |   res > 0
-                        const bool nb = res > thr;
-                        const uint32_t ob = (w32[((i0 + k) << 1) + half] >> sh) & 1u;
-                        delta[k] = ((float)nb - (float)ob) * (BIN ? 1.0f : 2.0f);
-                        const uint64_t nw = ballot64(nb);
-                        if (lane == 0) neww[k] = nw;              // the tile itself keeps the OLD bits until the block is resolved
-                    } else {
-                        delta[k] = 0.0f;
+                    for (int q4 = 0; q4 < 8; ++q4) {
+                        const f32x4u v = *reinterpret_cast<const f32x4u*>(Q + row * n + i0 + 4 * q4);
+                        qc[4 * q4] = v.x; qc[4 * q4 + 1] = v.y; qc[4 * q4 + 2] = v.z; qc[4 * q4 + 3] = v.w;
                     }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 32; ++k) qc[k] = (row < n && i0 + k < n) ? Q[row * n + i0 + k] : 0.0f;
                 }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
-                if (lane < kb) words[i0 + lane] = neww[lane];
+            }
+            f32x16 acc[2] = {{0}, {0}};
+            qm_block_dot<BIN, NT, true>(Q, n, i0, kb0, kb1, words, r, h, acc);
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                float* dst = mypart + (8 * (v / 4) + 4 * h + (v % 4)) * PS + r;
+                if constexpr (NT == 1) dst[0] = acc[0][v] + acc[1][v];
+                else { dst[0] = acc[0][v]; dst[32] = acc[1][v]; }
+            }
+            __syncthreads();
+            if (w == 0) {
+                // Resolve the block in order, variable i0 + k seeing the new values of i0 .. i0 + k - 1.  Step k reads row k
+                // of R (lanes of half hk = (k / 4) % 2, register 4 (k / 8) + k % 4), decides, and updates R by one MFMA
+                // per chain tile.  Rows <= k collect updates nobody reads.
+                const int kbk = (int)((n - i0) < 32 ? (n - i0) : 32);
+                f32x16 R[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        float sum = 0.0f;
+#pragma unroll
+                        for (int ww = 0; ww < W; ++ww) sum += part[(size_t)(ww * 32 + 8 * (v / 4) + 4 * h + (v % 4)) * PS + 32 * t + r];
+                        R[t][v] = sum;
+                    }
+                Word mine = 0;                                   // lane k ends up with the new word of variable i0 + k
+#pragma unroll
+                for (int k = 0; k < 32; ++k) {
+                    const int hk = (k / 4) & 1;
+                    const float thr = BIN ? (-qc[k] / 2.0f) : 0.0f;               // lane r = k holds Q_kk
+                    const float thr_k = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, thr), k));
+                    const Word old = words[i0 + k];              // the tile keeps the OLD bits until the block is resolved
+                    Word nw = 0;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const bool nb = R[t][4 * (k / 8) + (k % 4)] > thr_k;      // res > -Q_ii / 2   |   res > 0
+                        const uint64_t bal = ballot64(nb);
+                        nw |= (Word)(hk ? (uint32_t)(bal >> 32) : (uint32_t)bal) << (NT == 1 ? 0 : 32 * t);
+                        const uint32_t ob = (tile_word(old, t) >> r) & 1u;
+                        float d = ((float)nb - (float)ob) * (BIN ? 1.0f : 2.0f);
+                        if (h != hk) d = 0.0f;
+                        R[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(qc[k], d, R[t], 0, 0, 0);
+                    }
+                    if (lane == k) mine = nw;
+                }
+                if (lane < kbk) words[i0 + lane] = mine;
             }
             __syncthreads();
         }
     }
-    // value[c] = sum_i s_i (Q s)_i: the waves split the rows
-    float total = 0.0f;
-    for (int64_t i = w; i < n; i += W) {
-        const float r = row_result(i, false);
-        const uint32_t b = (w32[(i << 1) + half] >> sh) & 1u;
-        total += (BIN ? (float)b : (b ? 1.0f : -1.0f)) * r;
-    }
-    __syncthreads();
-    part[w * kWave + lane] = total;
-    __syncthreads();
-    if (w == 0 && valid) {
-        float t = 0.0f;
+    // value[c] = sum_i s_i (Q s)_i: every wave weighs its partial products with the rows' spins
+    float total[NT];
 #pragma unroll
-        for (int k = 0; k < W; ++k) t += part[k * kWave + lane];
-        value[c] = t;
+    for (int t = 0; t < NT; ++t) total[t] = 0.0f;
+    for (int64_t i0 = 0; i0 < n; i0 += 32) {
+        f32x16 acc[2] = {{0}, {0}};
+        qm_block_dot<BIN, NT, false>(Q, n, i0, kb0, kb1, words, r, h, acc);
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const Word wd = words[i0 + 8 * (v / 4) + 4 * h + (v % 4)];
+            if constexpr (NT == 1) total[0] += qm_spin<BIN>(wd, r) * (acc[0][v] + acc[1][v]);
+            else {
+                total[0] += qm_spin<BIN>((uint32_t)wd, r) * acc[0][v];
+                total[1] += qm_spin<BIN>((uint32_t)(wd >> 32), r) * acc[1][v];
+            }
+        }
     }
-    if (valid)
-        for (int64_t j = w; j < n; j += W) xs_out[j * C + c] = (float)((w32[(j << 1) + half] >> sh) & 1u);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const float both = total[t] + __shfl_xor(total[t], 32, 64);
+        if (h == 0) part[(w * NT + t) * 32 + r] = both;
+    }
+    __syncthreads();
+    if (w == 0 && lane < CH && c0 + lane < C) {
+        float sum = 0.0f;
+#pragma unroll
+        for (int k = 0; k < W; ++k) sum += part[(k * NT + (lane >> 5)) * 32 + r];
+        value[c0 + lane] = sum;
+    }
+    if constexpr (NT == 2) {
+        if (c0 + lane < C)
+            for (int64_t j = w; j < n; j += W) xs_out[j * C + c0 + lane] = (float)((words[j] >> lane) & 1ull);
+    } else {
+        if (c0 + r < C)
+            for (int64_t j = (int64_t)w * 2 + h; j < n; j += (int64_t)W * 2) xs_out[j * C + c0 + r] = (float)((words[j] >> r) & 1u);
+    }
 }
 
 // Sparse QUBO: the same coordinate search and value on Q in CSR form (rowptr / col / val,
@@ -228,20 +316,32 @@ extern "C" int rls_qubo_local_search_value(const float* Q, int64_t n, const floa
     RLS_REQUIRE(n > 0 && C >= 0 && num_ls >= 0, RLS_EINVAL, "bad sizes n=%lld C=%lld", (long long)n, (long long)C);
     if (C == 0) return RLS_OK;
     RLS_REQUIRE(Q && xs_in && xs_out && value, RLS_EINVAL, "NULL pointer");
-    const size_t lds = (size_t)n * 8 + (size_t)kQuboWaves * kWave * 4 + (size_t)kQuboWaves * 8;
+    // 64-chain workgroups (half the L2 traffic and resolution work per chain) once they fill the chip; 8 waves (two per
+    // SIMD, for the L2 latency) while a CU holds a single workgroup, 4 when several can share it
+    const bool nt2 = C >= (int64_t)2 * 64 * num_cus();
+    const bool w8 = !nt2 && ceil_div(C, 32) <= (int64_t)2 * num_cus();
+    const int W = w8 ? 8 : 4;
+    const int64_t n_pad = ceil_div(n, 32 * W) * 32 * W;
+    const size_t lds = (size_t)n_pad * (nt2 ? 8 : 4) + (size_t)W * 32 * (nt2 ? qm_part_stride<2>() : qm_part_stride<1>()) * 4;
     RLS_REQUIRE(lds <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "n=%lld needs %zu B of LDS (max %d)", (long long)n, lds,
                 kLdsBytes);
-    const dim3 grid((unsigned)ceil_div(C, kWave)), block(kQuboWaves * kWave);
+    const dim3 grid((unsigned)ceil_div(C, nt2 ? 64 : 32)), block(W * kWave);
+#define RLS_QM_LAUNCH(BIN_, NT_, W_)                                                                                  \
+    do {                                                                                                              \
+        auto kern = k_qubo_ls_value_mfma<BIN_, NT_, W_>;                                                              \
+        if (lds > 64 * 1024)                                                                                          \
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
+        hipLaunchKernelGGL(kern, grid, block, lds, as_stream(stream), Q, n, n_pad, xs_in, xs_out, C, num_ls, value);  \
+    } while (0)
     if (binary) {
-        auto kern = k_qubo_ls_value<true>;
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, grid, block, lds, as_stream(stream), Q, n, xs_in, xs_out, C, num_ls, value);
+        if (nt2) RLS_QM_LAUNCH(true, 2, 4);
+        else { if (w8) RLS_QM_LAUNCH(true, 1, 8); else RLS_QM_LAUNCH(true, 1, 4); }
     } else {
-        auto kern = k_qubo_ls_value<false>;
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, grid, block, lds, as_stream(stream), Q, n, xs_in, xs_out, C, num_ls, value);
+        if (nt2) RLS_QM_LAUNCH(false, 2, 4);
+        else { if (w8) RLS_QM_LAUNCH(false, 1, 8); else RLS_QM_LAUNCH(false, 1, 4); }
     }
-    return check_launch("k_qubo_ls_value");
+#undef RLS_QM_LAUNCH
+    return check_launch("k_qubo_ls_value_mfma");
 }
 
 extern "C" int rls_qubo_sparse_local_search_value(const int32_t* rowptr, const int32_t* col, const float* val, int64_t n,

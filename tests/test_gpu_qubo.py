@@ -90,3 +90,28 @@ def test_qubo_sampler_takes_the_sparse_path_below_a_quarter_fill():
     b = q.mcpg_sampling_qubo(dense, start, probs, 2, T, M, DEV, index=index, u=u)
     assert sparse["csr"] is not None and dense["csr"] is None
     assert all(torch.equal(x, y) for x, y in zip(a, b))
+
+
+@pytest.mark.parametrize("n,C", [(70, 32768 + 37), (45, 20000), (129, 100), (31, 64), (257, 33)])
+def test_qubo_dense_kernel_variants_equal_the_sequential_sweep(n, C):
+    """The launcher picks 64-chain workgroups from 2^15 chains on and 4 instead of 8 waves once the grid exceeds two
+    workgroups per CU; n is chosen off every alignment the kernel likes (rows not 16-byte aligned, ragged last block,
+    ragged last batch, ragged chain tile).  Integer Q: bit-exact against the variable-by-variable loop of
+    MCPG/sampling.py:332-337 / :357-362 and against x^T Q x."""
+    rng = np.random.RandomState(n + C)
+    Qn = rng.randint(-40, 41, size=(n, n)).astype(np.float32)
+    Qn = np.triu(Qn) + np.triu(Qn, 1).T
+    x0 = rng.randint(0, 2, size=(n, C)).astype(np.float32)
+    Q = dev(Qn)
+    for binary in (False, True):
+        s = x0.copy() if binary else 2 * x0 - 1
+        for cnt in range(2):
+            for i in range(n):
+                s[i] = 0
+                res = Qn[i] @ s
+                s[i] = ((res > -Qn[i, i] / 2).astype(np.float32)) if binary else (2 * (res > 0) - 1).astype(np.float32)
+        want_x = s if binary else (s + 1) / 2
+        want_v = np.einsum("ic,ij,jc->c", s, Qn, s).astype(np.float32)
+        xd, vd = q.qubo_local_search_value(Q, dev(x0), 2, binary)
+        assert np.array_equal(xd.cpu().numpy(), want_x)
+        assert np.array_equal(vd.cpu().numpy(), want_v)

@@ -200,7 +200,7 @@ def spin_suite(tag, n, m, B, T, iters):
              "algorithmic bytes = the rows the observation contract changes everywhere each step")
 
 
-def qubo_suite(tag, n, C, num_ls, iters):
+def qubo_suite(tag, n, C, num_ls, iters, sparse=True):
     from rlsolver_amd.methods import MCPG_qubo as mq
     rng = np.random.RandomState(3)
     Q = np.triu(rng.randint(10, 101, size=(n, n)) * rng.choice([-1, 1], size=(n, n)) * (rng.rand(n, n) < 0.8), 0)
@@ -212,9 +212,11 @@ def qubo_suite(tag, n, C, num_ls, iters):
         rec_flops = 2 * n * n * (num_ls + 1) * C / t
         print(json.dumps({"config": tag, "kernel": f"K11 qubo_local_search_value ({'0/1' if binary else '+-1'}, num_ls={num_ls})",
                           "us_per_launch": round(t * 1e6, 2), "unit": "variable updates", "units_per_s": C * n * (num_ls + 1) / t,
-                          "achieved_TFLOPs_f32": rec_flops / 1e12, "frac_of_157TFLOPs_vector_peak": rec_flops / 157.3e12,
-                          "note": f"n={n} dense, C={C}; compute-bound contraction: roofline = f32 vector peak (3 VALU per multiply-add "
-                                  "bound it at ~1/3)"}), flush=True)
+                          "achieved_TFLOPs_f32": rec_flops / 1e12, "frac_of_157TFLOPs_f32_matrix_peak": rec_flops / 157.3e12,
+                          "note": f"n={n} dense, C={C}; compute-bound contraction on v_mfma_f32_32x32x2_f32: roofline = the f32 "
+                                  "matrix peak; flops = 2 n^2 per chain per sweep plus one pass for the value"}), flush=True)
+    if not sparse:
+        return
     Qs = Q * (rng.rand(n, n) < 0.02)
     Qs = (np.triu(Qs) + np.triu(Qs, 1).T).astype(np.float32)
     csr = mq.qubo_to_csr(torch.from_numpy(Qs).to(dev))
@@ -242,5 +244,6 @@ if want("spin"):
     spin_suite("BA-200-sized (ECO), B=4096", 200, 784, 4096, 400, it)
 if want("qubo"):
     qubo_suite("nbiq-style dense QUBO n=1000, 2^13 chains", 1000, 1 << 13, 2, 2)
+    qubo_suite("nbiq-style dense QUBO n=1000, 2^15 chains", 1000, 1 << 15, 2, 2, sparse=False)
 if want("mcpg"):
     mcpg_suite("BA n=10^4 m=5, 2^18 chains", 10000, 5, 1 << 18 if not a.quick else 1 << 14, 8, 2)
