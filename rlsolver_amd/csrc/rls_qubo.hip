@@ -249,7 +249,9 @@ __global__ __launch_bounds__(kWave) void k_qubo_sparse_ls_value(const int32_t* _
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* words = reinterpret_cast<uint64_t*>(smem);
     const uint32_t* w32 = reinterpret_cast<const uint32_t*>(smem);
+    int* rp = reinterpret_cast<int*>(words + n);                 // rowptr[0 .. n]
     const int lane = threadIdx.x;
+    for (int64_t i = lane; i <= n; i += kWave) rp[i] = rowptr[i];
     const int64_t c0 = (int64_t)blockIdx.x * kWave;
     const int64_t c = c0 + lane;
     const bool valid = c < C;
@@ -257,50 +259,104 @@ __global__ __launch_bounds__(kWave) void k_qubo_sparse_ls_value(const int32_t* _
     for (int64_t n0 = 0; n0 < n; n0 += kWave) {
         const int lim = (int)((n - n0) < kWave ? (n - n0) : kWave);
         uint64_t mine = 0;
-        for (int k = 0; k < lim; ++k) {
-            const float v = valid ? xs_in[(n0 + k) * C + c] : 0.0f;
-            const uint64_t wd = ballot64(v > 0.0f);
-            if (lane == k) mine = wd;
+        for (int k8 = 0; k8 < lim; k8 += 8) {                    // 8 rows' loads in flight, then their ballots
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = (valid && k8 + u < lim) ? xs_in[(n0 + k8 + u) * C + c] : 0.0f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint64_t wd = ballot64(v[u] > 0.0f);
+                if (lane == k8 + u) mine = wd;
+            }
         }
         if (lane < lim) words[n0 + lane] = mine;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    auto spin = [&](int64_t j) -> float {
-        const uint32_t b = (w32[(j << 1) + half] >> sh) & 1u;
-        return BIN ? (float)b : (b ? 1.0f : -1.0f);
+    // Row i + 1's entries are fetched while row i is being summed (they do not depend on the chains), and a row is
+    // summed 8 entries at a time: 8 broadcast lane reads, 8 LDS reads in flight, 8 multiply-adds.  One entry per trip was
+    // a chain of LDS round trips behind a chain of L2 round trips per variable.
+    struct Row { int r0, r1, mc; float mv; };                    // mc = LDS byte offset of the neighbour's word (this lane's half)
+    const int half4 = half * 4;
+    auto fetch = [&](int64_t i) -> Row {                         // i wraps: the look-ahead past the last row is harmless
+        while (i >= n) i -= n;
+        Row rw;
+        rw.r0 = __builtin_amdgcn_readfirstlane(rp[i]);
+        rw.r1 = __builtin_amdgcn_readfirstlane(rp[i + 1]);
+        const bool in = lane < rw.r1 - rw.r0;
+        rw.mc = in ? col[rw.r0 + lane] : 0;
+        rw.mv = in ? val[rw.r0 + lane] : 0.0f;
+        return rw;
     };
-    auto row = [&](int64_t i, bool skip_diag, float& diag) -> float {
-        const int r0 = rowptr[i], r1 = rowptr[i + 1];
-        float acc = 0.0f;
-        diag = 0.0f;
-        for (int base = r0; base < r1; base += kWave) {
-            const int here = (r1 - base) < kWave ? (r1 - base) : kWave;
-            const int mc = lane < here ? col[base + lane] : 0;
-            const float mv = lane < here ? val[base + lane] : 0.0f;
-            for (int k = 0; k < here; ++k) {
-                const int j = __builtin_amdgcn_readlane(mc, k);
-                const float q = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mv), k));
-                if (j == i) {
-                    diag += q;
-                    if (skip_diag) continue;
-                }
-                acc += q * spin(j);
+    auto spin_bits = [&](int j) -> uint32_t { return (w32[(j << 1) + half] >> sh) & 1u; };
+    // One chunk (<= 64 entries, entry k in lane k; lanes past cnt hold (0, 0.0) and add nothing): ones += sum of the
+    // values whose neighbour bit is set, all += sum of the values; the diagonal entries (col == i) go to diag and, with
+    // skip_diag, out of both sums -- picked out per lane, once per chunk, so the entry loop carries no compare.
+    // Per entry: 2 v_readlane, address add, ds_read, v_bfe_i32 (bit -> 0 / -1 mask), and, 2 adds.
+    auto chunk_sum = [&](int mc, float mv, int cnt, int64_t i, bool skip_diag, float& ones, float& all, float& diag) {
+        uint64_t dm = ballot64(lane < cnt && mc == (int)i);
+        while (dm) {
+            const int l = __builtin_ctzll(dm);
+            diag += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mv), l));
+            dm &= dm - 1;
+        }
+        if (skip_diag && mc == (int)i) mv = 0.0f;
+        const int off = mc * 8;
+        for (int k = 0; k < cnt; k += 8) {
+            float q[8];
+            uint32_t wv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int jo = __builtin_amdgcn_readlane(off, k + u);
+                q[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mv), k + u));
+                wv[u] = *reinterpret_cast<const uint32_t*>(smem + (uint32_t)(jo + half4));
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int m = __builtin_amdgcn_sbfe((int)wv[u], sh, 1);       // 0 or -1
+                ones += __builtin_bit_cast(float, __builtin_bit_cast(int, q[u]) & m);
+                all += q[u];
             }
         }
-        return acc;
     };
-    for (int64_t cnt = 0; cnt < num_ls; ++cnt)
+    // sum_j Q_ij s_j over the row's entries (+-1: 2 * ones - all; 0/1: ones)
+    auto row = [&](const Row& rw, int64_t i, bool skip_diag, float& diag) -> float {
+        float ones = 0.0f, all = 0.0f;
+        diag = 0.0f;
+        const int deg = rw.r1 - rw.r0;
+        chunk_sum(rw.mc, rw.mv, deg < kWave ? deg : kWave, i, skip_diag, ones, all, diag);
+        for (int base = rw.r0 + kWave; base < rw.r1; base += kWave) {       // rows longer than a wave: the rest inline
+            const int here = (rw.r1 - base) < kWave ? (rw.r1 - base) : kWave;
+            const int mc = lane < here ? col[base + lane] : 0;
+            const float mv = lane < here ? val[base + lane] : 0.0f;
+            chunk_sum(mc, mv, here, i, skip_diag, ones, all, diag);
+        }
+        return BIN ? ones : (2.0f * ones - all);
+    };
+    // three rows of look-ahead: a row takes a fraction of the L2 round trip its entries need
+    for (int64_t cnt = 0; cnt < num_ls; ++cnt) {
+        Row cur = fetch(0), n1 = fetch(1), n2 = fetch(2);
         for (int64_t i = 0; i < n; ++i) {
+            const Row n3 = fetch(i + 3);
             float qii;
-            const float res = row(i, true, qii);
+            const float res = row(cur, i, true, qii);
             const uint64_t nw = ballot64(res > (BIN ? (-qii / 2.0f) : 0.0f));
             if (lane == 0) words[i] = nw;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
+            cur = n1; n1 = n2; n2 = n3;
         }
+    }
     float total = 0.0f, qii;
-    for (int64_t i = 0; i < n; ++i) total += spin(i) * row(i, false, qii);
+    {
+        Row cur = fetch(0), n1 = fetch(1), n2 = fetch(2);
+        for (int64_t i = 0; i < n; ++i) {
+            const Row n3 = fetch(i + 3);
+            const uint32_t bi = spin_bits((int)i);
+            total += (BIN ? (float)bi : (bi ? 1.0f : -1.0f)) * row(cur, i, false, qii);
+            cur = n1; n1 = n2; n2 = n3;
+        }
+    }
     if (valid) {
         value[c] = total;
         for (int64_t j = 0; j < n; ++j) xs_out[j * C + c] = (float)((w32[(j << 1) + half] >> sh) & 1u);
@@ -350,7 +406,7 @@ extern "C" int rls_qubo_sparse_local_search_value(const int32_t* rowptr, const i
     RLS_REQUIRE(n > 0 && C >= 0 && num_ls >= 0, RLS_EINVAL, "bad sizes n=%lld C=%lld", (long long)n, (long long)C);
     if (C == 0) return RLS_OK;
     RLS_REQUIRE(rowptr && col && val && xs_in && xs_out && value, RLS_EINVAL, "NULL pointer");
-    const size_t lds = (size_t)n * 8 + 16;
+    const size_t lds = (size_t)n * 8 + (size_t)(n + 1) * 4;
     RLS_REQUIRE(lds <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "n=%lld needs %zu B of LDS (max %d)", (long long)n, lds, kLdsBytes);
     const dim3 grid((unsigned)ceil_div(C, kWave)), block(kWave);
     if (binary) {

@@ -75,18 +75,31 @@ def qubo_sparse_local_search_value(csr, xs: TEN, num_ls: int, binary: bool):
     return out, value
 
 
-SPARSE_DENSITY = 0.25     # below this fill the CSR kernel does less work than the dense one
+def qubo_prefers_sparse(n: int, nnz: int, num_chains: int) -> bool:
+    """Which K11 kernel finishes a sweep first (measured on MI355X, tools/dev/time_qubo_sparse.py).
+
+    dense (MFMA):  a sweep is n / 32 blocks of about 4 + 5.4 n / 1000 us while one workgroup per CU suffices, and
+                   2 n^2 C flops at ~80 TFLOP/s beyond that;
+    sparse (CSR):  one wave walks the n rows in order, 0.38 us per row + 0.025 us per entry, whatever the number of
+                   chains until the chip is full of waves (64 chains each, ~2^19 chains).
+    So few chains or a short n favour the dense kernel even at 1 % fill; many chains favour the CSR kernel up to a
+    fill where its entry count catches up."""
+    if n <= 0 or nnz >= n * n:
+        return False
+    dense_us = max(2.0 * n * n * num_chains / 80e6, (n / 32.0) * (4.0 + 5.4 * n / 1000.0))
+    sparse_us = n * (0.38 + 0.025 * nnz / n) * max(1.0, num_chains / float(1 << 19))
+    return sparse_us < dense_us
 
 
 def _sample(data, start_result, probs, num_ls, change_times, total_mcmc_num, device, binary, index, u):
     Q = data['Q'].to(device=device, dtype=torch.float32).contiguous()
     raw_samples = metro_sampling(probs, start_result, change_times, device, index=index, u=u)   # never modifies its input
-    if 'csr' not in data and float((Q != 0).float().mean()) < SPARSE_DENSITY:
-        data['csr'] = qubo_to_csr(Q)
+    if 'csr' not in data:
+        nnz = int((Q != 0).sum())
+        data['csr'] = qubo_to_csr(Q) if qubo_prefers_sparse(Q.shape[0], nnz, raw_samples.shape[1]) else None
     if data.get('csr') is not None:
         samples, res_sample = qubo_sparse_local_search_value(data['csr'], raw_samples.contiguous(), num_ls, binary)
     else:
-        data.setdefault('csr', None)
         samples, res_sample = qubo_local_search_value(Q, raw_samples.contiguous(), num_ls, binary)
     res_reshape = res_sample.reshape(-1, total_mcmc_num)
     idx = torch.argmax(res_reshape, dim=0)

@@ -74,22 +74,28 @@ def test_qubo_sparse_equals_dense_and_block_sweep_equals_sequential(n, C, densit
         assert torch.equal(xd, xs_) and torch.equal(vd, vs_)
 
 
-def test_qubo_sampler_takes_the_sparse_path_below_a_quarter_fill():
+def test_qubo_sampler_picks_the_kernel_by_cost_and_both_agree():
+    """n = 1500 at 0.3 % fill over 2^15 chains: the CSR kernel's row walk beats 2 n^2 C flops (qubo_prefers_sparse);
+    the same instance over 64 chains goes dense.  Either way the sampler returns what the other kernel returns."""
     rng = np.random.RandomState(5)
-    n, M, R = 200, 16, 4
-    Qn = (rng.randint(-9, 10, size=(n, n)) * (rng.rand(n, n) < 0.03)).astype(np.float32)
+    n, M, R = 1500, 256, 128
+    Qn = (rng.randint(-9, 10, size=(n, n)) * (rng.rand(n, n) < 0.003)).astype(np.float32)
     Qn = np.triu(Qn) + np.triu(Qn, 1).T
     start = dev(rng.randint(0, 2, size=(n, M * R)).astype(np.float32))
     probs = dev((rng.rand(n) * 0.6 + 0.2).astype(np.float32))
-    T = n // 10
-    index = dev(rng.randint(0, n, size=(5 * T, M * R)).astype(np.int64))
-    u = dev(rng.rand(5 * T, M * R).astype(np.float32))
-    sparse = {"Q": dev(Qn), "nvar": n}
+    T = 8
+    index = torch.randint(0, n, (5 * T, M * R), device=DEV)
+    u = torch.rand(5 * T, M * R, device=DEV)
+    auto = {"Q": dev(Qn), "nvar": n}
     dense = {"Q": dev(Qn), "nvar": n, "csr": None}
-    a = q.mcpg_sampling_qubo(sparse, start, probs, 2, T, M, DEV, index=index, u=u)
+    a = q.mcpg_sampling_qubo(auto, start, probs, 2, T, M, DEV, index=index, u=u)
     b = q.mcpg_sampling_qubo(dense, start, probs, 2, T, M, DEV, index=index, u=u)
-    assert sparse["csr"] is not None and dense["csr"] is None
+    assert auto["csr"] is not None and dense["csr"] is None
     assert all(torch.equal(x, y) for x, y in zip(a, b))
+    few = {"Q": dev(Qn), "nvar": n}
+    q.mcpg_sampling_qubo(few, start[:, :64].contiguous(), probs, 1, T, 16, DEV, index=index[:, :64].contiguous(),
+                         u=u[:, :64].contiguous())
+    assert few["csr"] is None
 
 
 @pytest.mark.parametrize("n,C", [(70, 32768 + 37), (45, 20000), (129, 100), (31, 64), (257, 33)])
