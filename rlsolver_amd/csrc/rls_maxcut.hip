@@ -518,19 +518,35 @@ __global__ __launch_bounds__(kNsWaves * kWave) void k_node_stats_bits(const uint
         }
         const uint64_t pl[8] = {ones, twos, fours, c[0], c[1], c[2], c[3], c[4]};
         const int md = (e1 - e0) >> 6;                        // longest row of the group (wave-uniform)
-        for (int half = 0; half < 2; ++half) {
-            for (int r = 0; r < 8; ++r) {
-                if (half * 32 + r >= nenv) break;             // envs are consecutive: nothing further in this half
-                const uint32_t acc = md < 16 ? ns_extract4<4>(pl, half, r)
-                                             : (md < 64 ? ns_extract4<6>(pl, half, r) : ns_extract4<8>(pl, half, r));
+        auto emit = [&](int e, int cnt) {
+            if constexpr (MODE == 0) reinterpret_cast<int64_t*>(out_v)[(b0 + e) * N + i] = cnt;
+            else if constexpr (MODE == 1) reinterpret_cast<int32_t*>(out_v)[(b0 + e) * N + i] = deg - 2 * cnt;
+            else reinterpret_cast<int32_t*>(out_v)[(b0 + e) * N + i] = deg - mult * cnt;
+        };
+        if (nenv == kWave) {
+            // full tile: no per-store guards (each cost a scalar compare / exec save / branch around a 4-instruction store)
+            if (in) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int e = half * 32 + r + 8 * j;
-                    const int cnt = (int)((acc >> (8 * j)) & 0xFFu);
-                    if (e < nenv && in) {
-                        if constexpr (MODE == 0) reinterpret_cast<int64_t*>(out_v)[(b0 + e) * N + i] = cnt;
-                        else if constexpr (MODE == 1) reinterpret_cast<int32_t*>(out_v)[(b0 + e) * N + i] = deg - 2 * cnt;
-                        else reinterpret_cast<int32_t*>(out_v)[(b0 + e) * N + i] = deg - mult * cnt;
+                for (int half = 0; half < 2; ++half) {
+#pragma unroll 2
+                    for (int r = 0; r < 8; ++r) {
+                        const uint32_t acc = md < 16 ? ns_extract4<4>(pl, half, r)
+                                                     : (md < 64 ? ns_extract4<6>(pl, half, r) : ns_extract4<8>(pl, half, r));
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) emit(half * 32 + r + 8 * j, (int)((acc >> (8 * j)) & 0xFFu));
+                    }
+                }
+            }
+        } else {
+            for (int half = 0; half < 2; ++half) {
+                for (int r = 0; r < 8; ++r) {
+                    if (half * 32 + r >= nenv) break;         // envs are consecutive: nothing further in this half
+                    const uint32_t acc = md < 16 ? ns_extract4<4>(pl, half, r)
+                                                 : (md < 64 ? ns_extract4<6>(pl, half, r) : ns_extract4<8>(pl, half, r));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int e = half * 32 + r + 8 * j;
+                        if (e < nenv && in) emit(e, (int)((acc >> (8 * j)) & 0xFFu));
                     }
                 }
             }

@@ -1,0 +1,52 @@
+// Dev micro-benchmark: HBM write rate by store width and by the K3 pattern (a wave writes 256-byte pieces of 64 rows).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+
+__global__ void k_dword(uint32_t* out, size_t n) {            // contiguous, 4 B per lane
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = (uint32_t)i;
+}
+__global__ void k_dwordx4(uint4* out, size_t n4) {            // contiguous, 16 B per lane
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) out[i] = make_uint4(i, i, i, i);
+}
+// K3 pattern: workgroup = 64 rows (envs) x N columns; wave w takes 64-column groups g = w, w + 8, ...; per group 64
+// stores of 256 B, one per row
+__global__ __launch_bounds__(512) void k_rows256(uint32_t* out, int N) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t* base = out + (size_t)blockIdx.x * 64 * N;
+    for (int g = w; g < N / 64; g += 8)
+#pragma unroll 8
+        for (int e = 0; e < 64; ++e) base[(size_t)e * N + g * 64 + lane] = e + lane;
+}
+// same bytes, but a wave covers 4 rows x 256 B... per store 16 B per lane: lanes 0-15 row e, 16-31 row e+1, ...
+__global__ __launch_bounds__(512) void k_rows256x4(uint32_t* out, int N) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t* base = out + (size_t)blockIdx.x * 64 * N;
+    for (int g = w; g < N / 64; g += 8)
+#pragma unroll 8
+        for (int e = 0; e < 64; e += 4)
+            *reinterpret_cast<uint4*>(base + (size_t)(e + (lane >> 4)) * N + g * 64 + (lane & 15) * 4) = make_uint4(e, lane, e, lane);
+}
+
+int main() {
+    const int N = 2000 / 64 * 64 + 64;   // 2048 columns
+    const int B = 65536;
+    const size_t n = (size_t)B * N;
+    uint32_t* d;
+    hipMalloc(&d, n * 4);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    auto run = [&](const char* name, auto launch) {
+        launch(); hipDeviceSynchronize();
+        hipEventRecord(e0);
+        for (int i = 0; i < 10; ++i) launch();
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        printf("%-28s %.2f TB/s\n", name, n * 4.0 * 10 / (ms * 1e-3) / 1e12);
+    };
+    run("contiguous dword", [&] { hipLaunchKernelGGL(k_dword, dim3(8192), dim3(256), 0, 0, d, n); });
+    run("contiguous dwordx4", [&] { hipLaunchKernelGGL(k_dwordx4, dim3(8192), dim3(256), 0, 0, (uint4*)d, n / 4); });
+    run("64 rows x 256 B, dword", [&] { hipLaunchKernelGGL(k_rows256, dim3(B / 64), dim3(512), 0, 0, d, N); });
+    run("4 rows x 256 B, dwordx4", [&] { hipLaunchKernelGGL(k_rows256x4, dim3(B / 64), dim3(512), 0, 0, d, N); });
+    return 0;
+}
