@@ -275,17 +275,38 @@ def sampler_func_packed(data, xs: PackedChains, num_ls: int, total_mcmc_num: int
     return vs_good, xs_good, expected - expected.mean(), xs_loc
 
 
+def tie_coins_from_uniforms(data, uniforms: TEN) -> TEN:
+    """Recorded torch.rand draws f32 [num_ls, N (visiting position), C] -> the tie coins of the level-parallel kernel,
+    int64 words [num_ls * N, ceil(C / 64)].
+
+    The draw of MCPG.py:139-141 only ever decides a TIE: the neighbour sum s is a multiple of 1/2, so
+    (s + u/4) < (deg + 1/4)/2 is settled by s alone unless s == deg/2, and then it reads
+    fl(deg/2 + fl(u/4)) < deg/2 + 1/8 in float32 -- "u < 1/2" except within a few ulps below 1/2, where the sum rounds
+    up to the threshold (the larger deg, the wider that band).  The coin is that exact float32 expression per
+    (position, chain), so the kernel reproduces the reference for EVERY recorded draw, not only away from 1/2."""
+    num_ls, n, C = uniforms.shape
+    deg = torch.tensor(data.single_degree, dtype=torch.float32, device=uniforms.device)[data.sorted_degree_nodes.to(uniforms.device)]
+    k = torch.tensor(0.25, dtype=torch.float32, device=uniforms.device)
+    half = (deg / 2).view(1, n, 1)
+    thr = ((deg + k) / 2).view(1, n, 1)
+    coin = (half + uniforms.to(torch.float32) * k) < thr
+    words = PackedChains.pack(coin.reshape(num_ls * n, C).contiguous()).words          # [ceil(C / 64), num_ls * N]
+    return words.t().contiguous()
+
+
 def sampler_func(data, xs_sample: TEN, num_ls: int, total_mcmc_num: int, repeat_times: int, device=None,
                  uniforms: Optional[TEN] = None):
     """MCPG.py:120-166: node-sequential stochastic local search (K7), expected cut (K8), best of
     repeats.  ``uniforms`` f32 [num_ls, N, C] replaces torch.rand (test hook)."""
     xs_sample = xs_sample.contiguous()
-    if uniforms is None and _levels_ok(data):
-        # production path: level-parallel kernel (the draws only ever decide ties, so it carries coins, not uniforms);
-        # the f32 [N, C] input is read once, everything after it is bit-packed, xs_good leaves as f32 [N, M]
+    if _levels_ok(data):
+        # production path: level-parallel kernel (the draws only ever decide ties, so it carries coins, not uniforms;
+        # recorded draws become coins by the reference's own float32 expression); the f32 [N, C] input is read once,
+        # everything after it is bit-packed, xs_good leaves as f32 [N, M]
         out = PackedChains.empty(xs_sample.shape[0], xs_sample.shape[1], xs_sample.device)
+        coins = None if uniforms is None else tie_coins_from_uniforms(data, uniforms)
         xs_loc, expected = mops.mcpg_local_search_levels(data.graph, xs_sample, data._lv_ptr, data._lv_data, num_ls,
-                                                         _seed_from_torch(), out=out)
+                                                         0 if uniforms is not None else _seed_from_torch(), coins=coins, out=out)
         _, vs_good, xs_good = mops.mcpg_pick_best(expected, xs_loc, total_mcmc_num, repeat_times, data.num_edges)
         return vs_good, xs_good.unpack(), expected - expected.mean()
     xs_loc, expected = mops.mcpg_local_search(data.graph, xs_sample, data._order_i32, num_ls, uniforms,

@@ -102,6 +102,41 @@ def test_mcpg_level_parallel_kernel_vs_oracle(kind, n, m, C, num_ls):
     assert np.array_equal(exp_g.cpu().numpy(), exp_w)
 
 
+@pytest.mark.parametrize("kind,n,m,C,num_ls", [("ba", 600, 5, 200, 2), ("star", 400, 0, 70, 2), ("gnm", 300, 4000, 130, 2)])
+def test_mcpg_level_parallel_kernel_is_exact_within_ulps_of_one_half(kind, n, m, C, num_ls):
+    """Recorded draws packed within a few float32 ulps of 1/2, where (s + u/4) < (deg + 1/4)/2 stops being "u < 1/2"
+    (the sum rounds up to the threshold; the band widens with the degree): sampler_func turns them into tie coins by
+    the reference's own float32 expression (tie_coins_from_uniforms), and the production kernel must then reproduce the
+    sequential float pass of MCPG.py:136-142 bit for bit."""
+    from rlsolver_amd import graph as G
+    if kind == "gnm":
+        graph = gnm_arr(n, m, seed=5)
+    elif kind == "ba":
+        graph = np.asarray(G.generate_ba(n, m, seed=3), dtype=np.int64)
+    else:
+        graph = np.array([(0, j, 1) for j in range(1, 301)] + [(j, j + 1, 1) for j in range(1, n - 1)], dtype=np.int64)
+    ei = graph[:, :2].T.copy()
+    rng = np.random.RandomState(23)
+    deg = np.bincount(ei.reshape(-1), minlength=n)
+    order = np.argsort(-deg, kind="stable")
+    data = amcpg.make_data(n, ei[0], ei[1], DEV, sorted_degree_nodes=order)
+    assert data._lv_ptr is not None
+    xs0 = rng.randint(0, 2, size=(n, C)).astype(np.float32)
+    steps = rng.randint(-80, 81, size=(num_ls, n, C))                            # ulps of 0.5- (2^-25) around one half
+    uni = (np.float32(0.5) + steps.astype(np.float32) * np.float32(2.0 ** -25)).astype(np.float32)
+    coin_naive = uni < np.float32(0.5)
+    M = C // 2 if C % 2 == 0 else C
+    R = C // M
+    vs_w, xg_w, val_w, x_all, exp_w = onp.sampler_func(ei, n, order, xs0, num_ls, M, R, uni)
+    vs_g, xg_g, val_g = amcpg.sampler_func(data, dev(xs0), num_ls, M, R, DEV, uniforms=dev(uni))
+    assert np.array_equal(xg_g.cpu().numpy(), xg_w)
+    assert np.array_equal(vs_g.cpu().numpy(), vs_w)
+    # the band is real: the float rule and "u < 1/2" disagree somewhere on these draws
+    degp = deg[order].astype(np.float32)[None, :, None]
+    coin_exact = (degp / np.float32(2) + uni * np.float32(0.25)) < (degp + np.float32(0.25)) / np.float32(2)
+    assert (coin_exact != coin_naive).any()
+
+
 def test_mcpg_production_rng_is_distributionally_sane():
     n, m, C = 500, 3000, 4096
     graph = gnm_arr(n, m, seed=9)
