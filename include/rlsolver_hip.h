@@ -351,16 +351,20 @@ int rls_mcpg_local_search(const rls_graph* g, const void* xs_in, int spin_bytes,
                           float* expected, void* stream);
 
 /* [host] Level-parallel form of the K7 visiting order (lane = node; same dependency-level argument as
- * rls_graph_sweep_levels, levels taken over visiting POSITIONS: order[pos] = node).  Nodes of a level with degree
- * <= 64 are packed 64 to a group (sorted by degree so that rows of a group have similar length); a node of
- * higher degree forms a group of its own and is decided with lane = neighbour.  Group record in lv_data:
- *     64 words  node | K << 20 | tie << 31        K = ceil(deg / 2), tie = deg even            (passes >= 1)
+ * rls_graph_sweep_levels, levels taken over visiting POSITIONS: order[pos] = node).  The nodes of a level with degree
+ * <= 128 are packed into groups of 64 LANES, sorted by degree; a row too long for the level's cap (chosen per level by
+ * an instruction-count estimate: none / 32 / 16 / 8 entries per lane, always <= 64) takes L = 2, 4 or 8 ADJACENT lanes,
+ * lane j of them holding neighbours j, j + L, ... -- the kernel adds the lanes' counters before the compare, so a
+ * level's longest row costs deg / L rounds and pads 63 lanes that much less.  A node of higher degree forms a group of
+ * its own and is decided with lane = neighbour.  Group record in lv_data:
+ *     64 words  node | K << 20 | log2 L << 28 | tie << 31   K = ceil(deg / 2), tie = deg even               (passes >= 1)
  *     64 words  pos  | K0 << 20 | tie0 << 31      K0 = ceil((deg + nfresh) / 2), tie0 = (deg + nfresh) even  (pass 0)
- *     rounds of 64 words  nb | fresh << 31        padding / idle lanes: N
- * (a normal group has longest-row rounds, round k = k-th neighbour of each lane's node; a hub group uses lane 0 of
- * the two header rows plus word 2 of the first = deg, and ceil(deg / 64) rounds listing its neighbours).
+ *     rounds of 64 words  8 nb | fresh << 31      (8 nb = byte offset of the neighbour's word in the tile); padding: 8 N
+ * (a normal group has longest-lane rounds; idle lanes carry node = N; a hub group uses lane 0 of the two header rows --
+ * K / K0 in 11 bits, no L -- plus word 2 of the first = deg, and ceil(deg / 64) rounds listing its neighbours).
  * The accept rule of MCPG.py:139-141, (s + u/4) < (deg + 1/4)/2 with s in half-integers, is  2s < deg, or
- * 2s == deg and u < 1/2:  new bit = [count < K] | ([count == K] & tie & coin), count = #ones among the neighbours
+ * 2s == deg and u < 1/2 (in float32: see methods/MCPG.py tie_coins_from_uniforms):
+ * new bit = [count < K] | ([count == K] & tie & coin), count = #ones among the neighbours
  * (pass 0: #ones among visited + 2 #ones among not-yet-visited ones, against K0).
  * lv_ptr [host, groups+1]: offset | bit 31 = first group of a level | bit 30 = hub group.  NULL outputs: sizing.
  * Needs N < 2^20 and max degree < 1024. */

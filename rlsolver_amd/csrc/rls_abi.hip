@@ -167,7 +167,7 @@ int rls_mcpg_visit_levels(const int32_t* rowptr, const int32_t* col, int64_t N, 
     if (!rowptr || !order || N < 0 || (N > 0 && rowptr[N] > 0 && !col) || !num_groups || !total)
         return rls::fail(RLS_EINVAL, "rls_mcpg_visit_levels: bad arguments");
     if (N >= (1 << 20)) return rls::fail(RLS_EUNSUPPORTED, "rls_mcpg_visit_levels: N >= 2^20");
-    constexpr int32_t kHubDeg = 64;
+    constexpr int32_t kHubDeg = 128;             // longer rows get a group of their own, lane = neighbour
     std::vector<int32_t> pos_of((size_t)(N > 0 ? N : 1), -1);
     for (int64_t p = 0; p < N; ++p) {
         if (order[p] < 0 || order[p] >= N || pos_of[(size_t)order[p]] != -1)
@@ -200,51 +200,104 @@ int rls_mcpg_visit_levels(const int32_t* rowptr, const int32_t* col, int64_t N, 
         return degp(a) > degp(b);
     });
     int64_t ng = 0, off = 0;
-    auto header = [&](int32_t p, int32_t& h0, int32_t& h1) {
+    auto header = [&](int32_t p, int32_t lcode, int32_t& h0, int32_t& h1) {
         const int32_t i = order[p], deg = degp(p), t0 = deg + nfresh[(size_t)p];
-        h0 = (int32_t)((uint32_t)i | ((uint32_t)((deg + 1) >> 1) << 20) | ((deg & 1) ? 0u : 0x80000000u));
+        h0 = (int32_t)((uint32_t)i | ((uint32_t)((deg + 1) >> 1) << 20) | ((uint32_t)lcode << 28) | ((deg & 1) ? 0u : 0x80000000u));
         h1 = (int32_t)((uint32_t)p | ((uint32_t)((t0 + 1) >> 1) << 20) | ((t0 & 1) ? 0u : 0x80000000u));
     };
     auto entry = [&](int32_t p, int32_t r) {   // r-th neighbour word of position p
         const int32_t i = order[p], nb = col[rowptr[i] + r];
-        return (int32_t)((uint32_t)nb | (pos_of[(size_t)nb] > p ? 0x80000000u : 0u));
+        return (int32_t)(((uint32_t)nb * 8u) | (pos_of[(size_t)nb] > p ? 0x80000000u : 0u));   // LDS byte offset of the word
     };
+    // Lanes per node of a lane = node group.  A group costs its LONGEST lane and the waves of a workgroup meet at every
+    // level boundary, so one long row among short ones stalls the level and pads 63 lanes: a row longer than `cap`
+    // entries is spread over 2, 4 or 8 adjacent lanes (the kernel adds their counters across them, ~110 VALU per group
+    // that has any).  Per level the cap (none / 32 / 16 / 8 entries per lane) is the one with the least estimated time,
+    // the level's work over the waves plus its longest group, in VALU instructions as measured on gfx950: ~150 per group,
+    // ~85 per 8 rounds, ~110 for the cross-lane sums.
+    auto lanes_for = [](int32_t deg, int32_t cap) {           // log2 of the lanes a row of `deg` entries takes
+        int32_t lc = 0;
+        while (lc < 3 && ((cap > 0 && deg > (cap << lc)) || ((deg + (1 << lc) - 1) >> lc) > 64)) ++lc;
+        return lc;
+    };
+    struct Grp { int64_t k0, k1; int32_t rounds; bool multi; };
+    auto plan = [&](int64_t a, int64_t b, int32_t cap, std::vector<Grp>* out) -> int64_t {
+        int64_t total = 0, longest = 0, k = a;
+        while (k < b) {
+            Grp g{k, k, 0, false};
+            int32_t used = 0;
+            while (g.k1 < b) {
+                const int32_t deg = degp(sp[(size_t)g.k1]), lc = lanes_for(deg, cap), L = 1 << lc;
+                if (used + L > 64) break;
+                used += L;
+                const int32_t r = (deg + L - 1) / L;
+                if (r > g.rounds) g.rounds = r;
+                g.multi = g.multi || lc > 0;
+                ++g.k1;
+            }
+            const int64_t cost = 150 + 85 * (int64_t)((g.rounds + 7) / 8) + (g.multi ? 110 : 0);
+            total += cost;
+            if (cost > longest) longest = cost;
+            if (out) out->push_back(g);
+            k = g.k1;
+        }
+        return total / 8 + longest;
+    };
+    std::vector<Grp> groups;
     int64_t k0 = 0;
     while (k0 < N) {
         const int32_t lev = level[(size_t)sp[(size_t)k0]];
-        const bool level_start = (k0 == 0) || level[(size_t)sp[(size_t)(k0 - 1)]] != lev;
-        const bool hub = degp(sp[(size_t)k0]) > kHubDeg;
-        int64_t k1 = k0 + 1;
-        if (!hub)
-            while (k1 < N && k1 - k0 < 64 && level[(size_t)sp[(size_t)k1]] == lev && degp(sp[(size_t)k1]) <= kHubDeg) ++k1;
-        const int32_t md = degp(sp[(size_t)k0]);                       // degree-descending: the first is the longest
-        const int64_t rounds = hub ? (md + 63) / 64 : md;
-        const int64_t len = (2 + rounds) * 64;
-        if (off + len >= (int64_t)0x3fffffff) return rls::fail(RLS_EUNSUPPORTED, "rls_mcpg_visit_levels: too large");
-        if (lv_ptr) {
-            if (ng + 1 >= ptr_capacity) return rls::fail(RLS_EINVAL, "rls_mcpg_visit_levels: ptr capacity too small");
-            lv_ptr[ng] = (int32_t)((uint32_t)off | (level_start ? 0x80000000u : 0u) | (hub ? 0x40000000u : 0u));
+        // the level's lane = node rows [k0, kn) and its hubs [kn, ke)
+        int64_t kn = k0, ke;
+        while (kn < N && level[(size_t)sp[(size_t)kn]] == lev && degp(sp[(size_t)kn]) <= kHubDeg) ++kn;
+        ke = kn;
+        while (ke < N && level[(size_t)sp[(size_t)ke]] == lev) ++ke;
+        int32_t best_cap = 0;
+        int64_t best = -1;
+        for (int32_t cap : {0, 32, 16, 8}) {
+            const int64_t c = plan(k0, kn, cap, nullptr);
+            if (best < 0 || c < best) { best = c; best_cap = cap; }
         }
-        if (lv_data) {
-            if (off + len > data_capacity) return rls::fail(RLS_EINVAL, "rls_mcpg_visit_levels: data capacity too small");
-            int32_t* rec = lv_data + off;
-            for (int64_t e = 0; e < len; ++e) rec[e] = (int32_t)N;
-            if (hub) {
-                const int32_t p = sp[(size_t)k0];
-                header(p, rec[0], rec[64]);
-                rec[2] = md;
-                for (int32_t r = 0; r < md; ++r) rec[128 + r] = entry(p, r);
-            } else {
-                for (int64_t k = k0; k < k1; ++k) {
-                    const int32_t p = sp[(size_t)k], ln = (int32_t)(k - k0), deg = degp(p);
-                    header(p, rec[ln], rec[64 + ln]);
-                    for (int32_t r = 0; r < deg; ++r) rec[(int64_t)(2 + r) * 64 + ln] = entry(p, r);
+        groups.clear();
+        plan(k0, kn, best_cap, &groups);
+        for (int64_t h = kn; h < ke; ++h) groups.push_back(Grp{h, h + 1, (degp(sp[(size_t)h]) + 63) / 64, false});
+        bool level_start = true;
+        for (size_t gi = 0; gi < groups.size(); ++gi) {
+            const Grp& g = groups[gi];
+            const bool hub = g.k0 >= kn;
+            const int64_t rounds = g.rounds;
+            const int64_t len = (2 + rounds) * 64;
+            if (off + len >= (int64_t)0x3fffffff) return rls::fail(RLS_EUNSUPPORTED, "rls_mcpg_visit_levels: too large");
+            if (lv_ptr) {
+                if (ng + 1 >= ptr_capacity) return rls::fail(RLS_EINVAL, "rls_mcpg_visit_levels: ptr capacity too small");
+                lv_ptr[ng] = (int32_t)((uint32_t)off | (level_start ? 0x80000000u : 0u) | (hub ? 0x40000000u : 0u));
+            }
+            if (lv_data) {
+                if (off + len > data_capacity) return rls::fail(RLS_EINVAL, "rls_mcpg_visit_levels: data capacity too small");
+                int32_t* rec = lv_data + off;
+                for (int64_t e = 0; e < len; ++e) rec[e] = (int32_t)(e < 128 ? N : N * 8);      // idle header lanes: node N; padding: the zero word
+                if (hub) {
+                    const int32_t p = sp[(size_t)g.k0], md = degp(p);
+                    header(p, 0, rec[0], rec[64]);
+                    rec[2] = md;
+                    for (int32_t r = 0; r < md; ++r) rec[128 + r] = entry(p, r);
+                } else {
+                    int32_t ln = 0;
+                    for (int64_t k = g.k0; k < g.k1; ++k) {
+                        const int32_t p = sp[(size_t)k], deg = degp(p), lc = lanes_for(deg, best_cap), L = 1 << lc;
+                        for (int32_t j = 0; j < L; ++j) {          // lane j of the node's L takes neighbours j, j + L, ...
+                            header(p, lc, rec[ln + j], rec[64 + ln + j]);
+                            for (int32_t r = j; r < deg; r += L) rec[(int64_t)(2 + r / L) * 64 + ln + j] = entry(p, r);
+                        }
+                        ln += L;
+                    }
                 }
             }
+            off += len;
+            ++ng;
+            level_start = false;
         }
-        off += len;
-        ++ng;
-        k0 = k1;
+        k0 = ke;
     }
     if (lv_ptr) {
         if (ng >= ptr_capacity) return rls::fail(RLS_EINVAL, "rls_mcpg_visit_levels: ptr capacity too small");

@@ -549,7 +549,9 @@ __device__ __forceinline__ void lv_cmp(const uint64_t (&pl)[9], uint32_t K, uint
     eq = ((uint64_t)eq1 << 32) | eq0;
 }
 
-// 8 words into a (ones, twos, fours, c[0..4] = planes 3..7) vertical counter
+// 8 words into a (ones, twos, fours, c[0..NC-1] = planes 3..) vertical counter.  NC follows the group's number of
+// rounds (a count <= 7 never carries out of `fours`, <= 15 needs one more plane, ...): the ripple is 4 VALU per plane.
+template <int NC>
 __device__ __forceinline__ void lv_add8(const uint64_t (&d)[8], uint64_t& ones, uint64_t& twos, uint64_t& fours,
                                         uint64_t (&c)[5]) {
     uint64_t twosA, twosB, foursA, foursB, carry;
@@ -561,11 +563,115 @@ __device__ __forceinline__ void lv_add8(const uint64_t (&d)[8], uint64_t& ones, 
     csa(foursB, twos, twos, twosA, twosB);
     csa(carry, fours, fours, foursA, foursB);
 #pragma unroll
-    for (int p = 0; p < 5; ++p) {
+    for (int p = 0; p < NC; ++p) {
         const uint64_t t = c[p] & carry;
         c[p] ^= carry;
         carry = t;
     }
+}
+
+// lane exchange of a 64-bit plane with lane ^ 1, ^ 2 (DPP quad_perm 0xB1 / 0x4E) or ^ 4 (ds_swizzle bit mode), no memory
+template <int X>
+__device__ __forceinline__ uint64_t lv_lane_xor(uint64_t v) {
+    uint32_t lo, hi;
+    if constexpr (X == 4) {
+        lo = (uint32_t)__builtin_amdgcn_ds_swizzle((int)(uint32_t)v, 0x101F);          // and 0x1F, or 0, xor 4
+        hi = (uint32_t)__builtin_amdgcn_ds_swizzle((int)(uint32_t)(v >> 32), 0x101F);
+    } else {
+        constexpr int CTRL = X == 1 ? 0xB1 : 0x4E;
+        lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, 0xF, 0xF, false);
+        hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, 0xF, 0xF, false);
+    }
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// pl[0..7] += lane ^ X's pl[0..7] where `take` is all-ones (bit-sliced ripple-carry add, counts <= 128 in total)
+template <int X>
+__device__ __forceinline__ void lv_merge_planes(uint64_t (&pl)[8], uint64_t take) {
+    uint64_t carry = 0;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) csa(carry, pl[p], pl[p], lv_lane_xor<X>(pl[p]) & take, carry);
+}
+
+// One lane = node group: the vertical counters over its rounds, C = cV (+ 2 cF in pass 0) plane by plane, and the
+// bit-sliced compare with K.  NC = counter planes above `fours`, NP = planes of C that can be set; both follow the
+// number of rounds (wave-uniform), see the dispatch in the kernel.  Neighbour entries are LDS BYTE offsets of the
+// neighbour's word (| fresh << 31).
+// A node of long degree occupies L = 2, 4 or 8 ADJACENT lanes (lcode = log2 L; lane j of them holds neighbours j, j + L,
+// ...): the partial counters of those lanes are added across them before the compare, so a level's longest row
+// costs deg / L rounds instead of deg -- the group's rounds are what a level waits for.
+template <int NC, int NP>
+__device__ __forceinline__ void lv_node_group(const unsigned char* __restrict__ wbytes, const int32_t* __restrict__ data,
+                                              int64_t p0, int64_t p1, int rounds, const uint32_t (&e0)[8], bool pass0,
+                                              int lane, uint32_t pad, uint32_t K, uint32_t lcode, uint64_t& lt, uint64_t& eq) {
+    constexpr uint32_t M31 = 0x7fffffffu;
+    uint64_t vo = 0, vt = 0, vf = 0, vc[5] = {0, 0, 0, 0, 0};      // ones among visited (all, after pass 0)
+    uint64_t fo = 0, ft = 0, ff = 0, fc[5] = {0, 0, 0, 0, 0};      // ones among not-yet-visited (pass 0)
+    uint32_t e[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) e[q] = e0[q];
+    for (int r0 = 0; r0 < rounds; r0 += 8) {
+        uint32_t nxt[8];
+        if (NC > 0) {                                             // rounds <= 7: the prefetched eight are all there is
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int64_t at = p0 + (int64_t)(2 + r0 + 8 + q) * kWave;
+                nxt[q] = at < p1 ? (uint32_t)data[at + lane] : pad;
+            }
+        }
+        uint64_t d[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) d[q] = *reinterpret_cast<const uint64_t*>(wbytes + (e[q] & M31));
+        if (pass0) {
+            uint64_t dv[8], df[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const uint64_t fm = 0ull - (uint64_t)(e[q] >> 31);
+                df[q] = d[q] & fm;
+                dv[q] = d[q] & ~fm;
+            }
+            lv_add8<NC>(dv, vo, vt, vf, vc);
+            lv_add8<NC>(df, fo, ft, ff, fc);
+        } else {
+            lv_add8<NC>(d, vo, vt, vf, vc);
+        }
+        if (NC > 0) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) e[q] = nxt[q];
+        }
+    }
+    const int gl = __builtin_amdgcn_readlane((int)lcode, 0);      // lanes are sorted by L: lane 0 has the group's largest
+    if (gl > 0) {
+        uint64_t pv[8] = {vo, vt, vf, vc[0], vc[1], vc[2], vc[3], vc[4]};
+        uint64_t pf[8] = {fo, ft, ff, fc[0], fc[1], fc[2], fc[3], fc[4]};
+        const uint64_t t1 = 0ull - (uint64_t)(lcode >= 1u), t2 = 0ull - (uint64_t)(lcode >= 2u), t3 = 0ull - (uint64_t)(lcode >= 3u);
+        lv_merge_planes<1>(pv, t1);
+        if (pass0) lv_merge_planes<1>(pf, t1);
+        if (gl > 1) {
+            lv_merge_planes<2>(pv, t2);
+            if (pass0) lv_merge_planes<2>(pf, t2);
+        }
+        if (gl > 2) {
+            lv_merge_planes<4>(pv, t3);
+            if (pass0) lv_merge_planes<4>(pf, t3);
+        }
+        uint64_t pl[9] = {pv[0], pv[1], pv[2], pv[3], pv[4], pv[5], pv[6], pv[7], 0};
+        if (pass0) {
+            uint64_t carry = 0;
+#pragma unroll
+            for (int p = 1; p < 9; ++p) csa(carry, pl[p], pl[p], pf[p - 1], carry);
+        }
+        lv_cmp<9>(pl, K, lt, eq);
+        return;
+    }
+    uint64_t pl[9] = {vo, vt, vf, vc[0], vc[1], vc[2], vc[3], vc[4], 0};
+    if (pass0) {   // C = cV + 2 cF, plane by plane
+        const uint64_t fp[8] = {fo, ft, ff, fc[0], fc[1], fc[2], fc[3], fc[4]};
+        uint64_t carry = 0;
+#pragma unroll
+        for (int p = 1; p < NP; ++p) csa(carry, pl[p], pl[p], fp[p - 1], carry);
+    }
+    lv_cmp<NP>(pl, K, lt, eq);
 }
 
 // One node of high degree, lanes share its neighbours: per-lane vertical counters over the node's <= 2^NP - 1 rounds
@@ -581,7 +687,7 @@ __device__ __forceinline__ void lv_hub_counts(const uint64_t* words, const int32
 #pragma unroll
     for (int p = 0; p < NP; ++p) { cv[p] = 0; cf[p] = 0; }
     auto add = [&](uint32_t en) {
-        const uint64_t d = words[en & M31];
+        const uint64_t d = *reinterpret_cast<const uint64_t*>(reinterpret_cast<const unsigned char*>(words) + (en & M31));
         const uint64_t fm = pass0 ? 0ull - (uint64_t)(en >> 31) : 0ull;
         uint64_t carry = d & ~fm;
 #pragma unroll
@@ -635,6 +741,7 @@ __global__ __launch_bounds__(W * kWave) void k_mcpg_local_search_levels(
     const int64_t c = c0 + lane;
     const bool valid = c < C;
     const int64_t CB = (C + kWave - 1) / kWave;               // 64-chain blocks = words per coins row
+    const uint32_t pad = (uint32_t)N * 8u;                    // byte offset of the zero word behind the tile
     if (threadIdx.x == 0) words[N] = 0;                       // padding / idle lanes point here
     if (threadIdx.x < kWave) cut_slots[threadIdx.x] = 0;
     for (int64_t i = threadIdx.x; i <= G + 1; i += W * kWave) lvl[i] = i <= G ? lv_ptr[i] : lv_ptr[G];
@@ -663,7 +770,7 @@ __global__ __launch_bounds__(W * kWave) void k_mcpg_local_search_levels(
 #pragma unroll
                 for (int q = 0; q < 8; ++q) {
                     const int64_t at = p0 + (int64_t)(2 + q) * kWave;
-                    e0[q] = at < p1 ? (uint32_t)data[at + lane] : (uint32_t)N;
+                    e0[q] = at < p1 ? (uint32_t)data[at + lane] : pad;
                 }
             }
         };
@@ -681,53 +788,19 @@ __global__ __launch_bounds__(W * kWave) void k_mcpg_local_search_levels(
             const int64_t p0 = flags & M30, p1 = (uint32_t)__builtin_amdgcn_readlane(chunk_next, (int)(k & 63)) & M30;
             const int rounds = (int)((p1 - p0) >> 6) - 2;
             if (!((flags >> 30) & 1u)) {
-                // ---- 64 nodes, lane = node
+                // ---- 64 lanes of nodes (a long row takes 2, 4 or 8 adjacent lanes), K in 8 bits, log2 lanes-per-node above it
                 const uint32_t node = h0 & 0xFFFFFu, pos = h1 & 0xFFFFFu;
-                const uint32_t K = pass0 ? ((h1 >> 20) & 0x7FFu) : ((h0 >> 20) & 0x7FFu);
+                const uint32_t K = pass0 ? ((h1 >> 20) & 0xFFu) : ((h0 >> 20) & 0xFFu);
+                const uint32_t lcode = (h0 >> 28) & 3u;
                 const uint64_t tie = 0ull - (uint64_t)((pass0 ? h1 : h0) >> 31);
-                uint64_t vo = 0, vt = 0, vf = 0, vc[5] = {0, 0, 0, 0, 0};      // ones among visited (all, after pass 0)
-                uint64_t fo = 0, ft = 0, ff = 0, fc[5] = {0, 0, 0, 0, 0};      // ones among not-yet-visited (pass 0)
-                uint32_t e[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) e[q] = e0[q];
-                for (int r0 = 0; r0 < rounds; r0 += 8) {
-                    uint32_t nxt[8];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const int64_t at = p0 + (int64_t)(2 + r0 + 8 + q) * kWave;
-                        nxt[q] = at < p1 ? (uint32_t)data[at + lane] : (uint32_t)N;
-                    }
-                    uint64_t d[8];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) d[q] = words[e[q] & M31];
-                    if (pass0) {
-                        uint64_t dv[8], df[8];
-#pragma unroll
-                        for (int q = 0; q < 8; ++q) {
-                            const uint64_t fm = 0ull - (uint64_t)(e[q] >> 31);
-                            df[q] = d[q] & fm;
-                            dv[q] = d[q] & ~fm;
-                        }
-                        lv_add8(dv, vo, vt, vf, vc);
-                        lv_add8(df, fo, ft, ff, fc);
-                    } else {
-                        lv_add8(d, vo, vt, vf, vc);
-                    }
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) e[q] = nxt[q];
-                }
-                uint64_t pl[9] = {vo, vt, vf, vc[0], vc[1], vc[2], vc[3], vc[4], 0};
-                if (pass0) {   // C = cV + 2 cF, plane by plane
-                    const uint64_t fp[8] = {fo, ft, ff, fc[0], fc[1], fc[2], fc[3], fc[4]};
-                    uint64_t carry = 0;
-#pragma unroll
-                    for (int p = 1; p < 9; ++p) csa(carry, pl[p], pl[p], fp[p - 1], carry);
-                }
                 uint64_t lt, eq;
-                if (rounds < 8) lv_cmp<5>(pl, K, lt, eq);          // degrees <= 7: C <= 14
-                else lv_cmp<9>(pl, K, lt, eq);                     // degrees <= 64: C <= 128
+                // counts <= rounds, C = cV + 2 cF <= 2 rounds (the not-yet-visited neighbours count twice in pass 0)
+                if (rounds < 8) lv_node_group<0, 5>(smem, data, p0, p1, rounds, e0, pass0, lane, pad, K, lcode, lt, eq);
+                else if (rounds < 16) lv_node_group<1, 6>(smem, data, p0, p1, rounds, e0, pass0, lane, pad, K, lcode, lt, eq);
+                else if (rounds < 32) lv_node_group<2, 7>(smem, data, p0, p1, rounds, e0, pass0, lane, pad, K, lcode, lt, eq);
+                else lv_node_group<4, 8>(smem, data, p0, p1, rounds, e0, pass0, lane, pad, K, lcode, lt, eq);
                 const uint64_t nw = lt | (eq & tie & coin_word(cnt, pos));
-                if (node < (uint32_t)N) words[node] = nw;
+                if (node < (uint32_t)N && (lane & ((1 << lcode) - 1)) == 0) words[node] = nw;
             } else {
                 // ---- one node of high degree, lane = neighbour
                 const uint32_t g0 = (uint32_t)__builtin_amdgcn_readlane((int)h0, 0);
