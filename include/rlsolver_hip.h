@@ -360,7 +360,8 @@ int rls_mcpg_local_search(const rls_graph* g, const void* xs_in, int spin_bytes,
  *     64 words  node | K << 20 | log2 L << 28 | tie << 31   K = ceil(deg / 2), tie = deg even               (passes >= 1)
  *     64 words  pos  | K0 << 20 | tie0 << 31      K0 = ceil((deg + nfresh) / 2), tie0 = (deg + nfresh) even  (pass 0)
  *     rounds of 64 words  8 nb | fresh << 31      (8 nb = byte offset of the neighbour's word in the tile); padding: 8 N
- * (a normal group has longest-lane rounds; idle lanes carry node = N; a hub group uses lane 0 of the two header rows --
+ * (a normal group has longest-lane rounds, rounded up to a multiple of 8; idle lanes carry node = N; the table ends in
+ * eight spare rows counted in *total, so that a group's first eight rounds can be read unguarded; a hub group uses lane 0 of the two header rows --
  * K / K0 in 11 bits, no L -- plus word 2 of the first = deg, and ceil(deg / 64) rounds listing its neighbours).
  * The accept rule of MCPG.py:139-141, (s + u/4) < (deg + 1/4)/2 with s in half-integers, is  2s < deg, or
  * 2s == deg and u < 1/2 (in float32: see methods/MCPG.py tie_coins_from_uniforms):

@@ -235,7 +235,8 @@ int rls_mcpg_visit_levels(const int32_t* rowptr, const int32_t* col, int64_t N, 
                 g.multi = g.multi || lc > 0;
                 ++g.k1;
             }
-            const int64_t cost = 150 + 85 * (int64_t)((g.rounds + 7) / 8) + (g.multi ? 110 : 0);
+            g.rounds = (g.rounds + 7) / 8 * 8;                    // whole blocks of 8 rounds: the kernel loads them unguarded
+            const int64_t cost = 150 + 85 * (int64_t)(g.rounds / 8) + (g.multi ? 110 : 0);
             total += cost;
             if (cost > longest) longest = cost;
             if (out) out->push_back(g);
@@ -303,8 +304,13 @@ int rls_mcpg_visit_levels(const int32_t* rowptr, const int32_t* col, int64_t N, 
         if (ng >= ptr_capacity) return rls::fail(RLS_EINVAL, "rls_mcpg_visit_levels: ptr capacity too small");
         lv_ptr[ng] = (int32_t)off;
     }
+    // eight spare rows behind the last record: the kernel prefetches a group's first eight rounds without looking
+    if (lv_data) {
+        if (off + 8 * 64 > data_capacity) return rls::fail(RLS_EINVAL, "rls_mcpg_visit_levels: data capacity too small");
+        for (int64_t e = 0; e < 8 * 64; ++e) lv_data[off + e] = (int32_t)(N * 8);
+    }
     *num_groups = ng;
-    *total = off;
+    *total = off + 8 * 64;
     return RLS_OK;
 }
 

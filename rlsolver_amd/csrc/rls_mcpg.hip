@@ -610,14 +610,12 @@ __device__ __forceinline__ void lv_node_group(const unsigned char* __restrict__ 
     uint32_t e[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) e[q] = e0[q];
-    for (int r0 = 0; r0 < rounds; r0 += 8) {
+    const int32_t* rec = data + p0 + (2 + 8) * kWave + lane;      // round 8 of this lane
+    for (int r0 = 0; r0 < rounds; r0 += 8, rec += 8 * kWave) {
         uint32_t nxt[8];
-        if (NC > 0) {                                             // rounds <= 7: the prefetched eight are all there is
+        if (NC > 0 && r0 + 8 < rounds) {                          // (rounds are a multiple of 8: the next eight exist whole)
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int64_t at = p0 + (int64_t)(2 + r0 + 8 + q) * kWave;
-                nxt[q] = at < p1 ? (uint32_t)data[at + lane] : pad;
-            }
+            for (int q = 0; q < 8; ++q) nxt[q] = (uint32_t)rec[q * kWave];
         }
         uint64_t d[8];
 #pragma unroll
@@ -729,7 +727,7 @@ __global__ __launch_bounds__(W * kWave) void k_mcpg_local_search_levels(
     int64_t C, int64_t tiles_in, const int32_t* __restrict__ lv_ptr, const int32_t* __restrict__ data, int64_t G,
     int64_t num_ls, const uint64_t* __restrict__ coins, uint64_t seed, const int32_t* __restrict__ eu,
     const int32_t* __restrict__ ev, int64_t E, float* __restrict__ expected) {
-    constexpr uint32_t M30 = 0x3fffffffu, M31 = 0x7fffffffu;
+    constexpr uint32_t M30 = 0x3fffffffu;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* words = reinterpret_cast<uint64_t*>(smem);
     int* cut_slots = reinterpret_cast<int*>(smem + (size_t)(N + 2) * 8);          // [64]
@@ -764,14 +762,13 @@ __global__ __launch_bounds__(W * kWave) void k_mcpg_local_search_levels(
         uint32_t h0 = (uint32_t)N, h1 = (uint32_t)N, e0[8];
         auto prefetch = [&](int64_t k) {
             if (k < G) {
-                const int64_t p0 = lvp(k) & M30, p1 = lvp(k + 1) & M30;
-                h0 = (uint32_t)data[p0 + lane];
-                h1 = (uint32_t)data[p0 + kWave + lane];
+                // the two header rows and the first eight rounds, unguarded: a lane = node group's rounds are a multiple
+                // of 8 and the table ends in eight spare rows (a hub group reads at most its own rounds of these)
+                const int32_t* rec = data + (lvp(k) & M30) + lane;
+                h0 = (uint32_t)rec[0];
+                h1 = (uint32_t)rec[kWave];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const int64_t at = p0 + (int64_t)(2 + q) * kWave;
-                    e0[q] = at < p1 ? (uint32_t)data[at + lane] : pad;
-                }
+                for (int q = 0; q < 8; ++q) e0[q] = (uint32_t)rec[(2 + q) * kWave];
             }
         };
         prefetch(mine);
