@@ -259,9 +259,12 @@ int rls_mcpg_visit_levels(const int32_t* rowptr, const int32_t* col, int64_t N, 
             const int64_t c = plan(k0, kn, cap, nullptr);
             if (best < 0 || c < best) { best = c; best_cap = cap; }
         }
+        // the level's groups, the costly ones first: waves take groups round-robin, the long ones should not queue up behind
+        // a wave's earlier work
         groups.clear();
-        plan(k0, kn, best_cap, &groups);
         for (int64_t h = kn; h < ke; ++h) groups.push_back(Grp{h, h + 1, (degp(sp[(size_t)h]) + 63) / 64, false});
+        std::stable_sort(groups.begin(), groups.end(), [](const Grp& x, const Grp& y) { return x.rounds > y.rounds; });
+        plan(k0, kn, best_cap, &groups);
         bool level_start = true;
         for (size_t gi = 0; gi < groups.size(); ++gi) {
             const Grp& g = groups[gi];

@@ -751,6 +751,9 @@ __global__ __launch_bounds__(W * kWave) void k_mcpg_local_search_levels(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();   // the tile is complete before any wave reads a neighbour word
     auto lvp = [&](int64_t k) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane(lvl[k]); };
+    int num_levels = 0;                                       // level boundaries per pass (wave-uniform)
+    for (int64_t k0 = 0; k0 < G; k0 += kWave)
+        num_levels += __builtin_popcountll(ballot64(k0 + lane < G && (lvl[k0 + lane < G ? k0 + lane : G] >> 31) != 0));
     auto coin_word = [&](int64_t cnt, uint32_t pos) -> uint64_t {   // bit e: "u < 1/2" for chain c0 + e at (pass, pos)
         if (coins) return coins[((int64_t)cnt * N + pos) * CB + blockIdx.x];
         const uint32_t k = blk_key ^ (pos * 0x9E3779B1u) ^ ((uint32_t)cnt * 0x7FEB352Du + 0x165667B1u);
@@ -772,16 +775,25 @@ __global__ __launch_bounds__(W * kWave) void k_mcpg_local_search_levels(
             }
         };
         prefetch(mine);
+        // A wave walks ITS groups only (w, w + W, ...) and meets the others once per level boundary it crosses: the level
+        // of group k = the number of level-start flags up to k, counted from a ballot over the 64 offsets the wave holds
+        // in registers.  (Walking all G groups to find the boundaries cost every wave ~5 instructions per group and pass.)
         int chunk = 0, chunk_next = 0;                        // lvl[k0 + lane] and lvl[k0 + 1 + lane] of the current 64 groups
-        for (int64_t k = 0; k < G; ++k) {
-            if ((k & 63) == 0) {
-                const int64_t a0 = k + lane <= G ? k + lane : G, a1 = k + 1 + lane <= G ? k + 1 + lane : G;
+        int64_t cbase = -1;
+        uint64_t lmask = 0;                                   // level-start flags of the current 64 groups
+        int lev_base = 0, passed = 0;                         // level starts before the chunk; barriers done in this pass
+        for (int64_t k = mine; k < G; k += W) {
+            if ((k & ~(int64_t)63) != cbase) {
+                cbase = k & ~(int64_t)63;
+                lev_base += __builtin_popcountll(lmask);
+                const int64_t a0 = cbase + lane <= G ? cbase + lane : G, a1 = cbase + 1 + lane <= G ? cbase + 1 + lane : G;
                 chunk = lvl[a0];
                 chunk_next = lvl[a1];
+                lmask = ballot64(cbase + lane < G && (chunk >> 31) != 0);
             }
             const uint32_t flags = (uint32_t)__builtin_amdgcn_readlane(chunk, (int)(k & 63));
-            if (flags >> 31) __syncthreads();                 // new level (k = 0: new pass): earlier updates are visible
-            if (k != mine) continue;
+            const int need = lev_base + __builtin_popcountll(lmask & ((2ull << (k & 63)) - 1ull));
+            for (; passed < need; ++passed) __syncthreads();  // new level (k = 0: new pass): earlier updates are visible
             const int64_t p0 = flags & M30, p1 = (uint32_t)__builtin_amdgcn_readlane(chunk_next, (int)(k & 63)) & M30;
             const int rounds = (int)((p1 - p0) >> 6) - 2;
             if (!((flags >> 30) & 1u)) {
@@ -816,9 +828,9 @@ __global__ __launch_bounds__(W * kWave) void k_mcpg_local_search_levels(
                 const uint64_t nw = ballot64(bit);
                 if (lane == 0) words[node] = nw;
             }
-            mine += W;
-            prefetch(mine);
+            prefetch(k + W);
         }
+        for (; passed < num_levels; ++passed) __syncthreads();   // every wave crosses every boundary of the pass
     }
     __syncthreads();
     // K8: expected[c] = sum_e (2x_u - 1)(2x_v - 1) = E - 2 * cut; the W partial counts meet in 64 LDS slots
