@@ -70,7 +70,10 @@ def test_mcpg_random_vs_oracle(n, m, M, R, num_ls):
 
 
 @pytest.mark.parametrize("kind,n,m,C,num_ls", [("gnm", 300, 1500, 100, 2), ("gnm", 2000, 19990, 130, 1), ("ba", 600, 5, 64, 3),
-                                                ("star", 400, 0, 70, 2), ("gnm", 64, 200, 1, 3)])
+                                                ("star", 400, 0, 70, 2), ("gnm", 64, 200, 1, 3),
+                                                ("gnm", 200, 9000, 65, 2),      # degrees ~90: every row on 2-8 lanes
+                                                ("gnm", 150, 11175, 64, 2),     # complete graph, degree 149: hubs only
+                                                ("gnm", 700, 30000, 3, 2)])     # degrees 60-110 around the 64-round limit
 def test_mcpg_level_parallel_kernel_vs_oracle(kind, n, m, C, num_ls):
     """The production K7 kernel (lane = node on the level schedule, tie coins instead of uniforms) against the
     oracle's sequential pass fed with uniforms of 0.25 / 0.75: away from 1/2 the reference's float rule
