@@ -92,10 +92,16 @@ int rls_graph_sweep_schedule(const int32_t* rowptr, const int32_t* col, int64_t 
                              int32_t max_entries, int32_t* rowptr_flagged, int32_t* stream, int64_t* num_batches,
                              int64_t* num_levels);
 
-/* [host] The level schedule of rls_graph_sweep_schedule in lane-per-node form: the nodes of a level in groups of
- * 64 lanes.  Group record in lv_data: 64 words  node | (deg / 2) << 20  (node = N on idle lanes), then
- * longest-row-of-the-group rounds of 64 neighbour ids (round k = the k-th neighbour of each lane's node; the
- * node itself where its row is shorter, N on idle lanes).  A wave decides a whole group at once on 64-env
+/* [host] The level schedule of rls_graph_sweep_schedule in lane-per-node form: the nodes of a level, longest rows
+ * first, in groups of 64 LANES.  A group costs its longest lane and the waves meet at every level boundary, so a row
+ * too long for the level's cap (none / 32 / 16 / 8 entries per lane, chosen per level by an instruction-count
+ * estimate; never more than 64) takes L = 2, 4 or 8 ADJACENT lanes, lane j of them holding neighbours j, j + L, ...;
+ * the kernel adds the lanes' counters before the compare.  Group record in lv_data:
+ *     64 words  node | (deg / 2) << 20 | log2 L << 28      (node = N on idle lanes)
+ *     rounds of 64 words  8 nb                             (byte offset of the neighbour's word in the tile; the node's
+ *                                                           own where the lane's share of the row has ended, 8 N on idle lanes)
+ * with rounds = the group's longest lane rounded up to a multiple of 8; the table ends in eight spare rows (counted in
+ * *total) so that a group's first eight rounds can be read unguarded.  A wave decides a whole group at once on 64-env
  * words: bit-sliced count of differing neighbours, bit-sliced compare with deg/2, XOR of the flip mask into
  * the node's word -- bit-identical to the sequential pass (see rls_graph_sweep_schedule).
  * lv_ptr [host, groups+1] (bit 31 = first group of a level); lv_data [host, capacity] or NULL to size

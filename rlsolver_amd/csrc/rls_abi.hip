@@ -23,6 +23,59 @@ int check_launch(const char* kernel_name) {
     return RLS_OK;
 }
 
+// ---- lanes per row of a lane = node group (K5 / K7 level schedules) ------------------------------------------------
+// A group costs its LONGEST lane and the waves of a workgroup meet at every level boundary, so one long row among short
+// ones stalls the level and pads 63 lanes: a row longer than `cap` entries is spread over 2, 4 or 8 adjacent lanes
+// (lane j of them takes entries j, j + L, ...; the kernel adds the lanes' bit-sliced counters before the compare,
+// ~110 VALU per group that has any).  Per level the cap (none / 32 / 16 / 8 entries per lane; a lane never holds
+// more than 64) is the one with the least estimated time: the level's work over the waves plus its longest group, in
+// VALU instructions as measured on gfx950 (~150 per group, ~85 per 8 rounds, ~110 for the cross-lane sums).
+struct LaneGroup { int64_t k0, k1; int32_t rounds; bool multi; };   // rows [k0, k1) of the level's degree-descending order
+
+static inline int32_t lanes_log2_for(int32_t deg, int32_t cap) {
+    int32_t lc = 0;
+    while (lc < 3 && ((cap > 0 && deg > (cap << lc)) || ((deg + (1 << lc) - 1) >> lc) > 64)) ++lc;
+    return lc;
+}
+
+// groups of <= 64 lanes over rows [a, b) (degrees non-increasing: lanes of a row stay aligned to their count);
+// rounds come in whole blocks of 8 (the kernels load them unguarded).  Returns the estimate.
+template <class DegAt>
+static int64_t plan_lane_groups(int64_t a, int64_t b, int32_t cap, DegAt deg_at, std::vector<LaneGroup>* out) {
+    int64_t total = 0, longest = 0, k = a;
+    while (k < b) {
+        LaneGroup g{k, k, 0, false};
+        int32_t used = 0;
+        while (g.k1 < b) {
+            const int32_t deg = deg_at(g.k1), lc = lanes_log2_for(deg, cap), L = 1 << lc;
+            if (used + L > 64) break;
+            used += L;
+            const int32_t r = (deg + L - 1) / L;
+            if (r > g.rounds) g.rounds = r;
+            g.multi = g.multi || lc > 0;
+            ++g.k1;
+        }
+        g.rounds = (g.rounds + 7) / 8 * 8;
+        const int64_t cost = 150 + 85 * (int64_t)(g.rounds / 8) + (g.multi ? 110 : 0);
+        total += cost;
+        if (cost > longest) longest = cost;
+        if (out) out->push_back(g);
+        k = g.k1;
+    }
+    return total / 8 + longest;
+}
+
+template <class DegAt>
+static int32_t best_lane_cap(int64_t a, int64_t b, DegAt deg_at) {
+    int32_t best_cap = 0;
+    int64_t best = -1;
+    for (int32_t cap : {0, 32, 16, 8}) {
+        const int64_t c = plan_lane_groups(a, b, cap, deg_at, nullptr);
+        if (best < 0 || c < best) { best = c; best_cap = cap; }
+    }
+    return best_cap;
+}
+
 }  // namespace rls
 
 extern "C" {
@@ -122,30 +175,42 @@ int rls_graph_sweep_levels(const int32_t* rowptr, const int32_t* col, int64_t N,
         std::vector<int64_t> fill(start.begin(), start.end() - 1);
         for (int64_t i = 0; i < N; ++i) order[(size_t)fill[(size_t)level[(size_t)i]]++] = (int32_t)i;
     }
+    // nodes of a level are independent: longest rows first, so that the lanes a long row is spread over stay aligned
+    auto degn = [&](int32_t i) { return rowptr[i + 1] - rowptr[i]; };
+    for (int32_t l = 0; l < nlev; ++l)
+        std::stable_sort(order.begin() + start[(size_t)l], order.begin() + start[(size_t)l + 1],
+                         [&](int32_t x, int32_t y) { return degn(x) > degn(y); });
+    auto deg_at = [&](int64_t k) { return degn(order[(size_t)k]); };
     int64_t ng = 0, off = 0;
+    std::vector<rls::LaneGroup> groups;
     for (int32_t l = 0; l < nlev; ++l) {
-        for (int64_t k0 = start[(size_t)l]; k0 < start[(size_t)l + 1]; k0 += 64) {
-            const int64_t k1 = (k0 + 64 < start[(size_t)l + 1]) ? k0 + 64 : start[(size_t)l + 1];
-            int32_t md = 0;
-            for (int64_t k = k0; k < k1; ++k) {
-                const int32_t i = order[(size_t)k];
-                if (rowptr[i + 1] - rowptr[i] > md) md = rowptr[i + 1] - rowptr[i];
-            }
-            const int64_t len = (int64_t)(1 + md) * 64;
+        const int64_t a = start[(size_t)l], b = start[(size_t)l + 1];
+        const int32_t cap = rls::best_lane_cap(a, b, deg_at);
+        groups.clear();
+        rls::plan_lane_groups(a, b, cap, deg_at, &groups);
+        for (size_t gi = 0; gi < groups.size(); ++gi) {
+            const rls::LaneGroup& g = groups[gi];
+            const int64_t len = (int64_t)(1 + g.rounds) * 64;
             if (off + len >= (int64_t)0x7fffffff) return rls::fail(RLS_EUNSUPPORTED, "rls_graph_sweep_levels: too large");
             if (lv_ptr) {
                 if (ng + 1 >= ptr_capacity) return rls::fail(RLS_EINVAL, "rls_graph_sweep_levels: ptr capacity too small");
-                lv_ptr[ng] = (int32_t)((uint32_t)off | (k0 == start[(size_t)l] ? 0x80000000u : 0u));
+                lv_ptr[ng] = (int32_t)((uint32_t)off | (gi == 0 ? 0x80000000u : 0u));
             }
             if (lv_data) {
                 if (off + len > data_capacity) return rls::fail(RLS_EINVAL, "rls_graph_sweep_levels: data capacity too small");
-                for (int64_t ln = 0; ln < 64; ++ln) {
-                    const int64_t k = k0 + ln;
-                    const int32_t i = k < k1 ? order[(size_t)k] : (int32_t)N;
-                    const int32_t deg = k < k1 ? rowptr[i + 1] - rowptr[i] : 0;
-                    lv_data[off + ln] = (int32_t)((uint32_t)i | ((uint32_t)(deg >> 1) << 20));
-                    for (int32_t r = 0; r < md; ++r)
-                        lv_data[off + (int64_t)(1 + r) * 64 + ln] = (r < deg) ? col[rowptr[i] + r] : i;
+                int32_t* rec = lv_data + off;
+                for (int64_t e = 0; e < len; ++e) rec[e] = (int32_t)(e < 64 ? N : N * 8);   // idle lanes: node N, its (zero) word
+                int32_t ln = 0;
+                for (int64_t k = g.k0; k < g.k1; ++k) {
+                    const int32_t i = order[(size_t)k], deg = degn(i), lc = rls::lanes_log2_for(deg, cap), L = 1 << lc;
+                    for (int32_t j = 0; j < L; ++j) {              // lane j of the node's L takes neighbours j, j + L, ...
+                        rec[ln + j] = (int32_t)((uint32_t)i | ((uint32_t)(deg >> 1) << 20) | ((uint32_t)lc << 28));
+                        for (int32_t r = 0; r < g.rounds; ++r) {   // short lanes end in the node itself: x_i ^ x_i adds nothing
+                            const int32_t e = r * L + j;
+                            rec[(int64_t)(1 + r) * 64 + ln + j] = (int32_t)((uint32_t)(e < deg ? col[rowptr[i] + e] : i) * 8u);
+                        }
+                    }
+                    ln += L;
                 }
             }
             off += len;
@@ -156,8 +221,13 @@ int rls_graph_sweep_levels(const int32_t* rowptr, const int32_t* col, int64_t N,
         if (ng >= ptr_capacity) return rls::fail(RLS_EINVAL, "rls_graph_sweep_levels: ptr capacity too small");
         lv_ptr[ng] = (int32_t)off;
     }
+    // eight spare rows behind the last record: the kernel prefetches a group's first eight rounds without looking
+    if (lv_data) {
+        if (off + 8 * 64 > data_capacity) return rls::fail(RLS_EINVAL, "rls_graph_sweep_levels: data capacity too small");
+        for (int64_t e = 0; e < 8 * 64; ++e) lv_data[off + e] = (int32_t)(N * 8);
+    }
     *num_groups = ng;
-    *total = off;
+    *total = off + 8 * 64;
     return RLS_OK;
 }
 
@@ -209,41 +279,8 @@ int rls_mcpg_visit_levels(const int32_t* rowptr, const int32_t* col, int64_t N, 
         const int32_t i = order[p], nb = col[rowptr[i] + r];
         return (int32_t)(((uint32_t)nb * 8u) | (pos_of[(size_t)nb] > p ? 0x80000000u : 0u));   // LDS byte offset of the word
     };
-    // Lanes per node of a lane = node group.  A group costs its LONGEST lane and the waves of a workgroup meet at every
-    // level boundary, so one long row among short ones stalls the level and pads 63 lanes: a row longer than `cap`
-    // entries is spread over 2, 4 or 8 adjacent lanes (the kernel adds their counters across them, ~110 VALU per group
-    // that has any).  Per level the cap (none / 32 / 16 / 8 entries per lane) is the one with the least estimated time,
-    // the level's work over the waves plus its longest group, in VALU instructions as measured on gfx950: ~150 per group,
-    // ~85 per 8 rounds, ~110 for the cross-lane sums.
-    auto lanes_for = [](int32_t deg, int32_t cap) {           // log2 of the lanes a row of `deg` entries takes
-        int32_t lc = 0;
-        while (lc < 3 && ((cap > 0 && deg > (cap << lc)) || ((deg + (1 << lc) - 1) >> lc) > 64)) ++lc;
-        return lc;
-    };
-    struct Grp { int64_t k0, k1; int32_t rounds; bool multi; };
-    auto plan = [&](int64_t a, int64_t b, int32_t cap, std::vector<Grp>* out) -> int64_t {
-        int64_t total = 0, longest = 0, k = a;
-        while (k < b) {
-            Grp g{k, k, 0, false};
-            int32_t used = 0;
-            while (g.k1 < b) {
-                const int32_t deg = degp(sp[(size_t)g.k1]), lc = lanes_for(deg, cap), L = 1 << lc;
-                if (used + L > 64) break;
-                used += L;
-                const int32_t r = (deg + L - 1) / L;
-                if (r > g.rounds) g.rounds = r;
-                g.multi = g.multi || lc > 0;
-                ++g.k1;
-            }
-            g.rounds = (g.rounds + 7) / 8 * 8;                    // whole blocks of 8 rounds: the kernel loads them unguarded
-            const int64_t cost = 150 + 85 * (int64_t)(g.rounds / 8) + (g.multi ? 110 : 0);
-            total += cost;
-            if (cost > longest) longest = cost;
-            if (out) out->push_back(g);
-            k = g.k1;
-        }
-        return total / 8 + longest;
-    };
+    using Grp = rls::LaneGroup;
+    auto deg_at = [&](int64_t k) { return degp(sp[(size_t)k]); };
     std::vector<Grp> groups;
     int64_t k0 = 0;
     while (k0 < N) {
@@ -253,18 +290,13 @@ int rls_mcpg_visit_levels(const int32_t* rowptr, const int32_t* col, int64_t N, 
         while (kn < N && level[(size_t)sp[(size_t)kn]] == lev && degp(sp[(size_t)kn]) <= kHubDeg) ++kn;
         ke = kn;
         while (ke < N && level[(size_t)sp[(size_t)ke]] == lev) ++ke;
-        int32_t best_cap = 0;
-        int64_t best = -1;
-        for (int32_t cap : {0, 32, 16, 8}) {
-            const int64_t c = plan(k0, kn, cap, nullptr);
-            if (best < 0 || c < best) { best = c; best_cap = cap; }
-        }
+        const int32_t best_cap = rls::best_lane_cap(k0, kn, deg_at);
         // the level's groups, the costly ones first: waves take groups round-robin, the long ones should not queue up behind
         // a wave's earlier work
         groups.clear();
         for (int64_t h = kn; h < ke; ++h) groups.push_back(Grp{h, h + 1, (degp(sp[(size_t)h]) + 63) / 64, false});
         std::stable_sort(groups.begin(), groups.end(), [](const Grp& x, const Grp& y) { return x.rounds > y.rounds; });
-        plan(k0, kn, best_cap, &groups);
+        rls::plan_lane_groups(k0, kn, best_cap, deg_at, &groups);
         bool level_start = true;
         for (size_t gi = 0; gi < groups.size(); ++gi) {
             const Grp& g = groups[gi];
@@ -288,7 +320,7 @@ int rls_mcpg_visit_levels(const int32_t* rowptr, const int32_t* col, int64_t N, 
                 } else {
                     int32_t ln = 0;
                     for (int64_t k = g.k0; k < g.k1; ++k) {
-                        const int32_t p = sp[(size_t)k], deg = degp(p), lc = lanes_for(deg, best_cap), L = 1 << lc;
+                        const int32_t p = sp[(size_t)k], deg = degp(p), lc = rls::lanes_log2_for(deg, best_cap), L = 1 << lc;
                         for (int32_t j = 0; j < L; ++j) {          // lane j of the node's L takes neighbours j, j + L, ...
                             header(p, lc, rec[ln + j], rec[64 + ln + j]);
                             for (int32_t r = j; r < deg; r += L) rec[(int64_t)(2 + r / L) * 64 + ln + j] = entry(p, r);

@@ -159,70 +159,109 @@ __device__ __forceinline__ uint64_t lv_count_le(const uint64_t (&pl)[8], uint32_
     return ((uint64_t)(lt1 | eq1) << 32) | (lt0 | eq0);
 }
 
+// One group of the level schedule: vertical counters of "neighbour differs" over its rounds (entries = LDS byte
+// offsets of the neighbours' words; whole blocks of 8 rounds, loaded unguarded), summed across the 2 / 4 / 8 adjacent
+// lanes a long row is spread over (lcode = log2 of that, sorted so that lane 0 has the group's largest), then the
+// bit-sliced compare with the per-lane threshold.  NC = counter planes above `fours` that the rounds can reach.
+template <int NC, int NP>
+__device__ __forceinline__ uint64_t sweep_group_flips(const unsigned char* __restrict__ wbytes, const int32_t* __restrict__ rec8,
+                                                      int rounds, const uint32_t (&nb0)[8], uint64_t own, uint32_t thr,
+                                                      uint32_t lcode) {
+    uint64_t ones = 0, twos = 0, fours = 0, c[5] = {0, 0, 0, 0, 0};
+    uint32_t nb[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) nb[q] = nb0[q];
+    for (int r0 = 0; r0 < rounds; r0 += 8, rec8 += 8 * kWave) {
+        uint32_t nxt[8];                                 // the following 8 rounds, requested before these are used
+        if (r0 + 8 < rounds) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) nxt[q] = (uint32_t)rec8[q * kWave];
+        }
+        uint64_t d[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) d[q] = *reinterpret_cast<const uint64_t*>(wbytes + nb[q]) ^ own;   // padding = the node itself: 0
+        uint64_t twosA, twosB, foursA, foursB, carry;
+        csa(twosA, ones, ones, d[0], d[1]);
+        csa(twosB, ones, ones, d[2], d[3]);
+        csa(foursA, twos, twos, twosA, twosB);
+        csa(twosA, ones, ones, d[4], d[5]);
+        csa(twosB, ones, ones, d[6], d[7]);
+        csa(foursB, twos, twos, twosA, twosB);
+        csa(carry, fours, fours, foursA, foursB);
+#pragma unroll
+        for (int p = 0; p < NC; ++p) {
+            const uint64_t t = c[p] & carry;
+            c[p] ^= carry;
+            carry = t;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) nb[q] = nxt[q];
+    }
+    const int gl = __builtin_amdgcn_readlane((int)lcode, 0);
+    if (gl > 0) {   // degrees < 256: the sum over a row's lanes stays below 2^8
+        uint64_t pv[8] = {ones, twos, fours, c[0], c[1], c[2], c[3], c[4]};
+        lv_merge_planes<1>(pv, 0ull - (uint64_t)(lcode >= 1u));
+        if (gl > 1) lv_merge_planes<2>(pv, 0ull - (uint64_t)(lcode >= 2u));
+        if (gl > 2) lv_merge_planes<4>(pv, 0ull - (uint64_t)(lcode >= 3u));
+        return lv_count_le<8>(pv, thr);
+    }
+    const uint64_t pl[8] = {ones, twos, fours, c[0], c[1], c[2], c[3], c[4]};
+    return lv_count_le<NP>(pl, thr);
+}
+
 template <int W>
 __device__ __forceinline__ void sweep_tile_levels(uint64_t* words, const int32_t* lvp, const int32_t* __restrict__ data,
                                                   int64_t G, int64_t N, int lane, int w) {
     constexpr uint32_t M = 0x7fffffffu;
-    // prefetched head of this wave's next group: header word + the first 8 rounds
-    int64_t mine = w;                                  // next group this wave owns
+    const unsigned char* wbytes = reinterpret_cast<const unsigned char*>(words);
+    // prefetched head of this wave's next group: header word + the first 8 rounds (unguarded: rounds are whole blocks
+    // of 8 and the table ends in eight spare rows)
     uint32_t hdr = (uint32_t)N;
     uint32_t nb0[8];
     auto prefetch = [&](int64_t k) {
         if (k < G) {
-            const int64_t p0 = (uint32_t)lvp[k] & M, p1 = (uint32_t)lvp[k + 1] & M;
-            hdr = (uint32_t)data[p0 + lane];
+            const int32_t* rec = data + ((uint32_t)lvp[k] & M) + lane;
+            hdr = (uint32_t)rec[0];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int64_t pos = p0 + (int64_t)(1 + q) * kWave;
-                nb0[q] = pos < p1 ? (uint32_t)data[pos + lane] : (hdr & 0xFFFFFu);
-            }
+            for (int q = 0; q < 8; ++q) nb0[q] = (uint32_t)rec[(1 + q) * kWave];
         }
     };
-    prefetch(mine);
-    for (int64_t k = 0; k < G; ++k) {
-        if (((uint32_t)lvp[k]) >> 31) __syncthreads();   // a new level starts: every earlier flip is visible
-        if (k != mine) continue;
-        const int64_t p0 = (uint32_t)lvp[k] & M, p1 = (uint32_t)lvp[k + 1] & M;
-        const int md = (int)((p1 - p0) >> 6) - 1;        // rounds of this group (its longest row)
-        const uint32_t node = hdr & 0xFFFFFu, thr = hdr >> 20;
-        const uint64_t own = words[node];
-        uint64_t ones = 0, twos = 0, fours = 0, c[5] = {0, 0, 0, 0, 0};
-        uint32_t nb[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) nb[q] = nb0[q];
-        for (int r0 = 0; r0 < md; r0 += 8) {
-            uint32_t nxt[8];                             // the following 8 rounds, requested before these are used
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int64_t pos = p0 + (int64_t)(1 + r0 + 8 + q) * kWave;
-                nxt[q] = pos < p1 ? (uint32_t)data[pos + lane] : node;
-            }
-            uint64_t d[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) d[q] = words[nb[q]] ^ own;      // rounds past md hold the node itself: 0
-            uint64_t twosA, twosB, foursA, foursB, carry;
-            csa(twosA, ones, ones, d[0], d[1]);
-            csa(twosB, ones, ones, d[2], d[3]);
-            csa(foursA, twos, twos, twosA, twosB);
-            csa(twosA, ones, ones, d[4], d[5]);
-            csa(twosB, ones, ones, d[6], d[7]);
-            csa(foursB, twos, twos, twosA, twosB);
-            csa(carry, fours, fours, foursA, foursB);
-#pragma unroll
-            for (int p = 0; p < 5; ++p) {
-                const uint64_t t = c[p] & carry;
-                c[p] ^= carry;
-                carry = t;
-            }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) nb[q] = nxt[q];
+    prefetch(w);
+    // level boundaries of the pass, and per group: a wave walks ITS groups (w, w + W, ...) and meets the others once per
+    // boundary it crosses -- the level of group k = the number of level-start flags up to k, from a ballot over the 64
+    // offsets the wave holds in registers
+    int num_levels = 0;
+    for (int64_t k0 = 0; k0 < G; k0 += kWave)
+        num_levels += __builtin_popcountll(ballot64(k0 + lane < G && (lvp[k0 + lane < G ? k0 + lane : G] >> 31) != 0));
+    int chunk = 0, chunk_next = 0;
+    int64_t cbase = -1;
+    uint64_t lmask = 0;
+    int lev_base = 0, passed = 0;
+    for (int64_t k = w; k < G; k += W) {
+        if ((k & ~(int64_t)63) != cbase) {
+            cbase = k & ~(int64_t)63;
+            lev_base += __builtin_popcountll(lmask);
+            const int64_t a0 = cbase + lane <= G ? cbase + lane : G, a1 = cbase + 1 + lane <= G ? cbase + 1 + lane : G;
+            chunk = lvp[a0];
+            chunk_next = lvp[a1];
+            lmask = ballot64(cbase + lane < G && (chunk >> 31) != 0);
         }
-        const uint64_t pl[8] = {ones, twos, fours, c[0], c[1], c[2], c[3], c[4]};
-        const uint64_t flip = md < 16 ? lv_count_le<4>(pl, thr) : (md < 64 ? lv_count_le<6>(pl, thr) : lv_count_le<8>(pl, thr));
-        if (node < (uint32_t)N) words[node] = own ^ flip;
-        mine += W;
-        prefetch(mine);
+        const int need = lev_base + __builtin_popcountll(lmask & ((2ull << (k & 63)) - 1ull));
+        for (; passed < need; ++passed) __syncthreads();     // a new level starts: every earlier flip is visible
+        const int64_t p0 = (uint32_t)__builtin_amdgcn_readlane(chunk, (int)(k & 63)) & M;
+        const int64_t p1 = (uint32_t)__builtin_amdgcn_readlane(chunk_next, (int)(k & 63)) & M;
+        const int rounds = (int)((p1 - p0) >> 6) - 1;        // a multiple of 8
+        const uint32_t node = hdr & 0xFFFFFu, thr = (hdr >> 20) & 0xFFu, lcode = (hdr >> 28) & 3u;
+        const uint64_t own = words[node];
+        const int32_t* rec8 = data + p0 + (1 + 8) * kWave + lane;   // round 8 of this lane
+        uint64_t flip;
+        if (rounds <= 8) flip = sweep_group_flips<1, 4>(wbytes, rec8, rounds, nb0, own, thr, lcode);
+        else if (rounds <= 24) flip = sweep_group_flips<2, 5>(wbytes, rec8, rounds, nb0, own, thr, lcode);
+        else flip = sweep_group_flips<4, 7>(wbytes, rec8, rounds, nb0, own, thr, lcode);
+        if (node < (uint32_t)N && (lane & ((1 << lcode) - 1)) == 0) words[node] = own ^ flip;
+        prefetch(k + W);
     }
+    for (; passed < num_levels; ++passed) __syncthreads();
     __syncthreads();
 }
 

@@ -462,6 +462,29 @@ __device__ __forceinline__ void csa(uint64_t& hi, uint64_t& lo, uint64_t a, uint
     lo = ((uint64_t)l1 << 32) | l0;
 }
 
+// lane exchange of a 64-bit plane with lane ^ 1, ^ 2 (DPP quad_perm 0xB1 / 0x4E) or ^ 4 (ds_swizzle bit mode), no memory
+template <int X>
+__device__ __forceinline__ uint64_t lv_lane_xor(uint64_t v) {
+    uint32_t lo, hi;
+    if constexpr (X == 4) {
+        lo = (uint32_t)__builtin_amdgcn_ds_swizzle((int)(uint32_t)v, 0x101F);          // and 0x1F, or 0, xor 4
+        hi = (uint32_t)__builtin_amdgcn_ds_swizzle((int)(uint32_t)(v >> 32), 0x101F);
+    } else {
+        constexpr int CTRL = X == 1 ? 0xB1 : 0x4E;
+        lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, 0xF, 0xF, false);
+        hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, 0xF, 0xF, false);
+    }
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// pl[0..7] += lane ^ X's pl[0..7] where `take` is all-ones (bit-sliced ripple-carry add, counts <= 128 in total)
+template <int X>
+__device__ __forceinline__ void lv_merge_planes(uint64_t (&pl)[8], uint64_t take) {
+    uint64_t carry = 0;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) csa(carry, pl[p], pl[p], lv_lane_xor<X>(pl[p]) & take, carry);
+}
+
 __device__ __forceinline__ uint64_t shfl_xor64(uint64_t v, int mask) {
     uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
     lo = __shfl_xor(lo, mask, 64);

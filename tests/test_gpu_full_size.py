@@ -274,3 +274,27 @@ def test_graphs_beyond_the_bit_tile_cap_g81_size(bidir):
     for t in range(3):
         obs, r, d, c = genv.step(torch.randint(0, n, (B,), device=DEV))
     assert torch.equal(ops.maxcut_obj(genv.graph, obs).float(), c)
+
+
+@pytest.mark.parametrize("n,m,B", [(260, 26000, 2111), (400, 12000, 2048), (1000, 9990, 4099), (130, 8000, 64)])
+@pytest.mark.parametrize("bidir", [False, True])
+def test_level_parallel_sweep_with_rows_on_several_lanes_vs_c_oracle(n, m, B, bidir):
+    """K5 on graphs whose rows are long enough to be spread over 2 / 4 / 8 lanes of a level group (degrees 20-250:
+    the cross-lane counter sums, the 64-entry-per-lane limit, groups of mixed lane counts) against the C restatement
+    of the sequential pass of env_L2A.py:109-116, bit for bit, plus the fused local search's sweep on the same graph."""
+    from oracle import oracle_c as oc
+    garr = gnm_arr(n, m, seed=n + m)
+    g = device_graph(garr, n, int(bidir))
+    eu, ev = onp.stored_edges(garr, bidir)
+    rng = np.random.RandomState(B)
+    x_np = rng.randint(0, 2, size=(B, n)).astype(np.uint8)
+    xs = torch.from_numpy(x_np).to(DEV).bool()
+    vs = ops.maxcut_obj(g, xs)
+    assert np.array_equal(vs.cpu().numpy(), oc.maxcut_obj(x_np, eu, ev, int(bidir)))
+    x5, v5 = xs.clone(), vs.clone()
+    ops.maxcut_greedy_sweep(g, x5, v5)
+    sub = np.arange(0, B, max(1, B // 48))
+    wx, wv = x_np[sub].copy(), vs.cpu().numpy()[sub].copy()
+    oc.greedy_sweep(wx, wv, eu, ev, int(bidir))
+    assert np.array_equal(x5.cpu().numpy().astype(np.uint8)[sub], wx) and np.array_equal(v5.cpu().numpy()[sub], wv)
+    assert torch.equal(ops.maxcut_obj(g, x5), v5)

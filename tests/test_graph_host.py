@@ -120,13 +120,15 @@ def test_sweep_level_schedule_is_a_valid_reordering_of_the_sequential_pass():
 
 
 def test_sweep_level_groups_encode_the_same_schedule():
-    """rls_graph_sweep_levels: every node appears once, lanes of a group are pairwise non-adjacent, lower-numbered
-    neighbours sit in earlier LEVELS, rounds list each node's CSR row padded with the node itself."""
+    """rls_graph_sweep_levels: every node appears once (on L = 1, 2, 4 or 8 adjacent, L-aligned lanes, the longest
+    rows first), lower-numbered neighbours sit in earlier LEVELS, lane j of a node lists its CSR entries j, j + L, ...
+    as byte offsets of the neighbours' words and ends in the node itself, rounds come in whole blocks of 8, no lane holds
+    more than 64 entries, and the table ends in eight spare rows."""
     import ctypes as C
     from rlsolver_amd import _abi
     from rlsolver_amd.graph import build_csr, generate_gnm, generate_ba
     for g, n in ((generate_gnm(300, 1500, seed=3), 300), (generate_ba(200, 4, seed=1), 200), ([(0, 1, 1)], 70),
-                 (generate_gnm(2000, 19990, seed=22), 2000)):
+                 (generate_gnm(2000, 19990, seed=22), 2000), (generate_gnm(260, 26000, seed=5), 260)):
         csr = build_csr(g, num_nodes=n, if_bidirectional=False)
         rp = np.ascontiguousarray(csr.rowptr, dtype=np.int32)
         col = np.ascontiguousarray(csr.col, dtype=np.int32)
@@ -139,23 +141,33 @@ def test_sweep_level_groups_encode_the_same_schedule():
                   lvd.size, C.byref(ng), C.byref(tot))
         off = (lvp.view(np.uint32) & 0x7FFFFFFF).astype(np.int64)
         first = (lvp.view(np.uint32)[:-1] >> 31).astype(bool)
-        assert first[0] and off[-1] == tot.value
+        assert first[0] and off[-1] + 8 * 64 == tot.value and (lvd[off[-1]:] == n * 8).all()
         level_of_group = np.cumsum(first) - 1
         level_of = np.full(n, -1)
         seen = []
         for k in range(ng.value):
             rec = lvd[off[k]: off[k + 1]].reshape(-1, 64)
+            rounds = rec.shape[0] - 1
+            assert rounds % 8 == 0 and rounds <= 64
             hdr = rec[0].view(np.uint32)
-            nodes, half = (hdr & 0xFFFFF).astype(np.int64), hdr >> 20
+            nodes, half, lcode = (hdr & 0xFFFFF).astype(np.int64), (hdr >> 20) & 0xFF, (hdr >> 28) & 3
             live = nodes < n
-            seen += nodes[live].tolist()
-            level_of[nodes[live]] = level_of_group[k]
-            for ln in np.flatnonzero(live):
-                i = nodes[ln]
+            assert (np.diff(lcode[live].astype(int)) <= 0).all()             # longest rows (most lanes) first
+            ln = 0
+            while ln < 64 and live[ln]:
+                i, L = nodes[ln], 1 << int(lcode[ln])
+                assert ln % L == 0 and (nodes[ln: ln + L] == i).all() and (lcode[ln: ln + L] == lcode[ln]).all()
                 deg = rp[i + 1] - rp[i]
-                assert half[ln] == deg // 2
-                assert np.array_equal(rec[1:1 + deg, ln], col[rp[i]: rp[i + 1]]) and (rec[1 + deg:, ln] == i).all()
-            assert (rec[1:, ~live] == n).all()
+                assert (half[ln: ln + L] == deg // 2).all()
+                row = col[rp[i]: rp[i + 1]]
+                for j in range(L):
+                    mine = row[j::L]
+                    assert len(mine) <= rounds
+                    assert np.array_equal(rec[1:1 + len(mine), ln + j], mine * 8) and (rec[1 + len(mine):, ln + j] == i * 8).all()
+                seen.append(int(i))
+                level_of[i] = level_of_group[k]
+                ln += L
+            assert not live[ln:].any() and (rec[1:, ~live] == n * 8).all()
         assert sorted(seen) == list(range(n))
         for i in range(n):
             nbrs = col[rp[i]: rp[i + 1]]
