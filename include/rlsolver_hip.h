@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RLS_ABI_VERSION 4
+#define RLS_ABI_VERSION 5
 
 enum {
     RLS_OK = 0,
@@ -305,7 +305,7 @@ int rls_spin_step(const rls_graph* g, const rls_spin_env* env, int state_bytes, 
 /* K9  metro_sampling(probs, start_status, max_transfer_time)  methods/MCPG.py:88-117.
  * Runs rounds t = t_offset .. t_offset + min(T, *t_limit_dev) - 1 for every chain c:
  *   i = index[t,c]; p = x[i,c] ? probs[i] : 1 - probs[i];
- *   accept iff u[t,c] < (1 - p) / p  -> flip x[i,c];  accepts[t - t_offset] += #accepted chains.
+ *   accept iff u[t,c] < (1 - p) / p  -> flip x[i,c];  accepts[r][t - t_offset] += #accepted chains (r = tile % accept_rows).
  * index int64 [*,C] and u f32 [*,C] are the reference's randint / rand draws in call order (rows
  * indexed by the absolute round t; test mode) or both NULL for the in-kernel counter-based generator
  * (murmur3 finaliser) keyed by (seed, chain, t).
@@ -313,7 +313,8 @@ int rls_spin_step(const rls_graph* g, const rls_spin_env* env, int state_bytes, 
  * samples_in (same dtype, may be NULL = samples) is where the chains are READ; they are written to samples:
  * the first chunk of a call turns the caller's start state into the result buffer without a copy.
  * (one host sync per round there).  Here the caller walks the 5*T_transfer rounds in chunks: a dry
- * call (write_back = 0) fills accepts[T] (int64, zeroed by the caller), the stop round is derived
+ * call (write_back = 0) fills accepts [accept_rows][T] (int64, zeroed by the caller; a round's count is its COLUMN SUM --
+ * workgroups spread their adds over the rows, one row would serialise thousands of atomics per round), the stop round is derived
  * on the device, a second call with t_limit_dev pointing at it (device int64) and write_back = 1
  * applies the chunk; *t_limit_dev <= 0 makes a call return immediately, so chunks after the stop
  * round cost one empty launch.  t_limit_dev NULL = all T rounds.  samples is updated in place only
@@ -323,7 +324,8 @@ int rls_spin_step(const rls_graph* g, const rls_spin_env* env, int state_bytes, 
  * without materialising the repeat. */
 int rls_mcpg_metro_rounds(void* samples, const void* samples_in, int64_t C_in, int spin_bytes, int64_t N, int64_t C,
                           const float* probs, int64_t T, int64_t t_offset, const int64_t* index, const float* u,
-                          uint64_t seed, const int64_t* t_limit_dev, int write_back, int64_t* accepts, void* stream);
+                          uint64_t seed, const int64_t* t_limit_dev, int write_back, int64_t* accepts, int64_t accept_rows,
+                          void* stream);
 
 /* K7 + K8 first half  sampler_func  methods/MCPG.py:128-152.
  * xs_in [N,C] holds 0|1 (the sampler's input before the reference maps it to -0.5|1.5).

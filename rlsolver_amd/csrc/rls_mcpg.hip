@@ -118,7 +118,10 @@ __global__ __launch_bounds__(kMetroWaves * kWave) void k_mcpg_metro(T* samples, 
                                                       const int64_t* __restrict__ index,
                                                       const float* __restrict__ u, uint64_t seed,
                                                       const int64_t* __restrict__ t_limit_dev, int write_back,
-                                                      unsigned long long* __restrict__ accepts, int64_t t_offset) {
+                                                      unsigned long long* __restrict__ accepts_all, int64_t accept_rows, int64_t t_offset) {
+    // accept counts go to row (workgroup % accept_rows) of [accept_rows][T_rounds]: thousands of workgroups adding into ONE row
+    // serialise at the L2 atomic units (measured: 3/4 of the packed walk's time)
+    unsigned long long* accepts = accepts_all ? accepts_all + (int64_t)(blockIdx.x % (unsigned)accept_rows) * T_rounds : nullptr;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* words = reinterpret_cast<uint64_t*>(smem);
     // probs staged in LDS when it fits: a per-round random gather from global memory would put an
@@ -201,7 +204,10 @@ __global__ __launch_bounds__(kMetroPW * kWave) void k_mcpg_metro_packed(uint64_t
                                                              int64_t T_rounds, const int64_t* __restrict__ index,
                                                              const float* __restrict__ u, uint64_t seed,
                                                              const int64_t* __restrict__ t_limit_dev, int write_back,
-                                                             unsigned long long* __restrict__ accepts, int64_t t_offset) {
+                                                             unsigned long long* __restrict__ accepts_all, int64_t accept_rows, int64_t t_offset) {
+    // accept counts go to row (workgroup % accept_rows) of [accept_rows][T_rounds]: thousands of workgroups adding into ONE row
+    // serialise at the L2 atomic units (measured: 3/4 of the packed walk's time)
+    unsigned long long* accepts = accepts_all ? accepts_all + (int64_t)(blockIdx.x % (unsigned)accept_rows) * T_rounds : nullptr;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* words = reinterpret_cast<uint64_t*>(smem);
     uint32_t* queue = reinterpret_cast<uint32_t*>(smem + (size_t)((N + 1) & ~(int64_t)1) * 8);   // [2][kMetroWin][64]
@@ -243,13 +249,15 @@ __global__ __launch_bounds__(kMetroPW * kWave) void k_mcpg_metro_packed(uint64_t
             const float q1 = p, q0 = 1.0f - p;                    // torch.where(chosen_value, p, 1 - p)
             const bool a1 = uu < (1.0f - q1) / q1;                // MCPG.py:107 for a set bit
             const bool a0 = uu < (1.0f - q0) / q0;                //             for a clear bit
-            q[r * kWave + lane] = live ? ((uint32_t)i | ((uint32_t)a0 << 30) | ((uint32_t)a1 << 31)) : 0u;
+            // byte offset of the node's word | verdict for a set bit << 30 | verdict for a clear bit << 31: the walker
+            // shifts left by the current bit and reads the sign
+            q[r * kWave + lane] = live ? (((uint32_t)i << 3) | ((uint32_t)a1 << 30) | ((uint32_t)a0 << 31)) : 0u;
         }
     };
     if (w > 0 && nwin > 0) produce(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    const uint64_t mybit = 1ull << lane;
+    const BitXpose xc = bit_xpose_consts(lane);
     for (int64_t win = 0; win < nwin; ++win) {
         if (w == 0) {
             const uint32_t* q = queue + (win & 1) * (kMetroWin * kWave);
@@ -257,35 +265,58 @@ __global__ __launch_bounds__(kMetroPW * kWave) void k_mcpg_metro_packed(uint64_t
             uint32_t mycnt = 0;
             __builtin_amdgcn_s_setprio(3);                        // the walker is the critical path of the workgroup
             // entries come 8 rounds at a time (they do not depend on the chain state); the word of round r + 1 is
-            // requested before the flip of round r is issued
+            // requested before the flip of round r is issued.  A lane works on the 32-bit half of the word its chain
+            // lives in; the flip is an UNCONDITIONAL ds_xor with a zero mask for a rejected proposal (no exec
+            // juggling, and the wait for the early read never has to cover the atomic behind it); rounds past the stop
+            // rule carry entry 0 = no verdict.  ~14 VALU per round -- the walk is one wave's issue rate.
+            const uint32_t half4 = (uint32_t)(lane >> 5) * 4u, sh = (uint32_t)lane & 31u, mybit32 = 1u << sh;
+            auto addr_of = [&](uint32_t e) { return (e & 0x3fffffffu) | half4; };
+            auto half_at = [&](uint32_t a) { return *reinterpret_cast<const uint32_t*>(smem + a); };
             uint32_t eb[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) eb[k] = q[k * kWave + lane];
-            uint64_t wv = words[eb[0] & 0x3fffffffu];
+            // Two rounds of look-ahead: the word of round r + 2 is requested in round r, BEFORE that round's flip is
+            // issued, so it misses the flips of rounds r and r + 1; those two are patched in registers (m1 collects them
+            // for the word that is next in line) -- other lanes' flips touch other bits of the word.
+            uint32_t a0 = addr_of(eb[0]), a1 = addr_of(eb[1]);
+            uint32_t w0 = half_at(a0), w1 = half_at(a1), m1 = 0;
+            uint32_t alo = 0, ahi = 0;
             for (int r0 = 0; r0 < rounds; r0 += 8) {
-                uint32_t en8[8];
+                uint32_t en8[8], blk = 0;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) en8[k] = (r0 + 8 + k < kMetroWin) ? q[(r0 + 8 + k) * kWave + lane] : 0u;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    const int r = r0 + k;
-                    const uint32_t e = eb[k];
-                    const uint32_t i = e & 0x3fffffffu;
-                    const uint32_t bit = (uint32_t)(wv >> lane) & 1u;
-                    const bool acc = (r < rounds) && ((e >> (30 + bit)) & 1u);
-                    const uint32_t en = (k + 1 < 8) ? eb[(k + 1) & 7] : en8[0];
-                    const uint32_t inx = en & 0x3fffffffu;
-                    uint64_t wn = words[inx];
-                    if (acc) atomicXor(reinterpret_cast<unsigned long long*>(&words[i]), (unsigned long long)mybit);
-                    if (acc && inx == i) wn ^= mybit;             // the one flip the early read cannot have seen
-                    if (accepts) {
-                        const uint32_t cnt = (uint32_t)__popcll(ballot64(acc));
-                        if (lane == r) mycnt = cnt;
-                    }
-                    wv = wn;
+                    // (opaque from here on: otherwise the compiler folds the pending mask into the word the moment it is
+                    // read, i.e. waits for the look-ahead read right after issuing it)
+                    asm volatile("" : "+v"(m1));
+                    const uint32_t bit = (w0 >> sh) & 1u;
+                    const bool acc = (int32_t)(eb[k] << bit) < 0;
+                    const uint32_t flip = acc ? mybit32 : 0u;
+                    const uint32_t a2 = addr_of((k + 2 < 8) ? eb[(k + 2) & 7] : en8[(k + 2) & 7]);
+                    const uint32_t w2 = half_at(a2);
+                    __hip_atomic_fetch_xor(static_cast<uint32_t*>(__builtin_assume_aligned(smem + a0, 4)), flip, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+                    const uint32_t m2 = (a2 == a0) ? flip : 0u;
+                    m1 ^= (a1 == a0) ? flip : 0u;
+                    blk |= (flip >> sh) << k;                     // accept bit of round r0 + k (pure VALU: a ballot + popcount
+                                                                   // per round is a VALU -> SALU -> VALU round trip, 240 of the
+                                                                   // walker's 330 cycles per round when it was done that way)
+                    w0 = w1 ^ m1;
+                    a0 = a1;
+                    w1 = w2;
+                    m1 = m2;
+                    a1 = a2;
                 }
 #pragma unroll
                 for (int k = 0; k < 8; ++k) eb[k] = en8[k];
+                if (r0 < 32) alo |= blk << r0;
+                else ahi |= blk << (r0 - 32);
+            }
+            // lane l holds its chain's accept bits by round; transposed, lane r holds round r's accepts by chain
+            if (accepts) {
+                bit_transpose64(alo, ahi, xc);
+                mycnt = (uint32_t)(__builtin_popcount(alo) + __builtin_popcount(ahi));
             }
             __builtin_amdgcn_s_setprio(0);
             if (accepts && lane < rounds && mycnt) atomicAdd(&accepts[win * kMetroWin + lane], (unsigned long long)mycnt);
@@ -1052,13 +1083,16 @@ extern "C" {
 
 int rls_mcpg_metro_rounds(void* samples, const void* samples_in, int64_t C_in, int spin_bytes, int64_t N, int64_t C,
                           const float* probs, int64_t T, int64_t t_offset, const int64_t* index, const float* u,
-                          uint64_t seed, const int64_t* t_limit_dev, int write_back, int64_t* accepts, void* stream) {
+                          uint64_t seed, const int64_t* t_limit_dev, int write_back, int64_t* accepts, int64_t accept_rows,
+                          void* stream) {
     RLS_REQUIRE(N > 0 && C >= 0 && T >= 0 && t_offset >= 0, RLS_EINVAL, "bad sizes N=%lld C=%lld T=%lld", (long long)N, (long long)C,
                 (long long)T);
     if (C == 0) return RLS_OK;
     RLS_REQUIRE(samples && probs, RLS_EINVAL, "samples/probs is NULL");
     RLS_REQUIRE((index == nullptr) == (u == nullptr), RLS_EINVAL, "index and u must both be given or both be NULL");
     RLS_REQUIRE(spin_bytes == 0 || spin_bytes == 1 || spin_bytes == 4, RLS_EINVAL, "spin_bytes must be 0 (bit-packed), 1 or 4");
+    RLS_REQUIRE(!accepts || (accept_rows >= 1 && accept_rows < (1ll << 31)), RLS_EINVAL, "accept_rows must be >= 1 when accepts is given");
+    if (!accepts) accept_rows = 1;
     if (!samples_in) { samples_in = samples; C_in = C; }
     if (C_in <= 0) C_in = C;
     RLS_REQUIRE(samples_in == samples || write_back, RLS_EINVAL, "samples_in != samples needs write_back");
@@ -1073,7 +1107,7 @@ int rls_mcpg_metro_rounds(void* samples, const void* samples_in, int64_t C_in, i
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(C, kWave)), dim3(kMetroPW * kWave), lds, as_stream(stream),
                            (uint64_t*)samples, (const uint64_t*)samples_in, ceil_div(C_in, kWave), N, C, probs, T, index, u, seed,
-                           t_limit_dev, write_back, (unsigned long long*)accepts, t_offset);
+                           t_limit_dev, write_back, (unsigned long long*)accepts, accept_rows, t_offset);
         return check_launch("k_mcpg_metro_packed");
     }
     RLS_REQUIRE(C_in == C, RLS_EINVAL, "a broadcast start state (C_in != C) needs the bit-packed layout");
@@ -1090,7 +1124,7 @@ int rls_mcpg_metro_rounds(void* samples, const void* samples_in, int64_t C_in, i
         if (lds > 64 * 1024)                                                                                        \
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
         hipLaunchKernelGGL(kern, grid, block, lds, s, (TT*)samples, (const TT*)samples_in, N, C, probs, T, index, u, seed, t_limit_dev, \
-                           write_back, (unsigned long long*)accepts, t_offset);                                     \
+                           write_back, (unsigned long long*)accepts, accept_rows, t_offset);                        \
     } while (0)
     if (spin_bytes == 1) { if (probs_lds) LAUNCH_METRO(uint8_t, true); else LAUNCH_METRO(uint8_t, false); }
     else                 { if (probs_lds) LAUNCH_METRO(float, true);   else LAUNCH_METRO(float, false); }

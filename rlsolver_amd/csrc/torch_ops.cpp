@@ -213,9 +213,15 @@ void mcpg_metro_rounds(Tensor samples, const OptTensor& samples_in, int64_t C_in
     optdev(u, "u", F32);
     optdev(t_limit, "t_limit", I64);
     optdev(accepts, "accepts", I64);
+    int64_t accept_rows = 1;      // accepts is [T] or [rows, T]
+    if (accepts.has_value()) {
+        TORCH_CHECK((accepts->dim() == 1 || accepts->dim() == 2) && accepts->size(-1) == T, "accepts must be [T] or [rows, T]");
+        if (accepts->dim() == 2) accept_rows = accepts->size(0);
+    }
     const int64_t N = sb == 0 ? samples.size(1) : samples.size(0);
     ok(rls_mcpg_metro_rounds(p(samples), p(samples_in), C_in, sb, N, C, (const float*)p(probs), T, t_offset, (const int64_t*)p(index),
-                             (const float*)p(u), (uint64_t)seed, (const int64_t*)p(t_limit), write_back, (int64_t*)p(accepts), cur_stream(samples)),
+                             (const float*)p(u), (uint64_t)seed, (const int64_t*)p(t_limit), write_back, (int64_t*)p(accepts), accept_rows,
+                             cur_stream(samples)),
        "rls_mcpg_metro_rounds");
 }
 void mcpg_local_search(int64_t g, const Tensor& xs_in, Tensor xs_out, const Tensor& order, const OptTensor& visit_stream, int64_t num_ls,

@@ -153,6 +153,9 @@ def build_visit_stream(csr, order: np.ndarray, max_nodes: int = 32, max_entries:
     return (stream & 0xFFFFFFFF).astype(np.uint32).view(np.int32)
 
 
+ACCEPT_ROWS = 64      # rows the kernels spread their per-round accept counts over (one row = thousands of atomics per address)
+
+
 def metro_sampling_packed(probs: TEN, start: PackedChains, max_transfer_time: int, num_chains: Optional[int] = None,
                           index: Optional[TEN] = None, u: Optional[TEN] = None, out: Optional[PackedChains] = None) -> PackedChains:
     """metro_sampling (MCPG.py:88-117) on bit-packed chains.  ``start`` may hold fewer chains than ``num_chains`` (a
@@ -183,16 +186,16 @@ def metro_sampling_packed(probs: TEN, start: PackedChains, max_transfer_time: in
     for t0 in range(0, Tmax, chunk):
         tk = min(chunk, Tmax - t0)
         tk_dev = torch.full((), tk, dtype=torch.int64, device=device)
-        accepts = torch.zeros(tk, dtype=torch.int64, device=device)
+        accepts = torch.zeros((ACCEPT_ROWS, tk), dtype=torch.int64, device=device)
         if t0 == 0:
             mops.mcpg_metro_rounds(samples, probs, tk, index, u, seed, None, True, accepts, t_offset=0,
                                    samples_in=None if samples is start else start)
-            cum = accepts.cumsum(0)
+            cum = accepts.sum(0).cumsum(0)
             hit = cum[-1] >= target
         else:
             limit = torch.where(live, tk_dev, zero).reshape(1).contiguous()
             mops.mcpg_metro_rounds(samples, probs, tk, index, u, seed, limit, False, accepts, t_offset=t0)
-            cum = cum_prev + accepts.cumsum(0)
+            cum = cum_prev + accepts.sum(0).cumsum(0)
             reached = cum >= target
             hit = reached.any()
             t_stop = torch.where(hit, reached.to(torch.int64).argmax() + 1, tk_dev)
@@ -235,16 +238,16 @@ def metro_sampling(probs: TEN, start_status: TEN, max_transfer_time: int, device
     for t0 in range(0, Tmax, chunk):
         tk = min(chunk, Tmax - t0)
         tk_dev = torch.full((), tk, dtype=torch.int64, device=device)
-        accepts = torch.zeros(tk, dtype=torch.int64, device=device)
+        accepts = torch.zeros((ACCEPT_ROWS, tk), dtype=torch.int64, device=device)
         if t0 == 0:
             mops.mcpg_metro_rounds(samples, probs, tk, index, u, seed, None, True, accepts, t_offset=0,
                                    samples_in=None if samples is start else start)
-            cum = accepts.cumsum(0)
+            cum = accepts.sum(0).cumsum(0)
             hit = cum[-1] >= target
         else:
             limit = torch.where(live, tk_dev, zero).reshape(1).contiguous()
             mops.mcpg_metro_rounds(samples, probs, tk, index, u, seed, limit, False, accepts, t_offset=t0)
-            cum = cum_prev + accepts.cumsum(0)
+            cum = cum_prev + accepts.sum(0).cumsum(0)
             reached = cum >= target
             hit = reached.any()
             t_stop = torch.where(hit, reached.to(torch.int64).argmax() + 1, tk_dev)

@@ -89,10 +89,13 @@ def mcpg_metro_rounds(samples, probs: TEN, T: int, index: Optional[TEN] = None, 
             raise ValueError("index/u must be [>= t_offset + T, C]")
     if t_limit is not None:
         _check(t_limit, "t_limit", (torch.int64,), dev)
-    if accepts is not None:
+    accept_rows = 1
+    if accepts is not None:     # [T] or [rows, T]: workgroups spread their adds over the rows, a round's count = its column sum
         _check(accepts, "accepts", (torch.int64,), dev)
-        if accepts.numel() < T:
-            raise ValueError("accepts must hold T entries")
+        if accepts.dim() == 2:
+            accept_rows = accepts.shape[0]
+        if accepts.dim() not in (1, 2) or accepts.shape[-1] != T:
+            raise ValueError("accepts must be [T] or [rows, T]")
     sin, c_in = None, Cc
     if samples_in is not None:
         sin, sb_in, n_in, c_in = _chains(samples_in, "samples_in")
@@ -101,7 +104,7 @@ def mcpg_metro_rounds(samples, probs: TEN, T: int, index: Optional[TEN] = None, 
         if not write_back:
             raise ValueError("samples_in needs write_back")
     _abi.call("rls_mcpg_metro_rounds", _ptr(st), _ptr(sin), c_in, sb, N, Cc, _ptr(probs),
-              T, t_offset, _ptr(index), _ptr(u), _u64(seed), _ptr(t_limit), int(bool(write_back)), _ptr(accepts),
+              T, t_offset, _ptr(index), _ptr(u), _u64(seed), _ptr(t_limit), int(bool(write_back)), _ptr(accepts), accept_rows,
               _stream(dev))
 
 
