@@ -147,6 +147,8 @@ __global__ __launch_bounds__(kMetroWaves * kWave) void k_mcpg_metro(T* samples, 
     const uint32_t chain_key = k7_fmix32((uint32_t)seed ^ k7_fmix32((uint32_t)(seed >> 32) ^ k7_fmix32((uint32_t)c) ^
                                                                     ((uint32_t)((uint64_t)c >> 32) * 0x9E3779B1u)));
     const uint64_t mybit = 1ull << lane;
+    const BitXpose xc = bit_xpose_consts(lane);
+    uint32_t alo = 0, ahi = 0;                        // this chain's accept bits of the current 64 rounds
     for (int64_t t = 0; w == 0 && t < t_end; ++t) {   // the chain walk itself is one wave (64 chains = 64 lanes)
         int64_t i = 0;
         float uu = 2.0f;
@@ -171,8 +173,17 @@ __global__ __launch_bounds__(kMetroWaves * kWave) void k_mcpg_metro(T* samples, 
         // round's hash and address math overlap this round's LDS round trips.
         if (acc) atomicXor(reinterpret_cast<unsigned long long*>(&words[i]), (unsigned long long)mybit);
         if (accepts) {
-            const int cnt = __popcll(ballot64(acc));
-            if (lane == 0) acc_cnt[t] = (uint32_t)cnt;
+            // one bit per (chain, round) in registers and ONE 64 x 64 bit transpose + popcount per 64 rounds: a ballot +
+            // popcount per round is a VALU -> SALU -> VALU round trip on the walk's critical path
+            const uint32_t a = acc ? 1u : 0u;
+            if ((t & 32) == 0) alo |= a << (t & 31);
+            else ahi |= a << (t & 31);
+            if ((t & 63) == 63 || t + 1 == t_end) {
+                bit_transpose64(alo, ahi, xc);                   // lane r now holds round (t & ~63) + r by chain
+                const int64_t tr = (t & ~(int64_t)63) + lane;
+                if (tr <= t) acc_cnt[tr] = (uint32_t)(__builtin_popcount(alo) + __builtin_popcount(ahi));
+                alo = ahi = 0;
+            }
         }
     }
     __syncthreads();
