@@ -1064,26 +1064,61 @@ __global__ __launch_bounds__(kBitSumThreads) void k_mcpg_value_bit_sums_lut(cons
 }
 
 // bit-packed tiles <-> the reference's node-major f32 [N, C] surface (shims for callers that want it)
+// unpack: a thread writes four consecutive chains of one node as one 16-byte store (rows of C % 4 == 0 floats are 16-byte
+// aligned); grid.y walks the nodes, so no division per element
+template <bool V4>
 __global__ __launch_bounds__(256) void k_mcpg_unpack(const uint64_t* __restrict__ packed, int64_t N, int64_t C, float* __restrict__ xs) {
-    const int64_t total = N * C;
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t n = t / C, c = t - n * C;
-        xs[t] = (float)((packed[(c >> 6) * N + n] >> (c & 63)) & 1ull);
+    if constexpr (V4) {
+        const int64_t c4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;          // chains 4 c4 .. 4 c4 + 3
+        if (c4 * 4 >= C) return;
+        const int64_t tile = c4 >> 4;
+        const int sh = (int)(c4 & 15) * 4;
+        for (int64_t n = blockIdx.y; n < N; n += gridDim.y) {
+            const uint32_t b = (uint32_t)(packed[tile * N + n] >> sh) & 15u;
+            f32x4 v;
+            v[0] = (float)(b & 1u); v[1] = (float)((b >> 1) & 1u); v[2] = (float)((b >> 2) & 1u); v[3] = (float)(b >> 3);
+            *reinterpret_cast<f32x4*>(xs + n * C + c4 * 4) = v;
+        }
+    } else {
+        const int64_t total = N * C;
+        for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t n = t / C, c = t - n * C;
+            xs[t] = (float)((packed[(c >> 6) * N + n] >> (c & 63)) & 1ull);
+        }
     }
 }
 
+// pack: a workgroup turns 64 nodes x kPackTiles consecutive 64-chain tiles; each of its 4 waves takes 16 of the rows, all
+// 16 loads of a tile in flight and the next tile's requested before this one's ballots (one load -> ballot per trip was a
+// chain of memory round trips, and one tile per workgroup left the launch rate of its short-lived waves as the bound)
+constexpr int kPackTiles = 8;
 template <typename T>
-__global__ __launch_bounds__(kWave) void k_mcpg_pack(const T* __restrict__ xs, int64_t N, int64_t C, uint64_t* __restrict__ packed) {
-    const int lane = threadIdx.x;
-    const int64_t tile = blockIdx.y;
-    const int64_t c = tile * kWave + lane;
-    const int64_t n0 = (int64_t)blockIdx.x * kWave;
-    uint64_t mine = 0;
-    for (int k = 0; k < kWave && n0 + k < N; ++k) {
-        const uint64_t w = ballot64(c < C && spin_is_set(xs[(n0 + k) * C + c]));
-        if (lane == k) mine = w;
+__global__ __launch_bounds__(4 * kWave) void k_mcpg_pack(const T* __restrict__ xs, int64_t N, int64_t C, uint64_t* __restrict__ packed) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = threadIdx.x / kWave;
+    const int64_t tiles = (C + kWave - 1) / kWave;
+    const int64_t t0 = (int64_t)blockIdx.x * kPackTiles;
+    const int64_t n0 = (int64_t)blockIdx.y * kWave + 16 * w;
+    auto fetch = [&](int64_t tile, T (&v)[16]) {
+        const int64_t c = tile * kWave + lane;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = (tile < tiles && c < C && n0 + k < N) ? xs[(n0 + k) * C + c] : T(0);
+    };
+    T cur[16], nxt[16];
+    fetch(t0, cur);
+#pragma unroll 1
+    for (int i = 0; i < kPackTiles && t0 + i < tiles; ++i) {
+        fetch(t0 + i + 1 < t0 + kPackTiles ? t0 + i + 1 : tiles, nxt);
+        uint64_t mine = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const uint64_t wd = ballot64(spin_is_set(cur[k]));
+            if (lane == k) mine = wd;
+        }
+        if (lane < 16 && n0 + lane < N) packed[(t0 + i) * N + n0 + lane] = mine;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) cur[k] = nxt[k];
     }
-    if (n0 + lane < N) packed[tile * N + n0 + lane] = mine;
 }
 
 }  // namespace rls
@@ -1345,9 +1380,10 @@ int rls_mcpg_pack_chains(const void* xs, int spin_bytes, int64_t N, int64_t C, u
     if (C == 0) return RLS_OK;
     RLS_REQUIRE(xs && packed, RLS_EINVAL, "NULL pointer");
     RLS_REQUIRE(spin_bytes == 1 || spin_bytes == 4, RLS_EINVAL, "spin_bytes must be 1 or 4");
-    const dim3 grid((unsigned)ceil_div(N, kWave), (unsigned)ceil_div(C, kWave));
-    if (spin_bytes == 1) hipLaunchKernelGGL(k_mcpg_pack<uint8_t>, grid, dim3(kWave), 0, as_stream(stream), (const uint8_t*)xs, N, C, packed);
-    else hipLaunchKernelGGL(k_mcpg_pack<float>, grid, dim3(kWave), 0, as_stream(stream), (const float*)xs, N, C, packed);
+    RLS_REQUIRE(N < (1ll << 22), RLS_EUNSUPPORTED, "N=%lld: the pack grid walks 64-node blocks in grid.y", (long long)N);
+    const dim3 grid((unsigned)ceil_div(ceil_div(C, kWave), kPackTiles), (unsigned)ceil_div(N, kWave));   // x = run of chain tiles, y = 64-node block
+    if (spin_bytes == 1) hipLaunchKernelGGL(k_mcpg_pack<uint8_t>, grid, dim3(4 * kWave), 0, as_stream(stream), (const uint8_t*)xs, N, C, packed);
+    else hipLaunchKernelGGL(k_mcpg_pack<float>, grid, dim3(4 * kWave), 0, as_stream(stream), (const float*)xs, N, C, packed);
     return check_launch("k_mcpg_pack");
 }
 
@@ -1355,7 +1391,12 @@ int rls_mcpg_unpack_chains(const uint64_t* packed, int64_t N, int64_t C, float* 
     RLS_REQUIRE(N > 0 && C >= 0, RLS_EINVAL, "bad sizes");
     if (C == 0) return RLS_OK;
     RLS_REQUIRE(xs && packed, RLS_EINVAL, "NULL pointer");
-    hipLaunchKernelGGL(k_mcpg_unpack, dim3(grid_for(N * C, 256)), dim3(256), 0, as_stream(stream), packed, N, C, xs);
+    if (C % 4 == 0 && (reinterpret_cast<uintptr_t>(xs) & 15) == 0) {
+        const dim3 grid((unsigned)ceil_div(C / 4, 256), (unsigned)(N < 32768 ? N : 32768));
+        hipLaunchKernelGGL(k_mcpg_unpack<true>, grid, dim3(256), 0, as_stream(stream), packed, N, C, xs);
+    } else {
+        hipLaunchKernelGGL(k_mcpg_unpack<false>, dim3(grid_for(N * C, 256)), dim3(256), 0, as_stream(stream), packed, N, C, xs);
+    }
     return check_launch("k_mcpg_unpack");
 }
 

@@ -208,12 +208,22 @@ def metro_sampling_packed(probs: TEN, start: PackedChains, max_transfer_time: in
 
 def metro_sampling(probs: TEN, start_status: TEN, max_transfer_time: int, device=None,
                    index: Optional[TEN] = None, u: Optional[TEN] = None) -> TEN:
-    """MCPG.py:88-117 with the reference's surface (float32 [N, C] in and out, the caller's tensor untouched): the
-    node-major f32 kernel, whose 16 loader waves overlap the 2 x 4N bytes per chain of this surface with the walk
-    (routing it through pack -> packed walk -> unpack measured slower: 10.8 vs 6.9 ms at BA-10^4 / 2^18 chains).
-    The sync-free form of a sampling round is metro_sampling_packed.  Up to 5*T proposal rounds per chain, stopping
-    after the first round whose cumulative accept count reaches C*T -- evaluated on the device, where the reference
-    syncs once per round.  ``index``/``u`` ([>=5T, C]) replace the torch.randint / torch.rand draws (test hook)."""
+    """MCPG.py:88-117 with the reference's surface (float32 [N, C] in and out, the caller's tensor untouched): pack ->
+    the packed walk -> unpack while the tile plus the producers' window fit LDS (N <= 16 000; at BA-10^4 / 2^18 chains
+    the two surface conversions are 4.1 of the 5.3 ms), the node-major f32 kernel beyond that.  The sync-free form of a
+    sampling round is metro_sampling_packed.  Up to 5*T proposal rounds per chain, stopping after the first round whose
+    cumulative accept count reaches C*T -- evaluated on the device, where the reference syncs once per round.
+    ``index``/``u`` ([>=5T, C]) replace the torch.randint / torch.rand draws (test hook)."""
+    device = start_status.device if device is None else torch.device(device)
+    if start_status.shape[0] * 8 + 2 * 64 * 64 * 4 + 16 <= 160 * 1024:
+        start = start_status.to(device=device, dtype=torch.float32).contiguous()
+        return metro_sampling_packed(probs, PackedChains.pack(start), max_transfer_time, index=index, u=u).unpack()
+    return _metro_sampling_nodemajor(probs, start_status, max_transfer_time, device, index, u)
+
+
+def _metro_sampling_nodemajor(probs: TEN, start_status: TEN, max_transfer_time: int, device, index: Optional[TEN],
+                              u: Optional[TEN]) -> TEN:
+    """metro_sampling on the node-major f32 kernel (16 loader waves overlap the 2 x 4N bytes per chain with the walk)."""
     device = start_status.device if device is None else torch.device(device)
     start = start_status.to(device=device, dtype=torch.float32).contiguous()
     # the first chunk reads the caller's start state and writes the result buffer: no copy of the [N, C] state
@@ -306,10 +316,12 @@ def sampler_func(data, xs_sample: TEN, num_ls: int, total_mcmc_num: int, repeat_
         # production path: level-parallel kernel (the draws only ever decide ties, so it carries coins, not uniforms;
         # recorded draws become coins by the reference's own float32 expression); the f32 [N, C] input is read once,
         # everything after it is bit-packed, xs_good leaves as f32 [N, M]
-        out = PackedChains.empty(xs_sample.shape[0], xs_sample.shape[1], xs_sample.device)
+        # (packing first and running the 8-wave packed kernel beats letting the kernel's own loader read the f32 surface:
+        # 6.7 vs 8.5 ms at BA-10^4 / 2^18 chains)
+        packed = PackedChains.pack(xs_sample)
         coins = None if uniforms is None else tie_coins_from_uniforms(data, uniforms)
-        xs_loc, expected = mops.mcpg_local_search_levels(data.graph, xs_sample, data._lv_ptr, data._lv_data, num_ls,
-                                                         0 if uniforms is not None else _seed_from_torch(), coins=coins, out=out)
+        xs_loc, expected = mops.mcpg_local_search_levels(data.graph, packed, data._lv_ptr, data._lv_data, num_ls,
+                                                         0 if uniforms is not None else _seed_from_torch(), coins=coins, out=packed)
         _, vs_good, xs_good = mops.mcpg_pick_best(expected, xs_loc, total_mcmc_num, repeat_times, data.num_edges)
         return vs_good, xs_good.unpack(), expected - expected.mean()
     xs_loc, expected = mops.mcpg_local_search(data.graph, xs_sample, data._order_i32, num_ls, uniforms,
