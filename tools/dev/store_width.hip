@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
+#include <cstdlib>
 
 __global__ void k_dword(uint32_t* out, size_t n) {            // contiguous, 4 B per lane
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = (uint32_t)i;
@@ -28,8 +29,8 @@ __global__ __launch_bounds__(512) void k_rows256x4(uint32_t* out, int N) {
             *reinterpret_cast<uint4*>(base + (size_t)(e + (lane >> 4)) * N + g * 64 + (lane & 15) * 4) = make_uint4(e, lane, e, lane);
 }
 
-int main() {
-    const int N = 2000 / 64 * 64 + 64;   // 2048 columns
+int main(int argc, char** argv) {
+    const int N = argc > 1 ? atoi(argv[1]) : 2048;   // row length in dwords
     const int B = 65536;
     const size_t n = (size_t)B * N;
     uint32_t* d;
