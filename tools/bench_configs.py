@@ -164,7 +164,7 @@ def mcpg_suite(tag, n, m_ba, C, num_ls, iters):
     def ret(i):
         o = amcpg.get_return(pr, out, val)
         o.backward()
-    t = timeit(ret, iters, warm=1)
+    t = timeit(ret, max(iters, 20), warm=3)     # a handful of small torch ops around one kernel: host-paced, needs the repeats
     emit(tag, "get_return forward + backward from bit sums", "chains", C, t, n // 8, "bytes = the packed samples")
 
 
