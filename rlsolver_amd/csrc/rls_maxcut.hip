@@ -716,6 +716,48 @@ __global__ __launch_bounds__(256) void k_rand_spins(uint8_t* __restrict__ x, int
     }
 }
 
+// The same spins with ONE Philox call per 128 of them: a wave takes a row, lane l draws the row's l-th block of 128 spins,
+// parks its 16 bytes in LDS, and the wave then writes the row as 16-byte pieces (lane p of trip i = piece 64 i + p, whose
+// 16 bits sit in block p / 8) -- the per-piece kernel above recomputes the block's 10 Philox rounds for each of its 8
+// pieces, ~100 VALU per 16 bytes written, and is bound by that.
+__global__ __launch_bounds__(256) void k_rand_spins_rows(uint8_t* __restrict__ x, int64_t B, int64_t N, uint64_t seed, int64_t env_offset) {
+    __shared__ uint4 sh[4][kWave];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = threadIdx.x / kWave;
+    const int64_t chunks = N >> 4;                  // N % 16 == 0 here
+    const int64_t blocks = (chunks + 7) >> 3;       // 128-spin blocks per row
+    const Philox ph(seed);
+    for (int64_t b = (int64_t)blockIdx.x * 4 + w; b < B; b += (int64_t)gridDim.x * 4) {
+        const uint64_t gb = (uint64_t)(b + env_offset);
+        uint8_t* row = x + b * N;
+        for (int64_t g0 = 0; g0 < blocks; g0 += kWave) {
+            uint32_t r[4] = {0, 0, 0, 0};
+            if (g0 + lane < blocks) ph((uint32_t)gb, (uint32_t)(gb >> 32), (uint32_t)(g0 + lane), 0x5350494Eu, r);
+            if (g0 + lane == 0) r[0] &= ~1u;        // xs[:, 0] = 0, env_L2A.py:84
+            sh[w][lane] = make_uint4(r[0], r[1], r[2], r[3]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t* shw = reinterpret_cast<const uint32_t*>(sh[w]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int p = i * kWave + lane;
+                const int64_t ch = g0 * 8 + p;
+                if (ch < chunks) {
+                    const uint32_t bits = (shw[(p >> 3) * 4 + ((p & 7) >> 1)] >> ((p & 1) * 16)) & 0xffffu;
+                    uint4 v;
+                    v.x = ((bits & 0xFu) * 0x00204081u) & 0x01010101u;
+                    v.y = (((bits >> 4) & 0xFu) * 0x00204081u) & 0x01010101u;
+                    v.z = (((bits >> 8) & 0xFu) * 0x00204081u) & 0x01010101u;
+                    v.w = (((bits >> 12) & 0xFu) * 0x00204081u) & 0x01010101u;
+                    *reinterpret_cast<uint4*>(row + ch * 16) = v;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
 __global__ void k_rand_actions(int64_t* __restrict__ action, int64_t B, int64_t N, uint64_t seed, uint64_t step,
                                int64_t env_offset) {
     const Philox ph(seed);
@@ -1224,6 +1266,10 @@ int rls_rand_spins(uint8_t* x, int64_t B, int64_t N, uint64_t seed, int64_t env_
     if (B == 0) return RLS_OK;
     RLS_REQUIRE(x, RLS_EINVAL, "x is NULL");
     const bool vec16 = (N % 16 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0);
+    if (vec16 && N >= 512) {   // rows of at least four 128-spin blocks: one Philox call per block (a wave per row)
+        hipLaunchKernelGGL(k_rand_spins_rows, dim3(grid_for(B * kWave, 256)), dim3(256), 0, as_stream(stream), x, B, N, seed, env_offset);
+        return check_launch("k_rand_spins_rows");
+    }
     hipLaunchKernelGGL(vec16 ? k_rand_spins<true> : k_rand_spins<false>, dim3(grid_for(B * ((N + 15) >> 4), 256)),
                        dim3(256), 0, as_stream(stream), x, B, N, seed, env_offset);
     return check_launch("k_rand_spins");
