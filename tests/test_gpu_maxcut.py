@@ -305,3 +305,17 @@ def test_rand_spins_and_actions(B, N):
     a = ops.rand_actions(B, N, seed=99, step=5, device=DEV, env_offset=2)
     assert np.array_equal(a.cpu().numpy(), onp.rand_actions(B, N, 99, 5, 2))
     assert int(a.min()) >= 0 and int(a.max()) < N
+
+
+def test_rand_spins_is_one_sequence_whatever_kernel_writes_it():
+    """spin(b, n) = bit (n & 127) of Philox(seed; (b, n >> 7)) with node 0 := 0: independent of N, of the env offset
+    (rank invariance) and of the kernel that writes it (one Philox call per 128 spins for rows of >= 512 nodes, one per
+    16-byte piece below that, byte stores for rows that are not 16-byte multiples)."""
+    B = 300
+    big = ops.rand_spins(B, 2000, 99, DEV)                      # rows kernel
+    assert torch.equal(big[:, :496], ops.rand_spins(B, 496, 99, DEV))      # per-piece kernel
+    assert torch.equal(big[:, :1001], ops.rand_spins(B, 1001, 99, DEV))    # byte-store kernel
+    assert torch.equal(ops.rand_spins(B - 70, 2000, 99, DEV, env_offset=70), big[70:])
+    assert not bool(big[:, 0].any()) and 0.45 < float(big[:, 1:].float().mean()) < 0.55
+    wide = ops.rand_spins(5, 10000, 99, DEV)                    # two trips of 64 blocks per row
+    assert torch.equal(wide[:, :2000], big[:5])
