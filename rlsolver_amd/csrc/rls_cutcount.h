@@ -118,56 +118,6 @@ __device__ __forceinline__ int64_t tile_cut_count(const uint64_t* __restrict__ w
     return total;
 }
 
-// Same count with the edge list resident in LDS (persistent kernels): edges[] holds one dword per stored
-// edge, (8 u | 8 v << 16) = the LDS byte offsets of the two words, padded with (0, 0) self-pairs (XOR = 0)
-// to a multiple of 8 * 64 * W entries.  Wave w takes rounds w, w+W, ...
-// of 64 consecutive entries; no global memory on this path at all.
-template <int P>
-__device__ __forceinline__ int64_t tile_cut_count_lds(const uint64_t* __restrict__ words,
-                                                      const uint32_t* __restrict__ edges, int64_t Epad, int lane,
-                                                      int w, int W) {
-    HsState<P> st;
-#pragma unroll
-    for (int p = 0; p < HsState<P>::PL; ++p) st.c[p] = 0;
-    const unsigned char* wb = reinterpret_cast<const unsigned char*>(words);
-    const int64_t rounds = Epad / ((int64_t)kWave * W);        // per wave, a multiple of 8
-    auto fetch8 = [&](int64_t r0, uint64_t (&d)[8]) {
-        uint32_t p[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) p[k] = edges[((r0 + k) * W + w) * kWave + lane];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            d[k] = *reinterpret_cast<const uint64_t*>(wb + (p[k] & 0xFFFFu)) ^
-                   *reinterpret_cast<const uint64_t*>(wb + (p[k] >> 16));
-        }
-    };
-    int64_t r = 0;
-    for (; r + 16 <= rounds; r += 16) {
-        uint64_t dA[8], dB[8];
-        fetch8(r, dA);
-        fetch8(r + 8, dB);
-        hs_block16<P>(dA, dB, st);
-    }
-    if (r < rounds) {   // one group of 8 left
-        uint64_t dA[8];
-        fetch8(r, dA);
-        const uint64_t e8 = hs_eight<P>(dA, st);
-        uint64_t sixteens;
-        csa(sixteens, st.eights, st.eights, e8, 0ull);
-        hs_ripple16<P>(sixteens, st);
-    }
-    st.c[0] = st.ones; st.c[1] = st.twos; st.c[2] = st.fours; st.c[3] = st.eights;
-    const BitXpose xc = bit_xpose_consts(lane);
-    int64_t total = 0;
-#pragma unroll
-    for (int p = 0; p < HsState<P>::PL; ++p) {
-        uint32_t r0 = (uint32_t)st.c[p], r1 = (uint32_t)(st.c[p] >> 32);
-        bit_transpose64(r0, r1, xc);
-        total += (int64_t)(__builtin_popcount(r0) + __builtin_popcount(r1)) << p;
-    }
-    return total;
-}
-
 // Sum the per-wave partial counts of a W-wave workgroup through LDS (scratch: W*64 int64).
 // Every wave returns the full total for its lane's env.
 template <int W>

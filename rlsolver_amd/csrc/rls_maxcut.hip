@@ -57,65 +57,6 @@ __global__ __launch_bounds__(W * kWave) void k_maxcut_obj(const T* __restrict__ 
 #endif
 }
 
-// K1, wave-specialised and persistent: one workgroup per CU, edge list resident in LDS.
-// The plain kernel's count phase fetched 8 bytes of endpoint ids per edge through the same queues the
-// tile loads saturate (160 KB of ids per 128 KB tile for G22; a block of ids took ~2 us to arrive), and
-// load and count phases of a tile could only overlap with OTHER tiles on the CU.  Here
-//   * the stored edges sit in LDS as packed (u, v) dwords for the lifetime of the workgroup,
-//   * kPipeProd producer waves load + transpose tile k+1 into one LDS bit tile while
-//   * kPipeCons consumer waves count tile k out of the other (LDS + VALU only); one barrier per tile.
-// Needs 4 E' + 16 N + stages <= 160 KB (so 8 N < 2^16) and enough tiles per CU; otherwise the plain kernel runs.
-constexpr int kPipeProd = 8, kPipeCons = 8;
-constexpr int kPipeDepth = 4;                          // producer chunks in flight per wave
-constexpr int kPipeEdgePad = 8 * kWave * kPipeCons;    // edge padding granule
-constexpr int kPipeMinNodes = 1536;                    // shorter rows: the per-tile barrier + reduction outweigh the overlap (N = 1000: 74 vs 34 us)
-constexpr int kPipeMinTilesPerCu = 6;                  // below this the pipeline fill/drain (2 of n+1 steps) costs more than it saves
-
-template <int P>
-__global__ __launch_bounds__((kPipeProd + kPipeCons) * kWave) void k_maxcut_obj_pipe(
-    const uint8_t* __restrict__ x, int64_t B, int64_t N, const int32_t* __restrict__ eu,
-    const int32_t* __restrict__ ev, int64_t E, int64_t Epad, int halve, int64_t* __restrict__ obj) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint64_t* words0 = reinterpret_cast<uint64_t*>(smem);
-    uint64_t* words1 = words0 + N;
-    int64_t* scratch = reinterpret_cast<int64_t*>(words1 + N);                 // [2][kPipeCons * 64]
-    unsigned char* stages = reinterpret_cast<unsigned char*>(scratch + 2 * kPipeCons * kWave);
-    uint32_t* edges = reinterpret_cast<uint32_t*>(stages + kPipeProd * kStageBytes);
-    const int lane = threadIdx.x & (kWave - 1);
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
-    const bool producer = w < kPipeProd;
-    unsigned char* stage = stages + (producer ? w : 0) * kStageBytes;
-    const int64_t ntiles = (B + kWave - 1) / kWave;
-    int64_t t = blockIdx.x;
-    // (byte offset of words[u]) | (byte offset of words[v]) << 16 -- two bit tiles in LDS imply 8 N < 2^16
-    for (int64_t e = threadIdx.x; e < Epad; e += blockDim.x)
-        edges[e] = e < E ? (((uint32_t)eu[e] << 3) | ((uint32_t)ev[e] << 19)) : 0u;
-    if (producer && t < ntiles)
-        tile_load_bits<uint8_t, true, kPipeDepth>(x, B, N, t * kWave, words0, lane, w, kPipeProd, stage);
-    __syncthreads();
-    for (int k = 0; t < ntiles; t += gridDim.x, ++k) {
-        uint64_t* cur = (k & 1) ? words1 : words0;
-        uint64_t* nxt = (k & 1) ? words0 : words1;
-        int64_t* sc = scratch + (k & 1) * (kPipeCons * kWave);
-        if (producer) {
-            const int64_t tn = t + gridDim.x;
-            if (tn < ntiles)
-                tile_load_bits<uint8_t, true, kPipeDepth>(x, B, N, tn * kWave, nxt, lane, w, kPipeProd, stage);
-        } else {
-            const int cw = w - kPipeProd;
-            sc[cw * kWave + lane] = tile_cut_count_lds<P>(cur, edges, Epad, lane, cw, kPipeCons);
-        }
-        __syncthreads();
-        if (w == kPipeProd) {   // scratch is double-buffered: the other consumers may already be a tile ahead
-            int64_t total = 0;
-#pragma unroll
-            for (int c = 0; c < kPipeCons; ++c) total += sc[c * kWave + lane];
-            if (halve) total >>= 1;
-            if (t * kWave + lane < B) obj[t * kWave + lane] = total;
-        }
-    }
-}
-
 // K6: proposal = x ^ mask for 64 envs; accept the row when its cut is >= the incumbent.
 template <bool VEC, int P, int W>
 __global__ __launch_bounds__(W * kWave) void k_maxcut_propose_accept(uint8_t* __restrict__ x,
@@ -920,34 +861,6 @@ int rls_maxcut_obj(const rls_graph* g, const void* x, int spin_bytes, int64_t B,
     const dim3 grid((unsigned)ceil_div(B, kWave)), block(tw * kWave);
     hipStream_t s = as_stream(stream);
     const int halve = g->if_bidirectional ? 1 : 0;
-    {   // wave-specialised persistent variant: byte spins, aligned rows, two tiles + edges + stages fit in LDS
-        static const bool no_pipe = getenv("RLS_OBJ_NOPIPE") != nullptr;   // dev knob
-        const int64_t Epad = ceil_div(E, (int64_t)kPipeEdgePad) * kPipeEdgePad;
-        const size_t lds_p = (size_t)N * 16 + (size_t)2 * kPipeCons * kWave * 8 + (size_t)kPipeProd * kStageBytes +
-                             (size_t)Epad * 4;
-        if (!no_pipe && spin_bytes == 1 && vec && N >= kPipeMinNodes && N * 8 < 65536 && lds_p <= (size_t)kLdsBytes &&
-            ceil_div(B, kWave) >= (int64_t)kPipeMinTilesPerCu * num_cus()) {
-            int64_t gp = num_cus();
-            const int64_t ntiles = ceil_div(B, kWave);
-            if (gp > ntiles) gp = ntiles;
-            const dim3 gridp((unsigned)gp), blockp((kPipeProd + kPipeCons) * kWave);
-#define LAUNCH_PIPE(PP)                                                                                   \
-    do {                                                                                                      \
-        auto kern = k_maxcut_obj_pipe<PP>;                                                                    \
-        if (lds_p > 64 * 1024)                                                                                \
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p); \
-        hipLaunchKernelGGL(kern, gridp, blockp, lds_p, s, (const uint8_t*)x, B, N, g->eu, g->ev, E, Epad, halve, obj); \
-    } while (0)
-            switch (P) {
-                case 12: LAUNCH_PIPE(12); break;
-                case 16: LAUNCH_PIPE(16); break;
-                case 20: LAUNCH_PIPE(20); break;
-                default: LAUNCH_PIPE(24); break;
-            }
-#undef LAUNCH_PIPE
-            return check_launch("k_maxcut_obj_pipe");
-        }
-    }
 #define LAUNCH_OBJ(T, VEC, PP)                                                                             \
     do {                                                                                                   \
         auto kern = tw == kTileWavesMax ? k_maxcut_obj<T, VEC, PP, kTileWavesMax> : k_maxcut_obj<T, VEC, PP, kTileWaves>; \

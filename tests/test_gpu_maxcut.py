@@ -51,9 +51,9 @@ def test_obj_random_vs_oracle(n, m, B, bidir):
 
 @pytest.mark.parametrize("n,m,B,bidir", [(64, 300, 98304 + 37, 0), (2000, 19990, 98304 + 1, 0), (800, 4694, 131072, 1),
                                          (5008, 12000, 98304 + 64, 0)])
-def test_obj_large_batch_persistent_kernel(n, m, B, bidir):
-    """B >= 6 tiles per CU takes the wave-specialised persistent kernel (edges resident in LDS, producer /
-    consumer waves); n = 5008 does not fit two bit tiles + edges and stays on the plain one."""
+def test_obj_large_batch(n, m, B, bidir):
+    """Batches of 6 - 8 tiles per CU, ragged last tile included (the sizes at which round 1's persistent producer /
+    consumer variant used to take over; it was removed when the plain tile kernel overtook it)."""
     graph = gnm_arr(n, m, seed=n + m)
     g = device_graph(graph, n, bidir)
     xs = ops.rand_spins(B, n, 12345, DEV)

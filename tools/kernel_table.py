@@ -32,7 +32,6 @@ ROWS = [
     (r"k_maxcut_step<unsigned char, 8, 2, true", 256 // 8 * 64, 256, 2 * N14 + 20, "K4 maxcut_step emit u8 | G14 256 (launch-bound)"),
     (r"k_maxcut_obj<", T22 * 256, 65536, N22 + 8, "K1 maxcut_obj | G22 2^16"),
     (r"k_maxcut_obj<", T70 * 512, 131072, N70 + 8, "K1 maxcut_obj | G70 2^17"),
-    (r"k_maxcut_obj_pipe", None, 65536, N22 + 8, "K1 maxcut_obj (persistent) | G22 2^16"),
     (r"k_maxcut_propose_accept<", T22 * 256, 65536, 2 * N22 + 16, "K6 propose_accept | G22 2^16"),
     (r"k_maxcut_propose_accept<", T70 * 512, 131072, 2 * N70 + 16, "K6 propose_accept | G70 2^17"),
     (r"k_maxcut_greedy_sweep_levels<", T22 * 256, 65536, 2 * N22 + 16, "K5 greedy_sweep | G22 2^16 (on-chip bound)"),
