@@ -15,7 +15,7 @@ from rlsolver_amd.methods import MCPG as amcpg
 ap = argparse.ArgumentParser()
 ap.add_argument("--quick", action="store_true")
 ap.add_argument("--profile", action="store_true", help="few launches per kernel: for rocprofv3 passes (PMC serialises kernels)")
-ap.add_argument("--only", default="", help="comma list of suites: maxcut,ls,g70,g14,tsp,spin,qubo,mcpg")
+ap.add_argument("--only", default="", help="comma list of suites: maxcut,ls,g70,g14,tsp,isco,spin,qubo,mcpg")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 HBM = 8e12
@@ -181,6 +181,30 @@ def tsp_suite(tag, N, B, iters):
     emit(tag, "K13 tsp_swap_delta_all", "envs (N candidate moves each)", B, t, 8 * N + 8 * N + 13 * N)
 
 
+def isco_suite(iters):
+    """I1 / I2: one ISCO sampler step = one kernel (the reference: ~25-40 torch ops incl. two full sorts and an autograd
+    pass for MaxCut, a sort + searchsorted + [B, N, N-1] gather per round for TSP)."""
+    from rlsolver_amd.envs.env_ISCO import ISCO_TSP
+    from rlsolver_amd.envs.env_ISCO_maxcut import ISCO_maxcut
+    N, B, L = 100, 1 << 16, 8
+    dist, near, rnd = tsp_tables(generate_tsp_coords(N, 100), K=20)
+    params = {"num_nodes": N, "distance": torch.from_numpy(dist).to(dev), "nearest_indices": torch.from_numpy(near).to(dev),
+              "random_indices": torch.from_numpy(rnd).to(dev)}
+    env = ISCO_TSP(params, batch_size=B, K=20, device=dev)
+    x = env.random_gen_init_sample()
+    t = timeit(lambda i: env.step(x, L, 1.0), iters)
+    emit("TSP-100 uniform, B=2^16", f"I2 ISCO_TSP.step (path_length={L}: {L} rounds of opt_2 + softmax + Gumbel draw + swap, MH accept)",
+         "proposal rounds", B * L, t, None, "one kernel per step; tour, inverse and D in LDS")
+    n, m, Bm, Lm = 2000, 19990, 4096, 16
+    g = np.asarray(generate_gnm(n, m, 22), dtype=np.int64)
+    pm = {"num_nodes": n, "num_edges": m, "edge_from": torch.from_numpy(g[:, 0].copy()).to(dev), "edge_to": torch.from_numpy(g[:, 1].copy()).to(dev)}
+    envm = ISCO_maxcut(pm, batch_size=Bm, device=dev)
+    xm = envm.random_gen_init_sample()
+    t = timeit(lambda i: envm.step(xm, Lm, 1.0), iters)
+    emit("G22-sized G(2000,19990), 4096 samples", f"I1 ISCO_maxcut.step (path_length={Lm}: local distribution, Gumbel top-k, both path log-probs, MH accept)",
+         "sampler steps", Bm, t, 8 * n, "one kernel per step, wave per sample; bytes = the f32 sample in and out")
+
+
 def spin_suite(tag, n, m, B, T, iters):
     """S1: the S2V / ECO / PECO env step on a shared graph (resident O(deg) state; 6 rows x 4N bytes change per step
     under the ECO observables: time-since-flip read + write, four broadcast rows written)."""
@@ -247,6 +271,8 @@ if want("g14"):
     maxcut_suite("G14-sized G(800,4694), B=256", 800, 4694, 256, 14, it)
 if want("tsp"):
     tsp_suite("TSP-100 uniform, B=2^16", 100, 1 << 16, it)
+if want("isco"):
+    isco_suite(it)
 if want("spin"):
     spin_suite("G22-sized +-1 weighted, B=2^14", 2000, 19990, 1 << 14, 64, it)
     spin_suite("BA-200-sized (ECO), B=4096", 200, 784, 4096, 400, it)
