@@ -93,6 +93,7 @@ __device__ __forceinline__ float noreplacement_ll_sum(int count, float base, int
 // P = next power of two >= N.
 struct IscoMcArgs {
     const int32_t* rowptr; const int32_t* col;
+    const int32_t* ell_ptr; const int32_t* ell;          // lane-per-node slabs of the symmetric CSR (rls_graph_ell) or NULL
     const float* x; float* y_out; int64_t B, N;
     const int64_t* path_length; float temperature;
     const float* u_gumbel; const float* u_accept; uint64_t seed; int64_t env_offset;
@@ -104,18 +105,45 @@ struct IscoMcArgs {
 // gain_i = #same - #differing neighbours (the closed form of the reference's autograd, env_ISCO.py:51-63).
 // Returns cut(s) (every edge counted from both ends -> / 2).
 __device__ __forceinline__ int isco_local_dist(const uint8_t* s, float* lp, int64_t N, const int32_t* __restrict__ rowptr,
-                                               const int32_t* __restrict__ col, float temperature, int lane) {
+                                               const int32_t* __restrict__ col, const int32_t* __restrict__ ell_ptr,
+                                               const int32_t* __restrict__ ell, float temperature, int lane) {
     int differ = 0;
     float mx = -INFINITY;
-    for (int64_t i = lane; i < N; i += kWave) {
-        const int r0 = rowptr[i], r1 = rowptr[i + 1];
-        const uint8_t si = s[i];
-        int d = 0;
-        for (int j = r0; j < r1; ++j) d += (s[col[j]] != si);
-        differ += d;
-        const float sc = (float)((r1 - r0) - 2 * d) / (2.0f * temperature);
-        lp[i] = sc;
-        mx = fmaxf(mx, sc);
+    if (ell_ptr) {
+        // neighbour ids from the lane-per-node slabs: round k of the 64 nodes of a group is one coalesced load that does
+        // not depend on anything, eight rounds in flight -- walking col[rowptr[i] ..] per lane was a chain of ~deg L2 round
+        // trips per node (155 of the step's 207 us for one sample on a G22-sized graph)
+        for (int64_t g = 0; (g << 6) < N; ++g) {
+            const int64_t i = (g << 6) + lane;
+            const bool in = i < N;
+            const uint8_t si = in ? s[i] : 0;
+            const int e0 = ell_ptr[g], e1 = ell_ptr[g + 1];
+            int d = 0;
+            for (int k = e0; k < e1; k += 8 * kWave) {
+                int nb[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) nb[q] = (k + q * kWave < e1) ? ell[k + q * kWave + lane] : (int)(in ? i : 0);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) d += (s[nb[q]] != si);          // past a row's end the slab holds the node itself
+            }
+            if (in) {
+                differ += d;
+                const float sc = (float)((rowptr[i + 1] - rowptr[i]) - 2 * d) / (2.0f * temperature);
+                lp[i] = sc;
+                mx = fmaxf(mx, sc);
+            }
+        }
+    } else {
+        for (int64_t i = lane; i < N; i += kWave) {
+            const int r0 = rowptr[i], r1 = rowptr[i + 1];
+            const uint8_t si = s[i];
+            int d = 0;
+            for (int j = r0; j < r1; ++j) d += (s[col[j]] != si);
+            differ += d;
+            const float sc = (float)((r1 - r0) - 2 * d) / (2.0f * temperature);
+            lp[i] = sc;
+            mx = fmaxf(mx, sc);
+        }
     }
     mx = wave_max_f(mx);
     float se = 0.0f;
@@ -150,7 +178,7 @@ __global__ __launch_bounds__(256) void k_isco_maxcut_step(IscoMcArgs a) {
     for (int64_t i = lane; i < N; i += kWave) xb[i] = xr[i] > 0.0f ? 1 : 0;
     lds_fence();
     // ---- forward: ll_x, proposal distribution, Gumbel perturbation (env_ISCO.py:51-63, util.py:498-516)
-    const float ll_x = (float)isco_local_dist(xb, lp, N, a.rowptr, a.col, T, lane) / T;
+    const float ll_x = (float)isco_local_dist(xb, lp, N, a.rowptr, a.col, a.ell_ptr, a.ell, T, lane) / T;
     float lmax = -INFINITY;
     for (int64_t i = lane; i < N; i += kWave) {
         const float u = a.u_gumbel ? a.u_gumbel[b * N + i] : isco_unit(isco_draw(a.seed, genv, (uint32_t)i, 0, 1));
@@ -165,16 +193,36 @@ __global__ __launch_bounds__(256) void k_isco_maxcut_step(IscoMcArgs a) {
     L = L < 1 ? 1 : (L > N ? N : L);
     uint32_t prefix = 0;
     int want = (int)L;
-    for (int bit = 31; bit >= 0; --bit) {
-        const uint32_t hi_mask = bit == 31 ? 0u : (0xFFFFFFFFu << (bit + 1));
-        int cnt = 0;
-        for (int64_t i = lane; i < N; i += kWave) {
-            const uint32_t k = fkey(pert[i]);
-            cnt += ((k & hi_mask) == prefix) && ((k >> bit) & 1u);
+    if (N <= 32 * kWave) {
+        // the lane's <= 32 keys in registers for the 32 bit passes (re-reading them from LDS put an LDS round trip on
+        // every element of every pass); key 0 (out of range) has no bit set and is never counted
+        uint32_t kk[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const int64_t i = lane + (int64_t)j * kWave;
+            kk[j] = i < N ? fkey(pert[i]) : 0u;
         }
-        cnt = wave_sum_i32(cnt);
-        if (cnt >= want) prefix |= 1u << bit;                  // the L-th largest has this bit set
-        else want -= cnt;
+        for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t hi_mask = bit == 31 ? 0u : (0xFFFFFFFFu << (bit + 1));
+            int cnt = 0;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) cnt += ((kk[j] & hi_mask) == prefix) && ((kk[j] >> bit) & 1u);
+            cnt = wave_sum_i32(cnt);
+            if (cnt >= want) prefix |= 1u << bit;              // the L-th largest has this bit set
+            else want -= cnt;
+        }
+    } else {
+        for (int bit = 31; bit >= 0; --bit) {
+            const uint32_t hi_mask = bit == 31 ? 0u : (0xFFFFFFFFu << (bit + 1));
+            int cnt = 0;
+            for (int64_t i = lane; i < N; i += kWave) {
+                const uint32_t k = fkey(pert[i]);
+                cnt += ((k & hi_mask) == prefix) && ((k >> bit) & 1u);
+            }
+            cnt = wave_sum_i32(cnt);
+            if (cnt >= want) prefix |= 1u << bit;              // the L-th largest has this bit set
+            else want -= cnt;
+        }
     }
     // ---- selected set (perturbed >= threshold), compacted then sorted by perturbed value, descending
     int count = 0;
@@ -219,7 +267,7 @@ __global__ __launch_bounds__(256) void k_isco_maxcut_step(IscoMcArgs a) {
         for (int64_t i = lane; i < N; i += kWave) a.mask_out[b * N + i] = xb[i] ^ yb[i];
     }
     // ---- backward: ll_y and the probability of undoing the selection in reverse order (env_ISCO.py:65-77)
-    const float ll_y = (float)isco_local_dist(yb, lp, N, a.rowptr, a.col, T, lane) / T;
+    const float ll_y = (float)isco_local_dist(yb, lp, N, a.rowptr, a.col, a.ell_ptr, a.ell, T, lane) / T;
     float bmax = -INFINITY;
     for (int k = lane; k < count; k += kWave) bmax = fmaxf(bmax, lp[sidx[k]]);
     bmax = wave_max_f(bmax);
@@ -432,7 +480,8 @@ int rls_isco_maxcut_step(const rls_graph* g, const float* x, float* y_out, int64
     waves = waves > 4 ? 4 : waves;
     if (waves == 3) waves = 2;
     const size_t lds = per_wave * waves;
-    IscoMcArgs a{g->rowptr, g->col, x, y_out, B, N, path_length, temperature, u_gumbel, u_accept, seed, env_offset,
+    const bool use_ell = g->ell_sym_ptr && g->ell_sym && !g->wgt;
+    IscoMcArgs a{g->rowptr, g->col, use_ell ? g->ell_sym_ptr : nullptr, use_ell ? g->ell_sym : nullptr, x, y_out, B, N, path_length, temperature, u_gumbel, u_accept, seed, env_offset,
                  energy_out, acc_out, terms_out, mask_out, P};
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute((const void*)k_isco_maxcut_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
