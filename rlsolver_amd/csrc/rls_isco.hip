@@ -119,10 +119,19 @@ __device__ __forceinline__ int isco_local_dist(const uint8_t* s, float* lp, int6
             const uint8_t si = in ? s[i] : 0;
             const int e0 = ell_ptr[g], e1 = ell_ptr[g + 1];
             int d = 0;
+            const int self = (int)(in ? i : 0);
+            int nbn[8];                                                      // the next eight rounds, in flight while these are summed
+#pragma unroll
+            for (int q = 0; q < 8; ++q) nbn[q] = (e0 + q * kWave < e1) ? ell[e0 + q * kWave + lane] : self;
             for (int k = e0; k < e1; k += 8 * kWave) {
                 int nb[8];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) nb[q] = (k + q * kWave < e1) ? ell[k + q * kWave + lane] : (int)(in ? i : 0);
+                for (int q = 0; q < 8; ++q) nb[q] = nbn[q];
+                const int kn = k + 8 * kWave;
+                if (kn < e1) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) nbn[q] = (kn + q * kWave < e1) ? ell[kn + q * kWave + lane] : self;
+                }
 #pragma unroll
                 for (int q = 0; q < 8; ++q) d += (s[nb[q]] != si);          // past a row's end the slab holds the node itself
             }
