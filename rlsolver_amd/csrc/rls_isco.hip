@@ -113,11 +113,18 @@ __device__ __forceinline__ int isco_local_dist(const uint8_t* s, float* lp, int6
         // neighbour ids from the lane-per-node slabs: round k of the 64 nodes of a group is one coalesced load that does
         // not depend on anything, eight rounds in flight -- walking col[rowptr[i] ..] per lane was a chain of ~deg L2 round
         // trips per node (155 of the step's 207 us for one sample on a G22-sized graph)
-        for (int64_t g = 0; (g << 6) < N; ++g) {
+        const int64_t G = (N + 63) >> 6;
+        int ep0 = 0, ep1 = 0;                                                // slab offsets of 64 groups at a time, one per lane
+        for (int64_t g = 0; g < G; ++g) {
+            if ((g & 63) == 0) {
+                ep0 = ell_ptr[g + lane <= G ? g + lane : G];
+                ep1 = ell_ptr[g + lane + 1 <= G ? g + lane + 1 : G];
+            }
             const int64_t i = (g << 6) + lane;
             const bool in = i < N;
             const uint8_t si = in ? s[i] : 0;
-            const int e0 = ell_ptr[g], e1 = ell_ptr[g + 1];
+            const int e0 = __builtin_amdgcn_readlane(ep0, (int)(g & 63)), e1 = __builtin_amdgcn_readlane(ep1, (int)(g & 63));
+            const int deg = in ? rowptr[i + 1] - rowptr[i] : 0;             // requested before the rounds, used after them
             int d = 0;
             const int self = (int)(in ? i : 0);
             int nbn[8];                                                      // the next eight rounds, in flight while these are summed
@@ -137,7 +144,7 @@ __device__ __forceinline__ int isco_local_dist(const uint8_t* s, float* lp, int6
             }
             if (in) {
                 differ += d;
-                const float sc = (float)((rowptr[i + 1] - rowptr[i]) - 2 * d) / (2.0f * temperature);
+                const float sc = (float)(deg - 2 * d) / (2.0f * temperature);
                 lp[i] = sc;
                 mx = fmaxf(mx, sc);
             }
