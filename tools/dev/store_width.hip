@@ -29,6 +29,20 @@ __global__ __launch_bounds__(512) void k_rows256x4(uint32_t* out, int N) {
             *reinterpret_cast<uint4*>(base + (size_t)(e + (lane >> 4)) * N + g * 64 + (lane & 15) * 4) = make_uint4(e, lane, e, lane);
 }
 
+// a wave writes RUN contiguous KB (16 B per lane, 1 KB per instruction), then the next run somewhere else:
+// run r of wave w lives at ((r * nwaves + w) * RUN) KB  (S1 writes 8 KB rows this way)
+template <int RUN>
+__global__ __launch_bounds__(256) void k_runs(uint4* out, size_t n16) {
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    const size_t run16 = (size_t)RUN * 64;                       // 16-byte units per run
+    for (size_t r = wave; (r + 1) * run16 <= n16; r += nwaves) {
+        uint4* p = out + r * run16 + lane;
+#pragma unroll
+        for (int i = 0; i < RUN; ++i) p[i * 64] = make_uint4(i, lane, i, lane);
+    }
+}
+
 int main(int argc, char** argv) {
     const int N = argc > 1 ? atoi(argv[1]) : 2048;   // row length in dwords
     const int B = 65536;
@@ -47,6 +61,9 @@ int main(int argc, char** argv) {
     };
     run("contiguous dword", [&] { hipLaunchKernelGGL(k_dword, dim3(8192), dim3(256), 0, 0, d, n); });
     run("contiguous dwordx4", [&] { hipLaunchKernelGGL(k_dwordx4, dim3(8192), dim3(256), 0, 0, (uint4*)d, n / 4); });
+    run("runs of 1 KB per wave", [&] { hipLaunchKernelGGL(k_runs<1>, dim3(4096), dim3(256), 0, 0, (uint4*)d, n / 4); });
+    run("runs of 8 KB per wave", [&] { hipLaunchKernelGGL(k_runs<8>, dim3(4096), dim3(256), 0, 0, (uint4*)d, n / 4); });
+    run("runs of 32 KB per wave", [&] { hipLaunchKernelGGL(k_runs<32>, dim3(4096), dim3(256), 0, 0, (uint4*)d, n / 4); });
     run("64 rows x 256 B, dword", [&] { hipLaunchKernelGGL(k_rows256, dim3(B / 64), dim3(512), 0, 0, d, N); });
     run("4 rows x 256 B, dwordx4", [&] { hipLaunchKernelGGL(k_rows256x4, dim3(B / 64), dim3(512), 0, 0, d, N); });
     return 0;
