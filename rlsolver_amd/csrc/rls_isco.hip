@@ -304,6 +304,237 @@ __global__ __launch_bounds__(256) void k_isco_maxcut_step(IscoMcArgs a) {
     }
 }
 
+// The same step with a WORKGROUP per sample, for the few-chain regime the reference's own configs run in (one chain:
+// a lone wave is instruction-issue bound, ~155 us per step on a G22-sized graph).  The node loops are split over the
+// kIscoWgWaves waves; maxima / sums meet through LDS; the L-th largest perturbed value comes from four 8-bit histogram
+// passes (LDS atomics) instead of 32 one-bit passes; the <= L selected entries are sorted and their path
+// log-probabilities summed by wave 0 as before.  Same arithmetic per element; row sums are reduced wave by wave.
+constexpr int kIscoWgWaves = 16;
+
+struct IscoWgScratch { float f[kIscoWgWaves]; int i[kIscoWgWaves]; int hist[256]; int count; uint32_t prefix; int want; };
+
+__device__ __forceinline__ float isco_block_max(float v, IscoWgScratch* sc, int lane, int w) {
+    v = wave_max_f(v);
+    __syncthreads();
+    if (lane == 0) sc->f[w] = v;
+    __syncthreads();
+    float m = sc->f[0];
+#pragma unroll
+    for (int k = 1; k < kIscoWgWaves; ++k) m = fmaxf(m, sc->f[k]);
+    return m;
+}
+__device__ __forceinline__ float isco_block_sum(float v, IscoWgScratch* sc, int lane, int w) {
+    v = wave_sum_f32x(v);
+    __syncthreads();
+    if (lane == 0) sc->f[w] = v;
+    __syncthreads();
+    float m = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kIscoWgWaves; ++k) m += sc->f[k];
+    return m;
+}
+__device__ __forceinline__ int isco_block_sum_i(int v, IscoWgScratch* sc, int lane, int w) {
+    v = wave_sum_i32(v);
+    __syncthreads();
+    if (lane == 0) sc->i[w] = v;
+    __syncthreads();
+    int m = 0;
+#pragma unroll
+    for (int k = 0; k < kIscoWgWaves; ++k) m += sc->i[k];
+    return m;
+}
+
+// isco_local_dist over the whole workgroup: wave w takes the 64-node groups w, w + W, ...
+__device__ __forceinline__ int isco_local_dist_wg(const uint8_t* s, float* lp, int64_t N, const IscoMcArgs& a, float temperature,
+                                                  IscoWgScratch* sc, int lane, int w) {
+    int differ = 0;
+    float mx = -INFINITY;
+    const int64_t G = (N + 63) >> 6;
+    for (int64_t g = w; g < G; g += kIscoWgWaves) {
+        const int64_t i = (g << 6) + lane;
+        const bool in = i < N;
+        const uint8_t si = in ? s[i] : 0;
+        int d = 0;
+        const int deg = in ? a.rowptr[i + 1] - a.rowptr[i] : 0;
+        if (a.ell_ptr) {
+            const int e0 = a.ell_ptr[g], e1 = a.ell_ptr[g + 1];
+            const int self = (int)(in ? i : 0);
+            for (int k = e0; k < e1; k += 8 * kWave) {
+                int nb[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) nb[q] = (k + q * kWave < e1) ? a.ell[k + q * kWave + lane] : self;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) d += (s[nb[q]] != si);
+            }
+        } else if (in) {
+            for (int j = a.rowptr[i]; j < a.rowptr[i + 1]; ++j) d += (s[a.col[j]] != si);
+        }
+        if (in) {
+            differ += d;
+            const float v = (float)(deg - 2 * d) / (2.0f * temperature);
+            lp[i] = v;
+            mx = fmaxf(mx, v);
+        }
+    }
+    mx = isco_block_max(mx, sc, lane, w);
+    float se = 0.0f;
+    for (int64_t g = w; g < G; g += kIscoWgWaves) {
+        const int64_t i = (g << 6) + lane;
+        if (i < N) se += expf(lp[i] - mx);
+    }
+    const float lse = logf(isco_block_sum(se, sc, lane, w));
+    for (int64_t g = w; g < G; g += kIscoWgWaves) {
+        const int64_t i = (g << 6) + lane;
+        if (i < N) lp[i] = (lp[i] - mx) - lse;
+    }
+    const int tot = isco_block_sum_i(differ, sc, lane, w);        // (its barriers also publish lp[])
+    return tot >> 1;
+}
+
+__global__ __launch_bounds__(kIscoWgWaves * kWave) void k_isco_maxcut_step_wg(IscoMcArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    const int tid = threadIdx.x, NT = kIscoWgWaves * kWave;
+    const int64_t b = blockIdx.x;
+    const int64_t N = a.N;
+    const int P = a.P;
+    const size_t nb8 = ((size_t)N + 7) & ~(size_t)7;
+    uint8_t* xb = smem;
+    uint8_t* yb = smem + nb8;
+    float* lp = reinterpret_cast<float*>(smem + 2 * nb8);
+    float* pert = lp + N;
+    float* skey = pert + N;
+    int32_t* sidx = reinterpret_cast<int32_t*>(skey + P);
+    IscoWgScratch* sc = reinterpret_cast<IscoWgScratch*>(sidx + P);
+    const float* xr = a.x + b * N;
+    const float T = a.temperature;
+    const uint64_t genv = (uint64_t)(b + a.env_offset);
+
+    for (int64_t i = tid; i < N; i += NT) xb[i] = xr[i] > 0.0f ? 1 : 0;
+    __syncthreads();
+    // ---- forward: ll_x, proposal distribution, Gumbel perturbation
+    const float ll_x = (float)isco_local_dist_wg(xb, lp, N, a, T, sc, lane, w) / T;
+    float lmax = -INFINITY;
+    for (int64_t i = tid; i < N; i += NT) {
+        const float u = a.u_gumbel ? a.u_gumbel[b * N + i] : isco_unit(isco_draw(a.seed, genv, (uint32_t)i, 0, 1));
+        const float l = lp[i];
+        pert[i] = l - logf(-logf(u));
+        lmax = fmaxf(lmax, l);
+    }
+    lmax = isco_block_max(lmax, sc, lane, w);                  // ll_base of the forward renormalisation (also publishes pert[])
+    // ---- threshold = L-th largest perturbed value: radix select, 8 bits per pass
+    int64_t L = a.path_length[b];
+    L = L < 1 ? 1 : (L > N ? N : L);
+    uint32_t prefix = 0;
+    int want = (int)L;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        const uint32_t hi_mask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
+        for (int k = tid; k < 256; k += NT) sc->hist[k] = 0;
+        __syncthreads();
+        for (int64_t i = tid; i < N; i += NT) {
+            const uint32_t k = fkey(pert[i]);
+            if ((k & hi_mask) == prefix) atomicAdd(&sc->hist[(k >> shift) & 255u], 1);
+        }
+        __syncthreads();
+        if (w == 0) {   // the largest byte value v whose suffix count (entries with byte >= v) reaches `want`
+            int c[4], tot = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { c[q] = sc->hist[lane * 4 + q]; tot += c[q]; }
+            int suf = tot;                                        // inclusive suffix sum over lanes: lanes >= this one
+#pragma unroll
+            for (int d = 1; d < kWave; d <<= 1) {
+                const int o = __shfl_down(suf, d, 64);
+                if (lane + d < kWave) suf += o;
+            }
+            const int above = suf - tot;                          // entries in bins of higher lanes
+            // inside this lane's four bins, from the top
+            int byte_found = -1, want_left = 0, run = above;
+#pragma unroll
+            for (int q = 3; q >= 0; --q) {
+                if (byte_found < 0 && run < want && run + c[q] >= want) { byte_found = lane * 4 + q; want_left = want - run; }
+                run += c[q];
+            }
+            const uint64_t m = ballot64(byte_found >= 0);
+            if (byte_found >= 0) { sc->prefix = prefix | ((uint32_t)byte_found << shift); sc->want = want_left; }
+            (void)m;
+        }
+        __syncthreads();
+        prefix = sc->prefix;
+        want = sc->want;
+    }
+    // ---- selected set (perturbed >= threshold), compacted (any order: sorted next)
+    if (tid == 0) sc->count = 0;
+    __syncthreads();
+    for (int64_t i = tid; i < N; i += NT) {
+        if (fkey(pert[i]) >= prefix) {
+            const int at = atomicAdd(&sc->count, 1);
+            skey[at] = pert[i];
+            sidx[at] = (int)i;
+        }
+    }
+    __syncthreads();
+    const int count = sc->count;
+    float ll_x2y = 0.0f;
+    if (w == 0) {
+        int P2 = 1;
+        while (P2 < count) P2 <<= 1;
+        for (int k = count + lane; k < P2; k += kWave) { skey[k] = -INFINITY; sidx[k] = -1; }
+        lds_fence();
+        for (int size = 2; size <= P2; size <<= 1) {
+            for (int stride = size >> 1; stride >= 1; stride >>= 1) {
+                for (int t = lane; t < (P2 >> 1); t += kWave) {
+                    const int lo = ((t / stride) * (stride << 1)) + (t % stride);
+                    const int hi = lo + stride;
+                    const bool desc = ((lo & size) == 0);
+                    const float k0 = skey[lo], k1 = skey[hi];
+                    // equal keys: order by node id, so that the result does not depend on the compaction order
+                    const int i0 = sidx[lo], i1 = sidx[hi];
+                    const bool lt = (k0 < k1) || (k0 == k1 && i0 > i1);
+                    if (lt == desc) {
+                        skey[lo] = k1; skey[hi] = k0;
+                        sidx[lo] = i1; sidx[hi] = i0;
+                    }
+                }
+                lds_fence();
+            }
+        }
+        ll_x2y = noreplacement_ll_sum(count, lmax, lane, [&](int k) { return lp[sidx[k]]; });
+    }
+    // ---- y = x with the selected nodes flipped
+    for (int64_t i = tid; i < N; i += NT) yb[i] = xb[i];
+    __syncthreads();
+    for (int k = tid; k < count; k += NT) yb[sidx[k]] ^= 1;
+    __syncthreads();
+    if (a.mask_out) {
+        for (int64_t i = tid; i < N; i += NT) a.mask_out[b * N + i] = xb[i] ^ yb[i];
+    }
+    // ---- backward
+    const float ll_y = (float)isco_local_dist_wg(yb, lp, N, a, T, sc, lane, w) / T;
+    if (w == 0) {
+        float bmax = -INFINITY;
+        for (int k = lane; k < count; k += kWave) bmax = fmaxf(bmax, lp[sidx[k]]);
+        bmax = wave_max_f(bmax);
+        const float ll_y2x = noreplacement_ll_sum(count, bmax, lane, [&](int k) { return lp[sidx[count - 1 - k]]; });
+        const float log_acc = fminf(((ll_y + ll_y2x) - ll_x) - ll_x2y, 0.0f);
+        const float ua = a.u_accept ? a.u_accept[b] : isco_unit(isco_draw(a.seed, genv, 0xFFFFFFFFu, 0, 2));
+        const bool accept = logf(ua + 1e-24f) < log_acc;
+        if (lane == 0) {
+            sc->want = accept ? 1 : 0;
+            if (a.energy_out) a.energy_out[b] = ll_y * T;
+            if (a.acc_out) a.acc_out[b] = expf(log_acc);
+            if (a.terms_out) {
+                float* t = a.terms_out + b * 5;
+                t[0] = ll_x; t[1] = ll_x2y; t[2] = ll_y; t[3] = ll_y2x; t[4] = log_acc;
+            }
+        }
+    }
+    __syncthreads();
+    const bool accept = sc->want != 0;
+    float* yo = a.y_out + b * N;
+    for (int64_t i = tid; i < N; i += NT) yo[i] = (float)(accept ? yb[i] : xb[i]);
+}
+
 // ----------------------------------------------------------------------------------------------- TSP
 struct IscoTspArgs {
     const float* dist; int64_t N; int32_t K; int32_t random_stride; float near_threshold;
@@ -497,6 +728,17 @@ int rls_isco_maxcut_step(const rls_graph* g, const float* x, float* y_out, int64
     if (waves == 3) waves = 2;
     const size_t lds = per_wave * waves;
     const bool use_ell = g->ell_sym_ptr && g->ell_sym && !g->wgt;
+    // few chains (the reference's configs run one): a workgroup per sample; from ~4 samples per CU on the wave-per-sample
+    // kernel has the throughput
+    const size_t lds_wg = per_wave + sizeof(IscoWgScratch) + 16;
+    if (B <= (int64_t)2 * num_cus() && N >= 4 * kWave && lds_wg <= (size_t)kLdsBytes) {
+        IscoMcArgs aw{g->rowptr, g->col, use_ell ? g->ell_sym_ptr : nullptr, use_ell ? g->ell_sym : nullptr, x, y_out, B, N,
+                      path_length, temperature, u_gumbel, u_accept, seed, env_offset, energy_out, acc_out, terms_out, mask_out, P};
+        if (lds_wg > 64 * 1024)
+            (void)hipFuncSetAttribute((const void*)k_isco_maxcut_step_wg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wg);
+        hipLaunchKernelGGL(k_isco_maxcut_step_wg, dim3((unsigned)B), dim3(kIscoWgWaves * kWave), lds_wg, as_stream(stream), aw);
+        return check_launch("k_isco_maxcut_step_wg");
+    }
     IscoMcArgs a{g->rowptr, g->col, use_ell ? g->ell_sym_ptr : nullptr, use_ell ? g->ell_sym : nullptr, x, y_out, B, N, path_length, temperature, u_gumbel, u_accept, seed, env_offset,
                  energy_out, acc_out, terms_out, mask_out, P};
     if (lds > 64 * 1024)

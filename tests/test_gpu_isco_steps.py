@@ -58,7 +58,8 @@ def test_isco_maxcut_step_golden(golden, gname):
 
 @pytest.mark.parametrize("n,m,B", [(2000, 19990, 40), (333, 1500, 70), (64, 200, 5)])
 def test_isco_maxcut_step_vs_oracle(n, m, B):
-    """G22-sized graph, rows that are no multiple of the wave, path lengths from 1 to N / 2."""
+    """G22-sized graph, rows that are no multiple of the wave, path lengths from 1 to N / 2.  Up to two samples per CU
+    (and rows of >= 256 nodes) run the workgroup-per-sample kernel, the others the wave-per-sample one."""
     from rlsolver_amd.graph import generate_gnm
     g = np.asarray(generate_gnm(n, m, 9), dtype=np.int64)
     s = _maxcut_sampler(g, n, B)
@@ -86,6 +87,28 @@ def test_isco_maxcut_step_vs_oracle(n, m, B):
     for it in range(30):
         xs2, _, _ = s.step(xs2, torch.full((B,), 4, dtype=torch.int64, device=DEV), 0.5)
     assert torch.equal(xs, xs2)
+
+
+def test_isco_maxcut_both_kernels_agree():
+    """Up to two samples per CU a workgroup works on each sample, beyond that a wave: with the same recorded draws the
+    two kernels select the same nodes, propose and accept the same samples, and their log-probabilities agree to the
+    last few ulps of their magnitude (row sums are reduced in a different order)."""
+    from rlsolver_amd.graph import generate_gnm
+    n, m, B, Bs = 500, 3000, 600, 64
+    g = np.asarray(generate_gnm(n, m, 9), dtype=np.int64)
+    big, small = _maxcut_sampler(g, n, B), _maxcut_sampler(g, n, Bs)
+    rng = np.random.RandomState(5)
+    x = torch.from_numpy(rng.randint(0, 2, size=(B, n)).astype(np.float32)).to(DEV)
+    pl = torch.from_numpy(rng.randint(1, 40, size=B).astype(np.int64)).to(DEV)
+    draws = {"u_gumbel": torch.from_numpy(rng.rand(B, n).astype(np.float32).clip(1e-7, 1 - 1e-7)), "u_accept": torch.from_numpy(rng.rand(B).astype(np.float32))}
+    yb, eb, ab, tb, mb = big.step(x, pl, 0.7, draws=draws, want_terms=True)                         # wave per sample
+    ds = {k: v[:Bs] for k, v in draws.items()}
+    ys, es, as_, ts, ms = small.step(x[:Bs].contiguous(), pl[:Bs].contiguous(), 0.7, draws=ds, want_terms=True)   # workgroup per sample
+    assert torch.equal(mb[:Bs], ms)
+    scale = tb[:Bs, :4].abs().max(dim=1, keepdim=True).values
+    assert bool(((tb[:Bs] - ts).abs() <= 4e-7 * scale + 1e-6).all())
+    sure = (tb[:Bs, 4] - torch.log(ds["u_accept"].to(DEV) + 1e-24)).abs() > 1e-2       # accept decisions away from the margin
+    assert torch.equal(yb[:Bs][sure], ys[sure]) and int(sure.sum()) > Bs // 2
 
 
 def _tsp_sampler(z, p, B):
