@@ -293,6 +293,13 @@ int rls_spin_step(const rls_graph* g, const rls_spin_env* env, int state_bytes, 
                   double time_inc, double termination_value, int32_t reward_mode, double reward_div, int64_t hist_len,
                   int32_t use_stag, double stag_punishment, int32_t use_basin, double basin_reward, void* stream);
 
+/* get_observation()  ECO_S2V/src/envs/spinsystem_PECO.py:455 (cat(state, matrix.expand(B, N, N))) and spinsystem.py:484-495
+ * (vstack(state, matrix)): out T [B, num_rows + N, N] = the num_rows observable rows of state T [B, num_rows, N], row 0
+ * mapped from signed spins to (1 - s) / 2 when binary_basis (SpinBasis.BINARY), followed by the N rows of the shared
+ * matrix T [N, N]; matrix NULL: out = [B, num_rows, N] (the rows only).  One streaming pass, nothing else touched. */
+int rls_spin_observation(const void* state, const void* matrix, int state_bytes, int64_t B, int32_t num_rows, int64_t N,
+                         int32_t binary_basis, void* out, void* stream);
+
 /* -------------------------------------------------------------------- MCPG */
 /* Layouts of a batch of C chains:
  *   spin_bytes = 4 | 1   node-major x[N, C] as in the reference (chains are the fast axis): float32 0.0|1.0 (what

@@ -300,6 +300,35 @@ __global__ __launch_bounds__(256) void k_spin_reset(rls_spin_env env, int64_t B,
     }
 }
 
+// get_observation (spinsystem_PECO.py:455 / spinsystem.py:484-495): out[b] = rows of state[b] (row 0 mapped from signed to
+// {0, 1} spins under SpinBasis.BINARY: (1 - s) / 2) followed by the N rows of the shared matrix.  One streaming pass:
+// the reference clones the state, rewrites row 0 and concatenates a [B, N, N] expansion of the matrix.
+template <typename T, bool V4>
+__global__ __launch_bounds__(256) void k_spin_observation(const T* __restrict__ state, const T* __restrict__ matrix, int64_t B,
+                                                           int R, int64_t N, int binary, T* __restrict__ out) {
+    constexpr int PER = V4 ? (int)(16 / sizeof(T)) : 1;
+    const int64_t rows = R + (matrix ? N : 0), per_row = N / PER, per_env = rows * per_row;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= per_env) return;
+    const int64_t rr = idx / per_row, c = (idx - rr * per_row) * PER;
+    using V = typename RowVec<T>::type;
+    for (int64_t b = blockIdx.y; b < B; b += gridDim.y) {
+        const T* src = rr < R ? state + (b * R + rr) * N + c : matrix + (rr - R) * N + c;
+        T* dst = out + (b * rows + rr) * N + c;
+        if constexpr (V4) {
+            V v = *reinterpret_cast<const V*>(src);
+            if (binary && rr == 0) {
+#pragma unroll
+                for (int q = 0; q < PER; ++q) v[q] = ((T)1 - v[q]) / (T)2;
+            }
+            *reinterpret_cast<V*>(dst) = v;
+        } else {
+            const T v = src[0];
+            dst[0] = (binary && rr == 0) ? ((T)1 - v) / (T)2 : v;
+        }
+    }
+}
+
 }  // namespace rls
 
 using namespace rls;
@@ -367,6 +396,28 @@ int rls_spin_step(const rls_graph* g, const rls_spin_env* env, int state_bytes, 
     else                  { if (vec) LAUNCH_SPIN(double, true); else LAUNCH_SPIN(double, false); }
 #undef LAUNCH_SPIN
     return check_launch("k_spin_step");
+}
+
+int rls_spin_observation(const void* state, const void* matrix, int state_bytes, int64_t B, int32_t num_rows, int64_t N,
+                         int32_t binary_basis, void* out, void* stream) {
+    RLS_REQUIRE(B >= 0 && num_rows >= 1 && N > 0, RLS_EINVAL, "bad sizes B=%lld R=%d N=%lld", (long long)B, num_rows, (long long)N);
+    RLS_REQUIRE(state_bytes == 4 || state_bytes == 8, RLS_EINVAL, "state_bytes must be 4 (f32) or 8 (f64)");
+    if (B == 0) return RLS_OK;
+    RLS_REQUIRE(state && out, RLS_EINVAL, "state / out is NULL");
+    const int per = 16 / state_bytes;
+    const bool v4 = (N % per) == 0 && ((((uintptr_t)state) | ((uintptr_t)out) | ((uintptr_t)matrix)) & 15) == 0;
+    const int64_t rows = num_rows + (matrix ? N : 0);
+    const int64_t per_env = rows * (v4 ? N / per : N);
+    RLS_REQUIRE(per_env < (1ll << 31) * 256, RLS_EUNSUPPORTED, "observation of %lld elements per env", (long long)(rows * N));
+    const dim3 grid((unsigned)ceil_div(per_env, 256), (unsigned)(B < 16384 ? B : 16384)), block(256);
+    hipStream_t s = as_stream(stream);
+#define LAUNCH_OBS(T, V4)                                                                                                     \
+    hipLaunchKernelGGL((k_spin_observation<T, V4>), grid, block, 0, s, (const T*)state, (const T*)matrix, B, (int)num_rows, N,  \
+                       (int)binary_basis, (T*)out)
+    if (state_bytes == 4) { if (v4) LAUNCH_OBS(float, true); else LAUNCH_OBS(float, false); }
+    else                  { if (v4) LAUNCH_OBS(double, true); else LAUNCH_OBS(double, false); }
+#undef LAUNCH_OBS
+    return check_launch("k_spin_observation");
 }
 
 }  // extern "C"

@@ -188,6 +188,17 @@ void spin_reset(int64_t g, int64_t env, const Tensor& state, const Tensor& row_i
     ok(rls_spin_reset(G(g), reinterpret_cast<const rls_spin_env*>(env), sb, state.size(0), (int32_t)state.size(1), (const int32_t*)p(row_index),
                       max_local, weight_sum, cur_stream(state)), "rls_spin_reset");
 }
+void spin_observation(const Tensor& state, const OptTensor& matrix, bool binary_basis, Tensor out) {
+    dev(state, "state");
+    dev(out, "out", state.scalar_type());
+    optdev(matrix, "matrix", state.scalar_type());
+    TORCH_CHECK(state.dim() == 3 && out.dim() == 3, "state must be [B, R, N], out [B, R (+ N), N]");
+    const int64_t B = state.size(0), R = state.size(1), N = state.size(2);
+    TORCH_CHECK(out.size(0) == B && out.size(2) == N && out.size(1) == R + (matrix.has_value() ? N : 0), "out has the wrong shape");
+    if (matrix.has_value()) TORCH_CHECK(matrix->dim() == 2 && matrix->size(0) == N && matrix->size(1) == N, "matrix must be [N, N]");
+    const int sb = state.scalar_type() == F64 ? 8 : 4;
+    ok(rls_spin_observation(p(state), p(matrix), sb, B, (int32_t)R, N, binary_basis, p(out), cur_stream(state)), "rls_spin_observation");
+}
 void spin_step(int64_t g, int64_t env, const Tensor& state, const Tensor& row_index, const Tensor& action, Tensor reward,
                const OptTensor& visited_new, double max_local, double time_inc, double termination_value, int64_t reward_mode,
                double reward_div, int64_t hist_len, bool use_stag, double stag_punishment, bool use_basin, double basin_reward) {
@@ -411,6 +422,7 @@ TORCH_LIBRARY(rlsolver_hip, m) {
     m.def("rand_actions(Tensor(a!) action, int N, int seed, int step, int env_offset) -> ()");
     m.def("rand_perms(Tensor(a!) perm, int seed, int env_offset) -> ()");
     m.def("spin_reset(int graph, int env, Tensor(a!) state, Tensor row_index, float max_local, int weight_sum) -> ()");
+    m.def("spin_observation(Tensor state, Tensor? matrix, bool binary_basis, Tensor(a!) out) -> ()");
     m.def("spin_step(int graph, int env, Tensor(a!) state, Tensor row_index, Tensor action, Tensor(b!) reward, Tensor(c!)? visited_new, "
           "float max_local, float time_inc, float termination_value, int reward_mode, float reward_div, int hist_len, bool use_stag, "
           "float stag_punishment, bool use_basin, float basin_reward) -> ()");
@@ -460,6 +472,7 @@ TORCH_LIBRARY_IMPL(rlsolver_hip, CUDA, m) {   // "CUDA" is the HIP dispatch key 
     m.impl("rand_actions", &rand_actions);
     m.impl("rand_perms", &rand_perms);
     m.impl("spin_reset", &spin_reset);
+    m.impl("spin_observation", &spin_observation);
     m.impl("spin_step", &spin_step);
     m.impl("mcpg_metro_rounds", &mcpg_metro_rounds);
     m.impl("mcpg_local_search", &mcpg_local_search);

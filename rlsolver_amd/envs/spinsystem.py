@@ -224,13 +224,21 @@ class SpinSystem:
         done = torch.full((B,), self.current_step == self.max_steps, dtype=torch.bool, device=self.device)
         return self.get_observation(), rew, done
 
-    def get_observation(self):
-        state = self.state.clone()
-        if self.spin_basis == SpinBasis.BINARY:
-            state[:, 0, :] = (1 - state[:, 0, :]) / 2
-        if not self.include_adjacency:
-            return state
-        return torch.cat((state, self.matrix.unsqueeze(0).expand(state.shape[0], -1, -1)), dim=-2)
+    def get_observation(self, out=None):
+        """spinsystem_PECO.py:455: the observable rows (row 0 in the spin basis the agent sees) followed, with
+        ``include_adjacency``, by the N rows of the shared matrix -- [B, R (+ N), N], ONE streaming kernel
+        (rls_spin_observation; the reference clones the state, rewrites row 0 and concatenates a [B, N, N] expansion).
+        ``out``: a caller-owned buffer of that shape to write into (a rollout ring), else a fresh tensor."""
+        B, R, N = self.state.shape
+        rows = R + (N if self.include_adjacency else 0)
+        if out is None:
+            out = torch.empty((B, rows, N), dtype=self.dtype, device=self.device)
+        elif out.shape != (B, rows, N) or out.dtype != self.dtype or not out.is_contiguous():
+            raise ValueError(f"out must be a contiguous {self.dtype} tensor of shape {(B, rows, N)}")
+        _abi.call("rls_spin_observation", _ptr(self.state), _ptr(self.matrix if self.include_adjacency else None),
+                  8 if self.dtype == torch.float64 else 4, B, R, N, int(self.spin_basis == SpinBasis.BINARY), _ptr(out),
+                  _stream(self.device))
+        return out
 
     def get_immeditate_rewards_avaialable(self, spins=None):
         return self._delta.to(self.dtype)

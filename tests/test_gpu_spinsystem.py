@@ -147,3 +147,33 @@ def test_spin_step_rejects_out_of_range_action():
     _, r, _ = env.step(torch.tensor([3, 40, -1, 7], device=DEV))
     assert torch.isnan(r[1]) and torch.isnan(r[2]) and not torch.isnan(r[0]) and not torch.isnan(r[3])
     assert torch.equal(env.state[1:3], before[1:3]) and not torch.equal(env.state[0], before[0])
+
+
+@pytest.mark.parametrize("n,dtype,basis_binary,adj", [(200, torch.float32, True, True), (37, torch.float32, False, True),
+                                                       (64, torch.float64, True, True), (101, torch.float64, True, False),
+                                                       (128, torch.float32, True, False)])
+def test_observation_kernel_equals_the_reference_expression(n, dtype, basis_binary, adj):
+    """get_observation = cat(state with row 0 mapped to the agent's spin basis, matrix.expand(B, N, N))
+    (spinsystem_PECO.py:455) as one kernel: every element equal, for rows that are and are not multiples of 16 bytes,
+    both dtypes, with and without the adjacency rows, into a fresh tensor and into a caller's buffer."""
+    from rlsolver_amd.envs.spinsystem import ECO_PECO_OBSERVABLES, RewardSignal, SpinBasis, SpinSystem
+    from rlsolver_amd.graph import generate_gnm
+    rng = np.random.RandomState(n)
+    mg = [(u, v, int(rng.choice([-1, 1]))) for u, v, _ in generate_gnm(n, 3 * n, 5)]
+    B = 9
+    env = SpinSystem(mg, n, B, max_steps=50, observables=ECO_PECO_OBSERVABLES, reward_signal=RewardSignal.BLS, norm_rewards=True,
+                     spin_basis=SpinBasis.BINARY if basis_binary else SpinBasis.SIGNED, device=DEV, include_adjacency=adj,
+                     dtype=dtype)
+    env.reset()
+    for t in range(3):
+        obs, _, _ = env.step(torch.from_numpy(rng.randint(0, n, size=B)).to(DEV))
+    want = env.state.clone()
+    if basis_binary:
+        want[:, 0, :] = (1 - want[:, 0, :]) / 2
+    if adj:
+        want = torch.cat((want, env.matrix.unsqueeze(0).expand(B, -1, -1)), dim=-2)
+    assert obs.dtype == dtype and torch.equal(obs, want)
+    buf = torch.full_like(want, 7.0)
+    assert env.get_observation(out=buf) is buf and torch.equal(buf, want)
+    with pytest.raises(ValueError):
+        env.get_observation(out=buf[:, :-1].contiguous())
