@@ -474,6 +474,18 @@ int rls_tsp_apply_swap(int64_t* perm, int64_t B, int64_t N, const int64_t* pos,
 int rls_tsp_2opt_delta(const float* dist, int64_t N, const int64_t* perm, int64_t B,
                        const int64_t* i, const int64_t* j, float* delta, void* stream);
 
+/* One pass of local_search_2_opt  methods_problem_specific/TSP/opt_2.py:27-57: over all reversals [i..j], 0 <= i < j <= N-1,
+ * of the closed tour perm[b] (evaluated against that same tour, as the reference restores its seed after every candidate)
+ * the best one, the first in (i, j) order among equals.  dist float64 [N, N].
+ *   cur_length != NULL (float64 [B], the length the reference holds for the seed): candidates are compared by their WHOLE
+ *     length summed the way distance_calc does (float64, edge after edge) -- the reference's own comparison values, so
+ *     reversals that tie in exact arithmetic rank as they do there.  best_value[b] = that length (< cur_length[b]) and
+ *     (best_i, best_j)[b] the pair, or cur_length[b] and (-1, -1) when no candidate is shorter.  O(N) per candidate.
+ *   cur_length == NULL: candidates are compared by delta(i, j) = D[a,c] + D[b,e] - D[a,b] - D[c,e] (rls_tsp_2opt_delta's
+ *     formula in float64; SYMMETRIC dist), O(1) per candidate: best_value[b] = the most negative delta, or 0 / (-1, -1). */
+int rls_tsp_2opt_best(const double* dist, int64_t N, const int64_t* perm, int64_t B, const double* cur_length, int64_t* best_i,
+                      int64_t* best_j, double* best_value, void* stream);
+
 /* ------------------------------------------------------------------- ISCO sampler steps */
 
 /* ISCO_maxcut.step(x, path_length, temperature)  envs/env_ISCO.py:26-49 in ONE kernel (one wave per env):

@@ -587,3 +587,41 @@ def mcpg_sampling_maxcut(graph_w, num_nodes, sorted_degree_nodes, start_status, 
     index = np.arange(total_mcmc_num) + index * total_mcmc_num
     vs = (edge_weight_sum - expected[index]) / np.float32(2)
     return vs, x[:, index], start, expected - expected.mean(dtype=np.float32), expected
+
+
+# --------------------------------------------------------------------------- TSP true 2-opt local search
+
+
+def tsp_distance_calc(distance_matrix, tour_closed_1based):
+    """distance_calc, methods_problem_specific/TSP/opt_2.py:17-22: sequential float64 sum over the closed 1-based tour."""
+    d = 0
+    t = tour_closed_1based
+    for k in range(len(t) - 1):
+        d = d + distance_matrix[t[k] - 1, t[k + 1] - 1]
+    return d
+
+
+def tsp_local_search_2_opt(distance_matrix, tour_closed_1based, start_distance, recursive_seeding=-1):
+    """local_search_2_opt, methods_problem_specific/TSP/opt_2.py:27-57, in the reference's shape: every pass tries EVERY
+    reversal [i..j] of the pass's seed tour, recomputes the whole length of each candidate and keeps the shortest seen
+    (strictly shorter only); passes repeat until one brings nothing (recursive_seeding < 0) or `recursive_seeding` times."""
+    count = -2 if recursive_seeding < 0 else 0
+    best_tour, best_d = list(tour_closed_1based), start_distance
+    tracker = best_d * 2
+    while count < recursive_seeding:
+        seed = list(best_tour)
+        n = len(seed)
+        for i in range(0, n - 2):
+            for j in range(i + 1, n - 1):
+                cand = list(seed)
+                cand[i:j + 1] = cand[i:j + 1][::-1]
+                cand[-1] = cand[0]
+                dc = tsp_distance_calc(distance_matrix, cand)
+                if best_d > dc:
+                    best_tour, best_d = cand, dc
+        count += 1
+        if tracker > best_d and recursive_seeding < 0:
+            tracker, count, recursive_seeding = best_d, -2, -1
+        elif best_d >= tracker and recursive_seeding < 0:
+            count, recursive_seeding = -1, -2
+    return best_tour, best_d

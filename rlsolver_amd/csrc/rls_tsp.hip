@@ -207,6 +207,84 @@ __global__ __launch_bounds__(kWave) void k_rand_perms_lds(int64_t* __restrict__ 
     }
 }
 
+// One best-improvement pass of methods_problem_specific/TSP/opt_2.py:27-57: every reversal [i..j], 0 <= i < j <= N - 1, of
+// the closed tour is evaluated against the SAME seed tour and the best one wins (the first in (i, j) order among equals:
+// the reference keeps a candidate only when it is strictly shorter than the best so far).  A workgroup per tour.
+//   EXACT: the reference's own comparison values -- the candidate's whole length as distance_calc sums it (float64,
+//          edge after edge from the candidate's first city).  The edges before position i - 1 are the seed's, so the sum
+//          resumes from the seed's running sum S[i - 1] (the same additions in the same order) and walks the remaining
+//          N - i + 1 edges: candidates that tie in exact arithmetic (a reversal that only turns the cycle around) are
+//          ranked by their rounding, exactly as the reference ranks them.  value = that length, compared with cur[b].
+//   else:  delta(i, j) = D[a,c] + D[b,e] - D[a,b] - D[c,e] (a = t[i-1], b = t[i], c = t[j], e = t[j+1], cyclic; 0 for the
+//          whole tour), O(1) per candidate, for a SYMMETRIC matrix.  value = delta, compared with 0.
+template <bool EXACT>
+__global__ __launch_bounds__(256) void k_tsp_2opt_best(const double* __restrict__ dist, int64_t N, const int64_t* __restrict__ perm,
+                                                        int64_t B, const double* __restrict__ cur, int64_t* __restrict__ best_i,
+                                                        int64_t* __restrict__ best_j, double* __restrict__ best_value) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    double* rd = reinterpret_cast<double*>(smem);                           // [256]
+    int64_t* rk = reinterpret_cast<int64_t*>(rd + 256);                     // [256]
+    double* S = reinterpret_cast<double*>(rk + 256);                        // [N + 1] running sums of the seed (EXACT)
+    int32_t* t = reinterpret_cast<int32_t*>(S + (EXACT ? N + 1 : 0));       // [N]
+    const int64_t b = blockIdx.x;
+    const int tid = threadIdx.x;
+    for (int64_t k = tid; k < N; k += 256) t[k] = (int32_t)perm[b * N + k];
+    __syncthreads();
+    if (EXACT && tid == 0) {
+        double acc = 0.0;
+        S[0] = 0.0;
+        for (int64_t k = 0; k < N; ++k) {
+            acc = acc + dist[(int64_t)t[k] * N + t[k + 1 == N ? 0 : k + 1]];
+            S[k + 1] = acc;
+        }
+    }
+    __syncthreads();
+    double best = EXACT ? cur[b] : 0.0;                                     // only strictly better candidates count
+    int64_t key = -1;                                                       // i * N + j of the best so far
+    for (int64_t i = 0; i + 1 < N; ++i) {
+        const int64_t a = t[i == 0 ? N - 1 : i - 1], bb = t[i];
+        const double dab = dist[a * N + bb];
+        for (int64_t j = i + 1 + tid; j < N; j += 256) {
+            double v;
+            if constexpr (EXACT) {
+                auto city = [&](int64_t k) -> int64_t {                     // the candidate tour, closed
+                    if (k == N) k = 0;
+                    return (k >= i && k <= j) ? t[i + j - k] : t[k];
+                };
+                const int64_t k0 = i >= 1 ? i - 1 : 0;
+                v = S[k0];
+                int64_t c0 = city(k0);
+                for (int64_t k = k0; k < N; ++k) {
+                    const int64_t c1 = city(k + 1);
+                    v = v + dist[c0 * N + c1];
+                    c0 = c1;
+                }
+            } else {
+                if (i == 0 && j == N - 1) continue;                         // the whole tour reversed: the same cycle
+                const int64_t c = t[j], e = t[j + 1 == N ? 0 : j + 1];
+                v = (dist[a * N + c] + dist[bb * N + e]) - (dab + dist[c * N + e]);
+            }
+            if (v < best) { best = v; key = i * N + j; }                    // strict: the first of equals stays (i, then j ascending)
+        }
+    }
+    rd[tid] = best;
+    rk[tid] = key;
+    __syncthreads();
+    for (int sft = 128; sft >= 1; sft >>= 1) {
+        if (tid < sft) {
+            const double o = rd[tid + sft];
+            const int64_t ok = rk[tid + sft];
+            if (ok >= 0 && (rk[tid] < 0 || o < rd[tid] || (o == rd[tid] && ok < rk[tid]))) { rd[tid] = o; rk[tid] = ok; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        best_value[b] = rk[0] >= 0 ? rd[0] : (EXACT ? cur[b] : 0.0);
+        best_i[b] = rk[0] >= 0 ? rk[0] / N : -1;
+        best_j[b] = rk[0] >= 0 ? rk[0] % N : -1;
+    }
+}
+
 static inline bool dist_fits_lds(int64_t N, size_t extra) { return (size_t)N * N * 4 + extra <= (size_t)kLdsBytes - 1024; }
 
 static inline int tsp_block(int64_t N) { return N <= 256 ? kTspBlock : kTspBlockSmall; }
@@ -282,6 +360,25 @@ int rls_tsp_2opt_delta(const float* dist, int64_t N, const int64_t* perm, int64_
     hipLaunchKernelGGL(k_tsp_2opt_delta, dim3((unsigned)ceil_div(B, 256)), dim3(256), 0, as_stream(stream), dist, N,
                        perm, B, i, j, delta);
     return check_launch("k_tsp_2opt_delta");
+}
+
+int rls_tsp_2opt_best(const double* dist, int64_t N, const int64_t* perm, int64_t B, const double* cur_length, int64_t* best_i,
+                      int64_t* best_j, double* best_value, void* stream) {
+    RLS_REQUIRE(N > 2 && N < (1ll << 31) && B >= 0, RLS_EINVAL, "bad sizes N=%lld B=%lld", (long long)N, (long long)B);
+    if (B == 0) return RLS_OK;
+    RLS_REQUIRE(dist && perm && best_i && best_j && best_value, RLS_EINVAL, "NULL pointer");
+    const size_t lds = 256 * 16 + (cur_length ? (size_t)(N + 1) * 8 : 0) + (size_t)N * 4;
+    RLS_REQUIRE(lds <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS (max %d)", (long long)N, lds, kLdsBytes);
+    if (cur_length) {
+        auto kern = k_tsp_2opt_best<true>;
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(256), lds, as_stream(stream), dist, N, perm, B, cur_length, best_i, best_j, best_value);
+    } else {
+        auto kern = k_tsp_2opt_best<false>;
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(256), lds, as_stream(stream), dist, N, perm, B, cur_length, best_i, best_j, best_value);
+    }
+    return check_launch("k_tsp_2opt_best");
 }
 
 int rls_rand_perms(int64_t* perm, int64_t B, int64_t N, uint64_t seed, int64_t env_offset, void* stream) {

@@ -350,6 +350,19 @@ void tsp_apply_swap(Tensor perm, const Tensor& pos, const Tensor& indices) {
     ok(rls_tsp_apply_swap((int64_t*)p(perm), perm.size(0), perm.size(1), (const int64_t*)p(pos), (const int64_t*)p(indices), cur_stream(perm)),
        "rls_tsp_apply_swap");
 }
+void tsp_2opt_best(const Tensor& dist, const Tensor& perm, const OptTensor& cur_length, Tensor best_i, Tensor best_j, Tensor best_value) {
+    dev(dist, "dist", F64);
+    dev(perm, "perm", I64);
+    optdev(cur_length, "cur_length", F64);
+    dev(best_i, "best_i", I64);
+    dev(best_j, "best_j", I64);
+    dev(best_value, "best_value", F64);
+    TORCH_CHECK(perm.dim() == 2 && dist.dim() == 2 && dist.size(0) == perm.size(1) && dist.size(1) == perm.size(1), "dist must be [N, N], perm [B, N]");
+    TORCH_CHECK(best_i.numel() == perm.size(0) && best_j.numel() == perm.size(0) && best_value.numel() == perm.size(0), "outputs must hold B entries");
+    if (cur_length.has_value()) TORCH_CHECK(cur_length->numel() == perm.size(0), "cur_length must hold B entries");
+    ok(rls_tsp_2opt_best((const double*)p(dist), perm.size(1), (const int64_t*)p(perm), perm.size(0), (const double*)p(cur_length), (int64_t*)p(best_i),
+                         (int64_t*)p(best_j), (double*)p(best_value), cur_stream(perm)), "rls_tsp_2opt_best");
+}
 void tsp_2opt_delta(const Tensor& dist, const Tensor& perm, const Tensor& i, const Tensor& j, Tensor delta) {
     dev(dist, "dist", F32);
     dev(perm, "perm", I64);
@@ -447,6 +460,7 @@ TORCH_LIBRARY(rlsolver_hip, m) {
           "Tensor(c!) ban) -> ()");
     m.def("tsp_apply_swap(Tensor(a!) perm, Tensor pos, Tensor indices) -> ()");
     m.def("tsp_2opt_delta(Tensor dist, Tensor perm, Tensor i, Tensor j, Tensor(a!) delta) -> ()");
+    m.def("tsp_2opt_best(Tensor dist, Tensor perm, Tensor? cur_length, Tensor(a!) best_i, Tensor(b!) best_j, Tensor(c!) best_value) -> ()");
     m.def("isco_maxcut_step(int graph, Tensor x, Tensor(a!) y_out, Tensor path_length, float temperature, Tensor? u_gumbel, Tensor? u_accept, "
           "int seed, int env_offset, Tensor(b!)? energy_out, Tensor(c!)? acc_out, Tensor(d!)? terms_out, Tensor(e!)? mask_out) -> ()");
     m.def("isco_tsp_step(Tensor dist, Tensor nearest, float near_threshold, Tensor random, Tensor perm_in, Tensor(a!) perm_out, int path_length, "
@@ -488,6 +502,7 @@ TORCH_LIBRARY_IMPL(rlsolver_hip, CUDA, m) {   // "CUDA" is the HIP dispatch key 
     m.impl("tsp_swap_delta_all", &tsp_swap_delta_all);
     m.impl("tsp_apply_swap", &tsp_apply_swap);
     m.impl("tsp_2opt_delta", &tsp_2opt_delta);
+    m.impl("tsp_2opt_best", &tsp_2opt_best);
     m.impl("isco_maxcut_step", &isco_maxcut_step);
     m.impl("isco_tsp_step", &isco_tsp_step);
 }

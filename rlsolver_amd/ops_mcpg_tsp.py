@@ -260,3 +260,23 @@ def rand_perms(B: int, N: int, seed: int, device, env_offset: int = 0) -> TEN:
     out = torch.empty((B, N), dtype=torch.int64, device=device)
     _abi.call("rls_rand_perms", _ptr(out), B, N, _u64(seed), env_offset, _stream(device))
     return out
+
+
+def tsp_2opt_best(dist64: TEN, perm: TEN, cur_length: Optional[TEN] = None):
+    """One best-improvement 2-opt pass per tour (rls_tsp_2opt_best): -> (best_i, best_j int64 [B], best_value f64 [B]).
+    ``cur_length`` f64 [B]: candidates ranked by their whole length summed as the reference's distance_calc does (its own
+    comparison values); best_value = the best candidate's length, or cur_length and (-1, -1) where none is shorter.
+    Without it: ranked by the O(1) reversal delta (symmetric dist); best_value = the most negative delta, or 0."""
+    dev = perm.device
+    _check(dist64, "dist", (torch.float64,), dev)
+    _check(perm, "perm", (torch.int64,), dev)
+    B, N = perm.shape
+    if dist64.shape != (N, N):
+        raise ValueError(f"dist must be [{N}, {N}]")
+    if cur_length is not None:
+        _check(cur_length, "cur_length", (torch.float64,), dev, (B,))
+    bi = torch.empty(B, dtype=torch.int64, device=dev)
+    bj = torch.empty(B, dtype=torch.int64, device=dev)
+    bv = torch.empty(B, dtype=torch.float64, device=dev)
+    _abi.call("rls_tsp_2opt_best", _ptr(dist64), N, _ptr(perm), B, _ptr(cur_length), _ptr(bi), _ptr(bj), _ptr(bv), _stream(dev))
+    return bi, bj, bv

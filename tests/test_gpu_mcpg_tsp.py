@@ -442,3 +442,44 @@ def test_mcpg_weighted_sampler_vs_oracle(n, m, M, R, num_ls, wset):
     cutw = ((xg[g[:, 0]] != xg[g[:, 1]]) * g[:, 2][:, None]).sum(axis=0)
     assert np.array_equal(vs.cpu().numpy(), cutw.astype(np.float32))
     assert set(np.unique(xg)) <= {0.0, 1.0}
+
+
+def test_tsp_2opt_local_search_golden(golden):
+    """local_search_2_opt on the device (one kernel per pass) returns the reference's tours and float64 distances on
+    a5, berlin52 and two uniform instances, until-no-improvement and for exactly two passes; the batch form ends in
+    2-opt local optima no longer than it started and agrees with the oracle."""
+    from rlsolver_amd.methods import tsp_opt_2 as t2
+    z = golden("tsp_2opt")
+    for name in z["names"]:
+        d = z[f"{name}/distance_f64"]
+        for t in range(2):
+            start = [z[f"{name}/t{t}/start_tour"].tolist(), float(z[f"{name}/t{t}/start_distance"])]
+            assert t2.distance_calc(d, start) == start[1]
+            for rs in (-1, 2):
+                route, dist = t2.local_search_2_opt(d, start, recursive_seeding=rs, verbose=False, device=DEV)
+                assert route == z[f"{name}/t{t}/rs{rs}/tour"].tolist(), (name, t, rs)
+                assert dist == float(z[f"{name}/t{t}/rs{rs}/distance"])
+    rng = np.random.RandomState(3)
+    N, B = 30, 40
+    coords = rng.rand(N, 2) * 50
+    d = np.sqrt(((coords[:, None] - coords[None]) ** 2).sum(-1))
+    perms = np.stack([rng.permutation(N) for _ in range(B)])
+    dd = dev(d)
+    start_len = dd[dev(perms), torch.roll(dev(perms), -1, 1)].sum(1)
+    out, lengths = t2.local_search_2_opt_batch(d, dev(perms))                       # delta ranking
+    assert bool((lengths <= start_len + 1e-9).all()) and bool((out.sort(dim=1).values == torch.arange(N, device=DEV)).all())
+    bi, bj, bd = mops.tsp_2opt_best(dd, out)
+    assert bool((bd == 0).all()) and bool((bi == -1).all())                      # 2-opt local optima
+    seed_len = torch.tensor([onp.tsp_distance_calc(d, [int(c) + 1 for c in p] + [int(p[0]) + 1]) for p in perms], dtype=torch.float64, device=DEV)
+    oute, lene = t2.local_search_2_opt_batch(d, dev(perms), exact=True, lengths=seed_len)   # the reference's ranking
+    for b in range(6):
+        tour = [int(c) + 1 for c in perms[b]] + [int(perms[b][0]) + 1]
+        r, dist = onp.tsp_local_search_2_opt(d, tour, onp.tsp_distance_calc(d, tour), -1)
+        assert [int(c) + 1 for c in oute[b].tolist()] == r[:-1] and float(lene[b]) == dist
+    asym = d + np.triu(np.ones_like(d), 1)                                         # asymmetric: exact ranking only
+    tour = [int(c) + 1 for c in perms[0]] + [int(perms[0][0]) + 1]
+    r, dist = onp.tsp_local_search_2_opt(asym, tour, onp.tsp_distance_calc(asym, tour), 3)
+    r2, dist2 = t2.local_search_2_opt(asym, [tour, onp.tsp_distance_calc(asym, tour)], recursive_seeding=3, verbose=False, device=DEV)
+    assert r2 == r and dist2 == dist
+    with pytest.raises(ValueError):
+        t2.local_search_2_opt_batch(d + np.triu(np.ones_like(d), 1), dev(perms))   # asymmetric

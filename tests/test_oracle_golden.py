@@ -315,3 +315,19 @@ def test_mcpg_weighted_sampler_oracle(golden, gname):
     assert np.array_equal(vs, z[f"{gname}/vs"]) and np.array_equal(xs_good, z[f"{gname}/xs_good"])
     np.testing.assert_allclose(value, z[f"{gname}/value"], rtol=0, atol=1e-4)
     assert float(z[f"{gname}/edge_weight_sum"]) == float(g[:, 2].sum())
+
+
+def test_tsp_2opt_local_search_oracle_vs_reference(golden):
+    """The restatement of local_search_2_opt (methods_problem_specific/TSP/opt_2.py:27-57) reproduces what the reference
+    returned: the same tours and bit-identical float64 distances (berlin52's until-no-improvement run is left to the GPU
+    test: O(N^3) per pass in Python)."""
+    z = golden("tsp_2opt")
+    for name in z["names"]:
+        d = z[f"{name}/distance_f64"]
+        for t in range(2):
+            tour = z[f"{name}/t{t}/start_tour"].tolist()
+            sd = float(z[f"{name}/t{t}/start_distance"])
+            assert onp.tsp_distance_calc(d, tour) == sd
+            for rs in ((2,) if len(tour) > 40 else (-1, 2)):
+                r, dist = onp.tsp_local_search_2_opt(d, tour, sd, rs)
+                assert r == z[f"{name}/t{t}/rs{rs}/tour"].tolist() and dist == float(z[f"{name}/t{t}/rs{rs}/distance"])

@@ -407,6 +407,43 @@ def gen_tsp():
     save("tsp", **out)
 
 
+def gen_tsp_2opt():
+    """local_search_2_opt (methods_problem_specific/TSP/opt_2.py:27-57) run by the reference itself: a5, berlin52 and two
+    seeded uniform instances, from seeded random tours; until no pass improves (recursive_seeding = -1) and for exactly two
+    passes (recursive_seeding = 2)."""
+    from rlsolver.methods.ISCO import util_TSP
+    spec = importlib.util.spec_from_file_location(
+        "ref_opt2", os.path.join(REF, "rlsolver", "methods_problem_specific", "TSP", "opt_2.py"))
+    opt2 = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(opt2)
+    out = {}
+    rng = np.random.RandomState(20230)
+    cases = {}
+    for name in ("a5", "berlin52"):
+        coords = np.asarray(util_TSP.read_tsp_file(os.path.join(DATA, "tsplib", name + ".tsp")), dtype=np.float64)
+        cases[name] = coords
+    cases["uniform12"] = rng.rand(12, 2) * 100.0
+    cases["uniform30"] = rng.rand(30, 2) * 100.0
+    names = []
+    for name, coords in cases.items():
+        N = coords.shape[0]
+        d64 = np.sqrt(((coords[:, None, :] - coords[None, :, :]) ** 2).sum(-1))
+        out[f"{name}/distance_f64"] = d64
+        for t in range(2):
+            perm = rng.permutation(N)
+            tour = [int(c) + 1 for c in perm] + [int(perm[0]) + 1]
+            start = [tour, float(opt2.distance_calc(d64, [tour, 0.0]))]
+            out[f"{name}/t{t}/start_tour"] = np.asarray(tour, dtype=np.int64)
+            out[f"{name}/t{t}/start_distance"] = np.float64(start[1])
+            for rs in (-1, 2):
+                route, dist = opt2.local_search_2_opt(d64, start, recursive_seeding=rs, verbose=False)
+                out[f"{name}/t{t}/rs{rs}/tour"] = np.asarray(route, dtype=np.int64)
+                out[f"{name}/t{t}/rs{rs}/distance"] = np.float64(dist)
+        names.append(name)
+    out["names"] = np.asarray(names)
+    save("tsp_2opt", **out)
+
+
 # ----------------------------------------------------------------------------- misc
 def gen_encoder():
     from rlsolver.methods import util_evaluator as ue
@@ -888,7 +925,7 @@ def gen_isco_steps():
 
 
 ALL = {"mcpg_weighted": gen_mcpg_weighted, "isco_steps": gen_isco_steps, "spinsystem_cpu": gen_spinsystem_cpu, "spinsystem": gen_spinsystem, "qubo": gen_qubo, "isco_maxcut": gen_isco_maxcut, "maxcut": gen_maxcut, "sweep": gen_sweep, "lsclass": gen_local_search_class, "ppo": gen_ppo,
-       "select": gen_select, "mcpg": gen_mcpg, "tsp": gen_tsp, "encoder": gen_encoder,
+       "select": gen_select, "mcpg": gen_mcpg, "tsp": gen_tsp, "tsp_2opt": gen_tsp_2opt, "encoder": gen_encoder,
        "wgain": gen_weighted_gain}
 
 if __name__ == "__main__":
