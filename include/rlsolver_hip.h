@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RLS_ABI_VERSION 5
+#define RLS_ABI_VERSION 6
 
 enum {
     RLS_OK = 0,
@@ -293,12 +293,32 @@ int rls_spin_step(const rls_graph* g, const rls_spin_env* env, int state_bytes, 
                   double time_inc, double termination_value, int32_t reward_mode, double reward_div, int64_t hist_len,
                   int32_t use_stag, double stag_punishment, int32_t use_basin, double basin_reward, void* stream);
 
-/* get_observation()  ECO_S2V/src/envs/spinsystem_PECO.py:455 (cat(state, matrix.expand(B, N, N))) and spinsystem.py:484-495
+/* The same env with PER-ENV couplings: the training envs of spinsystem_PECO.py hold matrix T [B, N, N], redrawn by the graph
+ * generator at every reset (:150-160; util_envs_PECO.py:40-56, 86-112), and recompute s * (W s) with a batched dense matmul
+ * every step.  Here the flipped node's row of its env's matrix is the neighbour list of the same O(changed entries) update.
+ *
+ * rls_spin_reset_dense: after the caller has written the signed spins into row 0 of state: delta[b,i] = s_i sum_j W_ij s_j,
+ * max_local T [B] = max_i sum_j W_ij (_get_immeditate_cuts_avaialable on all-ones spins, :162-168), weight_sum T [B] =
+ * sum_ij W_ij, flags uint8 [B]: bit 0 = the reference draws the graph again (sum_i |sum_j W_ij| == 0 or max_local == 0, :164-169),
+ * bit 1 = not a symmetric integer-valued matrix (the int32 gain cache cannot hold it; diagonal entries are allowed and count as
+ * in the reference: flipping a changes the score by delta_a - 2 W_aa, :346-348); then everything
+ * rls_spin_reset does, with the per-env max_local / weight_sum.  The caller reads flags before stepping. */
+int rls_spin_reset_dense(const void* matrix, const rls_spin_env* env, int state_bytes, int64_t B, int64_t N, int32_t num_rows,
+                         const int32_t* row_index, void* max_local, void* weight_sum, uint8_t* flags, void* stream);
+
+/* rls_spin_step with matrix T [B, N, N] and max_local T [B] (as rls_spin_reset_dense left them) in place of the shared graph. */
+int rls_spin_step_dense(const void* matrix, const void* max_local, const rls_spin_env* env, int state_bytes, int64_t B, int64_t N,
+                        int32_t num_rows, const int32_t* row_index, const int64_t* action, void* reward, uint8_t* visited_new,
+                        double time_inc, double termination_value, int32_t reward_mode, double reward_div, int64_t hist_len,
+                        int32_t use_stag, double stag_punishment, int32_t use_basin, double basin_reward, void* stream);
+
+/* get_observation()  ECO_S2V/src/envs/spinsystem_PECO.py:455,497 (cat(state, matrix_obs)) and spinsystem.py:484-495
  * (vstack(state, matrix)): out T [B, num_rows + N, N] = the num_rows observable rows of state T [B, num_rows, N], row 0
- * mapped from signed spins to (1 - s) / 2 when binary_basis (SpinBasis.BINARY), followed by the N rows of the shared
- * matrix T [N, N]; matrix NULL: out = [B, num_rows, N] (the rows only).  One streaming pass, nothing else touched. */
-int rls_spin_observation(const void* state, const void* matrix, int state_bytes, int64_t B, int32_t num_rows, int64_t N,
-                         int32_t binary_basis, void* out, void* stream);
+ * mapped from signed spins to (1 - s) / 2 when binary_basis (SpinBasis.BINARY), followed by the N rows of the matrix:
+ * T [N, N] shared by all envs (matrix_per_env = 0) or T [B, N, N] (matrix_per_env = 1); matrix NULL: out = [B, num_rows, N]
+ * (the rows only).  One streaming pass, nothing else touched. */
+int rls_spin_observation(const void* state, const void* matrix, int32_t matrix_per_env, int state_bytes, int64_t B,
+                         int32_t num_rows, int64_t N, int32_t binary_basis, void* out, void* stream);
 
 /* -------------------------------------------------------------------- MCPG */
 /* Layouts of a batch of C chains:

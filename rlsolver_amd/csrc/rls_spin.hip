@@ -89,11 +89,15 @@ struct SpinStepArgs {
     int64_t hist_len;
 };
 
-template <typename T, bool VEC>
+// DENSE: per-env couplings matrix T [B, N, N] (the training envs: a fresh graph per env and reset) instead of the shared
+// CSR graph -- the flipped node's row of its env's matrix is the neighbour list (symmetric, integer-valued:
+// checked at reset), one lane per entry, no atomics; max_local is per env.
+template <typename T, bool VEC, bool DENSE>
 __global__ __launch_bounds__(256) void k_spin_step(rls_spin_env env, int64_t B, int64_t N, int R,
                                                    const int32_t* __restrict__ rowptr,
                                                    const int32_t* __restrict__ col,
                                                    const int32_t* __restrict__ wgt,
+                                                   const T* __restrict__ matrix, const T* __restrict__ max_local_env,
                                                    const int64_t* __restrict__ action, T* __restrict__ reward,
                                                    uint8_t* __restrict__ visited_new, SpinRows rows, SpinStepArgs p) {
     const int lane = threadIdx.x & (kWave - 1);
@@ -113,7 +117,7 @@ __global__ __launch_bounds__(256) void k_spin_step(rls_spin_env env, int64_t B, 
         }
         return;
     }
-    const T max_local = (T)p.max_local, time_inc = (T)p.time_inc;
+    const T max_local = DENSE ? max_local_env[b] : (T)p.max_local, time_inc = (T)p.time_inc;
 
     // 1. flip + score change (spinsystem_PECO.py:336-348): gain = delta[a] before the flip.  Neighbour updates
     //    are returning L2 atomics (multi-edges may hit one node twice in a wave-instruction): every lane sees
@@ -121,32 +125,60 @@ __global__ __launch_bounds__(256) void k_spin_step(rls_spin_env env, int64_t B, 
     const T s_old = spins[a];
     const T s_new = -s_old;
     const int sn = s_new > (T)0 ? 1 : -1;
-    const int gain = dl[a];
-    const int r0 = rowptr[a], r1 = rowptr[a + 1];
+    const int da = dl[a];
+    int gain = da;
     int adj = 0;
-    for (int j = r0 + lane; j < r1; j += kWave) {
-        const int nb = col[j];
-        const int w = wgt ? wgt[j] : 1;
-        const int sj = spins[nb] > (T)0 ? 1 : -1;
-        const int c = 2 * w * sj * sn;
-        const int old = atomicAdd(&dl[nb], c);
-        adj += (int)((old + c) <= 0) - (int)(old <= 0);
-    }
-    if (lane == 0) {
-        adj += (int)(-gain <= 0) - (int)(gain <= 0);
-        __hip_atomic_store(&dl[a], -gain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        spins[a] = s_new;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    if (rows.immediate >= 0) {   // only the entries whose gain changed (agent-scope loads see the atomics' results)
-        T* imm = st + (int64_t)rows.immediate * N;
+    if constexpr (DENSE) {
+        const T* wrow = matrix + (b * N + a) * N;
+        // a diagonal entry (the reference's BA training graphs carry W_ii = +-1 on their seed clique, util_envs_PECO.py:93-95)
+        // counts as the reference counts it: score change = -(s' * (W s'))_a = delta_a - 2 W_aa  (spinsystem_PECO.py:346-348)
+        gain = da - 2 * (int)wrow[a];
+        T* imm = rows.immediate >= 0 ? st + (int64_t)rows.immediate * N : nullptr;
+        for (int64_t n = lane; n < N; n += kWave) {
+            const T w = wrow[n];
+            if (w != (T)0 && n != a) {
+                const int sj = spins[n] > (T)0 ? 1 : -1;
+                const int c = 2 * (int)w * sj * sn;
+                const int old = dl[n];
+                dl[n] = old + c;
+                adj += (int)((old + c) <= 0) - (int)(old <= 0);
+                if (imm) imm[n] = (T)(old + c) / max_local;
+            }
+        }
+        if (lane == 0) {
+            adj += (int)(-gain <= 0) - (int)(da <= 0);
+            dl[a] = -gain;
+            spins[a] = s_new;
+            if (imm) imm[a] = (T)(-gain) / max_local;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    } else {
+        const int r0 = rowptr[a], r1 = rowptr[a + 1];
         for (int j = r0 + lane; j < r1; j += kWave) {
             const int nb = col[j];
-            const int d = __hip_atomic_load(&dl[nb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            imm[nb] = (T)d / max_local;
+            const int w = wgt ? wgt[j] : 1;
+            const int sj = spins[nb] > (T)0 ? 1 : -1;
+            const int c = 2 * w * sj * sn;
+            const int old = atomicAdd(&dl[nb], c);
+            adj += (int)((old + c) <= 0) - (int)(old <= 0);
         }
-        if (lane == 0) imm[a] = (T)(-gain) / max_local;
+        if (lane == 0) {
+            adj += (int)(-gain <= 0) - (int)(gain <= 0);
+            __hip_atomic_store(&dl[a], -gain, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            spins[a] = s_new;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (rows.immediate >= 0) {   // only the entries whose gain changed (agent-scope loads see the atomics' results)
+            T* imm = st + (int64_t)rows.immediate * N;
+            for (int j = r0 + lane; j < r1; j += kWave) {
+                const int nb = col[j];
+                const int d = __hip_atomic_load(&dl[nb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                imm[nb] = (T)d / max_local;
+            }
+            if (lane == 0) imm[a] = (T)(-gain) / max_local;
+        }
     }
     const int nonpos = env.num_nonpos[b] + wave_sum_i32(adj);
 
@@ -247,14 +279,16 @@ __global__ __launch_bounds__(256) void k_spin_step(rls_spin_env env, int64_t B, 
 // packed spins + hash, empty history.
 template <typename T>
 __global__ __launch_bounds__(256) void k_spin_reset(rls_spin_env env, int64_t B, int64_t N, int R, SpinRows rows,
-                                                    double max_local_d, int64_t weight_sum) {
+                                                    double max_local_d, int64_t weight_sum_all,
+                                                    const T* __restrict__ max_local_env, const T* __restrict__ weight_sum_env) {
     const int lane = threadIdx.x & (kWave - 1);
     const int64_t b = (int64_t)blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
     if (b >= B) return;
     T* st = reinterpret_cast<T*>(env.state) + b * R * N;
     const int32_t* dl = env.delta + b * N;
     T* bs = reinterpret_cast<T*>(env.best_spins) + b * N;
-    const T max_local = (T)max_local_d;
+    const T max_local = max_local_env ? max_local_env[b] : (T)max_local_d;
+    const int64_t weight_sum = weight_sum_env ? (int64_t)weight_sum_env[b] : weight_sum_all;
     int nonpos = 0;
     int64_t dsum = 0;
     uint64_t h = 0;
@@ -300,12 +334,63 @@ __global__ __launch_bounds__(256) void k_spin_reset(rls_spin_env env, int64_t B,
     }
 }
 
+// Per-env couplings (spinsystem_PECO.py:150-170 with the generators of util_envs_PECO.py): from matrix T [B, N, N] and the
+// signed spins in row 0 of state, the gain cache delta[b,i] = s_i sum_j W_ij s_j (_get_immeditate_cuts_avaialable, :660-661),
+// max_local[b] = max_i sum_j W_ij (the same expression on all-ones spins, :162-168), weight_sum[b] = sum_ij W_ij, and
+// flags[b]: bit 0 = the reference would draw the graph again (sum_i |sum_j W_ij| == 0 or max_local == 0), bit 1 = a matrix
+// the integer gain cache cannot hold (non-integer entry, not symmetric).  A workgroup per env, a wave per row.
+template <typename T>
+__global__ __launch_bounds__(256) void k_spin_dense_prepare(const T* __restrict__ matrix, const T* __restrict__ state, int64_t B,
+                                                             int64_t N, int R, int32_t* __restrict__ delta, T* __restrict__ max_local,
+                                                             T* __restrict__ weight_sum, uint8_t* __restrict__ flags) {
+    __shared__ double s_max[4], s_abs[4], s_tot[4];
+    __shared__ int s_bad[4];
+    const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
+    const int64_t b = blockIdx.x;
+    const T* m = matrix + b * N * N;
+    const T* spins = state + b * R * N;
+    double wmax = -INFINITY, wabs = 0.0, wtot = 0.0;
+    int bad = 0;
+    for (int64_t i = wv; i < N; i += 4) {
+        const T* row = m + i * N;
+        double dot = 0.0, rs = 0.0;
+        for (int64_t j = lane; j < N; j += kWave) {
+            const T w = row[j];
+            if (w != (T)0) {
+                dot += (double)w * (spins[j] > (T)0 ? 1.0 : -1.0);
+                rs += (double)w;
+                bad |= (int)(w != (T)rint((double)w)) | (int)(m[j * N + i] != w);
+            }
+        }
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) {
+            dot += __shfl_xor(dot, sft, 64);
+            rs += __shfl_xor(rs, sft, 64);
+        }
+        if (lane == 0) delta[b * N + i] = (int32_t)((spins[i] > (T)0 ? 1.0 : -1.0) * dot);
+        wmax = fmax(wmax, rs);
+        wabs += fabs(rs);
+        wtot += rs;
+    }
+    bad = ballot64(bad != 0) != 0;
+    if (lane == 0) { s_max[wv] = wmax; s_abs[wv] = wabs; s_tot[wv] = wtot; s_bad[wv] = bad; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double mx = fmax(fmax(s_max[0], s_max[1]), fmax(s_max[2], s_max[3]));
+        const double ab = s_abs[0] + s_abs[1] + s_abs[2] + s_abs[3];
+        max_local[b] = (T)mx;
+        weight_sum[b] = (T)(s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3]);
+        flags[b] = (uint8_t)((ab == 0.0 || mx == 0.0 ? 1 : 0) | ((s_bad[0] | s_bad[1] | s_bad[2] | s_bad[3]) ? 2 : 0));
+    }
+}
+
 // get_observation (spinsystem_PECO.py:455 / spinsystem.py:484-495): out[b] = rows of state[b] (row 0 mapped from signed to
 // {0, 1} spins under SpinBasis.BINARY: (1 - s) / 2) followed by the N rows of the shared matrix.  One streaming pass:
 // the reference clones the state, rewrites row 0 and concatenates a [B, N, N] expansion of the matrix.
 template <typename T, bool V4>
-__global__ __launch_bounds__(256) void k_spin_observation(const T* __restrict__ state, const T* __restrict__ matrix, int64_t B,
-                                                           int R, int64_t N, int binary, T* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_spin_observation(const T* __restrict__ state, const T* __restrict__ matrix,
+                                                           int64_t matrix_env_stride, int64_t B, int R, int64_t N, int binary,
+                                                           T* __restrict__ out) {
     constexpr int PER = V4 ? (int)(16 / sizeof(T)) : 1;
     const int64_t rows = R + (matrix ? N : 0), per_row = N / PER, per_env = rows * per_row;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -313,7 +398,7 @@ __global__ __launch_bounds__(256) void k_spin_observation(const T* __restrict__ 
     const int64_t rr = idx / per_row, c = (idx - rr * per_row) * PER;
     using V = typename RowVec<T>::type;
     for (int64_t b = blockIdx.y; b < B; b += gridDim.y) {
-        const T* src = rr < R ? state + (b * R + rr) * N + c : matrix + (rr - R) * N + c;
+        const T* src = rr < R ? state + (b * R + rr) * N + c : matrix + b * matrix_env_stride + (rr - R) * N + c;
         T* dst = out + (b * rows + rr) * N + c;
         if constexpr (V4) {
             V v = *reinterpret_cast<const V*>(src);
@@ -361,18 +446,41 @@ int rls_spin_reset(const rls_graph* g, const rls_spin_env* env, int state_bytes,
     const dim3 grid((unsigned)ceil_div(B, 4)), block(256);
     if (state_bytes == 4)
         hipLaunchKernelGGL(k_spin_reset<float>, grid, block, 0, as_stream(stream), *env, B, g->num_nodes, num_rows, rows,
-                           max_local, weight_sum);
+                           max_local, weight_sum, (const float*)nullptr, (const float*)nullptr);
     else
         hipLaunchKernelGGL(k_spin_reset<double>, grid, block, 0, as_stream(stream), *env, B, g->num_nodes, num_rows, rows,
-                           max_local, weight_sum);
+                           max_local, weight_sum, (const double*)nullptr, (const double*)nullptr);
     return check_launch("k_spin_reset");
 }
 
-int rls_spin_step(const rls_graph* g, const rls_spin_env* env, int state_bytes, int64_t B, int32_t num_rows,
-                  const int32_t* row_index, const int64_t* action, void* reward, uint8_t* visited_new, double max_local,
-                  double time_inc, double termination_value, int32_t reward_mode, double reward_div, int64_t hist_len,
-                  int32_t use_stag, double stag_punishment, int32_t use_basin, double basin_reward, void* stream) {
-    if (int rc = check_graph(g)) return rc;
+int rls_spin_reset_dense(const void* matrix, const rls_spin_env* env, int state_bytes, int64_t B, int64_t N, int32_t num_rows,
+                         const int32_t* row_index, void* max_local, void* weight_sum, uint8_t* flags, void* stream) {
+    RLS_REQUIRE(B >= 0 && N > 0 && N < (1ll << 24), RLS_EINVAL, "bad sizes B=%lld N=%lld", (long long)B, (long long)N);
+    SpinRows rows;
+    if (int rc = check_spin_env(env, state_bytes, num_rows, row_index, &rows)) return rc;
+    if (B == 0) return RLS_OK;
+    RLS_REQUIRE(matrix && max_local && weight_sum && flags, RLS_EINVAL, "NULL pointer");
+    hipStream_t s = as_stream(stream);
+    const dim3 grid((unsigned)ceil_div(B, 4)), block(256);
+    if (state_bytes == 4) {
+        hipLaunchKernelGGL(k_spin_dense_prepare<float>, dim3((unsigned)B), block, 0, s, (const float*)matrix, (const float*)env->state,
+                           B, N, (int)num_rows, env->delta, (float*)max_local, (float*)weight_sum, flags);
+        hipLaunchKernelGGL(k_spin_reset<float>, grid, block, 0, s, *env, B, N, num_rows, rows, 1.0, (int64_t)0,
+                           (const float*)max_local, (const float*)weight_sum);
+    } else {
+        hipLaunchKernelGGL(k_spin_dense_prepare<double>, dim3((unsigned)B), block, 0, s, (const double*)matrix, (const double*)env->state,
+                           B, N, (int)num_rows, env->delta, (double*)max_local, (double*)weight_sum, flags);
+        hipLaunchKernelGGL(k_spin_reset<double>, grid, block, 0, s, *env, B, N, num_rows, rows, 1.0, (int64_t)0,
+                           (const double*)max_local, (const double*)weight_sum);
+    }
+    return check_launch("k_spin_reset (dense)");
+}
+
+static int spin_step_common(const rls_graph* g, const void* matrix, const void* max_local_env, int64_t N, const rls_spin_env* env,
+                            int state_bytes, int64_t B, int32_t num_rows, const int32_t* row_index, const int64_t* action,
+                            void* reward, uint8_t* visited_new, double max_local, double time_inc, double termination_value,
+                            int32_t reward_mode, double reward_div, int64_t hist_len, int32_t use_stag, double stag_punishment,
+                            int32_t use_basin, double basin_reward, void* stream) {
     RLS_REQUIRE(B >= 0, RLS_EINVAL, "B < 0");
     SpinRows rows;
     if (int rc = check_spin_env(env, state_bytes, num_rows, row_index, &rows)) return rc;
@@ -383,23 +491,49 @@ int rls_spin_step(const rls_graph* g, const rls_spin_env* env, int state_bytes, 
     RLS_REQUIRE(!(use_stag || use_basin) || env->packed, RLS_EINVAL, "stag_punishment / basin_reward need the visited-state memory");
     RLS_REQUIRE(!env->packed || (hist_len >= 0 && hist_len < env->hist_cap), RLS_EINVAL,
                 "hist_len %lld outside [0, hist_cap = %lld)", (long long)hist_len, (long long)env->hist_cap);
-    const int64_t N = g->num_nodes;
     const bool vec = ((((uintptr_t)env->state) | ((uintptr_t)env->best_spins)) & 15) == 0 && (N * state_bytes) % 16 == 0;
     SpinStepArgs p{max_local, time_inc, termination_value, reward_div, stag_punishment, basin_reward,
                    reward_mode, use_stag, use_basin, hist_len};
     const dim3 grid((unsigned)ceil_div(B, 4)), block(256);
     hipStream_t s = as_stream(stream);
-#define LAUNCH_SPIN(T, VEC)                                                                                            \
-    hipLaunchKernelGGL((k_spin_step<T, VEC>), grid, block, 0, s, *env, B, N, num_rows, g->rowptr, g->col, g->wgt, action, \
-                       (T*)reward, visited_new, rows, p)
+#define LAUNCH_SPIN(T, VEC)                                                                                                     \
+    do {                                                                                                                        \
+        if (matrix)                                                                                                             \
+            hipLaunchKernelGGL((k_spin_step<T, VEC, true>), grid, block, 0, s, *env, B, N, num_rows, nullptr, nullptr, nullptr,   \
+                               (const T*)matrix, (const T*)max_local_env, action, (T*)reward, visited_new, rows, p);           \
+        else                                                                                                                    \
+            hipLaunchKernelGGL((k_spin_step<T, VEC, false>), grid, block, 0, s, *env, B, N, num_rows, g->rowptr, g->col, g->wgt,  \
+                               (const T*)nullptr, (const T*)nullptr, action, (T*)reward, visited_new, rows, p);                \
+    } while (0)
     if (state_bytes == 4) { if (vec) LAUNCH_SPIN(float, true); else LAUNCH_SPIN(float, false); }
     else                  { if (vec) LAUNCH_SPIN(double, true); else LAUNCH_SPIN(double, false); }
 #undef LAUNCH_SPIN
     return check_launch("k_spin_step");
 }
 
-int rls_spin_observation(const void* state, const void* matrix, int state_bytes, int64_t B, int32_t num_rows, int64_t N,
-                         int32_t binary_basis, void* out, void* stream) {
+int rls_spin_step(const rls_graph* g, const rls_spin_env* env, int state_bytes, int64_t B, int32_t num_rows,
+                  const int32_t* row_index, const int64_t* action, void* reward, uint8_t* visited_new, double max_local,
+                  double time_inc, double termination_value, int32_t reward_mode, double reward_div, int64_t hist_len,
+                  int32_t use_stag, double stag_punishment, int32_t use_basin, double basin_reward, void* stream) {
+    if (int rc = check_graph(g)) return rc;
+    return spin_step_common(g, nullptr, nullptr, g->num_nodes, env, state_bytes, B, num_rows, row_index, action, reward, visited_new,
+                            max_local, time_inc, termination_value, reward_mode, reward_div, hist_len, use_stag, stag_punishment,
+                            use_basin, basin_reward, stream);
+}
+
+int rls_spin_step_dense(const void* matrix, const void* max_local, const rls_spin_env* env, int state_bytes, int64_t B, int64_t N,
+                        int32_t num_rows, const int32_t* row_index, const int64_t* action, void* reward, uint8_t* visited_new,
+                        double time_inc, double termination_value, int32_t reward_mode, double reward_div, int64_t hist_len,
+                        int32_t use_stag, double stag_punishment, int32_t use_basin, double basin_reward, void* stream) {
+    RLS_REQUIRE(N > 0 && N < (1ll << 24), RLS_EINVAL, "bad N=%lld", (long long)N);
+    RLS_REQUIRE(B == 0 || (matrix && max_local), RLS_EINVAL, "matrix / max_local is NULL");
+    return spin_step_common(nullptr, matrix, max_local, N, env, state_bytes, B, num_rows, row_index, action, reward, visited_new, 1.0,
+                            time_inc, termination_value, reward_mode, reward_div, hist_len, use_stag, stag_punishment, use_basin,
+                            basin_reward, stream);
+}
+
+int rls_spin_observation(const void* state, const void* matrix, int32_t matrix_per_env, int state_bytes, int64_t B, int32_t num_rows,
+                         int64_t N, int32_t binary_basis, void* out, void* stream) {
     RLS_REQUIRE(B >= 0 && num_rows >= 1 && N > 0, RLS_EINVAL, "bad sizes B=%lld R=%d N=%lld", (long long)B, num_rows, (long long)N);
     RLS_REQUIRE(state_bytes == 4 || state_bytes == 8, RLS_EINVAL, "state_bytes must be 4 (f32) or 8 (f64)");
     if (B == 0) return RLS_OK;
@@ -412,8 +546,8 @@ int rls_spin_observation(const void* state, const void* matrix, int state_bytes,
     const dim3 grid((unsigned)ceil_div(per_env, 256), (unsigned)(B < 16384 ? B : 16384)), block(256);
     hipStream_t s = as_stream(stream);
 #define LAUNCH_OBS(T, V4)                                                                                                     \
-    hipLaunchKernelGGL((k_spin_observation<T, V4>), grid, block, 0, s, (const T*)state, (const T*)matrix, B, (int)num_rows, N,  \
-                       (int)binary_basis, (T*)out)
+    hipLaunchKernelGGL((k_spin_observation<T, V4>), grid, block, 0, s, (const T*)state, (const T*)matrix,                       \
+                       (int64_t)(matrix_per_env ? N * N : 0), B, (int)num_rows, N, (int)binary_basis, (T*)out)
     if (state_bytes == 4) { if (v4) LAUNCH_OBS(float, true); else LAUNCH_OBS(float, false); }
     else                  { if (v4) LAUNCH_OBS(double, true); else LAUNCH_OBS(double, false); }
 #undef LAUNCH_OBS

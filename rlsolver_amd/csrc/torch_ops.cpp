@@ -195,9 +195,48 @@ void spin_observation(const Tensor& state, const OptTensor& matrix, bool binary_
     TORCH_CHECK(state.dim() == 3 && out.dim() == 3, "state must be [B, R, N], out [B, R (+ N), N]");
     const int64_t B = state.size(0), R = state.size(1), N = state.size(2);
     TORCH_CHECK(out.size(0) == B && out.size(2) == N && out.size(1) == R + (matrix.has_value() ? N : 0), "out has the wrong shape");
-    if (matrix.has_value()) TORCH_CHECK(matrix->dim() == 2 && matrix->size(0) == N && matrix->size(1) == N, "matrix must be [N, N]");
+    bool per_env = false;
+    if (matrix.has_value()) {
+        per_env = matrix->dim() == 3;
+        TORCH_CHECK((matrix->dim() == 2 || (per_env && matrix->size(0) == B)) && matrix->size(-2) == N && matrix->size(-1) == N,
+                    "matrix must be [N, N] or [B, N, N]");
+    }
     const int sb = state.scalar_type() == F64 ? 8 : 4;
-    ok(rls_spin_observation(p(state), p(matrix), sb, B, (int32_t)R, N, binary_basis, p(out), cur_stream(state)), "rls_spin_observation");
+    ok(rls_spin_observation(p(state), p(matrix), per_env, sb, B, (int32_t)R, N, binary_basis, p(out), cur_stream(state)), "rls_spin_observation");
+}
+void spin_reset_dense(const Tensor& matrix, int64_t env, const Tensor& state, const Tensor& row_index, Tensor max_local, Tensor weight_sum,
+                      Tensor flags) {
+    dev(state, "state");
+    dev(matrix, "matrix", state.scalar_type());
+    dev(max_local, "max_local", state.scalar_type());
+    dev(weight_sum, "weight_sum", state.scalar_type());
+    dev(flags, "flags", U8);
+    TORCH_CHECK(!row_index.is_cuda() && row_index.scalar_type() == I32 && row_index.numel() == 7, "row_index must be a host int32[7]");
+    const int64_t B = state.size(0), N = state.size(2);
+    TORCH_CHECK(matrix.dim() == 3 && matrix.size(0) == B && matrix.size(1) == N && matrix.size(2) == N, "matrix must be [B, N, N]");
+    TORCH_CHECK(max_local.numel() == B && weight_sum.numel() == B && flags.numel() == B, "max_local / weight_sum / flags must hold B entries");
+    const int sb = state.scalar_type() == F64 ? 8 : 4;
+    ok(rls_spin_reset_dense(p(matrix), reinterpret_cast<const rls_spin_env*>(env), sb, B, N, (int32_t)state.size(1), (const int32_t*)p(row_index),
+                            p(max_local), p(weight_sum), (uint8_t*)p(flags), cur_stream(state)), "rls_spin_reset_dense");
+}
+void spin_step_dense(const Tensor& matrix, const Tensor& max_local, int64_t env, const Tensor& state, const Tensor& row_index, const Tensor& action,
+                     Tensor reward, const OptTensor& visited_new, double time_inc, double termination_value, int64_t reward_mode,
+                     double reward_div, int64_t hist_len, bool use_stag, double stag_punishment, bool use_basin, double basin_reward) {
+    dev(state, "state");
+    dev(matrix, "matrix", state.scalar_type());
+    dev(max_local, "max_local", state.scalar_type());
+    dev(action, "action", I64);
+    dev(reward, "reward", state.scalar_type());
+    optdev(visited_new, "visited_new", U8);
+    TORCH_CHECK(!row_index.is_cuda() && row_index.scalar_type() == I32 && row_index.numel() == 7, "row_index must be a host int32[7]");
+    const int64_t B = state.size(0), N = state.size(2);
+    TORCH_CHECK(matrix.dim() == 3 && matrix.size(0) == B && matrix.size(1) == N && matrix.size(2) == N, "matrix must be [B, N, N]");
+    TORCH_CHECK(max_local.numel() == B && action.numel() == B && reward.numel() == B, "max_local / action / reward must hold B entries");
+    const int sb = state.scalar_type() == F64 ? 8 : 4;
+    ok(rls_spin_step_dense(p(matrix), p(max_local), reinterpret_cast<const rls_spin_env*>(env), sb, B, N, (int32_t)state.size(1),
+                           (const int32_t*)p(row_index), (const int64_t*)p(action), p(reward), (uint8_t*)p(visited_new), time_inc, termination_value,
+                           (int32_t)reward_mode, reward_div, hist_len, use_stag, stag_punishment, use_basin, basin_reward, cur_stream(state)),
+       "rls_spin_step_dense");
 }
 void spin_step(int64_t g, int64_t env, const Tensor& state, const Tensor& row_index, const Tensor& action, Tensor reward,
                const OptTensor& visited_new, double max_local, double time_inc, double termination_value, int64_t reward_mode,
@@ -436,6 +475,10 @@ TORCH_LIBRARY(rlsolver_hip, m) {
     m.def("rand_perms(Tensor(a!) perm, int seed, int env_offset) -> ()");
     m.def("spin_reset(int graph, int env, Tensor(a!) state, Tensor row_index, float max_local, int weight_sum) -> ()");
     m.def("spin_observation(Tensor state, Tensor? matrix, bool binary_basis, Tensor(a!) out) -> ()");
+    m.def("spin_reset_dense(Tensor matrix, int env, Tensor(a!) state, Tensor row_index, Tensor(b!) max_local, Tensor(c!) weight_sum, Tensor(d!) flags) -> ()");
+    m.def("spin_step_dense(Tensor matrix, Tensor max_local, int env, Tensor(a!) state, Tensor row_index, Tensor action, Tensor(b!) reward, "
+          "Tensor(c!)? visited_new, float time_inc, float termination_value, int reward_mode, float reward_div, int hist_len, bool use_stag, "
+          "float stag_punishment, bool use_basin, float basin_reward) -> ()");
     m.def("spin_step(int graph, int env, Tensor(a!) state, Tensor row_index, Tensor action, Tensor(b!) reward, Tensor(c!)? visited_new, "
           "float max_local, float time_inc, float termination_value, int reward_mode, float reward_div, int hist_len, bool use_stag, "
           "float stag_punishment, bool use_basin, float basin_reward) -> ()");
@@ -487,6 +530,8 @@ TORCH_LIBRARY_IMPL(rlsolver_hip, CUDA, m) {   // "CUDA" is the HIP dispatch key 
     m.impl("rand_perms", &rand_perms);
     m.impl("spin_reset", &spin_reset);
     m.impl("spin_observation", &spin_observation);
+    m.impl("spin_reset_dense", &spin_reset_dense);
+    m.impl("spin_step_dense", &spin_step_dense);
     m.impl("spin_step", &spin_step);
     m.impl("mcpg_metro_rounds", &mcpg_metro_rounds);
     m.impl("mcpg_local_search", &mcpg_local_search);

@@ -1,5 +1,6 @@
 """SpinSystem -- the S2V / ECO / PECO environment surface (SURVEY.md section 8b "S2V/ECO obs
-contract", 8f item 1) for ONE shared signed-weight graph, on a HIP device.
+contract", 8f item 1) on a HIP device, for ONE shared signed-weight graph (instance-wise inference)
+or, with ``graph_generator=``, for per-env couplings matrix [B, N, N] redrawn at every reset (training).
 
 Mirrors the batched env of rlsolver/methods/ECO_S2V/src/envs/spinsystem_PECO.py (class
 SpinSystemUnbiased) and its instance-wise inference twin inference_network_env.py:
@@ -18,6 +19,11 @@ basin_reward (HistoryBuffer, util_envs_PECO.py:228-288: bit-packed states of the
 pre-allocated [B, max_steps, N/64] ring, exact compare behind a Zobrist-hash pre-filter) are ONE HIP
 kernel per step (rls_spin_step); reset is the K3 gain kernel + rls_spin_reset.  Edge weights must
 be integers (EdgeType.DISCRETE / unweighted).
+
+Training envs: ``SpinSystem(None, None, num_envs, graph_generator=gg, ...)`` keeps what the reference's training env keeps --
+``gg.get()`` (a float tensor [B, N, N] on the device; ``gg.n_spins``) is called at every reset, graphs the reference would
+reject (no edges / zero max local reward) are drawn again -- and steps with rls_spin_step_dense: the flipped node's row of
+its env's matrix is the neighbour list, max_local_reward_available is per env.  Generators: envs/util_envs_PECO.py.
 
 ``dtype=torch.float64`` gives the arithmetic of the reference's numpy env
 (ECO_S2V/src/envs/spinsystem.py); ``SpinSystemUnbiased`` below is that env's single-instance surface.
@@ -85,12 +91,12 @@ class SpinSystem:
         def __init__(self, n_spins, n_observables):
             self.shape = [n_spins, n_observables]
 
-    def __init__(self, mygraph, num_nodes: int, num_envs: int, max_steps: int = 20,
+    def __init__(self, mygraph, num_nodes: Optional[int], num_envs: int, max_steps: int = 20,
                  observables: Sequence[Observable] = ECO_PECO_OBSERVABLES,
                  reward_signal: RewardSignal = RewardSignal.DENSE, spin_basis: SpinBasis = SpinBasis.SIGNED,
                  norm_rewards: bool = False, horizon_length: Optional[int] = None,
                  stag_punishment: Optional[float] = None, basin_reward: Optional[float] = None,
-                 device=None, include_adjacency: bool = True, dtype=torch.float32):
+                 device=None, include_adjacency: bool = True, dtype=torch.float32, graph_generator=None):
         self.device = torch.device(device if device is not None else "cuda:0")
         if self.device.type != "cuda":
             raise TypeError(f"rlsolver_amd.SpinSystem needs a HIP device (got {self.device}); there is no CPU path")
@@ -102,6 +108,10 @@ class SpinSystem:
         if reward_signal not in _REWARD_MODE:
             raise NotImplementedError(f"reward_signal {reward_signal} is not supported on the batched env")
         self.observables = list(enumerate(observables))
+        if graph_generator is not None:
+            if mygraph is not None:
+                raise ValueError("pass either mygraph (one shared graph) or graph_generator (per-env matrices)")
+            num_nodes = int(graph_generator.n_spins) if num_nodes is None else num_nodes
         self.num_envs, self.n_spins, self.max_steps = num_envs, num_nodes, max_steps
         self.n_actions = num_nodes                       # extra_action = NONE
         self.reward_signal, self.norm_rewards, self.spin_basis = reward_signal, norm_rewards, spin_basis
@@ -111,20 +121,32 @@ class SpinSystem:
         self.include_adjacency = include_adjacency
         self.action_space = self._ActionSpace(self.n_actions, self.device)
         self.observation_space = self._ObservationSpace(self.n_spins, len(observables))
-        csr = build_csr(mygraph, num_nodes=num_nodes, if_bidirectional=False)
-        if np.any(csr.wgt != csr.wgt.astype(np.int32)):
-            raise ValueError("SpinSystem needs integer edge weights")
-        self.graph = ops.DeviceGraph(csr, self.device, use_weights=True)
-        wdeg = np.zeros(num_nodes, np.int64)
-        np.add.at(wdeg, np.repeat(np.arange(num_nodes), np.diff(csr.rowptr)), csr.wgt)
-        self._max_local = float(wdeg.max())              # host copy: reading it back from the device synced every step
-        self.max_local_reward_available_ = torch.full((num_envs,), self._max_local, device=self.device, dtype=dtype)
-        if float(wdeg.max()) == 0.0 or np.abs(wdeg).sum() == 0:
-            raise ValueError("empty graph / zero max local reward (the reference re-draws the graph here)")
+        self.gg = graph_generator
+        self._dense = graph_generator is not None
+        if self._dense:
+            if getattr(graph_generator, "biased", False):
+                raise NotImplementedError("biased graph generators are not supported")
+            self.graph = None
+            self._matrix = None
+            self._max_local = None
+            self.max_local_reward_available_ = torch.ones(num_envs, device=self.device, dtype=dtype)
+            self._weight_sum_env = torch.zeros(num_envs, device=self.device, dtype=dtype)
+            self._flags = torch.zeros(num_envs, device=self.device, dtype=torch.uint8)
+        else:
+            csr = build_csr(mygraph, num_nodes=num_nodes, if_bidirectional=False)
+            if np.any(csr.wgt != csr.wgt.astype(np.int32)):
+                raise ValueError("SpinSystem needs integer edge weights")
+            self.graph = ops.DeviceGraph(csr, self.device, use_weights=True)
+            wdeg = np.zeros(num_nodes, np.int64)
+            np.add.at(wdeg, np.repeat(np.arange(num_nodes), np.diff(csr.rowptr)), csr.wgt)
+            self._max_local = float(wdeg.max())          # host copy: reading it back from the device synced every step
+            self.max_local_reward_available_ = torch.full((num_envs,), self._max_local, device=self.device, dtype=dtype)
+            if float(wdeg.max()) == 0.0 or np.abs(wdeg).sum() == 0:
+                raise ValueError("empty graph / zero max local reward (the reference re-draws the graph here)")
+            self._matrix = None
+            self._weight_sum = int(csr.wgt.sum())         # sum of W over ordered pairs
         self.max_local_reward_available = self.max_local_reward_available_.unsqueeze(1).expand(-1, num_nodes)
         self._rows = (C.c_int32 * 7)(*[next((i for i, o in self.observables if o == want), -1) for want in _ROW_ORDER])
-        self._matrix = None
-        self._weight_sum = int(csr.wgt.sum())             # sum of W over ordered pairs
         R, B, N = len(observables), num_envs, num_nodes
         dt = self.dtype
         self.state = torch.zeros((B, R, N), dtype=dt, device=self.device)
@@ -156,6 +178,7 @@ class SpinSystem:
     # ---- dense adjacency only when somebody asks for it (N^2 floats)
     @property
     def matrix(self):
+        """[N, N] (shared graph) or [B, N, N] (graph_generator): the couplings in the env's float type."""
         if self._matrix is None:
             csr = self.graph.csr
             m = np.zeros((self.n_spins, self.n_spins), dtype=np.float64)
@@ -164,6 +187,12 @@ class SpinSystem:
         return self._matrix
 
     matrix_obs = matrix
+
+    def _draw_matrix(self):
+        m = torch.as_tensor(self.gg.get(), device=self.device).to(self.dtype).contiguous()
+        if m.shape != (self.num_envs, self.n_spins, self.n_spins):
+            raise ValueError(f"graph_generator.get() must return [{self.num_envs}, {self.n_spins}, {self.n_spins}], got {tuple(m.shape)}")
+        return m
 
     def _round(self, v: float) -> float:
         """A host scalar as the env's float type sees it (the f32 env rounds python floats to f32 first)."""
@@ -183,10 +212,25 @@ class SpinSystem:
             signed = (2 * spins - 1) if (self.spin_basis == SpinBasis.BINARY and spins.min() >= 0) else spins
             bits = (signed > 0).contiguous()
         self.state[:, 0, :] = 2 * bits.to(self.dtype) - 1
-        # gains of all single flips: delta_i = s_i sum_j W_ij s_j = sum_j W_ij (x_i == x_j ? 1 : -1): the K3 kernel
-        ops.maxcut_delta_all(self.graph, bits, out=self._delta)
-        _abi.call("rls_spin_reset", self.graph.ref, C.byref(self._env), self._sb, B, self.state.shape[1], self._rows,
-                  self._max_local, self._weight_sum, _stream(self.device))
+        if self._dense:
+            # a fresh matrix per env (spinsystem_PECO.py:150-170); graphs the reference rejects are drawn again
+            for _ in range(64):
+                self._matrix = self._draw_matrix()
+                _abi.call("rls_spin_reset_dense", _ptr(self._matrix), C.byref(self._env), self._sb, B, N, self.state.shape[1],
+                          self._rows, _ptr(self.max_local_reward_available_), _ptr(self._weight_sum_env), _ptr(self._flags),
+                          _stream(self.device))
+                flags = int(self._flags.max())            # the one host read of a reset (the reference's .any() tests)
+                if flags & 2:
+                    raise ValueError("graph_generator.get() must return symmetric integer-valued matrices")
+                if not flags & 1:
+                    break
+            else:
+                raise ValueError("graph_generator keeps producing empty graphs / zero max local reward")
+        else:
+            # gains of all single flips: delta_i = s_i sum_j W_ij s_j = sum_j W_ij (x_i == x_j ? 1 : -1): the K3 kernel
+            ops.maxcut_delta_all(self.graph, bits, out=self._delta)
+            _abi.call("rls_spin_reset", self.graph.ref, C.byref(self._env), self._sb, B, self.state.shape[1], self._rows,
+                      self._max_local, self._weight_sum, _stream(self.device))
         self.best_obs_score = self.best_score
         self.best_obs_spins = self.best_spins
         return self.get_observation()
@@ -196,7 +240,8 @@ class SpinSystem:
         exact in integers."""
         if spins is not None:
             raise NotImplementedError("calculate_cut(spins) for foreign spins: use rlsolver_amd.ops.maxcut_obj")
-        return (self._weight_sum - self._delta.sum(dim=1)).to(self.dtype) / 4
+        wsum = self._weight_sum_env.to(torch.int64) if self._dense else self._weight_sum
+        return (wsum - self._delta.sum(dim=1)).to(self.dtype) / 4
 
     def calculate_score(self, spins=None):
         return self.calculate_cut(spins)
@@ -215,12 +260,18 @@ class SpinSystem:
             term = float(max(np.float32(0.0), np.float32((self.current_step - self.max_steps) / self.horizon_length) + np.float32(1)))
         else:
             term = max(0.0, ((self.current_step - self.max_steps) / self.horizon_length) + 1)
-        _abi.call("rls_spin_step", self.graph.ref, C.byref(self._env), self._sb, B, self.state.shape[1], self._rows,
-                  _ptr(action), _ptr(rew), _ptr(self._visited_new), self._max_local, self._round(1.0 / self.max_steps), term,
-                  _REWARD_MODE[self.reward_signal], float(self.n_spins) if self.norm_rewards else 1.0,
-                  self.current_step - 1, int(self.stag_punishment is not None),
-                  self._round(self.stag_punishment or 0.0), int(self.basin_reward is not None),
-                  self._round(self.basin_reward or 0.0), _stream(self.device))
+        tail = (_REWARD_MODE[self.reward_signal], float(self.n_spins) if self.norm_rewards else 1.0,
+                self.current_step - 1, int(self.stag_punishment is not None),
+                self._round(self.stag_punishment or 0.0), int(self.basin_reward is not None),
+                self._round(self.basin_reward or 0.0), _stream(self.device))
+        if self._dense:
+            _abi.call("rls_spin_step_dense", _ptr(self._matrix), _ptr(self.max_local_reward_available_), C.byref(self._env),
+                      self._sb, B, self.n_spins, self.state.shape[1], self._rows, _ptr(action), _ptr(rew), _ptr(self._visited_new),
+                      self._round(1.0 / self.max_steps), term, *tail)
+        else:
+            _abi.call("rls_spin_step", self.graph.ref, C.byref(self._env), self._sb, B, self.state.shape[1], self._rows,
+                      _ptr(action), _ptr(rew), _ptr(self._visited_new), self._max_local, self._round(1.0 / self.max_steps), term,
+                      *tail)
         done = torch.full((B,), self.current_step == self.max_steps, dtype=torch.bool, device=self.device)
         return self.get_observation(), rew, done
 
@@ -236,7 +287,7 @@ class SpinSystem:
         elif out.shape != (B, rows, N) or out.dtype != self.dtype or not out.is_contiguous():
             raise ValueError(f"out must be a contiguous {self.dtype} tensor of shape {(B, rows, N)}")
         _abi.call("rls_spin_observation", _ptr(self.state), _ptr(self.matrix if self.include_adjacency else None),
-                  8 if self.dtype == torch.float64 else 4, B, R, N, int(self.spin_basis == SpinBasis.BINARY), _ptr(out),
+                  int(self._dense), 8 if self.dtype == torch.float64 else 4, B, R, N, int(self.spin_basis == SpinBasis.BINARY), _ptr(out),
                   _stream(self.device))
         return out
 
@@ -251,16 +302,17 @@ class SpinSystem:
 
     # ---- checkpoint of the env state: everything a later step depends on
     _STATE_KEYS = ("state", "_delta", "score", "best_score", "best_spins", "_num_nonpos", "_dist_best")
+    _DENSE_KEYS = ("_matrix", "max_local_reward_available_", "_weight_sum_env")
     _HIST_KEYS = ("_packed", "_hash", "_hist", "_hist_hash")
 
     def state_dict(self):
-        keys = self._STATE_KEYS + (self._HIST_KEYS if self._use_hist else ())
+        keys = self._STATE_KEYS + (self._HIST_KEYS if self._use_hist else ()) + (self._DENSE_KEYS if self._dense else ())
         d = {k.lstrip("_"): getattr(self, k).clone() for k in keys}
         d["current_step"] = self.current_step
         return d
 
     def load_state_dict(self, d):
-        keys = self._STATE_KEYS + (self._HIST_KEYS if self._use_hist else ())
+        keys = self._STATE_KEYS + (self._HIST_KEYS if self._use_hist else ()) + (self._DENSE_KEYS if self._dense else ())
         for k in keys:
             getattr(self, k).copy_(d[k.lstrip("_")])     # in place: the kernel's pointer table stays valid
         self.current_step = int(d["current_step"])

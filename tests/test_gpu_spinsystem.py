@@ -44,6 +44,79 @@ def test_spinsystem_golden(golden, gname, cname):
         env.step(torch.zeros(6, dtype=torch.int64, device=DEV))     # already done, like the reference
 
 
+@pytest.mark.parametrize("gname", ["ba20", "er24", "ba40u"])
+@pytest.mark.parametrize("cname", ["eco", "stag", "dense"])
+def test_spinsystem_per_env_matrices_golden(golden, gname, cname):
+    """The training form of the env (graph_generator=: a couplings matrix per env) against traces of the reference's PECO env
+    on graphs drawn by the reference's own BA / ER generators -- BA's seed clique carries self-loops, which the reference
+    counts in its own way (score change delta_a - 2 W_aa): observations (matrix rows included), rewards, scores, best."""
+    from rlsolver_amd.envs.spinsystem import ECO_PECO_OBSERVABLES, RewardSignal, SpinBasis, SpinSystem
+    z = golden("spinsystem_perenv")
+    tag = f"{gname}/{cname}"
+    m = z[f"{tag}/matrix"]
+    B, n, _ = m.shape
+
+    class Recorded:
+        n_spins, biased, calls = n, False, 0
+
+        def get(self):
+            Recorded.calls += 1
+            return torch.from_numpy(m).to(DEV)
+
+    cfg = {"eco": dict(reward_signal=RewardSignal.BLS, norm_rewards=True, basin_reward=1.0 / n),
+           "stag": dict(reward_signal=RewardSignal.CUSTOM_BLS, norm_rewards=False, basin_reward=0.25, stag_punishment=0.125),
+           "dense": dict(reward_signal=RewardSignal.DENSE, norm_rewards=False, basin_reward=None)}[cname]
+    env = SpinSystem(None, None, B, max_steps=2 * n, observables=ECO_PECO_OBSERVABLES, spin_basis=SpinBasis.BINARY, device=DEV,
+                     graph_generator=Recorded(), **cfg)
+    assert env.n_spins == n and Recorded.calls == 1
+    obs = env.reset(spins=torch.from_numpy(z[f"{tag}/spins0"]))
+    assert Recorded.calls == 2                                                  # a fresh draw per reset, as the reference
+    assert np.array_equal(env.max_local_reward_available_.cpu().numpy(), z[f"{tag}/max_local"])
+    assert np.array_equal(obs.cpu().numpy(), z[f"{tag}/obs0"])
+    assert np.array_equal(env.score.cpu().numpy(), z[f"{tag}/score0"])
+    assert np.array_equal(env.calculate_cut().cpu().numpy(), z[f"{tag}/score0"])
+    for t in range(2 * n):
+        o, r, d = env.step(torch.from_numpy(z[f"{tag}/actions"][t]).to(DEV))
+        assert np.array_equal(o[:, :7].cpu().numpy(), z[f"{tag}/obs"][t]), t
+        assert np.array_equal(r.cpu().numpy(), z[f"{tag}/rew"][t]), t
+        assert np.array_equal(env.score.cpu().numpy(), z[f"{tag}/score"][t])
+        assert np.array_equal(env.get_best_cut().cpu().numpy(), z[f"{tag}/best_score"][t])
+    assert np.array_equal(o.cpu().numpy(), z[f"{tag}/last_obs"]) and bool(d.all())
+    assert np.array_equal(env.best_spins.cpu().numpy(), z[f"{tag}/best_spins"])
+
+
+def test_spinsystem_per_env_matrices_rejections():
+    """Empty graphs are drawn again (spinsystem_PECO.py:164-169); matrices the integer gain cache cannot hold raise."""
+    from rlsolver_amd.envs.spinsystem import SpinSystem
+    n, B = 16, 5
+    rng = np.random.RandomState(0)
+    good = np.triu((rng.rand(B, n, n) < 0.3).astype(np.float32), 1)
+    good = good + good.transpose(0, 2, 1)
+
+    class Gen:
+        n_spins, biased = n, False
+
+        def __init__(self, seq):
+            self.seq, self.calls = seq, 0
+
+        def get(self):
+            self.calls += 1
+            return torch.from_numpy(self.seq[min(self.calls, len(self.seq)) - 1]).to(DEV)
+
+    empty = good.copy()
+    empty[3] = 0
+    g = Gen([empty, empty, good])
+    env = SpinSystem(None, None, B, graph_generator=g, device=DEV)
+    assert g.calls == 3 and torch.equal(env.matrix, torch.from_numpy(good).to(DEV))
+    for bad in (good * 0.5, np.triu(good)):
+        with pytest.raises(ValueError):
+            SpinSystem(None, None, B, graph_generator=Gen([bad.astype(np.float32)]), device=DEV)
+    with pytest.raises(ValueError):
+        SpinSystem(None, None, B, graph_generator=Gen([empty]), device=DEV)
+    with pytest.raises(ValueError):
+        SpinSystem([(0, 1, 1)], 2, B, graph_generator=Gen([good]), device=DEV)
+
+
 def test_spinsystem_large_consistency():
     """Incremental gain cache == recomputation, score == cut, on a G22-sized unweighted graph."""
     from rlsolver_amd import ops

@@ -746,6 +746,63 @@ def gen_spinsystem():
     save("spinsystem", **out)
 
 
+def gen_spinsystem_perenv():
+    """The batched PECO SpinSystem as its TRAINING loop builds it: per-env couplings drawn by the reference's own generators
+    (util_envs_PECO.py RandomBAGraphGenerator -- whose seed clique carries self-loops -- and RandomERGraphGenerator, on the
+    CPU, seeded), two configs each; the drawn matrix [B, N, N] is recorded with the trace."""
+    from rlsolver.methods.ECO_S2V.src.envs import spinsystem_PECO as sp
+    from rlsolver.methods.ECO_S2V.src.envs import util_envs_PECO as up
+    from rlsolver.methods.ECO_S2V.src.envs.util_envs import (ECO_PECO_OBSERVABLES, EdgeType, ExtraAction, OptimisationTarget,
+                                                             RewardSignal, SpinBasis)
+    out = {}
+    B = 6
+    gens = {"ba20": lambda: up.RandomBAGraphGenerator(n_spins=20, m_insertion_edges=4, edge_type=EdgeType.DISCRETE, num_envs=B, device="cpu"),
+            "er24": lambda: up.RandomERGraphGenerator(n_spins=24, p_connection=0.15, edge_type=EdgeType.RANDOM, num_envs=B, device="cpu"),
+            "ba40u": lambda: up.RandomBAGraphGenerator(n_spins=40, m_insertion_edges=4, edge_type=EdgeType.UNIFORM, num_envs=B, device="cpu")}
+    cfgs = {"eco": dict(reward_signal=RewardSignal.BLS, norm_rewards=True, basin_reward=None),
+            "stag": dict(reward_signal=RewardSignal.CUSTOM_BLS, norm_rewards=False, basin_reward=0.25, stag_punishment=0.125),
+            "dense": dict(reward_signal=RewardSignal.DENSE, norm_rewards=False, basin_reward=None)}
+    for gname, mk in gens.items():
+        for cname, cfg in cfgs.items():
+            th.manual_seed(11)
+            gg = mk()
+            n = gg.n_spins
+            max_steps = 2 * n
+            env = sp.SpinSystemFactory.get(gg, max_steps, observables=ECO_PECO_OBSERVABLES, extra_action=ExtraAction.NONE,
+                                           optimisation_target=OptimisationTarget.CUT, spin_basis=SpinBasis.BINARY,
+                                           memory_length=None, horizon_length=None, reversible_spins=True, device=th.device("cpu"),
+                                           num_envs=B, **{"stag_punishment": None, **cfg})
+            if cname == "eco":
+                env.basin_reward = 1.0 / n
+                env.reset()
+            tag = f"{gname}/{cname}"
+            out[f"{tag}/matrix"] = env.matrix.numpy().copy()
+            out[f"{tag}/spins0"] = env.state[:, 0, :].numpy().copy()
+            out[f"{tag}/obs0"] = env.get_observation().numpy().copy()
+            out[f"{tag}/score0"] = env.score.numpy().copy()
+            out[f"{tag}/max_local"] = env.max_local_reward_available_.numpy().copy()
+            g = th.Generator().manual_seed(19)
+            acts, obs, rews, scores, bests = [], [], [], [], []
+            for t in range(max_steps):
+                a = th.randint(0, n, (B,), generator=g)
+                if t % 5 == 1:
+                    a[:] = t % 5            # the seed clique's self-loop nodes get flipped too
+                if cname == "stag" and t % 3 == 2:
+                    a = acts_prev.clone()
+                acts_prev = a
+                o, r, d = env.step(a)
+                acts.append(a.numpy().copy()); obs.append(o[:, :7, :].numpy().copy()); rews.append(r.numpy().copy())
+                scores.append(env.score.numpy().copy()); bests.append(env.best_score.numpy().copy())
+            out[f"{tag}/last_obs"] = o.numpy().copy()
+            out[f"{tag}/actions"] = np.stack(acts)
+            out[f"{tag}/obs"] = np.stack(obs)
+            out[f"{tag}/rew"] = np.stack(rews)
+            out[f"{tag}/score"] = np.stack(scores)
+            out[f"{tag}/best_score"] = np.stack(bests)
+            out[f"{tag}/best_spins"] = env.best_spins.numpy().copy()
+    save("spinsystem_perenv", **out)
+
+
 def gen_spinsystem_cpu():
     """the numpy single-instance env (ECO_S2V/src/envs/spinsystem.py:333-482,
     SpinSystemUnbiased :588-661) in float64 on a fixed +-1-weighted graph: per step the full 7-row state, the all-node
@@ -924,7 +981,7 @@ def gen_isco_steps():
     save("isco_steps", **out)
 
 
-ALL = {"mcpg_weighted": gen_mcpg_weighted, "isco_steps": gen_isco_steps, "spinsystem_cpu": gen_spinsystem_cpu, "spinsystem": gen_spinsystem, "qubo": gen_qubo, "isco_maxcut": gen_isco_maxcut, "maxcut": gen_maxcut, "sweep": gen_sweep, "lsclass": gen_local_search_class, "ppo": gen_ppo,
+ALL = {"mcpg_weighted": gen_mcpg_weighted, "isco_steps": gen_isco_steps, "spinsystem_cpu": gen_spinsystem_cpu, "spinsystem": gen_spinsystem, "spinsystem_perenv": gen_spinsystem_perenv, "qubo": gen_qubo, "isco_maxcut": gen_isco_maxcut, "maxcut": gen_maxcut, "sweep": gen_sweep, "lsclass": gen_local_search_class, "ppo": gen_ppo,
        "select": gen_select, "mcpg": gen_mcpg, "tsp": gen_tsp, "tsp_2opt": gen_tsp_2opt, "encoder": gen_encoder,
        "wgain": gen_weighted_gain}
 
