@@ -312,6 +312,18 @@ int rls_spin_step_dense(const void* matrix, const void* max_local, const rls_spi
                         double time_inc, double termination_value, int32_t reward_mode, double reward_div, int64_t hist_len,
                         int32_t use_stag, double stag_punishment, int32_t use_basin, double basin_reward, void* stream);
 
+/* The graph generators of the training envs  ECO_S2V/src/envs/util_envs_PECO.py:15-112 in one launch: matrix T [B, N, N]
+ * (state_bytes 4 | 8), symmetric, entries 0 / +-1.
+ *   kind 0  RandomERGraphGenerator (:42-57): every pair i < j is an edge with probability p_connection; zero diagonal.
+ *   kind 1  RandomBAGraphGenerator (:84-113): seed clique on nodes 0..m INCLUDING its self-loops (as :93-95 sets them), each later
+ *           node attached to m_insertion_edges distinct earlier nodes in proportion to their degree (torch.multinomial without
+ *           replacement there; uniform draws over the edge-endpoint list with duplicates redrawn here: the same distribution).
+ *   edge_type 1 UNIFORM (+1), 2 DISCRETE (one +-1 per node pair, shared by all envs of the call), 3 RANDOM (+-1 per pair and env).
+ * Build-defined counter-based draws keyed by (seed, env_offset + b): distributionally equivalent to the reference's torch
+ * streams, independent of how the batch is sharded.  N < 65536; kind 1 needs N * m * 6 B of LDS. */
+int rls_rand_couplings(void* matrix, int state_bytes, int64_t B, int64_t N, int32_t kind, double p_connection, int32_t m_insertion_edges,
+                       int32_t edge_type, uint64_t seed, int64_t env_offset, void* stream);
+
 /* get_observation()  ECO_S2V/src/envs/spinsystem_PECO.py:455,497 (cat(state, matrix_obs)) and spinsystem.py:484-495
  * (vstack(state, matrix)): out T [B, num_rows + N, N] = the num_rows observable rows of state T [B, num_rows, N], row 0
  * mapped from signed spins to (1 - s) / 2 when binary_basis (SpinBasis.BINARY), followed by the N rows of the matrix:

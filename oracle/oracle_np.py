@@ -293,6 +293,69 @@ def rand_actions(B, N, seed, step, env_offset=0):
     return ((r0 * np.uint64(N)) >> np.uint64(32)).astype(np.int64)
 
 
+def _coupling_signs(edge_type, seed, gb, lo, hi):
+    """+-1 per (env gb, pair lo <= hi) as rls_rand_couplings draws it: UNIFORM (1) +1; DISCRETE (2) Philox(seed; lo, hi, 0,
+    'SIGN') shared by the envs; RANDOM (3) Philox(seed; gb_lo, gb_hi, lo * 65536 + hi, 'SIGO'); bit 0 set -> +1."""
+    k0, k1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+    gb, lo, hi = np.broadcast_arrays(np.asarray(gb, np.uint64), np.asarray(lo, np.uint64), np.asarray(hi, np.uint64))
+    if edge_type == 1:
+        return np.ones(gb.shape)
+    if edge_type == 2:
+        r0 = philox4x32_10(k0, k1, lo, hi, np.zeros_like(lo), np.uint64(0x5349474E))[0]
+    else:
+        r0 = philox4x32_10(k0, k1, gb & np.uint64(0xFFFFFFFF), gb >> np.uint64(32), lo * np.uint64(65536) + hi, np.uint64(0x5349474F))[0]
+    return np.where(r0 & np.uint64(1), 1.0, -1.0)
+
+
+def rand_couplings_er(B, N, p_connection, edge_type, seed, env_offset=0):
+    """rls_rand_couplings kind 0 (the distribution of RandomERGraphGenerator, util_envs_PECO.py:42-57): pair i < j of env gb is
+    an edge iff Philox(seed; gb_lo, gb_hi, i * 65536 + j, 'ERGP')[0] < floor(p * 2^32)."""
+    gb = (np.arange(B, dtype=np.uint64) + np.uint64(env_offset))[:, None, None]
+    i, j = np.meshgrid(np.arange(N, dtype=np.uint64), np.arange(N, dtype=np.uint64), indexing="ij")
+    lo, hi = np.minimum(i, j)[None], np.maximum(i, j)[None]
+    r0 = philox4x32_10(seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF, gb & np.uint64(0xFFFFFFFF) + 0 * lo, (gb >> np.uint64(32)) + 0 * lo,
+                       lo * np.uint64(65536) + hi + 0 * gb, np.uint64(0x45524750))[0]
+    thr = min(int(p_connection * 4294967296.0), 0xFFFFFFFF)
+    edge = ((r0 < np.uint64(thr)) | (p_connection >= 1.0)) & (lo != hi)
+    return np.where(edge, _coupling_signs(edge_type, seed, gb, lo, hi), 0.0)
+
+
+def rand_couplings_ba(B, N, m, edge_type, seed, env_offset=0):
+    """rls_rand_couplings kind 1 (the distribution of RandomBAGraphGenerator, util_envs_PECO.py:84-113): clique on 0..m with
+    self-loops; node v > m draws list positions idx = (r * L) >> 32, L = (m+1)^2 + 2m(v-m-1), with the 32-bit draws
+    r = Philox(seed; gb_lo, gb_hi, v * 4096 + a // 4, 'BAGR')[a % 4], a = 0, 1, ...; position idx is clique node idx // (m+1)
+    below (m+1)^2, else endpoint rr = q % 2m of node vv = m+1 + q // 2m (q = idx - (m+1)^2): target[vv][rr] if rr < m else vv;
+    duplicates are drawn again until m distinct targets are found."""
+    k0, k1 = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+    out = np.zeros((B, N, N))
+    L0 = (m + 1) * (m + 1)
+    for b in range(B):
+        gb = b + env_offset
+        tgt = np.zeros((N, m), dtype=np.int64)
+        for v in range(m + 1, N):
+            L = L0 + 2 * m * (v - m - 1)
+            chosen, a = [], 0
+            while len(chosen) < m:
+                if a % 4 == 0:
+                    r = [int(x) for x in philox4x32_10(k0, k1, gb & 0xFFFFFFFF, gb >> 32, v * 4096 + a // 4, 0x42414752)]
+                idx = (r[a % 4] * L) >> 32
+                a += 1
+                if idx < L0:
+                    node = idx // (m + 1)
+                else:
+                    q = idx - L0
+                    vv, rr = m + 1 + q // (2 * m), q % (2 * m)
+                    node = int(tgt[vv, rr]) if rr < m else vv
+                if node not in chosen:
+                    chosen.append(node)
+            tgt[v] = chosen
+        pairs = [(i, j) for i in range(m + 1) for j in range(m + 1)] + [(int(tgt[v, r]), v) for v in range(m + 1, N) for r in range(m)]
+        for i, j in pairs:
+            w = float(_coupling_signs(edge_type, seed, gb, min(i, j), max(i, j)))
+            out[b, i, j] = out[b, j, i] = w
+    return out
+
+
 # --------------------------------------------------------------------------- MCPG
 
 

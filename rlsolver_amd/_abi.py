@@ -89,6 +89,7 @@ SIGNATURES = {
     "rls_rand_spins": [_P, _I64, _I64, _U64, _I64, _P],
     "rls_rand_actions": [_P, _I64, _I64, _U64, _U64, _I64, _P],
     "rls_spin_observation": [_P, _P, C.c_int32, _INT, _I64, C.c_int32, _I64, C.c_int32, _P, _P],
+    "rls_rand_couplings": [_P, _INT, _I64, _I64, C.c_int32, _F64, C.c_int32, C.c_int32, _U64, _I64, _P],
     "rls_spin_reset_dense": [_P, _SE, _INT, _I64, _I64, C.c_int32, _P, _P, _P, _P, _P],
     "rls_spin_step_dense": [_P, _P, _SE, _INT, _I64, _I64, C.c_int32, _P, _P, _P, _P, _F64, _F64, C.c_int32, _F64, _I64, C.c_int32, _F64,
                             C.c_int32, _F64, _P],

@@ -384,6 +384,113 @@ __global__ __launch_bounds__(256) void k_spin_dense_prepare(const T* __restrict_
     }
 }
 
+// ---- batched random couplings for the training envs (util_envs_PECO.py:15-112).  The reference draws them with torch ops
+// (ER: rand < p, triu, symmetrise; BA: a Python loop over the nodes with adj.sum + multinomial + two scatters per node:
+// ~1000 launches and N full [B, N, N] reductions per reset at N = 200).  Build-defined counter-based draws (Philox keyed
+// by seed and GLOBAL env id, so a shard draws what the whole batch would), the same distributions:
+//   edge sign  EdgeType.UNIFORM (1): +1;  DISCRETE (2): one +-1 per node pair shared by all envs of the call (:23-26, 72-75);
+//              RANDOM (3): one +-1 per node pair and env (:30-33, 79-82)
+__device__ __forceinline__ float coupling_sign(const Philox& ph, int edge_type, uint64_t gb, uint32_t lo, uint32_t hi) {
+    if (edge_type == 1) return 1.0f;
+    uint32_t r[4];
+    if (edge_type == 2) ph(lo, hi, 0u, 0x5349474Eu, r);                       // 'SIGN': no env in the counter
+    else ph((uint32_t)gb, (uint32_t)(gb >> 32), lo * 65536u + hi, 0x5349474Fu, r);
+    return (r[0] & 1u) ? 1.0f : -1.0f;
+}
+
+// Erdos-Renyi (RandomERGraphGenerator.generate_er_graph :42-52): pair (i < j) is an edge iff its 32-bit draw < p * 2^32.
+// One thread per matrix element (both halves recompute the pair's draw): a streaming write of B * N^2 elements.
+template <typename T>
+__global__ __launch_bounds__(256) void k_rand_couplings_er(T* __restrict__ matrix, int64_t B, int64_t N, uint32_t threshold,
+                                                            int all_edges, int edge_type, uint64_t seed, int64_t env_offset) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N * N) return;
+    const int64_t i = e / N, j = e - i * N;
+    const uint32_t lo = (uint32_t)(i < j ? i : j), hi = (uint32_t)(i < j ? j : i);
+    const Philox ph(seed);
+    for (int64_t b = blockIdx.y; b < B; b += gridDim.y) {
+        const uint64_t gb = (uint64_t)(b + env_offset);
+        float w = 0.0f;
+        if (i != j) {
+            uint32_t r[4];
+            ph((uint32_t)gb, (uint32_t)(gb >> 32), lo * 65536u + hi, 0x45524750u, r);       // 'ERGP'
+            if (all_edges || r[0] < threshold) w = coupling_sign(ph, edge_type, gb, lo, hi);
+        }
+        matrix[(b * N + i) * N + j] = (T)w;
+    }
+}
+
+// Barabasi-Albert (RandomBAGraphGenerator.generate_barabasi_albert :84-107): a seed clique on nodes 0..m WITH its self-loops
+// (adj[:, i, :i+1] = 1 sets the diagonal too, :93-95 -- kept: it is what the reference trains on), then every node v > m
+// attaches to m distinct earlier nodes drawn in proportion to their degree (row sums of adj, self-loop counted once).
+// Degree-proportional = uniform over the list of edge endpoints, duplicates drawn again: the list is never stored -- entry
+// idx is a clique node for idx < (m+1)^2, else endpoint r of node vv's m edges: its target t[vv][r] (r < m) or vv itself.
+// Lane = env (epw envs per wave: 64 when the batch fills the chip that way, fewer for smaller batches so that more waves share
+// the writing), the targets of the wave's envs in LDS as uint16 [N * m][epw + 2]; then the wave writes each env's matrix: zero
+// fill, wait for the stores, scatter the signed edges.
+// q / d for q < 2^23 by a float reciprocal and one correction step (the divisors are run-time values: a generic 32-bit
+// division is ~35 instructions, and the draw loop below is one dependent chain per env)
+__device__ __forceinline__ uint32_t small_div(uint32_t q, uint32_t d, float inv_d) {
+    uint32_t est = (uint32_t)((float)q * inv_d);
+    const int32_t r = (int32_t)(q - est * d);
+    est += r < 0 ? -1 : (r >= (int32_t)d ? 1 : 0);
+    return est;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kWave) void k_rand_couplings_ba(T* __restrict__ matrix, int64_t B, int64_t N, int m, int edge_type,
+                                                              uint64_t seed, int64_t env_offset, int epw) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint16_t* t = reinterpret_cast<uint16_t*>(smem);                         // [(v * m + r) * kStride + lane]
+    const int kStride = epw + 2;
+    const int lane = threadIdx.x;
+    const int64_t b0 = (int64_t)blockIdx.x * epw, b = b0 + lane;
+    const Philox ph(seed);
+    const uint64_t gb = (uint64_t)(b + env_offset);
+    const uint32_t L0 = (uint32_t)(m + 1) * (uint32_t)(m + 1), m1 = (uint32_t)m + 1u, m2 = 2u * (uint32_t)m;
+    const float inv_m1 = 1.0f / (float)m1, inv_m2 = 1.0f / (float)m2;
+    for (uint32_t v = m1; v < (uint32_t)N && lane < epw; ++v) {
+        const uint32_t L = L0 + m2 * (v - m1);
+        int cnt = 0;
+        uint32_t r[4];
+        for (uint32_t a = 0; cnt < m; ++a) {
+            if ((a & 3u) == 0) ph((uint32_t)gb, (uint32_t)(gb >> 32), v * 4096u + (a >> 2), 0x42414752u, r);   // 'BAGR'
+            const uint32_t idx = __umulhi(r[a & 3u], L);
+            uint32_t node;
+            if (idx < L0) node = small_div(idx, m1, inv_m1);
+            else {
+                const uint32_t q = idx - L0, qd = small_div(q, m2, inv_m2), vv = m1 + qd, rr = q - qd * m2;
+                node = rr < (uint32_t)m ? t[(vv * m + rr) * kStride + lane] : vv;
+            }
+            bool dup = false;
+            for (int c = 0; c < cnt; ++c) dup |= t[(v * m + c) * kStride + lane] == node;
+            if (!dup) { t[(v * m + cnt) * kStride + lane] = (uint16_t)node; ++cnt; }
+        }
+    }
+    __syncthreads();
+    const int64_t nb = (B - b0 < epw) ? B - b0 : epw;
+    for (int64_t e = 0; e < nb; ++e) {
+        T* me = matrix + (b0 + e) * N * N;
+        for (int64_t k = lane; k < N * N; k += kWave) me[k] = (T)0;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    for (int64_t e = 0; e < nb; ++e) {
+        T* me = matrix + (b0 + e) * N * N;
+        const uint64_t ge = (uint64_t)(b0 + e + env_offset);
+        for (int64_t k = lane; k < (int64_t)L0; k += kWave) {               // the seed clique, diagonal included
+            const int64_t i = k / (m + 1), j = k - i * (m + 1);
+            me[i * N + j] = (T)coupling_sign(ph, edge_type, ge, (uint32_t)(i < j ? i : j), (uint32_t)(i < j ? j : i));
+        }
+        for (int64_t k = (int64_t)(m + 1) * m + lane; k < N * m; k += kWave) {
+            const int64_t v = k / m, u = t[k * kStride + e];
+            const T w = (T)coupling_sign(ph, edge_type, ge, (uint32_t)u, (uint32_t)v);
+            me[v * N + u] = w;
+            me[u * N + v] = w;
+        }
+    }
+}
+
 // get_observation (spinsystem_PECO.py:455 / spinsystem.py:484-495): out[b] = rows of state[b] (row 0 mapped from signed to
 // {0, 1} spins under SpinBasis.BINARY: (1 - s) / 2) followed by the N rows of the shared matrix.  One streaming pass:
 // the reference clones the state, rewrites row 0 and concatenates a [B, N, N] expansion of the matrix.
@@ -530,6 +637,47 @@ int rls_spin_step_dense(const void* matrix, const void* max_local, const rls_spi
     return spin_step_common(nullptr, matrix, max_local, N, env, state_bytes, B, num_rows, row_index, action, reward, visited_new, 1.0,
                             time_inc, termination_value, reward_mode, reward_div, hist_len, use_stag, stag_punishment, use_basin,
                             basin_reward, stream);
+}
+
+int rls_rand_couplings(void* matrix, int state_bytes, int64_t B, int64_t N, int32_t kind, double p_connection, int32_t m_insertion_edges,
+                       int32_t edge_type, uint64_t seed, int64_t env_offset, void* stream) {
+    RLS_REQUIRE(B >= 0 && N > 0 && N < 65536, RLS_EINVAL, "bad sizes B=%lld N=%lld", (long long)B, (long long)N);
+    RLS_REQUIRE(state_bytes == 4 || state_bytes == 8, RLS_EINVAL, "state_bytes must be 4 (f32) or 8 (f64)");
+    RLS_REQUIRE(edge_type >= 1 && edge_type <= 3, RLS_EINVAL, "edge_type must be 1 (UNIFORM), 2 (DISCRETE), 3 (RANDOM)");
+    RLS_REQUIRE(kind == 0 || kind == 1, RLS_EINVAL, "kind must be 0 (Erdos-Renyi) or 1 (Barabasi-Albert)");
+    if (B == 0) return RLS_OK;
+    RLS_REQUIRE(matrix, RLS_EINVAL, "matrix is NULL");
+    hipStream_t s = as_stream(stream);
+    if (kind == 0) {
+        RLS_REQUIRE(p_connection >= 0.0 && p_connection <= 1.0, RLS_EINVAL, "p_connection outside [0, 1]");
+        const double scaled = p_connection * 4294967296.0;
+        const uint32_t threshold = scaled >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)scaled;
+        const int all = p_connection >= 1.0;
+        const dim3 grid((unsigned)ceil_div(N * N, 256), (unsigned)(B < 16384 ? B : 16384)), block(256);
+        if (state_bytes == 4)
+            hipLaunchKernelGGL(k_rand_couplings_er<float>, grid, block, 0, s, (float*)matrix, B, N, threshold, all, (int)edge_type, seed, env_offset);
+        else
+            hipLaunchKernelGGL(k_rand_couplings_er<double>, grid, block, 0, s, (double*)matrix, B, N, threshold, all, (int)edge_type, seed, env_offset);
+        return check_launch("k_rand_couplings_er");
+    }
+    const int m = m_insertion_edges;
+    RLS_REQUIRE(m >= 1 && m + 1 <= N && m < 4096, RLS_EINVAL, "m_insertion_edges=%d outside [1, N - 1]", m);
+    int epw = kWave;                                                         // envs per wave: >= 2 waves per CU before lanes fill up
+    while (epw > 8 && B < (int64_t)epw * 2 * num_cus()) epw >>= 1;
+    while (epw > 1 && (size_t)N * m * (epw + 2) * sizeof(uint16_t) > (size_t)kLdsBytes) epw >>= 1;
+    const size_t lds = (size_t)N * m * (epw + 2) * sizeof(uint16_t);
+    RLS_REQUIRE(lds <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N * m = %lld needs %zu B of LDS (max %d)", (long long)N * m, lds, kLdsBytes);
+    const dim3 grid((unsigned)ceil_div(B, epw)), block(kWave);
+    if (state_bytes == 4) {
+        auto kern = k_rand_couplings_ba<float>;
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, grid, block, lds, s, (float*)matrix, B, N, m, (int)edge_type, seed, env_offset, epw);
+    } else {
+        auto kern = k_rand_couplings_ba<double>;
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, grid, block, lds, s, (double*)matrix, B, N, m, (int)edge_type, seed, env_offset, epw);
+    }
+    return check_launch("k_rand_couplings_ba");
 }
 
 int rls_spin_observation(const void* state, const void* matrix, int32_t matrix_per_env, int state_bytes, int64_t B, int32_t num_rows,

@@ -204,6 +204,13 @@ void spin_observation(const Tensor& state, const OptTensor& matrix, bool binary_
     const int sb = state.scalar_type() == F64 ? 8 : 4;
     ok(rls_spin_observation(p(state), p(matrix), per_env, sb, B, (int32_t)R, N, binary_basis, p(out), cur_stream(state)), "rls_spin_observation");
 }
+void rand_couplings(Tensor matrix, int64_t kind, double p_connection, int64_t m_insertion_edges, int64_t edge_type, int64_t seed, int64_t env_offset) {
+    dev(matrix, "matrix");
+    TORCH_CHECK(matrix.dim() == 3 && matrix.size(1) == matrix.size(2), "matrix must be [B, N, N]");
+    TORCH_CHECK(matrix.scalar_type() == F32 || matrix.scalar_type() == F64, "matrix must be float32 or float64");
+    ok(rls_rand_couplings(p(matrix), matrix.scalar_type() == F64 ? 8 : 4, matrix.size(0), matrix.size(1), (int32_t)kind, p_connection,
+                          (int32_t)m_insertion_edges, (int32_t)edge_type, (uint64_t)seed, env_offset, cur_stream(matrix)), "rls_rand_couplings");
+}
 void spin_reset_dense(const Tensor& matrix, int64_t env, const Tensor& state, const Tensor& row_index, Tensor max_local, Tensor weight_sum,
                       Tensor flags) {
     dev(state, "state");
@@ -475,6 +482,7 @@ TORCH_LIBRARY(rlsolver_hip, m) {
     m.def("rand_perms(Tensor(a!) perm, int seed, int env_offset) -> ()");
     m.def("spin_reset(int graph, int env, Tensor(a!) state, Tensor row_index, float max_local, int weight_sum) -> ()");
     m.def("spin_observation(Tensor state, Tensor? matrix, bool binary_basis, Tensor(a!) out) -> ()");
+    m.def("rand_couplings(Tensor(a!) matrix, int kind, float p_connection, int m_insertion_edges, int edge_type, int seed, int env_offset) -> ()");
     m.def("spin_reset_dense(Tensor matrix, int env, Tensor(a!) state, Tensor row_index, Tensor(b!) max_local, Tensor(c!) weight_sum, Tensor(d!) flags) -> ()");
     m.def("spin_step_dense(Tensor matrix, Tensor max_local, int env, Tensor(a!) state, Tensor row_index, Tensor action, Tensor(b!) reward, "
           "Tensor(c!)? visited_new, float time_inc, float termination_value, int reward_mode, float reward_div, int hist_len, bool use_stag, "
@@ -530,6 +538,7 @@ TORCH_LIBRARY_IMPL(rlsolver_hip, CUDA, m) {   // "CUDA" is the HIP dispatch key 
     m.impl("rand_perms", &rand_perms);
     m.impl("spin_reset", &spin_reset);
     m.impl("spin_observation", &spin_observation);
+    m.impl("rand_couplings", &rand_couplings);
     m.impl("spin_reset_dense", &spin_reset_dense);
     m.impl("spin_step_dense", &spin_step_dense);
     m.impl("spin_step", &spin_step);

@@ -1,0 +1,89 @@
+"""Graph generators of the batched spin-system env -- the surface of rlsolver/methods/ECO_S2V/src/envs/util_envs_PECO.py
+(RandomERGraphGenerator :15-57, RandomBAGraphGenerator :60-113, ValidationGraphGenerator / SetGraphGenerator :115-172) for
+``SpinSystem(graph_generator=...)``: ``get()`` returns the couplings of all envs, float [num_envs, n_spins, n_spins] on the
+device, a fresh draw per call.
+
+The reference builds them from torch ops (the BA generator loops over the nodes in Python: per node a full [B, N, N] row
+sum, a multinomial and two scatters); here a draw is ONE kernel (rls_rand_couplings).  Draws come from a counter-based
+generator seeded from torch's generator at every call -- the same distributions, not torch's streams.
+"""
+from __future__ import annotations
+
+from enum import Enum
+
+import torch
+
+from .. import _abi
+from ..ops import _ptr, _stream
+from .env_L2A import _seed_from_torch
+
+
+class EdgeType(Enum):  # ECO_S2V/src/envs/util_envs.py:11-14
+    UNIFORM = 1
+    DISCRETE = 2
+    RANDOM = 3
+
+
+class GraphGenerator:
+    """util_envs.py:62-81: what the env reads is n_spins, biased and get()."""
+
+    def __init__(self, n_spins, edge_type, biased=False, num_envs=None):
+        if biased:
+            raise NotImplementedError("biased generators are not part of the MaxCut path")
+        self.n_spins, self.edge_type, self.biased, self.num_envs = n_spins, edge_type, biased, num_envs
+
+    def get(self, with_padding=False):
+        raise NotImplementedError
+
+
+class _KernelGenerator(GraphGenerator):
+    _kind = None
+
+    def __init__(self, n_spins, edge_type, num_envs, device, dtype=torch.float32, env_offset=0):
+        super().__init__(n_spins, EdgeType(edge_type) if not isinstance(edge_type, EdgeType) else edge_type, False, num_envs)
+        self.device = torch.device(device if device is not None else "cuda:0")
+        if self.device.type != "cuda":
+            raise TypeError(f"{type(self).__name__} needs a HIP device (got {self.device}); there is no CPU path")
+        self.dtype, self.env_offset = dtype, env_offset
+        self._p, self._m = 0.0, 0
+
+    def get(self, with_padding=False, seed=None):
+        out = torch.empty((self.num_envs, self.n_spins, self.n_spins), dtype=self.dtype, device=self.device)
+        _abi.call("rls_rand_couplings", _ptr(out), 8 if self.dtype == torch.float64 else 4, self.num_envs, self.n_spins, self._kind,
+                  float(self._p), int(self._m), self.edge_type.value, _seed_from_torch() if seed is None else int(seed),
+                  self.env_offset, _stream(self.device))
+        return out
+
+
+class RandomERGraphGenerator(_KernelGenerator):
+    """util_envs_PECO.py:15-57: every pair an edge with probability p_connection, signs by edge_type."""
+    _kind = 0
+
+    def __init__(self, n_spins=20, p_connection=0.2, edge_type=EdgeType.DISCRETE, num_envs=8, device="cuda", **kw):
+        super().__init__(n_spins, edge_type, num_envs, device, **kw)
+        self.p_connection = self._p = p_connection
+
+
+class RandomBAGraphGenerator(_KernelGenerator):
+    """util_envs_PECO.py:60-113: seed clique on m + 1 nodes (self-loops included, as there), m degree-proportional edges per
+    later node, signs by edge_type."""
+    _kind = 1
+
+    def __init__(self, n_spins=20, m_insertion_edges=4, edge_type=EdgeType.DISCRETE, num_envs=8, device="cuda", **kw):
+        super().__init__(n_spins, edge_type, num_envs, device, **kw)
+        self.m_insertion_edges = self._m = m_insertion_edges
+
+
+class SetGraphGenerator(GraphGenerator):
+    """A fixed batch of matrices [num_envs, n_spins, n_spins] handed back at every get() (validation sets, recorded graphs:
+    util_envs_PECO.py:115-172 build theirs with networkx on the host and return the same kind of tensor)."""
+
+    def __init__(self, matrices, device=None):
+        m = torch.as_tensor(matrices)
+        if m.dim() != 3 or m.shape[1] != m.shape[2]:
+            raise ValueError("matrices must be [num_envs, n_spins, n_spins]")
+        super().__init__(int(m.shape[1]), None, False, int(m.shape[0]))
+        self.matrices = m.to(device) if device is not None else m
+
+    def get(self, with_padding=False):
+        return self.matrices

@@ -250,3 +250,56 @@ def test_observation_kernel_equals_the_reference_expression(n, dtype, basis_bina
     assert env.get_observation(out=buf) is buf and torch.equal(buf, want)
     with pytest.raises(ValueError):
         env.get_observation(out=buf[:, :-1].contiguous())
+
+
+@pytest.mark.parametrize("edge_type", [1, 2, 3])
+def test_rand_couplings_equal_their_restatement(edge_type):
+    """rls_rand_couplings bit for bit against the numpy restatement of its draws (ER and BA, every edge type, a shard offset),
+    plus the structure the reference's generators produce: symmetric 0 / +-1, ER zero diagonal, BA seed clique with its
+    self-loops and exactly m earlier neighbours per later node, DISCRETE signs shared by the envs, RANDOM not."""
+    from oracle import oracle_np as onp
+    from rlsolver_amd.envs.util_envs_PECO import EdgeType, RandomBAGraphGenerator, RandomERGraphGenerator
+    B, N, m = 70, 37, 4
+    er = RandomERGraphGenerator(N, 0.3, EdgeType(edge_type), B, DEV, env_offset=5).get(seed=1234).cpu().numpy()
+    assert np.array_equal(er, onp.rand_couplings_er(B, N, 0.3, edge_type, 1234, 5).astype(np.float32))
+    ba = RandomBAGraphGenerator(N, m, EdgeType(edge_type), B, DEV, env_offset=5, dtype=torch.float64).get(seed=99).cpu().numpy()
+    assert np.array_equal(ba, onp.rand_couplings_ba(B, N, m, edge_type, 99, 5))
+    for mat in (er, ba):
+        assert np.array_equal(mat, mat.transpose(0, 2, 1)) and set(np.unique(mat)) <= {-1.0, 0.0, 1.0}
+    assert not np.diagonal(er, axis1=1, axis2=2).any()
+    a = np.abs(ba)
+    assert (a[:, :m + 1, :m + 1] == 1).all() and not np.diagonal(a, axis1=1, axis2=2)[:, m + 1:].any()
+    assert all((np.tril(a[b], -1)[m + 1:].sum(1) == m).all() for b in range(B))
+    same = all(np.array_equal(np.sign(ba[0]) * (a[0] * a[b]), np.sign(ba[b]) * (a[0] * a[b])) for b in range(B))
+    assert same == (edge_type != 3)
+    shard = RandomBAGraphGenerator(N, m, EdgeType(edge_type), 6, DEV, env_offset=5 + 64, dtype=torch.float64).get(seed=99).cpu().numpy()
+    assert np.array_equal(shard, ba[64:70])                                   # a shard draws what the whole batch draws
+
+
+def test_rand_couplings_distributions_and_training_env():
+    """ER density = p; BA is preferential (old nodes collect more edges than late ones, degree ~ the reference's on the CPU
+    within sampling error); an env built on the kernel generators steps, redraws its graphs at reset, and its resident gain
+    cache equals s * (W s) on the drawn matrices after random steps."""
+    from rlsolver_amd.envs.spinsystem import SpinSystem
+    from rlsolver_amd.envs.util_envs_PECO import EdgeType, RandomBAGraphGenerator, RandomERGraphGenerator
+    torch.manual_seed(5)
+    B, N = 512, 64
+    er = RandomERGraphGenerator(N, 0.15, EdgeType.UNIFORM, B, DEV).get()
+    dens = float(er.sum() / (B * N * (N - 1)))
+    assert abs(dens - 0.15) < 0.004
+    ba = RandomBAGraphGenerator(N, 4, EdgeType.UNIFORM, B, DEV).get()
+    deg = ba.sum(-1).mean(0).cpu().numpy()
+    assert deg[:5].mean() > 2.5 * deg[-20:].mean() and abs(deg[-1] - 4.0) < 1e-6
+    # mean row sums of the reference's own generator (torch.multinomial without replacement; N = 64, m = 4, 4096 graphs drawn on
+    # the CPU when this test was written): node 0 21.9, node 5 16.4, node 16 8.45, node 32 5.72, node 48 4.62, node 63 4.0
+    for node, want, tol in ((0, 21.9, 1.5), (5, 16.4, 1.3), (16, 8.45, 0.6), (32, 5.72, 0.4), (48, 4.62, 0.25)):
+        assert abs(deg[node] - want) < tol, (node, deg[node])
+    gg = RandomBAGraphGenerator(N, 4, EdgeType.DISCRETE, B, DEV)
+    env = SpinSystem(None, None, B, max_steps=2 * N, graph_generator=gg, device=DEV)
+    m0 = env.matrix.clone()
+    for t in range(40):
+        env.step(torch.randint(0, N, (B,), device=DEV))
+    s = env.state[:, 0, :]
+    assert torch.equal(env._delta.to(torch.float32), s * torch.einsum("bij,bj->bi", env.matrix, s))
+    env.reset()
+    assert not torch.equal(env.matrix, m0) and env.current_step == 0

@@ -232,6 +232,62 @@ def spin_suite(tag, n, m, B, T, iters):
              "algorithmic bytes = the rows the observation contract changes everywhere each step")
 
 
+def spin_train_suite(tag, n, m_ins, B, T, iters):
+    """S1 on per-env couplings (the training envs): one draw of B Barabasi-Albert graphs, the dense reset, the step kernel and
+    the step through the class surface (observation [B, 7 + N, N] with each env's own matrix rows included); beside the draw,
+    the reference's way of drawing the same graphs with torch ops (a loop over the nodes: row sums of [B, N, N], multinomial,
+    two scatters)."""
+    from rlsolver_amd import _abi
+    import ctypes as C
+    from rlsolver_amd.envs.spinsystem import ECO_PECO_OBSERVABLES, RewardSignal, SpinBasis, SpinSystem
+    from rlsolver_amd.envs.util_envs_PECO import EdgeType, RandomBAGraphGenerator
+    gg = RandomBAGraphGenerator(n, m_ins, EdgeType.DISCRETE, B, dev)
+    t = timeit(lambda i: gg.get(seed=i), iters, warm=2)
+    emit(tag, "rand_couplings (BA, one kernel)", "graphs", B, t, 4 * n * n, "bytes = the f32 [B, N, N] result")
+
+    def torch_ba():
+        adj = torch.zeros((B, n, n), device=dev)
+        for i in range(m_ins + 1):
+            adj[:, i, :i + 1] = 1
+            adj[:, :i + 1, i] = 1
+        rows = torch.arange(B, device=dev).repeat_interleave(m_ins)
+        for v in range(m_ins + 1, n):
+            deg = adj.sum(dim=-1)
+            pick = torch.multinomial(deg / deg.sum(dim=-1, keepdim=True), m_ins, replacement=False).view(-1)
+            adj[rows, v, pick] = 1
+            adj[rows, pick, v] = 1
+        return adj
+    t0 = timeit(lambda i: torch_ba(), 2, warm=1)
+    emit(tag, "the same draw as a torch op chain (per-node loop, as the reference generator)", "graphs", B, t0, 4 * n * n, "baseline beside rand_couplings")
+    env = SpinSystem(None, None, B, max_steps=T, observables=ECO_PECO_OBSERVABLES, reward_signal=RewardSignal.BLS, norm_rewards=True,
+                     spin_basis=SpinBasis.BINARY, device=dev, graph_generator=gg)
+    t = timeit(lambda i: env.reset(), max(3, iters // 3), warm=1)
+    emit(tag, "SpinSystem.reset() on fresh graphs (draw + gain cache + rows + observation)", "envs", B, t, 4 * n * n * 2 + 4 * (7 + n) * n,
+         "bytes = matrix written + read, observation written")
+    acts = [ops.rand_actions(B, n, 11, s, dev) for s in range(8)]
+    rew = torch.empty(B, device=dev)
+
+    def one(i):
+        if env.current_step >= T:
+            env.current_step = 0
+        env.current_step += 1
+        _abi.call("rls_spin_step_dense", ops._ptr(env._matrix), ops._ptr(env.max_local_reward_available_), C.byref(env._env), 4, B, n, 7,
+                  env._rows, ops._ptr(acts[i % 8]), ops._ptr(rew), None, float(np.float32(1.0 / T)), 1.0, 1, float(n), env.current_step - 1,
+                  0, 0.0, 0, 0.0, ops._stream(dev))
+    t = timeit(one, iters)
+    emit(tag, "S1 spin_step_dense (ECO observables, BLS reward)", "env-steps", B, t, 6 * 4 * n + 4 * n,
+         "algorithmic bytes = the six rows that change everywhere + the flipped node's matrix row")
+    out = torch.empty((B, 7 + n, n), device=dev)
+
+    def full(i):
+        if env.current_step >= T:
+            env.current_step = 0
+        env.step(acts[i % 8])
+    t = timeit(full, iters)
+    emit(tag, "SpinSystem.step() incl. observation [B, 7 + N, N] with per-env matrix rows", "env-steps", B, t, 6 * 4 * n + 4 * n + 4 * (7 + n) * n + 4 * n * n + 4 * 7 * n,
+         "bytes = step + observation written + matrix and rows read")
+
+
 def qubo_suite(tag, n, C, num_ls, iters, sparse=True):
     from rlsolver_amd.methods import MCPG_qubo as mq
     rng = np.random.RandomState(3)
@@ -276,6 +332,8 @@ if want("isco"):
 if want("spin"):
     spin_suite("G22-sized +-1 weighted, B=2^14", 2000, 19990, 1 << 14, 64, it)
     spin_suite("BA-200-sized (ECO), B=4096", 200, 784, 4096, 400, it)
+    spin_train_suite("PECO training envs: BA-200 (m=4) per env, B=1024", 200, 4, 1024, 400, it)
+    spin_train_suite("PECO training envs: BA-20 (m=4) per env, B=4096", 20, 4, 4096, 40, it)
 if want("qubo"):
     qubo_suite("nbiq-style dense QUBO n=1000, 2^13 chains", 1000, 1 << 13, 2, 2)
     qubo_suite("nbiq-style dense QUBO n=1000, 2^15 chains", 1000, 1 << 15, 2, 2, sparse=False)
