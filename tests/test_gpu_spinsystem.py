@@ -303,3 +303,50 @@ def test_rand_couplings_distributions_and_training_env():
     assert torch.equal(env._delta.to(torch.float32), s * torch.einsum("bij,bj->bi", env.matrix, s))
     env.reset()
     assert not torch.equal(env.matrix, m0) and env.current_step == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_per_env_matrices_equal_the_shared_graph_env_on_one_graph(dtype):
+    """The dense (matrix per env) and the CSR (one shared graph) forms of the step are the same env when every env holds the
+    same zero-diagonal matrix: identical observations, rewards, scores, visited-state flags over a whole episode with
+    revisits, in f32 and f64; and state_dict round-trips the dense env (matrix included)."""
+    from rlsolver_amd.envs.spinsystem import ECO_PECO_OBSERVABLES, RewardSignal, SpinBasis, SpinSystem
+    from rlsolver_amd.envs.util_envs_PECO import SetGraphGenerator
+    rng = np.random.RandomState(4)
+    n, B, T = 48, 9, 60
+    up = np.triu((rng.rand(n, n) < 0.2) * rng.choice([-1, 1], size=(n, n)), 1)
+    W = (up + up.T).astype(np.float64)
+    mg = [(i, j, int(W[i, j])) for i in range(n) for j in range(i + 1, n) if W[i, j] != 0]
+    kw = dict(max_steps=T, observables=ECO_PECO_OBSERVABLES, reward_signal=RewardSignal.CUSTOM_BLS, spin_basis=SpinBasis.BINARY,
+              stag_punishment=0.125, basin_reward=0.25, device=DEV, dtype=dtype)
+    shared = SpinSystem(mg, n, B, **kw)
+    dense = SpinSystem(None, None, B, graph_generator=SetGraphGenerator(np.broadcast_to(W, (B, n, n)).copy(), DEV), **kw)
+    spins0 = torch.from_numpy(rng.randint(0, 2, size=(B, n)).astype(np.float64))
+    o1, o2 = shared.reset(spins0), dense.reset(spins0)
+    assert torch.equal(o1, o2) and torch.equal(shared.score, dense.score)
+    assert torch.equal(shared.max_local_reward_available_, dense.max_local_reward_available_)
+    g = torch.Generator().manual_seed(2)
+    prev = None
+    for t in range(T):
+        a = torch.randint(0, n, (B,), generator=g)
+        if t % 3 == 2:
+            a = prev.clone()                                                   # undo: a revisited state
+        prev = a
+        if t == T // 2:
+            snap = dense.state_dict()
+        (o1, r1, d1), (o2, r2, d2) = shared.step(a.to(DEV)), dense.step(a.to(DEV))
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2), t
+        assert torch.equal(shared._visited_new, dense._visited_new) and torch.equal(shared.best_spins, dense.best_spins)
+    assert torch.equal(shared.calculate_cut(), dense.calculate_cut())
+    end_obs = o2.clone()
+    dense.load_state_dict(snap)
+    g2 = torch.Generator().manual_seed(2)
+    acts = []
+    for t in range(T):
+        a = torch.randint(0, n, (B,), generator=g2)
+        if t % 3 == 2:
+            a = acts[-1].clone()
+        acts.append(a)
+    for t in range(T // 2, T):
+        o3, _, _ = dense.step(acts[t].to(DEV))
+    assert torch.equal(o3, end_obs)
