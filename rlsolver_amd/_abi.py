@@ -109,7 +109,7 @@ SIGNATURES = {
     "rls_tsp_swap_delta_all": [_P, _I64, _P, _I64, _P, _F32, _P, _P, _P, _P],
     "rls_tsp_apply_swap": [_P, _I64, _I64, _P, _P, _P],
     "rls_tsp_2opt_delta": [_P, _I64, _P, _I64, _P, _P, _P, _P],
-    "rls_tsp_2opt_best": [_P, _I64, _P, _I64, _P, _P, _P, _P, _P],
+    "rls_tsp_2opt_best": [_P, _I64, _P, _I64, _P, C.c_int32, _P, _P, _P, _P],
     "rls_rand_perms": [_P, _I64, _I64, _U64, _I64, _P],
     "rls_isco_maxcut_step": [_G, _P, _P, _I64, _P, _F32, _P, _P, _U64, _I64, _P, _P, _P, _P, _P],
     "rls_isco_tsp_step": [_P, _I64, _P, C.c_int32, _F32, _P, C.c_int32, _P, _P, _I64, C.c_int32, _F32, _P, _P, _P, _P, _P, _U64, _I64,

@@ -217,6 +217,10 @@ __global__ __launch_bounds__(kWave) void k_rand_perms_lds(int64_t* __restrict__ 
 //          ranked by their rounding, exactly as the reference ranks them.  value = that length, compared with cur[b].
 //   else:  delta(i, j) = D[a,c] + D[b,e] - D[a,b] - D[c,e] (a = t[i-1], b = t[i], c = t[j], e = t[j+1], cyclic; 0 for the
 //          whole tour), O(1) per candidate, for a SYMMETRIC matrix.  value = delta, compared with 0.
+// The N(N-1)/2 candidates are one list c = 0.. in (i, j) order, dealt round-robin over the threads of the tour's `slices`
+// workgroups (a lone tour -- the reference's use -- still spreads over the chip; rows of different cost interleave).  With
+// slices > 1 every workgroup leaves its best (value, key) in row blockIdx.y of the [slices, B] outputs and
+// k_tsp_2opt_reduce folds the rows into row 0.
 template <bool EXACT>
 __global__ __launch_bounds__(256) void k_tsp_2opt_best(const double* __restrict__ dist, int64_t N, const int64_t* __restrict__ perm,
                                                         int64_t B, const double* __restrict__ cur, int64_t* __restrict__ best_i,
@@ -228,44 +232,55 @@ __global__ __launch_bounds__(256) void k_tsp_2opt_best(const double* __restrict_
     int32_t* t = reinterpret_cast<int32_t*>(S + (EXACT ? N + 1 : 0));       // [N]
     const int64_t b = blockIdx.x;
     const int tid = threadIdx.x;
+    const int64_t slices = gridDim.y, slice = blockIdx.y;
     for (int64_t k = tid; k < N; k += 256) t[k] = (int32_t)perm[b * N + k];
     __syncthreads();
-    if (EXACT && tid == 0) {
-        double acc = 0.0;
-        S[0] = 0.0;
-        for (int64_t k = 0; k < N; ++k) {
-            acc = acc + dist[(int64_t)t[k] * N + t[k + 1 == N ? 0 : k + 1]];
-            S[k + 1] = acc;
+    if constexpr (EXACT) {                                                  // edges in parallel, then the one sequential sum
+        for (int64_t k = tid; k < N; k += 256) S[k + 1] = dist[(int64_t)t[k] * N + t[k + 1 == N ? 0 : k + 1]];
+        __syncthreads();
+        if (tid == 0) {
+            double acc = 0.0;
+            S[0] = 0.0;
+            for (int64_t k = 0; k < N; ++k) {
+                acc = acc + S[k + 1];
+                S[k + 1] = acc;
+            }
         }
+        __syncthreads();
     }
-    __syncthreads();
     double best = EXACT ? cur[b] : 0.0;                                     // only strictly better candidates count
     int64_t key = -1;                                                       // i * N + j of the best so far
-    for (int64_t i = 0; i + 1 < N; ++i) {
-        const int64_t a = t[i == 0 ? N - 1 : i - 1], bb = t[i];
-        const double dab = dist[a * N + bb];
-        for (int64_t j = i + 1 + tid; j < N; j += 256) {
-            double v;
-            if constexpr (EXACT) {
-                auto city = [&](int64_t k) -> int64_t {                     // the candidate tour, closed
-                    if (k == N) k = 0;
-                    return (k >= i && k <= j) ? t[i + j - k] : t[k];
-                };
-                const int64_t k0 = i >= 1 ? i - 1 : 0;
-                v = S[k0];
-                int64_t c0 = city(k0);
-                for (int64_t k = k0; k < N; ++k) {
-                    const int64_t c1 = city(k + 1);
-                    v = v + dist[c0 * N + c1];
-                    c0 = c1;
-                }
-            } else {
-                if (i == 0 && j == N - 1) continue;                         // the whole tour reversed: the same cycle
-                const int64_t c = t[j], e = t[j + 1 == N ? 0 : j + 1];
-                v = (dist[a * N + c] + dist[bb * N + e]) - (dab + dist[c * N + e]);
+    const int64_t M = N * (N - 1) / 2;
+    const double tn1 = (double)(2 * N - 1);
+    for (int64_t c = slice * 256 + tid; c < M; c += slices * 256) {
+        // row i holds candidates off(i) .. off(i + 1) - 1, off(i) = i (2N - i - 1) / 2
+        int64_t i = (int64_t)((tn1 - sqrt(tn1 * tn1 - 8.0 * (double)c)) * 0.5);
+        if (i < 0) i = 0;
+        if (i > N - 2) i = N - 2;
+        while (i * (2 * N - i - 1) / 2 > c) --i;
+        while ((i + 1) * (2 * N - i - 2) / 2 <= c) ++i;
+        const int64_t j = i + 1 + (c - i * (2 * N - i - 1) / 2);
+        double v;
+        if constexpr (EXACT) {
+            auto city = [&](int64_t k) -> int64_t {                         // the candidate tour, closed
+                if (k == N) k = 0;
+                return (k >= i && k <= j) ? t[i + j - k] : t[k];
+            };
+            const int64_t k0 = i >= 1 ? i - 1 : 0;
+            v = S[k0];
+            int64_t c0 = city(k0);
+            for (int64_t k = k0; k < N; ++k) {
+                const int64_t c1 = city(k + 1);
+                v = v + dist[c0 * N + c1];
+                c0 = c1;
             }
-            if (v < best) { best = v; key = i * N + j; }                    // strict: the first of equals stays (i, then j ascending)
+        } else {
+            if (i == 0 && j == N - 1) continue;                             // the whole tour reversed: the same cycle
+            const int64_t a = t[i == 0 ? N - 1 : i - 1], bb = t[i], cc = t[j], e = t[j + 1 == N ? 0 : j + 1];
+            v = (dist[a * N + cc] + dist[bb * N + e]) - (dist[a * N + bb] + dist[cc * N + e]);
         }
+        const int64_t kk = i * N + j;
+        if (v < best || (v == best && key >= 0 && kk < key)) { best = v; key = kk; }   // the first of equals in (i, j) order
     }
     rd[tid] = best;
     rk[tid] = key;
@@ -279,10 +294,31 @@ __global__ __launch_bounds__(256) void k_tsp_2opt_best(const double* __restrict_
         __syncthreads();
     }
     if (tid == 0) {
-        best_value[b] = rk[0] >= 0 ? rd[0] : (EXACT ? cur[b] : 0.0);
-        best_i[b] = rk[0] >= 0 ? rk[0] / N : -1;
-        best_j[b] = rk[0] >= 0 ? rk[0] % N : -1;
+        const int64_t o = slice * B + b;
+        best_value[o] = rk[0] >= 0 ? rd[0] : (EXACT ? cur[b] : 0.0);
+        if (slices == 1) {
+            best_i[o] = rk[0] >= 0 ? rk[0] / N : -1;
+            best_j[o] = rk[0] >= 0 ? rk[0] % N : -1;
+        } else {
+            best_i[o] = rk[0];                                               // the key; k_tsp_2opt_reduce splits the winner's
+        }
     }
+}
+
+__global__ void k_tsp_2opt_reduce(int64_t N, int64_t B, int64_t slices, int64_t* __restrict__ best_i, int64_t* __restrict__ best_j,
+                                  double* __restrict__ best_value) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double v = best_value[b];
+    int64_t key = best_i[b];
+    for (int64_t s = 1; s < slices; ++s) {
+        const double o = best_value[s * B + b];
+        const int64_t ok = best_i[s * B + b];
+        if (ok >= 0 && (key < 0 || o < v || (o == v && ok < key))) { v = o; key = ok; }
+    }
+    best_value[b] = v;
+    best_i[b] = key >= 0 ? key / N : -1;
+    best_j[b] = key >= 0 ? key % N : -1;
 }
 
 static inline bool dist_fits_lds(int64_t N, size_t extra) { return (size_t)N * N * 4 + extra <= (size_t)kLdsBytes - 1024; }
@@ -362,9 +398,10 @@ int rls_tsp_2opt_delta(const float* dist, int64_t N, const int64_t* perm, int64_
     return check_launch("k_tsp_2opt_delta");
 }
 
-int rls_tsp_2opt_best(const double* dist, int64_t N, const int64_t* perm, int64_t B, const double* cur_length, int64_t* best_i,
-                      int64_t* best_j, double* best_value, void* stream) {
-    RLS_REQUIRE(N > 2 && N < (1ll << 31) && B >= 0, RLS_EINVAL, "bad sizes N=%lld B=%lld", (long long)N, (long long)B);
+int rls_tsp_2opt_best(const double* dist, int64_t N, const int64_t* perm, int64_t B, const double* cur_length, int32_t slices,
+                      int64_t* best_i, int64_t* best_j, double* best_value, void* stream) {
+    RLS_REQUIRE(N > 2 && N < (1ll << 26) && B >= 0, RLS_EINVAL, "bad sizes N=%lld B=%lld", (long long)N, (long long)B);
+    RLS_REQUIRE(slices >= 1 && slices <= 65535, RLS_EINVAL, "slices=%d outside [1, 65535]", slices);
     if (B == 0) return RLS_OK;
     RLS_REQUIRE(dist && perm && best_i && best_j && best_value, RLS_EINVAL, "NULL pointer");
     const size_t lds = 256 * 16 + (cur_length ? (size_t)(N + 1) * 8 : 0) + (size_t)N * 4;
@@ -372,12 +409,15 @@ int rls_tsp_2opt_best(const double* dist, int64_t N, const int64_t* perm, int64_
     if (cur_length) {
         auto kern = k_tsp_2opt_best<true>;
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(256), lds, as_stream(stream), dist, N, perm, B, cur_length, best_i, best_j, best_value);
+        hipLaunchKernelGGL(kern, dim3((unsigned)B, (unsigned)slices), dim3(256), lds, as_stream(stream), dist, N, perm, B, cur_length, best_i, best_j, best_value);
     } else {
         auto kern = k_tsp_2opt_best<false>;
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, dim3((unsigned)B), dim3(256), lds, as_stream(stream), dist, N, perm, B, cur_length, best_i, best_j, best_value);
+        hipLaunchKernelGGL(kern, dim3((unsigned)B, (unsigned)slices), dim3(256), lds, as_stream(stream), dist, N, perm, B, cur_length, best_i, best_j, best_value);
     }
+    if (slices > 1)
+        hipLaunchKernelGGL(k_tsp_2opt_reduce, dim3((unsigned)ceil_div(B, 256)), dim3(256), 0, as_stream(stream), N, B, (int64_t)slices, best_i,
+                           best_j, best_value);
     return check_launch("k_tsp_2opt_best");
 }
 

@@ -404,10 +404,12 @@ void tsp_2opt_best(const Tensor& dist, const Tensor& perm, const OptTensor& cur_
     dev(best_j, "best_j", I64);
     dev(best_value, "best_value", F64);
     TORCH_CHECK(perm.dim() == 2 && dist.dim() == 2 && dist.size(0) == perm.size(1) && dist.size(1) == perm.size(1), "dist must be [N, N], perm [B, N]");
-    TORCH_CHECK(best_i.numel() == perm.size(0) && best_j.numel() == perm.size(0) && best_value.numel() == perm.size(0), "outputs must hold B entries");
+    const int64_t slices = perm.size(0) > 0 ? best_i.numel() / perm.size(0) : 1;
+    TORCH_CHECK(slices >= 1 && best_i.numel() == slices * perm.size(0) && best_j.numel() == best_i.numel() && best_value.numel() == best_i.numel(),
+                "outputs must hold slices * B entries each");
     if (cur_length.has_value()) TORCH_CHECK(cur_length->numel() == perm.size(0), "cur_length must hold B entries");
-    ok(rls_tsp_2opt_best((const double*)p(dist), perm.size(1), (const int64_t*)p(perm), perm.size(0), (const double*)p(cur_length), (int64_t*)p(best_i),
-                         (int64_t*)p(best_j), (double*)p(best_value), cur_stream(perm)), "rls_tsp_2opt_best");
+    ok(rls_tsp_2opt_best((const double*)p(dist), perm.size(1), (const int64_t*)p(perm), perm.size(0), (const double*)p(cur_length), (int32_t)slices,
+                         (int64_t*)p(best_i), (int64_t*)p(best_j), (double*)p(best_value), cur_stream(perm)), "rls_tsp_2opt_best");
 }
 void tsp_2opt_delta(const Tensor& dist, const Tensor& perm, const Tensor& i, const Tensor& j, Tensor delta) {
     dev(dist, "dist", F32);

@@ -262,11 +262,12 @@ def rand_perms(B: int, N: int, seed: int, device, env_offset: int = 0) -> TEN:
     return out
 
 
-def tsp_2opt_best(dist64: TEN, perm: TEN, cur_length: Optional[TEN] = None):
+def tsp_2opt_best(dist64: TEN, perm: TEN, cur_length: Optional[TEN] = None, slices: Optional[int] = None):
     """One best-improvement 2-opt pass per tour (rls_tsp_2opt_best): -> (best_i, best_j int64 [B], best_value f64 [B]).
     ``cur_length`` f64 [B]: candidates ranked by their whole length summed as the reference's distance_calc does (its own
     comparison values); best_value = the best candidate's length, or cur_length and (-1, -1) where none is shorter.
-    Without it: ranked by the O(1) reversal delta (symmetric dist); best_value = the most negative delta, or 0."""
+    Without it: ranked by the O(1) reversal delta (symmetric dist); best_value = the most negative delta, or 0.
+    ``slices`` workgroups share one tour's candidates (default: enough to put ~2 workgroups on every CU)."""
     dev = perm.device
     _check(dist64, "dist", (torch.float64,), dev)
     _check(perm, "perm", (torch.int64,), dev)
@@ -275,8 +276,11 @@ def tsp_2opt_best(dist64: TEN, perm: TEN, cur_length: Optional[TEN] = None):
         raise ValueError(f"dist must be [{N}, {N}]")
     if cur_length is not None:
         _check(cur_length, "cur_length", (torch.float64,), dev, (B,))
-    bi = torch.empty(B, dtype=torch.int64, device=dev)
-    bj = torch.empty(B, dtype=torch.int64, device=dev)
-    bv = torch.empty(B, dtype=torch.float64, device=dev)
-    _abi.call("rls_tsp_2opt_best", _ptr(dist64), N, _ptr(perm), B, _ptr(cur_length), _ptr(bi), _ptr(bj), _ptr(bv), _stream(dev))
-    return bi, bj, bv
+    if slices is None:   # ~512 workgroups in all; a workgroup gets >= 256 candidates (whole-length ranking: O(N) each) or >= 8192 (deltas)
+        per_wg = 256 if cur_length is not None else 8192
+        slices = max(1, min(512 // max(B, 1), (N * (N - 1) // 2 + per_wg - 1) // per_wg))
+    bi = torch.empty(slices * B, dtype=torch.int64, device=dev)
+    bj = torch.empty(slices * B, dtype=torch.int64, device=dev)
+    bv = torch.empty(slices * B, dtype=torch.float64, device=dev)
+    _abi.call("rls_tsp_2opt_best", _ptr(dist64), N, _ptr(perm), B, _ptr(cur_length), slices, _ptr(bi), _ptr(bj), _ptr(bv), _stream(dev))
+    return bi[:B], bj[:B], bv[:B]

@@ -483,3 +483,11 @@ def test_tsp_2opt_local_search_golden(golden):
     assert r2 == r and dist2 == dist
     with pytest.raises(ValueError):
         t2.local_search_2_opt_batch(d + np.triu(np.ones_like(d), 1), dev(perms))   # asymmetric
+    # any number of workgroups per tour picks the same pair (ties included: a matrix of small integers)
+    di = dev(np.rint(d / 10.0))
+    cur = di[dev(perms), torch.roll(dev(perms), -1, 1)].sum(1)
+    for cl in (None, cur):
+        want = mops.tsp_2opt_best(di, dev(perms), cl, slices=1)
+        for sl in (2, 7, None):
+            got = mops.tsp_2opt_best(di, dev(perms), cl, slices=sl)
+            assert all(torch.equal(g, w) for g, w in zip(got, want)), (cl is None, sl)
