@@ -72,6 +72,17 @@ class SpinBasis(Enum):
     BINARY = 2
 
 
+class ExtraAction(Enum):  # util_envs.py:24-27
+    PASS = 1
+    RANDOMISE = 2
+    NONE = 3
+
+
+class OptimisationTarget(Enum):  # util_envs.py:30-32
+    CUT = 1
+    ENERGY = 2
+
+
 _ROW_ORDER = [Observable.IMMEDIATE_REWARD_AVAILABLE, Observable.TIME_SINCE_FLIP, Observable.EPISODE_TIME,
               Observable.TERMINATION_IMMANENCY, Observable.NUMBER_OF_GREEDY_ACTIONS_AVAILABLE,
               Observable.DISTANCE_FROM_BEST_SCORE, Observable.DISTANCE_FROM_BEST_STATE]
@@ -118,6 +129,8 @@ class SpinSystem:
         self.horizon_length = horizon_length if horizon_length is not None else max_steps
         self.stag_punishment, self.basin_reward = stag_punishment, basin_reward
         self.reversible_spins = True
+        self.extra_action, self.optimisation_target = ExtraAction.NONE, OptimisationTarget.CUT
+        self.memory_length = None
         self.include_adjacency = include_adjacency
         self.action_space = self._ActionSpace(self.n_actions, self.device)
         self.observation_space = self._ObservationSpace(self.n_spins, len(observables))
@@ -316,6 +329,42 @@ class SpinSystem:
         for k in keys:
             getattr(self, k).copy_(d[k.lstrip("_")])     # in place: the kernel's pointer table stays valid
         self.current_step = int(d["current_step"])
+
+
+class SpinSystemFactory:
+    """SpinSystemFactory.get of spinsystem_PECO.py:16-47 (what ``ising_env.make("SpinSystem", ...)`` of core.py:9-16 calls, as
+    train_PECO.py:75-86 does): the batched env on the generator's graphs.  Only the configuration the reference's agents run is
+    built -- ExtraAction.NONE (dqn_PECO.py:252 asserts it), OptimisationTarget.CUT, infinite memory, reversible spins, unbiased
+    graphs; anything else raises NotImplementedError instead of silently doing something different."""
+
+    @staticmethod
+    def get(graph_generator=None, max_steps=20, observables=ECO_PECO_OBSERVABLES, reward_signal=RewardSignal.DENSE,
+            extra_action=ExtraAction.PASS, optimisation_target=OptimisationTarget.ENERGY, spin_basis=SpinBasis.SIGNED,
+            norm_rewards=False, memory_length=None, horizon_length=None, stag_punishment=None, basin_reward=None,
+            reversible_spins=True, init_snap=None, seed=None, device=None, num_envs=None):
+        unsupported = [name for name, bad in (("extra_action", extra_action.name != "NONE"),
+                                              ("optimisation_target", optimisation_target.name != "CUT"),
+                                              ("memory_length", memory_length is not None), ("reversible_spins", not reversible_spins),
+                                              ("init_snap", init_snap is not None),
+                                              ("biased graphs", bool(getattr(graph_generator, "biased", False)))) if bad]
+        if unsupported:
+            raise NotImplementedError("SpinSystem on the device supports ExtraAction.NONE, OptimisationTarget.CUT, infinite memory, "
+                                      f"reversible spins, unbiased graphs; got {', '.join(unsupported)}")
+        if seed is not None:
+            np.random.seed(seed)                              # spinsystem_PECO.py:98-99
+        same = lambda enum, v: enum[v.name]                   # the reference's own enum members are accepted by name
+        if num_envs is None:
+            num_envs = graph_generator.num_envs
+        return SpinSystem(None, None, num_envs, max_steps, [same(Observable, o) for o in observables], same(RewardSignal, reward_signal),
+                          same(SpinBasis, spin_basis), norm_rewards, horizon_length, stag_punishment, basin_reward, device,
+                          graph_generator=graph_generator)
+
+
+def make(id2, *args, **kwargs):
+    """ECO_S2V/src/envs/core.py:9-16."""
+    if id2 == "SpinSystem":
+        return SpinSystemFactory.get(*args, **kwargs)
+    raise NotImplementedError()
 
 
 class SpinSystemUnbiased:

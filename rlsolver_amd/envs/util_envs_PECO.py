@@ -74,6 +74,33 @@ class RandomBAGraphGenerator(_KernelGenerator):
         self.m_insertion_edges = self._m = m_insertion_edges
 
 
+class ValidationGraphGenerator(GraphGenerator):
+    """util_envs_PECO.py:115-136: num_envs fixed networkx graphs -- barabasi_albert_graph(n, 4, seed) / erdos_renyi_graph(n, 0.15,
+    seed) with seeds seed, seed + 1, ... -- as unit-weight matrices, zero diagonal; the same batch at every get().  Built on
+    the host once (the reference rebuilds it per call)."""
+
+    def __init__(self, device, n_spins=20, edge_type=EdgeType.DISCRETE, num_envs=2 ** 3, seed=None, graph_type="BA"):
+        super().__init__(n_spins, edge_type, False, num_envs)
+        import networkx as nx
+        import numpy as np
+        kind = getattr(graph_type, "name", graph_type)
+        if kind not in ("BA", "ER"):
+            raise NotImplementedError(f"graph_type {graph_type}")
+        if seed is None:
+            raise ValueError("ValidationGraphGenerator needs a seed (the reference returns uninitialised memory without one)")
+        mats = []
+        for k in range(num_envs):
+            g = nx.barabasi_albert_graph(n_spins, 4, seed=seed + k) if kind == "BA" else nx.erdos_renyi_graph(n_spins, 0.15, seed=seed + k)
+            m = nx.to_numpy_array(g).astype("float32")
+            np.fill_diagonal(m, 0)
+            mats.append(m)
+        self.device, self.seed, self.graph_type = torch.device(device), seed, graph_type
+        self.adj = torch.from_numpy(np.stack(mats)).to(self.device)
+
+    def get(self, with_padding=False):
+        return self.adj
+
+
 class SetGraphGenerator(GraphGenerator):
     """A fixed batch of matrices [num_envs, n_spins, n_spins] handed back at every get() (validation sets, recorded graphs:
     util_envs_PECO.py:115-172 build theirs with networkx on the host and return the same kind of tensor)."""

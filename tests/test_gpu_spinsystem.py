@@ -350,3 +350,31 @@ def test_per_env_matrices_equal_the_shared_graph_env_on_one_graph(dtype):
     for t in range(T // 2, T):
         o3, _, _ = dense.step(acts[t].to(DEV))
     assert torch.equal(o3, end_obs)
+
+
+def test_factory_make_builds_the_training_and_validation_envs():
+    """ising_env.make("SpinSystem", generator, max_steps, **env_args, device=, num_envs=) as train_PECO.py:33-86 calls it; the
+    validation generator hands back networkx's seeded graphs; configurations the device env does not build raise."""
+    import networkx as nx
+    from rlsolver_amd.envs import spinsystem as ss
+    from rlsolver_amd.envs.util_envs_PECO import EdgeType, RandomBAGraphGenerator, ValidationGraphGenerator
+    n, B = 20, 16
+    env_args = dict(observables=ss.ECO_PECO_OBSERVABLES, reward_signal=ss.RewardSignal.BLS, extra_action=ss.ExtraAction.NONE,
+                    optimisation_target=ss.OptimisationTarget.CUT, spin_basis=ss.SpinBasis.BINARY, norm_rewards=True, memory_length=None,
+                    horizon_length=None, stag_punishment=None, basin_reward=1.0 / n, reversible_spins=True)
+    train = ss.make("SpinSystem", RandomBAGraphGenerator(n, 4, EdgeType.DISCRETE, B, DEV), 2 * n, **env_args, device=DEV, num_envs=B)
+    assert train.extra_action == ss.ExtraAction.NONE and train.num_envs == B and train.max_steps == 2 * n
+    obs, rew, done = train.step(torch.zeros(B, dtype=torch.int64, device=DEV))
+    assert obs.shape == (B, 7 + n, n) and rew.shape == (B,) and not bool(done.any())
+    vg = ValidationGraphGenerator(DEV, n_spins=n, num_envs=4, seed=30, graph_type="BA")
+    test = ss.make("SpinSystem", vg, 2 * n, **env_args, device=DEV, num_envs=4)
+    want = np.stack([nx.to_numpy_array(nx.barabasi_albert_graph(n, 4, seed=30 + k)) for k in range(4)]).astype(np.float32)
+    assert np.array_equal(test.matrix.cpu().numpy(), want) and np.array_equal(vg.get().cpu().numpy(), want)
+    s = test.state[:, 0, :]
+    assert torch.equal(test.calculate_cut(), (0.25 * (test.matrix.sum((1, 2)) - (s * torch.einsum("bij,bj->bi", test.matrix, s)).sum(1))))
+    for bad in (dict(extra_action=ss.ExtraAction.PASS), dict(optimisation_target=ss.OptimisationTarget.ENERGY), dict(memory_length=5),
+                dict(reversible_spins=False)):
+        with pytest.raises(NotImplementedError):
+            ss.make("SpinSystem", vg, 2 * n, **{**env_args, **bad}, device=DEV, num_envs=4)
+    with pytest.raises(NotImplementedError):
+        ss.make("Other", vg)
