@@ -257,8 +257,9 @@ def spin_train_suite(tag, n, m_ins, B, T, iters):
             adj[rows, v, pick] = 1
             adj[rows, pick, v] = 1
         return adj
-    t0 = timeit(lambda i: torch_ba(), 2, warm=1)
-    emit(tag, "the same draw as a torch op chain (per-node loop, as the reference generator)", "graphs", B, t0, 4 * n * n, "baseline beside rand_couplings")
+    if not a.profile:   # thousands of small torch kernels: kept out of the rocprofv3 passes
+        t0 = timeit(lambda i: torch_ba(), 2, warm=1)
+        emit(tag, "the same draw as a torch op chain (per-node loop, as the reference generator)", "graphs", B, t0, 4 * n * n, "baseline beside rand_couplings")
     env = SpinSystem(None, None, B, max_steps=T, observables=ECO_PECO_OBSERVABLES, reward_signal=RewardSignal.BLS, norm_rewards=True,
                      spin_basis=SpinBasis.BINARY, device=dev, graph_generator=gg)
     t = timeit(lambda i: env.reset(), max(3, iters // 3), warm=1)

@@ -41,8 +41,11 @@ ROWS = [
     (r"k_node_stats_bits<2", T22 * 512, 65536, 5 * N22, "ls_weights pre-pass | G22 2^16"),
     (r"k_tsp_tour_length", None, 65536, 8 * NT + 4, "K12 tsp_tour_length | TSP-100 2^16"),
     (r"k_tsp_swap_delta_all", None, 65536, 29 * NT, "K13 tsp_swap_delta_all | TSP-100 2^16"),
-    (r"k_spin_step<float, true>", 16384 * 64, 16384, 24 * N22, "S1 spin_step | G22-sized 2^14 (6 rows x 4N change per step)"),
-    (r"k_spin_step<float, true>", 4096 * 64, 4096, 24 * 200, "S1 spin_step | BA-200 4096"),
+    (r"k_spin_step<float, true, false>", 16384 * 64, 16384, 24 * N22, "S1 spin_step | G22-sized 2^14 (6 rows x 4N change per step)"),
+    (r"k_spin_step<float, true, false>", 4096 * 64, 4096, 24 * 200, "S1 spin_step | BA-200 4096"),
+    (r"k_spin_step<float, true, true>", 1024 * 64, 1024, 28 * 200, "S1d spin_step_dense | per-env BA-200 matrices, 1024 envs (launch-bound)"),
+    (r"k_spin_observation<float, true>", 41 * 1024 * 256, 1024, 4 * (207 * 200 + 7 * 200 + 200 * 200), "S1d observation [B, 7+N, N] with per-env matrix rows | BA-200 1024"),
+    (r"k_rand_couplings_ba<float>", 128 * 64, 1024, 4 * 200 * 200, "rand_couplings BA (m=4) | 1024 x BA-200 (a dependent chain per env: latency-bound)"),
     (r"k_qubo_ls_value", None, None, None, None),
     (r"k_mcpg_local_search_levels<float, rls::Packed64", None, 262144, 4 * NBA + NBA // 8, "K7+K8 local_search_levels, f32 [N,C] in -> packed out | BA-1e4 2^18"),
     (r"k_mcpg_local_search_levels<rls::Packed64, rls::Packed64", None, 262144, 2 * (NBA // 8), "K7+K8 local_search_levels, bit-packed in place | BA-1e4 2^18 (VALU-bound)"),

@@ -20,5 +20,5 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${P}_cfg_fetch -
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${P}_cfg_write -o $P -- $CFG > $R/gpurun_out/${P}_cfg_write.jsonl 2> $R/gpurun_out/${P}_cfg_write.err
 cd $R
 # the raw per-dispatch traces are large; keep the stats and the counter tables
-find gpurun_out/${P}_* -name "*_kernel_trace.csv" -size +8M -delete; find gpurun_out/${P}_* -name "*.db" -delete
+find gpurun_out/${P}_* -name "*_kernel_trace.csv" -size +24M -delete; find gpurun_out/${P}_* -name "*.db" -delete
 ls -la gpurun_out/${P}_*
