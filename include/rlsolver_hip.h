@@ -515,6 +515,7 @@ int rls_tsp_2opt_delta(const float* dist, int64_t N, const int64_t* perm, int64_
  *     (best_i, best_j)[b] the pair, or cur_length[b] and (-1, -1) when no candidate is shorter.  O(N) per candidate.
  *   cur_length == NULL: candidates are compared by delta(i, j) = D[a,c] + D[b,e] - D[a,b] - D[c,e] (rls_tsp_2opt_delta's
  *     formula in float64; SYMMETRIC dist), O(1) per candidate: best_value[b] = the most negative delta, or 0 / (-1, -1).
+ * perm rows must be permutations of 0..N-1 (not checked on the device).
  * slices >= 1 workgroups share the candidates of one tour (a lone tour still fills the chip): best_i, best_j and best_value
  * must then hold slices * B entries; the results are the first B of each (the rest is scratch). */
 int rls_tsp_2opt_best(const double* dist, int64_t N, const int64_t* perm, int64_t B, const double* cur_length, int32_t slices,

@@ -63,6 +63,8 @@ def local_search_2_opt_batch(distance_matrix, perms, max_passes: int = -1, exact
         raise TypeError("local_search_2_opt_batch needs a HIP device; there is no CPU path")
     d = _device_matrix(distance_matrix, perms.device, symmetric=not exact)
     perms = perms.to(torch.int64).contiguous().clone()
+    if perms.dim() != 2 or perms.shape[1] != d.shape[0] or not bool((perms.sort(dim=1).values == torch.arange(d.shape[0], device=perms.device)).all()):
+        raise ValueError("perms must be [B, N] permutations of 0..N-1")
     if exact:
         cur = (_lengths(d, perms) if lengths is None else lengths.to(torch.float64)).contiguous().clone()
     done = 0
@@ -84,8 +86,11 @@ def local_search_2_opt(distance_matrix, city_tour, recursive_seeding: int = -1, 
     if device.type != "cuda":
         raise TypeError("local_search_2_opt needs a HIP device; there is no CPU path")
     route = [int(c) for c in city_tour[0]]
-    perm = torch.tensor([[c - 1 for c in route[:-1]]], dtype=torch.int64, device=device)
     d = _device_matrix(distance_matrix, device, symmetric=False)
+    n = d.shape[0]
+    if len(route) != n + 1 or route[0] != route[-1] or sorted(route[:-1]) != list(range(1, n + 1)):
+        raise ValueError("city_tour[0] must be a closed tour over cities 1..N (first city repeated at the end)")
+    perm = torch.tensor([[c - 1 for c in route[:-1]]], dtype=torch.int64, device=device)
     distance = city_tour[1]
     cur = torch.tensor([float(distance)], dtype=torch.float64, device=device)
     iteration = 0

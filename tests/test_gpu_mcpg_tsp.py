@@ -483,6 +483,9 @@ def test_tsp_2opt_local_search_golden(golden):
     assert r2 == r and dist2 == dist
     with pytest.raises(ValueError):
         t2.local_search_2_opt_batch(d + np.triu(np.ones_like(d), 1), dev(perms))   # asymmetric
+    for bad_route in ([1, 2, 3, 1], list(range(1, N + 1)) + [2], [1] + list(range(1, N)) + [1]):
+        with pytest.raises(ValueError):
+            t2.local_search_2_opt(d, [bad_route, 1.0], verbose=False, device=DEV)
     # any number of workgroups per tour picks the same pair (ties included: a matrix of small integers)
     di = dev(np.rint(d / 10.0))
     cur = di[dev(perms), torch.roll(dev(perms), -1, 1)].sum(1)
