@@ -298,3 +298,61 @@ def test_level_parallel_sweep_with_rows_on_several_lanes_vs_c_oracle(n, m, B, bi
     oc.greedy_sweep(wx, wv, eu, ev, int(bidir))
     assert np.array_equal(x5.cpu().numpy().astype(np.uint8)[sub], wx) and np.array_equal(v5.cpu().numpy()[sub], wv)
     assert torch.equal(ops.maxcut_obj(g, x5), v5)
+
+
+def test_training_envs_at_the_reference_size_stay_consistent():
+    """PECO training config (train_PECO.py): 1024 envs, a BA-200 graph each (m = 4, DISCRETE signs), ECO observables, BLS +
+    basin reward, 2N steps: the resident gain cache equals s * (W s) on every env's own matrix at the end of the episode, the
+    score equals the cut of the final spins plus the reference's self-loop bookkeeping, rewards are finite, best >= start."""
+    from rlsolver_amd.envs import spinsystem as ss
+    from rlsolver_amd.envs.util_envs_PECO import EdgeType, RandomBAGraphGenerator
+    n, B = 200, 1024
+    torch.manual_seed(1)
+    env = ss.make("SpinSystem", RandomBAGraphGenerator(n, 4, EdgeType.DISCRETE, B, DEV), 2 * n, observables=ss.ECO_PECO_OBSERVABLES,
+                  reward_signal=ss.RewardSignal.BLS, extra_action=ss.ExtraAction.NONE, optimisation_target=ss.OptimisationTarget.CUT,
+                  spin_basis=ss.SpinBasis.BINARY, norm_rewards=True, basin_reward=1.0 / n, device=DEV, num_envs=B)
+    W = env.matrix
+    start = env.score.clone()
+    diag_flips = torch.zeros(B, device=DEV)
+    wd = torch.diagonal(W, dim1=1, dim2=2)
+    for t in range(2 * n):
+        a = ops.rand_actions(B, n, 5, t, DEV)
+        diag_flips += wd.gather(1, a[:, None])[:, 0]
+        obs, rew, done = env.step(a)
+        assert bool(torch.isfinite(rew).all())
+    assert bool(done.all()) and obs.shape == (B, 7 + n, n) and torch.equal(obs[:, 7:, :], W)
+    s = env.state[:, 0, :]
+    assert torch.equal(env._delta.to(torch.float32), s * torch.einsum("bij,bj->bi", W, s))
+    # every flip of a self-loop node moved the score by W_aa less than the cut did (delta_a - 2 W_aa vs delta_a - W_aa)
+    assert torch.equal(env.score, env.calculate_cut() - diag_flips)
+    assert bool((env.best_score >= start).all())
+
+
+def test_2opt_pass_on_a_lone_thousand_city_tour():
+    """One exact best-improvement pass on 1000 cities (~500 workgroups share the 499 500 candidates): the reported length is
+    the float64 sequential sum of the reported reversal, and no sampled candidate is shorter."""
+    from rlsolver_amd.methods import tsp_opt_2 as t2
+    rng = np.random.RandomState(8)
+    N = 1000
+    c = rng.rand(N, 2)
+    d = np.sqrt(((c[:, None] - c[None]) ** 2).sum(-1))
+    tour = [int(v) + 1 for v in rng.permutation(N)]
+    tour.append(tour[0])
+    cur = onp.tsp_distance_calc(d, tour)
+    dd = torch.from_numpy(d).to(DEV)
+    perm = torch.tensor([[v - 1 for v in tour[:-1]]], device=DEV)
+    bi, bj, bv = mops.tsp_2opt_best(dd, perm, torch.tensor([cur], dtype=torch.float64, device=DEV))
+    i, j, v = int(bi[0]), int(bj[0]), float(bv[0])
+    assert 0 <= i < j < N and v < cur
+
+    def length_after(i, j):
+        cand = list(tour)
+        cand[i:j + 1] = cand[i:j + 1][::-1]
+        cand[-1] = cand[0]
+        return onp.tsp_distance_calc(d, cand)
+    assert length_after(i, j) == v
+    for _ in range(300):
+        a, b = sorted(rng.choice(N, 2, replace=False))
+        assert length_after(int(a), int(b)) >= v
+    route, dist = t2.local_search_2_opt(d, [tour, cur], recursive_seeding=1, verbose=False, device=DEV)
+    assert dist == v and route[:-1][i:j + 1] == tour[:-1][i:j + 1][::-1]
