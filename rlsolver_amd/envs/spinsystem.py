@@ -377,19 +377,31 @@ class SpinSystemUnbiased:
     attrs: n_spins, max_steps, current_step, score, best_score, best_spins, state (np [R, N]), matrix.
     ExtraAction.NONE, OptimisationTarget.CUT, infinite memory, reversible spins (what ECO / S2V use)."""
 
-    def __init__(self, mygraph, num_nodes: int, max_steps: int = 20,
+    class _OneGraph:
+        """A single-instance generator (get() -> [N, N] array, ECO_S2V/src/envs/util_envs.py:87-330) as a batch of one."""
+
+        def __init__(self, gg):
+            self.gg, self.n_spins, self.biased = gg, int(gg.n_spins), bool(getattr(gg, "biased", False))
+
+        def get(self):
+            return torch.as_tensor(np.asarray(self.gg.get(), dtype=np.float64))[None]
+
+    def __init__(self, mygraph, num_nodes: Optional[int], max_steps: int = 20,
                  observables: Sequence[Observable] = ECO_PECO_OBSERVABLES,
                  reward_signal: RewardSignal = RewardSignal.DENSE, spin_basis: SpinBasis = SpinBasis.SIGNED,
                  norm_rewards: bool = False, horizon_length: Optional[int] = None,
                  stag_punishment: Optional[float] = None, basin_reward: Optional[float] = None, device=None,
-                 init_spins=None):
+                 init_spins=None, graph_generator=None):
+        """``graph_generator`` (instead of mygraph): a fresh graph at every reset, as the ECO / S2V training loops run their
+        envs (train_ECO.py:83-94; any object with n_spins and get() -> [N, N] symmetric integer-valued array)."""
+        gg = self._OneGraph(graph_generator) if graph_generator is not None else None
+        num_nodes = gg.n_spins if gg is not None and num_nodes is None else num_nodes
         self._env = SpinSystem(mygraph, num_nodes, 1, max_steps, observables, reward_signal, spin_basis, norm_rewards,
                                horizon_length, stag_punishment, basin_reward, device, include_adjacency=True,
-                               dtype=torch.float64)
+                               dtype=torch.float64, graph_generator=gg)
         self.n_spins, self.max_steps, self.n_actions = num_nodes, max_steps, num_nodes
         self.observables = self._env.observables
         self.action_space, self.observation_space = self._env.action_space, self._env.observation_space
-        self.max_local_reward_available = self._env._max_local
         if init_spins is not None:
             self.reset(init_spins)
 
@@ -406,12 +418,13 @@ class SpinSystemUnbiased:
     def get_observation(self):
         return self._obs(self._env.get_observation())
 
+    max_local_reward_available = property(lambda self: float(self._env.max_local_reward_available_[0]))
     current_step = property(lambda self: self._env.current_step)
     score = property(lambda self: float(self._env.score[0]))
     best_score = property(lambda self: float(self._env.best_score[0]))
     best_spins = property(lambda self: self._env.best_spins[0].cpu().numpy())
     state = property(lambda self: self._env.state[0].cpu().numpy())
-    matrix = property(lambda self: self._env.matrix.cpu().numpy())
+    matrix = property(lambda self: (self._env.matrix[0] if self._env._dense else self._env.matrix).cpu().numpy())
 
     def get_immeditate_rewards_avaialable(self, spins=None):
         return self._env._delta[0].cpu().numpy().astype(np.float64)

@@ -378,3 +378,37 @@ def test_factory_make_builds_the_training_and_validation_envs():
             ss.make("SpinSystem", vg, 2 * n, **{**env_args, **bad}, device=DEV, num_envs=4)
     with pytest.raises(NotImplementedError):
         ss.make("Other", vg)
+
+
+def test_single_instance_env_on_a_graph_generator():
+    """SpinSystemUnbiased (float64, one env) with graph_generator=: a fresh [N, N] graph per reset, the same trajectory as the
+    env built on that graph's edge list."""
+    from rlsolver_amd.envs.spinsystem import ECO_PECO_OBSERVABLES, RewardSignal, SpinBasis, SpinSystemUnbiased
+    n = 30
+    rng = np.random.RandomState(6)
+
+    class Gen:
+        n_spins, biased, calls = n, False, 0
+
+        def get(self):
+            Gen.calls += 1
+            r = np.random.RandomState(100 + Gen.calls)
+            up = np.triu((r.rand(n, n) < 0.25) * r.choice([-1, 1], size=(n, n)), 1)
+            return (up + up.T).astype(np.float64)
+
+    kw = dict(max_steps=2 * n, observables=ECO_PECO_OBSERVABLES, reward_signal=RewardSignal.BLS, spin_basis=SpinBasis.BINARY,
+              norm_rewards=True, basin_reward=1.0 / n, device=DEV)
+    env = SpinSystemUnbiased(None, None, graph_generator=Gen(), **kw)
+    assert Gen.calls == 1 and env.n_spins == n
+    spins = rng.randint(0, 2, size=n).astype(np.float64)
+    obs = env.reset(spins)
+    W = env.matrix
+    assert Gen.calls == 2 and obs.shape == (7 + n, n) and np.array_equal(obs[7:], W) and obs.dtype == np.float64
+    ref = SpinSystemUnbiased([(i, j, int(W[i, j])) for i in range(n) for j in range(i + 1, n) if W[i, j]], n, **kw)
+    obs2 = ref.reset(spins)
+    assert np.array_equal(obs, obs2) and env.max_local_reward_available == ref.max_local_reward_available
+    for t in range(2 * n):
+        a = int(rng.randint(n))
+        (o1, r1, d1, _), (o2, r2, d2, _) = env.step(a), ref.step(a)
+        assert np.array_equal(o1, o2) and r1 == r2 and d1 == d2
+    assert env.best_score == ref.best_score and np.array_equal(env.best_spins, ref.best_spins)
