@@ -259,6 +259,25 @@ class SpinSystem:
     def calculate_score(self, spins=None):
         return self.calculate_cut(spins)
 
+    def _termination(self):
+        """max(0, (current_step - max_steps) / horizon_length + 1), evaluated in the env's float type like the reference."""
+        if self.dtype == torch.float32:
+            return float(max(np.float32(0.0), np.float32((self.current_step - self.max_steps) / self.horizon_length) + np.float32(1)))
+        return max(0.0, ((self.current_step - self.max_steps) / self.horizon_length) + 1)
+
+    def _step_consts(self):
+        """Everything a step passes that does not change from step to step (rebuilt when a public knob was reassigned)."""
+        key = (self.reward_signal, self.norm_rewards, self.stag_punishment, self.basin_reward, self.max_steps)
+        c = getattr(self, "_consts", None)
+        if c is None or c["key"] != key:
+            c = self._consts = dict(
+                key=key, env=C.byref(self._env), R=self.state.shape[1], visited=_ptr(self._visited_new),
+                time_inc=self._round(1.0 / self.max_steps), mode=_REWARD_MODE[self.reward_signal],
+                div=float(self.n_spins) if self.norm_rewards else 1.0,
+                tail=(int(self.stag_punishment is not None), self._round(self.stag_punishment or 0.0),
+                      int(self.basin_reward is not None), self._round(self.basin_reward or 0.0)))   # the stream is resolved per call
+        return c
+
     def step(self, action):
         """spinsystem_PECO.py:306-486 -> (obs, reward [B], done bool [B])"""
         self.current_step += 1
@@ -266,25 +285,20 @@ class SpinSystem:
             print("The environment has already returned done. Stop it!")
             raise NotImplementedError
         B = self.num_envs
-        action = torch.as_tensor(action, device=self.device).to(torch.int64).reshape(B).contiguous()
+        if not (torch.is_tensor(action) and action.dtype == torch.int64 and action.device == self.device and action.shape == (B,)
+                and action.is_contiguous()):
+            action = torch.as_tensor(action, device=self.device).to(torch.int64).reshape(B).contiguous()
         rew = torch.empty(B, dtype=self.dtype, device=self.device)
-        # max(0, (current_step - max_steps) / horizon_length + 1), evaluated in the env's float type like the reference
-        if self.dtype == torch.float32:
-            term = float(max(np.float32(0.0), np.float32((self.current_step - self.max_steps) / self.horizon_length) + np.float32(1)))
-        else:
-            term = max(0.0, ((self.current_step - self.max_steps) / self.horizon_length) + 1)
-        tail = (_REWARD_MODE[self.reward_signal], float(self.n_spins) if self.norm_rewards else 1.0,
-                self.current_step - 1, int(self.stag_punishment is not None),
-                self._round(self.stag_punishment or 0.0), int(self.basin_reward is not None),
-                self._round(self.basin_reward or 0.0), _stream(self.device))
+        c = self._step_consts()
         if self._dense:
-            _abi.call("rls_spin_step_dense", _ptr(self._matrix), _ptr(self.max_local_reward_available_), C.byref(self._env),
-                      self._sb, B, self.n_spins, self.state.shape[1], self._rows, _ptr(action), _ptr(rew), _ptr(self._visited_new),
-                      self._round(1.0 / self.max_steps), term, *tail)
+            _abi.call("rls_spin_step_dense", _ptr(self._matrix), _ptr(self.max_local_reward_available_), c["env"],
+                      self._sb, B, self.n_spins, c["R"], self._rows, _ptr(action), _ptr(rew), c["visited"],
+                      c["time_inc"], self._termination(), c["mode"], c["div"], self.current_step - 1, *c["tail"],
+                      _stream(self.device))
         else:
-            _abi.call("rls_spin_step", self.graph.ref, C.byref(self._env), self._sb, B, self.state.shape[1], self._rows,
-                      _ptr(action), _ptr(rew), _ptr(self._visited_new), self._max_local, self._round(1.0 / self.max_steps), term,
-                      *tail)
+            _abi.call("rls_spin_step", self.graph.ref, c["env"], self._sb, B, c["R"], self._rows,
+                      _ptr(action), _ptr(rew), c["visited"], self._max_local, c["time_inc"], self._termination(), c["mode"], c["div"],
+                      self.current_step - 1, *c["tail"], _stream(self.device))
         done = torch.full((B,), self.current_step == self.max_steps, dtype=torch.bool, device=self.device)
         return self.get_observation(), rew, done
 
