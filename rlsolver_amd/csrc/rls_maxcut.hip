@@ -388,7 +388,7 @@ __global__ __launch_bounds__(kTileWaves * kWave) void k_node_stats_tile(const ui
 }
 
 // =====================================================================================
-// K2 / K3 / local-search weights, bit-sliced with LANE = NODE (unweighted graphs, max degree < 256).
+// K2 / K3 / local-search weights, bit-sliced with LANE = NODE (unweighted graphs, max degree < 65536).
 // In the lane = env form above every (env, node, neighbour) costs ~4.5 instructions of one lane; here a lane owns
 // a node and works on 64-env WORDS: per neighbour one random ds_read_b64, one XOR with the node's own word and
 // a carry-save add into vertical counters -- c(e, i) = #{j in adj(i) : x_j != x_i} for all 64 envs in ~10
@@ -411,7 +411,22 @@ __device__ __forceinline__ uint32_t ns_extract4(const uint64_t (&pl)[8], int hal
     return acc;
 }
 
-template <int MODE, bool VEC>   // MODE 0: cutdeg int64, 1: flip gain int32, 2: local-search weight int32
+// two envs per dword (16-bit fields: counts up to 65535) from NP planes: envs r and r + 16 of the half
+template <int NP, int NPL>
+__device__ __forceinline__ uint32_t ns_extract2(const uint64_t (&pl)[NPL], int half, int r) {
+    uint32_t acc = 0;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const uint32_t h = half ? (uint32_t)(pl[p] >> 32) : (uint32_t)pl[p];
+        acc += ((h >> r) & 0x00010001u) << p;
+    }
+    return acc;
+}
+
+// WIDE: graphs with hubs (256 <= max degree < 65536, e.g. Barabasi-Albert at n = 10^4): 16 counter planes instead of 8; a
+// group whose longest row is >= 256 ripples its carries as far as its rows need and leaves through 16-bit fields, every
+// other group runs exactly as in the narrow kernel.
+template <int MODE, bool VEC, bool WIDE>   // MODE 0: cutdeg int64, 1: flip gain int32, 2: local-search weight int32
 __global__ __launch_bounds__(kNsWaves * kWave) void k_node_stats_bits(const uint8_t* __restrict__ x, int64_t B, int64_t N,
                                                                      const int32_t* __restrict__ rowptr,
                                                                      const int32_t* __restrict__ ell_ptr,
@@ -434,7 +449,13 @@ __global__ __launch_bounds__(kNsWaves * kWave) void k_node_stats_bits(const uint
         const uint64_t own = words[iself];
         const int e0 = ell_ptr[g], e1 = ell_ptr[g + 1];
         const int deg = in ? rowptr[i + 1] - rowptr[i] : 0;
-        uint64_t ones = 0, twos = 0, fours = 0, c[5] = {0, 0, 0, 0, 0};
+        constexpr int NCP = WIDE ? 13 : 5;
+        uint64_t ones = 0, twos = 0, fours = 0, c[NCP];
+#pragma unroll
+        for (int p = 0; p < NCP; ++p) c[p] = 0;
+        const int md = (e1 - e0) >> 6;                        // longest row of the group (wave-uniform)
+        int ncp = 5;                                          // carry planes this group can reach: counts < 8 << ncp
+        if constexpr (WIDE) while ((8 << ncp) <= md) ++ncp;
         for (int k = e0; k < e1; k += 8 * kWave) {
             uint32_t nb[8];
 #pragma unroll
@@ -451,19 +472,36 @@ __global__ __launch_bounds__(kNsWaves * kWave) void k_node_stats_bits(const uint
             csa(foursB, twos, twos, twosA, twosB);
             csa(carry, fours, fours, foursA, foursB);
 #pragma unroll
-            for (int p = 0; p < 5; ++p) {
-                const uint64_t t = c[p] & carry;
-                c[p] ^= carry;
-                carry = t;
+            for (int p = 0; p < NCP; ++p) {
+                if (p < 5 || p < ncp) {
+                    const uint64_t t = c[p] & carry;
+                    c[p] ^= carry;
+                    carry = t;
+                }
             }
         }
         const uint64_t pl[8] = {ones, twos, fours, c[0], c[1], c[2], c[3], c[4]};
-        const int md = (e1 - e0) >> 6;                        // longest row of the group (wave-uniform)
         auto emit = [&](int e, int cnt) {
             if constexpr (MODE == 0) reinterpret_cast<int64_t*>(out_v)[(b0 + e) * N + i] = cnt;
             else if constexpr (MODE == 1) reinterpret_cast<int32_t*>(out_v)[(b0 + e) * N + i] = deg - 2 * cnt;
             else reinterpret_cast<int32_t*>(out_v)[(b0 + e) * N + i] = deg - mult * cnt;
         };
+        if constexpr (WIDE) {
+            if (md >= 256) {                                  // a hub group: 16-bit fields, two envs per dword
+                const uint64_t pw[16] = {ones, twos, fours, c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8], c[9], c[10], c[11], c[12]};
+                for (int half = 0; half < 2; ++half) {
+                    for (int r = 0; r < 16; ++r) {
+                        const uint32_t acc = md < 1024 ? ns_extract2<10>(pw, half, r) : ns_extract2<16>(pw, half, r);
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const int e = half * 32 + r + 16 * j;
+                            if (e < nenv && in) emit(e, (int)((acc >> (16 * j)) & 0xFFFFu));
+                        }
+                    }
+                }
+                continue;
+            }
+        }
         if (nenv == kWave) {
             // full tile: no per-store guards (each cost a scalar compare / exec save / branch around a 4-instruction store)
             if (in) {
@@ -501,7 +539,7 @@ static inline size_t node_stats_bits_lds(int64_t N) {
 // the bit-sliced kernel needs the slabs, an unweighted graph, byte-sized counters and a tile that fits
 static inline bool node_stats_use_bits(const rls_graph* g, const int32_t* ell_ptr, const int32_t* ell, int64_t B) {
     static const bool off = getenv("RLS_NODE_STATS_LANE_ENV") != nullptr;   // dev knob: the lane = env kernels
-    return !off && ell_ptr && ell && !g->wgt && g->max_degree < 256 && B >= 2048 &&
+    return !off && ell_ptr && ell && !g->wgt && g->max_degree < 65536 && B >= 2048 &&
            node_stats_bits_lds(g->num_nodes) <= (size_t)kLdsBytes;
 }
 template <int MODE>
@@ -511,7 +549,9 @@ static int launch_node_stats_bits(const rls_graph* g, const uint8_t* x, int64_t 
     const size_t lds = node_stats_bits_lds(N);
     const dim3 grid((unsigned)ceil_div(B, kWave)), block(kNsWaves * kWave);
     const bool vec = tile_rows_aligned(x, N, 1);
-    auto kern = vec ? k_node_stats_bits<MODE, true> : k_node_stats_bits<MODE, false>;
+    const bool wide = g->max_degree >= 256;
+    auto kern = wide ? (vec ? k_node_stats_bits<MODE, true, true> : k_node_stats_bits<MODE, false, true>)
+                     : (vec ? k_node_stats_bits<MODE, true, false> : k_node_stats_bits<MODE, false, false>);
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, grid, block, lds, as_stream(stream), x, B, N, rowptr, ell_ptr, ell, mult, out);

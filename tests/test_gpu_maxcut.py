@@ -319,3 +319,45 @@ def test_rand_spins_is_one_sequence_whatever_kernel_writes_it():
     assert not bool(big[:, 0].any()) and 0.45 < float(big[:, 1:].float().mean()) < 0.55
     wide = ops.rand_spins(5, 10000, 99, DEV)                    # two trips of 64 blocks per row
     assert torch.equal(wide[:, :2000], big[:5])
+
+
+@pytest.mark.parametrize("case", ["ba_hubs", "star", "two_hubs_1100"])
+def test_node_stats_on_hub_graphs(case):
+    """K2 / K3 / local-search weights on graphs with hubs (max degree >= 256: the bit-sliced kernel's 16-plane form, 16-bit
+    fields for the hub groups; >= 1024 for the widest extraction) against the dense expression s * (A s), full and ragged
+    tiles, both adjacency forms."""
+    from rlsolver_amd.graph import generate_ba
+    rng = np.random.RandomState(12)
+    if case == "ba_hubs":
+        n = 5000
+        graph = np.asarray(generate_ba(n, 10, 4), dtype=np.int64)
+    elif case == "star":
+        n = 700
+        graph = np.asarray([(0, j, 1) for j in range(1, n)] + [(j, j + 1, 1) for j in range(1, n - 1, 3)], dtype=np.int64)
+    else:
+        n = 1500
+        e = {(0, j) for j in range(1, 1101)} | {(700, j) for j in range(701, 1400)} | {tuple(sorted(p)) for p in rng.randint(0, n, (3000, 2)) if p[0] != p[1]}
+        graph = np.asarray([(a, b, 1) for a, b in sorted(e)], dtype=np.int64)
+    deg = np.bincount(graph[:, :2].ravel(), minlength=n)
+    assert deg.max() >= 256
+    for bidir in (0, 1):
+        g = device_graph(graph, n, bidir)
+        A = torch.zeros((n, n), device=DEV)
+        A[graph[:, 0], graph[:, 1]] = 1
+        A = A + A.t()
+        for B in (2048, 2048 + 37):
+            xs = ops.rand_spins(B, n, 3 + B, DEV)
+            s = 2 * xs.float() - 1
+            want_delta = (s * (s @ A)).to(torch.int32)                           # sum_j (x_i == x_j ? 1 : -1)
+            assert torch.equal(ops.maxcut_delta_all(g, xs), want_delta)
+            st = A
+            if not bidir:                                                        # stored adjacency = each edge once, at its first node
+                st = torch.zeros((n, n), device=DEV)
+                st[graph[:, 0], graph[:, 1]] = 1
+            sdeg = st.sum(1)
+            cut = ((sdeg[None] - s * (s @ st.t())) / 2)
+            assert torch.equal(ops.maxcut_node_cutdeg(g, xs).float(), cut)
+            assert torch.equal(ops.maxcut_ls_weights(g, xs, 2)[0].float(), sdeg[None] - 2 * cut)
+            rows = [0, 1, B - 1]
+            assert np.array_equal(ops.maxcut_node_cutdeg(g, xs)[rows].cpu().numpy(),
+                                  onp.maxcut_node_cutdeg(xs[rows].cpu().numpy(), graph, n, bool(bidir)))

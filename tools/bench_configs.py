@@ -15,7 +15,7 @@ from rlsolver_amd.methods import MCPG as amcpg
 ap = argparse.ArgumentParser()
 ap.add_argument("--quick", action="store_true")
 ap.add_argument("--profile", action="store_true", help="few launches per kernel: for rocprofv3 passes (PMC serialises kernels)")
-ap.add_argument("--only", default="", help="comma list of suites: maxcut,ls,g70,g14,tsp,isco,spin,qubo,mcpg")
+ap.add_argument("--only", default="", help="comma list of suites: maxcut,synthetic,ls,g70,g14,tsp,isco,spin,qubo,mcpg")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 HBM = 8e12
@@ -45,8 +45,8 @@ def emit(config, kernel, unit, units_per_launch, t, alg_bytes_per_unit=None, not
     print(json.dumps(rec), flush=True)
 
 
-def maxcut_suite(tag, n, m, B, seed, iters):
-    g = ops.DeviceGraph(build_csr(generate_gnm(n, m, seed), num_nodes=n), dev)
+def maxcut_suite(tag, n, m, B, seed, iters, mygraph=None):
+    g = ops.DeviceGraph(build_csr(mygraph if mygraph is not None else generate_gnm(n, m, seed), num_nodes=n), dev)
     S = 4
     slots = [ops.rand_spins(B, n, s, dev) for s in range(S)]
     if B >= 4096:
@@ -68,7 +68,7 @@ def maxcut_suite(tag, n, m, B, seed, iters):
         import types
         from rlsolver_amd.envs.env_PPO import EnvMaxcut as Gym
         for dt, lab in ((torch.float32, "f32 reference surface"), (torch.bool, "1-byte spins")):
-            env = Gym(types.SimpleNamespace(num_nodes=n, num_envs=B, num_steps=10 ** 9), mygraph=generate_gnm(n, m, seed), device=dev,
+            env = Gym(types.SimpleNamespace(num_nodes=n, num_envs=B, num_steps=10 ** 9), mygraph=mygraph if mygraph is not None else generate_gnm(n, m, seed), device=dev,
                       spin_dtype=dt, reuse_buffers=True)
             env.reset()
             te = timeit(lambda i: env.step(acts[i % 8]), max(200, iters * 20))
@@ -319,6 +319,11 @@ only = set(w for w in a.only.split(",") if w)
 want = lambda k: not only or k in only
 if want("maxcut"):
     maxcut_suite("G22-sized G(2000,19990), B=2^16", 2000, 19990, 1 << 16, 22, it)
+if want("synthetic"):   # north_star: "throughput on Gset and synthetic BA/ER graphs"
+    from rlsolver_amd.graph import generate_ba
+    maxcut_suite("BA n=2000 m=4 (hubs: max degree ~150), B=2^16", 2000, 0, 1 << 16, 0, it, mygraph=generate_ba(2000, 4, 3))
+    maxcut_suite("BA n=10000 m=5, B=2^16", 10000, 0, 1 << 16, 0, max(3, it // 3), mygraph=generate_ba(10000, 5, 5))
+    maxcut_suite("ER G(n=2000, p=0.005 -> m=9995), B=2^16", 2000, 9995, 1 << 16, 31, it)
 if want("ls"):
     local_search_suite("G22-sized, dREINFORCE batch", 2000, 19990, 22, 4096, max(2, it // 5))
     local_search_suite("G22-sized, dREINFORCE batch x16", 2000, 19990, 22, 65536, max(2, it // 5))
