@@ -68,7 +68,7 @@ typedef struct rls_graph {
     const int32_t* ell_st_ptr;   /* [ceil(N/64)+1]   adjacency as stored (erowptr/ev): K2, local-search weights */
     const int32_t* ell_st;
     /* Level-parallel form of the sweep schedule (rls_graph_sweep_levels), or NULL / 0 */
-    const int32_t* sweep_lv_ptr; /* [num_sweep_groups+1] offset of each 64-node group in sweep_lv_data, bit 31 = first group of a level */
+    const int32_t* sweep_lv_ptr; /* [num_sweep_groups+1] offset of each 64-lane group in sweep_lv_data, bit 31 = first group of a level, bit 30 = hub group */
     const int32_t* sweep_lv_data;
     int64_t num_sweep_groups;
 } rls_graph;
@@ -104,8 +104,11 @@ int rls_graph_sweep_schedule(const int32_t* rowptr, const int32_t* col, int64_t 
  * *total) so that a group's first eight rounds can be read unguarded.  A wave decides a whole group at once on 64-env
  * words: bit-sliced count of differing neighbours, bit-sliced compare with deg/2, XOR of the flip mask into
  * the node's word -- bit-identical to the sequential pass (see rls_graph_sweep_schedule).
- * lv_ptr [host, groups+1] (bit 31 = first group of a level); lv_data [host, capacity] or NULL to size
- * (*num_groups, *total).  Needs N < 2^20 and max degree < 256. */
+ * A row of 256 or more entries (a hub) is a group of its own, the first of its level, with lane = neighbour:
+ *     64 words  [0] = node, [1] = degree, N elsewhere
+ *     rounds of 64 words  8 nb, the row 64 entries per round, the node's own offset past its end
+ * lv_ptr [host, groups+1] (bit 31 = first group of a level, bit 30 = hub group); lv_data [host, capacity] or NULL to size
+ * (*num_groups, *total).  Needs N < 2^20 and max degree < 4096. */
 int rls_graph_sweep_levels(const int32_t* rowptr, const int32_t* col, int64_t N, int32_t* lv_ptr, int64_t ptr_capacity,
                            int32_t* lv_data, int64_t data_capacity, int64_t* num_groups, int64_t* total);
 

@@ -160,7 +160,7 @@ int rls_graph_sweep_levels(const int32_t* rowptr, const int32_t* col, int64_t N,
     std::vector<int32_t> level((size_t)(N > 0 ? N : 1), 0);
     int32_t nlev = 0;
     for (int64_t i = 0; i < N; ++i) {
-        if (rowptr[i + 1] - rowptr[i] >= 256) return rls::fail(RLS_EUNSUPPORTED, "rls_graph_sweep_levels: degree >= 256");
+        if (rowptr[i + 1] - rowptr[i] >= 4096) return rls::fail(RLS_EUNSUPPORTED, "rls_graph_sweep_levels: degree >= 4096");
         int32_t l = 0;
         for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j)
             if (col[j] < i && level[(size_t)col[j]] + 1 > l) l = level[(size_t)col[j]] + 1;
@@ -175,7 +175,9 @@ int rls_graph_sweep_levels(const int32_t* rowptr, const int32_t* col, int64_t N,
         std::vector<int64_t> fill(start.begin(), start.end() - 1);
         for (int64_t i = 0; i < N; ++i) order[(size_t)fill[(size_t)level[(size_t)i]]++] = (int32_t)i;
     }
-    // nodes of a level are independent: longest rows first, so that the lanes a long row is spread over stay aligned
+    // nodes of a level are independent: longest rows first, so that the lanes a long row is spread over stay aligned.
+    // A row of 256 or more entries (a hub) is a group of its own, lane = neighbour (bit 30 of its lv_ptr entry).
+    constexpr int32_t kHub = 256;
     auto degn = [&](int32_t i) { return rowptr[i + 1] - rowptr[i]; };
     for (int32_t l = 0; l < nlev; ++l)
         std::stable_sort(order.begin() + start[(size_t)l], order.begin() + start[(size_t)l + 1],
@@ -184,22 +186,37 @@ int rls_graph_sweep_levels(const int32_t* rowptr, const int32_t* col, int64_t N,
     int64_t ng = 0, off = 0;
     std::vector<rls::LaneGroup> groups;
     for (int32_t l = 0; l < nlev; ++l) {
-        const int64_t a = start[(size_t)l], b = start[(size_t)l + 1];
+        const int64_t a0 = start[(size_t)l], b = start[(size_t)l + 1];
+        int64_t a = a0;                                    // [a0, a): the level's hubs (sorted first), [a, b): lane = node rows
+        while (a < b && deg_at(a) >= kHub) ++a;
         const int32_t cap = rls::best_lane_cap(a, b, deg_at);
         groups.clear();
+        for (int64_t h = a0; h < a; ++h) groups.push_back(rls::LaneGroup{h, h + 1, (int32_t)(((deg_at(h) + 63) / 64 + 7) & ~7), false});
+        const size_t nhub = groups.size();
         rls::plan_lane_groups(a, b, cap, deg_at, &groups);
         for (size_t gi = 0; gi < groups.size(); ++gi) {
             const rls::LaneGroup& g = groups[gi];
+            const bool hub = gi < nhub;
             const int64_t len = (int64_t)(1 + g.rounds) * 64;
-            if (off + len >= (int64_t)0x7fffffff) return rls::fail(RLS_EUNSUPPORTED, "rls_graph_sweep_levels: too large");
+            if (off + len >= (int64_t)0x3fffffff) return rls::fail(RLS_EUNSUPPORTED, "rls_graph_sweep_levels: too large");
             if (lv_ptr) {
                 if (ng + 1 >= ptr_capacity) return rls::fail(RLS_EINVAL, "rls_graph_sweep_levels: ptr capacity too small");
-                lv_ptr[ng] = (int32_t)((uint32_t)off | (gi == 0 ? 0x80000000u : 0u));
+                lv_ptr[ng] = (int32_t)((uint32_t)off | (gi == 0 ? 0x80000000u : 0u) | (hub ? 0x40000000u : 0u));
             }
             if (lv_data) {
                 if (off + len > data_capacity) return rls::fail(RLS_EINVAL, "rls_graph_sweep_levels: data capacity too small");
                 int32_t* rec = lv_data + off;
                 for (int64_t e = 0; e < len; ++e) rec[e] = (int32_t)(e < 64 ? N : N * 8);   // idle lanes: node N, its (zero) word
+                if (hub) {   // header: lane 0 = the node, lane 1 = its degree; then its neighbours 64 per round, padded with itself
+                    const int32_t i = order[(size_t)g.k0], deg = degn(i);
+                    rec[0] = i;
+                    rec[1] = deg;
+                    for (int64_t e = 0; e < (int64_t)g.rounds * 64; ++e)
+                        rec[64 + e] = (int32_t)((uint32_t)(e < deg ? col[rowptr[i] + e] : i) * 8u);
+                    off += len;
+                    ++ng;
+                    continue;
+                }
                 int32_t ln = 0;
                 for (int64_t k = g.k0; k < g.k1; ++k) {
                     const int32_t i = order[(size_t)k], deg = degn(i), lc = rls::lanes_log2_for(deg, cap), L = 1 << lc;

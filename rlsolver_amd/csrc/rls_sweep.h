@@ -209,10 +209,35 @@ __device__ __forceinline__ uint64_t sweep_group_flips(const unsigned char* __res
     return lv_count_le<NP>(pl, thr);
 }
 
+// A hub (a row of 256 ... 4095 entries) is a group of its own with lane = neighbour: per-lane vertical counters over its
+// rounds (64 neighbours each; the first eight rounds arrive prefetched), every plane transposed across the wave and
+// popcounted -- lane e then holds env e's count -- and the same rule c <= deg / 2.
+__device__ __forceinline__ uint64_t sweep_hub_flips(const unsigned char* __restrict__ wbytes, const int32_t* __restrict__ rec8,
+                                                    int rounds, const uint32_t (&nb0)[8], uint64_t own, uint32_t deg, int lane) {
+    uint64_t cv[7] = {0, 0, 0, 0, 0, 0, 0};                      // rounds <= 64
+    auto add = [&](uint32_t off) {
+        uint64_t carry = *reinterpret_cast<const uint64_t*>(wbytes + off) ^ own;
+#pragma unroll
+        for (int p = 0; p < 7; ++p) { const uint64_t t = cv[p] & carry; cv[p] ^= carry; carry = t; }
+    };
+#pragma unroll
+    for (int q = 0; q < 8; ++q) add(nb0[q]);
+    for (int r = 8; r < rounds; ++r, rec8 += kWave) add((uint32_t)rec8[0]);
+    const BitXpose xc = bit_xpose_consts(lane);
+    int cnt = 0;
+#pragma unroll
+    for (int p = 0; p < 7; ++p) {
+        uint32_t r0 = (uint32_t)cv[p], r1 = (uint32_t)(cv[p] >> 32);
+        bit_transpose64(r0, r1, xc);
+        cnt += (__builtin_popcount(r0) + __builtin_popcount(r1)) << p;
+    }
+    return ballot64((uint32_t)cnt <= (deg >> 1));
+}
+
 template <int W>
 __device__ __forceinline__ void sweep_tile_levels(uint64_t* words, const int32_t* lvp, const int32_t* __restrict__ data,
                                                   int64_t G, int64_t N, int lane, int w) {
-    constexpr uint32_t M = 0x7fffffffu;
+    constexpr uint32_t M = 0x3fffffffu;
     const unsigned char* wbytes = reinterpret_cast<const unsigned char*>(words);
     // prefetched head of this wave's next group: header word + the first 8 rounds (unguarded: rounds are whole blocks
     // of 8 and the table ends in eight spare rows)
@@ -251,9 +276,17 @@ __device__ __forceinline__ void sweep_tile_levels(uint64_t* words, const int32_t
         const int64_t p0 = (uint32_t)__builtin_amdgcn_readlane(chunk, (int)(k & 63)) & M;
         const int64_t p1 = (uint32_t)__builtin_amdgcn_readlane(chunk_next, (int)(k & 63)) & M;
         const int rounds = (int)((p1 - p0) >> 6) - 1;        // a multiple of 8
+        const int32_t* rec8 = data + p0 + (1 + 8) * kWave + lane;   // round 8 of this lane
+        if (((uint32_t)__builtin_amdgcn_readlane(chunk, (int)(k & 63)) >> 30) & 1u) {   // a hub: one node, lane = neighbour
+            const uint32_t hnode = (uint32_t)__builtin_amdgcn_readlane((int)hdr, 0), hdeg = (uint32_t)__builtin_amdgcn_readlane((int)hdr, 1);
+            const uint64_t hown = words[hnode];
+            const uint64_t hflip = sweep_hub_flips(wbytes, rec8, rounds, nb0, hown, hdeg, lane);
+            if (lane == 0) words[hnode] = hown ^ hflip;
+            prefetch(k + W);
+            continue;
+        }
         const uint32_t node = hdr & 0xFFFFFu, thr = (hdr >> 20) & 0xFFu, lcode = (hdr >> 28) & 3u;
         const uint64_t own = words[node];
-        const int32_t* rec8 = data + p0 + (1 + 8) * kWave + lane;   // round 8 of this lane
         uint64_t flip;
         if (rounds <= 8) flip = sweep_group_flips<1, 4>(wbytes, rec8, rounds, nb0, own, thr, lcode);
         else if (rounds <= 24) flip = sweep_group_flips<2, 5>(wbytes, rec8, rounds, nb0, own, thr, lcode);

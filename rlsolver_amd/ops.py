@@ -85,10 +85,11 @@ class DeviceGraph:
         ev_h = np.ascontiguousarray(csr.ev, dtype=np.int32)
         self.ell_sym_ptr, self.ell_sym = self._ell(rp_h, col_h, csr.num_nodes)
         self.ell_st_ptr, self.ell_st = self._ell(erp_h, ev_h, csr.num_nodes)
-        # the same level schedule in lane-per-node groups for the level-parallel sweep (N < 2^20, degrees < 256)
+        # the same level schedule in lane-per-node groups for the level-parallel sweep (N < 2^20, degrees < 4096: rows of 256
+        # or more entries are groups of their own)
         self.sweep_lv_ptr = self.sweep_lv_data = None
         self.num_sweep_groups = 0
-        if csr.num_nodes < (1 << 20) and csr.max_degree < 256:
+        if csr.num_nodes < (1 << 20) and csr.max_degree < 4096:
             ng, tot = C.c_int64(0), C.c_int64(0)
             a = (rp_h.ctypes.data_as(C.c_void_p), col_h.ctypes.data_as(C.c_void_p), csr.num_nodes)
             _abi.call("rls_graph_sweep_levels", *a, None, 0, None, 0, C.byref(ng), C.byref(tot))

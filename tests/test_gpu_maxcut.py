@@ -238,7 +238,7 @@ def _chain_fan_graph(chain=500, fan=1000, seed=0):
     return np.array([(a, b, 1) for a, b in e], dtype=np.int64), chain + fan
 
 
-@pytest.mark.parametrize("case", ["chain_fan", "g22", "fan_first"])
+@pytest.mark.parametrize("case", ["chain_fan", "g22", "fan_first", "ba_hubs", "star_mid", "two_hubs_1100"])
 def test_greedy_sweep_level_schedule_vs_sequential_oracle(case):
     """The level-scheduled multi-wave sweep against the C oracle's strictly sequential flip / re-evaluate /
     keep-if-not-worse loop (env_L2A.py:109-116) at sizes the numpy oracle cannot reach."""
@@ -249,11 +249,25 @@ def test_greedy_sweep_level_schedule_vs_sequential_oracle(case):
         graph, n = _chain_fan_graph(chain=300, fan=1200, seed=1)
         relabel = np.concatenate([np.arange(n - 300, n), np.arange(0, n - 300)])   # old id -> new id
         graph = np.stack([relabel[graph[:, 0]], relabel[graph[:, 1]], graph[:, 2]], axis=1)
+    elif case == "ba_hubs":         # hubs of degree 256 ... 373: groups of their own, lane = neighbour
+        from rlsolver_amd.graph import generate_ba
+        n = 5000
+        graph = np.asarray(generate_ba(n, 10, 4), dtype=np.int64)
+    elif case == "star_mid":        # one hub of degree 699 in the MIDDLE of the node order: decided after half its neighbours
+        n = 700
+        graph = np.asarray([(min(350, j), max(350, j), 1) for j in range(n) if j != 350] + [(j, j + 1, 1) for j in range(0, 349, 3)], dtype=np.int64)
+    elif case == "two_hubs_1100":
+        n = 1500
+        rng = np.random.RandomState(12)
+        e = {(0, j) for j in range(1, 1101)} | {(700, j) for j in range(701, 1400)} | {tuple(sorted(p)) for p in rng.randint(0, n, (3000, 2)).tolist() if p[0] != p[1]}
+        graph = np.asarray([(a, b, 1) for a, b in sorted(e)], dtype=np.int64)
     else:
         n = 2000
         graph = gnm_arr(2000, 19990, seed=22)
     B = 70
     g = device_graph(graph, n, 0)
+    if case in ("ba_hubs", "star_mid", "two_hubs_1100"):
+        assert g.sweep_lv_ptr is not None and np.bincount(graph[:, :2].ravel()).max() >= 256
     xs0 = np.random.RandomState(9).randint(0, 2, size=(B, n)).astype(np.uint8)
     xs = to_dev_bool(xs0).clone()
     vs = ops.maxcut_obj(g, xs)

@@ -123,12 +123,14 @@ def test_sweep_level_groups_encode_the_same_schedule():
     """rls_graph_sweep_levels: every node appears once (on L = 1, 2, 4 or 8 adjacent, L-aligned lanes, the longest
     rows first), lower-numbered neighbours sit in earlier LEVELS, lane j of a node lists its CSR entries j, j + L, ...
     as byte offsets of the neighbours' words and ends in the node itself, rounds come in whole blocks of 8, no lane holds
-    more than 64 entries, and the table ends in eight spare rows."""
+    more than 64 entries, and the table ends in eight spare rows.  A row of 256 or more entries is a group of its own
+    (bit 30 of its offset): node and degree in the header, its neighbours 64 per round, padded with itself."""
     import ctypes as C
     from rlsolver_amd import _abi
     from rlsolver_amd.graph import build_csr, generate_gnm, generate_ba
     for g, n in ((generate_gnm(300, 1500, seed=3), 300), (generate_ba(200, 4, seed=1), 200), ([(0, 1, 1)], 70),
-                 (generate_gnm(2000, 19990, seed=22), 2000), (generate_gnm(260, 26000, seed=5), 260)):
+                 (generate_gnm(2000, 19990, seed=22), 2000), (generate_gnm(260, 26000, seed=5), 260),
+                 ([(0, j, 1) for j in range(1, 700)] + [(j, j + 1, 1) for j in range(1, 699, 2)], 700), (generate_ba(5000, 10, seed=4), 5000)):
         csr = build_csr(g, num_nodes=n, if_bidirectional=False)
         rp = np.ascontiguousarray(csr.rowptr, dtype=np.int32)
         col = np.ascontiguousarray(csr.col, dtype=np.int32)
@@ -139,8 +141,10 @@ def test_sweep_level_groups_encode_the_same_schedule():
         lvd = np.empty(tot.value, dtype=np.int32)
         _abi.call("rls_graph_sweep_levels", *a, lvp.ctypes.data_as(C.c_void_p), lvp.size, lvd.ctypes.data_as(C.c_void_p),
                   lvd.size, C.byref(ng), C.byref(tot))
-        off = (lvp.view(np.uint32) & 0x7FFFFFFF).astype(np.int64)
+        off = (lvp.view(np.uint32) & 0x3FFFFFFF).astype(np.int64)
         first = (lvp.view(np.uint32)[:-1] >> 31).astype(bool)
+        is_hub = ((lvp.view(np.uint32)[:-1] >> 30) & 1).astype(bool)
+        assert is_hub.sum() == int((np.diff(rp) >= 256).sum())
         assert first[0] and off[-1] + 8 * 64 == tot.value and (lvd[off[-1]:] == n * 8).all()
         level_of_group = np.cumsum(first) - 1
         level_of = np.full(n, -1)
@@ -149,6 +153,14 @@ def test_sweep_level_groups_encode_the_same_schedule():
             rec = lvd[off[k]: off[k + 1]].reshape(-1, 64)
             rounds = rec.shape[0] - 1
             assert rounds % 8 == 0 and rounds <= 64
+            if is_hub[k]:
+                i, deg = int(rec[0, 0]), int(rec[0, 1])
+                assert deg == rp[i + 1] - rp[i] >= 256 and (rec[0, 2:] == n).all() and rounds * 64 >= deg
+                flat = rec[1:].reshape(-1)
+                assert np.array_equal(flat[:deg], col[rp[i]: rp[i + 1]] * 8) and (flat[deg:] == i * 8).all()
+                seen.append(i)
+                level_of[i] = level_of_group[k]
+                continue
             hdr = rec[0].view(np.uint32)
             nodes, half, lcode = (hdr & 0xFFFFF).astype(np.int64), (hdr >> 20) & 0xFF, (hdr >> 28) & 3
             live = nodes < n
