@@ -116,9 +116,9 @@ def maxcut_suite(tag, n, m, B, seed, iters, mygraph=None):
     return g
 
 
-def local_search_suite(tag, n, m, seed, B, iters):
+def local_search_suite(tag, n, m, seed, B, iters, mygraph=None):
     from rlsolver_amd.envs.env_L2A import EnvMaxcut
-    env = EnvMaxcut(mygraph=generate_gnm(n, m, seed), device=dev, num_nodes=n)
+    env = EnvMaxcut(mygraph=mygraph if mygraph is not None else generate_gnm(n, m, seed), device=dev, num_nodes=n)
     torch.manual_seed(0)
     xs = env.generate_xs_randomly(B)
     vs = env.calculate_obj_values(xs)
@@ -324,6 +324,8 @@ if want("synthetic"):   # north_star: "throughput on Gset and synthetic BA/ER gr
     maxcut_suite("BA n=2000 m=4 (hubs: max degree ~150), B=2^16", 2000, 0, 1 << 16, 0, it, mygraph=generate_ba(2000, 4, 3))
     maxcut_suite("BA n=10000 m=5, B=2^16", 10000, 0, 1 << 16, 0, max(3, it // 3), mygraph=generate_ba(10000, 5, 5))
     maxcut_suite("ER G(n=2000, p=0.005 -> m=9995), B=2^16", 2000, 9995, 1 << 16, 31, it)
+    local_search_suite("BA n=2000 m=4, dREINFORCE batch", 2000, 0, 0, 4096, max(2, it // 5), mygraph=generate_ba(2000, 4, 3))
+    local_search_suite("BA n=10000 m=5 (hubs of degree >= 256), dREINFORCE batch", 10000, 0, 0, 4096, max(2, it // 5), mygraph=generate_ba(10000, 5, 5))
 if want("ls"):
     local_search_suite("G22-sized, dREINFORCE batch", 2000, 19990, 22, 4096, max(2, it // 5))
     local_search_suite("G22-sized, dREINFORCE batch x16", 2000, 19990, 22, 65536, max(2, it // 5))
