@@ -319,7 +319,7 @@ only = set(w for w in a.only.split(",") if w)
 want = lambda k: not only or k in only
 if want("maxcut"):
     maxcut_suite("G22-sized G(2000,19990), B=2^16", 2000, 19990, 1 << 16, 22, it)
-if want("synthetic"):   # north_star: "throughput on Gset and synthetic BA/ER graphs"
+if want("synthetic") and not a.profile:   # (grids coincide with the BASELINE rows of tools/kernel_table.py) north_star: "throughput on Gset and synthetic BA/ER graphs"
     from rlsolver_amd.graph import generate_ba
     maxcut_suite("BA n=2000 m=4 (hubs: max degree ~150), B=2^16", 2000, 0, 1 << 16, 0, it, mygraph=generate_ba(2000, 4, 3))
     maxcut_suite("BA n=10000 m=5, B=2^16", 10000, 0, 1 << 16, 0, max(3, it // 3), mygraph=generate_ba(10000, 5, 5))
