@@ -127,8 +127,8 @@ def local_search_suite(tag, n, m, seed, B, iters, mygraph=None):
          B * (n + 8), t, None, f"B={B}; the reference performs N+8 full objective evaluations per env per call")
 
 
-def mcpg_suite(tag, n, m_ba, C, num_ls, iters):
-    mg = generate_ba(n, m_ba, seed=5)
+def mcpg_suite(tag, n, m_ba, C, num_ls, iters, mygraph=None):
+    mg = mygraph if mygraph is not None else generate_ba(n, m_ba, seed=5)
     arr = np.asarray(mg, dtype=np.int64)
     data = amcpg.make_data(n, arr[:, 0], arr[:, 1], dev)
     torch.manual_seed(0)
@@ -324,6 +324,7 @@ if want("synthetic") and not a.profile:   # (grids coincide with the BASELINE ro
     maxcut_suite("BA n=2000 m=4 (hubs: max degree ~150), B=2^16", 2000, 0, 1 << 16, 0, it, mygraph=generate_ba(2000, 4, 3))
     maxcut_suite("BA n=10000 m=5, B=2^16", 10000, 0, 1 << 16, 0, max(3, it // 3), mygraph=generate_ba(10000, 5, 5))
     maxcut_suite("ER G(n=2000, p=0.005 -> m=9995), B=2^16", 2000, 9995, 1 << 16, 31, it)
+    mcpg_suite("MCPG on a G22-sized G(2000, 19990), 2^16 chains", 2000, 0, 1 << 16, 8, max(3, it // 3), mygraph=generate_gnm(2000, 19990, 22))
     local_search_suite("BA n=2000 m=4, dREINFORCE batch", 2000, 0, 0, 4096, max(2, it // 5), mygraph=generate_ba(2000, 4, 3))
     local_search_suite("BA n=10000 m=5 (hubs of degree >= 256), dREINFORCE batch", 10000, 0, 0, 4096, max(2, it // 5), mygraph=generate_ba(10000, 5, 5))
 if want("ls"):
