@@ -774,7 +774,7 @@ __global__ __launch_bounds__(W * kWave) void k_mcpg_local_search_levels(
     for (int64_t k0 = 0; k0 < G; k0 += kWave)
         num_levels += __builtin_popcountll(ballot64(k0 + lane < G && (lvl[k0 + lane < G ? k0 + lane : G] >> 31) != 0));
     auto coin_word = [&](int64_t cnt, uint32_t pos) -> uint64_t {   // bit e: "u < 1/2" for chain c0 + e at (pass, pos)
-        if (coins) return coins[((int64_t)cnt * N + pos) * CB + blockIdx.x];
+        if (coins) return coins[((int64_t)cnt * N + (pos < (uint32_t)N ? pos : 0u)) * CB + blockIdx.x];   // idle lanes carry pos = N: past the last row
         const uint32_t k = blk_key ^ (pos * 0x9E3779B1u) ^ ((uint32_t)cnt * 0x7FEB352Du + 0x165667B1u);
         return ((uint64_t)k7_fmix32(k ^ 0x4C4F4353u) << 32) | k7_fmix32(k + 0x27D4EB2Fu);
     };
