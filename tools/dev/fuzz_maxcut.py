@@ -94,6 +94,17 @@ while time.time() < t_end:
         r = oc.step_u8(xo, a, eu, ev, bidir, last)
         assert np.array_equal(x1.cpu().numpy(), xo) and np.array_equal(obj.cpu().numpy(), last.astype(np.int32)), f"K4 step {s} " + tag
         assert np.array_equal(rew.cpu().numpy(), r.astype(np.float32)), f"K4 reward {s} " + tag
+    # K4 on the f32 gym surface, in place (env_PPO keeps float spins and flips them in place)
+    xf = xs.float().contiguous()
+    objf = torch.from_numpy(want.astype(np.int32)).to(DEV)
+    xo = xs0.copy()
+    last = want.astype(np.int64).copy()
+    for s in range(2):
+        a = rng.randint(0, n, B).astype(np.int64)
+        ops.maxcut_step(g, xf, xf, torch.from_numpy(a).to(DEV), objf, rew)
+        r = oc.step_u8(xo, a, eu, ev, bidir, last)
+        assert np.array_equal(xf.cpu().numpy(), xo.astype(np.float32)) and np.array_equal(objf.cpu().numpy(), last.astype(np.int32)), f"K4 f32 in place {s} " + tag
+        assert np.array_equal(rew.cpu().numpy(), r.astype(np.float32)), f"K4 f32 reward {s} " + tag
     # K6 + K5
     mask = torch.from_numpy((rng.rand(B, n) < 4.0 / n)).to(DEV)
     xk = xs.clone()
