@@ -977,11 +977,11 @@ __global__ __launch_bounds__(1024) void k_mcpg_merge_minmax(float* __restrict__ 
     uint64_t* d0 = now_info + (loi >> 6) * N;
     uint64_t* d1 = temp_info + (loi >> 6) * N;
     const int sb = (int)(hii & 63), db = (int)(loi & 63);
-    if (hii == loi) return;
-    for (int64_t n = threadIdx.x; n < N; n += blockDim.x) {
+    const bool same = hii == loi;                                               // one kept chain, or all incumbents equal: :389 is a
+    for (int64_t n = threadIdx.x; n < N; n += blockDim.x) {                     // no-op, :390 still seeds the next round from the incumbent
         const uint64_t bit = (srcw[n] >> sb) & 1ull;                            // read before either write: d0 may alias srcw's tile
         const uint64_t a = d0[n], b = d1[n];
-        d0[n] = (a & ~(1ull << db)) | (bit << db);                              // :389
+        if (!same) d0[n] = (a & ~(1ull << db)) | (bit << db);                   // :389
         d1[n] = (b & ~(1ull << db)) | (bit << db);                              // :390
     }
 }

@@ -494,3 +494,23 @@ def test_tsp_2opt_local_search_golden(golden):
         for sl in (2, 7, None):
             got = mops.tsp_2opt_best(di, dev(perms), cl, slices=sl)
             assert all(torch.equal(g, w) for g, w in zip(got, want)), (cl is None, sl)
+
+
+@pytest.mark.parametrize("M", [1, 5, 70])
+def test_merge_best_when_best_and_worst_incumbent_coincide(M):
+    """MCPG.py:383-391 with argmax == argmin (one kept chain, or every incumbent equal after the merge): the incumbent
+    column is left alone but temp_max_info's column STILL takes it -- it seeds the next round.  (Found by
+    tools/dev/fuzz_mcpg.py: the kernel used to return early.)"""
+    from rlsolver_amd.ops_mcpg_tsp import PackedChains
+    rng = np.random.RandomState(M)
+    n = 77
+    temp_max = np.full(M, 10.0, np.float32)
+    now_res = np.full(M, 12.0, np.float32)                      # all incumbents better and equal: argmax = argmin = 0
+    temp_info = (rng.rand(n, M) < 0.5).astype(np.float32)
+    now_info = (rng.rand(n, M) < 0.5).astype(np.float32)
+    w_res, w_info, w_temp, w_max, w_idx = onp.mcpg_merge_best(temp_max, temp_info, now_res, now_info)
+    assert w_idx == 0 and np.array_equal(w_temp[:, 0], now_info[:, 0])
+    d_res, d_info, d_temp = dev(now_res), PackedChains.pack(dev(now_info)), PackedChains.pack(dev(temp_info))
+    bv, bi = mops.mcpg_merge_best(dev(temp_max), d_temp, d_res, d_info)
+    assert np.array_equal(d_res.cpu().numpy(), w_res) and np.array_equal(d_info.unpack().cpu().numpy(), w_info)
+    assert np.array_equal(d_temp.unpack().cpu().numpy(), w_temp) and float(bv) == float(w_max) and int(bi) == w_idx

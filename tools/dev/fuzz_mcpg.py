@@ -7,6 +7,8 @@ sys.path.insert(0, ".")
 from oracle import oracle_np as onp
 from rlsolver_amd import graph as G
 from rlsolver_amd.methods import MCPG as amcpg
+from rlsolver_amd import ops_mcpg_tsp as mops
+from rlsolver_amd.ops_mcpg_tsp import PackedChains
 
 DEV = torch.device("cuda:0")
 dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
@@ -63,5 +65,14 @@ while time.time() < t_end:
     vs_g, xs_g, val_g = amcpg.sampler_func(data, got, num_ls, M, R, DEV, uniforms=dev(uni))
     assert np.array_equal(vs_g.cpu().numpy(), vs_w) and np.array_equal(xs_g.cpu().numpy(), xs_w), "sampler_func " + tag
     assert np.allclose(val_g.cpu().numpy(), val_w, atol=1e-3), "sampler_func value " + tag
+    # best-merge of the outer loop (MCPG.py:376-391) on bit-packed kept chains: incumbents partly better, partly worse, ties
+    now_res = (vs_w + rng.randint(-2, 3, size=M)).astype(np.float32)
+    now_info = (rng.rand(n, M) < 0.5).astype(np.float32)
+    w_res, w_info, w_temp, w_max, w_idx = onp.mcpg_merge_best(vs_w, xs_w, now_res, now_info)
+    d_res, d_info, xg_p = dev(now_res), PackedChains.pack(dev(now_info)), PackedChains.pack(xs_g.contiguous())
+    bv, bi = mops.mcpg_merge_best(vs_g.contiguous(), xg_p, d_res, d_info)
+    assert np.array_equal(d_res.cpu().numpy(), w_res) and np.array_equal(d_info.unpack().cpu().numpy(), w_info), "merge_best incumbents " + tag
+    ok_t, ok_v, ok_i = np.array_equal(xg_p.unpack().cpu().numpy(), w_temp), float(bv) == float(w_max), int(bi) == w_idx
+    assert ok_t and ok_v and ok_i, f"merge_best temp_info={ok_t} max={ok_v} ({float(bv)} vs {float(w_max)}) index={ok_i} ({int(bi)} vs {w_idx}) now_res={now_res} vs={vs_w} " + tag
     it += 1
 print(f"fuzz_mcpg: {it} random configurations, no mismatch")
