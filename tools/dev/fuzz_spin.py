@@ -1,4 +1,4 @@
-"""Differential fuzz of the per-env (dense) spin-system env against the numpy restatement of the reference's batched PECO env
+"""Differential fuzz of the spin-system env, per-env (dense) couplings and one shared graph (CSR), against the numpy restatement of the reference's batched PECO env
 (oracle/oracle_spin.py, one instance per env on that env's own matrix): random sizes, densities, +-1 couplings with and
 without diagonal entries, reward modes, visited-state memory, revisits.  `python tools/dev/fuzz_spin.py [seconds] [seed]`."""
 import sys, time
@@ -35,9 +35,21 @@ while time.time() < t_end:
     basin = None if rng.rand() < 0.4 else float(rng.choice([0.25, 1.0 / n, 0.5]))
     stag = None if rng.rand() < 0.5 else float(rng.choice([0.125, 0.25]))
     tag = f"it={it} n={n} B={B} T={T} mode={mode} norm={norm} basin={basin} stag={stag}"
-    env = SpinSystem(None, None, B, max_steps=T, observables=ECO_PECO_OBSERVABLES, reward_signal=RewardSignal[mode], norm_rewards=norm,
-                     spin_basis=SpinBasis.BINARY, basin_reward=basin, stag_punishment=stag, device=DEV,
-                     graph_generator=SetGraphGenerator(W, DEV))
+    shared = bool(rng.rand() < 0.4)
+    if shared:                                                                  # one graph for all envs: the CSR form of the step
+        W[:] = W[0]
+        W[:, np.arange(n), np.arange(n)] = 0
+        rs = W[0].sum(1)
+        if np.abs(rs).sum() == 0 or rs.max() == 0:
+            continue
+        mg = [(i, j, int(W[0, i, j])) for i in range(n) for j in range(i + 1, n) if W[0, i, j] != 0]
+        env = SpinSystem(mg, n, B, max_steps=T, observables=ECO_PECO_OBSERVABLES, reward_signal=RewardSignal[mode], norm_rewards=norm,
+                         spin_basis=SpinBasis.BINARY, basin_reward=basin, stag_punishment=stag, device=DEV)
+    else:
+        env = SpinSystem(None, None, B, max_steps=T, observables=ECO_PECO_OBSERVABLES, reward_signal=RewardSignal[mode], norm_rewards=norm,
+                         spin_basis=SpinBasis.BINARY, basin_reward=basin, stag_punishment=stag, device=DEV,
+                         graph_generator=SetGraphGenerator(W, DEV))
+    tag += f" shared={shared}"
     oras = [SpinSystemOracle(W[b], 1, T, reward=mode, norm_rewards=norm, basin_reward=basin, stag_punishment=stag) for b in range(B)]
     s0 = (2 * rng.randint(0, 2, size=(B, n)) - 1).astype(np.float32)
     obs = env.reset(torch.from_numpy(s0))
