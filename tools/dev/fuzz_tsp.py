@@ -33,6 +33,35 @@ while time.time() < t_end:
     got = mops.tsp_tour_length(torch.from_numpy(d32).to(DEV), pp).cpu().numpy()
     want = onp.tsp_tour_length_f64(d32, perms)
     assert np.allclose(got, want, rtol=1e-5, atol=0), "K12 " + tag
+    # K12 / K13 / 2-opt delta at sizes on both sides of "D fits LDS" (N ~ 200), the swap with recorded partner draws
+    if it % 3 == 0:
+        N2 = int(rng.choice([rng.randint(4, 60), rng.randint(60, 200), rng.randint(200, 420)]))
+        B2 = int(rng.choice([1, 5, 64, 65, 300]))
+        c2 = rng.rand(N2, 2).astype(np.float32)
+        dist2 = np.sqrt(((c2[:, None] - c2[None]) ** 2).sum(-1)).astype(np.float32)
+        pn = np.stack([rng.permutation(N2) for _ in range(B2)])
+        d2, p2 = torch.from_numpy(dist2).to(DEV), torch.from_numpy(pn).to(DEV)
+        t2tag = f"{tag} N2={N2} B2={B2}"
+        length = mops.tsp_tour_length(d2, p2).cpu().numpy()
+        assert np.allclose(length, onp.tsp_tour_length_f64(dist2, pn), rtol=1e-5), "K12 large " + t2tag
+        off = rng.randint(1, N2, size=(B2, N2))
+        sel = np.take_along_axis(pn, (np.arange(N2)[None, :] + off) % N2, axis=1)
+        Tt = float(rng.choice([0.1, 0.5, 2.0]))
+        lr_w, idx_w, ban_w = onp.tsp_swap_delta_all(dist2, pn, sel, Tt)
+        lr, idx, ban = mops.tsp_swap_delta_all(d2, p2, torch.from_numpy(sel).to(DEV), Tt)
+        assert np.array_equal(idx.cpu().numpy(), idx_w) and np.array_equal(ban.cpu().numpy(), ban_w), "K13 indices / ban " + t2tag
+        assert np.allclose(lr.cpu().numpy(), lr_w, rtol=1e-5, atol=1e-5 * length.max() / Tt), "K13 logratio " + t2tag
+        pos = rng.randint(0, N2, size=B2)
+        xw = onp.tsp_switch(pn, pos, idx_w)
+        xg = p2.clone()
+        mops.tsp_apply_swap(xg, torch.from_numpy(pos).to(DEV), idx)
+        assert np.array_equal(xg.cpu().numpy(), xw), "switch " + t2tag
+        i2 = rng.randint(0, N2 - 1, size=B2)
+        j2 = np.array([rng.randint(a + 1, N2) for a in i2])
+        dl = mops.tsp_2opt_delta(d2, p2, torch.from_numpy(i2).to(DEV), torch.from_numpy(j2).to(DEV)).cpu().numpy()
+        nb = min(B2, 6)
+        want_dl = onp.tsp_2opt_delta(dist2.astype(np.float64), pn, np.arange(nb), i2[:nb], j2[:nb])
+        assert np.allclose(dl[:len(want_dl)], want_dl, rtol=0, atol=2e-5 * length.max()), "2-opt delta " + t2tag
     # one exact pass per tour vs the restated loops
     cur = np.array([onp.tsp_distance_calc(d, [int(v) + 1 for v in p] + [int(p[0]) + 1]) for p in perms])
     bi, bj, bv = mops.tsp_2opt_best(dd, pp, torch.from_numpy(cur).to(DEV), slices=int(rng.choice([1, 3, 8])))
