@@ -45,7 +45,6 @@ while time.time() < t_end:
     yb, eb, ab, tb, mb = big.step(x, pl, T, draws=draws, want_terms=True)
     ds = {k: v[:Bs] for k, v in draws.items()}
     ys, es, as_, ts, ms = small.step(x[:Bs].contiguous(), pl[:Bs].contiguous(), T, draws=ds, want_terms=True)
-    assert torch.equal(mb[:Bs], ms), "selected nodes " + tag     # the two kernels compute the same perturbed values
     assert bool((mb.sum(1) >= pl).all()), "path length " + tag     # ties at the threshold are all selected (util.py:514-555)
     # the path log-probabilities are ill-conditioned in the reference itself (tests/isco_tol.py): tolerance from the float64 oracle
     r = oi.maxcut_step(x[:Bs].cpu().numpy(), g[:, 0], g[:, 1], pl[:Bs].cpu().numpy(), T, ds["u_gumbel"].numpy(), ds["u_accept"].numpy())
@@ -59,6 +58,10 @@ while time.time() < t_end:
     gaps = np.abs(np.diff(top, axis=1)) / np.maximum(np.abs(top[:, 1:]), 1e-3)
     near_tie = np.array([(gaps[e, :plh[e]] < 2e-6).any() for e in range(Bs)])
     mass[near_tie] = 0.0                                                        # excluded like ill-conditioned envs
+    keep = torch.from_numpy(~near_tie).to(DEV)
+    # (the two kernels reduce the softmax normaliser in different orders: their perturbed scores can differ in the last ulp,
+    #  so even the SELECTED SET may differ where the L-th and (L+1)-th score nearly tie -- seen once in ~330 000 envs)
+    assert torch.equal(mb[:Bs][keep], ms[keep]), "selected nodes " + tag
     assert np.array_equal(ms.cpu().numpy().astype(np.uint8)[~near_tie], r["mask"].astype(np.uint8)[~near_tie]), "selected nodes vs oracle " + tag
     for kern, tt in (("wave", tb[:Bs]), ("workgroup", ts)):
         tt = tt.cpu().numpy()
