@@ -7,54 +7,112 @@ Gset-G22-sized graph with 2^16 parallel envs per GPU, next-state emitted into a 
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+`python bench.py --gpus N` with N > 1 and no torchrun environment starts the N ranks itself (a fresh
+`python -m torch.distributed.run` child, started before this process touches the GPU), relays rank 0's JSON line
+as its last stdout line and exits with the children's return code.  `--dry-run` exercises the same launch, shard
+and exchange wiring on CPU (gloo) without a kernel.
+
 One "step" = one K4 pass over the whole batch: for every env flip node a_b, compute the cut gain
 from the action node's CSR row, update obj, write reward, and emit the next state.  Algorithmic
 HBM bytes per env-step = 2N + 20.  Envs are sharded over ranks with no
 data-path collective (weak scaling: 2^16 envs per GPU); the episode-boundary best-objective
-exchange (8-byte RCCL all-reduce) runs once at the end of the timed region when N > 1.
+exchange (8-byte RCCL all-reduce) runs once at the end of every timed region when N > 1.
+
+Timing: W warm-up steps, then R (`--repeats`, default 5) timed regions of EXACTLY K steps each, every region
+bracketed by barrier + synchronize on both sides and reduced with MAX over ranks; the line reports the MEDIAN
+region (`ms_per_step`, `value`) and all of them (`ms_per_step_all`).
 
 Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events on the launch stream;
 `cpu_baseline` is the C oracle (reference algorithm: flip + full objective re-evaluation, OpenMP)
 timed on the host cores on a bounded sample (rank 0, N = 1 only); `cpu_baseline_ref_shaped` is the reference's
-own op chain in torch-CPU ops (oracle/oracle_torch.py).  BASELINE config #5's per-GPU shard:
-`--gset 70 --envs-per-gpu 131072`.
+own op chain in torch-CPU ops (oracle/oracle_torch.py).  `config5_shard` is BASELINE config #5's per-GPU shard
+(G70-sized graph, 2^17 envs per GPU) measured the same way after the headline (skip with --no-config5); as a
+headline of its own: `--gset 70 --envs-per-gpu 131072`.
 """
 import argparse
 import json
+import math
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np
-import torch
-import torch.distributed as dist
-
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+METRIC = "env-steps/sec (all instances) on Gset G22 MaxCut; achieved HBM GB/s % peak"
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--repeats", type=int, default=5, help="timed regions of --steps steps each; the median is reported")
     ap.add_argument("--envs-per-gpu", type=int, default=1 << 16)
     ap.add_argument("--gset", type=int, default=22, help="Gset id whose (n, m) the graph has (22 = headline)")
     ap.add_argument("--slots", type=int, default=8, help="rollout ring depth (slots of B*N bytes)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-config5", action="store_true", help="skip the secondary G70 / 2^17-envs-per-GPU measurement")
     ap.add_argument("--via-env", action="store_true",
                     help="time the drop-in class surface, EnvMaxcutGym.step(action, out=slot) with 1-byte spins, instead of "
                          "the pre-validated C-ABI launcher (same kernel, plus the Python / ctypes path of the class)")
     ap.add_argument("--no-verify", action="store_true")
-    return ap.parse_args()
+    ap.add_argument("--dry-run", action="store_true",
+                    help="CPU only (gloo): launch, shard and exchange wiring of the N-rank run, no kernels")
+    return ap.parse_args(argv)
 
 
+# --------------------------------------------------------------------------- #
+# self-spawn: `python bench.py --gpus N` without torchrun
+# --------------------------------------------------------------------------- #
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_spawn(a, argv):
+    """Parent of an N-rank run.  Nothing here may touch the GPU (the children are fresh processes; a process that
+    has initialised HIP must never exec or be replaced)."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    rest = []
+    for ln in p.stdout.splitlines():
+        s = ln.strip()
+        if s.startswith("{") and '"metric"' in s:
+            try:
+                json.loads(s)
+                line = s
+                continue
+            except ValueError:
+                pass
+        rest.append(ln)
+    if rest:
+        print("\n".join(rest), file=sys.stderr, flush=True)
+    if line is None:
+        print(f"bench.py: the {a.gpus}-rank child run printed no result line (rc={p.returncode})", file=sys.stderr)
+        raise SystemExit(p.returncode or 1)
+    print(line, flush=True)
+    raise SystemExit(p.returncode)
+
+
+# --------------------------------------------------------------------------- #
+# CPU baselines (rank 0, N = 1 only; outside every timed region)
+# --------------------------------------------------------------------------- #
 def cpu_baseline(graph_arr, n, seconds):
     """The reference's env step on the host cores: flip + full cut re-evaluation per env
     (oracle/oracle.c: orc_step_u8, the algorithm of envs/env_PPO.py:92-121), OpenMP over envs."""
+    import numpy as np
     from oracle import oracle_c as oc
     from oracle import oracle_np as onp
     eu, ev = onp.stored_edges(graph_arr, False)
@@ -81,6 +139,7 @@ def cpu_baseline_ref_shaped(graph_arr, n, seconds):
     [B, E'] index tensors + two advanced-index gathers, envs/env_PPO.py:92-121) in torch-CPU ops on all host cores
     (oracle/oracle_torch.py, pinned on the reference's trace).  B is reduced so that the 24*B*E' bytes of index
     tensors fit comfortably in host memory."""
+    import numpy as np
     import torch as th
     from oracle.oracle_torch import PPOEnvRefShaped
     cores = os.cpu_count() or 1
@@ -120,26 +179,55 @@ def pmc_traffic_per_launch():
     return best
 
 
-def main():
-    a = parse()
+# --------------------------------------------------------------------------- #
+# dry run: the N-rank wiring on CPU
+# --------------------------------------------------------------------------- #
+def dry_run(a):
+    import torch
+    import torch.distributed as dist
+    from rlsolver_amd import dist as rdist
+    rank, local_rank, world = rdist.init_from_env(backend="gloo")
+    B = a.envs_per_gpu
+    env_offset = rank * B
+    off, cnt = rdist.env_shard(world * B, rank, world)
+    assert (off, cnt) == (env_offset, B), (off, cnt, env_offset, B)
+    # a stand-in objective vector whose global maximum sits in a known shard: env id e scores (e * 7919) % 1009
+    ids = torch.arange(env_offset, env_offset + min(B, 4096), dtype=torch.int64)
+    obj = (ids * 7919) % 1009
+    xs = ((ids[:, None] + torch.arange(16)[None, :]) % 3 == 0)
+    best, owner, bx = rdist.global_best(obj, xs, want_solution=True)
+    mine = {"rank": rank, "local_rank": local_rank, "env_offset": env_offset, "envs": B,
+            "local_best": int(obj.max())}
+    if world > 1:
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        allr = [mine]
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "dry_run": True, "n_gpus": world, "ranks": allr,
+                          "global_best": int(best), "owner": int(owner), "best_x": [int(v) for v in bx.tolist()]}),
+              flush=True)
+
+
+# --------------------------------------------------------------------------- #
+# the timed workload
+# --------------------------------------------------------------------------- #
+def measure(a, gset, B, steps, warmup, repeats, dev, rank, local_rank, world, via_env=False, verify=True):
+    """W warm-up steps, then `repeats` regions of exactly `steps` K4 launches.  Returns a dict with the per-region
+    wall times (MAX over ranks) and HIP-event kernel times of this rank."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
     from rlsolver_amd import dist as rdist
     from rlsolver_amd import ops
     from rlsolver_amd.graph import build_csr, load_gset
 
-    rank, local_rank, world = rdist.init_from_env()
-    if world != a.gpus:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
-                         f"--nproc-per-node {a.gpus}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
-
-    mygraph, n, is_real = load_gset(a.gset, os.path.join(ROOT, "data", "gset"))
-    graph_arr = np.asarray(mygraph, dtype=np.int64)
+    mygraph, n, is_real = load_gset(gset, os.path.join(ROOT, "data", "gset"))
     csr = build_csr(mygraph, num_nodes=n, if_bidirectional=False)
     g = ops.DeviceGraph(csr, dev)
-    B, N, S = a.envs_per_gpu, n, a.slots
+    N, S = n, a.slots
     env_offset = rank * B
 
     ring = torch.empty((S, B, N), dtype=torch.bool, device=dev)
@@ -152,9 +240,8 @@ def main():
 
     # one pre-validated launcher per (slot, action vector) pair of the cycle: the timed loop is then a
     # bare C-ABI call per step (the ring and the action pool are fixed buffers)
-    import math
     period = S * A // math.gcd(S, A)
-    if a.via_env:
+    if via_env:
         import types
         from rlsolver_amd.envs.env_PPO import EnvMaxcut as EnvMaxcutGym
         env = EnvMaxcutGym(types.SimpleNamespace(num_nodes=N, num_envs=B, num_steps=10 ** 9), mygraph=mygraph, device=dev,
@@ -171,7 +258,7 @@ def main():
             launchers[t % period]()
 
     t = 0
-    for _ in range(a.warmup):
+    for _ in range(warmup):
         step(t)
         t += 1
 
@@ -181,68 +268,128 @@ def main():
         if use_pg:
             dist.barrier(device_ids=[local_rank])
 
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize(dev)
-    barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    e0.record()
-    for _ in range(a.steps):
-        step(t)
-        t += 1
-    e1.record()
-    if use_pg:  # episode boundary: best objective over all shards (C1, 8 bytes over RCCL)
-        best, owner, _ = rdist.global_best(obj)
-    torch.cuda.synchronize(dev)
-    barrier()
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    kernel_s = e0.elapsed_time(e1) * 1e-3 / max(a.steps, 1)
+    wall, kern = [], []
+    for _ in range(repeats):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(dev)
+        barrier()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(steps):
+            step(t)
+            t += 1
+        e1.record()
+        if use_pg:  # episode boundary: best objective over all shards (C1, 8 bytes over RCCL)
+            rdist.global_best(obj)
+        torch.cuda.synchronize(dev)
+        barrier()
+        torch.cuda.synchronize(dev)
+        wall.append(time.perf_counter() - t0)
+        kern.append(e0.elapsed_time(e1) * 1e-3 / max(steps, 1))
 
     if use_pg:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor(wall, dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        wall = [float(v) for v in tt.tolist()]
 
-    if not a.no_verify:  # size-independent parity property at full size: incremental obj == recomputed
+    if verify:  # size-independent parity property at full size: incremental obj == recomputed
         final = slots[t % S]
         if not torch.equal(ops.maxcut_obj(g, final).to(torch.int32), obj):
             raise SystemExit("PARITY FAILURE: incremental objective != recomputed objective")
 
+    res = {"wall": wall, "kernel_s": kern, "N": N, "E": len(mygraph), "is_real": is_real, "B": B,
+           "graph_arr": np.asarray(mygraph, dtype=np.int64)}
+    return res          # the ring and the launchers die with this frame: the next workload gets the memory back
+
+
+def summarize(res, steps, world):
+    B, N = res["B"], res["N"]
+    el = statistics.median(res["wall"])
+    ks = statistics.median(res["kernel_s"])
+    bytes_per_launch = B * (2 * N + 20)
+    achieved = bytes_per_launch / ks / 1e9
+    return {"value": world * B * steps / el, "ms_per_step": el / steps * 1e3,
+            "ms_per_step_all": [w / steps * 1e3 for w in res["wall"]],
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
+                         "kernel": "k_maxcut_step<u8, emit>", "us_per_launch": ks * 1e6,
+                         "us_per_launch_all": [k * 1e6 for k in res["kernel_s"]],
+                         "algorithmic_bytes_per_launch": bytes_per_launch}}
+
+
+def main():
+    argv = sys.argv[1:]
+    a = parse(argv)
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_spawn(a, argv)          # never returns
+    if int(os.environ.get("WORLD_SIZE", "1")) != a.gpus:      # before any rendezvous: a mismatch must not hang
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE')}: launch with torch.distributed.run "
+                         f"--nproc-per-node {a.gpus} (or plain `python bench.py --gpus {a.gpus}`, which starts the ranks itself)")
+    if a.dry_run:
+        return dry_run(a)
+
+    import torch
+    import torch.distributed as dist
+    from rlsolver_amd import dist as rdist
+
+    rank, local_rank, world = rdist.init_from_env()
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    R = max(1, a.repeats)
+
+    res = measure(a, a.gset, a.envs_per_gpu, a.steps, a.warmup, R, dev, rank, local_rank, world,
+                  via_env=a.via_env, verify=not a.no_verify)
+    torch.cuda.empty_cache()
+    res5 = None
+    if not a.no_config5 and not (a.gset == 70 and a.envs_per_gpu == 131072):
+        # BASELINE config #5's per-GPU shard, measured the same way (never mixed into `value`)
+        res5 = measure(a, 70, 131072, max(1, min(a.steps, 200)), min(a.warmup, 20), R, dev, rank, local_rank, world,
+                       verify=not a.no_verify)
+
     out = None
     if rank == 0:
-        bytes_per_launch = B * (2 * N + 20)
-        achieved = bytes_per_launch / kernel_s / 1e9
+        B, N = res["B"], res["N"]
+        s = summarize(res, a.steps, world)
         out = {
-            "metric": "env-steps/sec (all instances) on Gset G22 MaxCut; achieved HBM GB/s % peak",
-            "value": world * B * a.steps / elapsed,
+            "metric": METRIC,
+            "value": s["value"],
             "unit": "env-steps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": elapsed / a.steps * 1e3,
+            "ms_per_step": s["ms_per_step"],
+            "repeats": R, "ms_per_step_all": s["ms_per_step_all"],
+            "timing": f"median of {R} regions of exactly {a.steps} steps, each bracketed by barrier + synchronize, MAX over ranks",
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": f"Gset G{a.gset}{'' if is_real else '-sized G(n,m) stand-in'} MaxCut "
-                                   f"(N={N}, E={len(mygraph)}), {B} envs per GPU, K4 gym step emitting the next "
-                                   f"state into a {S}-slot rollout ring, uniform random actions"
+            "config": {"workload": f"Gset G{a.gset}{'' if res['is_real'] else '-sized G(n,m) stand-in'} MaxCut "
+                                   f"(N={N}, E={res['E']}), {B} envs per GPU, K4 gym step emitting the next "
+                                   f"state into a {a.slots}-slot rollout ring, uniform random actions"
                                    + ("; through EnvMaxcutGym.step(action, out=slot)" if a.via_env else "")
                                    + ("; BASELINE config #5 shard (2^20 envs over 8 GPUs = 131072 per GPU)"
                                       if (a.gset == 70 and B == 131072) else ""),
                        "entry": "EnvMaxcutGym.step" if a.via_env else "rls_maxcut_step launcher",
-                       "num_nodes": N, "num_edges": len(mygraph), "envs_per_gpu": B, "global_envs": world * B,
+                       "num_nodes": N, "num_edges": res["E"], "envs_per_gpu": B, "global_envs": world * B,
                        "parallelism": f"env-shard x{world}"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
-                         "kernel": "k_maxcut_step<u8, emit>", "us_per_launch": kernel_s * 1e6,
-                         "algorithmic_bytes_per_launch": bytes_per_launch},
+            "roofline": s["roofline"],
         }
         tr = pmc_traffic_per_launch()
         if tr is not None and B == (1 << 16) and N == 2000:
             out["roofline"]["traffic"], out["roofline"]["traffic_source"] = tr[0], f"profiles/{tr[1]} (rocprofv3 --pmc)"
+        if res5 is not None:
+            st5 = max(1, min(a.steps, 200))
+            s5 = summarize(res5, st5, world)
+            out["config5_shard"] = {
+                "workload": f"Gset G70{'' if res5['is_real'] else '-sized G(n,m) stand-in'} MaxCut (N={res5['N']}, "
+                            f"E={res5['E']}), 131072 envs per GPU = 2^20 over 8 GPUs (BASELINE config #5), same K4 loop",
+                "value": s5["value"], "unit": "env-steps/s", "steps": st5, "ms_per_step": s5["ms_per_step"],
+                "global_envs": world * 131072, "roofline": s5["roofline"]}
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(graph_arr, N, a.cpu_seconds)
-            out["cpu_baseline_ref_shaped"] = cpu_baseline_ref_shaped(graph_arr, N, max(3.0, a.cpu_seconds / 2))
+            out["cpu_baseline"] = cpu_baseline(res["graph_arr"], N, a.cpu_seconds)
+            out["cpu_baseline_ref_shaped"] = cpu_baseline_ref_shaped(res["graph_arr"], N, max(3.0, a.cpu_seconds / 2))
 
-    if use_pg:
+    if dist.is_initialized():
         dist.barrier(device_ids=[local_rank])
         dist.destroy_process_group()
     if rank == 0:   # the JSON line is the last thing on stdout (RCCL prints its banner at init/teardown)

@@ -110,7 +110,8 @@ def global_best(local_vs: torch.Tensor, local_xs: Optional[torch.Tensor] = None,
     else:
         li, lbest = None, None
     finish = (lambda o: o.to(torch.float64) / 2) if is_float else (lambda o: o)
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    # RLS_FORCE_PG=1 keeps a 1-rank group on the collective path (the RCCL calls get exercised on a 1-GPU box)
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and os.environ.get("RLS_FORCE_PG") != "1"):
         if not n_local:
             raise ValueError("global_best: no envs at all")
         return finish(lbest), torch.zeros((), dtype=torch.int64, device=dev), \
@@ -122,9 +123,14 @@ def global_best(local_vs: torch.Tensor, local_xs: Optional[torch.Tensor] = None,
     best_x = None
     if want_solution and local_xs is not None:
         n = local_xs.shape[1]
+        if int(key[0]) == _EMPTY_KEY:                                   # (the host read below, taken one line early)
+            raise ValueError("global_best: no envs at all")             # every rank fails the same way, before C2
         src = int(owner)                                                # one host read per episode boundary
         buf = pack_bits(local_xs[li]) if (rank == src and n_local) else \
             torch.empty((n + 7) // 8, dtype=torch.uint8, device=local_xs.device)
         dist.broadcast(buf, src=src, group=group)                      # C2: ceil(N/8) bytes
         best_x = unpack_bits(buf, n, local_xs.dtype)
+    else:
+        # no host read on this path: an all-empty world trips the same error asynchronously on every rank
+        torch._assert_async(key[0] != _EMPTY_KEY, "global_best: no envs at all")
     return finish(obj), owner, best_x

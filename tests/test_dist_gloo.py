@@ -126,3 +126,67 @@ def test_pack_unpack_roundtrip():
     # ordering: larger obj wins; equal obj -> lower rank wins
     assert rdist.pack_key(torch.tensor(10), 1, 2) > rdist.pack_key(torch.tensor(9), 0, 2)
     assert rdist.pack_key(torch.tensor(10), 0, 2) > rdist.pack_key(torch.tensor(10), 1, 2)
+
+
+def _worker_empty(rank, world, port, ret):
+    """An all-empty world must fail the same way on every rank (it used to broadcast an uninitialised buffer)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    rdist.init_from_env(backend="gloo")
+    errs = 0
+    for want in (True, False):
+        try:
+            rdist.global_best(torch.empty(0, dtype=torch.int64), torch.empty((0, 9), dtype=torch.bool), want_solution=want)
+        except (ValueError, RuntimeError) as e:
+            assert "no envs at all" in str(e)
+            errs += 1
+    dist.barrier()
+    dist.destroy_process_group()
+    ret[rank] = errs
+
+
+def test_global_best_all_empty_world_raises_everywhere():
+    world = 2
+    port = _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_worker_empty, args=(world, port, ret), nprocs=world, join=True)
+    assert [ret.get(r) for r in range(world)] == [2, 2]
+
+
+def _run_bench(*args, env=None):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), *args], stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, env=e, timeout=600)
+    return p, (json.loads(p.stdout.strip().splitlines()[-1]) if p.stdout.strip() else None)
+
+
+@pytest.mark.parametrize("gpus", [1, 2, 4])
+def test_bench_self_spawn_dry_run(gpus):
+    """`python bench.py --gpus N` with no torchrun environment starts the N ranks itself; the JSON line is the LAST
+    stdout line; rank r owns envs [r * B, (r + 1) * B); the exchange finds the global maximum and its lowest owner."""
+    B = 3000
+    p, out = _run_bench("--gpus", str(gpus), "--dry-run", "--envs-per-gpu", str(B))
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert out["dry_run"] is True and out["n_gpus"] == gpus
+    assert [r["rank"] for r in out["ranks"]] == list(range(gpus))
+    assert [r["local_rank"] for r in out["ranks"]] == list(range(gpus))
+    assert [r["env_offset"] for r in out["ranks"]] == [r * B for r in range(gpus)]
+    score = lambda e: (e * 7919) % 1009
+    per_rank = [max(score(e) for e in range(r * B, (r + 1) * B)) for r in range(gpus)]
+    assert [r["local_best"] for r in out["ranks"]] == per_rank
+    assert out["global_best"] == max(per_rank) and out["owner"] == per_rank.index(max(per_rank))
+    e_star = next(e for e in range(out["owner"] * B, (out["owner"] + 1) * B) if score(e) == max(per_rank))
+    assert out["best_x"] == [int((e_star + k) % 3 == 0) for k in range(16)]
+
+
+def test_bench_refuses_world_mismatch():
+    p, _ = _run_bench("--gpus", "1", "--dry-run", env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0",
+                                                       "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port())})
+    assert p.returncode != 0

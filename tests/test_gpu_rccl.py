@@ -1,0 +1,77 @@
+"""The episode-boundary exchange over RCCL (backend "nccl") on the one GPU a test box has: a fresh child process
+forms a 1-rank group (RLS_FORCE_PG=1 keeps it on the collective path) and runs C1 / C2 on device tensors; a second
+child runs bench.py itself under the same group.  SURVEY.md section 8e; the multi-rank logic is covered by the gloo
+tests (tests/test_dist_gloo.py)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r"""
+import json, os, sys
+sys.path.insert(0, os.environ["RLS_ROOT"])
+import torch, torch.distributed as dist
+from rlsolver_amd import dist as rdist, ops
+from rlsolver_amd.graph import build_csr, generate_gnm
+rank, local_rank, world = rdist.init_from_env()
+assert dist.is_initialized() and dist.get_backend() == "nccl" and (rank, world) == (0, 1)
+dev = torch.device("cuda", local_rank)
+n, B = 203, 777
+mygraph = generate_gnm(n, 900, seed=3)
+g = ops.DeviceGraph(build_csr(mygraph, num_nodes=n, if_bidirectional=False), dev)
+xs = ops.rand_spins(B, n, seed=5, device=dev)
+obj = ops.maxcut_obj(g, xs)
+best, owner, bx = rdist.global_best(obj, xs, want_solution=True)     # C1 all_reduce(MAX) + C2 broadcast, on device
+i = int(obj.argmax())
+ok = int(best) == int(obj.max()) and int(owner) == 0 and torch.equal(bx, xs[i]) and bx.is_cuda
+# the float (bidirectional) form and the no-solution form
+bf, of, _ = rdist.global_best(obj.to(torch.float32) / 2)
+ok = ok and float(bf) == float(obj.max()) / 2 and int(of) == 0
+t = torch.arange(8, dtype=torch.int64, device=dev)
+dist.all_reduce(t, op=dist.ReduceOp.MAX)
+ok = ok and t.tolist() == list(range(8))
+dist.barrier(device_ids=[local_rank])
+dist.destroy_process_group()
+print(json.dumps({"ok": bool(ok), "best": int(best), "argmax": i}))
+"""
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _env():
+    e = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        e.pop(k, None)
+    e.update(RLS_FORCE_PG="1", RLS_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+             HSA_ENABLE_IPC_MODE_LEGACY="0")
+    return e
+
+
+def test_global_best_over_one_rank_rccl_group():
+    p = subprocess.run([sys.executable, "-c", CHILD], env=_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["ok"] is True
+
+
+def test_bench_under_one_rank_rccl_group():
+    """bench.py with an initialised RCCL group: barrier(device_ids), the all_reduce(MAX) of the region times and the
+    in-region global_best all run; the JSON line is the last stdout line."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--repeats", "3",
+                        "--envs-per-gpu", "4096", "--no-cpu-baseline", "--no-config5"], env=_env(),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads(p.stdout.strip().splitlines()[-1])
+    assert out["n_gpus"] == 1 and out["steps"] == 20 and out["repeats"] == 3 and len(out["ms_per_step_all"]) == 3
+    assert out["value"] > 0 and 0 < out["roofline"]["frac"] < 1
