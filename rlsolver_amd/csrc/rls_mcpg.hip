@@ -930,7 +930,7 @@ __global__ void k_mcpg_merge_mask(const float* __restrict__ temp_max, float* __r
     const bool take = in && t > r;
     if (take) now_max_res[m] = t;
     const uint64_t w = ballot64(take);
-    if ((threadIdx.x & 63) == 0 && m < M + 63) mask[m >> 6] = w;
+    if ((threadIdx.x & 63) == 0 && (m >> 6) < ((M + 63) >> 6)) mask[m >> 6] = w;   // exactly ceil(M / 64) words
 }
 
 __global__ void k_mcpg_merge_apply(const uint64_t* __restrict__ temp_info, uint64_t* __restrict__ now_info, int64_t N,

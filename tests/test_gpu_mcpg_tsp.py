@@ -514,3 +514,29 @@ def test_merge_best_when_best_and_worst_incumbent_coincide(M):
     bv, bi = mops.mcpg_merge_best(dev(temp_max), d_temp, d_res, d_info)
     assert np.array_equal(d_res.cpu().numpy(), w_res) and np.array_equal(d_info.unpack().cpu().numpy(), w_info)
     assert np.array_equal(d_temp.unpack().cpu().numpy(), w_temp) and float(bv) == float(w_max) and int(bi) == w_idx
+
+
+@pytest.mark.parametrize("M", [64, 128, 192, 320, 70])
+def test_merge_best_mask_scratch_is_exactly_ceil_M_over_64_words(M):
+    """rls_mcpg_merge_best's mask_scratch is uint64[ceil(M / 64)]: a canary word right behind a sub-allocated scratch
+    must survive (the mask kernel's wave leaders used to store one word past it whenever M % 64 != 1)."""
+    from rlsolver_amd import _abi
+    from rlsolver_amd.ops_mcpg_tsp import PackedChains, _ptr, _stream
+    rng = np.random.RandomState(M)
+    n = 50
+    temp_max = rng.randint(0, 50, M).astype(np.float32)
+    now_res = rng.randint(0, 50, M).astype(np.float32)
+    temp_info = (rng.rand(n, M) < 0.5).astype(np.float32)
+    now_info = (rng.rand(n, M) < 0.5).astype(np.float32)
+    w_res, w_info, w_temp, w_max, w_idx = onp.mcpg_merge_best(temp_max, temp_info, now_res, now_info)
+    d_res, d_info, d_temp = dev(now_res), PackedChains.pack(dev(now_info)), PackedChains.pack(dev(temp_info))
+    tiles = (M + 63) // 64
+    CANARY = 0x5A5A5A5A5A5A5A5A
+    arena = torch.full((tiles + 8,), CANARY, dtype=torch.int64, device=DEV)
+    bv = torch.empty(1, dtype=torch.float32, device=DEV)
+    bi = torch.empty(1, dtype=torch.int64, device=DEV)
+    _abi.call("rls_mcpg_merge_best", _ptr(dev(temp_max)), _ptr(d_temp.words), _ptr(d_res), _ptr(d_info.words), n, M,
+              _ptr(arena), _ptr(bv), _ptr(bi), _stream(torch.device(DEV)))
+    assert arena[tiles:].eq(CANARY).all(), "a word behind mask_scratch was written"
+    assert np.array_equal(d_res.cpu().numpy(), w_res) and np.array_equal(d_info.unpack().cpu().numpy(), w_info)
+    assert np.array_equal(d_temp.unpack().cpu().numpy(), w_temp) and float(bv) == float(w_max) and int(bi) == w_idx
