@@ -14,6 +14,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include "oracle.h"
 #ifdef _OPENMP
 #include <omp.h>
 #endif

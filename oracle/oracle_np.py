@@ -688,3 +688,40 @@ def tsp_local_search_2_opt(distance_matrix, tour_closed_1based, start_distance, 
         elif best_d >= tracker and recursive_seeding < 0:
             count, recursive_seeding = -1, -2
     return best_tour, best_d
+
+
+# --------------------------------------------------------------------------- Evaluator (best-so-far tracker)
+
+
+class EvaluatorOracle:
+    """Evaluator.record1 / record2, rlsolver/methods/util_evaluator.py:66-107, on numpy arrays: the constructor records
+    (0, v) and (0, v, .) without changing the incumbent (v > v is false); record2 takes the FIRST argmax (argmin when
+    minimising) of a batch, or the single solution as it is, logs its value, and replaces the incumbent only on STRICT
+    improvement.  Returns if_update like the reference."""
+
+    def __init__(self, x, v, if_maximize):
+        self.best_x, self.best_v, self.if_maximize = np.asarray(x).copy(), v, if_maximize
+        self.recorder1, self.recorder2 = [], []
+        self.record1(0, self.best_v)
+        self.record2(0, self.best_v, self.best_x)
+
+    def record1(self, i, v):
+        self.recorder1.append((i, v))
+
+    def record2(self, i, vs, xs):
+        xs = np.asarray(xs)
+        if xs.ndim == 2:
+            good_i = int(np.argmax(vs) if self.if_maximize else np.argmin(vs))
+            good_x, good_v = xs[good_i], vs[good_i]
+        else:
+            good_x, good_v = xs, vs
+        good_v = float(good_v)
+        self.recorder2.append((i, good_v))
+        if_update = (good_v > self.best_v) if self.if_maximize else (good_v < self.best_v)
+        if if_update:
+            self.best_x, self.best_v = good_x.copy(), good_v
+        return if_update
+
+    @property
+    def first_v(self):
+        return self.recorder2[0][1]

@@ -22,7 +22,7 @@ OPS_PATH = os.path.join(PKG_DIR, OPS_NAME)
 OPS_SRC = os.path.join(CSRC, "torch_ops.cpp")
 ARCH = "gfx950"
 
-SOURCES = ["rls_abi.hip", "rls_maxcut.hip", "rls_step.hip", "rls_mcpg.hip", "rls_tsp.hip", "rls_qubo.hip", "rls_spin.hip", "rls_localsearch.hip", "rls_isco.hip", "rls_track.hip"]
+SOURCES = ["rls_host.cpp", "rls_abi.hip", "rls_maxcut.hip", "rls_step.hip", "rls_mcpg.hip", "rls_tsp.hip", "rls_qubo.hip", "rls_spin.hip", "rls_localsearch.hip", "rls_isco.hip", "rls_track.hip"]
 
 
 def _hipcc() -> str:
@@ -92,12 +92,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
     common += os.environ.get("RLS_EXTRA_CFLAGS", "").split()   # dev builds, e.g. -DRLS_PROF
     procs = []
     for src in _sources():
-        obj = os.path.join(obj_dir, os.path.basename(src).replace(".hip", ".o"))
+        obj = os.path.join(obj_dir, os.path.splitext(os.path.basename(src))[0] + ".o")
         objs.append(obj)
         if (not force and os.path.exists(obj)
-                and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in _deps() if not d.endswith(".hip") or d == src)):
+                and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in _deps() if d.endswith(".h") or d == src)):
             continue
-        cmd = common + ["-c", src, "-o", obj]
+        cmd = common + (["-x", "c++"] if src.endswith(".cpp") else []) + ["-c", src, "-o", obj]     # rls_host.cpp: host-only C++
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -1,21 +1,8 @@
-// Error plumbing + trivial ABI entry points.
+// The HIP-dependent remainder of the ABI plumbing: launch-error check and the device count.  Everything host-only lives
+// in rls_host.cpp.
 #include "rls_common.h"
-#include <cstdarg>
-#include <cstdio>
-#include <algorithm>
-#include <vector>
 
 namespace rls {
-
-static thread_local char g_err[512] = "";
-
-int fail(int code, const char* fmt, ...) {
-    va_list ap;
-    va_start(ap, fmt);
-    vsnprintf(g_err, sizeof(g_err), fmt, ap);
-    va_end(ap);
-    return code;
-}
 
 int check_launch(const char* kernel_name) {
     hipError_t e = hipGetLastError();
@@ -23,378 +10,9 @@ int check_launch(const char* kernel_name) {
     return RLS_OK;
 }
 
-// ---- lanes per row of a lane = node group (K5 / K7 level schedules) ------------------------------------------------
-// A group costs its LONGEST lane and the waves of a workgroup meet at every level boundary, so one long row among short
-// ones stalls the level and pads 63 lanes: a row longer than `cap` entries is spread over 2, 4 or 8 adjacent lanes
-// (lane j of them takes entries j, j + L, ...; the kernel adds the lanes' bit-sliced counters before the compare,
-// ~110 VALU per group that has any).  Per level the cap (none / 32 / 16 / 8 entries per lane; a lane never holds
-// more than 64) is the one with the least estimated time: the level's work over the waves plus its longest group, in
-// VALU instructions as measured on gfx950 (~150 per group, ~85 per 8 rounds, ~110 for the cross-lane sums).
-struct LaneGroup { int64_t k0, k1; int32_t rounds; bool multi; };   // rows [k0, k1) of the level's degree-descending order
-
-static inline int32_t lanes_log2_for(int32_t deg, int32_t cap) {
-    int32_t lc = 0;
-    while (lc < 3 && ((cap > 0 && deg > (cap << lc)) || ((deg + (1 << lc) - 1) >> lc) > 64)) ++lc;
-    return lc;
-}
-
-// groups of <= 64 lanes over rows [a, b) (degrees non-increasing: lanes of a row stay aligned to their count);
-// rounds come in whole blocks of 8 (the kernels load them unguarded).  Returns the estimate.
-template <class DegAt>
-static int64_t plan_lane_groups(int64_t a, int64_t b, int32_t cap, DegAt deg_at, std::vector<LaneGroup>* out) {
-    int64_t total = 0, longest = 0, k = a;
-    while (k < b) {
-        LaneGroup g{k, k, 0, false};
-        int32_t used = 0;
-        while (g.k1 < b) {
-            const int32_t deg = deg_at(g.k1), lc = lanes_log2_for(deg, cap), L = 1 << lc;
-            if (used + L > 64) break;
-            used += L;
-            const int32_t r = (deg + L - 1) / L;
-            if (r > g.rounds) g.rounds = r;
-            g.multi = g.multi || lc > 0;
-            ++g.k1;
-        }
-        g.rounds = (g.rounds + 7) / 8 * 8;
-        const int64_t cost = 150 + 85 * (int64_t)(g.rounds / 8) + (g.multi ? 110 : 0);
-        total += cost;
-        if (cost > longest) longest = cost;
-        if (out) out->push_back(g);
-        k = g.k1;
-    }
-    return total / 8 + longest;
-}
-
-template <class DegAt>
-static int32_t best_lane_cap(int64_t a, int64_t b, DegAt deg_at) {
-    int32_t best_cap = 0;
-    int64_t best = -1;
-    for (int32_t cap : {0, 32, 16, 8}) {
-        const int64_t c = plan_lane_groups(a, b, cap, deg_at, nullptr);
-        if (best < 0 || c < best) { best = c; best_cap = cap; }
-    }
-    return best_cap;
-}
-
 }  // namespace rls
 
 extern "C" {
-
-int rls_version(void) { return RLS_ABI_VERSION; }
-
-const char* rls_last_error_string(void) { return rls::g_err; }
-
-int rls_graph_sweep_schedule(const int32_t* rowptr, const int32_t* col, int64_t N, int32_t max_nodes,
-                             int32_t max_entries, int32_t* rowptr_flagged, int32_t* stream, int64_t* num_batches,
-                             int64_t* num_levels) {
-    if (!rowptr || !rowptr_flagged || !stream || N < 0 || max_nodes < 1 || max_nodes > 64 || max_entries < 1 ||
-        (N > 0 && rowptr[N] > 0 && !col))
-        return rls::fail(RLS_EINVAL, "rls_graph_sweep_schedule: bad arguments");
-    if ((int64_t)rowptr[N > 0 ? N : 0] + N >= (int64_t)0x7fffffff)
-        return rls::fail(RLS_EUNSUPPORTED, "rls_graph_sweep_schedule: stream offsets need 31 bits");
-    std::vector<int32_t> level((size_t)(N > 0 ? N : 1), 0);
-    int32_t nlev = 0;
-    for (int64_t i = 0; i < N; ++i) {
-        int32_t l = 0;
-        for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j)
-            if (col[j] < i && level[(size_t)col[j]] + 1 > l) l = level[(size_t)col[j]] + 1;
-        level[(size_t)i] = l;
-        if (l + 1 > nlev) nlev = l + 1;
-    }
-    // counting sort by level (stable: ids ascending inside a level)
-    std::vector<int64_t> start((size_t)nlev + 1, 0);
-    for (int64_t i = 0; i < N; ++i) ++start[(size_t)level[(size_t)i] + 1];
-    for (int32_t l = 0; l < nlev; ++l) start[(size_t)l + 1] += start[(size_t)l];
-    std::vector<int32_t> order((size_t)(N > 0 ? N : 1));
-    {
-        std::vector<int64_t> fill(start.begin(), start.end() - 1);
-        for (int64_t i = 0; i < N; ++i) order[(size_t)fill[(size_t)level[(size_t)i]]++] = (int32_t)i;
-    }
-    int64_t nb = 0, off = 0;
-    int32_t nodes = 0, entries = 0, cur_level = -1;
-    for (int64_t k = 0; k < N; ++k) {
-        const int32_t i = order[(size_t)k];
-        const int32_t len = 1 + rowptr[i + 1] - rowptr[i];
-        const bool first = level[(size_t)i] != cur_level || nodes >= max_nodes || entries + len > max_entries;
-        if (first) { ++nb; nodes = 0; entries = 0; cur_level = level[(size_t)i]; }
-        ++nodes;
-        entries += len;
-        rowptr_flagged[k] = (int32_t)((uint32_t)off | (first ? 0x80000000u : 0u));
-        stream[off++] = i;
-        for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) stream[off++] = col[j];
-    }
-    rowptr_flagged[N] = (int32_t)off;
-    if (num_batches) *num_batches = nb;
-    if (num_levels) *num_levels = nlev;
-    return RLS_OK;
-}
-
-int rls_graph_sweep_batches(const int32_t* rowptr, const int32_t* col, int64_t N, int32_t max_nodes,
-                            int32_t max_entries, int32_t* rowptr_flagged, int64_t* num_batches) {
-    if (!rowptr || !rowptr_flagged || N < 0 || max_nodes < 1 || max_nodes > 64 || max_entries < 1 ||
-        (N > 0 && rowptr[N] > 0 && !col))
-        return rls::fail(RLS_EINVAL, "rls_graph_sweep_batches: bad arguments");
-    std::vector<int32_t> stamp((size_t)(N > 0 ? N : 1), -1);
-    int64_t nb = 0;
-    int32_t cur = -1, nodes = 0, entries = 0;
-    for (int64_t i = 0; i < N; ++i) {
-        const int32_t r0 = rowptr[i], r1 = rowptr[i + 1];
-        bool start = (i == 0) || nodes >= max_nodes || entries + (r1 - r0) > max_entries;
-        for (int32_t j = r0; j < r1 && !start; ++j) start = stamp[(size_t)col[j]] == cur;   // adjacent to a member
-        if (start) { ++cur; ++nb; nodes = 0; entries = 0; }
-        stamp[(size_t)i] = cur;
-        ++nodes;
-        entries += r1 - r0;
-        rowptr_flagged[i] = (int32_t)((uint32_t)r0 | (start ? 0x80000000u : 0u));
-    }
-    rowptr_flagged[N] = rowptr[N];
-    if (num_batches) *num_batches = nb;
-    return RLS_OK;
-}
-
-int rls_graph_sweep_levels(const int32_t* rowptr, const int32_t* col, int64_t N, int32_t* lv_ptr, int64_t ptr_capacity,
-                           int32_t* lv_data, int64_t data_capacity, int64_t* num_groups, int64_t* total) {
-    if (!rowptr || N < 0 || (N > 0 && rowptr[N] > 0 && !col) || !num_groups || !total)
-        return rls::fail(RLS_EINVAL, "rls_graph_sweep_levels: bad arguments");
-    if (N >= (1 << 20)) return rls::fail(RLS_EUNSUPPORTED, "rls_graph_sweep_levels: N >= 2^20");
-    std::vector<int32_t> level((size_t)(N > 0 ? N : 1), 0);
-    int32_t nlev = 0;
-    for (int64_t i = 0; i < N; ++i) {
-        if (rowptr[i + 1] - rowptr[i] >= 4096) return rls::fail(RLS_EUNSUPPORTED, "rls_graph_sweep_levels: degree >= 4096");
-        int32_t l = 0;
-        for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j)
-            if (col[j] < i && level[(size_t)col[j]] + 1 > l) l = level[(size_t)col[j]] + 1;
-        level[(size_t)i] = l;
-        if (l + 1 > nlev) nlev = l + 1;
-    }
-    std::vector<int64_t> start((size_t)nlev + 1, 0);
-    for (int64_t i = 0; i < N; ++i) ++start[(size_t)level[(size_t)i] + 1];
-    for (int32_t l = 0; l < nlev; ++l) start[(size_t)l + 1] += start[(size_t)l];
-    std::vector<int32_t> order((size_t)(N > 0 ? N : 1));
-    {
-        std::vector<int64_t> fill(start.begin(), start.end() - 1);
-        for (int64_t i = 0; i < N; ++i) order[(size_t)fill[(size_t)level[(size_t)i]]++] = (int32_t)i;
-    }
-    // nodes of a level are independent: longest rows first, so that the lanes a long row is spread over stay aligned.
-    // A row of 256 or more entries (a hub) is a group of its own, lane = neighbour (bit 30 of its lv_ptr entry).
-    constexpr int32_t kHub = 256;
-    auto degn = [&](int32_t i) { return rowptr[i + 1] - rowptr[i]; };
-    for (int32_t l = 0; l < nlev; ++l)
-        std::stable_sort(order.begin() + start[(size_t)l], order.begin() + start[(size_t)l + 1],
-                         [&](int32_t x, int32_t y) { return degn(x) > degn(y); });
-    auto deg_at = [&](int64_t k) { return degn(order[(size_t)k]); };
-    int64_t ng = 0, off = 0;
-    std::vector<rls::LaneGroup> groups;
-    for (int32_t l = 0; l < nlev; ++l) {
-        const int64_t a0 = start[(size_t)l], b = start[(size_t)l + 1];
-        int64_t a = a0;                                    // [a0, a): the level's hubs (sorted first), [a, b): lane = node rows
-        while (a < b && deg_at(a) >= kHub) ++a;
-        const int32_t cap = rls::best_lane_cap(a, b, deg_at);
-        groups.clear();
-        for (int64_t h = a0; h < a; ++h) groups.push_back(rls::LaneGroup{h, h + 1, (int32_t)(((deg_at(h) + 63) / 64 + 7) & ~7), false});
-        const size_t nhub = groups.size();
-        rls::plan_lane_groups(a, b, cap, deg_at, &groups);
-        for (size_t gi = 0; gi < groups.size(); ++gi) {
-            const rls::LaneGroup& g = groups[gi];
-            const bool hub = gi < nhub;
-            const int64_t len = (int64_t)(1 + g.rounds) * 64;
-            if (off + len >= (int64_t)0x3fffffff) return rls::fail(RLS_EUNSUPPORTED, "rls_graph_sweep_levels: too large");
-            if (lv_ptr) {
-                if (ng + 1 >= ptr_capacity) return rls::fail(RLS_EINVAL, "rls_graph_sweep_levels: ptr capacity too small");
-                lv_ptr[ng] = (int32_t)((uint32_t)off | (gi == 0 ? 0x80000000u : 0u) | (hub ? 0x40000000u : 0u));
-            }
-            if (lv_data) {
-                if (off + len > data_capacity) return rls::fail(RLS_EINVAL, "rls_graph_sweep_levels: data capacity too small");
-                int32_t* rec = lv_data + off;
-                for (int64_t e = 0; e < len; ++e) rec[e] = (int32_t)(e < 64 ? N : N * 8);   // idle lanes: node N, its (zero) word
-                if (hub) {   // header: lane 0 = the node, lane 1 = its degree; then its neighbours 64 per round, padded with itself
-                    const int32_t i = order[(size_t)g.k0], deg = degn(i);
-                    rec[0] = i;
-                    rec[1] = deg;
-                    for (int64_t e = 0; e < (int64_t)g.rounds * 64; ++e)
-                        rec[64 + e] = (int32_t)((uint32_t)(e < deg ? col[rowptr[i] + e] : i) * 8u);
-                    off += len;
-                    ++ng;
-                    continue;
-                }
-                int32_t ln = 0;
-                for (int64_t k = g.k0; k < g.k1; ++k) {
-                    const int32_t i = order[(size_t)k], deg = degn(i), lc = rls::lanes_log2_for(deg, cap), L = 1 << lc;
-                    for (int32_t j = 0; j < L; ++j) {              // lane j of the node's L takes neighbours j, j + L, ...
-                        rec[ln + j] = (int32_t)((uint32_t)i | ((uint32_t)(deg >> 1) << 20) | ((uint32_t)lc << 28));
-                        for (int32_t r = 0; r < g.rounds; ++r) {   // short lanes end in the node itself: x_i ^ x_i adds nothing
-                            const int32_t e = r * L + j;
-                            rec[(int64_t)(1 + r) * 64 + ln + j] = (int32_t)((uint32_t)(e < deg ? col[rowptr[i] + e] : i) * 8u);
-                        }
-                    }
-                    ln += L;
-                }
-            }
-            off += len;
-            ++ng;
-        }
-    }
-    if (lv_ptr) {
-        if (ng >= ptr_capacity) return rls::fail(RLS_EINVAL, "rls_graph_sweep_levels: ptr capacity too small");
-        lv_ptr[ng] = (int32_t)off;
-    }
-    // eight spare rows behind the last record: the kernel prefetches a group's first eight rounds without looking
-    if (lv_data) {
-        if (off + 8 * 64 > data_capacity) return rls::fail(RLS_EINVAL, "rls_graph_sweep_levels: data capacity too small");
-        for (int64_t e = 0; e < 8 * 64; ++e) lv_data[off + e] = (int32_t)(N * 8);
-    }
-    *num_groups = ng;
-    *total = off + 8 * 64;
-    return RLS_OK;
-}
-
-int rls_mcpg_visit_levels(const int32_t* rowptr, const int32_t* col, int64_t N, const int32_t* order, int32_t* lv_ptr,
-                          int64_t ptr_capacity, int32_t* lv_data, int64_t data_capacity, int64_t* num_groups,
-                          int64_t* total) {
-    if (!rowptr || !order || N < 0 || (N > 0 && rowptr[N] > 0 && !col) || !num_groups || !total)
-        return rls::fail(RLS_EINVAL, "rls_mcpg_visit_levels: bad arguments");
-    if (N >= (1 << 20)) return rls::fail(RLS_EUNSUPPORTED, "rls_mcpg_visit_levels: N >= 2^20");
-    constexpr int32_t kHubDeg = 128;             // longer rows get a group of their own, lane = neighbour
-    std::vector<int32_t> pos_of((size_t)(N > 0 ? N : 1), -1);
-    for (int64_t p = 0; p < N; ++p) {
-        if (order[p] < 0 || order[p] >= N || pos_of[(size_t)order[p]] != -1)
-            return rls::fail(RLS_EINVAL, "rls_mcpg_visit_levels: order is not a permutation");
-        pos_of[(size_t)order[p]] = (int32_t)p;
-    }
-    std::vector<int32_t> level((size_t)(N > 0 ? N : 1), 0), nfresh((size_t)(N > 0 ? N : 1), 0);   // per position
-    int32_t nlev = 0;
-    for (int64_t p = 0; p < N; ++p) {
-        const int32_t i = order[p];
-        if (rowptr[i + 1] - rowptr[i] >= 1024) return rls::fail(RLS_EUNSUPPORTED, "rls_mcpg_visit_levels: degree >= 1024");
-        int32_t l = 0, nf = 0;
-        for (int32_t j = rowptr[i]; j < rowptr[i + 1]; ++j) {
-            const int32_t q = pos_of[(size_t)col[j]];
-            if (q < p) { if (level[(size_t)q] + 1 > l) l = level[(size_t)q] + 1; }
-            else if (q > p) ++nf;
-        }
-        level[(size_t)p] = l;
-        nfresh[(size_t)p] = nf;
-        if (l + 1 > nlev) nlev = l + 1;
-    }
-    // positions by (level, hub last, degree descending, position)
-    std::vector<int32_t> sp((size_t)(N > 0 ? N : 1));
-    for (int64_t p = 0; p < N; ++p) sp[(size_t)p] = (int32_t)p;
-    auto degp = [&](int32_t p) { return rowptr[order[p] + 1] - rowptr[order[p]]; };
-    std::stable_sort(sp.begin(), sp.begin() + N, [&](int32_t a, int32_t b) {
-        if (level[(size_t)a] != level[(size_t)b]) return level[(size_t)a] < level[(size_t)b];
-        const bool ha = degp(a) > kHubDeg, hb = degp(b) > kHubDeg;
-        if (ha != hb) return hb;
-        return degp(a) > degp(b);
-    });
-    int64_t ng = 0, off = 0;
-    auto header = [&](int32_t p, int32_t lcode, int32_t& h0, int32_t& h1) {
-        const int32_t i = order[p], deg = degp(p), t0 = deg + nfresh[(size_t)p];
-        h0 = (int32_t)((uint32_t)i | ((uint32_t)((deg + 1) >> 1) << 20) | ((uint32_t)lcode << 28) | ((deg & 1) ? 0u : 0x80000000u));
-        h1 = (int32_t)((uint32_t)p | ((uint32_t)((t0 + 1) >> 1) << 20) | ((t0 & 1) ? 0u : 0x80000000u));
-    };
-    auto entry = [&](int32_t p, int32_t r) {   // r-th neighbour word of position p
-        const int32_t i = order[p], nb = col[rowptr[i] + r];
-        return (int32_t)(((uint32_t)nb * 8u) | (pos_of[(size_t)nb] > p ? 0x80000000u : 0u));   // LDS byte offset of the word
-    };
-    using Grp = rls::LaneGroup;
-    auto deg_at = [&](int64_t k) { return degp(sp[(size_t)k]); };
-    std::vector<Grp> groups;
-    int64_t k0 = 0;
-    while (k0 < N) {
-        const int32_t lev = level[(size_t)sp[(size_t)k0]];
-        // the level's lane = node rows [k0, kn) and its hubs [kn, ke)
-        int64_t kn = k0, ke;
-        while (kn < N && level[(size_t)sp[(size_t)kn]] == lev && degp(sp[(size_t)kn]) <= kHubDeg) ++kn;
-        ke = kn;
-        while (ke < N && level[(size_t)sp[(size_t)ke]] == lev) ++ke;
-        const int32_t best_cap = rls::best_lane_cap(k0, kn, deg_at);
-        // the level's groups, the costly ones first: waves take groups round-robin, the long ones should not queue up behind
-        // a wave's earlier work
-        groups.clear();
-        for (int64_t h = kn; h < ke; ++h) groups.push_back(Grp{h, h + 1, (degp(sp[(size_t)h]) + 63) / 64, false});
-        std::stable_sort(groups.begin(), groups.end(), [](const Grp& x, const Grp& y) { return x.rounds > y.rounds; });
-        rls::plan_lane_groups(k0, kn, best_cap, deg_at, &groups);
-        bool level_start = true;
-        for (size_t gi = 0; gi < groups.size(); ++gi) {
-            const Grp& g = groups[gi];
-            const bool hub = g.k0 >= kn;
-            const int64_t rounds = g.rounds;
-            const int64_t len = (2 + rounds) * 64;
-            if (off + len >= (int64_t)0x3fffffff) return rls::fail(RLS_EUNSUPPORTED, "rls_mcpg_visit_levels: too large");
-            if (lv_ptr) {
-                if (ng + 1 >= ptr_capacity) return rls::fail(RLS_EINVAL, "rls_mcpg_visit_levels: ptr capacity too small");
-                lv_ptr[ng] = (int32_t)((uint32_t)off | (level_start ? 0x80000000u : 0u) | (hub ? 0x40000000u : 0u));
-            }
-            if (lv_data) {
-                if (off + len > data_capacity) return rls::fail(RLS_EINVAL, "rls_mcpg_visit_levels: data capacity too small");
-                int32_t* rec = lv_data + off;
-                for (int64_t e = 0; e < len; ++e) rec[e] = (int32_t)(e < 128 ? N : N * 8);      // idle header lanes: node N; padding: the zero word
-                if (hub) {
-                    const int32_t p = sp[(size_t)g.k0], md = degp(p);
-                    header(p, 0, rec[0], rec[64]);
-                    rec[2] = md;
-                    for (int32_t r = 0; r < md; ++r) rec[128 + r] = entry(p, r);
-                } else {
-                    int32_t ln = 0;
-                    for (int64_t k = g.k0; k < g.k1; ++k) {
-                        const int32_t p = sp[(size_t)k], deg = degp(p), lc = rls::lanes_log2_for(deg, best_cap), L = 1 << lc;
-                        for (int32_t j = 0; j < L; ++j) {          // lane j of the node's L takes neighbours j, j + L, ...
-                            header(p, lc, rec[ln + j], rec[64 + ln + j]);
-                            for (int32_t r = j; r < deg; r += L) rec[(int64_t)(2 + r / L) * 64 + ln + j] = entry(p, r);
-                        }
-                        ln += L;
-                    }
-                }
-            }
-            off += len;
-            ++ng;
-            level_start = false;
-        }
-        k0 = ke;
-    }
-    if (lv_ptr) {
-        if (ng >= ptr_capacity) return rls::fail(RLS_EINVAL, "rls_mcpg_visit_levels: ptr capacity too small");
-        lv_ptr[ng] = (int32_t)off;
-    }
-    // eight spare rows behind the last record: the kernel prefetches a group's first eight rounds without looking
-    if (lv_data) {
-        if (off + 8 * 64 > data_capacity) return rls::fail(RLS_EINVAL, "rls_mcpg_visit_levels: data capacity too small");
-        for (int64_t e = 0; e < 8 * 64; ++e) lv_data[off + e] = (int32_t)(N * 8);
-    }
-    *num_groups = ng;
-    *total = off + 8 * 64;
-    return RLS_OK;
-}
-
-int rls_graph_ell(const int32_t* rowptr, const int32_t* col, int64_t N, int32_t* ell_ptr, int32_t* ell,
-                  int64_t capacity, int64_t* total) {
-    if (!rowptr || !ell_ptr || N < 0 || (N > 0 && rowptr[N] > 0 && !col))
-        return rls::fail(RLS_EINVAL, "rls_graph_ell: bad arguments");
-    const int64_t G = (N + 63) / 64;
-    int64_t off = 0;
-    for (int64_t g = 0; g < G; ++g) {
-        const int64_t i0 = g * 64, i1 = (i0 + 64 < N) ? i0 + 64 : N;
-        int32_t md = 0;
-        for (int64_t i = i0; i < i1; ++i)
-            if (rowptr[i + 1] - rowptr[i] > md) md = rowptr[i + 1] - rowptr[i];
-        if (off + (int64_t)md * 64 >= (int64_t)0x7fffffff) return rls::fail(RLS_EUNSUPPORTED, "rls_graph_ell: too large");
-        ell_ptr[g] = (int32_t)off;
-        if (ell) {
-            if (off + (int64_t)md * 64 > capacity) return rls::fail(RLS_EINVAL, "rls_graph_ell: capacity too small");
-            for (int32_t k = 0; k < md; ++k)
-                for (int64_t l = 0; l < 64; ++l) {
-                    const int64_t i = i0 + l;
-                    int32_t v = (int32_t)(i < N ? i : 0);
-                    if (i < N && rowptr[i] + k < rowptr[i + 1]) v = col[rowptr[i] + k];
-                    ell[off + (int64_t)k * 64 + l] = v;
-                }
-        }
-        off += (int64_t)md * 64;
-    }
-    ell_ptr[G] = (int32_t)off;
-    if (total) *total = off;
-    return RLS_OK;
-}
 
 int rls_device_count(void) {
     int n = 0;

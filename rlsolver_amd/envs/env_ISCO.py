@@ -11,15 +11,13 @@ time, they are explicit constructor arguments here.
 """
 from __future__ import annotations
 
-import ctypes as C
 from typing import Optional
 
 import numpy as np
 import torch
 
-from .. import _abi
 from .. import ops_mcpg_tsp as mops
-from ..ops import _check, _ptr, _stream
+from ..ops import _check, _s64, _t
 
 
 def _seed_from_torch() -> int:
@@ -66,11 +64,9 @@ class ISCO_TSP:
                           ("u_gumbel", torch.float32)):
                 d[k] = _check(draws[k].to(self.device).contiguous(), k, (dt,), self.device, (L, B, N))
             d["u_accept"] = _check(draws["u_accept"].to(self.device).contiguous(), "u_accept", (torch.float32,), self.device, (B,))
-        _abi.call("rls_isco_tsp_step", _ptr(self.distance), N, _ptr(self._near32), self.K, self._near_thr, _ptr(self._rand32), self._rand32.shape[1],
-                  _ptr(x), _ptr(y), B, L, float(temperature), _ptr(d.get("u_partner")), _ptr(d.get("r_near")),
-                  _ptr(d.get("r_rand")), _ptr(d.get("u_gumbel")), _ptr(d.get("u_accept")),
-                  C.c_uint64(0 if draws is not None else _seed_from_torch()), 0, _ptr(log_acc), _ptr(acc), _ptr(cur),
-                  _stream(self.device))
+        _t.isco_tsp_step(self.distance, self._near32, self._near_thr, self._rand32, x, y, L, float(temperature), d.get("u_partner"),
+                         d.get("r_near"), d.get("r_rand"), d.get("u_gumbel"), d.get("u_accept"),
+                         _s64(0 if draws is not None else _seed_from_torch()), 0, log_acc, acc, cur)
         if want_terms:
             return y, acc.mean(), log_acc, cur
         return y, acc.mean()

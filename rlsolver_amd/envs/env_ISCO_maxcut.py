@@ -9,15 +9,14 @@ Samples keep the reference's dtype / shape (float32 0/1, [B, N]).
 """
 from __future__ import annotations
 
-import ctypes as C
 from typing import Optional
 
 import numpy as np
 import torch
 
-from .. import _abi, ops
+from .. import ops
 from ..graph import build_csr
-from ..ops import _check, _ptr, _stream
+from ..ops import _check, _s64, _t
 from .env_ISCO import _seed_from_torch
 
 
@@ -66,9 +65,8 @@ class ISCO_maxcut:
         if draws is not None:
             ug = _check(draws["u_gumbel"].to(self.device).contiguous(), "u_gumbel", (torch.float32,), self.device, (B, N))
             ua = _check(draws["u_accept"].to(self.device).contiguous(), "u_accept", (torch.float32,), self.device, (B,))
-        _abi.call("rls_isco_maxcut_step", self.graph.ref, _ptr(x), _ptr(y), B, _ptr(pl), float(temperature), _ptr(ug),
-                  _ptr(ua), C.c_uint64(0 if draws is not None else _seed_from_torch()), 0, _ptr(energy), _ptr(acc),
-                  _ptr(terms), _ptr(mask), _stream(self.device))
+        _t.isco_maxcut_step(self.graph.handle, x, y, pl, float(temperature), ug, ua,
+                            _s64(0 if draws is not None else _seed_from_torch()), 0, energy, acc, terms, mask)
         if want_terms:
             return y, energy, acc, terms, mask
         return y, energy, acc

@@ -39,7 +39,7 @@ import torch
 
 from .. import _abi, ops
 from ..graph import build_csr
-from ..ops import _ptr, _stream
+from ..ops import _t
 from .env_L2A import _seed_from_torch
 
 
@@ -159,7 +159,8 @@ class SpinSystem:
             self._matrix = None
             self._weight_sum = int(csr.wgt.sum())         # sum of W over ordered pairs
         self.max_local_reward_available = self.max_local_reward_available_.unsqueeze(1).expand(-1, num_nodes)
-        self._rows = (C.c_int32 * 7)(*[next((i for i, o in self.observables if o == want), -1) for want in _ROW_ORDER])
+        # host int32[7]: where each observable of _ROW_ORDER sits in `state` (-1 = not observed)
+        self._rows = torch.tensor([next((i for i, o in self.observables if o == want), -1) for want in _ROW_ORDER], dtype=torch.int32)
         R, B, N = len(observables), num_envs, num_nodes
         dt = self.dtype
         self.state = torch.zeros((B, R, N), dtype=dt, device=self.device)
@@ -184,7 +185,7 @@ class SpinSystem:
             packed=self._packed.data_ptr() if self._use_hist else 0, hash=self._hash.data_ptr() if self._use_hist else 0,
             hist=self._hist.data_ptr() if self._use_hist else 0,
             hist_hash=self._hist_hash.data_ptr() if self._use_hist else 0, hist_cap=max_steps if self._use_hist else 0)
-        self._sb = 8 if dt == torch.float64 else 4
+        self._env_handle = C.addressof(self._env)     # the `env` argument of torch.ops.rlsolver_hip.spin_*
         self.current_step = 0
         self.reset()
 
@@ -229,9 +230,8 @@ class SpinSystem:
             # a fresh matrix per env (spinsystem_PECO.py:150-170); graphs the reference rejects are drawn again
             for _ in range(64):
                 self._matrix = self._draw_matrix()
-                _abi.call("rls_spin_reset_dense", _ptr(self._matrix), C.byref(self._env), self._sb, B, N, self.state.shape[1],
-                          self._rows, _ptr(self.max_local_reward_available_), _ptr(self._weight_sum_env), _ptr(self._flags),
-                          _stream(self.device))
+                _t.spin_reset_dense(self._matrix, self._env_handle, self.state, self._rows, self.max_local_reward_available_,
+                                    self._weight_sum_env, self._flags)
                 flags = int(self._flags.max())            # the one host read of a reset (the reference's .any() tests)
                 if flags & 2:
                     raise ValueError("graph_generator.get() must return symmetric integer-valued matrices")
@@ -242,8 +242,7 @@ class SpinSystem:
         else:
             # gains of all single flips: delta_i = s_i sum_j W_ij s_j = sum_j W_ij (x_i == x_j ? 1 : -1): the K3 kernel
             ops.maxcut_delta_all(self.graph, bits, out=self._delta)
-            _abi.call("rls_spin_reset", self.graph.ref, C.byref(self._env), self._sb, B, self.state.shape[1], self._rows,
-                      self._max_local, self._weight_sum, _stream(self.device))
+            _t.spin_reset(self.graph.handle, self._env_handle, self.state, self._rows, self._max_local, self._weight_sum)
         self.best_obs_score = self.best_score
         self.best_obs_spins = self.best_spins
         return self.get_observation()
@@ -271,11 +270,11 @@ class SpinSystem:
         c = getattr(self, "_consts", None)
         if c is None or c["key"] != key:
             c = self._consts = dict(
-                key=key, env=C.byref(self._env), R=self.state.shape[1], visited=_ptr(self._visited_new),
+                key=key,
                 time_inc=self._round(1.0 / self.max_steps), mode=_REWARD_MODE[self.reward_signal],
                 div=float(self.n_spins) if self.norm_rewards else 1.0,
-                tail=(int(self.stag_punishment is not None), self._round(self.stag_punishment or 0.0),
-                      int(self.basin_reward is not None), self._round(self.basin_reward or 0.0)))   # the stream is resolved per call
+                tail=(self.stag_punishment is not None, self._round(self.stag_punishment or 0.0),
+                      self.basin_reward is not None, self._round(self.basin_reward or 0.0)))
         return c
 
     def step(self, action):
@@ -291,14 +290,12 @@ class SpinSystem:
         rew = torch.empty(B, dtype=self.dtype, device=self.device)
         c = self._step_consts()
         if self._dense:
-            _abi.call("rls_spin_step_dense", _ptr(self._matrix), _ptr(self.max_local_reward_available_), c["env"],
-                      self._sb, B, self.n_spins, c["R"], self._rows, _ptr(action), _ptr(rew), c["visited"],
-                      c["time_inc"], self._termination(), c["mode"], c["div"], self.current_step - 1, *c["tail"],
-                      _stream(self.device))
+            _t.spin_step_dense(self._matrix, self.max_local_reward_available_, self._env_handle, self.state, self._rows, action, rew,
+                               self._visited_new, c["time_inc"], self._termination(), c["mode"], c["div"], self.current_step - 1,
+                               *c["tail"])
         else:
-            _abi.call("rls_spin_step", self.graph.ref, c["env"], self._sb, B, c["R"], self._rows,
-                      _ptr(action), _ptr(rew), c["visited"], self._max_local, c["time_inc"], self._termination(), c["mode"], c["div"],
-                      self.current_step - 1, *c["tail"], _stream(self.device))
+            _t.spin_step(self.graph.handle, self._env_handle, self.state, self._rows, action, rew, self._visited_new, self._max_local,
+                         c["time_inc"], self._termination(), c["mode"], c["div"], self.current_step - 1, *c["tail"])
         done = torch.full((B,), self.current_step == self.max_steps, dtype=torch.bool, device=self.device)
         return self.get_observation(), rew, done
 
@@ -313,9 +310,7 @@ class SpinSystem:
             out = torch.empty((B, rows, N), dtype=self.dtype, device=self.device)
         elif out.shape != (B, rows, N) or out.dtype != self.dtype or not out.is_contiguous():
             raise ValueError(f"out must be a contiguous {self.dtype} tensor of shape {(B, rows, N)}")
-        _abi.call("rls_spin_observation", _ptr(self.state), _ptr(self.matrix if self.include_adjacency else None),
-                  int(self._dense), 8 if self.dtype == torch.float64 else 4, B, R, N, int(self.spin_basis == SpinBasis.BINARY), _ptr(out),
-                  _stream(self.device))
+        _t.spin_observation(self.state, self.matrix if self.include_adjacency else None, self.spin_basis == SpinBasis.BINARY, out)
         return out
 
     def get_immeditate_rewards_avaialable(self, spins=None):

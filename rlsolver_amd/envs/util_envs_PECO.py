@@ -13,8 +13,7 @@ from enum import Enum
 
 import torch
 
-from .. import _abi
-from ..ops import _ptr, _stream
+from ..ops import _s64, _t
 from .env_L2A import _seed_from_torch
 
 
@@ -49,9 +48,8 @@ class _KernelGenerator(GraphGenerator):
 
     def get(self, with_padding=False, seed=None):
         out = torch.empty((self.num_envs, self.n_spins, self.n_spins), dtype=self.dtype, device=self.device)
-        _abi.call("rls_rand_couplings", _ptr(out), 8 if self.dtype == torch.float64 else 4, self.num_envs, self.n_spins, self._kind,
-                  float(self._p), int(self._m), self.edge_type.value, _seed_from_torch() if seed is None else int(seed),
-                  self.env_offset, _stream(self.device))
+        _t.rand_couplings(out, self._kind, float(self._p), int(self._m), self.edge_type.value,
+                          _s64(_seed_from_torch() if seed is None else int(seed)), self.env_offset)
         return out
 
 

@@ -109,20 +109,39 @@ def read_edge_arrays(filename: str, chunk_bytes: int = 64 << 20) -> Tuple[int, n
             tok = buf.split()
             if not tok:
                 continue
-            # decide by the first data row of the block: 3 tokens per row when the line has a weight
-            first_row = buf.lstrip().split(b"\n", 1)[0].split()
-            cols = len(first_row)
-            if cols not in (2, 3) or len(tok) % cols:
-                raise ValueError(f"{filename}: rows must be 'n0 n1 [weight]'")
-            try:
-                a = np.array(tok, dtype=np.int64).reshape(-1, cols)
-            except (ValueError, OverflowError):
-                a = np.array(tok, dtype=np.float64).reshape(-1, cols).astype(np.int64)
+            # fast path: every line of the block has the token count of its first data row (2, or 3 with a weight) --
+            # true exactly when rows * cols tokens sit on `rows` lines.  Anything else (blank lines, rows with and
+            # without a weight mixed) is parsed line by line like the reference's reader, which raises on a malformed row.
+            cols = len(buf.lstrip().split(b"\n", 1)[0].split())
+            lines = buf.count(b"\n") + (0 if buf.endswith(b"\n") else 1)
+            if cols in (2, 3) and len(tok) == cols * lines:
+                try:
+                    a = np.array(tok, dtype=np.int64).reshape(-1, cols)
+                except (ValueError, OverflowError):
+                    a = np.array(tok, dtype=np.float64).reshape(-1, cols).astype(np.int64)
+            else:
+                rows = []
+                for ln in buf.split(b"\n"):
+                    p = ln.split()
+                    if not p:
+                        continue
+                    if len(p) not in (2, 3):
+                        raise ValueError(f"{filename}: rows must be 'n0 n1 [weight]', got {ln.decode(errors='replace')!r}")
+                    rows.append((int(p[0]), int(p[1]), int(float(p[2])) if len(p) == 3 else 1))
+                a = np.array(rows, dtype=np.int64).reshape(-1, 3)
+                cols = 3
+            if a.size and (a[:, :2].min() < 1 or a[:, :2].max() > n):
+                bad = a[((a[:, :2] < 1) | (a[:, :2] > n)).any(axis=1)][0]
+                raise ValueError(f"{filename}: node id outside [1, {n}] in row {bad[0]} {bad[1]}")
             us.append((a[:, 0] - 1).astype(np.int32))
             vs.append((a[:, 1] - 1).astype(np.int32))
             ws.append(a[:, 2].astype(np.int32) if cols == 3 else np.ones(len(a), np.int32))
     if n is None:
         raise ValueError(f"empty graph file {filename}")
+    total = sum(len(u) for u in us)
+    if m is not None and total != m:
+        import warnings
+        warnings.warn(f"{filename}: header announces {m} edges, the file holds {total}")
     if not us:
         z = np.zeros(0, np.int32)
         return n, z, z.copy(), z.copy()

@@ -1,7 +1,7 @@
 """LocalSearch -- drop-in for rlsolver/methods/LocalSearch.py:27-86 on a HIP EnvMaxcut.
 
 The class only holds the incumbent batch (``good_xs`` / ``good_vs``); every search step is the env's kernels:
-``reset_search`` is one K1 launch over num_sims^2 random rows + one best-of-repeats pick (the reference loops
+``reset_search`` is a K1 launch + a best-of-repeats pick per memory-bounded chunk of repeats (the reference loops
 num_sims times), ``random_search`` is the env's local-search pipeline (fused kernel, or K2 + K6 + K5) with this
 class's weight factor and threshold rule, followed by the row-wise keep-better kernel.
 """
@@ -30,11 +30,25 @@ class LocalSearch:
         self.num_sims = xs.shape[0]
         return self.good_vs
 
+    RESET_SEARCH_MAX_BYTES = 1 << 30     # candidate rows held at once by reset_search
+
     def reset_search(self, num_sims):
-        """LocalSearch.py:44-50: num_sims incumbents, each the best of num_sims random rows (first best on ties)."""
+        """LocalSearch.py:44-50: num_sims incumbents, each the best of num_sims random rows (first best on ties).
+        The reference holds num_sims rows per iteration; here the num_sims repeats are taken in chunks of as many as fit
+        RESET_SEARCH_MAX_BYTES (row r * num_sims + s of a chunk = its candidate r of slot s), each chunk reduced by
+        one K1 launch + one best-of-repeats pick and merged into the running best by the keep-better kernel -- memory is
+        O(chunk * num_sims * N), never num_sims^2 * N."""
         sim = self.simulator
-        cand = sim.generate_xs_randomly(num_sims=num_sims * num_sims)      # row r * num_sims + s = candidate r of slot s
-        best, _ = ops.pick_best_of_repeats(cand, sim.calculate_obj_values(cand), num_sims, if_maximize=True)
+        per_repeat = max(1, num_sims * (sim.num_nodes + 8))
+        chunk = max(1, min(num_sims, self.RESET_SEARCH_MAX_BYTES // per_repeat))
+        best = best_v = None
+        for r0 in range(0, num_sims, chunk):
+            reps = min(chunk, num_sims - r0)
+            cand = sim.generate_xs_randomly(num_sims=reps * num_sims)
+            cx, cv = ops.pick_best_of_repeats(cand, sim.calculate_obj_values(cand), reps, if_maximize=True)
+            if best is not None:     # earlier repeats win ties: the running best replaces the chunk's row when it is >=
+                ops.select_better_rows(cx, cv, best, best_v, if_maximize=True)
+            best, best_v = cx, cv
         return best
 
     # ---- checkpoint (SURVEY.md section 5): the incumbents

@@ -3,14 +3,12 @@ rlsolver/methods/MCPG/sampling.py:323-370 (mcpg_sampling_qubo, mcpg_sampling_qub
 loader rlsolver/methods/MCPG/dataloader.py:278-294, on HIP tensors."""
 from __future__ import annotations
 
-import ctypes as C
 from typing import Optional
 
 import numpy as np
 import torch
 
-from .. import _abi
-from ..ops import _check, _ptr, _stream
+from ..ops import _check, _t
 from .MCPG import metro_sampling
 
 TEN = torch.Tensor
@@ -41,8 +39,7 @@ def qubo_local_search_value(Q: TEN, xs: TEN, num_ls: int, binary: bool):
     Cc = xs.shape[1]
     out = torch.empty_like(xs)
     value = torch.empty(Cc, dtype=torch.float32, device=dev)
-    _abi.call("rls_qubo_local_search_value", _ptr(Q), n, _ptr(xs), _ptr(out), Cc, num_ls, int(bool(binary)),
-              _ptr(value), _stream(dev))
+    _t.qubo_local_search_value(Q, xs, out, num_ls, bool(binary), value)
     return out, value
 
 
@@ -70,8 +67,7 @@ def qubo_sparse_local_search_value(csr, xs: TEN, num_ls: int, binary: bool):
         raise ValueError(f"xs must be [{n}, C]")
     out = torch.empty_like(xs)
     value = torch.empty(xs.shape[1], dtype=torch.float32, device=dev)
-    _abi.call("rls_qubo_sparse_local_search_value", _ptr(rowptr), _ptr(col), _ptr(val), n, _ptr(xs), _ptr(out), xs.shape[1], num_ls,
-              int(bool(binary)), _ptr(value), _stream(dev))
+    _t.qubo_sparse_local_search_value(rowptr, col, val, xs, out, num_ls, bool(binary), value)
     return out, value
 
 

@@ -16,7 +16,7 @@ from typing import Union
 import numpy as np
 import torch as th
 
-from .. import _abi, ops
+from .. import ops
 
 TEN = th.Tensor
 _DIGITS = "0123456789ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz_$"
@@ -116,10 +116,7 @@ class Evaluator:
         n = len(self._log_meta)
         if n == self._log.numel():                # grow the value log (amortised, stream-ordered copy)
             self._log = th.cat([self._log, th.zeros_like(self._log)])
-        _abi.call("rls_best_update", ops._ptr(xs2), ops._ptr(vs1), {th.int64: 0, th.float32: 1, th.float64: 2}[vs1.dtype],
-                  vs1.numel(), self._best_x.numel(), int(bool(self.if_maximize)), ops._ptr(self._best_x),
-                  ops._ptr(self._best_v), ops._ptr(self._improved), ops._ptr(self._log), n, int(bool(force)),
-                  ops._stream(self.device))
+        ops._t.best_update(xs2, vs1, bool(self.if_maximize), self._best_x, self._best_v, self._improved, self._log, n, bool(force))
         self._log_meta.append((i, time.time() - self.start_timer))
         return _DeviceFlag(self._improved)
 

@@ -4,7 +4,7 @@ from __future__ import annotations
 
 import torch as th
 
-from .. import _abi, ops
+from .. import ops
 from ..graph import (MyGraph, build_adjacency_bool, build_adjacency_indies,  # noqa: F401
                      calc_num_nodes_in_mygraph, load_mygraph2, read_mygraph, read_tsp_file)
 
@@ -51,8 +51,7 @@ def evolutionary_replacement(xs: TEN, vs: TEN, low_k: int, if_maximize: bool = T
     donors = donors.contiguous()
     if xs.dtype in (th.bool, th.uint8) and xs.is_cuda and xs.is_contiguous():
         v64 = vs if (vs.dtype == th.int64 and vs.is_contiguous()) else None
-        _abi.call("rls_copy_rows", ops._ptr(xs), ops._ptr(v64), xs.shape[1], ops._ptr(targets), ops._ptr(donors),
-                  targets.numel(), ops._stream(xs.device))
+        ops._t.copy_rows(xs, v64, targets, donors)
         if v64 is None:
             vs[targets] = vs[donors]
     else:

@@ -1,6 +1,8 @@
-"""Tensor-level wrappers over the C ABI: check device/dtype/contiguity, pass raw
-device pointers and torch's current HIP stream.  PyTorch is plumbing here
-(memory + streams); all arithmetic happens in the HIP kernels.
+"""Tensor-level wrappers over the kernels: allocate outputs, check device / dtype and call
+``torch.ops.rlsolver_hip.*`` (csrc/torch_ops.cpp: the native custom ops over the C ABI of
+include/rlsolver_hip.h, which check every shape, switch to the tensors' device and pass torch's
+current HIP stream).  ctypes is used only for the host-side schedule builders and queries of the
+C ABI.  PyTorch is plumbing here (memory + streams); all arithmetic happens in the HIP kernels.
 
 No CPU path: a CPU tensor is a TypeError, a missing library an ImportError.
 """
@@ -14,6 +16,15 @@ import torch
 
 from . import _abi
 from .graph import GraphCSR
+from .torch_ops import ops as _t
+
+_U64_MASK = (1 << 64) - 1
+
+
+def _s64(seed: int) -> int:
+    """A 64-bit seed as the int64 an op schema carries (the op casts it back to uint64)."""
+    seed &= _U64_MASK
+    return seed - (1 << 64) if seed >= (1 << 63) else seed
 
 TEN = torch.Tensor
 
@@ -114,7 +125,8 @@ class DeviceGraph:
             sweep_lv_ptr=0 if self.sweep_lv_ptr is None else self.sweep_lv_ptr.data_ptr(),
             sweep_lv_data=0 if self.sweep_lv_data is None else self.sweep_lv_data.data_ptr(),
             num_sweep_groups=self.num_sweep_groups)
-        self.ref = C.byref(self.struct)
+        self.ref = C.byref(self.struct)              # for the host-side queries of the C ABI (ctypes)
+        self.handle = C.addressof(self.struct)       # the `graph` argument of torch.ops.rlsolver_hip.*
 
 
 def _ell_build(self, rowptr_h, col_h, n):
@@ -145,21 +157,21 @@ def maxcut_obj(g: DeviceGraph, xs: TEN, out: Optional[TEN] = None) -> TEN:
     if out is None:
         out = torch.empty(B, dtype=torch.int64, device=g.device)
     _check(out, "out", (torch.int64,), g.device, (B,))
-    _abi.call("rls_maxcut_obj", g.ref, _ptr(xs), sb, B, _ptr(out), _stream(g.device))
+    _t.maxcut_obj(g.handle, xs, out)
     return out
 
 
 def maxcut_edge_cut_mask(g: DeviceGraph, xs: TEN) -> TEN:
     B, _ = _spins(xs, "xs", g)
     out = torch.empty((B, g.num_stored_edges), dtype=torch.bool, device=g.device)
-    _abi.call("rls_maxcut_edge_cut_mask", g.ref, _ptr(xs), B, _ptr(out), _stream(g.device))
+    _t.maxcut_edge_cut_mask(g.handle, xs, out)
     return out
 
 
 def maxcut_node_cutdeg(g: DeviceGraph, xs: TEN) -> TEN:
     B, _ = _spins(xs, "xs", g)
     out = torch.empty((B, g.num_nodes), dtype=torch.int64, device=g.device)
-    _abi.call("rls_maxcut_node_cutdeg", g.ref, _ptr(xs), B, _ptr(out), _stream(g.device))
+    _t.maxcut_node_cutdeg(g.handle, xs, out)
     return out
 
 
@@ -168,7 +180,7 @@ def maxcut_delta_all(g: DeviceGraph, xs: TEN, out: Optional[TEN] = None) -> TEN:
     if out is None:
         out = torch.empty((B, g.num_nodes), dtype=torch.int32, device=g.device)
     _check(out, "out", (torch.int32,), g.device, (B, g.num_nodes))
-    _abi.call("rls_maxcut_delta_all", g.ref, _ptr(xs), B, _ptr(out), _stream(g.device))
+    _t.maxcut_delta_all(g.handle, xs, out)
     return out
 
 
@@ -186,8 +198,7 @@ def maxcut_step(g: DeviceGraph, x_in: TEN, x_out: TEN, action: TEN, obj: TEN, re
         _check(cur, "cur", (torch.float32,), g.device, (B,))
     if done is not None:
         _check(done, "done", (torch.float32,), g.device, (B,))
-    _abi.call("rls_maxcut_step", g.ref, _ptr(x_in), _ptr(x_out), sb, B, _ptr(action), _ptr(obj),
-              _ptr(reward), _ptr(cur), _ptr(done), float(done_value), _stream(g.device))
+    _t.maxcut_step(g.handle, x_in, x_out, action, obj, reward, cur, done, float(done_value))
 
 
 def maxcut_step_launcher(g: DeviceGraph, x_in: TEN, x_out: TEN, action: TEN, obj: TEN, reward: TEN,
@@ -207,23 +218,18 @@ def maxcut_step_launcher(g: DeviceGraph, x_in: TEN, x_out: TEN, action: TEN, obj
         _check(cur, "cur", (torch.float32,), g.device, (B,))
     if done is not None:
         _check(done, "done", (torch.float32,), g.device, (B,))
-    fn = _abi.lib().rls_maxcut_step
-    args = (g.ref, _ptr(x_in), _ptr(x_out), sb, B, _ptr(action), _ptr(obj), _ptr(reward), _ptr(cur), _ptr(done),
-            C.c_float(done_value))
-    keep = (g, x_in, x_out, action, obj, reward, cur, done)   # keep the buffers alive with the closure
-    dev_index = g.device.index if g.device.index is not None else torch.cuda.current_device()
+    op = _t.maxcut_step.default      # the overload itself: skips the packet's overload resolution on every call
+    args = (g.handle, x_in, x_out, action, obj, reward, cur, done, float(done_value))   # the tuple keeps g and the buffers alive
 
-    def launch(_keep=keep):
-        rc = fn(*args, _raw_stream(dev_index))
-        if rc != 0:
-            raise _abi.RlsError("rls_maxcut_step", rc, _abi.lib().rls_last_error_string().decode())
+    def launch(_op=op, _args=args):
+        _op(*_args)
     return launch
 
 
 def maxcut_greedy_sweep(g: DeviceGraph, xs: TEN, obj: TEN) -> None:
     B, _ = _spins(xs, "xs", g)
     _check(obj, "obj", (torch.int64,), g.device, (B,))
-    _abi.call("rls_maxcut_greedy_sweep", g.ref, _ptr(xs), B, _ptr(obj), _stream(g.device))
+    _t.maxcut_greedy_sweep(g.handle, xs, obj)
 
 
 def maxcut_propose_accept(g: DeviceGraph, xs: TEN, mask: TEN, obj: TEN) -> None:
@@ -232,7 +238,7 @@ def maxcut_propose_accept(g: DeviceGraph, xs: TEN, mask: TEN, obj: TEN) -> None:
     if mask.shape[0] != B:
         raise ValueError("mask must have the same shape as xs")
     _check(obj, "obj", (torch.int64,), g.device, (B,))
-    _abi.call("rls_maxcut_propose_accept", g.ref, _ptr(xs), B, _ptr(mask), _ptr(obj), _stream(g.device))
+    _t.maxcut_propose_accept(g.handle, xs, mask, obj)
 
 
 LOCAL_SEARCH_MAX_SPIN = 15
@@ -248,7 +254,7 @@ def maxcut_ls_weights(g: DeviceGraph, xs: TEN, mult: int):
     """Pre-pass of the fused local search: (ws int32 [B,N], ws_std int32 [N] = max_b ws - min_b ws)."""
     B, _ = _spins(xs, "xs", g)
     ws = torch.empty((B, g.num_nodes), dtype=torch.int32, device=g.device)
-    _abi.call("rls_maxcut_ls_weights", g.ref, _ptr(xs), B, int(mult), _ptr(ws), _stream(g.device))
+    _t.maxcut_ls_weights(g.handle, xs, int(mult), ws)
     mn, mx = torch.aminmax(ws, dim=0)
     return ws, mx - mn
 
@@ -266,9 +272,8 @@ def maxcut_local_search(g: DeviceGraph, xs: TEN, ws: TEN, rd_std: TEN, obj: TEN,
         _check(noise, "noise", (torch.float32,), g.device)
         if noise.dim() != 3 or noise.shape[0] < need or tuple(noise.shape[1:]) != (B, g.num_nodes):
             raise ValueError(f"noise must be [>= {need}, {B}, {g.num_nodes}]")
-    _abi.call("rls_maxcut_local_search", g.ref, _ptr(xs), B, _ptr(ws), _ptr(rd_std), _ptr(noise),
-              C.c_uint64(seed & (2 ** 64 - 1)), env_offset, num_iters, num_spin, int(bool(first_draw_proposes)),
-              _ptr(obj), int(bool(compute_obj)), _stream(g.device))
+    _t.maxcut_local_search(g.handle, xs, ws, rd_std, noise, _s64(seed), env_offset, num_iters, num_spin,
+                           bool(first_draw_proposes), obj, bool(compute_obj))
 
 
 def select_better_rows(xs0: TEN, vs0: TEN, xs1: TEN, vs1: TEN, if_maximize: bool = True) -> None:
@@ -280,8 +285,7 @@ def select_better_rows(xs0: TEN, vs0: TEN, xs1: TEN, vs1: TEN, if_maximize: bool
     _check(xs1, "xs1", _SPIN_DTYPES, dev, (B, N))
     _check(vs0, "vs0", (torch.int64,), dev, (B,))
     _check(vs1, "vs1", (torch.int64,), dev, (B,))
-    _abi.call("rls_select_better_rows", _ptr(xs0), _ptr(vs0), _ptr(xs1), _ptr(vs1), B, N, int(bool(if_maximize)),
-              _stream(dev))
+    _t.select_better_rows(xs0, vs0, xs1, vs1, bool(if_maximize))
 
 
 def pick_best_of_repeats(xs: TEN, vs: TEN, num_repeats: int, if_maximize: bool = True):
@@ -293,8 +297,7 @@ def pick_best_of_repeats(xs: TEN, vs: TEN, num_repeats: int, if_maximize: bool =
     _check(vs, "vs", (torch.int64,), dev, (xs.shape[0],))
     gx = torch.empty((S, N), dtype=xs.dtype, device=dev)
     gv = torch.empty(S, dtype=torch.int64, device=dev)
-    _abi.call("rls_pick_best_of_repeats", _ptr(xs), _ptr(vs), num_repeats, S, N, int(bool(if_maximize)),
-              _ptr(gx), _ptr(gv), _stream(dev))
+    _t.pick_best_of_repeats(xs, vs, num_repeats, bool(if_maximize), gx, gv)
     return gx, gv
 
 
@@ -303,7 +306,7 @@ def rand_spins(B: int, N: int, seed: int, device, env_offset: int = 0, out: Opti
     if out is None:
         out = torch.empty((B, N), dtype=torch.bool, device=device)
     _check(out, "out", _SPIN_DTYPES, None, (B, N))
-    _abi.call("rls_rand_spins", _ptr(out), B, N, C.c_uint64(seed & (2 ** 64 - 1)), env_offset, _stream(out.device))
+    _t.rand_spins(out, _s64(seed), env_offset)
     return out
 
 
@@ -313,6 +316,5 @@ def rand_actions(B: int, N: int, seed: int, step: int, device, env_offset: int =
     if out is None:
         out = torch.empty(B, dtype=torch.int64, device=device)
     _check(out, "out", (torch.int64,), None, (B,))
-    _abi.call("rls_rand_actions", _ptr(out), B, N, C.c_uint64(seed & (2 ** 64 - 1)), C.c_uint64(step), env_offset,
-              _stream(out.device))
+    _t.rand_actions(out, N, _s64(seed), _s64(step), env_offset)
     return out

@@ -1,20 +1,15 @@
-"""Tensor-level wrappers for the MCPG and TSP entry points (same conventions as ops.py)."""
+"""Tensor-level wrappers for the MCPG and TSP entry points (same conventions as ops.py: outputs allocated here, the work
+goes through ``torch.ops.rlsolver_hip.*``)."""
 from __future__ import annotations
 
-import ctypes as C
 from typing import Optional
 
 import torch
 
-from . import _abi
-from .ops import DeviceGraph, _check, _ptr, _stream
+from .ops import DeviceGraph, _check, _ptr, _s64, _stream, _t  # noqa: F401  (_ptr / _stream: raw C-ABI calls in tests)
 
 TEN = torch.Tensor
 _NM_DTYPES = (torch.float32, torch.uint8, torch.bool)
-
-
-def _u64(v: int) -> C.c_uint64:
-    return C.c_uint64(v & (2 ** 64 - 1))
 
 
 # ------------------------------------------------------------------------------ MCPG
@@ -48,13 +43,13 @@ class PackedChains:
         _check(xs, "xs", _NM_DTYPES)
         N, Cc = xs.shape
         out = cls.empty(N, Cc, xs.device)
-        _abi.call("rls_mcpg_pack_chains", _ptr(xs), 4 if xs.dtype == torch.float32 else 1, N, Cc, _ptr(out.words), _stream(xs.device))
+        _t.mcpg_pack_chains(xs, out.words)
         return out
 
     def unpack(self) -> TEN:
         """-> node-major float32 [N, C] holding 0.0 | 1.0 (the reference's surface)."""
         xs = torch.empty((self.num_nodes, self.num_chains), dtype=torch.float32, device=self.device)
-        _abi.call("rls_mcpg_unpack_chains", _ptr(self.words), self.num_nodes, self.num_chains, _ptr(xs), _stream(self.device))
+        _t.mcpg_unpack_chains(self.words, self.num_chains, xs)
         return xs
 
     def clone(self):
@@ -103,9 +98,7 @@ def mcpg_metro_rounds(samples, probs: TEN, T: int, index: Optional[TEN] = None, 
             raise ValueError("samples_in must have the layout and node count of samples")
         if not write_back:
             raise ValueError("samples_in needs write_back")
-    _abi.call("rls_mcpg_metro_rounds", _ptr(st), _ptr(sin), c_in, sb, N, Cc, _ptr(probs),
-              T, t_offset, _ptr(index), _ptr(u), _u64(seed), _ptr(t_limit), int(bool(write_back)), _ptr(accepts), accept_rows,
-              _stream(dev))
+    _t.mcpg_metro_rounds(st, sin, c_in, Cc, probs, T, t_offset, index, u, _s64(seed), t_limit, bool(write_back), accepts)
 
 
 def mcpg_local_search(g: DeviceGraph, xs_in: TEN, order: TEN, num_ls: int, uniforms: Optional[TEN] = None,
@@ -127,9 +120,7 @@ def mcpg_local_search(g: DeviceGraph, xs_in: TEN, order: TEN, num_ls: int, unifo
         _check(visit_stream, "visit_stream", (torch.int32,), g.device)
     if edge_weights is not None:
         _check(edge_weights, "edge_weights", (torch.int32,), g.device, (g.num_stored_edges,))
-    _abi.call("rls_mcpg_local_search", g.ref, _ptr(xs_in), 4 if xs_in.dtype == torch.float32 else 1, _ptr(xs_out), Cc,
-              _ptr(order), _ptr(visit_stream), 0 if visit_stream is None else visit_stream.numel(), num_ls,
-              _ptr(uniforms), _u64(seed), _ptr(edge_weights), int(gauge_node), _ptr(expected), _stream(g.device))
+    _t.mcpg_local_search(g.handle, xs_in, xs_out, order, visit_stream, num_ls, uniforms, _s64(seed), edge_weights, int(gauge_node), expected)
     return xs_out, expected
 
 
@@ -156,8 +147,7 @@ def mcpg_local_search_levels(g: DeviceGraph, xs_in, lv_ptr: TEN, lv_data: TEN, n
             raise ValueError("out must be a PackedChains of num_chains chains")
         xs_out, ot, osb = out, out.words, 0
     expected = torch.empty(Cc, dtype=torch.float32, device=g.device)
-    _abi.call("rls_mcpg_local_search_levels", g.ref, _ptr(st), sb, c_in, _ptr(ot), osb, Cc, _ptr(lv_ptr), _ptr(lv_data),
-              lv_ptr.numel() - 1, num_ls, _ptr(coins), _u64(seed), _ptr(expected), _stream(g.device))
+    _t.mcpg_local_search_levels(g.handle, st, c_in, ot, Cc, lv_ptr, lv_data, num_ls, coins, _s64(seed), expected)
     return xs_out, expected
 
 
@@ -177,8 +167,7 @@ def mcpg_pick_best(expected: TEN, xs, total_mcmc_num: int, repeat_times: int, nu
         xgt = xg.words
     else:
         xg = xgt = torch.empty((N, total_mcmc_num), dtype=torch.float32, device=dev)
-    _abi.call("rls_mcpg_pick_best", _ptr(expected), _ptr(st), sb, N, total_mcmc_num, repeat_times, num_edges, _ptr(idx),
-              _ptr(vs), _ptr(xgt), _stream(dev))
+    _t.mcpg_pick_best(expected, st, N, total_mcmc_num, repeat_times, num_edges, idx, vs, xgt)
     return idx, vs, xg
 
 
@@ -192,8 +181,7 @@ def mcpg_merge_best(temp_max: TEN, temp_info: PackedChains, now_max_res: TEN, no
     mask = torch.empty((M + 63) // 64, dtype=torch.int64, device=dev)
     bv = torch.empty(1, dtype=torch.float32, device=dev)
     bi = torch.empty(1, dtype=torch.int64, device=dev)
-    _abi.call("rls_mcpg_merge_best", _ptr(temp_max), _ptr(temp_info.words), _ptr(now_max_res), _ptr(now_info.words), N, M,
-              _ptr(mask), _ptr(bv), _ptr(bi), _stream(dev))
+    _t.mcpg_merge_best(temp_max, temp_info.words, now_max_res, now_info.words, M, mask, bv, bi)
     return bv, bi
 
 
@@ -201,8 +189,7 @@ def mcpg_value_bit_sums(samples: PackedChains, value: TEN) -> TEN:
     """A[n] = sum_c value[c] * s[n, c]  (f32 [N]); see rls_mcpg_value_bit_sums."""
     _check(value, "value", (torch.float32,), samples.device, (samples.num_chains,))
     A = torch.zeros(samples.num_nodes, dtype=torch.float32, device=samples.device)
-    _abi.call("rls_mcpg_value_bit_sums", _ptr(samples.words), samples.num_nodes, samples.num_chains, _ptr(value), _ptr(A),
-              _stream(samples.device))
+    _t.mcpg_value_bit_sums(samples.words, samples.num_chains, value, A)
     return A
 
 
@@ -218,7 +205,7 @@ def tsp_tour_length(dist: TEN, perm: TEN) -> TEN:
     B, N = _perm(perm)
     _check(dist, "dist", (torch.float32,), perm.device, (N, N))
     out = torch.empty(B, dtype=torch.float32, device=perm.device)
-    _abi.call("rls_tsp_tour_length", _ptr(dist), N, _ptr(perm), B, _ptr(out), _stream(perm.device))
+    _t.tsp_tour_length(dist, perm, out)
     return out
 
 
@@ -230,8 +217,7 @@ def tsp_swap_delta_all(dist: TEN, perm: TEN, selected: TEN, temperature: float):
     logratio = torch.empty((B, N), dtype=torch.float32, device=dev)
     indices = torch.empty((B, N), dtype=torch.int64, device=dev)
     ban = torch.empty((B, N), dtype=torch.bool, device=dev)
-    _abi.call("rls_tsp_swap_delta_all", _ptr(dist), N, _ptr(perm), B, _ptr(selected), float(temperature),
-              _ptr(logratio), _ptr(indices), _ptr(ban), _stream(dev))
+    _t.tsp_swap_delta_all(dist, perm, selected, float(temperature), logratio, indices, ban)
     return logratio, indices, ban
 
 
@@ -239,7 +225,7 @@ def tsp_apply_swap(perm: TEN, pos: TEN, indices: TEN) -> None:
     B, N = _perm(perm)
     _check(pos, "pos", (torch.int64,), perm.device, (B,))
     _check(indices, "indices", (torch.int64,), perm.device, (B, N))
-    _abi.call("rls_tsp_apply_swap", _ptr(perm), B, N, _ptr(pos), _ptr(indices), _stream(perm.device))
+    _t.tsp_apply_swap(perm, pos, indices)
 
 
 def tsp_2opt_delta(dist: TEN, perm: TEN, i: TEN, j: TEN) -> TEN:
@@ -249,7 +235,7 @@ def tsp_2opt_delta(dist: TEN, perm: TEN, i: TEN, j: TEN) -> TEN:
     _check(i, "i", (torch.int64,), dev, (B,))
     _check(j, "j", (torch.int64,), dev, (B,))
     out = torch.empty(B, dtype=torch.float32, device=dev)
-    _abi.call("rls_tsp_2opt_delta", _ptr(dist), N, _ptr(perm), B, _ptr(i), _ptr(j), _ptr(out), _stream(dev))
+    _t.tsp_2opt_delta(dist, perm, i, j, out)
     return out
 
 
@@ -258,7 +244,7 @@ def rand_perms(B: int, N: int, seed: int, device, env_offset: int = 0) -> TEN:
     if device.type != "cuda":
         raise TypeError("rand_perms needs a HIP device")
     out = torch.empty((B, N), dtype=torch.int64, device=device)
-    _abi.call("rls_rand_perms", _ptr(out), B, N, _u64(seed), env_offset, _stream(device))
+    _t.rand_perms(out, _s64(seed), env_offset)
     return out
 
 
@@ -282,5 +268,5 @@ def tsp_2opt_best(dist64: TEN, perm: TEN, cur_length: Optional[TEN] = None, slic
     bi = torch.empty(slices * B, dtype=torch.int64, device=dev)
     bj = torch.empty(slices * B, dtype=torch.int64, device=dev)
     bv = torch.empty(slices * B, dtype=torch.float64, device=dev)
-    _abi.call("rls_tsp_2opt_best", _ptr(dist64), N, _ptr(perm), B, _ptr(cur_length), slices, _ptr(bi), _ptr(bj), _ptr(bv), _stream(dev))
+    _t.tsp_2opt_best(dist64, perm, cur_length, bi, bj, bv)
     return bi[:B], bj[:B], bv[:B]

@@ -10,8 +10,10 @@ from the dispatcher.
 The shared graph (and the spin-system env) travel as integer handles -- ``graph_handle(g)`` is the address of the
 host-side ``struct rls_graph`` that the DeviceGraph keeps alive.
 
-``ops.py`` / ``ops_mcpg_tsp.py`` bind the same C ABI through ctypes; the launch-bound paths (the gym step) call these
-ops instead: a dispatcher call costs about a third of a ctypes call with twelve converted arguments.
+These ops are the ONE host path of the package: ``ops.py`` / ``ops_mcpg_tsp.py``, ``envs/`` and ``methods/`` allocate
+outputs and call them; ctypes (``_abi.py``) is kept for the host-side schedule builders and queries, and for the tests
+that pin the ops against raw C-ABI calls.  A dispatcher call costs about a third of a ctypes call with twelve converted
+arguments.
 """
 from __future__ import annotations
 
@@ -30,7 +32,21 @@ if not os.path.exists(OPS_PATH):
                       "(run `python -m rlsolver_amd.build`); rlsolver_amd has no fallback for it")
 _abi.lib()                                   # librlsolver_hip.so first (the ops library links against it by rpath)
 torch.ops.load_library(OPS_PATH)
-ops = torch.ops.rlsolver_hip
+
+
+class _CallRecorder:
+    """Test hook (RLS_RECORD_OPS=1, set by tests/conftest.py): remembers which ops the process has asked for, so that the
+    GPU suite can assert that every device entry point was executed (tests/test_gpu_zz_op_coverage.py)."""
+
+    def __init__(self, ns):
+        self._ns, self.called = ns, set()
+
+    def __getattr__(self, name):
+        self.called.add(name)
+        return getattr(self._ns, name)
+
+
+ops = _CallRecorder(torch.ops.rlsolver_hip) if os.environ.get("RLS_RECORD_OPS") == "1" else torch.ops.rlsolver_hip
 
 # C-ABI device entry point -> op name (tests/test_abi.py checks this list against the header)
 DEVICE_ENTRY_POINTS = [

@@ -1,6 +1,8 @@
 import os
 import sys
 
+os.environ.setdefault("RLS_RECORD_OPS", "1")     # rlsolver_amd.torch_ops records which ops ran (test_gpu_zz_op_coverage.py)
+
 import numpy as np
 import pytest
 
@@ -40,6 +42,9 @@ def _has_gpu():
 
 
 def pytest_collection_modifyitems(config, items):
+    # the op-coverage check looks back at everything the session ran: keep it last
+    items.sort(key=lambda it: "test_gpu_zz_op_coverage" in it.nodeid)
+    config._rls_gpu_files_collected = {it.nodeid.split("::")[0] for it in items if "gpu" in it.keywords}
     # gpu-marked tests are skipped (not failed) where no GPU is visible, so `pytest tests/`
     # without -m still works in the CPU container
     if _has_gpu():

@@ -85,6 +85,13 @@ def test_local_search_class_golden(golden, gname):
         lsb.random_search(num_iters=1, num_spin=4)
     xs = ls.reset_search(4)
     assert xs.shape == (4, env.num_nodes) and xs.dtype == torch.bool
+    # chunked repeats (memory bound): a budget of one repeat at a time still returns num_sims incumbents, each at least
+    # as good as a lone random row would be on average (best of 16 draws)
+    ls.RESET_SEARCH_MAX_BYTES = 1
+    torch.manual_seed(0)
+    xs16 = ls.reset_search(16)
+    assert xs16.shape == (16, env.num_nodes)
+    assert float(env.calculate_obj_values(xs16).float().mean()) > float(env.calculate_obj_values(env.generate_xs_randomly(256)).float().mean())
 
 
 @pytest.mark.parametrize("gname", ["BA_100_ID0", "gset_14_stub"])
@@ -198,3 +205,26 @@ def test_evaluator_tracks_best_on_device(tmp_path):
             assert "best" in ev.logging_print(show_str="x", if_show_x=flag)
             ev.save_record_draw_plot()
             assert (tmp_path / f"{maximize}{dtype}" / "recorder2.npy").exists()
+
+
+@pytest.mark.parametrize("maximize", [True, False])
+@pytest.mark.parametrize("vdt", ["int64", "float32"])
+def test_evaluator_golden(golden, tmp_path, maximize, vdt):
+    """evaluator.npz: the reference's Evaluator (util_evaluator.py:66-107) on a seeded stream of batches and single
+    solutions.  The device tracker (rls_best_update) returns the same if_update, holds the same incumbent after every
+    call, and its logs read back as the reference's recorder1 / recorder2."""
+    from rlsolver_amd.methods.util_evaluator import Evaluator
+    from tests.test_oracle_golden import _evaluator_stream
+    z = golden("evaluator")
+    tag = f"max{int(maximize)}/{vdt}"
+    n = int(z[f"{tag}/num_bits"])
+    ev = Evaluator(str(tmp_path / "ev"), n, to_dev_bool(z[f"{tag}/x0"]), float(z[f"{tag}/v0"]), maximize)
+    for it, xs, vs, single, upd, best_v, best_x in _evaluator_stream(z, tag):
+        ev.record1(i=it, v=float(vs.max()))
+        dx, dv = torch.from_numpy(xs).to(DEV), torch.from_numpy(vs).to(DEV)
+        got = ev.record2(it, dv[0] if single else dv, dx[0] if single else dx)
+        assert bool(got) is upd, (tag, it)
+        assert ev.best_v == best_v and np.array_equal(ev.best_x.cpu().numpy(), best_x), (tag, it)
+    assert np.array_equal(np.asarray([(r[0], r[1]) for r in ev.recorder2], dtype=np.float64), z[f"{tag}/recorder2_i_v"])
+    assert np.array_equal(np.asarray(ev.recorder1, dtype=np.float64), z[f"{tag}/recorder1"])
+    assert ev.first_v == float(z[f"{tag}/first_v"]) and ev.best_x_str == str(z[f"{tag}/best_x_str"])

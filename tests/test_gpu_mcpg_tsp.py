@@ -540,3 +540,43 @@ def test_merge_best_mask_scratch_is_exactly_ceil_M_over_64_words(M):
     assert arena[tiles:].eq(CANARY).all(), "a word behind mask_scratch was written"
     assert np.array_equal(d_res.cpu().numpy(), w_res) and np.array_equal(d_info.unpack().cpu().numpy(), w_info)
     assert np.array_equal(d_temp.unpack().cpu().numpy(), w_temp) and float(bv) == float(w_max) and int(bi) == w_idx
+
+
+@pytest.mark.parametrize("gname", ["BA_100_ID0", "PL_20_ID0"])
+def test_mcpg_glue_golden_three_rounds(golden, gname):
+    """mcpg_glue.npz: three consecutive rounds of the reference's outer loop (metro_sampling -> sampler_func -> the
+    best-merge of MCPG.py:376-391, exec'd from the reference file -> get_return with its autograd gradient).  The HIP
+    path -- metro walk, level sampler, rls_mcpg_merge_best on bit-packed chains, rls_mcpg_value_bit_sums -- reproduces
+    every recorded state bit for bit (get_return: within f32 summation noise of the reference's f32 loop)."""
+    from rlsolver_amd.ops_mcpg_tsp import PackedChains
+    z = golden("mcpg_glue")
+    graph = z[f"{gname}/graph"]
+    n = int(graph[:, :2].max()) + 1
+    ei = graph[:, :2].T.copy()
+    M, R, num_ls, T = (int(z[f"{gname}/{k}"]) for k in ("M", "R", "num_ls", "T"))
+    data = amcpg.make_data(n, ei[0], ei[1], DEV, sorted_degree_nodes=z[f"{gname}/sorted_degree_nodes"])
+    probs = dev(z[f"{gname}/probs"])
+    for rnd in range(3):
+        t = f"{gname}/round{rnd}"
+        xs = amcpg.metro_sampling(probs, dev(z[f"{t}/start"], torch.float32), T, device=DEV, index=dev(z[f"{t}/metro_index"]),
+                                  u=dev(z[f"{t}/metro_u"]))
+        assert np.array_equal(xs.cpu().numpy().astype(np.uint8), z[f"{t}/xs_sample"])
+        temp_max, temp_info, value = amcpg.sampler_func(data, xs, num_ls, M, R, DEV, uniforms=dev(z[f"{t}/uniforms"]))
+        assert np.array_equal(temp_max.cpu().numpy(), z[f"{t}/temp_max"])
+        assert np.array_equal(temp_info.cpu().numpy(), z[f"{t}/temp_max_info"])
+        np.testing.assert_allclose(value.cpu().numpy(), z[f"{t}/value"], rtol=0, atol=1e-4)
+        # best-merge on the device, bit-packed
+        d_res = dev(z[f"{t}/now_max_res_before"])
+        d_info = PackedChains.pack(dev(z[f"{t}/now_max_info_before"]))
+        d_temp = PackedChains.pack(temp_info.contiguous())
+        bv, bi = mops.mcpg_merge_best(temp_max.contiguous(), d_temp, d_res, d_info)
+        assert np.array_equal(d_res.cpu().numpy(), z[f"{t}/now_max_res_after"])
+        assert np.array_equal(d_info.unpack().cpu().numpy(), z[f"{t}/now_max_info_after"])
+        assert np.array_equal(d_temp.unpack().cpu().numpy(), z[f"{t}/temp_max_info_after"])
+        assert float(bv) == float(z[f"{t}/now_max"]) and int(bi) == int(z[f"{t}/now_max_index"])
+        # get_return: value and gradient as autograd gives them in the reference (f32 there)
+        pl = probs.clone().requires_grad_(True)
+        obj = amcpg.get_return(pl, xs.t().contiguous(), dev(z[f"{t}/value"]), M, R)
+        obj.backward()
+        np.testing.assert_allclose(float(obj.detach()), float(z[f"{t}/get_return"]), rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(pl.grad.cpu().numpy(), z[f"{t}/get_return_grad"], rtol=1e-4, atol=1e-4)

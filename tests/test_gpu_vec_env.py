@@ -31,28 +31,38 @@ def test_vec_env_contract():
     assert np.array_equal(state.cpu().numpy(), ref.xs)
 
 
-def test_torch_ops_native_and_equal_to_ctypes_path():
-    """torch.ops.rlsolver_hip.* (C++ ops over the C ABI) give what the ctypes wrappers give, honour torch's current
-    stream, and the gym env's step goes through the native op."""
-    from rlsolver_amd import ops, ops_mcpg_tsp as mops, torch_ops
+def test_torch_ops_equal_raw_c_abi_calls_and_check_shapes():
+    """torch.ops.rlsolver_hip.* (C++ ops over the C ABI: the package's one host path) give what RAW ctypes calls of the
+    same C-ABI functions give, honour torch's current stream, and turn wrongly shaped / placed arguments into errors
+    instead of device out-of-bounds accesses."""
+    import ctypes as C
+    from rlsolver_amd import _abi, ops, ops_mcpg_tsp as mops, torch_ops
     from rlsolver_amd.graph import build_csr, generate_gnm, generate_tsp_coords, tsp_tables
     R = torch.ops.rlsolver_hip
+    P = lambda t: C.c_void_p(t.data_ptr())
+    S = lambda: C.c_void_p(torch.cuda.current_stream(DEV).cuda_stream)
     n, B = 256, 130
     g = ops.DeviceGraph(build_csr(generate_gnm(n, 1200, 5), num_nodes=n), DEV)
     h = torch_ops.graph_handle(g)
+    assert h == g.handle
     xs = ops.rand_spins(B, n, 3, DEV)
-    obj = torch.empty(B, dtype=torch.int64, device=DEV)
+    x_raw = torch.empty_like(xs)
+    _abi.call("rls_rand_spins", P(x_raw), B, n, C.c_uint64(3), 0, S())
+    assert torch.equal(xs, x_raw)
+    obj, obj_raw = torch.empty(B, dtype=torch.int64, device=DEV), torch.empty(B, dtype=torch.int64, device=DEV)
     R.maxcut_obj(h, xs, obj)
-    assert torch.equal(obj, ops.maxcut_obj(g, xs))
-    d = torch.empty((B, n), dtype=torch.int32, device=DEV)
+    _abi.call("rls_maxcut_obj", g.ref, P(xs), 1, B, P(obj_raw), S())
+    assert torch.equal(obj, obj_raw) and torch.equal(obj, ops.maxcut_obj(g, xs))
+    d, d_raw = torch.empty((B, n), dtype=torch.int32, device=DEV), torch.empty((B, n), dtype=torch.int32, device=DEV)
     R.maxcut_delta_all(h, xs, d)
-    assert torch.equal(d, ops.maxcut_delta_all(g, xs))
-    x2, v2 = xs.clone(), ops.maxcut_obj(g, xs)
-    x3, v3 = xs.clone(), v2.clone()
+    _abi.call("rls_maxcut_delta_all", g.ref, P(xs), B, P(d_raw), S())
+    assert torch.equal(d, d_raw)
+    x2, v2 = xs.clone(), obj.clone()
+    x3, v3 = xs.clone(), obj.clone()
     R.maxcut_greedy_sweep(h, x2, v2)
-    ops.maxcut_greedy_sweep(g, x3, v3)
+    _abi.call("rls_maxcut_greedy_sweep", g.ref, P(x3), B, P(v3), S())
     assert torch.equal(x2, x3) and torch.equal(v2, v3)
-    # K4 through the op == through ctypes, on a side stream
+    # K4 through the op on a side stream == the raw call on the current one
     act = ops.rand_actions(B, n, 1, 0, DEV)
     o1, o2 = obj.to(torch.int32), obj.to(torch.int32)
     r1, r2 = torch.empty(B, device=DEV), torch.empty(B, device=DEV)
@@ -62,23 +72,41 @@ def test_torch_ops_native_and_equal_to_ctypes_path():
     with torch.cuda.stream(side):
         R.maxcut_step(h, xs, y1, act, o1, r1, None, None, 0.0)
     side.synchronize()
-    ops.maxcut_step(g, xs, y2, act, o2, r2)
+    _abi.call("rls_maxcut_step", g.ref, P(xs), P(y2), 1, B, P(act), P(o2), P(r2), None, None, 0.0, S())
     assert torch.equal(y1, y2) and torch.equal(o1, o2) and torch.equal(r1, r2)
-    # a TSP op and a random op
+    # a TSP op and a random op; a seed with the top bit set survives the int64 schema
     dist, near, rnd = tsp_tables(generate_tsp_coords(40, 1), K=5)
-    perms = mops.rand_perms(64, 40, 9, DEV)
+    big = (1 << 63) + 12345
+    perms = mops.rand_perms(64, 40, big, DEV)
     p2 = torch.empty_like(perms)
-    R.rand_perms(p2, 9, 0)
+    _abi.call("rls_rand_perms", P(p2), 64, 40, C.c_uint64(big), 0, S())
     assert torch.equal(perms, p2)
-    length = torch.empty(64, device=DEV)
-    R.tsp_tour_length(torch.from_numpy(dist).to(DEV), perms, length)
-    assert torch.equal(length, mops.tsp_tour_length(torch.from_numpy(dist).to(DEV), perms))
+    dd = torch.from_numpy(dist).to(DEV)
+    length, l_raw = torch.empty(64, device=DEV), torch.empty(64, device=DEV)
+    R.tsp_tour_length(dd, perms, length)
+    _abi.call("rls_tsp_tour_length", P(dd), 40, P(perms), 64, P(l_raw), S())
+    assert torch.equal(length, l_raw)
     with pytest.raises(NotImplementedError):
         R.maxcut_obj(h, xs.cpu(), obj.cpu())                       # no CPU kernel registered
     with pytest.raises(RuntimeError):
         R.maxcut_obj(h, xs.float().double(), obj)                  # dtype checked in the op
     with pytest.raises(RuntimeError):
         R.maxcut_obj(0, xs, obj)                                   # null graph handle
+    # shapes are checked against the graph handle and against each other (no device out-of-bounds access)
+    with pytest.raises(RuntimeError, match="must be \\[B, 256\\]"):
+        R.maxcut_obj(h, xs[:, :200].contiguous(), obj)
+    with pytest.raises(RuntimeError, match="obj must hold 130"):
+        R.maxcut_obj(h, xs, obj[:100])
+    with pytest.raises(RuntimeError, match="out must be"):
+        R.maxcut_delta_all(h, xs, d[:, :100].contiguous())
+    with pytest.raises(RuntimeError, match="action must hold"):
+        R.maxcut_step(h, xs, y1, act[:5], o1, r1, None, None, 0.0)
+    with pytest.raises(RuntimeError, match="dist must be"):
+        R.tsp_tour_length(dd[:30, :30].contiguous(), perms, length)
+    with pytest.raises(RuntimeError, match="mask_scratch must hold at least"):
+        R.mcpg_merge_best(torch.zeros(128, device=DEV), torch.zeros((2, 50), dtype=torch.int64, device=DEV),
+                          torch.zeros(128, device=DEV), torch.zeros((2, 50), dtype=torch.int64, device=DEV), 128,
+                          torch.zeros(1, dtype=torch.int64, device=DEV), None, None)
     import types
     from rlsolver_amd.envs.env_PPO import EnvMaxcut as Gym
     env = Gym(types.SimpleNamespace(num_nodes=n, num_envs=B, num_steps=3), mygraph=generate_gnm(n, 1200, 5), device=DEV)

@@ -215,3 +215,30 @@ def test_streaming_reader_matches_line_reader_and_scales(tmp_path):
     dt = time.time() - t0
     assert n == N and eu.shape == (E,) and np.array_equal(eu, a[:, 0] - 1) and np.array_equal(ev, a[:, 1] - 1)
     assert set(np.unique(w)) == {-1, 1} and dt < 30
+
+
+def test_read_edge_arrays_validates_rows_ids_and_count(tmp_path):
+    """Rows with and without a weight mixed parse line by line (as the reference's reader does), never as a reshaped token
+    soup; node ids outside [1, n] raise; an edge count that contradicts the header warns."""
+    from rlsolver_amd.graph import read_edge_arrays
+    p = tmp_path / "mixed.txt"
+    p.write_text("4 4\n1 2 5\n2 3\n3 4\n1 4\n")                 # 9 tokens: used to become 3 bogus weighted rows
+    n, eu, ev, w = read_edge_arrays(str(p))
+    assert n == 4 and eu.tolist() == [0, 1, 2, 0] and ev.tolist() == [1, 2, 3, 3] and w.tolist() == [5, 1, 1, 1]
+    q = tmp_path / "blank.txt"
+    q.write_text("3 2\n\n1 2 7\n\n2 3 9\n")
+    n, eu, ev, w = read_edge_arrays(str(q))
+    assert (n, eu.tolist(), ev.tolist(), w.tolist()) == (3, [0, 1], [1, 2], [7, 9])
+    for body in ("3 1\n0 2\n", "3 1\n1 4\n", "3 2\n1 2\n5 1 1\n"):
+        r = tmp_path / "bad.txt"
+        r.write_text(body)
+        with pytest.raises(ValueError, match="outside"):
+            read_edge_arrays(str(r))
+    r = tmp_path / "bad4.txt"
+    r.write_text("3 1\n1 2 3 4\n")
+    with pytest.raises(ValueError):
+        read_edge_arrays(str(r))
+    s = tmp_path / "short.txt"
+    s.write_text("3 5\n1 2\n2 3\n")
+    with pytest.warns(UserWarning, match="announces 5 edges"):
+        read_edge_arrays(str(s))

@@ -331,3 +331,61 @@ def test_tsp_2opt_local_search_oracle_vs_reference(golden):
             for rs in ((2,) if len(tour) > 40 else (-1, 2)):
                 r, dist = onp.tsp_local_search_2_opt(d, tour, sd, rs)
                 assert r == z[f"{name}/t{t}/rs{rs}/tour"].tolist() and dist == float(z[f"{name}/t{t}/rs{rs}/distance"])
+
+
+@pytest.mark.parametrize("gname", ["BA_100_ID0", "PL_20_ID0"])
+def test_mcpg_glue_merge_and_get_return(golden, gname):
+    """mcpg_glue.npz: three rounds of the reference's metro_sampling -> sampler_func -> best-merge (MCPG.py:376-391,
+    exec'd from the reference file) -> get_return (:292-302, value and autograd gradient).  The restatements reproduce
+    every recorded array; merge and sampler outputs bit for bit."""
+    z = golden("mcpg_glue")
+    assert z["merge/reference_lines"].tolist() == [375, 391]     # "# update now_max" .. the temp_max_info re-seed
+    graph = z[f"{gname}/graph"]
+    n = int(graph[:, :2].max()) + 1
+    ei = graph[:, :2].T.copy()
+    M, R, num_ls, T = (int(z[f"{gname}/{k}"]) for k in ("M", "R", "num_ls", "T"))
+    order = z[f"{gname}/sorted_degree_nodes"]
+    probs = z[f"{gname}/probs"]
+    for rnd in range(3):
+        t = f"{gname}/round{rnd}"
+        if rnd:   # the next round starts from the re-seeded kept chains, repeated (MCPG.py:393-394)
+            assert np.array_equal(z[f"{t}/start"], np.tile(z[f"{gname}/round{rnd - 1}/temp_max_info_after"], (1, R)).astype(np.uint8))
+        xs, _ = onp.metro_sampling(probs, z[f"{t}/start"], T, z[f"{t}/metro_index"], z[f"{t}/metro_u"])
+        assert np.array_equal(xs.astype(np.uint8), z[f"{t}/xs_sample"])
+        vs_good, xs_good, value, _, _ = onp.sampler_func(ei, n, order, z[f"{t}/xs_sample"], num_ls, M, R, z[f"{t}/uniforms"])
+        assert np.array_equal(vs_good, z[f"{t}/temp_max"]) and np.array_equal(xs_good, z[f"{t}/temp_max_info"])
+        np.testing.assert_allclose(value, z[f"{t}/value"], rtol=0, atol=1e-4)
+        res, info, temp, now_max, idx = onp.mcpg_merge_best(z[f"{t}/temp_max"], z[f"{t}/temp_max_info"],
+                                                            z[f"{t}/now_max_res_before"], z[f"{t}/now_max_info_before"])
+        assert np.array_equal(res, z[f"{t}/now_max_res_after"]) and np.array_equal(info, z[f"{t}/now_max_info_after"])
+        assert np.array_equal(temp, z[f"{t}/temp_max_info_after"])
+        assert float(now_max) == float(z[f"{t}/now_max"]) and idx == int(z[f"{t}/now_max_index"])
+        obj, grad = onp.mcpg_get_return(probs, z[f"{t}/xs_sample"].T.astype(np.float32), z[f"{t}/value"], M, R)
+        np.testing.assert_allclose(obj, float(z[f"{t}/get_return"]), rtol=1e-5, atol=1e-5)    # the reference sums in f32; value has mean ~0
+        np.testing.assert_allclose(grad, z[f"{t}/get_return_grad"], rtol=1e-4, atol=1e-4)
+
+
+def _evaluator_stream(z, tag):
+    n = int(z[f"{tag}/num_bits"])
+    xs_all = np.unpackbits(z[f"{tag}/xs_packed"], axis=1)[:, :n].astype(bool)
+    best_x = np.unpackbits(z[f"{tag}/best_x_packed"], axis=1)[:, :n].astype(bool)
+    off = 0
+    for k, cnt in enumerate(z[f"{tag}/counts"].tolist()):
+        yield k + 1, xs_all[off:off + cnt], z[f"{tag}/vs"][off:off + cnt], bool(z[f"{tag}/single"][k]), \
+            bool(z[f"{tag}/if_update"][k]), float(z[f"{tag}/best_v"][k]), best_x[k]
+        off += cnt
+
+
+@pytest.mark.parametrize("maximize", [True, False])
+@pytest.mark.parametrize("vdt", ["int64", "float32"])
+def test_evaluator_oracle(golden, maximize, vdt):
+    z = golden("evaluator")
+    tag = f"max{int(maximize)}/{vdt}"
+    ev = onp.EvaluatorOracle(z[f"{tag}/x0"].astype(bool), float(z[f"{tag}/v0"]), maximize)
+    for it, xs, vs, single, upd, best_v, best_x in _evaluator_stream(z, tag):
+        ev.record1(it, float(vs.max()))
+        got = ev.record2(it, vs[0] if single else vs, xs[0] if single else xs)
+        assert bool(got) is upd and ev.best_v == best_v and np.array_equal(ev.best_x, best_x), (tag, it)
+    assert np.array_equal(np.asarray(ev.recorder2, dtype=np.float64), z[f"{tag}/recorder2_i_v"])
+    assert np.array_equal(np.asarray(ev.recorder1, dtype=np.float64), z[f"{tag}/recorder1"])
+    assert ev.first_v == float(z[f"{tag}/first_v"])

@@ -330,6 +330,133 @@ def gen_mcpg():
     save("mcpg", **out)
 
 
+def _reference_block(path, first_marker, last_marker):
+    """The statements of a reference function between two marker lines (inclusive), dedented -- read from the mounted
+    reference at generation time and exec'd on recorded inputs; the text itself is never written anywhere."""
+    import textwrap
+    lines = open(path).read().splitlines()
+    i0 = next(i for i, ln in enumerate(lines) if first_marker in ln)
+    i1 = next(i for i, ln in enumerate(lines) if i >= i0 and last_marker in ln)
+    return i0 + 1, i1 + 1, textwrap.dedent("\n".join(lines[i0:i1 + 1]))
+
+
+def gen_mcpg_glue():
+    """The outer-loop glue of mcpg(), rlsolver/methods/MCPG.py: (a) get_return (:292-302) -- objective AND the gradient
+    autograd gives probs -- for two (total_mcmc_num, repeat_times) on BA_100_ID0; (b) the best-merge block (:376-391:
+    per-chain keep-better loop, then the best incumbent overwrites the worst and re-seeds its chain) over three rounds of
+    the reference's own metro_sampling -> sampler_func on BA_100_ID0 and PL_20_ID0, every round's inputs and outputs
+    recorded.  The merge statements are exec'd from the reference file itself (located by their first / last line), on
+    the tensors its own sampler returned."""
+    m = load_mcpg_module()
+    from rlsolver.methods.util_read_data import read_mygraph
+    out = {}
+    dev = th.device("cpu")
+    ref_file = os.path.join(REF, "rlsolver", "methods", "MCPG.py")
+    l0, l1, block = _reference_block(ref_file, "# update now_max", "temp_max_info[:, now_min_index] = now_max_info[:, now_max_index]")
+    out["merge/reference_lines"] = np.array([l0, l1], dtype=np.int64)
+    code = compile(block, f"{ref_file}:{l0}-{l1}", "exec")
+    for gname, (M, R) in (("BA_100_ID0", (8, 4)), ("PL_20_ID0", (5, 3))):
+        path = os.path.join(DATA, GRAPHS[gname])
+        out[f"{gname}/graph"] = graph_arrays(read_mygraph(path))
+        data, num_nodes = m.maxcut_dataloader(path, device=dev)
+        out[f"{gname}/sorted_degree_nodes"] = data.sorted_degree_nodes.numpy().copy()
+        C = M * R
+        num_ls = 2
+        g = th.Generator().manual_seed(31)
+        probs = th.rand(num_nodes, generator=g) * 0.6 + 0.2
+        T = max(1, num_nodes // 10)
+        # incumbents: random chains and their cuts (the reference starts from LocalSearch results; any start is valid input)
+        now_max_info = th.randint(0, 2, (num_nodes, M), generator=g).float()
+        ei = data.edge_index
+        now_max_res = ((now_max_info[ei[0]] != now_max_info[ei[1]]).float().sum(dim=0))
+        xs_bool = now_max_info.repeat(1, R)
+        out[f"{gname}/M"], out[f"{gname}/R"], out[f"{gname}/num_ls"], out[f"{gname}/T"] = (np.int64(M), np.int64(R), np.int64(num_ls),
+                                                                                       np.int64(T))
+        out[f"{gname}/probs"] = probs.numpy().copy()
+        th.manual_seed(500 + M)
+        cfg = types.SimpleNamespace(total_mcmc_num=M, repeat_times=R)
+        for rnd in range(3):
+            with Recorder("rand", "randint") as rec:
+                xs_sample = m.metro_sampling(probs, xs_bool.clone(), T, device=dev)
+            nm = len(rec.log["randint"])
+            t = f"{gname}/round{rnd}"
+            out[f"{t}/start"] = u8(xs_bool)
+            out[f"{t}/metro_index"] = th.stack(rec.log["randint"]).numpy().copy()
+            out[f"{t}/metro_u"] = th.stack(rec.log["rand"][:nm]).numpy().copy()
+            out[f"{t}/xs_sample"] = u8(xs_sample)
+            with Recorder("rand") as rec:
+                temp_max, temp_max_info, value = m.sampler_func(data, xs_sample, num_ls, M, R, device=dev)
+            out[f"{t}/uniforms"] = th.stack(rec.log["rand"]).numpy().copy().reshape(num_ls, num_nodes, C)
+            out[f"{t}/temp_max"] = temp_max.numpy().copy()
+            out[f"{t}/temp_max_info"] = temp_max_info.numpy().copy()
+            out[f"{t}/value"] = value.numpy().copy()
+            out[f"{t}/now_max_res_before"] = now_max_res.numpy().copy()
+            out[f"{t}/now_max_info_before"] = now_max_info.numpy().copy()
+            ns = {"Config": cfg, "torch": th, "temp_max": temp_max, "temp_max_info": temp_max_info, "now_max_res": now_max_res,
+                  "now_max_info": now_max_info, "objs_each_epoch": [], "xs_each_epoch": [], "max": max}
+            exec(code, ns)                                  # MCPG.py:376-391 as written there
+            out[f"{t}/now_max_res_after"] = now_max_res.numpy().copy()
+            out[f"{t}/now_max_info_after"] = now_max_info.numpy().copy()
+            out[f"{t}/temp_max_info_after"] = temp_max_info.numpy().copy()
+            out[f"{t}/now_max"] = np.float64(ns["now_max"])
+            out[f"{t}/now_max_index"] = np.int64(int(ns["now_max_index"]))
+            out[f"{t}/now_min_index"] = np.int64(int(ns["now_min_index"]))
+            xs_bool = temp_max_info.clone().repeat(1, R)                    # :393-394
+            # (a) get_return on this round's samples, value and a probs leaf
+            pl = probs.clone().requires_grad_(True)
+            obj = m.get_return(pl, xs_sample.t(), value, M, R)
+            obj.backward()
+            out[f"{t}/get_return"] = np.float64(obj.item())
+            out[f"{t}/get_return_f32"] = obj.detach().numpy().copy()
+            out[f"{t}/get_return_grad"] = pl.grad.numpy().copy()
+    save("mcpg_glue", **out)
+
+
+def gen_evaluator():
+    """Evaluator.record1 / record2 (rlsolver/methods/util_evaluator.py:66-107) on a seeded stream of batches: the
+    constructor's first record, per call the returned if_update, best_v and best_x afterwards, recorder2's values -- both
+    directions, int64 and float32 values (ties included: small value range), batch and single-solution forms."""
+    import tempfile
+    from rlsolver.methods.util_evaluator import Evaluator
+    out = {}
+    N = 45
+    for maximize in (True, False):
+        for vdt in ("int64", "float32"):
+            tag = f"max{int(maximize)}/{vdt}"
+            rng = np.random.RandomState(17 + int(maximize))
+            x0 = th.from_numpy(rng.randint(0, 2, N).astype(bool))
+            v0 = 20.0
+            with tempfile.TemporaryDirectory() as d:
+                ev = Evaluator(save_dir=d, num_bits=N, x=x0, v=v0, if_maximize=maximize)
+                out[f"{tag}/x0"], out[f"{tag}/v0"] = u8(x0), np.float64(v0)
+                steps = 30
+                xs_all, vs_all, counts, singles, upds, best_vs, best_xs = [], [], [], [], [], [], []
+                for it in range(1, steps + 1):
+                    single = it % 7 == 0
+                    B = 1 if single else int(rng.randint(1, 40))
+                    xs = th.from_numpy(rng.randint(0, 2, (B, N)).astype(bool))
+                    vs = th.from_numpy(rng.randint(10, 32, B)).to(getattr(th, vdt))
+                    ev.record1(i=it, v=float(vs.max()))
+                    upd = ev.record2(i=it, vs=(vs[0] if single else vs), xs=(xs[0] if single else xs))
+                    xs_all.append(u8(xs)); vs_all.append(vs.numpy().copy()); counts.append(B); singles.append(single)
+                    upds.append(bool(upd)); best_vs.append(float(ev.best_v)); best_xs.append(u8(ev.best_x))
+                # batches concatenated (step k = rows counts[:k].sum() .. + counts[k]); spins bit-packed along N
+                out[f"{tag}/xs_packed"] = np.packbits(np.concatenate(xs_all), axis=1)
+                out[f"{tag}/vs"] = np.concatenate(vs_all)
+                out[f"{tag}/counts"] = np.asarray(counts, dtype=np.int64)
+                out[f"{tag}/single"] = np.asarray(singles, dtype=np.bool_)
+                out[f"{tag}/if_update"] = np.asarray(upds, dtype=np.bool_)
+                out[f"{tag}/best_v"] = np.asarray(best_vs, dtype=np.float64)
+                out[f"{tag}/best_x_packed"] = np.packbits(np.stack(best_xs), axis=1)
+                out[f"{tag}/num_bits"] = np.int64(N)
+                out[f"{tag}/recorder1"] = np.asarray(ev.recorder1, dtype=np.float64)
+                out[f"{tag}/recorder2_i_v"] = np.asarray([(r[0], r[1]) for r in ev.recorder2], dtype=np.float64)
+                out[f"{tag}/first_v"] = np.float64(ev.first_v)
+                out[f"{tag}/best_x_str"] = np.array(ev.best_x_str)
+    save("evaluator", **out)
+
+
+
 # ----------------------------------------------------------------------------- TSP
 def gen_tsp():
     import rlsolver.envs.env_ISCO as env_isco
@@ -983,7 +1110,7 @@ def gen_isco_steps():
 
 ALL = {"mcpg_weighted": gen_mcpg_weighted, "isco_steps": gen_isco_steps, "spinsystem_cpu": gen_spinsystem_cpu, "spinsystem": gen_spinsystem, "spinsystem_perenv": gen_spinsystem_perenv, "qubo": gen_qubo, "isco_maxcut": gen_isco_maxcut, "maxcut": gen_maxcut, "sweep": gen_sweep, "lsclass": gen_local_search_class, "ppo": gen_ppo,
        "select": gen_select, "mcpg": gen_mcpg, "tsp": gen_tsp, "tsp_2opt": gen_tsp_2opt, "encoder": gen_encoder,
-       "wgain": gen_weighted_gain}
+       "wgain": gen_weighted_gain, "mcpg_glue": gen_mcpg_glue, "evaluator": gen_evaluator}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
