@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RLS_ABI_VERSION 6
+#define RLS_ABI_VERSION 7
 
 enum {
     RLS_OK = 0,
@@ -186,12 +186,18 @@ int rls_maxcut_greedy_sweep(const rls_graph* g, uint8_t* x, int64_t B,
 int rls_maxcut_propose_accept(const rls_graph* g, uint8_t* x, int64_t B, const uint8_t* mask,
                               int64_t* obj, void* stream);
 
-/* Pre-pass of the fused local search  envs/env_L2A.py:90-92 (methods/LocalSearch.py:64):
- *   ws[b,i] = n0_num_n1[i] - mult * cutdeg[b,i]   (stored adjacency; int32 [B,N], exact)
+/* Pre-pass of the fused local search  envs/env_L2A.py:90-94 (methods/LocalSearch.py:64-65):
+ *   ws[b,i] = n0_num_n1[i] - mult * cutdeg[b,i]   (stored adjacency; exact)
+ *   ws_minmax[0][i] = min_b ws[b,i],  ws_minmax[1][i] = max_b ws[b,i]   (int32 [2][N], or NULL: not wanted)
  * mult = 1 for local_search_inplace in both env flavours (bidirectional: 2 * (cutdeg / 2)),
- * 2 for LocalSearch.random_search on a unidirectional env.  (ws_std = max_b ws - min_b ws is a
- * whole-batch statistic: one aminmax pass over ws by the caller.) */
-int rls_maxcut_ls_weights(const rls_graph* g, const uint8_t* x, int64_t B, int32_t mult, int32_t* ws, void* stream);
+ * 2 for LocalSearch.random_search on a unidirectional env.  ws is ws_bytes = 1 | 2 | 4 bytes per entry (int8 /
+ * int16 / int32 [B,N]): |ws| <= max(1, mult - 1) * max degree, and the fused kernel re-reads ws once per proposal
+ * round, so the narrowest type that holds the graph's degrees is what keeps that kernel off the HBM roofline
+ * (RLS_EINVAL when the range does not fit).  The reference's ws_std = max - min over the batch (:93) is
+ * ws_minmax[1] - ws_minmax[0]: the tiles fold their extremes in with atomics that fire only where they improve the
+ * table (the table is initialised here, also when B = 0). */
+int rls_maxcut_ls_weights(const rls_graph* g, const uint8_t* x, int64_t B, int32_t mult, void* ws, int32_t ws_bytes,
+                          int32_t* ws_minmax, void* stream);
 
 /* K2+K6+K5 fused: EnvMaxcut.local_search_inplace  envs/env_L2A.py:87-116 (first_draw_proposes = 0)
  * and the body of LocalSearch.random_search  methods/LocalSearch.py:53-83 (first_draw_proposes = 1)
@@ -200,14 +206,15 @@ int rls_maxcut_ls_weights(const rls_graph* g, const uint8_t* x, int64_t B, int32
  *   for t in rounds: mask = (ws + noise[t] * rd_std) > thresh; proposal = x ^ mask;
  *                    rows whose proposal has cut >= obj take it                     (:98-107)
  *   greedy single-flip sweep (:109-116)
- * ws int32 [B,N] = the reference's  n0_num_n1 - k * cutdeg  (exact integer), rd_std f32 [N] =
- * (max_b ws - min_b ws) * noise_std  -- a whole-batch statistic, hence computed by the caller.
+ * ws int8 / int16 [B,N] (ws_bytes = 1 | 2, as rls_maxcut_ls_weights wrote it) = the reference's
+ * n0_num_n1 - k * cutdeg  (exact integer), rd_std f32 [N] = (max_b ws - min_b ws) * noise_std  -- a whole-batch
+ * statistic, hence the pre-pass's ws_minmax.
  * noise f32 [num_iters + 1 - first_draw_proposes, B, N] = the randn_like draws in call order (test
  * mode: bit-exact against the reference) or NULL = in-kernel Philox + Box-Muller keyed by
  * (seed, env_offset + b, node, round).  obj int64 [B]: in/out, or out only when compute_obj != 0
  * (the reference's good_vs.shape == () case).  Unweighted graphs, max degree <= 512,
  * num_spin <= 15; RLS_EUNSUPPORTED otherwise (callers fall back to K2 / K6 / K5). */
-int rls_maxcut_local_search(const rls_graph* g, uint8_t* x, int64_t B, const int32_t* ws, const float* rd_std,
+int rls_maxcut_local_search(const rls_graph* g, uint8_t* x, int64_t B, const void* ws, int32_t ws_bytes, const float* rd_std,
                             const float* noise, uint64_t seed, int64_t env_offset, int32_t num_iters,
                             int32_t num_spin, int32_t first_draw_proposes, int64_t* obj, int32_t compute_obj,
                             void* stream);

@@ -15,27 +15,34 @@
 //   phase 3  wave 0 runs the greedy sweep (rls_sweep.h) on the resident tile
 //   phase 4  4 waves write the tile back
 //
-// ws = int32 [B, N] (the reference's  n0_num_n1 - k * cutdeg, an exact integer in both flavours) and
-// rd_std f32 [N] come from a pre-pass because rd_std is a statistic over the WHOLE batch
-// (max - min over dim 0, env_L2A.py:93-94).  noise = the randn_like draws (test mode, bit-exact
+// ws = int8 / int16 [B, N] (the reference's  n0_num_n1 - k * cutdeg, an exact integer in both flavours, |ws| <= the
+// largest degree: one byte per entry up to degree 127) and rd_std f32 [N] come from a pre-pass because rd_std is a
+// statistic over the WHOLE batch (max - min over dim 0, env_L2A.py:93-94).  ws is re-read by the threshold pass and
+// by every proposal round -- (num_iters + 1) B N entries: as int32 that was 4.7 GB of HBM reads for G22 / 2^16 envs
+// (6.3x the algorithmic bytes, half the kernel's time); as int8 it is 1.2 GB.  noise = the randn_like draws (test mode, bit-exact
 // against the reference) or NULL for an in-kernel counter-based hash + Box-Muller keyed by (seed, global env,
 // node, round).  f32 arithmetic follows torch: (float)ws + (noise * rd_std), two roundings.
 #include "rls_cutcount.h"
 #include "rls_sweep.h"
+#include <type_traits>
 
 namespace rls {
 
 constexpr int kLsMergeWaves = 4;   // waves that own the top-k merge and the batched sweep; a tile runs on 4 or 8 waves
 constexpr int kTopCap = 16;  // num_spin + 1 <= kTopCap
 
-__device__ __forceinline__ void top_insert(float (&t)[kTopCap], float v) {
+// insert v into the descending list t[0 .. DEPTH) (entries from DEPTH on are untouched: with DEPTH = num_spin + 1 = the
+// rank the threshold is read at, nothing below it can matter)
+template <int DEPTH>
+__device__ __forceinline__ void top_insert_n(float (&t)[kTopCap], float v) {
 #pragma unroll
-    for (int j = 0; j < kTopCap; ++j) {
+    for (int j = 0; j < DEPTH; ++j) {
         const float hi = fmaxf(t[j], v);
         v = fminf(t[j], v);
         t[j] = hi;
     }
 }
+__device__ __forceinline__ void top_insert(float (&t)[kTopCap], float v) { top_insert_n<kTopCap>(t, v); }
 
 // Counter-based noise for the production path: murmur3's 32-bit finaliser over (seed, global env,
 // node quad, round) -- order-independent like Philox (so results do not depend on how envs are
@@ -64,11 +71,13 @@ __device__ __forceinline__ void normal4(uint32_t env_key, uint32_t q, uint32_t i
     z[2] = rb * __builtin_amdgcn_cosf(t4); z[3] = rb * __builtin_amdgcn_sinf(t4);
 }
 
-template <bool VEC, bool V4, int P, int W>
+// ALIGNED: rows of x, ws and noise start on 16-byte boundaries (N % 16 == 0 and aligned bases): 16-byte row pieces
+// everywhere; else element-wise loads.  WT = int8_t | int16_t.
+template <bool ALIGNED, typename WT, int P, int W>
 __global__ __launch_bounds__(W * kWave) void k_maxcut_local_search(
     uint8_t* __restrict__ x, int64_t B, int64_t N, const int32_t* __restrict__ eu, const int32_t* __restrict__ ev,
     int64_t E, int halve, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ sweep_src, int64_t sweep_len,
-    const int32_t* __restrict__ ws, const float* __restrict__ rd_std, const float* __restrict__ noise, uint64_t seed,
+    const WT* __restrict__ ws, const float* __restrict__ rd_std, const float* __restrict__ noise, uint64_t seed,
     int64_t env_offset, int num_iters, int num_spin, int first_draw_proposes, int64_t* __restrict__ obj,
     int compute_obj, int batched) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -77,6 +86,7 @@ __global__ __launch_bounds__(W * kWave) void k_maxcut_local_search(
     // buffer in the ring (idle between the threshold pass and the first proposal round): 50 KB for G22, three
     // workgroups per CU instead of two.  With 8 waves per tile (few tiles) waves 4..7 stage in `tops`.
     constexpr bool COMPACT = (W == kLsMergeWaves);
+    constexpr bool VEC = ALIGNED, V4 = ALIGNED;
     uint64_t* words = reinterpret_cast<uint64_t*>(smem);
     uint64_t* prop = words + (N + 2);
     int32_t* rp = COMPACT ? reinterpret_cast<int32_t*>(prop) : reinterpret_cast<int32_t*>(prop + N);
@@ -121,9 +131,12 @@ __global__ __launch_bounds__(W * kWave) void k_maxcut_local_search(
         my_obj = valid ? obj[b] : 0;
     }
 
-    const int32_t* ws_row = ws + (valid ? b : 0) * N;
+    const WT* ws_row = ws + (valid ? b : 0) * N;
+    constexpr int NPC = 16 / (int)sizeof(WT);     // nodes per 16-byte piece of a ws row
+    constexpr int QPP = NPC / 4;                  // quads (4 nodes: the unit of the noise / mask code) per piece
     const int64_t nquads = (N + 3) >> 2;
-    const int64_t nchunks = (nquads + 3) >> 2;   // chunk = 4 consecutive quads = 64 bytes of a ws row
+    const int64_t npieces = (N + NPC - 1) / NPC;
+    const int64_t nchunks = (npieces + 3) >> 2;   // chunk = 4 consecutive pieces = 64 bytes of a ws row
     typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
     constexpr int D = 2;                          // chunks per trip; the next trip's loads fly during this trip's math
     // ws rows come in through the row-piece stage (rls_tile.h) like the spins: lane l of load i fetches piece
@@ -140,37 +153,31 @@ __global__ __launch_bounds__(W * kWave) void k_maxcut_local_search(
                 g[d][i] = i32x4{0, 0, 0, 0};
                 if constexpr (V4) {
                     const int64_t rw = b0 + kStageRows * i + io_r;
-                    const int64_t q = c * 4 + io_j;
-                    if (c < nchunks && rw < B && q < nquads) g[d][i] = *reinterpret_cast<const i32x4*>(ws + rw * N + q * 4);
-                } else {   // unaligned rows: each lane reads its own env's quad i of the chunk, element-wise
-                    const int64_t q = c * 4 + i;
-                    if (c < nchunks && valid)
+                    const int64_t pc = c * 4 + io_j;
+                    if (c < nchunks && rw < B && pc < npieces) g[d][i] = *reinterpret_cast<const i32x4*>(ws + rw * N + pc * NPC);
+                } else {   // unaligned rows: each lane reads its own env's piece i of the chunk, element-wise
+                    const int64_t n0 = (c * 4 + i) * NPC;
+                    if (c < nchunks && valid) {
 #pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            if (q * 4 + k < N) g[d][i][k] = ws_row[q * 4 + k];
+                        for (int k = 0; k < NPC; ++k) {
+                            const uint32_t e = (n0 + k < N) ? (uint32_t)ws_row[n0 + k] & (sizeof(WT) == 1 ? 0xFFu : 0xFFFFu) : 0u;
+                            constexpr int per = 4 / (int)sizeof(WT);          // entries per dword
+                            g[d][i][k / per] |= (int32_t)(e << (8 * (int)sizeof(WT) * (k % per)));
+                        }
+                    }
                 }
             }
         }
     };
-    // corner turn: afterwards wq[i] = this lane's env, quad 4c + i
-    auto turn = [&](const i32x4 (&gd)[4], i32x4 (&wq)[4]) {
-        if constexpr (V4) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) *reinterpret_cast<i32x4*>(wstage + (i << 10) + (lane << 4)) = gd[i];
-            asm volatile("" ::: "memory");   // LDS ops of one wave execute in order
-#pragma unroll
-            for (int i = 0; i < 4; ++i) wq[i] = *reinterpret_cast<const i32x4*>(wstage + stage_slot_off(lane, i));
-            asm volatile("" ::: "memory");
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) wq[i] = gd[i];
-        }
-    };
-    // spin_rand of quad q: v[k] = (float)ws + noise * rd_std
-    auto spin_rand_quad = [&](int64_t q, int it, const i32x4& wq, float (&v)[4]) {
-        const f32x4 sdq = *reinterpret_cast<const f32x4*>(sdl + q * 4);   // wave-uniform address: broadcast read
+    // spin_rand of quad q: v[k] = (float)ws + noise * rd_std.  Branch-free in the production path (a quad past the end
+    // of the row -- the last piece of a row whose length is not a multiple of the piece -- is computed on clamped
+    // inputs and masked by the consumer): the quads of a piece are independent chains the scheduler interleaves,
+    // which is what hides the latency of the hash -> log -> sqrt -> sin / cos sequence with two waves per SIMD.
+    auto spin_rand_quad = [&](int64_t q, int it, const int (&wq)[4], float (&v)[4], auto use_noise) {
+        const int64_t qs = q < nquads ? q : nquads - 1;
+        const f32x4 sdq = *reinterpret_cast<const f32x4*>(sdl + qs * 4);   // wave-uniform address: broadcast read
         float z[4] = {0.f, 0.f, 0.f, 0.f};
-        if (noise) {
+        if constexpr (decltype(use_noise)::value) {
             if (valid && q < nquads) {
                 if constexpr (V4) {
                     const f32x4 zz = *reinterpret_cast<const f32x4*>(noise + ((int64_t)it * B + b) * N + q * 4);
@@ -188,8 +195,28 @@ __global__ __launch_bounds__(W * kWave) void k_maxcut_local_search(
         for (int k = 0; k < 4; ++k)
             v[k] = (float)wq[k] + z[k] * sdq[k];   // two roundings (fp-contract off): torch's ws + randn * rd_std
     };
-    // one pass over the tile's ws: f(q, v) for every quad q of this wave's chunks
-    auto for_each_quad = [&](int it, auto&& f) {
+    // the NPC nodes of piece pc (16 bytes of this lane's ws row): f(pc, v[NPC]) sees them all at once, so that a
+    // consumer with a divergent store (the mask words) pays for ONE exec-masked region per piece, not one per quad
+    auto do_piece = [&](int64_t pc, const i32x4& piece, int it, auto use_noise, auto&& f) {
+        float vals[NPC];
+#pragma unroll
+        for (int sq = 0; sq < QPP; ++sq) {
+            const int64_t q = pc * QPP + sq;
+            int wv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if constexpr (sizeof(WT) == 1) wv[k] = (int)(int8_t)((uint32_t)piece[sq] >> (8 * k));
+                else wv[k] = (int)(int16_t)((uint32_t)piece[2 * sq + (k >> 1)] >> (16 * (k & 1)));
+            }
+            float v[4];
+            spin_rand_quad(q, it, wv, v, use_noise);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) vals[4 * sq + k] = v[k];
+        }
+        f(pc, vals);
+    };
+    // one pass over the tile's ws: f(pc, v) for every piece pc of this wave's chunks (f masks nodes >= N itself)
+    auto for_each_quad = [&](int it, auto use_noise, auto&& f) {
         i32x4 ga[D][4], gb[D][4];
         issue(w, ga);
         for (int64_t c0 = w; c0 < nchunks; c0 += (int64_t)D * W) {
@@ -198,16 +225,25 @@ __global__ __launch_bounds__(W * kWave) void k_maxcut_local_search(
             for (int d = 0; d < D; ++d) {
                 const int64_t c = c0 + (int64_t)d * W;
                 if (c < nchunks) {
-                    i32x4 wq[4];
-                    turn(ga[d], wq);
+                    const int np_here = (int)((npieces - c * 4) < 4 ? (npieces - c * 4) : 4);
+                    if constexpr (V4) {
+                        // corner turn through this wave's stage: afterwards slot (lane, i) = this lane's env, piece 4c + i.
+                        // The pieces are then taken one at a time by a ROLLED loop (a piece = 16 / 8 nodes: a loop body of
+                        // a few hundred instructions; unrolled over the chunk the round loop was 10 000 instructions
+                        // of single-quad basic blocks)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int64_t q = c * 4 + i;
-                        if (q < nquads) {
-                            float v[4];
-                            spin_rand_quad(q, it, wq[i], v);
-                            f(q, v);
+                        for (int i = 0; i < 4; ++i) *reinterpret_cast<i32x4*>(wstage + (i << 10) + (lane << 4)) = ga[d][i];
+                        asm volatile("" ::: "memory");   // LDS ops of one wave execute in order
+#pragma unroll 1
+                        for (int i = 0; i < np_here; ++i) {
+                            const i32x4 piece = *reinterpret_cast<const i32x4*>(wstage + stage_slot_off(lane, i));
+                            do_piece(c * 4 + i, piece, it, use_noise, f);
                         }
+                        asm volatile("" ::: "memory");
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (i < np_here) do_piece(c * 4 + i, ga[d][i], it, use_noise, f);
                     }
                 }
             }
@@ -217,15 +253,23 @@ __global__ __launch_bounds__(W * kWave) void k_maxcut_local_search(
                 for (int i = 0; i < 4; ++i) ga[d][i] = gb[d][i];
         }
     };
+    using with_noise = std::integral_constant<bool, true>;
+    using no_noise = std::integral_constant<bool, false>;
     // ---- phase 1: threshold = (num_spin + 1)-th largest of the first draw
     float t[kTopCap];
 #pragma unroll
     for (int j = 0; j < kTopCap; ++j) t[j] = -INFINITY;
-    for_each_quad(0, [&](int64_t q, const float (&v)[4]) {
+    auto top_pass = [&](auto use_noise, auto depth) {    // depth = entries of the insertion network that can matter
+        for_each_quad(0, use_noise, [&](int64_t pc, const float (&v)[NPC]) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (q * 4 + k < N) top_insert(t, v[k]);
-    });
+            for (int k = 0; k < NPC; ++k) top_insert_n<decltype(depth)::value>(t, (pc * NPC + k < N) ? v[k] : -INFINITY);
+        });
+    };
+    if (num_spin < 9) {
+        if (noise) top_pass(with_noise{}, std::integral_constant<int, 9>{}); else top_pass(no_noise{}, std::integral_constant<int, 9>{});
+    } else {
+        if (noise) top_pass(with_noise{}, std::integral_constant<int, kTopCap>{}); else top_pass(no_noise{}, std::integral_constant<int, kTopCap>{});
+    }
     __syncthreads();   // every wave is done with its stage (waves >= 4 stage inside `tops`)
     // waves 4.. hand their lists to waves 0..3, four at a time, through the merge buffer
     for (int base = kLsMergeWaves; base < W; base += kLsMergeWaves) {
@@ -267,15 +311,19 @@ __global__ __launch_bounds__(W * kWave) void k_maxcut_local_search(
     // ---- phase 2: proposal rounds
     for (int itp = 0; itp < num_iters; ++itp) {
         const int it = first_draw_proposes ? itp : itp + 1;
-        for_each_quad(it, [&](int64_t q, const float (&v)[4]) {
+        auto round_pass = [&](auto use_noise) {
+        for_each_quad(it, use_noise, [&](int64_t pc, const float (&v)[NPC]) {
             uint64_t mine = 0;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const uint64_t mm = ballot64(valid && (q * 4 + k < N) && (v[k] > thresh));   // spin_rand.gt(thresh)
+            for (int k = 0; k < NPC; ++k) {
+                const uint64_t mm = ballot64(valid && (v[k] > thresh));   // spin_rand.gt(thresh), bit e = env b0 + e
                 if (lane == k) mine = mm;
             }
-            if (lane < 4 && q * 4 + lane < N) prop[q * 4 + lane] = words[q * 4 + lane] ^ mine;
+            const int64_t node = pc * NPC + lane;
+            if (lane < NPC && node < N) prop[node] = words[node] ^ mine;
         });
+        };
+        if (noise) round_pass(with_noise{}); else round_pass(no_noise{});
         __syncthreads();
         int64_t total = block_sum_partials<W>(tile_cut_count<P>(prop, eu, ev, E, lane, w, W), scratch, lane, w);
         if (halve) total >>= 1;
@@ -344,7 +392,7 @@ extern "C" int rls_maxcut_local_search_supported(const rls_graph* g, int64_t B, 
     return ls_pick_waves(N, B > 0 ? B : 1) != 0;
 }
 
-extern "C" int rls_maxcut_local_search(const rls_graph* g, uint8_t* x, int64_t B, const int32_t* ws,
+extern "C" int rls_maxcut_local_search(const rls_graph* g, uint8_t* x, int64_t B, const void* ws, int32_t ws_bytes,
                                        const float* rd_std, const float* noise, uint64_t seed, int64_t env_offset,
                                        int32_t num_iters, int32_t num_spin, int32_t first_draw_proposes, int64_t* obj,
                                        int32_t compute_obj, void* stream) {
@@ -352,6 +400,7 @@ extern "C" int rls_maxcut_local_search(const rls_graph* g, uint8_t* x, int64_t B
     RLS_REQUIRE(B >= 0 && num_iters >= 0, RLS_EINVAL, "bad sizes");
     if (B == 0) return RLS_OK;
     RLS_REQUIRE(x && ws && rd_std && obj, RLS_EINVAL, "NULL pointer");
+    RLS_REQUIRE(ws_bytes == 1 || ws_bytes == 2, RLS_EINVAL, "ws_bytes must be 1 or 2 (rls_maxcut_ls_weights writes either)");
     const int64_t N = g->num_nodes, E = g->num_stored_edges;
     RLS_REQUIRE(num_spin >= 0 && num_spin + 1 <= kTopCap && num_spin < N, RLS_EUNSUPPORTED,
                 "num_spin=%d outside [0, %d] (and < N)", num_spin, kTopCap - 1);
@@ -362,8 +411,8 @@ extern "C" int rls_maxcut_local_search(const rls_graph* g, uint8_t* x, int64_t B
     const size_t lds = ls_lds_bytes(N, W);
     const int P = pick_planes(E);
     RLS_REQUIRE(P != 0, RLS_EUNSUPPORTED, "E'=%lld too large", (long long)E);
-    const bool vec = tile_rows_aligned(x, N, 1);
-    const bool v4 = (N % 4 == 0) && ((((uintptr_t)ws) | ((uintptr_t)noise)) & 15) == 0;   // 16-byte row slices of ws / noise
+    // 16-byte row pieces of x, ws and noise: N % 16 == 0 and aligned bases
+    const bool aligned = tile_rows_aligned(x, N, 1) && ((((uintptr_t)ws) | ((uintptr_t)noise)) & 15) == 0;
     const dim3 grid((unsigned)ceil_div(B, kWave)), block(W * kWave);
     hipStream_t s = as_stream(stream);
     const int halve = g->if_bidirectional ? 1 : 0;
@@ -375,24 +424,28 @@ extern "C" int rls_maxcut_local_search(const rls_graph* g, uint8_t* x, int64_t B
     const int32_t* rp_src = batched == 2 ? g->sweep_lv_ptr : (batched ? g->sweep_rowptr : g->rowptr);
     const int32_t* sw_src = batched == 2 ? g->sweep_lv_data : (batched ? g->sweep_stream : g->col);
     const int64_t sw_len = batched == 2 ? g->num_sweep_groups : (batched ? g->nnz + N : g->nnz);
-#define LAUNCH_LSF(VEC, PP)                                                                                          \
+#define LAUNCH_LSF(AL, WT, PP)                                                                                       \
     do {                                                                                                             \
-        auto kern = W == 8 ? (v4 ? k_maxcut_local_search<VEC, true, PP, 8> : k_maxcut_local_search<VEC, false, PP, 8>) \
-                           : (v4 ? k_maxcut_local_search<VEC, true, PP, 4> : k_maxcut_local_search<VEC, false, PP, 4>); \
+        auto kern = W == 8 ? k_maxcut_local_search<AL, WT, PP, 8> : k_maxcut_local_search<AL, WT, PP, 4>;              \
         if (lds > 64 * 1024)                                                                                         \
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
-        hipLaunchKernelGGL(kern, grid, block, lds, s, x, B, N, g->eu, g->ev, E, halve, rp_src, sw_src, sw_len, ws,    \
-                           rd_std, noise, seed, env_offset, (int)num_iters, (int)num_spin, (int)first_draw_proposes,  \
-                           obj, (int)compute_obj, batched);                                                          \
+        hipLaunchKernelGGL(kern, grid, block, lds, s, x, B, N, g->eu, g->ev, E, halve, rp_src, sw_src, sw_len,        \
+                           (const WT*)ws, rd_std, noise, seed, env_offset, (int)num_iters, (int)num_spin,             \
+                           (int)first_draw_proposes, obj, (int)compute_obj, batched);                                 \
     } while (0)
-#define DISPATCH_P(VEC)                       \
-    switch (P) {                              \
-        case 12: LAUNCH_LSF(VEC, 12); break;  \
-        case 16: LAUNCH_LSF(VEC, 16); break;  \
-        case 20: LAUNCH_LSF(VEC, 20); break;  \
-        default: LAUNCH_LSF(VEC, 24); break;  \
+#ifdef RLS_LS_ONE_P   /* dev builds (RLS_EXTRA_CFLAGS=-DRLS_LS_ONE_P): one counter width, a quarter of the compile time */
+#define DISPATCH_P(AL, WT) LAUNCH_LSF(AL, WT, 24);
+#else
+#define DISPATCH_P(AL, WT)                        \
+    switch (P) {                                  \
+        case 12: LAUNCH_LSF(AL, WT, 12); break;   \
+        case 16: LAUNCH_LSF(AL, WT, 16); break;   \
+        case 20: LAUNCH_LSF(AL, WT, 20); break;   \
+        default: LAUNCH_LSF(AL, WT, 24); break;   \
     }
-    if (vec) { DISPATCH_P(true) } else { DISPATCH_P(false) }
+#endif
+    if (ws_bytes == 1) { if (aligned) { DISPATCH_P(true, int8_t) } else { DISPATCH_P(false, int8_t) } }
+    else               { if (aligned) { DISPATCH_P(true, int16_t) } else { DISPATCH_P(false, int16_t) } }
 #undef DISPATCH_P
 #undef LAUNCH_LSF
     return check_launch("k_maxcut_local_search");

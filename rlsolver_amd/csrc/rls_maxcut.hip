@@ -270,9 +270,19 @@ __global__ void k_node_cutdeg(const uint8_t* __restrict__ x, int64_t B, int64_t 
     }
 }
 
+// whole-batch min / max of the local-search weights, minmax int32 [2][N] (row 0 = min, row 1 = max, filled with
+// INT32_MAX / INT32_MIN by the launcher): an atomic only where this tile improves what is already there -- after the
+// first few tiles almost never (unconditional atomics cost 3x the kernel).
+__device__ __forceinline__ void ws_minmax_update(int32_t* __restrict__ minmax, int64_t N, int64_t i, int lo, int hi) {
+    // agent-scope loads: served by L2, where the atomics land (a CU's L1 would keep showing the fill value)
+    if (lo < __hip_atomic_load(minmax + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(minmax + i, lo);
+    if (hi > __hip_atomic_load(minmax + N + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(minmax + N + i, hi);
+}
+
 // element-parallel local-search weights (no LDS tile: any N): ws[b,i] = #stored out-neighbours - mult * cutdeg[b,i]
+template <typename WT>
 __global__ void k_ls_weights_elem(const uint8_t* __restrict__ x, int64_t B, int64_t N, const int32_t* __restrict__ erowptr,
-                                  const int32_t* __restrict__ ev, int mult, int32_t* __restrict__ ws) {
+                                  const int32_t* __restrict__ ev, int mult, WT* __restrict__ ws, int32_t* __restrict__ minmax) {
     const int64_t total = B * N;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         const int64_t b = t / N, i = t - b * N;
@@ -281,8 +291,15 @@ __global__ void k_ls_weights_elem(const uint8_t* __restrict__ x, int64_t B, int6
         const int r0 = erowptr[i], r1 = erowptr[i + 1];
         int c = 0;
         for (int j = r0; j < r1; ++j) c += ((row[ev[j]] != 0) != xi);
-        ws[t] = (r1 - r0) - mult * c;
+        const int val = (r1 - r0) - mult * c;
+        ws[t] = (WT)val;
+        if (minmax) ws_minmax_update(minmax, N, i, val, val);
     }
+}
+
+__global__ void k_fill_minmax(int32_t* __restrict__ minmax, int64_t N) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) { minmax[i] = INT32_MAX; minmax[N + i] = INT32_MIN; }
 }
 
 template <bool WEIGHTED>
@@ -426,12 +443,29 @@ __device__ __forceinline__ uint32_t ns_extract2(const uint64_t (&pl)[NPL], int h
 // WIDE: graphs with hubs (256 <= max degree < 65536, e.g. Barabasi-Albert at n = 10^4): 16 counter planes instead of 8; a
 // group whose longest row is >= 256 ripples its carries as far as its rows need and leaves through 16-bit fields, every
 // other group runs exactly as in the narrow kernel.
-template <int MODE, bool VEC, bool WIDE>   // MODE 0: cutdeg int64, 1: flip gain int32, 2: local-search weight int32
+// max and min of a bit-sliced counter (planes pl[0..NP), LSB first) over the envs of `vm`: walk the planes from the top,
+// keeping the candidates that still can be the extremum
+template <int NP, int NPL>
+__device__ __forceinline__ void planes_minmax(const uint64_t (&pl)[NPL], uint64_t vm, int& mn, int& mx) {
+    uint64_t a = vm, b = vm;
+    mx = 0;
+    mn = 0;
+#pragma unroll
+    for (int p = NP - 1; p >= 0; --p) {
+        const uint64_t t = a & pl[p];
+        if (t) { a = t; mx |= 1 << p; }
+        const uint64_t u = b & ~pl[p];
+        if (u) b = u; else mn |= 1 << p;
+    }
+}
+
+// MODE 0: cutdeg int64, 1: flip gain int32, 2: local-search weight WT (int8 / int16 / int32) + the batch min / max per node
+template <int MODE, bool VEC, bool WIDE, typename WT = int32_t>
 __global__ __launch_bounds__(kNsWaves * kWave) void k_node_stats_bits(const uint8_t* __restrict__ x, int64_t B, int64_t N,
                                                                      const int32_t* __restrict__ rowptr,
                                                                      const int32_t* __restrict__ ell_ptr,
                                                                      const int32_t* __restrict__ ell, int mult,
-                                                                     void* __restrict__ out_v) {
+                                                                     void* __restrict__ out_v, int32_t* __restrict__ minmax) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* words = reinterpret_cast<uint64_t*>(smem);
     const int lane = threadIdx.x & (kWave - 1);
@@ -484,11 +518,19 @@ __global__ __launch_bounds__(kNsWaves * kWave) void k_node_stats_bits(const uint
         auto emit = [&](int e, int cnt) {
             if constexpr (MODE == 0) reinterpret_cast<int64_t*>(out_v)[(b0 + e) * N + i] = cnt;
             else if constexpr (MODE == 1) reinterpret_cast<int32_t*>(out_v)[(b0 + e) * N + i] = deg - 2 * cnt;
-            else reinterpret_cast<int32_t*>(out_v)[(b0 + e) * N + i] = deg - mult * cnt;
+            else reinterpret_cast<WT*>(out_v)[(b0 + e) * N + i] = (WT)(deg - mult * cnt);
         };
+        const uint64_t vmask = nenv == kWave ? ~0ull : ((1ull << nenv) - 1);
         if constexpr (WIDE) {
             if (md >= 256) {                                  // a hub group: 16-bit fields, two envs per dword
                 const uint64_t pw[16] = {ones, twos, fours, c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8], c[9], c[10], c[11], c[12]};
+                if constexpr (MODE == 2) {
+                    if (minmax && in) {
+                        int cmn, cmx;
+                        planes_minmax<16>(pw, vmask, cmn, cmx);
+                        ws_minmax_update(minmax, N, i, deg - mult * cmx, deg - mult * cmn);
+                    }
+                }
                 for (int half = 0; half < 2; ++half) {
                     for (int r = 0; r < 16; ++r) {
                         const uint32_t acc = md < 1024 ? ns_extract2<10>(pw, half, r) : ns_extract2<16>(pw, half, r);
@@ -500,6 +542,13 @@ __global__ __launch_bounds__(kNsWaves * kWave) void k_node_stats_bits(const uint
                     }
                 }
                 continue;
+            }
+        }
+        if constexpr (MODE == 2) {
+            if (minmax && in) {
+                int cmn, cmx;
+                planes_minmax<8>(pl, vmask, cmn, cmx);
+                ws_minmax_update(minmax, N, i, deg - mult * cmx, deg - mult * cmn);
             }
         }
         if (nenv == kWave) {
@@ -542,31 +591,32 @@ static inline bool node_stats_use_bits(const rls_graph* g, const int32_t* ell_pt
     return !off && ell_ptr && ell && !g->wgt && g->max_degree < 65536 && B >= 2048 &&
            node_stats_bits_lds(g->num_nodes) <= (size_t)kLdsBytes;
 }
-template <int MODE>
+template <int MODE, typename WT = int32_t>
 static int launch_node_stats_bits(const rls_graph* g, const uint8_t* x, int64_t B, const int32_t* rowptr,
-                                  const int32_t* ell_ptr, const int32_t* ell, int mult, void* out, void* stream) {
+                                  const int32_t* ell_ptr, const int32_t* ell, int mult, void* out, void* stream,
+                                  int32_t* minmax = nullptr) {
     const int64_t N = g->num_nodes;
     const size_t lds = node_stats_bits_lds(N);
     const dim3 grid((unsigned)ceil_div(B, kWave)), block(kNsWaves * kWave);
     const bool vec = tile_rows_aligned(x, N, 1);
     const bool wide = g->max_degree >= 256;
-    auto kern = wide ? (vec ? k_node_stats_bits<MODE, true, true> : k_node_stats_bits<MODE, false, true>)
-                     : (vec ? k_node_stats_bits<MODE, true, false> : k_node_stats_bits<MODE, false, false>);
+    auto kern = wide ? (vec ? k_node_stats_bits<MODE, true, true, WT> : k_node_stats_bits<MODE, false, true, WT>)
+                     : (vec ? k_node_stats_bits<MODE, true, false, WT> : k_node_stats_bits<MODE, false, false, WT>);
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, grid, block, lds, as_stream(stream), x, B, N, rowptr, ell_ptr, ell, mult, out);
+    hipLaunchKernelGGL(kern, grid, block, lds, as_stream(stream), x, B, N, rowptr, ell_ptr, ell, mult, out, minmax);
     return check_launch("k_node_stats_bits");
 }
 
-// Local-search weights: ws[b,i] = stored_deg(i) - mult * cutdeg(b,i) as int32 -- the pre-pass of
-// rls_maxcut_local_search (the whole-batch max/min per node is one aminmax pass over this tensor; doing
-// it here with 2 atomics per (tile, node) cost 3x the kernel itself).  Same structure as k_node_stats_tile.
-template <bool VEC>
+// Local-search weights: ws[b,i] = stored_deg(i) - mult * cutdeg(b,i) as WT (int8 / int16 / int32) -- the pre-pass of
+// rls_maxcut_local_search -- and their whole-batch min / max per node (ws_minmax_update).  Same structure as
+// k_node_stats_tile; the small-batch form (the bit-sliced kernel takes batches from 2048 envs).
+template <bool VEC, typename WT>
 __global__ __launch_bounds__(kTileWaves * kWave) void k_ls_weights(const uint8_t* __restrict__ x, int64_t B, int64_t N,
                                                                    const int32_t* __restrict__ rowptr,
                                                                    const int32_t* __restrict__ col, int mult,
-                                                                   int32_t* __restrict__ ws) {
-    constexpr int NB = 32, STRIDE = 144;
+                                                                   WT* __restrict__ ws, int32_t* __restrict__ minmax) {
+    constexpr int NB = 128 / (int)sizeof(WT), STRIDE = 144;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* words = reinterpret_cast<uint64_t*>(smem);
     const unsigned char* wbytes = smem;
@@ -605,18 +655,27 @@ __global__ __launch_bounds__(kTileWaves * kWave) void k_ls_weights(const uint8_t
             }
             const int deg = r1 - r0;
             const int val = deg - mult * (xi ? (deg - acc) : acc);
-            *reinterpret_cast<int32_t*>(stage + lane * STRIDE + k * 4) = val;
+            *reinterpret_cast<WT*>(stage + lane * STRIDE + k * (int)sizeof(WT)) = (WT)val;
+            if (minmax) {
+                int lo = valid ? val : INT32_MAX, hi = valid ? val : INT32_MIN;
+#pragma unroll
+                for (int sft = 32; sft >= 1; sft >>= 1) {
+                    lo = min(lo, __shfl_xor(lo, sft, kWave));
+                    hi = max(hi, __shfl_xor(hi, sft, kWave));
+                }
+                if (lane == 0) ws_minmax_update(minmax, N, i, lo, hi);
+            }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (valid) {
-            int32_t* dst = ws + b * N + i0;
+            WT* dst = ws + b * N + i0;
             const unsigned char* src = stage + lane * STRIDE;
             if (nb_here == NB && ((((uintptr_t)dst) & 15) == 0)) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q)
                     reinterpret_cast<u32x4*>(dst)[q] = *reinterpret_cast<const u32x4*>(src + q * 16);
             } else {
-                for (int k = 0; k < nb_here; ++k) dst[k] = *reinterpret_cast<const int32_t*>(src + k * 4);
+                for (int k = 0; k < nb_here; ++k) dst[k] = *reinterpret_cast<const WT*>(src + k * (int)sizeof(WT));
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1165,32 +1224,52 @@ int rls_maxcut_delta_all(const rls_graph* g, const uint8_t* x, int64_t B, int32_
     return check_launch("k_delta_all");
 }
 
-int rls_maxcut_ls_weights(const rls_graph* g, const uint8_t* x, int64_t B, int32_t mult, int32_t* ws, void* stream) {
-    if (int rc = check_graph(g)) return rc;
-    RLS_REQUIRE(B >= 0 && mult >= 0, RLS_EINVAL, "bad arguments");
-    if (B == 0) return RLS_OK;
-    RLS_REQUIRE(x && ws, RLS_EINVAL, "NULL pointer");
+}  // extern "C" (a template follows)
+
+template <typename WT>
+static int ls_weights_typed(const rls_graph* g, const uint8_t* x, int64_t B, int32_t mult, WT* ws, int32_t* minmax, void* stream) {
     if (node_stats_use_bits(g, g->ell_st_ptr, g->ell_st, B))
-        return launch_node_stats_bits<2>(g, x, B, g->erowptr, g->ell_st_ptr, g->ell_st, (int)mult, ws, stream);
+        return launch_node_stats_bits<2, WT>(g, x, B, g->erowptr, g->ell_st_ptr, g->ell_st, (int)mult, ws, stream, minmax);
     const int64_t N = g->num_nodes;
     const size_t lds = node_stats_lds(N);
     if (lds > (size_t)kLdsBytes) {   // no tile for this N: element-parallel
-        hipLaunchKernelGGL(k_ls_weights_elem, dim3(grid_for(B * N, 256)), dim3(256), 0, as_stream(stream), x, B, N, g->erowptr, g->ev,
-                           (int)mult, ws);
+        hipLaunchKernelGGL(k_ls_weights_elem<WT>, dim3(grid_for(B * N, 256)), dim3(256), 0, as_stream(stream), x, B, N, g->erowptr,
+                           g->ev, (int)mult, ws, minmax);
         return check_launch("k_ls_weights_elem");
     }
     const dim3 grid((unsigned)ceil_div(B, kWave)), block(kTileWaves * kWave);
     hipStream_t s = as_stream(stream);
 #define LAUNCH_LW(VEC)                                                                                           \
     do {                                                                                                         \
-        auto kern = k_ls_weights<VEC>;                                                                           \
+        auto kern = k_ls_weights<VEC, WT>;                                                                       \
         if (lds > 64 * 1024)                                                                                     \
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
-        hipLaunchKernelGGL(kern, grid, block, lds, s, x, B, N, g->erowptr, g->ev, (int)mult, ws);                 \
+        hipLaunchKernelGGL(kern, grid, block, lds, s, x, B, N, g->erowptr, g->ev, (int)mult, ws, minmax);         \
     } while (0)
     if (tile_rows_aligned(x, N, 1)) LAUNCH_LW(true); else LAUNCH_LW(false);
 #undef LAUNCH_LW
     return check_launch("k_ls_weights");
+}
+
+extern "C" {
+
+int rls_maxcut_ls_weights(const rls_graph* g, const uint8_t* x, int64_t B, int32_t mult, void* ws, int32_t ws_bytes,
+                          int32_t* ws_minmax, void* stream) {
+    if (int rc = check_graph(g)) return rc;
+    RLS_REQUIRE(B >= 0 && mult >= 0, RLS_EINVAL, "bad arguments");
+    RLS_REQUIRE(ws_bytes == 1 || ws_bytes == 2 || ws_bytes == 4, RLS_EINVAL, "ws_bytes must be 1, 2 or 4");
+    // ws lies in [-(mult - 1) deg, deg] with deg <= the graph's largest degree
+    const int64_t span = (int64_t)g->max_degree * (mult > 1 ? mult - 1 : 1);
+    RLS_REQUIRE(ws_bytes == 4 || span <= (ws_bytes == 1 ? 127 : 32767), RLS_EINVAL,
+                "weights up to %lld do not fit %d-byte entries", (long long)span, (int)ws_bytes);
+    if (ws_minmax)   // also for B == 0: the caller reads max - min
+        hipLaunchKernelGGL(k_fill_minmax, dim3((unsigned)ceil_div(g->num_nodes, 256)), dim3(256), 0, as_stream(stream), ws_minmax,
+                           g->num_nodes);
+    if (B == 0) return ws_minmax ? check_launch("k_fill_minmax") : RLS_OK;
+    RLS_REQUIRE(x && ws, RLS_EINVAL, "NULL pointer");
+    if (ws_bytes == 1) return ls_weights_typed<int8_t>(g, x, B, mult, (int8_t*)ws, ws_minmax, stream);
+    if (ws_bytes == 2) return ls_weights_typed<int16_t>(g, x, B, mult, (int16_t*)ws, ws_minmax, stream);
+    return ls_weights_typed<int32_t>(g, x, B, mult, (int32_t*)ws, ws_minmax, stream);
 }
 
 int rls_select_better_rows(uint8_t* xs0, int64_t* vs0, const uint8_t* xs1, const int64_t* vs1, int64_t B,

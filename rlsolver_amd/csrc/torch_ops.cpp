@@ -165,19 +165,30 @@ void maxcut_propose_accept(int64_t g, Tensor xs, const Tensor& mask, Tensor obj)
     ok(rls_maxcut_propose_accept(G(g), (uint8_t*)p(xs), B, (const uint8_t*)p(mask), (int64_t*)p(obj), cur_stream(xs)),
        "rls_maxcut_propose_accept");
 }
-void maxcut_ls_weights(int64_t g, const Tensor& xs, int64_t mult, Tensor ws) {
+// local-search weights: int8 / int16 / int32 -> ws_bytes
+inline int ws_bytes_of(const Tensor& ws, bool allow_i32) {
+    dev(ws, "ws");
+    if (ws.scalar_type() == at::kChar) return 1;
+    if (ws.scalar_type() == at::kShort) return 2;
+    TORCH_CHECK(allow_i32 && ws.scalar_type() == I32, "ws must be int8 / int16", allow_i32 ? " / int32" : "", ", got ", ws.scalar_type());
+    return 4;
+}
+void maxcut_ls_weights(int64_t g, const Tensor& xs, int64_t mult, Tensor ws, const OptTensor& ws_minmax) {
     spin_bytes(xs, "xs", false);
     const int64_t B = env_rows(xs, "xs", G(g));
-    dev(ws, "ws", I32);
+    const int wb = ws_bytes_of(ws, true);
     shape2(ws, "ws", B, G(g)->num_nodes);
+    optdev(ws_minmax, "ws_minmax", I32);
+    if (ws_minmax.has_value()) shape2(*ws_minmax, "ws_minmax", 2, G(g)->num_nodes);
     RLS_GUARD(xs);
-    ok(rls_maxcut_ls_weights(G(g), (const uint8_t*)p(xs), B, (int32_t)mult, (int32_t*)p(ws), cur_stream(xs)), "rls_maxcut_ls_weights");
+    ok(rls_maxcut_ls_weights(G(g), (const uint8_t*)p(xs), B, (int32_t)mult, p(ws), wb, (int32_t*)p(ws_minmax), cur_stream(xs)),
+       "rls_maxcut_ls_weights");
 }
 void maxcut_local_search(int64_t g, Tensor xs, const Tensor& ws, const Tensor& rd_std, const OptTensor& noise, int64_t seed,
                          int64_t env_offset, int64_t num_iters, int64_t num_spin, bool first_draw_proposes, Tensor obj, bool compute_obj) {
     spin_bytes(xs, "xs", false);
     const int64_t B = env_rows(xs, "xs", G(g)), N = G(g)->num_nodes;
-    dev(ws, "ws", I32);
+    const int wb = ws_bytes_of(ws, false);
     shape2(ws, "ws", B, N);
     dev(rd_std, "rd_std", F32);
     count(rd_std, "rd_std", N);
@@ -188,7 +199,7 @@ void maxcut_local_search(int64_t g, Tensor xs, const Tensor& ws, const Tensor& r
     dev(obj, "obj", I64);
     count(obj, "obj", B);
     RLS_GUARD(xs);
-    ok(rls_maxcut_local_search(G(g), (uint8_t*)p(xs), B, (const int32_t*)p(ws), (const float*)p(rd_std), (const float*)p(noise),
+    ok(rls_maxcut_local_search(G(g), (uint8_t*)p(xs), B, p(ws), wb, (const float*)p(rd_std), (const float*)p(noise),
                                (uint64_t)seed, env_offset, (int32_t)num_iters, (int32_t)num_spin, first_draw_proposes, (int64_t*)p(obj),
                                compute_obj, cur_stream(xs)), "rls_maxcut_local_search");
 }
@@ -697,7 +708,7 @@ TORCH_LIBRARY(rlsolver_hip, m) {
           "Tensor(e!)? done, float done_value) -> ()");
     m.def("maxcut_greedy_sweep(int graph, Tensor(a!) xs, Tensor(b!) obj) -> ()");
     m.def("maxcut_propose_accept(int graph, Tensor(a!) xs, Tensor mask, Tensor(b!) obj) -> ()");
-    m.def("maxcut_ls_weights(int graph, Tensor xs, int mult, Tensor(a!) ws) -> ()");
+    m.def("maxcut_ls_weights(int graph, Tensor xs, int mult, Tensor(a!) ws, Tensor(b!)? ws_minmax) -> ()");
     m.def("maxcut_local_search(int graph, Tensor(a!) xs, Tensor ws, Tensor rd_std, Tensor? noise, int seed, int env_offset, int num_iters, "
           "int num_spin, bool first_draw_proposes, Tensor(b!) obj, bool compute_obj) -> ()");
     m.def("select_better_rows(Tensor(a!) xs0, Tensor(b!) vs0, Tensor xs1, Tensor vs1, bool if_maximize) -> ()");

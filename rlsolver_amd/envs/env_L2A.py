@@ -121,7 +121,7 @@ class EnvMaxcut:
         One pre-pass + ONE fused kernel when the library covers the shape (rls_maxcut_local_search_supported), else
         K2-weights + torch noise / kthvalue + K6 per round + K5."""
         B = xs.shape[0]
-        ws32, ws_span = ops.maxcut_ls_weights(self.graph, xs, weight_mult)     # exact integers in both env flavours
+        ws32, ws_span = ops.maxcut_ls_weights(self.graph, xs, weight_mult)     # exact integers (int8 / int16) in both env flavours
         rd_std = (ws_span.float() * noise_std).contiguous()
         if noise is not None:
             noise = noise.to(device=self.device, dtype=th.float32).contiguous()

@@ -250,13 +250,21 @@ def local_search_fusable(g: DeviceGraph, num_spin: int, B: int = 1) -> bool:
     return bool(_abi.lib().rls_maxcut_local_search_supported(g.ref, int(B), int(num_spin)))
 
 
-def maxcut_ls_weights(g: DeviceGraph, xs: TEN, mult: int):
-    """Pre-pass of the fused local search: (ws int32 [B,N], ws_std int32 [N] = max_b ws - min_b ws)."""
+def ls_weight_dtype(g: DeviceGraph, mult: int):
+    """Narrowest integer type that holds ws = deg - mult * cutdeg on this graph (|ws| <= max(1, mult - 1) * max degree): the
+    fused local search streams ws once per proposal round, so its width is that kernel's HBM traffic."""
+    span = g.csr.max_degree * max(1, int(mult) - 1)
+    return torch.int8 if span <= 127 else (torch.int16 if span <= 32767 else torch.int32)
+
+
+def maxcut_ls_weights(g: DeviceGraph, xs: TEN, mult: int, dtype=None):
+    """Pre-pass of the fused local search: (ws [B, N] int8 / int16 / int32 -- ``dtype`` or the narrowest that fits --,
+    ws_std int32 [N] = max_b ws - min_b ws, folded in by the same kernel)."""
     B, _ = _spins(xs, "xs", g)
-    ws = torch.empty((B, g.num_nodes), dtype=torch.int32, device=g.device)
-    _t.maxcut_ls_weights(g.handle, xs, int(mult), ws)
-    mn, mx = torch.aminmax(ws, dim=0)
-    return ws, mx - mn
+    ws = torch.empty((B, g.num_nodes), dtype=ls_weight_dtype(g, mult) if dtype is None else dtype, device=g.device)
+    mm = torch.empty((2, g.num_nodes), dtype=torch.int32, device=g.device)
+    _t.maxcut_ls_weights(g.handle, xs, int(mult), ws, mm)
+    return ws, mm[1] - mm[0]
 
 
 def maxcut_local_search(g: DeviceGraph, xs: TEN, ws: TEN, rd_std: TEN, obj: TEN, num_iters: int, num_spin: int,
@@ -264,7 +272,7 @@ def maxcut_local_search(g: DeviceGraph, xs: TEN, ws: TEN, rd_std: TEN, obj: TEN,
                         first_draw_proposes: bool = False, compute_obj: bool = False) -> None:
     """Fused local search (include/rlsolver_hip.h: rls_maxcut_local_search).  xs / obj in place."""
     B, _ = _spins(xs, "xs", g)
-    _check(ws, "ws", (torch.int32,), g.device, (B, g.num_nodes))
+    _check(ws, "ws", (torch.int8, torch.int16), g.device, (B, g.num_nodes))
     _check(rd_std, "rd_std", (torch.float32,), g.device, (g.num_nodes,))
     _check(obj, "obj", (torch.int64,), g.device, (B,))
     if noise is not None:

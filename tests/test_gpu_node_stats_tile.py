@@ -33,10 +33,41 @@ def test_tile_and_element_kernels_agree(n, m, B, weighted, bidir):
     assert np.array_equal(c_tile[sub].cpu().numpy(), onp.maxcut_node_cutdeg(xs[sub], graph, n, bool(bidir)))
     if not weighted:
         # local-search weights ws = stored_deg - mult * cutdeg through the same kernel family
+        # (int8 where the degrees fit a byte, any wider type on request) and its whole-batch span max_b - min_b per node,
+        # folded in by the same kernel; large batch (bit-sliced kernel), small batch (lane = env kernel), ragged last tile
+        deg = torch.from_numpy(np.bincount(g.csr.eu, minlength=n)).to(DEV)
         for mult in (1, 2):
-            ws = ops.maxcut_ls_weights(g, x, mult)[0]
-            deg = torch.from_numpy(np.bincount(g.csr.eu, minlength=n)).to(DEV)
-            assert torch.equal(ws.long(), deg[None, :] - mult * c_tile)
+            want = deg[None, :] - mult * c_tile
+            for dt in (None, torch.int8, torch.int16, torch.int32):
+                if dt == torch.int8 and g.csr.max_degree * max(1, mult - 1) > 127:
+                    with pytest.raises(RuntimeError):
+                        ops.maxcut_ls_weights(g, x, mult, dtype=dt)
+                    continue
+                for rows in (B, 1000, 1):
+                    ws, span = ops.maxcut_ls_weights(g, x[:rows].contiguous(), mult, dtype=dt)
+                    assert ws.dtype == (dt or ops.ls_weight_dtype(g, mult))
+                    assert torch.equal(ws.long(), want[:rows])
+                    mn, mx = torch.aminmax(want[:rows], dim=0)
+                    assert span.dtype == torch.int32 and torch.equal(span.long(), mx - mn), (mult, dt, rows)
+
+
+def test_ls_weights_hub_graph_int16_and_span():
+    """Degrees of 256 .. 511 (16 counter planes, 16-bit fields): ws leaves as int16, the span still comes with it."""
+    n, B = 700, 2048 + 5
+    graph = np.array([(0, j, 1) for j in range(1, 401)] + [(j, j + 1, 1) for j in range(1, 699)], dtype=np.int64)
+    g = device_graph(graph, n, 0)
+    assert ops.ls_weight_dtype(g, 2) == torch.int16
+    xs = ops.rand_spins(B, n, 11, DEV)
+    c = ops.maxcut_node_cutdeg(g, xs)
+    deg = torch.from_numpy(np.bincount(g.csr.eu, minlength=n)).to(DEV)
+    for mult in (1, 2):
+        ws, span = ops.maxcut_ls_weights(g, xs, mult)
+        want = deg[None, :] - mult * c
+        mn, mx = torch.aminmax(want, dim=0)
+        assert ws.dtype == torch.int16 and torch.equal(ws.long(), want) and torch.equal(span.long(), mx - mn)
+    # no envs: the span table is still initialised (max - min of nothing: INT32_MIN - INT32_MAX wraps to 1; callers skip B = 0)
+    ws0, _ = ops.maxcut_ls_weights(g, xs[:0].contiguous(), 1)
+    assert ws0.shape == (0, n)
 
 
 def test_hub_graph_falls_back_to_lane_env_kernel():
