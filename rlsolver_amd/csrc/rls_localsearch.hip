@@ -406,13 +406,14 @@ extern "C" int rls_maxcut_local_search(const rls_graph* g, uint8_t* x, int64_t B
                 "num_spin=%d outside [0, %d] (and < N)", num_spin, kTopCap - 1);
     RLS_REQUIRE(!g->wgt && g->max_degree < kRingMaxRun, RLS_EUNSUPPORTED,
                 "fused local search needs an unweighted graph with max degree < %d", kRingMaxRun);
-    const int W = ls_pick_waves(N, B);
+    // 16-byte row pieces of x, ws and noise: N % 16 == 0 and aligned bases
+    const bool aligned = tile_rows_aligned(x, N, 1) && ((((uintptr_t)ws) | ((uintptr_t)noise)) & 15) == 0;
+    int W = ls_pick_waves(N, B);
     RLS_REQUIRE(W != 0, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS (max %d)", (long long)N, ls_lds_bytes(N, 4), kLdsBytes);
+    if (!aligned) W = 4;                       // (the 4-wave layout is the smaller one: it fits whenever the 8-wave one does)
     const size_t lds = ls_lds_bytes(N, W);
     const int P = pick_planes(E);
     RLS_REQUIRE(P != 0, RLS_EUNSUPPORTED, "E'=%lld too large", (long long)E);
-    // 16-byte row pieces of x, ws and noise: N % 16 == 0 and aligned bases
-    const bool aligned = tile_rows_aligned(x, N, 1) && ((((uintptr_t)ws) | ((uintptr_t)noise)) & 15) == 0;
     const dim3 grid((unsigned)ceil_div(B, kWave)), block(W * kWave);
     hipStream_t s = as_stream(stream);
     const int halve = g->if_bidirectional ? 1 : 0;
@@ -426,24 +427,21 @@ extern "C" int rls_maxcut_local_search(const rls_graph* g, uint8_t* x, int64_t B
     const int64_t sw_len = batched == 2 ? g->num_sweep_groups : (batched ? g->nnz + N : g->nnz);
 #define LAUNCH_LSF(AL, WT, PP)                                                                                       \
     do {                                                                                                             \
-        auto kern = W == 8 ? k_maxcut_local_search<AL, WT, PP, 8> : k_maxcut_local_search<AL, WT, PP, 4>;              \
+        auto kern = (W == 8 && AL) ? k_maxcut_local_search<AL, WT, PP, AL ? 8 : 4> : k_maxcut_local_search<AL, WT, PP, 4>; \
         if (lds > 64 * 1024)                                                                                         \
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
         hipLaunchKernelGGL(kern, grid, block, lds, s, x, B, N, g->eu, g->ev, E, halve, rp_src, sw_src, sw_len,        \
                            (const WT*)ws, rd_std, noise, seed, env_offset, (int)num_iters, (int)num_spin,             \
                            (int)first_draw_proposes, obj, (int)compute_obj, batched);                                 \
     } while (0)
-#ifdef RLS_LS_ONE_P   /* dev builds (RLS_EXTRA_CFLAGS=-DRLS_LS_ONE_P): one counter width, a quarter of the compile time */
-#define DISPATCH_P(AL, WT) LAUNCH_LSF(AL, WT, 24);
-#else
+    // two counter widths (the 12- and 20-plane forms of the edge counter save a few carry steps per 1024 edges: not worth
+    // a second pair of 190 KB kernels each); rows that are not 16-byte multiples always take the 4-wave layout
 #define DISPATCH_P(AL, WT)                        \
     switch (P) {                                  \
-        case 12: LAUNCH_LSF(AL, WT, 12); break;   \
+        case 12:                                  \
         case 16: LAUNCH_LSF(AL, WT, 16); break;   \
-        case 20: LAUNCH_LSF(AL, WT, 20); break;   \
         default: LAUNCH_LSF(AL, WT, 24); break;   \
     }
-#endif
     if (ws_bytes == 1) { if (aligned) { DISPATCH_P(true, int8_t) } else { DISPATCH_P(false, int8_t) } }
     else               { if (aligned) { DISPATCH_P(true, int16_t) } else { DISPATCH_P(false, int16_t) } }
 #undef DISPATCH_P

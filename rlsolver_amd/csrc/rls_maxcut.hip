@@ -1269,7 +1269,11 @@ int rls_maxcut_ls_weights(const rls_graph* g, const uint8_t* x, int64_t B, int32
     RLS_REQUIRE(x && ws, RLS_EINVAL, "NULL pointer");
     if (ws_bytes == 1) return ls_weights_typed<int8_t>(g, x, B, mult, (int8_t*)ws, ws_minmax, stream);
     if (ws_bytes == 2) return ls_weights_typed<int16_t>(g, x, B, mult, (int16_t*)ws, ws_minmax, stream);
-    return ls_weights_typed<int32_t>(g, x, B, mult, (int32_t*)ws, ws_minmax, stream);
+    // 4-byte entries: only graphs with degrees beyond 32767 need them (and only the decomposed local search reads them):
+    // the element-parallel kernel, no tile variants
+    hipLaunchKernelGGL(k_ls_weights_elem<int32_t>, dim3(grid_for(B * g->num_nodes, 256)), dim3(256), 0, as_stream(stream), x, B,
+                       g->num_nodes, g->erowptr, g->ev, (int)mult, (int32_t*)ws, ws_minmax);
+    return check_launch("k_ls_weights_elem");
 }
 
 int rls_select_better_rows(uint8_t* xs0, int64_t* vs0, const uint8_t* xs1, const int64_t* vs1, int64_t B,

@@ -6,7 +6,7 @@
 //          gain = deg - 2c); weighted graphs a wave shuffle reduction.
 //   emit : the run is streamed with 16-byte vectors, the flipped spin patched in flight.
 //
-// Three emit structures are kept (A/B-able in one process through RLS_STEP_MODE):
+// Three emit structures (which one runs where: see the launcher):
 //   MODE 0  gain first (gathers from global), then copy           -- first version
 //   MODE 1  issue the copy's loads first, compute the gain while they fly, patch, store
 //   MODE 2  stage the run in LDS with direct global->LDS loads (no VGPR round trip), gather
@@ -270,15 +270,14 @@ __global__ __launch_bounds__(256) void k_maxcut_step(const T* __restrict__ xin, 
     }
 }
 
-// development knobs, read once per process (no getenv on the launch path).  mode default 12 = MODE 2 (LDS staged) with nontemporal LDS-DMA loads
-// (every input byte is read exactly once: 45.1 us vs 51.0 us per G22 launch), plain stores (nontemporal stores
-// lose 2 us); epw / wpb = 0: automatic
-struct StepKnobs { int mode, epw, wpb; };
+// development knobs, read once per process (no getenv on the launch path): nts = -1 automatic | 0 | 1 (nontemporal
+// stores), epw / wpb = 0: automatic
+struct StepKnobs { int nts, epw, wpb; };
 static StepKnobs read_step_knobs() {
-    const char* m = getenv("RLS_STEP_MODE");
+    const char* m = getenv("RLS_STEP_NTS");
     const char* e = getenv("RLS_STEP_EPW");
     const char* w = getenv("RLS_STEP_WPB");
-    return StepKnobs{m ? atoi(m) : 12, e ? atoi(e) : 0, w ? atoi(w) : 0};
+    return StepKnobs{m ? atoi(m) : -1, e ? atoi(e) : 0, w ? atoi(w) : 0};
 }
 static StepKnobs step_knobs() {
     static const bool reread = getenv("RLS_DEV_REREAD_ENV") != nullptr;   // tools/microbench.py, tools/sweep_step.py: A/B in one process
@@ -290,6 +289,16 @@ static StepKnobs step_knobs() {
 
 using namespace rls;
 
+// Structures in production (round 3; the A/B history is in DESIGN.md section 6):
+//   emit, vectorisable runs   MODE 2: the run staged in LDS by LDS-DMA with nontemporal loads (every input byte is read once),
+//                             up to the whole 160 KB of a CU per workgroup (f32 rows of 10^4 nodes: 2 waves x 40 KB);
+//                             stores nontemporal when the batch is larger than the 256 MB Infinity Cache (nothing of it
+//                             can still be there when the next step reads it: +3 points at G70 size), plain otherwise
+//                             (the next step's reads hit what this step wrote: +6 points at G22 size)
+//   emit, rows too long       MODE 1 (register batches, gathers from global), nontemporal stores
+//   emit, odd row lengths     MODE 0 element-wise
+//   in place                  O(deg) bytes
+// Unweighted graphs only: the reference's gym env counts cut EDGES (envs/env_PPO.py:108-121).
 extern "C" int rls_maxcut_step(const rls_graph* g, const void* x_in, void* x_out, int spin_bytes, int64_t B,
                                const int64_t* action, int32_t* obj, float* reward, float* cur, float* done,
                                float done_value, void* stream) {
@@ -298,6 +307,7 @@ extern "C" int rls_maxcut_step(const rls_graph* g, const void* x_in, void* x_out
     if (B == 0) return RLS_OK;
     RLS_REQUIRE(x_in && x_out && action && obj && reward, RLS_EINVAL, "x_in/x_out/action/obj/reward is NULL");
     RLS_REQUIRE(spin_bytes == 1 || spin_bytes == 4, RLS_EINVAL, "spin_bytes must be 1 or 4");
+    RLS_REQUIRE(!g->wgt, RLS_EUNSUPPORTED, "rls_maxcut_step counts cut edges (env_PPO.py:108-121): build the graph without weights");
     const int64_t N = g->num_nodes;
     const bool emit = (x_in != x_out);
     RLS_REQUIRE(!emit || (const char*)x_in + (size_t)B * N * spin_bytes <= (const char*)x_out ||
@@ -313,62 +323,44 @@ extern "C" int rls_maxcut_step(const rls_graph* g, const void* x_in, void* x_out
     const int epw = knobs.epw ? knobs.epw : (emit ? epw_auto : 4);   // in place: nothing is staged
     // flat runs of EPW rows start 16-byte aligned when one RUN is a multiple of 16 bytes
     const bool vec = ((((uintptr_t)x_in) | ((uintptr_t)x_out)) & 15) == 0 && ((int64_t)epw * N * spin_bytes) % 16 == 0;
-    const int waves_per_block = knobs.wpb ? knobs.wpb : 4;
+    const size_t run_bytes = (size_t)epw * N * spin_bytes;
+    // waves per workgroup: 4, fewer while the staged runs of a workgroup would take more than half a CU's LDS
+    int waves_per_block = knobs.wpb ? knobs.wpb : 4;
+    if (!knobs.wpb && emit && vec)
+        while (waves_per_block > 1 && (size_t)waves_per_block * run_bytes > (size_t)kLdsBytes / 2) waves_per_block >>= 1;
     const dim3 grid((unsigned)ceil_div(ceil_div(B, epw), waves_per_block)), block(waves_per_block * kWave);
     hipStream_t s = as_stream(stream);
-    const bool weighted = g->wgt != nullptr;
-    // mode: units = structure (0/1/2), tens = nontemporal loads, hundreds = nontemporal stores
-    const int mode = knobs.mode;
-    int structure = mode % 10;
-    const bool ntl = (mode / 10) % 10, nts = (mode / 100) % 10;
-    size_t lds = 0;
-    if (structure == 2) {
-        lds = (size_t)waves_per_block * epw * N * spin_bytes;
-        if (lds > 64 * 1024) { structure = 1; lds = 0; }  // rows too long to stage: register path
-    }
+    const bool staged = emit && vec && (size_t)waves_per_block * run_bytes <= (size_t)kLdsBytes;
+    const size_t lds = staged ? (size_t)waves_per_block * run_bytes : 0;
+    const bool nts = knobs.nts >= 0 ? knobs.nts != 0 : ((size_t)B * N * spin_bytes > ((size_t)256 << 20));
 
-#define LAUNCH_STEP_E(T, EPW, MODE, EMIT, VEC, W, NTL, NTS)                                                    \
-    hipLaunchKernelGGL((k_maxcut_step<T, EPW, MODE, EMIT, VEC, W, NTL, NTS>), grid, block, lds, s, (const T*)x_in, \
-                       (T*)x_out, B, N, g->rowptr, g->col, g->wgt, action, obj, reward, cur, done, done_value)
-#define LAUNCH_STEP(T, MODE, EMIT, VEC, W, NTL, NTS)                           \
-    do {                                                                       \
-        if (epw == 2) LAUNCH_STEP_E(T, 2, MODE, EMIT, VEC, W, NTL, NTS);       \
-        else if (epw == 8) LAUNCH_STEP_E(T, 8, MODE, EMIT, VEC, W, NTL, NTS);  \
-        else if (epw == 1) LAUNCH_STEP_E(T, 1, MODE, EMIT, VEC, W, NTL, NTS);  \
-        else LAUNCH_STEP_E(T, 4, MODE, EMIT, VEC, W, NTL, NTS);                \
+#define LAUNCH_STEP_E(T, EPW, MODE, EMIT, VEC, NTL, NTS)                                                       \
+    do {                                                                                                       \
+        auto kern = k_maxcut_step<T, EPW, MODE, EMIT, VEC, false, NTL, NTS>;                                   \
+        if (lds > 64 * 1024)                                                                                   \
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(kern, grid, block, lds, s, (const T*)x_in, (T*)x_out, B, N, g->rowptr, g->col, g->wgt, \
+                           action, obj, reward, cur, done, done_value);                                        \
     } while (0)
-#define DISPATCH_NT(T, MODE, W)                                                    \
-    do {                                                                           \
-        if (ntl && nts) LAUNCH_STEP(T, MODE, true, true, W, true, true);           \
-        else if (ntl) LAUNCH_STEP(T, MODE, true, true, W, true, false);            \
-        else if (nts) LAUNCH_STEP(T, MODE, true, true, W, false, true);            \
-        else LAUNCH_STEP(T, MODE, true, true, W, false, false);                    \
-    } while (0)
-#define DISPATCH_MODE(T, W)                                  \
-    do {                                                     \
-        if (structure == 0) DISPATCH_NT(T, 0, W);            \
-        else if (structure == 2) DISPATCH_NT(T, 2, W);       \
-        else DISPATCH_NT(T, 1, W);                           \
+#define LAUNCH_STEP(T, MODE, EMIT, VEC, NTL, NTS)                           \
+    do {                                                                    \
+        if (epw == 2) LAUNCH_STEP_E(T, 2, MODE, EMIT, VEC, NTL, NTS);       \
+        else if (epw == 8) LAUNCH_STEP_E(T, 8, MODE, EMIT, VEC, NTL, NTS);  \
+        else if (epw == 1) LAUNCH_STEP_E(T, 1, MODE, EMIT, VEC, NTL, NTS);  \
+        else LAUNCH_STEP_E(T, 4, MODE, EMIT, VEC, NTL, NTS);                \
     } while (0)
 #define DISPATCH_T(T)                                                                       \
     do {                                                                                    \
-        if (!emit) {                                                                        \
-            if (weighted) LAUNCH_STEP(T, 0, false, false, true, false, false);              \
-            else LAUNCH_STEP(T, 0, false, false, false, false, false);                      \
-        } else if (!vec) {                                                                  \
-            if (weighted) LAUNCH_STEP(T, 0, true, false, true, false, false);               \
-            else LAUNCH_STEP(T, 0, true, false, false, false, false);                       \
-        } else if (weighted) {                                                              \
-            DISPATCH_MODE(T, true);                                                         \
-        } else {                                                                            \
-            DISPATCH_MODE(T, false);                                                        \
-        }                                                                                   \
+        if (!emit) LAUNCH_STEP_E(T, 4, 0, false, false, false, false);                      \
+        else if (!vec) LAUNCH_STEP(T, 0, true, false, false, false);                        \
+        else if (!staged) LAUNCH_STEP(T, 1, true, true, false, true);                       \
+        else if (nts) LAUNCH_STEP(T, 2, true, true, true, true);                            \
+        else LAUNCH_STEP(T, 2, true, true, true, false);                                    \
     } while (0)
+    RLS_REQUIRE(emit || epw == 4, RLS_EINVAL, "the in-place step runs 4 envs per wave");
     if (spin_bytes == 1) DISPATCH_T(uint8_t);
     else DISPATCH_T(float);
 #undef DISPATCH_T
-#undef DISPATCH_MODE
-#undef DISPATCH_NT
 #undef LAUNCH_STEP
 #undef LAUNCH_STEP_E
     return check_launch("k_maxcut_step");

@@ -375,3 +375,44 @@ def test_node_stats_on_hub_graphs(case):
             rows = [0, 1, B - 1]
             assert np.array_equal(ops.maxcut_node_cutdeg(g, xs)[rows].cpu().numpy(),
                                   onp.maxcut_node_cutdeg(xs[rows].cpu().numpy(), graph, n, bool(bidir)))
+
+
+@pytest.mark.parametrize("dtype,B", [(torch.bool, 27001), (torch.float32, 7001), (torch.float32, 300)])
+def test_step_long_rows_staged_beyond_64k_and_nontemporal_stores(dtype, B):
+    """K4 on rows of 10^4 nodes: f32 rows (40 KB) are staged with two waves per workgroup (80 KB of LDS, opted in past
+    the 64 KB default); a batch larger than the 256 MB Infinity Cache (27 001 x 10^4 bytes; 7 001 x 40 KB) leaves through
+    nontemporal stores.  Checked by what does not need a CPU oracle at this size: the next state is the state with
+    exactly the action's spin flipped, reward = the change of the recomputed cut, obj stays the recomputed cut;
+    ragged last workgroup; an out-of-range action leaves its env alone (reward NaN)."""
+    n = 10000
+    graph = gnm_arr(n, 9999, seed=70)
+    g = device_graph(graph, n, 0)
+    x = ops.rand_spins(B, n, 5, DEV)
+    x = x.float() if dtype == torch.float32 else x
+    obj0 = ops.maxcut_obj(g, x)
+    obj = obj0.to(torch.int32)
+    act = ops.rand_actions(B, n, 3, 0, DEV)
+    act[B // 2] = n + 5
+    y = torch.empty_like(x)
+    rew = torch.empty(B, dtype=torch.float32, device=DEV)
+    ops.maxcut_step(g, x, y, act, obj, rew)
+    ok = torch.ones(B, dtype=torch.bool, device=DEV)
+    ok[B // 2] = False
+    diff = (x != y)
+    assert torch.equal(diff.sum(dim=1), ok.long())
+    rows = torch.nonzero(ok).flatten()
+    assert bool(diff[rows, act[rows]].all())
+    obj1 = ops.maxcut_obj(g, y)
+    assert torch.equal(obj.long(), obj1)
+    assert torch.equal(rew[rows], (obj1 - obj0)[rows].float()) and bool(torch.isnan(rew[B // 2]))
+
+
+def test_step_refuses_weighted_graphs(golden):
+    """The gym env counts cut EDGES (env_PPO.py:108-121): a weighted graph handle is refused, not silently counted."""
+    z = golden("weighted_gain")
+    g = device_graph(z["graph"], 100, 0, use_weights=True)
+    x = to_dev_bool(z["xs"])
+    B = x.shape[0]
+    with pytest.raises(RuntimeError, match="counts cut edges"):
+        ops.maxcut_step(g, x, torch.empty_like(x), torch.zeros(B, dtype=torch.int64, device=DEV),
+                        torch.zeros(B, dtype=torch.int32, device=DEV), torch.empty(B, device=DEV))
