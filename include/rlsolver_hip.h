@@ -274,13 +274,24 @@ typedef struct rls_spin_env {
     uint64_t* hist;        /* [B, hist_cap, W] the state after each earlier step of the episode */
     uint64_t* hist_hash;   /* [B, hist_cap] */
     int64_t hist_cap;
+    /* the rows a step changes EVERYWHERE are not stored between observations (a step is O(deg)): */
+    int32_t* last_flip;    /* [B, N] the step (1-based) at which the node last flipped in this episode, 0 = not yet */
+    void* scalars;         /* T [B, 4] current value of the rows TERMINATION_IMMANENCY, NUMBER_OF_GREEDY_ACTIONS_AVAILABLE,
+                            * DISTANCE_FROM_BEST_SCORE, DISTANCE_FROM_BEST_STATE */
+    const void* time_table;/* T [table_len]: time_table[k] = 0 + inc + inc + ... (k additions in T, inc = (T)(1 / max_steps)):
+                            * what `state[TIME_SINCE_FLIP] += 1. / max_steps` (spinsystem_PECO.py:417) has accumulated after k steps */
+    int64_t table_len;     /* >= max_steps + 1 */
 } rls_spin_env;
 
-/* reset()  spinsystem_PECO.py:150-195 / spinsystem.py:176-252, after the caller has written the signed spins into
+/* State rows: row 0 (signed spins) and the IMMEDIATE_REWARD_AVAILABLE row of `state` are current after every call; the
+ * other observable rows are written by rls_spin_reset, and after steps on demand: rls_spin_observation builds them
+ * straight into the observation, rls_spin_materialize writes them into `state`.
+ *
+ * reset()  spinsystem_PECO.py:150-195 / spinsystem.py:176-252, after the caller has written the signed spins into
  * row 0 of state and their gains into delta (rls_maxcut_delta_all on the spins as bits: the two definitions
  * coincide).  Fills the IMMEDIATE_REWARD_AVAILABLE and NUMBER_OF_GREEDY_ACTIONS_AVAILABLE rows, zeroes the other
  * rows, score = best_score = cut = (weight_sum - sum_i delta_i) / 4 with weight_sum = sum of W over ORDERED pairs,
- * best_spins = spins, num_nonpos, dist_best = 0, packed / hash (the history starts empty: hist_len = 0).
+ * best_spins = spins, num_nonpos, dist_best = 0, last_flip = 0, scalars, packed / hash (the history starts empty: hist_len = 0).
  * row_index [host] int32[7]: as rls_spin_step. */
 int rls_spin_reset(const rls_graph* g, const rls_spin_env* env, int state_bytes, int64_t B, int32_t num_rows,
                    const int32_t* row_index, double max_local, int64_t weight_sum, void* stream);
@@ -291,8 +302,9 @@ int rls_spin_reset(const rls_graph* g, const rls_spin_env* env, int state_bytes,
  * 1 BLS = max(score - best_before, 0), 2 CUSTOM_BLS = impr / (impr + 0.1)), divided by reward_div (n_spins under
  * norm_rewards, else 1); visited-state test against the hist_len earlier states of the episode and append
  * (when env->packed): reward -= stag_punishment on a revisit (use_stag), reward += basin_reward on a first
- * visit of a state with no improving flip (use_basin); best_score / best_spins tracking; observable rows of
- * state written in place.  row_index [host] int32[7] gives the row of IMMEDIATE_REWARD_AVAILABLE,
+ * visit of a state with no improving flip (use_basin); best_score / best_spins tracking; last_flip[b, a] = hist_len + 1
+ * (hist_len = the number of steps already taken this episode, also without the visited-state memory) and the four
+ * scalars.  row_index [host] int32[7] gives the row of IMMEDIATE_REWARD_AVAILABLE,
  * TIME_SINCE_FLIP, EPISODE_TIME, TERMINATION_IMMANENCY, NUMBER_OF_GREEDY_ACTIONS_AVAILABLE,
  * DISTANCE_FROM_BEST_SCORE, DISTANCE_FROM_BEST_STATE in state (-1 = not observed; row 0 is always the signed
  * spins).  reward T [B]; visited_new uint8 [B] or NULL (1 = state not seen before).  The scalar parameters are
@@ -300,7 +312,7 @@ int rls_spin_reset(const rls_graph* g, const rls_spin_env* env, int state_bytes,
  * untouched and yields reward = NaN.  g->wgt = integer weights or NULL. */
 int rls_spin_step(const rls_graph* g, const rls_spin_env* env, int state_bytes, int64_t B, int32_t num_rows,
                   const int32_t* row_index, const int64_t* action, void* reward, uint8_t* visited_new, double max_local,
-                  double time_inc, double termination_value, int32_t reward_mode, double reward_div, int64_t hist_len,
+                  double termination_value, int32_t reward_mode, double reward_div, int64_t hist_len,
                   int32_t use_stag, double stag_punishment, int32_t use_basin, double basin_reward, void* stream);
 
 /* The same env with PER-ENV couplings: the training envs of spinsystem_PECO.py hold matrix T [B, N, N], redrawn by the graph
@@ -319,7 +331,7 @@ int rls_spin_reset_dense(const void* matrix, const rls_spin_env* env, int state_
 /* rls_spin_step with matrix T [B, N, N] and max_local T [B] (as rls_spin_reset_dense left them) in place of the shared graph. */
 int rls_spin_step_dense(const void* matrix, const void* max_local, const rls_spin_env* env, int state_bytes, int64_t B, int64_t N,
                         int32_t num_rows, const int32_t* row_index, const int64_t* action, void* reward, uint8_t* visited_new,
-                        double time_inc, double termination_value, int32_t reward_mode, double reward_div, int64_t hist_len,
+                        double termination_value, int32_t reward_mode, double reward_div, int64_t hist_len,
                         int32_t use_stag, double stag_punishment, int32_t use_basin, double basin_reward, void* stream);
 
 /* The graph generators of the training envs  ECO_S2V/src/envs/util_envs_PECO.py:15-112 in one launch: matrix T [B, N, N]
@@ -335,12 +347,20 @@ int rls_rand_couplings(void* matrix, int state_bytes, int64_t B, int64_t N, int3
                        int32_t edge_type, uint64_t seed, int64_t env_offset, void* stream);
 
 /* get_observation()  ECO_S2V/src/envs/spinsystem_PECO.py:455,497 (cat(state, matrix_obs)) and spinsystem.py:484-495
- * (vstack(state, matrix)): out T [B, num_rows + N, N] = the num_rows observable rows of state T [B, num_rows, N], row 0
- * mapped from signed spins to (1 - s) / 2 when binary_basis (SpinBasis.BINARY), followed by the N rows of the matrix:
- * T [N, N] shared by all envs (matrix_per_env = 0) or T [B, N, N] (matrix_per_env = 1); matrix NULL: out = [B, num_rows, N]
- * (the rows only).  One streaming pass, nothing else touched. */
-int rls_spin_observation(const void* state, const void* matrix, int32_t matrix_per_env, int state_bytes, int64_t B,
-                         int32_t num_rows, int64_t N, int32_t binary_basis, void* out, void* stream);
+ * (vstack(state, matrix)): out T [B, num_rows + N, N] = the num_rows observable rows as the reference's state tensor holds
+ * them after step_index steps of the episode (row 0 mapped from signed spins to (1 - s) / 2 when binary_basis,
+ * SpinBasis.BINARY; the rows a step does not store built from last_flip / time_table / scalars), followed by the N
+ * rows of the matrix: T [N, N] shared by all envs (matrix_per_env = 0) or T [B, N, N] (matrix_per_env = 1); matrix NULL:
+ * out = [B, num_rows, N] (the rows only).  One streaming pass, nothing else touched. */
+int rls_spin_observation(const rls_spin_env* env, const void* matrix, int32_t matrix_per_env, int state_bytes, int64_t B,
+                         int32_t num_rows, int64_t N, const int32_t* row_index, int64_t step_index, int32_t binary_basis, void* out,
+                         void* stream);
+
+/* Writes the rows a step does not store (TIME_SINCE_FLIP, EPISODE_TIME, TERMINATION_IMMANENCY, NUMBER_OF_GREEDY_ACTIONS_
+ * AVAILABLE, DISTANCE_FROM_BEST_SCORE, DISTANCE_FROM_BEST_STATE) into env->state as the reference holds them after
+ * step_index steps: for callers that read the state tensor itself (spinsystem.py's `env.state`). */
+int rls_spin_materialize(const rls_spin_env* env, int state_bytes, int64_t B, int64_t N, int32_t num_rows, const int32_t* row_index,
+                         int64_t step_index, void* stream);
 
 /* -------------------------------------------------------------------- MCPG */
 /* Layouts of a batch of C chains:

@@ -60,8 +60,9 @@ _G = C.POINTER(RlsGraph)
 
 class RlsSpinEnv(C.Structure):
     """struct rls_spin_env (host struct of device pointers)."""
-    _fields_ = [(n, C.c_void_p) for n in ("state", "delta", "score", "best_score", "best_spins", "num_nonpos", "dist_best",
-                                          "packed", "hash", "hist", "hist_hash")] + [("hist_cap", C.c_int64)]
+    _fields_ = ([(n, C.c_void_p) for n in ("state", "delta", "score", "best_score", "best_spins", "num_nonpos", "dist_best",
+                                           "packed", "hash", "hist", "hist_hash")] + [("hist_cap", C.c_int64)]
+                + [(n, C.c_void_p) for n in ("last_flip", "scalars", "time_table")] + [("table_len", C.c_int64)])
 
 
 _SE = C.POINTER(RlsSpinEnv)
@@ -88,13 +89,14 @@ SIGNATURES = {
     "rls_pick_best_of_repeats": [_P, _P, _I64, _I64, _I64, _INT, _P, _P, _P],
     "rls_rand_spins": [_P, _I64, _I64, _U64, _I64, _P],
     "rls_rand_actions": [_P, _I64, _I64, _U64, _U64, _I64, _P],
-    "rls_spin_observation": [_P, _P, C.c_int32, _INT, _I64, C.c_int32, _I64, C.c_int32, _P, _P],
+    "rls_spin_observation": [_SE, _P, C.c_int32, _INT, _I64, C.c_int32, _I64, _P, _I64, C.c_int32, _P, _P],
+    "rls_spin_materialize": [_SE, _INT, _I64, _I64, C.c_int32, _P, _I64, _P],
     "rls_rand_couplings": [_P, _INT, _I64, _I64, C.c_int32, _F64, C.c_int32, C.c_int32, _U64, _I64, _P],
     "rls_spin_reset_dense": [_P, _SE, _INT, _I64, _I64, C.c_int32, _P, _P, _P, _P, _P],
-    "rls_spin_step_dense": [_P, _P, _SE, _INT, _I64, _I64, C.c_int32, _P, _P, _P, _P, _F64, _F64, C.c_int32, _F64, _I64, C.c_int32, _F64,
+    "rls_spin_step_dense": [_P, _P, _SE, _INT, _I64, _I64, C.c_int32, _P, _P, _P, _P, _F64, C.c_int32, _F64, _I64, C.c_int32, _F64,
                             C.c_int32, _F64, _P],
     "rls_spin_reset": [_G, _SE, _INT, _I64, C.c_int32, _P, _F64, _I64, _P],
-    "rls_spin_step": [_G, _SE, _INT, _I64, C.c_int32, _P, _P, _P, _P, _F64, _F64, _F64, C.c_int32, _F64, _I64, C.c_int32, _F64,
+    "rls_spin_step": [_G, _SE, _INT, _I64, C.c_int32, _P, _P, _P, _P, _F64, _F64, C.c_int32, _F64, _I64, C.c_int32, _F64,
                       C.c_int32, _F64, _P],
     "rls_mcpg_metro_rounds": [_P, _P, _I64, _INT, _I64, _I64, _P, _I64, _I64, _P, _P, _U64, _P, _INT, _P, _I64, _P],
     "rls_mcpg_local_search": [_G, _P, _INT, _P, _I64, _P, _P, _I64, _I64, _P, _U64, _P, _I64, _P, _P],

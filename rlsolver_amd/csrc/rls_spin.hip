@@ -12,10 +12,15 @@
 //   num_nonpos[b] = #{i : delta_i <= 0}  (greedy-actions observable, basin test)
 //   dist_best[b]  = Hamming distance to best_spins
 //   packed[b,:], hash[b]                 bit-packed spins + their Zobrist hash (visited-state memory)
-// and only the entries of the IMMEDIATE_REWARD_AVAILABLE row that changed are rewritten.  What is left per
-// step is what the observation contract itself makes O(N): time-since-flip (+= 1/max_steps everywhere) and the
-// four broadcast rows (termination, greedy count, distance from best score / state): 6 * sizeof(T) * N bytes
-// per env-step with the ECO observables, streamed with 16-byte lanes.
+// and only the entries of the IMMEDIATE_REWARD_AVAILABLE row that changed are rewritten.  The rows the observation
+// contract changes EVERYWHERE every step are not stored at all between observations:
+//   time-since-flip / episode time   the reference adds fl(1/max_steps) to the row every step and zeroes the flipped entry:
+//                                     after k such additions an entry holds time_table[k] (the same float additions, done
+//                                     once on the host), k = step - last_flip[b, n]  -- last_flip int32 [B, N], one store per step
+//   termination, greedy count, distance from best score / state      four per-env scalars (env.scalars)
+// rls_spin_observation materialises them straight into the observation it has to write anyway; rls_spin_materialize
+// writes them into `state` for whoever reads that tensor.  A step is O(deg): it was 6 * sizeof(T) * N bytes per env
+// (250 us for 2^14 envs of a G22-sized graph, 38 us of which were the O(deg) chain).
 //
 // One wave per env.
 #include "rls_tile.h"
@@ -46,45 +51,8 @@ __device__ __forceinline__ uint64_t wave_xor_u64(uint64_t v) {
     return v;
 }
 
-// row[n] = f(n, row[n]) for all n; 16-byte lanes when VEC
-template <typename T, bool VEC, typename F>
-__device__ __forceinline__ void row_update(T* __restrict__ row, int64_t N, int lane, F f) {
-    if constexpr (VEC) {
-        using V = typename RowVec<T>::type;
-        constexpr int PER = RowVec<T>::n;
-        V* rv = reinterpret_cast<V*>(row);
-        const int64_t nv = N / PER;
-#pragma unroll 2
-        for (int64_t i = lane; i < nv; i += kWave) {
-            V v = rv[i];
-#pragma unroll
-            for (int q = 0; q < PER; ++q) v[q] = f(i * PER + q, v[q]);
-            rv[i] = v;
-        }
-    } else {
-        for (int64_t n = lane; n < N; n += kWave) row[n] = f(n, row[n]);
-    }
-}
-
-template <typename T, bool VEC>
-__device__ __forceinline__ void row_fill(T* __restrict__ row, int64_t N, int lane, T value) {
-    if constexpr (VEC) {
-        using V = typename RowVec<T>::type;
-        constexpr int PER = RowVec<T>::n;
-        V* rv = reinterpret_cast<V*>(row);
-        V v;
-#pragma unroll
-        for (int q = 0; q < PER; ++q) v[q] = value;
-        const int64_t nv = N / PER;
-#pragma unroll 4
-        for (int64_t i = lane; i < nv; i += kWave) rv[i] = v;
-    } else {
-        for (int64_t n = lane; n < N; n += kWave) row[n] = value;
-    }
-}
-
 struct SpinStepArgs {
-    double max_local, time_inc, termination_value, reward_div, stag_punishment, basin_reward;
+    double max_local, termination_value, reward_div, stag_punishment, basin_reward;
     int reward_mode, use_stag, use_basin;
     int64_t hist_len;
 };
@@ -117,7 +85,7 @@ __global__ __launch_bounds__(256) void k_spin_step(rls_spin_env env, int64_t B, 
         }
         return;
     }
-    const T max_local = DENSE ? max_local_env[b] : (T)p.max_local, time_inc = (T)p.time_inc;
+    const T max_local = DENSE ? max_local_env[b] : (T)p.max_local;
 
     // 1. flip + score change (spinsystem_PECO.py:336-348): gain = delta[a] before the flip.  Neighbour updates
     //    are returning L2 atomics (multi-edges may hit one node twice in a wave-instruction): every lane sees
@@ -253,17 +221,16 @@ __global__ __launch_bounds__(256) void k_spin_step(rls_spin_env env, int64_t B, 
         ham = env.dist_best[b] + ((bs[a] != s_new) ? 1 : -1);
     }
 
-    // 5. the rows that change everywhere every step (:412-451)
-    if (rows.time_since_flip >= 0)
-        row_update<T, VEC>(st + (int64_t)rows.time_since_flip * N, N, lane,
-                           [&](int64_t n, T v) { return n == a ? (T)0 : v + time_inc; });
-    if (rows.episode_time >= 0)
-        row_update<T, VEC>(st + (int64_t)rows.episode_time * N, N, lane, [&](int64_t, T v) { return v + time_inc; });
-    if (rows.termination >= 0) row_fill<T, VEC>(st + (int64_t)rows.termination * N, N, lane, (T)p.termination_value);
-    if (rows.greedy >= 0) row_fill<T, VEC>(st + (int64_t)rows.greedy * N, N, lane, (T)1 - (T)nonpos / (T)N);
-    if (rows.dist_score >= 0)
-        row_fill<T, VEC>(st + (int64_t)rows.dist_score * N, N, lane, (T)fabs((double)(sc - best_now)) / max_local);
-    if (rows.dist_state >= 0) row_fill<T, VEC>(st + (int64_t)rows.dist_state * N, N, lane, (T)ham);
+    // 5. the rows that change everywhere every step (:412-451) are a table lookup away: remember when a flipped and the four
+    //    broadcast values; rls_spin_observation / rls_spin_materialize write the rows
+    if (lane == 0) {
+        env.last_flip[b * N + a] = (int32_t)(p.hist_len + 1);
+        T* sc4 = reinterpret_cast<T*>(env.scalars) + b * 4;
+        sc4[0] = (T)p.termination_value;
+        sc4[1] = (T)1 - (T)nonpos / (T)N;
+        sc4[2] = (T)fabs((double)(sc - best_now)) / max_local;
+        sc4[3] = (T)ham;
+    }
     if (lane == 0) {
         score[b] = sc;
         best_score[b] = best_now;
@@ -311,6 +278,11 @@ __global__ __launch_bounds__(256) void k_spin_reset(rls_spin_env env, int64_t B,
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) dsum += __shfl_xor(dsum, m, 64);
     const T greedy = (T)1 - (T)nonpos / (T)N;
+    for (int64_t n = lane; n < N; n += kWave) env.last_flip[b * N + n] = 0;
+    if (lane == 0) {
+        T* sc4 = reinterpret_cast<T*>(env.scalars) + b * 4;
+        sc4[0] = (T)0; sc4[1] = greedy; sc4[2] = (T)0; sc4[3] = (T)0;
+    }
     for (int r = 1; r < R; ++r) {
         T* row = st + (int64_t)r * N;
         for (int64_t n = lane; n < N; n += kWave) {
@@ -491,32 +463,99 @@ __global__ __launch_bounds__(kWave) void k_rand_couplings_ba(T* __restrict__ mat
     }
 }
 
-// get_observation (spinsystem_PECO.py:455 / spinsystem.py:484-495): out[b] = rows of state[b] (row 0 mapped from signed to
-// {0, 1} spins under SpinBasis.BINARY: (1 - s) / 2) followed by the N rows of the shared matrix.  One streaming pass:
-// the reference clones the state, rewrites row 0 and concatenates a [B, N, N] expansion of the matrix.
+// The value of observable row rr of env b at columns c .. c + PER - 1 as the reference's state tensor would hold it after
+// `step` steps: resident rows (spins, immediate reward, anything this kernel family does not know) come from `state`, the
+// others from last_flip / time_table / scalars (see the header of this file).
+template <typename T, int PER>
+__device__ __forceinline__ void spin_row_values(const rls_spin_env& env, const SpinRows& rows, int64_t b, int R, int64_t N, int64_t rr,
+                                                int64_t c, int64_t step, T (&v)[PER]) {
+    const T* table = reinterpret_cast<const T*>(env.time_table);
+    const T* sc4 = reinterpret_cast<const T*>(env.scalars) + b * 4;
+    if (rr == rows.time_since_flip) {
+        const int32_t* lf = env.last_flip + b * N + c;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) v[q] = table[step - lf[q]];
+    } else if (rr == rows.episode_time) {
+#pragma unroll
+        for (int q = 0; q < PER; ++q) v[q] = table[step];
+    } else if (rr == rows.termination || rr == rows.greedy || rr == rows.dist_score || rr == rows.dist_state) {
+        const T x = sc4[rr == rows.termination ? 0 : (rr == rows.greedy ? 1 : (rr == rows.dist_score ? 2 : 3))];
+#pragma unroll
+        for (int q = 0; q < PER; ++q) v[q] = x;
+    } else {
+        const T* src = reinterpret_cast<const T*>(env.state) + (b * R + rr) * N + c;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) v[q] = src[q];
+    }
+}
+
+// get_observation (spinsystem_PECO.py:455 / spinsystem.py:484-495): out[b] = the R observable rows of env b (row 0 mapped
+// from signed to {0, 1} spins under SpinBasis.BINARY: (1 - s) / 2) followed by the N rows of the matrix.  One streaming
+// pass: the reference clones the state, rewrites row 0 and concatenates a [B, N, N] expansion of the matrix.
 template <typename T, bool V4>
-__global__ __launch_bounds__(256) void k_spin_observation(const T* __restrict__ state, const T* __restrict__ matrix,
+__global__ __launch_bounds__(256) void k_spin_observation(rls_spin_env env, SpinRows rows, int64_t step, const T* __restrict__ matrix,
                                                            int64_t matrix_env_stride, int64_t B, int R, int64_t N, int binary,
                                                            T* __restrict__ out) {
     constexpr int PER = V4 ? (int)(16 / sizeof(T)) : 1;
-    const int64_t rows = R + (matrix ? N : 0), per_row = N / PER, per_env = rows * per_row;
+    const int64_t nrows = R + (matrix ? N : 0), per_row = N / PER, per_env = nrows * per_row;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= per_env) return;
     const int64_t rr = idx / per_row, c = (idx - rr * per_row) * PER;
     using V = typename RowVec<T>::type;
     for (int64_t b = blockIdx.y; b < B; b += gridDim.y) {
-        const T* src = rr < R ? state + (b * R + rr) * N + c : matrix + b * matrix_env_stride + (rr - R) * N + c;
-        T* dst = out + (b * rows + rr) * N + c;
-        if constexpr (V4) {
-            V v = *reinterpret_cast<const V*>(src);
+        T v[PER];
+        if (rr < R) {
+            spin_row_values<T, PER>(env, rows, b, R, N, rr, c, step, v);
             if (binary && rr == 0) {
 #pragma unroll
                 for (int q = 0; q < PER; ++q) v[q] = ((T)1 - v[q]) / (T)2;
             }
-            *reinterpret_cast<V*>(dst) = v;
         } else {
-            const T v = src[0];
-            dst[0] = (binary && rr == 0) ? ((T)1 - v) / (T)2 : v;
+            const T* src = matrix + b * matrix_env_stride + (rr - R) * N + c;
+            if constexpr (V4) {
+                const V m = *reinterpret_cast<const V*>(src);
+#pragma unroll
+                for (int q = 0; q < PER; ++q) v[q] = m[q];
+            } else {
+                v[0] = src[0];
+            }
+        }
+        T* dst = out + (b * nrows + rr) * N + c;
+        if constexpr (V4) {
+            V o;
+#pragma unroll
+            for (int q = 0; q < PER; ++q) o[q] = v[q];
+            *reinterpret_cast<V*>(dst) = o;
+        } else {
+            dst[0] = v[0];
+        }
+    }
+}
+
+// The rows that a step does not store, written into `state` for whoever reads that tensor (rls_spin_materialize).
+template <typename T, bool V4>
+__global__ __launch_bounds__(256) void k_spin_materialize(rls_spin_env env, SpinRows rows, int64_t step, int64_t B, int R, int64_t N) {
+    constexpr int PER = V4 ? (int)(16 / sizeof(T)) : 1;
+    const int64_t per_row = N / PER;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= per_row) return;
+    const int64_t c = idx * PER;
+    const int64_t rr = blockIdx.y;   // one of the six lazy rows
+    const int which[6] = {rows.time_since_flip, rows.episode_time, rows.termination, rows.greedy, rows.dist_score, rows.dist_state};
+    const int r = which[rr];
+    if (r < 0) return;
+    using V = typename RowVec<T>::type;
+    for (int64_t b = blockIdx.z; b < B; b += gridDim.z) {
+        T v[PER];
+        spin_row_values<T, PER>(env, rows, b, R, N, r, c, step, v);
+        T* dst = reinterpret_cast<T*>(env.state) + (b * R + r) * N + c;
+        if constexpr (V4) {
+            V o;
+#pragma unroll
+            for (int q = 0; q < PER; ++q) o[q] = v[q];
+            *reinterpret_cast<V*>(dst) = o;
+        } else {
+            dst[0] = v[0];
         }
     }
 }
@@ -531,7 +570,7 @@ static int check_spin_env(const rls_spin_env* env, int state_bytes, int32_t num_
     RLS_REQUIRE(state_bytes == 4 || state_bytes == 8, RLS_EINVAL, "state_bytes must be 4 (f32) or 8 (f64)");
     RLS_REQUIRE(num_rows >= 1, RLS_EINVAL, "num_rows < 1");
     RLS_REQUIRE(env->state && env->delta && env->score && env->best_score && env->best_spins && env->num_nonpos &&
-                    env->dist_best, RLS_EINVAL, "NULL pointer in rls_spin_env");
+                    env->dist_best && env->last_flip && env->scalars && env->time_table, RLS_EINVAL, "NULL pointer in rls_spin_env");
     RLS_REQUIRE(!env->packed || (env->hash && env->hist && env->hist_hash && env->hist_cap > 0), RLS_EINVAL,
                 "visited-state memory needs packed, hash, hist, hist_hash and hist_cap > 0");
     *rows = SpinRows{row_index[0], row_index[1], row_index[2], row_index[3], row_index[4], row_index[5], row_index[6]};
@@ -585,7 +624,7 @@ int rls_spin_reset_dense(const void* matrix, const rls_spin_env* env, int state_
 
 static int spin_step_common(const rls_graph* g, const void* matrix, const void* max_local_env, int64_t N, const rls_spin_env* env,
                             int state_bytes, int64_t B, int32_t num_rows, const int32_t* row_index, const int64_t* action,
-                            void* reward, uint8_t* visited_new, double max_local, double time_inc, double termination_value,
+                            void* reward, uint8_t* visited_new, double max_local, double termination_value,
                             int32_t reward_mode, double reward_div, int64_t hist_len, int32_t use_stag, double stag_punishment,
                             int32_t use_basin, double basin_reward, void* stream) {
     RLS_REQUIRE(B >= 0, RLS_EINVAL, "B < 0");
@@ -598,8 +637,10 @@ static int spin_step_common(const rls_graph* g, const void* matrix, const void* 
     RLS_REQUIRE(!(use_stag || use_basin) || env->packed, RLS_EINVAL, "stag_punishment / basin_reward need the visited-state memory");
     RLS_REQUIRE(!env->packed || (hist_len >= 0 && hist_len < env->hist_cap), RLS_EINVAL,
                 "hist_len %lld outside [0, hist_cap = %lld)", (long long)hist_len, (long long)env->hist_cap);
+    RLS_REQUIRE(hist_len >= 0 && hist_len + 1 < env->table_len, RLS_EINVAL, "step %lld outside the time table of %lld entries",
+                (long long)hist_len + 1, (long long)env->table_len);
     const bool vec = ((((uintptr_t)env->state) | ((uintptr_t)env->best_spins)) & 15) == 0 && (N * state_bytes) % 16 == 0;
-    SpinStepArgs p{max_local, time_inc, termination_value, reward_div, stag_punishment, basin_reward,
+    SpinStepArgs p{max_local, termination_value, reward_div, stag_punishment, basin_reward,
                    reward_mode, use_stag, use_basin, hist_len};
     const dim3 grid((unsigned)ceil_div(B, 4)), block(256);
     hipStream_t s = as_stream(stream);
@@ -620,22 +661,22 @@ static int spin_step_common(const rls_graph* g, const void* matrix, const void* 
 
 int rls_spin_step(const rls_graph* g, const rls_spin_env* env, int state_bytes, int64_t B, int32_t num_rows,
                   const int32_t* row_index, const int64_t* action, void* reward, uint8_t* visited_new, double max_local,
-                  double time_inc, double termination_value, int32_t reward_mode, double reward_div, int64_t hist_len,
+                  double termination_value, int32_t reward_mode, double reward_div, int64_t hist_len,
                   int32_t use_stag, double stag_punishment, int32_t use_basin, double basin_reward, void* stream) {
     if (int rc = check_graph(g)) return rc;
     return spin_step_common(g, nullptr, nullptr, g->num_nodes, env, state_bytes, B, num_rows, row_index, action, reward, visited_new,
-                            max_local, time_inc, termination_value, reward_mode, reward_div, hist_len, use_stag, stag_punishment,
+                            max_local, termination_value, reward_mode, reward_div, hist_len, use_stag, stag_punishment,
                             use_basin, basin_reward, stream);
 }
 
 int rls_spin_step_dense(const void* matrix, const void* max_local, const rls_spin_env* env, int state_bytes, int64_t B, int64_t N,
                         int32_t num_rows, const int32_t* row_index, const int64_t* action, void* reward, uint8_t* visited_new,
-                        double time_inc, double termination_value, int32_t reward_mode, double reward_div, int64_t hist_len,
+                        double termination_value, int32_t reward_mode, double reward_div, int64_t hist_len,
                         int32_t use_stag, double stag_punishment, int32_t use_basin, double basin_reward, void* stream) {
     RLS_REQUIRE(N > 0 && N < (1ll << 24), RLS_EINVAL, "bad N=%lld", (long long)N);
     RLS_REQUIRE(B == 0 || (matrix && max_local), RLS_EINVAL, "matrix / max_local is NULL");
     return spin_step_common(nullptr, matrix, max_local, N, env, state_bytes, B, num_rows, row_index, action, reward, visited_new, 1.0,
-                            time_inc, termination_value, reward_mode, reward_div, hist_len, use_stag, stag_punishment, use_basin,
+                            termination_value, reward_mode, reward_div, hist_len, use_stag, stag_punishment, use_basin,
                             basin_reward, stream);
 }
 
@@ -680,26 +721,47 @@ int rls_rand_couplings(void* matrix, int state_bytes, int64_t B, int64_t N, int3
     return check_launch("k_rand_couplings_ba");
 }
 
-int rls_spin_observation(const void* state, const void* matrix, int32_t matrix_per_env, int state_bytes, int64_t B, int32_t num_rows,
-                         int64_t N, int32_t binary_basis, void* out, void* stream) {
+int rls_spin_observation(const rls_spin_env* env, const void* matrix, int32_t matrix_per_env, int state_bytes, int64_t B,
+                         int32_t num_rows, int64_t N, const int32_t* row_index, int64_t step_index, int32_t binary_basis, void* out,
+                         void* stream) {
     RLS_REQUIRE(B >= 0 && num_rows >= 1 && N > 0, RLS_EINVAL, "bad sizes B=%lld R=%d N=%lld", (long long)B, num_rows, (long long)N);
-    RLS_REQUIRE(state_bytes == 4 || state_bytes == 8, RLS_EINVAL, "state_bytes must be 4 (f32) or 8 (f64)");
+    SpinRows rows;
+    if (int rc = check_spin_env(env, state_bytes, num_rows, row_index, &rows)) return rc;
+    RLS_REQUIRE(step_index >= 0 && step_index < env->table_len, RLS_EINVAL, "step_index %lld outside the time table", (long long)step_index);
     if (B == 0) return RLS_OK;
-    RLS_REQUIRE(state && out, RLS_EINVAL, "state / out is NULL");
+    RLS_REQUIRE(out, RLS_EINVAL, "out is NULL");
     const int per = 16 / state_bytes;
-    const bool v4 = (N % per) == 0 && ((((uintptr_t)state) | ((uintptr_t)out) | ((uintptr_t)matrix)) & 15) == 0;
-    const int64_t rows = num_rows + (matrix ? N : 0);
-    const int64_t per_env = rows * (v4 ? N / per : N);
-    RLS_REQUIRE(per_env < (1ll << 31) * 256, RLS_EUNSUPPORTED, "observation of %lld elements per env", (long long)(rows * N));
+    const bool v4 = (N % per) == 0 && ((((uintptr_t)env->state) | ((uintptr_t)out) | ((uintptr_t)matrix)) & 15) == 0;
+    const int64_t nrows = num_rows + (matrix ? N : 0);
+    const int64_t per_env = nrows * (v4 ? N / per : N);
+    RLS_REQUIRE(per_env < (1ll << 31) * 256, RLS_EUNSUPPORTED, "observation of %lld elements per env", (long long)(nrows * N));
     const dim3 grid((unsigned)ceil_div(per_env, 256), (unsigned)(B < 16384 ? B : 16384)), block(256);
     hipStream_t s = as_stream(stream);
 #define LAUNCH_OBS(T, V4)                                                                                                     \
-    hipLaunchKernelGGL((k_spin_observation<T, V4>), grid, block, 0, s, (const T*)state, (const T*)matrix,                       \
+    hipLaunchKernelGGL((k_spin_observation<T, V4>), grid, block, 0, s, *env, rows, step_index, (const T*)matrix,                \
                        (int64_t)(matrix_per_env ? N * N : 0), B, (int)num_rows, N, (int)binary_basis, (T*)out)
     if (state_bytes == 4) { if (v4) LAUNCH_OBS(float, true); else LAUNCH_OBS(float, false); }
     else                  { if (v4) LAUNCH_OBS(double, true); else LAUNCH_OBS(double, false); }
 #undef LAUNCH_OBS
     return check_launch("k_spin_observation");
+}
+
+int rls_spin_materialize(const rls_spin_env* env, int state_bytes, int64_t B, int64_t N, int32_t num_rows, const int32_t* row_index,
+                         int64_t step_index, void* stream) {
+    RLS_REQUIRE(B >= 0 && N > 0, RLS_EINVAL, "bad sizes B=%lld N=%lld", (long long)B, (long long)N);
+    SpinRows rows;
+    if (int rc = check_spin_env(env, state_bytes, num_rows, row_index, &rows)) return rc;
+    RLS_REQUIRE(step_index >= 0 && step_index < env->table_len, RLS_EINVAL, "step_index %lld outside the time table", (long long)step_index);
+    if (B == 0) return RLS_OK;
+    const int per = 16 / state_bytes;
+    const bool v4 = (N % per) == 0 && (((uintptr_t)env->state) & 15) == 0;
+    const dim3 grid((unsigned)ceil_div(v4 ? N / per : N, 256), 6, (unsigned)(B < 8192 ? B : 8192)), block(256);
+    hipStream_t s = as_stream(stream);
+#define LAUNCH_MAT(T, V4) hipLaunchKernelGGL((k_spin_materialize<T, V4>), grid, block, 0, s, *env, rows, step_index, B, (int)num_rows, N)
+    if (state_bytes == 4) { if (v4) LAUNCH_MAT(float, true); else LAUNCH_MAT(float, false); }
+    else                  { if (v4) LAUNCH_MAT(double, true); else LAUNCH_MAT(double, false); }
+#undef LAUNCH_MAT
+    return check_launch("k_spin_materialize");
 }
 
 }  // extern "C"

@@ -302,12 +302,14 @@ void spin_reset(int64_t g, int64_t env, const Tensor& state, const Tensor& row_i
     ok(rls_spin_reset(G(g), SE(env), sb, state.size(0), (int32_t)state.size(1), (const int32_t*)p(row_index),
                       max_local, weight_sum, cur_stream(state)), "rls_spin_reset");
 }
-void spin_observation(const Tensor& state, const OptTensor& matrix, bool binary_basis, Tensor out) {
-    dev(state, "state");
+void spin_observation(int64_t env, const Tensor& state, const Tensor& row_index, int64_t step_index, const OptTensor& matrix, bool binary_basis,
+                      Tensor out) {
+    const int sb = state_bytes(state, SE(env));
+    row_index_ok(row_index);
     dev(out, "out", state.scalar_type());
     optdev(matrix, "matrix", state.scalar_type());
-    TORCH_CHECK(state.scalar_type() == F32 || state.scalar_type() == F64, "state must be float32 or float64");
-    TORCH_CHECK(state.dim() == 3 && out.dim() == 3, "state must be [B, R, N], out [B, R (+ N), N]");
+    TORCH_CHECK(out.dim() == 3, "state must be [B, R, N], out [B, R (+ N), N]");
+    TORCH_CHECK(step_index >= 0 && step_index < SE(env)->table_len, "step_index outside the env's time table");
     const int64_t B = state.size(0), R = state.size(1), N = state.size(2);
     TORCH_CHECK(out.size(0) == B && out.size(2) == N && out.size(1) == R + (matrix.has_value() ? N : 0), "out has the wrong shape");
     bool per_env = false;
@@ -316,9 +318,17 @@ void spin_observation(const Tensor& state, const OptTensor& matrix, bool binary_
         TORCH_CHECK((matrix->dim() == 2 || (per_env && matrix->size(0) == B)) && matrix->size(-2) == N && matrix->size(-1) == N,
                     "matrix must be [N, N] or [B, N, N]");
     }
-    const int sb = state.scalar_type() == F64 ? 8 : 4;
     RLS_GUARD(state);
-    ok(rls_spin_observation(p(state), p(matrix), per_env, sb, B, (int32_t)R, N, binary_basis, p(out), cur_stream(state)), "rls_spin_observation");
+    ok(rls_spin_observation(SE(env), p(matrix), per_env, sb, B, (int32_t)R, N, (const int32_t*)p(row_index), step_index, binary_basis, p(out),
+                            cur_stream(state)), "rls_spin_observation");
+}
+void spin_materialize(int64_t env, Tensor state, const Tensor& row_index, int64_t step_index) {
+    const int sb = state_bytes(state, SE(env));
+    row_index_ok(row_index);
+    TORCH_CHECK(step_index >= 0 && step_index < SE(env)->table_len, "step_index outside the env's time table");
+    RLS_GUARD(state);
+    ok(rls_spin_materialize(SE(env), sb, state.size(0), state.size(2), (int32_t)state.size(1), (const int32_t*)p(row_index), step_index,
+                            cur_stream(state)), "rls_spin_materialize");
 }
 void rand_couplings(Tensor matrix, int64_t kind, double p_connection, int64_t m_insertion_edges, int64_t edge_type, int64_t seed, int64_t env_offset) {
     dev(matrix, "matrix");
@@ -344,7 +354,7 @@ void spin_reset_dense(const Tensor& matrix, int64_t env, const Tensor& state, co
                             p(max_local), p(weight_sum), (uint8_t*)p(flags), cur_stream(state)), "rls_spin_reset_dense");
 }
 void spin_step_dense(const Tensor& matrix, const Tensor& max_local, int64_t env, const Tensor& state, const Tensor& row_index, const Tensor& action,
-                     Tensor reward, const OptTensor& visited_new, double time_inc, double termination_value, int64_t reward_mode,
+                     Tensor reward, const OptTensor& visited_new, double termination_value, int64_t reward_mode,
                      double reward_div, int64_t hist_len, bool use_stag, double stag_punishment, bool use_basin, double basin_reward) {
     const int sb = state_bytes(state, SE(env));
     dev(matrix, "matrix", state.scalar_type());
@@ -360,12 +370,12 @@ void spin_step_dense(const Tensor& matrix, const Tensor& max_local, int64_t env,
     TORCH_CHECK(hist_len >= 0 && (SE(env)->packed == nullptr || hist_len <= SE(env)->hist_cap), "hist_len outside the visited-state ring");
     RLS_GUARD(state);
     ok(rls_spin_step_dense(p(matrix), p(max_local), SE(env), sb, B, N, (int32_t)state.size(1),
-                           (const int32_t*)p(row_index), (const int64_t*)p(action), p(reward), (uint8_t*)p(visited_new), time_inc, termination_value,
+                           (const int32_t*)p(row_index), (const int64_t*)p(action), p(reward), (uint8_t*)p(visited_new), termination_value,
                            (int32_t)reward_mode, reward_div, hist_len, use_stag, stag_punishment, use_basin, basin_reward, cur_stream(state)),
        "rls_spin_step_dense");
 }
 void spin_step(int64_t g, int64_t env, const Tensor& state, const Tensor& row_index, const Tensor& action, Tensor reward,
-               const OptTensor& visited_new, double max_local, double time_inc, double termination_value, int64_t reward_mode,
+               const OptTensor& visited_new, double max_local, double termination_value, int64_t reward_mode,
                double reward_div, int64_t hist_len, bool use_stag, double stag_punishment, bool use_basin, double basin_reward) {
     const int sb = state_bytes(state, SE(env));
     dev(action, "action", I64);
@@ -379,7 +389,7 @@ void spin_step(int64_t g, int64_t env, const Tensor& state, const Tensor& row_in
     TORCH_CHECK(hist_len >= 0 && (SE(env)->packed == nullptr || hist_len <= SE(env)->hist_cap), "hist_len outside the visited-state ring");
     RLS_GUARD(state);
     ok(rls_spin_step(G(g), SE(env), sb, B, (int32_t)state.size(1), (const int32_t*)p(row_index),
-                     (const int64_t*)p(action), p(reward), (uint8_t*)p(visited_new), max_local, time_inc, termination_value, (int32_t)reward_mode,
+                     (const int64_t*)p(action), p(reward), (uint8_t*)p(visited_new), max_local, termination_value, (int32_t)reward_mode,
                      reward_div, hist_len, use_stag, stag_punishment, use_basin, basin_reward, cur_stream(state)), "rls_spin_step");
 }
 
@@ -720,14 +730,15 @@ TORCH_LIBRARY(rlsolver_hip, m) {
     m.def("rand_actions(Tensor(a!) action, int N, int seed, int step, int env_offset) -> ()");
     m.def("rand_perms(Tensor(a!) perm, int seed, int env_offset) -> ()");
     m.def("spin_reset(int graph, int env, Tensor(a!) state, Tensor row_index, float max_local, int weight_sum) -> ()");
-    m.def("spin_observation(Tensor state, Tensor? matrix, bool binary_basis, Tensor(a!) out) -> ()");
+    m.def("spin_observation(int env, Tensor state, Tensor row_index, int step_index, Tensor? matrix, bool binary_basis, Tensor(a!) out) -> ()");
+    m.def("spin_materialize(int env, Tensor(a!) state, Tensor row_index, int step_index) -> ()");
     m.def("rand_couplings(Tensor(a!) matrix, int kind, float p_connection, int m_insertion_edges, int edge_type, int seed, int env_offset) -> ()");
     m.def("spin_reset_dense(Tensor matrix, int env, Tensor(a!) state, Tensor row_index, Tensor(b!) max_local, Tensor(c!) weight_sum, Tensor(d!) flags) -> ()");
     m.def("spin_step_dense(Tensor matrix, Tensor max_local, int env, Tensor(a!) state, Tensor row_index, Tensor action, Tensor(b!) reward, "
-          "Tensor(c!)? visited_new, float time_inc, float termination_value, int reward_mode, float reward_div, int hist_len, bool use_stag, "
+          "Tensor(c!)? visited_new, float termination_value, int reward_mode, float reward_div, int hist_len, bool use_stag, "
           "float stag_punishment, bool use_basin, float basin_reward) -> ()");
     m.def("spin_step(int graph, int env, Tensor(a!) state, Tensor row_index, Tensor action, Tensor(b!) reward, Tensor(c!)? visited_new, "
-          "float max_local, float time_inc, float termination_value, int reward_mode, float reward_div, int hist_len, bool use_stag, "
+          "float max_local, float termination_value, int reward_mode, float reward_div, int hist_len, bool use_stag, "
           "float stag_punishment, bool use_basin, float basin_reward) -> ()");
     m.def("mcpg_metro_rounds(Tensor(a!) samples, Tensor? samples_in, int C_in, int C, Tensor probs, int T, int t_offset, Tensor? index, "
           "Tensor? u, int seed, Tensor? t_limit, bool write_back, Tensor(b!)? accepts) -> ()");
@@ -777,6 +788,7 @@ TORCH_LIBRARY_IMPL(rlsolver_hip, CUDA, m) {   // "CUDA" is the HIP dispatch key 
     m.impl("rand_perms", &rand_perms);
     m.impl("spin_reset", &spin_reset);
     m.impl("spin_observation", &spin_observation);
+    m.impl("spin_materialize", &spin_materialize);
     m.impl("rand_couplings", &rand_couplings);
     m.impl("spin_reset_dense", &spin_reset_dense);
     m.impl("spin_step_dense", &spin_step_dense);

@@ -163,7 +163,13 @@ class SpinSystem:
         self._rows = torch.tensor([next((i for i, o in self.observables if o == want), -1) for want in _ROW_ORDER], dtype=torch.int32)
         R, B, N = len(observables), num_envs, num_nodes
         dt = self.dtype
-        self.state = torch.zeros((B, R, N), dtype=dt, device=self.device)
+        # `_state`: rows 0 (signed spins) and IMMEDIATE_REWARD_AVAILABLE are current after every step; the rows a step changes
+        # everywhere live as last-flip steps + four per-env scalars and are written into it on demand (the `state` property)
+        self._state = torch.zeros((B, R, N), dtype=dt, device=self.device)
+        self._state_stale = False
+        self._last_flip = torch.zeros((B, N), dtype=torch.int32, device=self.device)
+        self._scalars = torch.zeros((B, 4), dtype=dt, device=self.device)
+        self._time_table = self._build_time_table()
         self._delta = torch.zeros((B, N), dtype=torch.int32, device=self.device)
         self._num_nonpos = torch.zeros(B, dtype=torch.int32, device=self.device)
         self._dist_best = torch.zeros(B, dtype=torch.int32, device=self.device)
@@ -179,15 +185,36 @@ class SpinSystem:
             self._hist_hash = torch.zeros((B, max_steps), dtype=torch.int64, device=self.device)
         self._visited_new = torch.ones(B, dtype=torch.uint8, device=self.device)
         self._env = _abi.RlsSpinEnv(
-            state=self.state.data_ptr(), delta=self._delta.data_ptr(), score=self.score.data_ptr(),
+            state=self._state.data_ptr(), delta=self._delta.data_ptr(), score=self.score.data_ptr(),
             best_score=self.best_score.data_ptr(), best_spins=self.best_spins.data_ptr(),
             num_nonpos=self._num_nonpos.data_ptr(), dist_best=self._dist_best.data_ptr(),
             packed=self._packed.data_ptr() if self._use_hist else 0, hash=self._hash.data_ptr() if self._use_hist else 0,
             hist=self._hist.data_ptr() if self._use_hist else 0,
-            hist_hash=self._hist_hash.data_ptr() if self._use_hist else 0, hist_cap=max_steps if self._use_hist else 0)
+            hist_hash=self._hist_hash.data_ptr() if self._use_hist else 0, hist_cap=max_steps if self._use_hist else 0,
+            last_flip=self._last_flip.data_ptr(), scalars=self._scalars.data_ptr(), time_table=self._time_table.data_ptr(),
+            table_len=self._time_table.numel())
         self._env_handle = C.addressof(self._env)     # the `env` argument of torch.ops.rlsolver_hip.spin_*
         self.current_step = 0
         self.reset()
+
+    def _build_time_table(self):
+        """time_table[k] = what `state[TIME_SINCE_FLIP] += 1. / max_steps` (spinsystem_PECO.py:417, spinsystem.py:436) holds
+        after k steps from 0: k additions of the increment in the env's float type, done here once."""
+        npdt = np.float32 if self.dtype == torch.float32 else np.float64
+        t = np.zeros(self.max_steps + 2, dtype=npdt)
+        inc = npdt(1.0 / self.max_steps)
+        for k in range(1, t.size):
+            t[k] = t[k - 1] + inc
+        return torch.from_numpy(t).to(self.device)
+
+    @property
+    def state(self):
+        """[B, R, N] observable rows as the reference's ``self.state`` holds them (row 0 = signed spins).  Rows that change
+        everywhere every step are written on the first read after a step (rls_spin_materialize)."""
+        if self._state_stale:
+            _t.spin_materialize(self._env_handle, self._state, self._rows, self.current_step)
+            self._state_stale = False
+        return self._state
 
     # ---- dense adjacency only when somebody asks for it (N^2 floats)
     @property
@@ -215,6 +242,10 @@ class SpinSystem:
     def reset(self, spins=None):
         """spinsystem_PECO.py:150-195.  spins: optional [B, N] in the env's spin basis."""
         self.current_step = 0
+        self._state_stale = False            # reset rewrites every row
+        if self._time_table.numel() != self.max_steps + 2:      # max_steps was reassigned: the increments change
+            self._time_table = self._build_time_table()
+            self._env.time_table, self._env.table_len = self._time_table.data_ptr(), self._time_table.numel()
         B, N = self.num_envs, self.n_spins
         if spins is None:
             bits = ops.rand_spins(B, N, _seed_from_torch(), self.device)
@@ -225,12 +256,12 @@ class SpinSystem:
             # not the inverse of get_observation's (1 - s) / 2); already-signed input passes through
             signed = (2 * spins - 1) if (self.spin_basis == SpinBasis.BINARY and spins.min() >= 0) else spins
             bits = (signed > 0).contiguous()
-        self.state[:, 0, :] = 2 * bits.to(self.dtype) - 1
+        self._state[:, 0, :] = 2 * bits.to(self.dtype) - 1
         if self._dense:
             # a fresh matrix per env (spinsystem_PECO.py:150-170); graphs the reference rejects are drawn again
             for _ in range(64):
                 self._matrix = self._draw_matrix()
-                _t.spin_reset_dense(self._matrix, self._env_handle, self.state, self._rows, self.max_local_reward_available_,
+                _t.spin_reset_dense(self._matrix, self._env_handle, self._state, self._rows, self.max_local_reward_available_,
                                     self._weight_sum_env, self._flags)
                 flags = int(self._flags.max())            # the one host read of a reset (the reference's .any() tests)
                 if flags & 2:
@@ -242,7 +273,7 @@ class SpinSystem:
         else:
             # gains of all single flips: delta_i = s_i sum_j W_ij s_j = sum_j W_ij (x_i == x_j ? 1 : -1): the K3 kernel
             ops.maxcut_delta_all(self.graph, bits, out=self._delta)
-            _t.spin_reset(self.graph.handle, self._env_handle, self.state, self._rows, self._max_local, self._weight_sum)
+            _t.spin_reset(self.graph.handle, self._env_handle, self._state, self._rows, self._max_local, self._weight_sum)
         self.best_obs_score = self.best_score
         self.best_obs_spins = self.best_spins
         return self.get_observation()
@@ -270,8 +301,7 @@ class SpinSystem:
         c = getattr(self, "_consts", None)
         if c is None or c["key"] != key:
             c = self._consts = dict(
-                key=key,
-                time_inc=self._round(1.0 / self.max_steps), mode=_REWARD_MODE[self.reward_signal],
+                key=key, mode=_REWARD_MODE[self.reward_signal],
                 div=float(self.n_spins) if self.norm_rewards else 1.0,
                 tail=(self.stag_punishment is not None, self._round(self.stag_punishment or 0.0),
                       self.basin_reward is not None, self._round(self.basin_reward or 0.0)))
@@ -290,12 +320,12 @@ class SpinSystem:
         rew = torch.empty(B, dtype=self.dtype, device=self.device)
         c = self._step_consts()
         if self._dense:
-            _t.spin_step_dense(self._matrix, self.max_local_reward_available_, self._env_handle, self.state, self._rows, action, rew,
-                               self._visited_new, c["time_inc"], self._termination(), c["mode"], c["div"], self.current_step - 1,
-                               *c["tail"])
+            _t.spin_step_dense(self._matrix, self.max_local_reward_available_, self._env_handle, self._state, self._rows, action, rew,
+                               self._visited_new, self._termination(), c["mode"], c["div"], self.current_step - 1, *c["tail"])
         else:
-            _t.spin_step(self.graph.handle, self._env_handle, self.state, self._rows, action, rew, self._visited_new, self._max_local,
-                         c["time_inc"], self._termination(), c["mode"], c["div"], self.current_step - 1, *c["tail"])
+            _t.spin_step(self.graph.handle, self._env_handle, self._state, self._rows, action, rew, self._visited_new, self._max_local,
+                         self._termination(), c["mode"], c["div"], self.current_step - 1, *c["tail"])
+        self._state_stale = True
         done = torch.full((B,), self.current_step == self.max_steps, dtype=torch.bool, device=self.device)
         return self.get_observation(), rew, done
 
@@ -304,13 +334,14 @@ class SpinSystem:
         ``include_adjacency``, by the N rows of the shared matrix -- [B, R (+ N), N], ONE streaming kernel
         (rls_spin_observation; the reference clones the state, rewrites row 0 and concatenates a [B, N, N] expansion).
         ``out``: a caller-owned buffer of that shape to write into (a rollout ring), else a fresh tensor."""
-        B, R, N = self.state.shape
+        B, R, N = self._state.shape
         rows = R + (N if self.include_adjacency else 0)
         if out is None:
             out = torch.empty((B, rows, N), dtype=self.dtype, device=self.device)
         elif out.shape != (B, rows, N) or out.dtype != self.dtype or not out.is_contiguous():
             raise ValueError(f"out must be a contiguous {self.dtype} tensor of shape {(B, rows, N)}")
-        _t.spin_observation(self.state, self.matrix if self.include_adjacency else None, self.spin_basis == SpinBasis.BINARY, out)
+        _t.spin_observation(self._env_handle, self._state, self._rows, self.current_step,
+                            self.matrix if self.include_adjacency else None, self.spin_basis == SpinBasis.BINARY, out)
         return out
 
     def get_immeditate_rewards_avaialable(self, spins=None):
@@ -323,12 +354,13 @@ class SpinSystem:
         return self.best_score
 
     # ---- checkpoint of the env state: everything a later step depends on
-    _STATE_KEYS = ("state", "_delta", "score", "best_score", "best_spins", "_num_nonpos", "_dist_best")
+    _STATE_KEYS = ("_state", "_delta", "score", "best_score", "best_spins", "_num_nonpos", "_dist_best", "_last_flip", "_scalars")
     _DENSE_KEYS = ("_matrix", "max_local_reward_available_", "_weight_sum_env")
     _HIST_KEYS = ("_packed", "_hash", "_hist", "_hist_hash")
 
     def state_dict(self):
         keys = self._STATE_KEYS + (self._HIST_KEYS if self._use_hist else ()) + (self._DENSE_KEYS if self._dense else ())
+        self.state                                            # (materialises the lazy rows first)
         d = {k.lstrip("_"): getattr(self, k).clone() for k in keys}
         d["current_step"] = self.current_step
         return d
@@ -338,6 +370,7 @@ class SpinSystem:
         for k in keys:
             getattr(self, k).copy_(d[k.lstrip("_")])     # in place: the kernel's pointer table stays valid
         self.current_step = int(d["current_step"])
+        self._state_stale = False
 
 
 class SpinSystemFactory:

@@ -206,8 +206,9 @@ def isco_suite(iters):
 
 
 def spin_suite(tag, n, m, B, T, iters):
-    """S1: the S2V / ECO / PECO env step on a shared graph (resident O(deg) state; 6 rows x 4N bytes change per step
-    under the ECO observables: time-since-flip read + write, four broadcast rows written)."""
+    """S1: the S2V / ECO / PECO env on a shared graph: the O(deg) step kernel (nothing streamed: the rows that change
+    everywhere are per-env scalars + a last-flip step), the rows-only observation that materialises them (7 rows written,
+    spins + immediate reward + last-flip read) and the step through the class surface."""
     from rlsolver_amd.envs.spinsystem import ECO_PECO_OBSERVABLES, RewardSignal, SpinBasis, SpinSystem
     rng = np.random.RandomState(1)
     mg = [(u, v, int(rng.choice([-1, 1]))) for u, v, _ in generate_gnm(n, m, 22)]
@@ -217,19 +218,29 @@ def spin_suite(tag, n, m, B, T, iters):
                          norm_rewards=True, spin_basis=SpinBasis.BINARY, device=dev, include_adjacency=False, **kw)
         acts = [ops.rand_actions(B, n, 11, s, dev) for s in range(8)]
         rew = torch.empty(B, device=dev)
-        from rlsolver_amd import _abi
-        import ctypes as C
+        R = torch.ops.rlsolver_hip
 
         def one(i):   # the bare kernel, as EnvMaxcutGym's launcher: no observation copy
             if env.current_step >= T:
                 env.current_step = 0
             env.current_step += 1
-            _abi.call("rls_spin_step", env.graph.ref, C.byref(env._env), 4, B, 7, env._rows, ops._ptr(acts[i % 8]),
-                      ops._ptr(rew), None, env._max_local, float(np.float32(1.0 / T)), 1.0, 1, float(n),
-                      env.current_step - 1, 0, 0.0, int("basin" in label), float(np.float32(1.0 / n)), ops._stream(dev))
+            R.spin_step(env.graph.handle, env._env_handle, env._state, env._rows, acts[i % 8], rew, None, env._max_local, 1.0, 1,
+                        float(n), env.current_step - 1, False, 0.0, "basin" in label, float(np.float32(1.0 / n)))
         t = timeit(one, iters)
-        emit(tag, f"S1 spin_step ({label})", "env-steps", B, t, 6 * 4 * n,
-             "algorithmic bytes = the rows the observation contract changes everywhere each step")
+        emit(tag, f"S1 spin_step ({label})", "env-steps", B, t, None,
+             "O(deg) per env: latency-bound, no row is streamed (round 2: 6 rows x 4N bytes per env-step, 250 us at 2^14 envs)")
+        out = torch.empty((B, 7, n), device=dev)
+        t = timeit(lambda i: env.get_observation(out=out), iters)
+        emit(tag, f"S1 get_observation, rows only ({label})", "envs", B, t, 4 * (7 + 2) * n + 4 * n,
+             "bytes = 7 rows written, spins + immediate reward read (f32), last-flip steps read (int32)")
+
+        def full(i):
+            if env.current_step >= T:
+                env.current_step = 0
+            env.step(acts[i % 8])
+        t = timeit(full, iters)
+        emit(tag, f"SpinSystem.step() incl. the rows-only observation ({label})", "env-steps", B, t, 4 * (7 + 2) * n + 4 * n,
+             "bytes = the observation kernel's")
 
 
 def spin_train_suite(tag, n, m_ins, B, T, iters):
@@ -237,8 +248,6 @@ def spin_train_suite(tag, n, m_ins, B, T, iters):
     the step through the class surface (observation [B, 7 + N, N] with each env's own matrix rows included); beside the draw,
     the reference's way of drawing the same graphs with torch ops (a loop over the nodes: row sums of [B, N, N], multinomial,
     two scatters)."""
-    from rlsolver_amd import _abi
-    import ctypes as C
     from rlsolver_amd.envs.spinsystem import ECO_PECO_OBSERVABLES, RewardSignal, SpinBasis, SpinSystem
     from rlsolver_amd.envs.util_envs_PECO import EdgeType, RandomBAGraphGenerator
     gg = RandomBAGraphGenerator(n, m_ins, EdgeType.DISCRETE, B, dev)
@@ -272,12 +281,11 @@ def spin_train_suite(tag, n, m_ins, B, T, iters):
         if env.current_step >= T:
             env.current_step = 0
         env.current_step += 1
-        _abi.call("rls_spin_step_dense", ops._ptr(env._matrix), ops._ptr(env.max_local_reward_available_), C.byref(env._env), 4, B, n, 7,
-                  env._rows, ops._ptr(acts[i % 8]), ops._ptr(rew), None, float(np.float32(1.0 / T)), 1.0, 1, float(n), env.current_step - 1,
-                  0, 0.0, 0, 0.0, ops._stream(dev))
+        torch.ops.rlsolver_hip.spin_step_dense(env._matrix, env.max_local_reward_available_, env._env_handle, env._state, env._rows,
+                                               acts[i % 8], rew, None, 1.0, 1, float(n), env.current_step - 1, False, 0.0, False, 0.0)
     t = timeit(one, iters)
-    emit(tag, "S1 spin_step_dense (ECO observables, BLS reward)", "env-steps", B, t, 6 * 4 * n + 4 * n,
-         "algorithmic bytes = the six rows that change everywhere + the flipped node's matrix row")
+    emit(tag, "S1 spin_step_dense (ECO observables, BLS reward)", "env-steps", B, t, 4 * n * 4,
+         "algorithmic bytes = the flipped node's matrix row read + the gains / immediate-reward entries it changes")
     out = torch.empty((B, 7 + n, n), device=dev)
 
     def full(i):
@@ -285,8 +293,8 @@ def spin_train_suite(tag, n, m_ins, B, T, iters):
             env.current_step = 0
         env.step(acts[i % 8])
     t = timeit(full, iters)
-    emit(tag, "SpinSystem.step() incl. observation [B, 7 + N, N] with per-env matrix rows", "env-steps", B, t, 6 * 4 * n + 4 * n + 4 * (7 + n) * n + 4 * n * n + 4 * 7 * n,
-         "bytes = step + observation written + matrix and rows read")
+    emit(tag, "SpinSystem.step() incl. observation [B, 7 + N, N] with per-env matrix rows", "env-steps", B, t, 4 * n + 4 * (7 + n) * n + 4 * n * n + 4 * 3 * n,
+         "bytes = step + observation written + matrix and resident rows read")
 
 
 def qubo_suite(tag, n, C, num_ls, iters, sparse=True):

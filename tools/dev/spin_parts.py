@@ -21,9 +21,8 @@ for label, obs in (("ECO observables", ECO_PECO_OBSERVABLES), ("spin state + imm
         if env.current_step >= T:
             env.current_step = 0
         env.current_step += 1
-        _abi.call("rls_spin_step", env.graph.ref, C.byref(env._env), 4, B, R, env._rows, ops._ptr(acts[i % 8]),
-                  ops._ptr(rew), None, env._max_local, float(np.float32(1.0 / T)), 1.0, 1, float(n),
-                  env.current_step - 1, 0, 0.0, 0, 0.0, ops._stream(dev))
+        torch.ops.rlsolver_hip.spin_step(env.graph.handle, env._env_handle, env._state, env._rows, acts[i % 8], rew, None, env._max_local, 1.0,
+                                         1, float(n), env.current_step - 1, False, 0.0, False, 0.0)
     for i in range(3):
         one(i)
     torch.cuda.synchronize()
