@@ -267,10 +267,11 @@ typedef struct rls_spin_env {
     void* best_spins;      /* T [B, N] */
     int32_t* num_nonpos;   /* [B] #{i : delta[b,i] <= 0}, kept incrementally (greedy-actions row, basin test :392-397) */
     int32_t* dist_best;    /* [B] Hamming distance between the spins and best_spins, kept incrementally */
-    /* visited-state memory behind stag_punishment / basin_reward (HistoryBuffer, util_envs_PECO.py:228-288,
-     * util_envs.py:355-381), or all NULL / 0: W = ceil(N / 64) words per state */
+    /* bit-packed spins (needed by the two memories below), or NULL: W = ceil((N + allow_pass) / 64) words per state */
     uint64_t* packed;      /* [B, W] current spins, bit n % 64 of word n / 64 = (s_n > 0) */
     uint64_t* hash;        /* [B] Zobrist hash of packed (pre-filter of the exact compare) */
+    /* visited-state memory behind stag_punishment / basin_reward (HistoryBuffer, util_envs_PECO.py:228-288,
+     * util_envs.py:355-381), or NULL / 0 */
     uint64_t* hist;        /* [B, hist_cap, W] the state after each earlier step of the episode */
     uint64_t* hist_hash;   /* [B, hist_cap] */
     int64_t hist_cap;
@@ -281,6 +282,15 @@ typedef struct rls_spin_env {
     const void* time_table;/* T [table_len]: time_table[k] = 0 + inc + inc + ... (k additions in T, inc = (T)(1 / max_steps)):
                             * what `state[TIME_SINCE_FLIP] += 1. / max_steps` (spinsystem_PECO.py:417) has accumulated after k steps */
     int64_t table_len;     /* >= max_steps + 1 */
+    /* options of the single-instance env (spinsystem.py; the batched reference env cannot be constructed with them): */
+    void* best_obs_score;  /* T [B] the best OBSERVABLE score: what rewards and the distance rows refer to (= best_score unless
+                            * the memory is finite) */
+    uint64_t* mem_spins;   /* [B, mem_len, ceil(N / 64)] finite memory (memory_length, spinsystem.py:398-404): the spins after each */
+    void* mem_score;       /* T [B, mem_len]             of the last mem_len steps and their scores; NULL / 0 = infinite memory */
+    int64_t mem_len;
+    int64_t allow_pass;    /* ExtraAction.PASS (spinsystem.py:349-351): action N is legal and flips nothing; the packed spins then
+                            * have ceil((N + 1) / 64) words per state, bit N = the parity of the passes (HistoryBuffer,
+                            * util_envs.py:361-366, keys its states by the set of actions taken an odd number of times) */
 } rls_spin_env;
 
 /* State rows: row 0 (signed spins) and the IMMEDIATE_REWARD_AVAILABLE row of `state` are current after every call; the

@@ -100,64 +100,81 @@ class SpinSystemOracle:
 class SpinSystemOracleF64:
     """The numpy single-instance env, rlsolver/methods/ECO_S2V/src/envs/spinsystem.py (SpinSystemUnbiased :588-661,
     step :333-482, reset :176-252, observation :484-495), restated in float64 with a DENSE matvec for the gains and
-    the action-parity-set visited memory of util_envs.py:355-381.  ECO_PECO_OBSERVABLES row order, ExtraAction.NONE,
-    OptimisationTarget.CUT, infinite memory.  Pinned against tests/golden/spinsystem_cpu.npz."""
+    the action-parity-set visited memory of util_envs.py:355-381.  ECO_PECO_OBSERVABLES row order, OptimisationTarget.CUT;
+    ExtraAction.NONE or PASS (``extra_pass``: n + 1 actions, every array carries the reference's padding column, :226-233,
+    :252-262), infinite or finite memory (``memory_length``, :206-209, :398-404).  Pinned against
+    tests/golden/spinsystem_cpu.npz and spinsystem_options.npz."""
     SPIN, IMMEDIATE, TIME_SINCE_FLIP, DIST_SCORE, DIST_STATE, GREEDY, TERMINATION = range(7)
 
-    def __init__(self, W, max_steps, reward="DENSE", norm_rewards=False, basin_reward=None, stag_punishment=None):
+    def __init__(self, W, max_steps, reward="DENSE", norm_rewards=False, basin_reward=None, stag_punishment=None,
+                 extra_pass=False, memory_length=None):
         self.W = np.asarray(W, np.float64)
         self.n = self.W.shape[0]
+        self.na = self.n + int(extra_pass)                                     # n_actions
         self.max_steps = max_steps
         self.reward, self.norm_rewards = reward, norm_rewards
         self.basin_reward, self.stag_punishment = basin_reward, stag_punishment
+        self.memory_length = memory_length
         imm1 = self._imm(np.ones(self.n))
         self.max_local = np.max(imm1[np.nonzero(imm1)])                        # :190-196
+        self.W_obs = np.zeros((self.na, self.na))                              # matrix_obs, zero-padded (:222-225)
+        self.W_obs[:self.n, :self.n] = self.W
 
     def _imm(self, s):
         return s * (self.W @ s)                                                # :659-661
 
     def reset(self, spins_signed):
+        n = self.n
         self.t = 0
-        st = np.zeros((7, self.n))
-        st[0] = spins_signed
-        imm = self._imm(st[0])
-        st[self.IMMEDIATE] = imm / self.max_local
-        st[self.GREEDY] = 1 - np.sum(imm <= 0) / self.n
+        st = np.zeros((7, self.na))
+        st[0, :n] = np.asarray(spins_signed)[:n]
+        imm = self._imm(st[0, :n])
+        st[self.IMMEDIATE, :n] = imm / self.max_local
+        st[self.GREEDY, :n] = 1 - np.sum(imm <= 0) / n                         # reset writes [:n_spins] only (:259-261)
         self.state = st
-        self.score = 0.25 * np.sum(self.W * (1 - np.outer(st[0], st[0])))      # :601-607
-        self.best_score = self.score
-        self.best_spins = st[0].copy()
+        self.score = 0.25 * np.sum(self.W * (1 - np.outer(st[0, :n], st[0, :n])))      # :601-607
+        self.best_score = self.best_obs_score = self.score
+        self.best_spins = st[0, :n].copy()
+        self.best_obs_spins = st[0, :n].copy()
+        if self.memory_length is not None:
+            self.score_memory = np.array([self.best_score] * self.memory_length)
+            self.spins_memory = np.array([self.best_spins] * self.memory_length)
+            self.idx_memory = 1
         self.flipped = frozenset()                                             # HistoryBuffer.current_action_hist
         self.seen = set()
         return self.observation()
 
     def observation(self):
         s = self.state.copy()
-        s[0] = (1 - s[0]) / 2                                                  # SpinBasis.BINARY
-        return np.vstack((s, self.W))
+        s[0] = (1 - s[0]) / 2                                                  # SpinBasis.BINARY (the padding spin 0 -> 0.5)
+        return np.vstack((s, self.W_obs))
 
     def gains(self):
-        return self._imm(self.state[0])
+        return self._imm(self.state[0, :self.n])
 
     def step(self, a):
+        n = self.n
         self.t += 1
         new = self.state.copy()
-        new[0, a] = -self.state[0, a]
-        delta = -1 * new[0, a] * (new[0] @ self.W[:, a])                       # _calculate_cut_change :631
-        self.score += delta
+        if a == n:                                                             # ExtraAction.PASS (:349-351)
+            delta = 0
+        else:
+            new[0, a] = -self.state[0, a]
+            delta = -1 * new[0, a] * (new[0, :n] @ self.W[:, a])               # _calculate_cut_change :631
+            self.score += delta
         self.state = new
-        imm = self._imm(new[0])
+        imm = self._imm(new[0, :n])
         rew = 0
-        if self.score > self.best_score:
+        if self.score > self.best_obs_score:
             if self.reward == "BLS":
-                rew = self.score - self.best_score
+                rew = self.score - self.best_obs_score
             elif self.reward == "CUSTOM_BLS":
-                rew = self.score - self.best_score
+                rew = self.score - self.best_obs_score
                 rew = rew / (rew + 0.1)
         if self.reward == "DENSE":
             rew = delta
         if self.norm_rewards:
-            rew /= self.n
+            rew /= n
         if self.stag_punishment is not None or self.basin_reward is not None:
             self.flipped = self.flipped ^ frozenset([a])
             fresh = self.flipped not in self.seen
@@ -168,13 +185,22 @@ class SpinSystemOracleF64:
                 rew += self.basin_reward
         if self.score > self.best_score:
             self.best_score = self.score
-            self.best_spins = new[0].copy()
+            self.best_spins = new[0, :n].copy()
+        if self.memory_length is not None:                                     # :398-404
+            self.score_memory[self.idx_memory] = self.score
+            self.spins_memory[self.idx_memory] = new[0, :n]
+            self.idx_memory = (self.idx_memory + 1) % self.memory_length
+            self.best_obs_score = self.score_memory.max()
+            self.best_obs_spins = self.spins_memory[self.score_memory.argmax()].copy()
+        else:
+            self.best_obs_score = self.best_score
+            self.best_obs_spins = self.best_spins.copy()
         st = self.state
-        st[self.IMMEDIATE] = imm / self.max_local
+        st[self.IMMEDIATE, :n] = imm / self.max_local
         st[self.TIME_SINCE_FLIP] += 1. / self.max_steps
         st[self.TIME_SINCE_FLIP, a] = 0
         st[self.TERMINATION] = max(0, ((self.t - self.max_steps) / self.max_steps) + 1)
-        st[self.GREEDY] = 1 - np.sum(imm <= 0) / self.n
-        st[self.DIST_SCORE] = np.abs(self.score - self.best_score) / self.max_local
-        st[self.DIST_STATE] = np.count_nonzero(self.best_spins - st[0])
+        st[self.GREEDY] = 1 - np.sum(imm <= 0) / n
+        st[self.DIST_SCORE] = np.abs(self.score - self.best_obs_score) / self.max_local
+        st[self.DIST_STATE, :n] = np.count_nonzero(self.best_obs_spins - st[0, :n])
         return self.observation(), rew, self.t == self.max_steps

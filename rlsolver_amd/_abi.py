@@ -62,7 +62,8 @@ class RlsSpinEnv(C.Structure):
     """struct rls_spin_env (host struct of device pointers)."""
     _fields_ = ([(n, C.c_void_p) for n in ("state", "delta", "score", "best_score", "best_spins", "num_nonpos", "dist_best",
                                            "packed", "hash", "hist", "hist_hash")] + [("hist_cap", C.c_int64)]
-                + [(n, C.c_void_p) for n in ("last_flip", "scalars", "time_table")] + [("table_len", C.c_int64)])
+                + [(n, C.c_void_p) for n in ("last_flip", "scalars", "time_table")] + [("table_len", C.c_int64)]
+                + [(n, C.c_void_p) for n in ("best_obs_score", "mem_spins", "mem_score")] + [("mem_len", C.c_int64), ("allow_pass", C.c_int64)])
 
 
 _SE = C.POINTER(RlsSpinEnv)

@@ -78,7 +78,9 @@ __global__ __launch_bounds__(256) void k_spin_step(rls_spin_env env, int64_t B, 
     T* best_score = reinterpret_cast<T*>(env.best_score);
     T* bs = reinterpret_cast<T*>(env.best_spins) + b * N;
     const int64_t a = action[b];
-    if ((uint64_t)a >= (uint64_t)N) {   // the reference raises an IndexError; leave the env untouched, report NaN
+    // ExtraAction.PASS (spinsystem.py:349-351): action N changes no spin and no score; everything else of a step happens
+    const bool is_pass = env.allow_pass != 0 && a == N;
+    if (!is_pass && (uint64_t)a >= (uint64_t)N) {   // the reference raises an IndexError; leave the env untouched, report NaN
         if (lane == 0) {
             reward[b] = (T)NAN;
             if (visited_new) visited_new[b] = 0;
@@ -86,16 +88,19 @@ __global__ __launch_bounds__(256) void k_spin_step(rls_spin_env env, int64_t B, 
         return;
     }
     const T max_local = DENSE ? max_local_env[b] : (T)p.max_local;
+    T* best_obs = reinterpret_cast<T*>(env.best_obs_score);
 
     // 1. flip + score change (spinsystem_PECO.py:336-348): gain = delta[a] before the flip.  Neighbour updates
     //    are returning L2 atomics (multi-edges may hit one node twice in a wave-instruction): every lane sees
     //    the value its own add replaced, so the <= 0 census telescopes correctly.
+    T s_new = (T)0;
+    int gain = 0, adj = 0;
+    if (!is_pass) {
     const T s_old = spins[a];
-    const T s_new = -s_old;
+    s_new = -s_old;
     const int sn = s_new > (T)0 ? 1 : -1;
     const int da = dl[a];
-    int gain = da;
-    int adj = 0;
+    gain = da;
     if constexpr (DENSE) {
         const T* wrow = matrix + (b * N + a) * N;
         // a diagonal entry (the reference's BA training graphs carry W_ii = +-1 on their seed clique, util_envs_PECO.py:93-95)
@@ -148,12 +153,13 @@ __global__ __launch_bounds__(256) void k_spin_step(rls_spin_env env, int64_t B, 
             if (lane == 0) imm[a] = (T)(-gain) / max_local;
         }
     }
+    }   // !is_pass
     const int nonpos = env.num_nonpos[b] + wave_sum_i32(adj);
 
     // 2. reward w.r.t. the best observed score, best tracking (:366-401)
     const T sc = score[b] + (T)gain;
     const T best_before = best_score[b];
-    const T improvement = sc - best_before;
+    const T improvement = sc - best_obs[b];            // w.r.t. the best OBSERVABLE score: the best of the finite memory, else the best ever
     T rew;
     if (p.reward_mode == 1) rew = improvement > (T)0 ? improvement : (T)0;                              // BLS
     else if (p.reward_mode == 2) rew = improvement > (T)0 ? improvement / (improvement + (T)0.1) : (T)0; // CUSTOM_BLS
@@ -165,38 +171,38 @@ __global__ __launch_bounds__(256) void k_spin_step(rls_spin_env env, int64_t B, 
     // 3. visited-state memory (util_envs_PECO.py:228-288 / util_envs.py:355-381): exact compare of the bit-packed
     //    spins against every earlier state of this env, Zobrist hash as the pre-filter
     bool fresh = true;
-    if (env.packed) {
-        const int64_t W = (N + 63) >> 6;
-        uint64_t* pk = env.packed + b * W;
+    const int64_t W = (N + (env.allow_pass ? 1 : 0) + 63) >> 6;      // (bit N = parity of the PASS actions: util_envs.py:361-366 toggles it)
+    uint64_t* pk = env.packed ? env.packed + b * W : nullptr;
+    if (pk) {
         const int64_t wa = a >> 6;
         const uint64_t bit = 1ull << (a & 63);
         const uint64_t h = env.hash[b] ^ spin_zobrist((uint32_t)a);
-        const uint64_t* hh = env.hist_hash + b * env.hist_cap;
-        const uint64_t* hs = env.hist + b * env.hist_cap * W;
-        bool found = false;
-        for (int64_t t0 = 0; t0 < p.hist_len; t0 += kWave) {
-            const int64_t t = t0 + lane;
-            bool cand = t < p.hist_len && hh[t] == h;
-            if (cand) {
-                const uint64_t* e = hs + t * W;
-                for (int64_t k = 0; k < W && cand; ++k) cand = e[k] == (pk[k] ^ (k == wa ? bit : 0ull));
+        if (env.hist) {
+            const uint64_t* hh = env.hist_hash + b * env.hist_cap;
+            const uint64_t* hs = env.hist + b * env.hist_cap * W;
+            bool found = false;
+            for (int64_t t0 = 0; t0 < p.hist_len; t0 += kWave) {
+                const int64_t t = t0 + lane;
+                bool cand = t < p.hist_len && hh[t] == h;
+                if (cand) {
+                    const uint64_t* e = hs + t * W;
+                    for (int64_t k = 0; k < W && cand; ++k) cand = e[k] == (pk[k] ^ (k == wa ? bit : 0ull));
+                }
+                found = found || cand;
             }
-            found = found || cand;
+            fresh = ballot64(found) == 0;
+            __builtin_amdgcn_wave_barrier();
+            uint64_t* dst = env.hist + (b * env.hist_cap + p.hist_len) * W;
+            for (int64_t k = lane; k < W; k += kWave) dst[k] = pk[k] ^ (k == wa ? bit : 0ull);
+            if (lane == 0) env.hist_hash[b * env.hist_cap + p.hist_len] = h;
+            if (p.use_stag && !fresh) rew = rew - (T)p.stag_punishment;
+            if (p.use_basin && fresh && nonpos == (int)N) rew = rew + (T)p.basin_reward;
         }
-        fresh = ballot64(found) == 0;
         __builtin_amdgcn_wave_barrier();
-        uint64_t* dst = env.hist + (b * env.hist_cap + p.hist_len) * W;
-        for (int64_t k = lane; k < W; k += kWave) {
-            const uint64_t cur = pk[k] ^ (k == wa ? bit : 0ull);
-            dst[k] = cur;
-            if (k == wa) pk[k] = cur;
-        }
-        if (lane == 0) {
-            env.hist_hash[b * env.hist_cap + p.hist_len] = h;
+        if (lane == 0) {                       // issued after every lane's read of the old word above
+            pk[wa] ^= bit;
             env.hash[b] = h;
         }
-        if (p.use_stag && !fresh) rew = rew - (T)p.stag_punishment;
-        if (p.use_basin && fresh && nonpos == (int)N) rew = rew + (T)p.basin_reward;
     }
 
     // 4. best spins / Hamming distance to them, kept incrementally
@@ -218,25 +224,61 @@ __global__ __launch_bounds__(256) void k_spin_step(rls_spin_env env, int64_t B, 
             for (int64_t n = lane; n < N; n += kWave) bs[n] = (n == a) ? s_new : spins[n];
         }
     } else {
-        ham = env.dist_best[b] + ((bs[a] != s_new) ? 1 : -1);
+        ham = env.dist_best[b] + (is_pass ? 0 : ((bs[a] != s_new) ? 1 : -1));
+    }
+    const int ham_best = ham;              // distance to the best-ever spins (kept incrementally across steps)
+
+    // 4b. finite memory (spinsystem.py:398-404): the ring of the last mem_len scores / spin configurations; the best
+    //     OBSERVABLE score and spins are the ring's maximum (first on ties, numpy argmax) -- what the reward of the next
+    //     step and the two distance rows refer to
+    T best_obs_now = best_now;
+    if (env.mem_len > 0) {
+        const int64_t M = env.mem_len, Wn = (N + 63) >> 6;
+        T* ms = reinterpret_cast<T*>(env.mem_score) + b * M;
+        uint64_t* mp = env.mem_spins + b * M * Wn;
+        const int64_t pos = (p.hist_len + 1) % M;           // idx_memory starts at 1 and advances once per step
+        const uint64_t passbit = env.allow_pass ? (1ull << (N & 63)) : 0ull;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // the flipped bit of pk is in memory
+        __builtin_amdgcn_wave_barrier();
+        for (int64_t k = lane; k < Wn; k += kWave) mp[pos * Wn + k] = pk[k] & ~(k == (N >> 6) ? passbit : 0ull);
+        if (lane == 0) ms[pos] = sc;
+        T bv = (T)-INFINITY;
+        int64_t bi = INT64_MAX;
+        for (int64_t t = lane; t < M; t += kWave) {
+            const T v = (t == pos) ? sc : ms[t];
+            if (v > bv) { bv = v; bi = t; }
+        }
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) {
+            const T ov = __shfl_xor(bv, sft, kWave);
+            const int64_t oi = __shfl_xor(bi, sft, kWave);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        best_obs_now = bv;
+        int hm = 0;
+        if (bi != pos)
+            for (int64_t k = lane; k < Wn; k += kWave)
+                hm += __builtin_popcountll((pk[k] & ~(k == (N >> 6) ? passbit : 0ull)) ^ mp[bi * Wn + k]);
+        ham = wave_sum_i32(hm);
     }
 
     // 5. the rows that change everywhere every step (:412-451) are a table lookup away: remember when a flipped and the four
     //    broadcast values; rls_spin_observation / rls_spin_materialize write the rows
     if (lane == 0) {
-        env.last_flip[b * N + a] = (int32_t)(p.hist_len + 1);
+        if (!is_pass) env.last_flip[b * N + a] = (int32_t)(p.hist_len + 1);
         T* sc4 = reinterpret_cast<T*>(env.scalars) + b * 4;
         sc4[0] = (T)p.termination_value;
         sc4[1] = (T)1 - (T)nonpos / (T)N;
-        sc4[2] = (T)fabs((double)(sc - best_now)) / max_local;
+        sc4[2] = (T)fabs((double)(sc - best_obs_now)) / max_local;
         sc4[3] = (T)ham;
+        best_obs[b] = best_obs_now;
     }
     if (lane == 0) {
         score[b] = sc;
         best_score[b] = best_now;
         reward[b] = rew;
         env.num_nonpos[b] = nonpos;
-        env.dist_best[b] = ham;
+        env.dist_best[b] = ham_best;
         if (visited_new) visited_new[b] = fresh ? 1 : 0;
     }
 }
@@ -259,7 +301,8 @@ __global__ __launch_bounds__(256) void k_spin_reset(rls_spin_env env, int64_t B,
     int nonpos = 0;
     int64_t dsum = 0;
     uint64_t h = 0;
-    const int64_t W = (N + 63) >> 6;
+    const int64_t W = (N + (env.allow_pass ? 1 : 0) + 63) >> 6, Wn = (N + 63) >> 6;
+    if (env.packed && W > Wn && lane == 0) env.packed[b * W + Wn] = 0;      // (the PASS parity bit alone in the last word)
     for (int64_t n0 = 0; n0 < N; n0 += kWave) {
         const int64_t n = n0 + lane;
         const bool in = n < N;
@@ -273,6 +316,8 @@ __global__ __launch_bounds__(256) void k_spin_reset(rls_spin_env env, int64_t B,
             if (in && s > (T)0) h ^= spin_zobrist((uint32_t)n);
             if (lane == 0) env.packed[b * W + (n0 >> 6)] = word;
         }
+        if (env.mem_len > 0 && lane < env.mem_len)      // the finite memory starts full of the initial configuration (spinsystem.py:206-209)
+            for (int64_t t = lane; t < env.mem_len; t += kWave) env.mem_spins[(b * env.mem_len + t) * Wn + (n0 >> 6)] = word;
     }
     nonpos = wave_sum_i32(nonpos);
 #pragma unroll
@@ -297,8 +342,13 @@ __global__ __launch_bounds__(256) void k_spin_reset(rls_spin_env env, int64_t B,
         const T sc = (T)(weight_sum - dsum) / (T)4;
         reinterpret_cast<T*>(env.score)[b] = sc;
         reinterpret_cast<T*>(env.best_score)[b] = sc;
+        reinterpret_cast<T*>(env.best_obs_score)[b] = sc;
         env.num_nonpos[b] = nonpos;
         env.dist_best[b] = 0;
+    }
+    if (env.mem_len > 0) {
+        const T sc = (T)(weight_sum - dsum) / (T)4;
+        for (int64_t t = lane; t < env.mem_len; t += kWave) reinterpret_cast<T*>(env.mem_score)[b * env.mem_len + t] = sc;
     }
     if (env.packed) {
         h = wave_xor_u64(h);
@@ -571,8 +621,12 @@ static int check_spin_env(const rls_spin_env* env, int state_bytes, int32_t num_
     RLS_REQUIRE(num_rows >= 1, RLS_EINVAL, "num_rows < 1");
     RLS_REQUIRE(env->state && env->delta && env->score && env->best_score && env->best_spins && env->num_nonpos &&
                     env->dist_best && env->last_flip && env->scalars && env->time_table, RLS_EINVAL, "NULL pointer in rls_spin_env");
-    RLS_REQUIRE(!env->packed || (env->hash && env->hist && env->hist_hash && env->hist_cap > 0), RLS_EINVAL,
+    RLS_REQUIRE(env->best_obs_score, RLS_EINVAL, "best_obs_score is NULL");
+    RLS_REQUIRE(!env->packed || env->hash, RLS_EINVAL, "packed spins need their hash");
+    RLS_REQUIRE(!env->hist || (env->packed && env->hist_hash && env->hist_cap > 0), RLS_EINVAL,
                 "visited-state memory needs packed, hash, hist, hist_hash and hist_cap > 0");
+    RLS_REQUIRE(env->mem_len >= 0 && (env->mem_len == 0 || (env->packed && env->mem_spins && env->mem_score)), RLS_EINVAL,
+                "a finite memory needs packed, mem_spins and mem_score");
     *rows = SpinRows{row_index[0], row_index[1], row_index[2], row_index[3], row_index[4], row_index[5], row_index[6]};
     const int* ri = &rows->immediate;
     for (int k = 0; k < 7; ++k) RLS_REQUIRE(ri[k] < num_rows && ri[k] != 0, RLS_EINVAL, "row_index[%d]=%d out of range", k, ri[k]);
@@ -634,8 +688,8 @@ static int spin_step_common(const rls_graph* g, const void* matrix, const void* 
     RLS_REQUIRE(action && reward, RLS_EINVAL, "action / reward is NULL");
     RLS_REQUIRE(reward_mode >= 0 && reward_mode <= 2, RLS_EINVAL, "reward_mode must be 0 (DENSE), 1 (BLS), 2 (CUSTOM_BLS)");
     RLS_REQUIRE(max_local != 0.0 && reward_div != 0.0, RLS_EINVAL, "max_local_reward_available / reward_div is 0");
-    RLS_REQUIRE(!(use_stag || use_basin) || env->packed, RLS_EINVAL, "stag_punishment / basin_reward need the visited-state memory");
-    RLS_REQUIRE(!env->packed || (hist_len >= 0 && hist_len < env->hist_cap), RLS_EINVAL,
+    RLS_REQUIRE(!(use_stag || use_basin) || env->hist, RLS_EINVAL, "stag_punishment / basin_reward need the visited-state memory");
+    RLS_REQUIRE(!env->hist || (hist_len >= 0 && hist_len < env->hist_cap), RLS_EINVAL,
                 "hist_len %lld outside [0, hist_cap = %lld)", (long long)hist_len, (long long)env->hist_cap);
     RLS_REQUIRE(hist_len >= 0 && hist_len + 1 < env->table_len, RLS_EINVAL, "step %lld outside the time table of %lld entries",
                 (long long)hist_len + 1, (long long)env->table_len);

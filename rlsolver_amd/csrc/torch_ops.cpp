@@ -367,7 +367,7 @@ void spin_step_dense(const Tensor& matrix, const Tensor& max_local, int64_t env,
     shape3(matrix, "matrix", B, N, N);
     TORCH_CHECK(max_local.numel() == B && action.numel() == B && reward.numel() == B, "max_local / action / reward must hold B entries");
     if (visited_new.has_value()) count(*visited_new, "visited_new", B);
-    TORCH_CHECK(hist_len >= 0 && (SE(env)->packed == nullptr || hist_len <= SE(env)->hist_cap), "hist_len outside the visited-state ring");
+    TORCH_CHECK(hist_len >= 0 && (SE(env)->hist == nullptr || hist_len <= SE(env)->hist_cap), "hist_len outside the visited-state ring");
     RLS_GUARD(state);
     ok(rls_spin_step_dense(p(matrix), p(max_local), SE(env), sb, B, N, (int32_t)state.size(1),
                            (const int32_t*)p(row_index), (const int64_t*)p(action), p(reward), (uint8_t*)p(visited_new), termination_value,
@@ -386,7 +386,7 @@ void spin_step(int64_t g, int64_t env, const Tensor& state, const Tensor& row_in
     TORCH_CHECK(state.size(2) == G(g)->num_nodes, "state must be [B, R, ", G(g)->num_nodes, "]");
     TORCH_CHECK(action.numel() == B && reward.numel() == B, "action / reward must hold B entries");
     if (visited_new.has_value()) count(*visited_new, "visited_new", B);
-    TORCH_CHECK(hist_len >= 0 && (SE(env)->packed == nullptr || hist_len <= SE(env)->hist_cap), "hist_len outside the visited-state ring");
+    TORCH_CHECK(hist_len >= 0 && (SE(env)->hist == nullptr || hist_len <= SE(env)->hist_cap), "hist_len outside the visited-state ring");
     RLS_GUARD(state);
     ok(rls_spin_step(G(g), SE(env), sb, B, (int32_t)state.size(1), (const int32_t*)p(row_index),
                      (const int64_t*)p(action), p(reward), (uint8_t*)p(visited_new), max_local, termination_value, (int32_t)reward_mode,

@@ -107,7 +107,8 @@ class SpinSystem:
                  reward_signal: RewardSignal = RewardSignal.DENSE, spin_basis: SpinBasis = SpinBasis.SIGNED,
                  norm_rewards: bool = False, horizon_length: Optional[int] = None,
                  stag_punishment: Optional[float] = None, basin_reward: Optional[float] = None,
-                 device=None, include_adjacency: bool = True, dtype=torch.float32, graph_generator=None):
+                 device=None, include_adjacency: bool = True, dtype=torch.float32, graph_generator=None,
+                 extra_action: ExtraAction = ExtraAction.NONE, memory_length: Optional[int] = None):
         self.device = torch.device(device if device is not None else "cuda:0")
         if self.device.type != "cuda":
             raise TypeError(f"rlsolver_amd.SpinSystem needs a HIP device (got {self.device}); there is no CPU path")
@@ -124,13 +125,23 @@ class SpinSystem:
                 raise ValueError("pass either mygraph (one shared graph) or graph_generator (per-env matrices)")
             num_nodes = int(graph_generator.n_spins) if num_nodes is None else num_nodes
         self.num_envs, self.n_spins, self.max_steps = num_envs, num_nodes, max_steps
-        self.n_actions = num_nodes                       # extra_action = NONE
+        # ExtraAction.PASS and a finite memory_length are options of the single-instance numpy env (spinsystem.py:349-351,
+        # 398-404; SpinSystemUnbiased below passes them).  The reference's BATCHED env cannot even be constructed with them
+        # (spinsystem_PECO.py raises in its constructor), so SpinSystemFactory.get keeps refusing them.
+        if extra_action not in (ExtraAction.NONE, ExtraAction.PASS):
+            raise NotImplementedError("ExtraAction.RANDOMISE: the reference itself raises on its first use (spinsystem.py:352-358 "
+                                      "multiplies an [n_spins + 1] row with an [n_spins] draw)")
+        if memory_length is not None and memory_length < 2:
+            raise ValueError("memory_length must be >= 2 or None (the reference starts writing its ring at index 1, spinsystem.py:209: "
+                             "a ring of one slot raises IndexError on its first step)")
+        self._pass = extra_action == ExtraAction.PASS
+        self.n_actions = num_nodes + int(self._pass)
         self.reward_signal, self.norm_rewards, self.spin_basis = reward_signal, norm_rewards, spin_basis
         self.horizon_length = horizon_length if horizon_length is not None else max_steps
         self.stag_punishment, self.basin_reward = stag_punishment, basin_reward
         self.reversible_spins = True
-        self.extra_action, self.optimisation_target = ExtraAction.NONE, OptimisationTarget.CUT
-        self.memory_length = None
+        self.extra_action, self.optimisation_target = extra_action, OptimisationTarget.CUT
+        self.memory_length = memory_length
         self.include_adjacency = include_adjacency
         self.action_space = self._ActionSpace(self.n_actions, self.device)
         self.observation_space = self._ObservationSpace(self.n_spins, len(observables))
@@ -177,22 +188,31 @@ class SpinSystem:
         self.best_score = torch.zeros(B, dtype=dt, device=self.device)
         self.best_spins = torch.zeros((B, N), dtype=dt, device=self.device)
         self._use_hist = stag_punishment is not None or basin_reward is not None
-        W = (N + 63) // 64
-        if self._use_hist:   # one slot per step of an episode; torch.int64 carries the uint64 bit patterns
+        self._use_packed = self._use_hist or memory_length is not None
+        W = (N + int(self._pass) + 63) // 64
+        self.best_obs_score = torch.zeros(B, dtype=dt, device=self.device)
+        if self._use_packed:   # torch.int64 carries the uint64 bit patterns
             self._packed = torch.zeros((B, W), dtype=torch.int64, device=self.device)
             self._hash = torch.zeros(B, dtype=torch.int64, device=self.device)
+        if self._use_hist:     # one slot per step of an episode
             self._hist = torch.zeros((B, max_steps, W), dtype=torch.int64, device=self.device)
             self._hist_hash = torch.zeros((B, max_steps), dtype=torch.int64, device=self.device)
+        if memory_length is not None:
+            self._mem_spins = torch.zeros((B, memory_length, (N + 63) // 64), dtype=torch.int64, device=self.device)
+            self._mem_score = torch.zeros((B, memory_length), dtype=dt, device=self.device)
         self._visited_new = torch.ones(B, dtype=torch.uint8, device=self.device)
         self._env = _abi.RlsSpinEnv(
             state=self._state.data_ptr(), delta=self._delta.data_ptr(), score=self.score.data_ptr(),
             best_score=self.best_score.data_ptr(), best_spins=self.best_spins.data_ptr(),
             num_nonpos=self._num_nonpos.data_ptr(), dist_best=self._dist_best.data_ptr(),
-            packed=self._packed.data_ptr() if self._use_hist else 0, hash=self._hash.data_ptr() if self._use_hist else 0,
+            packed=self._packed.data_ptr() if self._use_packed else 0, hash=self._hash.data_ptr() if self._use_packed else 0,
             hist=self._hist.data_ptr() if self._use_hist else 0,
             hist_hash=self._hist_hash.data_ptr() if self._use_hist else 0, hist_cap=max_steps if self._use_hist else 0,
             last_flip=self._last_flip.data_ptr(), scalars=self._scalars.data_ptr(), time_table=self._time_table.data_ptr(),
-            table_len=self._time_table.numel())
+            table_len=self._time_table.numel(), best_obs_score=self.best_obs_score.data_ptr(),
+            mem_spins=self._mem_spins.data_ptr() if memory_length is not None else 0,
+            mem_score=self._mem_score.data_ptr() if memory_length is not None else 0,
+            mem_len=memory_length or 0, allow_pass=int(self._pass))
         self._env_handle = C.addressof(self._env)     # the `env` argument of torch.ops.rlsolver_hip.spin_*
         self.current_step = 0
         self.reset()
@@ -274,8 +294,7 @@ class SpinSystem:
             # gains of all single flips: delta_i = s_i sum_j W_ij s_j = sum_j W_ij (x_i == x_j ? 1 : -1): the K3 kernel
             ops.maxcut_delta_all(self.graph, bits, out=self._delta)
             _t.spin_reset(self.graph.handle, self._env_handle, self._state, self._rows, self._max_local, self._weight_sum)
-        self.best_obs_score = self.best_score
-        self.best_obs_spins = self.best_spins
+        self.best_obs_spins = self.best_spins          # (with a finite memory the best observable spins live bit-packed in the ring)
         return self.get_observation()
 
     def calculate_cut(self, spins=None):
@@ -357,16 +376,23 @@ class SpinSystem:
     _STATE_KEYS = ("_state", "_delta", "score", "best_score", "best_spins", "_num_nonpos", "_dist_best", "_last_flip", "_scalars")
     _DENSE_KEYS = ("_matrix", "max_local_reward_available_", "_weight_sum_env")
     _HIST_KEYS = ("_packed", "_hash", "_hist", "_hist_hash")
+    _MEM_KEYS = ("_packed", "_hash", "_mem_spins", "_mem_score")
+
+    def _dict_keys(self):
+        keys = self._STATE_KEYS + ("best_obs_score",) + (self._HIST_KEYS if self._use_hist else ()) + (self._DENSE_KEYS if self._dense else ())
+        if self.memory_length is not None:
+            keys += tuple(k for k in self._MEM_KEYS if k not in keys)
+        return keys
 
     def state_dict(self):
-        keys = self._STATE_KEYS + (self._HIST_KEYS if self._use_hist else ()) + (self._DENSE_KEYS if self._dense else ())
+        keys = self._dict_keys()
         self.state                                            # (materialises the lazy rows first)
         d = {k.lstrip("_"): getattr(self, k).clone() for k in keys}
         d["current_step"] = self.current_step
         return d
 
     def load_state_dict(self, d):
-        keys = self._STATE_KEYS + (self._HIST_KEYS if self._use_hist else ()) + (self._DENSE_KEYS if self._dense else ())
+        keys = self._dict_keys()
         for k in keys:
             getattr(self, k).copy_(d[k.lstrip("_")])     # in place: the kernel's pointer table stays valid
         self.current_step = int(d["current_step"])
@@ -417,7 +443,14 @@ class SpinSystemUnbiased:
         step(action: int) -> (obs, reward: float, done: bool, None)                      (:333-482)
 
     attrs: n_spins, max_steps, current_step, score, best_score, best_spins, state (np [R, N]), matrix.
-    ExtraAction.NONE, OptimisationTarget.CUT, infinite memory, reversible spins (what ECO / S2V use)."""
+    OptimisationTarget.CUT, reversible spins (what ECO / S2V use); ExtraAction.NONE or PASS, infinite or finite memory.
+
+    With ``extra_action=ExtraAction.PASS`` (the reference's default) there are n_spins + 1 actions; action n_spins flips
+    nothing (spinsystem.py:349-351).  The reference then carries a padding column through its arrays -- state [R, N + 1],
+    matrix_obs [N + 1, N + 1], observation [R + N + 1, N + 1] -- whose entries are written by the row-wide assignments
+    of its step (:417-447) and by nothing else; this class adds exactly that column on the way out (the kernels work on
+    the N real spins).  ``memory_length`` = M: rewards and the two distance rows refer to the best of the last M
+    scores / configurations instead of the best ever (:398-404)."""
 
     class _OneGraph:
         """A single-instance generator (get() -> [N, N] array, ECO_S2V/src/envs/util_envs.py:87-330) as a batch of one."""
@@ -433,28 +466,70 @@ class SpinSystemUnbiased:
                  reward_signal: RewardSignal = RewardSignal.DENSE, spin_basis: SpinBasis = SpinBasis.SIGNED,
                  norm_rewards: bool = False, horizon_length: Optional[int] = None,
                  stag_punishment: Optional[float] = None, basin_reward: Optional[float] = None, device=None,
-                 init_spins=None, graph_generator=None):
+                 init_spins=None, graph_generator=None, extra_action: ExtraAction = ExtraAction.NONE,
+                 memory_length: Optional[int] = None):
         """``graph_generator`` (instead of mygraph): a fresh graph at every reset, as the ECO / S2V training loops run their
         envs (train_ECO.py:83-94; any object with n_spins and get() -> [N, N] symmetric integer-valued array)."""
         gg = self._OneGraph(graph_generator) if graph_generator is not None else None
         num_nodes = gg.n_spins if gg is not None and num_nodes is None else num_nodes
         self._env = SpinSystem(mygraph, num_nodes, 1, max_steps, observables, reward_signal, spin_basis, norm_rewards,
                                horizon_length, stag_punishment, basin_reward, device, include_adjacency=True,
-                               dtype=torch.float64, graph_generator=gg)
-        self.n_spins, self.max_steps, self.n_actions = num_nodes, max_steps, num_nodes
+                               dtype=torch.float64, graph_generator=gg, extra_action=ExtraAction[extra_action.name],
+                               memory_length=memory_length)
+        self._pass = self._env._pass
+        self.extra_action, self.memory_length = self._env.extra_action, memory_length
+        self.n_spins, self.max_steps, self.n_actions = num_nodes, max_steps, num_nodes + int(self._pass)
+        self._last_pass = 0                     # the step of the last PASS (the padding column's "last flip")
+        self._stepped = False
         self.observables = self._env.observables
         self.action_space, self.observation_space = self._env.action_space, self._env.observation_space
         if init_spins is not None:
             self.reset(init_spins)
 
+    def _pad_rows(self, rows: np.ndarray, binary_row0: bool) -> np.ndarray:
+        """[R, N] observable rows -> [R, N + 1] as the reference holds them under ExtraAction.PASS: the padding column takes what
+        the ROW-WIDE assignments of step() put there (time since the last PASS, episode time, termination, greedy count --
+        only once a step has run: reset writes it for the real spins alone, spinsystem.py:259-261 --, distance from the best
+        score) and stays 0 elsewhere (spin, immediate reward, distance from the best state: [:n_spins] assignments)."""
+        if not self._pass:
+            return rows
+        env = self._env
+        out = np.zeros((rows.shape[0], rows.shape[1] + 1), dtype=rows.dtype)
+        out[:, :-1] = rows
+        table = env._time_table.cpu().numpy()
+        for idx, ob in env.observables:
+            if ob == Observable.TIME_SINCE_FLIP:
+                out[idx, -1] = table[env.current_step - self._last_pass]
+            elif ob in (Observable.EPISODE_TIME, Observable.TERMINATION_IMMANENCY, Observable.DISTANCE_FROM_BEST_SCORE):
+                out[idx, -1] = rows[idx, 0]
+            elif ob == Observable.NUMBER_OF_GREEDY_ACTIONS_AVAILABLE and self._stepped:
+                out[idx, -1] = rows[idx, 0]
+        if binary_row0:
+            out[0, -1] = 0.5                     # get_observation maps the padding spin 0 to (1 - 0) / 2 (:487-489)
+        return out
+
     def _obs(self, obs):
-        return obs[0].cpu().numpy()
+        o = obs[0].cpu().numpy()
+        if not self._pass:
+            return o
+        R, N = len(self._env.observables), self.n_spins
+        out = np.zeros((R + N + 1, N + 1), dtype=o.dtype)
+        out[:R] = self._pad_rows(o[:R], self._env.spin_basis == SpinBasis.BINARY)
+        out[R:R + N, :N] = o[R:]                 # matrix_obs: the couplings padded with a zero row and column (:222-225)
+        return out
 
     def reset(self, spins=None):
-        return self._obs(self._env.reset(None if spins is None else np.asarray(spins, dtype=np.float64)[None, :]))
+        self._last_pass, self._stepped = 0, False
+        if spins is not None:
+            spins = np.asarray(spins, dtype=np.float64)[: self.n_spins][None, :]
+        return self._obs(self._env.reset(spins))
 
     def step(self, action):
-        obs, rew, done = self._env.step(torch.tensor([int(action)], dtype=torch.int64))
+        action = int(action)
+        if self._pass and action == self.n_spins:
+            self._last_pass = self._env.current_step + 1
+        obs, rew, done = self._env.step(torch.tensor([action], dtype=torch.int64))
+        self._stepped = True
         return self._obs(obs), float(rew[0]), bool(done[0]), None
 
     def get_observation(self):
@@ -465,7 +540,8 @@ class SpinSystemUnbiased:
     score = property(lambda self: float(self._env.score[0]))
     best_score = property(lambda self: float(self._env.best_score[0]))
     best_spins = property(lambda self: self._env.best_spins[0].cpu().numpy())
-    state = property(lambda self: self._env.state[0].cpu().numpy())
+    state = property(lambda self: self._pad_rows(self._env.state[0].cpu().numpy(), False))
+    best_obs_score = property(lambda self: float(self._env.best_obs_score[0]))
     matrix = property(lambda self: (self._env.matrix[0] if self._env._dense else self._env.matrix).cpu().numpy())
 
     def get_immeditate_rewards_avaialable(self, spins=None):

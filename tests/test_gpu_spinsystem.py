@@ -412,3 +412,77 @@ def test_single_instance_env_on_a_graph_generator():
         (o1, r1, d1, _), (o2, r2, d2, _) = env.step(a), ref.step(a)
         assert np.array_equal(o1, o2) and r1 == r2 and d1 == d2
     assert env.best_score == ref.best_score and np.array_equal(env.best_spins, ref.best_spins)
+
+
+@pytest.mark.parametrize("cname", ["pass", "mem3", "pass_mem4_stag"])
+def test_spinsystem_options_golden(golden, cname):
+    """spinsystem_options.npz (the reference's numpy env with ExtraAction.PASS -- its default -- and / or a finite
+    memory_length): SpinSystemUnbiased on the HIP env reproduces the padded observation and state, rewards, scores, best and
+    best OBSERVABLE score bit for bit over 48 steps with passes, undo moves and revisits."""
+    from rlsolver_amd.envs.spinsystem import ECO_PECO_OBSERVABLES, ExtraAction, RewardSignal, SpinBasis, SpinSystemUnbiased
+    z = golden("spinsystem_options")
+    g = z["graph"]
+    n = int(g[:, :2].max()) + 1
+    cfg = {"pass": dict(reward_signal=RewardSignal.BLS, norm_rewards=True, basin_reward=1.0 / n, extra_action=ExtraAction.PASS),
+           "mem3": dict(reward_signal=RewardSignal.BLS, norm_rewards=False, memory_length=3),
+           "pass_mem4_stag": dict(reward_signal=RewardSignal.CUSTOM_BLS, norm_rewards=False, basin_reward=0.25, stag_punishment=0.125,
+                                  extra_action=ExtraAction.PASS, memory_length=4)}[cname]
+    T = int(z["max_steps"])
+    env = SpinSystemUnbiased([tuple(int(v) for v in r) for r in g], n, max_steps=T, observables=ECO_PECO_OBSERVABLES,
+                             spin_basis=SpinBasis.BINARY, device=DEV, **cfg)
+    na = int(z[f"{cname}/n_actions"])
+    assert env.n_actions == na and env.action_space.n == na
+    obs = env.reset(z[f"{cname}/spins0"])
+    assert obs.shape == (7 + na, na) and np.array_equal(obs, z[f"{cname}/obs0"])
+    assert np.array_equal(env.state, z[f"{cname}/state0"])
+    for t in range(T):
+        o, r, d, info = env.step(int(z[f"{cname}/actions"][t]))
+        assert np.array_equal(o[:7], z[f"{cname}/obs"][t]), t
+        assert np.array_equal(env.state, z[f"{cname}/state"][t]), t
+        assert r == z[f"{cname}/rew"][t] and d == bool(z[f"{cname}/done"][t]), t
+        assert env.score == z[f"{cname}/score"][t] and env.best_score == z[f"{cname}/best_score"][t], t
+        assert env.best_obs_score == z[f"{cname}/best_obs_score"][t], t
+    assert np.array_equal(o[7:], z[f"{cname}/adj_rows"]) and np.array_equal(env.best_spins, z[f"{cname}/best_spins"])
+
+
+def test_spinsystem_options_against_oracle_random_and_refusals():
+    """PASS + finite memory at a size with three words per packed state (N = 130, the PASS bit in the third), both
+    visited-state rewards, random actions with passes and undo moves, against the float64 restatement; the options the
+    reference cannot run are refused."""
+    from oracle.oracle_spin import SpinSystemOracleF64
+    from rlsolver_amd.envs.spinsystem import (ECO_PECO_OBSERVABLES, ExtraAction, RewardSignal, SpinBasis, SpinSystem, SpinSystemFactory,
+                                              SpinSystemUnbiased)
+    from rlsolver_amd.graph import generate_gnm
+    for n, m, M in ((130, 420, 5), (64, 200, 2), (127, 380, 7)):
+        rng = np.random.RandomState(n + M)
+        mg = [(a, b, int(rng.choice([-1, 1]))) for a, b, _ in generate_gnm(n, m, 4)]
+        W = np.zeros((n, n))
+        for a, b, w in mg:
+            W[a, b] = W[b, a] = w
+        T = 70
+        env = SpinSystemUnbiased(mg, n, max_steps=T, observables=ECO_PECO_OBSERVABLES, spin_basis=SpinBasis.BINARY, device=DEV,
+                                 reward_signal=RewardSignal.BLS, norm_rewards=True, basin_reward=0.5, stag_punishment=0.25,
+                                 extra_action=ExtraAction.PASS, memory_length=M)
+        ora = SpinSystemOracleF64(W, T, reward="BLS", norm_rewards=True, basin_reward=0.5, stag_punishment=0.25, extra_pass=True,
+                                  memory_length=M)
+        s0 = (2 * rng.randint(0, 2, size=n) - 1).astype(np.float64)
+        assert np.array_equal(env.reset(s0), ora.reset(s0))
+        prev = 0
+        for t in range(T):
+            a = int(rng.randint(0, n))
+            a = prev if t % 4 == 3 else (n if t % 7 == 2 else a)
+            prev = a
+            o, r, d, _ = env.step(a)
+            wo, wr, wd = ora.step(a)
+            assert np.array_equal(o, wo) and r == wr and d == wd, (n, M, t)
+            assert env.best_obs_score == ora.best_obs_score and env.best_score == ora.best_score
+    mg = [(0, 1, 1), (1, 2, -1)]
+    with pytest.raises(NotImplementedError):
+        SpinSystemUnbiased(mg, 3, extra_action=ExtraAction.RANDOMISE, device=DEV)
+    with pytest.raises(ValueError):
+        SpinSystemUnbiased(mg, 3, memory_length=1, device=DEV)
+    with pytest.raises(NotImplementedError):      # the batched factory: the reference's own constructor raises for these
+        SpinSystemFactory.get(graph_generator=None, extra_action=ExtraAction.PASS)
+    env = SpinSystem(mg, 3, 2, device=DEV)
+    _, r, _ = env.step(torch.tensor([3, 0], device=DEV))             # without PASS action N stays out of range: NaN, env untouched
+    assert bool(torch.isnan(r[0])) and not bool(torch.isnan(r[1]))

@@ -67,3 +67,41 @@ def test_spin_oracle_f64_single_env_golden(golden, gname, cname):
     assert np.array_equal(env.best_spins, z[f"{tag}/best_spins"])
     assert np.array_equal(o[7:], z[f"{tag}/adj_rows"])
     assert (z[f"{tag}/rew"] != 0).any()
+
+
+@pytest.mark.parametrize("cname", ["pass", "mem3", "pass_mem4_stag"])
+def test_f64_oracle_options_golden(golden, cname):
+    """spinsystem_options.npz: ExtraAction.PASS and a finite memory_length on the reference's numpy env (spinsystem.py:349-351,
+    :398-404), alone and together with the visited-state rewards: the restatement reproduces the padded state, the
+    observation, rewards, scores and the best observable score bit for bit."""
+    z = golden("spinsystem_options")
+    g = z["graph"]
+    n = int(g[:, :2].max()) + 1
+    W = np.zeros((n, n))
+    for a, b, w in g:
+        W[a, b] = W[b, a] = w
+    cfg = {"pass": dict(reward="BLS", norm_rewards=True, basin_reward=1.0 / n, extra_pass=True),
+           "mem3": dict(reward="BLS", memory_length=3),
+           "pass_mem4_stag": dict(reward="CUSTOM_BLS", basin_reward=0.25, stag_punishment=0.125, extra_pass=True, memory_length=4)}[cname]
+    T = int(z["max_steps"])
+    env = SpinSystemOracleF64(W, T, **cfg)
+    assert env.na == int(z[f"{cname}/n_actions"])
+    obs = env.reset(z[f"{cname}/spins0"])
+    assert np.array_equal(obs, z[f"{cname}/obs0"]) and np.array_equal(env.state, z[f"{cname}/state0"])
+    for t in range(T):
+        o, r, d = env.step(int(z[f"{cname}/actions"][t]))
+        assert np.array_equal(o[:7], z[f"{cname}/obs"][t]), t
+        assert np.array_equal(env.state, z[f"{cname}/state"][t]), t
+        assert r == z[f"{cname}/rew"][t] and d == bool(z[f"{cname}/done"][t]), t
+        assert env.score == z[f"{cname}/score"][t] and env.best_score == z[f"{cname}/best_score"][t]
+        assert env.best_obs_score == z[f"{cname}/best_obs_score"][t], t
+    assert np.array_equal(o[7:], z[f"{cname}/adj_rows"]) and np.array_equal(env.best_spins, z[f"{cname}/best_spins"])
+
+
+def test_reference_facts_about_unrunnable_options(golden):
+    """What the reference does with the options the build refuses: the batched env cannot be constructed with an extra
+    action or a finite memory, RANDOMISE raises on first use in the numpy env (exception type names recorded by gen_golden)."""
+    z = golden("spinsystem_options")
+    assert str(z["facts/batched_none_constructs"]) == "ok"
+    assert str(z["facts/batched_pass_ctor"]) == "RuntimeError" and str(z["facts/batched_randomise_ctor"]) == "RuntimeError"
+    assert str(z["facts/batched_memory3_ctor"]) == "TypeError" and str(z["facts/numpy_randomise_first_use"]) == "ValueError"

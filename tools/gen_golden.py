@@ -997,6 +997,104 @@ def gen_spinsystem_cpu():
     save("spinsystem_cpu", **out)
 
 
+def gen_spinsystem_options():
+    """The options of the numpy single-instance env that its default arguments switch on (spinsystem.py:84-95):
+    ExtraAction.PASS (action n_spins flips nothing, :349-351; every array carries a padding column) and a finite
+    memory_length (the best OBSERVABLE score / spins are the best of the last M, :398-404), alone and together with the
+    visited-state rewards.  (The BATCHED env, spinsystem_PECO.py, raises in its constructor for either option, and
+    ExtraAction.RANDOMISE raises on first use in both: recorded as facts below.)"""
+    from rlsolver.methods.ECO_S2V.src.envs import spinsystem as spc
+    from rlsolver.methods.ECO_S2V.src.envs import spinsystem_PECO as spb
+    from rlsolver.methods.ECO_S2V.src.envs import util_envs_PECO as upe
+    from rlsolver.methods.ECO_S2V.src.envs.util_envs import (ECO_PECO_OBSERVABLES, EdgeType, ExtraAction, GraphGenerator,
+                                                             OptimisationTarget, RewardSignal, SpinBasis)
+    from rlsolver.methods.util_read_data import read_mygraph
+    out = {}
+    gname = "PL_20_ID0"
+    mygraph = read_mygraph(os.path.join(DATA, GRAPHS[gname]))
+    n = max(max(a, b) for a, b, _ in mygraph) + 1
+    rng = np.random.RandomState(44)
+    wl = [(a, b, int(rng.choice([-1, 1]))) for a, b, _ in mygraph]
+    W = np.zeros((n, n), dtype=np.float64)
+    for a, b, w in wl:
+        W[a, b] = W[b, a] = w
+    out["graph"] = np.asarray(wl, dtype=np.int64)
+
+    class Fixed(GraphGenerator):
+        def __init__(self):
+            super().__init__(n, EdgeType.DISCRETE, False)
+
+        def get(self, with_padding=False):
+            return W.copy()
+
+    cfgs = {"pass": dict(extra_action=ExtraAction.PASS, memory_length=None, reward_signal=RewardSignal.BLS, norm_rewards=True,
+                         basin_reward=1.0 / n, stag_punishment=None),
+            "mem3": dict(extra_action=ExtraAction.NONE, memory_length=3, reward_signal=RewardSignal.BLS, norm_rewards=False,
+                         basin_reward=None, stag_punishment=None),
+            "pass_mem4_stag": dict(extra_action=ExtraAction.PASS, memory_length=4, reward_signal=RewardSignal.CUSTOM_BLS,
+                                   norm_rewards=False, basin_reward=0.25, stag_punishment=0.125)}
+    max_steps = 48
+    for cname, cfg in cfgs.items():
+        env = spc.SpinSystemFactory.get(Fixed(), max_steps, observables=ECO_PECO_OBSERVABLES,
+                                        optimisation_target=OptimisationTarget.CUT, spin_basis=SpinBasis.BINARY,
+                                        horizon_length=None, reversible_spins=True, seed=23, **cfg)
+        na = env.n_actions
+        out[f"{cname}/n_actions"] = np.int64(na)
+        out[f"{cname}/spins0"] = env.state[0, :n].copy()
+        out[f"{cname}/obs0"] = env.get_observation().copy()
+        out[f"{cname}/state0"] = env.state.copy()
+        r2 = np.random.RandomState(29)
+        acts, states, obs, rews, dones, scores, bests, bobs = [], [], [], [], [], [], [], []
+        prev = 0
+        for t in range(max_steps):
+            a = int(r2.randint(0, n))
+            if t % 3 == 2:
+                a = prev                           # undo: a revisited state, and a score that leaves the finite memory
+            if na > n and t % 5 == 1:
+                a = n                              # PASS
+            prev = a
+            o, r, d, _ = env.step(a)
+            assert o.shape == (7 + na, na)
+            acts.append(a); obs.append(o[:7].copy()); states.append(env.state.copy()); rews.append(float(r)); dones.append(bool(d))
+            scores.append(float(env.score)); bests.append(float(env.best_score)); bobs.append(float(env.best_obs_score))
+        out[f"{cname}/adj_rows"] = o[7:].copy()
+        out[f"{cname}/actions"] = np.asarray(acts, dtype=np.int64)
+        out[f"{cname}/obs"] = np.stack(obs)
+        out[f"{cname}/state"] = np.stack(states)
+        out[f"{cname}/rew"] = np.asarray(rews, dtype=np.float64)
+        out[f"{cname}/done"] = np.asarray(dones)
+        out[f"{cname}/score"] = np.asarray(scores, dtype=np.float64)
+        out[f"{cname}/best_score"] = np.asarray(bests, dtype=np.float64)
+        out[f"{cname}/best_obs_score"] = np.asarray(bobs, dtype=np.float64)
+        out[f"{cname}/best_spins"] = np.asarray(env.best_spins, dtype=np.float64)
+    out["max_steps"] = np.int64(max_steps)
+
+    # what the reference does with the options it cannot run: exception type names, as facts
+    def outcome(fn):
+        try:
+            fn()
+            return "ok"
+        except Exception as e:       # noqa: BLE001 -- the type is the datum
+            return type(e).__name__
+    env = spc.SpinSystemFactory.get(Fixed(), 8, observables=ECO_PECO_OBSERVABLES, extra_action=ExtraAction.RANDOMISE,
+                                    optimisation_target=OptimisationTarget.CUT, spin_basis=SpinBasis.BINARY, reversible_spins=True, seed=1)
+    out["facts/numpy_randomise_first_use"] = np.array(outcome(lambda: env.step(n)))
+    gg = upe.RandomBAGraphGenerator(n_spins=20, m_insertion_edges=4, edge_type=EdgeType.DISCRETE, num_envs=4, device="cpu")
+
+    def batched(**kw):
+        base = dict(extra_action=ExtraAction.NONE, memory_length=None)
+        base.update(kw)
+        return lambda: spb.SpinSystemFactory.get(gg, 10, observables=ECO_PECO_OBSERVABLES, reward_signal=RewardSignal.BLS,
+                                                 extra_action=base["extra_action"], optimisation_target=OptimisationTarget.CUT,
+                                                 spin_basis=SpinBasis.BINARY, norm_rewards=True, memory_length=base["memory_length"],
+                                                 horizon_length=None, reversible_spins=True, device=th.device("cpu"), num_envs=4)
+    out["facts/batched_none_constructs"] = np.array(outcome(batched()))
+    out["facts/batched_pass_ctor"] = np.array(outcome(batched(extra_action=ExtraAction.PASS)))
+    out["facts/batched_randomise_ctor"] = np.array(outcome(batched(extra_action=ExtraAction.RANDOMISE)))
+    out["facts/batched_memory3_ctor"] = np.array(outcome(batched(memory_length=3)))
+    save("spinsystem_options", **out)
+
+
 def gen_isco_steps():
     """Full sampler steps of the two ISCO envs with every torch draw recorded:
     ISCO_maxcut.step (envs/env_ISCO.py:26-49; methods/util.py:498-570 multinomial / mh_step) and
@@ -1110,7 +1208,7 @@ def gen_isco_steps():
 
 ALL = {"mcpg_weighted": gen_mcpg_weighted, "isco_steps": gen_isco_steps, "spinsystem_cpu": gen_spinsystem_cpu, "spinsystem": gen_spinsystem, "spinsystem_perenv": gen_spinsystem_perenv, "qubo": gen_qubo, "isco_maxcut": gen_isco_maxcut, "maxcut": gen_maxcut, "sweep": gen_sweep, "lsclass": gen_local_search_class, "ppo": gen_ppo,
        "select": gen_select, "mcpg": gen_mcpg, "tsp": gen_tsp, "tsp_2opt": gen_tsp_2opt, "encoder": gen_encoder,
-       "wgain": gen_weighted_gain, "mcpg_glue": gen_mcpg_glue, "evaluator": gen_evaluator}
+       "wgain": gen_weighted_gain, "mcpg_glue": gen_mcpg_glue, "evaluator": gen_evaluator, "spinsystem_options": gen_spinsystem_options}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
