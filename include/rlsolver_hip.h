@@ -171,8 +171,8 @@ int rls_maxcut_step(const rls_graph* g, const void* x_in, void* x_out, int spin_
 /* K5  greedy single-flip sweep ("addition" loop)  envs/env_L2A.py:109-116,
  *     methods/LocalSearch.py:77-83:  for i in 0..N-1: flip i if the cut does
  *     not decrease (ties accept, update_xs_by_vs uses ge, util_read_data.py:199).
- * x [B,N] and obj [B] (int64) are updated in place.  One sequential O(E) pass
- * per env instead of N full objective evaluations. */
+ * x [B,N] and obj [B] (int64) are updated in place; obj[b] must hold the cut of x[b] on entry (the accept rule
+ * compares every candidate against it).  One sequential O(E) pass per env instead of N full objective evaluations. */
 int rls_maxcut_greedy_sweep(const rls_graph* g, uint8_t* x, int64_t B,
                             int64_t* obj, void* stream);
 

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(SW * kWave) void k_maxcut_greedy_sweep_batched(
 }
 
 // Level-parallel variant (rls_sweep.h: sweep_tile_levels): lane = node, one pass per dependency level.
-// obj += cut(after) - cut(before), both from the bit-sliced counter on the resident tile.
+// obj = cut(after) from the bit-sliced counter on the resident tile.
 template <bool VEC, int SW, int P>
 __global__ __launch_bounds__(SW * kWave) void k_maxcut_greedy_sweep_levels(
     uint8_t* __restrict__ x, int64_t B, int64_t N, const int32_t* __restrict__ lv_ptr,
@@ -185,12 +185,14 @@ __global__ __launch_bounds__(SW * kWave) void k_maxcut_greedy_sweep_levels(
     unsigned char* stage = VEC ? stages + (w % LW) * kStageBytes : nullptr;
     if (w < LW) tile_load_bits<uint8_t, VEC>(x, B, N, b0, words, lane, w, LW, stage);
     __syncthreads();
-    const int64_t before = block_sum_partials<SW>(tile_cut_count<P>(words, eu, ev, E, lane, w, SW), scratch, lane, w);
-    __syncthreads();
     sweep_tile_levels<SW>(words, lvp, lv_data, G, N, lane, w);
+    // obj[b] must be the cut of x[b] on entry (the sweep's accept rule compares against it in the reference: the level form
+    // decides by the local gain, which is the same thing exactly then) -- so on exit it is simply the cut of the new x[b],
+    // counted once on the resident tile (round 2 counted before AND after and added the difference: a quarter of the
+    // kernel's VALU work at G22 size, where the SQ counters show the SIMDs ~90 % busy)
     const int64_t after = block_sum_partials<SW>(tile_cut_count<P>(words, eu, ev, E, lane, w, SW), scratch, lane, w);
     if (w < LW) tile_store_bytes<VEC>(x, B, N, b0, words, lane, w, LW, true, stage);
-    if (w == 0 && b0 + lane < B) obj[b0 + lane] += halve ? ((after - before) >> 1) : (after - before);
+    if (w == 0 && b0 + lane < B) obj[b0 + lane] = halve ? (after >> 1) : after;
 }
 
 // generic fallback (weighted graphs, hubs with degree > kSweepMaxDeg): one global row fetch per node

@@ -28,7 +28,7 @@ ROWS = [
     (r"k_maxcut_step<unsigned char, 4, 2, true", 65536 // 4 * 64, 65536, 2 * N22 + 20, "K4 maxcut_step emit u8 | G22 2^16 (headline)"),
     (r"k_maxcut_step<float, 1, 2, true", 65536 * 64, 65536, 8 * N22 + 20, "K4 maxcut_step emit f32 gym surface | G22 2^16"),
     (r"k_maxcut_step<unsigned char, 1, 2, true", 131072 * 64, 131072, 2 * N70 + 20, "K4 maxcut_step emit u8 | G70 2^17"),
-    (r"k_maxcut_step<float, 1, 1, true", 131072 * 64, 131072, 8 * N70 + 20, "K4 maxcut_step emit f32 gym surface | G70 2^17"),
+    (r"k_maxcut_step<float, 1, 2, true", 131072 * 64, 131072, 8 * N70 + 20, "K4 maxcut_step emit f32 gym surface | G70 2^17 (80 KB of LDS per workgroup, nontemporal stores)"),
     (r"k_maxcut_step<unsigned char, 8, 2, true", 256 // 8 * 64, 256, 2 * N14 + 20, "K4 maxcut_step emit u8 | G14 256 (launch-bound)"),
     (r"k_maxcut_obj<", T22 * 256, 65536, N22 + 8, "K1 maxcut_obj | G22 2^16"),
     (r"k_maxcut_obj<", T70 * 512, 131072, N70 + 8, "K1 maxcut_obj | G70 2^17"),
@@ -38,12 +38,17 @@ ROWS = [
     (r"k_maxcut_greedy_sweep_levels<", T70 * 512, 131072, 2 * N70 + 16, "K5 greedy_sweep | G70 2^17 (on-chip bound)"),
     (r"k_node_stats_bits<1", T22 * 512, 65536, 5 * N22, "K3 delta_all | G22 2^16"),
     (r"k_node_stats_bits<1", T70 * 512, 131072, 5 * N70, "K3 delta_all | G70 2^17"),
-    (r"k_node_stats_bits<2", T22 * 512, 65536, 5 * N22, "ls_weights pre-pass | G22 2^16"),
+    (r"k_node_stats_bits<2, true, false, signed char>", T22 * 512, 65536, 2 * N22, "ls_weights pre-pass, int8 weights + batch min / max | G22 2^16"),
+    (r"k_node_stats_bits<2, true, false, signed char>", 64 * 512, 4096, 2 * N22, "ls_weights pre-pass, int8 weights + batch min / max | G22 4096"),
+    (r"k_maxcut_local_search<true, signed char, 16, 4>", T22 * 256, 65536, 3 * N22 + 8, "LS fused local search: threshold + 8 proposal rounds + sweep | G22 2^16 (VALU-bound; x in, int8 ws, x out)"),
+    (r"k_maxcut_local_search<true, signed char, 16, 8>", 64 * 512, 4096, 3 * N22 + 8, "LS fused local search: threshold + 8 proposal rounds + sweep | G22 4096 (64 workgroups: latency / VALU)"),
     (r"k_tsp_tour_length", None, 65536, 8 * NT + 4, "K12 tsp_tour_length | TSP-100 2^16"),
     (r"k_tsp_swap_delta_all", None, 65536, 29 * NT, "K13 tsp_swap_delta_all | TSP-100 2^16"),
-    (r"k_spin_step<float, true, false>", 16384 * 64, 16384, 24 * N22, "S1 spin_step | G22-sized 2^14 (6 rows x 4N change per step)"),
-    (r"k_spin_step<float, true, false>", 4096 * 64, 4096, 24 * 200, "S1 spin_step | BA-200 4096"),
-    (r"k_spin_step<float, true, true>", 1024 * 64, 1024, 28 * 200, "S1d spin_step_dense | per-env BA-200 matrices, 1024 envs (launch-bound)"),
+    (r"k_spin_step<float, true, false>", 16384 * 64, 16384, None, "S1 spin_step | G22-sized 2^14: O(deg) per env, nothing streamed (round 2: 24 N bytes per env-step, 250 us)"),
+    (r"k_spin_step<float, true, false>", 4096 * 64, 4096, None, "S1 spin_step | BA-200 4096: O(deg)"),
+    (r"k_spin_step<float, true, true>", 1024 * 64, 1024, 16 * 200, "S1d spin_step_dense | per-env BA-200 matrices, 1024 envs (launch-bound; the flipped node's matrix row + the entries it changes)"),
+    (r"k_spin_observation<float, true>", 14 * 256 * 16384, 16384, 40 * N22, "S1 observation, rows only [B, 7, N] | G22-sized 2^14 (7 rows written, spins + immediate + last-flip read)"),
+    (r"k_spin_observation<float, true>", 2 * 256 * 4096, 4096, 40 * 200, "S1 observation, rows only [B, 7, N] | BA-200 4096"),
     (r"k_spin_observation<float, true>", 41 * 1024 * 256, 1024, 4 * (207 * 200 + 7 * 200 + 200 * 200), "S1d observation [B, 7+N, N] with per-env matrix rows | BA-200 1024"),
     (r"k_rand_couplings_ba<float>", 128 * 64, 1024, 4 * 200 * 200, "rand_couplings BA (m=4) | 1024 x BA-200 (a dependent chain per env: latency-bound)"),
     (r"k_qubo_ls_value", None, None, None, None),
@@ -116,11 +121,12 @@ def main():
         for pat, want_grid, B, per_unit, label in ROWS:
             if label is None or re.search(pat, name) is None or (want_grid is not None and want_grid != grid):
                 continue
-            rec.update({"row": label, "units_per_launch": B, "algorithmic_bytes": B * per_unit,
-                        "achieved_GBps": B * per_unit / (rec["mean_us"] * 1e-6) / 1e9,
-                        "frac_of_8TBps": B * per_unit / (rec["mean_us"] * 1e-6) / HBM})
-            if "hbm_bytes" in rec:
-                rec["traffic_over_algorithmic"] = rec["hbm_bytes"] / (B * per_unit)
+            rec.update({"row": label, "units_per_launch": B})
+            if per_unit is not None:
+                rec.update({"algorithmic_bytes": B * per_unit, "achieved_GBps": B * per_unit / (rec["mean_us"] * 1e-6) / 1e9,
+                            "frac_of_8TBps": B * per_unit / (rec["mean_us"] * 1e-6) / HBM})
+                if "hbm_bytes" in rec:
+                    rec["traffic_over_algorithmic"] = rec["hbm_bytes"] / (B * per_unit)
             break
         out.append(rec)
     os.makedirs("profiles", exist_ok=True)
@@ -136,8 +142,8 @@ def main():
             f.write("| `{}` | {} x {} | {} | {} | {} | {:.1f} | {} | {} | {} | {} | {} | {} |\n".format(
                 r["kernel"][:90], r["grid"], r["workgroup"], r["lds_bytes"], r["vgpr"], r["launches"], r["mean_us"],
                 f"{r['read_bytes'] / 1e6:.1f}" if "read_bytes" in r else "", f"{r['write_bytes'] / 1e6:.1f}" if "write_bytes" in r else "",
-                r.get("row", ""), f"{r['algorithmic_bytes'] / 1e6:.1f}" if "row" in r else "",
-                f"{r['frac_of_8TBps']:.3f}" if "row" in r else "",
+                r.get("row", ""), f"{r['algorithmic_bytes'] / 1e6:.1f}" if "algorithmic_bytes" in r else "",
+                f"{r['frac_of_8TBps']:.3f}" if "frac_of_8TBps" in r else "",
                 f"{r['traffic_over_algorithmic']:.2f}" if "traffic_over_algorithmic" in r else ""))
     print(open(f"profiles/{a.tag}_kernels.md").read())
 
