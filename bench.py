@@ -19,8 +19,10 @@ data-path collective (weak scaling: 2^16 envs per GPU); the episode-boundary bes
 exchange (8-byte RCCL all-reduce) runs once at the end of every timed region when N > 1.
 
 Timing: W warm-up steps, then R (`--repeats`, default 5) timed regions of EXACTLY K steps each, every region
-bracketed by barrier + synchronize on both sides and reduced with MAX over ranks; the line reports the MEDIAN
-region (`ms_per_step`, `value`) and all of them (`ms_per_step_all`).
+bracketed by barrier + synchronize on both sides; a rank's time runs from the release of the opening barrier to its own
+synchronize after the last step and the exchange, and the region counts as the MAX over ranks (the closing barrier
+itself -- a second collective latency that no step waits for -- is not inside any rank's interval).  The line reports
+the MEDIAN region (`ms_per_step`, `value`) and all of them (`ms_per_step_all`).
 
 Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events on the launch stream;
 `cpu_baseline` is the C oracle (reference algorithm: flip + full objective re-evaluation, OpenMP)
@@ -268,6 +270,9 @@ def measure(a, gset, B, steps, warmup, repeats, dev, rank, local_rank, world, vi
         if use_pg:
             dist.barrier(device_ids=[local_rank])
 
+    if use_pg:   # the first collective builds the communicator (16 ms on a 1-rank RCCL group): not part of any region
+        rdist.global_best(obj)
+        barrier()
     wall, kern = [], []
     for _ in range(repeats):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -283,9 +288,9 @@ def measure(a, gset, B, steps, warmup, repeats, dev, rank, local_rank, world, vi
         if use_pg:  # episode boundary: best objective over all shards (C1, 8 bytes over RCCL)
             rdist.global_best(obj)
         torch.cuda.synchronize(dev)
+        wall.append(time.perf_counter() - t0)     # this rank's region; the slowest rank's is what counts (MAX below)
         barrier()
         torch.cuda.synchronize(dev)
-        wall.append(time.perf_counter() - t0)
         kern.append(e0.elapsed_time(e1) * 1e-3 / max(steps, 1))
 
     if use_pg:

@@ -243,6 +243,15 @@ int rls_best_update(const uint8_t* xs, const void* vs, int vs_kind, int64_t B, i
                     uint8_t* best_x, double* best_v, uint8_t* improved, double* log_v, int64_t log_index, int force,
                     void* stream);
 
+/* The key of the episode-boundary exchange between ranks ("one int64 key per rank,
+ * (best_obj << 20) + (W - 1 - rank)", reduced with MAX = MAXLOC; the single-device analogue is best_vs.argmax(),
+ * L2A/demo_instance.py:165) in one launch: key[0] = (max_b vs[b] << rank_bits) | low_code, index[0] (may be NULL) = the first
+ * position of the maximum.  vs_kind 0 = int64, 3 = int32, 1 = float32, 2 = float64; float values must be integers or
+ * half-integers (the bidirectional envs return count / 2) and are carried doubled.  flag[0] (int32, zeroed by the caller
+ * once) gets bit 0 set when |value| >= limit or a float value is not a half-integer: the key is then built from 0. */
+int rls_best_key(const void* vs, int vs_kind, int64_t B, int32_t rank_bits, int64_t low_code, int64_t limit, int64_t* key,
+                 int64_t* index, int32_t* flag, void* stream);
+
 /* K14 generate_xs_randomly(num_sims)  envs/env_L2A.py:82-85: i.i.d. Bernoulli(1/2)
  *     spins from a counter-based generator keyed by (seed, global env id), node 0
  *     forced to 0.  env_offset lets a rank generate its shard of a global batch. */

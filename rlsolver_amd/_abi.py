@@ -119,6 +119,7 @@ SIGNATURES = {
                           _P, _P, _P, _P],
     "rls_copy_rows": [_P, _P, _I64, _P, _P, _I64, _P],
     "rls_best_update": [_P, _P, _INT, _I64, _I64, _INT, _P, _P, _P, _P, _I64, _INT, _P],
+    "rls_best_key": [_P, _INT, _I64, C.c_int32, _I64, _I64, _P, _P, _P, _P],
 }
 # functions that return a value, not an error code
 PLAIN = {"rls_version": ([], _INT), "rls_device_count": ([], _INT), "rls_last_error_string": ([], C.c_char_p),

@@ -51,9 +51,66 @@ __global__ __launch_bounds__(kTrackThreads) void k_best_update(const uint8_t* __
     }
 }
 
+// The key of the episode-boundary exchange (rlsolver_amd/dist.py): one launch instead of an argmax and
+// half a dozen [1]-sized torch ops in front of the 8-byte all-reduce.  key[0] = (best << rank_bits) | low_code with best =
+// max_b vs[b] (doubled for float inputs, which carry integers or half-integers: the bidirectional envs return count / 2),
+// index[0] = its first position; flag[0] |= 1 when the value does not fit |best| < limit or is not a half-integer.
+template <typename V>
+__global__ __launch_bounds__(kTrackThreads) void k_best_key(const V* __restrict__ vs, int64_t B, int is_float, int rank_bits,
+                                                            int64_t low_code, int64_t limit, int64_t* __restrict__ key,
+                                                            int64_t* __restrict__ index, int32_t* __restrict__ flag) {
+    __shared__ double s_val[kTrackThreads / 64];
+    __shared__ int64_t s_idx[kTrackThreads / 64];
+    double bv = -INFINITY;
+    int64_t bi = INT64_MAX;
+    for (int64_t b = threadIdx.x; b < B; b += kTrackThreads) {
+        const double v = (double)vs[b];
+        if (v > bv) { bv = v; bi = b; }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const double ov = __shfl_xor(bv, m, 64);
+        const int64_t oi = __shfl_xor(bi, m, 64);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { s_val[threadIdx.x >> 6] = bv; s_idx[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kTrackThreads / 64; ++w)
+            if (s_val[w] > bv || (s_val[w] == bv && s_idx[w] < bi)) { bv = s_val[w]; bi = s_idx[w]; }
+        const double scaled = is_float ? bv * 2.0 : bv;
+        const double r = rint(scaled);
+        const bool ok = r == scaled && fabs(r) < (double)limit;
+        const int64_t best = ok ? (int64_t)r : 0;
+        key[0] = (int64_t)((uint64_t)best << rank_bits) | low_code;      // (arithmetic meaning: best * 2^rank_bits + low_code)
+        if (index) index[0] = bi;
+        if (!ok) atomicOr(flag, 1);
+    }
+}
+
 }  // namespace rls
 
 using namespace rls;
+
+extern "C" int rls_best_key(const void* vs, int vs_kind, int64_t B, int32_t rank_bits, int64_t low_code, int64_t limit, int64_t* key,
+                            int64_t* index, int32_t* flag, void* stream) {
+    RLS_REQUIRE(B >= 1, RLS_EINVAL, "B < 1");
+    RLS_REQUIRE(vs && key && flag, RLS_EINVAL, "NULL pointer");
+    RLS_REQUIRE(vs_kind >= 0 && vs_kind <= 3, RLS_EINVAL, "vs_kind must be 0 (int64), 1 (float32), 2 (float64) or 3 (int32)");
+    RLS_REQUIRE(rank_bits >= 0 && rank_bits < 32 && low_code >= 0 && low_code < (1ll << rank_bits) && limit > 0 &&
+                    limit <= (1ll << (62 - rank_bits)), RLS_EINVAL, "bad key layout");
+    hipStream_t s = as_stream(stream);
+    const dim3 grid(1), block(kTrackThreads);
+    if (vs_kind == 0)
+        hipLaunchKernelGGL(k_best_key<int64_t>, grid, block, 0, s, (const int64_t*)vs, B, 0, (int)rank_bits, low_code, limit, key, index, flag);
+    else if (vs_kind == 3)
+        hipLaunchKernelGGL(k_best_key<int32_t>, grid, block, 0, s, (const int32_t*)vs, B, 0, (int)rank_bits, low_code, limit, key, index, flag);
+    else if (vs_kind == 1)
+        hipLaunchKernelGGL(k_best_key<float>, grid, block, 0, s, (const float*)vs, B, 1, (int)rank_bits, low_code, limit, key, index, flag);
+    else
+        hipLaunchKernelGGL(k_best_key<double>, grid, block, 0, s, (const double*)vs, B, 1, (int)rank_bits, low_code, limit, key, index, flag);
+    return check_launch("k_best_key");
+}
 
 extern "C" int rls_best_update(const uint8_t* xs, const void* vs, int vs_kind, int64_t B, int64_t N, int if_maximize,
                                uint8_t* best_x, double* best_v, uint8_t* improved, double* log_v, int64_t log_index,

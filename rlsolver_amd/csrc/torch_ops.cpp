@@ -260,6 +260,22 @@ void best_update(const Tensor& xs, const Tensor& vs, bool if_maximize, Tensor be
     ok(rls_best_update((const uint8_t*)p(xs), p(vs), kind, vs.numel(), best_x.numel(), if_maximize, (uint8_t*)p(best_x), (double*)p(best_v),
                        (uint8_t*)p(improved), (double*)p(log_v), log_index, force, cur_stream(xs)), "rls_best_update");
 }
+void best_key(const Tensor& vs, int64_t rank_bits, int64_t low_code, int64_t limit, Tensor key, const OptTensor& index, Tensor flag) {
+    dev(vs, "vs");
+    const auto dt = vs.scalar_type();
+    const int kind = dt == I64 ? 0 : (dt == F32 ? 1 : (dt == F64 ? 2 : 3));
+    TORCH_CHECK(kind != 3 || dt == I32, "vs must be int64 / int32 / float32 / float64");
+    TORCH_CHECK(vs.numel() >= 1, "vs is empty");
+    dev(key, "key", I64);
+    optdev(index, "index", I64);
+    dev(flag, "flag", I32);
+    at_least(key, "key", 1);
+    at_least(flag, "flag", 1);
+    if (index.has_value()) at_least(*index, "index", 1);
+    RLS_GUARD(vs);
+    ok(rls_best_key(p(vs), kind, vs.numel(), (int32_t)rank_bits, low_code, limit, (int64_t*)p(key), (int64_t*)p(index), (int32_t*)p(flag),
+                    cur_stream(vs)), "rls_best_key");
+}
 void rand_spins(Tensor x, int64_t seed, int64_t env_offset) {
     spin_bytes(x, "x", false);
     TORCH_CHECK(x.dim() == 2, "x must be [B, N]");
@@ -726,6 +742,7 @@ TORCH_LIBRARY(rlsolver_hip, m) {
     m.def("copy_rows(Tensor(a!) xs, Tensor(b!)? vs, Tensor dst, Tensor src) -> ()");
     m.def("best_update(Tensor xs, Tensor vs, bool if_maximize, Tensor(a!) best_x, Tensor(b!) best_v, Tensor(c!) improved, Tensor(d!)? log_v, "
           "int log_index, bool force) -> ()");
+    m.def("best_key(Tensor vs, int rank_bits, int low_code, int limit, Tensor(a!) key, Tensor(b!)? index, Tensor(c!) flag) -> ()");
     m.def("rand_spins(Tensor(a!) x, int seed, int env_offset) -> ()");
     m.def("rand_actions(Tensor(a!) action, int N, int seed, int step, int env_offset) -> ()");
     m.def("rand_perms(Tensor(a!) perm, int seed, int env_offset) -> ()");
@@ -783,6 +800,7 @@ TORCH_LIBRARY_IMPL(rlsolver_hip, CUDA, m) {   // "CUDA" is the HIP dispatch key 
     m.impl("pick_best_of_repeats", &pick_best_of_repeats);
     m.impl("copy_rows", &copy_rows);
     m.impl("best_update", &best_update);
+    m.impl("best_key", &best_key);
     m.impl("rand_spins", &rand_spins);
     m.impl("rand_actions", &rand_actions);
     m.impl("rand_perms", &rand_perms);

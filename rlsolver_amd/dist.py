@@ -66,6 +66,17 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
 
 
 OBJ_LIMIT = 1 << 42   # |objective| (doubled for float inputs) must stay below this for the packed key
+_KEY_BUFFERS = {}
+
+
+def _key_buffers(device):
+    """Per-device scratch of the exchange: key int64 [1], index int64 [1], flag int32 [1] (zeroed once; the kernel only sets it)."""
+    b = _KEY_BUFFERS.get(device)
+    if b is None:
+        b = _KEY_BUFFERS[device] = {"key": torch.zeros(1, dtype=torch.int64, device=device),
+                                    "index": torch.zeros(1, dtype=torch.int64, device=device),
+                                    "flag": torch.zeros(1, dtype=torch.int32, device=device)}
+    return b
 _EMPTY_KEY = -(1 << 63)  # what a rank with no envs contributes: loses against every real key
 
 
@@ -96,10 +107,22 @@ def global_best(local_vs: torch.Tensor, local_xs: Optional[torch.Tensor] = None,
     degenerates to argmax over the local batch.
     """
     is_float = local_vs.is_floating_point()
-    scale = 2 if is_float else 1
     n_local = local_vs.numel()
     dev = local_vs.device
-    if n_local:
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    if world > (1 << RANK_BITS):
+        raise ValueError("world too large for the packed key")
+    li = lbest = key_dev = None
+    if n_local and local_vs.is_cuda and local_vs.dtype in (torch.int64, torch.int32, torch.float32, torch.float64):
+        # one launch: first argmax + the packed key (+ range / half-integer check) -- rls_best_key
+        from .torch_ops import ops as _t
+        bufs = _key_buffers(dev)
+        _t.best_key(local_vs.contiguous(), RANK_BITS, world - 1 - rank, OBJ_LIMIT, bufs["key"], bufs["index"], bufs["flag"])
+        torch._assert_async(bufs["flag"][0] == 0,
+                            "global_best: objective outside the packed-key range (|obj| < 2^42) or not a half-integer")
+        key_dev, li = bufs["key"], bufs["index"][0]
+    elif n_local:
         li = local_vs.argmax()
         raw = local_vs[li]
         lbest = torch.round(raw.to(torch.float64) * 2).to(torch.int64) if is_float else raw.to(torch.int64)
@@ -107,17 +130,19 @@ def global_best(local_vs: torch.Tensor, local_xs: Optional[torch.Tensor] = None,
         if is_float:
             ok = ok & (lbest.to(torch.float64) == raw.to(torch.float64) * 2)
         torch._assert_async(ok, "global_best: objective outside the packed-key range (|obj| < 2^42) or not a half-integer")
-    else:
-        li, lbest = None, None
     finish = (lambda o: o.to(torch.float64) / 2) if is_float else (lambda o: o)
     # RLS_FORCE_PG=1 keeps a 1-rank group on the collective path (the RCCL calls get exercised on a 1-GPU box)
     if not dist.is_initialized() or (dist.get_world_size(group) == 1 and os.environ.get("RLS_FORCE_PG") != "1"):
         if not n_local:
             raise ValueError("global_best: no envs at all")
+        if key_dev is not None:
+            lbest = key_dev[0] >> RANK_BITS
         return finish(lbest), torch.zeros((), dtype=torch.int64, device=dev), \
             (local_xs[li].clone() if (want_solution and local_xs is not None) else None)
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    key = (pack_key(lbest, rank, world) if n_local else torch.full((), _EMPTY_KEY, dtype=torch.int64, device=dev)).reshape(1)
+    if key_dev is not None:
+        key = key_dev                                                   # (a per-device buffer: consumed before the next call)
+    else:
+        key = (pack_key(lbest, rank, world) if n_local else torch.full((), _EMPTY_KEY, dtype=torch.int64, device=dev)).reshape(1)
     dist.all_reduce(key, op=dist.ReduceOp.MAX, group=group)            # C1: 8 bytes
     obj, owner = unpack_key(key[0], world)
     best_x = None
@@ -130,7 +155,8 @@ def global_best(local_vs: torch.Tensor, local_xs: Optional[torch.Tensor] = None,
             torch.empty((n + 7) // 8, dtype=torch.uint8, device=local_xs.device)
         dist.broadcast(buf, src=src, group=group)                      # C2: ceil(N/8) bytes
         best_x = unpack_bits(buf, n, local_xs.dtype)
-    else:
-        # no host read on this path: an all-empty world trips the same error asynchronously on every rank
+    elif not n_local:
+        # no host read on this path: an all-empty world trips the same error asynchronously on every rank (a rank that has
+        # envs knows the reduced key is a real one)
         torch._assert_async(key[0] != _EMPTY_KEY, "global_best: no envs at all")
     return finish(obj), owner, best_x

@@ -228,3 +228,31 @@ def test_evaluator_golden(golden, tmp_path, maximize, vdt):
     assert np.array_equal(np.asarray([(r[0], r[1]) for r in ev.recorder2], dtype=np.float64), z[f"{tag}/recorder2_i_v"])
     assert np.array_equal(np.asarray(ev.recorder1, dtype=np.float64), z[f"{tag}/recorder1"])
     assert ev.first_v == float(z[f"{tag}/first_v"]) and ev.best_x_str == str(z[f"{tag}/best_x_str"])
+
+
+def test_best_key_and_single_process_global_best():
+    """rls_best_key: first argmax + the packed MAXLOC key of the episode-boundary exchange in one launch (all value types,
+    ties, negative values, the float surface carried doubled, the range / half-integer flag), and dist.global_best on device
+    tensors without a process group."""
+    from rlsolver_amd import dist as rdist
+    R = torch.ops.rlsolver_hip
+    rng = np.random.RandomState(4)
+    key = torch.zeros(1, dtype=torch.int64, device=DEV)
+    idx = torch.zeros(1, dtype=torch.int64, device=DEV)
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    for B in (1, 63, 1024, 70001):
+        v = rng.randint(-500, 500, size=B).astype(np.int64)
+        v[rng.randint(B)] = v.max()                                       # (often a tie: the first position wins)
+        for dt, scale in ((torch.int64, 1), (torch.int32, 1), (torch.float32, 2), (torch.float64, 2)):
+            t = torch.from_numpy(v).to(DEV).to(dt)
+            if scale == 2:
+                t = t / 2                                                 # half-integers, as count / 2 of a bidirectional env
+            R.best_key(t, 20, 5, 1 << 42, key, idx, flag)
+            assert int(key) == (int(v.max()) << 20) | 5 and int(idx) == int(v.argmax()) and int(flag) == 0, (B, dt)
+            best, owner, bx = rdist.global_best(t, torch.zeros((B, 3), dtype=torch.bool, device=DEV), want_solution=True)
+            assert float(best) == v.max() / scale and int(owner) == 0 and bx.shape == (3,)
+    R.best_key(torch.tensor([0.25, 0.125], device=DEV), 20, 0, 1 << 42, key, None, flag)    # the maximum is not a half-integer
+    assert int(flag) == 1
+    flag.zero_()
+    R.best_key(torch.tensor([1 << 50], device=DEV), 20, 0, 1 << 42, key, None, flag)         # outside the key's range
+    assert int(flag) == 1
