@@ -4,8 +4,8 @@ without diagonal entries, reward modes, visited-state memory, revisits.  `python
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
-from oracle.oracle_spin import SpinSystemOracle
-from rlsolver_amd.envs.spinsystem import ECO_PECO_OBSERVABLES, RewardSignal, SpinBasis, SpinSystem
+from oracle.oracle_spin import SpinSystemOracle, SpinSystemOracleF64
+from rlsolver_amd.envs.spinsystem import ECO_PECO_OBSERVABLES, ExtraAction, RewardSignal, SpinBasis, SpinSystem, SpinSystemUnbiased
 from rlsolver_amd.envs.util_envs_PECO import SetGraphGenerator
 
 DEV = torch.device("cuda:0")
@@ -65,5 +65,37 @@ while time.time() < t_end:
         assert np.array_equal(o[:, :7].cpu().numpy(), np.concatenate([x[0] for x in res])), f"obs t={t} " + tag
         assert np.array_equal(r.cpu().numpy(), np.concatenate([x[1] for x in res])), f"reward t={t} " + tag
         assert np.array_equal(env.score.cpu().numpy(), np.concatenate([ora.score for ora in oras])), f"score t={t} " + tag
+        if t % 7 == 3:     # whoever reads env.state gets the rows a step does not store (rls_spin_materialize)
+            st = env.state.cpu().numpy().copy()
+            st[:, 0] = (1 - st[:, 0]) / 2
+            assert np.array_equal(st, np.concatenate([x[0] for x in res])), f"state t={t} " + tag
     it += 1
+    # the single-instance float64 surface with the reference's options: ExtraAction.PASS and / or a finite memory
+    if rng.rand() < 0.5:
+        Wd = W[0].astype(np.float64).copy()
+        Wd[np.arange(n), np.arange(n)] = 0
+        rs = Wd.sum(1)
+        if np.abs(rs).sum() == 0 or rs.max() <= 0 or not np.any(Wd):
+            continue
+        mg = [(i, j, int(Wd[i, j])) for i in range(n) for j in range(i + 1, n) if Wd[i, j] != 0]
+        ep = bool(rng.rand() < 0.6)
+        M = None if rng.rand() < 0.4 else int(rng.randint(2, 9))
+        tag1 = f"single: it={it} n={n} T={T} mode={mode} norm={norm} basin={basin} stag={stag} pass={ep} memory={M}"
+        e1 = SpinSystemUnbiased(mg, n, max_steps=T, observables=ECO_PECO_OBSERVABLES, reward_signal=RewardSignal[mode], norm_rewards=norm,
+                                spin_basis=SpinBasis.BINARY, basin_reward=basin, stag_punishment=stag, device=DEV,
+                                extra_action=ExtraAction.PASS if ep else ExtraAction.NONE, memory_length=M)
+        o1 = SpinSystemOracleF64(Wd, T, reward=mode, norm_rewards=norm, basin_reward=basin, stag_punishment=stag, extra_pass=ep, memory_length=M)
+        s1 = (2 * rng.randint(0, 2, size=n) - 1).astype(np.float64)
+        assert np.array_equal(e1.reset(s1), o1.reset(s1)), "reset " + tag1
+        prev = 0
+        for t in range(T):
+            a = int(rng.randint(0, n))
+            a = prev if t % 3 == 2 else (n if (ep and rng.rand() < 0.2) else a)
+            prev = a
+            go, gr, gd, _ = e1.step(a)
+            wo, wr, wd = o1.step(a)
+            assert np.array_equal(go, wo) and gr == wr and gd == wd, f"t={t} a={a} " + tag1
+            assert e1.best_obs_score == o1.best_obs_score and e1.score == o1.score, f"scores t={t} " + tag1
+            if t % 5 == 1:
+                assert np.array_equal(e1.state, o1.state), f"state t={t} " + tag1
 print(f"fuzz_spin: {it} random configurations, no mismatch")
