@@ -287,6 +287,12 @@ def measure(a, gset, B, steps, warmup, repeats, dev, rank, local_rank, world, vi
         e1.record()
         if use_pg:  # episode boundary: best objective over all shards (C1, 8 bytes over RCCL)
             rdist.global_best(obj)
+            e2 = torch.cuda.Event()
+            e2.record()
+        else:
+            e2 = e1
+        while not e2.query():     # busy-poll the last event, then synchronize (which returns at once): a blocking wait adds
+            pass                  # its wake-up latency (tens of us) to a region that may be under a millisecond long
         torch.cuda.synchronize(dev)
         wall.append(time.perf_counter() - t0)     # this rank's region; the slowest rank's is what counts (MAX below)
         barrier()
