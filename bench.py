@@ -164,18 +164,22 @@ def cpu_baseline_ref_shaped(graph_arr, n, seconds):
                       f"the reference's shape (per-env Python loop, int64 [B,E'] index gathers, {th.get_num_threads()} threads)"}
 
 
-def pmc_traffic_per_launch():
+def pmc_traffic_per_launch(algorithmic_bytes):
     """HBM bytes per k_maxcut_step launch from the committed rocprofv3 PMC summary (separate
     FETCH_SIZE / WRITE_SIZE passes of this same command, gfx950-corrected; tools/summarize_prof.py).
-    PMC counters cannot be read from inside the process, so this is the profiled figure, not live."""
+    PMC counters cannot be read from inside the process, so this is the profiled figure, not live.
+    The summary holds one entry per kernel instantiation the command launched (the headline's and the
+    config #5 shard's): the entry for a workload is the u8 step kernel whose measured bytes lie within
+    [0.9, 2] x that workload's algorithmic bytes; none in range -> None (reported as null)."""
     import glob
     best = None
     for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
         try:
             d = json.load(open(p))
             for k, v in d.get("kernels", {}).items():
-                if "k_maxcut_step<unsigned char" in k and "hbm_bytes_per_launch" in v and v.get("grid", 0) >= (1 << 20):
-                    best = (v["hbm_bytes_per_launch"], os.path.basename(p))
+                hb = v.get("hbm_bytes_per_launch")
+                if "k_maxcut_step<unsigned char" in k and hb and 0.9 * algorithmic_bytes <= hb <= 2.0 * algorithmic_bytes:
+                    best = (hb, f"{os.path.basename(p)}: {k.replace('rls::', '')}, grid {v.get('grid')}")
         except Exception:
             pass
     return best
@@ -385,12 +389,15 @@ def main():
                        "parallelism": f"env-shard x{world}"},
             "roofline": s["roofline"],
         }
-        tr = pmc_traffic_per_launch()
-        if tr is not None and B == (1 << 16) and N == 2000:
+        tr = pmc_traffic_per_launch(s["roofline"]["algorithmic_bytes_per_launch"])
+        if tr is not None:
             out["roofline"]["traffic"], out["roofline"]["traffic_source"] = tr[0], f"profiles/{tr[1]} (rocprofv3 --pmc)"
         if res5 is not None:
             st5 = max(1, min(a.steps, 200))
             s5 = summarize(res5, st5, world)
+            tr5 = pmc_traffic_per_launch(s5["roofline"]["algorithmic_bytes_per_launch"])
+            if tr5 is not None:
+                s5["roofline"]["traffic"], s5["roofline"]["traffic_source"] = tr5[0], f"profiles/{tr5[1]} (rocprofv3 --pmc)"
             out["config5_shard"] = {
                 "workload": f"Gset G70{'' if res5['is_real'] else '-sized G(n,m) stand-in'} MaxCut (N={res5['N']}, "
                             f"E={res5['E']}), 131072 envs per GPU = 2^20 over 8 GPUs (BASELINE config #5), same K4 loop",
