@@ -104,3 +104,11 @@ class ISCO_TSP:
     def random_gen_init_sample(self, params_dict=None):
         """env_ISCO.py:352-354: batch_size random permutations (Philox Fisher-Yates kernel seeded from torch)."""
         return mops.rand_perms(self.batch_size, self.num_nodes, _seed_from_torch(), self.device)
+
+
+def __getattr__(name):
+    # the reference keeps ISCO_maxcut in this module too (env_ISCO.py:17-100); here it has a file of its own
+    if name == "ISCO_maxcut":
+        from .env_ISCO_maxcut import ISCO_maxcut
+        return ISCO_maxcut
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")

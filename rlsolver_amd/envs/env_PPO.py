@@ -12,7 +12,7 @@ from typing import Optional
 import torch as th
 
 from .. import ops, torch_ops
-from ..graph import MyGraph, build_csr
+from ..graph import MyGraph, build_adjacency_indies, build_csr  # noqa: F401  (build_adjacency_indies: env_PPO.py:26-47 has its own copy)
 from .env_L2A import _seed_from_torch
 
 TEN = th.Tensor

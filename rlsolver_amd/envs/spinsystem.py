@@ -125,6 +125,7 @@ class SpinSystem:
                 raise ValueError("pass either mygraph (one shared graph) or graph_generator (per-env matrices)")
             num_nodes = int(graph_generator.n_spins) if num_nodes is None else num_nodes
         self.num_envs, self.n_spins, self.max_steps = num_envs, num_nodes, max_steps
+        self._seed = None
         # ExtraAction.PASS and a finite memory_length are options of the single-instance numpy env (spinsystem.py:349-351,
         # 398-404; SpinSystemUnbiased below passes them).  The reference's BATCHED env cannot even be constructed with them
         # (spinsystem_PECO.py raises in its constructor), so SpinSystemFactory.get keeps refusing them.
@@ -298,12 +299,36 @@ class SpinSystem:
         return self.get_observation()
 
     def calculate_cut(self, spins=None):
-        """cut = 1/4 * sum_ij W_ij (1 - s_i s_j)  (spinsystem_PECO.py:564-566) = (sum(W) - sum_i delta_i) / 4,
-        exact in integers."""
-        if spins is not None:
-            raise NotImplementedError("calculate_cut(spins) for foreign spins: use rlsolver_amd.ops.maxcut_obj")
+        """cut = 1/4 * sum_ij W_ij (1 - s_i s_j)  (spinsystem_PECO.py:601-607) = (sum(W) - sum_i delta_i) / 4,
+        exact in integers.  spins: None (the env's own) or signed [B, N] (used as given, like the reference: its
+        basis conversion is commented out there)."""
         wsum = self._weight_sum_env.to(torch.int64) if self._dense else self._weight_sum
-        return (wsum - self._delta.sum(dim=1)).to(self.dtype) / 4
+        if spins is None:
+            return (wsum - self._delta.sum(dim=1)).to(self.dtype) / 4
+        sp = torch.as_tensor(spins, device=self.device)
+        if sp.dim() == 1:
+            sp = sp[None, :]
+        if sp.shape[-1] != self.n_spins or sp.dim() != 2:
+            raise ValueError(f"spins must be [B, {self.n_spins}], got {tuple(sp.shape)}")
+        if self._dense:
+            # per-env matrices: a helper outside the step path, so the reference's own expression on the device
+            if sp.shape[0] != self.num_envs:
+                raise ValueError(f"spins must hold one row per env ({self.num_envs}), got {sp.shape[0]}")
+            sf = sp.to(self._matrix.dtype)
+            gains = torch.matmul(self._matrix, sf.unsqueeze(-1)).squeeze(-1) * sf
+            return (wsum.to(self.dtype) - gains.sum(dim=-1).to(self.dtype)) / 4
+        delta = ops.maxcut_delta_all(self.graph, (sp > 0).contiguous())        # K3: s_i sum_j W_ij s_j
+        return (wsum - delta.sum(dim=1)).to(self.dtype) / 4
+
+    def seed(self, seed=None):
+        """spinsystem_PECO.py:299-300 (sic: the reference returns the attribute that set_seed stores)."""
+        return self._seed
+
+    def set_seed(self, seed):
+        """spinsystem_PECO.py:302-304 (called by set_global_seed, ECO_S2V/src/agents/util.py:26-30, next to
+        torch.manual_seed -- which is what seeds this env's reset draws)."""
+        self._seed = seed
+        np.random.seed(seed)
 
     def calculate_score(self, spins=None):
         return self.calculate_cut(spins)
@@ -401,29 +426,39 @@ class SpinSystem:
 
 class SpinSystemFactory:
     """SpinSystemFactory.get of spinsystem_PECO.py:16-47 (what ``ising_env.make("SpinSystem", ...)`` of core.py:9-16 calls, as
-    train_PECO.py:75-86 does): the batched env on the generator's graphs.  Only the configuration the reference's agents run is
-    built -- ExtraAction.NONE (dqn_PECO.py:252 asserts it), OptimisationTarget.CUT, infinite memory, reversible spins, unbiased
-    graphs; anything else raises NotImplementedError instead of silently doing something different."""
+    train_PECO.py:75-86 does): the batched env on the generator's graphs -- and of spinsystem.py:24-60 (train_ECO.py:83-92):
+    with a single-instance generator (no ``num_envs``, get() -> [N, N]) and no ``num_envs`` argument, the single-instance numpy
+    surface ``SpinSystemUnbiased``.  OptimisationTarget.CUT, reversible spins, unbiased graphs; the batched env additionally
+    ExtraAction.NONE and infinite memory (the reference's batched env cannot be constructed otherwise, and dqn_PECO.py:252
+    asserts it); anything else raises NotImplementedError instead of silently doing something different."""
 
     @staticmethod
     def get(graph_generator=None, max_steps=20, observables=ECO_PECO_OBSERVABLES, reward_signal=RewardSignal.DENSE,
             extra_action=ExtraAction.PASS, optimisation_target=OptimisationTarget.ENERGY, spin_basis=SpinBasis.SIGNED,
             norm_rewards=False, memory_length=None, horizon_length=None, stag_punishment=None, basin_reward=None,
-            reversible_spins=True, init_snap=None, seed=None, device=None, num_envs=None):
-        unsupported = [name for name, bad in (("extra_action", extra_action.name != "NONE"),
+            reversible_spins=True, init_snap=None, seed=None, device=None, num_envs=None, if_greedy=False):
+        single = num_envs is None and getattr(graph_generator, "num_envs", None) is None
+        unsupported = [name for name, bad in (("extra_action", extra_action.name != "NONE" and not (single and extra_action.name == "PASS")),
                                               ("optimisation_target", optimisation_target.name != "CUT"),
-                                              ("memory_length", memory_length is not None), ("reversible_spins", not reversible_spins),
+                                              ("memory_length", memory_length is not None and not single),
+                                              ("reversible_spins", not reversible_spins),
                                               ("init_snap", init_snap is not None),
                                               ("biased graphs", bool(getattr(graph_generator, "biased", False)))) if bad]
         if unsupported:
-            raise NotImplementedError("SpinSystem on the device supports ExtraAction.NONE, OptimisationTarget.CUT, infinite memory, "
-                                      f"reversible spins, unbiased graphs; got {', '.join(unsupported)}")
+            raise NotImplementedError("SpinSystem on the device supports OptimisationTarget.CUT, reversible spins, unbiased graphs, and "
+                                      "on the batched env ExtraAction.NONE and infinite memory; got " + ", ".join(unsupported))
         if seed is not None:
-            np.random.seed(seed)                              # spinsystem_PECO.py:98-99
+            np.random.seed(seed)                              # spinsystem_PECO.py:98-99 / spinsystem.py:95-96
         same = lambda enum, v: enum[v.name]                   # the reference's own enum members are accepted by name
+        obs = [same(Observable, o) for o in observables]
+        if single:                                            # if_greedy: accepted and ignored, as spinsystem.py:46 does
+            return SpinSystemUnbiased(None, None, max_steps, obs, same(RewardSignal, reward_signal), same(SpinBasis, spin_basis),
+                                      norm_rewards, horizon_length, stag_punishment, basin_reward, device,
+                                      graph_generator=graph_generator, extra_action=same(ExtraAction, extra_action),
+                                      memory_length=memory_length)
         if num_envs is None:
             num_envs = graph_generator.num_envs
-        return SpinSystem(None, None, num_envs, max_steps, [same(Observable, o) for o in observables], same(RewardSignal, reward_signal),
+        return SpinSystem(None, None, num_envs, max_steps, obs, same(RewardSignal, reward_signal),
                           same(SpinBasis, spin_basis), norm_rewards, horizon_length, stag_punishment, basin_reward, device,
                           graph_generator=graph_generator)
 
@@ -547,8 +582,28 @@ class SpinSystemUnbiased:
     def get_immeditate_rewards_avaialable(self, spins=None):
         return self._env._delta[0].cpu().numpy().astype(np.float64)
 
+    def calculate_cut(self, spins=None):
+        """spinsystem.py:601-607: the env's own spins, or foreign ones in the env's basis (checked and converted like
+        _format_spins_to_signed, :548-557)."""
+        if spins is None:
+            return float(self._env.calculate_cut()[0])
+        sp = np.asarray(spins, dtype=np.float64)[: self.n_spins]
+        if self._env.spin_basis == SpinBasis.BINARY:
+            if not np.isin(sp, [0, 1]).all():
+                raise Exception("SpinSystem is configured for binary spins ([0,1]).")
+            sp = 2 * sp - 1
+        elif not np.isin(sp, [-1, 1]).all():
+            raise Exception("SpinSystem is configured for signed spins ([-1,1]).")
+        return float(self._env.calculate_cut(sp[None, :])[0])
+
     def calculate_score(self, spins=None):
-        return float(self._env.calculate_cut()[0])
+        return self.calculate_cut(spins)
+
+    def seed(self, seed=None):
+        return self._env.seed()
+
+    def set_seed(self, seed):
+        self._env.set_seed(seed)
 
     def get_best_cut(self):
         return self.best_score

@@ -100,15 +100,34 @@ class ValidationGraphGenerator(GraphGenerator):
 
 
 class SetGraphGenerator(GraphGenerator):
-    """A fixed batch of matrices [num_envs, n_spins, n_spins] handed back at every get() (validation sets, recorded graphs:
-    util_envs_PECO.py:115-172 build theirs with networkx on the host and return the same kind of tensor)."""
+    """A fixed batch of matrices [num_envs, n_spins, n_spins] (a tensor, or a list of [n_spins, n_spins]) handed back at every
+    get() (util_envs_PECO.py:139-171; validation sets and the instance-wise inference batches, inference_PECO.py:84).  The
+    edge type is read off the entries as there; biased sets are outside the MaxCut path."""
 
-    def __init__(self, matrices, device=None):
-        m = torch.as_tensor(matrices)
+    def __init__(self, matrices, biases=None, ordered=False, device=None):
+        if biases is not None:
+            raise NotImplementedError("biased graphs (SpinSystemBiased) are not part of the MaxCut path")
+        if isinstance(matrices, (list, tuple)):
+            if len({tuple(torch.as_tensor(m).shape) for m in matrices}) != 1:
+                raise NotImplementedError("All graphs in SetGraphGenerator must have the same dimension.")
+            m = torch.stack([torch.as_tensor(x) for x in matrices])
+        else:
+            m = torch.as_tensor(matrices)
         if m.dim() != 3 or m.shape[1] != m.shape[2]:
             raise ValueError("matrices must be [num_envs, n_spins, n_spins]")
-        super().__init__(int(m.shape[1]), None, False, int(m.shape[0]))
+        vals = torch.unique(m)
+        if bool(torch.isin(vals, torch.tensor([0, 1], dtype=vals.dtype, device=vals.device)).all()):
+            edge_type = EdgeType.UNIFORM
+        elif bool(torch.isin(vals, torch.tensor([0, -1, 1], dtype=vals.dtype, device=vals.device)).all()):
+            edge_type = EdgeType.DISCRETE
+        else:
+            edge_type = EdgeType.RANDOM
+        super().__init__(int(m.shape[1]), edge_type, False, int(m.shape[0]))
         self.matrices = m.to(device) if device is not None else m
+        self.graphs = self.matrices
+        self.ordered = ordered
+        if ordered:
+            self.i = 0
 
     def get(self, with_padding=False):
         return self.matrices

@@ -190,6 +190,22 @@ def load_mygraph2(dataDir: str = "./data/syn_PL", graph_name: str = "") -> MyGra
     raise ValueError(f"DataDir {dataDir} | graph_name {graph_name} txt_path {p}")
 
 
+def load_mygraph(DataDir: str, graph_name: str) -> MyGraph:
+    """util_read_data.py:98-119: ``<DataDir>/<graph_name>.txt``; else a name ``<type>_<n>_ID<i>`` or ``<type>_<n>`` is
+    generated (see load_mygraph2 on what "generated" means here); else ``graph_name`` itself as a path."""
+    p = f"{DataDir}/{graph_name}.txt"
+    if os.path.exists(p):
+        return read_mygraph(p)
+    parts = graph_name.split("_")
+    if parts[0] in ("BA", "ER", "PL") and len(parts) == 3:
+        return generate_mygraph(parts[0], int(parts[1]), seed=int(parts[2][len("ID"):]))[0]
+    if parts[0] in ("BA", "ER", "PL") and len(parts) == 2:
+        return generate_mygraph(parts[0], int(parts[1]))[0]
+    if os.path.isfile(graph_name):
+        return read_mygraph(graph_name)
+    raise ValueError(f"DataDir {DataDir} | graph_name {graph_name}")
+
+
 # --------------------------------------------------------------------------- #
 # adjacency forms of the reference surface
 # --------------------------------------------------------------------------- #

@@ -32,13 +32,54 @@ def maxcut_dataloader(path, device):
     return make_data(num_nodes, eu, ev, device), num_nodes
 
 
+class MCPGData(types.SimpleNamespace):
+    """The ``Data`` object of maxcut_dataloader (MCPG.py:187-232).  What the samplers here read is set eagerly by
+    make_data; the per-node / per-edge Python lists the reference also hangs on it (``neighbors``, ``neighbor_edges``,
+    ``add_items``, ``sorted_degree_edges``: MCPG.py:205-231, 235-252) are built on first access -- nothing in the HIP
+    path reads them, a caller's own code might."""
+
+    _LAZY = ("neighbors", "neighbor_edges", "add_items", "sorted_degree_edges")
+
+    def __getattr__(self, name):            # only reached for attributes that are not set yet
+        if name in MCPGData._LAZY:
+            append_neighbors(self)
+            return self.__dict__[name]
+        raise AttributeError(name)
+
+
+def append_neighbors(data, device=None):
+    """MCPG.py:235-289: ``data.neighbors[i]`` = node i's neighbours in edge-file order (both directions of every edge, int64
+    tensor), ``data.neighbor_edges[i]`` = their weights (all ones) as [1, deg] -- the shape maxcut_dataloader leaves them in
+    (:227-228) --, plus the dataloader's ``add_items`` [3, E] and ``sorted_degree_edges`` (:216-231).  One stable sort and
+    two device tensors; every list entry is a view.  (The reference's per-edge n0 / n1 neighbour lists -- O(E deg) memory,
+    read by nothing on the MaxCut path -- are not built.)"""
+    dev = torch.device(device) if device is not None else data.edge_index.device
+    ei = data.edge_index.cpu().numpy()
+    eu, ev = ei[0], ei[1]
+    E, N = eu.shape[0], data.num_nodes
+    rows = np.stack([eu, ev], axis=1).reshape(-1)               # edge k contributes (eu -> ev) then (ev -> eu)
+    nbrs = np.stack([ev, eu], axis=1).reshape(-1)
+    order = np.argsort(rows, kind="stable")
+    counts = np.bincount(rows, minlength=N).tolist()
+    flat = torch.from_numpy(nbrs[order]).to(dev)
+    data.neighbors = list(torch.split(flat, counts))
+    data.neighbor_edges = [t.unsqueeze(0) for t in torch.split(torch.ones(2 * E, dtype=torch.int64, device=dev), counts)]
+    wd = np.asarray(data.weighted_degree, dtype=np.float64)
+    add = np.stack([1 - wd[eu] / 2 - 0.05, 1 - wd[ev] / 2 - 0.05, np.full(E, 1 + 0.05)]).astype(np.float32)
+    data.add_items = torch.from_numpy(add).to(dev)
+    absdeg = np.abs(wd).astype(np.float32)
+    edge_degree = torch.from_numpy(absdeg[eu] + absdeg[ev])
+    data.sorted_degree_edges = torch.argsort(edge_degree, descending=True, stable=True)
+    return data
+
+
 def make_data(num_nodes: int, eu, ev, device, sorted_degree_nodes=None):
     device = torch.device(device)
     eu = np.asarray(eu, dtype=np.int64)
     ev = np.asarray(ev, dtype=np.int64)
     csr = build_csr((eu, ev, np.ones_like(eu)), num_nodes=num_nodes, if_bidirectional=False)
     # the objective kernel walks the edge list in file order semantics (order is irrelevant to a sum)
-    data = types.SimpleNamespace()
+    data = MCPGData()
     data.num_nodes = num_nodes
     data.edge_index = torch.from_numpy(np.stack([eu, ev])).to(device)
     data.num_edges = int(eu.shape[0])

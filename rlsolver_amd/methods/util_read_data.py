@@ -6,7 +6,7 @@ import torch as th
 
 from .. import ops
 from ..graph import (MyGraph, build_adjacency_bool, build_adjacency_indies,  # noqa: F401
-                     calc_num_nodes_in_mygraph, load_mygraph2, read_mygraph, read_tsp_file)
+                     calc_num_nodes_in_mygraph, load_mygraph, load_mygraph2, read_mygraph, read_tsp_file)
 
 TEN = th.Tensor
 

@@ -52,6 +52,62 @@ def write_graph_result(obj: Union[float, int], running_duration: Optional[int], 
     return filename
 
 
+def write_result(obj: Union[float, int], running_duration: Optional[int], alg_name: str, solution: Sequence, filename: str,
+                 plus1: bool = True, info_dict: Optional[dict] = None) -> str:
+    """util_write_read_result.py:28-36: write_graph_result without the num_nodes line."""
+    return write_graph_result(obj, running_duration, None, alg_name, solution, filename, plus1, info_dict)
+
+
+def obtain_first_number(s: str) -> int:
+    """The first run of digits / dots of ``s`` as an int (util_write_read_result.py:219-229)."""
+    res, seen = "", False
+    for ch in s:
+        if ch.isdigit() or ch == ".":
+            res += ch
+            seen = True
+        elif seen:
+            break
+    return int(float(res))
+
+
+def read_graph_result_comments(filename: str):
+    """-> (num_nodes, ID, running_duration, obj, obj_bound) from the ``//`` header of a result file whose name carries
+    ``ID<i>_`` (util_write_read_result.py:139-158: reading stops at the num_nodes line).  obj_bound is None when the file has
+    no such line (the reference leaves the name unbound there and raises)."""
+    num_nodes = running_duration = obj = obj_bound = None
+    ID = int(filename.split("ID")[1].split("_")[0])
+    with open(filename, "r", encoding="UTF-8") as f:
+        for line in f:
+            if "//" not in line:
+                continue
+            if "num_nodes:" in line:
+                num_nodes = int(line.split("num_nodes:")[1])
+                break
+            if "running_duration:" in line:
+                running_duration = obtain_first_number(line)
+            if "obj:" in line:
+                obj = float(line.split("obj:")[1])
+            if "obj_bound:" in line:
+                obj_bound = float(line.split("obj_bound:")[1])
+    return num_nodes, ID, running_duration, obj, obj_bound
+
+
+def calc_obj_maxcut_xstr(x_str: str, filename: str, device=None) -> int:
+    """Cut value of the base-64 solution string ``x_str`` on the graph file ``filename`` (util_write_read_result.py:232-239),
+    evaluated by the HIP objective kernel."""
+    import torch
+
+    from ..envs.env_L2A import EnvMaxcut
+    from ..graph import read_graph_header, read_mygraph
+    from .util_evaluator import EncoderBase64
+    mygraph = read_mygraph(filename)
+    num_nodes = read_graph_header(filename)[0]        # read_nxgraph adds every node of the header line (util_read_data.py:46-66)
+    dev = torch.device(device if device is not None else "cuda:0")
+    env = EnvMaxcut(mygraph=mygraph, device=dev, num_nodes=num_nodes)
+    x = EncoderBase64(encode_len=num_nodes).str_to_bool(x_str).to(dev)
+    return int(env.calculate_obj_values(x[None, :])[0])
+
+
 def read_graph_result(filename: str):
     """-> (header dict, labels int64 array as stored)."""
     header, labels = {}, []

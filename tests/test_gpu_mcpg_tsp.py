@@ -580,3 +580,31 @@ def test_mcpg_glue_golden_three_rounds(golden, gname):
         obj.backward()
         np.testing.assert_allclose(float(obj.detach()), float(z[f"{t}/get_return"]), rtol=1e-5, atol=1e-5)
         np.testing.assert_allclose(pl.grad.cpu().numpy(), z[f"{t}/get_return_grad"], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("gname", ["PL_20_ID0", "BA_100_ID0"])
+def test_mcpg_data_object_golden(golden, gname):
+    """The lists maxcut_dataloader hangs on its Data object (MCPG.py:187-289), built lazily here, against the reference's."""
+    z = golden("mcpg_data")
+    n, ei = int(z[f"{gname}/num_nodes"]), z[f"{gname}/edge_index"]
+    data = amcpg.make_data(n, ei[0], ei[1], DEV)
+    assert "neighbors" not in data.__dict__                         # nothing built until somebody asks
+    off = z[f"{gname}/neighbors_offsets"]
+    assert len(data.neighbors) == n and data.neighbors[0].dtype == torch.int64 and data.neighbors[0].device.type == "cuda"
+    assert np.array_equal(torch.cat(data.neighbors).cpu().numpy(), z[f"{gname}/neighbors_flat"])
+    assert [int(t.numel()) for t in data.neighbors] == np.diff(off).tolist()
+    assert np.array_equal(np.array([list(t.shape) for t in data.neighbor_edges]), z[f"{gname}/neighbor_edges_shapes"])
+    assert np.array_equal(torch.cat([t.reshape(-1) for t in data.neighbor_edges]).cpu().numpy(), z[f"{gname}/neighbor_edges_flat"])
+    assert data.single_degree == z[f"{gname}/single_degree"].tolist()
+    assert data.weighted_degree == z[f"{gname}/weighted_degree"].tolist()
+    assert data.add_items.dtype == torch.float32
+    assert np.array_equal(data.add_items.cpu().numpy(), z[f"{gname}/add_items"])
+    # both argsorts are unstable in the reference: any order with non-increasing keys is a valid outcome
+    wd = np.abs(z[f"{gname}/weighted_degree"]).astype(np.float32)
+    key_e = wd[ei[0]] + wd[ei[1]]
+    for mine, ref, key in ((data.sorted_degree_edges.cpu().numpy(), z[f"{gname}/sorted_degree_edges"], key_e),
+                           (data.sorted_degree_nodes.cpu().numpy(), z[f"{gname}/sorted_degree_nodes"], wd)):
+        assert sorted(mine.tolist()) == list(range(key.size))
+        assert np.all(np.diff(key[mine]) <= 0) and np.all(np.diff(key[ref]) <= 0)
+        assert np.array_equal(key[mine], key[ref])
+    assert amcpg.append_neighbors(data) is data

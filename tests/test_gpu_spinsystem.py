@@ -320,7 +320,7 @@ def test_per_env_matrices_equal_the_shared_graph_env_on_one_graph(dtype):
     kw = dict(max_steps=T, observables=ECO_PECO_OBSERVABLES, reward_signal=RewardSignal.CUSTOM_BLS, spin_basis=SpinBasis.BINARY,
               stag_punishment=0.125, basin_reward=0.25, device=DEV, dtype=dtype)
     shared = SpinSystem(mg, n, B, **kw)
-    dense = SpinSystem(None, None, B, graph_generator=SetGraphGenerator(np.broadcast_to(W, (B, n, n)).copy(), DEV), **kw)
+    dense = SpinSystem(None, None, B, graph_generator=SetGraphGenerator(np.broadcast_to(W, (B, n, n)).copy(), device=DEV), **kw)
     spins0 = torch.from_numpy(rng.randint(0, 2, size=(B, n)).astype(np.float64))
     o1, o2 = shared.reset(spins0), dense.reset(spins0)
     assert torch.equal(o1, o2) and torch.equal(shared.score, dense.score)
@@ -412,6 +412,24 @@ def test_single_instance_env_on_a_graph_generator():
         (o1, r1, d1, _), (o2, r2, d2, _) = env.step(a), ref.step(a)
         assert np.array_equal(o1, o2) and r1 == r2 and d1 == d2
     assert env.best_score == ref.best_score and np.array_equal(env.best_spins, ref.best_spins)
+    # the same env through the factory, the way train_ECO.py:83-92 builds it (keywords of spinsystem.py:30-46, PASS default)
+    from rlsolver_amd.envs import spinsystem as ss
+    fenv = ss.make("SpinSystem", Gen(), 2 * n, observables=ECO_PECO_OBSERVABLES, reward_signal=RewardSignal.BLS,
+                   extra_action=ss.ExtraAction.PASS, optimisation_target=ss.OptimisationTarget.CUT, spin_basis=SpinBasis.BINARY,
+                   norm_rewards=True, memory_length=None, horizon_length=None, stag_punishment=None, basin_reward=1.0 / n,
+                   reversible_spins=True, device=DEV, if_greedy=False)
+    assert isinstance(fenv, SpinSystemUnbiased) and fenv.n_actions == n + 1 and fenv.reset().shape == (7 + n + 1, n + 1)
+    # calculate_cut on the env's own and on foreign spins (spinsystem.py:601-607), set_seed (agents/util.py:26-30)
+    W = fenv.matrix
+    own = 1 - 2 * fenv.get_observation()[0, :n]                     # BINARY row 0 = (1 - s) / 2
+    assert fenv.calculate_cut() == 0.25 * np.sum(W * (1 - np.outer(own, own))) == fenv.calculate_score()
+    other = rng.randint(0, 2, size=n).astype(np.float64)
+    so = 2 * other - 1
+    assert fenv.calculate_cut(other) == 0.25 * np.sum(W * (1 - np.outer(so, so)))
+    with pytest.raises(Exception):
+        fenv.calculate_cut(so)                                       # signed spins into a BINARY env
+    fenv.set_seed(11)
+    assert fenv.seed() == 11
 
 
 @pytest.mark.parametrize("cname", ["pass", "mem3", "pass_mem4_stag"])
@@ -481,8 +499,41 @@ def test_spinsystem_options_against_oracle_random_and_refusals():
         SpinSystemUnbiased(mg, 3, extra_action=ExtraAction.RANDOMISE, device=DEV)
     with pytest.raises(ValueError):
         SpinSystemUnbiased(mg, 3, memory_length=1, device=DEV)
-    with pytest.raises(NotImplementedError):      # the batched factory: the reference's own constructor raises for these
-        SpinSystemFactory.get(graph_generator=None, extra_action=ExtraAction.PASS)
+    from rlsolver_amd.envs.spinsystem import OptimisationTarget
+    from rlsolver_amd.envs.util_envs_PECO import SetGraphGenerator
+    batch = SetGraphGenerator(np.zeros((2, 3, 3), dtype=np.float32) + np.array([[0, 1, 0], [1, 0, -1], [0, -1, 0]], dtype=np.float32),
+                              device=DEV)
+    assert batch.edge_type.name == "DISCRETE" and batch.num_envs == 2
+    for bad in (dict(extra_action=ExtraAction.PASS), dict(memory_length=4)):
+        with pytest.raises(NotImplementedError):      # the batched factory: the reference's own constructor raises for these
+            SpinSystemFactory.get(graph_generator=batch, **{**dict(extra_action=ExtraAction.NONE, optimisation_target=OptimisationTarget.CUT), **bad})
+    with pytest.raises(NotImplementedError):
+        SetGraphGenerator(np.zeros((2, 3, 3)), biases=[np.zeros(3)] * 2)
+    benv = SpinSystemFactory.get(graph_generator=batch, extra_action=ExtraAction.NONE, optimisation_target=OptimisationTarget.CUT, device=DEV)
+    benv.reset()
+    sp = torch.tensor([[1., -1., 1.], [1., 1., 1.]], device=DEV)
+    Wb = benv.matrix
+    want = 0.25 * (Wb.sum((1, 2)) - (sp * torch.einsum("bij,bj->bi", Wb, sp)).sum(1))
+    assert torch.equal(benv.calculate_cut(sp), want) and torch.equal(benv.calculate_score(sp), want)
     env = SpinSystem(mg, 3, 2, device=DEV)
     _, r, _ = env.step(torch.tensor([3, 0], device=DEV))             # without PASS action N stays out of range: NaN, env untouched
     assert bool(torch.isnan(r[0])) and not bool(torch.isnan(r[1]))
+
+
+def test_calculate_cut_of_foreign_spins_on_a_shared_graph():
+    """SpinSystem.calculate_cut(spins) (spinsystem_PECO.py:601-607) on the shared-graph form = the reference's expression."""
+    from rlsolver_amd.envs.spinsystem import SpinSystem
+    from rlsolver_amd.graph import generate_gnm
+    n, B = 70, 9
+    rng = np.random.RandomState(3)
+    mg = [(a, b, int(rng.choice([-1, 1, 2]))) for a, b, _ in generate_gnm(n, 300, 2)]
+    env = SpinSystem(mg, n, B, device=DEV)
+    env.reset()
+    W = env.matrix
+    sp = torch.from_numpy(2.0 * rng.randint(0, 2, size=(B, n)) - 1).to(DEV, torch.float32)
+    want = 0.25 * (torch.matmul(W, sp.unsqueeze(-1)).squeeze(-1) * -sp).sum(-1) + 0.25 * W.sum()
+    assert torch.equal(env.calculate_cut(sp), want)
+    own = env.state[:, 0, :]
+    assert torch.equal(env.calculate_cut(), env.calculate_cut(own))
+    env.set_seed(5)
+    assert env.seed() == 5

@@ -48,7 +48,7 @@ while time.time() < t_end:
     else:
         env = SpinSystem(None, None, B, max_steps=T, observables=ECO_PECO_OBSERVABLES, reward_signal=RewardSignal[mode], norm_rewards=norm,
                          spin_basis=SpinBasis.BINARY, basin_reward=basin, stag_punishment=stag, device=DEV,
-                         graph_generator=SetGraphGenerator(W, DEV))
+                         graph_generator=SetGraphGenerator(W, device=DEV))
     tag += f" shared={shared}"
     oras = [SpinSystemOracle(W[b], 1, T, reward=mode, norm_rewards=norm, basin_reward=basin, stag_punishment=stag) for b in range(B)]
     s0 = (2 * rng.randint(0, 2, size=(B, n)) - 1).astype(np.float32)

@@ -412,6 +412,29 @@ def gen_mcpg_glue():
     save("mcpg_glue", **out)
 
 
+def gen_mcpg_data():
+    """What maxcut_dataloader (rlsolver/methods/MCPG.py:187-232, with append_neighbors :235-289) hangs on its Data object,
+    for PL_20_ID0 and BA_100_ID0: the per-node neighbour lists (concatenated, with offsets), their weight rows, degrees,
+    add_items and the edge degrees behind sorted_degree_edges (an unstable argsort: the test checks the order is a valid one)."""
+    m = load_mcpg_module()
+    out = {}
+    for gname in ("PL_20_ID0", "BA_100_ID0"):
+        path = os.path.join(DATA, GRAPHS[gname])
+        data, num_nodes = m.maxcut_dataloader(path, device=th.device("cpu"))
+        out[f"{gname}/num_nodes"] = np.int64(num_nodes)
+        out[f"{gname}/edge_index"] = data.edge_index.numpy().copy()
+        out[f"{gname}/neighbors_flat"] = th.cat([t for t in data.neighbors]).numpy().copy()
+        out[f"{gname}/neighbors_offsets"] = np.cumsum([0] + [int(t.numel()) for t in data.neighbors]).astype(np.int64)
+        out[f"{gname}/neighbor_edges_shapes"] = np.array([list(t.shape) for t in data.neighbor_edges], dtype=np.int64)
+        out[f"{gname}/neighbor_edges_flat"] = th.cat([t.reshape(-1) for t in data.neighbor_edges]).numpy().copy()
+        out[f"{gname}/single_degree"] = np.array(data.single_degree, dtype=np.int64)
+        out[f"{gname}/weighted_degree"] = np.array(data.weighted_degree, dtype=np.float64)
+        out[f"{gname}/sorted_degree_nodes"] = data.sorted_degree_nodes.numpy().copy()
+        out[f"{gname}/add_items"] = data.add_items.numpy().copy()
+        out[f"{gname}/sorted_degree_edges"] = data.sorted_degree_edges.numpy().copy()
+    save("mcpg_data", **out)
+
+
 def gen_evaluator():
     """Evaluator.record1 / record2 (rlsolver/methods/util_evaluator.py:66-107) on a seeded stream of batches: the
     constructor's first record, per call the returned if_update, best_v and best_x afterwards, recorder2's values -- both
@@ -1206,9 +1229,48 @@ def gen_isco_steps():
     save("isco_steps", **out)
 
 
+API_FILES = (
+    "rlsolver/envs/env_L2A.py", "rlsolver/envs/env_MCPG.py", "rlsolver/envs/env_PPO.py", "rlsolver/envs/env_ISCO.py",
+    "rlsolver/methods/LocalSearch.py", "rlsolver/methods/MCPG.py", "rlsolver/methods/util_evaluator.py",
+    "rlsolver/methods/util_read_data.py", "rlsolver/methods/util.py", "rlsolver/methods/util_write_read_result.py",
+    "rlsolver/methods/ECO_S2V/src/envs/spinsystem_PECO.py", "rlsolver/methods/ECO_S2V/src/envs/spinsystem.py",
+    "rlsolver/methods/ECO_S2V/src/envs/util_envs_PECO.py", "rlsolver/methods/ECO_S2V/src/envs/core.py",
+    "rlsolver/methods_problem_specific/TSP/opt_2.py",
+)
+
+
+def gen_api_surface():
+    """The duck-typed boundary as data: for every file of the path, each public top-level function
+    and each public method (plus __init__) with the names of its positional parameters and how many have no default.
+    Read with ``ast`` -- nothing is imported or executed, and only names travel."""
+    import ast
+    import json
+    surface = {}
+    for rel in API_FILES:
+        tree = ast.parse(open(os.path.join(REF, rel), encoding="utf-8").read())
+        names = {}
+
+        def sig(fn):
+            a = fn.args
+            pos = [x.arg for x in a.posonlyargs + a.args]
+            return {"args": pos, "required": len(pos) - len(a.defaults), "varargs": bool(a.vararg or a.kwarg)}
+
+        for node in tree.body:
+            if isinstance(node, ast.FunctionDef) and not node.name.startswith("_"):
+                names[node.name] = sig(node)
+            elif isinstance(node, ast.ClassDef):
+                names[node.name] = {"class": True, "bases": [ast.unparse(b) for b in node.bases]}
+                for m in node.body:
+                    if isinstance(m, ast.FunctionDef) and (m.name == "__init__" or not m.name.startswith("_")):
+                        names[f"{node.name}.{m.name}"] = sig(m)
+        surface[rel] = names
+    save("api_surface", surface=np.array(json.dumps(surface, sort_keys=True, indent=0)))
+
+
 ALL = {"mcpg_weighted": gen_mcpg_weighted, "isco_steps": gen_isco_steps, "spinsystem_cpu": gen_spinsystem_cpu, "spinsystem": gen_spinsystem, "spinsystem_perenv": gen_spinsystem_perenv, "qubo": gen_qubo, "isco_maxcut": gen_isco_maxcut, "maxcut": gen_maxcut, "sweep": gen_sweep, "lsclass": gen_local_search_class, "ppo": gen_ppo,
        "select": gen_select, "mcpg": gen_mcpg, "tsp": gen_tsp, "tsp_2opt": gen_tsp_2opt, "encoder": gen_encoder,
-       "wgain": gen_weighted_gain, "mcpg_glue": gen_mcpg_glue, "evaluator": gen_evaluator, "spinsystem_options": gen_spinsystem_options}
+       "wgain": gen_weighted_gain, "mcpg_glue": gen_mcpg_glue, "evaluator": gen_evaluator, "spinsystem_options": gen_spinsystem_options,
+       "api_surface": gen_api_surface, "mcpg_data": gen_mcpg_data}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
