@@ -458,6 +458,19 @@ def tsp_tables(coords: np.ndarray, K: int = 20):
     return dist, nearest, rnd
 
 
+def load_data(tsp_file_path: str, K: int = 20, device=None) -> dict:
+    """ISCO/util_TSP.py:5-23: a TSPLIB file -> the ``params_dict`` ISCO_TSP is built from (``distance`` f32 [N, N],
+    ``nearest_indices`` int64 [N, K], ``random_indices`` int64 [N, N-1], ``num_nodes``) as torch tensors.  K and the
+    device are star-imported config constants there, arguments here."""
+    import torch
+    dist, nearest, rnd = tsp_tables(np.asarray(read_tsp_file(tsp_file_path), dtype=np.float32), K)
+    put = (lambda a: torch.from_numpy(a).to(device)) if device is not None else torch.from_numpy
+    return {"distance": put(dist), "nearest_indices": put(nearest), "random_indices": put(rnd), "num_nodes": int(dist.shape[0])}
+
+
+load_tsp = load_data
+
+
 def generate_tsp_coords(num_nodes: int, seed: int) -> np.ndarray:
     rng = np.random.Generator(np.random.PCG64(seed))
     return rng.random((num_nodes, 2), dtype=np.float64).astype(np.float32)

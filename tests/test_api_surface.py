@@ -28,6 +28,9 @@ MODULES = {
     "rlsolver/methods/ECO_S2V/src/envs/util_envs_PECO.py": "rlsolver_amd.envs.util_envs_PECO",
     "rlsolver/methods/ECO_S2V/src/envs/core.py": "rlsolver_amd.envs.spinsystem",
     "rlsolver/methods_problem_specific/TSP/opt_2.py": "rlsolver_amd.methods.tsp_opt_2",
+    "rlsolver/methods/ISCO/util_TSP.py": "rlsolver_amd.graph",
+    "rlsolver/methods/MCPG/sampling.py": ("rlsolver_amd.methods.MCPG_maxcut", "rlsolver_amd.methods.MCPG_qubo", "rlsolver_amd.methods.MCPG"),
+    "rlsolver/methods/MCPG/dataloader.py": ("rlsolver_amd.methods.MCPG_maxcut", "rlsolver_amd.methods.MCPG_qubo", "rlsolver_amd.methods.MCPG"),
 }
 # the reference's abstract base + concrete class are one class here
 CLASS_ALIAS = {
@@ -57,13 +60,18 @@ def _surface():
 
 
 def _resolve(file, name):
-    mod = importlib.import_module(MODULES[file])
+    mods = MODULES[file] if isinstance(MODULES[file], tuple) else (MODULES[file],)
     parts = name.split(".")
     parts[0] = CLASS_ALIAS.get((file, parts[0]), parts[0])
-    obj = mod
-    for p in parts:
-        obj = getattr(obj, p)
-    return obj
+    for k, m in enumerate(mods):
+        obj = importlib.import_module(m)
+        try:
+            for p in parts:
+                obj = getattr(obj, p)
+            return obj
+        except AttributeError:
+            if k == len(mods) - 1:
+                raise
 
 
 def collect():
@@ -131,6 +139,13 @@ for f in (S + "spinsystem.py", S + "spinsystem_PECO.py"):
     _skip(f, ["SpinSystemBase.calculate_energy", "SpinSystemUnbiased.calculate_energy", "SpinSystemBase.calculate_best_energy"],
           "OptimisationTarget.ENERGY / brute-force ground state; every agent asserts OptimisationTarget.CUT")
 _skip(S + "util_envs_PECO.py", ["PerturbedGraphGenerator.*"], "Gaussian-perturbed (non-integer) couplings")
+
+G = "rlsolver/methods/MCPG/"
+_skip(G + "sampling.py", ["mcpg_sampling_maxcut_edge", "mcpg_sampling_rcheegercut", "mcpg_sampling_ncheegercut", "mcpg_sampling_maxsat",
+                          "mcpg_sampling_mimo"], "edge-flip MaxCut variant / Cheeger cuts / MaxSAT / MIMO: other problems of the MCPG package")
+_skip(G + "sampling.py", ["sample_initializer", "sampler_select"], "problem dispatch of the mcpg script")
+_skip(G + "dataloader.py", ["dataloader_select", "Data_MaxSAT.*", "maxsat_dataloader", "sort_node", "read_data_mimo3", "read_data_mimo5"],
+      "problem dispatch / MaxSAT / MIMO loaders")
 
 # util.py is a grab-bag (plots, networkx converters, file-name helpers, samplers of other methods); the path uses one function
 ONLY = {M + "util.py": {"evolutionary_replacement"}}

@@ -242,3 +242,18 @@ def test_read_edge_arrays_validates_rows_ids_and_count(tmp_path):
     s.write_text("3 5\n1 2\n2 3\n")
     with pytest.warns(UserWarning, match="announces 5 edges"):
         read_edge_arrays(str(s))
+
+
+def test_load_data_builds_the_isco_tsp_params(tmp_path):
+    """ISCO/util_TSP.py:5-23: TSPLIB file -> params_dict (distance f32, K nearest without self, all-but-self table)."""
+    import torch
+    from rlsolver_amd.graph import generate_tsp_coords, load_data, tsp_tables
+    c = generate_tsp_coords(12, seed=4)
+    p = tmp_path / "t12.tsp"
+    p.write_text("NAME: t12\nTYPE: TSP\nDIMENSION: 12\nEDGE_WEIGHT_TYPE: EUC_2D\nNODE_COORD_SECTION\n"
+                 + "".join(f"{i + 1} {x!r} {y!r}\n" for i, (x, y) in enumerate(c.tolist())) + "EOF\n")
+    d = load_data(str(p), K=5)
+    dist, near, rnd = tsp_tables(np.asarray(c, dtype=np.float32), 5)
+    assert d["num_nodes"] == 12 and d["distance"].dtype == torch.float32 and d["nearest_indices"].dtype == torch.int64
+    assert np.array_equal(d["distance"].numpy(), dist) and np.array_equal(d["nearest_indices"].numpy(), near)
+    assert np.array_equal(d["random_indices"].numpy(), rnd) and d["random_indices"].shape == (12, 11)

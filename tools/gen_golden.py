@@ -1236,6 +1236,7 @@ API_FILES = (
     "rlsolver/methods/ECO_S2V/src/envs/spinsystem_PECO.py", "rlsolver/methods/ECO_S2V/src/envs/spinsystem.py",
     "rlsolver/methods/ECO_S2V/src/envs/util_envs_PECO.py", "rlsolver/methods/ECO_S2V/src/envs/core.py",
     "rlsolver/methods_problem_specific/TSP/opt_2.py",
+    "rlsolver/methods/ISCO/util_TSP.py", "rlsolver/methods/MCPG/sampling.py", "rlsolver/methods/MCPG/dataloader.py",
 )
 
 
