@@ -4,6 +4,9 @@ Restates rlsolver/methods/ECO_S2V/src/envs/spinsystem_PECO.py (SpinSystemUnbiase
 way the reference computes it: DENSE f32 matmul for the single-flip gains every step, per-step
 observable rows, BLS / DENSE reward, basin reward via an exact visited-state list.  Shared graph
 (one W for every env).  Pinned against tests/golden/spinsystem.npz (captured from the reference).
+``inference=True`` restates its instance-wise twin, ECO_S2V/src/envs/inference_network_env.py (pinned against
+tests/golden/spinsystem_inference.npz): best score / spins start from the best env of the batch (:203-206),
+step() returns (obs, done).
 """
 from __future__ import annotations
 
@@ -17,7 +20,8 @@ class SpinSystemOracle:
     SPIN, IMMEDIATE, TIME_SINCE_FLIP, DIST_SCORE, DIST_STATE, GREEDY, TERMINATION = range(7)
 
     def __init__(self, W, num_envs, max_steps, reward="DENSE", norm_rewards=False, basin_reward=None,
-                 stag_punishment=None):
+                 stag_punishment=None, inference=False):
+        self.inference = inference
         self.W = np.asarray(W, F)
         self.n = self.W.shape[0]
         self.B, self.max_steps = num_envs, max_steps
@@ -44,8 +48,12 @@ class SpinSystemOracle:
         self.score = self.calculate_cut(self.state[:, 0])
         self.best_score = self.score.copy()
         self.best_spins = self.state[:, 0].copy()
-        self.visited = [set() for _ in range(self.B)] if (self.basin_reward is not None or
-                                                              self.stag_punishment is not None) else None
+        if self.inference:                                                     # inference_network_env.py:203-206
+            i = int(np.argmax(self.score))
+            self.best_score = np.full(self.B, self.score[i], F)
+            self.best_spins = np.repeat(self.state[i:i + 1, 0], self.B, axis=0)
+        self.visited = [set() for _ in range(self.B)] if (not self.inference and (self.basin_reward is not None or
+                                                              self.stag_punishment is not None)) else None
         return self.observation()
 
     def observation(self):
@@ -94,6 +102,8 @@ class SpinSystemOracle:
         st[:, self.DIST_SCORE] = (np.abs(self.score - self.best_score) / self.max_local)[:, None]
         st[:, self.DIST_STATE] = np.count_nonzero(self.best_spins - st[:, 0], axis=-1)[:, None]
         done = np.full(self.B, self.t == self.max_steps)
+        if self.inference:
+            return self.observation(), done                                     # inference_network_env.py:444
         return self.observation(), rew, done
 
 

@@ -100,7 +100,8 @@ class ValidationGraphGenerator(GraphGenerator):
 
 
 class SetGraphGenerator(GraphGenerator):
-    """A fixed batch of matrices [num_envs, n_spins, n_spins] (a tensor, or a list of [n_spins, n_spins]) handed back at every
+    """A fixed batch of matrices [num_envs, n_spins, n_spins] (a tensor, or a list of [n_spins, n_spins]; or ONE [n_spins, n_spins]
+    tensor: the shared graph of the inference env) handed back at every
     get() (util_envs_PECO.py:139-171; validation sets and the instance-wise inference batches, inference_PECO.py:84).  The
     edge type is read off the entries as there; biased sets are outside the MaxCut path."""
 
@@ -113,8 +114,8 @@ class SetGraphGenerator(GraphGenerator):
             m = torch.stack([torch.as_tensor(x) for x in matrices])
         else:
             m = torch.as_tensor(matrices)
-        if m.dim() != 3 or m.shape[1] != m.shape[2]:
-            raise ValueError("matrices must be [num_envs, n_spins, n_spins]")
+        if m.dim() not in (2, 3) or m.shape[-1] != m.shape[-2]:
+            raise ValueError("matrices must be [num_envs, n_spins, n_spins], or one [n_spins, n_spins] graph for the inference env")
         vals = torch.unique(m)
         if bool(torch.isin(vals, torch.tensor([0, 1], dtype=vals.dtype, device=vals.device)).all()):
             edge_type = EdgeType.UNIFORM
@@ -122,7 +123,8 @@ class SetGraphGenerator(GraphGenerator):
             edge_type = EdgeType.DISCRETE
         else:
             edge_type = EdgeType.RANDOM
-        super().__init__(int(m.shape[1]), edge_type, False, int(m.shape[0]))
+        # one [N, N] tensor: the single shared graph of envs/inference_network_env.py (inference_PECO.py:84 passes exactly that)
+        super().__init__(int(m.shape[-1]), edge_type, False, int(m.shape[0]) if m.dim() == 3 else None)
         self.matrices = m.to(device) if device is not None else m
         self.graphs = self.matrices
         self.ordered = ordered

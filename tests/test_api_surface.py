@@ -27,6 +27,7 @@ MODULES = {
     "rlsolver/methods/ECO_S2V/src/envs/spinsystem.py": "rlsolver_amd.envs.spinsystem",
     "rlsolver/methods/ECO_S2V/src/envs/util_envs_PECO.py": "rlsolver_amd.envs.util_envs_PECO",
     "rlsolver/methods/ECO_S2V/src/envs/core.py": "rlsolver_amd.envs.spinsystem",
+    "rlsolver/methods/ECO_S2V/src/envs/inference_network_env.py": "rlsolver_amd.envs.inference_network_env",
     "rlsolver/methods_problem_specific/TSP/opt_2.py": "rlsolver_amd.methods.tsp_opt_2",
     "rlsolver/methods/ISCO/util_TSP.py": "rlsolver_amd.graph",
     "rlsolver/methods/MCPG/sampling.py": ("rlsolver_amd.methods.MCPG_maxcut", "rlsolver_amd.methods.MCPG_qubo", "rlsolver_amd.methods.MCPG"),
@@ -37,6 +38,7 @@ CLASS_ALIAS = {
     ("rlsolver/methods/ECO_S2V/src/envs/spinsystem_PECO.py", "SpinSystemBase"): "SpinSystem",
     ("rlsolver/methods/ECO_S2V/src/envs/spinsystem_PECO.py", "SpinSystemUnbiased"): "SpinSystem",
     ("rlsolver/methods/ECO_S2V/src/envs/spinsystem.py", "SpinSystemBase"): "SpinSystemUnbiased",
+    ("rlsolver/methods/ECO_S2V/src/envs/inference_network_env.py", "SpinSystemBase"): "SpinSystemUnbiased",
 }
 
 OUT_OF_SCOPE = {}       # filled below: "file::name" or "file::Class.*" -> reason
@@ -134,9 +136,10 @@ _skip(S + "util_envs_PECO.py", ["RandomERGraphGenerator.generate_er_graph", "Ran
       "inside get(): one rls_rand_couplings launch")
 _skip(S + "util_envs_PECO.py", ["HistoryBuffer.*"], "the visited-state memory is a pre-allocated ring inside rls_spin_step")
 # --- configurations outside the MaxCut path (OptimisationTarget.CUT, unbiased graphs, integer couplings)
-for f in (S + "spinsystem.py", S + "spinsystem_PECO.py"):
+for f in (S + "spinsystem.py", S + "spinsystem_PECO.py", S + "inference_network_env.py"):
     _skip(f, ["SpinSystemBiased.*"], "biased graphs: MaxCut is not defined for them (the reference raises)")
-    _skip(f, ["SpinSystemBase.calculate_energy", "SpinSystemUnbiased.calculate_energy", "SpinSystemBase.calculate_best_energy"],
+    _skip(f, ["SpinSystemBase.calculate_energy", "SpinSystemUnbiased.calculate_energy"]
+          + (["SpinSystemBase.calculate_best_energy"] if "inference" not in f else []),
           "OptimisationTarget.ENERGY / brute-force ground state; every agent asserts OptimisationTarget.CUT")
 _skip(S + "util_envs_PECO.py", ["PerturbedGraphGenerator.*"], "Gaussian-perturbed (non-integer) couplings")
 

@@ -537,3 +537,78 @@ def test_calculate_cut_of_foreign_spins_on_a_shared_graph():
     assert torch.equal(env.calculate_cut(), env.calculate_cut(own))
     env.set_seed(5)
     assert env.seed() == 5
+
+
+@pytest.mark.parametrize("gname", ["PL_20_ID0", "BA_100_ID0"])
+def test_inference_twin_golden(golden, gname):
+    """spinsystem_inference.npz, captured from ECO_S2V/src/envs/inference_network_env.py built as inference_PECO.py:84-99 builds
+    it: step() -> (obs, done), best score / spins seeded from the best env of the batch, get_best_cut() 0-dim before a step."""
+    from rlsolver_amd.envs import inference_network_env as inf
+    from rlsolver_amd.envs.util_envs_PECO import SetGraphGenerator
+    z = golden("spinsystem_inference")
+    g = z[f"{gname}/graph"]
+    n = int(g[:, :2].max()) + 1
+    W = np.zeros((n, n), np.float32)
+    W[g[:, 0], g[:, 1]] = g[:, 2]
+    W[g[:, 1], g[:, 0]] = g[:, 2]
+    T, B = int(z[f"{gname}/max_steps"]), z[f"{gname}/spins0"].shape[0]
+    gg = SetGraphGenerator(torch.from_numpy(W).to(DEV), device=DEV)
+    assert gg.n_spins == n and gg.num_envs is None and gg.get().shape == (n, n)
+    env = inf.SpinSystemFactory.get(gg, T, observables=inf.ECO_PECO_OBSERVABLES, reward_signal=inf.RewardSignal.BLS,
+                                    extra_action=inf.ExtraAction.NONE, optimisation_target=inf.OptimisationTarget.CUT,
+                                    spin_basis=inf.SpinBasis.BINARY, norm_rewards=True, memory_length=None, horizon_length=None,
+                                    stag_punishment=None, basin_reward=1.0 / n, reversible_spins=True, device=DEV, num_envs=B,
+                                    if_greedy=False, use_tensor_core=False)
+    assert env.num_envs == B and env.n_spins == n and env.max_steps == T and env.device == DEV
+    obs = env.reset(torch.from_numpy(z[f"{gname}/spins0"]))
+    assert obs.shape == (B, 7 + n, n) and np.array_equal(obs[:, :7].cpu().numpy(), z[f"{gname}/obs0"])
+    assert np.array_equal(env.score.cpu().numpy(), z[f"{gname}/score0"])
+    bc0 = env.get_best_cut()
+    assert bc0.dim() == 0 and bc0.item() == float(z[f"{gname}/best_cut0"])
+    assert np.array_equal(env.best_spins.cpu().numpy(), z[f"{gname}/best_spins0"])
+    for t in range(T):
+        res = env.step(torch.from_numpy(z[f"{gname}/actions"][t]).to(DEV))
+        assert len(res) == 2
+        o, d = res
+        assert np.array_equal(o[:, :7].cpu().numpy(), z[f"{gname}/obs"][t]), t
+        assert d.dtype == torch.bool and np.array_equal(d.cpu().numpy(), z[f"{gname}/done"][t])
+        assert np.array_equal(env.score.cpu().numpy(), z[f"{gname}/score"][t])
+        assert np.array_equal(env.get_best_cut().cpu().numpy(), z[f"{gname}/best_score"][t])
+    assert np.array_equal(o[:, 7:].cpu().numpy(), np.broadcast_to(z[f"{gname}/adj_rows"], (B, n, n)))
+    assert np.array_equal(env.best_spins.cpu().numpy(), z[f"{gname}/best_spins"])
+    with pytest.raises(NotImplementedError):
+        env.step(torch.zeros(B, dtype=torch.int64, device=DEV))                 # already done
+    for bad in (dict(use_tensor_core=True), dict(extra_action=inf.ExtraAction.PASS), dict(memory_length=3)):
+        with pytest.raises(NotImplementedError):
+            inf.SpinSystemFactory.get(gg, T, **{**dict(extra_action=inf.ExtraAction.NONE, optimisation_target=inf.OptimisationTarget.CUT,
+                                                      device=DEV, num_envs=B), **bad})
+
+
+def test_inference_twin_against_oracle_at_size():
+    """The same env at a size with several words per packed row and a larger batch, greedy and random actions, against the
+    oracle's inference flavour (pinned by the fixture above)."""
+    from oracle.oracle_spin import SpinSystemOracle
+    from rlsolver_amd.envs import inference_network_env as inf
+    from rlsolver_amd.envs.util_envs_PECO import SetGraphGenerator
+    from rlsolver_amd.graph import generate_gnm
+    n, B, T = 150, 40, 60
+    rng = np.random.RandomState(8)
+    W = np.zeros((n, n), np.float32)
+    for a, b, _ in generate_gnm(n, 600, 3):
+        W[a, b] = W[b, a] = rng.choice([-1, 1])
+    env = inf.SpinSystemFactory.get(SetGraphGenerator(torch.from_numpy(W), device=DEV), T, extra_action=inf.ExtraAction.NONE,
+                                    optimisation_target=inf.OptimisationTarget.CUT, spin_basis=inf.SpinBasis.BINARY,
+                                    reward_signal=inf.RewardSignal.BLS, norm_rewards=True, device=DEV, num_envs=B)
+    ora = SpinSystemOracle(W, B, T, reward="BLS", norm_rewards=True, inference=True)
+    s0 = env.state[:, 0, :].cpu().numpy().copy()
+    assert np.array_equal(env.get_observation()[:, :7].cpu().numpy(), ora.reset(s0))
+    assert env.get_best_cut().item() == ora.best_score[0] and np.array_equal(env.best_spins.cpu().numpy(), ora.best_spins)
+    for t in range(T):
+        a = rng.randint(0, n, size=B)
+        if t % 3 == 1:
+            a = ora.state[:, 1].argmax(-1)
+        o, d = env.step(torch.from_numpy(a).to(DEV))
+        wo, wd = ora.step(a)
+        assert np.array_equal(o[:, :7].cpu().numpy(), wo) and np.array_equal(d.cpu().numpy(), wd), t
+        assert np.array_equal(env.get_best_cut().cpu().numpy(), ora.best_score)
+    assert np.array_equal(env.best_spins.cpu().numpy(), ora.best_spins)

@@ -105,3 +105,29 @@ def test_reference_facts_about_unrunnable_options(golden):
     assert str(z["facts/batched_none_constructs"]) == "ok"
     assert str(z["facts/batched_pass_ctor"]) == "RuntimeError" and str(z["facts/batched_randomise_ctor"]) == "RuntimeError"
     assert str(z["facts/batched_memory3_ctor"]) == "TypeError" and str(z["facts/numpy_randomise_first_use"]) == "ValueError"
+
+
+@pytest.mark.parametrize("gname", ["PL_20_ID0", "BA_100_ID0"])
+def test_spin_oracle_inference_twin_golden(golden, gname):
+    """spinsystem_inference.npz (inference_network_env.py as inference_PECO.py builds it): the oracle's inference flavour --
+    best score / spins seeded from the best env of the batch, step() -> (obs, done) -- bit for bit."""
+    z = golden("spinsystem_inference")
+    g = z[f"{gname}/graph"]
+    n = int(g[:, :2].max()) + 1
+    W = np.zeros((n, n), np.float32)
+    W[g[:, 0], g[:, 1]] = g[:, 2]
+    W[g[:, 1], g[:, 0]] = g[:, 2]
+    T, B = int(z[f"{gname}/max_steps"]), z[f"{gname}/spins0"].shape[0]
+    env = SpinSystemOracle(W, B, T, reward="BLS", norm_rewards=True, basin_reward=1.0 / n, inference=True)
+    assert np.array_equal(env.reset(z[f"{gname}/spins0"]), z[f"{gname}/obs0"])
+    assert np.array_equal(env.score, z[f"{gname}/score0"])
+    assert z[f"{gname}/best_cut0"].ndim == 0 and np.all(env.best_score == z[f"{gname}/best_cut0"])
+    assert np.array_equal(env.best_spins, z[f"{gname}/best_spins0"])
+    for t in range(T):
+        o, d = env.step(z[f"{gname}/actions"][t])
+        assert np.array_equal(o, z[f"{gname}/obs"][t]), t
+        assert np.array_equal(d, z[f"{gname}/done"][t])
+        assert np.array_equal(env.score, z[f"{gname}/score"][t])
+        assert np.array_equal(env.best_score, z[f"{gname}/best_score"][t])
+    assert np.array_equal(env.best_spins, z[f"{gname}/best_spins"])
+    assert np.array_equal(W, z[f"{gname}/adj_rows"])

@@ -896,6 +896,68 @@ def gen_spinsystem():
     save("spinsystem", **out)
 
 
+def gen_spinsystem_inference():
+    """The instance-wise inference twin (ECO_S2V/src/envs/inference_network_env.py) built the way inference_PECO.py:84-99 builds
+    it -- the reference's own SetGraphGenerator on ONE [N, N] tensor, SpinSystemFactory.get(..., num_envs=B) -- on a +-1-weighted
+    PL_20_ID0 and an unweighted BA_100_ID0.  step() returns (obs, done); best_score / best_spins start from the best env of the
+    batch (:203-206).  Recorded: the drawn spins, get_best_cut() before any step (0-dim), per step the actions (random, some
+    repeated across envs, every fifth the greedy one), the 7 observable rows, done, score, best score; best spins at the end."""
+    from rlsolver.methods.ECO_S2V.src.envs import inference_network_env as inf
+    from rlsolver.methods.ECO_S2V.src.envs.util_envs import (ECO_PECO_OBSERVABLES, ExtraAction, OptimisationTarget,
+                                                             RewardSignal, SpinBasis)
+    from rlsolver.methods.ECO_S2V.src.envs.util_envs_PECO import SetGraphGenerator
+    from rlsolver.methods.util_read_data import read_mygraph
+    out = {}
+    for gname, signed in (("PL_20_ID0", True), ("BA_100_ID0", False)):
+        mygraph = read_mygraph(os.path.join(DATA, GRAPHS[gname]))
+        n = max(max(a, b) for a, b, _ in mygraph) + 1
+        rng = np.random.RandomState(43)
+        wl = [(a, b, int(rng.choice([-1, 1])) if signed else 1) for a, b, _ in mygraph]
+        W = np.zeros((n, n), dtype=np.float32)
+        for a, b, w in wl:
+            W[a, b] = W[b, a] = w
+        out[f"{gname}/graph"] = np.asarray(wl, dtype=np.int64)
+        B = 7
+        max_steps = 2 * n if n <= 20 else 50
+        th.manual_seed(17)
+        gg = SetGraphGenerator(th.from_numpy(W), device=th.device("cpu"))
+        env = inf.SpinSystemFactory.get(gg, max_steps, observables=ECO_PECO_OBSERVABLES, reward_signal=RewardSignal.BLS,
+                                        extra_action=ExtraAction.NONE, optimisation_target=OptimisationTarget.CUT,
+                                        spin_basis=SpinBasis.BINARY, norm_rewards=True, memory_length=None, horizon_length=None,
+                                        stag_punishment=None, basin_reward=1.0 / n, reversible_spins=True,
+                                        device=th.device("cpu"), num_envs=B, if_greedy=False, use_tensor_core=False)
+        out[f"{gname}/max_steps"] = np.int64(max_steps)
+        out[f"{gname}/spins0"] = env.state[:, 0, :].numpy().copy()
+        out[f"{gname}/obs0"] = env.get_observation()[:, :7, :].numpy().copy()
+        out[f"{gname}/score0"] = env.score.numpy().copy()
+        bc0 = env.get_best_cut()
+        assert bc0.dim() == 0
+        out[f"{gname}/best_cut0"] = bc0.numpy().copy()
+        out[f"{gname}/best_spins0"] = env.best_spins.numpy().copy()
+        g = th.Generator().manual_seed(19)
+        acts, obs, dones, scores, bests = [], [], [], [], []
+        for t in range(max_steps):
+            a = th.randint(0, n, (B,), generator=g)
+            if t % 7 == 3:
+                a[:] = a[0]
+            if t % 5 == 4:
+                a = env.state[:, 1, :].argmax(dim=-1)          # row 1 = immediate reward available: the greedy flip
+            res = env.step(a)
+            assert len(res) == 2
+            o, d = res
+            acts.append(a.numpy().copy()); obs.append(o[:, :7, :].numpy().copy()); dones.append(d.numpy().copy())
+            scores.append(env.score.numpy().copy()); bests.append(env.get_best_cut().numpy().copy())
+        assert o.shape == (B, 7 + n, n)
+        out[f"{gname}/adj_rows"] = o[0, 7:, :].numpy().copy()
+        out[f"{gname}/actions"] = np.stack(acts)
+        out[f"{gname}/obs"] = np.stack(obs)
+        out[f"{gname}/done"] = np.stack(dones)
+        out[f"{gname}/score"] = np.stack(scores)
+        out[f"{gname}/best_score"] = np.stack(bests)
+        out[f"{gname}/best_spins"] = env.best_spins.numpy().copy()
+    save("spinsystem_inference", **out)
+
+
 def gen_spinsystem_perenv():
     """The batched PECO SpinSystem as its TRAINING loop builds it: per-env couplings drawn by the reference's own generators
     (util_envs_PECO.py RandomBAGraphGenerator -- whose seed clique carries self-loops -- and RandomERGraphGenerator, on the
@@ -1235,6 +1297,7 @@ API_FILES = (
     "rlsolver/methods/util_read_data.py", "rlsolver/methods/util.py", "rlsolver/methods/util_write_read_result.py",
     "rlsolver/methods/ECO_S2V/src/envs/spinsystem_PECO.py", "rlsolver/methods/ECO_S2V/src/envs/spinsystem.py",
     "rlsolver/methods/ECO_S2V/src/envs/util_envs_PECO.py", "rlsolver/methods/ECO_S2V/src/envs/core.py",
+    "rlsolver/methods/ECO_S2V/src/envs/inference_network_env.py",
     "rlsolver/methods_problem_specific/TSP/opt_2.py",
     "rlsolver/methods/ISCO/util_TSP.py", "rlsolver/methods/MCPG/sampling.py", "rlsolver/methods/MCPG/dataloader.py",
 )
@@ -1271,7 +1334,8 @@ def gen_api_surface():
 ALL = {"mcpg_weighted": gen_mcpg_weighted, "isco_steps": gen_isco_steps, "spinsystem_cpu": gen_spinsystem_cpu, "spinsystem": gen_spinsystem, "spinsystem_perenv": gen_spinsystem_perenv, "qubo": gen_qubo, "isco_maxcut": gen_isco_maxcut, "maxcut": gen_maxcut, "sweep": gen_sweep, "lsclass": gen_local_search_class, "ppo": gen_ppo,
        "select": gen_select, "mcpg": gen_mcpg, "tsp": gen_tsp, "tsp_2opt": gen_tsp_2opt, "encoder": gen_encoder,
        "wgain": gen_weighted_gain, "mcpg_glue": gen_mcpg_glue, "evaluator": gen_evaluator, "spinsystem_options": gen_spinsystem_options,
-       "api_surface": gen_api_surface, "mcpg_data": gen_mcpg_data}
+       "api_surface": gen_api_surface, "mcpg_data": gen_mcpg_data,
+       "spinsystem_inference": gen_spinsystem_inference}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
