@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RLS_ABI_VERSION 7
+#define RLS_ABI_VERSION 8
 
 enum {
     RLS_OK = 0,
@@ -222,6 +222,23 @@ int rls_maxcut_local_search(const rls_graph* g, uint8_t* x, int64_t B, const voi
 /* 1 when rls_maxcut_local_search covers this graph / batch / num_spin (the same test its launcher applies: the
  * 8- or 4-wave LDS layout must fit 160 KB), else 0 -- callers then take the K2 + K6 + K5 path. */
 int rls_maxcut_local_search_supported(const rls_graph* g, int64_t B, int32_t num_spin);
+
+/* The same local search as separate launches, for graphs rls_maxcut_local_search does not cover (its LDS layout holds
+ * two tiles and rd_std: N <= ~6500; these hold one tile: N <= ~15 000, N % 16 == 0).  Both use the fused kernel's
+ * in-kernel draws -- normal(seed, env_offset + b, node, draw) -- so a caller that passes the same seed gets the result
+ * the fused kernel would give.  They replace the torch ops of the decomposed path (randn_like, ws + noise * rd_std,
+ * kthvalue, gt: envs/env_L2A.py:95-101, methods/LocalSearch.py:66-72) and K6's mask input.
+ *   rls_maxcut_ls_threshold: thresh[b] (f32 [B]) = kthvalue(ws[b,:] + normal(draw) * rd_std, k = N - num_spin)
+ *   rls_maxcut_ls_propose:   mask = ws + normal(draw) * rd_std > thresh[b]; rows of x whose x ^ mask has cut >= obj[b]
+ *                            take it, obj[b] updated (update_xs_by_vs, util_read_data.py:199)
+ * ws / ws_bytes / rd_std as for rls_maxcut_local_search; draw = 0 for the threshold, 1.. for the rounds
+ * (0.. when the first draw proposes: LocalSearch.random_search). */
+int rls_maxcut_ls_threshold(const rls_graph* g, int64_t B, const void* ws, int32_t ws_bytes, const float* rd_std, uint64_t seed,
+                            int64_t env_offset, int32_t draw, int32_t num_spin, float* thresh, void* stream);
+int rls_maxcut_ls_propose(const rls_graph* g, uint8_t* x, int64_t B, const void* ws, int32_t ws_bytes, const float* rd_std,
+                          const float* thresh, uint64_t seed, int64_t env_offset, int32_t draw, int64_t* obj, void* stream);
+/* 1 when the two entry points above cover this graph / num_spin, else 0 (callers then keep the torch ops + K6). */
+int rls_maxcut_ls_rounds_supported(const rls_graph* g, int32_t num_spin);
 
 /* K10 update_xs_by_vs(xs0, vs0, xs1, vs1, if_maximize)  methods/util_read_data.py:190-202:
  *     rows of (xs1, vs1) that are >= (<= when !if_maximize) replace (xs0, vs0). */

@@ -24,6 +24,7 @@
 // node, round).  f32 arithmetic follows torch: (float)ws + (noise * rd_std), two roundings.
 #include "rls_cutcount.h"
 #include "rls_sweep.h"
+#include <cstdlib>
 #include <type_traits>
 
 namespace rls {
@@ -360,6 +361,187 @@ __global__ __launch_bounds__(W * kWave) void k_maxcut_local_search(
     tile_store_bytes<VEC>(x, B, N, b0, words, lane, w, W, true, stage);
 }
 
+// =====================================================================================
+// The same local search as separate launches, for graphs the fused kernel does not cover (its LDS layout holds two
+// tiles + rd_std: N <= ~6500): the threshold pass and one proposal round per launch, with the fused kernel's
+// draws (normal4 keyed by seed, global env, node quad, draw index) -- so for a given seed both forms give the same
+// result.  Before, these steps were torch ops on [B, N] f32 tensors (randn, multiply-add, kthvalue, gt) around K6.
+// Rows must be 16-byte multiples (the row-piece stage); ws int8 / int16.
+// =====================================================================================
+__device__ __forceinline__ uint32_t ls_env_key(uint64_t seed, uint64_t gb) {   // (the fused kernel's mix)
+    return fmix32((uint32_t)seed ^ fmix32((uint32_t)(seed >> 32) ^ fmix32((uint32_t)gb) ^ ((uint32_t)(gb >> 32) * 0x9E3779B1u)));
+}
+
+// One pass over the ws rows of the tile's 64 envs (lane = env): f(pc, v[NPC]) for every 16-byte piece pc of this wave's
+// chunks, v = (float)ws + normal * rd_std (two roundings, as torch); f masks nodes >= N itself.  `sd` = rd_std in LDS or
+// global memory (wave-uniform addresses either way).
+template <typename WT, int W, typename F>
+__device__ __forceinline__ void ls_ws_pass(const WT* __restrict__ ws, int64_t B, int64_t N, int64_t b0, int lane, int w,
+                                           unsigned char* wstage, const float* sd, uint32_t env_key, int it, F&& f) {
+    typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+    constexpr int NPC = 16 / (int)sizeof(WT), QPP = NPC / 4, D = 2;
+    const int64_t nquads = (N + 3) >> 2, npieces = (N + NPC - 1) / NPC, nchunks = (npieces + 3) >> 2;
+    int io_r, io_j;
+    stage_io_lane(lane, io_r, io_j);
+    auto issue = [&](int64_t c0, i32x4 (&g)[D][4]) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int64_t c = c0 + (int64_t)d * W;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int64_t rw = b0 + kStageRows * i + io_r, pc = c * 4 + io_j;
+                g[d][i] = (c < nchunks && rw < B && pc < npieces) ? *reinterpret_cast<const i32x4*>(ws + rw * N + pc * NPC)
+                                                                  : i32x4{0, 0, 0, 0};
+            }
+        }
+    };
+    i32x4 ga[D][4], gb[D][4];
+    issue(w, ga);
+    for (int64_t c0 = w; c0 < nchunks; c0 += (int64_t)D * W) {
+        issue(c0 + (int64_t)D * W, gb);
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const int64_t c = c0 + (int64_t)d * W;
+            if (c < nchunks) {
+                const int np_here = (int)((npieces - c * 4) < 4 ? (npieces - c * 4) : 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) *reinterpret_cast<i32x4*>(wstage + (i << 10) + (lane << 4)) = ga[d][i];
+                asm volatile("" ::: "memory");   // LDS ops of one wave execute in order
+#pragma unroll 1
+                for (int i = 0; i < np_here; ++i) {
+                    const i32x4 piece = *reinterpret_cast<const i32x4*>(wstage + stage_slot_off(lane, i));
+                    const int64_t pc = c * 4 + i;
+                    float vals[NPC];
+#pragma unroll
+                    for (int sq = 0; sq < QPP; ++sq) {
+                        const int64_t q = pc * QPP + sq;
+                        const int64_t qs = q < nquads ? q : nquads - 1;
+                        const f32x4 sdq = *reinterpret_cast<const f32x4*>(sd + qs * 4);
+                        float z[4];
+                        normal4(env_key, (uint32_t)q, (uint32_t)it, z);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            int wv;
+                            if constexpr (sizeof(WT) == 1) wv = (int)(int8_t)((uint32_t)piece[sq] >> (8 * k));
+                            else wv = (int)(int16_t)((uint32_t)piece[2 * sq + (k >> 1)] >> (16 * (k & 1)));
+                            vals[4 * sq + k] = (float)wv + z[k] * sdq[k];
+                        }
+                    }
+                    f(pc, vals);
+                }
+                asm volatile("" ::: "memory");
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ga[d][i] = gb[d][i];
+    }
+}
+
+constexpr int kLsRoundWaves = 8;
+
+// thresh[b] = the (num_spin + 1)-th largest of ws[b, :] + normal(draw) * rd_std  (kthvalue(k = N - num_spin))
+template <typename WT, bool SD_LDS>
+__global__ __launch_bounds__(kLsRoundWaves * kWave) void k_ls_threshold(const WT* __restrict__ ws, int64_t B, int64_t N,
+                                                                        const float* __restrict__ rd_std, uint64_t seed,
+                                                                        int64_t env_offset, int draw, int num_spin,
+                                                                        float* __restrict__ thresh) {
+    constexpr int W = kLsRoundWaves, NPC = 16 / (int)sizeof(WT);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* tops = reinterpret_cast<float*>(smem);                                  // [W][kTopCap][64]
+    unsigned char* stages = smem + (size_t)W * kTopCap * kWave * 4;
+    float* sdl = reinterpret_cast<float*>(stages + (size_t)W * kStageBytes);
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    const int64_t b0 = (int64_t)blockIdx.x * kWave, b = b0 + lane;
+    const uint32_t env_key = ls_env_key(seed, (uint64_t)(b + env_offset));
+    if constexpr (SD_LDS) {
+        for (int64_t i = threadIdx.x; i < ((N + 3) & ~3ll); i += W * kWave) sdl[i] = i < N ? rd_std[i] : 0.0f;
+        __syncthreads();
+    }
+    float t[kTopCap];
+#pragma unroll
+    for (int j = 0; j < kTopCap; ++j) t[j] = -INFINITY;
+    auto pass = [&](auto depth) {
+        ls_ws_pass<WT, W>(ws, B, N, b0, lane, w, stages + (size_t)w * kStageBytes, SD_LDS ? sdl : rd_std, env_key, draw,
+                          [&](int64_t pc, const float (&v)[NPC]) {
+#pragma unroll
+                              for (int k = 0; k < NPC; ++k) top_insert_n<decltype(depth)::value>(t, (pc * NPC + k < N) ? v[k] : -INFINITY);
+                          });
+    };
+    if (num_spin < 9) pass(std::integral_constant<int, 9>{}); else pass(std::integral_constant<int, kTopCap>{});
+#pragma unroll
+    for (int j = 0; j < kTopCap; ++j) tops[(w * kTopCap + j) * kWave + lane] = t[j];
+    __syncthreads();
+    if (w == 0) {
+        for (int ow = 1; ow < W; ++ow)
+#pragma unroll
+            for (int j = 0; j < kTopCap; ++j) top_insert(t, tops[(ow * kTopCap + j) * kWave + lane]);
+        float th = t[0];
+#pragma unroll
+        for (int j = 1; j < kTopCap; ++j) th = (j == num_spin) ? t[j] : th;
+        if (b < B) thresh[b] = th;
+    }
+}
+
+// one proposal round: x ^= (ws + normal(draw) * rd_std > thresh) for the envs whose cut does not decrease; obj updated
+template <typename WT, int P, bool SD_LDS>
+__global__ __launch_bounds__(kLsRoundWaves * kWave) void k_ls_propose(uint8_t* __restrict__ x, int64_t B, int64_t N,
+                                                                      const int32_t* __restrict__ eu, const int32_t* __restrict__ ev,
+                                                                      int64_t E, int halve, const WT* __restrict__ ws,
+                                                                      const float* __restrict__ rd_std, const float* __restrict__ thresh,
+                                                                      uint64_t seed, int64_t env_offset, int draw,
+                                                                      int64_t* __restrict__ obj) {
+    constexpr int W = kLsRoundWaves, NPC = 16 / (int)sizeof(WT);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* words = reinterpret_cast<uint64_t*>(smem);
+    int64_t* scratch = reinterpret_cast<int64_t*>(words + ((N + 1) & ~1ll));
+    unsigned char* stages = reinterpret_cast<unsigned char*>(scratch + W * kWave);
+    float* sdl = reinterpret_cast<float*>(stages + (size_t)W * kStageBytes);
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    const int64_t b0 = (int64_t)blockIdx.x * kWave, b = b0 + lane;
+    const bool valid = b < B;
+    const uint32_t env_key = ls_env_key(seed, (uint64_t)(b + env_offset));
+    unsigned char* stage = stages + (size_t)w * kStageBytes;
+    if constexpr (SD_LDS)
+        for (int64_t i = threadIdx.x; i < ((N + 3) & ~3ll); i += W * kWave) sdl[i] = i < N ? rd_std[i] : 0.0f;
+    tile_load_bits<uint8_t, true>(x, B, N, b0, words, lane, w, W, stage);
+    const float th = valid ? thresh[b] : 0.0f;
+    __syncthreads();
+    // the mask words go straight into the tile: a node belongs to exactly one piece of one wave
+    ls_ws_pass<WT, W>(ws, B, N, b0, lane, w, stage, SD_LDS ? sdl : rd_std, env_key, draw, [&](int64_t pc, const float (&v)[NPC]) {
+        uint64_t mine = 0;
+#pragma unroll
+        for (int k = 0; k < NPC; ++k) {
+            const uint64_t mm = ballot64(valid && (v[k] > th));
+            if (lane == k) mine = mm;
+        }
+        const int64_t node = pc * NPC + lane;
+        if (lane < NPC && node < N) words[node] ^= mine;
+    });
+    __syncthreads();
+    int64_t total = block_sum_partials<W>(tile_cut_count<P>(words, eu, ev, E, lane, w, W), scratch, lane, w);
+    if (halve) total >>= 1;
+    const bool accept = valid && (total >= obj[b]);           // update_xs_by_vs: vs1.ge(vs0)
+    __syncthreads();                                          // every wave has read obj[b] before wave 0 updates it
+    if (accept && w == 0) obj[b] = total;
+    tile_store_bytes<true>(x, B, N, b0, words, lane, w, W, accept, stage);
+}
+
+static bool ls_sd_global() {   // dev knob: rd_std read from global memory even where it fits LDS
+    static const bool on = getenv("RLS_LS_SD_GLOBAL") != nullptr;
+    return on;
+}
+static size_t ls_threshold_lds(int64_t N, bool sd_lds) {
+    return (size_t)kLsRoundWaves * kTopCap * kWave * 4 + (size_t)kLsRoundWaves * kStageBytes + (sd_lds ? (size_t)((N + 3) & ~3ll) * 4 : 0);
+}
+static size_t ls_propose_lds(int64_t N, bool sd_lds) {
+    return (size_t)((N + 1) & ~1ll) * 8 + (size_t)kLsRoundWaves * kWave * 8 + (size_t)kLsRoundWaves * kStageBytes +
+           (sd_lds ? (size_t)((N + 3) & ~3ll) * 4 : 0);
+}
+
 }  // namespace rls
 
 using namespace rls;
@@ -447,4 +629,78 @@ extern "C" int rls_maxcut_local_search(const rls_graph* g, uint8_t* x, int64_t B
 #undef DISPATCH_P
 #undef LAUNCH_LSF
     return check_launch("k_maxcut_local_search");
+}
+
+// 1 when rls_maxcut_ls_threshold / rls_maxcut_ls_propose cover this graph (rows of 16-byte multiples whose tile fits LDS)
+extern "C" int rls_maxcut_ls_rounds_supported(const rls_graph* g, int32_t num_spin) {
+    if (!g || g->num_nodes <= 0) return 0;
+    const int64_t N = g->num_nodes;
+    if (num_spin < 0 || num_spin + 1 > kTopCap || num_spin >= N || (N & 15) != 0) return 0;
+    if (pick_planes(g->num_stored_edges) == 0) return 0;
+    return ls_propose_lds(N, false) <= (size_t)kLdsBytes;
+}
+
+extern "C" int rls_maxcut_ls_threshold(const rls_graph* g, int64_t B, const void* ws, int32_t ws_bytes, const float* rd_std,
+                                       uint64_t seed, int64_t env_offset, int32_t draw, int32_t num_spin, float* thresh, void* stream) {
+    if (int rc = check_graph(g)) return rc;
+    RLS_REQUIRE(B >= 0 && draw >= 0, RLS_EINVAL, "bad sizes");
+    if (B == 0) return RLS_OK;
+    RLS_REQUIRE(ws && rd_std && thresh, RLS_EINVAL, "NULL pointer");
+    RLS_REQUIRE(ws_bytes == 1 || ws_bytes == 2, RLS_EINVAL, "ws_bytes must be 1 or 2 (rls_maxcut_ls_weights writes either)");
+    const int64_t N = g->num_nodes;
+    RLS_REQUIRE(num_spin >= 0 && num_spin + 1 <= kTopCap && num_spin < N, RLS_EUNSUPPORTED, "num_spin=%d outside [0, %d] (and < N)",
+                num_spin, kTopCap - 1);
+    RLS_REQUIRE((N & 15) == 0 && (((uintptr_t)ws) & 15) == 0, RLS_EUNSUPPORTED, "ws rows must be 16-byte multiples on a 16-byte base (N=%lld)",
+                (long long)N);
+    const bool sd_lds = !ls_sd_global() && ls_threshold_lds(N, true) <= (size_t)kLdsBytes;
+    const size_t lds = ls_threshold_lds(N, sd_lds);
+    const dim3 grid((unsigned)ceil_div(B, kWave)), block(kLsRoundWaves * kWave);
+    hipStream_t s = as_stream(stream);
+#define LAUNCH_TH(WT, SD)                                                                                              \
+    do {                                                                                                               \
+        auto kern = k_ls_threshold<WT, SD>;                                                                            \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(kern, grid, block, lds, s, (const WT*)ws, B, N, rd_std, seed, env_offset, (int)draw, (int)num_spin, thresh); \
+    } while (0)
+    if (ws_bytes == 1) { if (sd_lds) LAUNCH_TH(int8_t, true); else LAUNCH_TH(int8_t, false); }
+    else               { if (sd_lds) LAUNCH_TH(int16_t, true); else LAUNCH_TH(int16_t, false); }
+#undef LAUNCH_TH
+    return check_launch("k_ls_threshold");
+}
+
+extern "C" int rls_maxcut_ls_propose(const rls_graph* g, uint8_t* x, int64_t B, const void* ws, int32_t ws_bytes, const float* rd_std,
+                                     const float* thresh, uint64_t seed, int64_t env_offset, int32_t draw, int64_t* obj, void* stream) {
+    if (int rc = check_graph(g)) return rc;
+    RLS_REQUIRE(B >= 0 && draw >= 0, RLS_EINVAL, "bad sizes");
+    if (B == 0) return RLS_OK;
+    RLS_REQUIRE(x && ws && rd_std && thresh && obj, RLS_EINVAL, "NULL pointer");
+    RLS_REQUIRE(ws_bytes == 1 || ws_bytes == 2, RLS_EINVAL, "ws_bytes must be 1 or 2 (rls_maxcut_ls_weights writes either)");
+    const int64_t N = g->num_nodes, E = g->num_stored_edges;
+    RLS_REQUIRE((N & 15) == 0 && ((((uintptr_t)ws) | ((uintptr_t)x)) & 15) == 0, RLS_EUNSUPPORTED,
+                "x and ws rows must be 16-byte multiples on 16-byte bases (N=%lld)", (long long)N);
+    RLS_REQUIRE(ls_propose_lds(N, false) <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS (max %d)", (long long)N,
+                ls_propose_lds(N, false), kLdsBytes);
+    const int P = pick_planes(E);
+    RLS_REQUIRE(P != 0, RLS_EUNSUPPORTED, "E'=%lld too large", (long long)E);
+    const bool sd_lds = !ls_sd_global() && ls_propose_lds(N, true) <= (size_t)kLdsBytes;
+    const size_t lds = ls_propose_lds(N, sd_lds);
+    const dim3 grid((unsigned)ceil_div(B, kWave)), block(kLsRoundWaves * kWave);
+    hipStream_t s = as_stream(stream);
+    const int halve = g->if_bidirectional ? 1 : 0;
+#define LAUNCH_PR(WT, PP, SD)                                                                                          \
+    do {                                                                                                               \
+        auto kern = k_ls_propose<WT, PP, SD>;                                                                          \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(kern, grid, block, lds, s, x, B, N, g->eu, g->ev, E, halve, (const WT*)ws, rd_std, thresh, seed, env_offset, \
+                           (int)draw, obj);                                                                            \
+    } while (0)
+#define DISPATCH_PR(WT)                                                                            \
+    do {                                                                                           \
+        if (P <= 16) { if (sd_lds) LAUNCH_PR(WT, 16, true); else LAUNCH_PR(WT, 16, false); }       \
+        else         { if (sd_lds) LAUNCH_PR(WT, 24, true); else LAUNCH_PR(WT, 24, false); }       \
+    } while (0)
+    if (ws_bytes == 1) DISPATCH_PR(int8_t); else DISPATCH_PR(int16_t);
+#undef DISPATCH_PR
+#undef LAUNCH_PR
+    return check_launch("k_ls_propose");
 }

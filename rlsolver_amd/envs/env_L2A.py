@@ -54,6 +54,7 @@ class EnvMaxcut:
         self._adjacency_indies = None
         self._adjacency_bool = None
         self.fused_local_search = True   # False: K2 + torch weights/noise/kthvalue + K6 + K5 as separate launches
+        self.force_ls_rounds = False     # True: the threshold / proposal-round kernels even where the fused kernel fits (tests)
 
     # ---- lazily built forms of the reference attributes
     @property
@@ -125,7 +126,7 @@ class EnvMaxcut:
         rd_std = (ws_span.float() * noise_std).contiguous()
         if noise is not None:
             noise = noise.to(device=self.device, dtype=th.float32).contiguous()
-        fused_ok = self.fused_local_search and ops.local_search_fusable(self.graph, num_spin, B)
+        fused_ok = self.fused_local_search and not self.force_ls_rounds and ops.local_search_fusable(self.graph, num_spin, B)
         if fused_ok and (num_iters > 0 or not first_draw_proposes):
             ops.maxcut_local_search(self.graph, xs, ws32, rd_std, vs, num_iters, num_spin, noise=noise,
                                     seed=0 if noise is not None else _seed_from_torch(),
@@ -133,6 +134,15 @@ class EnvMaxcut:
             return
         if compute_vs:
             ops.maxcut_obj(self.graph, xs, out=vs)
+        if noise is None and (self.fused_local_search or self.force_ls_rounds) and ws32.dtype in (th.int8, th.int16) and ops.ls_rounds_supported(self.graph, num_spin):
+            # the same steps as kernels with the fused kernel's draws (same seed => the fused kernel's result): graphs too
+            # large for the fused kernel's LDS layout
+            seed = _seed_from_torch()
+            thresh = ops.maxcut_ls_threshold(self.graph, ws32, rd_std, seed, num_spin, draw=0)
+            for it in range(0 if first_draw_proposes else 1, num_iters + (0 if first_draw_proposes else 1)):
+                ops.maxcut_ls_propose(self.graph, xs, ws32, rd_std, thresh, vs, seed, draw=it)
+            ops.maxcut_greedy_sweep(self.graph, xs, vs)
+            return
         draws = (lambda t: noise[t]) if noise is not None else (lambda t: th.randn((B, self.num_nodes), device=self.device))
         thresh, t = None, 0
         for it in range(num_iters + (0 if first_draw_proposes else 1)):

@@ -103,3 +103,71 @@ def test_local_search_class_golden_both_paths(golden, gname, fused):
                                         noise=torch.from_numpy(z[f"{tag}/round{r}/noise"]).to(DEV))
         assert np.array_equal(gx.cpu().numpy().astype(np.uint8), z[f"{tag}/round{r}/xs"])
         assert np.array_equal(gv.cpu().numpy(), z[f"{tag}/round{r}/vs"])
+
+
+@pytest.mark.parametrize("n,m,B,bidir,num_spin", [(2000, 19990, 130, False, 8), (320, 2000, 70, True, 6), (64, 400, 64, False, 3),
+                                                  (1008, 5000, 65, False, 12), (3008, 9000, 200, True, 8)])
+def test_round_kernels_equal_the_fused_kernel_for_the_same_seed(n, m, B, bidir, num_spin):
+    """rls_maxcut_ls_threshold + rls_maxcut_ls_propose per round + K5 draw what the fused kernel draws: under the same torch
+    seed local_search_inplace gives the same spins and cuts through either form (the fused one is pinned by the golden
+    fixtures with recorded draws and checked for sanity with its own); also LocalSearch.random_search's form, where the
+    first draw already proposes."""
+    from rlsolver_amd.envs.env_L2A import EnvMaxcut
+    garr = gnm_arr(n, m, seed=n + 1)
+    env = EnvMaxcut(mygraph=mygraph_of(garr), device=DEV, if_bidirectional=bidir, num_nodes=n)
+    g = torch.Generator(device="cpu").manual_seed(2)
+    xs0 = torch.randint(0, 2, (B, n), generator=g, dtype=torch.bool).to(DEV)
+    for first in (False, True):
+        outs = []
+        for rounds in (False, True):
+            env.force_ls_rounds = rounds
+            torch.manual_seed(77)
+            xs, vs = xs0.clone(), env.calculate_obj_values(xs0)
+            env.local_search_pipeline(xs, vs, weight_mult=2 if first else 1, num_iters=5, num_spin=num_spin, noise_std=0.3, noise=None,
+                                      first_draw_proposes=first)
+            outs.append((xs, vs))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), (first,)
+        assert np.array_equal(outs[1][1].cpu().numpy(), onp.maxcut_obj(outs[1][0].cpu().numpy(), garr, bidir))
+        assert not torch.equal(outs[1][0], xs0)
+
+
+@pytest.mark.parametrize("n,m", [(10000, 49975), (12000, 30000)])
+def test_round_kernels_beyond_the_fused_kernel(n, m):
+    """Graphs the fused kernel does not fit (N = 10^4: rd_std in LDS; N = 12 000: rd_std read from global memory): every round
+    keeps cuts non-decreasing and consistent, touches only rows it accepts, and proposes about num_spin flips per env."""
+    from rlsolver_amd import ops
+    from rlsolver_amd.envs.env_L2A import EnvMaxcut
+    B, num_spin = 192, 8
+    garr = gnm_arr(n, m, seed=5)
+    env = EnvMaxcut(mygraph=mygraph_of(garr), device=DEV, num_nodes=n)
+    assert not ops.local_search_fusable(env.graph, num_spin, B) and ops.ls_rounds_supported(env.graph, num_spin)
+    torch.manual_seed(3)
+    xs = env.generate_xs_randomly(B)
+    vs = env.calculate_obj_values(xs)
+    ws, span = ops.maxcut_ls_weights(env.graph, xs, 1)
+    rd_std = (span.float() * 0.3).contiguous()
+    thresh = ops.maxcut_ls_threshold(env.graph, ws, rd_std, seed=99, num_spin=num_spin)
+    assert thresh.shape == (B,) and bool(torch.isfinite(thresh).all())
+    assert bool((thresh > ws.float().mean(dim=1)).all())            # the 9th largest of 10^4 noisy weights sits in the upper tail
+    flips = []
+    for it in range(1, 5):
+        x0, v0 = xs.clone(), vs.clone()
+        ops.maxcut_ls_propose(env.graph, xs, ws, rd_std, thresh, vs, seed=99, draw=it)
+        changed = (xs != x0).any(dim=1)
+        assert bool((vs >= v0).all()) and torch.equal(env.calculate_obj_values(xs), vs)
+        assert bool((vs[~changed] == v0[~changed]).all())
+        nf = (xs != x0).sum(dim=1)[changed].float()
+        if nf.numel():
+            flips.append(float(nf.mean()))
+    assert flips and 0.25 * num_spin < np.mean(flips) < 4 * num_spin, flips
+    # the same seed and draw index give the same proposal; another draw index another one
+    a, b, c = xs.clone(), xs.clone(), xs.clone()
+    va, vb, vc = vs.clone(), vs.clone(), vs.clone()
+    ops.maxcut_ls_propose(env.graph, a, ws, rd_std, thresh, va, seed=99, draw=7)
+    ops.maxcut_ls_propose(env.graph, b, ws, rd_std, thresh, vb, seed=99, draw=7)
+    ops.maxcut_ls_propose(env.graph, c, ws, rd_std, thresh, vc, seed=99, draw=8)
+    assert torch.equal(a, b) and torch.equal(va, vb)
+    # and the whole call through the env
+    v1 = vs.clone()
+    env.local_search_inplace(xs, vs, num_iters=3, num_spin=num_spin)
+    assert bool((vs >= v1).all()) and torch.equal(env.calculate_obj_values(xs), vs)

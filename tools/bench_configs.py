@@ -15,7 +15,7 @@ from rlsolver_amd.methods import MCPG as amcpg
 ap = argparse.ArgumentParser()
 ap.add_argument("--quick", action="store_true")
 ap.add_argument("--profile", action="store_true", help="few launches per kernel: for rocprofv3 passes (PMC serialises kernels)")
-ap.add_argument("--only", default="", help="comma list of suites: maxcut,synthetic,ls,g70,g14,tsp,isco,spin,qubo,mcpg")
+ap.add_argument("--only", default="", help="comma list of suites: maxcut,synthetic,lsba,ls,g70,g14,tsp,isco,spin,qubo,mcpg")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 HBM = 8e12
@@ -123,7 +123,10 @@ def local_search_suite(tag, n, m, seed, B, iters, mygraph=None):
     xs = env.generate_xs_randomly(B)
     vs = env.calculate_obj_values(xs)
     t = timeit(lambda i: env.local_search_inplace(xs, vs, num_iters=8, num_spin=8, noise_std=0.3), iters, warm=1)
-    emit(tag, "local_search_inplace (ls_weights pre-pass + fused kernel: threshold, 8 proposal rounds, greedy sweep)", "candidate evaluations",
+    form = ("ls_weights pre-pass + fused kernel: threshold, 8 proposal rounds, greedy sweep" if ops.local_search_fusable(env.graph, 8, B)
+            else "ls_weights + threshold kernel + 8 proposal-round kernels + K5: a graph beyond the fused kernel's LDS layout"
+            if ops.ls_rounds_supported(env.graph, 8) else "ls_weights + torch noise / kthvalue + 8 x K6 + K5")
+    emit(tag, f"local_search_inplace ({form})", "candidate evaluations",
          B * (n + 8), t, None, f"B={B}; the reference performs N+8 full objective evaluations per env per call")
 
 
@@ -333,8 +336,11 @@ if want("synthetic") and not a.profile:   # (grids coincide with the BASELINE ro
     maxcut_suite("BA n=10000 m=5, B=2^16", 10000, 0, 1 << 16, 0, max(3, it // 3), mygraph=generate_ba(10000, 5, 5))
     maxcut_suite("ER G(n=2000, p=0.005 -> m=9995), B=2^16", 2000, 9995, 1 << 16, 31, it)
     mcpg_suite("MCPG on a G22-sized G(2000, 19990), 2^16 chains", 2000, 0, 1 << 16, 8, max(3, it // 3), mygraph=generate_gnm(2000, 19990, 22))
+if (want("synthetic") or want("lsba")) and not a.profile:
+    from rlsolver_amd.graph import generate_ba
     local_search_suite("BA n=2000 m=4, dREINFORCE batch", 2000, 0, 0, 4096, max(2, it // 5), mygraph=generate_ba(2000, 4, 3))
     local_search_suite("BA n=10000 m=5 (hubs of degree >= 256), dREINFORCE batch", 10000, 0, 0, 4096, max(2, it // 5), mygraph=generate_ba(10000, 5, 5))
+    local_search_suite("BA n=10000 m=5 (hubs of degree >= 256), dREINFORCE batch x16", 10000, 0, 0, 65536, max(2, it // 5), mygraph=generate_ba(10000, 5, 5))
 if want("ls"):
     local_search_suite("G22-sized, dREINFORCE batch", 2000, 19990, 22, 4096, max(2, it // 5))
     local_search_suite("G22-sized, dREINFORCE batch x16", 2000, 19990, 22, 65536, max(2, it // 5))
