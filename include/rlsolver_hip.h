@@ -234,9 +234,16 @@ int rls_maxcut_local_search_supported(const rls_graph* g, int64_t B, int32_t num
  * ws / ws_bytes / rd_std as for rls_maxcut_local_search; draw = 0 for the threshold, 1.. for the rounds
  * (0.. when the first draw proposes: LocalSearch.random_search). */
 int rls_maxcut_ls_threshold(const rls_graph* g, int64_t B, const void* ws, int32_t ws_bytes, const float* rd_std, uint64_t seed,
-                            int64_t env_offset, int32_t draw, int32_t num_spin, float* thresh, void* stream);
+                            int64_t env_offset, int32_t draw, int32_t num_spin, float* thresh, void* scratch, int64_t scratch_bytes,
+                            void* stream);
 int rls_maxcut_ls_propose(const rls_graph* g, uint8_t* x, int64_t B, const void* ws, int32_t ws_bytes, const float* rd_std,
-                          const float* thresh, uint64_t seed, int64_t env_offset, int32_t draw, int64_t* obj, void* stream);
+                          const float* thresh, uint64_t seed, int64_t env_offset, int32_t draw, int64_t* obj, void* scratch,
+                          int64_t scratch_bytes, void* stream);
+/* scratch (16-byte aligned device memory, contents irrelevant, may be shared by all calls of one local search) lets a small
+ * batch split each tile's noise pass -- the VALU-bound part -- over up to 8 workgroups: partial top-k lists / bit-packed mask
+ * words go through it.  rls_maxcut_ls_scratch_bytes gives the size that enables this for (graph, B, ws_bytes); 0 = nothing
+ * to gain.  With scratch = NULL (or too small) both run one workgroup per tile; the results are the same either way. */
+int64_t rls_maxcut_ls_scratch_bytes(const rls_graph* g, int64_t B, int32_t ws_bytes);
 /* 1 when the two entry points above cover this graph / num_spin, else 0 (callers then keep the torch ops + K6). */
 int rls_maxcut_ls_rounds_supported(const rls_graph* g, int32_t num_spin);
 

@@ -86,8 +86,8 @@ SIGNATURES = {
     "rls_maxcut_propose_accept": [_G, _P, _I64, _P, _P, _P],
     "rls_maxcut_ls_weights": [_G, _P, _I64, C.c_int32, _P, C.c_int32, _P, _P],
     "rls_maxcut_local_search": [_G, _P, _I64, _P, C.c_int32, _P, _P, _U64, _I64, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P],
-    "rls_maxcut_ls_threshold": [_G, _I64, _P, C.c_int32, _P, _U64, _I64, C.c_int32, C.c_int32, _P, _P],
-    "rls_maxcut_ls_propose": [_G, _P, _I64, _P, C.c_int32, _P, _P, _U64, _I64, C.c_int32, _P, _P],
+    "rls_maxcut_ls_threshold": [_G, _I64, _P, C.c_int32, _P, _U64, _I64, C.c_int32, C.c_int32, _P, _P, _I64, _P],
+    "rls_maxcut_ls_propose": [_G, _P, _I64, _P, C.c_int32, _P, _P, _U64, _I64, C.c_int32, _P, _P, _I64, _P],
     "rls_select_better_rows": [_P, _P, _P, _P, _I64, _I64, _INT, _P],
     "rls_pick_best_of_repeats": [_P, _P, _I64, _I64, _I64, _INT, _P, _P, _P],
     "rls_rand_spins": [_P, _I64, _I64, _U64, _I64, _P],
@@ -127,7 +127,8 @@ SIGNATURES = {
 PLAIN = {"rls_version": ([], _INT), "rls_device_count": ([], _INT), "rls_last_error_string": ([], C.c_char_p),
          "rls_maxcut_local_search_supported": ([_G, _I64, C.c_int32], _INT),
          "rls_mcpg_local_search_levels_supported": ([_G, _I64], _INT),
-         "rls_maxcut_ls_rounds_supported": ([_G, C.c_int32], _INT)}
+         "rls_maxcut_ls_rounds_supported": ([_G, C.c_int32], _INT),
+         "rls_maxcut_ls_scratch_bytes": ([_G, _I64, C.c_int32], _I64)}
 
 _lib = None
 _lock = threading.Lock()

@@ -375,12 +375,25 @@ __device__ __forceinline__ uint32_t ls_env_key(uint64_t seed, uint64_t gb) {   /
 // One pass over the ws rows of the tile's 64 envs (lane = env): f(pc, v[NPC]) for every 16-byte piece pc of this wave's
 // chunks, v = (float)ws + normal * rd_std (two roundings, as torch); f masks nodes >= N itself.  `sd` = rd_std in LDS or
 // global memory (wave-uniform addresses either way).
+template <typename WT>
+__host__ __device__ inline int64_t ls_num_chunks(int64_t N) {   // chunk = 4 pieces of 16 bytes = 64 bytes of a ws row
+    constexpr int NPC = 16 / (int)sizeof(WT);
+    return ((N + NPC - 1) / NPC + 3) >> 2;
+}
+// the chunks of slice `sl` of `S` (a tile's pass may be split over S workgroups when there are few tiles)
+__device__ __forceinline__ void ls_slice_chunks(int64_t nchunks_all, int sl, int S, int64_t& c_begin, int64_t& c_end) {
+    const int64_t per = (nchunks_all + S - 1) / S;
+    c_begin = per * sl;
+    c_end = c_begin + per < nchunks_all ? c_begin + per : nchunks_all;
+}
+
 template <typename WT, int W, typename F>
 __device__ __forceinline__ void ls_ws_pass(const WT* __restrict__ ws, int64_t B, int64_t N, int64_t b0, int lane, int w,
-                                           unsigned char* wstage, const float* sd, uint32_t env_key, int it, F&& f) {
+                                           unsigned char* wstage, const float* sd, uint32_t env_key, int it,
+                                           int64_t c_begin, int64_t nchunks, F&& f) {   // chunks [c_begin, nchunks)
     typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
     constexpr int NPC = 16 / (int)sizeof(WT), QPP = NPC / 4, D = 2;
-    const int64_t nquads = (N + 3) >> 2, npieces = (N + NPC - 1) / NPC, nchunks = (npieces + 3) >> 2;
+    const int64_t nquads = (N + 3) >> 2, npieces = (N + NPC - 1) / NPC;
     int io_r, io_j;
     stage_io_lane(lane, io_r, io_j);
     auto issue = [&](int64_t c0, i32x4 (&g)[D][4]) {
@@ -396,8 +409,8 @@ __device__ __forceinline__ void ls_ws_pass(const WT* __restrict__ ws, int64_t B,
         }
     };
     i32x4 ga[D][4], gb[D][4];
-    issue(w, ga);
-    for (int64_t c0 = w; c0 < nchunks; c0 += (int64_t)D * W) {
+    issue(c_begin + w, ga);
+    for (int64_t c0 = c_begin + w; c0 < nchunks; c0 += (int64_t)D * W) {
         issue(c0 + (int64_t)D * W, gb);
 #pragma unroll
         for (int d = 0; d < D; ++d) {
@@ -442,11 +455,13 @@ __device__ __forceinline__ void ls_ws_pass(const WT* __restrict__ ws, int64_t B,
 constexpr int kLsRoundWaves = 8;
 
 // thresh[b] = the (num_spin + 1)-th largest of ws[b, :] + normal(draw) * rd_std  (kthvalue(k = N - num_spin))
-template <typename WT, bool SD_LDS>
+template <typename WT>
 __global__ __launch_bounds__(kLsRoundWaves * kWave) void k_ls_threshold(const WT* __restrict__ ws, int64_t B, int64_t N,
                                                                         const float* __restrict__ rd_std, uint64_t seed,
                                                                         int64_t env_offset, int draw, int num_spin,
-                                                                        float* __restrict__ thresh) {
+                                                                        float* __restrict__ thresh, float* __restrict__ partial) {
+    // gridDim.y > 1: this workgroup takes one slice of the rows and leaves its merged list in partial[tile][slice][kTopCap][64]
+    // (k_ls_threshold_merge reads the threshold off the slices' lists); else it writes thresh itself
     constexpr int W = kLsRoundWaves, NPC = 16 / (int)sizeof(WT);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* tops = reinterpret_cast<float*>(smem);                                  // [W][kTopCap][64]
@@ -456,15 +471,15 @@ __global__ __launch_bounds__(kLsRoundWaves * kWave) void k_ls_threshold(const WT
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     const int64_t b0 = (int64_t)blockIdx.x * kWave, b = b0 + lane;
     const uint32_t env_key = ls_env_key(seed, (uint64_t)(b + env_offset));
-    if constexpr (SD_LDS) {
-        for (int64_t i = threadIdx.x; i < ((N + 3) & ~3ll); i += W * kWave) sdl[i] = i < N ? rd_std[i] : 0.0f;
-        __syncthreads();
-    }
+    for (int64_t i = threadIdx.x; i < ((N + 3) & ~3ll); i += W * kWave) sdl[i] = i < N ? rd_std[i] : 0.0f;   // rd_std: one broadcast read per quad
+    __syncthreads();
     float t[kTopCap];
 #pragma unroll
     for (int j = 0; j < kTopCap; ++j) t[j] = -INFINITY;
+    int64_t c_begin, c_end;
+    ls_slice_chunks(ls_num_chunks<WT>(N), (int)blockIdx.y, (int)gridDim.y, c_begin, c_end);
     auto pass = [&](auto depth) {
-        ls_ws_pass<WT, W>(ws, B, N, b0, lane, w, stages + (size_t)w * kStageBytes, SD_LDS ? sdl : rd_std, env_key, draw,
+        ls_ws_pass<WT, W>(ws, B, N, b0, lane, w, stages + (size_t)w * kStageBytes, sdl, env_key, draw, c_begin, c_end,
                           [&](int64_t pc, const float (&v)[NPC]) {
 #pragma unroll
                               for (int k = 0; k < NPC; ++k) top_insert_n<decltype(depth)::value>(t, (pc * NPC + k < N) ? v[k] : -INFINITY);
@@ -478,21 +493,81 @@ __global__ __launch_bounds__(kLsRoundWaves * kWave) void k_ls_threshold(const WT
         for (int ow = 1; ow < W; ++ow)
 #pragma unroll
             for (int j = 0; j < kTopCap; ++j) top_insert(t, tops[(ow * kTopCap + j) * kWave + lane]);
-        float th = t[0];
+        if (gridDim.y > 1) {
+            float* dst = partial + ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * kTopCap * kWave;
 #pragma unroll
-        for (int j = 1; j < kTopCap; ++j) th = (j == num_spin) ? t[j] : th;
-        if (b < B) thresh[b] = th;
+            for (int j = 0; j < kTopCap; ++j) dst[j * kWave + lane] = t[j];
+        } else {
+            float th = t[0];
+#pragma unroll
+            for (int j = 1; j < kTopCap; ++j) th = (j == num_spin) ? t[j] : th;
+            if (b < B) thresh[b] = th;
+        }
     }
 }
 
+__global__ __launch_bounds__(kWave) void k_ls_threshold_merge(const float* __restrict__ partial, int S, int64_t B, int num_spin,
+                                                               float* __restrict__ thresh) {
+    const int lane = threadIdx.x;
+    const int64_t b = (int64_t)blockIdx.x * kWave + lane;
+    float t[kTopCap];
+#pragma unroll
+    for (int j = 0; j < kTopCap; ++j) t[j] = -INFINITY;
+    for (int sl = 0; sl < S; ++sl) {
+        const float* src = partial + ((int64_t)blockIdx.x * S + sl) * kTopCap * kWave;
+#pragma unroll
+        for (int j = 0; j < kTopCap; ++j) top_insert(t, src[j * kWave + lane]);
+    }
+    float th = t[0];
+#pragma unroll
+    for (int j = 1; j < kTopCap; ++j) th = (j == num_spin) ? t[j] : th;
+    if (b < B) thresh[b] = th;
+}
+
+// the mask words of one proposal round for a slice of the nodes: maskw[tile][node] (bit e = env 64 tile + e), for batches of so
+// few tiles that one workgroup per tile would leave most of the chip idle through the VALU-bound noise generation
+template <typename WT>
+__global__ __launch_bounds__(kLsRoundWaves * kWave) void k_ls_mask(const WT* __restrict__ ws, int64_t B, int64_t N,
+                                                                   const float* __restrict__ rd_std, const float* __restrict__ thresh,
+                                                                   uint64_t seed, int64_t env_offset, int draw,
+                                                                   uint64_t* __restrict__ maskw) {
+    constexpr int W = kLsRoundWaves, NPC = 16 / (int)sizeof(WT);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* stages = smem;
+    float* sdl = reinterpret_cast<float*>(stages + (size_t)W * kStageBytes);
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    const int64_t b0 = (int64_t)blockIdx.x * kWave, b = b0 + lane;
+    const bool valid = b < B;
+    const uint32_t env_key = ls_env_key(seed, (uint64_t)(b + env_offset));
+    for (int64_t i = threadIdx.x; i < ((N + 3) & ~3ll); i += W * kWave) sdl[i] = i < N ? rd_std[i] : 0.0f;   // rd_std: one broadcast read per quad
+    __syncthreads();
+    const float th = valid ? thresh[b] : 0.0f;
+    int64_t c_begin, c_end;
+    ls_slice_chunks(ls_num_chunks<WT>(N), (int)blockIdx.y, (int)gridDim.y, c_begin, c_end);
+    uint64_t* out = maskw + (int64_t)blockIdx.x * N;
+    ls_ws_pass<WT, W>(ws, B, N, b0, lane, w, stages + (size_t)w * kStageBytes, sdl, env_key, draw, c_begin, c_end,
+                      [&](int64_t pc, const float (&v)[NPC]) {
+                          uint64_t mine = 0;
+#pragma unroll
+                          for (int k = 0; k < NPC; ++k) {
+                              const uint64_t mm = ballot64(valid && (v[k] > th));
+                              if (lane == k) mine = mm;
+                          }
+                          const int64_t node = pc * NPC + lane;
+                          if (lane < NPC && node < N) out[node] = mine;
+                      });
+}
+
 // one proposal round: x ^= (ws + normal(draw) * rd_std > thresh) for the envs whose cut does not decrease; obj updated
-template <typename WT, int P, bool SD_LDS>
+// PREMASK: the mask words come from k_ls_mask (maskw[tile][node]) instead of being generated here
+template <typename WT, int P, bool SD_LDS, bool PREMASK>
 __global__ __launch_bounds__(kLsRoundWaves * kWave) void k_ls_propose(uint8_t* __restrict__ x, int64_t B, int64_t N,
                                                                       const int32_t* __restrict__ eu, const int32_t* __restrict__ ev,
                                                                       int64_t E, int halve, const WT* __restrict__ ws,
                                                                       const float* __restrict__ rd_std, const float* __restrict__ thresh,
                                                                       uint64_t seed, int64_t env_offset, int draw,
-                                                                      int64_t* __restrict__ obj) {
+                                                                      int64_t* __restrict__ obj, const uint64_t* __restrict__ maskw) {
     constexpr int W = kLsRoundWaves, NPC = 16 / (int)sizeof(WT);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* words = reinterpret_cast<uint64_t*>(smem);
@@ -505,22 +580,28 @@ __global__ __launch_bounds__(kLsRoundWaves * kWave) void k_ls_propose(uint8_t* _
     const bool valid = b < B;
     const uint32_t env_key = ls_env_key(seed, (uint64_t)(b + env_offset));
     unsigned char* stage = stages + (size_t)w * kStageBytes;
-    if constexpr (SD_LDS)
+    if constexpr (SD_LDS && !PREMASK)
         for (int64_t i = threadIdx.x; i < ((N + 3) & ~3ll); i += W * kWave) sdl[i] = i < N ? rd_std[i] : 0.0f;
     tile_load_bits<uint8_t, true>(x, B, N, b0, words, lane, w, W, stage);
-    const float th = valid ? thresh[b] : 0.0f;
     __syncthreads();
-    // the mask words go straight into the tile: a node belongs to exactly one piece of one wave
-    ls_ws_pass<WT, W>(ws, B, N, b0, lane, w, stage, SD_LDS ? sdl : rd_std, env_key, draw, [&](int64_t pc, const float (&v)[NPC]) {
-        uint64_t mine = 0;
+    if constexpr (PREMASK) {
+        const uint64_t* mw = maskw + (int64_t)blockIdx.x * N;
+        for (int64_t n = threadIdx.x; n < N; n += W * kWave) words[n] ^= mw[n];
+    } else {
+        const float th = valid ? thresh[b] : 0.0f;
+        // the mask words go straight into the tile: a node belongs to exactly one piece of one wave
+        ls_ws_pass<WT, W>(ws, B, N, b0, lane, w, stage, SD_LDS ? sdl : rd_std, env_key, draw, 0, ls_num_chunks<WT>(N),
+                          [&](int64_t pc, const float (&v)[NPC]) {
+                              uint64_t mine = 0;
 #pragma unroll
-        for (int k = 0; k < NPC; ++k) {
-            const uint64_t mm = ballot64(valid && (v[k] > th));
-            if (lane == k) mine = mm;
-        }
-        const int64_t node = pc * NPC + lane;
-        if (lane < NPC && node < N) words[node] ^= mine;
-    });
+                              for (int k = 0; k < NPC; ++k) {
+                                  const uint64_t mm = ballot64(valid && (v[k] > th));
+                                  if (lane == k) mine = mm;
+                              }
+                              const int64_t node = pc * NPC + lane;
+                              if (lane < NPC && node < N) words[node] ^= mine;
+                          });
+    }
     __syncthreads();
     int64_t total = block_sum_partials<W>(tile_cut_count<P>(words, eu, ev, E, lane, w, W), scratch, lane, w);
     if (halve) total >>= 1;
@@ -534,8 +615,25 @@ static bool ls_sd_global() {   // dev knob: rd_std read from global memory even 
     static const bool on = getenv("RLS_LS_SD_GLOBAL") != nullptr;
     return on;
 }
-static size_t ls_threshold_lds(int64_t N, bool sd_lds) {
-    return (size_t)kLsRoundWaves * kTopCap * kWave * 4 + (size_t)kLsRoundWaves * kStageBytes + (sd_lds ? (size_t)((N + 3) & ~3ll) * 4 : 0);
+// workgroups per tile for the noise passes: 1 once the tiles alone fill the chip, else up to 8 slices of the rows
+static int ls_slices(int64_t B, int64_t nchunks) {
+    static const int force = getenv("RLS_LS_SLICES") ? atoi(getenv("RLS_LS_SLICES")) : 0;   // dev knob
+    const int64_t tiles = ceil_div(B, kWave);
+    int S = force > 0 ? force : (int)(num_cus() / (tiles > 0 ? tiles : 1));
+    if (S > 8) S = 8;
+    if ((int64_t)S * 2 * kLsRoundWaves > nchunks) S = (int)(nchunks / (2 * kLsRoundWaves));   // a slice keeps every wave busy
+    return S < 1 ? 1 : S;
+}
+static size_t ls_scratch_bytes(int64_t B, int64_t N, int S) {
+    if (S <= 1) return 0;
+    const size_t tiles = (size_t)ceil_div(B, kWave);
+    const size_t lists = tiles * S * kTopCap * kWave * 4, masks = tiles * (size_t)N * 8;
+    return lists > masks ? lists : masks;
+}
+// (rd_std always fits LDS beside the stages here: 4 N bytes, N bounded by the proposal kernel's tile)
+static size_t ls_mask_lds(int64_t N) { return (size_t)kLsRoundWaves * kStageBytes + (size_t)((N + 3) & ~3ll) * 4; }
+static size_t ls_threshold_lds(int64_t N) {
+    return (size_t)kLsRoundWaves * kTopCap * kWave * 4 + (size_t)kLsRoundWaves * kStageBytes + (size_t)((N + 3) & ~3ll) * 4;
 }
 static size_t ls_propose_lds(int64_t N, bool sd_lds) {
     return (size_t)((N + 1) & ~1ll) * 8 + (size_t)kLsRoundWaves * kWave * 8 + (size_t)kLsRoundWaves * kStageBytes +
@@ -624,8 +722,10 @@ extern "C" int rls_maxcut_local_search(const rls_graph* g, uint8_t* x, int64_t B
         case 16: LAUNCH_LSF(AL, WT, 16); break;   \
         default: LAUNCH_LSF(AL, WT, 24); break;   \
     }
-    if (ws_bytes == 1) { if (aligned) { DISPATCH_P(true, int8_t) } else { DISPATCH_P(false, int8_t) } }
-    else               { if (aligned) { DISPATCH_P(true, int16_t) } else { DISPATCH_P(false, int16_t) } }
+    // (rows that are not 16-byte multiples: the element-wise loader makes these the largest kernels of the library, 180-300 KB
+    // each, so they exist for the wide counter only -- a few more carry steps per 1024 edges on small graphs)
+    if (ws_bytes == 1) { if (aligned) { DISPATCH_P(true, int8_t) } else { LAUNCH_LSF(false, int8_t, 24); } }
+    else               { if (aligned) { DISPATCH_P(true, int16_t) } else { LAUNCH_LSF(false, int16_t, 24); } }
 #undef DISPATCH_P
 #undef LAUNCH_LSF
     return check_launch("k_maxcut_local_search");
@@ -640,8 +740,18 @@ extern "C" int rls_maxcut_ls_rounds_supported(const rls_graph* g, int32_t num_sp
     return ls_propose_lds(N, false) <= (size_t)kLdsBytes;
 }
 
+// bytes of caller-provided scratch with which the two entry points below split a tile's noise pass over several workgroups
+// (0: the batch alone fills the chip, or the rows are too short to split); without it they run one workgroup per tile
+extern "C" int64_t rls_maxcut_ls_scratch_bytes(const rls_graph* g, int64_t B, int32_t ws_bytes) {
+    if (!g || g->num_nodes <= 0 || B <= 0 || (ws_bytes != 1 && ws_bytes != 2)) return 0;
+    const int64_t N = g->num_nodes;
+    const int64_t nch = ws_bytes == 1 ? ls_num_chunks<int8_t>(N) : ls_num_chunks<int16_t>(N);
+    return (int64_t)ls_scratch_bytes(B, N, ls_slices(B, nch));
+}
+
 extern "C" int rls_maxcut_ls_threshold(const rls_graph* g, int64_t B, const void* ws, int32_t ws_bytes, const float* rd_std,
-                                       uint64_t seed, int64_t env_offset, int32_t draw, int32_t num_spin, float* thresh, void* stream) {
+                                       uint64_t seed, int64_t env_offset, int32_t draw, int32_t num_spin, float* thresh,
+                                       void* scratch, int64_t scratch_bytes, void* stream) {
     if (int rc = check_graph(g)) return rc;
     RLS_REQUIRE(B >= 0 && draw >= 0, RLS_EINVAL, "bad sizes");
     if (B == 0) return RLS_OK;
@@ -652,24 +762,32 @@ extern "C" int rls_maxcut_ls_threshold(const rls_graph* g, int64_t B, const void
                 num_spin, kTopCap - 1);
     RLS_REQUIRE((N & 15) == 0 && (((uintptr_t)ws) & 15) == 0, RLS_EUNSUPPORTED, "ws rows must be 16-byte multiples on a 16-byte base (N=%lld)",
                 (long long)N);
-    const bool sd_lds = !ls_sd_global() && ls_threshold_lds(N, true) <= (size_t)kLdsBytes;
-    const size_t lds = ls_threshold_lds(N, sd_lds);
-    const dim3 grid((unsigned)ceil_div(B, kWave)), block(kLsRoundWaves * kWave);
+    const size_t lds = ls_threshold_lds(N);
+    RLS_REQUIRE(lds <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS (max %d)", (long long)N, lds, kLdsBytes);
+    int S = ls_slices(B, ws_bytes == 1 ? ls_num_chunks<int8_t>(N) : ls_num_chunks<int16_t>(N));
+    if (!scratch || (size_t)scratch_bytes < ls_scratch_bytes(B, N, S) || (((uintptr_t)scratch) & 15) != 0) S = 1;
+    const dim3 grid((unsigned)ceil_div(B, kWave), (unsigned)S), block(kLsRoundWaves * kWave);
     hipStream_t s = as_stream(stream);
-#define LAUNCH_TH(WT, SD)                                                                                              \
+#define LAUNCH_TH(WT)                                                                                                  \
     do {                                                                                                               \
-        auto kern = k_ls_threshold<WT, SD>;                                                                            \
+        auto kern = k_ls_threshold<WT>;                                                                                \
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL(kern, grid, block, lds, s, (const WT*)ws, B, N, rd_std, seed, env_offset, (int)draw, (int)num_spin, thresh); \
+        hipLaunchKernelGGL(kern, grid, block, lds, s, (const WT*)ws, B, N, rd_std, seed, env_offset, (int)draw, (int)num_spin, thresh, \
+                           (float*)scratch);                                                                           \
     } while (0)
-    if (ws_bytes == 1) { if (sd_lds) LAUNCH_TH(int8_t, true); else LAUNCH_TH(int8_t, false); }
-    else               { if (sd_lds) LAUNCH_TH(int16_t, true); else LAUNCH_TH(int16_t, false); }
+    if (ws_bytes == 1) LAUNCH_TH(int8_t); else LAUNCH_TH(int16_t);
 #undef LAUNCH_TH
-    return check_launch("k_ls_threshold");
+    if (int rc = check_launch("k_ls_threshold")) return rc;
+    if (S > 1) {
+        hipLaunchKernelGGL(k_ls_threshold_merge, dim3(grid.x), dim3(kWave), 0, s, (const float*)scratch, S, B, (int)num_spin, thresh);
+        return check_launch("k_ls_threshold_merge");
+    }
+    return RLS_OK;
 }
 
 extern "C" int rls_maxcut_ls_propose(const rls_graph* g, uint8_t* x, int64_t B, const void* ws, int32_t ws_bytes, const float* rd_std,
-                                     const float* thresh, uint64_t seed, int64_t env_offset, int32_t draw, int64_t* obj, void* stream) {
+                                     const float* thresh, uint64_t seed, int64_t env_offset, int32_t draw, int64_t* obj,
+                                     void* scratch, int64_t scratch_bytes, void* stream) {
     if (int rc = check_graph(g)) return rc;
     RLS_REQUIRE(B >= 0 && draw >= 0, RLS_EINVAL, "bad sizes");
     if (B == 0) return RLS_OK;
@@ -682,24 +800,41 @@ extern "C" int rls_maxcut_ls_propose(const rls_graph* g, uint8_t* x, int64_t B, 
                 ls_propose_lds(N, false), kLdsBytes);
     const int P = pick_planes(E);
     RLS_REQUIRE(P != 0, RLS_EUNSUPPORTED, "E'=%lld too large", (long long)E);
-    const bool sd_lds = !ls_sd_global() && ls_propose_lds(N, true) <= (size_t)kLdsBytes;
-    const size_t lds = ls_propose_lds(N, sd_lds);
+    int S = ls_slices(B, ws_bytes == 1 ? ls_num_chunks<int8_t>(N) : ls_num_chunks<int16_t>(N));
+    if (!scratch || (size_t)scratch_bytes < ls_scratch_bytes(B, N, S) || (((uintptr_t)scratch) & 15) != 0) S = 1;
     const dim3 grid((unsigned)ceil_div(B, kWave)), block(kLsRoundWaves * kWave);
     hipStream_t s = as_stream(stream);
     const int halve = g->if_bidirectional ? 1 : 0;
-#define LAUNCH_PR(WT, PP, SD)                                                                                          \
+    if (S > 1) {   // the mask words first, S workgroups per tile
+        const size_t ldm = ls_mask_lds(N);
+        const dim3 gm(grid.x, (unsigned)S);
+#define LAUNCH_MK(WT)                                                                                                  \
     do {                                                                                                               \
-        auto kern = k_ls_propose<WT, PP, SD>;                                                                          \
+        auto kern = k_ls_mask<WT>;                                                                                     \
+        if (ldm > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldm); \
+        hipLaunchKernelGGL(kern, gm, block, ldm, s, (const WT*)ws, B, N, rd_std, thresh, seed, env_offset, (int)draw, (uint64_t*)scratch); \
+    } while (0)
+        if (ws_bytes == 1) LAUNCH_MK(int8_t); else LAUNCH_MK(int16_t);
+#undef LAUNCH_MK
+        if (int rc = check_launch("k_ls_mask")) return rc;
+    }
+    const bool sd_lds = S == 1 && !ls_sd_global() && ls_propose_lds(N, true) <= (size_t)kLdsBytes;
+    const size_t lds = ls_propose_lds(N, sd_lds);
+#define LAUNCH_PR(WT, PP, SD, PM)                                                                                      \
+    do {                                                                                                               \
+        auto kern = k_ls_propose<WT, PP, SD, PM>;                                                                      \
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(kern, grid, block, lds, s, x, B, N, g->eu, g->ev, E, halve, (const WT*)ws, rd_std, thresh, seed, env_offset, \
-                           (int)draw, obj);                                                                            \
+                           (int)draw, obj, (const uint64_t*)scratch);                                                  \
     } while (0)
 #define DISPATCH_PR(WT)                                                                            \
     do {                                                                                           \
-        if (P <= 16) { if (sd_lds) LAUNCH_PR(WT, 16, true); else LAUNCH_PR(WT, 16, false); }       \
-        else         { if (sd_lds) LAUNCH_PR(WT, 24, true); else LAUNCH_PR(WT, 24, false); }       \
+        if (P <= 16) { if (sd_lds) LAUNCH_PR(WT, 16, true, false); else LAUNCH_PR(WT, 16, false, false); }       \
+        else         { if (sd_lds) LAUNCH_PR(WT, 24, true, false); else LAUNCH_PR(WT, 24, false, false); }       \
     } while (0)
-    if (ws_bytes == 1) DISPATCH_PR(int8_t); else DISPATCH_PR(int16_t);
+    if (S > 1) {   // (WT and SD_LDS play no part once the mask is given: one instantiation per counter width)
+        if (P <= 16) LAUNCH_PR(int8_t, 16, false, true); else LAUNCH_PR(int8_t, 24, false, true);
+    } else if (ws_bytes == 1) DISPATCH_PR(int8_t); else DISPATCH_PR(int16_t);
 #undef DISPATCH_PR
 #undef LAUNCH_PR
     return check_launch("k_ls_propose");

@@ -203,8 +203,13 @@ void maxcut_local_search(int64_t g, Tensor xs, const Tensor& ws, const Tensor& r
                                (uint64_t)seed, env_offset, (int32_t)num_iters, (int32_t)num_spin, first_draw_proposes, (int64_t*)p(obj),
                                compute_obj, cur_stream(xs)), "rls_maxcut_local_search");
 }
+static int64_t scratch_of(const OptTensor& scratch) {   // a flat byte buffer on the device, or none
+    if (!scratch.has_value()) return 0;
+    TORCH_CHECK(scratch->is_cuda() && scratch->scalar_type() == at::kByte && scratch->is_contiguous(), "scratch must be a contiguous uint8 HIP tensor");
+    return scratch->numel();
+}
 void maxcut_ls_threshold(int64_t g, const Tensor& ws, const Tensor& rd_std, int64_t seed, int64_t env_offset, int64_t draw,
-                         int64_t num_spin, Tensor thresh) {
+                         int64_t num_spin, Tensor thresh, const OptTensor& scratch) {
     const int64_t N = G(g)->num_nodes;
     const int wb = ws_bytes_of(ws, false);
     TORCH_CHECK(ws.dim() == 2 && ws.size(1) == N, "ws must be [B, ", N, "], got ", ws.sizes());
@@ -215,10 +220,10 @@ void maxcut_ls_threshold(int64_t g, const Tensor& ws, const Tensor& rd_std, int6
     count(thresh, "thresh", B);
     RLS_GUARD(ws);
     ok(rls_maxcut_ls_threshold(G(g), B, p(ws), wb, (const float*)p(rd_std), (uint64_t)seed, env_offset, (int32_t)draw, (int32_t)num_spin,
-                               (float*)p(thresh), cur_stream(ws)), "rls_maxcut_ls_threshold");
+                               (float*)p(thresh), p(scratch), scratch_of(scratch), cur_stream(ws)), "rls_maxcut_ls_threshold");
 }
 void maxcut_ls_propose(int64_t g, Tensor xs, const Tensor& ws, const Tensor& rd_std, const Tensor& thresh, int64_t seed,
-                       int64_t env_offset, int64_t draw, Tensor obj) {
+                       int64_t env_offset, int64_t draw, Tensor obj, const OptTensor& scratch) {
     spin_bytes(xs, "xs", false);
     const int64_t B = env_rows(xs, "xs", G(g)), N = G(g)->num_nodes;
     const int wb = ws_bytes_of(ws, false);
@@ -231,7 +236,8 @@ void maxcut_ls_propose(int64_t g, Tensor xs, const Tensor& ws, const Tensor& rd_
     count(obj, "obj", B);
     RLS_GUARD(xs);
     ok(rls_maxcut_ls_propose(G(g), (uint8_t*)p(xs), B, p(ws), wb, (const float*)p(rd_std), (const float*)p(thresh), (uint64_t)seed,
-                             env_offset, (int32_t)draw, (int64_t*)p(obj), cur_stream(xs)), "rls_maxcut_ls_propose");
+                             env_offset, (int32_t)draw, (int64_t*)p(obj), p(scratch), scratch_of(scratch), cur_stream(xs)),
+       "rls_maxcut_ls_propose");
 }
 void select_better_rows(Tensor xs0, Tensor vs0, const Tensor& xs1, const Tensor& vs1, bool if_maximize) {
     spin_bytes(xs0, "xs0", false);
@@ -767,9 +773,9 @@ TORCH_LIBRARY(rlsolver_hip, m) {
     m.def("maxcut_ls_weights(int graph, Tensor xs, int mult, Tensor(a!) ws, Tensor(b!)? ws_minmax) -> ()");
     m.def("maxcut_local_search(int graph, Tensor(a!) xs, Tensor ws, Tensor rd_std, Tensor? noise, int seed, int env_offset, int num_iters, "
           "int num_spin, bool first_draw_proposes, Tensor(b!) obj, bool compute_obj) -> ()");
-    m.def("maxcut_ls_threshold(int graph, Tensor ws, Tensor rd_std, int seed, int env_offset, int draw, int num_spin, Tensor(a!) thresh) -> ()");
+    m.def("maxcut_ls_threshold(int graph, Tensor ws, Tensor rd_std, int seed, int env_offset, int draw, int num_spin, Tensor(a!) thresh, Tensor(b!)? scratch) -> ()");
     m.def("maxcut_ls_propose(int graph, Tensor(a!) xs, Tensor ws, Tensor rd_std, Tensor thresh, int seed, int env_offset, int draw, "
-          "Tensor(b!) obj) -> ()");
+          "Tensor(b!) obj, Tensor(c!)? scratch) -> ()");
     m.def("select_better_rows(Tensor(a!) xs0, Tensor(b!) vs0, Tensor xs1, Tensor vs1, bool if_maximize) -> ()");
     m.def("pick_best_of_repeats(Tensor xs, Tensor vs, int R, bool if_maximize, Tensor(a!) good_xs, Tensor(b!) good_vs) -> ()");
     m.def("copy_rows(Tensor(a!) xs, Tensor(b!)? vs, Tensor dst, Tensor src) -> ()");

@@ -289,8 +289,15 @@ def ls_rounds_supported(g: DeviceGraph, num_spin: int) -> bool:
     return bool(_abi.lib().rls_maxcut_ls_rounds_supported(g.ref, int(num_spin)))
 
 
+def ls_scratch(g: DeviceGraph, B: int, ws: TEN) -> Optional[TEN]:
+    """The scratch buffer with which the round kernels split a small batch's noise passes over more workgroups (None when
+    there is nothing to gain: rls_maxcut_ls_scratch_bytes)."""
+    n = int(_abi.lib().rls_maxcut_ls_scratch_bytes(g.ref, int(B), ws.element_size()))
+    return torch.empty(n, dtype=torch.uint8, device=g.device) if n > 0 else None
+
+
 def maxcut_ls_threshold(g: DeviceGraph, ws: TEN, rd_std: TEN, seed: int, num_spin: int, draw: int = 0, env_offset: int = 0,
-                        out: Optional[TEN] = None) -> TEN:
+                        out: Optional[TEN] = None, scratch: Optional[TEN] = None) -> TEN:
     """thresh f32 [B] = kthvalue(ws + normal(draw) * rd_std, k = N - num_spin) with the fused local search's draws."""
     _check(ws, "ws", (torch.int8, torch.int16), g.device)
     if ws.dim() != 2 or ws.shape[1] != g.num_nodes:
@@ -298,19 +305,19 @@ def maxcut_ls_threshold(g: DeviceGraph, ws: TEN, rd_std: TEN, seed: int, num_spi
     _check(rd_std, "rd_std", (torch.float32,), g.device, (g.num_nodes,))
     out = torch.empty(ws.shape[0], dtype=torch.float32, device=g.device) if out is None else out
     _check(out, "out", (torch.float32,), g.device, (ws.shape[0],))
-    _t.maxcut_ls_threshold(g.handle, ws, rd_std, _s64(seed), env_offset, int(draw), int(num_spin), out)
+    _t.maxcut_ls_threshold(g.handle, ws, rd_std, _s64(seed), env_offset, int(draw), int(num_spin), out, scratch)
     return out
 
 
 def maxcut_ls_propose(g: DeviceGraph, xs: TEN, ws: TEN, rd_std: TEN, thresh: TEN, obj: TEN, seed: int, draw: int,
-                      env_offset: int = 0) -> None:
+                      env_offset: int = 0, scratch: Optional[TEN] = None) -> None:
     """One proposal round in place: rows of xs whose xs ^ (ws + normal(draw) * rd_std > thresh) has cut >= obj take it."""
     B, _ = _spins(xs, "xs", g)
     _check(ws, "ws", (torch.int8, torch.int16), g.device, (B, g.num_nodes))
     _check(rd_std, "rd_std", (torch.float32,), g.device, (g.num_nodes,))
     _check(thresh, "thresh", (torch.float32,), g.device, (B,))
     _check(obj, "obj", (torch.int64,), g.device, (B,))
-    _t.maxcut_ls_propose(g.handle, xs, ws, rd_std, thresh, _s64(seed), env_offset, int(draw), obj)
+    _t.maxcut_ls_propose(g.handle, xs, ws, rd_std, thresh, _s64(seed), env_offset, int(draw), obj, scratch)
 
 
 def select_better_rows(xs0: TEN, vs0: TEN, xs1: TEN, vs1: TEN, if_maximize: bool = True) -> None:

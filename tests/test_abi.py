@@ -15,7 +15,7 @@ def declared_functions():
     for h in glob.glob(os.path.join(ROOT, "include", "*.h")):
         src = open(h).read()
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-        for m in re.finditer(r"\b(int|const char\*)\s+(rls_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+        for m in re.finditer(r"\b(int|int64_t|const char\*)\s+(rls_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
             args = [a.strip() for a in m.group(3).split(",")]
             nargs = 0 if args == ["void"] else len(args)
             names[m.group(2)] = nargs
@@ -27,7 +27,7 @@ def declared_signatures():
     sigs = {}
     for h in glob.glob(os.path.join(ROOT, "include", "*.h")):
         src = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
-        for m in re.finditer(r"\b(int|const char\*)\s+(rls_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+        for m in re.finditer(r"\b(int|int64_t|const char\*)\s+(rls_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
             args = [" ".join(a.split()) for a in m.group(3).split(",")]
             sigs[m.group(2)] = [] if args == ["void"] else [re.sub(r"\s*\w+$", "", a) if not a.endswith("*") else a
                                                             for a in args]

@@ -106,7 +106,8 @@ def test_local_search_class_golden_both_paths(golden, gname, fused):
 
 
 @pytest.mark.parametrize("n,m,B,bidir,num_spin", [(2000, 19990, 130, False, 8), (320, 2000, 70, True, 6), (64, 400, 64, False, 3),
-                                                  (1008, 5000, 65, False, 12), (3008, 9000, 200, True, 8)])
+                                                  (1008, 5000, 65, False, 12), (3008, 9000, 200, True, 8),
+                                                  (320, 2000, 16500, False, 8)])      # (the last: enough tiles for one workgroup each)
 def test_round_kernels_equal_the_fused_kernel_for_the_same_seed(n, m, B, bidir, num_spin):
     """rls_maxcut_ls_threshold + rls_maxcut_ls_propose per round + K5 draw what the fused kernel draws: under the same torch
     seed local_search_inplace gives the same spins and cuts through either form (the fused one is pinned by the golden
@@ -160,6 +161,15 @@ def test_round_kernels_beyond_the_fused_kernel(n, m):
         if nf.numel():
             flips.append(float(nf.mean()))
     assert flips and 0.25 * num_spin < np.mean(flips) < 4 * num_spin, flips
+    # with the scratch buffer a small batch's noise passes are split over several workgroups: same threshold, same round
+    scratch = ops.ls_scratch(env.graph, B, ws)
+    assert scratch is not None and scratch.numel() >= (B + 63) // 64 * n * 8
+    assert torch.equal(ops.maxcut_ls_threshold(env.graph, ws, rd_std, seed=99, num_spin=num_spin, scratch=scratch), thresh)
+    p, q, vp, vq = xs.clone(), xs.clone(), vs.clone(), vs.clone()
+    ops.maxcut_ls_propose(env.graph, p, ws, rd_std, thresh, vp, seed=99, draw=5)
+    ops.maxcut_ls_propose(env.graph, q, ws, rd_std, thresh, vq, seed=99, draw=5, scratch=scratch)
+    assert torch.equal(p, q) and torch.equal(vp, vq)
+    assert ops.ls_scratch(env.graph, 1 << 16, ws) is None           # a batch that fills the chip by itself
     # the same seed and draw index give the same proposal; another draw index another one
     a, b, c = xs.clone(), xs.clone(), xs.clone()
     va, vb, vc = vs.clone(), vs.clone(), vs.clone()

@@ -1,6 +1,7 @@
 """Differential fuzz of local_search_inplace with recorded noise: the fused kernel against the decomposed K2 / K6 / K5 path on
 random graphs (incl. hubs, where the two take different kernels), and both against the reference-shaped numpy oracle on small
-ones; random batch sizes around the tile, num_iters 0-6, num_spin 1-8, both adjacency forms.
+ones; random batch sizes around the tile, num_iters 0-6, num_spin 1-8, both adjacency forms.  Where the rows are 16-byte
+multiples, additionally the threshold / proposal-round kernels against the fused kernel with in-kernel draws (same seed).
 `python tools/dev/fuzz_ls.py [seconds] [seed]`."""
 import sys, time
 import numpy as np, torch
@@ -13,10 +14,12 @@ DEV = torch.device("cuda:0")
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 t_end = time.time() + budget
-it = 0
+it = nrounds = 0
 while time.time() < t_end:
     kind = rng.choice(["gnm", "ba", "hub", "tiny"])
     n = int(rng.randint(10, 64)) if kind == "tiny" else int(rng.choice([rng.randint(64, 400), rng.randint(400, 2500)]))
+    if kind != "tiny" and rng.rand() < 0.5:
+        n = max(64, n // 16 * 16)
     if kind in ("gnm", "tiny"):
         garr = np.asarray(G.generate_gnm(n, int(rng.randint(n, min(n * (n - 1) // 2, n * 8))), int(rng.randint(1 << 30))), dtype=np.int64)
     elif kind == "ba":
@@ -49,5 +52,21 @@ while time.time() < t_end:
     if n <= 64 and B <= 65:
         wx, wv = onp.local_search_inplace(xs0.cpu().numpy(), garr, n, bidir, noise.cpu().numpy(), num_iters=num_iters, num_spin=num_spin)
         assert np.array_equal(outs[0][0].cpu().numpy(), wx) and np.array_equal(outs[0][1].cpu().numpy(), wv), "vs oracle " + tag
+    from rlsolver_amd import ops
+    env.fused_local_search = True
+    if n % 16 == 0 and ops.local_search_fusable(env.graph, num_spin, B) and ops.ls_rounds_supported(env.graph, num_spin):
+        first = bool(rng.rand() < 0.5)
+        if num_iters > 0 or not first:
+            res = []
+            for rounds in (False, True):
+                env.force_ls_rounds = rounds
+                torch.manual_seed(1000 + it)
+                xs, vs = xs0.clone(), env.calculate_obj_values(xs0)
+                env.local_search_pipeline(xs, vs, weight_mult=2 if first else 1, num_iters=num_iters, num_spin=num_spin, noise_std=0.3,
+                                          noise=None, first_draw_proposes=first)
+                res.append((xs, vs))
+            env.force_ls_rounds = False
+            assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), "round kernels vs fused " + tag
+            nrounds += 1
     it += 1
-print(f"fuzz_ls: {it} random configurations, no mismatch")
+print(f"fuzz_ls: {it} random configurations ({nrounds} also round kernels vs fused), no mismatch")
