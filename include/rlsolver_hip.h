@@ -223,6 +223,12 @@ int rls_maxcut_local_search(const rls_graph* g, uint8_t* x, int64_t B, const voi
  * 8- or 4-wave LDS layout must fit 160 KB), else 0 -- callers then take the K2 + K6 + K5 path. */
 int rls_maxcut_local_search_supported(const rls_graph* g, int64_t B, int32_t num_spin);
 
+/* Which kernel family rls_maxcut_node_cutdeg / rls_maxcut_ls_weights (what = 0) or rls_maxcut_delta_all (what = 1) take for
+ * a batch of B envs on this graph: 1 = bit-sliced, lane = node (unweighted graphs; a tile of 64 envs costs the same however
+ * few it holds, so from the batch that pays for it), 2 = lane = env tile (weighted graphs, from a larger batch still),
+ * 0 = element-parallel.  All three give the same result; tests use this to know which one they exercised. */
+int rls_maxcut_node_stats_form(const rls_graph* g, int64_t B, int32_t what);
+
 /* The same local search as separate launches, for graphs rls_maxcut_local_search does not cover (its LDS layout holds
  * two tiles and rd_std: N <= ~6500; these hold one tile: N <= ~15 000, N % 16 == 0).  Both use the fused kernel's
  * in-kernel draws -- normal(seed, env_offset + b, node, draw) -- so a caller that passes the same seed gets the result

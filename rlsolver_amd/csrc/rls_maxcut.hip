@@ -587,10 +587,18 @@ __global__ __launch_bounds__(kNsWaves * kWave) void k_node_stats_bits(const uint
 static inline size_t node_stats_bits_lds(int64_t N) {
     return (((size_t)N * 8 + 15) & ~(size_t)15) + (size_t)kNsWaves * kStageBytes;
 }
-// the bit-sliced kernel needs the slabs, an unweighted graph, byte-sized counters and a tile that fits
+// the bit-sliced kernel needs the slabs, an unweighted graph, byte-sized counters and a tile that fits.  A tile costs about
+// 0.011 us per node however few envs it holds, the element-parallel kernels about 2e-6 us per (env, node + entry): K3 on a
+// G22-sized graph 28 us flat vs 9 / 21 / 68 us at 64 / 256 / 1024 envs, N = 10^4 with 10^4 edges 88 flat vs 7 / 17 / 70
+// (tools/dev/node_stats_forms.py) -- so small batches go element-parallel
+static inline bool node_stats_batch_fills_tiles(const rls_graph* g, int64_t B) {
+    static const int64_t force = getenv("RLS_NODE_STATS_MIN_B") ? atoll(getenv("RLS_NODE_STATS_MIN_B")) : -1;   // dev knob
+    if (force >= 0) return B >= force;
+    return (double)B * (double)(g->num_nodes + g->nnz) > 4000.0 * (double)g->num_nodes;
+}
 static inline bool node_stats_use_bits(const rls_graph* g, const int32_t* ell_ptr, const int32_t* ell, int64_t B) {
     static const bool off = getenv("RLS_NODE_STATS_LANE_ENV") != nullptr;   // dev knob: the lane = env kernels
-    return !off && ell_ptr && ell && !g->wgt && g->max_degree < 65536 && B >= 2048 &&
+    return !off && ell_ptr && ell && !g->wgt && g->max_degree < 65536 && node_stats_batch_fills_tiles(g, B) &&
            node_stats_bits_lds(g->num_nodes) <= (size_t)kLdsBytes;
 }
 template <int MODE, typename WT = int32_t>
@@ -610,79 +618,6 @@ static int launch_node_stats_bits(const rls_graph* g, const uint8_t* x, int64_t 
     return check_launch("k_node_stats_bits");
 }
 
-// Local-search weights: ws[b,i] = stored_deg(i) - mult * cutdeg(b,i) as WT (int8 / int16 / int32) -- the pre-pass of
-// rls_maxcut_local_search -- and their whole-batch min / max per node (ws_minmax_update).  Same structure as
-// k_node_stats_tile; the small-batch form (the bit-sliced kernel takes batches from 2048 envs).
-template <bool VEC, typename WT>
-__global__ __launch_bounds__(kTileWaves * kWave) void k_ls_weights(const uint8_t* __restrict__ x, int64_t B, int64_t N,
-                                                                   const int32_t* __restrict__ rowptr,
-                                                                   const int32_t* __restrict__ col, int mult,
-                                                                   WT* __restrict__ ws, int32_t* __restrict__ minmax) {
-    constexpr int NB = 128 / (int)sizeof(WT), STRIDE = 144;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint64_t* words = reinterpret_cast<uint64_t*>(smem);
-    const unsigned char* wbytes = smem;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
-    unsigned char* stage = smem + (size_t)(N + 2) * 8 + (size_t)w * kWave * STRIDE;
-    const int64_t b0 = (int64_t)blockIdx.x * kWave;
-    if (threadIdx.x == 0) words[N] = 0;
-    static_assert(kWave * STRIDE >= kStageBytes, "the output staging rows double as the tile-load stage");
-    tile_load_bits<uint8_t, VEC>(x, B, N, b0, words, lane, w, kTileWaves, VEC ? stage : nullptr);
-    __syncthreads();
-    const int sh = lane & 31;
-    const uint32_t half4 = (uint32_t)(lane >> 5) * 4u;
-    const int64_t b = b0 + lane;
-    const bool valid = b < B;
-    for (int64_t i0 = (int64_t)w * NB; i0 < N; i0 += (int64_t)kTileWaves * NB) {
-        const int nb_here = (int)((N - i0) < NB ? (N - i0) : NB);
-        for (int k = 0; k < nb_here; ++k) {
-            const int64_t i = i0 + k;
-            const int r0 = rowptr[i], r1 = rowptr[i + 1];
-            const uint32_t xi = (*reinterpret_cast<const uint32_t*>(wbytes + ((uint32_t)i * 8u + half4)) >> sh) & 1u;
-            int acc = 0;
-            for (int base = r0; base < r1; base += kWave) {
-                const int cnt = (r1 - base) < kWave ? (r1 - base) : kWave;
-                const uint32_t my_nb = (lane < cnt) ? (uint32_t)col[base + lane] : (uint32_t)N;
-                for (int j = 0; j < cnt; j += 8) {
-                    uint32_t wv[8];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const uint32_t nb = (uint32_t)__builtin_amdgcn_readlane((int)my_nb, j + q);
-                        wv[q] = *reinterpret_cast<const uint32_t*>(wbytes + (nb * 8u + half4));
-                    }
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) acc += (int)((wv[q] >> sh) & 1u);
-                }
-            }
-            const int deg = r1 - r0;
-            const int val = deg - mult * (xi ? (deg - acc) : acc);
-            *reinterpret_cast<WT*>(stage + lane * STRIDE + k * (int)sizeof(WT)) = (WT)val;
-            if (minmax) {
-                int lo = valid ? val : INT32_MAX, hi = valid ? val : INT32_MIN;
-#pragma unroll
-                for (int sft = 32; sft >= 1; sft >>= 1) {
-                    lo = min(lo, __shfl_xor(lo, sft, kWave));
-                    hi = max(hi, __shfl_xor(hi, sft, kWave));
-                }
-                if (lane == 0) ws_minmax_update(minmax, N, i, lo, hi);
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (valid) {
-            WT* dst = ws + b * N + i0;
-            const unsigned char* src = stage + lane * STRIDE;
-            if (nb_here == NB && ((((uintptr_t)dst) & 15) == 0)) {
-#pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    reinterpret_cast<u32x4*>(dst)[q] = *reinterpret_cast<const u32x4*>(src + q * 16);
-            } else {
-                for (int k = 0; k < nb_here; ++k) dst[k] = *reinterpret_cast<const WT*>(src + k * (int)sizeof(WT));
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-}
 
 // one wave per row
 __global__ __launch_bounds__(256) void k_select_better_rows(uint8_t* __restrict__ xs0, int64_t* __restrict__ vs0,
@@ -1160,8 +1095,24 @@ int rls_maxcut_edge_cut_mask(const rls_graph* g, const uint8_t* x, int64_t B, ui
 }
 
 static inline size_t node_stats_lds(int64_t N) { return (size_t)(N + 2) * 8 + (size_t)kTileWaves * kWave * 144; }
-// the tile kernels are latency-bound per node; with few tiles the element-parallel kernels win
-static inline bool node_stats_use_tile(int64_t B, int64_t N) { return B >= 2048 && node_stats_lds(N) <= (size_t)kLdsBytes; }
+// the lane = env tile kernels (weighted graphs, degrees >= 65536) walk every node and entry of the graph once per tile, 0.10 us
+// per node + 0.008 us per entry whatever the batch (K3 on a +-1-weighted G22-sized graph: 530 us from 2048 to 16 384 envs), the
+// element-parallel kernels 2.75e-6 us per (env, node + entry) (250 / 480 / 1890 us at 2048 / 4096 / 16 384): the tile form from
+// the batch where it is the cheaper one (tools/dev/node_stats_forms.py)
+static inline bool node_stats_use_tile(const rls_graph* g, int64_t B) {
+    static const bool off = getenv("RLS_NODE_STATS_NO_TILE") != nullptr;   // dev knob
+    const int64_t N = g->num_nodes;
+    return !off && node_stats_lds(N) <= (size_t)kLdsBytes &&
+           2.75e-6 * (double)B * (double)(N + g->nnz) > 0.103 * (double)N + 0.008 * (double)g->nnz;
+}
+
+// which kernel family K2 / K3 / the local-search weights take for a batch of B envs: 1 bit-sliced (lane = node), 2 lane = env
+// tile, 0 element-parallel -- the launchers' own tests (what = 0: K2 / weights, the adjacency as stored; 1: K3, symmetric)
+int rls_maxcut_node_stats_form(const rls_graph* g, int64_t B, int32_t what) {
+    if (!g || g->num_nodes <= 0 || B <= 0) return 0;
+    if (what ? node_stats_use_bits(g, g->ell_sym_ptr, g->ell_sym, B) : node_stats_use_bits(g, g->ell_st_ptr, g->ell_st, B)) return 1;
+    return node_stats_use_tile(g, B) ? 2 : 0;
+}
 
 int rls_maxcut_node_cutdeg(const rls_graph* g, const uint8_t* x, int64_t B, int64_t* cutdeg, void* stream) {
     if (int rc = check_graph(g)) return rc;
@@ -1172,7 +1123,7 @@ int rls_maxcut_node_cutdeg(const rls_graph* g, const uint8_t* x, int64_t B, int6
         return launch_node_stats_bits<0>(g, x, B, g->erowptr, g->ell_st_ptr, g->ell_st, 0, cutdeg, stream);
     const int64_t N = g->num_nodes;
     const size_t lds = node_stats_lds(N);
-    if (node_stats_use_tile(B, N)) {
+    if (node_stats_use_tile(g, B)) {
         const dim3 grid((unsigned)ceil_div(B, kWave)), block(kTileWaves * kWave);
         hipStream_t s = as_stream(stream);
 #define LAUNCH_NS(VEC)                                                                                           \
@@ -1200,7 +1151,7 @@ int rls_maxcut_delta_all(const rls_graph* g, const uint8_t* x, int64_t B, int32_
         return launch_node_stats_bits<1>(g, x, B, g->rowptr, g->ell_sym_ptr, g->ell_sym, 0, delta, stream);
     const int64_t N = g->num_nodes;
     const size_t lds = node_stats_lds(N);
-    if (node_stats_use_tile(B, N)) {
+    if (node_stats_use_tile(g, B)) {
         const dim3 grid((unsigned)ceil_div(B, kWave)), block(kTileWaves * kWave);
         hipStream_t s = as_stream(stream);
 #define LAUNCH_ND(W, VEC)                                                                                        \
@@ -1230,27 +1181,13 @@ int rls_maxcut_delta_all(const rls_graph* g, const uint8_t* x, int64_t B, int32_
 
 template <typename WT>
 static int ls_weights_typed(const rls_graph* g, const uint8_t* x, int64_t B, int32_t mult, WT* ws, int32_t* minmax, void* stream) {
+    // (a lane = env tile kernel used to take the small batches: 850 us per call on a G22-sized graph at any batch size, against
+    // 30 us for the bit-sliced one and 20 - 100 us for the element-parallel one: tools/dev/ls_weights_forms.py)
     if (node_stats_use_bits(g, g->ell_st_ptr, g->ell_st, B))
         return launch_node_stats_bits<2, WT>(g, x, B, g->erowptr, g->ell_st_ptr, g->ell_st, (int)mult, ws, stream, minmax);
-    const int64_t N = g->num_nodes;
-    const size_t lds = node_stats_lds(N);
-    if (lds > (size_t)kLdsBytes) {   // no tile for this N: element-parallel
-        hipLaunchKernelGGL(k_ls_weights_elem<WT>, dim3(grid_for(B * N, 256)), dim3(256), 0, as_stream(stream), x, B, N, g->erowptr,
-                           g->ev, (int)mult, ws, minmax);
-        return check_launch("k_ls_weights_elem");
-    }
-    const dim3 grid((unsigned)ceil_div(B, kWave)), block(kTileWaves * kWave);
-    hipStream_t s = as_stream(stream);
-#define LAUNCH_LW(VEC)                                                                                           \
-    do {                                                                                                         \
-        auto kern = k_ls_weights<VEC, WT>;                                                                       \
-        if (lds > 64 * 1024)                                                                                     \
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
-        hipLaunchKernelGGL(kern, grid, block, lds, s, x, B, N, g->erowptr, g->ev, (int)mult, ws, minmax);         \
-    } while (0)
-    if (tile_rows_aligned(x, N, 1)) LAUNCH_LW(true); else LAUNCH_LW(false);
-#undef LAUNCH_LW
-    return check_launch("k_ls_weights");
+    hipLaunchKernelGGL(k_ls_weights_elem<WT>, dim3(grid_for(B * g->num_nodes, 256)), dim3(256), 0, as_stream(stream), x, B, g->num_nodes,
+                       g->erowptr, g->ev, (int)mult, ws, minmax);
+    return check_launch("k_ls_weights_elem");
 }
 
 extern "C" {

@@ -284,6 +284,12 @@ def maxcut_local_search(g: DeviceGraph, xs: TEN, ws: TEN, rd_std: TEN, obj: TEN,
                            bool(first_draw_proposes), obj, bool(compute_obj))
 
 
+def node_stats_form(g: DeviceGraph, B: int, symmetric: bool) -> str:
+    """Which kernel family K2 / the local-search weights (symmetric=False) or K3 (True) take at this batch size: "bits" |
+    "tile" | "elem" (rls_maxcut_node_stats_form)."""
+    return ("elem", "bits", "tile")[int(_abi.lib().rls_maxcut_node_stats_form(g.ref, int(B), int(bool(symmetric))))]
+
+
 def ls_rounds_supported(g: DeviceGraph, num_spin: int) -> bool:
     """Whether rls_maxcut_ls_threshold / rls_maxcut_ls_propose cover this graph (the library's own test)."""
     return bool(_abi.lib().rls_maxcut_ls_rounds_supported(g.ref, int(num_spin)))

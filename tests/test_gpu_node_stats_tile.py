@@ -1,6 +1,6 @@
-"""K2/K3 have three implementations (B >= 2048: bit-sliced lane = node kernel on unweighted graphs of max degree
-< 256, lane = env bit-tile kernel otherwise; element-parallel below 2048 envs): they must agree with each other
-and with the oracle, incl. ragged N, weights, bidirectional, hubs."""
+"""K2/K3 have three implementations (bit-sliced lane = node kernel on unweighted graphs, lane = env bit-tile kernel on weighted
+ones, element-parallel for batches too small to pay for a tile: ops.node_stats_form says which one a batch takes): they must agree
+with each other and with the oracle, incl. ragged N, weights, bidirectional, hubs."""
 import numpy as np
 import pytest
 import torch
@@ -21,20 +21,24 @@ def test_tile_and_element_kernels_agree(n, m, B, weighted, bidir):
     if weighted:
         graph[:, 2] = rng.choice([-3, -1, 1, 2], size=len(graph))
     g = device_graph(graph, n, bidir, use_weights=weighted)
+    big = "tile" if weighted else "bits"
+    while ops.node_stats_form(g, B, True) != big or ops.node_stats_form(g, B, False) != big:
+        B = B * 3 // 2 + 1                                        # (the weighted tile form pays from a few thousand envs on)
+    assert B < 40000 and ops.node_stats_form(g, 100, True) == ops.node_stats_form(g, 100, False) == "elem"
     xs = rng.randint(0, 2, size=(B, n)).astype(np.uint8)
     x = to_dev_bool(xs)
-    d_tile = ops.maxcut_delta_all(g, x)                       # B >= 2048 -> tile kernel
+    d_tile = ops.maxcut_delta_all(g, x)                       # the bit-sliced / tile kernel
     c_tile = ops.maxcut_node_cutdeg(g, x)
-    d_el = torch.cat([ops.maxcut_delta_all(g, x[i:i + 1000].contiguous()) for i in range(0, B, 1000)])
-    c_el = torch.cat([ops.maxcut_node_cutdeg(g, x[i:i + 1000].contiguous()) for i in range(0, B, 1000)])
-    assert torch.equal(d_tile, d_el) and torch.equal(c_tile, c_el)
+    d_el = torch.cat([ops.maxcut_delta_all(g, x[i:i + 100].contiguous()) for i in range(0, min(B, 1500), 100)])
+    c_el = torch.cat([ops.maxcut_node_cutdeg(g, x[i:i + 100].contiguous()) for i in range(0, min(B, 1500), 100)])
+    assert torch.equal(d_tile[:1500], d_el) and torch.equal(c_tile[:1500], c_el)
     sub = rng.choice(B, 6, replace=False)
     assert np.array_equal(d_tile[sub].cpu().numpy(), onp.maxcut_delta_all(xs[sub], graph, n, graph[:, 2] if weighted else None))
     assert np.array_equal(c_tile[sub].cpu().numpy(), onp.maxcut_node_cutdeg(xs[sub], graph, n, bool(bidir)))
     if not weighted:
         # local-search weights ws = stored_deg - mult * cutdeg through the same kernel family
         # (int8 where the degrees fit a byte, any wider type on request) and its whole-batch span max_b - min_b per node,
-        # folded in by the same kernel; large batch (bit-sliced kernel), small batch (lane = env kernel), ragged last tile
+        # folded in by the same kernel; large batch (bit-sliced kernel), small batches (element-parallel kernel), ragged last tile
         deg = torch.from_numpy(np.bincount(g.csr.eu, minlength=n)).to(DEV)
         for mult in (1, 2):
             want = deg[None, :] - mult * c_tile
@@ -43,7 +47,7 @@ def test_tile_and_element_kernels_agree(n, m, B, weighted, bidir):
                     with pytest.raises(RuntimeError):
                         ops.maxcut_ls_weights(g, x, mult, dtype=dt)
                     continue
-                for rows in (B, 1000, 1):
+                for rows in (B, 1000, 70, 1):
                     ws, span = ops.maxcut_ls_weights(g, x[:rows].contiguous(), mult, dtype=dt)
                     assert ws.dtype == (dt or ops.ls_weight_dtype(g, mult))
                     assert torch.equal(ws.long(), want[:rows])

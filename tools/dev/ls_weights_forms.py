@@ -1,0 +1,19 @@
+"""The local-search weights pre-pass at small batches: time per call (the form is chosen by the dev knob RLS_LS_WEIGHTS_FORM)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np, torch
+from rlsolver_amd import ops
+from rlsolver_amd.graph import build_csr, generate_ba, generate_gnm
+dev = torch.device("cuda:0")
+for name, n, mg in (("G22", 2000, generate_gnm(2000, 19990, 22)), ("G14", 800, generate_gnm(800, 4694, 14)), ("BA-1e4", 10000, generate_ba(10000, 5, 5))):
+    g = ops.DeviceGraph(build_csr(mg, n, False), dev)
+    row = []
+    for B in (1, 64, 256, 1024, 2048, 4096):
+        xs = torch.rand(B, n, device=dev) < 0.5
+        for _ in range(3): ops.maxcut_ls_weights(g, xs, 1)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10): ops.maxcut_ls_weights(g, xs, 1)
+        e1.record(); torch.cuda.synchronize()
+        row.append(f"B={B}: {e0.elapsed_time(e1) * 100:.0f}")
+    print(os.environ.get("RLS_LS_WEIGHTS_FORM", "default"), name, " ".join(row), "us")
