@@ -445,6 +445,15 @@ int rls_mcpg_metro_rounds(void* samples, const void* samples_in, int64_t C_in, i
                           uint64_t seed, const int64_t* t_limit_dev, int write_back, int64_t* accepts, int64_t accept_rows,
                           void* stream);
 
+/* The stop rule between two chunks of rls_mcpg_metro_rounds (MCPG.py:103,115: the reference compares `count` with
+ * total_mcmc_num * max_transfer_time on the host after every round), one small launch instead of a chain of [T]-sized torch ops:
+ * accepts [accept_rows][T] as the chunk's dry (or, for the first chunk, direct) pass filled it; ctl int64 [3] on the device =
+ * {accepts of the earlier chunks, walk still live (0 / 1), limit of the next dry pass} -- written, and read unless first != 0;
+ * *apply_limit (device int64, may be NULL) = min(this chunk's limit, the first round at which the running count reaches
+ * target) for the apply pass; ctl[2] = next_T while the walk is live, else 0 (rls_mcpg_metro_rounds returns at once on 0). */
+int rls_mcpg_metro_stop(const int64_t* accepts, int64_t accept_rows, int64_t T, int64_t target, int32_t first, int64_t next_T,
+                        int64_t* ctl, int64_t* apply_limit, void* stream);
+
 /* K7 + K8 first half  sampler_func  methods/MCPG.py:128-152.
  * xs_in [N,C] holds 0|1 (the sampler's input before the reference maps it to -0.5|1.5).
  * For each of num_ls passes, for pos in 0..N-1, node = order[pos] (int32 [N], degree-descending):

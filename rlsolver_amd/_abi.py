@@ -102,6 +102,7 @@ SIGNATURES = {
     "rls_spin_step": [_G, _SE, _INT, _I64, C.c_int32, _P, _P, _P, _P, _F64, _F64, C.c_int32, _F64, _I64, C.c_int32, _F64,
                       C.c_int32, _F64, _P],
     "rls_mcpg_metro_rounds": [_P, _P, _I64, _INT, _I64, _I64, _P, _I64, _I64, _P, _P, _U64, _P, _INT, _P, _I64, _P],
+    "rls_mcpg_metro_stop": [_P, _I64, _I64, _I64, C.c_int32, _I64, _P, _P, _P],
     "rls_mcpg_local_search": [_G, _P, _INT, _P, _I64, _P, _P, _I64, _I64, _P, _U64, _P, _I64, _P, _P],
     "rls_mcpg_pick_best": [_P, _P, _INT, _I64, _I64, _I64, _I64, _P, _P, _P, _P],
     "rls_mcpg_merge_best": [_P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P],

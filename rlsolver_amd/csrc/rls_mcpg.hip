@@ -1121,6 +1121,54 @@ __global__ __launch_bounds__(4 * kWave) void k_mcpg_pack(const T* __restrict__ x
     }
 }
 
+// The stop rule of metro_sampling between two chunks of rounds (MCPG.py:103,115: stop after the first round whose cumulative
+// accept count reaches C * T), as ONE small launch: column sums of accepts [rows][T], their running total on top of the earlier
+// chunks', the first round that reaches the target.  ctl = {accepts so far, walk still live, limit of the next dry pass}.
+//   first chunk (applied directly, all T rounds ran):  hit = total >= target
+//   later chunks: *apply_limit = min(limit, stop round) for the apply pass of this chunk
+// Before, this was ten [1]- to [T]-sized torch ops per chunk -- 70 launches per call, 440 us of dispatch around 20 us of kernels
+// on a G22-sized graph.
+constexpr int kStopThreads = 256;
+__global__ __launch_bounds__(kStopThreads) void k_metro_stop(const int64_t* __restrict__ accepts, int64_t rows, int64_t T, int64_t target,
+                                                             int first, int64_t next_T, int64_t* __restrict__ ctl,
+                                                             int64_t* __restrict__ apply_limit) {
+    __shared__ int64_t seg[kStopThreads];
+    __shared__ int64_t stop_at;
+    const int tid = threadIdx.x;
+    const int64_t per = (T + kStopThreads - 1) / kStopThreads, t0 = per * tid, t1 = t0 + per < T ? t0 + per : T;
+    int64_t mine = 0;
+    for (int64_t t = t0; t < t1; ++t)
+        for (int64_t r = 0; r < rows; ++r) mine += accepts[r * T + t];
+    seg[tid] = mine;
+    if (tid == 0) stop_at = INT64_MAX;
+    __syncthreads();
+    int64_t before = first ? 0 : ctl[0];     // accepts before this thread's segment
+    int64_t total = before;
+    for (int k = 0; k < kStopThreads; ++k) {
+        if (k < tid) before += seg[k];
+        total += seg[k];
+    }
+    // the first round of this segment at which the running count reaches the target
+    int64_t run = before, found = INT64_MAX;
+    for (int64_t t = t0; t < t1 && found == INT64_MAX; ++t) {
+        for (int64_t r = 0; r < rows; ++r) run += accepts[r * T + t];
+        if (run >= target) found = t + 1;
+    }
+    if (found != INT64_MAX) atomicMin((unsigned long long*)&stop_at, (unsigned long long)found);
+    __syncthreads();
+    if (tid == 0) {
+        const bool live = first ? true : ctl[1] != 0;
+        const int64_t limit = first ? T : ctl[2];
+        const bool hit = first ? total >= target : stop_at != INT64_MAX;
+        const int64_t t_stop = hit && !first ? stop_at : T;
+        if (apply_limit) apply_limit[0] = limit < t_stop ? limit : t_stop;
+        const bool live_next = live && !hit;
+        ctl[0] = total;
+        ctl[1] = live_next ? 1 : 0;
+        ctl[2] = live_next ? next_T : 0;
+    }
+}
+
 }  // namespace rls
 
 using namespace rls;
@@ -1176,6 +1224,16 @@ int rls_mcpg_metro_rounds(void* samples, const void* samples_in, int64_t C_in, i
     else                 { if (probs_lds) LAUNCH_METRO(float, true);   else LAUNCH_METRO(float, false); }
 #undef LAUNCH_METRO
     return check_launch("k_mcpg_metro");
+}
+
+int rls_mcpg_metro_stop(const int64_t* accepts, int64_t accept_rows, int64_t T, int64_t target, int32_t first, int64_t next_T,
+                        int64_t* ctl, int64_t* apply_limit, void* stream) {
+    RLS_REQUIRE(accepts && ctl, RLS_EINVAL, "NULL pointer");
+    RLS_REQUIRE(accept_rows >= 1 && T >= 1 && next_T >= 0 && target >= 0, RLS_EINVAL, "bad sizes rows=%lld T=%lld next_T=%lld",
+                (long long)accept_rows, (long long)T, (long long)next_T);
+    hipLaunchKernelGGL(k_metro_stop, dim3(1), dim3(kStopThreads), 0, as_stream(stream), accepts, accept_rows, T, target, (int)first, next_T,
+                       ctl, apply_limit);
+    return check_launch("k_metro_stop");
 }
 
 static size_t lv_lds_bytes(int64_t N, int64_t num_groups) {

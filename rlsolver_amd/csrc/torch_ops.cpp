@@ -487,6 +487,17 @@ void mcpg_metro_rounds(Tensor samples, const OptTensor& samples_in, int64_t C_in
                              cur_stream(samples)),
        "rls_mcpg_metro_rounds");
 }
+void mcpg_metro_stop(const Tensor& accepts, int64_t target, bool first, int64_t next_T, Tensor ctl, const OptTensor& apply_limit) {
+    dev(accepts, "accepts", I64);
+    TORCH_CHECK(accepts.dim() == 2 && accepts.size(1) >= 1, "accepts must be [rows, T]");
+    dev(ctl, "ctl", I64);
+    count(ctl, "ctl", 3);
+    optdev(apply_limit, "apply_limit", I64);
+    if (apply_limit.has_value()) count(*apply_limit, "apply_limit", 1);
+    RLS_GUARD(accepts);
+    ok(rls_mcpg_metro_stop((const int64_t*)p(accepts), accepts.size(0), accepts.size(1), target, first, next_T, (int64_t*)p(ctl),
+                           (int64_t*)p(apply_limit), cur_stream(accepts)), "rls_mcpg_metro_stop");
+}
 void mcpg_local_search(int64_t g, const Tensor& xs_in, Tensor xs_out, const Tensor& order, const OptTensor& visit_stream, int64_t num_ls,
                        const OptTensor& uniforms, int64_t seed, const OptTensor& edge_weights, int64_t gauge_node, Tensor expected) {
     const int sb = chain_bytes(xs_in, "xs_in");
@@ -798,6 +809,7 @@ TORCH_LIBRARY(rlsolver_hip, m) {
           "float stag_punishment, bool use_basin, float basin_reward) -> ()");
     m.def("mcpg_metro_rounds(Tensor(a!) samples, Tensor? samples_in, int C_in, int C, Tensor probs, int T, int t_offset, Tensor? index, "
           "Tensor? u, int seed, Tensor? t_limit, bool write_back, Tensor(b!)? accepts) -> ()");
+    m.def("mcpg_metro_stop(Tensor accepts, int target, bool first, int next_T, Tensor(a!) ctl, Tensor(b!)? apply_limit) -> ()");
     m.def("mcpg_local_search(int graph, Tensor xs_in, Tensor(a!) xs_out, Tensor order, Tensor? visit_stream, int num_ls, Tensor? uniforms, "
           "int seed, Tensor? edge_weights, int gauge_node, Tensor(b!) expected) -> ()");
     m.def("mcpg_local_search_levels(int graph, Tensor xs_in, int C_in, Tensor(a!) xs_out, int C, Tensor lv_ptr, Tensor lv_data, int num_ls, "
@@ -853,6 +865,7 @@ TORCH_LIBRARY_IMPL(rlsolver_hip, CUDA, m) {   // "CUDA" is the HIP dispatch key 
     m.impl("spin_step_dense", &spin_step_dense);
     m.impl("spin_step", &spin_step);
     m.impl("mcpg_metro_rounds", &mcpg_metro_rounds);
+    m.impl("mcpg_metro_stop", &mcpg_metro_stop);
     m.impl("mcpg_local_search", &mcpg_local_search);
     m.impl("mcpg_local_search_levels", &mcpg_local_search_levels);
     m.impl("mcpg_pick_best", &mcpg_pick_best);

@@ -197,6 +197,33 @@ def build_visit_stream(csr, order: np.ndarray, max_nodes: int = 32, max_entries:
 ACCEPT_ROWS = 64      # rows the kernels spread their per-round accept counts over (one row = thousands of atomics per address)
 
 
+def _walk_chunks(samples, start, probs: TEN, max_transfer_time: int, Tmax: int, Cc: int, index, u, seed: int) -> None:
+    """The rounds of metro_sampling in chunks of T, with the reference's stop rule (MCPG.py:103,115) evaluated on the device.
+    A round accepts at most C proposals, so the cumulative count cannot reach C*T before the LAST round of the first chunk:
+    that chunk is applied directly (one pass, counting as it goes, reading the caller's start state and writing the result
+    buffer).  Later chunks: dry pass -> accept counts -> stop round (rls_mcpg_metro_stop: one launch) -> apply.  Chunks after
+    the stop round see a zero limit and return at once.  15 launches per call (was ~70: the stop rule as torch ops)."""
+    device = probs.device
+    chunk = max(1, max_transfer_time)
+    target = Cc * max_transfer_time
+    starts = list(range(0, Tmax, chunk))
+    sizes = [min(chunk, Tmax - t0) for t0 in starts]
+    accepts = torch.zeros((len(starts), ACCEPT_ROWS, chunk), dtype=torch.int64, device=device)
+    ctl = torch.empty(3, dtype=torch.int64, device=device)            # {accepts so far, live, limit of the next dry pass}
+    apply_limit = torch.empty(1, dtype=torch.int64, device=device)
+    for k, (t0, tk) in enumerate(zip(starts, sizes)):
+        acc = accepts[k] if tk == chunk else accepts[k].reshape(-1)[: ACCEPT_ROWS * tk].view(ACCEPT_ROWS, tk)
+        next_tk = sizes[k + 1] if k + 1 < len(sizes) else 0
+        if k == 0:
+            mops.mcpg_metro_rounds(samples, probs, tk, index, u, seed, None, True, acc, t_offset=0,
+                                   samples_in=None if samples is start else start)
+            mops.mcpg_metro_stop(acc, target, True, next_tk, ctl)
+        else:
+            mops.mcpg_metro_rounds(samples, probs, tk, index, u, seed, ctl[2:3], False, acc, t_offset=t0)
+            mops.mcpg_metro_stop(acc, target, False, next_tk, ctl, apply_limit)
+            mops.mcpg_metro_rounds(samples, probs, tk, index, u, seed, apply_limit, True, None, t_offset=t0)
+
+
 def metro_sampling_packed(probs: TEN, start: PackedChains, max_transfer_time: int, num_chains: Optional[int] = None,
                           index: Optional[TEN] = None, u: Optional[TEN] = None, out: Optional[PackedChains] = None) -> PackedChains:
     """metro_sampling (MCPG.py:88-117) on bit-packed chains.  ``start`` may hold fewer chains than ``num_chains`` (a
@@ -215,35 +242,7 @@ def metro_sampling_packed(probs: TEN, start: PackedChains, max_transfer_time: in
     if Tmax <= 0:   # no rounds (N < 10 gives T = int(N / 10) = 0): the start state, broadcast
         mops.mcpg_metro_rounds(samples, probs, 0, None, None, 0, None, True, None, samples_in=start)
         return samples
-    # Walk the rounds in chunks of T.  A round accepts at most C proposals, so the cumulative count cannot reach
-    # C*T before the LAST round of the first chunk: that chunk is applied directly (one pass, counting as it
-    # goes, reading the caller's start state and writing the result buffer).  Later chunks: dry pass -> accept counts
-    # -> stop round (on the device) -> apply.  Chunks after the stop round see a zero limit and return at once.
-    chunk = max(1, max_transfer_time)
-    target = Cc * max_transfer_time
-    cum_prev = torch.zeros((), dtype=torch.int64, device=device)
-    live = torch.ones((), dtype=torch.bool, device=device)
-    zero = torch.zeros((), dtype=torch.int64, device=device)
-    for t0 in range(0, Tmax, chunk):
-        tk = min(chunk, Tmax - t0)
-        tk_dev = torch.full((), tk, dtype=torch.int64, device=device)
-        accepts = torch.zeros((ACCEPT_ROWS, tk), dtype=torch.int64, device=device)
-        if t0 == 0:
-            mops.mcpg_metro_rounds(samples, probs, tk, index, u, seed, None, True, accepts, t_offset=0,
-                                   samples_in=None if samples is start else start)
-            cum = accepts.sum(0).cumsum(0)
-            hit = cum[-1] >= target
-        else:
-            limit = torch.where(live, tk_dev, zero).reshape(1).contiguous()
-            mops.mcpg_metro_rounds(samples, probs, tk, index, u, seed, limit, False, accepts, t_offset=t0)
-            cum = cum_prev + accepts.sum(0).cumsum(0)
-            reached = cum >= target
-            hit = reached.any()
-            t_stop = torch.where(hit, reached.to(torch.int64).argmax() + 1, tk_dev)
-            apply_limit = torch.minimum(limit[0], t_stop).reshape(1).contiguous()
-            mops.mcpg_metro_rounds(samples, probs, tk, index, u, seed, apply_limit, True, None, t_offset=t0)
-        cum_prev = cum[-1]
-        live = live & ~hit
+    _walk_chunks(samples, start, probs, max_transfer_time, Tmax, Cc, index, u, seed)
     return samples
 
 
@@ -277,35 +276,7 @@ def _metro_sampling_nodemajor(probs: TEN, start_status: TEN, max_transfer_time: 
     if Tmax <= 0:   # no rounds (N < 10 gives T = int(N / 10) = 0): the reference returns start_status.bool().float()
         return start.clone() if samples is not start else start
     seed = _seed_from_torch() if index is None else 0
-    # Walk the rounds in chunks of T.  A round accepts at most C proposals, so the cumulative count cannot reach
-    # C*T before the LAST round of the first chunk: that chunk is applied directly (one pass, counting as it
-    # goes).  Later chunks: dry pass -> accept counts -> stop round (on the device) -> apply.  Chunks after the
-    # stop round see a zero limit and return at once.
-    chunk = max(1, max_transfer_time)
-    target = Cc * max_transfer_time
-    cum_prev = torch.zeros((), dtype=torch.int64, device=device)
-    live = torch.ones((), dtype=torch.bool, device=device)
-    zero = torch.zeros((), dtype=torch.int64, device=device)
-    for t0 in range(0, Tmax, chunk):
-        tk = min(chunk, Tmax - t0)
-        tk_dev = torch.full((), tk, dtype=torch.int64, device=device)
-        accepts = torch.zeros((ACCEPT_ROWS, tk), dtype=torch.int64, device=device)
-        if t0 == 0:
-            mops.mcpg_metro_rounds(samples, probs, tk, index, u, seed, None, True, accepts, t_offset=0,
-                                   samples_in=None if samples is start else start)
-            cum = accepts.sum(0).cumsum(0)
-            hit = cum[-1] >= target
-        else:
-            limit = torch.where(live, tk_dev, zero).reshape(1).contiguous()
-            mops.mcpg_metro_rounds(samples, probs, tk, index, u, seed, limit, False, accepts, t_offset=t0)
-            cum = cum_prev + accepts.sum(0).cumsum(0)
-            reached = cum >= target
-            hit = reached.any()
-            t_stop = torch.where(hit, reached.to(torch.int64).argmax() + 1, tk_dev)
-            apply_limit = torch.minimum(limit[0], t_stop).reshape(1).contiguous()
-            mops.mcpg_metro_rounds(samples, probs, tk, index, u, seed, apply_limit, True, None, t_offset=t0)
-        cum_prev = cum[-1]
-        live = live & ~hit
+    _walk_chunks(samples, start, probs, max_transfer_time, Tmax, Cc, index, u, seed)
     return samples
 
 
