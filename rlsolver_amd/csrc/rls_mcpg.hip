@@ -1128,39 +1128,75 @@ __global__ __launch_bounds__(4 * kWave) void k_mcpg_pack(const T* __restrict__ x
 //   later chunks: *apply_limit = min(limit, stop round) for the apply pass of this chunk
 // Before, this was ten [1]- to [T]-sized torch ops per chunk -- 70 launches per call, 440 us of dispatch around 20 us of kernels
 // on a G22-sized graph.
-constexpr int kStopThreads = 256;
-__global__ __launch_bounds__(kStopThreads) void k_metro_stop(const int64_t* __restrict__ accepts, int64_t rows, int64_t T, int64_t target,
-                                                             int first, int64_t next_T, int64_t* __restrict__ ctl,
-                                                             int64_t* __restrict__ apply_limit) {
-    __shared__ int64_t seg[kStopThreads];
-    __shared__ int64_t stop_at;
-    const int tid = threadIdx.x;
-    const int64_t per = (T + kStopThreads - 1) / kStopThreads, t0 = per * tid, t1 = t0 + per < T ? t0 + per : T;
+constexpr int kStopWaves = 16;
+__global__ __launch_bounds__(kStopWaves * kWave) void k_metro_stop(const int64_t* __restrict__ accepts, int64_t rows, int64_t T, int64_t target,
+                                                                   int first, int64_t next_T, int64_t* __restrict__ ctl,
+                                                                   int64_t* __restrict__ apply_limit) {
+    // a wave owns a contiguous run of rounds, its lanes consecutive rounds (coalesced reads of every row); the column sums of up to
+    // kKeep blocks of 64 rounds stay in registers between the two phases (segment totals, then the running count)
+    constexpr int kKeep = 4;
+    __shared__ int64_t seg[kStopWaves];
+    __shared__ unsigned long long stop_at;
+    const int lane = threadIdx.x & (kWave - 1), w = threadIdx.x / kWave;
+    const int64_t blocks = (T + kWave - 1) / kWave;                         // blocks of 64 rounds
+    const int64_t per = (blocks + kStopWaves - 1) / kStopWaves;             // blocks per wave
+    const int64_t b0 = per * w, b1 = b0 + per < blocks ? b0 + per : blocks;
+    auto colsum = [&](int64_t blk) {
+        const int64_t t = blk * kWave + lane;
+        int64_t v = 0;
+        if (t < T) {
+#pragma unroll 8
+            for (int64_t r = 0; r < rows; ++r) v += accepts[r * T + t];
+        }
+        return v;
+    };
+    int64_t keep[kKeep];
     int64_t mine = 0;
-    for (int64_t t = t0; t < t1; ++t)
-        for (int64_t r = 0; r < rows; ++r) mine += accepts[r * T + t];
-    seg[tid] = mine;
-    if (tid == 0) stop_at = INT64_MAX;
+#pragma unroll
+    for (int k = 0; k < kKeep; ++k) {
+        keep[k] = b0 + k < b1 ? colsum(b0 + k) : 0;
+        mine += keep[k];
+    }
+    for (int64_t blk = b0 + kKeep; blk < b1; ++blk) mine += colsum(blk);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) mine += __shfl_xor(mine, m, kWave);
+    if (lane == 0) seg[w] = mine;
+    if (threadIdx.x == 0) stop_at = ~0ull;
     __syncthreads();
-    int64_t before = first ? 0 : ctl[0];     // accepts before this thread's segment
+    int64_t before = first ? 0 : ctl[0];
     int64_t total = before;
-    for (int k = 0; k < kStopThreads; ++k) {
-        if (k < tid) before += seg[k];
+    for (int k = 0; k < kStopWaves; ++k) {
+        if (k < w) before += seg[k];
         total += seg[k];
     }
-    // the first round of this segment at which the running count reaches the target
-    int64_t run = before, found = INT64_MAX;
-    for (int64_t t = t0; t < t1 && found == INT64_MAX; ++t) {
-        for (int64_t r = 0; r < rows; ++r) run += accepts[r * T + t];
-        if (run >= target) found = t + 1;
-    }
-    if (found != INT64_MAX) atomicMin((unsigned long long*)&stop_at, (unsigned long long)found);
+    // the first round of this wave's run at which the running count reaches the target
+    int64_t run = before;
+    bool done = false;
+    auto step = [&](int64_t blk, int64_t v) {            // wave-uniform result: this block reaches the target
+        int64_t inc = v;                                 // inclusive scan over the 64 lanes
+#pragma unroll
+        for (int d = 1; d < kWave; d <<= 1) {
+            const int64_t o = __shfl_up(inc, d, kWave);
+            if (lane >= d) inc += o;
+        }
+        const uint64_t reached = ballot64(run + inc >= target && blk * kWave + lane < T);
+        if (reached) {
+            if (lane == 0) atomicMin(&stop_at, (unsigned long long)(blk * kWave + __builtin_ctzll(reached) + 1));
+            return true;
+        }
+        run += __shfl(inc, kWave - 1, kWave);
+        return false;
+    };
+#pragma unroll
+    for (int k = 0; k < kKeep; ++k)
+        if (!done && b0 + k < b1) done = step(b0 + k, keep[k]);
+    for (int64_t blk = b0 + kKeep; blk < b1 && !done; ++blk) done = step(blk, colsum(blk));
     __syncthreads();
-    if (tid == 0) {
+    if (threadIdx.x == 0) {
         const bool live = first ? true : ctl[1] != 0;
         const int64_t limit = first ? T : ctl[2];
-        const bool hit = first ? total >= target : stop_at != INT64_MAX;
-        const int64_t t_stop = hit && !first ? stop_at : T;
+        const bool hit = first ? total >= target : stop_at != ~0ull;
+        const int64_t t_stop = hit && !first ? (int64_t)stop_at : T;
         if (apply_limit) apply_limit[0] = limit < t_stop ? limit : t_stop;
         const bool live_next = live && !hit;
         ctl[0] = total;
@@ -1231,7 +1267,7 @@ int rls_mcpg_metro_stop(const int64_t* accepts, int64_t accept_rows, int64_t T, 
     RLS_REQUIRE(accepts && ctl, RLS_EINVAL, "NULL pointer");
     RLS_REQUIRE(accept_rows >= 1 && T >= 1 && next_T >= 0 && target >= 0, RLS_EINVAL, "bad sizes rows=%lld T=%lld next_T=%lld",
                 (long long)accept_rows, (long long)T, (long long)next_T);
-    hipLaunchKernelGGL(k_metro_stop, dim3(1), dim3(kStopThreads), 0, as_stream(stream), accepts, accept_rows, T, target, (int)first, next_T,
+    hipLaunchKernelGGL(k_metro_stop, dim3(1), dim3(kStopWaves * kWave), 0, as_stream(stream), accepts, accept_rows, T, target, (int)first, next_T,
                        ctl, apply_limit);
     return check_launch("k_metro_stop");
 }
