@@ -350,9 +350,10 @@ class _ReturnFn(torch.autograd.Function):
     (one kernel over the packed chains) and V = sum_c value_c."""
 
     @staticmethod
-    def forward(ctx, probs, samples, value):
-        A = mops.mcpg_value_bit_sums(samples, value)
-        V = value.sum()
+    def forward(ctx, probs, samples, value, sums=None):
+        # sums = (A, V) of an earlier call on the same samples and value (they do not depend on probs: the eight policy epochs
+        # of a round share them, MCPG.py:397-403)
+        A, V = sums if sums is not None else (mops.mcpg_value_bit_sums(samples, value), value.sum())
         C = samples.num_chains
         lp, l1p = probs.log(), (1 - probs).log()
         ctx.save_for_backward(probs, A, V)
@@ -362,7 +363,7 @@ class _ReturnFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         probs, A, V = ctx.saved_tensors
-        return g * (A / probs - (V - A) / (1 - probs)) / ctx.C, None, None
+        return g * (A / probs - (V - A) / (1 - probs)) / ctx.C, None, None, None
 
 
 def get_return(probs: TEN, samples, value: TEN, total_mcmc_num: int = 0, repeat_times: int = 0):
@@ -398,6 +399,7 @@ class MCPGRound:
         self.samples = PackedChains.empty(self.N, self.M * self.R, info.device)              # the round's metro output
         self.work = PackedChains.empty(self.N, self.M * self.R, info.device)                 # after the local search
         self.value = None
+        self._sums = None
         self.best_value = self.best_index = None
 
     def step(self, xs_prob: TEN):
@@ -410,10 +412,14 @@ class MCPGRound:
         self.best_value, self.best_index = mops.mcpg_merge_best(temp_max, temp_info, self.now_max_res, self.now_max_info)
         self.start = temp_info
         self.value = expected - expected.mean()
+        self._sums = None
         return self.value, self.best_value
 
     def get_return(self, xs_prob: TEN):
-        return get_return(xs_prob, self.samples, self.value)
+        """get_return of the round's samples; the two sums over the chains are formed once per round, not once per epoch."""
+        if self._sums is None:
+            self._sums = (mops.mcpg_value_bit_sums(self.samples, self.value), self.value.sum())
+        return _ReturnFn.apply(xs_prob, self.samples, self.value, self._sums)
 
     def best_solution(self):
         """(value: float, x: bool [N]) of the best incumbent -- a host read, for the end of a run."""

@@ -384,6 +384,21 @@ def test_mcpg_round_on_device_improves_and_prints_like_the_reference():
     assert sum(l.startswith("num_samples_per_second:") for l in lines) == 6
     assert v >= float(vs0.max()) and v > 0.6 * data.num_edges
     assert int(ops.maxcut_obj(data.graph, x[None, :].contiguous())) == int(v)
+    # the round's get_return forms its two chain sums once and reuses them over the policy epochs: same objective and gradient as
+    # the stand-alone function on the same samples, for any probs
+    rnd = amcpg.MCPGRound(data, xs0.t().contiguous().float(), vs0, M, R, num_ls=2)
+    rnd.step(torch.full((n,), 0.5, device=DEV))
+    for k in range(3):
+        pr = (torch.rand(n, device=DEV, generator=torch.Generator(device=DEV).manual_seed(k)) * 0.8 + 0.1).requires_grad_()
+        a = rnd.get_return(pr)
+        ga, = torch.autograd.grad(a, pr)
+        pr2 = pr.detach().clone().requires_grad_()
+        b = amcpg.get_return(pr2, rnd.samples, rnd.value)
+        gb, = torch.autograd.grad(b, pr2)
+        assert torch.equal(a.detach(), b.detach()) and torch.equal(ga, gb)
+    sums = rnd._sums
+    rnd.step(torch.full((n,), 0.5, device=DEV))
+    assert rnd._sums is None and sums is not None            # a new round drops them
 
 
 # ------------------------------------------------------------------ weighted sampler of the upstream MCPG package
