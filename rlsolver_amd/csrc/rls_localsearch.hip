@@ -119,7 +119,7 @@ __global__ __launch_bounds__(W * kWave) void k_maxcut_local_search(
                   "ring (+ merge buffer for waves 4..7) double as the row-piece stages");
     unsigned char* wstage = (w < kLsMergeWaves ? reinterpret_cast<unsigned char*>(ring) + w * kStageBytes
                                                : reinterpret_cast<unsigned char*>(tops) + (w - kLsMergeWaves) * kStageBytes);
-    unsigned char* stage = VEC ? wstage : nullptr;
+    unsigned char* stage = wstage;   // (rows that are not 4-byte aligned go through its funnel-shift form)
     for (int64_t i = threadIdx.x; i < ((N + 3) & ~3ll); i += W * kWave) sdl[i] = i < N ? rd_std[i] : 0.0f;
     tile_load_bits<uint8_t, VEC>(x, B, N, b0, words, lane, w, W, stage);
     __syncthreads();

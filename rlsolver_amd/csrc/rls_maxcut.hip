@@ -120,7 +120,7 @@ __global__ __launch_bounds__(kWave) void k_maxcut_greedy_sweep(uint8_t* __restri
     if (lane == 0) words[N] = 0;   // sentinel word
     for (int64_t i = lane; i <= N; i += kWave) rp[i] = rowptr[i];
     // the ring is idle before and after the sweep: it doubles as the row-piece stage of the tile load / store
-    unsigned char* stage = VEC ? reinterpret_cast<unsigned char*>(ring) : nullptr;
+    unsigned char* stage = reinterpret_cast<unsigned char*>(ring);
     tile_load_bits<uint8_t, VEC>(x, B, N, b0, words, lane, 0, 1, stage);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(SW * kWave) void k_maxcut_greedy_sweep_batched(
     if (threadIdx.x == 0) words[N] = 0;
     for (int64_t i = threadIdx.x; i <= N; i += SW * kWave) rp[i] = rowptr_flagged[i];
     static_assert(kRing * 4 >= kSweepLoadWaves * kStageBytes, "the ring doubles as the tile stage");
-    unsigned char* stage = VEC ? reinterpret_cast<unsigned char*>(ring) + (w % kSweepLoadWaves) * kStageBytes : nullptr;
+    unsigned char* stage = reinterpret_cast<unsigned char*>(ring) + (w % kSweepLoadWaves) * kStageBytes;
     if (w < kSweepLoadWaves) tile_load_bits<uint8_t, VEC>(x, B, N, b0, words, lane, w, kSweepLoadWaves, stage);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(SW * kWave) void k_maxcut_greedy_sweep_levels(
     const int64_t b0 = (int64_t)blockIdx.x * kWave;
     if (threadIdx.x == 0) words[N] = 0;
     for (int64_t i = threadIdx.x; i <= G; i += SW * kWave) lvp[i] = lv_ptr[i];
-    unsigned char* stage = VEC ? stages + (w % LW) * kStageBytes : nullptr;
+    unsigned char* stage = stages + (w % LW) * kStageBytes;
     if (w < LW) tile_load_bits<uint8_t, VEC>(x, B, N, b0, words, lane, w, LW, stage);
     __syncthreads();
     sweep_tile_levels<SW>(words, lvp, lv_data, G, N, lane, w);
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(kTileWaves * kWave) void k_node_stats_tile(const ui
     const int64_t b0 = (int64_t)blockIdx.x * kWave;
     if (threadIdx.x == 0) words[N] = 0;               // sentinel word: lanes past a row's end read zero
     static_assert(kWave * STRIDE >= kStageBytes, "the output staging rows double as the tile-load stage");
-    tile_load_bits<uint8_t, VEC>(x, B, N, b0, words, lane, w, kTileWaves, VEC ? stage : nullptr);
+    tile_load_bits<uint8_t, VEC>(x, B, N, b0, words, lane, w, kTileWaves, stage);
     __syncthreads();
     const int sh = lane & 31;
     const uint32_t half4 = (uint32_t)(lane >> 5) * 4u;
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(kNsWaves * kWave) void k_node_stats_bits(const uint
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     unsigned char* stage = smem + (((size_t)N * 8 + 15) & ~(size_t)15) + (size_t)w * kStageBytes;
     const int64_t b0 = (int64_t)blockIdx.x * kWave;
-    tile_load_bits<uint8_t, VEC>(x, B, N, b0, words, lane, w, kNsWaves, VEC ? stage : nullptr);
+    tile_load_bits<uint8_t, VEC>(x, B, N, b0, words, lane, w, kNsWaves, stage);
     __syncthreads();
     const int64_t G = (N + 63) >> 6;
     const int nenv = (int)((B - b0) < kWave ? (B - b0) : kWave);
@@ -697,12 +697,16 @@ __global__ __launch_bounds__(256) void k_rand_spins(uint8_t* __restrict__ x, int
 // parks its 16 bytes in LDS, and the wave then writes the row as 16-byte pieces (lane p of trip i = piece 64 i + p, whose
 // 16 bits sit in block p / 8) -- the per-piece kernel above recomputes the block's 10 Philox rounds for each of its 8
 // pieces, ~100 VALU per 16 bytes written, and is bound by that.
+// CH = bytes (= spins) per store: 16, or 8 / 4 for rows that are multiples of 8 / 4 bytes only (N = 1000, 3000, 5000, 7000 of the
+// Gset sizes: the per-piece kernel took 158 us for 2^16 x 2000-ish rows there, this one 22)
+template <int CH>
 __global__ __launch_bounds__(256) void k_rand_spins_rows(uint8_t* __restrict__ x, int64_t B, int64_t N, uint64_t seed, int64_t env_offset) {
     __shared__ uint4 sh[4][kWave];
+    constexpr int CPB = 128 / CH;                   // chunks per 128-spin block
     const int lane = threadIdx.x & (kWave - 1);
     const int w = threadIdx.x / kWave;
-    const int64_t chunks = N >> 4;                  // N % 16 == 0 here
-    const int64_t blocks = (chunks + 7) >> 3;       // 128-spin blocks per row
+    const int64_t chunks = N / CH;                  // N % CH == 0 here
+    const int64_t blocks = (chunks + CPB - 1) / CPB;
     const Philox ph(seed);
     for (int64_t b = (int64_t)blockIdx.x * 4 + w; b < B; b += (int64_t)gridDim.x * 4) {
         const uint64_t gb = (uint64_t)(b + env_offset);
@@ -714,19 +718,30 @@ __global__ __launch_bounds__(256) void k_rand_spins_rows(uint8_t* __restrict__ x
             sh[w][lane] = make_uint4(r[0], r[1], r[2], r[3]);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
-            const uint32_t* shw = reinterpret_cast<const uint32_t*>(sh[w]);
+            const uint32_t* shw = reinterpret_cast<const uint32_t*>(sh[w]);   // the 64 blocks as one array of 8192 bits
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int p = i * kWave + lane;
-                const int64_t ch = g0 * 8 + p;
+            for (int i = 0; i < CPB; ++i) {
+                const int p = i * kWave + lane;     // chunk p of the window: bits [CH p, CH p + CH)
+                const int64_t ch = g0 * CPB + p;
                 if (ch < chunks) {
-                    const uint32_t bits = (shw[(p >> 3) * 4 + ((p & 7) >> 1)] >> ((p & 1) * 16)) & 0xffffu;
-                    uint4 v;
-                    v.x = ((bits & 0xFu) * 0x00204081u) & 0x01010101u;
-                    v.y = (((bits >> 4) & 0xFu) * 0x00204081u) & 0x01010101u;
-                    v.z = (((bits >> 8) & 0xFu) * 0x00204081u) & 0x01010101u;
-                    v.w = (((bits >> 12) & 0xFu) * 0x00204081u) & 0x01010101u;
-                    *reinterpret_cast<uint4*>(row + ch * 16) = v;
+                    const uint32_t bits = (shw[(p * CH) >> 5] >> ((p * CH) & 31)) & ((1u << CH) - 1u);
+                    // nibble -> 4 bytes of 0/1: the multiply puts bit j at bit 8j (+ copies the mask drops)
+                    const uint32_t v0 = ((bits & 0xFu) * 0x00204081u) & 0x01010101u;
+                    if constexpr (CH == 4) {
+                        *reinterpret_cast<uint32_t*>(row + ch * 4) = v0;
+                    } else {
+                        const uint32_t v1 = (((bits >> 4) & 0xFu) * 0x00204081u) & 0x01010101u;
+                        if constexpr (CH == 8) {
+                            *reinterpret_cast<uint2*>(row + ch * 8) = make_uint2(v0, v1);
+                        } else {
+                            uint4 v;
+                            v.x = v0;
+                            v.y = v1;
+                            v.z = (((bits >> 8) & 0xFu) * 0x00204081u) & 0x01010101u;
+                            v.w = (((bits >> 12) & 0xFu) * 0x00204081u) & 0x01010101u;
+                            *reinterpret_cast<uint4*>(row + ch * 16) = v;
+                        }
+                    }
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -893,7 +908,7 @@ int rls_maxcut_obj(const rls_graph* g, const void* x, int spin_bytes, int64_t B,
     const int P = pick_planes(E);
     RLS_REQUIRE(P != 0, RLS_EUNSUPPORTED, "E'=%lld too large", (long long)E);
     const bool vec = tile_rows_aligned(x, N, spin_bytes);
-    const int stage_off = tile_stage_offset(&lds, tw, vec && spin_bytes == 1);
+    const int stage_off = tile_stage_offset(&lds, tw, spin_bytes == 1);   // (unaligned byte rows use it too)
     const dim3 grid((unsigned)ceil_div(B, kWave)), block(tw * kWave);
     hipStream_t s = as_stream(stream);
     const int halve = g->if_bidirectional ? 1 : 0;
@@ -942,7 +957,7 @@ int rls_maxcut_propose_accept(const rls_graph* g, uint8_t* x, int64_t B, const u
     const int P = pick_planes(E);
     RLS_REQUIRE(P != 0, RLS_EUNSUPPORTED, "E'=%lld too large", (long long)E);
     const bool vec = tile_rows_aligned(x, N, 1) && tile_rows_aligned(mask, N, 1);
-    const int stage_off = tile_stage_offset(&lds, tw, vec);
+    const int stage_off = tile_stage_offset(&lds, tw, true);
     const dim3 grid((unsigned)ceil_div(B, kWave)), block(tw * kWave);
     hipStream_t s = as_stream(stream);
     const int halve = g->if_bidirectional ? 1 : 0;
@@ -1241,8 +1256,12 @@ int rls_rand_spins(uint8_t* x, int64_t B, int64_t N, uint64_t seed, int64_t env_
     if (B == 0) return RLS_OK;
     RLS_REQUIRE(x, RLS_EINVAL, "x is NULL");
     const bool vec16 = (N % 16 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0);
-    if (vec16 && N >= 512) {   // rows of at least four 128-spin blocks: one Philox call per block (a wave per row)
-        hipLaunchKernelGGL(k_rand_spins_rows, dim3(grid_for(B * kWave, 256)), dim3(256), 0, as_stream(stream), x, B, N, seed, env_offset);
+    if (N >= 512 && (N & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+        // rows of at least four 128-spin blocks, 4-byte aligned: one Philox call per block (a wave per row)
+        const dim3 grid(grid_for(B * kWave, 256)), block(256);
+        if ((N & 15) == 0) hipLaunchKernelGGL(k_rand_spins_rows<16>, grid, block, 0, as_stream(stream), x, B, N, seed, env_offset);
+        else if ((N & 7) == 0) hipLaunchKernelGGL(k_rand_spins_rows<8>, grid, block, 0, as_stream(stream), x, B, N, seed, env_offset);
+        else hipLaunchKernelGGL(k_rand_spins_rows<4>, grid, block, 0, as_stream(stream), x, B, N, seed, env_offset);
         return check_launch("k_rand_spins_rows");
     }
     hipLaunchKernelGGL(vec16 ? k_rand_spins<true> : k_rand_spins<false>, dim3(grid_for(B * ((N + 15) >> 4), 256)),

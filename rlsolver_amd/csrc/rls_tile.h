@@ -325,9 +325,103 @@ __device__ __forceinline__ void tile_store_bytes_staged(uint8_t* __restrict__ x,
     }
 }
 
+// ---- the same corner turn for rows that are NOT 4-byte aligned (N % 4 != 0, or a base pointer that is not 16-byte aligned):
+// 4-byte pieces at row offsets 4 j, each fetched as the one or two ALIGNED dwords that hold it and funnel-shifted
+// (v_alignbyte); stores go out as bytes.  Twice the load instructions of the 4-byte form and four times its stores, against 64
+// byte loads and 64 ballots per lane and chunk without it (K1 on N = 1999 / 2^16 envs: 482 us, 35 at N = 2000).
+// `last` = address of the last byte of the whole [B, N] array: the second dword of a piece is only read when it holds bytes
+// of the array (the first one always does).
+template <int DEPTH, bool XORW>
+__device__ __forceinline__ void tile_load_bits_staged_unal(const uint8_t* __restrict__ x, int64_t B, int64_t N, int64_t b0,
+                                                           uint64_t* __restrict__ words, int lane, int w, int W,
+                                                           unsigned char* stage) {
+    constexpr int PB = 4, PP = 16, RPI = 4;
+    const int64_t nchunk = (N + 63) >> 6;
+    const BitXpose xc = bit_xpose_consts(lane);
+    const int r = lane % RPI, j = lane / RPI;
+    const uintptr_t last = (uintptr_t)(x + B * N - 1);
+    for (int64_t ch0 = w; ch0 < nchunk; ch0 += (int64_t)W * DEPTH) {
+        uint32_t g[DEPTH][PP];
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const int64_t off = ((ch0 + (int64_t)d * W) << 6) + j * PB;
+#pragma unroll
+            for (int i = 0; i < PP; ++i) {
+                const int64_t rw = b0 + RPI * i + r;
+                uint32_t v = 0;
+                if (rw < B && off < N) {
+                    const uintptr_t addr = (uintptr_t)(x + rw * N + off), a = addr & ~(uintptr_t)3;
+                    const uint32_t lo = *reinterpret_cast<const uint32_t*>(a);
+                    const uint32_t hi = (a + 4 <= last) ? *reinterpret_cast<const uint32_t*>(a + 4) : 0u;
+                    v = __builtin_amdgcn_alignbyte(hi, lo, (uint32_t)(addr & 3));
+                    // bytes past the end of the row are the next row's -- or, in the last row, whatever follows the array:
+                    // pack_bits takes 0 | 1 bytes only, anything else would spill into the bits of the row's own nodes
+                    if (N - off < 4) v &= (1u << (8 * (int)(N - off))) - 1u;
+                }
+                g[d][i] = v;
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const int64_t ch = ch0 + (int64_t)d * W;
+            if (ch < nchunk) {
+#pragma unroll
+                for (int i = 0; i < PP; ++i) *reinterpret_cast<uint32_t*>(stage + (j * 64 + RPI * i + r) * PB) = g[d][i];
+                asm volatile("" ::: "memory");   // LDS ops of one wave execute in order
+                uint32_t dw[16];
+#pragma unroll
+                for (int q = 0; q < PP; ++q) dw[q] = *reinterpret_cast<const uint32_t*>(stage + (q * 64 + lane) * PB);
+                asm volatile("" ::: "memory");
+                uint32_t r0 = pack_bits(u32x4{dw[0], dw[1], dw[2], dw[3]}, u32x4{dw[4], dw[5], dw[6], dw[7]});
+                uint32_t r1 = pack_bits(u32x4{dw[8], dw[9], dw[10], dw[11]}, u32x4{dw[12], dw[13], dw[14], dw[15]});
+                bit_transpose64(r0, r1, xc);
+                const int64_t n = (ch << 6) + xc.node;
+                if (n < N) put_word<XORW>(words, n, ((uint64_t)r1 << 32) | r0);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void tile_store_bytes_staged_unal(uint8_t* __restrict__ x, int64_t N, int64_t b0,
+                                                             const uint64_t* __restrict__ words, int lane, int w, int W,
+                                                             uint64_t rows_ok, unsigned char* stage) {
+    constexpr int PB = 4, PP = 16, RPI = 4;
+    const int64_t nchunk = (N + 63) >> 6;
+    const BitXpose xc = bit_xpose_consts(lane);
+    const int r = lane % RPI, j = lane / RPI;
+    for (int64_t ch = w; ch < nchunk; ch += W) {
+        const int64_t n = (ch << 6) + xc.node;
+        const uint64_t wd = (n < N) ? words[n] : 0ull;
+        uint32_t r0 = (uint32_t)wd, r1 = (uint32_t)(wd >> 32);
+        bit_transpose64(r0, r1, xc);
+        u32x4 v[4];
+        unpack_bits(r0, v[0], v[1]);
+        unpack_bits(r1, v[2], v[3]);
+        const uint32_t dw[16] = {v[0][0], v[0][1], v[0][2], v[0][3], v[1][0], v[1][1], v[1][2], v[1][3],
+                                 v[2][0], v[2][1], v[2][2], v[2][3], v[3][0], v[3][1], v[3][2], v[3][3]};
+#pragma unroll
+        for (int q = 0; q < PP; ++q) *reinterpret_cast<uint32_t*>(stage + (q * 64 + lane) * PB) = dw[q];
+        asm volatile("" ::: "memory");   // LDS ops of one wave execute in order
+        const int64_t off = (ch << 6) + j * PB;
+#pragma unroll
+        for (int i = 0; i < PP; ++i) {
+            const int rr = RPI * i + r;
+            const uint32_t o = *reinterpret_cast<const uint32_t*>(stage + (j * 64 + rr) * PB);
+            if ((rows_ok >> rr) & 1ull) {
+                uint8_t* dst = x + (b0 + rr) * N + off;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (off + k < N) dst[k] = (uint8_t)(o >> (8 * k));
+            }
+        }
+        asm volatile("" ::: "memory");
+    }
+}
+
 // Load the tile of envs [b0, b0+64) x nodes [0, N) into words[0..N).
 // VEC = true requires x 16-byte aligned and rows 4-byte aligned (tile_rows_aligned); without a stage, byte spins
-// with N % 16 != 0 fall back to the element-wise path.
+// with N % 16 != 0 fall back to the element-wise path.  VEC = false with a stage (byte spins): any alignment, through the
+// funnel-shift form of the stage.
 // W waves of one workgroup may share the job (wave w of W takes every W-th batch of columns); every
 // wave sees all 64 envs, so each ballot still yields a complete word.  Callers sync afterwards.
 template <typename T, bool VEC, int DEPTH = kStageDepth, bool XORW = false>
@@ -394,6 +488,12 @@ __device__ __forceinline__ void tile_load_bits(const T* __restrict__ x, int64_t 
         }
         return;
     }
+    if constexpr (!VEC && sizeof(T) == 1) {
+        if (stage != nullptr) {   // rows (or the base) not 4-byte aligned: the funnel-shift form of the row-piece stage
+            tile_load_bits_staged_unal<(DEPTH > 2 ? 2 : DEPTH), XORW>(reinterpret_cast<const uint8_t*>(x), B, N, b0, words, lane, w, W, stage);
+            return;
+        }
+    }
     for (int64_t n0 = (int64_t)w * 64; n0 < N; n0 += (int64_t)W * 64) {
         uint64_t mine = 0;
         const int lim = (int)((N - n0) < 64 ? (N - n0) : 64);
@@ -444,6 +544,12 @@ __device__ __forceinline__ void tile_store_bytes(uint8_t* __restrict__ x, int64_
                 if (valid && idx < nv) rv[idx] = v[j];
             }
         }
+            return;
+        }
+    }
+    if constexpr (!VEC) {
+        if (stage != nullptr) {
+            tile_store_bytes_staged_unal(x, N, b0, words, lane, w, W, ballot64(valid), stage);
             return;
         }
     }

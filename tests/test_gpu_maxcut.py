@@ -333,6 +333,9 @@ def test_rand_spins_is_one_sequence_whatever_kernel_writes_it():
     assert not bool(big[:, 0].any()) and 0.45 < float(big[:, 1:].float().mean()) < 0.55
     wide = ops.rand_spins(5, 10000, 99, DEV)                    # two trips of 64 blocks per row
     assert torch.equal(wide[:, :2000], big[:5])
+    assert torch.equal(big[:, :1000], ops.rand_spins(B, 1000, 99, DEV))    # rows kernel, 8-byte stores (N % 16 == 8)
+    assert torch.equal(big[:, :1996], ops.rand_spins(B, 1996, 99, DEV))    # rows kernel, 4-byte stores (N % 8 == 4)
+    assert torch.equal(wide[:, :9000], ops.rand_spins(5, 9000, 99, DEV)) and torch.equal(wide[:, :8204], ops.rand_spins(5, 8204, 99, DEV))
 
 
 @pytest.mark.parametrize("case", ["ba_hubs", "star", "two_hubs_1100"])
@@ -416,3 +419,46 @@ def test_step_refuses_weighted_graphs(golden):
     with pytest.raises(RuntimeError, match="counts cut edges"):
         ops.maxcut_step(g, x, torch.empty_like(x), torch.zeros(B, dtype=torch.int64, device=DEV),
                         torch.zeros(B, dtype=torch.int32, device=DEV), torch.empty(B, device=DEV))
+
+
+@pytest.mark.parametrize("n,B,lead", [(1999, 130, 0), (1999, 65, 3), (337, 9, 1), (81, 64, 2), (2001, 200, 5), (333, 70, 16), (2004, 67, 6)])
+def test_rows_that_are_not_dword_aligned_with_garbage_around(n, B, lead):
+    """Spin rows that are not 4-byte aligned (odd N, or a view that starts at an odd byte) go through the funnel-shift form of the
+    row-piece stage.  The array sits inside a buffer of 0xFF bytes: nothing outside it may leak into a result (the bytes after the
+    last row share a dword with it) and nothing outside it may be written."""
+    from rlsolver_amd.envs.env_L2A import EnvMaxcut
+    garr = gnm_arr(n, 5 * n, seed=n + lead)
+    g = device_graph(garr, n, 0)
+    rng = np.random.RandomState(n + B)
+    xs = rng.randint(0, 2, size=(B, n)).astype(np.uint8)
+    buf = torch.full((lead + B * n + 37,), 255, dtype=torch.uint8, device=DEV)
+    x = buf[lead:lead + B * n].view(B, n)
+    x.copy_(torch.from_numpy(xs).to(DEV))
+    xb = x.view(torch.bool)
+    assert xb.data_ptr() == buf.data_ptr() + lead
+    want = onp.maxcut_obj(xs, garr, False)
+    assert np.array_equal(ops.maxcut_obj(g, xb).cpu().numpy(), want)                                     # K1
+    sub = [0, B // 2, B - 1]
+    assert np.array_equal(ops.maxcut_node_cutdeg(g, xb)[sub].cpu().numpy(), onp.maxcut_node_cutdeg(xs[sub], garr, n, False))   # K2
+    assert np.array_equal(ops.maxcut_delta_all(g, xb)[sub].cpu().numpy(), onp.maxcut_delta_all(xs[sub], garr, n, None))        # K3
+    # K6: a proposal that flips the last nodes of every row (the pieces that straddle the row ends)
+    mask = torch.zeros((B, n), dtype=torch.bool, device=DEV)
+    mask[:, -3:] = True
+    mask[:, 0] = True
+    vs = torch.from_numpy(want).to(DEV)
+    ops.maxcut_propose_accept(g, xb, mask, vs)
+    after = x.cpu().numpy()
+    prop = xs ^ mask.cpu().numpy().astype(np.uint8)
+    pv = onp.maxcut_obj(prop, garr, False)
+    acc = pv >= want
+    assert np.array_equal(after, np.where(acc[:, None], prop, xs)) and np.array_equal(vs.cpu().numpy(), np.where(acc, pv, want))
+    # K5 and the fused local search write the tile back: values stay 0 | 1, the cut is consistent, the buffer around is untouched
+    ops.maxcut_greedy_sweep(g, xb, vs)
+    wx, wv = onp.greedy_sweep(after.astype(bool), vs.cpu().numpy() * 0 + onp.maxcut_obj(after, garr, False), garr, False)
+    assert np.array_equal(x.cpu().numpy(), wx.astype(np.uint8)) and np.array_equal(vs.cpu().numpy(), wv)
+    env = EnvMaxcut(mygraph=[tuple(int(v) for v in r) for r in garr], device=DEV, num_nodes=n)
+    v0 = vs.clone()
+    env.local_search_inplace(xb, vs, num_iters=3, num_spin=3)
+    assert bool((vs >= v0).all()) and int(x.max()) <= 1
+    assert np.array_equal(vs.cpu().numpy(), onp.maxcut_obj(x.cpu().numpy(), garr, False))
+    assert bool((buf[:lead] == 255).all()) and bool((buf[lead + B * n:] == 255).all())
