@@ -336,11 +336,15 @@ if want("synthetic") and not a.profile:   # (grids coincide with the BASELINE ro
     maxcut_suite("BA n=10000 m=5, B=2^16", 10000, 0, 1 << 16, 0, max(3, it // 3), mygraph=generate_ba(10000, 5, 5))
     maxcut_suite("ER G(n=2000, p=0.005 -> m=9995), B=2^16", 2000, 9995, 1 << 16, 31, it)
     mcpg_suite("MCPG on a G22-sized G(2000, 19990), 2^16 chains", 2000, 0, 1 << 16, 8, max(3, it // 3), mygraph=generate_gnm(2000, 19990, 22))
-if (want("synthetic") or want("lsba")) and not a.profile:
+if want("synthetic") or want("lsba"):   # (under --profile too: the round kernels have rows of their own in tools/kernel_table.py)
     from rlsolver_amd.graph import generate_ba
-    local_search_suite("BA n=2000 m=4, dREINFORCE batch", 2000, 0, 0, 4096, max(2, it // 5), mygraph=generate_ba(2000, 4, 3))
+    if not a.profile:
+        local_search_suite("BA n=2000 m=4, dREINFORCE batch", 2000, 0, 0, 4096, max(2, it // 5), mygraph=generate_ba(2000, 4, 3))
     local_search_suite("BA n=10000 m=5 (hubs of degree >= 256), dREINFORCE batch", 10000, 0, 0, 4096, max(2, it // 5), mygraph=generate_ba(10000, 5, 5))
-    local_search_suite("BA n=10000 m=5 (hubs of degree >= 256), dREINFORCE batch x16", 10000, 0, 0, 65536, max(2, it // 5), mygraph=generate_ba(10000, 5, 5))
+    if a.profile:   # (2^15 envs: at 2^16 the sweep kernel's grid would coincide with the G22 row's)
+        local_search_suite("BA n=10000 m=5 (hubs of degree >= 256), dREINFORCE batch x8", 10000, 0, 0, 32768, max(2, it // 5), mygraph=generate_ba(10000, 5, 5))
+    else:
+        local_search_suite("BA n=10000 m=5 (hubs of degree >= 256), dREINFORCE batch x16", 10000, 0, 0, 65536, max(2, it // 5), mygraph=generate_ba(10000, 5, 5))
 if want("ls"):
     local_search_suite("G22-sized, dREINFORCE batch", 2000, 19990, 22, 4096, max(2, it // 5))
     local_search_suite("G22-sized, dREINFORCE batch x16", 2000, 19990, 22, 65536, max(2, it // 5))
