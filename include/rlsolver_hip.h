@@ -197,7 +197,7 @@ int rls_maxcut_propose_accept(const rls_graph* g, uint8_t* x, int64_t B, const u
  * ws_minmax[1] - ws_minmax[0]: the tiles fold their extremes in with atomics that fire only where they improve the
  * table (the table is initialised here, also when B = 0). */
 int rls_maxcut_ls_weights(const rls_graph* g, const uint8_t* x, int64_t B, int32_t mult, void* ws, int32_t ws_bytes,
-                          int32_t* ws_minmax, void* stream);
+                          int64_t ws_pitch, int32_t* ws_minmax, void* stream);
 
 /* K2+K6+K5 fused: EnvMaxcut.local_search_inplace  envs/env_L2A.py:87-116 (first_draw_proposes = 0)
  * and the body of LocalSearch.random_search  methods/LocalSearch.py:53-83 (first_draw_proposes = 1)
@@ -230,7 +230,7 @@ int rls_maxcut_local_search_supported(const rls_graph* g, int64_t B, int32_t num
 int rls_maxcut_node_stats_form(const rls_graph* g, int64_t B, int32_t what);
 
 /* The same local search as separate launches, for graphs rls_maxcut_local_search does not cover (its LDS layout holds
- * two tiles and rd_std: N <= ~6500; these hold one tile: N <= ~15 000, N % 16 == 0).  Both use the fused kernel's
+ * two tiles and rd_std: N <= ~6500; these hold one tile: N <= ~15 000).  Both use the fused kernel's
  * in-kernel draws -- normal(seed, env_offset + b, node, draw) -- so a caller that passes the same seed gets the result
  * the fused kernel would give.  They replace the torch ops of the decomposed path (randn_like, ws + noise * rd_std,
  * kthvalue, gt: envs/env_L2A.py:95-101, methods/LocalSearch.py:66-72) and K6's mask input.
@@ -238,13 +238,16 @@ int rls_maxcut_node_stats_form(const rls_graph* g, int64_t B, int32_t what);
  *   rls_maxcut_ls_propose:   mask = ws + normal(draw) * rd_std > thresh[b]; rows of x whose x ^ mask has cut >= obj[b]
  *                            take it, obj[b] updated (update_xs_by_vs, util_read_data.py:199)
  * ws / ws_bytes / rd_std as for rls_maxcut_local_search; draw = 0 for the threshold, 1.. for the rounds
- * (0.. when the first draw proposes: LocalSearch.random_search). */
-int rls_maxcut_ls_threshold(const rls_graph* g, int64_t B, const void* ws, int32_t ws_bytes, const float* rd_std, uint64_t seed,
-                            int64_t env_offset, int32_t draw, int32_t num_spin, float* thresh, void* scratch, int64_t scratch_bytes,
-                            void* stream);
-int rls_maxcut_ls_propose(const rls_graph* g, uint8_t* x, int64_t B, const void* ws, int32_t ws_bytes, const float* rd_std,
-                          const float* thresh, uint64_t seed, int64_t env_offset, int32_t draw, int64_t* obj, void* scratch,
-                          int64_t scratch_bytes, void* stream);
+ * (0.. when the first draw proposes: LocalSearch.random_search).  ws_pitch = entries between the starts of two rows of ws
+ * (0 = N; rls_maxcut_ls_weights writes that layout when given the same pitch): the rows must start 16-byte aligned, which a
+ * pitch rounded up to 16 bytes gives for ANY N (the entries between N and the pitch are never read); x may have any N and
+ * any alignment. */
+int rls_maxcut_ls_threshold(const rls_graph* g, int64_t B, const void* ws, int32_t ws_bytes, int64_t ws_pitch, const float* rd_std,
+                            uint64_t seed, int64_t env_offset, int32_t draw, int32_t num_spin, float* thresh, void* scratch,
+                            int64_t scratch_bytes, void* stream);
+int rls_maxcut_ls_propose(const rls_graph* g, uint8_t* x, int64_t B, const void* ws, int32_t ws_bytes, int64_t ws_pitch,
+                          const float* rd_std, const float* thresh, uint64_t seed, int64_t env_offset, int32_t draw, int64_t* obj,
+                          void* scratch, int64_t scratch_bytes, void* stream);
 /* scratch (16-byte aligned device memory, contents irrelevant, may be shared by all calls of one local search) lets a small
  * batch split each tile's noise pass -- the VALU-bound part -- over up to 8 workgroups: partial top-k lists / bit-packed mask
  * words go through it.  rls_maxcut_ls_scratch_bytes gives the size that enables this for (graph, B, ws_bytes); 0 = nothing

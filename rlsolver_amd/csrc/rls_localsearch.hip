@@ -388,7 +388,7 @@ __device__ __forceinline__ void ls_slice_chunks(int64_t nchunks_all, int sl, int
 }
 
 template <typename WT, int W, typename F>
-__device__ __forceinline__ void ls_ws_pass(const WT* __restrict__ ws, int64_t B, int64_t N, int64_t b0, int lane, int w,
+__device__ __forceinline__ void ls_ws_pass(const WT* __restrict__ ws, int64_t pitch, int64_t B, int64_t N, int64_t b0, int lane, int w,
                                            unsigned char* wstage, const float* sd, uint32_t env_key, int it,
                                            int64_t c_begin, int64_t nchunks, F&& f) {   // chunks [c_begin, nchunks)
     typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
@@ -403,7 +403,7 @@ __device__ __forceinline__ void ls_ws_pass(const WT* __restrict__ ws, int64_t B,
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int64_t rw = b0 + kStageRows * i + io_r, pc = c * 4 + io_j;
-                g[d][i] = (c < nchunks && rw < B && pc < npieces) ? *reinterpret_cast<const i32x4*>(ws + rw * N + pc * NPC)
+                g[d][i] = (c < nchunks && rw < B && pc < npieces) ? *reinterpret_cast<const i32x4*>(ws + rw * pitch + pc * NPC)
                                                                   : i32x4{0, 0, 0, 0};
             }
         }
@@ -456,7 +456,7 @@ constexpr int kLsRoundWaves = 8;
 
 // thresh[b] = the (num_spin + 1)-th largest of ws[b, :] + normal(draw) * rd_std  (kthvalue(k = N - num_spin))
 template <typename WT>
-__global__ __launch_bounds__(kLsRoundWaves * kWave) void k_ls_threshold(const WT* __restrict__ ws, int64_t B, int64_t N,
+__global__ __launch_bounds__(kLsRoundWaves * kWave) void k_ls_threshold(const WT* __restrict__ ws, int64_t pitch, int64_t B, int64_t N,
                                                                         const float* __restrict__ rd_std, uint64_t seed,
                                                                         int64_t env_offset, int draw, int num_spin,
                                                                         float* __restrict__ thresh, float* __restrict__ partial) {
@@ -479,7 +479,7 @@ __global__ __launch_bounds__(kLsRoundWaves * kWave) void k_ls_threshold(const WT
     int64_t c_begin, c_end;
     ls_slice_chunks(ls_num_chunks<WT>(N), (int)blockIdx.y, (int)gridDim.y, c_begin, c_end);
     auto pass = [&](auto depth) {
-        ls_ws_pass<WT, W>(ws, B, N, b0, lane, w, stages + (size_t)w * kStageBytes, sdl, env_key, draw, c_begin, c_end,
+        ls_ws_pass<WT, W>(ws, pitch, B, N, b0, lane, w, stages + (size_t)w * kStageBytes, sdl, env_key, draw, c_begin, c_end,
                           [&](int64_t pc, const float (&v)[NPC]) {
 #pragma unroll
                               for (int k = 0; k < NPC; ++k) top_insert_n<decltype(depth)::value>(t, (pc * NPC + k < N) ? v[k] : -INFINITY);
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(kWave) void k_ls_threshold_merge(const float* __res
 // the mask words of one proposal round for a slice of the nodes: maskw[tile][node] (bit e = env 64 tile + e), for batches of so
 // few tiles that one workgroup per tile would leave most of the chip idle through the VALU-bound noise generation
 template <typename WT>
-__global__ __launch_bounds__(kLsRoundWaves * kWave) void k_ls_mask(const WT* __restrict__ ws, int64_t B, int64_t N,
+__global__ __launch_bounds__(kLsRoundWaves * kWave) void k_ls_mask(const WT* __restrict__ ws, int64_t pitch, int64_t B, int64_t N,
                                                                    const float* __restrict__ rd_std, const float* __restrict__ thresh,
                                                                    uint64_t seed, int64_t env_offset, int draw,
                                                                    uint64_t* __restrict__ maskw) {
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(kLsRoundWaves * kWave) void k_ls_mask(const WT* __r
     int64_t c_begin, c_end;
     ls_slice_chunks(ls_num_chunks<WT>(N), (int)blockIdx.y, (int)gridDim.y, c_begin, c_end);
     uint64_t* out = maskw + (int64_t)blockIdx.x * N;
-    ls_ws_pass<WT, W>(ws, B, N, b0, lane, w, stages + (size_t)w * kStageBytes, sdl, env_key, draw, c_begin, c_end,
+    ls_ws_pass<WT, W>(ws, pitch, B, N, b0, lane, w, stages + (size_t)w * kStageBytes, sdl, env_key, draw, c_begin, c_end,
                       [&](int64_t pc, const float (&v)[NPC]) {
                           uint64_t mine = 0;
 #pragma unroll
@@ -564,10 +564,11 @@ __global__ __launch_bounds__(kLsRoundWaves * kWave) void k_ls_mask(const WT* __r
 template <typename WT, int P, bool SD_LDS, bool PREMASK>
 __global__ __launch_bounds__(kLsRoundWaves * kWave) void k_ls_propose(uint8_t* __restrict__ x, int64_t B, int64_t N,
                                                                       const int32_t* __restrict__ eu, const int32_t* __restrict__ ev,
-                                                                      int64_t E, int halve, const WT* __restrict__ ws,
+                                                                      int64_t E, int halve, const WT* __restrict__ ws, int64_t pitch,
                                                                       const float* __restrict__ rd_std, const float* __restrict__ thresh,
                                                                       uint64_t seed, int64_t env_offset, int draw,
-                                                                      int64_t* __restrict__ obj, const uint64_t* __restrict__ maskw) {
+                                                                      int64_t* __restrict__ obj, const uint64_t* __restrict__ maskw,
+                                                                      int x_aligned) {   // rows of x 4-byte aligned on a 16-byte base
     constexpr int W = kLsRoundWaves, NPC = 16 / (int)sizeof(WT);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* words = reinterpret_cast<uint64_t*>(smem);
@@ -582,7 +583,8 @@ __global__ __launch_bounds__(kLsRoundWaves * kWave) void k_ls_propose(uint8_t* _
     unsigned char* stage = stages + (size_t)w * kStageBytes;
     if constexpr (SD_LDS && !PREMASK)
         for (int64_t i = threadIdx.x; i < ((N + 3) & ~3ll); i += W * kWave) sdl[i] = i < N ? rd_std[i] : 0.0f;
-    tile_load_bits<uint8_t, true>(x, B, N, b0, words, lane, w, W, stage);
+    if (x_aligned) tile_load_bits<uint8_t, true>(x, B, N, b0, words, lane, w, W, stage);
+    else tile_load_bits<uint8_t, false>(x, B, N, b0, words, lane, w, W, stage);
     __syncthreads();
     if constexpr (PREMASK) {
         const uint64_t* mw = maskw + (int64_t)blockIdx.x * N;
@@ -590,7 +592,7 @@ __global__ __launch_bounds__(kLsRoundWaves * kWave) void k_ls_propose(uint8_t* _
     } else {
         const float th = valid ? thresh[b] : 0.0f;
         // the mask words go straight into the tile: a node belongs to exactly one piece of one wave
-        ls_ws_pass<WT, W>(ws, B, N, b0, lane, w, stage, SD_LDS ? sdl : rd_std, env_key, draw, 0, ls_num_chunks<WT>(N),
+        ls_ws_pass<WT, W>(ws, pitch, B, N, b0, lane, w, stage, SD_LDS ? sdl : rd_std, env_key, draw, 0, ls_num_chunks<WT>(N),
                           [&](int64_t pc, const float (&v)[NPC]) {
                               uint64_t mine = 0;
 #pragma unroll
@@ -608,7 +610,8 @@ __global__ __launch_bounds__(kLsRoundWaves * kWave) void k_ls_propose(uint8_t* _
     const bool accept = valid && (total >= obj[b]);           // update_xs_by_vs: vs1.ge(vs0)
     __syncthreads();                                          // every wave has read obj[b] before wave 0 updates it
     if (accept && w == 0) obj[b] = total;
-    tile_store_bytes<true>(x, B, N, b0, words, lane, w, W, accept, stage);
+    if (x_aligned) tile_store_bytes<true>(x, B, N, b0, words, lane, w, W, accept, stage);
+    else tile_store_bytes<false>(x, B, N, b0, words, lane, w, W, accept, stage);
 }
 
 static bool ls_sd_global() {   // dev knob: rd_std read from global memory even where it fits LDS
@@ -731,11 +734,11 @@ extern "C" int rls_maxcut_local_search(const rls_graph* g, uint8_t* x, int64_t B
     return check_launch("k_maxcut_local_search");
 }
 
-// 1 when rls_maxcut_ls_threshold / rls_maxcut_ls_propose cover this graph (rows of 16-byte multiples whose tile fits LDS)
+// 1 when rls_maxcut_ls_threshold / rls_maxcut_ls_propose cover this graph (a tile that fits LDS; ws rows on a 16-byte pitch)
 extern "C" int rls_maxcut_ls_rounds_supported(const rls_graph* g, int32_t num_spin) {
     if (!g || g->num_nodes <= 0) return 0;
     const int64_t N = g->num_nodes;
-    if (num_spin < 0 || num_spin + 1 > kTopCap || num_spin >= N || (N & 15) != 0) return 0;
+    if (num_spin < 0 || num_spin + 1 > kTopCap || num_spin >= N) return 0;
     if (pick_planes(g->num_stored_edges) == 0) return 0;
     return ls_propose_lds(N, false) <= (size_t)kLdsBytes;
 }
@@ -749,9 +752,14 @@ extern "C" int64_t rls_maxcut_ls_scratch_bytes(const rls_graph* g, int64_t B, in
     return (int64_t)ls_scratch_bytes(B, N, ls_slices(B, nch));
 }
 
-extern "C" int rls_maxcut_ls_threshold(const rls_graph* g, int64_t B, const void* ws, int32_t ws_bytes, const float* rd_std,
-                                       uint64_t seed, int64_t env_offset, int32_t draw, int32_t num_spin, float* thresh,
-                                       void* scratch, int64_t scratch_bytes, void* stream) {
+// ws rows start ws_pitch ENTRIES apart (0 = N): any N works once the pitch is a multiple of 16 bytes
+static bool ls_pitch_ok(const void* ws, int64_t pitch, int32_t ws_bytes, int64_t N) {
+    return pitch >= N && ((pitch * ws_bytes) & 15) == 0 && (((uintptr_t)ws) & 15) == 0;
+}
+
+extern "C" int rls_maxcut_ls_threshold(const rls_graph* g, int64_t B, const void* ws, int32_t ws_bytes, int64_t ws_pitch,
+                                       const float* rd_std, uint64_t seed, int64_t env_offset, int32_t draw, int32_t num_spin,
+                                       float* thresh, void* scratch, int64_t scratch_bytes, void* stream) {
     if (int rc = check_graph(g)) return rc;
     RLS_REQUIRE(B >= 0 && draw >= 0, RLS_EINVAL, "bad sizes");
     if (B == 0) return RLS_OK;
@@ -760,8 +768,9 @@ extern "C" int rls_maxcut_ls_threshold(const rls_graph* g, int64_t B, const void
     const int64_t N = g->num_nodes;
     RLS_REQUIRE(num_spin >= 0 && num_spin + 1 <= kTopCap && num_spin < N, RLS_EUNSUPPORTED, "num_spin=%d outside [0, %d] (and < N)",
                 num_spin, kTopCap - 1);
-    RLS_REQUIRE((N & 15) == 0 && (((uintptr_t)ws) & 15) == 0, RLS_EUNSUPPORTED, "ws rows must be 16-byte multiples on a 16-byte base (N=%lld)",
-                (long long)N);
+    if (ws_pitch == 0) ws_pitch = N;
+    RLS_REQUIRE(ls_pitch_ok(ws, ws_pitch, ws_bytes, N), RLS_EUNSUPPORTED,
+                "ws rows must start 16-byte aligned: pitch %lld entries of %d bytes (N=%lld)", (long long)ws_pitch, (int)ws_bytes, (long long)N);
     const size_t lds = ls_threshold_lds(N);
     RLS_REQUIRE(lds <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS (max %d)", (long long)N, lds, kLdsBytes);
     int S = ls_slices(B, ws_bytes == 1 ? ls_num_chunks<int8_t>(N) : ls_num_chunks<int16_t>(N));
@@ -772,7 +781,7 @@ extern "C" int rls_maxcut_ls_threshold(const rls_graph* g, int64_t B, const void
     do {                                                                                                               \
         auto kern = k_ls_threshold<WT>;                                                                                \
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL(kern, grid, block, lds, s, (const WT*)ws, B, N, rd_std, seed, env_offset, (int)draw, (int)num_spin, thresh, \
+        hipLaunchKernelGGL(kern, grid, block, lds, s, (const WT*)ws, ws_pitch, B, N, rd_std, seed, env_offset, (int)draw, (int)num_spin, thresh, \
                            (float*)scratch);                                                                           \
     } while (0)
     if (ws_bytes == 1) LAUNCH_TH(int8_t); else LAUNCH_TH(int16_t);
@@ -785,17 +794,19 @@ extern "C" int rls_maxcut_ls_threshold(const rls_graph* g, int64_t B, const void
     return RLS_OK;
 }
 
-extern "C" int rls_maxcut_ls_propose(const rls_graph* g, uint8_t* x, int64_t B, const void* ws, int32_t ws_bytes, const float* rd_std,
-                                     const float* thresh, uint64_t seed, int64_t env_offset, int32_t draw, int64_t* obj,
-                                     void* scratch, int64_t scratch_bytes, void* stream) {
+extern "C" int rls_maxcut_ls_propose(const rls_graph* g, uint8_t* x, int64_t B, const void* ws, int32_t ws_bytes, int64_t ws_pitch,
+                                     const float* rd_std, const float* thresh, uint64_t seed, int64_t env_offset, int32_t draw,
+                                     int64_t* obj, void* scratch, int64_t scratch_bytes, void* stream) {
     if (int rc = check_graph(g)) return rc;
     RLS_REQUIRE(B >= 0 && draw >= 0, RLS_EINVAL, "bad sizes");
     if (B == 0) return RLS_OK;
     RLS_REQUIRE(x && ws && rd_std && thresh && obj, RLS_EINVAL, "NULL pointer");
     RLS_REQUIRE(ws_bytes == 1 || ws_bytes == 2, RLS_EINVAL, "ws_bytes must be 1 or 2 (rls_maxcut_ls_weights writes either)");
     const int64_t N = g->num_nodes, E = g->num_stored_edges;
-    RLS_REQUIRE((N & 15) == 0 && ((((uintptr_t)ws) | ((uintptr_t)x)) & 15) == 0, RLS_EUNSUPPORTED,
-                "x and ws rows must be 16-byte multiples on 16-byte bases (N=%lld)", (long long)N);
+    if (ws_pitch == 0) ws_pitch = N;
+    RLS_REQUIRE(ls_pitch_ok(ws, ws_pitch, ws_bytes, N), RLS_EUNSUPPORTED,
+                "ws rows must start 16-byte aligned: pitch %lld entries of %d bytes (N=%lld)", (long long)ws_pitch, (int)ws_bytes, (long long)N);
+    const int x_aligned = tile_rows_aligned(x, N, 1) ? 1 : 0;   // else the funnel-shift form of the row-piece stage
     RLS_REQUIRE(ls_propose_lds(N, false) <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS (max %d)", (long long)N,
                 ls_propose_lds(N, false), kLdsBytes);
     const int P = pick_planes(E);
@@ -812,7 +823,7 @@ extern "C" int rls_maxcut_ls_propose(const rls_graph* g, uint8_t* x, int64_t B, 
     do {                                                                                                               \
         auto kern = k_ls_mask<WT>;                                                                                     \
         if (ldm > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldm); \
-        hipLaunchKernelGGL(kern, gm, block, ldm, s, (const WT*)ws, B, N, rd_std, thresh, seed, env_offset, (int)draw, (uint64_t*)scratch); \
+        hipLaunchKernelGGL(kern, gm, block, ldm, s, (const WT*)ws, ws_pitch, B, N, rd_std, thresh, seed, env_offset, (int)draw, (uint64_t*)scratch); \
     } while (0)
         if (ws_bytes == 1) LAUNCH_MK(int8_t); else LAUNCH_MK(int16_t);
 #undef LAUNCH_MK
@@ -824,17 +835,17 @@ extern "C" int rls_maxcut_ls_propose(const rls_graph* g, uint8_t* x, int64_t B, 
     do {                                                                                                               \
         auto kern = k_ls_propose<WT, PP, SD, PM>;                                                                      \
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL(kern, grid, block, lds, s, x, B, N, g->eu, g->ev, E, halve, (const WT*)ws, rd_std, thresh, seed, env_offset, \
-                           (int)draw, obj, (const uint64_t*)scratch);                                                  \
+        hipLaunchKernelGGL(kern, grid, block, lds, s, x, B, N, g->eu, g->ev, E, halve, (const WT*)ws, ws_pitch, rd_std, thresh, seed,  \
+                           env_offset, (int)draw, obj, (const uint64_t*)scratch, x_aligned);                           \
     } while (0)
+    // (one counter width: the round is bound by its noise generation, the few carry steps a narrower counter saves per 1024
+    // edges do not show, and every instantiation is ~40 KB)
 #define DISPATCH_PR(WT)                                                                            \
     do {                                                                                           \
-        if (P <= 16) { if (sd_lds) LAUNCH_PR(WT, 16, true, false); else LAUNCH_PR(WT, 16, false, false); }       \
-        else         { if (sd_lds) LAUNCH_PR(WT, 24, true, false); else LAUNCH_PR(WT, 24, false, false); }       \
+        if (sd_lds) LAUNCH_PR(WT, 24, true, false); else LAUNCH_PR(WT, 24, false, false);          \
     } while (0)
-    if (S > 1) {   // (WT and SD_LDS play no part once the mask is given: one instantiation per counter width)
-        if (P <= 16) LAUNCH_PR(int8_t, 16, false, true); else LAUNCH_PR(int8_t, 24, false, true);
-    } else if (ws_bytes == 1) DISPATCH_PR(int8_t); else DISPATCH_PR(int16_t);
+    if (S > 1) LAUNCH_PR(int8_t, 24, false, true);   // (WT and SD_LDS play no part once the mask is given)
+    else if (ws_bytes == 1) DISPATCH_PR(int8_t); else DISPATCH_PR(int16_t);
 #undef DISPATCH_PR
 #undef LAUNCH_PR
     return check_launch("k_ls_propose");

@@ -284,7 +284,8 @@ __device__ __forceinline__ void ws_minmax_update(int32_t* __restrict__ minmax, i
 // element-parallel local-search weights (no LDS tile: any N): ws[b,i] = #stored out-neighbours - mult * cutdeg[b,i]
 template <typename WT>
 __global__ void k_ls_weights_elem(const uint8_t* __restrict__ x, int64_t B, int64_t N, const int32_t* __restrict__ erowptr,
-                                  const int32_t* __restrict__ ev, int mult, WT* __restrict__ ws, int32_t* __restrict__ minmax) {
+                                  const int32_t* __restrict__ ev, int mult, WT* __restrict__ ws, int64_t pitch,
+                                  int32_t* __restrict__ minmax) {
     const int64_t total = B * N;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         const int64_t b = t / N, i = t - b * N;
@@ -294,7 +295,7 @@ __global__ void k_ls_weights_elem(const uint8_t* __restrict__ x, int64_t B, int6
         int c = 0;
         for (int j = r0; j < r1; ++j) c += ((row[ev[j]] != 0) != xi);
         const int val = (r1 - r0) - mult * c;
-        ws[t] = (WT)val;
+        ws[b * pitch + i] = (WT)val;
         if (minmax) ws_minmax_update(minmax, N, i, val, val);
     }
 }
@@ -467,7 +468,8 @@ __global__ __launch_bounds__(kNsWaves * kWave) void k_node_stats_bits(const uint
                                                                      const int32_t* __restrict__ rowptr,
                                                                      const int32_t* __restrict__ ell_ptr,
                                                                      const int32_t* __restrict__ ell, int mult,
-                                                                     void* __restrict__ out_v, int32_t* __restrict__ minmax) {
+                                                                     void* __restrict__ out_v, int32_t* __restrict__ minmax,
+                                                                     int64_t out_pitch) {   // row pitch of out_v in elements (MODE 2; N otherwise)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* words = reinterpret_cast<uint64_t*>(smem);
     const int lane = threadIdx.x & (kWave - 1);
@@ -520,7 +522,7 @@ __global__ __launch_bounds__(kNsWaves * kWave) void k_node_stats_bits(const uint
         auto emit = [&](int e, int cnt) {
             if constexpr (MODE == 0) reinterpret_cast<int64_t*>(out_v)[(b0 + e) * N + i] = cnt;
             else if constexpr (MODE == 1) reinterpret_cast<int32_t*>(out_v)[(b0 + e) * N + i] = deg - 2 * cnt;
-            else reinterpret_cast<WT*>(out_v)[(b0 + e) * N + i] = (WT)(deg - mult * cnt);
+            else reinterpret_cast<WT*>(out_v)[(b0 + e) * out_pitch + i] = (WT)(deg - mult * cnt);
         };
         const uint64_t vmask = nenv == kWave ? ~0ull : ((1ull << nenv) - 1);
         if constexpr (WIDE) {
@@ -604,7 +606,7 @@ static inline bool node_stats_use_bits(const rls_graph* g, const int32_t* ell_pt
 template <int MODE, typename WT = int32_t>
 static int launch_node_stats_bits(const rls_graph* g, const uint8_t* x, int64_t B, const int32_t* rowptr,
                                   const int32_t* ell_ptr, const int32_t* ell, int mult, void* out, void* stream,
-                                  int32_t* minmax = nullptr) {
+                                  int32_t* minmax = nullptr, int64_t out_pitch = 0) {
     const int64_t N = g->num_nodes;
     const size_t lds = node_stats_bits_lds(N);
     const dim3 grid((unsigned)ceil_div(B, kWave)), block(kNsWaves * kWave);
@@ -614,7 +616,8 @@ static int launch_node_stats_bits(const rls_graph* g, const uint8_t* x, int64_t 
                      : (vec ? k_node_stats_bits<MODE, true, false, WT> : k_node_stats_bits<MODE, false, false, WT>);
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, grid, block, lds, as_stream(stream), x, B, N, rowptr, ell_ptr, ell, mult, out, minmax);
+    hipLaunchKernelGGL(kern, grid, block, lds, as_stream(stream), x, B, N, rowptr, ell_ptr, ell, mult, out, minmax,
+                       out_pitch > 0 ? out_pitch : N);
     return check_launch("k_node_stats_bits");
 }
 
@@ -1195,22 +1198,25 @@ int rls_maxcut_delta_all(const rls_graph* g, const uint8_t* x, int64_t B, int32_
 }  // extern "C" (a template follows)
 
 template <typename WT>
-static int ls_weights_typed(const rls_graph* g, const uint8_t* x, int64_t B, int32_t mult, WT* ws, int32_t* minmax, void* stream) {
+static int ls_weights_typed(const rls_graph* g, const uint8_t* x, int64_t B, int32_t mult, WT* ws, int64_t pitch, int32_t* minmax,
+                            void* stream) {
     // (a lane = env tile kernel used to take the small batches: 850 us per call on a G22-sized graph at any batch size, against
     // 30 us for the bit-sliced one and 20 - 100 us for the element-parallel one: tools/dev/ls_weights_forms.py)
     if (node_stats_use_bits(g, g->ell_st_ptr, g->ell_st, B))
-        return launch_node_stats_bits<2, WT>(g, x, B, g->erowptr, g->ell_st_ptr, g->ell_st, (int)mult, ws, stream, minmax);
+        return launch_node_stats_bits<2, WT>(g, x, B, g->erowptr, g->ell_st_ptr, g->ell_st, (int)mult, ws, stream, minmax, pitch);
     hipLaunchKernelGGL(k_ls_weights_elem<WT>, dim3(grid_for(B * g->num_nodes, 256)), dim3(256), 0, as_stream(stream), x, B, g->num_nodes,
-                       g->erowptr, g->ev, (int)mult, ws, minmax);
+                       g->erowptr, g->ev, (int)mult, ws, pitch, minmax);
     return check_launch("k_ls_weights_elem");
 }
 
 extern "C" {
 
 int rls_maxcut_ls_weights(const rls_graph* g, const uint8_t* x, int64_t B, int32_t mult, void* ws, int32_t ws_bytes,
-                          int32_t* ws_minmax, void* stream) {
+                          int64_t ws_pitch, int32_t* ws_minmax, void* stream) {
     if (int rc = check_graph(g)) return rc;
     RLS_REQUIRE(B >= 0 && mult >= 0, RLS_EINVAL, "bad arguments");
+    if (ws_pitch == 0) ws_pitch = g->num_nodes;
+    RLS_REQUIRE(ws_pitch >= g->num_nodes, RLS_EINVAL, "ws_pitch %lld < N", (long long)ws_pitch);
     RLS_REQUIRE(ws_bytes == 1 || ws_bytes == 2 || ws_bytes == 4, RLS_EINVAL, "ws_bytes must be 1, 2 or 4");
     // ws lies in [-(mult - 1) deg, deg] with deg <= the graph's largest degree
     const int64_t span = (int64_t)g->max_degree * (mult > 1 ? mult - 1 : 1);
@@ -1221,12 +1227,12 @@ int rls_maxcut_ls_weights(const rls_graph* g, const uint8_t* x, int64_t B, int32
                            g->num_nodes);
     if (B == 0) return ws_minmax ? check_launch("k_fill_minmax") : RLS_OK;
     RLS_REQUIRE(x && ws, RLS_EINVAL, "NULL pointer");
-    if (ws_bytes == 1) return ls_weights_typed<int8_t>(g, x, B, mult, (int8_t*)ws, ws_minmax, stream);
-    if (ws_bytes == 2) return ls_weights_typed<int16_t>(g, x, B, mult, (int16_t*)ws, ws_minmax, stream);
+    if (ws_bytes == 1) return ls_weights_typed<int8_t>(g, x, B, mult, (int8_t*)ws, ws_pitch, ws_minmax, stream);
+    if (ws_bytes == 2) return ls_weights_typed<int16_t>(g, x, B, mult, (int16_t*)ws, ws_pitch, ws_minmax, stream);
     // 4-byte entries: only graphs with degrees beyond 32767 need them (and only the decomposed local search reads them):
     // the element-parallel kernel, no tile variants
     hipLaunchKernelGGL(k_ls_weights_elem<int32_t>, dim3(grid_for(B * g->num_nodes, 256)), dim3(256), 0, as_stream(stream), x, B,
-                       g->num_nodes, g->erowptr, g->ev, (int)mult, (int32_t*)ws, ws_minmax);
+                       g->num_nodes, g->erowptr, g->ev, (int)mult, (int32_t*)ws, ws_pitch, ws_minmax);
     return check_launch("k_ls_weights_elem");
 }
 

@@ -177,11 +177,13 @@ void maxcut_ls_weights(int64_t g, const Tensor& xs, int64_t mult, Tensor ws, con
     spin_bytes(xs, "xs", false);
     const int64_t B = env_rows(xs, "xs", G(g));
     const int wb = ws_bytes_of(ws, true);
-    shape2(ws, "ws", B, G(g)->num_nodes);
+    // ws [B, pitch >= N] contiguous: entries N .. pitch of a row are padding (the round kernels want rows on a 16-byte pitch)
+    TORCH_CHECK(ws.dim() == 2 && ws.size(0) == B && ws.size(1) >= G(g)->num_nodes, "ws must be [", B, ", >= ", G(g)->num_nodes, "], got ",
+                ws.sizes());
     optdev(ws_minmax, "ws_minmax", I32);
     if (ws_minmax.has_value()) shape2(*ws_minmax, "ws_minmax", 2, G(g)->num_nodes);
     RLS_GUARD(xs);
-    ok(rls_maxcut_ls_weights(G(g), (const uint8_t*)p(xs), B, (int32_t)mult, p(ws), wb, (int32_t*)p(ws_minmax), cur_stream(xs)),
+    ok(rls_maxcut_ls_weights(G(g), (const uint8_t*)p(xs), B, (int32_t)mult, p(ws), wb, ws.size(1), (int32_t*)p(ws_minmax), cur_stream(xs)),
        "rls_maxcut_ls_weights");
 }
 void maxcut_local_search(int64_t g, Tensor xs, const Tensor& ws, const Tensor& rd_std, const OptTensor& noise, int64_t seed,
@@ -212,14 +214,14 @@ void maxcut_ls_threshold(int64_t g, const Tensor& ws, const Tensor& rd_std, int6
                          int64_t num_spin, Tensor thresh, const OptTensor& scratch) {
     const int64_t N = G(g)->num_nodes;
     const int wb = ws_bytes_of(ws, false);
-    TORCH_CHECK(ws.dim() == 2 && ws.size(1) == N, "ws must be [B, ", N, "], got ", ws.sizes());
+    TORCH_CHECK(ws.dim() == 2 && ws.size(1) >= N, "ws must be [B, >= ", N, "], got ", ws.sizes());
     const int64_t B = ws.size(0);
     dev(rd_std, "rd_std", F32);
     count(rd_std, "rd_std", N);
     dev(thresh, "thresh", F32);
     count(thresh, "thresh", B);
     RLS_GUARD(ws);
-    ok(rls_maxcut_ls_threshold(G(g), B, p(ws), wb, (const float*)p(rd_std), (uint64_t)seed, env_offset, (int32_t)draw, (int32_t)num_spin,
+    ok(rls_maxcut_ls_threshold(G(g), B, p(ws), wb, ws.size(1), (const float*)p(rd_std), (uint64_t)seed, env_offset, (int32_t)draw, (int32_t)num_spin,
                                (float*)p(thresh), p(scratch), scratch_of(scratch), cur_stream(ws)), "rls_maxcut_ls_threshold");
 }
 void maxcut_ls_propose(int64_t g, Tensor xs, const Tensor& ws, const Tensor& rd_std, const Tensor& thresh, int64_t seed,
@@ -227,7 +229,7 @@ void maxcut_ls_propose(int64_t g, Tensor xs, const Tensor& ws, const Tensor& rd_
     spin_bytes(xs, "xs", false);
     const int64_t B = env_rows(xs, "xs", G(g)), N = G(g)->num_nodes;
     const int wb = ws_bytes_of(ws, false);
-    shape2(ws, "ws", B, N);
+    TORCH_CHECK(ws.dim() == 2 && ws.size(0) == B && ws.size(1) >= N, "ws must be [", B, ", >= ", N, "], got ", ws.sizes());
     dev(rd_std, "rd_std", F32);
     count(rd_std, "rd_std", N);
     dev(thresh, "thresh", F32);
@@ -235,7 +237,7 @@ void maxcut_ls_propose(int64_t g, Tensor xs, const Tensor& ws, const Tensor& rd_
     dev(obj, "obj", I64);
     count(obj, "obj", B);
     RLS_GUARD(xs);
-    ok(rls_maxcut_ls_propose(G(g), (uint8_t*)p(xs), B, p(ws), wb, (const float*)p(rd_std), (const float*)p(thresh), (uint64_t)seed,
+    ok(rls_maxcut_ls_propose(G(g), (uint8_t*)p(xs), B, p(ws), wb, ws.size(1), (const float*)p(rd_std), (const float*)p(thresh), (uint64_t)seed,
                              env_offset, (int32_t)draw, (int64_t*)p(obj), p(scratch), scratch_of(scratch), cur_stream(xs)),
        "rls_maxcut_ls_propose");
 }

@@ -122,11 +122,14 @@ class EnvMaxcut:
         One pre-pass + ONE fused kernel when the library covers the shape (rls_maxcut_local_search_supported), else
         K2-weights + torch noise / kthvalue + K6 per round + K5."""
         B = xs.shape[0]
-        ws32, ws_span = ops.maxcut_ls_weights(self.graph, xs, weight_mult)     # exact integers (int8 / int16) in both env flavours
+        fused_ok = self.fused_local_search and not self.force_ls_rounds and ops.local_search_fusable(self.graph, num_spin, B)
+        rounds_ok = (not fused_ok and noise is None and (self.fused_local_search or self.force_ls_rounds)
+                     and ops.ls_weight_dtype(self.graph, weight_mult) != th.int32 and ops.ls_rounds_supported(self.graph, num_spin))
+        # exact integers (int8 / int16) in both env flavours; the round kernels read them on a 16-byte row pitch (any N)
+        ws32, ws_span = ops.maxcut_ls_weights(self.graph, xs, weight_mult, padded=rounds_ok)
         rd_std = (ws_span.float() * noise_std).contiguous()
         if noise is not None:
             noise = noise.to(device=self.device, dtype=th.float32).contiguous()
-        fused_ok = self.fused_local_search and not self.force_ls_rounds and ops.local_search_fusable(self.graph, num_spin, B)
         if fused_ok and (num_iters > 0 or not first_draw_proposes):
             ops.maxcut_local_search(self.graph, xs, ws32, rd_std, vs, num_iters, num_spin, noise=noise,
                                     seed=0 if noise is not None else _seed_from_torch(),
@@ -134,7 +137,7 @@ class EnvMaxcut:
             return
         if compute_vs:
             ops.maxcut_obj(self.graph, xs, out=vs)
-        if noise is None and (self.fused_local_search or self.force_ls_rounds) and ws32.dtype in (th.int8, th.int16) and ops.ls_rounds_supported(self.graph, num_spin):
+        if rounds_ok:
             # the same steps as kernels with the fused kernel's draws (same seed => the fused kernel's result): graphs too
             # large for the fused kernel's LDS layout
             seed = _seed_from_torch()

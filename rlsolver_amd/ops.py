@@ -257,11 +257,15 @@ def ls_weight_dtype(g: DeviceGraph, mult: int):
     return torch.int8 if span <= 127 else (torch.int16 if span <= 32767 else torch.int32)
 
 
-def maxcut_ls_weights(g: DeviceGraph, xs: TEN, mult: int, dtype=None):
-    """Pre-pass of the fused local search: (ws [B, N] int8 / int16 / int32 -- ``dtype`` or the narrowest that fits --,
-    ws_std int32 [N] = max_b ws - min_b ws, folded in by the same kernel)."""
+def maxcut_ls_weights(g: DeviceGraph, xs: TEN, mult: int, dtype=None, padded: bool = False):
+    """Pre-pass of the local search: (ws [B, N] int8 / int16 / int32 -- ``dtype`` or the narrowest that fits --,
+    ws_std int32 [N] = max_b ws - min_b ws, folded in by the same kernel).  ``padded``: ws comes back as [B, P], P = N rounded
+    up to 16 bytes of entries (the layout the round kernels read for any N; entries N .. P are padding)."""
     B, _ = _spins(xs, "xs", g)
-    ws = torch.empty((B, g.num_nodes), dtype=ls_weight_dtype(g, mult) if dtype is None else dtype, device=g.device)
+    dt = ls_weight_dtype(g, mult) if dtype is None else dtype
+    per = 16 // torch.empty((), dtype=dt).element_size()
+    P = (g.num_nodes + per - 1) // per * per if padded else g.num_nodes
+    ws = torch.empty((B, P), dtype=dt, device=g.device)
     mm = torch.empty((2, g.num_nodes), dtype=torch.int32, device=g.device)
     _t.maxcut_ls_weights(g.handle, xs, int(mult), ws, mm)
     return ws, mm[1] - mm[0]
@@ -306,8 +310,8 @@ def maxcut_ls_threshold(g: DeviceGraph, ws: TEN, rd_std: TEN, seed: int, num_spi
                         out: Optional[TEN] = None, scratch: Optional[TEN] = None) -> TEN:
     """thresh f32 [B] = kthvalue(ws + normal(draw) * rd_std, k = N - num_spin) with the fused local search's draws."""
     _check(ws, "ws", (torch.int8, torch.int16), g.device)
-    if ws.dim() != 2 or ws.shape[1] != g.num_nodes:
-        raise ValueError(f"ws must be [B, {g.num_nodes}]")
+    if ws.dim() != 2 or ws.shape[1] < g.num_nodes:
+        raise ValueError(f"ws must be [B, >= {g.num_nodes}]")
     _check(rd_std, "rd_std", (torch.float32,), g.device, (g.num_nodes,))
     out = torch.empty(ws.shape[0], dtype=torch.float32, device=g.device) if out is None else out
     _check(out, "out", (torch.float32,), g.device, (ws.shape[0],))
@@ -319,7 +323,9 @@ def maxcut_ls_propose(g: DeviceGraph, xs: TEN, ws: TEN, rd_std: TEN, thresh: TEN
                       env_offset: int = 0, scratch: Optional[TEN] = None) -> None:
     """One proposal round in place: rows of xs whose xs ^ (ws + normal(draw) * rd_std > thresh) has cut >= obj take it."""
     B, _ = _spins(xs, "xs", g)
-    _check(ws, "ws", (torch.int8, torch.int16), g.device, (B, g.num_nodes))
+    _check(ws, "ws", (torch.int8, torch.int16), g.device)
+    if ws.dim() != 2 or ws.shape[0] != B or ws.shape[1] < g.num_nodes:
+        raise ValueError(f"ws must be [{B}, >= {g.num_nodes}]")
     _check(rd_std, "rd_std", (torch.float32,), g.device, (g.num_nodes,))
     _check(thresh, "thresh", (torch.float32,), g.device, (B,))
     _check(obj, "obj", (torch.int64,), g.device, (B,))

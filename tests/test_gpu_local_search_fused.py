@@ -107,7 +107,9 @@ def test_local_search_class_golden_both_paths(golden, gname, fused):
 
 @pytest.mark.parametrize("n,m,B,bidir,num_spin", [(2000, 19990, 130, False, 8), (320, 2000, 70, True, 6), (64, 400, 64, False, 3),
                                                   (1008, 5000, 65, False, 12), (3008, 9000, 200, True, 8),
-                                                  (320, 2000, 16500, False, 8)])      # (the last: enough tiles for one workgroup each)
+                                                  (320, 2000, 16500, False, 8),       # (enough tiles for one workgroup each)
+                                                  (333, 2000, 70, False, 5), (1001, 5000, 130, True, 8), (2004, 9000, 65, False, 8),
+                                                  (1999, 9000, 200, False, 8)])       # rows that are not 16-byte multiples
 def test_round_kernels_equal_the_fused_kernel_for_the_same_seed(n, m, B, bidir, num_spin):
     """rls_maxcut_ls_threshold + rls_maxcut_ls_propose per round + K5 draw what the fused kernel draws: under the same torch
     seed local_search_inplace gives the same spins and cuts through either form (the fused one is pinned by the golden
@@ -132,9 +134,10 @@ def test_round_kernels_equal_the_fused_kernel_for_the_same_seed(n, m, B, bidir, 
         assert not torch.equal(outs[1][0], xs0)
 
 
-@pytest.mark.parametrize("n,m", [(10000, 49975), (12000, 30000)])
+@pytest.mark.parametrize("n,m", [(10000, 49975), (12000, 30000), (9000, 27000), (9001, 27000)])
 def test_round_kernels_beyond_the_fused_kernel(n, m):
-    """Graphs the fused kernel does not fit (N = 10^4: rd_std in LDS; N = 12 000: rd_std read from global memory): every round
+    """Graphs the fused kernel does not fit (N = 10^4: rd_std in LDS; N = 12 000: rd_std read from global memory; N = 9000 -- a Gset
+    size -- and 9001: rows that are not 16-byte multiples, read on a padded pitch / through the funnel-shift stage): every round
     keeps cuts non-decreasing and consistent, touches only rows it accepts, and proposes about num_spin flips per env."""
     from rlsolver_amd import ops
     from rlsolver_amd.envs.env_L2A import EnvMaxcut
@@ -145,11 +148,14 @@ def test_round_kernels_beyond_the_fused_kernel(n, m):
     torch.manual_seed(3)
     xs = env.generate_xs_randomly(B)
     vs = env.calculate_obj_values(xs)
-    ws, span = ops.maxcut_ls_weights(env.graph, xs, 1)
+    ws, span = ops.maxcut_ls_weights(env.graph, xs, 1, padded=True)
+    assert ws.shape[1] % 16 == 0 and 0 <= ws.shape[1] - n < 16
+    ws_flat, span_flat = ops.maxcut_ls_weights(env.graph, xs, 1)
+    assert torch.equal(ws[:, :n], ws_flat) and torch.equal(span, span_flat)
     rd_std = (span.float() * 0.3).contiguous()
     thresh = ops.maxcut_ls_threshold(env.graph, ws, rd_std, seed=99, num_spin=num_spin)
     assert thresh.shape == (B,) and bool(torch.isfinite(thresh).all())
-    assert bool((thresh > ws.float().mean(dim=1)).all())            # the 9th largest of 10^4 noisy weights sits in the upper tail
+    assert bool((thresh > ws_flat.float().mean(dim=1)).all())       # the 9th largest of 10^4 noisy weights sits in the upper tail
     flips = []
     for it in range(1, 5):
         x0, v0 = xs.clone(), vs.clone()
