@@ -88,6 +88,7 @@ SIGNATURES = {
     "rls_maxcut_local_search": [_G, _P, _I64, _P, C.c_int32, _P, _P, _U64, _I64, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P],
     "rls_maxcut_ls_threshold": [_G, _I64, _P, C.c_int32, _I64, _P, _U64, _I64, C.c_int32, C.c_int32, _P, _P, _I64, _P],
     "rls_maxcut_ls_propose": [_G, _P, _I64, _P, C.c_int32, _I64, _P, _P, _U64, _I64, C.c_int32, _P, _P, _I64, _P],
+    "rls_maxcut_ls_rounds": [_G, _P, _I64, _P, C.c_int32, _I64, _P, _P, _U64, _I64, C.c_int32, C.c_int32, _P, _P, _I64, _P],
     "rls_select_better_rows": [_P, _P, _P, _P, _I64, _I64, _INT, _P],
     "rls_pick_best_of_repeats": [_P, _P, _I64, _I64, _I64, _INT, _P, _P, _P],
     "rls_rand_spins": [_P, _I64, _I64, _U64, _I64, _P],
@@ -130,7 +131,7 @@ PLAIN = {"rls_version": ([], _INT), "rls_device_count": ([], _INT), "rls_last_er
          "rls_mcpg_local_search_levels_supported": ([_G, _I64], _INT),
          "rls_maxcut_ls_rounds_supported": ([_G, C.c_int32], _INT),
          "rls_maxcut_node_stats_form": ([_G, _I64, C.c_int32], _INT),
-         "rls_maxcut_ls_scratch_bytes": ([_G, _I64, C.c_int32], _I64)}
+         "rls_maxcut_ls_scratch_bytes": ([_G, _I64, C.c_int32, C.c_int32], _I64)}
 
 _lib = None
 _lock = threading.Lock()

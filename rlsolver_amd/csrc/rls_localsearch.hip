@@ -614,6 +614,50 @@ __global__ __launch_bounds__(kLsRoundWaves * kWave) void k_ls_propose(uint8_t* _
     else tile_store_bytes<false>(x, B, N, b0, words, lane, w, W, accept, stage);
 }
 
+// All the proposal rounds of a small batch on ONE load of the tile: the mask words of every round come from k_ls_mask
+// (maskw[round][tile][node]; they depend on the weights, the threshold and the draw, not on x), a round is XOR -> count ->
+// accept -> XOR back where rejected, the tile goes out once.  Per round that is two passes over 8 N bytes of L2-resident mask
+// words instead of a tile load from and a tile store to HBM plus a launch (BA n = 10^4, 4096 envs: 47 us per round).
+template <int P>
+__global__ __launch_bounds__(kLsRoundWaves * kWave) void k_ls_apply_rounds(uint8_t* __restrict__ x, int64_t B, int64_t N,
+                                                                           const int32_t* __restrict__ eu, const int32_t* __restrict__ ev,
+                                                                           int64_t E, int halve, const uint64_t* __restrict__ maskw,
+                                                                           int rounds, int64_t* __restrict__ obj, int x_aligned) {
+    constexpr int W = kLsRoundWaves;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* words = reinterpret_cast<uint64_t*>(smem);
+    int64_t* scratch = reinterpret_cast<int64_t*>(words + ((N + 1) & ~1ll));
+    unsigned char* stages = reinterpret_cast<unsigned char*>(scratch + W * kWave);
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    const int64_t b0 = (int64_t)blockIdx.x * kWave, b = b0 + lane;
+    const bool valid = b < B;
+    unsigned char* stage = stages + (size_t)w * kStageBytes;
+    if (x_aligned) tile_load_bits<uint8_t, true>(x, B, N, b0, words, lane, w, W, stage);
+    else tile_load_bits<uint8_t, false>(x, B, N, b0, words, lane, w, W, stage);
+    int64_t my_obj = valid ? obj[b] : 0;
+    bool changed = false;
+    __syncthreads();
+    for (int r = 0; r < rounds; ++r) {
+        const uint64_t* mw = maskw + ((int64_t)r * gridDim.x + blockIdx.x) * N;
+        for (int64_t n = threadIdx.x; n < N; n += W * kWave) words[n] ^= mw[n];
+        __syncthreads();
+        int64_t total = block_sum_partials<W>(tile_cut_count<P>(words, eu, ev, E, lane, w, W), scratch, lane, w);
+        if (halve) total >>= 1;
+        const bool accept = valid && (total >= my_obj);          // update_xs_by_vs: vs1.ge(vs0)
+        if (accept) my_obj = total;
+        changed = changed || accept;
+        const uint64_t am = ballot64(accept);
+        __syncthreads();
+        if (~am)
+            for (int64_t n = threadIdx.x; n < N; n += W * kWave) words[n] ^= mw[n] & ~am;
+        __syncthreads();
+    }
+    if (w == 0 && valid) obj[b] = my_obj;
+    if (x_aligned) tile_store_bytes<true>(x, B, N, b0, words, lane, w, W, changed, stage);
+    else tile_store_bytes<false>(x, B, N, b0, words, lane, w, W, changed, stage);
+}
+
 static bool ls_sd_global() {   // dev knob: rd_std read from global memory even where it fits LDS
     static const bool on = getenv("RLS_LS_SD_GLOBAL") != nullptr;
     return on;
@@ -627,10 +671,10 @@ static int ls_slices(int64_t B, int64_t nchunks) {
     if ((int64_t)S * 2 * kLsRoundWaves > nchunks) S = (int)(nchunks / (2 * kLsRoundWaves));   // a slice keeps every wave busy
     return S < 1 ? 1 : S;
 }
-static size_t ls_scratch_bytes(int64_t B, int64_t N, int S) {
+static size_t ls_scratch_bytes(int64_t B, int64_t N, int S, int rounds = 1) {   // rounds: mask words of that many rounds at once
     if (S <= 1) return 0;
     const size_t tiles = (size_t)ceil_div(B, kWave);
-    const size_t lists = tiles * S * kTopCap * kWave * 4, masks = tiles * (size_t)N * 8;
+    const size_t lists = tiles * S * kTopCap * kWave * 4, masks = tiles * (size_t)N * 8 * (size_t)(rounds > 1 ? rounds : 1);
     return lists > masks ? lists : masks;
 }
 // (rd_std always fits LDS beside the stages here: 4 N bytes, N bounded by the proposal kernel's tile)
@@ -745,11 +789,11 @@ extern "C" int rls_maxcut_ls_rounds_supported(const rls_graph* g, int32_t num_sp
 
 // bytes of caller-provided scratch with which the two entry points below split a tile's noise pass over several workgroups
 // (0: the batch alone fills the chip, or the rows are too short to split); without it they run one workgroup per tile
-extern "C" int64_t rls_maxcut_ls_scratch_bytes(const rls_graph* g, int64_t B, int32_t ws_bytes) {
+extern "C" int64_t rls_maxcut_ls_scratch_bytes(const rls_graph* g, int64_t B, int32_t ws_bytes, int32_t num_draws) {
     if (!g || g->num_nodes <= 0 || B <= 0 || (ws_bytes != 1 && ws_bytes != 2)) return 0;
     const int64_t N = g->num_nodes;
     const int64_t nch = ws_bytes == 1 ? ls_num_chunks<int8_t>(N) : ls_num_chunks<int16_t>(N);
-    return (int64_t)ls_scratch_bytes(B, N, ls_slices(B, nch));
+    return (int64_t)ls_scratch_bytes(B, N, ls_slices(B, nch), num_draws);
 }
 
 // ws rows start ws_pitch ENTRIES apart (0 = N): any N works once the pitch is a multiple of 16 bytes
@@ -849,4 +893,53 @@ extern "C" int rls_maxcut_ls_propose(const rls_graph* g, uint8_t* x, int64_t B, 
 #undef DISPATCH_PR
 #undef LAUNCH_PR
     return check_launch("k_ls_propose");
+}
+
+// num_draws proposal rounds (draws first_draw .. first_draw + num_draws - 1) in place.  A small batch with enough scratch for all
+// rounds' mask words (rls_maxcut_ls_scratch_bytes(.., num_draws)) gets them from num_draws mask launches and applies them on one
+// load of the tile; otherwise one rls_maxcut_ls_propose per round.  Same result either way.
+extern "C" int rls_maxcut_ls_rounds(const rls_graph* g, uint8_t* x, int64_t B, const void* ws, int32_t ws_bytes, int64_t ws_pitch,
+                                    const float* rd_std, const float* thresh, uint64_t seed, int64_t env_offset, int32_t first_draw,
+                                    int32_t num_draws, int64_t* obj, void* scratch, int64_t scratch_bytes, void* stream) {
+    if (int rc = check_graph(g)) return rc;
+    RLS_REQUIRE(B >= 0 && first_draw >= 0 && num_draws >= 0, RLS_EINVAL, "bad sizes");
+    if (B == 0 || num_draws == 0) return RLS_OK;
+    RLS_REQUIRE(x && ws && rd_std && thresh && obj, RLS_EINVAL, "NULL pointer");
+    RLS_REQUIRE(ws_bytes == 1 || ws_bytes == 2, RLS_EINVAL, "ws_bytes must be 1 or 2 (rls_maxcut_ls_weights writes either)");
+    const int64_t N = g->num_nodes, E = g->num_stored_edges;
+    if (ws_pitch == 0) ws_pitch = N;
+    const int S = ls_slices(B, ws_bytes == 1 ? ls_num_chunks<int8_t>(N) : ls_num_chunks<int16_t>(N));
+    static const bool per_round = getenv("RLS_LS_PER_ROUND") != nullptr;   // dev knob: one propose launch per round
+    const bool all_at_once = !per_round && S > 1 && num_draws > 1 && scratch && (((uintptr_t)scratch) & 15) == 0 &&
+                             (size_t)scratch_bytes >= ls_scratch_bytes(B, N, S, num_draws) && ls_pitch_ok(ws, ws_pitch, ws_bytes, N) &&
+                             ls_propose_lds(N, false) <= (size_t)kLdsBytes && pick_planes(E) != 0;
+    if (!all_at_once) {
+        for (int32_t r = 0; r < num_draws; ++r)
+            if (int rc = rls_maxcut_ls_propose(g, x, B, ws, ws_bytes, ws_pitch, rd_std, thresh, seed, env_offset, first_draw + r, obj, scratch,
+                                               scratch_bytes, stream))
+                return rc;
+        return RLS_OK;
+    }
+    const dim3 grid((unsigned)ceil_div(B, kWave)), block(kLsRoundWaves * kWave), gm(grid.x, (unsigned)S);
+    hipStream_t s = as_stream(stream);
+    const size_t ldm = ls_mask_lds(N);
+    for (int32_t r = 0; r < num_draws; ++r) {
+        uint64_t* out = (uint64_t*)scratch + (size_t)r * grid.x * (size_t)N;
+        if (ws_bytes == 1) {
+            auto kern = k_ls_mask<int8_t>;
+            if (ldm > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldm);
+            hipLaunchKernelGGL(kern, gm, block, ldm, s, (const int8_t*)ws, ws_pitch, B, N, rd_std, thresh, seed, env_offset, (int)(first_draw + r), out);
+        } else {
+            auto kern = k_ls_mask<int16_t>;
+            if (ldm > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldm);
+            hipLaunchKernelGGL(kern, gm, block, ldm, s, (const int16_t*)ws, ws_pitch, B, N, rd_std, thresh, seed, env_offset, (int)(first_draw + r), out);
+        }
+    }
+    if (int rc = check_launch("k_ls_mask")) return rc;
+    const size_t lds = ls_propose_lds(N, false);
+    const int halve = g->if_bidirectional ? 1 : 0, x_aligned = tile_rows_aligned(x, N, 1) ? 1 : 0;
+    auto kern = k_ls_apply_rounds<24>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, grid, block, lds, s, x, B, N, g->eu, g->ev, E, halve, (const uint64_t*)scratch, (int)num_draws, obj, x_aligned);
+    return check_launch("k_ls_apply_rounds");
 }

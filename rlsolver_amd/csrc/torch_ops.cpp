@@ -241,6 +241,23 @@ void maxcut_ls_propose(int64_t g, Tensor xs, const Tensor& ws, const Tensor& rd_
                              env_offset, (int32_t)draw, (int64_t*)p(obj), p(scratch), scratch_of(scratch), cur_stream(xs)),
        "rls_maxcut_ls_propose");
 }
+void maxcut_ls_rounds(int64_t g, Tensor xs, const Tensor& ws, const Tensor& rd_std, const Tensor& thresh, int64_t seed,
+                      int64_t env_offset, int64_t first_draw, int64_t num_draws, Tensor obj, const OptTensor& scratch) {
+    spin_bytes(xs, "xs", false);
+    const int64_t B = env_rows(xs, "xs", G(g)), N = G(g)->num_nodes;
+    const int wb = ws_bytes_of(ws, false);
+    TORCH_CHECK(ws.dim() == 2 && ws.size(0) == B && ws.size(1) >= N, "ws must be [", B, ", >= ", N, "], got ", ws.sizes());
+    dev(rd_std, "rd_std", F32);
+    count(rd_std, "rd_std", N);
+    dev(thresh, "thresh", F32);
+    count(thresh, "thresh", B);
+    dev(obj, "obj", I64);
+    count(obj, "obj", B);
+    RLS_GUARD(xs);
+    ok(rls_maxcut_ls_rounds(G(g), (uint8_t*)p(xs), B, p(ws), wb, ws.size(1), (const float*)p(rd_std), (const float*)p(thresh), (uint64_t)seed,
+                            env_offset, (int32_t)first_draw, (int32_t)num_draws, (int64_t*)p(obj), p(scratch), scratch_of(scratch), cur_stream(xs)),
+       "rls_maxcut_ls_rounds");
+}
 void select_better_rows(Tensor xs0, Tensor vs0, const Tensor& xs1, const Tensor& vs1, bool if_maximize) {
     spin_bytes(xs0, "xs0", false);
     spin_bytes(xs1, "xs1", false);
@@ -789,6 +806,8 @@ TORCH_LIBRARY(rlsolver_hip, m) {
     m.def("maxcut_ls_threshold(int graph, Tensor ws, Tensor rd_std, int seed, int env_offset, int draw, int num_spin, Tensor(a!) thresh, Tensor(b!)? scratch) -> ()");
     m.def("maxcut_ls_propose(int graph, Tensor(a!) xs, Tensor ws, Tensor rd_std, Tensor thresh, int seed, int env_offset, int draw, "
           "Tensor(b!) obj, Tensor(c!)? scratch) -> ()");
+    m.def("maxcut_ls_rounds(int graph, Tensor(a!) xs, Tensor ws, Tensor rd_std, Tensor thresh, int seed, int env_offset, int first_draw, "
+          "int num_draws, Tensor(b!) obj, Tensor(c!)? scratch) -> ()");
     m.def("select_better_rows(Tensor(a!) xs0, Tensor(b!) vs0, Tensor xs1, Tensor vs1, bool if_maximize) -> ()");
     m.def("pick_best_of_repeats(Tensor xs, Tensor vs, int R, bool if_maximize, Tensor(a!) good_xs, Tensor(b!) good_vs) -> ()");
     m.def("copy_rows(Tensor(a!) xs, Tensor(b!)? vs, Tensor dst, Tensor src) -> ()");
@@ -851,6 +870,7 @@ TORCH_LIBRARY_IMPL(rlsolver_hip, CUDA, m) {   // "CUDA" is the HIP dispatch key 
     m.impl("maxcut_local_search", &maxcut_local_search);
     m.impl("maxcut_ls_threshold", &maxcut_ls_threshold);
     m.impl("maxcut_ls_propose", &maxcut_ls_propose);
+    m.impl("maxcut_ls_rounds", &maxcut_ls_rounds);
     m.impl("select_better_rows", &select_better_rows);
     m.impl("pick_best_of_repeats", &pick_best_of_repeats);
     m.impl("copy_rows", &copy_rows);

@@ -141,10 +141,10 @@ class EnvMaxcut:
             # the same steps as kernels with the fused kernel's draws (same seed => the fused kernel's result): graphs too
             # large for the fused kernel's LDS layout
             seed = _seed_from_torch()
-            scratch = ops.ls_scratch(self.graph, B, ws32)      # small batches: a tile's noise pass over several workgroups
+            # small batches: a tile's noise pass over several workgroups, all rounds applied on one load of the tile
+            scratch = ops.ls_scratch(self.graph, B, ws32, num_draws=num_iters)
             thresh = ops.maxcut_ls_threshold(self.graph, ws32, rd_std, seed, num_spin, draw=0, scratch=scratch)
-            for it in range(0 if first_draw_proposes else 1, num_iters + (0 if first_draw_proposes else 1)):
-                ops.maxcut_ls_propose(self.graph, xs, ws32, rd_std, thresh, vs, seed, draw=it, scratch=scratch)
+            ops.maxcut_ls_rounds(self.graph, xs, ws32, rd_std, thresh, vs, seed, 0 if first_draw_proposes else 1, num_iters, scratch=scratch)
             ops.maxcut_greedy_sweep(self.graph, xs, vs)
             return
         draws = (lambda t: noise[t]) if noise is not None else (lambda t: th.randn((B, self.num_nodes), device=self.device))

@@ -299,10 +299,10 @@ def ls_rounds_supported(g: DeviceGraph, num_spin: int) -> bool:
     return bool(_abi.lib().rls_maxcut_ls_rounds_supported(g.ref, int(num_spin)))
 
 
-def ls_scratch(g: DeviceGraph, B: int, ws: TEN) -> Optional[TEN]:
-    """The scratch buffer with which the round kernels split a small batch's noise passes over more workgroups (None when
-    there is nothing to gain: rls_maxcut_ls_scratch_bytes)."""
-    n = int(_abi.lib().rls_maxcut_ls_scratch_bytes(g.ref, int(B), ws.element_size()))
+def ls_scratch(g: DeviceGraph, B: int, ws: TEN, num_draws: int = 1) -> Optional[TEN]:
+    """The scratch buffer with which the round kernels split a small batch's noise passes over more workgroups -- sized for the
+    mask words of ``num_draws`` rounds at once (maxcut_ls_rounds) -- or None when there is nothing to gain."""
+    n = int(_abi.lib().rls_maxcut_ls_scratch_bytes(g.ref, int(B), ws.element_size(), int(num_draws)))
     return torch.empty(n, dtype=torch.uint8, device=g.device) if n > 0 else None
 
 
@@ -330,6 +330,20 @@ def maxcut_ls_propose(g: DeviceGraph, xs: TEN, ws: TEN, rd_std: TEN, thresh: TEN
     _check(thresh, "thresh", (torch.float32,), g.device, (B,))
     _check(obj, "obj", (torch.int64,), g.device, (B,))
     _t.maxcut_ls_propose(g.handle, xs, ws, rd_std, thresh, _s64(seed), env_offset, int(draw), obj, scratch)
+
+
+def maxcut_ls_rounds(g: DeviceGraph, xs: TEN, ws: TEN, rd_std: TEN, thresh: TEN, obj: TEN, seed: int, first_draw: int, num_draws: int,
+                     env_offset: int = 0, scratch: Optional[TEN] = None) -> None:
+    """``num_draws`` proposal rounds in place (draws first_draw, first_draw + 1, ...): maxcut_ls_propose per round, or -- small
+    batch, scratch from ls_scratch(.., num_draws) -- every round's mask words first and all rounds on one load of each tile."""
+    B, _ = _spins(xs, "xs", g)
+    _check(ws, "ws", (torch.int8, torch.int16), g.device)
+    if ws.dim() != 2 or ws.shape[0] != B or ws.shape[1] < g.num_nodes:
+        raise ValueError(f"ws must be [{B}, >= {g.num_nodes}]")
+    _check(rd_std, "rd_std", (torch.float32,), g.device, (g.num_nodes,))
+    _check(thresh, "thresh", (torch.float32,), g.device, (B,))
+    _check(obj, "obj", (torch.int64,), g.device, (B,))
+    _t.maxcut_ls_rounds(g.handle, xs, ws, rd_std, thresh, _s64(seed), env_offset, int(first_draw), int(num_draws), obj, scratch)
 
 
 def select_better_rows(xs0: TEN, vs0: TEN, xs1: TEN, vs1: TEN, if_maximize: bool = True) -> None:
