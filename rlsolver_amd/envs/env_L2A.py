@@ -55,6 +55,7 @@ class EnvMaxcut:
         self._adjacency_bool = None
         self.fused_local_search = True   # False: K2 + torch weights/noise/kthvalue + K6 + K5 as separate launches
         self.force_ls_rounds = False     # True: the threshold / proposal-round kernels even where the fused kernel fits (tests)
+        self.force_ls_fused = False      # True: the fused kernel wherever it fits, also for batches of few tiles (tests)
 
     # ---- lazily built forms of the reference attributes
     @property
@@ -122,9 +123,15 @@ class EnvMaxcut:
         One pre-pass + ONE fused kernel when the library covers the shape (rls_maxcut_local_search_supported), else
         K2-weights + torch noise / kthvalue + K6 per round + K5."""
         B = xs.shape[0]
-        fused_ok = self.fused_local_search and not self.force_ls_rounds and ops.local_search_fusable(self.graph, num_spin, B)
-        rounds_ok = (not fused_ok and noise is None and (self.fused_local_search or self.force_ls_rounds)
-                     and ops.ls_weight_dtype(self.graph, weight_mult) != th.int32 and ops.ls_rounds_supported(self.graph, num_spin))
+        wdt = ops.ls_weight_dtype(self.graph, weight_mult)
+        rounds_can = (noise is None and (self.fused_local_search or self.force_ls_rounds) and wdt != th.int32
+                      and ops.ls_rounds_supported(self.graph, num_spin))
+        # a batch of few tiles: the round kernels spread each tile's noise passes over several workgroups and beat the fused
+        # kernel's one workgroup per tile (G22-sized, 256 - 8192 envs: 0.32 - 0.35 vs 0.39 - 0.41 ms; same result bit for bit)
+        few_tiles = rounds_can and num_iters > 0 and not self.force_ls_fused and ops.ls_scratch_bytes(self.graph, B, wdt, num_iters) > 0
+        fused_ok = (self.fused_local_search and not self.force_ls_rounds and not few_tiles
+                    and ops.local_search_fusable(self.graph, num_spin, B))
+        rounds_ok = not fused_ok and rounds_can
         # exact integers (int8 / int16) in both env flavours; the round kernels read them on a 16-byte row pitch (any N)
         ws32, ws_span = ops.maxcut_ls_weights(self.graph, xs, weight_mult, padded=rounds_ok)
         rd_std = (ws_span.float() * noise_std).contiguous()

@@ -299,6 +299,12 @@ def ls_rounds_supported(g: DeviceGraph, num_spin: int) -> bool:
     return bool(_abi.lib().rls_maxcut_ls_rounds_supported(g.ref, int(num_spin)))
 
 
+def ls_scratch_bytes(g: DeviceGraph, B: int, ws_dtype, num_draws: int = 1) -> int:
+    """Bytes of scratch with which a batch this small splits its noise passes (0: the batch fills the chip by itself, or the
+    rows are too short to split) -- rls_maxcut_ls_scratch_bytes."""
+    return int(_abi.lib().rls_maxcut_ls_scratch_bytes(g.ref, int(B), torch.empty((), dtype=ws_dtype).element_size(), int(num_draws)))
+
+
 def ls_scratch(g: DeviceGraph, B: int, ws: TEN, num_draws: int = 1) -> Optional[TEN]:
     """The scratch buffer with which the round kernels split a small batch's noise passes over more workgroups -- sized for the
     mask words of ``num_draws`` rounds at once (maxcut_ls_rounds) -- or None when there is nothing to gain."""

@@ -124,6 +124,7 @@ def test_round_kernels_equal_the_fused_kernel_for_the_same_seed(n, m, B, bidir, 
         outs = []
         for rounds in (False, True):
             env.force_ls_rounds = rounds
+            env.force_ls_fused = not rounds
             torch.manual_seed(77)
             xs, vs = xs0.clone(), env.calculate_obj_values(xs0)
             env.local_search_pipeline(xs, vs, weight_mult=2 if first else 1, num_iters=5, num_spin=num_spin, noise_std=0.3, noise=None,

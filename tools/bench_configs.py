@@ -123,7 +123,10 @@ def local_search_suite(tag, n, m, seed, B, iters, mygraph=None):
     xs = env.generate_xs_randomly(B)
     vs = env.calculate_obj_values(xs)
     t = timeit(lambda i: env.local_search_inplace(xs, vs, num_iters=8, num_spin=8, noise_std=0.3), iters, warm=1)
-    form = ("ls_weights pre-pass + fused kernel: threshold, 8 proposal rounds, greedy sweep" if ops.local_search_fusable(env.graph, 8, B)
+    few = ops.ls_rounds_supported(env.graph, 8) and ops.ls_scratch_bytes(env.graph, B, ops.ls_weight_dtype(env.graph, 1), 8) > 0
+    form = ("ls_weights + threshold kernel + 8 mask kernels (a tile's rows over several workgroups) + all rounds on one tile load + K5: "
+            "a batch of few tiles" if few
+            else "ls_weights pre-pass + fused kernel: threshold, 8 proposal rounds, greedy sweep" if ops.local_search_fusable(env.graph, 8, B)
             else "ls_weights + threshold kernel + 8 proposal-round kernels + K5: a graph beyond the fused kernel's LDS layout"
             if ops.ls_rounds_supported(env.graph, 8) else "ls_weights + torch noise / kthvalue + 8 x K6 + K5")
     emit(tag, f"local_search_inplace ({form})", "candidate evaluations",

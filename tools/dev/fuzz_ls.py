@@ -60,12 +60,13 @@ while time.time() < t_end:
             res = []
             for rounds in (False, True):
                 env.force_ls_rounds = rounds
+                env.force_ls_fused = not rounds
                 torch.manual_seed(1000 + it)
                 xs, vs = xs0.clone(), env.calculate_obj_values(xs0)
                 env.local_search_pipeline(xs, vs, weight_mult=2 if first else 1, num_iters=num_iters, num_spin=num_spin, noise_std=0.3,
                                           noise=None, first_draw_proposes=first)
                 res.append((xs, vs))
-            env.force_ls_rounds = False
+            env.force_ls_rounds = env.force_ls_fused = False
             assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), "round kernels vs fused " + tag
             nrounds += 1
     it += 1

@@ -31,6 +31,7 @@ def main():
             out = []
             for rounds in (False, True):
                 env.force_ls_rounds = rounds
+                env.force_ls_fused = not rounds
                 out.append(timeit(lambda: env.local_search_inplace(xs, vs, num_iters=8, num_spin=8, noise_std=0.3)))
             print(f"{name} B={B}: fused {out[0]:.0f} us, round kernels {out[1]:.0f} us")
 
