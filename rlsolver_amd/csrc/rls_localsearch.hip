@@ -716,6 +716,7 @@ extern "C" int rls_maxcut_local_search_supported(const rls_graph* g, int64_t B, 
     if (num_spin < 0 || num_spin + 1 > kTopCap || num_spin >= N) return 0;
     if (g->wgt || g->max_degree >= kRingMaxRun) return 0;
     if (pick_planes(g->num_stored_edges) == 0) return 0;
+    if ((N & 3) != 0) return 0;   // rows that are not dword-aligned: the round kernels (any N, and faster there than an element-wise fused form was)
     return ls_pick_waves(N, B > 0 ? B : 1) != 0;
 }
 
@@ -735,9 +736,10 @@ extern "C" int rls_maxcut_local_search(const rls_graph* g, uint8_t* x, int64_t B
                 "fused local search needs an unweighted graph with max degree < %d", kRingMaxRun);
     // 16-byte row pieces of x, ws and noise: N % 16 == 0 and aligned bases
     const bool aligned = tile_rows_aligned(x, N, 1) && ((((uintptr_t)ws) | ((uintptr_t)noise)) & 15) == 0;
+    RLS_REQUIRE(aligned, RLS_EUNSUPPORTED, "fused local search needs rows of x, ws and noise that start 4-byte aligned on 16-byte bases "
+                "(N=%lld): rls_maxcut_ls_threshold / rls_maxcut_ls_rounds take any layout", (long long)N);
     int W = ls_pick_waves(N, B);
     RLS_REQUIRE(W != 0, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS (max %d)", (long long)N, ls_lds_bytes(N, 4), kLdsBytes);
-    if (!aligned) W = 4;                       // (the 4-wave layout is the smaller one: it fits whenever the 8-wave one does)
     const size_t lds = ls_lds_bytes(N, W);
     const int P = pick_planes(E);
     RLS_REQUIRE(P != 0, RLS_EUNSUPPORTED, "E'=%lld too large", (long long)E);
@@ -754,7 +756,7 @@ extern "C" int rls_maxcut_local_search(const rls_graph* g, uint8_t* x, int64_t B
     const int64_t sw_len = batched == 2 ? g->num_sweep_groups : (batched ? g->nnz + N : g->nnz);
 #define LAUNCH_LSF(AL, WT, PP)                                                                                       \
     do {                                                                                                             \
-        auto kern = (W == 8 && AL) ? k_maxcut_local_search<AL, WT, PP, AL ? 8 : 4> : k_maxcut_local_search<AL, WT, PP, 4>; \
+        auto kern = W == 8 ? k_maxcut_local_search<AL, WT, PP, 8> : k_maxcut_local_search<AL, WT, PP, 4>;             \
         if (lds > 64 * 1024)                                                                                         \
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
         hipLaunchKernelGGL(kern, grid, block, lds, s, x, B, N, g->eu, g->ev, E, halve, rp_src, sw_src, sw_len,        \
@@ -769,10 +771,9 @@ extern "C" int rls_maxcut_local_search(const rls_graph* g, uint8_t* x, int64_t B
         case 16: LAUNCH_LSF(AL, WT, 16); break;   \
         default: LAUNCH_LSF(AL, WT, 24); break;   \
     }
-    // (rows that are not 16-byte multiples: the element-wise loader makes these the largest kernels of the library, 180-300 KB
-    // each, so they exist for the wide counter only -- a few more carry steps per 1024 edges on small graphs)
-    if (ws_bytes == 1) { if (aligned) { DISPATCH_P(true, int8_t) } else { LAUNCH_LSF(false, int8_t, 24); } }
-    else               { if (aligned) { DISPATCH_P(true, int16_t) } else { LAUNCH_LSF(false, int16_t, 24); } }
+    // (an element-wise form for rows that are not dword-aligned existed until round 3: 180 - 300 KB per instantiation, and slower
+    // there than the round kernels, which read the weights on a padded pitch)
+    if (ws_bytes == 1) { DISPATCH_P(true, int8_t) } else { DISPATCH_P(true, int16_t) }
 #undef DISPATCH_P
 #undef LAUNCH_LSF
     return check_launch("k_maxcut_local_search");

@@ -123,6 +123,8 @@ class EnvMaxcut:
         One pre-pass + ONE fused kernel when the library covers the shape (rls_maxcut_local_search_supported), else
         K2-weights + torch noise / kthvalue + K6 per round + K5."""
         B = xs.shape[0]
+        if noise is not None:
+            noise = noise.to(device=self.device, dtype=th.float32).contiguous()
         wdt = ops.ls_weight_dtype(self.graph, weight_mult)
         rounds_can = (noise is None and (self.fused_local_search or self.force_ls_rounds) and wdt != th.int32
                       and ops.ls_rounds_supported(self.graph, num_spin))
@@ -130,13 +132,12 @@ class EnvMaxcut:
         # kernel's one workgroup per tile (G22-sized, 256 - 8192 envs: 0.32 - 0.35 vs 0.39 - 0.41 ms; same result bit for bit)
         few_tiles = rounds_can and num_iters > 0 and not self.force_ls_fused and ops.ls_scratch_bytes(self.graph, B, wdt, num_iters) > 0
         fused_ok = (self.fused_local_search and not self.force_ls_rounds and not few_tiles
-                    and ops.local_search_fusable(self.graph, num_spin, B))
+                    and ops.local_search_fusable(self.graph, num_spin, B)
+                    and xs.data_ptr() % 16 == 0 and (noise is None or noise.data_ptr() % 16 == 0))   # (views that start mid-row)
         rounds_ok = not fused_ok and rounds_can
         # exact integers (int8 / int16) in both env flavours; the round kernels read them on a 16-byte row pitch (any N)
         ws32, ws_span = ops.maxcut_ls_weights(self.graph, xs, weight_mult, padded=rounds_ok)
         rd_std = (ws_span.float() * noise_std).contiguous()
-        if noise is not None:
-            noise = noise.to(device=self.device, dtype=th.float32).contiguous()
         if fused_ok and (num_iters > 0 or not first_draw_proposes):
             ops.maxcut_local_search(self.graph, xs, ws32, rd_std, vs, num_iters, num_spin, noise=noise,
                                     seed=0 if noise is not None else _seed_from_torch(),

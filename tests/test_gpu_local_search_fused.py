@@ -26,7 +26,8 @@ def test_local_search_inplace_golden_both_paths(golden, gname, bidir, fused):
     env.fused_local_search = fused
     tag = f"{gname}/bidir{int(bidir)}"
     num_spin = int(z[f"{tag}/ls/num_spin"])
-    assert ops.local_search_fusable(env.graph, num_spin)
+    # (rows that are not dword-aligned -- the 14-node stub -- have no fused form: both legs take the decomposed path there)
+    assert ops.local_search_fusable(env.graph, num_spin) == (env.num_nodes % 4 == 0)
     xs = to_dev_bool(z[f"{tag}/ls/xs_in"]).clone()
     noise = torch.from_numpy(z[f"{tag}/ls/noise"]).to(DEV)
     gx, gv = env.local_search_inplace(xs, torch.empty(()), num_iters=8, num_spin=num_spin, noise_std=0.3, noise=noise)
