@@ -1,4 +1,5 @@
-"""The local-search weights pre-pass at small batches: time per call (the form is chosen by the dev knob RLS_LS_WEIGHTS_FORM)."""
+"""The local-search weights pre-pass at small batches: time per call.  Forms: RLS_NODE_STATS_MIN_B=0 forces the bit-sliced kernel,
+RLS_NODE_STATS_MIN_B=1000000000 the element-parallel one (the lane = env tile form this tool measured at 850 us per call is gone)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
@@ -16,4 +17,4 @@ for name, n, mg in (("G22", 2000, generate_gnm(2000, 19990, 22)), ("G14", 800, g
         for _ in range(10): ops.maxcut_ls_weights(g, xs, 1)
         e1.record(); torch.cuda.synchronize()
         row.append(f"B={B}: {e0.elapsed_time(e1) * 100:.0f}")
-    print(os.environ.get("RLS_LS_WEIGHTS_FORM", "default"), name, " ".join(row), "us")
+    print("min_b=" + os.environ.get("RLS_NODE_STATS_MIN_B", "auto"), name, " ".join(row), "us")
