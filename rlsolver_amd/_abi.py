@@ -143,6 +143,10 @@ def lib() -> C.CDLL:
     if _lib is None:
         with _lock:
             if _lib is None:
+                # torch first: it ships its own libamdhip64; whichever copy of that soname is loaded first serves the whole process,
+                # and with the system copy in place torch.cuda.is_available() turns False (seen with build() -> smoke() in one
+                # interpreter that had not imported torch yet)
+                import torch  # noqa: F401
                 if not os.path.exists(LIB_PATH):
                     raise ImportError(
                         f"{LIB_PATH} is missing: the HIP extension has not been built "
