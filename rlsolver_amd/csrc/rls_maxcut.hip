@@ -170,7 +170,7 @@ template <bool VEC, int SW, int P>
 __global__ __launch_bounds__(SW * kWave) void k_maxcut_greedy_sweep_levels(
     uint8_t* __restrict__ x, int64_t B, int64_t N, const int32_t* __restrict__ lv_ptr,
     const int32_t* __restrict__ lv_data, int64_t G, const int32_t* __restrict__ eu, const int32_t* __restrict__ ev,
-    int64_t E, int halve, int64_t* __restrict__ obj) {
+    int64_t E, int halve, int64_t* __restrict__ obj, int has_stage) {   // has_stage 0: the tile fills LDS (N ~ 20 000)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* words = reinterpret_cast<uint64_t*>(smem);
     int32_t* lvp = reinterpret_cast<int32_t*>(smem + (size_t)(N + 2) * 8);
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(SW * kWave) void k_maxcut_greedy_sweep_levels(
     const int64_t b0 = (int64_t)blockIdx.x * kWave;
     if (threadIdx.x == 0) words[N] = 0;
     for (int64_t i = threadIdx.x; i <= G; i += SW * kWave) lvp[i] = lv_ptr[i];
-    unsigned char* stage = stages + (w % LW) * kStageBytes;
+    unsigned char* stage = has_stage ? stages + (w % LW) * kStageBytes : nullptr;
     if (w < LW) tile_load_bits<uint8_t, VEC>(x, B, N, b0, words, lane, w, LW, stage);
     __syncthreads();
     sweep_tile_levels<SW>(words, lvp, lv_data, G, N, lane, w);
@@ -469,14 +469,15 @@ __global__ __launch_bounds__(kNsWaves * kWave) void k_node_stats_bits(const uint
                                                                      const int32_t* __restrict__ ell_ptr,
                                                                      const int32_t* __restrict__ ell, int mult,
                                                                      void* __restrict__ out_v, int32_t* __restrict__ minmax,
-                                                                     int64_t out_pitch) {   // row pitch of out_v in elements (MODE 2; N otherwise)
+                                                                     int64_t out_pitch,     // row pitch of out_v in elements (MODE 2; N otherwise)
+                                                                     int has_stage) {       // 0: the tile alone fills LDS (N ~ 20 000): lane-per-env loads
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* words = reinterpret_cast<uint64_t*>(smem);
     const int lane = threadIdx.x & (kWave - 1);
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     unsigned char* stage = smem + (((size_t)N * 8 + 15) & ~(size_t)15) + (size_t)w * kStageBytes;
     const int64_t b0 = (int64_t)blockIdx.x * kWave;
-    tile_load_bits<uint8_t, VEC>(x, B, N, b0, words, lane, w, kNsWaves, stage);
+    tile_load_bits<uint8_t, VEC>(x, B, N, b0, words, lane, w, kNsWaves, has_stage ? stage : nullptr);
     __syncthreads();
     const int64_t G = (N + 63) >> 6;
     const int nenv = (int)((B - b0) < kWave ? (B - b0) : kWave);
@@ -586,8 +587,8 @@ __global__ __launch_bounds__(kNsWaves * kWave) void k_node_stats_bits(const uint
     }
 }
 
-static inline size_t node_stats_bits_lds(int64_t N) {
-    return (((size_t)N * 8 + 15) & ~(size_t)15) + (size_t)kNsWaves * kStageBytes;
+static inline size_t node_stats_bits_lds(int64_t N, bool with_stage = true) {
+    return (((size_t)N * 8 + 15) & ~(size_t)15) + (with_stage ? (size_t)kNsWaves * kStageBytes : 0);
 }
 // the bit-sliced kernel needs the slabs, an unweighted graph, byte-sized counters and a tile that fits.  A tile costs about
 // 0.011 us per node however few envs it holds, the element-parallel kernels about 2e-6 us per (env, node + entry): K3 on a
@@ -601,14 +602,15 @@ static inline bool node_stats_batch_fills_tiles(const rls_graph* g, int64_t B) {
 static inline bool node_stats_use_bits(const rls_graph* g, const int32_t* ell_ptr, const int32_t* ell, int64_t B) {
     static const bool off = getenv("RLS_NODE_STATS_LANE_ENV") != nullptr;   // dev knob: the lane = env kernels
     return !off && ell_ptr && ell && !g->wgt && g->max_degree < 65536 && node_stats_batch_fills_tiles(g, B) &&
-           node_stats_bits_lds(g->num_nodes) <= (size_t)kLdsBytes;
+           node_stats_bits_lds(g->num_nodes, false) <= (size_t)kLdsBytes;   // (without the row-piece stage if need be)
 }
 template <int MODE, typename WT = int32_t>
 static int launch_node_stats_bits(const rls_graph* g, const uint8_t* x, int64_t B, const int32_t* rowptr,
                                   const int32_t* ell_ptr, const int32_t* ell, int mult, void* out, void* stream,
                                   int32_t* minmax = nullptr, int64_t out_pitch = 0) {
     const int64_t N = g->num_nodes;
-    const size_t lds = node_stats_bits_lds(N);
+    const int has_stage = node_stats_bits_lds(N, true) <= (size_t)kLdsBytes ? 1 : 0;
+    const size_t lds = node_stats_bits_lds(N, has_stage != 0);
     const dim3 grid((unsigned)ceil_div(B, kWave)), block(kNsWaves * kWave);
     const bool vec = tile_rows_aligned(x, N, 1);
     const bool wide = g->max_degree >= 256;
@@ -617,7 +619,7 @@ static int launch_node_stats_bits(const rls_graph* g, const uint8_t* x, int64_t 
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(kern, grid, block, lds, as_stream(stream), x, B, N, rowptr, ell_ptr, ell, mult, out, minmax,
-                       out_pitch > 0 ? out_pitch : N);
+                       out_pitch > 0 ? out_pitch : N, has_stage);
     return check_launch("k_node_stats_bits");
 }
 
@@ -891,8 +893,14 @@ int rls_maxcut_obj(const rls_graph* g, const void* x, int spin_bytes, int64_t B,
     RLS_REQUIRE(x && obj, RLS_EINVAL, "x/obj is NULL");
     RLS_REQUIRE(spin_bytes == 1 || spin_bytes == 4, RLS_EINVAL, "spin_bytes must be 1 or 4");
     const int64_t N = g->num_nodes, E = g->num_stored_edges;
-    const int tw = tile_waves_for(N);
+    int tw = tile_waves_for(N);
     size_t lds = (size_t)N * 8 + (size_t)tw * kWave * 8;
+    if (lds > (size_t)kLdsBytes && (size_t)N * 8 + (size_t)kTileWaves * kWave * 8 <= (size_t)kLdsBytes) {
+        // the tile alone still fits (N <= 20 224: Gset's 20 000-node G81): 4 waves, no row-piece stage (lane-per-env loads at
+        // ~2.5 TB/s) -- an order of magnitude ahead of the one-env-per-wave form below
+        tw = kTileWaves;
+        lds = (size_t)N * 8 + (size_t)tw * kWave * 8;
+    }
     if (lds > (size_t)kLdsBytes) {   // the 64-env bit tile does not fit: one env per wave on a byte row
         const int rw = rows_waves(N);
         RLS_REQUIRE(rw > 0, RLS_EUNSUPPORTED, "N=%lld: a row of %lld bytes does not fit LDS (max %d)", (long long)N, (long long)N, kLdsBytes);
@@ -946,8 +954,12 @@ int rls_maxcut_propose_accept(const rls_graph* g, uint8_t* x, int64_t B, const u
     if (B == 0) return RLS_OK;
     RLS_REQUIRE(x && mask && obj, RLS_EINVAL, "x/mask/obj is NULL");
     const int64_t N = g->num_nodes, E = g->num_stored_edges;
-    const int tw = tile_waves_for(N);
+    int tw = tile_waves_for(N);
     size_t lds = (size_t)N * 8 + (size_t)tw * kWave * 8;
+    if (lds > (size_t)kLdsBytes && (size_t)N * 8 + (size_t)kTileWaves * kWave * 8 <= (size_t)kLdsBytes) {
+        tw = kTileWaves;              // (as in rls_maxcut_obj: the tile alone fits, 4 waves without the row-piece stage)
+        lds = (size_t)N * 8 + (size_t)tw * kWave * 8;
+    }
     if (lds > (size_t)kLdsBytes) {   // the 64-env bit tile does not fit: one env per wave on a byte row
         const int rw = rows_waves(N);
         RLS_REQUIRE(rw > 0, RLS_EUNSUPPORTED, "N=%lld: a row does not fit LDS (max %d)", (long long)N, kLdsBytes);
@@ -1004,9 +1016,18 @@ int rls_maxcut_greedy_sweep(const rls_graph* g, uint8_t* x, int64_t B, int64_t* 
         static const int force_lw = getenv("RLS_SWEEP_WAVES") ? atoi(getenv("RLS_SWEEP_WAVES")) : 0;
         // one group per level (G22: 44 nodes per group): a level is ONE wave's pass and the others only prefetch -- few
         // waves, more tiles per CU; well-filled groups (G70: 9 levels of ~17 groups): 8 waves share a level
-        const int sw = force_lw == 2 || force_lw == 4 || force_lw == 8 || force_lw == 16 ? force_lw : (N >= 56 * G ? 8 : 4);
-        const size_t lds_l = (size_t)(N + 2) * 8 + (((size_t)(G + 1) * 4 + 15) & ~(size_t)15) + (size_t)sw * kWave * 8 +
-                             (size_t)kSweepLoadWaves * kStageBytes;
+        int sw = force_lw == 2 || force_lw == 4 || force_lw == 8 || force_lw == 16 ? force_lw : (N >= 56 * G ? 8 : 4);
+        auto lds_of = [&](int waves, bool stage) {
+            return (size_t)(N + 2) * 8 + (((size_t)(G + 1) * 4 + 15) & ~(size_t)15) + (size_t)waves * kWave * 8 +
+                   (stage ? (size_t)kSweepLoadWaves * kStageBytes : 0);
+        };
+        int has_stage = 1;
+        if (lds_of(sw, true) > (size_t)kLdsBytes) {   // the tile nearly fills LDS (N ~ 20 000): no row-piece stage, fewer waves
+            has_stage = 0;
+            if (lds_of(sw, false) > (size_t)kLdsBytes) sw = 4;
+            if (lds_of(sw, false) > (size_t)kLdsBytes) sw = 2;
+        }
+        const size_t lds_l = lds_of(sw, has_stage != 0);
         if (!no_levels && !g->wgt && g->sweep_lv_ptr && g->sweep_lv_data && G > 0 && P != 0 && lds_l <= (size_t)kLdsBytes) {
             const dim3 blockl(sw * kWave);
             const int halve = g->if_bidirectional ? 1 : 0;
@@ -1016,7 +1037,7 @@ int rls_maxcut_greedy_sweep(const rls_graph* g, uint8_t* x, int64_t B, int64_t* 
         if (lds_l > 64 * 1024)                                                                               \
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l); \
         hipLaunchKernelGGL(kern, grid, blockl, lds_l, s, x, B, N, g->sweep_lv_ptr, g->sweep_lv_data, G, g->eu, g->ev, \
-                           E, halve, obj);                                                                    \
+                           E, halve, obj, has_stage);                                                         \
     } while (0)
 #define DISPATCH_SWL_P(VEC, SWV)                       \
     switch (P) {                                       \
