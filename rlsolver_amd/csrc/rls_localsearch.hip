@@ -618,12 +618,12 @@ __global__ __launch_bounds__(kLsRoundWaves * kWave) void k_ls_propose(uint8_t* _
 // (maskw[round][tile][node]; they depend on the weights, the threshold and the draw, not on x), a round is XOR -> count ->
 // accept -> XOR back where rejected, the tile goes out once.  Per round that is two passes over 8 N bytes of L2-resident mask
 // words instead of a tile load from and a tile store to HBM plus a launch (BA n = 10^4, 4096 envs: 47 us per round).
-template <int P>
-__global__ __launch_bounds__(kLsRoundWaves * kWave) void k_ls_apply_rounds(uint8_t* __restrict__ x, int64_t B, int64_t N,
-                                                                           const int32_t* __restrict__ eu, const int32_t* __restrict__ ev,
-                                                                           int64_t E, int halve, const uint64_t* __restrict__ maskw,
-                                                                           int rounds, int64_t* __restrict__ obj, int x_aligned) {
-    constexpr int W = kLsRoundWaves;
+template <int P, int W>
+__global__ __launch_bounds__(W * kWave) void k_ls_apply_rounds(uint8_t* __restrict__ x, int64_t B, int64_t N,
+                                                               const int32_t* __restrict__ eu, const int32_t* __restrict__ ev,
+                                                               int64_t E, int halve, const uint64_t* __restrict__ maskw,
+                                                               int rounds, int64_t* __restrict__ obj, int x_aligned, int has_stage) {
+    // W = 8 with a row-piece stage per wave, or W = 4 without stages where the tile nearly fills LDS (N ~ 20 000)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* words = reinterpret_cast<uint64_t*>(smem);
     int64_t* scratch = reinterpret_cast<int64_t*>(words + ((N + 1) & ~1ll));
@@ -632,7 +632,7 @@ __global__ __launch_bounds__(kLsRoundWaves * kWave) void k_ls_apply_rounds(uint8
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     const int64_t b0 = (int64_t)blockIdx.x * kWave, b = b0 + lane;
     const bool valid = b < B;
-    unsigned char* stage = stages + (size_t)w * kStageBytes;
+    unsigned char* stage = has_stage ? stages + (size_t)w * kStageBytes : nullptr;
     if (x_aligned) tile_load_bits<uint8_t, true>(x, B, N, b0, words, lane, w, W, stage);
     else tile_load_bits<uint8_t, false>(x, B, N, b0, words, lane, w, W, stage);
     int64_t my_obj = valid ? obj[b] : 0;
@@ -658,6 +658,14 @@ __global__ __launch_bounds__(kLsRoundWaves * kWave) void k_ls_apply_rounds(uint8
     else tile_store_bytes<false>(x, B, N, b0, words, lane, w, W, changed, stage);
 }
 
+static size_t ls_apply_lds(int64_t N, int W, bool stage) {
+    return (size_t)((N + 1) & ~1ll) * 8 + (size_t)W * kWave * 8 + (stage ? (size_t)W * kStageBytes : 0);
+}
+// N beyond the proposal kernel's tile + stages but within the bare tile (15 500 < N <= 20 224): mask kernels + the 4-wave apply kernel
+static bool ls_big_tile(int64_t N) {
+    return (size_t)((N + 1) & ~1ll) * 8 + (size_t)kLsRoundWaves * kWave * 8 + (size_t)kLsRoundWaves * kStageBytes > (size_t)kLdsBytes &&
+           ls_apply_lds(N, 4, false) <= (size_t)kLdsBytes;
+}
 static bool ls_sd_global() {   // dev knob: rd_std read from global memory even where it fits LDS
     static const bool on = getenv("RLS_LS_SD_GLOBAL") != nullptr;
     return on;
@@ -785,7 +793,7 @@ extern "C" int rls_maxcut_ls_rounds_supported(const rls_graph* g, int32_t num_sp
     const int64_t N = g->num_nodes;
     if (num_spin < 0 || num_spin + 1 > kTopCap || num_spin >= N) return 0;
     if (pick_planes(g->num_stored_edges) == 0) return 0;
-    return ls_propose_lds(N, false) <= (size_t)kLdsBytes;
+    return ls_propose_lds(N, false) <= (size_t)kLdsBytes || ls_big_tile(N);   // (the latter needs the scratch buffer)
 }
 
 // bytes of caller-provided scratch with which the two entry points below split a tile's noise pass over several workgroups
@@ -794,6 +802,12 @@ extern "C" int64_t rls_maxcut_ls_scratch_bytes(const rls_graph* g, int64_t B, in
     if (!g || g->num_nodes <= 0 || B <= 0 || (ws_bytes != 1 && ws_bytes != 2)) return 0;
     const int64_t N = g->num_nodes;
     const int64_t nch = ws_bytes == 1 ? ls_num_chunks<int8_t>(N) : ls_num_chunks<int16_t>(N);
+    if (ls_big_tile(N)) {   // the mask words are how the rounds run at all here: every round's while that stays under 1 GB, else one round's
+        const size_t one = (size_t)ceil_div(B, kWave) * (size_t)N * 8, all = one * (size_t)(num_draws > 1 ? num_draws : 1);
+        const size_t lists = ls_scratch_bytes(B, N, ls_slices(B, nch), 1);
+        const size_t m = all <= ((size_t)1 << 30) ? all : one;
+        return (int64_t)(m > lists ? m : lists);
+    }
     return (int64_t)ls_scratch_bytes(B, N, ls_slices(B, nch), num_draws);
 }
 
@@ -839,6 +853,10 @@ extern "C" int rls_maxcut_ls_threshold(const rls_graph* g, int64_t B, const void
     return RLS_OK;
 }
 
+extern "C" int rls_maxcut_ls_rounds(const rls_graph* g, uint8_t* x, int64_t B, const void* ws, int32_t ws_bytes, int64_t ws_pitch,
+                                    const float* rd_std, const float* thresh, uint64_t seed, int64_t env_offset, int32_t first_draw,
+                                    int32_t num_draws, int64_t* obj, void* scratch, int64_t scratch_bytes, void* stream);
+
 extern "C" int rls_maxcut_ls_propose(const rls_graph* g, uint8_t* x, int64_t B, const void* ws, int32_t ws_bytes, int64_t ws_pitch,
                                      const float* rd_std, const float* thresh, uint64_t seed, int64_t env_offset, int32_t draw,
                                      int64_t* obj, void* scratch, int64_t scratch_bytes, void* stream) {
@@ -852,6 +870,8 @@ extern "C" int rls_maxcut_ls_propose(const rls_graph* g, uint8_t* x, int64_t B, 
     RLS_REQUIRE(ls_pitch_ok(ws, ws_pitch, ws_bytes, N), RLS_EUNSUPPORTED,
                 "ws rows must start 16-byte aligned: pitch %lld entries of %d bytes (N=%lld)", (long long)ws_pitch, (int)ws_bytes, (long long)N);
     const int x_aligned = tile_rows_aligned(x, N, 1) ? 1 : 0;   // else the funnel-shift form of the row-piece stage
+    if (ls_propose_lds(N, false) > (size_t)kLdsBytes && ls_big_tile(N))   // mask kernel + the 4-wave apply kernel (needs the scratch)
+        return rls_maxcut_ls_rounds(g, x, B, ws, ws_bytes, ws_pitch, rd_std, thresh, seed, env_offset, draw, 1, obj, scratch, scratch_bytes, stream);
     RLS_REQUIRE(ls_propose_lds(N, false) <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS (max %d)", (long long)N,
                 ls_propose_lds(N, false), kLdsBytes);
     const int P = pick_planes(E);
@@ -911,36 +931,59 @@ extern "C" int rls_maxcut_ls_rounds(const rls_graph* g, uint8_t* x, int64_t B, c
     if (ws_pitch == 0) ws_pitch = N;
     const int S = ls_slices(B, ws_bytes == 1 ? ls_num_chunks<int8_t>(N) : ls_num_chunks<int16_t>(N));
     static const bool per_round = getenv("RLS_LS_PER_ROUND") != nullptr;   // dev knob: one propose launch per round
-    const bool all_at_once = !per_round && S > 1 && num_draws > 1 && scratch && (((uintptr_t)scratch) & 15) == 0 &&
-                             (size_t)scratch_bytes >= ls_scratch_bytes(B, N, S, num_draws) && ls_pitch_ok(ws, ws_pitch, ws_bytes, N) &&
-                             ls_propose_lds(N, false) <= (size_t)kLdsBytes && pick_planes(E) != 0;
-    if (!all_at_once) {
+    const bool big = ls_big_tile(N);
+    const size_t one_round = (size_t)ceil_div(B, kWave) * (size_t)N * 8;
+    const bool scratch_ok = scratch && (((uintptr_t)scratch) & 15) == 0 && ls_pitch_ok(ws, ws_pitch, ws_bytes, N) && pick_planes(E) != 0;
+    RLS_REQUIRE(!big || (scratch_ok && (size_t)scratch_bytes >= one_round), RLS_EUNSUPPORTED,
+                "N=%lld: the proposal rounds need %zu bytes of scratch (rls_maxcut_ls_scratch_bytes) and ws rows on a 16-byte pitch",
+                (long long)N, one_round);
+    const bool all_at_once = !per_round && num_draws > 1 && scratch_ok && (big ? (size_t)scratch_bytes >= one_round * (size_t)num_draws
+                                                                                : S > 1 && (size_t)scratch_bytes >= ls_scratch_bytes(B, N, S, num_draws) &&
+                                                                                      ls_propose_lds(N, false) <= (size_t)kLdsBytes);
+    if (!all_at_once && !big) {
         for (int32_t r = 0; r < num_draws; ++r)
             if (int rc = rls_maxcut_ls_propose(g, x, B, ws, ws_bytes, ws_pitch, rd_std, thresh, seed, env_offset, first_draw + r, obj, scratch,
                                                scratch_bytes, stream))
                 return rc;
         return RLS_OK;
     }
-    const dim3 grid((unsigned)ceil_div(B, kWave)), block(kLsRoundWaves * kWave), gm(grid.x, (unsigned)S);
+    const dim3 grid((unsigned)ceil_div(B, kWave)), gm(grid.x, (unsigned)S);
     hipStream_t s = as_stream(stream);
     const size_t ldm = ls_mask_lds(N);
-    for (int32_t r = 0; r < num_draws; ++r) {
-        uint64_t* out = (uint64_t*)scratch + (size_t)r * grid.x * (size_t)N;
-        if (ws_bytes == 1) {
-            auto kern = k_ls_mask<int8_t>;
-            if (ldm > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldm);
-            hipLaunchKernelGGL(kern, gm, block, ldm, s, (const int8_t*)ws, ws_pitch, B, N, rd_std, thresh, seed, env_offset, (int)(first_draw + r), out);
-        } else {
-            auto kern = k_ls_mask<int16_t>;
-            if (ldm > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldm);
-            hipLaunchKernelGGL(kern, gm, block, ldm, s, (const int16_t*)ws, ws_pitch, B, N, rd_std, thresh, seed, env_offset, (int)(first_draw + r), out);
-        }
-    }
-    if (int rc = check_launch("k_ls_mask")) return rc;
-    const size_t lds = ls_propose_lds(N, false);
     const int halve = g->if_bidirectional ? 1 : 0, x_aligned = tile_rows_aligned(x, N, 1) ? 1 : 0;
-    auto kern = k_ls_apply_rounds<24>;
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, grid, block, lds, s, x, B, N, g->eu, g->ev, E, halve, (const uint64_t*)scratch, (int)num_draws, obj, x_aligned);
-    return check_launch("k_ls_apply_rounds");
+    const int per_launch = all_at_once ? num_draws : 1;       // rounds whose mask words are in the scratch at once
+    for (int32_t r0 = 0; r0 < num_draws; r0 += per_launch) {
+        for (int32_t r = 0; r < per_launch; ++r) {
+            uint64_t* out = (uint64_t*)scratch + (size_t)r * grid.x * (size_t)N;
+            const dim3 block(kLsRoundWaves * kWave);
+            if (ws_bytes == 1) {
+                auto kern = k_ls_mask<int8_t>;
+                if (ldm > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldm);
+                hipLaunchKernelGGL(kern, gm, block, ldm, s, (const int8_t*)ws, ws_pitch, B, N, rd_std, thresh, seed, env_offset,
+                                   (int)(first_draw + r0 + r), out);
+            } else {
+                auto kern = k_ls_mask<int16_t>;
+                if (ldm > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldm);
+                hipLaunchKernelGGL(kern, gm, block, ldm, s, (const int16_t*)ws, ws_pitch, B, N, rd_std, thresh, seed, env_offset,
+                                   (int)(first_draw + r0 + r), out);
+            }
+        }
+        if (int rc = check_launch("k_ls_mask")) return rc;
+        if (big) {   // the bare tile: 4 waves, lane-per-env loads and stores
+            const size_t lds = ls_apply_lds(N, 4, false);
+            auto kern = k_ls_apply_rounds<24, 4>;
+            if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, grid, dim3(4 * kWave), lds, s, x, B, N, g->eu, g->ev, E, halve, (const uint64_t*)scratch, per_launch, obj,
+                               x_aligned, 0);
+        } else {
+            const size_t lds = ls_apply_lds(N, kLsRoundWaves, true);
+            auto kern = k_ls_apply_rounds<24, kLsRoundWaves>;
+            if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, grid, dim3(kLsRoundWaves * kWave), lds, s, x, B, N, g->eu, g->ev, E, halve, (const uint64_t*)scratch,
+                               per_launch, obj, x_aligned, 1);
+        }
+        if (int rc = check_launch("k_ls_apply_rounds")) return rc;
+    }
+    return RLS_OK;
 }
+

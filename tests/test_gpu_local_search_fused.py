@@ -189,3 +189,43 @@ def test_round_kernels_beyond_the_fused_kernel(n, m):
     v1 = vs.clone()
     env.local_search_inplace(xs, vs, num_iters=3, num_spin=num_spin)
     assert bool((vs >= v1).all()) and torch.equal(env.calculate_obj_values(xs), vs)
+
+
+def test_round_kernels_at_g81_size_where_the_tile_fills_lds():
+    """N = 20 000 (Gset's G81): the 64-env tile takes 160 000 of LDS's 163 840 bytes, so the proposal rounds run as mask kernels
+    + the 4-wave apply kernel through the scratch buffer (which is required here), the threshold as usual; same invariants, and
+    all rounds at once == one round per call for the same seed."""
+    from rlsolver_amd import ops
+    from rlsolver_amd.envs.env_L2A import EnvMaxcut
+    n, m, B, num_spin = 20000, 40000, 130, 8
+    garr = gnm_arr(n, m, seed=81)
+    env = EnvMaxcut(mygraph=mygraph_of(garr), device=DEV, num_nodes=n)
+    assert not ops.local_search_fusable(env.graph, num_spin, B) and ops.ls_rounds_supported(env.graph, num_spin)
+    torch.manual_seed(4)
+    xs = env.generate_xs_randomly(B)
+    vs = env.calculate_obj_values(xs)
+    assert np.array_equal(vs.cpu().numpy(), onp.maxcut_obj(xs.cpu().numpy(), garr, False))              # K1 on the 4-wave tile form
+    ws, span = ops.maxcut_ls_weights(env.graph, xs, 1, padded=True)
+    c = ops.maxcut_node_cutdeg(env.graph, xs)
+    deg = torch.from_numpy(np.bincount(env.graph.csr.eu, minlength=n)).to(DEV)
+    assert torch.equal(ws[:, :n].long(), deg[None, :] - c)                                                # weights without the stage
+    rd_std = (span.float() * 0.3).contiguous()
+    scratch1 = ops.ls_scratch(env.graph, B, ws, num_draws=1)
+    scratch4 = ops.ls_scratch(env.graph, B, ws, num_draws=4)
+    assert scratch1 is not None and scratch4.numel() == 4 * scratch1.numel() == 4 * 3 * n * 8
+    thresh = ops.maxcut_ls_threshold(env.graph, ws, rd_std, seed=7, num_spin=num_spin, scratch=scratch1)
+    with pytest.raises(RuntimeError):
+        ops.maxcut_ls_propose(env.graph, xs.clone(), ws, rd_std, thresh, vs.clone(), seed=7, draw=1)       # no scratch
+    a, va = xs.clone(), vs.clone()
+    for it in range(1, 5):
+        x0, v0 = a.clone(), va.clone()
+        ops.maxcut_ls_propose(env.graph, a, ws, rd_std, thresh, va, seed=7, draw=it, scratch=scratch1)
+        changed = (a != x0).any(dim=1)
+        assert bool((va >= v0).all()) and bool((va[~changed] == v0[~changed]).all())
+    assert np.array_equal(va.cpu().numpy(), onp.maxcut_obj(a.cpu().numpy(), garr, False)) and bool((va > vs).any())
+    b, vb = xs.clone(), vs.clone()
+    ops.maxcut_ls_rounds(env.graph, b, ws, rd_std, thresh, vb, seed=7, first_draw=1, num_draws=4, scratch=scratch4)
+    assert torch.equal(a, b) and torch.equal(va, vb)
+    v1 = vb.clone()
+    env.local_search_inplace(b, vb, num_iters=3, num_spin=num_spin)                                        # + K5 without the stage
+    assert bool((vb >= v1).all()) and np.array_equal(vb.cpu().numpy(), onp.maxcut_obj(b.cpu().numpy(), garr, False))
