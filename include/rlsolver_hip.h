@@ -461,9 +461,14 @@ int rls_mcpg_metro_rounds(void* samples, const void* samples_in, int64_t C_in, i
  * accepts [accept_rows][T] as the chunk's dry (or, for the first chunk, direct) pass filled it; ctl int64 [3] on the device =
  * {accepts of the earlier chunks, walk still live (0 / 1), limit of the next dry pass} -- written, and read unless first != 0;
  * *apply_limit (device int64, may be NULL) = min(this chunk's limit, the first round at which the running count reaches
- * target) for the apply pass; ctl[2] = next_T while the walk is live, else 0 (rls_mcpg_metro_rounds returns at once on 0). */
+ * target) for the apply pass; ctl[2] = next_T while the walk is live, else 0 (rls_mcpg_metro_rounds returns at once on 0).
+ * first: 1 = the call's first chunk (applied directly: a round accepts at most C proposals, so the count cannot reach C * T
+ * before round T), 2 = a later chunk inside the first T rounds, applied directly as well (ctl is read), 0 = a dry pass. */
 int rls_mcpg_metro_stop(const int64_t* accepts, int64_t accept_rows, int64_t T, int64_t target, int32_t first, int64_t next_T,
                         int64_t* ctl, int64_t* apply_limit, void* stream);
+/* Rounds one rls_mcpg_metro_rounds launch can take with accept counts (the node-major kernels keep them in LDS beside the
+ * 64-chain tile: a G81-sized graph, N = 20 000, leaves room for 956); 0 = this layout does not fit at all for N. */
+int64_t rls_mcpg_metro_max_rounds(int64_t N, int32_t spin_bytes);
 
 /* K7 + K8 first half  sampler_func  methods/MCPG.py:128-152.
  * xs_in [N,C] holds 0|1 (the sampler's input before the reference maps it to -0.5|1.5).

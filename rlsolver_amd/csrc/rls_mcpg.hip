@@ -1163,7 +1163,7 @@ __global__ __launch_bounds__(kStopWaves * kWave) void k_metro_stop(const int64_t
     if (lane == 0) seg[w] = mine;
     if (threadIdx.x == 0) stop_at = ~0ull;
     __syncthreads();
-    int64_t before = first ? 0 : ctl[0];
+    int64_t before = first == 1 ? 0 : ctl[0];     // first: 1 = the call's first chunk, 2 = a later chunk that was applied directly
     int64_t total = before;
     for (int k = 0; k < kStopWaves; ++k) {
         if (k < w) before += seg[k];
@@ -1193,7 +1193,7 @@ __global__ __launch_bounds__(kStopWaves * kWave) void k_metro_stop(const int64_t
     for (int64_t blk = b0 + kKeep; blk < b1 && !done; ++blk) done = step(blk, colsum(blk));
     __syncthreads();
     if (threadIdx.x == 0) {
-        const bool live = first ? true : ctl[1] != 0;
+        const bool live = first == 1 ? true : ctl[1] != 0;
         const int64_t limit = first ? T : ctl[2];
         const bool hit = first ? total >= target : stop_at != ~0ull;
         const int64_t t_stop = hit && !first ? (int64_t)stop_at : T;
@@ -1260,6 +1260,16 @@ int rls_mcpg_metro_rounds(void* samples, const void* samples_in, int64_t C_in, i
     else                 { if (probs_lds) LAUNCH_METRO(float, true);   else LAUNCH_METRO(float, false); }
 #undef LAUNCH_METRO
     return check_launch("k_mcpg_metro");
+}
+
+// rounds one rls_mcpg_metro_rounds launch can take WITH accept counts (they sit in LDS beside the tile in the node-major
+// kernels): 0 = the layout does not fit at all for this N
+int64_t rls_mcpg_metro_max_rounds(int64_t N, int32_t spin_bytes) {
+    if (N <= 0) return 0;
+    if (spin_bytes == 0)
+        return (size_t)((N + 1) & ~(int64_t)1) * 8 + (size_t)2 * kMetroWin * kWave * 4 <= (size_t)kLdsBytes ? ((int64_t)1 << 40) : 0;
+    const int64_t room = (int64_t)kLdsBytes - N * 8 - 16;
+    return room >= 4 ? room / 4 : 0;
 }
 
 int rls_mcpg_metro_stop(const int64_t* accepts, int64_t accept_rows, int64_t T, int64_t target, int32_t first, int64_t next_T,

@@ -506,7 +506,7 @@ void mcpg_metro_rounds(Tensor samples, const OptTensor& samples_in, int64_t C_in
                              cur_stream(samples)),
        "rls_mcpg_metro_rounds");
 }
-void mcpg_metro_stop(const Tensor& accepts, int64_t target, bool first, int64_t next_T, Tensor ctl, const OptTensor& apply_limit) {
+void mcpg_metro_stop(const Tensor& accepts, int64_t target, int64_t first, int64_t next_T, Tensor ctl, const OptTensor& apply_limit) {
     dev(accepts, "accepts", I64);
     TORCH_CHECK(accepts.dim() == 2 && accepts.size(1) >= 1, "accepts must be [rows, T]");
     dev(ctl, "ctl", I64);
@@ -514,7 +514,8 @@ void mcpg_metro_stop(const Tensor& accepts, int64_t target, bool first, int64_t 
     optdev(apply_limit, "apply_limit", I64);
     if (apply_limit.has_value()) count(*apply_limit, "apply_limit", 1);
     RLS_GUARD(accepts);
-    ok(rls_mcpg_metro_stop((const int64_t*)p(accepts), accepts.size(0), accepts.size(1), target, first, next_T, (int64_t*)p(ctl),
+    TORCH_CHECK(first >= 0 && first <= 2, "first must be 0, 1 or 2");
+    ok(rls_mcpg_metro_stop((const int64_t*)p(accepts), accepts.size(0), accepts.size(1), target, (int32_t)first, next_T, (int64_t*)p(ctl),
                            (int64_t*)p(apply_limit), cur_stream(accepts)), "rls_mcpg_metro_stop");
 }
 void mcpg_local_search(int64_t g, const Tensor& xs_in, Tensor xs_out, const Tensor& order, const OptTensor& visit_stream, int64_t num_ls,
@@ -830,7 +831,7 @@ TORCH_LIBRARY(rlsolver_hip, m) {
           "float stag_punishment, bool use_basin, float basin_reward) -> ()");
     m.def("mcpg_metro_rounds(Tensor(a!) samples, Tensor? samples_in, int C_in, int C, Tensor probs, int T, int t_offset, Tensor? index, "
           "Tensor? u, int seed, Tensor? t_limit, bool write_back, Tensor(b!)? accepts) -> ()");
-    m.def("mcpg_metro_stop(Tensor accepts, int target, bool first, int next_T, Tensor(a!) ctl, Tensor(b!)? apply_limit) -> ()");
+    m.def("mcpg_metro_stop(Tensor accepts, int target, int first, int next_T, Tensor(a!) ctl, Tensor(b!)? apply_limit) -> ()");
     m.def("mcpg_local_search(int graph, Tensor xs_in, Tensor(a!) xs_out, Tensor order, Tensor? visit_stream, int num_ls, Tensor? uniforms, "
           "int seed, Tensor? edge_weights, int gauge_node, Tensor(b!) expected) -> ()");
     m.def("mcpg_local_search_levels(int graph, Tensor xs_in, int C_in, Tensor(a!) xs_out, int C, Tensor lv_ptr, Tensor lv_data, int num_ls, "

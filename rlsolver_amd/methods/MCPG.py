@@ -198,13 +198,18 @@ ACCEPT_ROWS = 64      # rows the kernels spread their per-round accept counts ov
 
 
 def _walk_chunks(samples, start, probs: TEN, max_transfer_time: int, Tmax: int, Cc: int, index, u, seed: int) -> None:
-    """The rounds of metro_sampling in chunks of T, with the reference's stop rule (MCPG.py:103,115) evaluated on the device.
-    A round accepts at most C proposals, so the cumulative count cannot reach C*T before the LAST round of the first chunk:
-    that chunk is applied directly (one pass, counting as it goes, reading the caller's start state and writing the result
-    buffer).  Later chunks: dry pass -> accept counts -> stop round (rls_mcpg_metro_stop: one launch) -> apply.  Chunks after
-    the stop round see a zero limit and return at once.  15 launches per call (was ~70: the stop rule as torch ops)."""
+    """The rounds of metro_sampling in chunks, with the reference's stop rule (MCPG.py:103,115) evaluated on the device.
+    A round accepts at most C proposals, so the cumulative count cannot reach C*T before round T: chunks inside the first T
+    rounds are applied directly (one pass, counting as it goes; the first one reads the caller's start state and writes the
+    result buffer).  Later chunks: dry pass -> accept counts -> stop round (rls_mcpg_metro_stop: one launch) -> apply.  Chunks
+    after the stop round see a zero limit and return at once.  A chunk is T rounds, or fewer where a launch cannot take that many
+    (the node-major kernels keep the accept counts in LDS beside the tile: 956 rounds at N = 20 000)."""
     device = probs.device
-    chunk = max(1, max_transfer_time)
+    st, sb, N, _ = mops._chains(samples, "samples")
+    cap = mops.mcpg_metro_max_rounds(N, sb)
+    if cap <= 0:
+        raise RuntimeError(f"metro_sampling: {N} nodes do not fit this layout's tile in LDS")
+    chunk = max(1, min(max_transfer_time, cap))
     target = Cc * max_transfer_time
     starts = list(range(0, Tmax, chunk))
     sizes = [min(chunk, Tmax - t0) for t0 in starts]
@@ -214,13 +219,13 @@ def _walk_chunks(samples, start, probs: TEN, max_transfer_time: int, Tmax: int, 
     for k, (t0, tk) in enumerate(zip(starts, sizes)):
         acc = accepts[k] if tk == chunk else accepts[k].reshape(-1)[: ACCEPT_ROWS * tk].view(ACCEPT_ROWS, tk)
         next_tk = sizes[k + 1] if k + 1 < len(sizes) else 0
-        if k == 0:
-            mops.mcpg_metro_rounds(samples, probs, tk, index, u, seed, None, True, acc, t_offset=0,
-                                   samples_in=None if samples is start else start)
-            mops.mcpg_metro_stop(acc, target, True, next_tk, ctl)
+        if t0 + tk <= max(1, max_transfer_time):                       # inside the first T rounds: direct
+            mops.mcpg_metro_rounds(samples, probs, tk, index, u, seed, None, True, acc, t_offset=t0,
+                                   samples_in=None if (k > 0 or samples is start) else start)
+            mops.mcpg_metro_stop(acc, target, 1 if k == 0 else 2, next_tk, ctl)
         else:
             mops.mcpg_metro_rounds(samples, probs, tk, index, u, seed, ctl[2:3], False, acc, t_offset=t0)
-            mops.mcpg_metro_stop(acc, target, False, next_tk, ctl, apply_limit)
+            mops.mcpg_metro_stop(acc, target, 0, next_tk, ctl, apply_limit)
             mops.mcpg_metro_rounds(samples, probs, tk, index, u, seed, apply_limit, True, None, t_offset=t0)
 
 
@@ -396,15 +401,27 @@ class MCPGRound:
         self.now_max_info = info
         self.now_max_res = now_max_res.to(torch.float32).clone()
         self.start = info.clone()                                                            # xs_bool, before the repeat
-        self.samples = PackedChains.empty(self.N, self.M * self.R, info.device)              # the round's metro output
-        self.work = PackedChains.empty(self.N, self.M * self.R, info.device)                 # after the local search
+        packed_fits = mops.mcpg_metro_max_rounds(self.N, 0) > 0
+        self.samples = PackedChains.empty(self.N, self.M * self.R, info.device) if packed_fits else None   # the round's metro output
+        self.work = PackedChains.empty(self.N, self.M * self.R, info.device) if packed_fits else None      # after the local search
         self.value = None
         self._sums = None
         self.best_value = self.best_index = None
+        # the bit-packed walk keeps a 32 KB window of draws beside the tile: up to N ~ 16 000.  Beyond (G81: 20 000 nodes) the round
+        # runs on the node-major kernels through the f32 surface and packs what it keeps
+        self._nodemajor = mops.mcpg_metro_max_rounds(self.N, 0) == 0
 
     def step(self, xs_prob: TEN):
         """One round; returns (value f32 [C], best value so far f32 [1]) -- device tensors, nothing is read back."""
         C = self.M * self.R
+        if self._nodemajor:
+            xs_sample = metro_sampling(xs_prob, self.start.unpack().repeat(1, self.R), self.change_times)
+            temp_max, temp_f32, value = sampler_func(self.data, xs_sample, self.num_ls, self.M, self.R)
+            self.samples = PackedChains.pack(xs_sample)
+            temp_info = PackedChains.pack(temp_f32.contiguous())
+            self.best_value, self.best_index = mops.mcpg_merge_best(temp_max, temp_info, self.now_max_res, self.now_max_info)
+            self.start, self.value, self._sums = temp_info, value, None
+            return self.value, self.best_value
         metro_sampling_packed(xs_prob, self.start, self.change_times, num_chains=C, out=self.samples)
         xs_loc, expected = mops.mcpg_local_search_levels(self.data.graph, self.samples, self.data._lv_ptr, self.data._lv_data,
                                                          self.num_ls, _seed_from_torch(), out=self.work)

@@ -101,15 +101,22 @@ def mcpg_metro_rounds(samples, probs: TEN, T: int, index: Optional[TEN] = None, 
     _t.mcpg_metro_rounds(st, sin, c_in, Cc, probs, T, t_offset, index, u, _s64(seed), t_limit, bool(write_back), accepts)
 
 
-def mcpg_metro_stop(accepts: TEN, target: int, first: bool, next_T: int, ctl: TEN, apply_limit: Optional[TEN] = None) -> None:
+def mcpg_metro_max_rounds(N: int, spin_bytes: int) -> int:
+    """Rounds one mcpg_metro_rounds launch can take with accept counts in this layout (0: N does not fit at all)."""
+    from . import _abi
+    return int(_abi.lib().rls_mcpg_metro_max_rounds(int(N), int(spin_bytes)))
+
+
+def mcpg_metro_stop(accepts: TEN, target: int, first: int, next_T: int, ctl: TEN, apply_limit: Optional[TEN] = None) -> None:
     """The stop rule between two chunks of metro rounds (include/rlsolver_hip.h: rls_mcpg_metro_stop).  accepts int64 [rows, T],
-    ctl int64 [3] = {accepts so far, live, limit of the next dry pass} (in / out), apply_limit int64 [1] (out)."""
+    ctl int64 [3] = {accepts so far, live, limit of the next dry pass} (in / out), apply_limit int64 [1] (out).  first: 1 the
+    call's first chunk, 2 a later chunk applied directly (inside the first T rounds), 0 a dry pass."""
     dev = accepts.device
     _check(accepts, "accepts", (torch.int64,), dev)
     _check(ctl, "ctl", (torch.int64,), dev, (3,))
     if apply_limit is not None:
         _check(apply_limit, "apply_limit", (torch.int64,), dev, (1,))
-    _t.mcpg_metro_stop(accepts, int(target), bool(first), int(next_T), ctl, apply_limit)
+    _t.mcpg_metro_stop(accepts, int(target), int(first), int(next_T), ctl, apply_limit)
 
 
 def mcpg_local_search(g: DeviceGraph, xs_in: TEN, order: TEN, num_ls: int, uniforms: Optional[TEN] = None,

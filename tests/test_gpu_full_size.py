@@ -356,3 +356,55 @@ def test_2opt_pass_on_a_lone_thousand_city_tour():
         assert length_after(int(a), int(b)) >= v
     route, dist = t2.local_search_2_opt(d, [tour, cur], recursive_seeding=1, verbose=False, device=DEV)
     assert dist == v and route[:-1][i:j + 1] == tour[:-1][i:j + 1][::-1]
+
+
+def test_metro_sampling_at_g81_size_in_capped_chunks():
+    """N = 20 000: the node-major kernels keep the accept counts in LDS beside the 64-chain tile, which leaves room for 956 rounds
+    per launch, fewer than T = N / 10 -- the walk is cut into more chunks (those inside the first T rounds still applied
+    directly) and gives what recorded draws say it must: the sequential restatement, stop rule included."""
+    from oracle import oracle_np as onp
+    from rlsolver_amd.methods import MCPG as amcpg
+    from rlsolver_amd import ops_mcpg_tsp as mops
+    n, C, T = 20000, 64, 2000
+    assert 0 < mops.mcpg_metro_max_rounds(n, 4) < T and mops.mcpg_metro_max_rounds(n, 0) == 0
+    rng = np.random.RandomState(81)
+    probs = (rng.rand(n) * 0.8 + 0.1).astype(np.float32)
+    start = rng.randint(0, 2, size=(n, C)).astype(np.float32)
+    # draws that accept most proposals, so that the stop rule (C * T accepts) fires a little after round T, inside a later chunk
+    index = rng.randint(0, n, size=(5 * T, C)).astype(np.int64)
+    u = (rng.rand(5 * T, C) * 0.5).astype(np.float32)
+    want, t_used = onp.metro_sampling(probs, start, T, index, u)
+    assert T < t_used < 5 * T                                       # the stop rule fired inside a later chunk
+    got = amcpg.metro_sampling(torch.from_numpy(probs).to(DEV), torch.from_numpy(start).to(DEV), T, DEV,
+                               index=torch.from_numpy(index).to(DEV), u=torch.from_numpy(u).to(DEV))
+    assert got.shape == (n, C) and np.array_equal(got.cpu().numpy(), want)
+    # and with the production draws: runs, changes the chains, stays 0 / 1
+    out = amcpg.metro_sampling(torch.from_numpy(probs).to(DEV), torch.from_numpy(start).to(DEV), T, DEV)
+    assert set(np.unique(out.cpu().numpy()).tolist()) <= {0.0, 1.0} and not np.array_equal(out.cpu().numpy(), start)
+
+
+def test_mcpg_round_at_g81_size_runs_on_the_node_major_kernels():
+    """MCPGRound at N = 20 000, where the bit-packed walk's window does not fit beside the tile: the round goes through the
+    node-major kernels and packs what it keeps.  Incumbents never get worse, each is the cut of its kept chain, get_return works."""
+    from rlsolver_amd import ops
+    from rlsolver_amd.methods import MCPG as amcpg
+    n, M, R = 20000, 64, 2
+    garr = gnm_arr(n, 40000, seed=81)
+    data = amcpg.make_data(n, garr[:, 0].copy(), garr[:, 1].copy(), DEV)
+    torch.manual_seed(1)
+    xs0 = ops.rand_spins(M, n, 5, DEV)
+    vs0 = ops.maxcut_obj(data.graph, xs0).float()
+    rnd = amcpg.MCPGRound(data, xs0.t().contiguous().float(), vs0, M, R, num_ls=2)
+    assert rnd._nodemajor
+    probs = torch.full((n,), 0.5, device=DEV)
+    prev = vs0.clone()
+    for _ in range(2):
+        value, best = rnd.step(probs)
+        assert value.shape == (M * R,) and bool((rnd.now_max_res >= prev).all())
+        prev = rnd.now_max_res.clone()
+        kept = rnd.now_max_info.unpack().t().contiguous().bool()
+        assert torch.equal(ops.maxcut_obj(data.graph, kept).float(), rnd.now_max_res)
+        pr = probs.clone().requires_grad_()
+        rnd.get_return(pr).backward()
+        assert bool(torch.isfinite(pr.grad).all())
+    assert float(rnd.best_value) == float(rnd.now_max_res.max()) > float(vs0.max())
