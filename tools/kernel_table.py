@@ -45,7 +45,7 @@ ROWS = [
     (r"k_ls_propose<short, 24, true, false>", 512 * 512, 32768, 4 * NBA + 16, "LS round kernel: noise + mask + count + accept (one proposal round per launch) | BA-1e4 2^15 (VALU-bound; x in, int16 ws in, accepted rows out)"),
     (r"k_ls_threshold<short>", 512 * 512, 32768, 2 * NBA + 4, "LS threshold kernel: noise + top-9 per env | BA-1e4 2^15 (VALU-bound; int16 ws in)"),
     (r"k_ls_mask<short>", 4 * 64 * 512, 4096, 2 * NBA + NBA // 8, "LS mask kernel: noise + mask for a quarter of the rows per workgroup | BA-1e4 4096 (64 tiles x 4 slices)"),
-    (r"k_ls_propose<signed char, 24, false, true>", 64 * 512, 4096, 2 * NBA + NBA // 8 + 16, "LS apply kernel: x ^ mask words, count, accept | BA-1e4 4096"),
+    (r"k_ls_apply_rounds<24, 8>", 64 * 512, 4096, 2 * NBA + 8 * (NBA // 8) * 8 + 16, "LS apply kernel: 8 rounds of (x ^ mask words, count, accept, undo) on one load of the tile | BA-1e4 4096"),
     (r"k_node_stats_bits<2, true, true, short>", 512 * 512, 32768, 3 * NBA, "ls_weights pre-pass, int16 weights (hub graph: 16 counter planes) | BA-1e4 2^15"),
     (r"k_tsp_tour_length", None, 65536, 8 * NT + 4, "K12 tsp_tour_length | TSP-100 2^16"),
     (r"k_tsp_swap_delta_all", None, 65536, 29 * NT, "K13 tsp_swap_delta_all | TSP-100 2^16"),
