@@ -408,3 +408,35 @@ def test_mcpg_round_at_g81_size_runs_on_the_node_major_kernels():
         rnd.get_return(pr).backward()
         assert bool(torch.isfinite(pr.grad).all())
     assert float(rnd.best_value) == float(rnd.now_max_res.max()) > float(vs0.max())
+
+
+@pytest.mark.parametrize("n", [20000, 20224, 20225])
+def test_tile_kernels_where_the_tile_fills_lds(n):
+    """N = 20 000 (G81) and 20 224 (the last N whose 64-env tile + 4 waves of scratch fit LDS: exactly 163 840 bytes) run on the tile
+    without the row-piece stage, 20 225 on the one-env-per-wave forms: K1 / K2 / K3 / K5 / K6 against the oracle, ragged batch."""
+    B = 70
+    garr = gnm_arr(n, 2 * n, seed=n)
+    g = device_graph(garr, n, 0)
+    rng = np.random.RandomState(n)
+    xs = rng.randint(0, 2, size=(B, n)).astype(np.uint8)
+    x = torch.from_numpy(xs).to(DEV).view(torch.bool)
+    want = onp.maxcut_obj(xs, garr, False)
+    vs = ops.maxcut_obj(g, x)
+    assert np.array_equal(vs.cpu().numpy(), want)
+    sub = [0, 33, B - 1]
+    assert np.array_equal(ops.maxcut_node_cutdeg(g, x)[sub].cpu().numpy(), onp.maxcut_node_cutdeg(xs[sub], garr, n, False))
+    assert np.array_equal(ops.maxcut_delta_all(g, x)[sub].cpu().numpy(), onp.maxcut_delta_all(xs[sub], garr, n, None))
+    mask = torch.zeros((B, n), dtype=torch.bool, device=DEV)
+    mask[:, ::997] = True
+    x6, v6 = x.clone(), vs.clone()
+    ops.maxcut_propose_accept(g, x6, mask, v6)
+    prop = xs ^ mask.cpu().numpy().astype(np.uint8)
+    pv = onp.maxcut_obj(prop, garr, False)
+    acc = pv >= want
+    assert np.array_equal(x6.cpu().numpy().astype(np.uint8), np.where(acc[:, None], prop, xs)) and np.array_equal(v6.cpu().numpy(), np.where(acc, pv, want))
+    from oracle import oracle_c as oc                       # (the numpy restatement needs minutes at this size)
+    eu, ev = onp.stored_edges(garr, False)
+    x5, v5 = x[:6].clone(), vs[:6].clone()
+    ops.maxcut_greedy_sweep(g, x5, v5)
+    wx, wv = oc.greedy_sweep(xs[:6].copy(), want[:6].astype(np.int64).copy(), eu, ev, 0)
+    assert np.array_equal(x5.cpu().numpy().astype(np.uint8), wx) and np.array_equal(v5.cpu().numpy(), wv)
