@@ -231,7 +231,7 @@ int rls_maxcut_local_search_supported(const rls_graph* g, int64_t B, int32_t num
 int rls_maxcut_node_stats_form(const rls_graph* g, int64_t B, int32_t what);
 
 /* The same local search as separate launches, for graphs rls_maxcut_local_search does not cover (its LDS layout holds
- * two tiles and rd_std: N <= ~6500; these hold one tile: N <= ~15 000 -- and up to N = 20 224, where the tile
+ * two tiles and rd_std: N <= ~7100; these hold one tile: N <= ~15 000 -- and up to N = 20 224, where the tile
  * nearly fills LDS, through the scratch buffer, which is then REQUIRED).  Both use the fused kernel's
  * in-kernel draws -- normal(seed, env_offset + b, node, draw) -- so a caller that passes the same seed gets the result
  * the fused kernel would give.  They replace the torch ops of the decomposed path (randn_like, ws + noise * rd_std,
