@@ -253,7 +253,8 @@ int rls_maxcut_ls_propose(const rls_graph* g, uint8_t* x, int64_t B, const void*
 /* scratch (16-byte aligned device memory, contents irrelevant, may be shared by all calls of one local search) lets a small
  * batch split each tile's noise pass -- the VALU-bound part -- over up to 8 workgroups: partial top-k lists / bit-packed mask
  * words go through it.  rls_maxcut_ls_scratch_bytes gives the size that enables this for (graph, B, ws_bytes) and num_draws
- * rounds' worth of mask words (1 for the per-round entry points); 0 = nothing to gain.  With scratch = NULL (or too small) both run one workgroup per tile; the results are the same either way. */
+ * rounds' worth of mask words (1 for the per-round entry points; more than one: every round's, for any batch, while they stay under
+ * 1 GiB); 0 = nothing to gain.  With scratch = NULL (or too small) both run one workgroup per tile; the results are the same either way. */
 int64_t rls_maxcut_ls_scratch_bytes(const rls_graph* g, int64_t B, int32_t ws_bytes, int32_t num_draws);
 /* num_draws rounds of rls_maxcut_ls_propose (draws first_draw, first_draw + 1, ...) in one call.  With scratch of
  * rls_maxcut_ls_scratch_bytes(g, B, ws_bytes, num_draws) bytes a small batch computes the mask words of all rounds first (they do
@@ -261,6 +262,9 @@ int64_t rls_maxcut_ls_scratch_bytes(const rls_graph* g, int64_t B, int32_t ws_by
 int rls_maxcut_ls_rounds(const rls_graph* g, uint8_t* x, int64_t B, const void* ws, int32_t ws_bytes, int64_t ws_pitch,
                          const float* rd_std, const float* thresh, uint64_t seed, int64_t env_offset, int32_t first_draw,
                          int32_t num_draws, int64_t* obj, void* scratch, int64_t scratch_bytes, void* stream);
+/* Workgroups per tile the noise passes of a batch of B envs are split over when the scratch buffer is there (1 = the tiles fill the
+ * chip by themselves). */
+int rls_maxcut_ls_slices(const rls_graph* g, int64_t B, int32_t ws_bytes);
 /* 1 when the two entry points above cover this graph / num_spin, else 0 (callers then keep the torch ops + K6). */
 int rls_maxcut_ls_rounds_supported(const rls_graph* g, int32_t num_spin);
 

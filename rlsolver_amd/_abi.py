@@ -132,7 +132,8 @@ PLAIN = {"rls_version": ([], _INT), "rls_device_count": ([], _INT), "rls_last_er
          "rls_maxcut_ls_rounds_supported": ([_G, C.c_int32], _INT),
          "rls_maxcut_node_stats_form": ([_G, _I64, C.c_int32], _INT),
          "rls_mcpg_metro_max_rounds": ([_I64, C.c_int32], _I64),
-         "rls_maxcut_ls_scratch_bytes": ([_G, _I64, C.c_int32, C.c_int32], _I64)}
+         "rls_maxcut_ls_scratch_bytes": ([_G, _I64, C.c_int32, C.c_int32], _I64),
+         "rls_maxcut_ls_slices": ([_G, _I64, C.c_int32], _INT)}
 
 _lib = None
 _lock = threading.Lock()

@@ -679,10 +679,13 @@ static int ls_slices(int64_t B, int64_t nchunks) {
     if ((int64_t)S * 2 * kLsRoundWaves > nchunks) S = (int)(nchunks / (2 * kLsRoundWaves));   // a slice keeps every wave busy
     return S < 1 ? 1 : S;
 }
+constexpr size_t kLsMaxMaskBytes = (size_t)1 << 30;   // all rounds' mask words at once only while they stay under 1 GiB
 static size_t ls_scratch_bytes(int64_t B, int64_t N, int S, int rounds = 1) {   // rounds: mask words of that many rounds at once
-    if (S <= 1) return 0;
     const size_t tiles = (size_t)ceil_div(B, kWave);
-    const size_t lists = tiles * S * kTopCap * kWave * 4, masks = tiles * (size_t)N * 8 * (size_t)(rounds > 1 ? rounds : 1);
+    const size_t lists = S > 1 ? tiles * S * kTopCap * kWave * 4 : 0;
+    const size_t all = tiles * (size_t)N * 8 * (size_t)(rounds > 1 ? rounds : 1);
+    // one round's words when the noise pass is split (S > 1); every round's whenever more than one is asked for and they fit
+    const size_t masks = rounds > 1 ? (all <= kLsMaxMaskBytes ? all : (S > 1 ? tiles * (size_t)N * 8 : 0)) : (S > 1 ? all : 0);
     return lists > masks ? lists : masks;
 }
 // (rd_std always fits LDS beside the stages here: 4 N bytes, N bounded by the proposal kernel's tile)
@@ -802,13 +805,19 @@ extern "C" int64_t rls_maxcut_ls_scratch_bytes(const rls_graph* g, int64_t B, in
     if (!g || g->num_nodes <= 0 || B <= 0 || (ws_bytes != 1 && ws_bytes != 2)) return 0;
     const int64_t N = g->num_nodes;
     const int64_t nch = ws_bytes == 1 ? ls_num_chunks<int8_t>(N) : ls_num_chunks<int16_t>(N);
-    if (ls_big_tile(N)) {   // the mask words are how the rounds run at all here: every round's while that stays under 1 GB, else one round's
-        const size_t one = (size_t)ceil_div(B, kWave) * (size_t)N * 8, all = one * (size_t)(num_draws > 1 ? num_draws : 1);
-        const size_t lists = ls_scratch_bytes(B, N, ls_slices(B, nch), 1);
-        const size_t m = all <= ((size_t)1 << 30) ? all : one;
-        return (int64_t)(m > lists ? m : lists);
+    const size_t need = ls_scratch_bytes(B, N, ls_slices(B, nch), num_draws);
+    if (ls_big_tile(N)) {   // the mask words are how the rounds run at all here: at least one round's
+        const size_t one = (size_t)ceil_div(B, kWave) * (size_t)N * 8;
+        return (int64_t)(need > one ? need : one);
     }
-    return (int64_t)ls_scratch_bytes(B, N, ls_slices(B, nch), num_draws);
+    return (int64_t)need;
+}
+
+// workgroups per tile the noise passes of a batch of B envs are split over when the scratch buffer is there (1: the tiles fill
+// the chip by themselves)
+extern "C" int rls_maxcut_ls_slices(const rls_graph* g, int64_t B, int32_t ws_bytes) {
+    if (!g || g->num_nodes <= 0 || B <= 0 || (ws_bytes != 1 && ws_bytes != 2)) return 1;
+    return ls_slices(B, ws_bytes == 1 ? ls_num_chunks<int8_t>(g->num_nodes) : ls_num_chunks<int16_t>(g->num_nodes));
 }
 
 // ws rows start ws_pitch ENTRIES apart (0 = N): any N works once the pitch is a multiple of 16 bytes
@@ -937,9 +946,8 @@ extern "C" int rls_maxcut_ls_rounds(const rls_graph* g, uint8_t* x, int64_t B, c
     RLS_REQUIRE(!big || (scratch_ok && (size_t)scratch_bytes >= one_round), RLS_EUNSUPPORTED,
                 "N=%lld: the proposal rounds need %zu bytes of scratch (rls_maxcut_ls_scratch_bytes) and ws rows on a 16-byte pitch",
                 (long long)N, one_round);
-    const bool all_at_once = !per_round && num_draws > 1 && scratch_ok && (big ? (size_t)scratch_bytes >= one_round * (size_t)num_draws
-                                                                                : S > 1 && (size_t)scratch_bytes >= ls_scratch_bytes(B, N, S, num_draws) &&
-                                                                                      ls_propose_lds(N, false) <= (size_t)kLdsBytes);
+    const bool all_at_once = !per_round && num_draws > 1 && scratch_ok && (size_t)scratch_bytes >= one_round * (size_t)num_draws &&
+                             (big || ls_propose_lds(N, false) <= (size_t)kLdsBytes);
     if (!all_at_once && !big) {
         for (int32_t r = 0; r < num_draws; ++r)
             if (int rc = rls_maxcut_ls_propose(g, x, B, ws, ws_bytes, ws_pitch, rd_std, thresh, seed, env_offset, first_draw + r, obj, scratch,

@@ -130,7 +130,7 @@ class EnvMaxcut:
                       and ops.ls_rounds_supported(self.graph, num_spin))
         # a batch of few tiles: the round kernels spread each tile's noise passes over several workgroups and beat the fused
         # kernel's one workgroup per tile (G22-sized, 256 - 8192 envs: 0.32 - 0.35 vs 0.39 - 0.41 ms; same result bit for bit)
-        few_tiles = rounds_can and num_iters > 0 and not self.force_ls_fused and ops.ls_scratch_bytes(self.graph, B, wdt, num_iters) > 0
+        few_tiles = rounds_can and num_iters > 0 and not self.force_ls_fused and ops.ls_slices(self.graph, B, wdt) > 1
         fused_ok = (self.fused_local_search and not self.force_ls_rounds and not few_tiles
                     and ops.local_search_fusable(self.graph, num_spin, B)
                     and xs.data_ptr() % 16 == 0 and (noise is None or noise.data_ptr() % 16 == 0))   # (views that start mid-row)

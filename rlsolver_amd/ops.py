@@ -338,10 +338,15 @@ def maxcut_ls_propose(g: DeviceGraph, xs: TEN, ws: TEN, rd_std: TEN, thresh: TEN
     _t.maxcut_ls_propose(g.handle, xs, ws, rd_std, thresh, _s64(seed), env_offset, int(draw), obj, scratch)
 
 
+def ls_slices(g: DeviceGraph, B: int, ws_dtype) -> int:
+    """Workgroups per tile the noise passes of a batch of B envs are split over (1: the tiles fill the chip by themselves)."""
+    return int(_abi.lib().rls_maxcut_ls_slices(g.ref, int(B), torch.empty((), dtype=ws_dtype).element_size()))
+
+
 def maxcut_ls_rounds(g: DeviceGraph, xs: TEN, ws: TEN, rd_std: TEN, thresh: TEN, obj: TEN, seed: int, first_draw: int, num_draws: int,
                      env_offset: int = 0, scratch: Optional[TEN] = None) -> None:
-    """``num_draws`` proposal rounds in place (draws first_draw, first_draw + 1, ...): maxcut_ls_propose per round, or -- small
-    batch, scratch from ls_scratch(.., num_draws) -- every round's mask words first and all rounds on one load of each tile."""
+    """``num_draws`` proposal rounds in place (draws first_draw, first_draw + 1, ...): maxcut_ls_propose per round, or -- scratch
+    from ls_scratch(.., num_draws) -- every round's mask words first and all rounds on one load of each tile."""
     B, _ = _spins(xs, "xs", g)
     _check(ws, "ws", (torch.int8, torch.int16), g.device)
     if ws.dim() != 2 or ws.shape[0] != B or ws.shape[1] < g.num_nodes:
