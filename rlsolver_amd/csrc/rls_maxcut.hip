@@ -481,21 +481,12 @@ __global__ __launch_bounds__(kNsWaves * kWave) void k_node_stats_bits(const uint
     __syncthreads();
     const int64_t G = (N + 63) >> 6;
     const int nenv = (int)((B - b0) < kWave ? (B - b0) : kWave);
-    for (int64_t g = w; g < G; g += kNsWaves) {
-        const int64_t i = (g << 6) + lane;
-        const bool in = i < N;
-        const uint32_t iself = in ? (uint32_t)i : 0u;
-        const uint64_t own = words[iself];
-        const int e0 = ell_ptr[g], e1 = ell_ptr[g + 1];
-        const int deg = in ? rowptr[i + 1] - rowptr[i] : 0;
-        constexpr int NCP = WIDE ? 13 : 5;
-        uint64_t ones = 0, twos = 0, fours = 0, c[NCP];
-#pragma unroll
-        for (int p = 0; p < NCP; ++p) c[p] = 0;
-        const int md = (e1 - e0) >> 6;                        // longest row of the group (wave-uniform)
-        int ncp = 5;                                          // carry planes this group can reach: counts < 8 << ncp
-        if constexpr (WIDE) while ((8 << ncp) <= md) ++ncp;
-        for (int k = e0; k < e1; k += 8 * kWave) {
+    const uint64_t vmask = nenv == kWave ? ~0ull : ((1ull << nenv) - 1);
+    constexpr int NCP = WIDE ? 13 : 5;
+    // c(e, i) for the group's 64 nodes over the neighbour blocks first, first + step, ... of 8 rounds each
+    auto count_blocks = [&](int e0, int e1, uint32_t iself, uint64_t own, int ncp, int first, int step, uint64_t& ones, uint64_t& twos,
+                            uint64_t& fours, uint64_t (&c)[NCP]) {
+        for (int k = e0 + first * 8 * kWave; k < e1; k += step * 8 * kWave) {
             uint32_t nb[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) nb[q] = (k + q * kWave < e1) ? (uint32_t)ell[k + q * kWave + lane] : iself;
@@ -519,33 +510,97 @@ __global__ __launch_bounds__(kNsWaves * kWave) void k_node_stats_bits(const uint
                 }
             }
         }
-        const uint64_t pl[8] = {ones, twos, fours, c[0], c[1], c[2], c[3], c[4]};
-        auto emit = [&](int e, int cnt) {
-            if constexpr (MODE == 0) reinterpret_cast<int64_t*>(out_v)[(b0 + e) * N + i] = cnt;
-            else if constexpr (MODE == 1) reinterpret_cast<int32_t*>(out_v)[(b0 + e) * N + i] = deg - 2 * cnt;
-            else reinterpret_cast<WT*>(out_v)[(b0 + e) * out_pitch + i] = (WT)(deg - mult * cnt);
-        };
-        const uint64_t vmask = nenv == kWave ? ~0ull : ((1ull << nenv) - 1);
-        if constexpr (WIDE) {
-            if (md >= 256) {                                  // a hub group: 16-bit fields, two envs per dword
-                const uint64_t pw[16] = {ones, twos, fours, c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7], c[8], c[9], c[10], c[11], c[12]};
-                if constexpr (MODE == 2) {
-                    if (minmax && in) {
-                        int cmn, cmx;
-                        planes_minmax<16>(pw, vmask, cmn, cmx);
-                        ws_minmax_update(minmax, N, i, deg - mult * cmx, deg - mult * cmn);
-                    }
-                }
-                for (int half = 0; half < 2; ++half) {
-                    for (int r = 0; r < 16; ++r) {
-                        const uint32_t acc = md < 1024 ? ns_extract2<10>(pw, half, r) : ns_extract2<16>(pw, half, r);
+    };
+    auto emit = [&](int64_t i, int deg, int e, int cnt) {
+        if constexpr (MODE == 0) reinterpret_cast<int64_t*>(out_v)[(b0 + e) * N + i] = cnt;
+        else if constexpr (MODE == 1) reinterpret_cast<int32_t*>(out_v)[(b0 + e) * N + i] = deg - 2 * cnt;
+        else reinterpret_cast<WT*>(out_v)[(b0 + e) * out_pitch + i] = (WT)(deg - mult * cnt);
+    };
+    // a hub group (longest row >= 256): 16-bit fields, two envs per dword
+    auto emit_hub = [&](int64_t i, bool in, int deg, int md, const uint64_t (&pw)[16]) {
+        if constexpr (MODE == 2) {
+            if (minmax && in) {
+                int cmn, cmx;
+                planes_minmax<16>(pw, vmask, cmn, cmx);
+                ws_minmax_update(minmax, N, i, deg - mult * cmx, deg - mult * cmn);
+            }
+        }
+        for (int half = 0; half < 2; ++half) {
+            for (int r = 0; r < 16; ++r) {
+                const uint32_t acc = md < 1024 ? ns_extract2<10>(pw, half, r) : ns_extract2<16>(pw, half, r);
 #pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            const int e = half * 32 + r + 16 * j;
-                            if (e < nenv && in) emit(e, (int)((acc >> (16 * j)) & 0xFFFFu));
+                for (int j = 0; j < 2; ++j) {
+                    const int e = half * 32 + r + 16 * j;
+                    if (e < nenv && in) emit(i, deg, e, (int)((acc >> (16 * j)) & 0xFFFFu));
+                }
+            }
+        }
+    };
+    // WIDE: the hub groups first, ALL waves on each -- a hub's row is hundreds of rounds (BA n = 10^4: ~370, a star: N), which one
+    // wave used to walk alone while the other seven finished their twenty short groups each.  The blocks of 8 rounds are dealt
+    // round-robin over the waves, the waves' bit-sliced counters added pairwise through the (now idle) row-piece stages --
+    // 16 planes x 64 lanes x 8 B = 8 KB per wave, four waves' worth at a time -- and wave 0 writes the group.
+    const bool coop = WIDE && has_stage;
+    if constexpr (WIDE) {
+        if (coop) {
+            uint64_t* xch = reinterpret_cast<uint64_t*>(smem + (((size_t)N * 8 + 15) & ~(size_t)15));   // [4][16][64]
+            static_assert(kNsWaves == 8 && kNsWaves * kStageBytes >= 4 * 16 * kWave * 8, "four waves' planes fit the stages");
+            for (int64_t g = 0; g < G; ++g) {
+                const int e0 = ell_ptr[g], e1 = ell_ptr[g + 1];
+                const int md = (e1 - e0) >> 6;
+                if (md < 256) continue;                          // (wave-uniform)
+                const int64_t i = (g << 6) + lane;
+                const bool in = i < N;
+                const uint32_t iself = in ? (uint32_t)i : 0u;
+                const uint64_t own = words[iself];
+                const int deg = in ? rowptr[i + 1] - rowptr[i] : 0;
+                uint64_t ones = 0, twos = 0, fours = 0, c[NCP];
+#pragma unroll
+                for (int p = 0; p < NCP; ++p) c[p] = 0;
+                count_blocks(e0, e1, iself, own, NCP, w, kNsWaves, ones, twos, fours, c);
+                uint64_t pw[16] = {ones, twos, fours, c[0], c[1], c[2], c[3], c[4], c[5 % NCP], c[6 % NCP], c[7 % NCP], c[8 % NCP],
+                                   c[9 % NCP], c[10 % NCP], c[11 % NCP], c[12 % NCP]};
+                for (int half = kNsWaves / 2; half >= 1; half >>= 1) {
+                    __syncthreads();                             // (the previous step's readers are done with xch)
+                    if (w >= half && w < 2 * half) {
+#pragma unroll
+                        for (int p = 0; p < 16; ++p) xch[((w - half) * 16 + p) * kWave + lane] = pw[p];
+                    }
+                    __syncthreads();
+                    if (w < half) {
+                        uint64_t cy = 0;
+#pragma unroll
+                        for (int p = 0; p < 16; ++p) {           // ripple add of two 16-plane numbers
+                            const uint64_t o = xch[(w * 16 + p) * kWave + lane];
+                            csa(cy, pw[p], pw[p], o, cy);
                         }
                     }
                 }
+                if (w == 0) emit_hub(i, in, deg, md, pw);
+            }
+        }
+    }
+    for (int64_t g = w; g < G; g += kNsWaves) {
+        const int64_t i = (g << 6) + lane;
+        const bool in = i < N;
+        const uint32_t iself = in ? (uint32_t)i : 0u;
+        const uint64_t own = words[iself];
+        const int e0 = ell_ptr[g], e1 = ell_ptr[g + 1];
+        const int deg = in ? rowptr[i + 1] - rowptr[i] : 0;
+        const int md = (e1 - e0) >> 6;                        // longest row of the group (wave-uniform)
+        if (coop && md >= 256) continue;                      // done above
+        uint64_t ones = 0, twos = 0, fours = 0, c[NCP];
+#pragma unroll
+        for (int p = 0; p < NCP; ++p) c[p] = 0;
+        int ncp = 5;                                          // carry planes this group can reach: counts < 8 << ncp
+        if constexpr (WIDE) while ((8 << ncp) <= md) ++ncp;
+        count_blocks(e0, e1, iself, own, ncp, 0, 1, ones, twos, fours, c);
+        const uint64_t pl[8] = {ones, twos, fours, c[0], c[1], c[2], c[3], c[4]};
+        if constexpr (WIDE) {
+            if (md >= 256) {                                  // a hub group without the stages (N ~ 20 000): one wave walks it
+                const uint64_t pw[16] = {ones, twos, fours, c[0], c[1], c[2], c[3], c[4], c[5 % NCP], c[6 % NCP], c[7 % NCP], c[8 % NCP],
+                                         c[9 % NCP], c[10 % NCP], c[11 % NCP], c[12 % NCP]};
+                emit_hub(i, in, deg, md, pw);
                 continue;
             }
         }
@@ -566,7 +621,7 @@ __global__ __launch_bounds__(kNsWaves * kWave) void k_node_stats_bits(const uint
                         const uint32_t acc = md < 16 ? ns_extract4<4>(pl, half, r)
                                                      : (md < 64 ? ns_extract4<6>(pl, half, r) : ns_extract4<8>(pl, half, r));
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) emit(half * 32 + r + 8 * j, (int)((acc >> (8 * j)) & 0xFFu));
+                        for (int j = 0; j < 4; ++j) emit(i, deg, half * 32 + r + 8 * j, (int)((acc >> (8 * j)) & 0xFFu));
                     }
                 }
             }
@@ -579,7 +634,7 @@ __global__ __launch_bounds__(kNsWaves * kWave) void k_node_stats_bits(const uint
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int e = half * 32 + r + 8 * j;
-                        if (e < nenv && in) emit(e, (int)((acc >> (8 * j)) & 0xFFu));
+                        if (e < nenv && in) emit(i, deg, e, (int)((acc >> (8 * j)) & 0xFFu));
                     }
                 }
             }
