@@ -213,7 +213,8 @@ int rls_maxcut_ls_weights(const rls_graph* g, const uint8_t* x, int64_t B, int32
  * mode: bit-exact against the reference) or NULL = in-kernel Philox + Box-Muller keyed by
  * (seed, env_offset + b, node, round).  obj int64 [B]: in/out, or out only when compute_obj != 0
  * (the reference's good_vs.shape == () case).  Unweighted graphs, max degree <= 512,
- * num_spin <= 15, rows of x / ws / noise that start 4-byte aligned on 16-byte bases (N % 4 == 0); RLS_EUNSUPPORTED
+ * num_spin <= 15, rows of x / ws / noise that start 4-byte aligned on 16-byte bases (N % 4 == 0; ws is read in 16-byte
+ * pieces: when a row is not a 16-byte multiple, 16 bytes behind the end of the array must be readable); RLS_EUNSUPPORTED
  * otherwise (callers take rls_maxcut_ls_threshold + rls_maxcut_ls_rounds, or K2 / K6 / K5). */
 int rls_maxcut_local_search(const rls_graph* g, uint8_t* x, int64_t B, const void* ws, int32_t ws_bytes, const float* rd_std,
                             const float* noise, uint64_t seed, int64_t env_offset, int32_t num_iters,

@@ -265,7 +265,9 @@ def maxcut_ls_weights(g: DeviceGraph, xs: TEN, mult: int, dtype=None, padded: bo
     dt = ls_weight_dtype(g, mult) if dtype is None else dtype
     per = 16 // torch.empty((), dtype=dt).element_size()
     P = (g.num_nodes + per - 1) // per * per if padded else g.num_nodes
-    ws = torch.empty((B, P), dtype=dt, device=g.device)
+    # 16 bytes of slack behind the array: the kernels read the weights in 16-byte pieces, and the last piece of the LAST row runs
+    # past the end of an unpadded row that is not a 16-byte multiple (include/rlsolver_hip.h: rls_maxcut_local_search)
+    ws = torch.empty(B * P + per, dtype=dt, device=g.device)[: B * P].view(B, P)
     mm = torch.empty((2, g.num_nodes), dtype=torch.int32, device=g.device)
     _t.maxcut_ls_weights(g.handle, xs, int(mult), ws, mm)
     return ws, mm[1] - mm[0]
