@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RLS_ABI_VERSION 8
+#define RLS_ABI_VERSION 9
 
 enum {
     RLS_OK = 0,
@@ -213,11 +213,13 @@ int rls_maxcut_ls_weights(const rls_graph* g, const uint8_t* x, int64_t B, int32
  * mode: bit-exact against the reference) or NULL = in-kernel Philox + Box-Muller keyed by
  * (seed, env_offset + b, node, round).  obj int64 [B]: in/out, or out only when compute_obj != 0
  * (the reference's good_vs.shape == () case).  Unweighted graphs, max degree <= 512,
- * num_spin <= 15, rows of x / ws / noise that start 4-byte aligned on 16-byte bases (N % 4 == 0; ws is read in 16-byte
- * pieces: when a row is not a 16-byte multiple, 16 bytes behind the end of the array must be readable); RLS_EUNSUPPORTED
+ * num_spin <= 15, rows of x / noise that start 4-byte aligned on 16-byte bases (N % 4 == 0).  ws is read in 16-byte pieces:
+ * its rows sit ws_pitch ENTRIES apart (0 = N) and ws_pitch * ws_bytes must be a multiple of 16 on a 16-byte base -- the layout
+ * rls_maxcut_ls_weights writes with a padded pitch -- so that no piece leaves its row; an exactly sized [B, N] array whose rows
+ * are not 16-byte multiples is refused, never over-read.  RLS_EUNSUPPORTED
  * otherwise (callers take rls_maxcut_ls_threshold + rls_maxcut_ls_rounds, or K2 / K6 / K5). */
-int rls_maxcut_local_search(const rls_graph* g, uint8_t* x, int64_t B, const void* ws, int32_t ws_bytes, const float* rd_std,
-                            const float* noise, uint64_t seed, int64_t env_offset, int32_t num_iters,
+int rls_maxcut_local_search(const rls_graph* g, uint8_t* x, int64_t B, const void* ws, int32_t ws_bytes, int64_t ws_pitch,
+                            const float* rd_std, const float* noise, uint64_t seed, int64_t env_offset, int32_t num_iters,
                             int32_t num_spin, int32_t first_draw_proposes, int64_t* obj, int32_t compute_obj,
                             void* stream);
 
@@ -263,6 +265,11 @@ int64_t rls_maxcut_ls_scratch_bytes(const rls_graph* g, int64_t B, int32_t ws_by
 int rls_maxcut_ls_rounds(const rls_graph* g, uint8_t* x, int64_t B, const void* ws, int32_t ws_bytes, int64_t ws_pitch,
                          const float* rd_std, const float* thresh, uint64_t seed, int64_t env_offset, int32_t first_draw,
                          int32_t num_draws, int64_t* obj, void* scratch, int64_t scratch_bytes, void* stream);
+/* The draws of the local-search kernels as a tensor: out f32 [B, N], out[b, n] = normal(seed, env_offset + b, n, draw) -- the
+ * value rls_maxcut_local_search / _ls_threshold / _ls_propose use for that (env, node, draw).  Replaces torch.randn_like
+ * (envs/env_L2A.py:95,99; methods/LocalSearch.py:66) on the decomposed path (weights wider than 16 bits), so that path too is
+ * keyed by the global env id, and feeds the statistical tests of the generator. */
+int rls_maxcut_ls_normals(float* out, int64_t B, int64_t N, uint64_t seed, int64_t env_offset, int32_t draw, void* stream);
 /* Workgroups per tile the noise passes of a batch of B envs are split over when the scratch buffer is there (1 = the tiles fill the
  * chip by themselves). */
 int rls_maxcut_ls_slices(const rls_graph* g, int64_t B, int32_t ws_bytes);
@@ -436,13 +443,29 @@ int rls_spin_materialize(const rls_spin_env* env, int state_bytes, int64_t B, in
  *                        surface's bytes, a 64-chain tile is N consecutive words; the form in which a sampling round
  *                        stays on the device (rls_mcpg_pack_chains / rls_mcpg_unpack_chains convert). */
 
+/* [host struct] Global ids of a shard's chains ("per-env RNG keyed by global env id, not rank").  The in-kernel
+ * generators of the three entry points below are keyed by (seed, GLOBAL chain id, round / pass / position); the global id of
+ * local chain c is
+ *     offset + c + (period > 0 ? (c / period) * skip : 0)
+ * A rank that owns kept chains [m0, m0 + M_local) of a batch of M kept chains x R repeats (chain = repeat * M + kept, the
+ * column order of the reference's  xs_bool.repeat(1, repeat_times), MCPG.py:393-394) passes {m0, M_local, M - M_local}: its
+ * chains then draw exactly what they draw in the one-process run, whatever the rank count.  NULL = {0, 0, 0}, the
+ * single-process numbering.  rls_mcpg_local_search_levels draws one coin WORD per 64-chain tile: there offset, period and
+ * skip must be multiples of 64 (RLS_EINVAL otherwise).  Recorded draws (index / u / uniforms / coins: test hooks) stay
+ * indexed by the LOCAL chain. */
+typedef struct rls_chain_ids {
+    int64_t offset;
+    int64_t period;
+    int64_t skip;
+} rls_chain_ids;
+
 /* K9  metro_sampling(probs, start_status, max_transfer_time)  methods/MCPG.py:88-117.
  * Runs rounds t = t_offset .. t_offset + min(T, *t_limit_dev) - 1 for every chain c:
  *   i = index[t,c]; p = x[i,c] ? probs[i] : 1 - probs[i];
  *   accept iff u[t,c] < (1 - p) / p  -> flip x[i,c];  accepts[r][t - t_offset] += #accepted chains (r = tile % accept_rows).
  * index int64 [*,C] and u f32 [*,C] are the reference's randint / rand draws in call order (rows
  * indexed by the absolute round t; test mode) or both NULL for the in-kernel counter-based generator
- * (murmur3 finaliser) keyed by (seed, chain, t).
+ * (murmur3 finaliser) keyed by (seed, global chain id, t) -- chain_ids [host] maps local chains to global ids (NULL: identity).
  * The reference stops after the first round whose cumulative accept count reaches C*T_transfer
  * samples_in (same dtype, may be NULL = samples) is where the chains are READ; they are written to samples:
  * the first chunk of a call turns the caller's start state into the result buffer without a copy.
@@ -459,7 +482,7 @@ int rls_spin_materialize(const rls_spin_env* env, int state_bytes, int64_t B, in
 int rls_mcpg_metro_rounds(void* samples, const void* samples_in, int64_t C_in, int spin_bytes, int64_t N, int64_t C,
                           const float* probs, int64_t T, int64_t t_offset, const int64_t* index, const float* u,
                           uint64_t seed, const int64_t* t_limit_dev, int write_back, int64_t* accepts, int64_t accept_rows,
-                          void* stream);
+                          const rls_chain_ids* chain_ids, void* stream);
 
 /* The stop rule between two chunks of rls_mcpg_metro_rounds (MCPG.py:103,115: the reference compares `count` with
  * total_mcmc_num * max_transfer_time on the host after every round), one small launch instead of a chain of [T]-sized torch ops:
@@ -482,7 +505,7 @@ int64_t rls_mcpg_metro_max_rounds(int64_t N, int32_t spin_bytes);
  *                                            pass 0, else 0|1 (MCPG.py:131-133,142)
  *     x[node,c] = (s + u * 0.25f) < (deg(node) + 0.25f) / 2
  * with u = uniforms[pass, pos, c] (f32 [num_ls,N,C], the torch.rand draws in visiting order; NULL =
- * in-kernel Philox).  Then expected[c] = sum_e (2x_u - 1)(2x_v - 1) over the stored edge list
+ * in-kernel Philox / counter hash keyed by (seed, global chain id [chain_ids, host; NULL = identity], pass, position)).  Then expected[c] = sum_e (2x_u - 1)(2x_v - 1) over the stored edge list
  * (= E - 2*cut, exact in f32).  Outputs xs_out f32 [N,C] (0|1) and expected f32 [C].
  * visit_stream (optional, int32) is the visiting order flattened by the caller: visiting positions level-
  * scheduled (a position's level = 1 + max level of its earlier-visited neighbours; sorted by (level, position))
@@ -504,7 +527,7 @@ int64_t rls_mcpg_metro_max_rounds(int64_t N, int32_t spin_bytes);
 int rls_mcpg_local_search(const rls_graph* g, const void* xs_in, int spin_bytes, float* xs_out, int64_t C,
                           const int32_t* order, const int32_t* visit_stream, int64_t visit_len, int64_t num_ls,
                           const float* uniforms, uint64_t seed, const int32_t* edge_weights, int64_t gauge_node,
-                          float* expected, void* stream);
+                          float* expected, const rls_chain_ids* chain_ids, void* stream);
 
 /* [host] Level-parallel form of the K7 visiting order (lane = node; same dependency-level argument as
  * rls_graph_sweep_levels, levels taken over visiting POSITIONS: order[pos] = node).  The nodes of a level with degree
@@ -529,15 +552,15 @@ int rls_mcpg_visit_levels(const int32_t* rowptr, const int32_t* col, int64_t N, 
                           int64_t ptr_capacity, int32_t* lv_data, int64_t data_capacity, int64_t* num_groups,
                           int64_t* total);
 
-/* K7 + K8 first half on that schedule (production path: tie coins from a counter hash keyed by (seed, 64-chain
- * block, pass, position); coins uint64 [num_ls * N, ceil(C / 64)] -- bit c % 64 of word [pass * N + pos, c / 64] =
+/* K7 + K8 first half on that schedule (production path: tie coins from a counter hash keyed by (seed, GLOBAL 64-chain
+ * block [chain_ids, host; NULL = identity], pass, position); coins uint64 [num_ls * N, ceil(C / 64)] -- bit c % 64 of word [pass * N + pos, c / 64] =
  * "u < 1/2" for chain c -- replaces them for tests).  Same outputs as rls_mcpg_local_search; xs_out is float32
  * node-major (out_spin_bytes = 4) or bit-packed (0; then xs_out may alias a bit-packed xs_in).  C_in: as in
  * rls_mcpg_metro_rounds. */
 int rls_mcpg_local_search_levels(const rls_graph* g, const void* xs_in, int spin_bytes, int64_t C_in, void* xs_out,
                                  int out_spin_bytes, int64_t C, const int32_t* lv_ptr, const int32_t* lv_data,
                                  int64_t num_groups, int64_t num_ls, const uint64_t* coins, uint64_t seed, float* expected,
-                                 void* stream);
+                                 const rls_chain_ids* chain_ids, void* stream);
 
 /* 1 when rls_mcpg_local_search_levels covers this graph with a schedule of num_groups groups (bit tile + group
  * offsets + scratch within 160 KB of LDS, unweighted, N < 2^20, degrees < 1024), else 0. */
@@ -556,9 +579,13 @@ int rls_mcpg_pick_best(const float* expected, const void* xs, int spin_bytes, in
  *   hi = first argmax, lo = first argmin of now_max_res; now_max_res[lo] = now_max_res[hi];
  *   now_info[:, lo] = now_info[:, hi]; temp_info[:, lo] = now_info[:, hi]                                     (:383-391)
  * temp_info afterwards is the start state of the next round (rls_mcpg_metro_rounds with C_in = M).  mask_scratch
- * uint64 [ceil(M/64)]; best_value f32 [1] / best_index int64 [1] (may be NULL) receive max(now_max_res) and its chain. */
+ * uint64 [ceil(M/64)]; best_value f32 [1] / best_index int64 [1] (may be NULL) receive max(now_max_res) and its chain.
+ * replace_worst = 0 (a rank's shard of the kept chains: the worst and the best incumbent are properties of the WHOLE batch):
+ * only the per-chain merge (:377-380) is applied, and best_value / best_index are [2] = {max, min} of the shard's now_max_res
+ * and their first chains -- what the caller needs to replace the global worst by the global best itself. */
 int rls_mcpg_merge_best(const float* temp_max, uint64_t* temp_info, float* now_max_res, uint64_t* now_info, int64_t N,
-                        int64_t total_mcmc_num, uint64_t* mask_scratch, float* best_value, int64_t* best_index, void* stream);
+                        int64_t total_mcmc_num, uint64_t* mask_scratch, float* best_value, int64_t* best_index,
+                        int32_t replace_worst, void* stream);
 
 /* What get_return  methods/MCPG.py:292-302 needs from the samples: A[n] += sum_c value[c] * s[n, c] over the C
  * bit-packed chains (A f32 [N], zeroed by the caller).  With s in {0,1},  log(s p + (1-s)(1-p)) summed over nodes is

@@ -74,7 +74,7 @@ SIGNATURES = {
     "rls_graph_sweep_batches": [_P, _P, _I64, C.c_int32, C.c_int32, _P, _P],
     "rls_graph_sweep_levels": [_P, _P, _I64, _P, _I64, _P, _I64, _P, _P],
     "rls_mcpg_visit_levels": [_P, _P, _I64, _P, _P, _I64, _P, _I64, _P, _P],
-    "rls_mcpg_local_search_levels": [_G, _P, _INT, _I64, _P, _INT, _I64, _P, _P, _I64, _I64, _P, _U64, _P, _P],
+    "rls_mcpg_local_search_levels": [_G, _P, _INT, _I64, _P, _INT, _I64, _P, _P, _I64, _I64, _P, _U64, _P, _P, _P],
     "rls_graph_ell": [_P, _P, _I64, _P, _P, _I64, _P],
     "rls_graph_sweep_schedule": [_P, _P, _I64, C.c_int32, C.c_int32, _P, _P, _P, _P],
     "rls_maxcut_obj": [_G, _P, _INT, _I64, _P, _P],
@@ -85,7 +85,8 @@ SIGNATURES = {
     "rls_maxcut_greedy_sweep": [_G, _P, _I64, _P, _P],
     "rls_maxcut_propose_accept": [_G, _P, _I64, _P, _P, _P],
     "rls_maxcut_ls_weights": [_G, _P, _I64, C.c_int32, _P, C.c_int32, _I64, _P, _P],
-    "rls_maxcut_local_search": [_G, _P, _I64, _P, C.c_int32, _P, _P, _U64, _I64, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P],
+    "rls_maxcut_local_search": [_G, _P, _I64, _P, C.c_int32, _I64, _P, _P, _U64, _I64, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P],
+    "rls_maxcut_ls_normals": [_P, _I64, _I64, _U64, _I64, C.c_int32, _P],
     "rls_maxcut_ls_threshold": [_G, _I64, _P, C.c_int32, _I64, _P, _U64, _I64, C.c_int32, C.c_int32, _P, _P, _I64, _P],
     "rls_maxcut_ls_propose": [_G, _P, _I64, _P, C.c_int32, _I64, _P, _P, _U64, _I64, C.c_int32, _P, _P, _I64, _P],
     "rls_maxcut_ls_rounds": [_G, _P, _I64, _P, C.c_int32, _I64, _P, _P, _U64, _I64, C.c_int32, C.c_int32, _P, _P, _I64, _P],
@@ -102,11 +103,11 @@ SIGNATURES = {
     "rls_spin_reset": [_G, _SE, _INT, _I64, C.c_int32, _P, _F64, _I64, _P],
     "rls_spin_step": [_G, _SE, _INT, _I64, C.c_int32, _P, _P, _P, _P, _F64, _F64, C.c_int32, _F64, _I64, C.c_int32, _F64,
                       C.c_int32, _F64, _P],
-    "rls_mcpg_metro_rounds": [_P, _P, _I64, _INT, _I64, _I64, _P, _I64, _I64, _P, _P, _U64, _P, _INT, _P, _I64, _P],
+    "rls_mcpg_metro_rounds": [_P, _P, _I64, _INT, _I64, _I64, _P, _I64, _I64, _P, _P, _U64, _P, _INT, _P, _I64, _P, _P],
     "rls_mcpg_metro_stop": [_P, _I64, _I64, _I64, C.c_int32, _I64, _P, _P, _P],
-    "rls_mcpg_local_search": [_G, _P, _INT, _P, _I64, _P, _P, _I64, _I64, _P, _U64, _P, _I64, _P, _P],
+    "rls_mcpg_local_search": [_G, _P, _INT, _P, _I64, _P, _P, _I64, _I64, _P, _U64, _P, _I64, _P, _P, _P],
     "rls_mcpg_pick_best": [_P, _P, _INT, _I64, _I64, _I64, _I64, _P, _P, _P, _P],
-    "rls_mcpg_merge_best": [_P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P],
+    "rls_mcpg_merge_best": [_P, _P, _P, _P, _I64, _I64, _P, _P, _P, C.c_int32, _P],
     "rls_mcpg_value_bit_sums": [_P, _I64, _I64, _P, _P, _P],
     "rls_mcpg_pack_chains": [_P, _INT, _I64, _I64, _P, _P],
     "rls_mcpg_unpack_chains": [_P, _I64, _I64, _P, _P],

@@ -72,13 +72,14 @@ __device__ __forceinline__ void normal4(uint32_t env_key, uint32_t q, uint32_t i
     z[2] = rb * __builtin_amdgcn_cosf(t4); z[3] = rb * __builtin_amdgcn_sinf(t4);
 }
 
-// ALIGNED: rows of x, ws and noise start on 16-byte boundaries (N % 16 == 0 and aligned bases): 16-byte row pieces
-// everywhere; else element-wise loads.  WT = int8_t | int16_t.
+// ALIGNED (the only form built since round 3): rows of x and noise start 4-byte aligned on 16-byte bases (N % 4 == 0), rows
+// of ws sit `pitch` entries apart, a multiple of 16 bytes, so every 16-byte piece of a ws row lies inside the row.
+// WT = int8_t | int16_t.
 template <bool ALIGNED, typename WT, int P, int W>
 __global__ __launch_bounds__(W * kWave) void k_maxcut_local_search(
     uint8_t* __restrict__ x, int64_t B, int64_t N, const int32_t* __restrict__ eu, const int32_t* __restrict__ ev,
     int64_t E, int halve, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ sweep_src, int64_t sweep_len,
-    const WT* __restrict__ ws, const float* __restrict__ rd_std, const float* __restrict__ noise, uint64_t seed,
+    const WT* __restrict__ ws, int64_t pitch, const float* __restrict__ rd_std, const float* __restrict__ noise, uint64_t seed,
     int64_t env_offset, int num_iters, int num_spin, int first_draw_proposes, int64_t* __restrict__ obj,
     int compute_obj, int batched) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -132,7 +133,7 @@ __global__ __launch_bounds__(W * kWave) void k_maxcut_local_search(
         my_obj = valid ? obj[b] : 0;
     }
 
-    const WT* ws_row = ws + (valid ? b : 0) * N;
+    const WT* ws_row = ws + (valid ? b : 0) * pitch;   // rows `pitch` entries apart, a multiple of 16 bytes: every 16-byte piece lies inside its row
     constexpr int NPC = 16 / (int)sizeof(WT);     // nodes per 16-byte piece of a ws row
     constexpr int QPP = NPC / 4;                  // quads (4 nodes: the unit of the noise / mask code) per piece
     const int64_t nquads = (N + 3) >> 2;
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(W * kWave) void k_maxcut_local_search(
                 if constexpr (V4) {
                     const int64_t rw = b0 + kStageRows * i + io_r;
                     const int64_t pc = c * 4 + io_j;
-                    if (c < nchunks && rw < B && pc < npieces) g[d][i] = *reinterpret_cast<const i32x4*>(ws + rw * N + pc * NPC);
+                    if (c < nchunks && rw < B && pc < npieces) g[d][i] = *reinterpret_cast<const i32x4*>(ws + rw * pitch + pc * NPC);
                 } else {   // unaligned rows: each lane reads its own env's piece i of the chunk, element-wise
                     const int64_t n0 = (c * 4 + i) * NPC;
                     if (c < nchunks && valid) {
@@ -370,6 +371,23 @@ __global__ __launch_bounds__(W * kWave) void k_maxcut_local_search(
 // =====================================================================================
 __device__ __forceinline__ uint32_t ls_env_key(uint64_t seed, uint64_t gb) {   // (the fused kernel's mix)
     return fmix32((uint32_t)seed ^ fmix32((uint32_t)(seed >> 32) ^ fmix32((uint32_t)gb) ^ ((uint32_t)(gb >> 32) * 0x9E3779B1u)));
+}
+
+// The draws themselves, as a tensor: out[b, n] = normal(seed, env_offset + b, n, draw), the value every local-search kernel
+// above and below uses for that (env, node, draw).  For the decomposed path (weights wider than 16 bits, graphs outside
+// every tile form), which used torch.randn -- not keyed by the global env -- and for the statistical tests of the draws.
+__global__ __launch_bounds__(256) void k_ls_normals(float* __restrict__ out, int64_t B, int64_t N, uint64_t seed,
+                                                   int64_t env_offset, int draw) {
+    const int64_t nquads = (N + 3) >> 2;
+    const int64_t total = B * nquads;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / nquads, q = i - b * nquads;
+        float z[4];
+        normal4(ls_env_key(seed, (uint64_t)(b + env_offset)), (uint32_t)q, (uint32_t)draw, z);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (q * 4 + k < N) out[b * N + q * 4 + k] = z[k];
+    }
 }
 
 // One pass over the ws rows of the tile's 64 envs (lane = env): f(pc, v[NPC]) for every 16-byte piece pc of this wave's
@@ -721,6 +739,11 @@ static int ls_pick_waves(int64_t N, int64_t B) {
     return ls_lds_bytes(N, W) <= (size_t)kLdsBytes ? W : 0;
 }
 
+// ws rows start ws_pitch ENTRIES apart (0 = N): any N works once the pitch is a multiple of 16 bytes
+static bool ls_pitch_ok(const void* ws, int64_t pitch, int32_t ws_bytes, int64_t N) {
+    return pitch >= N && ((pitch * ws_bytes) & 15) == 0 && (((uintptr_t)ws) & 15) == 0;
+}
+
 extern "C" int rls_maxcut_local_search_supported(const rls_graph* g, int64_t B, int32_t num_spin) {
     if (!g || g->num_nodes <= 0) return 0;
     const int64_t N = g->num_nodes;
@@ -731,7 +754,7 @@ extern "C" int rls_maxcut_local_search_supported(const rls_graph* g, int64_t B, 
     return ls_pick_waves(N, B > 0 ? B : 1) != 0;
 }
 
-extern "C" int rls_maxcut_local_search(const rls_graph* g, uint8_t* x, int64_t B, const void* ws, int32_t ws_bytes,
+extern "C" int rls_maxcut_local_search(const rls_graph* g, uint8_t* x, int64_t B, const void* ws, int32_t ws_bytes, int64_t ws_pitch,
                                        const float* rd_std, const float* noise, uint64_t seed, int64_t env_offset,
                                        int32_t num_iters, int32_t num_spin, int32_t first_draw_proposes, int64_t* obj,
                                        int32_t compute_obj, void* stream) {
@@ -745,9 +768,15 @@ extern "C" int rls_maxcut_local_search(const rls_graph* g, uint8_t* x, int64_t B
                 "num_spin=%d outside [0, %d] (and < N)", num_spin, kTopCap - 1);
     RLS_REQUIRE(!g->wgt && g->max_degree < kRingMaxRun, RLS_EUNSUPPORTED,
                 "fused local search needs an unweighted graph with max degree < %d", kRingMaxRun);
-    // 16-byte row pieces of x, ws and noise: N % 16 == 0 and aligned bases
-    const bool aligned = tile_rows_aligned(x, N, 1) && ((((uintptr_t)ws) | ((uintptr_t)noise)) & 15) == 0;
-    RLS_REQUIRE(aligned, RLS_EUNSUPPORTED, "fused local search needs rows of x, ws and noise that start 4-byte aligned on 16-byte bases "
+    // x and noise: rows that start 4-byte aligned on 16-byte bases (N % 4 == 0).  ws is read in 16-byte pieces, the last piece
+    // of a row included: its rows sit ws_pitch entries apart, a multiple of 16 bytes (rls_maxcut_ls_weights writes that layout),
+    // so no piece leaves its row -- an exactly sized [B, N] array whose rows are not 16-byte multiples is refused, not over-read
+    if (ws_pitch == 0) ws_pitch = N;
+    RLS_REQUIRE(ls_pitch_ok(ws, ws_pitch, ws_bytes, N), RLS_EUNSUPPORTED,
+                "fused local search reads ws in 16-byte pieces: rows must sit a multiple of 16 bytes apart on a 16-byte base "
+                "(ws_pitch=%lld entries of %d bytes, N=%lld)", (long long)ws_pitch, (int)ws_bytes, (long long)N);
+    const bool aligned = tile_rows_aligned(x, N, 1) && (((uintptr_t)noise) & 15) == 0;
+    RLS_REQUIRE(aligned, RLS_EUNSUPPORTED, "fused local search needs rows of x and noise that start 4-byte aligned on 16-byte bases "
                 "(N=%lld): rls_maxcut_ls_threshold / rls_maxcut_ls_rounds take any layout", (long long)N);
     int W = ls_pick_waves(N, B);
     RLS_REQUIRE(W != 0, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS (max %d)", (long long)N, ls_lds_bytes(N, 4), kLdsBytes);
@@ -771,7 +800,7 @@ extern "C" int rls_maxcut_local_search(const rls_graph* g, uint8_t* x, int64_t B
         if (lds > 64 * 1024)                                                                                         \
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
         hipLaunchKernelGGL(kern, grid, block, lds, s, x, B, N, g->eu, g->ev, E, halve, rp_src, sw_src, sw_len,        \
-                           (const WT*)ws, rd_std, noise, seed, env_offset, (int)num_iters, (int)num_spin,             \
+                           (const WT*)ws, ws_pitch, rd_std, noise, seed, env_offset, (int)num_iters, (int)num_spin,   \
                            (int)first_draw_proposes, obj, (int)compute_obj, batched);                                 \
     } while (0)
     // two counter widths (the 12- and 20-plane forms of the edge counter save a few carry steps per 1024 edges: not worth
@@ -820,10 +849,6 @@ extern "C" int rls_maxcut_ls_slices(const rls_graph* g, int64_t B, int32_t ws_by
     return ls_slices(B, ws_bytes == 1 ? ls_num_chunks<int8_t>(g->num_nodes) : ls_num_chunks<int16_t>(g->num_nodes));
 }
 
-// ws rows start ws_pitch ENTRIES apart (0 = N): any N works once the pitch is a multiple of 16 bytes
-static bool ls_pitch_ok(const void* ws, int64_t pitch, int32_t ws_bytes, int64_t N) {
-    return pitch >= N && ((pitch * ws_bytes) & 15) == 0 && (((uintptr_t)ws) & 15) == 0;
-}
 
 extern "C" int rls_maxcut_ls_threshold(const rls_graph* g, int64_t B, const void* ws, int32_t ws_bytes, int64_t ws_pitch,
                                        const float* rd_std, uint64_t seed, int64_t env_offset, int32_t draw, int32_t num_spin,
@@ -995,3 +1020,11 @@ extern "C" int rls_maxcut_ls_rounds(const rls_graph* g, uint8_t* x, int64_t B, c
     return RLS_OK;
 }
 
+extern "C" int rls_maxcut_ls_normals(float* out, int64_t B, int64_t N, uint64_t seed, int64_t env_offset, int32_t draw, void* stream) {
+    RLS_REQUIRE(B >= 0 && N > 0 && draw >= 0 && env_offset >= 0, RLS_EINVAL, "bad sizes B=%lld N=%lld draw=%d", (long long)B, (long long)N, (int)draw);
+    if (B == 0) return RLS_OK;
+    RLS_REQUIRE(out, RLS_EINVAL, "out is NULL");
+    hipLaunchKernelGGL(k_ls_normals, dim3((unsigned)grid_for(B * ((N + 3) >> 2), 256)), dim3(256), 0, as_stream(stream), out, B, N, seed,
+                       env_offset, (int)draw);
+    return check_launch("k_ls_normals");
+}

@@ -112,13 +112,25 @@ __device__ __forceinline__ uint32_t k7_fmix32(uint32_t h) {
     return h;
 }
 
+// Global id of local chain c (rls_chain_ids): the key of every counter-based draw, so that a rank's shard of the chains
+// draws exactly what those chains draw in an unsharded run.  period > 0: the local batch is repeats of `period` kept
+// chains (chain c = repeat c / period of kept chain c % period) cut out of a global batch whose repeats are period + skip
+// chains apart.
+struct ChainIds {
+    int64_t offset, period, skip;
+    __device__ __forceinline__ int64_t operator()(int64_t c) const {
+        return offset + c + (period > 0 ? (c / period) * skip : 0);
+    }
+};
+
 template <typename T, bool PROBS_LDS>
 __global__ __launch_bounds__(kMetroWaves * kWave) void k_mcpg_metro(T* samples, const T* samples_in, int64_t N, int64_t C,
                                                       const float* __restrict__ probs, int64_t T_rounds,
                                                       const int64_t* __restrict__ index,
                                                       const float* __restrict__ u, uint64_t seed,
                                                       const int64_t* __restrict__ t_limit_dev, int write_back,
-                                                      unsigned long long* __restrict__ accepts_all, int64_t accept_rows, int64_t t_offset) {
+                                                      unsigned long long* __restrict__ accepts_all, int64_t accept_rows, int64_t t_offset,
+                                                      ChainIds ids) {
     // accept counts go to row (workgroup % accept_rows) of [accept_rows][T_rounds]: thousands of workgroups adding into ONE row
     // serialise at the L2 atomic units (measured: 3/4 of the packed walk's time)
     unsigned long long* accepts = accepts_all ? accepts_all + (int64_t)(blockIdx.x % (unsigned)accept_rows) * T_rounds : nullptr;
@@ -144,8 +156,9 @@ __global__ __launch_bounds__(kMetroWaves * kWave) void k_mcpg_metro(T* samples, 
         const int64_t lim = *t_limit_dev;
         t_end = lim < T_rounds ? (lim > 0 ? lim : 0) : T_rounds;
     }
-    const uint32_t chain_key = k7_fmix32((uint32_t)seed ^ k7_fmix32((uint32_t)(seed >> 32) ^ k7_fmix32((uint32_t)c) ^
-                                                                    ((uint32_t)((uint64_t)c >> 32) * 0x9E3779B1u)));
+    const int64_t gc = ids(c);                                  // the chain's global id
+    const uint32_t chain_key = k7_fmix32((uint32_t)seed ^ k7_fmix32((uint32_t)(seed >> 32) ^ k7_fmix32((uint32_t)gc) ^
+                                                                    ((uint32_t)((uint64_t)gc >> 32) * 0x9E3779B1u)));
     const uint64_t mybit = 1ull << lane;
     const BitXpose xc = bit_xpose_consts(lane);
     uint32_t alo = 0, ahi = 0;                        // this chain's accept bits of the current 64 rounds
@@ -215,7 +228,8 @@ __global__ __launch_bounds__(kMetroPW * kWave) void k_mcpg_metro_packed(uint64_t
                                                              int64_t T_rounds, const int64_t* __restrict__ index,
                                                              const float* __restrict__ u, uint64_t seed,
                                                              const int64_t* __restrict__ t_limit_dev, int write_back,
-                                                             unsigned long long* __restrict__ accepts_all, int64_t accept_rows, int64_t t_offset) {
+                                                             unsigned long long* __restrict__ accepts_all, int64_t accept_rows, int64_t t_offset,
+                                                             ChainIds ids) {
     // accept counts go to row (workgroup % accept_rows) of [accept_rows][T_rounds]: thousands of workgroups adding into ONE row
     // serialise at the L2 atomic units (measured: 3/4 of the packed walk's time)
     unsigned long long* accepts = accepts_all ? accepts_all + (int64_t)(blockIdx.x % (unsigned)accept_rows) * T_rounds : nullptr;
@@ -235,8 +249,9 @@ __global__ __launch_bounds__(kMetroPW * kWave) void k_mcpg_metro_packed(uint64_t
     }
     if (t_end == 0 && in_place) return;           // stop rule already met and nothing to move
     tile_load_packed(samples_in, N, C, tile, tiles_in, words, threadIdx.x, kMetroPW * kWave);
-    const uint32_t chain_key = k7_fmix32((uint32_t)seed ^ k7_fmix32((uint32_t)(seed >> 32) ^ k7_fmix32((uint32_t)c) ^
-                                                                    ((uint32_t)((uint64_t)c >> 32) * 0x9E3779B1u)));
+    const int64_t gc = ids(c);                                  // the chain's global id
+    const uint32_t chain_key = k7_fmix32((uint32_t)seed ^ k7_fmix32((uint32_t)(seed >> 32) ^ k7_fmix32((uint32_t)gc) ^
+                                                                    ((uint32_t)((uint64_t)gc >> 32) * 0x9E3779B1u)));
     const int64_t nwin = (t_end + kMetroWin - 1) / kMetroWin;
     auto produce = [&](int64_t win) {             // waves 1 .. PW-1 share the window's rounds
         uint32_t* q = queue + (win & 1) * (kMetroWin * kWave);
@@ -350,7 +365,7 @@ __global__ __launch_bounds__(kWave) void k_mcpg_local_search(const TI* __restric
                                                              const float* __restrict__ uniforms, uint64_t seed,
                                                              const int32_t* __restrict__ eu,
                                                              const int32_t* __restrict__ ev, int64_t E,
-                                                             float* __restrict__ expected) {
+                                                             float* __restrict__ expected, ChainIds ids) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* words = reinterpret_cast<uint64_t*>(smem);
     uint32_t* updated = reinterpret_cast<uint32_t*>(words + N);  // 1 bit per node: visited in pass 0
@@ -364,6 +379,7 @@ __global__ __launch_bounds__(kWave) void k_mcpg_local_search(const TI* __restric
     __syncthreads();
     const int half = lane >> 5, sh = lane & 31;
     const Philox ph(seed);
+    const int64_t gc = ids(c);                                  // the chain's global id
     for (int64_t cnt = 0; cnt < num_ls; ++cnt) {
         for (int64_t pos = 0; pos < N; ++pos) {
             const int node = order[pos];
@@ -385,7 +401,7 @@ __global__ __launch_bounds__(kWave) void k_mcpg_local_search(const TI* __restric
                 uu = valid ? uniforms[(cnt * N + pos) * C + c] : 0.0f;
             } else {
                 uint32_t r[4];
-                ph((uint32_t)c, (uint32_t)((uint64_t)c >> 32), (uint32_t)(cnt * N + pos), 0x4C4F4353u, r);
+                ph((uint32_t)gc, (uint32_t)((uint64_t)gc >> 32), (uint32_t)(cnt * N + pos), 0x4C4F4353u, r);
                 uu = u32_to_unit_float(r[0]);
             }
             const float rv = (float)s2 * 0.5f + uu * 0.25f;                   // MCPG.py:139-141
@@ -431,7 +447,7 @@ __global__ __launch_bounds__(kK7Waves * kWave) void k_mcpg_local_search_stream(
     const TI* __restrict__ xs_in, float* __restrict__ xs_out, int64_t N, int64_t C,
     const int32_t* __restrict__ vstream, int64_t vlen, int64_t num_ls, const float* __restrict__ uniforms,
     uint64_t seed, const int32_t* __restrict__ eu, const int32_t* __restrict__ ev, const int32_t* __restrict__ ew, int64_t E,
-    int gauge_node, float* __restrict__ expected) {
+    int gauge_node, float* __restrict__ expected, ChainIds ids) {
     constexpr int HDR = WEIGHTED ? 5 : 4;                 // header words of a node record
     constexpr int FIRST = WEIGHTED ? 28 : 56;             // neighbours whose entries sit in the record's first 64 words
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -456,8 +472,9 @@ __global__ __launch_bounds__(kK7Waves * kWave) void k_mcpg_local_search_stream(
     const int sh = lane & 31;
     const uint32_t half4 = (uint32_t)(lane >> 5) * 4u;
     const uint32_t sentinel = (uint32_t)N;
-    const uint32_t chain_key = k7_fmix32((uint32_t)seed ^ k7_fmix32((uint32_t)(seed >> 32) ^ k7_fmix32((uint32_t)c) ^
-                                                                    ((uint32_t)((uint64_t)c >> 32) * 0x9E3779B1u)));
+    const int64_t gc = ids(c);                                  // the chain's global id
+    const uint32_t chain_key = k7_fmix32((uint32_t)seed ^ k7_fmix32((uint32_t)(seed >> 32) ^ k7_fmix32((uint32_t)gc) ^
+                                                                    ((uint32_t)((uint64_t)gc >> 32) * 0x9E3779B1u)));
     auto bit_of = [&](uint32_t e) -> uint32_t {
         return (*reinterpret_cast<const uint32_t*>(wbytes + ((e & 0x7fffffffu) * 8u + half4)) >> sh) & 1u;
     };
@@ -745,7 +762,7 @@ __global__ __launch_bounds__(W * kWave) void k_mcpg_local_search_levels(
     const typename ChainStore<TI>::type* __restrict__ xs_in, typename ChainStore<TO>::type* __restrict__ xs_out, int64_t N,
     int64_t C, int64_t tiles_in, const int32_t* __restrict__ lv_ptr, const int32_t* __restrict__ data, int64_t G,
     int64_t num_ls, const uint64_t* __restrict__ coins, uint64_t seed, const int32_t* __restrict__ eu,
-    const int32_t* __restrict__ ev, int64_t E, float* __restrict__ expected) {
+    const int32_t* __restrict__ ev, int64_t E, float* __restrict__ expected, ChainIds ids) {
     constexpr uint32_t M30 = 0x3fffffffu;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* words = reinterpret_cast<uint64_t*>(smem);
@@ -765,7 +782,7 @@ __global__ __launch_bounds__(W * kWave) void k_mcpg_local_search_levels(
     if constexpr (std::is_same<TI, Packed64>::value) tile_load_packed(xs_in, N, C, blockIdx.x, tiles_in, words, threadIdx.x, W * kWave);
     else tile_load_bits_nodemajor<TI>(xs_in, N, C, c0, words, lane, w, W);
     const uint32_t blk_key = k7_fmix32((uint32_t)seed ^ k7_fmix32((uint32_t)(seed >> 32) ^
-                                                                  k7_fmix32((uint32_t)blockIdx.x * 0x9E3779B1u + 0x632BE5ABu)));
+                                                                  k7_fmix32((uint32_t)(ids(c0) >> 6) * 0x9E3779B1u + 0x632BE5ABu)));   // the tile's global id
     const BitXpose xc = bit_xpose_consts(lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();   // the tile is complete before any wave reads a neighbour word
@@ -944,7 +961,8 @@ __global__ void k_mcpg_merge_apply(const uint64_t* __restrict__ temp_info, uint6
 
 __global__ __launch_bounds__(1024) void k_mcpg_merge_minmax(float* __restrict__ now_max_res, int64_t M, int64_t N,
                                                             uint64_t* __restrict__ now_info, uint64_t* __restrict__ temp_info,
-                                                            float* __restrict__ best_value, int64_t* __restrict__ best_index) {
+                                                            float* __restrict__ best_value, int64_t* __restrict__ best_index,
+                                                            int replace_worst) {
     __shared__ float s_hi[16], s_lo[16];
     __shared__ int64_t s_hii[16], s_loi[16];
     float hi = -INFINITY, lo = INFINITY;
@@ -967,6 +985,13 @@ __global__ __launch_bounds__(1024) void k_mcpg_merge_minmax(float* __restrict__ 
     for (int k = 0; k < (int)(blockDim.x >> 6); ++k) {
         if (s_hi[k] > hi || (s_hi[k] == hi && s_hii[k] < hii)) { hi = s_hi[k]; hii = s_hii[k]; }
         if (s_lo[k] < lo || (s_lo[k] == lo && s_loi[k] < loi)) { lo = s_lo[k]; loi = s_loi[k]; }
+    }
+    if (!replace_worst) {   // a shard of the kept chains: the caller replaces the GLOBAL worst by the GLOBAL best itself
+        if (threadIdx.x == 0) {
+            best_value[0] = hi; best_value[1] = lo;
+            best_index[0] = hii; best_index[1] = loi;
+        }
+        return;
     }
     if (threadIdx.x == 0) {
         now_max_res[loi] = hi;                                                  // :388
@@ -1209,12 +1234,25 @@ __global__ __launch_bounds__(kStopWaves * kWave) void k_metro_stop(const int64_t
 
 using namespace rls;
 
+// rls_chain_ids -> the kernels' by-value form; NULL = the identity (a single-process run)
+static int chain_ids_arg(const rls_chain_ids* in, bool whole_tiles, ChainIds& out) {
+    out = ChainIds{0, 0, 0};
+    if (!in) return RLS_OK;
+    RLS_REQUIRE(in->offset >= 0 && in->period >= 0 && in->skip >= 0, RLS_EINVAL, "chain_ids: negative offset / period / skip");
+    RLS_REQUIRE(!whole_tiles || ((in->offset | in->period | in->skip) & (kWave - 1)) == 0, RLS_EINVAL,
+                "chain_ids: this kernel draws per 64-chain tile; offset, period and skip must be multiples of 64");
+    out = ChainIds{in->offset, in->period, in->period > 0 ? in->skip : 0};
+    return RLS_OK;
+}
+
 extern "C" {
 
 int rls_mcpg_metro_rounds(void* samples, const void* samples_in, int64_t C_in, int spin_bytes, int64_t N, int64_t C,
                           const float* probs, int64_t T, int64_t t_offset, const int64_t* index, const float* u,
                           uint64_t seed, const int64_t* t_limit_dev, int write_back, int64_t* accepts, int64_t accept_rows,
-                          void* stream) {
+                          const rls_chain_ids* chain_ids, void* stream) {
+    ChainIds ids;
+    if (int rc = chain_ids_arg(chain_ids, false, ids)) return rc;
     RLS_REQUIRE(N > 0 && C >= 0 && T >= 0 && t_offset >= 0, RLS_EINVAL, "bad sizes N=%lld C=%lld T=%lld", (long long)N, (long long)C,
                 (long long)T);
     if (C == 0) return RLS_OK;
@@ -1237,7 +1275,7 @@ int rls_mcpg_metro_rounds(void* samples, const void* samples_in, int64_t C_in, i
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(C, kWave)), dim3(kMetroPW * kWave), lds, as_stream(stream),
                            (uint64_t*)samples, (const uint64_t*)samples_in, ceil_div(C_in, kWave), N, C, probs, T, index, u, seed,
-                           t_limit_dev, write_back, (unsigned long long*)accepts, accept_rows, t_offset);
+                           t_limit_dev, write_back, (unsigned long long*)accepts, accept_rows, t_offset, ids);
         return check_launch("k_mcpg_metro_packed");
     }
     RLS_REQUIRE(C_in == C, RLS_EINVAL, "a broadcast start state (C_in != C) needs the bit-packed layout");
@@ -1254,7 +1292,7 @@ int rls_mcpg_metro_rounds(void* samples, const void* samples_in, int64_t C_in, i
         if (lds > 64 * 1024)                                                                                        \
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
         hipLaunchKernelGGL(kern, grid, block, lds, s, (TT*)samples, (const TT*)samples_in, N, C, probs, T, index, u, seed, t_limit_dev, \
-                           write_back, (unsigned long long*)accepts, accept_rows, t_offset);                        \
+                           write_back, (unsigned long long*)accepts, accept_rows, t_offset, ids);                   \
     } while (0)
     if (spin_bytes == 1) { if (probs_lds) LAUNCH_METRO(uint8_t, true); else LAUNCH_METRO(uint8_t, false); }
     else                 { if (probs_lds) LAUNCH_METRO(float, true);   else LAUNCH_METRO(float, false); }
@@ -1296,8 +1334,10 @@ int rls_mcpg_local_search_levels_supported(const rls_graph* g, int64_t num_group
 int rls_mcpg_local_search_levels(const rls_graph* g, const void* xs_in, int spin_bytes, int64_t C_in, void* xs_out,
                                  int out_spin_bytes, int64_t C, const int32_t* lv_ptr, const int32_t* lv_data,
                                  int64_t num_groups, int64_t num_ls, const uint64_t* coins, uint64_t seed, float* expected,
-                                 void* stream) {
+                                 const rls_chain_ids* chain_ids, void* stream) {
     if (int rc = check_graph(g)) return rc;
+    ChainIds ids;
+    if (int rc = chain_ids_arg(chain_ids, true, ids)) return rc;
     RLS_REQUIRE(C >= 0 && num_ls >= 0 && num_groups > 0, RLS_EINVAL, "bad sizes");
     if (C == 0) return RLS_OK;
     RLS_REQUIRE(xs_in && xs_out && lv_ptr && lv_data && expected, RLS_EINVAL, "NULL pointer");
@@ -1327,7 +1367,7 @@ int rls_mcpg_local_search_levels(const rls_graph* g, const void* xs_in, int spin
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(kern, grid, dim3(WW * kWave), lds, s, (const typename ChainStore<TI>::type*)xs_in,   \
                            (typename ChainStore<TO>::type*)xs_out, N, C, tiles_in, lv_ptr, lv_data, num_groups,  \
-                           num_ls, coins, seed, g->eu, g->ev, E, expected);                                      \
+                           num_ls, coins, seed, g->eu, g->ev, E, expected, ids);                                 \
     } while (0)
 #define DISPATCH_LVL(TI, TO, WW)                      \
     switch (P) {                                      \
@@ -1354,8 +1394,10 @@ int rls_mcpg_local_search_levels(const rls_graph* g, const void* xs_in, int spin
 int rls_mcpg_local_search(const rls_graph* g, const void* xs_in, int spin_bytes, float* xs_out, int64_t C,
                           const int32_t* order, const int32_t* visit_stream, int64_t visit_len, int64_t num_ls,
                           const float* uniforms, uint64_t seed, const int32_t* edge_weights, int64_t gauge_node,
-                          float* expected, void* stream) {
+                          float* expected, const rls_chain_ids* chain_ids, void* stream) {
     if (int rc = check_graph(g)) return rc;
+    ChainIds ids;
+    if (int rc = chain_ids_arg(chain_ids, false, ids)) return rc;
     RLS_REQUIRE(C >= 0 && num_ls >= 0, RLS_EINVAL, "bad sizes");
     if (C == 0) return RLS_OK;
     RLS_REQUIRE(xs_in && xs_out && order && expected, RLS_EINVAL, "NULL pointer");
@@ -1386,7 +1428,7 @@ int rls_mcpg_local_search(const rls_graph* g, const void* xs_in, int spin_bytes,
         if (lds_fast > 64 * 1024)                                                                                    \
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fast); \
         hipLaunchKernelGGL(kern, grid, block, lds_fast, s, (const TI*)xs_in, xs_out, N, C, visit_stream, visit_len,   \
-                           num_ls, uniforms, seed, g->eu, g->ev, edge_weights, E, gn, expected);                      \
+                           num_ls, uniforms, seed, g->eu, g->ev, edge_weights, E, gn, expected, ids);                 \
     } while (0)
 #define DISPATCH_PS(TI)                              \
     if (weighted) { LAUNCH_LSS(TI, 12, true); }      \
@@ -1410,7 +1452,7 @@ int rls_mcpg_local_search(const rls_graph* g, const void* xs_in, int spin_bytes,
         if (lds > 64 * 1024)                                                                                    \
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(kern, grid, block, lds, s, (const TI*)xs_in, xs_out, N, C, g->rowptr, g->col, order, \
-                           num_ls, uniforms, seed, g->eu, g->ev, E, expected);                                  \
+                           num_ls, uniforms, seed, g->eu, g->ev, E, expected, ids);                             \
     } while (0)
 #define DISPATCH_P(TI)                       \
     switch (P) {                             \
@@ -1444,9 +1486,11 @@ int rls_mcpg_pick_best(const float* expected, const void* xs, int spin_bytes, in
 }
 
 int rls_mcpg_merge_best(const float* temp_max, uint64_t* temp_info, float* now_max_res, uint64_t* now_info, int64_t N,
-                        int64_t total_mcmc_num, uint64_t* mask_scratch, float* best_value, int64_t* best_index, void* stream) {
+                        int64_t total_mcmc_num, uint64_t* mask_scratch, float* best_value, int64_t* best_index,
+                        int32_t replace_worst, void* stream) {
     RLS_REQUIRE(N > 0 && total_mcmc_num > 0, RLS_EINVAL, "bad sizes");
     RLS_REQUIRE(temp_max && temp_info && now_max_res && now_info && mask_scratch, RLS_EINVAL, "NULL pointer");
+    RLS_REQUIRE(replace_worst || (best_value && best_index), RLS_EINVAL, "replace_worst = 0 reports {max, min}: best_value / best_index [2] are needed");
     const int64_t M = total_mcmc_num, tiles = ceil_div(M, kWave);
     hipStream_t s = as_stream(stream);
     hipLaunchKernelGGL(k_mcpg_merge_mask, dim3((unsigned)ceil_div(tiles * kWave, 256)), dim3(256), 0, s, temp_max, now_max_res, M,
@@ -1454,7 +1498,7 @@ int rls_mcpg_merge_best(const float* temp_max, uint64_t* temp_info, float* now_m
     hipLaunchKernelGGL(k_mcpg_merge_apply, dim3(grid_for(tiles * N, 256)), dim3(256), 0, s, temp_info, now_info, N, tiles,
                        mask_scratch);
     hipLaunchKernelGGL(k_mcpg_merge_minmax, dim3(1), dim3(1024), 0, s, now_max_res, M, N, now_info, temp_info, best_value,
-                       best_index);
+                       best_index, (int)(replace_worst != 0));
     return check_launch("k_mcpg_merge_best");
 }
 

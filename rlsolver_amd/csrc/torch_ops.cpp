@@ -191,7 +191,8 @@ void maxcut_local_search(int64_t g, Tensor xs, const Tensor& ws, const Tensor& r
     spin_bytes(xs, "xs", false);
     const int64_t B = env_rows(xs, "xs", G(g)), N = G(g)->num_nodes;
     const int wb = ws_bytes_of(ws, false);
-    shape2(ws, "ws", B, N);
+    // rows of ws sit ws.size(1) entries apart; the library refuses a pitch that is not a multiple of 16 bytes (it reads 16-byte pieces)
+    TORCH_CHECK(ws.dim() == 2 && ws.size(0) == B && ws.size(1) >= N, "ws must be [", B, ", >= ", N, "], got ", ws.sizes());
     dev(rd_std, "rd_std", F32);
     count(rd_std, "rd_std", N);
     optdev(noise, "noise", F32);
@@ -201,9 +202,16 @@ void maxcut_local_search(int64_t g, Tensor xs, const Tensor& ws, const Tensor& r
     dev(obj, "obj", I64);
     count(obj, "obj", B);
     RLS_GUARD(xs);
-    ok(rls_maxcut_local_search(G(g), (uint8_t*)p(xs), B, p(ws), wb, (const float*)p(rd_std), (const float*)p(noise),
+    ok(rls_maxcut_local_search(G(g), (uint8_t*)p(xs), B, p(ws), wb, ws.size(1), (const float*)p(rd_std), (const float*)p(noise),
                                (uint64_t)seed, env_offset, (int32_t)num_iters, (int32_t)num_spin, first_draw_proposes, (int64_t*)p(obj),
                                compute_obj, cur_stream(xs)), "rls_maxcut_local_search");
+}
+void maxcut_ls_normals(Tensor out, int64_t seed, int64_t env_offset, int64_t draw) {
+    dev(out, "out", F32);
+    TORCH_CHECK(out.dim() == 2, "out must be [B, N]");
+    RLS_GUARD(out);
+    ok(rls_maxcut_ls_normals((float*)p(out), out.size(0), out.size(1), (uint64_t)seed, env_offset, (int32_t)draw, cur_stream(out)),
+       "rls_maxcut_ls_normals");
 }
 static int64_t scratch_of(const OptTensor& scratch) {   // a flat byte buffer on the device, or none
     if (!scratch.has_value()) return 0;
@@ -474,9 +482,19 @@ inline void chain_shape(const Tensor& t, int sb, int64_t N, int64_t C, const cha
     if (sb == 0) shape2(t, name, (C + 63) / 64, N);
     else shape2(t, name, N, C);
 }
+// (offset, period, skip) of the op schemas -> rls_chain_ids; all zero = NULL (the single-process numbering)
+struct ChainIdsArg {
+    rls_chain_ids ids;
+    bool any;
+    ChainIdsArg(int64_t offset, int64_t period, int64_t skip) : ids{offset, period, skip}, any(offset != 0 || period != 0 || skip != 0) {
+        TORCH_CHECK(offset >= 0 && period >= 0 && skip >= 0, "chain_offset / chain_period / chain_skip must be >= 0");
+    }
+    const rls_chain_ids* ptr() const { return any ? &ids : nullptr; }
+};
 void mcpg_metro_rounds(Tensor samples, const OptTensor& samples_in, int64_t C_in, int64_t C, const Tensor& probs, int64_t T,
                        int64_t t_offset, const OptTensor& index, const OptTensor& u, int64_t seed, const OptTensor& t_limit, bool write_back,
-                       const OptTensor& accepts) {
+                       const OptTensor& accepts, int64_t chain_offset, int64_t chain_period, int64_t chain_skip) {
+    const ChainIdsArg cid(chain_offset, chain_period, chain_skip);
     const int sb = chain_bytes(samples, "samples");
     const int64_t N = chain_nodes(samples, sb, "samples");
     chain_shape(samples, sb, N, C, "samples");
@@ -503,7 +521,7 @@ void mcpg_metro_rounds(Tensor samples, const OptTensor& samples_in, int64_t C_in
     RLS_GUARD(samples);
     ok(rls_mcpg_metro_rounds(p(samples), p(samples_in), C_in, sb, N, C, (const float*)p(probs), T, t_offset, (const int64_t*)p(index),
                              (const float*)p(u), (uint64_t)seed, (const int64_t*)p(t_limit), write_back, (int64_t*)p(accepts), accept_rows,
-                             cur_stream(samples)),
+                             cid.ptr(), cur_stream(samples)),
        "rls_mcpg_metro_rounds");
 }
 void mcpg_metro_stop(const Tensor& accepts, int64_t target, int64_t first, int64_t next_T, Tensor ctl, const OptTensor& apply_limit) {
@@ -519,7 +537,9 @@ void mcpg_metro_stop(const Tensor& accepts, int64_t target, int64_t first, int64
                            (int64_t*)p(apply_limit), cur_stream(accepts)), "rls_mcpg_metro_stop");
 }
 void mcpg_local_search(int64_t g, const Tensor& xs_in, Tensor xs_out, const Tensor& order, const OptTensor& visit_stream, int64_t num_ls,
-                       const OptTensor& uniforms, int64_t seed, const OptTensor& edge_weights, int64_t gauge_node, Tensor expected) {
+                       const OptTensor& uniforms, int64_t seed, const OptTensor& edge_weights, int64_t gauge_node, Tensor expected,
+                       int64_t chain_offset, int64_t chain_period, int64_t chain_skip) {
+    const ChainIdsArg cid(chain_offset, chain_period, chain_skip);
     const int sb = chain_bytes(xs_in, "xs_in");
     TORCH_CHECK(sb != 0, "rls_mcpg_local_search takes node-major chains");
     const int64_t N = G(g)->num_nodes;
@@ -540,10 +560,12 @@ void mcpg_local_search(int64_t g, const Tensor& xs_in, Tensor xs_out, const Tens
     RLS_GUARD(xs_in);
     ok(rls_mcpg_local_search(G(g), p(xs_in), sb, (float*)p(xs_out), C, (const int32_t*)p(order), (const int32_t*)p(visit_stream),
                              visit_stream.has_value() ? visit_stream->numel() : 0, num_ls, (const float*)p(uniforms), (uint64_t)seed,
-                             (const int32_t*)p(edge_weights), gauge_node, (float*)p(expected), cur_stream(xs_in)), "rls_mcpg_local_search");
+                             (const int32_t*)p(edge_weights), gauge_node, (float*)p(expected), cid.ptr(), cur_stream(xs_in)), "rls_mcpg_local_search");
 }
 void mcpg_local_search_levels(int64_t g, const Tensor& xs_in, int64_t C_in, Tensor xs_out, int64_t C, const Tensor& lv_ptr,
-                              const Tensor& lv_data, int64_t num_ls, const OptTensor& coins, int64_t seed, Tensor expected) {
+                              const Tensor& lv_data, int64_t num_ls, const OptTensor& coins, int64_t seed, Tensor expected,
+                              int64_t chain_offset, int64_t chain_period, int64_t chain_skip) {
+    const ChainIdsArg cid(chain_offset, chain_period, chain_skip);
     const int sb = chain_bytes(xs_in, "xs_in"), osb = chain_bytes(xs_out, "xs_out");
     const int64_t N = G(g)->num_nodes;
     chain_shape(xs_in, sb, N, C_in > 0 ? C_in : C, "xs_in");
@@ -558,7 +580,7 @@ void mcpg_local_search_levels(int64_t g, const Tensor& xs_in, int64_t C_in, Tens
     count(expected, "expected", C);
     RLS_GUARD(xs_in);
     ok(rls_mcpg_local_search_levels(G(g), p(xs_in), sb, C_in, p(xs_out), osb, C, (const int32_t*)p(lv_ptr), (const int32_t*)p(lv_data),
-                                    lv_ptr.numel() - 1, num_ls, (const uint64_t*)p(coins), (uint64_t)seed, (float*)p(expected), cur_stream(xs_in)),
+                                    lv_ptr.numel() - 1, num_ls, (const uint64_t*)p(coins), (uint64_t)seed, (float*)p(expected), cid.ptr(), cur_stream(xs_in)),
        "rls_mcpg_local_search_levels");
 }
 void mcpg_pick_best(const Tensor& expected, const Tensor& xs, int64_t N, int64_t total_mcmc_num, int64_t repeat_times, int64_t num_edges,
@@ -579,7 +601,7 @@ void mcpg_pick_best(const Tensor& expected, const Tensor& xs, int64_t N, int64_t
                           (float*)p(vs_good), p(xs_good), cur_stream(xs)), "rls_mcpg_pick_best");
 }
 void mcpg_merge_best(const Tensor& temp_max, Tensor temp_info, Tensor now_max_res, Tensor now_info, int64_t total_mcmc_num, Tensor mask_scratch,
-                     const OptTensor& best_value, const OptTensor& best_index) {
+                     const OptTensor& best_value, const OptTensor& best_index, bool replace_worst) {
     dev(temp_max, "temp_max", F32);
     dev(temp_info, "temp_info", I64);
     dev(now_max_res, "now_max_res", F32);
@@ -593,11 +615,13 @@ void mcpg_merge_best(const Tensor& temp_max, Tensor temp_info, Tensor now_max_re
     count(temp_max, "temp_max", M);
     count(now_max_res, "now_max_res", M);
     at_least(mask_scratch, "mask_scratch", tiles);
-    if (best_value.has_value()) at_least(*best_value, "best_value", 1);
-    if (best_index.has_value()) at_least(*best_index, "best_index", 1);
+    if (best_value.has_value()) at_least(*best_value, "best_value", replace_worst ? 1 : 2);
+    if (best_index.has_value()) at_least(*best_index, "best_index", replace_worst ? 1 : 2);
+    TORCH_CHECK(replace_worst || (best_value.has_value() && best_index.has_value()), "replace_worst = False reports {max, min} in best_value / best_index [2]");
     RLS_GUARD(temp_info);
     ok(rls_mcpg_merge_best((const float*)p(temp_max), (uint64_t*)p(temp_info), (float*)p(now_max_res), (uint64_t*)p(now_info), temp_info.size(1),
-                           total_mcmc_num, (uint64_t*)p(mask_scratch), (float*)p(best_value), (int64_t*)p(best_index), cur_stream(temp_info)),
+                           total_mcmc_num, (uint64_t*)p(mask_scratch), (float*)p(best_value), (int64_t*)p(best_index), replace_worst ? 1 : 0,
+                           cur_stream(temp_info)),
        "rls_mcpg_merge_best");
 }
 void mcpg_value_bit_sums(const Tensor& samples, int64_t C, const Tensor& value, Tensor A) {
@@ -804,6 +828,7 @@ TORCH_LIBRARY(rlsolver_hip, m) {
     m.def("maxcut_ls_weights(int graph, Tensor xs, int mult, Tensor(a!) ws, Tensor(b!)? ws_minmax) -> ()");
     m.def("maxcut_local_search(int graph, Tensor(a!) xs, Tensor ws, Tensor rd_std, Tensor? noise, int seed, int env_offset, int num_iters, "
           "int num_spin, bool first_draw_proposes, Tensor(b!) obj, bool compute_obj) -> ()");
+    m.def("maxcut_ls_normals(Tensor(a!) out, int seed, int env_offset, int draw) -> ()");
     m.def("maxcut_ls_threshold(int graph, Tensor ws, Tensor rd_std, int seed, int env_offset, int draw, int num_spin, Tensor(a!) thresh, Tensor(b!)? scratch) -> ()");
     m.def("maxcut_ls_propose(int graph, Tensor(a!) xs, Tensor ws, Tensor rd_std, Tensor thresh, int seed, int env_offset, int draw, "
           "Tensor(b!) obj, Tensor(c!)? scratch) -> ()");
@@ -830,16 +855,16 @@ TORCH_LIBRARY(rlsolver_hip, m) {
           "float max_local, float termination_value, int reward_mode, float reward_div, int hist_len, bool use_stag, "
           "float stag_punishment, bool use_basin, float basin_reward) -> ()");
     m.def("mcpg_metro_rounds(Tensor(a!) samples, Tensor? samples_in, int C_in, int C, Tensor probs, int T, int t_offset, Tensor? index, "
-          "Tensor? u, int seed, Tensor? t_limit, bool write_back, Tensor(b!)? accepts) -> ()");
+          "Tensor? u, int seed, Tensor? t_limit, bool write_back, Tensor(b!)? accepts, int chain_offset=0, int chain_period=0, int chain_skip=0) -> ()");
     m.def("mcpg_metro_stop(Tensor accepts, int target, int first, int next_T, Tensor(a!) ctl, Tensor(b!)? apply_limit) -> ()");
     m.def("mcpg_local_search(int graph, Tensor xs_in, Tensor(a!) xs_out, Tensor order, Tensor? visit_stream, int num_ls, Tensor? uniforms, "
-          "int seed, Tensor? edge_weights, int gauge_node, Tensor(b!) expected) -> ()");
+          "int seed, Tensor? edge_weights, int gauge_node, Tensor(b!) expected, int chain_offset=0, int chain_period=0, int chain_skip=0) -> ()");
     m.def("mcpg_local_search_levels(int graph, Tensor xs_in, int C_in, Tensor(a!) xs_out, int C, Tensor lv_ptr, Tensor lv_data, int num_ls, "
-          "Tensor? coins, int seed, Tensor(b!) expected) -> ()");
+          "Tensor? coins, int seed, Tensor(b!) expected, int chain_offset=0, int chain_period=0, int chain_skip=0) -> ()");
     m.def("mcpg_pick_best(Tensor expected, Tensor xs, int N, int total_mcmc_num, int repeat_times, int num_edges, Tensor(a!) best_index, "
           "Tensor(b!) vs_good, Tensor(c!) xs_good) -> ()");
     m.def("mcpg_merge_best(Tensor temp_max, Tensor(a!) temp_info, Tensor(b!) now_max_res, Tensor(c!) now_info, int total_mcmc_num, "
-          "Tensor(d!) mask_scratch, Tensor(e!)? best_value, Tensor(f!)? best_index) -> ()");
+          "Tensor(d!) mask_scratch, Tensor(e!)? best_value, Tensor(f!)? best_index, bool replace_worst=True) -> ()");
     m.def("mcpg_value_bit_sums(Tensor samples, int C, Tensor value, Tensor(a!) A) -> ()");
     m.def("mcpg_pack_chains(Tensor xs, Tensor(a!) packed) -> ()");
     m.def("mcpg_unpack_chains(Tensor packed, int C, Tensor(a!) xs) -> ()");
@@ -869,6 +894,7 @@ TORCH_LIBRARY_IMPL(rlsolver_hip, CUDA, m) {   // "CUDA" is the HIP dispatch key 
     m.impl("maxcut_propose_accept", &maxcut_propose_accept);
     m.impl("maxcut_ls_weights", &maxcut_ls_weights);
     m.impl("maxcut_local_search", &maxcut_local_search);
+    m.impl("maxcut_ls_normals", &maxcut_ls_normals);
     m.impl("maxcut_ls_threshold", &maxcut_ls_threshold);
     m.impl("maxcut_ls_propose", &maxcut_ls_propose);
     m.impl("maxcut_ls_rounds", &maxcut_ls_rounds);

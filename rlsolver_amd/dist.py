@@ -65,19 +65,54 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     return rank, local_rank, world
 
 
+def _through_host(t: torch.Tensor, group) -> bool:
+    """Device tensors under a backend that only moves host memory (gloo: the CPU tests, and the two-processes-on-one-GPU
+    test) are staged through the host; RCCL takes them as they are."""
+    return t.is_cuda and dist.get_backend(group) != "nccl"
+
+
+def _all_reduce(t: torch.Tensor, op, group) -> torch.Tensor:
+    if _through_host(t, group):
+        h = t.cpu()
+        dist.all_reduce(h, op=op, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+    return t
+
+
+def all_reduce_minmax(mm: torch.Tensor, group=None) -> torch.Tensor:
+    """mm int32 [2, N] = per-node (min, max) of a whole-batch statistic over the LOCAL envs -> over every rank's envs, in
+    place and returned.  One collective of 8 N bytes: the minima travel negated under MAX.  The local search's
+    ``rd_std = (max_b ws - min_b ws) * noise_std`` (envs/env_L2A.py:93-94) is the one such statistic on the path."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return mm
+    mm[0].neg_()
+    _all_reduce(mm, dist.ReduceOp.MAX, group)
+    mm[0].neg_()
+    return mm
+
+
+def all_reduce_sum(t: torch.Tensor, group=None) -> torch.Tensor:
+    """Sum over the ranks, in place and returned (float64 / int64 tensors: callers convert first so that the result does not
+    depend on how a float32 sum would have been ordered)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return t
+    return _all_reduce(t, dist.ReduceOp.SUM, group)
+
+
 OBJ_LIMIT = 1 << 42   # |objective| (doubled for float inputs) must stay below this for the packed key
-_KEY_BUFFERS = {}
-
-
-def _key_buffers(device):
-    """Per-device scratch of the exchange: key int64 [1], index int64 [1], flag int32 [1] (zeroed once; the kernel only sets it)."""
-    b = _KEY_BUFFERS.get(device)
-    if b is None:
-        b = _KEY_BUFFERS[device] = {"key": torch.zeros(1, dtype=torch.int64, device=device),
-                                    "index": torch.zeros(1, dtype=torch.int64, device=device),
-                                    "flag": torch.zeros(1, dtype=torch.int32, device=device)}
-    return b
 _EMPTY_KEY = -(1 << 63)  # what a rank with no envs contributes: loses against every real key
+
+
+def _broadcast(t: torch.Tensor, src: int, group) -> torch.Tensor:
+    if _through_host(t, group):
+        h = t.cpu()
+        dist.broadcast(h, src=src, group=group)
+        t.copy_(h)
+    else:
+        dist.broadcast(t, src=src, group=group)
+    return t
 
 
 def pack_bits(x: torch.Tensor) -> torch.Tensor:
@@ -96,15 +131,48 @@ def unpack_bits(p: torch.Tensor, n: int, dtype=torch.bool) -> torch.Tensor:
     return ((p[:, None] >> sh) & 1).reshape(-1)[:n].to(dtype)
 
 
-def global_best(local_vs: torch.Tensor, local_xs: Optional[torch.Tensor] = None, want_solution: bool = False,
-                group=None):
+def _local_best(local_vs: torch.Tensor, rank: int, world: int):
+    """(key int64 [1] or None for an empty shard, first argmax index 0-dim tensor or None).  Device tensors: ONE launch
+    (rls_best_key: first argmax + packed key + range / half-integer check) into scratch allocated per call -- a buffer
+    shared between calls would let an in-flight all_reduce or a result still held by the caller be overwritten, and a flag
+    that is only ever OR-ed would poison every later call."""
+    is_float = local_vs.is_floating_point()
+    if not local_vs.numel():
+        return None, None
+    if local_vs.is_cuda and local_vs.dtype in (torch.int64, torch.int32, torch.float32, torch.float64):
+        from .torch_ops import ops as _t
+        buf = torch.zeros(3, dtype=torch.int64, device=local_vs.device)       # {key, index, flag}
+        flag = buf[2:3].view(torch.int32)[0:1]
+        _t.best_key(local_vs.contiguous(), RANK_BITS, world - 1 - rank, OBJ_LIMIT, buf[0:1], buf[1:2], flag)
+        torch._assert_async(flag[0] == 0,
+                            "global_best: objective outside the packed-key range (|obj| < 2^42) or not a half-integer")
+        return buf[0:1], buf[1]
+    li = local_vs.argmax()
+    raw = local_vs[li]
+    lbest = torch.round(raw.to(torch.float64) * 2).to(torch.int64) if is_float else raw.to(torch.int64)
+    ok = lbest.abs() < OBJ_LIMIT
+    if is_float:
+        ok = ok & (lbest.to(torch.float64) == raw.to(torch.float64) * 2)
+    torch._assert_async(ok, "global_best: objective outside the packed-key range (|obj| < 2^42) or not a half-integer")
+    return pack_key(lbest, rank, world).reshape(1), li
+
+
+def _row(local_xs, li):
+    """The winner's row: local_xs is [B_local, N], or a callable li -> [N] (rows that live bit-packed, MCPG's kept chains)."""
+    return local_xs(li) if callable(local_xs) else local_xs[li]
+
+
+def global_best(local_vs: torch.Tensor, local_xs=None, want_solution: bool = False, group=None,
+                env_offset: Optional[int] = None, num_nodes: Optional[int] = None):
     """Episode-boundary exchange.  local_vs [B_local] integer, or float holding integers / half-integers (the
-    bidirectional envs return ``count / 2`` as float); local_xs [B_local, N] (bool/uint8).  B_local may be 0
-    (env_shard gives some ranks nothing when B < world): such a rank still joins every collective.
+    bidirectional envs return ``count / 2`` as float); local_xs [B_local, N] (bool/uint8), or a callable
+    ``index -> row [N]`` with ``num_nodes`` = N.  B_local may be 0 (env_shard gives some ranks nothing when
+    B < world): such a rank still joins every collective.
 
     Returns (best_obj 0-dim tensor -- int64, or float64 for float input --, owner_rank int64 0-dim, best_x or
-    None).  The solution travels bit-packed (ceil(N/8) bytes).  Single-process (no group initialised)
-    degenerates to argmax over the local batch.
+    None), plus -- when ``env_offset`` (the global id of this rank's env 0) is given -- the winner's GLOBAL env index as
+    a fourth element (int64 0-dim).  The solution travels bit-packed (ceil(N/8) bytes), the index in the same message.
+    Single-process (no group initialised) degenerates to argmax over the local batch.
     """
     is_float = local_vs.is_floating_point()
     n_local = local_vs.numel()
@@ -113,50 +181,59 @@ def global_best(local_vs: torch.Tensor, local_xs: Optional[torch.Tensor] = None,
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     if world > (1 << RANK_BITS):
         raise ValueError("world too large for the packed key")
-    li = lbest = key_dev = None
-    if n_local and local_vs.is_cuda and local_vs.dtype in (torch.int64, torch.int32, torch.float32, torch.float64):
-        # one launch: first argmax + the packed key (+ range / half-integer check) -- rls_best_key
-        from .torch_ops import ops as _t
-        bufs = _key_buffers(dev)
-        _t.best_key(local_vs.contiguous(), RANK_BITS, world - 1 - rank, OBJ_LIMIT, bufs["key"], bufs["index"], bufs["flag"])
-        torch._assert_async(bufs["flag"][0] == 0,
-                            "global_best: objective outside the packed-key range (|obj| < 2^42) or not a half-integer")
-        key_dev, li = bufs["key"], bufs["index"][0]
-    elif n_local:
-        li = local_vs.argmax()
-        raw = local_vs[li]
-        lbest = torch.round(raw.to(torch.float64) * 2).to(torch.int64) if is_float else raw.to(torch.int64)
-        ok = lbest.abs() < OBJ_LIMIT
-        if is_float:
-            ok = ok & (lbest.to(torch.float64) == raw.to(torch.float64) * 2)
-        torch._assert_async(ok, "global_best: objective outside the packed-key range (|obj| < 2^42) or not a half-integer")
+    key, li = _local_best(local_vs, rank, world)
     finish = (lambda o: o.to(torch.float64) / 2) if is_float else (lambda o: o)
+    want_x = want_solution and local_xs is not None
+    want_i = env_offset is not None
+    tail = (lambda gi: (gi,)) if want_i else (lambda gi: ())
     # RLS_FORCE_PG=1 keeps a 1-rank group on the collective path (the RCCL calls get exercised on a 1-GPU box)
-    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and os.environ.get("RLS_FORCE_PG") != "1"):
+    if not dist.is_initialized() or (world == 1 and os.environ.get("RLS_FORCE_PG") != "1"):
         if not n_local:
             raise ValueError("global_best: no envs at all")
-        if key_dev is not None:
-            lbest = key_dev[0] >> RANK_BITS
-        return finish(lbest), torch.zeros((), dtype=torch.int64, device=dev), \
-            (local_xs[li].clone() if (want_solution and local_xs is not None) else None)
-    if key_dev is not None:
-        key = key_dev                                                   # (a per-device buffer: consumed before the next call)
-    else:
-        key = (pack_key(lbest, rank, world) if n_local else torch.full((), _EMPTY_KEY, dtype=torch.int64, device=dev)).reshape(1)
-    dist.all_reduce(key, op=dist.ReduceOp.MAX, group=group)            # C1: 8 bytes
+        return (finish(key[0] >> RANK_BITS), torch.zeros((), dtype=torch.int64, device=dev),
+                (_row(local_xs, li).clone() if want_x else None)) + tail(li + env_offset if want_i else None)
+    if key is None:
+        key = torch.full((1,), _EMPTY_KEY, dtype=torch.int64, device=dev)
+    _all_reduce(key, dist.ReduceOp.MAX, group)                          # C1: 8 bytes
     obj, owner = unpack_key(key[0], world)
-    best_x = None
-    if want_solution and local_xs is not None:
-        n = local_xs.shape[1]
+    best_x = gi = None
+    if want_x or want_i:
         if int(key[0]) == _EMPTY_KEY:                                   # (the host read below, taken one line early)
             raise ValueError("global_best: no envs at all")             # every rank fails the same way, before C2
         src = int(owner)                                                # one host read per episode boundary
-        buf = pack_bits(local_xs[li]) if (rank == src and n_local) else \
-            torch.empty((n + 7) // 8, dtype=torch.uint8, device=local_xs.device)
-        dist.broadcast(buf, src=src, group=group)                      # C2: ceil(N/8) bytes
-        best_x = unpack_bits(buf, n, local_xs.dtype)
+        if want_x:
+            n = num_nodes if callable(local_xs) else local_xs.shape[1]
+            if n is None:
+                raise ValueError("global_best: a callable local_xs needs num_nodes")
+        nb = ((n + 7) // 8) if want_x else 0
+        # one message: [8 bytes: the winner's global index (little endian) | ceil(N / 8) bytes: its solution, bit-packed]
+        buf = torch.zeros(8 * want_i + nb, dtype=torch.uint8, device=dev)
+        if rank == src and n_local:
+            if want_i:
+                g = (li + env_offset).to(torch.int64).reshape(1)
+                buf[:8] = ((g[:, None] >> (8 * torch.arange(8, device=dev))) & 0xFF).to(torch.uint8).reshape(8)
+            if want_x:
+                buf[8 * want_i:] = pack_bits(_row(local_xs, li))
+        _broadcast(buf, src, group)                                     # C2: (8 +) ceil(N/8) bytes
+        if want_i:
+            gi = (buf[:8].to(torch.int64) << (8 * torch.arange(8, device=dev))).sum()
+        if want_x:
+            dt = torch.bool if callable(local_xs) else local_xs.dtype
+            best_x = unpack_bits(buf[8 * want_i:], n, dt)
     elif not n_local:
         # no host read on this path: an all-empty world trips the same error asynchronously on every rank (a rank that has
         # envs knows the reduced key is a real one)
         torch._assert_async(key[0] != _EMPTY_KEY, "global_best: no envs at all")
-    return finish(obj), owner, best_x
+    return (finish(obj), owner, best_x) + tail(gi)
+
+
+def share_best(xs: torch.Tensor, vs: torch.Tensor, group=None):
+    """The sharded form of the reference's "everyone restarts from the best" lines (envs/env_MCPG.py:452-458:
+    ``best_i = best_vs.argmax(); best_xs[:] = best_xs[best_i]; best_vs[:] = best_vs[best_i]``; the same move in
+    methods/L2A/demo_instance.py): C1 + C2, then every local row becomes the GLOBAL best.  In place; returns
+    (best value 0-dim, owner rank 0-dim)."""
+    best, owner, bx = global_best(vs, xs, want_solution=True, group=group)
+    if xs.shape[0]:
+        xs[:] = bx.to(xs.dtype)
+        vs[:] = best.to(vs.dtype)
+    return best, owner

@@ -18,15 +18,14 @@ import torch
 
 from .. import ops_mcpg_tsp as mops
 from ..ops import _check, _s64, _t
+from ..seeding import Sharded, seed_from_torch as _seed_from_torch  # noqa: F401
 
 
-def _seed_from_torch() -> int:
-    return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
-
-
-class ISCO_TSP:
+class ISCO_TSP(Sharded):
     def __init__(self, params_dict, batch_size: int = 1, K: int = 20, device=None, chain_length: int = 10000,
-                 init_temperature: float = 1.0, final_temperature: float = 0.1):
+                 init_temperature: float = 1.0, final_temperature: float = 0.1, env_offset: int = 0, seed: Optional[int] = None):
+        """``env_offset`` / ``seed``: rlsolver_amd/seeding.py (``batch_size`` tours whose global ids start at env_offset)."""
+        self._init_shard(env_offset, seed)
         self.distance = params_dict['distance']
         self.device = torch.device(device) if device is not None else self.distance.device
         if self.device.type != 'cuda':
@@ -66,7 +65,7 @@ class ISCO_TSP:
             d["u_accept"] = _check(draws["u_accept"].to(self.device).contiguous(), "u_accept", (torch.float32,), self.device, (B,))
         _t.isco_tsp_step(self.distance, self._near32, self._near_thr, self._rand32, x, y, L, float(temperature), d.get("u_partner"),
                          d.get("r_near"), d.get("r_rand"), d.get("u_gumbel"), d.get("u_accept"),
-                         _s64(0 if draws is not None else _seed_from_torch()), 0, log_acc, acc, cur)
+                         _s64(0 if draws is not None else self._next_seed()), self.env_offset, log_acc, acc, cur)
         if want_terms:
             return y, acc.mean(), log_acc, cur
         return y, acc.mean()
@@ -103,7 +102,7 @@ class ISCO_TSP:
 
     def random_gen_init_sample(self, params_dict=None):
         """env_ISCO.py:352-354: batch_size random permutations (Philox Fisher-Yates kernel seeded from torch)."""
-        return mops.rand_perms(self.batch_size, self.num_nodes, _seed_from_torch(), self.device)
+        return mops.rand_perms(self.batch_size, self.num_nodes, self._next_seed(), self.device, env_offset=self.env_offset)
 
 
 def __getattr__(name):

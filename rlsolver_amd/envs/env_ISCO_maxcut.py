@@ -17,12 +17,14 @@ import torch
 from .. import ops
 from ..graph import build_csr
 from ..ops import _check, _s64, _t
-from .env_ISCO import _seed_from_torch
+from ..seeding import Sharded
 
 
-class ISCO_maxcut:
+class ISCO_maxcut(Sharded):
     def __init__(self, params_dict, batch_size: int = 1, device=None, chain_length: int = 200,
-                 init_temperature: float = 1.0, final_temperature: float = 0.0):
+                 init_temperature: float = 1.0, final_temperature: float = 0.0, env_offset: int = 0, seed: Optional[int] = None):
+        """``env_offset`` / ``seed``: rlsolver_amd/seeding.py (``batch_size`` samples whose global ids start at env_offset)."""
+        self._init_shard(env_offset, seed)
         self.edge_from = params_dict['edge_from']
         self.edge_to = params_dict['edge_to']
         self.device = torch.device(device) if device is not None else self.edge_from.device
@@ -41,8 +43,9 @@ class ISCO_maxcut:
 
     def random_gen_init_sample(self, params_dict=None):
         """env_ISCO.py:22-25: Bernoulli(1/2) samples as float32 (Philox kernel seeded from torch)."""
-        bits = ops.rand_spins(self.batch_size, self.max_num_nodes, _seed_from_torch(), self.device)
-        bits[:, 0] = torch.randint(0, 2, (self.batch_size,), device=self.device, dtype=torch.bool)   # no gauge fixing here
+        bits = ops.rand_spins(self.batch_size, self.max_num_nodes, self._next_seed(), self.device, env_offset=self.env_offset)
+        # no gauge fixing here: node 0 is a coin like the others (bit 0 of a second keyed draw's node 1)
+        bits[:, 0] = ops.rand_spins(self.batch_size, 2, self._next_seed(), self.device, env_offset=self.env_offset)[:, 1]
         return bits.to(torch.float32)
 
     def step(self, x, path_length, temperature, draws: Optional[dict] = None, want_terms: bool = False):
@@ -66,7 +69,7 @@ class ISCO_maxcut:
             ug = _check(draws["u_gumbel"].to(self.device).contiguous(), "u_gumbel", (torch.float32,), self.device, (B, N))
             ua = _check(draws["u_accept"].to(self.device).contiguous(), "u_accept", (torch.float32,), self.device, (B,))
         _t.isco_maxcut_step(self.graph.handle, x, y, pl, float(temperature), ug, ua,
-                            _s64(0 if draws is not None else _seed_from_torch()), 0, energy, acc, terms, mask)
+                            _s64(0 if draws is not None else self._next_seed()), self.env_offset, energy, acc, terms, mask)
         if want_terms:
             return y, energy, acc, terms, mask
         return y, energy, acc

@@ -7,7 +7,11 @@ touches spins launches a HIP kernel (rlsolver_amd.ops).  Differences, all delibe
 * ``device`` must be a HIP device: there is no CPU path;
 * no per-env index tensors are materialised (the reference caches three int64 [B, E'] tensors);
   ``n0_ids`` / ``n1_ids`` keep their [1, E'] form for callers that read them;
-* ``adjacency_bool`` (dense N x N) is built lazily on first access instead of in ``__init__``.
+* ``adjacency_bool`` (dense N x N) is built lazily on first access instead of in ``__init__``;
+* two extra keywords, ``env_offset`` and ``seed`` (rlsolver_amd/seeding.py): the global id of this object's env 0 in a
+  batch sharded over ranks, and an optional private seed stream.  Every random draw is keyed by (seed, global env id, ...),
+  so rank r of W running envs [r B / W, (r + 1) B / W) with ``env_offset = r B / W`` computes exactly those rows of the
+  one-process run.
 """
 from __future__ import annotations
 
@@ -18,18 +22,16 @@ import torch as th
 
 from .. import ops
 from ..graph import MyGraph, build_csr, calc_num_nodes_in_mygraph, load_mygraph2
+from ..seeding import Sharded, seed_from_torch as _seed_from_torch  # noqa: F401  (re-exported: other modules import it from here)
 
 TEN = th.Tensor
 
 
-def _seed_from_torch() -> int:
-    # consume torch's CPU generator so th.manual_seed() makes kernel RNG reproducible
-    return int(th.randint(0, 2 ** 62, (1,), dtype=th.int64).item())
-
-
-class EnvMaxcut:
+class EnvMaxcut(Sharded):
     def __init__(self, sim_name: str = 'max_cut', mygraph: MyGraph = (),
-                 device=th.device('cpu'), if_bidirectional: bool = False, num_nodes: int = 0):
+                 device=th.device('cpu'), if_bidirectional: bool = False, num_nodes: int = 0,
+                 env_offset: int = 0, seed: Optional[int] = None, group=None):
+        self._init_shard(env_offset, seed, group)
         self.device = th.device(device)
         if self.device.type != 'cuda':
             raise TypeError(f"rlsolver_amd.EnvMaxcut needs a HIP device (got {self.device}); "
@@ -96,8 +98,8 @@ class EnvMaxcut:
         return values
 
     def generate_xs_randomly(self, num_sims):
-        """env_L2A.py:82-85: Bernoulli(1/2) spins, node 0 := 0 (Philox kernel seeded from torch)."""
-        return ops.rand_spins(num_sims, self.num_nodes, _seed_from_torch(), self.device)
+        """env_L2A.py:82-85: Bernoulli(1/2) spins, node 0 := 0 (Philox kernel keyed by (seed, env_offset + row))."""
+        return ops.rand_spins(num_sims, self.num_nodes, self._next_seed(), self.device, env_offset=self.env_offset)
 
     # ---- local search
     def local_search_inplace(self, good_xs: TEN, good_vs: TEN,
@@ -136,11 +138,14 @@ class EnvMaxcut:
                     and xs.data_ptr() % 16 == 0 and (noise is None or noise.data_ptr() % 16 == 0))   # (views that start mid-row)
         rounds_ok = not fused_ok and rounds_can
         # exact integers (int8 / int16) in both env flavours; the round kernels read them on a 16-byte row pitch (any N)
-        ws32, ws_span = ops.maxcut_ls_weights(self.graph, xs, weight_mult, padded=rounds_ok)
-        rd_std = (ws_span.float() * noise_std).contiguous()
-        if fused_ok and (num_iters > 0 or not first_draw_proposes):
+        fused_now = fused_ok and (num_iters > 0 or not first_draw_proposes)
+        ws32, mm = ops.maxcut_ls_weights(self.graph, xs, weight_mult, padded=rounds_ok or fused_now, return_minmax=True)
+        mm = self._global_minmax(mm)        # a statistic of the WHOLE batch (env_L2A.py:93-94): reduced over the ranks of a sharded one
+        rd_std = ((mm[1] - mm[0]).float() * noise_std).contiguous()
+        off = self.env_offset
+        if fused_now:
             ops.maxcut_local_search(self.graph, xs, ws32, rd_std, vs, num_iters, num_spin, noise=noise,
-                                    seed=0 if noise is not None else _seed_from_torch(),
+                                    seed=0 if noise is not None else self._next_seed(), env_offset=off,
                                     first_draw_proposes=first_draw_proposes, compute_obj=compute_vs)
             return
         if compute_vs:
@@ -148,14 +153,23 @@ class EnvMaxcut:
         if rounds_ok:
             # the same steps as kernels with the fused kernel's draws (same seed => the fused kernel's result): graphs too
             # large for the fused kernel's LDS layout
-            seed = _seed_from_torch()
+            seed = self._next_seed()
             # small batches: a tile's noise pass over several workgroups, all rounds applied on one load of the tile
             scratch = ops.ls_scratch(self.graph, B, ws32, num_draws=num_iters)
-            thresh = ops.maxcut_ls_threshold(self.graph, ws32, rd_std, seed, num_spin, draw=0, scratch=scratch)
-            ops.maxcut_ls_rounds(self.graph, xs, ws32, rd_std, thresh, vs, seed, 0 if first_draw_proposes else 1, num_iters, scratch=scratch)
+            thresh = ops.maxcut_ls_threshold(self.graph, ws32, rd_std, seed, num_spin, draw=0, env_offset=off, scratch=scratch)
+            ops.maxcut_ls_rounds(self.graph, xs, ws32, rd_std, thresh, vs, seed, 0 if first_draw_proposes else 1, num_iters,
+                                 env_offset=off, scratch=scratch)
             ops.maxcut_greedy_sweep(self.graph, xs, vs)
             return
-        draws = (lambda t: noise[t]) if noise is not None else (lambda t: th.randn((B, self.num_nodes), device=self.device))
+        if ws32.shape[1] != self.num_nodes:
+            ws32 = ws32[:, :self.num_nodes]
+        if noise is not None:
+            draws = lambda t: noise[t]                                      # noqa: E731
+        else:
+            # the kernels' own draws as a tensor (keyed by the global env like them; torch.randn is not): same seed => the result
+            # of the fused / round kernels wherever those also cover the shape
+            seed = self._next_seed()
+            draws = lambda t: ops.maxcut_ls_normals(B, self.num_nodes, seed, t, self.device, env_offset=off)   # noqa: E731
         thresh, t = None, 0
         for it in range(num_iters + (0 if first_draw_proposes else 1)):
             noisy = ws32 + draws(t) * rd_std

@@ -13,18 +13,21 @@ import torch as th
 
 from .. import ops, torch_ops
 from ..graph import MyGraph, build_adjacency_indies, build_csr  # noqa: F401  (build_adjacency_indies: env_PPO.py:26-47 has its own copy)
-from .env_L2A import _seed_from_torch
+from ..seeding import Sharded
 
 TEN = th.Tensor
 
 
-class EnvMaxcut:
+class EnvMaxcut(Sharded):
     def __init__(self, args, mygraph: MyGraph = (), device=th.device('cpu'), if_bidirectional: bool = False,
-                 spin_dtype=th.float32, reuse_buffers: bool = False):
+                 spin_dtype=th.float32, reuse_buffers: bool = False, env_offset: int = 0, seed: Optional[int] = None):
         """``spin_dtype``: torch.float32 is the reference's surface (xs cast to float, env_PPO.py:87); torch.bool keeps
         the state at 1 byte per spin (4x less HBM traffic per step) for callers that cast where they consume it.
         ``reuse_buffers``: reward / done / cur are written into two alternating pre-allocated sets instead of fresh
-        tensors (no allocator call on the step path); a returned tensor then stays valid for ONE further step."""
+        tensors (no allocator call on the step path); a returned tensor then stays valid for ONE further step.
+        ``env_offset`` / ``seed``: rlsolver_amd/seeding.py -- ``args.num_envs`` is this rank's share of a sharded batch and
+        ``env_offset`` the global id of its env 0 (reset draws are keyed by the global env id; a step draws nothing)."""
+        self._init_shard(env_offset, seed)
         self.device = th.device(device)
         if self.device.type != 'cuda':
             raise TypeError(f"rlsolver_amd.EnvMaxcut needs a HIP device (got {self.device}); there is no CPU path")
@@ -91,7 +94,7 @@ class EnvMaxcut:
         return values
 
     def generate_xs_randomly(self, num_sims):
-        return ops.rand_spins(num_sims, self.num_nodes, _seed_from_torch(), self.device)
+        return ops.rand_spins(num_sims, self.num_nodes, self._next_seed(), self.device, env_offset=self.env_offset)
 
     # ---- checkpoint of the env state
     def state_dict(self):

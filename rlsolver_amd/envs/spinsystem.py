@@ -40,7 +40,7 @@ import torch
 from .. import _abi, ops
 from ..graph import build_csr
 from ..ops import _t
-from .env_L2A import _seed_from_torch
+from ..seeding import Sharded
 
 
 class Observable(Enum):  # ECO_S2V/src/envs/util_envs.py:40-51
@@ -89,7 +89,7 @@ _ROW_ORDER = [Observable.IMMEDIATE_REWARD_AVAILABLE, Observable.TIME_SINCE_FLIP,
 _REWARD_MODE = {RewardSignal.DENSE: 0, RewardSignal.BLS: 1, RewardSignal.CUSTOM_BLS: 2}
 
 
-class SpinSystem:
+class SpinSystem(Sharded):
     class _ActionSpace:
         def __init__(self, n, device):
             self.n, self.device = n, device
@@ -108,7 +108,11 @@ class SpinSystem:
                  norm_rewards: bool = False, horizon_length: Optional[int] = None,
                  stag_punishment: Optional[float] = None, basin_reward: Optional[float] = None,
                  device=None, include_adjacency: bool = True, dtype=torch.float32, graph_generator=None,
-                 extra_action: ExtraAction = ExtraAction.NONE, memory_length: Optional[int] = None):
+                 extra_action: ExtraAction = ExtraAction.NONE, memory_length: Optional[int] = None,
+                 env_offset: int = 0, seed: Optional[int] = None, group=None):
+        # env_offset / seed / group: rlsolver_amd/seeding.py -- num_envs is this rank's share of a sharded batch, reset draws
+        # are keyed by the global env id (a graph_generator carries its own env_offset: give it the same one)
+        self._init_shard(env_offset, seed, group)
         self.device = torch.device(device if device is not None else "cuda:0")
         if self.device.type != "cuda":
             raise TypeError(f"rlsolver_amd.SpinSystem needs a HIP device (got {self.device}); there is no CPU path")
@@ -269,8 +273,9 @@ class SpinSystem:
             self._env.time_table, self._env.table_len = self._time_table.data_ptr(), self._time_table.numel()
         B, N = self.num_envs, self.n_spins
         if spins is None:
-            bits = ops.rand_spins(B, N, _seed_from_torch(), self.device)
-            bits[:, 0] = torch.randint(0, 2, (B,), device=self.device, dtype=torch.bool)  # no gauge fixing here
+            bits = ops.rand_spins(B, N, self._next_seed(), self.device, env_offset=self.env_offset)
+            # no gauge fixing here: node 0 is a coin like the others (node 1 of a second keyed draw)
+            bits[:, 0] = ops.rand_spins(B, 2, self._next_seed(), self.device, env_offset=self.env_offset)[:, 1]
         else:
             spins = torch.as_tensor(spins, device=self.device, dtype=self.dtype).reshape(B, N)
             # _format_spins_to_signed (spinsystem_PECO.py:548-557): 0/1 input under the BINARY basis -> 2 s - 1 (sic:
@@ -284,10 +289,12 @@ class SpinSystem:
                 self._matrix = self._draw_matrix()
                 _t.spin_reset_dense(self._matrix, self._env_handle, self._state, self._rows, self.max_local_reward_available_,
                                     self._weight_sum_env, self._flags)
-                flags = int(self._flags.max())            # the one host read of a reset (the reference's .any() tests)
-                if flags & 2:
+                f = self._flags.max().to(torch.int64)
+                # (a redraw is a decision about the WHOLE batch: every rank of a sharded one takes it together)
+                flags = self._global_sum(torch.stack([f & 1, (f >> 1) & 1])).tolist()   # the one host read of a reset (the reference's .any() tests)
+                if flags[1]:
                     raise ValueError("graph_generator.get() must return symmetric integer-valued matrices")
-                if not flags & 1:
+                if not flags[0]:
                     break
             else:
                 raise ValueError("graph_generator keeps producing empty graphs / zero max local reward")

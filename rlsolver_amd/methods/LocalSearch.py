@@ -32,19 +32,30 @@ class LocalSearch:
 
     RESET_SEARCH_MAX_BYTES = 1 << 30     # candidate rows held at once by reset_search
 
-    def reset_search(self, num_sims):
+    def reset_search(self, num_sims, num_repeats: Optional[int] = None):
         """LocalSearch.py:44-50: num_sims incumbents, each the best of num_sims random rows (first best on ties).
         The reference holds num_sims rows per iteration; here the num_sims repeats are taken in chunks of as many as fit
         RESET_SEARCH_MAX_BYTES (row r * num_sims + s of a chunk = its candidate r of slot s), each chunk reduced by
         one K1 launch + one best-of-repeats pick and merged into the running best by the keep-better kernel -- memory is
-        O(chunk * num_sims * N), never num_sims^2 * N."""
+        O(chunk * num_sims * N), never num_sims^2 * N.
+        Sharded (the simulator's ``env_offset``, rlsolver_amd/seeding.py): ``num_sims`` is this rank's share of the incumbents;
+        the number of repeats is the batch's GLOBAL size (``num_repeats``, default num_sims: the single-process meaning), and
+        repeat r of incumbent s is keyed by (one seed per call mixed with r, global id of s) -- the same row whatever the rank
+        count or the chunking."""
+        return self._reset_search(num_sims, num_sims if num_repeats is None else num_repeats)
+
+    def _reset_search(self, num_sims: int, num_repeats: int):
         sim = self.simulator
         per_repeat = max(1, num_sims * (sim.num_nodes + 8))
-        chunk = max(1, min(num_sims, self.RESET_SEARCH_MAX_BYTES // per_repeat))
+        chunk = max(1, min(num_repeats, self.RESET_SEARCH_MAX_BYTES // per_repeat))
         best = best_v = None
-        for r0 in range(0, num_sims, chunk):
-            reps = min(chunk, num_sims - r0)
-            cand = sim.generate_xs_randomly(num_sims=reps * num_sims)
+        base_seed = sim._next_seed()
+        for r0 in range(0, num_repeats, chunk):
+            reps = min(chunk, num_repeats - r0)
+            cand = th.empty((reps * num_sims, sim.num_nodes), dtype=th.bool, device=sim.device)
+            for r in range(reps):       # one keyed launch per repeat: row r * num_sims + s = repeat r0 + r of incumbent s
+                ops.rand_spins(num_sims, sim.num_nodes, sim._seeds.derive(base_seed, r0 + r), sim.device,
+                               env_offset=sim.env_offset, out=cand[r * num_sims:(r + 1) * num_sims])
             cx, cv = ops.pick_best_of_repeats(cand, sim.calculate_obj_values(cand), reps, if_maximize=True)
             if best is not None:     # earlier repeats win ties: the running best replaces the chunk's row when it is >=
                 ops.select_better_rows(cx, cv, best, best_v, if_maximize=True)

@@ -15,12 +15,9 @@ import torch
 from .. import _abi, ops, ops_mcpg_tsp as mops
 from ..ops_mcpg_tsp import PackedChains
 from ..graph import build_csr, read_edge_arrays
+from ..seeding import Sharded, seed_from_torch as _seed_from_torch
 
 TEN = torch.Tensor
-
-
-def _seed_from_torch() -> int:
-    return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
 
 
 def maxcut_dataloader(path, device):
@@ -197,20 +194,28 @@ def build_visit_stream(csr, order: np.ndarray, max_nodes: int = 32, max_entries:
 ACCEPT_ROWS = 64      # rows the kernels spread their per-round accept counts over (one row = thousands of atomics per address)
 
 
-def _walk_chunks(samples, start, probs: TEN, max_transfer_time: int, Tmax: int, Cc: int, index, u, seed: int) -> None:
+def _walk_chunks(samples, start, probs: TEN, max_transfer_time: int, Tmax: int, Cc: int, index, u, seed: int,
+                 chain_ids=None, stats=None, total_chains: Optional[int] = None) -> None:
     """The rounds of metro_sampling in chunks, with the reference's stop rule (MCPG.py:103,115) evaluated on the device.
     A round accepts at most C proposals, so the cumulative count cannot reach C*T before round T: chunks inside the first T
     rounds are applied directly (one pass, counting as it goes; the first one reads the caller's start state and writes the
     result buffer).  Later chunks: dry pass -> accept counts -> stop round (rls_mcpg_metro_stop: one launch) -> apply.  Chunks
     after the stop round see a zero limit and return at once.  A chunk is T rounds, or fewer where a launch cannot take that many
-    (the node-major kernels keep the accept counts in LDS beside the tile: 956 rounds at N = 20 000)."""
+    (the node-major kernels keep the accept counts in LDS beside the tile: 956 rounds at N = 20 000).
+    A shard of the chains (``chain_ids``: their global ids; ``stats``: the Sharded object whose group the ranks share;
+    ``total_chains``: the GLOBAL chain count): the stop rule is a statistic of the whole batch, so each chunk's per-round
+    accept counts are summed over the ranks before the stop kernel reads them -- every rank then stops at the round the
+    one-process run stops at."""
     device = probs.device
     st, sb, N, _ = mops._chains(samples, "samples")
     cap = mops.mcpg_metro_max_rounds(N, sb)
     if cap <= 0:
         raise RuntimeError(f"metro_sampling: {N} nodes do not fit this layout's tile in LDS")
     chunk = max(1, min(max_transfer_time, cap))
-    target = Cc * max_transfer_time
+    target = (Cc if total_chains is None else total_chains) * max_transfer_time
+
+    def counts(acc):        # what the stop kernel reads: this rank's rows, or one row of whole-batch counts
+        return acc if stats is None else stats._global_sum(acc.sum(dim=0, keepdim=True))
     starts = list(range(0, Tmax, chunk))
     sizes = [min(chunk, Tmax - t0) for t0 in starts]
     accepts = torch.zeros((len(starts), ACCEPT_ROWS, chunk), dtype=torch.int64, device=device)
@@ -221,20 +226,23 @@ def _walk_chunks(samples, start, probs: TEN, max_transfer_time: int, Tmax: int, 
         next_tk = sizes[k + 1] if k + 1 < len(sizes) else 0
         if t0 + tk <= max(1, max_transfer_time):                       # inside the first T rounds: direct
             mops.mcpg_metro_rounds(samples, probs, tk, index, u, seed, None, True, acc, t_offset=t0,
-                                   samples_in=None if (k > 0 or samples is start) else start)
-            mops.mcpg_metro_stop(acc, target, 1 if k == 0 else 2, next_tk, ctl)
+                                   samples_in=None if (k > 0 or samples is start) else start, chain_ids=chain_ids)
+            mops.mcpg_metro_stop(counts(acc), target, 1 if k == 0 else 2, next_tk, ctl)
         else:
-            mops.mcpg_metro_rounds(samples, probs, tk, index, u, seed, ctl[2:3], False, acc, t_offset=t0)
-            mops.mcpg_metro_stop(acc, target, 0, next_tk, ctl, apply_limit)
-            mops.mcpg_metro_rounds(samples, probs, tk, index, u, seed, apply_limit, True, None, t_offset=t0)
+            mops.mcpg_metro_rounds(samples, probs, tk, index, u, seed, ctl[2:3], False, acc, t_offset=t0, chain_ids=chain_ids)
+            mops.mcpg_metro_stop(counts(acc), target, 0, next_tk, ctl, apply_limit)
+            mops.mcpg_metro_rounds(samples, probs, tk, index, u, seed, apply_limit, True, None, t_offset=t0, chain_ids=chain_ids)
 
 
 def metro_sampling_packed(probs: TEN, start: PackedChains, max_transfer_time: int, num_chains: Optional[int] = None,
-                          index: Optional[TEN] = None, u: Optional[TEN] = None, out: Optional[PackedChains] = None) -> PackedChains:
+                          index: Optional[TEN] = None, u: Optional[TEN] = None, out: Optional[PackedChains] = None,
+                          seed: Optional[int] = None, chain_ids=None, stats=None, total_chains: Optional[int] = None) -> PackedChains:
     """metro_sampling (MCPG.py:88-117) on bit-packed chains.  ``start`` may hold fewer chains than ``num_chains`` (a
     multiple of 64): chain c starts from chain c % start.num_chains, the reference's ``xs_bool.repeat(1, repeat_times)``.
     Up to 5*T proposal rounds per chain, stopping after the first round whose cumulative accept count reaches C*T --
-    evaluated on the device (no host sync), where the reference syncs once per round."""
+    evaluated on the device (no host sync), where the reference syncs once per round.
+    ``seed``: the kernel seed (default: one draw of torch's generator); ``chain_ids`` / ``stats`` / ``total_chains``: a shard
+    of a larger batch, see _walk_chunks."""
     device = start.device
     Cc = start.num_chains if num_chains is None else num_chains
     N = start.num_nodes
@@ -243,11 +251,14 @@ def metro_sampling_packed(probs: TEN, start: PackedChains, max_transfer_time: in
     Tmax = max_transfer_time * 5
     if index is not None:
         Tmax = min(Tmax, index.shape[0])
-    seed = _seed_from_torch() if index is None else 0
+    if index is not None:
+        seed = 0
+    elif seed is None:
+        seed = _seed_from_torch()
     if Tmax <= 0:   # no rounds (N < 10 gives T = int(N / 10) = 0): the start state, broadcast
         mops.mcpg_metro_rounds(samples, probs, 0, None, None, 0, None, True, None, samples_in=start)
         return samples
-    _walk_chunks(samples, start, probs, max_transfer_time, Tmax, Cc, index, u, seed)
+    _walk_chunks(samples, start, probs, max_transfer_time, Tmax, Cc, index, u, seed, chain_ids, stats, total_chains)
     return samples
 
 
@@ -291,7 +302,7 @@ def _levels_ok(data) -> bool:
 
 
 def sampler_func_packed(data, xs: PackedChains, num_ls: int, total_mcmc_num: int, repeat_times: int,
-                        num_chains: Optional[int] = None, in_place: bool = True):
+                        num_chains: Optional[int] = None, in_place: bool = True, seed: Optional[int] = None, chain_ids=None):
     """sampler_func (MCPG.py:120-166) on bit-packed chains, production draws: level-parallel K7 (in place on ``xs``
     unless told otherwise), expected cut, best of repeats.  Returns (vs_good f32 [M], xs_good PackedChains of M
     chains, value f32 [C], xs after the local search)."""
@@ -299,8 +310,9 @@ def sampler_func_packed(data, xs: PackedChains, num_ls: int, total_mcmc_num: int
         raise _abi.RlsError("sampler_func_packed", -2, "the level-parallel K7 kernel does not cover this graph")
     Cc = xs.num_chains if num_chains is None else num_chains
     out = xs if (in_place and xs.num_chains == Cc) else PackedChains.empty(xs.num_nodes, Cc, xs.device)
-    xs_loc, expected = mops.mcpg_local_search_levels(data.graph, xs, data._lv_ptr, data._lv_data, num_ls, _seed_from_torch(),
-                                                     out=out, num_chains=Cc)
+    xs_loc, expected = mops.mcpg_local_search_levels(data.graph, xs, data._lv_ptr, data._lv_data, num_ls,
+                                                     _seed_from_torch() if seed is None else seed,
+                                                     out=out, num_chains=Cc, chain_ids=chain_ids)
     _, vs_good, xs_good = mops.mcpg_pick_best(expected, xs_loc, total_mcmc_num, repeat_times, data.num_edges)
     return vs_good, xs_good, expected - expected.mean(), xs_loc
 
@@ -358,8 +370,8 @@ class _ReturnFn(torch.autograd.Function):
     def forward(ctx, probs, samples, value, sums=None):
         # sums = (A, V) of an earlier call on the same samples and value (they do not depend on probs: the eight policy epochs
         # of a round share them, MCPG.py:397-403)
-        A, V = sums if sums is not None else (mops.mcpg_value_bit_sums(samples, value), value.sum())
-        C = samples.num_chains
+        A, V = sums[:2] if sums is not None else (mops.mcpg_value_bit_sums(samples, value), value.sum())
+        C = sums[2] if (sums is not None and len(sums) > 2) else samples.num_chains    # (a shard: the GLOBAL sums and chain count)
         lp, l1p = probs.log(), (1 - probs).log()
         ctx.save_for_backward(probs, A, V)
         ctx.C = C
@@ -379,7 +391,20 @@ def get_return(probs: TEN, samples, value: TEN, total_mcmc_num: int = 0, repeat_
     return _ReturnFn.apply(probs, samples, value.detach().to(torch.float32).contiguous())
 
 
-class MCPGRound:
+def _get_column(pc: PackedChains, i) -> TEN:
+    """Chain i of a PackedChains as bool [N]; i a python int or a 0-dim device tensor (no host read)."""
+    i = torch.as_tensor(i, dtype=torch.int64, device=pc.device)
+    return ((pc.words.index_select(0, (i // 64).reshape(1))[0] >> (i % 64)) & 1).bool()
+
+
+def _set_column(pc: PackedChains, i: int, bits: TEN) -> None:
+    sh = i % 64
+    mask = torch.ones((), dtype=torch.int64, device=pc.device) << sh
+    row = pc.words[i // 64]
+    pc.words[i // 64] = (row & ~mask) | (bits.to(torch.int64) << sh)
+
+
+class MCPGRound(Sharded):
     """One sampling round of the MCPG outer loop (methods/MCPG.py:366-413) kept on the device, sync-free:
 
         xs_sample = metro_sampling(xs_prob, xs_bool, change_times)                    K9, bit-packed
@@ -388,13 +413,31 @@ class MCPGRound:
         xs_bool = temp_max_info.repeat(1, repeat_times)                               never materialised (C_in broadcast)
         get_return(xs_prob, xs_sample.t(), value, ...) for the policy update          rls_mcpg_value_bit_sums
 
-    State: now_max_res f32 [M], now_max_info / start PackedChains of M chains, samples PackedChains of C = M * R."""
+    State: now_max_res f32 [M], now_max_info / start PackedChains of M chains, samples PackedChains of C = M * R.
+
+    Sharded over ranks: the KEPT chains are split -- ``total_mcmc_num`` is this rank's share M_local
+    (a multiple of 64), ``kept_offset`` the global index of its kept chain 0 (shards contiguous in rank order),
+    ``total_kept`` the global M, ``group`` the process group.  All repeats of a kept chain live on its rank, so sampling,
+    local search, best-of-repeats and the per-chain merge need no exchange, and every draw is keyed by the chain's GLOBAL id
+    (rls_chain_ids) -- a shard's chains are bit for bit the chains of the one-process run.  What the reference computes over
+    the WHOLE batch is reduced over the group: the walk's stop rule (per-round accept counts, MCPG.py:103,115), the mean of
+    ``expected`` (:165), the best / worst incumbent of the min/max replacement (:383-391: C1 twice + C2 once per round) and
+    get_return's two chain sums (:292-302).  Every rank then holds the same loss and gradient: the policy parameters stay in
+    step without a gradient all-reduce."""
 
     def __init__(self, data, now_max_info, now_max_res: TEN, total_mcmc_num: int, repeat_times: int, num_ls: int,
-                 change_times: Optional[int] = None):
+                 change_times: Optional[int] = None, kept_offset: int = 0, total_kept: Optional[int] = None, group=None,
+                 seed: Optional[int] = None):
+        self._init_shard(kept_offset, seed, group)
         self.data, self.M, self.R, self.num_ls = data, total_mcmc_num, repeat_times, num_ls
         if total_mcmc_num % 64 != 0:
             raise ValueError("total_mcmc_num must be a multiple of 64 (one bit tile holds 64 chains)")
+        self.M_total = total_mcmc_num if total_kept is None else int(total_kept)
+        if self.M_total % 64 != 0 or kept_offset % 64 != 0 or kept_offset + total_mcmc_num > self.M_total:
+            raise ValueError("kept_offset / total_kept: shards of the kept chains are whole 64-chain tiles inside [0, total_kept)")
+        self.sharded = self.M_total != self.M or group is not None
+        # global id of local chain c = repeat (c // M) * M_total + kept_offset + c % M
+        self.chain_ids = (kept_offset, self.M, self.M_total - self.M) if self.M_total != self.M else None
         self.N = data.num_nodes
         self.change_times = int(self.N / 10) if change_times is None else change_times     # MCPG.py:331
         info = now_max_info if isinstance(now_max_info, PackedChains) else PackedChains.pack(now_max_info.contiguous())
@@ -406,13 +449,41 @@ class MCPGRound:
         self.work = PackedChains.empty(self.N, self.M * self.R, info.device) if packed_fits else None      # after the local search
         self.value = None
         self._sums = None
-        self.best_value = self.best_index = None
+        self.best_value = self.best_index = self.best_x = None
         # the bit-packed walk keeps a 32 KB window of draws beside the tile: up to N ~ 16 000.  Beyond (G81: 20 000 nodes) the round
         # runs on the node-major kernels through the f32 surface and packs what it keeps
         self._nodemajor = mops.mcpg_metro_max_rounds(self.N, 0) == 0
+        if self._nodemajor and self.sharded:
+            raise NotImplementedError("a sharded MCPGRound needs the bit-packed walk (N <= ~16 000)")
+
+    def _global_best(self, values: TEN, rows: Optional[PackedChains], maximize: bool):
+        """(best value 0-dim, GLOBAL index 0-dim int64, its chain bool [N] or None) over every rank's ``values``; first index on
+        ties (shards are contiguous in rank order)."""
+        vs = values if maximize else -values
+        row_of = (lambda li: _get_column(rows, li)) if rows is not None else None
+        if self.stat_hook is not None:
+            return self.stat_hook("best", (vs, row_of, self.env_offset, maximize))
+        from .. import dist
+        v, _, x, gi = dist.global_best(vs, row_of, want_solution=rows is not None, group=self.group,
+                                       env_offset=self.env_offset, num_nodes=self.N)
+        return (v if maximize else -v), gi, x
+
+    def _replace_global_worst(self, temp_info: PackedChains) -> None:
+        """MCPG.py:383-391 over the WHOLE batch: the first worst incumbent (and the start state of its chain) becomes the
+        first best one.  C1 for the best (+ C2: its chain, N / 8 bytes), C1 for the worst; the owner of the worst rewrites it."""
+        hi_v, hi_g, x_hi = self._global_best(self.now_max_res, self.now_max_info, True)
+        _, lo_g, _ = self._global_best(self.now_max_res, None, False)
+        lo = int(lo_g) - self.env_offset                                  # (a host read: the sharded round has them anyway)
+        if 0 <= lo < self.M:
+            self.now_max_res[lo] = hi_v.to(torch.float32)
+            _set_column(self.now_max_info, lo, x_hi)
+            _set_column(temp_info, lo, x_hi)
+        self.best_value = hi_v.to(torch.float32).reshape(1)
+        self.best_index, self.best_x = hi_g.reshape(1), x_hi
 
     def step(self, xs_prob: TEN):
-        """One round; returns (value f32 [C], best value so far f32 [1]) -- device tensors, nothing is read back."""
+        """One round; returns (value f32 [C], best value so far f32 [1]) -- device tensors, nothing is read back (a sharded
+        round reads the two owners of its exchange)."""
         C = self.M * self.R
         if self._nodemajor:
             xs_sample = metro_sampling(xs_prob, self.start.unpack().repeat(1, self.R), self.change_times)
@@ -422,39 +493,60 @@ class MCPGRound:
             self.best_value, self.best_index = mops.mcpg_merge_best(temp_max, temp_info, self.now_max_res, self.now_max_info)
             self.start, self.value, self._sums = temp_info, value, None
             return self.value, self.best_value
-        metro_sampling_packed(xs_prob, self.start, self.change_times, num_chains=C, out=self.samples)
+        Cg = self.M_total * self.R
+        metro_sampling_packed(xs_prob, self.start, self.change_times, num_chains=C, out=self.samples, seed=self._next_seed(),
+                              chain_ids=self.chain_ids, stats=self if self.sharded else None, total_chains=Cg)
         xs_loc, expected = mops.mcpg_local_search_levels(self.data.graph, self.samples, self.data._lv_ptr, self.data._lv_data,
-                                                         self.num_ls, _seed_from_torch(), out=self.work)
+                                                         self.num_ls, self._next_seed(), out=self.work, chain_ids=self.chain_ids)
         _, temp_max, temp_info = mops.mcpg_pick_best(expected, xs_loc, self.M, self.R, self.data.num_edges)
-        self.best_value, self.best_index = mops.mcpg_merge_best(temp_max, temp_info, self.now_max_res, self.now_max_info)
+        if not self.sharded:
+            self.best_value, self.best_index = mops.mcpg_merge_best(temp_max, temp_info, self.now_max_res, self.now_max_info)
+            self.value = expected - expected.mean()
+        else:
+            mops.mcpg_merge_best(temp_max, temp_info, self.now_max_res, self.now_max_info, replace_worst=False)
+            self._replace_global_worst(temp_info)
+            total = self._global_sum(expected.sum(dtype=torch.float64).reshape(1))          # the mean over the whole batch (:165)
+            self.value = expected - (total[0] / Cg).to(torch.float32)
+        self.expected = expected
         self.start = temp_info
-        self.value = expected - expected.mean()
         self._sums = None
         return self.value, self.best_value
 
     def get_return(self, xs_prob: TEN):
-        """get_return of the round's samples; the two sums over the chains are formed once per round, not once per epoch."""
+        """get_return of the round's samples; the two sums over the chains are formed once per round, not once per epoch (and
+        over every rank's chains when the round is a shard)."""
         if self._sums is None:
-            self._sums = (mops.mcpg_value_bit_sums(self.samples, self.value), self.value.sum())
+            A, V = mops.mcpg_value_bit_sums(self.samples, self.value), self.value.sum()
+            if self.sharded:
+                tot = self._global_sum(torch.cat([A.to(torch.float64), V.to(torch.float64).reshape(1)]))
+                self._sums = (tot[:-1].to(torch.float32), tot[-1].to(torch.float32), self.M_total * self.R)
+            else:
+                self._sums = (A, V)
         return _ReturnFn.apply(xs_prob, self.samples, self.value, self._sums)
 
     def best_solution(self):
         """(value: float, x: bool [N]) of the best incumbent -- a host read, for the end of a run."""
+        if self.sharded:
+            return float(self.best_value.item()), self.best_x
         i = int(self.best_index.item())
         word = self.now_max_info.words[i // 64]
         return float(self.best_value.item()), ((word >> (i % 64)) & 1).bool()
 
 
 def run_mcpg(data, xs_init: TEN, vs_init: TEN, total_mcmc_num: int, repeat_times: int, num_ls: int, num_rounds: int,
-             sample_epoch_num: int = 8, lr: float = 8e-2, log=print):
+             sample_epoch_num: int = 8, lr: float = 8e-2, log=print, kept_offset: int = 0, total_kept: Optional[int] = None,
+             group=None, seed: Optional[int] = None):
     """The sampling loop of mcpg() (methods/MCPG.py:353-413) on MCPGRound, with the reference's per-round prints
     ("value ... entropy ..." and "num_samples_per_second: ..." as defined at :405-411: kept chains per round divided
     by the wall time of metro + sampler + merge).  ``xs_init`` [N, M] / ``vs_init`` [M]: the incumbents the reference
     gets from LocalSearch (:337-346).  The policy is the reference's parameter vector through a sigmoid (Simpler,
-    :62-73) trained with Adam: dense torch, out of the hot path.  Returns (best value, best x bool [N], samples/s list)."""
+    :62-73) trained with Adam: dense torch, out of the hot path.  Returns (best value, best x bool [N], samples/s list).
+    ``kept_offset`` / ``total_kept`` / ``group``: this process runs a shard of the kept chains (see MCPGRound); value, best x
+    and the policy are those of the whole batch on every rank."""
     import time
     device = data.graph.device
-    rnd = MCPGRound(data, xs_init, vs_init, total_mcmc_num, repeat_times, num_ls)
+    rnd = MCPGRound(data, xs_init, vs_init, total_mcmc_num, repeat_times, num_ls, kept_offset=kept_offset,
+                    total_kept=total_kept, group=group, seed=seed)
     lin = torch.nn.Parameter(torch.zeros(data.num_nodes, device=device))
     opt = torch.optim.Adam([lin], lr=lr)
     xs_prob = torch.full((data.num_nodes,), 0.5, device=device)
@@ -468,7 +560,7 @@ def run_mcpg(data, xs_init: TEN, vs_init: TEN, total_mcmc_num: int, repeat_times
         now_max = float(best.item())                                   # the reference reads it for the print, too
         running = time.time() - t0
         log(f"value {now_max: 9.2f}  entropy {float(entropy): 9.3f}")
-        rates.append(total_mcmc_num / running)
+        rates.append(rnd.M_total / running)
         log("num_samples_per_second: ", rates[-1])
         for _ in range(sample_epoch_num):
             xs_prob = torch.sigmoid(lin)

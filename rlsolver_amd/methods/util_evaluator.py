@@ -123,8 +123,17 @@ class Evaluator:
     def record1(self, i: float, v):
         self.recorder1.append((i, v))
 
-    def record2(self, i: float, vs: Union[TEN, float], xs: TEN):
-        """util_evaluator.py:90-107.  Returns a flag object whose truth value is the reference's ``if_update``."""
+    def record2(self, i: float, vs: Union[TEN, float], xs: TEN, group=None):
+        """util_evaluator.py:90-107.  Returns a flag object whose truth value is the reference's ``if_update``.
+        ``group`` (a torch.distributed group; ``dist.group.WORLD`` for the default one): ``vs`` / ``xs`` are this rank's shard
+        of the batch -- the batch's best row is found over all ranks first (rlsolver_amd.dist.global_best: C1 all_reduce(MAX)
+        of one packed key, C2 broadcast of the winner's N / 8 bytes), so every rank's evaluator records what the
+        one-process evaluator records (ties: the first row of the lowest rank, i.e. the first row of the whole batch)."""
+        if group is not None and th.is_tensor(vs) and xs.dim() == 2:
+            from .. import dist
+            sign = 1 if self.if_maximize else -1
+            best, _, bx = dist.global_best(vs * sign if sign < 0 else vs, xs, want_solution=True, group=group)
+            return self._record(i, (best * sign).reshape(1).to(vs.dtype if vs.is_floating_point() else th.int64), bx[None, :])
         return self._record(i, vs, xs)
 
     # ---- host views (each is a device read)

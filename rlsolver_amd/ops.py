@@ -219,9 +219,11 @@ def maxcut_step_launcher(g: DeviceGraph, x_in: TEN, x_out: TEN, action: TEN, obj
     if done is not None:
         _check(done, "done", (torch.float32,), g.device, (B,))
     op = _t.maxcut_step.default      # the overload itself: skips the packet's overload resolution on every call
-    args = (g.handle, x_in, x_out, action, obj, reward, cur, done, float(done_value))   # the tuple keeps g and the buffers alive
+    # g.handle is a plain int (the address of the ctypes struct the DeviceGraph owns): the closure holds g itself, or a caller that
+    # drops its graph would leave the launcher with a dangling host pointer; the tuple keeps the buffers alive
+    args = (g.handle, x_in, x_out, action, obj, reward, cur, done, float(done_value))
 
-    def launch(_op=op, _args=args):
+    def launch(_op=op, _args=args, _keep=g):
         _op(*_args)
     return launch
 
@@ -257,28 +259,30 @@ def ls_weight_dtype(g: DeviceGraph, mult: int):
     return torch.int8 if span <= 127 else (torch.int16 if span <= 32767 else torch.int32)
 
 
-def maxcut_ls_weights(g: DeviceGraph, xs: TEN, mult: int, dtype=None, padded: bool = False):
+def maxcut_ls_weights(g: DeviceGraph, xs: TEN, mult: int, dtype=None, padded: bool = False, return_minmax: bool = False):
     """Pre-pass of the local search: (ws [B, N] int8 / int16 / int32 -- ``dtype`` or the narrowest that fits --,
     ws_std int32 [N] = max_b ws - min_b ws, folded in by the same kernel).  ``padded``: ws comes back as [B, P], P = N rounded
-    up to 16 bytes of entries (the layout the round kernels read for any N; entries N .. P are padding)."""
+    up to 16 bytes of entries (the layout the round kernels read for any N; entries N .. P are padding).  ``return_minmax``:
+    the second result is the int32 [2, N] table (min_b ws, max_b ws) itself -- what a sharded batch reduces over its ranks."""
     B, _ = _spins(xs, "xs", g)
     dt = ls_weight_dtype(g, mult) if dtype is None else dtype
     per = 16 // torch.empty((), dtype=dt).element_size()
     P = (g.num_nodes + per - 1) // per * per if padded else g.num_nodes
-    # 16 bytes of slack behind the array: the kernels read the weights in 16-byte pieces, and the last piece of the LAST row runs
-    # past the end of an unpadded row that is not a 16-byte multiple (include/rlsolver_hip.h: rls_maxcut_local_search)
-    ws = torch.empty(B * P + per, dtype=dt, device=g.device)[: B * P].view(B, P)
+    ws = torch.empty((B, P), dtype=dt, device=g.device)    # (every kernel that reads 16-byte pieces asks for the padded pitch)
     mm = torch.empty((2, g.num_nodes), dtype=torch.int32, device=g.device)
     _t.maxcut_ls_weights(g.handle, xs, int(mult), ws, mm)
-    return ws, mm[1] - mm[0]
+    return ws, (mm if return_minmax else mm[1] - mm[0])
 
 
 def maxcut_local_search(g: DeviceGraph, xs: TEN, ws: TEN, rd_std: TEN, obj: TEN, num_iters: int, num_spin: int,
                         noise: Optional[TEN] = None, seed: int = 0, env_offset: int = 0,
                         first_draw_proposes: bool = False, compute_obj: bool = False) -> None:
-    """Fused local search (include/rlsolver_hip.h: rls_maxcut_local_search).  xs / obj in place."""
+    """Fused local search (include/rlsolver_hip.h: rls_maxcut_local_search).  xs / obj in place.  ws [B, P >= N] with rows a
+    multiple of 16 bytes apart (maxcut_ls_weights(padded=True)); the library refuses any other pitch."""
     B, _ = _spins(xs, "xs", g)
-    _check(ws, "ws", (torch.int8, torch.int16), g.device, (B, g.num_nodes))
+    _check(ws, "ws", (torch.int8, torch.int16), g.device)
+    if ws.dim() != 2 or ws.shape[0] != B or ws.shape[1] < g.num_nodes:
+        raise ValueError(f"ws must be [{B}, >= {g.num_nodes}]")
     _check(rd_std, "rd_std", (torch.float32,), g.device, (g.num_nodes,))
     _check(obj, "obj", (torch.int64,), g.device, (B,))
     if noise is not None:
@@ -288,6 +292,15 @@ def maxcut_local_search(g: DeviceGraph, xs: TEN, ws: TEN, rd_std: TEN, obj: TEN,
             raise ValueError(f"noise must be [>= {need}, {B}, {g.num_nodes}]")
     _t.maxcut_local_search(g.handle, xs, ws, rd_std, noise, _s64(seed), env_offset, num_iters, num_spin,
                            bool(first_draw_proposes), obj, bool(compute_obj))
+
+
+def maxcut_ls_normals(B: int, N: int, seed: int, draw: int, device, env_offset: int = 0, out: Optional[TEN] = None) -> TEN:
+    """f32 [B, N]: the standard normals the local-search kernels draw for (seed, env_offset + b, node, draw)."""
+    if out is None:
+        out = torch.empty((B, N), dtype=torch.float32, device=torch.device(device))
+    _check(out, "out", (torch.float32,), None, (B, N))
+    _t.maxcut_ls_normals(out, _s64(seed), int(env_offset), int(draw))
+    return out
 
 
 def node_stats_form(g: DeviceGraph, B: int, symmetric: bool) -> str:

@@ -66,12 +66,20 @@ def _chains(x, name):
     return x, (4 if x.dtype == torch.float32 else 1), x.shape[0], x.shape[1]
 
 
+def _chain_ids(chain_ids) -> tuple:
+    """(offset, period, skip) of include/rlsolver_hip.h: rls_chain_ids; None = the single-process numbering."""
+    if chain_ids is None:
+        return (0, 0, 0)
+    off, per, skip = (int(v) for v in chain_ids)
+    return (off, per, skip)
+
+
 def mcpg_metro_rounds(samples, probs: TEN, T: int, index: Optional[TEN] = None, u: Optional[TEN] = None,
                       seed: int = 0, t_limit: Optional[TEN] = None, write_back: bool = True,
-                      accepts: Optional[TEN] = None, t_offset: int = 0, samples_in=None) -> None:
+                      accepts: Optional[TEN] = None, t_offset: int = 0, samples_in=None, chain_ids=None) -> None:
     """K9 (see include/rlsolver_hip.h).  samples [N, C] f32/uint8 or PackedChains, in place, or read from
     ``samples_in`` (same layout; a PackedChains with fewer chains -- a multiple of 64 -- is broadcast) and written to
-    ``samples``."""
+    ``samples``.  ``chain_ids`` = (offset, period, skip): the global ids of a shard's chains (rls_chain_ids)."""
     st, sb, N, Cc = _chains(samples, "samples")
     dev = st.device
     _check(probs, "probs", (torch.float32,), dev, (N,))
@@ -98,7 +106,8 @@ def mcpg_metro_rounds(samples, probs: TEN, T: int, index: Optional[TEN] = None, 
             raise ValueError("samples_in must have the layout and node count of samples")
         if not write_back:
             raise ValueError("samples_in needs write_back")
-    _t.mcpg_metro_rounds(st, sin, c_in, Cc, probs, T, t_offset, index, u, _s64(seed), t_limit, bool(write_back), accepts)
+    _t.mcpg_metro_rounds(st, sin, c_in, Cc, probs, T, t_offset, index, u, _s64(seed), t_limit, bool(write_back), accepts,
+                         *_chain_ids(chain_ids))
 
 
 def mcpg_metro_max_rounds(N: int, spin_bytes: int) -> int:
@@ -121,7 +130,7 @@ def mcpg_metro_stop(accepts: TEN, target: int, first: int, next_T: int, ctl: TEN
 
 def mcpg_local_search(g: DeviceGraph, xs_in: TEN, order: TEN, num_ls: int, uniforms: Optional[TEN] = None,
                       seed: int = 0, visit_stream: Optional[TEN] = None, edge_weights: Optional[TEN] = None,
-                      gauge_node: int = -1):
+                      gauge_node: int = -1, chain_ids=None):
     """K7 + expected cut.  Returns (xs_out f32 [N, C], expected f32 [C]).  ``edge_weights`` int32 [E'] (in the order of
     the graph's stored edges) + a weighted visit stream select the weighted sampler; ``gauge_node`` >= 0 XORs every
     chain with its value at that node first (rlsolver/methods/MCPG/sampling.py:101-104)."""
@@ -138,12 +147,13 @@ def mcpg_local_search(g: DeviceGraph, xs_in: TEN, order: TEN, num_ls: int, unifo
         _check(visit_stream, "visit_stream", (torch.int32,), g.device)
     if edge_weights is not None:
         _check(edge_weights, "edge_weights", (torch.int32,), g.device, (g.num_stored_edges,))
-    _t.mcpg_local_search(g.handle, xs_in, xs_out, order, visit_stream, num_ls, uniforms, _s64(seed), edge_weights, int(gauge_node), expected)
+    _t.mcpg_local_search(g.handle, xs_in, xs_out, order, visit_stream, num_ls, uniforms, _s64(seed), edge_weights, int(gauge_node), expected,
+                         *_chain_ids(chain_ids))
     return xs_out, expected
 
 
 def mcpg_local_search_levels(g: DeviceGraph, xs_in, lv_ptr: TEN, lv_data: TEN, num_ls: int, seed: int = 0,
-                             coins: Optional[TEN] = None, out=None, num_chains: Optional[int] = None):
+                             coins: Optional[TEN] = None, out=None, num_chains: Optional[int] = None, chain_ids=None):
     """K7 + expected cut on the level-parallel schedule (rls_mcpg_visit_levels).  ``xs_in``: node-major [N, C] or
     PackedChains (which may hold fewer chains than ``num_chains``, a multiple of 64: broadcast).  ``coins`` int64 (bit
     pattern of uint64) [num_ls * N, ceil(C / 64)]: the tie coins "u < 1/2" -- test hook; None = counter hash keyed by
@@ -165,7 +175,8 @@ def mcpg_local_search_levels(g: DeviceGraph, xs_in, lv_ptr: TEN, lv_data: TEN, n
             raise ValueError("out must be a PackedChains of num_chains chains")
         xs_out, ot, osb = out, out.words, 0
     expected = torch.empty(Cc, dtype=torch.float32, device=g.device)
-    _t.mcpg_local_search_levels(g.handle, st, c_in, ot, Cc, lv_ptr, lv_data, num_ls, coins, _s64(seed), expected)
+    _t.mcpg_local_search_levels(g.handle, st, c_in, ot, Cc, lv_ptr, lv_data, num_ls, coins, _s64(seed), expected,
+                                *_chain_ids(chain_ids))
     return xs_out, expected
 
 
@@ -189,17 +200,19 @@ def mcpg_pick_best(expected: TEN, xs, total_mcmc_num: int, repeat_times: int, nu
     return idx, vs, xg
 
 
-def mcpg_merge_best(temp_max: TEN, temp_info: PackedChains, now_max_res: TEN, now_info: PackedChains):
-    """The best-merge of methods/MCPG.py:376-391 in place on the device.  Returns (best value f32 [1], its chain int64 [1])."""
+def mcpg_merge_best(temp_max: TEN, temp_info: PackedChains, now_max_res: TEN, now_info: PackedChains, replace_worst: bool = True):
+    """The best-merge of methods/MCPG.py:376-391 in place on the device.  Returns (best value f32 [1], its chain int64 [1]);
+    with ``replace_worst=False`` (a shard of the kept chains) only the per-chain merge is applied and the results are
+    [2] = {max, min} of now_max_res and their first chains."""
     M, N, dev = temp_info.num_chains, temp_info.num_nodes, temp_info.device
     _check(temp_max, "temp_max", (torch.float32,), dev, (M,))
     _check(now_max_res, "now_max_res", (torch.float32,), dev, (M,))
     if now_info.num_chains != M or now_info.num_nodes != N:
         raise ValueError("now_info must match temp_info")
     mask = torch.empty((M + 63) // 64, dtype=torch.int64, device=dev)
-    bv = torch.empty(1, dtype=torch.float32, device=dev)
-    bi = torch.empty(1, dtype=torch.int64, device=dev)
-    _t.mcpg_merge_best(temp_max, temp_info.words, now_max_res, now_info.words, M, mask, bv, bi)
+    bv = torch.empty(1 if replace_worst else 2, dtype=torch.float32, device=dev)
+    bi = torch.empty(1 if replace_worst else 2, dtype=torch.int64, device=dev)
+    _t.mcpg_merge_best(temp_max, temp_info.words, now_max_res, now_info.words, M, mask, bv, bi, bool(replace_worst))
     return bv, bi
 
 

@@ -40,9 +40,65 @@ def _worker(rank, world, port, ret):
     # negative objectives survive the packing
     obj, owner, _ = rdist.global_best(torch.tensor([-7 - rank, -9]))
     assert int(obj) == -7 and int(owner) == 0
+    # the winner's GLOBAL index travels with its row (one message); rows may come from a callable (bit-packed storage)
+    for shift in (0, 4):
+        v = torch.roll(vs_all, shift)
+        obj, owner, bx, gi = rdist.global_best(v[off:off + cnt], lambda li: xs_all[off + int(li)], want_solution=True,
+                                               env_offset=off, num_nodes=N)
+        assert int(gi) == int(v.argmax()) and torch.equal(bx, xs_all[int(gi)]) and bx.dtype == torch.bool
+        obj, owner, bx, gi = rdist.global_best(-v[off:off + cnt], env_offset=off)             # MINLOC by negation, no row
+        assert int(gi) == int(v.argmin()) and bx is None and int(obj) == -int(v.min())
+    # whole-batch statistics of a sharded batch: per-node (min, max) in ONE collective, float64 sums
+    mm_all = torch.stack([vs_all[:, None] - torch.arange(5)[None, :], vs_all[:, None] + torch.arange(5)[None, :]]).to(torch.int32)
+    mm = torch.stack([mm_all[0, off:off + cnt].min(dim=0)[0], mm_all[1, off:off + cnt].max(dim=0)[0]])
+    out = rdist.all_reduce_minmax(mm)
+    assert out is mm and torch.equal(mm[0], mm_all[0].min(dim=0)[0]) and torch.equal(mm[1], mm_all[1].max(dim=0)[0])
+    t = vs_all[off:off + cnt].to(torch.float64).sum().reshape(1)
+    assert float(rdist.all_reduce_sum(t)[0]) == float(vs_all.sum())
+    # the Sharded mixin routes through the group it was given; share_best = "everyone restarts from the best row"
+    from rlsolver_amd.seeding import Sharded
+    sh = Sharded()
+    sh._init_shard(off, None, dist.group.WORLD)
+    mm2 = torch.stack([mm_all[0, off:off + cnt].min(dim=0)[0], mm_all[1, off:off + cnt].max(dim=0)[0]])
+    assert torch.equal(sh._global_minmax(mm2), mm)
+    xs_l, vs_l = xs_all[off:off + cnt].clone(), vs_all[off:off + cnt].clone()
+    best, owner = rdist.share_best(xs_l, vs_l)
+    assert int(best) == 9 and bool((vs_l == 9).all()) and bool((xs_l == xs_all[1]).all())
     dist.barrier()
     dist.destroy_process_group()
     ret[rank] = True
+
+
+def test_seed_stream_and_chain_id_numbering():
+    """SeedStream: a private stream is a function of (seed, call count) only; the default draws from torch's generator.  The
+    chain numbering of rls_chain_ids as MCPGRound builds it covers the global batch exactly once over the shards."""
+    from rlsolver_amd.seeding import SeedStream
+    a, b = SeedStream(5), SeedStream(5)
+    sa = [a.next() for _ in range(4)]
+    assert sa == [b.next() for _ in range(4)] and len(set(sa)) == 4 and all(0 <= s < 2 ** 62 for s in sa)
+    assert SeedStream(6).next() != sa[0]
+    assert a.derive(sa[0], 0) != a.derive(sa[0], 1) and a.derive(sa[0], 3) == b.derive(sa[0], 3)
+    st = a.state_dict()
+    nxt = a.next()
+    c = SeedStream()
+    c.load_state_dict(st)
+    assert c.next() == nxt
+    torch.manual_seed(3)
+    d = SeedStream().next()
+    torch.manual_seed(3)
+    assert SeedStream().next() == d
+    M, R = 512, 3
+    seen = []
+    for W in (1, 2, 4, 8):
+        ids = set()
+        for r in range(W):
+            m0, ml = rdist.env_shard(M // 64, r, W)
+            m0, ml = m0 * 64, ml * 64
+            off, per, skip = m0, ml, M - ml
+            for c_ in range(ml * R):
+                ids.add(off + c_ + (c_ // per) * skip if per else off + c_)
+        assert ids == set(range(M * R))
+        seen.append(ids)
 
 
 def test_global_best_two_ranks():

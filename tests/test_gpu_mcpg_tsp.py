@@ -551,7 +551,7 @@ def test_merge_best_mask_scratch_is_exactly_ceil_M_over_64_words(M):
     bv = torch.empty(1, dtype=torch.float32, device=DEV)
     bi = torch.empty(1, dtype=torch.int64, device=DEV)
     _abi.call("rls_mcpg_merge_best", _ptr(dev(temp_max)), _ptr(d_temp.words), _ptr(d_res), _ptr(d_info.words), n, M,
-              _ptr(arena), _ptr(bv), _ptr(bi), _stream(torch.device(DEV)))
+              _ptr(arena), _ptr(bv), _ptr(bi), 1, _stream(torch.device(DEV)))
     assert arena[tiles:].eq(CANARY).all(), "a word behind mask_scratch was written"
     assert np.array_equal(d_res.cpu().numpy(), w_res) and np.array_equal(d_info.unpack().cpu().numpy(), w_info)
     assert np.array_equal(d_temp.unpack().cpu().numpy(), w_temp) and float(bv) == float(w_max) and int(bi) == w_idx
