@@ -49,9 +49,9 @@ class StatTape:
         return hook
 
 
-def _env(n, m, seed, offset=0, bidir=False, **kw):
+def _env(n, m, gseed, offset=0, bidir=False, **kw):
     from rlsolver_amd.envs.env_L2A import EnvMaxcut
-    return EnvMaxcut(mygraph=generate_gnm(n, m, seed), device=DEV, if_bidirectional=bidir, num_nodes=n, env_offset=offset, **kw)
+    return EnvMaxcut(mygraph=generate_gnm(n, m, gseed), device=DEV, if_bidirectional=bidir, num_nodes=n, env_offset=offset, **kw)
 
 
 @pytest.mark.parametrize("form", ["fused", "rounds", "decomposed"])
@@ -229,7 +229,7 @@ def test_dense_spinsystem_reset_halves_equal_whole(kind):
         env.stat_hook = hook
         torch.manual_seed(8)
         obs = env.reset().clone()
-        act = torch.arange(count, device=DEV) % n
+        act = (torch.arange(count, device=DEV) + off) % n          # the action of GLOBAL env e is e % n
         obs2, rew, done = env.step(act)
         return obs, env._matrix.clone(), obs2.clone(), rew.clone()
 
