@@ -63,6 +63,10 @@ def parse(argv=None):
     ap.add_argument("--via-env", action="store_true",
                     help="time the drop-in class surface, EnvMaxcutGym.step(action, out=slot) with 1-byte spins, instead of "
                          "the pre-validated C-ABI launcher (same kernel, plus the Python / ctypes path of the class)")
+    ap.add_argument("--graph", choices=("auto", "on", "off"), default="auto",
+                    help="launcher mode: enqueue each timed region of --steps launches as ONE hipGraph (captured before the region, "
+                         "replayed inside it).  auto = on when --steps <= 100, where the first launch's latency is a visible share of "
+                         "the region; the kernels, buffers and the end-of-run parity check are the same either way")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU only (gloo): launch, shard and exchange wiring of the N-rank run, no kernels")
@@ -164,21 +168,23 @@ def cpu_baseline_ref_shaped(graph_arr, n, seconds):
                       f"the reference's shape (per-env Python loop, int64 [B,E'] index gathers, {th.get_num_threads()} threads)"}
 
 
-def pmc_traffic_per_launch(algorithmic_bytes):
+def pmc_traffic_per_launch(envs, nodes, slots):
     """HBM bytes per k_maxcut_step launch from the committed rocprofv3 PMC summary (separate
     FETCH_SIZE / WRITE_SIZE passes of this same command, gfx950-corrected; tools/summarize_prof.py).
     PMC counters cannot be read from inside the process, so this is the profiled figure, not live.
-    The summary holds one entry per kernel instantiation the command launched (the headline's and the
-    config #5 shard's): the entry for a workload is the u8 step kernel whose measured bytes lie within
-    [0.9, 2] x that workload's algorithmic bytes; none in range -> None (reported as null)."""
+    The summary holds one entry per kernel instantiation the profiled command launched; tools/summarize_prof.py tags
+    the step kernel's entries with the workload they were measured on (envs per GPU, nodes, ring slots -- from the
+    profiled run's own JSON line).  Only an entry whose workload is EXACTLY this run's is reported; a run with other
+    --envs-per-gpu / --gset / --slots gets None (null in the line), never another configuration's traffic."""
     import glob
     best = None
+    want = {"envs": int(envs), "nodes": int(nodes), "slots": int(slots)}
     for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))):
         try:
             d = json.load(open(p))
             for k, v in d.get("kernels", {}).items():
                 hb = v.get("hbm_bytes_per_launch")
-                if "k_maxcut_step<unsigned char" in k and hb and 0.9 * algorithmic_bytes <= hb <= 2.0 * algorithmic_bytes:
+                if "k_maxcut_step<unsigned char" in k and hb and v.get("workload") == want:
                     best = (hb, f"{os.path.basename(p)}: {k.replace('rls::', '')}, grid {v.get('grid')}")
         except Exception:
             pass
@@ -269,6 +275,20 @@ def measure(a, gset, B, steps, warmup, repeats, dev, rank, local_rank, world, vi
         t += 1
 
     use_pg = dist.is_initialized()
+    use_graph = (not via_env) and (a.graph == "on" or (a.graph == "auto" and steps <= 100))
+    graphs = []
+    if use_graph:
+        # one hipGraph per timed region: region r runs steps t_r .. t_r + steps - 1 of the ring / action cycle (capture enqueues
+        # nothing: the launchers resolve torch's current stream at every call, which is the capture stream here)
+        torch.cuda.synchronize(dev)
+        tc = t
+        for _ in range(repeats):
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                for k in range(steps):
+                    step(tc + k)
+            graphs.append(gr)
+            tc += steps
 
     def barrier():
         if use_pg:
@@ -278,16 +298,20 @@ def measure(a, gset, B, steps, warmup, repeats, dev, rank, local_rank, world, vi
         rdist.global_best(obj)
         barrier()
     wall, kern = [], []
-    for _ in range(repeats):
+    for rep in range(repeats):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize(dev)
         barrier()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         e0.record()
-        for _ in range(steps):
-            step(t)
-            t += 1
+        if use_graph:
+            graphs[rep].replay()
+            t += steps
+        else:
+            for _ in range(steps):
+                step(t)
+                t += 1
         e1.record()
         if use_pg:  # episode boundary: best objective over all shards (C1, 8 bytes over RCCL)
             rdist.global_best(obj)
@@ -313,7 +337,7 @@ def measure(a, gset, B, steps, warmup, repeats, dev, rank, local_rank, world, vi
         if not torch.equal(ops.maxcut_obj(g, final).to(torch.int32), obj):
             raise SystemExit("PARITY FAILURE: incremental objective != recomputed objective")
 
-    res = {"wall": wall, "kernel_s": kern, "N": N, "E": len(mygraph), "is_real": is_real, "B": B,
+    res = {"wall": wall, "kernel_s": kern, "N": N, "E": len(mygraph), "is_real": is_real, "B": B, "graph": use_graph,
            "graph_arr": np.asarray(mygraph, dtype=np.int64)}
     return res          # the ring and the launchers die with this frame: the next workload gets the memory back
 
@@ -377,25 +401,29 @@ def main():
             "repeats": R, "ms_per_step_all": s["ms_per_step_all"],
             "timing": f"median of {R} regions of exactly {a.steps} steps, each bracketed by barrier + synchronize, MAX over ranks",
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8", "data": "synthetic",
+            # the graph: the real Gset file when data/gset/gset_<k>.txt is present, else the G(n, m) stand-in of its size; spins
+            # and actions are drawn either way
+            "dtype": "u8", "data": "real Gset graph, synthetic spins and actions" if res["is_real"] else "synthetic",
             "config": {"workload": f"Gset G{a.gset}{'' if res['is_real'] else '-sized G(n,m) stand-in'} MaxCut "
                                    f"(N={N}, E={res['E']}), {B} envs per GPU, K4 gym step emitting the next "
                                    f"state into a {a.slots}-slot rollout ring, uniform random actions"
                                    + ("; through EnvMaxcutGym.step(action, out=slot)" if a.via_env else "")
                                    + ("; BASELINE config #5 shard (2^20 envs over 8 GPUs = 131072 per GPU)"
                                       if (a.gset == 70 and B == 131072) else ""),
-                       "entry": "EnvMaxcutGym.step" if a.via_env else "rls_maxcut_step launcher",
-                       "num_nodes": N, "num_edges": res["E"], "envs_per_gpu": B, "global_envs": world * B,
+                       "entry": "EnvMaxcutGym.step" if a.via_env else ("rls_maxcut_step launcher, each timed region of "
+                                                                        f"{a.steps} launches enqueued as one hipGraph" if res["graph"]
+                                                                        else "rls_maxcut_step launcher"),
+                       "num_nodes": N, "num_edges": res["E"], "envs_per_gpu": B, "global_envs": world * B, "slots": a.slots,
                        "parallelism": f"env-shard x{world}"},
             "roofline": s["roofline"],
         }
-        tr = pmc_traffic_per_launch(s["roofline"]["algorithmic_bytes_per_launch"])
+        tr = pmc_traffic_per_launch(B, N, a.slots)
         if tr is not None:
             out["roofline"]["traffic"], out["roofline"]["traffic_source"] = tr[0], f"profiles/{tr[1]} (rocprofv3 --pmc)"
         if res5 is not None:
             st5 = max(1, min(a.steps, 200))
             s5 = summarize(res5, st5, world)
-            tr5 = pmc_traffic_per_launch(s5["roofline"]["algorithmic_bytes_per_launch"])
+            tr5 = pmc_traffic_per_launch(res5["B"], res5["N"], a.slots)
             if tr5 is not None:
                 s5["roofline"]["traffic"], s5["roofline"]["traffic_source"] = tr5[0], f"profiles/{tr5[1]} (rocprofv3 --pmc)"
             out["config5_shard"] = {

@@ -171,8 +171,12 @@ int rls_maxcut_step(const rls_graph* g, const void* x_in, void* x_out, int spin_
 /* K5  greedy single-flip sweep ("addition" loop)  envs/env_L2A.py:109-116,
  *     methods/LocalSearch.py:77-83:  for i in 0..N-1: flip i if the cut does
  *     not decrease (ties accept, update_xs_by_vs uses ge, util_read_data.py:199).
- * x [B,N] and obj [B] (int64) are updated in place; obj[b] must hold the cut of x[b] on entry (the accept rule
- * compares every candidate against it).  One sequential O(E) pass per env instead of N full objective evaluations. */
+ * x [B,N] and obj [B] (int64) are updated in place.  PRECONDITION: obj[b] == cut(x[b]) on entry.  The accept rule itself works on
+ * gains (flip i iff its gain >= 0) and does not read obj; what is written back differs by kernel form -- the level-parallel form
+ * (the one every unweighted graph with a level schedule takes) counts the cut of the swept tile once and OVERWRITES obj with it,
+ * the stream / generic forms ADD the accepted gains to the incoming obj.  The two agree exactly when the precondition holds, which
+ * is how every caller on the path uses it (envs/env_L2A.py:91-92 computes good_vs first); a stale or offset obj gives a
+ * form-dependent result and is a caller error.  One sequential O(E) pass per env instead of N full objective evaluations. */
 int rls_maxcut_greedy_sweep(const rls_graph* g, uint8_t* x, int64_t B,
                             int64_t* obj, void* stream);
 

@@ -648,7 +648,7 @@ static inline size_t node_stats_bits_lds(int64_t N, bool with_stage = true) {
 // the bit-sliced kernel needs the slabs, an unweighted graph, byte-sized counters and a tile that fits.  A tile costs about
 // 0.011 us per node however few envs it holds, the element-parallel kernels about 2e-6 us per (env, node + entry): K3 on a
 // G22-sized graph 28 us flat vs 9 / 21 / 68 us at 64 / 256 / 1024 envs, N = 10^4 with 10^4 edges 88 flat vs 7 / 17 / 70
-// (tools/dev/node_stats_forms.py) -- so small batches go element-parallel
+// (tools/sweeps/node_stats_forms.py) -- so small batches go element-parallel
 static inline bool node_stats_batch_fills_tiles(const rls_graph* g, int64_t B) {
     static const int64_t force = getenv("RLS_NODE_STATS_MIN_B") ? atoll(getenv("RLS_NODE_STATS_MIN_B")) : -1;   // dev knob
     if (force >= 0) return B >= force;
@@ -1192,7 +1192,7 @@ static inline size_t node_stats_lds(int64_t N) { return (size_t)(N + 2) * 8 + (s
 // the lane = env tile kernels (weighted graphs, degrees >= 65536) walk every node and entry of the graph once per tile, 0.10 us
 // per node + 0.008 us per entry whatever the batch (K3 on a +-1-weighted G22-sized graph: 530 us from 2048 to 16 384 envs), the
 // element-parallel kernels 2.75e-6 us per (env, node + entry) (250 / 480 / 1890 us at 2048 / 4096 / 16 384): the tile form from
-// the batch where it is the cheaper one (tools/dev/node_stats_forms.py)
+// the batch where it is the cheaper one (tools/sweeps/node_stats_forms.py)
 static inline bool node_stats_use_tile(const rls_graph* g, int64_t B) {
     static const bool off = getenv("RLS_NODE_STATS_NO_TILE") != nullptr;   // dev knob
     const int64_t N = g->num_nodes;
@@ -1277,7 +1277,7 @@ template <typename WT>
 static int ls_weights_typed(const rls_graph* g, const uint8_t* x, int64_t B, int32_t mult, WT* ws, int64_t pitch, int32_t* minmax,
                             void* stream) {
     // (a lane = env tile kernel used to take the small batches: 850 us per call on a G22-sized graph at any batch size, against
-    // 30 us for the bit-sliced one and 20 - 100 us for the element-parallel one: tools/dev/ls_weights_forms.py)
+    // 30 us for the bit-sliced one and 20 - 100 us for the element-parallel one: tools/sweeps/ls_weights_forms.py)
     if (node_stats_use_bits(g, g->ell_st_ptr, g->ell_st, B))
         return launch_node_stats_bits<2, WT>(g, x, B, g->erowptr, g->ell_st_ptr, g->ell_st, (int)mult, ws, stream, minmax, pitch);
     hipLaunchKernelGGL(k_ls_weights_elem<WT>, dim3(grid_for(B * g->num_nodes, 256)), dim3(256), 0, as_stream(stream), x, B, g->num_nodes,

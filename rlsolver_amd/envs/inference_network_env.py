@@ -35,12 +35,19 @@ def _edges_of(matrix) -> tuple:
 
 
 class SpinSystemUnbiased(SpinSystem):
-    """inference_network_env.py:541-595 on SpinSystem's kernels.  Positional parameters as there (:81-99)."""
+    """inference_network_env.py:541-595 on SpinSystem's kernels.  Positional parameters as there (:81-99).
+
+    Defaults: the reference's own defaults for ``extra_action`` / ``optimisation_target`` / ``reversible_spins`` (PASS, ENERGY,
+    False) select configurations no MaxCut caller uses -- every agent passes ExtraAction.NONE, OptimisationTarget.CUT,
+    reversible_spins=True explicitly (select_best_neural_network.py:121-136, ECO_S2V/util.py:146-160) and dqn_PECO.py:252
+    asserts them -- and this env refuses them.  So that ``SpinSystemUnbiased(gg, num_envs=B)`` is a working env rather than an
+    exception, the defaults here are the supported values; passing the reference's defaults explicitly still raises
+    NotImplementedError, naming the option."""
 
     def __init__(self, graph_generator=None, max_steps=20, observables=ECO_PECO_OBSERVABLES, reward_signal=RewardSignal.DENSE,
-                 extra_action=ExtraAction.PASS, optimisation_target=OptimisationTarget.ENERGY, spin_basis=SpinBasis.SIGNED,
+                 extra_action=ExtraAction.NONE, optimisation_target=OptimisationTarget.CUT, spin_basis=SpinBasis.SIGNED,
                  norm_rewards=False, memory_length=None, horizon_length=None, stag_punishment=None, basin_reward=None,
-                 reversible_spins=False, init_snap=None, seed=None, device=None, num_envs=None, use_tensor_core=False):
+                 reversible_spins=True, init_snap=None, seed=None, device=None, num_envs=None, use_tensor_core=False):
         unsupported = [name for name, bad in (("extra_action", extra_action.name != "NONE"),
                                               ("optimisation_target", optimisation_target.name != "CUT"),
                                               ("memory_length", memory_length is not None), ("reversible_spins", not reversible_spins),
@@ -87,7 +94,7 @@ class SpinSystemFactory:
 
     @staticmethod
     def get(graph_generator=None, max_steps=20, observables=ECO_PECO_OBSERVABLES, reward_signal=RewardSignal.DENSE,
-            extra_action=ExtraAction.PASS, optimisation_target=OptimisationTarget.ENERGY, spin_basis=SpinBasis.SIGNED,
+            extra_action=ExtraAction.NONE, optimisation_target=OptimisationTarget.CUT, spin_basis=SpinBasis.SIGNED,
             norm_rewards=False, memory_length=None, horizon_length=None, stag_punishment=None, basin_reward=None,
             reversible_spins=True, init_snap=None, seed=None, device=None, num_envs=None, if_greedy=False, use_tensor_core=False):
         return SpinSystemUnbiased(graph_generator, max_steps, observables, reward_signal, extra_action, optimisation_target, spin_basis,

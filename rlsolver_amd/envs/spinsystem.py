@@ -421,10 +421,21 @@ class SpinSystem(Sharded):
         self.state                                            # (materialises the lazy rows first)
         d = {k.lstrip("_"): getattr(self, k).clone() for k in keys}
         d["current_step"] = self.current_step
+        d["format"] = self.STATE_DICT_FORMAT
+        d["seeds"] = self._seeds.state_dict()
         return d
+
+    STATE_DICT_FORMAT = 2     # 1 (round 2): no last_flip / scalars / best_obs_score -- the O(deg) step keeps those instead of five rows
 
     def load_state_dict(self, d):
         keys = self._dict_keys()
+        missing = [k.lstrip("_") for k in keys if k.lstrip("_") not in d]
+        if missing:
+            raise ValueError(f"SpinSystem.load_state_dict: this checkpoint (format {d.get('format', 1)}) lacks {missing}; format "
+                             f"{self.STATE_DICT_FORMAT} keeps per-node flip times and per-env scalars where format 1 kept the "
+                             "observation rows, and they cannot be rebuilt from those rows: reset() the env instead")
+        if "seeds" in d:
+            self._seeds.load_state_dict(d["seeds"])
         for k in keys:
             getattr(self, k).copy_(d[k.lstrip("_")])     # in place: the kernel's pointer table stays valid
         self.current_step = int(d["current_step"])

@@ -72,7 +72,7 @@ def qubo_sparse_local_search_value(csr, xs: TEN, num_ls: int, binary: bool):
 
 
 def qubo_prefers_sparse(n: int, nnz: int, num_chains: int) -> bool:
-    """Which K11 kernel finishes a sweep first (measured on MI355X, tools/dev/time_qubo_sparse.py).
+    """Which K11 kernel finishes a sweep first (measured on MI355X, tools/sweeps/time_qubo_sparse.py).
 
     dense (MFMA):  a sweep is n / 32 blocks of about 4 + 5.4 n / 1000 us while one workgroup per CU suffices, and
                    2 n^2 C flops at ~80 TFLOP/s beyond that;

@@ -229,6 +229,8 @@ def maxcut_step_launcher(g: DeviceGraph, x_in: TEN, x_out: TEN, action: TEN, obj
 
 
 def maxcut_greedy_sweep(g: DeviceGraph, xs: TEN, obj: TEN) -> None:
+    """K5 in place.  ``obj[b]`` must equal the cut of ``xs[b]`` on entry (include/rlsolver_hip.h: the level-parallel form overwrites
+    obj with the swept rows' cut, the stream forms add the accepted gains: the same thing exactly under that precondition)."""
     B, _ = _spins(xs, "xs", g)
     _check(obj, "obj", (torch.int64,), g.device, (B,))
     _t.maxcut_greedy_sweep(g.handle, xs, obj)

@@ -515,7 +515,7 @@ def test_tsp_2opt_local_search_golden(golden):
 def test_merge_best_when_best_and_worst_incumbent_coincide(M):
     """MCPG.py:383-391 with argmax == argmin (one kept chain, or every incumbent equal after the merge): the incumbent
     column is left alone but temp_max_info's column STILL takes it -- it seeds the next round.  (Found by
-    tools/dev/fuzz_mcpg.py: the kernel used to return early.)"""
+    tools/fuzz/fuzz_mcpg.py: the kernel used to return early.)"""
     from rlsolver_amd.ops_mcpg_tsp import PackedChains
     rng = np.random.RandomState(M)
     n = 77

@@ -3,7 +3,7 @@ from rlsolver_amd.methods.MCPG_qubo import qubo_prefers_sparse
 
 
 def test_qubo_kernel_choice_follows_the_measured_crossovers():
-    # (n, fill, chains) -> CSR kernel wins; measured on MI355X (tools/dev/time_qubo_sparse.py, round 2)
+    # (n, fill, chains) -> CSR kernel wins; measured on MI355X (tools/sweeps/time_qubo_sparse.py, round 2)
     measured = [
         (1000, 0.02, 1 << 13, False), (1000, 0.02, 1 << 16, True), (1000, 0.1, 1 << 16, False),
         (500, 0.005, 1 << 13, False), (500, 0.005, 1 << 16, True), (2000, 0.005, 1 << 13, False),

@@ -389,3 +389,20 @@ def test_evaluator_oracle(golden, maximize, vdt):
     assert np.array_equal(np.asarray(ev.recorder2, dtype=np.float64), z[f"{tag}/recorder2_i_v"])
     assert np.array_equal(np.asarray(ev.recorder1, dtype=np.float64), z[f"{tag}/recorder1"])
     assert ev.first_v == float(z[f"{tag}/first_v"])
+
+
+@pytest.mark.parametrize("k,rows,cols", [(49, 30, 100), (50, 25, 120)])
+def test_oracle_on_toroidal_gset_known_answer(golden, k, rows, cols):
+    """SURVEY 8c item 10 without a data file: Gset's G49 / G50 are 4-regular toroidal grids, and the reference's X_G49 / X_G50
+    strings (util_evaluator.py:272-281) flip phase every 100 / 120 nodes -- on the 30 x 100 / 25 x 120 torus with row-major
+    numbering they cut exactly the claimed 6000 / 5880 edges.  The oracle's objective on the decoded string is that number."""
+    from oracle import oracle_np as onp
+    z = golden("encoder_base64")
+    x = z[f"kat/G{k}/x"].astype(np.uint8)
+    idx = np.arange(rows * cols).reshape(rows, cols)
+    e = np.concatenate([np.stack([idx, np.roll(idx, -1, axis=1)], axis=-1).reshape(-1, 2),
+                        np.stack([idx, np.roll(idx, -1, axis=0)], axis=-1).reshape(-1, 2)])
+    graph = np.concatenate([np.sort(e, axis=1), np.ones((e.shape[0], 1), dtype=np.int64)], axis=1)
+    for bidir in (False, True):
+        got = onp.maxcut_obj(np.stack([x, 1 - x]), graph, bidir)
+        assert got.tolist() == [int(z[f"kat/G{k}/claimed_cut"])] * 2

@@ -1,5 +1,5 @@
 // HBM ceiling calibration: plain 16-B/lane copy of n bytes, several shapes.  Build:
-//   hipcc --offload-arch=gfx950 -O3 -o tools/dev/copy_bench tools/dev/copy_bench.hip
+//   hipcc --offload-arch=gfx950 -O3 -o tools/dev/copy_bench tools/ceilings/copy_bench.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>

@@ -1,6 +1,6 @@
 """Differential fuzz of the gym env class (env_PPO.EnvMaxcut: reset / step with the done rule, in place and emitting into
 rollout slots, f32 reference surface and 1-byte spins, reuse_buffers) against the numpy restatement of the reference's env on
-random graphs, env counts and episode lengths.  `python tools/dev/fuzz_gym.py [seconds] [seed]`."""
+random graphs, env counts and episode lengths.  `python tools/fuzz/fuzz_gym.py [seconds] [seed]`."""
 import sys, time, types
 import numpy as np, torch
 sys.path.insert(0, ".")

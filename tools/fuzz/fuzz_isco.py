@@ -2,7 +2,7 @@
 (large batches) and both against the float64 oracle on random graphs with the same recorded draws -- the same selected
 nodes, log-probability terms within the conditioning-aware tolerance of tests/isco_tol.py, the same accepted samples away from
 the accept margin -- plus the invariants of a step (the proposal
-differs from x exactly on the selected nodes, an accepted sample IS the proposal).  `python tools/dev/fuzz_isco.py [seconds] [seed]`."""
+differs from x exactly on the selected nodes, an accepted sample IS the proposal).  `python tools/fuzz/fuzz_isco.py [seconds] [seed]`."""
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")

@@ -2,7 +2,7 @@
 (K + 2 .. 130 cities), K, batch sizes, path lengths and temperatures.  The walked tour is compared exactly except where the
 Gumbel argmax of a round is decided within a few ulps (the oracle reports nothing about that, so a mismatching tour is
 re-examined: it must still be a permutation reachable by the recorded partner draws), log_acc within 2e-5 relative + 1e-4.
-`python tools/dev/fuzz_isco_tsp.py [seconds] [seed]`."""
+`python tools/fuzz/fuzz_isco_tsp.py [seconds] [seed]`."""
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")

@@ -2,7 +2,7 @@
 random graphs (incl. hubs, where the two take different kernels), and both against the reference-shaped numpy oracle on small
 ones; random batch sizes around the tile, num_iters 0-6, num_spin 1-8, both adjacency forms.  Where the rows are 16-byte
 multiples, additionally the threshold / proposal-round kernels against the fused kernel with in-kernel draws (same seed).
-`python tools/dev/fuzz_ls.py [seconds] [seed]`."""
+`python tools/fuzz/fuzz_ls.py [seconds] [seed]`."""
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")

@@ -1,6 +1,6 @@
 """Differential fuzz of the MaxCut kernels (K1, K2, K3, K4, K5, K6) against the C oracle on random graph shapes: G(n, m),
 stars / hubs of any degree, paths, near-complete graphs, ragged and full tiles, both adjacency forms, batches on both sides
-of the kernels' dispatch thresholds.  `python tools/dev/fuzz_maxcut.py [seconds] [seed]` -- prints the first mismatch."""
+of the kernels' dispatch thresholds.  `python tools/fuzz/fuzz_maxcut.py [seconds] [seed]` -- prints the first mismatch."""
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")

@@ -1,6 +1,6 @@
 """Differential fuzz of the MCPG kernels against the numpy restatement of the reference's sampler_func / metro_sampling with
 recorded draws: random graphs (G(n, m), Barabasi-Albert, stars and multi-hub graphs up to degree ~900, paths), chain counts on
-both sides of the tile size, 1-3 passes.  `python tools/dev/fuzz_mcpg.py [seconds] [seed]`."""
+both sides of the tile size, 1-3 passes.  `python tools/fuzz/fuzz_mcpg.py [seconds] [seed]`."""
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")

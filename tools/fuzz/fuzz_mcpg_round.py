@@ -2,7 +2,7 @@
 (G(n, m), BA, hubs), kept-chain counts M and repeats R around the tile sizes, a few rounds each.  Invariants: incumbents never
 get worse, every incumbent value is the cut of its kept chain, the best value / index are the arg-max of the incumbents, the
 worst incumbent has been replaced by the best, get_return is finite with a finite gradient.
-`python tools/dev/fuzz_mcpg_round.py [seconds] [seed]`."""
+`python tools/fuzz/fuzz_mcpg_round.py [seconds] [seed]`."""
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")

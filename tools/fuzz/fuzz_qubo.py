@@ -1,7 +1,7 @@
 """Differential fuzz of the QUBO coordinate search (K11 on the matrix cores, and its CSR form) against the numpy restatement of
 the reference's variable-by-variable loop (MCPG/sampling.py:332-337, :357-362): random sizes on both sides of every block
 boundary, integer matrices (every sum exact in float32), with and without a diagonal, dense and sparse, 0-3 sweeps, chain
-counts around the 32 / 64-chain tiles and the wave split.  `python tools/dev/fuzz_qubo.py [seconds] [seed]`."""
+counts around the 32 / 64-chain tiles and the wave split.  `python tools/fuzz/fuzz_qubo.py [seconds] [seed]`."""
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")

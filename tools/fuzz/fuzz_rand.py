@@ -1,6 +1,6 @@
 """Differential fuzz of the counter-based generators against their numpy restatements at random (often odd) sizes: rand_spins,
 rand_actions, rand_perms, rand_couplings (ER / BA, every edge type, shard offsets), written into tensors with a canary row
-behind them.  `python tools/dev/fuzz_rand.py [seconds] [seed]`."""
+behind them.  `python tools/fuzz/fuzz_rand.py [seconds] [seed]`."""
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")

@@ -1,6 +1,6 @@
 """Differential fuzz of the row-selection ops against the numpy restatements: update_xs_by_vs and pick_xs_by_vs
 at random shapes incl. ties, both directions of optimisation.
-`python tools/dev/fuzz_select.py [seconds] [seed]`."""
+`python tools/fuzz/fuzz_select.py [seconds] [seed]`."""
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")

@@ -1,6 +1,6 @@
 """Differential fuzz of the spin-system env, per-env (dense) couplings and one shared graph (CSR), against the numpy restatement of the reference's batched PECO env
 (oracle/oracle_spin.py, one instance per env on that env's own matrix): random sizes, densities, +-1 couplings with and
-without diagonal entries, reward modes, visited-state memory, revisits.  `python tools/dev/fuzz_spin.py [seconds] [seed]`."""
+without diagonal entries, reward modes, visited-state memory, revisits.  `python tools/fuzz/fuzz_spin.py [seconds] [seed]`."""
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")

@@ -1,6 +1,6 @@
 """Differential fuzz of the TSP kernels against the numpy restatements: tour length (f32, 1e-5 relative), the 2-opt reversal
 delta (f64), the best-improvement 2-opt pass in both rankings and the whole local_search_2_opt (routes and float64 distances
-bit for bit), on Euclidean, integer (ties everywhere) and asymmetric matrices.  `python tools/dev/fuzz_tsp.py [seconds] [seed]`."""
+bit for bit), on Euclidean, integer (ties everywhere) and asymmetric matrices.  `python tools/fuzz/fuzz_tsp.py [seconds] [seed]`."""
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")

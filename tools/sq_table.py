@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""SQ counter evidence for the kernels whose bound is on chip (rocprofv3 --pmc passes of tools/dev/pmc_passes.sh over
+"""SQ counter evidence for the kernels whose bound is on chip (rocprofv3 --pmc passes of tools/sweeps/pmc_passes.sh over
 tools/bench_configs.py --profile):
 
     python tools/sq_table.py r03 gpurun_out/r03_sq   ->  profiles/r03_sq_counters.md / .json
@@ -61,7 +61,7 @@ for (name, grid, wg), c in sorted(acc.items(), key=lambda kv: -sum(kv[1].get("SQ
 os.makedirs("profiles", exist_ok=True)
 json.dump({"note": __doc__.strip(), "source": src, "groups": rows}, open(f"profiles/{tag}_sq_counters.json", "w"), indent=1)
 with open(f"profiles/{tag}_sq_counters.md", "w") as f:
-    f.write(f"# {tag}: SQ counters of the on-chip-bound kernels (tools/dev/pmc_passes.sh -> tools/sq_table.py)\n\n")
+    f.write(f"# {tag}: SQ counters of the on-chip-bound kernels (tools/sweeps/pmc_passes.sh -> tools/sq_table.py)\n\n")
     f.write("Means per launch; separate `rocprofv3 --pmc` passes, never combined with trace domains.  Shares are of SQ_WAVE_CYCLES "
             "(quad-cycles a wave is resident): VALU = SQ_ACTIVE_INST_VALU, wait-inst = SQ_WAIT_INST_ANY, wait-any = SQ_WAIT_ANY, "
             "LDS = SQ_ACTIVE_INST_LDS; conflicts = SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS.  VALU share x resident waves per SIMD "

@@ -1,6 +1,6 @@
 """Every batched entry point at batch sizes from 1 to 16 384: time per call.  Looks for forms that are slow at SMALL batches
 (a per-tile cost that does not shrink with the batch), the way the lane = env weights kernel was.
-`python tools/dev/batch_sweep.py [g22|g14|ba1e4]`."""
+`python tools/sweeps/batch_sweep.py [g22|g14|ba1e4]`."""
 import os, sys, types
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch

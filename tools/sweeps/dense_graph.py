@@ -1,5 +1,5 @@
 """A dense graph (N = 3000, E = 1.2 M; stored edges 2.4 M when bidirectional): the MaxCut entry points run and match the C oracle
-on a small batch -- looks for limits in the counter widths / degree caps (max degree ~900).  `python tools/dev/dense_graph.py`."""
+on a small batch -- looks for limits in the counter widths / degree caps (max degree ~900).  `python tools/sweeps/dense_graph.py`."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch

@@ -1,6 +1,6 @@
 """The tile kernels over graph SHAPES at one size (N = 2000-ish, 2^14 envs): G(n, m) at several densities, a torus (Gset G48-50),
 a path, a star, a hub graph, BA.  Looks for schedules that degenerate (levels = N on a path, one giant row on a star).
-`python tools/dev/graph_shape_sweep.py`."""
+`python tools/sweeps/graph_shape_sweep.py`."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch

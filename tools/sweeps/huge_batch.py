@@ -1,5 +1,5 @@
 """2^20 + 2^16 envs of a G22-sized graph on ONE GPU (2.1e9 spins: past 2^31 elements): every MaxCut entry point runs and a sample of
-rows matches the oracle -- looks for 32-bit index arithmetic.  `python tools/dev/huge_batch.py`."""
+rows matches the oracle -- looks for 32-bit index arithmetic.  `python tools/sweeps/huge_batch.py`."""
 import os, sys, types
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch

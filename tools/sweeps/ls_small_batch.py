@@ -1,5 +1,5 @@
 """local_search_inplace at small batches: the fused kernel (one workgroup per tile) against the round kernels (a tile's noise
-passes split over several workgroups).  `python tools/dev/ls_small_batch.py`."""
+passes split over several workgroups).  `python tools/sweeps/ls_small_batch.py`."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch

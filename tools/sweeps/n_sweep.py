@@ -1,6 +1,6 @@
 """The MaxCut entry points over the Gset node counts (800 ... 20 000) at two batch sizes: us per call and ns per (env, node).
 Looks for cliffs where a kernel form changes (fused local search <= ~7100 nodes, round kernels and the 64-env tile <= ~15 500 /
-~19 000, one env per wave beyond).  `python tools/dev/n_sweep.py`."""
+~19 000, one env per wave beyond).  `python tools/sweeps/n_sweep.py`."""
 import os, sys, types
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch

@@ -1,4 +1,4 @@
-"""MCPG / ISCO / spin-env entry points over the Gset node counts: us per call.  `python tools/dev/n_sweep2.py`."""
+"""MCPG / ISCO / spin-env entry points over the Gset node counts: us per call.  `python tools/sweeps/n_sweep2.py`."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch

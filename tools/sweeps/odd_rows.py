@@ -1,5 +1,5 @@
 """Rows that are not 16-byte multiples: every batched MaxCut entry point at N = 2000 next to N = 1999 / 2001 / 2004 / 2008 (same
-density), two batch sizes.  Looks for slow unaligned forms.  `python tools/dev/odd_rows.py`."""
+density), two batch sizes.  Looks for slow unaligned forms.  `python tools/sweeps/odd_rows.py`."""
 import os, sys, types
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch

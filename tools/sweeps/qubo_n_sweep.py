@@ -1,4 +1,4 @@
-"""K11 (dense QUBO coordinate search + value) over problem sizes: us per call and TFLOP/s.  `python tools/dev/qubo_n_sweep.py`."""
+"""K11 (dense QUBO coordinate search + value) over problem sizes: us per call and TFLOP/s.  `python tools/sweeps/qubo_n_sweep.py`."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch

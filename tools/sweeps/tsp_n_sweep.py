@@ -1,5 +1,5 @@
 """The TSP entry points over city counts either side of "the distance matrix fits LDS" (N = 200): us per call.
-`python tools/dev/tsp_n_sweep.py`."""
+`python tools/sweeps/tsp_n_sweep.py`."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch

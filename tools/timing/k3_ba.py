@@ -1,5 +1,5 @@
 """K3 (delta_all) and the local-search weights on a hub graph (BA n = 10^4, m = 5) next to a flat graph of the same size: what
-the hub groups cost the lane = node kernel.  `python tools/dev/k3_ba.py [log2 B]`."""
+the hub groups cost the lane = node kernel.  `python tools/timing/k3_ba.py [log2 B]`."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
