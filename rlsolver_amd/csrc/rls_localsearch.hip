@@ -54,13 +54,30 @@ __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
     return h;
 }
 
-// four standard normals (Box-Muller) for nodes 4q..4q+3 in round `it`; env_key = per-env mixed seed.
-// Two hashes per quad: each 32-bit hash gives a 16-bit radius uniform and a 16-bit angle (the radius
-// tail ends at sqrt(2 ln 2^16) = 4.7 sigma); hardware log2 / sqrt / sin / cos (v_sin/v_cos take
-// revolutions).  This is the VALU floor of the proposal rounds: 2000 x 64 normals per round and tile.
-__device__ __forceinline__ void normal4(uint32_t env_key, uint32_t q, uint32_t it, float (&z)[4]) {
-    const uint32_t k = env_key ^ (q * 0x9E3779B1u) ^ (it * 0x7FEB352Du + 0x165667B1u);
-    const uint32_t r0 = fmix32(k), r1 = fmix32(k + 0x27D4EB2Fu);
+// The per-env half of a draw's key: TWO independent 32-bit mixes of (seed, global env id).  (One 32-bit key per env, as until
+// round 3, makes two of a call's 2^16 envs share ALL their draws with probability ~1/2 per call -- 2^31 pairs against 2^32 keys.)
+struct EnvKey { uint32_t k0, k1; };
+__device__ __forceinline__ EnvKey ls_env_key(uint64_t seed, uint64_t gb) {
+    const uint32_t lo = (uint32_t)gb, hi = (uint32_t)(gb >> 32);
+    EnvKey k;
+    k.k0 = fmix32((uint32_t)seed ^ fmix32((uint32_t)(seed >> 32) ^ fmix32(lo) ^ (hi * 0x9E3779B1u)));
+    k.k1 = fmix32((uint32_t)(seed >> 32) + 0x3C6EF372u + fmix32((uint32_t)seed ^ fmix32(lo + 0x7F4A7C15u) ^ (hi * 0x85EBCA77u)));
+    return k;
+}
+
+// four standard normals (Box-Muller) for nodes 4q..4q+3 in round `it`.
+// Two hashes per quad, each of its OWN 32-bit key (k0 / k1 mixed with the quad and the round through different odd
+// multipliers): a 32-bit hash value necessarily coincides between ~7 % of the 2.9 * 10^8 (env, quad, round) triples of a
+// G22 / 2^16 call -- as 32-bit draws of an ideal generator would -- but with one shared key (round 3) a coincidence gave
+// two triples all FOUR normals; with independent keys the pairs coincide independently (all four: 2^-64 per pair of triples).
+// Each hash gives a 16-bit radius uniform and a 16-bit angle (the radius tail ends at sqrt(2 ln 2^16) = 4.7 sigma); hardware
+// log2 / sqrt / sin / cos (v_sin / v_cos take revolutions).  This is the VALU floor of the proposal rounds: 2000 x 64 normals
+// per round and tile.  tests/test_gpu_draw_statistics.py holds the generator to moments, tails, lag correlations and a
+// chi-square of the probability integral transform.
+__device__ __forceinline__ void normal4(EnvKey env_key, uint32_t q, uint32_t it, float (&z)[4]) {
+    const uint32_t ka = env_key.k0 ^ (q * 0x9E3779B1u) ^ (it * 0x7FEB352Du + 0x165667B1u);
+    const uint32_t kb = env_key.k1 ^ (q * 0xC2B2AE3Du) ^ (it * 0x27D4EB2Fu + 0x85EBCA6Bu);
+    const uint32_t r0 = fmix32(ka), r1 = fmix32(kb);
     const float u1 = ((float)(r0 >> 16) + 1.0f) * (1.0f / 65536.0f);   // (0, 1]
     const float u3 = ((float)(r1 >> 16) + 1.0f) * (1.0f / 65536.0f);
     const float t2 = (float)(r0 & 0xFFFFu) * (1.0f / 65536.0f);        // [0, 1) revolutions
@@ -105,9 +122,7 @@ __global__ __launch_bounds__(W * kWave) void k_maxcut_local_search(
     const int64_t b0 = (int64_t)blockIdx.x * kWave;
     const int64_t b = b0 + lane;
     const bool valid = b < B;
-    const uint64_t gb = (uint64_t)(b + env_offset);
-    const uint32_t env_key = fmix32((uint32_t)seed ^ fmix32((uint32_t)(seed >> 32) ^ fmix32((uint32_t)gb) ^
-                                                            ((uint32_t)(gb >> 32) * 0x9E3779B1u)));
+    const EnvKey env_key = ls_env_key(seed, (uint64_t)(b + env_offset));
 
     // ---- phase 0
     if (threadIdx.x == 0) words[N] = 0;
@@ -369,9 +384,6 @@ __global__ __launch_bounds__(W * kWave) void k_maxcut_local_search(
 // result.  Before, these steps were torch ops on [B, N] f32 tensors (randn, multiply-add, kthvalue, gt) around K6.
 // Rows must be 16-byte multiples (the row-piece stage); ws int8 / int16.
 // =====================================================================================
-__device__ __forceinline__ uint32_t ls_env_key(uint64_t seed, uint64_t gb) {   // (the fused kernel's mix)
-    return fmix32((uint32_t)seed ^ fmix32((uint32_t)(seed >> 32) ^ fmix32((uint32_t)gb) ^ ((uint32_t)(gb >> 32) * 0x9E3779B1u)));
-}
 
 // The draws themselves, as a tensor: out[b, n] = normal(seed, env_offset + b, n, draw), the value every local-search kernel
 // above and below uses for that (env, node, draw).  For the decomposed path (weights wider than 16 bits, graphs outside
@@ -407,7 +419,7 @@ __device__ __forceinline__ void ls_slice_chunks(int64_t nchunks_all, int sl, int
 
 template <typename WT, int W, typename F>
 __device__ __forceinline__ void ls_ws_pass(const WT* __restrict__ ws, int64_t pitch, int64_t B, int64_t N, int64_t b0, int lane, int w,
-                                           unsigned char* wstage, const float* sd, uint32_t env_key, int it,
+                                           unsigned char* wstage, const float* sd, EnvKey env_key, int it,
                                            int64_t c_begin, int64_t nchunks, F&& f) {   // chunks [c_begin, nchunks)
     typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
     constexpr int NPC = 16 / (int)sizeof(WT), QPP = NPC / 4, D = 2;
@@ -488,7 +500,7 @@ __global__ __launch_bounds__(kLsRoundWaves * kWave) void k_ls_threshold(const WT
     const int lane = threadIdx.x & (kWave - 1);
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     const int64_t b0 = (int64_t)blockIdx.x * kWave, b = b0 + lane;
-    const uint32_t env_key = ls_env_key(seed, (uint64_t)(b + env_offset));
+    const EnvKey env_key = ls_env_key(seed, (uint64_t)(b + env_offset));
     for (int64_t i = threadIdx.x; i < ((N + 3) & ~3ll); i += W * kWave) sdl[i] = i < N ? rd_std[i] : 0.0f;   // rd_std: one broadcast read per quad
     __syncthreads();
     float t[kTopCap];
@@ -557,7 +569,7 @@ __global__ __launch_bounds__(kLsRoundWaves * kWave) void k_ls_mask(const WT* __r
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     const int64_t b0 = (int64_t)blockIdx.x * kWave, b = b0 + lane;
     const bool valid = b < B;
-    const uint32_t env_key = ls_env_key(seed, (uint64_t)(b + env_offset));
+    const EnvKey env_key = ls_env_key(seed, (uint64_t)(b + env_offset));
     for (int64_t i = threadIdx.x; i < ((N + 3) & ~3ll); i += W * kWave) sdl[i] = i < N ? rd_std[i] : 0.0f;   // rd_std: one broadcast read per quad
     __syncthreads();
     const float th = valid ? thresh[b] : 0.0f;
@@ -597,7 +609,7 @@ __global__ __launch_bounds__(kLsRoundWaves * kWave) void k_ls_propose(uint8_t* _
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     const int64_t b0 = (int64_t)blockIdx.x * kWave, b = b0 + lane;
     const bool valid = b < B;
-    const uint32_t env_key = ls_env_key(seed, (uint64_t)(b + env_offset));
+    const EnvKey env_key = ls_env_key(seed, (uint64_t)(b + env_offset));
     unsigned char* stage = stages + (size_t)w * kStageBytes;
     if constexpr (SD_LDS && !PREMASK)
         for (int64_t i = threadIdx.x; i < ((N + 3) & ~3ll); i += W * kWave) sdl[i] = i < N ? rd_std[i] : 0.0f;
