@@ -16,10 +16,6 @@ def t(f, K=30):
 for B in (4096, 65536):
     xs = env.generate_xs_randomly(B); vs = env.calculate_obj_values(xs)
     us_w = t(lambda: ops.maxcut_ls_weights(env.graph, xs, 1))
-    ws = torch.empty((B, n), dtype=torch.int32, device=dev)
-    from rlsolver_amd import _abi
-    import ctypes as C
-    us_k = t(lambda: _abi.call("rls_maxcut_ls_weights", env.graph.ref, C.c_void_p(xs.data_ptr()), B, 1, C.c_void_p(ws.data_ptr()), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)))
     us_all = t(lambda: env.local_search_inplace(xs.clone(), vs.clone()))
     us_clone = t(lambda: (xs.clone(), vs.clone()))
-    print(f"B={B}: ls_weights op {us_w:.1f} us (kernel alone {us_k:.1f}), whole local_search_inplace {us_all:.1f} us (clones {us_clone:.1f})")
+    print(f"B={B}: ls_weights op {us_w:.1f} us, whole local_search_inplace {us_all:.1f} us (clones {us_clone:.1f})")
