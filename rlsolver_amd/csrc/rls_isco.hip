@@ -16,6 +16,7 @@
 // the tolerance north_star states for floating-point results).
 #include "rls_tile.h"
 #include <cmath>
+#include <cstdlib>
 
 namespace rls {
 
@@ -88,9 +89,38 @@ __device__ __forceinline__ float noreplacement_ll_sum(int count, float base, int
     return wave_sum_f32x(total);
 }
 
+// Order of a selection that does not fit the LDS list (count > capacity: path lengths in the thousands on a graph whose
+// rows nearly fill LDS -- the reference draws Poisson(~10) path lengths, main_ISCO_maxcut.py:22-30): repeated extraction of
+// the maximum, O(count N / 64) per sample, ONE wave.  The node ids leave in order into `ord` -- global scratch, the sample's
+// own row of y_out reinterpreted (written last by the step) -- `taken` is N bytes of LDS that are free at this point (yb).
+// Equal keys: lowest node first.
+__device__ __noinline__ void isco_order_by_extraction(const float* pert, uint8_t* taken, int64_t N, uint32_t prefix, int count,
+                                                      int32_t* ord, int lane) {
+    for (int64_t i = lane; i < N; i += kWave) taken[i] = 0;
+    lds_fence();
+    for (int k = 0; k < count; ++k) {
+        uint32_t bk = 0;
+        int bi = 0x7FFFFFFF;
+        for (int64_t i = lane; i < N; i += kWave) {
+            const uint32_t key = fkey(pert[i]);
+            if (key >= prefix && !taken[i] && key > bk) { bk = key; bi = (int)i; }
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const uint32_t ok = (uint32_t)__shfl_xor((int)bk, m, 64);
+            const int oi = __shfl_xor(bi, m, 64);
+            if (ok > bk || (ok == bk && oi < bi)) { bk = ok; bi = oi; }
+        }
+        if (lane == 0) { ord[k] = bi; taken[bi] = 1; }
+        lds_fence();
+    }
+    __threadfence();      // the list is read back by every lane (and, in the workgroup kernel, by every wave after a barrier)
+}
+
 // ----------------------------------------------------------------------------------------------- MaxCut
 // LDS per wave: xb[N] yb[N] bytes (padded to 8) | lp[N] f32 | pert[N] f32 | sel_key[P] f32 | sel_idx[P] i32,
-// P = next power of two >= N.
+// P = the list's capacity: the next power of two >= N while that fits LDS, else the largest power of two that does
+// (N = 10^4, G70: 4096 entries).  A selection larger than P takes isco_order_by_extraction.
 struct IscoMcArgs {
     const int32_t* rowptr; const int32_t* col;
     const int32_t* ell_ptr; const int32_t* ell;          // lane-per-node slabs of the symmetric CSR (rls_graph_ell) or NULL
@@ -248,36 +278,45 @@ __global__ __launch_bounds__(256) void k_isco_maxcut_step(IscoMcArgs a) {
         const uint64_t m = ballot64(sel);
         if (sel) {
             const int at = count + __popcll(m & ((1ull << lane) - 1ull));
-            skey[at] = pert[i];
-            sidx[at] = (int)i;
+            if (at < P) {
+                skey[at] = pert[i];
+                sidx[at] = (int)i;
+            }
         }
         count += __popcll(m);
     }
-    int P2 = 1;
-    while (P2 < count) P2 <<= 1;
-    for (int k = count + lane; k < P2; k += kWave) { skey[k] = -INFINITY; sidx[k] = -1; }
-    lds_fence();
-    for (int size = 2; size <= P2; size <<= 1) {
-        for (int stride = size >> 1; stride >= 1; stride >>= 1) {
-            for (int t = lane; t < (P2 >> 1); t += kWave) {
-                const int lo = ((t / stride) * (stride << 1)) + (t % stride);
-                const int hi = lo + stride;
-                const bool desc = ((lo & size) == 0);
-                const float k0 = skey[lo], k1 = skey[hi];
-                if ((k0 < k1) == desc) {
-                    skey[lo] = k1; skey[hi] = k0;
-                    const int t0 = sidx[lo]; sidx[lo] = sidx[hi]; sidx[hi] = t0;
+    const bool big = count > P;                                  // (wave-uniform) the list does not hold the selection
+    int32_t* ord = reinterpret_cast<int32_t*>(a.y_out + b * N);  // its order then lives in this sample's output row until the end
+    if (big) {
+        isco_order_by_extraction(pert, yb, N, prefix, count, ord, lane);
+    } else {
+        int P2 = 1;
+        while (P2 < count) P2 <<= 1;
+        for (int k = count + lane; k < P2; k += kWave) { skey[k] = -INFINITY; sidx[k] = -1; }
+        lds_fence();
+        for (int size = 2; size <= P2; size <<= 1) {
+            for (int stride = size >> 1; stride >= 1; stride >>= 1) {
+                for (int t = lane; t < (P2 >> 1); t += kWave) {
+                    const int lo = ((t / stride) * (stride << 1)) + (t % stride);
+                    const int hi = lo + stride;
+                    const bool desc = ((lo & size) == 0);
+                    const float k0 = skey[lo], k1 = skey[hi];
+                    if ((k0 < k1) == desc) {
+                        skey[lo] = k1; skey[hi] = k0;
+                        const int t0 = sidx[lo]; sidx[lo] = sidx[hi]; sidx[hi] = t0;
+                    }
                 }
+                lds_fence();
             }
-            lds_fence();
         }
     }
+    auto sel_at = [&](int k) -> int { return big ? ord[k] : sidx[k]; };
     // ---- ll_x2y: log-probability of drawing the selected set in that order (util.py:530-552)
-    const float ll_x2y = noreplacement_ll_sum(count, lmax, lane, [&](int k) { return lp[sidx[k]]; });
+    const float ll_x2y = noreplacement_ll_sum(count, lmax, lane, [&](int k) { return lp[sel_at(k)]; });
     // ---- y = x with the selected nodes flipped (env_ISCO.py:41-43)
     for (int64_t i = lane; i < N; i += kWave) yb[i] = xb[i];
     lds_fence();
-    for (int k = lane; k < count; k += kWave) yb[sidx[k]] ^= 1;
+    for (int k = lane; k < count; k += kWave) yb[sel_at(k)] ^= 1;
     lds_fence();
     if (a.mask_out) {
         for (int64_t i = lane; i < N; i += kWave) a.mask_out[b * N + i] = xb[i] ^ yb[i];
@@ -285,9 +324,9 @@ __global__ __launch_bounds__(256) void k_isco_maxcut_step(IscoMcArgs a) {
     // ---- backward: ll_y and the probability of undoing the selection in reverse order (env_ISCO.py:65-77)
     const float ll_y = (float)isco_local_dist(yb, lp, N, a.rowptr, a.col, a.ell_ptr, a.ell, T, lane) / T;
     float bmax = -INFINITY;
-    for (int k = lane; k < count; k += kWave) bmax = fmaxf(bmax, lp[sidx[k]]);
+    for (int k = lane; k < count; k += kWave) bmax = fmaxf(bmax, lp[sel_at(k)]);
     bmax = wave_max_f(bmax);
-    const float ll_y2x = noreplacement_ll_sum(count, bmax, lane, [&](int k) { return lp[sidx[count - 1 - k]]; });
+    const float ll_y2x = noreplacement_ll_sum(count, bmax, lane, [&](int k) { return lp[sel_at(count - 1 - k)]; });
     // ---- Metropolis-Hastings accept (env_ISCO.py:31-33, util.py:556-570)
     const float log_acc = fminf(((ll_y + ll_y2x) - ll_x) - ll_x2y, 0.0f);
     const float ua = a.u_accept ? a.u_accept[b] : isco_unit(isco_draw(a.seed, genv, 0xFFFFFFFFu, 0, 2));
@@ -469,14 +508,22 @@ __global__ __launch_bounds__(kIscoWgWaves * kWave) void k_isco_maxcut_step_wg(Is
     for (int64_t i = tid; i < N; i += NT) {
         if (fkey(pert[i]) >= prefix) {
             const int at = atomicAdd(&sc->count, 1);
-            skey[at] = pert[i];
-            sidx[at] = (int)i;
+            if (at < P) {
+                skey[at] = pert[i];
+                sidx[at] = (int)i;
+            }
         }
     }
     __syncthreads();
     const int count = sc->count;
+    const bool big = count > P;                                  // the list does not hold the selection: order by extraction
+    int32_t* ord = reinterpret_cast<int32_t*>(a.y_out + b * N);  // (this sample's output row, written last)
+    auto sel_at = [&](int k) -> int { return big ? ord[k] : sidx[k]; };
     float ll_x2y = 0.0f;
-    if (w == 0) {
+    if (w == 0 && big) {
+        isco_order_by_extraction(pert, yb, N, prefix, count, ord, lane);
+        ll_x2y = noreplacement_ll_sum(count, lmax, lane, [&](int k) { return lp[ord[k]]; });
+    } else if (w == 0) {
         int P2 = 1;
         while (P2 < count) P2 <<= 1;
         for (int k = count + lane; k < P2; k += kWave) { skey[k] = -INFINITY; sidx[k] = -1; }
@@ -502,9 +549,10 @@ __global__ __launch_bounds__(kIscoWgWaves * kWave) void k_isco_maxcut_step_wg(Is
         ll_x2y = noreplacement_ll_sum(count, lmax, lane, [&](int k) { return lp[sidx[k]]; });
     }
     // ---- y = x with the selected nodes flipped
+    __syncthreads();                                              // (wave 0 may have used yb as the extraction's marks)
     for (int64_t i = tid; i < N; i += NT) yb[i] = xb[i];
     __syncthreads();
-    for (int k = tid; k < count; k += NT) yb[sidx[k]] ^= 1;
+    for (int k = tid; k < count; k += NT) yb[sel_at(k)] ^= 1;
     __syncthreads();
     if (a.mask_out) {
         for (int64_t i = tid; i < N; i += NT) a.mask_out[b * N + i] = xb[i] ^ yb[i];
@@ -513,9 +561,9 @@ __global__ __launch_bounds__(kIscoWgWaves * kWave) void k_isco_maxcut_step_wg(Is
     const float ll_y = (float)isco_local_dist_wg(yb, lp, N, a, T, sc, lane, w) / T;
     if (w == 0) {
         float bmax = -INFINITY;
-        for (int k = lane; k < count; k += kWave) bmax = fmaxf(bmax, lp[sidx[k]]);
+        for (int k = lane; k < count; k += kWave) bmax = fmaxf(bmax, lp[sel_at(k)]);
         bmax = wave_max_f(bmax);
-        const float ll_y2x = noreplacement_ll_sum(count, bmax, lane, [&](int k) { return lp[sidx[count - 1 - k]]; });
+        const float ll_y2x = noreplacement_ll_sum(count, bmax, lane, [&](int k) { return lp[sel_at(count - 1 - k)]; });
         const float log_acc = fminf(((ll_y + ll_y2x) - ll_x) - ll_x2y, 0.0f);
         const float ua = a.u_accept ? a.u_accept[b] : isco_unit(isco_draw(a.seed, genv, 0xFFFFFFFFu, 0, 2));
         const bool accept = logf(ua + 1e-24f) < log_acc;
@@ -718,11 +766,20 @@ int rls_isco_maxcut_step(const rls_graph* g, const float* x, float* y_out, int64
     RLS_REQUIRE((u_gumbel == nullptr) == (u_accept == nullptr), RLS_EINVAL, "u_gumbel and u_accept must both be given or both be NULL");
     RLS_REQUIRE(temperature > 0.0f, RLS_EINVAL, "temperature must be > 0");
     const int64_t N = g->num_nodes;
+    RLS_REQUIRE((const void*)x != (const void*)y_out, RLS_EINVAL, "y_out must not alias x (a rejected proposal restores x; the row also serves as scratch)");
+    // capacity of the selected-set list in LDS: a power of two >= N while that fits (N <= 4096: as before), else the largest
+    // power of two the rows leave room for, at least 64 (N = 10^4: 4096; N = 15 000: 512) -- a larger selection takes the
+    // extraction path.  The rows themselves (two byte rows, two f32 rows) bound N at ~15 900.
+    static const int force_cap = getenv("RLS_ISCO_SEL_CAP") ? atoi(getenv("RLS_ISCO_SEL_CAP")) : 0;   // dev / test knob
+    const size_t rows = 2 * (((size_t)N + 7) & ~(size_t)7) + (size_t)N * 8;
+    const size_t fixed = sizeof(IscoWgScratch) + 16;
     int P = 1;
     while (P < N) P <<= 1;
-    const size_t per_wave = 2 * (((size_t)N + 7) & ~(size_t)7) + (size_t)N * 8 + (size_t)P * 8;
-    RLS_REQUIRE(per_wave <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS per env (max %d)", (long long)N,
-                per_wave, kLdsBytes);
+    while (P > 64 && rows + (size_t)P * 8 + fixed > (size_t)kLdsBytes) P >>= 1;
+    if (force_cap >= 2 && force_cap < P && (force_cap & (force_cap - 1)) == 0) P = force_cap;
+    const size_t per_wave = rows + (size_t)P * 8;
+    RLS_REQUIRE(per_wave + fixed <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS per env (max %d)", (long long)N,
+                per_wave + fixed, kLdsBytes);
     int waves = (int)((size_t)kLdsBytes / per_wave);
     waves = waves > 4 ? 4 : waves;
     if (waves == 3) waves = 2;

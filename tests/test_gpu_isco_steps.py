@@ -89,6 +89,49 @@ def test_isco_maxcut_step_vs_oracle(n, m, B):
     assert torch.equal(xs, xs2)
 
 
+@pytest.mark.parametrize("n,m,B,pl_hi", [(10000, 9999, 6, 300),       # G70's size: the list holds 4096 of 16384 possible entries
+                                          (10000, 9999, 700, 60),      # the same through the wave-per-sample kernel
+                                          (15000, 30000, 3, 1400),     # rows nearly fill LDS: 512 entries; longer paths are
+                                          (15000, 30000, 600, 900)])   # ordered by extraction (both kernels)
+def test_isco_maxcut_step_on_large_graphs_vs_oracle(n, m, B, pl_hi):
+    """ISCO_maxcut.step had a size limit the reference has not (env_ISCO.py:51-86): its selected-set list was sized for all N
+    nodes and the rows stopped fitting LDS at N = 8192 -- below G70, a BASELINE graph.  The list now takes what the rows leave,
+    and a selection beyond its capacity is ordered by repeated extraction; both against the oracle with recorded draws."""
+    from rlsolver_amd.graph import generate_gnm
+    g = np.asarray(generate_gnm(n, m, 70), dtype=np.int64)
+    s = _maxcut_sampler(g, n, B)
+    rng = np.random.RandomState(B)
+    x = rng.randint(0, 2, size=(B, n)).astype(np.float32)
+    check = min(B, 6)                                         # the oracle sorts whole rows: a few samples of the batch
+    pl = rng.randint(1, 40, size=B).astype(np.int64)
+    pl[0], pl[1], pl[check - 1] = 1, pl_hi, pl_hi // 2
+    ug = rng.rand(B, n).astype(np.float32).clip(1e-7, 1 - 1e-7)
+    ua = rng.rand(B).astype(np.float32)
+    y, energy, acc, terms, mask = s.step(torch.from_numpy(x).to(DEV), torch.from_numpy(pl).to(DEV), 0.8,
+                                         draws={"u_gumbel": torch.from_numpy(ug), "u_accept": torch.from_numpy(ua)}, want_terms=True)
+    r = oi.maxcut_step(x[:check], g[:, 0], g[:, 1], pl[:check], 0.8, ug[:check], ua[:check])
+    assert np.array_equal(mask[:check].cpu().numpy().astype(np.uint8), r["mask"].astype(np.uint8))
+    assert mask.sum(dim=1).cpu().numpy().tolist() == pl.tolist()
+    t = terms[:check].cpu().numpy()
+    np.testing.assert_allclose(t[:, 0], r["ll_x"], rtol=RTOL, atol=1e-5)
+    np.testing.assert_allclose(t[:, 2], r["ll_y"], rtol=RTOL, atol=1e-5)
+    n_ok = [assert_ll_close(t[:, c], r[k], r["remaining_mass"], k, pl[:check]) for c, k in ((1, "ll_x2y"), (3, "ll_y2x"), (4, "log_acc"))]
+    assert min(n_ok) >= check // 2
+    sure = r["accept_margin"] > 2 * (ll_atol(r["remaining_mass"], pl[:check]) + RTOL * np.abs(r["log_acc"]))
+    assert np.array_equal(y[:check].cpu().numpy()[sure], r["y"][sure].astype(np.float32))
+    yk = y.cpu().numpy()
+    assert set(np.unique(yk)) <= {0.0, 1.0}
+    # every sample is either its input (rejected) or its input with exactly the selected nodes flipped (accepted)
+    flipped = (yk != x)
+    mk = mask.cpu().numpy().astype(bool)
+    assert all((not flipped[b].any()) or np.array_equal(flipped[b], mk[b]) for b in range(B))
+    # production draws at this size: runs, stays binary, reproducible under the seed
+    torch.manual_seed(1)
+    a1 = s.step(torch.from_numpy(x).to(DEV), torch.full((B,), 12, dtype=torch.int64, device=DEV), 0.5)[0]
+    torch.manual_seed(1)
+    assert torch.equal(a1, s.step(torch.from_numpy(x).to(DEV), torch.full((B,), 12, dtype=torch.int64, device=DEV), 0.5)[0])
+
+
 def test_isco_maxcut_both_kernels_agree():
     """Up to two samples per CU a workgroup works on each sample, beyond that a wave: with the same recorded draws the
     two kernels select the same nodes, propose and accept the same samples, and their log-probabilities agree to the
