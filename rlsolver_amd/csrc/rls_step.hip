@@ -52,6 +52,27 @@ template <bool NT, typename V> __device__ __forceinline__ void st_vec(V* p, V v)
     else *p = v;
 }
 
+// s_waitcnt vmcnt(k) for a wave-uniform RUN-TIME k (the instruction takes an immediate): a scalar jump over 64 one-line cases
+__device__ __forceinline__ void wait_vmcnt_le(int k) {
+    k = __builtin_amdgcn_readfirstlane(k);
+#define RLS_W(n) case n: asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); break;
+#define RLS_W8(b) RLS_W(b + 0) RLS_W(b + 1) RLS_W(b + 2) RLS_W(b + 3) RLS_W(b + 4) RLS_W(b + 5) RLS_W(b + 6) RLS_W(b + 7)
+    switch (k) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        RLS_W(1) RLS_W(2) RLS_W(3) RLS_W(4) RLS_W(5) RLS_W(6) RLS_W(7)
+        RLS_W(8) RLS_W(9) RLS_W(10) RLS_W(11) RLS_W(12) RLS_W(13) RLS_W(14) RLS_W(15)
+        RLS_W(16) RLS_W(17) RLS_W(18) RLS_W(19) RLS_W(20) RLS_W(21) RLS_W(22) RLS_W(23)
+        RLS_W(24) RLS_W(25) RLS_W(26) RLS_W(27) RLS_W(28) RLS_W(29) RLS_W(30) RLS_W(31)
+        RLS_W(32) RLS_W(33) RLS_W(34) RLS_W(35) RLS_W(36) RLS_W(37) RLS_W(38) RLS_W(39)
+        RLS_W(40) RLS_W(41) RLS_W(42) RLS_W(43) RLS_W(44) RLS_W(45) RLS_W(46) RLS_W(47)
+        RLS_W(48) RLS_W(49) RLS_W(50) RLS_W(51) RLS_W(52) RLS_W(53) RLS_W(54) RLS_W(55)
+        RLS_W(56) RLS_W(57) RLS_W(58) RLS_W(59) RLS_W(60) RLS_W(61) RLS_W(62)
+        default: asm volatile("s_waitcnt vmcnt(63)" ::: "memory"); break;
+    }
+#undef RLS_W8
+#undef RLS_W
+}
+
 template <typename T, int EPW, int MODE, bool EMIT, bool VEC, bool WEIGHTED, bool NTL, bool NTS>
 __global__ __launch_bounds__(256) void k_maxcut_step(const T* __restrict__ xin, T* __restrict__ xout,
                                                      int64_t B, int64_t N,
@@ -65,12 +86,16 @@ __global__ __launch_bounds__(256) void k_maxcut_step(const T* __restrict__ xin, 
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & (kWave - 1);
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
-    const int64_t wave = (int64_t)blockIdx.x * (blockDim.x / kWave) + wib;
-    const int64_t b0 = wave * EPW;
-    if (b0 >= B) return;
-    const int nenv = (int)((B - b0) < EPW ? (B - b0) : EPW);
     using V = typename SpinVec<T>::type;
     constexpr int PER = SpinVec<T>::n;
+    // a wave takes runs wave, wave + (waves of the grid), ...: with a grid that covers every run this is one trip (the plain
+    // launch); with a grid that just fills the chip -- MODE 2 on long rows -- the wave is persistent: the stores of run k are
+    // still in flight while the loads of run k + 1 are issued (the LDS stage is free once its ds_reads have returned), and no
+    // workgroup is dispatched or retired mid-kernel
+    const int64_t wave_stride = (int64_t)gridDim.x * (blockDim.x / kWave);
+  for (int64_t wave = (int64_t)blockIdx.x * (blockDim.x / kWave) + wib; wave * EPW < B; wave += wave_stride) {
+    const int64_t b0 = wave * EPW;
+    const int nenv = (int)((B - b0) < EPW ? (B - b0) : EPW);
 
     int64_t act[EPW];
 #pragma unroll
@@ -132,7 +157,7 @@ __global__ __launch_bounds__(256) void k_maxcut_step(const T* __restrict__ xin, 
                 if (act[k] >= 0 && i == (int64_t)k * N + act[k]) v = spin_flip<T>(v);
             dst[i] = v;
         }
-        return;
+        continue;
     } else {
         // VEC: a full run of EPW rows is a whole number of 16-byte vectors and starts 16-byte aligned (the rows
         // themselves need not be: N = 1000 bytes works with EPW = 4).  Only the last run of a batch can be
@@ -209,6 +234,68 @@ __global__ __launch_bounds__(256) void k_maxcut_step(const T* __restrict__ xin, 
                 }
             }
             tail_copy();
+        } else if constexpr (MODE == 3) {
+            // MODE 3: MODE 2's staging with the stores CHASING the loads.  The flip needs no gain (a gym step flips its action node
+            // whatever the reward), so 1 KB piece j of the run can leave as soon as it has landed: the wave's stores are in flight
+            // beside its own later loads instead of starting when the last load is back.  The vector-memory counter completes in
+            // order; the ops younger than load j are the later loads, the neighbour-id loads and the stores of the pieces before
+            // j -- (n - 1 - j) + E + j = n - 1 + E of them whatever j, so ONE wait value serves every trip.  The gain is read from
+            // the staged (unpatched: the flip is applied in registers) row afterwards.
+            T* stage = reinterpret_cast<T*>(smem) + (int64_t)wib * EPW * N;
+            V* stage_v = reinterpret_cast<V*>(stage);
+            const int nch = (int)((nvec + kWave - 1) / kWave);
+            for (int64_t base = 0; base < nvec; base += kWave) {
+                const int64_t i = base + lane;
+                if (i < nvec) glds16<NTL>(src + i, stage_v + base);
+            }
+            if (nvec * PER < nel) {   // a short last run: its elements past the last whole vector are staged by hand (the gain reads them)
+                for (int64_t i = nvec * PER + lane; i < nel; i += kWave) stage[i] = xin[b0 * N + i];
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            int r0[EPW], deg[EPW], nb[EPW], nlo = 0;
+#pragma unroll
+            for (int k = 0; k < EPW; ++k) {
+                r0[k] = 0; deg[k] = 0; nb[k] = 0;
+                if (act[k] >= 0) {
+                    r0[k] = rowptr[act[k]];
+                    deg[k] = rowptr[act[k] + 1] - r0[k];
+                    // hand-issued (and hand-waited, below): a compiler-tracked load pending at the store loop's head makes the
+                    // compiler drain the vector-memory counter there -- which waits for the whole run and ends the chase
+                    const int32_t* pn = col + r0[k] + (lane < deg[k] ? lane : 0);
+                    asm volatile("global_load_dword %0, %1, off" : "=v"(nb[k]) : "v"(pn) : "memory");
+                    ++nlo;
+                }
+            }
+            const int keep = nch - 1 + nlo;
+            for (int j = 0; j < nch; ++j) {
+                wait_vmcnt_le(keep);
+                const int64_t i = (int64_t)j * kWave + lane;
+                if (i < nvec) {
+                    V v = stage_v[i];
+#pragma unroll
+                    for (int k = 0; k < EPW; ++k)
+                        if (i == fvec[k]) v = SpinVec<T>::flip_at(v, fidx[k]);
+                    st_vec<NTS>(dst + i, v);
+                }
+            }
+            tail_copy();                                                     // (a short last run only)
+            wait_vmcnt_le(nch < 62 ? nch : 62);                              // the neighbour ids are older than every store
+#pragma unroll
+            for (int k = 0; k < EPW; ++k)
+                if (act[k] >= 0) {
+                    const T* row = stage + (int64_t)k * N;
+                    const bool xa = spin_is_set(row[act[k]]);
+                    int d;
+                    if (deg[k] <= kWave) {
+                        const bool on = lane < deg[k];
+                        const bool xn = on ? spin_is_set(row[nb[k]]) : xa;
+                        d = deg[k] - 2 * __popcll(ballot64(xn != xa));
+                    } else {
+                        d = flip_gain<T, WEIGHTED>(row, act[k], rowptr, col, wgt, lane);
+                    }
+                    if (lane == k) my_delta = d;
+                }
+            publish();
         } else {
             // MODE 2: LDS staged.  Per-wave region of EPW*N*sizeof(T) bytes (16-byte multiple).
             T* stage = reinterpret_cast<T*>(smem) + (int64_t)wib * EPW * N;
@@ -268,16 +355,19 @@ __global__ __launch_bounds__(256) void k_maxcut_step(const T* __restrict__ xin, 
             for (int64_t i = nvec * PER + lane; i < nel; i += kWave) xout[b0 * N + i] = stage[i];
         }
     }
+  }   // runs of this wave
 }
 
 // development knobs, read once per process (no getenv on the launch path): nts = -1 automatic | 0 | 1 (nontemporal
 // stores), epw / wpb = 0: automatic
-struct StepKnobs { int nts, epw, wpb; };
+struct StepKnobs { int nts, epw, wpb, persist, chase; };
 static StepKnobs read_step_knobs() {
     const char* m = getenv("RLS_STEP_NTS");
     const char* e = getenv("RLS_STEP_EPW");
     const char* w = getenv("RLS_STEP_WPB");
-    return StepKnobs{m ? atoi(m) : -1, e ? atoi(e) : 0, w ? atoi(w) : 0};
+    const char* p = getenv("RLS_STEP_PERSIST");     // -1 automatic | 0 one run per wave | k: k workgroup rounds per CU resident, waves loop
+    const char* c = getenv("RLS_STEP_CHASE");       // -1 automatic | 0 MODE 2 (stores after the last load) | 1 MODE 3 (stores chase the loads)
+    return StepKnobs{m ? atoi(m) : -1, e ? atoi(e) : 0, w ? atoi(w) : 0, p ? atoi(p) : -1, c ? atoi(c) : -1};
 }
 static StepKnobs step_knobs() {
     static const bool reread = getenv("RLS_DEV_REREAD_ENV") != nullptr;   // tools/microbench.py, tools/sweep_step.py: A/B in one process
@@ -328,10 +418,23 @@ extern "C" int rls_maxcut_step(const rls_graph* g, const void* x_in, void* x_out
     int waves_per_block = knobs.wpb ? knobs.wpb : 4;
     if (!knobs.wpb && emit && vec)
         while (waves_per_block > 1 && (size_t)waves_per_block * run_bytes > (size_t)kLdsBytes / 2) waves_per_block >>= 1;
-    const dim3 grid((unsigned)ceil_div(ceil_div(B, epw), waves_per_block)), block(waves_per_block * kWave);
     hipStream_t s = as_stream(stream);
     const bool staged = emit && vec && (size_t)waves_per_block * run_bytes <= (size_t)kLdsBytes;
     const size_t lds = staged ? (size_t)waves_per_block * run_bytes : 0;
+    int64_t nblocks = ceil_div(ceil_div(B, epw), waves_per_block);
+    if (staged && knobs.persist != 0) {
+        // persistent form: as many workgroups as are resident at once (LDS-limited, at most 8 per CU), each wave looping over runs
+        const int64_t per_cu = (int64_t)((size_t)kLdsBytes / lds) < 8 ? (int64_t)((size_t)kLdsBytes / lds) : 8;
+        const int64_t resident = (int64_t)num_cus() * per_cu;
+        const bool want = knobs.persist > 0 || (knobs.persist < 0 && false);
+        if (want && nblocks > resident) nblocks = resident;
+    }
+    const dim3 grid((unsigned)nblocks), block(waves_per_block * kWave);
+    // MODE 3 needs its run's pieces + the neighbour-id loads to stay within the 6-bit counter: <= 54 KB runs
+    const int64_t nch_run = ceil_div((int64_t)run_bytes, 16 * kWave);
+    // measured (tools/sweep_step.py, SW_CHASE=0,1): f32 rows gain 3 - 6 % (N = 10^4: 0.674 -> 0.701; N = 2000: 0.707 -> 0.752 of
+    // 8 TB/s), 1-byte rows nothing (0.694 / 0.694, 0.738 / 0.739): their runs are 8 - 10 pieces, back before the first could leave
+    const bool chase = staged && nch_run + epw <= 62 && (knobs.chase > 0 || (knobs.chase < 0 && spin_bytes == 4));
     const bool nts = knobs.nts >= 0 ? knobs.nts != 0 : ((size_t)B * N * spin_bytes > ((size_t)256 << 20));
 
 #define LAUNCH_STEP_E(T, EPW, MODE, EMIT, VEC, NTL, NTS)                                                       \
@@ -354,6 +457,8 @@ extern "C" int rls_maxcut_step(const rls_graph* g, const void* x_in, void* x_out
         if (!emit) LAUNCH_STEP_E(T, 4, 0, false, false, false, false);                      \
         else if (!vec) LAUNCH_STEP(T, 0, true, false, false, false);                        \
         else if (!staged) LAUNCH_STEP(T, 1, true, true, false, true);                       \
+        else if (chase && nts) LAUNCH_STEP(T, 3, true, true, true, true);                   \
+        else if (chase) LAUNCH_STEP(T, 3, true, true, true, false);                         \
         else if (nts) LAUNCH_STEP(T, 2, true, true, true, true);                            \
         else LAUNCH_STEP(T, 2, true, true, true, false);                                    \
     } while (0)
