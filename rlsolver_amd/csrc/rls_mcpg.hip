@@ -639,7 +639,7 @@ __device__ __forceinline__ void lv_add8(const uint64_t (&d)[8], uint64_t& ones, 
 template <int NC, int NP>
 __device__ __forceinline__ void lv_node_group(const unsigned char* __restrict__ wbytes, const int32_t* __restrict__ data,
                                               int64_t p0, int64_t p1, int rounds, const uint32_t (&e0)[8], bool pass0,
-                                              int lane, uint32_t pad, uint32_t K, uint32_t lcode, uint64_t& lt, uint64_t& eq) {
+                                              int lane, uint32_t pad, uint32_t S, uint32_t lcode, uint64_t coin, uint64_t& nw) {
     constexpr uint32_t M31 = 0x7fffffffu;
     uint64_t vo = 0, vt = 0, vf = 0, vc[5] = {0, 0, 0, 0, 0};      // ones among visited (all, after pass 0)
     uint64_t fo = 0, ft = 0, ff = 0, fc[5] = {0, 0, 0, 0, 0};      // ones among not-yet-visited (pass 0)
@@ -695,7 +695,7 @@ __device__ __forceinline__ void lv_node_group(const unsigned char* __restrict__ 
 #pragma unroll
             for (int p = 1; p < 9; ++p) csa(carry, pl[p], pl[p], pf[p - 1], carry);
         }
-        lv_cmp<9>(pl, K, lt, eq);
+        nw = lv_le_const_x2<9, 9>(pl, ~coin, S);
         return;
     }
     uint64_t pl[9] = {vo, vt, vf, vc[0], vc[1], vc[2], vc[3], vc[4], 0};
@@ -705,7 +705,7 @@ __device__ __forceinline__ void lv_node_group(const unsigned char* __restrict__ 
 #pragma unroll
         for (int p = 1; p < NP; ++p) csa(carry, pl[p], pl[p], fp[p - 1], carry);
     }
-    lv_cmp<NP>(pl, K, lt, eq);
+    nw = lv_le_const_x2<NP, 9>(pl, ~coin, S);
 }
 
 // One node of high degree, lanes share its neighbours: per-lane vertical counters over the node's <= 2^NP - 1 rounds
@@ -757,8 +757,10 @@ __device__ __forceinline__ void lv_hub_counts(const uint64_t* words, const int32
 // LDS: the bit tile (N + 2 words), 64 int32 slots for the cut reduction and the group offsets lv_ptr[] (G + 2 dwords; a
 // wave reads them 64 at a time into a register and walks them with v_readlane) -- small enough that two workgroups fit
 // a CU at N = 10^4 (2 x ~81.3 KB).
+// (two 8-wave workgroups per CU at N = 10^4 are 4 waves per SIMD: the second launch bound keeps the kernel at <= 128 registers --
+// without it the compiler spent 129 on the same code once a 64-bit division appeared in the prologue, and one workgroup per CU ran)
 template <typename TI, typename TO, int P, int W>
-__global__ __launch_bounds__(W * kWave) void k_mcpg_local_search_levels(
+__global__ __launch_bounds__(W * kWave, 4) void k_mcpg_local_search_levels(
     const typename ChainStore<TI>::type* __restrict__ xs_in, typename ChainStore<TO>::type* __restrict__ xs_out, int64_t N,
     int64_t C, int64_t tiles_in, const int32_t* __restrict__ lv_ptr, const int32_t* __restrict__ data, int64_t G,
     int64_t num_ls, const uint64_t* __restrict__ coins, uint64_t seed, const int32_t* __restrict__ eu,
@@ -837,14 +839,18 @@ __global__ __launch_bounds__(W * kWave) void k_mcpg_local_search_levels(
                 const uint32_t node = h0 & 0xFFFFFu, pos = h1 & 0xFFFFFu;
                 const uint32_t K = pass0 ? ((h1 >> 20) & 0xFFu) : ((h0 >> 20) & 0xFFu);
                 const uint32_t lcode = (h0 >> 28) & 3u;
-                const uint64_t tie = 0ull - (uint64_t)((pass0 ? h1 : h0) >> 31);
-                uint64_t lt, eq;
+                // new bit = [C < K] | ([C == K] & tie & coin) with K = ceil(S / 2), tie = S even (S = the degree; + the not-yet-
+                // visited neighbours in pass 0)  <=>  2 C + !coin <= S: ONE bit-sliced "<= constant" on the counter shifted up a
+                // plane with the coin below it (carry chain of D + ~S, rls_tile.h) -- the scan that kept "smaller so far" and
+                // "equal so far" per plane cost ~2.5x the instructions
+                const uint32_t S = 2u * K - 1u + ((pass0 ? h1 : h0) >> 31);
+                uint64_t nw;
+                const uint64_t coin = coin_word(cnt, pos);
                 // counts <= rounds, C = cV + 2 cF <= 2 rounds (the not-yet-visited neighbours count twice in pass 0)
-                if (rounds < 8) lv_node_group<0, 5>(smem, data, p0, p1, rounds, e0, pass0, lane, pad, K, lcode, lt, eq);
-                else if (rounds < 16) lv_node_group<1, 6>(smem, data, p0, p1, rounds, e0, pass0, lane, pad, K, lcode, lt, eq);
-                else if (rounds < 32) lv_node_group<2, 7>(smem, data, p0, p1, rounds, e0, pass0, lane, pad, K, lcode, lt, eq);
-                else lv_node_group<4, 8>(smem, data, p0, p1, rounds, e0, pass0, lane, pad, K, lcode, lt, eq);
-                const uint64_t nw = lt | (eq & tie & coin_word(cnt, pos));
+                if (rounds < 8) lv_node_group<0, 5>(smem, data, p0, p1, rounds, e0, pass0, lane, pad, S, lcode, coin, nw);
+                else if (rounds < 16) lv_node_group<1, 6>(smem, data, p0, p1, rounds, e0, pass0, lane, pad, S, lcode, coin, nw);
+                else if (rounds < 32) lv_node_group<2, 7>(smem, data, p0, p1, rounds, e0, pass0, lane, pad, S, lcode, coin, nw);
+                else lv_node_group<4, 8>(smem, data, p0, p1, rounds, e0, pass0, lane, pad, S, lcode, coin, nw);
                 if (node < (uint32_t)N && (lane & ((1 << lcode) - 1)) == 0) words[node] = nw;
             } else {
                 // ---- one node of high degree, lane = neighbour

@@ -147,16 +147,8 @@ __device__ __forceinline__ int64_t sweep_tile_batched(uint64_t* words, const int
 // words[N] must be 0 (idle lanes point there).  The caller recounts the objective afterwards.
 template <int NP>
 __device__ __forceinline__ uint64_t lv_count_le(const uint64_t (&pl)[8], uint32_t thr) {
-    // mask of envs whose NP-bit vertical counter is <= thr (per lane), scanning from the top plane down
-    uint32_t lt0 = 0, lt1 = 0, eq0 = 0xFFFFFFFFu, eq1 = 0xFFFFFFFFu;
-#pragma unroll
-    for (int p = NP - 1; p >= 0; --p) {
-        const uint32_t kb = 0u - ((thr >> p) & 1u);                 // all ones where the constant has bit p set
-        const uint32_t c0 = (uint32_t)pl[p], c1 = (uint32_t)(pl[p] >> 32);
-        lt0 |= eq0 & ~c0 & kb;  lt1 |= eq1 & ~c1 & kb;              // counter bit 0, constant bit 1: smaller from here
-        eq0 &= ~(c0 ^ kb);      eq1 &= ~(c1 ^ kb);
-    }
-    return ((uint64_t)(lt1 | eq1) << 32) | (lt0 | eq0);
+    // mask of envs whose NP-bit vertical counter is <= thr (per lane): the carry chain of c + ~thr (rls_tile.h: lv_le_const)
+    return lv_le_const<NP, 8>(pl, thr);
 }
 
 // One group of the level schedule: vertical counters of "neighbour differs" over its rounds (entries = LDS byte

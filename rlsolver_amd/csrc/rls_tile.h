@@ -591,6 +591,41 @@ __device__ __forceinline__ void lv_merge_planes(uint64_t (&pl)[8], uint64_t take
     for (int p = 0; p < 8; ++p) csa(carry, pl[p], pl[p], lv_lane_xor<X>(pl[p]) & take, carry);
 }
 
+// Bit-sliced compare of 64 vertical counters (planes pl[0 .. NP), plane p = bit p of every count) with a per-LANE constant
+// thr < 2^NP:   c <= thr  <=>  c + (2^NP - 1 - thr) < 2^NP  <=>  adding ~thr (NP bits) to c carries nothing out of plane
+// NP - 1.  Only the carry chain is needed -- one 3-input majority (v_bitop3) per plane and half, one v_bfe_i32 per plane for
+// the constant's bit -- where the scan from the top plane down ("smaller so far / equal so far") took four operations per
+// plane and half.  Returns the mask of counters that are <= thr.
+template <int NP, int CAP>
+__device__ __forceinline__ uint64_t lv_le_const(const uint64_t (&pl)[CAP], uint32_t thr) {
+    static_assert(NP <= CAP, "planes");
+    const int nt = (int)~thr;
+    uint32_t c0 = 0, c1 = 0;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const uint32_t kb = (uint32_t)__builtin_amdgcn_sbfe(nt, p, 1);      // all ones where thr has bit p CLEAR
+        c0 = __builtin_amdgcn_bitop3_b32((uint32_t)pl[p], kb, c0, 0xE8);
+        c1 = __builtin_amdgcn_bitop3_b32((uint32_t)(pl[p] >> 32), kb, c1, 0xE8);
+    }
+    return ~(((uint64_t)c1 << 32) | c0);
+}
+
+// The same with one more plane below: mask of [2 c + low <= thr2], `low` a 0 | 1 bit per counter (a 64-bit word), thr2 < 2^(NP+1).
+template <int NP, int CAP>
+__device__ __forceinline__ uint64_t lv_le_const_x2(const uint64_t (&pl)[CAP], uint64_t low, uint32_t thr2) {
+    static_assert(NP <= CAP, "planes");
+    const int nt = (int)~thr2;
+    const uint32_t k0 = (uint32_t)__builtin_amdgcn_sbfe(nt, 0, 1);
+    uint32_t c0 = (uint32_t)low & k0, c1 = (uint32_t)(low >> 32) & k0;       // majority with carry-in 0
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const uint32_t kb = (uint32_t)__builtin_amdgcn_sbfe(nt, p + 1, 1);
+        c0 = __builtin_amdgcn_bitop3_b32((uint32_t)pl[p], kb, c0, 0xE8);
+        c1 = __builtin_amdgcn_bitop3_b32((uint32_t)(pl[p] >> 32), kb, c1, 0xE8);
+    }
+    return ~(((uint64_t)c1 << 32) | c0);
+}
+
 __device__ __forceinline__ uint64_t shfl_xor64(uint64_t v, int mask) {
     uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
     lo = __shfl_xor(lo, mask, 64);

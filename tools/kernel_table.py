@@ -10,6 +10,15 @@ passes with the gfx950 correction of MI355X_MICROARCH.md (FETCH_SIZE tallies 64 
 coalesced read -> read bytes = 2 x FETCH_SIZE; WRITE_SIZE exact for 16-B-per-lane stores; both in KB of 1024 B),
 and -- where the group is one of the rows below -- the ALGORITHMIC bytes per launch (SURVEY.md section 8d x the units
 one launch processes) and achieved / 8 TB/s.
+
+Kernels whose bound is on chip get a second roofline, the VALU ISSUE roofline, from the SQ passes of the same command
+(profiles/<tag>_sq_counters.json, tools/sq_table.py): SQ_INSTS_VALU wave-instructions per launch spread over the chip's 1024
+SIMDs.  One wave's own stream issues a vector instruction every 4 cycles (MI355X_MICROARCH.md, "vector-instruction ISSUE
+cost"); with two or more waves resident a SIMD-32 retires a wave64 instruction every 2.  `valu floor us` is the 4-cycle
+figure at 2.4 GHz -- instructions x 4 / (1024 x 2.4e9) -- and `valu frac` = floor / mean duration: 1.0 means every SIMD
+issued from one stream without a gap for the whole launch; values above 1 are possible (and mean the waves of a SIMD
+overlapped their issue) up to 2.0, the 2-cycle bound.  A kernel far below 1 on BOTH rooflines is waiting (barriers,
+latency): its lever is neither bytes nor instruction count.
 """
 import argparse
 import collections
@@ -59,13 +68,15 @@ ROWS = [
     (r"k_spin_observation<float, true>", 41 * 1024 * 256, 1024, 4 * (207 * 200 + 7 * 200 + 200 * 200), "S1d observation [B, 7+N, N] with per-env matrix rows | BA-200 1024"),
     (r"k_rand_couplings_ba<float>", 128 * 64, 1024, 4 * 200 * 200, "rand_couplings BA (m=4) | 1024 x BA-200 (a dependent chain per env: latency-bound)"),
     (r"k_qubo_ls_value", None, None, None, None),
-    (r"k_mcpg_local_search_levels<float, rls::Packed64", None, 262144, 4 * NBA + NBA // 8, "K7+K8 local_search_levels, f32 [N,C] in -> packed out | BA-1e4 2^18"),
-    (r"k_mcpg_local_search_levels<rls::Packed64, rls::Packed64", None, 262144, 2 * (NBA // 8), "K7+K8 local_search_levels, bit-packed in place | BA-1e4 2^18 (VALU-bound)"),
+    (r"k_mcpg_local_search_levels<float, Packed64", None, 262144, 4 * NBA + NBA // 8, "K7+K8 local_search_levels, f32 [N,C] in -> packed out | BA-1e4 2^18"),
+    (r"k_mcpg_local_search_levels<Packed64, Packed64", None, 262144, 2 * (NBA // 8), "K7+K8 local_search_levels, bit-packed in place | BA-1e4 2^18 (VALU-bound)"),
     (r"k_mcpg_metro_packed", None, 262144, 2 * (NBA // 8), "K9 metro rounds, bit-packed (1000 rounds per launch) | BA-1e4 2^18 (latency-bound walk)"),
     (r"k_mcpg_pick_gather_packed", None, 2048, 64 * (NBA // 8), "K8b best-of-repeats gather, bit-packed | 2048 kept chains (reads 64 tiles per kept tile)"),
     (r"k_mcpg_value_bit_sums", None, 262144, NBA // 8, "get_return bit sums | BA-1e4 2^18"),
-    (r"k_isco", None, None, None, None),
+    (r"k_isco_maxcut_step", None, 4096, 8 * N22, "I1 ISCO_maxcut.step | G22-sized, 4096 samples (f32 sample in, f32 sample out)"),
+    (r"k_isco_tsp_step", None, 65536, 16 * NT, "I2 ISCO_TSP.step, 8 rounds | TSP-100 2^16 (int64 tour in, int64 tour out)"),
 ]
+CLOCK_HZ, SIMDS = 2.4e9, 1024
 
 
 def short(n):
@@ -101,7 +112,15 @@ def main():
     ap.add_argument("tag")
     ap.add_argument("--src", default=None, help="prefix of the gpurun_out directories (default gpurun_out/<tag>)")
     ap.add_argument("--what", default="cfg")
+    ap.add_argument("--sq", default=None, help="profiles/<tag>_sq_counters.json of the same command (default: that path if it exists)")
     a = ap.parse_args()
+    sq_path = a.sq or f"profiles/{a.tag}_sq_counters.json"
+    sq = {}
+    if os.path.exists(sq_path):
+        for g in json.load(open(sq_path))["groups"]:
+            v = g["counters"].get("SQ_INSTS_VALU")
+            if v:
+                sq[(g["kernel"][:100], g["grid"], g["workgroup"])] = g
     src = a.src or f"gpurun_out/{a.tag}"
     pfx = os.path.basename(src)
     trace, meta = load_trace(f"{src}_{a.what}_kt/{pfx}_kernel_trace.csv")
@@ -135,6 +154,15 @@ def main():
                 if "hbm_bytes" in rec:
                     rec["traffic_over_algorithmic"] = rec["hbm_bytes"] / (B * per_unit)
             break
+        g = sq.get((name[:100], grid, wg))
+        if g is not None:
+            insts = g["counters"]["SQ_INSTS_VALU"]
+            rec["valu_insts"] = insts
+            rec["valu_floor_us"] = insts * 4 / (SIMDS * CLOCK_HZ) * 1e6
+            rec["valu_frac"] = rec["valu_floor_us"] / rec["mean_us"]
+            for k in ("valu_share_of_wave_cycles", "wait_any_share_of_wave_cycles", "lds_bank_conflict_share"):
+                if k in g:
+                    rec[k] = g[k]
         out.append(rec)
     os.makedirs("profiles", exist_ok=True)
     json.dump({"note": __doc__.strip().split("\n\n")[1], "source": f"{src}_{a.what}_*", "groups": out},
@@ -143,15 +171,21 @@ def main():
         f.write(f"# {a.tag}: per-kernel rocprofv3 summary (tools/profile_round.sh -> tools/kernel_table.py)\n\n")
         f.write("mean us = kernel-trace duration (first launch of a group dropped); read = 2 x FETCH_SIZE, write = WRITE_SIZE "
                 "(separate --pmc passes, KB of 1024 B); frac = algorithmic bytes / mean / 8 TB/s\n\n")
-        f.write("| kernel | grid x wg | LDS | VGPR | launches | mean us | read MB | write MB | row | alg MB | frac | traffic/alg |\n")
-        f.write("|---|---|---|---|---|---|---|---|---|---|---|---|\n")
+        f.write("valu floor us = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz), valu frac = floor / mean us (the VALU-issue roofline of the "
+                "on-chip-bound kernels: 1.0 = every SIMD issuing from one stream for the whole launch, 2.0 = the SIMD-32 bound with >= 2 waves); "
+                "wait = SQ_WAIT_ANY / SQ_WAVE_CYCLES; conflicts = SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS\n\n")
+        f.write("| kernel | grid x wg | LDS | VGPR | launches | mean us | read MB | write MB | row | alg MB | frac | traffic/alg | valu floor us | valu frac | wait | conflicts |\n")
+        f.write("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|\n")
         for r in out:
-            f.write("| `{}` | {} x {} | {} | {} | {} | {:.1f} | {} | {} | {} | {} | {} | {} |\n".format(
+            f.write("| `{}` | {} x {} | {} | {} | {} | {:.1f} | {} | {} | {} | {} | {} | {} | {} | {} | {} | {} |\n".format(
                 r["kernel"][:90], r["grid"], r["workgroup"], r["lds_bytes"], r["vgpr"], r["launches"], r["mean_us"],
                 f"{r['read_bytes'] / 1e6:.1f}" if "read_bytes" in r else "", f"{r['write_bytes'] / 1e6:.1f}" if "write_bytes" in r else "",
                 r.get("row", ""), f"{r['algorithmic_bytes'] / 1e6:.1f}" if "algorithmic_bytes" in r else "",
                 f"{r['frac_of_8TBps']:.3f}" if "frac_of_8TBps" in r else "",
-                f"{r['traffic_over_algorithmic']:.2f}" if "traffic_over_algorithmic" in r else ""))
+                f"{r['traffic_over_algorithmic']:.2f}" if "traffic_over_algorithmic" in r else "",
+                f"{r['valu_floor_us']:.1f}" if "valu_floor_us" in r else "", f"{r['valu_frac']:.2f}" if "valu_frac" in r else "",
+                f"{r['wait_any_share_of_wave_cycles']:.2f}" if "wait_any_share_of_wave_cycles" in r else "",
+                f"{r['lds_bank_conflict_share']:.2f}" if "lds_bank_conflict_share" in r else ""))
     print(open(f"profiles/{a.tag}_kernels.md").read())
 
 
