@@ -454,9 +454,10 @@ int rls_spin_materialize(const rls_spin_env* env, int state_bytes, int64_t B, in
  * A rank that owns kept chains [m0, m0 + M_local) of a batch of M kept chains x R repeats (chain = repeat * M + kept, the
  * column order of the reference's  xs_bool.repeat(1, repeat_times), MCPG.py:393-394) passes {m0, M_local, M - M_local}: its
  * chains then draw exactly what they draw in the one-process run, whatever the rank count.  NULL = {0, 0, 0}, the
- * single-process numbering.  rls_mcpg_local_search_levels draws one coin WORD per 64-chain tile: there offset, period and
- * skip must be multiples of 64 (RLS_EINVAL otherwise).  Recorded draws (index / u / uniforms / coins: test hooks) stay
- * indexed by the LOCAL chain. */
+ * single-process numbering.  period > 0 (with skip > 0) must be a multiple of 64 that divides the launch's chain count C -- the
+ * kernels then run one grid row per repeat instead of dividing on the device.  rls_mcpg_local_search_levels draws one coin WORD
+ * per 64-chain tile: there offset and skip must be multiples of 64 as well (RLS_EINVAL otherwise).  Recorded draws (index / u /
+ * uniforms / coins: test hooks) stay indexed by the LOCAL chain. */
 typedef struct rls_chain_ids {
     int64_t offset;
     int64_t period;

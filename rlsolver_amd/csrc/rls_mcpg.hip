@@ -115,13 +115,13 @@ __device__ __forceinline__ uint32_t k7_fmix32(uint32_t h) {
 // Global id of local chain c (rls_chain_ids): the key of every counter-based draw, so that a rank's shard of the chains
 // draws exactly what those chains draw in an unsharded run.  period > 0: the local batch is repeats of `period` kept
 // chains (chain c = repeat c / period of kept chain c % period) cut out of a global batch whose repeats are period + skip
-// chains apart.
+// chains apart.  No division in the kernels: in that mode the launch is TWO-dimensional -- blockIdx.y = the repeat,
+// blockIdx.x = the 64-chain tile inside it (period a multiple of 64) -- and a kernel's linear tile index is mcpg_tile().
 struct ChainIds {
-    int64_t offset, period, skip;
-    __device__ __forceinline__ int64_t operator()(int64_t c) const {
-        return offset + c + (period > 0 ? (c / period) * skip : 0);
-    }
+    int64_t offset, skip;
+    __device__ __forceinline__ int64_t operator()(int64_t c) const { return offset + c + (int64_t)blockIdx.y * skip; }
 };
+__device__ __forceinline__ int64_t mcpg_tile() { return (int64_t)blockIdx.y * gridDim.x + blockIdx.x; }
 
 template <typename T, bool PROBS_LDS>
 __global__ __launch_bounds__(kMetroWaves * kWave) void k_mcpg_metro(T* samples, const T* samples_in, int64_t N, int64_t C,
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(kMetroWaves * kWave) void k_mcpg_metro(T* samples, 
                                                       ChainIds ids) {
     // accept counts go to row (workgroup % accept_rows) of [accept_rows][T_rounds]: thousands of workgroups adding into ONE row
     // serialise at the L2 atomic units (measured: 3/4 of the packed walk's time)
-    unsigned long long* accepts = accepts_all ? accepts_all + (int64_t)(blockIdx.x % (unsigned)accept_rows) * T_rounds : nullptr;
+    unsigned long long* accepts = accepts_all ? accepts_all + (int64_t)((uint64_t)mcpg_tile() % (uint64_t)accept_rows) * T_rounds : nullptr;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* words = reinterpret_cast<uint64_t*>(smem);
     // probs staged in LDS when it fits: a per-round random gather from global memory would put an
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(kMetroWaves * kWave) void k_mcpg_metro(T* samples, 
     uint32_t* acc_cnt = reinterpret_cast<uint32_t*>(probs_l + (PROBS_LDS ? N : 0));   // per-round accept counts
     const int lane = threadIdx.x & (kWave - 1);
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
-    const int64_t c0 = (int64_t)blockIdx.x * kWave;
+    const int64_t c0 = mcpg_tile() * kWave;
     const int64_t c = c0 + lane;
     const bool valid = c < C;
     // nothing to do for this chunk (stop rule already met) -- unless the chains still have to be moved to `samples`
@@ -232,16 +232,16 @@ __global__ __launch_bounds__(kMetroPW * kWave) void k_mcpg_metro_packed(uint64_t
                                                              ChainIds ids) {
     // accept counts go to row (workgroup % accept_rows) of [accept_rows][T_rounds]: thousands of workgroups adding into ONE row
     // serialise at the L2 atomic units (measured: 3/4 of the packed walk's time)
-    unsigned long long* accepts = accepts_all ? accepts_all + (int64_t)(blockIdx.x % (unsigned)accept_rows) * T_rounds : nullptr;
+    unsigned long long* accepts = accepts_all ? accepts_all + (int64_t)((uint64_t)mcpg_tile() % (uint64_t)accept_rows) * T_rounds : nullptr;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* words = reinterpret_cast<uint64_t*>(smem);
     uint32_t* queue = reinterpret_cast<uint32_t*>(smem + (size_t)((N + 1) & ~(int64_t)1) * 8);   // [2][kMetroWin][64]
     const int lane = threadIdx.x & (kWave - 1);
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
-    const int64_t tile = blockIdx.x;
+    const int64_t tile = mcpg_tile();
     const int64_t c = tile * kWave + lane;
     const bool valid = c < C;
-    const bool in_place = (samples_in == samples) && tiles_in == (int64_t)gridDim.x;
+    const bool in_place = (samples_in == samples) && tiles_in == (int64_t)gridDim.x * gridDim.y;
     int64_t t_end = T_rounds;
     if (t_limit_dev) {
         const int64_t lim = *t_limit_dev;
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(kWave) void k_mcpg_local_search(const TI* __restric
     uint32_t* updated = reinterpret_cast<uint32_t*>(words + N);  // 1 bit per node: visited in pass 0
     const uint32_t* w32 = reinterpret_cast<const uint32_t*>(smem);
     const int lane = threadIdx.x;
-    const int64_t c0 = (int64_t)blockIdx.x * kWave;
+    const int64_t c0 = mcpg_tile() * kWave;
     const int64_t c = c0 + lane;
     const bool valid = c < C;
     tile_load_bits_nodemajor<TI>(xs_in, N, C, c0, words, lane);
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(kK7Waves * kWave) void k_mcpg_local_search_stream(
     const unsigned char* wbytes = smem;
     const int lane = threadIdx.x & (kWave - 1);
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
-    const int64_t c0 = (int64_t)blockIdx.x * kWave;
+    const int64_t c0 = mcpg_tile() * kWave;
     const int64_t c = c0 + lane;
     const bool valid = c < C;
     if (threadIdx.x == 0) words[N] = 0;   // sentinel word for lanes past a row's end
@@ -773,7 +773,7 @@ __global__ __launch_bounds__(W * kWave, 4) void k_mcpg_local_search_levels(
     const uint32_t* w32 = reinterpret_cast<const uint32_t*>(smem);
     const int lane = threadIdx.x & (kWave - 1);
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
-    const int64_t c0 = (int64_t)blockIdx.x * kWave;
+    const int64_t c0 = mcpg_tile() * kWave;
     const int64_t c = c0 + lane;
     const bool valid = c < C;
     const int64_t CB = (C + kWave - 1) / kWave;               // 64-chain blocks = words per coins row
@@ -781,7 +781,7 @@ __global__ __launch_bounds__(W * kWave, 4) void k_mcpg_local_search_levels(
     if (threadIdx.x == 0) words[N] = 0;                       // padding / idle lanes point here
     if (threadIdx.x < kWave) cut_slots[threadIdx.x] = 0;
     for (int64_t i = threadIdx.x; i <= G + 1; i += W * kWave) lvl[i] = i <= G ? lv_ptr[i] : lv_ptr[G];
-    if constexpr (std::is_same<TI, Packed64>::value) tile_load_packed(xs_in, N, C, blockIdx.x, tiles_in, words, threadIdx.x, W * kWave);
+    if constexpr (std::is_same<TI, Packed64>::value) tile_load_packed(xs_in, N, C, mcpg_tile(), tiles_in, words, threadIdx.x, W * kWave);
     else tile_load_bits_nodemajor<TI>(xs_in, N, C, c0, words, lane, w, W);
     const uint32_t blk_key = k7_fmix32((uint32_t)seed ^ k7_fmix32((uint32_t)(seed >> 32) ^
                                                                   k7_fmix32((uint32_t)(ids(c0) >> 6) * 0x9E3779B1u + 0x632BE5ABu)));   // the tile's global id
@@ -793,7 +793,7 @@ __global__ __launch_bounds__(W * kWave, 4) void k_mcpg_local_search_levels(
     for (int64_t k0 = 0; k0 < G; k0 += kWave)
         num_levels += __builtin_popcountll(ballot64(k0 + lane < G && (lvl[k0 + lane < G ? k0 + lane : G] >> 31) != 0));
     auto coin_word = [&](int64_t cnt, uint32_t pos) -> uint64_t {   // bit e: "u < 1/2" for chain c0 + e at (pass, pos)
-        if (coins) return coins[((int64_t)cnt * N + (pos < (uint32_t)N ? pos : 0u)) * CB + blockIdx.x];   // idle lanes carry pos = N: past the last row
+        if (coins) return coins[((int64_t)cnt * N + (pos < (uint32_t)N ? pos : 0u)) * CB + mcpg_tile()];   // idle lanes carry pos = N: past the last row
         const uint32_t k = blk_key ^ (pos * 0x9E3779B1u) ^ ((uint32_t)cnt * 0x7FEB352Du + 0x165667B1u);
         return ((uint64_t)k7_fmix32(k ^ 0x4C4F4353u) << 32) | k7_fmix32(k + 0x27D4EB2Fu);
     };
@@ -881,7 +881,7 @@ __global__ __launch_bounds__(W * kWave, 4) void k_mcpg_local_search_levels(
     __syncthreads();
     if (valid && w == 0) expected[c] = (float)(E - 2 * (int64_t)cut_slots[lane]);
     if constexpr (std::is_same<TO, Packed64>::value) {
-        tile_store_packed(xs_out, N, blockIdx.x, words, threadIdx.x, W * kWave);
+        tile_store_packed(xs_out, N, mcpg_tile(), words, threadIdx.x, W * kWave);
     } else {
         if (valid) {
             const int half = lane >> 5, sh = lane & 31;
@@ -1240,14 +1240,21 @@ __global__ __launch_bounds__(kStopWaves * kWave) void k_metro_stop(const int64_t
 
 using namespace rls;
 
-// rls_chain_ids -> the kernels' by-value form; NULL = the identity (a single-process run)
-static int chain_ids_arg(const rls_chain_ids* in, bool whole_tiles, ChainIds& out) {
-    out = ChainIds{0, 0, 0};
+// rls_chain_ids -> the kernels' by-value form + the launch grid for C chains; NULL = the identity (a single-process run, 1-D grid)
+static int chain_ids_arg(const rls_chain_ids* in, int64_t C, ChainIds& out, dim3& grid) {
+    out = ChainIds{0, 0};
+    grid = dim3((unsigned)ceil_div(C, kWave));
     if (!in) return RLS_OK;
     RLS_REQUIRE(in->offset >= 0 && in->period >= 0 && in->skip >= 0, RLS_EINVAL, "chain_ids: negative offset / period / skip");
-    RLS_REQUIRE(!whole_tiles || ((in->offset | in->period | in->skip) & (kWave - 1)) == 0, RLS_EINVAL,
-                "chain_ids: this kernel draws per 64-chain tile; offset, period and skip must be multiples of 64");
-    out = ChainIds{in->offset, in->period, in->period > 0 ? in->skip : 0};
+    out.offset = in->offset;
+    if (in->period > 0 && in->skip > 0) {
+        // repeats of `period` chains: one grid row per repeat (no division on the device)
+        RLS_REQUIRE((in->period & (kWave - 1)) == 0 && C % in->period == 0 && C / in->period < 65536, RLS_EINVAL,
+                    "chain_ids: period=%lld must be a multiple of 64 that divides C=%lld (fewer than 65536 repeats)", (long long)in->period,
+                    (long long)C);
+        out.skip = in->skip;
+        grid = dim3((unsigned)(in->period / kWave), (unsigned)(C / in->period));
+    }
     return RLS_OK;
 }
 
@@ -1257,11 +1264,12 @@ int rls_mcpg_metro_rounds(void* samples, const void* samples_in, int64_t C_in, i
                           const float* probs, int64_t T, int64_t t_offset, const int64_t* index, const float* u,
                           uint64_t seed, const int64_t* t_limit_dev, int write_back, int64_t* accepts, int64_t accept_rows,
                           const rls_chain_ids* chain_ids, void* stream) {
-    ChainIds ids;
-    if (int rc = chain_ids_arg(chain_ids, false, ids)) return rc;
     RLS_REQUIRE(N > 0 && C >= 0 && T >= 0 && t_offset >= 0, RLS_EINVAL, "bad sizes N=%lld C=%lld T=%lld", (long long)N, (long long)C,
                 (long long)T);
     if (C == 0) return RLS_OK;
+    ChainIds ids;
+    dim3 cgrid;
+    if (int rc = chain_ids_arg(chain_ids, C, ids, cgrid)) return rc;
     RLS_REQUIRE(samples && probs, RLS_EINVAL, "samples/probs is NULL");
     RLS_REQUIRE((index == nullptr) == (u == nullptr), RLS_EINVAL, "index and u must both be given or both be NULL");
     RLS_REQUIRE(spin_bytes == 0 || spin_bytes == 1 || spin_bytes == 4, RLS_EINVAL, "spin_bytes must be 0 (bit-packed), 1 or 4");
@@ -1279,7 +1287,7 @@ int rls_mcpg_metro_rounds(void* samples, const void* samples_in, int64_t C_in, i
         RLS_REQUIRE(lds <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS (max %d)", (long long)N, lds, kLdsBytes);
         auto kern = index ? k_mcpg_metro_packed<true> : k_mcpg_metro_packed<false>;
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(C, kWave)), dim3(kMetroPW * kWave), lds, as_stream(stream),
+        hipLaunchKernelGGL(kern, cgrid, dim3(kMetroPW * kWave), lds, as_stream(stream),
                            (uint64_t*)samples, (const uint64_t*)samples_in, ceil_div(C_in, kWave), N, C, probs, T, index, u, seed,
                            t_limit_dev, write_back, (unsigned long long*)accepts, accept_rows, t_offset, ids);
         return check_launch("k_mcpg_metro_packed");
@@ -1290,7 +1298,7 @@ int rls_mcpg_metro_rounds(void* samples, const void* samples_in, int64_t C_in, i
     const size_t lds = lds_base + (probs_lds ? (size_t)N * 4 : 0);
     RLS_REQUIRE(lds <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld, T=%lld need %zu B of LDS (max %d)", (long long)N,
                 (long long)T, lds, kLdsBytes);
-    const dim3 grid((unsigned)ceil_div(C, kWave)), block(kMetroWaves * kWave);
+    const dim3 grid = cgrid, block(kMetroWaves * kWave);
     hipStream_t s = as_stream(stream);
 #define LAUNCH_METRO(TT, PL)                                                                                        \
     do {                                                                                                            \
@@ -1342,10 +1350,13 @@ int rls_mcpg_local_search_levels(const rls_graph* g, const void* xs_in, int spin
                                  int64_t num_groups, int64_t num_ls, const uint64_t* coins, uint64_t seed, float* expected,
                                  const rls_chain_ids* chain_ids, void* stream) {
     if (int rc = check_graph(g)) return rc;
-    ChainIds ids;
-    if (int rc = chain_ids_arg(chain_ids, true, ids)) return rc;
     RLS_REQUIRE(C >= 0 && num_ls >= 0 && num_groups > 0, RLS_EINVAL, "bad sizes");
     if (C == 0) return RLS_OK;
+    ChainIds ids;
+    dim3 cgrid;
+    if (int rc = chain_ids_arg(chain_ids, C, ids, cgrid)) return rc;
+    RLS_REQUIRE((ids.offset & (kWave - 1)) == 0 && (ids.skip & (kWave - 1)) == 0, RLS_EINVAL,
+                "chain_ids: this kernel draws per 64-chain tile; offset, period and skip must be multiples of 64");
     RLS_REQUIRE(xs_in && xs_out && lv_ptr && lv_data && expected, RLS_EINVAL, "NULL pointer");
     RLS_REQUIRE(spin_bytes == 0 || spin_bytes == 1 || spin_bytes == 4, RLS_EINVAL, "spin_bytes must be 0 (bit-packed), 1 or 4");
     RLS_REQUIRE(out_spin_bytes == 0 || out_spin_bytes == 4, RLS_EINVAL, "out_spin_bytes must be 0 (bit-packed) or 4 (float32)");
@@ -1363,7 +1374,7 @@ int rls_mcpg_local_search_levels(const rls_graph* g, const void* xs_in, int spin
     RLS_REQUIRE(lds <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS (max %d)", (long long)N, lds,
                 kLdsBytes);
     const int64_t tiles_in = ceil_div(C_in, kWave);
-    const dim3 grid((unsigned)ceil_div(C, kWave));
+    const dim3 grid = cgrid;
     hipStream_t s = as_stream(stream);
     static const int force_w = getenv("RLS_K7_WAVES") ? atoi(getenv("RLS_K7_WAVES")) : 0;   // dev knob
 #define LAUNCH_LVL(TI, TO, PP, WW)                                                                              \
@@ -1402,17 +1413,18 @@ int rls_mcpg_local_search(const rls_graph* g, const void* xs_in, int spin_bytes,
                           const float* uniforms, uint64_t seed, const int32_t* edge_weights, int64_t gauge_node,
                           float* expected, const rls_chain_ids* chain_ids, void* stream) {
     if (int rc = check_graph(g)) return rc;
-    ChainIds ids;
-    if (int rc = chain_ids_arg(chain_ids, false, ids)) return rc;
     RLS_REQUIRE(C >= 0 && num_ls >= 0, RLS_EINVAL, "bad sizes");
     if (C == 0) return RLS_OK;
+    ChainIds ids;
+    dim3 cgrid;
+    if (int rc = chain_ids_arg(chain_ids, C, ids, cgrid)) return rc;
     RLS_REQUIRE(xs_in && xs_out && order && expected, RLS_EINVAL, "NULL pointer");
     RLS_REQUIRE(spin_bytes == 1 || spin_bytes == 4, RLS_EINVAL, "spin_bytes must be 1 or 4");
     const int64_t N = g->num_nodes, E = g->num_stored_edges;
     RLS_REQUIRE(gauge_node >= -1 && gauge_node < N, RLS_EINVAL, "gauge_node %lld outside [-1, N)", (long long)gauge_node);
     const int P = pick_planes(E);
     RLS_REQUIRE(P != 0, RLS_EUNSUPPORTED, "E=%lld too large", (long long)E);
-    const dim3 grid((unsigned)ceil_div(C, kWave)), block(kWave);
+    const dim3 grid = cgrid, block(kWave);
     hipStream_t s = as_stream(stream);
     const bool weighted = edge_weights != nullptr;
     const size_t lds_fast = (size_t)(N + 2) * 8 + (size_t)kRing * 4 + (size_t)kK7Waves * kWave * 8;
