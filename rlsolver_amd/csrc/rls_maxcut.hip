@@ -463,8 +463,8 @@ __device__ __forceinline__ void planes_minmax(const uint64_t (&pl)[NPL], uint64_
 }
 
 // MODE 0: cutdeg int64, 1: flip gain int32, 2: local-search weight WT (int8 / int16 / int32) + the batch min / max per node
-template <int MODE, bool VEC, bool WIDE, typename WT = int32_t>
-__global__ __launch_bounds__(kNsWaves * kWave) void k_node_stats_bits(const uint8_t* __restrict__ x, int64_t B, int64_t N,
+template <int MODE, bool VEC, bool WIDE, typename WT = int32_t, int NSW = kNsWaves>
+__global__ __launch_bounds__(NSW * kWave) void k_node_stats_bits(const uint8_t* __restrict__ x, int64_t B, int64_t N,
                                                                      const int32_t* __restrict__ rowptr,
                                                                      const int32_t* __restrict__ ell_ptr,
                                                                      const int32_t* __restrict__ ell, int mult,
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(kNsWaves * kWave) void k_node_stats_bits(const uint
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     unsigned char* stage = smem + (((size_t)N * 8 + 15) & ~(size_t)15) + (size_t)w * kStageBytes;
     const int64_t b0 = (int64_t)blockIdx.x * kWave;
-    tile_load_bits<uint8_t, VEC>(x, B, N, b0, words, lane, w, kNsWaves, has_stage ? stage : nullptr);
+    tile_load_bits<uint8_t, VEC>(x, B, N, b0, words, lane, w, NSW, has_stage ? stage : nullptr);
     __syncthreads();
     const int64_t G = (N + 63) >> 6;
     const int nenv = (int)((B - b0) < kWave ? (B - b0) : kWave);
@@ -486,6 +486,8 @@ __global__ __launch_bounds__(kNsWaves * kWave) void k_node_stats_bits(const uint
     // c(e, i) for the group's 64 nodes over the neighbour blocks first, first + step, ... of 8 rounds each
     auto count_blocks = [&](int e0, int e1, uint32_t iself, uint64_t own, int ncp, int first, int step, uint64_t& ones, uint64_t& twos,
                             uint64_t& fours, uint64_t (&c)[NCP]) {
+        // (requesting the next block's neighbour ids before this block's words are read -- the sweep's prefetch -- was measured here
+        // and changes nothing: K3 G22 2^16 168.7 vs 167.2 us, weights 141 vs 139; six waves per SIMD already cover the round trip)
         for (int k = e0 + first * 8 * kWave; k < e1; k += step * 8 * kWave) {
             uint32_t nb[8];
 #pragma unroll
@@ -544,7 +546,7 @@ __global__ __launch_bounds__(kNsWaves * kWave) void k_node_stats_bits(const uint
     if constexpr (WIDE) {
         if (coop) {
             uint64_t* xch = reinterpret_cast<uint64_t*>(smem + (((size_t)N * 8 + 15) & ~(size_t)15));   // [4][16][64]
-            static_assert(kNsWaves == 8 && kNsWaves * kStageBytes >= 4 * 16 * kWave * 8, "four waves' planes fit the stages");
+            static_assert(NSW == 8 && NSW * kStageBytes >= 4 * 16 * kWave * 8, "four waves' planes fit the stages");
             for (int64_t g = 0; g < G; ++g) {
                 const int e0 = ell_ptr[g], e1 = ell_ptr[g + 1];
                 const int md = (e1 - e0) >> 6;
@@ -557,10 +559,10 @@ __global__ __launch_bounds__(kNsWaves * kWave) void k_node_stats_bits(const uint
                 uint64_t ones = 0, twos = 0, fours = 0, c[NCP];
 #pragma unroll
                 for (int p = 0; p < NCP; ++p) c[p] = 0;
-                count_blocks(e0, e1, iself, own, NCP, w, kNsWaves, ones, twos, fours, c);
+                count_blocks(e0, e1, iself, own, NCP, w, NSW, ones, twos, fours, c);
                 uint64_t pw[16] = {ones, twos, fours, c[0], c[1], c[2], c[3], c[4], c[5 % NCP], c[6 % NCP], c[7 % NCP], c[8 % NCP],
                                    c[9 % NCP], c[10 % NCP], c[11 % NCP], c[12 % NCP]};
-                for (int half = kNsWaves / 2; half >= 1; half >>= 1) {
+                for (int half = NSW / 2; half >= 1; half >>= 1) {
                     __syncthreads();                             // (the previous step's readers are done with xch)
                     if (w >= half && w < 2 * half) {
 #pragma unroll
@@ -580,7 +582,7 @@ __global__ __launch_bounds__(kNsWaves * kWave) void k_node_stats_bits(const uint
             }
         }
     }
-    for (int64_t g = w; g < G; g += kNsWaves) {
+    for (int64_t g = w; g < G; g += NSW) {
         const int64_t i = (g << 6) + lane;
         const bool in = i < N;
         const uint32_t iself = in ? (uint32_t)i : 0u;
@@ -609,6 +611,34 @@ __global__ __launch_bounds__(kNsWaves * kWave) void k_node_stats_bits(const uint
                 int cmn, cmx;
                 planes_minmax<8>(pl, vmask, cmn, cmx);
                 ws_minmax_update(minmax, N, i, deg - mult * cmx, deg - mult * cmn);
+            }
+        }
+        if constexpr (MODE == 2 && sizeof(WT) == 1) {
+            if (nenv == kWave && (out_pitch & 3) == 0 && (N & 3) == 0) {
+                // int8 weights of a full tile leave as DWORDS: per (half, r) every lane holds its node's values for the 4 envs
+                // r, r + 8, r + 16, r + 24 of the half as bytes; a 4 x 4 byte transpose inside each lane quad (two DPP moves + two
+                // v_perm) turns that into 4 consecutive NODES of ONE env per lane -- 16 store instructions of 4 x 64 bytes per
+                // group where the byte stores took 64 of 64 bytes (the pre-pass was store-issue bound: 0.24 of HBM)
+                const uint32_t sel1 = (lane & 1) ? 0x03070105u : 0x06020400u, sel2 = (lane & 2) ? 0x03020706u : 0x05040100u;
+                const uint32_t bias = (uint32_t)(deg + 128) * 0x01010101u;       // per byte deg + 128 - mult * cnt in [1, 255]: no borrows
+                int8_t* const obase = reinterpret_cast<int8_t*>(out_v) + (b0 + (lane & 3) * 8) * out_pitch + ((g << 6) + (lane & ~3));
+                if (in) {      // (N % 4 == 0: a quad of nodes is inside the row or outside it as a whole)
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+#pragma unroll 2
+                        for (int r = 0; r < 8; ++r) {
+                            const uint32_t acc = md < 16 ? ns_extract4<4>(pl, half, r)
+                                                         : (md < 64 ? ns_extract4<6>(pl, half, r) : ns_extract4<8>(pl, half, r));
+                            uint32_t v = (bias - (uint32_t)mult * acc) ^ 0x80808080u;     // 4 envs x int8(deg - mult * cnt)
+                            uint32_t o = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);      // lane ^ 1
+                            v = __builtin_amdgcn_perm(o, v, sel1);
+                            o = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);               // lane ^ 2
+                            v = __builtin_amdgcn_perm(o, v, sel2);
+                            *reinterpret_cast<uint32_t*>(obase + (int64_t)(half * 32 + r) * out_pitch) = v;
+                        }
+                    }
+                }
+                continue;
             }
         }
         if (nenv == kWave) {
@@ -642,8 +672,8 @@ __global__ __launch_bounds__(kNsWaves * kWave) void k_node_stats_bits(const uint
     }
 }
 
-static inline size_t node_stats_bits_lds(int64_t N, bool with_stage = true) {
-    return (((size_t)N * 8 + 15) & ~(size_t)15) + (with_stage ? (size_t)kNsWaves * kStageBytes : 0);
+static inline size_t node_stats_bits_lds(int64_t N, bool with_stage = true, int waves = kNsWaves) {
+    return (((size_t)N * 8 + 15) & ~(size_t)15) + (with_stage ? (size_t)waves * kStageBytes : 0);
 }
 // the bit-sliced kernel needs the slabs, an unweighted graph, byte-sized counters and a tile that fits.  A tile costs about
 // 0.011 us per node however few envs it holds, the element-parallel kernels about 2e-6 us per (env, node + entry): K3 on a
@@ -665,16 +695,43 @@ static int launch_node_stats_bits(const rls_graph* g, const uint8_t* x, int64_t 
                                   int32_t* minmax = nullptr, int64_t out_pitch = 0) {
     const int64_t N = g->num_nodes;
     const int has_stage = node_stats_bits_lds(N, true) <= (size_t)kLdsBytes ? 1 : 0;
-    const size_t lds = node_stats_bits_lds(N, has_stage != 0);
-    const dim3 grid((unsigned)ceil_div(B, kWave)), block(kNsWaves * kWave);
     const bool vec = tile_rows_aligned(x, N, 1);
     const bool wide = g->max_degree >= 256;
-    auto kern = wide ? (vec ? k_node_stats_bits<MODE, true, true, WT> : k_node_stats_bits<MODE, false, true, WT>)
-                     : (vec ? k_node_stats_bits<MODE, true, false, WT> : k_node_stats_bits<MODE, false, false, WT>);
-    if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kern, grid, block, lds, as_stream(stream), x, B, N, rowptr, ell_ptr, ell, mult, out, minmax,
-                       out_pitch > 0 ? out_pitch : N, has_stage);
+    // 8 waves per tile, or 4 where that turns a launch of one-and-a-bit rounds of workgroups into ONE round: a G22-sized tile
+    // is 16 KB + 4 KB of row-piece stage per wave -- 3 eight-wave workgroups per CU (768 resident: 1024 tiles = a full round
+    // and a third of one), 5 four-wave ones (every tile resident at once)
+    static const int force_w = getenv("RLS_NS_WAVES") ? atoi(getenv("RLS_NS_WAVES")) : 0;     // dev knob
+    const int64_t tiles = ceil_div(B, kWave);
+    auto resident = [&](int wv) {
+        const int64_t by_lds = (int64_t)((size_t)kLdsBytes / node_stats_bits_lds(N, has_stage != 0, wv)), by_waves = 32 / wv;
+        return (int64_t)num_cus() * (by_lds < by_waves ? by_lds : by_waves);
+    };
+    // measured (tools/timing/k7_packed.py, ls_parts.py with RLS_NS_WAVES=4 | 8; G22 2^16): K3 171 vs 167 us, weights 156 vs 139 us,
+    // G70 2^17 K3 1889 vs 1656 -- the single round does not pay for halving a tile's waves: 8 stays, 4 is a knob
+    (void)resident;
+    const bool four = force_w == 4 && !wide && has_stage;
+    const int waves = four ? 4 : kNsWaves;
+    const size_t lds = node_stats_bits_lds(N, has_stage != 0, waves);
+    const dim3 grid((unsigned)tiles), block(waves * kWave);
+#define RLS_NS_LAUNCH(KERN)                                                                                         \
+    do {                                                                                                            \
+        auto kern = KERN;                                                                                           \
+        if (lds > 64 * 1024)                                                                                        \
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
+        hipLaunchKernelGGL(kern, grid, block, lds, as_stream(stream), x, B, N, rowptr, ell_ptr, ell, mult, out, minmax, \
+                           out_pitch > 0 ? out_pitch : N, has_stage);                                               \
+    } while (0)
+    if (four) {
+        if (vec) RLS_NS_LAUNCH((k_node_stats_bits<MODE, true, false, WT, 4>));
+        else RLS_NS_LAUNCH((k_node_stats_bits<MODE, false, false, WT, 4>));
+    } else if (wide) {
+        if (vec) RLS_NS_LAUNCH((k_node_stats_bits<MODE, true, true, WT>));
+        else RLS_NS_LAUNCH((k_node_stats_bits<MODE, false, true, WT>));
+    } else {
+        if (vec) RLS_NS_LAUNCH((k_node_stats_bits<MODE, true, false, WT>));
+        else RLS_NS_LAUNCH((k_node_stats_bits<MODE, false, false, WT>));
+    }
+#undef RLS_NS_LAUNCH
     return check_launch("k_node_stats_bits");
 }
 
