@@ -1045,7 +1045,7 @@ __global__ __launch_bounds__(256) void k_mcpg_value_bit_sums(const uint64_t* __r
 // whole cost of the kernel above -- to one per (workgroup, node).  Per tile the 64 values become 8 tables of 256 partial
 // sums (table q, entry i = sum of the values of chains 8q + j over the set bits j of i): a word costs 8 lookups + 8 adds
 // instead of 64 selects + 64 adds.
-constexpr int kBitSumThreads = 256;
+constexpr int kBitSumThreads = 512;   // (256: 117 us at BA-1e4 / 2^18; the lookups want more waves per CU than 3 workgroups x 4 gave)
 __global__ __launch_bounds__(kBitSumThreads) void k_mcpg_value_bit_sums_lut(const uint64_t* __restrict__ samples, int64_t N,
                                                                             int64_t C, int64_t tiles,
                                                                             const float* __restrict__ value,
@@ -1063,12 +1063,14 @@ __global__ __launch_bounds__(kBitSumThreads) void k_mcpg_value_bit_sums_lut(cons
             v[t] = c < C ? value[c] : 0.0f;
         }
         __syncthreads();
+        if (t < 256) {
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            float sum = 0.0f;
+            for (int q = 0; q < 8; ++q) {
+                float sum = 0.0f;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) sum += ((t >> j) & 1) ? v[8 * q + j] : 0.0f;
-            lut[q * 256 + t] = sum;
+                for (int j = 0; j < 8; ++j) sum += ((t >> j) & 1) ? v[8 * q + j] : 0.0f;
+                lut[q * 256 + t] = sum;
+            }
         }
         __syncthreads();
         const uint64_t* row = samples + tile * N;
@@ -1086,7 +1088,7 @@ __global__ __launch_bounds__(kBitSumThreads) void k_mcpg_value_bit_sums_lut(cons
                 float sum = 0.0f;
 #pragma unroll
                 for (int q = 0; q < 8; ++q) sum += lut[q * 256 + (int)((wd[u] >> (8 * q)) & 255u)];
-                acc[n] += sum;                            // n = t mod 256: this thread's own slot
+                acc[n] += sum;                            // n = t mod the workgroup size: this thread's own slot
             }
         }
     }

@@ -10,7 +10,7 @@ def t(fn, it=10):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / it * 1e3
 for N in (800, 832, 1000, 2000, 10000):
-    for C in (4096, 65536):
+    for C in (4096, 65536, 262144):
         words = torch.randint(-2**63, 2**63 - 1, (C // 64, N), dtype=torch.int64, device=dev)
         pc = mops.PackedChains(words, C)
         val = torch.randn(C, device=dev)
