@@ -113,8 +113,9 @@ int rls_graph_sweep_levels(const int32_t* rowptr, const int32_t* col, int64_t N,
                            int32_t* lv_data, int64_t data_capacity, int64_t* num_groups, int64_t* total);
 
 /* [host] Lane-per-node ("ELL") slabs of a CSR adjacency for the bit-sliced per-node kernels: nodes in groups of
- * 64; group g holds max-degree-in-group rounds of 64 entries, round k = the k-th neighbour of each of the 64
- * nodes (the node itself where its row is shorter: x_i ^ x_i contributes nothing).  ell_ptr [host, G+1] with
+ * 64; group g holds max-degree-in-group rounds of 64 entries, every lane's column = the neighbours of its node in an
+ * order chosen by the builder (the node itself where its row is shorter: x_i ^ x_i contributes nothing) -- each round's 32 words
+ * of a half-wave are spread over the LDS bank classes n mod 32 as far as the rows allow; consumers must not rely on an order.  ell_ptr [host, G+1] with
  * G = ceil(N/64); ell [host, capacity] or NULL to only compute *total (= ell_ptr[G]) for sizing. */
 int rls_graph_ell(const int32_t* rowptr, const int32_t* col, int64_t N, int32_t* ell_ptr, int32_t* ell,
                   int64_t capacity, int64_t* total);

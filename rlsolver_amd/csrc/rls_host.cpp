@@ -73,6 +73,48 @@ static int32_t best_lane_cap(int64_t a, int64_t b, DegAt deg_at) {
     return best_cap;
 }
 
+// ---- LDS banks of a lane = node group ---------------------------------------------------------------------------------
+// A group's round is one ds_read_b64 per lane at the byte offset the table holds: word n of the tile covers banks 2 (n mod 32)
+// and + 1, a half-wave (32 lanes) is served in one LDS cycle when its 32 words fall in 32 different classes n mod 32 (equal
+// addresses broadcast), and every further word of a class costs a cycle.  Graph neighbours are as good as random (SQ counters,
+// round 3: 1.6 - 2.4 conflict cycles per active LDS cycle in K3 / K7 / K9 / the ISCO step) -- but the ORDER in which a lane
+// visits its neighbours is free (a count does not depend on it), so each lane's entries are dealt to the rounds greedily: round
+// by round, every lane of a half-wave takes, of the entries it still holds, the one whose class is least used in this round.
+// rows = [rounds][64] table entries (bit 31 may carry a flag); in place; a pure permutation inside every lane's column.
+static void spread_banks(int32_t* rows, int64_t rounds, int shift = 3) {   // shift 3: entries are byte offsets of 8-byte words; 0: word indices
+    if (rounds < 2 || rounds > 128) return;     // (rows of hundreds of entries are hub groups: other kernels, and O(rounds^2) here)
+    for (int half = 0; half < 2; ++half) {
+        std::vector<std::vector<int32_t>> have(32);
+        for (int l = 0; l < 32; ++l) {
+            have[(size_t)l].resize((size_t)rounds);
+            for (int64_t r = 0; r < rounds; ++r) have[(size_t)l][(size_t)r] = rows[r * 64 + half * 32 + l];
+        }
+        for (int64_t r = 0; r < rounds; ++r) {
+            int load[32] = {0};
+            std::vector<uint32_t> placed;                       // addresses already in this round (a repeat broadcasts)
+            placed.reserve(32);
+            for (int q = 0; q < 32; ++q) {
+                const int l = (int)((q + r) & 31);              // (rotate who chooses first)
+                std::vector<int32_t>& h = have[(size_t)l];
+                size_t best = 0;
+                int best_cost = 1 << 30;
+                for (size_t k = 0; k < h.size(); ++k) {
+                    const uint32_t addr = (uint32_t)h[k] & 0x7fffffffu;
+                    int cost = load[(addr >> shift) & 31];
+                    for (uint32_t a : placed)
+                        if (a == addr) { cost = -1; break; }
+                    if (cost < best_cost) { best_cost = cost; best = k; }
+                }
+                const int32_t e = h[best];
+                h.erase(h.begin() + (std::ptrdiff_t)best);
+                rows[r * 64 + half * 32 + l] = e;
+                const uint32_t addr = (uint32_t)e & 0x7fffffffu;
+                if (best_cost >= 0) { ++load[(addr >> shift) & 31]; placed.push_back(addr); }
+            }
+        }
+    }
+}
+
 }  // namespace rls
 
 extern "C" {
@@ -226,6 +268,7 @@ int rls_graph_sweep_levels(const int32_t* rowptr, const int32_t* col, int64_t N,
                     }
                     ln += L;
                 }
+                rls::spread_banks(rec + 64, g.rounds);
             }
             off += len;
             ++ng;
@@ -341,6 +384,7 @@ int rls_mcpg_visit_levels(const int32_t* rowptr, const int32_t* col, int64_t N, 
                         }
                         ln += L;
                     }
+                    rls::spread_banks(rec + 128, rounds);
                 }
             }
             off += len;
@@ -385,6 +429,7 @@ int rls_graph_ell(const int32_t* rowptr, const int32_t* col, int64_t N, int32_t*
                     if (i < N && rowptr[i] + k < rowptr[i + 1]) v = col[rowptr[i] + k];
                     ell[off + (int64_t)k * 64 + l] = v;
                 }
+            rls::spread_banks(ell + off, md, 0);       // a lane's neighbours in the order that spreads each round over the LDS banks
         }
         off += (int64_t)md * 64;
     }

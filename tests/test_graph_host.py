@@ -175,7 +175,10 @@ def test_sweep_level_groups_encode_the_same_schedule():
                 for j in range(L):
                     mine = row[j::L]
                     assert len(mine) <= rounds
-                    assert np.array_equal(rec[1:1 + len(mine), ln + j], mine * 8) and (rec[1 + len(mine):, ln + j] == i * 8).all()
+                    # the lane's column = its share of the row in the builder's (LDS-bank-spreading) order, padded with the node itself:
+                    # the same multiset, nothing else
+                    want = np.sort(np.concatenate([mine * 8, np.full(rounds - len(mine), i * 8, dtype=mine.dtype)]))
+                    assert np.array_equal(np.sort(rec[1:, ln + j]), want)
                 seen.append(int(i))
                 level_of[i] = level_of_group[k]
                 ln += L

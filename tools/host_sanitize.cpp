@@ -141,11 +141,19 @@ static void run_builders(const Graph& g, std::mt19937_64& rng) {
         for (int64_t gq = 0; gq < groups; ++gq) {
             const int64_t rounds = (ptr[(size_t)gq + 1] - ptr[(size_t)gq]) / 64;
             for (int64_t l = 0; l < 64; ++l) {
+                // a lane's column = its node's neighbours in the builder's (bank-spreading) order + the node itself as padding:
+                // the same multiset as the CSR row, nothing else
                 const int64_t node = gq * 64 + l;
-                for (int64_t k = 0; k < rounds; ++k) {
-                    const int32_t v = ell[(size_t)(ptr[(size_t)gq] + 64 * k + l)];
-                    if (node < N && k < rp[node + 1] - rp[node]) CHECK(v == col[rp[node] + k], "ell entry");
-                    else CHECK(v >= 0 && v < std::max<int64_t>(N, 1) + 64, "ell padding %d", v);
+                std::vector<int32_t> have, want;
+                for (int64_t k = 0; k < rounds; ++k) have.push_back(ell[(size_t)(ptr[(size_t)gq] + 64 * k + l)]);
+                if (node < N) {
+                    for (int64_t j = rp[node]; j < rp[node + 1]; ++j) want.push_back(col[j]);
+                    while ((int64_t)want.size() < rounds) want.push_back((int32_t)node);
+                    std::sort(have.begin(), have.end());
+                    std::sort(want.begin(), want.end());
+                    CHECK(have == want, "ell column of node %lld", (long long)node);
+                } else {
+                    for (int32_t v : have) CHECK(v >= 0 && v < std::max<int64_t>(N, 1) + 64, "ell padding %d", v);
                 }
             }
         }
