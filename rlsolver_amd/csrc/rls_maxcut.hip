@@ -1035,6 +1035,10 @@ int rls_maxcut_obj(const rls_graph* g, const void* x, int spin_bytes, int64_t B,
     const dim3 grid((unsigned)ceil_div(B, kWave)), block(tw * kWave);
     hipStream_t s = as_stream(stream);
     const int halve = g->if_bidirectional ? 1 : 0;
+    // dev knob: ask for more LDS than the tile needs, i.e. fewer resident workgroups per CU and a second round of them whose loads
+    // could hide the first round's counting (RLS_K1_LDS_KB = kilobytes per workgroup)
+    static const int pad_kb = getenv("RLS_K1_LDS_KB") ? atoi(getenv("RLS_K1_LDS_KB")) : 0;
+    if (pad_kb > 0 && (size_t)pad_kb * 1024 > lds && (size_t)pad_kb * 1024 <= (size_t)kLdsBytes) lds = (size_t)pad_kb * 1024;
 #define LAUNCH_OBJ(T, VEC, PP)                                                                             \
     do {                                                                                                   \
         auto kern = tw == kTileWavesMax ? k_maxcut_obj<T, VEC, PP, kTileWavesMax> : k_maxcut_obj<T, VEC, PP, kTileWaves>; \
