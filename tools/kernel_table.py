@@ -35,9 +35,9 @@ N22, N70, N14, NT, NBA = 2000, 10000, 800, 100, 10000
 T22, T70 = 65536 // 64, 131072 // 64          # 64-env tiles
 ROWS = [
     (r"k_maxcut_step<unsigned char, 4, 2, true", 65536 // 4 * 64, 65536, 2 * N22 + 20, "K4 maxcut_step emit u8 | G22 2^16 (headline)"),
-    (r"k_maxcut_step<float, 1, 2, true", 65536 * 64, 65536, 8 * N22 + 20, "K4 maxcut_step emit f32 gym surface | G22 2^16"),
+    (r"k_maxcut_step<float, 1, [23], true", 65536 * 64, 65536, 8 * N22 + 20, "K4 maxcut_step emit f32 gym surface | G22 2^16 (round 4: stores chase the loads)"),
     (r"k_maxcut_step<unsigned char, 1, 2, true", 131072 * 64, 131072, 2 * N70 + 20, "K4 maxcut_step emit u8 | G70 2^17"),
-    (r"k_maxcut_step<float, 1, 2, true", 131072 * 64, 131072, 8 * N70 + 20, "K4 maxcut_step emit f32 gym surface | G70 2^17 (80 KB of LDS per workgroup, nontemporal stores)"),
+    (r"k_maxcut_step<float, 1, [23], true", 131072 * 64, 131072, 8 * N70 + 20, "K4 maxcut_step emit f32 gym surface | G70 2^17 (80 KB of LDS per workgroup, nontemporal stores)"),
     (r"k_maxcut_step<unsigned char, 8, 2, true", 256 // 8 * 64, 256, 2 * N14 + 20, "K4 maxcut_step emit u8 | G14 256 (launch-bound)"),
     (r"k_maxcut_obj<", T22 * 256, 65536, N22 + 8, "K1 maxcut_obj | G22 2^16"),
     (r"k_maxcut_obj<", T70 * 512, 131072, N70 + 8, "K1 maxcut_obj | G70 2^17"),
@@ -47,15 +47,15 @@ ROWS = [
     (r"k_maxcut_greedy_sweep_levels<", T70 * 512, 131072, 2 * N70 + 16, "K5 greedy_sweep | G70 2^17 (on-chip bound)"),
     (r"k_node_stats_bits<1", T22 * 512, 65536, 5 * N22, "K3 delta_all | G22 2^16"),
     (r"k_node_stats_bits<1", T70 * 512, 131072, 5 * N70, "K3 delta_all | G70 2^17"),
-    (r"k_node_stats_bits<2, true, false, signed char>", T22 * 512, 65536, 2 * N22, "ls_weights pre-pass, int8 weights + batch min / max | G22 2^16"),
-    (r"k_node_stats_bits<2, true, false, signed char>", 64 * 512, 4096, 2 * N22, "ls_weights pre-pass, int8 weights + batch min / max | G22 4096"),
+    (r"k_node_stats_bits<2, true, false, signed char", T22 * 512, 65536, 2 * N22, "ls_weights pre-pass, int8 weights + batch min / max | G22 2^16"),
+    (r"k_node_stats_bits<2, true, false, signed char", 64 * 512, 4096, 2 * N22, "ls_weights pre-pass, int8 weights + batch min / max | G22 4096"),
     (r"k_maxcut_local_search<true, signed char, 16, 4>", T22 * 256, 65536, 3 * N22 + 8, "LS fused local search: threshold + 8 proposal rounds + sweep | G22 2^16 (VALU-bound; x in, int8 ws, x out)"),
     (r"k_maxcut_local_search<true, signed char, 16, 8>", 64 * 512, 4096, 3 * N22 + 8, "LS fused local search: threshold + 8 proposal rounds + sweep | G22 4096 (64 workgroups: latency / VALU)"),
     (r"k_ls_propose<short, 24, true, false>", 512 * 512, 32768, 4 * NBA + 16, "LS round kernel: noise + mask + count + accept (one proposal round per launch) | BA-1e4 2^15 (VALU-bound; x in, int16 ws in, accepted rows out)"),
     (r"k_ls_threshold<short>", 512 * 512, 32768, 2 * NBA + 4, "LS threshold kernel: noise + top-9 per env | BA-1e4 2^15 (VALU-bound; int16 ws in)"),
     (r"k_ls_mask<short>", 4 * 64 * 512, 4096, 2 * NBA + NBA // 8, "LS mask kernel: noise + mask for a quarter of the rows per workgroup | BA-1e4 4096 (64 tiles x 4 slices)"),
     (r"k_ls_apply_rounds<24, 8>", 64 * 512, 4096, 2 * NBA + 8 * (NBA // 8) * 8 + 16, "LS apply kernel: 8 rounds of (x ^ mask words, count, accept, undo) on one load of the tile | BA-1e4 4096"),
-    (r"k_node_stats_bits<2, true, true, short>", 512 * 512, 32768, 3 * NBA, "ls_weights pre-pass, int16 weights (hub graph: 16 counter planes) | BA-1e4 2^15"),
+    (r"k_node_stats_bits<2, true, true, short", 512 * 512, 32768, 3 * NBA, "ls_weights pre-pass, int16 weights (hub graph: 16 counter planes) | BA-1e4 2^15"),
     (r"k_tsp_tour_length", None, 65536, 8 * NT + 4, "K12 tsp_tour_length | TSP-100 2^16"),
     (r"k_tsp_swap_delta_all", None, 65536, 29 * NT, "K13 tsp_swap_delta_all | TSP-100 2^16"),
     (r"k_spin_step<float, true, false>", 16384 * 64, 16384, None, "S1 spin_step | G22-sized 2^14: O(deg) per env, nothing streamed (round 2: 24 N bytes per env-step, 250 us)"),
