@@ -75,6 +75,14 @@ __device__ __forceinline__ EnvKey ls_env_key(uint64_t seed, uint64_t gb) {
 // per round and tile.  tests/test_gpu_draw_statistics.py holds the generator to moments, tails, lag correlations and a
 // chi-square of the probability integral transform.
 __device__ __forceinline__ void normal4(EnvKey env_key, uint32_t q, uint32_t it, float (&z)[4]) {
+#ifdef RLS_LS_FAKE_NOISE   // timing experiment only: what the kernel costs when a draw is one hash per quad and no transcendental
+    {
+        const uint32_t r = fmix32(env_key.k0 ^ (q * 0x9E3779B1u) ^ (it * 0x7FEB352Du + 0x165667B1u));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) z[k] = (float)(int)((r >> (8 * k)) & 0xFFu) * (1.0f / 64.0f) - 2.0f;
+        return;
+    }
+#endif
     const uint32_t ka = env_key.k0 ^ (q * 0x9E3779B1u) ^ (it * 0x7FEB352Du + 0x165667B1u);
     const uint32_t kb = env_key.k1 ^ (q * 0xC2B2AE3Du) ^ (it * 0x27D4EB2Fu + 0x85EBCA6Bu);
     const uint32_t r0 = fmix32(ka), r1 = fmix32(kb);
