@@ -134,3 +134,17 @@ def test_cpu_tensor_is_rejected():
     from rlsolver_amd.envs.env_L2A import EnvMaxcut
     with pytest.raises(TypeError):
         EnvMaxcut(mygraph=[(0, 1, 1)], device=torch.device("cpu"))
+
+
+def test_graft_entry_build_runs_and_versions_agree():
+    """The driver's "does it build" check is __graft_entry__.build(): it must run here (no GPU) and its idea of the ABI version
+    must be the header's (round 4 bumped the header to v9 and left `== 8` in build(): every parity test was green)."""
+    import re
+    import sys
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as entry
+    from rlsolver_amd import _abi
+    hdr = open(os.path.join(ROOT, "include", "rlsolver_hip.h")).read()
+    want = int(re.search(r"#define RLS_ABI_VERSION (\d+)", hdr).group(1))
+    assert _abi.version() == want
+    entry.build()
