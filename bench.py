@@ -68,6 +68,11 @@ def parse(argv=None):
                          "replayed inside it).  auto = on when --steps <= 100, where the first launch's latency is a visible share of "
                          "the region; the kernels, buffers and the end-of-run parity check are the same either way")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="TEST MODE for boxes with one GPU: every rank runs on cuda:0 and the ranks talk over gloo (keys and timings "
+                         "staged through the host).  Exercises the whole N > 1 path -- shard offsets, per-region exchange, MAX over "
+                         "ranks, rank 0's JSON line -- with real kernels; the number it prints is not a scaling measurement and the "
+                         "line says so")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU only (gloo): launch, shard and exchange wiring of the N-rank run, no kernels")
     return ap.parse_args(argv)
@@ -290,9 +295,11 @@ def measure(a, gset, B, steps, warmup, repeats, dev, rank, local_rank, world, vi
             graphs.append(gr)
             tc += steps
 
+    nccl = use_pg and dist.get_backend() == "nccl"
+
     def barrier():
         if use_pg:
-            dist.barrier(device_ids=[local_rank])
+            dist.barrier(device_ids=[local_rank]) if nccl else dist.barrier()
 
     if use_pg:   # the first collective builds the communicator (16 ms on a 1-rank RCCL group): not part of any region
         rdist.global_best(obj)
@@ -328,7 +335,7 @@ def measure(a, gset, B, steps, warmup, repeats, dev, rank, local_rank, world, vi
         kern.append(e0.elapsed_time(e1) * 1e-3 / max(steps, 1))
 
     if use_pg:
-        tt = torch.tensor(wall, dtype=torch.float64, device=dev)
+        tt = torch.tensor(wall, dtype=torch.float64, device=dev if nccl else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall = [float(v) for v in tt.tolist()]
 
@@ -372,9 +379,11 @@ def main():
     import torch.distributed as dist
     from rlsolver_amd import dist as rdist
 
-    rank, local_rank, world = rdist.init_from_env()
+    rank, local_rank, world = rdist.init_from_env(backend="gloo" if a.share_gpu else None)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    if a.share_gpu:
+        local_rank = 0                                  # test mode: all ranks on the one GPU of the box
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     R = max(1, a.repeats)
@@ -414,7 +423,8 @@ def main():
                                                                         f"{a.steps} launches enqueued as one hipGraph" if res["graph"]
                                                                         else "rls_maxcut_step launcher"),
                        "num_nodes": N, "num_edges": res["E"], "envs_per_gpu": B, "global_envs": world * B, "slots": a.slots,
-                       "parallelism": f"env-shard x{world}"},
+                       "parallelism": f"env-shard x{world}" + (" (TEST MODE --share-gpu: all ranks on one GPU over gloo; not a scaling "
+                                                                "measurement)" if a.share_gpu else "")},
             "roofline": s["roofline"],
         }
         tr = pmc_traffic_per_launch(B, N, a.slots)
@@ -436,7 +446,7 @@ def main():
             out["cpu_baseline_ref_shaped"] = cpu_baseline_ref_shaped(res["graph_arr"], N, max(3.0, a.cpu_seconds / 2))
 
     if dist.is_initialized():
-        dist.barrier(device_ids=[local_rank])
+        dist.barrier(device_ids=[local_rank]) if dist.get_backend() == "nccl" else dist.barrier()
         dist.destroy_process_group()
     if rank == 0:   # the JSON line is the last thing on stdout (RCCL prints its banner at init/teardown)
         sys.stdout.flush()

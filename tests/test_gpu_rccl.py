@@ -75,3 +75,33 @@ def test_bench_under_one_rank_rccl_group():
     out = json.loads(p.stdout.strip().splitlines()[-1])
     assert out["n_gpus"] == 1 and out["steps"] == 20 and out["repeats"] == 3 and len(out["ms_per_step_all"]) == 3
     assert out["value"] > 0 and 0 < out["roofline"]["frac"] < 1
+
+
+@pytest.mark.parametrize("launch", ["self-spawn", "torchrun"])
+def test_bench_two_ranks_sharing_the_gpu(launch):
+    """The driver's N > 1 command line as far as ONE GPU can run it: `bench.py --gpus 2` (started by itself, or under
+    torch.distributed.run as the contract launches it) with --share-gpu -- both ranks on cuda:0, gloo between them.  Real
+    kernels, real shard offsets (rank 1's envs are keyed 8192 ..), the exchange at the end of every timed region, the MAX over
+    ranks, the end-of-run parity check on both ranks and rank 0's JSON as the last stdout line.  (The RCCL calls themselves are
+    the 1-rank group's tests above; a number printed in this mode is not a scaling measurement and says so.)"""
+    e = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "RLS_FORCE_PG"):
+        e.pop(k, None)
+    e["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    args = ["--gpus", "2", "--share-gpu", "--steps", "20", "--warmup", "5", "--repeats", "3", "--envs-per-gpu", "8192",
+            "--no-cpu-baseline", "--no-config5"]
+    if launch == "self-spawn":
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), *args]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), *args]
+    p = subprocess.run(cmd, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    lines = [ln for ln in p.stdout.strip().splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(lines) == 1, p.stdout[-1500:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 20 and len(out["ms_per_step_all"]) == 3 and out["scaling"] == "weak"
+    assert out["config"]["envs_per_gpu"] == 8192 and out["config"]["global_envs"] == 16384
+    assert "TEST MODE" in out["config"]["parallelism"] and out["value"] > 0
+    # value = the units ALL ranks processed / the slowest rank's region
+    assert abs(out["value"] - 16384 * 20 / (out["ms_per_step"] * 20 * 1e-3)) / out["value"] < 1e-6
