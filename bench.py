@@ -280,20 +280,28 @@ def measure(a, gset, B, steps, warmup, repeats, dev, rank, local_rank, world, vi
         t += 1
 
     use_pg = dist.is_initialized()
-    use_graph = (not via_env) and (a.graph == "on" or (a.graph == "auto" and steps <= 100))
+    # (auto needs at least one eager warm-up launch: a kernel's first launch loads its code object, which a capture must not do)
+    use_graph = (not via_env) and (a.graph == "on" or (a.graph == "auto" and steps <= 100 and warmup > 0))
     graphs = []
     if use_graph:
         # one hipGraph per timed region: region r runs steps t_r .. t_r + steps - 1 of the ring / action cycle (capture enqueues
         # nothing: the launchers resolve torch's current stream at every call, which is the capture stream here)
-        torch.cuda.synchronize(dev)
-        tc = t
-        for _ in range(repeats):
-            gr = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gr):
-                for k in range(steps):
-                    step(tc + k)
-            graphs.append(gr)
-            tc += steps
+        try:
+            torch.cuda.synchronize(dev)
+            tc = t
+            for _ in range(repeats):
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr):
+                    for k in range(steps):
+                        step(tc + k)
+                graphs.append(gr)
+                tc += steps
+        except Exception as ex:          # a capture that fails must not fail the measurement: the eager launcher loop is the same work
+            if a.graph == "on":
+                raise
+            print(f"bench.py: hipGraph capture failed ({type(ex).__name__}: {ex}); timing the eager launcher loop", file=sys.stderr)
+            graphs, use_graph = [], False
+            torch.cuda.synchronize(dev)
 
     nccl = use_pg and dist.get_backend() == "nccl"
 
