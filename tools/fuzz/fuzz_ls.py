@@ -1,7 +1,9 @@
 """Differential fuzz of local_search_inplace with recorded noise: the fused kernel against the decomposed K2 / K6 / K5 path on
 random graphs (incl. hubs, where the two take different kernels), and both against the reference-shaped numpy oracle on small
 ones; random batch sizes around the tile, num_iters 0-6, num_spin 1-8, both adjacency forms.  Where the rows are 16-byte
-multiples, additionally the threshold / proposal-round kernels against the fused kernel with in-kernel draws (same seed).
+multiples, additionally the threshold / proposal-round kernels against the fused kernel with in-kernel draws (same seed), at a
+random env_offset, and -- the decomposed path now draws the kernels' own normals -- the decomposed path too; every few
+configurations the batch is also run as two shards (env_offset, env_offset + B / 2) that must equal the whole batch.
 `python tools/fuzz/fuzz_ls.py [seconds] [seed]`."""
 import sys, time
 import numpy as np, torch
@@ -57,17 +59,33 @@ while time.time() < t_end:
     if n % 16 == 0 and ops.local_search_fusable(env.graph, num_spin, B) and ops.ls_rounds_supported(env.graph, num_spin):
         first = bool(rng.rand() < 0.5)
         if num_iters > 0 or not first:
-            res = []
-            for rounds in (False, True):
-                env.force_ls_rounds = rounds
-                env.force_ls_fused = not rounds
+            off = int(rng.choice([0, 64, 1000003, 1 << 33]))
+            env.set_shard(off)
+
+            def run(e, x_in, form):
+                e.fused_local_search = form != "decomposed"
+                e.force_ls_rounds, e.force_ls_fused = form == "rounds", form == "fused"
                 torch.manual_seed(1000 + it)
-                xs, vs = xs0.clone(), env.calculate_obj_values(xs0)
-                env.local_search_pipeline(xs, vs, weight_mult=2 if first else 1, num_iters=num_iters, num_spin=num_spin, noise_std=0.3,
-                                          noise=None, first_draw_proposes=first)
-                res.append((xs, vs))
+                xs, vs = x_in.clone(), e.calculate_obj_values(x_in)
+                e.local_search_pipeline(xs, vs, weight_mult=2 if first else 1, num_iters=num_iters, num_spin=num_spin, noise_std=0.3,
+                                        noise=None, first_draw_proposes=first)
+                return xs, vs
+            res = [run(env, xs0, form) for form in ("fused", "rounds", "decomposed")]
+            for k in (1, 2):
+                assert torch.equal(res[0][0], res[k][0]) and torch.equal(res[0][1], res[k][1]), ("rounds", "decomposed")[k - 1] + " vs fused " + tag
+            if B >= 2 and it % 3 == 0:       # two shards under the whole batch's weight range = the whole batch
+                form = ("fused", "rounds", "decomposed")[it // 3 % 3]
+                mm = ops.maxcut_ls_weights(env.graph, xs0, 2 if first else 1, return_minmax=True)[1]
+                h = B // 2
+                for lo, hi in ((0, h), (h, B)):
+                    part = EnvMaxcut(mygraph=[tuple(int(v) for v in r) for r in garr], device=DEV, if_bidirectional=bidir, num_nodes=n,
+                                     env_offset=off + lo)
+                    part.stat_hook = lambda kind, t: mm.clone()
+                    px, pv = run(part, xs0[lo:hi].contiguous(), form)
+                    assert torch.equal(px, res[0][0][lo:hi]) and torch.equal(pv, res[0][1][lo:hi]), f"shard [{lo}, {hi}) {form} " + tag
             env.force_ls_rounds = env.force_ls_fused = False
-            assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), "round kernels vs fused " + tag
+            env.fused_local_search = True
+            env.set_shard(0)
             nrounds += 1
     it += 1
 print(f"fuzz_ls: {it} random configurations ({nrounds} also round kernels vs fused), no mismatch")
