@@ -594,20 +594,6 @@ __global__ __launch_bounds__(kK7Waves * kWave) void k_mcpg_local_search_stream(
 constexpr int kLvWaves = 16;      // f32 / uint8 node-major surface: 16 waves mostly to move the tile
 constexpr int kLvWavesPacked = 8; // bit-packed chains: the tile is a straight copy; 8 waves, two workgroups per CU at N = 10^4
 
-template <int NP>
-__device__ __forceinline__ void lv_cmp(const uint64_t (&pl)[9], uint32_t K, uint64_t& lt, uint64_t& eq) {
-    uint32_t lt0 = 0, lt1 = 0, eq0 = 0xFFFFFFFFu, eq1 = 0xFFFFFFFFu;
-#pragma unroll
-    for (int p = NP - 1; p >= 0; --p) {
-        const uint32_t kb = 0u - ((K >> p) & 1u);
-        const uint32_t c0 = (uint32_t)pl[p], c1 = (uint32_t)(pl[p] >> 32);
-        lt0 |= eq0 & ~c0 & kb;  lt1 |= eq1 & ~c1 & kb;
-        eq0 &= ~(c0 ^ kb);      eq1 &= ~(c1 ^ kb);
-    }
-    lt = ((uint64_t)lt1 << 32) | lt0;
-    eq = ((uint64_t)eq1 << 32) | eq0;
-}
-
 // 8 words into a (ones, twos, fours, c[0..NC-1] = planes 3..) vertical counter.  NC follows the group's number of
 // rounds (a count <= 7 never carries out of `fours`, <= 15 needs one more plane, ...): the ripple is 4 VALU per plane.
 template <int NC>
