@@ -485,6 +485,10 @@ class MCPGRound(Sharded):
         """One round; returns (value f32 [C], best value so far f32 [1]) -- device tensors, nothing is read back (a sharded
         round reads the two owners of its exchange)."""
         C = self.M * self.R
+        if self.M_total != self.M and self.group is None and self.stat_hook is None:
+            raise RuntimeError("this MCPGRound holds a shard of the kept chains (total_kept > total_mcmc_num): it needs group= (the process "
+                               "group of the other shards) for the whole-batch statistics -- without it the stop rule, the mean and the "
+                               "best / worst incumbent would silently be those of the shard")
         if self._nodemajor:
             xs_sample = metro_sampling(xs_prob, self.start.unpack().repeat(1, self.R), self.change_times)
             temp_max, temp_f32, value = sampler_func(self.data, xs_sample, self.num_ls, self.M, self.R)

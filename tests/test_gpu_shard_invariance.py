@@ -321,6 +321,19 @@ def test_mcpg_round_shards_equal_whole():
             assert torch.allclose(rc["loss"], ra["loss"], rtol=1e-4, atol=1e-4)
 
 
+def test_a_shard_without_a_group_refuses_to_step():
+    n, M = 128, 128
+    amcpg, data = _mcpg_setup(n, 400, 3)
+    xs = (torch.rand(n, 64, device=DEV) < 0.5).float()
+    rnd = amcpg.MCPGRound(data, xs, torch.zeros(64, device=DEV), 64, 2, 1, kept_offset=64, total_kept=M)
+    with pytest.raises(RuntimeError, match="needs group="):
+        rnd.step(torch.full((n,), 0.5, device=DEV))
+    with pytest.raises(ValueError):
+        amcpg.MCPGRound(data, xs, torch.zeros(64, device=DEV), 64, 2, 1, kept_offset=32, total_kept=M)     # not a whole tile
+    with pytest.raises(ValueError):
+        amcpg.MCPGRound(data, xs, torch.zeros(64, device=DEV), 64, 2, 1, kept_offset=128, total_kept=M)    # outside the batch
+
+
 def test_chain_ids_validation_and_functional_api():
     """metro_sampling_packed / sampler_func_packed with chain_ids: a plain offset shard equals the tail of the whole batch;
     the level kernel refuses ids that are not whole tiles."""
