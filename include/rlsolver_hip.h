@@ -187,8 +187,10 @@ int rls_maxcut_greedy_sweep(const rls_graph* g, uint8_t* x, int64_t B,
  * mask uint8 [B,N] is the caller's spin_rand.gt(thresh) (the noise and the
  * kthvalue threshold stay torch ops so they consume torch's generator exactly as
  * the reference does).  x/obj (int64) are updated in place: rows whose proposal
- * has cut >= obj[b] take the proposal. */
-int rls_maxcut_propose_accept(const rls_graph* g, uint8_t* x, int64_t B, const uint8_t* mask,
+ * has cut >= obj[b] take the proposal.
+ * mask_bits != 0: the mask is bit-packed, uint64 [ceil(B/64), N], bit e of word (t, n) = env 64 t + e at node n (bits of envs >= B
+ * zero) -- the tile the kernel works on, N / 8 bytes per env instead of N (graphs within the 64-env tile, N <= 20 224). */
+int rls_maxcut_propose_accept(const rls_graph* g, uint8_t* x, int64_t B, const void* mask, int32_t mask_bits,
                               int64_t* obj, void* stream);
 
 /* Pre-pass of the fused local search  envs/env_L2A.py:90-94 (methods/LocalSearch.py:64-65):

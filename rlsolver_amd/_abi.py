@@ -83,7 +83,7 @@ SIGNATURES = {
     "rls_maxcut_delta_all": [_G, _P, _I64, _P, _P],
     "rls_maxcut_step": [_G, _P, _P, _INT, _I64, _P, _P, _P, _P, _P, _F32, _P],
     "rls_maxcut_greedy_sweep": [_G, _P, _I64, _P, _P],
-    "rls_maxcut_propose_accept": [_G, _P, _I64, _P, _P, _P],
+    "rls_maxcut_propose_accept": [_G, _P, _I64, _P, C.c_int32, _P, _P],
     "rls_maxcut_ls_weights": [_G, _P, _I64, C.c_int32, _P, C.c_int32, _I64, _P, _P],
     "rls_maxcut_local_search": [_G, _P, _I64, _P, C.c_int32, _I64, _P, _P, _U64, _I64, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P],
     "rls_maxcut_ls_normals": [_P, _I64, _I64, _U64, _I64, C.c_int32, _P],

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(W * kWave) void k_maxcut_obj(const T* __restrict__ 
 }
 
 // K6: proposal = x ^ mask for 64 envs; accept the row when its cut is >= the incumbent.
-template <bool VEC, int P, int W>
+template <bool VEC, int P, int W, bool MASK_BITS = false>
 __global__ __launch_bounds__(W * kWave) void k_maxcut_propose_accept(uint8_t* __restrict__ x,
                                                                               const uint8_t* __restrict__ mask,
                                                                               int64_t B, int64_t N,
@@ -76,7 +76,15 @@ __global__ __launch_bounds__(W * kWave) void k_maxcut_propose_accept(uint8_t* __
     // proposal = x ^ mask, built in ONE bit tile: the mask pass XORs into the words the x pass wrote (same lane of
     // the same wave owns a word in both passes); a second tile halved the workgroups per CU for N >= 5000
     tile_load_bits<uint8_t, VEC>(x, B, N, b0, words, lane, w, W, stage);
-    tile_load_bits<uint8_t, VEC, kStageDepth, true>(mask, B, N, b0, words, lane, w, W, stage);
+    if constexpr (MASK_BITS) {
+        // the mask arrives as the tile it is going to be: word (t, n) of uint64 [ceil(B / 64), N] -- N / 8 bytes per env instead
+        // of N, no byte -> bit pass (with the byte mask K6 moved 1.36x its algorithmic bytes at N = 10^4)
+        __syncthreads();
+        const uint64_t* mw = reinterpret_cast<const uint64_t*>(mask) + (int64_t)blockIdx.x * N;
+        for (int64_t n = threadIdx.x; n < N; n += W * kWave) words[n] ^= mw[n];
+    } else {
+        tile_load_bits<uint8_t, VEC, kStageDepth, true>(mask, B, N, b0, words, lane, w, W, stage);
+    }
     __syncthreads();
     int64_t total = block_sum_partials<W>(tile_cut_count<P>(words, eu, ev, E, lane, w, W), scratch, lane, w);
     if (halve) total >>= 1;
@@ -1063,12 +1071,14 @@ int rls_maxcut_obj(const rls_graph* g, const void* x, int spin_bytes, int64_t B,
     return check_launch("k_maxcut_obj");
 }
 
-int rls_maxcut_propose_accept(const rls_graph* g, uint8_t* x, int64_t B, const uint8_t* mask, int64_t* obj,
+int rls_maxcut_propose_accept(const rls_graph* g, uint8_t* x, int64_t B, const void* mask_v, int32_t mask_bits, int64_t* obj,
                               void* stream) {
     if (int rc = check_graph(g)) return rc;
     RLS_REQUIRE(B >= 0, RLS_EINVAL, "B < 0");
     if (B == 0) return RLS_OK;
+    const uint8_t* mask = static_cast<const uint8_t*>(mask_v);
     RLS_REQUIRE(x && mask && obj, RLS_EINVAL, "x/mask/obj is NULL");
+    RLS_REQUIRE(!mask_bits || (((uintptr_t)mask) & 7) == 0, RLS_EINVAL, "a bit-packed mask is uint64 words: 8-byte aligned");
     const int64_t N = g->num_nodes, E = g->num_stored_edges;
     int tw = tile_waves_for(N);
     size_t lds = (size_t)N * 8 + (size_t)tw * kWave * 8;
@@ -1079,6 +1089,7 @@ int rls_maxcut_propose_accept(const rls_graph* g, uint8_t* x, int64_t B, const u
     if (lds > (size_t)kLdsBytes) {   // the 64-env bit tile does not fit: one env per wave on a byte row
         const int rw = rows_waves(N);
         RLS_REQUIRE(rw > 0, RLS_EUNSUPPORTED, "N=%lld: a row does not fit LDS (max %d)", (long long)N, kLdsBytes);
+        RLS_REQUIRE(!mask_bits, RLS_EUNSUPPORTED, "N=%lld: beyond the 64-env tile the mask must be bytes [B, N]", (long long)N);
         const size_t lr = (size_t)rw * (((size_t)N + 15) & ~(size_t)15);
         if (lr > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_maxcut_propose_accept_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lr);
         hipLaunchKernelGGL(k_maxcut_propose_accept_rows, dim3((unsigned)ceil_div(B, rw)), dim3(rw * kWave), lr, as_stream(stream), x, mask, B, N,
@@ -1087,15 +1098,17 @@ int rls_maxcut_propose_accept(const rls_graph* g, uint8_t* x, int64_t B, const u
     }
     const int P = pick_planes(E);
     RLS_REQUIRE(P != 0, RLS_EUNSUPPORTED, "E'=%lld too large", (long long)E);
-    const bool vec = tile_rows_aligned(x, N, 1) && tile_rows_aligned(mask, N, 1);
+    const bool vec = tile_rows_aligned(x, N, 1) && (mask_bits || tile_rows_aligned(mask, N, 1));
     const int stage_off = tile_stage_offset(&lds, tw, true);
     const dim3 grid((unsigned)ceil_div(B, kWave)), block(tw * kWave);
     hipStream_t s = as_stream(stream);
     const int halve = g->if_bidirectional ? 1 : 0;
 #define LAUNCH_PA(VEC, PP)                                                                                 \
     do {                                                                                                   \
-        auto kern = tw == kTileWavesMax ? k_maxcut_propose_accept<VEC, PP, kTileWavesMax>                 \
-                                        : k_maxcut_propose_accept<VEC, PP, kTileWaves>;                   \
+        auto kern = mask_bits ? (tw == kTileWavesMax ? k_maxcut_propose_accept<VEC, PP, kTileWavesMax, true>   \
+                                                     : k_maxcut_propose_accept<VEC, PP, kTileWaves, true>)     \
+                              : (tw == kTileWavesMax ? k_maxcut_propose_accept<VEC, PP, kTileWavesMax>         \
+                                                     : k_maxcut_propose_accept<VEC, PP, kTileWaves>);          \
         if (lds > 64 * 1024)                                                                               \
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(kern, grid, block, lds, s, x, mask, B, N, g->eu, g->ev, E, halve, obj, stage_off); \

@@ -157,12 +157,18 @@ void maxcut_greedy_sweep(int64_t g, Tensor xs, Tensor obj) {
 void maxcut_propose_accept(int64_t g, Tensor xs, const Tensor& mask, Tensor obj) {
     spin_bytes(xs, "xs", false);
     const int64_t B = env_rows(xs, "xs", G(g));
-    spin_bytes(mask, "mask", false);
-    shape2(mask, "mask", B, G(g)->num_nodes);
+    const bool packed = mask.scalar_type() == I64;      // uint64 bit patterns [ceil(B / 64), N]: the mask as a bit tile
+    if (packed) {
+        dev(mask, "mask", I64);
+        shape2(mask, "mask", (B + 63) / 64, G(g)->num_nodes);
+    } else {
+        spin_bytes(mask, "mask", false);
+        shape2(mask, "mask", B, G(g)->num_nodes);
+    }
     dev(obj, "obj", I64);
     count(obj, "obj", B);
     RLS_GUARD(xs);
-    ok(rls_maxcut_propose_accept(G(g), (uint8_t*)p(xs), B, (const uint8_t*)p(mask), (int64_t*)p(obj), cur_stream(xs)),
+    ok(rls_maxcut_propose_accept(G(g), (uint8_t*)p(xs), B, p(mask), packed ? 1 : 0, (int64_t*)p(obj), cur_stream(xs)),
        "rls_maxcut_propose_accept");
 }
 // local-search weights: int8 / int16 / int32 -> ws_bytes

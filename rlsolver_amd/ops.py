@@ -237,10 +237,15 @@ def maxcut_greedy_sweep(g: DeviceGraph, xs: TEN, obj: TEN) -> None:
 
 
 def maxcut_propose_accept(g: DeviceGraph, xs: TEN, mask: TEN, obj: TEN) -> None:
+    """K6 in place.  ``mask``: bool / uint8 [B, N], or bit-packed int64 words [ceil(B / 64), N] (bit e of word (t, n) = env 64 t + e:
+    what ``ops_mcpg_tsp.PackedChains.pack(mask.t())`` gives) -- an eighth of the bytes."""
     B, _ = _spins(xs, "xs", g)
-    _spins(mask, "mask", g)
-    if mask.shape[0] != B:
-        raise ValueError("mask must have the same shape as xs")
+    if mask.dtype == torch.int64:
+        _check(mask, "mask", (torch.int64,), g.device, ((B + 63) // 64, g.num_nodes))
+    else:
+        _spins(mask, "mask", g)
+        if mask.shape[0] != B:
+            raise ValueError("mask must have the same shape as xs")
     _check(obj, "obj", (torch.int64,), g.device, (B,))
     _t.maxcut_propose_accept(g.handle, xs, mask, obj)
 

@@ -296,6 +296,16 @@ def test_propose_accept(n, m, B, bidir):
     ops.maxcut_propose_accept(g, xs, to_dev_bool(mask), vs)
     assert np.array_equal(xs.cpu().numpy(), want_x)
     assert np.array_equal(vs.cpu().numpy(), want_v)
+    # the same proposal with the mask as the bit tile it becomes (uint64 [ceil(B / 64), N]: an eighth of the bytes)
+    from rlsolver_amd.ops_mcpg_tsp import PackedChains
+    words = PackedChains.pack(to_dev_bool(mask).t().contiguous()).words
+    assert words.shape == ((B + 63) // 64, n)
+    xs2 = to_dev_bool(xs0).clone()
+    vs2 = torch.from_numpy(vs0).to(DEV)
+    ops.maxcut_propose_accept(g, xs2, words, vs2)
+    assert np.array_equal(xs2.cpu().numpy(), want_x) and np.array_equal(vs2.cpu().numpy(), want_v)
+    with pytest.raises((ValueError, RuntimeError)):
+        ops.maxcut_propose_accept(g, xs2, words[:, :-1].contiguous(), vs2)
 
 
 def test_select_ops_golden(golden):

@@ -100,6 +100,11 @@ def maxcut_suite(tag, n, m, B, seed, iters, mygraph=None):
     vs = ops.maxcut_obj(g, x)
     t = timeit(lambda i: ops.maxcut_propose_accept(g, x, mask, vs), max(3, iters // 4))
     emit(tag, "K6 propose_accept", "proposals", B, t, 2 * n + 16)
+    if n * 8 + 4096 <= 160 * 1024:
+        from rlsolver_amd.ops_mcpg_tsp import PackedChains
+        mwords = PackedChains.pack(mask.t().contiguous()).words
+        t = timeit(lambda i: ops.maxcut_propose_accept(g, x, mwords, vs), max(3, iters // 4))
+        emit(tag, "K6 propose_accept, bit-packed mask", "proposals", B, t, 2 * n + n // 8 + 16, "x in, mask words in, accepted rows out")
     t = timeit(lambda i: ops.maxcut_greedy_sweep(g, x, vs), max(2, iters // 10))
     # LDS-op rate: a sweep reads one 64-env word per (node, neighbour) and per node, and writes one per node;
     # LDS peak = 128 B / clk / CU x 256 CUs x 2.4 GHz = 78.6 TB/s
