@@ -200,7 +200,7 @@ __device__ __forceinline__ int isco_local_dist(const uint8_t* s, float* lp, int6
     return wave_sum_i32(differ) >> 1;
 }
 
-__global__ __launch_bounds__(256) void k_isco_maxcut_step(IscoMcArgs a) {
+__global__ __launch_bounds__(512) void k_isco_maxcut_step(IscoMcArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & (kWave - 1);
     const int wib = threadIdx.x / kWave;
@@ -780,15 +780,25 @@ int rls_isco_maxcut_step(const rls_graph* g, const float* x, float* y_out, int64
     const size_t per_wave = rows + (size_t)P * 8;
     RLS_REQUIRE(per_wave + fixed <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS per env (max %d)", (long long)N,
                 per_wave + fixed, kLdsBytes);
-    int waves = (int)((size_t)kLdsBytes / per_wave);
-    waves = waves > 4 ? 4 : waves;
-    if (waves == 3) waves = 2;
-    const size_t lds = per_wave * waves;
+    const bool use_wg = B <= (int64_t)2 * num_cus() && N >= 4 * kWave && per_wave + fixed <= (size_t)kLdsBytes;
+    // wave-per-sample kernel: one wave per SIMD is latency-bound (round 3: 4 samples per CU), so the list gives up capacity for
+    // resident samples while it stays >= 512 entries -- the reference draws Poisson(~10) path lengths, a longer selection takes
+    // the extraction path -- G22-sized rows: 2048 entries x 4 samples -> 512 x 6 per CU, 4096 samples 606 -> 508 us
+    static const int max_waves = getenv("RLS_ISCO_WAVES") ? atoi(getenv("RLS_ISCO_WAVES")) : 8;     // dev knob (<= 8)
+    auto waves_for = [&](int cap) {
+        int wv = (int)((size_t)kLdsBytes / (rows + (size_t)cap * 8));
+        return wv > max_waves ? max_waves : wv;
+    };
+    int Pw = P;
+    if (!use_wg && force_cap == 0)
+        while (Pw > 512 && waves_for(Pw >> 1) > waves_for(Pw)) Pw >>= 1;
+    const int waves = waves_for(Pw) < 1 ? 1 : waves_for(Pw);
+    const size_t lds = (rows + (size_t)Pw * 8) * waves;
     const bool use_ell = g->ell_sym_ptr && g->ell_sym && !g->wgt;
     // few chains (the reference's configs run one): a workgroup per sample; from ~4 samples per CU on the wave-per-sample
     // kernel has the throughput
     const size_t lds_wg = per_wave + sizeof(IscoWgScratch) + 16;
-    if (B <= (int64_t)2 * num_cus() && N >= 4 * kWave && lds_wg <= (size_t)kLdsBytes) {
+    if (use_wg) {
         IscoMcArgs aw{g->rowptr, g->col, use_ell ? g->ell_sym_ptr : nullptr, use_ell ? g->ell_sym : nullptr, x, y_out, B, N,
                       path_length, temperature, u_gumbel, u_accept, seed, env_offset, energy_out, acc_out, terms_out, mask_out, P};
         if (lds_wg > 64 * 1024)
@@ -797,7 +807,7 @@ int rls_isco_maxcut_step(const rls_graph* g, const float* x, float* y_out, int64
         return check_launch("k_isco_maxcut_step_wg");
     }
     IscoMcArgs a{g->rowptr, g->col, use_ell ? g->ell_sym_ptr : nullptr, use_ell ? g->ell_sym : nullptr, x, y_out, B, N, path_length, temperature, u_gumbel, u_accept, seed, env_offset,
-                 energy_out, acc_out, terms_out, mask_out, P};
+                 energy_out, acc_out, terms_out, mask_out, Pw};
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute((const void*)k_isco_maxcut_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_isco_maxcut_step, dim3((unsigned)ceil_div(B, waves)), dim3(waves * kWave), lds, as_stream(stream), a);
