@@ -394,3 +394,23 @@ def test_launcher_keeps_its_graph_alive():
     torch.cuda.synchronize()
     assert torch.equal(ops.maxcut_obj(ref_g, out).to(torch.int32), obj)
     del junk
+
+
+def test_an_empty_shard_goes_through_every_call():
+    """env_shard gives some ranks nothing when B < world: such a rank still makes every call (and so joins every exchange)."""
+    from rlsolver_amd.methods.LocalSearch import LocalSearch
+    env = _env(200, 900, 3, offset=77)
+    seen = []
+    env.stat_hook = lambda kind, t: (seen.append((kind, t.clone())), t)[1]
+    torch.manual_seed(1)
+    xs = env.generate_xs_randomly(0)
+    assert xs.shape == (0, 200)
+    xs, vs = env.local_search_inplace(xs, torch.empty(()), num_iters=3, num_spin=5)
+    assert xs.shape == (0, 200) and vs.shape == (0,)
+    assert [k for k, _ in seen] == ["minmax"]
+    mm = seen[0][1]
+    assert bool((mm[0] > mm[1]).all())                      # the neutral element of (min, max): loses against every real row
+    ls = LocalSearch(env, 200)
+    ls.reset(xs)
+    gx, gv, n = ls.random_search(num_iters=2, num_spin=4)
+    assert gx.shape == (0, 200) and int(n) == 0
