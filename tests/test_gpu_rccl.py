@@ -105,3 +105,26 @@ def test_bench_two_ranks_sharing_the_gpu(launch):
     assert "TEST MODE" in out["config"]["parallelism"] and out["value"] > 0
     # value = the units ALL ranks processed / the slowest rank's region
     assert abs(out["value"] - 16384 * 20 / (out["ms_per_step"] * 20 * 1e-3)) / out["value"] < 1e-6
+
+
+def test_sharded_search_loop_example_is_rank_count_invariant():
+    """examples/sharded_local_search.py -- the reference's search loop (env_MCPG.py:407-493) on the sharded classes -- with one
+    rank and with two ranks sharing the GPU: the same best cut AND the same solution string."""
+    e = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "RLS_FORCE_PG"):
+        e.pop(k, None)
+    e["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    script = os.path.join(ROOT, "examples", "sharded_local_search.py")
+    args = ["--nodes", "300", "--edges", "1500", "--num-sims", "512", "--num-iter1", "4", "--num-iter0", "2", "--ls-iters", "8", "--seed", "3"]
+    outs = []
+    for world in (1, 2):
+        cmd = [sys.executable, script, *args] if world == 1 else \
+            [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+             "--master-port", str(_free_port()), script, *args, "--share-gpu"]
+        p = subprocess.run(cmd, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900, cwd=ROOT)
+        assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+        outs.append(json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{") and '"x_str"' in ln][-1]))
+    one, two = outs
+    assert (one["ranks"], two["ranks"]) == (1, 2)
+    assert one["best"] == two["best"] == one["cut_of_x"] == two["cut_of_x"] and one["x_str"] == two["x_str"]
+    assert one["best"] > 1500 * 0.6                                   # and the search found something: well above a random cut
