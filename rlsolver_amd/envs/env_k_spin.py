@@ -25,16 +25,16 @@ class _SimulatorBase(_EnvMaxcut):
 
 class SimulatorGraphMaxCut(_SimulatorBase):
     def __init__(self, sim_name: str = 'max_cut', graph: MyGraph = (), device=th.device('cpu'),
-                 if_bidirectional: bool = False):
-        super().__init__(sim_name=sim_name, mygraph=graph, device=device, if_bidirectional=if_bidirectional)
+                 if_bidirectional: bool = False, **shard):      # shard: env_offset / seed / group (rlsolver_amd/seeding.py)
+        super().__init__(sim_name=sim_name, mygraph=graph, device=device, if_bidirectional=if_bidirectional, **shard)
 
 
 class MaxcutSimulatorReinforce(_SimulatorBase):
-    def __init__(self, graph: MyGraph, device=th.device('cpu'), if_bidirectional: bool = False):
-        super().__init__(sim_name='max_cut', mygraph=graph, device=device, if_bidirectional=if_bidirectional)
+    def __init__(self, graph: MyGraph, device=th.device('cpu'), if_bidirectional: bool = False, **shard):
+        super().__init__(sim_name='max_cut', mygraph=graph, device=device, if_bidirectional=if_bidirectional, **shard)
 
 
 class SimulatorMaxcutAutoregressive(_SimulatorBase):
-    def __init__(self, graph_name: str, device=th.device('cpu'), if_bidirectional: bool = False):
+    def __init__(self, graph_name: str, device=th.device('cpu'), if_bidirectional: bool = False, **shard):
         super().__init__(sim_name=graph_name, mygraph=load_mygraph2(graph_name=graph_name), device=device,
-                         if_bidirectional=if_bidirectional)
+                         if_bidirectional=if_bidirectional, **shard)

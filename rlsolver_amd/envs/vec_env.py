@@ -20,12 +20,13 @@ from .env_PPO import EnvMaxcut as _GymEnv
 
 class MaxcutVecEnv:
     def __init__(self, mygraph, num_nodes: int, num_envs: int, max_step: int = 12345, gpu_id: int = 0,
-                 if_bidirectional: bool = False, env_name: str = "maxcut"):
+                 if_bidirectional: bool = False, env_name: str = "maxcut", env_offset: int = 0, seed=None):
+        """``env_offset`` / ``seed``: rlsolver_amd/seeding.py -- ``num_envs`` is this rank's share of a sharded batch."""
         if gpu_id < 0:
             raise TypeError("MaxcutVecEnv needs a HIP device (gpu_id >= 0); there is no CPU path")
         self.device = th.device(f"cuda:{gpu_id}")
         args = types.SimpleNamespace(num_nodes=num_nodes, num_envs=num_envs, num_steps=max_step)
-        self._env = _GymEnv(args, mygraph=mygraph, device=self.device, if_bidirectional=if_bidirectional)
+        self._env = _GymEnv(args, mygraph=mygraph, device=self.device, if_bidirectional=if_bidirectional, env_offset=env_offset, seed=seed)
         self.env_name = env_name
         self.num_envs = num_envs
         self.max_step = max_step
