@@ -1032,6 +1032,8 @@ __global__ __launch_bounds__(256) void k_mcpg_value_bit_sums(const uint64_t* __r
 // sums (table q, entry i = sum of the values of chains 8q + j over the set bits j of i): a word costs 8 lookups + 8 adds
 // instead of 64 selects + 64 adds.
 constexpr int kBitSumThreads = 512;   // (256: 117 us at BA-1e4 / 2^18; the lookups want more waves per CU than 3 workgroups x 4 gave)
+constexpr int kBitSumRegs = 24;       // nodes per thread whose partial sums stay in registers: N <= 24 * 512
+template <bool REGS>                  // REGS: the workgroup's partial A[] lives in registers (thread t owns nodes t, t + 512, ...), else in LDS
 __global__ __launch_bounds__(kBitSumThreads) void k_mcpg_value_bit_sums_lut(const uint64_t* __restrict__ samples, int64_t N,
                                                                             int64_t C, int64_t tiles,
                                                                             const float* __restrict__ value,
@@ -1039,9 +1041,15 @@ __global__ __launch_bounds__(kBitSumThreads) void k_mcpg_value_bit_sums_lut(cons
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* lut = reinterpret_cast<float*>(smem);          // [8][256]
     float* v = lut + 8 * 256;                             // [64]
-    float* acc = v + kWave;                               // [N]
+    float* acc = v + kWave;                               // [N] (not REGS)
     const int t = threadIdx.x;
-    for (int64_t n = t; n < N; n += kBitSumThreads) acc[n] = 0.0f;
+    float accr[kBitSumRegs];
+    if constexpr (REGS) {
+#pragma unroll
+        for (int u = 0; u < kBitSumRegs; ++u) accr[u] = 0.0f;
+    } else {
+        for (int64_t n = t; n < N; n += kBitSumThreads) acc[n] = 0.0f;
+    }
     for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         __syncthreads();                                  // the previous tile's lookups are done
         if (t < kWave) {
@@ -1060,26 +1068,56 @@ __global__ __launch_bounds__(kBitSumThreads) void k_mcpg_value_bit_sums_lut(cons
         }
         __syncthreads();
         const uint64_t* row = samples + tile * N;
-        for (int64_t n0 = t; n0 < N; n0 += 4 * kBitSumThreads) {
-            uint64_t wd[4];
+        if constexpr (REGS) {
+            // four words in flight per trip; the sums never leave the registers between tiles (the LDS form read and wrote
+            // acc[n] once per word: two of its ten LDS operations)
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int64_t n = n0 + (int64_t)u * kBitSumThreads;
-                wd[u] = n < N ? row[n] : 0ull;
+            for (int u0 = 0; u0 < kBitSumRegs; u0 += 4) {
+                if ((int64_t)u0 * kBitSumThreads >= N) break;            // (uniform)
+                uint64_t wd[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t n = t + (int64_t)(u0 + u) * kBitSumThreads;
+                    wd[u] = n < N ? row[n] : 0ull;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float sum = 0.0f;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) sum += lut[q * 256 + (int)((wd[u] >> (8 * q)) & 255u)];     // (word 0: entry 0 of every table = 0)
+                    accr[u0 + u] += sum;
+                }
             }
+        } else {
+            for (int64_t n0 = t; n0 < N; n0 += 4 * kBitSumThreads) {
+                uint64_t wd[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int64_t n = n0 + (int64_t)u * kBitSumThreads;
-                if (n >= N) break;
-                float sum = 0.0f;
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t n = n0 + (int64_t)u * kBitSumThreads;
+                    wd[u] = n < N ? row[n] : 0ull;
+                }
 #pragma unroll
-                for (int q = 0; q < 8; ++q) sum += lut[q * 256 + (int)((wd[u] >> (8 * q)) & 255u)];
-                acc[n] += sum;                            // n = t mod the workgroup size: this thread's own slot
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t n = n0 + (int64_t)u * kBitSumThreads;
+                    if (n >= N) break;
+                    float sum = 0.0f;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) sum += lut[q * 256 + (int)((wd[u] >> (8 * q)) & 255u)];
+                    acc[n] += sum;                            // n = t mod the workgroup size: this thread's own slot
+                }
             }
         }
     }
-    for (int64_t n = t; n < N; n += kBitSumThreads)
-        if (acc[n] != 0.0f) atomicAdd(&A[n], acc[n]);
+    if constexpr (REGS) {
+#pragma unroll
+        for (int u = 0; u < kBitSumRegs; ++u) {
+            const int64_t n = t + (int64_t)u * kBitSumThreads;
+            if (n < N && accr[u] != 0.0f) atomicAdd(&A[n], accr[u]);
+        }
+    } else {
+        for (int64_t n = t; n < N; n += kBitSumThreads)
+            if (acc[n] != 0.0f) atomicAdd(&A[n], acc[n]);
+    }
 }
 
 // bit-packed tiles <-> the reference's node-major f32 [N, C] surface (shims for callers that want it)
@@ -1513,12 +1551,14 @@ int rls_mcpg_value_bit_sums(const uint64_t* samples, int64_t N, int64_t C, const
     if (C == 0) return RLS_OK;
     RLS_REQUIRE(samples && value && A, RLS_EINVAL, "NULL pointer");
     const int64_t tiles = ceil_div(C, kWave);
-    const size_t lds = (size_t)(8 * 256 + kWave) * 4 + (size_t)N * 4;
+    const bool regs = N <= (int64_t)kBitSumRegs * kBitSumThreads;
+    const size_t lds = (size_t)(8 * 256 + kWave) * 4 + (regs ? 0 : (size_t)N * 4);
     if (lds <= (size_t)kLdsBytes / 2) {
-        auto kern = k_mcpg_value_bit_sums_lut;
+        auto kern = regs ? k_mcpg_value_bit_sums_lut<true> : k_mcpg_value_bit_sums_lut<false>;
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        const int64_t per_cu = (int64_t)kLdsBytes / (int64_t)lds;           // resident workgroups per CU by LDS
-        int64_t grid = 256 * (per_cu < 8 ? per_cu : 8);
+        int64_t per_cu = (int64_t)kLdsBytes / (int64_t)lds;           // resident workgroups per CU by LDS ...
+        if (per_cu > 2048 / kBitSumThreads) per_cu = 2048 / kBitSumThreads;   // ... and by threads
+        int64_t grid = 256 * per_cu;
         if (grid > tiles) grid = tiles;
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kBitSumThreads), lds, as_stream(stream), samples, N, C, tiles,
                            value, A);
