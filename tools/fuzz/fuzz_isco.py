@@ -39,7 +39,10 @@ while time.time() < t_end:
                                 "edge_to": torch.from_numpy(g[:, 1].copy()).to(DEV)}, batch_size=b, device=DEV)
     big, small = mk(B), mk(Bs)
     x = torch.from_numpy(rng.randint(0, 2, size=(B, n)).astype(np.float32)).to(DEV)
-    pl = torch.from_numpy(rng.randint(1, min(40, n), size=B).astype(np.int64)).to(DEV)
+    pln = rng.randint(1, min(40, n), size=B).astype(np.int64)
+    if n >= 1100 and rng.rand() < 0.4:      # a path longer than the wave kernel's selected-set list (512 entries once it trades capacity
+        pln[int(rng.randint(0, Bs))] = int(rng.randint(520, n // 2))    # for resident samples): ordered by extraction there, sorted in the other kernel
+    pl = torch.from_numpy(pln).to(DEV)
     draws = {"u_gumbel": torch.from_numpy(rng.rand(B, n).astype(np.float32).clip(1e-7, 1 - 1e-7)),
              "u_accept": torch.from_numpy(rng.rand(B).astype(np.float32))}
     yb, eb, ab, tb, mb = big.step(x, pl, T, draws=draws, want_terms=True)

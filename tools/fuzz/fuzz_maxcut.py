@@ -114,6 +114,11 @@ while time.time() < t_end:
     pv = oc.maxcut_obj(prop, eu, ev, bidir)
     acc = pv >= want
     assert np.array_equal(vk.cpu().numpy(), np.where(acc, pv, want)) and np.array_equal(xk.cpu().numpy().astype(np.uint8), np.where(acc[:, None], prop, xs0)), "K6 " + tag
+    if n * 8 + 8192 <= 160 * 1024:          # the same proposal with the mask as a bit tile (uint64 [ceil(B / 64), N])
+        from rlsolver_amd.ops_mcpg_tsp import PackedChains
+        xk2, vk2 = xs.clone(), torch.from_numpy(want).to(DEV)
+        ops.maxcut_propose_accept(g, xk2, PackedChains.pack(mask.t().contiguous()).words, vk2)
+        assert torch.equal(xk2, xk) and torch.equal(vk2, vk), "K6 bit-packed mask " + tag
     if B <= 130 or n <= 1500:
         xsw = xs.clone()
         vsw = torch.from_numpy(want).to(DEV)
