@@ -108,16 +108,16 @@ __global__ __launch_bounds__(W * kWave) void k_maxcut_local_search(
     int64_t env_offset, int num_iters, int num_spin, int first_draw_proposes, int64_t* __restrict__ obj,
     int compute_obj, int batched) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // LDS: words | prop | [rp] | ring | scratch | [tops].  With 4 waves per tile (many tiles: occupancy matters) the
-    // sweep schedule offsets `rp` live in `prop` (proposals are over when the sweep starts) and the top-k merge
-    // buffer in the ring (idle between the threshold pass and the first proposal round): 50 KB for G22, three
-    // workgroups per CU instead of two.  With 8 waves per tile (few tiles) waves 4..7 stage in `tops`.
+    // LDS: words | prop | ring | scratch | [tops] | rd_std.  The sweep schedule offsets `rp` live in `prop` (the proposals are
+    // over when the sweep starts).  With 4 waves per tile the top-k merge buffer lives in the ring (idle between the threshold
+    // pass and the first proposal round): 58 KB for G22, two workgroups per CU (the kernel's ~240 registers allow two waves per
+    // SIMD).  With 8 waves per tile (a CU holds one tile: ls_pick_waves) waves 4..7 stage in `tops`.
     constexpr bool COMPACT = (W == kLsMergeWaves);
     constexpr bool VEC = ALIGNED, V4 = ALIGNED;
     uint64_t* words = reinterpret_cast<uint64_t*>(smem);
     uint64_t* prop = words + (N + 2);
-    int32_t* rp = COMPACT ? reinterpret_cast<int32_t*>(prop) : reinterpret_cast<int32_t*>(prop + N);
-    int32_t* ring = COMPACT ? reinterpret_cast<int32_t*>(prop + N) : rp + ((N + 1 + 3) & ~3ll);
+    int32_t* rp = reinterpret_cast<int32_t*>(prop);
+    int32_t* ring = reinterpret_cast<int32_t*>(prop + N);
     int64_t* scratch = reinterpret_cast<int64_t*>(ring + kRing);
     float* tops = COMPACT ? reinterpret_cast<float*>(ring)
                           : reinterpret_cast<float*>(scratch + W * kWave);   // [kLsMergeWaves][kTopCap][64]
@@ -134,9 +134,6 @@ __global__ __launch_bounds__(W * kWave) void k_maxcut_local_search(
 
     // ---- phase 0
     if (threadIdx.x == 0) words[N] = 0;
-    // rp: CSR rowptr / schedule offsets (N + 1 entries), or the level-group offsets (sweep_len + 1 <= N + 1 entries)
-    if constexpr (!COMPACT)
-        for (int64_t i = threadIdx.x; i <= (batched == 2 ? sweep_len : N); i += W * kWave) rp[i] = rowptr[i];
     // the ring is idle outside the sweep: it doubles as the row-piece stage of the tile load / store
     // waves 0..3 stage in the ring, waves 4..7 in the top-k merge buffer (free until the merge, see the barrier there)
     static_assert(kRing * 4 >= kLsMergeWaves * kStageBytes && kLsMergeWaves * kTopCap * kWave * 4 >= (W - kLsMergeWaves) * kStageBytes,
@@ -360,10 +357,10 @@ __global__ __launch_bounds__(W * kWave) void k_maxcut_local_search(
         __syncthreads();
     }
     // ---- phase 3: greedy sweep on the resident tile
-    if constexpr (COMPACT) {   // the schedule offsets move into `prop` now that the proposals are over
-        for (int64_t i = threadIdx.x; i <= (batched == 2 ? sweep_len : N); i += W * kWave) rp[i] = rowptr[i];
-        __syncthreads();
-    }
+    // rp: CSR rowptr / schedule offsets (N + 1 entries), or the level-group offsets (sweep_len + 1 <= N + 1 entries); they
+    // move into `prop` now that the proposals are over
+    for (int64_t i = threadIdx.x; i <= (batched == 2 ? sweep_len : N); i += W * kWave) rp[i] = rowptr[i];
+    __syncthreads();
     if (batched == 2) {   // level-parallel (lane = node): sweep_src = group records, sweep_len = number of groups
         const int64_t before = block_sum_partials<W>(tile_cut_count<P>(words, eu, ev, E, lane, w, W), scratch, lane, w);
         __syncthreads();
@@ -746,15 +743,19 @@ static size_t ls_lds_bytes(int64_t N, int W) {
     const size_t sd_bytes = (size_t)((N + 3) & ~3ll) * 4;   // rd_std in LDS
     return sd_bytes + (W == kLsMergeWaves
                            ? (size_t)(N + 2) * 8 + (size_t)N * 8 + (size_t)kRing * 4 + (size_t)W * kWave * 8
-                           : (size_t)(N + 2) * 8 + (size_t)N * 8 + (size_t)((N + 1 + 3) & ~3ll) * 4 + (size_t)kRing * 4 +
+                           : (size_t)(N + 2) * 8 + (size_t)N * 8 + (size_t)kRing * 4 +
                                  (size_t)W * kWave * 8 + (size_t)kLsMergeWaves * kTopCap * kWave * 4);
 }
 
-// 8 waves per tile when there are few tiles (<= 2 per CU: the noise / top-k / mask phases are VALU-latency bound with
-// one wave per SIMD) and that layout fits LDS; else 4 waves per tile (two tiles per CU); 0 = neither layout fits
+// Waves per tile.  What counts is waves per SIMD (the VALU issues a wave's stream at ~5 cycles per instruction and two or more
+// waves' at ~2.6: tools/ceilings/valu_issue.hip): 8 waves when a CU holds one tile anyway -- at most one tile per CU in the launch, or
+// rows so long that two 4-wave layouts do not fit LDS (N > ~3100) -- else 4 waves and two tiles per CU.  Measured
+// (tools/timing/ls_waves.py): G22-sized 2^14 envs 0.53 -> 0.46 ms with 8, 2^15 0.83 -> 0.72 with 4; G(5000, 20000) 2^16 4.02 -> 3.13
+// with 8.  0 = neither layout fits.
 static int ls_pick_waves(int64_t N, int64_t B) {
     static const int force_w = getenv("RLS_LS_WAVES") ? atoi(getenv("RLS_LS_WAVES")) : 0;   // dev knob
-    int W = force_w == 4 || force_w == 8 ? force_w : (ceil_div(B, kWave) <= 2 * (int64_t)num_cus() ? 8 : 4);
+    const bool two_small = 2 * ls_lds_bytes(N, 4) <= (size_t)kLdsBytes;
+    int W = force_w == 4 || force_w == 8 ? force_w : (ceil_div(B, kWave) <= (int64_t)num_cus() || !two_small ? 8 : 4);
     if (W == 8 && ls_lds_bytes(N, 8) > (size_t)kLdsBytes) W = 4;
     return ls_lds_bytes(N, W) <= (size_t)kLdsBytes ? W : 0;
 }

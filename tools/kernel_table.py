@@ -17,8 +17,14 @@ SIMDs.  One wave's own stream issues a vector instruction every 4 cycles (MI355X
 cost"); with two or more waves resident a SIMD-32 retires a wave64 instruction every 2.  `valu floor us` is the 4-cycle
 figure at 2.4 GHz -- instructions x 4 / (1024 x 2.4e9) -- and `valu frac` = floor / mean duration: 1.0 means every SIMD
 issued from one stream without a gap for the whole launch; values above 1 are possible (and mean the waves of a SIMD
-overlapped their issue) up to 2.0, the 2-cycle bound.  A kernel far below 1 on BOTH rooflines is waiting (barriers,
-latency): its lever is neither bytes nor instruction count.
+overlapped their issue) up to 2.0, the 2-cycle bound.  Measured on this pool (tools/ceilings/valu_issue.hip, independent
+register-only instructions, cycles per wave-instruction per SIMD at the nominal 2.4 GHz): one wave per SIMD 4.8-5.5 whatever
+the instruction; with two or four waves 2.4-2.6 for v_xor / v_and / v_bitop3 / v_add_u32 / v_mov / v_lshrrev / v_ashrrev /
+v_fma_f32 / v_mul_f32 (valu frac 1.5-1.65), 4.2-4.3 for v_lshlrev / v_lshl_or / v_and_or / v_or3 / v_bfi / v_bfe / v_perm /
+v_alignbit / v_bcnt / v_mul_lo / v_mul_u32_u24 / v_mad_u32_u24 / v_add3 / v_add_co / v_cvt and the 64-bit shift (0.93), 8.2
+for v_log / v_sin / v_sqrt (0.49) -- so the ceiling of a bit-sliced counter kernel (mostly bitop3 / xor / and) is ~1.5,
+that of a hash- or transpose-heavy one (multiplies, perm, alignbit) nearer 1.  A kernel far below 1 on BOTH rooflines is
+waiting (barriers, latency): its lever is neither bytes nor instruction count.
 """
 import argparse
 import collections
@@ -174,7 +180,8 @@ def main():
         f.write("mean us = kernel-trace duration (first launch of a group dropped); read = 2 x FETCH_SIZE, write = WRITE_SIZE "
                 "(separate --pmc passes, KB of 1024 B); frac = algorithmic bytes / mean / 8 TB/s\n\n")
         f.write("valu floor us = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz), valu frac = floor / mean us (the VALU-issue roofline of the "
-                "on-chip-bound kernels: 1.0 = every SIMD issuing from one stream for the whole launch, 2.0 = the SIMD-32 bound with >= 2 waves); "
+                "on-chip-bound kernels: 1.0 = every SIMD issuing from one stream for the whole launch, 2.0 = the SIMD-32 bound with >= 2 waves; measured ceiling with >= 2 waves per SIMD: ~1.5 for "
+                "bitop3 / xor / and / add streams, 0.93 for perm / alignbit / bfe / lshl_or / integer-multiply streams, tools/ceilings/valu_issue.hip); "
                 "wait = SQ_WAIT_ANY / SQ_WAVE_CYCLES; conflicts = SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS\n\n")
         f.write("| kernel | grid x wg | LDS | VGPR | launches | mean us | read MB | write MB | row | alg MB | frac | traffic/alg | valu floor us | valu frac | wait | conflicts |\n")
         f.write("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|\n")
