@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RLS_ABI_VERSION 9
+#define RLS_ABI_VERSION 10
 
 enum {
     RLS_OK = 0,
@@ -378,8 +378,10 @@ int rls_spin_reset(const rls_graph* g, const rls_spin_env* env, int state_bytes,
 /* One env step of SpinSystemUnbiased  ECO_S2V/src/envs/spinsystem_PECO.py:306-486 (f32, batched) and
  * ECO_S2V/src/envs/spinsystem.py:333-482 (f64, B = 1) on a shared graph: flip action[b]; gain = delta[b,a];
  * incremental update of delta (O(deg), cf. S2V_PPO/env.py:197-206); score += gain; reward (mode 0 DENSE = gain,
- * 1 BLS = max(score - best_before, 0), 2 CUSTOM_BLS = impr / (impr + 0.1)), divided by reward_div (n_spins under
- * norm_rewards, else 1); visited-state test against the hist_len earlier states of the episode and append
+ * 1 BLS = max(score - best_before, 0), 2 CUSTOM_BLS = impr / (impr + 0.1), 3 = impr / (impr + 0.05): CUSTOM_BLS for a caller
+ * whose score is twice the one kept here -- OptimisationTarget.ENERGY, spinsystem.py:531-543, run as CUT on the negated
+ * couplings: -E = 2 cut(-W) + const; with reward_div halved for modes 0 and 1 every reward is the reference's bit for bit), divided by
+ * reward_div (n_spins under norm_rewards, else 1); visited-state test against the hist_len earlier states of the episode and append
  * (when env->packed): reward -= stag_punishment on a revisit (use_stag), reward += basin_reward on a first
  * visit of a state with no improving flip (use_basin); best_score / best_spins tracking; last_flip[b, a] = hist_len + 1
  * (hist_len = the number of steps already taken this episode, also without the visited-state memory) and the four
@@ -401,6 +403,8 @@ int rls_spin_step(const rls_graph* g, const rls_spin_env* env, int state_bytes, 
  * rls_spin_reset_dense: after the caller has written the signed spins into row 0 of state: delta[b,i] = s_i sum_j W_ij s_j,
  * max_local T [B] = max_i sum_j W_ij (_get_immeditate_cuts_avaialable on all-ones spins, :162-168), weight_sum T [B] =
  * sum_ij W_ij, flags uint8 [B]: bit 0 = the reference draws the graph again (sum_i |sum_j W_ij| == 0 or max_local == 0, :164-169),
+ * bit 2 = that maximum is 0 although rows with a nonzero (negative) sum exist: max_local then holds the maximum over the NONZERO
+ * row sums, which is the rule of the single-instance numpy env (spinsystem.py:190-196: it goes on where the batched env draws again),
  * bit 1 = not a symmetric integer-valued matrix (the int32 gain cache cannot hold it; diagonal entries are allowed and count as
  * in the reference: flipping a changes the score by delta_a - 2 W_aa, :346-348); then everything
  * rls_spin_reset does, with the per-env max_local / weight_sum.  The caller reads flags before stepping. */

@@ -110,14 +110,18 @@ class SpinSystemOracle:
 class SpinSystemOracleF64:
     """The numpy single-instance env, rlsolver/methods/ECO_S2V/src/envs/spinsystem.py (SpinSystemUnbiased :588-661,
     step :333-482, reset :176-252, observation :484-495), restated in float64 with a DENSE matvec for the gains and
-    the action-parity-set visited memory of util_envs.py:355-381.  ECO_PECO_OBSERVABLES row order, OptimisationTarget.CUT;
-    ExtraAction.NONE or PASS (``extra_pass``: n + 1 actions, every array carries the reference's padding column, :226-233,
-    :252-262), infinite or finite memory (``memory_length``, :206-209, :398-404).  Pinned against
-    tests/golden/spinsystem_cpu.npz and spinsystem_options.npz."""
+    the action-parity-set visited memory of util_envs.py:355-381.  ECO_PECO_OBSERVABLES row order (``s2v=True``: S2V_OBSERVABLES,
+    the spin row alone); OptimisationTarget.CUT or ENERGY (``target``: score = -E = s'Ws / 2, :531-533, :632-647; immediate
+    rewards -2 s (W s), :498-499, :654-656); ExtraAction.NONE or PASS (``extra_pass``: n + 1 actions, every array carries the
+    reference's padding column, :226-233, :252-262), infinite or finite memory (``memory_length``, :206-209, :398-404),
+    reversible or irreversible spins (``reversible=False``: reset to all +1, :262-264; done once no spin is +1, :476-480).
+    Pinned against tests/golden/spinsystem_cpu.npz, spinsystem_options.npz and spinsystem_s2v.npz."""
     SPIN, IMMEDIATE, TIME_SINCE_FLIP, DIST_SCORE, DIST_STATE, GREEDY, TERMINATION = range(7)
 
     def __init__(self, W, max_steps, reward="DENSE", norm_rewards=False, basin_reward=None, stag_punishment=None,
-                 extra_pass=False, memory_length=None):
+                 extra_pass=False, memory_length=None, target="CUT", reversible=True, s2v=False, binary=True):
+        assert target in ("CUT", "ENERGY")
+        self.target, self.reversible, self.s2v, self.binary = target, reversible, s2v, binary
         self.W = np.asarray(W, np.float64)
         self.n = self.W.shape[0]
         self.na = self.n + int(extra_pass)                                     # n_actions
@@ -131,18 +135,28 @@ class SpinSystemOracleF64:
         self.W_obs[:self.n, :self.n] = self.W
 
     def _imm(self, s):
+        if self.target == "ENERGY":
+            return -1 * (2 * s * (self.W @ s))                                 # :498-499 on :654-656
         return s * (self.W @ s)                                                # :659-661
 
-    def reset(self, spins_signed):
+    def _score(self, s):
+        if self.target == "ENERGY":
+            return -1. * (-(s @ (self.W @ s)) / 2)                             # :531-533 on :644-647
+        return 0.25 * np.sum(self.W * (1 - np.outer(s, s)))                    # :601-607
+
+    def reset(self, spins_signed=None):
         n = self.n
         self.t = 0
         st = np.zeros((7, self.na))
+        if spins_signed is None:
+            assert not self.reversible, "reversible spins start from a random draw: pass it"
+            spins_signed = np.ones(n)                                          # :262-264
         st[0, :n] = np.asarray(spins_signed)[:n]
         imm = self._imm(st[0, :n])
         st[self.IMMEDIATE, :n] = imm / self.max_local
         st[self.GREEDY, :n] = 1 - np.sum(imm <= 0) / n                         # reset writes [:n_spins] only (:259-261)
         self.state = st
-        self.score = 0.25 * np.sum(self.W * (1 - np.outer(st[0, :n], st[0, :n])))      # :601-607
+        self.score = self._score(st[0, :n])
         self.best_score = self.best_obs_score = self.score
         self.best_spins = st[0, :n].copy()
         self.best_obs_spins = st[0, :n].copy()
@@ -156,7 +170,10 @@ class SpinSystemOracleF64:
 
     def observation(self):
         s = self.state.copy()
-        s[0] = (1 - s[0]) / 2                                                  # SpinBasis.BINARY (the padding spin 0 -> 0.5)
+        if self.binary:
+            s[0] = (1 - s[0]) / 2                                              # SpinBasis.BINARY (the padding spin 0 -> 0.5)
+        if self.s2v:
+            s = s[:1]
         return np.vstack((s, self.W_obs))
 
     def gains(self):
@@ -170,7 +187,10 @@ class SpinSystemOracleF64:
             delta = 0
         else:
             new[0, a] = -self.state[0, a]
-            delta = -1 * new[0, a] * (new[0, :n] @ self.W[:, a])               # _calculate_cut_change :631
+            if self.target == "ENERGY":
+                delta = -1. * (-2 * new[0, a] * (new[0, :n] @ self.W[:, a]))   # :542-543 on :626
+            else:
+                delta = -1 * new[0, a] * (new[0, :n] @ self.W[:, a])           # _calculate_cut_change :631
             self.score += delta
         self.state = new
         imm = self._imm(new[0, :n])
@@ -213,4 +233,7 @@ class SpinSystemOracleF64:
         st[self.GREEDY] = 1 - np.sum(imm <= 0) / n
         st[self.DIST_SCORE] = np.abs(self.score - self.best_obs_score) / self.max_local
         st[self.DIST_STATE, :n] = np.count_nonzero(self.best_obs_spins - st[0, :n])
-        return self.observation(), rew, self.t == self.max_steps
+        done = self.t == self.max_steps
+        if not self.reversible and not np.any(st[0, :n] > 0):                  # :476-480
+            done = True
+        return self.observation(), rew, done

@@ -163,6 +163,7 @@ __global__ __launch_bounds__(256) void k_spin_step(rls_spin_env env, int64_t B, 
     T rew;
     if (p.reward_mode == 1) rew = improvement > (T)0 ? improvement : (T)0;                              // BLS
     else if (p.reward_mode == 2) rew = improvement > (T)0 ? improvement / (improvement + (T)0.1) : (T)0; // CUSTOM_BLS
+    else if (p.reward_mode == 3) rew = improvement > (T)0 ? improvement / (improvement + (T)0.05) : (T)0; // CUSTOM_BLS, score in half units
     else rew = (T)gain;                                                                                  // DENSE
     rew = rew / (T)p.reward_div;                                                                        // norm_rewards
     const bool new_best = sc > best_before;
@@ -365,13 +366,13 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_spin_dense_prepare(const T* __restrict__ matrix, const T* __restrict__ state, int64_t B,
                                                              int64_t N, int R, int32_t* __restrict__ delta, T* __restrict__ max_local,
                                                              T* __restrict__ weight_sum, uint8_t* __restrict__ flags) {
-    __shared__ double s_max[4], s_abs[4], s_tot[4];
+    __shared__ double s_max[4], s_mnz[4], s_abs[4], s_tot[4];
     __shared__ int s_bad[4];
     const int lane = threadIdx.x & (kWave - 1), wv = threadIdx.x / kWave;
     const int64_t b = blockIdx.x;
     const T* m = matrix + b * N * N;
     const T* spins = state + b * R * N;
-    double wmax = -INFINITY, wabs = 0.0, wtot = 0.0;
+    double wmax = -INFINITY, wmnz = -INFINITY, wabs = 0.0, wtot = 0.0;   // wmnz: the maximum over the NONZERO row sums
     int bad = 0;
     for (int64_t i = wv; i < N; i += 4) {
         const T* row = m + i * N;
@@ -391,18 +392,23 @@ __global__ __launch_bounds__(256) void k_spin_dense_prepare(const T* __restrict_
         }
         if (lane == 0) delta[b * N + i] = (int32_t)((spins[i] > (T)0 ? 1.0 : -1.0) * dot);
         wmax = fmax(wmax, rs);
+        if (rs != 0.0) wmnz = fmax(wmnz, rs);
         wabs += fabs(rs);
         wtot += rs;
     }
     bad = ballot64(bad != 0) != 0;
-    if (lane == 0) { s_max[wv] = wmax; s_abs[wv] = wabs; s_tot[wv] = wtot; s_bad[wv] = bad; }
+    if (lane == 0) { s_max[wv] = wmax; s_mnz[wv] = wmnz; s_abs[wv] = wabs; s_tot[wv] = wtot; s_bad[wv] = bad; }
     __syncthreads();
     if (threadIdx.x == 0) {
         const double mx = fmax(fmax(s_max[0], s_max[1]), fmax(s_max[2], s_max[3]));
         const double ab = s_abs[0] + s_abs[1] + s_abs[2] + s_abs[3];
-        max_local[b] = (T)mx;
+        // the numpy env takes the maximum over the NONZERO entries (spinsystem.py:190-196): it differs from the batched env's
+        // rule only where that one draws again -- a zero maximum although rows with a (negative) sum exist -- and is delivered
+        // for exactly that case, with flag bit 2
+        const bool nz_case = mx == 0.0 && ab != 0.0;
+        max_local[b] = (T)(nz_case ? fmax(fmax(s_mnz[0], s_mnz[1]), fmax(s_mnz[2], s_mnz[3])) : mx);
         weight_sum[b] = (T)(s_tot[0] + s_tot[1] + s_tot[2] + s_tot[3]);
-        flags[b] = (uint8_t)((ab == 0.0 || mx == 0.0 ? 1 : 0) | ((s_bad[0] | s_bad[1] | s_bad[2] | s_bad[3]) ? 2 : 0));
+        flags[b] = (uint8_t)((ab == 0.0 || mx == 0.0 ? 1 : 0) | ((s_bad[0] | s_bad[1] | s_bad[2] | s_bad[3]) ? 2 : 0) | (nz_case ? 4 : 0));
     }
 }
 
@@ -719,7 +725,8 @@ static int spin_step_common(const rls_graph* g, const void* matrix, const void* 
     if (int rc = check_spin_env(env, state_bytes, num_rows, row_index, &rows)) return rc;
     if (B == 0) return RLS_OK;
     RLS_REQUIRE(action && reward, RLS_EINVAL, "action / reward is NULL");
-    RLS_REQUIRE(reward_mode >= 0 && reward_mode <= 2, RLS_EINVAL, "reward_mode must be 0 (DENSE), 1 (BLS), 2 (CUSTOM_BLS)");
+    RLS_REQUIRE(reward_mode >= 0 && reward_mode <= 3, RLS_EINVAL,
+                "reward_mode must be 0 (DENSE), 1 (BLS), 2 (CUSTOM_BLS), 3 (CUSTOM_BLS on a score kept in half units)");
     RLS_REQUIRE(max_local != 0.0 && reward_div != 0.0, RLS_EINVAL, "max_local_reward_available / reward_div is 0");
     RLS_REQUIRE(!(use_stag || use_basin) || env->hist, RLS_EINVAL, "stag_punishment / basin_reward need the visited-state memory");
     RLS_REQUIRE(!env->hist || (hist_len >= 0 && hist_len < env->hist_cap), RLS_EINVAL,

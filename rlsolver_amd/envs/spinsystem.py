@@ -109,7 +109,12 @@ class SpinSystem(Sharded):
                  stag_punishment: Optional[float] = None, basin_reward: Optional[float] = None,
                  device=None, include_adjacency: bool = True, dtype=torch.float32, graph_generator=None,
                  extra_action: ExtraAction = ExtraAction.NONE, memory_length: Optional[int] = None,
-                 env_offset: int = 0, seed: Optional[int] = None, group=None):
+                 env_offset: int = 0, seed: Optional[int] = None, group=None, _numpy_env_rules: bool = False,
+                 _score_scale: float = 1.0):
+        # _numpy_env_rules / _score_scale: set by SpinSystemUnbiased below, the single-instance numpy surface -- the maximum local
+        # reward is taken over the NONZERO entries (spinsystem.py:190-196; the batched env takes it over all and draws again at
+        # 0); rewards count a score kept in units of 1 / _score_scale (OptimisationTarget.ENERGY = 2 x CUT on the negated graph)
+        self._numpy_env_rules, self._score_scale = bool(_numpy_env_rules), float(_score_scale)
         # env_offset / seed / group: rlsolver_amd/seeding.py -- num_envs is this rank's share of a sharded batch, reset draws
         # are keyed by the global env id (a graph_generator carries its own env_offset: give it the same one)
         self._init_shard(env_offset, seed, group)
@@ -168,9 +173,10 @@ class SpinSystem(Sharded):
             self.graph = ops.DeviceGraph(csr, self.device, use_weights=True)
             wdeg = np.zeros(num_nodes, np.int64)
             np.add.at(wdeg, np.repeat(np.arange(num_nodes), np.diff(csr.rowptr)), csr.wgt)
-            self._max_local = float(wdeg.max())          # host copy: reading it back from the device synced every step
+            wmax = wdeg[wdeg != 0].max() if self._numpy_env_rules and np.any(wdeg != 0) else wdeg.max()
+            self._max_local = float(wmax)                # host copy: reading it back from the device synced every step
             self.max_local_reward_available_ = torch.full((num_envs,), self._max_local, device=self.device, dtype=dtype)
-            if float(wdeg.max()) == 0.0 or np.abs(wdeg).sum() == 0:
+            if float(wmax) == 0.0 or np.abs(wdeg).sum() == 0:
                 raise ValueError("empty graph / zero max local reward (the reference re-draws the graph here)")
             self._matrix = None
             self._weight_sum = int(csr.wgt.sum())         # sum of W over ordered pairs
@@ -289,9 +295,12 @@ class SpinSystem(Sharded):
                 self._matrix = self._draw_matrix()
                 _t.spin_reset_dense(self._matrix, self._env_handle, self._state, self._rows, self.max_local_reward_available_,
                                     self._weight_sum_env, self._flags)
-                f = self._flags.max().to(torch.int64)
+                f = self._flags.to(torch.int64)
+                # bit 2: a zero maximum over all rows although nonzero ones exist -- the numpy env goes on with the maximum over those
+                # (already in max_local), the batched env draws again
+                again = (f & 1) & (~(f >> 2) & 1) if self._numpy_env_rules else f & 1
                 # (a redraw is a decision about the WHOLE batch: every rank of a sharded one takes it together)
-                flags = self._global_sum(torch.stack([f & 1, (f >> 1) & 1])).tolist()   # the one host read of a reset (the reference's .any() tests)
+                flags = self._global_sum(torch.stack([again.max(), ((f >> 1) & 1).max()])).tolist()   # the one host read of a reset (the reference's .any() tests)
                 if flags[1]:
                     raise ValueError("graph_generator.get() must return symmetric integer-valued matrices")
                 if not flags[0]:
@@ -351,9 +360,14 @@ class SpinSystem(Sharded):
         key = (self.reward_signal, self.norm_rewards, self.stag_punishment, self.basin_reward, self.max_steps)
         c = getattr(self, "_consts", None)
         if c is None or c["key"] != key:
+            mode = _REWARD_MODE[self.reward_signal]
+            if self._score_scale != 1.0:              # (only ever 2: the ABI's mode 3 is CUSTOM_BLS on a score in half units)
+                assert self._score_scale == 2.0
+                mode = 3 if mode == 2 else mode
             c = self._consts = dict(
-                key=key, mode=_REWARD_MODE[self.reward_signal],
-                div=float(self.n_spins) if self.norm_rewards else 1.0,
+                key=key, mode=mode,
+                # (the ratio impr / (impr + eps) of CUSTOM_BLS is scale-free once eps is halved: only DENSE / BLS count double)
+                div=(float(self.n_spins) if self.norm_rewards else 1.0) / (1.0 if mode == 3 else self._score_scale),
                 tail=(self.stag_punishment is not None, self._round(self.stag_punishment or 0.0),
                       self.basin_reward is not None, self._round(self.basin_reward or 0.0)))
         return c
@@ -446,9 +460,12 @@ class SpinSystemFactory:
     """SpinSystemFactory.get of spinsystem_PECO.py:16-47 (what ``ising_env.make("SpinSystem", ...)`` of core.py:9-16 calls, as
     train_PECO.py:75-86 does): the batched env on the generator's graphs -- and of spinsystem.py:24-60 (train_ECO.py:83-92):
     with a single-instance generator (no ``num_envs``, get() -> [N, N]) and no ``num_envs`` argument, the single-instance numpy
-    surface ``SpinSystemUnbiased``.  OptimisationTarget.CUT, reversible spins, unbiased graphs; the batched env additionally
-    ExtraAction.NONE and infinite memory (the reference's batched env cannot be constructed otherwise, and dqn_PECO.py:252
-    asserts it); anything else raises NotImplementedError instead of silently doing something different."""
+    surface ``SpinSystemUnbiased`` with every option its callers use: CUT or ENERGY, reversible or irreversible spins (S2V-DQN:
+    train_S2V.py:37-47), NONE or PASS, infinite or finite memory.  The BATCHED env: OptimisationTarget.CUT, reversible spins,
+    ExtraAction.NONE, infinite memory -- the reference's batched env cannot be constructed with ENERGY, an extra action or a
+    finite memory, its irreversible reset fills env 0's rows and leaves the other envs' spins at 0 (facts recorded in
+    tests/golden/spinsystem_options.npz / spinsystem_s2v.npz), and dqn_PECO.py:252 asserts NONE.  Unbiased graphs only (no
+    caller builds a biased generator).  Anything else raises NotImplementedError instead of silently doing something different."""
 
     @staticmethod
     def get(graph_generator=None, max_steps=20, observables=ECO_PECO_OBSERVABLES, reward_signal=RewardSignal.DENSE,
@@ -457,14 +474,14 @@ class SpinSystemFactory:
             reversible_spins=True, init_snap=None, seed=None, device=None, num_envs=None, if_greedy=False):
         single = num_envs is None and getattr(graph_generator, "num_envs", None) is None
         unsupported = [name for name, bad in (("extra_action", extra_action.name != "NONE" and not (single and extra_action.name == "PASS")),
-                                              ("optimisation_target", optimisation_target.name != "CUT"),
+                                              ("optimisation_target", optimisation_target.name != "CUT" and not (single and optimisation_target.name == "ENERGY")),
                                               ("memory_length", memory_length is not None and not single),
-                                              ("reversible_spins", not reversible_spins),
+                                              ("reversible_spins", not reversible_spins and not single),
                                               ("init_snap", init_snap is not None),
                                               ("biased graphs", bool(getattr(graph_generator, "biased", False)))) if bad]
         if unsupported:
-            raise NotImplementedError("SpinSystem on the device supports OptimisationTarget.CUT, reversible spins, unbiased graphs, and "
-                                      "on the batched env ExtraAction.NONE and infinite memory; got " + ", ".join(unsupported))
+            raise NotImplementedError("SpinSystem on the device supports unbiased graphs and no init_snap; the batched env additionally only "
+                                      "OptimisationTarget.CUT, reversible spins, ExtraAction.NONE and infinite memory; got " + ", ".join(unsupported))
         if seed is not None:
             np.random.seed(seed)                              # spinsystem_PECO.py:98-99 / spinsystem.py:95-96
         same = lambda enum, v: enum[v.name]                   # the reference's own enum members are accepted by name
@@ -473,7 +490,8 @@ class SpinSystemFactory:
             return SpinSystemUnbiased(None, None, max_steps, obs, same(RewardSignal, reward_signal), same(SpinBasis, spin_basis),
                                       norm_rewards, horizon_length, stag_punishment, basin_reward, device,
                                       graph_generator=graph_generator, extra_action=same(ExtraAction, extra_action),
-                                      memory_length=memory_length)
+                                      memory_length=memory_length, reversible_spins=reversible_spins,
+                                      optimisation_target=same(OptimisationTarget, optimisation_target))
         if num_envs is None:
             num_envs = graph_generator.num_envs
         return SpinSystem(None, None, num_envs, max_steps, obs, same(RewardSignal, reward_signal),
@@ -496,7 +514,19 @@ class SpinSystemUnbiased:
         step(action: int) -> (obs, reward: float, done: bool, None)                      (:333-482)
 
     attrs: n_spins, max_steps, current_step, score, best_score, best_spins, state (np [R, N]), matrix.
-    OptimisationTarget.CUT, reversible spins (what ECO / S2V use); ExtraAction.NONE or PASS, infinite or finite memory.
+    OptimisationTarget.CUT or ENERGY, reversible or irreversible spins, ExtraAction.NONE or PASS, infinite or finite memory,
+    unbiased graphs (no caller in the reference builds a biased generator).
+
+    ``reversible_spins=False`` -- what S2V-DQN trains and infers with (train_S2V.py:37-47, inference.py:59) -- starts an
+    episode from all +1 (spinsystem.py:262-264), reports done as soon as no spin is +1 (:476-480) and answers
+    get_allowed_action_states() with the one spin value an agent may still flip (:514-527); like the reference, step()
+    itself does not refuse to flip a spin back.
+
+    ``optimisation_target=OptimisationTarget.ENERGY`` (the default of SpinSystemFactory.get): score = -E = s'Ws / 2
+    (:531-533, :644-647), immediate rewards -2 s (W s) (:498-499, :654-656).  -E = 2 cut_{-W}(s) + sum(W) / 2, so the
+    HIP env runs as CUT on the NEGATED couplings with its rewards counted double (reward_div halved; CUSTOM_BLS as the
+    ABI's mode 3): every normalised row is the same number, every score and reward the reference's bit for bit
+    (tests/golden/spinsystem_s2v.npz), and the observation's matrix rows are negated back on the way out.
 
     With ``extra_action=ExtraAction.PASS`` (the reference's default) there are n_spins + 1 actions; action n_spins flips
     nothing (spinsystem.py:349-351).  The reference then carries a padding column through its arrays -- state [R, N + 1],
@@ -508,11 +538,12 @@ class SpinSystemUnbiased:
     class _OneGraph:
         """A single-instance generator (get() -> [N, N] array, ECO_S2V/src/envs/util_envs.py:87-330) as a batch of one."""
 
-        def __init__(self, gg):
-            self.gg, self.n_spins, self.biased = gg, int(gg.n_spins), bool(getattr(gg, "biased", False))
+        def __init__(self, gg, negate=False):
+            self.gg, self.n_spins, self.biased, self.negate = gg, int(gg.n_spins), bool(getattr(gg, "biased", False)), negate
 
         def get(self):
-            return torch.as_tensor(np.asarray(self.gg.get(), dtype=np.float64))[None]
+            m = np.asarray(self.gg.get(), dtype=np.float64)
+            return torch.as_tensor(0.0 - m if self.negate else m)[None]
 
     def __init__(self, mygraph, num_nodes: Optional[int], max_steps: int = 20,
                  observables: Sequence[Observable] = ECO_PECO_OBSERVABLES,
@@ -520,15 +551,26 @@ class SpinSystemUnbiased:
                  norm_rewards: bool = False, horizon_length: Optional[int] = None,
                  stag_punishment: Optional[float] = None, basin_reward: Optional[float] = None, device=None,
                  init_spins=None, graph_generator=None, extra_action: ExtraAction = ExtraAction.NONE,
-                 memory_length: Optional[int] = None):
+                 memory_length: Optional[int] = None, reversible_spins: bool = True,
+                 optimisation_target: OptimisationTarget = OptimisationTarget.CUT):
         """``graph_generator`` (instead of mygraph): a fresh graph at every reset, as the ECO / S2V training loops run their
         envs (train_ECO.py:83-94; any object with n_spins and get() -> [N, N] symmetric integer-valued array)."""
-        gg = self._OneGraph(graph_generator) if graph_generator is not None else None
+        if optimisation_target.name not in ("CUT", "ENERGY"):
+            raise NotImplementedError(f"Optimisation target {optimisation_target} not recognised.")
+        self.optimisation_target = OptimisationTarget[optimisation_target.name]
+        self._energy = self.optimisation_target == OptimisationTarget.ENERGY
+        self.reversible_spins = bool(reversible_spins)
+        if getattr(graph_generator, "biased", False):
+            raise NotImplementedError("biased graph generators are not supported")
+        gg = self._OneGraph(graph_generator, negate=self._energy) if graph_generator is not None else None
         num_nodes = gg.n_spins if gg is not None and num_nodes is None else num_nodes
+        if self._energy and mygraph is not None:
+            mygraph = [(int(a), int(b), -w) for a, b, w in mygraph]
         self._env = SpinSystem(mygraph, num_nodes, 1, max_steps, observables, reward_signal, spin_basis, norm_rewards,
                                horizon_length, stag_punishment, basin_reward, device, include_adjacency=True,
                                dtype=torch.float64, graph_generator=gg, extra_action=ExtraAction[extra_action.name],
-                               memory_length=memory_length)
+                               memory_length=memory_length, _numpy_env_rules=True, _score_scale=2.0 if self._energy else 1.0)
+        self._env.reversible_spins, self._env.optimisation_target = self.reversible_spins, self.optimisation_target
         self._pass = self._env._pass
         self.extra_action, self.memory_length = self._env.extra_action, memory_length
         self.n_spins, self.max_steps, self.n_actions = num_nodes, max_steps, num_nodes + int(self._pass)
@@ -563,9 +605,11 @@ class SpinSystemUnbiased:
 
     def _obs(self, obs):
         o = obs[0].cpu().numpy()
+        R, N = len(self._env.observables), self.n_spins
+        if self._energy:
+            o[R:] = 0.0 - o[R:]                  # the env ran on -W: the agent sees W
         if not self._pass:
             return o
-        R, N = len(self._env.observables), self.n_spins
         out = np.zeros((R + N + 1, N + 1), dtype=o.dtype)
         out[:R] = self._pad_rows(o[:R], self._env.spin_basis == SpinBasis.BINARY)
         out[R:R + N, :N] = o[R:]                 # matrix_obs: the couplings padded with a zero row and column (:222-225)
@@ -575,6 +619,8 @@ class SpinSystemUnbiased:
         self._last_pass, self._stepped = 0, False
         if spins is not None:
             spins = np.asarray(spins, dtype=np.float64)[: self.n_spins][None, :]
+        elif not self.reversible_spins:
+            spins = np.ones((1, self.n_spins), dtype=np.float64)      # every spin may still be flipped (spinsystem.py:262-264; signed +1)
         return self._obs(self._env.reset(spins))
 
     def step(self, action):
@@ -583,28 +629,43 @@ class SpinSystemUnbiased:
             self._last_pass = self._env.current_step + 1
         obs, rew, done = self._env.step(torch.tensor([action], dtype=torch.int64))
         self._stepped = True
-        return self._obs(obs), float(rew[0]), bool(done[0]), None
+        done = bool(done[0])
+        if not self.reversible_spins:                                  # no more spins to flip --> done (:476-480)
+            row0 = obs[0, 0]
+            left = (row0 == 0) if self._env.spin_basis == SpinBasis.BINARY else (row0 > 0)
+            done = done or not bool(left.any())
+        return self._obs(obs), float(rew[0]), done, None
 
     def get_observation(self):
         return self._obs(self._env.get_observation())
 
-    max_local_reward_available = property(lambda self: float(self._env.max_local_reward_available_[0]))
+    def _weight_sum(self) -> float:
+        """sum of the DEVICE env's couplings over ordered pairs (= -sum(W) under ENERGY)."""
+        return float(self._env._weight_sum_env[0]) if self._env._dense else float(self._env._weight_sum)
+
+    def _score_out(self, v: float) -> float:
+        """A score of the device env in the caller's units: -E = 2 cut_{-W} + sum(W) / 2 under ENERGY (exact: integers and halves)."""
+        return 2.0 * v - self._weight_sum() / 2.0 if self._energy else v
+
+    max_local_reward_available = property(lambda self: float(self._env.max_local_reward_available_[0]) * (2.0 if self._energy else 1.0))
     current_step = property(lambda self: self._env.current_step)
-    score = property(lambda self: float(self._env.score[0]))
-    best_score = property(lambda self: float(self._env.best_score[0]))
+    score = property(lambda self: self._score_out(float(self._env.score[0])))
+    best_score = property(lambda self: self._score_out(float(self._env.best_score[0])))
     best_spins = property(lambda self: self._env.best_spins[0].cpu().numpy())
     state = property(lambda self: self._pad_rows(self._env.state[0].cpu().numpy(), False))
-    best_obs_score = property(lambda self: float(self._env.best_obs_score[0]))
-    matrix = property(lambda self: (self._env.matrix[0] if self._env._dense else self._env.matrix).cpu().numpy())
+    best_obs_score = property(lambda self: self._score_out(float(self._env.best_obs_score[0])))
+
+    @property
+    def matrix(self):
+        m = (self._env.matrix[0] if self._env._dense else self._env.matrix).cpu().numpy()
+        return 0.0 - m if self._energy else m
 
     def get_immeditate_rewards_avaialable(self, spins=None):
-        return self._env._delta[0].cpu().numpy().astype(np.float64)
+        d = self._env._delta[0].cpu().numpy().astype(np.float64)
+        return 2.0 * d if self._energy else d     # -2 s (W s) = 2 s ((-W) s)  (spinsystem.py:498-499)
 
-    def calculate_cut(self, spins=None):
-        """spinsystem.py:601-607: the env's own spins, or foreign ones in the env's basis (checked and converted like
-        _format_spins_to_signed, :548-557)."""
-        if spins is None:
-            return float(self._env.calculate_cut()[0])
+    def _signed(self, spins):
+        """_format_spins_to_signed, spinsystem.py:548-557."""
         sp = np.asarray(spins, dtype=np.float64)[: self.n_spins]
         if self._env.spin_basis == SpinBasis.BINARY:
             if not np.isin(sp, [0, 1]).all():
@@ -612,10 +673,25 @@ class SpinSystemUnbiased:
             sp = 2 * sp - 1
         elif not np.isin(sp, [-1, 1]).all():
             raise Exception("SpinSystem is configured for signed spins ([-1,1]).")
-        return float(self._env.calculate_cut(sp[None, :])[0])
+        return sp
+
+    def _device_cut(self, spins=None) -> float:
+        return float(self._env.calculate_cut(None if spins is None else self._signed(spins)[None, :])[0])
+
+    def calculate_cut(self, spins=None):
+        """spinsystem.py:601-607: the env's own spins, or foreign ones in the env's basis (checked and converted like
+        _format_spins_to_signed, :548-557).  (Under ENERGY the device env holds -W: cut_W = -cut_{-W}.)"""
+        c = self._device_cut(spins)
+        return 0.0 - c if self._energy else c
+
+    def calculate_energy(self, spins=None):
+        """spinsystem.py:590-599: E = -s'Ws / 2."""
+        c = self._device_cut(spins)
+        return 0.0 - (2.0 * c - self._weight_sum() / 2.0) if self._energy else 2.0 * c - self._weight_sum() / 2.0
 
     def calculate_score(self, spins=None):
-        return self.calculate_cut(spins)
+        """spinsystem.py:529-536."""
+        return -1. * self.calculate_energy(spins) if self._energy else self.calculate_cut(spins)
 
     def seed(self, seed=None):
         return self._env.seed()
@@ -624,7 +700,12 @@ class SpinSystemUnbiased:
         self._env.set_seed(seed)
 
     def get_best_cut(self):
+        if self._energy:                                              # spinsystem.py:609-613
+            raise NotImplementedError("Can't return best cut when optimisation target is set to energy.")
         return self.best_score
 
     def get_allowed_action_states(self):
-        return self._env.get_allowed_action_states()
+        """spinsystem.py:514-527: both spin values while spins are reversible, else the value of a spin not flipped yet."""
+        if self.reversible_spins:
+            return self._env.get_allowed_action_states()
+        return 0 if self._env.spin_basis == SpinBasis.BINARY else 1

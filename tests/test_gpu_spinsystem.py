@@ -612,3 +612,126 @@ def test_inference_twin_against_oracle_at_size():
         assert np.array_equal(o[:, :7].cpu().numpy(), wo) and np.array_equal(d.cpu().numpy(), wd), t
         assert np.array_equal(env.get_best_cut().cpu().numpy(), ora.best_score)
     assert np.array_equal(env.best_spins.cpu().numpy(), ora.best_spins)
+
+
+def _s2v_case(cname, n):
+    from rlsolver_amd.envs.spinsystem import (ECO_PECO_OBSERVABLES, S2V_OBSERVABLES, ExtraAction, OptimisationTarget, RewardSignal,
+                                              SpinBasis)
+    E, C = OptimisationTarget.ENERGY, OptimisationTarget.CUT
+    return {
+        "s2v": dict(observables=S2V_OBSERVABLES, reward_signal=RewardSignal.DENSE, extra_action=ExtraAction.NONE, optimisation_target=C,
+                    spin_basis=SpinBasis.BINARY, norm_rewards=True, reversible_spins=False),
+        "eco_irreversible": dict(observables=ECO_PECO_OBSERVABLES, reward_signal=RewardSignal.BLS, extra_action=ExtraAction.NONE,
+                                 optimisation_target=C, spin_basis=SpinBasis.SIGNED, norm_rewards=True, basin_reward=1.0 / n,
+                                 reversible_spins=False),
+        "defaults": dict(),                       # SpinSystemFactory.get(gg, max_steps): DENSE, PASS, ENERGY, SIGNED, reversible
+        "energy_bls_mem": dict(observables=ECO_PECO_OBSERVABLES, reward_signal=RewardSignal.BLS, extra_action=ExtraAction.PASS,
+                               optimisation_target=E, spin_basis=SpinBasis.BINARY, norm_rewards=True, basin_reward=1.0 / n, memory_length=3),
+        "energy_custom_stag": dict(observables=ECO_PECO_OBSERVABLES, reward_signal=RewardSignal.CUSTOM_BLS, extra_action=ExtraAction.NONE,
+                                   optimisation_target=E, spin_basis=SpinBasis.SIGNED, norm_rewards=False, basin_reward=0.25,
+                                   stag_punishment=0.125),
+        "energy_irreversible": dict(observables=ECO_PECO_OBSERVABLES, reward_signal=RewardSignal.DENSE, extra_action=ExtraAction.NONE,
+                                    optimisation_target=E, spin_basis=SpinBasis.BINARY, norm_rewards=True, reversible_spins=False),
+        "energy_isolated": dict(observables=ECO_PECO_OBSERVABLES, reward_signal=RewardSignal.BLS, extra_action=ExtraAction.NONE,
+                                optimisation_target=E, spin_basis=SpinBasis.SIGNED, norm_rewards=False),
+    }[cname]
+
+
+@pytest.mark.parametrize("via", ["shared_graph", "generator"])
+@pytest.mark.parametrize("cname", ["s2v", "eco_irreversible", "defaults", "energy_bls_mem", "energy_custom_stag", "energy_irreversible",
+                                   "energy_isolated"])
+def test_spinsystem_s2v_energy_golden(golden, cname, via):
+    """spinsystem_s2v.npz: traces of the reference's numpy env with IRREVERSIBLE spins (S2V-DQN's env, train_S2V.py:37-47) and with
+    OptimisationTarget.ENERGY (the default of SpinSystemFactory.get), through ``ising_env.make`` exactly as the training scripts
+    call it (a generator -> per-env couplings on the device) and through the class on a shared graph: observation, state, reward,
+    done (early, once no spin is +1), scores, best / best observable score, the maximum local reward (over the NONZERO entries:
+    negative on the positive graph with an isolated node), immediate rewards, energy and cut -- bit for bit."""
+    from rlsolver_amd.envs import spinsystem as sp
+    z = golden("spinsystem_s2v")
+    g = z["graph_isolated"] if cname == "energy_isolated" else z["graph"]
+    n = 12 if cname == "energy_isolated" else int(g[:, :2].max()) + 1
+    cfg = _s2v_case(cname, n)
+    T = int(z[f"{cname}/max_steps"])
+    if via == "generator":
+        W = np.zeros((n, n))
+        for a, b, w in g:
+            W[a, b] = W[b, a] = w
+
+        class Fixed:
+            n_spins, biased = n, False
+
+            def get(self, with_padding=False):
+                return W.copy()
+        env = sp.make("SpinSystem", Fixed(), T, device=DEV, **cfg)
+    else:
+        full = dict(extra_action=sp.ExtraAction.PASS, optimisation_target=sp.OptimisationTarget.ENERGY) if cname == "defaults" else cfg
+        env = sp.SpinSystemUnbiased([tuple(int(v) for v in r) for r in g], n, max_steps=T, device=DEV, **full)
+    assert isinstance(env, sp.SpinSystemUnbiased)
+    irreversible = cfg.get("reversible_spins", True) is False
+    assert env.reversible_spins == (not irreversible)
+    R, na = len(env.observables), int(z[f"{cname}/n_actions"])
+    assert env.n_actions == na
+    obs = env.reset() if irreversible else env.reset(z[f"{cname}/spins0"])
+    assert env.max_local_reward_available == float(z[f"{cname}/max_local"])
+    allowed = env.get_allowed_action_states()
+    assert np.array_equal(np.asarray(allowed).reshape(-1), z[f"{cname}/allowed"]) and isinstance(allowed, int) == irreversible
+    assert obs.shape == (R + na, na) and np.array_equal(obs, z[f"{cname}/obs0"])
+    assert np.array_equal(env.state, z[f"{cname}/state0"]) and env.score == float(z[f"{cname}/score0"])
+    assert np.array_equal(env.get_immeditate_rewards_avaialable(), z[f"{cname}/imm0"])
+    acts = z[f"{cname}/actions"]
+    for t, a in enumerate(acts):
+        o, r, d, info = env.step(int(a))
+        assert np.array_equal(o[:R], z[f"{cname}/obs"][t]), t
+        assert np.array_equal(env.state, z[f"{cname}/state"][t]), t
+        assert r == z[f"{cname}/rew"][t] and d == bool(z[f"{cname}/done"][t]), t
+        assert env.score == z[f"{cname}/score"][t] and env.best_score == z[f"{cname}/best_score"][t], t
+        assert env.best_obs_score == z[f"{cname}/best_obs_score"][t], t
+    assert d and (len(acts) < T) == irreversible
+    assert np.array_equal(o[R:], z[f"{cname}/adj_rows"]) and np.array_equal(env.best_spins, z[f"{cname}/best_spins"])
+    assert np.array_equal(env.get_immeditate_rewards_avaialable(), z[f"{cname}/imm_end"])
+    if f"{cname}/energy_end" in z.files:
+        assert env.calculate_energy() == float(z[f"{cname}/energy_end"]) and env.calculate_cut() == float(z[f"{cname}/cut_end"])
+        assert env.calculate_score() == env.score
+        with pytest.raises(NotImplementedError):
+            env.get_best_cut()                                          # facts/energy_get_best_cut
+        assert np.array_equal(env.matrix, o[R:R + n, :n])
+
+
+def test_spinsystem_s2v_energy_against_oracle_random():
+    """ENERGY / irreversible at sizes past one packed word with the visited-state rewards and a finite memory, random actions,
+    against the float64 restatement; the batched factory keeps refusing what the reference's batched env cannot run."""
+    from oracle.oracle_spin import SpinSystemOracleF64
+    from rlsolver_amd.envs import spinsystem as sp
+    from rlsolver_amd.graph import generate_gnm
+    for n, m, M, rev in ((130, 420, 5, True), (70, 200, None, False), (127, 380, 3, False)):
+        rng = np.random.RandomState(n + (M or 0))
+        mg = [(a, b, int(rng.choice([-1, 1, 2]))) for a, b, _ in generate_gnm(n, m, 4)]
+        W = np.zeros((n, n))
+        for a, b, w in mg:
+            W[a, b] = W[b, a] = w
+        T = 90
+        env = sp.SpinSystemUnbiased(mg, n, max_steps=T, observables=sp.ECO_PECO_OBSERVABLES, spin_basis=sp.SpinBasis.BINARY, device=DEV,
+                                    reward_signal=sp.RewardSignal.CUSTOM_BLS, norm_rewards=True, basin_reward=0.5, stag_punishment=0.25,
+                                    extra_action=sp.ExtraAction.PASS, memory_length=M, reversible_spins=rev,
+                                    optimisation_target=sp.OptimisationTarget.ENERGY)
+        ora = SpinSystemOracleF64(W, T, reward="CUSTOM_BLS", norm_rewards=True, basin_reward=0.5, stag_punishment=0.25, extra_pass=True,
+                                  memory_length=M, target="ENERGY", reversible=rev)
+        s0 = (2 * rng.randint(0, 2, size=n) - 1).astype(np.float64)
+        assert np.array_equal(env.reset(s0 if rev else None), ora.reset(s0 if rev else None))
+        assert env.max_local_reward_available == ora.max_local
+        prev = 0
+        for t in range(T):
+            a = int(rng.randint(0, n))
+            a = prev if t % 4 == 3 else (n if t % 7 == 2 else a)
+            prev = a
+            o, r, d, _ = env.step(a)
+            wo, wr, wd = ora.step(a)
+            assert np.array_equal(o, wo) and r == wr and d == wd, (n, M, t)
+            assert env.score == ora.score and env.best_obs_score == ora.best_obs_score and env.best_score == ora.best_score
+    from rlsolver_amd.envs.util_envs_PECO import SetGraphGenerator
+    batch = SetGraphGenerator(np.zeros((2, 3, 3), dtype=np.float32) + np.array([[0, 1, 0], [1, 0, -1], [0, -1, 0]], dtype=np.float32),
+                              device=DEV)
+    for bad in (dict(optimisation_target=sp.OptimisationTarget.ENERGY), dict(reversible_spins=False)):
+        with pytest.raises(NotImplementedError):
+            sp.SpinSystemFactory.get(graph_generator=batch, **{**dict(extra_action=sp.ExtraAction.NONE,
+                                                                    optimisation_target=sp.OptimisationTarget.CUT), **bad})

@@ -131,3 +131,56 @@ def test_spin_oracle_inference_twin_golden(golden, gname):
         assert np.array_equal(env.best_score, z[f"{gname}/best_score"][t])
     assert np.array_equal(env.best_spins, z[f"{gname}/best_spins"])
     assert np.array_equal(W, z[f"{gname}/adj_rows"])
+
+
+S2V_CASES = {
+    "s2v": dict(reward="DENSE", norm_rewards=True, reversible=False, s2v=True, binary=True),
+    "eco_irreversible": dict(reward="BLS", norm_rewards=True, basin_reward=1.0 / 20, reversible=False, binary=False),
+    "defaults": dict(reward="DENSE", extra_pass=True, target="ENERGY", binary=False),
+    "energy_bls_mem": dict(reward="BLS", norm_rewards=True, basin_reward=1.0 / 20, extra_pass=True, memory_length=3, target="ENERGY", binary=True),
+    "energy_custom_stag": dict(reward="CUSTOM_BLS", basin_reward=0.25, stag_punishment=0.125, target="ENERGY", binary=False),
+    "energy_irreversible": dict(reward="DENSE", norm_rewards=True, reversible=False, target="ENERGY", binary=True),
+    "energy_isolated": dict(reward="BLS", target="ENERGY", binary=False),
+}
+
+
+@pytest.mark.parametrize("cname", sorted(S2V_CASES))
+def test_f64_oracle_s2v_energy_golden(golden, cname):
+    """spinsystem_s2v.npz: irreversible spins (S2V-DQN's config, train_S2V.py:37-47) and OptimisationTarget.ENERGY (the default of
+    SpinSystemFactory.get) on the reference's numpy env: the restatement reproduces state, observation, rewards, done, scores,
+    the maximum local reward (over the NONZERO entries: negative on the positive graph with an isolated node) bit for bit."""
+    z = golden("spinsystem_s2v")
+    g = z["graph_isolated"] if cname == "energy_isolated" else z["graph"]
+    n = 12 if cname == "energy_isolated" else int(g[:, :2].max()) + 1
+    W = np.zeros((n, n))
+    for a, b, w in g:
+        W[a, b] = W[b, a] = w
+    cfg = S2V_CASES[cname]
+    T = int(z[f"{cname}/max_steps"])
+    env = SpinSystemOracleF64(W, T, **cfg)
+    R = 1 if cfg.get("s2v") else 7
+    assert env.na == int(z[f"{cname}/n_actions"]) and env.max_local == float(z[f"{cname}/max_local"])
+    obs = env.reset(None if not cfg.get("reversible", True) else z[f"{cname}/spins0"])
+    assert np.array_equal(env.state[0, :n], z[f"{cname}/spins0"])
+    assert np.array_equal(obs, z[f"{cname}/obs0"]) and np.array_equal(env.state[:R], z[f"{cname}/state0"])
+    assert env.score == float(z[f"{cname}/score0"]) and np.array_equal(env.gains(), z[f"{cname}/imm0"])
+    acts = z[f"{cname}/actions"]
+    for t, a in enumerate(acts):
+        o, r, d = env.step(int(a))
+        assert np.array_equal(o[:R], z[f"{cname}/obs"][t]), t
+        assert np.array_equal(env.state[:R], z[f"{cname}/state"][t]), t
+        assert r == z[f"{cname}/rew"][t] and d == bool(z[f"{cname}/done"][t]), t
+        assert env.score == z[f"{cname}/score"][t] and env.best_score == z[f"{cname}/best_score"][t]
+        assert env.best_obs_score == z[f"{cname}/best_obs_score"][t], t
+    assert d and (len(acts) < T) == (cname in ("s2v", "eco_irreversible", "energy_irreversible"))   # done early: no spin left at +1
+    assert np.array_equal(o[R:], z[f"{cname}/adj_rows"]) and np.array_equal(env.best_spins, z[f"{cname}/best_spins"])
+    assert np.array_equal(env.gains(), z[f"{cname}/imm_end"])
+
+
+def test_reference_facts_about_batched_s2v_options(golden):
+    """The BATCHED reference env with these options: ENERGY cannot be constructed (AttributeError in its constructor); irreversible
+    spins construct and step, but the reset line `state[0, :n_spins] = 1` (spinsystem_PECO.py:221) fills every ROW of env 0 and
+    leaves the other envs' spins at 0 -- not a behaviour to reproduce: the batched factory here refuses both."""
+    z = golden("spinsystem_s2v")
+    assert str(z["facts/batched_energy_ctor"]) == "AttributeError" and str(z["facts/energy_get_best_cut"]) == "NotImplementedError"
+    assert str(z["facts/batched_irreversible_ctor"]) == "ok" and str(z["facts/batched_irreversible_step"]) == "ok"

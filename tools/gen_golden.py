@@ -1180,6 +1180,152 @@ def gen_spinsystem_options():
     save("spinsystem_options", **out)
 
 
+def gen_spinsystem_s2v():
+    """The two options of the numpy single-instance env that its callers and its own defaults switch on beyond
+    spinsystem_options: IRREVERSIBLE spins -- what S2V-DQN trains and infers with (train_S2V.py:37-47, inference.py:59,
+    select_best_neural_network.py:54-66: reset to all +1, spinsystem.py:262-264; done as soon as no spin is +1, :476-480;
+    get_allowed_action_states() -> 1 | 0, :514-527) -- and OptimisationTarget.ENERGY, the default of SpinSystemFactory.get
+    (:31; score = -E = s'Js / 2, :531-533, :632-647; immediate rewards -2 s (J s), :498-499, :654-656; max local reward over the
+    NONZERO entries, :190-196).  Traces of the reference's own env: S2V's config; ECO's config on irreversible spins with a
+    spin flipped back; the factory's literal defaults; ENERGY with each reward signal, PASS, a finite memory and the
+    visited-state rewards; ENERGY on a positive graph with an isolated node (every nonzero immediate reward at all-ones is
+    negative: the maximum the normalised rows divide by is negative, and the zero row sum must not win it)."""
+    from rlsolver.methods.ECO_S2V.src.envs import spinsystem as spc
+    from rlsolver.methods.ECO_S2V.src.envs import spinsystem_PECO as spb
+    from rlsolver.methods.ECO_S2V.src.envs import util_envs_PECO as upe
+    from rlsolver.methods.ECO_S2V.src.envs.util_envs import (ECO_PECO_OBSERVABLES, S2V_OBSERVABLES, EdgeType, ExtraAction,
+                                                             GraphGenerator, OptimisationTarget, RewardSignal, SpinBasis)
+    from rlsolver.methods.util_read_data import read_mygraph
+    out = {}
+    mygraph = read_mygraph(os.path.join(DATA, GRAPHS["PL_20_ID0"]))
+    n = max(max(a, b) for a, b, _ in mygraph) + 1
+    rng = np.random.RandomState(61)
+    wl = [(a, b, int(rng.choice([-1, 1]))) for a, b, _ in mygraph]
+    out["graph"] = np.asarray(wl, dtype=np.int64)
+    iso = [(a, b, 1) for a, b in [(0, 1), (0, 2), (1, 2), (2, 3), (3, 4), (4, 5), (5, 6), (6, 7), (7, 8), (8, 9), (9, 10), (10, 0), (3, 8), (1, 6)]]
+    out["graph_isolated"] = np.asarray(iso, dtype=np.int64)          # 12 nodes, node 11 has no edge
+
+    def matrix(edges, nn):
+        W = np.zeros((nn, nn), dtype=np.float64)
+        for a, b, w in edges:
+            W[a, b] = W[b, a] = w
+        return W
+
+    def fixed(W):
+        class Fixed(GraphGenerator):
+            def __init__(self):
+                super().__init__(W.shape[0], EdgeType.DISCRETE, False)
+
+            def get(self, with_padding=False):
+                return W.copy()
+        return Fixed()
+
+    E, C = OptimisationTarget.ENERGY, OptimisationTarget.CUT
+    cfgs = {
+        "s2v": dict(W=matrix(wl, n), observables=S2V_OBSERVABLES, reward_signal=RewardSignal.DENSE, extra_action=ExtraAction.NONE,
+                    optimisation_target=C, spin_basis=SpinBasis.BINARY, norm_rewards=True, reversible_spins=False, extra_steps=4, plan="once"),
+        "eco_irreversible": dict(W=matrix(wl, n), observables=ECO_PECO_OBSERVABLES, reward_signal=RewardSignal.BLS, extra_action=ExtraAction.NONE,
+                                 optimisation_target=C, spin_basis=SpinBasis.SIGNED, norm_rewards=True, basin_reward=1.0 / n,
+                                 reversible_spins=False, extra_steps=6, plan="back"),
+        "defaults": dict(W=matrix(wl, n), plan="random"),                 # SpinSystemFactory.get(gg, max_steps): DENSE, PASS, ENERGY, SIGNED
+        "energy_bls_mem": dict(W=matrix(wl, n), observables=ECO_PECO_OBSERVABLES, reward_signal=RewardSignal.BLS, extra_action=ExtraAction.PASS,
+                               optimisation_target=E, spin_basis=SpinBasis.BINARY, norm_rewards=True, basin_reward=1.0 / n, memory_length=3,
+                               plan="random"),
+        "energy_custom_stag": dict(W=matrix(wl, n), observables=ECO_PECO_OBSERVABLES, reward_signal=RewardSignal.CUSTOM_BLS,
+                                   extra_action=ExtraAction.NONE, optimisation_target=E, spin_basis=SpinBasis.SIGNED, norm_rewards=False,
+                                   basin_reward=0.25, stag_punishment=0.125, plan="random"),
+        "energy_irreversible": dict(W=matrix(wl, n), observables=ECO_PECO_OBSERVABLES, reward_signal=RewardSignal.DENSE,
+                                    extra_action=ExtraAction.NONE, optimisation_target=E, spin_basis=SpinBasis.BINARY, norm_rewards=True,
+                                    reversible_spins=False, extra_steps=3, plan="once"),
+        "energy_isolated": dict(W=matrix(iso, 12), observables=ECO_PECO_OBSERVABLES, reward_signal=RewardSignal.BLS, extra_action=ExtraAction.NONE,
+                                optimisation_target=E, spin_basis=SpinBasis.SIGNED, norm_rewards=False, plan="random"),
+    }
+    for cname, cfg in cfgs.items():
+        cfg = dict(cfg)
+        W, plan, extra = cfg.pop("W"), cfg.pop("plan"), cfg.pop("extra_steps", 0)
+        nn = W.shape[0]
+        irreversible = cfg.get("reversible_spins", True) is False
+        max_steps = nn + extra if irreversible else 40
+        env = spc.SpinSystemFactory.get(fixed(W), max_steps, seed=31, horizon_length=None, **cfg)
+        R = len(env.observables)
+        na = env.n_actions
+        out[f"{cname}/n_actions"], out[f"{cname}/max_steps"] = np.int64(na), np.int64(max_steps)
+        out[f"{cname}/max_local"] = np.float64(env.max_local_reward_available)
+        out[f"{cname}/allowed"] = np.asarray(env.get_allowed_action_states(), dtype=np.int64).reshape(-1)
+        out[f"{cname}/spins0"] = env.state[0, :nn].copy()
+        out[f"{cname}/obs0"] = env.get_observation().copy()
+        out[f"{cname}/state0"] = env.state.copy()
+        out[f"{cname}/score0"] = np.float64(env.score)
+        out[f"{cname}/imm0"] = np.asarray(env.get_immeditate_rewards_avaialable(), dtype=np.float64)
+        r2 = np.random.RandomState(37)
+        order = r2.permutation(nn)
+        acts, states, obs, rews, dones, scores, bests, bobs = [], [], [], [], [], [], [], []
+        prev, t, k = 0, 0, 0
+        while True:
+            if plan == "once":                         # every spin flipped exactly once: what an agent on irreversible spins does
+                a = int(order[k]); k += 1
+            elif plan == "back":                       # ... and one flipped BACK on the way (the env allows it; it is +1 again)
+                if t == 5:
+                    a = int(order[1])
+                elif t == 9:
+                    a = int(order[1])
+                else:
+                    a = int(order[k]); k += 1
+            else:
+                a = int(r2.randint(0, nn))
+                if t % 3 == 2:
+                    a = prev
+                if na > nn and t % 5 == 1:
+                    a = nn
+            prev = a
+            o, r, d, _ = env.step(a)
+            assert o.shape == (R + na, na)
+            acts.append(a); obs.append(o[:R].copy()); states.append(env.state.copy()); rews.append(float(r)); dones.append(bool(d))
+            scores.append(float(env.score)); bests.append(float(env.best_score)); bobs.append(float(env.best_obs_score))
+            t += 1
+            if d or t == max_steps:
+                break
+        out[f"{cname}/adj_rows"] = o[R:].copy()
+        out[f"{cname}/actions"] = np.asarray(acts, dtype=np.int64)
+        out[f"{cname}/obs"] = np.stack(obs)
+        out[f"{cname}/state"] = np.stack(states)
+        out[f"{cname}/rew"] = np.asarray(rews, dtype=np.float64)
+        out[f"{cname}/done"] = np.asarray(dones)
+        out[f"{cname}/score"] = np.asarray(scores, dtype=np.float64)
+        out[f"{cname}/best_score"] = np.asarray(bests, dtype=np.float64)
+        out[f"{cname}/best_obs_score"] = np.asarray(bobs, dtype=np.float64)
+        out[f"{cname}/best_spins"] = np.asarray(env.best_spins, dtype=np.float64)
+        out[f"{cname}/imm_end"] = np.asarray(env.get_immeditate_rewards_avaialable(), dtype=np.float64)
+        if cfg.get("optimisation_target", E) == E:
+            out[f"{cname}/energy_end"] = np.float64(env.calculate_energy())
+            out[f"{cname}/cut_end"] = np.float64(env.calculate_cut())
+
+    # what the reference's other entry points do with these options: exception type names, as facts
+    def outcome(fn):
+        try:
+            fn()
+            return "ok"
+        except Exception as e:       # noqa: BLE001 -- the type is the datum
+            return type(e).__name__
+    env = spc.SpinSystemFactory.get(fixed(matrix(wl, n)), 8, optimisation_target=E, seed=1)
+    out["facts/energy_get_best_cut"] = np.array(outcome(env.get_best_cut))
+    gg = upe.RandomBAGraphGenerator(n_spins=20, m_insertion_edges=4, edge_type=EdgeType.DISCRETE, num_envs=4, device="cpu")
+
+    def batched(steps, **kw):
+        def run():
+            e = spb.SpinSystemFactory.get(gg, 10, observables=ECO_PECO_OBSERVABLES, reward_signal=RewardSignal.BLS,
+                                          extra_action=ExtraAction.NONE, spin_basis=SpinBasis.BINARY, norm_rewards=True,
+                                          memory_length=None, horizon_length=None, device=th.device("cpu"), num_envs=4, **kw)
+            for _ in range(steps):
+                e.step(th.zeros(4, dtype=th.long))
+        return run
+    out["facts/batched_irreversible_ctor"] = np.array(outcome(batched(0, optimisation_target=C, reversible_spins=False)))
+    out["facts/batched_irreversible_step"] = np.array(outcome(batched(1, optimisation_target=C, reversible_spins=False)))
+    out["facts/batched_energy_ctor"] = np.array(outcome(batched(0, optimisation_target=E, reversible_spins=True)))
+    out["facts/batched_energy_step"] = np.array(outcome(batched(1, optimisation_target=E, reversible_spins=True)))
+    save("spinsystem_s2v", **out)
+
+
 def gen_isco_steps():
     """Full sampler steps of the two ISCO envs with every torch draw recorded:
     ISCO_maxcut.step (envs/env_ISCO.py:26-49; methods/util.py:498-570 multinomial / mh_step) and
@@ -1335,7 +1481,7 @@ ALL = {"mcpg_weighted": gen_mcpg_weighted, "isco_steps": gen_isco_steps, "spinsy
        "select": gen_select, "mcpg": gen_mcpg, "tsp": gen_tsp, "tsp_2opt": gen_tsp_2opt, "encoder": gen_encoder,
        "wgain": gen_weighted_gain, "mcpg_glue": gen_mcpg_glue, "evaluator": gen_evaluator, "spinsystem_options": gen_spinsystem_options,
        "api_surface": gen_api_surface, "mcpg_data": gen_mcpg_data,
-       "spinsystem_inference": gen_spinsystem_inference}
+       "spinsystem_inference": gen_spinsystem_inference, "spinsystem_s2v": gen_spinsystem_s2v}
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
