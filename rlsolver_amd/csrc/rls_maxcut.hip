@@ -2,6 +2,7 @@
 // reference call site each entry point replaces, DESIGN.md for layouts and rooflines.
 #include "rls_cutcount.h"
 #include "rls_sweep.h"
+#include "rls_tile32.h"
 #include <cstdlib>
 
 namespace rls {
@@ -57,6 +58,27 @@ __global__ __launch_bounds__(W * kWave) void k_maxcut_obj(const T* __restrict__ 
 #endif
 }
 
+// K1 on HALF tiles (rls_tile32.h): one workgroup = 32 envs, words of 32 bits -- N * 4 bytes of LDS, so graphs past the 64-env tile
+// (20 224 < N <= ~40 000) keep the tile form, 2 x the edge-list reads per env instead of the one-env-per-wave kernel's byte gathers.
+template <typename T, bool VEC, int P, int W>
+__global__ __launch_bounds__(W * kWave) void k_maxcut_obj32(const T* __restrict__ x, int64_t B, int64_t N,
+                                                           const int32_t* __restrict__ eu, const int32_t* __restrict__ ev, int64_t E,
+                                                           int halve, int64_t* __restrict__ obj, int stage_off) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* words32 = reinterpret_cast<uint32_t*>(smem);
+    int64_t* scratch = reinterpret_cast<int64_t*>(smem + (((size_t)N * 4 + 15) & ~(size_t)15));
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    const int64_t b0 = (int64_t)blockIdx.x * kHalf;
+    unsigned char* stage = stage_off >= 0 ? smem + stage_off + w * kStageBytes : nullptr;
+    tile32_load_bits<T, VEC>(x, B, N, b0, words32, lane, w, W, stage);
+    __syncthreads();
+    const int64_t part = tile32_cut_count<P>(words32, eu, ev, E, lane, w, W);
+    int64_t total = block_sum_partials<W>(part, scratch, lane, w);
+    if (halve) total >>= 1;
+    if (w == 0 && lane < kHalf && b0 + lane < B) obj[b0 + lane] = total;
+}
+
 // K6: proposal = x ^ mask for 64 envs; accept the row when its cut is >= the incumbent.
 template <bool VEC, int P, int W, bool MASK_BITS = false>
 __global__ __launch_bounds__(W * kWave) void k_maxcut_propose_accept(uint8_t* __restrict__ x,
@@ -94,6 +116,38 @@ __global__ __launch_bounds__(W * kWave) void k_maxcut_propose_accept(uint8_t* __
     if (accept && w == 0) obj[b] = total;
     // accepted rows take the proposal (each wave writes a quarter of the columns); others are untouched
     tile_store_bytes<VEC>(x, B, N, b0, words, lane, w, W, accept, stage);
+}
+
+// K6 on half tiles (graphs past the 64-env tile, N <= ~40 000): the same steps on 32-bit words.  A bit-packed mask stays
+// uint64 [ceil(B / 64), N]: half tile h takes the low (even h) or high dword of word (h / 2, n).
+template <bool VEC, int P, int W, bool MASK_BITS>
+__global__ __launch_bounds__(W * kWave) void k_maxcut_propose_accept32(uint8_t* __restrict__ x, const uint8_t* __restrict__ mask,
+                                                                      int64_t B, int64_t N, const int32_t* __restrict__ eu,
+                                                                      const int32_t* __restrict__ ev, int64_t E, int halve,
+                                                                      int64_t* __restrict__ obj) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* words32 = reinterpret_cast<uint32_t*>(smem);
+    int64_t* scratch = reinterpret_cast<int64_t*>(smem + (((size_t)N * 4 + 15) & ~(size_t)15));
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    const int64_t b0 = (int64_t)blockIdx.x * kHalf;
+    tile32_load_bits<uint8_t, VEC>(x, B, N, b0, words32, lane, w, W, nullptr);
+    if constexpr (MASK_BITS) {
+        __syncthreads();
+        const uint32_t* mw = reinterpret_cast<const uint32_t*>(mask) + ((int64_t)(blockIdx.x >> 1) * N) * 2 + (blockIdx.x & 1);
+        for (int64_t n = threadIdx.x; n < N; n += W * kWave) words32[n] ^= mw[n * 2];
+    } else {
+        tile32_load_bits<uint8_t, VEC, true>(mask, B, N, b0, words32, lane, w, W, nullptr);
+    }
+    __syncthreads();
+    int64_t total = block_sum_partials<W>(tile32_cut_count<P>(words32, eu, ev, E, lane, w, W), scratch, lane, w);
+    if (halve) total >>= 1;
+    const int64_t b = b0 + (lane & (kHalf - 1));
+    const bool accept = (b < B) && (total >= obj[b]);     // (block_sum_partials leaves lanes 32..63 with 0: they hold their env's verdict below)
+    const bool acc_env = (bool)((ballot64(accept && lane < kHalf) >> (lane & (kHalf - 1))) & 1ull);
+    __syncthreads();                                      // every wave has read obj[b] before wave 0 updates it
+    if (acc_env && w == 0 && lane < kHalf) obj[b] = total;
+    tile32_store_bytes<VEC>(x, B, N, b0, words32, lane, w, W, acc_env);
 }
 
 // =====================================================================================
@@ -1021,7 +1075,51 @@ int rls_maxcut_obj(const rls_graph* g, const void* x, int spin_bytes, int64_t B,
         tw = kTileWaves;
         lds = (size_t)N * 8 + (size_t)tw * kWave * 8;
     }
-    if (lds > (size_t)kLdsBytes) {   // the 64-env bit tile does not fit: one env per wave on a byte row
+    // Half tiles (32 envs, 32-bit words: rls_tile32.h).  Where the 64-env tile does not fit but N * 4 bytes do (20 224 < N <=
+    // 40 448) -- and, for byte rows of 16-byte multiples (their fast loader), where they measure faster (tools/timing/k1_tile32.py):
+    // rows past 8192 nodes, whose 64-env tile leaves one workgroup per CU or no room for the row-piece stage (G70-sized 2^17:
+    // 280 -> 262 us, N = 20 000 2^16: 374 -> 282), and launches of at most two 64-env tiles per CU (G22-sized 2^14: 14.8 -> 13.4 us;
+    // at 2^16 the half tiles LOSE, 34.4 -> 36.3: twice the edge-list reads per env).  Dev knob RLS_K1_TILE32 = 0 | 1 forces the choice.
+    static const int knob32 = getenv("RLS_K1_TILE32") ? atoi(getenv("RLS_K1_TILE32")) : -1;
+    {
+        int w32 = (size_t)N * 4 > 64 * 1024 ? kTileWavesMax : kTileWaves;
+        auto lds32 = [&](int ww) { return (((size_t)N * 4 + 15) & ~(size_t)15) + (size_t)ww * kWave * 8; };
+        if (lds32(w32) > (size_t)kLdsBytes) w32 = kTileWaves;
+        size_t l32 = lds32(w32);
+        const int P32 = pick_planes(E);
+        const bool vec = tile_rows_aligned(x, N, spin_bytes);
+        const bool fast32 = spin_bytes == 1 && vec && (N & 15) == 0;
+        const bool want32 = knob32 >= 0 ? knob32 != 0
+                                        : fast32 && ((size_t)N * 8 > 64 * 1024 || ceil_div(B, kWave) <= 2 * (int64_t)num_cus());
+        if ((want32 || lds > (size_t)kLdsBytes) && l32 <= (size_t)kLdsBytes && P32 != 0) {
+            const int st_off = tile_stage_offset(&l32, w32, spin_bytes == 1 && vec && (N & 15) == 0);
+            const dim3 g32((unsigned)ceil_div(B, (int64_t)kHalf)), b32(w32 * kWave);
+            const int hv = g->if_bidirectional ? 1 : 0;
+            hipStream_t s32 = as_stream(stream);
+#define LAUNCH_OBJ32(T, VEC, PP)                                                                                        \
+    do {                                                                                                                \
+        auto kern = w32 == kTileWavesMax ? k_maxcut_obj32<T, VEC, PP, kTileWavesMax> : k_maxcut_obj32<T, VEC, PP, kTileWaves>; \
+        if (l32 > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l32); \
+        hipLaunchKernelGGL(kern, g32, b32, l32, s32, (const T*)x, B, N, g->eu, g->ev, E, hv, obj, st_off);              \
+    } while (0)
+#define DISPATCH_P32(T, VEC)                        \
+    switch (P32) {                                  \
+        case 12: LAUNCH_OBJ32(T, VEC, 12); break;   \
+        case 16: LAUNCH_OBJ32(T, VEC, 16); break;   \
+        case 20: LAUNCH_OBJ32(T, VEC, 20); break;   \
+        default: LAUNCH_OBJ32(T, VEC, 24); break;   \
+    }
+            if (spin_bytes == 1) {
+                if (vec) { DISPATCH_P32(uint8_t, true) } else { DISPATCH_P32(uint8_t, false) }
+            } else {
+                DISPATCH_P32(float, false)
+            }
+#undef DISPATCH_P32
+#undef LAUNCH_OBJ32
+            return check_launch("k_maxcut_obj32");
+        }
+    }
+    if (lds > (size_t)kLdsBytes) {   // neither tile fits: one env per wave on a byte row
         const int rw = rows_waves(N);
         RLS_REQUIRE(rw > 0, RLS_EUNSUPPORTED, "N=%lld: a row of %lld bytes does not fit LDS (max %d)", (long long)N, (long long)N, kLdsBytes);
         const size_t lr = (size_t)rw * (((size_t)N + 15) & ~(size_t)15);
@@ -1086,10 +1184,44 @@ int rls_maxcut_propose_accept(const rls_graph* g, uint8_t* x, int64_t B, const v
         tw = kTileWaves;              // (as in rls_maxcut_obj: the tile alone fits, 4 waves without the row-piece stage)
         lds = (size_t)N * 8 + (size_t)tw * kWave * 8;
     }
-    if (lds > (size_t)kLdsBytes) {   // the 64-env bit tile does not fit: one env per wave on a byte row
+    static const int knob32 = getenv("RLS_K6_TILE32") ? atoi(getenv("RLS_K6_TILE32")) : -1;   // dev knob: half tiles at any size
+    if (knob32 > 0 || lds > (size_t)kLdsBytes) {   // half tiles (rls_tile32.h) where the 64-env tile does not fit and N * 4 bytes do
+        int w32 = kTileWavesMax;
+        auto lds32 = [&](int ww) { return (((size_t)N * 4 + 15) & ~(size_t)15) + (size_t)ww * kWave * 8; };
+        if (lds32(w32) > (size_t)kLdsBytes) w32 = kTileWaves;
+        const size_t l32 = lds32(w32);
+        const int P32 = pick_planes(E);
+        if (l32 <= (size_t)kLdsBytes && P32 != 0) {
+            const bool vec = tile_rows_aligned(x, N, 1) && (mask_bits || tile_rows_aligned(mask, N, 1));
+            const dim3 g32((unsigned)ceil_div(B, (int64_t)kHalf)), b32(w32 * kWave);
+            hipStream_t s32 = as_stream(stream);
+            const int hv = g->if_bidirectional ? 1 : 0;
+#define LAUNCH_PA32(VEC, PP)                                                                                            \
+    do {                                                                                                                \
+        auto kern = mask_bits ? (w32 == kTileWavesMax ? k_maxcut_propose_accept32<VEC, PP, kTileWavesMax, true>         \
+                                                      : k_maxcut_propose_accept32<VEC, PP, kTileWaves, true>)           \
+                              : (w32 == kTileWavesMax ? k_maxcut_propose_accept32<VEC, PP, kTileWavesMax, false>        \
+                                                      : k_maxcut_propose_accept32<VEC, PP, kTileWaves, false>);         \
+        if (l32 > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l32); \
+        hipLaunchKernelGGL(kern, g32, b32, l32, s32, x, mask, B, N, g->eu, g->ev, E, hv, obj);                          \
+    } while (0)
+#define DISPATCH_P32(VEC)                      \
+    switch (P32) {                             \
+        case 12: LAUNCH_PA32(VEC, 12); break;  \
+        case 16: LAUNCH_PA32(VEC, 16); break;  \
+        case 20: LAUNCH_PA32(VEC, 20); break;  \
+        default: LAUNCH_PA32(VEC, 24); break;  \
+    }
+            if (vec) { DISPATCH_P32(true) } else { DISPATCH_P32(false) }
+#undef DISPATCH_P32
+#undef LAUNCH_PA32
+            return check_launch("k_maxcut_propose_accept32");
+        }
+    }
+    if (lds > (size_t)kLdsBytes) {   // neither tile fits: one env per wave on a byte row
         const int rw = rows_waves(N);
         RLS_REQUIRE(rw > 0, RLS_EUNSUPPORTED, "N=%lld: a row does not fit LDS (max %d)", (long long)N, kLdsBytes);
-        RLS_REQUIRE(!mask_bits, RLS_EUNSUPPORTED, "N=%lld: beyond the 64-env tile the mask must be bytes [B, N]", (long long)N);
+        RLS_REQUIRE(!mask_bits, RLS_EUNSUPPORTED, "N=%lld: beyond the tiles the mask must be bytes [B, N]", (long long)N);
         const size_t lr = (size_t)rw * (((size_t)N + 15) & ~(size_t)15);
         if (lr > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_maxcut_propose_accept_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lr);
         hipLaunchKernelGGL(k_maxcut_propose_accept_rows, dim3((unsigned)ceil_div(B, rw)), dim3(rw * kWave), lr, as_stream(stream), x, mask, B, N,
