@@ -257,6 +257,33 @@ __global__ __launch_bounds__(SW * kWave) void k_maxcut_greedy_sweep_levels(
     if (w == 0 && b0 + lane < B) obj[b0 + lane] = halve ? (after >> 1) : after;
 }
 
+// The level-parallel sweep on HALF tiles (rls_tile32.h): graphs past the 64-env tile (N <= ~39 000 with the schedule offsets beside
+// the words), the same schedule, obj = cut(after).
+template <bool VEC, int SW, int P>
+__global__ __launch_bounds__(SW * kWave) void k_maxcut_greedy_sweep_levels32(
+    uint8_t* __restrict__ x, int64_t B, int64_t N, const int32_t* __restrict__ lv_ptr, const int32_t* __restrict__ lv_data, int64_t G,
+    const int32_t* __restrict__ eu, const int32_t* __restrict__ ev, int64_t E, int halve, int64_t* __restrict__ obj, int has_stage) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* words32 = reinterpret_cast<uint32_t*>(smem);
+    const size_t wbytes = ((size_t)(N + 2) * 4 + 15) & ~(size_t)15;
+    int32_t* lvp = reinterpret_cast<int32_t*>(smem + wbytes);
+    int64_t* scratch = reinterpret_cast<int64_t*>(smem + wbytes + (((size_t)(G + 1) * 4 + 15) & ~(size_t)15));
+    unsigned char* stages = reinterpret_cast<unsigned char*>(scratch + SW * kWave);
+    constexpr int LW = SW < kSweepLoadWaves ? SW : kSweepLoadWaves;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    const int64_t b0 = (int64_t)blockIdx.x * kHalf;
+    if (threadIdx.x == 0) words32[N] = 0;
+    for (int64_t i = threadIdx.x; i <= G; i += SW * kWave) lvp[i] = lv_ptr[i];
+    unsigned char* stage = has_stage ? stages + (w % LW) * kStageBytes : nullptr;
+    if (w < LW) tile32_load_bits<uint8_t, VEC>(x, B, N, b0, words32, lane, w, LW, stage);
+    __syncthreads();
+    sweep32_tile_levels<SW>(words32, lvp, lv_data, G, N, lane, w);
+    const int64_t after = block_sum_partials<SW>(tile32_cut_count<P>(words32, eu, ev, E, lane, w, SW), scratch, lane, w);
+    if (w < LW) tile32_store_bytes<VEC>(x, B, N, b0, words32, lane, w, LW, true);
+    if (w == 0 && lane < kHalf && b0 + lane < B) obj[b0 + lane] = halve ? (after >> 1) : after;
+}
+
 // generic fallback (weighted graphs, hubs with degree > kSweepMaxDeg): one global row fetch per node
 template <bool VEC, bool WEIGHTED>
 __global__ __launch_bounds__(kWave) void k_maxcut_greedy_sweep_generic(uint8_t* __restrict__ x, int64_t B, int64_t N,
@@ -734,6 +761,108 @@ __global__ __launch_bounds__(NSW * kWave) void k_node_stats_bits(const uint8_t* 
     }
 }
 
+// K2 / K3 / the weights pre-pass on HALF tiles (rls_tile32.h), for graphs past the 64-env tile: lane = node over the same ELL slabs,
+// counters on 32-bit planes, every group walked by one wave (hub rows included: 16 planes, 16-bit fields), plain per-env stores.
+template <int MODE, bool VEC, bool WIDE, typename WT>
+__global__ __launch_bounds__(kNsWaves * kWave) void k_node_stats_bits32(const uint8_t* __restrict__ x, int64_t B, int64_t N,
+                                                                       const int32_t* __restrict__ rowptr, const int32_t* __restrict__ ell_ptr,
+                                                                       const int32_t* __restrict__ ell, int mult, void* __restrict__ out_v,
+                                                                       int32_t* __restrict__ minmax, int64_t out_pitch, int has_stage) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* words32 = reinterpret_cast<uint32_t*>(smem);
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    unsigned char* stage = smem + (((size_t)N * 4 + 15) & ~(size_t)15) + (size_t)w * kStageBytes;
+    const int64_t b0 = (int64_t)blockIdx.x * kHalf;
+    tile32_load_bits<uint8_t, VEC>(x, B, N, b0, words32, lane, w, kNsWaves, has_stage ? stage : nullptr);
+    __syncthreads();
+    const int64_t G = (N + 63) >> 6;
+    const int nenv = (int)((B - b0) < kHalf ? (B - b0) : kHalf);
+    const uint64_t vmask = (1ull << nenv) - 1;
+    constexpr int NCP = WIDE ? 13 : 5;
+    auto emit = [&](int64_t i, int deg, int e, int cnt) {
+        if constexpr (MODE == 0) reinterpret_cast<int64_t*>(out_v)[(b0 + e) * N + i] = cnt;
+        else if constexpr (MODE == 1) reinterpret_cast<int32_t*>(out_v)[(b0 + e) * N + i] = deg - 2 * cnt;
+        else reinterpret_cast<WT*>(out_v)[(b0 + e) * out_pitch + i] = (WT)(deg - mult * cnt);
+    };
+    for (int64_t g = w; g < G; g += kNsWaves) {
+        const int64_t i = (g << 6) + lane;
+        const bool in = i < N;
+        const uint32_t iself = in ? (uint32_t)i : 0u;
+        const uint32_t own = words32[iself];
+        const int e0 = ell_ptr[g], e1 = ell_ptr[g + 1];
+        const int deg = in ? rowptr[i + 1] - rowptr[i] : 0;
+        const int md = (e1 - e0) >> 6;                        // longest row of the group (wave-uniform)
+        uint32_t ones = 0, twos = 0, fours = 0, c[NCP];
+#pragma unroll
+        for (int p = 0; p < NCP; ++p) c[p] = 0;
+        int ncp = 5;
+        if constexpr (WIDE) while ((8 << ncp) <= md) ++ncp;
+        for (int k = e0; k < e1; k += 8 * kWave) {
+            uint32_t nb[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) nb[q] = (k + q * kWave < e1) ? (uint32_t)ell[k + q * kWave + lane] : iself;
+            uint32_t d[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) d[q] = words32[nb[q]] ^ own;
+            uint32_t twosA, twosB, foursA, foursB, carry;
+            csa32(twosA, ones, ones, d[0], d[1]);
+            csa32(twosB, ones, ones, d[2], d[3]);
+            csa32(foursA, twos, twos, twosA, twosB);
+            csa32(twosA, ones, ones, d[4], d[5]);
+            csa32(twosB, ones, ones, d[6], d[7]);
+            csa32(foursB, twos, twos, twosA, twosB);
+            csa32(carry, fours, fours, foursA, foursB);
+#pragma unroll
+            for (int p = 0; p < NCP; ++p) {
+                if (p < 5 || p < ncp) {
+                    const uint32_t t = c[p] & carry;
+                    c[p] ^= carry;
+                    carry = t;
+                }
+            }
+        }
+        const uint32_t pw[16] = {ones, twos, fours, c[0], c[1], c[2], c[3], c[4], c[5 % NCP], c[6 % NCP], c[7 % NCP], c[8 % NCP],
+                                 c[9 % NCP], c[10 % NCP], c[11 % NCP], c[12 % NCP]};
+        const int np = (WIDE && md >= 256) ? 16 : 8;          // planes that can be set (wave-uniform)
+        if constexpr (MODE == 2) {
+            if (minmax && in) {
+                uint64_t a = vmask, bm = vmask;
+                int mx = 0, mn = 0;
+                for (int p = np - 1; p >= 0; --p) {           // planes_minmax on the half tile's envs
+                    const uint64_t t = a & pw[p];
+                    if (t) { a = t; mx |= 1 << p; }
+                    const uint64_t u = bm & ~(uint64_t)pw[p];
+                    if (u) bm = u; else mn |= 1 << p;
+                }
+                ws_minmax_update(minmax, N, i, deg - mult * mx, deg - mult * mn);
+            }
+        }
+        if (!in) continue;
+        if (np == 16) {                                       // a hub group: 16-bit fields, envs r and r + 16
+            for (int r = 0; r < 16; ++r) {
+                uint32_t acc = 0;
+#pragma unroll
+                for (int p = 0; p < 16; ++p) acc += ((pw[p] >> r) & 0x00010001u) << p;
+                if (r < nenv) emit(i, deg, r, (int)(acc & 0xFFFFu));
+                if (r + 16 < nenv) emit(i, deg, r + 16, (int)(acc >> 16));
+            }
+        } else {                                              // byte fields, envs r, r + 8, r + 16, r + 24
+            for (int r = 0; r < 8; ++r) {
+                uint32_t acc = 0;
+#pragma unroll
+                for (int p = 0; p < 8; ++p) acc += ((pw[p] >> r) & 0x01010101u) << p;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (r + 8 * j < nenv) emit(i, deg, r + 8 * j, (int)((acc >> (8 * j)) & 0xFFu));
+            }
+        }
+    }
+}
+
+static inline size_t node_stats_bits32_lds(int64_t N, bool with_stage) {
+    return (((size_t)N * 4 + 15) & ~(size_t)15) + (with_stage ? (size_t)kNsWaves * kStageBytes : 0);
+}
 static inline size_t node_stats_bits_lds(int64_t N, bool with_stage = true, int waves = kNsWaves) {
     return (((size_t)N * 8 + 15) & ~(size_t)15) + (with_stage ? (size_t)waves * kStageBytes : 0);
 }
@@ -749,16 +878,38 @@ static inline bool node_stats_batch_fills_tiles(const rls_graph* g, int64_t B) {
 static inline bool node_stats_use_bits(const rls_graph* g, const int32_t* ell_ptr, const int32_t* ell, int64_t B) {
     static const bool off = getenv("RLS_NODE_STATS_LANE_ENV") != nullptr;   // dev knob: the lane = env kernels
     return !off && ell_ptr && ell && !g->wgt && g->max_degree < 65536 && node_stats_batch_fills_tiles(g, B) &&
-           node_stats_bits_lds(g->num_nodes, false) <= (size_t)kLdsBytes;   // (without the row-piece stage if need be)
+           node_stats_bits32_lds(g->num_nodes, false) <= (size_t)kLdsBytes;   // (half tiles, without the row-piece stage, if need be)
 }
 template <int MODE, typename WT = int32_t>
 static int launch_node_stats_bits(const rls_graph* g, const uint8_t* x, int64_t B, const int32_t* rowptr,
                                   const int32_t* ell_ptr, const int32_t* ell, int mult, void* out, void* stream,
                                   int32_t* minmax = nullptr, int64_t out_pitch = 0) {
     const int64_t N = g->num_nodes;
-    const int has_stage = node_stats_bits_lds(N, true) <= (size_t)kLdsBytes ? 1 : 0;
     const bool vec = tile_rows_aligned(x, N, 1);
     const bool wide = g->max_degree >= 256;
+    static const int knob32 = getenv("RLS_NS_TILE32") ? atoi(getenv("RLS_NS_TILE32")) : -1;   // dev knob: half tiles at any size
+    if (knob32 > 0 || node_stats_bits_lds(N, false) > (size_t)kLdsBytes) {   // past the 64-env tile: half tiles (rls_tile32.h)
+        const int st32 = (vec && (N & 15) == 0 && node_stats_bits32_lds(N, true) <= (size_t)kLdsBytes) ? 1 : 0;
+        const size_t l32 = node_stats_bits32_lds(N, st32 != 0);
+        const dim3 g32((unsigned)ceil_div(B, (int64_t)kHalf)), b32(kNsWaves * kWave);
+#define RLS_NS32_LAUNCH(KERN)                                                                                        \
+    do {                                                                                                            \
+        auto kern = KERN;                                                                                           \
+        if (l32 > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l32); \
+        hipLaunchKernelGGL(kern, g32, b32, l32, as_stream(stream), x, B, N, rowptr, ell_ptr, ell, mult, out, minmax,  \
+                           out_pitch > 0 ? out_pitch : N, st32);                                                     \
+    } while (0)
+        if (wide) {
+            if (vec) RLS_NS32_LAUNCH((k_node_stats_bits32<MODE, true, true, WT>));
+            else RLS_NS32_LAUNCH((k_node_stats_bits32<MODE, false, true, WT>));
+        } else {
+            if (vec) RLS_NS32_LAUNCH((k_node_stats_bits32<MODE, true, false, WT>));
+            else RLS_NS32_LAUNCH((k_node_stats_bits32<MODE, false, false, WT>));
+        }
+#undef RLS_NS32_LAUNCH
+        return check_launch("k_node_stats_bits32");
+    }
+    const int has_stage = node_stats_bits_lds(N, true) <= (size_t)kLdsBytes ? 1 : 0;
     // 8 waves per tile, or 4 where that turns a launch of one-and-a-bit rounds of workgroups into ONE round: a G22-sized tile
     // is 16 KB + 4 KB of row-piece stage per wave -- 3 eight-wave workgroups per CU (768 resident: 1024 tiles = a full round
     // and a third of one), 5 four-wave ones (every tile resident at once)
@@ -1184,8 +1335,14 @@ int rls_maxcut_propose_accept(const rls_graph* g, uint8_t* x, int64_t B, const v
         tw = kTileWaves;              // (as in rls_maxcut_obj: the tile alone fits, 4 waves without the row-piece stage)
         lds = (size_t)N * 8 + (size_t)tw * kWave * 8;
     }
-    static const int knob32 = getenv("RLS_K6_TILE32") ? atoi(getenv("RLS_K6_TILE32")) : -1;   // dev knob: half tiles at any size
-    if (knob32 > 0 || lds > (size_t)kLdsBytes) {   // half tiles (rls_tile32.h) where the 64-env tile does not fit and N * 4 bytes do
+    // Half tiles (rls_tile32.h): where the 64-env tile does not fit and N * 4 bytes do, where it fits but leaves no room for the
+    // row-piece stage (N > ~15 800: N = 20 000 2^15 387 -> 303 us), and for short rows in launches of at most one 64-env tile per
+    // CU (G22-sized 2^12: 21.8 -> 9.9 us, 2^14: 26.8 -> 20.3; at 2^16 they lose, 63.6 -> 67.9).  tools/timing/k5_tile32.py.
+    static const int knob32 = getenv("RLS_K6_TILE32") ? atoi(getenv("RLS_K6_TILE32")) : -1;   // dev knob: 0 | 1 forces the choice
+    const bool no_stage64 = lds + (size_t)tw * kStageBytes > (size_t)kLdsBytes;
+    const bool want32 = knob32 >= 0 ? knob32 != 0
+                                    : no_stage64 || ((size_t)N * 8 <= 64 * 1024 && ceil_div(B, kWave) <= (int64_t)num_cus());
+    if (want32 || lds > (size_t)kLdsBytes) {
         int w32 = kTileWavesMax;
         auto lds32 = [&](int ww) { return (((size_t)N * 4 + 15) & ~(size_t)15) + (size_t)ww * kWave * 8; };
         if (lds32(w32) > (size_t)kLdsBytes) w32 = kTileWaves;
@@ -1289,6 +1446,48 @@ int rls_maxcut_greedy_sweep(const rls_graph* g, uint8_t* x, int64_t B, int64_t* 
             if (lds_of(sw, false) > (size_t)kLdsBytes) sw = 2;
         }
         const size_t lds_l = lds_of(sw, has_stage != 0);
+        // half tiles (rls_tile32.h) where the 64-env tile does not fit (dev knob RLS_K5_TILE32 = 1: at any size)
+        static const int knob32 = getenv("RLS_K5_TILE32") ? atoi(getenv("RLS_K5_TILE32")) : -1;
+        if ((knob32 > 0 || lds_l > (size_t)kLdsBytes) && !no_levels && !g->wgt && g->sweep_lv_ptr && g->sweep_lv_data && G > 0 && P != 0) {
+            int sw32 = force_lw == 2 || force_lw == 4 || force_lw == 8 ? force_lw : (N >= 56 * G ? 8 : 4);
+            auto lds32_of = [&](int waves, bool stage) {
+                return (((size_t)(N + 2) * 4 + 15) & ~(size_t)15) + (((size_t)(G + 1) * 4 + 15) & ~(size_t)15) + (size_t)waves * kWave * 8 +
+                       (stage ? (size_t)kSweepLoadWaves * kStageBytes : 0);
+            };
+            int stage32 = vec && (N & 15) == 0 ? 1 : 0;
+            if (stage32 && lds32_of(sw32, true) > (size_t)kLdsBytes) stage32 = 0;
+            if (lds32_of(sw32, stage32 != 0) > (size_t)kLdsBytes) sw32 = 4;
+            if (lds32_of(sw32, stage32 != 0) > (size_t)kLdsBytes) sw32 = 2;
+            const size_t l32 = lds32_of(sw32, stage32 != 0);
+            if (l32 <= (size_t)kLdsBytes) {
+                const dim3 g32((unsigned)ceil_div(B, (int64_t)kHalf)), b32(sw32 * kWave);
+                const int hv = g->if_bidirectional ? 1 : 0;
+#define LAUNCH_SWL32(VEC, SWV, PP)                                                                                          \
+    do {                                                                                                                    \
+        auto kern = k_maxcut_greedy_sweep_levels32<VEC, SWV, PP>;                                                           \
+        if (l32 > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l32); \
+        hipLaunchKernelGGL(kern, g32, b32, l32, s, x, B, N, g->sweep_lv_ptr, g->sweep_lv_data, G, g->eu, g->ev, E, hv, obj, stage32); \
+    } while (0)
+#define DISPATCH_SWL32_P(VEC, SWV)                       \
+    switch (P) {                                         \
+        case 12: LAUNCH_SWL32(VEC, SWV, 12); break;      \
+        case 16: LAUNCH_SWL32(VEC, SWV, 16); break;      \
+        case 20: LAUNCH_SWL32(VEC, SWV, 20); break;      \
+        default: LAUNCH_SWL32(VEC, SWV, 24); break;      \
+    }
+#define DISPATCH_SWL32(VEC)                                     \
+    do {                                                        \
+        if (sw32 == 4) { DISPATCH_SWL32_P(VEC, 4) }             \
+        else if (sw32 == 2) { DISPATCH_SWL32_P(VEC, 2) }        \
+        else { DISPATCH_SWL32_P(VEC, 8) }                       \
+    } while (0)
+                if (vec) DISPATCH_SWL32(true); else DISPATCH_SWL32(false);
+#undef DISPATCH_SWL32
+#undef DISPATCH_SWL32_P
+#undef LAUNCH_SWL32
+                return check_launch("k_maxcut_greedy_sweep_levels32");
+            }
+        }
         if (!no_levels && !g->wgt && g->sweep_lv_ptr && g->sweep_lv_data && G > 0 && P != 0 && lds_l <= (size_t)kLdsBytes) {
             const dim3 blockl(sw * kWave);
             const int halve = g->if_bidirectional ? 1 : 0;

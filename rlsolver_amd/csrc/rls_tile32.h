@@ -230,4 +230,156 @@ __device__ __forceinline__ int64_t tile32_cut_count(const uint32_t* __restrict__
     return half == 0 ? total + other : 0;
 }
 
+// ---- the level-parallel sweep (rls_sweep.h: sweep_tile_levels) on half-tile words.  The SAME schedule: its entries are byte
+// offsets of 64-bit words (node * 8), halved here; a group costs the same instructions per plane and HALF as many planes' halves.
+template <int X>
+__device__ __forceinline__ uint32_t lv32_lane_xor(uint32_t v) {
+    if constexpr (X == 4) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x101F);
+    else return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, X == 1 ? 0xB1 : 0x4E, 0xF, 0xF, false);
+}
+template <int X>
+__device__ __forceinline__ void lv32_merge_planes(uint32_t (&pl)[8], uint32_t take) {
+    uint32_t carry = 0;
+#pragma unroll
+    for (int p = 0; p < 8; ++p) csa32(carry, pl[p], pl[p], lv32_lane_xor<X>(pl[p]) & take, carry);
+}
+template <int NP>
+__device__ __forceinline__ uint32_t lv32_le_const(const uint32_t (&pl)[8], uint32_t thr) {   // rls_tile.h: lv_le_const
+    const int nt = (int)~thr;
+    uint32_t c0 = 0;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) c0 = __builtin_amdgcn_bitop3_b32(pl[p], (uint32_t)__builtin_amdgcn_sbfe(nt, p, 1), c0, 0xE8);
+    return ~c0;
+}
+
+template <int NC, int NP>
+__device__ __forceinline__ uint32_t sweep32_group_flips(const unsigned char* __restrict__ wbytes, const int32_t* __restrict__ rec8,
+                                                        int rounds, const uint32_t (&nb0)[8], uint32_t own, uint32_t thr, uint32_t lcode) {
+    uint32_t ones = 0, twos = 0, fours = 0, c[5] = {0, 0, 0, 0, 0};
+    uint32_t nb[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) nb[q] = nb0[q];
+    for (int r0 = 0; r0 < rounds; r0 += 8, rec8 += 8 * kWave) {
+        uint32_t nxt[8];
+        if (r0 + 8 < rounds) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) nxt[q] = (uint32_t)rec8[q * kWave];
+        }
+        uint32_t d[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) d[q] = *reinterpret_cast<const uint32_t*>(wbytes + (nb[q] >> 1)) ^ own;   // padding = the node itself: 0
+        uint32_t twosA, twosB, foursA, foursB, carry;
+        csa32(twosA, ones, ones, d[0], d[1]);
+        csa32(twosB, ones, ones, d[2], d[3]);
+        csa32(foursA, twos, twos, twosA, twosB);
+        csa32(twosA, ones, ones, d[4], d[5]);
+        csa32(twosB, ones, ones, d[6], d[7]);
+        csa32(foursB, twos, twos, twosA, twosB);
+        csa32(carry, fours, fours, foursA, foursB);
+#pragma unroll
+        for (int p = 0; p < NC; ++p) {
+            const uint32_t t = c[p] & carry;
+            c[p] ^= carry;
+            carry = t;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) nb[q] = nxt[q];
+    }
+    const int gl = __builtin_amdgcn_readlane((int)lcode, 0);
+    if (gl > 0) {
+        uint32_t pv[8] = {ones, twos, fours, c[0], c[1], c[2], c[3], c[4]};
+        lv32_merge_planes<1>(pv, 0u - (uint32_t)(lcode >= 1u));
+        if (gl > 1) lv32_merge_planes<2>(pv, 0u - (uint32_t)(lcode >= 2u));
+        if (gl > 2) lv32_merge_planes<4>(pv, 0u - (uint32_t)(lcode >= 3u));
+        return lv32_le_const<8>(pv, thr);
+    }
+    const uint32_t pl[8] = {ones, twos, fours, c[0], c[1], c[2], c[3], c[4]};
+    return lv32_le_const<NP>(pl, thr);
+}
+
+// a hub: lane = neighbour, per-lane counters over its rounds, every plane transposed across the wave and popcounted (two planes
+// per transpose: lanes 0..31 get plane p of env lane, lanes 32..63 plane p + 1 of env lane - 32)
+__device__ __forceinline__ uint32_t sweep32_hub_flips(const unsigned char* __restrict__ wbytes, const int32_t* __restrict__ rec8, int rounds,
+                                                      const uint32_t (&nb0)[8], uint32_t own, uint32_t deg, int lane) {
+    uint32_t cv[8] = {0, 0, 0, 0, 0, 0, 0, 0};                      // rounds <= 64: 7 planes (+ 1 to pair them)
+    auto add = [&](uint32_t off) {
+        uint32_t carry = *reinterpret_cast<const uint32_t*>(wbytes + (off >> 1)) ^ own;
+#pragma unroll
+        for (int p = 0; p < 7; ++p) { const uint32_t t = cv[p] & carry; cv[p] ^= carry; carry = t; }
+    };
+#pragma unroll
+    for (int q = 0; q < 8; ++q) add(nb0[q]);
+    for (int r = 8; r < rounds; ++r, rec8 += kWave) add((uint32_t)rec8[0]);
+    const BitXpose xc = bit_xpose_consts(lane);
+    const int half = lane >> 5;
+    int cnt = 0;
+#pragma unroll
+    for (int p = 0; p < 8; p += 2) {
+        uint32_t r0 = cv[p], r1 = cv[p + 1];
+        bit_transpose64(r0, r1, xc);
+        cnt += (__builtin_popcount(r0) + __builtin_popcount(r1)) << (p + half);
+    }
+    cnt += __shfl_xor(cnt, 32, 64);
+    return (uint32_t)ballot64(lane < kHalf && (uint32_t)cnt <= (deg >> 1));
+}
+
+template <int W>
+__device__ __forceinline__ void sweep32_tile_levels(uint32_t* words32, const int32_t* lvp, const int32_t* __restrict__ data, int64_t G,
+                                                    int64_t N, int lane, int w) {
+    constexpr uint32_t M = 0x3fffffffu;
+    const unsigned char* wbytes = reinterpret_cast<const unsigned char*>(words32);
+    uint32_t hdr = (uint32_t)N;
+    uint32_t nb0[8];
+    auto prefetch = [&](int64_t k) {
+        if (k < G) {
+            const int32_t* rec = data + ((uint32_t)lvp[k] & M) + lane;
+            hdr = (uint32_t)rec[0];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) nb0[q] = (uint32_t)rec[(1 + q) * kWave];
+        }
+    };
+    prefetch(w);
+    int num_levels = 0;
+    for (int64_t k0 = 0; k0 < G; k0 += kWave)
+        num_levels += __builtin_popcountll(ballot64(k0 + lane < G && (lvp[k0 + lane < G ? k0 + lane : G] >> 31) != 0));
+    int chunk = 0, chunk_next = 0;
+    int64_t cbase = -1;
+    uint64_t lmask = 0;
+    int lev_base = 0, passed = 0;
+    for (int64_t k = w; k < G; k += W) {
+        if ((k & ~(int64_t)63) != cbase) {
+            cbase = k & ~(int64_t)63;
+            lev_base += __builtin_popcountll(lmask);
+            const int64_t a0 = cbase + lane <= G ? cbase + lane : G, a1 = cbase + 1 + lane <= G ? cbase + 1 + lane : G;
+            chunk = lvp[a0];
+            chunk_next = lvp[a1];
+            lmask = ballot64(cbase + lane < G && (chunk >> 31) != 0);
+        }
+        const int need = lev_base + __builtin_popcountll(lmask & ((2ull << (k & 63)) - 1ull));
+        for (; passed < need; ++passed) __syncthreads();
+        const int64_t p0 = (uint32_t)__builtin_amdgcn_readlane(chunk, (int)(k & 63)) & M;
+        const int64_t p1 = (uint32_t)__builtin_amdgcn_readlane(chunk_next, (int)(k & 63)) & M;
+        const int rounds = (int)((p1 - p0) >> 6) - 1;
+        const int32_t* rec8 = data + p0 + (1 + 8) * kWave + lane;
+        if (((uint32_t)__builtin_amdgcn_readlane(chunk, (int)(k & 63)) >> 30) & 1u) {
+            const uint32_t hnode = (uint32_t)__builtin_amdgcn_readlane((int)hdr, 0), hdeg = (uint32_t)__builtin_amdgcn_readlane((int)hdr, 1);
+            const uint32_t hown = words32[hnode];
+            const uint32_t hflip = sweep32_hub_flips(wbytes, rec8, rounds, nb0, hown, hdeg, lane);
+            if (lane == 0) words32[hnode] = hown ^ hflip;
+            prefetch(k + W);
+            continue;
+        }
+        const uint32_t node = hdr & 0xFFFFFu, thr = (hdr >> 20) & 0xFFu, lcode = (hdr >> 28) & 3u;
+        const uint32_t own = words32[node];
+        uint32_t flip;
+        if (rounds <= 8) flip = sweep32_group_flips<1, 4>(wbytes, rec8, rounds, nb0, own, thr, lcode);
+        else if (rounds <= 24) flip = sweep32_group_flips<2, 5>(wbytes, rec8, rounds, nb0, own, thr, lcode);
+        else flip = sweep32_group_flips<4, 7>(wbytes, rec8, rounds, nb0, own, thr, lcode);
+        if (node < (uint32_t)N && (lane & ((1 << lcode) - 1)) == 0) words32[node] = own ^ flip;
+        prefetch(k + W);
+    }
+    for (; passed < num_levels; ++passed) __syncthreads();
+    __syncthreads();
+}
+
 }  // namespace rls
