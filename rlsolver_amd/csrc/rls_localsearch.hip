@@ -24,6 +24,7 @@
 // node, round).  f32 arithmetic follows torch: (float)ws + (noise * rd_std), two roundings.
 #include "rls_cutcount.h"
 #include "rls_sweep.h"
+#include "rls_tile32.h"
 #include <cstdlib>
 #include <type_traits>
 
@@ -490,7 +491,9 @@ __device__ __forceinline__ void ls_ws_pass(const WT* __restrict__ ws, int64_t pi
 constexpr int kLsRoundWaves = 8;
 
 // thresh[b] = the (num_spin + 1)-th largest of ws[b, :] + normal(draw) * rd_std  (kthvalue(k = N - num_spin))
-template <typename WT>
+// SD_LDS: rd_std [N] staged in LDS (one broadcast read per quad); false: read from global memory -- rows so long that the
+// 4 N bytes do not fit beside the lists and the stages (N > ~24 900; N % 4 == 0 so that a quad never leaves the array)
+template <typename WT, bool SD_LDS = true>
 __global__ __launch_bounds__(kLsRoundWaves * kWave) void k_ls_threshold(const WT* __restrict__ ws, int64_t pitch, int64_t B, int64_t N,
                                                                         const float* __restrict__ rd_std, uint64_t seed,
                                                                         int64_t env_offset, int draw, int num_spin,
@@ -506,15 +509,17 @@ __global__ __launch_bounds__(kLsRoundWaves * kWave) void k_ls_threshold(const WT
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     const int64_t b0 = (int64_t)blockIdx.x * kWave, b = b0 + lane;
     const EnvKey env_key = ls_env_key(seed, (uint64_t)(b + env_offset));
-    for (int64_t i = threadIdx.x; i < ((N + 3) & ~3ll); i += W * kWave) sdl[i] = i < N ? rd_std[i] : 0.0f;   // rd_std: one broadcast read per quad
-    __syncthreads();
+    if constexpr (SD_LDS) {
+        for (int64_t i = threadIdx.x; i < ((N + 3) & ~3ll); i += W * kWave) sdl[i] = i < N ? rd_std[i] : 0.0f;   // rd_std: one broadcast read per quad
+        __syncthreads();
+    }
     float t[kTopCap];
 #pragma unroll
     for (int j = 0; j < kTopCap; ++j) t[j] = -INFINITY;
     int64_t c_begin, c_end;
     ls_slice_chunks(ls_num_chunks<WT>(N), (int)blockIdx.y, (int)gridDim.y, c_begin, c_end);
     auto pass = [&](auto depth) {
-        ls_ws_pass<WT, W>(ws, pitch, B, N, b0, lane, w, stages + (size_t)w * kStageBytes, sdl, env_key, draw, c_begin, c_end,
+        ls_ws_pass<WT, W>(ws, pitch, B, N, b0, lane, w, stages + (size_t)w * kStageBytes, SD_LDS ? sdl : rd_std, env_key, draw, c_begin, c_end,
                           [&](int64_t pc, const float (&v)[NPC]) {
 #pragma unroll
                               for (int k = 0; k < NPC; ++k) top_insert_n<decltype(depth)::value>(t, (pc * NPC + k < N) ? v[k] : -INFINITY);
@@ -561,7 +566,7 @@ __global__ __launch_bounds__(kWave) void k_ls_threshold_merge(const float* __res
 
 // the mask words of one proposal round for a slice of the nodes: maskw[tile][node] (bit e = env 64 tile + e), for batches of so
 // few tiles that one workgroup per tile would leave most of the chip idle through the VALU-bound noise generation
-template <typename WT>
+template <typename WT, bool SD_LDS = true>
 __global__ __launch_bounds__(kLsRoundWaves * kWave) void k_ls_mask(const WT* __restrict__ ws, int64_t pitch, int64_t B, int64_t N,
                                                                    const float* __restrict__ rd_std, const float* __restrict__ thresh,
                                                                    uint64_t seed, int64_t env_offset, int draw,
@@ -575,13 +580,15 @@ __global__ __launch_bounds__(kLsRoundWaves * kWave) void k_ls_mask(const WT* __r
     const int64_t b0 = (int64_t)blockIdx.x * kWave, b = b0 + lane;
     const bool valid = b < B;
     const EnvKey env_key = ls_env_key(seed, (uint64_t)(b + env_offset));
-    for (int64_t i = threadIdx.x; i < ((N + 3) & ~3ll); i += W * kWave) sdl[i] = i < N ? rd_std[i] : 0.0f;   // rd_std: one broadcast read per quad
-    __syncthreads();
+    if constexpr (SD_LDS) {
+        for (int64_t i = threadIdx.x; i < ((N + 3) & ~3ll); i += W * kWave) sdl[i] = i < N ? rd_std[i] : 0.0f;   // rd_std: one broadcast read per quad
+        __syncthreads();
+    }
     const float th = valid ? thresh[b] : 0.0f;
     int64_t c_begin, c_end;
     ls_slice_chunks(ls_num_chunks<WT>(N), (int)blockIdx.y, (int)gridDim.y, c_begin, c_end);
     uint64_t* out = maskw + (int64_t)blockIdx.x * N;
-    ls_ws_pass<WT, W>(ws, pitch, B, N, b0, lane, w, stages + (size_t)w * kStageBytes, sdl, env_key, draw, c_begin, c_end,
+    ls_ws_pass<WT, W>(ws, pitch, B, N, b0, lane, w, stages + (size_t)w * kStageBytes, SD_LDS ? sdl : rd_std, env_key, draw, c_begin, c_end,
                       [&](int64_t pc, const float (&v)[NPC]) {
                           uint64_t mine = 0;
 #pragma unroll
@@ -693,6 +700,48 @@ __global__ __launch_bounds__(W * kWave) void k_ls_apply_rounds(uint8_t* __restri
     else tile_store_bytes<false>(x, B, N, b0, words, lane, w, W, changed, stage);
 }
 
+// the same on HALF tiles (rls_tile32.h) for graphs past the 64-env tile: the mask words stay those of 64-env tiles, half tile h
+// takes the low (even h) or high dword of word (h / 2, n)
+template <int P, int W>
+__global__ __launch_bounds__(W * kWave) void k_ls_apply_rounds32(uint8_t* __restrict__ x, int64_t B, int64_t N, const int32_t* __restrict__ eu,
+                                                                 const int32_t* __restrict__ ev, int64_t E, int halve,
+                                                                 const uint64_t* __restrict__ maskw, int64_t tiles64, int rounds,
+                                                                 int64_t* __restrict__ obj, int x_aligned) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t* words32 = reinterpret_cast<uint32_t*>(smem);
+    int64_t* scratch = reinterpret_cast<int64_t*>(smem + (((size_t)N * 4 + 15) & ~(size_t)15));
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    const int64_t b0 = (int64_t)blockIdx.x * kHalf, b = b0 + (lane & (kHalf - 1));
+    const bool valid = b < B && lane < kHalf;
+    if (x_aligned) tile32_load_bits<uint8_t, true>(x, B, N, b0, words32, lane, w, W, nullptr);
+    else tile32_load_bits<uint8_t, false>(x, B, N, b0, words32, lane, w, W, nullptr);
+    int64_t my_obj = valid ? obj[b] : 0;
+    bool changed = false;
+    __syncthreads();
+    for (int r = 0; r < rounds; ++r) {
+        const uint32_t* mw = reinterpret_cast<const uint32_t*>(maskw + ((int64_t)r * tiles64 + (blockIdx.x >> 1)) * N) + (blockIdx.x & 1);
+        for (int64_t n = threadIdx.x; n < N; n += W * kWave) words32[n] ^= mw[2 * n];
+        __syncthreads();
+        int64_t total = block_sum_partials<W>(tile32_cut_count<P>(words32, eu, ev, E, lane, w, W), scratch, lane, w);
+        if (halve) total >>= 1;
+        const bool accept = valid && (total >= my_obj);          // update_xs_by_vs: vs1.ge(vs0)
+        if (accept) my_obj = total;
+        changed = changed || accept;
+        const uint32_t am = (uint32_t)ballot64(accept);
+        __syncthreads();
+        if (~am)
+            for (int64_t n = threadIdx.x; n < N; n += W * kWave) words32[n] ^= mw[2 * n] & ~am;
+        __syncthreads();
+    }
+    if (w == 0 && valid) obj[b] = my_obj;
+    const bool ch_env = (bool)((ballot64(changed) >> (lane & (kHalf - 1))) & 1ull);      // lanes 32..63 store their env's second block
+    if (x_aligned) tile32_store_bytes<true>(x, B, N, b0, words32, lane, w, W, ch_env);
+    else tile32_store_bytes<false>(x, B, N, b0, words32, lane, w, W, ch_env);
+}
+
+static size_t ls_apply32_lds(int64_t N, int W) { return (((size_t)N * 4 + 15) & ~(size_t)15) + (size_t)W * kWave * 8; }
+
 static size_t ls_apply_lds(int64_t N, int W, bool stage) {
     return (size_t)((N + 1) & ~1ll) * 8 + (size_t)W * kWave * 8 + (stage ? (size_t)W * kStageBytes : 0);
 }
@@ -700,6 +749,10 @@ static size_t ls_apply_lds(int64_t N, int W, bool stage) {
 static bool ls_big_tile(int64_t N) {
     return (size_t)((N + 1) & ~1ll) * 8 + (size_t)kLsRoundWaves * kWave * 8 + (size_t)kLsRoundWaves * kStageBytes > (size_t)kLdsBytes &&
            ls_apply_lds(N, 4, false) <= (size_t)kLdsBytes;
+}
+// N past the 64-env tile altogether but within the half tile (20 224 < N <= ~39 900): mask kernels + the apply kernel on half tiles
+static bool ls_half_tile(int64_t N) {
+    return !ls_big_tile(N) && ls_apply_lds(N, 4, false) > (size_t)kLdsBytes && ls_apply32_lds(N, kLsRoundWaves) <= (size_t)kLdsBytes;
 }
 static bool ls_sd_global() {   // dev knob: rd_std read from global memory even where it fits LDS
     static const bool on = getenv("RLS_LS_SD_GLOBAL") != nullptr;
@@ -724,10 +777,13 @@ static size_t ls_scratch_bytes(int64_t B, int64_t N, int S, int rounds = 1) {   
     return lists > masks ? lists : masks;
 }
 // (rd_std always fits LDS beside the stages here: 4 N bytes, N bounded by the proposal kernel's tile)
-static size_t ls_mask_lds(int64_t N) { return (size_t)kLsRoundWaves * kStageBytes + (size_t)((N + 3) & ~3ll) * 4; }
-static size_t ls_threshold_lds(int64_t N) {
-    return (size_t)kLsRoundWaves * kTopCap * kWave * 4 + (size_t)kLsRoundWaves * kStageBytes + (size_t)((N + 3) & ~3ll) * 4;
+// rd_std beside the stages (sd_lds), or read from global memory where 4 N bytes do not fit (needs N % 4 == 0)
+static size_t ls_mask_lds(int64_t N, bool sd_lds = true) { return (size_t)kLsRoundWaves * kStageBytes + (sd_lds ? (size_t)((N + 3) & ~3ll) * 4 : 0); }
+static size_t ls_threshold_lds(int64_t N, bool sd_lds = true) {
+    return (size_t)kLsRoundWaves * kTopCap * kWave * 4 + (size_t)kLsRoundWaves * kStageBytes + (sd_lds ? (size_t)((N + 3) & ~3ll) * 4 : 0);
 }
+static bool ls_noise_sd_lds(int64_t N) { return ls_threshold_lds(N, true) <= (size_t)kLdsBytes; }   // (the threshold kernel is the larger)
+static bool ls_noise_passes_fit(int64_t N) { return ls_noise_sd_lds(N) || (N & 3) == 0; }
 static size_t ls_propose_lds(int64_t N, bool sd_lds) {
     return (size_t)((N + 1) & ~1ll) * 8 + (size_t)kLsRoundWaves * kWave * 8 + (size_t)kLsRoundWaves * kStageBytes +
            (sd_lds ? (size_t)((N + 3) & ~3ll) * 4 : 0);
@@ -846,7 +902,8 @@ extern "C" int rls_maxcut_ls_rounds_supported(const rls_graph* g, int32_t num_sp
     const int64_t N = g->num_nodes;
     if (num_spin < 0 || num_spin + 1 > kTopCap || num_spin >= N) return 0;
     if (pick_planes(g->num_stored_edges) == 0) return 0;
-    return ls_propose_lds(N, false) <= (size_t)kLdsBytes || ls_big_tile(N);   // (the latter needs the scratch buffer)
+    // (the bare 64-env tile and the half tile need the scratch buffer: the rounds run through the mask words there)
+    return ls_propose_lds(N, false) <= (size_t)kLdsBytes || ((ls_big_tile(N) || ls_half_tile(N)) && ls_noise_passes_fit(N));
 }
 
 // bytes of caller-provided scratch with which the two entry points below split a tile's noise pass over several workgroups
@@ -856,7 +913,7 @@ extern "C" int64_t rls_maxcut_ls_scratch_bytes(const rls_graph* g, int64_t B, in
     const int64_t N = g->num_nodes;
     const int64_t nch = ws_bytes == 1 ? ls_num_chunks<int8_t>(N) : ls_num_chunks<int16_t>(N);
     const size_t need = ls_scratch_bytes(B, N, ls_slices(B, nch), num_draws);
-    if (ls_big_tile(N)) {   // the mask words are how the rounds run at all here: at least one round's
+    if (ls_big_tile(N) || ls_half_tile(N)) {   // the mask words are how the rounds run at all here: at least one round's
         const size_t one = (size_t)ceil_div(B, kWave) * (size_t)N * 8;
         return (int64_t)(need > one ? need : one);
     }
@@ -885,15 +942,16 @@ extern "C" int rls_maxcut_ls_threshold(const rls_graph* g, int64_t B, const void
     if (ws_pitch == 0) ws_pitch = N;
     RLS_REQUIRE(ls_pitch_ok(ws, ws_pitch, ws_bytes, N), RLS_EUNSUPPORTED,
                 "ws rows must start 16-byte aligned: pitch %lld entries of %d bytes (N=%lld)", (long long)ws_pitch, (int)ws_bytes, (long long)N);
-    const size_t lds = ls_threshold_lds(N);
-    RLS_REQUIRE(lds <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS (max %d)", (long long)N, lds, kLdsBytes);
+    const bool sd_lds = ls_noise_sd_lds(N);
+    RLS_REQUIRE(ls_noise_passes_fit(N), RLS_EUNSUPPORTED, "N=%lld: rd_std does not fit LDS and N is not a multiple of 4", (long long)N);
+    const size_t lds = ls_threshold_lds(N, sd_lds);
     int S = ls_slices(B, ws_bytes == 1 ? ls_num_chunks<int8_t>(N) : ls_num_chunks<int16_t>(N));
     if (!scratch || (size_t)scratch_bytes < ls_scratch_bytes(B, N, S) || (((uintptr_t)scratch) & 15) != 0) S = 1;
     const dim3 grid((unsigned)ceil_div(B, kWave), (unsigned)S), block(kLsRoundWaves * kWave);
     hipStream_t s = as_stream(stream);
 #define LAUNCH_TH(WT)                                                                                                  \
     do {                                                                                                               \
-        auto kern = k_ls_threshold<WT>;                                                                                \
+        auto kern = sd_lds ? k_ls_threshold<WT, true> : k_ls_threshold<WT, false>;                                     \
         if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(kern, grid, block, lds, s, (const WT*)ws, ws_pitch, B, N, rd_std, seed, env_offset, (int)draw, (int)num_spin, thresh, \
                            (float*)scratch);                                                                           \
@@ -925,7 +983,7 @@ extern "C" int rls_maxcut_ls_propose(const rls_graph* g, uint8_t* x, int64_t B, 
     RLS_REQUIRE(ls_pitch_ok(ws, ws_pitch, ws_bytes, N), RLS_EUNSUPPORTED,
                 "ws rows must start 16-byte aligned: pitch %lld entries of %d bytes (N=%lld)", (long long)ws_pitch, (int)ws_bytes, (long long)N);
     const int x_aligned = tile_rows_aligned(x, N, 1) ? 1 : 0;   // else the funnel-shift form of the row-piece stage
-    if (ls_propose_lds(N, false) > (size_t)kLdsBytes && ls_big_tile(N))   // mask kernel + the 4-wave apply kernel (needs the scratch)
+    if (ls_propose_lds(N, false) > (size_t)kLdsBytes && (ls_big_tile(N) || ls_half_tile(N)))   // mask kernel + the apply kernel (needs the scratch)
         return rls_maxcut_ls_rounds(g, x, B, ws, ws_bytes, ws_pitch, rd_std, thresh, seed, env_offset, draw, 1, obj, scratch, scratch_bytes, stream);
     RLS_REQUIRE(ls_propose_lds(N, false) <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS (max %d)", (long long)N,
                 ls_propose_lds(N, false), kLdsBytes);
@@ -986,7 +1044,9 @@ extern "C" int rls_maxcut_ls_rounds(const rls_graph* g, uint8_t* x, int64_t B, c
     if (ws_pitch == 0) ws_pitch = N;
     const int S = ls_slices(B, ws_bytes == 1 ? ls_num_chunks<int8_t>(N) : ls_num_chunks<int16_t>(N));
     static const bool per_round = getenv("RLS_LS_PER_ROUND") != nullptr;   // dev knob: one propose launch per round
-    const bool big = ls_big_tile(N);
+    const bool half = ls_half_tile(N);
+    const bool big = ls_big_tile(N) || half;
+    RLS_REQUIRE(!half || ls_noise_passes_fit(N), RLS_EUNSUPPORTED, "N=%lld: rd_std does not fit LDS and N is not a multiple of 4", (long long)N);
     const size_t one_round = (size_t)ceil_div(B, kWave) * (size_t)N * 8;
     const bool scratch_ok = scratch && (((uintptr_t)scratch) & 15) == 0 && ls_pitch_ok(ws, ws_pitch, ws_bytes, N) && pick_planes(E) != 0;
     RLS_REQUIRE(!big || (scratch_ok && (size_t)scratch_bytes >= one_round), RLS_EUNSUPPORTED,
@@ -1003,7 +1063,8 @@ extern "C" int rls_maxcut_ls_rounds(const rls_graph* g, uint8_t* x, int64_t B, c
     }
     const dim3 grid((unsigned)ceil_div(B, kWave)), gm(grid.x, (unsigned)S);
     hipStream_t s = as_stream(stream);
-    const size_t ldm = ls_mask_lds(N);
+    const bool sd_lds = ls_noise_sd_lds(N);
+    const size_t ldm = ls_mask_lds(N, sd_lds);
     const int halve = g->if_bidirectional ? 1 : 0, x_aligned = tile_rows_aligned(x, N, 1) ? 1 : 0;
     const int per_launch = all_at_once ? num_draws : 1;       // rounds whose mask words are in the scratch at once
     for (int32_t r0 = 0; r0 < num_draws; r0 += per_launch) {
@@ -1011,19 +1072,25 @@ extern "C" int rls_maxcut_ls_rounds(const rls_graph* g, uint8_t* x, int64_t B, c
             uint64_t* out = (uint64_t*)scratch + (size_t)r * grid.x * (size_t)N;
             const dim3 block(kLsRoundWaves * kWave);
             if (ws_bytes == 1) {
-                auto kern = k_ls_mask<int8_t>;
+                auto kern = sd_lds ? k_ls_mask<int8_t, true> : k_ls_mask<int8_t, false>;
                 if (ldm > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldm);
                 hipLaunchKernelGGL(kern, gm, block, ldm, s, (const int8_t*)ws, ws_pitch, B, N, rd_std, thresh, seed, env_offset,
                                    (int)(first_draw + r0 + r), out);
             } else {
-                auto kern = k_ls_mask<int16_t>;
+                auto kern = sd_lds ? k_ls_mask<int16_t, true> : k_ls_mask<int16_t, false>;
                 if (ldm > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldm);
                 hipLaunchKernelGGL(kern, gm, block, ldm, s, (const int16_t*)ws, ws_pitch, B, N, rd_std, thresh, seed, env_offset,
                                    (int)(first_draw + r0 + r), out);
             }
         }
         if (int rc = check_launch("k_ls_mask")) return rc;
-        if (big) {   // the bare tile: 4 waves, lane-per-env loads and stores
+        if (half) {  // past the 64-env tile: half tiles (twice the workgroups, the same mask words)
+            const size_t lds = ls_apply32_lds(N, kLsRoundWaves);
+            auto kern = k_ls_apply_rounds32<24, kLsRoundWaves>;
+            if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(B, (int64_t)kHalf)), dim3(kLsRoundWaves * kWave), lds, s, x, B, N, g->eu, g->ev, E,
+                               halve, (const uint64_t*)scratch, (int64_t)grid.x, per_launch, obj, x_aligned);
+        } else if (big) {   // the bare tile: 4 waves, lane-per-env loads and stores
             const size_t lds = ls_apply_lds(N, 4, false);
             auto kern = k_ls_apply_rounds<24, 4>;
             if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

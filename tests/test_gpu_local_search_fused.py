@@ -229,3 +229,54 @@ def test_round_kernels_at_g81_size_where_the_tile_fills_lds():
     v1 = vb.clone()
     env.local_search_inplace(b, vb, num_iters=3, num_spin=num_spin)                                        # + K5 without the stage
     assert bool((vb >= v1).all()) and np.array_equal(vb.cpu().numpy(), onp.maxcut_obj(b.cpu().numpy(), garr, False))
+
+
+@pytest.mark.parametrize("n,m", [(24000, 48000), (36000, 54000), (39936, 60000)])
+def test_round_kernels_past_the_64_env_tile_on_half_tiles(n, m):
+    """20 224 < N <= 39 936: no 64-env tile fits LDS; the weights pre-pass, K1, the apply kernel of the proposal rounds and the sweep
+    run on HALF tiles (32 envs, 32-bit words: csrc/rls_tile32.h), the threshold / mask kernels as before (rd_std in LDS at 24 000,
+    read from global memory beyond ~24 900).  Invariants of every round, all rounds at once == one round per call, and the whole
+    local_search_inplace == the decomposed path (torch kthvalue + K6 per round on the kernels' own draws) for the same seed, bit
+    for bit."""
+    from rlsolver_amd import ops
+    from rlsolver_amd.envs.env_L2A import EnvMaxcut
+    B, num_spin = 100, 8
+    garr = gnm_arr(n, m, seed=81)
+    env = EnvMaxcut(mygraph=mygraph_of(garr), device=DEV, num_nodes=n, seed=11)
+    assert not ops.local_search_fusable(env.graph, num_spin, B) and ops.ls_rounds_supported(env.graph, num_spin)
+    xs = env.generate_xs_randomly(B)
+    vs = env.calculate_obj_values(xs)
+    assert np.array_equal(vs.cpu().numpy(), onp.maxcut_obj(xs.cpu().numpy(), garr, False))
+    ws, span = ops.maxcut_ls_weights(env.graph, xs, 1, padded=True)
+    c = ops.maxcut_node_cutdeg(env.graph, xs)
+    deg = torch.from_numpy(np.bincount(env.graph.csr.eu, minlength=n)).to(DEV)
+    assert torch.equal(ws[:, :n].long(), deg[None, :] - c)
+    assert torch.equal(span.long(), (deg[None, :] - c).max(0)[0] - (deg[None, :] - c).min(0)[0])
+    rd_std = (span.float() * 0.3).contiguous()
+    scratch1 = ops.ls_scratch(env.graph, B, ws, num_draws=1)
+    scratch4 = ops.ls_scratch(env.graph, B, ws, num_draws=4)
+    assert scratch1 is not None and scratch4.numel() == 4 * scratch1.numel()
+    thresh = ops.maxcut_ls_threshold(env.graph, ws, rd_std, seed=7, num_spin=num_spin, scratch=scratch1)
+    # the threshold against torch on the kernels' own draws
+    noisy0 = ws[:, :n].float() + ops.maxcut_ls_normals(B, n, 7, 0, DEV) * rd_std
+    assert torch.equal(thresh, torch.kthvalue(noisy0, k=n - num_spin, dim=1)[0])
+    a, va = xs.clone(), vs.clone()
+    for it in range(1, 5):
+        x0, v0 = a.clone(), va.clone()
+        ops.maxcut_ls_propose(env.graph, a, ws, rd_std, thresh, va, seed=7, draw=it, scratch=scratch1)
+        changed = (a != x0).any(dim=1)
+        assert bool((va >= v0).all()) and bool((va[~changed] == v0[~changed]).all())
+    assert np.array_equal(va.cpu().numpy(), onp.maxcut_obj(a.cpu().numpy(), garr, False)) and bool((va > vs).any())
+    b, vb = xs.clone(), vs.clone()
+    ops.maxcut_ls_rounds(env.graph, b, ws, rd_std, thresh, vb, seed=7, first_draw=1, num_draws=4, scratch=scratch4)
+    assert torch.equal(a, b) and torch.equal(va, vb)
+    # the whole call: round kernels (half tiles) == the decomposed path, same seed stream
+    outs = []
+    for fused in (True, False):
+        e2 = EnvMaxcut(mygraph=mygraph_of(garr), device=DEV, num_nodes=n, seed=23)
+        e2.fused_local_search = fused
+        x2, v2 = xs.clone(), vs.clone()
+        e2.local_search_inplace(x2, v2, num_iters=3, num_spin=num_spin)
+        assert np.array_equal(v2.cpu().numpy(), onp.maxcut_obj(x2.cpu().numpy(), garr, False)) and bool((v2 >= vs).all())
+        outs.append((x2, v2))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
