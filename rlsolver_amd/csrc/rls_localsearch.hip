@@ -746,13 +746,15 @@ static size_t ls_apply_lds(int64_t N, int W, bool stage) {
     return (size_t)((N + 1) & ~1ll) * 8 + (size_t)W * kWave * 8 + (stage ? (size_t)W * kStageBytes : 0);
 }
 // N beyond the proposal kernel's tile + stages but within the bare tile (15 500 < N <= 20 224): mask kernels + the 4-wave apply kernel
+// (rows of 16-byte multiples take half tiles there instead: their loader keeps 64-byte runs, the bare tile's reads 16 B per env)
 static bool ls_big_tile(int64_t N) {
     return (size_t)((N + 1) & ~1ll) * 8 + (size_t)kLsRoundWaves * kWave * 8 + (size_t)kLsRoundWaves * kStageBytes > (size_t)kLdsBytes &&
-           ls_apply_lds(N, 4, false) <= (size_t)kLdsBytes;
+           ls_apply_lds(N, 4, false) <= (size_t)kLdsBytes && (N & 15) != 0;
 }
 // N past the 64-env tile altogether but within the half tile (20 224 < N <= ~39 900): mask kernels + the apply kernel on half tiles
 static bool ls_half_tile(int64_t N) {
-    return !ls_big_tile(N) && ls_apply_lds(N, 4, false) > (size_t)kLdsBytes && ls_apply32_lds(N, kLsRoundWaves) <= (size_t)kLdsBytes;
+    return !ls_big_tile(N) && ls_apply32_lds(N, kLsRoundWaves) <= (size_t)kLdsBytes &&
+           (size_t)((N + 1) & ~1ll) * 8 + (size_t)kLsRoundWaves * kWave * 8 + (size_t)kLsRoundWaves * kStageBytes > (size_t)kLdsBytes;
 }
 static bool ls_sd_global() {   // dev knob: rd_std read from global memory even where it fits LDS
     static const bool on = getenv("RLS_LS_SD_GLOBAL") != nullptr;

@@ -888,7 +888,12 @@ static int launch_node_stats_bits(const rls_graph* g, const uint8_t* x, int64_t 
     const bool vec = tile_rows_aligned(x, N, 1);
     const bool wide = g->max_degree >= 256;
     static const int knob32 = getenv("RLS_NS_TILE32") ? atoi(getenv("RLS_NS_TILE32")) : -1;   // dev knob: half tiles at any size
-    if (knob32 > 0 || node_stats_bits_lds(N, false) > (size_t)kLdsBytes) {   // past the 64-env tile: half tiles (rls_tile32.h)
+    // past the 64-env tile, and -- for batches of few tiles -- where that tile leaves no room for the row-piece stage (N > ~15 800)
+    // while the half tile's does fit (K3 at N = 20 000: 4096 envs 278 -> 186 us; at 16 384 envs the plain per-env stores of the
+    // half-tile kernel lose, 402 -> 499, so larger batches keep the 64-env form)
+    const bool prefer32 = knob32 < 0 && node_stats_bits_lds(N, true) > (size_t)kLdsBytes && vec && (N & 15) == 0 &&
+                          node_stats_bits32_lds(N, true) <= (size_t)kLdsBytes && 2 * ceil_div(B, kWave) <= (int64_t)num_cus();
+    if (knob32 > 0 || prefer32 || node_stats_bits_lds(N, false) > (size_t)kLdsBytes) {   // half tiles (rls_tile32.h)
         const int st32 = (vec && (N & 15) == 0 && node_stats_bits32_lds(N, true) <= (size_t)kLdsBytes) ? 1 : 0;
         const size_t l32 = node_stats_bits32_lds(N, st32 != 0);
         const dim3 g32((unsigned)ceil_div(B, (int64_t)kHalf)), b32(kNsWaves * kWave);
@@ -1340,8 +1345,10 @@ int rls_maxcut_propose_accept(const rls_graph* g, uint8_t* x, int64_t B, const v
     // CU (G22-sized 2^12: 21.8 -> 9.9 us, 2^14: 26.8 -> 20.3; at 2^16 they lose, 63.6 -> 67.9).  tools/timing/k5_tile32.py.
     static const int knob32 = getenv("RLS_K6_TILE32") ? atoi(getenv("RLS_K6_TILE32")) : -1;   // dev knob: 0 | 1 forces the choice
     const bool no_stage64 = lds + (size_t)tw * kStageBytes > (size_t)kLdsBytes;
+    // (the half tile's fast loader wants byte rows of 16-byte multiples on a 16-byte base; other rows keep the 64-env forms)
+    const bool fast32 = (N & 15) == 0 && tile_rows_aligned(x, N, 1) && (mask_bits || tile_rows_aligned(mask, N, 1));
     const bool want32 = knob32 >= 0 ? knob32 != 0
-                                    : no_stage64 || ((size_t)N * 8 <= 64 * 1024 && ceil_div(B, kWave) <= (int64_t)num_cus());
+                                    : fast32 && (no_stage64 || ((size_t)N * 8 <= 64 * 1024 && ceil_div(B, kWave) <= (int64_t)num_cus()));
     if (want32 || lds > (size_t)kLdsBytes) {
         int w32 = kTileWavesMax;
         auto lds32 = [&](int ww) { return (((size_t)N * 4 + 15) & ~(size_t)15) + (size_t)ww * kWave * 8; };
@@ -1448,7 +1455,9 @@ int rls_maxcut_greedy_sweep(const rls_graph* g, uint8_t* x, int64_t B, int64_t* 
         const size_t lds_l = lds_of(sw, has_stage != 0);
         // half tiles (rls_tile32.h) where the 64-env tile does not fit (dev knob RLS_K5_TILE32 = 1: at any size)
         static const int knob32 = getenv("RLS_K5_TILE32") ? atoi(getenv("RLS_K5_TILE32")) : -1;
-        if ((knob32 > 0 || lds_l > (size_t)kLdsBytes) && !no_levels && !g->wgt && g->sweep_lv_ptr && g->sweep_lv_data && G > 0 && P != 0) {
+        // ... and where the 64-env tile leaves no room for the row-piece stage (N > ~15 800: N = 20 000 4096 envs 171 -> ~105 us)
+        const bool prefer32 = knob32 < 0 && !has_stage && vec && (N & 15) == 0;
+        if ((knob32 > 0 || prefer32 || lds_l > (size_t)kLdsBytes) && !no_levels && !g->wgt && g->sweep_lv_ptr && g->sweep_lv_data && G > 0 && P != 0) {
             int sw32 = force_lw == 2 || force_lw == 4 || force_lw == 8 ? force_lw : (N >= 56 * G ? 8 : 4);
             auto lds32_of = [&](int waves, bool stage) {
                 return (((size_t)(N + 2) * 4 + 15) & ~(size_t)15) + (((size_t)(G + 1) * 4 + 15) & ~(size_t)15) + (size_t)waves * kWave * 8 +

@@ -191,13 +191,15 @@ def test_round_kernels_beyond_the_fused_kernel(n, m):
     assert bool((vs >= v1).all()) and torch.equal(env.calculate_obj_values(xs), vs)
 
 
-def test_round_kernels_at_g81_size_where_the_tile_fills_lds():
+@pytest.mark.parametrize("n", [20000, 20008])
+def test_round_kernels_at_g81_size_where_the_tile_fills_lds(n):
     """N = 20 000 (Gset's G81): the 64-env tile takes 160 000 of LDS's 163 840 bytes, so the proposal rounds run as mask kernels
-    + the 4-wave apply kernel through the scratch buffer (which is required here), the threshold as usual; same invariants, and
+    + an apply kernel through the scratch buffer (which is required here) -- on half tiles (32 envs: rows of 16-byte multiples,
+    N = 20 000) or on the bare 64-env tile with 4 waves (other rows, N = 20 008) --, the threshold as usual; same invariants, and
     all rounds at once == one round per call for the same seed."""
     from rlsolver_amd import ops
     from rlsolver_amd.envs.env_L2A import EnvMaxcut
-    n, m, B, num_spin = 20000, 40000, 130, 8
+    m, B, num_spin = 40000, 130, 8
     garr = gnm_arr(n, m, seed=81)
     env = EnvMaxcut(mygraph=mygraph_of(garr), device=DEV, num_nodes=n)
     assert not ops.local_search_fusable(env.graph, num_spin, B) and ops.ls_rounds_supported(env.graph, num_spin)

@@ -1,6 +1,7 @@
-"""The MaxCut entry points over the Gset node counts (800 ... 20 000) at two batch sizes: us per call and ns per (env, node).
-Looks for cliffs where a kernel form changes (fused local search <= ~7100 nodes, round kernels and the 64-env tile <= ~15 500 /
-~19 000, one env per wave beyond).  `python tools/sweeps/n_sweep.py`."""
+"""The MaxCut entry points over the Gset node counts (800 ... 20 000) and past them (24 000 ... 44 000) at two batch sizes: us per
+call and ns per (env, node).  Looks for cliffs where a kernel form changes (fused local search <= ~7100 nodes, round kernels and
+the 64-env tile <= ~15 500 / 20 224, half tiles of 32 envs <= 39 936 / 40 448, one env per wave beyond).
+`python tools/sweeps/n_sweep.py`."""
 import os, sys, types
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
@@ -10,7 +11,7 @@ from rlsolver_amd.envs.env_PPO import EnvMaxcut as Gym
 from rlsolver_amd.graph import generate_gnm
 
 dev = torch.device("cuda:0")
-NS = (800, 1000, 2000, 3000, 5000, 7000, 8000, 9000, 10000, 14000, 20000)
+NS = (800, 1000, 2000, 3000, 5000, 7000, 8000, 9000, 10000, 14000, 20000, 20240, 24000, 32000, 39936, 44000)
 
 
 def t_us(f, n=4):
@@ -22,7 +23,7 @@ def t_us(f, n=4):
     return e0.elapsed_time(e1) / n * 1e3
 
 
-for B in (4096, 32768):
+for B in (4096, 16384):
     print(f"B = {B}; graphs G(N, 3 N); us per call [ns per (env, node)]")
     print(f"{'':30s}" + "".join(f"{n:>15d}" for n in NS))
     rows = {}
