@@ -22,6 +22,10 @@
  *     4 = float32 holding 0.0f|1.0f, the env_PPO surface);
  *   - B = number of parallel environments ("sims"), N = nodes, E' = edges as
  *     stored by the env (E, or 2E when if_bidirectional).
+ *   - graph size: the MaxCut kernels keep a bit tile of the spins in LDS -- 64 envs x N nodes (N <= 20 224) or, past
+ *     that and wherever it measures faster, a half tile of 32 envs (N <= ~40 000; csrc/rls_tile32.h).  Larger graphs take
+ *     one-env-per-wave forms (N <= 160 000): correct, an order of magnitude slower.  The choice is per launch and changes
+ *     no result.
  */
 #ifndef RLSOLVER_HIP_H
 #define RLSOLVER_HIP_H
@@ -189,7 +193,8 @@ int rls_maxcut_greedy_sweep(const rls_graph* g, uint8_t* x, int64_t B,
  * the reference does).  x/obj (int64) are updated in place: rows whose proposal
  * has cut >= obj[b] take the proposal.
  * mask_bits != 0: the mask is bit-packed, uint64 [ceil(B/64), N], bit e of word (t, n) = env 64 t + e at node n (bits of envs >= B
- * zero) -- the tile the kernel works on, N / 8 bytes per env instead of N (graphs within the 64-env tile, N <= 20 224). */
+ * zero) -- the tile the kernel works on, N / 8 bytes per env instead of N (graphs within the 64-env tile, N <= 20 224, or the
+ * half tile of 32 envs, N <= 40 448, which takes the matching dword of each word). */
 int rls_maxcut_propose_accept(const rls_graph* g, uint8_t* x, int64_t B, const void* mask, int32_t mask_bits,
                               int64_t* obj, void* stream);
 
@@ -241,8 +246,9 @@ int rls_maxcut_local_search_supported(const rls_graph* g, int64_t B, int32_t num
 int rls_maxcut_node_stats_form(const rls_graph* g, int64_t B, int32_t what);
 
 /* The same local search as separate launches, for graphs rls_maxcut_local_search does not cover (its LDS layout holds
- * two tiles and rd_std: N <= ~7100; these hold one tile: N <= ~15 000 -- and up to N = 20 224, where the tile
- * nearly fills LDS, through the scratch buffer, which is then REQUIRED).  Both use the fused kernel's
+ * two tiles and rd_std: N <= ~7100; these hold one tile: N <= ~15 000 -- and up to N = 39 936 on half tiles of 32 envs
+ * (the bare 64-env tile for rows that are not 16-byte multiples, N <= 20 224), through the scratch buffer, which is
+ * then REQUIRED; past ~24 900 nodes rd_std is read from global memory and N must be a multiple of 4).  Both use the fused kernel's
  * in-kernel draws -- normal(seed, env_offset + b, node, draw) -- so a caller that passes the same seed gets the result
  * the fused kernel would give.  They replace the torch ops of the decomposed path (randn_like, ws + noise * rd_std,
  * kthvalue, gt: envs/env_L2A.py:95-101, methods/LocalSearch.py:66-72) and K6's mask input.
