@@ -47,7 +47,7 @@ ROWS = [
     (r"k_maxcut_step<unsigned char, 8, 2, true", 256 // 8 * 64, 256, 2 * N14 + 20, "K4 maxcut_step emit u8 | G14 256 (launch-bound)"),
     (r"k_maxcut_obj<", T22 * 256, 65536, N22 + 8, "K1 maxcut_obj | G22 2^16"),
     (r"k_maxcut_obj<", T70 * 512, 131072, N70 + 8, "K1 maxcut_obj | G70 2^17"),
-    (r"k_maxcut_obj32<", 2 * T70 * 512, 131072, N70 + 8, "K1 maxcut_obj on half tiles (32 envs per workgroup: rows past 8192 nodes) | G70 2^17"),
+    (r"k_maxcut_obj32<", 2 * T70 * 256, 131072, N70 + 8, "K1 maxcut_obj on half tiles (32 envs per workgroup: rows past 8192 nodes) | G70 2^17"),
     (r"k_maxcut_propose_accept<true, \d+, \d+, true>", T22 * 256, 65536, 2 * N22 + N22 // 8 + 16, "K6 propose_accept, bit-packed mask | G22 2^16"),
     (r"k_maxcut_propose_accept<true, \d+, \d+, true>", T70 * 512, 131072, 2 * N70 + N70 // 8 + 16, "K6 propose_accept, bit-packed mask | G70 2^17"),
     (r"k_maxcut_propose_accept<", T22 * 256, 65536, 2 * N22 + 16, "K6 propose_accept, byte mask | G22 2^16"),
