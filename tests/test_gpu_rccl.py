@@ -128,3 +128,12 @@ def test_sharded_search_loop_example_is_rank_count_invariant():
     assert (one["ranks"], two["ranks"]) == (1, 2)
     assert one["best"] == two["best"] == one["cut_of_x"] == two["cut_of_x"] and one["x_str"] == two["x_str"]
     assert one["best"] > 1500 * 0.6                                   # and the search found something: well above a random cut
+
+
+def test_s2v_episode_example_runs():
+    """examples/s2v_episodes.py: S2V-DQN's env_args (train_S2V.py:37-47: irreversible spins) through ising_env.make and the
+    agent's action masking (dqn.py:254, 419-430), asserting inside that an episode ends after every spin was flipped once and that
+    the DENSE rewards sum to the cut change."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "s2v_episodes.py"), "--nodes", "30", "--episodes", "3"], cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().splitlines()[-1] == "s2v_episodes: ok", r.stdout[-3000:]
