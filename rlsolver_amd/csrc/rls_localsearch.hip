@@ -363,12 +363,14 @@ __global__ __launch_bounds__(W * kWave) void k_maxcut_local_search(
     for (int64_t i = threadIdx.x; i <= (batched == 2 ? sweep_len : N); i += W * kWave) rp[i] = rowptr[i];
     __syncthreads();
     if (batched == 2) {   // level-parallel (lane = node): sweep_src = group records, sweep_len = number of groups
-        const int64_t before = block_sum_partials<W>(tile_cut_count<P>(words, eu, ev, E, lane, w, W), scratch, lane, w);
-        __syncthreads();
+        // my_obj IS the cut of the tile here (counted in phase 0 or handed in as such, then every accepted proposal's count): the
+        // sweep's result is one count of the new tile -- not after - before (a tenth of the kernel's edge counts) -- and the tile's
+        // stores go out first, draining under that count (both only read the words)
         sweep_tile_levels<W>(words, rp, sweep_src, sweep_len, N, lane, w);
+        tile_store_bytes<VEC>(x, B, N, b0, words, lane, w, W, true, stage);
         const int64_t after = block_sum_partials<W>(tile_cut_count<P>(words, eu, ev, E, lane, w, W), scratch, lane, w);
-        my_obj += halve ? ((after - before) >> 1) : (after - before);
-        if (w == 0 && valid) obj[b] = my_obj;
+        if (w == 0 && valid) obj[b] = halve ? (after >> 1) : after;
+        return;
     } else if (batched) {   // all W waves over the host-built level schedule, one node per wave step (rp carries the batch flags)
         const int64_t part = sweep_tile_batched<W>(words, rp, ring, sweep_src, sweep_len, N, lane, w);
         my_obj += block_sum_partials<W>(part, scratch, lane, w);
