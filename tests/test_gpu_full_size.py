@@ -440,3 +440,55 @@ def test_tile_kernels_where_the_tile_fills_lds(n):
     ops.maxcut_greedy_sweep(g, x5, v5)
     wx, wv = oc.greedy_sweep(xs[:6].copy(), want[:6].astype(np.int64).copy(), eu, ev, 0)
     assert np.array_equal(x5.cpu().numpy().astype(np.uint8), wx) and np.array_equal(v5.cpu().numpy(), wv)
+
+
+@pytest.mark.parametrize("n,m,B", [(32000, 64000, 1 << 13), (39936, 60000, 1 << 12)])
+def test_half_tile_forms_at_scale(n, m, B):
+    """Graphs past the 64-env tile (20 224 < N <= 39 936) at thousands of envs: every MaxCut entry point runs on half tiles there
+    (csrc/rls_tile32.h).  K1 against an independent torch formulation on every env; K3 / K2 / the weights pre-pass against each other
+    and torch on a sample; K6 accepts exactly the proposals that do not lower the cut (byte mask == bit-packed mask); the sweep and
+    the local search leave obj == the recomputed cut, never lower, rows untouched where nothing was accepted."""
+    from rlsolver_amd.envs.env_L2A import EnvMaxcut
+    from rlsolver_amd.ops_mcpg_tsp import PackedChains
+    graph = gnm_arr(n, m, seed=91)
+    env = EnvMaxcut(mygraph=[tuple(int(v) for v in r) for r in graph], device=DEV, num_nodes=n, seed=3)
+    g = env.graph
+    x = env.generate_xs_randomly(B)
+    v = ops.maxcut_obj(g, x)
+    eu, ev = g.eu.long(), g.ev.long()
+    want = torch.zeros(B, dtype=torch.int64, device=DEV)
+    for e0 in range(0, len(eu), 16000):                                # [B, 16 000] slices: the whole batch, not a sample
+        want += (x[:, eu[e0:e0 + 16000]] ^ x[:, ev[e0:e0 + 16000]]).sum(dim=1)
+    assert torch.equal(v, want) and torch.equal(ops.maxcut_obj(g, ~x), v) and torch.equal(ops.maxcut_obj(g, x.float()), v)
+    rows = torch.arange(0, B, 257, device=DEV)
+    d = ops.maxcut_delta_all(g, x)
+    cd = ops.maxcut_node_cutdeg(g, x)
+    assert int(cd.sum(dim=1)[0]) == int(v[0])                          # each cut edge counted at its stored end
+    for r in rows[:4].tolist():                                        # flipping node i changes the cut by delta[i]
+        i = int(torch.randint(0, n, (1,)))
+        x1 = x[r:r + 1].clone()
+        x1[0, i] = ~x1[0, i]
+        assert int(ops.maxcut_obj(g, x1)[0]) - int(v[r]) == int(d[r, i])
+    ws, span = ops.maxcut_ls_weights(g, x, 1, padded=True)
+    deg_st = torch.bincount(eu, minlength=n)
+    assert torch.equal(ws[:, :n].long()[rows], (deg_st[None, :] - cd)[rows])
+    # K6
+    mask = torch.rand((B, n), device=DEV) < 0.002
+    mask[0] = False
+    x1 = x ^ mask
+    v1 = ops.maxcut_obj(g, x1)
+    take = v1 >= v
+    xa, va = x.clone(), v.clone()
+    ops.maxcut_propose_accept(g, xa, mask, va)
+    assert torch.equal(va, torch.where(take, v1, v)) and torch.equal(xa, torch.where(take[:, None], x1, x)) and bool(take.any()) and not bool(take.all())
+    xb, vb = x.clone(), v.clone()
+    ops.maxcut_propose_accept(g, xb, PackedChains.pack(mask.t().contiguous()).words, vb)
+    assert torch.equal(xa, xb) and torch.equal(va, vb)
+    # K5 and the whole local search
+    xs, vs = x.clone(), v.clone()
+    ops.maxcut_greedy_sweep(g, xs, vs)
+    assert bool((vs >= v).all()) and bool((vs > v).any()) and torch.equal(ops.maxcut_obj(g, xs), vs)
+    assert ops.ls_rounds_supported(g, 8)
+    xl, vl = x.clone(), v.clone()
+    env.local_search_inplace(xl, vl, num_iters=4, num_spin=8)
+    assert bool((vl >= v).all()) and torch.equal(ops.maxcut_obj(g, xl), vl)
