@@ -708,7 +708,7 @@ template <int P, int W>
 __global__ __launch_bounds__(W * kWave) void k_ls_apply_rounds32(uint8_t* __restrict__ x, int64_t B, int64_t N, const int32_t* __restrict__ eu,
                                                                  const int32_t* __restrict__ ev, int64_t E, int halve,
                                                                  const uint64_t* __restrict__ maskw, int64_t tiles64, int rounds,
-                                                                 int64_t* __restrict__ obj, int x_aligned) {
+                                                                 int64_t* __restrict__ obj, int x_aligned, int has_stage) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* words32 = reinterpret_cast<uint32_t*>(smem);
     int64_t* scratch = reinterpret_cast<int64_t*>(smem + (((size_t)N * 4 + 15) & ~(size_t)15));
@@ -716,8 +716,9 @@ __global__ __launch_bounds__(W * kWave) void k_ls_apply_rounds32(uint8_t* __rest
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     const int64_t b0 = (int64_t)blockIdx.x * kHalf, b = b0 + (lane & (kHalf - 1));
     const bool valid = b < B && lane < kHalf;
-    if (x_aligned) tile32_load_bits<uint8_t, true>(x, B, N, b0, words32, lane, w, W, nullptr);
-    else tile32_load_bits<uint8_t, false>(x, B, N, b0, words32, lane, w, W, nullptr);
+    unsigned char* stage = has_stage ? reinterpret_cast<unsigned char*>(scratch + W * kWave) + (size_t)w * kStageBytes : nullptr;
+    if (x_aligned) tile32_load_bits<uint8_t, true>(x, B, N, b0, words32, lane, w, W, stage);
+    else tile32_load_bits<uint8_t, false>(x, B, N, b0, words32, lane, w, W, stage);
     int64_t my_obj = valid ? obj[b] : 0;
     bool changed = false;
     __syncthreads();
@@ -738,11 +739,13 @@ __global__ __launch_bounds__(W * kWave) void k_ls_apply_rounds32(uint8_t* __rest
     }
     if (w == 0 && valid) obj[b] = my_obj;
     const bool ch_env = (bool)((ballot64(changed) >> (lane & (kHalf - 1))) & 1ull);      // lanes 32..63 store their env's second block
-    if (x_aligned) tile32_store_bytes<true>(x, B, N, b0, words32, lane, w, W, ch_env);
-    else tile32_store_bytes<false>(x, B, N, b0, words32, lane, w, W, ch_env);
+    if (x_aligned) tile32_store_bytes<true>(x, B, N, b0, words32, lane, w, W, ch_env, stage);
+    else tile32_store_bytes<false>(x, B, N, b0, words32, lane, w, W, ch_env, stage);
 }
 
-static size_t ls_apply32_lds(int64_t N, int W) { return (((size_t)N * 4 + 15) & ~(size_t)15) + (size_t)W * kWave * 8; }
+static size_t ls_apply32_lds(int64_t N, int W, bool stage = false) {
+    return (((size_t)N * 4 + 15) & ~(size_t)15) + (size_t)W * kWave * 8 + (stage ? (size_t)W * kStageBytes : 0);
+}
 
 static size_t ls_apply_lds(int64_t N, int W, bool stage) {
     return (size_t)((N + 1) & ~1ll) * 8 + (size_t)W * kWave * 8 + (stage ? (size_t)W * kStageBytes : 0);
@@ -1089,11 +1092,12 @@ extern "C" int rls_maxcut_ls_rounds(const rls_graph* g, uint8_t* x, int64_t B, c
         }
         if (int rc = check_launch("k_ls_mask")) return rc;
         if (half) {  // past the 64-env tile: half tiles (twice the workgroups, the same mask words)
-            const size_t lds = ls_apply32_lds(N, kLsRoundWaves);
+            const int st32 = (x_aligned && (N & 15) == 0 && ls_apply32_lds(N, kLsRoundWaves, true) <= (size_t)kLdsBytes) ? 1 : 0;
+            const size_t lds = ls_apply32_lds(N, kLsRoundWaves, st32 != 0);
             auto kern = k_ls_apply_rounds32<24, kLsRoundWaves>;
             if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(B, (int64_t)kHalf)), dim3(kLsRoundWaves * kWave), lds, s, x, B, N, g->eu, g->ev, E,
-                               halve, (const uint64_t*)scratch, (int64_t)grid.x, per_launch, obj, x_aligned);
+                               halve, (const uint64_t*)scratch, (int64_t)grid.x, per_launch, obj, x_aligned, st32);
         } else if (big) {   // the bare tile: 4 waves, lane-per-env loads and stores
             const size_t lds = ls_apply_lds(N, 4, false);
             auto kern = k_ls_apply_rounds<24, 4>;

@@ -124,20 +124,21 @@ template <bool VEC, int P, int W, bool MASK_BITS>
 __global__ __launch_bounds__(W * kWave) void k_maxcut_propose_accept32(uint8_t* __restrict__ x, const uint8_t* __restrict__ mask,
                                                                       int64_t B, int64_t N, const int32_t* __restrict__ eu,
                                                                       const int32_t* __restrict__ ev, int64_t E, int halve,
-                                                                      int64_t* __restrict__ obj) {
+                                                                      int64_t* __restrict__ obj, int stage_off) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t* words32 = reinterpret_cast<uint32_t*>(smem);
     int64_t* scratch = reinterpret_cast<int64_t*>(smem + (((size_t)N * 4 + 15) & ~(size_t)15));
     const int lane = threadIdx.x & (kWave - 1);
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     const int64_t b0 = (int64_t)blockIdx.x * kHalf;
-    tile32_load_bits<uint8_t, VEC>(x, B, N, b0, words32, lane, w, W, nullptr);
+    unsigned char* stage = stage_off >= 0 ? smem + stage_off + w * kStageBytes : nullptr;
+    tile32_load_bits<uint8_t, VEC>(x, B, N, b0, words32, lane, w, W, stage);
     if constexpr (MASK_BITS) {
         __syncthreads();
         const uint32_t* mw = reinterpret_cast<const uint32_t*>(mask) + ((int64_t)(blockIdx.x >> 1) * N) * 2 + (blockIdx.x & 1);
         for (int64_t n = threadIdx.x; n < N; n += W * kWave) words32[n] ^= mw[n * 2];
     } else {
-        tile32_load_bits<uint8_t, VEC, true>(mask, B, N, b0, words32, lane, w, W, nullptr);
+        tile32_load_bits<uint8_t, VEC, true>(mask, B, N, b0, words32, lane, w, W, stage);
     }
     __syncthreads();
     int64_t total = block_sum_partials<W>(tile32_cut_count<P>(words32, eu, ev, E, lane, w, W), scratch, lane, w);
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(W * kWave) void k_maxcut_propose_accept32(uint8_t* 
     const bool acc_env = (bool)((ballot64(accept && lane < kHalf) >> (lane & (kHalf - 1))) & 1ull);
     __syncthreads();                                      // every wave has read obj[b] before wave 0 updates it
     if (acc_env && w == 0 && lane < kHalf) obj[b] = total;
-    tile32_store_bytes<VEC>(x, B, N, b0, words32, lane, w, W, acc_env);
+    tile32_store_bytes<VEC>(x, B, N, b0, words32, lane, w, W, acc_env, stage);
 }
 
 // =====================================================================================
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(SW * kWave) void k_maxcut_greedy_sweep_levels32(
     if (w < LW) tile32_load_bits<uint8_t, VEC>(x, B, N, b0, words32, lane, w, LW, stage);
     __syncthreads();
     sweep32_tile_levels<SW>(words32, lvp, lv_data, G, N, lane, w);
-    if (w < LW) tile32_store_bytes<VEC>(x, B, N, b0, words32, lane, w, LW, true);   // (stores first: they drain under the count)
+    if (w < LW) tile32_store_bytes<VEC>(x, B, N, b0, words32, lane, w, LW, true, stage);   // (stores first: they drain under the count)
     const int64_t after = block_sum_partials<SW>(tile32_cut_count<P>(words32, eu, ev, E, lane, w, SW), scratch, lane, w);
     if (w == 0 && lane < kHalf && b0 + lane < B) obj[b0 + lane] = halve ? (after >> 1) : after;
 }
@@ -1355,10 +1356,11 @@ int rls_maxcut_propose_accept(const rls_graph* g, uint8_t* x, int64_t B, const v
         int w32 = kTileWavesMax;
         auto lds32 = [&](int ww) { return (((size_t)N * 4 + 15) & ~(size_t)15) + (size_t)ww * kWave * 8; };
         if (lds32(w32) > (size_t)kLdsBytes) w32 = kTileWaves;
-        const size_t l32 = lds32(w32);
+        size_t l32 = lds32(w32);
         const int P32 = pick_planes(E);
         if (l32 <= (size_t)kLdsBytes && P32 != 0) {
             const bool vec = tile_rows_aligned(x, N, 1) && (mask_bits || tile_rows_aligned(mask, N, 1));
+            const int st32 = tile_stage_offset(&l32, w32, vec && (N & 15) == 0);   // (row-piece stages when they fit beside the tile)
             const dim3 g32((unsigned)ceil_div(B, (int64_t)kHalf)), b32(w32 * kWave);
             hipStream_t s32 = as_stream(stream);
             const int hv = g->if_bidirectional ? 1 : 0;
@@ -1369,7 +1371,7 @@ int rls_maxcut_propose_accept(const rls_graph* g, uint8_t* x, int64_t B, const v
                               : (w32 == kTileWavesMax ? k_maxcut_propose_accept32<VEC, PP, kTileWavesMax, false>        \
                                                       : k_maxcut_propose_accept32<VEC, PP, kTileWaves, false>);         \
         if (l32 > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l32); \
-        hipLaunchKernelGGL(kern, g32, b32, l32, s32, x, mask, B, N, g->eu, g->ev, E, hv, obj);                          \
+        hipLaunchKernelGGL(kern, g32, b32, l32, s32, x, mask, B, N, g->eu, g->ev, E, hv, obj, st32);                    \
     } while (0)
 #define DISPATCH_P32(VEC)                      \
     switch (P32) {                             \

@@ -112,12 +112,41 @@ __device__ __forceinline__ void tile32_load_bits(const T* __restrict__ x, int64_
 // takes part whatever it stores.
 template <bool VEC>
 __device__ __forceinline__ void tile32_store_bytes(uint8_t* __restrict__ x, int64_t B, int64_t N, int64_t b0,
-                                                   const uint32_t* __restrict__ words32, int lane, int w, int W, bool store_row) {
+                                                   const uint32_t* __restrict__ words32, int lane, int w, int W, bool store_row,
+                                                   unsigned char* stage = nullptr) {
     const int env = lane & (kHalf - 1), blk = lane >> 5;
     const int64_t b = b0 + env;
     const bool valid = b < B && store_row;
     uint8_t* row = x + (b < B ? b : 0) * N;
     if constexpr (VEC) {
+        if ((N & 15) == 0 && stage != nullptr) {
+            // through the row-piece stage (the loader's corner turn backwards): lane l = (env, block) parks its four 16-byte pieces,
+            // instruction i then writes rows 8 i .. 8 i + 7 as 128-byte runs (lane -> row 8 i + (l & 7), piece l >> 3)
+            const uint32_t rows_ok = (uint32_t)ballot64(valid && blk == 0);
+            const int64_t nchunk = (N + 127) >> 7;
+            const BitXpose xc = bit_xpose_consts(lane);
+            const int r = lane & 7, j = lane >> 3;
+            for (int64_t ch = w; ch < nchunk; ch += W) {
+                const int64_t n = (ch << 7) + xc.node;
+                uint32_t r0 = (n < N) ? words32[n] : 0u, r1 = (n + 64 < N) ? words32[n + 64] : 0u;
+                bit_transpose64(r0, r1, xc);
+                u32x4 v[4];
+                unpack_bits(r0, v[0], v[1]);
+                unpack_bits(r1, v[2], v[3]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) *reinterpret_cast<u32x4*>(stage + ((4 * blk + q) * 32 + env) * 16) = v[q];
+                asm volatile("" ::: "memory");   // LDS ops of one wave execute in order
+                const int64_t off = (ch << 7) + j * 16;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int rr = 8 * i + r;
+                    const u32x4 o = *reinterpret_cast<const u32x4*>(stage + (j * 32 + rr) * 16);
+                    if (((rows_ok >> rr) & 1u) && off < N) *reinterpret_cast<u32x4*>(x + (b0 + rr) * N + off) = o;
+                }
+                asm volatile("" ::: "memory");
+            }
+            return;
+        }
         if ((N & 15) == 0) {
             // inverse of the load: lane p fetches the two words of node p (blocks 2c, 2c + 1), the transpose hands lane l = (env,
             // block) that env's 64 bits of that block, unpacked to 64 bytes = four 16-byte stores
