@@ -1343,15 +1343,16 @@ int rls_maxcut_propose_accept(const rls_graph* g, uint8_t* x, int64_t B, const v
         tw = kTileWaves;              // (as in rls_maxcut_obj: the tile alone fits, 4 waves without the row-piece stage)
         lds = (size_t)N * 8 + (size_t)tw * kWave * 8;
     }
-    // Half tiles (rls_tile32.h): where the 64-env tile does not fit and N * 4 bytes do, where it fits but leaves no room for the
-    // row-piece stage (N > ~15 800: N = 20 000 2^15 387 -> 303 us), and for short rows in launches of at most one 64-env tile per
-    // CU (G22-sized 2^12: 21.8 -> 9.9 us, 2^14: 26.8 -> 20.3; at 2^16 they lose, 63.6 -> 67.9).  tools/timing/k5_tile32.py.
+    // Half tiles (rls_tile32.h): where the 64-env tile does not fit and N * 4 bytes do, for rows past 8192 nodes (G70-sized 2^17,
+    // byte mask: 608 -> 481 us; N = 20 000 2^15, where the 64-env tile has no room for its stage: 387 -> 299), and in launches of
+    // at most one 64-env tile per CU (G22-sized 2^12: 21.8 -> 11.4 us, 2^14: 26.8 -> 20.9; at 2^16 they lose, 63.6 -> 67.3).
+    // tools/timing/k5_tile32.py.
     static const int knob32 = getenv("RLS_K6_TILE32") ? atoi(getenv("RLS_K6_TILE32")) : -1;   // dev knob: 0 | 1 forces the choice
     const bool no_stage64 = lds + (size_t)tw * kStageBytes > (size_t)kLdsBytes;
     // (the half tile's fast loader wants byte rows of 16-byte multiples on a 16-byte base; other rows keep the 64-env forms)
     const bool fast32 = (N & 15) == 0 && tile_rows_aligned(x, N, 1) && (mask_bits || tile_rows_aligned(mask, N, 1));
     const bool want32 = knob32 >= 0 ? knob32 != 0
-                                    : fast32 && (no_stage64 || ((size_t)N * 8 <= 64 * 1024 && ceil_div(B, kWave) <= (int64_t)num_cus()));
+                                    : fast32 && (no_stage64 || (size_t)N * 8 > 64 * 1024 || ceil_div(B, kWave) <= (int64_t)num_cus());
     if (want32 || lds > (size_t)kLdsBytes) {
         int w32 = kTileWavesMax;
         auto lds32 = [&](int ww) { return (((size_t)N * 4 + 15) & ~(size_t)15) + (size_t)ww * kWave * 8; };
@@ -1459,8 +1460,12 @@ int rls_maxcut_greedy_sweep(const rls_graph* g, uint8_t* x, int64_t B, int64_t* 
         const size_t lds_l = lds_of(sw, has_stage != 0);
         // half tiles (rls_tile32.h) where the 64-env tile does not fit (dev knob RLS_K5_TILE32 = 1: at any size)
         static const int knob32 = getenv("RLS_K5_TILE32") ? atoi(getenv("RLS_K5_TILE32")) : -1;
-        // ... and where the 64-env tile leaves no room for the row-piece stage (N > ~15 800: N = 20 000 4096 envs 171 -> ~105 us)
-        const bool prefer32 = knob32 < 0 && !has_stage && vec && (N & 15) == 0;
+        // ... and, for byte rows of 16-byte multiples (the half tile's staged loader / store), where they measure faster
+        // (tools/timing/k5_tile32.py): rows past 8192 nodes (G70-sized 2^17: 780 -> 705 us; N = 20 000, where the 64-env tile has no
+        // room for its stage, 4096 envs: 171 -> 100) and launches of at most one 64-env tile per CU (G22-sized 2^14: 63 -> 53 us;
+        // at 2^16 the half tiles lose, 113 -> 128: twice the schedule reads per env)
+        const bool prefer32 = knob32 < 0 && vec && (N & 15) == 0 &&
+                              (!has_stage || (size_t)N * 8 > 64 * 1024 || ceil_div(B, kWave) <= (int64_t)num_cus());
         if ((knob32 > 0 || prefer32 || lds_l > (size_t)kLdsBytes) && !no_levels && !g->wgt && g->sweep_lv_ptr && g->sweep_lv_data && G > 0 && P != 0) {
             int sw32 = force_lw == 2 || force_lw == 4 || force_lw == 8 ? force_lw : (N >= 56 * G ? 8 : 4);
             auto lds32_of = [&](int waves, bool stage) {
