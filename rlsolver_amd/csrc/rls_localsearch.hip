@@ -1091,7 +1091,13 @@ extern "C" int rls_maxcut_ls_rounds(const rls_graph* g, uint8_t* x, int64_t B, c
             }
         }
         if (int rc = check_launch("k_ls_mask")) return rc;
-        if (half) {  // past the 64-env tile: half tiles (twice the workgroups, the same mask words)
+        // half tiles (twice the workgroups, the same mask words): past the 64-env tile, and for batches that leave half the CUs
+        // without a 64-env tile (whole local_search_inplace calls, 4096 envs: G22-sized 0.324 -> 0.305 ms, BA n = 10^4 0.893 -> 0.816,
+        // G70-sized 0.689 -> 0.642; at 16 384 envs no gain).  Dev knob RLS_LS_APPLY32 = 0 | 1 forces the choice.
+        static const int knob32 = getenv("RLS_LS_APPLY32") ? atoi(getenv("RLS_LS_APPLY32")) : -1;
+        const bool fast32 = x_aligned && (N & 15) == 0 && ls_apply32_lds(N, kLsRoundWaves, true) <= (size_t)kLdsBytes;
+        const bool few32 = knob32 >= 0 ? knob32 != 0 : 2 * (int64_t)grid.x <= (int64_t)num_cus();
+        if (half || (few32 && fast32)) {
             const int st32 = (x_aligned && (N & 15) == 0 && ls_apply32_lds(N, kLsRoundWaves, true) <= (size_t)kLdsBytes) ? 1 : 0;
             const size_t lds = ls_apply32_lds(N, kLsRoundWaves, st32 != 0);
             auto kern = k_ls_apply_rounds32<24, kLsRoundWaves>;
