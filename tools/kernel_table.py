@@ -67,6 +67,7 @@ ROWS = [
     (r"k_ls_threshold<short>", 512 * 512, 32768, 2 * NBA + 4, "LS threshold kernel: noise + top-9 per env | BA-1e4 2^15 (VALU-bound; int16 ws in)"),
     (r"k_ls_mask<short>", 4 * 64 * 512, 4096, 2 * NBA + NBA // 8, "LS mask kernel: noise + mask for a quarter of the rows per workgroup | BA-1e4 4096 (64 tiles x 4 slices)"),
     (r"k_ls_apply_rounds<24, 8>", 64 * 512, 4096, 2 * NBA + 8 * (NBA // 8) * 8 + 16, "LS apply kernel: 8 rounds of (x ^ mask words, count, accept, undo) on one load of the tile | BA-1e4 4096"),
+    (r"k_ls_apply_rounds32<24, 8>", 128 * 512, 4096, 2 * NBA + 8 * (NBA // 8) * 8 + 16, "LS apply kernel on half tiles (a batch of few tiles: 128 workgroups instead of 64): 8 rounds on one load of the tile | BA-1e4 4096"),
     (r"k_node_stats_bits<2, true, true, short", 512 * 512, 32768, 3 * NBA, "ls_weights pre-pass, int16 weights (hub graph: 16 counter planes) | BA-1e4 2^15"),
     (r"k_tsp_tour_length", None, 65536, 8 * NT + 4, "K12 tsp_tour_length | TSP-100 2^16"),
     (r"k_tsp_swap_delta_all", None, 65536, 29 * NT, "K13 tsp_swap_delta_all | TSP-100 2^16"),

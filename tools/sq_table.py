@@ -21,7 +21,7 @@ import sys
 tag, src = sys.argv[1], sys.argv[2]
 WANT = [r"k_maxcut_greedy_sweep_levels", r"k_maxcut_propose_accept32", r"k_mcpg_local_search_levels", r"k_maxcut_local_search", r"k_mcpg_metro_packed", r"k_isco_maxcut_step",
         r"k_isco_tsp_step", r"k_qubo_ls_value_mfma", r"k_qubo_sparse_ls_value", r"k_maxcut_obj<", r"k_maxcut_obj32<", r"k_node_stats_bits", r"k_maxcut_step<",
-        r"k_spin_step", r"k_tsp_2opt", r"k_ls_threshold<", r"k_ls_mask<", r"k_ls_propose<", r"k_ls_apply_rounds<"]
+        r"k_spin_step", r"k_tsp_2opt", r"k_ls_threshold<", r"k_ls_mask<", r"k_ls_propose<", r"k_ls_apply_rounds<", r"k_ls_apply_rounds32<"]
 
 
 def short(n):
