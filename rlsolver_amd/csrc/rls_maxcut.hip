@@ -891,11 +891,17 @@ static int launch_node_stats_bits(const rls_graph* g, const uint8_t* x, int64_t 
     const bool vec = tile_rows_aligned(x, N, 1);
     const bool wide = g->max_degree >= 256;
     static const int knob32 = getenv("RLS_NS_TILE32") ? atoi(getenv("RLS_NS_TILE32")) : -1;   // dev knob: half tiles at any size
-    // past the 64-env tile, and -- for batches of few tiles -- where that tile leaves no room for the row-piece stage (N > ~15 800)
-    // while the half tile's does fit (K3 at N = 20 000: 4096 envs 278 -> 186 us; at 16 384 envs the plain per-env stores of the
-    // half-tile kernel lose, 402 -> 499, so larger batches keep the 64-env form)
-    const bool prefer32 = knob32 < 0 && node_stats_bits_lds(N, true) > (size_t)kLdsBytes && vec && (N & 15) == 0 &&
-                          node_stats_bits32_lds(N, true) <= (size_t)kLdsBytes && 2 * ceil_div(B, kWave) <= (int64_t)num_cus();
+    // Half tiles: past the 64-env tile; and, for byte rows of 16-byte multiples whose half tile has room for its stage, where they
+    // measure faster (this round's GPU runs): batches of few tiles -- a tile costs the same however few envs it holds, so twice
+    // as many half as long workgroups win while CUs are idle: K3 / K2 up to 8192 envs (G22-sized 4096: 31 -> 23 us, BA n = 10^4
+    // 135 -> 101, G70-sized 88 -> 62), the weights pre-pass up to 2048 (its 64-env kernel has the dword stores) --, K3 on short
+    // rows at full batches (G22-sized 2^16: 166 -> 154 us), and -- few tiles again -- rows whose 64-env tile has no room for its
+    // stage (N > ~15 800: K3 at N = 20 000, 4096 envs 278 -> 186 us)
+    const int64_t t64 = ceil_div(B, kWave);
+    const bool few = MODE == 2 ? 8 * t64 <= (int64_t)num_cus() : 2 * t64 <= (int64_t)num_cus();
+    const bool full_k3 = MODE == 1 && t64 >= 4 * (int64_t)num_cus() && (size_t)N * 8 <= 64 * 1024;
+    const bool prefer32 = knob32 < 0 && vec && (N & 15) == 0 && node_stats_bits32_lds(N, true) <= (size_t)kLdsBytes &&
+                          (few || full_k3 || (node_stats_bits_lds(N, true) > (size_t)kLdsBytes && 2 * t64 <= (int64_t)num_cus()));
     if (knob32 > 0 || prefer32 || node_stats_bits_lds(N, false) > (size_t)kLdsBytes) {   // half tiles (rls_tile32.h)
         const int st32 = (vec && (N & 15) == 0 && node_stats_bits32_lds(N, true) <= (size_t)kLdsBytes) ? 1 : 0;
         const size_t l32 = node_stats_bits32_lds(N, st32 != 0);
