@@ -58,6 +58,7 @@ ROWS = [
     (r"k_maxcut_propose_accept32<true, \d+, \d+, true>", 2 * T70 * 512, 131072, 2 * N70 + N70 // 8 + 16, "K6 propose_accept on half tiles, bit-packed mask | G70 2^17"),
     (r"k_maxcut_propose_accept32<", 2 * T70 * 512, 131072, 2 * N70 + 16, "K6 propose_accept on half tiles, byte mask | G70 2^17"),
     (r"k_node_stats_bits<1", T22 * 512, 65536, 5 * N22, "K3 delta_all | G22 2^16"),
+    (r"k_node_stats_bits32<1", 2 * T22 * 512, 65536, 5 * N22, "K3 delta_all on half tiles (short rows at a full batch) | G22 2^16"),
     (r"k_node_stats_bits<1", T70 * 512, 131072, 5 * N70, "K3 delta_all | G70 2^17"),
     (r"k_node_stats_bits<2, true, false, signed char", T22 * 512, 65536, 2 * N22, "ls_weights pre-pass, int8 weights + batch min / max | G22 2^16"),
     (r"k_node_stats_bits<2, true, false, signed char", 64 * 512, 4096, 2 * N22, "ls_weights pre-pass, int8 weights + batch min / max | G22 4096"),
