@@ -16,6 +16,8 @@
 
 namespace rls {
 
+constexpr int kStepPad = 128;   // spare bytes per wave's LDS stage: MODE 2 shifts a run by up to 112 bytes (see there)
+
 template <typename T> __device__ __forceinline__ T spin_flip(T v);
 template <> __device__ __forceinline__ uint8_t spin_flip<uint8_t>(uint8_t v) { return v == 0 ? 1 : 0; }
 template <> __device__ __forceinline__ float spin_flip<float>(float v) { return v == 0.0f ? 1.0f : 0.0f; }  // logical_not
@@ -241,7 +243,7 @@ __global__ __launch_bounds__(256) void k_maxcut_step(const T* __restrict__ xin, 
             // order; the ops younger than load j are the later loads, the neighbour-id loads and the stores of the pieces before
             // j -- (n - 1 - j) + E + j = n - 1 + E of them whatever j, so ONE wait value serves every trip.  The gain is read from
             // the staged (unpatched: the flip is applied in registers) row afterwards.
-            T* stage = reinterpret_cast<T*>(smem) + (int64_t)wib * EPW * N;
+            T* stage = reinterpret_cast<T*>(smem + (size_t)wib * ((size_t)EPW * N * sizeof(T) + kStepPad));
             V* stage_v = reinterpret_cast<V*>(stage);
             const int nch = (int)((nvec + kWave - 1) / kWave);
             for (int64_t base = 0; base < nvec; base += kWave) {
@@ -297,12 +299,22 @@ __global__ __launch_bounds__(256) void k_maxcut_step(const T* __restrict__ xin, 
                 }
             publish();
         } else {
-            // MODE 2: LDS staged.  Per-wave region of EPW*N*sizeof(T) bytes (16-byte multiple).
-            T* stage = reinterpret_cast<T*>(smem) + (int64_t)wib * EPW * N;
-            V* stage_v = reinterpret_cast<V*>(stage);
-            for (int64_t base = 0; base < nvec; base += kWave) {
-                const int64_t i = base + lane;
-                if (i < nvec) glds16<NTL>(src + i, stage_v + base);  // LDS dst = wave base + lane*16
+            // MODE 2: LDS staged.  Per-wave region of EPW*N*sizeof(T) bytes (16-byte multiple) + 128.
+            // A run starts 16-byte aligned, not 128-byte aligned (rows of 2000 or 10 000 bytes: a run starts 0, 16, ... 112 bytes
+            // into a cache line), and a 1 KB wave-instruction that starts mid-line touches NINE lines instead of eight -- the
+            // texture path prices lines: rows of 12 000 / 15 984 / 16 016 bytes ran at 0.63 of HBM, rows of 12 288 / 16 000 /
+            // 16 128 at 0.71 - 0.73.  So the instruction boundaries are put on the lines of the GLOBAL side: vector i of the run
+            // lives in LDS slot i + h (h = 16-byte units between the line's start and the run's, 0..7; the region has 128
+            // spare bytes), the first load instruction carries 64 - h vectors, every later one starts on a line; the stores likewise
+            // with the output's own h.
+            unsigned char* region = smem + (size_t)wib * ((size_t)EPW * N * sizeof(T) + kStepPad);
+            const int h_in = (int)((reinterpret_cast<uintptr_t>(src) >> 4) & 7), h_out = (int)((reinterpret_cast<uintptr_t>(dst) >> 4) & 7);
+            V* region_v = reinterpret_cast<V*>(region);
+            V* stage_v = region_v + h_in;
+            T* stage = reinterpret_cast<T*>(stage_v);
+            for (int64_t slot0 = 0; slot0 < nvec + h_in; slot0 += kWave) {
+                const int64_t i = slot0 + lane - h_in;
+                if (i >= 0 && i < nvec) glds16<NTL>(src + i, region_v + slot0);  // LDS dst = wave base + lane*16
             }
             for (int64_t i = nvec * PER + lane; i < nel; i += kWave) stage[i] = xin[b0 * N + i];   // short last run only
             // while the rows fly: CSR row bounds (scalar loads) and this lane's neighbour id / weight
@@ -351,7 +363,10 @@ __global__ __launch_bounds__(256) void k_maxcut_step(const T* __restrict__ xin, 
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
 #pragma unroll 4
-            for (int64_t i = lane; i < nvec; i += kWave) st_vec<NTS>(dst + i, stage_v[i]);
+            for (int64_t slot0 = 0; slot0 < nvec + h_out; slot0 += kWave) {
+                const int64_t i = slot0 + lane - h_out;
+                if (i >= 0 && i < nvec) st_vec<NTS>(dst + i, stage_v[i]);
+            }
             for (int64_t i = nvec * PER + lane; i < nel; i += kWave) xout[b0 * N + i] = stage[i];
         }
     }
@@ -417,10 +432,10 @@ extern "C" int rls_maxcut_step(const rls_graph* g, const void* x_in, void* x_out
     // waves per workgroup: 4, fewer while the staged runs of a workgroup would take more than half a CU's LDS
     int waves_per_block = knobs.wpb ? knobs.wpb : 4;
     if (!knobs.wpb && emit && vec)
-        while (waves_per_block > 1 && (size_t)waves_per_block * run_bytes > (size_t)kLdsBytes / 2) waves_per_block >>= 1;
+        while (waves_per_block > 1 && (size_t)waves_per_block * (run_bytes + kStepPad) > (size_t)kLdsBytes / 2) waves_per_block >>= 1;
     hipStream_t s = as_stream(stream);
-    const bool staged = emit && vec && (size_t)waves_per_block * run_bytes <= (size_t)kLdsBytes;
-    const size_t lds = staged ? (size_t)waves_per_block * run_bytes : 0;
+    const bool staged = emit && vec && (size_t)waves_per_block * (run_bytes + kStepPad) <= (size_t)kLdsBytes;
+    const size_t lds = staged ? (size_t)waves_per_block * (run_bytes + kStepPad) : 0;
     int64_t nblocks = ceil_div(ceil_div(B, epw), waves_per_block);
     if (staged && knobs.persist != 0) {
         // persistent form: as many workgroups as are resident at once (LDS-limited, at most 8 per CU), each wave looping over runs
