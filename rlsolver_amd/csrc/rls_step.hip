@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void k_maxcut_step(const T* __restrict__ xin, 
                                                      const int64_t* __restrict__ action,
                                                      int32_t* __restrict__ obj, float* __restrict__ reward,
                                                      float* __restrict__ cur, float* __restrict__ done,
-                                                     float done_value) {
+                                                     float done_value, int align_lines) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & (kWave - 1);
     const int wib = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
@@ -308,7 +308,8 @@ __global__ __launch_bounds__(256) void k_maxcut_step(const T* __restrict__ xin, 
             // spare bytes), the first load instruction carries 64 - h vectors, every later one starts on a line; the stores likewise
             // with the output's own h.
             unsigned char* region = smem + (size_t)wib * ((size_t)EPW * N * sizeof(T) + kStepPad);
-            const int h_in = (int)((reinterpret_cast<uintptr_t>(src) >> 4) & 7), h_out = (int)((reinterpret_cast<uintptr_t>(dst) >> 4) & 7);
+            const int h_in = align_lines ? (int)((reinterpret_cast<uintptr_t>(src) >> 4) & 7) : 0;
+            const int h_out = align_lines ? (int)((reinterpret_cast<uintptr_t>(dst) >> 4) & 7) : 0;
             V* region_v = reinterpret_cast<V*>(region);
             V* stage_v = region_v + h_in;
             T* stage = reinterpret_cast<T*>(stage_v);
@@ -375,14 +376,15 @@ __global__ __launch_bounds__(256) void k_maxcut_step(const T* __restrict__ xin, 
 
 // development knobs, read once per process (no getenv on the launch path): nts = -1 automatic | 0 | 1 (nontemporal
 // stores), epw / wpb = 0: automatic
-struct StepKnobs { int nts, epw, wpb, persist, chase; };
+struct StepKnobs { int nts, epw, wpb, persist, chase, align; };
 static StepKnobs read_step_knobs() {
     const char* m = getenv("RLS_STEP_NTS");
     const char* e = getenv("RLS_STEP_EPW");
     const char* w = getenv("RLS_STEP_WPB");
     const char* p = getenv("RLS_STEP_PERSIST");     // -1 automatic | 0 one run per wave | k: k workgroup rounds per CU resident, waves loop
     const char* c = getenv("RLS_STEP_CHASE");       // -1 automatic | 0 MODE 2 (stores after the last load) | 1 MODE 3 (stores chase the loads)
-    return StepKnobs{m ? atoi(m) : -1, e ? atoi(e) : 0, w ? atoi(w) : 0, p ? atoi(p) : -1, c ? atoi(c) : -1};
+    const char* al = getenv("RLS_STEP_ALIGN");      // 0: load / store instructions start where the run starts (before round 4's fix)
+    return StepKnobs{m ? atoi(m) : -1, e ? atoi(e) : 0, w ? atoi(w) : 0, p ? atoi(p) : -1, c ? atoi(c) : -1, al ? atoi(al) : 1};
 }
 static StepKnobs step_knobs() {
     static const bool reread = getenv("RLS_DEV_REREAD_ENV") != nullptr;   // tools/microbench.py, tools/sweep_step.py: A/B in one process
@@ -458,7 +460,7 @@ extern "C" int rls_maxcut_step(const rls_graph* g, const void* x_in, void* x_out
         if (lds > 64 * 1024)                                                                                   \
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(kern, grid, block, lds, s, (const T*)x_in, (T*)x_out, B, N, g->rowptr, g->col, g->wgt, \
-                           action, obj, reward, cur, done, done_value);                                        \
+                           action, obj, reward, cur, done, done_value, knobs.align);                           \
     } while (0)
 #define LAUNCH_STEP(T, MODE, EMIT, VEC, NTL, NTS)                           \
     do {                                                                    \

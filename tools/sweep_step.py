@@ -34,12 +34,14 @@ def timeit(iters=int(os.environ.get('SW_ITERS', 200))):
     return e0.elapsed_time(e1) / iters * 1e-3
 
 
-configs = [dict(RLS_STEP_NTS=str(md), RLS_STEP_EPW=str(e), RLS_STEP_WPB=str(w), RLS_STEP_PERSIST=str(ps), RLS_STEP_CHASE=str(ch))   # nontemporal stores 0 | 1 (-1 = the launcher's rule)
-           for md, e, w, ps, ch in itertools.product(os.environ.get("SW_NTS", "0,1").split(","),
-                                                 os.environ.get("SW_EPW", "1,2,4,8").split(","),
-                                                 os.environ.get("SW_WPB", "1,2,4").split(","),
-                                                 os.environ.get("SW_PERSIST", "0").split(","),
-                                                 os.environ.get("SW_CHASE", "0").split(","))]
+configs = [dict(RLS_STEP_NTS=str(md), RLS_STEP_EPW=str(e), RLS_STEP_WPB=str(w), RLS_STEP_PERSIST=str(ps), RLS_STEP_CHASE=str(ch),
+                RLS_STEP_ALIGN=str(al))   # nontemporal stores 0 | 1 (-1 = the launcher's rule); ALIGN: instruction boundaries on cache lines
+           for md, e, w, ps, ch, al in itertools.product(os.environ.get("SW_NTS", "0,1").split(","),
+                                                     os.environ.get("SW_EPW", "1,2,4,8").split(","),
+                                                     os.environ.get("SW_WPB", "1,2,4").split(","),
+                                                     os.environ.get("SW_PERSIST", "0").split(","),
+                                                     os.environ.get("SW_CHASE", "0").split(","),
+                                                     os.environ.get("SW_ALIGN", "1").split(","))]
 res = {i: [] for i in range(len(configs))}
 for rep in range(3):
     for i, c in enumerate(configs):
