@@ -1247,8 +1247,10 @@ int rls_maxcut_obj(const rls_graph* g, const void* x, int spin_bytes, int64_t B,
     // at 2^16 the half tiles LOSE, 34.4 -> 36.3: twice the edge-list reads per env).  Dev knob RLS_K1_TILE32 = 0 | 1 forces the choice.
     static const int knob32 = getenv("RLS_K1_TILE32") ? atoi(getenv("RLS_K1_TILE32")) : -1;
     {
-        int w32 = (size_t)N * 4 > 64 * 1024 ? kTileWavesMax : kTileWaves;
         auto lds32 = [&](int ww) { return (((size_t)N * 4 + 15) & ~(size_t)15) + (size_t)ww * kWave * 8; };
+        // 8 waves once two 4-wave workgroups (with their stages) no longer share a CU: one 4-wave workgroup per CU cannot keep
+        // enough loads in flight (N = 15 984 .. 16 384 ran at 0.43 of HBM beside 0.61 at 15 872, where two still fit)
+        int w32 = 2 * (lds32(kTileWaves) + (size_t)kTileWaves * kStageBytes) > (size_t)kLdsBytes ? kTileWavesMax : kTileWaves;
         if (lds32(w32) > (size_t)kLdsBytes) w32 = kTileWaves;
         size_t l32 = lds32(w32);
         const int P32 = pick_planes(E);
