@@ -243,12 +243,18 @@ __global__ __launch_bounds__(256) void k_maxcut_step(const T* __restrict__ xin, 
             // order; the ops younger than load j are the later loads, the neighbour-id loads and the stores of the pieces before
             // j -- (n - 1 - j) + E + j = n - 1 + E of them whatever j, so ONE wait value serves every trip.  The gain is read from
             // the staged (unpatched: the flip is applied in registers) row afterwards.
-            T* stage = reinterpret_cast<T*>(smem + (size_t)wib * ((size_t)EPW * N * sizeof(T) + kStepPad));
-            V* stage_v = reinterpret_cast<V*>(stage);
-            const int nch = (int)((nvec + kWave - 1) / kWave);
-            for (int64_t base = 0; base < nvec; base += kWave) {
-                const int64_t i = base + lane;
-                if (i < nvec) glds16<NTL>(src + i, stage_v + base);
+            // (instruction boundaries on the global side's cache lines, as in MODE 2 below -- when the input and the output run start
+            // the same distance into a line, so that store piece j still needs exactly load piece j: the wait arithmetic stands)
+            unsigned char* region = smem + (size_t)wib * ((size_t)EPW * N * sizeof(T) + kStepPad);
+            const int h_in = (int)((reinterpret_cast<uintptr_t>(src) >> 4) & 7), h_out = (int)((reinterpret_cast<uintptr_t>(dst) >> 4) & 7);
+            const int h = (align_lines && h_in == h_out) ? h_in : 0;
+            V* region_v = reinterpret_cast<V*>(region);
+            V* stage_v = region_v + h;
+            T* stage = reinterpret_cast<T*>(stage_v);
+            const int nch = (int)((nvec + h + kWave - 1) / kWave);
+            for (int64_t slot0 = 0; slot0 < nvec + h; slot0 += kWave) {
+                const int64_t i = slot0 + lane - h;
+                if (i >= 0 && i < nvec) glds16<NTL>(src + i, region_v + slot0);
             }
             if (nvec * PER < nel) {   // a short last run: its elements past the last whole vector are staged by hand (the gain reads them)
                 for (int64_t i = nvec * PER + lane; i < nel; i += kWave) stage[i] = xin[b0 * N + i];
@@ -271,8 +277,8 @@ __global__ __launch_bounds__(256) void k_maxcut_step(const T* __restrict__ xin, 
             const int keep = nch - 1 + nlo;
             for (int j = 0; j < nch; ++j) {
                 wait_vmcnt_le(keep);
-                const int64_t i = (int64_t)j * kWave + lane;
-                if (i < nvec) {
+                const int64_t i = (int64_t)j * kWave + lane - h;
+                if (i >= 0 && i < nvec) {
                     V v = stage_v[i];
 #pragma unroll
                     for (int k = 0; k < EPW; ++k)
@@ -451,7 +457,7 @@ extern "C" int rls_maxcut_step(const rls_graph* g, const void* x_in, void* x_out
     const int64_t nch_run = ceil_div((int64_t)run_bytes, 16 * kWave);
     // measured (tools/sweep_step.py, SW_CHASE=0,1): f32 rows gain 3 - 6 % (N = 10^4: 0.674 -> 0.701; N = 2000: 0.707 -> 0.752 of
     // 8 TB/s), 1-byte rows nothing (0.694 / 0.694, 0.738 / 0.739): their runs are 8 - 10 pieces, back before the first could leave
-    const bool chase = staged && nch_run + epw <= 62 && (knobs.chase > 0 || (knobs.chase < 0 && spin_bytes == 4));
+    const bool chase = staged && nch_run + 1 + epw <= 62 && (knobs.chase > 0 || (knobs.chase < 0 && spin_bytes == 4));   // (+ 1: a shifted run's extra piece)
     const bool nts = knobs.nts >= 0 ? knobs.nts != 0 : ((size_t)B * N * spin_bytes > ((size_t)256 << 20));
 
 #define LAUNCH_STEP_E(T, EPW, MODE, EMIT, VEC, NTL, NTS)                                                       \
