@@ -472,3 +472,42 @@ def test_rows_that_are_not_dword_aligned_with_garbage_around(n, B, lead):
     assert bool((vs >= v0).all()) and int(x.max()) <= 1
     assert np.array_equal(vs.cpu().numpy(), onp.maxcut_obj(x.cpu().numpy(), garr, False))
     assert bool((buf[:lead] == 255).all()) and bool((buf[lead + B * n:] == 255).all())
+
+
+@pytest.mark.parametrize("dt", ["u8", "f32"])
+@pytest.mark.parametrize("n,m,B,off_in,off_out", [(2000, 19990, 131, 16, 16), (2000, 19990, 131, 48, 112), (10000, 9999, 70, 0, 64),
+                                                   (12000, 24000, 37, 80, 80), (1000, 5000, 203, 32, 96)])
+def test_step_runs_that_start_anywhere_in_a_cache_line(dt, n, m, B, off_in, off_out):
+    """K4's staged emit puts its load / store instructions on the cache lines of the global side: a run that starts h x 16 bytes into
+    a line lives h slots further into the LDS stage (csrc/rls_step.hip).  Input and output as views at every 16-byte offset inside
+    buffers of 0xFF bytes, the same and different offsets on the two sides (f32: the chase form takes the shift only when they
+    agree): results against the oracle, nothing written outside the views."""
+    graph = gnm_arr(n, m, seed=3)
+    g = device_graph(graph, n, 0)
+    rng = np.random.RandomState(n + off_in)
+    xs = rng.randint(0, 2, size=(B, n)).astype(np.uint8)
+    env = onp.PPOEnvOracle(graph, n, 10 ** 9, False)
+    env.reset_to(xs)
+    esz = 1 if dt == "u8" else 4
+    tdt = torch.bool if dt == "u8" else torch.float32
+    nbytes = B * n * esz
+
+    def view(off):
+        buf = torch.full((nbytes + 512,), 255, dtype=torch.uint8, device=DEV)
+        return buf, buf[off:off + nbytes].view(tdt).view(B, n)
+    bx, x = view(off_in)
+    by, y = view(off_out)
+    x.copy_(to_dev_bool(xs) if dt == "u8" else to_dev_bool(xs).float())
+    obj = ops.maxcut_obj(g, x).to(torch.int32)
+    reward = torch.empty(B, dtype=torch.float32, device=DEV)
+    for t in range(6):
+        a = rng.randint(0, n, size=B)
+        _, r, _, c = env.step(a)
+        ops.maxcut_step(g, x, y, torch.from_numpy(a).to(DEV), obj, reward)
+        x, y = y, x
+        bx, by = by, bx
+        off_in, off_out = off_out, off_in
+        assert np.array_equal(reward.cpu().numpy(), r) and np.array_equal(obj.cpu().numpy().astype(np.float32), c), t
+        assert np.array_equal(x.float().cpu().numpy(), env.xs), t
+        for buf, off in ((bx, off_in), (by, off_out)):            # the bytes around the views are still 0xFF
+            assert bool((buf[:off] == 255).all()) and bool((buf[off + nbytes:] == 255).all()), t
