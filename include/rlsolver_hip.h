@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define RLS_ABI_VERSION 10
+#define RLS_ABI_VERSION 11
 
 enum {
     RLS_OK = 0,
@@ -81,6 +81,17 @@ int rls_version(void);
 const char* rls_last_error_string(void);
 /* Number of HIP devices visible (0 on a CPU-only host; never an error). */
 int rls_device_count(void);
+
+/* [host] Tuning table (ABI v11).  Which tile form / wave count / store policy a launch takes is decided per launch from
+ * its shapes; every such choice can be FORCED by name ("RLS_K1_TILE32", "RLS_STEP_CHASE", ... -- rls_tuning_name
+ * enumerates them; the "RLS_" prefix is optional) for A/B measurements and for the forced-form parity tests.  Forcing a
+ * form never changes a result.  The production library reads no environment variable; only a -DRLS_DEV build seeds this
+ * table from the environment once, when it is loaded.  The reference has no counterpart (it has no launch policies).
+ * rls_tuning_unset(NULL) clears every entry.  Process-wide, not per stream. */
+int rls_tuning_set(const char* name, int64_t value);
+int rls_tuning_unset(const char* name);
+int rls_tuning_get(const char* name, int64_t* value, int32_t* is_set);
+int rls_tuning_name(int32_t index, const char** name);   /* index 0 .. until RLS_EINVAL */
 
 /* [host] Level schedule of the sequential greedy sweep (envs/env_L2A.py:109-116 visits i = 0..N-1 and every
  * decision sees the flips of the earlier nodes).  level(i) = 1 + max level of i's lower-numbered neighbours:
@@ -323,6 +334,12 @@ int rls_best_key(const void* vs, int vs_kind, int64_t B, int32_t rank_bits, int6
  *     forced to 0.  env_offset lets a rank generate its shard of a global batch. */
 int rls_rand_spins(uint8_t* x, int64_t B, int64_t N, uint64_t seed, int64_t env_offset,
                    void* stream);
+/* The same generator for R repeats of S envs in ONE launch (ABI v11): row r * S + s of x [R * S, N] is what
+ * rls_rand_spins(seed = repeat_seeds[r], env_offset) writes for env s -- methods/LocalSearch.py:44-50 draws num_sims
+ * batches of num_sims random rows in a Python loop.  repeat_seeds: DEVICE uint64 [R]. */
+int rls_rand_spins_repeats(uint8_t* x, int64_t R, int64_t S, int64_t N, const uint64_t* repeat_seeds, int64_t env_offset,
+                           void* stream);
+
 
 /* uniform actions in [0, N) from the same generator (bench / MCMC proposals). */
 int rls_rand_actions(int64_t* action, int64_t B, int64_t N, uint64_t seed, uint64_t step,

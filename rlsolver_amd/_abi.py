@@ -93,6 +93,7 @@ SIGNATURES = {
     "rls_select_better_rows": [_P, _P, _P, _P, _I64, _I64, _INT, _P],
     "rls_pick_best_of_repeats": [_P, _P, _I64, _I64, _I64, _INT, _P, _P, _P],
     "rls_rand_spins": [_P, _I64, _I64, _U64, _I64, _P],
+    "rls_rand_spins_repeats": [_P, _I64, _I64, _I64, _P, _I64, _P],
     "rls_rand_actions": [_P, _I64, _I64, _U64, _U64, _I64, _P],
     "rls_spin_observation": [_SE, _P, C.c_int32, _INT, _I64, C.c_int32, _I64, _P, _I64, C.c_int32, _P, _P],
     "rls_spin_materialize": [_SE, _INT, _I64, _I64, C.c_int32, _P, _I64, _P],
@@ -125,6 +126,10 @@ SIGNATURES = {
     "rls_copy_rows": [_P, _P, _I64, _P, _P, _I64, _P],
     "rls_best_update": [_P, _P, _INT, _I64, _I64, _INT, _P, _P, _P, _P, _I64, _INT, _P],
     "rls_best_key": [_P, _INT, _I64, C.c_int32, _I64, _I64, _P, _P, _P, _P],
+    "rls_tuning_set": [_P, _I64],
+    "rls_tuning_unset": [_P],
+    "rls_tuning_get": [_P, _P, _P],
+    "rls_tuning_name": [C.c_int32, _P],
 }
 # functions that return a value, not an error code
 PLAIN = {"rls_version": ([], _INT), "rls_device_count": ([], _INT), "rls_last_error_string": ([], C.c_char_p),
@@ -178,3 +183,40 @@ def version() -> int:
 
 def device_count() -> int:
     return lib().rls_device_count()
+
+
+# ---- tuning table (ABI v11): explicit, in-process; the production library reads no environment variable ----
+def tuning_set(name: str, value: int) -> None:
+    call("rls_tuning_set", name.encode(), int(value))
+
+
+def tuning_unset(name=None) -> None:
+    call("rls_tuning_unset", None if name is None else name.encode())
+
+
+def tuning_get(name: str):
+    """The forced value of a knob, or None when the launch policy decides."""
+    v, st = C.c_int64(0), C.c_int32(0)
+    call("rls_tuning_get", name.encode(), C.byref(v), C.byref(st))
+    return int(v.value) if st.value else None
+
+
+def tuning_names():
+    out, i = [], 0
+    while True:
+        p = C.c_char_p()
+        if lib().rls_tuning_name(i, C.byref(p)) != RLS_OK:
+            return out
+        out.append(p.value.decode())
+        i += 1
+
+
+def tuning_from_env(environ=None) -> dict:
+    """TEST / TOOL helper: copy RLS_<KNOB> variables of `environ` into the table (what a -DRLS_DEV build does at load)."""
+    environ = os.environ if environ is None else environ
+    done = {}
+    for n in tuning_names():
+        if n in environ:
+            tuning_set(n, int(environ[n]))
+            done[n] = int(environ[n])
+    return done

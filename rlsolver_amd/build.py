@@ -6,6 +6,7 @@ the kernels are plain HIP behind a C ABI (include/rlsolver_hip.h).
 """
 from __future__ import annotations
 
+import hashlib
 import os
 import shutil
 import subprocess
@@ -43,19 +44,57 @@ def _deps():
     return deps
 
 
+def _flags():
+    return ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function", "-Wno-pass-failed",
+            f"--offload-arch={ARCH}"] + os.environ.get("RLS_EXTRA_CFLAGS", "").split()   # dev builds, e.g. -DRLS_PROF / -DRLS_DEV
+
+
+def _digest(paths, extra=()) -> str:
+    """Content hash of `paths` (by name relative to the repo + bytes) and of `extra` strings.  Staleness is decided by
+    CONTENT, never by mtime: a transport that rewrites mtimes (a checkout beside shipped binaries, rsync without -t) neither
+    triggers a 2.5-minute rebuild nor lets a binary older than its sources pass."""
+    h = hashlib.sha256()
+    for p in sorted(paths):
+        h.update(os.path.relpath(p, ROOT).encode() + b"\0")
+        with open(p, "rb") as f:
+            h.update(hashlib.sha256(f.read()).digest())
+    for e in extra:
+        h.update(b"\1" + e.encode())
+    return h.hexdigest()
+
+
+def _stamp(path: str) -> str:
+    return path + ".srchash"
+
+
+def _stamp_matches(path: str, digest: str) -> bool:
+    try:
+        return os.path.exists(path) and open(_stamp(path)).read().strip() == digest
+    except OSError:
+        return False
+
+
+def _write_stamp(path: str, digest: str) -> None:
+    with open(_stamp(path), "w") as f:
+        f.write(digest + "\n")
+
+
+def lib_digest() -> str:
+    return _digest(_deps(), _flags())
+
+
+def ops_digest() -> str:
+    import torch
+    deps = [OPS_SRC] + [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE) if f.endswith(".h")]
+    return _digest(deps, [lib_digest(), torch.__version__])
+
+
 def is_stale() -> bool:
-    if not os.path.exists(LIB_PATH):
-        return True
-    t = os.path.getmtime(LIB_PATH)
-    return any(os.path.getmtime(d) > t for d in _deps())
+    return not _stamp_matches(LIB_PATH, lib_digest())
 
 
 def ops_is_stale() -> bool:
-    if not os.path.exists(OPS_PATH):
-        return True
-    t = os.path.getmtime(OPS_PATH)
-    deps = [OPS_SRC, LIB_PATH] + [os.path.join(INCLUDE, f) for f in os.listdir(INCLUDE) if f.endswith(".h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return not _stamp_matches(OPS_PATH, ops_digest())
 
 
 def build_torch_ops(force: bool = False, verbose: bool = False) -> str:
@@ -77,6 +116,7 @@ def build_torch_ops(force: bool = False, verbose: bool = False) -> str:
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"building {OPS_NAME} failed:\n{r.stdout}")
+    _write_stamp(OPS_PATH, ops_digest())
     return OPS_PATH
 
 
@@ -87,30 +127,35 @@ def build(force: bool = False, verbose: bool = False) -> str:
     objs = []
     obj_dir = os.path.join(PKG_DIR, "csrc", "build")
     os.makedirs(obj_dir, exist_ok=True)
-    common = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-              f"-I{INCLUDE}", f"-I{CSRC}", "-Wall", "-Wno-unused-function", "-Wno-pass-failed"]
-    common += os.environ.get("RLS_EXTRA_CFLAGS", "").split()   # dev builds, e.g. -DRLS_PROF
+    common = [_hipcc()] + _flags() + [f"-I{INCLUDE}", f"-I{CSRC}"]
+    headers = [d for d in _deps() if d.endswith(".h")]
     procs = []
     for src in _sources():
         obj = os.path.join(obj_dir, os.path.splitext(os.path.basename(src))[0] + ".o")
         objs.append(obj)
-        if (not force and os.path.exists(obj)
-                and all(os.path.getmtime(obj) >= os.path.getmtime(d) for d in _deps() if d.endswith(".h") or d == src)):
+        dg = _digest(headers + [src], _flags())
+        if not force and _stamp_matches(obj, dg):
             continue
         cmd = common + (["-x", "c++"] if src.endswith(".cpp") else []) + ["-c", src, "-o", obj]     # rls_host.cpp: host-only C++
         if verbose:
             print(" ".join(cmd), flush=True)
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
-    for src, p in procs:
+        procs.append((src, obj, dg, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    failed = None
+    for src, obj, dg, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
-            raise RuntimeError(f"hipcc failed on {src}:\n{out}")
+            failed = failed or RuntimeError(f"hipcc failed on {src}:\n{out}")
+            continue
+        _write_stamp(obj, dg)
         if verbose and out.strip():
             print(out)
+    if failed:
+        raise failed
     link = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH] + objs
     r = subprocess.run(link, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}")
+    _write_stamp(LIB_PATH, lib_digest())
     return LIB_PATH
 
 

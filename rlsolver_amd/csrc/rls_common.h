@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "rlsolver_hip.h"
+#include "rls_host.h"
 
 namespace rls {
 
@@ -10,7 +11,6 @@ constexpr int kWave = 64;                 // CDNA wavefront
 constexpr int kLdsBytes = 160 * 1024;     // per-CU LDS on MI355X
 constexpr int kMaxDynLds = 64 * 1024 * 2; // what we are willing to ask for per workgroup
 
-int fail(int code, const char* fmt, ...);  // records the message, returns code
 int check_launch(const char* kernel_name); // hipGetLastError -> RLS_ELAUNCH
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
@@ -73,6 +73,28 @@ inline int num_cus() {
         if (n <= 0) n = 256;
     }
     return n;
+}
+
+// Dynamic LDS beyond 64 KB needs the function attribute raised -- ONCE per (kernel instantiation, device), not per launch
+// (a host call on the hot path: every G70-sized step).  A lock-free table of the pairs already raised to the whole LDS.
+inline void ensure_dyn_lds(const void* kern, size_t lds) {
+    if (lds <= 64 * 1024) return;
+    static std::atomic<uintptr_t> seen[1024];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uintptr_t key = (uintptr_t)kern ^ ((uintptr_t)(dev + 1) << 56);
+    size_t h = (size_t)((key >> 4) * 0x9E3779B97F4A7C15ull >> 54);
+    for (int probe = 0; probe < 1024; ++probe, h = (h + 1) & 1023) {
+        const uintptr_t cur = seen[h].load(std::memory_order_acquire);
+        if (cur == key) return;
+        if (cur == 0) {
+            (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+            uintptr_t expect = 0;
+            seen[h].compare_exchange_strong(expect, key, std::memory_order_release);
+            return;
+        }
+    }
+    (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);   // table full: as before
 }
 
 inline int grid_for(int64_t total, int block) {

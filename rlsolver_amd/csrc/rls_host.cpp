@@ -6,11 +6,38 @@
 #include <cstdarg>
 #include <cstdio>
 #include <algorithm>
+#include <cstdlib>
+#include <cstring>
 #include <vector>
 
 namespace rls {
 
 static thread_local char g_err[512] = "";
+
+static const char* const kKnobNames[KN_COUNT] = {
+#define RLS_X(n) "RLS_" #n,
+    RLS_KNOB_LIST(RLS_X)
+#undef RLS_X
+};
+std::atomic<int64_t> g_knobs[KN_COUNT];
+static int knob_index(const char* name) {
+    if (!name) return -1;
+    for (int i = 0; i < KN_COUNT; ++i)
+        if (std::strcmp(name, kKnobNames[i]) == 0 || std::strcmp(name, kKnobNames[i] + 4) == 0) return i;
+    return -1;
+}
+namespace {
+struct KnobInit {
+    KnobInit() {
+        for (int i = 0; i < KN_COUNT; ++i) g_knobs[i].store(kKnobUnset, std::memory_order_relaxed);
+#ifdef RLS_DEV   // development builds only: the environment seeds the table once, at load
+        for (int i = 0; i < KN_COUNT; ++i)
+            if (const char* v = std::getenv(kKnobNames[i])) g_knobs[i].store(std::atoll(v), std::memory_order_relaxed);
+#endif
+    }
+};
+static KnobInit g_knob_init;
+}  // namespace
 
 int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -122,6 +149,40 @@ extern "C" {
 int rls_version(void) { return RLS_ABI_VERSION; }
 
 const char* rls_last_error_string(void) { return rls::g_err; }
+
+int rls_tuning_set(const char* name, int64_t value) {
+    const int i = rls::knob_index(name);
+    if (i < 0) return rls::fail(RLS_EINVAL, "rls_tuning_set: unknown knob '%s'", name ? name : "(null)");
+    if (value == rls::kKnobUnset) return rls::fail(RLS_EINVAL, "rls_tuning_set: INT64_MIN is the 'unset' marker");
+    rls::g_knobs[i].store(value, std::memory_order_relaxed);
+    return RLS_OK;
+}
+
+int rls_tuning_unset(const char* name) {
+    if (name == nullptr) {   // all of them
+        for (int i = 0; i < rls::KN_COUNT; ++i) rls::g_knobs[i].store(rls::kKnobUnset, std::memory_order_relaxed);
+        return RLS_OK;
+    }
+    const int i = rls::knob_index(name);
+    if (i < 0) return rls::fail(RLS_EINVAL, "rls_tuning_unset: unknown knob '%s'", name);
+    rls::g_knobs[i].store(rls::kKnobUnset, std::memory_order_relaxed);
+    return RLS_OK;
+}
+
+int rls_tuning_get(const char* name, int64_t* value, int32_t* is_set) {
+    const int i = rls::knob_index(name);
+    if (i < 0 || !value || !is_set) return rls::fail(RLS_EINVAL, "rls_tuning_get: unknown knob or NULL output");
+    const int64_t v = rls::g_knobs[i].load(std::memory_order_relaxed);
+    *is_set = v != rls::kKnobUnset;
+    *value = *is_set ? v : 0;
+    return RLS_OK;
+}
+
+int rls_tuning_name(int32_t index, const char** name) {
+    if (!name || index < 0 || index >= rls::KN_COUNT) return rls::fail(RLS_EINVAL, "rls_tuning_name: index out of range");
+    *name = rls::kKnobNames[index];
+    return RLS_OK;
+}
 
 int rls_graph_sweep_schedule(const int32_t* rowptr, const int32_t* col, int64_t N, int32_t max_nodes,
                              int32_t max_entries, int32_t* rowptr_flagged, int32_t* stream, int64_t* num_batches,

@@ -770,7 +770,7 @@ int rls_isco_maxcut_step(const rls_graph* g, const float* x, float* y_out, int64
     // capacity of the selected-set list in LDS: a power of two >= N while that fits (N <= 4096: as before), else the largest
     // power of two the rows leave room for, at least 64 (N = 10^4: 4096; N = 15 000: 512) -- a larger selection takes the
     // extraction path.  The rows themselves (two byte rows, two f32 rows) bound N at ~15 900.
-    static const int force_cap = getenv("RLS_ISCO_SEL_CAP") ? atoi(getenv("RLS_ISCO_SEL_CAP")) : 0;   // dev / test knob
+    const int force_cap = (int)knob(KN_ISCO_SEL_CAP, 0);   // dev / test knob
     const size_t rows = 2 * (((size_t)N + 7) & ~(size_t)7) + (size_t)N * 8;
     const size_t fixed = sizeof(IscoWgScratch) + 16;
     int P = 1;
@@ -784,7 +784,7 @@ int rls_isco_maxcut_step(const rls_graph* g, const float* x, float* y_out, int64
     // wave-per-sample kernel: one wave per SIMD is latency-bound (round 3: 4 samples per CU), so the list gives up capacity for
     // resident samples while it stays >= 512 entries -- the reference draws Poisson(~10) path lengths, a longer selection takes
     // the extraction path -- G22-sized rows: 2048 entries x 4 samples -> 512 x 6 per CU, 4096 samples 606 -> 508 us
-    static const int max_waves = getenv("RLS_ISCO_WAVES") ? atoi(getenv("RLS_ISCO_WAVES")) : 8;     // dev knob (<= 8)
+    const int max_waves = (int)knob(KN_ISCO_WAVES, 8);     // dev knob (<= 8)
     auto waves_for = [&](int cap) {
         int wv = (int)((size_t)kLdsBytes / (rows + (size_t)cap * 8));
         return wv > max_waves ? max_waves : wv;
@@ -802,14 +802,14 @@ int rls_isco_maxcut_step(const rls_graph* g, const float* x, float* y_out, int64
         IscoMcArgs aw{g->rowptr, g->col, use_ell ? g->ell_sym_ptr : nullptr, use_ell ? g->ell_sym : nullptr, x, y_out, B, N,
                       path_length, temperature, u_gumbel, u_accept, seed, env_offset, energy_out, acc_out, terms_out, mask_out, P};
         if (lds_wg > 64 * 1024)
-            (void)hipFuncSetAttribute((const void*)k_isco_maxcut_step_wg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_wg);
+            ensure_dyn_lds((const void*)k_isco_maxcut_step_wg, lds_wg);
         hipLaunchKernelGGL(k_isco_maxcut_step_wg, dim3((unsigned)B), dim3(kIscoWgWaves * kWave), lds_wg, as_stream(stream), aw);
         return check_launch("k_isco_maxcut_step_wg");
     }
     IscoMcArgs a{g->rowptr, g->col, use_ell ? g->ell_sym_ptr : nullptr, use_ell ? g->ell_sym : nullptr, x, y_out, B, N, path_length, temperature, u_gumbel, u_accept, seed, env_offset,
                  energy_out, acc_out, terms_out, mask_out, Pw};
     if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute((const void*)k_isco_maxcut_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        ensure_dyn_lds((const void*)k_isco_maxcut_step, lds);
     hipLaunchKernelGGL(k_isco_maxcut_step, dim3((unsigned)ceil_div(B, waves)), dim3(waves * kWave), lds, as_stream(stream), a);
     return check_launch("k_isco_maxcut_step");
 }
@@ -843,10 +843,10 @@ int rls_isco_tsp_step(const float* dist, int64_t N, const int32_t* nearest, int3
                   u_gumbel, u_accept, seed, env_offset, log_acc_out, acc_out, cur_out};
     const dim3 grid((unsigned)ceil_div(B, waves)), block(waves * kWave);
     if (lds_d) {
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_isco_tsp_step<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (lds > 64 * 1024) ensure_dyn_lds((const void*)k_isco_tsp_step<true>, lds);
         hipLaunchKernelGGL(k_isco_tsp_step<true>, grid, block, lds, as_stream(stream), a);
     } else {
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_isco_tsp_step<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (lds > 64 * 1024) ensure_dyn_lds((const void*)k_isco_tsp_step<false>, lds);
         hipLaunchKernelGGL(k_isco_tsp_step<false>, grid, block, lds, as_stream(stream), a);
     }
     return check_launch("k_isco_tsp_step");

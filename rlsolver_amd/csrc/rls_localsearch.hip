@@ -762,12 +762,12 @@ static bool ls_half_tile(int64_t N) {
            (size_t)((N + 1) & ~1ll) * 8 + (size_t)kLsRoundWaves * kWave * 8 + (size_t)kLsRoundWaves * kStageBytes > (size_t)kLdsBytes;
 }
 static bool ls_sd_global() {   // dev knob: rd_std read from global memory even where it fits LDS
-    static const bool on = getenv("RLS_LS_SD_GLOBAL") != nullptr;
+    const bool on = knob_on(KN_LS_SD_GLOBAL);
     return on;
 }
 // workgroups per tile for the noise passes: 1 once the tiles alone fill the chip, else up to 8 slices of the rows
 static int ls_slices(int64_t B, int64_t nchunks) {
-    static const int force = getenv("RLS_LS_SLICES") ? atoi(getenv("RLS_LS_SLICES")) : 0;   // dev knob
+    const int force = (int)knob(KN_LS_SLICES, 0);   // dev knob
     const int64_t tiles = ceil_div(B, kWave);
     int S = force > 0 ? force : (int)(num_cus() / (tiles > 0 ? tiles : 1));
     if (S > 8) S = 8;
@@ -816,7 +816,7 @@ static size_t ls_lds_bytes(int64_t N, int W) {
 // (tools/timing/ls_waves.py): G22-sized 2^14 envs 0.53 -> 0.46 ms with 8, 2^15 0.83 -> 0.72 with 4; G(5000, 20000) 2^16 4.02 -> 3.13
 // with 8.  0 = neither layout fits.
 static int ls_pick_waves(int64_t N, int64_t B) {
-    static const int force_w = getenv("RLS_LS_WAVES") ? atoi(getenv("RLS_LS_WAVES")) : 0;   // dev knob
+    const int force_w = (int)knob(KN_LS_WAVES, 0);   // dev knob
     const bool two_small = 2 * ls_lds_bytes(N, 4) <= (size_t)kLdsBytes;
     int W = force_w == 4 || force_w == 8 ? force_w : (ceil_div(B, kWave) <= (int64_t)num_cus() || !two_small ? 8 : 4);
     if (W == 8 && ls_lds_bytes(N, 8) > (size_t)kLdsBytes) W = 4;
@@ -870,7 +870,7 @@ extern "C" int rls_maxcut_local_search(const rls_graph* g, uint8_t* x, int64_t B
     const dim3 grid((unsigned)ceil_div(B, kWave)), block(W * kWave);
     hipStream_t s = as_stream(stream);
     const int halve = g->if_bidirectional ? 1 : 0;
-    static const bool no_levels = getenv("RLS_SWEEP_NO_LEVELS") != nullptr;   // dev knob
+    const bool no_levels = knob_on(KN_SWEEP_NO_LEVELS);   // dev knob
     const bool levels = !no_levels && g->sweep_lv_ptr && g->sweep_lv_data && g->num_sweep_groups > 0 &&
                         g->num_sweep_groups <= N;
     const int batched = levels ? 2 : (g->sweep_rowptr != nullptr && g->sweep_stream != nullptr ? 1 : 0);
@@ -882,7 +882,7 @@ extern "C" int rls_maxcut_local_search(const rls_graph* g, uint8_t* x, int64_t B
     do {                                                                                                             \
         auto kern = W == 8 ? k_maxcut_local_search<AL, WT, PP, 8> : k_maxcut_local_search<AL, WT, PP, 4>;             \
         if (lds > 64 * 1024)                                                                                         \
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
+            ensure_dyn_lds((const void*)kern, lds);      \
         hipLaunchKernelGGL(kern, grid, block, lds, s, x, B, N, g->eu, g->ev, E, halve, rp_src, sw_src, sw_len,        \
                            (const WT*)ws, ws_pitch, rd_std, noise, seed, env_offset, (int)num_iters, (int)num_spin,   \
                            (int)first_draw_proposes, obj, (int)compute_obj, batched);                                 \
@@ -959,7 +959,7 @@ extern "C" int rls_maxcut_ls_threshold(const rls_graph* g, int64_t B, const void
 #define LAUNCH_TH(WT)                                                                                                  \
     do {                                                                                                               \
         auto kern = sd_lds ? k_ls_threshold<WT, true> : k_ls_threshold<WT, false>;                                     \
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (lds > 64 * 1024) ensure_dyn_lds((const void*)kern, lds); \
         hipLaunchKernelGGL(kern, grid, block, lds, s, (const WT*)ws, ws_pitch, B, N, rd_std, seed, env_offset, (int)draw, (int)num_spin, thresh, \
                            (float*)scratch);                                                                           \
     } while (0)
@@ -1007,7 +1007,7 @@ extern "C" int rls_maxcut_ls_propose(const rls_graph* g, uint8_t* x, int64_t B, 
 #define LAUNCH_MK(WT)                                                                                                  \
     do {                                                                                                               \
         auto kern = k_ls_mask<WT>;                                                                                     \
-        if (ldm > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldm); \
+        if (ldm > 64 * 1024) ensure_dyn_lds((const void*)kern, ldm); \
         hipLaunchKernelGGL(kern, gm, block, ldm, s, (const WT*)ws, ws_pitch, B, N, rd_std, thresh, seed, env_offset, (int)draw, (uint64_t*)scratch); \
     } while (0)
         if (ws_bytes == 1) LAUNCH_MK(int8_t); else LAUNCH_MK(int16_t);
@@ -1019,7 +1019,7 @@ extern "C" int rls_maxcut_ls_propose(const rls_graph* g, uint8_t* x, int64_t B, 
 #define LAUNCH_PR(WT, PP, SD, PM)                                                                                      \
     do {                                                                                                               \
         auto kern = k_ls_propose<WT, PP, SD, PM>;                                                                      \
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (lds > 64 * 1024) ensure_dyn_lds((const void*)kern, lds); \
         hipLaunchKernelGGL(kern, grid, block, lds, s, x, B, N, g->eu, g->ev, E, halve, (const WT*)ws, ws_pitch, rd_std, thresh, seed,  \
                            env_offset, (int)draw, obj, (const uint64_t*)scratch, x_aligned);                           \
     } while (0)
@@ -1050,7 +1050,7 @@ extern "C" int rls_maxcut_ls_rounds(const rls_graph* g, uint8_t* x, int64_t B, c
     const int64_t N = g->num_nodes, E = g->num_stored_edges;
     if (ws_pitch == 0) ws_pitch = N;
     const int S = ls_slices(B, ws_bytes == 1 ? ls_num_chunks<int8_t>(N) : ls_num_chunks<int16_t>(N));
-    static const bool per_round = getenv("RLS_LS_PER_ROUND") != nullptr;   // dev knob: one propose launch per round
+    const bool per_round = knob_on(KN_LS_PER_ROUND);   // dev knob: one propose launch per round
     const bool half = ls_half_tile(N);
     const bool big = ls_big_tile(N) || half;
     RLS_REQUIRE(!half || ls_noise_passes_fit(N), RLS_EUNSUPPORTED, "N=%lld: rd_std does not fit LDS and N is not a multiple of 4", (long long)N);
@@ -1080,12 +1080,12 @@ extern "C" int rls_maxcut_ls_rounds(const rls_graph* g, uint8_t* x, int64_t B, c
             const dim3 block(kLsRoundWaves * kWave);
             if (ws_bytes == 1) {
                 auto kern = sd_lds ? k_ls_mask<int8_t, true> : k_ls_mask<int8_t, false>;
-                if (ldm > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldm);
+                if (ldm > 64 * 1024) ensure_dyn_lds((const void*)kern, ldm);
                 hipLaunchKernelGGL(kern, gm, block, ldm, s, (const int8_t*)ws, ws_pitch, B, N, rd_std, thresh, seed, env_offset,
                                    (int)(first_draw + r0 + r), out);
             } else {
                 auto kern = sd_lds ? k_ls_mask<int16_t, true> : k_ls_mask<int16_t, false>;
-                if (ldm > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldm);
+                if (ldm > 64 * 1024) ensure_dyn_lds((const void*)kern, ldm);
                 hipLaunchKernelGGL(kern, gm, block, ldm, s, (const int16_t*)ws, ws_pitch, B, N, rd_std, thresh, seed, env_offset,
                                    (int)(first_draw + r0 + r), out);
             }
@@ -1094,26 +1094,26 @@ extern "C" int rls_maxcut_ls_rounds(const rls_graph* g, uint8_t* x, int64_t B, c
         // half tiles (twice the workgroups, the same mask words): past the 64-env tile, and for batches that leave half the CUs
         // without a 64-env tile (whole local_search_inplace calls, 4096 envs: G22-sized 0.324 -> 0.305 ms, BA n = 10^4 0.893 -> 0.816,
         // G70-sized 0.689 -> 0.642; at 16 384 envs no gain).  Dev knob RLS_LS_APPLY32 = 0 | 1 forces the choice.
-        static const int knob32 = getenv("RLS_LS_APPLY32") ? atoi(getenv("RLS_LS_APPLY32")) : -1;
+        const int knob32 = (int)knob(KN_LS_APPLY32, -1);
         const bool fast32 = x_aligned && (N & 15) == 0 && ls_apply32_lds(N, kLsRoundWaves, true) <= (size_t)kLdsBytes;
         const bool few32 = knob32 >= 0 ? knob32 != 0 : 2 * (int64_t)grid.x <= (int64_t)num_cus();
         if (half || (few32 && fast32)) {
             const int st32 = (x_aligned && (N & 15) == 0 && ls_apply32_lds(N, kLsRoundWaves, true) <= (size_t)kLdsBytes) ? 1 : 0;
             const size_t lds = ls_apply32_lds(N, kLsRoundWaves, st32 != 0);
             auto kern = k_ls_apply_rounds32<24, kLsRoundWaves>;
-            if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (lds > 64 * 1024) ensure_dyn_lds((const void*)kern, lds);
             hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(B, (int64_t)kHalf)), dim3(kLsRoundWaves * kWave), lds, s, x, B, N, g->eu, g->ev, E,
                                halve, (const uint64_t*)scratch, (int64_t)grid.x, per_launch, obj, x_aligned, st32);
         } else if (big) {   // the bare tile: 4 waves, lane-per-env loads and stores
             const size_t lds = ls_apply_lds(N, 4, false);
             auto kern = k_ls_apply_rounds<24, 4>;
-            if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (lds > 64 * 1024) ensure_dyn_lds((const void*)kern, lds);
             hipLaunchKernelGGL(kern, grid, dim3(4 * kWave), lds, s, x, B, N, g->eu, g->ev, E, halve, (const uint64_t*)scratch, per_launch, obj,
                                x_aligned, 0);
         } else {
             const size_t lds = ls_apply_lds(N, kLsRoundWaves, true);
             auto kern = k_ls_apply_rounds<24, kLsRoundWaves>;
-            if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (lds > 64 * 1024) ensure_dyn_lds((const void*)kern, lds);
             hipLaunchKernelGGL(kern, grid, dim3(kLsRoundWaves * kWave), lds, s, x, B, N, g->eu, g->ev, E, halve, (const uint64_t*)scratch,
                                per_launch, obj, x_aligned, 1);
         }

@@ -874,12 +874,12 @@ static inline size_t node_stats_bits_lds(int64_t N, bool with_stage = true, int 
 // G22-sized graph 28 us flat vs 9 / 21 / 68 us at 64 / 256 / 1024 envs, N = 10^4 with 10^4 edges 88 flat vs 7 / 17 / 70
 // (tools/sweeps/node_stats_forms.py) -- so small batches go element-parallel
 static inline bool node_stats_batch_fills_tiles(const rls_graph* g, int64_t B) {
-    static const int64_t force = getenv("RLS_NODE_STATS_MIN_B") ? atoll(getenv("RLS_NODE_STATS_MIN_B")) : -1;   // dev knob
+    const int64_t force = (int64_t)knob(KN_NODE_STATS_MIN_B, -1);   // dev knob
     if (force >= 0) return B >= force;
     return (double)B * (double)(g->num_nodes + g->nnz) > 4000.0 * (double)g->num_nodes;
 }
 static inline bool node_stats_use_bits(const rls_graph* g, const int32_t* ell_ptr, const int32_t* ell, int64_t B) {
-    static const bool off = getenv("RLS_NODE_STATS_LANE_ENV") != nullptr;   // dev knob: the lane = env kernels
+    const bool off = knob_on(KN_NODE_STATS_LANE_ENV);   // dev knob: the lane = env kernels
     return !off && ell_ptr && ell && !g->wgt && g->max_degree < 65536 && node_stats_batch_fills_tiles(g, B) &&
            node_stats_bits32_lds(g->num_nodes, false) <= (size_t)kLdsBytes;   // (half tiles, without the row-piece stage, if need be)
 }
@@ -890,7 +890,7 @@ static int launch_node_stats_bits(const rls_graph* g, const uint8_t* x, int64_t 
     const int64_t N = g->num_nodes;
     const bool vec = tile_rows_aligned(x, N, 1);
     const bool wide = g->max_degree >= 256;
-    static const int knob32 = getenv("RLS_NS_TILE32") ? atoi(getenv("RLS_NS_TILE32")) : -1;   // dev knob: half tiles at any size
+    const int knob32 = (int)knob(KN_NS_TILE32, -1);   // dev knob: half tiles at any size
     // Half tiles: past the 64-env tile; and, for byte rows of 16-byte multiples whose half tile has room for its stage, where they
     // measure faster (this round's GPU runs): batches of few tiles -- a tile costs the same however few envs it holds, so twice
     // as many half as long workgroups win while CUs are idle: K3 / K2 up to 8192 envs (G22-sized 4096: 31 -> 23 us, BA n = 10^4
@@ -909,7 +909,7 @@ static int launch_node_stats_bits(const rls_graph* g, const uint8_t* x, int64_t 
 #define RLS_NS32_LAUNCH(KERN)                                                                                        \
     do {                                                                                                            \
         auto kern = KERN;                                                                                           \
-        if (l32 > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l32); \
+        if (l32 > 64 * 1024) ensure_dyn_lds((const void*)kern, l32); \
         hipLaunchKernelGGL(kern, g32, b32, l32, as_stream(stream), x, B, N, rowptr, ell_ptr, ell, mult, out, minmax,  \
                            out_pitch > 0 ? out_pitch : N, st32);                                                     \
     } while (0)
@@ -927,7 +927,7 @@ static int launch_node_stats_bits(const rls_graph* g, const uint8_t* x, int64_t 
     // 8 waves per tile, or 4 where that turns a launch of one-and-a-bit rounds of workgroups into ONE round: a G22-sized tile
     // is 16 KB + 4 KB of row-piece stage per wave -- 3 eight-wave workgroups per CU (768 resident: 1024 tiles = a full round
     // and a third of one), 5 four-wave ones (every tile resident at once)
-    static const int force_w = getenv("RLS_NS_WAVES") ? atoi(getenv("RLS_NS_WAVES")) : 0;     // dev knob
+    const int force_w = (int)knob(KN_NS_WAVES, 0);     // dev knob
     const int64_t tiles = ceil_div(B, kWave);
     auto resident = [&](int wv) {
         const int64_t by_lds = (int64_t)((size_t)kLdsBytes / node_stats_bits_lds(N, has_stage != 0, wv)), by_waves = 32 / wv;
@@ -944,7 +944,7 @@ static int launch_node_stats_bits(const rls_graph* g, const uint8_t* x, int64_t 
     do {                                                                                                            \
         auto kern = KERN;                                                                                           \
         if (lds > 64 * 1024)                                                                                        \
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
+            ensure_dyn_lds((const void*)kern, lds);     \
         hipLaunchKernelGGL(kern, grid, block, lds, as_stream(stream), x, B, N, rowptr, ell_ptr, ell, mult, out, minmax, \
                            out_pitch > 0 ? out_pitch : N, has_stage);                                               \
     } while (0)
@@ -1009,14 +1009,18 @@ __global__ __launch_bounds__(256) void k_pick_best_of_repeats(const uint8_t* __r
 // A thread owns 16 spins = one 16-byte store (VEC16: rows start 16-byte aligned), consecutive lanes consecutive
 // pieces, so a wave's store covers 1 KB of a row.  (One byte store per spin ran at 0.8 TB/s.)
 template <bool VEC16>
-__global__ __launch_bounds__(256) void k_rand_spins(uint8_t* __restrict__ x, int64_t B, int64_t N, uint64_t seed, int64_t env_offset) {
+// (repeat_seeds != nullptr: row b is repeat b / S of env b % S and takes that repeat's seed -- LocalSearch.reset_search's
+// num_sims x num_sims candidates in one launch)
+__global__ __launch_bounds__(256) void k_rand_spins(uint8_t* __restrict__ x, int64_t B, int64_t N, uint64_t seed, int64_t env_offset,
+                                                    const uint64_t* __restrict__ repeat_seeds, int64_t S) {
     const int64_t chunks = (N + 15) >> 4;  // 16 spins per thread
     const int64_t total = B * chunks;
-    const Philox ph(seed);
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
          t += (int64_t)gridDim.x * blockDim.x) {
         const int64_t b = t / chunks, ch = t - b * chunks;
-        const uint64_t gb = (uint64_t)(b + env_offset);
+        const int64_t rep = repeat_seeds ? b / S : 0;
+        const Philox ph(repeat_seeds ? repeat_seeds[rep] : seed);
+        const uint64_t gb = (uint64_t)(b - rep * S + env_offset);
         uint32_t r[4];
         ph((uint32_t)gb, (uint32_t)(gb >> 32), (uint32_t)(ch >> 3), 0x5350494Eu, r);
         uint32_t bits = (r[(ch & 7) >> 1] >> (((ch & 7) & 1) * 16)) & 0xffffu;
@@ -1044,16 +1048,18 @@ __global__ __launch_bounds__(256) void k_rand_spins(uint8_t* __restrict__ x, int
 // CH = bytes (= spins) per store: 16, or 8 / 4 for rows that are multiples of 8 / 4 bytes only (N = 1000, 3000, 5000, 7000 of the
 // Gset sizes: the per-piece kernel took 158 us for 2^16 x 2000-ish rows there, this one 22)
 template <int CH>
-__global__ __launch_bounds__(256) void k_rand_spins_rows(uint8_t* __restrict__ x, int64_t B, int64_t N, uint64_t seed, int64_t env_offset) {
+__global__ __launch_bounds__(256) void k_rand_spins_rows(uint8_t* __restrict__ x, int64_t B, int64_t N, uint64_t seed, int64_t env_offset,
+                                                         const uint64_t* __restrict__ repeat_seeds, int64_t S) {
     __shared__ uint4 sh[4][kWave];
     constexpr int CPB = 128 / CH;                   // chunks per 128-spin block
     const int lane = threadIdx.x & (kWave - 1);
     const int w = threadIdx.x / kWave;
     const int64_t chunks = N / CH;                  // N % CH == 0 here
     const int64_t blocks = (chunks + CPB - 1) / CPB;
-    const Philox ph(seed);
     for (int64_t b = (int64_t)blockIdx.x * 4 + w; b < B; b += (int64_t)gridDim.x * 4) {
-        const uint64_t gb = (uint64_t)(b + env_offset);
+        const int64_t rep = repeat_seeds ? b / S : 0;
+        const Philox ph(repeat_seeds ? repeat_seeds[rep] : seed);
+        const uint64_t gb = (uint64_t)(b - rep * S + env_offset);
         uint8_t* row = x + b * N;
         for (int64_t g0 = 0; g0 < blocks; g0 += kWave) {
             uint32_t r[4] = {0, 0, 0, 0};
@@ -1245,7 +1251,7 @@ int rls_maxcut_obj(const rls_graph* g, const void* x, int spin_bytes, int64_t B,
     // rows past 8192 nodes, whose 64-env tile leaves one workgroup per CU or no room for the row-piece stage (G70-sized 2^17:
     // 280 -> 262 us, N = 20 000 2^16: 374 -> 282), and launches of at most two 64-env tiles per CU (G22-sized 2^14: 14.8 -> 13.4 us;
     // at 2^16 the half tiles LOSE, 34.4 -> 36.3: twice the edge-list reads per env).  Dev knob RLS_K1_TILE32 = 0 | 1 forces the choice.
-    static const int knob32 = getenv("RLS_K1_TILE32") ? atoi(getenv("RLS_K1_TILE32")) : -1;
+    const int knob32 = (int)knob(KN_K1_TILE32, -1);
     {
         auto lds32 = [&](int ww) { return (((size_t)N * 4 + 15) & ~(size_t)15) + (size_t)ww * kWave * 8; };
         // 8 waves once two 4-wave workgroups (with their stages) no longer share a CU: one 4-wave workgroup per CU cannot keep
@@ -1266,7 +1272,7 @@ int rls_maxcut_obj(const rls_graph* g, const void* x, int spin_bytes, int64_t B,
 #define LAUNCH_OBJ32(T, VEC, PP)                                                                                        \
     do {                                                                                                                \
         auto kern = w32 == kTileWavesMax ? k_maxcut_obj32<T, VEC, PP, kTileWavesMax> : k_maxcut_obj32<T, VEC, PP, kTileWaves>; \
-        if (l32 > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l32); \
+        if (l32 > 64 * 1024) ensure_dyn_lds((const void*)kern, l32); \
         hipLaunchKernelGGL(kern, g32, b32, l32, s32, (const T*)x, B, N, g->eu, g->ev, E, hv, obj, st_off);              \
     } while (0)
 #define DISPATCH_P32(T, VEC)                        \
@@ -1293,10 +1299,10 @@ int rls_maxcut_obj(const rls_graph* g, const void* x, int spin_bytes, int64_t B,
         const dim3 gr((unsigned)ceil_div(B, rw)), br(rw * kWave);
         const int hv = g->if_bidirectional ? 1 : 0;
         if (spin_bytes == 1) {
-            if (lr > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_maxcut_obj_rows<uint8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lr);
+            if (lr > 64 * 1024) ensure_dyn_lds((const void*)k_maxcut_obj_rows<uint8_t>, lr);
             hipLaunchKernelGGL(k_maxcut_obj_rows<uint8_t>, gr, br, lr, as_stream(stream), (const uint8_t*)x, B, N, g->eu, g->ev, E, hv, obj);
         } else {
-            if (lr > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_maxcut_obj_rows<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lr);
+            if (lr > 64 * 1024) ensure_dyn_lds((const void*)k_maxcut_obj_rows<float>, lr);
             hipLaunchKernelGGL(k_maxcut_obj_rows<float>, gr, br, lr, as_stream(stream), (const float*)x, B, N, g->eu, g->ev, E, hv, obj);
         }
         return check_launch("k_maxcut_obj_rows");
@@ -1310,13 +1316,13 @@ int rls_maxcut_obj(const rls_graph* g, const void* x, int spin_bytes, int64_t B,
     const int halve = g->if_bidirectional ? 1 : 0;
     // dev knob: ask for more LDS than the tile needs, i.e. fewer resident workgroups per CU and a second round of them whose loads
     // could hide the first round's counting (RLS_K1_LDS_KB = kilobytes per workgroup)
-    static const int pad_kb = getenv("RLS_K1_LDS_KB") ? atoi(getenv("RLS_K1_LDS_KB")) : 0;
+    const int pad_kb = (int)knob(KN_K1_LDS_KB, 0);
     if (pad_kb > 0 && (size_t)pad_kb * 1024 > lds && (size_t)pad_kb * 1024 <= (size_t)kLdsBytes) lds = (size_t)pad_kb * 1024;
 #define LAUNCH_OBJ(T, VEC, PP)                                                                             \
     do {                                                                                                   \
         auto kern = tw == kTileWavesMax ? k_maxcut_obj<T, VEC, PP, kTileWavesMax> : k_maxcut_obj<T, VEC, PP, kTileWaves>; \
         if (lds > 64 * 1024)                                                                               \
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            ensure_dyn_lds((const void*)kern, lds); \
         hipLaunchKernelGGL(kern, grid, block, lds, s, (const T*)x, B, N, g->eu, g->ev, E, halve, obj, stage_off); \
     } while (0)
 #define DISPATCH_P(T, VEC)                       \
@@ -1355,7 +1361,7 @@ int rls_maxcut_propose_accept(const rls_graph* g, uint8_t* x, int64_t B, const v
     // byte mask: 608 -> 481 us; N = 20 000 2^15, where the 64-env tile has no room for its stage: 387 -> 299), and in launches of
     // at most one 64-env tile per CU (G22-sized 2^12: 21.8 -> 11.4 us, 2^14: 26.8 -> 20.9; at 2^16 they lose, 63.6 -> 67.3).
     // tools/timing/k5_tile32.py.
-    static const int knob32 = getenv("RLS_K6_TILE32") ? atoi(getenv("RLS_K6_TILE32")) : -1;   // dev knob: 0 | 1 forces the choice
+    const int knob32 = (int)knob(KN_K6_TILE32, -1);   // dev knob: 0 | 1 forces the choice
     const bool no_stage64 = lds + (size_t)tw * kStageBytes > (size_t)kLdsBytes;
     // (the half tile's fast loader wants byte rows of 16-byte multiples on a 16-byte base; other rows keep the 64-env forms)
     const bool fast32 = (N & 15) == 0 && tile_rows_aligned(x, N, 1) && (mask_bits || tile_rows_aligned(mask, N, 1));
@@ -1379,7 +1385,7 @@ int rls_maxcut_propose_accept(const rls_graph* g, uint8_t* x, int64_t B, const v
                                                       : k_maxcut_propose_accept32<VEC, PP, kTileWaves, true>)           \
                               : (w32 == kTileWavesMax ? k_maxcut_propose_accept32<VEC, PP, kTileWavesMax, false>        \
                                                       : k_maxcut_propose_accept32<VEC, PP, kTileWaves, false>);         \
-        if (l32 > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l32); \
+        if (l32 > 64 * 1024) ensure_dyn_lds((const void*)kern, l32); \
         hipLaunchKernelGGL(kern, g32, b32, l32, s32, x, mask, B, N, g->eu, g->ev, E, hv, obj, st32);                    \
     } while (0)
 #define DISPATCH_P32(VEC)                      \
@@ -1400,7 +1406,7 @@ int rls_maxcut_propose_accept(const rls_graph* g, uint8_t* x, int64_t B, const v
         RLS_REQUIRE(rw > 0, RLS_EUNSUPPORTED, "N=%lld: a row does not fit LDS (max %d)", (long long)N, kLdsBytes);
         RLS_REQUIRE(!mask_bits, RLS_EUNSUPPORTED, "N=%lld: beyond the tiles the mask must be bytes [B, N]", (long long)N);
         const size_t lr = (size_t)rw * (((size_t)N + 15) & ~(size_t)15);
-        if (lr > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_maxcut_propose_accept_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lr);
+        if (lr > 64 * 1024) ensure_dyn_lds((const void*)k_maxcut_propose_accept_rows, lr);
         hipLaunchKernelGGL(k_maxcut_propose_accept_rows, dim3((unsigned)ceil_div(B, rw)), dim3(rw * kWave), lr, as_stream(stream), x, mask, B, N,
                            g->eu, g->ev, E, g->if_bidirectional ? 1 : 0, obj);
         return check_launch("k_maxcut_propose_accept_rows");
@@ -1419,7 +1425,7 @@ int rls_maxcut_propose_accept(const rls_graph* g, uint8_t* x, int64_t B, const v
                               : (tw == kTileWavesMax ? k_maxcut_propose_accept<VEC, PP, kTileWavesMax>         \
                                                      : k_maxcut_propose_accept<VEC, PP, kTileWaves>);          \
         if (lds > 64 * 1024)                                                                               \
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            ensure_dyn_lds((const void*)kern, lds); \
         hipLaunchKernelGGL(kern, grid, block, lds, s, x, mask, B, N, g->eu, g->ev, E, halve, obj, stage_off); \
     } while (0)
 #define DISPATCH_P(VEC)                      \
@@ -1448,10 +1454,10 @@ int rls_maxcut_greedy_sweep(const rls_graph* g, uint8_t* x, int64_t B, int64_t* 
     const bool fast = !g->wgt && g->max_degree < kSweepMaxDeg && lds_fast <= (size_t)kLdsBytes &&
                       (((uintptr_t)g->col) & 3) == 0;
     {   // level-parallel sweep: needs the lane-per-node schedule (N < 2^20, degrees < 256) and the tile in LDS
-        static const bool no_levels = getenv("RLS_SWEEP_NO_LEVELS") != nullptr;   // dev knob
+        const bool no_levels = knob_on(KN_SWEEP_NO_LEVELS);   // dev knob
         const int64_t G = g->num_sweep_groups, E = g->num_stored_edges;
         const int P = pick_planes(E);
-        static const int force_lw = getenv("RLS_SWEEP_WAVES") ? atoi(getenv("RLS_SWEEP_WAVES")) : 0;
+        const int force_lw = (int)knob(KN_SWEEP_WAVES, 0);
         // one group per level (G22: 44 nodes per group): a level is ONE wave's pass and the others only prefetch -- few
         // waves, more tiles per CU; well-filled groups (G70: 9 levels of ~17 groups): 8 waves share a level
         int sw = force_lw == 2 || force_lw == 4 || force_lw == 8 || force_lw == 16 ? force_lw : (N >= 56 * G ? 8 : 4);
@@ -1467,7 +1473,7 @@ int rls_maxcut_greedy_sweep(const rls_graph* g, uint8_t* x, int64_t B, int64_t* 
         }
         const size_t lds_l = lds_of(sw, has_stage != 0);
         // half tiles (rls_tile32.h) where the 64-env tile does not fit (dev knob RLS_K5_TILE32 = 1: at any size)
-        static const int knob32 = getenv("RLS_K5_TILE32") ? atoi(getenv("RLS_K5_TILE32")) : -1;
+        const int knob32 = (int)knob(KN_K5_TILE32, -1);
         // ... and, for byte rows of 16-byte multiples (the half tile's staged loader / store), where they measure faster
         // (tools/timing/k5_tile32.py): rows past 8192 nodes (G70-sized 2^17: 780 -> 705 us; N = 20 000, where the 64-env tile has no
         // room for its stage, 4096 envs: 171 -> 100) and launches of at most one 64-env tile per CU (G22-sized 2^14: 63 -> 53 us;
@@ -1491,7 +1497,7 @@ int rls_maxcut_greedy_sweep(const rls_graph* g, uint8_t* x, int64_t B, int64_t* 
 #define LAUNCH_SWL32(VEC, SWV, PP)                                                                                          \
     do {                                                                                                                    \
         auto kern = k_maxcut_greedy_sweep_levels32<VEC, SWV, PP>;                                                           \
-        if (l32 > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l32); \
+        if (l32 > 64 * 1024) ensure_dyn_lds((const void*)kern, l32); \
         hipLaunchKernelGGL(kern, g32, b32, l32, s, x, B, N, g->sweep_lv_ptr, g->sweep_lv_data, G, g->eu, g->ev, E, hv, obj, stage32); \
     } while (0)
 #define DISPATCH_SWL32_P(VEC, SWV)                       \
@@ -1521,7 +1527,7 @@ int rls_maxcut_greedy_sweep(const rls_graph* g, uint8_t* x, int64_t B, int64_t* 
     do {                                                                                                     \
         auto kern = k_maxcut_greedy_sweep_levels<VEC, SWV, PP>;                                              \
         if (lds_l > 64 * 1024)                                                                               \
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_l); \
+            ensure_dyn_lds((const void*)kern, lds_l); \
         hipLaunchKernelGGL(kern, grid, blockl, lds_l, s, x, B, N, g->sweep_lv_ptr, g->sweep_lv_data, G, g->eu, g->ev, \
                            E, halve, obj, has_stage);                                                         \
     } while (0)
@@ -1546,9 +1552,9 @@ int rls_maxcut_greedy_sweep(const rls_graph* g, uint8_t* x, int64_t B, int64_t* 
             return check_launch("k_maxcut_greedy_sweep_levels");
         }
     }
-    static const bool unbatched = getenv("RLS_SWEEP_UNBATCHED") != nullptr;   // dev knob
+    const bool unbatched = knob_on(KN_SWEEP_UNBATCHED);   // dev knob
     if (fast && g->sweep_rowptr && g->sweep_stream && !unbatched) {
-        static const int force_sw = getenv("RLS_SWEEP_WAVES") ? atoi(getenv("RLS_SWEEP_WAVES")) : 0;   // dev knob
+        const int force_sw = (int)knob(KN_SWEEP_WAVES, 0);   // dev knob
         const int sw = force_sw == 4 || force_sw == 8 || force_sw == 16 ? force_sw
                                                                          : (ceil_div(B, kWave) <= (int64_t)num_cus() ? 16 : 8);
         const size_t lds_b = lds_fast + (size_t)sw * kWave * 8;
@@ -1558,7 +1564,7 @@ int rls_maxcut_greedy_sweep(const rls_graph* g, uint8_t* x, int64_t B, int64_t* 
         auto kern = sw == 16 ? k_maxcut_greedy_sweep_batched<VEC, 16>                                      \
                              : (sw == 8 ? k_maxcut_greedy_sweep_batched<VEC, 8> : k_maxcut_greedy_sweep_batched<VEC, 4>); \
         if (lds_b > 64 * 1024)                                                                             \
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_b); \
+            ensure_dyn_lds((const void*)kern, lds_b); \
         hipLaunchKernelGGL(kern, grid, blockw, lds_b, s, x, B, N, g->sweep_rowptr, g->sweep_stream, g->nnz + N, obj); \
     } while (0)
         if (lds_b <= (size_t)kLdsBytes) {
@@ -1572,7 +1578,7 @@ int rls_maxcut_greedy_sweep(const rls_graph* g, uint8_t* x, int64_t B, int64_t* 
     do {                                                                                                   \
         auto kern = k_maxcut_greedy_sweep<VEC>;                                                            \
         if (lds_fast > 64 * 1024)                                                                          \
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fast); \
+            ensure_dyn_lds((const void*)kern, lds_fast); \
         hipLaunchKernelGGL(kern, grid, block, lds_fast, s, x, B, N, g->rowptr, g->col, g->nnz, obj);       \
     } while (0)
         if (vec) LAUNCH_SWF(true); else LAUNCH_SWF(false);
@@ -1587,10 +1593,10 @@ int rls_maxcut_greedy_sweep(const rls_graph* g, uint8_t* x, int64_t B, int64_t* 
         const dim3 gr((unsigned)ceil_div(B, rw)), br(rw * kWave);
         // the symmetric CSR counts every undirected edge once per endpoint: the gain of a flip needs no halving
         if (g->wgt) {
-            if (lr > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_maxcut_greedy_sweep_rows<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lr);
+            if (lr > 64 * 1024) ensure_dyn_lds((const void*)k_maxcut_greedy_sweep_rows<true>, lr);
             hipLaunchKernelGGL(k_maxcut_greedy_sweep_rows<true>, gr, br, lr, s, x, B, N, g->rowptr, g->col, g->wgt, 0, obj);
         } else {
-            if (lr > 64 * 1024) (void)hipFuncSetAttribute((const void*)k_maxcut_greedy_sweep_rows<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lr);
+            if (lr > 64 * 1024) ensure_dyn_lds((const void*)k_maxcut_greedy_sweep_rows<false>, lr);
             hipLaunchKernelGGL(k_maxcut_greedy_sweep_rows<false>, gr, br, lr, s, x, B, N, g->rowptr, g->col, g->wgt, 0, obj);
         }
         return check_launch("k_maxcut_greedy_sweep_rows");
@@ -1599,7 +1605,7 @@ int rls_maxcut_greedy_sweep(const rls_graph* g, uint8_t* x, int64_t B, int64_t* 
     do {                                                                                                   \
         auto kern = k_maxcut_greedy_sweep_generic<VEC, W>;                                                 \
         if (lds > 64 * 1024)                                                                               \
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            ensure_dyn_lds((const void*)kern, lds); \
         hipLaunchKernelGGL(kern, grid, block, lds, s, x, B, N, g->rowptr, g->col, g->wgt, obj);            \
     } while (0)
     if (g->wgt) { if (vec) LAUNCH_SW(true, true); else LAUNCH_SW(false, true); }
@@ -1625,7 +1631,7 @@ static inline size_t node_stats_lds(int64_t N) { return (size_t)(N + 2) * 8 + (s
 // element-parallel kernels 2.75e-6 us per (env, node + entry) (250 / 480 / 1890 us at 2048 / 4096 / 16 384): the tile form from
 // the batch where it is the cheaper one (tools/sweeps/node_stats_forms.py)
 static inline bool node_stats_use_tile(const rls_graph* g, int64_t B) {
-    static const bool off = getenv("RLS_NODE_STATS_NO_TILE") != nullptr;   // dev knob
+    const bool off = knob_on(KN_NODE_STATS_NO_TILE);   // dev knob
     const int64_t N = g->num_nodes;
     return !off && node_stats_lds(N) <= (size_t)kLdsBytes &&
            2.75e-6 * (double)B * (double)(N + g->nnz) > 0.103 * (double)N + 0.008 * (double)g->nnz;
@@ -1655,7 +1661,7 @@ int rls_maxcut_node_cutdeg(const rls_graph* g, const uint8_t* x, int64_t B, int6
     do {                                                                                                         \
         auto kern = k_node_stats_tile<int64_t, false, false, VEC>;                                               \
         if (lds > 64 * 1024)                                                                                     \
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+            ensure_dyn_lds((const void*)kern, lds);  \
         hipLaunchKernelGGL(kern, grid, block, lds, s, x, B, N, g->erowptr, g->ev, (const int32_t*)nullptr, cutdeg); \
     } while (0)
         if (tile_rows_aligned(x, N, 1)) LAUNCH_NS(true); else LAUNCH_NS(false);
@@ -1683,7 +1689,7 @@ int rls_maxcut_delta_all(const rls_graph* g, const uint8_t* x, int64_t B, int32_
     do {                                                                                                         \
         auto kern = k_node_stats_tile<int32_t, true, W, VEC>;                                                    \
         if (lds > 64 * 1024)                                                                                     \
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+            ensure_dyn_lds((const void*)kern, lds);  \
         hipLaunchKernelGGL(kern, grid, block, lds, s, x, B, N, g->rowptr, g->col, g->wgt, delta);               \
     } while (0)
         const bool vec = tile_rows_aligned(x, N, 1);
@@ -1764,22 +1770,34 @@ int rls_pick_best_of_repeats(const uint8_t* xs, const int64_t* vs, int64_t R, in
     return check_launch("k_pick_best_of_repeats");
 }
 
-int rls_rand_spins(uint8_t* x, int64_t B, int64_t N, uint64_t seed, int64_t env_offset, void* stream) {
-    RLS_REQUIRE(B >= 0 && N > 0, RLS_EINVAL, "bad sizes");
-    if (B == 0) return RLS_OK;
-    RLS_REQUIRE(x, RLS_EINVAL, "x is NULL");
+static int rand_spins_launch(uint8_t* x, int64_t B, int64_t N, uint64_t seed, int64_t env_offset, const uint64_t* repeat_seeds, int64_t S,
+                             void* stream) {
     const bool vec16 = (N % 16 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0);
     if (N >= 512 && (N & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
         // rows of at least four 128-spin blocks, 4-byte aligned: one Philox call per block (a wave per row)
         const dim3 grid(grid_for(B * kWave, 256)), block(256);
-        if ((N & 15) == 0) hipLaunchKernelGGL(k_rand_spins_rows<16>, grid, block, 0, as_stream(stream), x, B, N, seed, env_offset);
-        else if ((N & 7) == 0) hipLaunchKernelGGL(k_rand_spins_rows<8>, grid, block, 0, as_stream(stream), x, B, N, seed, env_offset);
-        else hipLaunchKernelGGL(k_rand_spins_rows<4>, grid, block, 0, as_stream(stream), x, B, N, seed, env_offset);
+        if ((N & 15) == 0) hipLaunchKernelGGL(k_rand_spins_rows<16>, grid, block, 0, as_stream(stream), x, B, N, seed, env_offset, repeat_seeds, S);
+        else if ((N & 7) == 0) hipLaunchKernelGGL(k_rand_spins_rows<8>, grid, block, 0, as_stream(stream), x, B, N, seed, env_offset, repeat_seeds, S);
+        else hipLaunchKernelGGL(k_rand_spins_rows<4>, grid, block, 0, as_stream(stream), x, B, N, seed, env_offset, repeat_seeds, S);
         return check_launch("k_rand_spins_rows");
     }
     hipLaunchKernelGGL(vec16 ? k_rand_spins<true> : k_rand_spins<false>, dim3(grid_for(B * ((N + 15) >> 4), 256)),
-                       dim3(256), 0, as_stream(stream), x, B, N, seed, env_offset);
+                       dim3(256), 0, as_stream(stream), x, B, N, seed, env_offset, repeat_seeds, S);
     return check_launch("k_rand_spins");
+}
+
+int rls_rand_spins(uint8_t* x, int64_t B, int64_t N, uint64_t seed, int64_t env_offset, void* stream) {
+    RLS_REQUIRE(B >= 0 && N > 0, RLS_EINVAL, "bad sizes");
+    if (B == 0) return RLS_OK;
+    RLS_REQUIRE(x, RLS_EINVAL, "x is NULL");
+    return rand_spins_launch(x, B, N, seed, env_offset, nullptr, 1, stream);
+}
+
+int rls_rand_spins_repeats(uint8_t* x, int64_t R, int64_t S, int64_t N, const uint64_t* repeat_seeds, int64_t env_offset, void* stream) {
+    RLS_REQUIRE(R >= 0 && S >= 0 && N > 0, RLS_EINVAL, "bad sizes");
+    if (R == 0 || S == 0) return RLS_OK;
+    RLS_REQUIRE(x && repeat_seeds, RLS_EINVAL, "x / repeat_seeds is NULL");
+    return rand_spins_launch(x, R * S, N, 0, env_offset, repeat_seeds, S, stream);
 }
 
 int rls_rand_actions(int64_t* action, int64_t B, int64_t N, uint64_t seed, uint64_t step, int64_t env_offset,

@@ -1312,7 +1312,7 @@ int rls_mcpg_metro_rounds(void* samples, const void* samples_in, int64_t C_in, i
         const size_t lds = (size_t)((N + 1) & ~(int64_t)1) * 8 + (size_t)2 * kMetroWin * kWave * 4;
         RLS_REQUIRE(lds <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS (max %d)", (long long)N, lds, kLdsBytes);
         auto kern = index ? k_mcpg_metro_packed<true> : k_mcpg_metro_packed<false>;
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (lds > 64 * 1024) ensure_dyn_lds((const void*)kern, lds);
         hipLaunchKernelGGL(kern, cgrid, dim3(kMetroPW * kWave), lds, as_stream(stream),
                            (uint64_t*)samples, (const uint64_t*)samples_in, ceil_div(C_in, kWave), N, C, probs, T, index, u, seed,
                            t_limit_dev, write_back, (unsigned long long*)accepts, accept_rows, t_offset, ids);
@@ -1330,7 +1330,7 @@ int rls_mcpg_metro_rounds(void* samples, const void* samples_in, int64_t C_in, i
     do {                                                                                                            \
         auto kern = k_mcpg_metro<TT, PL>;                                                                           \
         if (lds > 64 * 1024)                                                                                        \
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
+            ensure_dyn_lds((const void*)kern, lds);     \
         hipLaunchKernelGGL(kern, grid, block, lds, s, (TT*)samples, (const TT*)samples_in, N, C, probs, T, index, u, seed, t_limit_dev, \
                            write_back, (unsigned long long*)accepts, accept_rows, t_offset, ids);                   \
     } while (0)
@@ -1402,12 +1402,12 @@ int rls_mcpg_local_search_levels(const rls_graph* g, const void* xs_in, int spin
     const int64_t tiles_in = ceil_div(C_in, kWave);
     const dim3 grid = cgrid;
     hipStream_t s = as_stream(stream);
-    static const int force_w = getenv("RLS_K7_WAVES") ? atoi(getenv("RLS_K7_WAVES")) : 0;   // dev knob
+    const int force_w = (int)knob(KN_K7_WAVES, 0);   // dev knob
 #define LAUNCH_LVL(TI, TO, PP, WW)                                                                              \
     do {                                                                                                        \
         auto kern = k_mcpg_local_search_levels<TI, TO, PP, WW>;                                                 \
         if (lds > 64 * 1024)                                                                                    \
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            ensure_dyn_lds((const void*)kern, lds); \
         hipLaunchKernelGGL(kern, grid, dim3(WW * kWave), lds, s, (const typename ChainStore<TI>::type*)xs_in,   \
                            (typename ChainStore<TO>::type*)xs_out, N, C, tiles_in, lv_ptr, lv_data, num_groups,  \
                            num_ls, coins, seed, g->eu, g->ev, E, expected, ids);                                 \
@@ -1470,7 +1470,7 @@ int rls_mcpg_local_search(const rls_graph* g, const void* xs_in, int spin_bytes,
     do {                                                                                                             \
         auto kern = k_mcpg_local_search_stream<TI, PP, WGT>;                                                         \
         if (lds_fast > 64 * 1024)                                                                                    \
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_fast); \
+            ensure_dyn_lds((const void*)kern, lds_fast); \
         hipLaunchKernelGGL(kern, grid, block, lds_fast, s, (const TI*)xs_in, xs_out, N, C, visit_stream, visit_len,   \
                            num_ls, uniforms, seed, g->eu, g->ev, edge_weights, E, gn, expected, ids);                 \
     } while (0)
@@ -1494,7 +1494,7 @@ int rls_mcpg_local_search(const rls_graph* g, const void* xs_in, int spin_bytes,
     do {                                                                                                        \
         auto kern = k_mcpg_local_search<TI, PP>;                                                                \
         if (lds > 64 * 1024)                                                                                    \
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            ensure_dyn_lds((const void*)kern, lds); \
         hipLaunchKernelGGL(kern, grid, block, lds, s, (const TI*)xs_in, xs_out, N, C, g->rowptr, g->col, order, \
                            num_ls, uniforms, seed, g->eu, g->ev, E, expected, ids);                             \
     } while (0)
@@ -1555,7 +1555,7 @@ int rls_mcpg_value_bit_sums(const uint64_t* samples, int64_t N, int64_t C, const
     const size_t lds = (size_t)(8 * 256 + kWave) * 4 + (regs ? 0 : (size_t)N * 4);
     if (lds <= (size_t)kLdsBytes / 2) {
         auto kern = regs ? k_mcpg_value_bit_sums_lut<true> : k_mcpg_value_bit_sums_lut<false>;
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (lds > 64 * 1024) ensure_dyn_lds((const void*)kern, lds);
         int64_t per_cu = (int64_t)kLdsBytes / (int64_t)lds;           // resident workgroups per CU by LDS ...
         if (per_cu > 2048 / kBitSumThreads) per_cu = 2048 / kBitSumThreads;   // ... and by threads
         int64_t grid = 256 * per_cu;

@@ -386,7 +386,7 @@ extern "C" int rls_qubo_local_search_value(const float* Q, int64_t n, const floa
     do {                                                                                                              \
         auto kern = k_qubo_ls_value_mfma<BIN_, NT_, W_>;                                                              \
         if (lds > 64 * 1024)                                                                                          \
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
+            ensure_dyn_lds((const void*)kern, lds);       \
         hipLaunchKernelGGL(kern, grid, block, lds, as_stream(stream), Q, n, n_pad, xs_in, xs_out, C, num_ls, value);  \
     } while (0)
     if (binary) {
@@ -411,11 +411,11 @@ extern "C" int rls_qubo_sparse_local_search_value(const int32_t* rowptr, const i
     const dim3 grid((unsigned)ceil_div(C, kWave)), block(kWave);
     if (binary) {
         auto kern = k_qubo_sparse_ls_value<true>;
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (lds > 64 * 1024) ensure_dyn_lds((const void*)kern, lds);
         hipLaunchKernelGGL(kern, grid, block, lds, as_stream(stream), rowptr, col, val, n, xs_in, xs_out, C, num_ls, value);
     } else {
         auto kern = k_qubo_sparse_ls_value<false>;
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (lds > 64 * 1024) ensure_dyn_lds((const void*)kern, lds);
         hipLaunchKernelGGL(kern, grid, block, lds, as_stream(stream), rowptr, col, val, n, xs_in, xs_out, C, num_ls, value);
     }
     return check_launch("k_qubo_sparse_ls_value");

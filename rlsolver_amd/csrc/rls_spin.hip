@@ -805,11 +805,11 @@ int rls_rand_couplings(void* matrix, int state_bytes, int64_t B, int64_t N, int3
     const dim3 grid((unsigned)ceil_div(B, epw)), block(kWave);
     if (state_bytes == 4) {
         auto kern = k_rand_couplings_ba<float>;
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (lds > 64 * 1024) ensure_dyn_lds((const void*)kern, lds);
         hipLaunchKernelGGL(kern, grid, block, lds, s, (float*)matrix, B, N, m, (int)edge_type, seed, env_offset, epw);
     } else {
         auto kern = k_rand_couplings_ba<double>;
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (lds > 64 * 1024) ensure_dyn_lds((const void*)kern, lds);
         hipLaunchKernelGGL(kern, grid, block, lds, s, (double*)matrix, B, N, m, (int)edge_type, seed, env_offset, epw);
     }
     return check_launch("k_rand_couplings_ba");

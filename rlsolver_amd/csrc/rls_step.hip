@@ -268,10 +268,14 @@ __global__ __launch_bounds__(256) void k_maxcut_step(const T* __restrict__ xin, 
                     r0[k] = rowptr[act[k]];
                     deg[k] = rowptr[act[k] + 1] - r0[k];
                     // hand-issued (and hand-waited, below): a compiler-tracked load pending at the store loop's head makes the
-                    // compiler drain the vector-memory counter there -- which waits for the whole run and ends the chase
-                    const int32_t* pn = col + r0[k] + (lane < deg[k] ? lane : 0);
-                    asm volatile("global_load_dword %0, %1, off" : "=v"(nb[k]) : "v"(pn) : "memory");
-                    ++nlo;
+                    // compiler drain the vector-memory counter there -- which waits for the whole run and ends the chase.
+                    // Only for a node that HAS neighbours (deg is wave-uniform, so `nlo` stays exact): an isolated node at the
+                    // end of the CSR has r0 == nnz, and col + nnz is one entry past the array (col may be NULL when nnz == 0)
+                    if (deg[k] > 0) {
+                        const int32_t* pn = col + r0[k] + (lane < deg[k] ? lane : 0);
+                        asm volatile("global_load_dword %0, %1, off" : "=v"(nb[k]) : "v"(pn) : "memory");
+                        ++nlo;
+                    }
                 }
             }
             const int keep = nch - 1 + nlo;
@@ -288,6 +292,10 @@ __global__ __launch_bounds__(256) void k_maxcut_step(const T* __restrict__ xin, 
             }
             tail_copy();                                                     // (a short last run only)
             wait_vmcnt_le(nch < 62 ? nch : 62);                              // the neighbour ids are older than every store
+            // the compiler does not know that nb[k] only became valid at the wait above: every use below goes through a value it
+            // must treat as (re)defined HERE, after the wait
+#pragma unroll
+            for (int k = 0; k < EPW; ++k) asm volatile("" : "+v"(nb[k]) :: "memory");
 #pragma unroll
             for (int k = 0; k < EPW; ++k)
                 if (act[k] >= 0) {
@@ -380,22 +388,14 @@ __global__ __launch_bounds__(256) void k_maxcut_step(const T* __restrict__ xin, 
   }   // runs of this wave
 }
 
-// development knobs, read once per process (no getenv on the launch path): nts = -1 automatic | 0 | 1 (nontemporal
-// stores), epw / wpb = 0: automatic
+// tuning knobs (rls_tuning_set; no environment variable is read by the production library): nts = -1 automatic | 0 | 1
+// (nontemporal stores), epw / wpb = 0: automatic, persist = -1 automatic | 0 one run per wave | k: k workgroup rounds per CU
+// resident, waves loop; chase = -1 automatic | 0 MODE 2 (stores after the last load) | 1 MODE 3 (stores chase the loads);
+// align = 0: load / store instructions start where the run starts (before round 4's fix)
 struct StepKnobs { int nts, epw, wpb, persist, chase, align; };
-static StepKnobs read_step_knobs() {
-    const char* m = getenv("RLS_STEP_NTS");
-    const char* e = getenv("RLS_STEP_EPW");
-    const char* w = getenv("RLS_STEP_WPB");
-    const char* p = getenv("RLS_STEP_PERSIST");     // -1 automatic | 0 one run per wave | k: k workgroup rounds per CU resident, waves loop
-    const char* c = getenv("RLS_STEP_CHASE");       // -1 automatic | 0 MODE 2 (stores after the last load) | 1 MODE 3 (stores chase the loads)
-    const char* al = getenv("RLS_STEP_ALIGN");      // 0: load / store instructions start where the run starts (before round 4's fix)
-    return StepKnobs{m ? atoi(m) : -1, e ? atoi(e) : 0, w ? atoi(w) : 0, p ? atoi(p) : -1, c ? atoi(c) : -1, al ? atoi(al) : 1};
-}
 static StepKnobs step_knobs() {
-    static const bool reread = getenv("RLS_DEV_REREAD_ENV") != nullptr;   // tools/microbench.py, tools/sweep_step.py: A/B in one process
-    static const StepKnobs k = read_step_knobs();
-    return reread ? read_step_knobs() : k;
+    return StepKnobs{(int)knob(KN_STEP_NTS, -1), (int)knob(KN_STEP_EPW, 0), (int)knob(KN_STEP_WPB, 0), (int)knob(KN_STEP_PERSIST, -1),
+                     (int)knob(KN_STEP_CHASE, -1), (int)knob(KN_STEP_ALIGN, 1)};
 }
 
 }  // namespace rls
@@ -464,7 +464,7 @@ extern "C" int rls_maxcut_step(const rls_graph* g, const void* x_in, void* x_out
     do {                                                                                                       \
         auto kern = k_maxcut_step<T, EPW, MODE, EMIT, VEC, false, NTL, NTS>;                                   \
         if (lds > 64 * 1024)                                                                                   \
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            ensure_dyn_lds((const void*)kern, lds); \
         hipLaunchKernelGGL(kern, grid, block, lds, s, (const T*)x_in, (T*)x_out, B, N, g->rowptr, g->col, g->wgt, \
                            action, obj, reward, cur, done, done_value, knobs.align);                           \
     } while (0)

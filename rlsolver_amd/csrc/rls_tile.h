@@ -145,7 +145,7 @@ constexpr int kStageDepth = 3;                       // chunks in flight per wav
 
 // Host side: append W stages to a kernel's dynamic LDS when they fit; returns their byte offset or -1.
 inline int tile_stage_offset(size_t* lds_bytes, int W, bool wanted) {
-    static const bool off = getenv("RLS_TILE_NOSTAGE") != nullptr;   // dev knob: lane-per-env global access
+    const bool off = knob_on(KN_TILE_NOSTAGE);   // dev knob: lane-per-env global access
     const size_t base = (*lds_bytes + 15) & ~(size_t)15;
     if (!wanted || off || base + (size_t)W * kStageBytes > (size_t)kLdsBytes) return -1;
     *lds_bytes = base + (size_t)W * kStageBytes;

@@ -347,7 +347,7 @@ int rls_tsp_tour_length(const float* dist, int64_t N, const int64_t* perm, int64
     if (dist_fits_lds(N, 0)) {
         const size_t lds = (size_t)N * N * 4;
         auto kern = k_tsp_tour_length<true>;
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (lds > 64 * 1024) ensure_dyn_lds((const void*)kern, lds);
         hipLaunchKernelGGL(kern, grid, block, lds, as_stream(stream), dist, N, perm, B, length);
     } else {
         hipLaunchKernelGGL(k_tsp_tour_length<false>, grid, block, 0, as_stream(stream), dist, N, perm, B, length);
@@ -367,12 +367,12 @@ int rls_tsp_swap_delta_all(const float* dist, int64_t N, const int64_t* perm, in
     if (dist_fits_lds(N, scratch)) {
         const size_t lds = (size_t)N * N * 4 + scratch;
         auto kern = k_tsp_swap_delta_all<true>;
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (lds > 64 * 1024) ensure_dyn_lds((const void*)kern, lds);
         hipLaunchKernelGGL(kern, grid, block, lds, as_stream(stream), dist, N, perm, B, selected, temperature, logratio,
                            indices, ban);
     } else {
         auto kern = k_tsp_swap_delta_all<false>;
-        if (scratch > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)scratch);
+        if (scratch > 64 * 1024) ensure_dyn_lds((const void*)kern, scratch);
         hipLaunchKernelGGL(kern, grid, block, scratch, as_stream(stream), dist, N, perm, B, selected, temperature,
                            logratio, indices, ban);
     }
@@ -408,11 +408,11 @@ int rls_tsp_2opt_best(const double* dist, int64_t N, const int64_t* perm, int64_
     RLS_REQUIRE(lds <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS (max %d)", (long long)N, lds, kLdsBytes);
     if (cur_length) {
         auto kern = k_tsp_2opt_best<true>;
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (lds > 64 * 1024) ensure_dyn_lds((const void*)kern, lds);
         hipLaunchKernelGGL(kern, dim3((unsigned)B, (unsigned)slices), dim3(256), lds, as_stream(stream), dist, N, perm, B, cur_length, best_i, best_j, best_value);
     } else {
         auto kern = k_tsp_2opt_best<false>;
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (lds > 64 * 1024) ensure_dyn_lds((const void*)kern, lds);
         hipLaunchKernelGGL(kern, dim3((unsigned)B, (unsigned)slices), dim3(256), lds, as_stream(stream), dist, N, perm, B, cur_length, best_i, best_j, best_value);
     }
     if (slices > 1)
@@ -428,7 +428,7 @@ int rls_rand_perms(int64_t* perm, int64_t B, int64_t N, uint64_t seed, int64_t e
     const size_t lds = (size_t)N * kPermStride * sizeof(uint16_t);
     if (N <= 65535 && lds <= (size_t)kLdsBytes / 2) {
         auto kern = k_rand_perms_lds;
-        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (lds > 64 * 1024) ensure_dyn_lds((const void*)kern, lds);
         hipLaunchKernelGGL(kern, dim3((unsigned)ceil_div(B, kWave)), dim3(kWave), lds, as_stream(stream), perm, B, N, seed,
                            env_offset);
         return check_launch("k_rand_perms_lds");

@@ -351,6 +351,15 @@ void rand_spins(Tensor x, int64_t seed, int64_t env_offset) {
     RLS_GUARD(x);
     ok(rls_rand_spins((uint8_t*)p(x), x.size(0), x.size(1), (uint64_t)seed, env_offset, cur_stream(x)), "rls_rand_spins");
 }
+void rand_spins_repeats(Tensor x, Tensor repeat_seeds, int64_t env_offset) {
+    spin_bytes(x, "x", false);
+    dev(repeat_seeds, "repeat_seeds", I64);
+    same_device(x, repeat_seeds, "repeat_seeds");
+    TORCH_CHECK(x.dim() == 3 && repeat_seeds.dim() == 1 && repeat_seeds.size(0) == x.size(0), "x must be [R, S, N] and repeat_seeds [R]");
+    RLS_GUARD(x);
+    ok(rls_rand_spins_repeats((uint8_t*)p(x), x.size(0), x.size(1), x.size(2), (const uint64_t*)p(repeat_seeds), env_offset, cur_stream(x)),
+       "rls_rand_spins_repeats");
+}
 void rand_actions(Tensor action, int64_t N, int64_t seed, int64_t step, int64_t env_offset) {
     dev(action, "action", I64);
     RLS_GUARD(action);
@@ -847,6 +856,7 @@ TORCH_LIBRARY(rlsolver_hip, m) {
           "int log_index, bool force) -> ()");
     m.def("best_key(Tensor vs, int rank_bits, int low_code, int limit, Tensor(a!) key, Tensor(b!)? index, Tensor(c!) flag) -> ()");
     m.def("rand_spins(Tensor(a!) x, int seed, int env_offset) -> ()");
+    m.def("rand_spins_repeats(Tensor(a!) x, Tensor repeat_seeds, int env_offset) -> ()");
     m.def("rand_actions(Tensor(a!) action, int N, int seed, int step, int env_offset) -> ()");
     m.def("rand_perms(Tensor(a!) perm, int seed, int env_offset) -> ()");
     m.def("spin_reset(int graph, int env, Tensor(a!) state, Tensor row_index, float max_local, int weight_sum) -> ()");
@@ -910,6 +920,7 @@ TORCH_LIBRARY_IMPL(rlsolver_hip, CUDA, m) {   // "CUDA" is the HIP dispatch key 
     m.impl("best_update", &best_update);
     m.impl("best_key", &best_key);
     m.impl("rand_spins", &rand_spins);
+    m.impl("rand_spins_repeats", &rand_spins_repeats);
     m.impl("rand_actions", &rand_actions);
     m.impl("rand_perms", &rand_perms);
     m.impl("spin_reset", &spin_reset);

@@ -50,12 +50,13 @@ class LocalSearch:
         chunk = max(1, min(num_repeats, self.RESET_SEARCH_MAX_BYTES // per_repeat))
         best = best_v = None
         base_seed = sim._next_seed()
+        if num_sims == 0:            # an empty shard: nothing to draw (the seed above is still consumed, as on every rank)
+            return th.empty((0, sim.num_nodes), dtype=th.bool, device=sim.device)
         for r0 in range(0, num_repeats, chunk):
             reps = min(chunk, num_repeats - r0)
-            cand = th.empty((reps * num_sims, sim.num_nodes), dtype=th.bool, device=sim.device)
-            for r in range(reps):       # one keyed launch per repeat: row r * num_sims + s = repeat r0 + r of incumbent s
-                ops.rand_spins(num_sims, sim.num_nodes, sim._seeds.derive(base_seed, r0 + r), sim.device,
-                               env_offset=sim.env_offset, out=cand[r * num_sims:(r + 1) * num_sims])
+            # ONE keyed launch per chunk: row r * num_sims + s = repeat r0 + r of incumbent s, drawn under that repeat's seed
+            cand = ops.rand_spins_repeats([sim._seeds.derive(base_seed, r0 + r) for r in range(reps)], num_sims, sim.num_nodes,
+                                          sim.device, env_offset=sim.env_offset)
             cx, cv = ops.pick_best_of_repeats(cand, sim.calculate_obj_values(cand), reps, if_maximize=True)
             if best is not None:     # earlier repeats win ties: the running best replaces the chunk's row when it is >=
                 ops.select_better_rows(cx, cv, best, best_v, if_maximize=True)

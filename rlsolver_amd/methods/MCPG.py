@@ -455,6 +455,15 @@ class MCPGRound(Sharded):
         self._nodemajor = mops.mcpg_metro_max_rounds(self.N, 0) == 0
         if self._nodemajor and self.sharded:
             raise NotImplementedError("a sharded MCPGRound needs the bit-packed walk (N <= ~16 000)")
+        if self.sharded and self.now_max_res.numel():
+            # the incumbents travel between ranks as a packed MAXLOC key of DOUBLED integers (dist.global_best): cut values of
+            # this build's integer-weighted graphs are integers or half-integers.  Anything else would trip a device-side assert
+            # rounds later -- refuse it here, by name (one host read, at construction only)
+            twice = self.now_max_res.to(torch.float64) * 2
+            if not bool(((twice == twice.round()) & (twice.abs() < float(1 << 43))).all()):
+                raise ValueError("a sharded MCPGRound exchanges its incumbents as integer MAXLOC keys: now_max_res must hold integers "
+                                 "or half-integers below 2^42 in magnitude (cut values of an integer-weighted graph); run graphs "
+                                 "with non-integer weights unsharded")
 
     def _global_best(self, values: TEN, rows: Optional[PackedChains], maximize: bool):
         """(best value 0-dim, GLOBAL index 0-dim int64, its chain bool [N] or None) over every rank's ``values``; first index on

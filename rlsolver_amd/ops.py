@@ -413,6 +413,21 @@ def rand_spins(B: int, N: int, seed: int, device, env_offset: int = 0, out: Opti
     return out
 
 
+def rand_spins_repeats(seeds, S: int, N: int, device, env_offset: int = 0, out: Optional[TEN] = None) -> TEN:
+    """R repeats of S envs in one launch: row r * S + s = what ``rand_spins(S, N, seeds[r], env_offset)`` writes for env s
+    (LocalSearch.reset_search's candidates).  ``seeds``: a sequence of ints (uploaded) or an int64 device tensor [R]."""
+    device = torch.device(device)
+    if not isinstance(seeds, torch.Tensor):
+        seeds = torch.tensor([_s64(int(v)) for v in seeds], dtype=torch.int64).to(device, non_blocking=True)
+    R = int(seeds.shape[0])
+    if out is None:
+        out = torch.empty((R * S, N), dtype=torch.bool, device=device)
+    _check(out, "out", _SPIN_DTYPES, None, (R * S, N))
+    if R * S:
+        _t.rand_spins_repeats(out.view(R, S, N), _check(seeds, "seeds", (torch.int64,), out.device, (R,)), env_offset)
+    return out
+
+
 def rand_actions(B: int, N: int, seed: int, step: int, device, env_offset: int = 0,
                  out: Optional[TEN] = None) -> TEN:
     device = torch.device(device)

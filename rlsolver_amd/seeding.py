@@ -58,6 +58,14 @@ class SeedStream:
         self.seed, self.calls = d["seed"], int(d["calls"])
 
 
+class _Keep:
+    def __repr__(self):
+        return "KEEP"
+
+
+KEEP = _Keep()          # set_shard(): "leave this attribute as it is" (None is a value there)
+
+
 class Sharded:
     """Mixin: ``env_offset`` + ``SeedStream`` (+ the process group of the few whole-batch statistics) for the env / sampler
     classes.  ``group``: a torch.distributed group (``dist.group.WORLD`` for the default one) over which statistics of the
@@ -77,10 +85,21 @@ class Sharded:
         self.group = group
         self._seeds = SeedStream(seed)
 
-    def set_shard(self, env_offset: int, seed: Optional[int] = None, group=None):
+    def set_shard(self, env_offset: int, seed=KEEP, group=KEEP):
         """Make this object rank-aware after construction: global id of its env 0 (+ optionally a private seed stream and
-        the group over which whole-batch statistics are reduced)."""
-        self._init_shard(env_offset, self._seeds.seed if seed is None else seed, self.group if group is None else group)
+        the group over which whole-batch statistics are reduced).  ``seed`` / ``group`` left out = unchanged (KEEP); None is
+        a value: back to torch's generator / back to "this object's batch is the whole batch".  A seed stream that is kept
+        keeps its call counter -- re-sharding an object that has already drawn must not hand out the same kernel seeds
+        again; only a NEW seed starts a fresh stream."""
+        if env_offset < 0:
+            raise ValueError("env_offset must be >= 0")
+        self.env_offset = int(env_offset)
+        if group is not KEEP:
+            self.group = group
+        if seed is not KEEP:
+            new = None if seed is None else int(seed) & _M64
+            if new != self._seeds.seed:
+                self._seeds = SeedStream(seed)
         return self
 
     def _next_seed(self) -> int:

@@ -511,3 +511,50 @@ def test_step_runs_that_start_anywhere_in_a_cache_line(dt, n, m, B, off_in, off_
         assert np.array_equal(x.float().cpu().numpy(), env.xs), t
         for buf, off in ((bx, off_in), (by, off_out)):            # the bytes around the views are still 0xFF
             assert bool((buf[:off] == 255).all()) and bool((buf[off + nbytes:] == 255).all()), t
+
+
+@pytest.mark.parametrize("dt", ["u8", "f32"])
+def test_step_on_the_last_isolated_node_with_col_at_the_end_of_its_buffer(dt):
+    """MODE 3 (the f32 emit step) issued its hand-written neighbour-id load for EVERY valid action, also for a node
+    without neighbours -- for an isolated node at the end of the CSR that address is col + nnz, one entry past the array.  The
+    graph here leaves its last three nodes isolated and its `col` array ends exactly where a 2 MB device buffer ends (the
+    DeviceGraph's own tensor is swapped for a view at the tail of a block the allocator hands out whole), so the over-read left the
+    allocation; every env acts on an isolated node in two of the steps."""
+    n, m, B = 2000, 6000, 131
+    rng = np.random.RandomState(7)
+    graph = gnm_arr(n - 3, m, seed=11)                       # nodes n-3 .. n-1 have no edge
+    g = device_graph(graph, n, 0)
+    assert int(g.csr.rowptr[n - 3]) == g.nnz == int(g.csr.rowptr[n])
+    block = torch.zeros((2 << 20) // 4, dtype=torch.int32, device=DEV)          # one whole 2 MB allocator block
+    tail = block[block.numel() - g.nnz:]
+    tail.copy_(g.col)
+    g.col = tail
+    g.struct.col = tail.data_ptr()
+    xs = rng.randint(0, 2, size=(B, n)).astype(np.uint8)
+    env = onp.PPOEnvOracle(graph, n, 10 ** 9, False)
+    env.reset_to(xs)
+    x = to_dev_bool(xs) if dt == "u8" else to_dev_bool(xs).float()
+    y = torch.empty_like(x)
+    obj = ops.maxcut_obj(g, x).to(torch.int32)
+    reward = torch.empty(B, dtype=torch.float32, device=DEV)
+    for t in range(6):
+        a = rng.randint(0, n, size=B)
+        if t in (1, 4):
+            a[:] = n - 1 - (np.arange(B) % 3)                # isolated nodes only: gain 0, the spin still flips
+        _, r, _, c = env.step(a)
+        ops.maxcut_step(g, x, y, torch.from_numpy(a).to(DEV), obj, reward)
+        x, y = y, x
+        assert np.array_equal(reward.cpu().numpy(), r) and np.array_equal(obj.cpu().numpy().astype(np.float32), c), t
+        assert np.array_equal(x.float().cpu().numpy(), env.xs), t
+
+
+def test_rand_spins_repeats_is_the_per_repeat_launches_in_one():
+    """rls_rand_spins_repeats (ABI v11): row r * S + s = rls_rand_spins(seed = seeds[r], env_offset) of env s, for both
+    kernels (rows of >= 512 spins take the wave-per-row form) and at a shard offset."""
+    for S, N, off in ((37, 2000, 0), (5, 100, 1 << 33), (64, 1000, 12345), (3, 20, 7)):
+        seeds = [(0x9E3779B97F4A7C15 * (k + 1)) & ((1 << 62) - 1) for k in range(6)]
+        got = ops.rand_spins_repeats(seeds, S, N, DEV, env_offset=off)
+        assert got.shape == (6 * S, N)
+        for r, sd in enumerate(seeds):
+            assert torch.equal(got[r * S:(r + 1) * S], ops.rand_spins(S, N, sd, DEV, env_offset=off)), (S, N, r)
+    assert ops.rand_spins_repeats([], 4, 64, DEV).shape == (0, 64)

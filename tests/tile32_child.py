@@ -13,6 +13,7 @@ from oracle import oracle_np as onp
 from rlsolver_amd import graph as G, ops
 from rlsolver_amd.graph import build_csr
 from rlsolver_amd.ops_mcpg_tsp import PackedChains
+from rlsolver_amd import _abi; _abi.tuning_from_env()   # RLS_<KNOB> variables -> rls_tuning_set (the library itself reads no environment)
 
 DEV = torch.device("cuda:0")
 rng = np.random.RandomState(int(sys.argv[1]) if len(sys.argv) > 1 else 3)

@@ -9,6 +9,7 @@ sys.path.insert(0, ".")
 from oracle import oracle_isco as oi
 from tests.isco_tol import RTOL, assert_ll_close, ll_atol
 from rlsolver_amd import graph as G
+from rlsolver_amd import _abi; _abi.tuning_from_env()   # RLS_<KNOB> variables -> rls_tuning_set (forced forms)
 from rlsolver_amd.envs.env_ISCO_maxcut import ISCO_maxcut
 
 DEV = torch.device("cuda:0")

@@ -6,6 +6,7 @@ import numpy as np, torch
 sys.path.insert(0, ".")
 from oracle import oracle_c as oc
 from rlsolver_amd import ops
+from rlsolver_amd import _abi; _abi.tuning_from_env()   # RLS_<KNOB> variables -> rls_tuning_set (forced forms)
 from rlsolver_amd.graph import build_csr
 
 DEV = torch.device("cuda:0")

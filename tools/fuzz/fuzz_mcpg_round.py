@@ -11,6 +11,7 @@ import numpy as np, torch
 sys.path.insert(0, ".")
 from oracle import oracle_np as onp
 from rlsolver_amd import graph as G
+from rlsolver_amd import _abi; _abi.tuning_from_env()   # RLS_<KNOB> variables -> rls_tuning_set (forced forms)
 from rlsolver_amd.methods import MCPG as amcpg
 from rlsolver_amd.ops_mcpg_tsp import PackedChains
 

@@ -6,6 +6,7 @@ import numpy as np, torch
 sys.path.insert(0, ".")
 from oracle import oracle_np as onp
 from rlsolver_amd import ops, _abi
+from rlsolver_amd import _abi; _abi.tuning_from_env()   # RLS_<KNOB> variables -> rls_tuning_set (forced forms)
 from rlsolver_amd import ops_mcpg_tsp as mops
 from rlsolver_amd.ops import _ptr, _stream
 

@@ -4,9 +4,8 @@ import argparse
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-os.environ["RLS_DEV_REREAD_ENV"] = "1"   # the library reads its knobs once per process otherwise
 import torch
-from rlsolver_amd import ops
+from rlsolver_amd import _abi, ops
 from rlsolver_amd.graph import build_csr, generate_gnm
 
 ap = argparse.ArgumentParser()
@@ -44,13 +43,13 @@ if "step" in which:
     reward = torch.empty(B, dtype=torch.float32, device=dev)
     acts = [ops.rand_actions(B, N, 7, s, dev) for s in range(16)]
     by = B * (2 * N + 20)
-    modes = [int(m) for m in os.environ.get("NTS", "0,1").split(",")]      # nontemporal stores off / on (RLS_DEV_REREAD_ENV=1)
+    modes = [int(m) for m in os.environ.get("NTS", "0,1").split(",")]      # nontemporal stores off / on (rls_tuning_set)
     for rep in range(2):
         for mode in modes:
-            os.environ["RLS_STEP_NTS"] = str(mode)
+            _abi.tuning_set("RLS_STEP_NTS", mode)
             t = timeit(lambda i: ops.maxcut_step(g, slots[i % a.slots], slots[(i + 1) % a.slots], acts[i % 16], obj, reward), a.iters)
             print(f"step emit, nontemporal stores {mode}: {t*1e6:9.1f} us  {B/t:.3e} steps/s  {by/t/1e9:8.1f} GB/s algorithmic ({by/t/8e12*100:.1f}% of 8 TB/s)")
-    os.environ.pop("RLS_STEP_NTS")
+    _abi.tuning_unset("RLS_STEP_NTS")
 if "step_inplace" in which:
     obj = ops.maxcut_obj(g, x).to(torch.int32)
     reward = torch.empty(B, dtype=torch.float32, device=dev)

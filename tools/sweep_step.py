@@ -2,9 +2,8 @@
 """A/B the step kernel's development knobs in one process (interleaved rounds; guide rule 24)."""
 import itertools, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["RLS_DEV_REREAD_ENV"] = "1"   # the library reads its knobs once per process otherwise
 import torch
-from rlsolver_amd import ops
+from rlsolver_amd import _abi, ops
 from rlsolver_amd.graph import build_csr, generate_gnm
 
 n, m, B, S = (int(os.environ.get(k, d)) for k, d in (("SW_N", 2000), ("SW_M", 19990), ("SW_B", 65536), ("SW_S", 8)))
@@ -45,7 +44,8 @@ configs = [dict(RLS_STEP_NTS=str(md), RLS_STEP_EPW=str(e), RLS_STEP_WPB=str(w), 
 res = {i: [] for i in range(len(configs))}
 for rep in range(3):
     for i, c in enumerate(configs):
-        os.environ.update(c)
+        for k_, v_ in c.items():
+            _abi.tuning_set(k_, int(v_))
         try:
             res[i].append(timeit())
         except Exception as ex:

@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import numpy as np, torch
 from rlsolver_amd import ops
 from rlsolver_amd.graph import build_csr, generate_ba, generate_gnm
+from rlsolver_amd import _abi; _abi.tuning_from_env()   # RLS_<KNOB> variables -> rls_tuning_set (the library itself reads no environment)
 dev = torch.device("cuda:0")
 for name, n, mg in (("G22", 2000, generate_gnm(2000, 19990, 22)), ("G14", 800, generate_gnm(800, 4694, 14)), ("BA-1e4", 10000, generate_ba(10000, 5, 5))):
     g = ops.DeviceGraph(build_csr(mg, n, False), dev)

@@ -4,6 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import numpy as np, torch
 from rlsolver_amd import ops
 from rlsolver_amd.graph import build_csr, generate_gnm
+from rlsolver_amd import _abi; _abi.tuning_from_env()   # RLS_<KNOB> variables -> rls_tuning_set (the library itself reads no environment)
 dev = torch.device("cuda:0")
 rng = np.random.RandomState(0)
 for name, n, m, weighted in (("G22", 2000, 19990, False), ("G22 +-1", 2000, 19990, True), ("G70", 10000, 9999, False), ("G70 +-1", 10000, 9999, True)):

@@ -1,6 +1,7 @@
 import sys, os, torch
 from rlsolver_amd import ops
 from rlsolver_amd.graph import build_csr, generate_gnm
+from rlsolver_amd import _abi; _abi.tuning_from_env()   # RLS_<KNOB> variables -> rls_tuning_set (the library itself reads no environment)
 dev = torch.device("cuda:0")
 for tag, n, m, B in (("G22 2^16", 2000, 19990, 1 << 16), ("G70 2^17", 10000, 9999, 1 << 17)):
     g = ops.DeviceGraph(build_csr(generate_gnm(n, m, 22), num_nodes=n), dev)

@@ -6,6 +6,7 @@ import numpy as np, torch
 from rlsolver_amd import graph, ops, ops_mcpg_tsp as mops
 from rlsolver_amd.graph import build_csr, generate_gnm
 from rlsolver_amd.methods import MCPG as amcpg
+from rlsolver_amd import _abi; _abi.tuning_from_env()   # RLS_<KNOB> variables -> rls_tuning_set
 dev = torch.device('cuda:0')
 
 

@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import numpy as np, torch
 from rlsolver_amd import graph
 from rlsolver_amd.envs.env_L2A import EnvMaxcut
+from rlsolver_amd import _abi; _abi.tuning_from_env()   # RLS_<KNOB> variables -> rls_tuning_set (the library itself reads no environment)
 dev = torch.device('cuda:0')
 
 
