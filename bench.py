@@ -60,6 +60,12 @@ def parse(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config5", action="store_true", help="skip the secondary G70 / 2^17-envs-per-GPU measurement")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="skip the `configs` block: BASELINE configs #2 (dREINFORCE-shaped local search), #3 (BA MCMC) and #4 (TSP) at "
+                         "their stated sizes, each a bounded wall-clock measurement after the headline (never mixed into `value`)")
+    ap.add_argument("--global-envs", type=int, default=0,
+                    help="STRONG scaling: this many envs in total, split over the ranks (rlsolver_amd.dist.env_shard) -- "
+                         "`--gset 70 --global-envs 1048576 --gpus 8` is BASELINE config #5 as the headline; 0 = --envs-per-gpu each (weak)")
     ap.add_argument("--via-env", action="store_true",
                     help="time the drop-in class surface, EnvMaxcutGym.step(action, out=slot) with 1-byte spins, instead of "
                          "the pre-validated C-ABI launcher (same kernel, plus the Python / ctypes path of the class)")
@@ -197,6 +203,211 @@ def pmc_traffic_per_launch(envs, nodes, slots):
 
 
 # --------------------------------------------------------------------------- #
+# BASELINE configs #2, #3, #4 (rank 0, N = 1 only; after the headline, never mixed into `value`)
+# --------------------------------------------------------------------------- #
+def _profiled(kernel_sub, row_sub, field):
+    """A figure that cannot be measured live (SQ / TCC counters), from the newest committed per-kernel table
+    (profiles/rNN_kernels.json: tools/kernel_table.py over the round's rocprofv3 passes), or None."""
+    import glob
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernels.json")), reverse=True):
+        try:
+            for grp in json.load(open(p)).get("groups", []):
+                for r in (grp if isinstance(grp, list) else grp.get("rows", [])):
+                    if kernel_sub in r.get("kernel", "") and row_sub in r.get("row", "") and r.get(field) is not None:
+                        return {"value": r[field], "source": f"profiles/{os.path.basename(p)}: {r['kernel']}"}
+        except Exception:
+            pass
+    return None
+
+
+def _time_calls(fn, iters, warm=2):
+    import torch
+    for i in range(warm):
+        fn(i)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(iters):
+        fn(i)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / iters
+
+
+def config2_local_search(dev):
+    """BASELINE config #2's outer-loop body: dREINFORCE's `local_search_inplace` (envs/env_L2A.py:87-116: 8 noisy
+    top-k multi-flip proposals + one greedy sweep) on B = 64 x 1024 rows of a G22-sized graph.  The reference evaluates
+    N + 8 full objectives per env per call; a call is ONE pre-pass + ONE fused kernel here."""
+    import torch
+    from rlsolver_amd.envs.env_L2A import EnvMaxcut
+    from rlsolver_amd.graph import load_gset
+    mygraph, n, is_real = load_gset(22, os.path.join(ROOT, "data", "gset"))
+    B = 64 * 1024
+    env = EnvMaxcut(mygraph=mygraph, device=dev, num_nodes=n)
+    torch.manual_seed(0)
+    xs = env.generate_xs_randomly(B)
+    vs = env.calculate_obj_values(xs)
+    v0 = vs.clone()
+    t = _time_calls(lambda i: env.local_search_inplace(xs, vs, num_iters=8, num_spin=8, noise_std=0.3), 30, warm=2)
+    ok = bool((vs >= v0).all()) and torch.equal(env.calculate_obj_values(xs), vs)
+    if not ok:
+        raise SystemExit("PARITY FAILURE (config #2): local_search_inplace lost value or its vs != recomputed objective")
+    out = {"workload": f"G22{'' if is_real else '-sized G(n,m) stand-in'} (N={n}, E={len(mygraph)}), {B} envs: "
+                       "EnvMaxcut.local_search_inplace(num_iters=8, num_spin=8) -- dREINFORCE's outer-loop body",
+           "ms_per_call": t * 1e3, "candidate_evaluations_per_s": B * (n + 8) / t, "env_sweeps_per_s": B / t,
+           "unit_note": "the reference performs N + 8 full objective evaluations per env per call (env-steps in its sense)",
+           "bound": "valu", "check": "32 calls chained; vs never drops and equals the recomputed objective of xs: ok",
+           "mean_gain_over_random": float((vs - v0).float().mean())}
+    vf = _profiled("k_maxcut_local_search", "G22", "valu_frac")
+    if vf:
+        out["valu_issue_frac"] = vf
+    return out
+
+
+def config3_mcpg(dev):
+    """BASELINE config #3: BA n = 10^4, m = 5, 2^18 chains = 2048 kept x 128 repeats, num_ls = 8 sweeps in degree-descending
+    order (methods/MCPG.py:120-166) + metro_sampling (:88-118) + the best-merge (:376-391).  `num_samples_per_second` is the
+    reference's own print (MCPG.py:409-412): kept chains per round time."""
+    import numpy as np
+    import torch
+    from rlsolver_amd import ops
+    from rlsolver_amd.graph import generate_ba
+    from rlsolver_amd.methods import MCPG as amcpg
+    from rlsolver_amd.ops_mcpg_tsp import PackedChains
+    n, C, R, num_ls = 10000, 1 << 18, 128, 8
+    M, T = C // R, n // 10
+    arr = np.asarray(generate_ba(n, 5, seed=5), dtype=np.int64)
+    data = amcpg.make_data(n, arr[:, 0], arr[:, 1], dev)
+    torch.manual_seed(0)
+    probs = torch.full((n,), 0.5, device=dev)
+    kept = PackedChains.pack((torch.rand((n, M), device=dev) < 0.5).float())
+    chains = PackedChains.empty(n, C, dev)
+    t_metro = _time_calls(lambda i: amcpg.metro_sampling_packed(probs, kept, T, num_chains=C, out=chains), 12, warm=2)
+    res = {}
+
+    def ls(i):
+        res["r"] = amcpg.sampler_func_packed(data, chains, num_ls, M, R)
+    t_ls = _time_calls(ls, 12, warm=2)
+    vs_good, xs_good, value, _ = res["r"]
+    cut = ops.maxcut_obj(data.graph, (xs_good.unpack().t() > 0).contiguous())
+    if not (torch.equal(cut.float(), vs_good) and float(vs_good.mean()) > 0.6 * data.num_edges):
+        raise SystemExit("PARITY FAILURE (config #3): a kept chain's reported value is not its cut")
+    rnd = amcpg.MCPGRound(data, kept.clone(), torch.zeros(M, device=dev), M, R, num_ls)
+    best = []
+
+    def step(i):
+        best.append(rnd.step(probs)[1])
+    t_round = _time_calls(step, 12, warm=2)
+    bv = torch.cat(best).cpu()
+    if not bool((bv[1:] >= bv[:-1]).all()):
+        raise SystemExit("PARITY FAILURE (config #3): the incumbent of the MCPG round got worse")
+    out = {"workload": f"BA n={n} m=5 (E={data.num_edges}), {C} chains = {M} kept x {R} repeats, num_ls={num_ls}, T={T} walk rounds",
+           "sampler_func_packed_ms": t_ls * 1e3, "chain_sweeps_per_s": C * num_ls / t_ls, "node_updates_per_s": C * num_ls * n / t_ls,
+           "metro_sampling_packed_ms": t_metro * 1e3, "proposals_per_s": C * T / t_metro,
+           "mcpg_round_ms": t_round * 1e3, "num_samples_per_second": M / t_round, "bound": "valu",
+           "check": "every kept chain's value == its recomputed cut; 14 rounds chained, incumbent never worse: ok"}
+    # the reference-shaped surface: f32 [N, C] in and out (MCPG.py:88-166 as the training loop calls it)
+    try:
+        xs = torch.empty((n, C), device=dev)
+        for c0 in range(0, C, 1 << 15):
+            xs[:, c0:c0 + (1 << 15)] = (torch.rand((n, 1 << 15), device=dev) < 0.5).float()
+        out["metro_sampling_f32_ms"] = _time_calls(lambda i: amcpg.metro_sampling(probs, xs, T, dev), 5, warm=1) * 1e3
+        out["sampler_func_f32_ms"] = _time_calls(lambda i: amcpg.sampler_func(data, xs, num_ls, M, R, dev), 5, warm=1) * 1e3
+        del xs
+    except torch.cuda.OutOfMemoryError:
+        out["metro_sampling_f32_ms"] = out["sampler_func_f32_ms"] = None
+    for key, ksub in (("k7_valu_issue_frac", "valu_frac"), ("k7_wait_any_share", "wait_any_share_of_wave_cycles")):
+        vf = _profiled("k_mcpg_local_search_levels", "BA-1e4", ksub)
+        if vf:
+            out[key] = vf
+    return out
+
+
+def config4_tsp(dev):
+    """BASELINE config #4: TSP-100 random Euclidean, 2^16 tours: tour length (K12, envs/env_ISCO.py:346-350) and the swap /
+    2-opt delta of every position (K13, :232-296)."""
+    import torch
+    from rlsolver_amd import ops_mcpg_tsp as mops
+    from rlsolver_amd.graph import generate_tsp_coords, tsp_tables
+    N, B = 100, 1 << 16
+    dist, near, rnd = tsp_tables(generate_tsp_coords(N, 100), K=20)
+    d = torch.from_numpy(dist).to(dev)
+    perms = mops.rand_perms(B, N, 3, dev)
+    sel = torch.roll(perms, 7, 1).contiguous()
+    t12 = _time_calls(lambda i: mops.tsp_tour_length(d, perms), 300, warm=5)
+    t13 = _time_calls(lambda i: mops.tsp_swap_delta_all(d, perms, sel, 0.5), 300, warm=5)
+    length = mops.tsp_tour_length(d, perms)
+    rel = 0.0
+    for other in (torch.roll(perms, 17, 1).contiguous(), torch.flip(perms, [1]).contiguous()):
+        rel = max(rel, float(((mops.tsp_tour_length(d, other) - length).abs() / length).max()))
+    lr, idx, ban = mops.tsp_swap_delta_all(d, perms, sel, 0.5)
+    ar = torch.arange(B, device=dev)
+    pos = torch.argmin(ban.to(torch.uint8), dim=1)
+    okm = ~ban[ar, pos]
+    x = perms.clone()
+    mops.tsp_apply_swap(x, torch.where(okm, pos, torch.full_like(pos, -1)), idx)
+    err = ((mops.tsp_tour_length(d, x) - length) - (-lr[ar, pos] * 0.5)).abs()
+    rel13 = float((err[okm] / length[okm]).max())
+    if not (rel <= 1e-5 and rel13 <= 2e-5):
+        raise SystemExit(f"PARITY FAILURE (config #4): rotation / reversal {rel:.2e}, swap delta vs length difference {rel13:.2e}")
+    b12, b13 = B * (8 * N + 4), B * (8 * N + 8 * N + 13 * N)
+    return {"workload": f"TSP-{N} uniform Euclidean, {B} tours (int64 [B, N] permutations, f32 distances)",
+            "k12_tour_length_us": t12 * 1e6, "k12_tours_per_s": B / t12, "k12_hbm_frac": b12 / t12 / 1e9 / HBM_PEAK_GBS,
+            "k13_swap_delta_all_us": t13 * 1e6, "k13_candidate_moves_per_s": B * N / t13, "k13_hbm_frac": b13 / t13 / 1e9 / HBM_PEAK_GBS,
+            "bound": "hbm", "algorithmic_bytes_per_tour": {"k12": 8 * N + 4, "k13": 29 * N},
+            "check": f"lengths invariant under rotation / reversal to {rel:.1e} relative (tolerance 1e-5); swap delta == length "
+                     f"difference of the applied swap to {rel13:.1e}: ok"}
+
+
+def extra_configs(dev):
+    import torch
+    out = {}
+    for key, fn in (("config2_local_search", config2_local_search), ("config3_mcpg", config3_mcpg), ("config4_tsp", config4_tsp)):
+        t0 = time.perf_counter()
+        out[key] = fn(dev)
+        torch.cuda.synchronize()
+        out[key]["wall_s_incl_setup"] = round(time.perf_counter() - t0, 2)
+        torch.cuda.empty_cache()
+    return out
+
+
+# --------------------------------------------------------------------------- #
+# N > 1: the shards cover the global batch exactly once (envs, and the MCPG chain ids of the same batch)
+# --------------------------------------------------------------------------- #
+def shard_cover(G, rank, world, repeat_times=128):
+    """This rank's env interval (rlsolver_amd.dist.env_shard) and -- when the batch can be an MCPG batch of G = M_total x
+    `repeat_times` chains whose kept chains split in whole 64-chain tiles -- the global ids its chains get through
+    rls_chain_ids (offset, period, skip): id(c) = (c // period) * (period + skip) + offset + c % period, the kernels' rule
+    (include/rlsolver_hip.h).  Rank 0 checks that all ranks' sets tile [0, G) exactly once (check_cover)."""
+    import numpy as np
+    from rlsolver_amd import dist as rdist
+    off, cnt = rdist.env_shard(G, rank, world)
+    rec = {"rank": rank, "env_offset": off, "envs": cnt, "chain_ids": None}
+    if G % repeat_times == 0 and (G // repeat_times) % (64 * world) == 0:
+        m_total = G // repeat_times
+        koff, m = rdist.env_shard(m_total // 64, rank, world)
+        koff, m = koff * 64, m * 64                     # kept chains [koff, koff + m) of m_total, whole tiles
+        rec["chain_ids"] = (koff, m, m_total - m)       # what MCPGRound(kept_offset=koff, total_kept=m_total) passes to the kernels
+        c = np.arange(m * repeat_times, dtype=np.int64)
+        rec["_ids"] = (c // m) * m_total + koff + c % m
+    return rec
+
+
+def check_cover(recs, G):
+    import numpy as np
+    iv = sorted((r["env_offset"], r["env_offset"] + r["envs"]) for r in recs)
+    envs_ok = iv[0][0] == 0 and iv[-1][1] == G and all(iv[i][1] == iv[i + 1][0] for i in range(len(iv) - 1))
+    out = {"global": G, "ranks": len(recs), "envs": "each exactly once" if envs_ok else "BROKEN"}
+    if all(r.get("_ids") is not None for r in recs):
+        cnt = np.bincount(np.concatenate([r["_ids"] for r in recs]), minlength=G)
+        out["mcpg_chain_ids"] = "each exactly once" if (cnt.size == G and bool((cnt == 1).all())) else "BROKEN"
+        out["chain_ids_per_rank"] = [list(r["chain_ids"]) for r in sorted(recs, key=lambda r: r["rank"])]
+    if "BROKEN" in out.values():
+        raise SystemExit(f"shard cover broken: {out}")
+    return out
+
+
+# --------------------------------------------------------------------------- #
 # dry run: the N-rank wiring on CPU
 # --------------------------------------------------------------------------- #
 def dry_run(a):
@@ -204,10 +415,10 @@ def dry_run(a):
     import torch.distributed as dist
     from rlsolver_amd import dist as rdist
     rank, local_rank, world = rdist.init_from_env(backend="gloo")
-    B = a.envs_per_gpu
-    env_offset = rank * B
-    off, cnt = rdist.env_shard(world * B, rank, world)
-    assert (off, cnt) == (env_offset, B), (off, cnt, env_offset, B)
+    G = a.global_envs if a.global_envs > 0 else world * a.envs_per_gpu
+    env_offset, B = rdist.env_shard(G, rank, world)
+    if a.global_envs <= 0:
+        assert (env_offset, B) == (rank * a.envs_per_gpu, a.envs_per_gpu), (env_offset, B)
     # a stand-in objective vector whose global maximum sits in a known shard: env id e scores (e * 7919) % 1009
     ids = torch.arange(env_offset, env_offset + min(B, 4096), dtype=torch.int64)
     obj = (ids * 7919) % 1009
@@ -215,15 +426,20 @@ def dry_run(a):
     best, owner, bx = rdist.global_best(obj, xs, want_solution=True)
     mine = {"rank": rank, "local_rank": local_rank, "env_offset": env_offset, "envs": B,
             "local_best": int(obj.max())}
+    cov = shard_cover(G, rank, world)
     if world > 1:
-        allr = [None] * world
+        allr, covs = [None] * world, [None] * world
         dist.all_gather_object(allr, mine)
+        dist.all_gather_object(covs, cov)
         dist.barrier()
         dist.destroy_process_group()
     else:
-        allr = [mine]
+        allr, covs = [mine], [cov]
     if rank == 0:
-        print(json.dumps({"metric": METRIC, "dry_run": True, "n_gpus": world, "ranks": allr,
+        cover = sorted((r["env_offset"], r["env_offset"] + r["envs"]) for r in allr)     # the shards tile [0, G) exactly once
+        assert cover[0][0] == 0 and cover[-1][1] == G and all(cover[i][1] == cover[i + 1][0] for i in range(world - 1)), cover
+        print(json.dumps({"metric": METRIC, "dry_run": True, "n_gpus": world, "global_envs": G,
+                          "scaling": "strong" if a.global_envs > 0 else "weak", "ranks": allr, "shard_cover": check_cover(covs, G),
                           "global_best": int(best), "owner": int(owner), "best_x": [int(v) for v in bx.tolist()]}),
               flush=True)
 
@@ -231,9 +447,11 @@ def dry_run(a):
 # --------------------------------------------------------------------------- #
 # the timed workload
 # --------------------------------------------------------------------------- #
-def measure(a, gset, B, steps, warmup, repeats, dev, rank, local_rank, world, via_env=False, verify=True):
+def measure(a, gset, B, steps, warmup, repeats, dev, rank, local_rank, world, via_env=False, verify=True, env_offset=None):
     """W warm-up steps, then `repeats` regions of exactly `steps` K4 launches.  Returns a dict with the per-region
-    wall times (MAX over ranks) and HIP-event kernel times of this rank."""
+    wall times (MAX over ranks), the HIP-event kernel times of this rank and -- N > 1 -- every rank's own kernel / exchange /
+    region times (what an N > 1 line needs to attribute a shortfall: slow kernels on one rank, the exchange, or skew).
+    `env_offset`: global id of this rank's env 0 (default rank * B: weak scaling, equal shards)."""
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -245,7 +463,7 @@ def measure(a, gset, B, steps, warmup, repeats, dev, rank, local_rank, world, vi
     csr = build_csr(mygraph, num_nodes=n, if_bidirectional=False)
     g = ops.DeviceGraph(csr, dev)
     N, S = n, a.slots
-    env_offset = rank * B
+    env_offset = rank * B if env_offset is None else env_offset
 
     ring = torch.empty((S, B, N), dtype=torch.bool, device=dev)
     ops.rand_spins(B, N, seed=0, device=dev, env_offset=env_offset, out=ring[0])
@@ -312,7 +530,7 @@ def measure(a, gset, B, steps, warmup, repeats, dev, rank, local_rank, world, vi
     if use_pg:   # the first collective builds the communicator (16 ms on a 1-rank RCCL group): not part of any region
         rdist.global_best(obj)
         barrier()
-    wall, kern = [], []
+    wall, kern, exch = [], [], []
     for rep in range(repeats):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize(dev)
@@ -330,7 +548,7 @@ def measure(a, gset, B, steps, warmup, repeats, dev, rank, local_rank, world, vi
         e1.record()
         if use_pg:  # episode boundary: best objective over all shards (C1, 8 bytes over RCCL)
             rdist.global_best(obj)
-            e2 = torch.cuda.Event()
+            e2 = torch.cuda.Event(enable_timing=True)
             e2.record()
         else:
             e2 = e1
@@ -341,8 +559,15 @@ def measure(a, gset, B, steps, warmup, repeats, dev, rank, local_rank, world, vi
         barrier()
         torch.cuda.synchronize(dev)
         kern.append(e0.elapsed_time(e1) * 1e-3 / max(steps, 1))
+        exch.append(e1.elapsed_time(e2) * 1e-3 if use_pg else 0.0)      # device time from the last step's end to the exchange's end
 
+    per_rank = None
     if use_pg:
+        # every rank's own figures (outside every timed region), then the region time that counts: MAX over ranks
+        mine = {"rank": rank, "device": str(dev), "envs": int(B), "env_offset": int(env_offset), "region_s": list(wall),
+                "kernel_s_per_step": list(kern), "exchange_s": list(exch)}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
         tt = torch.tensor(wall, dtype=torch.float64, device=dev if nccl else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall = [float(v) for v in tt.tolist()]
@@ -352,18 +577,42 @@ def measure(a, gset, B, steps, warmup, repeats, dev, rank, local_rank, world, vi
         if not torch.equal(ops.maxcut_obj(g, final).to(torch.int32), obj):
             raise SystemExit("PARITY FAILURE: incremental objective != recomputed objective")
 
-    res = {"wall": wall, "kernel_s": kern, "N": N, "E": len(mygraph), "is_real": is_real, "B": B, "graph": use_graph,
-           "graph_arr": np.asarray(mygraph, dtype=np.int64)}
+    res = {"wall": wall, "kernel_s": kern, "exchange_s": exch, "per_rank": per_rank, "N": N, "E": len(mygraph), "is_real": is_real,
+           "B": B, "graph": use_graph, "graph_arr": np.asarray(mygraph, dtype=np.int64)}
     return res          # the ring and the launchers die with this frame: the next workload gets the memory back
 
 
-def summarize(res, steps, world):
+def rank_breakdown(res, steps):
+    """Per rank, for the MEDIAN region (the one `value` is computed from): kernel time per step (HIP events around the region's
+    launches on that rank), the exchange (device time from the last step's end to the end of the best-objective all-reduce) and
+    the rank's own wall time of the region; `skew_ms` = MAX - MIN of those wall times.  A shortfall at N > 1 then reads off:
+    kernel_us_per_step up on every rank = the kernels themselves (clocks / HBM sharing), one rank's region_ms high = a straggler,
+    exchange_us high = the collective."""
+    pr = res.get("per_rank")
+    if not pr:
+        return None
+    order = sorted(range(len(res["wall"])), key=lambda i: res["wall"][i])
+    mid = order[len(order) // 2]
+    ranks = [{"rank": r["rank"], "device": r["device"], "envs": r["envs"], "env_offset": r["env_offset"],
+              "kernel_us_per_step": r["kernel_s_per_step"][mid] * 1e6, "exchange_us": r["exchange_s"][mid] * 1e6,
+              "region_ms": r["region_s"][mid] * 1e3} for r in sorted(pr, key=lambda r: r["rank"])]
+    reg = [r["region_ms"] for r in ranks]
+    return {"region_index": mid, "ranks": ranks, "skew_ms": max(reg) - min(reg),
+            "kernel_us_per_step_max": max(r["kernel_us_per_step"] for r in ranks),
+            "kernel_us_per_step_min": min(r["kernel_us_per_step"] for r in ranks),
+            "exchange_us_max": max(r["exchange_us"] for r in ranks),
+            "skew_ms_all_regions": [(max(r["region_s"][i] for r in pr) - min(r["region_s"][i] for r in pr)) * 1e3
+                                    for i in range(len(res["wall"]))]}
+
+
+def summarize(res, steps, world, total_envs=None):
     B, N = res["B"], res["N"]
     el = statistics.median(res["wall"])
     ks = statistics.median(res["kernel_s"])
     bytes_per_launch = B * (2 * N + 20)
     achieved = bytes_per_launch / ks / 1e9
-    return {"value": world * B * steps / el, "ms_per_step": el / steps * 1e3,
+    total = world * B if total_envs is None else total_envs
+    return {"value": total * steps / el, "ms_per_step": el / steps * 1e3, "rank_breakdown": rank_breakdown(res, steps),
             "ms_per_step_all": [w / steps * 1e3 for w in res["wall"]],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_source": None,
@@ -396,19 +645,33 @@ def main():
     torch.cuda.set_device(dev)
     R = max(1, a.repeats)
 
-    res = measure(a, a.gset, a.envs_per_gpu, a.steps, a.warmup, R, dev, rank, local_rank, world,
-                  via_env=a.via_env, verify=not a.no_verify)
+    strong = a.global_envs > 0
+    G = a.global_envs if strong else world * a.envs_per_gpu
+    env_offset, B_rank = rdist.env_shard(G, rank, world)          # weak: rank * envs_per_gpu, envs_per_gpu
+    res = measure(a, a.gset, B_rank, a.steps, a.warmup, R, dev, rank, local_rank, world,
+                  via_env=a.via_env, verify=not a.no_verify, env_offset=env_offset)
     torch.cuda.empty_cache()
     res5 = None
-    if not a.no_config5 and not (a.gset == 70 and a.envs_per_gpu == 131072):
+    is_c5 = a.gset == 70 and (G == world * 131072)
+    if not a.no_config5 and not is_c5:
         # BASELINE config #5's per-GPU shard, measured the same way (never mixed into `value`)
         res5 = measure(a, 70, 131072, max(1, min(a.steps, 200)), min(a.warmup, 20), R, dev, rank, local_rank, world,
                        verify=not a.no_verify)
+        torch.cuda.empty_cache()
+    cfgs = None
+    if rank == 0 and world == 1 and not a.no_configs:
+        cfgs = extra_configs(dev)
+    cover = None
+    if world > 1:
+        covs = [None] * world
+        dist.all_gather_object(covs, shard_cover(G, rank, world))
+        if rank == 0:
+            cover = check_cover(covs, G)
 
     out = None
     if rank == 0:
         B, N = res["B"], res["N"]
-        s = summarize(res, a.steps, world)
+        s = summarize(res, a.steps, world, total_envs=G)
         out = {
             "metric": METRIC,
             "value": s["value"],
@@ -417,24 +680,30 @@ def main():
             "ms_per_step": s["ms_per_step"],
             "repeats": R, "ms_per_step_all": s["ms_per_step_all"],
             "timing": f"median of {R} regions of exactly {a.steps} steps, each bracketed by barrier + synchronize, MAX over ranks",
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             # the graph: the real Gset file when data/gset/gset_<k>.txt is present, else the G(n, m) stand-in of its size; spins
             # and actions are drawn either way
             "dtype": "u8", "data": "real Gset graph, synthetic spins and actions" if res["is_real"] else "synthetic",
             "config": {"workload": f"Gset G{a.gset}{'' if res['is_real'] else '-sized G(n,m) stand-in'} MaxCut "
                                    f"(N={N}, E={res['E']}), {B} envs per GPU, K4 gym step emitting the next "
                                    f"state into a {a.slots}-slot rollout ring, uniform random actions"
+                                   + ("" if a.via_env else "; the launcher passes cur = done = NULL (the rollout loop reads reward and keeps "
+                                      "obj: 12 of the 20 scalar bytes per env-step are written; --via-env writes all four vectors)")
+                                   + (f"; STRONG scaling: {G} envs in total split over {world} ranks" if strong else "")
                                    + ("; through EnvMaxcutGym.step(action, out=slot)" if a.via_env else "")
-                                   + ("; BASELINE config #5 shard (2^20 envs over 8 GPUs = 131072 per GPU)"
-                                      if (a.gset == 70 and B == 131072) else ""),
+                                   + ("; BASELINE config #5 (2^20 envs over 8 GPUs = 131072 per GPU)" if is_c5 else ""),
                        "entry": "EnvMaxcutGym.step" if a.via_env else ("rls_maxcut_step launcher, each timed region of "
                                                                         f"{a.steps} launches enqueued as one hipGraph" if res["graph"]
                                                                         else "rls_maxcut_step launcher"),
-                       "num_nodes": N, "num_edges": res["E"], "envs_per_gpu": B, "global_envs": world * B, "slots": a.slots,
+                       "num_nodes": N, "num_edges": res["E"], "envs_per_gpu": B, "global_envs": G, "slots": a.slots,
                        "parallelism": f"env-shard x{world}" + (" (TEST MODE --share-gpu: all ranks on one GPU over gloo; not a scaling "
                                                                 "measurement)" if a.share_gpu else "")},
             "roofline": s["roofline"],
         }
+        if s["rank_breakdown"] is not None:
+            out["rank_breakdown"] = s["rank_breakdown"]
+        if cover is not None:
+            out["shard_cover"] = cover
         tr = pmc_traffic_per_launch(B, N, a.slots)
         if tr is not None:
             out["roofline"]["traffic"], out["roofline"]["traffic_source"] = tr[0], f"profiles/{tr[1]} (rocprofv3 --pmc)"
@@ -449,6 +718,10 @@ def main():
                             f"E={res5['E']}), 131072 envs per GPU = 2^20 over 8 GPUs (BASELINE config #5), same K4 loop",
                 "value": s5["value"], "unit": "env-steps/s", "steps": st5, "ms_per_step": s5["ms_per_step"],
                 "global_envs": world * 131072, "roofline": s5["roofline"]}
+            if s5["rank_breakdown"] is not None:
+                out["config5_shard"]["rank_breakdown"] = s5["rank_breakdown"]
+        if cfgs is not None:
+            out["configs"] = cfgs
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(res["graph_arr"], N, a.cpu_seconds)
             out["cpu_baseline_ref_shaped"] = cpu_baseline_ref_shaped(res["graph_arr"], N, max(3.0, a.cpu_seconds / 2))

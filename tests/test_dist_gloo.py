@@ -242,6 +242,24 @@ def test_bench_self_spawn_dry_run(gpus):
     assert out["best_x"] == [int((e_star + k) % 3 == 0) for k in range(16)]
 
 
+def test_bench_eight_rank_dry_run_is_config5():
+    """BASELINE config #5 as the driver would launch it, wiring only: `--gset 70 --global-envs 1048576 --gpus 8` (strong scaling:
+    2^20 envs split over the ranks) -- eight rendezvous, shard offsets of 2^17, and the shards AND the MCPG chain ids of the same
+    batch (rls_chain_ids: 8192 kept chains x 128 repeats, 1024 kept per rank) cover 2^20 exactly once."""
+    p, out = _run_bench("--gpus", "8", "--dry-run", "--gset", "70", "--global-envs", str(1 << 20))
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert out["n_gpus"] == 8 and out["global_envs"] == 1 << 20 and out["scaling"] == "strong"
+    assert [(r["env_offset"], r["envs"]) for r in out["ranks"]] == [(k << 17, 1 << 17) for k in range(8)]
+    cov = out["shard_cover"]
+    assert cov["envs"] == cov["mcpg_chain_ids"] == "each exactly once" and cov["global"] == 1 << 20
+    assert cov["chain_ids_per_rank"] == [[1024 * k, 1024, 7168] for k in range(8)]
+    # a global batch that does not divide: the first (G % W) ranks take one env more, still an exact cover
+    p, out = _run_bench("--gpus", "4", "--dry-run", "--global-envs", "10003")
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert [r["envs"] for r in out["ranks"]] == [2501, 2501, 2501, 2500] and out["shard_cover"]["envs"] == "each exactly once"
+    assert "mcpg_chain_ids" not in out["shard_cover"]
+
+
 def test_bench_refuses_world_mismatch():
     p, _ = _run_bench("--gpus", "1", "--dry-run", env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0",
                                                        "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port())})

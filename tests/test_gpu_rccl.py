@@ -69,7 +69,7 @@ def test_bench_under_one_rank_rccl_group():
     """bench.py with an initialised RCCL group: barrier(device_ids), the all_reduce(MAX) of the region times and the
     in-region global_best all run; the JSON line is the last stdout line."""
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--repeats", "3",
-                        "--envs-per-gpu", "4096", "--no-cpu-baseline", "--no-config5"], env=_env(),
+                        "--envs-per-gpu", "4096", "--no-cpu-baseline", "--no-config5", "--no-configs"], env=_env(),
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     out = json.loads(p.stdout.strip().splitlines()[-1])
@@ -105,6 +105,34 @@ def test_bench_two_ranks_sharing_the_gpu(launch):
     assert "TEST MODE" in out["config"]["parallelism"] and out["value"] > 0
     # value = the units ALL ranks processed / the slowest rank's region
     assert abs(out["value"] - 16384 * 20 / (out["ms_per_step"] * 20 * 1e-3)) / out["value"] < 1e-6
+
+
+def test_bench_eight_ranks_sharing_the_gpu_strong_scaling_line_explains_itself():
+    """the 8-rank wiring once on the one GPU -- `--gpus 8 --share-gpu --global-envs 16384` (strong scaling: 2048
+    envs per rank): eight rendezvous, eight shard offsets, and a line that can attribute a shortfall: every rank's kernel time
+    per step (HIP events), its exchange time, its region time, MAX - MIN of the region times; the shards and the MCPG chain ids of
+    the same batch cover it exactly once."""
+    e = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "RLS_FORCE_PG"):
+        e.pop(k, None)
+    e["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--share-gpu", "--steps", "20", "--warmup", "5", "--repeats", "3",
+           "--global-envs", "16384", "--no-cpu-baseline", "--no-config5"]
+    p = subprocess.run(cmd, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1500, cwd=ROOT)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    out = json.loads([ln for ln in p.stdout.strip().splitlines() if ln.startswith("{") and '"metric"' in ln][-1])
+    assert out["n_gpus"] == 8 and out["scaling"] == "strong" and out["config"]["global_envs"] == 16384
+    assert abs(out["value"] - 16384 * 20 / (out["ms_per_step"] * 20 * 1e-3)) / out["value"] < 1e-6
+    rb = out["rank_breakdown"]
+    assert [r["rank"] for r in rb["ranks"]] == list(range(8))
+    assert [(r["env_offset"], r["envs"]) for r in rb["ranks"]] == [(2048 * k, 2048) for k in range(8)]
+    assert all(r["kernel_us_per_step"] > 0 and r["exchange_us"] > 0 and r["region_ms"] > 0 for r in rb["ranks"])
+    assert rb["skew_ms"] >= 0 and len(rb["skew_ms_all_regions"]) == 3
+    # the region that counts is the slowest rank's
+    assert abs(max(r["region_ms"] for r in rb["ranks"]) - out["ms_per_step"] * 20) < 1e-6 * out["ms_per_step"] * 20 + 1e-9
+    cov = out["shard_cover"]
+    assert cov["envs"] == "each exactly once" and cov["global"] == 16384
+    assert "configs" not in out and "cpu_baseline" not in out          # rank-0, N = 1 legs only
 
 
 def test_sharded_search_loop_example_is_rank_count_invariant():
