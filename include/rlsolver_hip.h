@@ -570,13 +570,18 @@ int rls_mcpg_local_search(const rls_graph* g, const void* xs_in, int spin_bytes,
  * an instruction-count estimate: none / 32 / 16 / 8 entries per lane, always <= 64) takes L = 2, 4 or 8 ADJACENT lanes,
  * lane j of them holding neighbours j, j + L, ... -- the kernel adds the lanes' counters before the compare, so a
  * level's longest row costs deg / L rounds and pads 63 lanes that much less.  A node of higher degree forms a group of
- * its own and is decided with lane = neighbour.  Group record in lv_data:
- *     64 words  node | K << 20 | log2 L << 28 | tie << 31   K = ceil(deg / 2), tie = deg even               (passes >= 1)
- *     64 words  pos  | K0 << 20 | tie0 << 31      K0 = ceil((deg + nfresh) / 2), tie0 = (deg + nfresh) even  (pass 0)
- *     rounds of 64 words  8 nb | fresh << 31      (8 nb = byte offset of the neighbour's word in the tile); padding: 8 N
- * (a normal group has longest-lane rounds, rounded up to a multiple of 8; idle lanes carry node = N; the table ends in
- * eight spare rows counted in *total, so that a group's first eight rounds can be read unguarded; a hub group uses lane 0 of the two header rows --
- * K / K0 in 11 bits, no L -- plus word 2 of the first = deg, and ceil(deg / 64) rounds listing its neighbours).
+ * its own and is decided with lane = neighbour.  Group record in lv_data (ABI v11: LANE-major, so that a lane fetches its
+ * header in one 8-byte load and a block of 8 rounds in two 16-byte loads):
+ *     64 x 2 words  per lane l, words 2 l and 2 l + 1:
+ *                   node | K << 20 | log2 L << 28 | tie << 31   K = ceil(deg / 2), tie = deg even               (passes >= 1)
+ *                   pos  | K0 << 20 | tie0 << 31      K0 = ceil((deg + nfresh) / 2), tie0 = (deg + nfresh) even  (pass 0)
+ *     per block of 8 rounds, 2 slabs of [64 lanes][4 rounds]: round r of lane l at 128 + 512 (r / 8) + 256 ((r / 4) % 2) + 4 l + r % 4:
+ *                   8 nb | fresh << 31      (8 nb = byte offset of the neighbour's word in the tile); padding: 8 N
+ * (rounds = the longest lane's, rounded up to a multiple of 8; idle lanes carry node = N; a hub group uses lane 0's two header
+ * words -- K / K0 in 11 bits, no L --, word 4 = deg, and lists neighbour r in round r / 64 of lane r % 64).  Behind the last
+ * record come eight spare rows (a group's header and first block are requested unguarded), and behind those THE SAME TABLE
+ * AGAIN with the fresh flags cleared, at offset (lv_ptr[groups] & 0x3fffffff) + 512: passes >= 1 read it and use an entry as
+ * the LDS address it is.  *total counts both copies.
  * The accept rule of MCPG.py:139-141, (s + u/4) < (deg + 1/4)/2 with s in half-integers, is  2s < deg, or
  * 2s == deg and u < 1/2 (in float32: see methods/MCPG.py tie_coins_from_uniforms):
  * new bit = [count < K] | ([count == K] & tie & coin), count = #ones among the neighbours

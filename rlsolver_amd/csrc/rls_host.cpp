@@ -397,9 +397,14 @@ int rls_mcpg_visit_levels(const int32_t* rowptr, const int32_t* col, int64_t N, 
         const int32_t i = order[p], nb = col[rowptr[i] + r];
         return (int32_t)(((uint32_t)nb * 8u) | (pos_of[(size_t)nb] > p ? 0x80000000u : 0u));   // LDS byte offset of the word
     };
+    // Record layout (round 5): LANE-major, so that a lane fetches its data in a few wide loads instead of one dword per row --
+    // dwords [2 l, 2 l + 1] = lane l's two header words (one 8-byte load), then per block of 8 rounds two slabs of [64 lanes][4
+    // rounds] (two 16-byte loads per lane and block; a wave-instruction reads 1 KB contiguous).  Round r of lane l:
+    auto slot = [](int64_t r, int64_t l) { return 128 + (r >> 3) * 512 + ((r >> 2) & 1) * 256 + l * 4 + (r & 3); };
     using Grp = rls::LaneGroup;
     auto deg_at = [&](int64_t k) { return degp(sp[(size_t)k]); };
     std::vector<Grp> groups;
+    std::vector<int32_t> rows;      // a group's rounds as [rounds][64] (what spread_banks permutes)
     int64_t k0 = 0;
     while (k0 < N) {
         const int32_t lev = level[(size_t)sp[(size_t)k0]];
@@ -419,9 +424,9 @@ int rls_mcpg_visit_levels(const int32_t* rowptr, const int32_t* col, int64_t N, 
         for (size_t gi = 0; gi < groups.size(); ++gi) {
             const Grp& g = groups[gi];
             const bool hub = g.k0 >= kn;
-            const int64_t rounds = g.rounds;
+            const int64_t rounds = (g.rounds + 7) / 8 * 8;      // whole blocks (a hub's own count of rounds is ceil(deg / 64): word 4)
             const int64_t len = (2 + rounds) * 64;
-            if (off + len >= (int64_t)0x3fffffff) return rls::fail(RLS_EUNSUPPORTED, "rls_mcpg_visit_levels: too large");
+            if (off + len >= (int64_t)0x3fffffff / 2) return rls::fail(RLS_EUNSUPPORTED, "rls_mcpg_visit_levels: too large");
             if (lv_ptr) {
                 if (ng + 1 >= ptr_capacity) return rls::fail(RLS_EINVAL, "rls_mcpg_visit_levels: ptr capacity too small");
                 lv_ptr[ng] = (int32_t)((uint32_t)off | (level_start ? 0x80000000u : 0u) | (hub ? 0x40000000u : 0u));
@@ -430,23 +435,26 @@ int rls_mcpg_visit_levels(const int32_t* rowptr, const int32_t* col, int64_t N, 
                 if (off + len > data_capacity) return rls::fail(RLS_EINVAL, "rls_mcpg_visit_levels: data capacity too small");
                 int32_t* rec = lv_data + off;
                 for (int64_t e = 0; e < len; ++e) rec[e] = (int32_t)(e < 128 ? N : N * 8);      // idle header lanes: node N; padding: the zero word
+                rows.assign((size_t)(rounds * 64), (int32_t)(N * 8));
                 if (hub) {
                     const int32_t p = sp[(size_t)g.k0], md = degp(p);
-                    header(p, 0, rec[0], rec[64]);
-                    rec[2] = md;
-                    for (int32_t r = 0; r < md; ++r) rec[128 + r] = entry(p, r);
+                    header(p, 0, rec[0], rec[1]);
+                    rec[4] = md;                                   // lane 2's first header word
+                    for (int32_t r = 0; r < md; ++r) rows[(size_t)r] = entry(p, r);      // neighbour r: round r / 64, lane r % 64
                 } else {
                     int32_t ln = 0;
                     for (int64_t k = g.k0; k < g.k1; ++k) {
                         const int32_t p = sp[(size_t)k], deg = degp(p), lc = rls::lanes_log2_for(deg, best_cap), L = 1 << lc;
                         for (int32_t j = 0; j < L; ++j) {          // lane j of the node's L takes neighbours j, j + L, ...
-                            header(p, lc, rec[ln + j], rec[64 + ln + j]);
-                            for (int32_t r = j; r < deg; r += L) rec[(int64_t)(2 + r / L) * 64 + ln + j] = entry(p, r);
+                            header(p, lc, rec[2 * (ln + j)], rec[2 * (ln + j) + 1]);
+                            for (int32_t r = j; r < deg; r += L) rows[(size_t)((r / L) * 64 + ln + j)] = entry(p, r);
                         }
                         ln += L;
                     }
-                    rls::spread_banks(rec + 128, rounds);
+                    rls::spread_banks(rows.data(), rounds);
                 }
+                for (int64_t r = 0; r < rounds; ++r)
+                    for (int64_t l = 0; l < 64; ++l) rec[slot(r, l)] = rows[(size_t)(r * 64 + l)];
             }
             off += len;
             ++ng;
@@ -458,13 +466,22 @@ int rls_mcpg_visit_levels(const int32_t* rowptr, const int32_t* col, int64_t N, 
         if (ng >= ptr_capacity) return rls::fail(RLS_EINVAL, "rls_mcpg_visit_levels: ptr capacity too small");
         lv_ptr[ng] = (int32_t)off;
     }
-    // eight spare rows behind the last record: the kernel prefetches a group's first eight rounds without looking
+    // eight spare rows behind the last record (the kernel requests a group's header and first block without looking), then the
+    // whole table AGAIN with the `fresh` flags cleared: passes >= 1 do not need them, and an entry that is nothing but the LDS
+    // address of its word goes into the read instruction as it was loaded (one VALU less per neighbour and 64 chains)
+    const int64_t half = off + 8 * 64;
     if (lv_data) {
-        if (off + 8 * 64 > data_capacity) return rls::fail(RLS_EINVAL, "rls_mcpg_visit_levels: data capacity too small");
+        if (2 * half > data_capacity) return rls::fail(RLS_EINVAL, "rls_mcpg_visit_levels: data capacity too small");
         for (int64_t e = 0; e < 8 * 64; ++e) lv_data[off + e] = (int32_t)(N * 8);
+        for (int64_t e = 0; e < half; ++e) lv_data[half + e] = lv_data[e];
+        for (int64_t q = 0; q < ng && lv_ptr; ++q) {
+            const int64_t a = (uint32_t)lv_ptr[q] & 0x3fffffffu, b = (uint32_t)lv_ptr[q + 1] & 0x3fffffffu;
+            for (int64_t e = a + 128; e < b; ++e) lv_data[half + e] &= 0x7fffffff;
+        }
+        if (!lv_ptr) return rls::fail(RLS_EINVAL, "rls_mcpg_visit_levels: lv_data without lv_ptr");
     }
     *num_groups = ng;
-    *total = off + 8 * 64;
+    *total = 2 * half;
     return RLS_OK;
 }
 

@@ -615,6 +615,35 @@ __device__ __forceinline__ void lv_add8(const uint64_t (&d)[8], uint64_t& ones, 
     }
 }
 
+// rls_tile.h: lv_merge_planes, on nine planes
+template <int X>
+__device__ __forceinline__ void lv_merge_planes9(uint64_t (&pl)[9], uint64_t take) {
+    uint64_t carry = 0;
+#pragma unroll
+    for (int p = 0; p < 9; ++p) csa(carry, pl[p], pl[p], lv_lane_xor<X>(pl[p]) & take, carry);
+}
+
+// The same eight words at weight TWO: they enter at the `twos` plane (pass 0 counts a not-yet-visited neighbour twice, C = cV + 2 cF:
+// one counter takes both kinds, each at its own weight -- a second set of planes for cF and the plane-by-plane sum at the end cost
+// 16 registers and NP more adders).  NCW = planes above `fours` (>= 1).
+template <int NCW>
+__device__ __forceinline__ void lv_add8_x2(const uint64_t (&d)[8], uint64_t& twos, uint64_t& fours, uint64_t (&c)[5]) {
+    uint64_t fA, fB, eA, eB, carry;
+    csa(fA, twos, twos, d[0], d[1]);
+    csa(fB, twos, twos, d[2], d[3]);
+    csa(eA, fours, fours, fA, fB);
+    csa(fA, twos, twos, d[4], d[5]);
+    csa(fB, twos, twos, d[6], d[7]);
+    csa(eB, fours, fours, fA, fB);
+    csa(carry, c[0], c[0], eA, eB);
+#pragma unroll
+    for (int p = 1; p < NCW; ++p) {
+        const uint64_t t = c[p] & carry;
+        c[p] ^= carry;
+        carry = t;
+    }
+}
+
 // One lane = node group: the vertical counters over its rounds, C = cV (+ 2 cF in pass 0) plane by plane, and the
 // bit-sliced compare with K.  NC = counter planes above `fours`, NP = planes of C that can be set; both follow the
 // number of rounds (wave-uniform), see the dispatch in the kernel.  Neighbour entries are LDS BYTE offsets of the
@@ -622,27 +651,31 @@ __device__ __forceinline__ void lv_add8(const uint64_t (&d)[8], uint64_t& ones, 
 // A node of long degree occupies L = 2, 4 or 8 ADJACENT lanes (lcode = log2 L; lane j of them holds neighbours j, j + L,
 // ...): the partial counters of those lanes are added across them before the compare, so a level's longest row
 // costs deg / L rounds instead of deg -- the group's rounds are what a level waits for.
+typedef const uint64_t __attribute__((address_space(3))) lds_cu64;
+// the tile word at LDS byte address `a` (the kernel's dynamic LDS starts at address 0: checked at its top) -- a table entry goes
+// into the read instruction as it was loaded, where `words + (entry & mask)` cost an AND and the add of the LDS base per neighbour
+__device__ __forceinline__ uint64_t lds_word_at(uint32_t a) { return *(lds_cu64*)(uintptr_t)a; }
+
 template <int NC, int NP>
-__device__ __forceinline__ void lv_node_group(const unsigned char* __restrict__ wbytes, const int32_t* __restrict__ data,
-                                              int64_t p0, int64_t p1, int rounds, const uint32_t (&e0)[8], bool pass0,
-                                              int lane, uint32_t pad, uint32_t S, uint32_t lcode, uint64_t coin, uint64_t& nw) {
+__device__ __forceinline__ void lv_node_group(const int32_t* __restrict__ blk, int rounds, const uint32_t (&e0)[8], bool pass0,
+                                              uint32_t S, uint32_t lcode, uint64_t coin, uint64_t& nw) {
     constexpr uint32_t M31 = 0x7fffffffu;
-    uint64_t vo = 0, vt = 0, vf = 0, vc[5] = {0, 0, 0, 0, 0};      // ones among visited (all, after pass 0)
-    uint64_t fo = 0, ft = 0, ff = 0, fc[5] = {0, 0, 0, 0, 0};      // ones among not-yet-visited (pass 0)
+    constexpr int NCW = NP - 3;                                   // pass 0: C = cV + 2 cF <= 3 rounds needs every plane of C
+    static_assert(NCW >= 1 && NCW <= 5 && NC <= NCW, "planes");
+    uint64_t vo = 0, vt = 0, vf = 0, vc[5] = {0, 0, 0, 0, 0};      // ones among the neighbours (pass 0: visited x 1 + not-yet-visited x 2)
     uint32_t e[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) e[q] = e0[q];
-    const int32_t* rec = data + p0 + (2 + 8) * kWave + lane;      // round 8 of this lane
-    for (int r0 = 0; r0 < rounds; r0 += 8, rec += 8 * kWave) {
-        uint32_t nxt[8];
-        if (NC > 0 && r0 + 8 < rounds) {                          // (rounds are a multiple of 8: the next eight exist whole)
-#pragma unroll
-            for (int q = 0; q < 8; ++q) nxt[q] = (uint32_t)rec[q * kWave];
+    for (int r0 = 0; r0 < rounds; r0 += 8, blk += 512) {
+        u32x4 na, nb;                                             // (read below only where they were loaded)
+        if (NC > 0 && r0 + 8 < rounds) {                          // (rounds are a multiple of 8: the next block exists whole)
+            na = *reinterpret_cast<const u32x4*>(blk);
+            nb = *reinterpret_cast<const u32x4*>(blk + 256);
         }
         uint64_t d[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) d[q] = *reinterpret_cast<const uint64_t*>(wbytes + (e[q] & M31));
         if (pass0) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) d[q] = lds_word_at(e[q] & M31);
             uint64_t dv[8], df[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
@@ -650,47 +683,30 @@ __device__ __forceinline__ void lv_node_group(const unsigned char* __restrict__ 
                 df[q] = d[q] & fm;
                 dv[q] = d[q] & ~fm;
             }
-            lv_add8<NC>(dv, vo, vt, vf, vc);
-            lv_add8<NC>(df, fo, ft, ff, fc);
+            lv_add8<NCW>(dv, vo, vt, vf, vc);
+            lv_add8_x2<NCW>(df, vt, vf, vc);
         } else {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) d[q] = lds_word_at(e[q]);   // (the flag-free copy of the table)
             lv_add8<NC>(d, vo, vt, vf, vc);
         }
         if (NC > 0) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) e[q] = nxt[q];
+            e[0] = na.x; e[1] = na.y; e[2] = na.z; e[3] = na.w;
+            e[4] = nb.x; e[5] = nb.y; e[6] = nb.z; e[7] = nb.w;
         }
     }
     const int gl = __builtin_amdgcn_readlane((int)lcode, 0);      // lanes are sorted by L: lane 0 has the group's largest
     if (gl > 0) {
-        uint64_t pv[8] = {vo, vt, vf, vc[0], vc[1], vc[2], vc[3], vc[4]};
-        uint64_t pf[8] = {fo, ft, ff, fc[0], fc[1], fc[2], fc[3], fc[4]};
-        const uint64_t t1 = 0ull - (uint64_t)(lcode >= 1u), t2 = 0ull - (uint64_t)(lcode >= 2u), t3 = 0ull - (uint64_t)(lcode >= 3u);
-        lv_merge_planes<1>(pv, t1);
-        if (pass0) lv_merge_planes<1>(pf, t1);
-        if (gl > 1) {
-            lv_merge_planes<2>(pv, t2);
-            if (pass0) lv_merge_planes<2>(pf, t2);
-        }
-        if (gl > 2) {
-            lv_merge_planes<4>(pv, t3);
-            if (pass0) lv_merge_planes<4>(pf, t3);
-        }
-        uint64_t pl[9] = {pv[0], pv[1], pv[2], pv[3], pv[4], pv[5], pv[6], pv[7], 0};
-        if (pass0) {
-            uint64_t carry = 0;
-#pragma unroll
-            for (int p = 1; p < 9; ++p) csa(carry, pl[p], pl[p], pf[p - 1], carry);
-        }
-        nw = lv_le_const_x2<9, 9>(pl, ~coin, S);
+        // (a lane holds <= 64 entries: its own count fits the 8 planes, C <= 128; the node's -- up to 8 lanes, degree <= 128,
+        // C <= 256 in pass 0 -- needs the ninth)
+        uint64_t pv[9] = {vo, vt, vf, vc[0], vc[1], vc[2], vc[3], vc[4], 0};
+        lv_merge_planes9<1>(pv, 0ull - (uint64_t)(lcode >= 1u));
+        if (gl > 1) lv_merge_planes9<2>(pv, 0ull - (uint64_t)(lcode >= 2u));
+        if (gl > 2) lv_merge_planes9<4>(pv, 0ull - (uint64_t)(lcode >= 3u));
+        nw = lv_le_const_x2<9, 9>(pv, ~coin, S);
         return;
     }
-    uint64_t pl[9] = {vo, vt, vf, vc[0], vc[1], vc[2], vc[3], vc[4], 0};
-    if (pass0) {   // C = cV + 2 cF, plane by plane
-        const uint64_t fp[8] = {fo, ft, ff, fc[0], fc[1], fc[2], fc[3], fc[4]};
-        uint64_t carry = 0;
-#pragma unroll
-        for (int p = 1; p < NP; ++p) csa(carry, pl[p], pl[p], fp[p - 1], carry);
-    }
+    const uint64_t pl[9] = {vo, vt, vf, vc[0], vc[1], vc[2], vc[3], vc[4], 0};
     nw = lv_le_const_x2<NP, 9>(pl, ~coin, S);
 }
 
@@ -721,7 +737,8 @@ __device__ __forceinline__ void lv_hub_counts(const uint64_t* words, const int32
 #pragma unroll
     for (int q = 0; q < 8; ++q)
         if (q < rounds) add(e0[q]);
-    for (int r = 8; r < rounds; ++r) add((uint32_t)data[p0 + (int64_t)(2 + r) * kWave + lane]);
+    for (int r = 8; r < rounds; ++r)      // (lane-major record: include/rlsolver_hip.h)
+        add((uint32_t)data[p0 + 128 + (int64_t)(r >> 3) * 512 + ((r >> 2) & 1) * 256 + lane * 4 + (r & 3)]);
     cV = 0;
     cF = 0;
 #pragma unroll
@@ -745,6 +762,14 @@ __device__ __forceinline__ void lv_hub_counts(const uint64_t* words, const int32
 // a CU at N = 10^4 (2 x ~81.3 KB).
 // (two 8-wave workgroups per CU at N = 10^4 are 4 waves per SIMD: the second launch bound keeps the kernel at <= 128 registers --
 // without it the compiler spent 129 on the same code once a 64-bit division appeared in the prologue, and one workgroup per CU ran)
+#ifdef RLS_K7_PROF   // dev build (RLS_EXTRA_CFLAGS=-DRLS_K7_PROF): cycles per wave at a level barrier / waiting for a header / in a group
+static __device__ unsigned long long g_k7_prof[2048 * 16 * 6];
+#define K7_NOW() __builtin_readcyclecounter()
+#endif
+
+// (Requesting the next group's header BEFORE this group's work instead of after it -- ten more live registers, no spills once pass 0
+// kept one counter -- is SLOWER, 4.19 -> 4.40 ms: the per-wave cycle stamps of -DRLS_K7_PROF show a wave waiting 16 cycles per group
+// for its header, i.e. the request already hides under the level barrier, where a wave spends half its cycles.)
 template <typename TI, typename TO, int P, int W>
 __global__ __launch_bounds__(W * kWave, 4) void k_mcpg_local_search_levels(
     const typename ChainStore<TI>::type* __restrict__ xs_in, typename ChainStore<TO>::type* __restrict__ xs_out, int64_t N,
@@ -763,7 +788,9 @@ __global__ __launch_bounds__(W * kWave, 4) void k_mcpg_local_search_levels(
     const int64_t c = c0 + lane;
     const bool valid = c < C;
     const int64_t CB = (C + kWave - 1) / kWave;               // 64-chain blocks = words per coins row
-    const uint32_t pad = (uint32_t)N * 8u;                    // byte offset of the zero word behind the tile
+    // table entries are used as LDS addresses: the tile must sit at LDS address 0 (it does: this kernel has no static LDS)
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem != 0u) __builtin_trap();
+    const int64_t clean_off = (int64_t)((uint32_t)lv_ptr[G] & M30) + 512;      // the flag-free copy of the table (rls_mcpg_visit_levels)
     if (threadIdx.x == 0) words[N] = 0;                       // padding / idle lanes point here
     if (threadIdx.x < kWave) cut_slots[threadIdx.x] = 0;
     for (int64_t i = threadIdx.x; i <= G + 1; i += W * kWave) lvl[i] = i <= G ? lv_ptr[i] : lv_ptr[G];
@@ -783,19 +810,28 @@ __global__ __launch_bounds__(W * kWave, 4) void k_mcpg_local_search_levels(
         const uint32_t k = blk_key ^ (pos * 0x9E3779B1u) ^ ((uint32_t)cnt * 0x7FEB352Du + 0x165667B1u);
         return ((uint64_t)k7_fmix32(k ^ 0x4C4F4353u) << 32) | k7_fmix32(k + 0x27D4EB2Fu);
     };
+#ifdef RLS_K7_PROF
+    unsigned long long pf_bar = 0, pf_hdr = 0, pf_comp = 0, pf_n = 0, pf_hub = 0;
+    const unsigned long long pf_t0 = K7_NOW();
+#endif
     for (int64_t cnt = 0; cnt < num_ls; ++cnt) {
         const bool pass0 = cnt == 0;
         int64_t mine = w;
         uint32_t h0 = (uint32_t)N, h1 = (uint32_t)N, e0[8];
         auto prefetch = [&](int64_t k) {
             if (k < G) {
-                // the two header rows and the first eight rounds, unguarded: a lane = node group's rounds are a multiple
-                // of 8 and the table ends in eight spare rows (a hub group reads at most its own rounds of these)
-                const int32_t* rec = data + (lvp(k) & M30) + lane;
-                h0 = (uint32_t)rec[0];
-                h1 = (uint32_t)rec[kWave];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) e0[q] = (uint32_t)rec[(2 + q) * kWave];
+                // this lane's two header words and its first block of eight rounds: three wide loads, unguarded (a record is whole
+                // blocks and the table ends in eight spare rows).  Passes >= 1 read the entries of a lane = node group from the
+                // flag-free copy of the table
+                const uint32_t lp = lvp(k);
+                const int32_t* rec = data + (lp & M30);
+                const int32_t* ent = (pass0 || ((lp >> 30) & 1u)) ? rec : rec + clean_off;
+                const uint2 hh = *reinterpret_cast<const uint2*>(rec + 2 * lane);
+                const u32x4 a = *reinterpret_cast<const u32x4*>(ent + 128 + 4 * lane), b = *reinterpret_cast<const u32x4*>(ent + 384 + 4 * lane);
+                h0 = hh.x;
+                h1 = hh.y;
+                e0[0] = a.x; e0[1] = a.y; e0[2] = a.z; e0[3] = a.w;
+                e0[4] = b.x; e0[5] = b.y; e0[6] = b.z; e0[7] = b.w;
             }
         };
         prefetch(mine);
@@ -817,9 +853,21 @@ __global__ __launch_bounds__(W * kWave, 4) void k_mcpg_local_search_levels(
             }
             const uint32_t flags = (uint32_t)__builtin_amdgcn_readlane(chunk, (int)(k & 63));
             const int need = lev_base + __builtin_popcountll(lmask & ((2ull << (k & 63)) - 1ull));
+#ifdef RLS_K7_PROF
+            const unsigned long long pf_a = K7_NOW();
+#endif
             for (; passed < need; ++passed) __syncthreads();  // new level (k = 0: new pass): earlier updates are visible
+#ifdef RLS_K7_PROF
+            const unsigned long long pf_b = K7_NOW();
+            pf_bar += pf_b - pf_a;
+#endif
             const int64_t p0 = flags & M30, p1 = (uint32_t)__builtin_amdgcn_readlane(chunk_next, (int)(k & 63)) & M30;
             const int rounds = (int)((p1 - p0) >> 6) - 2;
+#ifdef RLS_K7_PROF
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned long long pf_c = K7_NOW();
+            pf_hdr += pf_c - pf_b;
+#endif
             if (!((flags >> 30) & 1u)) {
                 // ---- 64 lanes of nodes (a long row takes 2, 4 or 8 adjacent lanes), K in 8 bits, log2 lanes-per-node above it
                 const uint32_t node = h0 & 0xFFFFFu, pos = h1 & 0xFFFFFu;
@@ -833,10 +881,10 @@ __global__ __launch_bounds__(W * kWave, 4) void k_mcpg_local_search_levels(
                 uint64_t nw;
                 const uint64_t coin = coin_word(cnt, pos);
                 // counts <= rounds, C = cV + 2 cF <= 2 rounds (the not-yet-visited neighbours count twice in pass 0)
-                if (rounds < 8) lv_node_group<0, 5>(smem, data, p0, p1, rounds, e0, pass0, lane, pad, S, lcode, coin, nw);
-                else if (rounds < 16) lv_node_group<1, 6>(smem, data, p0, p1, rounds, e0, pass0, lane, pad, S, lcode, coin, nw);
-                else if (rounds < 32) lv_node_group<2, 7>(smem, data, p0, p1, rounds, e0, pass0, lane, pad, S, lcode, coin, nw);
-                else lv_node_group<4, 8>(smem, data, p0, p1, rounds, e0, pass0, lane, pad, S, lcode, coin, nw);
+                const int32_t* blk = (pass0 ? data : data + clean_off) + p0 + 128 + 512 + 4 * lane;    // this lane's slab of block 1
+                if (rounds < 16) lv_node_group<1, 6>(blk, rounds, e0, pass0, S, lcode, coin, nw);
+                else if (rounds < 32) lv_node_group<2, 7>(blk, rounds, e0, pass0, S, lcode, coin, nw);
+                else lv_node_group<4, 8>(blk, rounds, e0, pass0, S, lcode, coin, nw);
                 if (node < (uint32_t)N && (lane & ((1 << lcode) - 1)) == 0) words[node] = nw;
             } else {
                 // ---- one node of high degree, lane = neighbour
@@ -846,6 +894,7 @@ __global__ __launch_bounds__(W * kWave, 4) void k_mcpg_local_search_levels(
                 const uint32_t K = pass0 ? ((g1 >> 20) & 0x7FFu) : ((g0 >> 20) & 0x7FFu);
                 const bool tie = (pass0 ? g1 : g0) >> 31;
                 int cV, cF;                                                   // lane = chain after the call
+                const int rounds = ((int)__builtin_amdgcn_readlane((int)h0, 2) + 63) >> 6;     // the hub's own rounds: ceil(deg / 64)
                 if (rounds <= 1) lv_hub_counts<1>(words, data, p0, rounds, e0, pass0, lane, xc, cV, cF);
                 else if (rounds <= 3) lv_hub_counts<2>(words, data, p0, rounds, e0, pass0, lane, xc, cV, cF);
                 else if (rounds <= 7) lv_hub_counts<3>(words, data, p0, rounds, e0, pass0, lane, xc, cV, cF);
@@ -856,10 +905,29 @@ __global__ __launch_bounds__(W * kWave, 4) void k_mcpg_local_search_levels(
                 const uint64_t nw = ballot64(bit);
                 if (lane == 0) words[node] = nw;
             }
+#ifdef RLS_K7_PROF
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const unsigned long long pf_d = K7_NOW();
+            pf_comp += pf_d - pf_c;
+            if ((flags >> 30) & 1u) pf_hub += pf_d - pf_c;
+            ++pf_n;
+#endif
             prefetch(k + W);
         }
+#ifdef RLS_K7_PROF
+        const unsigned long long pf_e = K7_NOW();
+#endif
         for (; passed < num_levels; ++passed) __syncthreads();   // every wave crosses every boundary of the pass
+#ifdef RLS_K7_PROF
+        pf_bar += K7_NOW() - pf_e;
+#endif
     }
+#ifdef RLS_K7_PROF
+    if (lane == 0 && blockIdx.x < 2048 && blockIdx.y == 0) {
+        unsigned long long* q = g_k7_prof + ((size_t)blockIdx.x * 16 + w) * 6;
+        q[0] = K7_NOW() - pf_t0; q[1] = pf_bar; q[2] = pf_hdr; q[3] = pf_comp; q[4] = pf_n; q[5] = pf_hub;
+    }
+#endif
     __syncthreads();
     // K8: expected[c] = sum_e (2x_u - 1)(2x_v - 1) = E - 2 * cut; the W partial counts meet in 64 LDS slots
     const int part = (int)tile_cut_count<P>(words, eu, ev, E, lane, w, W);
@@ -1363,6 +1431,12 @@ int rls_mcpg_metro_stop(const int64_t* accepts, int64_t accept_rows, int64_t T, 
 static size_t lv_lds_bytes(int64_t N, int64_t num_groups) {
     return (size_t)(N + 2) * 8 + (size_t)kWave * 4 + (((size_t)(num_groups + 2) * 4 + 15) & ~(size_t)15);
 }
+
+#ifdef RLS_K7_PROF
+int rls_dev_k7_prof(unsigned long long* out) {   // dev builds only: [2048 workgroups][16 waves][total, barrier, header, group, groups, hub] cycles
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_k7_prof), sizeof(unsigned long long) * 2048 * 16 * 6);
+}
+#endif
 
 int rls_mcpg_local_search_levels_supported(const rls_graph* g, int64_t num_groups) {
     if (!g || g->num_nodes <= 0 || num_groups <= 0) return 0;
