@@ -579,8 +579,8 @@ int rls_mcpg_local_search(const rls_graph* g, const void* xs_in, int spin_bytes,
  *                   8 nb | fresh << 31      (8 nb = byte offset of the neighbour's word in the tile); padding: 8 N
  * (rounds = the longest lane's, rounded up to a multiple of 8; idle lanes carry node = N; a hub group uses lane 0's two header
  * words -- K / K0 in 11 bits, no L --, word 4 = deg, and lists neighbour r in round r / 64 of lane r % 64).  Behind the last
- * record come eight spare rows (a group's header and first block are requested unguarded), and behind those THE SAME TABLE
- * AGAIN with the fresh flags cleared, at offset (lv_ptr[groups] & 0x3fffffff) + 512: passes >= 1 read it and use an entry as
+ * record come sixteen spare rows (a group's header and first two blocks are requested unguarded), and behind those THE SAME TABLE
+ * AGAIN with the fresh flags cleared, at offset (lv_ptr[groups] & 0x3fffffff) + 1024: passes >= 1 read it and use an entry as
  * the LDS address it is.  *total counts both copies.
  * The accept rule of MCPG.py:139-141, (s + u/4) < (deg + 1/4)/2 with s in half-integers, is  2s < deg, or
  * 2s == deg and u < 1/2 (in float32: see methods/MCPG.py tie_coins_from_uniforms):

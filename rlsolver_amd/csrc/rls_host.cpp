@@ -466,13 +466,13 @@ int rls_mcpg_visit_levels(const int32_t* rowptr, const int32_t* col, int64_t N, 
         if (ng >= ptr_capacity) return rls::fail(RLS_EINVAL, "rls_mcpg_visit_levels: ptr capacity too small");
         lv_ptr[ng] = (int32_t)off;
     }
-    // eight spare rows behind the last record (the kernel requests a group's header and first block without looking), then the
+    // sixteen spare rows behind the last record (the kernel requests a group's header and first two blocks without looking), then the
     // whole table AGAIN with the `fresh` flags cleared: passes >= 1 do not need them, and an entry that is nothing but the LDS
     // address of its word goes into the read instruction as it was loaded (one VALU less per neighbour and 64 chains)
-    const int64_t half = off + 8 * 64;
+    const int64_t half = off + 16 * 64;
     if (lv_data) {
         if (2 * half > data_capacity) return rls::fail(RLS_EINVAL, "rls_mcpg_visit_levels: data capacity too small");
-        for (int64_t e = 0; e < 8 * 64; ++e) lv_data[off + e] = (int32_t)(N * 8);
+        for (int64_t e = 0; e < 16 * 64; ++e) lv_data[off + e] = (int32_t)(N * 8);
         for (int64_t e = 0; e < half; ++e) lv_data[half + e] = lv_data[e];
         for (int64_t q = 0; q < ng && lv_ptr; ++q) {
             const int64_t a = (uint32_t)lv_ptr[q] & 0x3fffffffu, b = (uint32_t)lv_ptr[q + 1] & 0x3fffffffu;

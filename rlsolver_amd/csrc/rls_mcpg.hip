@@ -656,43 +656,60 @@ typedef const uint64_t __attribute__((address_space(3))) lds_cu64;
 // into the read instruction as it was loaded, where `words + (entry & mask)` cost an AND and the add of the LDS base per neighbour
 __device__ __forceinline__ uint64_t lds_word_at(uint32_t a) { return *(lds_cu64*)(uintptr_t)a; }
 
-template <int NC, int NP>
-__device__ __forceinline__ void lv_node_group(const int32_t* __restrict__ blk, int rounds, const uint32_t (&e0)[8], bool pass0,
-                                              uint32_t S, uint32_t lcode, uint64_t coin, uint64_t& nw) {
+// eight neighbour words of a lane into its counter (pass 0: a not-yet-visited neighbour counts twice)
+template <int NC, int NCW>
+__device__ __forceinline__ void lv_count_block(const uint32_t (&e)[8], bool pass0, uint64_t& vo, uint64_t& vt, uint64_t& vf, uint64_t (&vc)[5]) {
     constexpr uint32_t M31 = 0x7fffffffu;
+    uint64_t d[8];
+    if (pass0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) d[q] = lds_word_at(e[q] & M31);
+        uint64_t dv[8], df[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const uint64_t fm = 0ull - (uint64_t)(e[q] >> 31);
+            df[q] = d[q] & fm;
+            dv[q] = d[q] & ~fm;
+        }
+        lv_add8<NCW>(dv, vo, vt, vf, vc);
+        lv_add8_x2<NCW>(df, vt, vf, vc);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) d[q] = lds_word_at(e[q]);   // (the flag-free copy of the table)
+        lv_add8<NC>(d, vo, vt, vf, vc);
+    }
+}
+
+// NB = the group's blocks of 8 rounds when that is 1 or 2 -- what most groups have, straight-line code on the registers the
+// header came with --, 0: any number, a loop that requests block b + 2 while block b is counted
+template <int NB, int NC, int NP>
+__device__ __forceinline__ void lv_node_group(const int32_t* __restrict__ blk, int rounds, const uint32_t (&e0)[8], const uint32_t (&e1)[8],
+                                              bool pass0, uint32_t S, uint32_t lcode, uint64_t coin, uint64_t& nw) {
     constexpr int NCW = NP - 3;                                   // pass 0: C = cV + 2 cF <= 3 rounds needs every plane of C
     static_assert(NCW >= 1 && NCW <= 5 && NC <= NCW, "planes");
     uint64_t vo = 0, vt = 0, vf = 0, vc[5] = {0, 0, 0, 0, 0};      // ones among the neighbours (pass 0: visited x 1 + not-yet-visited x 2)
-    uint32_t e[8];
+    // blocks 0 and 1 came with the header (requested before the level boundary): a group of 8 or 16 rounds, which is what a level
+    // usually waits for, issues no load of its own
+    if constexpr (NB == 1) {
+        lv_count_block<NC, NCW>(e0, pass0, vo, vt, vf, vc);
+    } else if constexpr (NB == 2) {
+        lv_count_block<NC, NCW>(e0, pass0, vo, vt, vf, vc);
+        lv_count_block<NC, NCW>(e1, pass0, vo, vt, vf, vc);
+    } else {
+        uint32_t e[8], nx[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) e[q] = e0[q];
-    for (int r0 = 0; r0 < rounds; r0 += 8, blk += 512) {
-        u32x4 na, nb;                                             // (read below only where they were loaded)
-        if (NC > 0 && r0 + 8 < rounds) {                          // (rounds are a multiple of 8: the next block exists whole)
-            na = *reinterpret_cast<const u32x4*>(blk);
-            nb = *reinterpret_cast<const u32x4*>(blk + 256);
-        }
-        uint64_t d[8];
-        if (pass0) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) d[q] = lds_word_at(e[q] & M31);
-            uint64_t dv[8], df[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const uint64_t fm = 0ull - (uint64_t)(e[q] >> 31);
-                df[q] = d[q] & fm;
-                dv[q] = d[q] & ~fm;
+        for (int q = 0; q < 8; ++q) { e[q] = e0[q]; nx[q] = e1[q]; }
+        for (int r0 = 0; r0 < rounds; r0 += 8, blk += 512) {      // blk: this lane's slab of block r0 / 8 + 2
+            u32x4 na, nb;                                         // (read below only where they were loaded)
+            if (r0 + 16 < rounds) {                               // (rounds are a multiple of 8: a block exists whole)
+                na = *reinterpret_cast<const u32x4*>(blk);
+                nb = *reinterpret_cast<const u32x4*>(blk + 256);
             }
-            lv_add8<NCW>(dv, vo, vt, vf, vc);
-            lv_add8_x2<NCW>(df, vt, vf, vc);
-        } else {
+            lv_count_block<NC, NCW>(e, pass0, vo, vt, vf, vc);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) d[q] = lds_word_at(e[q]);   // (the flag-free copy of the table)
-            lv_add8<NC>(d, vo, vt, vf, vc);
-        }
-        if (NC > 0) {
-            e[0] = na.x; e[1] = na.y; e[2] = na.z; e[3] = na.w;
-            e[4] = nb.x; e[5] = nb.y; e[6] = nb.z; e[7] = nb.w;
+            for (int q = 0; q < 8; ++q) e[q] = nx[q];
+            nx[0] = na.x; nx[1] = na.y; nx[2] = na.z; nx[3] = na.w;
+            nx[4] = nb.x; nx[5] = nb.y; nx[6] = nb.z; nx[7] = nb.w;
         }
     }
     const int gl = __builtin_amdgcn_readlane((int)lcode, 0);      // lanes are sorted by L: lane 0 has the group's largest
@@ -790,7 +807,7 @@ __global__ __launch_bounds__(W * kWave, 4) void k_mcpg_local_search_levels(
     const int64_t CB = (C + kWave - 1) / kWave;               // 64-chain blocks = words per coins row
     // table entries are used as LDS addresses: the tile must sit at LDS address 0 (it does: this kernel has no static LDS)
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem != 0u) __builtin_trap();
-    const int64_t clean_off = (int64_t)((uint32_t)lv_ptr[G] & M30) + 512;      // the flag-free copy of the table (rls_mcpg_visit_levels)
+    const int64_t clean_off = (int64_t)((uint32_t)lv_ptr[G] & M30) + 1024;      // the flag-free copy of the table (rls_mcpg_visit_levels)
     if (threadIdx.x == 0) words[N] = 0;                       // padding / idle lanes point here
     if (threadIdx.x < kWave) cut_slots[threadIdx.x] = 0;
     for (int64_t i = threadIdx.x; i <= G + 1; i += W * kWave) lvl[i] = i <= G ? lv_ptr[i] : lv_ptr[G];
@@ -817,21 +834,24 @@ __global__ __launch_bounds__(W * kWave, 4) void k_mcpg_local_search_levels(
     for (int64_t cnt = 0; cnt < num_ls; ++cnt) {
         const bool pass0 = cnt == 0;
         int64_t mine = w;
-        uint32_t h0 = (uint32_t)N, h1 = (uint32_t)N, e0[8];
+        uint32_t h0 = (uint32_t)N, h1 = (uint32_t)N, e0[8], e1[8];
         auto prefetch = [&](int64_t k) {
             if (k < G) {
-                // this lane's two header words and its first block of eight rounds: three wide loads, unguarded (a record is whole
-                // blocks and the table ends in eight spare rows).  Passes >= 1 read the entries of a lane = node group from the
+                // this lane's two header words and its first TWO blocks of eight rounds: five wide loads, unguarded (a record is whole
+                // blocks and the table ends in sixteen spare rows).  Passes >= 1 read the entries of a lane = node group from the
                 // flag-free copy of the table
                 const uint32_t lp = lvp(k);
                 const int32_t* rec = data + (lp & M30);
                 const int32_t* ent = (pass0 || ((lp >> 30) & 1u)) ? rec : rec + clean_off;
                 const uint2 hh = *reinterpret_cast<const uint2*>(rec + 2 * lane);
                 const u32x4 a = *reinterpret_cast<const u32x4*>(ent + 128 + 4 * lane), b = *reinterpret_cast<const u32x4*>(ent + 384 + 4 * lane);
+                const u32x4 c = *reinterpret_cast<const u32x4*>(ent + 640 + 4 * lane), d = *reinterpret_cast<const u32x4*>(ent + 896 + 4 * lane);
                 h0 = hh.x;
                 h1 = hh.y;
                 e0[0] = a.x; e0[1] = a.y; e0[2] = a.z; e0[3] = a.w;
                 e0[4] = b.x; e0[5] = b.y; e0[6] = b.z; e0[7] = b.w;
+                e1[0] = c.x; e1[1] = c.y; e1[2] = c.z; e1[3] = c.w;
+                e1[4] = d.x; e1[5] = d.y; e1[6] = d.z; e1[7] = d.w;
             }
         };
         prefetch(mine);
@@ -881,10 +901,12 @@ __global__ __launch_bounds__(W * kWave, 4) void k_mcpg_local_search_levels(
                 uint64_t nw;
                 const uint64_t coin = coin_word(cnt, pos);
                 // counts <= rounds, C = cV + 2 cF <= 2 rounds (the not-yet-visited neighbours count twice in pass 0)
-                const int32_t* blk = (pass0 ? data : data + clean_off) + p0 + 128 + 512 + 4 * lane;    // this lane's slab of block 1
-                if (rounds < 16) lv_node_group<1, 6>(blk, rounds, e0, pass0, S, lcode, coin, nw);
-                else if (rounds < 32) lv_node_group<2, 7>(blk, rounds, e0, pass0, S, lcode, coin, nw);
-                else lv_node_group<4, 8>(blk, rounds, e0, pass0, S, lcode, coin, nw);
+                const int32_t* blk = (pass0 ? data : data + clean_off) + p0 + 128 + 1024 + 4 * lane;    // this lane's slab of block 2
+                if (rounds == 8) lv_node_group<1, 1, 6>(blk, rounds, e0, e1, pass0, S, lcode, coin, nw);
+                else if (rounds == 16) lv_node_group<2, 2, 7>(blk, rounds, e0, e1, pass0, S, lcode, coin, nw);
+                else if (rounds < 8) lv_node_group<0, 1, 6>(blk, rounds, e0, e1, pass0, S, lcode, coin, nw);   // (isolated nodes: no round at all)
+                else if (rounds < 32) lv_node_group<0, 2, 7>(blk, rounds, e0, e1, pass0, S, lcode, coin, nw);
+                else lv_node_group<0, 4, 8>(blk, rounds, e0, e1, pass0, S, lcode, coin, nw);
                 if (node < (uint32_t)N && (lane & ((1 << lcode) - 1)) == 0) words[node] = nw;
             } else {
                 // ---- one node of high degree, lane = neighbour
@@ -1243,6 +1265,97 @@ __global__ __launch_bounds__(4 * kWave) void k_mcpg_pack(const T* __restrict__ x
         if (lane < 16 && n0 + lane < N) packed[(t0 + i) * N + n0 + lane] = mine;
 #pragma unroll
         for (int k = 0; k < 16; ++k) cur[k] = nxt[k];
+    }
+}
+
+// ---- round 5: the f32 shims as line-wide streams ----------------------------------------------------------------------------
+// What a caller of the reference-shaped surface (f32 [N, C], MCPG.py:88-166) pays beside the bit-packed kernels is 4 N bytes per
+// chain each way, so the shims must run at what a plain stream reaches.  Both take one 16-byte vector per lane: a wave-instruction
+// moves 1 KB of ONE row = 256 chains = four 64-chain tiles (the kernels above moved 256 B per instruction on the f32 side).
+//
+// pack: lane l holds chains 4 l .. 4 l + 3 of the span as a nibble; the 16 lanes of a DPP row are one tile: the nibble shifted to
+// its place in the 64-bit word (lanes 0..7 fill the low dword, 8..15 the high one) and OR-ed over the row in four DPP steps (the two
+// quad permutes, rotate by 4, rotate by 8) -- afterwards every lane of the row holds the tile's word.  A wave takes 16 rows; lane
+// 16 t + k keeps row k's word of tile t, so the result leaves as 16 consecutive words (128 B) per tile.  ~25 VALU per KB read.
+__device__ __forceinline__ uint32_t row_or16(uint32_t v) {
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);    // quad_perm [1,0,3,2]
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);    // quad_perm [2,3,0,1]
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xF, 0xF, false);   // row_ror:4
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, false);   // row_ror:8
+    return v;
+}
+constexpr int kPackSpans = 4;     // 256-chain spans a wave walks (16 rows x 4 KB: 64 KB read per wave)
+__global__ __launch_bounds__(4 * kWave) void k_mcpg_pack_f32x4(const float* __restrict__ xs, int64_t N, int64_t C, uint64_t* __restrict__ packed) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = threadIdx.x / kWave;
+    const int64_t tiles = (C + kWave - 1) / kWave;
+    const int64_t n0 = ((int64_t)blockIdx.y * 4 + w) * 16;
+    if (n0 >= N) return;
+    const int sh = 4 * (lane & 7);
+    const bool hi_half = (lane & 8) != 0;
+    auto fetch = [&](int64_t span, int r0, f32x4 (&v)[8]) {          // rows n0 + r0 .. + 7 of the span
+        const int64_t c = span * 256 + 4 * lane;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            v[k] = (c < C && n0 + r0 + k < N) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xs + (n0 + r0 + k) * C + c))
+                                              : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    const int64_t s0 = (int64_t)blockIdx.x * kPackSpans;
+    f32x4 cur[8], nxt[8];
+    fetch(s0, 0, cur);
+    uint32_t keep_lo = 0, keep_hi = 0;
+#pragma unroll 1
+    for (int i = 0; i < 2 * kPackSpans; ++i) {                          // half-batches: (span, rows 0..7), (span, rows 8..15), ...
+        const int64_t span = s0 + (i >> 1);
+        if (span * 256 >= C) break;
+        const int r0 = (i & 1) * 8;
+        if (i + 1 < 2 * kPackSpans) fetch(s0 + ((i + 1) >> 1), ((i + 1) & 1) * 8, nxt);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t nib = (cur[k][0] > 0.0f ? 1u : 0u) | (cur[k][1] > 0.0f ? 2u : 0u) | (cur[k][2] > 0.0f ? 4u : 0u) |
+                                 (cur[k][3] > 0.0f ? 8u : 0u);
+            const uint32_t pl = nib << sh;
+            const uint32_t lo = row_or16(hi_half ? 0u : pl), hi = row_or16(hi_half ? pl : 0u);
+            if ((lane & 15) == r0 + k) { keep_lo = lo; keep_hi = hi; }
+        }
+        if (i & 1) {
+            const int64_t tile = span * 4 + (lane >> 4), n = n0 + (lane & 15);
+            if (tile < tiles && n < N) packed[tile * N + n] = ((uint64_t)keep_hi << 32) | keep_lo;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) cur[k] = nxt[k];
+    }
+}
+
+// unpack: the same geometry the other way -- lane l writes chains 4 l .. 4 l + 3 of a row as one 16-byte vector (non-temporal: the
+// [N, C] result is far larger than the Infinity Cache and nobody on the chip reads it back), a wave takes 16 rows of a 256-chain span;
+// the dword of the tile word a lane needs (low for lanes 0..7 of its row of 16, else high) is a 4-byte load that 8 lanes share.
+__global__ __launch_bounds__(4 * kWave) void k_mcpg_unpack_f32x4(const uint64_t* __restrict__ packed, int64_t N, int64_t C, float* __restrict__ xs) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = threadIdx.x / kWave;
+    const int64_t n0 = ((int64_t)blockIdx.y * 4 + w) * 16;
+    if (n0 >= N) return;
+    const int sh = 4 * (lane & 7);
+    const int64_t s0 = (int64_t)blockIdx.x * kPackSpans;
+    const uint32_t* p32 = reinterpret_cast<const uint32_t*>(packed);
+#pragma unroll 1
+    for (int i = 0; i < kPackSpans; ++i) {
+        const int64_t c = (s0 + i) * 256 + 4 * lane;
+        if ((s0 + i) * 256 >= C) break;
+        const int64_t tile = (s0 + i) * 4 + (lane >> 4);
+        const bool in = c < C;
+        uint32_t wd[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) wd[k] = (in && n0 + k < N) ? p32[((tile * N + n0 + k) << 1) + ((lane >> 3) & 1)] : 0u;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if (in && n0 + k < N) {
+                const uint32_t b = (wd[k] >> sh) & 15u;
+                f32x4 v;
+                v[0] = (float)(b & 1u); v[1] = (float)((b >> 1) & 1u); v[2] = (float)((b >> 2) & 1u); v[3] = (float)(b >> 3);
+                __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(xs + (n0 + k) * C + c));
+            }
+        }
     }
 }
 
@@ -1650,6 +1763,12 @@ int rls_mcpg_pack_chains(const void* xs, int spin_bytes, int64_t N, int64_t C, u
     RLS_REQUIRE(spin_bytes == 1 || spin_bytes == 4, RLS_EINVAL, "spin_bytes must be 1 or 4");
     RLS_REQUIRE(N < (1ll << 22), RLS_EUNSUPPORTED, "N=%lld: the pack grid walks 64-node blocks in grid.y", (long long)N);
     const dim3 grid((unsigned)ceil_div(ceil_div(C, kWave), kPackTiles), (unsigned)ceil_div(N, kWave));   // x = run of chain tiles, y = 64-node block
+    const int shim = (int)knob(KN_MCPG_SHIM, 1);     // 0: the round-4 kernels (A/B)
+    if (spin_bytes == 4 && shim && C % 4 == 0 && (reinterpret_cast<uintptr_t>(xs) & 15) == 0 && N < (1ll << 21)) {
+        const dim3 g2((unsigned)ceil_div(ceil_div(C, 256), kPackSpans), (unsigned)ceil_div(N, 64));   // x = run of 256-chain spans, y = 64 rows
+        hipLaunchKernelGGL(k_mcpg_pack_f32x4, g2, dim3(4 * kWave), 0, as_stream(stream), (const float*)xs, N, C, packed);
+        return check_launch("k_mcpg_pack_f32x4");
+    }
     if (spin_bytes == 1) hipLaunchKernelGGL(k_mcpg_pack<uint8_t>, grid, dim3(4 * kWave), 0, as_stream(stream), (const uint8_t*)xs, N, C, packed);
     else hipLaunchKernelGGL(k_mcpg_pack<float>, grid, dim3(4 * kWave), 0, as_stream(stream), (const float*)xs, N, C, packed);
     return check_launch("k_mcpg_pack");
@@ -1659,6 +1778,11 @@ int rls_mcpg_unpack_chains(const uint64_t* packed, int64_t N, int64_t C, float* 
     RLS_REQUIRE(N > 0 && C >= 0, RLS_EINVAL, "bad sizes");
     if (C == 0) return RLS_OK;
     RLS_REQUIRE(xs && packed, RLS_EINVAL, "NULL pointer");
+    if (knob(KN_MCPG_SHIM, 1) != 0 && C % 4 == 0 && (reinterpret_cast<uintptr_t>(xs) & 15) == 0 && N < (1ll << 21)) {
+        const dim3 g2((unsigned)ceil_div(ceil_div(C, 256), kPackSpans), (unsigned)ceil_div(N, 64));
+        hipLaunchKernelGGL(k_mcpg_unpack_f32x4, g2, dim3(4 * kWave), 0, as_stream(stream), packed, N, C, xs);
+        return check_launch("k_mcpg_unpack_f32x4");
+    }
     if (C % 4 == 0 && (reinterpret_cast<uintptr_t>(xs) & 15) == 0) {
         const dim3 grid((unsigned)ceil_div(C / 4, 256), (unsigned)(N < 32768 ? N : 32768));
         hipLaunchKernelGGL(k_mcpg_unpack<true>, grid, dim3(256), 0, as_stream(stream), packed, N, C, xs);
