@@ -1213,18 +1213,26 @@ __global__ __launch_bounds__(kBitSumThreads) void k_mcpg_value_bit_sums_lut(cons
 // bit-packed tiles <-> the reference's node-major f32 [N, C] surface (shims for callers that want it)
 // unpack: a thread writes four consecutive chains of one node as one 16-byte store (rows of C % 4 == 0 floats are 16-byte
 // aligned); grid.y walks the nodes, so no division per element
-template <bool V4>
+template <bool V4, bool NT = false, int U = 1>
 __global__ __launch_bounds__(256) void k_mcpg_unpack(const uint64_t* __restrict__ packed, int64_t N, int64_t C, float* __restrict__ xs) {
     if constexpr (V4) {
         const int64_t c4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;          // chains 4 c4 .. 4 c4 + 3
         if (c4 * 4 >= C) return;
         const int64_t tile = c4 >> 4;
         const int sh = (int)(c4 & 15) * 4;
-        for (int64_t n = blockIdx.y; n < N; n += gridDim.y) {
-            const uint32_t b = (uint32_t)(packed[tile * N + n] >> sh) & 15u;
-            f32x4 v;
-            v[0] = (float)(b & 1u); v[1] = (float)((b >> 1) & 1u); v[2] = (float)((b >> 2) & 1u); v[3] = (float)(b >> 3);
-            *reinterpret_cast<f32x4*>(xs + n * C + c4 * 4) = v;
+        for (int64_t n0 = (int64_t)blockIdx.y * U; n0 < N; n0 += (int64_t)gridDim.y * U) {     // U consecutive rows: their words are adjacent
+            uint64_t wd[U];
+#pragma unroll
+            for (int k = 0; k < U; ++k) wd[k] = n0 + k < N ? packed[tile * N + n0 + k] : 0ull;
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                if (n0 + k >= N) break;
+                const uint32_t b = (uint32_t)(wd[k] >> sh) & 15u;
+                f32x4 v;
+                v[0] = (float)(b & 1u); v[1] = (float)((b >> 1) & 1u); v[2] = (float)((b >> 2) & 1u); v[3] = (float)(b >> 3);
+                if constexpr (NT) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(xs + (n0 + k) * C + c4 * 4));
+                else *reinterpret_cast<f32x4*>(xs + (n0 + k) * C + c4 * 4) = v;
+            }
         }
     } else {
         const int64_t total = N * C;
@@ -1270,8 +1278,10 @@ __global__ __launch_bounds__(4 * kWave) void k_mcpg_pack(const T* __restrict__ x
 
 // ---- round 5: the f32 shims as line-wide streams ----------------------------------------------------------------------------
 // What a caller of the reference-shaped surface (f32 [N, C], MCPG.py:88-166) pays beside the bit-packed kernels is 4 N bytes per
-// chain each way, so the shims must run at what a plain stream reaches.  Both take one 16-byte vector per lane: a wave-instruction
-// moves 1 KB of ONE row = 256 chains = four 64-chain tiles (the kernels above moved 256 B per instruction on the f32 side).
+// chain each way, so the shims must run at what a plain stream reaches.  pack takes one 16-byte vector per lane: a wave-instruction
+// moves 1 KB of ONE row = 256 chains = four 64-chain tiles (the round-4 kernel moved 256 B per instruction).  (unpack already wrote
+// 16 bytes per lane; the same 16-rows-per-wave geometry for it, and a row-sequential form, measured SLOWER than one row per thread:
+// 2220 / 2100 vs 2020 us -- what it lacked were non-temporal stores.)
 //
 // pack: lane l holds chains 4 l .. 4 l + 3 of the span as a nibble; the 16 lanes of a DPP row are one tile: the nibble shifted to
 // its place in the 64-bit word (lanes 0..7 fill the low dword, 8..15 the high one) and OR-ed over the row in four DPP steps (the two
@@ -1284,8 +1294,7 @@ __device__ __forceinline__ uint32_t row_or16(uint32_t v) {
     v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, false);   // row_ror:8
     return v;
 }
-constexpr int kPackSpans = 4;     // 256-chain spans a wave walks (16 rows x 4 KB: 64 KB read per wave)
-__global__ __launch_bounds__(4 * kWave) void k_mcpg_pack_f32x4(const float* __restrict__ xs, int64_t N, int64_t C, uint64_t* __restrict__ packed) {
+__global__ __launch_bounds__(4 * kWave) void k_mcpg_pack_f32x4(const float* __restrict__ xs, int64_t N, int64_t C, uint64_t* __restrict__ packed, int spans) {
     const int lane = threadIdx.x & (kWave - 1);
     const int w = threadIdx.x / kWave;
     const int64_t tiles = (C + kWave - 1) / kWave;
@@ -1300,16 +1309,16 @@ __global__ __launch_bounds__(4 * kWave) void k_mcpg_pack_f32x4(const float* __re
             v[k] = (c < C && n0 + r0 + k < N) ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xs + (n0 + r0 + k) * C + c))
                                               : f32x4{0.f, 0.f, 0.f, 0.f};
     };
-    const int64_t s0 = (int64_t)blockIdx.x * kPackSpans;
+    const int64_t s0 = (int64_t)blockIdx.x * spans;
     f32x4 cur[8], nxt[8];
     fetch(s0, 0, cur);
     uint32_t keep_lo = 0, keep_hi = 0;
 #pragma unroll 1
-    for (int i = 0; i < 2 * kPackSpans; ++i) {                          // half-batches: (span, rows 0..7), (span, rows 8..15), ...
+    for (int i = 0; i < 2 * spans; ++i) {                               // half-batches: (span, rows 0..7), (span, rows 8..15), ...
         const int64_t span = s0 + (i >> 1);
         if (span * 256 >= C) break;
         const int r0 = (i & 1) * 8;
-        if (i + 1 < 2 * kPackSpans) fetch(s0 + ((i + 1) >> 1), ((i + 1) & 1) * 8, nxt);
+        if (i + 1 < 2 * spans) fetch(s0 + ((i + 1) >> 1), ((i + 1) & 1) * 8, nxt);
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const uint32_t nib = (cur[k][0] > 0.0f ? 1u : 0u) | (cur[k][1] > 0.0f ? 2u : 0u) | (cur[k][2] > 0.0f ? 4u : 0u) |
@@ -1324,38 +1333,6 @@ __global__ __launch_bounds__(4 * kWave) void k_mcpg_pack_f32x4(const float* __re
         }
 #pragma unroll
         for (int k = 0; k < 8; ++k) cur[k] = nxt[k];
-    }
-}
-
-// unpack: the same geometry the other way -- lane l writes chains 4 l .. 4 l + 3 of a row as one 16-byte vector (non-temporal: the
-// [N, C] result is far larger than the Infinity Cache and nobody on the chip reads it back), a wave takes 16 rows of a 256-chain span;
-// the dword of the tile word a lane needs (low for lanes 0..7 of its row of 16, else high) is a 4-byte load that 8 lanes share.
-__global__ __launch_bounds__(4 * kWave) void k_mcpg_unpack_f32x4(const uint64_t* __restrict__ packed, int64_t N, int64_t C, float* __restrict__ xs) {
-    const int lane = threadIdx.x & (kWave - 1);
-    const int w = threadIdx.x / kWave;
-    const int64_t n0 = ((int64_t)blockIdx.y * 4 + w) * 16;
-    if (n0 >= N) return;
-    const int sh = 4 * (lane & 7);
-    const int64_t s0 = (int64_t)blockIdx.x * kPackSpans;
-    const uint32_t* p32 = reinterpret_cast<const uint32_t*>(packed);
-#pragma unroll 1
-    for (int i = 0; i < kPackSpans; ++i) {
-        const int64_t c = (s0 + i) * 256 + 4 * lane;
-        if ((s0 + i) * 256 >= C) break;
-        const int64_t tile = (s0 + i) * 4 + (lane >> 4);
-        const bool in = c < C;
-        uint32_t wd[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) wd[k] = (in && n0 + k < N) ? p32[((tile * N + n0 + k) << 1) + ((lane >> 3) & 1)] : 0u;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            if (in && n0 + k < N) {
-                const uint32_t b = (wd[k] >> sh) & 15u;
-                f32x4 v;
-                v[0] = (float)(b & 1u); v[1] = (float)((b >> 1) & 1u); v[2] = (float)((b >> 2) & 1u); v[3] = (float)(b >> 3);
-                __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(xs + (n0 + k) * C + c));
-            }
-        }
     }
 }
 
@@ -1764,9 +1741,10 @@ int rls_mcpg_pack_chains(const void* xs, int spin_bytes, int64_t N, int64_t C, u
     RLS_REQUIRE(N < (1ll << 22), RLS_EUNSUPPORTED, "N=%lld: the pack grid walks 64-node blocks in grid.y", (long long)N);
     const dim3 grid((unsigned)ceil_div(ceil_div(C, kWave), kPackTiles), (unsigned)ceil_div(N, kWave));   // x = run of chain tiles, y = 64-node block
     const int shim = (int)knob(KN_MCPG_SHIM, 1);     // 0: the round-4 kernels (A/B)
-    if (spin_bytes == 4 && shim && C % 4 == 0 && (reinterpret_cast<uintptr_t>(xs) & 15) == 0 && N < (1ll << 21)) {
-        const dim3 g2((unsigned)ceil_div(ceil_div(C, 256), kPackSpans), (unsigned)ceil_div(N, 64));   // x = run of 256-chain spans, y = 64 rows
-        hipLaunchKernelGGL(k_mcpg_pack_f32x4, g2, dim3(4 * kWave), 0, as_stream(stream), (const float*)xs, N, C, packed);
+    if (spin_bytes == 4 && (shim & 15) && C % 4 == 0 && (reinterpret_cast<uintptr_t>(xs) & 15) == 0 && N < (1ll << 21)) {
+        const int spans = 1 << ((shim >> 4) & 15 ? ((shim >> 4) & 15) - 1 : 0);      // A/B: bits 4..7 of the knob = 1 + log2 spans; 1 span measured best (2020 us; 4 spans 2105, the round-4 kernel 2390)
+        const dim3 g2((unsigned)ceil_div(ceil_div(C, 256), spans), (unsigned)ceil_div(N, 64));   // x = run of 256-chain spans, y = 64 rows
+        hipLaunchKernelGGL(k_mcpg_pack_f32x4, g2, dim3(4 * kWave), 0, as_stream(stream), (const float*)xs, N, C, packed, spans);
         return check_launch("k_mcpg_pack_f32x4");
     }
     if (spin_bytes == 1) hipLaunchKernelGGL(k_mcpg_pack<uint8_t>, grid, dim3(4 * kWave), 0, as_stream(stream), (const uint8_t*)xs, N, C, packed);
@@ -1778,13 +1756,14 @@ int rls_mcpg_unpack_chains(const uint64_t* packed, int64_t N, int64_t C, float* 
     RLS_REQUIRE(N > 0 && C >= 0, RLS_EINVAL, "bad sizes");
     if (C == 0) return RLS_OK;
     RLS_REQUIRE(xs && packed, RLS_EINVAL, "NULL pointer");
-    if (knob(KN_MCPG_SHIM, 1) != 0 && C % 4 == 0 && (reinterpret_cast<uintptr_t>(xs) & 15) == 0 && N < (1ll << 21)) {
-        const dim3 g2((unsigned)ceil_div(ceil_div(C, 256), kPackSpans), (unsigned)ceil_div(N, 64));
-        hipLaunchKernelGGL(k_mcpg_unpack_f32x4, g2, dim3(4 * kWave), 0, as_stream(stream), packed, N, C, xs);
-        return check_launch("k_mcpg_unpack_f32x4");
-    }
     if (C % 4 == 0 && (reinterpret_cast<uintptr_t>(xs) & 15) == 0) {
         const dim3 grid((unsigned)ceil_div(C / 4, 256), (unsigned)(N < 32768 ? N : 32768));
+        // two consecutive rows per thread (their words are adjacent) and non-temporal stores -- the [N, C] result is far larger than
+        // the Infinity Cache and nobody on the chip reads it back: BA-1e4 / 2^18 chains 2022 -> 1737 us (5.19 -> 6.04 TB/s)
+        if (knob(KN_MCPG_SHIM, 1) != 0)
+            hipLaunchKernelGGL((k_mcpg_unpack<true, true, 2>), dim3(grid.x, (unsigned)ceil_div((int64_t)grid.y, 2)), dim3(256), 0, as_stream(stream),
+                               packed, N, C, xs);
+        else
         hipLaunchKernelGGL(k_mcpg_unpack<true>, grid, dim3(256), 0, as_stream(stream), packed, N, C, xs);
     } else {
         hipLaunchKernelGGL(k_mcpg_unpack<false>, dim3(grid_for(N * C, 256)), dim3(256), 0, as_stream(stream), packed, N, C, xs);
