@@ -113,15 +113,18 @@ int rls_graph_sweep_schedule(const int32_t* rowptr, const int32_t* col, int64_t 
  * estimate; never more than 64) takes L = 2, 4 or 8 ADJACENT lanes, lane j of them holding neighbours j, j + L, ...;
  * the kernel adds the lanes' counters before the compare.  Group record in lv_data:
  *     64 words  node | (deg / 2) << 20 | log2 L << 28      (node = N on idle lanes)
- *     rounds of 64 words  8 nb                             (byte offset of the neighbour's word in the tile; the node's
+ *     per block of 8 rounds, 2 slabs of [64 lanes][4 rounds] (ABI v11: a lane fetches a block in two 16-byte loads) --
+ *     round r of lane l at 64 + 512 (r / 8) + 256 ((r / 4) % 2) + 4 l + r % 4:
+ *               8 nb                                       (byte offset of the neighbour's word in the tile; the node's
  *                                                           own where the lane's share of the row has ended, 8 N on idle lanes)
- * with rounds = the group's longest lane rounded up to a multiple of 8; the table ends in eight spare rows (counted in
- * *total) so that a group's first eight rounds can be read unguarded.  A wave decides a whole group at once on 64-env
+ * with rounds = the group's longest lane rounded up to a multiple of 8; the table ends in sixteen spare rows (counted in
+ * *total) so that a group's first two blocks can be read unguarded.  A wave decides a whole group at once on 64-env
  * words: bit-sliced count of differing neighbours, bit-sliced compare with deg/2, XOR of the flip mask into
  * the node's word -- bit-identical to the sequential pass (see rls_graph_sweep_schedule).
  * A row of 256 or more entries (a hub) is a group of its own, the first of its level, with lane = neighbour:
  *     64 words  [0] = node, [1] = degree, N elsewhere
- *     rounds of 64 words  8 nb, the row 64 entries per round, the node's own offset past its end
+ *     rounds (a multiple of 8) in the same block layout: 8 nb, neighbour e in round e / 64 of lane e % 64, the node's own
+ *     offset past its end
  * lv_ptr [host, groups+1] (bit 31 = first group of a level, bit 30 = hub group); lv_data [host, capacity] or NULL to size
  * (*num_groups, *total).  Needs N < 2^20 and max degree < 4096. */
 int rls_graph_sweep_levels(const int32_t* rowptr, const int32_t* col, int64_t N, int32_t* lv_ptr, int64_t ptr_capacity,

@@ -285,6 +285,10 @@ int rls_graph_sweep_levels(const int32_t* rowptr, const int32_t* col, int64_t N,
     auto deg_at = [&](int64_t k) { return degn(order[(size_t)k]); };
     int64_t ng = 0, off = 0;
     std::vector<rls::LaneGroup> groups;
+    std::vector<int32_t> rows;      // a group's rounds as [rounds][64] (what spread_banks permutes)
+    // Record layout (round 5, as rls_mcpg_visit_levels): 64 header words (lane l's at l), then per block of 8 rounds two slabs of
+    // [64 lanes][4 rounds] -- a lane fetches a block in two 16-byte loads.  Round r of lane l:
+    auto slot = [](int64_t r, int64_t l) { return 64 + (r >> 3) * 512 + ((r >> 2) & 1) * 256 + l * 4 + (r & 3); };
     for (int32_t l = 0; l < nlev; ++l) {
         const int64_t a0 = start[(size_t)l], b = start[(size_t)l + 1];
         int64_t a = a0;                                    // [a0, a): the level's hubs (sorted first), [a, b): lane = node rows
@@ -306,30 +310,31 @@ int rls_graph_sweep_levels(const int32_t* rowptr, const int32_t* col, int64_t N,
             if (lv_data) {
                 if (off + len > data_capacity) return rls::fail(RLS_EINVAL, "rls_graph_sweep_levels: data capacity too small");
                 int32_t* rec = lv_data + off;
-                for (int64_t e = 0; e < len; ++e) rec[e] = (int32_t)(e < 64 ? N : N * 8);   // idle lanes: node N, its (zero) word
+                for (int64_t e = 0; e < 64; ++e) rec[e] = (int32_t)N;                          // idle lanes: node N (its word is zero)
+                rows.assign((size_t)(g.rounds * 64), (int32_t)(N * 8));
                 if (hub) {   // header: lane 0 = the node, lane 1 = its degree; then its neighbours 64 per round, padded with itself
                     const int32_t i = order[(size_t)g.k0], deg = degn(i);
                     rec[0] = i;
                     rec[1] = deg;
                     for (int64_t e = 0; e < (int64_t)g.rounds * 64; ++e)
-                        rec[64 + e] = (int32_t)((uint32_t)(e < deg ? col[rowptr[i] + e] : i) * 8u);
-                    off += len;
-                    ++ng;
-                    continue;
-                }
-                int32_t ln = 0;
-                for (int64_t k = g.k0; k < g.k1; ++k) {
-                    const int32_t i = order[(size_t)k], deg = degn(i), lc = rls::lanes_log2_for(deg, cap), L = 1 << lc;
-                    for (int32_t j = 0; j < L; ++j) {              // lane j of the node's L takes neighbours j, j + L, ...
-                        rec[ln + j] = (int32_t)((uint32_t)i | ((uint32_t)(deg >> 1) << 20) | ((uint32_t)lc << 28));
-                        for (int32_t r = 0; r < g.rounds; ++r) {   // short lanes end in the node itself: x_i ^ x_i adds nothing
-                            const int32_t e = r * L + j;
-                            rec[(int64_t)(1 + r) * 64 + ln + j] = (int32_t)((uint32_t)(e < deg ? col[rowptr[i] + e] : i) * 8u);
+                        rows[(size_t)e] = (int32_t)((uint32_t)(e < deg ? col[rowptr[i] + e] : i) * 8u);
+                } else {
+                    int32_t ln = 0;
+                    for (int64_t k = g.k0; k < g.k1; ++k) {
+                        const int32_t i = order[(size_t)k], deg = degn(i), lc = rls::lanes_log2_for(deg, cap), L = 1 << lc;
+                        for (int32_t j = 0; j < L; ++j) {              // lane j of the node's L takes neighbours j, j + L, ...
+                            rec[ln + j] = (int32_t)((uint32_t)i | ((uint32_t)(deg >> 1) << 20) | ((uint32_t)lc << 28));
+                            for (int32_t r = 0; r < g.rounds; ++r) {   // short lanes end in the node itself: x_i ^ x_i adds nothing
+                                const int32_t e = r * L + j;
+                                rows[(size_t)((int64_t)r * 64 + ln + j)] = (int32_t)((uint32_t)(e < deg ? col[rowptr[i] + e] : i) * 8u);
+                            }
                         }
+                        ln += L;
                     }
-                    ln += L;
+                    rls::spread_banks(rows.data(), g.rounds);
                 }
-                rls::spread_banks(rec + 64, g.rounds);
+                for (int64_t r = 0; r < g.rounds; ++r)
+                    for (int64_t q = 0; q < 64; ++q) rec[slot(r, q)] = rows[(size_t)(r * 64 + q)];
             }
             off += len;
             ++ng;
@@ -339,13 +344,13 @@ int rls_graph_sweep_levels(const int32_t* rowptr, const int32_t* col, int64_t N,
         if (ng >= ptr_capacity) return rls::fail(RLS_EINVAL, "rls_graph_sweep_levels: ptr capacity too small");
         lv_ptr[ng] = (int32_t)off;
     }
-    // eight spare rows behind the last record: the kernel prefetches a group's first eight rounds without looking
+    // sixteen spare rows behind the last record: the kernel requests a group's first two blocks of rounds without looking
     if (lv_data) {
-        if (off + 8 * 64 > data_capacity) return rls::fail(RLS_EINVAL, "rls_graph_sweep_levels: data capacity too small");
-        for (int64_t e = 0; e < 8 * 64; ++e) lv_data[off + e] = (int32_t)(N * 8);
+        if (off + 16 * 64 > data_capacity) return rls::fail(RLS_EINVAL, "rls_graph_sweep_levels: data capacity too small");
+        for (int64_t e = 0; e < 16 * 64; ++e) lv_data[off + e] = (int32_t)(N * 8);
     }
     *num_groups = ng;
-    *total = off + 8 * 64;
+    *total = off + 16 * 64;
     return RLS_OK;
 }
 

@@ -152,42 +152,62 @@ __device__ __forceinline__ uint64_t lv_count_le(const uint64_t (&pl)[8], uint32_
 }
 
 // One group of the level schedule: vertical counters of "neighbour differs" over its rounds (entries = LDS byte
-// offsets of the neighbours' words; whole blocks of 8 rounds, loaded unguarded), summed across the 2 / 4 / 8 adjacent
-// lanes a long row is spread over (lcode = log2 of that, sorted so that lane 0 has the group's largest), then the
-// bit-sliced compare with the per-lane threshold.  NC = counter planes above `fours` that the rounds can reach.
-template <int NC, int NP>
-__device__ __forceinline__ uint64_t sweep_group_flips(const unsigned char* __restrict__ wbytes, const int32_t* __restrict__ rec8,
-                                                      int rounds, const uint32_t (&nb0)[8], uint64_t own, uint32_t thr,
-                                                      uint32_t lcode) {
+// offsets of the neighbours' words -- the tile sits at LDS address 0, so an entry goes into the read as it was loaded; whole
+// blocks of 8 rounds, loaded unguarded), summed across the 2 / 4 / 8 adjacent lanes a long row is spread over (lcode = log2 of
+// that, sorted so that lane 0 has the group's largest), then the bit-sliced compare with the per-lane threshold.
+// NC = counter planes above `fours` that the rounds can reach.  NB = the group's blocks when that is 1 or 2 (straight-line code
+// on the registers that came with the header), 0: a loop that requests block b + 2 while block b is counted (blk = this lane's
+// slab of block 2).
+typedef const uint64_t __attribute__((address_space(3))) sweep_lds_cu64;
+__device__ __forceinline__ uint64_t sweep_word_at(uint32_t a) { return *(sweep_lds_cu64*)(uintptr_t)a; }
+
+template <int NC>
+__device__ __forceinline__ void sweep_count_block(const uint32_t (&nb)[8], uint64_t own, uint64_t& ones, uint64_t& twos, uint64_t& fours,
+                                                  uint64_t (&c)[5]) {
+    uint64_t d[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) d[q] = sweep_word_at(nb[q]) ^ own;   // padding = the node itself: 0
+    uint64_t twosA, twosB, foursA, foursB, carry;
+    csa(twosA, ones, ones, d[0], d[1]);
+    csa(twosB, ones, ones, d[2], d[3]);
+    csa(foursA, twos, twos, twosA, twosB);
+    csa(twosA, ones, ones, d[4], d[5]);
+    csa(twosB, ones, ones, d[6], d[7]);
+    csa(foursB, twos, twos, twosA, twosB);
+    csa(carry, fours, fours, foursA, foursB);
+#pragma unroll
+    for (int p = 0; p < NC; ++p) {
+        const uint64_t t = c[p] & carry;
+        c[p] ^= carry;
+        carry = t;
+    }
+}
+
+template <int NB, int NC, int NP>
+__device__ __forceinline__ uint64_t sweep_group_flips(const int32_t* __restrict__ blk, int rounds, const uint32_t (&nb0)[8],
+                                                      const uint32_t (&nb1)[8], uint64_t own, uint32_t thr, uint32_t lcode) {
     uint64_t ones = 0, twos = 0, fours = 0, c[5] = {0, 0, 0, 0, 0};
-    uint32_t nb[8];
+    if constexpr (NB == 1) {
+        sweep_count_block<NC>(nb0, own, ones, twos, fours, c);
+    } else if constexpr (NB == 2) {
+        sweep_count_block<NC>(nb0, own, ones, twos, fours, c);
+        sweep_count_block<NC>(nb1, own, ones, twos, fours, c);
+    } else {
+        uint32_t nb[8], nx[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) nb[q] = nb0[q];
-    for (int r0 = 0; r0 < rounds; r0 += 8, rec8 += 8 * kWave) {
-        uint32_t nxt[8];                                 // the following 8 rounds, requested before these are used
-        if (r0 + 8 < rounds) {
+        for (int q = 0; q < 8; ++q) { nb[q] = nb0[q]; nx[q] = nb1[q]; }
+        for (int r0 = 0; r0 < rounds; r0 += 8, blk += 512) {
+            u32x4 na, nbv;                                   // block r0 / 8 + 2, requested before block r0 / 8 is counted
+            if (r0 + 16 < rounds) {
+                na = *reinterpret_cast<const u32x4*>(blk);
+                nbv = *reinterpret_cast<const u32x4*>(blk + 256);
+            }
+            sweep_count_block<NC>(nb, own, ones, twos, fours, c);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) nxt[q] = (uint32_t)rec8[q * kWave];
+            for (int q = 0; q < 8; ++q) nb[q] = nx[q];
+            nx[0] = na.x; nx[1] = na.y; nx[2] = na.z; nx[3] = na.w;
+            nx[4] = nbv.x; nx[5] = nbv.y; nx[6] = nbv.z; nx[7] = nbv.w;
         }
-        uint64_t d[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) d[q] = *reinterpret_cast<const uint64_t*>(wbytes + nb[q]) ^ own;   // padding = the node itself: 0
-        uint64_t twosA, twosB, foursA, foursB, carry;
-        csa(twosA, ones, ones, d[0], d[1]);
-        csa(twosB, ones, ones, d[2], d[3]);
-        csa(foursA, twos, twos, twosA, twosB);
-        csa(twosA, ones, ones, d[4], d[5]);
-        csa(twosB, ones, ones, d[6], d[7]);
-        csa(foursB, twos, twos, twosA, twosB);
-        csa(carry, fours, fours, foursA, foursB);
-#pragma unroll
-        for (int p = 0; p < NC; ++p) {
-            const uint64_t t = c[p] & carry;
-            c[p] ^= carry;
-            carry = t;
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) nb[q] = nxt[q];
     }
     const int gl = __builtin_amdgcn_readlane((int)lcode, 0);
     if (gl > 0) {   // degrees < 256: the sum over a row's lanes stays below 2^8
@@ -204,17 +224,17 @@ __device__ __forceinline__ uint64_t sweep_group_flips(const unsigned char* __res
 // A hub (a row of 256 ... 4095 entries) is a group of its own with lane = neighbour: per-lane vertical counters over its
 // rounds (64 neighbours each; the first eight rounds arrive prefetched), every plane transposed across the wave and
 // popcounted -- lane e then holds env e's count -- and the same rule c <= deg / 2.
-__device__ __forceinline__ uint64_t sweep_hub_flips(const unsigned char* __restrict__ wbytes, const int32_t* __restrict__ rec8,
-                                                    int rounds, const uint32_t (&nb0)[8], uint64_t own, uint32_t deg, int lane) {
+__device__ __forceinline__ uint64_t sweep_hub_flips(const int32_t* __restrict__ ent, int rounds, const uint32_t (&nb0)[8], uint64_t own,
+                                                    uint32_t deg, int lane) {       // ent = the record's entries (behind its 64 header words)
     uint64_t cv[7] = {0, 0, 0, 0, 0, 0, 0};                      // rounds <= 64
     auto add = [&](uint32_t off) {
-        uint64_t carry = *reinterpret_cast<const uint64_t*>(wbytes + off) ^ own;
+        uint64_t carry = sweep_word_at(off) ^ own;
 #pragma unroll
         for (int p = 0; p < 7; ++p) { const uint64_t t = cv[p] & carry; cv[p] ^= carry; carry = t; }
     };
 #pragma unroll
     for (int q = 0; q < 8; ++q) add(nb0[q]);
-    for (int r = 8; r < rounds; ++r, rec8 += kWave) add((uint32_t)rec8[0]);
+    for (int r = 8; r < rounds; ++r) add((uint32_t)ent[(r >> 3) * 512 + ((r >> 2) & 1) * 256 + lane * 4 + (r & 3)]);
     const BitXpose xc = bit_xpose_consts(lane);
     int cnt = 0;
 #pragma unroll
@@ -230,17 +250,21 @@ template <int W>
 __device__ __forceinline__ void sweep_tile_levels(uint64_t* words, const int32_t* lvp, const int32_t* __restrict__ data,
                                                   int64_t G, int64_t N, int lane, int w) {
     constexpr uint32_t M = 0x3fffffffu;
-    const unsigned char* wbytes = reinterpret_cast<const unsigned char*>(words);
-    // prefetched head of this wave's next group: header word + the first 8 rounds (unguarded: rounds are whole blocks
-    // of 8 and the table ends in eight spare rows)
+    // table entries are used as LDS addresses: the tile must sit at LDS address 0 (every caller puts it first in its dynamic LDS
+    // and has no static LDS)
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)words != 0u) __builtin_trap();
+    // prefetched head of this wave's next group: header word + the first TWO blocks of 8 rounds, five loads (unguarded: rounds
+    // are whole blocks of 8 and the table ends in sixteen spare rows)
     uint32_t hdr = (uint32_t)N;
-    uint32_t nb0[8];
+    uint32_t nb0[8], nb1[8];
     auto prefetch = [&](int64_t k) {
         if (k < G) {
-            const int32_t* rec = data + ((uint32_t)lvp[k] & M) + lane;
-            hdr = (uint32_t)rec[0];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) nb0[q] = (uint32_t)rec[(1 + q) * kWave];
+            const int32_t* rec = data + ((uint32_t)lvp[k] & M);
+            hdr = (uint32_t)rec[lane];
+            const u32x4 a = *reinterpret_cast<const u32x4*>(rec + 64 + 4 * lane), b = *reinterpret_cast<const u32x4*>(rec + 320 + 4 * lane);
+            const u32x4 c = *reinterpret_cast<const u32x4*>(rec + 576 + 4 * lane), d = *reinterpret_cast<const u32x4*>(rec + 832 + 4 * lane);
+            nb0[0] = a.x; nb0[1] = a.y; nb0[2] = a.z; nb0[3] = a.w; nb0[4] = b.x; nb0[5] = b.y; nb0[6] = b.z; nb0[7] = b.w;
+            nb1[0] = c.x; nb1[1] = c.y; nb1[2] = c.z; nb1[3] = c.w; nb1[4] = d.x; nb1[5] = d.y; nb1[6] = d.z; nb1[7] = d.w;
         }
     };
     prefetch(w);
@@ -268,21 +292,22 @@ __device__ __forceinline__ void sweep_tile_levels(uint64_t* words, const int32_t
         const int64_t p0 = (uint32_t)__builtin_amdgcn_readlane(chunk, (int)(k & 63)) & M;
         const int64_t p1 = (uint32_t)__builtin_amdgcn_readlane(chunk_next, (int)(k & 63)) & M;
         const int rounds = (int)((p1 - p0) >> 6) - 1;        // a multiple of 8
-        const int32_t* rec8 = data + p0 + (1 + 8) * kWave + lane;   // round 8 of this lane
         if (((uint32_t)__builtin_amdgcn_readlane(chunk, (int)(k & 63)) >> 30) & 1u) {   // a hub: one node, lane = neighbour
             const uint32_t hnode = (uint32_t)__builtin_amdgcn_readlane((int)hdr, 0), hdeg = (uint32_t)__builtin_amdgcn_readlane((int)hdr, 1);
             const uint64_t hown = words[hnode];
-            const uint64_t hflip = sweep_hub_flips(wbytes, rec8, rounds, nb0, hown, hdeg, lane);
+            const uint64_t hflip = sweep_hub_flips(data + p0 + 64, rounds, nb0, hown, hdeg, lane);
             if (lane == 0) words[hnode] = hown ^ hflip;
             prefetch(k + W);
             continue;
         }
         const uint32_t node = hdr & 0xFFFFFu, thr = (hdr >> 20) & 0xFFu, lcode = (hdr >> 28) & 3u;
         const uint64_t own = words[node];
+        const int32_t* blk = data + p0 + 64 + 1024 + 4 * lane;      // this lane's slab of block 2
         uint64_t flip;
-        if (rounds <= 8) flip = sweep_group_flips<1, 4>(wbytes, rec8, rounds, nb0, own, thr, lcode);
-        else if (rounds <= 24) flip = sweep_group_flips<2, 5>(wbytes, rec8, rounds, nb0, own, thr, lcode);
-        else flip = sweep_group_flips<4, 7>(wbytes, rec8, rounds, nb0, own, thr, lcode);
+        if (rounds == 8) flip = sweep_group_flips<1, 1, 4>(blk, rounds, nb0, nb1, own, thr, lcode);
+        else if (rounds == 16) flip = sweep_group_flips<2, 2, 5>(blk, rounds, nb0, nb1, own, thr, lcode);
+        else if (rounds <= 24) flip = sweep_group_flips<0, 2, 5>(blk, rounds, nb0, nb1, own, thr, lcode);     // (0: isolated nodes; 24)
+        else flip = sweep_group_flips<0, 4, 7>(blk, rounds, nb0, nb1, own, thr, lcode);
         if (node < (uint32_t)N && (lane & ((1 << lcode) - 1)) == 0) words[node] = own ^ flip;
         prefetch(k + W);
     }

@@ -281,38 +281,57 @@ __device__ __forceinline__ uint32_t lv32_le_const(const uint32_t (&pl)[8], uint3
     return ~c0;
 }
 
-template <int NC, int NP>
-__device__ __forceinline__ uint32_t sweep32_group_flips(const unsigned char* __restrict__ wbytes, const int32_t* __restrict__ rec8,
-                                                        int rounds, const uint32_t (&nb0)[8], uint32_t own, uint32_t thr, uint32_t lcode) {
+typedef const uint32_t __attribute__((address_space(3))) sweep_lds_cu32;
+__device__ __forceinline__ uint32_t sweep32_word_at(uint32_t a) { return *(sweep_lds_cu32*)(uintptr_t)a; }   // (the tile sits at LDS address 0)
+
+template <int NC>
+__device__ __forceinline__ void sweep32_count_block(const uint32_t (&nb)[8], uint32_t own, uint32_t& ones, uint32_t& twos, uint32_t& fours,
+                                                    uint32_t (&c)[5]) {
+    uint32_t d[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) d[q] = sweep32_word_at(nb[q] >> 1) ^ own;   // padding = the node itself: 0
+    uint32_t twosA, twosB, foursA, foursB, carry;
+    csa32(twosA, ones, ones, d[0], d[1]);
+    csa32(twosB, ones, ones, d[2], d[3]);
+    csa32(foursA, twos, twos, twosA, twosB);
+    csa32(twosA, ones, ones, d[4], d[5]);
+    csa32(twosB, ones, ones, d[6], d[7]);
+    csa32(foursB, twos, twos, twosA, twosB);
+    csa32(carry, fours, fours, foursA, foursB);
+#pragma unroll
+    for (int p = 0; p < NC; ++p) {
+        const uint32_t t = c[p] & carry;
+        c[p] ^= carry;
+        carry = t;
+    }
+}
+
+// (rls_sweep.h: sweep_group_flips -- NB = the group's blocks when 1 or 2, 0 = the loop; blk = this lane's slab of block 2)
+template <int NB, int NC, int NP>
+__device__ __forceinline__ uint32_t sweep32_group_flips(const int32_t* __restrict__ blk, int rounds, const uint32_t (&nb0)[8],
+                                                        const uint32_t (&nb1)[8], uint32_t own, uint32_t thr, uint32_t lcode) {
     uint32_t ones = 0, twos = 0, fours = 0, c[5] = {0, 0, 0, 0, 0};
-    uint32_t nb[8];
+    if constexpr (NB == 1) {
+        sweep32_count_block<NC>(nb0, own, ones, twos, fours, c);
+    } else if constexpr (NB == 2) {
+        sweep32_count_block<NC>(nb0, own, ones, twos, fours, c);
+        sweep32_count_block<NC>(nb1, own, ones, twos, fours, c);
+    } else {
+        uint32_t nb[8], nx[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) nb[q] = nb0[q];
-    for (int r0 = 0; r0 < rounds; r0 += 8, rec8 += 8 * kWave) {
-        uint32_t nxt[8];
-        if (r0 + 8 < rounds) {
+        for (int q = 0; q < 8; ++q) { nb[q] = nb0[q]; nx[q] = nb1[q]; }
+        for (int r0 = 0; r0 < rounds; r0 += 8, blk += 512) {
+            u32x4 na, nbv;
+            if (r0 + 16 < rounds) {
+                na = *reinterpret_cast<const u32x4*>(blk);
+                nbv = *reinterpret_cast<const u32x4*>(blk + 256);
+            }
+            sweep32_count_block<NC>(nb, own, ones, twos, fours, c);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) nxt[q] = (uint32_t)rec8[q * kWave];
+            for (int q = 0; q < 8; ++q) nb[q] = nx[q];
+            nx[0] = na.x; nx[1] = na.y; nx[2] = na.z; nx[3] = na.w;
+            nx[4] = nbv.x; nx[5] = nbv.y; nx[6] = nbv.z; nx[7] = nbv.w;
         }
-        uint32_t d[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) d[q] = *reinterpret_cast<const uint32_t*>(wbytes + (nb[q] >> 1)) ^ own;   // padding = the node itself: 0
-        uint32_t twosA, twosB, foursA, foursB, carry;
-        csa32(twosA, ones, ones, d[0], d[1]);
-        csa32(twosB, ones, ones, d[2], d[3]);
-        csa32(foursA, twos, twos, twosA, twosB);
-        csa32(twosA, ones, ones, d[4], d[5]);
-        csa32(twosB, ones, ones, d[6], d[7]);
-        csa32(foursB, twos, twos, twosA, twosB);
-        csa32(carry, fours, fours, foursA, foursB);
-#pragma unroll
-        for (int p = 0; p < NC; ++p) {
-            const uint32_t t = c[p] & carry;
-            c[p] ^= carry;
-            carry = t;
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) nb[q] = nxt[q];
     }
     const int gl = __builtin_amdgcn_readlane((int)lcode, 0);
     if (gl > 0) {
@@ -328,17 +347,17 @@ __device__ __forceinline__ uint32_t sweep32_group_flips(const unsigned char* __r
 
 // a hub: lane = neighbour, per-lane counters over its rounds, every plane transposed across the wave and popcounted (two planes
 // per transpose: lanes 0..31 get plane p of env lane, lanes 32..63 plane p + 1 of env lane - 32)
-__device__ __forceinline__ uint32_t sweep32_hub_flips(const unsigned char* __restrict__ wbytes, const int32_t* __restrict__ rec8, int rounds,
-                                                      const uint32_t (&nb0)[8], uint32_t own, uint32_t deg, int lane) {
+__device__ __forceinline__ uint32_t sweep32_hub_flips(const int32_t* __restrict__ ent, int rounds, const uint32_t (&nb0)[8], uint32_t own,
+                                                      uint32_t deg, int lane) {     // ent = the record's entries (behind its 64 header words)
     uint32_t cv[8] = {0, 0, 0, 0, 0, 0, 0, 0};                      // rounds <= 64: 7 planes (+ 1 to pair them)
     auto add = [&](uint32_t off) {
-        uint32_t carry = *reinterpret_cast<const uint32_t*>(wbytes + (off >> 1)) ^ own;
+        uint32_t carry = sweep32_word_at(off >> 1) ^ own;
 #pragma unroll
         for (int p = 0; p < 7; ++p) { const uint32_t t = cv[p] & carry; cv[p] ^= carry; carry = t; }
     };
 #pragma unroll
     for (int q = 0; q < 8; ++q) add(nb0[q]);
-    for (int r = 8; r < rounds; ++r, rec8 += kWave) add((uint32_t)rec8[0]);
+    for (int r = 8; r < rounds; ++r) add((uint32_t)ent[(r >> 3) * 512 + ((r >> 2) & 1) * 256 + lane * 4 + (r & 3)]);
     const BitXpose xc = bit_xpose_consts(lane);
     const int half = lane >> 5;
     int cnt = 0;
@@ -356,15 +375,17 @@ template <int W>
 __device__ __forceinline__ void sweep32_tile_levels(uint32_t* words32, const int32_t* lvp, const int32_t* __restrict__ data, int64_t G,
                                                     int64_t N, int lane, int w) {
     constexpr uint32_t M = 0x3fffffffu;
-    const unsigned char* wbytes = reinterpret_cast<const unsigned char*>(words32);
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)words32 != 0u) __builtin_trap();   // entries are LDS addresses (rls_sweep.h)
     uint32_t hdr = (uint32_t)N;
-    uint32_t nb0[8];
+    uint32_t nb0[8], nb1[8];
     auto prefetch = [&](int64_t k) {
         if (k < G) {
-            const int32_t* rec = data + ((uint32_t)lvp[k] & M) + lane;
-            hdr = (uint32_t)rec[0];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) nb0[q] = (uint32_t)rec[(1 + q) * kWave];
+            const int32_t* rec = data + ((uint32_t)lvp[k] & M);
+            hdr = (uint32_t)rec[lane];
+            const u32x4 a = *reinterpret_cast<const u32x4*>(rec + 64 + 4 * lane), b = *reinterpret_cast<const u32x4*>(rec + 320 + 4 * lane);
+            const u32x4 c = *reinterpret_cast<const u32x4*>(rec + 576 + 4 * lane), d = *reinterpret_cast<const u32x4*>(rec + 832 + 4 * lane);
+            nb0[0] = a.x; nb0[1] = a.y; nb0[2] = a.z; nb0[3] = a.w; nb0[4] = b.x; nb0[5] = b.y; nb0[6] = b.z; nb0[7] = b.w;
+            nb1[0] = c.x; nb1[1] = c.y; nb1[2] = c.z; nb1[3] = c.w; nb1[4] = d.x; nb1[5] = d.y; nb1[6] = d.z; nb1[7] = d.w;
         }
     };
     prefetch(w);
@@ -389,21 +410,22 @@ __device__ __forceinline__ void sweep32_tile_levels(uint32_t* words32, const int
         const int64_t p0 = (uint32_t)__builtin_amdgcn_readlane(chunk, (int)(k & 63)) & M;
         const int64_t p1 = (uint32_t)__builtin_amdgcn_readlane(chunk_next, (int)(k & 63)) & M;
         const int rounds = (int)((p1 - p0) >> 6) - 1;
-        const int32_t* rec8 = data + p0 + (1 + 8) * kWave + lane;
         if (((uint32_t)__builtin_amdgcn_readlane(chunk, (int)(k & 63)) >> 30) & 1u) {
             const uint32_t hnode = (uint32_t)__builtin_amdgcn_readlane((int)hdr, 0), hdeg = (uint32_t)__builtin_amdgcn_readlane((int)hdr, 1);
             const uint32_t hown = words32[hnode];
-            const uint32_t hflip = sweep32_hub_flips(wbytes, rec8, rounds, nb0, hown, hdeg, lane);
+            const uint32_t hflip = sweep32_hub_flips(data + p0 + 64, rounds, nb0, hown, hdeg, lane);
             if (lane == 0) words32[hnode] = hown ^ hflip;
             prefetch(k + W);
             continue;
         }
         const uint32_t node = hdr & 0xFFFFFu, thr = (hdr >> 20) & 0xFFu, lcode = (hdr >> 28) & 3u;
         const uint32_t own = words32[node];
+        const int32_t* blk = data + p0 + 64 + 1024 + 4 * lane;      // this lane's slab of block 2
         uint32_t flip;
-        if (rounds <= 8) flip = sweep32_group_flips<1, 4>(wbytes, rec8, rounds, nb0, own, thr, lcode);
-        else if (rounds <= 24) flip = sweep32_group_flips<2, 5>(wbytes, rec8, rounds, nb0, own, thr, lcode);
-        else flip = sweep32_group_flips<4, 7>(wbytes, rec8, rounds, nb0, own, thr, lcode);
+        if (rounds == 8) flip = sweep32_group_flips<1, 1, 4>(blk, rounds, nb0, nb1, own, thr, lcode);
+        else if (rounds == 16) flip = sweep32_group_flips<2, 2, 5>(blk, rounds, nb0, nb1, own, thr, lcode);
+        else if (rounds <= 24) flip = sweep32_group_flips<0, 2, 5>(blk, rounds, nb0, nb1, own, thr, lcode);
+        else flip = sweep32_group_flips<0, 4, 7>(blk, rounds, nb0, nb1, own, thr, lcode);
         if (node < (uint32_t)N && (lane & ((1 << lcode) - 1)) == 0) words32[node] = own ^ flip;
         prefetch(k + W);
     }
