@@ -402,7 +402,7 @@ static StepKnobs step_knobs() {
 
 using namespace rls;
 
-// Structures in production (round 3; the A/B history is in DESIGN.md section 6):
+// Structures in production (round 3; the A/B history is in DESIGN_HISTORY.md section 6):
 //   emit, vectorisable runs   MODE 2: the run staged in LDS by LDS-DMA with nontemporal loads (every input byte is read once),
 //                             up to the whole 160 KB of a CU per workgroup (f32 rows of 10^4 nodes: 2 waves x 40 KB);
 //                             stores nontemporal when the batch is larger than the 256 MB Infinity Cache (nothing of it

@@ -259,6 +259,11 @@ def local_search_fusable(g: DeviceGraph, num_spin: int, B: int = 1) -> bool:
     return bool(_abi.lib().rls_maxcut_local_search_supported(g.ref, int(B), int(num_spin)))
 
 
+LS_PITCH_BYTES = 16      # row pitch of the padded local-search weights: what the kernels need.  Whole cache lines (128) were measured
+                         # (tools/timing/ls_pitch.py, interleaved): local_search_inplace G22 2^16 1.292 vs 1.306 ms, N = 10^4 5.48 vs 5.43,
+                         # G22 4096 envs 0.296 vs 0.301 -- nothing, so the rows stay as short as they can be
+
+
 def ls_weight_dtype(g: DeviceGraph, mult: int):
     """Narrowest integer type that holds ws = deg - mult * cutdeg on this graph (|ws| <= max(1, mult - 1) * max degree): the
     fused local search streams ws once per proposal round, so its width is that kernel's HBM traffic."""
@@ -273,7 +278,8 @@ def maxcut_ls_weights(g: DeviceGraph, xs: TEN, mult: int, dtype=None, padded: bo
     the second result is the int32 [2, N] table (min_b ws, max_b ws) itself -- what a sharded batch reduces over its ranks."""
     B, _ = _spins(xs, "xs", g)
     dt = ls_weight_dtype(g, mult) if dtype is None else dtype
-    per = 16 // torch.empty((), dtype=dt).element_size()
+    # rows a whole number of LS_PITCH_BYTES apart (16: what the kernels need)
+    per = LS_PITCH_BYTES // torch.empty((), dtype=dt).element_size()
     P = (g.num_nodes + per - 1) // per * per if padded else g.num_nodes
     ws = torch.empty((B, P), dtype=dt, device=g.device)    # (every kernel that reads 16-byte pieces asks for the padded pitch)
     mm = torch.empty((2, g.num_nodes), dtype=torch.int32, device=g.device)

@@ -151,7 +151,8 @@ def test_round_kernels_beyond_the_fused_kernel(n, m):
     xs = env.generate_xs_randomly(B)
     vs = env.calculate_obj_values(xs)
     ws, span = ops.maxcut_ls_weights(env.graph, xs, 1, padded=True)
-    assert ws.shape[1] % 16 == 0 and 0 <= ws.shape[1] - n < 16
+    pitch_b = ws.shape[1] * ws.element_size()       # rows a whole number of ops.LS_PITCH_BYTES apart (cache lines; >= the 16 bytes the kernels need)
+    assert pitch_b % ops.LS_PITCH_BYTES == 0 and ops.LS_PITCH_BYTES % 16 == 0 and 0 <= pitch_b - n * ws.element_size() < ops.LS_PITCH_BYTES
     ws_flat, span_flat = ops.maxcut_ls_weights(env.graph, xs, 1)
     assert torch.equal(ws[:, :n], ws_flat) and torch.equal(span, span_flat)
     rd_std = (span.float() * 0.3).contiguous()

@@ -1,5 +1,5 @@
 """Rank-count invariance of every seeded entry point ("per-env RNG keyed by global env id, not rank";
-DESIGN.md section 7).  One process, one GPU: the batch is run once whole and once as two half-batches whose objects carry
+DESIGN.md section 8).  One process, one GPU: the batch is run once whole and once as two half-batches whose objects carry
 ``env_offset = 0`` and ``B / 2`` -- the halves must equal the corresponding rows of the whole batch BIT FOR BIT.
 
 The few statistics the reference takes over the WHOLE batch (the local search's per-node weight range, the PECO reset's
