@@ -80,7 +80,7 @@ static int64_t plan_lane_groups(int64_t a, int64_t b, int32_t cap, DegAt deg_at,
             ++g.k1;
         }
         g.rounds = (g.rounds + 7) / 8 * 8;
-        const int64_t cost = 150 + 85 * (int64_t)(g.rounds / 8) + (g.multi ? 110 : 0);
+        const int64_t cost = knob(KN_PLAN_FIXED, 150) + knob(KN_PLAN_BLOCK, 85) * (int64_t)(g.rounds / 8) + (g.multi ? knob(KN_PLAN_MERGE, 110) : 0);
         total += cost;
         if (cost > longest) longest = cost;
         if (out) out->push_back(g);
