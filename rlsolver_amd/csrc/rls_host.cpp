@@ -53,7 +53,7 @@ int fail(int code, const char* fmt, ...) {
 // (lane j of them takes entries j, j + L, ...; the kernel adds the lanes' bit-sliced counters before the compare,
 // ~110 VALU per group that has any).  Per level the cap (none / 32 / 16 / 8 entries per lane; a lane never holds
 // more than 64) is the one with the least estimated time: the level's work over the waves plus its longest group, in
-// VALU instructions as measured on gfx950 (~150 per group, ~85 per 8 rounds, ~110 for the cross-lane sums).
+// VALU instructions (~150 per group, ~50 per 8 rounds, ~60 for the cross-lane sums: see plan_lane_groups).
 struct LaneGroup { int64_t k0, k1; int32_t rounds; bool multi; };   // rows [k0, k1) of the level's degree-descending order
 
 static inline int32_t lanes_log2_for(int32_t deg, int32_t cap) {
@@ -80,7 +80,10 @@ static int64_t plan_lane_groups(int64_t a, int64_t b, int32_t cap, DegAt deg_at,
             ++g.k1;
         }
         g.rounds = (g.rounds + 7) / 8 * 8;
-        const int64_t cost = knob(KN_PLAN_FIXED, 150) + knob(KN_PLAN_BLOCK, 85) * (int64_t)(g.rounds / 8) + (g.multi ? knob(KN_PLAN_MERGE, 110) : 0);
+        // (round 5: 150 / 50 / 60 -- a block of 8 rounds costs the kernels ~45 instructions since the tables are lane-major, a
+        // cross-lane merge step ~64; with round 4's 150 / 85 / 110 a G22-sized graph got 129 groups, now 101: K5 110.6 -> 103 us,
+        // K7 at BA-1e4 and seven other graph shapes unchanged within 1 %: tools/timing/plan_ab.py, plan_shapes.py)
+        const int64_t cost = knob(KN_PLAN_FIXED, 150) + knob(KN_PLAN_BLOCK, 50) * (int64_t)(g.rounds / 8) + (g.multi ? knob(KN_PLAN_MERGE, 60) : 0);
         total += cost;
         if (cost > longest) longest = cost;
         if (out) out->push_back(g);
