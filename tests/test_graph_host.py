@@ -123,7 +123,7 @@ def test_sweep_level_groups_encode_the_same_schedule():
     """rls_graph_sweep_levels: every node appears once (on L = 1, 2, 4 or 8 adjacent, L-aligned lanes, the longest
     rows first), lower-numbered neighbours sit in earlier LEVELS, lane j of a node lists its CSR entries j, j + L, ...
     as byte offsets of the neighbours' words and ends in the node itself, rounds come in whole blocks of 8, no lane holds
-    more than 64 entries, and the table ends in eight spare rows.  A row of 256 or more entries is a group of its own
+    more than 64 entries, and the table ends in sixteen spare rows (the kernels request a group's first two blocks unguarded).  A row of 256 or more entries is a group of its own
     (bit 30 of its offset): node and degree in the header, its neighbours 64 per round, padded with itself."""
     import ctypes as C
     from rlsolver_amd import _abi
@@ -145,14 +145,20 @@ def test_sweep_level_groups_encode_the_same_schedule():
         first = (lvp.view(np.uint32)[:-1] >> 31).astype(bool)
         is_hub = ((lvp.view(np.uint32)[:-1] >> 30) & 1).astype(bool)
         assert is_hub.sum() == int((np.diff(rp) >= 256).sum())
-        assert first[0] and off[-1] + 8 * 64 == tot.value and (lvd[off[-1]:] == n * 8).all()
+        assert first[0] and off[-1] + 16 * 64 == tot.value and (lvd[off[-1]:] == n * 8).all()      # sixteen spare rows (ABI v11)
         level_of_group = np.cumsum(first) - 1
         level_of = np.full(n, -1)
         seen = []
         for k in range(ng.value):
-            rec = lvd[off[k]: off[k + 1]].reshape(-1, 64)
-            rounds = rec.shape[0] - 1
+            raw = lvd[off[k]: off[k + 1]]
+            rounds = raw.size // 64 - 1
             assert rounds % 8 == 0 and rounds <= 64
+            # ABI v11 record: 64 header words, then per block of 8 rounds two slabs of [64 lanes][4 rounds] -- round r of lane l at
+            # 64 + 512 (r / 8) + 256 ((r / 4) % 2) + 4 l + r % 4.  Decoded back to [1 + rounds][64] for the checks below
+            rec = np.empty((1 + rounds, 64), dtype=raw.dtype)
+            rec[0] = raw[:64]
+            for r in range(rounds):
+                rec[1 + r] = raw[64 + 512 * (r // 8) + 256 * ((r // 4) % 2) + 4 * np.arange(64) + r % 4]
             if is_hub[k]:
                 i, deg = int(rec[0, 0]), int(rec[0, 1])
                 assert deg == rp[i + 1] - rp[i] >= 256 and (rec[0, 2:] == n).all() and rounds * 64 >= deg
@@ -260,3 +266,71 @@ def test_load_data_builds_the_isco_tsp_params(tmp_path):
     assert d["num_nodes"] == 12 and d["distance"].dtype == torch.float32 and d["nearest_indices"].dtype == torch.int64
     assert np.array_equal(d["distance"].numpy(), dist) and np.array_equal(d["nearest_indices"].numpy(), near)
     assert np.array_equal(d["random_indices"].numpy(), rnd) and d["random_indices"].shape == (12, 11)
+
+
+def test_mcpg_visit_level_table_layout_abi_v11():
+    """rls_mcpg_visit_levels (ABI v11): lane-major records -- words 2 l, 2 l + 1 = lane l's two header words, round r of lane l at
+    128 + 512 (r / 8) + 256 ((r / 4) % 2) + 4 l + r % 4 --, every visiting position on L adjacent lanes once, a lane's entries =
+    its share of the node's neighbours as LDS byte offsets with bit 31 set on the not-yet-visited ones, sixteen spare rows, then the
+    SAME table again with the fresh flags cleared (headers untouched) at offset (lv_ptr[G] & 0x3fffffff) + 1024."""
+    import ctypes as C
+    from rlsolver_amd import _abi
+    from rlsolver_amd.graph import build_csr, generate_gnm, generate_ba
+    for g, n in ((generate_gnm(300, 1500, seed=3), 300), (generate_ba(400, 5, seed=1), 400), ([(0, 1, 1)], 70),
+                 ([(0, j, 1) for j in range(1, 500)] + [(j, j + 1, 1) for j in range(1, 499, 2)], 500)):
+        csr = build_csr(g, num_nodes=n, if_bidirectional=False)
+        rp = np.ascontiguousarray(csr.rowptr, dtype=np.int32)
+        col = np.ascontiguousarray(csr.col, dtype=np.int32)
+        deg = np.diff(rp)
+        order = np.argsort(-deg, kind="stable").astype(np.int32)
+        pos_of = np.empty(n, dtype=np.int64)
+        pos_of[order] = np.arange(n)
+        a = (rp.ctypes.data_as(C.c_void_p), col.ctypes.data_as(C.c_void_p), n, order.ctypes.data_as(C.c_void_p))
+        ng, tot = C.c_int64(0), C.c_int64(0)
+        _abi.call("rls_mcpg_visit_levels", *a, None, 0, None, 0, C.byref(ng), C.byref(tot))
+        lvp = np.empty(ng.value + 1, dtype=np.int32)
+        lvd = np.full(tot.value, -12345, dtype=np.int32)
+        _abi.call("rls_mcpg_visit_levels", *a, lvp.ctypes.data_as(C.c_void_p), lvp.size, lvd.ctypes.data_as(C.c_void_p), lvd.size,
+                  C.byref(ng), C.byref(tot))
+        off = (lvp.view(np.uint32) & 0x3FFFFFFF).astype(np.int64)
+        is_hub = ((lvp.view(np.uint32)[:-1] >> 30) & 1).astype(bool)
+        half = off[-1] + 16 * 64
+        assert tot.value == 2 * half and (lvd[off[-1]: half] == n * 8).all() and not (lvd == -12345).any()
+        first, clean = lvd[:half].view(np.uint32), lvd[half:].view(np.uint32)
+        seen = []
+        for k in range(ng.value):
+            raw, cl = first[off[k]: off[k + 1]], clean[off[k]: off[k + 1]]
+            rounds = raw.size // 64 - 2
+            assert rounds % 8 == 0 and rounds >= 0
+            assert np.array_equal(raw[:128], cl[:128]) and np.array_equal(raw[128:] & 0x7FFFFFFF, cl[128:]) and not (cl[128:] >> 31).any()
+            ent = np.empty((rounds, 64), dtype=np.uint32)
+            for r in range(rounds):
+                ent[r] = raw[128 + 512 * (r // 8) + 256 * ((r // 4) % 2) + 4 * np.arange(64) + r % 4]
+            h0, h1 = raw[0:128:2], raw[1:128:2]
+            if is_hub[k]:
+                i, p, d = int(h0[0] & 0xFFFFF), int(h1[0] & 0xFFFFF), int(raw[4])
+                assert order[p] == i and d == deg[i] > 128
+                nbrs = col[rp[i]: rp[i + 1]]
+                want = nbrs.astype(np.uint32) * 8 | np.where(pos_of[nbrs] > p, np.uint32(1 << 31), np.uint32(0))
+                flat = ent.reshape(-1)                                   # neighbour e in round e / 64 of lane e % 64
+                assert np.array_equal(np.sort(flat[:d]), np.sort(want)) and (flat[d:] == n * 8).all()
+                seen.append(p)
+                continue
+            ln = 0
+            while ln < 64 and (h0[ln] & 0xFFFFF) < n:
+                i, p, L = int(h0[ln] & 0xFFFFF), int(h1[ln] & 0xFFFFF), 1 << int((h0[ln] >> 28) & 3)
+                assert order[p] == i and ln % L == 0 and ((h0[ln: ln + L] & 0xFFFFF) == i).all()
+                assert int((h0[ln] >> 20) & 0xFF) == (deg[i] + 1) // 2 and bool(h0[ln] >> 31) == (deg[i] % 2 == 0)
+                nbrs = col[rp[i]: rp[i + 1]]
+                nfresh = int((pos_of[nbrs] > p).sum())
+                assert int((h1[ln] >> 20) & 0xFF) == (deg[i] + nfresh + 1) // 2 and bool(h1[ln] >> 31) == ((deg[i] + nfresh) % 2 == 0)
+                want = nbrs.astype(np.uint32) * 8 | np.where(pos_of[nbrs] > p, np.uint32(1 << 31), np.uint32(0))
+                got = np.concatenate([ent[:, ln + j] for j in range(L)])
+                got = got[got != n * 8]
+                assert np.array_equal(np.sort(got), np.sort(want))          # the row, dealt over its L lanes in any order, padding apart
+                for j in range(L):
+                    assert (ent[:, ln + j] != n * 8).sum() == len(nbrs[j::L])
+                seen.append(p)
+                ln += L
+            assert ((h0[ln:] & 0xFFFFF) >= n).all() and (ent[:, ln:] == n * 8).all()
+        assert sorted(seen) == list(range(n))
