@@ -77,8 +77,8 @@ ROWS = [
     (r"k_spin_step<float, true, true>", 1024 * 64, 1024, 16 * 200, "S1d spin_step_dense | per-env BA-200 matrices, 1024 envs (launch-bound; the flipped node's matrix row + the entries it changes)"),
     (r"k_spin_observation_rows<float, true>", 2 * 256 * 16384, 16384, 40 * N22, "S1 observation, rows only [B, 7, N] | G22-sized 2^14 (7 rows written, spins + immediate + last-flip read)"),
     (r"k_spin_observation_rows<float, true>", 1 * 256 * 4096, 4096, 40 * 200, "S1 observation, rows only [B, 7, N] | BA-200 4096"),
-    (r"k_mcpg_pack_f32x4", None, 262144, 4 * NBA + NBA // 8, "f32 [N, C] -> bit-packed chains (the shim of the reference-shaped MCPG calls) | BA-1e4 2^18"),
-    (r"k_mcpg_unpack<true, true, 2>", None, 262144, 4 * NBA + NBA // 8, "bit-packed chains -> f32 [N, C] (the shim of the reference-shaped MCPG calls) | BA-1e4 2^18"),
+    (r"k_mcpg_pack_f32x4", 41156608, 262144, 4 * NBA + NBA // 8, "f32 [N, C] -> bit-packed chains (the shim of the reference-shaped MCPG calls) | BA-1e4 2^18"),
+    (r"k_mcpg_unpack<true, true, 2>", 327680000, 262144, 4 * NBA + NBA // 8, "bit-packed chains -> f32 [N, C] (the shim of the reference-shaped MCPG calls) | BA-1e4 2^18"),
     (r"k_spin_observation<float, true>", 41 * 1024 * 256, 1024, 4 * (207 * 200 + 7 * 200 + 200 * 200), "S1d observation [B, 7+N, N] with per-env matrix rows | BA-200 1024"),
     (r"k_rand_couplings_ba<float>", 128 * 64, 1024, 4 * 200 * 200, "rand_couplings BA (m=4) | 1024 x BA-200 (a dependent chain per env: latency-bound)"),
     (r"k_qubo_ls_value", None, None, None, None),
