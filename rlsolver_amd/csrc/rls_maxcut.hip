@@ -562,8 +562,7 @@ __global__ __launch_bounds__(NSW * kWave) void k_node_stats_bits(const uint8_t* 
                                                                      const int32_t* __restrict__ ell, int mult,
                                                                      void* __restrict__ out_v, int32_t* __restrict__ minmax,
                                                                      int64_t out_pitch,     // row pitch of out_v in elements (MODE 2; N otherwise)
-                                                                     int stage_flags) {     // bit 0 clear: the tile alone fills LDS (N ~ 20 000): lane-per-env loads; bit 1: K3 with dword stores (A/B)
-    const int has_stage = stage_flags & 1;
+                                                                     int has_stage) {       // 0: the tile alone fills LDS (N ~ 20 000): lane-per-env loads
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* words = reinterpret_cast<uint64_t*>(smem);
     const int lane = threadIdx.x & (kWave - 1);
@@ -734,43 +733,11 @@ __global__ __launch_bounds__(NSW * kWave) void k_node_stats_bits(const uint8_t* 
                 continue;
             }
         }
-        if constexpr (MODE == 1) {
-            if (nenv == kWave && (N & 3) == 0 && !(stage_flags & 2)) {
-                // K3, full tile: the flip gains leave as 16-BYTE stores (round 5).  Per (half, r) a lane holds its node's counts for
-                // the 4 envs r, r + 8, r + 16, r + 24 of the half as bytes; the 4 x 4 byte transpose inside each lane quad (two DPP
-                // moves + two v_perm: the int8 weights' trick) turns that into the counts of 4 consecutive NODES of ONE env, which
-                // become deg - 2 c with the quad's four degrees (fetched once per group by DPP) -- 16 store instructions of 4 rows x
-                // 256 bytes per group where the dword stores took 64 of 256 bytes, and ~14 instead of ~20 VALU per 4 results
-                const uint32_t sel1 = (lane & 1) ? 0x03070105u : 0x06020400u, sel2 = (lane & 2) ? 0x03020706u : 0x05040100u;
-                int dq[4];
-                dq[0] = __builtin_amdgcn_mov_dpp(deg, 0x00, 0xF, 0xF, true);      // quad_perm [0,0,0,0]
-                dq[1] = __builtin_amdgcn_mov_dpp(deg, 0x55, 0xF, 0xF, true);      // [1,1,1,1]
-                dq[2] = __builtin_amdgcn_mov_dpp(deg, 0xAA, 0xF, 0xF, true);      // [2,2,2,2]
-                dq[3] = __builtin_amdgcn_mov_dpp(deg, 0xFF, 0xF, 0xF, true);      // [3,3,3,3]
-                typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
-                int32_t* const obase = reinterpret_cast<int32_t*>(out_v) + (b0 + (lane & 3) * 8) * N + ((g << 6) + (lane & ~3));
-                if (in) {      // (N % 4 == 0: a quad of nodes is inside the row or outside it as a whole)
-#pragma unroll
-                    for (int half = 0; half < 2; ++half) {
-#pragma unroll 2
-                        for (int r = 0; r < 8; ++r) {
-                            uint32_t v = md < 16 ? ns_extract4<4>(pl, half, r) : (md < 64 ? ns_extract4<6>(pl, half, r) : ns_extract4<8>(pl, half, r));
-                            uint32_t o = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);      // lane ^ 1
-                            v = __builtin_amdgcn_perm(o, v, sel1);
-                            o = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);               // lane ^ 2
-                            v = __builtin_amdgcn_perm(o, v, sel2);
-                            i32x4 q;
-                            q[0] = dq[0] - 2 * (int)(v & 0xFFu);
-                            q[1] = dq[1] - 2 * (int)((v >> 8) & 0xFFu);
-                            q[2] = dq[2] - 2 * (int)((v >> 16) & 0xFFu);
-                            q[3] = dq[3] - 2 * (int)(v >> 24);
-                            *reinterpret_cast<i32x4*>(obase + (int64_t)(half * 32 + r) * N) = q;
-                        }
-                    }
-                }
-                continue;
-            }
-        }
+        // (K3 with 16-BYTE stores -- the int8 weights' quad transpose applied to the int32 gains, 16 store instructions of 4 rows x
+        // 256 bytes per group instead of 64 of 256 bytes, ~30 % fewer VALU -- was built and measured in round 5: G22 2^16 164.6 ->
+        // 161.8 us, G70 2^17 1647 -> 1719, BA-1e4 1099 -> 1083: nothing.  K3 sits at what its WRITE PATTERN reaches on this pool --
+        // 64 rows x 256-byte pieces, rows 4N bytes apart and every other one starting mid-line: 4.0 TB/s in isolation
+        // (tools/ceilings/store_width.hip) -- not at an instruction bound)
         if (nenv == kWave) {
             // full tile: no per-store guards (each cost a scalar compare / exec save / branch around a 4-instruction store)
             if (in) {
@@ -984,7 +951,7 @@ static int launch_node_stats_bits(const rls_graph* g, const uint8_t* x, int64_t 
         if (lds > 64 * 1024)                                                                                        \
             ensure_dyn_lds((const void*)kern, lds);     \
         hipLaunchKernelGGL(kern, grid, block, lds, as_stream(stream), x, B, N, rowptr, ell_ptr, ell, mult, out, minmax, \
-                           out_pitch > 0 ? out_pitch : N, has_stage | (knob(KN_NS_WIDE_STORE, 1) != 0 ? 0 : 2));           \
+                           out_pitch > 0 ? out_pitch : N, has_stage);                                               \
     } while (0)
     if (four) {
         if (vec) RLS_NS_LAUNCH((k_node_stats_bits<MODE, true, false, WT, 4>));
