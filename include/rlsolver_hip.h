@@ -520,7 +520,12 @@ typedef struct rls_chain_ids {
 int rls_mcpg_metro_rounds(void* samples, const void* samples_in, int64_t C_in, int spin_bytes, int64_t N, int64_t C,
                           const float* probs, int64_t T, int64_t t_offset, const int64_t* index, const float* u,
                           uint64_t seed, const int64_t* t_limit_dev, int write_back, int64_t* accepts, int64_t accept_rows,
-                          const rls_chain_ids* chain_ids, void* stream);
+                          const rls_chain_ids* chain_ids, void* scratch, int64_t scratch_bytes, void* stream);
+/* ABI v11: `scratch` (device, may be NULL) of at least rls_mcpg_metro_scratch_bytes(N, C) bytes lets the bit-packed walk keep its
+ * draw windows (32 KB per 64-chain tile) in L2-resident global memory instead of LDS where that makes room for a second workgroup
+ * per CU (N = 10^4: the tile alone is 80 KB); 0 from the query = the windows stay in LDS and scratch is ignored.  Contents are
+ * undefined afterwards; results do not depend on it. */
+int64_t rls_mcpg_metro_scratch_bytes(int64_t N, int64_t C);
 
 /* The stop rule between two chunks of rls_mcpg_metro_rounds (MCPG.py:103,115: the reference compares `count` with
  * total_mcmc_num * max_transfer_time on the host after every round), one small launch instead of a chain of [T]-sized torch ops:

@@ -104,7 +104,7 @@ SIGNATURES = {
     "rls_spin_reset": [_G, _SE, _INT, _I64, C.c_int32, _P, _F64, _I64, _P],
     "rls_spin_step": [_G, _SE, _INT, _I64, C.c_int32, _P, _P, _P, _P, _F64, _F64, C.c_int32, _F64, _I64, C.c_int32, _F64,
                       C.c_int32, _F64, _P],
-    "rls_mcpg_metro_rounds": [_P, _P, _I64, _INT, _I64, _I64, _P, _I64, _I64, _P, _P, _U64, _P, _INT, _P, _I64, _P, _P],
+    "rls_mcpg_metro_rounds": [_P, _P, _I64, _INT, _I64, _I64, _P, _I64, _I64, _P, _P, _U64, _P, _INT, _P, _I64, _P, _P, _I64, _P],
     "rls_mcpg_metro_stop": [_P, _I64, _I64, _I64, C.c_int32, _I64, _P, _P, _P],
     "rls_mcpg_local_search": [_G, _P, _INT, _P, _I64, _P, _P, _I64, _I64, _P, _U64, _P, _I64, _P, _P, _P],
     "rls_mcpg_pick_best": [_P, _P, _INT, _I64, _I64, _I64, _I64, _P, _P, _P, _P],
@@ -138,6 +138,7 @@ PLAIN = {"rls_version": ([], _INT), "rls_device_count": ([], _INT), "rls_last_er
          "rls_maxcut_ls_rounds_supported": ([_G, C.c_int32], _INT),
          "rls_maxcut_node_stats_form": ([_G, _I64, C.c_int32], _INT),
          "rls_mcpg_metro_max_rounds": ([_I64, C.c_int32], _I64),
+         "rls_mcpg_metro_scratch_bytes": ([_I64, _I64], _I64),
          "rls_maxcut_ls_scratch_bytes": ([_G, _I64, C.c_int32, C.c_int32], _I64),
          "rls_maxcut_ls_slices": ([_G, _I64, C.c_int32], _INT)}
 

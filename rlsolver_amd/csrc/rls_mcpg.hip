@@ -221,7 +221,14 @@ __global__ __launch_bounds__(kMetroWaves * kWave) void k_mcpg_metro(T* samples, 
 constexpr int kMetroPW = 8;       // waves per workgroup
 constexpr int kMetroWin = 64;     // rounds per window
 
-template <bool GIVEN>   // GIVEN: the reference's recorded draws (tests); else the counter hash
+#ifdef RLS_K7_PROF   // dev build (RLS_EXTRA_CFLAGS=-DRLS_K7_PROF): cycles per wave at a level barrier / waiting for a header / in a group
+static __device__ unsigned long long g_k7_prof[2048 * 16 * 6];   // (k_mcpg_metro_packed: [workgroup][0] = total, walking, at the window barrier, windows)
+#define K7_NOW() __builtin_readcyclecounter()
+#endif
+
+// QG: the draw windows live in GLOBAL scratch (32 KB per workgroup, L2-resident) instead of LDS -- at N = 10^4 the tile is 80 KB and the
+// 32 KB of windows beside it left ONE workgroup per CU, i.e. one walking wave per CU; without them two fit (round 5: 1.00 -> 0.5x ms).
+template <bool GIVEN, bool QG = false>   // GIVEN: the reference's recorded draws (tests); else the counter hash
 __global__ __launch_bounds__(kMetroPW * kWave) void k_mcpg_metro_packed(uint64_t* __restrict__ samples,
                                                              const uint64_t* __restrict__ samples_in, int64_t tiles_in,
                                                              int64_t N, int64_t C, const float* __restrict__ probs,
@@ -229,16 +236,17 @@ __global__ __launch_bounds__(kMetroPW * kWave) void k_mcpg_metro_packed(uint64_t
                                                              const float* __restrict__ u, uint64_t seed,
                                                              const int64_t* __restrict__ t_limit_dev, int write_back,
                                                              unsigned long long* __restrict__ accepts_all, int64_t accept_rows, int64_t t_offset,
-                                                             ChainIds ids) {
+                                                             ChainIds ids, uint32_t* __restrict__ gqueue) {
     // accept counts go to row (workgroup % accept_rows) of [accept_rows][T_rounds]: thousands of workgroups adding into ONE row
     // serialise at the L2 atomic units (measured: 3/4 of the packed walk's time)
     unsigned long long* accepts = accepts_all ? accepts_all + (int64_t)((uint64_t)mcpg_tile() % (uint64_t)accept_rows) * T_rounds : nullptr;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* words = reinterpret_cast<uint64_t*>(smem);
-    uint32_t* queue = reinterpret_cast<uint32_t*>(smem + (size_t)((N + 1) & ~(int64_t)1) * 8);   // [2][kMetroWin][64]
     const int lane = threadIdx.x & (kWave - 1);
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     const int64_t tile = mcpg_tile();
+    uint32_t* queue = QG ? gqueue + tile * (2 * kMetroWin * kWave)
+                         : reinterpret_cast<uint32_t*>(smem + (size_t)((N + 1) & ~(int64_t)1) * 8);   // [2][kMetroWin][64]
     const int64_t c = tile * kWave + lane;
     const bool valid = c < C;
     const bool in_place = (samples_in == samples) && tiles_in == (int64_t)gridDim.x * gridDim.y;
@@ -254,12 +262,15 @@ __global__ __launch_bounds__(kMetroPW * kWave) void k_mcpg_metro_packed(uint64_t
                                                                     ((uint32_t)((uint64_t)gc >> 32) * 0x9E3779B1u)));
     const int64_t nwin = (t_end + kMetroWin - 1) / kMetroWin;
     auto produce = [&](int64_t win) {             // waves 1 .. PW-1 share the window's rounds
+        // A producer's rounds are a chain draw -> probs[] gather (an L2 round trip) -> verdicts; the NEXT round's draw and gather are
+        // issued before this round's verdicts, so a round trip hides behind the arithmetic of its neighbours.  (All ten gathers
+        // first, verdicts after, was measured in round 5 and is slower: the bursts take issue slots from the walker, 139 -> 171
+        // cycles per round; so is a per-node table of the two thresholds in place of the divisions: the 8-byte gather costs more
+        // than the divisions it saves.)
         uint32_t* q = queue + (win & 1) * (kMetroWin * kWave);
-        for (int r = w - 1; r < kMetroWin; r += kMetroPW - 1) {
+        auto draw = [&](int r, int64_t& i, float& uu, bool& live) {
             const int64_t t = win * kMetroWin + r;
-            const bool live = valid && t < t_end;
-            int64_t i;
-            float uu;
+            live = valid && r < kMetroWin && t < t_end;
             if constexpr (GIVEN) {
                 const int64_t at = live ? (t_offset + t) * C + c : 0;
                 i = index[at];
@@ -271,20 +282,36 @@ __global__ __launch_bounds__(kMetroPW * kWave) void k_mcpg_metro_packed(uint64_t
                 uu = u32_to_unit_float(r1);
             }
             i = live ? i : 0;
-            const float p = probs[i];
+        };
+        int64_t i, i_n;
+        float uu, uu_n;
+        bool live, live_n;
+        draw(w - 1, i, uu, live);
+        float p = probs[i];
+        for (int r = w - 1; r < kMetroWin; r += kMetroPW - 1) {
+            draw(r + kMetroPW - 1, i_n, uu_n, live_n);
+            const float p_n = probs[i_n];
             const float q1 = p, q0 = 1.0f - p;                    // torch.where(chosen_value, p, 1 - p)
             const bool a1 = uu < (1.0f - q1) / q1;                // MCPG.py:107 for a set bit
             const bool a0 = uu < (1.0f - q0) / q0;                //             for a clear bit
             // byte offset of the node's word | verdict for a set bit << 30 | verdict for a clear bit << 31: the walker
             // shifts left by the current bit and reads the sign
             q[r * kWave + lane] = live ? (((uint32_t)i << 3) | ((uint32_t)a1 << 30) | ((uint32_t)a0 << 31)) : 0u;
+            i = i_n; uu = uu_n; live = live_n; p = p_n;
         }
     };
     if (w > 0 && nwin > 0) produce(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const BitXpose xc = bit_xpose_consts(lane);
+#ifdef RLS_K7_PROF
+    unsigned long long pf_walk = 0, pf_sync = 0;
+    const unsigned long long pf_t0 = K7_NOW();
+#endif
     for (int64_t win = 0; win < nwin; ++win) {
+#ifdef RLS_K7_PROF
+        const unsigned long long pf_a = K7_NOW();
+#endif
         if (w == 0) {
             const uint32_t* q = queue + (win & 1) * (kMetroWin * kWave);
             const int rounds = (int)((t_end - win * kMetroWin) < kMetroWin ? (t_end - win * kMetroWin) : kMetroWin);
@@ -350,8 +377,21 @@ __global__ __launch_bounds__(kMetroPW * kWave) void k_mcpg_metro_packed(uint64_t
             produce(win + 1);
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#ifdef RLS_K7_PROF
+        const unsigned long long pf_b = K7_NOW();
+        pf_walk += pf_b - pf_a;
+#endif
         __syncthreads();
+#ifdef RLS_K7_PROF
+        pf_sync += K7_NOW() - pf_b;
+#endif
     }
+#ifdef RLS_K7_PROF
+    if (lane == 0 && blockIdx.x < 2048 && blockIdx.y == 0) {
+        unsigned long long* q = g_k7_prof + ((size_t)blockIdx.x * 16 + w) * 6;
+        q[0] = K7_NOW() - pf_t0; q[1] = pf_sync; q[2] = 0; q[3] = pf_walk; q[4] = (unsigned long long)nwin; q[5] = 0;
+    }
+#endif
     if (write_back) tile_store_packed(samples, N, tile, words, threadIdx.x, kMetroPW * kWave);
 }
 
@@ -779,11 +819,6 @@ __device__ __forceinline__ void lv_hub_counts(const uint64_t* words, const int32
 // a CU at N = 10^4 (2 x ~81.3 KB).
 // (two 8-wave workgroups per CU at N = 10^4 are 4 waves per SIMD: the second launch bound keeps the kernel at <= 128 registers --
 // without it the compiler spent 129 on the same code once a 64-bit division appeared in the prologue, and one workgroup per CU ran)
-#ifdef RLS_K7_PROF   // dev build (RLS_EXTRA_CFLAGS=-DRLS_K7_PROF): cycles per wave at a level barrier / waiting for a header / in a group
-static __device__ unsigned long long g_k7_prof[2048 * 16 * 6];
-#define K7_NOW() __builtin_readcyclecounter()
-#endif
-
 // (Requesting the next group's header BEFORE this group's work instead of after it -- ten more live registers, no spills once pass 0
 // kept one counter -- is SLOWER, 4.19 -> 4.40 ms: the per-wave cycle stamps of -DRLS_K7_PROF show a wave waiting 16 cycles per group
 // for its header, i.e. the request already hides under the level barrier, where a wave spends half its cycles.)
@@ -1447,7 +1482,7 @@ extern "C" {
 int rls_mcpg_metro_rounds(void* samples, const void* samples_in, int64_t C_in, int spin_bytes, int64_t N, int64_t C,
                           const float* probs, int64_t T, int64_t t_offset, const int64_t* index, const float* u,
                           uint64_t seed, const int64_t* t_limit_dev, int write_back, int64_t* accepts, int64_t accept_rows,
-                          const rls_chain_ids* chain_ids, void* stream) {
+                          const rls_chain_ids* chain_ids, void* scratch, int64_t scratch_bytes, void* stream) {
     RLS_REQUIRE(N > 0 && C >= 0 && T >= 0 && t_offset >= 0, RLS_EINVAL, "bad sizes N=%lld C=%lld T=%lld", (long long)N, (long long)C,
                 (long long)T);
     if (C == 0) return RLS_OK;
@@ -1467,13 +1502,23 @@ int rls_mcpg_metro_rounds(void* samples, const void* samples_in, int64_t C_in, i
                     "broadcast start state: C_in=%lld must be a multiple of 64 below C (and write_back set)", (long long)C_in);
         RLS_REQUIRE(samples_in != samples || C_in == C, RLS_EINVAL, "a broadcast start state cannot be updated in place");
         RLS_REQUIRE(N < (1 << 30), RLS_EUNSUPPORTED, "N=%lld: the packed walk keeps node ids in 30 bits", (long long)N);
-        const size_t lds = (size_t)((N + 1) & ~(int64_t)1) * 8 + (size_t)2 * kMetroWin * kWave * 4;
+        const size_t tile_b = (size_t)((N + 1) & ~(int64_t)1) * 8, win_b = (size_t)2 * kMetroWin * kWave * 4;
+        // the draw windows go to the caller's scratch where that lets a second workgroup share the CU (rls_mcpg_metro_scratch_bytes)
+        const int64_t need = rls_mcpg_metro_scratch_bytes(N, C);
+        const bool qg = need > 0 && scratch != nullptr && scratch_bytes >= need && knob(KN_METRO_QG, 1) != 0;
+        const size_t lds = tile_b + (qg ? 0 : win_b);
         RLS_REQUIRE(lds <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS (max %d)", (long long)N, lds, kLdsBytes);
-        auto kern = index ? k_mcpg_metro_packed<true> : k_mcpg_metro_packed<false>;
-        if (lds > 64 * 1024) ensure_dyn_lds((const void*)kern, lds);
-        hipLaunchKernelGGL(kern, cgrid, dim3(kMetroPW * kWave), lds, as_stream(stream),
-                           (uint64_t*)samples, (const uint64_t*)samples_in, ceil_div(C_in, kWave), N, C, probs, T, index, u, seed,
-                           t_limit_dev, write_back, (unsigned long long*)accepts, accept_rows, t_offset, ids);
+#define LAUNCH_MP(GV, QQ)                                                                                                      \
+    do {                                                                                                                       \
+        auto kern = k_mcpg_metro_packed<GV, QQ>;                                                                               \
+        if (lds > 64 * 1024) ensure_dyn_lds((const void*)kern, lds);                                                           \
+        hipLaunchKernelGGL(kern, cgrid, dim3(kMetroPW * kWave), lds, as_stream(stream), (uint64_t*)samples,                     \
+                           (const uint64_t*)samples_in, ceil_div(C_in, kWave), N, C, probs, T, index, u, seed, t_limit_dev,    \
+                           write_back, (unsigned long long*)accepts, accept_rows, t_offset, ids, (uint32_t*)scratch);         \
+    } while (0)
+        if (index) { if (qg) LAUNCH_MP(true, true); else LAUNCH_MP(true, false); }
+        else       { if (qg) LAUNCH_MP(false, true); else LAUNCH_MP(false, false); }
+#undef LAUNCH_MP
         return check_launch("k_mcpg_metro_packed");
     }
     RLS_REQUIRE(C_in == C, RLS_EINVAL, "a broadcast start state (C_in != C) needs the bit-packed layout");
@@ -1496,6 +1541,18 @@ int rls_mcpg_metro_rounds(void* samples, const void* samples_in, int64_t C_in, i
     else                 { if (probs_lds) LAUNCH_METRO(float, true);   else LAUNCH_METRO(float, false); }
 #undef LAUNCH_METRO
     return check_launch("k_mcpg_metro");
+}
+
+// scratch the bit-packed walk wants for its draw windows (0: they stay in LDS): used when the tile + windows leave one workgroup per
+// CU but two tiles alone fit -- 32 KB per 64-chain tile of the launch
+int64_t rls_mcpg_metro_scratch_bytes(int64_t N, int64_t C) {
+    if (N <= 0 || C <= 0) return 0;
+    const size_t tile_b = (size_t)((N + 1) & ~(int64_t)1) * 8, win_b = (size_t)2 * kMetroWin * kWave * 4;
+    const bool two_with = 2 * (tile_b + win_b) <= (size_t)kLdsBytes, two_without = 2 * tile_b <= (size_t)kLdsBytes;
+    const bool fits_with = tile_b + win_b <= (size_t)kLdsBytes;
+    if ((two_with || !two_without) && fits_with) return 0;
+    if (tile_b > (size_t)kLdsBytes) return 0;
+    return ceil_div(C, kWave) * (int64_t)win_b;
 }
 
 // rounds one rls_mcpg_metro_rounds launch can take WITH accept counts (they sit in LDS beside the tile in the node-major

@@ -508,7 +508,7 @@ struct ChainIdsArg {
 };
 void mcpg_metro_rounds(Tensor samples, const OptTensor& samples_in, int64_t C_in, int64_t C, const Tensor& probs, int64_t T,
                        int64_t t_offset, const OptTensor& index, const OptTensor& u, int64_t seed, const OptTensor& t_limit, bool write_back,
-                       const OptTensor& accepts, int64_t chain_offset, int64_t chain_period, int64_t chain_skip) {
+                       const OptTensor& accepts, int64_t chain_offset, int64_t chain_period, int64_t chain_skip, const OptTensor& scratch) {
     const ChainIdsArg cid(chain_offset, chain_period, chain_skip);
     const int sb = chain_bytes(samples, "samples");
     const int64_t N = chain_nodes(samples, sb, "samples");
@@ -533,10 +533,17 @@ void mcpg_metro_rounds(Tensor samples, const OptTensor& samples_in, int64_t C_in
         TORCH_CHECK((accepts->dim() == 1 || accepts->dim() == 2) && accepts->size(-1) == T, "accepts must be [T] or [rows, T]");
         if (accepts->dim() == 2) accept_rows = accepts->size(0);
     }
+    int64_t scratch_bytes = 0;
+    if (scratch.has_value()) {
+        dev(*scratch, "scratch");
+        same_device(samples, *scratch, "scratch");
+        TORCH_CHECK(scratch->is_contiguous(), "scratch must be contiguous");
+        scratch_bytes = (int64_t)scratch->nbytes();
+    }
     RLS_GUARD(samples);
     ok(rls_mcpg_metro_rounds(p(samples), p(samples_in), C_in, sb, N, C, (const float*)p(probs), T, t_offset, (const int64_t*)p(index),
                              (const float*)p(u), (uint64_t)seed, (const int64_t*)p(t_limit), write_back, (int64_t*)p(accepts), accept_rows,
-                             cid.ptr(), cur_stream(samples)),
+                             cid.ptr(), p(scratch), scratch_bytes, cur_stream(samples)),
        "rls_mcpg_metro_rounds");
 }
 void mcpg_metro_stop(const Tensor& accepts, int64_t target, int64_t first, int64_t next_T, Tensor ctl, const OptTensor& apply_limit) {
@@ -871,7 +878,8 @@ TORCH_LIBRARY(rlsolver_hip, m) {
           "float max_local, float termination_value, int reward_mode, float reward_div, int hist_len, bool use_stag, "
           "float stag_punishment, bool use_basin, float basin_reward) -> ()");
     m.def("mcpg_metro_rounds(Tensor(a!) samples, Tensor? samples_in, int C_in, int C, Tensor probs, int T, int t_offset, Tensor? index, "
-          "Tensor? u, int seed, Tensor? t_limit, bool write_back, Tensor(b!)? accepts, int chain_offset=0, int chain_period=0, int chain_skip=0) -> ()");
+          "Tensor? u, int seed, Tensor? t_limit, bool write_back, Tensor(b!)? accepts, int chain_offset=0, int chain_period=0, int chain_skip=0, "
+          "Tensor(c!)? scratch=None) -> ()");
     m.def("mcpg_metro_stop(Tensor accepts, int target, int first, int next_T, Tensor(a!) ctl, Tensor(b!)? apply_limit) -> ()");
     m.def("mcpg_local_search(int graph, Tensor xs_in, Tensor(a!) xs_out, Tensor order, Tensor? visit_stream, int num_ls, Tensor? uniforms, "
           "int seed, Tensor? edge_weights, int gauge_node, Tensor(b!) expected, int chain_offset=0, int chain_period=0, int chain_skip=0) -> ()");

@@ -221,17 +221,18 @@ def _walk_chunks(samples, start, probs: TEN, max_transfer_time: int, Tmax: int, 
     accepts = torch.zeros((len(starts), ACCEPT_ROWS, chunk), dtype=torch.int64, device=device)
     ctl = torch.empty(3, dtype=torch.int64, device=device)            # {accepts so far, live, limit of the next dry pass}
     apply_limit = torch.empty(1, dtype=torch.int64, device=device)
+    scratch = mops.metro_scratch(N, Cc, device) if sb == 0 else None     # the packed walk's draw windows, one buffer for every chunk
     for k, (t0, tk) in enumerate(zip(starts, sizes)):
         acc = accepts[k] if tk == chunk else accepts[k].reshape(-1)[: ACCEPT_ROWS * tk].view(ACCEPT_ROWS, tk)
         next_tk = sizes[k + 1] if k + 1 < len(sizes) else 0
         if t0 + tk <= max(1, max_transfer_time):                       # inside the first T rounds: direct
             mops.mcpg_metro_rounds(samples, probs, tk, index, u, seed, None, True, acc, t_offset=t0,
-                                   samples_in=None if (k > 0 or samples is start) else start, chain_ids=chain_ids)
+                                   samples_in=None if (k > 0 or samples is start) else start, chain_ids=chain_ids, scratch=scratch)
             mops.mcpg_metro_stop(counts(acc), target, 1 if k == 0 else 2, next_tk, ctl)
         else:
-            mops.mcpg_metro_rounds(samples, probs, tk, index, u, seed, ctl[2:3], False, acc, t_offset=t0, chain_ids=chain_ids)
+            mops.mcpg_metro_rounds(samples, probs, tk, index, u, seed, ctl[2:3], False, acc, t_offset=t0, chain_ids=chain_ids, scratch=scratch)
             mops.mcpg_metro_stop(counts(acc), target, 0, next_tk, ctl, apply_limit)
-            mops.mcpg_metro_rounds(samples, probs, tk, index, u, seed, apply_limit, True, None, t_offset=t0, chain_ids=chain_ids)
+            mops.mcpg_metro_rounds(samples, probs, tk, index, u, seed, apply_limit, True, None, t_offset=t0, chain_ids=chain_ids, scratch=scratch)
 
 
 def metro_sampling_packed(probs: TEN, start: PackedChains, max_transfer_time: int, num_chains: Optional[int] = None,

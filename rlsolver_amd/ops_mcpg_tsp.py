@@ -76,7 +76,7 @@ def _chain_ids(chain_ids) -> tuple:
 
 def mcpg_metro_rounds(samples, probs: TEN, T: int, index: Optional[TEN] = None, u: Optional[TEN] = None,
                       seed: int = 0, t_limit: Optional[TEN] = None, write_back: bool = True,
-                      accepts: Optional[TEN] = None, t_offset: int = 0, samples_in=None, chain_ids=None) -> None:
+                      accepts: Optional[TEN] = None, t_offset: int = 0, samples_in=None, chain_ids=None, scratch: Optional[TEN] = None) -> None:
     """K9 (see include/rlsolver_hip.h).  samples [N, C] f32/uint8 or PackedChains, in place, or read from
     ``samples_in`` (same layout; a PackedChains with fewer chains -- a multiple of 64 -- is broadcast) and written to
     ``samples``.  ``chain_ids`` = (offset, period, skip): the global ids of a shard's chains (rls_chain_ids)."""
@@ -106,8 +106,18 @@ def mcpg_metro_rounds(samples, probs: TEN, T: int, index: Optional[TEN] = None, 
             raise ValueError("samples_in must have the layout and node count of samples")
         if not write_back:
             raise ValueError("samples_in needs write_back")
+    if scratch is None and sb == 0:     # the packed walk's draw windows (include/rlsolver_hip.h: rls_mcpg_metro_scratch_bytes)
+        scratch = metro_scratch(N, Cc, dev)
     _t.mcpg_metro_rounds(st, sin, c_in, Cc, probs, T, t_offset, index, u, _s64(seed), t_limit, bool(write_back), accepts,
-                         *_chain_ids(chain_ids))
+                         *_chain_ids(chain_ids), scratch)
+
+
+def metro_scratch(N: int, C: int, device) -> Optional[TEN]:
+    """The scratch the bit-packed walk wants at this size (None: it keeps its draw windows in LDS).  A caller that walks in chunks
+    allocates it once and passes it to every mcpg_metro_rounds call."""
+    from . import _abi
+    need = int(_abi.lib().rls_mcpg_metro_scratch_bytes(int(N), int(C)))
+    return torch.empty(need, dtype=torch.uint8, device=device) if need > 0 else None
 
 
 def mcpg_metro_max_rounds(N: int, spin_bytes: int) -> int:
