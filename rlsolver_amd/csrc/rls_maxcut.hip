@@ -287,6 +287,86 @@ __global__ __launch_bounds__(SW * kWave) void k_maxcut_greedy_sweep_levels32(
     if (w == 0 && lane < kHalf && b0 + lane < B) obj[b0 + lane] = halve ? (after >> 1) : after;
 }
 
+// ---- K1 / K6 / K5 on NARROW tiles (rls_tile32.h: 16 or 8 envs per workgroup, WT = uint16_t / uint8_t words -- 2 N / N bytes of LDS):
+// graphs past the half tile, N > ~40 000 up to ~80 000 / ~160 000 nodes, which ran ONE ENV PER WAVE on a byte row until round 5
+// (K5 120 ms, local_search_inplace 158 ms for 4096 envs at N = 44 000 against 0.4 / 2.5 ms at N = 39 936).  Same steps, same
+// schedules, same counters as the half-tile kernels; 8 waves per workgroup.
+constexpr int kNarrowWaves = 8;
+template <typename WT> __host__ __device__ constexpr size_t narrow_words_bytes(int64_t N) { return (((size_t)(N + 2) * sizeof(WT)) + 15) & ~(size_t)15; }
+
+template <typename T, bool VEC, int P, typename WT>
+__global__ __launch_bounds__(kNarrowWaves * kWave) void k_maxcut_obj_n(const T* __restrict__ x, int64_t B, int64_t N,
+                                                                      const int32_t* __restrict__ eu, const int32_t* __restrict__ ev, int64_t E,
+                                                                      int halve, int64_t* __restrict__ obj) {
+    constexpr int W = kNarrowWaves, EN = narrow_tile<WT>::E;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    WT* words = reinterpret_cast<WT*>(smem);
+    int64_t* scratch = reinterpret_cast<int64_t*>(smem + narrow_words_bytes<WT>(N));
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    const int64_t b0 = (int64_t)blockIdx.x * EN;
+    tilen_load_bits<T, WT, VEC>(x, B, N, b0, words, lane, w, W);
+    __syncthreads();
+    int64_t total = block_sum_partials<W>(tile32_cut_count<P, WT>(words, eu, ev, E, lane, w, W), scratch, lane, w);
+    if (halve) total >>= 1;
+    if (w == 0 && lane < EN && b0 + lane < B) obj[b0 + lane] = total;
+}
+
+// (a bit-packed mask stays uint64 [ceil(B / 64), N]: narrow tile h takes piece h % (64 / E) of word (h / (64 / E), n))
+template <bool VEC, int P, typename WT, bool MASK_BITS>
+__global__ __launch_bounds__(kNarrowWaves * kWave) void k_maxcut_propose_accept_n(uint8_t* __restrict__ x, const uint8_t* __restrict__ mask,
+                                                                                 int64_t B, int64_t N, const int32_t* __restrict__ eu,
+                                                                                 const int32_t* __restrict__ ev, int64_t E, int halve,
+                                                                                 int64_t* __restrict__ obj) {
+    constexpr int W = kNarrowWaves, EN = narrow_tile<WT>::E, NB = narrow_tile<WT>::NB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    WT* words = reinterpret_cast<WT*>(smem);
+    int64_t* scratch = reinterpret_cast<int64_t*>(smem + narrow_words_bytes<WT>(N));
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    const int64_t b0 = (int64_t)blockIdx.x * EN;
+    tilen_load_bits<uint8_t, WT, VEC>(x, B, N, b0, words, lane, w, W);
+    if constexpr (MASK_BITS) {
+        __syncthreads();
+        const WT* mw = reinterpret_cast<const WT*>(mask) + ((int64_t)(blockIdx.x / NB) * N) * NB + (blockIdx.x % NB);
+        for (int64_t n = threadIdx.x; n < N; n += W * kWave) words[n] = (WT)(words[n] ^ mw[n * NB]);
+    } else {
+        tilen_load_bits<uint8_t, WT, VEC, true>(mask, B, N, b0, words, lane, w, W);
+    }
+    __syncthreads();
+    int64_t total = block_sum_partials<W>(tile32_cut_count<P, WT>(words, eu, ev, E, lane, w, W), scratch, lane, w);
+    if (halve) total >>= 1;
+    const int64_t b = b0 + (lane % EN);
+    const bool accept = (b < B) && (total >= obj[b]);     // (lanes >= E hold 0: they take their env's verdict below)
+    const bool acc_env = (bool)((ballot64(accept && lane < EN) >> (lane % EN)) & 1ull);
+    __syncthreads();                                      // every wave has read obj[b] before wave 0 updates it
+    if (acc_env && w == 0 && lane < EN) obj[b] = total;
+    tilen_store_bytes<WT, VEC>(x, B, N, b0, words, lane, w, W, acc_env);
+}
+
+template <bool VEC, int P, typename WT>
+__global__ __launch_bounds__(kNarrowWaves * kWave) void k_maxcut_greedy_sweep_levels_n(
+    uint8_t* __restrict__ x, int64_t B, int64_t N, const int32_t* __restrict__ lv_ptr, const int32_t* __restrict__ lv_data, int64_t G,
+    const int32_t* __restrict__ eu, const int32_t* __restrict__ ev, int64_t E, int halve, int64_t* __restrict__ obj) {
+    constexpr int SW = kNarrowWaves, EN = narrow_tile<WT>::E;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    WT* words = reinterpret_cast<WT*>(smem);
+    const size_t wbytes = narrow_words_bytes<WT>(N);
+    int32_t* lvp = reinterpret_cast<int32_t*>(smem + wbytes);
+    int64_t* scratch = reinterpret_cast<int64_t*>(smem + wbytes + (((size_t)(G + 1) * 4 + 15) & ~(size_t)15));
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    const int64_t b0 = (int64_t)blockIdx.x * EN;
+    if (threadIdx.x == 0) words[N] = 0;
+    for (int64_t i = threadIdx.x; i <= G; i += SW * kWave) lvp[i] = lv_ptr[i];
+    tilen_load_bits<uint8_t, WT, VEC>(x, B, N, b0, words, lane, w, SW);
+    __syncthreads();
+    sweep32_tile_levels<SW, WT>(words, lvp, lv_data, G, N, lane, w);
+    tilen_store_bytes<WT, VEC>(x, B, N, b0, words, lane, w, SW, true);
+    const int64_t after = block_sum_partials<SW>(tile32_cut_count<P, WT>(words, eu, ev, E, lane, w, SW), scratch, lane, w);
+    if (w == 0 && lane < EN && b0 + lane < B) obj[b0 + lane] = halve ? (after >> 1) : after;
+}
+
 // generic fallback (weighted graphs, hubs with degree > kSweepMaxDeg): one global row fetch per node
 template <bool VEC, bool WEIGHTED>
 __global__ __launch_bounds__(kWave) void k_maxcut_greedy_sweep_generic(uint8_t* __restrict__ x, int64_t B, int64_t N,
@@ -1297,6 +1377,35 @@ int rls_maxcut_obj(const rls_graph* g, const void* x, int spin_bytes, int64_t B,
             return check_launch("k_maxcut_obj32");
         }
     }
+    if (lds > (size_t)kLdsBytes && knob(KN_NARROW_TILE, 1) != 0) {   // neither the 64-env nor the half tile fits: 16 or 8 envs per workgroup
+        const int Pn = pick_planes(E) == 12 ? 16 : pick_planes(E);
+        const bool vecn = tile_rows_aligned(x, N, spin_bytes);
+        const int hv = g->if_bidirectional ? 1 : 0;
+        const size_t l16 = narrow_words_bytes<uint16_t>(N) + (size_t)kNarrowWaves * kWave * 8, l8 = narrow_words_bytes<uint8_t>(N) + (size_t)kNarrowWaves * kWave * 8;
+        if (Pn != 0 && l8 <= (size_t)kLdsBytes) {
+            const bool w16 = l16 <= (size_t)kLdsBytes;
+            const size_t ln = w16 ? l16 : l8;
+            const dim3 gn((unsigned)ceil_div(B, (int64_t)(w16 ? 16 : 8))), bn(kNarrowWaves * kWave);
+#define LAUNCH_OBJN(T, VEC, PP)                                                                                         \
+    do {                                                                                                                \
+        if (w16) { auto kern = k_maxcut_obj_n<T, VEC, PP, uint16_t>; ensure_dyn_lds((const void*)kern, ln);             \
+                   hipLaunchKernelGGL(kern, gn, bn, ln, as_stream(stream), (const T*)x, B, N, g->eu, g->ev, E, hv, obj); } \
+        else     { auto kern = k_maxcut_obj_n<T, VEC, PP, uint8_t>; ensure_dyn_lds((const void*)kern, ln);              \
+                   hipLaunchKernelGGL(kern, gn, bn, ln, as_stream(stream), (const T*)x, B, N, g->eu, g->ev, E, hv, obj); } \
+    } while (0)
+#define DISPATCH_PN(T, VEC)                        \
+    switch (Pn) {                                  \
+        case 16: LAUNCH_OBJN(T, VEC, 16); break;   \
+        case 20: LAUNCH_OBJN(T, VEC, 20); break;   \
+        default: LAUNCH_OBJN(T, VEC, 24); break;   \
+    }
+            if (spin_bytes == 1) { if (vecn) { DISPATCH_PN(uint8_t, true) } else { DISPATCH_PN(uint8_t, false) } }
+            else { DISPATCH_PN(float, false) }
+#undef DISPATCH_PN
+#undef LAUNCH_OBJN
+            return check_launch("k_maxcut_obj_n");
+        }
+    }
     if (lds > (size_t)kLdsBytes) {   // neither tile fits: one env per wave on a byte row
         const int rw = rows_waves(N);
         RLS_REQUIRE(rw > 0, RLS_EUNSUPPORTED, "N=%lld: a row of %lld bytes does not fit LDS (max %d)", (long long)N, (long long)N, kLdsBytes);
@@ -1404,6 +1513,35 @@ int rls_maxcut_propose_accept(const rls_graph* g, uint8_t* x, int64_t B, const v
 #undef DISPATCH_P32
 #undef LAUNCH_PA32
             return check_launch("k_maxcut_propose_accept32");
+        }
+    }
+    if (lds > (size_t)kLdsBytes && knob(KN_NARROW_TILE, 1) != 0) {   // neither the 64-env nor the half tile fits: 16 or 8 envs per workgroup
+        const int Pn = pick_planes(E) == 12 ? 16 : pick_planes(E);
+        const bool vecn = tile_rows_aligned(x, N, 1) && (mask_bits || tile_rows_aligned(mask, N, 1));
+        const int hv = g->if_bidirectional ? 1 : 0;
+        const size_t l16 = narrow_words_bytes<uint16_t>(N) + (size_t)kNarrowWaves * kWave * 8, l8 = narrow_words_bytes<uint8_t>(N) + (size_t)kNarrowWaves * kWave * 8;
+        if (Pn != 0 && l8 <= (size_t)kLdsBytes) {
+            const bool w16 = l16 <= (size_t)kLdsBytes;
+            const size_t ln = w16 ? l16 : l8;
+            const dim3 gn((unsigned)ceil_div(B, (int64_t)(w16 ? 16 : 8))), bn(kNarrowWaves * kWave);
+#define LAUNCH_PAN(VEC, PP, MB)                                                                                          \
+    do {                                                                                                                \
+        if (w16) { auto kern = k_maxcut_propose_accept_n<VEC, PP, uint16_t, MB>; ensure_dyn_lds((const void*)kern, ln); \
+                   hipLaunchKernelGGL(kern, gn, bn, ln, as_stream(stream), x, mask, B, N, g->eu, g->ev, E, hv, obj); }  \
+        else     { auto kern = k_maxcut_propose_accept_n<VEC, PP, uint8_t, MB>; ensure_dyn_lds((const void*)kern, ln);  \
+                   hipLaunchKernelGGL(kern, gn, bn, ln, as_stream(stream), x, mask, B, N, g->eu, g->ev, E, hv, obj); }  \
+    } while (0)
+#define DISPATCH_PN(VEC, MB)                       \
+    switch (Pn) {                                  \
+        case 16: LAUNCH_PAN(VEC, 16, MB); break;   \
+        case 20: LAUNCH_PAN(VEC, 20, MB); break;   \
+        default: LAUNCH_PAN(VEC, 24, MB); break;   \
+    }
+            if (mask_bits) { if (vecn) { DISPATCH_PN(true, true) } else { DISPATCH_PN(false, true) } }
+            else { if (vecn) { DISPATCH_PN(true, false) } else { DISPATCH_PN(false, false) } }
+#undef DISPATCH_PN
+#undef LAUNCH_PAN
+            return check_launch("k_maxcut_propose_accept_n");
         }
     }
     if (lds > (size_t)kLdsBytes) {   // neither tile fits: one env per wave on a byte row
@@ -1523,6 +1661,33 @@ int rls_maxcut_greedy_sweep(const rls_graph* g, uint8_t* x, int64_t B, int64_t* 
 #undef DISPATCH_SWL32_P
 #undef LAUNCH_SWL32
                 return check_launch("k_maxcut_greedy_sweep_levels32");
+            }
+            // the half tile does not fit either: 16 or 8 envs per workgroup (the same level schedule)
+            const int Pn = P == 12 ? 16 : P;
+            auto ldsn_of = [&](size_t wb) { return wb + (((size_t)(G + 1) * 4 + 15) & ~(size_t)15) + (size_t)kNarrowWaves * kWave * 8; };
+            const size_t l16 = ldsn_of(narrow_words_bytes<uint16_t>(N)), l8 = ldsn_of(narrow_words_bytes<uint8_t>(N));
+            if (knob(KN_NARROW_TILE, 1) != 0 && l8 <= (size_t)kLdsBytes) {
+                const bool w16 = l16 <= (size_t)kLdsBytes;
+                const size_t ln = w16 ? l16 : l8;
+                const dim3 gn((unsigned)ceil_div(B, (int64_t)(w16 ? 16 : 8))), bn(kNarrowWaves * kWave);
+                const int hv = g->if_bidirectional ? 1 : 0;
+#define LAUNCH_SWLN(VEC, PP)                                                                                                       \
+    do {                                                                                                                           \
+        if (w16) { auto kern = k_maxcut_greedy_sweep_levels_n<VEC, PP, uint16_t>; ensure_dyn_lds((const void*)kern, ln);           \
+                   hipLaunchKernelGGL(kern, gn, bn, ln, s, x, B, N, g->sweep_lv_ptr, g->sweep_lv_data, G, g->eu, g->ev, E, hv, obj); } \
+        else     { auto kern = k_maxcut_greedy_sweep_levels_n<VEC, PP, uint8_t>; ensure_dyn_lds((const void*)kern, ln);            \
+                   hipLaunchKernelGGL(kern, gn, bn, ln, s, x, B, N, g->sweep_lv_ptr, g->sweep_lv_data, G, g->eu, g->ev, E, hv, obj); } \
+    } while (0)
+#define DISPATCH_SWLN(VEC)                        \
+    switch (Pn) {                                 \
+        case 16: LAUNCH_SWLN(VEC, 16); break;     \
+        case 20: LAUNCH_SWLN(VEC, 20); break;     \
+        default: LAUNCH_SWLN(VEC, 24); break;     \
+    }
+                if (vec) { DISPATCH_SWLN(true) } else { DISPATCH_SWLN(false) }
+#undef DISPATCH_SWLN
+#undef LAUNCH_SWLN
+                return check_launch("k_maxcut_greedy_sweep_levels_n");
             }
         }
         if (!no_levels && !g->wgt && g->sweep_lv_ptr && g->sweep_lv_data && G > 0 && P != 0 && lds_l <= (size_t)kLdsBytes) {

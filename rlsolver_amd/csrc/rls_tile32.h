@@ -174,12 +174,122 @@ __device__ __forceinline__ void tile32_store_bytes(uint8_t* __restrict__ x, int6
     for (int64_t n = w; n < N; n += W) row[n] = (uint8_t)((words32[n] >> env) & 1u);
 }
 
+// ---- NARROW tiles (round 5): 16 or 8 envs per workgroup, words of 16 / 8 bits -- 2 N / N bytes of LDS, for graphs past the half tile
+// (N > ~40 000: up to ~80 000 / ~160 000 nodes).  The schedules, the counters and the compare are the half tile's (planes in 32-bit
+// registers whose upper bits stay zero); only the LDS word and the byte <-> bit corner turn differ: a wave still turns 64 x 64 bits
+// at a time, row l of the transpose = env l % E of node block l / E (E = 16: four blocks of 64 nodes per turn), so lane p ends
+// with the E-bit words of node p in 64 / E consecutive blocks.  Per env the work is 32 / E times the half tile's (the edge list and
+// the schedule are walked once per E envs) -- against one env per WAVE on a byte row, which these sizes fell to before.
+template <typename WT> struct narrow_tile {
+    static constexpr int E = 8 * (int)sizeof(WT);       // envs per tile
+    static constexpr int NB = 64 / E;                   // 64-node blocks per transpose
+    static constexpr uint32_t MASK = sizeof(WT) == 4 ? 0xFFFFFFFFu : ((1u << (E & 31)) - 1u);
+};
+
+template <typename WT, bool XORW> __device__ __forceinline__ void put_word_n(WT* words, int64_t n, uint32_t v) {
+    if constexpr (XORW) words[n] = (WT)((uint32_t)words[n] ^ v);
+    else words[n] = (WT)v;
+}
+
+// env-major bytes -> narrow bit tile.  VEC: rows are 16-byte multiples on a 16-byte base (each lane reads the 64 bytes of its (env,
+// block) itself); anything else takes one ballot per node.
+template <typename T, typename WT, bool VEC, bool XORW = false>
+__device__ __forceinline__ void tilen_load_bits(const T* __restrict__ x, int64_t B, int64_t N, int64_t b0, WT* __restrict__ words,
+                                                int lane, int w, int W) {
+    constexpr int E = narrow_tile<WT>::E, NB = narrow_tile<WT>::NB;
+    const int env = lane % E, blk = lane / E;
+    const int64_t b = b0 + env;
+    const bool valid = b < B;
+    if constexpr (VEC && sizeof(T) == 1) {
+        if ((N & 15) == 0) {
+            const uint8_t* xb = reinterpret_cast<const uint8_t*>(x);
+            const u32x4* rv = reinterpret_cast<const u32x4*>(xb + (valid ? b : 0) * N);
+            const int64_t nv = N >> 4;
+            const int64_t nchunk = (N + 64 * NB - 1) / (64 * NB);        // chunk = NB blocks of 64 nodes = one transpose
+            const BitXpose xc = bit_xpose_consts(lane);
+            for (int64_t ch = w; ch < nchunk; ch += W) {
+                u32x4 v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int64_t idx = (ch * NB + blk) * 4 + q;
+                    v[q] = (valid && idx < nv) ? rv[idx] : u32x4{0, 0, 0, 0};
+                }
+                uint32_t r0 = pack_bits(v[0], v[1]), r1 = pack_bits(v[2], v[3]);
+                bit_transpose64(r0, r1, xc);
+                // this lane: node xc.node of each of the NB blocks; rows k E .. k E + E - 1 of the turn = block k
+#pragma unroll
+                for (int k = 0; k < NB; ++k) {
+                    const uint32_t half = (k * E) < 32 ? r0 : r1;
+                    const uint32_t wd = (half >> ((k * E) & 31)) & narrow_tile<WT>::MASK;
+                    const int64_t n = (ch * NB + k) * 64 + xc.node;
+                    if (n < N) put_word_n<WT, XORW>(words, n, wd);
+                }
+            }
+            return;
+        }
+    }
+    const T* row = x + (valid ? b : 0) * N;
+    for (int64_t n0 = (int64_t)w * 64; n0 < N; n0 += (int64_t)W * 64) {
+        uint32_t mine = 0;
+        const int lim = (int)((N - n0) < 64 ? (N - n0) : 64);
+        for (int k = 0; k < lim; ++k) {
+            const T v = (valid && blk == 0) ? row[n0 + k] : T(0);
+            const uint32_t wd = (uint32_t)ballot64(spin_is_set(v)) & narrow_tile<WT>::MASK;
+            if (lane == k) mine = wd;
+        }
+        if (lane < lim) put_word_n<WT, XORW>(words, n0 + lane, mine);
+    }
+}
+
+// narrow bit tile -> env-major bytes (0 | 1); rows with store_row == false stay untouched (store_row: per lane, by lane % E)
+template <typename WT, bool VEC>
+__device__ __forceinline__ void tilen_store_bytes(uint8_t* __restrict__ x, int64_t B, int64_t N, int64_t b0, const WT* __restrict__ words,
+                                                  int lane, int w, int W, bool store_row) {
+    constexpr int E = narrow_tile<WT>::E, NB = narrow_tile<WT>::NB;
+    const int env = lane % E, blk = lane / E;
+    const int64_t b = b0 + env;
+    const bool valid = b < B && store_row;
+    uint8_t* row = x + (b < B ? b : 0) * N;
+    if constexpr (VEC) {
+        if ((N & 15) == 0) {
+            u32x4* rv = reinterpret_cast<u32x4*>(row);
+            const int64_t nv = N >> 4;
+            const int64_t nchunk = (N + 64 * NB - 1) / (64 * NB);
+            const BitXpose xc = bit_xpose_consts(lane);
+            for (int64_t ch = w; ch < nchunk; ch += W) {
+                uint32_t r0 = 0, r1 = 0;
+#pragma unroll
+                for (int k = 0; k < NB; ++k) {
+                    const int64_t n = (ch * NB + k) * 64 + xc.node;
+                    const uint32_t wd = (n < N) ? (uint32_t)words[n] : 0u;
+                    if ((k * E) < 32) r0 |= wd << ((k * E) & 31);
+                    else r1 |= wd << ((k * E) & 31);
+                }
+                bit_transpose64(r0, r1, xc);
+                u32x4 v[4];
+                unpack_bits(r0, v[0], v[1]);
+                unpack_bits(r1, v[2], v[3]);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int64_t idx = (ch * NB + blk) * 4 + q;
+                    if (valid && idx < nv) rv[idx] = v[q];
+                }
+            }
+            return;
+        }
+    }
+    if (!valid || blk != 0) return;
+    for (int64_t n = w; n < N; n += W) row[n] = (uint8_t)(((uint32_t)words[n] >> env) & 1u);
+}
+
 // K1 core on a half tile: every lane takes every 64th stored edge, XORs the two 32-env words and feeds a bit-sliced
 // Harley-Seal counter (rls_cutcount.h on 32-bit planes); the 64 lanes' counts are summed by transposing two planes at a time
 // across the wave (lanes 0..31 receive plane p of env lane, lanes 32..63 plane p + 1 of env lane - 32) and popcounting.
 // Returns, in lanes 0..31, wave w's partial count for env b0 + lane (lanes 32..63: 0).
-template <int P>
-__device__ __forceinline__ int64_t tile32_cut_count(const uint32_t* __restrict__ words32, const int32_t* __restrict__ eu,
+// (WT: the LDS word -- uint32_t for the half tile, uint16_t / uint8_t for the narrow tiles below, whose planes simply leave the upper
+// bits of the 32-bit registers zero: lanes beyond the tile's envs end with a count of 0)
+template <int P, typename WT = uint32_t>
+__device__ __forceinline__ int64_t tile32_cut_count(const WT* __restrict__ words32, const int32_t* __restrict__ eu,
                                                     const int32_t* __restrict__ ev, int64_t E, int lane, int w, int W) {
     constexpr int PL = (P - 5) < 5 ? 5 : (P - 5);           // per-lane count <= ceil(E / 64) < 2^(P - 5)
     constexpr int PLE = (PL + 1) & ~1;
@@ -218,9 +328,9 @@ __device__ __forceinline__ int64_t tile32_cut_count(const uint32_t* __restrict__
         for (int k = 0; k < 16; ++k) { u[k] = pu[k * kWave]; v[k] = pv[k * kWave]; }
         uint32_t dA[8], dB[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) dA[k] = words32[u[k]] ^ words32[v[k]];
+        for (int k = 0; k < 8; ++k) dA[k] = (uint32_t)words32[u[k]] ^ (uint32_t)words32[v[k]];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) dB[k] = words32[u[8 + k]] ^ words32[v[8 + k]];
+        for (int k = 0; k < 8; ++k) dB[k] = (uint32_t)words32[u[8 + k]] ^ (uint32_t)words32[v[8 + k]];
         block16(dA, dB);
     }
     if (nfull * BLK < E && (nfull % W) == w) {   // the ragged last block: clamped, unconditional loads, masked afterwards
@@ -236,7 +346,7 @@ __device__ __forceinline__ int64_t tile32_cut_count(const uint32_t* __restrict__
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             const int64_t e = nfull * BLK + k * kWave + lane;
-            const uint32_t d = (e < E) ? (words32[u[k]] ^ words32[v[k]]) : 0u;
+            const uint32_t d = (e < E) ? ((uint32_t)words32[u[k]] ^ (uint32_t)words32[v[k]]) : 0u;
             if (k < 8) dA[k] = d; else dB[k - 8] = d;
         }
         block16(dA, dB);
@@ -281,15 +391,20 @@ __device__ __forceinline__ uint32_t lv32_le_const(const uint32_t (&pl)[8], uint3
     return ~c0;
 }
 
-typedef const uint32_t __attribute__((address_space(3))) sweep_lds_cu32;
-__device__ __forceinline__ uint32_t sweep32_word_at(uint32_t a) { return *(sweep_lds_cu32*)(uintptr_t)a; }   // (the tile sits at LDS address 0)
+// the tile word of the node whose 64-bit-word byte offset is `nb` (the schedule's entries): the tile sits at LDS address 0
+template <typename WT>
+__device__ __forceinline__ uint32_t sweep32_word_at(uint32_t nb) {
+    typedef const WT __attribute__((address_space(3))) lds_cwt;
+    constexpr int SH = sizeof(WT) == 4 ? 1 : (sizeof(WT) == 2 ? 2 : 3);
+    return (uint32_t)*(lds_cwt*)(uintptr_t)(nb >> SH);
+}
 
-template <int NC>
+template <int NC, typename WT>
 __device__ __forceinline__ void sweep32_count_block(const uint32_t (&nb)[8], uint32_t own, uint32_t& ones, uint32_t& twos, uint32_t& fours,
                                                     uint32_t (&c)[5]) {
     uint32_t d[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) d[q] = sweep32_word_at(nb[q] >> 1) ^ own;   // padding = the node itself: 0
+    for (int q = 0; q < 8; ++q) d[q] = sweep32_word_at<WT>(nb[q]) ^ own;   // padding = the node itself: 0
     uint32_t twosA, twosB, foursA, foursB, carry;
     csa32(twosA, ones, ones, d[0], d[1]);
     csa32(twosB, ones, ones, d[2], d[3]);
@@ -307,15 +422,15 @@ __device__ __forceinline__ void sweep32_count_block(const uint32_t (&nb)[8], uin
 }
 
 // (rls_sweep.h: sweep_group_flips -- NB = the group's blocks when 1 or 2, 0 = the loop; blk = this lane's slab of block 2)
-template <int NB, int NC, int NP>
+template <int NB, int NC, int NP, typename WT>
 __device__ __forceinline__ uint32_t sweep32_group_flips(const int32_t* __restrict__ blk, int rounds, const uint32_t (&nb0)[8],
                                                         const uint32_t (&nb1)[8], uint32_t own, uint32_t thr, uint32_t lcode) {
     uint32_t ones = 0, twos = 0, fours = 0, c[5] = {0, 0, 0, 0, 0};
     if constexpr (NB == 1) {
-        sweep32_count_block<NC>(nb0, own, ones, twos, fours, c);
+        sweep32_count_block<NC, WT>(nb0, own, ones, twos, fours, c);
     } else if constexpr (NB == 2) {
-        sweep32_count_block<NC>(nb0, own, ones, twos, fours, c);
-        sweep32_count_block<NC>(nb1, own, ones, twos, fours, c);
+        sweep32_count_block<NC, WT>(nb0, own, ones, twos, fours, c);
+        sweep32_count_block<NC, WT>(nb1, own, ones, twos, fours, c);
     } else {
         uint32_t nb[8], nx[8];
 #pragma unroll
@@ -326,7 +441,7 @@ __device__ __forceinline__ uint32_t sweep32_group_flips(const int32_t* __restric
                 na = *reinterpret_cast<const u32x4*>(blk);
                 nbv = *reinterpret_cast<const u32x4*>(blk + 256);
             }
-            sweep32_count_block<NC>(nb, own, ones, twos, fours, c);
+            sweep32_count_block<NC, WT>(nb, own, ones, twos, fours, c);
 #pragma unroll
             for (int q = 0; q < 8; ++q) nb[q] = nx[q];
             nx[0] = na.x; nx[1] = na.y; nx[2] = na.z; nx[3] = na.w;
@@ -347,11 +462,12 @@ __device__ __forceinline__ uint32_t sweep32_group_flips(const int32_t* __restric
 
 // a hub: lane = neighbour, per-lane counters over its rounds, every plane transposed across the wave and popcounted (two planes
 // per transpose: lanes 0..31 get plane p of env lane, lanes 32..63 plane p + 1 of env lane - 32)
+template <typename WT>
 __device__ __forceinline__ uint32_t sweep32_hub_flips(const int32_t* __restrict__ ent, int rounds, const uint32_t (&nb0)[8], uint32_t own,
                                                       uint32_t deg, int lane) {     // ent = the record's entries (behind its 64 header words)
     uint32_t cv[8] = {0, 0, 0, 0, 0, 0, 0, 0};                      // rounds <= 64: 7 planes (+ 1 to pair them)
     auto add = [&](uint32_t off) {
-        uint32_t carry = sweep32_word_at(off >> 1) ^ own;
+        uint32_t carry = sweep32_word_at<WT>(off) ^ own;
 #pragma unroll
         for (int p = 0; p < 7; ++p) { const uint32_t t = cv[p] & carry; cv[p] ^= carry; carry = t; }
     };
@@ -368,11 +484,11 @@ __device__ __forceinline__ uint32_t sweep32_hub_flips(const int32_t* __restrict_
         cnt += (__builtin_popcount(r0) + __builtin_popcount(r1)) << (p + half);
     }
     cnt += __shfl_xor(cnt, 32, 64);
-    return (uint32_t)ballot64(lane < kHalf && (uint32_t)cnt <= (deg >> 1));
+    return (uint32_t)ballot64(lane < 8 * (int)sizeof(WT) && (uint32_t)cnt <= (deg >> 1));
 }
 
-template <int W>
-__device__ __forceinline__ void sweep32_tile_levels(uint32_t* words32, const int32_t* lvp, const int32_t* __restrict__ data, int64_t G,
+template <int W, typename WT = uint32_t>
+__device__ __forceinline__ void sweep32_tile_levels(WT* words32, const int32_t* lvp, const int32_t* __restrict__ data, int64_t G,
                                                     int64_t N, int lane, int w) {
     constexpr uint32_t M = 0x3fffffffu;
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)words32 != 0u) __builtin_trap();   // entries are LDS addresses (rls_sweep.h)
@@ -412,21 +528,21 @@ __device__ __forceinline__ void sweep32_tile_levels(uint32_t* words32, const int
         const int rounds = (int)((p1 - p0) >> 6) - 1;
         if (((uint32_t)__builtin_amdgcn_readlane(chunk, (int)(k & 63)) >> 30) & 1u) {
             const uint32_t hnode = (uint32_t)__builtin_amdgcn_readlane((int)hdr, 0), hdeg = (uint32_t)__builtin_amdgcn_readlane((int)hdr, 1);
-            const uint32_t hown = words32[hnode];
-            const uint32_t hflip = sweep32_hub_flips(data + p0 + 64, rounds, nb0, hown, hdeg, lane);
-            if (lane == 0) words32[hnode] = hown ^ hflip;
+            const uint32_t hown = (uint32_t)words32[hnode];
+            const uint32_t hflip = sweep32_hub_flips<WT>(data + p0 + 64, rounds, nb0, hown, hdeg, lane);
+            if (lane == 0) words32[hnode] = (WT)(hown ^ hflip);
             prefetch(k + W);
             continue;
         }
         const uint32_t node = hdr & 0xFFFFFu, thr = (hdr >> 20) & 0xFFu, lcode = (hdr >> 28) & 3u;
-        const uint32_t own = words32[node];
+        const uint32_t own = (uint32_t)words32[node];
         const int32_t* blk = data + p0 + 64 + 1024 + 4 * lane;      // this lane's slab of block 2
         uint32_t flip;
-        if (rounds == 8) flip = sweep32_group_flips<1, 1, 4>(blk, rounds, nb0, nb1, own, thr, lcode);
-        else if (rounds == 16) flip = sweep32_group_flips<2, 2, 5>(blk, rounds, nb0, nb1, own, thr, lcode);
-        else if (rounds <= 24) flip = sweep32_group_flips<0, 2, 5>(blk, rounds, nb0, nb1, own, thr, lcode);
-        else flip = sweep32_group_flips<0, 4, 7>(blk, rounds, nb0, nb1, own, thr, lcode);
-        if (node < (uint32_t)N && (lane & ((1 << lcode) - 1)) == 0) words32[node] = own ^ flip;
+        if (rounds == 8) flip = sweep32_group_flips<1, 1, 4, WT>(blk, rounds, nb0, nb1, own, thr, lcode);
+        else if (rounds == 16) flip = sweep32_group_flips<2, 2, 5, WT>(blk, rounds, nb0, nb1, own, thr, lcode);
+        else if (rounds <= 24) flip = sweep32_group_flips<0, 2, 5, WT>(blk, rounds, nb0, nb1, own, thr, lcode);
+        else flip = sweep32_group_flips<0, 4, 7, WT>(blk, rounds, nb0, nb1, own, thr, lcode);
+        if (node < (uint32_t)N && (lane & ((1 << lcode) - 1)) == 0) words32[node] = (WT)(own ^ flip);
         prefetch(k + W);
     }
     for (; passed < num_levels; ++passed) __syncthreads();

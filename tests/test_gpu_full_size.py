@@ -492,3 +492,54 @@ def test_half_tile_forms_at_scale(n, m, B):
     xl, vl = x.clone(), v.clone()
     env.local_search_inplace(xl, vl, num_iters=4, num_spin=8)
     assert bool((vl >= v).all()) and torch.equal(ops.maxcut_obj(g, xl), vl)
+
+
+@pytest.mark.parametrize("n,m,B,words", [(44000, 88000, 37, 16), (44008, 60000, 21, 16), (100000, 150000, 13, 8), (81003, 90000, 10, 8)])
+def test_narrow_tiles_past_the_half_tile_vs_c_oracle(n, m, B, words):
+    """Round 5: K1 / K6 / K5 past the half tile (N > ~40 000) run on NARROW tiles -- 16 envs per workgroup on uint16 words up to ~80 000
+    nodes, 8 envs on bytes up to ~160 000 -- instead of one env per wave on a byte row.  Against the C oracle, with rows that are and
+    are not 16-byte multiples (the ballot loader), ragged last tiles, a byte mask and a bit-packed one; the same calls with the
+    narrow tiles switched off (rls_tuning_set: the one-env-per-wave kernels) must give the same bits."""
+    from oracle import oracle_c as oc
+    from rlsolver_amd import _abi
+    from rlsolver_amd.envs.env_L2A import EnvMaxcut
+    from rlsolver_amd.graph import generate_gnm
+    from rlsolver_amd.ops_mcpg_tsp import PackedChains
+    mg = generate_gnm(n, m, n % 97)
+    garr = np.asarray(mg, dtype=np.int64)
+    env = EnvMaxcut(mygraph=mg, device=DEV, num_nodes=n)
+    eu, ev = onp.stored_edges(garr, False)
+    assert (n + 2) * 4 + 8 * 64 * 8 > 160 * 1024 and ((n + 2) * 2 + 4096 <= 160 * 1024) == (words == 16)
+    torch.manual_seed(n)
+    xs = env.generate_xs_randomly(B)
+    x_np = xs.cpu().numpy().astype(np.uint8)
+    mask = torch.rand((B, n), device=DEV) < 6.0 / n
+    res = {}
+    for narrow in (1, 0):
+        _abi.tuning_set("RLS_NARROW_TILE", narrow)
+        try:
+            vs = env.calculate_obj_values(xs)                                       # K1 (+ f32 spins: the ballot loader)
+            x6, v6 = xs.clone(), vs.clone()
+            ops.maxcut_propose_accept(env.graph, x6, mask, v6)                      # K6, byte mask
+            x5, v5 = xs[:5].clone(), vs[:5].clone()
+            ops.maxcut_greedy_sweep(env.graph, x5, v5)                              # K5
+            res[narrow] = (vs, env.calculate_obj_values(xs.float()), x6, v6, x5, v5)
+            if narrow and n % 16 == 0:                                              # K6, bit-packed mask (tile-major uint64 words)
+                xb, vb = xs.clone(), vs.clone()
+                ops.maxcut_propose_accept(env.graph, xb, PackedChains.pack(mask.t().contiguous().float()).words, vb)
+                assert torch.equal(xb, x6) and torch.equal(vb, v6)
+        finally:
+            _abi.tuning_unset("RLS_NARROW_TILE")
+    for a, b in zip(res[1], res[0]):
+        assert torch.equal(a, b)
+    vs, vf, x6, v6, x5, v5 = res[1]
+    assert np.array_equal(vs.cpu().numpy(), oc.maxcut_obj(x_np, eu, ev, 0)) and torch.equal(vf, vs)
+    prop = x_np ^ mask.cpu().numpy().astype(np.uint8)
+    pv = oc.maxcut_obj(prop, eu, ev, 0)
+    take = pv >= vs.cpu().numpy()
+    assert np.array_equal(v6.cpu().numpy(), np.where(take, pv, vs.cpu().numpy()))
+    assert np.array_equal(x6.cpu().numpy().astype(np.uint8), np.where(take[:, None], prop, x_np))
+    wx, wv = x_np[:3].copy(), vs[:3].cpu().numpy().copy()                          # (the oracle evaluates N full objectives per env)
+    oc.greedy_sweep(wx, wv, eu, ev, 0)
+    assert np.array_equal(x5[:3].cpu().numpy().astype(np.uint8), wx) and np.array_equal(v5[:3].cpu().numpy(), wv)
+    assert torch.equal(env.calculate_obj_values(x5), v5)
