@@ -1300,6 +1300,121 @@ static inline int rows_waves(int64_t N) {   // waves (= envs) per workgroup of a
 
 using namespace rls;
 
+// ---- narrow-tile launches (16 or 8 envs per workgroup: rls_tile32.h).  `want`: 0 = the widest that fits, 16 / 8 = that one.
+// kNarrowNo: not applicable here (nothing was launched, no error recorded).
+constexpr int kNarrowNo = 1;
+// Which tile a launch of B envs should take when several fit: a tile's load / sweep / store is a chain of its own whatever it holds,
+// so a batch of few tiles wants NARROWER ones until the chip is full -- 4096 envs are 64 / 128 / 256 / 512 tiles of 64 / 32 / 16 / 8
+// envs on 256 CUs.  Returns 0 (the wide tiles), 16 or 8.  RLS_NARROW_TILE: 0 never, 1 automatic, 2 / 3 force 16 / 8 where they fit.
+static int narrow_policy(int64_t N, int64_t B, bool rows_vec, Knob wide_knob) {
+    const int64_t k = knob(KN_NARROW_TILE, 1);
+    if (k == 0 || (k == 1 && knob(wide_knob, -1) >= 0)) return 0;      // (a forced 64-env / half-tile form is honoured)
+    if (k == 2) return 16;
+    if (k == 3) return 8;
+    // automatic (tools/timing/narrow_policy.py, K1 / K6 / K5 in us, wide -> narrow): N = 10^4, 4096 envs 21.8 / 31.6 / 47.6 -> 11.7 /
+    // 22.4 / 39.2 (16 envs), 256 envs 19.4 / 27.8 / 42.4 -> 7.6 / 13.2 / 24.9 (8 envs); N = 39 936, 4096 envs 47 / 120 / 356 -> 36 / 86 /
+    // 135; N = 2000, 4096 envs 10.4 / 11.6 / 47 -> 7.1 / 9.1 / 46; N = 800: nothing.  From 16 384 envs on the wide tiles win
+    // (N = 10^4: 29.7 / 77.5 / 69.8 vs 32.8 / 89.6 / 110) -- the chip is full and a narrow tile walks the edge list / schedule per 16 envs.
+    if (!rows_vec || (N & 15) != 0 || N < 1536) return 0;     // (the narrow loader's fast path: byte rows of 16-byte multiples)
+    const int64_t cus = num_cus();
+    if (ceil_div(B, 8) <= cus) return 8;
+    if (ceil_div(B, 16) <= cus) return 16;
+    return 0;
+}
+
+static int launch_obj_narrow(const rls_graph* g, const void* x, int spin_bytes, int64_t B, int64_t* obj, int want, void* stream) {
+    const int64_t N = g->num_nodes, E = g->num_stored_edges;
+    const int Pn = pick_planes(E) == 12 ? 16 : pick_planes(E);
+    const bool vecn = tile_rows_aligned(x, N, spin_bytes);
+    const int hv = g->if_bidirectional ? 1 : 0;
+    const size_t l16 = narrow_words_bytes<uint16_t>(N) + (size_t)kNarrowWaves * kWave * 8, l8 = narrow_words_bytes<uint8_t>(N) + (size_t)kNarrowWaves * kWave * 8;
+    if (Pn == 0 || l8 > (size_t)kLdsBytes) return kNarrowNo;
+    const bool w16 = want != 8 && l16 <= (size_t)kLdsBytes;
+    const size_t ln = w16 ? l16 : l8;
+    const dim3 gn((unsigned)ceil_div(B, (int64_t)(w16 ? 16 : 8))), bn(kNarrowWaves * kWave);
+#define LAUNCH_OBJN(T, VEC, PP)                                                                                         \
+    do {                                                                                                                \
+        if (w16) { auto kern = k_maxcut_obj_n<T, VEC, PP, uint16_t>; ensure_dyn_lds((const void*)kern, ln);             \
+                   hipLaunchKernelGGL(kern, gn, bn, ln, as_stream(stream), (const T*)x, B, N, g->eu, g->ev, E, hv, obj); } \
+        else     { auto kern = k_maxcut_obj_n<T, VEC, PP, uint8_t>; ensure_dyn_lds((const void*)kern, ln);              \
+                   hipLaunchKernelGGL(kern, gn, bn, ln, as_stream(stream), (const T*)x, B, N, g->eu, g->ev, E, hv, obj); } \
+    } while (0)
+#define DISPATCH_PN(T, VEC)                        \
+    switch (Pn) {                                  \
+        case 16: LAUNCH_OBJN(T, VEC, 16); break;   \
+        case 20: LAUNCH_OBJN(T, VEC, 20); break;   \
+        default: LAUNCH_OBJN(T, VEC, 24); break;   \
+    }
+    if (spin_bytes == 1) { if (vecn) { DISPATCH_PN(uint8_t, true) } else { DISPATCH_PN(uint8_t, false) } }
+    else { DISPATCH_PN(float, false) }
+#undef DISPATCH_PN
+#undef LAUNCH_OBJN
+    return check_launch("k_maxcut_obj_n");
+}
+
+static int launch_propose_accept_narrow(const rls_graph* g, uint8_t* x, int64_t B, const uint8_t* mask, int32_t mask_bits, int64_t* obj, int want,
+                                        void* stream) {
+    const int64_t N = g->num_nodes, E = g->num_stored_edges;
+    const int Pn = pick_planes(E) == 12 ? 16 : pick_planes(E);
+    const bool vecn = tile_rows_aligned(x, N, 1) && (mask_bits || tile_rows_aligned(mask, N, 1));
+    const int hv = g->if_bidirectional ? 1 : 0;
+    const size_t l16 = narrow_words_bytes<uint16_t>(N) + (size_t)kNarrowWaves * kWave * 8, l8 = narrow_words_bytes<uint8_t>(N) + (size_t)kNarrowWaves * kWave * 8;
+    if (Pn == 0 || l8 > (size_t)kLdsBytes) return kNarrowNo;
+    const bool w16 = want != 8 && l16 <= (size_t)kLdsBytes;
+    const size_t ln = w16 ? l16 : l8;
+    const dim3 gn((unsigned)ceil_div(B, (int64_t)(w16 ? 16 : 8))), bn(kNarrowWaves * kWave);
+#define LAUNCH_PAN(VEC, PP, MB)                                                                                          \
+    do {                                                                                                                \
+        if (w16) { auto kern = k_maxcut_propose_accept_n<VEC, PP, uint16_t, MB>; ensure_dyn_lds((const void*)kern, ln); \
+                   hipLaunchKernelGGL(kern, gn, bn, ln, as_stream(stream), x, mask, B, N, g->eu, g->ev, E, hv, obj); }  \
+        else     { auto kern = k_maxcut_propose_accept_n<VEC, PP, uint8_t, MB>; ensure_dyn_lds((const void*)kern, ln);  \
+                   hipLaunchKernelGGL(kern, gn, bn, ln, as_stream(stream), x, mask, B, N, g->eu, g->ev, E, hv, obj); }  \
+    } while (0)
+#define DISPATCH_PN(VEC, MB)                       \
+    switch (Pn) {                                  \
+        case 16: LAUNCH_PAN(VEC, 16, MB); break;   \
+        case 20: LAUNCH_PAN(VEC, 20, MB); break;   \
+        default: LAUNCH_PAN(VEC, 24, MB); break;   \
+    }
+    if (mask_bits) { if (vecn) { DISPATCH_PN(true, true) } else { DISPATCH_PN(false, true) } }
+    else { if (vecn) { DISPATCH_PN(true, false) } else { DISPATCH_PN(false, false) } }
+#undef DISPATCH_PN
+#undef LAUNCH_PAN
+    return check_launch("k_maxcut_propose_accept_n");
+}
+
+static int launch_sweep_narrow(const rls_graph* g, uint8_t* x, int64_t B, int64_t* obj, int want, void* stream) {
+    const int64_t N = g->num_nodes, E = g->num_stored_edges, G = g->num_sweep_groups;
+    if (g->wgt || !g->sweep_lv_ptr || !g->sweep_lv_data || G <= 0 || knob_on(KN_SWEEP_NO_LEVELS)) return kNarrowNo;
+    const int Pn = pick_planes(E) == 12 ? 16 : pick_planes(E);
+    const bool vec = tile_rows_aligned(x, N, 1);
+    auto ldsn_of = [&](size_t wb) { return wb + (((size_t)(G + 1) * 4 + 15) & ~(size_t)15) + (size_t)kNarrowWaves * kWave * 8; };
+    const size_t l16 = ldsn_of(narrow_words_bytes<uint16_t>(N)), l8 = ldsn_of(narrow_words_bytes<uint8_t>(N));
+    if (Pn == 0 || l8 > (size_t)kLdsBytes) return kNarrowNo;
+    const bool w16 = want != 8 && l16 <= (size_t)kLdsBytes;
+    const size_t ln = w16 ? l16 : l8;
+    const dim3 gn((unsigned)ceil_div(B, (int64_t)(w16 ? 16 : 8))), bn(kNarrowWaves * kWave);
+    const int hv = g->if_bidirectional ? 1 : 0;
+    hipStream_t s = as_stream(stream);
+#define LAUNCH_SWLN(VEC, PP)                                                                                                       \
+    do {                                                                                                                           \
+        if (w16) { auto kern = k_maxcut_greedy_sweep_levels_n<VEC, PP, uint16_t>; ensure_dyn_lds((const void*)kern, ln);           \
+                   hipLaunchKernelGGL(kern, gn, bn, ln, s, x, B, N, g->sweep_lv_ptr, g->sweep_lv_data, G, g->eu, g->ev, E, hv, obj); } \
+        else     { auto kern = k_maxcut_greedy_sweep_levels_n<VEC, PP, uint8_t>; ensure_dyn_lds((const void*)kern, ln);            \
+                   hipLaunchKernelGGL(kern, gn, bn, ln, s, x, B, N, g->sweep_lv_ptr, g->sweep_lv_data, G, g->eu, g->ev, E, hv, obj); } \
+    } while (0)
+#define DISPATCH_SWLN(VEC)                        \
+    switch (Pn) {                                 \
+        case 16: LAUNCH_SWLN(VEC, 16); break;     \
+        case 20: LAUNCH_SWLN(VEC, 20); break;     \
+        default: LAUNCH_SWLN(VEC, 24); break;     \
+    }
+    if (vec) { DISPATCH_SWLN(true) } else { DISPATCH_SWLN(false) }
+#undef DISPATCH_SWLN
+#undef LAUNCH_SWLN
+    return check_launch("k_maxcut_greedy_sweep_levels_n");
+}
+
 extern "C" {
 
 #ifdef RLS_PROF
@@ -1323,6 +1438,8 @@ int rls_maxcut_obj(const rls_graph* g, const void* x, int spin_bytes, int64_t B,
     RLS_REQUIRE(x && obj, RLS_EINVAL, "x/obj is NULL");
     RLS_REQUIRE(spin_bytes == 1 || spin_bytes == 4, RLS_EINVAL, "spin_bytes must be 1 or 4");
     const int64_t N = g->num_nodes, E = g->num_stored_edges;
+    if (const int nw = narrow_policy(N, B, tile_rows_aligned(x, N, spin_bytes), KN_K1_TILE32))
+        if (const int rc = launch_obj_narrow(g, x, spin_bytes, B, obj, nw, stream); rc != kNarrowNo) return rc;
     int tw = tile_waves_for(N);
     size_t lds = (size_t)N * 8 + (size_t)tw * kWave * 8;
     if (lds > (size_t)kLdsBytes && (size_t)N * 8 + (size_t)kTileWaves * kWave * 8 <= (size_t)kLdsBytes) {
@@ -1377,35 +1494,8 @@ int rls_maxcut_obj(const rls_graph* g, const void* x, int spin_bytes, int64_t B,
             return check_launch("k_maxcut_obj32");
         }
     }
-    if (lds > (size_t)kLdsBytes && knob(KN_NARROW_TILE, 1) != 0) {   // neither the 64-env nor the half tile fits: 16 or 8 envs per workgroup
-        const int Pn = pick_planes(E) == 12 ? 16 : pick_planes(E);
-        const bool vecn = tile_rows_aligned(x, N, spin_bytes);
-        const int hv = g->if_bidirectional ? 1 : 0;
-        const size_t l16 = narrow_words_bytes<uint16_t>(N) + (size_t)kNarrowWaves * kWave * 8, l8 = narrow_words_bytes<uint8_t>(N) + (size_t)kNarrowWaves * kWave * 8;
-        if (Pn != 0 && l8 <= (size_t)kLdsBytes) {
-            const bool w16 = l16 <= (size_t)kLdsBytes;
-            const size_t ln = w16 ? l16 : l8;
-            const dim3 gn((unsigned)ceil_div(B, (int64_t)(w16 ? 16 : 8))), bn(kNarrowWaves * kWave);
-#define LAUNCH_OBJN(T, VEC, PP)                                                                                         \
-    do {                                                                                                                \
-        if (w16) { auto kern = k_maxcut_obj_n<T, VEC, PP, uint16_t>; ensure_dyn_lds((const void*)kern, ln);             \
-                   hipLaunchKernelGGL(kern, gn, bn, ln, as_stream(stream), (const T*)x, B, N, g->eu, g->ev, E, hv, obj); } \
-        else     { auto kern = k_maxcut_obj_n<T, VEC, PP, uint8_t>; ensure_dyn_lds((const void*)kern, ln);              \
-                   hipLaunchKernelGGL(kern, gn, bn, ln, as_stream(stream), (const T*)x, B, N, g->eu, g->ev, E, hv, obj); } \
-    } while (0)
-#define DISPATCH_PN(T, VEC)                        \
-    switch (Pn) {                                  \
-        case 16: LAUNCH_OBJN(T, VEC, 16); break;   \
-        case 20: LAUNCH_OBJN(T, VEC, 20); break;   \
-        default: LAUNCH_OBJN(T, VEC, 24); break;   \
-    }
-            if (spin_bytes == 1) { if (vecn) { DISPATCH_PN(uint8_t, true) } else { DISPATCH_PN(uint8_t, false) } }
-            else { DISPATCH_PN(float, false) }
-#undef DISPATCH_PN
-#undef LAUNCH_OBJN
-            return check_launch("k_maxcut_obj_n");
-        }
-    }
+    if (lds > (size_t)kLdsBytes && knob(KN_NARROW_TILE, 1) != 0)      // neither the 64-env nor the half tile fits: 16 or 8 envs per workgroup
+        if (const int rc = launch_obj_narrow(g, x, spin_bytes, B, obj, 0, stream); rc != kNarrowNo) return rc;
     if (lds > (size_t)kLdsBytes) {   // neither tile fits: one env per wave on a byte row
         const int rw = rows_waves(N);
         RLS_REQUIRE(rw > 0, RLS_EUNSUPPORTED, "N=%lld: a row of %lld bytes does not fit LDS (max %d)", (long long)N, (long long)N, kLdsBytes);
@@ -1465,6 +1555,8 @@ int rls_maxcut_propose_accept(const rls_graph* g, uint8_t* x, int64_t B, const v
     RLS_REQUIRE(x && mask && obj, RLS_EINVAL, "x/mask/obj is NULL");
     RLS_REQUIRE(!mask_bits || (((uintptr_t)mask) & 7) == 0, RLS_EINVAL, "a bit-packed mask is uint64 words: 8-byte aligned");
     const int64_t N = g->num_nodes, E = g->num_stored_edges;
+    if (const int nw = narrow_policy(N, B, tile_rows_aligned(x, N, 1) && (mask_bits || tile_rows_aligned(mask, N, 1)), KN_K6_TILE32))
+        if (const int rc = launch_propose_accept_narrow(g, x, B, mask, mask_bits, obj, nw, stream); rc != kNarrowNo) return rc;
     int tw = tile_waves_for(N);
     size_t lds = (size_t)N * 8 + (size_t)tw * kWave * 8;
     if (lds > (size_t)kLdsBytes && (size_t)N * 8 + (size_t)kTileWaves * kWave * 8 <= (size_t)kLdsBytes) {
@@ -1515,35 +1607,8 @@ int rls_maxcut_propose_accept(const rls_graph* g, uint8_t* x, int64_t B, const v
             return check_launch("k_maxcut_propose_accept32");
         }
     }
-    if (lds > (size_t)kLdsBytes && knob(KN_NARROW_TILE, 1) != 0) {   // neither the 64-env nor the half tile fits: 16 or 8 envs per workgroup
-        const int Pn = pick_planes(E) == 12 ? 16 : pick_planes(E);
-        const bool vecn = tile_rows_aligned(x, N, 1) && (mask_bits || tile_rows_aligned(mask, N, 1));
-        const int hv = g->if_bidirectional ? 1 : 0;
-        const size_t l16 = narrow_words_bytes<uint16_t>(N) + (size_t)kNarrowWaves * kWave * 8, l8 = narrow_words_bytes<uint8_t>(N) + (size_t)kNarrowWaves * kWave * 8;
-        if (Pn != 0 && l8 <= (size_t)kLdsBytes) {
-            const bool w16 = l16 <= (size_t)kLdsBytes;
-            const size_t ln = w16 ? l16 : l8;
-            const dim3 gn((unsigned)ceil_div(B, (int64_t)(w16 ? 16 : 8))), bn(kNarrowWaves * kWave);
-#define LAUNCH_PAN(VEC, PP, MB)                                                                                          \
-    do {                                                                                                                \
-        if (w16) { auto kern = k_maxcut_propose_accept_n<VEC, PP, uint16_t, MB>; ensure_dyn_lds((const void*)kern, ln); \
-                   hipLaunchKernelGGL(kern, gn, bn, ln, as_stream(stream), x, mask, B, N, g->eu, g->ev, E, hv, obj); }  \
-        else     { auto kern = k_maxcut_propose_accept_n<VEC, PP, uint8_t, MB>; ensure_dyn_lds((const void*)kern, ln);  \
-                   hipLaunchKernelGGL(kern, gn, bn, ln, as_stream(stream), x, mask, B, N, g->eu, g->ev, E, hv, obj); }  \
-    } while (0)
-#define DISPATCH_PN(VEC, MB)                       \
-    switch (Pn) {                                  \
-        case 16: LAUNCH_PAN(VEC, 16, MB); break;   \
-        case 20: LAUNCH_PAN(VEC, 20, MB); break;   \
-        default: LAUNCH_PAN(VEC, 24, MB); break;   \
-    }
-            if (mask_bits) { if (vecn) { DISPATCH_PN(true, true) } else { DISPATCH_PN(false, true) } }
-            else { if (vecn) { DISPATCH_PN(true, false) } else { DISPATCH_PN(false, false) } }
-#undef DISPATCH_PN
-#undef LAUNCH_PAN
-            return check_launch("k_maxcut_propose_accept_n");
-        }
-    }
+    if (lds > (size_t)kLdsBytes && knob(KN_NARROW_TILE, 1) != 0)      // neither the 64-env nor the half tile fits: 16 or 8 envs per workgroup
+        if (const int rc = launch_propose_accept_narrow(g, x, B, mask, mask_bits, obj, 0, stream); rc != kNarrowNo) return rc;
     if (lds > (size_t)kLdsBytes) {   // neither tile fits: one env per wave on a byte row
         const int rw = rows_waves(N);
         RLS_REQUIRE(rw > 0, RLS_EUNSUPPORTED, "N=%lld: a row does not fit LDS (max %d)", (long long)N, kLdsBytes);
@@ -1591,6 +1656,8 @@ int rls_maxcut_greedy_sweep(const rls_graph* g, uint8_t* x, int64_t B, int64_t* 
     RLS_REQUIRE(x && obj, RLS_EINVAL, "x/obj is NULL");
     const int64_t N = g->num_nodes;
     const bool vec = tile_rows_aligned(x, N, 1);
+    if (const int nw = narrow_policy(N, B, vec, KN_K5_TILE32))
+        if (const int rc = launch_sweep_narrow(g, x, B, obj, nw, stream); rc != kNarrowNo) return rc;
     const dim3 grid((unsigned)ceil_div(B, kWave)), block(kWave);
     hipStream_t s = as_stream(stream);
     const size_t lds_fast = (size_t)(N + 2) * 8 + (size_t)((N + 1 + 3) & ~3ll) * 4 + (size_t)kRing * 4;
@@ -1633,6 +1700,10 @@ int rls_maxcut_greedy_sweep(const rls_graph* g, uint8_t* x, int64_t B, int64_t* 
             if (stage32 && lds32_of(sw32, true) > (size_t)kLdsBytes) stage32 = 0;
             if (lds32_of(sw32, stage32 != 0) > (size_t)kLdsBytes) sw32 = 4;
             if (lds32_of(sw32, stage32 != 0) > (size_t)kLdsBytes) sw32 = 2;
+            // a half tile that leaves room for two waves only (N ~ 40 000: the words fill LDS) sweeps slower than 16-env tiles with
+            // eight at every batch size (N = 39 936: 2^12 envs 356 -> 135 us, 2^16 3779 -> 2332)
+            if (sw32 == 2 && knob(KN_NARROW_TILE, 1) == 1 && knob32 < 0)
+                if (const int rc = launch_sweep_narrow(g, x, B, obj, 16, stream); rc != kNarrowNo) return rc;
             const size_t l32 = lds32_of(sw32, stage32 != 0);
             if (l32 <= (size_t)kLdsBytes) {
                 const dim3 g32((unsigned)ceil_div(B, (int64_t)kHalf)), b32(sw32 * kWave);
@@ -1663,32 +1734,8 @@ int rls_maxcut_greedy_sweep(const rls_graph* g, uint8_t* x, int64_t B, int64_t* 
                 return check_launch("k_maxcut_greedy_sweep_levels32");
             }
             // the half tile does not fit either: 16 or 8 envs per workgroup (the same level schedule)
-            const int Pn = P == 12 ? 16 : P;
-            auto ldsn_of = [&](size_t wb) { return wb + (((size_t)(G + 1) * 4 + 15) & ~(size_t)15) + (size_t)kNarrowWaves * kWave * 8; };
-            const size_t l16 = ldsn_of(narrow_words_bytes<uint16_t>(N)), l8 = ldsn_of(narrow_words_bytes<uint8_t>(N));
-            if (knob(KN_NARROW_TILE, 1) != 0 && l8 <= (size_t)kLdsBytes) {
-                const bool w16 = l16 <= (size_t)kLdsBytes;
-                const size_t ln = w16 ? l16 : l8;
-                const dim3 gn((unsigned)ceil_div(B, (int64_t)(w16 ? 16 : 8))), bn(kNarrowWaves * kWave);
-                const int hv = g->if_bidirectional ? 1 : 0;
-#define LAUNCH_SWLN(VEC, PP)                                                                                                       \
-    do {                                                                                                                           \
-        if (w16) { auto kern = k_maxcut_greedy_sweep_levels_n<VEC, PP, uint16_t>; ensure_dyn_lds((const void*)kern, ln);           \
-                   hipLaunchKernelGGL(kern, gn, bn, ln, s, x, B, N, g->sweep_lv_ptr, g->sweep_lv_data, G, g->eu, g->ev, E, hv, obj); } \
-        else     { auto kern = k_maxcut_greedy_sweep_levels_n<VEC, PP, uint8_t>; ensure_dyn_lds((const void*)kern, ln);            \
-                   hipLaunchKernelGGL(kern, gn, bn, ln, s, x, B, N, g->sweep_lv_ptr, g->sweep_lv_data, G, g->eu, g->ev, E, hv, obj); } \
-    } while (0)
-#define DISPATCH_SWLN(VEC)                        \
-    switch (Pn) {                                 \
-        case 16: LAUNCH_SWLN(VEC, 16); break;     \
-        case 20: LAUNCH_SWLN(VEC, 20); break;     \
-        default: LAUNCH_SWLN(VEC, 24); break;     \
-    }
-                if (vec) { DISPATCH_SWLN(true) } else { DISPATCH_SWLN(false) }
-#undef DISPATCH_SWLN
-#undef LAUNCH_SWLN
-                return check_launch("k_maxcut_greedy_sweep_levels_n");
-            }
+            if (knob(KN_NARROW_TILE, 1) != 0)
+                if (const int rc = launch_sweep_narrow(g, x, B, obj, 0, stream); rc != kNarrowNo) return rc;
         }
         if (!no_levels && !g->wgt && g->sweep_lv_ptr && g->sweep_lv_data && G > 0 && P != 0 && lds_l <= (size_t)kLdsBytes) {
             const dim3 blockl(sw * kWave);

@@ -13,13 +13,17 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 
 
-@pytest.mark.parametrize("knob", ["auto", "0", "1"])
+@pytest.mark.parametrize("knob", ["auto", "0", "1", "narrow16", "narrow8"])
 def test_k1_k6_tile_forms_match_oracle(knob):
+    """(round 5: "narrow16" / "narrow8" force the 16- / 8-env narrow tiles of K1 / K6 / K5 at every size that fits them --
+    RLS_NARROW_TILE = 2 / 3 -- where the launchers otherwise take them for small batches and past the half tile only)"""
     env = dict(os.environ)
-    for k in ("RLS_K1_TILE32", "RLS_K5_TILE32", "RLS_K6_TILE32", "RLS_NS_TILE32"):
+    for k in ("RLS_K1_TILE32", "RLS_K5_TILE32", "RLS_K6_TILE32", "RLS_NS_TILE32", "RLS_NARROW_TILE"):
         env.pop(k, None)
-        if knob != "auto":
+        if knob in ("0", "1"):
             env[k] = knob
+    if knob.startswith("narrow"):
+        env["RLS_NARROW_TILE"] = "2" if knob == "narrow16" else "3"
     r = subprocess.run([sys.executable, os.path.join(HERE, "tile32_child.py"), "7"], env=env, cwd=ROOT, stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-4000:]
