@@ -795,6 +795,13 @@ static size_t ls_propose_lds(int64_t N, bool sd_lds) {
     return (size_t)((N + 1) & ~1ll) * 8 + (size_t)kLsRoundWaves * kWave * 8 + (size_t)kLsRoundWaves * kStageBytes +
            (sd_lds ? (size_t)((N + 3) & ~3ll) * 4 : 0);
 }
+// N past the half tile too, within the narrow tiles (rls_tile32.h: 16 / 8 envs per workgroup; ~39 900 < N <= ~155 000): mask kernels,
+// then every round's proposal through K6 on narrow tiles with the mask words as its bit-packed mask (round 5; such graphs ran the
+// search as torch ops on [B, N] float tensors around K6: 16.6 ms for 4096 envs at N = 44 000)
+static bool ls_narrow_tile(int64_t N) {
+    return !ls_big_tile(N) && !ls_half_tile(N) && ls_propose_lds(N, false) > (size_t)kLdsBytes &&
+           (((size_t)(N + 2) + 15) & ~(size_t)15) + (size_t)8 * kWave * 8 <= (size_t)kLdsBytes && knob(KN_NARROW_TILE, 1) != 0;
+}
 
 }  // namespace rls
 
@@ -910,7 +917,7 @@ extern "C" int rls_maxcut_ls_rounds_supported(const rls_graph* g, int32_t num_sp
     if (num_spin < 0 || num_spin + 1 > kTopCap || num_spin >= N) return 0;
     if (pick_planes(g->num_stored_edges) == 0) return 0;
     // (the bare 64-env tile and the half tile need the scratch buffer: the rounds run through the mask words there)
-    return ls_propose_lds(N, false) <= (size_t)kLdsBytes || ((ls_big_tile(N) || ls_half_tile(N)) && ls_noise_passes_fit(N));
+    return ls_propose_lds(N, false) <= (size_t)kLdsBytes || ((ls_big_tile(N) || ls_half_tile(N) || ls_narrow_tile(N)) && ls_noise_passes_fit(N));
 }
 
 // bytes of caller-provided scratch with which the two entry points below split a tile's noise pass over several workgroups
@@ -920,7 +927,7 @@ extern "C" int64_t rls_maxcut_ls_scratch_bytes(const rls_graph* g, int64_t B, in
     const int64_t N = g->num_nodes;
     const int64_t nch = ws_bytes == 1 ? ls_num_chunks<int8_t>(N) : ls_num_chunks<int16_t>(N);
     const size_t need = ls_scratch_bytes(B, N, ls_slices(B, nch), num_draws);
-    if (ls_big_tile(N) || ls_half_tile(N)) {   // the mask words are how the rounds run at all here: at least one round's
+    if (ls_big_tile(N) || ls_half_tile(N) || ls_narrow_tile(N)) {   // the mask words are how the rounds run at all here: at least one round's
         const size_t one = (size_t)ceil_div(B, kWave) * (size_t)N * 8;
         return (int64_t)(need > one ? need : one);
     }
@@ -990,7 +997,7 @@ extern "C" int rls_maxcut_ls_propose(const rls_graph* g, uint8_t* x, int64_t B, 
     RLS_REQUIRE(ls_pitch_ok(ws, ws_pitch, ws_bytes, N), RLS_EUNSUPPORTED,
                 "ws rows must start 16-byte aligned: pitch %lld entries of %d bytes (N=%lld)", (long long)ws_pitch, (int)ws_bytes, (long long)N);
     const int x_aligned = tile_rows_aligned(x, N, 1) ? 1 : 0;   // else the funnel-shift form of the row-piece stage
-    if (ls_propose_lds(N, false) > (size_t)kLdsBytes && (ls_big_tile(N) || ls_half_tile(N)))   // mask kernel + the apply kernel (needs the scratch)
+    if (ls_propose_lds(N, false) > (size_t)kLdsBytes && (ls_big_tile(N) || ls_half_tile(N) || ls_narrow_tile(N)))   // mask kernel + the apply kernel (needs the scratch)
         return rls_maxcut_ls_rounds(g, x, B, ws, ws_bytes, ws_pitch, rd_std, thresh, seed, env_offset, draw, 1, obj, scratch, scratch_bytes, stream);
     RLS_REQUIRE(ls_propose_lds(N, false) <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS (max %d)", (long long)N,
                 ls_propose_lds(N, false), kLdsBytes);
@@ -1051,9 +1058,9 @@ extern "C" int rls_maxcut_ls_rounds(const rls_graph* g, uint8_t* x, int64_t B, c
     if (ws_pitch == 0) ws_pitch = N;
     const int S = ls_slices(B, ws_bytes == 1 ? ls_num_chunks<int8_t>(N) : ls_num_chunks<int16_t>(N));
     const bool per_round = knob_on(KN_LS_PER_ROUND);   // dev knob: one propose launch per round
-    const bool half = ls_half_tile(N);
-    const bool big = ls_big_tile(N) || half;
-    RLS_REQUIRE(!half || ls_noise_passes_fit(N), RLS_EUNSUPPORTED, "N=%lld: rd_std does not fit LDS and N is not a multiple of 4", (long long)N);
+    const bool half = ls_half_tile(N), narrow = ls_narrow_tile(N);
+    const bool big = ls_big_tile(N) || half || narrow;
+    RLS_REQUIRE(!(half || narrow) || ls_noise_passes_fit(N), RLS_EUNSUPPORTED, "N=%lld: rd_std does not fit LDS and N is not a multiple of 4", (long long)N);
     const size_t one_round = (size_t)ceil_div(B, kWave) * (size_t)N * 8;
     const bool scratch_ok = scratch && (((uintptr_t)scratch) & 15) == 0 && ls_pitch_ok(ws, ws_pitch, ws_bytes, N) && pick_planes(E) != 0;
     RLS_REQUIRE(!big || (scratch_ok && (size_t)scratch_bytes >= one_round), RLS_EUNSUPPORTED,
@@ -1091,6 +1098,11 @@ extern "C" int rls_maxcut_ls_rounds(const rls_graph* g, uint8_t* x, int64_t B, c
             }
         }
         if (int rc = check_launch("k_ls_mask")) return rc;
+        if (narrow) {   // past the half tile: each round's mask words are K6's bit-packed mask (narrow tiles there: rls_maxcut.hip)
+            for (int32_t r = 0; r < per_launch; ++r)
+                if (int rc = rls_maxcut_propose_accept(g, x, B, (const uint64_t*)scratch + (size_t)r * grid.x * (size_t)N, 1, obj, stream)) return rc;
+            continue;
+        }
         // half tiles (twice the workgroups, the same mask words): past the 64-env tile, and for batches that leave half the CUs
         // without a 64-env tile (whole local_search_inplace calls, 4096 envs: G22-sized 0.324 -> 0.305 ms, BA n = 10^4 0.893 -> 0.816,
         // G70-sized 0.689 -> 0.642; at 16 384 envs no gain).  Dev knob RLS_LS_APPLY32 = 0 | 1 forces the choice.

@@ -523,7 +523,10 @@ def test_narrow_tiles_past_the_half_tile_vs_c_oracle(n, m, B, words):
             ops.maxcut_propose_accept(env.graph, x6, mask, v6)                      # K6, byte mask
             x5, v5 = xs[:5].clone(), vs[:5].clone()
             ops.maxcut_greedy_sweep(env.graph, x5, v5)                              # K5
-            res[narrow] = (vs, env.calculate_obj_values(xs.float()), x6, v6, x5, v5)
+            x7, v7 = xs.clone(), vs.clone()                                         # the whole search: past the half tile the rounds run as
+            torch.manual_seed(5)                                                    # mask kernels + K6 on narrow tiles (narrow) or decomposed
+            env.local_search_inplace(x7, v7, num_iters=3, num_spin=8)               # into torch ops around the row kernels: same draws
+            res[narrow] = (vs, env.calculate_obj_values(xs.float()), x6, v6, x5, v5, x7, v7)
             if narrow and n % 16 == 0:                                              # K6, bit-packed mask (tile-major uint64 words)
                 xb, vb = xs.clone(), vs.clone()
                 ops.maxcut_propose_accept(env.graph, xb, PackedChains.pack(mask.t().contiguous().float()).words, vb)
@@ -532,7 +535,10 @@ def test_narrow_tiles_past_the_half_tile_vs_c_oracle(n, m, B, words):
             _abi.tuning_unset("RLS_NARROW_TILE")
     for a, b in zip(res[1], res[0]):
         assert torch.equal(a, b)
-    vs, vf, x6, v6, x5, v5 = res[1]
+    vs, vf, x6, v6, x5, v5, x7, v7 = res[1]
+    assert bool((v7 >= vs).all()) and torch.equal(env.calculate_obj_values(x7), v7) and not torch.equal(x7, xs)
+    if n % 4 == 0:
+        assert ops.ls_rounds_supported(env.graph, 8)
     assert np.array_equal(vs.cpu().numpy(), oc.maxcut_obj(x_np, eu, ev, 0)) and torch.equal(vf, vs)
     prop = x_np ^ mask.cpu().numpy().astype(np.uint8)
     pv = oc.maxcut_obj(prop, eu, ev, 0)
