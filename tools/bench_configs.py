@@ -15,7 +15,7 @@ from rlsolver_amd.methods import MCPG as amcpg
 ap = argparse.ArgumentParser()
 ap.add_argument("--quick", action="store_true")
 ap.add_argument("--profile", action="store_true", help="few launches per kernel: for rocprofv3 passes (PMC serialises kernels)")
-ap.add_argument("--only", default="", help="comma list of suites: maxcut,synthetic,lsba,ls,g70,g14,tsp,isco,spin,qubo,mcpg")
+ap.add_argument("--only", default="", help="comma list of suites: maxcut,synthetic,lsba,ls,g70,g14,narrow,tsp,isco,spin,qubo,mcpg")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 HBM = 8e12
@@ -360,6 +360,11 @@ if want("g70"):
     maxcut_suite("G70-sized G(10000,9999), B=2^17 (one GPU's shard of 2^20)", 10000, 9999, 1 << 17, 70, max(3, it // 3))
 if want("g14"):
     maxcut_suite("G14-sized G(800,4694), B=256", 800, 4694, 256, 14, it)
+if want("narrow") and not a.profile:   # round 5: small batches and graphs past the half tile run on narrow tiles (16 / 8 envs per workgroup)
+    maxcut_suite("G70-sized G(10000,9999), B=4096 (the reference's batch: narrow tiles)", 10000, 9999, 4096, 70, it)
+    maxcut_suite("G(44000, 88000), B=4096 (past the half tile: narrow tiles, uint16 words)", 44000, 88000, 4096, 44, max(3, it // 3))
+    local_search_suite("G(44000, 88000), past the half tile", 44000, 88000, 44, 4096, 2)
+    maxcut_suite("G(100000, 200000), B=4096 (narrow tiles, byte words)", 100000, 200000, 4096, 100, max(3, it // 3))
 if want("tsp"):
     tsp_suite("TSP-100 uniform, B=2^16", 100, 1 << 16, it)
 if want("isco"):
