@@ -851,21 +851,28 @@ __global__ __launch_bounds__(NSW * kWave) void k_node_stats_bits(const uint8_t* 
 
 // K2 / K3 / the weights pre-pass on HALF tiles (rls_tile32.h), for graphs past the 64-env tile: lane = node over the same ELL slabs,
 // counters on 32-bit planes, every group walked by one wave (hub rows included: 16 planes, 16-bit fields), plain per-env stores.
-template <int MODE, bool VEC, bool WIDE, typename WT>
+template <int MODE, bool VEC, bool WIDE, typename WT, typename NT = uint32_t>
 __global__ __launch_bounds__(kNsWaves * kWave) void k_node_stats_bits32(const uint8_t* __restrict__ x, int64_t B, int64_t N,
                                                                        const int32_t* __restrict__ rowptr, const int32_t* __restrict__ ell_ptr,
                                                                        const int32_t* __restrict__ ell, int mult, void* __restrict__ out_v,
                                                                        int32_t* __restrict__ minmax, int64_t out_pitch, int has_stage) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t* words32 = reinterpret_cast<uint32_t*>(smem);
+    // NT: the tile's word -- uint32_t = the half tile; uint16_t / uint8_t = the narrow tiles of 16 / 8 envs (rls_tile32.h) for rows
+    // whose half tile is past the LDS; the planes stay 32-bit registers with the upper bits clear
+    constexpr int EN = narrow_tile<NT>::E;
+    NT* words32 = reinterpret_cast<NT*>(smem);
     const int lane = threadIdx.x & (kWave - 1);
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
-    unsigned char* stage = smem + (((size_t)N * 4 + 15) & ~(size_t)15) + (size_t)w * kStageBytes;
-    const int64_t b0 = (int64_t)blockIdx.x * kHalf;
-    tile32_load_bits<uint8_t, VEC>(x, B, N, b0, words32, lane, w, kNsWaves, has_stage ? stage : nullptr);
+    const int64_t b0 = (int64_t)blockIdx.x * EN;
+    if constexpr (sizeof(NT) == 4) {
+        unsigned char* stage = smem + (((size_t)N * 4 + 15) & ~(size_t)15) + (size_t)w * kStageBytes;
+        tile32_load_bits<uint8_t, VEC>(x, B, N, b0, words32, lane, w, kNsWaves, has_stage ? stage : nullptr);
+    } else {
+        tilen_load_bits<uint8_t, NT, VEC>(x, B, N, b0, words32, lane, w, kNsWaves);
+    }
     __syncthreads();
     const int64_t G = (N + 63) >> 6;
-    const int nenv = (int)((B - b0) < kHalf ? (B - b0) : kHalf);
+    const int nenv = (int)((B - b0) < EN ? (B - b0) : EN);
     const uint64_t vmask = (1ull << nenv) - 1;
     constexpr int NCP = WIDE ? 13 : 5;
     auto emit = [&](int64_t i, int deg, int e, int cnt) {
@@ -877,7 +884,7 @@ __global__ __launch_bounds__(kNsWaves * kWave) void k_node_stats_bits32(const ui
         const int64_t i = (g << 6) + lane;
         const bool in = i < N;
         const uint32_t iself = in ? (uint32_t)i : 0u;
-        const uint32_t own = words32[iself];
+        const uint32_t own = (uint32_t)words32[iself];
         const int e0 = ell_ptr[g], e1 = ell_ptr[g + 1];
         const int deg = in ? rowptr[i + 1] - rowptr[i] : 0;
         const int md = (e1 - e0) >> 6;                        // longest row of the group (wave-uniform)
@@ -892,7 +899,7 @@ __global__ __launch_bounds__(kNsWaves * kWave) void k_node_stats_bits32(const ui
             for (int q = 0; q < 8; ++q) nb[q] = (k + q * kWave < e1) ? (uint32_t)ell[k + q * kWave + lane] : iself;
             uint32_t d[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) d[q] = words32[nb[q]] ^ own;
+            for (int q = 0; q < 8; ++q) d[q] = (uint32_t)words32[nb[q]] ^ own;
             uint32_t twosA, twosB, foursA, foursB, carry;
             csa32(twosA, ones, ones, d[0], d[1]);
             csa32(twosB, ones, ones, d[2], d[3]);
@@ -928,12 +935,13 @@ __global__ __launch_bounds__(kNsWaves * kWave) void k_node_stats_bits32(const ui
         }
         if (!in) continue;
         if (np == 16) {                                       // a hub group: 16-bit fields, envs r and r + 16
-            for (int r = 0; r < 16; ++r) {
+            for (int r = 0; r < (EN < 16 ? EN : 16); ++r) {
                 uint32_t acc = 0;
 #pragma unroll
                 for (int p = 0; p < 16; ++p) acc += ((pw[p] >> r) & 0x00010001u) << p;
                 if (r < nenv) emit(i, deg, r, (int)(acc & 0xFFFFu));
-                if (r + 16 < nenv) emit(i, deg, r + 16, (int)(acc >> 16));
+                if constexpr (EN > 16)
+                    if (r + 16 < nenv) emit(i, deg, r + 16, (int)(acc >> 16));
             }
         } else {                                              // byte fields, envs r, r + 8, r + 16, r + 24
             for (int r = 0; r < 8; ++r) {
@@ -941,7 +949,7 @@ __global__ __launch_bounds__(kNsWaves * kWave) void k_node_stats_bits32(const ui
 #pragma unroll
                 for (int p = 0; p < 8; ++p) acc += ((pw[p] >> r) & 0x01010101u) << p;
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < EN / 8; ++j)
                     if (r + 8 * j < nenv) emit(i, deg, r + 8 * j, (int)((acc >> (8 * j)) & 0xFFu));
             }
         }
@@ -966,7 +974,8 @@ static inline bool node_stats_batch_fills_tiles(const rls_graph* g, int64_t B) {
 static inline bool node_stats_use_bits(const rls_graph* g, const int32_t* ell_ptr, const int32_t* ell, int64_t B) {
     const bool off = knob_on(KN_NODE_STATS_LANE_ENV);   // dev knob: the lane = env kernels
     return !off && ell_ptr && ell && !g->wgt && g->max_degree < 65536 && node_stats_batch_fills_tiles(g, B) &&
-           node_stats_bits32_lds(g->num_nodes, false) <= (size_t)kLdsBytes;   // (half tiles, without the row-piece stage, if need be)
+           (knob(KN_NARROW_TILE, 1) != 0 ? narrow_words_bytes<uint8_t>(g->num_nodes)     // (half tiles without the row-piece stage if
+                                         : node_stats_bits32_lds(g->num_nodes, false)) <= (size_t)kLdsBytes;   // need be, narrow ones past them)
 }
 template <int MODE, typename WT = int32_t>
 static int launch_node_stats_bits(const rls_graph* g, const uint8_t* x, int64_t B, const int32_t* rowptr,
@@ -987,6 +996,39 @@ static int launch_node_stats_bits(const rls_graph* g, const uint8_t* x, int64_t 
     const bool full_k3 = MODE == 1 && t64 >= 4 * (int64_t)num_cus() && (size_t)N * 8 <= 64 * 1024;
     const bool prefer32 = knob32 < 0 && vec && (N & 15) == 0 && node_stats_bits32_lds(N, true) <= (size_t)kLdsBytes &&
                           (few || full_k3 || (node_stats_bits_lds(N, true) > (size_t)kLdsBytes && 2 * t64 <= (int64_t)num_cus()));
+    // Narrow tiles (16 / 8 envs, rls_tile32.h) where the half tile is past the LDS (N > 40 960): the rows these took before went
+    // element-parallel -- one L2 gather per (env, entry)
+    // -- and, like K1 / K6 / K5 (narrow_policy), for batches of few tiles on rows the narrow loader's fast path takes: a tile's load,
+    // count and stores are one chain whatever it holds, so 256 CUs want 256+ tiles (tools/timing/narrow_ns_ab.py, K3 / K2 / weights in us,
+    // wide -> narrow: N = 10^4, 4096 envs 62 / 83 / 95 -> 44 / 74 / 91 (16 envs); N = 20 000, 1024 envs 128 / 102 / 148 -> 75 / 55 / 114
+    // (8 envs); G22-sized, 256 envs 18.4 / 15.3 / 25.5 -> 11.9 / 9.5 / 22.5).  The weights' 8-env tiles only up to 512 envs (every tile
+    // folds its min / max into the table with atomics: G22-sized 1024 envs 27.8 -> 32.6)
+    const int64_t nk = knob(KN_NARROW_TILE, 1);
+    int auto_n = 0;
+    if (nk == 1 && knob32 < 0 && vec && (N & 15) == 0) {
+        const int64_t cus = num_cus();
+        if (ceil_div(B, 8) <= (MODE == 2 ? cus / 4 : cus)) auto_n = 8;
+        else if (ceil_div(B, 16) <= cus) auto_n = 16;
+    }
+    if (nk != 0 && (nk >= 2 || auto_n || node_stats_bits32_lds(N, false) > (size_t)kLdsBytes)) {
+        const size_t l16 = narrow_words_bytes<uint16_t>(N), l8 = narrow_words_bytes<uint8_t>(N);
+        const bool w16 = nk != 3 && auto_n != 8 && l16 <= (size_t)kLdsBytes;
+        const size_t ln = w16 ? l16 : l8;
+        const dim3 gn((unsigned)ceil_div(B, (int64_t)(w16 ? 16 : 8))), bn(kNsWaves * kWave);
+#define RLS_NSN_LAUNCH(VEC, WIDE)                                                                                    \
+    do {                                                                                                            \
+        if (w16) { auto kern = k_node_stats_bits32<MODE, VEC, WIDE, WT, uint16_t>; ensure_dyn_lds((const void*)kern, ln);   \
+                   hipLaunchKernelGGL(kern, gn, bn, ln, as_stream(stream), x, B, N, rowptr, ell_ptr, ell, mult, out, minmax, \
+                                      out_pitch > 0 ? out_pitch : N, 0); }                                          \
+        else     { auto kern = k_node_stats_bits32<MODE, VEC, WIDE, WT, uint8_t>; ensure_dyn_lds((const void*)kern, ln);    \
+                   hipLaunchKernelGGL(kern, gn, bn, ln, as_stream(stream), x, B, N, rowptr, ell_ptr, ell, mult, out, minmax, \
+                                      out_pitch > 0 ? out_pitch : N, 0); }                                          \
+    } while (0)
+        if (wide) { if (vec) RLS_NSN_LAUNCH(true, true); else RLS_NSN_LAUNCH(false, true); }
+        else      { if (vec) RLS_NSN_LAUNCH(true, false); else RLS_NSN_LAUNCH(false, false); }
+#undef RLS_NSN_LAUNCH
+        return check_launch("k_node_stats_bits32<narrow>");
+    }
     if (knob32 > 0 || prefer32 || node_stats_bits_lds(N, false) > (size_t)kLdsBytes) {   // half tiles (rls_tile32.h)
         const int st32 = (vec && (N & 15) == 0 && node_stats_bits32_lds(N, true) <= (size_t)kLdsBytes) ? 1 : 0;
         const size_t l32 = node_stats_bits32_lds(N, st32 != 0);

@@ -549,3 +549,54 @@ def test_narrow_tiles_past_the_half_tile_vs_c_oracle(n, m, B, words):
     oc.greedy_sweep(wx, wv, eu, ev, 0)
     assert np.array_equal(x5[:3].cpu().numpy().astype(np.uint8), wx) and np.array_equal(v5[:3].cpu().numpy(), wv)
     assert torch.equal(env.calculate_obj_values(x5), v5)
+
+
+@pytest.mark.parametrize("n,m,hub,B", [(44000, 88000, 0, 37), (44008, 60000, 300, 21), (100000, 150000, 0, 13), (81003, 90000, 70000, 10)])
+def test_node_stats_on_narrow_tiles_past_the_half_tile(n, m, hub, B):
+    """Round 5: K2 / K3 / the local-search weights past the half tile (N > 40 960) run bit-sliced on narrow tiles (16 envs on uint16
+    words, 8 on bytes) -- lane = node, carry-save counters in 32-bit planes -- instead of element-parallel.  Against the vectorised
+    restatement (cut degree from the stored adjacency, delta = degree - 2 * cut degree on the symmetric one), on graphs with and
+    without a hub (256+ neighbours: the 16-bit fields; 65 536+: back to the element-parallel kernels), rows that are and are not
+    16-byte multiples, ragged last tiles; and bit-identical to the element-parallel kernels (narrow tiles switched off)."""
+    from rlsolver_amd import _abi
+    from rlsolver_amd.envs.env_L2A import EnvMaxcut
+    from rlsolver_amd.graph import generate_gnm
+    mg = list(generate_gnm(n, m, n % 89))
+    if hub:
+        have = {(a, b) for a, b, _ in mg}
+        mg += [(7, j, 1) for j in range(8, 8 + hub) if (7, j) not in have]
+    garr = np.asarray(mg, dtype=np.int64)
+    env = EnvMaxcut(mygraph=mg, device=DEV, num_nodes=n)
+    g = env.graph
+    torch.manual_seed(n + 1)
+    xs = env.generate_xs_randomly(B)
+    xb = xs.cpu().numpy().astype(bool)
+    u, v = garr[:, 0], garr[:, 1]
+    d = (xb[:, u] ^ xb[:, v]).astype(np.int64)
+    cutdeg_st = np.zeros((B, n), np.int64)                  # the stored (unidirectional) adjacency: row u holds v
+    np.add.at(cutdeg_st.T, u, d.T)
+    cutdeg_sym = cutdeg_st.copy()
+    np.add.at(cutdeg_sym.T, v, d.T)
+    deg_st = np.bincount(u, minlength=n)
+    deg_sym = deg_st + np.bincount(v, minlength=n)
+    res = {}
+    for narrow in (1, 0):
+        _abi.tuning_set("RLS_NARROW_TILE", narrow)
+        _abi.tuning_set("RLS_NODE_STATS_MIN_B", 0 if narrow else 1 << 40)     # (a batch this small goes element-parallel by itself)
+        try:
+            form = ops.node_stats_form(g, B, True)
+            ws, mm = ops.maxcut_ls_weights(g, xs, 4, return_minmax=True)
+            res[narrow] = (ops.maxcut_node_cutdeg(g, xs), ops.maxcut_delta_all(g, xs), ws, mm)
+        finally:
+            _abi.tuning_unset("RLS_NARROW_TILE")
+            _abi.tuning_unset("RLS_NODE_STATS_MIN_B")
+        if narrow:
+            assert (form == "bits") == (hub < 65536), form
+    for a, b in zip(res[1], res[0]):
+        assert a.dtype == b.dtype and torch.equal(a, b)
+    k2, k3, ws, mm = res[1]
+    assert np.array_equal(k2.cpu().numpy(), cutdeg_st)
+    assert np.array_equal(k3.cpu().numpy(), deg_sym[None, :] - 2 * cutdeg_sym)
+    want_ws = deg_st[None, :] - 4 * cutdeg_st
+    assert np.array_equal(ws.cpu().numpy().astype(np.int64), want_ws)
+    assert np.array_equal(mm.cpu().numpy(), np.stack([want_ws.min(0), want_ws.max(0)]))
