@@ -718,11 +718,16 @@ int rls_tsp_2opt_best(const double* dist, int64_t N, const int64_t* perm, int64_
  * reference's two torch.rand draws in call order (tests), or both NULL: counter-based generator keyed by
  * (seed, env_offset + b, node).  Outputs (each may be NULL): energy_out f32 [B] = ll_y * T (of the PROPOSAL, as
  * the reference returns it), acc_out f32 [B] = exp(log_acc), terms_out f32 [B, 5] = ll_x, ll_x2y, ll_y, ll_y2x,
- * log_acc, mask_out uint8 [B, N] = the selected nodes.  Unweighted (the reference's energy ignores weights). */
+ * log_acc, mask_out uint8 [B, N] = the selected nodes.  Unweighted (the reference's energy ignores weights).
+ * scratch: device memory of rls_isco_maxcut_scratch_bytes(g, B) bytes -- 0 (scratch may be NULL) while a sample's rows fit LDS
+ * (N <= ~15 900); past that the two f32 rows of every sample (log-probabilities, perturbed values: 8 N bytes) live there and a
+ * workgroup takes each sample (N <= ~81 000: the two byte rows still sit in LDS; RLS_EUNSUPPORTED beyond).  Contents need not
+ * survive between calls. */
+int64_t rls_isco_maxcut_scratch_bytes(const rls_graph* g, int64_t B);
 int rls_isco_maxcut_step(const rls_graph* g, const float* x, float* y_out, int64_t B, const int64_t* path_length,
                          float temperature, const float* u_gumbel, const float* u_accept, uint64_t seed,
                          int64_t env_offset, float* energy_out, float* acc_out, float* terms_out, uint8_t* mask_out,
-                         void* stream);
+                         void* scratch, int64_t scratch_bytes, void* stream);
 
 /* ISCO_TSP.step(x, path_length, temperature)  envs/env_ISCO.py:188-236 in ONE kernel (one wave per env, the tour,
  * its inverse and -- when it fits -- the distance matrix in LDS): path_length times { opt_2 (:238-335: partner

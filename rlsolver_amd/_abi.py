@@ -120,7 +120,7 @@ SIGNATURES = {
     "rls_tsp_2opt_delta": [_P, _I64, _P, _I64, _P, _P, _P, _P],
     "rls_tsp_2opt_best": [_P, _I64, _P, _I64, _P, C.c_int32, _P, _P, _P, _P],
     "rls_rand_perms": [_P, _I64, _I64, _U64, _I64, _P],
-    "rls_isco_maxcut_step": [_G, _P, _P, _I64, _P, _F32, _P, _P, _U64, _I64, _P, _P, _P, _P, _P],
+    "rls_isco_maxcut_step": [_G, _P, _P, _I64, _P, _F32, _P, _P, _U64, _I64, _P, _P, _P, _P, _P, _I64, _P],
     "rls_isco_tsp_step": [_P, _I64, _P, C.c_int32, _F32, _P, C.c_int32, _P, _P, _I64, C.c_int32, _F32, _P, _P, _P, _P, _P, _U64, _I64,
                           _P, _P, _P, _P],
     "rls_copy_rows": [_P, _P, _I64, _P, _P, _I64, _P],
@@ -139,6 +139,7 @@ PLAIN = {"rls_version": ([], _INT), "rls_device_count": ([], _INT), "rls_last_er
          "rls_maxcut_node_stats_form": ([_G, _I64, C.c_int32], _INT),
          "rls_mcpg_metro_max_rounds": ([_I64, C.c_int32], _I64),
          "rls_mcpg_metro_scratch_bytes": ([_I64, _I64], _I64),
+         "rls_isco_maxcut_scratch_bytes": ([_G, _I64], _I64),
          "rls_maxcut_ls_scratch_bytes": ([_G, _I64, C.c_int32, C.c_int32], _I64),
          "rls_maxcut_ls_slices": ([_G, _I64, C.c_int32], _INT)}
 

@@ -129,6 +129,7 @@ struct IscoMcArgs {
     const float* u_gumbel; const float* u_accept; uint64_t seed; int64_t env_offset;
     float* energy_out; float* acc_out; float* terms_out; uint8_t* mask_out;
     int P;
+    float* rows;                                         // caller's scratch f32 [B, 2, N] (lp, pert) for rows past the LDS, else NULL
 };
 
 // log-probabilities of the single-flip proposal distribution of state `s`: lp_i = log_softmax(gain_i / (2T)),
@@ -430,6 +431,10 @@ __device__ __forceinline__ int isco_local_dist_wg(const uint8_t* s, float* lp, i
     return tot >> 1;
 }
 
+// GROWS: the two f32 rows (lp, pert) live in the caller's scratch (global memory, L2-resident while a sample is worked on) and
+// LDS holds the byte rows and the list only -- N past ~15 900, up to ~81 000.  The workgroup's barriers order its global
+// stores and loads as they do the LDS ones (__syncthreads fences both at workgroup scope; the L1 is the CU's).
+template <bool GROWS>
 __global__ __launch_bounds__(kIscoWgWaves * kWave) void k_isco_maxcut_step_wg(IscoMcArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & (kWave - 1);
@@ -441,9 +446,9 @@ __global__ __launch_bounds__(kIscoWgWaves * kWave) void k_isco_maxcut_step_wg(Is
     const size_t nb8 = ((size_t)N + 7) & ~(size_t)7;
     uint8_t* xb = smem;
     uint8_t* yb = smem + nb8;
-    float* lp = reinterpret_cast<float*>(smem + 2 * nb8);
+    float* lp = GROWS ? a.rows + b * 2 * N : reinterpret_cast<float*>(smem + 2 * nb8);
     float* pert = lp + N;
-    float* skey = pert + N;
+    float* skey = GROWS ? reinterpret_cast<float*>(smem + 2 * nb8) : pert + N;
     int32_t* sidx = reinterpret_cast<int32_t*>(skey + P);
     IscoWgScratch* sc = reinterpret_cast<IscoWgScratch*>(sidx + P);
     const float* xr = a.x + b * N;
@@ -755,10 +760,20 @@ using namespace rls;
 
 extern "C" {
 
+// bytes of LDS a sample needs with its two f32 rows in LDS and the smallest list (64 entries)
+static inline size_t isco_mc_lds_min(int64_t N) {
+    return 2 * (((size_t)N + 7) & ~(size_t)7) + (size_t)N * 8 + 64 * 8 + sizeof(IscoWgScratch) + 16;
+}
+
+int64_t rls_isco_maxcut_scratch_bytes(const rls_graph* g, int64_t B) {
+    if (!g || B <= 0 || (isco_mc_lds_min(g->num_nodes) <= (size_t)kLdsBytes && !knob_on(KN_ISCO_GLOBAL_ROWS))) return 0;
+    return B * g->num_nodes * 8;
+}
+
 int rls_isco_maxcut_step(const rls_graph* g, const float* x, float* y_out, int64_t B, const int64_t* path_length,
                          float temperature, const float* u_gumbel, const float* u_accept, uint64_t seed,
                          int64_t env_offset, float* energy_out, float* acc_out, float* terms_out, uint8_t* mask_out,
-                         void* stream) {
+                         void* scratch, int64_t scratch_bytes, void* stream) {
     if (int rc = check_graph(g)) return rc;
     RLS_REQUIRE(B >= 0, RLS_EINVAL, "B < 0");
     if (B == 0) return RLS_OK;
@@ -771,8 +786,29 @@ int rls_isco_maxcut_step(const rls_graph* g, const float* x, float* y_out, int64
     // power of two the rows leave room for, at least 64 (N = 10^4: 4096; N = 15 000: 512) -- a larger selection takes the
     // extraction path.  The rows themselves (two byte rows, two f32 rows) bound N at ~15 900.
     const int force_cap = (int)knob(KN_ISCO_SEL_CAP, 0);   // dev / test knob
-    const size_t rows = 2 * (((size_t)N + 7) & ~(size_t)7) + (size_t)N * 8;
     const size_t fixed = sizeof(IscoWgScratch) + 16;
+    const bool use_ell = g->ell_sym_ptr && g->ell_sym && !g->wgt;
+    if (isco_mc_lds_min(N) > (size_t)kLdsBytes || knob_on(KN_ISCO_GLOBAL_ROWS)) {
+        // rows past the LDS: a workgroup per sample with lp / pert in the caller's scratch (rls_isco_maxcut_scratch_bytes), the byte
+        // rows and a list of up to 4096 entries in LDS
+        const size_t brow = 2 * (((size_t)N + 7) & ~(size_t)7);
+        RLS_REQUIRE(brow + 64 * 8 + fixed <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld: the two byte rows of a sample need %zu B of LDS (max %d)",
+                    (long long)N, brow + 64 * 8 + fixed, kLdsBytes);
+        RLS_REQUIRE(scratch && scratch_bytes >= B * N * 8, RLS_EINVAL,
+                    "N=%lld needs %lld B of scratch (rls_isco_maxcut_scratch_bytes), got %lld", (long long)N, (long long)(B * N * 8),
+                    (long long)(scratch ? scratch_bytes : 0));
+        int Pg = 64;
+        while (Pg < 4096 && Pg < N && brow + (size_t)Pg * 16 + fixed <= (size_t)kLdsBytes) Pg <<= 1;
+        if (force_cap >= 2 && force_cap < Pg && (force_cap & (force_cap - 1)) == 0) Pg = force_cap;
+        const size_t lds_g = brow + (size_t)Pg * 8 + fixed;
+        IscoMcArgs ag{g->rowptr, g->col, use_ell ? g->ell_sym_ptr : nullptr, use_ell ? g->ell_sym : nullptr, x, y_out, B, N,
+                      path_length, temperature, u_gumbel, u_accept, seed, env_offset, energy_out, acc_out, terms_out, mask_out, Pg,
+                      static_cast<float*>(scratch)};
+        ensure_dyn_lds((const void*)k_isco_maxcut_step_wg<true>, lds_g);
+        hipLaunchKernelGGL(k_isco_maxcut_step_wg<true>, dim3((unsigned)B), dim3(kIscoWgWaves * kWave), lds_g, as_stream(stream), ag);
+        return check_launch("k_isco_maxcut_step_wg<global rows>");
+    }
+    const size_t rows = 2 * (((size_t)N + 7) & ~(size_t)7) + (size_t)N * 8;
     int P = 1;
     while (P < N) P <<= 1;
     while (P > 64 && rows + (size_t)P * 8 + fixed > (size_t)kLdsBytes) P >>= 1;
@@ -794,20 +830,19 @@ int rls_isco_maxcut_step(const rls_graph* g, const float* x, float* y_out, int64
         while (Pw > 512 && waves_for(Pw >> 1) > waves_for(Pw)) Pw >>= 1;
     const int waves = waves_for(Pw) < 1 ? 1 : waves_for(Pw);
     const size_t lds = (rows + (size_t)Pw * 8) * waves;
-    const bool use_ell = g->ell_sym_ptr && g->ell_sym && !g->wgt;
     // few chains (the reference's configs run one): a workgroup per sample; from ~4 samples per CU on the wave-per-sample
     // kernel has the throughput
     const size_t lds_wg = per_wave + sizeof(IscoWgScratch) + 16;
     if (use_wg) {
         IscoMcArgs aw{g->rowptr, g->col, use_ell ? g->ell_sym_ptr : nullptr, use_ell ? g->ell_sym : nullptr, x, y_out, B, N,
-                      path_length, temperature, u_gumbel, u_accept, seed, env_offset, energy_out, acc_out, terms_out, mask_out, P};
+                      path_length, temperature, u_gumbel, u_accept, seed, env_offset, energy_out, acc_out, terms_out, mask_out, P, nullptr};
         if (lds_wg > 64 * 1024)
-            ensure_dyn_lds((const void*)k_isco_maxcut_step_wg, lds_wg);
-        hipLaunchKernelGGL(k_isco_maxcut_step_wg, dim3((unsigned)B), dim3(kIscoWgWaves * kWave), lds_wg, as_stream(stream), aw);
+            ensure_dyn_lds((const void*)k_isco_maxcut_step_wg<false>, lds_wg);
+        hipLaunchKernelGGL(k_isco_maxcut_step_wg<false>, dim3((unsigned)B), dim3(kIscoWgWaves * kWave), lds_wg, as_stream(stream), aw);
         return check_launch("k_isco_maxcut_step_wg");
     }
     IscoMcArgs a{g->rowptr, g->col, use_ell ? g->ell_sym_ptr : nullptr, use_ell ? g->ell_sym : nullptr, x, y_out, B, N, path_length, temperature, u_gumbel, u_accept, seed, env_offset,
-                 energy_out, acc_out, terms_out, mask_out, Pw};
+                 energy_out, acc_out, terms_out, mask_out, Pw, nullptr};
     if (lds > 64 * 1024)
         ensure_dyn_lds((const void*)k_isco_maxcut_step, lds);
     hipLaunchKernelGGL(k_isco_maxcut_step, dim3((unsigned)ceil_div(B, waves)), dim3(waves * kWave), lds, as_stream(stream), a);

@@ -772,7 +772,7 @@ void tsp_2opt_delta(const Tensor& dist, const Tensor& perm, const Tensor& i, con
 }
 void isco_maxcut_step(int64_t g, const Tensor& x, Tensor y_out, const Tensor& path_length, double temperature, const OptTensor& u_gumbel,
                       const OptTensor& u_accept, int64_t seed, int64_t env_offset, const OptTensor& energy_out, const OptTensor& acc_out,
-                      const OptTensor& terms_out, const OptTensor& mask_out) {
+                      const OptTensor& terms_out, const OptTensor& mask_out, const OptTensor& scratch) {
     dev(x, "x", F32);
     dev(y_out, "y_out", F32);
     dev(path_length, "path_length", I64);
@@ -793,7 +793,8 @@ void isco_maxcut_step(int64_t g, const Tensor& x, Tensor y_out, const Tensor& pa
     RLS_GUARD(x);
     ok(rls_isco_maxcut_step(G(g), (const float*)p(x), (float*)p(y_out), B, (const int64_t*)p(path_length), (float)temperature,
                             (const float*)p(u_gumbel), (const float*)p(u_accept), (uint64_t)seed, env_offset, (float*)p(energy_out),
-                            (float*)p(acc_out), (float*)p(terms_out), (uint8_t*)p(mask_out), cur_stream(x)), "rls_isco_maxcut_step");
+                            (float*)p(acc_out), (float*)p(terms_out), (uint8_t*)p(mask_out), p(scratch),
+                            scratch.has_value() ? (int64_t)scratch->nbytes() : 0, cur_stream(x)), "rls_isco_maxcut_step");
 }
 void isco_tsp_step(const Tensor& dist, const Tensor& nearest, double near_threshold, const Tensor& random, const Tensor& perm_in, Tensor perm_out,
                    int64_t path_length, double temperature, const OptTensor& u_partner, const OptTensor& r_near, const OptTensor& r_rand,
@@ -902,7 +903,7 @@ TORCH_LIBRARY(rlsolver_hip, m) {
     m.def("tsp_2opt_delta(Tensor dist, Tensor perm, Tensor i, Tensor j, Tensor(a!) delta) -> ()");
     m.def("tsp_2opt_best(Tensor dist, Tensor perm, Tensor? cur_length, Tensor(a!) best_i, Tensor(b!) best_j, Tensor(c!) best_value) -> ()");
     m.def("isco_maxcut_step(int graph, Tensor x, Tensor(a!) y_out, Tensor path_length, float temperature, Tensor? u_gumbel, Tensor? u_accept, "
-          "int seed, int env_offset, Tensor(b!)? energy_out, Tensor(c!)? acc_out, Tensor(d!)? terms_out, Tensor(e!)? mask_out) -> ()");
+          "int seed, int env_offset, Tensor(b!)? energy_out, Tensor(c!)? acc_out, Tensor(d!)? terms_out, Tensor(e!)? mask_out, Tensor(f!)? scratch=None) -> ()");
     m.def("isco_tsp_step(Tensor dist, Tensor nearest, float near_threshold, Tensor random, Tensor perm_in, Tensor(a!) perm_out, int path_length, "
           "float temperature, Tensor? u_partner, Tensor? r_near, Tensor? r_rand, Tensor? u_gumbel, Tensor? u_accept, int seed, int env_offset, "
           "Tensor(b!)? log_acc_out, Tensor(c!)? acc_out, Tensor(d!)? cur_out) -> ()");

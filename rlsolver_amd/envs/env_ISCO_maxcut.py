@@ -14,7 +14,7 @@ from typing import Optional
 import numpy as np
 import torch
 
-from .. import ops
+from .. import _abi, ops
 from ..graph import build_csr
 from ..ops import _check, _s64, _t
 from ..seeding import Sharded
@@ -48,6 +48,16 @@ class ISCO_maxcut(Sharded):
         bits[:, 0] = ops.rand_spins(self.batch_size, 2, self._next_seed(), self.device, env_offset=self.env_offset)[:, 1]
         return bits.to(torch.float32)
 
+    def _step_scratch(self, B: int):
+        """The step's scratch for rows past the LDS (N > ~15 900: rls_isco_maxcut_scratch_bytes), kept between steps; else None."""
+        need = int(_abi.lib().rls_isco_maxcut_scratch_bytes(self.graph.ref, int(B)))
+        if need == 0:
+            return None
+        have = getattr(self, "_scratch", None)
+        if have is None or have.numel() < need:
+            have = self._scratch = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return have
+
     def step(self, x, path_length, temperature, draws: Optional[dict] = None, want_terms: bool = False):
         """env_ISCO.py:26-35 -> (y f32 [B, N], ll_y * temperature f32 [B], acceptance probability f32 [B]).
 
@@ -69,7 +79,8 @@ class ISCO_maxcut(Sharded):
             ug = _check(draws["u_gumbel"].to(self.device).contiguous(), "u_gumbel", (torch.float32,), self.device, (B, N))
             ua = _check(draws["u_accept"].to(self.device).contiguous(), "u_accept", (torch.float32,), self.device, (B,))
         _t.isco_maxcut_step(self.graph.handle, x, y, pl, float(temperature), ug, ua,
-                            _s64(0 if draws is not None else self._next_seed()), self.env_offset, energy, acc, terms, mask)
+                            _s64(0 if draws is not None else self._next_seed()), self.env_offset, energy, acc, terms, mask,
+                            self._step_scratch(B))
         if want_terms:
             return y, energy, acc, terms, mask
         return y, energy, acc

@@ -92,7 +92,10 @@ def test_isco_maxcut_step_vs_oracle(n, m, B):
 @pytest.mark.parametrize("n,m,B,pl_hi", [(10000, 9999, 6, 300),       # G70's size: the list holds 4096 of 16384 possible entries
                                           (10000, 9999, 700, 60),      # the same through the wave-per-sample kernel
                                           (15000, 30000, 3, 1400),     # rows nearly fill LDS: 512 entries; longer paths are
-                                          (15000, 30000, 600, 900)])   # ordered by extraction (both kernels)
+                                          (15000, 30000, 600, 900),    # ordered by extraction (both kernels)
+                                          (20000, 40000, 4, 1400),     # past the LDS (N > ~15 900): the f32 rows in the step's scratch
+                                          (44000, 88000, 5, 5000),     # ... a selection past the 4096-entry list: by extraction
+                                          (80000, 100000, 300, 90)])   # ... near the byte rows' limit, a workgroup per sample at any batch
 def test_isco_maxcut_step_on_large_graphs_vs_oracle(n, m, B, pl_hi):
     """ISCO_maxcut.step had a size limit the reference has not (env_ISCO.py:51-86): its selected-set list was sized for all N
     nodes and the rows stopped fitting LDS at N = 8192 -- below G70, a BASELINE graph.  The list now takes what the rows leave,
@@ -152,6 +155,34 @@ def test_isco_maxcut_both_kernels_agree():
     assert bool(((tb[:Bs] - ts).abs() <= 4e-7 * scale + 1e-6).all())
     sure = (tb[:Bs, 4] - torch.log(ds["u_accept"].to(DEV) + 1e-24)).abs() > 1e-2       # accept decisions away from the margin
     assert torch.equal(yb[:Bs][sure], ys[sure]) and int(sure.sum()) > Bs // 2
+
+
+def test_isco_maxcut_rows_in_scratch_agree_with_rows_in_lds():
+    """Round 5: past ~15 900 nodes the two f32 rows of a sample (log-probabilities, perturbed values) live in the step's scratch
+    (global memory) instead of LDS.  Forced at a size both forms take (rls_tuning_set), with the same recorded draws: the same
+    arithmetic per element in the same order -- bit-identical outputs against the workgroup-per-sample kernel with rows in LDS."""
+    from rlsolver_amd import _abi
+    from rlsolver_amd.graph import generate_gnm
+    n, m, B = 3000, 9000, 40
+    g = np.asarray(generate_gnm(n, m, 4), dtype=np.int64)
+    s = _maxcut_sampler(g, n, B)
+    rng = np.random.RandomState(8)
+    x = torch.from_numpy(rng.randint(0, 2, size=(B, n)).astype(np.float32)).to(DEV)
+    pl = torch.from_numpy(rng.randint(1, 60, size=B).astype(np.int64)).to(DEV)
+    draws = {"u_gumbel": torch.from_numpy(rng.rand(B, n).astype(np.float32).clip(1e-7, 1 - 1e-7)), "u_accept": torch.from_numpy(rng.rand(B).astype(np.float32))}
+    assert s._step_scratch(B) is None
+    want = s.step(x, pl, 0.7, draws=draws, want_terms=True)
+    _abi.tuning_set("RLS_ISCO_GLOBAL_ROWS", 1)
+    try:
+        assert s._step_scratch(B).numel() == B * n * 8
+        got = s.step(x, pl, 0.7, draws=draws, want_terms=True)
+        _abi.tuning_set("RLS_ISCO_SEL_CAP", 16)                  # ... and with selections past the list (ordered by extraction)
+        got16 = s.step(x, pl, 0.7, draws=draws, want_terms=True)
+    finally:
+        _abi.tuning_unset("RLS_ISCO_GLOBAL_ROWS")
+        _abi.tuning_unset("RLS_ISCO_SEL_CAP")
+    for a, b, c in zip(want, got, got16):
+        assert torch.equal(a, b) and torch.equal(a, c)
 
 
 def _tsp_sampler(z, p, B):
