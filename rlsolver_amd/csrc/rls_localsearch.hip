@@ -35,16 +35,35 @@ constexpr int kTopCap = 16;  // num_spin + 1 <= kTopCap
 
 // insert v into the descending list t[0 .. DEPTH) (entries from DEPTH on are untouched: with DEPTH = num_spin + 1 = the
 // rank the threshold is read at, nothing below it can matter)
+// One v_med3 per level: with t[j-1] >= t[j], the new t[j] is the median of (t[j-1], t[j], v) -- v between them: v; v above both:
+// the old t[j-1] moves down; v below both: t[j] stays -- and every level reads only OLD entries (bottom-up in place), so the levels
+// are independent instructions.  (Until round 5: a chain of max / min pairs, two dependent instructions per level -- 18 of the
+// threshold pass's ~30 instructions per (env, node).)
 template <int DEPTH>
 __device__ __forceinline__ void top_insert_n(float (&t)[kTopCap], float v) {
 #pragma unroll
-    for (int j = 0; j < DEPTH; ++j) {
-        const float hi = fmaxf(t[j], v);
-        v = fminf(t[j], v);
-        t[j] = hi;
-    }
+    for (int j = DEPTH - 1; j >= 1; --j) t[j] = __builtin_amdgcn_fmed3f(t[j - 1], t[j], v);
+    t[0] = fmaxf(t[0], v);
 }
 __device__ __forceinline__ void top_insert(float (&t)[kTopCap], float v) { top_insert_n<kTopCap>(t, v); }
+
+// The mask words of a piece of NPC nodes: lane k < NPC ends with the 64-env word of node k, bit e = (v[k] > th) in env e.
+// One v_cmp per node writes the word into a scalar pair; two v_writelane put it into lane k.  (Until round 5 this was
+// ballot64(valid && v > th) + `if (lane == k) mine = mm`: compare, cndmask + cmp_ne of HIP's int ballot, and two mov + two cndmask
+// for the lane select -- 8 VALU instructions per node where 3 do, a fifth of a proposal round.)  Envs past the batch are masked
+// by `valid_mask` (wave-uniform) once per piece.
+template <int NPC>
+__device__ __forceinline__ uint64_t ls_piece_mask_words(const float (&v)[NPC], float th, uint64_t valid_mask) {
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (int k = 0; k < NPC; ++k) {
+        const uint64_t mm = __builtin_amdgcn_ballot_w64(v[k] > th) & valid_mask;
+        // (the scalar operands come out of an s_and: no VALU-writes-SGPR hazard in front of the v_writelane)
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(lo) : "s"((uint32_t)mm), "n"(k));
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(hi) : "s"((uint32_t)(mm >> 32)), "n"(k));
+    }
+    return ((uint64_t)hi << 32) | lo;
+}
 
 // Counter-based noise for the production path: murmur3's 32-bit finaliser over (seed, global env,
 // node quad, round) -- order-independent like Philox (so results do not depend on how envs are
@@ -332,16 +351,12 @@ __global__ __launch_bounds__(W * kWave) void k_maxcut_local_search(
     }
 
     // ---- phase 2: proposal rounds
+    const uint64_t valid_mask = ballot64(valid);
     for (int itp = 0; itp < num_iters; ++itp) {
         const int it = first_draw_proposes ? itp : itp + 1;
         auto round_pass = [&](auto use_noise) {
         for_each_quad(it, use_noise, [&](int64_t pc, const float (&v)[NPC]) {
-            uint64_t mine = 0;
-#pragma unroll
-            for (int k = 0; k < NPC; ++k) {
-                const uint64_t mm = ballot64(valid && (v[k] > thresh));   // spin_rand.gt(thresh), bit e = env b0 + e
-                if (lane == k) mine = mm;
-            }
+            const uint64_t mine = ls_piece_mask_words<NPC>(v, thresh, valid_mask);   // spin_rand.gt(thresh), bit e = env b0 + e
             const int64_t node = pc * NPC + lane;
             if (lane < NPC && node < N) prop[node] = words[node] ^ mine;
         });
@@ -587,17 +602,13 @@ __global__ __launch_bounds__(kLsRoundWaves * kWave) void k_ls_mask(const WT* __r
         __syncthreads();
     }
     const float th = valid ? thresh[b] : 0.0f;
+    const uint64_t valid_mask = ballot64(valid);
     int64_t c_begin, c_end;
     ls_slice_chunks(ls_num_chunks<WT>(N), (int)blockIdx.y, (int)gridDim.y, c_begin, c_end);
     uint64_t* out = maskw + (int64_t)blockIdx.x * N;
     ls_ws_pass<WT, W>(ws, pitch, B, N, b0, lane, w, stages + (size_t)w * kStageBytes, SD_LDS ? sdl : rd_std, env_key, draw, c_begin, c_end,
                       [&](int64_t pc, const float (&v)[NPC]) {
-                          uint64_t mine = 0;
-#pragma unroll
-                          for (int k = 0; k < NPC; ++k) {
-                              const uint64_t mm = ballot64(valid && (v[k] > th));
-                              if (lane == k) mine = mm;
-                          }
+                          const uint64_t mine = ls_piece_mask_words<NPC>(v, th, valid_mask);
                           const int64_t node = pc * NPC + lane;
                           if (lane < NPC && node < N) out[node] = mine;
                       });
@@ -635,15 +646,11 @@ __global__ __launch_bounds__(kLsRoundWaves * kWave) void k_ls_propose(uint8_t* _
         for (int64_t n = threadIdx.x; n < N; n += W * kWave) words[n] ^= mw[n];
     } else {
         const float th = valid ? thresh[b] : 0.0f;
+        const uint64_t valid_mask = ballot64(valid);
         // the mask words go straight into the tile: a node belongs to exactly one piece of one wave
         ls_ws_pass<WT, W>(ws, pitch, B, N, b0, lane, w, stage, SD_LDS ? sdl : rd_std, env_key, draw, 0, ls_num_chunks<WT>(N),
                           [&](int64_t pc, const float (&v)[NPC]) {
-                              uint64_t mine = 0;
-#pragma unroll
-                              for (int k = 0; k < NPC; ++k) {
-                                  const uint64_t mm = ballot64(valid && (v[k] > th));
-                                  if (lane == k) mine = mm;
-                              }
+                              const uint64_t mine = ls_piece_mask_words<NPC>(v, th, valid_mask);
                               const int64_t node = pc * NPC + lane;
                               if (lane < NPC && node < N) words[node] ^= mine;
                           });

@@ -46,7 +46,9 @@ template <> struct SpinVec<float> {
 };
 
 // 64-bit ballot as two dwords
-__device__ __forceinline__ uint64_t ballot64(bool p) { return __ballot(p); }
+// (HIP's __ballot takes an int: bool -> v_cndmask 0 / 1 -> v_cmp_ne, two VALU instructions per ballot on top of the compare
+// that already wrote the lane mask -- the builtin takes the i1 itself)
+__device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
 // ---- 64x64 bit-matrix transpose across a wavefront.
 // Lane l holds row l as (r1:r0); afterwards lane p holds column p (bit l = old bit p of lane l).

@@ -1,3 +1,6 @@
+"""local_search_inplace at G22 size (weights pre-pass + fused kernel), 4096 and 2^16 envs."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from rlsolver_amd import ops, graph
 from rlsolver_amd.envs.env_L2A import EnvMaxcut
