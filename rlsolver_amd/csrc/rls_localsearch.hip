@@ -586,8 +586,12 @@ __global__ __launch_bounds__(kWave) void k_ls_threshold_merge(const float* __res
 template <typename WT, bool SD_LDS = true>
 __global__ __launch_bounds__(kLsRoundWaves * kWave) void k_ls_mask(const WT* __restrict__ ws, int64_t pitch, int64_t B, int64_t N,
                                                                    const float* __restrict__ rd_std, const float* __restrict__ thresh,
-                                                                   uint64_t seed, int64_t env_offset, int draw,
-                                                                   uint64_t* __restrict__ maskw) {
+                                                                   uint64_t seed, int64_t env_offset, int first_draw,
+                                                                   uint64_t* __restrict__ maskw_all, int64_t round_words) {
+    // blockIdx.z = the round: draw first_draw + z into maskw_all + z * round_words (all rounds of a call in ONE launch: a round of a
+    // 4096-env batch is 128 workgroups -- 8 launches of 12.8 us where the chip does the eight in ~25)
+    const int draw = first_draw + (int)blockIdx.z;
+    uint64_t* maskw = maskw_all + (int64_t)blockIdx.z * round_words;
     constexpr int W = kLsRoundWaves, NPC = 16 / (int)sizeof(WT);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* stages = smem;
@@ -1022,7 +1026,7 @@ extern "C" int rls_maxcut_ls_propose(const rls_graph* g, uint8_t* x, int64_t B, 
     do {                                                                                                               \
         auto kern = k_ls_mask<WT>;                                                                                     \
         if (ldm > 64 * 1024) ensure_dyn_lds((const void*)kern, ldm); \
-        hipLaunchKernelGGL(kern, gm, block, ldm, s, (const WT*)ws, ws_pitch, B, N, rd_std, thresh, seed, env_offset, (int)draw, (uint64_t*)scratch); \
+        hipLaunchKernelGGL(kern, gm, block, ldm, s, (const WT*)ws, ws_pitch, B, N, rd_std, thresh, seed, env_offset, (int)draw, (uint64_t*)scratch, (int64_t)0); \
     } while (0)
         if (ws_bytes == 1) LAUNCH_MK(int8_t); else LAUNCH_MK(int16_t);
 #undef LAUNCH_MK
@@ -1089,19 +1093,19 @@ extern "C" int rls_maxcut_ls_rounds(const rls_graph* g, uint8_t* x, int64_t B, c
     const int halve = g->if_bidirectional ? 1 : 0, x_aligned = tile_rows_aligned(x, N, 1) ? 1 : 0;
     const int per_launch = all_at_once ? num_draws : 1;       // rounds whose mask words are in the scratch at once
     for (int32_t r0 = 0; r0 < num_draws; r0 += per_launch) {
-        for (int32_t r = 0; r < per_launch; ++r) {
-            uint64_t* out = (uint64_t*)scratch + (size_t)r * grid.x * (size_t)N;
-            const dim3 block(kLsRoundWaves * kWave);
+        {   // the mask words of the per_launch rounds: one launch, blockIdx.z = round
+            const dim3 block(kLsRoundWaves * kWave), gz(gm.x, gm.y, (unsigned)per_launch);
+            const int64_t round_words = (int64_t)grid.x * N;
             if (ws_bytes == 1) {
                 auto kern = sd_lds ? k_ls_mask<int8_t, true> : k_ls_mask<int8_t, false>;
                 if (ldm > 64 * 1024) ensure_dyn_lds((const void*)kern, ldm);
-                hipLaunchKernelGGL(kern, gm, block, ldm, s, (const int8_t*)ws, ws_pitch, B, N, rd_std, thresh, seed, env_offset,
-                                   (int)(first_draw + r0 + r), out);
+                hipLaunchKernelGGL(kern, gz, block, ldm, s, (const int8_t*)ws, ws_pitch, B, N, rd_std, thresh, seed, env_offset,
+                                   (int)(first_draw + r0), (uint64_t*)scratch, round_words);
             } else {
                 auto kern = sd_lds ? k_ls_mask<int16_t, true> : k_ls_mask<int16_t, false>;
                 if (ldm > 64 * 1024) ensure_dyn_lds((const void*)kern, ldm);
-                hipLaunchKernelGGL(kern, gm, block, ldm, s, (const int16_t*)ws, ws_pitch, B, N, rd_std, thresh, seed, env_offset,
-                                   (int)(first_draw + r0 + r), out);
+                hipLaunchKernelGGL(kern, gz, block, ldm, s, (const int16_t*)ws, ws_pitch, B, N, rd_std, thresh, seed, env_offset,
+                                   (int)(first_draw + r0), (uint64_t*)scratch, round_words);
             }
         }
         if (int rc = check_launch("k_ls_mask")) return rc;

@@ -19,7 +19,7 @@ def t(f, reps=5):
 
 
 for n, m, Bs in ((44000, 88000, (256, 4096)), (100000, 200000, (256, 4096)), (160000, 320000, (4096,)), (10000, 9999, (256, 1024, 4096)),
-                 (20000, 40000, (256, 1024, 4096)), (2000, 19990, (256, 1024))):
+                 (20000, 40000, (256, 1024, 4096)), (2000, 19990, (256, 1024, 2048, 4096, 8192))):
     env = EnvMaxcut(mygraph=generate_gnm(n, m, 7), device=dev, num_nodes=n)
     g = env.graph
     for B in Bs:
