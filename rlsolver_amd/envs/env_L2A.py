@@ -114,6 +114,12 @@ class EnvMaxcut(Sharded):
                                    noise=noise, first_draw_proposes=False, compute_vs=compute_vs)
         return good_xs, vs
 
+    def _num_cus(self) -> int:
+        n = getattr(self, "_cus", None)
+        if n is None:
+            n = self._cus = int(th.cuda.get_device_properties(self.device).multi_processor_count)
+        return n
+
     def local_search_pipeline(self, xs: TEN, vs: TEN, weight_mult: int, num_iters: int, num_spin: int, noise_std: float,
                               noise: Optional[TEN], first_draw_proposes: bool, compute_vs: bool = False) -> None:
         """The common body of local_search_inplace (env_L2A.py:87-116) and LocalSearch.random_search
@@ -132,7 +138,10 @@ class EnvMaxcut(Sharded):
                       and ops.ls_rounds_supported(self.graph, num_spin))
         # a batch of few tiles: the round kernels spread each tile's noise passes over several workgroups and beat the fused
         # kernel's one workgroup per tile (G22-sized, 256 - 8192 envs: 0.32 - 0.35 vs 0.39 - 0.41 ms; same result bit for bit)
-        few_tiles = rounds_can and num_iters > 0 and not self.force_ls_fused and ops.ls_slices(self.graph, B, wdt) > 1
+        # (also where a short row leaves one slice per tile -- G14-sized, 2048 / 8192 envs: 117 / 150 vs 170 / 176 us --: all rounds' mask
+        # words are one launch of tiles x rounds workgroups; tools/timing/ls_forms.py)
+        few_tiles = (rounds_can and num_iters > 0 and not self.force_ls_fused
+                     and (ops.ls_slices(self.graph, B, wdt) > 1 or 2 * ((B + 63) // 64) <= self._num_cus()))
         fused_ok = (self.fused_local_search and not self.force_ls_rounds and not few_tiles
                     and ops.local_search_fusable(self.graph, num_spin, B)
                     and xs.data_ptr() % 16 == 0 and (noise is None or noise.data_ptr() % 16 == 0))   # (views that start mid-row)
