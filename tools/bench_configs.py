@@ -98,13 +98,27 @@ def maxcut_suite(tag, n, m, B, seed, iters, mygraph=None):
     emit(tag, "K1 maxcut_obj", "evals", B, t, n + 8)
     mask = torch.rand((B, n), device=dev) < 8.0 / n
     vs = ops.maxcut_obj(g, x)
+    # accepted rows are WRITTEN (N bytes each): the same mask applied again and again flips a row back and forth, and at least one of
+    # the two directions is accepted (ties are) -- the accept rate of this loop is measured and its rows counted
+    def accept_rate(m):
+        acc = 0.0
+        for _ in range(4):
+            v0 = vs.clone()
+            x0 = x.clone()
+            ops.maxcut_propose_accept(g, x, m, vs)
+            acc += float((x != x0).any(dim=1).float().mean()) / 4
+            del v0, x0
+        return acc
     t = timeit(lambda i: ops.maxcut_propose_accept(g, x, mask, vs), max(3, iters // 4))
-    emit(tag, "K6 propose_accept", "proposals", B, t, 2 * n + 16)
+    ar = accept_rate(mask)
+    emit(tag, "K6 propose_accept", "proposals", B, t, 2 * n + 16 + ar * n, f"x in, byte mask in, accepted rows out (accept rate of this loop {ar:.3f})")
     if n * 8 + 4096 <= 160 * 1024:
         from rlsolver_amd.ops_mcpg_tsp import PackedChains
         mwords = PackedChains.pack(mask.t().contiguous()).words
         t = timeit(lambda i: ops.maxcut_propose_accept(g, x, mwords, vs), max(3, iters // 4))
-        emit(tag, "K6 propose_accept, bit-packed mask", "proposals", B, t, 2 * n + n // 8 + 16, "x in, mask words in, accepted rows out")
+        ar = accept_rate(mwords)
+        emit(tag, "K6 propose_accept, bit-packed mask", "proposals", B, t, 2 * n + n // 8 + 16 + ar * n,
+             f"x in, mask words in, accepted rows out (accept rate of this loop {ar:.3f})")
     t = timeit(lambda i: ops.maxcut_greedy_sweep(g, x, vs), max(2, iters // 10))
     # LDS-op rate: a sweep reads one 64-env word per (node, neighbour) and per node, and writes one per node;
     # LDS peak = 128 B / clk / CU x 256 CUs x 2.4 GHz = 78.6 TB/s

@@ -140,6 +140,19 @@ def main():
     trace, meta = load_trace(f"{src}_{a.what}_kt/{pfx}_kernel_trace.csv")
     fetch = load_pmc(f"{src}_{a.what}_fetch/{pfx}_counter_collection.csv", "FETCH_SIZE")
     write = load_pmc(f"{src}_{a.what}_write/{pfx}_counter_collection.csv", "WRITE_SIZE")
+    # K6 writes its accepted rows: the accept rate of the timed loop is measured by tools/bench_configs.py (in the row's note) and those
+    # N bytes per accepted proposal are algorithmic bytes of the launch
+    k6_rate = {}
+    cfg_path = f"profiles/{a.tag}_configs_profiled.jsonl"
+    if os.path.exists(cfg_path):
+        for line in open(cfg_path):
+            try:
+                r = json.loads(line)
+            except ValueError:
+                continue
+            m = re.search(r"accept rate of this loop ([0-9.]+)", r.get("note", ""))
+            if m and r.get("kernel", "").startswith("K6"):
+                k6_rate[(r["config"][:3], "bit-packed" in r["kernel"])] = float(m.group(1))
     out = []
     for k, durs in sorted(trace.items(), key=lambda kv: -sum(kv[1])):
         name, grid, wg, lds = k
@@ -162,6 +175,12 @@ def main():
             if label is None or re.search(pat, name) is None or (want_grid is not None and want_grid != grid):
                 continue
             rec.update({"row": label, "units_per_launch": B})
+            if per_unit is not None and label.startswith("K6"):
+                size = "G22" if "G22" in label else "G70"
+                rate = k6_rate.get((size, "bit-packed" in label))
+                if rate is not None:
+                    per_unit = per_unit + rate * (N22 if size == "G22" else N70)
+                    rec["row"] = label + f" (accept rate {rate:.2f}: those rows are written)"
             if per_unit is not None:
                 rec.update({"algorithmic_bytes": B * per_unit, "achieved_GBps": B * per_unit / (rec["mean_us"] * 1e-6) / 1e9,
                             "frac_of_8TBps": B * per_unit / (rec["mean_us"] * 1e-6) / HBM})
