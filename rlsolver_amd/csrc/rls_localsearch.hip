@@ -122,6 +122,87 @@ __device__ __forceinline__ void normal4(EnvKey env_key, uint32_t q, uint32_t it,
     z[2] = rb * __builtin_amdgcn_cosf(t4); z[3] = rb * __builtin_amdgcn_sinf(t4);
 }
 
+// =====================================================================================
+// One proposal round's mask words with LANE = NODE (round 5): a lane owns 8 (int8 weights) / 4 (int16) consecutive nodes of a 512- /
+// 256-node slot and walks 32 of the tile's 64 envs; env e's compare writes a lane mask, and ONE v_addc shifts that bit into the
+// node's half word (envs 31 .. 0 of the half in that order, so env e lands on bit e).  A task = (slot, half of the envs); wave gw of
+// GW takes every GW-th task and writes its 32-bit halves of the mask words -- G22-sized rows: 8 tasks per tile and round.
+// Against the lane = env form (kept for the threshold pass, whose top-k is per env): no corner turn of ws through LDS, rd_std in
+// registers for the 32 envs, the per-env key / threshold as scalars, 1 instruction per node for the mask bit where v_writelane
+// needed 2 -- 14.5 issue slots per (env, node) against 16.75.  The draws are normal4's: the same values whatever the form.
+//   key / thresh: the caller's lane = env registers (lane e holds env b0 + e; thresh = +inf in lanes past the batch: their envs
+//   propose nothing);  noise_it: recorded draws of this round (f32 [B, N], test hook) or NULL;  emit(node, half, word32) is called by the lane that owns `node`, for node < N.
+// ws rows sit `pitch` entries apart (a multiple of 16 bytes), N % 4 == 0.
+// =====================================================================================
+template <typename WT, bool USE_NOISE, int LB = 8, typename Emit>   // LB: bytes of a ws row per lane and env (8 | 16)
+__device__ __forceinline__ void ls_round_words_lane_node(const WT* __restrict__ ws, int64_t pitch, int64_t B, int64_t N, int64_t b0, int lane,
+                                                         int gw, int GW, const float* __restrict__ rd_std, EnvKey key, float thresh,
+                                                         const float* __restrict__ noise_it, int it, Emit&& emit) {
+    constexpr int NPL = LB / (int)sizeof(WT), QPL = NPL / 4;     // nodes / quads per lane
+    constexpr int64_t SPAN = 64 * NPL;                           // nodes per slot
+    constexpr int PF = 8;                                        // envs whose pieces are in flight
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(LB / 4)));
+    const int64_t ntasks = 2 * ((N + SPAN - 1) / SPAN);
+    for (int64_t t = gw; t < ntasks; t += GW) {
+        const int half = (int)(t & 1);
+        const int64_t node = (t >> 1) * SPAN + (int64_t)lane * NPL;
+        const int64_t nodec = node < N ? node : 0;               // (lanes past the row read its start and emit nothing)
+        float sd[NPL];
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) sd[k] = (node + k < N) ? rd_std[node + k] : 0.0f;
+        uint32_t acc[NPL];
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) acc[k] = 0u;
+        const uint32_t q0 = (uint32_t)(nodec >> 2);
+        const int ebase = 32 * half;
+        auto row_of = [&](int e) { const int64_t b = b0 + e; return b < B ? b : b0; };
+        auto fetch = [&](int e) { return *reinterpret_cast<const u32x2*>(ws + row_of(e) * pitch + nodec); };
+        auto one_env = [&](int e, u32x2 piece) {
+            EnvKey ek;
+            ek.k0 = (uint32_t)__builtin_amdgcn_readlane((int)key.k0, e);
+            ek.k1 = (uint32_t)__builtin_amdgcn_readlane((int)key.k1, e);
+            const float th = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, thresh), e));
+#pragma unroll
+            for (int sq = 0; sq < QPL; ++sq) {
+                float z[4];
+                if constexpr (USE_NOISE) {
+                    const f32x4 zz = *reinterpret_cast<const f32x4*>(noise_it + row_of(e) * N + nodec + 4 * sq);
+                    z[0] = zz[0]; z[1] = zz[1]; z[2] = zz[2]; z[3] = zz[3];
+                } else {
+                    normal4(ek, q0 + (uint32_t)sq, (uint32_t)it, z);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    int wv;
+                    if constexpr (sizeof(WT) == 1) wv = (int)(int8_t)(piece[sq] >> (8 * k));
+                    else wv = (int)(int16_t)(piece[2 * sq + (k >> 1)] >> (16 * (k & 1)));
+                    const float v = (float)wv + z[k] * sd[4 * sq + k];          // two roundings: torch's ws + randn * rd_std
+                    uint64_t m = __builtin_amdgcn_ballot_w64(v > th);           // lane mask of "this lane's node k is proposed in env e"
+                    // acc = 2 acc + (this lane's bit of m): the carry-in of an add-with-carry (the carry-out lands in the same pair)
+                    asm("v_addc_co_u32_e64 %0, %1, %0, %0, %1" : "+v"(acc[4 * sq + k]), "+s"(m));
+                }
+            }
+        };
+        u32x2 cur[PF], nxt[PF];
+#pragma unroll
+        for (int j = 0; j < PF; ++j) nxt[j] = cur[j] = fetch(ebase + 31 - j);
+#pragma unroll 1
+        for (int e0 = 31; e0 >= 0; e0 -= PF) {
+            if (e0 - PF >= 0) {
+#pragma unroll
+                for (int j = 0; j < PF; ++j) nxt[j] = fetch(ebase + e0 - PF - j);
+            }
+#pragma unroll
+            for (int j = 0; j < PF; ++j) one_env(ebase + e0 - j, cur[j]);
+#pragma unroll
+            for (int j = 0; j < PF; ++j) cur[j] = nxt[j];
+        }
+#pragma unroll
+        for (int k = 0; k < NPL; ++k)
+            if (node + k < N) emit(node + k, half, acc[k]);
+    }
+}
+
 // ALIGNED (the only form built since round 3): rows of x and noise start 4-byte aligned on 16-byte bases (N % 4 == 0), rows
 // of ws sit `pitch` entries apart, a multiple of 16 bytes, so every 16-byte piece of a ws row lies inside the row.
 // WT = int8_t | int16_t.
@@ -356,9 +437,12 @@ __global__ __launch_bounds__(W * kWave) void k_maxcut_local_search(
     }
 
     // ---- phase 2: proposal rounds
+#ifdef RLS_LS_ROUND_LANE_ENV
     const uint64_t valid_mask = ballot64(valid);
+#endif
     for (int itp = 0; itp < num_iters; ++itp) {
         const int it = first_draw_proposes ? itp : itp + 1;
+#ifdef RLS_LS_ROUND_LANE_ENV   // dev build: the lane = env round (until round 5), for A/B timing
         auto round_pass = [&](auto use_noise) {
         for_each_quad(it, use_noise, [&](int64_t pc, const float (&v)[NPC]) {
             const uint64_t mine = ls_piece_mask_words<NPC>(v, thresh, valid_mask);   // spin_rand.gt(thresh), bit e = env b0 + e
@@ -367,6 +451,19 @@ __global__ __launch_bounds__(W * kWave) void k_maxcut_local_search(
         });
         };
         if (noise) round_pass(with_noise{}); else round_pass(no_noise{});
+#else
+        {   // spin_rand.gt(thresh) with lane = node: a wave's tasks write their 32-bit halves of prop[] (bit e = env b0 + e)
+            uint32_t* prop32 = reinterpret_cast<uint32_t*>(prop);
+            const uint32_t* words32 = reinterpret_cast<const uint32_t*>(words);
+            auto put = [&](int64_t node, int half, uint32_t wd) { prop32[2 * node + half] = words32[2 * node + half] ^ wd; };
+            const float th_e = valid ? thresh : INFINITY;
+#ifndef RLS_LS_LB
+#define RLS_LS_LB 8
+#endif
+            if (noise) ls_round_words_lane_node<WT, true>(ws, pitch, B, N, b0, lane, w, W, rd_std, env_key, th_e, noise + (int64_t)it * B * N, it, put);
+            else ls_round_words_lane_node<WT, false, RLS_LS_LB>(ws, pitch, B, N, b0, lane, w, W, rd_std, env_key, th_e, nullptr, it, put);
+        }
+#endif
         __syncthreads();
         int64_t total = block_sum_partials<W>(tile_cut_count<P>(prop, eu, ev, E, lane, w, W), scratch, lane, w);
         if (halve) total >>= 1;
@@ -597,30 +694,18 @@ __global__ __launch_bounds__(kLsRoundWaves * kWave) void k_ls_mask(const WT* __r
     // 4096-env batch is 128 workgroups -- 8 launches of 12.8 us where the chip does the eight in ~25)
     const int draw = first_draw + (int)blockIdx.z;
     uint64_t* maskw = maskw_all + (int64_t)blockIdx.z * round_words;
-    constexpr int W = kLsRoundWaves, NPC = 16 / (int)sizeof(WT);
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* stages = smem;
-    float* sdl = reinterpret_cast<float*>(stages + (size_t)W * kStageBytes);
+    constexpr int W = kLsRoundWaves;
     const int lane = threadIdx.x & (kWave - 1);
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
     const int64_t b0 = (int64_t)blockIdx.x * kWave, b = b0 + lane;
     const bool valid = b < B;
     const EnvKey env_key = ls_env_key(seed, (uint64_t)(b + env_offset));
-    if constexpr (SD_LDS) {
-        for (int64_t i = threadIdx.x; i < ((N + 3) & ~3ll); i += W * kWave) sdl[i] = i < N ? rd_std[i] : 0.0f;   // rd_std: one broadcast read per quad
-        __syncthreads();
-    }
-    const float th = valid ? thresh[b] : 0.0f;
-    const uint64_t valid_mask = ballot64(valid);
-    int64_t c_begin, c_end;
-    ls_slice_chunks(ls_num_chunks<WT>(N), (int)blockIdx.y, (int)gridDim.y, c_begin, c_end);
-    uint64_t* out = maskw + (int64_t)blockIdx.x * N;
-    ls_ws_pass<WT, W>(ws, pitch, B, N, b0, lane, w, stages + (size_t)w * kStageBytes, SD_LDS ? sdl : rd_std, env_key, draw, c_begin, c_end,
-                      [&](int64_t pc, const float (&v)[NPC]) {
-                          const uint64_t mine = ls_piece_mask_words<NPC>(v, th, valid_mask);
-                          const int64_t node = pc * NPC + lane;
-                          if (lane < NPC && node < N) out[node] = mine;
-                      });
+    const float th = valid ? thresh[b] : INFINITY;
+    // lane = node (ls_round_words_lane_node): the tile's tasks over the waves of its gridDim.y workgroups; rd_std straight from
+    // global memory into registers (SD_LDS and the dynamic LDS the launcher still sizes are unused by this form)
+    uint32_t* out32 = reinterpret_cast<uint32_t*>(maskw + (int64_t)blockIdx.x * N);
+    ls_round_words_lane_node<WT, false>(ws, pitch, B, N, b0, lane, (int)blockIdx.y * W + w, (int)gridDim.y * W, rd_std, env_key, th, nullptr, draw,
+                                        [&](int64_t node, int half, uint32_t wd) { out32[2 * node + half] = wd; });
 }
 
 // one proposal round: x ^= (ws + normal(draw) * rd_std > thresh) for the envs whose cut does not decrease; obj updated
@@ -654,15 +739,11 @@ __global__ __launch_bounds__(kLsRoundWaves * kWave) void k_ls_propose(uint8_t* _
         const uint64_t* mw = maskw + (int64_t)blockIdx.x * N;
         for (int64_t n = threadIdx.x; n < N; n += W * kWave) words[n] ^= mw[n];
     } else {
-        const float th = valid ? thresh[b] : 0.0f;
-        const uint64_t valid_mask = ballot64(valid);
+        const float th = valid ? thresh[b] : INFINITY;
         // the mask words go straight into the tile: a node belongs to exactly one piece of one wave
-        ls_ws_pass<WT, W>(ws, pitch, B, N, b0, lane, w, stage, SD_LDS ? sdl : rd_std, env_key, draw, 0, ls_num_chunks<WT>(N),
-                          [&](int64_t pc, const float (&v)[NPC]) {
-                              const uint64_t mine = ls_piece_mask_words<NPC>(v, th, valid_mask);
-                              const int64_t node = pc * NPC + lane;
-                              if (lane < NPC && node < N) words[node] ^= mine;
-                          });
+        uint32_t* words32 = reinterpret_cast<uint32_t*>(words);
+        ls_round_words_lane_node<WT, false>(ws, pitch, B, N, b0, lane, w, W, rd_std, env_key, th, nullptr, draw,
+                                            [&](int64_t node, int half, uint32_t wd) { words32[2 * node + half] ^= wd; });
     }
     __syncthreads();
     int64_t total = block_sum_partials<W>(tile_cut_count<P>(words, eu, ev, E, lane, w, W), scratch, lane, w);
