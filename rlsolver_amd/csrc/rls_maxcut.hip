@@ -642,11 +642,19 @@ __global__ __launch_bounds__(NSW * kWave) void k_node_stats_bits(const uint8_t* 
                                                                      const int32_t* __restrict__ ell, int mult,
                                                                      void* __restrict__ out_v, int32_t* __restrict__ minmax,
                                                                      int64_t out_pitch,     // row pitch of out_v in elements (MODE 2; N otherwise)
-                                                                     int has_stage) {       // 0: the tile alone fills LDS (N ~ 20 000): lane-per-env loads
+                                                                     int stage_flags) {     // bit 0: row-piece stages (0: the tile alone fills LDS,
+                                                                                            // N ~ 20 000: lane-per-env loads); bit 1: min / max stash
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint64_t* words = reinterpret_cast<uint64_t*>(smem);
     const int lane = threadIdx.x & (kWave - 1);
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    const int has_stage = stage_flags & 1;
+    // MODE 2's batch min / max: every tile of the first round of workgroups reaches a node's fold at about the same time, finds the fill
+    // value there and sends its atomic -- 768 of them per node, serialised in L2 (G22 2^16: 55 of the pre-pass's 131 us).  So only the
+    // first few tiles ("seeds": 16) fold as they go; the others park (lo, hi) per node in LDS (the stages' bytes, idle after the tile load)
+    // and fold after their last store, when the seeds' values are in the table and the test in front of the atomic fails almost always
+    const bool park = MODE == 2 && (stage_flags & 2) && (int)blockIdx.x >= (stage_flags >> 8);     // (bits 8..: the number of seed tiles)
+    uint32_t* stash = reinterpret_cast<uint32_t*>(smem + (((size_t)N * 8 + 15) & ~(size_t)15));      // [N] (lo + 32768) | (hi + 32768) << 16
     unsigned char* stage = smem + (((size_t)N * 8 + 15) & ~(size_t)15) + (size_t)w * kStageBytes;
     const int64_t b0 = (int64_t)blockIdx.x * kWave;
     tile_load_bits<uint8_t, VEC>(x, B, N, b0, words, lane, w, NSW, has_stage ? stage : nullptr);
@@ -752,6 +760,7 @@ __global__ __launch_bounds__(NSW * kWave) void k_node_stats_bits(const uint8_t* 
                 }
                 if (w == 0) emit_hub(i, in, deg, md, pw);
             }
+            if (park) __syncthreads();                           // the stash lies where the last exchange was read
         }
     }
     for (int64_t g = w; g < G; g += NSW) {
@@ -782,7 +791,9 @@ __global__ __launch_bounds__(NSW * kWave) void k_node_stats_bits(const uint8_t* 
             if (minmax && in) {
                 int cmn, cmx;
                 planes_minmax<8>(pl, vmask, cmn, cmx);
-                ws_minmax_update(minmax, N, i, deg - mult * cmx, deg - mult * cmn);
+                const int lo = deg - mult * cmx, hi = deg - mult * cmn;
+                if (park) stash[i] = (uint32_t)(lo + 32768) | ((uint32_t)(hi + 32768) << 16);
+                else ws_minmax_update(minmax, N, i, lo, hi);
             }
         }
         if constexpr (MODE == 2 && sizeof(WT) == 1) {
@@ -843,6 +854,36 @@ __global__ __launch_bounds__(NSW * kWave) void k_node_stats_bits(const uint8_t* 
                         const int e = half * 32 + r + 8 * j;
                         if (e < nenv && in) emit(i, deg, e, (int)((acc >> (8 * j)) & 0xFFu));
                     }
+                }
+            }
+        }
+    }
+    if constexpr (MODE == 2) {
+        if (park && minmax) {      // the parked folds, in the order the seeds folded theirs (every wave reads what it wrote itself)
+            // ... in eight phases ~1 us apart (a tile's phase = its index mod 8), so that a phase finds what the phases before it folded
+            // (G22 2^16: 110 -> 96 us; without the fold the pre-pass is 80)
+            for (int k = 0; k < (int)(blockIdx.x & 7); ++k) __builtin_amdgcn_s_sleep(32);
+            // four groups at a time: their eight table reads are in flight together (one after the other they were a chain of L2 round
+            // trips per wave)
+            for (int64_t g0 = w; g0 < G; g0 += 4 * NSW) {
+                int cur_lo[4], cur_hi[4];
+                bool on[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int64_t g = g0 + (int64_t)q * NSW, i = (g << 6) + lane;
+                    on[q] = g < G && i < N && ((ell_ptr[g + 1] - ell_ptr[g]) >> 6) < 256;   // (a hub group: folded by emit_hub as it went)
+                    const int64_t ic = on[q] ? i : 0;
+                    cur_lo[q] = __hip_atomic_load(minmax + ic, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    cur_hi[q] = __hip_atomic_load(minmax + N + ic, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (!on[q]) continue;
+                    const int64_t i = ((g0 + (int64_t)q * NSW) << 6) + lane;
+                    const uint32_t v = stash[i];
+                    const int lo = (int)(v & 0xFFFFu) - 32768, hi = (int)(v >> 16) - 32768;
+                    if (lo < cur_lo[q]) atomicMin(minmax + i, lo);
+                    if (hi > cur_hi[q]) atomicMax(minmax + N + i, hi);
                 }
             }
         }
@@ -1070,7 +1111,16 @@ static int launch_node_stats_bits(const rls_graph* g, const uint8_t* x, int64_t 
     (void)resident;
     const bool four = force_w == 4 && !wide && has_stage;
     const int waves = four ? 4 : kNsWaves;
-    const size_t lds = node_stats_bits_lds(N, has_stage != 0, waves);
+    size_t lds = node_stats_bits_lds(N, has_stage != 0, waves);
+    // MODE 2's parked min / max folds (the kernel's comment): 4 N bytes behind the tile, over the stages' bytes -- where they fit
+    // without costing the CU a workgroup
+    int stage_flags = has_stage;
+    const int seeds = (int)knob(KN_NS_PARK, 16);       // dev knob: 0 = every tile folds as it goes
+    if (MODE == 2 && minmax && seeds > 0 && tiles > seeds) {
+        const size_t with_stash = node_stats_bits_lds(N, false, waves) + (size_t)N * 4;
+        const size_t need = with_stash > lds ? with_stash : lds;
+        if (need <= (size_t)kLdsBytes && (size_t)kLdsBytes / need == (size_t)kLdsBytes / lds) { lds = need; stage_flags |= 2 | (seeds << 8); }
+    }
     const dim3 grid((unsigned)tiles), block(waves * kWave);
 #define RLS_NS_LAUNCH(KERN)                                                                                         \
     do {                                                                                                            \
@@ -1078,7 +1128,7 @@ static int launch_node_stats_bits(const rls_graph* g, const uint8_t* x, int64_t 
         if (lds > 64 * 1024)                                                                                        \
             ensure_dyn_lds((const void*)kern, lds);     \
         hipLaunchKernelGGL(kern, grid, block, lds, as_stream(stream), x, B, N, rowptr, ell_ptr, ell, mult, out, minmax, \
-                           out_pitch > 0 ? out_pitch : N, has_stage);                                               \
+                           out_pitch > 0 ? out_pitch : N, stage_flags);                                             \
     } while (0)
     if (four) {
         if (vec) RLS_NS_LAUNCH((k_node_stats_bits<MODE, true, false, WT, 4>));
