@@ -49,6 +49,15 @@ while time.time() < t_end:
     yb, eb, ab, tb, mb = big.step(x, pl, T, draws=draws, want_terms=True)
     ds = {k: v[:Bs] for k, v in draws.items()}
     ys, es, as_, ts, ms = small.step(x[:Bs].contiguous(), pl[:Bs].contiguous(), T, draws=ds, want_terms=True)
+    if it % 3 == 0 and n >= 256:     # (n >= 256: the workgroup kernel either way) the same samples with the f32 rows in the step's
+                                      # scratch (the form N > ~15 900 takes): the same bits
+        _abi.tuning_set("RLS_ISCO_GLOBAL_ROWS", 1)
+        try:
+            got = small.step(x[:Bs].contiguous(), pl[:Bs].contiguous(), T, draws=ds, want_terms=True)
+        finally:
+            _abi.tuning_unset("RLS_ISCO_GLOBAL_ROWS")
+        for a, b in zip((ys, es, as_, ts, ms), got):
+            assert torch.equal(a, b), "rows in scratch vs rows in LDS " + tag
     assert bool((mb.sum(1) >= pl).all()), "path length " + tag     # ties at the threshold are all selected (util.py:514-555)
     # the path log-probabilities are ill-conditioned in the reference itself (tests/isco_tol.py): tolerance from the float64 oracle
     r = oi.maxcut_step(x[:Bs].cpu().numpy(), g[:, 0], g[:, 1], pl[:Bs].cpu().numpy(), T, ds["u_gumbel"].numpy(), ds["u_accept"].numpy())
