@@ -828,7 +828,8 @@ __global__ __launch_bounds__(NSW * kWave) void k_node_stats_bits(const uint8_t* 
         // 256 bytes per group instead of 64 of 256 bytes, ~30 % fewer VALU -- was built and measured in round 5: G22 2^16 164.6 ->
         // 161.8 us, G70 2^17 1647 -> 1719, BA-1e4 1099 -> 1083: nothing.  K3 sits at what its WRITE PATTERN reaches on this pool --
         // 64 rows x 256-byte pieces, rows 4N bytes apart and every other one starting mid-line: 4.0 TB/s in isolation
-        // (tools/ceilings/store_width.hip) -- not at an instruction bound)
+        // (tools/ceilings/store_width.hip) -- not at an instruction bound.  Non-temporal result stores, also round 5: G70 2^17 K3 1627 vs
+        // 1628 us, K2 2320-2340 either way, BA-1e4 2^15 546 vs 545: nothing)
         if (nenv == kWave) {
             // full tile: no per-store guards (each cost a scalar compare / exec save / branch around a 4-instruction store)
             if (in) {
