@@ -816,7 +816,13 @@ int rls_isco_maxcut_step(const rls_graph* g, const float* x, float* y_out, int64
     const size_t per_wave = rows + (size_t)P * 8;
     RLS_REQUIRE(per_wave + fixed <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "N=%lld needs %zu B of LDS per env (max %d)", (long long)N,
                 per_wave + fixed, kLdsBytes);
-    const bool use_wg = B <= (int64_t)2 * num_cus() && N >= 4 * kWave && per_wave + fixed <= (size_t)kLdsBytes;
+    const int force_wg = (int)knob(KN_ISCO_FORCE_WG, -1);      // dev knob: 0 wave per sample, 1 workgroup per sample
+    // The workgroup kernel (8-bit radix passes, node loops over 16 waves) also wins at LARGE batches from ~1500 nodes on: a wave's
+    // select is 32 one-bit passes over all its keys (from LDS past 2048 nodes) and its rows leave a CU ever fewer samples -- 4096
+    // samples (tools/timing/isco_kernels.py): N = 2000 485 vs 427 us, N = 4000 2121 vs 527, G70's 10^4 8410 vs 852, N = 15 000 14 526
+    // vs 1320; at N = 800 the wave kernel keeps the large batches (163 vs 301)
+    const bool use_wg = force_wg >= 0 ? (force_wg != 0 && N >= 4 * kWave)
+                                      : (B <= (int64_t)2 * num_cus() || N >= 1536) && N >= 4 * kWave && per_wave + fixed <= (size_t)kLdsBytes;
     // wave-per-sample kernel: one wave per SIMD is latency-bound (round 3: 4 samples per CU), so the list gives up capacity for
     // resident samples while it stays >= 512 entries -- the reference draws Poisson(~10) path lengths, a longer selection takes
     // the extraction path -- G22-sized rows: 2048 entries x 4 samples -> 512 x 6 per CU, 4096 samples 606 -> 508 us

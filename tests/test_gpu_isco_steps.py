@@ -90,7 +90,8 @@ def test_isco_maxcut_step_vs_oracle(n, m, B):
 
 
 @pytest.mark.parametrize("n,m,B,pl_hi", [(10000, 9999, 6, 300),       # G70's size: the list holds 4096 of 16384 possible entries
-                                          (10000, 9999, 700, 60),      # the same through the wave-per-sample kernel
+                                          (10000, 9999, 700, 60),      # the same through the wave-per-sample kernel (forced)
+                                          (10000, 9999, 650, 60),      # ... and a large batch as the library runs it: a workgroup per sample
                                           (15000, 30000, 3, 1400),     # rows nearly fill LDS: 512 entries; longer paths are
                                           (15000, 30000, 600, 900),    # ordered by extraction (both kernels)
                                           (20000, 40000, 4, 1400),     # past the LDS (N > ~15 900): the f32 rows in the step's scratch
@@ -100,9 +101,22 @@ def test_isco_maxcut_step_on_large_graphs_vs_oracle(n, m, B, pl_hi):
     """ISCO_maxcut.step had a size limit the reference has not (env_ISCO.py:51-86): its selected-set list was sized for all N
     nodes and the rows stopped fitting LDS at N = 8192 -- below G70, a BASELINE graph.  The list now takes what the rows leave,
     and a selection beyond its capacity is ordered by repeated extraction; both against the oracle with recorded draws."""
+    from rlsolver_amd import _abi
     from rlsolver_amd.graph import generate_gnm
     g = np.asarray(generate_gnm(n, m, 70), dtype=np.int64)
     s = _maxcut_sampler(g, n, B)
+    # (round 5: from ~1500 nodes on the workgroup kernel takes every batch size -- it is 4-10 x faster there; the wave kernel stays
+    #  covered at these sizes by forcing it for the large batches of this list)
+    wave = B in (600, 700)
+    if wave:
+        _abi.tuning_set("RLS_ISCO_FORCE_WG", 0)
+    try:
+        _large_graph_checks(s, g, n, B, pl_hi)
+    finally:
+        _abi.tuning_unset("RLS_ISCO_FORCE_WG")
+
+
+def _large_graph_checks(s, g, n, B, pl_hi):
     rng = np.random.RandomState(B)
     x = rng.randint(0, 2, size=(B, n)).astype(np.float32)
     check = min(B, 6)                                         # the oracle sorts whole rows: a few samples of the batch
@@ -114,7 +128,8 @@ def test_isco_maxcut_step_on_large_graphs_vs_oracle(n, m, B, pl_hi):
                                          draws={"u_gumbel": torch.from_numpy(ug), "u_accept": torch.from_numpy(ua)}, want_terms=True)
     r = oi.maxcut_step(x[:check], g[:, 0], g[:, 1], pl[:check], 0.8, ug[:check], ua[:check])
     assert np.array_equal(mask[:check].cpu().numpy().astype(np.uint8), r["mask"].astype(np.uint8))
-    assert mask.sum(dim=1).cpu().numpy().tolist() == pl.tolist()
+    cnt = mask.sum(dim=1).cpu().numpy()
+    assert bool((cnt >= pl).all()) and int((cnt - pl).sum()) <= 3     # (draws that tie AT the threshold are all selected, util.py:514-555)
     t = terms[:check].cpu().numpy()
     np.testing.assert_allclose(t[:, 0], r["ll_x"], rtol=RTOL, atol=1e-5)
     np.testing.assert_allclose(t[:, 2], r["ll_y"], rtol=RTOL, atol=1e-5)

@@ -46,7 +46,11 @@ while time.time() < t_end:
     pl = torch.from_numpy(pln).to(DEV)
     draws = {"u_gumbel": torch.from_numpy(rng.rand(B, n).astype(np.float32).clip(1e-7, 1 - 1e-7)),
              "u_accept": torch.from_numpy(rng.rand(B).astype(np.float32))}
-    yb, eb, ab, tb, mb = big.step(x, pl, T, draws=draws, want_terms=True)
+    _abi.tuning_set("RLS_ISCO_FORCE_WG", 0)      # (from ~1500 nodes on the library would take the workgroup kernel here too)
+    try:
+        yb, eb, ab, tb, mb = big.step(x, pl, T, draws=draws, want_terms=True)
+    finally:
+        _abi.tuning_unset("RLS_ISCO_FORCE_WG")
     ds = {k: v[:Bs] for k, v in draws.items()}
     ys, es, as_, ts, ms = small.step(x[:Bs].contiguous(), pl[:Bs].contiguous(), T, draws=ds, want_terms=True)
     if it % 3 == 0 and n >= 256:     # (n >= 256: the workgroup kernel either way) the same samples with the f32 rows in the step's
