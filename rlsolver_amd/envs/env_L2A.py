@@ -142,6 +142,10 @@ class EnvMaxcut(Sharded):
         # words are one launch of tiles x rounds workgroups; tools/timing/ls_forms.py)
         few_tiles = (rounds_can and num_iters > 0 and not self.force_ls_fused
                      and (ops.ls_slices(self.graph, B, wdt) > 1 or 2 * ((B + 63) // 64) <= self._num_cus()))
+        # rows at the end of the fused kernel's LDS layout (N > ~6200 of <= ~6500): the round kernels win at every batch size
+        # (N = 6496, 2^15 / 2^16 envs: 1.58 / 3.17 vs 1.94 / 3.85 ms; N = 6000: 1.46 vs 1.44; tools/timing/ls_forms_n.py)
+        if rounds_can and num_iters > 0 and not self.force_ls_fused and self.num_nodes > 6200:
+            few_tiles = True
         fused_ok = (self.fused_local_search and not self.force_ls_rounds and not few_tiles
                     and ops.local_search_fusable(self.graph, num_spin, B)
                     and xs.data_ptr() % 16 == 0 and (noise is None or noise.data_ptr() % 16 == 0))   # (views that start mid-row)
