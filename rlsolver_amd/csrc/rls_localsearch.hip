@@ -882,7 +882,8 @@ static size_t ls_scratch_bytes(int64_t B, int64_t N, int S, int rounds = 1) {   
 }
 // (rd_std always fits LDS beside the stages here: 4 N bytes, N bounded by the proposal kernel's tile)
 // rd_std beside the stages (sd_lds), or read from global memory where 4 N bytes do not fit (needs N % 4 == 0)
-static size_t ls_mask_lds(int64_t N, bool sd_lds = true) { return (size_t)kLsRoundWaves * kStageBytes + (sd_lds ? (size_t)((N + 3) & ~3ll) * 4 : 0); }
+// (the lane = node mask kernel keeps nothing in LDS: rd_std in registers, ws read as it lies)
+static size_t ls_mask_lds(int64_t, bool = true) { return 0; }
 static size_t ls_threshold_lds(int64_t N, bool sd_lds = true) {
     return (size_t)kLsRoundWaves * kTopCap * kWave * 4 + (size_t)kLsRoundWaves * kStageBytes + (sd_lds ? (size_t)((N + 3) & ~3ll) * 4 : 0);
 }
