@@ -166,7 +166,8 @@ __device__ __forceinline__ void ls_round_words_lane_node(const WT* __restrict__ 
             for (int sq = 0; sq < QPL; ++sq) {
                 float z[4];
                 if constexpr (USE_NOISE) {
-                    const f32x4 zz = *reinterpret_cast<const f32x4*>(noise_it + row_of(e) * N + nodec + 4 * sq);
+                    // (a lane's second quad may lie past the row when N % 8 == 4: the last row's would be past the tensor)
+                    const f32x4 zz = nodec + 4 * sq < N ? *reinterpret_cast<const f32x4*>(noise_it + row_of(e) * N + nodec + 4 * sq) : f32x4{0.f, 0.f, 0.f, 0.f};
                     z[0] = zz[0]; z[1] = zz[1]; z[2] = zz[2]; z[3] = zz[3];
                 } else {
                     normal4(ek, q0 + (uint32_t)sq, (uint32_t)it, z);
