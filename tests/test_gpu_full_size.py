@@ -600,3 +600,27 @@ def test_node_stats_on_narrow_tiles_past_the_half_tile(n, m, hub, B):
     want_ws = deg_st[None, :] - 4 * cutdeg_st
     assert np.array_equal(ws.cpu().numpy().astype(np.int64), want_ws)
     assert np.array_equal(mm.cpu().numpy(), np.stack([want_ws.min(0), want_ws.max(0)]))
+
+
+@pytest.mark.parametrize("kind,n,B", [("gnm", 2000, 1 << 16), ("gnm", 2000, 1100), ("ba", 10000, 1 << 13), ("gnm", 804, 5000)])
+def test_ls_weights_batch_minmax_is_the_minmax_of_the_weights(kind, n, B):
+    """The weights pre-pass folds min_b ws / max_b ws per node into a table with atomics; from 17 tiles on only 16 seed tiles fold as
+    they go, the others park their (lo, hi) in LDS and fold after their last store, in staggered phases (round 5: the first round of
+    tiles all found the fill value).  Whatever the order: the table is exactly the column min / max of the weights written."""
+    from rlsolver_amd import graph as G
+    from rlsolver_amd.envs.env_L2A import EnvMaxcut
+    mg = G.generate_gnm(n, 10 * n, 3) if kind == "gnm" else G.generate_ba(n, 5, 3)
+    env = EnvMaxcut(mygraph=mg, device=DEV, num_nodes=n)
+    xs = env.generate_xs_randomly(B)
+    for mult in (1, 4):
+        ws, mm = ops.maxcut_ls_weights(env.graph, xs, mult, padded=True, return_minmax=True)
+        w = ws[:, :n].to(torch.int32)
+        assert torch.equal(mm[0], w.min(dim=0).values) and torch.equal(mm[1], w.max(dim=0).values)
+    garr = np.asarray(mg, dtype=np.int64)
+    rows = np.arange(0, B, max(1, B // 7))[:7]
+    xb = xs[torch.from_numpy(rows).to(DEV)].cpu().numpy().astype(bool)
+    d = (xb[:, garr[:, 0]] ^ xb[:, garr[:, 1]]).astype(np.int64)
+    cut = np.zeros((len(rows), n), np.int64)
+    np.add.at(cut.T, garr[:, 0], d.T)
+    want = np.bincount(garr[:, 0], minlength=n)[None, :] - 4 * cut
+    assert np.array_equal(ws[torch.from_numpy(rows).to(DEV), :n].cpu().numpy().astype(np.int64), want)
