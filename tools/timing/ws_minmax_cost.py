@@ -18,14 +18,16 @@ def t(f, K=20):
     return s.elapsed_time(e) / K * 1e3
 
 
-for name, g, n, B in (("G22", graph.generate_gnm(2000, 19990, seed=22), 2000, 1 << 16), ("BA-1e4", graph.generate_ba(10000, 5, seed=5), 10000, 1 << 15)):
+for name, g, n, B in (("G22", graph.generate_gnm(2000, 19990, seed=22), 2000, 1 << 16), ("BA-1e4", graph.generate_ba(10000, 5, seed=5), 10000, 1 << 15),
+                      ("G22", graph.generate_gnm(2000, 19990, seed=22), 2000, 4096), ("G22", graph.generate_gnm(2000, 19990, seed=22), 2000, 16384),
+                      ("BA-1e4", graph.generate_ba(10000, 5, seed=5), 10000, 4096)):
     env = EnvMaxcut(mygraph=g, device=dev, num_nodes=n)
     xs = env.generate_xs_randomly(B)
     dt = ops.ls_weight_dtype(env.graph, 1)
     P = (n + 15) // 16 * 16
     ws = torch.empty((B, P), dtype=dt, device=dev)
     mm = torch.empty((2, n), dtype=torch.int32, device=dev)
-    for seeds in (0, 4, 16, 64, 256):
+    for seeds in (0, 16):
         _abi.tuning_set("RLS_NS_PARK", seeds)
         print(f"  seeds={seeds}: {t(lambda: _t.maxcut_ls_weights(env.graph.handle, xs, 1, ws, mm)):.1f} us", flush=True)
     _abi.tuning_unset("RLS_NS_PARK")
