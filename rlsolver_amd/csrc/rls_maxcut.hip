@@ -1047,7 +1047,7 @@ static int launch_node_stats_bits(const rls_graph* g, const uint8_t* x, int64_t 
     // folds its min / max into the table with atomics: G22-sized 1024 envs 27.8 -> 32.6)
     const int64_t nk = knob(KN_NARROW_TILE, 1);
     int auto_n = 0;
-    if (nk == 1 && knob32 < 0 && vec && (N & 15) == 0) {
+    if (nk == 1 && knob32 < 0 && vec && (N & 7) == 0) {
         const int64_t cus = num_cus();
         if (MODE == 2) {    // (G22-sized, 4096 envs on 16-env tiles: 31 -> 57 us -- 256 tiles' worth of min / max atomics per node)
             if (ceil_div(B, 8) <= cus / 4) auto_n = 8;
@@ -1413,7 +1413,7 @@ static int narrow_policy(int64_t N, int64_t B, bool rows_vec, Knob wide_knob) {
     // 22.4 / 39.2 (16 envs), 256 envs 19.4 / 27.8 / 42.4 -> 7.6 / 13.2 / 24.9 (8 envs); N = 39 936, 4096 envs 47 / 120 / 356 -> 36 / 86 /
     // 135; N = 2000, 4096 envs 10.4 / 11.6 / 47 -> 7.1 / 9.1 / 46; N = 800: nothing.  From 16 384 envs on the wide tiles win
     // (N = 10^4: 29.7 / 77.5 / 69.8 vs 32.8 / 89.6 / 110) -- the chip is full and a narrow tile walks the edge list / schedule per 16 envs.
-    if (!rows_vec || (N & 15) != 0 || N < 1536) return 0;     // (the narrow loader's fast path: byte rows of 16-byte multiples)
+    if (!rows_vec || (N & 7) != 0 || N < 1536) return 0;      // (the narrow loader's fast path: byte rows of 16- or 8-byte multiples)
     const int64_t cus = num_cus();
     if (ceil_div(B, 8) <= cus) return 8;
     if (ceil_div(B, 16) <= cus) return 16;

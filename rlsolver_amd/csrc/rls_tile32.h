@@ -201,10 +201,15 @@ __device__ __forceinline__ void tilen_load_bits(const T* __restrict__ x, int64_t
     const int64_t b = b0 + env;
     const bool valid = b < B;
     if constexpr (VEC && sizeof(T) == 1) {
-        if ((N & 15) == 0) {
+        if ((N & 7) == 0) {
+            // rows of 16-byte multiples: 16-byte loads; of 8-byte multiples (every other row starts mid-vector -- the Gset sizes 1000,
+            // 3000, 5000, 7000, 9000): the same 64 bytes as eight 8-byte loads
+            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
             const uint8_t* xb = reinterpret_cast<const uint8_t*>(x);
             const u32x4* rv = reinterpret_cast<const u32x4*>(xb + (valid ? b : 0) * N);
-            const int64_t nv = N >> 4;
+            const u32x2* r2 = reinterpret_cast<const u32x2*>(rv);
+            const bool a16 = (N & 15) == 0;
+            const int64_t nv = N >> 4, n8 = N >> 3;
             const int64_t nchunk = (N + 64 * NB - 1) / (64 * NB);        // chunk = NB blocks of 64 nodes = one transpose
             const BitXpose xc = bit_xpose_consts(lane);
             for (int64_t ch = w; ch < nchunk; ch += W) {
@@ -212,7 +217,13 @@ __device__ __forceinline__ void tilen_load_bits(const T* __restrict__ x, int64_t
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int64_t idx = (ch * NB + blk) * 4 + q;
-                    v[q] = (valid && idx < nv) ? rv[idx] : u32x4{0, 0, 0, 0};
+                    if (a16) {
+                        v[q] = (valid && idx < nv) ? rv[idx] : u32x4{0, 0, 0, 0};
+                    } else {
+                        const u32x2 lo = (valid && 2 * idx < n8) ? r2[2 * idx] : u32x2{0, 0};
+                        const u32x2 hi = (valid && 2 * idx + 1 < n8) ? r2[2 * idx + 1] : u32x2{0, 0};
+                        v[q] = u32x4{lo.x, lo.y, hi.x, hi.y};
+                    }
                 }
                 uint32_t r0 = pack_bits(v[0], v[1]), r1 = pack_bits(v[2], v[3]);
                 bit_transpose64(r0, r1, xc);
@@ -251,9 +262,12 @@ __device__ __forceinline__ void tilen_store_bytes(uint8_t* __restrict__ x, int64
     const bool valid = b < B && store_row;
     uint8_t* row = x + (b < B ? b : 0) * N;
     if constexpr (VEC) {
-        if ((N & 15) == 0) {
+        if ((N & 7) == 0) {      // (16-byte stores, or 8-byte ones for rows of 8-byte multiples: tilen_load_bits)
+            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
             u32x4* rv = reinterpret_cast<u32x4*>(row);
-            const int64_t nv = N >> 4;
+            u32x2* r2 = reinterpret_cast<u32x2*>(row);
+            const bool a16 = (N & 15) == 0;
+            const int64_t nv = N >> 4, n8 = N >> 3;
             const int64_t nchunk = (N + 64 * NB - 1) / (64 * NB);
             const BitXpose xc = bit_xpose_consts(lane);
             for (int64_t ch = w; ch < nchunk; ch += W) {
@@ -272,7 +286,12 @@ __device__ __forceinline__ void tilen_store_bytes(uint8_t* __restrict__ x, int64
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const int64_t idx = (ch * NB + blk) * 4 + q;
-                    if (valid && idx < nv) rv[idx] = v[q];
+                    if (a16) {
+                        if (valid && idx < nv) rv[idx] = v[q];
+                    } else {
+                        if (valid && 2 * idx < n8) r2[2 * idx] = u32x2{v[q].x, v[q].y};
+                        if (valid && 2 * idx + 1 < n8) r2[2 * idx + 1] = u32x2{v[q].z, v[q].w};
+                    }
                 }
             }
             return;
