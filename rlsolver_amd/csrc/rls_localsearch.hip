@@ -849,10 +849,10 @@ static size_t ls_apply_lds(int64_t N, int W, bool stage) {
     return (size_t)((N + 1) & ~1ll) * 8 + (size_t)W * kWave * 8 + (stage ? (size_t)W * kStageBytes : 0);
 }
 // N beyond the proposal kernel's tile + stages but within the bare tile (15 500 < N <= 20 224): mask kernels + the 4-wave apply kernel
-// (rows of 16-byte multiples take half tiles there instead: their loader keeps 64-byte runs, the bare tile's reads 16 B per env)
+// (rows of 16- or 8-byte multiples take half tiles there instead: their loader keeps 64-byte runs, the bare tile's reads 16 B per env)
 static bool ls_big_tile(int64_t N) {
     return (size_t)((N + 1) & ~1ll) * 8 + (size_t)kLsRoundWaves * kWave * 8 + (size_t)kLsRoundWaves * kStageBytes > (size_t)kLdsBytes &&
-           ls_apply_lds(N, 4, false) <= (size_t)kLdsBytes && (N & 15) != 0;
+           ls_apply_lds(N, 4, false) <= (size_t)kLdsBytes && (N & 7) != 0;
 }
 // N past the 64-env tile altogether but within the half tile (20 224 < N <= ~39 900): mask kernels + the apply kernel on half tiles
 static bool ls_half_tile(int64_t N) {
@@ -1206,10 +1206,10 @@ extern "C" int rls_maxcut_ls_rounds(const rls_graph* g, uint8_t* x, int64_t B, c
         // without a 64-env tile (whole local_search_inplace calls, 4096 envs: G22-sized 0.324 -> 0.305 ms, BA n = 10^4 0.893 -> 0.816,
         // G70-sized 0.689 -> 0.642; at 16 384 envs no gain).  Dev knob RLS_LS_APPLY32 = 0 | 1 forces the choice.
         const int knob32 = (int)knob(KN_LS_APPLY32, -1);
-        const bool fast32 = x_aligned && (N & 15) == 0 && ls_apply32_lds(N, kLsRoundWaves, true) <= (size_t)kLdsBytes;
+        const bool fast32 = x_aligned && (N & 7) == 0 && ls_apply32_lds(N, kLsRoundWaves, true) <= (size_t)kLdsBytes;
         const bool few32 = knob32 >= 0 ? knob32 != 0 : 2 * (int64_t)grid.x <= (int64_t)num_cus();
         if (half || (few32 && fast32)) {
-            const int st32 = (x_aligned && (N & 15) == 0 && ls_apply32_lds(N, kLsRoundWaves, true) <= (size_t)kLdsBytes) ? 1 : 0;
+            const int st32 = (x_aligned && (N & 7) == 0 && ls_apply32_lds(N, kLsRoundWaves, true) <= (size_t)kLdsBytes) ? 1 : 0;
             const size_t lds = ls_apply32_lds(N, kLsRoundWaves, st32 != 0);
             auto kern = k_ls_apply_rounds32<24, kLsRoundWaves>;
             if (lds > 64 * 1024) ensure_dyn_lds((const void*)kern, lds);

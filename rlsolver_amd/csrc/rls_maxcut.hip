@@ -1036,7 +1036,7 @@ static int launch_node_stats_bits(const rls_graph* g, const uint8_t* x, int64_t 
     const int64_t t64 = ceil_div(B, kWave);
     const bool few = MODE == 2 ? 8 * t64 <= (int64_t)num_cus() : 2 * t64 <= (int64_t)num_cus();
     const bool full_k3 = MODE == 1 && t64 >= 4 * (int64_t)num_cus() && (size_t)N * 8 <= 64 * 1024;
-    const bool prefer32 = knob32 < 0 && vec && (N & 15) == 0 && node_stats_bits32_lds(N, true) <= (size_t)kLdsBytes &&
+    const bool prefer32 = knob32 < 0 && vec && (N & 7) == 0 && node_stats_bits32_lds(N, true) <= (size_t)kLdsBytes &&
                           (few || full_k3 || (node_stats_bits_lds(N, true) > (size_t)kLdsBytes && 2 * t64 <= (int64_t)num_cus()));
     // Narrow tiles (16 / 8 envs, rls_tile32.h) where the half tile is past the LDS (N > 40 960): the rows these took before went
     // element-parallel -- one L2 gather per (env, entry)
@@ -1077,7 +1077,7 @@ static int launch_node_stats_bits(const rls_graph* g, const uint8_t* x, int64_t 
         return check_launch("k_node_stats_bits32<narrow>");
     }
     if (knob32 > 0 || prefer32 || node_stats_bits_lds(N, false) > (size_t)kLdsBytes) {   // half tiles (rls_tile32.h)
-        const int st32 = (vec && (N & 15) == 0 && node_stats_bits32_lds(N, true) <= (size_t)kLdsBytes) ? 1 : 0;
+        const int st32 = (vec && (N & 7) == 0 && node_stats_bits32_lds(N, true) <= (size_t)kLdsBytes) ? 1 : 0;
         const size_t l32 = node_stats_bits32_lds(N, st32 != 0);
         const dim3 g32((unsigned)ceil_div(B, (int64_t)kHalf)), b32(kNsWaves * kWave);
 #define RLS_NS32_LAUNCH(KERN)                                                                                        \
@@ -1561,11 +1561,11 @@ int rls_maxcut_obj(const rls_graph* g, const void* x, int spin_bytes, int64_t B,
         size_t l32 = lds32(w32);
         const int P32 = pick_planes(E);
         const bool vec = tile_rows_aligned(x, N, spin_bytes);
-        const bool fast32 = spin_bytes == 1 && vec && (N & 15) == 0;
+        const bool fast32 = spin_bytes == 1 && vec && (N & 7) == 0;      // (rows of 16- or 8-byte multiples: rls_tile32.h)
         const bool want32 = knob32 >= 0 ? knob32 != 0
                                         : fast32 && ((size_t)N * 8 > 64 * 1024 || ceil_div(B, kWave) <= 2 * (int64_t)num_cus());
         if ((want32 || lds > (size_t)kLdsBytes) && l32 <= (size_t)kLdsBytes && P32 != 0) {
-            const int st_off = tile_stage_offset(&l32, w32, spin_bytes == 1 && vec && (N & 15) == 0);
+            const int st_off = tile_stage_offset(&l32, w32, spin_bytes == 1 && vec && (N & 7) == 0);
             const dim3 g32((unsigned)ceil_div(B, (int64_t)kHalf)), b32(w32 * kWave);
             const int hv = g->if_bidirectional ? 1 : 0;
             hipStream_t s32 = as_stream(stream);
@@ -1668,7 +1668,7 @@ int rls_maxcut_propose_accept(const rls_graph* g, uint8_t* x, int64_t B, const v
     const int knob32 = (int)knob(KN_K6_TILE32, -1);   // dev knob: 0 | 1 forces the choice
     const bool no_stage64 = lds + (size_t)tw * kStageBytes > (size_t)kLdsBytes;
     // (the half tile's fast loader wants byte rows of 16-byte multiples on a 16-byte base; other rows keep the 64-env forms)
-    const bool fast32 = (N & 15) == 0 && tile_rows_aligned(x, N, 1) && (mask_bits || tile_rows_aligned(mask, N, 1));
+    const bool fast32 = (N & 7) == 0 && tile_rows_aligned(x, N, 1) && (mask_bits || tile_rows_aligned(mask, N, 1));
     const bool want32 = knob32 >= 0 ? knob32 != 0
                                     : fast32 && (no_stage64 || (size_t)N * 8 > 64 * 1024 || ceil_div(B, kWave) <= (int64_t)num_cus());
     if (want32 || lds > (size_t)kLdsBytes) {
@@ -1679,7 +1679,7 @@ int rls_maxcut_propose_accept(const rls_graph* g, uint8_t* x, int64_t B, const v
         const int P32 = pick_planes(E);
         if (l32 <= (size_t)kLdsBytes && P32 != 0) {
             const bool vec = tile_rows_aligned(x, N, 1) && (mask_bits || tile_rows_aligned(mask, N, 1));
-            const int st32 = tile_stage_offset(&l32, w32, vec && (N & 15) == 0);   // (row-piece stages when they fit beside the tile)
+            const int st32 = tile_stage_offset(&l32, w32, vec && (N & 7) == 0);    // (row-piece stages when they fit beside the tile)
             const dim3 g32((unsigned)ceil_div(B, (int64_t)kHalf)), b32(w32 * kWave);
             hipStream_t s32 = as_stream(stream);
             const int hv = g->if_bidirectional ? 1 : 0;
@@ -1786,7 +1786,7 @@ int rls_maxcut_greedy_sweep(const rls_graph* g, uint8_t* x, int64_t B, int64_t* 
         // (tools/timing/k5_tile32.py): rows past 8192 nodes (G70-sized 2^17: 780 -> 705 us; N = 20 000, where the 64-env tile has no
         // room for its stage, 4096 envs: 171 -> 100) and launches of at most one 64-env tile per CU (G22-sized 2^14: 63 -> 53 us;
         // at 2^16 the half tiles lose, 113 -> 128: twice the schedule reads per env)
-        const bool prefer32 = knob32 < 0 && vec && (N & 15) == 0 &&
+        const bool prefer32 = knob32 < 0 && vec && (N & 7) == 0 &&
                               (!has_stage || (size_t)N * 8 > 64 * 1024 || ceil_div(B, kWave) <= (int64_t)num_cus());
         if ((knob32 > 0 || prefer32 || lds_l > (size_t)kLdsBytes) && !no_levels && !g->wgt && g->sweep_lv_ptr && g->sweep_lv_data && G > 0 && P != 0) {
             int sw32 = force_lw == 2 || force_lw == 4 || force_lw == 8 ? force_lw : (N >= 56 * G ? 8 : 4);
@@ -1794,7 +1794,7 @@ int rls_maxcut_greedy_sweep(const rls_graph* g, uint8_t* x, int64_t B, int64_t* 
                 return (((size_t)(N + 2) * 4 + 15) & ~(size_t)15) + (((size_t)(G + 1) * 4 + 15) & ~(size_t)15) + (size_t)waves * kWave * 8 +
                        (stage ? (size_t)kSweepLoadWaves * kStageBytes : 0);
             };
-            int stage32 = vec && (N & 15) == 0 ? 1 : 0;
+            int stage32 = vec && (N & 7) == 0 ? 1 : 0;
             if (stage32 && lds32_of(sw32, true) > (size_t)kLdsBytes) stage32 = 0;
             if (lds32_of(sw32, stage32 != 0) > (size_t)kLdsBytes) sw32 = 4;
             if (lds32_of(sw32, stage32 != 0) > (size_t)kLdsBytes) sw32 = 2;

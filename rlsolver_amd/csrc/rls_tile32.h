@@ -24,6 +24,22 @@ __device__ __forceinline__ void csa32(uint32_t& hi, uint32_t& lo, uint32_t a, ui
 // instruction fetches 8 rows x 128 B, whole cache lines; the wave turns the corner through 4 KB of LDS: lane l = (env l & 31,
 // block l >> 5) reads back the four 16-byte pieces of ITS 64 nodes -- else each lane reads its 64 bytes itself; anything else
 // (float spins, ragged rows) takes one ballot per node.
+// 16 bytes of a byte row at offset `off` (a multiple of 16) of a row whose start is 16- (a16) or only 8-byte aligned (rows of 8-byte
+// multiples: every other row starts mid-vector -- the Gset sizes 1000 ... 9000): one 16-byte access or two 8-byte ones; bytes at and
+// past N are neither read nor written (with N % 16 == 8 the last piece is half a piece)
+typedef uint32_t u32x2_t32 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32x4 row_ld16(const uint8_t* p, bool a16, int64_t off, int64_t N) {
+    if (a16) return *reinterpret_cast<const u32x4*>(p);
+    const u32x2_t32 lo = *reinterpret_cast<const u32x2_t32*>(p);
+    const u32x2_t32 hi = (off + 8 < N) ? *reinterpret_cast<const u32x2_t32*>(p + 8) : u32x2_t32{0, 0};
+    return u32x4{lo.x, lo.y, hi.x, hi.y};
+}
+__device__ __forceinline__ void row_st16(uint8_t* p, bool a16, int64_t off, int64_t N, u32x4 v) {
+    if (a16) { *reinterpret_cast<u32x4*>(p) = v; return; }
+    *reinterpret_cast<u32x2_t32*>(p) = u32x2_t32{v.x, v.y};
+    if (off + 8 < N) *reinterpret_cast<u32x2_t32*>(p + 8) = u32x2_t32{v.z, v.w};
+}
+
 template <bool XORW> __device__ __forceinline__ void put_word32(uint32_t* words32, int64_t n, uint32_t v) {
     if constexpr (XORW) words32[n] ^= v;   // (x ^ mask without a second tile: the same lane of the same wave owns a word in both passes)
     else words32[n] = v;
@@ -36,7 +52,8 @@ __device__ __forceinline__ void tile32_load_bits(const T* __restrict__ x, int64_
     const int64_t b = b0 + env;
     const bool valid = b < B;
     if constexpr (VEC && sizeof(T) == 1) {
-        if ((N & 15) == 0) {
+        if ((N & 7) == 0) {
+            const bool a16 = (N & 15) == 0;
             const uint8_t* xb = reinterpret_cast<const uint8_t*>(x);
             const int64_t nchunk = (N + 127) >> 7;                       // 128-node chunks = one transpose each
             const BitXpose xc = bit_xpose_consts(lane);
@@ -52,7 +69,7 @@ __device__ __forceinline__ void tile32_load_bits(const T* __restrict__ x, int64_
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             const int64_t rw = b0 + 8 * i + r;
-                            g[d][i] = (rw < B && off < N) ? *reinterpret_cast<const u32x4*>(xb + rw * N + off) : u32x4{0, 0, 0, 0};
+                            g[d][i] = (rw < B && off < N) ? row_ld16(xb + rw * N + off, a16, off, N) : u32x4{0, 0, 0, 0};
                         }
                     }
 #pragma unroll
@@ -76,14 +93,13 @@ __device__ __forceinline__ void tile32_load_bits(const T* __restrict__ x, int64_
                 }
                 return;
             }
-            const u32x4* rv = reinterpret_cast<const u32x4*>(xb + (valid ? b : 0) * N);
-            const int64_t nv = N >> 4;
+            const uint8_t* rowb = xb + (valid ? b : 0) * N;
             for (int64_t ch = w; ch < nchunk; ch += W) {
                 u32x4 v[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int64_t idx = (ch << 3) + 4 * blk + q;
-                    v[q] = (valid && idx < nv) ? rv[idx] : u32x4{0, 0, 0, 0};
+                    const int64_t off = ((ch << 3) + 4 * blk + q) << 4;
+                    v[q] = (valid && off < N) ? row_ld16(rowb + off, a16, off, N) : u32x4{0, 0, 0, 0};
                 }
                 uint32_t r0 = pack_bits(v[0], v[1]), r1 = pack_bits(v[2], v[3]);
                 bit_transpose64(r0, r1, xc);
@@ -118,8 +134,9 @@ __device__ __forceinline__ void tile32_store_bytes(uint8_t* __restrict__ x, int6
     const int64_t b = b0 + env;
     const bool valid = b < B && store_row;
     uint8_t* row = x + (b < B ? b : 0) * N;
+    const bool a16 = (N & 15) == 0;
     if constexpr (VEC) {
-        if ((N & 15) == 0 && stage != nullptr) {
+        if ((N & 7) == 0 && stage != nullptr) {
             // through the row-piece stage (the loader's corner turn backwards): lane l = (env, block) parks its four 16-byte pieces,
             // instruction i then writes rows 8 i .. 8 i + 7 as 128-byte runs (lane -> row 8 i + (l & 7), piece l >> 3)
             const uint32_t rows_ok = (uint32_t)ballot64(valid && blk == 0);
@@ -141,17 +158,15 @@ __device__ __forceinline__ void tile32_store_bytes(uint8_t* __restrict__ x, int6
                 for (int i = 0; i < 4; ++i) {
                     const int rr = 8 * i + r;
                     const u32x4 o = *reinterpret_cast<const u32x4*>(stage + (j * 32 + rr) * 16);
-                    if (((rows_ok >> rr) & 1u) && off < N) *reinterpret_cast<u32x4*>(x + (b0 + rr) * N + off) = o;
+                    if (((rows_ok >> rr) & 1u) && off < N) row_st16(x + (b0 + rr) * N + off, a16, off, N, o);
                 }
                 asm volatile("" ::: "memory");
             }
             return;
         }
-        if ((N & 15) == 0) {
+        if ((N & 7) == 0) {
             // inverse of the load: lane p fetches the two words of node p (blocks 2c, 2c + 1), the transpose hands lane l = (env,
             // block) that env's 64 bits of that block, unpacked to 64 bytes = four 16-byte stores
-            u32x4* rv = reinterpret_cast<u32x4*>(row);
-            const int64_t nv = N >> 4;
             const int64_t nchunk = (N + 127) >> 7;
             const BitXpose xc = bit_xpose_consts(lane);
             for (int64_t ch = w; ch < nchunk; ch += W) {
@@ -163,8 +178,8 @@ __device__ __forceinline__ void tile32_store_bytes(uint8_t* __restrict__ x, int6
                 unpack_bits(r1, v[2], v[3]);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int64_t idx = (ch << 3) + 4 * blk + q;
-                    if (valid && idx < nv) rv[idx] = v[q];
+                    const int64_t off = ((ch << 3) + 4 * blk + q) << 4;
+                    if (valid && off < N) row_st16(row + off, a16, off, N, v[q]);
                 }
             }
             return;

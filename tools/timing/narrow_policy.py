@@ -19,7 +19,7 @@ def t(f, reps=20):
 
 for n, m in ((800, 4694), (2000, 19990), (10000, 9999), (20000, 40000), (39936, 80000)):
     g = ops.DeviceGraph(build_csr(generate_gnm(n, m, 7), num_nodes=n), dev)
-    for B in (256, 1024, 4096, 16384, 65536):
+    for B in (tuple(int(b) for b in os.environ["NP_BATCHES"].split(",")) if "NP_BATCHES" in os.environ else (256, 1024, 4096, 16384, 65536)):
         if B * n > 3e9: continue
         xs = ops.rand_spins(B, n, 1, dev)
         vs = ops.maxcut_obj(g, xs)
