@@ -1563,7 +1563,10 @@ int rls_maxcut_obj(const rls_graph* g, const void* x, int spin_bytes, int64_t B,
         const bool vec = tile_rows_aligned(x, N, spin_bytes);
         const bool fast32 = spin_bytes == 1 && vec && (N & 7) == 0;      // (rows of 16- or 8-byte multiples: rls_tile32.h)
         const bool want32 = knob32 >= 0 ? knob32 != 0
-                                        : fast32 && ((size_t)N * 8 > 64 * 1024 || ceil_div(B, kWave) <= 2 * (int64_t)num_cus());
+                                        : fast32 && (N >= 3000 || ceil_div(B, kWave) <= 2 * (int64_t)num_cus());
+        // (N >= 3000, round 5: until then "rows past 8192 nodes" -- at 2^16 envs the half tile also wins from 3000 nodes on, K1 N = 3008 /
+        // 5008 / 7008: 42.6 / 77.5 / 103.8 -> 38.6 / 75.1 / 102.2 us, rows of 8-byte multiples 49.8 / 89.4 / 124.0 -> 43.1 / 83.1 / 116.3;
+        // at G22's 2000 it loses, 36.3 vs 34.4: tools/sweeps/align_sweep.py with RLS_K1_TILE32 = 1)
         if ((want32 || lds > (size_t)kLdsBytes) && l32 <= (size_t)kLdsBytes && P32 != 0) {
             const int st_off = tile_stage_offset(&l32, w32, spin_bytes == 1 && vec && (N & 7) == 0);
             const dim3 g32((unsigned)ceil_div(B, (int64_t)kHalf)), b32(w32 * kWave);
@@ -1670,7 +1673,9 @@ int rls_maxcut_propose_accept(const rls_graph* g, uint8_t* x, int64_t B, const v
     // (the half tile's fast loader wants byte rows of 16-byte multiples on a 16-byte base; other rows keep the 64-env forms)
     const bool fast32 = (N & 7) == 0 && tile_rows_aligned(x, N, 1) && (mask_bits || tile_rows_aligned(mask, N, 1));
     const bool want32 = knob32 >= 0 ? knob32 != 0
-                                    : fast32 && (no_stage64 || (size_t)N * 8 > 64 * 1024 || ceil_div(B, kWave) <= (int64_t)num_cus());
+                                    : fast32 && (no_stage64 || N >= 3000 || ceil_div(B, kWave) <= (int64_t)num_cus());
+    // (N >= 3000, round 5, as for K1: K6 with a byte mask at 2^16 envs, N = 3008 / 5008 / 7008: 101 / 173 / 236 -> 95 / 158 / 212 us,
+    // rows of 8-byte multiples 116 / 194 / 271 -> 101 / 165 / 236)
     if (want32 || lds > (size_t)kLdsBytes) {
         int w32 = kTileWavesMax;
         auto lds32 = [&](int ww) { return (((size_t)N * 4 + 15) & ~(size_t)15) + (size_t)ww * kWave * 8; };

@@ -3,7 +3,7 @@ K5, K3 -- us per call and bytes-per-us normalised by N."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
-from rlsolver_amd import ops
+from rlsolver_amd import ops, _abi; _abi.tuning_from_env()
 from rlsolver_amd.graph import build_csr, generate_gnm
 dev = torch.device("cuda:0")
 
