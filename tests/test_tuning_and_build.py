@@ -100,3 +100,24 @@ def test_reshard_keeps_the_seed_stream():
     o.set_shard(8, seed=None, group=None)                                  # None is a value: back to torch's generator, no group
     assert o.group is None and o._seeds.seed is None
     assert repr(KEEP) == "KEEP"
+
+
+def test_isco_scratch_query_is_host_logic():
+    """rls_isco_maxcut_scratch_bytes (round 5): 0 while a sample's rows fit LDS (N <= ~15 900), 8 N bytes per sample past that; a
+    forced knob asks for the scratch at any size.  Pure host logic: runs without a GPU."""
+    import ctypes as C
+    from rlsolver_amd import _abi
+    lib = _abi.lib()
+    g = _abi.RlsGraph()
+    for n, want in ((2000, 0), (10000, 0), (15000, 0), (20000, 8 * 20000), (80000, 8 * 80000)):
+        g.num_nodes = n
+        assert lib.rls_isco_maxcut_scratch_bytes(C.byref(g), 1) == want
+        assert lib.rls_isco_maxcut_scratch_bytes(C.byref(g), 37) == 37 * want
+    g.num_nodes = 2000
+    assert lib.rls_isco_maxcut_scratch_bytes(C.byref(g), 0) == 0 and lib.rls_isco_maxcut_scratch_bytes(None, 5) == 0
+    _abi.tuning_set("RLS_ISCO_GLOBAL_ROWS", 1)
+    try:
+        assert lib.rls_isco_maxcut_scratch_bytes(C.byref(g), 3) == 3 * 8 * 2000
+    finally:
+        _abi.tuning_unset("RLS_ISCO_GLOBAL_ROWS")
+    assert lib.rls_isco_maxcut_scratch_bytes(C.byref(g), 3) == 0
