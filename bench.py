@@ -45,7 +45,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-METRIC = "env-steps/sec (all instances) on Gset G22 MaxCut; achieved HBM GB/s % peak"
+METRIC = "env-steps/sec (all instances) on Gset G22 MaxCut; achieved HBM GB/s % peak"     # BASELINE.json's, for --gset 22
+MALL_BYTES = 256 << 20   # Infinity Cache
+
+
+def metric_for(gset):
+    """BASELINE.json's metric string names G22; a headline on another graph size (--gset 70 = config #5) says so."""
+    return METRIC.replace("G22", f"G{gset}")
 
 
 def parse(argv=None):
@@ -59,6 +65,7 @@ def parse(argv=None):
     ap.add_argument("--slots", type=int, default=8, help="rollout ring depth (slots of B*N bytes)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hbm-only", action="store_true", help="skip the nontemporal-store repeat of the headline loop (roofline.hbm_only)")
     ap.add_argument("--no-config5", action="store_true", help="skip the secondary G70 / 2^17-envs-per-GPU measurement")
     ap.add_argument("--no-configs", action="store_true",
                     help="skip the `configs` block: BASELINE configs #2 (dREINFORCE-shaped local search), #3 (BA MCMC) and #4 (TSP) at "
@@ -73,12 +80,18 @@ def parse(argv=None):
                     help="launcher mode: enqueue each timed region of --steps launches as ONE hipGraph (captured before the region, "
                          "replayed inside it).  auto = on when --steps <= 100, where the first launch's latency is a visible share of "
                          "the region; the kernels, buffers and the end-of-run parity check are the same either way")
+    ap.add_argument("--graph-exchange", choices=("auto", "off"), default="auto",
+                    help="N > 1 over RCCL: capture the region's exchange in the region's hipGraph (auto) or launch it eagerly (off)")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--share-gpu", action="store_true",
                     help="TEST MODE for boxes with one GPU: every rank runs on cuda:0 and the ranks talk over gloo (keys and timings "
                          "staged through the host).  Exercises the whole N > 1 path -- shard offsets, per-region exchange, MAX over "
                          "ranks, rank 0's JSON line -- with real kernels; the number it prints is not a scaling measurement and the "
                          "line says so")
+    ap.add_argument("--exchange-probe", action="store_true",
+                    help="child mode of the N = 1 line: time the episode-boundary exchange (rls_best_key + 8-byte all_reduce) on a "
+                         "1-rank RCCL group (RLS_FORCE_PG=1), print one JSON line and exit")
+    ap.add_argument("--no-exchange-probe", action="store_true")
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU only (gloo): launch, shard and exchange wiring of the N-rank run, no kernels")
     return ap.parse_args(argv)
@@ -121,6 +134,104 @@ def self_spawn(a, argv):
         raise SystemExit(p.returncode or 1)
     print(line, flush=True)
     raise SystemExit(p.returncode)
+
+
+# --------------------------------------------------------------------------- #
+# exchange probe: what the N > 1 line's per-region exchange costs, measured on the 1-rank RCCL group a 1-GPU box can form
+# --------------------------------------------------------------------------- #
+def exchange_probe_child(a):
+    """Runs in a fresh process (RLS_FORCE_PG=1, WORLD_SIZE=1): the exchange of one timed region -- BestExchange.exchange =
+    one rls_best_key launch + one 8-byte all_reduce(MAX) over RCCL -- eager and inside a hipGraph, timed with HIP events on
+    the launch stream.  A 1-rank group has no peer: this is the launch + collective-kernel floor, not xGMI latency."""
+    import torch
+    import torch.distributed as dist
+    from rlsolver_amd import dist as rdist
+    rank, local_rank, world = rdist.init_from_env()
+    dev = torch.device("cuda", local_rank)
+    B = a.envs_per_gpu
+    obj = (torch.arange(B, dtype=torch.int64, device=dev) * 7919 % 10007).to(torch.int32)
+    ex = rdist.BestExchange(dev)
+    for _ in range(20):                         # communicator set-up + code objects
+        ex.exchange(obj)
+    torch.cuda.synchronize(dev)
+    out = {"backend": dist.get_backend(), "world": world, "envs": B, "ops_per_exchange": "1 launch (rls_best_key) + 1 all_reduce(MAX, 8 B)"}
+
+    def timed(fn, n):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        e0.record()
+        fn()
+        e1.record()
+        th = time.perf_counter() - t0
+        torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) * 1e3 / n, th * 1e6 / n
+
+    n = 200
+    runs = [timed(lambda: [ex.exchange(obj) for _ in range(n)], n) for _ in range(5)]
+    out["exchange_us"] = statistics.median(r[0] for r in runs)            # device time per exchange, back to back
+    out["exchange_host_us"] = statistics.median(r[1] for r in runs)       # host time to enqueue one
+    # one exchange on an idle stream (what a region's end pays: nothing to overlap with)
+    singles = []
+    for _ in range(30):
+        singles.append(timed(lambda: ex.exchange(obj), 1)[0])
+    out["exchange_us_single"] = statistics.median(singles)
+    key = ex.exchange(obj)
+    o, w = ex.unpack(key)
+    ex.check()
+    out["check"] = "ok" if (int(o) == int(obj.max()) and int(w) == 0) else "BROKEN"
+    try:            # the same inside a hipGraph (torch's NCCL ops are capturable): what bench.py does at N > 1
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(20):
+                ex.exchange(obj)
+        g.replay()
+        torch.cuda.synchronize(dev)
+        out["exchange_us_in_graph"] = statistics.median(timed(g.replay, 20)[0] for _ in range(5))
+        out["graph_capturable"] = True
+    except Exception as e:
+        out["graph_capturable"] = False
+        out["graph_error"] = f"{type(e).__name__}: {e}"[:200]
+    torch.cuda.synchronize(dev)
+    dist.barrier(device_ids=[local_rank])
+    dist.destroy_process_group()
+    sys.stdout.flush()
+    print("EXCHANGE_PROBE " + json.dumps(out), flush=True)
+
+
+def exchange_probe_parent(a):
+    """Called by the N = 1 run BEFORE it touches the GPU: start the probe as a child process, wait for it, return its line
+    (or why there is none -- the probe never fails the benchmark)."""
+    env = dict(os.environ)
+    env.update({"RLS_FORCE_PG": "1", "WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1",
+                "MASTER_PORT": str(_free_port())})
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, os.path.abspath(__file__), "--exchange-probe", "--envs-per-gpu", str(a.envs_per_gpu)]
+    try:
+        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
+    except subprocess.TimeoutExpired:
+        return {"error": "probe child timed out"}
+    for ln in p.stdout.splitlines():
+        if ln.startswith("EXCHANGE_PROBE "):
+            out = json.loads(ln[len("EXCHANGE_PROBE "):])
+            tr = exchange_trace()
+            if tr is not None:
+                out["kernel_trace"] = tr
+            return out
+    return {"error": f"probe child printed no line (rc={p.returncode})", "stderr_tail": p.stderr[-300:]}
+
+
+def exchange_trace():
+    """Launches per exchange from the committed rocprofv3 kernel trace of this same probe (profiles/rNN_exchange.json: written by
+    tools/timing/exchange_trace.sh; a trace cannot be taken from inside the process)."""
+    import glob
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_exchange.json")), reverse=True):
+        try:
+            d = json.load(open(p))
+            return {"launches_per_exchange": d["launches_per_exchange"], "kernels": d["kernels"], "source": f"profiles/{os.path.basename(p)}"}
+        except Exception:
+            pass
+    return None
 
 
 # --------------------------------------------------------------------------- #
@@ -212,7 +323,7 @@ def _profiled(kernel_sub, row_sub, field):
     for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_kernels.json")), reverse=True):
         try:
             for grp in json.load(open(p)).get("groups", []):
-                for r in (grp if isinstance(grp, list) else grp.get("rows", [])):
+                for r in (grp if isinstance(grp, list) else grp.get("rows", [grp])):     # (a flat list of row dicts since r02)
                     if kernel_sub in r.get("kernel", "") and row_sub in r.get("row", "") and r.get(field) is not None:
                         return {"value": r[field], "source": f"profiles/{os.path.basename(p)}: {r['kernel']}"}
         except Exception:
@@ -438,7 +549,7 @@ def dry_run(a):
     if rank == 0:
         cover = sorted((r["env_offset"], r["env_offset"] + r["envs"]) for r in allr)     # the shards tile [0, G) exactly once
         assert cover[0][0] == 0 and cover[-1][1] == G and all(cover[i][1] == cover[i + 1][0] for i in range(world - 1)), cover
-        print(json.dumps({"metric": METRIC, "dry_run": True, "n_gpus": world, "global_envs": G,
+        print(json.dumps({"metric": metric_for(a.gset), "dry_run": True, "n_gpus": world, "global_envs": G,
                           "scaling": "strong" if a.global_envs > 0 else "weak", "ranks": allr, "shard_cover": check_cover(covs, G),
                           "global_best": int(best), "owner": int(owner), "best_x": [int(v) for v in bx.tolist()]}),
               flush=True)
@@ -481,7 +592,7 @@ def measure(a, gset, B, steps, warmup, repeats, dev, rank, local_rank, world, vi
         from rlsolver_amd.envs.env_PPO import EnvMaxcut as EnvMaxcutGym
         env = EnvMaxcutGym(types.SimpleNamespace(num_nodes=N, num_envs=B, num_steps=10 ** 9), mygraph=mygraph, device=dev,
                            spin_dtype=torch.bool, reuse_buffers=True)
-        env.xs, env._obj = slots[0], obj        # same initial state as the launcher mode
+        env._xs, env._obj = slots[0], obj       # same initial state as the launcher mode (env._xs: no resync needed, obj IS its cut)
 
         def step(t):
             env.step(actions[t % A], out=slots[(t + 1) % S])
@@ -498,37 +609,60 @@ def measure(a, gset, B, steps, warmup, repeats, dev, rank, local_rank, world, vi
         t += 1
 
     use_pg = dist.is_initialized()
+    nccl = use_pg and dist.get_backend() == "nccl"
+    # the region's exchange: ONE rls_best_key launch + ONE 8-byte all_reduce(MAX) (rlsolver_amd.dist.BestExchange); the key is
+    # unpacked and the range flag read after the last region, never inside one
+    ex = rdist.BestExchange(dev) if use_pg else None
+    if use_pg:   # the first collective builds the communicator (16 ms on a 1-rank RCCL group): not part of any region, and
+        ex.exchange(obj)          # not something a capture may do
+        torch.cuda.synchronize(dev)
     # (auto needs at least one eager warm-up launch: a kernel's first launch loads its code object, which a capture must not do)
     use_graph = (not via_env) and (a.graph == "on" or (a.graph == "auto" and steps <= 100 and warmup > 0))
     graphs = []
     if use_graph:
         # one hipGraph per timed region: region r runs steps t_r .. t_r + steps - 1 of the ring / action cycle (capture enqueues
         # nothing: the launchers resolve torch's current stream at every call, which is the capture stream here)
-        try:
+        def capture(with_exchange):
+            out, tc = [], t
             torch.cuda.synchronize(dev)
-            tc = t
             for _ in range(repeats):
                 gr = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gr):
                     for k in range(steps):
                         step(tc + k)
-                graphs.append(gr)
+                    if with_exchange:
+                        ex.exchange(obj)
+                out.append(gr)
                 tc += steps
-        except Exception as ex:          # a capture that fails must not fail the measurement: the eager launcher loop is the same work
-            if a.graph == "on":
-                raise
-            print(f"bench.py: hipGraph capture failed ({type(ex).__name__}: {ex}); timing the eager launcher loop", file=sys.stderr)
-            graphs, use_graph = [], False
-            torch.cuda.synchronize(dev)
-
-    nccl = use_pg and dist.get_backend() == "nccl"
+            return out
+        # over RCCL the region's exchange is captured with its steps (torch's NCCL ops are capturable): a region is then ONE
+        # graph launch.  Keys staged through the host (gloo: --share-gpu) cannot be captured: steps in the graph, exchange eager
+        exch_in_graph = False
+        if nccl and a.graph_exchange != "off":
+            try:
+                graphs = capture(True)
+                exch_in_graph = True
+            except Exception as e:
+                print(f"bench.py: capturing the exchange failed ({type(e).__name__}: {e}); exchange stays eager", file=sys.stderr)
+                graphs = []
+                torch.cuda.synchronize(dev)
+        if not graphs:
+            try:
+                graphs = capture(False)
+            except Exception as e:       # a capture that fails must not fail the measurement: the eager launcher loop is the same work
+                if a.graph == "on":
+                    raise
+                print(f"bench.py: hipGraph capture failed ({type(e).__name__}: {e}); timing the eager launcher loop", file=sys.stderr)
+                graphs, use_graph = [], False
+                torch.cuda.synchronize(dev)
+    else:
+        exch_in_graph = False
 
     def barrier():
         if use_pg:
             dist.barrier(device_ids=[local_rank]) if nccl else dist.barrier()
 
-    if use_pg:   # the first collective builds the communicator (16 ms on a 1-rank RCCL group): not part of any region
-        rdist.global_best(obj)
+    if use_pg:
         barrier()
     wall, kern, exch = [], [], []
     for rep in range(repeats):
@@ -546,8 +680,8 @@ def measure(a, gset, B, steps, warmup, repeats, dev, rank, local_rank, world, vi
                 step(t)
                 t += 1
         e1.record()
-        if use_pg:  # episode boundary: best objective over all shards (C1, 8 bytes over RCCL)
-            rdist.global_best(obj)
+        if use_pg and not exch_in_graph:  # episode boundary: best objective over all shards (C1, 8 bytes over RCCL)
+            key = ex.exchange(obj)
             e2 = torch.cuda.Event(enable_timing=True)
             e2.record()
         else:
@@ -559,13 +693,42 @@ def measure(a, gset, B, steps, warmup, repeats, dev, rank, local_rank, world, vi
         barrier()
         torch.cuda.synchronize(dev)
         kern.append(e0.elapsed_time(e1) * 1e-3 / max(steps, 1))
-        exch.append(e1.elapsed_time(e2) * 1e-3 if use_pg else 0.0)      # device time from the last step's end to the exchange's end
+        exch.append(e1.elapsed_time(e2) * 1e-3 if (use_pg and not exch_in_graph) else 0.0)   # last step's end -> the exchange's end
 
     per_rank = None
+    exch_probe_s = None
+    if use_pg:
+        # the exchange by itself, outside every region (what `exchange_us` is when the regions hold it inside their graph): 50
+        # back to back, HIP events, all ranks in step
+        barrier()
+        torch.cuda.synchronize(dev)
+        ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ea.record()
+        for _ in range(50):
+            key = ex.exchange(obj)
+        eb.record()
+        torch.cuda.synchronize(dev)
+        exch_probe_s = ea.elapsed_time(eb) * 1e-3 / 50
+        if exch_in_graph:                    # a graph region's kernel time holds its exchange: take the stand-alone figure out
+            kern = [max(0.0, (k * steps - exch_probe_s) / max(steps, 1)) for k in kern]
+            exch = [exch_probe_s] * len(exch)
+        # the exchange is checked here, after the regions: the key is the maximum over every rank's objectives, the flag clean
+        best, owner = ex.unpack(key)
+        ex.check()
+        mx = obj.max().to(torch.int64).reshape(1)
+        if nccl:
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        else:
+            hm = mx.cpu()
+            dist.all_reduce(hm, op=dist.ReduceOp.MAX)
+            mx = hm
+        if int(best) != int(mx[0]) or not (0 <= int(owner) < world):
+            raise SystemExit(f"PARITY FAILURE: exchanged best {int(best)} (owner {int(owner)}) != max over ranks {int(mx[0])}")
     if use_pg:
         # every rank's own figures (outside every timed region), then the region time that counts: MAX over ranks
         mine = {"rank": rank, "device": str(dev), "envs": int(B), "env_offset": int(env_offset), "region_s": list(wall),
-                "kernel_s_per_step": list(kern), "exchange_s": list(exch)}
+                "kernel_s_per_step": list(kern), "exchange_s": list(exch), "exchange_in_graph": bool(exch_in_graph),
+                "exchange_alone_s": exch_probe_s}
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
         tt = torch.tensor(wall, dtype=torch.float64, device=dev if nccl else "cpu")
@@ -601,6 +764,10 @@ def rank_breakdown(res, steps):
             "kernel_us_per_step_max": max(r["kernel_us_per_step"] for r in ranks),
             "kernel_us_per_step_min": min(r["kernel_us_per_step"] for r in ranks),
             "exchange_us_max": max(r["exchange_us"] for r in ranks),
+            "exchange": "1 rls_best_key launch + 1 all_reduce(MAX, 8 B) per region"
+                        + (", captured in the region's hipGraph (exchange_us = the same exchange timed alone, 50 back to back)"
+                           if pr[0].get("exchange_in_graph") else ", eager after the region's last step"),
+            "exchange_alone_us_max": max((r.get("exchange_alone_s") or 0.0) for r in pr) * 1e6,
             "skew_ms_all_regions": [(max(r["region_s"][i] for r in pr) - min(r["region_s"][i] for r in pr)) * 1e3
                                     for i in range(len(res["wall"]))]}
 
@@ -631,6 +798,11 @@ def main():
                          f"--nproc-per-node {a.gpus} (or plain `python bench.py --gpus {a.gpus}`, which starts the ranks itself)")
     if a.dry_run:
         return dry_run(a)
+    if a.exchange_probe:
+        return exchange_probe_child(a)
+    probe = None
+    if a.gpus == 1 and not a.no_exchange_probe and os.environ.get("RLS_FORCE_PG") != "1":
+        probe = exchange_probe_parent(a)        # a child process, started and finished before this one touches the GPU
 
     import torch
     import torch.distributed as dist
@@ -658,6 +830,19 @@ def main():
         res5 = measure(a, 70, 131072, max(1, min(a.steps, 200)), min(a.warmup, 20), R, dev, rank, local_rank, world,
                        verify=not a.no_verify)
         torch.cuda.empty_cache()
+    res_nts = None
+    if world == 1 and not a.no_hbm_only and res["B"] * res["N"] <= MALL_BYTES:
+        # the same loop with nontemporal stores: a ring slot of B*N bytes fits the 256 MB Infinity Cache, and with plain stores
+        # (the launcher's choice at this size) the next step's reads hit what this step wrote -- FETCH_SIZE counts those hits.
+        # With nontemporal stores nothing a step writes is kept for the next one to find: the HBM-only figure.
+        from rlsolver_amd import _abi
+        _abi.tuning_set("RLS_STEP_NTS", 1)
+        try:
+            res_nts = measure(a, a.gset, B_rank, max(1, min(a.steps, 200)), min(a.warmup, 20), R, dev, rank, local_rank, world,
+                              verify=not a.no_verify, env_offset=env_offset)
+        finally:
+            _abi.tuning_unset("RLS_STEP_NTS")
+        torch.cuda.empty_cache()
     cfgs = None
     if rank == 0 and world == 1 and not a.no_configs:
         cfgs = extra_configs(dev)
@@ -673,7 +858,7 @@ def main():
         B, N = res["B"], res["N"]
         s = summarize(res, a.steps, world, total_envs=G)
         out = {
-            "metric": METRIC,
+            "metric": metric_for(a.gset),
             "value": s["value"],
             "unit": "env-steps/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -707,6 +892,18 @@ def main():
         tr = pmc_traffic_per_launch(B, N, a.slots)
         if tr is not None:
             out["roofline"]["traffic"], out["roofline"]["traffic_source"] = tr[0], f"profiles/{tr[1]} (rocprofv3 --pmc)"
+        slot = B * N
+        if slot <= MALL_BYTES:
+            out["roofline"]["bound_detail"] = (f"hbm + infinity cache: a ring slot is {slot / 1e6:.0f} MB < 256 MB of MALL and the launcher "
+                                               "stores plainly at this size, so part of a step's reads are served by what the previous step "
+                                               "wrote (FETCH_SIZE counts MALL hits); `hbm_only` is the same loop with nontemporal stores")
+        else:
+            out["roofline"]["bound_detail"] = (f"hbm only: a ring slot is {slot / 1e6:.0f} MB > 256 MB of MALL, stores are nontemporal")
+        if res_nts is not None:
+            sn = summarize(res_nts, max(1, min(a.steps, 200)), world, total_envs=G)["roofline"]
+            out["roofline"]["hbm_only"] = {"frac": sn["frac"], "achieved": sn["achieved"], "unit": "GB/s", "us_per_launch": sn["us_per_launch"],
+                                           "how": "rls_tuning_set(\"RLS_STEP_NTS\", 1): the same workload, nontemporal stores",
+                                           "kernel": "k_maxcut_step<u8, emit, nontemporal stores>"}
         if res5 is not None:
             st5 = max(1, min(a.steps, 200))
             s5 = summarize(res5, st5, world)
@@ -722,6 +919,8 @@ def main():
                 out["config5_shard"]["rank_breakdown"] = s5["rank_breakdown"]
         if cfgs is not None:
             out["configs"] = cfgs
+        if probe is not None:
+            out["exchange_probe"] = probe
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(res["graph_arr"], N, a.cpu_seconds)
             out["cpu_baseline_ref_shaped"] = cpu_baseline_ref_shaped(res["graph_arr"], N, max(3.0, a.cpu_seconds / 2))

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define RLS_ABI_VERSION 11
+#define RLS_ABI_VERSION 12
 
 enum {
     RLS_OK = 0,
@@ -331,6 +331,13 @@ int rls_best_update(const uint8_t* xs, const void* vs, int vs_kind, int64_t B, i
  * once) gets bit 0 set when |value| >= limit or a float value is not a half-integer: the key is then built from 0. */
 int rls_best_key(const void* vs, int vs_kind, int64_t B, int32_t rank_bits, int64_t low_code, int64_t limit, int64_t* key,
                  int64_t* index, int32_t* flag, void* stream);
+/* ABI v12.  The reduced key back into what the caller wants, in one launch after the all-reduce (dist.py did it with three
+ * [1]-sized torch ops): obj_out = key >> rank_bits as int64[1], or -- as_float -- double[1] = that / 2 (the doubled
+ * half-integers of rls_best_key); owner_out (may be NULL) = world - 1 - (key & (2^rank_bits - 1)), the rank whose key won
+ * (the `best_vs.argmax()` of L2A/demo_instance.py:165 across ranks).  flag (may be NULL): bit 1 set when key == empty_key,
+ * the value a rank without envs contributes -- it survives the MAX only when no rank had any. */
+int rls_key_unpack(const int64_t* key, int32_t rank_bits, int64_t world, int as_float, void* obj_out, int64_t* owner_out,
+                   int64_t empty_key, int32_t* flag, void* stream);
 
 /* K14 generate_xs_randomly(num_sims)  envs/env_L2A.py:82-85: i.i.d. Bernoulli(1/2)
  *     spins from a counter-based generator keyed by (seed, global env id), node 0

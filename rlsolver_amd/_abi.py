@@ -126,6 +126,7 @@ SIGNATURES = {
     "rls_copy_rows": [_P, _P, _I64, _P, _P, _I64, _P],
     "rls_best_update": [_P, _P, _INT, _I64, _I64, _INT, _P, _P, _P, _P, _I64, _INT, _P],
     "rls_best_key": [_P, _INT, _I64, C.c_int32, _I64, _I64, _P, _P, _P, _P],
+    "rls_key_unpack": [_P, C.c_int32, _I64, _INT, _P, _P, _I64, _P, _P],
     "rls_tuning_set": [_P, _I64],
     "rls_tuning_unset": [_P],
     "rls_tuning_get": [_P, _P, _P],

@@ -88,7 +88,12 @@ inline void ensure_dyn_lds(const void* kern, size_t lds) {
         const uintptr_t cur = seen[h].load(std::memory_order_acquire);
         if (cur == key) return;
         if (cur == 0) {
-            (void)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+            // recorded only when the attribute really was raised: a failed first attempt is retried by the next launch (whose
+            // own launch error then names the kernel), never remembered as done
+            if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes) != hipSuccess) {
+                (void)hipGetLastError();
+                return;
+            }
             uintptr_t expect = 0;
             seen[h].compare_exchange_strong(expect, key, std::memory_order_release);
             return;

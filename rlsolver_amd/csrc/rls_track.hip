@@ -88,9 +88,34 @@ __global__ __launch_bounds__(kTrackThreads) void k_best_key(const V* __restrict_
     }
 }
 
+// After the all-reduce: the reduced key back into (objective, owner rank) in ONE launch (the host-side alternative is a shift,
+// a mask and a subtraction of [1]-sized tensors, three launches on the only cross-rank path).  obj_out is int64[1], or
+// double[1] = key's objective / 2 for float inputs; owner = world - 1 - low code.  A key equal to empty_key (what a rank
+// without envs contributes) that survived the reduction means no rank had an env: flag bit 1.
+__global__ void k_key_unpack(const int64_t* __restrict__ key, int rank_bits, int64_t world, int as_float, void* __restrict__ obj_out,
+                             int64_t* __restrict__ owner_out, int64_t empty_key, int32_t* __restrict__ flag) {
+    if (threadIdx.x) return;
+    const int64_t k = key[0];
+    const int64_t obj = k >> rank_bits;                                   // arithmetic: negative objectives survive
+    const int64_t low = k & ((1ll << rank_bits) - 1);
+    if (as_float) ((double*)obj_out)[0] = (double)obj * 0.5;
+    else ((int64_t*)obj_out)[0] = obj;
+    if (owner_out) owner_out[0] = world - 1 - low;
+    if (flag && k == empty_key) atomicOr(flag, 2);
+}
+
 }  // namespace rls
 
 using namespace rls;
+
+extern "C" int rls_key_unpack(const int64_t* key, int32_t rank_bits, int64_t world, int as_float, void* obj_out, int64_t* owner_out,
+                              int64_t empty_key, int32_t* flag, void* stream) {
+    RLS_REQUIRE(key && obj_out, RLS_EINVAL, "NULL pointer");
+    RLS_REQUIRE(rank_bits >= 0 && rank_bits < 32 && world >= 1 && world <= (1ll << rank_bits), RLS_EINVAL, "bad key layout");
+    hipLaunchKernelGGL(k_key_unpack, dim3(1), dim3(64), 0, as_stream(stream), key, (int)rank_bits, world, as_float, obj_out, owner_out,
+                       empty_key, flag);
+    return check_launch("k_key_unpack");
+}
 
 extern "C" int rls_best_key(const void* vs, int vs_kind, int64_t B, int32_t rank_bits, int64_t low_code, int64_t limit, int64_t* key,
                             int64_t* index, int32_t* flag, void* stream) {

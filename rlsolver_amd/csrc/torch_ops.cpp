@@ -345,6 +345,22 @@ void best_key(const Tensor& vs, int64_t rank_bits, int64_t low_code, int64_t lim
     ok(rls_best_key(p(vs), kind, vs.numel(), (int32_t)rank_bits, low_code, limit, (int64_t*)p(key), (int64_t*)p(index), (int32_t*)p(flag),
                     cur_stream(vs)), "rls_best_key");
 }
+void key_unpack(const Tensor& key, int64_t rank_bits, int64_t world, Tensor obj, const OptTensor& owner, int64_t empty_key,
+                const OptTensor& flag) {
+    dev(key, "key", I64);
+    at_least(key, "key", 1);
+    dev(obj, "obj");
+    TORCH_CHECK(obj.scalar_type() == I64 || obj.scalar_type() == F64, "obj must be int64 or float64");
+    at_least(obj, "obj", 1);
+    optdev(owner, "owner", I64);
+    optdev(flag, "flag", I32);
+    if (owner.has_value()) at_least(*owner, "owner", 1);
+    if (flag.has_value()) at_least(*flag, "flag", 1);
+    same_device(key, obj, "obj");
+    RLS_GUARD(key);
+    ok(rls_key_unpack((const int64_t*)p(key), (int32_t)rank_bits, world, obj.scalar_type() == F64, p(obj), (int64_t*)p(owner), empty_key,
+                      (int32_t*)p(flag), cur_stream(key)), "rls_key_unpack");
+}
 void rand_spins(Tensor x, int64_t seed, int64_t env_offset) {
     spin_bytes(x, "x", false);
     TORCH_CHECK(x.dim() == 2, "x must be [B, N]");
@@ -790,6 +806,11 @@ void isco_maxcut_step(int64_t g, const Tensor& x, Tensor y_out, const Tensor& pa
     if (acc_out.has_value()) count(*acc_out, "acc_out", B);
     if (terms_out.has_value()) shape2(*terms_out, "terms_out", B, 5);
     if (mask_out.has_value()) { spin_bytes(*mask_out, "mask_out", false); shape2(*mask_out, "mask_out", B, N); }
+    if (scratch.has_value()) {      // the kernel's f32 rows past ~15 900 nodes: a device pointer it writes through
+        dev(*scratch, "scratch");
+        same_device(x, *scratch, "scratch");
+        TORCH_CHECK(scratch->is_contiguous(), "scratch must be contiguous");
+    }
     RLS_GUARD(x);
     ok(rls_isco_maxcut_step(G(g), (const float*)p(x), (float*)p(y_out), B, (const int64_t*)p(path_length), (float)temperature,
                             (const float*)p(u_gumbel), (const float*)p(u_accept), (uint64_t)seed, env_offset, (float*)p(energy_out),
@@ -863,6 +884,7 @@ TORCH_LIBRARY(rlsolver_hip, m) {
     m.def("best_update(Tensor xs, Tensor vs, bool if_maximize, Tensor(a!) best_x, Tensor(b!) best_v, Tensor(c!) improved, Tensor(d!)? log_v, "
           "int log_index, bool force) -> ()");
     m.def("best_key(Tensor vs, int rank_bits, int low_code, int limit, Tensor(a!) key, Tensor(b!)? index, Tensor(c!) flag) -> ()");
+    m.def("key_unpack(Tensor key, int rank_bits, int world, Tensor(a!) obj, Tensor(b!)? owner, int empty_key, Tensor(c!)? flag) -> ()");
     m.def("rand_spins(Tensor(a!) x, int seed, int env_offset) -> ()");
     m.def("rand_spins_repeats(Tensor(a!) x, Tensor repeat_seeds, int env_offset) -> ()");
     m.def("rand_actions(Tensor(a!) action, int N, int seed, int step, int env_offset) -> ()");
@@ -928,6 +950,7 @@ TORCH_LIBRARY_IMPL(rlsolver_hip, CUDA, m) {   // "CUDA" is the HIP dispatch key 
     m.impl("copy_rows", &copy_rows);
     m.impl("best_update", &best_update);
     m.impl("best_key", &best_key);
+    m.impl("key_unpack", &key_unpack);
     m.impl("rand_spins", &rand_spins);
     m.impl("rand_spins_repeats", &rand_spins_repeats);
     m.impl("rand_actions", &rand_actions);

@@ -131,22 +131,105 @@ def unpack_bits(p: torch.Tensor, n: int, dtype=torch.bool) -> torch.Tensor:
     return ((p[:, None] >> sh) & 1).reshape(-1)[:n].to(dtype)
 
 
+_FLAG_MSG = ("global_best: objective outside the packed-key range (|obj| < 2^42) or not a half-integer (flag bit 0), or no rank "
+             "had an env (flag bit 1)")
+
+
+class BestExchange:
+    """The episode-boundary exchange of ONE call site as exactly two device operations: one ``rls_best_key`` launch (first
+    argmax + packed key + range / half-integer check) into a slot of a persistent ring, and the 8-byte ``all_reduce(MAX)``
+    on that slot (C1; the single-device analogue is ``best_vs.argmax()``, rlsolver/methods/L2A/demo_instance.py:165).
+    Nothing is allocated, no [1]-sized torch op runs, nothing is read by the host:
+
+        ex = BestExchange(device, group)          # once per call site
+        key = ex.exchange(local_vs)               # per episode boundary: 1 launch + 1 collective
+        ...
+        obj, owner = ex.unpack(key)               # when the caller wants the numbers: 1 launch (rls_key_unpack)
+        ex.check()                                # lazily: one host read of the sticky flag word
+
+    A slot is reused after ``depth`` exchanges: a key the caller still holds then changes under it (``unpack`` writes fresh
+    tensors).  The flag word is sticky and shared by the ring: it is asserted asynchronously every ``depth``-th exchange and
+    on ``check()``, never per call.  The slot's layout is {key, index of the local maximum, spare}."""
+
+    def __init__(self, device, group=None, depth: int = 64):
+        self.device = torch.device(device)
+        self.group = group
+        self.depth = int(depth)
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if self.world > (1 << RANK_BITS):
+            raise ValueError("world too large for the packed key")
+        self.ring = torch.zeros((self.depth, 4), dtype=torch.int64, device=self.device)
+        self.flag = torch.zeros(2, dtype=torch.int32, device=self.device)[0:1]
+        self._keys = [self.ring[i, 0:1] for i in range(self.depth)]      # views made once: a slice is a host-side cost per call
+        self._idx = [self.ring[i, 1:2] for i in range(self.depth)]
+        self._n = 0
+        self._collective = (dist.is_initialized() and (self.world > 1 or os.environ.get("RLS_FORCE_PG") == "1"))
+        self._host = self._collective and dist.get_backend(group) != "nccl"
+        self.last_index = None
+
+    def exchange(self, local_vs: torch.Tensor) -> torch.Tensor:
+        """-> the REDUCED key, int64 [1] (a ring slot).  ``last_index`` = int64 [1] view of the local maximum's position."""
+        from .torch_ops import ops as _t
+        i = self._n % self.depth
+        self._n += 1
+        key, idx = self._keys[i], self._idx[i]
+        if local_vs.numel():
+            _t.best_key(local_vs if local_vs.is_contiguous() else local_vs.contiguous(), RANK_BITS, self.world - 1 - self.rank,
+                        OBJ_LIMIT, key, idx, self.flag)
+        else:
+            key.fill_(_EMPTY_KEY)
+        self.last_index = idx
+        if self._collective:
+            if self._host:
+                h = key.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.MAX, group=self.group)
+                key.copy_(h)
+            else:
+                dist.all_reduce(key, op=dist.ReduceOp.MAX, group=self.group)            # C1: 8 bytes
+        if i == self.depth - 1:
+            torch._assert_async(self.flag[0] == 0, _FLAG_MSG)
+        return key
+
+    def unpack(self, key: torch.Tensor, as_float: bool = False):
+        """(best objective 0-dim -- int64, or float64 = half the doubled key for float inputs --, owner rank int64 0-dim) as
+        fresh tensors, one launch."""
+        from .torch_ops import ops as _t
+        obj = torch.empty(1, dtype=torch.float64 if as_float else torch.int64, device=self.device)
+        owner = torch.empty(1, dtype=torch.int64, device=self.device)
+        _t.key_unpack(key, RANK_BITS, self.world, obj, owner, _EMPTY_KEY, self.flag)
+        return obj[0], owner[0]
+
+    def check(self):
+        """One host read of the sticky flag: raises what the per-call assert of earlier rounds raised."""
+        f = int(self.flag[0])
+        if f:
+            raise ValueError(_FLAG_MSG + f" [flag = {f}]")
+
+
+_SITES = {}
+
+
+def _site(device, group) -> BestExchange:
+    """global_best()'s own call site per (device, group, world): created on first use, lives as long as the process."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    k = (str(device), id(group) if group is not None else None, world, dist.is_initialized())
+    ex = _SITES.get(k)
+    if ex is None or ex.rank != (dist.get_rank(group) if dist.is_initialized() else 0):     # (a group torn down and rebuilt)
+        ex = _SITES[k] = BestExchange(device, group)
+    return ex
+
+
+def _on_device(local_vs: torch.Tensor) -> bool:
+    return local_vs.is_cuda and local_vs.dtype in (torch.int64, torch.int32, torch.float32, torch.float64)
+
+
 def _local_best(local_vs: torch.Tensor, rank: int, world: int):
-    """(key int64 [1] or None for an empty shard, first argmax index 0-dim tensor or None).  Device tensors: ONE launch
-    (rls_best_key: first argmax + packed key + range / half-integer check) into scratch allocated per call -- a buffer
-    shared between calls would let an in-flight all_reduce or a result still held by the caller be overwritten, and a flag
-    that is only ever OR-ed would poison every later call."""
+    """Host-tensor form (gloo CPU tests, dry runs): (key int64 [1] or None for an empty shard, first argmax index 0-dim
+    tensor or None).  Device tensors take BestExchange."""
     is_float = local_vs.is_floating_point()
     if not local_vs.numel():
         return None, None
-    if local_vs.is_cuda and local_vs.dtype in (torch.int64, torch.int32, torch.float32, torch.float64):
-        from .torch_ops import ops as _t
-        buf = torch.zeros(3, dtype=torch.int64, device=local_vs.device)       # {key, index, flag}
-        flag = buf[2:3].view(torch.int32)[0:1]
-        _t.best_key(local_vs.contiguous(), RANK_BITS, world - 1 - rank, OBJ_LIMIT, buf[0:1], buf[1:2], flag)
-        torch._assert_async(flag[0] == 0,
-                            "global_best: objective outside the packed-key range (|obj| < 2^42) or not a half-integer")
-        return buf[0:1], buf[1]
     li = local_vs.argmax()
     raw = local_vs[li]
     lbest = torch.round(raw.to(torch.float64) * 2).to(torch.int64) if is_float else raw.to(torch.int64)
@@ -181,21 +264,35 @@ def global_best(local_vs: torch.Tensor, local_xs=None, want_solution: bool = Fal
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     if world > (1 << RANK_BITS):
         raise ValueError("world too large for the packed key")
-    key, li = _local_best(local_vs, rank, world)
     finish = (lambda o: o.to(torch.float64) / 2) if is_float else (lambda o: o)
     want_x = want_solution and local_xs is not None
     want_i = env_offset is not None
     tail = (lambda gi: (gi,)) if want_i else (lambda gi: ())
     # RLS_FORCE_PG=1 keeps a 1-rank group on the collective path (the RCCL calls get exercised on a 1-GPU box)
-    if not dist.is_initialized() or (world == 1 and os.environ.get("RLS_FORCE_PG") != "1"):
-        if not n_local:
+    single = not dist.is_initialized() or (world == 1 and os.environ.get("RLS_FORCE_PG") != "1")
+    if _on_device(local_vs):
+        # device path: rls_best_key + all_reduce (+ rls_key_unpack): two launches and one collective, nothing allocated but the
+        # two result words, nothing read by the host (BestExchange); the range / half-integer flag is checked lazily
+        if single and not n_local:
             raise ValueError("global_best: no envs at all")
-        return (finish(key[0] >> RANK_BITS), torch.zeros((), dtype=torch.int64, device=dev),
-                (_row(local_xs, li).clone() if want_x else None)) + tail(li + env_offset if want_i else None)
-    if key is None:
-        key = torch.full((1,), _EMPTY_KEY, dtype=torch.int64, device=dev)
-    _all_reduce(key, dist.ReduceOp.MAX, group)                          # C1: 8 bytes
-    obj, owner = unpack_key(key[0], world)
+        ex = _site(dev, group)
+        key = ex.exchange(local_vs)
+        li = ex.last_index[0] if n_local else None
+        obj, owner = ex.unpack(key, as_float=is_float)
+        if single:
+            return (obj, owner, (_row(local_xs, li).clone() if want_x else None)) + tail(li + env_offset if want_i else None)
+        finish = lambda o: o                                            # (rls_key_unpack has halved a float key already)
+    else:
+        key, li = _local_best(local_vs, rank, world)
+        if single:
+            if not n_local:
+                raise ValueError("global_best: no envs at all")
+            return (finish(key[0] >> RANK_BITS), torch.zeros((), dtype=torch.int64, device=dev),
+                    (_row(local_xs, li).clone() if want_x else None)) + tail(li + env_offset if want_i else None)
+        if key is None:
+            key = torch.full((1,), _EMPTY_KEY, dtype=torch.int64, device=dev)
+        _all_reduce(key, dist.ReduceOp.MAX, group)                      # C1: 8 bytes
+        obj, owner = unpack_key(key[0], world)
     best_x = gi = None
     if want_x or want_i:
         if int(key[0]) == _EMPTY_KEY:                                   # (the host read below, taken one line early)
@@ -220,9 +317,9 @@ def global_best(local_vs: torch.Tensor, local_xs=None, want_solution: bool = Fal
         if want_x:
             dt = torch.bool if callable(local_xs) else local_xs.dtype
             best_x = unpack_bits(buf[8 * want_i:], n, dt)
-    elif not n_local:
+    elif not n_local and not _on_device(local_vs):
         # no host read on this path: an all-empty world trips the same error asynchronously on every rank (a rank that has
-        # envs knows the reduced key is a real one)
+        # envs knows the reduced key is a real one; the device path raises flag bit 1 in rls_key_unpack instead)
         torch._assert_async(key[0] != _EMPTY_KEY, "global_best: no envs at all")
     return (finish(obj), owner, best_x) + tail(gi)
 

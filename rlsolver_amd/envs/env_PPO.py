@@ -35,7 +35,9 @@ class EnvMaxcut(Sharded):
         self.if_bidirectional = if_bidirectional
         self.num_nodes = args.num_nodes
         self.num_envs = args.num_envs
-        self.xs = None
+        self._xs = None
+        self._stale = False
+        self._carry = None
         self.action_count = 0
         self.last_reward = None
         self.num_steps = args.num_steps
@@ -55,12 +57,43 @@ class EnvMaxcut(Sharded):
             if reuse_buffers else None
         self._flip = 0
 
+    # The reference recomputes the cut from ``self.xs`` on every step (env_PPO.py:96-98); this class keeps it incrementally
+    # (``_obj`` + the action node's gain).  A caller that changes the state behind the env's back must say so:
+    #   * ``env.xs = tensor`` (assignment) is seen by the property below and re-synchronises by itself at the next step;
+    #   * an IN-PLACE edit (``env.xs[3, 7] = 1``) cannot be seen: call ``env.resync()`` after it.
+    # Either way the next step's reward is the reference's: new cut - last_reward, the edit's own change included.
+    @property
+    def xs(self):
+        return self._xs
+
+    @xs.setter
+    def xs(self, value):
+        self._xs = value
+        self._stale = value is not None
+
+    def resync(self):
+        """Recompute the incremental objective from ``self.xs`` (call after editing ``env.xs`` in place between steps).  The
+        cut change of the edit is carried into the next step's reward, as ``cur_reward - self.last_reward`` of
+        env_PPO.py:97-98 would hold it."""
+        self._stale = False
+        if self._xs is None:
+            return self
+        if self._xs.dtype != self.spin_dtype or self._xs.device != self.device or not self._xs.is_contiguous():
+            self._xs = self._xs.to(device=self.device, dtype=self.spin_dtype).contiguous()
+        new = ops.maxcut_obj(self.graph, self._xs).to(th.int32)
+        if self.last_reward is not None:
+            carry = new.to(th.float32) - self.last_reward
+            self._carry = carry if self._carry is None else self._carry + carry
+        self._obj.copy_(new)
+        return self
+
     def reset(self):
         xs = self.generate_xs_randomly(num_sims=self.num_envs)
-        self.xs = xs.to(self.spin_dtype)
-        self._obj.copy_(ops.maxcut_obj(self.graph, self.xs))
+        self._xs = xs.to(self.spin_dtype)
+        self._stale, self._carry = False, None
+        self._obj.copy_(ops.maxcut_obj(self.graph, self._xs))
         self.last_reward = self._obj.to(th.float)
-        return self.xs
+        return self._xs
 
     def step(self, action, out: Optional[TEN] = None):
         """env_PPO.py:92-106.  ``out`` (f32 [B, N]) makes the step emit the next state there (the
@@ -78,11 +111,16 @@ class EnvMaxcut(Sharded):
             done_value = 1.0
         else:
             done_value = 0.0
-        dst = self.xs if out is None else out
-        self._step_op(self._gh, self.xs, dst, action, self._obj, reward, cur, next_done, done_value)
-        self.xs = dst
+        if self._stale:
+            self.resync()
+        dst = self._xs if out is None else out
+        self._step_op(self._gh, self._xs, dst, action, self._obj, reward, cur, next_done, done_value)
+        self._xs = dst
+        if self._carry is not None:            # only after a resync(): the edit's own cut change belongs to this reward
+            reward += self._carry
+            self._carry = None
         self.last_reward = cur
-        return self.xs, reward, next_done, cur
+        return self._xs, reward, next_done, cur
 
     def calculate_obj_values(self, if_sum: bool = True) -> TEN:
         """env_PPO.py:108-121 (objective of the env's own state)."""
@@ -102,7 +140,8 @@ class EnvMaxcut(Sharded):
                 "last_reward": None if self.last_reward is None else self.last_reward.clone()}
 
     def load_state_dict(self, d):
-        self.xs = d["xs"].to(device=self.device, dtype=self.spin_dtype).clone()
+        self._xs = d["xs"].to(device=self.device, dtype=self.spin_dtype).clone()
+        self._stale, self._carry = False, None
         self._obj.copy_(d["obj"])
         self.action_count = int(d["action_count"])
         self.last_reward = None if d["last_reward"] is None else d["last_reward"].clone()

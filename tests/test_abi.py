@@ -105,7 +105,7 @@ def test_every_device_entry_point_is_a_torch_op():
 
 def test_loads_without_gpu_and_reports_errors():
     from rlsolver_amd import _abi
-    assert _abi.version() == 11
+    assert _abi.version() == 12
     assert _abi.device_count() >= 0
     # argument validation happens before any device work
     with pytest.raises(_abi.RlsError) as e:

@@ -126,6 +126,41 @@ def test_env_ppo_class_golden(golden, gname, bidir):
     assert xs.data_ptr() == slot.data_ptr() and torch.equal(slot[:, 1:], prev[:, 1:]) and torch.equal(slot[:, 0], 1 - prev[:, 0])
 
 
+@pytest.mark.parametrize("bidir", [False, True])
+def test_env_ppo_state_edited_behind_the_env(golden, bidir):
+    """The reference recomputes the cut from self.xs every step (env_PPO.py:96-98): a caller that edits env.xs between steps
+    gets reward = new cut - last_reward there.  Here the objective is incremental: an in-place edit needs resync(), an
+    assignment to env.xs is seen by itself -- rewards / curs then equal the reference-shaped oracle's, edit included."""
+    from oracle.oracle_torch import PPOEnvRefShaped
+    from rlsolver_amd.envs.env_PPO import EnvMaxcut
+    z = golden("env_ppo")
+    graph = z["BA_100_ID0/graph"]
+    tag = f"BA_100_ID0/bidir{int(bidir)}"
+    n = int(graph[:, :2].max()) + 1
+    args = types.SimpleNamespace(num_nodes=n, num_envs=16, num_steps=20)
+    env = EnvMaxcut(args, mygraph=mygraph_of(graph), device=DEV, if_bidirectional=bidir)
+    ref = PPOEnvRefShaped(graph, n, 16, 20, bidir)
+    env.reset()
+    env.xs = torch.from_numpy(z[f"{tag}/xs0"]).to(DEV).float()               # assignment: seen, no call needed
+    ref.reset_to(z[f"{tag}/xs0"] > 0)
+    env.last_reward = ref.last_reward.to(DEV)
+    rng = np.random.RandomState(3)
+    for t in range(12):
+        if t in (3, 7):                                                      # an in-place edit of a block of spins, both sides
+            rows, cols = rng.randint(0, 16, 5), rng.randint(1, n, 5)
+            env.xs[torch.from_numpy(rows).to(DEV), torch.from_numpy(cols).to(DEV)] = 1.0
+            ref.xs[torch.from_numpy(rows), torch.from_numpy(cols)] = 1.0
+            env.resync()
+        if t == 9:                                                           # a whole new state by assignment
+            new = torch.from_numpy(rng.randint(0, 2, (16, n))).float()
+            env.xs = new.to(DEV)
+            ref.xs = new.clone()
+        a = torch.from_numpy(z[f"{tag}/actions"][t])
+        xs, r, d, c = env.step(a.to(DEV))
+        rx, rr, rd, rc = ref.step(a)
+        assert torch.equal(xs.cpu(), rx) and torch.equal(r.cpu(), rr) and torch.equal(c.cpu(), rc) and torch.equal(d.cpu(), rd), t
+
+
 def test_select_wrappers_golden(golden):
     from rlsolver_amd.methods.util_read_data import evolutionary_replacement, pick_xs_by_vs, update_xs_by_vs
     z = golden("select_ops")

@@ -33,6 +33,27 @@ ok = int(best) == int(obj.max()) and int(owner) == 0 and torch.equal(bx, xs[i]) 
 # the float (bidirectional) form and the no-solution form
 bf, of, _ = rdist.global_best(obj.to(torch.float32) / 2)
 ok = ok and float(bf) == float(obj.max()) / 2 and int(of) == 0
+# the lean form (VERDICT r5 item 1): one rls_best_key launch + one all_reduce per exchange, unpack / flag check deferred
+ex = rdist.BestExchange(dev, depth=4)
+for rep in range(9):                                                   # (more than the ring's depth: slots are reused)
+    key = ex.exchange(obj + rep)
+o, w = ex.unpack(key)
+ok = ok and int(o) == int(obj.max()) + 8 and int(w) == 0 and int(ex.last_index[0]) == i
+ex.check()
+# ... and captured in a hipGraph with the work before it, as bench.py's regions do at N > 1
+obj2 = obj.clone()
+gr = torch.cuda.CUDAGraph()
+with torch.cuda.graph(gr):
+    obj2.add_(1)
+    k2 = ex.exchange(obj2)
+gr.replay(); gr.replay()
+torch.cuda.synchronize()
+ok = ok and int(ex.unpack(k2)[0]) == int(obj.max()) + 2
+ex.exchange(torch.full((4,), 1 << 50, dtype=torch.int64, device=dev))  # outside the key's range: the sticky flag, read lazily
+try:
+    ex.check(); ok = False
+except ValueError:
+    pass
 t = torch.arange(8, dtype=torch.int64, device=dev)
 dist.all_reduce(t, op=dist.ReduceOp.MAX)
 ok = ok and t.tolist() == list(range(8))
@@ -75,6 +96,25 @@ def test_bench_under_one_rank_rccl_group():
     out = json.loads(p.stdout.strip().splitlines()[-1])
     assert out["n_gpus"] == 1 and out["steps"] == 20 and out["repeats"] == 3 and len(out["ms_per_step_all"]) == 3
     assert out["value"] > 0 and 0 < out["roofline"]["frac"] < 1
+
+
+def test_bench_line_carries_the_exchange_probe():
+    """The N = 1 line's `exchange_probe`: a child process (started before bench.py touches the GPU) times the exchange on a
+    1-rank RCCL group -- eager, alone, and inside a hipGraph."""
+    e = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "RLS_FORCE_PG"):
+        e.pop(k, None)
+    e["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--repeats", "3",
+                        "--envs-per-gpu", "4096", "--no-cpu-baseline", "--no-config5", "--no-configs"], env=e,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads(p.stdout.strip().splitlines()[-1])
+    pr = out["exchange_probe"]
+    assert "error" not in pr, pr
+    assert pr["backend"] == "nccl" and pr["check"] == "ok" and 0 < pr["exchange_us"] < 1000 and pr["exchange_us_single"] > 0
+    assert pr["graph_capturable"] in (True, False)
+    assert out["roofline"]["hbm_only"]["frac"] > 0 and "bound_detail" in out["roofline"]
 
 
 @pytest.mark.parametrize("launch", ["self-spawn", "torchrun"])

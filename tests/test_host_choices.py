@@ -13,3 +13,21 @@ def test_qubo_kernel_choice_follows_the_measured_crossovers():
         assert qubo_prefers_sparse(n, int(n * n * fill), C) == want, (n, fill, C)
     assert not qubo_prefers_sparse(64, 64 * 64, 1 << 20)      # a full matrix never goes sparse
     assert not qubo_prefers_sparse(0, 0, 10)
+
+
+def test_bench_profiled_reader_finds_the_committed_rows():
+    """bench.py's _profiled(): the SQ-counter figures of the config rows come from the newest committed per-kernel table
+    (profiles/rNN_kernels.json, a flat list of row dicts since r02) -- ADVICE r5: the reader looked for a 'rows' key and
+    silently found nothing."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    k7 = bench._profiled("k_mcpg_local_search_levels", "BA-1e4", "valu_frac")
+    assert k7 is not None and 0 < k7["value"] < 1 and k7["source"].startswith("profiles/r")
+    ls = bench._profiled("k_maxcut_local_search", "G22", "valu_frac")
+    assert ls is not None and 0 < ls["value"] < 1
+    assert bench._profiled("no_such_kernel", "G22", "valu_frac") is None
+    assert bench.metric_for(22) == bench.METRIC and "G70" in bench.metric_for(70)
