@@ -63,7 +63,29 @@ __global__ __launch_bounds__(kTrackThreads) void k_best_key(const V* __restrict_
     __shared__ int64_t s_idx[kTrackThreads / 64];
     double bv = -INFINITY;
     int64_t bi = INT64_MAX;
-    for (int64_t b = threadIdx.x; b < B; b += kTrackThreads) {
+    // one workgroup (the key must come out of ONE launch with no scratch): 16 bytes per lane per load and four loads in flight,
+    // or the 64 dependent 4-byte loads per thread of a 2^16-env batch are 15 us of latency on the only cross-rank path.  A
+    // thread's indices grow with its iterations, so the strict compare keeps the FIRST maximum (torch.argmax).
+    constexpr int VEC = 16 / (int)sizeof(V);
+    int64_t done = 0;
+    if ((reinterpret_cast<uintptr_t>(vs) & 15) == 0) {
+        const int64_t nvec = B / VEC;
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4* __restrict__ v4 = reinterpret_cast<const u32x4*>(vs);
+#pragma unroll 4
+        for (int64_t i = threadIdx.x; i < nvec; i += kTrackThreads) {
+            const u32x4 raw = __builtin_nontemporal_load(v4 + i);
+            V e[VEC];
+            __builtin_memcpy(e, &raw, 16);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const double v = (double)e[j];
+                if (v > bv) { bv = v; bi = i * VEC + j; }
+            }
+        }
+        done = nvec * VEC;
+    }
+    for (int64_t b = done + threadIdx.x; b < B; b += kTrackThreads) {
         const double v = (double)vs[b];
         if (v > bv) { bv = v; bi = b; }
     }

@@ -154,7 +154,7 @@ class EnvMaxcut(Sharded):
         fused_now = fused_ok and (num_iters > 0 or not first_draw_proposes)
         ws32, mm = ops.maxcut_ls_weights(self.graph, xs, weight_mult, padded=rounds_ok or fused_now, return_minmax=True)
         mm = self._global_minmax(mm)        # a statistic of the WHOLE batch (env_L2A.py:93-94): reduced over the ranks of a sharded one
-        rd_std = (mm[1] - mm[0]).to(torch.float32).mul_(float(noise_std))   # f32 whatever torch's default dtype is: float(span) * noise_std
+        rd_std = (mm[1] - mm[0]).to(th.float32).mul_(float(noise_std))   # f32 whatever torch's default dtype is: float(span) * noise_std
         off = self.env_offset
         if fused_now:
             ops.maxcut_local_search(self.graph, xs, ws32, rd_std, vs, num_iters, num_spin, noise=noise,

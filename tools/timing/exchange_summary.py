@@ -17,28 +17,38 @@ K = 100
 files = glob.glob(os.path.join(ROOT, "gpurun_out", f"{P}_exchange_kt", "**", "*kernel_trace.csv"), recursive=True)
 if not files:
     raise SystemExit("no kernel trace")
-cnt, dur = collections.Counter(), collections.defaultdict(float)
+rows = []
 for f in files:
-    for r in csv.DictReader(open(f)):
-        name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("rls::", "")
-        cnt[name] += 1
-        dur[name] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3
-# the stretch of K BestExchange.exchange calls + K global_best calls: every kernel whose count is a multiple of K belongs to it
-kern = {}
-for name, c in sorted(cnt.items(), key=lambda kv: -kv[1]):
-    kern[name] = {"launches": c, "mean_us": dur[name] / c}
-per_exchange = {n: v["launches"] for n, v in kern.items()}
-best_key = sum(c for n, c in per_exchange.items() if "k_best_key" in n)
-unpack = sum(c for n, c in per_exchange.items() if "k_key_unpack" in n)
-coll = sum(c for n, c in per_exchange.items() if "ccl" in n.lower() or "allreduce" in n.lower() or "AllReduce" in n)
-other = {n: c for n, c in per_exchange.items() if not ("k_best_key" in n or "k_key_unpack" in n or "ccl" in n.lower() or "allreduce" in n.lower())}
+    rows += list(csv.DictReader(open(f)))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+name_of = lambda r: re.sub(r"\(.*", "", r["Kernel_Name"]).replace("rls::", "").replace("void ", "")
+bk = [i for i, r in enumerate(rows) if "k_best_key" in r["Kernel_Name"]]
+assert len(bk) == 2 * K, len(bk)
+
+
+def window(lo, hi):
+    """Every kernel dispatched from the lo-th to just before the hi-th k_best_key launch: hi - lo whole exchanges."""
+    cnt, dur = collections.Counter(), collections.defaultdict(float)
+    for r in rows[bk[lo]:(bk[hi] if hi < len(bk) else bk[-1] + 1)]:
+        cnt[name_of(r)] += 1
+        dur[name_of(r)] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3
+    n = (hi - lo) if hi < len(bk) else (hi - lo)
+    span = (int(rows[bk[min(hi, len(bk) - 1)]]["Start_Timestamp"]) - int(rows[bk[lo]]["Start_Timestamp"])) * 1e-3
+    return {"exchanges": n, "kernels": {k: {"launches": c, "per_exchange": c / n, "mean_us": dur[k] / c} for k, c in cnt.items()},
+            "launches_per_exchange": sum(cnt.values()) / n, "start_to_start_us": span / max(1, min(hi, len(bk) - 1) - lo)}
+
+
+ex_only = window(1, K)                 # BestExchange.exchange x (K - 1)
+gb = window(K + 1, 2 * K - 1)          # dist.global_best x (K - 2)
 out = {
     "what": "rocprofv3 --kernel-trace of tools/timing/exchange_trace.py: 100 BestExchange.exchange calls, then 100 dist.global_best "
-            "calls (exchange + rls_key_unpack), 1-rank RCCL group on one MI355X",
-    "launches_per_exchange": {"rls_best_key": best_key / (2 * K), "collective_kernels": coll / (2 * K),
-                              "rls_key_unpack (global_best only, after the collective)": unpack / K},
-    "kernels": kern,
-    "other_kernels_in_the_whole_trace (set-up: arange / mul / remainder / to of the test vector, barrier)": other,
+            "calls (exchange + rls_key_unpack), 1-rank RCCL group on one MI355X.  On a 1-rank group RCCL's in-place all_reduce "
+            "dispatches no kernel of its own (at N > 1 it is one RCCL kernel): the trace shows what THIS build launches around it",
+    "launches_per_exchange": ex_only["launches_per_exchange"],
+    "launches_per_global_best": gb["launches_per_exchange"],
+    "kernels": ex_only["kernels"],
+    "BestExchange.exchange": ex_only,
+    "dist.global_best": gb,
 }
 probe = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out", f"{P}_exchange_probe.json")
 if os.path.exists(probe):
@@ -46,4 +56,4 @@ if os.path.exists(probe):
         if ln.startswith("EXCHANGE_PROBE "):
             out["probe"] = json.loads(ln[len("EXCHANGE_PROBE "):])
 json.dump(out, open(os.path.join(ROOT, "profiles", f"{P}_exchange.json"), "w"), indent=1)
-print(json.dumps(out["launches_per_exchange"]), json.dumps(out.get("probe", {})))
+print(out["launches_per_exchange"], out["launches_per_global_best"], json.dumps(out.get("probe", {})))
