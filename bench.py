@@ -443,15 +443,25 @@ def config4_tsp(dev):
     N, B = 100, 1 << 16
     dist, near, rnd = tsp_tables(generate_tsp_coords(N, 100), K=20)
     d = torch.from_numpy(dist).to(dev)
+    K = near.shape[1]
+    near32, rnd32 = torch.from_numpy(near.astype("int32")).to(dev), torch.from_numpy(rnd.astype("int32")).to(dev)
+    tab8 = mops.tsp_tables8(near32, rnd32)
+    thr = K / (K + 1)
     perms = mops.rand_perms(B, N, 3, dev)
-    sel = torch.roll(perms, 7, 1).contiguous()
     t12 = _time_calls(lambda i: mops.tsp_tour_length(d, perms), 300, warm=5)
-    t13 = _time_calls(lambda i: mops.tsp_swap_delta_all(d, perms, sel, 0.5), 300, warm=5)
+    # K13 as the reference runs it (env_ISCO.py:238-335): partners drawn inside the call -- 8N bytes in, 13N out per tour
+    t13 = _time_calls(lambda i: mops.tsp_swap_delta_all(d, perms, None, 0.5, nearest=near32, random=rnd32, near_threshold=thr, seed=i, tables8=tab8),
+                      300, warm=5)
+    sel = torch.roll(perms, 7, 1).contiguous()
+    t13s = _time_calls(lambda i: mops.tsp_swap_delta_all(d, perms, sel, 0.5), 100, warm=3)       # the recorded-draw hook: + 8N in
     length = mops.tsp_tour_length(d, perms)
     rel = 0.0
     for other in (torch.roll(perms, 17, 1).contiguous(), torch.flip(perms, [1]).contiguous()):
         rel = max(rel, float(((mops.tsp_tour_length(d, other) - length).abs() / length).max()))
-    lr, idx, ban = mops.tsp_swap_delta_all(d, perms, sel, 0.5)
+    lr, idx, ban, drawn = mops.tsp_swap_delta_all(d, perms, None, 0.5, nearest=near32, random=rnd32, near_threshold=thr, seed=11, tables8=tab8,
+                                                  return_selected=True)
+    if not torch.equal(torch.gather(perms, 1, idx), drawn):
+        raise SystemExit("PARITY FAILURE (config #4): indices do not point at the drawn partner cities")
     ar = torch.arange(B, device=dev)
     pos = torch.argmin(ban.to(torch.uint8), dim=1)
     okm = ~ban[ar, pos]
@@ -461,13 +471,14 @@ def config4_tsp(dev):
     rel13 = float((err[okm] / length[okm]).max())
     if not (rel <= 1e-5 and rel13 <= 2e-5):
         raise SystemExit(f"PARITY FAILURE (config #4): rotation / reversal {rel:.2e}, swap delta vs length difference {rel13:.2e}")
-    b12, b13 = B * (8 * N + 4), B * (8 * N + 8 * N + 13 * N)
+    b12, b13 = B * (8 * N + 4), B * (8 * N + 13 * N)            # K13 = 8N in + 13N out
     return {"workload": f"TSP-{N} uniform Euclidean, {B} tours (int64 [B, N] permutations, f32 distances)",
             "k12_tour_length_us": t12 * 1e6, "k12_tours_per_s": B / t12, "k12_hbm_frac": b12 / t12 / 1e9 / HBM_PEAK_GBS,
             "k13_swap_delta_all_us": t13 * 1e6, "k13_candidate_moves_per_s": B * N / t13, "k13_hbm_frac": b13 / t13 / 1e9 / HBM_PEAK_GBS,
-            "bound": "hbm", "algorithmic_bytes_per_tour": {"k12": 8 * N + 4, "k13": 29 * N},
-            "check": f"lengths invariant under rotation / reversal to {rel:.1e} relative (tolerance 1e-5); swap delta == length "
-                     f"difference of the applied swap to {rel13:.1e}: ok"}
+            "k13_with_selected_tensor_us": t13s * 1e6,
+            "bound": "hbm", "algorithmic_bytes_per_tour": {"k12": 8 * N + 4, "k13": 21 * N},
+            "check": f"lengths invariant under rotation / reversal to {rel:.1e} relative (tolerance 1e-5); partners drawn in the kernel, "
+                     f"indices point at them; swap delta == length difference of the applied swap to {rel13:.1e}: ok"}
 
 
 def extra_configs(dev):

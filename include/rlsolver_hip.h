@@ -675,15 +675,25 @@ int rls_qubo_sparse_local_search_value(const int32_t* rowptr, const int32_t* col
 int rls_tsp_tour_length(const float* dist, int64_t N, const int64_t* perm, int64_t B,
                         float* length, void* stream);
 
-/* K13 the delta part of ISCO_TSP.opt_2  envs/env_ISCO.py:256-335, given the
- * partner city already drawn for every position (selected int64 [B,N]):
- * j = position of selected[b,i] in perm[b]; ban = partner adjacent to i+1's
- * neighbours (:291-293); delta of swapping the cities at positions i+1 and j
- * (:318-333).  Outputs logratio = -delta / temperature f32 [B,N], indices
- * int64 [B,N], ban uint8 [B,N]. */
-int rls_tsp_swap_delta_all(const float* dist, int64_t N, const int64_t* perm, int64_t B,
-                           const int64_t* selected, float temperature,
+/* K13 ISCO_TSP.opt_2(sample, temperature)  envs/env_ISCO.py:238-335 (ABI v12: the whole of it).
+ * For every position i of every tour: the partner CITY (:245-262: rand < K / (K + 1) ? nearest[city_i, randint(K)] :
+ * random[city_i, randint(N - K - 1)]), j = its position in perm[b] (:265-272), ban = the partner is a neighbour of position
+ * i + 1 (:291-293), delta of swapping the cities at positions i + 1 and j (:318-333).  Outputs logratio = -delta /
+ * temperature f32 [B,N], indices int64 [B,N], ban uint8 [B,N].
+ *   selected == NULL (production): the partners are drawn IN the kernel from (seed, env_offset + b, i) -- the generator and the
+ *     counters of rls_isco_tsp_step's iteration 0 -- through nearest int32 [N, K] / random int32 [N, random_stride]
+ *     (random_stride >= N - K - 1; or their byte form tables8, below), near_threshold = K / (K + 1); selected_out (may be
+ *     NULL) records them, int64 [B,N].
+ *     Algorithmic bytes per tour: 8N in, 13N out.
+ *   selected != NULL (the recorded-draw hook of the golden tests): int64 [B,N] partner cities, tables / seed ignored. */
+int rls_tsp_swap_delta_all(const float* dist, int64_t N, const int64_t* perm, int64_t B, const int64_t* selected,
+                           const int32_t* nearest, int32_t K, const int32_t* random, int32_t random_stride, const uint8_t* tables8,
+                           float near_threshold, uint64_t seed, int64_t env_offset, int64_t* selected_out, float temperature,
                            float* logratio, int64_t* indices, uint8_t* ban, void* stream);
+/* tables8 (may be NULL; N <= 256): the same two tables as BYTES for the kernel to keep in LDS beside the distance matrix --
+ * rls_tsp_tables8_bytes(N, K) bytes, 4-byte aligned: uint8 [N, K] nearest, zero-padded to a multiple of 16 bytes, then uint8
+ * [N, N - K - 1] = the first N - K - 1 columns of random, zero-padded likewise (0 = no byte form for this N / K). */
+int64_t rls_tsp_tables8_bytes(int64_t N, int32_t K);
 
 /* ISCO_TSP.switch  envs/env_ISCO.py:337-344 for one chosen position per env:
  * if pos[b] >= 0 swap perm[b, (pos[b]+1) % N] and perm[b, indices[b, pos[b]]]. */

@@ -115,7 +115,7 @@ SIGNATURES = {
     "rls_qubo_local_search_value": [_P, _I64, _P, _P, _I64, _I64, _INT, _P, _P],
     "rls_qubo_sparse_local_search_value": [_P, _P, _P, _I64, _P, _P, _I64, _I64, _INT, _P, _P],
     "rls_tsp_tour_length": [_P, _I64, _P, _I64, _P, _P],
-    "rls_tsp_swap_delta_all": [_P, _I64, _P, _I64, _P, _F32, _P, _P, _P, _P],
+    "rls_tsp_swap_delta_all": [_P, _I64, _P, _I64, _P, _P, C.c_int32, _P, C.c_int32, _P, _F32, C.c_uint64, _I64, _P, _F32, _P, _P, _P, _P],
     "rls_tsp_apply_swap": [_P, _I64, _I64, _P, _P, _P],
     "rls_tsp_2opt_delta": [_P, _I64, _P, _I64, _P, _P, _P, _P],
     "rls_tsp_2opt_best": [_P, _I64, _P, _I64, _P, C.c_int32, _P, _P, _P, _P],
@@ -140,6 +140,7 @@ PLAIN = {"rls_version": ([], _INT), "rls_device_count": ([], _INT), "rls_last_er
          "rls_maxcut_node_stats_form": ([_G, _I64, C.c_int32], _INT),
          "rls_mcpg_metro_max_rounds": ([_I64, C.c_int32], _I64),
          "rls_mcpg_metro_scratch_bytes": ([_I64, _I64], _I64),
+         "rls_tsp_tables8_bytes": ([_I64, C.c_int32], _I64),
          "rls_isco_maxcut_scratch_bytes": ([_G, _I64], _I64),
          "rls_maxcut_ls_scratch_bytes": ([_G, _I64, C.c_int32, C.c_int32], _I64),
          "rls_maxcut_ls_slices": ([_G, _I64, C.c_int32], _INT)}

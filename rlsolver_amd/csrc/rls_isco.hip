@@ -15,6 +15,7 @@
 // tree reductions / scans, not torch's order: results agree with the reference to ~1e-6 relative (tests: 1e-5,
 // the tolerance north_star states for floating-point results).
 #include "rls_tile.h"
+#include "rls_draw.h"
 #include <cmath>
 #include <cstdlib>
 
@@ -34,22 +35,6 @@ __device__ __forceinline__ void lds_fence() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
 }
-
-// murmur3 finaliser as a counter-based generator (production draws; tests supply the reference's draws)
-__device__ __forceinline__ uint32_t isco_mix(uint32_t h) {
-    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
-    return h;
-}
-__device__ __forceinline__ uint32_t isco_draw(uint64_t seed, uint64_t env, uint32_t a, uint32_t b, uint32_t stream) {
-    uint32_t h = isco_mix((uint32_t)seed ^ 0x9E3779B9u);
-    h = isco_mix(h ^ (uint32_t)(seed >> 32));
-    h = isco_mix(h ^ (uint32_t)env);
-    h = isco_mix(h ^ (uint32_t)(env >> 32) ^ (a * 0x9E3779B1u));
-    h = isco_mix(h ^ (b * 0x85EBCA77u) ^ (stream * 0xC2B2AE3Du));
-    return h;
-}
-// torch.rand-like uniform in [0, 1) with 24 bits
-__device__ __forceinline__ float isco_unit(uint32_t r) { return (float)(r >> 8) * (1.0f / 16777216.0f); }
 
 // monotone map float -> uint32 (larger float <=> larger key)
 __device__ __forceinline__ uint32_t fkey(float f) {

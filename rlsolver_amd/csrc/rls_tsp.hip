@@ -6,6 +6,7 @@
 // so perm reads and the [B, N] outputs are coalesced.
 #include "rls_tile.h"
 #include "rls_ring.h"
+#include "rls_draw.h"
 
 namespace rls {
 
@@ -71,17 +72,33 @@ __global__ __launch_bounds__(kTspBlock) void k_tsp_tour_length(const float* __re
     }
 }
 
-// K13: all-position swap delta of ISCO_TSP.opt_2 given the drawn partner city per position.
-template <bool LDS_D>
+// K13: ISCO_TSP.opt_2 (env_ISCO.py:238-335) for every position of every tour.  (What bounds it, round 6: not HBM -- each position
+// makes 12 RANDOM LDS gathers (8 matrix entries, 2 tour cities, the inverse, the table entry), and 64 random addresses over 32 banks
+// serialise ~4-5 deep: ~31 us of LDS time at TSP-100 / 2^16 whatever the bytes moved.  A "flat" form (T tours per wave pass as one
+// run of T * N positions, 98 % of the lane slots busy instead of 78 %, byte-sized tours) was built and measured: 42.4 / 38.6 us vs
+// 41.3 / 34.2 for this one -- the same gathers in fewer, fuller passes conflict more; not kept.)  The partner city is drawn IN the
+// kernel (DRAW:
+// rand < K / (K + 1) picks one of the K nearest, else one of the N - K - 1 others; the generator and the counters of the fused
+// ISCO step's iteration 0, so the [B, N] int64 `selected` tensor of a two-op opt_2 -- 8N of the 29N bytes per tour -- never
+// exists), or given (selected != NULL: the recorded-draw hook of the golden tests); then the position of the partner, the ban
+// mask and the swap delta.
+struct TspDraw {
+    const int32_t* nearest; const int32_t* random; int32_t K; int32_t random_stride; float near_threshold;
+    uint64_t seed; int64_t env_offset; int64_t* selected_out;
+    const uint8_t* tables8; int32_t tables8_bytes;      // both tables as bytes, [N, K] (padded to 16 B) then [N, N - K - 1], or NULL
+};
+
+// TAB8: the two neighbour tables in LDS as bytes (city ids < 256: TSP-100 = 2 + 7.9 KB beside the 40 KB matrix; the caller's
+// tables8 block, LDS-DMA'd with the matrix) -- from global memory the table entry is a dependent load on every position's path
+template <bool LDS_D, bool DRAW, bool TAB8 = false>
 __global__ __launch_bounds__(kTspBlock) void k_tsp_swap_delta_all(const float* __restrict__ dist, int64_t N,
                                                                   const int64_t* __restrict__ perm, int64_t B,
-                                                                  const int64_t* __restrict__ selected, float temperature,
+                                                                  const int64_t* __restrict__ selected, TspDraw dr, float temperature,
                                                                   float* __restrict__ logratio,
                                                                   int64_t* __restrict__ indices,
                                                                   uint8_t* __restrict__ ban) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float* dl = reinterpret_cast<float*>(smem);
-    const float* D = stage_dist<LDS_D>(dist, N, dl);
     // per-wave scratch after the (optional) matrix: tour and its inverse, int32 each
     int32_t* scratch = reinterpret_cast<int32_t*>(smem + (LDS_D ? (size_t)N * N * 4 : 0));
     const int wib = threadIdx.x / kWave;
@@ -91,6 +108,22 @@ __global__ __launch_bounds__(kTspBlock) void k_tsp_swap_delta_all(const float* _
     const int64_t wave = (int64_t)blockIdx.x * (blockDim.x / kWave) + wib;
     const int64_t nwaves = (int64_t)gridDim.x * (blockDim.x / kWave);
     const int n = (int)N;
+    const int K = dr.K, NR = n - K - 1;
+    uint8_t* near8 = reinterpret_cast<uint8_t*>(scratch + (int64_t)(blockDim.x / kWave) * 2 * N);      // [N, K]
+    uint8_t* rand8 = near8 + (((size_t)n * K + 15) & ~(size_t)15);                                      // [N, NR]
+    if constexpr (DRAW && TAB8) {
+        // the byte tables travel with the matrix: LDS-DMA, 256 B per wave instruction, published by stage_dist's barrier
+        const int ndw = dr.tables8_bytes >> 2;
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(dr.tables8);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(near8);
+        for (int c = (threadIdx.x >> 6) * kWave; c < ndw; c += blockDim.x)
+            if (c + lane < ndw) glds4(src + c + lane, dst + c);
+        if constexpr (!LDS_D) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+    const float* D = stage_dist<LDS_D>(dist, N, dl);
     for (int64_t b = wave; b < B; b += nwaves) {
         const int64_t* p = perm + b * N;
         for (int k = lane; k < n; k += kWave) {
@@ -100,8 +133,26 @@ __global__ __launch_bounds__(kTspBlock) void k_tsp_swap_delta_all(const float* _
         }
         __builtin_amdgcn_wave_barrier();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // (a wave owns the tour: its global id and the env key of the generator are scalars)
+        const uint64_t genv = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)(b + dr.env_offset) >> 32)) << 32) |
+                              (uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(b + dr.env_offset));
+        const uint32_t ekey = DRAW ? isco_env_key(dr.seed, genv) : 0u;
         for (int i = lane; i < n; i += kWave) {
-            const int sel = (int)selected[b * N + i];
+            int sel;
+            if constexpr (DRAW) {
+                // env_ISCO.py:246-266 with the draws of rls_isco_tsp_step's iteration 0: streams 3 (coin), 4 (near pick), 5 (far
+                // pick) -- the pick's stream chosen per lane, so a position costs one position key and two draws
+                const int city = P[i];
+                const uint32_t pkey = isco_pos_key(ekey, genv, (uint32_t)i);
+                const bool near = isco_unit(isco_draw_at(pkey, 0u, 3)) < dr.near_threshold;
+                const uint32_t pick = isco_draw_at(pkey, 0u, near ? 4u : 5u);
+                const int r = (int)__umulhi(pick, (uint32_t)(near ? K : NR));
+                if (near) sel = TAB8 ? (int)near8[__umul24(city, K) + r] : dr.nearest[(int64_t)city * K + r];
+                else sel = TAB8 ? (int)rand8[__umul24(city, NR) + r] : dr.random[(int64_t)city * dr.random_stride + r];
+                if (dr.selected_out) dr.selected_out[b * N + i] = sel;
+            } else {
+                sel = (int)selected[b * N + i];
+            }
             const int j = INV[sel];
             const int i0 = (i == 0) ? n - 1 : i - 1;
             const int i1 = (i + 1 == n) ? 0 : i + 1;
@@ -113,7 +164,7 @@ __global__ __launch_bounds__(kTspBlock) void k_tsp_swap_delta_all(const float* _
             const int s_i0 = P[j0], s_i1 = P[j1], s_i = P[j];
             const bool c3 = (s_m1 == s_i0);                                // partner sits at position i+2
             const int nm = P[i], nm1 = s_m1, nm2 = P[i2];
-            auto DD = [&](int a, int c) { return D[(int64_t)a * n + c]; };
+            auto DD = [&](int a, int c) { return D[__umul24(a, n) + c]; };  // (N < 2^24: a full-rate multiply)
             float delta;
             if (banned) {
                 delta = 0.0f;
@@ -355,27 +406,47 @@ int rls_tsp_tour_length(const float* dist, int64_t N, const int64_t* perm, int64
     return check_launch("k_tsp_tour_length");
 }
 
+int64_t rls_tsp_tables8_bytes(int64_t N, int32_t K) {
+    if (N < 3 || N > 256 || K < 1 || K >= N) return 0;
+    return (int64_t)((((size_t)N * K + 15) & ~(size_t)15) + (((size_t)N * (N - K - 1) + 15) & ~(size_t)15));
+}
+
 int rls_tsp_swap_delta_all(const float* dist, int64_t N, const int64_t* perm, int64_t B, const int64_t* selected,
-                           float temperature, float* logratio, int64_t* indices, uint8_t* ban, void* stream) {
+                           const int32_t* nearest, int32_t K, const int32_t* random, int32_t random_stride, const uint8_t* tables8,
+                           float near_threshold, uint64_t seed, int64_t env_offset, int64_t* selected_out, float temperature,
+                           float* logratio, int64_t* indices, uint8_t* ban, void* stream) {
     RLS_REQUIRE(N > 2 && N < (1 << 24) && B >= 0, RLS_EINVAL, "bad sizes N=%lld B=%lld", (long long)N, (long long)B);
     if (B == 0) return RLS_OK;
-    RLS_REQUIRE(dist && perm && selected && logratio && indices && ban, RLS_EINVAL, "NULL pointer");
+    RLS_REQUIRE(dist && perm && logratio && indices && ban, RLS_EINVAL, "NULL pointer");
+    const bool draw = selected == nullptr;
+    if (draw) {
+        RLS_REQUIRE(nearest && random, RLS_EINVAL, "selected == NULL draws the partners in the kernel: nearest / random must be given");
+        RLS_REQUIRE(K >= 1 && K < N && random_stride >= N - K - 1, RLS_EINVAL, "bad neighbour tables K=%d stride=%d N=%lld", K,
+                    random_stride, (long long)N);
+    } else {
+        RLS_REQUIRE(!selected_out, RLS_EINVAL, "selected_out is the in-kernel draw's record: it needs selected == NULL");
+    }
+    const size_t tabs = (draw && tables8 && N <= 256) ? (size_t)rls_tsp_tables8_bytes(N, K) : 0;
+    RLS_REQUIRE(!tables8 || (((uintptr_t)tables8) & 3) == 0, RLS_EINVAL, "tables8 must be 4-byte aligned");
+    const TspDraw dr{nearest, random, K, random_stride, near_threshold, seed, env_offset, selected_out, tables8, (int32_t)tabs};
     const size_t scratch = (size_t)(tsp_block(N) / kWave) * 2 * N * 4;
     RLS_REQUIRE(scratch <= (size_t)kLdsBytes - 1024, RLS_EUNSUPPORTED, "N=%lld too large for the per-wave tour scratch",
                 (long long)N);
     const dim3 grid(tsp_grid(B, tsp_block(N))), block(tsp_block(N));
-    if (dist_fits_lds(N, scratch)) {
-        const size_t lds = (size_t)N * N * 4 + scratch;
-        auto kern = k_tsp_swap_delta_all<true>;
-        if (lds > 64 * 1024) ensure_dyn_lds((const void*)kern, lds);
-        hipLaunchKernelGGL(kern, grid, block, lds, as_stream(stream), dist, N, perm, B, selected, temperature, logratio,
-                           indices, ban);
-    } else {
-        auto kern = k_tsp_swap_delta_all<false>;
-        if (scratch > 64 * 1024) ensure_dyn_lds((const void*)kern, scratch);
-        hipLaunchKernelGGL(kern, grid, block, scratch, as_stream(stream), dist, N, perm, B, selected, temperature,
-                           logratio, indices, ban);
-    }
+    // the neighbour tables as bytes in LDS when the ids fit a byte and they fit beside the matrix and the scratch
+    const bool tab8 = tabs > 0 && dist_fits_lds(N, scratch + tabs);
+    const bool in_lds = dist_fits_lds(N, scratch + (tab8 ? tabs : 0));
+    const size_t lds = (in_lds ? (size_t)N * N * 4 : 0) + scratch + (tab8 ? tabs : 0);
+#define LAUNCH_K13(LD, DRW)                                                                                              \
+    do {                                                                                                                 \
+        auto kern = (DRW && tab8) ? k_tsp_swap_delta_all<LD, DRW, true> : k_tsp_swap_delta_all<LD, DRW, false>;          \
+        if (lds > 64 * 1024) ensure_dyn_lds((const void*)kern, lds);                                                     \
+        hipLaunchKernelGGL(kern, grid, block, lds, as_stream(stream), dist, N, perm, B, selected, dr, temperature, logratio, \
+                           indices, ban);                                                                                \
+    } while (0)
+    if (in_lds) { if (draw) LAUNCH_K13(true, true); else LAUNCH_K13(true, false); }
+    else { if (draw) LAUNCH_K13(false, true); else LAUNCH_K13(false, false); }
+#undef LAUNCH_K13
     return check_launch("k_tsp_swap_delta_all");
 }
 

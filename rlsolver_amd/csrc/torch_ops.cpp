@@ -736,18 +736,45 @@ void tsp_tour_length(const Tensor& dist, const Tensor& perm, Tensor length) {
     ok(rls_tsp_tour_length((const float*)p(dist), perm.size(1), (const int64_t*)p(perm), perm.size(0), (float*)p(length), cur_stream(perm)),
        "rls_tsp_tour_length");
 }
-void tsp_swap_delta_all(const Tensor& dist, const Tensor& perm, const Tensor& selected, double temperature, Tensor logratio, Tensor indices,
-                        Tensor ban) {
+void tsp_swap_delta_all(const Tensor& dist, const Tensor& perm, const OptTensor& selected, const OptTensor& nearest, const OptTensor& random,
+                        const OptTensor& tables8, double near_threshold, int64_t seed, int64_t env_offset, const OptTensor& selected_out, double temperature,
+                        Tensor logratio, Tensor indices, Tensor ban) {
     perm_and_dist(dist, perm, F32);
-    dev(selected, "selected", I64);
+    optdev(selected, "selected", I64);
+    optdev(nearest, "nearest", I32);
+    optdev(random, "random", I32);
+    optdev(selected_out, "selected_out", I64);
     dev(logratio, "logratio", F32);
     dev(indices, "indices", I64);
     spin_bytes(ban, "ban", false);
-    TORCH_CHECK(selected.sizes() == perm.sizes() && logratio.sizes() == perm.sizes() && indices.sizes() == perm.sizes() && ban.sizes() == perm.sizes(),
-                "selected / logratio / indices / ban must have the shape of perm");
+    const int64_t N = perm.size(1);
+    TORCH_CHECK(logratio.sizes() == perm.sizes() && indices.sizes() == perm.sizes() && ban.sizes() == perm.sizes(),
+                "logratio / indices / ban must have the shape of perm");
+    int32_t K = 0, stride = 0;
+    if (selected.has_value()) {
+        TORCH_CHECK(selected->sizes() == perm.sizes(), "selected must have the shape of perm");
+        TORCH_CHECK(!selected_out.has_value(), "selected_out records the in-kernel draw: it needs selected = None");
+    } else {
+        TORCH_CHECK(nearest.has_value() && random.has_value(), "selected = None draws the partners in the kernel: nearest / random must be given");
+        TORCH_CHECK(nearest->dim() == 2 && nearest->size(0) == N && random->dim() == 2 && random->size(0) == N, "nearest / random must be [N, *]");
+        same_device(perm, *nearest, "nearest");
+        same_device(perm, *random, "random");
+        K = (int32_t)nearest->size(1);
+        stride = (int32_t)random->size(1);
+        if (selected_out.has_value()) TORCH_CHECK(selected_out->sizes() == perm.sizes(), "selected_out must have the shape of perm");
+        if (tables8.has_value()) {
+            dev(*tables8, "tables8", at::kByte);
+            same_device(perm, *tables8, "tables8");
+            TORCH_CHECK(tables8->is_contiguous() && tables8->numel() == rls_tsp_tables8_bytes(N, K) && tables8->numel() > 0,
+                        "tables8 must hold rls_tsp_tables8_bytes(N, K) bytes");
+        }
+    }
     RLS_GUARD(perm);
-    ok(rls_tsp_swap_delta_all((const float*)p(dist), perm.size(1), (const int64_t*)p(perm), perm.size(0), (const int64_t*)p(selected),
-                              (float)temperature, (float*)p(logratio), (int64_t*)p(indices), (uint8_t*)p(ban), cur_stream(perm)),
+    ok(rls_tsp_swap_delta_all((const float*)p(dist), N, (const int64_t*)p(perm), perm.size(0), (const int64_t*)p(selected),
+                              (const int32_t*)p(nearest), K, (const int32_t*)p(random), stride, (const uint8_t*)p(tables8),
+                              (float)near_threshold, (uint64_t)seed,
+                              env_offset, (int64_t*)p(selected_out), (float)temperature, (float*)p(logratio), (int64_t*)p(indices),
+                              (uint8_t*)p(ban), cur_stream(perm)),
        "rls_tsp_swap_delta_all");
 }
 void tsp_apply_swap(Tensor perm, const Tensor& pos, const Tensor& indices) {
@@ -919,8 +946,8 @@ TORCH_LIBRARY(rlsolver_hip, m) {
     m.def("qubo_sparse_local_search_value(Tensor rowptr, Tensor col, Tensor val, Tensor xs_in, Tensor(a!) xs_out, int num_ls, bool binary, "
           "Tensor(b!) value) -> ()");
     m.def("tsp_tour_length(Tensor dist, Tensor perm, Tensor(a!) length) -> ()");
-    m.def("tsp_swap_delta_all(Tensor dist, Tensor perm, Tensor selected, float temperature, Tensor(a!) logratio, Tensor(b!) indices, "
-          "Tensor(c!) ban) -> ()");
+    m.def("tsp_swap_delta_all(Tensor dist, Tensor perm, Tensor? selected, Tensor? nearest, Tensor? random, Tensor? tables8, float near_threshold, int seed, "
+          "int env_offset, Tensor(d!)? selected_out, float temperature, Tensor(a!) logratio, Tensor(b!) indices, Tensor(c!) ban) -> ()");
     m.def("tsp_apply_swap(Tensor(a!) perm, Tensor pos, Tensor indices) -> ()");
     m.def("tsp_2opt_delta(Tensor dist, Tensor perm, Tensor i, Tensor j, Tensor(a!) delta) -> ()");
     m.def("tsp_2opt_best(Tensor dist, Tensor perm, Tensor? cur_length, Tensor(a!) best_i, Tensor(b!) best_j, Tensor(c!) best_value) -> ()");

@@ -43,6 +43,7 @@ class ISCO_TSP(Sharded):
         self._rand32 = self.random_indices.to(torch.int32).contiguous()
         # rand < K / (K + 1): the python double is rounded to f32 by the comparison with an f32 tensor
         self._near_thr = float(np.float32(K / (K + 1)))
+        self._tab8 = mops.tsp_tables8(self._near32, self._rand32)          # the byte form opt_2's kernel keeps in LDS (N <= 256)
 
     def step(self, x, path_length, temperature, draws: Optional[dict] = None, want_terms: bool = False):
         """env_ISCO.py:188-201 -> (y int64 [B, N], mean acceptance probability 0-dim f32).
@@ -81,12 +82,17 @@ class ISCO_TSP(Sharded):
         pick_far = torch.randint(0, N - K - 1, (B, N), device=self.device)
         return torch.where(coin, self.nearest_indices[sample, pick_near], self.random_indices[sample, pick_far])
 
-    def opt_2(self, sample, temperature, selected=None):
-        """env_ISCO.py:238-335 -> (-delta/T f32 [B,N], indices int64 [B,N], ban bool [B,N])."""
+    def opt_2(self, sample, temperature, selected=None, return_selected: bool = False):
+        """env_ISCO.py:238-335 -> (-delta/T f32 [B,N], indices int64 [B,N], ban bool [B,N]).  ONE kernel: the partner cities
+        (:245-262) are drawn inside it (the counter-based generator of ``step``, keyed by this object's seed stream and the
+        GLOBAL tour id) -- ``selected`` (int64 [B,N] partner cities, e.g. from ``draw_partners``: torch's generator, the
+        reference's three draws) replaces the draw; ``return_selected`` appends what the kernel drew."""
         sample = sample.contiguous()
-        if selected is None:
-            selected = self.draw_partners(sample)
-        return mops.tsp_swap_delta_all(self.distance, sample, selected.contiguous(), float(temperature))
+        if selected is not None:
+            return mops.tsp_swap_delta_all(self.distance, sample, selected.contiguous(), float(temperature))
+        return mops.tsp_swap_delta_all(self.distance, sample, None, float(temperature), nearest=self._near32, random=self._rand32,
+                                       near_threshold=self._near_thr, seed=self._next_seed(), env_offset=self.env_offset,
+                                       return_selected=return_selected, tables8=self._tab8)
 
     def switch(self, sample, swap_env_mask, swap_sample_mask, indices):
         """env_ISCO.py:337-344 (at most one position per env, as proposal() produces)."""

@@ -250,16 +250,50 @@ def tsp_tour_length(dist: TEN, perm: TEN) -> TEN:
     return out
 
 
-def tsp_swap_delta_all(dist: TEN, perm: TEN, selected: TEN, temperature: float):
+def tsp_tables8(nearest: TEN, random: TEN) -> Optional[TEN]:
+    """The two neighbour tables of ISCO_TSP as the byte block K13 keeps in LDS (include/rlsolver_hip.h: rls_tsp_tables8_bytes):
+    uint8 [N, K] then the first N - K - 1 columns of ``random`` as uint8, each zero-padded to 16 bytes; None when N > 256."""
+    from . import _abi
+    N, K = int(nearest.shape[0]), int(nearest.shape[1])
+    nb = int(_abi.lib().rls_tsp_tables8_bytes(N, K))
+    if nb == 0:
+        return None
+    out = torch.zeros(nb, dtype=torch.uint8, device=nearest.device)
+    a = (N * K + 15) // 16 * 16
+    out[:N * K] = nearest.reshape(-1).to(torch.uint8)
+    out[a:a + N * (N - K - 1)] = random[:, :N - K - 1].reshape(-1).to(torch.uint8)
+    return out
+
+
+def tsp_swap_delta_all(dist: TEN, perm: TEN, selected: Optional[TEN], temperature: float, nearest: Optional[TEN] = None,
+                       random: Optional[TEN] = None, near_threshold: float = 0.0, seed: int = 0, env_offset: int = 0,
+                       return_selected: bool = False, tables8: Optional[TEN] = None):
+    """K13, ISCO_TSP.opt_2 (env_ISCO.py:238-335) -> (logratio f32, indices int64, ban bool), all [B, N].
+    ``selected`` int64 [B, N]: the partner cities, given (the recorded-draw hook of the golden tests); None (production): drawn
+    in the kernel from (seed, env_offset + b, position) through ``nearest`` int32 [N, K] / ``random`` int32 [N, >= N - K - 1]
+    with ``near_threshold`` = K / (K + 1) -- ``return_selected`` appends the drawn cities (int64 [B, N]); ``tables8`` =
+    ``tsp_tables8(nearest, random)``, built once by the caller, lets the kernel keep both tables in LDS (N <= 256)."""
     B, N = _perm(perm)
     dev = perm.device
     _check(dist, "dist", (torch.float32,), dev, (N, N))
-    _check(selected, "selected", (torch.int64,), dev, (B, N))
+    sel_out = None
+    if selected is not None:
+        _check(selected, "selected", (torch.int64,), dev, (B, N))
+        if return_selected:
+            raise ValueError("return_selected records the in-kernel draw: it needs selected=None")
+    else:
+        if nearest is None or random is None:
+            raise ValueError("selected=None draws the partners in the kernel: nearest / random tables must be given")
+        _check(nearest, "nearest", (torch.int32,), dev)
+        _check(random, "random", (torch.int32,), dev)
+        if return_selected:
+            sel_out = torch.empty((B, N), dtype=torch.int64, device=dev)
     logratio = torch.empty((B, N), dtype=torch.float32, device=dev)
     indices = torch.empty((B, N), dtype=torch.int64, device=dev)
     ban = torch.empty((B, N), dtype=torch.bool, device=dev)
-    _t.tsp_swap_delta_all(dist, perm, selected, float(temperature), logratio, indices, ban)
-    return logratio, indices, ban
+    _t.tsp_swap_delta_all(dist, perm, selected, nearest, random, tables8, float(near_threshold), _s64(seed), int(env_offset), sel_out,
+                          float(temperature), logratio, indices, ban)
+    return (logratio, indices, ban, sel_out) if return_selected else (logratio, indices, ban)
 
 
 def tsp_apply_swap(perm: TEN, pos: TEN, indices: TEN) -> None:

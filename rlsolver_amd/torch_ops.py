@@ -60,7 +60,7 @@ DEVICE_ENTRY_POINTS = [
 # declared in the header but not device work: host-side schedule builders and queries (plain C calls, no op)
 HOST_ENTRY_POINTS = [
     "version", "last_error_string", "device_count", "graph_sweep_schedule", "graph_sweep_levels", "graph_ell", "graph_sweep_batches",
-    "mcpg_visit_levels", "maxcut_local_search_supported", "mcpg_local_search_levels_supported", "maxcut_ls_rounds_supported", "maxcut_ls_scratch_bytes", "maxcut_ls_slices", "maxcut_node_stats_form", "mcpg_metro_max_rounds", "mcpg_metro_scratch_bytes", "isco_maxcut_scratch_bytes",
+    "mcpg_visit_levels", "maxcut_local_search_supported", "mcpg_local_search_levels_supported", "maxcut_ls_rounds_supported", "maxcut_ls_scratch_bytes", "maxcut_ls_slices", "maxcut_node_stats_form", "mcpg_metro_max_rounds", "mcpg_metro_scratch_bytes", "isco_maxcut_scratch_bytes", "tsp_tables8_bytes",
     "tuning_set", "tuning_unset", "tuning_get", "tuning_name",
 ]
 

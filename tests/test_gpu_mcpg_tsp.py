@@ -188,6 +188,88 @@ def test_tsp_golden(golden, name):
                                atol=1e-5 * float(z[f"{name}/length_f32"].max()))
 
 
+def _isco_draw_np(seed, env, a, b, stream):
+    """The counter-based generator of the ISCO kernels (csrc/rls_draw.h: five murmur3 finalisers over seed, global env id, two
+    counters and a stream id) restated in numpy -- the SPEC the in-kernel partner draw of K13 is held to."""
+    M = np.uint64(0xFFFFFFFF)
+
+    def mix(h):
+        h = h ^ (h >> np.uint64(16)); h = (h * np.uint64(0x85EBCA6B)) & M
+        h = h ^ (h >> np.uint64(13)); h = (h * np.uint64(0xC2B2AE35)) & M
+        return h ^ (h >> np.uint64(16))
+    seed, env = np.uint64(seed), np.asarray(env, dtype=np.uint64)
+    a = np.asarray(a, dtype=np.uint64)
+    h = mix((seed & M) ^ np.uint64(0x9E3779B9))
+    h = mix(h ^ (seed >> np.uint64(32)))
+    h = mix(h ^ (env & M))
+    h = mix(h ^ (env >> np.uint64(32)) ^ ((a * np.uint64(0x9E3779B1)) & M))
+    return mix(h ^ np.uint64((b * 0x85EBCA77) & 0xFFFFFFFF) ^ np.uint64((stream * 0xC2B2AE3D) & 0xFFFFFFFF))
+
+
+@pytest.mark.parametrize("N,B,K", [(100, 1000, 20), (52, 130, 20), (7, 64, 3), (200, 70, 20)])
+def test_tsp_opt_2_draws_its_partners_in_the_kernel(N, B, K):
+    """K13 as the reference runs it (env_ISCO.py:245-262 draws inside opt_2): selected = None.  The drawn cities are exactly
+    what the generator's numpy restatement predicts (streams 3 / 4 / 5 of iteration 0 -- the fused step's counters), always
+    from the position's own neighbour tables; feeding them back through the recorded-draw hook reproduces every output bit
+    for bit and the numpy oracle agrees; a shard of the batch under its env_offset draws what the whole batch draws."""
+    from rlsolver_amd.graph import generate_tsp_coords, tsp_tables
+    dist, near, rnd = tsp_tables(generate_tsp_coords(N, seed=N), K=K)
+    d, near32, rnd32 = dev(dist), dev(near.astype(np.int32)), dev(rnd.astype(np.int32))
+    thr = float(np.float32(K / (K + 1)))
+    perms = mops.rand_perms(B, N, seed=3, device=DEV)
+    pn = perms.cpu().numpy()
+    seed, off = 0x1234567ABCDEF, 7000
+    lr, idx, ban, sel = mops.tsp_swap_delta_all(d, perms, None, 0.5, nearest=near32, random=rnd32, near_threshold=thr, seed=seed,
+                                                env_offset=off, return_selected=True)
+    env = (np.arange(B, dtype=np.uint64) + np.uint64(off))[:, None]
+    pos = np.arange(N, dtype=np.uint64)[None, :]
+    up = (_isco_draw_np(seed, env, pos, 0, 3) >> np.uint64(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    rn = ((_isco_draw_np(seed, env, pos, 0, 4) * np.uint64(K)) >> np.uint64(32)).astype(np.int64)
+    rr = ((_isco_draw_np(seed, env, pos, 0, 5) * np.uint64(N - K - 1)) >> np.uint64(32)).astype(np.int64)
+    want = np.where(up < np.float32(thr), near[pn, rn], rnd[pn, np.minimum(rr, rnd.shape[1] - 1)])
+    assert np.array_equal(sel.cpu().numpy(), want)
+    assert (sel.cpu().numpy() != pn).all()                                    # never the position's own city
+    lr2, idx2, ban2 = mops.tsp_swap_delta_all(d, perms, sel, 0.5)
+    assert torch.equal(lr, lr2) and torch.equal(idx, idx2) and torch.equal(ban, ban2)
+    lr_w, idx_w, ban_w = onp.tsp_swap_delta_all(dist, pn, want, 0.5)
+    assert np.array_equal(idx.cpu().numpy(), idx_w) and np.array_equal(ban.cpu().numpy(), ban_w)
+    length = onp.tsp_tour_length_f64(dist, pn)
+    np.testing.assert_allclose(lr.cpu().numpy(), lr_w, rtol=1e-5, atol=1e-5 * length.max() / 0.5)
+    # the byte form of the tables (kept in LDS by the kernel) draws the same partners as the int32 tables read from memory
+    tab8 = mops.tsp_tables8(near32, rnd32)
+    assert tab8 is not None and tab8.dtype == torch.uint8
+    lr8, idx8, ban8, sel8 = mops.tsp_swap_delta_all(d, perms, None, 0.5, nearest=near32, random=rnd32, near_threshold=thr, seed=seed,
+                                                    env_offset=off, return_selected=True, tables8=tab8)
+    assert torch.equal(sel8, sel) and torch.equal(lr8, lr) and torch.equal(idx8, idx) and torch.equal(ban8, ban)
+    h = B // 2
+    lr_h, idx_h, ban_h = mops.tsp_swap_delta_all(d, perms[h:].contiguous(), None, 0.5, nearest=near32, random=rnd32, near_threshold=thr,
+                                                 seed=seed, env_offset=off + h, tables8=tab8)
+    assert torch.equal(lr_h, lr[h:]) and torch.equal(idx_h, idx[h:]) and torch.equal(ban_h, ban[h:])
+    with pytest.raises((ValueError, RuntimeError)):
+        mops.tsp_swap_delta_all(d, perms, None, 0.5)                          # no tables, nothing to draw from
+
+
+def test_isco_tsp_class_opt_2_is_one_kernel_with_its_own_draws():
+    """ISCO_TSP.opt_2(sample, T) -- the reference's signature -- draws inside the kernel from the object's seed stream; the
+    near / far split is K / (K + 1) and `draw_partners` + selected= stays as the torch-generator form."""
+    from rlsolver_amd.envs.env_ISCO import ISCO_TSP
+    from rlsolver_amd.graph import generate_tsp_coords, tsp_tables
+    dist, near, rnd = tsp_tables(generate_tsp_coords(60, seed=2), K=10)
+    params = {"num_nodes": 60, "distance": dev(dist), "nearest_indices": dev(near), "random_indices": dev(rnd)}
+    env = ISCO_TSP(params, batch_size=4096, device=DEV, K=10, seed=5)
+    x = env.random_gen_init_sample()
+    lr, idx, ban, sel = env.opt_2(x, 0.7, return_selected=True)
+    near_hit = (env.nearest_indices[x] == sel[:, :, None]).any(dim=2).float().mean().item()
+    # (the far branch picks among the first N - K - 1 of all other cities, which may be one of the K nearest too)
+    want = 10 / 11 + (1 / 11) * (env.nearest_indices[:, :, None] == env.random_indices[:, None, :60 - 10 - 1]).any(dim=2).float().sum(dim=1).mean().item() / (60 - 10 - 1)
+    assert abs(near_hit - want) < 5e-3
+    lr_b, idx_b, ban_b = env.opt_2(x, 0.7)                                     # the next seed of the stream: other partners
+    assert not torch.equal(idx, idx_b)
+    s2 = env.draw_partners(x)
+    lr_c, idx_c, ban_c = env.opt_2(x, 0.7, selected=s2)
+    assert torch.equal(torch.gather(x, 1, idx_c), s2)                          # indices = where the partner city sits
+
+
 @pytest.mark.parametrize("N,B", [(100, 1000), (52, 65), (200, 130), (7, 64), (256, 70), (300, 50)])
 def test_tsp_random_properties(N, B):
     from rlsolver_amd.graph import generate_tsp_coords, tsp_tables

@@ -201,9 +201,14 @@ def tsp_suite(tag, N, B, iters):
     emit(tag, "K14 rand_perms", "tours", B, t, 8 * N, "bytes = the int64 [B, N] result")
     t = timeit(lambda i: mops.tsp_tour_length(d, perms), iters)
     emit(tag, "K12 tsp_tour_length", "tours", B, t, 8 * N + 4)
+    K = near.shape[1]
+    near32, rnd32 = torch.from_numpy(near.astype("int32")).to(dev), torch.from_numpy(rnd.astype("int32")).to(dev)
+    tab8 = mops.tsp_tables8(near32, rnd32)
+    t = timeit(lambda i: mops.tsp_swap_delta_all(d, perms, None, 0.5, nearest=near32, random=rnd32, near_threshold=K / (K + 1), seed=i, tables8=tab8), iters)
+    emit(tag, "K13 tsp_swap_delta_all", "envs (N candidate moves each)", B, t, 8 * N + 13 * N, "partners drawn in the kernel (SURVEY 8d: 21N)")
     sel = torch.roll(perms, 7, 1).contiguous()
-    t = timeit(lambda i: mops.tsp_swap_delta_all(d, perms, sel, 0.5), iters)
-    emit(tag, "K13 tsp_swap_delta_all", "envs (N candidate moves each)", B, t, 8 * N + 8 * N + 13 * N)
+    t = timeit(lambda i: mops.tsp_swap_delta_all(d, perms, sel, 0.5), max(3, iters // 2))
+    emit(tag, "K13 tsp_swap_delta_all, selected given", "envs (N candidate moves each)", B, t, 8 * N + 8 * N + 13 * N, "the recorded-draw hook: + 8N in")
 
 
 def isco_suite(iters):
