@@ -556,15 +556,16 @@ def b64_bool_to_str(x_bool, encode_len: int) -> str:
 
 
 def rand_perms(B, N, seed, env_offset=0):
-    """K14 (TSP) definition: Fisher-Yates with Philox draws keyed by (seed, global env id, k):
-    p = identity; for k = N-1..1: j = (r0 * (k+1)) >> 32; swap(p[k], p[j]).  Build-defined (the
+    """K14 (TSP) definition: Fisher-Yates with Philox draws keyed by (seed, global env id, k >> 2), swap k taking word k & 3 of
+    the call's four (round 6: one call per FOUR swaps -- the kernel spent its time in ten Philox rounds per swap):
+    p = identity; for k = N-1..1: j = (r[k & 3] * (k+1)) >> 32; swap(p[k], p[j]).  Build-defined (the
     reference stacks torch.randperm calls, env_ISCO.py:352-354)."""
     gb = np.arange(B, dtype=np.uint64) + np.uint64(env_offset)
     p = np.tile(np.arange(N, dtype=np.int64), (B, 1))
     rows = np.arange(B)
     for k in range(N - 1, 0, -1):
         r0 = philox4x32_10(seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF, gb & np.uint64(0xFFFFFFFF),
-                           gb >> np.uint64(32), np.uint64(k) + np.zeros_like(gb), np.uint64(0x5045524D))[0]
+                           gb >> np.uint64(32), np.uint64(k >> 2) + np.zeros_like(gb), np.uint64(0x5045524D))[k & 3]
         j = ((r0 * np.uint64(k + 1)) >> np.uint64(32)).astype(np.int64)
         tk = p[rows, k].copy()
         p[rows, k] = p[rows, j]

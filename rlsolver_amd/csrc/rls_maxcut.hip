@@ -1283,6 +1283,72 @@ __global__ __launch_bounds__(256) void k_rand_spins_rows(uint8_t* __restrict__ x
     }
 }
 
+// The same spins, RP ROWS per wave pass (round 6): the row-per-wave kernel above runs its Philox call on `blocks` of 64 lanes (16
+// at G22's 2000 nodes, 79 = 64 + 15 at G70's 10^4: its time was ten Philox rounds at a quarter / 62 % of the lanes, 0.60-0.66 of
+// HBM where plain stores reach 0.84).  The RP * blocks Philox calls of a pass are dealt over the lanes as one list (RP = 64 /
+// blocks for short rows, up to 4 rows of long ones: 316 calls in 5 full wave passes at N = 10^4); the RP rows are ONE contiguous
+// run of RP * N bytes, written as 16 / 8 / 4-byte pieces c = 64 k + lane of that run -- whole 1 KB wave stores that do not care
+// where a row ends.  Plain stores: G22 / 2^16 21.0 us vs 23.0 nontemporal (a fresh batch is the next kernel's input).
+constexpr int kSpinMaxBlk = 320;     // 128-spin blocks a wave pass may hold (5 KB of LDS per wave)
+template <int CH>
+__global__ __launch_bounds__(256) void k_rand_spins_multi(uint8_t* __restrict__ x, int64_t B, int64_t N, uint64_t seed, int64_t env_offset,
+                                                          const uint64_t* __restrict__ repeat_seeds, int64_t S, int nb, int RP) {
+    __shared__ uint32_t sh[4][kSpinMaxBlk * 4];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = threadIdx.x / kWave;
+    const int cpr = (int)(N / CH);                  // pieces per row (N % CH == 0 here)
+    // (row, block) of lane l's first Philox call and (row, piece) of its first store, and how both move per 64 lanes
+    const int br_first = lane / nb, bk_first = lane - br_first * nb, bq = kWave / nb, brem = kWave - bq * nb;
+    const int r_first = lane / cpr, p_first = lane - r_first * cpr, q = kWave / cpr, rem = kWave - q * cpr;
+    const int64_t npass = (B + RP - 1) / RP;
+    for (int64_t ps = (int64_t)blockIdx.x * 4 + w; ps < npass; ps += (int64_t)gridDim.x * 4) {
+        const int64_t b0 = ps * RP;
+        const int nr = (int)((B - b0) < RP ? (B - b0) : RP);
+        {
+            int br = br_first, bk = bk_first;
+            for (int blk = lane; blk < nr * nb; blk += kWave) {
+                const int64_t b = b0 + br;
+                const int64_t rep = repeat_seeds ? b / S : 0;
+                const Philox ph(repeat_seeds ? repeat_seeds[rep] : seed);
+                const uint64_t gb = (uint64_t)(b - rep * S + env_offset);
+                uint32_t r[4];
+                ph((uint32_t)gb, (uint32_t)(gb >> 32), (uint32_t)bk, 0x5350494Eu, r);
+                if (bk == 0) r[0] &= ~1u;           // xs[:, 0] = 0, env_L2A.py:84
+                *reinterpret_cast<uint4*>(&sh[w][blk * 4]) = make_uint4(r[0], r[1], r[2], r[3]);
+                br += bq; bk += brem;
+                if (bk >= nb) { bk -= nb; ++br; }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        uint8_t* run = x + b0 * N;
+        const int total = nr * cpr;
+        int rr = r_first, p = p_first;
+        for (int c = lane; c < total; c += kWave) {
+            const int bit = p * CH;                 // first spin of the piece within its row
+            const uint32_t bits = (sh[w][(rr * nb + (bit >> 7)) * 4 + ((bit >> 5) & 3)] >> (bit & 31)) & ((1u << CH) - 1u);
+            // nibble -> 4 bytes of 0/1: the multiply puts bit j at bit 8j (+ copies the mask drops); 24-bit operands: a full-rate multiply
+            const uint32_t v0 = __umul24(bits & 0xFu, 0x00204081u) & 0x01010101u;
+            if constexpr (CH == 4) {
+                *reinterpret_cast<uint32_t*>(run + (int64_t)c * 4) = v0;
+            } else {
+                const uint32_t v1 = __umul24((bits >> 4) & 0xFu, 0x00204081u) & 0x01010101u;
+                if constexpr (CH == 8) {
+                    *reinterpret_cast<uint2*>(run + (int64_t)c * 8) = make_uint2(v0, v1);
+                } else {
+                    const uint32_t v2 = __umul24((bits >> 8) & 0xFu, 0x00204081u) & 0x01010101u;
+                    const uint32_t v3 = __umul24((bits >> 12) & 0xFu, 0x00204081u) & 0x01010101u;
+                    *reinterpret_cast<uint4*>(run + (int64_t)c * 16) = make_uint4(v0, v1, v2, v3);
+                }
+            }
+            rr += q; p += rem;
+            while (p >= cpr) { p -= cpr; ++rr; }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 __global__ void k_rand_actions(int64_t* __restrict__ action, int64_t B, int64_t N, uint64_t seed, uint64_t step,
                                int64_t env_offset) {
     const Philox ph(seed);
@@ -2093,6 +2159,25 @@ int rls_pick_best_of_repeats(const uint8_t* xs, const int64_t* vs, int64_t R, in
 static int rand_spins_launch(uint8_t* x, int64_t B, int64_t N, uint64_t seed, int64_t env_offset, const uint64_t* repeat_seeds, int64_t S,
                              void* stream) {
     const bool vec16 = (N % 16 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0);
+    if (N >= 128 && (N & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && ((N + 127) >> 7) <= kSpinMaxBlk) {
+        // several rows per wave pass, every lane draws blocks (k_rand_spins_multi): RP = as many rows as fill one wave of calls
+        // (short rows), else the 1..4 rows that leave the fewest idle lanes in the last wave of calls
+        const int nb = (int)((N + 127) >> 7);
+        int RP = nb <= kWave ? kWave / nb : 1;
+        if (nb > kWave) {
+            double best = 2.0;
+            for (int r = 1; r <= 4 && r * nb <= kSpinMaxBlk; ++r) {
+                const double waste = (double)(ceil_div((int64_t)r * nb, kWave) * kWave) / (double)(r * nb);
+                if (waste < best - 1e-9) { best = waste; RP = r; }
+            }
+        }
+        const int ch = (N & 15) == 0 ? 16 : ((N & 7) == 0 ? 8 : 4);      // (pieces are cut on the run of RP rows: RP * N is a multiple too)
+        const dim3 grid(grid_for(ceil_div(B, (int64_t)RP) * kWave, 256)), block(256);
+        if (ch == 16) hipLaunchKernelGGL(k_rand_spins_multi<16>, grid, block, 0, as_stream(stream), x, B, N, seed, env_offset, repeat_seeds, S, nb, RP);
+        else if (ch == 8) hipLaunchKernelGGL(k_rand_spins_multi<8>, grid, block, 0, as_stream(stream), x, B, N, seed, env_offset, repeat_seeds, S, nb, RP);
+        else hipLaunchKernelGGL(k_rand_spins_multi<4>, grid, block, 0, as_stream(stream), x, B, N, seed, env_offset, repeat_seeds, S, nb, RP);
+        return check_launch("k_rand_spins_multi");
+    }
     if (N >= 512 && (N & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
         // rows of at least four 128-spin blocks, 4-byte aligned: one Philox call per block (a wave per row)
         const dim3 grid(grid_for(B * kWave, 256)), block(256);

@@ -209,8 +209,8 @@ __global__ void k_tsp_2opt_delta(const float* __restrict__ dist, int64_t N, cons
     delta[b] = (dist[a * N + d] + dist[c * N + e]) - (dist[a * N + c] + dist[d * N + e]);
 }
 
-// Fisher-Yates with Philox draws keyed by (seed, global env id, k): p = identity; for k = N-1..1:
-// j = (r * (k+1)) >> 32; swap(p[k], p[j]).
+// Fisher-Yates with Philox draws keyed by (seed, global env id, k >> 2), swap k taking word k & 3 of the call's four:
+// p = identity; for k = N-1..1: j = (r[k & 3] * (k+1)) >> 32; swap(p[k], p[j]).
 __global__ void k_rand_perms(int64_t* __restrict__ perm, int64_t B, int64_t N, uint64_t seed, int64_t env_offset) {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
@@ -218,10 +218,10 @@ __global__ void k_rand_perms(int64_t* __restrict__ perm, int64_t B, int64_t N, u
     for (int64_t k = 0; k < N; ++k) p[k] = k;
     const Philox ph(seed);
     const uint64_t gb = (uint64_t)(b + env_offset);
+    uint32_t r[4] = {0, 0, 0, 0};
     for (int64_t k = N - 1; k >= 1; --k) {
-        uint32_t r[4];
-        ph((uint32_t)gb, (uint32_t)(gb >> 32), (uint32_t)k, 0x5045524Du, r);
-        const int64_t j = (int64_t)(((uint64_t)r[0] * (uint64_t)(k + 1)) >> 32);
+        if (k == N - 1 || (k & 3) == 3) ph((uint32_t)gb, (uint32_t)(gb >> 32), (uint32_t)(k >> 2), 0x5045524Du, r);
+        const int64_t j = (int64_t)(((uint64_t)r[k & 3] * (uint64_t)(k + 1)) >> 32);
         const int64_t t = p[k];
         p[k] = p[j];
         p[j] = t;
@@ -242,16 +242,42 @@ __global__ __launch_bounds__(kWave) void k_rand_perms_lds(int64_t* __restrict__ 
     for (int64_t k = 0; k < N; ++k) p[k * kPermStride + lane] = (uint16_t)k;
     const Philox ph(seed);
     const uint64_t gb = (uint64_t)(b + env_offset);
-    for (int64_t k = N - 1; k >= 1; --k) {
-        uint32_t r[4];
-        ph((uint32_t)gb, (uint32_t)(gb >> 32), (uint32_t)k, 0x5045524Du, r);
-        const int64_t j = (int64_t)(((uint64_t)r[0] * (uint64_t)(k + 1)) >> 32);
-        const uint16_t t = p[k * kPermStride + lane];
-        p[k * kPermStride + lane] = p[j * kPermStride + lane];
-        p[j * kPermStride + lane] = t;
+    // the swaps in groups of four under one Philox call (word k & 3 of call k >> 2): the topmost group may be partial
+    // (two calls at a time: with one wave per SIMD at 2^16 tours the ten dependent rounds of a single call leave the VALU idle
+    // between issues; two independent chains interleave)
+    for (int64_t k4 = (N - 1) >> 2; k4 >= 0; k4 -= 2) {
+        uint32_t r[8];
+        ph((uint32_t)gb, (uint32_t)(gb >> 32), (uint32_t)k4, 0x5045524Du, r + 4);
+        ph((uint32_t)gb, (uint32_t)(gb >> 32), (uint32_t)(k4 >= 1 ? k4 - 1 : 0), 0x5045524Du, r);
+#pragma unroll
+        for (int q = 7; q >= 0; --q) {
+            const int64_t k = (k4 - 1) * 4 + q;
+            if (k >= 1 && k <= N - 1) {
+                const int64_t j = (int64_t)__umulhi(r[q], (uint32_t)(k + 1));
+                const uint16_t t = p[k * kPermStride + lane];
+                p[k * kPermStride + lane] = p[j * kPermStride + lane];
+                p[j * kPermStride + lane] = t;
+            }
+        }
     }
     __syncthreads();
     const int64_t nb = (B - b0 < kWave) ? B - b0 : kWave;
+    if ((N & 1) == 0 && (reinterpret_cast<uintptr_t>(perm) & 15) == 0) {
+        // the nb rows are one contiguous run of nb * N int64: 16-byte pieces (two positions of one tour) c = 64 trip + lane of that
+        // run, 1 KB per wave store, nontemporal
+        typedef int64_t i64x2 __attribute__((ext_vector_type(2)));
+        i64x2* run = reinterpret_cast<i64x2*>(perm + b0 * N);
+        const int half = (int)(N >> 1), total = (int)nb * half;
+        const int q = kWave / half, rem = kWave - q * half;
+        int e = lane / half, h = lane - e * half;
+        for (int c = lane; c < total; c += kWave) {
+            const int64_t k = 2 * h;
+            __builtin_nontemporal_store(i64x2{(int64_t)p[k * kPermStride + e], (int64_t)p[(k + 1) * kPermStride + e]}, run + c);
+            e += q; h += rem;
+            if (h >= half) { h -= half; ++e; }
+        }
+        return;
+    }
     for (int64_t e = 0; e < nb; ++e) {
         int64_t* row = perm + (b0 + e) * N;
         for (int64_t k = lane; k < N; k += kWave) row[k] = (int64_t)p[k * kPermStride + e];
