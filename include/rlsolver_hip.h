@@ -663,8 +663,12 @@ int rls_qubo_local_search_value(const float* Q, int64_t n, const float* xs_in, f
 
 /* K11, sparse form: the same coordinate search and value with Q in CSR form -- rowptr int32
  * [n+1], col int32 [nnz], val f32 [nnz], the diagonal stored as ordinary entries; step i costs O(nnz_i), not O(n).
- * Same arguments and outputs otherwise; same exactness condition (integer-valued Q). */
+ * Same arguments and outputs otherwise; same exactness condition (integer-valued Q).
+ * ABI v12: lv_ptr int32 [num_levels + 1] / lv_rows int32 [n] (both NULL = none): the rows grouped by level(i) = 1 + max level of
+ * the neighbours j < i (rows in ascending order within a level) -- rows of one level share no entry, so the waves of a
+ * workgroup sweep them side by side and the result is the sequential sweep's; without them one wave walks the rows in order. */
 int rls_qubo_sparse_local_search_value(const int32_t* rowptr, const int32_t* col, const float* val, int64_t n,
+                                       const int32_t* lv_ptr, const int32_t* lv_rows, int32_t num_levels,
                                        const float* xs_in, float* xs_out, int64_t C, int64_t num_ls, int binary,
                                        float* value, void* stream);
 

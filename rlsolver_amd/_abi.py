@@ -113,7 +113,7 @@ SIGNATURES = {
     "rls_mcpg_pack_chains": [_P, _INT, _I64, _I64, _P, _P],
     "rls_mcpg_unpack_chains": [_P, _I64, _I64, _P, _P],
     "rls_qubo_local_search_value": [_P, _I64, _P, _P, _I64, _I64, _INT, _P, _P],
-    "rls_qubo_sparse_local_search_value": [_P, _P, _P, _I64, _P, _P, _I64, _I64, _INT, _P, _P],
+    "rls_qubo_sparse_local_search_value": [_P, _P, _P, _I64, _P, _P, C.c_int32, _P, _P, _I64, _I64, _INT, _P, _P],
     "rls_tsp_tour_length": [_P, _I64, _P, _I64, _P, _P],
     "rls_tsp_swap_delta_all": [_P, _I64, _P, _I64, _P, _P, C.c_int32, _P, C.c_int32, _P, _F32, C.c_uint64, _I64, _P, _F32, _P, _P, _P, _P],
     "rls_tsp_apply_swap": [_P, _I64, _I64, _P, _P, _P],

@@ -363,6 +363,139 @@ __global__ __launch_bounds__(kWave) void k_qubo_sparse_ls_value(const int32_t* _
     }
 }
 
+// Sparse QUBO by LEVELS (round 6).  The kernel above is one wave per 64 chains walking the n rows in order: 2^13 chains are
+// 128 waves on a 1024-SIMD chip, 0.38 us per row -- 2.5 x slower than the dense MFMA kernel on a 2 %-filled 1000 x 1000 Q.  Row i
+// needs the NEW bits of its neighbours j < i and the OLD bits of its neighbours j > i, so with level(i) = 1 + max level of the
+// neighbours below i (host: MCPG_qubo.qubo_levels) the rows of one level have no entry between them and every neighbour above
+// a row sits in a later level: the W waves of a 64-chain workgroup take a level's rows side by side, one barrier per level, and
+// the result is the sequential sweep's bit for bit (the sums are order-independent for integer-valued Q, as everywhere in K11).
+// (Measured and not kept: the schedule and row bounds staged in LDS + the next level's first row requested before the barrier --
+// 487 -> 539 us at n = 1000, 2 % fill, 2^13 chains: the scalar cache already holds them, the time is the dependent VALU chain of a
+// row with one wave per SIMD.)
+template <bool BIN, int W>
+__global__ __launch_bounds__(W * kWave) void k_qubo_sparse_levels(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                                  const float* __restrict__ val, int64_t n,
+                                                                  const int32_t* __restrict__ lv_ptr, const int32_t* __restrict__ lv_rows,
+                                                                  int32_t L, const float* __restrict__ xs_in, float* __restrict__ xs_out,
+                                                                  int64_t C, int64_t num_ls, float* __restrict__ value) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint64_t* words = reinterpret_cast<uint64_t*>(smem);
+    const uint32_t* w32 = reinterpret_cast<const uint32_t*>(smem);
+    float* part = reinterpret_cast<float*>(words + n);           // [W][64]
+    const int lane = threadIdx.x & (kWave - 1);
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    const int64_t c0 = (int64_t)blockIdx.x * kWave;
+    const int64_t c = c0 + lane;
+    const bool valid = c < C;
+    const int half = lane >> 5, sh = lane & 31, half4 = half * 4;
+    // the tile: wave w turns rows 8 (w + W t) .. + 7 into words, 8 loads in flight
+    for (int64_t j0 = (int64_t)w * 8; j0 < n; j0 += (int64_t)W * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = (valid && j0 + u < n) ? xs_in[(j0 + u) * C + c] : 0.0f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint64_t wd = ballot64(v[u] > 0.0f);
+            if (lane == 0 && j0 + u < n) words[j0 + u] = wd;
+        }
+    }
+    __syncthreads();
+    struct Row { int i, r0, r1, mc; float mv; };
+    auto fetch = [&](int i) -> Row {                             // i is wave-uniform: scalar loads of the row's bounds
+        Row rw;
+        rw.i = i;
+        rw.r0 = rowptr[i];
+        rw.r1 = rowptr[i + 1];
+        const bool in = lane < rw.r1 - rw.r0;
+        rw.mc = in ? col[rw.r0 + lane] : 0;
+        rw.mv = in ? val[rw.r0 + lane] : 0.0f;
+        return rw;
+    };
+    // one chunk of <= 64 entries (entry k in lane k): the sequential kernel's chunk_sum
+    auto chunk_sum = [&](int mc, float mv, int cnt, int i, bool skip_diag, float& ones, float& all, float& diag) {
+        uint64_t dm = ballot64(lane < cnt && mc == i);
+        while (dm) {
+            const int l = __builtin_ctzll(dm);
+            diag += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mv), l));
+            dm &= dm - 1;
+        }
+        if (skip_diag && mc == i) mv = 0.0f;
+        const int off = mc * 8;
+        for (int k = 0; k < cnt; k += 8) {
+            float q[8];
+            uint32_t wv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int jo = __builtin_amdgcn_readlane(off, k + u);
+                q[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mv), k + u));
+                wv[u] = *reinterpret_cast<const uint32_t*>(smem + (uint32_t)(jo + half4));
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int m = __builtin_amdgcn_sbfe((int)wv[u], sh, 1);       // 0 or -1
+                ones += __builtin_bit_cast(float, __builtin_bit_cast(int, q[u]) & m);
+                all += q[u];
+            }
+        }
+    };
+    auto row = [&](const Row& rw, bool skip_diag, float& diag) -> float {
+        float ones = 0.0f, all = 0.0f;
+        diag = 0.0f;
+        const int deg = rw.r1 - rw.r0;
+        chunk_sum(rw.mc, rw.mv, deg < kWave ? deg : kWave, rw.i, skip_diag, ones, all, diag);
+        for (int base = rw.r0 + kWave; base < rw.r1; base += kWave) {
+            const int here = (rw.r1 - base) < kWave ? (rw.r1 - base) : kWave;
+            const int mc = lane < here ? col[base + lane] : 0;
+            const float mv = lane < here ? val[base + lane] : 0.0f;
+            chunk_sum(mc, mv, here, rw.i, skip_diag, ones, all, diag);
+        }
+        return BIN ? ones : (2.0f * ones - all);
+    };
+    for (int64_t cnt = 0; cnt < num_ls; ++cnt) {
+        for (int lv = 0; lv < L; ++lv) {
+            const int e0 = lv_ptr[lv], e1 = lv_ptr[lv + 1];
+            int e = e0 + w;
+            Row cur;
+            if (e < e1) cur = fetch(lv_rows[e]);
+            for (; e < e1; e += W) {
+                Row nxt = cur;
+                if (e + W < e1) nxt = fetch(lv_rows[e + W]);        // the wave's next row of this level, behind the current one's sums
+                float qii;
+                const float res = row(cur, true, qii);
+                const uint64_t nw = ballot64(res > (BIN ? (-qii / 2.0f) : 0.0f));
+                if (lane == 0) words[cur.i] = nw;                   // no row of this level reads word i
+                cur = nxt;
+            }
+            __syncthreads();
+        }
+    }
+    // value = s^T Q s: the rows dealt over the waves, the partial sums through LDS
+    float total = 0.0f;
+    {
+        int i = w;
+        Row cur;
+        if (i < n) cur = fetch(i);
+        for (; i < n; i += W) {
+            Row nxt = cur;
+            if (i + W < n) nxt = fetch(i + W);
+            float qii;
+            const uint32_t bi = (w32[(i << 1) + half] >> sh) & 1u;
+            total += (BIN ? (float)bi : (bi ? 1.0f : -1.0f)) * row(cur, false, qii);
+            cur = nxt;
+        }
+    }
+    part[w * kWave + lane] = total;
+    __syncthreads();
+    if (w == 0 && valid) {
+        float sum = 0.0f;
+#pragma unroll
+        for (int k = 0; k < W; ++k) sum += part[k * kWave + lane];
+        value[c] = sum;
+    }
+    if (valid)
+        for (int64_t j = w; j < n; j += W) xs_out[j * C + c] = (float)((w32[(j << 1) + half] >> sh) & 1u);
+}
+
 }  // namespace rls
 
 using namespace rls;
@@ -401,11 +534,37 @@ extern "C" int rls_qubo_local_search_value(const float* Q, int64_t n, const floa
 }
 
 extern "C" int rls_qubo_sparse_local_search_value(const int32_t* rowptr, const int32_t* col, const float* val, int64_t n,
+                                                  const int32_t* lv_ptr, const int32_t* lv_rows, int32_t num_levels,
                                                   const float* xs_in, float* xs_out, int64_t C, int64_t num_ls, int binary,
                                                   float* value, void* stream) {
     RLS_REQUIRE(n > 0 && C >= 0 && num_ls >= 0, RLS_EINVAL, "bad sizes n=%lld C=%lld", (long long)n, (long long)C);
     if (C == 0) return RLS_OK;
     RLS_REQUIRE(rowptr && col && val && xs_in && xs_out && value, RLS_EINVAL, "NULL pointer");
+    RLS_REQUIRE((lv_ptr != nullptr) == (lv_rows != nullptr) && (!lv_ptr || num_levels >= 1), RLS_EINVAL,
+                "lv_ptr / lv_rows / num_levels come together");
+    if (lv_ptr && knob(KN_QUBO_LEVELS, 1) != 0) {
+        // the level schedule: W waves per 64-chain tile -- 16 while that leaves at most two waves per SIMD (a row's sums are a
+        // dependent VALU chain: a second wave fills its issue gaps), 8 up to four, then 4
+        const int64_t tiles = ceil_div(C, kWave);
+        const int kw = (int)knob(KN_QUBO_LEVELS, 1);
+        const int Wv = kw == 4 || kw == 8 || kw == 16 ? kw : (tiles * 16 <= (int64_t)8 * num_cus() ? 16 : (tiles * 8 <= (int64_t)16 * num_cus() ? 8 : 4));
+        const size_t ldl = (size_t)n * 8 + (size_t)Wv * kWave * 4;
+        if (ldl <= (size_t)kLdsBytes) {
+            const dim3 gl((unsigned)tiles), bl(Wv * kWave);
+#define RLS_QL_LAUNCH(BIN_, W_)                                                                                                  \
+    do {                                                                                                                         \
+        auto kern = k_qubo_sparse_levels<BIN_, W_>;                                                                              \
+        if (ldl > 64 * 1024) ensure_dyn_lds((const void*)kern, ldl);                                                             \
+        hipLaunchKernelGGL(kern, gl, bl, ldl, as_stream(stream), rowptr, col, val, n, lv_ptr, lv_rows, num_levels, xs_in, xs_out, \
+                           C, num_ls, value);                                                                                    \
+    } while (0)
+#define RLS_QL_W(BIN_) do { if (Wv == 16) RLS_QL_LAUNCH(BIN_, 16); else if (Wv == 8) RLS_QL_LAUNCH(BIN_, 8); else RLS_QL_LAUNCH(BIN_, 4); } while (0)
+            if (binary) RLS_QL_W(true); else RLS_QL_W(false);
+#undef RLS_QL_W
+#undef RLS_QL_LAUNCH
+            return check_launch("k_qubo_sparse_levels");
+        }
+    }
     const size_t lds = (size_t)n * 8 + (size_t)(n + 1) * 4;
     RLS_REQUIRE(lds <= (size_t)kLdsBytes, RLS_EUNSUPPORTED, "n=%lld needs %zu B of LDS (max %d)", (long long)n, lds, kLdsBytes);
     const dim3 grid((unsigned)ceil_div(C, kWave)), block(kWave);

@@ -703,9 +703,17 @@ void qubo_local_search_value(const Tensor& Q, const Tensor& xs_in, Tensor xs_out
                                    (float*)p(value), cur_stream(Q)), "rls_qubo_local_search_value");
 }
 
-void qubo_sparse_local_search_value(const Tensor& rowptr, const Tensor& col, const Tensor& val, const Tensor& xs_in, Tensor xs_out,
-                                    int64_t num_ls, bool binary, Tensor value) {
+void qubo_sparse_local_search_value(const Tensor& rowptr, const Tensor& col, const Tensor& val, const OptTensor& lv_ptr,
+                                    const OptTensor& lv_rows, const Tensor& xs_in, Tensor xs_out, int64_t num_ls, bool binary, Tensor value) {
     dev(rowptr, "rowptr", I32);
+    optdev(lv_ptr, "lv_ptr", I32);
+    optdev(lv_rows, "lv_rows", I32);
+    TORCH_CHECK(lv_ptr.has_value() == lv_rows.has_value(), "lv_ptr and lv_rows come together");
+    if (lv_ptr.has_value()) {
+        TORCH_CHECK(lv_ptr->numel() >= 2 && lv_rows->numel() == rowptr.numel() - 1, "lv_ptr must be [levels + 1], lv_rows [n]");
+        same_device(xs_in, *lv_ptr, "lv_ptr");
+        same_device(xs_in, *lv_rows, "lv_rows");
+    }
     dev(col, "col", I32);
     dev(val, "val", F32);
     dev(xs_in, "xs_in", F32);
@@ -717,7 +725,8 @@ void qubo_sparse_local_search_value(const Tensor& rowptr, const Tensor& col, con
     count(value, "value", xs_in.size(1));
     RLS_GUARD(xs_in);
     ok(rls_qubo_sparse_local_search_value((const int32_t*)p(rowptr), (const int32_t*)p(col), (const float*)p(val), rowptr.numel() - 1,
-                                          (const float*)p(xs_in), (float*)p(xs_out), xs_in.size(1), num_ls, binary, (float*)p(value),
+                                          (const int32_t*)p(lv_ptr), (const int32_t*)p(lv_rows),
+                                          lv_ptr.has_value() ? (int32_t)(lv_ptr->numel() - 1) : 0, (const float*)p(xs_in), (float*)p(xs_out), xs_in.size(1), num_ls, binary, (float*)p(value),
                                           cur_stream(xs_in)), "rls_qubo_sparse_local_search_value");
 }
 
@@ -943,7 +952,7 @@ TORCH_LIBRARY(rlsolver_hip, m) {
     m.def("mcpg_pack_chains(Tensor xs, Tensor(a!) packed) -> ()");
     m.def("mcpg_unpack_chains(Tensor packed, int C, Tensor(a!) xs) -> ()");
     m.def("qubo_local_search_value(Tensor Q, Tensor xs_in, Tensor(a!) xs_out, int num_ls, bool binary, Tensor(b!) value) -> ()");
-    m.def("qubo_sparse_local_search_value(Tensor rowptr, Tensor col, Tensor val, Tensor xs_in, Tensor(a!) xs_out, int num_ls, bool binary, "
+    m.def("qubo_sparse_local_search_value(Tensor rowptr, Tensor col, Tensor val, Tensor? lv_ptr, Tensor? lv_rows, Tensor xs_in, Tensor(a!) xs_out, int num_ls, bool binary, "
           "Tensor(b!) value) -> ()");
     m.def("tsp_tour_length(Tensor dist, Tensor perm, Tensor(a!) length) -> ()");
     m.def("tsp_swap_delta_all(Tensor dist, Tensor perm, Tensor? selected, Tensor? nearest, Tensor? random, Tensor? tables8, float near_threshold, int seed, "

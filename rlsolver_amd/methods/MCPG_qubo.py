@@ -43,20 +43,49 @@ def qubo_local_search_value(Q: TEN, xs: TEN, num_ls: int, binary: bool):
     return out, value
 
 
-def qubo_to_csr(Q: TEN):
-    """Dense Q [n, n] -> (rowptr int32 [n+1], col int32 [nnz], val f32 [nnz]) on Q's device, diagonal included."""
+def qubo_to_csr(Q: TEN, levels: bool = True):
+    """Dense Q [n, n] -> (rowptr int32 [n+1], col int32 [nnz], val f32 [nnz], lv_ptr, lv_rows) on Q's device, diagonal included;
+    the last two are the level schedule of ``qubo_levels`` (``levels=False``: the bare CSR triple)."""
     Qc = Q.detach().to(torch.float32)
     nz = Qc != 0
     counts = nz.sum(dim=1)
     rowptr = torch.zeros(Qc.shape[0] + 1, dtype=torch.int32, device=Q.device)
     rowptr[1:] = counts.cumsum(0).to(torch.int32)
     idx = nz.nonzero()
-    return rowptr.contiguous(), idx[:, 1].to(torch.int32).contiguous(), Qc[nz].contiguous()
+    rowptr, col = rowptr.contiguous(), idx[:, 1].to(torch.int32).contiguous()
+    if not levels:
+        return rowptr, col, Qc[nz].contiguous()
+    return (rowptr, col, Qc[nz].contiguous()) + qubo_levels(rowptr, col)
+
+
+def qubo_levels(rowptr, col):
+    """Level schedule of the Gauss-Seidel sweep over a CSR pattern: level(i) = 1 + max(level(j): j < i, Q_ij != 0).  Rows of one
+    level share no entry and every neighbour above a row sits in a later level, so a level's rows can be updated side by side
+    with the sequential sweep's result.  -> (lv_ptr int32 [L + 1], lv_rows int32 [n]: rows by (level, index)), on rowptr's
+    device.  Host work, once per matrix."""
+    rp = rowptr.detach().cpu().numpy().astype(np.int64)
+    cl = col.detach().cpu().numpy().astype(np.int64)
+    n = rp.size - 1
+    level = np.zeros(n, dtype=np.int64)
+    for i in range(n):
+        nb = cl[rp[i]:rp[i + 1]]
+        nb = nb[nb < i]
+        if nb.size:
+            level[i] = level[nb].max() + 1
+    order = np.lexsort((np.arange(n), level))
+    L = int(level.max()) + 1 if n else 1
+    lv_ptr = np.zeros(L + 1, dtype=np.int32)
+    lv_ptr[1:] = np.cumsum(np.bincount(level, minlength=L))
+    dev = rowptr.device
+    return torch.from_numpy(lv_ptr).to(dev), torch.from_numpy(order.astype(np.int32)).to(dev)
 
 
 def qubo_sparse_local_search_value(csr, xs: TEN, num_ls: int, binary: bool):
-    """The same coordinate search + value on a CSR matrix (rowptr, col, val) -- O(nnz) per sweep."""
-    rowptr, col, val = csr
+    """The same coordinate search + value on a CSR matrix (rowptr, col, val[, lv_ptr, lv_rows]) -- O(nnz) per sweep.
+    With the level schedule of ``qubo_levels`` (``qubo_to_csr`` appends it) the waves of a workgroup sweep the rows of a level side
+    by side; a bare 3-tuple runs one wave per 64 chains over the rows in order.  Same result either way."""
+    rowptr, col, val = csr[:3]
+    lv_ptr, lv_rows = (csr[3], csr[4]) if len(csr) >= 5 else (None, None)
     dev = xs.device
     _check(rowptr, "rowptr", (torch.int32,), dev)
     _check(col, "col", (torch.int32,), dev)
@@ -67,7 +96,7 @@ def qubo_sparse_local_search_value(csr, xs: TEN, num_ls: int, binary: bool):
         raise ValueError(f"xs must be [{n}, C]")
     out = torch.empty_like(xs)
     value = torch.empty(xs.shape[1], dtype=torch.float32, device=dev)
-    _t.qubo_sparse_local_search_value(rowptr, col, val, xs, out, num_ls, bool(binary), value)
+    _t.qubo_sparse_local_search_value(rowptr, col, val, lv_ptr, lv_rows, xs, out, num_ls, bool(binary), value)
     return out, value
 
 

@@ -69,9 +69,22 @@ def test_qubo_sparse_equals_dense_and_block_sweep_equals_sequential(n, C, densit
         want_x = s if binary else (s + 1) / 2
         want_v = np.einsum("ic,ij,jc->c", s, Qn, s).astype(np.float32)
         xd, vd = q.qubo_local_search_value(Q, dev(x0), 2, binary)
-        xs_, vs_ = q.qubo_sparse_local_search_value(csr, dev(x0), 2, binary)
+        xs_, vs_ = q.qubo_sparse_local_search_value(csr, dev(x0), 2, binary)            # by levels: the waves of a workgroup side by side
+        xq_, vq_ = q.qubo_sparse_local_search_value(csr[:3], dev(x0), 2, binary)        # one wave walking the rows in order
         assert np.array_equal(xd.cpu().numpy(), want_x) and np.array_equal(vd.cpu().numpy(), want_v)
-        assert torch.equal(xd, xs_) and torch.equal(vd, vs_)
+        assert torch.equal(xd, xs_) and torch.equal(vd, vs_) and torch.equal(xd, xq_) and torch.equal(vd, vq_)
+    # the level schedule itself: every row once, ascending within a level, no entry between two rows of a level, and every
+    # neighbour below a row in an earlier level
+    lv_ptr, lv_rows = csr[3].cpu().numpy(), csr[4].cpu().numpy()
+    assert sorted(lv_rows.tolist()) == list(range(n)) and lv_ptr[0] == 0 and lv_ptr[-1] == n
+    level = np.empty(n, dtype=np.int64)
+    for lv in range(lv_ptr.size - 1):
+        rows = lv_rows[lv_ptr[lv]:lv_ptr[lv + 1]]
+        assert (np.diff(rows) > 0).all()
+        level[rows] = lv
+    ii, jj = np.nonzero(Qn)
+    off = ii != jj
+    assert (level[ii[off]] != level[jj[off]]).all() and (level[jj[off & (jj < ii)]] < level[ii[off & (jj < ii)]]).all()
 
 
 def test_qubo_sampler_picks_the_kernel_by_cost_and_both_agree():

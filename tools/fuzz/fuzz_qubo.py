@@ -42,6 +42,8 @@ while time.time() < t_end:
     if (Qn != 0).any():
         csr = q.qubo_to_csr(Q)
         xs_, vs_ = q.qubo_sparse_local_search_value(csr, dev(x0), num_ls, binary)
-        assert torch.equal(xd, xs_) and torch.equal(vd, vs_), "sparse " + tag
+        assert torch.equal(xd, xs_) and torch.equal(vd, vs_), "sparse (levels) " + tag
+        xs_, vs_ = q.qubo_sparse_local_search_value(csr[:3], dev(x0), num_ls, binary)
+        assert torch.equal(xd, xs_) and torch.equal(vd, vs_), "sparse (sequential) " + tag
     it += 1
 print(f"fuzz_qubo: {it} random configurations, no mismatch")

@@ -17,15 +17,17 @@ def t_us(fn, it=3):
 
 
 rng = np.random.RandomState(0)
-for n in (500, 1000, 2000):
+for n in (1000, 2000):
     base = rng.randint(10, 101, size=(n, n)) * rng.choice([-1, 1], size=(n, n))
-    for fill in (0.005, 0.02, 0.1, 0.25):
+    for fill in (0.005, 0.02, 0.1):
         Qn = base * (rng.rand(n, n) < fill)
         Qn = (np.triu(Qn) + np.triu(Qn, 1).T).astype(np.float32)
         Q = torch.from_numpy(Qn).to(dev)
         csr = q.qubo_to_csr(Q)
-        for C in (1 << 13, 1 << 16):
+        for C in (1 << 13, 1 << 15):
             x0 = (torch.rand(n, C, device=dev) < 0.5).float()
             td = t_us(lambda: q.qubo_local_search_value(Q, x0, 2, False))
             ts = t_us(lambda: q.qubo_sparse_local_search_value(csr, x0, 2, False))
-            print("n=%d fill=%.3f (deg %.1f) C=%d: dense %.0f us  sparse %.0f us" % (n, fill, int(csr[0][-1]) / n, C, td, ts), flush=True)
+            tq = t_us(lambda: q.qubo_sparse_local_search_value(csr[:3], x0, 2, False))
+            print("n=%d fill=%.3f (deg %.1f, %d levels) C=%d: dense %.0f us  sparse by levels %.0f us  sparse sequential %.0f us" %
+                  (n, fill, int(csr[0][-1]) / n, csr[3].numel() - 1, C, td, ts, tq), flush=True)
