@@ -101,18 +101,24 @@ def qubo_sparse_local_search_value(csr, xs: TEN, num_ls: int, binary: bool):
 
 
 def qubo_prefers_sparse(n: int, nnz: int, num_chains: int) -> bool:
-    """Which K11 kernel finishes a sweep first (measured on MI355X, tools/sweeps/time_qubo_sparse.py).
+    """Which K11 kernel finishes a sweep first (measured on MI355X, tools/sweeps/time_qubo_sparse.py; round 6: the CSR kernel by
+    levels).
 
     dense (MFMA):  a sweep is n / 32 blocks of about 4 + 5.4 n / 1000 us while one workgroup per CU suffices, and
                    2 n^2 C flops at ~80 TFLOP/s beyond that;
-    sparse (CSR):  one wave walks the n rows in order, 0.38 us per row + 0.025 us per entry, whatever the number of
-                   chains until the chip is full of waves (64 chains each, ~2^19 chains).
-    So few chains or a short n favour the dense kernel even at 1 % fill; many chains favour the CSR kernel up to a
-    fill where its entry count catches up."""
+    sparse (CSR, level schedule): W = 16 / 8 / 4 waves per 64-chain tile share a level's rows.  A row costs a wave
+                   0.6 + 0.075 deg us when it has the SIMD to itself (a dependent chain) and a quarter of that in issue slots
+                   once four waves share a SIMD; a level ends in a barrier (~0.8 us; ~1.65 deg + 8 levels in a random pattern).
+    n = 1000, 2 % fill, 2 sweeps + value: 2^13 chains 410 us vs 883 dense, 2^15 770 vs 2402; at 10 % fill the dense kernel wins
+    (1884 vs 882, 3119 vs 2405)."""
     if n <= 0 or nnz >= n * n:
         return False
+    deg = nnz / float(n)
     dense_us = max(2.0 * n * n * num_chains / 80e6, (n / 32.0) * (4.0 + 5.4 * n / 1000.0))
-    sparse_us = n * (0.38 + 0.025 * nnz / n) * max(1.0, num_chains / float(1 << 19))
+    tiles = (num_chains + 63) // 64
+    W = 16 if tiles * 16 <= 2048 else (8 if tiles * 8 <= 4096 else 4)
+    row_us = 0.6 + 0.075 * deg
+    sparse_us = max((n / float(W)) * row_us, tiles * n * (row_us / 4.0) / 1024.0) + (1.65 * deg + 8.0) * 0.8
     return sparse_us < dense_us
 
 

@@ -88,8 +88,8 @@ def test_qubo_sparse_equals_dense_and_block_sweep_equals_sequential(n, C, densit
 
 
 def test_qubo_sampler_picks_the_kernel_by_cost_and_both_agree():
-    """n = 1500 at 0.3 % fill over 2^15 chains: the CSR kernel's row walk beats 2 n^2 C flops (qubo_prefers_sparse);
-    the same instance over 64 chains goes dense.  Either way the sampler returns what the other kernel returns."""
+    """n = 1500 at 0.3 % fill over 2^15 chains: the CSR kernel's level sweep beats 2 n^2 C flops (qubo_prefers_sparse);
+    a 30 %-filled matrix goes dense.  Either way the sampler returns what the other kernel returns."""
     rng = np.random.RandomState(5)
     n, M, R = 1500, 256, 128
     Qn = (rng.randint(-9, 10, size=(n, n)) * (rng.rand(n, n) < 0.003)).astype(np.float32)
@@ -105,7 +105,9 @@ def test_qubo_sampler_picks_the_kernel_by_cost_and_both_agree():
     b = q.mcpg_sampling_qubo(dense, start, probs, 2, T, M, DEV, index=index, u=u)
     assert auto["csr"] is not None and dense["csr"] is None
     assert all(torch.equal(x, y) for x, y in zip(a, b))
-    few = {"Q": dev(Qn), "nvar": n}
+    # a 30 %-filled matrix goes dense at any chain count (the CSR kernel's entry count has caught up)
+    Qd = (rng.randint(-9, 10, size=(n, n)) * (rng.rand(n, n) < 0.3)).astype(np.float32)
+    few = {"Q": dev(np.triu(Qd) + np.triu(Qd, 1).T), "nvar": n}
     q.mcpg_sampling_qubo(few, start[:, :64].contiguous(), probs, 1, T, 16, DEV, index=index[:, :64].contiguous(),
                          u=u[:, :64].contiguous())
     assert few["csr"] is None

@@ -3,11 +3,14 @@ from rlsolver_amd.methods.MCPG_qubo import qubo_prefers_sparse
 
 
 def test_qubo_kernel_choice_follows_the_measured_crossovers():
-    # (n, fill, chains) -> CSR kernel wins; measured on MI355X (tools/sweeps/time_qubo_sparse.py, round 2)
+    # (n, fill, chains) -> CSR kernel wins; measured on MI355X (tools/sweeps/time_qubo_sparse.py, round 6: the CSR kernel sweeps by
+    # levels -- n = 1000 at 2 % fill now wins at 2^13 chains too, 410 vs 883 us; 10 % fill stays dense at every chain count)
     measured = [
-        (1000, 0.02, 1 << 13, False), (1000, 0.02, 1 << 16, True), (1000, 0.1, 1 << 16, False),
-        (500, 0.005, 1 << 13, False), (500, 0.005, 1 << 16, True), (2000, 0.005, 1 << 13, False),
-        (2000, 0.02, 1 << 16, True), (2000, 0.1, 1 << 16, False), (2000, 0.25, 1 << 16, False),
+        (1000, 0.005, 1 << 13, True), (1000, 0.02, 1 << 13, True), (1000, 0.1, 1 << 13, False),
+        (1000, 0.005, 1 << 15, True), (1000, 0.02, 1 << 15, True), (1000, 0.1, 1 << 15, False),
+        (2000, 0.005, 1 << 13, True), (2000, 0.02, 1 << 13, True), (2000, 0.1, 1 << 13, False),
+        (2000, 0.005, 1 << 15, True), (2000, 0.02, 1 << 15, True), (2000, 0.1, 1 << 15, False),
+        (1000, 0.02, 1 << 16, True), (1000, 0.1, 1 << 16, False), (2000, 0.25, 1 << 16, False),
     ]
     for n, fill, C, want in measured:
         assert qubo_prefers_sparse(n, int(n * n * fill), C) == want, (n, fill, C)
