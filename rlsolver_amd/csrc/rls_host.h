@@ -18,7 +18,7 @@ int fail(int code, const char* fmt, ...);  // records the message (thread local)
     X(STEP_NTS) X(STEP_EPW) X(STEP_WPB) X(STEP_PERSIST) X(STEP_CHASE) X(STEP_ALIGN)                                       \
     X(ISCO_SEL_CAP) X(ISCO_WAVES) X(ISCO_GLOBAL_ROWS) X(ISCO_FORCE_WG)                                                                                         \
     X(LS_SD_GLOBAL) X(LS_SLICES) X(LS_WAVES) X(LS_PER_ROUND) X(LS_APPLY32) X(SWEEP_NO_LEVELS) X(SWEEP_WAVES) X(SWEEP_UNBATCHED) \
-    X(NODE_STATS_MIN_B) X(NODE_STATS_LANE_ENV) X(NODE_STATS_NO_TILE) X(NS_TILE32) X(NS_WAVES) X(NS_PARK)                             \
+    X(NODE_STATS_MIN_B) X(NODE_STATS_LANE_ENV) X(NODE_STATS_NO_TILE) X(NS_TILE32) X(NS_WAVES) X(NS_PARK) X(NS_ROWS)                             \
     X(K1_TILE32) X(K1_LDS_KB) X(K5_TILE32) X(K6_TILE32) X(K7_WAVES) X(K7_PAIR) X(TILE_NOSTAGE) X(TILE_LINECUT) X(MCPG_SHIM) X(PLAN_FIXED) X(PLAN_BLOCK) X(PLAN_MERGE) X(METRO_QG) X(NARROW_TILE) X(QUBO_LEVELS)
 enum Knob {
 #define RLS_X(n) KN_##n,

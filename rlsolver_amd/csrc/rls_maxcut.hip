@@ -763,6 +763,97 @@ __global__ __launch_bounds__(NSW * kWave) void k_node_stats_bits(const uint8_t* 
             if (park) __syncthreads();                           // the stash lies where the last exchange was read
         }
     }
+    // ---- K2 / K3 of a FULL tile through row staging (round 6, stage_flags bit 2): the per-group form below writes, per env, the 64
+    // nodes of a group -- 256-byte pieces of rows 4N bytes apart, every other one starting mid-line: three lines touched, two of them
+    // partially, per piece (4.3 TB/s in isolation at N = 2000, 4.1 at 10^4; 1 KB pieces of the same rows 5.4 / 4.8:
+    // tools/ceilings/store_width.hip).  Here a wave counts TWO consecutive groups, parks their counts as bytes in its OWN 8 KB of
+    // LDS [env][128 nodes] (the int8 weights' quad transpose makes a lane's dword four consecutive nodes of one env) and writes two
+    // envs' 128 nodes per store instruction, 16 bytes per lane: 512-byte (K3) / 1 KB (K2) pieces.  Wave-private: no barrier, the
+    // eight waves of a tile stay out of step as they are in the per-group form (a version with a tile-wide staging of 256-node blocks
+    // behind two barriers per block was built first: G70 2^17 1908 us against 1662 per group -- its count and store phases ran in turn).
+    if constexpr (MODE != 2 && NSW == 8) {
+        if ((stage_flags & 4) && nenv == kWave) {
+            constexpr int kRowPitch = 132;                                // bytes per env row of a wave's staging: 128 + 4 (banks)
+            unsigned char* const stg = smem + (((size_t)N * 8 + 15) & ~(size_t)15) + (size_t)w * (kWave * kRowPitch);
+            const uint32_t sel1 = (lane & 1) ? 0x03070105u : 0x06020400u, sel2 = (lane & 2) ? 0x03020706u : 0x05040100u;
+            if (coop) __syncthreads();                                    // (the hub groups' last exchange was read from these bytes)
+            const int64_t NP = (G + 1) >> 1;                              // pairs of groups
+            for (int64_t pr = w; pr < NP; pr += NSW) {
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const int64_t g = 2 * pr + h2;
+                    if (g >= G) break;
+                    const int64_t i = (g << 6) + lane;
+                    const bool in = i < N;
+                    const uint32_t iself = in ? (uint32_t)i : 0u;
+                    const uint64_t own = words[iself];
+                    const int e0 = ell_ptr[g], e1 = ell_ptr[g + 1];
+                    const int md = (e1 - e0) >> 6;                        // longest row of the group (wave-uniform)
+                    if (WIDE && md >= 256) continue;                      // (a hub group: written by the cooperative pass above)
+                    uint64_t ones = 0, twos = 0, fours = 0, c[NCP];
+#pragma unroll
+                    for (int p = 0; p < NCP; ++p) c[p] = 0;
+                    int ncp = 5;
+                    if constexpr (WIDE) while ((8 << ncp) <= md) ++ncp;
+                    count_blocks(e0, e1, iself, own, ncp, 0, 1, ones, twos, fours, c);
+                    const uint64_t pl[8] = {ones, twos, fours, c[0], c[1], c[2], c[3], c[4]};
+                    unsigned char* const obase = stg + (size_t)((lane & 3) * 8) * kRowPitch + h2 * 64 + (lane & ~3);
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+#pragma unroll 2
+                        for (int r = 0; r < 8; ++r) {
+                            uint32_t v = md < 16 ? ns_extract4<4>(pl, half, r)
+                                                 : (md < 64 ? ns_extract4<6>(pl, half, r) : ns_extract4<8>(pl, half, r));   // 4 envs x count
+                            uint32_t o = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);      // lane ^ 1
+                            v = __builtin_amdgcn_perm(o, v, sel1);
+                            o = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);               // lane ^ 2
+                            v = __builtin_amdgcn_perm(o, v, sel2);                    // 4 consecutive nodes of env half * 32 + r + 8 (lane & 3)
+                            *reinterpret_cast<uint32_t*>(obase + (size_t)(half * 32 + r) * kRowPitch) = v;
+                        }
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // LDS ops of one wave execute in order; the compiler must not move them
+                __builtin_amdgcn_wave_barrier();
+                // the pair's 128 nodes of two envs per store: lanes 0 .. 31 env 2k, lanes 32 .. 63 env 2k + 1, four nodes each
+                const int sub = lane >> 5, q4 = (lane & 31) * 4;
+                const int64_t i4 = (pr << 7) + q4;
+                bool on = i4 < N;                                          // (N % 4 == 0: all four or none)
+                int dg[4] = {0, 0, 0, 0};
+                if (on) {
+                    int rp[5];
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) rp[j] = rowptr[i4 + j];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) dg[j] = rp[j + 1] - rp[j];
+                    if constexpr (WIDE) {
+                        const int64_t gi = i4 >> 6;
+                        if (((ell_ptr[gi + 1] - ell_ptr[gi]) >> 6) >= 256) on = false;       // a hub group's nodes: already written
+                    }
+                }
+#pragma unroll 4
+                for (int k = 0; k < kWave / 2; ++k) {
+                    const int e = 2 * k + sub;
+                    const uint32_t d = *reinterpret_cast<const uint32_t*>(stg + (size_t)e * kRowPitch + q4);
+                    if (on) {
+                        if constexpr (MODE == 1) {
+                            typedef int i32x4 __attribute__((ext_vector_type(4)));
+                            const i32x4 o = {dg[0] - 2 * (int)(d & 0xFFu), dg[1] - 2 * (int)((d >> 8) & 0xFFu),
+                                             dg[2] - 2 * (int)((d >> 16) & 0xFFu), dg[3] - 2 * (int)(d >> 24)};
+                            *reinterpret_cast<i32x4*>(reinterpret_cast<int32_t*>(out_v) + (b0 + e) * N + i4) = o;
+                        } else {
+                            typedef int64_t i64x2 __attribute__((ext_vector_type(2)));
+                            int64_t* const q = reinterpret_cast<int64_t*>(out_v) + (b0 + e) * N + i4;
+                            *reinterpret_cast<i64x2*>(q) = i64x2{(int64_t)(d & 0xFFu), (int64_t)((d >> 8) & 0xFFu)};
+                            *reinterpret_cast<i64x2*>(q + 2) = i64x2{(int64_t)((d >> 16) & 0xFFu), (int64_t)(d >> 24)};
+                        }
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+            }
+            return;
+        }
+    }
     for (int64_t g = w; g < G; g += NSW) {
         const int64_t i = (g << 6) + lane;
         const bool in = i < N;
@@ -1121,6 +1212,19 @@ static int launch_node_stats_bits(const rls_graph* g, const uint8_t* x, int64_t 
         const size_t with_stash = node_stats_bits_lds(N, false, waves) + (size_t)N * 4;
         const size_t need = with_stash > lds ? with_stash : lds;
         if (need <= (size_t)kLdsBytes && (size_t)kLdsBytes / need == (size_t)kLdsBytes / lds) { lds = need; stage_flags |= 2 | (seeds << 8); }
+    }
+    // K2 / K3 of full tiles through row staging (the kernel's comment): 16-byte-aligned output rows of 4-node multiples, 8 KB + of
+    // LDS per wave behind the tile (where the row-piece stages are: the hub groups' cooperative pass needs those)
+    const int rows_knob = (int)knob(KN_NS_ROWS, -1);
+    const size_t lds_rows = node_stats_bits_lds(N, false, waves) + (size_t)kNsWaves * kWave * 132;
+    // measured (tools/timing/k3_rows.py, per group -> rows): K3 G70-sized 2^17 1648 -> 1574 us, BA n = 10^4 2^16 1136 -> 1032; G22-sized
+    // 2^16 169 -> 178 and N = 3008 117 -> 123 (the 64 KB of staging cost the CU a workgroup there); K2's int64 rows lose everywhere
+    // (G70 2274 -> 2361): K3, on tiles that leave one workgroup per CU either way
+    const bool rows_auto = MODE == 1 && 2 * node_stats_bits_lds(N, true, waves) > (size_t)kLdsBytes;
+    if (MODE != 2 && waves == kNsWaves && has_stage && (N & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
+        (rows_knob < 0 ? rows_auto : rows_knob != 0) && lds_rows <= (size_t)kLdsBytes) {
+        stage_flags |= 4;
+        if (lds_rows > lds) lds = lds_rows;
     }
     const dim3 grid((unsigned)tiles), block(waves * kWave);
 #define RLS_NS_LAUNCH(KERN)                                                                                         \

@@ -96,3 +96,40 @@ def test_degree_200_graph_uses_all_eight_counter_planes():
     sub = np.arange(0, B, 211)
     assert np.array_equal(ops.maxcut_delta_all(g, x)[sub].cpu().numpy(), onp.maxcut_delta_all(xs[sub], graph, n, None))
     assert np.array_equal(ops.maxcut_node_cutdeg(g, x)[sub].cpu().numpy(), onp.maxcut_node_cutdeg(xs[sub], graph, n, False))
+
+
+@pytest.mark.parametrize("n,m,B,kind", [(2000, 19990, 4096 + 70, "gnm"), (10000, 9999, 2048, "gnm"), (1000, 0, 4096 + 13, "ba-hub"),
+                                         (516, 2000, 4100, "gnm"), (64, 300, 4096, "gnm")])
+def test_k3_k2_row_staged_stores_equal_the_per_group_form(n, m, B, kind):
+    """Round 6: K3 / K2 of a full 64-env tile through wave-private row staging (two groups' counts parked as bytes, two envs' 128
+    nodes per store: csrc/rls_maxcut.hip) -- forced at every size through RLS_NS_ROWS = 1 on the 64-env kernel (RLS_NS_TILE32 = 0)
+    and compared with the per-group stores (RLS_NS_ROWS = 0), the launcher's own choice and the oracle: ragged last tile (the
+    per-group form takes it), a last group of fewer than 64 nodes, an odd number of groups, hub groups (written by the cooperative
+    pass, skipped by the row stores)."""
+    from rlsolver_amd import _abi
+    from rlsolver_amd.graph import generate_ba
+    rng = np.random.RandomState(n + B)
+    if kind == "ba-hub":
+        graph = np.asarray(generate_ba(n, 4, seed=2), dtype=np.int64)
+        star = np.stack([np.zeros(400, dtype=np.int64), np.arange(500, 900), np.ones(400, dtype=np.int64)], axis=1)   # a degree-400+ hub
+        graph = np.unique(np.concatenate([graph, star]), axis=0)
+        graph = graph[graph[:, 0] != graph[:, 1]]
+    else:
+        graph = gnm_arr(n, m, seed=n)
+    g = device_graph(graph, n, 0)
+    xs = rng.randint(0, 2, size=(B, n)).astype(np.uint8)
+    x = to_dev_bool(xs)
+    got = {}
+    try:
+        for label, t32, rows in (("auto", None, None), ("groups", 0, 0), ("rows", 0, 1)):
+            for k, v in (("RLS_NS_TILE32", t32), ("RLS_NS_ROWS", rows)):
+                _abi.tuning_unset(k) if v is None else _abi.tuning_set(k, v)
+            got[label] = (ops.maxcut_delta_all(g, x), ops.maxcut_node_cutdeg(g, x))
+    finally:
+        _abi.tuning_unset("RLS_NS_TILE32")
+        _abi.tuning_unset("RLS_NS_ROWS")
+    for label in ("groups", "rows"):
+        assert torch.equal(got[label][0], got["auto"][0]) and torch.equal(got[label][1], got["auto"][1]), label
+    sub = np.concatenate([rng.choice(B, 5, replace=False), [B - 1]])
+    assert np.array_equal(got["rows"][0][sub].cpu().numpy(), onp.maxcut_delta_all(xs[sub], graph, n, None))
+    assert np.array_equal(got["rows"][1][sub].cpu().numpy(), onp.maxcut_node_cutdeg(xs[sub], graph, n, False))
