@@ -339,6 +339,16 @@ int rls_best_key(const void* vs, int vs_kind, int64_t B, int32_t rank_bits, int6
 int rls_key_unpack(const int64_t* key, int32_t rank_bits, int64_t world, int as_float, void* obj_out, int64_t* owner_out,
                    int64_t empty_key, int32_t* flag, void* stream);
 
+/* ABI v12.  C2 of the episode-boundary exchange without a host read ("everyone restarts from the best", envs/env_MCPG.py:452-458:
+ * best_xs[:] = best_xs[best_vs.argmax()], across ranks).  After the key's all-reduce every rank calls rls_winner_message: the rank
+ * whose low code survived in the reduced key[0] writes msg = { (index[0] + env_offset) as 8 little-endian bytes | its row xs[index[0]]
+ * bit-packed, bit k of byte j = x[8 j + k] }, every other rank (and a rank with B = 0) zeros -- msg uint8 [8 + ceil(N / 8)].  A
+ * SUM all-reduce of msg is then the winner's message on every rank, and rls_winner_unpack turns it into x_out uint8 [N] (may be
+ * NULL) and index_out int64[1] (may be NULL).  xs uint8 [B, N] 0|1; B == 1: the row itself (index only supplies the env id). */
+int rls_winner_message(const uint8_t* xs, int64_t B, int64_t N, const int64_t* index, const int64_t* key, int32_t rank_bits,
+                       int64_t my_low_code, int64_t env_offset, uint8_t* msg, void* stream);
+int rls_winner_unpack(const uint8_t* msg, int64_t N, uint8_t* x_out, int64_t* index_out, void* stream);
+
 /* K14 generate_xs_randomly(num_sims)  envs/env_L2A.py:82-85: i.i.d. Bernoulli(1/2)
  *     spins from a counter-based generator keyed by (seed, global env id), node 0
  *     forced to 0.  env_offset lets a rank generate its shard of a global batch. */

@@ -127,6 +127,8 @@ SIGNATURES = {
     "rls_best_update": [_P, _P, _INT, _I64, _I64, _INT, _P, _P, _P, _P, _I64, _INT, _P],
     "rls_best_key": [_P, _INT, _I64, C.c_int32, _I64, _I64, _P, _P, _P, _P],
     "rls_key_unpack": [_P, C.c_int32, _I64, _INT, _P, _P, _I64, _P, _P],
+    "rls_winner_message": [_P, _I64, _I64, _P, _P, C.c_int32, _I64, _I64, _P, _P],
+    "rls_winner_unpack": [_P, _I64, _P, _P, _P],
     "rls_tuning_set": [_P, _I64],
     "rls_tuning_unset": [_P],
     "rls_tuning_get": [_P, _P, _P],

@@ -126,9 +126,65 @@ __global__ void k_key_unpack(const int64_t* __restrict__ key, int rank_bits, int
     if (flag && k == empty_key) atomicOr(flag, 2);
 }
 
+// C2 without a host read (round 6): after the key's all-reduce every rank writes ITS candidate message -- the winner (the rank whose
+// low code survived in the reduced key) its global env index and its row bit-packed, everyone else zeros -- and a SUM all-reduce of
+// the messages is the winner's message on every rank.  msg: uint8 [8 + ceil(N / 8)] = { global index, little endian | bit k of
+// byte j = x[8 j + k] }.  xs is this rank's [B, N] (row index[0]) or a single row (B = 1, index ignored).
+__global__ __launch_bounds__(256) void k_winner_message(const uint8_t* __restrict__ xs, int64_t B, int64_t N, const int64_t* __restrict__ index,
+                                                        const int64_t* __restrict__ key, int rank_bits, int64_t my_low_code,
+                                                        int64_t env_offset, uint8_t* __restrict__ msg, int64_t msg_bytes) {
+    const bool mine = xs != nullptr && (key[0] & ((1ll << rank_bits) - 1)) == my_low_code;
+    const int64_t li = (B > 1 && index) ? index[0] : 0;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < msg_bytes; j += (int64_t)gridDim.x * blockDim.x) {
+        uint8_t v = 0;
+        if (mine) {
+            if (j < 8) {
+                v = (uint8_t)((uint64_t)((index ? index[0] : 0) + env_offset) >> (8 * j));
+            } else {
+                const int64_t n0 = (j - 8) * 8;
+                const uint8_t* row = xs + li * N;
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (n0 + k < N && row[n0 + k]) v |= (uint8_t)(1u << k);
+            }
+        }
+        msg[j] = v;
+    }
+}
+__global__ __launch_bounds__(256) void k_winner_unpack(const uint8_t* __restrict__ msg, int64_t N, uint8_t* __restrict__ x_out,
+                                                       int64_t* __restrict__ index_out) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t == 0 && index_out) {
+        uint64_t g = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g |= (uint64_t)msg[j] << (8 * j);
+        index_out[0] = (int64_t)g;
+    }
+    if (x_out)
+        for (int64_t n = t; n < N; n += (int64_t)gridDim.x * blockDim.x) x_out[n] = (msg[8 + (n >> 3)] >> (n & 7)) & 1u;
+}
+
 }  // namespace rls
 
 using namespace rls;
+
+extern "C" int rls_winner_message(const uint8_t* xs, int64_t B, int64_t N, const int64_t* index, const int64_t* key, int32_t rank_bits,
+                                  int64_t my_low_code, int64_t env_offset, uint8_t* msg, void* stream) {
+    RLS_REQUIRE(N >= 1 && B >= 0, RLS_EINVAL, "bad sizes B=%lld N=%lld", (long long)B, (long long)N);
+    RLS_REQUIRE(key && msg, RLS_EINVAL, "NULL pointer");
+    RLS_REQUIRE(B == 0 || xs, RLS_EINVAL, "xs is NULL");
+    RLS_REQUIRE(rank_bits >= 0 && rank_bits < 32 && my_low_code >= 0 && my_low_code < (1ll << rank_bits), RLS_EINVAL, "bad key layout");
+    const int64_t nb = 8 + (N + 7) / 8;
+    hipLaunchKernelGGL(k_winner_message, dim3((unsigned)grid_for(nb, 256)), dim3(256), 0, as_stream(stream), B > 0 ? xs : nullptr, B, N, index,
+                       key, (int)rank_bits, my_low_code, env_offset, msg, nb);
+    return check_launch("k_winner_message");
+}
+
+extern "C" int rls_winner_unpack(const uint8_t* msg, int64_t N, uint8_t* x_out, int64_t* index_out, void* stream) {
+    RLS_REQUIRE(N >= 1 && msg, RLS_EINVAL, "bad arguments");
+    hipLaunchKernelGGL(k_winner_unpack, dim3((unsigned)grid_for(N, 256)), dim3(256), 0, as_stream(stream), msg, N, x_out, index_out);
+    return check_launch("k_winner_unpack");
+}
 
 extern "C" int rls_key_unpack(const int64_t* key, int32_t rank_bits, int64_t world, int as_float, void* obj_out, int64_t* owner_out,
                               int64_t empty_key, int32_t* flag, void* stream) {

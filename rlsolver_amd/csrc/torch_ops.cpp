@@ -361,6 +361,36 @@ void key_unpack(const Tensor& key, int64_t rank_bits, int64_t world, Tensor obj,
     ok(rls_key_unpack((const int64_t*)p(key), (int32_t)rank_bits, world, obj.scalar_type() == F64, p(obj), (int64_t*)p(owner), empty_key,
                       (int32_t*)p(flag), cur_stream(key)), "rls_key_unpack");
 }
+void winner_message(const OptTensor& xs, const OptTensor& index, const Tensor& key, int64_t rank_bits, int64_t my_low_code, int64_t env_offset,
+                    int64_t N, Tensor msg) {
+    dev(key, "key", I64);
+    at_least(key, "key", 1);
+    dev(msg, "msg", at::kByte);
+    TORCH_CHECK(msg.is_contiguous() && msg.numel() == 8 + (N + 7) / 8, "msg must hold 8 + ceil(N / 8) bytes");
+    optdev(index, "index", I64);
+    int64_t B = 0;
+    if (xs.has_value()) {
+        spin_bytes(*xs, "xs", false);
+        TORCH_CHECK((xs->dim() == 2 && xs->size(1) == N) || (xs->dim() == 1 && xs->size(0) == N), "xs must be [B, N] or [N]");
+        B = xs->dim() == 2 ? xs->size(0) : 1;
+        same_device(key, *xs, "xs");
+        TORCH_CHECK(B <= 1 || index.has_value(), "a [B, N] xs needs the row index");
+    }
+    if (index.has_value()) at_least(*index, "index", 1);
+    same_device(key, msg, "msg");
+    RLS_GUARD(key);
+    ok(rls_winner_message((const uint8_t*)p(xs), B, N, (const int64_t*)p(index), (const int64_t*)p(key), (int32_t)rank_bits, my_low_code,
+                          env_offset, (uint8_t*)p(msg), cur_stream(key)), "rls_winner_message");
+}
+void winner_unpack(const Tensor& msg, int64_t N, const OptTensor& x_out, const OptTensor& index_out) {
+    dev(msg, "msg", at::kByte);
+    TORCH_CHECK(msg.is_contiguous() && msg.numel() == 8 + (N + 7) / 8, "msg must hold 8 + ceil(N / 8) bytes");
+    if (x_out.has_value()) { spin_bytes(*x_out, "x_out", false); TORCH_CHECK(x_out->numel() == N && x_out->is_contiguous(), "x_out must be [N]"); same_device(msg, *x_out, "x_out"); }
+    optdev(index_out, "index_out", I64);
+    if (index_out.has_value()) at_least(*index_out, "index_out", 1);
+    RLS_GUARD(msg);
+    ok(rls_winner_unpack((const uint8_t*)p(msg), N, (uint8_t*)p(x_out), (int64_t*)p(index_out), cur_stream(msg)), "rls_winner_unpack");
+}
 void rand_spins(Tensor x, int64_t seed, int64_t env_offset) {
     spin_bytes(x, "x", false);
     TORCH_CHECK(x.dim() == 2, "x must be [B, N]");
@@ -921,6 +951,8 @@ TORCH_LIBRARY(rlsolver_hip, m) {
           "int log_index, bool force) -> ()");
     m.def("best_key(Tensor vs, int rank_bits, int low_code, int limit, Tensor(a!) key, Tensor(b!)? index, Tensor(c!) flag) -> ()");
     m.def("key_unpack(Tensor key, int rank_bits, int world, Tensor(a!) obj, Tensor(b!)? owner, int empty_key, Tensor(c!)? flag) -> ()");
+    m.def("winner_message(Tensor? xs, Tensor? index, Tensor key, int rank_bits, int my_low_code, int env_offset, int N, Tensor(a!) msg) -> ()");
+    m.def("winner_unpack(Tensor msg, int N, Tensor(a!)? x_out, Tensor(b!)? index_out) -> ()");
     m.def("rand_spins(Tensor(a!) x, int seed, int env_offset) -> ()");
     m.def("rand_spins_repeats(Tensor(a!) x, Tensor repeat_seeds, int env_offset) -> ()");
     m.def("rand_actions(Tensor(a!) action, int N, int seed, int step, int env_offset) -> ()");
@@ -987,6 +1019,8 @@ TORCH_LIBRARY_IMPL(rlsolver_hip, CUDA, m) {   // "CUDA" is the HIP dispatch key 
     m.impl("best_update", &best_update);
     m.impl("best_key", &best_key);
     m.impl("key_unpack", &key_unpack);
+    m.impl("winner_message", &winner_message);
+    m.impl("winner_unpack", &winner_unpack);
     m.impl("rand_spins", &rand_spins);
     m.impl("rand_spins_repeats", &rand_spins_repeats);
     m.impl("rand_actions", &rand_actions);

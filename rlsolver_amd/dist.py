@@ -6,7 +6,9 @@ boundaries:
 
   C1  all_reduce(MAX) of ONE int64 key per rank, key = (best_obj << RANK_BITS) | (W-1-rank)
       (MAXLOC emulation: the largest objective wins, ties go to the lowest rank);
-  C2  broadcast of the winner's solution (N bytes) when the caller wants it
+  C2  the winner's solution (bit-packed, ceil(N / 8) bytes + its global index) when the caller wants it -- on device tensors a
+      SUM all-reduce of per-rank candidate messages (only the winner's is non-zero: no rank needs to know the owner on the host),
+      on host tensors (the gloo CPU tests) a broadcast from the owner
       (the single-device analogue is best_xs[best_vs.argmax()] / Evaluator.record2,
       rlsolver/methods/L2A/demo_instance.py:165, rlsolver/methods/util_evaluator.py:90-107).
 
@@ -281,6 +283,37 @@ def global_best(local_vs: torch.Tensor, local_xs=None, want_solution: bool = Fal
         obj, owner = ex.unpack(key, as_float=is_float)
         if single:
             return (obj, owner, (_row(local_xs, li).clone() if want_x else None)) + tail(li + env_offset if want_i else None)
+        if want_x or want_i:
+            # C2 without a host read: every rank writes its candidate message (the winner its global index + bit-packed row,
+            # the others zeros: rls_winner_message), a SUM all-reduce is the winner's message everywhere, rls_winner_unpack
+            # turns it back -- 2 launches + 1 collective, where the broadcast form needed int(owner) on the host first
+            from .torch_ops import ops as _t
+            n = (num_nodes if callable(local_xs) else local_xs.shape[1]) if want_x else 1
+            if n is None:
+                raise ValueError("global_best: a callable local_xs needs num_nodes")
+            xs_arg = None
+            if n_local:
+                if not want_x:
+                    xs_arg = torch.zeros(1, dtype=torch.uint8, device=dev)                 # (only the index travels)
+                elif callable(local_xs):
+                    xs_arg = local_xs(li).reshape(-1)
+                else:
+                    xs_arg = local_xs
+                if xs_arg.dtype not in (torch.bool, torch.uint8) or not xs_arg.is_contiguous():
+                    xs_arg = (xs_arg[li] if xs_arg.dim() == 2 else xs_arg).gt(0).contiguous()
+            msg = torch.empty(8 + (n + 7) // 8, dtype=torch.uint8, device=dev)
+            _t.winner_message(xs_arg, ex.last_index if n_local else None, key, RANK_BITS, world - 1 - rank,
+                              int(env_offset) if want_i else 0, n, msg)
+            _all_reduce(msg, dist.ReduceOp.SUM, group)                                     # C2: 8 + ceil(N / 8) bytes
+            best_x = gi = None
+            if want_x:
+                dt = torch.bool if callable(local_xs) else local_xs.dtype
+                best_x = torch.empty(n, dtype=dt if dt in (torch.bool, torch.uint8) else torch.uint8, device=dev)
+            gi1 = torch.empty(1, dtype=torch.int64, device=dev) if want_i else None
+            _t.winner_unpack(msg, n, best_x, gi1)
+            if want_x and best_x.dtype != dt:
+                best_x = best_x.to(dt)
+            return (obj, owner, best_x) + tail(gi1[0] if want_i else None)
         finish = lambda o: o                                            # (rls_key_unpack has halved a float key already)
     else:
         key, li = _local_best(local_vs, rank, world)

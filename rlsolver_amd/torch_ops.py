@@ -52,7 +52,7 @@ ops = _CallRecorder(torch.ops.rlsolver_hip) if os.environ.get("RLS_RECORD_OPS") 
 DEVICE_ENTRY_POINTS = [
     "maxcut_obj", "maxcut_edge_cut_mask", "maxcut_node_cutdeg", "maxcut_delta_all", "maxcut_step", "maxcut_greedy_sweep",
     "maxcut_propose_accept", "maxcut_ls_weights", "maxcut_local_search", "maxcut_ls_normals", "maxcut_ls_threshold", "maxcut_ls_propose", "maxcut_ls_rounds", "select_better_rows", "pick_best_of_repeats", "copy_rows",
-    "best_update", "best_key", "key_unpack", "rand_spins", "rand_spins_repeats", "rand_actions", "rand_perms", "spin_reset", "spin_step", "spin_observation", "spin_materialize", "spin_reset_dense", "spin_step_dense", "rand_couplings", "mcpg_metro_rounds", "mcpg_metro_stop", "mcpg_local_search",
+    "best_update", "best_key", "key_unpack", "winner_message", "winner_unpack", "rand_spins", "rand_spins_repeats", "rand_actions", "rand_perms", "spin_reset", "spin_step", "spin_observation", "spin_materialize", "spin_reset_dense", "spin_step_dense", "rand_couplings", "mcpg_metro_rounds", "mcpg_metro_stop", "mcpg_local_search",
     "mcpg_local_search_levels", "mcpg_pick_best", "mcpg_merge_best", "mcpg_value_bit_sums", "mcpg_pack_chains", "mcpg_unpack_chains",
     "qubo_local_search_value", "qubo_sparse_local_search_value", "tsp_tour_length", "tsp_swap_delta_all", "tsp_apply_swap", "tsp_2opt_delta", "tsp_2opt_best", "isco_maxcut_step",
     "isco_tsp_step",

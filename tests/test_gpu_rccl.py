@@ -33,6 +33,15 @@ ok = int(best) == int(obj.max()) and int(owner) == 0 and torch.equal(bx, xs[i]) 
 # the float (bidirectional) form and the no-solution form
 bf, of, _ = rdist.global_best(obj.to(torch.float32) / 2)
 ok = ok and float(bf) == float(obj.max()) / 2 and int(of) == 0
+# C2 on device tensors = candidate messages + SUM all-reduce, no host read: with the global index, a callable row source, f32 rows
+b4, o4, x4, g4 = rdist.global_best(obj, xs, want_solution=True, env_offset=1000)
+ok = ok and int(b4) == int(obj.max()) and int(g4) == 1000 + i and torch.equal(x4, xs[i]) and x4.dtype == xs.dtype
+b5, o5, x5, g5 = rdist.global_best(obj, lambda li: xs[li], want_solution=True, env_offset=7, num_nodes=n)
+ok = ok and int(g5) == 7 + i and torch.equal(x5, xs[i].bool())
+b6, o6, x6 = rdist.global_best(obj, xs.float(), want_solution=True)
+ok = ok and x6.dtype == torch.float32 and torch.equal(x6, xs[i].float())
+b7, o7, x7, g7 = rdist.global_best(obj, None, env_offset=5)
+ok = ok and x7 is None and int(g7) == 5 + i
 # the lean form (VERDICT r5 item 1): one rls_best_key launch + one all_reduce per exchange, unpack / flag check deferred
 ex = rdist.BestExchange(dev, depth=4)
 for rep in range(9):                                                   # (more than the ring's depth: slots are reused)
