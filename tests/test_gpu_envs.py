@@ -265,6 +265,43 @@ def test_evaluator_golden(golden, tmp_path, maximize, vdt):
     assert ev.first_v == float(z[f"{tag}/first_v"]) and ev.best_x_str == str(z[f"{tag}/best_x_str"])
 
 
+def test_winner_message_round_trip_and_key_unpack():
+    """C2's device half (rls_winner_message / rls_winner_unpack) and rls_key_unpack: the rank whose low code is in the reduced
+    key writes its global index + bit-packed row (the layout of dist.pack_bits), every other rank zeros; a SUM of the messages
+    unpacks to the winner's row and index."""
+    from rlsolver_amd import dist as rdist
+    R = torch.ops.rlsolver_hip
+    rng = np.random.RandomState(9)
+    for N, B in ((203, 40), (8, 3), (64, 1), (1001, 7)):
+        xs = torch.from_numpy(rng.randint(0, 2, size=(B, N)).astype(np.uint8)).to(DEV).bool()
+        li = int(rng.randint(B))
+        index = torch.tensor([li], dtype=torch.int64, device=DEV)
+        key = torch.tensor([(12345 << 20) | 5], dtype=torch.int64, device=DEV)
+        nb = 8 + (N + 7) // 8
+        mine, other = torch.empty(nb, dtype=torch.uint8, device=DEV), torch.full((nb,), 7, dtype=torch.uint8, device=DEV)
+        R.winner_message(xs, index, key, 20, 5, 1 << 33, N, mine)            # my code is the key's: I am the winner
+        R.winner_message(xs, index, key, 20, 4, 1 << 33, N, other)           # another rank: zeros
+        R.winner_message(None, None, key, 20, 5, 0, N, other[:nb])           # ... and a rank without envs: zeros too
+        assert int(other.sum()) == 0
+        assert torch.equal(mine[8:], rdist.pack_bits(xs[li]))
+        assert int.from_bytes(bytes(mine[:8].cpu().tolist()), "little") == (1 << 33) + li
+        x_out, g_out = torch.empty(N, dtype=torch.bool, device=DEV), torch.empty(1, dtype=torch.int64, device=DEV)
+        R.winner_unpack(mine + other, N, x_out, g_out)
+        assert torch.equal(x_out, xs[li]) and int(g_out) == (1 << 33) + li
+        R.winner_message(xs[li].contiguous(), index, key, 20, 5, 0, N, mine)  # the single-row form: index only supplies the env id
+        R.winner_unpack(mine, N, x_out, g_out)
+        assert torch.equal(x_out, xs[li]) and int(g_out) == li
+    obj, owner = torch.empty(1, dtype=torch.int64, device=DEV), torch.empty(1, dtype=torch.int64, device=DEV)
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    R.key_unpack(torch.tensor([(-77 << 20) | 3], dtype=torch.int64, device=DEV), 20, 8, obj, owner, -(1 << 63), flag)
+    assert int(obj) == -77 and int(owner) == 8 - 1 - 3 and int(flag) == 0
+    objf = torch.empty(1, dtype=torch.float64, device=DEV)
+    R.key_unpack(torch.tensor([(15 << 20) | 0], dtype=torch.int64, device=DEV), 20, 1, objf, None, -(1 << 63), flag)
+    assert float(objf) == 7.5
+    R.key_unpack(torch.tensor([-(1 << 63)], dtype=torch.int64, device=DEV), 20, 4, obj, owner, -(1 << 63), flag)
+    assert int(flag) == 2                                                      # no rank had an env
+
+
 def test_best_key_and_single_process_global_best():
     """rls_best_key: first argmax + the packed MAXLOC key of the episode-boundary exchange in one launch (all value types,
     ties, negative values, the float surface carried doubled, the range / half-integer flag), and dist.global_best on device

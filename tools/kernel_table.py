@@ -71,8 +71,13 @@ ROWS = [
     (r"k_ls_apply_rounds32<24, 8>", 128 * 512, 4096, 2 * NBA + 8 * (NBA // 8) * 8 + 16, "LS apply kernel on half tiles (a batch of few tiles: 128 workgroups instead of 64): 8 rounds on one load of the tile | BA-1e4 4096"),
     (r"k_node_stats_bits<2, true, true, short", 512 * 512, 32768, 3 * NBA, "ls_weights pre-pass, int16 weights (hub graph: 16 counter planes) | BA-1e4 2^15"),
     (r"k_tsp_tour_length", None, 65536, 8 * NT + 4, "K12 tsp_tour_length | TSP-100 2^16"),
-    (r"k_tsp_swap_delta_all<true, true>", None, 65536, 21 * NT, "K13 tsp_swap_delta_all, partners drawn in the kernel | TSP-100 2^16"),
-    (r"k_tsp_swap_delta_all<true, false>", None, 65536, 29 * NT, "K13 tsp_swap_delta_all, selected [B, N] given (test hook) | TSP-100 2^16"),
+    (r"k_tsp_swap_delta_all<true, true, ", None, 65536, 21 * NT, "K13 tsp_swap_delta_all = ISCO_TSP.opt_2, partners drawn in the kernel | TSP-100 2^16 (LDS-gather-bound)"),
+    (r"k_tsp_swap_delta_all<true, false, ", None, 65536, 29 * NT, "K13 tsp_swap_delta_all, selected [B, N] given (test hook) | TSP-100 2^16"),
+    (r"k_rand_spins_multi<16>", None, 65536, N22, "K14 rand_spins (reset path) | G22 2^16 (write-only)"),
+    (r"k_rand_spins_multi<16>", None, 131072, N70, "K14 rand_spins (reset path) | G70 2^17 (write-only)"),
+    (r"k_rand_perms_lds", None, 65536, 8 * NT, "K14 rand_perms (reset path) | TSP-100 2^16 (write-only; Fisher-Yates chain per lane)"),
+    (r"k_qubo_sparse_levels<", None, None, None, None),
+    (r"k_best_key<int>", None, 65536, 4, "C1 rls_best_key: argmax + packed key of one rank's objectives | 2^16 envs (one workgroup: latency)"),
     (r"k_spin_step<float, true, false>", 16384 * 64, 16384, None, "S1 spin_step | G22-sized 2^14: O(deg) per env, nothing streamed (round 2: 24 N bytes per env-step, 250 us)"),
     (r"k_spin_step<float, true, false>", 4096 * 64, 4096, None, "S1 spin_step | BA-200 4096: O(deg)"),
     (r"k_spin_step<float, true, true>", 1024 * 64, 1024, 16 * 200, "S1d spin_step_dense | per-env BA-200 matrices, 1024 envs (launch-bound; the flipped node's matrix row + the entries it changes)"),
