@@ -73,8 +73,8 @@ ROWS = [
     (r"k_tsp_tour_length", None, 65536, 8 * NT + 4, "K12 tsp_tour_length | TSP-100 2^16"),
     (r"k_tsp_swap_delta_all<true, true, ", None, 65536, 21 * NT, "K13 tsp_swap_delta_all = ISCO_TSP.opt_2, partners drawn in the kernel | TSP-100 2^16 (LDS-gather-bound)"),
     (r"k_tsp_swap_delta_all<true, false, ", None, 65536, 29 * NT, "K13 tsp_swap_delta_all, selected [B, N] given (test hook) | TSP-100 2^16"),
-    (r"k_rand_spins_multi<16>", None, 65536, N22, "K14 rand_spins (reset path) | G22 2^16 (write-only)"),
-    (r"k_rand_spins_multi<16>", None, 131072, N70, "K14 rand_spins (reset path) | G70 2^17 (write-only)"),
+    (r"k_rand_spins_multi<16>", 1048576, 65536, N22, "K14 rand_spins (reset path) | G22 2^16 (write-only)"),
+    (r"k_rand_spins_multi<16>", 2097152, 131072, N70, "K14 rand_spins (reset path) | G70 2^17 (write-only)"),
     (r"k_rand_perms_lds", None, 65536, 8 * NT, "K14 rand_perms (reset path) | TSP-100 2^16 (write-only; Fisher-Yates chain per lane)"),
     (r"k_qubo_sparse_levels<", None, None, None, None),
     (r"k_best_key<int>", None, 65536, 4, "C1 rls_best_key: argmax + packed key of one rank's objectives | 2^16 envs (one workgroup: latency)"),

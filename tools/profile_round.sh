@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collect the round's evidence on the GPU box (run through gpurun from the repo root):
-#   tools/profile_round.sh r05
+#   tools/profile_round.sh r06
 # 1. WALL-CLOCK tables, no profiler attached: tools/bench_configs.py (every kernel of every BASELINE config, full iteration counts)
 #    -> ${P}_configs.jsonl, and bench.py three ways (default 2000-step regions, the driver's 20-step regions, --via-env).
 # 2. PROFILED passes of the same commands, kept apart (a profiler roughly doubles every launch-bound row: VERDICT r4 found the
@@ -10,13 +10,14 @@
 # 3. Four SQ counter passes over bench_configs.py --profile (tools/sweeps/pmc_passes.sh).
 # Outputs land under gpurun_out/<prefix>_*; tools/collect_profiles.sh <prefix> condenses them into profiles/ (run it here, after gpurun).
 set -u
-P=${1:-r05}
+P=${1:-r06}
 R=$(pwd)
 export TMPDIR=/tmp
 python3 $R/tools/bench_configs.py > $R/gpurun_out/${P}_configs.jsonl 2> $R/gpurun_out/${P}_configs.err
 python3 $R/bench.py > $R/gpurun_out/${P}_bench_n1.json 2> $R/gpurun_out/${P}_bench_n1.err
 python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $R/gpurun_out/${P}_bench_20steps.json 2>> $R/gpurun_out/${P}_bench_n1.err
 python3 $R/bench.py --via-env --no-cpu-baseline --no-config5 --no-configs > $R/gpurun_out/${P}_bench_via_env.json 2>> $R/gpurun_out/${P}_bench_n1.err
+bash $R/tools/timing/exchange_trace.sh $P > $R/gpurun_out/${P}_exchange.log 2>&1      # the exchange: probe + kernel trace
 cd /tmp
 BENCH="python3 $R/bench.py --steps 500 --warmup 20 --no-cpu-baseline --no-configs"
 CFG="python3 $R/tools/bench_configs.py --profile"

@@ -29,4 +29,10 @@ for N, B in ((100, 1 << 16), (100, 1 << 18), (52, 1 << 16), (200, 1 << 15)):
     a = t_us(lambda i: mops.tsp_swap_delta_all(d, perms, None, 0.5, nearest=near32, random=rnd32, near_threshold=20 / 21, seed=i, tables8=tab8))
     b = t_us(lambda i: mops.tsp_swap_delta_all(d, perms, sel, 0.5))
     c = t_us(lambda i: mops.tsp_tour_length(d, perms))
+    if N == 100 and B == 1 << 16:      # what the two-op form of rounds 1-5 paid before its kernel: ISCO_TSP.draw_partners (torch RNG + gathers)
+        from rlsolver_amd.envs.env_ISCO import ISCO_TSP
+        params = {"num_nodes": N, "distance": d, "nearest_indices": torch.from_numpy(near).to(dev), "random_indices": torch.from_numpy(rnd).to(dev)}
+        env = ISCO_TSP(params, batch_size=B, K=20, device=dev)
+        e = t_us(lambda i: env.draw_partners(perms), 10)
+        print(f"N={N} B={B}: ISCO_TSP.draw_partners (3 torch draws + 2 gathers + where) {e:.1f} us -> the two-op opt_2 cost {e + b:.1f} us, the one-kernel opt_2 {a:.1f}")
     print(f"N={N} B={B}: K13 draw {a:.1f} us ({B * 21 * N / a / 8e6:.3f} of 8 TB/s on 21N) | selected given {b:.1f} us ({B * 29 * N / b / 8e6:.3f} on 29N) | K12 {c:.1f} us ({B * (8 * N + 4) / c / 8e6:.3f})")
