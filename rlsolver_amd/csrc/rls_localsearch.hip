@@ -207,8 +207,11 @@ __device__ __forceinline__ void ls_round_words_lane_node(const WT* __restrict__ 
 // ALIGNED (the only form built since round 3): rows of x and noise start 4-byte aligned on 16-byte bases (N % 4 == 0), rows
 // of ws sit `pitch` entries apart, a multiple of 16 bytes, so every 16-byte piece of a ws row lies inside the row.
 // WT = int8_t | int16_t.
+// Waves per SIMD: the 4-wave layout is built for THREE workgroups per CU (round 6: 168 registers, 4 of them spilled outside the
+// round loop, and rd_std's LDS copy aliased onto the proposal tile -- 50 KB per workgroup at G22 size instead of 58): the rounds are
+// VALU-issue bound and a third wave per SIMD fills the issue gaps of the other two; the 8-wave layout (one tile per CU) keeps two.
 template <bool ALIGNED, typename WT, int P, int W>
-__global__ __launch_bounds__(W * kWave) void k_maxcut_local_search(
+__global__ __launch_bounds__(W * kWave) __attribute__((amdgpu_waves_per_eu(W == 4 ? 3 : 2, W == 4 ? 3 : 2))) void k_maxcut_local_search(
     uint8_t* __restrict__ x, int64_t B, int64_t N, const int32_t* __restrict__ eu, const int32_t* __restrict__ ev,
     int64_t E, int halve, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ sweep_src, int64_t sweep_len,
     const WT* __restrict__ ws, int64_t pitch, const float* __restrict__ rd_std, const float* __restrict__ noise, uint64_t seed,
@@ -230,7 +233,13 @@ __global__ __launch_bounds__(W * kWave) void k_maxcut_local_search(
                           : reinterpret_cast<float*>(scratch + W * kWave);   // [kLsMergeWaves][kTopCap][64]
     // rd_std [N] in LDS: read per quad as one broadcast ds_read_b128 (kept in SGPRs a trip ahead it cost 64 scalar
     // registers and pushed the kernel to ~200 SGPR spills)
+    // (compact layout: sdl lives IN the proposal tile -- only the threshold pass reads it (the lane = node rounds take rd_std from
+    // memory into registers), and the first proposal is written after that pass's last barrier)
+#ifdef RLS_LS_ROUND_LANE_ENV
     float* sdl = COMPACT ? reinterpret_cast<float*>(scratch + W * kWave) : tops + kLsMergeWaves * kTopCap * kWave;
+#else
+    float* sdl = COMPACT ? reinterpret_cast<float*>(prop) : tops + kLsMergeWaves * kTopCap * kWave;
+#endif
     static_assert(kRing * 4 >= kLsMergeWaves * kTopCap * kWave * 4, "the ring holds the merge buffer");
     const int lane = threadIdx.x & (kWave - 1);
     const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
@@ -909,11 +918,16 @@ using namespace rls;
 
 // LDS bytes of the W-wave layout (W = 4: compact, the sweep offsets reuse the proposal tile; W = 8: separate tables)
 static size_t ls_lds_bytes(int64_t N, int W) {
-    const size_t sd_bytes = (size_t)((N + 3) & ~3ll) * 4;   // rd_std in LDS
-    return sd_bytes + (W == kLsMergeWaves
-                           ? (size_t)(N + 2) * 8 + (size_t)N * 8 + (size_t)kRing * 4 + (size_t)W * kWave * 8
-                           : (size_t)(N + 2) * 8 + (size_t)N * 8 + (size_t)kRing * 4 +
-                                 (size_t)W * kWave * 8 + (size_t)kLsMergeWaves * kTopCap * kWave * 4);
+    const size_t sd_bytes = (size_t)((N + 3) & ~3ll) * 4;   // rd_std in LDS (W = 8; the compact layout keeps it in the proposal tile)
+#ifdef RLS_LS_ROUND_LANE_ENV
+    const size_t sd4 = sd_bytes;
+#else
+    const size_t sd4 = 0;
+#endif
+    return W == kLsMergeWaves
+               ? sd4 + (size_t)(N + 2) * 8 + (size_t)N * 8 + (size_t)kRing * 4 + (size_t)W * kWave * 8
+               : sd_bytes + (size_t)(N + 2) * 8 + (size_t)N * 8 + (size_t)kRing * 4 + (size_t)W * kWave * 8 +
+                     (size_t)kLsMergeWaves * kTopCap * kWave * 4;
 }
 
 // Waves per tile.  What counts is waves per SIMD (the VALU issues a wave's stream at ~5 cycles per instruction and two or more
@@ -923,10 +937,15 @@ static size_t ls_lds_bytes(int64_t N, int W) {
 // with 8.  0 = neither layout fits.
 static int ls_pick_waves(int64_t N, int64_t B) {
     const int force_w = (int)knob(KN_LS_WAVES, 0);   // dev knob
-    const bool two_small = 2 * ls_lds_bytes(N, 4) <= (size_t)kLdsBytes;
+    // (which graphs the fused kernel takes, and from where two 4-wave tiles share a CU, is decided on the layout WITH rd_std's own
+    // 4N bytes, as until round 6: the compact layout now keeps rd_std inside the proposal tile and launches with less, but the
+    // rows that gains -- N ~ 6500 .. 9000, one tile per CU -- are rows the round kernels win on (envs/env_L2A.py))
+    const size_t sd = (size_t)((N + 3) & ~3ll) * 4;
+    auto fit = [&](int w) { return ls_lds_bytes(N, w) + (w == kLsMergeWaves ? sd : 0); };
+    const bool two_small = 2 * fit(4) <= (size_t)kLdsBytes;
     int W = force_w == 4 || force_w == 8 ? force_w : (ceil_div(B, kWave) <= (int64_t)num_cus() || !two_small ? 8 : 4);
-    if (W == 8 && ls_lds_bytes(N, 8) > (size_t)kLdsBytes) W = 4;
-    return ls_lds_bytes(N, W) <= (size_t)kLdsBytes ? W : 0;
+    if (W == 8 && fit(8) > (size_t)kLdsBytes) W = 4;
+    return fit(W) <= (size_t)kLdsBytes ? W : 0;
 }
 
 // ws rows start ws_pitch ENTRIES apart (0 = N): any N works once the pitch is a multiple of 16 bytes
