@@ -15,7 +15,7 @@ int fail(int code, const char* fmt, ...);  // records the message (thread local)
 // variable; a development build (-DRLS_DEV: RLS_EXTRA_CFLAGS=-DRLS_DEV python -m rlsolver_amd.build --force) additionally seeds
 // the table from the environment variables of the same names when it is loaded.  Forcing a form never changes a result.
 #define RLS_KNOB_LIST(X)                                                                                                  \
-    X(STEP_NTS) X(STEP_EPW) X(STEP_WPB) X(STEP_PERSIST) X(STEP_CHASE) X(STEP_ALIGN)                                       \
+    X(STEP_NTS) X(STEP_EPW) X(STEP_WPB) X(STEP_PERSIST) X(STEP_CHASE) X(STEP_ALIGN) X(STEP_NOSTAGE)                                       \
     X(ISCO_SEL_CAP) X(ISCO_WAVES) X(ISCO_GLOBAL_ROWS) X(ISCO_FORCE_WG)                                                                                         \
     X(LS_SD_GLOBAL) X(LS_SLICES) X(LS_WAVES) X(LS_PER_ROUND) X(LS_APPLY32) X(SWEEP_NO_LEVELS) X(SWEEP_WAVES) X(SWEEP_UNBATCHED) \
     X(NODE_STATS_MIN_B) X(NODE_STATS_LANE_ENV) X(NODE_STATS_NO_TILE) X(NS_TILE32) X(NS_WAVES) X(NS_PARK) X(NS_ROWS)                             \

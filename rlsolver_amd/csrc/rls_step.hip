@@ -204,6 +204,8 @@ __global__ __launch_bounds__(256) void k_maxcut_step(const T* __restrict__ xin, 
             }
             tail_copy();
         } else if constexpr (MODE == 1) {
+            // (two batches per wave in flight -- the next one requested before this one is stored -- were measured in round 6: N = 10^5,
+            // 4096 envs 0.574 -> 0.548 of HBM: 133 registers, three waves per SIMD instead of four)
             constexpr int BATCH = 8;  // 8 x 16 B per lane = 8 KB per wave in flight
             V buf[BATCH];
             bool first = true;
@@ -439,10 +441,16 @@ extern "C" int rls_maxcut_step(const rls_graph* g, const void* x_in, void* x_out
     const size_t run_bytes = (size_t)epw * N * spin_bytes;
     // waves per workgroup: 4, fewer while the staged runs of a workgroup would take more than half a CU's LDS
     int waves_per_block = knobs.wpb ? knobs.wpb : 4;
-    if (!knobs.wpb && emit && vec)
+    if (!knobs.wpb && emit && vec && !knob_on(KN_STEP_NOSTAGE))
         while (waves_per_block > 1 && (size_t)waves_per_block * (run_bytes + kStepPad) > (size_t)kLdsBytes / 2) waves_per_block >>= 1;
     hipStream_t s = as_stream(stream);
-    const bool staged = emit && vec && (size_t)waves_per_block * (run_bytes + kStepPad) <= (size_t)kLdsBytes;
+    // rows so long that ONE staged run is all a CU's LDS holds (N > ~81 900 bytes) go unstaged: a single wave per CU alternates
+    // between filling and draining its run (tools/timing/k4_long_rows.py: N = 10^5, 4096 envs staged 0.46 of HBM, unstaged 0.57 before
+    // its double batch); two runs per CU (N = 80 000) still stage at 0.70-0.71
+    const bool lone_run = !knobs.wpb && emit && vec && waves_per_block == 1 && 2 * (run_bytes + kStepPad) > (size_t)kLdsBytes;
+    if (lone_run) waves_per_block = 4;
+    const bool staged = emit && vec && !lone_run && (size_t)waves_per_block * (run_bytes + kStepPad) <= (size_t)kLdsBytes &&
+                        !knob_on(KN_STEP_NOSTAGE);
     const size_t lds = staged ? (size_t)waves_per_block * (run_bytes + kStepPad) : 0;
     int64_t nblocks = ceil_div(ceil_div(B, epw), waves_per_block);
     if (staged && knobs.persist != 0) {
