@@ -555,17 +555,33 @@ def b64_bool_to_str(x_bool, encode_len: int) -> str:
     return x_str.zfill(string_len)
 
 
+def _murmur_mix32(h):
+    """murmur3's 32-bit finaliser on uint64 arrays holding 32-bit values (csrc/rls_draw.h: isco_mix)."""
+    M = np.uint64(0xFFFFFFFF)
+    h = h ^ (h >> np.uint64(16)); h = (h * np.uint64(0x85EBCA6B)) & M
+    h = h ^ (h >> np.uint64(13)); h = (h * np.uint64(0xC2B2AE35)) & M
+    return h ^ (h >> np.uint64(16))
+
+
 def rand_perms(B, N, seed, env_offset=0):
-    """K14 (TSP) definition: Fisher-Yates with Philox draws keyed by (seed, global env id, k >> 2), swap k taking word k & 3 of
-    the call's four (round 6: one call per FOUR swaps -- the kernel spent its time in ten Philox rounds per swap):
-    p = identity; for k = N-1..1: j = (r[k & 3] * (k+1)) >> 32; swap(p[k], p[j]).  Build-defined (the
-    reference stacks torch.randperm calls, env_ISCO.py:352-354)."""
+    """K14 (TSP) definition (round 6): Fisher-Yates with counter-based murmur draws -- the generator of the ISCO kernels
+    (csrc/rls_draw.h), stream 7: env key = three finaliser rounds over (seed, global env id), swap k draws
+    r = mix(mix(env_key ^ env_hi ^ k * 0x9E3779B1) ^ 7 * 0xC2B2AE3D):
+    p = identity; for k = N-1..1: j = (r * (k+1)) >> 32; swap(p[k], p[j]).  Build-defined (the reference stacks
+    torch.randperm calls, env_ISCO.py:352-354).  (Until round 6 a Philox call per swap: ten rounds per draw were the
+    kernel's whole time.)"""
+    M = np.uint64(0xFFFFFFFF)
+    seed = int(seed) & 0xFFFFFFFFFFFFFFFF
     gb = np.arange(B, dtype=np.uint64) + np.uint64(env_offset)
+    h = _murmur_mix32(np.uint64(seed & 0xFFFFFFFF) ^ np.uint64(0x9E3779B9))
+    h = _murmur_mix32(h ^ np.uint64(seed >> 32))
+    ekey = _murmur_mix32(h ^ (gb & M)) ^ (gb >> np.uint64(32))
     p = np.tile(np.arange(N, dtype=np.int64), (B, 1))
     rows = np.arange(B)
+    sconst = np.uint64((7 * 0xC2B2AE3D) & 0xFFFFFFFF)
     for k in range(N - 1, 0, -1):
-        r0 = philox4x32_10(seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF, gb & np.uint64(0xFFFFFFFF),
-                           gb >> np.uint64(32), np.uint64(k >> 2) + np.zeros_like(gb), np.uint64(0x5045524D))[k & 3]
+        pk = _murmur_mix32(ekey ^ np.uint64((k * 0x9E3779B1) & 0xFFFFFFFF))
+        r0 = _murmur_mix32(pk ^ sconst)
         j = ((r0 * np.uint64(k + 1)) >> np.uint64(32)).astype(np.int64)
         tk = p[rows, k].copy()
         p[rows, k] = p[rows, j]

@@ -209,19 +209,20 @@ __global__ void k_tsp_2opt_delta(const float* __restrict__ dist, int64_t N, cons
     delta[b] = (dist[a * N + d] + dist[c * N + e]) - (dist[a * N + c] + dist[d * N + e]);
 }
 
-// Fisher-Yates with Philox draws keyed by (seed, global env id, k >> 2), swap k taking word k & 3 of the call's four:
-// p = identity; for k = N-1..1: j = (r[k & 3] * (k+1)) >> 32; swap(p[k], p[j]).
+// Fisher-Yates with counter-based murmur draws (round 6; csrc/rls_draw.h, stream 7): p = identity; for k = N-1..1:
+// j = (draw(seed, global env id, k) * (k+1)) >> 32; swap(p[k], p[j]).  (A Philox call per swap -- ten rounds of two 32 x 32 -> 64
+// multiplies -- was the kernel's whole time: 0.21 of the write stream; four swaps per call 0.30.)
+__device__ __forceinline__ uint32_t perm_draw(uint32_t ekey, uint64_t gb, uint32_t k) { return isco_draw_at(isco_pos_key(ekey, gb, k), 0u, 7u); }
+
 __global__ void k_rand_perms(int64_t* __restrict__ perm, int64_t B, int64_t N, uint64_t seed, int64_t env_offset) {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     int64_t* p = perm + b * N;
     for (int64_t k = 0; k < N; ++k) p[k] = k;
-    const Philox ph(seed);
     const uint64_t gb = (uint64_t)(b + env_offset);
-    uint32_t r[4] = {0, 0, 0, 0};
+    const uint32_t ekey = isco_env_key(seed, gb);
     for (int64_t k = N - 1; k >= 1; --k) {
-        if (k == N - 1 || (k & 3) == 3) ph((uint32_t)gb, (uint32_t)(gb >> 32), (uint32_t)(k >> 2), 0x5045524Du, r);
-        const int64_t j = (int64_t)(((uint64_t)r[k & 3] * (uint64_t)(k + 1)) >> 32);
+        const int64_t j = (int64_t)__umulhi(perm_draw(ekey, gb, (uint32_t)k), (uint32_t)(k + 1));
         const int64_t t = p[k];
         p[k] = p[j];
         p[j] = t;
@@ -240,25 +241,17 @@ __global__ __launch_bounds__(kWave) void k_rand_perms_lds(int64_t* __restrict__ 
     const int lane = threadIdx.x;
     const int64_t b0 = (int64_t)blockIdx.x * kWave, b = b0 + lane;
     for (int64_t k = 0; k < N; ++k) p[k * kPermStride + lane] = (uint16_t)k;
-    const Philox ph(seed);
     const uint64_t gb = (uint64_t)(b + env_offset);
-    // the swaps in groups of four under one Philox call (word k & 3 of call k >> 2): the topmost group may be partial
-    // (two calls at a time: with one wave per SIMD at 2^16 tours the ten dependent rounds of a single call leave the VALU idle
-    // between issues; two independent chains interleave)
-    for (int64_t k4 = (N - 1) >> 2; k4 >= 0; k4 -= 2) {
-        uint32_t r[8];
-        ph((uint32_t)gb, (uint32_t)(gb >> 32), (uint32_t)k4, 0x5045524Du, r + 4);
-        ph((uint32_t)gb, (uint32_t)(gb >> 32), (uint32_t)(k4 >= 1 ? k4 - 1 : 0), 0x5045524Du, r);
-#pragma unroll
-        for (int q = 7; q >= 0; --q) {
-            const int64_t k = (k4 - 1) * 4 + q;
-            if (k >= 1 && k <= N - 1) {
-                const int64_t j = (int64_t)__umulhi(r[q], (uint32_t)(k + 1));
-                const uint16_t t = p[k * kPermStride + lane];
-                p[k * kPermStride + lane] = p[j * kPermStride + lane];
-                p[j * kPermStride + lane] = t;
-            }
-        }
+    const uint32_t ekey = isco_env_key(seed, gb);
+    // the draw of swap k - 1 is computed while swap k's LDS round trip is in flight (it depends on k only)
+    uint32_t r = perm_draw(ekey, gb, (uint32_t)(N - 1));
+    for (int64_t k = N - 1; k >= 1; --k) {
+        const int64_t j = (int64_t)__umulhi(r, (uint32_t)(k + 1));
+        const uint16_t t = p[k * kPermStride + lane];
+        const uint16_t u = p[j * kPermStride + lane];
+        if (k > 1) r = perm_draw(ekey, gb, (uint32_t)(k - 1));
+        p[k * kPermStride + lane] = u;
+        p[j * kPermStride + lane] = t;
     }
     __syncthreads();
     const int64_t nb = (B - b0 < kWave) ? B - b0 : kWave;
