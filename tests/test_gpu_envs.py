@@ -270,7 +270,7 @@ def test_winner_message_round_trip_and_key_unpack():
     key writes its global index + bit-packed row (the layout of dist.pack_bits), every other rank zeros; a SUM of the messages
     unpacks to the winner's row and index."""
     from rlsolver_amd import dist as rdist
-    R = torch.ops.rlsolver_hip
+    from rlsolver_amd.torch_ops import ops as R          # (the recorder of tests/test_gpu_zz_op_coverage.py when it is on)
     rng = np.random.RandomState(9)
     for N, B in ((203, 40), (8, 3), (64, 1), (1001, 7)):
         xs = torch.from_numpy(rng.randint(0, 2, size=(B, N)).astype(np.uint8)).to(DEV).bool()
