@@ -84,7 +84,16 @@ if pmc and a.bench_json and os.path.exists(a.bench_json):
             alg = envs * (2 * nodes + 20)
             hits = [k for k, d in pmc.items() if "k_maxcut_step<unsigned char" in k and "hbm_bytes_per_launch" in d
                     and 0.9 * alg <= d["hbm_bytes_per_launch"] <= 2.0 * alg]
-            if len(hits) == 1:       # unambiguous: this instantiation ran this workload
+            if len(hits) > 1:
+                # round 6: bench.py also runs the headline loop with nontemporal stores (roofline.hbm_only) -- the same workload on a
+                # second instantiation, far fewer launches.  The instantiation with the most launches is the headline's; the others
+                # are marked as variants of the same workload (bench.py matches `workload` only)
+                hits.sort(key=lambda k: -pmc[k].get("FETCH_SIZE_launches", 0))
+                for k in hits[1:]:
+                    pmc[k]["workload_variant"] = {"envs": envs, "nodes": nodes, "slots": slots, "of": hits[0]}
+                    pmc[k]["algorithmic_bytes_per_launch"] = alg
+                hits = hits[:1]
+            if len(hits) == 1:       # this instantiation ran this workload
                 pmc[hits[0]]["workload"] = {"envs": envs, "nodes": nodes, "slots": slots}
                 pmc[hits[0]]["algorithmic_bytes_per_launch"] = alg
             else:
