@@ -23,7 +23,7 @@ for f in files:
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 name_of = lambda r: re.sub(r"\(.*", "", r["Kernel_Name"]).replace("rls::", "").replace("void ", "")
 bk = [i for i, r in enumerate(rows) if "k_best_key" in r["Kernel_Name"]]
-assert len(bk) == 2 * K, len(bk)
+assert len(bk) in (2 * K, 3 * K), len(bk)
 
 
 def window(lo, hi):
@@ -40,6 +40,7 @@ def window(lo, hi):
 
 ex_only = window(1, K)                 # BestExchange.exchange x (K - 1)
 gb = window(K + 1, 2 * K - 1)          # dist.global_best x (K - 2)
+c2 = window(2 * K + 1, 3 * K - 1) if len(bk) == 3 * K else None       # dist.global_best(want_solution=True, env_offset=..) x (K - 2)
 out = {
     "what": "rocprofv3 --kernel-trace of tools/timing/exchange_trace.py: 100 BestExchange.exchange calls, then 100 dist.global_best "
             "calls (exchange + rls_key_unpack), 1-rank RCCL group on one MI355X.  On a 1-rank group RCCL's in-place all_reduce "
@@ -50,10 +51,13 @@ out = {
     "BestExchange.exchange": ex_only,
     "dist.global_best": gb,
 }
+if c2 is not None:
+    out["launches_per_global_best_with_solution"] = c2["launches_per_exchange"]
+    out["dist.global_best(want_solution=True, env_offset=...)"] = c2
 probe = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "gpurun_out", f"{P}_exchange_probe.json")
 if os.path.exists(probe):
     for ln in open(probe):
         if ln.startswith("EXCHANGE_PROBE "):
             out["probe"] = json.loads(ln[len("EXCHANGE_PROBE "):])
 json.dump(out, open(os.path.join(ROOT, "profiles", f"{P}_exchange.json"), "w"), indent=1)
-print(out["launches_per_exchange"], out["launches_per_global_best"], json.dumps(out.get("probe", {})))
+print(out["launches_per_exchange"], out["launches_per_global_best"], out.get("launches_per_global_best_with_solution"), json.dumps(out.get("probe", {})))
