@@ -63,6 +63,15 @@ try:
     ex.check(); ok = False
 except ValueError:
     pass
+# a rank WITHOUT envs joins every collective (env_shard gives some ranks nothing when B < world): here it is the only rank, so the
+# reduced key is the empty key -- zeros come back and the sticky flag (bit 1: "no rank had an env") trips at the lazy check
+be, oe, xe, ge = rdist.global_best(torch.empty(0, dtype=torch.int64, device=dev), torch.empty((0, n), dtype=torch.bool, device=dev),
+                                   want_solution=True, env_offset=0)
+ok = ok and xe.shape == (n,) and not bool(xe.any()) and int(ge) == 0
+try:
+    rdist._site(dev, None).check(); ok = False
+except ValueError:
+    pass
 t = torch.arange(8, dtype=torch.int64, device=dev)
 dist.all_reduce(t, op=dist.ReduceOp.MAX)
 ok = ok and t.tolist() == list(range(8))
