@@ -999,7 +999,7 @@ __global__ __launch_bounds__(kNsWaves * kWave) void k_node_stats_bits32(const ui
     const int64_t b0 = (int64_t)blockIdx.x * EN;
     if constexpr (sizeof(NT) == 4) {
         unsigned char* stage = smem + (((size_t)N * 4 + 15) & ~(size_t)15) + (size_t)w * kStageBytes;
-        tile32_load_bits<uint8_t, VEC>(x, B, N, b0, words32, lane, w, kNsWaves, has_stage ? stage : nullptr);
+        tile32_load_bits<uint8_t, VEC>(x, B, N, b0, words32, lane, w, kNsWaves, (has_stage & 1) ? stage : nullptr);
     } else {
         tilen_load_bits<uint8_t, NT, VEC>(x, B, N, b0, words32, lane, w, kNsWaves);
     }
@@ -1013,6 +1013,115 @@ __global__ __launch_bounds__(kNsWaves * kWave) void k_node_stats_bits32(const ui
         else if constexpr (MODE == 1) reinterpret_cast<int32_t*>(out_v)[(b0 + e) * N + i] = deg - 2 * cnt;
         else reinterpret_cast<WT*>(out_v)[(b0 + e) * out_pitch + i] = (WT)(deg - mult * cnt);
     };
+    // K3 of a FULL half tile through wave-private row staging (round 6; has_stage bit 2; the 64-env kernel's comment): two groups'
+    // counts parked as bytes [env][128 nodes], two envs' 128 nodes per store instruction, 16 bytes per lane -- 512-byte row pieces
+    // where the per-group form below writes 256-byte ones.  The staging takes the bytes of the (idle) row-piece stages + 2 KB.
+    if constexpr (MODE == 1 && sizeof(NT) == 4) {
+        if ((has_stage & 4) && nenv == EN) {
+            constexpr int kRowPitch = 132;
+            unsigned char* const stg = smem + (((size_t)N * 4 + 15) & ~(size_t)15) + (size_t)w * (EN * kRowPitch);
+            const uint32_t sel1 = (lane & 1) ? 0x03070105u : 0x06020400u, sel2 = (lane & 2) ? 0x03020706u : 0x05040100u;
+            const int64_t NP = (G + 1) >> 1;
+            for (int64_t pr = w; pr < NP; pr += kNsWaves) {
+                bool hub[2] = {false, false};
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const int64_t g = 2 * pr + h2;
+                    if (g >= G) break;
+                    const int64_t i = (g << 6) + lane;
+                    const bool in = i < N;
+                    const uint32_t iself = in ? (uint32_t)i : 0u;
+                    const uint32_t own = (uint32_t)words32[iself];
+                    const int e0 = ell_ptr[g], e1 = ell_ptr[g + 1];
+                    const int md = (e1 - e0) >> 6;
+                    uint32_t ones = 0, twos = 0, fours = 0, c[NCP];
+#pragma unroll
+                    for (int p = 0; p < NCP; ++p) c[p] = 0;
+                    int ncp = 5;
+                    if constexpr (WIDE) while ((8 << ncp) <= md) ++ncp;
+                    for (int k = e0; k < e1; k += 8 * kWave) {
+                        uint32_t nb[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) nb[q] = (k + q * kWave < e1) ? (uint32_t)ell[k + q * kWave + lane] : iself;
+                        uint32_t d[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) d[q] = (uint32_t)words32[nb[q]] ^ own;
+                        uint32_t twosA, twosB, foursA, foursB, carry;
+                        csa32(twosA, ones, ones, d[0], d[1]);
+                        csa32(twosB, ones, ones, d[2], d[3]);
+                        csa32(foursA, twos, twos, twosA, twosB);
+                        csa32(twosA, ones, ones, d[4], d[5]);
+                        csa32(twosB, ones, ones, d[6], d[7]);
+                        csa32(foursB, twos, twos, twosA, twosB);
+                        csa32(carry, fours, fours, foursA, foursB);
+#pragma unroll
+                        for (int p = 0; p < NCP; ++p) {
+                            if (p < 5 || p < ncp) {
+                                const uint32_t t = c[p] & carry;
+                                c[p] ^= carry;
+                                carry = t;
+                            }
+                        }
+                    }
+                    const uint32_t pw[16] = {ones, twos, fours, c[0], c[1], c[2], c[3], c[4], c[5 % NCP], c[6 % NCP], c[7 % NCP], c[8 % NCP],
+                                             c[9 % NCP], c[10 % NCP], c[11 % NCP], c[12 % NCP]};
+                    if (WIDE && md >= 256) {                      // a hub group: 16-bit counts, written here as the per-group form writes them
+                        hub[h2] = true;
+                        if (in) {
+                            const int deg = rowptr[i + 1] - rowptr[i];
+                            for (int r = 0; r < 16; ++r) {
+                                uint32_t acc = 0;
+#pragma unroll
+                                for (int p = 0; p < 16; ++p) acc += ((pw[p] >> r) & 0x00010001u) << p;
+                                emit(i, deg, r, (int)(acc & 0xFFFFu));
+                                emit(i, deg, r + 16, (int)(acc >> 16));
+                            }
+                        }
+                        continue;
+                    }
+                    unsigned char* const obase = stg + (size_t)((lane & 3) * 8) * kRowPitch + h2 * 64 + (lane & ~3);
+#pragma unroll 2
+                    for (int r = 0; r < 8; ++r) {
+                        uint32_t v = 0;
+#pragma unroll
+                        for (int p = 0; p < 8; ++p) v += ((pw[p] >> r) & 0x01010101u) << p;                 // envs r, r + 8, r + 16, r + 24 of this node
+                        uint32_t o = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);      // lane ^ 1
+                        v = __builtin_amdgcn_perm(o, v, sel1);
+                        o = (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);               // lane ^ 2
+                        v = __builtin_amdgcn_perm(o, v, sel2);                        // 4 consecutive nodes of env r + 8 (lane & 3)
+                        *reinterpret_cast<uint32_t*>(obase + (size_t)r * kRowPitch) = v;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                const int sub = lane >> 5, q4 = (lane & 31) * 4;
+                const int64_t i4 = (pr << 7) + q4;
+                bool on = i4 < N && !hub[(q4 >> 6) & 1];                  // (N % 4 == 0: all four nodes or none)
+                int dg[4] = {0, 0, 0, 0};
+                if (on) {
+                    int rp[5];
+#pragma unroll
+                    for (int j = 0; j < 5; ++j) rp[j] = rowptr[i4 + j];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) dg[j] = rp[j + 1] - rp[j];
+                }
+#pragma unroll 4
+                for (int k = 0; k < EN / 2; ++k) {
+                    const int e = 2 * k + sub;
+                    const uint32_t d = *reinterpret_cast<const uint32_t*>(stg + (size_t)e * kRowPitch + q4);
+                    if (on) {
+                        typedef int i32x4 __attribute__((ext_vector_type(4)));
+                        const i32x4 o = {dg[0] - 2 * (int)(d & 0xFFu), dg[1] - 2 * (int)((d >> 8) & 0xFFu),
+                                         dg[2] - 2 * (int)((d >> 16) & 0xFFu), dg[3] - 2 * (int)(d >> 24)};
+                        *reinterpret_cast<i32x4*>(reinterpret_cast<int32_t*>(out_v) + (b0 + e) * N + i4) = o;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+            }
+            return;
+        }
+    }
     for (int64_t g = w; g < G; g += kNsWaves) {
         const int64_t i = (g << 6) + lane;
         const bool in = i < N;
@@ -1126,7 +1235,8 @@ static int launch_node_stats_bits(const rls_graph* g, const uint8_t* x, int64_t 
     // stage (N > ~15 800: K3 at N = 20 000, 4096 envs 278 -> 186 us)
     const int64_t t64 = ceil_div(B, kWave);
     const bool few = MODE == 2 ? 8 * t64 <= (int64_t)num_cus() : 2 * t64 <= (int64_t)num_cus();
-    const bool full_k3 = MODE == 1 && t64 >= 4 * (int64_t)num_cus() && (size_t)N * 8 <= 64 * 1024;
+    // (round 6: from two 64-env tiles per CU on -- N = 3008, 2^15 envs: 121 us on 64-env tiles, 109-112 on half tiles)
+    const bool full_k3 = MODE == 1 && t64 >= 2 * (int64_t)num_cus() && (size_t)N * 8 <= 64 * 1024;
     const bool prefer32 = knob32 < 0 && vec && (N & 7) == 0 && node_stats_bits32_lds(N, true) <= (size_t)kLdsBytes &&
                           (few || full_k3 || (node_stats_bits_lds(N, true) > (size_t)kLdsBytes && 2 * t64 <= (int64_t)num_cus()));
     // Narrow tiles (16 / 8 envs, rls_tile32.h) where the half tile is past the LDS (N > 40 960): the rows these took before went
@@ -1168,8 +1278,19 @@ static int launch_node_stats_bits(const rls_graph* g, const uint8_t* x, int64_t 
         return check_launch("k_node_stats_bits32<narrow>");
     }
     if (knob32 > 0 || prefer32 || node_stats_bits_lds(N, false) > (size_t)kLdsBytes) {   // half tiles (rls_tile32.h)
-        const int st32 = (vec && (N & 7) == 0 && node_stats_bits32_lds(N, true) <= (size_t)kLdsBytes) ? 1 : 0;
-        const size_t l32 = node_stats_bits32_lds(N, st32 != 0);
+        int st32 = (vec && (N & 7) == 0 && node_stats_bits32_lds(N, true) <= (size_t)kLdsBytes) ? 1 : 0;
+        size_t l32 = node_stats_bits32_lds(N, st32 != 0);
+        {   // K3's row staging on full half tiles (the kernel's comment): 16-byte-aligned output, rows of 4-node multiples
+            const int rk = (int)knob(KN_NS_ROWS, -1);
+            const size_t lrows = node_stats_bits32_lds(N, false) + (size_t)kNsWaves * kHalf * 132;
+            // measured (tools/timing/k3_rows.py, half tiles per group -> rows): N = 3008 112 -> 109 us, G70-sized 1603 -> 1527, BA n = 10^4
+            // 1093 -> 1043; G22-sized 162 -> 167 (sixteen 512-byte pieces per pair are too few stores to pay for the staging): from 3000 nodes
+            if (MODE == 1 && st32 && (N & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (rk < 0 ? N >= 3000 : rk != 0) &&
+                lrows <= (size_t)kLdsBytes) {
+                st32 |= 4;
+                if (lrows > l32) l32 = lrows;
+            }
+        }
         const dim3 g32((unsigned)ceil_div(B, (int64_t)kHalf)), b32(kNsWaves * kWave);
 #define RLS_NS32_LAUNCH(KERN)                                                                                        \
     do {                                                                                                            \

@@ -121,14 +121,14 @@ def test_k3_k2_row_staged_stores_equal_the_per_group_form(n, m, B, kind):
     x = to_dev_bool(xs)
     got = {}
     try:
-        for label, t32, rows in (("auto", None, None), ("groups", 0, 0), ("rows", 0, 1)):
+        for label, t32, rows in (("auto", None, None), ("groups", 0, 0), ("rows", 0, 1), ("half groups", 1, 0), ("half rows", 1, 1)):
             for k, v in (("RLS_NS_TILE32", t32), ("RLS_NS_ROWS", rows)):
                 _abi.tuning_unset(k) if v is None else _abi.tuning_set(k, v)
             got[label] = (ops.maxcut_delta_all(g, x), ops.maxcut_node_cutdeg(g, x))
     finally:
         _abi.tuning_unset("RLS_NS_TILE32")
         _abi.tuning_unset("RLS_NS_ROWS")
-    for label in ("groups", "rows"):
+    for label in ("groups", "rows", "half groups", "half rows"):
         assert torch.equal(got[label][0], got["auto"][0]) and torch.equal(got[label][1], got["auto"][1]), label
     sub = np.concatenate([rng.choice(B, 5, replace=False), [B - 1]])
     assert np.array_equal(got["rows"][0][sub].cpu().numpy(), onp.maxcut_delta_all(xs[sub], graph, n, None))

@@ -18,7 +18,7 @@ for name, N, E, B, gen in (("G22", 2000, 19990, 65536, "gnm"), ("G70", 10000, 99
     dg = ops.DeviceGraph(graph.build_csr(g, num_nodes=N, if_bidirectional=False), dev)
     xs = ops.rand_spins(B, N, 1, dev)
     row, ref3, ref2 = [], None, None
-    for label, t32, rows in (("auto", None, None), ("tile64 groups", 0, 0), ("tile64 rows", 0, 1), ("half tiles", 1, None)):
+    for label, t32, rows in (("auto", None, None), ("tile64 groups", 0, 0), ("tile64 rows", 0, 1), ("half groups", 1, 0), ("half rows", 1, 1)):
         for k, v in (("RLS_NS_TILE32", t32), ("RLS_NS_ROWS", rows)):
             _abi.tuning_unset(k) if v is None else _abi.tuning_set(k, v)
         try:
