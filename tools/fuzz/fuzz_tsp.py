@@ -52,6 +52,37 @@ while time.time() < t_end:
         lr, idx, ban = mops.tsp_swap_delta_all(d2, p2, torch.from_numpy(sel).to(DEV), Tt)
         assert np.array_equal(idx.cpu().numpy(), idx_w) and np.array_equal(ban.cpu().numpy(), ban_w), "K13 indices / ban " + t2tag
         assert np.allclose(lr.cpu().numpy(), lr_w, rtol=1e-5, atol=1e-5 * length.max() / Tt), "K13 logratio " + t2tag
+        # K13 as the reference runs it: the partners drawn in the kernel (round 6) -- what it drew, fed back through the recorded-draw
+        # hook, reproduces it bit for bit; the byte tables (N <= 256) and the tables read from memory draw the same partners; every
+        # partner comes from the position's own tables and is never the position's own city; a shard draws what the batch draws
+        if N2 >= 4:
+            from rlsolver_amd.graph import tsp_tables
+            Kt = int(rng.randint(1, min(20, N2 - 2) + 1))
+            _, near, rnd = tsp_tables(c2, K=Kt)
+            n32, r32 = torch.from_numpy(near.astype(np.int32)).to(DEV), torch.from_numpy(rnd.astype(np.int32)).to(DEV)
+            thr = float(np.float32(Kt / (Kt + 1)))
+            sd, eo = int(rng.randint(0, 2 ** 62)), int(rng.randint(0, 10 ** 6))
+            t8 = mops.tsp_tables8(n32, r32)
+            a = mops.tsp_swap_delta_all(d2, p2, None, Tt, nearest=n32, random=r32, near_threshold=thr, seed=sd, env_offset=eo, return_selected=True)
+            if t8 is not None:
+                b = mops.tsp_swap_delta_all(d2, p2, None, Tt, nearest=n32, random=r32, near_threshold=thr, seed=sd, env_offset=eo,
+                                            return_selected=True, tables8=t8)
+                assert all(torch.equal(u, v) for u, v in zip(a, b)), "K13 draw: byte tables vs memory tables " + t2tag
+            c = mops.tsp_swap_delta_all(d2, p2, a[3], Tt)
+            assert all(torch.equal(u, v) for u, v in zip(a[:3], c)), "K13 draw vs its own partners fed back " + t2tag
+            sel_d = a[3].cpu().numpy()
+            assert (sel_d != pn).all(), "K13 draw: own city " + t2tag
+            allowed = np.zeros((N2, N2), dtype=bool)
+            allowed[np.arange(N2)[:, None], near] = True
+            allowed[np.arange(N2)[:, None], rnd[:, :N2 - Kt - 1]] = True
+            assert allowed[pn, sel_d].all(), "K13 draw: partner outside the tables " + t2tag
+            lw, iw, bw = onp.tsp_swap_delta_all(dist2, pn, sel_d, Tt)
+            assert np.array_equal(a[1].cpu().numpy(), iw) and np.array_equal(a[2].cpu().numpy(), bw), "K13 draw vs oracle " + t2tag
+            if B2 > 1:
+                h = B2 // 2
+                e = mops.tsp_swap_delta_all(d2, p2[h:].contiguous(), None, Tt, nearest=n32, random=r32, near_threshold=thr, seed=sd,
+                                            env_offset=eo + h, tables8=t8)
+                assert all(torch.equal(u[h:], v) for u, v in zip(a[:3], e)), "K13 draw: shard " + t2tag
         pos = rng.randint(0, N2, size=B2)
         xw = onp.tsp_switch(pn, pos, idx_w)
         xg = p2.clone()
